@@ -1,0 +1,236 @@
+/*
+ * lsn_oracle.h - CPU ORACLE for the LTESniffer per-subframe hot path.
+ *
+ * >>> TEST INFRASTRUCTURE ONLY. <<<  Nothing in ltesniffer_amd/ may include, link or call this.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it (as the checker /
+ * as the timed CPU baseline), never as the shipped path.
+ *
+ * PARITY UNPINNED: the reference's arithmetic for this path lives in an un-vendored, unpinned
+ * srsRAN fork (github.com/ShaoPaoLao/srsRAN2 @ master, /root/reference/external/cmake/
+ * srsRAN.CMakeLists.txt.in:8-9) that is absent from /root/reference and cannot be built here.
+ * This oracle is a plain scalar C restatement of
+ *   - the reference's in-tree control logic (file:line cited at each function), and
+ *   - the published 3GPP algorithms (TS 36.211/36.212/36.213) for the DSP that the reference
+ *     reaches through srsran_* calls (call sites cited).
+ * The only golden vectors the reference ships pin the MAC-LTE pcap framing
+ * (pcap_file_example/*.pcap); tests/test_oracle_pcap.py checks the writer against them.
+ *
+ * Float arithmetic contract (so that a GPU implementation can be BIT-IDENTICAL): every float
+ * expression is evaluated in binary32 with one rounding per + - * / (compile with
+ * -ffp-contract=off, no fast-math); reductions use the fixed order of o_reduce256(); all
+ * transcendental calls (cos/sin/exp/log10/atan2) happen on the host only.
+ */
+#ifndef LSN_ORACLE_H
+#define LSN_ORACLE_H
+#include <stdint.h>
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { float r, i; } ocf_t;
+
+#define O_MAX_PRB 110
+#define O_MAX_PORTS 2
+#define O_MAX_RX 2
+#define O_NSYMB 14
+#define O_MAX_CCE 87
+#define O_MAX_NUM_OF_CCE 84 /* falcon_pdcch.h:36 - the search never looks past CCE 83 */
+#define O_MAX_LOCATIONS 160 /* falcon_ue_dl.h:39 MAX_CANDIDATES_BLIND */
+#define O_DCI_MAX_BITS 128
+#define O_NOF_FORMATS 9
+
+/* RNTI constants: srsRAN phy_common.h [not in tree], SURVEY.md appendix E */
+#define O_SIRNTI 0xFFFF
+#define O_PRNTI 0xFFFE
+#define O_MRNTI 0xFFFD
+#define O_RARNTI_START 0x0001
+#define O_RARNTI_END 0x000A
+#define O_CRNTI_START 0x000B
+#define O_CRNTI_END 0xFFF3
+#define O_RNTI_ISUSER(r) ((r) >= O_CRNTI_START && (r) <= O_CRNTI_END)
+#define O_RNTI_ISRAR(r) ((r) >= O_RARNTI_START && (r) <= O_RARNTI_END)
+
+/* DCI formats, in the order of falcon_ue_all_formats (DCISearch.cc:84-95): index == global_index */
+enum { O_FMT0 = 0, O_FMT1, O_FMT1A, O_FMT1B, O_FMT1C, O_FMT1D, O_FMT2, O_FMT2A, O_FMT2B };
+/* srsRAN's srsran_dci_format_t order differs (0,1,1A,1B?,...): the reference only compares formats
+ * with ==, <= FORMAT1A, > FORMAT1A and >= FORMAT2; srsRAN enum order is 0,1,1A,1B,1C,1D,2,2A,2B,
+ * identical to the list above, so the same integers are used for both. */
+
+enum { O_MOD_QPSK = 2, O_MOD_16QAM = 4, O_MOD_64QAM = 6, O_MOD_256QAM = 8 };
+enum { O_TX_PORT0 = 0, O_TX_DIVERSITY, O_TX_SPATIALMUX, O_TX_CDD };
+enum { O_TABLE_64QAM = 0, O_TABLE_256QAM = 1, O_TABLE_UNKNOWN = 2, O_TABLE_BOTH = 3, O_TABLE_FULL = 4 };
+
+typedef struct {
+  uint32_t nof_prb;   /* 6,15,25,50,100 (power-of-two FFT sizes only) */
+  uint32_t nof_ports; /* 1 or 2 CRS ports */
+  uint32_t id;        /* physical cell id 0..503 */
+  uint32_t phich_ng_x6; /* Ng*6: 1 (=1/6), 3, 6, 12 ; LTESniffer_Core.cc:211-212 forces 1/6 */
+} o_cell_t;
+
+/* ---------- bit-level primitives (o_bits.c) ---------- */
+uint32_t o_crc_bits(uint32_t poly, int order, const uint8_t* bits, int n);
+#define O_CRC24A 0x1864CFBu
+#define O_CRC24B 0x1800063u
+#define O_CRC16 0x11021u
+#define O_CRC8 0x19Bu
+void o_gold(uint32_t cinit, uint8_t* c, int len);
+void o_unpack_bytes(const uint8_t* bytes, uint8_t* bits, int nbits);
+void o_pack_bits(const uint8_t* bits, uint8_t* bytes, int nbits);
+float o_reduce256(const float* v, int n);
+
+/* ---------- OFDM + channel estimation + control region (o_phy.c) ---------- */
+int o_fft_size(uint32_t nof_prb);
+void o_fft_twiddles(int N, ocf_t* w /* N/2 */);
+void o_fft(int N, const ocf_t* w, ocf_t* a /* in place, natural order in and out */);
+/* in: 15*N samples of one subframe, cfo_phase_inc: NCO increment (0 = no correction); out: grid[14][12*nprb] */
+void o_ofdm_rx(const o_cell_t* cell, const ocf_t* in, uint32_t nco_dphi, ocf_t* grid);
+void o_nco_tables(ocf_t* coarse /*4096*/, ocf_t* fine /*1024*/);
+uint32_t o_nco_dphi(float cfo_hz, int fft_size);
+
+typedef struct {
+  float noise[O_MAX_RX][O_MAX_PORTS];
+  float rsrp[O_MAX_RX][O_MAX_PORTS];
+  float cepow[O_MAX_RX][O_MAX_PORTS]; /* mean |smoothed pilot|^2 */
+  ocf_t cfo_corr;      /* sum of pilot correlations one slot apart */
+  float noise_avg, rsrp_avg, snr_db, cfo_hz, chan_ref; /* chan_ref = sum cepow */
+} o_chest_res_t;
+
+void o_crs_table(const o_cell_t* cell, uint32_t sf_idx, ocf_t* crs /* [port][4][2*nprb] */);
+/* grid[rx][14][nre] -> ce[port][rx][14][nre], pilots kept in work arrays */
+void o_chest(const o_cell_t* cell, uint32_t nof_rx, uint32_t sf_idx, const ocf_t* grid, ocf_t* ce,
+             o_chest_res_t* res);
+
+typedef struct { uint16_t k0; uint8_t l; uint8_t assigned; } o_reg_t;
+typedef struct {
+  uint32_t nof_regs[3];           /* PDCCH REGs per CFI */
+  uint32_t nof_cce[3];
+  uint16_t pdcch_reg_k0[3][800];  /* quadruplet q (post de-interleave, = CCE*9 + i) -> first RE index */
+  uint8_t pdcch_reg_l[3][800];
+  uint16_t pcfich_k0[4];
+  uint32_t ngroups_phich;
+} o_regs_t;
+void o_regs_init(const o_cell_t* cell, o_regs_t* regs);
+/* PCFICH: returns cfi 1..3 (36.211 6.7), corr out optional */
+uint32_t o_pcfich_decode(const o_cell_t* cell, const o_regs_t* regs, uint32_t nof_rx, uint32_t sf_idx,
+                         const ocf_t* grid, const ocf_t* ce, float noise, float* corr3);
+/* PDCCH LLRs for the decoded cfi: llr[nof_cce*72] (positive = bit 1) */
+void o_pdcch_llr(const o_cell_t* cell, const o_regs_t* regs, uint32_t nof_rx, uint32_t sf_idx, uint32_t cfi,
+                 const ocf_t* grid, const ocf_t* ce, float noise, float* llr);
+void o_subframe_power(const o_cell_t* cell, const ocf_t* grid_ant0, float* rb_power_db, float* pmin, float* pmax);
+
+/* ---------- convolutional code / DCI candidate decode (o_conv.c) ---------- */
+void o_rm_conv_rx(const float* e, int E, float* out, int D3 /* 3*(n+16) */);
+void o_viterbi_tb(const uint8_t* sym /* 3*D quantised */, int D, uint8_t* bits);
+/* decode one candidate: llr points at ncce*72, E = 72<<L, n payload bits; returns crc_rem (=RNTI) */
+uint16_t o_dci_decode(const float* llr, int E, int nof_bits, uint8_t* payload);
+
+/* ---------- DCI formats and resource allocation (o_dci.c) ---------- */
+uint32_t o_dci_format_sizeof(const o_cell_t* cell, int format);
+typedef struct { uint32_t mcs_idx; int rv; uint32_t ndi; uint32_t cw_idx; } o_dci_tb_t;
+typedef struct {
+  uint16_t rnti; int format; uint32_t L, ncce;
+  int alloc_type;          /* 0,1,2 */
+  uint32_t rbg_bitmask;    /* type0 */
+  uint32_t t1_vrb_bitmask, t1_rbg_subset, t1_shift;
+  uint32_t riv; int t2_dist; int t2_ngap2; int t2_nprb1a_is2; /* type2 */
+  uint32_t pid; o_dci_tb_t tb[2]; uint32_t tb_cw_swap; uint32_t pinfo; uint32_t tpc;
+  int is_ra_order;
+} o_dci_dl_t;
+typedef struct {
+  uint16_t rnti; uint32_t L, ncce;
+  uint32_t freq_hop_fl; uint32_t riv; uint32_t mcs_idx; int rv; uint32_t ndi; uint32_t tpc; uint32_t n_dmrs; uint32_t cqi_req;
+} o_dci_ul_t;
+typedef struct { uint32_t mcs_idx; int rv; uint32_t cw_idx; int enabled; int mod; int tbs; int nof_bits; } o_tb_t;
+typedef struct {
+  uint8_t prb_idx[2][O_MAX_PRB]; uint32_t nof_prb; uint32_t nof_re; uint32_t nof_tb;
+  o_tb_t tb[2]; int tx_scheme; uint32_t pmi; uint32_t nof_layers;
+} o_pdsch_grant_t;
+typedef struct { uint32_t L_prb, n_prb; uint32_t mcs_idx; int mod; int tbs; int rv; } o_pusch_grant_t;
+
+int o_dci_unpack_dl(const o_cell_t* cell, const uint8_t* payload, uint32_t nof_bits, int format, uint16_t rnti, o_dci_dl_t* dci);
+int o_dci_unpack_ul(const o_cell_t* cell, const uint8_t* payload, uint32_t nof_bits, uint16_t rnti, o_dci_ul_t* dci);
+int o_ra_dl_dci_to_grant(const o_cell_t* cell, uint32_t sf_idx, uint32_t cfi, int use_256qam_table, const o_dci_dl_t* dci, o_pdsch_grant_t* g);
+int o_ra_ul_dci_to_grant(const o_cell_t* cell, const o_dci_ul_t* dci, o_pusch_grant_t* g);
+int o_config_mimo(const o_cell_t* cell, int format, const o_dci_dl_t* dci, o_pdsch_grant_t* g);
+uint32_t o_ra_nof_re(const o_cell_t* cell, uint32_t sf_idx, uint32_t cfi, const o_pdsch_grant_t* g);
+int o_tbs_from_idx(int i_tbs, uint32_t n_prb);
+/* PDSCH RE position helper shared by nof_re and extraction: 1 if (l,k) carries PDSCH for this cell/subframe */
+int o_pdsch_re_ok(const o_cell_t* cell, uint32_t sf_idx, uint32_t l, uint32_t k);
+
+/* ---------- search space + FALCON bookkeeping (o_falcon.c) ---------- */
+uint32_t o_validate_location(uint32_t nof_cce, uint32_t ncce, uint32_t l, uint32_t nsubframe, uint16_t rnti);
+typedef struct o_rntiman o_rntiman_t;
+o_rntiman_t* o_rntiman_new(uint32_t nformats, uint32_t max_cand_per_step, uint32_t threshold);
+void o_rntiman_free(o_rntiman_t*);
+void o_rntiman_add_evergreen(o_rntiman_t*, uint16_t a, uint16_t b, uint32_t f);
+void o_rntiman_add_forbidden(o_rntiman_t*, uint16_t a, uint16_t b, uint32_t f);
+void o_rntiman_add_candidate(o_rntiman_t*, uint16_t rnti, uint32_t f);
+int o_rntiman_validate_and_refresh(o_rntiman_t*, uint16_t rnti, uint32_t f);
+void o_rntiman_activate_and_refresh(o_rntiman_t*, uint16_t rnti, uint32_t f, int reason);
+int o_rntiman_is_forbidden(o_rntiman_t*, uint16_t rnti, uint32_t f);
+uint32_t o_rntiman_get_frequency(o_rntiman_t*, uint16_t rnti, uint32_t f);
+int o_rntiman_get_activation_reason(o_rntiman_t*, uint16_t rnti);
+void o_rntiman_step_time(o_rntiman_t*);
+uint32_t o_rntiman_nof_active(o_rntiman_t*);
+enum { O_ACT_UNSET = 0, O_ACT_EVERGREEN, O_ACT_RAR, O_ACT_SHORTCUT, O_ACT_HISTOGRAM, O_ACT_OTHER };
+
+/* ---------- PDSCH (o_pdsch.c) ---------- */
+typedef struct { int C, Cp, Cm, Kp, Km, F, tbs; } o_cbsegm_t;
+int o_cbsegm(o_cbsegm_t* s, int tbs);
+int o_qpp_find(int K, int* f1, int* f2);
+/* demod: extract+equalise+soft-demod+descramble one grant. llr_out[cw][nof_re*Qm] int16 */
+int o_pdsch_demod(const o_cell_t* cell, uint32_t nof_rx, uint32_t sf_idx, uint32_t cfi, uint16_t rnti,
+                  const o_pdsch_grant_t* g, const ocf_t* grid, const ocf_t* ce, float noise, float chan_ref,
+                  float rho_a_db, int16_t* llr_cw0, int16_t* llr_cw1);
+/* rate-dematch CB r of a codeword into sys/par1/par2 arrays (K+4 each, natural turbo order incl. tail) */
+void o_rm_turbo_rx_cb(const int16_t* e, int E, int K, int F, int rv, int16_t* d3 /* 3*(K+4): d0|d1|d2 */);
+/* windowed max-log-MAP turbo decoder; returns number of iterations run, bits out[K]; crc_ok flag */
+int o_turbo_decode_cb(const int16_t* d3, int K, int max_iter, uint32_t crc_poly, uint8_t* bits, int* crc_ok);
+/* whole transport block: llr e[G] -> payload bytes (tbs/8); returns crc ok */
+int o_pdsch_decode_tb(const int16_t* e, int G, int tbs, int Qm, int nof_layers_rm, int rv, int max_iter,
+                      uint8_t* payload, int* iters_total);
+int o_turbo_nwin(int K);
+
+/* ---------- pcap (o_pcap.c) ---------- */
+typedef struct o_pcap o_pcap_t;
+o_pcap_t* o_pcap_open_mem(void);
+o_pcap_t* o_pcap_open_file(const char* path);
+void o_pcap_write(o_pcap_t*, const uint8_t* pdu, uint32_t len, uint32_t tti, uint16_t rnti, uint8_t direction, uint8_t rnti_type, uint8_t crc_ok, uint32_t ts_sec, uint32_t ts_usec);
+const uint8_t* o_pcap_mem(o_pcap_t*, size_t* len);
+uint32_t o_pcap_nof_records(o_pcap_t*);
+void o_pcap_close(o_pcap_t*);
+enum { O_PCAP_NO_RNTI = 0, O_PCAP_P_RNTI = 1, O_PCAP_RA_RNTI = 2, O_PCAP_C_RNTI = 3, O_PCAP_SI_RNTI = 4 };
+
+/* ---------- the per-subframe worker (o_worker.c) ---------- */
+typedef struct o_worker o_worker_t;
+typedef struct {
+  uint32_t nof_decoded_locations, nof_cce, nof_missed_cce, nof_subframes, nof_subframe_collisions_dw,
+      nof_subframe_collisions_up, nof_locations;
+} o_stats_t;
+typedef struct {
+  o_cell_t cell; uint32_t nof_rx; uint32_t histogram_threshold; double split_ratio; int skip_secondary;
+  int mcs_tracking_mode; /* 1 = on (default) */ int max_turbo_iter; int enable_shortcut;
+} o_worker_cfg_t;
+o_worker_t* o_worker_new(const o_worker_cfg_t* cfg);
+void o_worker_free(o_worker_t*);
+void o_worker_set_pcap(o_worker_t*, o_pcap_t*);
+/* iq[rx] -> 15*N samples each; returns number of pcap records written for this subframe */
+int o_worker_work(o_worker_t*, const ocf_t* const* iq, uint32_t sf_idx, uint32_t sfn, int update_meta_formats, float cfo_correct_hz);
+const o_stats_t* o_worker_stats(o_worker_t*);
+/* stage taps for parity tests (valid until the next work()) */
+const ocf_t* o_worker_grid(o_worker_t*);
+const ocf_t* o_worker_ce(o_worker_t*);
+const float* o_worker_llr(o_worker_t*, uint32_t* n);
+const o_chest_res_t* o_worker_chest(o_worker_t*);
+uint32_t o_worker_cfi(o_worker_t*);
+/* accepted DCIs of the last subframe, flat: {rnti, format, L, ncce, nof_bits, histval} x n */
+uint32_t o_worker_accepted(o_worker_t*, uint32_t* out6, uint32_t max);
+o_rntiman_t* o_worker_rntiman(o_worker_t*);
+uint64_t o_worker_total_iters(o_worker_t*);
+uint64_t o_worker_algo_bytes(o_worker_t*);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,626 @@
+/* o_worker.c - ORACLE (test infrastructure only): one subframe through the LTESniffer downlink worker with
+ * strictly sequential-subframe semantics.
+ *   SubframeWorker::work / run_dl_mode      /root/reference/src/src/SubframeWorker.cc:142-235
+ *   DCISearch::search / recursive / inspect /root/reference/src/src/DCISearch.cc:102-578
+ *   falcon location map + CCE power         /root/reference/lib/src/phy/falcon_phch/falcon_pdcch.c:110-170,321-367,561-620
+ *   DCIMetaFormats::update_formats          /root/reference/src/src/MetaFormats.cc:41-89
+ *   DCICollection::addCandidate             /root/reference/src/src/DCICollection.cc:97-298
+ *   srsran_dci_msg_to_trace_timestamp       /root/reference/lib/src/phy/falcon_phch/falcon_dci.c:148-352
+ *   PDSCH_Decoder::decode_dl_mode           /root/reference/src/src/DL_Sniffer_PDSCH.cc:881-1291 (+ :611-632, :782-797, :1398-1418)
+ *   MCSTracking (DL table learning)         /root/reference/src/src/MCSTracking.cc:758-848,1269-1291
+ *   evergreen / forbidden setup             /root/reference/src/src/LTESniffer_Core.cc:398-417
+ * Deviations that any deterministic restatement needs (DESIGN.md "determinism"): wall-clock / clock() fields are
+ * dropped; grants that the reference leaves uninitialised (new srsran_pdsch_grant_t without the table's
+ * dci_to_grant call, DL_Sniffer_PDSCH.cc:887 reads them) are defined as "not computed" and the decode gate is
+ * evaluated on the grant that is actually used; RRC ConnectionSetup parsing (p_a feedback) is out of scope
+ *  so p_a stays at the MCSTracking default 0 dB (MCSTracking.cc:1536). */
+#include "lsn_oracle.h"
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct { uint32_t L, ncce; uint8_t used, occupied, checked, sufficient_power; float power; } floc_t;
+typedef struct { floc_t* location[4]; float power; } cce_map_t;
+typedef struct { uint8_t payload[O_DCI_MAX_BITS]; uint32_t nof_bits; int format; uint16_t rnti; } dci_msg_t;
+typedef struct { uint16_t rnti; dci_msg_t msg; uint32_t match; } cand_t;
+typedef struct { int format; uint32_t global_index; uint32_t hits; } meta_t;
+typedef struct { uint16_t rnti; uint32_t L, ncce; int format; cand_t cand; } temp_dci0_t;
+
+typedef struct { /* DL_Sniffer_DCI_DL */
+  uint16_t rnti; int format; uint32_t nof_bits, L, ncce, histval; int mcs_table;
+  o_dci_dl_t dci; uint16_t dci_rnti; /* ran_dci_dl->rnti, zeroed on grant failure */
+  o_pdsch_grant_t g64, g256; int has64, has256;
+} dl_entry_t;
+typedef struct { uint16_t rnti; uint32_t nof_bits, L, ncce, histval; o_dci_ul_t dci; o_pusch_grant_t g; } ul_entry_t;
+
+typedef struct { uint8_t present, has_rar; uint16_t nof_msg_after_rar; uint8_t table; } mcs_entry_t;
+
+struct o_worker {
+  o_worker_cfg_t cfg;
+  o_regs_t regs;
+  o_rntiman_t* rm;
+  meta_t all[O_NOF_FORMATS];
+  meta_t* primary[O_NOF_FORMATS];
+  meta_t* secondary[O_NOF_FORMATS];
+  uint32_t nprimary, nsecondary;
+  o_pcap_t* pcap;
+  o_stats_t stats;
+  mcs_entry_t* mcs; /* [65536] */
+  uint32_t mcs_count;
+  /* per-subframe state */
+  ocf_t *grid, *ce;
+  float* llr;
+  o_chest_res_t chest;
+  uint32_t cfi, sf_idx, sfn;
+  float rb_power[O_MAX_PRB];
+  temp_dci0_t temp0[64];
+  uint32_t ntemp0;
+  dl_entry_t dl[64];
+  uint32_t ndl;
+  ul_entry_t ul[64];
+  uint32_t nul;
+  uint16_t rb_map_dl[O_MAX_PRB], rb_map_ul[O_MAX_PRB];
+  int dl_collision, ul_collision;
+  uint32_t acc[64][6];
+  uint32_t nacc;
+  int16_t *llr0, *llr1;
+  uint8_t* payload;
+  uint64_t total_iters, algo_bytes;
+  int records;
+};
+
+
+/* MetaFormats.cc:41-89 */
+static void update_formats(o_worker_t* w)
+{
+  meta_t* sorted[O_NOF_FORMATS];
+  double total = 0;
+  int n = O_NOF_FORMATS;
+  for (int i = 0; i < n; i++) {
+    sorted[i] = &w->all[i];
+    total += sorted[i]->hits;
+  }
+  for (int i = 0; i < n - 1; i++) {
+    int mx = i;
+    for (int j = mx; j < n; j++)
+      if (sorted[j]->hits > sorted[mx]->hits) mx = j;
+    meta_t* d = sorted[i];
+    sorted[i] = sorted[mx];
+    sorted[mx] = d;
+  }
+  double thr = total * w->cfg.split_ratio, cum = 0;
+  w->nprimary = w->nsecondary = 0;
+  for (int i = 0; i < n; i++) {
+    if (cum <= thr)
+      w->primary[w->nprimary++] = sorted[i];
+    else
+      w->secondary[w->nsecondary++] = sorted[i];
+    cum += sorted[i]->hits;
+    sorted[i]->hits = 0;
+  }
+}
+
+o_worker_t* o_worker_new(const o_worker_cfg_t* cfg)
+{
+  if (o_fft_size(cfg->cell.nof_prb) < 0 || cfg->cell.nof_ports < 1 || cfg->cell.nof_ports > 2 || cfg->nof_rx < 1 ||
+      cfg->nof_rx > O_MAX_RX)
+    return NULL;
+  o_worker_t* w = (o_worker_t*)calloc(1, sizeof(*w));
+  w->cfg = *cfg;
+  if (w->cfg.max_turbo_iter <= 0) w->cfg.max_turbo_iter = 12; /* SubframeWorker.cc:365 */
+  o_regs_init(&cfg->cell, &w->regs);
+  w->rm = o_rntiman_new(O_NOF_FORMATS, 304 / 5, cfg->histogram_threshold); /* PhyCommon.cc:11 */
+  /* LTESniffer_Core.cc:402-417 */
+  o_rntiman_add_evergreen(w->rm, O_RARNTI_START, O_RARNTI_END, O_FMT1A);
+  o_rntiman_add_evergreen(w->rm, O_PRNTI, O_SIRNTI, O_FMT1A);
+  o_rntiman_add_evergreen(w->rm, O_RARNTI_START, O_RARNTI_END, O_FMT1C);
+  o_rntiman_add_evergreen(w->rm, O_PRNTI, O_SIRNTI, O_FMT1C);
+  for (uint32_t f = 0; f < O_NOF_FORMATS; f++) o_rntiman_add_forbidden(w->rm, 0, 0, f);
+  for (int i = 0; i < O_NOF_FORMATS; i++) {
+    w->all[i].format = i;
+    w->all[i].global_index = (uint32_t)i;
+    w->all[i].hits = 0;
+  }
+  update_formats(w);
+  size_t nre = 12u * cfg->cell.nof_prb;
+  w->grid = (ocf_t*)calloc(cfg->nof_rx * 14u * nre, sizeof(ocf_t));
+  w->ce = (ocf_t*)calloc((size_t)cfg->cell.nof_ports * cfg->nof_rx * 14u * nre, sizeof(ocf_t));
+  w->llr = (float*)calloc(8 * 800, sizeof(float));
+  w->mcs = (mcs_entry_t*)calloc(65536, sizeof(mcs_entry_t));
+  w->llr0 = (int16_t*)calloc(14u * nre * 8u, sizeof(int16_t));
+  w->llr1 = (int16_t*)calloc(14u * nre * 8u, sizeof(int16_t));
+  w->payload = (uint8_t*)calloc(32768, 1);
+  return w;
+}
+
+void o_worker_free(o_worker_t* w)
+{
+  if (!w) return;
+  o_rntiman_free(w->rm);
+  free(w->grid); free(w->ce); free(w->llr); free(w->mcs); free(w->llr0); free(w->llr1); free(w->payload);
+  free(w);
+}
+void o_worker_set_pcap(o_worker_t* w, o_pcap_t* p) { w->pcap = p; }
+const o_stats_t* o_worker_stats(o_worker_t* w) { return &w->stats; }
+const ocf_t* o_worker_grid(o_worker_t* w) { return w->grid; }
+const ocf_t* o_worker_ce(o_worker_t* w) { return w->ce; }
+const float* o_worker_llr(o_worker_t* w, uint32_t* n) { if (n) *n = w->regs.nof_cce[w->cfi - 1] * 72; return w->llr; }
+const o_chest_res_t* o_worker_chest(o_worker_t* w) { return &w->chest; }
+uint32_t o_worker_cfi(o_worker_t* w) { return w->cfi; }
+o_rntiman_t* o_worker_rntiman(o_worker_t* w) { return w->rm; }
+uint64_t o_worker_total_iters(o_worker_t* w) { return w->total_iters; }
+uint64_t o_worker_algo_bytes(o_worker_t* w) { return w->algo_bytes; }
+uint32_t o_worker_accepted(o_worker_t* w, uint32_t* out6, uint32_t max)
+{
+  uint32_t n = w->nacc < max ? w->nacc : max;
+  memcpy(out6, w->acc, n * 6 * sizeof(uint32_t));
+  return w->nacc;
+}
+
+/* ---------------- MCSTracking, DL part ---------------- */
+static int mcs_find(o_worker_t* w, uint16_t rnti) /* MCSTracking.cc:758-782 */
+{
+  if (!w->mcs[rnti].present) return w->mcs_count < 250 ? O_TABLE_UNKNOWN : O_TABLE_FULL;
+  return w->mcs[rnti].table;
+}
+static void mcs_add(o_worker_t* w, uint16_t rnti)
+{
+  if (!w->mcs[rnti].present) {
+    memset(&w->mcs[rnti], 0, sizeof(mcs_entry_t));
+    w->mcs[rnti].present = 1;
+    w->mcs[rnti].table = O_TABLE_UNKNOWN;
+    w->mcs_count++;
+  }
+}
+static void mcs_update(o_worker_t* w, uint16_t rnti, int table) /* MCSTracking.cc:797-825 */
+{
+  mcs_entry_t* e = &w->mcs[rnti];
+  if (e->present) {
+    if (e->has_rar) {
+      if (e->nof_msg_after_rar > 3) {
+        e->table = (uint8_t)table;
+        e->has_rar = 0;
+      } else {
+        e->table = O_TABLE_UNKNOWN;
+      }
+    } else {
+      e->table = (uint8_t)table;
+    }
+  } else {
+    mcs_add(w, rnti);
+  }
+}
+static void mcs_rar(o_worker_t* w, uint16_t crnti) /* MCSTracking.cc:827-848 */
+{
+  mcs_add(w, crnti);
+  w->mcs[crnti].has_rar = 1;
+  w->mcs[crnti].table = O_TABLE_UNKNOWN;
+}
+static void mcs_statistic(o_worker_t* w, uint16_t rnti, int format) /* MCSTracking.cc:1269-1291 */
+{
+  mcs_add(w, rnti);
+  if (format > O_FMT1A && w->mcs[rnti].has_rar) w->mcs[rnti].nof_msg_after_rar++;
+}
+
+/* ---------------- DCICollection::addCandidate ---------------- */
+static void add_candidate(o_worker_t* w, const cand_t* c, uint32_t L, uint32_t ncce, uint32_t histval)
+{
+  const o_cell_t* cell = &w->cfg.cell;
+  int fmt = c->msg.format;
+  if (w->nacc < 64) {
+    uint32_t* a = w->acc[w->nacc++];
+    a[0] = c->rnti; a[1] = (uint32_t)fmt; a[2] = L; a[3] = ncce; a[4] = c->msg.nof_bits; a[5] = histval;
+  }
+  int table;
+  if (w->cfg.mcs_tracking_mode == 1) { /* DCICollection.cc:107-134 */
+    if (c->rnti == O_SIRNTI || c->rnti == O_PRNTI || O_RNTI_ISRAR(c->rnti) || fmt == O_FMT1A)
+      table = O_TABLE_64QAM;
+    else
+      table = mcs_find(w, c->rnti);
+  } else if (w->cfg.mcs_tracking_mode == 2) {
+    table = O_TABLE_UNKNOWN;
+  } else {
+    table = O_TABLE_64QAM;
+  }
+  if (fmt == O_FMT0) { /* falcon_dci.c:204-265 */
+    if (w->nul >= 64) return;
+    ul_entry_t* u = &w->ul[w->nul];
+    memset(u, 0, sizeof(*u));
+    u->rnti = c->rnti; u->nof_bits = c->msg.nof_bits; u->L = L; u->ncce = ncce; u->histval = histval;
+    u->dci.L = L; u->dci.ncce = ncce;
+    int ok = c->msg.payload[0] == 0 && o_dci_unpack_ul(cell, c->msg.payload, c->msg.nof_bits, c->rnti, &u->dci) == 0 &&
+             o_ra_ul_dci_to_grant(cell, &u->dci, &u->g) == 0;
+    if (!ok) u->dci.rnti = 0;
+    if (ok) /* DCICollection.cc:275-280 */
+      for (uint32_t i = 0; i < u->g.L_prb; i++) {
+        if (w->rb_map_ul[u->g.n_prb + i] != 0) w->ul_collision = 1;
+        w->rb_map_ul[u->g.n_prb + i] = c->rnti;
+      }
+    w->nul++;
+    return;
+  }
+  if (w->ndl >= 64) return;
+  dl_entry_t* e = &w->dl[w->ndl];
+  memset(e, 0, sizeof(*e));
+  e->rnti = c->rnti; e->format = fmt; e->nof_bits = c->msg.nof_bits; e->L = L; e->ncce = ncce; e->histval = histval;
+  e->mcs_table = table;
+  e->dci.L = L; e->dci.ncce = ncce;
+  e->dci_rnti = c->rnti;
+  if (o_dci_unpack_dl(cell, c->msg.payload, c->msg.nof_bits, fmt, c->rnti, &e->dci) == 0) { /* falcon_dci.c:271-310 */
+    if (table == O_TABLE_64QAM || table >= O_TABLE_UNKNOWN) {
+      e->has64 = 1;
+      if (o_ra_dl_dci_to_grant(cell, w->sf_idx, w->cfi, 0, &e->dci, &e->g64)) e->dci_rnti = 0;
+    }
+    if (table == O_TABLE_256QAM || table >= O_TABLE_UNKNOWN) {
+      e->has256 = 1;
+      if (o_ra_dl_dci_to_grant(cell, w->sf_idx, w->cfi, 1, &e->dci, &e->g256)) e->dci_rnti = 0;
+    }
+  }
+  const o_pdsch_grant_t* gm = e->has64 ? &e->g64 : &e->g256; /* convert_dl_grant source, falcon_dci.c:290,297,307 */
+  for (uint32_t rb = 0; rb < cell->nof_prb; rb++) /* DCICollection.cc:215-223 */
+    if (gm->prb_idx[0][rb]) {
+      if (w->rb_map_dl[rb] != 0) w->dl_collision = 1;
+      w->rb_map_dl[rb] = c->rnti;
+    }
+  for (int i = 0; i < 2; i++) { /* DCICollection.cc:252-259 */
+    if (e->g64.tb[i].nof_bits <= 0) e->g64.tb[i].enabled = 0;
+    if (e->g256.tb[i].nof_bits <= 0) e->g256.tb[i].enabled = 0;
+  }
+  w->ndl++;
+}
+
+/* ---------------- candidate decode (falcon_pdcch.c:110-170) ---------------- */
+static void decode_msg(o_worker_t* w, const floc_t* loc, int format, cand_t* c)
+{
+  uint32_t ncce_tot = w->regs.nof_cce[w->cfi - 1];
+  uint32_t E = 72u << loc->L;
+  if (loc->ncce * 72 + E > ncce_tot * 72) return;
+  uint32_t nof_bits = o_dci_format_sizeof(&w->cfg.cell, format);
+  const float* l = w->llr + loc->ncce * 72;
+  double mean = 0;
+  for (uint32_t i = 0; i < E; i++) mean += (l[i] < 0 ? -l[i] : l[i]);
+  mean /= E;
+  if (mean > 0.0) {
+    c->rnti = o_dci_decode(l, (int)E, (int)nof_bits, c->msg.payload);
+    c->msg.nof_bits = nof_bits;
+    if (format == O_FMT0 || format == O_FMT1A)
+      c->msg.format = c->msg.payload[0] == 0 ? O_FMT0 : O_FMT1A;
+    else
+      c->msg.format = format;
+  }
+}
+
+/* DCISearch::inspect_dci_location_recursively, DCISearch.cc:102-447 */
+static int inspect(o_worker_t* w, cce_map_t* map, uint32_t ncce, uint32_t L, uint32_t max_depth, meta_t** metas,
+                   uint32_t nformats, uint32_t discovery, const cand_t* parent)
+{
+  int hist_max_idx = -1;
+  uint32_t hist_max_val = 0, n_ok = 0;
+  cand_t cand[O_NOF_FORMATS];
+  memset(cand, 0, sizeof(cand));
+  floc_t* loc = map[ncce].location[L];
+  if (!(loc && !loc->occupied && !loc->checked && loc->sufficient_power)) return 0;
+
+  for (uint32_t fi = 0; fi < nformats; fi++) {
+    decode_msg(w, loc, metas[fi]->format, &cand[fi]);
+    w->stats.nof_decoded_locations++;
+    if (o_rntiman_get_activation_reason(w->rm, cand[fi].rnti) == O_ACT_RAR && cand[fi].msg.format == O_FMT0) { /* :139-158 */
+      int add = 1;
+      for (uint32_t i = 0; i < w->ntemp0; i++)
+        if (w->temp0[i].format == cand[fi].msg.format && w->temp0[i].rnti == cand[fi].rnti && w->temp0[i].ncce == ncce) add = 0;
+      if (add && w->ntemp0 < 64) {
+        temp_dci0_t* t = &w->temp0[w->ntemp0++];
+        t->rnti = cand[fi].rnti; t->L = L; t->ncce = ncce; t->format = cand[fi].msg.format; t->cand = cand[fi];
+      }
+    }
+    if (metas[fi]->format != cand[fi].msg.format) { /* :163 */
+      cand[fi].rnti = 0;
+      continue;
+    }
+    if (metas[fi]->format == O_FMT1C && cand[fi].rnti > O_RARNTI_END && cand[fi].rnti < O_PRNTI) { /* :174 */
+      cand[fi].rnti = 0;
+      continue;
+    }
+    if (cand[fi].rnti > O_RARNTI_START && cand[fi].rnti < O_RARNTI_END) /* :181-197 */
+      if (metas[fi]->format != O_FMT1A && metas[fi]->format != O_FMT1C) {
+        cand[fi].rnti = 0;
+        continue;
+      }
+    if (w->cfg.enable_shortcut && discovery && parent != NULL && parent[fi].rnti == cand[fi].rnti &&
+        !o_rntiman_is_forbidden(w->rm, cand[fi].rnti, metas[fi]->global_index)) /* :200-211 */
+      return -((int)fi + 1);
+    cand[fi].match = o_validate_location(w->regs.nof_cce[w->cfi - 1], ncce, L, w->sf_idx, cand[fi].rnti); /* :214 */
+    if (cand[fi].match == 0) {
+      cand[fi].rnti = 0;
+      continue;
+    }
+    if (o_rntiman_validate_and_refresh(w->rm, cand[fi].rnti, metas[fi]->global_index)) { /* :245-250 */
+      n_ok++;
+      hist_max_idx = (int)fi;
+      hist_max_val = o_rntiman_get_frequency(w->rm, cand[fi].rnti, metas[fi]->global_index);
+    }
+  }
+  if (n_ok > 1) { /* :255-280 */
+    hist_max_idx = -1;
+    uint32_t hmax = 0;
+    for (uint32_t fi = 0; fi < nformats; fi++)
+      if (cand[fi].rnti != 0) {
+        uint32_t h = o_rntiman_get_frequency(w->rm, cand[fi].rnti, metas[fi]->global_index);
+        if (h > hmax) {
+          hmax = h;
+          hist_max_idx = (int)fi;
+          hist_max_val = h;
+        }
+      }
+    if (hist_max_idx == -1) n_ok = 0;
+  }
+  loc->checked = 1; /* :282 */
+  int disamb = 0;
+  if (n_ok > 0 && cand[hist_max_idx].match == 1) { /* :288-298 */
+    if (L > 0 && max_depth > 0)
+      disamb = inspect(w, map, ncce + (1u << (L - 1)), L - 1, max_depth - 1, metas, nformats, 0, NULL);
+  } else if (n_ok == 0) { /* :302-368 */
+    int rr = 0;
+    if (L > 0 && max_depth > 0) {
+      rr += inspect(w, map, ncce, L - 1, max_depth - 1, metas, nformats, discovery, cand);
+      if (rr < 0) {
+        hist_max_idx = -rr - 1;
+        hist_max_val = o_rntiman_get_frequency(w->rm, cand[hist_max_idx].rnti, metas[hist_max_idx]->global_index);
+        n_ok = 1;
+        if (cand[hist_max_idx].match == 1) {
+          uint32_t md = max_depth < 99 ? max_depth : 99;
+          disamb = inspect(w, map, ncce + (1u << (L - 1)), L - 1, md - 1, metas, nformats, 0, NULL);
+        }
+        o_rntiman_activate_and_refresh(w->rm, cand[hist_max_idx].rnti, metas[hist_max_idx]->global_index, O_ACT_SHORTCUT);
+      } else {
+        rr += inspect(w, map, ncce + (1u << (L - 1)), L - 1, max_depth - 1, metas, nformats, discovery, NULL);
+      }
+    }
+    if (rr == 0) {
+      if (discovery)
+        for (uint32_t fi = 0; fi < nformats; fi++)
+          if (cand[fi].rnti != 0) o_rntiman_add_candidate(w->rm, cand[fi].rnti, metas[fi]->global_index);
+      return 0;
+    } else if (rr > 0) {
+      return rr;
+    }
+  }
+  if (n_ok > 0) { /* :371-439 */
+    loc->used = 1;
+    for (uint32_t ci = ncce; ci < ncce + (1u << L); ci++)
+      for (int a = 0; a < 4; a++)
+        if (map[ci].location[a]) {
+          map[ci].location[a]->occupied = 1;
+          map[ci].location[a]->checked = 1;
+        }
+    o_rntiman_add_candidate(w->rm, cand[hist_max_idx].rnti, metas[hist_max_idx]->global_index);
+    metas[hist_max_idx]->hits++;
+    uint32_t Ld = disamb > 0 ? L - 1 : L;
+    cand[hist_max_idx].msg.rnti = cand[hist_max_idx].rnti;
+    if (cand[hist_max_idx].rnti != 0) {
+      int add = 1;
+      if (cand[hist_max_idx].msg.format == O_FMT0)
+        for (uint32_t i = 0; i < w->ntemp0; i++)
+          if (w->temp0[i].format == O_FMT0 && w->temp0[i].rnti == cand[hist_max_idx].rnti && w->temp0[i].ncce == ncce) add = 0;
+      if (add) add_candidate(w, &cand[hist_max_idx], Ld, ncce, hist_max_val);
+      for (uint32_t i = 0; i < w->ntemp0; i++) { /* :422-432 - temp_dci0 entries all carry format 0 */
+        uint32_t hv = o_rntiman_get_frequency(w->rm, w->temp0[i].rnti, (uint32_t)w->temp0[i].format);
+        add_candidate(w, &w->temp0[i].cand, w->temp0[i].L, w->temp0[i].ncce, hv);
+      }
+      w->ntemp0 = 0;
+    }
+    return 1 + disamb;
+  }
+  return 0;
+}
+
+/* DCISearch::recursive_blind_dci_search, DCISearch.cc:449-528 */
+static void blind_search(o_worker_t* w)
+{
+  floc_t locs[O_MAX_LOCATIONS];
+  cce_map_t map[O_MAX_NUM_OF_CCE];
+  memset(map, 0, sizeof(map));
+  uint32_t ncce = w->regs.nof_cce[w->cfi - 1];
+  uint32_t lim = ncce < O_MAX_NUM_OF_CCE ? ncce : O_MAX_NUM_OF_CCE;
+  w->stats.nof_cce += ncce;
+  uint32_t k = 0;
+  for (int l = 3; l >= 0; l--) { /* falcon_pdcch.c:321-356 */
+    uint32_t L = 1u << l;
+    for (uint32_t i = 0; i < lim / L; i++)
+      if (k < O_MAX_LOCATIONS) {
+        memset(&locs[k], 0, sizeof(floc_t));
+        locs[k].L = (uint32_t)l;
+        locs[k].ncce = L * (i % (ncce / L));
+        locs[k].sufficient_power = 1;
+        for (uint32_t m = locs[k].ncce; m < locs[k].ncce + L; m++) map[m].location[l] = &locs[k];
+        k++;
+      }
+  }
+  uint32_t nloc = k;
+  w->stats.nof_locations += nloc;
+  for (uint32_t c = 0; c < ncce && c < O_MAX_NUM_OF_CCE; c++) { /* falcon_pdcch.c:595-620 */
+    double mean = 0;
+    for (int i = 0; i < 72; i++) {
+      float v = w->llr[c * 72 + (uint32_t)i];
+      mean += (v < 0 ? -v : v);
+    }
+    map[c].power = (float)(mean / 72);
+    if (map[c].power < 0.7f)
+      for (int a = 0; a < 4; a++)
+        if (map[c].location[a]) map[c].location[a]->sufficient_power = 0;
+  }
+  for (uint32_t i = 0; i < nloc; i++)
+    inspect(w, map, locs[i].ncce, locs[i].L, 99, w->primary, w->nprimary, 1, NULL);
+  if (!w->cfg.skip_secondary) {
+    for (uint32_t i = 0; i < nloc; i++) locs[i].checked = 0;
+    for (uint32_t i = 0; i < nloc; i++)
+      inspect(w, map, locs[i].ncce, locs[i].L, 99, w->secondary, w->nsecondary, 1, NULL);
+  }
+  if (w->dl_collision) w->stats.nof_subframe_collisions_dw++;
+  if (w->ul_collision) w->stats.nof_subframe_collisions_up++;
+  uint32_t missed = 0; /* falcon_pdcch.c:561-593 */
+  for (uint32_t c = 0; c < ncce && c < O_MAX_NUM_OF_CCE; c++) {
+    if (map[c].power < 0.7f) continue;
+    int m = 1;
+    for (int a = 0; a < 4; a++)
+      if (map[c].location[a] && map[c].location[a]->used) {
+        m = 0;
+        break;
+      }
+    if (m) missed++;
+  }
+  w->stats.nof_missed_cce += missed;
+  o_rntiman_step_time(w->rm);
+}
+
+/* ---------------- PDSCH ---------------- */
+static void write_pcap(o_worker_t* w, const char* name, const uint8_t* pdu, uint32_t len, uint16_t rnti, uint32_t tti)
+{
+  if (!w->pcap) return;
+  w->records++;
+  if (name[0] == 'S') o_pcap_write(w->pcap, pdu, len, tti, O_SIRNTI, 1, O_PCAP_SI_RNTI, 1, 0, 0);
+  else if (name[0] == 'P') o_pcap_write(w->pcap, pdu, len, tti, O_PRNTI, 1, O_PCAP_P_RNTI, 1, 0, 0);
+  else if (name[0] == 'R') o_pcap_write(w->pcap, pdu, len, tti, rnti, 1, O_PCAP_RA_RNTI, 1, 0, 0);
+  else o_pcap_write(w->pcap, pdu, len, tti, rnti, 1, O_PCAP_C_RNTI, 1, 0, 0);
+}
+
+static const char* rnti_name(uint16_t r) /* DL_Sniffer_PDSCH.cc:1398-1418 */
+{
+  if (r == O_SIRNTI) return "SI_RNTI";
+  if (r == O_PRNTI) return "P_RNTI";
+  if (r > O_RARNTI_START && r < O_RARNTI_END) return "RA_RNTI";
+  return "C_RNTI";
+}
+
+/* MAC RAR PDU (TS 36.321 6.1.5 / 6.2.2-6.2.3) walked like srsran::rar_pdu; DL_Sniffer_PDSCH.cc:782-797 */
+static void unpack_rar(o_worker_t* w, const uint8_t* p, int len)
+{
+  int nsub = 0, is_rapid[32], pos = 0;
+  while (pos < len && nsub < 32) {
+    uint8_t b = p[pos++];
+    is_rapid[nsub++] = (b & 0x40) ? 1 : 0;
+    if (!(b & 0x80)) break;
+  }
+  for (int i = 0; i < nsub; i++) {
+    uint16_t t_crnti = 0;
+    if (is_rapid[i]) {
+      if (pos + 6 > len) break;
+      t_crnti = (uint16_t)((p[pos + 4] << 8) | p[pos + 5]);
+      pos += 6;
+    }
+    mcs_rar(w, t_crnti);
+    o_rntiman_activate_and_refresh(w->rm, t_crnti, 0, O_ACT_RAR);
+  }
+}
+
+/* one srsran_ue_dl_decode_pdsch call: returns crc[2]; payload of TB i at w->payload + i*8192 */
+static void decode_grant(o_worker_t* w, const dl_entry_t* e, const o_pdsch_grant_t* g, int* crc)
+{
+  crc[0] = crc[1] = 0;
+  if (!(g->tb[0].enabled || g->tb[1].enabled)) return;
+  memset(w->llr0, 0, sizeof(int16_t) * g->nof_re * 8);
+  memset(w->llr1, 0, sizeof(int16_t) * g->nof_re * 8);
+  if (o_pdsch_demod(&w->cfg.cell, w->cfg.nof_rx, w->sf_idx, w->cfi, e->rnti, g, w->grid, w->ce, w->chest.noise_avg,
+                    w->chest.chan_ref, 0.0f, w->llr0, w->llr1))
+    return;
+  for (int i = 0; i < 2; i++)
+    if (g->tb[i].enabled && g->tb[i].tbs > 0) {
+      const int16_t* llr = (g->tb[i].cw_idx & 1) ? w->llr1 : w->llr0;
+      int its = 0;
+      crc[i] = o_pdsch_decode_tb(llr, g->tb[i].nof_bits, g->tb[i].tbs, g->tb[i].mod, g->tx_scheme == O_TX_DIVERSITY ? 2 : 1,
+                                 g->tb[i].rv, w->cfg.max_turbo_iter, w->payload + i * 8192 * 2, &its);
+      w->total_iters += (uint64_t)its;
+      w->algo_bytes += 2ull * (uint64_t)g->tb[i].nof_bits * 2ull + (uint64_t)g->tb[i].tbs / 8ull;
+    }
+}
+
+/* PDSCH_Decoder::decode_dl_mode, DL_Sniffer_PDSCH.cc:881-1291 */
+static void decode_dl_mode(o_worker_t* w)
+{
+  uint32_t tti = w->sfn * 10 + w->sf_idx;
+  for (uint32_t di = 0; di < w->ndl; di++) {
+    dl_entry_t* e = &w->dl[di];
+    o_pdsch_grant_t* cur = (e->mcs_table == O_TABLE_256QAM) ? &e->g256 : &e->g64;
+    o_pdsch_grant_t* cur256 = &e->g256;
+    int two_tb = (e->has64 && e->g64.nof_tb == 2) || (e->has256 && e->g256.nof_tb == 2);
+    int gate = (cur->tb[0].tbs > 0 && e->dci_rnti > 0 && !(w->cfg.nof_rx == 1 && two_tb)) || e->rnti == O_PRNTI; /* :887-889 */
+    if (!gate) continue;
+    if (e->dci.tb[0].rv < 0 && e->rnti == O_SIRNTI) cur->tb[0].rv = 0; /* :891-897 */
+    const char* name = rnti_name(e->rnti);
+    int crc[2] = {0, 0};
+    int mimo_ret;
+    if (e->mcs_table == O_TABLE_64QAM || e->mcs_table == O_TABLE_256QAM) { /* :932-1083 */
+      mimo_ret = o_config_mimo(&w->cfg.cell, e->format, &e->dci, cur);
+      if (mimo_ret == 0) {
+        decode_grant(w, e, cur, crc);
+        for (int tb = 0; tb < 2; tb++) {
+          int len = cur->tb[tb].tbs / 8;
+          if (crc[tb] && len > 0) {
+            write_pcap(w, name, w->payload + tb * 16384, (uint32_t)len, e->rnti, tti);
+            if (name[0] == 'R') unpack_rar(w, w->payload + tb * 16384, len);
+          }
+        }
+      }
+    } else { /* unknown table: 64QAM first, then 256QAM if both TBs failed, :1089-1243 */
+      mimo_ret = o_config_mimo(&w->cfg.cell, e->format, &e->dci, cur);
+      if (mimo_ret == 0) {
+        decode_grant(w, e, cur, crc);
+        for (int tb = 0; tb < 2; tb++) {
+          int len = cur->tb[tb].tbs / 8;
+          if (crc[tb] && len > 0) {
+            write_pcap(w, name, w->payload + tb * 16384, (uint32_t)len, e->rnti, tti);
+            if (name[0] == 'R') unpack_rar(w, w->payload + tb * 16384, len);
+            if (e->dci.tb[tb].mcs_idx > 0 && e->dci.tb[tb].mcs_idx < 29 && e->format > O_FMT1A) mcs_update(w, e->rnti, O_TABLE_64QAM);
+          }
+        }
+      }
+      if (!crc[0] && !crc[1] && mimo_ret == 0) {
+        mimo_ret = o_config_mimo(&w->cfg.cell, e->format, &e->dci, cur256);
+        if (mimo_ret == 0) {
+          int crc2[2];
+          decode_grant(w, e, cur256, crc2);
+          for (int tb = 0; tb < 2; tb++) {
+            if (cur256->tb[tb].enabled) crc[tb] = crc2[tb];
+            int len = cur256->tb[tb].tbs / 8;
+            if (crc[tb] && len > 0) {
+              write_pcap(w, name, w->payload + tb * 16384, (uint32_t)len, e->rnti, tti);
+              if (e->dci.tb[tb].mcs_idx > 0 && e->dci.tb[tb].mcs_idx < 28 && e->format > O_FMT1A) mcs_update(w, e->rnti, O_TABLE_256QAM);
+            }
+          }
+        }
+      }
+    }
+    if (name[0] == 'C' && w->cfg.mcs_tracking_mode) mcs_statistic(w, e->rnti, e->format); /* :1268-1285 */
+  }
+}
+
+int o_worker_work(o_worker_t* w, const ocf_t* const* iq, uint32_t sf_idx, uint32_t sfn, int update_meta, float cfo_hz)
+{
+  const o_cell_t* cell = &w->cfg.cell;
+  size_t nre = 12u * cell->nof_prb;
+  w->sf_idx = sf_idx;
+  w->sfn = sfn;
+  w->records = 0;
+  w->ndl = w->nul = w->nacc = w->ntemp0 = 0;
+  w->dl_collision = w->ul_collision = 0;
+  memset(w->rb_map_dl, 0, sizeof(w->rb_map_dl));
+  memset(w->rb_map_ul, 0, sizeof(w->rb_map_ul));
+  if (update_meta) update_formats(w); /* SubframeWorker.cc:148-151 */
+  uint32_t dphi = cfo_hz != 0.0f ? o_nco_dphi(cfo_hz, o_fft_size(cell->nof_prb)) : 0;
+  /* srsran_ue_dl_decode_fft_estimate, DCISearch.cc:562 */
+  for (uint32_t rx = 0; rx < w->cfg.nof_rx; rx++) o_ofdm_rx(cell, iq[rx], dphi, w->grid + rx * 14u * nre);
+  o_chest(cell, w->cfg.nof_rx, sf_idx, w->grid, w->ce, &w->chest);
+  w->cfi = o_pcfich_decode(cell, &w->regs, w->cfg.nof_rx, sf_idx, w->grid, w->ce, w->chest.noise_avg, NULL);
+  o_pdcch_llr(cell, &w->regs, w->cfg.nof_rx, sf_idx, w->cfi, w->grid, w->ce, w->chest.noise_avg, w->llr);
+  o_subframe_power(cell, w->grid, w->rb_power, NULL, NULL); /* DCISearch.cc:565 */
+  uint32_t A = w->cfg.nof_rx, P = cell->nof_ports;
+  w->algo_bytes += A * (uint64_t)(15 * o_fft_size(cell->nof_prb)) * 8ull + 2ull * A * 14ull * nre * 8ull + 2ull * P * A * 14ull * nre * 8ull +
+                   2ull * w->regs.nof_cce[w->cfi - 1] * 72ull * 4ull;
+  if (w->chest.snr_db > 6.0f) { /* DCISearch.cc:568-574 */
+    blind_search(w);
+    w->stats.nof_subframes++;
+    decode_dl_mode(w); /* SubframeWorker.cc:224 */
+  } else {
+    w->stats.nof_subframes++;
+  }
+  return w->records;
+}

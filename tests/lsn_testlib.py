@@ -1,0 +1,278 @@
+"""ctypes bindings used by the tests, smoke() and bench.py's cpu_baseline leg:
+   - the CPU ORACLE (oracle/_build/liblsn_oracle.so)  -- test infrastructure, never the product path
+   - the synthetic eNB transmitter (tools/txgen/_build/libtxgen.so) -- test tooling
+"""
+import ctypes as C
+import os
+import struct
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_SO = os.path.join(ROOT, "oracle", "_build", "liblsn_oracle.so")
+TXGEN_SO = os.path.join(ROOT, "tools", "txgen", "_build", "libtxgen.so")
+
+
+def _ensure(path, mkdir):
+    if not os.path.exists(path):
+        subprocess.check_call(["make", "-C", mkdir], stdout=subprocess.DEVNULL)
+    return path
+
+
+class OCell(C.Structure):
+    _fields_ = [("nof_prb", C.c_uint32), ("nof_ports", C.c_uint32), ("id", C.c_uint32), ("phich_ng_x6", C.c_uint32)]
+
+
+class OWorkerCfg(C.Structure):
+    _fields_ = [("cell", OCell), ("nof_rx", C.c_uint32), ("histogram_threshold", C.c_uint32), ("split_ratio", C.c_double),
+                ("skip_secondary", C.c_int), ("mcs_tracking_mode", C.c_int), ("max_turbo_iter", C.c_int),
+                ("enable_shortcut", C.c_int)]
+
+
+class OChestRes(C.Structure):
+    _fields_ = [("noise", C.c_float * 4), ("rsrp", C.c_float * 4), ("cepow", C.c_float * 4), ("cfo_corr", C.c_float * 2),
+                ("noise_avg", C.c_float), ("rsrp_avg", C.c_float), ("snr_db", C.c_float), ("cfo_hz", C.c_float),
+                ("chan_ref", C.c_float)]
+
+
+class OStats(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("nof_decoded_locations", "nof_cce", "nof_missed_cce", "nof_subframes",
+                                          "nof_subframe_collisions_dw", "nof_subframe_collisions_up", "nof_locations")]
+
+
+class TxgCfg(C.Structure):
+    _fields_ = [("nof_prb", C.c_uint32), ("nof_ports", C.c_uint32), ("cell_id", C.c_uint32), ("phich_ng_x6", C.c_uint32),
+                ("nof_rx", C.c_uint32), ("snr_db", C.c_float), ("cfo_hz", C.c_float), ("delay_samples", C.c_uint32),
+                ("seed", C.c_uint64), ("n_rnti", C.c_uint32), ("dl_min", C.c_uint32), ("dl_max", C.c_uint32),
+                ("ul_min", C.c_uint32), ("ul_max", C.c_uint32), ("cfi", C.c_uint32), ("mix_tm3_pct", C.c_uint32),
+                ("mix_tm4_pct", C.c_uint32), ("pct_256qam", C.c_uint32), ("mcs_min", C.c_uint32), ("mcs_max", C.c_uint32),
+                ("sib_period", C.c_uint32), ("rar_period", C.c_uint32), ("paging_period", C.c_uint32),
+                ("start_tti", C.c_uint32), ("fixed_L", C.c_uint32)]
+
+
+class TxgPdu(C.Structure):
+    _fields_ = [("rnti", C.c_uint16), ("format", C.c_uint8), ("L", C.c_uint8), ("ncce", C.c_uint16), ("tti", C.c_uint32),
+                ("nbytes", C.c_uint32), ("offset", C.c_uint32), ("tb", C.c_uint8), ("mod", C.c_uint8),
+                ("table256", C.c_uint8), ("is_ul", C.c_uint8), ("nof_prb", C.c_uint32), ("mcs", C.c_uint32)]
+
+
+_oracle = None
+_txgen = None
+
+
+def oracle():
+    global _oracle
+    if _oracle is None:
+        lib = C.CDLL(_ensure(ORACLE_SO, os.path.join(ROOT, "oracle")))
+        lib.o_crc_bits.restype = C.c_uint32
+        lib.o_crc_bits.argtypes = [C.c_uint32, C.c_int, C.c_void_p, C.c_int]
+        lib.o_gold.argtypes = [C.c_uint32, C.c_void_p, C.c_int]
+        lib.o_reduce256.restype = C.c_float
+        lib.o_reduce256.argtypes = [C.c_void_p, C.c_int]
+        lib.o_fft_size.argtypes = [C.c_uint32]
+        lib.o_fft.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
+        lib.o_fft_twiddles.argtypes = [C.c_int, C.c_void_p]
+        lib.o_ofdm_rx.argtypes = [C.POINTER(OCell), C.c_void_p, C.c_uint32, C.c_void_p]
+        lib.o_dci_format_sizeof.restype = C.c_uint32
+        lib.o_dci_format_sizeof.argtypes = [C.POINTER(OCell), C.c_int]
+        lib.o_dci_decode.restype = C.c_uint16
+        lib.o_dci_decode.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        lib.o_validate_location.restype = C.c_uint32
+        lib.o_validate_location.argtypes = [C.c_uint32] * 4 + [C.c_uint16]
+        lib.o_turbo_nwin.argtypes = [C.c_int]
+        lib.o_turbo_decode_cb.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_uint32, C.c_void_p, C.POINTER(C.c_int)]
+        lib.o_rm_turbo_rx_cb.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        lib.o_pdsch_decode_tb.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                          C.POINTER(C.c_int)]
+        lib.o_tbs_from_idx.argtypes = [C.c_int, C.c_uint32]
+        lib.o_worker_new.restype = C.c_void_p
+        lib.o_worker_new.argtypes = [C.POINTER(OWorkerCfg)]
+        lib.o_worker_free.argtypes = [C.c_void_p]
+        lib.o_worker_set_pcap.argtypes = [C.c_void_p, C.c_void_p]
+        lib.o_worker_work.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_uint32, C.c_uint32, C.c_int, C.c_float]
+        lib.o_worker_stats.restype = C.POINTER(OStats)
+        lib.o_worker_stats.argtypes = [C.c_void_p]
+        lib.o_worker_grid.restype = C.c_void_p
+        lib.o_worker_grid.argtypes = [C.c_void_p]
+        lib.o_worker_ce.restype = C.c_void_p
+        lib.o_worker_ce.argtypes = [C.c_void_p]
+        lib.o_worker_llr.restype = C.c_void_p
+        lib.o_worker_llr.argtypes = [C.c_void_p, C.POINTER(C.c_uint32)]
+        lib.o_worker_chest.restype = C.POINTER(OChestRes)
+        lib.o_worker_chest.argtypes = [C.c_void_p]
+        lib.o_worker_cfi.restype = C.c_uint32
+        lib.o_worker_cfi.argtypes = [C.c_void_p]
+        lib.o_worker_accepted.restype = C.c_uint32
+        lib.o_worker_accepted.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        lib.o_worker_total_iters.restype = C.c_uint64
+        lib.o_worker_total_iters.argtypes = [C.c_void_p]
+        lib.o_worker_algo_bytes.restype = C.c_uint64
+        lib.o_worker_algo_bytes.argtypes = [C.c_void_p]
+        lib.o_worker_rntiman.restype = C.c_void_p
+        lib.o_worker_rntiman.argtypes = [C.c_void_p]
+        lib.o_rntiman_nof_active.restype = C.c_uint32
+        lib.o_rntiman_nof_active.argtypes = [C.c_void_p]
+        lib.o_pcap_open_mem.restype = C.c_void_p
+        lib.o_pcap_open_file.restype = C.c_void_p
+        lib.o_pcap_open_file.argtypes = [C.c_char_p]
+        lib.o_pcap_write.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint16, C.c_uint8, C.c_uint8,
+                                     C.c_uint8, C.c_uint32, C.c_uint32]
+        lib.o_pcap_mem.restype = C.c_void_p
+        lib.o_pcap_mem.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+        lib.o_pcap_nof_records.restype = C.c_uint32
+        lib.o_pcap_nof_records.argtypes = [C.c_void_p]
+        lib.o_pcap_close.argtypes = [C.c_void_p]
+        _oracle = lib
+    return _oracle
+
+
+def txgen():
+    global _txgen
+    if _txgen is None:
+        lib = C.CDLL(_ensure(TXGEN_SO, os.path.join(ROOT, "tools", "txgen")))
+        lib.txg_new.restype = C.c_void_p
+        lib.txg_new.argtypes = [C.POINTER(TxgCfg)]
+        lib.txg_free.argtypes = [C.c_void_p]
+        lib.txg_next.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(TxgPdu), C.c_int, C.c_void_p, C.c_int]
+        lib.txg_sf_len.restype = C.c_uint32
+        lib.txg_sf_len.argtypes = [C.c_void_p]
+        lib.txg_tti.restype = C.c_uint32
+        lib.txg_tti.argtypes = [C.c_void_p]
+        _txgen = lib
+    return _txgen
+
+
+# -------- scenario presets (sizes scaled by the caller) --------
+def scenario(name, seed=1, **over):
+    base = dict(nof_prb=100, nof_ports=2, cell_id=1, phich_ng_x6=1, nof_rx=2, snr_db=30.0, cfo_hz=0.0, delay_samples=0,
+                seed=seed, n_rnti=32, dl_min=6, dl_max=6, ul_min=2, ul_max=2, cfi=3, mix_tm3_pct=0, mix_tm4_pct=0,
+                pct_256qam=0, mcs_min=0, mcs_max=28, sib_period=1, rar_period=0, paging_period=0, start_tti=0, fixed_L=0)
+    presets = {
+        # config 1: 10 MHz, single RNTI, TM1 QPSK, 1 port / 1 rx
+        "cfg1": dict(nof_prb=50, nof_ports=1, nof_rx=1, snr_db=20.0, cfo_hz=300.0, n_rnti=1, dl_min=1, dl_max=1, ul_min=0,
+                     ul_max=1, cfi=2, mcs_min=0, mcs_max=9),
+        # config 2: 20 MHz, 32 RNTIs, TM2, 64QAM
+        "cfg2": dict(n_rnti=32, snr_db=28.0, dl_min=6, dl_max=6, ul_min=2, ul_max=2, mcs_min=17, mcs_max=28),
+        # config 3: 20 MHz, 150 RNTIs, TM3/TM4 mix up to 256QAM (north-star)
+        "cfg3": dict(n_rnti=150, snr_db=30.0, dl_min=8, dl_max=14, ul_min=3, ul_max=6, mix_tm3_pct=40, mix_tm4_pct=30,
+                     pct_256qam=50, mcs_min=0, mcs_max=28, rar_period=200, paging_period=64),
+        "small": dict(nof_prb=25, nof_ports=2, nof_rx=2, n_rnti=4, dl_min=2, dl_max=3, ul_min=0, ul_max=1, cfi=2,
+                      mcs_min=2, mcs_max=20),
+    }
+    d = dict(base)
+    d.update(presets[name])
+    d.update(over)
+    return d
+
+
+class TxGen:
+    def __init__(self, **kw):
+        self.lib = txgen()
+        self.cfg = TxgCfg(**kw)
+        self.h = self.lib.txg_new(C.byref(self.cfg))
+        assert self.h, "txg_new failed"
+        self.sf_len = self.lib.txg_sf_len(self.h)
+        self.nof_rx = self.cfg.nof_rx
+        self._pdus = (TxgPdu * 128)()
+        self._pbuf = np.zeros(1 << 19, dtype=np.uint8)
+
+    def next(self):
+        """-> (tti, iq[nof_rx, sf_len] complex64, pdus list of dict(with payload bytes))"""
+        tti = self.lib.txg_tti(self.h)
+        iq = np.zeros((self.nof_rx, self.sf_len), dtype=np.complex64)
+        n = self.lib.txg_next(self.h, iq.ctypes.data, self._pdus, 128, self._pbuf.ctypes.data, self._pbuf.size)
+        out = []
+        for i in range(n):
+            p = self._pdus[i]
+            out.append(dict(rnti=p.rnti, format=p.format, L=p.L, ncce=p.ncce, tti=p.tti, tb=p.tb, mod=p.mod,
+                            table256=p.table256, is_ul=p.is_ul, nof_prb=p.nof_prb, mcs=p.mcs,
+                            payload=bytes(self._pbuf[p.offset:p.offset + p.nbytes]) if not p.is_ul else b""))
+        return tti, iq, out
+
+    def __del__(self):
+        try:
+            self.lib.txg_free(self.h)
+        except Exception:
+            pass
+
+
+class OracleWorker:
+    def __init__(self, nof_prb, nof_ports, cell_id, nof_rx, phich_ng_x6=1, threshold=5, split_ratio=0.99, skip_secondary=0,
+                 mcs_tracking_mode=1, max_turbo_iter=12, enable_shortcut=1):
+        self.lib = oracle()
+        self.cfg = OWorkerCfg(OCell(nof_prb, nof_ports, cell_id, phich_ng_x6), nof_rx, threshold, split_ratio, skip_secondary,
+                              mcs_tracking_mode, max_turbo_iter, enable_shortcut)
+        self.h = self.lib.o_worker_new(C.byref(self.cfg))
+        assert self.h
+        self.pcap = self.lib.o_pcap_open_mem()
+        self.lib.o_worker_set_pcap(self.h, self.pcap)
+        self.nof_rx = nof_rx
+        self.nre = 12 * nof_prb
+        self.nof_ports = nof_ports
+
+    def work(self, iq, tti, update_meta=None, cfo_hz=0.0):
+        iq = np.ascontiguousarray(iq, dtype=np.complex64)
+        ptrs = (C.c_void_p * self.nof_rx)(*[iq[r].ctypes.data for r in range(self.nof_rx)])
+        if update_meta is None:
+            update_meta = 0
+        return self.lib.o_worker_work(self.h, ptrs, tti % 10, (tti // 10) % 1024, int(update_meta), float(cfo_hz))
+
+    def grid(self):
+        a = np.ctypeslib.as_array(C.cast(self.lib.o_worker_grid(self.h), C.POINTER(C.c_float)),
+                                  shape=(self.nof_rx, 14, self.nre, 2))
+        return a.copy().view(np.complex64)[..., 0]
+
+    def ce(self):
+        a = np.ctypeslib.as_array(C.cast(self.lib.o_worker_ce(self.h), C.POINTER(C.c_float)),
+                                  shape=(self.nof_ports, self.nof_rx, 14, self.nre, 2))
+        return a.copy().view(np.complex64)[..., 0]
+
+    def llr(self):
+        n = C.c_uint32()
+        p = self.lib.o_worker_llr(self.h, C.byref(n))
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(n.value,)).copy()
+
+    def chest(self):
+        return self.lib.o_worker_chest(self.h).contents
+
+    def cfi(self):
+        return self.lib.o_worker_cfi(self.h)
+
+    def accepted(self):
+        buf = (C.c_uint32 * (64 * 6))()
+        n = self.lib.o_worker_accepted(self.h, buf, 64)
+        return [tuple(buf[6 * i:6 * i + 6]) for i in range(min(n, 64))]
+
+    def stats(self):
+        return self.lib.o_worker_stats(self.h).contents
+
+    def pcap_bytes(self):
+        n = C.c_size_t()
+        p = self.lib.o_pcap_mem(self.pcap, C.byref(n))
+        return C.string_at(p, n.value)
+
+    def nof_active(self):
+        return self.lib.o_rntiman_nof_active(self.lib.o_worker_rntiman(self.h))
+
+    def __del__(self):
+        try:
+            self.lib.o_worker_free(self.h)
+            self.lib.o_pcap_close(self.pcap)
+        except Exception:
+            pass
+
+
+def parse_pcap(data):
+    """-> list of dict(direction, rnti_type, rnti, sfn, sf, crc, pdu) ; timestamps dropped"""
+    assert data[:4] == b"\xd4\xc3\xb2\xa1"
+    off, out = 24, []
+    while off < len(data):
+        ts, tu, il, ol = struct.unpack("<IIII", data[off:off + 16])
+        off += 16
+        p = data[off:off + il]
+        off += il
+        fs = (p[10] << 8) | p[11]
+        out.append(dict(direction=p[1], rnti_type=p[2], rnti=(p[4] << 8) | p[5], sfn=fs >> 4, sf=fs & 15, crc=p[13],
+                        pdu=bytes(p[19:]), ctx=bytes(p[:19])))
+    return out

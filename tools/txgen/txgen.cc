@@ -1,0 +1,673 @@
+// txgen.cc - synthetic LTE eNB downlink transmitter + channel (TEST TOOLING, not product, not oracle).
+// Encoder-side implementation of TS 36.211/36.212 written independently of the receiver code so that
+// transmitter -> receiver loop-backs are meaningful known-answer tests.
+// Produces pre-aligned subframes: IQ[rx][15*N] cf32 + the ground-truth list of MAC PDUs.
+#include "../../spec/lte_tables.h"
+#include <cmath>
+#include <complex>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+typedef std::complex<float> cf;
+typedef std::vector<uint8_t> bits_t;
+
+namespace {
+
+// ---------------- rng (xorshift64*) ----------------
+struct Rng {
+  uint64_t s;
+  explicit Rng(uint64_t seed) : s(seed * 0x9E3779B97F4A7C15ull + 0x1234567ull) { next(); next(); }
+  uint64_t next() { s ^= s >> 12; s ^= s << 25; s ^= s >> 27; return s * 0x2545F4914F6CDD1Dull; }
+  uint32_t u32() { return (uint32_t)(next() >> 32); }
+  uint32_t below(uint32_t n) { return n ? (uint32_t)(((uint64_t)u32() * n) >> 32) : 0; }
+  double uni() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); }
+  double gauss() { double u1 = uni(), u2 = uni(); if (u1 < 1e-300) u1 = 1e-300; return std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2); }
+};
+
+// ---------------- bit primitives ----------------
+uint32_t crc_calc(const uint8_t* b, int n, uint32_t poly, int order) {
+  uint32_t reg = 0, top = 1u << order;
+  for (int i = 0; i < n + order; i++) { reg = (reg << 1) | (i < n ? b[i] : 0); if (reg & top) reg ^= poly; }
+  return reg & (top - 1);
+}
+void crc_attach(bits_t& b, uint32_t poly, int order, uint32_t xormask = 0) {
+  uint32_t c = crc_calc(b.data(), (int)b.size(), poly, order) ^ xormask;
+  for (int i = order - 1; i >= 0; i--) b.push_back((c >> i) & 1);
+}
+bits_t gold(uint32_t cinit, int len) {
+  bits_t c(len);
+  uint32_t x1 = 1, x2 = cinit & 0x7FFFFFFF;
+  for (int n = 0; n < 1600 + len; n++) {
+    if (n >= 1600) c[n - 1600] = (x1 ^ x2) & 1;
+    uint32_t n1 = ((x1 >> 3) ^ x1) & 1, n2 = ((x2 >> 3) ^ (x2 >> 2) ^ (x2 >> 1) ^ x2) & 1;
+    x1 = (x1 >> 1) | (n1 << 30); x2 = (x2 >> 1) | (n2 << 30);
+  }
+  return c;
+}
+int par6(unsigned x) { x ^= x >> 4; x ^= x >> 2; x ^= x >> 1; return x & 1; }
+
+// tail-biting conv code 36.212 5.1.3.1: out[3*D], streams interleaved per bit (d0,d1,d2)
+std::vector<bits_t> conv_encode(const bits_t& c) {
+  int D = (int)c.size();
+  std::vector<bits_t> d(3, bits_t(D));
+  unsigned s = 0;
+  for (int i = 0; i < 6; i++) s |= (unsigned)c[D - 1 - i] << i;  // bit0 = most recent
+  for (int k = 0; k < D; k++) {
+    int b = c[k];
+    d[0][k] = b ^ par6(s & 0x36); d[1][k] = b ^ par6(s & 0x27); d[2][k] = b ^ par6(s & 0x2B);
+    s = ((s << 1) | b) & 63;
+  }
+  return d;
+}
+bits_t rm_conv_tx(const std::vector<bits_t>& d, int E) {
+  int D = (int)d[0].size(), R = (D + 31) / 32, KP = 32 * R, ND = KP - D;
+  std::vector<int> w(3 * KP);  // -1 = NULL, else bit
+  for (int s = 0; s < 3; s++)
+    for (int col = 0; col < 32; col++)
+      for (int r = 0; r < R; r++) { int idx = r * 32 + lsn_perm_cc[col]; w[s * KP + col * R + r] = idx >= ND ? d[s][idx - ND] : -1; }
+  bits_t e(E);
+  int k = 0, j = 0;
+  while (k < E) { if (w[j] >= 0) e[k++] = (uint8_t)w[j]; j = (j + 1) % (3 * KP); }
+  return e;
+}
+
+// turbo encoder 36.212 5.1.3.2 -> d0,d1,d2 each K+4
+void rsc(const bits_t& in, bits_t& par, uint8_t* tail_x, uint8_t* tail_z) {
+  int s1 = 0, s2 = 0, s3 = 0, K = (int)in.size();
+  par.resize(K);
+  for (int k = 0; k < K; k++) { int a = in[k] ^ s2 ^ s3; par[k] = a ^ s1 ^ s3; s3 = s2; s2 = s1; s1 = a; }
+  for (int t = 0; t < 3; t++) { int u = s2 ^ s3; tail_x[t] = u; tail_z[t] = s1 ^ s3; s3 = s2; s2 = s1; s1 = 0; }
+}
+bool qpp(int K, int& f1, int& f2) {
+  for (int i = 0; i < LSN_QPP_NSIZES; i++) if (lsn_qpp_table[i][0] == K) { f1 = lsn_qpp_table[i][1]; f2 = lsn_qpp_table[i][2]; return true; }
+  return false;
+}
+std::vector<bits_t> turbo_encode(const bits_t& c) {
+  int K = (int)c.size(), f1, f2;
+  if (!qpp(K, f1, f2)) { fprintf(stderr, "txgen: bad K %d\n", K); abort(); }
+  bits_t ci(K), z, zp; uint8_t x[3], zz[3], xp[3], zzp[3];
+  for (int i = 0; i < K; i++) ci[i] = c[(int)(((long long)f1 * i + (long long)f2 * i * i) % K)];
+  rsc(c, z, x, zz); rsc(ci, zp, xp, zzp);
+  std::vector<bits_t> d(3, bits_t(K + 4));
+  for (int k = 0; k < K; k++) { d[0][k] = c[k]; d[1][k] = z[k]; d[2][k] = zp[k]; }
+  d[0][K] = x[0]; d[1][K] = zz[0]; d[2][K] = x[1];
+  d[0][K + 1] = zz[1]; d[1][K + 1] = x[2]; d[2][K + 1] = zz[2];
+  d[0][K + 2] = xp[0]; d[1][K + 2] = zzp[0]; d[2][K + 2] = xp[1];
+  d[0][K + 3] = zzp[1]; d[1][K + 3] = xp[2]; d[2][K + 3] = zzp[2];
+  return d;
+}
+bits_t rm_turbo_tx(const std::vector<bits_t>& d, int F, int rv, int E) {
+  int D = (int)d[0].size(), R = (D + 31) / 32, KP = 32 * R, ND = KP - D, Ncb = 3 * KP;
+  std::vector<int> w(Ncb);
+  for (int k = 0; k < KP; k++) {
+    int col = k / R, row = k % R, y = row * 32 + lsn_perm_tc[col], i01 = y - ND;
+    w[k] = (i01 >= 0 && i01 >= F) ? d[0][i01] : -1;
+    w[KP + 2 * k] = (i01 >= 0 && i01 >= F) ? d[1][i01] : -1;
+    int pi = (lsn_perm_tc[col] + 32 * row + 1) % KP;
+    w[KP + 2 * k + 1] = pi - ND >= 0 ? d[2][pi - ND] : -1;
+  }
+  int k0 = R * (2 * ((Ncb + 8 * R - 1) / (8 * R)) * rv + 2);
+  bits_t e(E);
+  int k = 0, j = 0;
+  while (k < E) { int v = w[(k0 + j) % Ncb]; if (v >= 0) e[k++] = (uint8_t)v; j++; }
+  return e;
+}
+
+struct Segm { int C, Cp, Cm, Kp, Km, F; };
+bool cbsegm(int tbs, Segm& s) {
+  int B = tbs + 24, Bp;
+  if (B <= 6144) { s.C = 1; Bp = B; } else { s.C = (B + 6119) / 6120; Bp = B + 24 * s.C; }
+  int idx = -1;
+  for (int i = 0; i < LSN_QPP_NSIZES; i++) if (s.C * (int)lsn_qpp_table[i][0] >= Bp) { idx = i; break; }
+  if (idx < 0) return false;
+  s.Kp = lsn_qpp_table[idx][0];
+  if (s.C == 1) { s.Cp = 1; s.Km = 0; s.Cm = 0; }
+  else { s.Km = lsn_qpp_table[idx - 1][0]; s.Cm = (s.C * s.Kp - Bp) / (s.Kp - s.Km); s.Cp = s.C - s.Cm; }
+  s.F = s.Cp * s.Kp + s.Cm * s.Km - Bp;
+  return true;
+}
+// DL-SCH: payload bytes -> G coded bits
+bits_t dlsch_encode(const uint8_t* payload, int tbs, int G, int Qm, int NL, int rv) {
+  bits_t a(tbs);
+  for (int i = 0; i < tbs; i++) a[i] = (payload[i >> 3] >> (7 - (i & 7))) & 1;
+  crc_attach(a, 0x1864CFB, 24);
+  Segm s; cbsegm(tbs, s);
+  bits_t out; out.reserve(G);
+  int Gp = G / (NL * Qm), gamma = Gp % s.C, rp = 0;
+  for (int r = 0; r < s.C; r++) {
+    int K = r < s.Cm ? s.Km : s.Kp, F = r == 0 ? s.F : 0;
+    bits_t cb(K, 0);
+    int n = K - F - (s.C > 1 ? 24 : 0);
+    for (int i = 0; i < n; i++) cb[F + i] = a[rp + i];
+    rp += n;
+    if (s.C > 1) { bits_t t(cb.begin(), cb.begin() + K - 24); crc_attach(t, 0x1800063, 24); cb = t; }
+    auto d = turbo_encode(cb);
+    int E = (r <= s.C - gamma - 1) ? NL * Qm * (Gp / s.C) : NL * Qm * ((Gp + s.C - 1) / s.C);
+    bits_t e = rm_turbo_tx(d, F, rv, E);
+    out.insert(out.end(), e.begin(), e.end());
+  }
+  out.resize(G, 0);
+  return out;
+}
+
+// ---------------- modulation 36.211 7.1 ----------------
+void modulate(const bits_t& b, int Qm, std::vector<cf>& out) {
+  int n = (int)b.size() / Qm;
+  out.resize(n);
+  static const int a64[4] = {3, 1, 5, 7};
+  static const int a256[8] = {5, 7, 3, 1, 11, 9, 13, 15};
+  for (int i = 0; i < n; i++) {
+    const uint8_t* p = &b[(size_t)i * Qm];
+    float I, Q;
+    switch (Qm) {
+      case 2: I = (1 - 2 * p[0]) * 0.70710678f; Q = (1 - 2 * p[1]) * 0.70710678f; break;
+      case 4: I = (1 - 2 * p[0]) * (p[2] ? 3 : 1) * 0.31622777f; Q = (1 - 2 * p[1]) * (p[3] ? 3 : 1) * 0.31622777f; break;
+      case 6: I = (1 - 2 * p[0]) * a64[p[2] * 2 + p[4]] * 0.15430335f; Q = (1 - 2 * p[1]) * a64[p[3] * 2 + p[5]] * 0.15430335f; break;
+      default: I = (1 - 2 * p[0]) * a256[p[2] * 4 + p[4] * 2 + p[6]] * 0.076696499f; Q = (1 - 2 * p[1]) * a256[p[3] * 4 + p[5] * 2 + p[7]] * 0.076696499f; break;
+    }
+    out[i] = cf(I, Q);
+  }
+}
+
+// ---------------- fft (double) ----------------
+void fft_d(std::vector<std::complex<double>>& a, bool inv) {
+  int N = (int)a.size(), lg = 0;
+  while ((1 << lg) < N) lg++;
+  for (int i = 0; i < N; i++) { int j = 0; for (int b = 0; b < lg; b++) if (i & (1 << b)) j |= 1 << (lg - 1 - b); if (j > i) std::swap(a[i], a[j]); }
+  for (int len = 2; len <= N; len <<= 1) {
+    double ang = 2 * M_PI / len * (inv ? 1 : -1);
+    for (int i = 0; i < N; i += len)
+      for (int j = 0; j < len / 2; j++) {
+        std::complex<double> w(std::cos(ang * j), std::sin(ang * j)), u = a[i + j], v = a[i + j + len / 2] * w;
+        a[i + j] = u + v; a[i + j + len / 2] = u - v;
+      }
+  }
+}
+
+uint32_t log2ceil(uint32_t x) { uint32_t n = 0; while ((1u << n) < x) n++; return n; }
+uint32_t riv_nbits(uint32_t n) { return log2ceil(n * (n + 1) / 2); }
+uint32_t ra_P(uint32_t n) { return n <= 10 ? 1 : n <= 26 ? 2 : n <= 63 ? 3 : 4; }
+bool amb(uint32_t n) { static const uint32_t a[10] = {12, 14, 16, 20, 24, 26, 32, 40, 44, 56}; for (auto v : a) if (v == n) return true; return false; }
+void put(bits_t& b, uint32_t v, uint32_t n) { for (int i = (int)n - 1; i >= 0; i--) b.push_back((v >> i) & 1); }
+
+}  // namespace
+
+// =====================================================================================================
+extern "C" {
+
+enum { TXG_FMT0 = 0, TXG_FMT1 = 1, TXG_FMT1A = 2, TXG_FMT1C = 4, TXG_FMT2 = 6, TXG_FMT2A = 7 };
+
+typedef struct {
+  uint32_t nof_prb, nof_ports, cell_id, phich_ng_x6, nof_rx;
+  float snr_db, cfo_hz;
+  uint32_t delay_samples;  // second rx path extra delay (0 = flat)
+  uint64_t seed;
+  // scenario
+  uint32_t n_rnti, dl_min, dl_max, ul_min, ul_max;
+  uint32_t cfi;           // 1..3 fixed; 0 = random per subframe
+  uint32_t mix_tm3_pct, mix_tm4_pct;  // rest: TM1/TM2 (format 1 / 1A)
+  uint32_t pct_256qam;    // share of UEs on the 256QAM table
+  uint32_t mcs_min, mcs_max;
+  uint32_t sib_period;    // SI-RNTI DCI1A on sf 5 of even frames if != 0
+  uint32_t rar_period;    // one RAR every n subframes (0 = none)
+  uint32_t paging_period;
+  uint32_t start_tti;
+  uint32_t fixed_L;       // 0 = random aggregation level
+} txg_cfg_t;
+
+typedef struct { uint16_t rnti; uint8_t format, L; uint16_t ncce; uint32_t tti; uint32_t nbytes; uint32_t offset; uint8_t tb, mod, table256, is_ul; uint32_t nof_prb; uint32_t mcs; } txg_pdu_t;
+
+struct txg;
+typedef struct txg txg_t;
+txg_t* txg_new(const txg_cfg_t* cfg);
+void txg_free(txg_t*);
+int txg_next(txg_t*, float* iq, txg_pdu_t* pdus, int max_pdus, uint8_t* payload_buf, int payload_cap);
+uint32_t txg_sf_len(const txg_t*);
+uint32_t txg_tti(const txg_t*);
+}
+
+struct Ue { uint16_t rnti; int tm; bool t256; };
+struct RegInfo { std::vector<uint16_t> k0[3]; std::vector<uint8_t> l[3]; uint32_t nregs[3], ncce[3]; uint16_t pcfich_k0[4]; };
+
+struct txg {
+  txg_cfg_t c;
+  int N, nre;
+  Rng rng;
+  std::vector<Ue> ues;
+  RegInfo regs;
+  uint32_t tti;
+  cf h[2][2];
+  explicit txg(const txg_cfg_t& cfg) : c(cfg), rng(cfg.seed) {}
+};
+
+static int fft_size(uint32_t nprb) { switch (nprb) { case 6: return 128; case 15: return 256; case 25: return 512; case 50: return 1024; case 100: return 2048; default: return -1; } }
+
+static void build_regs(txg* g) {
+  int nprb = g->c.nof_prb, nre = 12 * nprb, n0 = nre / 6, id = g->c.cell_id;
+  std::vector<uint8_t> used0(n0, 0);
+  int kbar = 6 * (id % (2 * nprb));
+  for (int i = 0; i < 4; i++) { int k = (kbar + (i * nprb / 2) * 6) % nre; g->regs.pcfich_k0[i] = (uint16_t)k; used0[k / 6] = 1; }
+  int ng = (g->c.phich_ng_x6 * nprb + 47) / 48;
+  std::vector<int> avail;
+  for (int i = 0; i < n0; i++) if (!used0[i]) avail.push_back(i);
+  int na = (int)avail.size();
+  for (int m = 0; m < ng; m++) for (int i = 0; i < 3; i++) used0[avail[(id + m + (i * na) / 3) % na]] = 1;
+  for (int cfi = 1; cfi <= 3; cfi++) {
+    int nsym = cfi + (nprb <= 10 ? 1 : 0);
+    std::vector<uint16_t> tk; std::vector<uint8_t> tl;
+    for (int k = 0; k < nre; k++) for (int l = 0; l < nsym; l++) {
+      int w = l == 0 ? 6 : 4;
+      if (k % w) continue;
+      if (l == 0 && used0[k / 6]) continue;
+      tk.push_back((uint16_t)k); tl.push_back((uint8_t)l);
+    }
+    int M = (int)tk.size(), R = (M + 31) / 32, ND = 32 * R - M;
+    std::vector<int> perm;
+    for (int j = 0; j < 32; j++) for (int r = 0; r < R; r++) { int idx = r * 32 + lsn_perm_cc[j]; if (idx >= ND) perm.push_back(idx - ND); }
+    g->regs.nregs[cfi - 1] = M; g->regs.ncce[cfi - 1] = M / 9;
+    g->regs.k0[cfi - 1].assign(M, 0); g->regs.l[cfi - 1].assign(M, 0);
+    for (int mp = 0; mp < M; mp++) { int q = perm[(mp + id) % M]; g->regs.k0[cfi - 1][q] = tk[mp]; g->regs.l[cfi - 1][q] = tl[mp]; }
+  }
+}
+
+extern "C" txg_t* txg_new(const txg_cfg_t* cfg) {
+  if (fft_size(cfg->nof_prb) < 0) return nullptr;
+  txg* g = new txg(*cfg);
+  g->N = fft_size(cfg->nof_prb); g->nre = 12 * cfg->nof_prb; g->tti = cfg->start_tti;
+  build_regs(g);
+  // static channel: unit-ish gains with random phases, mild imbalance
+  for (int r = 0; r < 2; r++) for (int p = 0; p < 2; p++) {
+    double ph = g->rng.uni() * 2 * M_PI, mag = 0.7 + 0.5 * g->rng.uni();
+    g->h[r][p] = cf((float)(mag * std::cos(ph)), (float)(mag * std::sin(ph)));
+  }
+  for (uint32_t i = 0; i < cfg->n_rnti; i++) {
+    Ue u; u.rnti = (uint16_t)(0x0100 + g->rng.below(0xFFF3 - 0x0100));
+    bool dup = false; for (auto& o : g->ues) if (o.rnti == u.rnti) dup = true;
+    if (dup) { i--; continue; }
+    uint32_t r = g->rng.below(100);
+    u.tm = (cfg->nof_ports < 2 || cfg->nof_rx < 2) ? 1 : r < cfg->mix_tm3_pct ? 3 : r < cfg->mix_tm3_pct + cfg->mix_tm4_pct ? 4 : 2;
+    u.t256 = g->rng.below(100) < cfg->pct_256qam;
+    g->ues.push_back(u);
+  }
+  return g;
+}
+extern "C" void txg_free(txg_t* g) { delete g; }
+extern "C" uint32_t txg_sf_len(const txg_t* g) { return 15u * g->N; }
+extern "C" uint32_t txg_tti(const txg_t* g) { return g->tti; }
+
+// ---------------- DCI sizes / packing ----------------
+static uint32_t f0raw(uint32_t n) { return 1 + 1 + riv_nbits(n) + 5 + 1 + 2 + 3 + 1; }
+static uint32_t f1a_sz(uint32_t n) { uint32_t s = 1 + 1 + riv_nbits(n) + 5 + 3 + 1 + 2 + 2; while (s < f0raw(n)) s++; if (amb(s)) s++; return s; }
+static uint32_t f0_sz(uint32_t n) { uint32_t s = f0raw(n); while (s < f1a_sz(n)) s++; return s; }
+static uint32_t alloc_bits(uint32_t n) { return (n > 10 ? 1 : 0) + (n + ra_P(n) - 1) / ra_P(n); }
+static uint32_t f1_sz(uint32_t n) { uint32_t s = alloc_bits(n) + 5 + 3 + 1 + 2 + 2; while (s == f0_sz(n) || s == f1a_sz(n) || amb(s)) s++; return s; }
+static uint32_t f2_sz(uint32_t n, uint32_t ports) { uint32_t s = alloc_bits(n) + 2 + 3 + 1 + 16 + (ports == 2 ? 3 : ports == 4 ? 6 : 0); while (amb(s)) s++; return s; }
+static uint32_t f2a_sz(uint32_t n, uint32_t ports) { uint32_t s = alloc_bits(n) + 2 + 3 + 1 + 16 + (ports == 4 ? 2 : 0); while (amb(s)) s++; return s; }
+
+struct Grant {
+  uint16_t rnti; int format; int L; int ncce;
+  bool type0; uint32_t rbg_mask; uint32_t riv; std::vector<int> prbs;
+  int ntb; uint32_t mcs[2]; int rv[2]; uint32_t ndi[2]; uint32_t pid; uint32_t pinfo; uint32_t swap;
+  bool t256; bool nprb1a_is2; int tbs[2]; int qm[2];
+  int scheme;  // 0 port0, 1 div, 2 SM, 3 CDD
+  int pmi, nlayers;
+  bool is_ul;
+};
+
+static bits_t dci_pack(const txg* g, const Grant& gr) {
+  uint32_t n = g->c.nof_prb;
+  bits_t b;
+  bool user = gr.rnti >= 0x000B && gr.rnti <= 0xFFF3;
+  switch (gr.format) {
+    case TXG_FMT0:
+      put(b, 0, 1); put(b, 0, 1); put(b, gr.riv, riv_nbits(n)); put(b, gr.mcs[0], 5); put(b, gr.ndi[0], 1); put(b, 1, 2); put(b, 0, 3); put(b, 0, 1);
+      while (b.size() < f0_sz(n)) b.push_back(0);
+      break;
+    case TXG_FMT1A:
+      put(b, 1, 1); put(b, 0, 1); put(b, gr.riv, riv_nbits(n)); put(b, gr.mcs[0], 5); put(b, gr.pid, 3);
+      put(b, user ? gr.ndi[0] : 0, 1); put(b, (uint32_t)gr.rv[0], 2);
+      if (user) put(b, 1, 2); else { put(b, 0, 1); put(b, gr.nprb1a_is2 ? 0 : 1, 1); }
+      while (b.size() < f1a_sz(n)) b.push_back(0);
+      break;
+    case TXG_FMT1:
+      if (n > 10) put(b, 0, 1);
+      put(b, gr.rbg_mask, (n + ra_P(n) - 1) / ra_P(n)); put(b, gr.mcs[0], 5); put(b, gr.pid, 3); put(b, gr.ndi[0], 1); put(b, (uint32_t)gr.rv[0], 2); put(b, 1, 2);
+      while (b.size() < f1_sz(n)) b.push_back(0);
+      break;
+    case TXG_FMT2:
+    case TXG_FMT2A:
+      if (n > 10) put(b, 0, 1);
+      put(b, gr.rbg_mask, (n + ra_P(n) - 1) / ra_P(n)); put(b, 1, 2); put(b, gr.pid, 3); put(b, gr.swap, 1);
+      for (int i = 0; i < 2; i++) {
+        if (i < gr.ntb) { put(b, gr.mcs[i], 5); put(b, gr.ndi[i], 1); put(b, (uint32_t)gr.rv[i], 2); }
+        else { put(b, 0, 5); put(b, 0, 1); put(b, 1, 2); }  // disabled TB: mcs 0, rv 1
+      }
+      if (gr.format == TXG_FMT2) put(b, gr.pinfo, g->c.nof_ports == 2 ? 3 : 6);
+      else if (g->c.nof_ports == 4) put(b, gr.pinfo, 2);
+      while (b.size() < (gr.format == TXG_FMT2 ? f2_sz(n, g->c.nof_ports) : f2a_sz(n, g->c.nof_ports))) b.push_back(0);
+      break;
+    default: break;
+  }
+  return b;
+}
+
+// ---------------- search space ----------------
+static void ss_candidates(uint32_t ncce, uint32_t sf, uint16_t rnti, int l, bool common, std::vector<int>& out) {
+  out.clear();
+  uint32_t L = 1u << l;
+  if (ncce < L) return;
+  if (common) { for (uint32_t i = 0; i < std::min<uint32_t>(ncce, 16) / L; i++) out.push_back((int)(L * (i % (ncce / L)))); return; }
+  static const uint32_t nc[4] = {6, 6, 2, 2};
+  uint32_t Yk = rnti;
+  for (uint32_t m = 0; m < sf + 1; m++) Yk = (39827u * Yk) % 65537u;
+  for (uint32_t i = 0; i < nc[l]; i++) { uint32_t n = L * ((Yk + i) % (ncce / L)); if (n + L <= ncce) out.push_back((int)n); }
+}
+
+static bool pdsch_re_ok(const txg* g, uint32_t sf, int l, int k) {
+  int nprb = g->c.nof_prb, id = g->c.cell_id;
+  if (l == 0 || l == 4 || l == 7 || l == 11) {
+    if (g->c.nof_ports >= 2) { if (k % 3 == id % 3) return false; }
+    else { int v = (l == 0 || l == 7) ? 0 : 3; if (k % 6 == (v + id % 6) % 6) return false; }
+  }
+  int kc0 = 6 * nprb - 36;
+  if (k >= kc0 && k < kc0 + 72) {
+    if ((sf == 0 || sf == 5) && (l == 5 || l == 6)) return false;
+    if (sf == 0 && l >= 7 && l <= 10) return false;
+  }
+  return true;
+}
+
+static void sfbc_pair(cf x0, cf x1, cf* p0, cf* p1) {
+  const float s = 0.70710678f;
+  p0[0] = x0 * s; p0[1] = x1 * s; p1[0] = -std::conj(x1) * s; p1[1] = std::conj(x0) * s;
+}
+
+extern "C" int txg_next(txg_t* g, float* iq, txg_pdu_t* pdus, int max_pdus, uint8_t* pbuf, int pcap) {
+  const txg_cfg_t& c = g->c;
+  int nprb = c.nof_prb, nre = g->nre, N = g->N, P = c.nof_ports, id = c.cell_id;
+  uint32_t tti = g->tti, sf = tti % 10, sfn = (tti / 10) % 1024;
+  uint32_t cfi = c.cfi ? c.cfi : 1 + g->rng.below(3);
+  uint32_t ncce = g->regs.ncce[cfi - 1];
+  std::vector<std::vector<cf>> grid(P, std::vector<cf>(14 * nre, cf(0, 0)));
+  int npdu = 0, poff = 0;
+
+  // ---- CRS ----
+  static const int crs_sym[4] = {0, 4, 7, 11};
+  for (int s = 0; s < 4; s++) {
+    int l = crs_sym[s];
+    uint32_t ns = 2 * sf + (l >= 7), lsl = l % 7;
+    bits_t cc = gold(1024u * (7u * (ns + 1) + lsl + 1) * (2u * id + 1) + 2u * id + 1, 440);
+    for (int p = 0; p < P; p++) {
+      int v = p == 0 ? ((s & 1) ? 3 : 0) : ((s & 1) ? 0 : 3), koff = (v + id % 6) % 6;
+      for (int m = 0; m < 2 * nprb; m++) {
+        int mp = m + 110 - nprb;
+        grid[p][l * nre + 6 * m + koff] = cf((1 - 2 * cc[2 * mp]) * 0.70710678f, (1 - 2 * cc[2 * mp + 1]) * 0.70710678f);
+      }
+    }
+  }
+  auto map_quad = [&](int k0, int l, const cf* x) {  // 4 symbols onto the data REs of a REG
+    int kk[4], n = 0;
+    if (l == 0) { for (int k = k0; k < k0 + 6; k++) if (k % 3 != id % 3) kk[n++] = k; }
+    else for (int k = k0; k < k0 + 4; k++) kk[n++] = k;
+    if (P == 1) { for (int i = 0; i < 4; i++) grid[0][l * nre + kk[i]] = x[i]; }
+    else for (int i = 0; i < 4; i += 2) {
+      cf p0[2], p1[2]; sfbc_pair(x[i], x[i + 1], p0, p1);
+      grid[0][l * nre + kk[i]] = p0[0]; grid[0][l * nre + kk[i + 1]] = p0[1];
+      grid[1][l * nre + kk[i]] = p1[0]; grid[1][l * nre + kk[i + 1]] = p1[1];
+    }
+  };
+  // ---- PCFICH ----
+  {
+    static const char* cw[3] = {"01101101101101101101101101101101", "10110110110110110110110110110110", "11011011011011011011011011011011"};
+    bits_t sc = gold((sf + 1) * (2u * id + 1) * 512u + id, 32), b(32);
+    for (int i = 0; i < 32; i++) b[i] = (cw[cfi - 1][i] == '1') ^ sc[i];
+    std::vector<cf> sy; modulate(b, 2, sy);
+    for (int i = 0; i < 4; i++) map_quad(g->regs.pcfich_k0[i], 0, &sy[4 * i]);
+  }
+
+  // ---- schedule ----
+  std::vector<Grant> grants;
+  std::vector<uint8_t> cce_used(ncce, 0);
+  auto place = [&](Grant& gr, bool common) -> bool {
+    std::vector<int> cand;
+    for (int attempt = 0; attempt < 4; attempt++) {
+      int l = gr.L;
+      if (common && l < 2) l = 2;
+      ss_candidates(ncce, sf, gr.rnti, l, common, cand);
+      for (int nc : cand) {
+        bool freec = true;
+        for (int i = 0; i < (1 << l); i++) if (cce_used[nc + i]) freec = false;
+        if (freec) { for (int i = 0; i < (1 << l); i++) cce_used[nc + i] = 1; gr.ncce = nc; gr.L = l; return true; }
+      }
+      gr.L = (gr.L + 3) % 4;  // try another level
+    }
+    return false;
+  };
+  auto pickL = [&]() -> int { if (c.fixed_L) return (int)c.fixed_L - 1; uint32_t r = g->rng.below(10); return r < 4 ? 0 : r < 7 ? 1 : r < 9 ? 2 : 3; };
+  int l0 = cfi + (nprb <= 10 ? 1 : 0);
+  uint32_t Prbg = ra_P(nprb), nrbg = (nprb + Prbg - 1) / Prbg;
+  int next_rbg = 0;  // RBGs handed out left to right
+
+  auto count_re = [&](const std::vector<int>& prbs) { int n = 0; for (int l = l0; l < 14; l++) for (int p : prbs) for (int k = 12 * p; k < 12 * p + 12; k++) n += pdsch_re_ok(g, sf, l, k); return n; };
+  auto set_tbs = [&](Grant& gr, int nre_g) {
+    for (int i = 0; i < gr.ntb; i++) {
+      int mcs = (int)gr.mcs[i];
+      for (;; mcs--) {
+        const int8_t(*t)[2] = gr.t256 ? lsn_mcs_dl_256qam : lsn_mcs_dl_64qam;
+        int itbs = t[mcs][1]; gr.qm[i] = t[mcs][0];
+        gr.tbs[i] = lsn_tbs_table[itbs][gr.prbs.size() - 1];
+        double rate = (gr.tbs[i] + 24.0) / ((double)nre_g * gr.qm[i]);
+        if (rate <= 0.88 || mcs == 0) break;
+      }
+      gr.mcs[i] = (uint32_t)mcs;
+    }
+  };
+  // broadcast-type grants first (common search space, DCI 1A, 64QAM table, QPSK)
+  auto add_common = [&](uint16_t rnti, int nbytes_hint, const uint8_t* fixed_payload, int fixed_len) {
+    if (next_rbg + 3 > (int)nrbg) return;
+    Grant gr{}; gr.rnti = rnti; gr.format = TXG_FMT1A; gr.L = 2; gr.type0 = false; gr.ntb = 1; gr.is_ul = false;
+    int start = next_rbg * (int)Prbg, Lcrb = 3 * (int)Prbg;
+    if (start + Lcrb > nprb) return;
+    gr.riv = (uint32_t)(nprb * (Lcrb - 1) + start);
+    if (Lcrb - 1 > nprb / 2) gr.riv = (uint32_t)(nprb * (nprb - Lcrb + 1) + (nprb - 1 - start));
+    for (int i = 0; i < Lcrb; i++) gr.prbs.push_back(start + i);
+    gr.nprb1a_is2 = false; gr.mcs[0] = 2 + g->rng.below(6); gr.rv[0] = 0; gr.t256 = false;
+    gr.tbs[0] = lsn_tbs_table[gr.mcs[0]][2]; gr.qm[0] = 2; gr.scheme = P == 1 ? 0 : 1; gr.nlayers = P;
+    (void)nbytes_hint;
+    if (!place(gr, true)) return;
+    next_rbg += 3;
+    grants.push_back(gr);
+    // payload
+    int nb = gr.tbs[0] / 8;
+    if (npdu < max_pdus && poff + nb <= pcap) {
+      for (int i = 0; i < nb; i++) pbuf[poff + i] = (uint8_t)g->rng.u32();
+      if (fixed_payload) { memset(pbuf + poff, 0, nb); memcpy(pbuf + poff, fixed_payload, std::min(nb, fixed_len)); }
+      txg_pdu_t& pd = pdus[npdu++];
+      pd = txg_pdu_t{rnti, (uint8_t)gr.format, (uint8_t)gr.L, (uint16_t)gr.ncce, tti, (uint32_t)nb, (uint32_t)poff, 0, 2, 0, 0, (uint32_t)gr.prbs.size(), gr.mcs[0]};
+      poff += nb;
+    }
+  };
+  if (c.sib_period && sf == 5 && (sfn % 2) == 0) add_common(0xFFFF, 0, nullptr, 0);
+  if (c.paging_period && (tti % c.paging_period) == 3) add_common(0xFFFE, 0, nullptr, 0);
+  if (c.rar_period && (tti % c.rar_period) == 7) {
+    // MAC RAR PDU: one RAPID subheader + one RAR with a fresh temporary C-RNTI
+    uint16_t t_crnti = (uint16_t)(0x0100 + g->rng.below(0xFFF3 - 0x0100));
+    uint8_t rar[7] = {(uint8_t)(0x40 | g->rng.below(64)), 0x00, 0x10, 0x0c, 0x00, (uint8_t)(t_crnti >> 8), (uint8_t)t_crnti};
+    add_common((uint16_t)(2 + g->rng.below(8)), 0, rar, 7);
+    if (!g->ues.empty()) {  // the new UE replaces a random old one and is scheduled from now on
+      Ue u = g->ues[g->rng.below((uint32_t)g->ues.size())]; u.rnti = t_crnti;
+      g->ues[g->rng.below((uint32_t)g->ues.size())] = u;
+    }
+  }
+  // unicast DL
+  uint32_t kdl = c.dl_min + g->rng.below(c.dl_max - c.dl_min + 1);
+  std::vector<int> picked;
+  int rbg_left = (int)nrbg - next_rbg;
+  if ((int)kdl > rbg_left) kdl = (uint32_t)std::max(rbg_left, 0);
+  std::vector<int> share(kdl, 1);
+  for (int i = 0; i < rbg_left - (int)kdl; i++) share[g->rng.below(kdl)]++;
+  for (uint32_t q = 0; q < kdl && !g->ues.empty(); q++) {
+    int ui; bool dupl;
+    int tries = 0;
+    do { ui = (int)g->rng.below((uint32_t)g->ues.size()); dupl = false; for (int p : picked) if (p == ui) dupl = true; } while (dupl && ++tries < 20);
+    if (dupl) continue;
+    picked.push_back(ui);
+    const Ue& u = g->ues[ui];
+    Grant gr{}; gr.rnti = u.rnti; gr.L = pickL(); gr.is_ul = false; gr.t256 = u.t256; gr.pid = g->rng.below(8);
+    int r0 = next_rbg, nr = share[q];
+    next_rbg += nr;
+    for (int r = r0; r < r0 + nr; r++) for (int p = r * (int)Prbg; p < (r + 1) * (int)Prbg && p < nprb; p++) gr.prbs.push_back(p);
+    gr.type0 = true; gr.rbg_mask = 0;
+    for (int r = r0; r < r0 + nr; r++) gr.rbg_mask |= 1u << (nrbg - 1 - r);
+    uint32_t mlo = c.mcs_min, mhi = std::min<uint32_t>(c.mcs_max, u.t256 ? 27 : 28);
+    if (mlo > mhi) mlo = mhi;
+    if (u.tm == 3 || u.tm == 4) {
+      gr.format = u.tm == 3 ? TXG_FMT2A : TXG_FMT2; gr.ntb = 2; gr.swap = 0;
+      if (u.tm == 3) { gr.scheme = 3; gr.nlayers = 2; gr.pinfo = 0; }
+      else { gr.scheme = 2; gr.nlayers = 2; gr.pinfo = g->rng.below(2); gr.pmi = (int)gr.pinfo; }
+      for (int i = 0; i < 2; i++) { gr.mcs[i] = mlo + g->rng.below(mhi - mlo + 1); gr.rv[i] = 0; gr.ndi[i] = g->rng.below(2); }
+    } else {
+      bool f1a = g->rng.below(4) == 0;
+      gr.format = f1a ? TXG_FMT1A : TXG_FMT1; gr.ntb = 1; gr.scheme = P == 1 ? 0 : 1; gr.nlayers = P;
+      gr.mcs[0] = mlo + g->rng.below(mhi - mlo + 1); gr.rv[0] = 0; gr.ndi[0] = g->rng.below(2);
+      if (f1a) {
+        gr.type0 = false; gr.t256 = false;  // 1A always uses the 64QAM table
+        if (gr.mcs[0] > 28) gr.mcs[0] = 28;
+        int start = gr.prbs.front(), Lc = (int)gr.prbs.size();
+        gr.riv = (Lc - 1 <= nprb / 2) ? (uint32_t)(nprb * (Lc - 1) + start) : (uint32_t)(nprb * (nprb - Lc + 1) + (nprb - 1 - start));
+      }
+    }
+    int nre_g = count_re(gr.prbs);
+    if (nre_g < 24) continue;
+    set_tbs(gr, nre_g);
+    if (!place(gr, false)) continue;
+    grants.push_back(gr);
+    for (int i = 0; i < gr.ntb; i++) {
+      int nb = gr.tbs[i] / 8;
+      if (npdu < max_pdus && poff + nb <= pcap) {
+        for (int b = 0; b < nb; b++) pbuf[poff + b] = (uint8_t)g->rng.u32();
+        pbuf[poff] |= 0x20;  // never an all-zero TB; avoid LCID-0 looking headers
+        txg_pdu_t& pd = pdus[npdu++];
+        pd = txg_pdu_t{gr.rnti, (uint8_t)gr.format, (uint8_t)gr.L, (uint16_t)gr.ncce, tti, (uint32_t)nb, (uint32_t)poff, (uint8_t)i, (uint8_t)gr.qm[i], (uint8_t)gr.t256, 0, (uint32_t)gr.prbs.size(), gr.mcs[i]};
+        poff += nb;
+      }
+    }
+  }
+  // UL grants (DCI 0 only; PUSCH itself is not generated)
+  uint32_t kul = c.ul_min + g->rng.below(c.ul_max - c.ul_min + 1);
+  int ul_next = 0;
+  for (uint32_t q = 0; q < kul && !g->ues.empty(); q++) {
+    const Ue& u = g->ues[g->rng.below((uint32_t)g->ues.size())];
+    bool dupl = false; for (auto& o : grants) if (o.rnti == u.rnti && o.is_ul) dupl = true;
+    if (dupl) continue;
+    Grant gr{}; gr.rnti = u.rnti; gr.format = TXG_FMT0; gr.L = pickL(); gr.is_ul = true; gr.ntb = 0;
+    int Lc = 2 + (int)g->rng.below(8), start = ul_next; ul_next += Lc;
+    if (start + Lc > nprb) break;
+    gr.riv = (Lc - 1 <= nprb / 2) ? (uint32_t)(nprb * (Lc - 1) + start) : (uint32_t)(nprb * (nprb - Lc + 1) + (nprb - 1 - start));
+    gr.mcs[0] = g->rng.below(25); gr.ndi[0] = g->rng.below(2);
+    if (!place(gr, false)) continue;
+    grants.push_back(gr);
+    if (npdu < max_pdus) { txg_pdu_t& pd = pdus[npdu++]; pd = txg_pdu_t{gr.rnti, 0, (uint8_t)gr.L, (uint16_t)gr.ncce, tti, 0, 0, 0, 0, 0, 1, (uint32_t)Lc, gr.mcs[0]}; }
+  }
+
+  // ---- PDCCH ----
+  {
+    uint32_t nbits = 8 * g->regs.nregs[cfi - 1];
+    std::vector<int> ctl(nbits, -1);
+    for (auto& gr : grants) {
+      bits_t b = dci_pack(g, gr);
+      crc_attach(b, 0x11021, 16, gr.rnti);
+      bits_t e = rm_conv_tx(conv_encode(b), 72 << gr.L);
+      for (size_t i = 0; i < e.size(); i++) ctl[gr.ncce * 72 + i] = e[i];
+    }
+    bits_t sc = gold(sf * 512u + id, (int)nbits);
+    for (uint32_t q = 0; q < ncce * 9; q++) {
+      cf x[4]; bool any = false;
+      for (int j = 0; j < 4; j++) {
+        int b0 = ctl[8 * q + 2 * j], b1 = ctl[8 * q + 2 * j + 1];
+        if (b0 < 0) { x[j] = cf(0, 0); continue; }
+        any = true;
+        b0 ^= sc[8 * q + 2 * j]; b1 ^= sc[8 * q + 2 * j + 1];
+        x[j] = cf((1 - 2 * b0) * 0.70710678f, (1 - 2 * b1) * 0.70710678f);
+      }
+      if (any) map_quad(g->regs.k0[cfi - 1][q], g->regs.l[cfi - 1][q], x);
+    }
+  }
+
+  // ---- PDSCH ----
+  int pdu_i = 0;
+  const float rho_b = P == 1 ? std::sqrt(0.8f) : 1.0f;
+  for (auto& gr : grants) {
+    if (gr.is_ul) continue;
+    while (pdu_i < npdu && !(pdus[pdu_i].rnti == gr.rnti && !pdus[pdu_i].is_ul)) pdu_i++;
+    std::vector<std::pair<int, int>> res;
+    for (int l = l0; l < 14; l++) for (int p : gr.prbs) for (int k = 12 * p; k < 12 * p + 12; k++) if (pdsch_re_ok(g, sf, l, k)) res.push_back({l, k});
+    int nre_g = (int)res.size();
+    std::vector<cf> sym[2];
+    for (int i = 0; i < gr.ntb; i++) {
+      if (pdu_i + i >= npdu) break;
+      const txg_pdu_t& pd = pdus[pdu_i + i];
+      int G = nre_g * gr.qm[i], NL = gr.scheme == 1 ? 2 : 1;
+      bits_t e = dlsch_encode(pbuf + pd.offset, gr.tbs[i], G, gr.qm[i], NL, gr.rv[i]);
+      bits_t sc = gold(((uint32_t)gr.rnti << 14) | ((uint32_t)i << 13) | (sf << 9) | (uint32_t)id, G);
+      for (int b = 0; b < G; b++) e[b] ^= sc[b];
+      modulate(e, gr.qm[i], sym[i]);
+    }
+    pdu_i += gr.ntb;
+    for (int i = 0; i < nre_g; i++) {
+      int l = res[i].first, k = res[i].second;
+      float amp = (l == 0 || l == 4 || l == 7 || l == 11) ? rho_b : 1.0f;
+      cf* g0 = &grid[0][l * nre + k];
+      cf* g1 = P > 1 ? &grid[1][l * nre + k] : nullptr;
+      switch (gr.scheme) {
+        case 0: *g0 = sym[0][i] * amp; break;
+        case 1:
+          if ((i & 1) == 0 && i + 1 < nre_g) {
+            cf p0[2], p1[2]; sfbc_pair(sym[0][i], sym[0][i + 1], p0, p1);
+            int l2 = res[i + 1].first, k2 = res[i + 1].second;
+            *g0 = p0[0] * amp; *g1 = p1[0] * amp; grid[0][l2 * nre + k2] = p0[1] * amp; grid[1][l2 * nre + k2] = p1[1] * amp;
+          }
+          break;
+        case 3: { cf x0 = sym[0][i], x1 = sym[1][i]; float s = (i & 1) ? -1.f : 1.f; *g0 = (x0 + x1) * 0.5f * amp; *g1 = (x0 - x1) * (0.5f * s) * amp; break; }
+        case 2:
+          if (gr.nlayers == 2) { cf x0 = sym[0][i], x1 = sym[1][i], d = (x0 - x1) * 0.5f; *g0 = (x0 + x1) * 0.5f * amp; *g1 = (gr.pmi == 0 ? d : cf(-d.imag(), d.real())) * amp; }
+          break;
+      }
+    }
+  }
+
+  // ---- OFDM + channel ----
+  int sflen = 15 * N;
+  std::vector<std::vector<cf>> tx(P, std::vector<cf>(sflen));
+  std::vector<std::complex<double>> buf(N);
+  for (int p = 0; p < P; p++) {
+    int pos = 0;
+    for (int l = 0; l < 14; l++) {
+      int cp = ((l % 7) == 0 ? 160 : 144) * N / 2048;
+      for (auto& v : buf) v = 0;
+      for (int k = 0; k < nre; k++) { int bin = k < nre / 2 ? N - nre / 2 + k : k - nre / 2 + 1; buf[bin] = grid[p][l * nre + k]; }
+      fft_d(buf, true);
+      for (int n = 0; n < N; n++) tx[p][pos + cp + n] = cf((float)(buf[n].real() / N), (float)(buf[n].imag() / N));
+      for (int n = 0; n < cp; n++) tx[p][pos + n] = tx[p][pos + cp + N - cp + n];
+      pos += cp + N;
+    }
+  }
+  double sigma = std::sqrt(std::pow(10.0, -c.snr_db / 10.0) / (2.0 * N));  // per real dimension, time domain
+  double fs = 15000.0 * N;
+  for (uint32_t r = 0; r < c.nof_rx; r++) {
+    float* out = iq + (size_t)r * sflen * 2;
+    int dly = (r == 1) ? (int)c.delay_samples : 0;
+    for (int n = 0; n < sflen; n++) {
+      std::complex<double> y(0, 0);
+      for (int p = 0; p < P; p++) { int m = n - dly; cf v = m >= 0 ? tx[p][m] : cf(0, 0); y += std::complex<double>(g->h[r][p]) * std::complex<double>(v); }
+      if (c.cfo_hz != 0) { double ph = 2 * M_PI * c.cfo_hz * ((double)n + (double)(tti - c.start_tti) * sflen) / fs; y *= std::complex<double>(std::cos(ph), std::sin(ph)); }
+      out[2 * n] = (float)(y.real() + sigma * g->rng.gauss());
+      out[2 * n + 1] = (float)(y.imag() + sigma * g->rng.gauss());
+    }
+  }
+  g->tti = (g->tti + 1) % 10240;
+  return npdu;
+}
