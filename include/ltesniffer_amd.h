@@ -1,0 +1,136 @@
+/*
+ * ltesniffer_amd.h - C ABI of the MI355X-native LTESniffer per-subframe worker (the drop-in boundary).
+ *
+ * Everything behind LTESniffer's Phy / SubframeWorker pair is replaced by this library:
+ *   class Phy            /root/reference/src/include/Phy.h:22-66
+ *   class SubframeWorker /root/reference/src/include/SubframeWorker.h:16-86
+ * The caller (LTESniffer_Core::run, /root/reference/src/src/LTESniffer_Core.cc:292-299,365,434-451,547)
+ * keeps filling antenna buffers and calling prepare/putPending; decoded MAC PDUs come back through a sink
+ * callback that carries exactly the fields LTESniffer_pcap_writer::pack_and_write serialises
+ * (/root/reference/src/src/PcapWriter.cc:93-118), in (tti, DCI acceptance order, TB) order.
+ *
+ * Plain C: pointers + sizes, int return codes (0 ok, <0 error: same convention as SRSRAN_SUCCESS / SRSRAN_ERROR /
+ * SRSRAN_ERROR_INVALID_INPUTS), no exceptions cross the boundary.  The library REQUIRES a HIP device; there is no
+ * CPU fallback: lsn_phy_create fails with LSN_ERROR_NO_DEVICE when none is visible.
+ */
+#ifndef LTESNIFFER_AMD_H
+#define LTESNIFFER_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LSN_SUCCESS 0
+#define LSN_ERROR (-1)
+#define LSN_ERROR_INVALID_INPUTS (-2)
+#define LSN_ERROR_NO_DEVICE (-3)
+
+typedef struct lsn_phy lsn_phy_t;       /* replaces class Phy (Phy.h:22) */
+typedef struct lsn_worker lsn_worker_t; /* replaces class SubframeWorker (SubframeWorker.h:16) */
+
+/* srsran_cell_t subset that crosses the boundary (SubframeWorker::setCell, SubframeWorker.cc:100-107) */
+typedef struct {
+  uint32_t nof_prb;         /* 6, 15, 25, 50, 100 */
+  uint32_t nof_ports;       /* 1 or 2 CRS ports */
+  uint32_t id;              /* physical cell id */
+  uint32_t cp;              /* 0 = normal (only value supported) */
+  uint32_t phich_length;    /* 0 = normal */
+  uint32_t phich_resources; /* 0: 1/6, 1: 1/2, 2: 1, 3: 2 (LTESniffer_Core.cc:211-212 forces 1/6) */
+  uint32_t frame_type;      /* 0 = FDD */
+} lsn_cell_t;
+
+/* srsran_dl_sf_cfg_t subset passed by SubframeWorker::prepare (SubframeWorker.cc:109-116, LTESniffer_Core.cc:429-434) */
+typedef struct {
+  uint32_t tti;
+  uint32_t cfi;     /* ignored on input: decoded from PCFICH per subframe */
+  uint32_t sf_type; /* 0 = SRSRAN_SF_NORM */
+} lsn_dl_sf_cfg_t;
+
+/* Constructor arguments of Phy::Phy (Phy.h:24-36) that influence the hot path */
+typedef struct {
+  uint32_t nof_rx_antennas;
+  uint32_t nof_workers;             /* worker (buffer) pool size; Phy.h:19 uses 20 */
+  uint32_t max_batch;               /* subframes processed per GPU batch (0 = default 64) */
+  int skip_secondary_meta_formats;  /* Phy ctor skipSecondaryMetaFormats */
+  double meta_format_split_ratio;   /* Settings.h:55, default 0.99 */
+  uint32_t histogram_threshold;     /* Settings.h:57, default 5 */
+  int mcs_tracking_mode;            /* ArgManager.cc:52, default 1 */
+  int harq_mode;                    /* ArgManager.cc:50: always 0 in the reference; only 0 supported */
+  int device;                       /* HIP device ordinal */
+  int max_turbo_iterations;         /* SubframeWorker.cc:365, default 12 (0 = default) */
+} lsn_phy_cfg_t;
+
+/* What LTESniffer_pcap_writer::pack_and_write receives (PcapWriter.cc:93-111) */
+typedef struct {
+  uint32_t tti;       /* sfn*10 + sf */
+  uint16_t rnti;      /* SI/P constants already substituted (PcapWriter.cc:162-170) */
+  uint8_t direction;  /* 0 UL, 1 DL */
+  uint8_t rnti_type;  /* 0 NO, 1 P, 2 RA, 3 C, 4 SI */
+  uint8_t crc_ok;
+  uint8_t is_retx;
+  uint8_t tb;         /* transport block index within the DCI */
+  uint8_t reserved;
+} lsn_pdu_ctx_t;
+typedef void (*lsn_pdu_sink_t)(void* user, const lsn_pdu_ctx_t* ctx, const uint8_t* pdu, uint32_t len);
+
+/* DCIBlindSearchStats (PhyCommon.h:12-26) */
+typedef struct {
+  uint32_t nof_locations, nof_decoded_locations, nof_cce, nof_missed_cce, nof_subframes, nof_subframe_collisions_dw,
+      nof_subframe_collisions_up;
+} lsn_blind_stats_t;
+
+/* ---- Phy ---- */
+int lsn_phy_create(const lsn_phy_cfg_t* cfg, lsn_phy_t** out);          /* Phy::Phy, Phy.cc:5 */
+void lsn_phy_destroy(lsn_phy_t* phy);                                     /* Phy::~Phy */
+int lsn_phy_set_cell(lsn_phy_t* phy, const lsn_cell_t* cell);             /* Phy::setCell, Phy.cc:111 */
+lsn_worker_t* lsn_phy_get_avail(lsn_phy_t* phy, int blocking);            /* Phy::getAvail / getAvailImmediate, Phy.cc:79-89 */
+int lsn_phy_put_pending(lsn_phy_t* phy, lsn_worker_t* w);                 /* Phy::putPending, Phy.cc:95 */
+int lsn_phy_join_pending(lsn_phy_t* phy);                                 /* Phy::joinPending, Phy.cc:100 */
+int lsn_phy_set_pdu_sink(lsn_phy_t* phy, lsn_pdu_sink_t cb, void* user);  /* stands in for the pcapwriter ctor argument */
+int lsn_phy_get_stats(lsn_phy_t* phy, lsn_blind_stats_t* out);            /* PhyCommon::getStats, PhyCommon.cc:60 */
+float lsn_phy_get_est_cfo(lsn_phy_t* phy);                                /* SubframeWorker.cc:203 est_cfo */
+int lsn_phy_add_evergreen(lsn_phy_t* phy, uint16_t rnti_start, uint16_t rnti_end, uint32_t format_idx); /* RNTIManager::addEvergreen */
+int lsn_phy_add_forbidden(lsn_phy_t* phy, uint16_t rnti_start, uint16_t rnti_end, uint32_t format_idx); /* RNTIManager::addForbidden */
+int lsn_phy_setup_default_rnti_intervals(lsn_phy_t* phy);                 /* LTESniffer_Core.cc:398-417 in one call */
+uint32_t lsn_phy_nof_active_rnti(lsn_phy_t* phy);
+
+/* ---- SubframeWorker ---- */
+float** lsn_worker_buffers(lsn_worker_t* w);         /* SubframeWorker::getBuffers: [antenna] -> interleaved cf32, pinned host */
+uint32_t lsn_worker_buffer_len(lsn_worker_t* w);     /* complex samples per antenna buffer (3 * SF_LEN, SubframeBuffer.cc:25) */
+int lsn_worker_prepare(lsn_worker_t* w, uint32_t sf_idx, uint32_t sfn, int update_meta_formats, const lsn_dl_sf_cfg_t* sf); /* SubframeWorker::prepare */
+uint32_t lsn_worker_sf_idx(lsn_worker_t* w);
+uint32_t lsn_worker_sfn(lsn_worker_t* w);
+
+/* ---- resident (offline / file-replay) path: the IQ of n subframes is ALREADY in device memory ----
+ * d_iq layout: [subframe][antenna][15*N] interleaved cf32 (N = FFT size). Subframe i has tti = start_tti + i.
+ * update_meta_period: metaFormats.update_formats() runs when (sf_cnt % period) == 0 (LTESniffer_Core.cc:434), 0 = never.
+ * stream: a hipStream_t (may be NULL for the default stream). Blocks until all PDUs of the batch have been delivered. */
+int lsn_phy_process_device(lsn_phy_t* phy, const void* d_iq, uint32_t n_subframes, uint32_t start_tti,
+                           uint32_t update_meta_period, void* stream);
+/* same, from host memory (copies through pinned staging) */
+int lsn_phy_process_host(lsn_phy_t* phy, const float* iq, uint32_t n_subframes, uint32_t start_tti, uint32_t update_meta_period);
+
+/* ---- measurement + parity taps (not part of the reference surface) ---- */
+enum { LSN_TAP_GRID = 0, LSN_TAP_CE = 1, LSN_TAP_PDCCH_LLR = 2, LSN_TAP_CHEST = 3, LSN_TAP_CFI = 4, LSN_TAP_CANDIDATES = 5,
+       LSN_TAP_CCE_POWER = 6, LSN_TAP_ACCEPTED = 7, LSN_TAP_RB_POWER = 8 };
+/* copies tap `what` of subframe `sf_in_batch` of the LAST processed batch into out (host); returns bytes written or <0 */
+long lsn_phy_tap(lsn_phy_t* phy, int what, uint32_t sf_in_batch, void* out, size_t cap);
+typedef struct {
+  double ms_stage_a, ms_search, ms_stage_c, ms_commit, ms_total; /* wall clock of the last process call */
+  double kernel_ms[16];                                          /* HIP-event time per kernel class, last call */
+  uint64_t kernel_launches[16];
+  uint64_t algo_bytes;        /* algorithmic HBM bytes of the last call (SURVEY.md 8d formula) */
+  uint64_t turbo_algo_bytes;  /* part of algo_bytes moved by the turbo kernel */
+  uint64_t nof_tb_decodes, nof_cb_decodes, nof_turbo_iterations, nof_candidates_decoded, nof_ondemand_decodes, nof_pdus;
+} lsn_perf_t;
+int lsn_phy_get_perf(lsn_phy_t* phy, lsn_perf_t* out);
+enum { LSN_K_OFDM = 0, LSN_K_CHEST, LSN_K_CHEST_FIN, LSN_K_PCFICH, LSN_K_PDCCH_LLR, LSN_K_CCE_POWER, LSN_K_VITERBI,
+       LSN_K_PDSCH_PREP, LSN_K_PDSCH_DEMOD, LSN_K_TURBO, LSN_K_RB_POWER, LSN_K_COUNT };
+const char* lsn_kernel_name(int k);
+const char* lsn_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

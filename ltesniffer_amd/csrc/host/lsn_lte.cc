@@ -1,0 +1,552 @@
+// lsn_lte.cc - see lsn_lte.h.  Product code: must not include anything from oracle/.
+#include "lsn_lte.h"
+#include "../../../spec/lte_tables.h"
+#include <algorithm>
+
+namespace lsn {
+
+const DciFormat falcon_ue_all_formats[NOF_FORMATS] = {FORMAT0, FORMAT1, FORMAT1A, FORMAT1B, FORMAT1C, FORMAT1D, FORMAT2, FORMAT2A, FORMAT2B};
+
+// ---------------------------------------------------------------------------------------------- small helpers
+static uint32_t ceil_log2(uint32_t x) { uint32_t n = 0; while ((1u << n) < x) n++; return n; }
+static uint32_t riv_nbits(uint32_t nprb) { return ceil_log2(nprb * (nprb + 1) / 2); }
+static uint32_t ra_type0_P(uint32_t nprb) { return nprb <= 10 ? 1 : (nprb <= 26 ? 2 : (nprb <= 63 ? 3 : 4)); }
+static bool is_ambiguous_size(uint32_t n)
+{
+  for (uint32_t a : {12u, 14u, 16u, 20u, 24u, 26u, 32u, 40u, 44u, 56u}) if (a == n) return true;
+  return false;
+}
+static uint32_t ra_type2_ngap(uint32_t nprb, bool gap2)
+{
+  if (!gap2) {
+    if (nprb <= 10) return (nprb + 1) / 2;
+    if (nprb == 11) return 4;
+    if (nprb <= 19) return 8;
+    if (nprb <= 26) return 12;
+    if (nprb <= 44) return 18;
+    if (nprb <= 63) return 27;
+    if (nprb <= 79) return 32;
+    return 48;
+  }
+  return nprb < 50 ? 0 : (nprb <= 63 ? 9 : 16);
+}
+static uint32_t ra_type2_n_vrb_dl(uint32_t nprb, bool gap2)
+{
+  uint32_t g = ra_type2_ngap(nprb, gap2);
+  if (!gap2) return 2 * std::min(g, nprb - g);
+  return g ? (nprb / (2 * g)) * 2 * g : 0;
+}
+static uint32_t ra_type2_n_rb_step(uint32_t nprb) { return nprb < 50 ? 2 : 4; }
+
+// ---------------------------------------------------------------------------------------------- DCI sizes (36.212 5.3.3.1)
+namespace {
+struct Sizer {
+  uint32_t n, ports;
+  uint32_t alloc() const { return (n > 10 ? 1u : 0u) + (n + ra_type0_P(n) - 1) / ra_type0_P(n); }
+  uint32_t f0_raw() const { return 2 + riv_nbits(n) + 5 + 1 + 2 + 3 + 1; }
+  uint32_t f1a() const { uint32_t s = 2 + riv_nbits(n) + 5 + 3 + 1 + 2 + 2; s = std::max(s, f0_raw()); return is_ambiguous_size(s) ? s + 1 : s; }
+  uint32_t f0() const { return std::max(f0_raw(), f1a()); }
+  uint32_t f1() const { uint32_t s = alloc() + 13; while (s == f0() || s == f1a() || is_ambiguous_size(s)) s++; return s; }
+  uint32_t compact(uint32_t extra) const { uint32_t s = 1 + riv_nbits(n) + 13 + extra; while (is_ambiguous_size(s)) s++; return s; }
+  uint32_t f1c() const { uint32_t q = ra_type2_n_vrb_dl(n, false) / ra_type2_n_rb_step(n); return (n < 50 ? 0u : 1u) + ceil_log2(q * (q + 1) / 2) + 5; }
+  uint32_t f2x(uint32_t pbits) const { uint32_t s = alloc() + 2 + 3 + 1 + 16 + pbits; while (is_ambiguous_size(s)) s++; return s; }
+};
+}  // namespace
+
+uint32_t dci_format_sizeof(const Cell& cell, DciFormat f)
+{
+  Sizer z{cell.nof_prb, cell.nof_ports};
+  const uint32_t tpmi = cell.nof_ports == 4 ? 4 : 2;
+  switch (f) {
+    case FORMAT0: return z.f0();
+    case FORMAT1: return z.f1();
+    case FORMAT1A: return z.f1a();
+    case FORMAT1B: return z.compact(tpmi + 1);
+    case FORMAT1C: return z.f1c();
+    case FORMAT1D: return z.compact(tpmi + 1);
+    case FORMAT2: return z.f2x(cell.nof_ports == 2 ? 3 : (cell.nof_ports == 4 ? 6 : 0));
+    case FORMAT2A: return z.f2x(cell.nof_ports == 4 ? 2 : 0);
+    case FORMAT2B: return z.f2x(0);
+    default: return 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- DCI unpack
+namespace {
+struct BitReader {
+  const uint8_t* p;
+  uint32_t get(uint32_t n) { uint32_t v = 0; while (n--) v = (v << 1) | (*p++ & 1u); return v; }
+};
+void read_type01(const Cell& cell, BitReader& br, DciDl& d)
+{
+  const uint32_t n = cell.nof_prb, P = ra_type0_P(n), nbits = (n + P - 1) / P;
+  d.alloc_type = n > 10 ? (int)br.get(1) : 0;
+  if (d.alloc_type == 0) {
+    d.rbg_bitmask = br.get(nbits);
+  } else {
+    const uint32_t lb = ceil_log2(P);
+    d.rbg_subset = br.get(lb);
+    d.shift = br.get(1);
+    d.vrb_bitmask = br.get(nbits - lb - 1);
+  }
+}
+}  // namespace
+
+bool dci_msg_unpack_pdsch(const Cell& cell, const uint8_t* bits, uint32_t nof_bits, DciFormat f, uint16_t rnti, DciDl& d)
+{
+  const uint32_t keepL = d.L, keepN = d.ncce;
+  d = DciDl();
+  d.L = keepL; d.ncce = keepN; d.rnti = rnti; d.format = f;
+  if (nof_bits != dci_format_sizeof(cell, f)) return false;
+  BitReader br{bits};
+  const uint32_t n = cell.nof_prb;
+  const bool user = rnti_isuser(rnti);
+  switch (f) {
+    case FORMAT1:
+      read_type01(cell, br, d);
+      d.tb[0].mcs_idx = br.get(5); d.pid = br.get(3); d.tb[0].ndi = br.get(1); d.tb[0].rv = (int)br.get(2); d.tpc = br.get(2);
+      return true;
+    case FORMAT1A: case FORMAT1B: case FORMAT1D: {
+      if (f == FORMAT1A && br.get(1) != 1) return false;
+      d.alloc_type = 2;
+      d.distributed = br.get(1) != 0;
+      uint32_t gapbit = 0;
+      if (user && d.distributed && n >= 50) { d.ngap2 = br.get(1) != 0; gapbit = 1; }
+      d.riv = br.get(riv_nbits(n) - gapbit);
+      d.tb[0].mcs_idx = br.get(5);
+      d.pid = br.get(3);
+      if (!user && f == FORMAT1A) { uint32_t b = br.get(1); if (n >= 50 && d.distributed) d.ngap2 = b != 0; }
+      else d.tb[0].ndi = br.get(1);
+      d.tb[0].rv = (int)br.get(2);
+      if (user || f != FORMAT1A) d.tpc = br.get(2);
+      else { br.get(1); d.nprb1a_is2 = br.get(1) == 0; }
+      if (f != FORMAT1A) d.pinfo = br.get(cell.nof_ports == 4 ? 4 : 2);
+      return true;
+    }
+    case FORMAT1C: {
+      if (n >= 50) d.ngap2 = br.get(1) != 0;
+      const uint32_t q = ra_type2_n_vrb_dl(n, d.ngap2) / ra_type2_n_rb_step(n);
+      d.alloc_type = 2; d.distributed = true;
+      d.riv = br.get(ceil_log2(q * (q + 1) / 2));
+      d.tb[0].mcs_idx = br.get(5);
+      d.tb[0].rv = -1;  // resolved by the caller (DL_Sniffer_PDSCH.cc:891-897, dl_sniffer_pdsch.c:112-119)
+      return true;
+    }
+    case FORMAT2: case FORMAT2A: case FORMAT2B: {
+      read_type01(cell, br, d);
+      d.tpc = br.get(2); d.pid = br.get(3); d.tb_cw_swap = br.get(1);
+      for (auto& tb : d.tb) { tb.mcs_idx = br.get(5); tb.ndi = br.get(1); tb.rv = (int)br.get(2); }
+      if (f == FORMAT2) d.pinfo = br.get(cell.nof_ports == 2 ? 3 : (cell.nof_ports == 4 ? 6 : 0));
+      if (f == FORMAT2A) d.pinfo = br.get(cell.nof_ports == 4 ? 2 : 0);
+      const bool en0 = !(d.tb[0].mcs_idx == 0 && d.tb[0].rv == 1), en1 = !(d.tb[1].mcs_idx == 0 && d.tb[1].rv == 1);
+      const bool swap = f != FORMAT2B && d.tb_cw_swap;
+      d.tb[0].cw_idx = (en0 && en1 && swap) ? 1 : 0;
+      d.tb[1].cw_idx = (en0 && en1 && !swap) ? 1 : 0;
+      return true;
+    }
+    default: return false;
+  }
+}
+
+bool dci_msg_unpack_pusch(const Cell& cell, const uint8_t* bits, uint32_t nof_bits, uint16_t rnti, DciUl& d)
+{
+  const uint32_t keepL = d.L, keepN = d.ncce;
+  d = DciUl();
+  d.L = keepL; d.ncce = keepN; d.rnti = rnti;
+  if (nof_bits != dci_format_sizeof(cell, FORMAT0)) return false;
+  BitReader br{bits};
+  if (br.get(1) != 0) return false;
+  d.hopping = br.get(1); d.riv = br.get(riv_nbits(cell.nof_prb)); d.mcs_idx = br.get(5); d.ndi = br.get(1);
+  d.tpc = br.get(2); d.n_dmrs = br.get(3); d.cqi_req = br.get(1);
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------- resource allocation
+static void ra_type2_from_riv(uint32_t riv, uint32_t& L, uint32_t& start, uint32_t nprb, uint32_t nvrb)
+{
+  L = riv / nprb + 1;
+  start = riv % nprb;
+  if (L > nvrb - start) { L = nprb - L + 2; start = nprb - 1 - start; }
+}
+
+// 36.211 6.2.3.2 virtual resource blocks of distributed type
+static void distributed_vrb_to_prb(uint32_t nprb, bool gap2, uint32_t vrb, uint32_t& prb_even, uint32_t& prb_odd)
+{
+  const uint32_t P = ra_type0_P(nprb), G = ra_type2_ngap(nprb, gap2);
+  const uint32_t Nt = gap2 ? 2 * G : ra_type2_n_vrb_dl(nprb, false);
+  const uint32_t Nrow = ((Nt + 4 * P - 1) / (4 * P)) * P, Nnull = 4 * Nrow - Nt;
+  const uint32_t nt = vrb % Nt, blk = vrb / Nt;
+  const uint32_t p1 = 2 * Nrow * (nt % 2) + nt / 2 + Nt * blk, p2 = Nrow * (nt % 4) + nt / 4 + Nt * blk;
+  uint32_t e;
+  if (Nnull && nt >= Nt - Nnull) e = (nt % 2) ? p1 - Nrow : p1 - Nrow + Nnull / 2;
+  else if (Nnull && (nt % 4) >= 2) e = p2 - Nnull / 2;
+  else e = p2;
+  const uint32_t eb = e % Nt, ob = (eb + Nt / 2) % Nt;
+  prb_even = (eb < Nt / 2 ? eb : eb + G - Nt / 2) + Nt * blk;
+  prb_odd = (ob < Nt / 2 ? ob : ob + G - Nt / 2) + Nt * blk;
+}
+
+static bool ra_dl_grant_to_grant_prb_allocation(const Cell& cell, const DciDl& d, PdschGrant& g)
+{
+  const uint32_t n = cell.nof_prb, P = ra_type0_P(n);
+  auto set_both = [&](uint32_t prb) { if (prb < n && !g.prb_idx[0][prb]) { g.prb_idx[0][prb] = g.prb_idx[1][prb] = true; g.nof_prb++; } };
+  if (d.alloc_type == 0) {
+    const uint32_t nb = (n + P - 1) / P;
+    for (uint32_t i = 0; i < nb; i++)
+      if (d.rbg_bitmask & (1u << (nb - 1 - i)))
+        for (uint32_t j = 0; j < P; j++) set_both(i * P + j);
+  } else if (d.alloc_type == 1) {
+    const uint32_t lb = ceil_log2(P), n1 = (n + P - 1) / P - lb - 1, p = d.rbg_subset;
+    const uint32_t base = ((n - 1) / (P * P)) * P, edge = ((n - 1) / P) % P;
+    const uint32_t subset = p < edge ? base + P : (p == edge ? base + ((n - 1) % P) + 1 : base);
+    const uint32_t shift = d.shift ? subset - n1 : 0;
+    for (uint32_t i = 0; i < n1; i++)
+      if (d.vrb_bitmask & (1u << (n1 - 1 - i))) set_both(((i + shift) / P) * P * P + p * P + (i + shift) % P);
+  } else if (d.alloc_type == 2) {
+    uint32_t L, start;
+    if (d.format == FORMAT1C) {
+      const uint32_t st = ra_type2_n_rb_step(n), nv = ra_type2_n_vrb_dl(n, d.ngap2) / st;
+      if (!nv) return false;
+      ra_type2_from_riv(d.riv, L, start, nv, nv);
+      L *= st; start *= st;
+    } else {
+      ra_type2_from_riv(d.riv, L, start, n, n);
+    }
+    if (!d.distributed) {
+      for (uint32_t i = 0; i < L; i++) set_both(start + i);
+    } else {
+      const uint32_t nv = ra_type2_n_vrb_dl(n, d.ngap2);
+      if (!nv) return false;
+      for (uint32_t i = 0; i < L; i++) {
+        uint32_t v = start + i, pe, po;
+        if (v >= nv) continue;
+        distributed_vrb_to_prb(n, d.ngap2, v, pe, po);
+        if (pe < n && po < n) { g.prb_idx[0][pe] = true; g.prb_idx[1][po] = true; g.nof_prb++; }
+      }
+    }
+  } else {
+    return false;
+  }
+  return g.nof_prb > 0;
+}
+
+int ra_tbs_from_idx(int i_tbs, uint32_t n_prb)
+{
+  if (i_tbs < 0 || i_tbs >= LSN_TBS_NROWS || n_prb < 1 || n_prb > 110) return -1;
+  return lsn_tbs_table[i_tbs][n_prb - 1];
+}
+
+bool pdsch_re_usable(const Cell& cell, uint32_t sf_idx, uint32_t l, uint32_t k)
+{
+  const bool crs_symbol = l == 0 || l == 4 || l == 7 || l == 11;
+  if (crs_symbol) {
+    if (cell.nof_ports >= 2) { if (k % 3 == cell.id % 3) return false; }
+    else if (k % 6 == (((l == 0 || l == 7) ? 0u : 3u) + cell.id % 6) % 6) return false;
+  }
+  const uint32_t lo = 6 * cell.nof_prb - 36;
+  if (k >= lo && k < lo + 72) {
+    if ((sf_idx == 0 || sf_idx == 5) && (l == 5 || l == 6)) return false;
+    if (sf_idx == 0 && l >= 7 && l <= 10) return false;
+  }
+  return true;
+}
+
+static uint32_t ra_dl_compute_nof_re(const Cell& cell, uint32_t sf_idx, uint32_t cfi, const PdschGrant& g)
+{
+  uint32_t n = 0;
+  for (uint32_t l = cfi + (cell.nof_prb <= 10 ? 1 : 0); l < 14; l++)
+    for (uint32_t prb = 0; prb < cell.nof_prb; prb++)
+      if (g.prb_idx[l / 7][prb])
+        for (uint32_t k = 12 * prb; k < 12 * prb + 12; k++) n += pdsch_re_usable(cell, sf_idx, l, k) ? 1 : 0;
+  return n;
+}
+
+// dl_sniffer_compute_tb, dl_sniffer_pdsch.c:14-92
+static bool dl_sniffer_compute_tb(bool use_alt, const DciDl& d, PdschGrant& g)
+{
+  for (int i = 0; i < 2; i++) {
+    GrantTb& tb = g.tb[i];
+    tb.mcs_idx = d.tb[i].mcs_idx; tb.rv = d.tb[i].rv; tb.cw_idx = d.tb[i].cw_idx;
+    const bool tb_en = !(d.tb[i].mcs_idx == 0 && d.tb[i].rv == 1);
+    tb.enabled = (tb_en && d.format >= FORMAT2) || (d.format < FORMAT2 && i == 0);
+    if (tb.enabled) g.nof_tb++;
+  }
+  if (d.format == FORMAT1A || !rnti_isuser(d.rnti)) use_alt = false;
+  if (!rnti_isuser(d.rnti)) {
+    int tbs;
+    if (d.format == FORMAT1A) {
+      tbs = ra_tbs_from_idx((int)d.tb[0].mcs_idx, d.nprb1a_is2 ? 2 : 3);
+      if (tbs < 0) return false;
+    } else if (d.format == FORMAT1C) {
+      if (d.tb[0].mcs_idx >= 32) return false;
+      tbs = lsn_tbs_format1c_table[d.tb[0].mcs_idx];
+    } else {
+      return false;
+    }
+    g.tb[0].mod = 2;
+    g.tb[0].tbs = tbs;
+    return true;
+  }
+  const int8_t(*table)[2] = use_alt ? lsn_mcs_dl_256qam : lsn_mcs_dl_64qam;
+  for (auto& tb : g.tb) {
+    if (!tb.enabled) { tb.tbs = 0; continue; }
+    tb.mod = table[tb.mcs_idx & 31][0];
+    const int i_tbs = table[tb.mcs_idx & 31][1];
+    tb.tbs = i_tbs >= 0 ? ra_tbs_from_idx(i_tbs, g.nof_prb) : 0;  // reserved MCS: last_tbs is 0 without HARQ
+    if (tb.tbs < 0) return false;
+  }
+  return true;
+}
+
+bool dl_sniffer_ra_dl_dci_to_grant(const Cell& cell, uint32_t sf_idx, uint32_t cfi, bool use_alt, const DciDl& dci, PdschGrant& g)
+{
+  g = PdschGrant();
+  if (!ra_dl_grant_to_grant_prb_allocation(cell, dci, g)) return false;
+  if (!dl_sniffer_compute_tb(use_alt, dci, g)) return false;
+  g.nof_re = ra_dl_compute_nof_re(cell, sf_idx, cfi, g);
+  for (auto& tb : g.tb) tb.nof_bits = tb.enabled ? (int)g.nof_re * tb.mod : 0;
+  if (dci.format == FORMAT1C && (rnti_israr(dci.rnti) || dci.rnti == PRNTI))
+    for (auto& tb : g.tb) tb.rv = 0;
+  return true;
+}
+
+bool ra_ul_dci_to_grant(const Cell& cell, const DciUl& d, PuschGrant& g)
+{
+  g = PuschGrant();
+  uint32_t L, start;
+  ra_type2_from_riv(d.riv, L, start, cell.nof_prb, cell.nof_prb);
+  if (L == 0 || start + L > cell.nof_prb) return false;
+  g.L_prb = L; g.n_prb = start; g.mcs_idx = d.mcs_idx;
+  g.mod = lsn_mcs_ul_64qam[d.mcs_idx & 31][0];
+  const int i_tbs = lsn_mcs_ul_64qam[d.mcs_idx & 31][1];
+  if (i_tbs >= 0) g.tbs = ra_tbs_from_idx(i_tbs, L); else g.rv = (int)d.mcs_idx - 28;
+  return true;
+}
+
+// dl_sniffer_config_mimo, dl_sniffer_pdsch.c:134-276
+int dl_sniffer_config_mimo(const Cell& cell, DciFormat f, const DciDl& dci, PdschGrant& g)
+{
+  switch (f) {
+    case FORMAT1: case FORMAT1A: case FORMAT1C: g.tx_scheme = cell.nof_ports == 1 ? TXSCHEME_PORT0 : TXSCHEME_DIVERSITY; break;
+    case FORMAT2: g.tx_scheme = (g.nof_tb == 1 && dci.pinfo == 0) ? TXSCHEME_DIVERSITY : TXSCHEME_SPATIALMUX; break;
+    case FORMAT2A: g.tx_scheme = (g.nof_tb == 1 && dci.pinfo == 0) ? TXSCHEME_DIVERSITY : TXSCHEME_CDD; break;
+    default: return 1;
+  }
+  if (g.tx_scheme == TXSCHEME_SPATIALMUX) {
+    if (g.nof_tb == 1) { if (dci.pinfo < 1 || dci.pinfo > 4) return 2; g.pmi = dci.pinfo - 1; }
+    else { if (dci.pinfo >= 2) return 2; g.pmi = dci.pinfo % 2; }
+  }
+  switch (g.tx_scheme) {
+    case TXSCHEME_PORT0: if (g.nof_tb != 1) return 3; g.nof_layers = 1; break;
+    case TXSCHEME_DIVERSITY: if (g.nof_tb != 1) return 3; g.nof_layers = cell.nof_ports; break;
+    case TXSCHEME_SPATIALMUX: if (g.nof_tb != 1 && g.nof_tb != 2) return 3; g.nof_layers = g.nof_tb; break;
+    case TXSCHEME_CDD: if (g.nof_tb != 2) return 3; g.nof_layers = 2; break;
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------- search space (36.213 9.1.1)
+namespace {
+struct Loc { uint32_t L, ncce; };
+uint32_t ue_locations(uint32_t nof_cce, Loc* c, uint32_t cap, uint32_t nsubframe, uint16_t rnti)
+{
+  static const uint32_t ncand[4] = {6, 6, 2, 2};
+  uint32_t Yk = rnti, k = 0;
+  for (uint32_t m = 0; m <= nsubframe; m++) Yk = (39827u * Yk) % 65537u;
+  for (int l = 3; l >= 0; l--) {
+    const uint32_t L = 1u << l;
+    if (nof_cce < L) continue;
+    for (uint32_t i = 0; i < ncand[l]; i++) {
+      const uint32_t ncce = L * ((Yk + i) % (nof_cce / L));
+      if (k < cap && ncce + L <= nof_cce) c[k++] = {(uint32_t)l, ncce};
+    }
+  }
+  return k;
+}
+uint32_t common_locations(uint32_t nof_cce, Loc* c, uint32_t cap)
+{
+  uint32_t k = 0;
+  for (int l = 3; l > 1; l--) {
+    const uint32_t L = 1u << l;
+    for (uint32_t i = 0; i < std::min(nof_cce, 16u) / L; i++) {
+      const uint32_t ncce = L * (i % (nof_cce / L));
+      if (k < cap && ncce + L <= nof_cce) c[k++] = {(uint32_t)l, ncce};
+    }
+  }
+  return k;
+}
+}  // namespace
+
+uint32_t pdcch_validate_location(uint32_t nof_cce, uint32_t ncce, uint32_t l, uint32_t nsubframe, uint16_t rnti)
+{
+  Loc loc[22];
+  uint32_t n = 0;
+  if (rnti_israr(rnti)) n = common_locations(nof_cce, loc, 22);
+  else if (rnti_isuser(rnti)) { n = ue_locations(nof_cce, loc, 22, nsubframe, rnti); n += common_locations(nof_cce, loc + n, 22 - n); }
+  else if (rnti >= MRNTI) n = common_locations(nof_cce, loc, 22);
+  bool ambiguous = false, valid = false;
+  for (uint32_t i = 0; i < n; i++) {
+    if (loc[i].ncce != ncce) continue;
+    if (l > 0 && loc[i].L == l - 1) ambiguous = true;
+    if (loc[i].L == l) valid = true;
+  }
+  return valid ? (ambiguous ? 1 : 2) : 0;
+}
+
+// ---------------------------------------------------------------------------------------------- segmentation
+bool cbsegm(int tbs, CbSegm& s)
+{
+  s = CbSegm();
+  if (tbs <= 0) return false;
+  const int B = tbs + 24;
+  int Bp = B;
+  s.C = 1;
+  if (B > 6144) { s.C = (B + 6119) / 6120; Bp = B + 24 * s.C; }
+  int idx = -1;
+  for (int i = 0; i < LSN_QPP_NSIZES && idx < 0; i++) if (s.C * (int)lsn_qpp_table[i][0] >= Bp) idx = i;
+  if (idx < 0) return false;
+  s.Kp = lsn_qpp_table[idx][0];
+  if (s.C == 1) { s.Cp = 1; }
+  else {
+    if (idx == 0) return false;
+    s.Km = lsn_qpp_table[idx - 1][0];
+    s.Cm = (s.C * s.Kp - Bp) / (s.Kp - s.Km);
+    s.Cp = s.C - s.Cm;
+  }
+  s.F = s.Cp * s.Kp + s.Cm * s.Km - Bp;
+  return true;
+}
+bool qpp_params(int K, uint32_t& f1, uint32_t& f2)
+{
+  for (int i = 0; i < LSN_QPP_NSIZES; i++) if (lsn_qpp_table[i][0] == K) { f1 = lsn_qpp_table[i][1]; f2 = lsn_qpp_table[i][2]; return true; }
+  return false;
+}
+
+// ---------------------------------------------------------------------------------------------- Histogram / RNTIManager
+Histogram::Histogram(uint32_t itemCount, uint32_t valueRange)
+    : rnti_histogram(valueRange, 0), rnti_history(itemCount, 0), rnti_history_current(0), rnti_history_end(itemCount), rnti_histogram_ready(false) {}
+void Histogram::add(uint16_t item, uint32_t nTimes)
+{
+  while (nTimes-- > 0) {
+    if (rnti_histogram_ready) rnti_histogram[rnti_history[rnti_history_current]]--;
+    rnti_history[rnti_history_current] = item;
+    rnti_histogram[item]++;
+    if (++rnti_history_current == rnti_history_end) { rnti_histogram_ready = true; rnti_history_current = 0; }
+  }
+}
+
+RNTIManager::RNTIManager(uint32_t nf, uint32_t maxCand, uint32_t thr)
+    : nformats(nf), histograms(nf, Histogram(200 * (304 / 5), 65536)), evergreen(nf), forbidden(nf), active(65536, 0), reason(65536, 0),
+      lastSeen(65536, 0), assocFormatIdx(65536, 0), nactive(0), timestamp(0), lifetime(10000), threshold(thr),
+      maxCandidatesPerStepPerFormat(maxCand), remainingCandidates(nf, (int32_t)maxCand) {}
+void RNTIManager::addCandidate(uint16_t rnti, uint32_t f) { histograms[f].add(rnti); remainingCandidates[f]--; }
+bool RNTIManager::isEvergreen(uint16_t rnti, uint32_t f) const { for (auto& i : evergreen[f]) if (i.matches(rnti)) return true; return false; }
+bool RNTIManager::isForbidden(uint16_t rnti, uint32_t f) const { for (auto& i : forbidden[f]) if (i.matches(rnti)) return true; return false; }
+void RNTIManager::activateRNTI(uint16_t rnti, ActivationReason r) { if (!active[rnti]) { active[rnti] = 1; reason[rnti] = (uint8_t)r; nactive++; } }
+void RNTIManager::deactivateRNTI(uint16_t rnti) { if (active[rnti]) { active[rnti] = 0; assocFormatIdx[rnti] = 0; nactive--; } }
+uint32_t RNTIManager::getLikelyDlFormatIdx(uint16_t rnti) const
+{
+  uint32_t best = 0, mx = 0;
+  for (uint32_t f = 1; f < nformats; f++) { uint32_t c = histograms[f].getFrequency(rnti); if (c > mx) { mx = c; best = f; } }
+  return best;
+}
+bool RNTIManager::validate(uint16_t rnti, uint32_t f)
+{
+  if (isEvergreen(rnti, f)) return true;
+  if (isForbidden(rnti, f)) return false;
+  if (active[rnti]) {
+    if (timestamp - lastSeen[rnti] < lifetime) return true;
+    deactivateRNTI(rnti);
+  }
+  const uint32_t likely = getLikelyDlFormatIdx(rnti);
+  if (f != 0 && f != likely) return false;
+  const uint32_t ul = histograms[0].getFrequency(rnti), dl = likely ? histograms[likely].getFrequency(rnti) : 0;
+  if (ul + dl <= threshold) return false;
+  activateRNTI(rnti, RM_ACT_HISTOGRAM);
+  assocFormatIdx[rnti] = dl > threshold ? likely : 0;
+  return true;
+}
+bool RNTIManager::validateAndRefresh(uint16_t rnti, uint32_t f) { bool ok = validate(rnti, f); if (ok) lastSeen[rnti] = timestamp; return ok; }
+void RNTIManager::activateAndRefresh(uint16_t rnti, uint32_t f, ActivationReason r) { activateRNTI(rnti, r); lastSeen[rnti] = timestamp; assocFormatIdx[rnti] = f; }
+void RNTIManager::stepTime()
+{
+  for (uint32_t i = 0; i < nformats; i++) {
+    if (remainingCandidates[i] > 0) histograms[i].add(0, (uint32_t)remainingCandidates[i]);
+    remainingCandidates[i] = (int32_t)maxCandidatesPerStepPerFormat;
+  }
+  timestamp++;
+}
+
+// ---------------------------------------------------------------------------------------------- DCIMetaFormats
+DCIMetaFormats::DCIMetaFormats(uint32_t nformats, double ratio) : all(nformats), primary(nformats), secondary(nformats), split_ratio(ratio)
+{
+  for (uint32_t i = 0; i < nformats; i++) all[i] = {falcon_ue_all_formats[i], i, 0};
+  update_formats();
+}
+void DCIMetaFormats::update_formats()
+{
+  const int n = (int)all.size();
+  std::vector<MetaFormat*> sorted(n);
+  double total = 0;
+  for (int i = 0; i < n; i++) { sorted[i] = &all[i]; total += all[i].hits; }
+  for (int i = 0; i < n - 1; i++) {  // selection sort exactly as MetaFormats.cc:52-62 (ties keep the first maximum)
+    int mx = i;
+    for (int j = mx; j < n; j++) if (sorted[j]->hits > sorted[mx]->hits) mx = j;
+    std::swap(sorted[i], sorted[mx]);
+  }
+  const double thr = total * split_ratio;
+  double cum = 0;
+  nprimary = nsecondary = 0;
+  for (int i = 0; i < n; i++) {
+    if (cum <= thr) primary[nprimary++] = sorted[i]; else secondary[nsecondary++] = sorted[i];
+    cum += sorted[i]->hits;
+    sorted[i]->hits = 0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------- MCSTracking
+McsTable MCSTracking::find_tracking_info_RNTI_dl(uint16_t rnti) const
+{
+  if (!db[rnti].present) return count < max_size ? TABLE_UNKNOWN : TABLE_FULL_BUFFER;
+  return (McsTable)db[rnti].table;
+}
+void MCSTracking::add_RNTI_dl(uint16_t rnti) { if (!db[rnti].present) { db[rnti] = Entry(); db[rnti].present = 1; count++; } }
+void MCSTracking::update_RNTI_dl(uint16_t rnti, McsTable t)
+{
+  Entry& e = db[rnti];
+  if (!e.present) { add_RNTI_dl(rnti); return; }
+  if (e.has_rar) {
+    if (e.nof_msg_after_rar > rar_thresold) { e.table = (uint8_t)t; e.has_rar = 0; }
+    else e.table = TABLE_UNKNOWN;
+  } else {
+    e.table = (uint8_t)t;
+  }
+}
+void MCSTracking::update_rar_time_crnti(uint16_t crnti) { add_RNTI_dl(crnti); db[crnti].has_rar = 1; db[crnti].table = TABLE_UNKNOWN; }
+void MCSTracking::update_statistic_dl(uint16_t rnti, DciFormat f) { add_RNTI_dl(rnti); if (f > FORMAT1A && db[rnti].has_rar) db[rnti].nof_msg_after_rar++; }
+
+// ---------------------------------------------------------------------------------------------- CRC helpers
+uint32_t crc_bits(uint32_t poly, int order, const uint8_t* bits, int n)
+{
+  uint32_t reg = 0, top = 1u << order;
+  for (int i = 0; i < n + order; i++) { reg = (reg << 1) | (i < n ? (bits[i] & 1u) : 0u); if (reg & top) reg ^= poly; }
+  return reg & (top - 1);
+}
+uint32_t crc24a_mulmod(uint32_t a, uint32_t b)
+{
+  uint32_t r = 0;
+  for (int i = 23; i >= 0; i--) {
+    r <<= 1;
+    if (r & 0x1000000u) r ^= 0x1864CFBu;
+    if ((b >> i) & 1u) r ^= a;
+  }
+  return r & 0xFFFFFFu;
+}
+uint32_t crc24a_xpow(uint64_t n)
+{
+  uint32_t result = 1, base = 2;  // x^0, x^1
+  while (n) { if (n & 1) result = crc24a_mulmod(result, base); base = crc24a_mulmod(base, base); n >>= 1; }
+  return result;
+}
+
+}  // namespace lsn

@@ -1,0 +1,145 @@
+// lsn_lte.h - host-side LTE control logic of the product (integer logic that the reference also keeps on the CPU:
+// SURVEY.md section 8a rows a5, a8-a12, a19).  C++ mirror of the reference's own types:
+//   RNTIManager / Histogram / Interval  /root/reference/lib/src/util/{RNTIManager,Histogram,Interval}.cc
+//   DCIMetaFormats                      /root/reference/src/src/MetaFormats.cc
+//   dl_sniffer_* grant logic            /root/reference/lib/src/phy/falcon_phch/dl_sniffer_pdsch.c
+//   search-space validation             /root/reference/lib/src/phy/falcon_phch/falcon_pdcch.c:183-250
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <list>
+#include <string>
+#include <vector>
+
+namespace lsn {
+
+enum DciFormat { FORMAT0 = 0, FORMAT1, FORMAT1A, FORMAT1B, FORMAT1C, FORMAT1D, FORMAT2, FORMAT2A, FORMAT2B, NOF_FORMATS };
+extern const DciFormat falcon_ue_all_formats[NOF_FORMATS];  // DCISearch.cc:84-95
+enum TxScheme { TXSCHEME_PORT0 = 0, TXSCHEME_DIVERSITY, TXSCHEME_SPATIALMUX, TXSCHEME_CDD };
+enum McsTable { TABLE_64QAM = 0, TABLE_256QAM = 1, TABLE_UNKNOWN = 2, TABLE_BOTH = 3, TABLE_FULL_BUFFER = 4 };  // falcon_dci.h dl_sniffer_mcs_table_t
+enum ActivationReason { RM_ACT_UNSET = 0, RM_ACT_EVERGREEN, RM_ACT_RAR, RM_ACT_SHORTCUT, RM_ACT_HISTOGRAM, RM_ACT_OTHER };
+
+constexpr uint16_t SIRNTI = 0xFFFF, PRNTI = 0xFFFE, MRNTI = 0xFFFD, RARNTI_START = 0x0001, RARNTI_END = 0x000A,
+                   CRNTI_START = 0x000B, CRNTI_END = 0xFFF3;
+inline bool rnti_isuser(uint16_t r) { return r >= CRNTI_START && r <= CRNTI_END; }
+inline bool rnti_israr(uint16_t r) { return r >= RARNTI_START && r <= RARNTI_END; }
+
+struct Cell { uint32_t nof_prb = 0, nof_ports = 0, id = 0, phich_ng_x6 = 1; };
+
+// ---- DCI ----
+uint32_t dci_format_sizeof(const Cell& cell, DciFormat f);
+struct DciTb { uint32_t mcs_idx = 0; int rv = 0; uint32_t ndi = 0; uint32_t cw_idx = 0; };
+struct DciDl {
+  uint16_t rnti = 0; DciFormat format = FORMAT1; uint32_t L = 0, ncce = 0;
+  int alloc_type = 0; uint32_t rbg_bitmask = 0, vrb_bitmask = 0, rbg_subset = 0, shift = 0;
+  uint32_t riv = 0; bool distributed = false, ngap2 = false, nprb1a_is2 = false;
+  uint32_t pid = 0; DciTb tb[2]; uint32_t tb_cw_swap = 0, pinfo = 0, tpc = 0;
+};
+struct DciUl { uint16_t rnti = 0; uint32_t L = 0, ncce = 0, hopping = 0, riv = 0, mcs_idx = 0, ndi = 0, tpc = 0, n_dmrs = 0, cqi_req = 0; };
+struct GrantTb { uint32_t mcs_idx = 0; int rv = 0; uint32_t cw_idx = 0; bool enabled = false; int mod = 0; int tbs = 0; int nof_bits = 0; };
+struct PdschGrant {
+  bool prb_idx[2][110]; uint32_t nof_prb = 0, nof_re = 0, nof_tb = 0; GrantTb tb[2]; TxScheme tx_scheme = TXSCHEME_PORT0;
+  uint32_t pmi = 0, nof_layers = 0;
+  PdschGrant() { std::memset(prb_idx, 0, sizeof(prb_idx)); }
+};
+struct PuschGrant { uint32_t L_prb = 0, n_prb = 0, mcs_idx = 0; int mod = 0, tbs = 0, rv = 0; };
+
+bool dci_msg_unpack_pdsch(const Cell& cell, const uint8_t* bits, uint32_t nof_bits, DciFormat f, uint16_t rnti, DciDl& out);
+bool dci_msg_unpack_pusch(const Cell& cell, const uint8_t* bits, uint32_t nof_bits, uint16_t rnti, DciUl& out);
+bool dl_sniffer_ra_dl_dci_to_grant(const Cell& cell, uint32_t sf_idx, uint32_t cfi, bool use_tbs_index_alt, const DciDl& dci, PdschGrant& g);
+bool ra_ul_dci_to_grant(const Cell& cell, const DciUl& dci, PuschGrant& g);
+int dl_sniffer_config_mimo(const Cell& cell, DciFormat f, const DciDl& dci, PdschGrant& g);  // 0 ok
+bool pdsch_re_usable(const Cell& cell, uint32_t sf_idx, uint32_t l, uint32_t k);
+int ra_tbs_from_idx(int i_tbs, uint32_t n_prb);
+uint32_t pdcch_validate_location(uint32_t nof_cce, uint32_t ncce, uint32_t l, uint32_t nsubframe, uint16_t rnti);
+
+struct CbSegm { int C = 0, Cp = 0, Cm = 0, Kp = 0, Km = 0, F = 0; };
+bool cbsegm(int tbs, CbSegm& s);
+bool qpp_params(int K, uint32_t& f1, uint32_t& f2);
+
+// ---- Histogram / RNTIManager ----
+class Histogram {
+public:
+  Histogram(uint32_t itemCount, uint32_t valueRange);
+  void add(uint16_t item, uint32_t nTimes = 1);
+  uint32_t getFrequency(uint16_t item) const { return rnti_histogram[item]; }
+private:
+  std::vector<uint32_t> rnti_histogram;
+  std::vector<uint16_t> rnti_history;
+  uint32_t rnti_history_current, rnti_history_end;
+  bool rnti_histogram_ready;
+};
+struct Interval { uint16_t start, end; bool matches(uint16_t v) const { return v >= start && v <= end; } };
+
+class RNTIManager {
+public:
+  RNTIManager(uint32_t nformats, uint32_t maxCandidatesPerStepPerFormat, uint32_t histogramThreshold);
+  void addEvergreen(uint16_t a, uint16_t b, uint32_t formatIdx) { evergreen[formatIdx].push_back({a, b}); }
+  void addForbidden(uint16_t a, uint16_t b, uint32_t formatIdx) { forbidden[formatIdx].push_back({a, b}); }
+  void addCandidate(uint16_t rnti, uint32_t formatIdx);
+  bool validate(uint16_t rnti, uint32_t formatIdx);
+  bool validateAndRefresh(uint16_t rnti, uint32_t formatIdx);
+  void activateAndRefresh(uint16_t rnti, uint32_t formatIdx, ActivationReason reason);
+  bool isEvergreen(uint16_t rnti, uint32_t formatIdx) const;
+  bool isForbidden(uint16_t rnti, uint32_t formatIdx) const;
+  void stepTime();
+  uint32_t getFrequency(uint16_t rnti, uint32_t formatIdx) const { return histograms[formatIdx].getFrequency(rnti); }
+  ActivationReason getActivationReason(uint16_t rnti) const { return active[rnti] ? (ActivationReason)reason[rnti] : RM_ACT_UNSET; }
+  uint32_t nofActive() const { return nactive; }
+private:
+  uint32_t getLikelyDlFormatIdx(uint16_t rnti) const;
+  void activateRNTI(uint16_t rnti, ActivationReason r);
+  void deactivateRNTI(uint16_t rnti);
+  uint32_t nformats;
+  std::vector<Histogram> histograms;
+  std::vector<std::vector<Interval>> evergreen, forbidden;
+  std::vector<uint8_t> active, reason;
+  std::vector<uint32_t> lastSeen, assocFormatIdx;
+  uint32_t nactive, timestamp, lifetime, threshold, maxCandidatesPerStepPerFormat;
+  std::vector<int32_t> remainingCandidates;
+};
+
+// ---- DCIMetaFormats ----
+struct MetaFormat { DciFormat format; uint32_t global_index; uint32_t hits; };
+class DCIMetaFormats {
+public:
+  explicit DCIMetaFormats(uint32_t nformats, double split_ratio = 1.0);
+  void update_formats();
+  MetaFormat** getPrimaryMetaFormats() { return primary.data(); }
+  MetaFormat** getSecondaryMetaFormats() { return secondary.data(); }
+  uint32_t getNofPrimaryMetaFormats() const { return nprimary; }
+  uint32_t getNofSecondaryMetaFormats() const { return nsecondary; }
+  void setSkipSecondaryMetaFormats(bool s) { skip_secondary = s; }
+  bool skipSecondaryMetaFormats() const { return skip_secondary; }
+private:
+  std::vector<MetaFormat> all;
+  std::vector<MetaFormat*> primary, secondary;
+  uint32_t nprimary = 0, nsecondary = 0;
+  bool skip_secondary = false;
+  double split_ratio;
+};
+
+// ---- MCSTracking (DL table learning only; MCSTracking.cc:758-848,1269-1291) ----
+class MCSTracking {
+public:
+  McsTable find_tracking_info_RNTI_dl(uint16_t rnti) const;
+  void update_RNTI_dl(uint16_t rnti, McsTable t);
+  void update_rar_time_crnti(uint16_t crnti);
+  void update_statistic_dl(uint16_t rnti, DciFormat f);
+  McsTable peek(uint16_t rnti) const { return db[rnti].present ? (McsTable)db[rnti].table : TABLE_UNKNOWN; }
+  MCSTracking() : db(65536) {}
+private:
+  struct Entry { uint8_t present = 0, has_rar = 0, table = TABLE_UNKNOWN; uint16_t nof_msg_after_rar = 0; };
+  void add_RNTI_dl(uint16_t rnti);
+  std::vector<Entry> db;
+  uint32_t count = 0;
+  static constexpr uint32_t max_size = 250;  // MCSTracking.h:30
+  static constexpr uint16_t rar_thresold = 3;
+};
+
+// ---- GF(2) helpers for the transport-block CRC combine ----
+uint32_t crc24a_xpow(uint64_t n);                 // x^n mod g_CRC24A
+uint32_t crc24a_mulmod(uint32_t a, uint32_t b);   // a*b mod g_CRC24A
+uint32_t crc_bits(uint32_t poly, int order, const uint8_t* bits, int n);
+
+}  // namespace lsn

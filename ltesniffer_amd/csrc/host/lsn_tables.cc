@@ -1,0 +1,237 @@
+// lsn_tables.cc - cell-constant device tables (twiddles, CRS, REG maps, scrambling, Viterbi gather ranks, PDSCH RE
+// masks, Gold-sequence masks, CRC remainder tables) and device buffer allocation for the engine.
+#include "lsn_engine.h"
+#include "../../../spec/lte_tables.h"
+#include <cmath>
+#include <cstdio>
+#include <stdexcept>
+
+#define HIP_CHECK(x)                                                                                       \
+  do {                                                                                                     \
+    hipError_t _e = (x);                                                                                   \
+    if (_e != hipSuccess) throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(_e) + " at " #x); \
+  } while (0)
+
+namespace lsn {
+
+// c(n) = x1(n+1600) ^ x2(n+1600), TS 36.211 7.2
+void gold_sequence(uint32_t cinit, uint8_t* c, int len)
+{
+  uint32_t x1 = 1, x2 = cinit & 0x7FFFFFFFu;
+  for (int n = 0; n < 1600 + len; n++) {
+    if (n >= 1600) c[n - 1600] = (uint8_t)((x1 ^ x2) & 1u);
+    x1 = (x1 >> 1) | ((((x1 >> 3) ^ x1) & 1u) << 30);
+    x2 = (x2 >> 1) | ((((x2 >> 3) ^ (x2 >> 2) ^ (x2 >> 1) ^ x2) & 1u) << 30);
+  }
+}
+
+static int fft_size_for(uint32_t nprb)
+{
+  switch (nprb) { case 6: return 128; case 15: return 256; case 25: return 512; case 50: return 1024; case 100: return 2048; default: return -1; }
+}
+
+template <typename T>
+static T* upload(std::vector<void*>& allocs, const std::vector<T>& v)
+{
+  void* d = nullptr;
+  HIP_CHECK(hipMalloc(&d, v.size() * sizeof(T) + 16));
+  HIP_CHECK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+  allocs.push_back(d);
+  return (T*)d;
+}
+template <typename T>
+static T* dalloc(std::vector<void*>& allocs, size_t n)
+{
+  void* d = nullptr;
+  HIP_CHECK(hipMalloc(&d, n * sizeof(T) + 16));
+  HIP_CHECK(hipMemset(d, 0, n * sizeof(T)));
+  allocs.push_back(d);
+  return (T*)d;
+}
+
+void Engine::freeDevice()
+{
+  for (void* p : dev_allocs) (void)hipFree(p);
+  dev_allocs.clear();
+  auto hf = [](void* p) { if (p) (void)hipHostFree(p); };
+  hf(h_cand); hf(h_ccepow); hf(h_chest); hf(h_cfi); hf(h_rbp); hf(h_payload_pinned); hf(h_cbres_pinned);
+  h_cand = nullptr; h_ccepow = nullptr; h_chest = nullptr; h_cfi = nullptr; h_rbp = nullptr; h_payload_pinned = nullptr; h_cbres_pinned = nullptr;
+  h_payload_cap = h_cbres_cap = 0;
+  auto df = [](void* p) { if (p) (void)hipFree(p); };
+  df(d_jobs); df(d_cbs); df(d_cbres); df(d_prefix); df(d_llr16); df(d_payload);
+  d_jobs = nullptr; d_cbs = nullptr; d_cbres = nullptr; d_prefix = nullptr; d_llr16 = nullptr; d_payload = nullptr;
+  jobs_cap = cbs_cap = 0; prefix_cap = llr16_cap = payload_cap = 0;
+}
+
+void Engine::buildTables()
+{
+  const uint32_t nprb = cell.nof_prb, P = cell.nof_ports, id = cell.id;
+  const int N = fft_size_for(nprb);
+  cd = LsnCellDev{};
+  cd.nof_prb = nprb; cd.nof_ports = P; cd.id = id; cd.nof_rx = cfg.nof_rx_antennas;
+  cd.N = (uint32_t)N; cd.lgN = 0; while ((1 << cd.lgN) < N) cd.lgN++;
+  cd.nre = 12 * nprb; cd.nref = 2 * nprb; cd.sflen = 15u * (uint32_t)N;
+  // FFT twiddles and NCO tables (double -> float, same generation as the oracle's definition)
+  std::vector<cf32> tw((size_t)N / 2), coarse(4096), fine(1024);
+  for (int k = 0; k < N / 2; k++) { double a = 2.0 * M_PI * k / N; tw[k] = {(float)std::cos(a), (float)(-std::sin(a))}; }
+  for (int k = 0; k < 4096; k++) { double a = 2.0 * M_PI * k / 4096.0; coarse[k] = {(float)std::cos(a), (float)std::sin(a)}; }
+  for (int k = 0; k < 1024; k++) { double a = 2.0 * M_PI * k / 4194304.0; fine[k] = {(float)std::cos(a), (float)std::sin(a)}; }
+  cd.twiddle = upload(dev_allocs, tw); cd.nco_coarse = upload(dev_allocs, coarse); cd.nco_fine = upload(dev_allocs, fine);
+  // CRS values for every subframe index (36.211 6.10.1.1)
+  {
+    const float s = 0.70710678118654752440f;
+    std::vector<cf32> crs((size_t)10 * P * 4 * cd.nref);
+    std::vector<uint8_t> c(440);
+    static const int sym[4] = {0, 4, 7, 11};
+    for (uint32_t sf = 0; sf < 10; sf++)
+      for (int q = 0; q < 4; q++) {
+        const uint32_t l = sym[q], ns = 2 * sf + (l >= 7 ? 1 : 0), lsl = l % 7;
+        gold_sequence(1024u * (7u * (ns + 1) + lsl + 1) * (2u * id + 1) + 2u * id + 1, c.data(), 440);
+        for (uint32_t m = 0; m < cd.nref; m++) {
+          const uint32_t mp = m + 110 - nprb;
+          cf32 v{c[2 * mp] ? -s : s, c[2 * mp + 1] ? -s : s};
+          for (uint32_t p = 0; p < P; p++) crs[((sf * P + p) * 4 + q) * cd.nref + m] = v;
+        }
+      }
+    cd.crs = upload(dev_allocs, crs);
+  }
+  // REGs: PCFICH (36.211 6.7.4), PHICH (6.9.3, normal duration), PDCCH quadruplet -> REG map (6.8.5)
+  {
+    const int nre = (int)cd.nre, n0 = nre / 6;
+    std::vector<uint8_t> used0((size_t)n0, 0);
+    const int kbar = 6 * (int)(id % (2 * nprb));
+    for (int i = 0; i < 4; i++) { int k = (kbar + (i * (int)nprb / 2) * 6) % nre; cd.pcfich_k0[i] = (uint32_t)k; used0[k / 6] = 1; }
+    const int ng = (int)((cell.phich_ng_x6 * nprb + 47) / 48);
+    std::vector<int> avail;
+    for (int i = 0; i < n0; i++) if (!used0[i]) avail.push_back(i);
+    const int na = (int)avail.size();
+    for (int m = 0; m < ng; m++) for (int i = 0; i < 3; i++) used0[avail[((int)id + m + (i * na) / 3) % na]] = 1;
+    std::vector<uint16_t> rk(3 * 800, 0);
+    std::vector<uint8_t> rl(3 * 800, 0);
+    for (int cfi = 1; cfi <= 3; cfi++) {
+      const int nsym = cfi + (nprb <= 10 ? 1 : 0);
+      std::vector<std::pair<uint16_t, uint8_t>> regs;
+      for (int k = 0; k < nre; k++)
+        for (int l = 0; l < nsym; l++) {
+          const int w = l == 0 ? 6 : 4;
+          if (k % w || (l == 0 && used0[k / 6])) continue;
+          regs.push_back({(uint16_t)k, (uint8_t)l});
+        }
+      const int M = (int)regs.size(), R = (M + 31) / 32, ND = 32 * R - M;
+      std::vector<int> perm;
+      for (int j = 0; j < 32; j++) for (int r = 0; r < R; r++) { int idx = r * 32 + lsn_perm_cc[j]; if (idx >= ND) perm.push_back(idx - ND); }
+      cd.nof_regs[cfi - 1] = (uint32_t)M; cd.nof_cce[cfi - 1] = (uint32_t)(M / 9);
+      for (int mp = 0; mp < M; mp++) {
+        const int q = perm[(mp + (int)id) % M];
+        if (q < 800) { rk[(cfi - 1) * 800 + q] = regs[mp].first; rl[(cfi - 1) * 800 + q] = regs[mp].second; }
+      }
+    }
+    cd.reg_k0 = upload(dev_allocs, rk); cd.reg_l = upload(dev_allocs, rl);
+  }
+  // scrambling sequences of the control region
+  {
+    std::vector<uint8_t> scr((size_t)10 * LSN_LLR_STRIDE), pscr(10 * 32);
+    for (uint32_t sf = 0; sf < 10; sf++) {
+      gold_sequence(sf * 512u + id, scr.data() + (size_t)sf * LSN_LLR_STRIDE, LSN_LLR_STRIDE);
+      gold_sequence((sf + 1) * (2u * id + 1) * 512u + id, pscr.data() + sf * 32, 32);
+    }
+    cd.pdcch_scr = upload(dev_allocs, scr); cd.pcfich_scr = upload(dev_allocs, pscr);
+  }
+  // Gaussian smoothing taps: srsran_chest_set_smooth_filter_gauss(order 4, std 1) [srsRAN], SubframeWorker.cc:381-383
+  {
+    float sum = 0.0f;
+    for (int i = 0; i < 5; i++) { float d = (float)(i - 2); cd.taps[i] = expf(-(d * d) / 2.0f); }
+    for (int i = 0; i < 5; i++) sum = sum + cd.taps[i];
+    const float inv = 1.0f / sum;
+    for (int i = 0; i < 5; i++) cd.taps[i] = cd.taps[i] * inv;
+  }
+  // distinct DCI sizes + the de-rate-matching rank of every Viterbi input position (36.212 5.1.4.2)
+  {
+    std::vector<uint32_t> sizes;
+    for (int f = 0; f < NOF_FORMATS; f++) {
+      size_of_format[f] = dci_format_sizeof(cell, (DciFormat)f);
+      if (std::find(sizes.begin(), sizes.end(), size_of_format[f]) == sizes.end()) sizes.push_back(size_of_format[f]);
+    }
+    std::sort(sizes.begin(), sizes.end());
+    if (sizes.size() > LSN_MAX_SIZES || sizes.back() > 64) throw std::runtime_error("unsupported DCI size set");
+    cd.nsizes = (uint32_t)sizes.size();
+    for (size_t i = 0; i < sizes.size(); i++) cd.sizes[i] = sizes[i];
+    for (int f = 0; f < NOF_FORMATS; f++) size_index_of_format[f] = (int)(std::find(sizes.begin(), sizes.end(), size_of_format[f]) - sizes.begin());
+    std::vector<uint16_t> rank((size_t)LSN_MAX_SIZES * 3 * LSN_MAX_DCI_D, 0);
+    for (size_t si = 0; si < sizes.size(); si++) {
+      const int D = (int)sizes[si] + 16, R = (D + 31) / 32, KP = 32 * R, ND = KP - D;
+      int nonnull = 0;
+      for (int s = 0; s < 3; s++)
+        for (int col = 0; col < 32; col++)
+          for (int r = 0; r < R; r++) {
+            const int idx = r * 32 + lsn_perm_cc[col];
+            if (idx >= ND) rank[si * 3 * LSN_MAX_DCI_D + 3 * (idx - ND) + s] = (uint16_t)nonnull++;
+          }
+    }
+    cd.rankmap = upload(dev_allocs, rank);
+  }
+  // PDSCH-capable RE masks per (subframe class, symbol, PRB)
+  {
+    std::vector<uint16_t> vm((size_t)3 * 14 * nprb, 0);
+    const uint32_t cls_sf[3] = {0, 5, 1};
+    for (int cl = 0; cl < 3; cl++)
+      for (uint32_t l = 0; l < 14; l++)
+        for (uint32_t prb = 0; prb < nprb; prb++) {
+          uint16_t m = 0;
+          for (uint32_t kk = 0; kk < 12; kk++) if (pdsch_re_usable(cell, cls_sf[cl], l, 12 * prb + kk)) m |= (uint16_t)(1u << kk);
+          vm[((size_t)cl * 14 + l) * nprb + prb] = m;
+        }
+    cd.validmask = upload(dev_allocs, vm);
+  }
+  // Gold sequence as a table: x1 part + the GF(2)-linear map cinit -> x2(n+1600)
+  {
+    std::vector<uint8_t> x1v(LSN_GOLD_LEN);
+    std::vector<uint32_t> m2(LSN_GOLD_LEN);
+    uint32_t x1 = 1;
+    uint32_t st[31];
+    for (int i = 0; i < 31; i++) st[i] = 1u << i;  // st[i] = mask of cinit bits that make up x2(n+i)
+    int head = 0;
+    for (int n = 0; n < 1600 + LSN_GOLD_LEN; n++) {
+      if (n >= 1600) { x1v[n - 1600] = (uint8_t)(x1 & 1u); m2[n - 1600] = st[head]; }
+      x1 = (x1 >> 1) | ((((x1 >> 3) ^ x1) & 1u) << 30);
+      const uint32_t nm = st[(head + 3) % 31] ^ st[(head + 2) % 31] ^ st[(head + 1) % 31] ^ st[head];
+      st[head] = nm;  // slot of x2(n) becomes x2(n+31)
+      head = (head + 1) % 31;
+    }
+    cd.gold_x1 = upload(dev_allocs, x1v); cd.gold_x2mask = upload(dev_allocs, m2);
+  }
+  // x^j mod g for the two 24-bit CRCs
+  {
+    std::vector<uint32_t> ta(6144), tb(6144);
+    uint32_t a = 1, b = 1;
+    for (int j = 0; j < 6144; j++) {
+      ta[j] = a; tb[j] = b;
+      a <<= 1; if (a & 0x1000000u) a ^= 0x1864CFBu;
+      b <<= 1; if (b & 0x1000000u) b ^= 0x1800063u;
+    }
+    cd.crc_tab_a = upload(dev_allocs, ta); cd.crc_tab_b = upload(dev_allocs, tb);
+  }
+  // batch buffers
+  const size_t B = max_batch, A = cfg.nof_rx_antennas;
+  d_grid = dalloc<cf32>(dev_allocs, B * A * 14 * cd.nre);
+  d_ce = dalloc<cf32>(dev_allocs, B * P * A * 14 * cd.nre);
+  d_chest_raw = dalloc<float>(dev_allocs, B * A * P * 8);
+  d_chest = dalloc<LsnChest>(dev_allocs, B);
+  d_cfi = dalloc<uint32_t>(dev_allocs, B);
+  d_sfidx = dalloc<uint32_t>(dev_allocs, B);
+  d_pcfich_corr = dalloc<float>(dev_allocs, B * 3);
+  d_llr = dalloc<float>(dev_allocs, B * LSN_LLR_STRIDE);
+  d_ccepow = dalloc<float>(dev_allocs, B * LSN_CCE_STRIDE);
+  d_cand = dalloc<LsnCand>(dev_allocs, B * LSN_MAX_LOC * LSN_MAX_SIZES);
+  d_rbp = dalloc<float>(dev_allocs, B * 128);
+  d_iq_staging = dalloc<cf32>(dev_allocs, B * A * cd.sflen);
+  HIP_CHECK(hipHostMalloc((void**)&h_cand, B * LSN_MAX_LOC * LSN_MAX_SIZES * sizeof(LsnCand)));
+  HIP_CHECK(hipHostMalloc((void**)&h_ccepow, B * LSN_CCE_STRIDE * sizeof(float)));
+  HIP_CHECK(hipHostMalloc((void**)&h_chest, B * sizeof(LsnChest)));
+  HIP_CHECK(hipHostMalloc((void**)&h_cfi, B * sizeof(uint32_t)));
+  HIP_CHECK(hipHostMalloc((void**)&h_rbp, B * 128 * sizeof(float)));
+  ctx.assign(B, SubframeCtx());
+  rb_map_dl.assign(nprb, 0); rb_map_ul.assign(nprb, 0);
+}
+
+}  // namespace lsn

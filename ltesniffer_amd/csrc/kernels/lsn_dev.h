@@ -1,0 +1,100 @@
+// lsn_dev.h - device-side data layout shared by the HIP kernels and the host engine (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct cf32 { float r, i; };
+
+#define LSN_MAX_RX 2
+#define LSN_MAX_PORTS 2
+#define LSN_LLR_STRIDE 6400   // PDCCH LLR floats reserved per subframe (>= 8*787)
+#define LSN_CCE_STRIDE 96
+#define LSN_MAX_LOC 160       // falcon_ue_dl.h:39
+#define LSN_MAX_SIZES 8
+#define LSN_MAX_NUM_OF_CCE 84 // falcon_pdcch.h:36
+#define LSN_MAX_DCI_D 144     // payload + 16
+#define LSN_NEG_METRIC (-12000)
+#define LSN_LLR_CLIP 511
+#define LSN_EXT_CLIP 2047
+
+// one blind-decode result: (location, DCI size) of one subframe
+struct LsnCand {
+  unsigned long long bits;  // payload bit i at position 63-i
+  uint32_t rnti;            // CRC remainder
+  uint32_t flags;           // 1 = decoded, 0 = skipped (location out of range / insufficient power / all-zero LLRs)
+};
+
+// per-subframe channel estimation scalars produced on the device (the host adds snr_db / cfo_hz)
+struct LsnChest {
+  float noise_avg, rsrp_avg, chan_ref, corr_r, corr_i;
+  float noise[4], rsrp[4], cepow[4];  // [rx*nof_ports + port]
+  float pad[3];
+};
+
+// cell-constant tables, passed to kernels by value
+struct LsnCellDev {
+  uint32_t nof_prb, nof_ports, id, nof_rx, N, lgN, nre, nref, sflen;
+  const cf32* twiddle;      // [N/2] exp(-2 pi i k/N)
+  const cf32* nco_coarse;   // [4096]
+  const cf32* nco_fine;     // [1024]
+  const cf32* crs;          // [10][ports][4][nref]
+  const uint16_t* reg_k0;   // [3][800] quadruplet -> first RE of its REG
+  const uint8_t* reg_l;     // [3][800]
+  const uint8_t* pdcch_scr; // [10][LSN_LLR_STRIDE] scrambling bits
+  const uint8_t* pcfich_scr;// [10][32]
+  uint32_t nof_cce[3], nof_regs[3];
+  uint32_t pcfich_k0[4];
+  float taps[5];
+  uint32_t nsizes;
+  uint32_t sizes[LSN_MAX_SIZES];   // distinct DCI payload sizes, ascending
+  const uint16_t* rankmap;         // [LSN_MAX_SIZES][3*LSN_MAX_DCI_D]: output position -> rank in the circular buffer
+  // PDSCH
+  const uint16_t* validmask;       // [3][14][nof_prb]: 12-bit mask of PDSCH-capable REs (class 0: sf0, 1: sf5, 2: other)
+  const uint8_t* gold_x1;          // [LSN_GOLD_LEN] x1(n+1600)
+  const uint32_t* gold_x2mask;     // [LSN_GOLD_LEN] x2(n+1600) = parity(mask & cinit)
+  const uint32_t* crc_tab_a;       // [6144] x^j mod gCRC24A
+  const uint32_t* crc_tab_b;       // [6144] x^j mod gCRC24B
+};
+#define LSN_GOLD_LEN 115200
+
+// one PDSCH decode job = one (accepted DCI, MCS table) pair
+struct LsnGrantDev {
+  uint32_t sf;          // subframe index inside the batch
+  uint32_t sf_idx;      // 0..9
+  uint32_t l0;          // first PDSCH symbol
+  uint32_t prb_mask[2][4];
+  uint32_t nof_re;
+  uint32_t tx_scheme, pmi, nof_layers;
+  uint32_t qm[2];       // per codeword, 0 = unused
+  uint32_t cinit[2];
+  uint32_t llr_off[2];  // int16 element offsets into the LLR arena
+  uint32_t prefix_off;  // u16 element offset into the prefix arena: [14][nof_prb] then [16] symbol offsets
+  float inv_amp_a, inv_amp_b;
+};
+
+// one turbo code block
+struct LsnCbDev {
+  uint32_t e_off;     // int16 element offset of this code block's rate-matched LLRs
+  uint32_t E;
+  uint32_t K, F, rv;
+  uint32_t crc_b;     // 1: CRC24B (C>1), 0: CRC24A
+  uint32_t out_off;   // byte offset in the payload arena
+  uint32_t out_bytes; // (K - F - 24*crc_b)/8
+  uint32_t f1, f2;
+  uint32_t max_iter;
+  uint32_t pad;
+};
+struct LsnCbRes { uint32_t ok, iters, rem_a, pad; };
+
+// launchers (stage_a.hip / stage_c.hip)
+void lsn_launch_ofdm(const LsnCellDev& c, const cf32* iq, const uint32_t* dphi, cf32* grid, uint32_t nsf, hipStream_t s);
+void lsn_launch_chest(const LsnCellDev& c, const cf32* grid, const uint32_t* sf_idx, cf32* ce, float* raw, uint32_t nsf, hipStream_t s);
+void lsn_launch_chest_fin(const LsnCellDev& c, const float* raw, LsnChest* out, uint32_t nsf, hipStream_t s);
+void lsn_launch_pcfich(const LsnCellDev& c, const cf32* grid, const cf32* ce, const LsnChest* ch, const uint32_t* sf_idx, uint32_t* cfi, float* corr, uint32_t nsf, hipStream_t s);
+void lsn_launch_pdcch_llr(const LsnCellDev& c, const cf32* grid, const cf32* ce, const LsnChest* ch, const uint32_t* sf_idx, const uint32_t* cfi, float* llr, uint32_t nsf, hipStream_t s);
+void lsn_launch_cce_power(const LsnCellDev& c, const float* llr, const uint32_t* cfi, float* pw, uint32_t nsf, hipStream_t s);
+void lsn_launch_viterbi(const LsnCellDev& c, const float* llr, const float* pw, const uint32_t* cfi, LsnCand* cand, uint32_t nsf, hipStream_t s);
+void lsn_launch_rb_power(const LsnCellDev& c, const cf32* grid, float* rbp, uint32_t nsf, hipStream_t s);
+void lsn_launch_pdsch_prep(const LsnCellDev& c, const LsnGrantDev* g, uint16_t* prefix, uint32_t njobs, hipStream_t s);
+void lsn_launch_pdsch_demod(const LsnCellDev& c, const LsnGrantDev* g, const uint16_t* prefix, const cf32* grid, const cf32* ce, const LsnChest* ch, int16_t* llr, uint32_t njobs, hipStream_t s);
+void lsn_launch_turbo(const LsnCellDev& c, const LsnCbDev* cb, const int16_t* llr, uint8_t* payload, LsnCbRes* res, uint32_t ncb, hipStream_t s);

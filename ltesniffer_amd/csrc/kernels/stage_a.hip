@@ -1,0 +1,476 @@
+// stage_a.hip - gfx950 kernels for the control-plane half of the LTESniffer worker:
+//   OFDM demodulation, CRS channel estimation, PCFICH, PDCCH LLR extraction, CCE power, exhaustive PDCCH Viterbi.
+// These replace what DCISearch::search obtains from srsran_ue_dl_decode_fft_estimate
+// (/root/reference/src/src/DCISearch.cc:562) and every srsran_pdcch_decode_msg_limit_avg_llr_power call of the blind
+// search (/root/reference/src/src/DCISearch.cc:133 -> /root/reference/lib/src/phy/falcon_phch/falcon_pdcch.c:110-170).
+// Layout: one workgroup per (subframe, antenna, OFDM symbol) for the FFT (LDS-staged radix-2^3 passes, coalesced
+// float2 loads of the IQ); one workgroup per (subframe, antenna, port) for the estimator; one wavefront (64 lanes =
+// the 64 trellis states) per (subframe, location, DCI size) for the tail-biting Viterbi with __ballot decision words.
+// Float arithmetic is written one rounding per operation (compiled with -ffp-contract=off) so that results are
+// bit-identical to the CPU oracle used by the tests.
+#include "lsn_dev.h"
+
+#define SQRT2F 1.41421356237309504880f
+
+__device__ __forceinline__ cf32 cmul(cf32 a, cf32 b) { cf32 c; c.r = a.r * b.r - a.i * b.i; c.i = a.r * b.i + a.i * b.r; return c; }
+__device__ __forceinline__ cf32 cmulconj(cf32 a, cf32 b) { cf32 c; c.r = a.r * b.r + a.i * b.i; c.i = a.i * b.r - a.r * b.i; return c; }
+
+// ------------------------------------------------------------------------------------------------ OFDM
+template <int R>
+__device__ __forceinline__ void fft_pass(cf32* a, const cf32* w, int s, int N, int lgN, int tid)
+{
+  constexpr int G = 1 << R;
+  const int h = 1 << s;
+#pragma unroll
+  for (int u = 0; u < (8 >> R); u++) {
+    int g = tid * (8 >> R) + u;
+    if (g >= (N >> R)) break;
+    int low = g & (h - 1), high = g >> s, base = (high << (s + R)) | low;
+    cf32 e[G];
+#pragma unroll
+    for (int j = 0; j < G; j++) e[j] = a[base + j * h];
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+#pragma unroll
+      for (int j = 0; j < G; j++) {
+        if (j & (1 << q)) continue;
+        int pos = low + (j & ((1 << q) - 1)) * h;
+        cf32 v = cmul(e[j + (1 << q)], w[pos << (lgN - (s + q + 1))]);
+        cf32 uu = e[j];
+        e[j].r = uu.r + v.r; e[j].i = uu.i + v.i;
+        e[j + (1 << q)].r = uu.r - v.r; e[j + (1 << q)].i = uu.i - v.i;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < G; j++) a[base + j * h] = e[j];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_ofdm(LsnCellDev c, const cf32* __restrict__ iq, const uint32_t* __restrict__ dphi_sf,
+                                              cf32* __restrict__ grid)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int N = (int)c.N, lgN = (int)c.lgN, tid = threadIdx.x;
+  cf32* a = (cf32*)smem;
+  cf32* w = a + N;
+  const int blk = blockIdx.x, l = blk % 14, rx = (blk / 14) % (int)c.nof_rx, sf = blk / (14 * (int)c.nof_rx);
+  const int cp0 = 160 * N / 2048, cp1 = 144 * N / 2048;
+  const int slot = l / 7, ls = l % 7;
+  const int pos = slot * (cp0 + 6 * cp1 + 7 * N) + cp0 + ls * (N + cp1);
+  const cf32* in = iq + ((size_t)sf * c.nof_rx + rx) * c.sflen + pos;
+  const uint32_t dphi = dphi_sf ? dphi_sf[sf] : 0u;
+  for (int n = tid; n < N / 2; n += 256) w[n] = c.twiddle[n];
+  for (int n = tid; n < N; n += 256) {
+    cf32 x = in[n];
+    if (dphi != 0u) {
+      uint32_t ph = (uint32_t)(pos + n) * dphi;
+      cf32 rot = cmul(c.nco_coarse[ph >> 20], c.nco_fine[(ph >> 10) & 1023u]);
+      x = cmul(x, rot);
+    }
+    a[__brev((unsigned)n) >> (32 - lgN)] = x;
+  }
+  __syncthreads();
+  int s = 0;
+  while (s < lgN) {
+    int r = lgN - s;
+    if (r >= 3) { fft_pass<3>(a, w, s, N, lgN, tid); s += 3; }
+    else if (r == 2) { fft_pass<2>(a, w, s, N, lgN, tid); s += 2; }
+    else { fft_pass<1>(a, w, s, N, lgN, tid); s += 1; }
+    __syncthreads();
+  }
+  const int nre = (int)c.nre;
+  cf32* out = grid + (((size_t)sf * c.nof_rx + rx) * 14 + l) * nre;
+  for (int k = tid; k < nre; k += 256) {
+    int bin = (k < nre / 2) ? (N - nre / 2 + k) : (k - nre / 2 + 1);
+    out[k] = a[bin];
+  }
+}
+
+void lsn_launch_ofdm(const LsnCellDev& c, const cf32* iq, const uint32_t* dphi, cf32* grid, uint32_t nsf, hipStream_t s)
+{
+  size_t lds = sizeof(cf32) * (c.N + c.N / 2);
+  hipLaunchKernelGGL(k_ofdm, dim3(nsf * c.nof_rx * 14), dim3(256), lds, s, c, iq, dphi, grid);
+}
+
+// ------------------------------------------------------------------------------------------------ channel estimation
+__device__ __forceinline__ int crs_koff(const LsnCellDev& c, int port, int s)
+{
+  int v = (port == 0) ? ((s & 1) ? 3 : 0) : ((s & 1) ? 0 : 3);
+  return (v + (int)(c.id % 6)) % 6;
+}
+
+// raw[(sf*A+rx)*P+p][8] = {noise_sum, ls_r_sum, ls_i_sum, cepow_sum, cfo_r_sum, cfo_i_sum, -, -}
+__global__ __launch_bounds__(256) void k_chest(LsnCellDev c, const cf32* __restrict__ grid, const uint32_t* __restrict__ sf_idx_arr,
+                                               cf32* __restrict__ ce, float* __restrict__ raw)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int nre = (int)c.nre, nref = (int)c.nref, tid = threadIdx.x;
+  const int P = (int)c.nof_ports, A = (int)c.nof_rx;
+  const int blk = blockIdx.x, p = blk % P, rx = (blk / P) % A, sf = blk / (P * A);
+  cf32* ls = (cf32*)smem;           // [4*nref]
+  cf32* sm = ls + 4 * nref;         // [4*nref]
+  float* part = (float*)(sm + 4 * nref);  // [6][256]
+  const int sym[4] = {0, 4, 7, 11};
+  const cf32* g = grid + ((size_t)sf * A + rx) * 14 * nre;
+  const cf32* crs = c.crs + ((size_t)sf_idx_arr[sf] * P + p) * 4 * nref;
+  const int n4 = 4 * nref;
+  for (int i = tid; i < n4; i += 256) {
+    int s = i / nref, m = i - s * nref;
+    ls[i] = cmulconj(g[sym[s] * nre + 6 * m + crs_koff(c, p, s)], crs[i]);
+  }
+  __syncthreads();
+  for (int i = tid; i < n4; i += 256) {
+    int s = i / nref, m = i - s * nref;
+    float ar = 0.0f, ai = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      int q = m + j - 2;
+      if (q < 0 || q >= nref) continue;
+      ar = ar + c.taps[j] * ls[s * nref + q].r;
+      ai = ai + c.taps[j] * ls[s * nref + q].i;
+    }
+    sm[i].r = ar; sm[i].i = ai;
+  }
+  __syncthreads();
+  // six strided partial sums per thread, then one shared tree (o_reduce256 order)
+  float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f, p4 = 0.0f, p5 = 0.0f;
+  for (int i = tid; i < n4; i += 256) {
+    float dr = sm[i].r - ls[i].r, di = sm[i].i - ls[i].i;
+    p0 = p0 + (dr * dr + di * di);
+    p1 = p1 + ls[i].r;
+    p2 = p2 + ls[i].i;
+    p3 = p3 + (sm[i].r * sm[i].r + sm[i].i * sm[i].i);
+  }
+  for (int i = tid; i < 2 * nref; i += 256) {
+    cf32 t = (i < nref) ? cmulconj(ls[2 * nref + i], ls[i]) : cmulconj(ls[3 * nref + (i - nref)], ls[nref + (i - nref)]);
+    p4 = p4 + t.r;
+    p5 = p5 + t.i;
+  }
+  part[0 * 256 + tid] = p0; part[1 * 256 + tid] = p1; part[2 * 256 + tid] = p2;
+  part[3 * 256 + tid] = p3; part[4 * 256 + tid] = p4; part[5 * 256 + tid] = p5;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) {
+#pragma unroll
+      for (int q = 0; q < 6; q++) part[q * 256 + tid] = part[q * 256 + tid] + part[q * 256 + tid + s];
+    }
+    __syncthreads();
+  }
+  if (tid < 6) raw[(((size_t)sf * A + rx) * P + p) * 8 + tid] = part[tid * 256];
+  // interpolation: frequency (linear, pilot spacing 6, edges extrapolated) then time (0,4,7,11; 12,13 extrapolated)
+  cf32* co = ce + (((size_t)sf * P + p) * A + rx) * 14 * nre;
+  for (int k = tid; k < nre; k += 256) {
+    cf32 row[4];
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+      int koff = crs_koff(c, p, s);
+      const cf32* pl = sm + s * nref;
+      int m = (k - koff) >= 0 ? (k - koff) / 6 : 0;
+      if (m > nref - 2) m = nref - 2;
+      float dr = (pl[m + 1].r - pl[m].r) / 6.0f, di = (pl[m + 1].i - pl[m].i) / 6.0f;
+      float f = (float)(k - (6 * m + koff));
+      row[s].r = pl[m].r + dr * f;
+      row[s].i = pl[m].i + di * f;
+    }
+    cf32 c0 = row[0], c4 = row[1], c7 = row[2], c11 = row[3];
+    float d01r = (c4.r - c0.r) / 4.0f, d01i = (c4.i - c0.i) / 4.0f;
+    float d12r = (c7.r - c4.r) / 3.0f, d12i = (c7.i - c4.i) / 3.0f;
+    float d23r = (c11.r - c7.r) / 4.0f, d23i = (c11.i - c7.i) / 4.0f;
+    co[0 * nre + k] = c0; co[4 * nre + k] = c4; co[7 * nre + k] = c7; co[11 * nre + k] = c11;
+#pragma unroll
+    for (int l = 1; l <= 3; l++) { cf32 v; v.r = c0.r + d01r * (float)l; v.i = c0.i + d01i * (float)l; co[l * nre + k] = v; }
+#pragma unroll
+    for (int l = 5; l <= 6; l++) { cf32 v; v.r = c4.r + d12r * (float)(l - 4); v.i = c4.i + d12i * (float)(l - 4); co[l * nre + k] = v; }
+#pragma unroll
+    for (int l = 8; l <= 10; l++) { cf32 v; v.r = c7.r + d23r * (float)(l - 7); v.i = c7.i + d23i * (float)(l - 7); co[l * nre + k] = v; }
+#pragma unroll
+    for (int l = 12; l <= 13; l++) { cf32 v; v.r = c11.r + d23r * (float)(l - 11); v.i = c11.i + d23i * (float)(l - 11); co[l * nre + k] = v; }
+  }
+}
+
+void lsn_launch_chest(const LsnCellDev& c, const cf32* grid, const uint32_t* sf_idx, cf32* ce, float* raw, uint32_t nsf, hipStream_t s)
+{
+  size_t lds = sizeof(cf32) * 8 * c.nref + sizeof(float) * 6 * 256;
+  hipLaunchKernelGGL(k_chest, dim3(nsf * c.nof_rx * c.nof_ports), dim3(256), lds, s, c, grid, sf_idx, ce, raw);
+}
+
+__global__ void k_chest_fin(LsnCellDev c, const float* __restrict__ raw, LsnChest* __restrict__ out, uint32_t nsf)
+{
+  uint32_t sf = blockIdx.x * blockDim.x + threadIdx.x;
+  if (sf >= nsf) return;
+  const int A = (int)c.nof_rx, P = (int)c.nof_ports;
+  const float n = (float)(4 * c.nref);
+  LsnChest o;
+  float ns = 0.0f, rs = 0.0f, cp = 0.0f, cr = 0.0f, ci = 0.0f;
+  for (int q = 0; q < 4; q++) { o.noise[q] = 0.0f; o.rsrp[q] = 0.0f; o.cepow[q] = 0.0f; }
+  for (int rx = 0; rx < A; rx++)
+    for (int p = 0; p < P; p++) {
+      const float* r = raw + (((size_t)sf * A + rx) * P + p) * 8;
+      float noise = r[0] / n, mr = r[1] / n, mi = r[2] / n, cepow = r[3] / n;
+      float rsrp = mr * mr + mi * mi;
+      o.noise[rx * P + p] = noise; o.rsrp[rx * P + p] = rsrp; o.cepow[rx * P + p] = cepow;
+      ns = ns + noise; rs = rs + rsrp; cp = cp + cepow;
+      cr = cr + r[4]; ci = ci + r[5];
+    }
+  float cnt = (float)(A * P);
+  o.noise_avg = ns / cnt; o.rsrp_avg = rs / cnt; o.chan_ref = cp; o.corr_r = cr; o.corr_i = ci;
+  o.pad[0] = o.pad[1] = o.pad[2] = 0.0f;
+  out[sf] = o;
+}
+void lsn_launch_chest_fin(const LsnCellDev& c, const float* raw, LsnChest* out, uint32_t nsf, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_chest_fin, dim3((nsf + 63) / 64), dim3(64), 0, s, c, raw, out, nsf);
+}
+
+// ------------------------------------------------------------------------------------------------ control region
+// equalise the 4 data REs of one REG (36.211 6.2.4) -> 4 QPSK symbols; single port: MRC/(|h|^2+noise), two ports: SFBC
+__device__ __forceinline__ void reg_equalise(const LsnCellDev& c, const cf32* __restrict__ g, const cf32* __restrict__ ce, float noise,
+                                             int l, int k0, cf32* x)
+{
+  const int nre = (int)c.nre, A = (int)c.nof_rx;
+  int kk[4], n = 0;
+  if (l == 0) {
+    for (int k = k0; k < k0 + 6; k++)
+      if ((k % 3) != (int)(c.id % 3)) { if (n < 4) kk[n] = k; n++; }
+  } else {
+    for (int k = 0; k < 4; k++) kk[k] = k0 + k;
+  }
+  if (c.nof_ports == 1) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      float nr = 0.0f, ni = 0.0f, den = 0.0f;
+      for (int rx = 0; rx < A; rx++) {
+        cf32 y = g[((size_t)rx * 14 + l) * nre + kk[i]];
+        cf32 h = ce[((size_t)rx * 14 + l) * nre + kk[i]];
+        cf32 t = cmulconj(y, h);
+        float hp = h.r * h.r + h.i * h.i;
+        if (rx == 0) { nr = t.r; ni = t.i; den = hp; } else { nr = nr + t.r; ni = ni + t.i; den = den + hp; }
+      }
+      den = den + noise;
+      x[i].r = nr / den; x[i].i = ni / den;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; i += 2) {
+      float x0r = 0, x0i = 0, x1r = 0, x1i = 0, hh = 0;
+      for (int rx = 0; rx < A; rx++) {
+        size_t b0 = ((size_t)rx * 14 + l) * nre, b1 = (((size_t)A + rx) * 14 + l) * nre;
+        cf32 r0 = g[b0 + kk[i]], r1 = g[b0 + kk[i + 1]];
+        cf32 h00 = ce[b0 + kk[i]], h01 = ce[b0 + kk[i + 1]], h10 = ce[b1 + kk[i]], h11 = ce[b1 + kk[i + 1]];
+        float hp = (h00.r * h00.r + h00.i * h00.i) + (h11.r * h11.r + h11.i * h11.i);
+        cf32 a = cmulconj(r0, h00), b = cmulconj(h11, r1), cc = cmulconj(h10, r0), d = cmulconj(r1, h01);
+        float t0r = a.r + b.r, t0i = a.i + b.i, t1r = d.r - cc.r, t1i = d.i - cc.i;
+        if (rx == 0) { x0r = t0r; x0i = t0i; x1r = t1r; x1i = t1i; hh = hp; }
+        else { x0r = x0r + t0r; x0i = x0i + t0i; x1r = x1r + t1r; x1i = x1i + t1i; hh = hh + hp; }
+      }
+      x[i].r = x0r / hh * SQRT2F; x[i].i = x0i / hh * SQRT2F;
+      x[i + 1].r = x1r / hh * SQRT2F; x[i + 1].i = x1i / hh * SQRT2F;
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void k_pcfich(LsnCellDev c, const cf32* __restrict__ grid, const cf32* __restrict__ ce,
+                                               const LsnChest* __restrict__ ch, const uint32_t* __restrict__ sf_idx_arr,
+                                               uint32_t* __restrict__ cfi_out, float* __restrict__ corr_out)
+{
+  __shared__ float llr[32];
+  const int sf = blockIdx.x, lane = threadIdx.x;
+  const cf32* g = grid + (size_t)sf * c.nof_rx * 14 * c.nre;
+  const cf32* e = ce + (size_t)sf * c.nof_ports * c.nof_rx * 14 * c.nre;
+  const uint8_t* scr = c.pcfich_scr + sf_idx_arr[sf] * 32;
+  if (lane < 4) {
+    cf32 x[4];
+    reg_equalise(c, g, e, ch[sf].noise_avg, 0, (int)c.pcfich_k0[lane], x);
+    for (int j = 0; j < 4; j++) {
+      float a = -(x[j].r * SQRT2F), b = -(x[j].i * SQRT2F);
+      llr[8 * lane + 2 * j] = scr[8 * lane + 2 * j] ? -a : a;
+      llr[8 * lane + 2 * j + 1] = scr[8 * lane + 2 * j + 1] ? -b : b;
+    }
+  }
+  __syncthreads();
+  if (lane == 0) {
+    // CFI codewords <0,1,1>, <1,0,1>, <1,1,0> repeated (36.212 5.3.4): bit i of codeword w is (i % 3 != w)
+    uint32_t best = 0; float bestc = 0.0f;
+    for (int w = 0; w < 3; w++) {
+      float acc = 0.0f;
+      for (int i = 0; i < 32; i++) acc = acc + (((i % 3) != w) ? llr[i] : -llr[i]);
+      corr_out[sf * 3 + w] = acc;
+      if (w == 0 || acc > bestc) { bestc = acc; best = (uint32_t)w; }
+    }
+    cfi_out[sf] = best + 1;
+  }
+}
+void lsn_launch_pcfich(const LsnCellDev& c, const cf32* grid, const cf32* ce, const LsnChest* ch, const uint32_t* sf_idx, uint32_t* cfi, float* corr, uint32_t nsf, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_pcfich, dim3(nsf), dim3(64), 0, s, c, grid, ce, ch, sf_idx, cfi, corr);
+}
+
+__global__ __launch_bounds__(64) void k_pdcch_llr(LsnCellDev c, const cf32* __restrict__ grid, const cf32* __restrict__ ce,
+                                                  const LsnChest* __restrict__ ch, const uint32_t* __restrict__ sf_idx_arr,
+                                                  const uint32_t* __restrict__ cfi_arr, float* __restrict__ llr)
+{
+  const int sf = blockIdx.y;
+  const uint32_t cfi = cfi_arr[sf];
+  const uint32_t q = blockIdx.x * 64 + threadIdx.x;
+  if (q >= c.nof_cce[cfi - 1] * 9) return;
+  const cf32* g = grid + (size_t)sf * c.nof_rx * 14 * c.nre;
+  const cf32* e = ce + (size_t)sf * c.nof_ports * c.nof_rx * 14 * c.nre;
+  const uint8_t* scr = c.pdcch_scr + (size_t)sf_idx_arr[sf] * LSN_LLR_STRIDE;
+  cf32 x[4];
+  reg_equalise(c, g, e, ch[sf].noise_avg, (int)c.reg_l[(cfi - 1) * 800 + q], (int)c.reg_k0[(cfi - 1) * 800 + q], x);
+  float* o = llr + (size_t)sf * LSN_LLR_STRIDE + 8 * q;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    float a = -(x[j].r * SQRT2F), b = -(x[j].i * SQRT2F);
+    o[2 * j] = scr[8 * q + 2 * j] ? -a : a;
+    o[2 * j + 1] = scr[8 * q + 2 * j + 1] ? -b : b;
+  }
+}
+void lsn_launch_pdcch_llr(const LsnCellDev& c, const cf32* grid, const cf32* ce, const LsnChest* ch, const uint32_t* sf_idx, const uint32_t* cfi, float* llr, uint32_t nsf, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_pdcch_llr, dim3((87 * 9 + 63) / 64, nsf), dim3(64), 0, s, c, grid, ce, ch, sf_idx, cfi, llr);
+}
+
+// falcon_pdcch.c:595-620: mean |llr| over the 72 LLRs of each CCE, accumulated in double in index order
+__global__ __launch_bounds__(128) void k_cce_power(LsnCellDev c, const float* __restrict__ llr, const uint32_t* __restrict__ cfi_arr,
+                                                   float* __restrict__ pw)
+{
+  const int sf = blockIdx.x, cce = threadIdx.x;
+  if (cce >= LSN_CCE_STRIDE) return;
+  float out = 0.0f;
+  if ((uint32_t)cce < c.nof_cce[cfi_arr[sf] - 1]) {
+    const float* l = llr + (size_t)sf * LSN_LLR_STRIDE + 72 * cce;
+    double mean = 0.0;
+    for (int i = 0; i < 72; i++) mean += (double)fabsf(l[i]);
+    out = (float)(mean / 72.0);
+  }
+  pw[sf * LSN_CCE_STRIDE + cce] = out;
+}
+void lsn_launch_cce_power(const LsnCellDev& c, const float* llr, const uint32_t* cfi, float* pw, uint32_t nsf, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_cce_power, dim3(nsf), dim3(128), 0, s, c, llr, cfi, pw);
+}
+
+// ------------------------------------------------------------------------------------------------ PDCCH Viterbi
+// One wavefront per (location, size, subframe).  Rate de-matching is a gather through a host-built rank table;
+// u8 quantisation 127.5 + 32*llr (truncated); 32-bit path metrics; 3 passes over the tail-biting block, middle pass kept.
+__global__ __launch_bounds__(64) void k_viterbi(LsnCellDev c, const float* __restrict__ llr, const float* __restrict__ pw,
+                                                const uint32_t* __restrict__ cfi_arr, LsnCand* __restrict__ cand)
+{
+  __shared__ unsigned char sym[3 * LSN_MAX_DCI_D];
+  __shared__ unsigned long long dec[3 * LSN_MAX_DCI_D];
+  const int lane = threadIdx.x, sf = blockIdx.z, sz = blockIdx.y;
+  int li = blockIdx.x;
+  LsnCand* out = cand + ((size_t)sf * LSN_MAX_LOC + blockIdx.x) * LSN_MAX_SIZES + sz;
+  const uint32_t ncce_tot = c.nof_cce[cfi_arr[sf] - 1];
+  const uint32_t lim = ncce_tot < LSN_MAX_NUM_OF_CCE ? ncce_tot : LSN_MAX_NUM_OF_CCE;
+  // location enumeration of srsran_pdcch_ue_locations_all_map (falcon_pdcch.c:321-356)
+  int L = -1; uint32_t ncce = 0;
+  for (int l = 3; l >= 0; l--) {
+    int cnt = (int)(lim >> l);
+    if (li < cnt) { L = l; ncce = ((uint32_t)li % (ncce_tot >> l)) << l; break; }
+    li -= cnt;
+  }
+  bool ok = L >= 0;
+  const uint32_t E = ok ? (72u << L) : 0u;
+  if (ok && ncce * 72 + E > ncce_tot * 72) ok = false;
+  if (ok) {
+    for (uint32_t i = 0; i < (1u << L); i++)
+      if (pw[sf * LSN_CCE_STRIDE + ncce + i] < 0.7f) ok = false;  // location->sufficient_power (falcon_pdcch.c:610-614)
+  }
+  if (!ok) {
+    if (lane == 0) { out->bits = 0; out->rnti = 0; out->flags = 0; }
+    return;
+  }
+  const float* e = llr + (size_t)sf * LSN_LLR_STRIDE + ncce * 72;
+  const uint32_t nbits = c.sizes[sz], D = nbits + 16, D3 = 3 * D;
+  const uint16_t* rank = c.rankmap + sz * 3 * LSN_MAX_DCI_D;
+  bool nz = false;
+  for (uint32_t o = lane; o < D3; o += 64) {
+    float acc = 0.0f;
+    bool first = true;
+    for (uint32_t k = rank[o]; k < E; k += D3) {
+      float v = e[k];
+      if (v != 0.0f) nz = true;
+      if (first) { acc = v; first = false; } else acc = acc + v;
+    }
+    float q = 127.5f + 32.0f * acc;
+    q = q < 0.0f ? 0.0f : q;
+    q = q > 255.0f ? 255.0f : q;
+    sym[o] = (unsigned char)q;
+  }
+  if (__ballot(nz) == 0ull) {  // mean |llr| == 0: the reference skips the decode (falcon_pdcch.c:141)
+    if (lane == 0) { out->bits = 0; out->rnti = 0; out->flags = 0; }
+    return;
+  }
+  __syncthreads();
+  // lane = new state j: input bit b = j&1, predecessors j>>1 and (j>>1)|32; generator masks on the old state
+  const int b = lane & 1, s0 = lane >> 1;
+  const int c0 = b ^ (__popc(s0 & 0x36) & 1), c1 = b ^ (__popc(s0 & 0x27) & 1), c2 = b ^ (__popc(s0 & 0x2B) & 1);
+  int m = 0;
+  const int T = (int)D3;  // 3 passes of D steps
+  for (int t = 0; t < T; t++) {
+    int tt = t % (int)D;
+    int q0 = sym[3 * tt], q1 = sym[3 * tt + 1], q2 = sym[3 * tt + 2];
+    int bm0 = (c0 ? 255 - q0 : q0) + (c1 ? 255 - q1 : q1) + (c2 ? 255 - q2 : q2);
+    int a0 = __shfl(m, s0) + bm0, a1 = __shfl(m, s0 | 32) + (765 - bm0);
+    bool d = a1 < a0;
+    m = d ? a1 : a0;
+    unsigned long long dw = __ballot(d);
+    if (lane == 0) dec[t] = dw;
+  }
+  // best end state: minimum metric, lowest index on ties
+  unsigned long long key = ((unsigned long long)(unsigned)m << 6) | (unsigned)lane;
+  for (int off = 32; off > 0; off >>= 1) {
+    unsigned long long o2 = __shfl_xor(key, off);
+    key = o2 < key ? o2 : key;
+  }
+  __syncthreads();
+  if (lane == 0) {
+    int st = (int)(key & 63ull);
+    unsigned long long bits = 0;  // decoded bit i of the middle pass at position 63-i (payload then 16 CRC bits handled below)
+    unsigned int tailcrc = 0;
+    for (int t = T - 1; t >= 0; t--) {
+      if (t >= (int)D && t < 2 * (int)D) {
+        int i = t - (int)D;
+        if (i < (int)nbits) bits |= (unsigned long long)(st & 1) << (63 - i);
+        else tailcrc |= (unsigned)(st & 1) << (15 - (i - (int)nbits));
+      }
+      int dd = (int)((dec[t] >> st) & 1ull);
+      st = (st >> 1) | (dd << 5);
+    }
+    // CRC16 (x^16+x^12+x^5+1) over the payload, zero-augmented long division
+    unsigned int reg = 0;
+    for (int i = 0; i < (int)nbits + 16; i++) {
+      unsigned int bit = i < (int)nbits ? (unsigned)((bits >> (63 - i)) & 1ull) : 0u;
+      reg = (reg << 1) | bit;
+      if (reg & 0x10000u) reg ^= 0x11021u;
+    }
+    out->bits = bits;
+    out->rnti = (tailcrc ^ reg) & 0xFFFFu;
+    out->flags = 1;
+  }
+}
+void lsn_launch_viterbi(const LsnCellDev& c, const float* llr, const float* pw, const uint32_t* cfi, LsnCand* cand, uint32_t nsf, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_viterbi, dim3(LSN_MAX_LOC, c.nsizes, nsf), dim3(64), 0, s, c, llr, pw, cfi, cand);
+}
+
+// SubframePower::computePower (SubframePower.cc:18-42) linear part: sum over 14 symbols of mean |x|^2 per PRB (antenna 0)
+__global__ void k_rb_power(LsnCellDev c, const cf32* __restrict__ grid, float* __restrict__ rbp)
+{
+  const int sf = blockIdx.x, prb = threadIdx.x;
+  if (prb >= (int)c.nof_prb) return;
+  const cf32* g = grid + (size_t)sf * c.nof_rx * 14 * c.nre;
+  float acc = 0.0f;
+  for (int j = 0; j < 14; j++) {
+    float s = 0.0f;
+    for (int k = 0; k < 12; k++) { cf32 x = g[j * c.nre + prb * 12 + k]; s = s + (x.r * x.r + x.i * x.i); }
+    acc = acc + s / 12.0f;
+  }
+  rbp[sf * 128 + prb] = acc;
+}
+void lsn_launch_rb_power(const LsnCellDev& c, const cf32* grid, float* rbp, uint32_t nsf, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_rb_power, dim3(nsf), dim3(128), 0, s, c, grid, rbp);
+}

@@ -1,0 +1,440 @@
+// stage_c.hip - gfx950 kernels for the data-plane half of the LTESniffer worker: PDSCH RE gather + equalisation
+// (single port MRC, SFBC, large-delay CDD / closed-loop spatial multiplexing with 2x2 MMSE) + soft demodulation +
+// descrambling, and the per-code-block turbo decoder (gather rate de-matching, windowed max-log-MAP with
+// next-iteration boundary init, early stop on the code-block CRC).  They replace srsran_ue_dl_decode_pdsch as called
+// from /root/reference/src/src/DL_Sniffer_PDSCH.cc:997,1110,1207 (config /root/reference/src/src/SubframeWorker.cc:362-371).
+// Mapping: demod = one thread per resource element (coalesced float2 loads of grid / channel estimates, int16 LLR
+// stores); turbo = one wavefront per code block, lane = trellis window, all soft data of the block staged in LDS,
+// forward metrics check-pointed every 16 steps and recomputed so that the block fits 2 workgroups per CU.
+#include "lsn_dev.h"
+#include "lsn_rm.h"
+
+#define SQRT1_2F 0.70710678118654752440f
+#define SQRT2F 1.41421356237309504880f
+#define LLR_Q 180.0f
+
+__device__ __forceinline__ cf32 cmulconj(cf32 a, cf32 b) { cf32 c; c.r = a.r * b.r + a.i * b.i; c.i = a.i * b.r - a.r * b.i; return c; }
+__device__ __forceinline__ float cabs2(cf32 a) { return a.r * a.r + a.i * a.i; }
+
+// ------------------------------------------------------------------------------------------------ RE bookkeeping
+// prefix[l][prb] = number of PDSCH REs of this grant in symbol l before PRB prb; prefix[14*nprb + l] = REs before symbol l
+__global__ __launch_bounds__(64) void k_pdsch_prep(LsnCellDev c, const LsnGrantDev* __restrict__ jobs, uint16_t* __restrict__ prefix)
+{
+  __shared__ uint32_t tot[16];
+  const LsnGrantDev& g = jobs[blockIdx.x];
+  const int l = threadIdx.x, nprb = (int)c.nof_prb;
+  uint16_t* pf = prefix + g.prefix_off;
+  const int cls = g.sf_idx == 0 ? 0 : (g.sf_idx == 5 ? 1 : 2);
+  if (l < 14) {
+    uint32_t run = 0;
+    for (int prb = 0; prb < nprb; prb++) {
+      pf[l * nprb + prb] = (uint16_t)run;
+      if (l >= (int)g.l0 && ((g.prb_mask[l / 7][prb >> 5] >> (prb & 31)) & 1u))
+        run += __popc((unsigned)c.validmask[(cls * 14 + l) * nprb + prb]);
+    }
+    tot[l] = run;
+  }
+  __syncthreads();
+  if (l == 0) {
+    uint32_t run = 0;
+    for (int i = 0; i < 14; i++) { pf[14 * nprb + i] = (uint16_t)run; run += tot[i]; }
+    pf[14 * nprb + 14] = (uint16_t)run;
+  }
+}
+void lsn_launch_pdsch_prep(const LsnCellDev& c, const LsnGrantDev* g, uint16_t* prefix, uint32_t njobs, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_pdsch_prep, dim3(njobs), dim3(64), 0, s, c, g, prefix);
+}
+
+// ------------------------------------------------------------------------------------------------ soft demodulation
+__device__ __forceinline__ void demod_llr(int Qm, float I, float Q, float* L)
+{
+  float aI = fabsf(I), aQ = fabsf(Q);
+  L[0] = -I; L[1] = -Q;
+  if (Qm == 4) {
+    const float a = 0.31622776601683794f;
+    L[2] = aI - 2.0f * a; L[3] = aQ - 2.0f * a;
+  } else if (Qm == 6) {
+    const float a = 0.15430334996209191f;
+    float tI = aI - 4.0f * a, tQ = aQ - 4.0f * a;
+    L[2] = tI; L[3] = tQ; L[4] = fabsf(tI) - 2.0f * a; L[5] = fabsf(tQ) - 2.0f * a;
+  } else if (Qm == 8) {
+    const float a = 0.07669649888473704f;
+    float tI = aI - 8.0f * a, tQ = aQ - 8.0f * a;
+    float uI = fabsf(tI) - 4.0f * a, uQ = fabsf(tQ) - 4.0f * a;
+    L[2] = tI; L[3] = tQ; L[4] = uI; L[5] = uQ; L[6] = fabsf(uI) - 2.0f * a; L[7] = fabsf(uQ) - 2.0f * a;
+  }
+}
+
+__device__ __forceinline__ void emit(const LsnCellDev& c, int Qm, cf32 x, float w, float inv_amp, uint32_t cinit, uint32_t idx,
+                                     int16_t* __restrict__ out)
+{
+  float L[8];
+  float wq = w * LLR_Q;
+  demod_llr(Qm, x.r * inv_amp, x.i * inv_amp, L);
+  const uint32_t n0 = idx * (uint32_t)Qm;
+  for (int b = 0; b < Qm; b++) {
+    float r = rintf(L[b] * wq);
+    r = r > (float)LSN_LLR_CLIP ? (float)LSN_LLR_CLIP : r;
+    r = r < (float)-LSN_LLR_CLIP ? (float)-LSN_LLR_CLIP : r;
+    int q = (int)r;
+    uint32_t n = n0 + (uint32_t)b;
+    uint32_t cbit = (uint32_t)c.gold_x1[n] ^ (uint32_t)(__popc(c.gold_x2mask[n] & cinit) & 1);
+    out[n] = (int16_t)(cbit ? -q : q);
+  }
+}
+
+__global__ __launch_bounds__(192) void k_pdsch_demod(LsnCellDev c, const LsnGrantDev* __restrict__ jobs, const uint16_t* __restrict__ prefix,
+                                                     const cf32* __restrict__ grid, const cf32* __restrict__ ce,
+                                                     const LsnChest* __restrict__ chest, int16_t* __restrict__ llr)
+{
+  const LsnGrantDev& g = jobs[blockIdx.z];
+  const int nprb = (int)c.nof_prb, nre = (int)c.nre, A = (int)c.nof_rx;
+  const int l = blockIdx.y, prb = blockIdx.x * 16 + (int)threadIdx.x / 12, kk = (int)threadIdx.x % 12;
+  if (l < (int)g.l0 || prb >= nprb) return;
+  if (!((g.prb_mask[l / 7][prb >> 5] >> (prb & 31)) & 1u)) return;
+  const int cls = g.sf_idx == 0 ? 0 : (g.sf_idx == 5 ? 1 : 2);
+  const unsigned mask = c.validmask[(cls * 14 + l) * nprb + prb];
+  if (!((mask >> kk) & 1u)) return;
+  const uint16_t* pf = prefix + g.prefix_off;
+  const uint32_t idx = (uint32_t)pf[14 * nprb + l] + (uint32_t)pf[l * nprb + prb] + (uint32_t)__popc(mask & ((1u << kk) - 1u));
+  const int k = 12 * prb + kk;
+  const LsnChest ch = chest[g.sf];
+  const float noise = ch.noise_avg, chan_ref = ch.chan_ref;
+  const float inv_amp = (l == 0 || l == 4 || l == 7 || l == 11) ? g.inv_amp_b : g.inv_amp_a;
+  const cf32* gr = grid + (size_t)g.sf * A * 14 * nre;
+  const cf32* ch0 = ce + (size_t)g.sf * c.nof_ports * A * 14 * nre;
+#define GRID(rx, kq) gr[((size_t)(rx) * 14 + l) * nre + (kq)]
+#define CE(p, rx, kq) ch0[(((size_t)(p) * A + (rx)) * 14 + l) * nre + (kq)]
+  int16_t* out0 = llr + g.llr_off[0];
+  int16_t* out1 = llr + g.llr_off[1];
+  switch (g.tx_scheme) {
+    case 0: {  // single antenna port
+      float nr = 0, ni = 0, den = 0;
+      for (int rx = 0; rx < A; rx++) {
+        cf32 h = CE(0, rx, k);
+        cf32 t = cmulconj(GRID(rx, k), h);
+        float hp = cabs2(h);
+        if (rx == 0) { nr = t.r; ni = t.i; den = hp; } else { nr = nr + t.r; ni = ni + t.i; den = den + hp; }
+      }
+      float dn = den + noise;
+      cf32 x; x.r = nr / dn; x.i = ni / dn;
+      emit(c, (int)g.qm[0], x, den / chan_ref, inv_amp, g.cinit[0], idx, out0);
+      break;
+    }
+    case 1: {  // transmit diversity (SFBC), pairs of consecutive REs of the mapping order
+      if (idx & 1u) return;
+      unsigned hi = mask >> (kk + 1);
+      if (!hi) return;
+      const int k2 = k + 1 + (__ffs(hi) - 1);
+      float x0r = 0, x0i = 0, x1r = 0, x1i = 0, hh = 0;
+      for (int rx = 0; rx < A; rx++) {
+        cf32 r0 = GRID(rx, k), r1 = GRID(rx, k2);
+        cf32 h00 = CE(0, rx, k), h01 = CE(0, rx, k2), h10 = CE(1, rx, k), h11 = CE(1, rx, k2);
+        float hp = cabs2(h00) + cabs2(h11);
+        cf32 a = cmulconj(r0, h00), b = cmulconj(h11, r1), cc = cmulconj(h10, r0), d = cmulconj(r1, h01);
+        float t0r = a.r + b.r, t0i = a.i + b.i, t1r = d.r - cc.r, t1i = d.i - cc.i;
+        if (rx == 0) { x0r = t0r; x0i = t0i; x1r = t1r; x1i = t1i; hh = hp; }
+        else { x0r = x0r + t0r; x0i = x0i + t0i; x1r = x1r + t1r; x1i = x1i + t1i; hh = hh + hp; }
+      }
+      cf32 x0, x1;
+      x0.r = x0r / hh * SQRT2F; x0.i = x0i / hh * SQRT2F; x1.r = x1r / hh * SQRT2F; x1.i = x1i / hh * SQRT2F;
+      float w = hh / chan_ref;
+      emit(c, (int)g.qm[0], x0, w, inv_amp, g.cinit[0], idx, out0);
+      emit(c, (int)g.qm[0], x1, w, inv_amp, g.cinit[0], idx + 1, out0);
+      break;
+    }
+    default: {  // 2: closed-loop spatial multiplexing, 3: large-delay CDD
+      if (g.nof_layers == 1) {
+        float nr = 0, ni = 0, den = 0;
+        for (int rx = 0; rx < A; rx++) {
+          cf32 h0 = CE(0, rx, k), h1 = CE(1, rx, k), qh;
+          switch (g.pmi) {
+            case 0: qh = h1; break;
+            case 1: qh.r = -h1.r; qh.i = -h1.i; break;
+            case 2: qh.r = -h1.i; qh.i = h1.r; break;
+            default: qh.r = h1.i; qh.i = -h1.r; break;
+          }
+          cf32 he; he.r = (h0.r + qh.r) * SQRT1_2F; he.i = (h0.i + qh.i) * SQRT1_2F;
+          cf32 t = cmulconj(GRID(rx, k), he);
+          float hp = cabs2(he);
+          if (rx == 0) { nr = t.r; ni = t.i; den = hp; } else { nr = nr + t.r; ni = ni + t.i; den = den + hp; }
+        }
+        float dn = den + noise;
+        cf32 x; x.r = nr / dn; x.i = ni / dn;
+        emit(c, (int)g.qm[0], x, den * 2.0f / chan_ref, inv_amp, g.cinit[0], idx, out0);
+      } else {
+        float a = 0, d = 0, br = 0, bi = 0, z0r = 0, z0i = 0, z1r = 0, z1i = 0;
+        for (int rx = 0; rx < A; rx++) {
+          cf32 h0 = CE(0, rx, k), h1 = CE(1, rx, k), qh, y = GRID(rx, k);
+          if (g.tx_scheme == 3) {
+            if (idx & 1u) { qh.r = -h1.r; qh.i = -h1.i; } else qh = h1;
+          } else if (g.pmi == 0) {
+            qh = h1;
+          } else {
+            qh.r = -h1.i; qh.i = h1.r;
+          }
+          cf32 e0, e1;
+          e0.r = (h0.r + qh.r) * 0.5f; e0.i = (h0.i + qh.i) * 0.5f;
+          e1.r = (h0.r - qh.r) * 0.5f; e1.i = (h0.i - qh.i) * 0.5f;
+          cf32 b = cmulconj(e1, e0);
+          cf32 t0 = cmulconj(y, e0), t1 = cmulconj(y, e1);
+          float p0 = cabs2(e0), p1 = cabs2(e1);
+          if (rx == 0) { a = p0; d = p1; br = b.r; bi = b.i; z0r = t0.r; z0i = t0.i; z1r = t1.r; z1i = t1.i; }
+          else { a = a + p0; d = d + p1; br = br + b.r; bi = bi + b.i; z0r = z0r + t0.r; z0i = z0i + t0.i; z1r = z1r + t1.r; z1i = z1i + t1.i; }
+        }
+        a = a + noise; d = d + noise;
+        float det = a * d - (br * br + bi * bi);
+        cf32 x0, x1;
+        x0.r = (d * z0r - (br * z1r - bi * z1i)) / det;
+        x0.i = (d * z0i - (br * z1i + bi * z1r)) / det;
+        x1.r = (a * z1r - (br * z0r + bi * z0i)) / det;
+        x1.i = (a * z1i - (br * z0i - bi * z0r)) / det;
+        float w0 = det / d * 4.0f / chan_ref, w1 = det / a * 4.0f / chan_ref;
+        if (g.qm[0]) emit(c, (int)g.qm[0], x0, w0, inv_amp, g.cinit[0], idx, out0);
+        if (g.qm[1]) emit(c, (int)g.qm[1], x1, w1, inv_amp, g.cinit[1], idx, out1);
+      }
+      break;
+    }
+  }
+#undef GRID
+#undef CE
+}
+void lsn_launch_pdsch_demod(const LsnCellDev& c, const LsnGrantDev* g, const uint16_t* prefix, const cf32* grid, const cf32* ce,
+                            const LsnChest* ch, int16_t* llr, uint32_t njobs, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_pdsch_demod, dim3((c.nof_prb + 15) / 16, 14, njobs), dim3(192), 0, s, c, g, prefix, grid, ce, ch, llr);
+}
+
+// ------------------------------------------------------------------------------------------------ turbo decoder
+#define TB_S 16      // sub-block length between alpha checkpoints
+#define TB_MAXSB 6   // ceil(96/16)
+
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int ext_scale(int x)
+{
+  int a = x < 0 ? -x : x;
+  a = (a * 3) >> 2;
+  a = a > LSN_EXT_CLIP ? LSN_EXT_CLIP : a;
+  return x < 0 ? -a : a;
+}
+// a[0] is always 0 after normalisation and is not stored
+__device__ __forceinline__ void step_fwd(int* a, int lsa, int lp)
+{
+  const int g01 = lp, g10 = lsa, g11 = lsa + lp;
+  int n0 = imax(a[0], a[1] + g11), n1 = imax(a[2] + g10, a[3] + g01), n2 = imax(a[4] + g01, a[5] + g10), n3 = imax(a[6] + g11, a[7]);
+  int n4 = imax(a[0] + g11, a[1]), n5 = imax(a[2] + g01, a[3] + g10), n6 = imax(a[4] + g10, a[5] + g01), n7 = imax(a[6], a[7] + g11);
+  a[0] = 0; a[1] = n1 - n0; a[2] = n2 - n0; a[3] = n3 - n0; a[4] = n4 - n0; a[5] = n5 - n0; a[6] = n6 - n0; a[7] = n7 - n0;
+}
+
+struct TurboLds {
+  int16_t *sys, *p1, *p2, *ext;
+  uint32_t* hard;
+  int16_t *ablk, *posblk, *ckpt, *ckpq, *nii;
+};
+
+// one constituent decoder over all windows (lane = window)
+template <bool IL>
+__device__ __forceinline__ void map_pass(const TurboLds& m, int lane, int K, int P, int W, int f1, int f2, const int16_t* par,
+                                         int16_t* nii_a, int16_t* nii_b, const int* beta_tail)
+{
+  if (lane >= P) return;
+  const int t0 = lane * W;
+  const int nsb = (W + TB_S - 1) / TB_S;
+  int a[8], b[8];
+  a[0] = 0;
+  if (lane == 0) { for (int s = 1; s < 8; s++) a[s] = LSN_NEG_METRIC; }
+  else { for (int s = 1; s < 8; s++) a[s] = nii_a[(s - 1) * 64 + lane]; }
+  int pi = t0, gq = 0;
+  const int twof2 = (2 * f2) % K;
+  if (IL) {
+    pi = (int)(((long long)f1 * t0 + (long long)f2 * t0 % K * t0) % K);
+    gq = (int)(((long long)f1 + f2 + 2ll * f2 % K * t0) % K);
+  }
+  // forward sweep: checkpoint the metrics (and the interleaver state) at every sub-block start
+  for (int sb = 0; sb < nsb; sb++) {
+    for (int s = 1; s < 8; s++) m.ckpt[(sb * 7 + (s - 1)) * 64 + lane] = (int16_t)a[s];
+    if (IL) { m.ckpq[(sb * 2 + 0) * 64 + lane] = (int16_t)pi; m.ckpq[(sb * 2 + 1) * 64 + lane] = (int16_t)gq; }
+    const int tend = (sb + 1) * TB_S < W ? (sb + 1) * TB_S : W;
+    for (int t = sb * TB_S; t < tend; t++) {
+      const int pos = IL ? pi : t0 + t;
+      step_fwd(a, (int)m.sys[pos] + (int)m.ext[pos], (int)par[t0 + t]);
+      if (IL) { pi += gq; pi = pi >= K ? pi - K : pi; gq += twof2; gq = gq >= K ? gq - K : gq; }
+    }
+  }
+  int a_end[8];
+  for (int s = 0; s < 8; s++) a_end[s] = a[s];
+  b[0] = 0;
+  if (lane == P - 1) { for (int s = 1; s < 8; s++) b[s] = beta_tail[s]; }
+  else { for (int s = 1; s < 8; s++) b[s] = nii_b[(s - 1) * 64 + lane]; }
+  // backward sweep, sub-block by sub-block: recompute alphas into LDS, then run beta + LLR
+  for (int sb = nsb - 1; sb >= 0; sb--) {
+    a[0] = 0;
+    for (int s = 1; s < 8; s++) a[s] = m.ckpt[(sb * 7 + (s - 1)) * 64 + lane];
+    if (IL) { pi = m.ckpq[(sb * 2 + 0) * 64 + lane]; gq = m.ckpq[(sb * 2 + 1) * 64 + lane]; }
+    const int tbeg = sb * TB_S, tend = (sb + 1) * TB_S < W ? (sb + 1) * TB_S : W;
+    for (int t = tbeg; t < tend; t++) {
+      const int u = t - tbeg;
+      const int pos = IL ? pi : t0 + t;
+      for (int s = 1; s < 8; s++) m.ablk[(u * 7 + (s - 1)) * 64 + lane] = (int16_t)a[s];
+      m.posblk[u * 64 + lane] = (int16_t)pos;
+      step_fwd(a, (int)m.sys[pos] + (int)m.ext[pos], (int)par[t0 + t]);
+      if (IL) { pi += gq; pi = pi >= K ? pi - K : pi; gq += twof2; gq = gq >= K ? gq - K : gq; }
+    }
+    for (int t = tend - 1; t >= tbeg; t--) {
+      const int u = t - tbeg;
+      const int pos = m.posblk[u * 64 + lane];
+      const int lsa = (int)m.sys[pos] + (int)m.ext[pos], lp = (int)par[t0 + t];
+      int al[8];
+      al[0] = 0;
+      for (int s = 1; s < 8; s++) al[s] = m.ablk[(u * 7 + (s - 1)) * 64 + lane];
+      const int g01 = lp, g10 = lsa, g11 = lsa + lp;
+      // branch metrics + beta of the successor, per state: x0 = input 0, x1 = input 1
+      const int x00 = b[0], x01 = b[4] + g11;
+      const int x10 = b[4], x11 = b[0] + g11;
+      const int x20 = b[5] + g01, x21 = b[1] + g10;
+      const int x30 = b[1] + g01, x31 = b[5] + g10;
+      const int x40 = b[2] + g01, x41 = b[6] + g10;
+      const int x50 = b[6] + g01, x51 = b[2] + g10;
+      const int x60 = b[7], x61 = b[3] + g11;
+      const int x70 = b[3], x71 = b[7] + g11;
+      int m0 = imax(imax(imax(al[0] + x00, al[1] + x10), imax(al[2] + x20, al[3] + x30)),
+                    imax(imax(al[4] + x40, al[5] + x50), imax(al[6] + x60, al[7] + x70)));
+      int m1 = imax(imax(imax(al[0] + x01, al[1] + x11), imax(al[2] + x21, al[3] + x31)),
+                    imax(imax(al[4] + x41, al[5] + x51), imax(al[6] + x61, al[7] + x71)));
+      const int L = m1 - m0;
+      m.ext[pos] = (int16_t)ext_scale(L - lsa);
+      if (IL && L > 0) atomicOr(&m.hard[pos >> 5], 1u << (pos & 31));
+      const int n0 = imax(x00, x01);
+      b[1] = imax(x10, x11) - n0; b[2] = imax(x20, x21) - n0; b[3] = imax(x30, x31) - n0; b[4] = imax(x40, x41) - n0;
+      b[5] = imax(x50, x51) - n0; b[6] = imax(x60, x61) - n0; b[7] = imax(x70, x71) - n0;
+      b[0] = 0;
+    }
+  }
+  // publish the window boundaries for the next iteration (all lanes have consumed theirs: single wavefront, in order)
+  if (lane + 1 < P) for (int s = 1; s < 8; s++) nii_a[(s - 1) * 64 + lane + 1] = (int16_t)a_end[s];
+  if (lane > 0) for (int s = 1; s < 8; s++) nii_b[(s - 1) * 64 + lane - 1] = (int16_t)b[s];
+}
+
+__device__ __forceinline__ void tail_beta(const int16_t* ts, const int16_t* tp, int* beta)
+{
+  int b[8], bn[8];
+  for (int S = 0; S < 8; S++) b[S] = S == 0 ? 0 : LSN_NEG_METRIC;
+  for (int t = 2; t >= 0; t--) {
+    for (int S = 0; S < 8; S++) {
+      int s1 = (S >> 2) & 1, s2 = (S >> 1) & 1, s3 = S & 1;
+      int u = s2 ^ s3, z = s1 ^ s3, Sn = (s1 << 1) | s2;
+      bn[S] = b[Sn] + (u ? (int)ts[t] : 0) + (z ? (int)tp[t] : 0);
+    }
+    for (int S = 0; S < 8; S++) b[S] = bn[S];
+  }
+  for (int S = 7; S >= 0; S--) beta[S] = b[S] - b[0];
+}
+
+__device__ __forceinline__ int turbo_nwin(int K)
+{
+  int P = 64;
+  while (P > 1 && ((K % P) != 0 || K / P < 32)) P >>= 1;
+  return P;
+}
+
+__global__ __launch_bounds__(64) void k_turbo(LsnCellDev c, const LsnCbDev* __restrict__ cbs, const int16_t* __restrict__ llr,
+                                              uint8_t* __restrict__ payload, LsnCbRes* __restrict__ res)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ LsnRmGeom geom;
+  const LsnCbDev cb = cbs[blockIdx.x];
+  const int lane = threadIdx.x, K = (int)cb.K, D = K + 4, Dp = (D + 7) & ~7, F = (int)cb.F;
+  TurboLds m;
+  m.sys = (int16_t*)smem; m.p1 = m.sys + Dp; m.p2 = m.p1 + Dp; m.ext = m.p2 + Dp;
+  m.hard = (uint32_t*)(m.ext + Dp);
+  const int nhw = (K + 31) / 32;
+  m.ablk = (int16_t*)(m.hard + ((nhw + 3) & ~3));
+  m.posblk = m.ablk + TB_S * 7 * 64;
+  m.ckpt = m.posblk + TB_S * 64;
+  m.ckpq = m.ckpt + TB_MAXSB * 7 * 64;
+  m.nii = m.ckpq + TB_MAXSB * 2 * 64;  // [4][7][64]: a1, b1, a2, b2
+  if (lane == 0) lsn_rm_geom(geom, K, F, (int)cb.rv);
+  __syncthreads();
+  // ---- rate de-matching as a gather (36.212 5.1.4.1.2), soft-combining repeated bits, clip to +-511 ----
+  const int16_t* e = llr + cb.e_off;
+  const int E = (int)cb.E, nn = geom.nn;
+  for (int o = lane; o < 3 * D; o += 64) {
+    int s = o / D, i = o - s * D;
+    int r = lsn_rm_rank(geom, s, i);
+    int v;
+    if (r < 0) {
+      v = -LSN_LLR_CLIP;  // filler bits are known zeros
+    } else {
+      int acc = 0;
+      for (int k = r; k < E; k += nn) acc += (int)e[k];
+      v = acc > LSN_LLR_CLIP ? LSN_LLR_CLIP : (acc < -LSN_LLR_CLIP ? -LSN_LLR_CLIP : acc);
+    }
+    (s == 0 ? m.sys : (s == 1 ? m.p1 : m.p2))[i] = (int16_t)v;
+  }
+  for (int i = lane; i < K; i += 64) m.ext[i] = 0;
+  for (int i = lane; i < 4 * 7 * 64; i += 64) m.nii[i] = 0;
+  __syncthreads();
+  // ---- termination (36.212 5.1.3.2.2) ----
+  int bt1[8], bt2[8];
+  {
+    int16_t ts1[3] = {m.sys[K], m.p2[K], m.p1[K + 1]}, tp1[3] = {m.p1[K], m.sys[K + 1], m.p2[K + 1]};
+    int16_t ts2[3] = {m.sys[K + 2], m.p2[K + 2], m.p1[K + 3]}, tp2[3] = {m.p1[K + 2], m.sys[K + 3], m.p2[K + 3]};
+    tail_beta(ts1, tp1, bt1);
+    tail_beta(ts2, tp2, bt2);
+  }
+  const int P = turbo_nwin(K), W = K / P;
+  const uint32_t* tab = cb.crc_b ? c.crc_tab_b : c.crc_tab_a;
+  int it = 0;
+  bool ok = false;
+  while (it < (int)cb.max_iter && !ok) {
+    map_pass<false>(m, lane, K, P, W, (int)cb.f1, (int)cb.f2, m.p1, m.nii, m.nii + 7 * 64, bt1);
+    for (int i = lane; i < nhw; i += 64) m.hard[i] = 0;
+    __syncthreads();
+    map_pass<true>(m, lane, K, P, W, (int)cb.f1, (int)cb.f2, m.p2, m.nii + 14 * 64, m.nii + 21 * 64, bt2);
+    __syncthreads();
+    it++;
+    // CRC over all K decided bits == 0  <=>  data || parity divisible by g(x)
+    uint32_t rem = 0;
+    for (int i = lane; i < K; i += 64)
+      if ((m.hard[i >> 5] >> (i & 31)) & 1u) rem ^= tab[K - 1 - i];
+    for (int off = 32; off > 0; off >>= 1) rem ^= __shfl_xor(rem, off);
+    ok = rem == 0;
+  }
+  // ---- output: payload bytes of this code block + its CRC24A remainder contribution ----
+  const int nout = (int)cb.out_bytes;
+  uint8_t* outp = payload + cb.out_off;
+  uint32_t rema = 0;
+  for (int j = lane; j < nout; j += 64) {
+    int i = F + 8 * j;
+    uint32_t bits8 = (m.hard[i >> 5] >> (i & 31)) & 0xFFu;  // bit i at LSB
+    outp[j] = (uint8_t)(__brev(bits8) >> 24);
+    for (int q = 0; q < 8; q++)
+      if ((bits8 >> q) & 1u) rema ^= c.crc_tab_a[8 * nout - 1 - (8 * j + q)];
+  }
+  for (int off = 32; off > 0; off >>= 1) rema ^= __shfl_xor(rema, off);
+  if (lane == 0) {
+    LsnCbRes r; r.ok = ok ? 1u : 0u; r.iters = (uint32_t)it; r.rem_a = rema; r.pad = 0;
+    res[blockIdx.x] = r;
+  }
+}
+
+size_t lsn_turbo_lds_bytes(uint32_t K)
+{
+  size_t Dp = ((K + 4) + 7) & ~7u;
+  size_t nhw = (K + 31) / 32;
+  return Dp * 4 * sizeof(int16_t) + ((nhw + 3) & ~3u) * 4 +
+         sizeof(int16_t) * (TB_S * 7 * 64 + TB_S * 64 + TB_MAXSB * 7 * 64 + TB_MAXSB * 2 * 64 + 4 * 7 * 64);
+}
+
+void lsn_launch_turbo(const LsnCellDev& c, const LsnCbDev* cb, const int16_t* llr, uint8_t* payload, LsnCbRes* res, uint32_t ncb, hipStream_t s)
+{
+  // dynamic LDS sized for the largest block (K = 6144); smaller blocks simply leave part of it unused
+  static bool attr_set = false;
+  size_t lds = lsn_turbo_lds_bytes(6144);
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)k_turbo, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(k_turbo, dim3(ncb), dim3(64), lds, s, c, cb, llr, payload, res);
+}
