@@ -1,0 +1,268 @@
+"""ltesniffer_amd - MI355X-native (gfx950, HIP) replacement of LTESniffer's per-subframe worker.
+
+The product is the C-ABI shared library ``ltesniffer_amd/lib/libltesniffer_amd.so`` (include/ltesniffer_amd.h); this
+module is only the ctypes binding used by tests, ``bench.py`` and ``__graft_entry__`` plus thin Python mirrors of the
+reference's ``Phy`` / ``SubframeWorker`` pair (/root/reference/src/include/Phy.h:22-66,
+/root/reference/src/include/SubframeWorker.h:16-86).  There is no CPU fallback: importing works without a GPU (so
+that the symbol table can be checked), but creating a ``Phy`` without a HIP device raises.
+"""
+import ctypes as C
+import os
+import struct
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libltesniffer_amd.so")
+
+LSN_SUCCESS, LSN_ERROR, LSN_ERROR_INVALID_INPUTS, LSN_ERROR_NO_DEVICE = 0, -1, -2, -3
+TAP_GRID, TAP_CE, TAP_PDCCH_LLR, TAP_CHEST, TAP_CFI, TAP_CANDIDATES, TAP_CCE_POWER, TAP_ACCEPTED, TAP_RB_POWER = range(9)
+KERNELS = ["k_ofdm", "k_chest", "k_chest_fin", "k_pcfich", "k_pdcch_llr", "k_cce_power", "k_viterbi", "k_pdsch_prep",
+           "k_pdsch_demod", "k_turbo", "k_rb_power"]
+
+# every symbol include/ltesniffer_amd.h declares
+EXPORTS = ["lsn_phy_create", "lsn_phy_destroy", "lsn_phy_set_cell", "lsn_phy_get_avail", "lsn_phy_put_pending",
+           "lsn_phy_join_pending", "lsn_phy_set_pdu_sink", "lsn_phy_get_stats", "lsn_phy_get_est_cfo",
+           "lsn_phy_add_evergreen", "lsn_phy_add_forbidden", "lsn_phy_setup_default_rnti_intervals",
+           "lsn_phy_nof_active_rnti", "lsn_worker_buffers", "lsn_worker_buffer_len", "lsn_worker_prepare",
+           "lsn_worker_sf_idx", "lsn_worker_sfn", "lsn_phy_process_device", "lsn_phy_process_host", "lsn_phy_tap",
+           "lsn_phy_get_perf", "lsn_kernel_name", "lsn_version"]
+
+
+class Cell(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("nof_prb", "nof_ports", "id", "cp", "phich_length", "phich_resources", "frame_type")]
+
+
+class DlSfCfg(C.Structure):
+    _fields_ = [("tti", C.c_uint32), ("cfi", C.c_uint32), ("sf_type", C.c_uint32)]
+
+
+class PhyCfg(C.Structure):
+    _fields_ = [("nof_rx_antennas", C.c_uint32), ("nof_workers", C.c_uint32), ("max_batch", C.c_uint32),
+                ("skip_secondary_meta_formats", C.c_int), ("meta_format_split_ratio", C.c_double),
+                ("histogram_threshold", C.c_uint32), ("mcs_tracking_mode", C.c_int), ("harq_mode", C.c_int),
+                ("device", C.c_int), ("max_turbo_iterations", C.c_int)]
+
+
+class PduCtx(C.Structure):
+    _fields_ = [("tti", C.c_uint32), ("rnti", C.c_uint16), ("direction", C.c_uint8), ("rnti_type", C.c_uint8),
+                ("crc_ok", C.c_uint8), ("is_retx", C.c_uint8), ("tb", C.c_uint8), ("reserved", C.c_uint8)]
+
+
+class BlindStats(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("nof_locations", "nof_decoded_locations", "nof_cce", "nof_missed_cce",
+                                          "nof_subframes", "nof_subframe_collisions_dw", "nof_subframe_collisions_up")]
+
+
+class Perf(C.Structure):
+    _fields_ = [("ms_stage_a", C.c_double), ("ms_search", C.c_double), ("ms_stage_c", C.c_double), ("ms_commit", C.c_double),
+                ("ms_total", C.c_double), ("kernel_ms", C.c_double * 16), ("kernel_launches", C.c_uint64 * 16),
+                ("algo_bytes", C.c_uint64), ("turbo_algo_bytes", C.c_uint64), ("nof_tb_decodes", C.c_uint64),
+                ("nof_cb_decodes", C.c_uint64), ("nof_turbo_iterations", C.c_uint64), ("nof_candidates_decoded", C.c_uint64),
+                ("nof_ondemand_decodes", C.c_uint64), ("nof_pdus", C.c_uint64)]
+
+
+SINK_T = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(PduCtx), C.POINTER(C.c_uint8), C.c_uint32)
+
+_lib = None
+
+
+def build(verbose=False):
+    """Compile the HIP kernels + host engine for gfx950 (hipcc cross-compiles without a GPU)."""
+    out = None if verbose else subprocess.DEVNULL
+    subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-j8"], stdout=out)
+    return LIB_PATH
+
+
+def lib():
+    """The C-ABI library. Fails loudly when it has not been built: there is no other implementation to fall back to."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("ltesniffer_amd: %s is missing - run ltesniffer_amd.build() / __graft_entry__.build() "
+                               "(the HIP extension is the only implementation; there is no CPU fallback)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.lsn_phy_create.argtypes = [C.POINTER(PhyCfg), C.POINTER(C.c_void_p)]
+        L.lsn_phy_destroy.argtypes = [C.c_void_p]
+        L.lsn_phy_destroy.restype = None
+        L.lsn_phy_set_cell.argtypes = [C.c_void_p, C.POINTER(Cell)]
+        L.lsn_phy_get_avail.argtypes = [C.c_void_p, C.c_int]
+        L.lsn_phy_get_avail.restype = C.c_void_p
+        L.lsn_phy_put_pending.argtypes = [C.c_void_p, C.c_void_p]
+        L.lsn_phy_join_pending.argtypes = [C.c_void_p]
+        L.lsn_phy_set_pdu_sink.argtypes = [C.c_void_p, SINK_T, C.c_void_p]
+        L.lsn_phy_get_stats.argtypes = [C.c_void_p, C.POINTER(BlindStats)]
+        L.lsn_phy_get_est_cfo.argtypes = [C.c_void_p]
+        L.lsn_phy_get_est_cfo.restype = C.c_float
+        L.lsn_phy_add_evergreen.argtypes = [C.c_void_p, C.c_uint16, C.c_uint16, C.c_uint32]
+        L.lsn_phy_add_forbidden.argtypes = [C.c_void_p, C.c_uint16, C.c_uint16, C.c_uint32]
+        L.lsn_phy_setup_default_rnti_intervals.argtypes = [C.c_void_p]
+        L.lsn_phy_nof_active_rnti.argtypes = [C.c_void_p]
+        L.lsn_phy_nof_active_rnti.restype = C.c_uint32
+        L.lsn_worker_buffers.argtypes = [C.c_void_p]
+        L.lsn_worker_buffers.restype = C.POINTER(C.POINTER(C.c_float))
+        L.lsn_worker_buffer_len.argtypes = [C.c_void_p]
+        L.lsn_worker_buffer_len.restype = C.c_uint32
+        L.lsn_worker_prepare.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(DlSfCfg)]
+        L.lsn_worker_sf_idx.argtypes = [C.c_void_p]
+        L.lsn_worker_sf_idx.restype = C.c_uint32
+        L.lsn_worker_sfn.argtypes = [C.c_void_p]
+        L.lsn_worker_sfn.restype = C.c_uint32
+        L.lsn_phy_process_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.lsn_phy_process_host.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.lsn_phy_tap.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_size_t]
+        L.lsn_phy_tap.restype = C.c_long
+        L.lsn_phy_get_perf.argtypes = [C.c_void_p, C.POINTER(Perf)]
+        L.lsn_kernel_name.argtypes = [C.c_int]
+        L.lsn_kernel_name.restype = C.c_char_p
+        L.lsn_version.restype = C.c_char_p
+        _lib = L
+    return _lib
+
+
+def _check(rc, what):
+    if rc != LSN_SUCCESS:
+        raise RuntimeError("%s failed: %d%s" % (what, rc, " (no HIP device: this library has no CPU path)"
+                                                if rc == LSN_ERROR_NO_DEVICE else ""))
+
+
+class SubframeWorker:
+    """Mirror of SubframeWorker (SubframeWorker.h:16-86): buffers to fill + prepare(); work() runs inside Phy."""
+
+    def __init__(self, phy, handle):
+        self._phy, self._h = phy, handle
+
+    def getBuffers(self):
+        """-> list of numpy complex64 views (one per rx antenna, 3 * SF_LEN samples) of the pinned IQ buffers"""
+        L = lib()
+        n = L.lsn_worker_buffer_len(self._h)
+        bufs = L.lsn_worker_buffers(self._h)
+        out = []
+        for rx in range(self._phy.nof_rx_antennas):
+            a = np.ctypeslib.as_array(bufs[rx], shape=(2 * n,))
+            out.append(a.view(np.complex64))
+        return out
+
+    def prepare(self, sf_idx, sfn, updateMetaFormats, dl_sf_cfg=None):
+        cfg = dl_sf_cfg if dl_sf_cfg is not None else DlSfCfg(sfn * 10 + sf_idx, 0, 0)
+        _check(lib().lsn_worker_prepare(self._h, sf_idx, sfn, int(bool(updateMetaFormats)), C.byref(cfg)), "prepare")
+
+    def getSfidx(self):
+        return lib().lsn_worker_sf_idx(self._h)
+
+    def getSfn(self):
+        return lib().lsn_worker_sfn(self._h)
+
+
+class Phy:
+    """Mirror of Phy (Phy.h:22-66). Constructor arguments keep the reference's names; the pcap writer argument is
+    replaced by a PDU sink callable ``sink(ctx_dict, pdu_bytes)`` receiving what pack_and_write would serialise."""
+
+    def __init__(self, nof_rx_antennas=2, nof_workers=20, skipSecondaryMetaFormats=False, metaFormatSplitRatio=0.99,
+                 histogramThreshold=5, sink=None, mcs_tracking_mode=1, harq_mode=0, device=0, max_batch=64,
+                 max_turbo_iterations=12, default_rnti_intervals=True):
+        self.nof_rx_antennas = nof_rx_antennas
+        self._cfg = PhyCfg(nof_rx_antennas, nof_workers, max_batch, int(skipSecondaryMetaFormats), metaFormatSplitRatio,
+                           histogramThreshold, mcs_tracking_mode, harq_mode, device, max_turbo_iterations)
+        self._h = C.c_void_p()
+        _check(lib().lsn_phy_create(C.byref(self._cfg), C.byref(self._h)), "lsn_phy_create")
+        self.pdus = []
+        self._user_sink = sink
+        self._cb = SINK_T(self._on_pdu)
+        _check(lib().lsn_phy_set_pdu_sink(self._h, self._cb, None), "set_pdu_sink")
+        if default_rnti_intervals:
+            _check(lib().lsn_phy_setup_default_rnti_intervals(self._h), "rnti intervals")
+        self.cell = None
+
+    def _on_pdu(self, user, ctx, pdu, n):
+        c = ctx.contents
+        d = dict(tti=c.tti, rnti=c.rnti, direction=c.direction, rnti_type=c.rnti_type, crc_ok=c.crc_ok, tb=c.tb)
+        data = C.string_at(pdu, n)
+        if self._user_sink is not None:
+            self._user_sink(d, data)
+        else:
+            self.pdus.append((d, data))
+
+    def setCell(self, nof_prb, nof_ports, cell_id, phich_resources=0):
+        self.cell = Cell(nof_prb, nof_ports, cell_id, 0, 0, phich_resources, 0)
+        rc = lib().lsn_phy_set_cell(self._h, C.byref(self.cell))
+        return rc == LSN_SUCCESS
+
+    def getAvail(self):
+        h = lib().lsn_phy_get_avail(self._h, 1)
+        return SubframeWorker(self, h) if h else None
+
+    def getAvailImmediate(self):
+        h = lib().lsn_phy_get_avail(self._h, 0)
+        return SubframeWorker(self, h) if h else None
+
+    def putPending(self, worker):
+        _check(lib().lsn_phy_put_pending(self._h, worker._h), "putPending")
+
+    def joinPending(self):
+        _check(lib().lsn_phy_join_pending(self._h), "joinPending")
+
+    # ---- offline / file-replay path ----
+    def process_host(self, iq, start_tti, update_meta_period=0):
+        """iq: complex64 [n_subframes, nof_rx, 15*N]"""
+        iq = np.ascontiguousarray(iq, dtype=np.complex64)
+        _check(lib().lsn_phy_process_host(self._h, iq.ctypes.data, iq.shape[0], start_tti, update_meta_period), "process_host")
+
+    def process_device(self, dev_ptr, n_subframes, start_tti, update_meta_period=0, stream=None):
+        _check(lib().lsn_phy_process_device(self._h, C.c_void_p(dev_ptr), n_subframes, start_tti, update_meta_period,
+                                            C.c_void_p(stream or 0)), "process_device")
+
+    # ---- taps / stats ----
+    def tap(self, what, sf, dtype, count):
+        buf = np.zeros(count, dtype=dtype)
+        n = lib().lsn_phy_tap(self._h, what, sf, buf.ctypes.data, buf.nbytes)
+        if n < 0:
+            raise RuntimeError("tap %d failed: %d" % (what, n))
+        return buf[: n // buf.itemsize]
+
+    def perf(self):
+        p = Perf()
+        _check(lib().lsn_phy_get_perf(self._h, C.byref(p)), "get_perf")
+        return p
+
+    def getStats(self):
+        s = BlindStats()
+        _check(lib().lsn_phy_get_stats(self._h, C.byref(s)), "get_stats")
+        return s
+
+    def est_cfo(self):
+        return lib().lsn_phy_get_est_cfo(self._h)
+
+    def nof_active_rnti(self):
+        return lib().lsn_phy_nof_active_rnti(self._h)
+
+    def close(self):
+        if self._h:
+            lib().lsn_phy_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def mac_lte_record(ctx, pdu):
+    """MAC-LTE (DLT 147) framing of one PDU exactly as LTESniffer_pcap_writer::pack_and_write emits it
+    (/root/reference/src/src/PcapWriter.cc:93-118; byte layout SURVEY.md appendix B). -> context header + PDU bytes."""
+    tti = ctx["tti"]
+    fs = ((tti // 10) << 4) | (tti % 10)
+    hdr = bytes([1, ctx["direction"], ctx["rnti_type"], 2, ctx["rnti"] >> 8, ctx["rnti"] & 255, 3, 0, 0, 4, (fs >> 8) & 255,
+                 fs & 255, 7, ctx["crc_ok"], 10, 0, 15, 0, 1])
+    return hdr + pdu
+
+
+def write_pcap(path, records, ts=(0, 0)):
+    """records: iterable of (ctx, pdu). Writes the same global header as the reference (network 147)."""
+    with open(path, "wb") as f:
+        f.write(struct.pack("<IHHiIII", 0xA1B2C3D4, 2, 4, 0, 0, 65535, 147))
+        for ctx, pdu in records:
+            body = mac_lte_record(ctx, pdu)
+            f.write(struct.pack("<IIII", ts[0], ts[1], len(body), len(body)) + body)

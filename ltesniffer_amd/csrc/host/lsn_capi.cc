@@ -1,0 +1,264 @@
+// lsn_capi.cc - the C ABI of include/ltesniffer_amd.h: Phy (worker pool + pending queue) and SubframeWorker (pinned IQ
+// buffers) on top of the batched GPU engine.
+//   Phy::Phy / getAvail / getAvailImmediate / putPending / joinPending   /root/reference/src/src/Phy.cc:5-109
+//   SnifferThread::execute_worker                                        /root/reference/src/src/WorkerThread.cc:78-91
+//   SubframeBuffer (3 * SF_LEN_PRB(100) samples per antenna)             /root/reference/src/src/SubframeBuffer.cc:25-28
+// The reference runs `nof_workers` CPU threads each calling SubframeWorker::work(); here ONE dispatcher thread drains the
+// pending queue in FIFO (= TTI) order into GPU batches, which is the reference's sequential (-W 1, file replay) semantic.
+#include "lsn_engine.h"
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
+
+struct lsn_worker {
+  lsn_phy* phy = nullptr;
+  float* buf[LSN_MAX_RX] = {nullptr, nullptr};
+  uint32_t buf_len = 0;  // complex samples per antenna
+  uint32_t sf_idx = 0, sfn = 0;
+  int update_meta = 0;
+  lsn_dl_sf_cfg_t sf_cfg{};
+};
+
+struct lsn_phy {
+  std::unique_ptr<lsn::Engine> engine;
+  lsn_phy_cfg_t cfg{};
+  std::vector<std::unique_ptr<lsn_worker>> workers;
+  std::deque<lsn_worker*> avail, pending;
+  std::mutex mtx;
+  std::condition_variable cv_avail, cv_pending, cv_idle;
+  std::thread dispatcher;
+  bool stop = false, busy = false;
+  float* staging = nullptr;  // pinned [max_batch][rx][sflen] cf32
+  int last_error = 0;
+
+  void dispatch_loop();
+};
+
+void lsn_phy::dispatch_loop()
+{
+  std::vector<lsn_worker*> batch;
+  for (;;) {
+    {
+      std::unique_lock<std::mutex> lk(mtx);
+      cv_pending.wait(lk, [&] { return stop || !pending.empty(); });
+      if (pending.empty() && stop) return;
+      batch.clear();
+      // consecutive TTIs only: a batch is a contiguous run of subframes (start_tti + i)
+      const uint32_t maxb = engine->maxBatch();
+      uint32_t prev_tti = 0;
+      while (!pending.empty() && batch.size() < maxb) {
+        lsn_worker* w = pending.front();
+        const uint32_t tti = w->sfn * 10 + w->sf_idx;
+        if (!batch.empty() && (tti != (prev_tti + 1) % 10240 || w->update_meta)) break;
+        prev_tti = tti;
+        batch.push_back(w);
+        pending.pop_front();
+      }
+      busy = true;
+    }
+    const uint32_t A = engine->nofRx(), sflen = engine->sfLen();
+    for (size_t i = 0; i < batch.size(); i++)
+      for (uint32_t rx = 0; rx < A; rx++)
+        std::memcpy(staging + ((i * A + rx) * sflen) * 2, batch[i]->buf[rx], (size_t)sflen * 2 * sizeof(float));
+    // SubframeWorker::prepare's updateMetaFormats flag (LTESniffer_Core.cc:434) applies to the first subframe of the batch
+    const uint32_t tti0 = batch[0]->sfn * 10 + batch[0]->sf_idx;
+    if (batch[0]->update_meta) engine->forceMetaUpdateNext();
+    const int r = engine->processHost(staging, (uint32_t)batch.size(), tti0, 0u);
+    {
+      std::unique_lock<std::mutex> lk(mtx);
+      if (r != LSN_SUCCESS) last_error = r;
+      for (auto* w : batch) avail.push_back(w);
+      busy = false;
+    }
+    cv_avail.notify_all();
+    cv_idle.notify_all();
+  }
+}
+
+extern "C" {
+
+int lsn_phy_create(const lsn_phy_cfg_t* cfg, lsn_phy_t** out)
+{
+  if (!cfg || !out) return LSN_ERROR_INVALID_INPUTS;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return LSN_ERROR_NO_DEVICE;  // no CPU fallback
+  if (cfg->device < 0 || cfg->device >= ndev) return LSN_ERROR_INVALID_INPUTS;
+  try {
+    std::unique_ptr<lsn_phy> p(new lsn_phy());
+    p->cfg = *cfg;
+    if (p->cfg.nof_workers == 0) p->cfg.nof_workers = 20;  // Phy.h:19
+    p->engine.reset(new lsn::Engine(p->cfg));
+    *out = p.release();
+    return LSN_SUCCESS;
+  } catch (const std::invalid_argument&) {
+    return LSN_ERROR_INVALID_INPUTS;
+  } catch (const std::exception& ex) {
+    fprintf(stderr, "ltesniffer_amd: %s\n", ex.what());
+    return LSN_ERROR;
+  }
+}
+
+void lsn_phy_destroy(lsn_phy_t* phy)
+{
+  if (!phy) return;
+  {
+    std::unique_lock<std::mutex> lk(phy->mtx);
+    phy->stop = true;
+  }
+  phy->cv_pending.notify_all();
+  if (phy->dispatcher.joinable()) phy->dispatcher.join();
+  for (auto& w : phy->workers)
+    for (auto& b : w->buf)
+      if (b) (void)hipHostFree(b);
+  if (phy->staging) (void)hipHostFree(phy->staging);
+  delete phy;
+}
+
+int lsn_phy_set_cell(lsn_phy_t* phy, const lsn_cell_t* cell)
+{
+  if (!phy || !cell) return LSN_ERROR_INVALID_INPUTS;
+  if (phy->dispatcher.joinable()) {
+    lsn_phy_join_pending(phy);
+    {
+      std::unique_lock<std::mutex> lk(phy->mtx);
+      phy->stop = true;
+    }
+    phy->cv_pending.notify_all();
+    phy->dispatcher.join();
+    phy->stop = false;
+  }
+  const int r = phy->engine->setCell(*cell);
+  if (r != LSN_SUCCESS) return r;
+  // worker pool: SubframeBuffer allocates 3 * SF_LEN per antenna (SubframeBuffer.cc:25)
+  for (auto& w : phy->workers)
+    for (auto& b : w->buf)
+      if (b) { (void)hipHostFree(b); b = nullptr; }
+  phy->workers.clear(); phy->avail.clear(); phy->pending.clear();
+  if (phy->staging) { (void)hipHostFree(phy->staging); phy->staging = nullptr; }
+  const uint32_t sflen = phy->engine->sfLen(), A = phy->engine->nofRx();
+  for (uint32_t i = 0; i < phy->cfg.nof_workers; i++) {
+    std::unique_ptr<lsn_worker> w(new lsn_worker());
+    w->phy = phy; w->buf_len = 3 * sflen;
+    for (uint32_t rx = 0; rx < A; rx++)
+      if (hipHostMalloc((void**)&w->buf[rx], (size_t)w->buf_len * 2 * sizeof(float)) != hipSuccess) return LSN_ERROR;
+    phy->avail.push_back(w.get());
+    phy->workers.push_back(std::move(w));
+  }
+  if (hipHostMalloc((void**)&phy->staging, (size_t)phy->engine->maxBatch() * A * sflen * 2 * sizeof(float)) != hipSuccess) return LSN_ERROR;
+  phy->dispatcher = std::thread([phy] { phy->dispatch_loop(); });
+  return LSN_SUCCESS;
+}
+
+lsn_worker_t* lsn_phy_get_avail(lsn_phy_t* phy, int blocking)
+{
+  if (!phy) return nullptr;
+  std::unique_lock<std::mutex> lk(phy->mtx);
+  if (blocking) phy->cv_avail.wait(lk, [&] { return !phy->avail.empty() || phy->workers.empty(); });
+  if (phy->avail.empty()) return nullptr;  // getAvailImmediate: nullptr when none (Phy.cc:84-89)
+  lsn_worker* w = phy->avail.front();
+  phy->avail.pop_front();
+  return w;
+}
+
+int lsn_phy_put_pending(lsn_phy_t* phy, lsn_worker_t* w)
+{
+  if (!phy || !w || w->phy != phy) return LSN_ERROR_INVALID_INPUTS;
+  {
+    std::unique_lock<std::mutex> lk(phy->mtx);
+    phy->pending.push_back(w);
+  }
+  phy->cv_pending.notify_one();
+  return LSN_SUCCESS;
+}
+
+int lsn_phy_join_pending(lsn_phy_t* phy)
+{
+  if (!phy) return LSN_ERROR_INVALID_INPUTS;
+  std::unique_lock<std::mutex> lk(phy->mtx);
+  phy->cv_idle.wait(lk, [&] { return phy->pending.empty() && !phy->busy; });
+  const int r = phy->last_error;
+  phy->last_error = 0;
+  return r;
+}
+
+int lsn_phy_set_pdu_sink(lsn_phy_t* phy, lsn_pdu_sink_t cb, void* user)
+{
+  if (!phy) return LSN_ERROR_INVALID_INPUTS;
+  phy->engine->setSink(cb, user);
+  return LSN_SUCCESS;
+}
+
+int lsn_phy_get_stats(lsn_phy_t* phy, lsn_blind_stats_t* out)
+{
+  if (!phy || !out) return LSN_ERROR_INVALID_INPUTS;
+  phy->engine->getStats(out);
+  return LSN_SUCCESS;
+}
+
+float lsn_phy_get_est_cfo(lsn_phy_t* phy) { return phy ? phy->engine->estCfo() : 0.0f; }
+
+int lsn_phy_add_evergreen(lsn_phy_t* phy, uint16_t a, uint16_t b, uint32_t f)
+{
+  if (!phy || f >= lsn::NOF_FORMATS) return LSN_ERROR_INVALID_INPUTS;
+  phy->engine->rntiManager().addEvergreen(a, b, f);
+  return LSN_SUCCESS;
+}
+int lsn_phy_add_forbidden(lsn_phy_t* phy, uint16_t a, uint16_t b, uint32_t f)
+{
+  if (!phy || f >= lsn::NOF_FORMATS) return LSN_ERROR_INVALID_INPUTS;
+  phy->engine->rntiManager().addForbidden(a, b, f);
+  return LSN_SUCCESS;
+}
+int lsn_phy_setup_default_rnti_intervals(lsn_phy_t* phy)
+{
+  if (!phy) return LSN_ERROR_INVALID_INPUTS;
+  phy->engine->setupDefaultIntervals();
+  return LSN_SUCCESS;
+}
+uint32_t lsn_phy_nof_active_rnti(lsn_phy_t* phy) { return phy ? phy->engine->rntiManager().nofActive() : 0; }
+
+float** lsn_worker_buffers(lsn_worker_t* w) { return w ? w->buf : nullptr; }
+uint32_t lsn_worker_buffer_len(lsn_worker_t* w) { return w ? w->buf_len : 0; }
+int lsn_worker_prepare(lsn_worker_t* w, uint32_t sf_idx, uint32_t sfn, int update_meta_formats, const lsn_dl_sf_cfg_t* sf)
+{
+  if (!w || sf_idx > 9) return LSN_ERROR_INVALID_INPUTS;
+  w->sf_idx = sf_idx; w->sfn = sfn; w->update_meta = update_meta_formats;
+  if (sf) w->sf_cfg = *sf;
+  return LSN_SUCCESS;
+}
+uint32_t lsn_worker_sf_idx(lsn_worker_t* w) { return w ? w->sf_idx : 0; }
+uint32_t lsn_worker_sfn(lsn_worker_t* w) { return w ? w->sfn : 0; }
+
+int lsn_phy_process_device(lsn_phy_t* phy, const void* d_iq, uint32_t n, uint32_t start_tti, uint32_t update_meta_period, void* stream)
+{
+  if (!phy) return LSN_ERROR_INVALID_INPUTS;
+  return phy->engine->process(d_iq, n, start_tti, update_meta_period, (hipStream_t)stream);
+}
+int lsn_phy_process_host(lsn_phy_t* phy, const float* iq, uint32_t n, uint32_t start_tti, uint32_t update_meta_period)
+{
+  if (!phy || (!iq && n)) return LSN_ERROR_INVALID_INPUTS;
+  return phy->engine->processHost(iq, n, start_tti, update_meta_period);
+}
+
+long lsn_phy_tap(lsn_phy_t* phy, int what, uint32_t sf, void* out, size_t cap)
+{
+  if (!phy || !out) return LSN_ERROR_INVALID_INPUTS;
+  return phy->engine->tap(what, sf, out, cap);
+}
+int lsn_phy_get_perf(lsn_phy_t* phy, lsn_perf_t* out)
+{
+  if (!phy || !out) return LSN_ERROR_INVALID_INPUTS;
+  phy->engine->getPerf(out);
+  return LSN_SUCCESS;
+}
+const char* lsn_kernel_name(int k)
+{
+  static const char* names[LSN_K_COUNT] = {"k_ofdm", "k_chest", "k_chest_fin", "k_pcfich", "k_pdcch_llr", "k_cce_power", "k_viterbi",
+                                           "k_pdsch_prep", "k_pdsch_demod", "k_turbo", "k_rb_power"};
+  return (k >= 0 && k < LSN_K_COUNT) ? names[k] : "";
+}
+const char* lsn_version(void) { return "ltesniffer_amd 0.1 (gfx950)"; }
+
+}  // extern "C"

@@ -13,7 +13,7 @@
 
 namespace lsn {
 
-struct DciMsg { uint8_t payload[64]; uint32_t nof_bits = 0; DciFormat format = FORMAT0; };
+struct DciMsg { uint8_t payload[64] = {}; uint32_t nof_bits = 0; DciFormat format = FORMAT0; };
 struct DciCandidate { uint16_t rnti = 0; DciMsg msg; uint32_t search_space_match_result = 0; };
 
 struct DlEntry {  // DL_Sniffer_DCI_DL (Sniffer_dependency.h:90)
@@ -61,6 +61,8 @@ public:
   uint32_t maxBatch() const { return max_batch; }
   void* stagingDevice() { return d_iq_staging; }
   void setupDefaultIntervals();
+  void forceMetaUpdateNext() { force_meta_next = true; }
+  void setCfoCorrection(float hz) { cfo_correct_hz = hz; }
 
 private:
   void freeDevice();
@@ -131,6 +133,8 @@ private:
   hipEvent_t ev[2 * LSN_K_COUNT + 2];
   size_t llr16_used = 0, prefix_used = 0, payload_used = 0;
   hipStream_t cur_stream = nullptr;
+  bool force_meta_next = false;
+  float cfo_correct_hz = 0.0f;
 };
 
 // table builders (lsn_tables.cc)

@@ -1,0 +1,72 @@
+"""Shared driver of the GPU-vs-oracle parity tests: runs the same seeded synthetic subframes through the HIP path
+(C ABI, ltesniffer_amd.Phy) and through the CPU oracle, and compares every stage tap and the MAC-LTE record stream."""
+import numpy as np
+
+import ltesniffer_amd as la
+from lsn_testlib import OracleWorker, TxGen, parse_pcap, scenario
+
+
+def gen_subframes(sc, n):
+    tx = TxGen(**sc)
+    iq = np.zeros((n, sc["nof_rx"], tx.sf_len), dtype=np.complex64)
+    truth = []
+    tti0 = None
+    for i in range(n):
+        tti, x, pdus = tx.next()
+        if tti0 is None:
+            tti0 = tti
+        iq[i] = x
+        truth.append(pdus)
+    return tti0, iq, truth
+
+
+def run_oracle(sc, tti0, iq, update_meta_period=0, taps=True, **okw):
+    ow = OracleWorker(sc["nof_prb"], sc["nof_ports"], sc["cell_id"], sc["nof_rx"], sc["phich_ng_x6"], **okw)
+    per_sf = []
+    for i in range(iq.shape[0]):
+        upd = 1 if (update_meta_period and i % update_meta_period == 0) else 0
+        ow.work(iq[i], tti0 + i, update_meta=upd)
+        if taps:
+            ch = ow.chest()
+            per_sf.append(dict(grid=ow.grid(), ce=ow.ce(), llr=ow.llr(), cfi=ow.cfi(), accepted=ow.accepted(),
+                               chest=np.array(list(ch.noise) + list(ch.rsrp) + list(ch.cepow) + list(ch.cfo_corr) +
+                                              [ch.noise_avg, ch.rsrp_avg, ch.snr_db, ch.cfo_hz, ch.chan_ref], dtype=np.float32)))
+    recs = parse_pcap(ow.pcap_bytes())
+    return ow, per_sf, recs
+
+
+def gpu_records(phy):
+    return [la.mac_lte_record(ctx, pdu) for ctx, pdu in phy.pdus]
+
+
+def oracle_records(recs):
+    return [r["ctx"] + r["pdu"] for r in recs]
+
+
+def compare_taps(phy, per_sf, sc, base=0, nsf=None):
+    """bit-exact comparison of the stage taps of the LAST GPU batch against oracle subframes base..base+nsf"""
+    A, P, nre = sc["nof_rx"], sc["nof_ports"], 12 * sc["nof_prb"]
+    bad = []
+    n = nsf if nsf is not None else len(per_sf) - base
+    for i in range(n):
+        o = per_sf[base + i]
+        g = phy.tap(la.TAP_GRID, i, np.complex64, A * 14 * nre).reshape(A, 14, nre)
+        if not np.array_equal(g.view(np.uint32), o["grid"].view(np.uint32)):
+            bad.append((i, "grid", float(np.abs(g - o["grid"]).max())))
+        ce = phy.tap(la.TAP_CE, i, np.complex64, P * A * 14 * nre).reshape(P, A, 14, nre)
+        if not np.array_equal(ce.view(np.uint32), o["ce"].view(np.uint32)):
+            bad.append((i, "ce", float(np.abs(ce - o["ce"]).max())))
+        cfi = int(phy.tap(la.TAP_CFI, i, np.uint32, 1)[0])
+        if cfi != o["cfi"]:
+            bad.append((i, "cfi", cfi, o["cfi"]))
+            continue
+        llr = phy.tap(la.TAP_PDCCH_LLR, i, np.float32, 6400)
+        if not np.array_equal(llr.view(np.uint32), o["llr"].view(np.uint32)):
+            bad.append((i, "llr", len(llr), len(o["llr"])))
+        ch = phy.tap(la.TAP_CHEST, i, np.float32, 19)
+        if not np.array_equal(ch.view(np.uint32), o["chest"].view(np.uint32)):
+            bad.append((i, "chest", ch.tolist(), o["chest"].tolist()))
+        acc = phy.tap(la.TAP_ACCEPTED, i, np.uint32, 64 * 6).reshape(-1, 6)
+        if [tuple(int(v) for v in r) for r in acc] != [tuple(r) for r in o["accepted"]]:
+            bad.append((i, "accepted", acc.tolist(), o["accepted"]))
+    return bad
