@@ -102,6 +102,20 @@ int lsn_worker_prepare(lsn_worker_t* w, uint32_t sf_idx, uint32_t sfn, int updat
 uint32_t lsn_worker_sf_idx(lsn_worker_t* w);
 uint32_t lsn_worker_sfn(lsn_worker_t* w);
 
+/* ---- MAC-LTE pcap writer: replaces LTESniffer_pcap_writer (PcapWriter.h:39-51, PcapWriter.cc:75-118) ----
+ * Record layout = LTE_PCAP_MAC_WritePDU [srsRAN], pinned by the captures under /root/reference/pcap_file_example/ (DLT 147). */
+typedef struct lsn_pcap lsn_pcap_t;
+lsn_pcap_t* lsn_pcap_open(const char* path);                 /* LTESniffer_pcap_writer::open, PcapWriter.cc:75 */
+lsn_pcap_t* lsn_pcap_open_mem(void);                         /* in-memory capture with zero timestamps (tests, bench) */
+void lsn_pcap_set_wall_clock(lsn_pcap_t* p, int on);         /* record timestamps: gettimeofday (default for files) or 0 */
+int lsn_pcap_write(lsn_pcap_t* p, const lsn_pdu_ctx_t* ctx, const uint8_t* pdu, uint32_t len); /* pack_and_write, PcapWriter.cc:93 */
+void lsn_pcap_sink(void* user /* lsn_pcap_t* */, const lsn_pdu_ctx_t* ctx, const uint8_t* pdu, uint32_t len); /* an lsn_pdu_sink_t */
+const uint8_t* lsn_pcap_mem(lsn_pcap_t* p, size_t* len);
+uint32_t lsn_pcap_nof_records(lsn_pcap_t* p);
+void lsn_pcap_reset(lsn_pcap_t* p);
+void lsn_pcap_close(lsn_pcap_t* p);                          /* LTESniffer_pcap_writer::close */
+int lsn_phy_set_pcap_writer(lsn_phy_t* phy, lsn_pcap_t* p);  /* Phy ctor argument `LTESniffer_pcap_writer*` (Phy.h:31) */
+
 /* ---- resident (offline / file-replay) path: the IQ of n subframes is ALREADY in device memory ----
  * d_iq layout: [subframe][antenna][15*N] interleaved cf32 (N = FFT size). Subframe i has tti = start_tti + i.
  * update_meta_period: metaFormats.update_formats() runs when (sf_cnt % period) == 0 (LTESniffer_Core.cc:434), 0 = never.

@@ -27,7 +27,9 @@ EXPORTS = ["lsn_phy_create", "lsn_phy_destroy", "lsn_phy_set_cell", "lsn_phy_get
            "lsn_phy_add_evergreen", "lsn_phy_add_forbidden", "lsn_phy_setup_default_rnti_intervals",
            "lsn_phy_nof_active_rnti", "lsn_worker_buffers", "lsn_worker_buffer_len", "lsn_worker_prepare",
            "lsn_worker_sf_idx", "lsn_worker_sfn", "lsn_phy_process_device", "lsn_phy_process_host", "lsn_phy_tap",
-           "lsn_phy_get_perf", "lsn_kernel_name", "lsn_version"]
+           "lsn_phy_get_perf", "lsn_kernel_name", "lsn_version", "lsn_pcap_open", "lsn_pcap_open_mem",
+           "lsn_pcap_set_wall_clock", "lsn_pcap_write", "lsn_pcap_sink", "lsn_pcap_mem", "lsn_pcap_nof_records",
+           "lsn_pcap_reset", "lsn_pcap_close", "lsn_phy_set_pcap_writer"]
 
 
 class Cell(C.Structure):
@@ -75,6 +77,27 @@ def build(verbose=False):
     return LIB_PATH
 
 
+def _preload_hip_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so.7 / libhsa-runtime64.so.1.  If this library pulled in
+    /opt/rocm's copies first and torch were imported afterwards, the process would hold two HIP/HSA runtimes and device
+    discovery fails.  When torch is installed, bind to its copy (one runtime per process, whichever is imported first)."""
+    import importlib.util
+    try:
+        with open("/proc/self/maps") as f:
+            if "libamdhip64" in f.read():
+                return
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        d = os.path.join(list(spec.submodule_search_locations)[0], "lib")
+        for n in ("libhsa-runtime64.so", "libamdhip64.so"):
+            p = os.path.join(d, n)
+            if os.path.exists(p):
+                C.CDLL(p, mode=C.RTLD_GLOBAL)
+    except OSError:
+        pass
+
+
 def lib():
     """The C-ABI library. Fails loudly when it has not been built: there is no other implementation to fall back to."""
     global _lib
@@ -82,6 +105,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("ltesniffer_amd: %s is missing - run ltesniffer_amd.build() / __graft_entry__.build() "
                                "(the HIP extension is the only implementation; there is no CPU fallback)" % LIB_PATH)
+        _preload_hip_runtime()
         L = C.CDLL(LIB_PATH)
         L.lsn_phy_create.argtypes = [C.POINTER(PhyCfg), C.POINTER(C.c_void_p)]
         L.lsn_phy_destroy.argtypes = [C.c_void_p]
@@ -117,6 +141,21 @@ def lib():
         L.lsn_kernel_name.argtypes = [C.c_int]
         L.lsn_kernel_name.restype = C.c_char_p
         L.lsn_version.restype = C.c_char_p
+        L.lsn_pcap_open.argtypes = [C.c_char_p]
+        L.lsn_pcap_open.restype = C.c_void_p
+        L.lsn_pcap_open_mem.restype = C.c_void_p
+        L.lsn_pcap_set_wall_clock.argtypes = [C.c_void_p, C.c_int]
+        L.lsn_pcap_set_wall_clock.restype = None
+        L.lsn_pcap_write.argtypes = [C.c_void_p, C.POINTER(PduCtx), C.c_void_p, C.c_uint32]
+        L.lsn_pcap_mem.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+        L.lsn_pcap_mem.restype = C.c_void_p
+        L.lsn_pcap_nof_records.argtypes = [C.c_void_p]
+        L.lsn_pcap_nof_records.restype = C.c_uint32
+        L.lsn_pcap_reset.argtypes = [C.c_void_p]
+        L.lsn_pcap_reset.restype = None
+        L.lsn_pcap_close.argtypes = [C.c_void_p]
+        L.lsn_pcap_close.restype = None
+        L.lsn_phy_set_pcap_writer.argtypes = [C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -125,6 +164,38 @@ def _check(rc, what):
     if rc != LSN_SUCCESS:
         raise RuntimeError("%s failed: %d%s" % (what, rc, " (no HIP device: this library has no CPU path)"
                                                 if rc == LSN_ERROR_NO_DEVICE else ""))
+
+
+class PcapWriter:
+    """Mirror of LTESniffer_pcap_writer (PcapWriter.h:39-51) on the native writer; path=None -> in-memory capture."""
+
+    def __init__(self, path=None, wall_clock=None):
+        L = lib()
+        self._h = L.lsn_pcap_open(path.encode()) if path else L.lsn_pcap_open_mem()
+        if not self._h:
+            raise RuntimeError("cannot open pcap %r" % path)
+        if wall_clock is not None:
+            L.lsn_pcap_set_wall_clock(self._h, int(wall_clock))
+
+    def write(self, ctx, pdu):
+        c = PduCtx(ctx["tti"], ctx["rnti"], ctx["direction"], ctx["rnti_type"], ctx.get("crc_ok", 1), 0, ctx.get("tb", 0), 0)
+        _check(lib().lsn_pcap_write(self._h, C.byref(c), pdu, len(pdu)), "pcap_write")
+
+    def bytes(self):
+        n = C.c_size_t()
+        p = lib().lsn_pcap_mem(self._h, C.byref(n))
+        return C.string_at(p, n.value)
+
+    def nof_records(self):
+        return lib().lsn_pcap_nof_records(self._h)
+
+    def reset(self):
+        lib().lsn_pcap_reset(self._h)
+
+    def close(self):
+        if self._h:
+            lib().lsn_pcap_close(self._h)
+            self._h = None
 
 
 class SubframeWorker:
@@ -161,7 +232,7 @@ class Phy:
 
     def __init__(self, nof_rx_antennas=2, nof_workers=20, skipSecondaryMetaFormats=False, metaFormatSplitRatio=0.99,
                  histogramThreshold=5, sink=None, mcs_tracking_mode=1, harq_mode=0, device=0, max_batch=64,
-                 max_turbo_iterations=12, default_rnti_intervals=True):
+                 max_turbo_iterations=12, default_rnti_intervals=True, pcapwriter=None):
         self.nof_rx_antennas = nof_rx_antennas
         self._cfg = PhyCfg(nof_rx_antennas, nof_workers, max_batch, int(skipSecondaryMetaFormats), metaFormatSplitRatio,
                            histogramThreshold, mcs_tracking_mode, harq_mode, device, max_turbo_iterations)
@@ -170,7 +241,11 @@ class Phy:
         self.pdus = []
         self._user_sink = sink
         self._cb = SINK_T(self._on_pdu)
-        _check(lib().lsn_phy_set_pdu_sink(self._h, self._cb, None), "set_pdu_sink")
+        self.pcapwriter = pcapwriter
+        if pcapwriter is not None:  # native consumer, like the reference's LTESniffer_pcap_writer* ctor argument
+            _check(lib().lsn_phy_set_pcap_writer(self._h, pcapwriter._h), "set_pcap_writer")
+        else:
+            _check(lib().lsn_phy_set_pdu_sink(self._h, self._cb, None), "set_pdu_sink")
         if default_rnti_intervals:
             _check(lib().lsn_phy_setup_default_rnti_intervals(self._h), "rnti intervals")
         self.cell = None

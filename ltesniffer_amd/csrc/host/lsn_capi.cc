@@ -190,6 +190,13 @@ int lsn_phy_set_pdu_sink(lsn_phy_t* phy, lsn_pdu_sink_t cb, void* user)
   return LSN_SUCCESS;
 }
 
+int lsn_phy_set_pcap_writer(lsn_phy_t* phy, lsn_pcap_t* p)
+{
+  if (!phy) return LSN_ERROR_INVALID_INPUTS;
+  phy->engine->setSink(p ? lsn_pcap_sink : nullptr, p);
+  return LSN_SUCCESS;
+}
+
 int lsn_phy_get_stats(lsn_phy_t* phy, lsn_blind_stats_t* out)
 {
   if (!phy || !out) return LSN_ERROR_INVALID_INPUTS;

@@ -1,0 +1,106 @@
+// lsn_pcap.cc - MAC-LTE (DLT 147) pcap writer, the native consumer of the PDU sink.
+// Replaces LTESniffer_pcap_writer (/root/reference/src/src/PcapWriter.cc:75-118: open, pack_and_write) and the srsRAN
+// primitives it calls (DLT_PCAP_Open, LTE_PCAP_MAC_WritePDU [srsRAN pcap.h, not in tree]); record layout pinned by the
+// reference's example captures (pcap_file_example/*.pcap).
+#include "../../../include/ltesniffer_amd.h"
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <sys/time.h>
+#include <vector>
+
+struct lsn_pcap {
+  FILE* f = nullptr;
+  std::vector<uint8_t> mem;
+  bool to_mem = false;
+  bool wall_clock = true;
+  uint32_t nrec = 0;
+  std::mutex mtx;  // PcapWriter.h:53
+  void put(const void* d, size_t n)
+  {
+    if (to_mem) mem.insert(mem.end(), (const uint8_t*)d, (const uint8_t*)d + n);
+    else if (f) fwrite(d, 1, n, f);
+  }
+  void header()
+  {
+    const uint32_t h[6] = {0xa1b2c3d4u, 0x00040002u, 0, 0, 65535, 147};  // MAC_LTE_DLT 147, PcapWriter.cc:77
+    put(h, sizeof(h));
+  }
+};
+
+extern "C" {
+
+lsn_pcap_t* lsn_pcap_open(const char* path)
+{
+  if (!path) return nullptr;
+  lsn_pcap* p = new lsn_pcap();
+  p->f = fopen(path, "wb");
+  if (!p->f) { delete p; return nullptr; }
+  p->header();
+  return p;
+}
+
+lsn_pcap_t* lsn_pcap_open_mem(void)
+{
+  lsn_pcap* p = new lsn_pcap();
+  p->to_mem = true;
+  p->wall_clock = false;  // deterministic captures: timestamps are zero
+  p->header();
+  return p;
+}
+
+void lsn_pcap_set_wall_clock(lsn_pcap_t* p, int on) { if (p) p->wall_clock = on != 0; }
+
+int lsn_pcap_write(lsn_pcap_t* p, const lsn_pdu_ctx_t* c, const uint8_t* pdu, uint32_t len)
+{
+  if (!p || !c || (!pdu && len)) return LSN_ERROR_INVALID_INPUTS;
+  uint8_t h[19];
+  const uint16_t fs = (uint16_t)((((c->tti / 10) & 0xFFF) << 4) | (c->tti % 10));  // PcapWriter.cc:102-103
+  h[0] = 1;  // FDD_RADIO, PcapWriter.cc:108
+  h[1] = c->direction;
+  h[2] = c->rnti_type;
+  h[3] = 0x02; h[4] = (uint8_t)(c->rnti >> 8); h[5] = (uint8_t)c->rnti;
+  h[6] = 0x03; h[7] = 0; h[8] = 0;
+  h[9] = 0x04; h[10] = (uint8_t)(fs >> 8); h[11] = (uint8_t)fs;
+  h[12] = 0x07; h[13] = c->crc_ok;
+  h[14] = 0x0a; h[15] = 0;
+  h[16] = 0x0f; h[17] = 0;
+  h[18] = 0x01;
+  uint32_t rec[4] = {0, 0, len + 19, len + 19};
+  if (p->wall_clock) {
+    struct timeval t;
+    gettimeofday(&t, nullptr);
+    rec[0] = (uint32_t)t.tv_sec; rec[1] = (uint32_t)t.tv_usec;
+  }
+  std::lock_guard<std::mutex> lk(p->mtx);
+  p->put(rec, sizeof(rec));
+  p->put(h, sizeof(h));
+  p->put(pdu, len);
+  p->nrec++;
+  return LSN_SUCCESS;
+}
+
+void lsn_pcap_sink(void* user, const lsn_pdu_ctx_t* ctx, const uint8_t* pdu, uint32_t len) { (void)lsn_pcap_write((lsn_pcap_t*)user, ctx, pdu, len); }
+
+const uint8_t* lsn_pcap_mem(lsn_pcap_t* p, size_t* len)
+{
+  if (!p || !len) return nullptr;
+  *len = p->mem.size();
+  return p->mem.data();
+}
+uint32_t lsn_pcap_nof_records(lsn_pcap_t* p) { return p ? p->nrec : 0; }
+void lsn_pcap_reset(lsn_pcap_t* p)
+{
+  if (!p) return;
+  std::lock_guard<std::mutex> lk(p->mtx);
+  if (p->to_mem) { p->mem.clear(); p->header(); }
+  p->nrec = 0;
+}
+void lsn_pcap_close(lsn_pcap_t* p)
+{
+  if (!p) return;
+  if (p->f) fclose(p->f);
+  delete p;
+}
+
+}  // extern "C"

@@ -36,6 +36,8 @@ def run_oracle(sc, tti0, iq, update_meta_period=0, taps=True, **okw):
 
 
 def gpu_records(phy):
+    if phy.pcapwriter is not None:
+        return oracle_records(parse_pcap(phy.pcapwriter.bytes()))
     return [la.mac_lte_record(ctx, pdu) for ctx, pdu in phy.pdus]
 
 
