@@ -251,10 +251,36 @@ bool pdsch_re_usable(const Cell& cell, uint32_t sf_idx, uint32_t l, uint32_t k)
   return true;
 }
 
+void cell_build_re_tables(Cell& cell)
+{
+  const uint32_t n = cell.nof_prb;
+  auto t = std::make_shared<std::vector<uint16_t>>((size_t)3 * 5 * 2 * n, (uint16_t)0);
+  const uint32_t cls_sf[3] = {0, 5, 1};
+  Cell plain = cell;
+  plain.re_count.reset();
+  for (uint32_t cl = 0; cl < 3; cl++)
+    for (uint32_t l0 = 0; l0 < 5; l0++)
+      for (uint32_t l = l0; l < 14; l++)
+        for (uint32_t prb = 0; prb < n; prb++) {
+          uint16_t c = 0;
+          for (uint32_t k = 12 * prb; k < 12 * prb + 12; k++) c += pdsch_re_usable(plain, cls_sf[cl], l, k) ? 1 : 0;
+          (*t)[((cl * 5 + l0) * 2 + l / 7) * n + prb] += c;
+        }
+  cell.re_count = t;
+}
+
 static uint32_t ra_dl_compute_nof_re(const Cell& cell, uint32_t sf_idx, uint32_t cfi, const PdschGrant& g)
 {
+  const uint32_t l0 = cfi + (cell.nof_prb <= 10 ? 1 : 0);
   uint32_t n = 0;
-  for (uint32_t l = cfi + (cell.nof_prb <= 10 ? 1 : 0); l < 14; l++)
+  if (cell.re_count && l0 < 5) {
+    const uint32_t cl = sf_idx == 0 ? 0 : (sf_idx == 5 ? 1 : 2);
+    const uint16_t* t0 = cell.re_count->data() + ((size_t)(cl * 5 + l0) * 2) * cell.nof_prb;
+    const uint16_t* t1 = t0 + cell.nof_prb;
+    for (uint32_t prb = 0; prb < cell.nof_prb; prb++) n += (g.prb_idx[0][prb] ? t0[prb] : 0u) + (g.prb_idx[1][prb] ? t1[prb] : 0u);
+    return n;
+  }
+  for (uint32_t l = l0; l < 14; l++)
     for (uint32_t prb = 0; prb < cell.nof_prb; prb++)
       if (g.prb_idx[l / 7][prb])
         for (uint32_t k = 12 * prb; k < 12 * prb + 12; k++) n += pdsch_re_usable(cell, sf_idx, l, k) ? 1 : 0;
@@ -308,6 +334,26 @@ bool dl_sniffer_ra_dl_dci_to_grant(const Cell& cell, uint32_t sf_idx, uint32_t c
   if (dci.format == FORMAT1C && (rnti_israr(dci.rnti) || dci.rnti == PRNTI))
     for (auto& tb : g.tb) tb.rv = 0;
   return true;
+}
+
+void dl_sniffer_ra_dl_dci_to_grant_both(const Cell& cell, uint32_t sf_idx, uint32_t cfi, const DciDl& dci, PdschGrant& g64, bool& ok64,
+                                        PdschGrant& g256, bool& ok256)
+{
+  g64 = PdschGrant();
+  ok64 = ok256 = false;
+  if (!ra_dl_grant_to_grant_prb_allocation(cell, dci, g64)) { g256 = g64; return; }
+  g256 = g64;  // the PRB set does not depend on the MCS table
+  ok64 = dl_sniffer_compute_tb(false, dci, g64);
+  ok256 = dl_sniffer_compute_tb(true, dci, g256);
+  if (!ok64 && !ok256) return;
+  const uint32_t nof_re = ra_dl_compute_nof_re(cell, sf_idx, cfi, g64);
+  const bool rv0 = dci.format == FORMAT1C && (rnti_israr(dci.rnti) || dci.rnti == PRNTI);
+  for (int t = 0; t < 2; t++) {
+    PdschGrant& g = t ? g256 : g64;
+    if (!(t ? ok256 : ok64)) continue;
+    g.nof_re = nof_re;
+    for (auto& tb : g.tb) { tb.nof_bits = tb.enabled ? (int)nof_re * tb.mod : 0; if (rv0) tb.rv = 0; }
+  }
 }
 
 bool ra_ul_dci_to_grant(const Cell& cell, const DciUl& d, PuschGrant& g)
@@ -428,9 +474,10 @@ Histogram::Histogram(uint32_t itemCount, uint32_t valueRange)
 void Histogram::add(uint16_t item, uint32_t nTimes)
 {
   while (nTimes-- > 0) {
-    if (rnti_histogram_ready) rnti_histogram[rnti_history[rnti_history_current]]--;
+    if (rnti_histogram_ready) { rnti_histogram[rnti_history[rnti_history_current]]--; total[rnti_history[rnti_history_current]]--; }
     rnti_history[rnti_history_current] = item;
     rnti_histogram[item]++;
+    total[item]++;
     if (++rnti_history_current == rnti_history_end) { rnti_histogram_ready = true; rnti_history_current = 0; }
   }
 }
@@ -438,7 +485,11 @@ void Histogram::add(uint16_t item, uint32_t nTimes)
 RNTIManager::RNTIManager(uint32_t nf, uint32_t maxCand, uint32_t thr)
     : nformats(nf), histograms(nf, Histogram(200 * (304 / 5), 65536)), evergreen(nf), forbidden(nf), active(65536, 0), reason(65536, 0),
       lastSeen(65536, 0), assocFormatIdx(65536, 0), nactive(0), timestamp(0), lifetime(10000), threshold(thr),
-      maxCandidatesPerStepPerFormat(maxCand), remainingCandidates(nf, (int32_t)maxCand) {}
+      maxCandidatesPerStepPerFormat(maxCand), remainingCandidates(nf, (int32_t)maxCand)
+{
+  totals.assign(65536, 0);
+  for (auto& h : histograms) h.setTotals(totals.data());
+}
 void RNTIManager::addCandidate(uint16_t rnti, uint32_t f) { histograms[f].add(rnti); remainingCandidates[f]--; }
 bool RNTIManager::isEvergreen(uint16_t rnti, uint32_t f) const { for (auto& i : evergreen[f]) if (i.matches(rnti)) return true; return false; }
 bool RNTIManager::isForbidden(uint16_t rnti, uint32_t f) const { for (auto& i : forbidden[f]) if (i.matches(rnti)) return true; return false; }
@@ -458,6 +509,8 @@ bool RNTIManager::validate(uint16_t rnti, uint32_t f)
     if (timestamp - lastSeen[rnti] < lifetime) return true;
     deactivateRNTI(rnti);
   }
+  // RNTIManager::validateByHistogram needs freq_UL + freq_bestDL > threshold; both are bounded by the sum over all formats
+  if (totals[rnti] <= threshold) return false;
   const uint32_t likely = getLikelyDlFormatIdx(rnti);
   if (f != 0 && f != likely) return false;
   const uint32_t ul = histograms[0].getFrequency(rnti), dl = likely ? histograms[likely].getFrequency(rnti) : 0;

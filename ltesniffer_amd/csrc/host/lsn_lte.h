@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstring>
 #include <list>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -24,7 +25,13 @@ constexpr uint16_t SIRNTI = 0xFFFF, PRNTI = 0xFFFE, MRNTI = 0xFFFD, RARNTI_START
 inline bool rnti_isuser(uint16_t r) { return r >= CRNTI_START && r <= CRNTI_END; }
 inline bool rnti_israr(uint16_t r) { return r >= RARNTI_START && r <= RARNTI_END; }
 
-struct Cell { uint32_t nof_prb = 0, nof_ports = 0, id = 0, phich_ng_x6 = 1; };
+struct Cell {
+  uint32_t nof_prb = 0, nof_ports = 0, id = 0, phich_ng_x6 = 1;
+  // optional acceleration table built by cell_build_re_tables(): PDSCH-capable REs per (subframe class, first PDSCH
+  // symbol l0 0..4, slot, PRB); class 0: subframe 0, 1: subframe 5, 2: any other (srsran_ra_dl_compute_nof_re [srsRAN])
+  std::shared_ptr<std::vector<uint16_t>> re_count;
+};
+void cell_build_re_tables(Cell& cell);
 
 // ---- DCI ----
 uint32_t dci_format_sizeof(const Cell& cell, DciFormat f);
@@ -47,6 +54,9 @@ struct PuschGrant { uint32_t L_prb = 0, n_prb = 0, mcs_idx = 0; int mod = 0, tbs
 bool dci_msg_unpack_pdsch(const Cell& cell, const uint8_t* bits, uint32_t nof_bits, DciFormat f, uint16_t rnti, DciDl& out);
 bool dci_msg_unpack_pusch(const Cell& cell, const uint8_t* bits, uint32_t nof_bits, uint16_t rnti, DciUl& out);
 bool dl_sniffer_ra_dl_dci_to_grant(const Cell& cell, uint32_t sf_idx, uint32_t cfi, bool use_tbs_index_alt, const DciDl& dci, PdschGrant& g);
+// both MCS tables at once (falcon_dci.c:284-310 calls the function above twice): same results as two separate calls
+void dl_sniffer_ra_dl_dci_to_grant_both(const Cell& cell, uint32_t sf_idx, uint32_t cfi, const DciDl& dci, PdschGrant& g64, bool& ok64,
+                                        PdschGrant& g256, bool& ok256);
 bool ra_ul_dci_to_grant(const Cell& cell, const DciUl& dci, PuschGrant& g);
 int dl_sniffer_config_mimo(const Cell& cell, DciFormat f, const DciDl& dci, PdschGrant& g);  // 0 ok
 bool pdsch_re_usable(const Cell& cell, uint32_t sf_idx, uint32_t l, uint32_t k);
@@ -62,12 +72,14 @@ class Histogram {
 public:
   Histogram(uint32_t itemCount, uint32_t valueRange);
   void add(uint16_t item, uint32_t nTimes = 1);
+  void setTotals(uint32_t* t) { total = t; }  // shared per-RNTI sum over all formats (fast reject in RNTIManager::validate)
   uint32_t getFrequency(uint16_t item) const { return rnti_histogram[item]; }
 private:
   std::vector<uint32_t> rnti_histogram;
   std::vector<uint16_t> rnti_history;
   uint32_t rnti_history_current, rnti_history_end;
   bool rnti_histogram_ready;
+  uint32_t* total = nullptr;
 };
 struct Interval { uint16_t start, end; bool matches(uint16_t v) const { return v >= start && v <= end; } };
 
@@ -94,7 +106,7 @@ private:
   std::vector<Histogram> histograms;
   std::vector<std::vector<Interval>> evergreen, forbidden;
   std::vector<uint8_t> active, reason;
-  std::vector<uint32_t> lastSeen, assocFormatIdx;
+  std::vector<uint32_t> lastSeen, assocFormatIdx, totals;
   uint32_t nactive, timestamp, lifetime, threshold, maxCandidatesPerStepPerFormat;
   std::vector<int32_t> remainingCandidates;
 };

@@ -1,0 +1,319 @@
+// lsn_search.cc - see lsn_search.h.  Product code (HIP-free): must not include anything from oracle/.
+#include "lsn_search.h"
+#include <algorithm>
+#include <cstring>
+#include <stdexcept>
+
+namespace lsn {
+
+const char* rnti_name(uint16_t r)
+{
+  if (r == SIRNTI) return "SI_RNTI";
+  if (r == PRNTI) return "P_RNTI";
+  if (r > RARNTI_START && r < RARNTI_END) return "RA_RNTI";
+  return "C_RNTI";
+}
+
+// ------------------------------------------------------------------------------------------------ search space
+void SearchSpace::init(const uint32_t n[3])
+{
+  std::memset(common, 0, sizeof(common));
+  for (int c = 0; c < 3; c++) {
+    nof_cce[c] = n[c];
+    // srsran_pdcch_common_locations_ncce [srsRAN]: L = 8, 4 inside the first 16 CCEs
+    for (int l = 3; l > 1; l--) {
+      const uint32_t L = 1u << l;
+      if (n[c] < L) continue;
+      const uint32_t lim = std::min(n[c], 16u) / L;
+      for (uint32_t i = 0; i < lim; i++) {
+        const uint32_t ncce = L * (i % (n[c] / L));
+        if (ncce + L <= n[c] && ncce < LSN_CCE_STRIDE) common[c][l][ncce] = 1;
+      }
+    }
+  }
+}
+
+uint32_t SearchSpace::validate(uint32_t cfi, uint32_t ncce, uint32_t l, uint32_t nsubframe, uint16_t rnti) const
+{
+  static const uint32_t ncand[4] = {6, 6, 2, 2};
+  const uint32_t n = nof_cce[cfi - 1];
+  const uint8_t(*cm)[LSN_CCE_STRIDE] = common[cfi - 1];
+  bool ue = false;
+  if (rnti_isuser(rnti)) ue = true;
+  else if (!(rnti_israr(rnti) || rnti >= MRNTI)) return 0;  // reserved interval or RNTI 0: no locations at all
+  auto member = [&](uint32_t lv, uint32_t Yk) -> bool {
+    if (cm[lv][ncce]) return true;
+    if (!ue) return false;
+    const uint32_t L = 1u << lv;
+    if (n < L || (ncce & (L - 1))) return false;
+    const uint32_t M = n / L, q = ncce / L;
+    if (q >= M) return false;
+    return (q + M - Yk % M) % M < ncand[lv];
+  };
+  uint32_t Yk = rnti;
+  if (ue)
+    for (uint32_t m = 0; m <= nsubframe; m++) Yk = (39827u * Yk) % 65537u;
+  if (!member(l, Yk)) return 0;
+  if (l > 0 && member(l - 1, Yk)) return 1;
+  return 2;
+}
+
+// ------------------------------------------------------------------------------------------------ FalconSearch
+FalconSearch::FalconSearch(uint32_t threshold, double split_ratio, bool skip_secondary)
+{
+  rnti_manager.reset(new RNTIManager(NOF_FORMATS, 304 / 5, threshold));  // PhyCommon.cc:11
+  meta_formats.reset(new DCIMetaFormats(NOF_FORMATS, split_ratio));
+  meta_formats->setSkipSecondaryMetaFormats(skip_secondary);
+}
+
+void FalconSearch::setupDefaultIntervals()
+{
+  rnti_manager->addEvergreen(RARNTI_START, RARNTI_END, FORMAT1A);
+  rnti_manager->addEvergreen(PRNTI, SIRNTI, FORMAT1A);
+  rnti_manager->addEvergreen(RARNTI_START, RARNTI_END, FORMAT1C);
+  rnti_manager->addEvergreen(PRNTI, SIRNTI, FORMAT1C);
+  for (uint32_t f = 0; f < NOF_FORMATS; f++) rnti_manager->addForbidden(0, 0, f);
+}
+
+void FalconSearch::setCell(const Cell& c, const uint32_t n[3])
+{
+  cell = c;
+  cell_build_re_tables(cell);
+  for (int i = 0; i < 3; i++) nof_cce[i] = n[i];
+  sspace.init(n);
+  std::vector<uint32_t> sizes;
+  for (int f = 0; f < NOF_FORMATS; f++) {
+    size_of_format[f] = dci_format_sizeof(cell, (DciFormat)f);
+    if (std::find(sizes.begin(), sizes.end(), size_of_format[f]) == sizes.end()) sizes.push_back(size_of_format[f]);
+  }
+  std::sort(sizes.begin(), sizes.end());
+  if (sizes.size() > LSN_MAX_SIZES || sizes.back() > 64) throw std::runtime_error("unsupported DCI size set");
+  nsizes = (uint32_t)sizes.size();
+  for (size_t i = 0; i < sizes.size(); i++) size_list[i] = sizes[i];
+  for (int f = 0; f < NOF_FORMATS; f++) size_index_of_format[f] = (int)(std::find(sizes.begin(), sizes.end(), size_of_format[f]) - sizes.begin());
+  rb_map_dl.assign(cell.nof_prb, 0);
+  rb_map_ul.assign(cell.nof_prb, 0);
+}
+
+// srsran_pdcch_decode_msg_limit_avg_llr_power (falcon_pdcch.c:110-170) as a lookup in the exhaustive candidate table
+void FalconSearch::decodeCandidate(const FalconLocation& loc, DciFormat format, DciCandidate& cand)
+{
+  const LsnCand& c = cur_cand[(size_t)loc.index * LSN_MAX_SIZES + size_index_of_format[format]];
+  nof_lookups++;
+  if (!c.flags) return;
+  cand.msg.bits = c.bits;
+  cand.msg.nof_bits = size_of_format[format];
+  cand.rnti = (uint16_t)c.rnti;
+  if (format == FORMAT0 || format == FORMAT1A) cand.msg.format = (c.bits >> 63) == 0 ? FORMAT0 : FORMAT1A;  // falcon_pdcch.c:147-148
+  else cand.msg.format = format;
+}
+
+// DCICollection::addCandidate (DCICollection.cc:97-298) + srsran_dci_msg_to_trace_timestamp (falcon_dci.c:148-352).
+// Both MCS tables' grants are computed here; which of them "exists" for the reference is resolved at commit time,
+// when the MCS-tracking state of this subframe is known.
+void FalconSearch::addCandidate(SubframeCtx& c, const DciCandidate& cand, uint32_t L, uint32_t ncce, uint32_t histval)
+{
+  const DciFormat fmt = cand.msg.format;
+  if (c.accepted.size() < 64 * 6) {
+    const uint32_t a[6] = {cand.rnti, (uint32_t)fmt, L, ncce, cand.msg.nof_bits, histval};
+    c.accepted.insert(c.accepted.end(), a, a + 6);
+  }
+  uint8_t payload[64] = {0};
+  cand.msg.unpack(payload);
+  if (fmt == FORMAT0) {
+    if (c.ul.size() >= 64) return;
+    c.ul.emplace_back();
+    UlEntry& u = c.ul.back();
+    u.rnti = cand.rnti; u.nof_bits = cand.msg.nof_bits; u.L = L; u.ncce = ncce; u.histval = histval;
+    u.dci.L = L; u.dci.ncce = ncce;
+    u.ok = payload[0] == 0 && dci_msg_unpack_pusch(cell, payload, cand.msg.nof_bits, cand.rnti, u.dci) && ra_ul_dci_to_grant(cell, u.dci, u.grant);
+    if (u.ok)
+      for (uint32_t i = 0; i < u.grant.L_prb; i++) {  // DCICollection.cc:275-280
+        if (rb_map_ul[u.grant.n_prb + i] != 0) ul_collision = true;
+        rb_map_ul[u.grant.n_prb + i] = cand.rnti;
+      }
+    return;
+  }
+  if (c.dl.size() >= 64) return;
+  c.dl.emplace_back();
+  DlEntry& e = c.dl.back();
+  e.rnti = cand.rnti; e.format = fmt; e.nof_bits = cand.msg.nof_bits; e.L = L; e.ncce = ncce; e.histval = histval;
+  e.dci.L = L; e.dci.ncce = ncce;
+  e.unpack_ok = dci_msg_unpack_pdsch(cell, payload, cand.msg.nof_bits, fmt, cand.rnti, e.dci);
+  if (e.unpack_ok) {
+    dl_sniffer_ra_dl_dci_to_grant_both(cell, c.sf_idx, c.cfi, e.dci, e.grant64, e.ok64, e.grant256, e.ok256);
+    for (uint32_t rb = 0; rb < cell.nof_prb; rb++)  // DCICollection.cc:215-223 (the PRB set does not depend on the MCS table)
+      if (e.grant64.prb_idx[0][rb]) {
+        if (rb_map_dl[rb] != 0) dl_collision = true;
+        rb_map_dl[rb] = cand.rnti;
+      }
+    for (int i = 0; i < 2; i++) {  // DCICollection.cc:252-259
+      if (e.grant64.tb[i].nof_bits <= 0) e.grant64.tb[i].enabled = false;
+      if (e.grant256.tb[i].nof_bits <= 0) e.grant256.tb[i].enabled = false;
+    }
+  }
+}
+
+// DCISearch::inspect_dci_location_recursively, DCISearch.cc:102-447
+int FalconSearch::inspect_dci_location_recursively(SubframeCtx& c, CceMap* cce_map, uint32_t ncce, uint32_t L, uint32_t max_depth, MetaFormat** metas,
+                                                   uint32_t nof_formats, uint32_t enable_discovery, const DciCandidate* parent_cand)
+{
+  int hist_max_format_idx = -1;
+  uint32_t hist_max_format_value = 0, nof_cand_above_threshold = 0;
+  FalconLocation* loc = cce_map[ncce].location[L];
+  if (!(loc && !loc->occupied && !loc->checked && loc->sufficient_power)) return 0;  // :124-127
+  DciCandidate cand[NOF_FORMATS];
+
+  for (uint32_t fi = 0; fi < nof_formats; fi++) {
+    decodeCandidate(*loc, metas[fi]->format, cand[fi]);
+    stats.nof_decoded_locations++;
+    if (cand[fi].msg.format == FORMAT0 && rnti_manager->getActivationReason(cand[fi].rnti) == RM_ACT_RAR) {  // :139-158
+      bool add = true;
+      for (auto& t : temp_dci0)
+        if (t.format == cand[fi].msg.format && t.rnti == cand[fi].rnti && t.ncce == ncce) add = false;
+      if (add && temp_dci0.size() < 64) temp_dci0.push_back({cand[fi].rnti, L, ncce, cand[fi].msg.format, cand[fi]});
+    }
+    if (metas[fi]->format != cand[fi].msg.format) { cand[fi].rnti = 0; continue; }  // :163
+    if (metas[fi]->format == FORMAT1C && cand[fi].rnti > RARNTI_END && cand[fi].rnti < PRNTI) { cand[fi].rnti = 0; continue; }  // :174
+    if (cand[fi].rnti > RARNTI_START && cand[fi].rnti < RARNTI_END)  // :181-197
+      if (metas[fi]->format != FORMAT1A && metas[fi]->format != FORMAT1C) { cand[fi].rnti = 0; continue; }
+    if (enable_discovery && parent_cand != nullptr && parent_cand[fi].rnti == cand[fi].rnti &&
+        !rnti_manager->isForbidden(cand[fi].rnti, metas[fi]->global_index))  // :200-211 (shortcut discovery)
+      return -((int)fi + 1);
+    cand[fi].search_space_match_result = sspace.validate(c.cfi, ncce, L, c.sf_idx, cand[fi].rnti);  // :214
+    if (cand[fi].search_space_match_result == 0) { cand[fi].rnti = 0; continue; }
+    if (rnti_manager->validateAndRefresh(cand[fi].rnti, metas[fi]->global_index)) {  // :245-250
+      nof_cand_above_threshold++;
+      hist_max_format_idx = (int)fi;
+      hist_max_format_value = rnti_manager->getFrequency(cand[fi].rnti, metas[fi]->global_index);
+    }
+  }
+  if (nof_cand_above_threshold > 1) {  // :255-280
+    hist_max_format_idx = -1;
+    uint32_t hmax = 0;
+    for (uint32_t fi = 0; fi < nof_formats; fi++)
+      if (cand[fi].rnti != 0) {
+        const uint32_t h = rnti_manager->getFrequency(cand[fi].rnti, metas[fi]->global_index);
+        if (h > hmax) { hmax = h; hist_max_format_idx = (int)fi; hist_max_format_value = h; }
+      }
+    if (hist_max_format_idx == -1) nof_cand_above_threshold = 0;
+  }
+  loc->checked = true;  // :282
+  int disamb = 0;
+  if (nof_cand_above_threshold > 0 && cand[hist_max_format_idx].search_space_match_result == 1) {  // :288-298
+    if (L > 0 && max_depth > 0)
+      disamb = inspect_dci_location_recursively(c, cce_map, ncce + (1u << (L - 1)), L - 1, max_depth - 1, metas, nof_formats, 0, nullptr);
+  } else if (nof_cand_above_threshold == 0) {  // :302-368
+    int rr = 0;
+    if (L > 0 && max_depth > 0) {
+      rr += inspect_dci_location_recursively(c, cce_map, ncce, L - 1, max_depth - 1, metas, nof_formats, enable_discovery, cand);
+      if (rr < 0) {
+        hist_max_format_idx = -rr - 1;
+        hist_max_format_value = rnti_manager->getFrequency(cand[hist_max_format_idx].rnti, metas[hist_max_format_idx]->global_index);
+        nof_cand_above_threshold = 1;
+        if (cand[hist_max_format_idx].search_space_match_result == 1) {
+          const uint32_t md = max_depth < 99 ? max_depth : 99;
+          disamb = inspect_dci_location_recursively(c, cce_map, ncce + (1u << (L - 1)), L - 1, md - 1, metas, nof_formats, 0, nullptr);
+        }
+        rnti_manager->activateAndRefresh(cand[hist_max_format_idx].rnti, metas[hist_max_format_idx]->global_index, RM_ACT_SHORTCUT);
+      } else {
+        rr += inspect_dci_location_recursively(c, cce_map, ncce + (1u << (L - 1)), L - 1, max_depth - 1, metas, nof_formats, enable_discovery, nullptr);
+      }
+    }
+    if (rr == 0) {
+      if (enable_discovery)
+        for (uint32_t fi = 0; fi < nof_formats; fi++)
+          if (cand[fi].rnti != 0) rnti_manager->addCandidate(cand[fi].rnti, metas[fi]->global_index);
+      return 0;
+    } else if (rr > 0) {
+      return rr;
+    }
+  }
+  if (nof_cand_above_threshold > 0) {  // :371-439
+    loc->used = true;
+    for (uint32_t ci = ncce; ci < ncce + (1u << L); ci++)
+      for (int a = 0; a < 4; a++)
+        if (cce_map[ci].location[a]) { cce_map[ci].location[a]->occupied = true; cce_map[ci].location[a]->checked = true; }
+    DciCandidate& best = cand[hist_max_format_idx];
+    rnti_manager->addCandidate(best.rnti, metas[hist_max_format_idx]->global_index);
+    metas[hist_max_format_idx]->hits++;
+    const uint32_t Ld = disamb > 0 ? L - 1 : L;
+    if (best.rnti != 0) {
+      bool add = true;
+      if (best.msg.format == FORMAT0)
+        for (auto& t : temp_dci0)
+          if (t.format == FORMAT0 && t.rnti == best.rnti && t.ncce == ncce) add = false;
+      if (add) addCandidate(c, best, Ld, ncce, hist_max_format_value);
+      for (auto& t : temp_dci0)  // :422-432
+        addCandidate(c, t.cand, t.L, t.ncce, rnti_manager->getFrequency(t.rnti, (uint32_t)t.format));
+      temp_dci0.clear();
+    }
+    return 1 + disamb;
+  }
+  return 0;
+}
+
+// DCISearch::recursive_blind_dci_search, DCISearch.cc:449-528
+void FalconSearch::recursive_blind_dci_search(SubframeCtx& c)
+{
+  CceMap cce_map[LSN_MAX_NUM_OF_CCE];
+  std::memset(cce_map, 0, sizeof(cce_map));
+  const uint32_t ncce = nof_cce[c.cfi - 1];
+  const uint32_t lim = std::min<uint32_t>(ncce, LSN_MAX_NUM_OF_CCE);
+  stats.nof_cce += ncce;
+  uint32_t k = 0;
+  for (int l = 3; l >= 0; l--) {  // srsran_pdcch_ue_locations_all_map, falcon_pdcch.c:321-356
+    const uint32_t L = 1u << l;
+    for (uint32_t i = 0; i < lim / L; i++)
+      if (k < LSN_MAX_LOC) {
+        FalconLocation& f = locations[k];
+        f = FalconLocation{(uint32_t)l, L * (i % (ncce / L)), false, false, false, true, k};
+        for (uint32_t m = f.ncce; m < f.ncce + L; m++) cce_map[m].location[l] = &f;
+        k++;
+      }
+  }
+  const uint32_t nloc = k;
+  stats.nof_locations += nloc;
+  for (uint32_t cc = 0; cc < lim; cc++) {  // srsran_pdcch_cce_avg_llr_power, falcon_pdcch.c:595-620
+    cce_map[cc].power = cur_ccepow[cc];
+    if (cce_map[cc].power < 0.7f)
+      for (int a = 0; a < 4; a++)
+        if (cce_map[cc].location[a]) cce_map[cc].location[a]->sufficient_power = false;
+  }
+  for (uint32_t i = 0; i < nloc; i++)
+    inspect_dci_location_recursively(c, cce_map, locations[i].ncce, locations[i].L, 99, meta_formats->getPrimaryMetaFormats(),
+                                     meta_formats->getNofPrimaryMetaFormats(), 1, nullptr);
+  if (!meta_formats->skipSecondaryMetaFormats()) {
+    for (uint32_t i = 0; i < nloc; i++) locations[i].checked = false;
+    for (uint32_t i = 0; i < nloc; i++)
+      inspect_dci_location_recursively(c, cce_map, locations[i].ncce, locations[i].L, 99, meta_formats->getSecondaryMetaFormats(),
+                                       meta_formats->getNofSecondaryMetaFormats(), 1, nullptr);
+  }
+  if (dl_collision) stats.nof_subframe_collisions_dw++;
+  if (ul_collision) stats.nof_subframe_collisions_up++;
+  uint32_t missed = 0;  // falcon_pdcch.c:561-593
+  for (uint32_t cc = 0; cc < lim; cc++) {
+    if (cce_map[cc].power < 0.7f) continue;
+    bool m = true;
+    for (int a = 0; a < 4; a++)
+      if (cce_map[cc].location[a] && cce_map[cc].location[a]->used) { m = false; break; }
+    if (m) missed++;
+  }
+  stats.nof_missed_cce += missed;
+  rnti_manager->stepTime();
+}
+
+void FalconSearch::search(SubframeCtx& c, const LsnCand* cand, const float* ccepow, bool update_meta)
+{
+  cur_cand = cand; cur_ccepow = ccepow;
+  temp_dci0.clear();
+  dl_collision = ul_collision = false;
+  std::fill(rb_map_dl.begin(), rb_map_dl.end(), 0);
+  std::fill(rb_map_ul.begin(), rb_map_ul.end(), 0);
+  if (update_meta) meta_formats->update_formats();  // SubframeWorker.cc:148-151
+  c.searched = c.snr_db > 6.0f;                     // DCISearch.cc:568-574
+  if (c.searched) recursive_blind_dci_search(c);
+  stats.nof_subframes++;
+}
+
+}  // namespace lsn

@@ -1,0 +1,100 @@
+// lsn_search.h - FALCON blind-DCI decision logic over an exhaustive candidate table (HIP-free host code).
+//   DCISearch::search / recursive_blind_dci_search / inspect_dci_location_recursively   /root/reference/src/src/DCISearch.cc:102-578
+//   srsran_pdcch_ue_locations_all_map, srsran_pdcch_cce_avg_llr_power (thresholding)     /root/reference/lib/src/phy/falcon_phch/falcon_pdcch.c:321-367,595-620
+//   DCICollection::addCandidate + srsran_dci_msg_to_trace_timestamp                      /root/reference/src/src/DCICollection.cc:97-298, falcon_dci.c:148-352
+// The GPU decodes EVERY (location, DCI size) pair of a subframe; srsran_pdcch_decode_msg_limit_avg_llr_power
+// (falcon_pdcch.c:110-170) becomes a table lookup and the order-dependent decisions below stay sequential on the host.
+#pragma once
+#include "lsn_lte.h"
+#include "lsn_types.h"
+#include <functional>
+#include <memory>
+#include <vector>
+
+namespace lsn {
+
+struct DciMsg {
+  unsigned long long bits = 0;  // payload bit i at position 63-i
+  uint32_t nof_bits = 0;
+  DciFormat format = FORMAT0;
+  void unpack(uint8_t* payload) const { for (uint32_t i = 0; i < nof_bits; i++) payload[i] = (uint8_t)((bits >> (63 - i)) & 1ull); }
+};
+struct DciCandidate { uint16_t rnti = 0; DciMsg msg; uint32_t search_space_match_result = 0; };
+
+struct DlEntry {  // DL_Sniffer_DCI_DL (Sniffer_dependency.h:90)
+  uint16_t rnti = 0; DciFormat format = FORMAT1; uint32_t nof_bits = 0, L = 0, ncce = 0, histval = 0;
+  DciDl dci; bool unpack_ok = false;
+  PdschGrant grant64, grant256; bool ok64 = false, ok256 = false;  // both tables computed; selection happens at commit
+  int job[2] = {-1, -1};                                          // decode job index per table
+};
+struct UlEntry { uint16_t rnti = 0; uint32_t nof_bits = 0, L = 0, ncce = 0, histval = 0; DciUl dci; PuschGrant grant; bool ok = false; };
+
+struct SubframeCtx {
+  uint32_t tti = 0, sf_idx = 0, sfn = 0, cfi = 0;
+  float snr_db = 0, cfo_hz = 0;
+  bool searched = false;
+  std::vector<DlEntry> dl;
+  std::vector<UlEntry> ul;
+  std::vector<uint32_t> accepted;  // 6 words per accepted DCI: rnti, format, L, ncce, nof_bits, histval
+  void reset(uint32_t tti_) { tti = tti_; sf_idx = tti_ % 10; sfn = (tti_ / 10) % 1024; cfi = 0; snr_db = cfo_hz = 0; searched = false; dl.clear(); ul.clear(); accepted.clear(); }
+};
+
+struct BlindStats { uint32_t nof_locations = 0, nof_decoded_locations = 0, nof_cce = 0, nof_missed_cce = 0, nof_subframes = 0, nof_subframe_collisions_dw = 0, nof_subframe_collisions_up = 0; };
+
+// closed-form 36.213 9.1.1 search-space membership (srsran_pdcch_validate_location, falcon_pdcch.c:223-250)
+class SearchSpace {
+public:
+  void init(const uint32_t nof_cce_per_cfi[3]);
+  // 0 invalid, 1 valid but ambiguous with aggregation level l-1 at the same CCE, 2 valid
+  uint32_t validate(uint32_t cfi, uint32_t ncce, uint32_t l, uint32_t nsubframe, uint16_t rnti) const;
+private:
+  uint32_t nof_cce[3] = {0, 0, 0};
+  uint8_t common[3][4][LSN_CCE_STRIDE];
+};
+
+class FalconSearch {
+public:
+  FalconSearch(uint32_t histogram_threshold, double split_ratio, bool skip_secondary);
+  void setCell(const Cell& cell, const uint32_t nof_cce_per_cfi[3]);
+  // cand: [LSN_MAX_LOC][LSN_MAX_SIZES] of this subframe, ccepow: [LSN_CCE_STRIDE]; c.cfi / c.snr_db / c.sf_idx must be set
+  void search(SubframeCtx& c, const LsnCand* cand, const float* ccepow, bool update_meta);
+  RNTIManager& rntiManager() { return *rnti_manager; }
+  DCIMetaFormats& metaFormats() { return *meta_formats; }
+  const BlindStats& getStats() const { return stats; }
+  uint32_t sizeOfFormat(int f) const { return size_of_format[f]; }
+  int sizeIndexOfFormat(int f) const { return size_index_of_format[f]; }
+  uint32_t nofSizes() const { return nsizes; }
+  const uint32_t* sizes() const { return size_list; }
+  void setupDefaultIntervals();  // LTESniffer_Core.cc:398-417
+  uint64_t nof_lookups = 0;
+
+private:
+  struct FalconLocation { uint32_t L, ncce; bool used, occupied, checked, sufficient_power; uint32_t index; };
+  struct CceMap { FalconLocation* location[4]; float power; };
+  struct TempDci0 { uint16_t rnti; uint32_t L, ncce; DciFormat format; DciCandidate cand; };
+  int inspect_dci_location_recursively(SubframeCtx& c, CceMap* cce_map, uint32_t ncce, uint32_t L, uint32_t max_depth, MetaFormat** meta_formats_,
+                                       uint32_t nof_formats, uint32_t enable_discovery, const DciCandidate* parent_cand);
+  void recursive_blind_dci_search(SubframeCtx& c);
+  void decodeCandidate(const FalconLocation& loc, DciFormat format, DciCandidate& cand);
+  void addCandidate(SubframeCtx& c, const DciCandidate& cand, uint32_t L, uint32_t ncce, uint32_t histval);
+
+  Cell cell;
+  uint32_t nof_cce[3] = {0, 0, 0};
+  SearchSpace sspace;
+  std::unique_ptr<RNTIManager> rnti_manager;
+  std::unique_ptr<DCIMetaFormats> meta_formats;
+  uint32_t size_of_format[NOF_FORMATS] = {0};
+  int size_index_of_format[NOF_FORMATS] = {0};
+  uint32_t size_list[LSN_MAX_SIZES] = {0}, nsizes = 0;
+  std::vector<TempDci0> temp_dci0;
+  std::vector<uint16_t> rb_map_dl, rb_map_ul;
+  bool dl_collision = false, ul_collision = false;
+  FalconLocation locations[LSN_MAX_LOC];
+  const LsnCand* cur_cand = nullptr;
+  const float* cur_ccepow = nullptr;
+  BlindStats stats;
+};
+
+const char* rnti_name(uint16_t r);  // DL_Sniffer_PDSCH.cc:1398-1418
+
+}  // namespace lsn

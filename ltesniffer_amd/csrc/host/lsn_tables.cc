@@ -53,14 +53,68 @@ void Engine::freeDevice()
 {
   for (void* p : dev_allocs) (void)hipFree(p);
   dev_allocs.clear();
-  auto hf = [](void* p) { if (p) (void)hipHostFree(p); };
-  hf(h_cand); hf(h_ccepow); hf(h_chest); hf(h_cfi); hf(h_rbp); hf(h_payload_pinned); hf(h_cbres_pinned);
-  h_cand = nullptr; h_ccepow = nullptr; h_chest = nullptr; h_cfi = nullptr; h_rbp = nullptr; h_payload_pinned = nullptr; h_cbres_pinned = nullptr;
-  h_payload_cap = h_cbres_cap = 0;
-  auto df = [](void* p) { if (p) (void)hipFree(p); };
-  df(d_jobs); df(d_cbs); df(d_cbres); df(d_prefix); df(d_llr16); df(d_payload);
-  d_jobs = nullptr; d_cbs = nullptr; d_cbres = nullptr; d_prefix = nullptr; d_llr16 = nullptr; d_payload = nullptr;
-  jobs_cap = cbs_cap = 0; prefix_cap = llr16_cap = payload_cap = 0;
+  for (void* p : host_allocs) (void)hipHostFree(p);
+  host_allocs.clear();
+  for (auto& ch : chunks) {
+    for (auto& e : ch.ev_a)
+      if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    ch = Chunk();
+  }
+  freeRunner(runner_c);
+  freeRunner(runner_s);
+  d_dphi = nullptr; d_iq_staging = nullptr; staging_sf = 0;
+  last_chunk = nullptr;
+}
+
+void Engine::freeRunner(JobRunner& r)
+{
+  auto df = [](auto*& p) { if (p) (void)hipFree(p); p = nullptr; };
+  auto hf = [](auto*& p) { if (p) (void)hipHostFree(p); p = nullptr; };
+  df(r.d_jobs); df(r.d_cbs); df(r.d_cbres); df(r.d_prefix); df(r.d_llr16); df(r.d_payload);
+  hf(r.h_payload_pinned); hf(r.h_cbres_pinned); hf(r.h_jobs_pinned); hf(r.h_cbs_pinned);
+  r.jobs_cap = r.cbs_cap = r.cbres_cap = r.prefix_cap = r.llr16_cap = r.payload_cap = r.h_payload_cap = r.h_cbres_cap = r.h_jobs_cap = r.h_cbs_cap = 0;
+  for (auto& e : r.ev)
+    if (e) { (void)hipEventDestroy(e); e = nullptr; }
+  if (r.stream) { (void)hipStreamDestroy(r.stream); r.stream = nullptr; }
+}
+
+void Engine::allocRunner(JobRunner& r)
+{
+  HIP_CHECK(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
+  for (auto& e : r.ev) HIP_CHECK(hipEventCreate(&e));
+}
+
+template <typename T>
+static T* halloc(std::vector<void*>& allocs, size_t n)
+{
+  void* h = nullptr;
+  HIP_CHECK(hipHostMalloc(&h, n * sizeof(T) + 16));
+  allocs.push_back(h);
+  return (T*)h;
+}
+
+void Engine::allocChunk(Chunk& ch)
+{
+  const size_t B = max_batch, A = cfg.nof_rx_antennas, P = cell.nof_ports;
+  ch.d_grid = dalloc<cf32>(dev_allocs, B * A * 14 * cd.nre);
+  ch.d_ce = dalloc<cf32>(dev_allocs, B * P * A * 14 * cd.nre);
+  ch.d_chest_raw = dalloc<float>(dev_allocs, B * A * P * 8);
+  ch.d_chest = dalloc<LsnChest>(dev_allocs, B);
+  ch.d_cfi = dalloc<uint32_t>(dev_allocs, B);
+  ch.d_sfidx = dalloc<uint32_t>(dev_allocs, B);
+  ch.d_pcfich_corr = dalloc<float>(dev_allocs, B * 3);
+  ch.d_llr = dalloc<float>(dev_allocs, B * LSN_LLR_STRIDE);
+  ch.d_ccepow = dalloc<float>(dev_allocs, B * LSN_CCE_STRIDE);
+  ch.d_cand = dalloc<LsnCand>(dev_allocs, B * LSN_MAX_LOC * LSN_MAX_SIZES);
+  ch.d_rbp = dalloc<float>(dev_allocs, B * 128);
+  ch.h_cand = halloc<LsnCand>(host_allocs, B * LSN_MAX_LOC * LSN_MAX_SIZES);
+  ch.h_ccepow = halloc<float>(host_allocs, B * LSN_CCE_STRIDE);
+  ch.h_chest = halloc<LsnChest>(host_allocs, B);
+  ch.h_cfi = halloc<uint32_t>(host_allocs, B);
+  ch.h_rbp = halloc<float>(host_allocs, B * 128);
+  ch.h_sfidx = halloc<uint32_t>(host_allocs, B);
+  ch.ctx.assign(B, SubframeCtx());
+  for (auto& e : ch.ev_a) HIP_CHECK(hipEventCreate(&e));
 }
 
 void Engine::buildTables()
@@ -147,16 +201,10 @@ void Engine::buildTables()
   }
   // distinct DCI sizes + the de-rate-matching rank of every Viterbi input position (36.212 5.1.4.2)
   {
-    std::vector<uint32_t> sizes;
-    for (int f = 0; f < NOF_FORMATS; f++) {
-      size_of_format[f] = dci_format_sizeof(cell, (DciFormat)f);
-      if (std::find(sizes.begin(), sizes.end(), size_of_format[f]) == sizes.end()) sizes.push_back(size_of_format[f]);
-    }
-    std::sort(sizes.begin(), sizes.end());
-    if (sizes.size() > LSN_MAX_SIZES || sizes.back() > 64) throw std::runtime_error("unsupported DCI size set");
+    search->setCell(cell, cd.nof_cce);
+    std::vector<uint32_t> sizes(search->sizes(), search->sizes() + search->nofSizes());
     cd.nsizes = (uint32_t)sizes.size();
     for (size_t i = 0; i < sizes.size(); i++) cd.sizes[i] = sizes[i];
-    for (int f = 0; f < NOF_FORMATS; f++) size_index_of_format[f] = (int)(std::find(sizes.begin(), sizes.end(), size_of_format[f]) - sizes.begin());
     std::vector<uint16_t> rank((size_t)LSN_MAX_SIZES * 3 * LSN_MAX_DCI_D, 0);
     for (size_t si = 0; si < sizes.size(); si++) {
       const int D = (int)sizes[si] + 16, R = (D + 31) / 32, KP = 32 * R, ND = KP - D;
@@ -211,27 +259,12 @@ void Engine::buildTables()
     }
     cd.crc_tab_a = upload(dev_allocs, ta); cd.crc_tab_b = upload(dev_allocs, tb);
   }
-  // batch buffers
-  const size_t B = max_batch, A = cfg.nof_rx_antennas;
-  d_grid = dalloc<cf32>(dev_allocs, B * A * 14 * cd.nre);
-  d_ce = dalloc<cf32>(dev_allocs, B * P * A * 14 * cd.nre);
-  d_chest_raw = dalloc<float>(dev_allocs, B * A * P * 8);
-  d_chest = dalloc<LsnChest>(dev_allocs, B);
-  d_cfi = dalloc<uint32_t>(dev_allocs, B);
-  d_sfidx = dalloc<uint32_t>(dev_allocs, B);
-  d_pcfich_corr = dalloc<float>(dev_allocs, B * 3);
-  d_llr = dalloc<float>(dev_allocs, B * LSN_LLR_STRIDE);
-  d_ccepow = dalloc<float>(dev_allocs, B * LSN_CCE_STRIDE);
-  d_cand = dalloc<LsnCand>(dev_allocs, B * LSN_MAX_LOC * LSN_MAX_SIZES);
-  d_rbp = dalloc<float>(dev_allocs, B * 128);
-  d_iq_staging = dalloc<cf32>(dev_allocs, B * A * cd.sflen);
-  HIP_CHECK(hipHostMalloc((void**)&h_cand, B * LSN_MAX_LOC * LSN_MAX_SIZES * sizeof(LsnCand)));
-  HIP_CHECK(hipHostMalloc((void**)&h_ccepow, B * LSN_CCE_STRIDE * sizeof(float)));
-  HIP_CHECK(hipHostMalloc((void**)&h_chest, B * sizeof(LsnChest)));
-  HIP_CHECK(hipHostMalloc((void**)&h_cfi, B * sizeof(uint32_t)));
-  HIP_CHECK(hipHostMalloc((void**)&h_rbp, B * 128 * sizeof(float)));
-  ctx.assign(B, SubframeCtx());
-  rb_map_dl.assign(nprb, 0); rb_map_ul.assign(nprb, 0);
+  // pipeline slots, decode runners, staging
+  for (auto& ch : chunks) allocChunk(ch);
+  allocRunner(runner_c);
+  allocRunner(runner_s);
+  staging_sf = max_batch * NSLOTS;
+  d_iq_staging = dalloc<cf32>(dev_allocs, staging_sf * cfg.nof_rx_antennas * cd.sflen);
 }
 
 }  // namespace lsn

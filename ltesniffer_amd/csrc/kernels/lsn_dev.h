@@ -2,27 +2,17 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "../host/lsn_types.h"
 
 struct cf32 { float r, i; };
 
 #define LSN_MAX_RX 2
 #define LSN_MAX_PORTS 2
 #define LSN_LLR_STRIDE 6400   // PDCCH LLR floats reserved per subframe (>= 8*787)
-#define LSN_CCE_STRIDE 96
-#define LSN_MAX_LOC 160       // falcon_ue_dl.h:39
-#define LSN_MAX_SIZES 8
-#define LSN_MAX_NUM_OF_CCE 84 // falcon_pdcch.h:36
 #define LSN_MAX_DCI_D 144     // payload + 16
 #define LSN_NEG_METRIC (-12000)
 #define LSN_LLR_CLIP 511
 #define LSN_EXT_CLIP 2047
-
-// one blind-decode result: (location, DCI size) of one subframe
-struct LsnCand {
-  unsigned long long bits;  // payload bit i at position 63-i
-  uint32_t rnti;            // CRC remainder
-  uint32_t flags;           // 1 = decoded, 0 = skipped (location out of range / insufficient power / all-zero LLRs)
-};
 
 // per-subframe channel estimation scalars produced on the device (the host adds snr_db / cfo_hz)
 struct LsnChest {
@@ -97,4 +87,4 @@ void lsn_launch_viterbi(const LsnCellDev& c, const float* llr, const float* pw, 
 void lsn_launch_rb_power(const LsnCellDev& c, const cf32* grid, float* rbp, uint32_t nsf, hipStream_t s);
 void lsn_launch_pdsch_prep(const LsnCellDev& c, const LsnGrantDev* g, uint16_t* prefix, uint32_t njobs, hipStream_t s);
 void lsn_launch_pdsch_demod(const LsnCellDev& c, const LsnGrantDev* g, const uint16_t* prefix, const cf32* grid, const cf32* ce, const LsnChest* ch, int16_t* llr, uint32_t njobs, hipStream_t s);
-void lsn_launch_turbo(const LsnCellDev& c, const LsnCbDev* cb, const int16_t* llr, uint8_t* payload, LsnCbRes* res, uint32_t ncb, hipStream_t s);
+void lsn_launch_turbo(const LsnCellDev& c, const LsnCbDev* cb, const int16_t* llr, uint8_t* payload, LsnCbRes* res, uint32_t ncb, uint32_t kmax, hipStream_t s);

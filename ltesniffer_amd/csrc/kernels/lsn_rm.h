@@ -1,6 +1,7 @@
 // lsn_rm.h - closed-form index arithmetic of the LTE turbo rate matcher (TS 36.212 5.1.4.1), usable on host and
-// device.  Instead of walking the circular buffer, every destination soft bit computes the rank it has among the
-// non-<NULL> entries after k0, so that de-rate-matching becomes a gather: d = sum_m e[rank + m*nn].
+// device.  The circular buffer w = v0 | interleave(v1, v2) is never materialised: for every buffer position (sub-block
+// column, row) the number of non-<NULL> entries in front of it is a closed form, so de-rate-matching is a gather
+// d[dest(j)] = sum_m e[eidx(j) + m*nn] with coalesced reads of e.
 #pragma once
 #include <stdint.h>
 #ifndef LSN_HD
@@ -12,55 +13,38 @@
 #endif
 
 struct LsnRmGeom {
-  int K, D, R, KP, ND, F, Ncb, nn, k0, cum_k0;
+  int K, D, R, KP, ND, F, Ncb, nn, nn0, k0, cum_k0;
   int pre01[33];  // pre01[c] = number of <NULL> entries of v0 (== v1) in columns < c
   int pre2[33];   // same for v2
   uint8_t cnt01[32];
+  uint8_t first2[32];
 };
 
-// 36.212 Table 5.1.4-1 inter-column permutation and its inverse
-LSN_HD int lsn_perm_tc_f(int c)
-{
-  const uint8_t p[32] = {0, 16, 8, 24, 4, 20, 12, 28, 2, 18, 10, 26, 6, 22, 14, 30, 1, 17, 9, 25, 5, 21, 13, 29, 3, 19, 11, 27, 7, 23, 15, 31};
-  return p[c];
-}
-LSN_HD int lsn_perm_tc_inv(int v)
-{
-  // P is the 5-bit bit reversal, which is an involution
-  return lsn_perm_tc_f(v);
-}
+// 36.212 Table 5.1.4-1 inter-column permutation = 5-bit bit reversal (an involution)
+LSN_HD int lsn_perm_tc_f(int c) { return ((c & 1) << 4) | ((c & 2) << 2) | (c & 4) | ((c & 8) >> 2) | ((c & 16) >> 4); }
 
-// number of <NULL>s of v0/v1 at positions < k (k = col*R + row)
-LSN_HD int lsn_rm_nb01(const LsnRmGeom& g, int k)
+// <NULL>s of v0/v1 at buffer positions before (col,row)
+LSN_HD int lsn_rm_nb01_cr(const LsnRmGeom& g, int col, int row)
 {
-  int col = k / g.R, row = k - col * g.R;
   if (col >= 32) return g.pre01[32];
-  int c = g.cnt01[col];
+  const int c = g.cnt01[col];
   return g.pre01[col] + (row < c ? row : c);
 }
-LSN_HD int lsn_rm_isnull01(const LsnRmGeom& g, int k)
+LSN_HD int lsn_rm_isnull01_cr(const LsnRmGeom& g, int col, int row) { return row < (int)g.cnt01[col]; }
+// <NULL>s of v2 before (col,row)
+LSN_HD int lsn_rm_nb2_cr(const LsnRmGeom& g, int col, int row)
 {
-  int col = k / g.R, row = k - col * g.R;
-  return row * 32 + lsn_perm_tc_f(col) < g.ND + g.F;
-}
-// number of <NULL>s of v2 at positions < k
-LSN_HD int lsn_rm_nb2(const LsnRmGeom& g, int k)
-{
-  int col = k / g.R, row = k - col * g.R;
   if (col >= 32) return g.pre2[32];
-  int first = (lsn_perm_tc_f(col) + 1 < g.ND) ? 1 : 0;  // the row-0 entry of this column is <NULL>
-  return g.pre2[col] + ((row > 0) ? first : 0);
+  return g.pre2[col] + ((row > 0) ? (int)g.first2[col] : 0);
 }
-// non-<NULL> entries of the circular buffer at indices < j
-LSN_HD int lsn_rm_cum(const LsnRmGeom& g, int j)
+// non-<NULL> entries in front of v0[k], v1[k], v2[k] in the circular buffer, k = col*R + row
+LSN_HD int lsn_rm_cum_v0(const LsnRmGeom& g, int col, int row) { return col * g.R + row - lsn_rm_nb01_cr(g, col, row); }
+LSN_HD int lsn_rm_cum_v1(const LsnRmGeom& g, int col, int row)
 {
-  if (j < g.KP) return j - lsn_rm_nb01(g, j);
-  int jp = j - g.KP, k = jp >> 1, odd = jp & 1;
-  int nn0 = g.KP - g.pre01[32];
-  int v = nn0 + (k - lsn_rm_nb01(g, k)) + (k - lsn_rm_nb2(g, k));
-  if (odd) v += lsn_rm_isnull01(g, k) ? 0 : 1;
-  return v;
+  const int k = col * g.R + row;
+  return g.nn0 + (k - lsn_rm_nb01_cr(g, col, row)) + (k - lsn_rm_nb2_cr(g, col, row));
 }
+LSN_HD int lsn_rm_cum_v2(const LsnRmGeom& g, int col, int row) { return lsn_rm_cum_v1(g, col, row) + (lsn_rm_isnull01_cr(g, col, row) ? 0 : 1); }
 
 LSN_HD void lsn_rm_geom(LsnRmGeom& g, int K, int F, int rv)
 {
@@ -71,30 +55,40 @@ LSN_HD void lsn_rm_geom(LsnRmGeom& g, int K, int F, int rv)
     int c01 = (T01 > p) ? (T01 - p + 31) / 32 : 0;
     g.cnt01[c] = (uint8_t)c01;
     g.pre01[c] = a01; a01 += c01;
-    int c2 = ((p + 1 < g.ND) ? 1 : 0) + ((p == 31 && g.ND > 0) ? 1 : 0);
+    g.first2[c] = (uint8_t)((p + 1 < g.ND) ? 1 : 0);  // the row-0 entry of this column of v2 is <NULL>
+    int c2 = (int)g.first2[c] + ((p == 31 && g.ND > 0) ? 1 : 0);
     g.pre2[c] = a2; a2 += c2;
   }
   g.pre01[32] = a01; g.pre2[32] = a2;
+  g.nn0 = g.KP - a01;
   g.nn = 3 * g.KP - 2 * a01 - a2;
-  g.k0 = g.R * (2 * ((g.Ncb + 8 * g.R - 1) / (8 * g.R)) * rv + 2);
-  g.cum_k0 = lsn_rm_cum(g, g.k0);
+  const int c0 = 2 * ((g.Ncb + 8 * g.R - 1) / (8 * g.R)) * rv + 2;  // k0 = R * c0: always at row 0 of a column
+  g.k0 = g.R * c0;
+  if (c0 < 32) {
+    g.cum_k0 = lsn_rm_cum_v0(g, c0, 0);
+  } else {
+    const int jp = g.k0 - g.KP, k = jp >> 1, col = k / g.R, row = k - col * g.R;
+    g.cum_k0 = (col >= 32) ? g.nn : ((jp & 1) ? lsn_rm_cum_v2(g, col, row) : lsn_rm_cum_v1(g, col, row));
+  }
+}
+
+// first e index that lands on buffer position with `cum` non-<NULL> predecessors
+LSN_HD int lsn_rm_eidx(const LsnRmGeom& g, int cum)
+{
+  int r = cum - g.cum_k0;
+  return r < 0 ? r + g.nn : r;
 }
 
 // rank (first e index) of destination (stream s in 0..2, index i in 0..D-1); -1 if the destination is <NULL>/filler
 LSN_HD int lsn_rm_rank(const LsnRmGeom& g, int s, int i)
 {
-  int j;
   if (s < 2) {
     if (i < g.F) return -1;
-    int y = i + g.ND, row = y >> 5, col = lsn_perm_tc_inv(y & 31), k = col * g.R + row;
-    j = (s == 0) ? k : g.KP + 2 * k;
-  } else {
-    int y2 = i + g.ND;
-    int z = y2 - 1; if (z < 0) z += g.KP;
-    int row = z >> 5, col = lsn_perm_tc_inv(z & 31), k = col * g.R + row;
-    j = g.KP + 2 * k + 1;
+    const int y = i + g.ND, row = y >> 5, col = lsn_perm_tc_f(y & 31);
+    return lsn_rm_eidx(g, s == 0 ? lsn_rm_cum_v0(g, col, row) : lsn_rm_cum_v1(g, col, row));
   }
-  int r = lsn_rm_cum(g, j) - g.cum_k0;
-  if (r < 0) r += g.nn;
-  return r;
+  int z = i + g.ND - 1;
+  if (z < 0) z += g.KP;
+  const int row = z >> 5, col = lsn_perm_tc_f(z & 31);
+  return lsn_rm_eidx(g, lsn_rm_cum_v2(g, col, row));
 }

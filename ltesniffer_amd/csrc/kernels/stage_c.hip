@@ -207,8 +207,20 @@ void lsn_launch_pdsch_demod(const LsnCellDev& c, const LsnGrantDev* g, const uin
 }
 
 // ------------------------------------------------------------------------------------------------ turbo decoder
-#define TB_S 16      // sub-block length between alpha checkpoints
-#define TB_MAXSB 6   // ceil(96/16)
+// One wavefront per code block, lane = trellis window (P = turbo_nwin(K) <= 64 windows of W = K/P steps), four code
+// blocks per CU (<= 40 KiB of LDS each, one wave per SIMD).
+// LDS: spp[K] packs the three rate-dematched soft streams of a position (10-bit signed fields: systematic | parity 1 |
+// parity 2), ext[K] holds extrinsic * 2 + hard decision.  Both are stored TRANSPOSED, idx(x) = (x % W) * P + x / W:
+// the in-order decoder reads consecutive lanes = consecutive addresses and the QPP-interleaved one is (nearly)
+// conflict free by the contention-free property of the QPP (36.212 5.1.3.2.3).
+// Schedule per constituent decoder: forward sweep in sub-blocks of TB_S steps (operands of a sub-block are fetched
+// from LDS in one burst, the recursion then runs on registers), alpha check-pointed at sub-block starts; backward
+// sub-block by sub-block: burst fetch, recompute the TB_S alphas into registers (packed int16), beta + LLR + extrinsic.
+// The interleaver addresses of the backward phase are generated by stepping the QPP recursion in reverse.
+// Window-boundary metrics of the previous iteration (next-iteration initialisation) stay in registers and move
+// between lanes with shuffles.
+#define TB_S 16      // sub-block length
+#define TB_CKPT 4    // check-points kept in LDS: sub-blocks 1 .. nsb-2 (nsb <= 6)
 
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 __device__ __forceinline__ int ext_scale(int x)
@@ -218,7 +230,7 @@ __device__ __forceinline__ int ext_scale(int x)
   a = a > LSN_EXT_CLIP ? LSN_EXT_CLIP : a;
   return x < 0 ? -a : a;
 }
-// a[0] is always 0 after normalisation and is not stored
+// a[0] is always 0 after normalisation
 __device__ __forceinline__ void step_fwd(int* a, int lsa, int lp)
 {
   const int g01 = lp, g10 = lsa, g11 = lsa + lp;
@@ -228,95 +240,165 @@ __device__ __forceinline__ void step_fwd(int* a, int lsa, int lp)
 }
 
 struct TurboLds {
-  int16_t *sys, *p1, *p2, *ext;
-  uint32_t* hard;
-  int16_t *ablk, *posblk, *ckpt, *ckpq, *nii;
+  uint32_t* spp;   // [K] sys | p1 << 10 | p2 << 20 (10-bit two's complement fields), transposed
+  int16_t* ext;    // [K] extrinsic * 2 + hard bit, transposed
+  int16_t* ckpt;   // [TB_CKPT][7][64]
 };
 
-// one constituent decoder over all windows (lane = window)
-template <bool IL>
-__device__ __forceinline__ void map_pass(const TurboLds& m, int lane, int K, int P, int W, int f1, int f2, const int16_t* par,
-                                         int16_t* nii_a, int16_t* nii_b, const int* beta_tail)
+__device__ __forceinline__ int tr_idx(int x, int W, int P, uint32_t magicW)
 {
-  if (lane >= P) return;
-  const int t0 = lane * W;
+  const int q = (int)__umulhi((uint32_t)x, magicW);
+  return (x - q * W) * P + q;
+}
+__device__ __forceinline__ int fld0(uint32_t w) { return (int)(w << 22) >> 22; }
+__device__ __forceinline__ int fld1(uint32_t w) { return (int)(w << 12) >> 22; }
+__device__ __forceinline__ int fld2(uint32_t w) { return (int)(w << 2) >> 22; }
+
+// GF(2) polynomial product a*b mod g (24-bit CRC generators, poly includes the x^24 term)
+__device__ __forceinline__ uint32_t mulmod24(uint32_t a, uint32_t b, uint32_t poly)
+{
+  uint32_t r = 0;
+#pragma unroll
+  for (int i = 23; i >= 0; i--) {
+    r <<= 1;
+    r ^= (r & 0x1000000u) ? poly : 0u;
+    r ^= ((b >> i) & 1u) ? a : 0u;
+  }
+  return r & 0xFFFFFFu;
+}
+
+// one constituent decoder over all windows (lane = window); nii_a / nii_b: boundary metrics (states 1..7) in registers
+template <bool IL>
+__device__ __forceinline__ void map_pass(const TurboLds& m, int lane, bool active, int K, int P, int W, uint32_t magicW, int f1, int f2,
+                                         int* nii_a, int* nii_b, const int* beta_tail)
+{
+  const int wl = active ? lane : 0;  // window this lane computes (idle lanes shadow window 0 and never store soft data)
+  const int t0 = wl * W;
   const int nsb = (W + TB_S - 1) / TB_S;
-  int a[8], b[8];
+  int a[8], b[8], a0[7];
   a[0] = 0;
-  if (lane == 0) { for (int s = 1; s < 8; s++) a[s] = LSN_NEG_METRIC; }
-  else { for (int s = 1; s < 8; s++) a[s] = nii_a[(s - 1) * 64 + lane]; }
+#pragma unroll
+  for (int s = 1; s < 8; s++) { a[s] = (wl == 0) ? LSN_NEG_METRIC : nii_a[s - 1]; a0[s - 1] = a[s]; }
   int pi = t0, gq = 0;
   const int twof2 = (2 * f2) % K;
   if (IL) {
     pi = (int)(((long long)f1 * t0 + (long long)f2 * t0 % K * t0) % K);
     gq = (int)(((long long)f1 + f2 + 2ll * f2 % K * t0) % K);
   }
-  // forward sweep: checkpoint the metrics (and the interleaver state) at every sub-block start
-  for (int sb = 0; sb < nsb; sb++) {
-    for (int s = 1; s < 8; s++) m.ckpt[(sb * 7 + (s - 1)) * 64 + lane] = (int16_t)a[s];
-    if (IL) { m.ckpq[(sb * 2 + 0) * 64 + lane] = (int16_t)pi; m.ckpq[(sb * 2 + 1) * 64 + lane] = (int16_t)gq; }
-    const int tend = (sb + 1) * TB_S < W ? (sb + 1) * TB_S : W;
-    for (int t = sb * TB_S; t < tend; t++) {
-      const int pos = IL ? pi : t0 + t;
-      step_fwd(a, (int)m.sys[pos] + (int)m.ext[pos], (int)par[t0 + t]);
-      if (IL) { pi += gq; pi = pi >= K ? pi - K : pi; gq += twof2; gq = gq >= K ? gq - K : gq; }
+  int g[TB_S];  // operands of one sub-block: lsa (low 16 bits) | lp << 16
+  // ---- forward sweep over sub-blocks 0 .. nsb-2 (the last one is covered by the recompute below) ----
+  for (int sb = 0; sb + 1 < nsb; sb++) {
+    if (sb >= 1) {
+#pragma unroll
+      for (int s = 1; s < 8; s++) m.ckpt[((sb - 1) * 7 + (s - 1)) * 64 + lane] = (int16_t)a[s];
     }
+    const int tb = sb * TB_S;
+#pragma unroll
+    for (int u = 0; u < TB_S; u++) {
+      const int nat = (tb + u) * P + wl;
+      if (IL) {
+        const int idx = tr_idx(pi, W, P, magicW);
+        pi += gq; pi = pi >= K ? pi - K : pi; gq += twof2; gq = gq >= K ? gq - K : gq;
+        g[u] = ((fld0(m.spp[idx]) + ((int)m.ext[idx] >> 1)) & 0xFFFF) | (fld2(m.spp[nat]) << 16);
+      } else {
+        const uint32_t w = m.spp[nat];
+        g[u] = ((fld0(w) + ((int)m.ext[nat] >> 1)) & 0xFFFF) | (fld1(w) << 16);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < TB_S; u++) step_fwd(a, (int)(g[u] << 16) >> 16, g[u] >> 16);
   }
-  int a_end[8];
-  for (int s = 0; s < 8; s++) a_end[s] = a[s];
+  if (IL) {  // interleaver state -> end of the window
+    for (int t = (nsb - 1) * TB_S; t < W; t++) { pi += gq; pi = pi >= K ? pi - K : pi; gq += twof2; gq = gq >= K ? gq - K : gq; }
+  }
+  int a_end[7];
   b[0] = 0;
-  if (lane == P - 1) { for (int s = 1; s < 8; s++) b[s] = beta_tail[s]; }
-  else { for (int s = 1; s < 8; s++) b[s] = nii_b[(s - 1) * 64 + lane]; }
-  // backward sweep, sub-block by sub-block: recompute alphas into LDS, then run beta + LLR
+#pragma unroll
+  for (int s = 1; s < 8; s++) b[s] = (wl == P - 1) ? beta_tail[s] : nii_b[s - 1];
+  // ---- backward, sub-block by sub-block ----
+  int ix[TB_S];          // LDS index of the systematic / extrinsic value of each step
+  uint32_t A[TB_S][4];   // alphas of the sub-block, packed int16: (a1,a2) (a3,a4) (a5,a6) (a7)
   for (int sb = nsb - 1; sb >= 0; sb--) {
-    a[0] = 0;
-    for (int s = 1; s < 8; s++) a[s] = m.ckpt[(sb * 7 + (s - 1)) * 64 + lane];
-    if (IL) { pi = m.ckpq[(sb * 2 + 0) * 64 + lane]; gq = m.ckpq[(sb * 2 + 1) * 64 + lane]; }
-    const int tbeg = sb * TB_S, tend = (sb + 1) * TB_S < W ? (sb + 1) * TB_S : W;
-    for (int t = tbeg; t < tend; t++) {
-      const int u = t - tbeg;
-      const int pos = IL ? pi : t0 + t;
-      for (int s = 1; s < 8; s++) m.ablk[(u * 7 + (s - 1)) * 64 + lane] = (int16_t)a[s];
-      m.posblk[u * 64 + lane] = (int16_t)pos;
-      step_fwd(a, (int)m.sys[pos] + (int)m.ext[pos], (int)par[t0 + t]);
-      if (IL) { pi += gq; pi = pi >= K ? pi - K : pi; gq += twof2; gq = gq >= K ? gq - K : gq; }
+    const int tb = sb * TB_S, n = (tb + TB_S < W) ? TB_S : W - tb;
+    if (sb + 1 < nsb) {
+      a[0] = 0;
+      if (sb == 0) {
+#pragma unroll
+        for (int s = 1; s < 8; s++) a[s] = a0[s - 1];
+      } else {
+#pragma unroll
+        for (int s = 1; s < 8; s++) a[s] = m.ckpt[((sb - 1) * 7 + (s - 1)) * 64 + lane];
+      }
     }
-    for (int t = tend - 1; t >= tbeg; t--) {
-      const int u = t - tbeg;
-      const int pos = m.posblk[u * 64 + lane];
-      const int lsa = (int)m.sys[pos] + (int)m.ext[pos], lp = (int)par[t0 + t];
-      int al[8];
-      al[0] = 0;
-      for (int s = 1; s < 8; s++) al[s] = m.ablk[(u * 7 + (s - 1)) * 64 + lane];
-      const int g01 = lp, g10 = lsa, g11 = lsa + lp;
-      // branch metrics + beta of the successor, per state: x0 = input 0, x1 = input 1
-      const int x00 = b[0], x01 = b[4] + g11;
-      const int x10 = b[4], x11 = b[0] + g11;
-      const int x20 = b[5] + g01, x21 = b[1] + g10;
-      const int x30 = b[1] + g01, x31 = b[5] + g10;
-      const int x40 = b[2] + g01, x41 = b[6] + g10;
-      const int x50 = b[6] + g01, x51 = b[2] + g10;
-      const int x60 = b[7], x61 = b[3] + g11;
-      const int x70 = b[3], x71 = b[7] + g11;
-      int m0 = imax(imax(imax(al[0] + x00, al[1] + x10), imax(al[2] + x20, al[3] + x30)),
-                    imax(imax(al[4] + x40, al[5] + x50), imax(al[6] + x60, al[7] + x70)));
-      int m1 = imax(imax(imax(al[0] + x01, al[1] + x11), imax(al[2] + x21, al[3] + x31)),
-                    imax(imax(al[4] + x41, al[5] + x51), imax(al[6] + x61, al[7] + x71)));
-      const int L = m1 - m0;
-      m.ext[pos] = (int16_t)ext_scale(L - lsa);
-      if (IL && L > 0) atomicOr(&m.hard[pos >> 5], 1u << (pos & 31));
-      const int n0 = imax(x00, x01);
-      b[1] = imax(x10, x11) - n0; b[2] = imax(x20, x21) - n0; b[3] = imax(x30, x31) - n0; b[4] = imax(x40, x41) - n0;
-      b[5] = imax(x50, x51) - n0; b[6] = imax(x60, x61) - n0; b[7] = imax(x70, x71) - n0;
-      b[0] = 0;
+    // operand burst, last step first (the QPP recursion runs in reverse)
+#pragma unroll
+    for (int u = TB_S - 1; u >= 0; u--) {
+      if (u < n) {
+        const int nat = (tb + u) * P + wl;
+        if (IL) {
+          gq -= twof2; gq = gq < 0 ? gq + K : gq; pi -= gq; pi = pi < 0 ? pi + K : pi;
+          const int idx = tr_idx(pi, W, P, magicW);
+          ix[u] = idx;
+          g[u] = ((fld0(m.spp[idx]) + ((int)m.ext[idx] >> 1)) & 0xFFFF) | (fld2(m.spp[nat]) << 16);
+        } else {
+          const uint32_t w = m.spp[nat];
+          ix[u] = nat;
+          g[u] = ((fld0(w) + ((int)m.ext[nat] >> 1)) & 0xFFFF) | (fld1(w) << 16);
+        }
+      }
+    }
+    // recompute the alphas of this sub-block into registers
+#pragma unroll
+    for (int u = 0; u < TB_S; u++) {
+      if (u < n) {
+        A[u][0] = ((uint32_t)a[1] & 0xFFFFu) | ((uint32_t)a[2] << 16);
+        A[u][1] = ((uint32_t)a[3] & 0xFFFFu) | ((uint32_t)a[4] << 16);
+        A[u][2] = ((uint32_t)a[5] & 0xFFFFu) | ((uint32_t)a[6] << 16);
+        A[u][3] = (uint32_t)a[7];
+        step_fwd(a, (int)(g[u] << 16) >> 16, g[u] >> 16);
+      }
+    }
+    if (sb == nsb - 1) {
+#pragma unroll
+      for (int s = 1; s < 8; s++) a_end[s - 1] = a[s];
+    }
+    // beta recursion + LLR + extrinsic
+#pragma unroll
+    for (int u = TB_S - 1; u >= 0; u--) {
+      if (u < n) {
+        const int lsa = (int)(g[u] << 16) >> 16, lp = g[u] >> 16;
+        const int al1 = (int)(A[u][0] << 16) >> 16, al2 = (int)A[u][0] >> 16, al3 = (int)(A[u][1] << 16) >> 16, al4 = (int)A[u][1] >> 16;
+        const int al5 = (int)(A[u][2] << 16) >> 16, al6 = (int)A[u][2] >> 16, al7 = (int)A[u][3];
+        const int g01 = lp, g10 = lsa, g11 = lsa + lp;
+        // branch metrics + beta of the successor, per state: x0 = input 0, x1 = input 1
+        const int x00 = b[0], x01 = b[4] + g11;
+        const int x10 = b[4], x11 = b[0] + g11;
+        const int x20 = b[5] + g01, x21 = b[1] + g10;
+        const int x30 = b[1] + g01, x31 = b[5] + g10;
+        const int x40 = b[2] + g01, x41 = b[6] + g10;
+        const int x50 = b[6] + g01, x51 = b[2] + g10;
+        const int x60 = b[7], x61 = b[3] + g11;
+        const int x70 = b[3], x71 = b[7] + g11;
+        const int m0 = imax(imax(imax(x00, al1 + x10), imax(al2 + x20, al3 + x30)), imax(imax(al4 + x40, al5 + x50), imax(al6 + x60, al7 + x70)));
+        const int m1 = imax(imax(imax(x01, al1 + x11), imax(al2 + x21, al3 + x31)), imax(imax(al4 + x41, al5 + x51), imax(al6 + x61, al7 + x71)));
+        const int L = m1 - m0;
+        if (active) m.ext[ix[u]] = (int16_t)((ext_scale(L - lsa) << 1) | (L > 0 ? 1 : 0));
+        const int n0 = imax(x00, x01);
+        b[1] = imax(x10, x11) - n0; b[2] = imax(x20, x21) - n0; b[3] = imax(x30, x31) - n0; b[4] = imax(x40, x41) - n0;
+        b[5] = imax(x50, x51) - n0; b[6] = imax(x60, x61) - n0; b[7] = imax(x70, x71) - n0;
+        b[0] = 0;
+      }
     }
   }
-  // publish the window boundaries for the next iteration (all lanes have consumed theirs: single wavefront, in order)
-  if (lane + 1 < P) for (int s = 1; s < 8; s++) nii_a[(s - 1) * 64 + lane + 1] = (int16_t)a_end[s];
-  if (lane > 0) for (int s = 1; s < 8; s++) nii_b[(s - 1) * 64 + lane - 1] = (int16_t)b[s];
+  // next-iteration initialisation: window p starts from the end of window p-1 and ends at the start of window p+1
+#pragma unroll
+  for (int s = 1; s < 8; s++) {
+    nii_a[s - 1] = __shfl_up(a_end[s - 1], 1);
+    nii_b[s - 1] = __shfl_down(b[s], 1);
+  }
 }
 
-__device__ __forceinline__ void tail_beta(const int16_t* ts, const int16_t* tp, int* beta)
+__device__ __forceinline__ void tail_beta(const int* ts, const int* tp, int* beta)
 {
   int b[8], bn[8];
   for (int S = 0; S < 8; S++) b[S] = S == 0 ? 0 : LSN_NEG_METRIC;
@@ -324,7 +406,7 @@ __device__ __forceinline__ void tail_beta(const int16_t* ts, const int16_t* tp, 
     for (int S = 0; S < 8; S++) {
       int s1 = (S >> 2) & 1, s2 = (S >> 1) & 1, s3 = S & 1;
       int u = s2 ^ s3, z = s1 ^ s3, Sn = (s1 << 1) | s2;
-      bn[S] = b[Sn] + (u ? (int)ts[t] : 0) + (z ? (int)tp[t] : 0);
+      bn[S] = b[Sn] + (u ? ts[t] : 0) + (z ? tp[t] : 0);
     }
     for (int S = 0; S < 8; S++) b[S] = bn[S];
   }
@@ -339,79 +421,108 @@ __device__ __forceinline__ int turbo_nwin(int K)
 }
 
 __global__ __launch_bounds__(64) void k_turbo(LsnCellDev c, const LsnCbDev* __restrict__ cbs, const int16_t* __restrict__ llr,
-                                              uint8_t* __restrict__ payload, LsnCbRes* __restrict__ res)
+                                              uint8_t* __restrict__ payload, LsnCbRes* __restrict__ res, uint32_t kmax)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ LsnRmGeom geom;
   const LsnCbDev cb = cbs[blockIdx.x];
-  const int lane = threadIdx.x, K = (int)cb.K, D = K + 4, Dp = (D + 7) & ~7, F = (int)cb.F;
+  const int lane = threadIdx.x, K = (int)cb.K, F = (int)cb.F;
+  const int P = turbo_nwin(K), W = K / P;
+  const uint32_t magicW = (uint32_t)(0x100000000ull / (unsigned)W) + (((W & (W - 1)) == 0) ? 0u : 1u);
+  const bool active = lane < P;
   TurboLds m;
-  m.sys = (int16_t*)smem; m.p1 = m.sys + Dp; m.p2 = m.p1 + Dp; m.ext = m.p2 + Dp;
-  m.hard = (uint32_t*)(m.ext + Dp);
-  const int nhw = (K + 31) / 32;
-  m.ablk = (int16_t*)(m.hard + ((nhw + 3) & ~3));
-  m.posblk = m.ablk + TB_S * 7 * 64;
-  m.ckpt = m.posblk + TB_S * 64;
-  m.ckpq = m.ckpt + TB_MAXSB * 7 * 64;
-  m.nii = m.ckpq + TB_MAXSB * 2 * 64;  // [4][7][64]: a1, b1, a2, b2
+  m.spp = (uint32_t*)smem; m.ext = (int16_t*)(m.spp + kmax); m.ckpt = m.ext + kmax;
+  // the check-point area doubles as scratch for the rate-matcher geometry and the 12 termination values
+  LsnRmGeom& geom = *(LsnRmGeom*)m.ckpt;
+  int* tail = (int*)(m.ckpt + 1024);
   if (lane == 0) lsn_rm_geom(geom, K, F, (int)cb.rv);
+  for (int i = lane; i < K; i += 64) { m.spp[i] = 0u; m.ext[i] = 0; }
   __syncthreads();
-  // ---- rate de-matching as a gather (36.212 5.1.4.1.2), soft-combining repeated bits, clip to +-511 ----
-  const int16_t* e = llr + cb.e_off;
-  const int E = (int)cb.E, nn = geom.nn;
-  for (int o = lane; o < 3 * D; o += 64) {
-    int s = o / D, i = o - s * D;
-    int r = lsn_rm_rank(geom, s, i);
-    int v;
-    if (r < 0) {
-      v = -LSN_LLR_CLIP;  // filler bits are known zeros
-    } else {
+  // ---- rate de-matching as a gather over the circular buffer (36.212 5.1.4.1.2): lanes walk the rows of one sub-block
+  //      column, so the e[] reads are contiguous; repeated bits are soft-combined, results clipped to +-511 ----
+  {
+    const int16_t* e = llr + cb.e_off;
+    const int E = (int)cb.E, nn = geom.nn, R = geom.R, ND = geom.ND, KP = geom.KP, nn0 = geom.nn0;
+    auto gather = [&](int cum) -> int {
       int acc = 0;
-      for (int k = r; k < E; k += nn) acc += (int)e[k];
-      v = acc > LSN_LLR_CLIP ? LSN_LLR_CLIP : (acc < -LSN_LLR_CLIP ? -LSN_LLR_CLIP : acc);
+      for (int k = lsn_rm_eidx(geom, cum); k < E; k += nn) acc += (int)e[k];
+      return acc > LSN_LLR_CLIP ? LSN_LLR_CLIP : (acc < -LSN_LLR_CLIP ? -LSN_LLR_CLIP : acc);
+    };
+    auto put = [&](int s, int i, int v) {
+      if (i < K) atomicOr(&m.spp[tr_idx(i, W, P, magicW)], ((uint32_t)v & 0x3FFu) << (10 * s)); else tail[s * 4 + (i - K)] = v;
+    };
+    for (int i = lane; i < F; i += 64) { put(0, i, -LSN_LLR_CLIP); put(1, i, -LSN_LLR_CLIP); }  // filler bits are known zeros
+    for (int col = 0; col < 32; col++) {
+      const int p = lsn_perm_tc_f(col), c01 = (int)geom.cnt01[col];
+      const int base01 = geom.pre01[col], base2 = geom.pre2[col], f2c = (int)geom.first2[col];
+      for (int row = lane; row < R; row += 64) {
+        const int k = col * R + row, y = row * 32 + p;
+        const int nb01 = base01 + (row < c01 ? row : c01), nb2 = base2 + (row > 0 ? f2c : 0);
+        const bool null01 = row < c01;
+        const int cum1 = nn0 + (k - nb01) + (k - nb2);
+        if (!null01) {
+          put(0, y - ND, gather(k - nb01));
+          put(1, y - ND, gather(cum1));
+        }
+        const int i2 = (y + 1 == KP ? 0 : y + 1) - ND;
+        if (i2 >= 0) put(2, i2, gather(cum1 + (null01 ? 0 : 1)));
+      }
     }
-    (s == 0 ? m.sys : (s == 1 ? m.p1 : m.p2))[i] = (int16_t)v;
   }
-  for (int i = lane; i < K; i += 64) m.ext[i] = 0;
-  for (int i = lane; i < 4 * 7 * 64; i += 64) m.nii[i] = 0;
   __syncthreads();
-  // ---- termination (36.212 5.1.3.2.2) ----
+  // ---- termination (36.212 5.1.3.2.2): tail[s*4 + j] = stream s at position K + j ----
   int bt1[8], bt2[8];
   {
-    int16_t ts1[3] = {m.sys[K], m.p2[K], m.p1[K + 1]}, tp1[3] = {m.p1[K], m.sys[K + 1], m.p2[K + 1]};
-    int16_t ts2[3] = {m.sys[K + 2], m.p2[K + 2], m.p1[K + 3]}, tp2[3] = {m.p1[K + 2], m.sys[K + 3], m.p2[K + 3]};
+    const int *s4 = tail, *q1 = tail + 4, *q2 = tail + 8;
+    int ts1[3] = {s4[0], q2[0], q1[1]}, tp1[3] = {q1[0], s4[1], q2[1]};
+    int ts2[3] = {s4[2], q2[2], q1[3]}, tp2[3] = {q1[2], s4[3], q2[3]};
     tail_beta(ts1, tp1, bt1);
     tail_beta(ts2, tp2, bt2);
   }
-  const int P = turbo_nwin(K), W = K / P;
-  const uint32_t* tab = cb.crc_b ? c.crc_tab_b : c.crc_tab_a;
+  __syncthreads();  // scratch is dead from here on: the area becomes the check-point store
+  const uint32_t poly = cb.crc_b ? 0x1800063u : 0x1864CFBu;
+  // weight of this lane's window in the block polynomial: x^((P-1-lane) W) mod g
+  const uint32_t cw = active ? (cb.crc_b ? c.crc_tab_b : c.crc_tab_a)[(P - 1 - lane) * W] : 0u;
+  int na1[7], nb1[7], na2[7], nb2[7];
+#pragma unroll
+  for (int s = 0; s < 7; s++) { na1[s] = 0; nb1[s] = 0; na2[s] = 0; nb2[s] = 0; }
   int it = 0;
   bool ok = false;
   while (it < (int)cb.max_iter && !ok) {
-    map_pass<false>(m, lane, K, P, W, (int)cb.f1, (int)cb.f2, m.p1, m.nii, m.nii + 7 * 64, bt1);
-    for (int i = lane; i < nhw; i += 64) m.hard[i] = 0;
+    map_pass<false>(m, lane, active, K, P, W, magicW, (int)cb.f1, (int)cb.f2, na1, nb1, bt1);
     __syncthreads();
-    map_pass<true>(m, lane, K, P, W, (int)cb.f1, (int)cb.f2, m.p2, m.nii + 14 * 64, m.nii + 21 * 64, bt2);
+    map_pass<true>(m, lane, active, K, P, W, magicW, (int)cb.f1, (int)cb.f2, na2, nb2, bt2);
     __syncthreads();
     it++;
-    // CRC over all K decided bits == 0  <=>  data || parity divisible by g(x)
+    // CRC over all K decided bits == 0  <=>  data || parity divisible by g(x): Horner over the lane's own window, then
+    // weighting with x^((P-1-lane) W) and an XOR reduction over the windows
     uint32_t rem = 0;
-    for (int i = lane; i < K; i += 64)
-      if ((m.hard[i >> 5] >> (i & 31)) & 1u) rem ^= tab[K - 1 - i];
+    if (active) {
+      for (int t = 0; t < W; t++) {
+        rem = (rem << 1) | ((uint32_t)m.ext[t * P + lane] & 1u);
+        rem ^= (rem & 0x1000000u) ? poly : 0u;
+      }
+      rem = mulmod24(rem, cw, poly);
+    }
     for (int off = 32; off > 0; off >>= 1) rem ^= __shfl_xor(rem, off);
     ok = rem == 0;
   }
-  // ---- output: payload bytes of this code block + its CRC24A remainder contribution ----
+  // ---- output: payload bytes of this code block + its CRC24A remainder contribution (each lane a contiguous run) ----
   const int nout = (int)cb.out_bytes;
   uint8_t* outp = payload + cb.out_off;
+  const int per = (nout + 63) >> 6, j0 = lane * per, j1 = (j0 + per < nout) ? j0 + per : nout;
   uint32_t rema = 0;
-  for (int j = lane; j < nout; j += 64) {
-    int i = F + 8 * j;
-    uint32_t bits8 = (m.hard[i >> 5] >> (i & 31)) & 0xFFu;  // bit i at LSB
-    outp[j] = (uint8_t)(__brev(bits8) >> 24);
-    for (int q = 0; q < 8; q++)
-      if ((bits8 >> q) & 1u) rema ^= c.crc_tab_a[8 * nout - 1 - (8 * j + q)];
+  for (int j = j0; j < j1; j++) {
+    uint32_t byte = 0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const uint32_t bit = (uint32_t)m.ext[tr_idx(F + 8 * j + q, W, P, magicW)] & 1u;
+      byte = (byte << 1) | bit;
+      rema = (rema << 1) | bit;
+      rema ^= (rema & 0x1000000u) ? 0x1864CFBu : 0u;
+    }
+    outp[j] = (uint8_t)byte;
   }
+  if (j0 < j1) rema = mulmod24(rema, c.crc_tab_a[8 * (nout - j1)], 0x1864CFBu);
   for (int off = 32; off > 0; off >>= 1) rema ^= __shfl_xor(rema, off);
   if (lane == 0) {
     LsnCbRes r; r.ok = ok ? 1u : 0u; r.iters = (uint32_t)it; r.rem_a = rema; r.pad = 0;
@@ -419,22 +530,19 @@ __global__ __launch_bounds__(64) void k_turbo(LsnCellDev c, const LsnCbDev* __re
   }
 }
 
-size_t lsn_turbo_lds_bytes(uint32_t K)
-{
-  size_t Dp = ((K + 4) + 7) & ~7u;
-  size_t nhw = (K + 31) / 32;
-  return Dp * 4 * sizeof(int16_t) + ((nhw + 3) & ~3u) * 4 +
-         sizeof(int16_t) * (TB_S * 7 * 64 + TB_S * 64 + TB_MAXSB * 7 * 64 + TB_MAXSB * 2 * 64 + 4 * 7 * 64);
-}
+size_t lsn_turbo_lds_bytes(uint32_t kmax) { return 6 * (size_t)kmax + sizeof(int16_t) * TB_CKPT * 7 * 64; }
 
-void lsn_launch_turbo(const LsnCellDev& c, const LsnCbDev* cb, const int16_t* llr, uint8_t* payload, LsnCbRes* res, uint32_t ncb, hipStream_t s)
+void lsn_launch_turbo(const LsnCellDev& c, const LsnCbDev* cb, const int16_t* llr, uint8_t* payload, LsnCbRes* res, uint32_t ncb, uint32_t kmax,
+                      hipStream_t s)
 {
-  // dynamic LDS sized for the largest block (K = 6144); smaller blocks simply leave part of it unused
+  // dynamic LDS sized for the largest block of this launch (40 KiB at K = 6144 -> four code blocks per CU)
   static bool attr_set = false;
-  size_t lds = lsn_turbo_lds_bytes(6144);
+  if (kmax < 512) kmax = 512;  // the scratch in the check-point area needs room
+  kmax = (kmax + 7u) & ~7u;
+  const size_t lds = lsn_turbo_lds_bytes(kmax);
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)k_turbo, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)k_turbo, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lsn_turbo_lds_bytes(6144));
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_turbo, dim3(ncb), dim3(64), lds, s, c, cb, llr, payload, res);
+  hipLaunchKernelGGL(k_turbo, dim3(ncb), dim3(64), lds, s, c, cb, llr, payload, res, kmax);
 }

@@ -276,3 +276,93 @@ def parse_pcap(data):
         out.append(dict(direction=p[1], rnti_type=p[2], rnti=(p[4] << 8) | p[5], sfn=fs >> 4, sf=fs & 15, crc=p[13],
                         pdu=bytes(p[19:]), ctx=bytes(p[:19])))
     return out
+
+
+# -------- product host logic (HIP-free) through the test glue tests/native/liblsn_hosttest.so --------
+HOSTTEST_SO = os.path.join(ROOT, "tests", "native", "_build", "liblsn_hosttest.so")
+_host = None
+
+
+class LsnCand(C.Structure):
+    _fields_ = [("bits", C.c_uint64), ("rnti", C.c_uint32), ("flags", C.c_uint32)]
+
+
+class OGrant(C.Structure):  # o_pdsch_grant_t / grant_out
+    class TB(C.Structure):
+        _fields_ = [("mcs_idx", C.c_uint32), ("rv", C.c_int), ("cw_idx", C.c_uint32), ("enabled", C.c_int), ("mod", C.c_int),
+                    ("tbs", C.c_int), ("nof_bits", C.c_int)]
+    _fields_ = [("prb_idx", (C.c_uint8 * 110) * 2), ("nof_prb", C.c_uint32), ("nof_re", C.c_uint32), ("nof_tb", C.c_uint32),
+                ("tb", TB * 2), ("tx_scheme", C.c_int), ("pmi", C.c_uint32), ("nof_layers", C.c_uint32)]
+
+
+def hosttest():
+    global _host
+    if _host is None:
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "native")], stdout=subprocess.DEVNULL)
+        lib = C.CDLL(HOSTTEST_SO)
+        lib.lsnh_dci_format_sizeof.restype = C.c_uint32
+        lib.lsnh_dci_format_sizeof.argtypes = [C.c_uint32, C.c_uint32, C.c_int]
+        lib.lsnh_validate_location.restype = C.c_uint32
+        lib.lsnh_validate_location.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint16]
+        lib.lsnh_validate_location_enum.restype = C.c_uint32
+        lib.lsnh_validate_location_enum.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint16]
+        lib.lsnh_dl_grant.argtypes = [C.c_uint32] * 5 + [C.c_int, C.c_void_p, C.c_uint32, C.c_int, C.c_uint16, C.c_int, C.POINTER(OGrant)]
+        lib.lsnh_ul_grant.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint16, C.c_void_p]
+        lib.lsnh_cbsegm.argtypes = [C.c_int, C.c_void_p]
+        lib.lsnh_search_new.restype = C.c_void_p
+        lib.lsnh_search_new.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_double, C.c_int]
+        lib.lsnh_search_free.argtypes = [C.c_void_p]
+        lib.lsnh_search_size_index.argtypes = [C.c_void_p, C.c_int]
+        lib.lsnh_search_nof_sizes.argtypes = [C.c_void_p]
+        lib.lsnh_search_nof_sizes.restype = C.c_uint32
+        lib.lsnh_search_size.argtypes = [C.c_void_p, C.c_uint32]
+        lib.lsnh_search_size.restype = C.c_uint32
+        lib.lsnh_search_run.restype = C.c_uint32
+        lib.lsnh_search_run.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_float, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_uint32]
+        lib.lsnh_search_activate_rar.argtypes = [C.c_void_p, C.c_uint16]
+        lib.lsnh_search_stats.argtypes = [C.c_void_p, C.c_void_p]
+        lib.lsnh_search_nof_active.argtypes = [C.c_void_p]
+        lib.lsnh_search_nof_active.restype = C.c_uint32
+        lib.lsnh_search_bench.restype = C.c_double
+        lib.lsnh_search_bench.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _host = lib
+    return _host
+
+
+MAX_LOC, MAX_SIZES, CCE_STRIDE = 160, 8, 96
+
+
+def candidate_table(llr, nof_cce, sizes):
+    """What k_viterbi + k_cce_power produce for one subframe, computed with the ORACLE's candidate decoder:
+    -> (cand[MAX_LOC*MAX_SIZES] LsnCand array, ccepow float32[CCE_STRIDE])."""
+    lib = oracle()
+    cand = (LsnCand * (MAX_LOC * MAX_SIZES))()
+    pw = np.zeros(CCE_STRIDE, dtype=np.float32)
+    llr = np.ascontiguousarray(llr, dtype=np.float32)
+    for c in range(nof_cce):
+        m = 0.0
+        for v in llr[72 * c:72 * c + 72]:
+            m += abs(float(v))
+        pw[c] = np.float32(m / 72)
+    lim = min(nof_cce, 84)
+    li = 0
+    payload = (C.c_uint8 * 256)()
+    for l in (3, 2, 1, 0):
+        L = 1 << l
+        for i in range(lim // L):
+            ncce = L * (i % (nof_cce // L))
+            E = 72 * L
+            ok = ncce * 72 + E <= nof_cce * 72 and all(pw[ncce + q] >= np.float32(0.7) for q in range(L))
+            seg = llr[ncce * 72:ncce * 72 + E]
+            if ok and not np.any(seg != 0):
+                ok = False
+            if ok:
+                for si, nb in enumerate(sizes):
+                    rnti = lib.o_dci_decode(seg.ctypes.data, E, nb, payload)
+                    bits = 0
+                    for b in range(nb):
+                        bits |= int(payload[b]) << (63 - b)
+                    e = cand[li * MAX_SIZES + si]
+                    e.bits, e.rnti, e.flags = bits, rnti, 1
+            li += 1
+    return cand, pw

@@ -1,0 +1,145 @@
+// Test glue (NOT product): exposes the HIP-free host logic of the product (lsn_lte.cc, lsn_search.cc) through a
+// C interface so that the CPU test-suite can compare it with the oracle without a GPU.
+#include "../../ltesniffer_amd/csrc/host/lsn_search.h"
+#include <chrono>
+#include <cstring>
+
+using namespace lsn;
+
+struct hsearch {
+  Cell cell;
+  std::unique_ptr<FalconSearch> s;
+  SubframeCtx ctx;
+};
+
+// same layout as oracle/lsn_oracle.h o_pdsch_grant_t
+struct grant_out {
+  uint8_t prb_idx[2][110];
+  uint32_t nof_prb, nof_re, nof_tb;
+  struct { uint32_t mcs_idx; int rv; uint32_t cw_idx; int enabled; int mod; int tbs; int nof_bits; } tb[2];
+  int tx_scheme; uint32_t pmi; uint32_t nof_layers;
+};
+
+extern "C" {
+
+uint32_t lsnh_dci_format_sizeof(uint32_t nof_prb, uint32_t nof_ports, int format)
+{
+  Cell c; c.nof_prb = nof_prb; c.nof_ports = nof_ports;
+  return dci_format_sizeof(c, (DciFormat)format);
+}
+
+uint32_t lsnh_validate_location(const uint32_t* nof_cce3, uint32_t cfi, uint32_t ncce, uint32_t l, uint32_t nsubframe, uint16_t rnti)
+{
+  SearchSpace sp;
+  sp.init(nof_cce3);
+  return sp.validate(cfi, ncce, l, nsubframe, rnti);
+}
+// brute-force form kept in lsn_lte.cc (enumerates the locations like the reference does)
+uint32_t lsnh_validate_location_enum(uint32_t nof_cce, uint32_t ncce, uint32_t l, uint32_t nsubframe, uint16_t rnti)
+{
+  return pdcch_validate_location(nof_cce, ncce, l, nsubframe, rnti);
+}
+
+// unpack + dci->grant (+ config_mimo) for one DL DCI; returns bit0 unpack ok, bit1 grant ok, bits 8.. mimo return code
+int lsnh_dl_grant(uint32_t nof_prb, uint32_t nof_ports, uint32_t cell_id, uint32_t sf_idx, uint32_t cfi, int alt, const uint8_t* payload,
+                  uint32_t nof_bits, int format, uint16_t rnti, int do_mimo, grant_out* out)
+{
+  Cell c; c.nof_prb = nof_prb; c.nof_ports = nof_ports; c.id = cell_id;
+  DciDl d;
+  std::memset(out, 0, sizeof(*out));
+  if (!dci_msg_unpack_pdsch(c, payload, nof_bits, (DciFormat)format, rnti, d)) return 0;
+  PdschGrant g;
+  int r = 1;
+  bool ok = dl_sniffer_ra_dl_dci_to_grant(c, sf_idx, cfi, alt != 0, d, g);
+  {  // the fused two-table variant with the RE-count tables must agree with the plain single-table call
+    Cell c2 = c;
+    cell_build_re_tables(c2);
+    PdschGrant a, b; bool oka, okb;
+    dl_sniffer_ra_dl_dci_to_grant_both(c2, sf_idx, cfi, d, a, oka, b, okb);
+    const PdschGrant& x = alt ? b : a;
+    const bool okx = alt ? okb : oka;
+    if (okx != ok) return -99;
+    if (ok && (std::memcmp(x.prb_idx, g.prb_idx, sizeof(g.prb_idx)) || x.nof_prb != g.nof_prb || x.nof_re != g.nof_re || x.nof_tb != g.nof_tb)) return -98;
+    for (int i = 0; ok && i < 2; i++)
+      if (x.tb[i].mod != g.tb[i].mod || x.tb[i].tbs != g.tb[i].tbs || x.tb[i].nof_bits != g.tb[i].nof_bits || x.tb[i].rv != g.tb[i].rv ||
+          x.tb[i].enabled != g.tb[i].enabled || x.tb[i].cw_idx != g.tb[i].cw_idx || x.tb[i].mcs_idx != g.tb[i].mcs_idx) return -97;
+  }
+  if (ok) r |= 2;
+  if (ok && do_mimo) r |= dl_sniffer_config_mimo(c, (DciFormat)format, d, g) << 8;
+  for (int s = 0; s < 2; s++)
+    for (uint32_t i = 0; i < nof_prb; i++) out->prb_idx[s][i] = g.prb_idx[s][i];
+  out->nof_prb = g.nof_prb; out->nof_re = g.nof_re; out->nof_tb = g.nof_tb;
+  for (int i = 0; i < 2; i++) {
+    out->tb[i].mcs_idx = g.tb[i].mcs_idx; out->tb[i].rv = g.tb[i].rv; out->tb[i].cw_idx = g.tb[i].cw_idx; out->tb[i].enabled = g.tb[i].enabled;
+    out->tb[i].mod = g.tb[i].mod; out->tb[i].tbs = g.tb[i].tbs; out->tb[i].nof_bits = g.tb[i].nof_bits;
+  }
+  out->tx_scheme = (int)g.tx_scheme; out->pmi = g.pmi; out->nof_layers = g.nof_layers;
+  return r;
+}
+
+int lsnh_ul_grant(uint32_t nof_prb, uint32_t nof_ports, const uint8_t* payload, uint32_t nof_bits, uint16_t rnti, uint32_t* out6)
+{
+  Cell c; c.nof_prb = nof_prb; c.nof_ports = nof_ports;
+  DciUl d;
+  if (!dci_msg_unpack_pusch(c, payload, nof_bits, rnti, d)) return 0;
+  PuschGrant g;
+  if (!ra_ul_dci_to_grant(c, d, g)) return 1;
+  out6[0] = g.L_prb; out6[1] = g.n_prb; out6[2] = g.mcs_idx; out6[3] = (uint32_t)g.mod; out6[4] = (uint32_t)g.tbs; out6[5] = (uint32_t)g.rv;
+  return 3;
+}
+
+int lsnh_cbsegm(int tbs, int* out6)
+{
+  CbSegm s;
+  if (!cbsegm(tbs, s)) return -1;
+  out6[0] = s.C; out6[1] = s.Cp; out6[2] = s.Cm; out6[3] = s.Kp; out6[4] = s.Km; out6[5] = s.F;
+  return 0;
+}
+
+hsearch* lsnh_search_new(uint32_t nof_prb, uint32_t nof_ports, uint32_t cell_id, const uint32_t* nof_cce3, uint32_t threshold, double split, int skip)
+{
+  hsearch* h = new hsearch();
+  h->cell.nof_prb = nof_prb; h->cell.nof_ports = nof_ports; h->cell.id = cell_id;
+  h->s.reset(new FalconSearch(threshold, split, skip != 0));
+  h->s->setCell(h->cell, nof_cce3);
+  h->s->setupDefaultIntervals();
+  return h;
+}
+void lsnh_search_free(hsearch* h) { delete h; }
+int lsnh_search_size_index(hsearch* h, int format) { return h->s->sizeIndexOfFormat(format); }
+uint32_t lsnh_search_nof_sizes(hsearch* h) { return h->s->nofSizes(); }
+uint32_t lsnh_search_size(hsearch* h, uint32_t i) { return h->s->sizes()[i]; }
+// returns number of accepted DCIs, 6 words each
+uint32_t lsnh_search_run(hsearch* h, uint32_t tti, uint32_t cfi, float snr_db, const LsnCand* cand, const float* ccepow, int update_meta,
+                         uint32_t* out, uint32_t max_words)
+{
+  h->ctx.reset(tti);
+  h->ctx.cfi = cfi; h->ctx.snr_db = snr_db;
+  h->s->search(h->ctx, cand, ccepow, update_meta != 0);
+  const uint32_t n = (uint32_t)h->ctx.accepted.size();
+  std::memcpy(out, h->ctx.accepted.data(), sizeof(uint32_t) * (n < max_words ? n : max_words));
+  return n / 6;
+}
+void lsnh_search_activate_rar(hsearch* h, uint16_t rnti) { h->s->rntiManager().activateAndRefresh(rnti, 0, RM_ACT_RAR); }
+void lsnh_search_stats(hsearch* h, uint32_t* out7)
+{
+  const BlindStats& b = h->s->getStats();
+  out7[0] = b.nof_decoded_locations; out7[1] = b.nof_cce; out7[2] = b.nof_missed_cce; out7[3] = b.nof_subframes;
+  out7[4] = b.nof_subframe_collisions_dw; out7[5] = b.nof_subframe_collisions_up; out7[6] = b.nof_locations;
+}
+uint32_t lsnh_search_nof_active(hsearch* h) { return h->s->rntiManager().nofActive(); }
+// microseconds per subframe of the search over n recorded subframes, repeated `reps` times (state keeps evolving)
+double lsnh_search_bench(hsearch* h, uint32_t n, uint32_t reps, const uint32_t* tti, const uint32_t* cfi, const LsnCand* cand, const float* ccepow)
+{
+  const auto t0 = std::chrono::steady_clock::now();
+  for (uint32_t r = 0; r < reps; r++)
+    for (uint32_t i = 0; i < n; i++) {
+      h->ctx.reset(tti[i] + r * n);
+      h->ctx.cfi = cfi[i]; h->ctx.snr_db = 20.0f;
+      h->s->search(h->ctx, cand + (size_t)i * LSN_MAX_LOC * LSN_MAX_SIZES, ccepow + (size_t)i * LSN_CCE_STRIDE, false);
+    }
+  const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+  return us / ((double)n * reps);
+}
+
+}  // extern "C"
