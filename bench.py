@@ -92,6 +92,8 @@ def main():
     turbo_bytes = 0
     algo_bytes = 0
     npdus = 0
+    acc = {k: 0 for k in ("nof_tb_decodes", "nof_cb_decodes", "nof_turbo_iterations", "nof_ondemand_decodes", "turbo_cyc_rm",
+                          "turbo_cyc_map", "turbo_cyc_out", "ms_stage_a", "ms_search", "ms_search_core", "ms_rar", "ms_stage_c", "ms_commit")}
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
@@ -101,6 +103,8 @@ def main():
         turbo_bytes += p.turbo_algo_bytes
         algo_bytes += p.algo_bytes
         npdus += p.nof_pdus
+        for k in acc:
+            acc[k] += getattr(p, k)
         pcap.reset()
     torch.cuda.synchronize()
     if world > 1:
@@ -132,9 +136,10 @@ def main():
                          "avg_launch_ms": round(kms[kt] / max(1, klaunch[kt]), 4), "launches": int(klaunch[kt]),
                          "algo_bytes_per_launch": int(turbo_bytes / max(1, klaunch[kt])),
                          "dominant_by_time": la.KERNELS[dom]},
-            "cpu_baseline": cpu,
+            "cpu_baseline": cpu, "host": {"cpu_count": os.cpu_count()},
             "detail": {"pdus_per_step": npdus / args.steps, "algo_bytes_per_subframe": int(algo_bytes / (args.steps * nsf)),
                        "whole_path_GBps": round(algo_bytes / 1e9 / dt, 2),
+                       "per_step": {k: round(v / args.steps, 3) for k, v in acc.items()},
                        "kernel_ms_per_step": {la.KERNELS[k]: round(kms[k] / args.steps, 4) for k in range(len(la.KERNELS))}},
         }
         print(json.dumps(out), flush=True)

@@ -137,6 +137,9 @@ typedef struct {
   uint64_t algo_bytes;        /* algorithmic HBM bytes of the last call (SURVEY.md 8d formula) */
   uint64_t turbo_algo_bytes;  /* part of algo_bytes moved by the turbo kernel */
   uint64_t nof_tb_decodes, nof_cb_decodes, nof_turbo_iterations, nof_candidates_decoded, nof_ondemand_decodes, nof_pdus;
+  double ms_search_core;      /* part of ms_search inside the FALCON decision tree proper */
+  double ms_rar;              /* part of ms_search spent waiting for on-demand RAR decodes */
+  uint64_t turbo_cyc_rm, turbo_cyc_map, turbo_cyc_out;  /* shader cycles summed over code blocks: rate-dematch / MAP iterations / output */
 } lsn_perf_t;
 int lsn_phy_get_perf(lsn_phy_t* phy, lsn_perf_t* out);
 enum { LSN_K_OFDM = 0, LSN_K_CHEST, LSN_K_CHEST_FIN, LSN_K_PCFICH, LSN_K_PDCCH_LLR, LSN_K_CCE_POWER, LSN_K_VITERBI,

@@ -62,7 +62,8 @@ class Perf(C.Structure):
                 ("ms_total", C.c_double), ("kernel_ms", C.c_double * 16), ("kernel_launches", C.c_uint64 * 16),
                 ("algo_bytes", C.c_uint64), ("turbo_algo_bytes", C.c_uint64), ("nof_tb_decodes", C.c_uint64),
                 ("nof_cb_decodes", C.c_uint64), ("nof_turbo_iterations", C.c_uint64), ("nof_candidates_decoded", C.c_uint64),
-                ("nof_ondemand_decodes", C.c_uint64), ("nof_pdus", C.c_uint64)]
+                ("nof_ondemand_decodes", C.c_uint64), ("nof_pdus", C.c_uint64), ("ms_search_core", C.c_double), ("ms_rar", C.c_double), ("turbo_cyc_rm", C.c_uint64),
+                ("turbo_cyc_map", C.c_uint64), ("turbo_cyc_out", C.c_uint64)]
 
 
 SINK_T = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(PduCtx), C.POINTER(C.c_uint8), C.c_uint32)

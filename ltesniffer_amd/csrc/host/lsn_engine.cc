@@ -5,10 +5,13 @@
 //   PDSCH_Decoder::decode_dl_mode           /root/reference/src/src/DL_Sniffer_PDSCH.cc:881-1291
 // Product code: no CPU fallback, nothing from oracle/ is included or linked.
 #include "lsn_engine.h"
+#include "../kernels/lsn_rm.h"
 #include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <fstream>
+#include <sched.h>
 #include <stdexcept>
 #include <string>
 
@@ -27,6 +30,52 @@ static double now_ms()
 
 static const int kStageA[8] = {LSN_K_OFDM, LSN_K_CHEST, LSN_K_CHEST_FIN, LSN_K_PCFICH, LSN_K_PDCCH_LLR, LSN_K_CCE_POWER, LSN_K_VITERBI, LSN_K_RB_POWER};
 
+// ------------------------------------------------------------------------------------------------ NUMA placement
+// The sequential search reads candidate tables the GPU has just DMA-written; on a two-socket host a thread on the far
+// socket pays a remote-memory miss for every lookup.  All engine threads (and the caller while it is inside the
+// library) are therefore bound to the CPUs of the GPU's NUMA node (sysfs: PCI device -> numa_node -> cpulist).
+void Engine::detectNumaCpus()
+{
+  numa_cpus.clear();
+  if (getenv("LSN_NO_PIN")) return;
+  char bus[64] = {0};
+  if (hipDeviceGetPCIBusId(bus, sizeof(bus), cfg.device) != hipSuccess) return;
+  std::string id(bus);
+  for (auto& ch : id) ch = (char)tolower(ch);
+  int node = -1;
+  { std::ifstream f("/sys/bus/pci/devices/" + id + "/numa_node"); if (!(f >> node)) node = -1; }
+  if (node < 0) return;
+  std::ifstream f("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist");
+  std::string list;
+  if (!(f >> list)) return;
+  size_t pos = 0;
+  while (pos < list.size()) {  // "0-63,128-191"
+    size_t end = list.find(',', pos);
+    if (end == std::string::npos) end = list.size();
+    const std::string tok = list.substr(pos, end - pos);
+    const size_t dash = tok.find('-');
+    const int a = atoi(tok.c_str()), b = dash == std::string::npos ? a : atoi(tok.c_str() + dash + 1);
+    for (int c = a; c <= b && c < CPU_SETSIZE; c++) numa_cpus.push_back(c);
+    pos = end + 1;
+  }
+}
+
+bool Engine::pinThisThread(void* saved)
+{
+  if (numa_cpus.empty()) return false;
+  cpu_set_t* old = (cpu_set_t*)saved;
+  if (old && sched_getaffinity(0, sizeof(cpu_set_t), old) != 0) return false;
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  int n = 0;
+  for (int c : numa_cpus)
+    if (!old || CPU_ISSET(c, old)) { CPU_SET(c, &set); n++; }  // never widen what the caller was allowed to use
+  if (n == 0) return false;
+  return sched_setaffinity(0, sizeof(set), &set) == 0;
+}
+
+void Engine::unpinThisThread(const void* saved) { (void)sched_setaffinity(0, sizeof(cpu_set_t), (const cpu_set_t*)saved); }
+
 // ------------------------------------------------------------------------------------------------ life cycle
 Engine::Engine(const lsn_phy_cfg_t& c) : cfg(c)
 {
@@ -38,10 +87,15 @@ Engine::Engine(const lsn_phy_cfg_t& c) : cfg(c)
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) throw std::runtime_error("no HIP device");
   HIP_CHECK(hipSetDevice(cfg.device));
+  detectNumaCpus();
   search.reset(new FalconSearch(cfg.histogram_threshold, cfg.meta_format_split_ratio, cfg.skip_secondary_meta_formats != 0));
-  HIP_CHECK(hipStreamCreateWithFlags(&stream_a, hipStreamNonBlocking));
+  {
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    HIP_CHECK(hipStreamCreateWithPriority(&stream_a, hipStreamNonBlocking, hi));  // stage A feeds the sequential search
+  }
   HIP_CHECK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
-  commit_thread = std::thread([this] { commitLoop(); });
+  for (int i = 0; i < NDEC; i++) decode_threads[i] = std::thread([this, i] { decodeLoop(i); });
 }
 
 Engine::~Engine()
@@ -51,7 +105,8 @@ Engine::~Engine()
     stop = true;
   }
   cv_work.notify_all();
-  if (commit_thread.joinable()) commit_thread.join();
+  for (auto& t : decode_threads)
+    if (t.joinable()) t.join();
   (void)hipDeviceSynchronize();
   freeDevice();
   if (stream_a) (void)hipStreamDestroy(stream_a);
@@ -64,6 +119,9 @@ int Engine::setCell(const lsn_cell_t& c)
   if (c.cp != 0 || c.frame_type != 0 || c.phich_length != 0 || c.phich_resources > 3) return LSN_ERROR_INVALID_INPUTS;
   if (c.nof_ports < 1 || c.nof_ports > 2 || c.id > 503) return LSN_ERROR_INVALID_INPUTS;
   switch (c.nof_prb) { case 6: case 15: case 25: case 50: case 100: break; default: return LSN_ERROR_INVALID_INPUTS; }
+  cpu_set_t saved_mask;
+  const bool pinned = pinThisThread(&saved_mask);  // pinned host buffers are first touched on the GPU's node
+  struct Unpin { Engine* e; bool on; cpu_set_t* m; ~Unpin() { if (on) e->unpinThisThread(m); } } unpin{this, pinned, &saved_mask};
   try {
     HIP_CHECK(hipSetDevice(cfg.device));
     (void)hipDeviceSynchronize();
@@ -91,6 +149,8 @@ void Engine::mergePerf(const lsn_perf_t& p)
   perf.ms_stage_a += p.ms_stage_a; perf.ms_search += p.ms_search; perf.ms_stage_c += p.ms_stage_c; perf.ms_commit += p.ms_commit;
   perf.algo_bytes += p.algo_bytes; perf.turbo_algo_bytes += p.turbo_algo_bytes;
   perf.nof_tb_decodes += p.nof_tb_decodes; perf.nof_cb_decodes += p.nof_cb_decodes; perf.nof_turbo_iterations += p.nof_turbo_iterations;
+  perf.ms_search_core += p.ms_search_core; perf.ms_rar += p.ms_rar;
+  perf.turbo_cyc_rm += p.turbo_cyc_rm; perf.turbo_cyc_map += p.turbo_cyc_map; perf.turbo_cyc_out += p.turbo_cyc_out;
   perf.nof_candidates_decoded += p.nof_candidates_decoded; perf.nof_ondemand_decodes += p.nof_ondemand_decodes; perf.nof_pdus += p.nof_pdus;
   for (int k = 0; k < 16; k++) { perf.kernel_ms[k] += p.kernel_ms[k]; perf.kernel_launches[k] += p.kernel_launches[k]; }
 }
@@ -147,14 +207,28 @@ void Engine::finishStageA(Chunk& ch)
 }
 
 // ------------------------------------------------------------------------------------------------ stage B (caller thread)
+// The candidate tables were just written by DMA, i.e. none of their lines is in a CPU cache: pull the next subframe's
+// table (157 locations x 128 B) towards the core while the current subframe is searched.
+static inline void prefetch_cand(const LsnCand* cand, const float* ccepow)
+{
+  const char* p = (const char*)cand;
+  for (size_t off = 0; off < (size_t)LSN_MAX_LOC * LSN_MAX_SIZES * sizeof(LsnCand); off += 64) __builtin_prefetch(p + off, 0, 1);
+  const char* q = (const char*)ccepow;
+  for (size_t off = 0; off < LSN_CCE_STRIDE * sizeof(float); off += 64) __builtin_prefetch(q + off, 0, 1);
+}
+
 void Engine::searchChunk(Chunk& ch, uint32_t update_meta_period)
 {
+  prefetch_cand(ch.h_cand, ch.h_ccepow);
   for (uint32_t sf = 0; sf < ch.nsf; sf++) {
     SubframeCtx& c = ch.ctx[sf];
+    if (sf + 1 < ch.nsf) prefetch_cand(ch.h_cand + (size_t)(sf + 1) * LSN_MAX_LOC * LSN_MAX_SIZES, ch.h_ccepow + (size_t)(sf + 1) * LSN_CCE_STRIDE);
     const bool upd = (update_meta_period && (sf_cnt % update_meta_period) == 0) || force_meta_next;  // LTESniffer_Core.cc:434
     force_meta_next = false;
     sf_cnt++;
+    const double ts0 = now_ms();
     search->search(c, ch.h_cand + (size_t)sf * LSN_MAX_LOC * LSN_MAX_SIZES, ch.h_ccepow + (size_t)sf * LSN_CCE_STRIDE, upd);
+    perf.ms_search_core += now_ms() - ts0;
     est_cfo = c.cfo_hz;  // SubframeWorker.cc:203
     if (!c.searched) continue;
     // RAR grants feed the RNTI manager before the next subframe is searched (DL_Sniffer_PDSCH.cc:782-797): decode them now
@@ -166,7 +240,9 @@ void Engine::searchChunk(Chunk& ch, uint32_t update_meta_period)
       const int j = newJob(ch, sf, e, 0);
       e.job[0] = j;
       if (j < 0) continue;
+      const double tr0 = now_ms();
       ensureJob(ch, runner_s, j);
+      runner_s.perf.ms_rar += now_ms() - tr0;
       runner_s.perf.nof_ondemand_decodes++;
       for (int tb = 0; tb < 2; tb++) {
         const int len = ch.jobs[j].grant.tb[tb].tbs / 8;
@@ -316,6 +392,8 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
     r.h_jobs.push_back(d);
   }
   const uint32_t njobs = (uint32_t)r.h_jobs.size(), ncb = (uint32_t)r.h_cbs.size();
+  uint32_t n128 = 0, kmax128 = 0, kmax64 = 0;
+  std::vector<uint32_t> order;
   if (njobs) {
     grow_dev(r.d_jobs, r.jobs_cap, njobs, st);
     grow_dev(r.d_cbs, r.cbs_cap, ncb, st);
@@ -330,7 +408,21 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
     std::memcpy(r.h_jobs_pinned, r.h_jobs.data(), njobs * sizeof(LsnGrantDev));
     HIP_CHECK(hipMemcpyAsync(r.d_jobs, r.h_jobs_pinned, njobs * sizeof(LsnGrantDev), hipMemcpyHostToDevice, st));
     if (ncb) {
-      std::memcpy(r.h_cbs_pinned, r.h_cbs.data(), ncb * sizeof(LsnCbDev));
+      // launch order: two-wavefront blocks first, each class by descending size (longest jobs first)
+      order.resize(ncb);
+      for (uint32_t i = 0; i < ncb; i++) { r.h_cbs[i].res_idx = i; order[i] = i; }
+      std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+        const uint32_t kx = r.h_cbs[x].K, ky = r.h_cbs[y].K;
+        const bool bx = lsn_turbo_nwin((int)kx) > 64, by = lsn_turbo_nwin((int)ky) > 64;
+        if (bx != by) return bx;
+        if (kx != ky) return kx > ky;
+        return x < y;
+      });
+      for (uint32_t i = 0; i < ncb; i++) {
+        const LsnCbDev& q = r.h_cbs[order[i]];
+        r.h_cbs_pinned[i] = q;
+        if (lsn_turbo_nwin((int)q.K) > 64) { n128++; kmax128 = std::max(kmax128, q.K); } else kmax64 = std::max(kmax64, q.K);
+      }
       HIP_CHECK(hipMemcpyAsync(r.d_cbs, r.h_cbs_pinned, ncb * sizeof(LsnCbDev), hipMemcpyHostToDevice, st));
     }
     HIP_CHECK(hipMemsetAsync(r.d_llr16, 0, llr_n * sizeof(int16_t), st));
@@ -340,9 +432,7 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
     lsn_launch_pdsch_demod(cd, r.d_jobs, r.d_prefix, ch.d_grid, ch.d_ce, ch.d_chest, r.d_llr16, njobs, st);
     HIP_CHECK(hipEventRecord(r.ev[2], st));
     if (ncb) {
-      uint32_t kmax = 0;
-      for (const auto& cbq : r.h_cbs) kmax = std::max(kmax, cbq.K);
-      lsn_launch_turbo(cd, r.d_cbs, r.d_llr16, r.d_payload, r.d_cbres, ncb, kmax, st);
+      lsn_launch_turbo(cd, r.d_cbs, r.d_llr16, r.d_payload, r.d_cbres, n128, kmax128, ncb - n128, kmax64, st);
       HIP_CHECK(hipEventRecord(r.ev[3], st));
       HIP_CHECK(hipMemcpyAsync(r.h_cbres_pinned, r.d_cbres, ncb * sizeof(LsnCbRes), hipMemcpyDeviceToHost, st));
       HIP_CHECK(hipMemcpyAsync(r.h_payload_pinned, r.d_payload, pay_n - pay0, hipMemcpyDeviceToHost, st));
@@ -370,6 +460,7 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
         all_ok = all_ok && cr.ok != 0;
         j.iters += cr.iters;
         pf.nof_turbo_iterations += cr.iters;
+        pf.turbo_cyc_rm += cr.cyc_rm; pf.turbo_cyc_map += cr.cyc_map; pf.turbo_cyc_out += cr.cyc_out;
         rem ^= crc24a_mulmod(cr.rem_a, crc24a_xpow(bits_after));
         bits_after += 8ull * r.h_cbs[t.cb_first + q].out_bytes;
       }
@@ -392,11 +483,12 @@ void Engine::ensureJob(Chunk& ch, JobRunner& r, int j)
 
 // wave 1: the first decode the reference would attempt for every accepted DL DCI, predicted from the MCS-tracking
 // state as of now; wave 2: the 256QAM-table retry of "unknown table" grants whose first attempt failed on both TBs
-void Engine::planJobs(Chunk& ch)
+void Engine::planJobs(Chunk& ch, JobRunner& r)
 {
   std::vector<int> wave;
   struct Pending { uint32_t sf; size_t di; };
   std::vector<Pending> retry;
+  std::unique_lock<std::mutex> mcs_lk(mcs_mtx);
   for (uint32_t sf = 0; sf < ch.nsf; sf++) {
     SubframeCtx& c = ch.ctx[sf];
     if (!c.searched) continue;
@@ -418,7 +510,8 @@ void Engine::planJobs(Chunk& ch)
       if (table >= TABLE_UNKNOWN && e.ok256) retry.push_back({sf, di});
     }
   }
-  runJobs(ch, runner_c, wave);
+  mcs_lk.unlock();
+  runJobs(ch, r, wave);
   wave.clear();
   for (auto& p : retry) {
     DlEntry& e = ch.ctx[p.sf].dl[p.di];
@@ -427,13 +520,13 @@ void Engine::planJobs(Chunk& ch)
     if (e.job[1] < 0) e.job[1] = newJob(ch, p.sf, e, 1);
     if (e.job[1] >= 0) wave.push_back(e.job[1]);
   }
-  runJobs(ch, runner_c, wave);
+  runJobs(ch, r, wave);
 }
 
 // ------------------------------------------------------------------------------------------------ commit
-void Engine::emitPdu(const char* name, const uint8_t* pdu, uint32_t len, uint16_t rnti, uint32_t tti, uint8_t tb)
+void Engine::emitPdu(JobRunner& r, const char* name, const uint8_t* pdu, uint32_t len, uint16_t rnti, uint32_t tti, uint8_t tb)
 {
-  runner_c.perf.nof_pdus++;
+  r.perf.nof_pdus++;
   if (!sink) return;
   lsn_pdu_ctx_t c{};
   c.tti = tti; c.direction = 1; c.crc_ok = 1; c.is_retx = 0; c.tb = tb;
@@ -446,8 +539,9 @@ void Engine::emitPdu(const char* name, const uint8_t* pdu, uint32_t len, uint16_
 }
 
 // PDSCH_Decoder::decode_dl_mode (DL_Sniffer_PDSCH.cc:881-1291) over the decode results of every subframe of the chunk
-void Engine::commitChunk(Chunk& ch)
+void Engine::commitChunk(Chunk& ch, JobRunner& r)
 {
+  std::unique_lock<std::mutex> mcs_lk(mcs_mtx);
   std::vector<McsTable> tables;
   for (uint32_t sf = 0; sf < ch.nsf; sf++) {
     SubframeCtx& c = ch.ctx[sf];
@@ -478,7 +572,7 @@ void Engine::commitChunk(Chunk& ch)
       auto run = [&](int t) -> int {
         if (!(t ? has256 : has64)) return -1;
         if (e.job[t] < 0) e.job[t] = newJob(ch, sf, e, t);
-        if (e.job[t] >= 0 && !ch.jobs[e.job[t]].done) { ensureJob(ch, runner_c, e.job[t]); runner_c.perf.nof_ondemand_decodes++; }
+        if (e.job[t] >= 0 && !ch.jobs[e.job[t]].done) { ensureJob(ch, r, e.job[t]); r.perf.nof_ondemand_decodes++; }
         return e.job[t];
       };
       auto payload_of = [&](int j, int tb) { return ch.h_payload.data() + ch.jobs[j].payload_off[tb]; };
@@ -489,7 +583,7 @@ void Engine::commitChunk(Chunk& ch)
           for (int tb = 0; tb < 2; tb++) {
             const int len = ch.jobs[j].grant.tb[tb].tbs / 8;
             if (ch.jobs[j].crc[tb] && len > 0) {
-              emitPdu(name, payload_of(j, tb), (uint32_t)len, e.rnti, c.tti, (uint8_t)tb);
+              emitPdu(r, name, payload_of(j, tb), (uint32_t)len, e.rnti, c.tti, (uint8_t)tb);
               if (name[0] == 'R') unpackRar(payload_of(j, tb), len, false);
             }
           }
@@ -500,7 +594,7 @@ void Engine::commitChunk(Chunk& ch)
             const int len = ch.jobs[j].grant.tb[tb].tbs / 8;
             crc[tb] = ch.jobs[j].crc[tb];
             if (crc[tb] && len > 0) {
-              emitPdu(name, payload_of(j, tb), (uint32_t)len, e.rnti, c.tti, (uint8_t)tb);
+              emitPdu(r, name, payload_of(j, tb), (uint32_t)len, e.rnti, c.tti, (uint8_t)tb);
               if (name[0] == 'R') unpackRar(payload_of(j, tb), len, false);
               if (e.dci.tb[tb].mcs_idx > 0 && e.dci.tb[tb].mcs_idx < 29 && e.format > FORMAT1A) mcs_tracking.update_RNTI_dl(e.rnti, TABLE_64QAM);
             }
@@ -511,7 +605,7 @@ void Engine::commitChunk(Chunk& ch)
               for (int tb = 0; tb < 2; tb++) {
                 const int len = ch.jobs[j2].grant.tb[tb].tbs / 8;
                 if (ch.jobs[j2].crc[tb] && len > 0) {
-                  emitPdu(name, payload_of(j2, tb), (uint32_t)len, e.rnti, c.tti, (uint8_t)tb);
+                  emitPdu(r, name, payload_of(j2, tb), (uint32_t)len, e.rnti, c.tti, (uint8_t)tb);
                   if (e.dci.tb[tb].mcs_idx > 0 && e.dci.tb[tb].mcs_idx < 28 && e.format > FORMAT1A) mcs_tracking.update_RNTI_dl(e.rnti, TABLE_256QAM);
                 }
               }
@@ -523,9 +617,12 @@ void Engine::commitChunk(Chunk& ch)
   }
 }
 
-// commit thread: plan + decode (stream C) + commit, chunk after chunk in TTI order
-void Engine::commitLoop()
+// decode threads: each takes the next chunk of the queue, plans and runs its PDSCH decodes on its own stream, then commits
+// when every earlier chunk has been committed (PDU order and MCS-table learning stay in TTI order)
+void Engine::decodeLoop(int idx)
 {
+  JobRunner& r = runner_c[idx];
+  pinThisThread(nullptr);
   for (;;) {
     Chunk* ch = nullptr;
     {
@@ -533,22 +630,32 @@ void Engine::commitLoop()
       cv_work.wait(lk, [&] { return stop || !commit_queue.empty(); });
       if (commit_queue.empty()) return;
       ch = commit_queue.front();
+      commit_queue.pop_front();
     }
+    std::string err;
     try {
       (void)hipSetDevice(cfg.device);
       const double t0 = now_ms();
-      planJobs(*ch);
-      const double t1 = now_ms();
-      commitChunk(*ch);
-      runner_c.perf.ms_stage_c += t1 - t0;
-      runner_c.perf.ms_commit += now_ms() - t1;
+      planJobs(*ch, r);
+      r.perf.ms_stage_c += now_ms() - t0;
     } catch (const std::exception& ex) {
-      std::unique_lock<std::mutex> lk(mtx);
-      commit_error = ex.what();
+      err = ex.what();
     }
     {
       std::unique_lock<std::mutex> lk(mtx);
-      commit_queue.pop_front();
+      cv_done.wait(lk, [&] { return seq_committed == ch->seq; });
+    }
+    try {
+      const double t1 = now_ms();
+      if (err.empty()) commitChunk(*ch, r);
+      r.perf.ms_commit += now_ms() - t1;
+    } catch (const std::exception& ex) {
+      err = ex.what();
+    }
+    {
+      std::unique_lock<std::mutex> lk(mtx);
+      if (!err.empty()) commit_error = err;
+      seq_committed++;
       ch->busy = false;
     }
     cv_done.notify_all();
@@ -560,10 +667,13 @@ int Engine::process(const void* d_iq, uint32_t nsf_total, uint32_t start_tti, ui
 {
   if (!cell_set) return LSN_ERROR;
   if (!d_iq && nsf_total) return LSN_ERROR_INVALID_INPUTS;
+  cpu_set_t saved_mask;
+  const bool pinned = pinThisThread(&saved_mask);
+  struct Unpin { Engine* e; bool on; cpu_set_t* m; ~Unpin() { if (on) e->unpinThisThread(m); } } unpin{this, pinned, &saved_mask};
   try {
     HIP_CHECK(hipSetDevice(cfg.device));
     perf = lsn_perf_t{};
-    runner_c.perf = lsn_perf_t{};
+    for (auto& r : runner_c) r.perf = lsn_perf_t{};
     runner_s.perf = lsn_perf_t{};
     const double t_all = now_ms();
     // the caller's stream orders the IQ buffer: stage A starts after everything queued on it so far
@@ -597,6 +707,7 @@ int Engine::process(const void* d_iq, uint32_t nsf_total, uint32_t start_tti, ui
       perf.ms_search += now_ms() - t1;
       {
         std::unique_lock<std::mutex> lk(mtx);
+        cur->seq = seq_pushed++;
         commit_queue.push_back(cur);
       }
       cv_work.notify_one();
@@ -605,11 +716,11 @@ int Engine::process(const void* d_iq, uint32_t nsf_total, uint32_t start_tti, ui
     }
     {
       std::unique_lock<std::mutex> lk(mtx);
-      cv_done.wait(lk, [&] { return commit_queue.empty(); });
+      cv_done.wait(lk, [&] { return seq_committed == seq_pushed; });
       if (!commit_error.empty()) { std::string e = commit_error; commit_error.clear(); throw std::runtime_error(e); }
     }
     perf.nof_candidates_decoded = search->nof_lookups; search->nof_lookups = 0;
-    mergePerf(runner_c.perf);
+    for (auto& r : runner_c) mergePerf(r.perf);
     mergePerf(runner_s.perf);
     perf.ms_total = now_ms() - t_all;
     return LSN_SUCCESS;
@@ -617,7 +728,7 @@ int Engine::process(const void* d_iq, uint32_t nsf_total, uint32_t start_tti, ui
     fprintf(stderr, "ltesniffer_amd: %s\n", ex.what());
     // drain the pipeline so that the slots are reusable
     std::unique_lock<std::mutex> lk(mtx);
-    cv_done.wait(lk, [&] { return commit_queue.empty(); });
+    cv_done.wait(lk, [&] { return seq_committed == seq_pushed; });
     for (auto& ch : chunks) ch.busy = false;
     return LSN_ERROR;
   }

@@ -44,6 +44,7 @@ struct Chunk {
   std::vector<uint8_t> h_payload;
   hipEvent_t ev_a[2 * 8 + 1] = {};  // per stage-A kernel class start/stop + "mirrors on host"
   bool busy = false;                 // owned by the pipeline (slot not reusable yet)
+  uint64_t seq = 0;                  // position in the commit order
 };
 
 // one stream + its device/host arenas for PDSCH decode launches
@@ -85,7 +86,8 @@ public:
   void forceMetaUpdateNext() { force_meta_next = true; }
 
 private:
-  static constexpr int NSLOTS = 3;
+  static constexpr int NDEC = 3;             // decode threads (each: plan + stage-C launches of one chunk; commits stay in order)
+  static constexpr int NSLOTS = NDEC + 2;
   void freeDevice();
   void buildTables();
   void allocChunk(Chunk& ch);
@@ -94,15 +96,18 @@ private:
   void launchStageA(Chunk& ch, const void* d_iq);
   void finishStageA(Chunk& ch);
   void searchChunk(Chunk& ch, uint32_t update_meta_period);
-  void planJobs(Chunk& ch);
+  void planJobs(Chunk& ch, JobRunner& r);
   void runJobs(Chunk& ch, JobRunner& r, std::vector<int>& job_ids);
   void ensureJob(Chunk& ch, JobRunner& r, int j);
-  void commitChunk(Chunk& ch);
+  void commitChunk(Chunk& ch, JobRunner& r);
   int newJob(Chunk& ch, uint32_t sf, const DlEntry& e, int table);
   void unpackRar(const uint8_t* p, int len, bool at_search);
-  void emitPdu(const char* name, const uint8_t* pdu, uint32_t len, uint16_t rnti, uint32_t tti, uint8_t tb);
-  void commitLoop();
+  void emitPdu(JobRunner& r, const char* name, const uint8_t* pdu, uint32_t len, uint16_t rnti, uint32_t tti, uint8_t tb);
+  void decodeLoop(int idx);
   void mergePerf(const lsn_perf_t& p);
+  void detectNumaCpus();
+  bool pinThisThread(void* saved_mask);   // bind the calling thread to the CPUs of the GPU's NUMA node
+  void unpinThisThread(const void* saved_mask);
 
   lsn_phy_cfg_t cfg;
   Cell cell;
@@ -114,13 +119,15 @@ private:
   void* d_iq_staging = nullptr;
   size_t staging_sf = 0;
   Chunk chunks[NSLOTS];
-  JobRunner runner_c, runner_s;  // commit thread / search thread (on-demand RAR decodes)
+  JobRunner runner_c[NDEC], runner_s;  // decode threads / search thread (on-demand RAR decodes)
   hipStream_t stream_a = nullptr;
   hipEvent_t ev_in = nullptr;
   std::unique_ptr<FalconSearch> search;
   MCSTracking mcs_tracking;
-  // commit thread
-  std::thread commit_thread;
+  std::mutex mcs_mtx;  // planJobs (prediction) vs commitChunk (authoritative updates)
+  // decode threads
+  std::thread decode_threads[NDEC];
+  uint64_t seq_pushed = 0, seq_committed = 0;  // chunks queued / committed (commit order = queue order)
   std::mutex mtx;
   std::condition_variable cv_work, cv_done;
   std::deque<Chunk*> commit_queue;
@@ -132,6 +139,7 @@ private:
   uint64_t sf_cnt = 0;
   Chunk* last_chunk = nullptr;
   bool force_meta_next = false;
+  std::vector<int> numa_cpus;  // CPUs local to the GPU (empty: unknown, no pinning)
 };
 
 // table builders (lsn_tables.cc)

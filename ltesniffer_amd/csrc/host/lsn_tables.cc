@@ -60,7 +60,7 @@ void Engine::freeDevice()
       if (e) { (void)hipEventDestroy(e); e = nullptr; }
     ch = Chunk();
   }
-  freeRunner(runner_c);
+  for (auto& r : runner_c) freeRunner(r);
   freeRunner(runner_s);
   d_dphi = nullptr; d_iq_staging = nullptr; staging_sf = 0;
   last_chunk = nullptr;
@@ -80,7 +80,25 @@ void Engine::freeRunner(JobRunner& r)
 
 void Engine::allocRunner(JobRunner& r)
 {
-  HIP_CHECK(hipStreamCreateWithFlags(&r.stream, hipStreamNonBlocking));
+  // the search thread's runner (on-demand RAR decodes) sits on the critical path of the sequential search: high priority
+  int lo = 0, hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+  if (&r == &runner_s) {
+    HIP_CHECK(hipStreamCreateWithPriority(&r.stream, hipStreamNonBlocking, hi));
+  } else {
+    // bulk decode streams leave a few CUs alone, so that the latency-critical launches (stage A, on-demand RAR decodes)
+    // never queue behind thousands of resident turbo workgroups
+    hipDeviceProp_t prop;
+    HIP_CHECK(hipGetDeviceProperties(&prop, cfg.device));
+    const int ncu = prop.multiProcessorCount;
+    const char* env = getenv("LSN_RESERVED_CUS");
+    const int reserve = env ? atoi(env) : 8;
+    std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+    for (int i = 0; i < ncu; i++)
+      if (!(reserve > 0 && i % (ncu / (reserve > 0 ? reserve : 1)) == 0)) mask[i / 32] |= 1u << (i % 32);
+    if (reserve <= 0 || reserve >= ncu || hipExtStreamCreateWithCUMask(&r.stream, (uint32_t)mask.size(), mask.data()) != hipSuccess)
+      HIP_CHECK(hipStreamCreateWithPriority(&r.stream, hipStreamNonBlocking, lo));
+  }
   for (auto& e : r.ev) HIP_CHECK(hipEventCreate(&e));
 }
 
@@ -261,7 +279,7 @@ void Engine::buildTables()
   }
   // pipeline slots, decode runners, staging
   for (auto& ch : chunks) allocChunk(ch);
-  allocRunner(runner_c);
+  for (auto& r : runner_c) allocRunner(r);
   allocRunner(runner_s);
   staging_sf = max_batch * NSLOTS;
   d_iq_staging = dalloc<cf32>(dev_allocs, staging_sf * cfg.nof_rx_antennas * cd.sflen);

@@ -72,9 +72,9 @@ struct LsnCbDev {
   uint32_t out_bytes; // (K - F - 24*crc_b)/8
   uint32_t f1, f2;
   uint32_t max_iter;
-  uint32_t pad;
+  uint32_t res_idx;   // slot of this block's LsnCbRes (launch order is sorted by size, results are not)
 };
-struct LsnCbRes { uint32_t ok, iters, rem_a, pad; };
+struct LsnCbRes { uint32_t ok, iters, rem_a, pad; uint32_t cyc_rm, cyc_map, cyc_out, cyc_all; };  // cyc_*: shader cycles per phase (s_memtime)
 
 // launchers (stage_a.hip / stage_c.hip)
 void lsn_launch_ofdm(const LsnCellDev& c, const cf32* iq, const uint32_t* dphi, cf32* grid, uint32_t nsf, hipStream_t s);
@@ -87,4 +87,5 @@ void lsn_launch_viterbi(const LsnCellDev& c, const float* llr, const float* pw, 
 void lsn_launch_rb_power(const LsnCellDev& c, const cf32* grid, float* rbp, uint32_t nsf, hipStream_t s);
 void lsn_launch_pdsch_prep(const LsnCellDev& c, const LsnGrantDev* g, uint16_t* prefix, uint32_t njobs, hipStream_t s);
 void lsn_launch_pdsch_demod(const LsnCellDev& c, const LsnGrantDev* g, const uint16_t* prefix, const cf32* grid, const cf32* ce, const LsnChest* ch, int16_t* llr, uint32_t njobs, hipStream_t s);
-void lsn_launch_turbo(const LsnCellDev& c, const LsnCbDev* cb, const int16_t* llr, uint8_t* payload, LsnCbRes* res, uint32_t ncb, uint32_t kmax, hipStream_t s);
+void lsn_launch_turbo(const LsnCellDev& c, const LsnCbDev* cb, const int16_t* llr, uint8_t* payload, LsnCbRes* res, uint32_t n128, uint32_t kmax128,
+                      uint32_t n64, uint32_t kmax64, hipStream_t s);

@@ -92,3 +92,16 @@ LSN_HD int lsn_rm_rank(const LsnRmGeom& g, int s, int i)
   const int row = z >> 5, col = lsn_perm_tc_f(z & 31);
   return lsn_rm_eidx(g, lsn_rm_cum_v2(g, col, row));
 }
+
+// Number of trellis windows the turbo decoder cuts a code block of K bits into (windows of W = K / P >= 32 steps,
+// decoded in parallel with next-iteration boundary initialisation): the largest divisor of K that fills one wavefront
+// (P <= 64), or two wavefronts when a divisor in 96..128 exists.
+LSN_HD int lsn_turbo_nwin(int K)
+{
+  int p1 = 1, p2 = 1;
+  for (int P = (K / 32 < 128 ? K / 32 : 128); P >= 1; P--)
+    if (K % P == 0) { p2 = P; break; }
+  for (int P = (K / 32 < 64 ? K / 32 : 64); P >= 1; P--)
+    if (K % P == 0) { p1 = P; break; }
+  return p2 >= 96 ? p2 : p1;
+}

@@ -207,8 +207,8 @@ void lsn_launch_pdsch_demod(const LsnCellDev& c, const LsnGrantDev* g, const uin
 }
 
 // ------------------------------------------------------------------------------------------------ turbo decoder
-// One wavefront per code block, lane = trellis window (P = turbo_nwin(K) <= 64 windows of W = K/P steps), four code
-// blocks per CU (<= 40 KiB of LDS each, one wave per SIMD).
+// One workgroup per code block, thread = trellis window (P = lsn_turbo_nwin(K) windows of W = K/P steps): one
+// wavefront when P <= 64, two when 96 <= P <= 128; four code blocks per CU (<= 40 KiB of LDS each).
 // LDS: spp[K] packs the three rate-dematched soft streams of a position (10-bit signed fields: systematic | parity 1 |
 // parity 2), ext[K] holds extrinsic * 2 + hard decision.  Both are stored TRANSPOSED, idx(x) = (x % W) * P + x / W:
 // the in-order decoder reads consecutive lanes = consecutive addresses and the QPP-interleaved one is (nearly)
@@ -220,7 +220,8 @@ void lsn_launch_pdsch_demod(const LsnCellDev& c, const LsnGrantDev* g, const uin
 // Window-boundary metrics of the previous iteration (next-iteration initialisation) stay in registers and move
 // between lanes with shuffles.
 #define TB_S 16      // sub-block length
-#define TB_CKPT 4    // check-points kept in LDS: sub-blocks 1 .. nsb-2 (nsb <= 6)
+#define TB_CKPT_I16 (4 * 7 * 64)  // check-point store (int16): sub-blocks 1 .. nsb-2, [slot][state][thread];
+                                 // 64 threads: W <= 96 -> 4 slots, 128 threads: W <= 64 -> 2 slots
 
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 __device__ __forceinline__ int ext_scale(int x)
@@ -242,7 +243,7 @@ __device__ __forceinline__ void step_fwd(int* a, int lsa, int lp)
 struct TurboLds {
   uint32_t* spp;   // [K] sys | p1 << 10 | p2 << 20 (10-bit two's complement fields), transposed
   int16_t* ext;    // [K] extrinsic * 2 + hard bit, transposed
-  int16_t* ckpt;   // [TB_CKPT][7][64]
+  int16_t* ckpt;   // [slot][7][NT]; also the exchange buffer for the window-boundary metrics
 };
 
 __device__ __forceinline__ int tr_idx(int x, int W, int P, uint32_t magicW)
@@ -268,7 +269,7 @@ __device__ __forceinline__ uint32_t mulmod24(uint32_t a, uint32_t b, uint32_t po
 }
 
 // one constituent decoder over all windows (lane = window); nii_a / nii_b: boundary metrics (states 1..7) in registers
-template <bool IL>
+template <bool IL, int NT>
 __device__ __forceinline__ void map_pass(const TurboLds& m, int lane, bool active, int K, int P, int W, uint32_t magicW, int f1, int f2,
                                          int* nii_a, int* nii_b, const int* beta_tail)
 {
@@ -290,7 +291,7 @@ __device__ __forceinline__ void map_pass(const TurboLds& m, int lane, bool activ
   for (int sb = 0; sb + 1 < nsb; sb++) {
     if (sb >= 1) {
 #pragma unroll
-      for (int s = 1; s < 8; s++) m.ckpt[((sb - 1) * 7 + (s - 1)) * 64 + lane] = (int16_t)a[s];
+      for (int s = 1; s < 8; s++) m.ckpt[((sb - 1) * 7 + (s - 1)) * NT + lane] = (int16_t)a[s];
     }
     const int tb = sb * TB_S;
 #pragma unroll
@@ -327,7 +328,7 @@ __device__ __forceinline__ void map_pass(const TurboLds& m, int lane, bool activ
         for (int s = 1; s < 8; s++) a[s] = a0[s - 1];
       } else {
 #pragma unroll
-        for (int s = 1; s < 8; s++) a[s] = m.ckpt[((sb - 1) * 7 + (s - 1)) * 64 + lane];
+        for (int s = 1; s < 8; s++) a[s] = m.ckpt[((sb - 1) * 7 + (s - 1)) * NT + lane];
       }
     }
     // operand burst, last step first (the QPP recursion runs in reverse)
@@ -390,12 +391,22 @@ __device__ __forceinline__ void map_pass(const TurboLds& m, int lane, bool activ
       }
     }
   }
-  // next-iteration initialisation: window p starts from the end of window p-1 and ends at the start of window p+1
+  // next-iteration initialisation: window p starts from the end of window p-1 and ends at the start of window p+1.
+  // The exchange goes through the (now idle) check-point area: [14][NT] int16.
+  __syncthreads();
 #pragma unroll
   for (int s = 1; s < 8; s++) {
-    nii_a[s - 1] = __shfl_up(a_end[s - 1], 1);
-    nii_b[s - 1] = __shfl_down(b[s], 1);
+    m.ckpt[(s - 1) * NT + lane] = (int16_t)a_end[s - 1];
+    m.ckpt[(7 + s - 1) * NT + lane] = (int16_t)b[s];
   }
+  __syncthreads();
+  const int lm = lane > 0 ? lane - 1 : 0, lq = lane + 1 < NT ? lane + 1 : lane;
+#pragma unroll
+  for (int s = 1; s < 8; s++) {
+    nii_a[s - 1] = m.ckpt[(s - 1) * NT + lm];
+    nii_b[s - 1] = m.ckpt[(7 + s - 1) * NT + lq];
+  }
+  __syncthreads();
 }
 
 __device__ __forceinline__ void tail_beta(const int* ts, const int* tp, int* beta)
@@ -413,20 +424,30 @@ __device__ __forceinline__ void tail_beta(const int* ts, const int* tp, int* bet
   for (int S = 7; S >= 0; S--) beta[S] = b[S] - b[0];
 }
 
-__device__ __forceinline__ int turbo_nwin(int K)
+// XOR-reduce a value over the workgroup (NT = 64: one wave; 128: two waves through LDS scratch)
+template <int NT>
+__device__ __forceinline__ uint32_t wg_xor(uint32_t v, int16_t* scratch, int tid)
 {
-  int P = 64;
-  while (P > 1 && ((K % P) != 0 || K / P < 32)) P >>= 1;
-  return P;
+  for (int off = 32; off > 0; off >>= 1) v ^= __shfl_xor(v, off);
+  if (NT == 64) return v;
+  uint32_t* w = (uint32_t*)scratch;
+  __syncthreads();
+  if ((tid & 63) == 0) w[tid >> 6] = v;
+  __syncthreads();
+  v = w[0] ^ w[1];
+  __syncthreads();
+  return v;
 }
 
-__global__ __launch_bounds__(64) void k_turbo(LsnCellDev c, const LsnCbDev* __restrict__ cbs, const int16_t* __restrict__ llr,
+template <int NT>
+__global__ __launch_bounds__(NT) void k_turbo(LsnCellDev c, const LsnCbDev* __restrict__ cbs, const int16_t* __restrict__ llr,
                                               uint8_t* __restrict__ payload, LsnCbRes* __restrict__ res, uint32_t kmax)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const long long tc0 = clock64();
   const LsnCbDev cb = cbs[blockIdx.x];
   const int lane = threadIdx.x, K = (int)cb.K, F = (int)cb.F;
-  const int P = turbo_nwin(K), W = K / P;
+  const int P = lsn_turbo_nwin(K), W = K / P;
   const uint32_t magicW = (uint32_t)(0x100000000ull / (unsigned)W) + (((W & (W - 1)) == 0) ? 0u : 1u);
   const bool active = lane < P;
   TurboLds m;
@@ -435,36 +456,57 @@ __global__ __launch_bounds__(64) void k_turbo(LsnCellDev c, const LsnCbDev* __re
   LsnRmGeom& geom = *(LsnRmGeom*)m.ckpt;
   int* tail = (int*)(m.ckpt + 1024);
   if (lane == 0) lsn_rm_geom(geom, K, F, (int)cb.rv);
-  for (int i = lane; i < K; i += 64) { m.spp[i] = 0u; m.ext[i] = 0; }
+  for (int i = lane; i < K; i += NT) { m.spp[i] = 0u; m.ext[i] = 0; }
   __syncthreads();
-  // ---- rate de-matching as a gather over the circular buffer (36.212 5.1.4.1.2): lanes walk the rows of one sub-block
-  //      column, so the e[] reads are contiguous; repeated bits are soft-combined, results clipped to +-511 ----
+  // ---- rate de-matching as a gather over the circular buffer (36.212 5.1.4.1.2): threads walk the rows of one
+  //      sub-block column, so the e[] reads are contiguous; repeated bits are soft-combined, results clipped to +-511 ----
   {
     const int16_t* e = llr + cb.e_off;
     const int E = (int)cb.E, nn = geom.nn, R = geom.R, ND = geom.ND, KP = geom.KP, nn0 = geom.nn0;
-    auto gather = [&](int cum) -> int {
-      int acc = 0;
-      for (int k = lsn_rm_eidx(geom, cum); k < E; k += nn) acc += (int)e[k];
-      return acc > LSN_LLR_CLIP ? LSN_LLR_CLIP : (acc < -LSN_LLR_CLIP ? -LSN_LLR_CLIP : acc);
-    };
     auto put = [&](int s, int i, int v) {
       if (i < K) atomicOr(&m.spp[tr_idx(i, W, P, magicW)], ((uint32_t)v & 0x3FFu) << (10 * s)); else tail[s * 4 + (i - K)] = v;
     };
-    for (int i = lane; i < F; i += 64) { put(0, i, -LSN_LLR_CLIP); put(1, i, -LSN_LLR_CLIP); }  // filler bits are known zeros
-    for (int col = 0; col < 32; col++) {
-      const int p = lsn_perm_tc_f(col), c01 = (int)geom.cnt01[col];
-      const int base01 = geom.pre01[col], base2 = geom.pre2[col], f2c = (int)geom.first2[col];
-      for (int row = lane; row < R; row += 64) {
-        const int k = col * R + row, y = row * 32 + p;
-        const int nb01 = base01 + (row < c01 ? row : c01), nb2 = base2 + (row > 0 ? f2c : 0);
-        const bool null01 = row < c01;
-        const int cum1 = nn0 + (k - nb01) + (k - nb2);
-        if (!null01) {
-          put(0, y - ND, gather(k - nb01));
-          put(1, y - ND, gather(cum1));
+    for (int i = lane; i < F; i += NT) { put(0, i, -LSN_LLR_CLIP); put(1, i, -LSN_LLR_CLIP); }  // filler bits are known zeros
+    // threads own rows, eight sub-block columns (24 buffer entries) are gathered per batch so that the global loads of a
+    // batch are all in flight together; entry j of the batch adds e[first_j + r * nn] for r = 0 .. nrep-1 (repetition)
+    const int nrep = E > 0 ? (E + nn - 1) / nn : 0;
+    for (int row = lane; row < R; row += NT) {
+      for (int cb8 = 0; cb8 < 32; cb8 += 8) {
+        int first[24], acc[24];
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const int col = cb8 + q, p = lsn_perm_tc_f(col), c01 = (int)geom.cnt01[col];
+          const int k = col * R + row, y = row * 32 + p;
+          const int nb01 = geom.pre01[col] + (row < c01 ? row : c01), nb2 = geom.pre2[col] + (row > 0 ? (int)geom.first2[col] : 0);
+          const bool null01 = row < c01;
+          const int cum1 = nn0 + (k - nb01) + (k - nb2);
+          const int i2 = (y + 1 == KP ? 0 : y + 1) - ND;
+          first[3 * q + 0] = null01 ? E : lsn_rm_eidx(geom, k - nb01);
+          first[3 * q + 1] = null01 ? E : lsn_rm_eidx(geom, cum1);
+          first[3 * q + 2] = i2 < 0 ? E : lsn_rm_eidx(geom, cum1 + (null01 ? 0 : 1));
+          acc[3 * q + 0] = 0; acc[3 * q + 1] = 0; acc[3 * q + 2] = 0;
         }
-        const int i2 = (y + 1 == KP ? 0 : y + 1) - ND;
-        if (i2 >= 0) put(2, i2, gather(cum1 + (null01 ? 0 : 1)));
+        for (int r = 0; r < nrep; r++) {
+#pragma unroll
+          for (int j = 0; j < 24; j++) {
+            const int k = first[j] + r * nn;
+            const int v = (int)e[k < E ? k : E - 1];
+            acc[j] += k < E ? v : 0;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+          const int col = cb8 + q, p = lsn_perm_tc_f(col), y = row * 32 + p;
+          const bool null01 = row < (int)geom.cnt01[col];
+          const int i2 = (y + 1 == KP ? 0 : y + 1) - ND;
+#pragma unroll
+          for (int j = 0; j < 3; j++) {
+            int v = acc[3 * q + j];
+            v = v > LSN_LLR_CLIP ? LSN_LLR_CLIP : (v < -LSN_LLR_CLIP ? -LSN_LLR_CLIP : v);
+            if (j < 2) { if (!null01) put(j, y - ND, v); }
+            else if (i2 >= 0) put(2, i2, v);
+          }
+        }
       }
     }
   }
@@ -479,8 +521,9 @@ __global__ __launch_bounds__(64) void k_turbo(LsnCellDev c, const LsnCbDev* __re
     tail_beta(ts2, tp2, bt2);
   }
   __syncthreads();  // scratch is dead from here on: the area becomes the check-point store
+  const long long tc1 = clock64();
   const uint32_t poly = cb.crc_b ? 0x1800063u : 0x1864CFBu;
-  // weight of this lane's window in the block polynomial: x^((P-1-lane) W) mod g
+  // weight of this thread's window in the block polynomial: x^((P-1-window) W) mod g
   const uint32_t cw = active ? (cb.crc_b ? c.crc_tab_b : c.crc_tab_a)[(P - 1 - lane) * W] : 0u;
   int na1[7], nb1[7], na2[7], nb2[7];
 #pragma unroll
@@ -488,13 +531,11 @@ __global__ __launch_bounds__(64) void k_turbo(LsnCellDev c, const LsnCbDev* __re
   int it = 0;
   bool ok = false;
   while (it < (int)cb.max_iter && !ok) {
-    map_pass<false>(m, lane, active, K, P, W, magicW, (int)cb.f1, (int)cb.f2, na1, nb1, bt1);
-    __syncthreads();
-    map_pass<true>(m, lane, active, K, P, W, magicW, (int)cb.f1, (int)cb.f2, na2, nb2, bt2);
-    __syncthreads();
+    map_pass<false, NT>(m, lane, active, K, P, W, magicW, (int)cb.f1, (int)cb.f2, na1, nb1, bt1);
+    map_pass<true, NT>(m, lane, active, K, P, W, magicW, (int)cb.f1, (int)cb.f2, na2, nb2, bt2);
     it++;
-    // CRC over all K decided bits == 0  <=>  data || parity divisible by g(x): Horner over the lane's own window, then
-    // weighting with x^((P-1-lane) W) and an XOR reduction over the windows
+    // CRC over all K decided bits == 0  <=>  data || parity divisible by g(x): Horner over the thread's own window,
+    // then weighting with x^((P-1-window) W) and an XOR reduction over the windows
     uint32_t rem = 0;
     if (active) {
       for (int t = 0; t < W; t++) {
@@ -503,13 +544,13 @@ __global__ __launch_bounds__(64) void k_turbo(LsnCellDev c, const LsnCbDev* __re
       }
       rem = mulmod24(rem, cw, poly);
     }
-    for (int off = 32; off > 0; off >>= 1) rem ^= __shfl_xor(rem, off);
-    ok = rem == 0;
+    ok = wg_xor<NT>(rem, m.ckpt, lane) == 0;
   }
-  // ---- output: payload bytes of this code block + its CRC24A remainder contribution (each lane a contiguous run) ----
+  const long long tc2 = clock64();
+  // ---- output: payload bytes of this code block + its CRC24A remainder contribution (each thread a contiguous run) ----
   const int nout = (int)cb.out_bytes;
   uint8_t* outp = payload + cb.out_off;
-  const int per = (nout + 63) >> 6, j0 = lane * per, j1 = (j0 + per < nout) ? j0 + per : nout;
+  const int per = (nout + NT - 1) / NT, j0 = lane * per, j1 = (j0 + per < nout) ? j0 + per : nout;
   uint32_t rema = 0;
   for (int j = j0; j < j1; j++) {
     uint32_t byte = 0;
@@ -523,26 +564,29 @@ __global__ __launch_bounds__(64) void k_turbo(LsnCellDev c, const LsnCbDev* __re
     outp[j] = (uint8_t)byte;
   }
   if (j0 < j1) rema = mulmod24(rema, c.crc_tab_a[8 * (nout - j1)], 0x1864CFBu);
-  for (int off = 32; off > 0; off >>= 1) rema ^= __shfl_xor(rema, off);
+  rema = wg_xor<NT>(rema, m.ckpt, lane);
   if (lane == 0) {
+    const long long tc3 = clock64();
     LsnCbRes r; r.ok = ok ? 1u : 0u; r.iters = (uint32_t)it; r.rem_a = rema; r.pad = 0;
-    res[blockIdx.x] = r;
+    r.cyc_rm = (uint32_t)(tc1 - tc0); r.cyc_map = (uint32_t)(tc2 - tc1); r.cyc_out = (uint32_t)(tc3 - tc2); r.cyc_all = (uint32_t)(tc3 - tc0);
+    res[cb.res_idx] = r;
   }
 }
 
-size_t lsn_turbo_lds_bytes(uint32_t kmax) { return 6 * (size_t)kmax + sizeof(int16_t) * TB_CKPT * 7 * 64; }
+size_t lsn_turbo_lds_bytes(uint32_t kmax) { return 6 * (size_t)kmax + sizeof(int16_t) * TB_CKPT_I16; }
 
-void lsn_launch_turbo(const LsnCellDev& c, const LsnCbDev* cb, const int16_t* llr, uint8_t* payload, LsnCbRes* res, uint32_t ncb, uint32_t kmax,
-                      hipStream_t s)
+// cb[0 .. n128) use two wavefronts per code block (P > 64), cb[n128 .. ncb) one; each range is launched with the LDS
+// size of its largest block (40 KiB at K = 6144 -> four code blocks per CU)
+void lsn_launch_turbo(const LsnCellDev& c, const LsnCbDev* cb, const int16_t* llr, uint8_t* payload, LsnCbRes* res, uint32_t n128, uint32_t kmax128,
+                      uint32_t n64, uint32_t kmax64, hipStream_t s)
 {
-  // dynamic LDS sized for the largest block of this launch (40 KiB at K = 6144 -> four code blocks per CU)
   static bool attr_set = false;
-  if (kmax < 512) kmax = 512;  // the scratch in the check-point area needs room
-  kmax = (kmax + 7u) & ~7u;
-  const size_t lds = lsn_turbo_lds_bytes(kmax);
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)k_turbo, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lsn_turbo_lds_bytes(6144));
+    (void)hipFuncSetAttribute((const void*)k_turbo<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lsn_turbo_lds_bytes(6144));
+    (void)hipFuncSetAttribute((const void*)k_turbo<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lsn_turbo_lds_bytes(6144));
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_turbo, dim3(ncb), dim3(64), lds, s, c, cb, llr, payload, res, kmax);
+  auto fix = [](uint32_t k) { return ((k < 512 ? 512u : k) + 7u) & ~7u; };  // the scratch in the check-point area needs room
+  if (n128) hipLaunchKernelGGL(k_turbo<128>, dim3(n128), dim3(128), lsn_turbo_lds_bytes(fix(kmax128)), s, c, cb, llr, payload, res, fix(kmax128));
+  if (n64) hipLaunchKernelGGL(k_turbo<64>, dim3(n64), dim3(64), lsn_turbo_lds_bytes(fix(kmax64)), s, c, cb + n128, llr, payload, res, fix(kmax64));
 }

@@ -315,9 +315,14 @@ void o_rm_turbo_rx_cb(const int16_t* e, int E, int K, int F, int rv, int16_t* d3
 /* ---- windowed max-log-MAP turbo decoder ---- */
 int o_turbo_nwin(int K)
 {
-  int P = 64;
-  while (P > 1 && ((K % P) != 0 || K / P < 32)) P >>= 1;
-  return P;
+  /* largest divisor of K with windows of >= 32 steps that fills one 64-lane group, or two groups when a divisor in
+   * 96..128 exists (design parameter of this restatement: srsRAN's SIMD decoders use 8..32 windows) */
+  int p1 = 1, p2 = 1;
+  for (int P = (K / 32 < 128 ? K / 32 : 128); P >= 1; P--)
+    if (K % P == 0) { p2 = P; break; }
+  for (int P = (K / 32 < 64 ? K / 32 : 64); P >= 1; P--)
+    if (K % P == 0) { p1 = P; break; }
+  return p2 >= 96 ? p2 : p1;
 }
 
 static uint8_t tr_next[8][2], tr_par[8][2];
