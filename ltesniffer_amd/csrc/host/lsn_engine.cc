@@ -95,7 +95,10 @@ Engine::Engine(const lsn_phy_cfg_t& c) : cfg(c)
     HIP_CHECK(hipStreamCreateWithPriority(&stream_a, hipStreamNonBlocking, hi));  // stage A feeds the sequential search
   }
   HIP_CHECK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
-  for (int i = 0; i < NDEC; i++) decode_threads[i] = std::thread([this, i] { decodeLoop(i); });
+  if (const char* e = getenv("LSN_DECODE_THREADS")) ndec = std::max(1, std::min((int)NDEC, atoi(e)));
+  nslots = ndec + 3;
+  front_thread = std::thread([this] { frontLoop(); });
+  for (int i = 0; i < ndec; i++) decode_threads[i] = std::thread([this, i] { decodeLoop(i); });
 }
 
 Engine::~Engine()
@@ -105,6 +108,8 @@ Engine::~Engine()
     stop = true;
   }
   cv_work.notify_all();
+  cv_front.notify_all();
+  if (front_thread.joinable()) front_thread.join();
   for (auto& t : decode_threads)
     if (t.joinable()) t.join();
   (void)hipDeviceSynchronize();
@@ -191,8 +196,8 @@ void Engine::finishStageA(Chunk& ch)
   HIP_CHECK(hipEventSynchronize(ch.ev_a[16]));
   for (int n = 0; n < 8; n++) {
     float ms = 0;
-    if (hipEventElapsedTime(&ms, ch.ev_a[2 * n], ch.ev_a[2 * n + 1]) == hipSuccess) perf.kernel_ms[kStageA[n]] += ms;
-    perf.kernel_launches[kStageA[n]]++;
+    if (hipEventElapsedTime(&ms, ch.ev_a[2 * n], ch.ev_a[2 * n + 1]) == hipSuccess) perf_front.kernel_ms[kStageA[n]] += ms;
+    perf_front.kernel_launches[kStageA[n]]++;
   }
   const uint64_t A = cfg.nof_rx_antennas, P = cell.nof_ports;
   for (uint32_t i = 0; i < ch.nsf; i++) {
@@ -201,7 +206,7 @@ void Engine::finishStageA(Chunk& ch)
     // host-side scalars, same expressions as the device-free part of the estimator
     c.snr_db = 10.0f * log10f(ch.h_chest[i].rsrp_avg / ch.h_chest[i].noise_avg);
     c.cfo_hz = atan2f(ch.h_chest[i].corr_i, ch.h_chest[i].corr_r) / (2.0f * (float)M_PI * 0.0005f);
-    perf.algo_bytes += A * cd.sflen * 8ull + 2ull * A * 14ull * cd.nre * 8ull + 2ull * P * A * 14ull * cd.nre * 8ull +
+    perf_front.algo_bytes += A * cd.sflen * 8ull + 2ull * A * 14ull * cd.nre * 8ull + 2ull * P * A * 14ull * cd.nre * 8ull +
                        2ull * cd.nof_cce[c.cfi - 1] * 72ull * 4ull;
   }
 }
@@ -663,6 +668,64 @@ void Engine::decodeLoop(int idx)
 }
 
 // ------------------------------------------------------------------------------------------------ batch driver
+// front thread: stage A of chunk i+1 is launched before chunk i is waited for, finished chunks go to the search thread
+void Engine::frontLoop()
+{
+  pinThisThread(nullptr);
+  for (;;) {
+    FrontJob job;
+    {
+      std::unique_lock<std::mutex> lk(mtx);
+      cv_front.wait(lk, [&] { return stop || front_job.pending; });
+      if (!front_job.pending) return;
+      job = front_job;
+      front_job.pending = false;
+    }
+    const uint32_t nchunks = (job.nsf_total + max_batch - 1) / max_batch;
+    std::string err;
+    try {
+      (void)hipSetDevice(cfg.device);
+      const size_t sf_stride = (size_t)cfg.nof_rx_antennas * cd.sflen * sizeof(cf32);
+      auto acquire = [&](uint32_t ci) -> Chunk* {
+        Chunk& ch = chunks[ci % (uint32_t)nslots];
+        {
+          std::unique_lock<std::mutex> lk(mtx);
+          cv_done.wait(lk, [&] { return !ch.busy; });
+          ch.busy = true;
+        }
+        const uint32_t base = ci * max_batch;
+        ch.nsf = std::min(max_batch, job.nsf_total - base);
+        ch.start_tti = job.start_tti + base;
+        ch.jobs.clear(); ch.h_payload.clear();
+        for (uint32_t i = 0; i < ch.nsf; i++) ch.ctx[i].reset(ch.start_tti + i);
+        launchStageA(ch, (const uint8_t*)job.d_iq + (size_t)base * sf_stride);
+        return &ch;
+      };
+      Chunk* cur = nchunks ? acquire(0) : nullptr;
+      for (uint32_t ci = 0; ci < nchunks; ci++) {
+        Chunk* next = (ci + 1 < nchunks) ? acquire(ci + 1) : nullptr;
+        const double t0 = now_ms();
+        finishStageA(*cur);
+        perf_front.ms_stage_a += now_ms() - t0;
+        {
+          std::unique_lock<std::mutex> lk(mtx);
+          search_queue.push_back(cur);
+        }
+        cv_search.notify_one();
+        cur = next;
+      }
+    } catch (const std::exception& ex) {
+      err = ex.what();
+    }
+    if (!err.empty()) {
+      std::unique_lock<std::mutex> lk(mtx);
+      front_error = err;
+      search_queue.push_back(nullptr);
+      cv_search.notify_one();
+    }
+  }
+}
+
 int Engine::process(const void* d_iq, uint32_t nsf_total, uint32_t start_tti, uint32_t update_meta_period, hipStream_t stream)
 {
   if (!cell_set) return LSN_ERROR;
@@ -673,36 +736,31 @@ int Engine::process(const void* d_iq, uint32_t nsf_total, uint32_t start_tti, ui
   try {
     HIP_CHECK(hipSetDevice(cfg.device));
     perf = lsn_perf_t{};
+    perf_front = lsn_perf_t{};
     for (auto& r : runner_c) r.perf = lsn_perf_t{};
     runner_s.perf = lsn_perf_t{};
     const double t_all = now_ms();
     // the caller's stream orders the IQ buffer: stage A starts after everything queued on it so far
     HIP_CHECK(hipEventRecord(ev_in, stream));
     HIP_CHECK(hipStreamWaitEvent(stream_a, ev_in, 0));
-    const size_t sf_stride = (size_t)cfg.nof_rx_antennas * cd.sflen * sizeof(cf32);
     const uint32_t nchunks = (nsf_total + max_batch - 1) / max_batch;
-    auto acquire = [&](uint32_t ci) -> Chunk& {
-      Chunk& ch = chunks[ci % NSLOTS];
+    {
+      std::unique_lock<std::mutex> lk(mtx);
+      front_job.d_iq = d_iq; front_job.nsf_total = nsf_total; front_job.start_tti = start_tti; front_job.pending = true;
+    }
+    cv_front.notify_one();
+    std::string err;
+    for (uint32_t ci = 0; ci < nchunks; ci++) {
+      Chunk* cur = nullptr;
       {
         std::unique_lock<std::mutex> lk(mtx);
-        cv_done.wait(lk, [&] { return !ch.busy; });
-        ch.busy = true;
+        cv_search.wait(lk, [&] { return !search_queue.empty(); });
+        cur = search_queue.front();
+        search_queue.pop_front();
+        if (!cur) { err = front_error; front_error.clear(); }
       }
-      const uint32_t base = ci * max_batch;
-      ch.nsf = std::min(max_batch, nsf_total - base);
-      ch.start_tti = start_tti + base;
-      ch.jobs.clear(); ch.h_payload.clear();
-      for (uint32_t i = 0; i < ch.nsf; i++) ch.ctx[i].reset(ch.start_tti + i);
-      launchStageA(ch, (const uint8_t*)d_iq + (size_t)base * sf_stride);
-      return ch;
-    };
-    Chunk* cur = nchunks ? &acquire(0) : nullptr;
-    for (uint32_t ci = 0; ci < nchunks; ci++) {
-      Chunk* next = (ci + 1 < nchunks) ? &acquire(ci + 1) : nullptr;  // stage A of the next chunk overlaps this chunk's search
-      double t0 = now_ms();
-      finishStageA(*cur);
-      double t1 = now_ms();
-      perf.ms_stage_a += t1 - t0;
+      if (!cur) break;
+      const double t1 = now_ms();
       searchChunk(*cur, update_meta_period);
       perf.ms_search += now_ms() - t1;
       {
@@ -712,24 +770,26 @@ int Engine::process(const void* d_iq, uint32_t nsf_total, uint32_t start_tti, ui
       }
       cv_work.notify_one();
       last_chunk = cur;
-      cur = next;
     }
     {
       std::unique_lock<std::mutex> lk(mtx);
       cv_done.wait(lk, [&] { return seq_committed == seq_pushed; });
-      if (!commit_error.empty()) { std::string e = commit_error; commit_error.clear(); throw std::runtime_error(e); }
+      if (err.empty() && !commit_error.empty()) err = commit_error;
+      commit_error.clear();
+    }
+    if (!err.empty()) {
+      std::unique_lock<std::mutex> lk(mtx);
+      for (auto& ch : chunks) ch.busy = false;
+      throw std::runtime_error(err);
     }
     perf.nof_candidates_decoded = search->nof_lookups; search->nof_lookups = 0;
+    mergePerf(perf_front);
     for (auto& r : runner_c) mergePerf(r.perf);
     mergePerf(runner_s.perf);
     perf.ms_total = now_ms() - t_all;
     return LSN_SUCCESS;
   } catch (const std::exception& ex) {
     fprintf(stderr, "ltesniffer_amd: %s\n", ex.what());
-    // drain the pipeline so that the slots are reusable
-    std::unique_lock<std::mutex> lk(mtx);
-    cv_done.wait(lk, [&] { return seq_committed == seq_pushed; });
-    for (auto& ch : chunks) ch.busy = false;
     return LSN_ERROR;
   }
 }

@@ -86,8 +86,9 @@ public:
   void forceMetaUpdateNext() { force_meta_next = true; }
 
 private:
-  static constexpr int NDEC = 3;             // decode threads (each: plan + stage-C launches of one chunk; commits stay in order)
+  static constexpr int NDEC = 8;             // max decode threads (each: plan + stage-C launches of one chunk; commits stay in order)
   static constexpr int NSLOTS = NDEC + 2;
+  int ndec = 6, nslots = 9;                  // in use (LSN_DECODE_THREADS)
   void freeDevice();
   void buildTables();
   void allocChunk(Chunk& ch);
@@ -104,6 +105,7 @@ private:
   void unpackRar(const uint8_t* p, int len, bool at_search);
   void emitPdu(JobRunner& r, const char* name, const uint8_t* pdu, uint32_t len, uint16_t rnti, uint32_t tti, uint8_t tb);
   void decodeLoop(int idx);
+  void frontLoop();
   void mergePerf(const lsn_perf_t& p);
   void detectNumaCpus();
   bool pinThisThread(void* saved_mask);   // bind the calling thread to the CPUs of the GPU's NUMA node
@@ -125,6 +127,13 @@ private:
   std::unique_ptr<FalconSearch> search;
   MCSTracking mcs_tracking;
   std::mutex mcs_mtx;  // planJobs (prediction) vs commitChunk (authoritative updates)
+  // front thread: launches stage A chunk after chunk, hands finished chunks to the search (caller) thread
+  std::thread front_thread;
+  struct FrontJob { const void* d_iq = nullptr; uint32_t nsf_total = 0, start_tti = 0; bool pending = false; } front_job;
+  std::deque<Chunk*> search_queue;
+  std::condition_variable cv_front, cv_search;
+  std::string front_error;
+  lsn_perf_t perf_front{};
   // decode threads
   std::thread decode_threads[NDEC];
   uint64_t seq_pushed = 0, seq_committed = 0;  // chunks queued / committed (commit order = queue order)

@@ -278,10 +278,10 @@ void Engine::buildTables()
     cd.crc_tab_a = upload(dev_allocs, ta); cd.crc_tab_b = upload(dev_allocs, tb);
   }
   // pipeline slots, decode runners, staging
-  for (auto& ch : chunks) allocChunk(ch);
-  for (auto& r : runner_c) allocRunner(r);
+  for (int i = 0; i < nslots; i++) allocChunk(chunks[i]);
+  for (int i = 0; i < ndec; i++) allocRunner(runner_c[i]);
   allocRunner(runner_s);
-  staging_sf = max_batch * NSLOTS;
+  staging_sf = (size_t)max_batch * nslots;
   d_iq_staging = dalloc<cf32>(dev_allocs, staging_sf * cfg.nof_rx_antennas * cd.sflen);
 }
 

@@ -8,6 +8,7 @@
 // forward metrics check-pointed every 16 steps and recomputed so that the block fits 2 workgroups per CU.
 #include "lsn_dev.h"
 #include "lsn_rm.h"
+#include <type_traits>
 
 #define SQRT1_2F 0.70710678118654752440f
 #define SQRT2F 1.41421356237309504880f
@@ -227,7 +228,7 @@ __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 __device__ __forceinline__ int ext_scale(int x)
 {
   int a = x < 0 ? -x : x;
-  a = (a * 3) >> 2;
+  a = (a + (a << 1)) >> 2;  // * 3/4
   a = a > LSN_EXT_CLIP ? LSN_EXT_CLIP : a;
   return x < 0 ? -a : a;
 }
@@ -246,10 +247,12 @@ struct TurboLds {
   int16_t* ckpt;   // [slot][7][NT]; also the exchange buffer for the window-boundary metrics
 };
 
+// x -> (x % W) * P + x / W with full-rate 24-bit multiplies; magicW = ceil(2^20 / W) is exact for x < 6144, W <= 96
+// (error x / 2^20 < 1 / W)
 __device__ __forceinline__ int tr_idx(int x, int W, int P, uint32_t magicW)
 {
-  const int q = (int)__umulhi((uint32_t)x, magicW);
-  return (x - q * W) * P + q;
+  const int q = (int)(__umul24((uint32_t)x, magicW) >> 20);
+  return __mul24(x - __mul24(q, W), P) + q;
 }
 __device__ __forceinline__ int fld0(uint32_t w) { return (int)(w << 22) >> 22; }
 __device__ __forceinline__ int fld1(uint32_t w) { return (int)(w << 12) >> 22; }
@@ -331,19 +334,22 @@ __device__ __forceinline__ void map_pass(const TurboLds& m, int lane, bool activ
         for (int s = 1; s < 8; s++) a[s] = m.ckpt[((sb - 1) * 7 + (s - 1)) * NT + lane];
       }
     }
+    // (only the last sub-block of a window can be shorter than TB_S: the full-length variant carries no per-step guards)
+    auto subblock = [&](auto fullc) {
+      constexpr bool FULL = decltype(fullc)::value;
     // operand burst, last step first (the QPP recursion runs in reverse)
 #pragma unroll
     for (int u = TB_S - 1; u >= 0; u--) {
-      if (u < n) {
+      if (FULL || u < n) {
         const int nat = (tb + u) * P + wl;
         if (IL) {
           gq -= twof2; gq = gq < 0 ? gq + K : gq; pi -= gq; pi = pi < 0 ? pi + K : pi;
           const int idx = tr_idx(pi, W, P, magicW);
-          ix[u] = idx;
+          ix[u] = active ? idx : K;
           g[u] = ((fld0(m.spp[idx]) + ((int)m.ext[idx] >> 1)) & 0xFFFF) | (fld2(m.spp[nat]) << 16);
         } else {
           const uint32_t w = m.spp[nat];
-          ix[u] = nat;
+          ix[u] = active ? nat : K;
           g[u] = ((fld0(w) + ((int)m.ext[nat] >> 1)) & 0xFFFF) | (fld1(w) << 16);
         }
       }
@@ -351,7 +357,7 @@ __device__ __forceinline__ void map_pass(const TurboLds& m, int lane, bool activ
     // recompute the alphas of this sub-block into registers
 #pragma unroll
     for (int u = 0; u < TB_S; u++) {
-      if (u < n) {
+      if (FULL || u < n) {
         A[u][0] = ((uint32_t)a[1] & 0xFFFFu) | ((uint32_t)a[2] << 16);
         A[u][1] = ((uint32_t)a[3] & 0xFFFFu) | ((uint32_t)a[4] << 16);
         A[u][2] = ((uint32_t)a[5] & 0xFFFFu) | ((uint32_t)a[6] << 16);
@@ -366,7 +372,7 @@ __device__ __forceinline__ void map_pass(const TurboLds& m, int lane, bool activ
     // beta recursion + LLR + extrinsic
 #pragma unroll
     for (int u = TB_S - 1; u >= 0; u--) {
-      if (u < n) {
+      if (FULL || u < n) {
         const int lsa = (int)(g[u] << 16) >> 16, lp = g[u] >> 16;
         const int al1 = (int)(A[u][0] << 16) >> 16, al2 = (int)A[u][0] >> 16, al3 = (int)(A[u][1] << 16) >> 16, al4 = (int)A[u][1] >> 16;
         const int al5 = (int)(A[u][2] << 16) >> 16, al6 = (int)A[u][2] >> 16, al7 = (int)A[u][3];
@@ -383,13 +389,15 @@ __device__ __forceinline__ void map_pass(const TurboLds& m, int lane, bool activ
         const int m0 = imax(imax(imax(x00, al1 + x10), imax(al2 + x20, al3 + x30)), imax(imax(al4 + x40, al5 + x50), imax(al6 + x60, al7 + x70)));
         const int m1 = imax(imax(imax(x01, al1 + x11), imax(al2 + x21, al3 + x31)), imax(imax(al4 + x41, al5 + x51), imax(al6 + x61, al7 + x71)));
         const int L = m1 - m0;
-        if (active) m.ext[ix[u]] = (int16_t)((ext_scale(L - lsa) << 1) | (L > 0 ? 1 : 0));
+        m.ext[ix[u]] = (int16_t)((ext_scale(L - lsa) << 1) | (L > 0 ? 1 : 0));  // idle lanes: spare slot ext[K]
         const int n0 = imax(x00, x01);
         b[1] = imax(x10, x11) - n0; b[2] = imax(x20, x21) - n0; b[3] = imax(x30, x31) - n0; b[4] = imax(x40, x41) - n0;
         b[5] = imax(x50, x51) - n0; b[6] = imax(x60, x61) - n0; b[7] = imax(x70, x71) - n0;
         b[0] = 0;
       }
     }
+      };
+    if (n == TB_S) subblock(std::true_type{}); else subblock(std::false_type{});
   }
   // next-iteration initialisation: window p starts from the end of window p-1 and ends at the start of window p+1.
   // The exchange goes through the (now idle) check-point area: [14][NT] int16.
@@ -440,7 +448,8 @@ __device__ __forceinline__ uint32_t wg_xor(uint32_t v, int16_t* scratch, int tid
 }
 
 template <int NT>
-__global__ __launch_bounds__(NT) void k_turbo(LsnCellDev c, const LsnCbDev* __restrict__ cbs, const int16_t* __restrict__ llr,
+__global__ __launch_bounds__(NT) void k_turbo(const uint32_t* __restrict__ crc_tab_a, const uint32_t* __restrict__ crc_tab_b,
+                                              const LsnCbDev* __restrict__ cbs, const int16_t* __restrict__ llr,
                                               uint8_t* __restrict__ payload, LsnCbRes* __restrict__ res, uint32_t kmax)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -448,10 +457,10 @@ __global__ __launch_bounds__(NT) void k_turbo(LsnCellDev c, const LsnCbDev* __re
   const LsnCbDev cb = cbs[blockIdx.x];
   const int lane = threadIdx.x, K = (int)cb.K, F = (int)cb.F;
   const int P = lsn_turbo_nwin(K), W = K / P;
-  const uint32_t magicW = (uint32_t)(0x100000000ull / (unsigned)W) + (((W & (W - 1)) == 0) ? 0u : 1u);
+  const uint32_t magicW = ((1u << 20) + (uint32_t)W - 1u) / (uint32_t)W;
   const bool active = lane < P;
   TurboLds m;
-  m.spp = (uint32_t*)smem; m.ext = (int16_t*)(m.spp + kmax); m.ckpt = m.ext + kmax;
+  m.spp = (uint32_t*)smem; m.ext = (int16_t*)(m.spp + kmax); m.ckpt = m.ext + kmax + 8;  // ext[K] = spare slot for idle lanes
   // the check-point area doubles as scratch for the rate-matcher geometry and the 12 termination values
   LsnRmGeom& geom = *(LsnRmGeom*)m.ckpt;
   int* tail = (int*)(m.ckpt + 1024);
@@ -470,15 +479,21 @@ __global__ __launch_bounds__(NT) void k_turbo(LsnCellDev c, const LsnCbDev* __re
     // threads own rows, eight sub-block columns (24 buffer entries) are gathered per batch so that the global loads of a
     // batch are all in flight together; entry j of the batch adds e[first_j + r * nn] for r = 0 .. nrep-1 (repetition)
     const int nrep = E > 0 ? (E + nn - 1) / nn : 0;
-    for (int row = lane; row < R; row += NT) {
-      for (int cb8 = 0; cb8 < 32; cb8 += 8) {
+    for (int cb8 = 0; cb8 < 32; cb8 += 8) {
+      // per-column constants of the batch (registers: the LDS copy cannot be hoisted past the atomics below)
+      int c01[8], b01[8], b2[8], f2c[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) {
+        c01[q] = (int)geom.cnt01[cb8 + q]; b01[q] = geom.pre01[cb8 + q]; b2[q] = geom.pre2[cb8 + q]; f2c[q] = (int)geom.first2[cb8 + q];
+      }
+      for (int row = lane; row < R; row += NT) {
         int first[24], acc[24];
 #pragma unroll
         for (int q = 0; q < 8; q++) {
-          const int col = cb8 + q, p = lsn_perm_tc_f(col), c01 = (int)geom.cnt01[col];
+          const int col = cb8 + q, p = lsn_perm_tc_f(col);
           const int k = col * R + row, y = row * 32 + p;
-          const int nb01 = geom.pre01[col] + (row < c01 ? row : c01), nb2 = geom.pre2[col] + (row > 0 ? (int)geom.first2[col] : 0);
-          const bool null01 = row < c01;
+          const int nb01 = b01[q] + (row < c01[q] ? row : c01[q]), nb2 = b2[q] + (row > 0 ? f2c[q] : 0);
+          const bool null01 = row < c01[q];
           const int cum1 = nn0 + (k - nb01) + (k - nb2);
           const int i2 = (y + 1 == KP ? 0 : y + 1) - ND;
           first[3 * q + 0] = null01 ? E : lsn_rm_eidx(geom, k - nb01);
@@ -497,7 +512,7 @@ __global__ __launch_bounds__(NT) void k_turbo(LsnCellDev c, const LsnCbDev* __re
 #pragma unroll
         for (int q = 0; q < 8; q++) {
           const int col = cb8 + q, p = lsn_perm_tc_f(col), y = row * 32 + p;
-          const bool null01 = row < (int)geom.cnt01[col];
+          const bool null01 = row < c01[q];
           const int i2 = (y + 1 == KP ? 0 : y + 1) - ND;
 #pragma unroll
           for (int j = 0; j < 3; j++) {
@@ -524,7 +539,7 @@ __global__ __launch_bounds__(NT) void k_turbo(LsnCellDev c, const LsnCbDev* __re
   const long long tc1 = clock64();
   const uint32_t poly = cb.crc_b ? 0x1800063u : 0x1864CFBu;
   // weight of this thread's window in the block polynomial: x^((P-1-window) W) mod g
-  const uint32_t cw = active ? (cb.crc_b ? c.crc_tab_b : c.crc_tab_a)[(P - 1 - lane) * W] : 0u;
+  const uint32_t cw = active ? (cb.crc_b ? crc_tab_b : crc_tab_a)[(P - 1 - lane) * W] : 0u;
   int na1[7], nb1[7], na2[7], nb2[7];
 #pragma unroll
   for (int s = 0; s < 7; s++) { na1[s] = 0; nb1[s] = 0; na2[s] = 0; nb2[s] = 0; }
@@ -563,7 +578,7 @@ __global__ __launch_bounds__(NT) void k_turbo(LsnCellDev c, const LsnCbDev* __re
     }
     outp[j] = (uint8_t)byte;
   }
-  if (j0 < j1) rema = mulmod24(rema, c.crc_tab_a[8 * (nout - j1)], 0x1864CFBu);
+  if (j0 < j1) rema = mulmod24(rema, crc_tab_a[8 * (nout - j1)], 0x1864CFBu);
   rema = wg_xor<NT>(rema, m.ckpt, lane);
   if (lane == 0) {
     const long long tc3 = clock64();
@@ -573,7 +588,7 @@ __global__ __launch_bounds__(NT) void k_turbo(LsnCellDev c, const LsnCbDev* __re
   }
 }
 
-size_t lsn_turbo_lds_bytes(uint32_t kmax) { return 6 * (size_t)kmax + sizeof(int16_t) * TB_CKPT_I16; }
+size_t lsn_turbo_lds_bytes(uint32_t kmax) { return 6 * (size_t)kmax + 16 + sizeof(int16_t) * TB_CKPT_I16; }
 
 // cb[0 .. n128) use two wavefronts per code block (P > 64), cb[n128 .. ncb) one; each range is launched with the LDS
 // size of its largest block (40 KiB at K = 6144 -> four code blocks per CU)
@@ -587,6 +602,6 @@ void lsn_launch_turbo(const LsnCellDev& c, const LsnCbDev* cb, const int16_t* ll
     attr_set = true;
   }
   auto fix = [](uint32_t k) { return ((k < 512 ? 512u : k) + 7u) & ~7u; };  // the scratch in the check-point area needs room
-  if (n128) hipLaunchKernelGGL(k_turbo<128>, dim3(n128), dim3(128), lsn_turbo_lds_bytes(fix(kmax128)), s, c, cb, llr, payload, res, fix(kmax128));
-  if (n64) hipLaunchKernelGGL(k_turbo<64>, dim3(n64), dim3(64), lsn_turbo_lds_bytes(fix(kmax64)), s, c, cb + n128, llr, payload, res, fix(kmax64));
+  if (n128) hipLaunchKernelGGL(k_turbo<128>, dim3(n128), dim3(128), lsn_turbo_lds_bytes(fix(kmax128)), s, c.crc_tab_a, c.crc_tab_b, cb, llr, payload, res, fix(kmax128));
+  if (n64) hipLaunchKernelGGL(k_turbo<64>, dim3(n64), dim3(64), lsn_turbo_lds_bytes(fix(kmax64)), s, c.crc_tab_a, c.crc_tab_b, cb + n128, llr, payload, res, fix(kmax64));
 }
