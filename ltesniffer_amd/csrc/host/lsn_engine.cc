@@ -211,6 +211,45 @@ void Engine::finishStageA(Chunk& ch)
   }
 }
 
+// RA-RNTI grants feed the RNTI manager between two subframes of the sequential search (DL_Sniffer_PDSCH.cc:782-797).
+// Every candidate the search could possibly accept as such a grant - CRC remainder 2..9, format 1A / 1C, a location of
+// the common search space - is decoded here, ahead of the search and in one batch per chunk, so that the search thread
+// finds the result instead of waiting for a GPU round trip.  Unused speculative decodes are simply dropped.
+void Engine::speculateRar(Chunk& ch)
+{
+  ch.spec_rar.clear();
+  std::vector<int> ids;
+  const DciFormat fmts[2] = {FORMAT1A, FORMAT1C};
+  for (uint32_t sf = 0; sf < ch.nsf; sf++) {
+    const SubframeCtx& c = ch.ctx[sf];
+    if (!(c.snr_db > 6.0f)) continue;
+    const uint32_t ncce = cd.nof_cce[c.cfi - 1], lim = std::min<uint32_t>(ncce, LSN_MAX_NUM_OF_CCE);
+    uint32_t li = 0;
+    for (int l = 3; l >= 2; l--) {  // aggregation levels 8 and 4 come first in the location enumeration
+      const uint32_t L = 1u << l, cnt = lim / L;
+      for (uint32_t i = 0; i < cnt; i++, li++) {
+        if (L * (i % (ncce / L)) >= 16) continue;  // common search space: first 16 CCEs
+        for (DciFormat f : fmts) {
+          const LsnCand& q = ch.h_cand[((size_t)sf * LSN_MAX_LOC + li) * LSN_MAX_SIZES + search->sizeIndexOfFormat(f)];
+          if (!q.flags || !(q.rnti > RARNTI_START && q.rnti < RARNTI_END)) continue;
+          if (f == FORMAT1A && (q.bits >> 63) == 0) continue;  // that payload is a format 0
+          bool dup = false;
+          for (auto& s : ch.spec_rar) dup = dup || (s.sf == sf && s.rnti == q.rnti && s.format == f && s.bits == q.bits);
+          if (dup) continue;
+          DlEntry e;
+          if (!search->buildDlEntry(c, (uint16_t)q.rnti, f, q.bits, e) || !e.ok64) continue;
+          if (!(e.grant64.tb[0].tbs > 0) || (cfg.nof_rx_antennas == 1 && e.grant64.nof_tb == 2)) continue;
+          const int j = newJob(ch, sf, e, 0);
+          if (j < 0) continue;
+          ch.spec_rar.push_back({sf, (uint16_t)q.rnti, f, q.bits, j});
+          ids.push_back(j);
+        }
+      }
+    }
+  }
+  if (!ids.empty()) runJobs(ch, runner_f, ids);
+}
+
 // ------------------------------------------------------------------------------------------------ stage B (caller thread)
 // The candidate tables were just written by DMA, i.e. none of their lines is in a CPU cache: pull the next subframe's
 // table (157 locations x 128 B) towards the core while the current subframe is searched.
@@ -242,13 +281,18 @@ void Engine::searchChunk(Chunk& ch, uint32_t update_meta_period)
       const bool dci_ok = e.unpack_ok && e.ok64;
       const bool two_tb = e.grant64.nof_tb == 2;
       if (!(e.grant64.tb[0].tbs > 0 && dci_ok && !(cfg.nof_rx_antennas == 1 && two_tb))) continue;
-      const int j = newJob(ch, sf, e, 0);
+      int j = -1;
+      for (auto& s : ch.spec_rar)  // decoded ahead by the front thread?
+        if (s.sf == sf && s.rnti == e.rnti && s.format == e.format && s.bits == e.bits && ch.jobs[s.job].done) { j = s.job; break; }
+      if (j < 0) {
+        j = newJob(ch, sf, e, 0);
+        if (j < 0) continue;
+        const double tr0 = now_ms();
+        ensureJob(ch, runner_s, j);
+        runner_s.perf.ms_rar += now_ms() - tr0;
+        runner_s.perf.nof_ondemand_decodes++;
+      }
       e.job[0] = j;
-      if (j < 0) continue;
-      const double tr0 = now_ms();
-      ensureJob(ch, runner_s, j);
-      runner_s.perf.ms_rar += now_ms() - tr0;
-      runner_s.perf.nof_ondemand_decodes++;
       for (int tb = 0; tb < 2; tb++) {
         const int len = ch.jobs[j].grant.tb[tb].tbs / 8;
         if (ch.jobs[j].crc[tb] && len > 0) unpackRar(ch.h_payload.data() + ch.jobs[j].payload_off[tb], len, true);
@@ -706,6 +750,7 @@ void Engine::frontLoop()
         Chunk* next = (ci + 1 < nchunks) ? acquire(ci + 1) : nullptr;
         const double t0 = now_ms();
         finishStageA(*cur);
+        speculateRar(*cur);
         perf_front.ms_stage_a += now_ms() - t0;
         {
           std::unique_lock<std::mutex> lk(mtx);
@@ -739,6 +784,7 @@ int Engine::process(const void* d_iq, uint32_t nsf_total, uint32_t start_tti, ui
     perf_front = lsn_perf_t{};
     for (auto& r : runner_c) r.perf = lsn_perf_t{};
     runner_s.perf = lsn_perf_t{};
+    runner_f.perf = lsn_perf_t{};
     const double t_all = now_ms();
     // the caller's stream orders the IQ buffer: stage A starts after everything queued on it so far
     HIP_CHECK(hipEventRecord(ev_in, stream));
@@ -786,6 +832,7 @@ int Engine::process(const void* d_iq, uint32_t nsf_total, uint32_t start_tti, ui
     mergePerf(perf_front);
     for (auto& r : runner_c) mergePerf(r.perf);
     mergePerf(runner_s.perf);
+    mergePerf(runner_f.perf);
     perf.ms_total = now_ms() - t_all;
     return LSN_SUCCESS;
   } catch (const std::exception& ex) {

@@ -43,6 +43,8 @@ struct Chunk {
   std::vector<DecodeJob> jobs;
   std::vector<uint8_t> h_payload;
   hipEvent_t ev_a[2 * 8 + 1] = {};  // per stage-A kernel class start/stop + "mirrors on host"
+  struct SpecRar { uint32_t sf; uint16_t rnti; DciFormat format; unsigned long long bits; int job; };
+  std::vector<SpecRar> spec_rar;     // RA-RNTI grants decoded ahead of the search (front thread)
   bool busy = false;                 // owned by the pipeline (slot not reusable yet)
   uint64_t seq = 0;                  // position in the commit order
 };
@@ -97,6 +99,7 @@ private:
   void launchStageA(Chunk& ch, const void* d_iq);
   void finishStageA(Chunk& ch);
   void searchChunk(Chunk& ch, uint32_t update_meta_period);
+  void speculateRar(Chunk& ch);
   void planJobs(Chunk& ch, JobRunner& r);
   void runJobs(Chunk& ch, JobRunner& r, std::vector<int>& job_ids);
   void ensureJob(Chunk& ch, JobRunner& r, int j);
@@ -121,7 +124,7 @@ private:
   void* d_iq_staging = nullptr;
   size_t staging_sf = 0;
   Chunk chunks[NSLOTS];
-  JobRunner runner_c[NDEC], runner_s;  // decode threads / search thread (on-demand RAR decodes)
+  JobRunner runner_c[NDEC], runner_s, runner_f;  // decode threads / search thread (on-demand RAR decodes) / front thread (speculative RAR decodes)
   hipStream_t stream_a = nullptr;
   hipEvent_t ev_in = nullptr;
   std::unique_ptr<FalconSearch> search;

@@ -55,6 +55,7 @@ struct Sizer {
 
 uint32_t dci_format_sizeof(const Cell& cell, DciFormat f)
 {
+  if ((unsigned)f < 9u && cell.fmt_size[f]) return cell.fmt_size[f];
   Sizer z{cell.nof_prb, cell.nof_ports};
   const uint32_t tpmi = cell.nof_ports == 4 ? 4 : 2;
   switch (f) {
@@ -267,6 +268,8 @@ void cell_build_re_tables(Cell& cell)
           (*t)[((cl * 5 + l0) * 2 + l / 7) * n + prb] += c;
         }
   cell.re_count = t;
+  for (int f = 0; f < 9; f++) cell.fmt_size[f] = 0;
+  for (int f = 0; f < 9; f++) cell.fmt_size[f] = dci_format_sizeof(plain, (DciFormat)f);
 }
 
 static uint32_t ra_dl_compute_nof_re(const Cell& cell, uint32_t sf_idx, uint32_t cfi, const PdschGrant& g)
@@ -482,6 +485,23 @@ void Histogram::add(uint16_t item, uint32_t nTimes)
   }
 }
 
+void Histogram::addZeros(uint32_t nTimes)
+{
+  uint32_t gained = 0;  // net increase of the count of item 0
+  while (nTimes-- > 0) {
+    if (rnti_histogram_ready) {
+      const uint16_t old = rnti_history[rnti_history_current];
+      if (old) { rnti_histogram[old]--; total[old]--; rnti_history[rnti_history_current] = 0; gained++; }
+    } else {
+      rnti_history[rnti_history_current] = 0;
+      gained++;
+    }
+    if (++rnti_history_current == rnti_history_end) { rnti_histogram_ready = true; rnti_history_current = 0; }
+  }
+  rnti_histogram[0] += gained;
+  total[0] += gained;
+}
+
 RNTIManager::RNTIManager(uint32_t nf, uint32_t maxCand, uint32_t thr)
     : nformats(nf), histograms(nf, Histogram(200 * (304 / 5), 65536)), evergreen(nf), forbidden(nf), active(65536, 0), reason(65536, 0),
       lastSeen(65536, 0), assocFormatIdx(65536, 0), nactive(0), timestamp(0), lifetime(10000), threshold(thr),
@@ -524,7 +544,7 @@ void RNTIManager::activateAndRefresh(uint16_t rnti, uint32_t f, ActivationReason
 void RNTIManager::stepTime()
 {
   for (uint32_t i = 0; i < nformats; i++) {
-    if (remainingCandidates[i] > 0) histograms[i].add(0, (uint32_t)remainingCandidates[i]);
+    if (remainingCandidates[i] > 0) histograms[i].addZeros((uint32_t)remainingCandidates[i]);
     remainingCandidates[i] = (int32_t)maxCandidatesPerStepPerFormat;
   }
   timestamp++;

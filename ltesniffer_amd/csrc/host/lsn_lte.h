@@ -30,6 +30,7 @@ struct Cell {
   // optional acceleration table built by cell_build_re_tables(): PDSCH-capable REs per (subframe class, first PDSCH
   // symbol l0 0..4, slot, PRB); class 0: subframe 0, 1: subframe 5, 2: any other (srsran_ra_dl_compute_nof_re [srsRAN])
   std::shared_ptr<std::vector<uint16_t>> re_count;
+  uint32_t fmt_size[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};  // cached dci_format_sizeof (0 = not cached), filled by cell_build_re_tables()
 };
 void cell_build_re_tables(Cell& cell);
 
@@ -72,6 +73,7 @@ class Histogram {
 public:
   Histogram(uint32_t itemCount, uint32_t valueRange);
   void add(uint16_t item, uint32_t nTimes = 1);
+  void addZeros(uint32_t nTimes);  // == add(0, nTimes), without touching the counters of slots that already hold 0
   void setTotals(uint32_t* t) { total = t; }  // shared per-RNTI sum over all formats (fast reject in RNTIManager::validate)
   uint32_t getFrequency(uint16_t item) const { return rnti_histogram[item]; }
 private:

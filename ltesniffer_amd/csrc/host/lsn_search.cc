@@ -52,7 +52,11 @@ uint32_t SearchSpace::validate(uint32_t cfi, uint32_t ncce, uint32_t l, uint32_t
   };
   uint32_t Yk = rnti;
   if (ue)
-    for (uint32_t m = 0; m <= nsubframe; m++) Yk = (39827u * Yk) % 65537u;
+    for (uint32_t m = 0; m <= nsubframe; m++) {  // Yk = (39827 * Yk) mod 65537 with 65537 = 2^16 + 1: x mod = lo16 - hi16 (+ 65537)
+      const uint32_t x = 39827u * Yk;
+      const int32_t t = (int32_t)(x & 0xFFFFu) - (int32_t)(x >> 16);
+      Yk = (uint32_t)(t < 0 ? t + 65537 : t);
+    }
   if (!member(l, Yk)) return 0;
   if (l > 0 && member(l - 1, Yk)) return 1;
   return 2;
@@ -137,7 +141,7 @@ void FalconSearch::addCandidate(SubframeCtx& c, const DciCandidate& cand, uint32
   if (c.dl.size() >= 64) return;
   c.dl.emplace_back();
   DlEntry& e = c.dl.back();
-  e.rnti = cand.rnti; e.format = fmt; e.nof_bits = cand.msg.nof_bits; e.L = L; e.ncce = ncce; e.histval = histval;
+  e.rnti = cand.rnti; e.format = fmt; e.nof_bits = cand.msg.nof_bits; e.L = L; e.ncce = ncce; e.histval = histval; e.bits = cand.msg.bits;
   e.dci.L = L; e.dci.ncce = ncce;
   e.unpack_ok = dci_msg_unpack_pdsch(cell, payload, cand.msg.nof_bits, fmt, cand.rnti, e.dci);
   if (e.unpack_ok) {
@@ -152,6 +156,24 @@ void FalconSearch::addCandidate(SubframeCtx& c, const DciCandidate& cand, uint32
       if (e.grant256.tb[i].nof_bits <= 0) e.grant256.tb[i].enabled = false;
     }
   }
+}
+
+bool FalconSearch::buildDlEntry(const SubframeCtx& c, uint16_t rnti, DciFormat fmt, unsigned long long bits, DlEntry& e) const
+{
+  DciMsg msg;
+  msg.bits = bits; msg.nof_bits = size_of_format[fmt]; msg.format = fmt;
+  uint8_t payload[64] = {0};
+  msg.unpack(payload);
+  e = DlEntry();
+  e.rnti = rnti; e.format = fmt; e.nof_bits = msg.nof_bits; e.bits = bits;
+  e.unpack_ok = dci_msg_unpack_pdsch(cell, payload, msg.nof_bits, fmt, rnti, e.dci);
+  if (!e.unpack_ok) return false;
+  dl_sniffer_ra_dl_dci_to_grant_both(cell, c.sf_idx, c.cfi, e.dci, e.grant64, e.ok64, e.grant256, e.ok256);
+  for (int i = 0; i < 2; i++) {
+    if (e.grant64.tb[i].nof_bits <= 0) e.grant64.tb[i].enabled = false;
+    if (e.grant256.tb[i].nof_bits <= 0) e.grant256.tb[i].enabled = false;
+  }
+  return true;
 }
 
 // DCISearch::inspect_dci_location_recursively, DCISearch.cc:102-447

@@ -23,6 +23,7 @@ struct DciCandidate { uint16_t rnti = 0; DciMsg msg; uint32_t search_space_match
 
 struct DlEntry {  // DL_Sniffer_DCI_DL (Sniffer_dependency.h:90)
   uint16_t rnti = 0; DciFormat format = FORMAT1; uint32_t nof_bits = 0, L = 0, ncce = 0, histval = 0;
+  unsigned long long bits = 0;  // DCI payload as decoded (bit i at position 63-i)
   DciDl dci; bool unpack_ok = false;
   PdschGrant grant64, grant256; bool ok64 = false, ok256 = false;  // both tables computed; selection happens at commit
   int job[2] = {-1, -1};                                          // decode job index per table
@@ -66,6 +67,8 @@ public:
   uint32_t nofSizes() const { return nsizes; }
   const uint32_t* sizes() const { return size_list; }
   void setupDefaultIntervals();  // LTESniffer_Core.cc:398-417
+  // the DL entry addCandidate() would build for this candidate (no state is touched): used to decode RA-RNTI grants ahead
+  bool buildDlEntry(const SubframeCtx& c, uint16_t rnti, DciFormat fmt, unsigned long long bits, DlEntry& e) const;
   uint64_t nof_lookups = 0;
 
 private:

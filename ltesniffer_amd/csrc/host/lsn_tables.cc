@@ -62,6 +62,7 @@ void Engine::freeDevice()
   }
   for (auto& r : runner_c) freeRunner(r);
   freeRunner(runner_s);
+  freeRunner(runner_f);
   d_dphi = nullptr; d_iq_staging = nullptr; staging_sf = 0;
   last_chunk = nullptr;
 }
@@ -83,7 +84,7 @@ void Engine::allocRunner(JobRunner& r)
   // the search thread's runner (on-demand RAR decodes) sits on the critical path of the sequential search: high priority
   int lo = 0, hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-  if (&r == &runner_s) {
+  if (&r == &runner_s || &r == &runner_f) {
     HIP_CHECK(hipStreamCreateWithPriority(&r.stream, hipStreamNonBlocking, hi));
   } else {
     // bulk decode streams leave a few CUs alone, so that the latency-critical launches (stage A, on-demand RAR decodes)
@@ -281,6 +282,7 @@ void Engine::buildTables()
   for (int i = 0; i < nslots; i++) allocChunk(chunks[i]);
   for (int i = 0; i < ndec; i++) allocRunner(runner_c[i]);
   allocRunner(runner_s);
+  allocRunner(runner_f);
   staging_sf = (size_t)max_batch * nslots;
   d_iq_staging = dalloc<cf32>(dev_allocs, staging_sf * cfg.nof_rx_antennas * cd.sflen);
 }

@@ -23,7 +23,7 @@ else:
     pickle.dump((ttis, cfis, cands, pws), open(cache, "wb"))
 T = (C.c_uint32 * n)(*ttis); F = (C.c_uint32 * n)(*cfis)
 CB = C.create_string_buffer(b"".join(cands)); PB = C.create_string_buffer(b"".join(pws))
-for reps in (2, 3, 3):
+for reps in (5, 5, 5, 5):
     print("search: %.2f us/subframe" % h.lsnh_search_bench(hs, n, reps, T, F, CB, PB), "active", h.lsnh_search_nof_active(hs))
 st = (C.c_uint32 * 7)(); h.lsnh_search_stats(hs, st)
 print("decoded locations/sf %.1f, subframes %d" % (st[0] / st[3], st[3]))
