@@ -24,11 +24,11 @@ import torch
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--nsf", type=int, default=200, help="subframes per step (multiple of 20)")
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--nsf", type=int, default=1600, help="subframes per step (multiple of 20)")
     ap.add_argument("--config", default="cfg3", help="scenario preset: cfg3 = 20 MHz, 150 RNTIs, TM3/TM4 up to 256QAM")
-    ap.add_argument("--batch", type=int, default=0, help="GPU batch size inside a step (0 = nsf)")
+    ap.add_argument("--batch", type=int, default=100, help="subframes per pipeline chunk inside a step")
     ap.add_argument("--cpu-sample", type=int, default=120, help="subframes timed on the CPU oracle (rank 0, N=1 only)")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -50,8 +50,9 @@ def main():
     from parity import gen_subframes, gpu_records, oracle_records, run_oracle
 
     nsf = max(20, (args.nsf // 20) * 20)
-    batch = args.batch or nsf
-    sc = scenario(args.config, seed=3 + 50 * rank, cell_id=1 + rank)  # one synthetic cell per rank (SURVEY 8d config 5 style)
+    batch = min(args.batch or nsf, nsf)
+    from ltesniffer_amd import dist as ld
+    sc = scenario(args.config, **ld.rank_workload(args.config, rank))  # one synthetic cell per rank (SURVEY 8d config 5 style)
     tti0, iq, truth = gen_subframes(sc, nsf)
     d_iq = torch.from_numpy(iq.view(np.float32)).to(dev)  # [nsf][rx][15*N] interleaved cf32, resident in HBM
     torch.cuda.synchronize()
@@ -90,6 +91,7 @@ def main():
     kms = np.zeros(16)
     klaunch = np.zeros(16)
     turbo_bytes = 0
+    turbo128_bytes = 0
     algo_bytes = 0
     npdus = 0
     acc = {k: 0 for k in ("nof_tb_decodes", "nof_cb_decodes", "nof_turbo_iterations", "nof_ondemand_decodes", "turbo_cyc_rm",
@@ -101,6 +103,7 @@ def main():
         kms += np.array(p.kernel_ms[:])
         klaunch += np.array(p.kernel_launches[:])
         turbo_bytes += p.turbo_algo_bytes
+        turbo128_bytes += p.turbo128_algo_bytes
         algo_bytes += p.algo_bytes
         npdus += p.nof_pdus
         for k in acc:
@@ -118,10 +121,13 @@ def main():
     value = total_sf / dt
 
     if rank == 0:
-        kt = la.KERNELS.index("k_turbo")
         dom = int(np.argmax(kms[:len(la.KERNELS)]))
-        # roofline of the dominant kernel (turbo decoder): algorithmic bytes = int16 LLRs read + payload bytes written
-        ach = (turbo_bytes / 1e9) / (kms[kt] / 1e3) if kms[kt] > 0 else 0.0
+        # roofline of the dominant kernel (one of the two turbo-decoder variants): algorithmic bytes = rate-matched int16
+        # LLRs read (E * 2 per code block) + payload bytes written, per launch; duration from HIP events on the launch stream
+        k64, k128 = la.KERNELS.index("k_turbo<64>"), la.KERNELS.index("k_turbo<128>")
+        kt = k128 if kms[k128] >= kms[k64] else k64
+        kbytes = turbo128_bytes if kt == k128 else turbo_bytes - turbo128_bytes
+        ach = (kbytes / 1e9) / (kms[kt] / 1e3) if kms[kt] > 0 else 0.0
         out = {
             "metric": "subframes/s (20 MHz, 150 RNTIs)", "value": round(value, 1), "unit": "subframes/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
@@ -131,10 +137,10 @@ def main():
                                    "CFI 3, 8-14 DL + 3-6 UL DCIs per subframe (BASELINE.json configs[2])" % args.config
                        if args.config == "cfg3" else args.config,
                        "subframes_per_step": nsf, "gpu_batch": batch, "cells": world, "parallelism": "cell/subframe shards, no collective"},
-            "roofline": {"bound": "hbm", "kernel": "k_turbo", "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": la.KERNELS[kt], "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(ach / 8000.0, 6), "traffic": None,
                          "avg_launch_ms": round(kms[kt] / max(1, klaunch[kt]), 4), "launches": int(klaunch[kt]),
-                         "algo_bytes_per_launch": int(turbo_bytes / max(1, klaunch[kt])),
+                         "algo_bytes_per_launch": int(kbytes / max(1, klaunch[kt])),
                          "dominant_by_time": la.KERNELS[dom]},
             "cpu_baseline": cpu, "host": {"cpu_count": os.cpu_count()},
             "detail": {"pdus_per_step": npdus / args.steps, "algo_bytes_per_subframe": int(algo_bytes / (args.steps * nsf)),

@@ -135,7 +135,8 @@ typedef struct {
   double kernel_ms[16];                                          /* HIP-event time per kernel class, last call */
   uint64_t kernel_launches[16];
   uint64_t algo_bytes;        /* algorithmic HBM bytes of the last call (SURVEY.md 8d formula) */
-  uint64_t turbo_algo_bytes;  /* part of algo_bytes moved by the turbo kernel */
+  uint64_t turbo_algo_bytes;  /* part of algo_bytes moved by the turbo kernels */
+  uint64_t turbo128_algo_bytes; /* ... of which by k_turbo<128> */
   uint64_t nof_tb_decodes, nof_cb_decodes, nof_turbo_iterations, nof_candidates_decoded, nof_ondemand_decodes, nof_pdus;
   double ms_search_core;      /* part of ms_search inside the FALCON decision tree proper */
   double ms_rar;              /* part of ms_search spent waiting for on-demand RAR decodes */
@@ -143,7 +144,8 @@ typedef struct {
 } lsn_perf_t;
 int lsn_phy_get_perf(lsn_phy_t* phy, lsn_perf_t* out);
 enum { LSN_K_OFDM = 0, LSN_K_CHEST, LSN_K_CHEST_FIN, LSN_K_PCFICH, LSN_K_PDCCH_LLR, LSN_K_CCE_POWER, LSN_K_VITERBI,
-       LSN_K_PDSCH_PREP, LSN_K_PDSCH_DEMOD, LSN_K_TURBO, LSN_K_RB_POWER, LSN_K_COUNT };
+       LSN_K_PDSCH_PREP, LSN_K_PDSCH_DEMOD, LSN_K_TURBO, LSN_K_RB_POWER, LSN_K_TURBO128, LSN_K_COUNT };
+/* LSN_K_TURBO = k_turbo<64> (one wavefront per code block), LSN_K_TURBO128 = k_turbo<128> (two) */
 const char* lsn_kernel_name(int k);
 const char* lsn_version(void);
 

@@ -1,0 +1,69 @@
+// ltesniffer_amd.hpp - header-only C++ mirror of the reference's Phy / SubframeWorker classes on top of the C ABI
+// (ltesniffer_amd.h).  It keeps the names, argument order and meaning of
+//   class Phy            /root/reference/src/include/Phy.h:22-66
+//   class SubframeWorker /root/reference/src/include/SubframeWorker.h:16-86
+// so that LTESniffer_Core.cc compiles against it unchanged apart from the srsRAN PODs (re-declared in the C header)
+// and the singletons this library owns itself (RNTIManager, MCSTracking, DCIMetaFormats live behind lsn_phy_t).
+#pragma once
+#include "ltesniffer_amd.h"
+#include <complex>
+#include <memory>
+#include <stdexcept>
+
+namespace lsn_amd {
+
+typedef std::complex<float> cf_t;  // srsRAN cf_t = float _Complex, same layout
+
+class Phy;
+
+class SubframeWorker {
+public:
+  cf_t** getBuffers() { return reinterpret_cast<cf_t**>(lsn_worker_buffers(h)); }   // SubframeWorker.h:37
+  uint32_t getBufferLen() const { return lsn_worker_buffer_len(h); }                // 3 * SF_LEN samples per antenna
+  void prepare(uint32_t sf_idx, uint32_t sfn, bool updateMetaFormats, const lsn_dl_sf_cfg_t& dl_sf)  // SubframeWorker.h:32
+  {
+    if (lsn_worker_prepare(h, sf_idx, sfn, updateMetaFormats ? 1 : 0, &dl_sf) != LSN_SUCCESS) throw std::invalid_argument("prepare");
+  }
+  uint32_t getSfidx() const { return lsn_worker_sf_idx(h); }
+  uint32_t getSfn() const { return lsn_worker_sfn(h); }
+  // work() is not exposed: the engine runs it for whole batches (SnifferThread::execute_worker, WorkerThread.cc:78-91)
+private:
+  friend class Phy;
+  explicit SubframeWorker(lsn_worker_t* w) : h(w) {}
+  lsn_worker_t* h;
+};
+
+class Phy {
+public:
+  // Phy.h:24-36.  dciFileName / statsFileName / HARQ* / ULSchedule* of the reference are not consumed by this path.
+  Phy(uint32_t nof_rx_antennas, uint32_t nof_workers, bool skipSecondaryMetaFormats, double metaFormatSplitRatio, uint32_t histogramThreshold,
+      lsn_pcap_t* pcapwriter, int mcs_tracking_mode = 1, int harq_mode = 0, int device = 0)
+  {
+    lsn_phy_cfg_t cfg{};
+    cfg.nof_rx_antennas = nof_rx_antennas; cfg.nof_workers = nof_workers; cfg.skip_secondary_meta_formats = skipSecondaryMetaFormats;
+    cfg.meta_format_split_ratio = metaFormatSplitRatio; cfg.histogram_threshold = histogramThreshold;
+    cfg.mcs_tracking_mode = mcs_tracking_mode; cfg.harq_mode = harq_mode; cfg.device = device;
+    const int r = lsn_phy_create(&cfg, &h);
+    if (r == LSN_ERROR_NO_DEVICE) throw std::runtime_error("ltesniffer_amd: no HIP device (this library has no CPU path)");
+    if (r != LSN_SUCCESS) throw std::runtime_error("lsn_phy_create failed");
+    lsn_phy_setup_default_rnti_intervals(h);  // LTESniffer_Core.cc:398-417
+    if (pcapwriter) lsn_phy_set_pcap_writer(h, pcapwriter);
+  }
+  ~Phy() { lsn_phy_destroy(h); }
+  Phy(const Phy&) = delete;
+  Phy& operator=(const Phy&) = delete;
+  bool setCell(const lsn_cell_t& cell) { return lsn_phy_set_cell(h, &cell) == LSN_SUCCESS; }               // Phy.cc:111
+  std::shared_ptr<SubframeWorker> getAvail() { return wrap(lsn_phy_get_avail(h, 1)); }                      // Phy.cc:79 (blocking)
+  std::shared_ptr<SubframeWorker> getAvailImmediate() { return wrap(lsn_phy_get_avail(h, 0)); }             // Phy.cc:84
+  void putPending(std::shared_ptr<SubframeWorker> w) { lsn_phy_put_pending(h, w->h); }                      // Phy.cc:95
+  void joinPending() { lsn_phy_join_pending(h); }                                                           // Phy.cc:100
+  void setPduSink(lsn_pdu_sink_t cb, void* user) { lsn_phy_set_pdu_sink(h, cb, user); }
+  lsn_blind_stats_t getStats() { lsn_blind_stats_t s{}; lsn_phy_get_stats(h, &s); return s; }              // PhyCommon::getStats
+  float getEstCfo() { return lsn_phy_get_est_cfo(h); }                                                      // SubframeWorker.cc:203
+  lsn_phy_t* handle() { return h; }
+private:
+  static std::shared_ptr<SubframeWorker> wrap(lsn_worker_t* w) { return w ? std::shared_ptr<SubframeWorker>(new SubframeWorker(w)) : nullptr; }
+  lsn_phy_t* h = nullptr;
+};
+
+}  // namespace lsn_amd

@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libltesniffer_amd.so")
 LSN_SUCCESS, LSN_ERROR, LSN_ERROR_INVALID_INPUTS, LSN_ERROR_NO_DEVICE = 0, -1, -2, -3
 TAP_GRID, TAP_CE, TAP_PDCCH_LLR, TAP_CHEST, TAP_CFI, TAP_CANDIDATES, TAP_CCE_POWER, TAP_ACCEPTED, TAP_RB_POWER = range(9)
 KERNELS = ["k_ofdm", "k_chest", "k_chest_fin", "k_pcfich", "k_pdcch_llr", "k_cce_power", "k_viterbi", "k_pdsch_prep",
-           "k_pdsch_demod", "k_turbo", "k_rb_power"]
+           "k_pdsch_demod", "k_turbo<64>", "k_rb_power", "k_turbo<128>"]
 
 # every symbol include/ltesniffer_amd.h declares
 EXPORTS = ["lsn_phy_create", "lsn_phy_destroy", "lsn_phy_set_cell", "lsn_phy_get_avail", "lsn_phy_put_pending",
@@ -60,7 +60,8 @@ class BlindStats(C.Structure):
 class Perf(C.Structure):
     _fields_ = [("ms_stage_a", C.c_double), ("ms_search", C.c_double), ("ms_stage_c", C.c_double), ("ms_commit", C.c_double),
                 ("ms_total", C.c_double), ("kernel_ms", C.c_double * 16), ("kernel_launches", C.c_uint64 * 16),
-                ("algo_bytes", C.c_uint64), ("turbo_algo_bytes", C.c_uint64), ("nof_tb_decodes", C.c_uint64),
+                ("algo_bytes", C.c_uint64), ("turbo_algo_bytes", C.c_uint64), ("turbo128_algo_bytes", C.c_uint64),
+                ("nof_tb_decodes", C.c_uint64),
                 ("nof_cb_decodes", C.c_uint64), ("nof_turbo_iterations", C.c_uint64), ("nof_candidates_decoded", C.c_uint64),
                 ("nof_ondemand_decodes", C.c_uint64), ("nof_pdus", C.c_uint64), ("ms_search_core", C.c_double), ("ms_rar", C.c_double), ("turbo_cyc_rm", C.c_uint64),
                 ("turbo_cyc_map", C.c_uint64), ("turbo_cyc_out", C.c_uint64)]

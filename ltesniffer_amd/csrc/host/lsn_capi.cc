@@ -263,7 +263,7 @@ int lsn_phy_get_perf(lsn_phy_t* phy, lsn_perf_t* out)
 const char* lsn_kernel_name(int k)
 {
   static const char* names[LSN_K_COUNT] = {"k_ofdm", "k_chest", "k_chest_fin", "k_pcfich", "k_pdcch_llr", "k_cce_power", "k_viterbi",
-                                           "k_pdsch_prep", "k_pdsch_demod", "k_turbo", "k_rb_power"};
+                                           "k_pdsch_prep", "k_pdsch_demod", "k_turbo<64>", "k_rb_power", "k_turbo<128>"};
   return (k >= 0 && k < LSN_K_COUNT) ? names[k] : "";
 }
 const char* lsn_version(void) { return "ltesniffer_amd 0.1 (gfx950)"; }

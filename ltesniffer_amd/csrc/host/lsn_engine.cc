@@ -152,7 +152,7 @@ void Engine::getStats(lsn_blind_stats_t* s) const
 void Engine::mergePerf(const lsn_perf_t& p)
 {
   perf.ms_stage_a += p.ms_stage_a; perf.ms_search += p.ms_search; perf.ms_stage_c += p.ms_stage_c; perf.ms_commit += p.ms_commit;
-  perf.algo_bytes += p.algo_bytes; perf.turbo_algo_bytes += p.turbo_algo_bytes;
+  perf.algo_bytes += p.algo_bytes; perf.turbo_algo_bytes += p.turbo_algo_bytes; perf.turbo128_algo_bytes += p.turbo128_algo_bytes;
   perf.nof_tb_decodes += p.nof_tb_decodes; perf.nof_cb_decodes += p.nof_cb_decodes; perf.nof_turbo_iterations += p.nof_turbo_iterations;
   perf.ms_search_core += p.ms_search_core; perf.ms_rar += p.ms_rar;
   perf.turbo_cyc_rm += p.turbo_cyc_rm; perf.turbo_cyc_map += p.turbo_cyc_map; perf.turbo_cyc_out += p.turbo_cyc_out;
@@ -481,7 +481,7 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
     lsn_launch_pdsch_demod(cd, r.d_jobs, r.d_prefix, ch.d_grid, ch.d_ce, ch.d_chest, r.d_llr16, njobs, st);
     HIP_CHECK(hipEventRecord(r.ev[2], st));
     if (ncb) {
-      lsn_launch_turbo(cd, r.d_cbs, r.d_llr16, r.d_payload, r.d_cbres, n128, kmax128, ncb - n128, kmax64, st);
+      lsn_launch_turbo(cd, r.d_cbs, r.d_llr16, r.d_payload, r.d_cbres, n128, kmax128, ncb - n128, kmax64, st, r.ev[4]);
       HIP_CHECK(hipEventRecord(r.ev[3], st));
       HIP_CHECK(hipMemcpyAsync(r.h_cbres_pinned, r.d_cbres, ncb * sizeof(LsnCbRes), hipMemcpyDeviceToHost, st));
       HIP_CHECK(hipMemcpyAsync(r.h_payload_pinned, r.d_payload, pay_n - pay0, hipMemcpyDeviceToHost, st));
@@ -492,8 +492,9 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
     if (hipEventElapsedTime(&ms, r.ev[1], r.ev[2]) == hipSuccess) pf.kernel_ms[LSN_K_PDSCH_DEMOD] += ms;
     pf.kernel_launches[LSN_K_PDSCH_PREP]++; pf.kernel_launches[LSN_K_PDSCH_DEMOD]++;
     if (ncb) {
-      if (hipEventElapsedTime(&ms, r.ev[2], r.ev[3]) == hipSuccess) pf.kernel_ms[LSN_K_TURBO] += ms;
-      pf.kernel_launches[LSN_K_TURBO]++;
+      if (n128 && hipEventElapsedTime(&ms, r.ev[2], r.ev[4]) == hipSuccess) { pf.kernel_ms[LSN_K_TURBO128] += ms; pf.kernel_launches[LSN_K_TURBO128]++; }
+      if (ncb > n128 && hipEventElapsedTime(&ms, r.ev[4], r.ev[3]) == hipSuccess) { pf.kernel_ms[LSN_K_TURBO] += ms; pf.kernel_launches[LSN_K_TURBO]++; }
+      for (uint32_t i = 0; i < n128; i++) pf.turbo128_algo_bytes += (uint64_t)r.h_cbs_pinned[i].E * 2ull + r.h_cbs_pinned[i].out_bytes;
     }
     ch.h_payload.resize(pay_n);
     if (pay_n > pay0) std::memcpy(ch.h_payload.data() + pay0, r.h_payload_pinned, pay_n - pay0);

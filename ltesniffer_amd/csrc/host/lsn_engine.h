@@ -63,7 +63,7 @@ struct JobRunner {
   LsnGrantDev* h_jobs_pinned = nullptr; size_t h_jobs_cap = 0;
   LsnCbDev* h_cbs_pinned = nullptr; size_t h_cbs_cap = 0;
   std::vector<LsnGrantDev> h_jobs; std::vector<LsnCbDev> h_cbs;
-  hipEvent_t ev[6] = {};
+  hipEvent_t ev[8] = {};
   lsn_perf_t perf{};
 };
 

@@ -88,4 +88,4 @@ void lsn_launch_rb_power(const LsnCellDev& c, const cf32* grid, float* rbp, uint
 void lsn_launch_pdsch_prep(const LsnCellDev& c, const LsnGrantDev* g, uint16_t* prefix, uint32_t njobs, hipStream_t s);
 void lsn_launch_pdsch_demod(const LsnCellDev& c, const LsnGrantDev* g, const uint16_t* prefix, const cf32* grid, const cf32* ce, const LsnChest* ch, int16_t* llr, uint32_t njobs, hipStream_t s);
 void lsn_launch_turbo(const LsnCellDev& c, const LsnCbDev* cb, const int16_t* llr, uint8_t* payload, LsnCbRes* res, uint32_t n128, uint32_t kmax128,
-                      uint32_t n64, uint32_t kmax64, hipStream_t s);
+                      uint32_t n64, uint32_t kmax64, hipStream_t s, hipEvent_t between);

@@ -593,7 +593,7 @@ size_t lsn_turbo_lds_bytes(uint32_t kmax) { return 6 * (size_t)kmax + 16 + sizeo
 // cb[0 .. n128) use two wavefronts per code block (P > 64), cb[n128 .. ncb) one; each range is launched with the LDS
 // size of its largest block (40 KiB at K = 6144 -> four code blocks per CU)
 void lsn_launch_turbo(const LsnCellDev& c, const LsnCbDev* cb, const int16_t* llr, uint8_t* payload, LsnCbRes* res, uint32_t n128, uint32_t kmax128,
-                      uint32_t n64, uint32_t kmax64, hipStream_t s)
+                      uint32_t n64, uint32_t kmax64, hipStream_t s, hipEvent_t between)
 {
   static bool attr_set = false;
   if (!attr_set) {
@@ -603,5 +603,6 @@ void lsn_launch_turbo(const LsnCellDev& c, const LsnCbDev* cb, const int16_t* ll
   }
   auto fix = [](uint32_t k) { return ((k < 512 ? 512u : k) + 7u) & ~7u; };  // the scratch in the check-point area needs room
   if (n128) hipLaunchKernelGGL(k_turbo<128>, dim3(n128), dim3(128), lsn_turbo_lds_bytes(fix(kmax128)), s, c.crc_tab_a, c.crc_tab_b, cb, llr, payload, res, fix(kmax128));
+  if (between) (void)hipEventRecord(between, s);
   if (n64) hipLaunchKernelGGL(k_turbo<64>, dim3(n64), dim3(64), lsn_turbo_lds_bytes(fix(kmax64)), s, c.crc_tab_a, c.crc_tab_b, cb + n128, llr, payload, res, fix(kmax64));
 }

@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/pcap_records.json from the reference's example captures
+(/root/reference/pcap_file_example/*.pcap - the only golden data the reference ships for this path: they pin the
+MAC-LTE (DLT 147) record framing that LTESniffer_pcap_writer::pack_and_write emits, PcapWriter.cc:93-118).
+Run in the build container (the GPU box has no /root/reference); the JSON is committed."""
+import json, struct, sys, os
+src = sys.argv[1] if len(sys.argv) > 1 else "/root/reference/pcap_file_example"
+out = {}
+for name in ("ltesniffer_dl_mode.pcap", "ltesniffer_ul_mode.pcap", "api_collector.pcap"):
+    data = open(os.path.join(src, name), "rb").read()
+    recs, off = [], 24
+    while off < len(data):
+        ts, tu, il, ol = struct.unpack("<IIII", data[off:off + 16]); off += 16
+        recs.append(data[off:off + il]); off += il
+    # keep every distinct (direction, rnti type) combination + the first records, full bytes for short ones
+    keep, seen = [], set()
+    for i, r in enumerate(recs):
+        key = (r[1], r[2])
+        if i < 12 or key not in seen or len(r) < 40 and len(keep) < 60:
+            seen.add(key); keep.append(r)
+    out[name] = {"global_header": data[:24].hex(), "nof_records": len(recs),
+                 "records": [r[:19 + 48].hex() for r in keep], "record_lens": [len(r) for r in keep]}
+json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "pcap_records.json"), "w"), indent=0)
+print({k: (v["nof_records"], len(v["records"])) for k, v in out.items()})

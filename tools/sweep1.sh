@@ -1,4 +1,3 @@
 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-for n in 4 6; do TAG="ndec=$n b100" LSN_DECODE_THREADS=$n python tools/bench_show.py --steps 5 --warmup 2 --nsf 1600 --batch 100 --no-cpu; done
-for n in 6; do TAG="ndec=$n b200" LSN_DECODE_THREADS=$n python tools/bench_show.py --steps 5 --warmup 2 --nsf 1600 --batch 200 --no-cpu; done
-for n in 6; do TAG="ndec=$n b50" LSN_DECODE_THREADS=$n python tools/bench_show.py --steps 5 --warmup 2 --nsf 1600 --batch 50 --no-cpu; done
+python bench.py > gpurun_out/bench_r01b.json 2> gpurun_out/bench_r01b.err; tail -2 gpurun_out/bench_r01b.err; cat gpurun_out/bench_r01b.json | cut -c1-1500
+cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof3 -o r03 -- python $GRAFT_REPO_ROOT/bench.py --no-cpu > $GRAFT_REPO_ROOT/gpurun_out/prof3.log 2>&1; tail -1 $GRAFT_REPO_ROOT/gpurun_out/prof3.log | cut -c1-200
