@@ -128,6 +128,19 @@ def main():
         kt = k128 if kms[k128] >= kms[k64] else k64
         kbytes = turbo128_bytes if kt == k128 else turbo_bytes - turbo128_bytes
         ach = (kbytes / 1e9) / (kms[kt] / 1e3) if kms[kt] > 0 else 0.0
+        # HBM traffic of the same kernel from the PMC counters: collected by SEPARATE rocprofv3 --pmc passes of this command
+        # (tools/pmc_summary.py -> profiles/*_pmc_hbm.json); FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md
+        traffic, traffic_src = None, None
+        try:
+            import glob
+            cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json")))
+            if cand:
+                pj = json.load(open(cand[-1])).get(la.KERNELS[kt])
+                if pj:
+                    traffic = int(pj["fetch_corrected_bytes_per_launch"] + pj["write_bytes_per_launch"])
+                    traffic_src = os.path.relpath(cand[-1], ROOT)
+        except Exception:
+            pass
         out = {
             "metric": "subframes/s (20 MHz, 150 RNTIs)", "value": round(value, 1), "unit": "subframes/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
@@ -138,7 +151,7 @@ def main():
                        if args.config == "cfg3" else args.config,
                        "subframes_per_step": nsf, "gpu_batch": batch, "cells": world, "parallelism": "cell/subframe shards, no collective"},
             "roofline": {"bound": "hbm", "kernel": la.KERNELS[kt], "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(ach / 8000.0, 6), "traffic": None,
+                         "frac": round(ach / 8000.0, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": round(kms[kt] / max(1, klaunch[kt]), 4), "launches": int(klaunch[kt]),
                          "algo_bytes_per_launch": int(kbytes / max(1, klaunch[kt])),
                          "dominant_by_time": la.KERNELS[dom]},
