@@ -101,3 +101,69 @@ def test_invalid_inputs_are_rejected():
     with pytest.raises(RuntimeError):
         phy.process_host(np.zeros((1, 2, 30720), dtype=np.complex64), 0)  # no cell set
     phy.close()
+
+
+# ---------------------------------------------------------------------------------------------- edge cases
+def test_redundancy_versions_1_2_3():
+    _run("cfg2", 24, seed=31, pct_rv=70, mcs_min=4, mcs_max=16)
+
+
+def test_mid_snr_many_crc_failures():
+    n = _run("cfg3", 24, seed=33, snr_db=14.0)
+    assert n > 0
+
+
+def test_low_snr_subframes_are_skipped():
+    """estimated SNR <= 6 dB: DCISearch::search returns before the blind search (DCISearch.cc:568-574) -> no records"""
+    sc = scenario("small", seed=35, snr_db=2.0)
+    tti0, iq, _ = gen_subframes(sc, 12)
+    ow, per_sf, orecs = run_oracle(sc, tti0, iq)
+    phy = la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=12)
+    assert phy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"])
+    phy.process_host(iq, tti0, 0)
+    assert not compare_taps(phy, per_sf, sc, 0, 12)
+    assert gpu_records(phy) == oracle_records(orecs) == []
+    assert phy.getStats().nof_subframes == 12 and phy.getStats().nof_locations == ow.stats().nof_locations == 0
+    phy.close()
+
+
+def test_frequency_selective_channel_and_cfo():
+    _run("cfg2", 20, seed=37, delay_samples=9, cfo_hz=450.0)
+
+
+def test_one_rx_antenna_two_ports():
+    """TM2 decodes on one rx antenna; two-codeword grants are gated off (DL_Sniffer_PDSCH.cc:887-889)"""
+    _run("cfg3", 20, seed=39, nof_rx=1, n_rnti=20)
+
+
+def test_full_band_two_codeword_256qam_max_size():
+    """one UE over all 100 PRBs, 2 codewords, top MCS of the 256QAM table: 13+ code blocks of K = 6144 per TB"""
+    _run("cfg3", 8, seed=41, n_rnti=1, dl_min=1, dl_max=1, ul_min=0, ul_max=0, mix_tm3_pct=100, mix_tm4_pct=0, pct_256qam=100,
+         mcs_min=26, mcs_max=27, snr_db=40.0, rar_period=0, paging_period=0)
+
+
+def test_cfi_1_2_random_and_phy_options():
+    _run("cfg2", 20, seed=43, cfi=0)
+    sc = scenario("small", seed=45)
+    tti0, iq, _ = gen_subframes(sc, 24)
+    for kw, okw in ((dict(skipSecondaryMetaFormats=True), dict(skip_secondary=1)), (dict(histogramThreshold=2), dict(threshold=2)),
+                    (dict(max_turbo_iterations=3), dict(max_turbo_iter=3)), (dict(mcs_tracking_mode=2), dict(mcs_tracking_mode=2)),
+                    (dict(mcs_tracking_mode=0), dict(mcs_tracking_mode=0))):
+        _, _, orecs = run_oracle(sc, tti0, iq, update_meta_period=10, taps=False, **okw)
+        phy = la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=10, **kw)
+        assert phy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"])
+        phy.process_host(iq, tti0, 10)
+        assert gpu_records(phy) == oracle_records(orecs), kw
+        phy.close()
+
+
+def test_all_zero_and_noise_only_input():
+    phy = la.Phy(nof_rx_antennas=2, max_batch=4)
+    assert phy.setCell(25, 2, 7)
+    z = np.zeros((4, 2, 15 * 512), dtype=np.complex64)
+    phy.process_host(z, 0, 0)          # NaN SNR (0/0) -> not > 6 dB -> skipped, must not crash
+    rng = np.random.default_rng(0)
+    nz = (rng.standard_normal(z.shape) + 1j * rng.standard_normal(z.shape)).astype(np.complex64)
+    phy.process_host(nz, 4, 0)
+    assert phy.pdus == []
+    phy.close()

@@ -216,6 +216,7 @@ typedef struct {
   uint32_t paging_period;
   uint32_t start_tti;
   uint32_t fixed_L;       // 0 = random aggregation level
+  uint32_t pct_rv;        // share of C-RNTI transport blocks sent with a random redundancy version (else rv 0)
 } txg_cfg_t;
 
 typedef struct { uint16_t rnti; uint8_t format, L; uint16_t ncce; uint32_t tti; uint32_t nbytes; uint32_t offset; uint8_t tb, mod, table256, is_ul; uint32_t nof_prb; uint32_t mcs; } txg_pdu_t;
@@ -528,11 +529,15 @@ extern "C" int txg_next(txg_t* g, float* iq, txg_pdu_t* pdus, int max_pdus, uint
       gr.format = u.tm == 3 ? TXG_FMT2A : TXG_FMT2; gr.ntb = 2; gr.swap = 0;
       if (u.tm == 3) { gr.scheme = 3; gr.nlayers = 2; gr.pinfo = 0; }
       else { gr.scheme = 2; gr.nlayers = 2; gr.pinfo = g->rng.below(2); gr.pmi = (int)gr.pinfo; }
-      for (int i = 0; i < 2; i++) { gr.mcs[i] = mlo + g->rng.below(mhi - mlo + 1); gr.rv[i] = 0; gr.ndi[i] = g->rng.below(2); }
+      for (int i = 0; i < 2; i++) {
+        gr.mcs[i] = mlo + g->rng.below(mhi - mlo + 1); gr.rv[i] = 0; gr.ndi[i] = g->rng.below(2);
+        if (c.pct_rv && g->rng.below(100) < c.pct_rv) { gr.rv[i] = (int)g->rng.below(4); if (gr.mcs[i] == 0 && gr.rv[i] == 1) gr.rv[i] = 2; }  // (mcs 0, rv 1) = TB disabled
+      }
     } else {
       bool f1a = g->rng.below(4) == 0;
       gr.format = f1a ? TXG_FMT1A : TXG_FMT1; gr.ntb = 1; gr.scheme = P == 1 ? 0 : 1; gr.nlayers = P;
       gr.mcs[0] = mlo + g->rng.below(mhi - mlo + 1); gr.rv[0] = 0; gr.ndi[0] = g->rng.below(2);
+      if (c.pct_rv && g->rng.below(100) < c.pct_rv) gr.rv[0] = (int)g->rng.below(4);
       if (f1a) {
         gr.type0 = false; gr.t256 = false;  // 1A always uses the 64QAM table
         if (gr.mcs[0] > 28) gr.mcs[0] = 28;
