@@ -39,7 +39,12 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        backend = os.environ.get("LSN_DIST_BACKEND", "nccl")  # nccl = RCCL on ROCm; "gloo" only to smoke-test N > 1 on a 1-GPU box
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+            local = local % max(1, torch.cuda.device_count())
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the library has no CPU path)")
     torch.cuda.set_device(local)
@@ -114,9 +119,9 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        rdev = dev if dist.get_backend() == "nccl" else None
+        dt, total = ld.reduce_max_sum(dt, args.steps * nsf, rdev)
+        assert total == args.steps * nsf * world
     total_sf = args.steps * nsf * world
     value = total_sf / dt
 
