@@ -13,7 +13,7 @@
  *   - the published 3GPP algorithms (TS 36.211/36.212/36.213) for the DSP that the reference
  *     reaches through srsran_* calls (call sites cited).
  * The only golden vectors the reference ships pin the MAC-LTE pcap framing
- * (pcap_file_example/*.pcap); tests/test_oracle_pcap.py checks the writer against them.
+ * (the captures under pcap_file_example/); tests/test_oracle_pcap.py checks the writer against them.
  *
  * Float arithmetic contract (so that a GPU implementation can be BIT-IDENTICAL): every float
  * expression is evaluated in binary32 with one rounding per + - * / (compile with
@@ -191,6 +191,19 @@ int o_turbo_decode_cb(const int16_t* d3, int K, int max_iter, uint32_t crc_poly,
 int o_pdsch_decode_tb(const int16_t* e, int G, int tbs, int Qm, int nof_layers_rm, int rv, int max_iter,
                       uint8_t* payload, int* iters_total);
 int o_turbo_nwin(int K);
+
+/* ---------- uplink: SC-FDMA demodulation + PUSCH (o_pusch.c) ---------- */
+typedef struct { uint32_t cyclic_shift; /* SIB2 cyclicShift 0..7 */ uint32_t delta_ss; /* SIB2 groupAssignmentPUSCH 0..29 */ } o_ul_cfg_t;
+int o_ul_valid_prb(uint32_t L);
+void o_ul_shift_table(int N, ocf_t* t);
+void o_ul_fft(const o_cell_t* cell, const ocf_t* in, ocf_t* grid);
+int o_dmrs_base(uint32_t u, int M_sc, ocf_t* r);
+uint32_t o_dmrs_ncs(const o_cell_t* cell, const o_ul_cfg_t* ul, uint32_t ns, uint32_t n_dmrs_dci);
+void o_idft_table(int M, ocf_t* w);
+int o_pusch_demod(const o_cell_t* cell, const o_ul_cfg_t* ul, uint32_t sf_idx, uint16_t rnti, const o_pusch_grant_t* g, uint32_t n_dmrs_dci,
+                  const ocf_t* grid, int16_t* e, float* noise_out, float* sigpow_out);
+int o_pusch_decode(const o_cell_t* cell, const o_ul_cfg_t* ul, uint32_t sf_idx, uint16_t rnti, const o_pusch_grant_t* g, uint32_t n_dmrs_dci,
+                   const ocf_t* grid, int max_iter, uint8_t* payload, int* iters, float* snr_db);
 
 /* ---------- pcap (o_pcap.c) ---------- */
 typedef struct o_pcap o_pcap_t;

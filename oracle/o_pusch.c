@@ -1,0 +1,240 @@
+/* o_pusch.c - ORACLE (test infrastructure only): uplink receive chain for one PUSCH grant.
+ * Restates what the reference obtains from srsran_enb_ul_fft (/root/reference/src/src/UL_Sniffer_PUSCH.cc:392),
+ * srsran_chest_ul_estimate_pusch (:256) and srsran_pusch_decode (:262) [srsRAN, not in tree], following TS 36.211
+ * 5.6 (SC-FDMA, 7.5 kHz shift), 5.5.1/5.5.2.1 (DMRS: Zadoff-Chu base sequences, cyclic shifts), 5.3 (scrambling,
+ * modulation, transform precoding) and TS 36.212 5.2.2 (UL-SCH coding, channel interleaver).
+ * Scope of this restatement: one receive antenna (the reference uses antenna 1 for the uplink,
+ * UL_Sniffer_PUSCH.cc:391), no group / sequence hopping, no frequency hopping, no SRS, no UCI multiplexed into the
+ * PUSCH, allocations of >= 3 PRB (the 1- and 2-PRB base sequences are tabulated phases that are not reproduced here).
+ * Arithmetic contract as in lsn_oracle.h: one float rounding per operation, fixed summation orders, all cos/sin on the
+ * "host" side (tables). */
+#include "lsn_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define LLR_Q 180.0f
+#define LLR_CLIP 511
+
+static inline ocf_t cmul(ocf_t a, ocf_t b) { ocf_t c = {a.r * b.r - a.i * b.i, a.r * b.i + a.i * b.r}; return c; }
+static inline ocf_t cmulconj(ocf_t a, ocf_t b) { ocf_t c = {a.r * b.r + a.i * b.i, a.i * b.r - a.r * b.i}; return c; }
+
+/* UL_Sniffer_PUSCH.cc:3-10: L_prb = 2^a 3^b 5^c */
+int o_ul_valid_prb(uint32_t L)
+{
+  if (L == 0 || L > 110) return 0;
+  while (L % 2 == 0) L /= 2;
+  while (L % 3 == 0) L /= 3;
+  while (L % 5 == 0) L /= 5;
+  return L == 1;
+}
+
+/* half-subcarrier (7.5 kHz) shift table: exp(-j pi n / N), n = 0..N-1 (applied to each symbol after CP removal) */
+void o_ul_shift_table(int N, ocf_t* t)
+{
+  for (int n = 0; n < N; n++) {
+    double a = M_PI * (double)n / (double)N;
+    t[n].r = (float)cos(a);
+    t[n].i = (float)(-sin(a));
+  }
+}
+
+/* SC-FDMA demodulation of one subframe, one antenna: CP strip, 7.5 kHz shift, N-point FFT, keep the 12*nprb carriers
+ * around DC: grid[l][k], k < 6 nprb -> bin N - 6 nprb + k, else bin k - 6 nprb (no DC gap in the uplink). */
+void o_ul_fft(const o_cell_t* cell, const ocf_t* in, ocf_t* grid)
+{
+  int N = o_fft_size(cell->nof_prb), nre = 12 * (int)cell->nof_prb;
+  ocf_t* w = (ocf_t*)malloc(sizeof(ocf_t) * (size_t)(N / 2));
+  ocf_t* sh = (ocf_t*)malloc(sizeof(ocf_t) * (size_t)N);
+  ocf_t* buf = (ocf_t*)malloc(sizeof(ocf_t) * (size_t)N);
+  o_fft_twiddles(N, w);
+  o_ul_shift_table(N, sh);
+  int pos = 0;
+  for (int l = 0; l < 14; l++) {
+    pos += ((l % 7) == 0 ? 160 : 144) * N / 2048;
+    for (int n = 0; n < N; n++) buf[n] = cmul(in[pos + n], sh[n]);
+    o_fft(N, w, buf);
+    for (int k = 0; k < nre; k++) grid[l * nre + k] = buf[(k < nre / 2) ? (N - nre / 2 + k) : (k - nre / 2)];
+    pos += N;
+  }
+  free(w); free(sh); free(buf);
+}
+
+static int largest_prime_below(int n)
+{
+  for (int p = n - 1; p >= 2; p--) {
+    int ok = 1;
+    for (int d = 2; d * d <= p; d++)
+      if (p % d == 0) { ok = 0; break; }
+    if (ok) return p;
+  }
+  return 2;
+}
+
+/* base sequence r_{u,0}(n), n < M_sc = 12 L, L >= 3 (36.211 5.5.1.1) */
+int o_dmrs_base(uint32_t u, int M_sc, ocf_t* r)
+{
+  if (M_sc < 36) return -1;
+  int Nzc = largest_prime_below(M_sc);
+  double qb = (double)Nzc * (double)(u + 1) / 31.0;
+  int q = (int)floor(qb + 0.5); /* v = 0 */
+  for (int n = 0; n < M_sc; n++) {
+    long long m = n % Nzc;
+    long long ph = ((long long)q * m * (m + 1)) % (2ll * Nzc); /* exp(-j pi q m(m+1)/Nzc) has period 2 Nzc in the product */
+    double a = M_PI * (double)ph / (double)Nzc;
+    r[n].r = (float)cos(a);
+    r[n].i = (float)(-sin(a));
+  }
+  return 0;
+}
+
+static const uint32_t n_dmrs1_tab[8] = {0, 2, 3, 4, 6, 8, 9, 10}; /* 36.211 Table 5.5.2.1.1-2 (cyclicShift of SIB2) */
+static const uint32_t n_dmrs2_tab[8] = {0, 6, 3, 4, 2, 8, 10, 9}; /* Table 5.5.2.1.1-1 (cyclic shift field of DCI 0) */
+
+/* n_cs of slot ns (36.211 5.5.2.1.1) */
+uint32_t o_dmrs_ncs(const o_cell_t* cell, const o_ul_cfg_t* ul, uint32_t ns, uint32_t n_dmrs_dci)
+{
+  uint32_t fss = ((cell->id % 30u) + ul->delta_ss) % 30u;
+  uint8_t c[8 * 7 * 20 + 8];
+  o_gold(((cell->id / 30u) << 5) + fss, c, 8 * 7 * 20 + 8);
+  uint32_t npn = 0;
+  for (int i = 0; i < 8; i++) npn += (uint32_t)c[8 * 7 * ns + (uint32_t)i] << i;
+  return (n_dmrs1_tab[ul->cyclic_shift & 7] + n_dmrs2_tab[n_dmrs_dci & 7] + npn) % 12u;
+}
+
+static void demod_llr(int Qm, float I, float Q, float* L)
+{
+  float aI = fabsf(I), aQ = fabsf(Q);
+  L[0] = -I;
+  L[1] = -Q;
+  if (Qm == 4) {
+    const float a = 0.31622776601683794f;
+    L[2] = aI - 2.0f * a; L[3] = aQ - 2.0f * a;
+  } else if (Qm == 6) {
+    const float a = 0.15430334996209191f;
+    float tI = aI - 4.0f * a, tQ = aQ - 4.0f * a;
+    L[2] = tI; L[3] = tQ; L[4] = fabsf(tI) - 2.0f * a; L[5] = fabsf(tQ) - 2.0f * a;
+  } else if (Qm == 8) {
+    const float a = 0.07669649888473704f;
+    float tI = aI - 8.0f * a, tQ = aQ - 8.0f * a;
+    float uI = fabsf(tI) - 4.0f * a, uQ = fabsf(tQ) - 4.0f * a;
+    L[2] = tI; L[3] = tQ; L[4] = uI; L[5] = uQ; L[6] = fabsf(uI) - 2.0f * a; L[7] = fabsf(uQ) - 2.0f * a;
+  }
+}
+
+/* IDFT twiddles exp(+2 pi j k / M), k < M */
+void o_idft_table(int M, ocf_t* w)
+{
+  for (int k = 0; k < M; k++) {
+    double a = 2.0 * M_PI * (double)k / (double)M;
+    w[k].r = (float)cos(a);
+    w[k].i = (float)sin(a);
+  }
+}
+
+/* One grant: DMRS channel estimate (LS on symbols 3 and 10, 3-tap frequency smoothing, one estimate per slot), 1-tap
+ * MMSE equaliser, transform de-precoding (direct IDFT of size M_sc, summation in increasing carrier order, scale
+ * 1/sqrt(M_sc)), soft demodulation, descrambling and channel de-interleaving -> e[nof_re * Qm] int16 (UL-SCH order).
+ * noise_out / sigpow_out: scalar estimates (mean |ls - smoothed|^2, mean |smoothed|^2). Returns 0 or -1. */
+int o_pusch_demod(const o_cell_t* cell, const o_ul_cfg_t* ul, uint32_t sf_idx, uint16_t rnti, const o_pusch_grant_t* g, uint32_t n_dmrs_dci,
+                  const ocf_t* grid, int16_t* e, float* noise_out, float* sigpow_out)
+{
+  int L = (int)g->L_prb, M = 12 * L, nre = 12 * (int)cell->nof_prb, Qm = g->mod;
+  if (L < 3 || !o_ul_valid_prb(g->L_prb) || g->n_prb + g->L_prb > cell->nof_prb || Qm <= 0) return -1;
+  int k0 = 12 * (int)g->n_prb;
+  ocf_t* base = (ocf_t*)malloc(sizeof(ocf_t) * (size_t)M);
+  ocf_t* ls = (ocf_t*)malloc(sizeof(ocf_t) * (size_t)(2 * M));
+  ocf_t* hs = (ocf_t*)malloc(sizeof(ocf_t) * (size_t)(2 * M));
+  float* tmp = (float*)malloc(sizeof(float) * (size_t)(2 * M));
+  ocf_t* x = (ocf_t*)malloc(sizeof(ocf_t) * (size_t)M);
+  ocf_t* w = (ocf_t*)malloc(sizeof(ocf_t) * (size_t)M);
+  uint8_t* c = (uint8_t*)malloc((size_t)(12 * M * Qm));
+  uint32_t u = (((cell->id % 30u) + ul->delta_ss) % 30u) % 30u; /* group hopping off: u = f_ss^PUSCH */
+  o_dmrs_base(u, M, base);
+  o_idft_table(M, w);
+  o_gold(((uint32_t)rnti << 14) | (sf_idx << 9) | cell->id, c, 12 * M * Qm);
+  /* cyclic-shift phasors exp(j 2 pi m / 12) */
+  ocf_t ph12[12];
+  for (int m = 0; m < 12; m++) {
+    double a = 2.0 * M_PI * (double)m / 12.0;
+    ph12[m].r = (float)cos(a);
+    ph12[m].i = (float)sin(a);
+  }
+  for (int s = 0; s < 2; s++) {
+    uint32_t ncs = o_dmrs_ncs(cell, ul, 2 * sf_idx + (uint32_t)s, n_dmrs_dci);
+    const ocf_t* y = grid + (size_t)(3 + 7 * s) * (size_t)nre + (size_t)k0;
+    for (int n = 0; n < M; n++) {
+      ocf_t r = cmul(base[n], ph12[(ncs * (uint32_t)n) % 12u]);
+      ls[s * M + n] = cmulconj(y[n], r);
+    }
+    for (int n = 0; n < M; n++) {
+      ocf_t a;
+      if (n == 0) { a.r = (ls[s * M].r + ls[s * M + 1].r) / 2.0f; a.i = (ls[s * M].i + ls[s * M + 1].i) / 2.0f; }
+      else if (n == M - 1) { a.r = (ls[s * M + n - 1].r + ls[s * M + n].r) / 2.0f; a.i = (ls[s * M + n - 1].i + ls[s * M + n].i) / 2.0f; }
+      else { a.r = ((ls[s * M + n - 1].r + ls[s * M + n].r) + ls[s * M + n + 1].r) / 3.0f; a.i = ((ls[s * M + n - 1].i + ls[s * M + n].i) + ls[s * M + n + 1].i) / 3.0f; }
+      hs[s * M + n] = a;
+    }
+  }
+  for (int i = 0; i < 2 * M; i++) { float dr = hs[i].r - ls[i].r, di = hs[i].i - ls[i].i; tmp[i] = dr * dr + di * di; }
+  float noise = o_reduce256(tmp, 2 * M) / (float)(2 * M);
+  for (int i = 0; i < 2 * M; i++) tmp[i] = hs[i].r * hs[i].r + hs[i].i * hs[i].i;
+  float sigpow = o_reduce256(tmp, 2 * M) / (float)(2 * M);
+  if (noise_out) *noise_out = noise;
+  if (sigpow_out) *sigpow_out = sigpow;
+  const float scale = 1.0f / sqrtf((float)M);
+  int col = 0;
+  for (int l = 0; l < 14; l++) {
+    if (l == 3 || l == 10) continue;
+    const ocf_t* y = grid + (size_t)l * (size_t)nre + (size_t)k0;
+    const ocf_t* h = hs + (l / 7) * M;
+    for (int n = 0; n < M; n++) {
+      ocf_t t = cmulconj(y[n], h[n]);
+      float den = (h[n].r * h[n].r + h[n].i * h[n].i) + noise;
+      x[n].r = t.r / den;
+      x[n].i = t.i / den;
+    }
+    for (int r = 0; r < M; r++) { /* z[r] = scale * sum_n x[n] exp(+2 pi j n r / M) */
+      float ar = 0.0f, ai = 0.0f;
+      int idx = 0;
+      for (int n = 0; n < M; n++) {
+        ocf_t p = cmul(x[n], w[idx]);
+        ar = ar + p.r;
+        ai = ai + p.i;
+        idx += r;
+        if (idx >= M) idx -= M;
+      }
+      float Lb[8];
+      demod_llr(Qm, ar * scale, ai * scale, Lb);
+      for (int b = 0; b < Qm; b++) {
+        float v = rintf(Lb[b] * LLR_Q);
+        if (v > (float)LLR_CLIP) v = (float)LLR_CLIP;
+        if (v < (float)-LLR_CLIP) v = (float)-LLR_CLIP;
+        int16_t q = (int16_t)v;
+        /* scrambling runs over the transmitted (column-major) order, the decoder wants the row-major UL-SCH order
+         * (36.212 5.2.2.8: R_mux x 12 matrix written row by row, read column by column) */
+        if (c[((size_t)col * (size_t)M + (size_t)r) * (size_t)Qm + (size_t)b]) q = (int16_t)-q;
+        e[((size_t)r * 12 + (size_t)col) * (size_t)Qm + (size_t)b] = q;
+      }
+    }
+    col++;
+  }
+  free(base); free(ls); free(hs); free(tmp); free(x); free(w); free(c);
+  return 0;
+}
+
+/* srsran_chest_ul_estimate_pusch + srsran_pusch_decode for one grant: returns 1 when the transport block CRC passes */
+int o_pusch_decode(const o_cell_t* cell, const o_ul_cfg_t* ul, uint32_t sf_idx, uint16_t rnti, const o_pusch_grant_t* g, uint32_t n_dmrs_dci,
+                   const ocf_t* grid, int max_iter, uint8_t* payload, int* iters, float* snr_db)
+{
+  if (g->tbs <= 0) return 0;
+  int M = 12 * (int)g->L_prb, G = 12 * M * g->mod;
+  int16_t* e = (int16_t*)malloc(sizeof(int16_t) * (size_t)(G > 0 ? G : 1));
+  float noise = 0, sig = 0;
+  int ok = 0;
+  if (o_pusch_demod(cell, ul, sf_idx, rnti, g, n_dmrs_dci, grid, e, &noise, &sig) == 0) {
+    ok = o_pdsch_decode_tb(e, G, g->tbs, g->mod, 1, g->rv, max_iter, payload, iters);
+    if (snr_db) *snr_db = 10.0f * log10f(sig / noise);
+  }
+  free(e);
+  return ok;
+}

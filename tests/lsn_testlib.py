@@ -366,3 +366,62 @@ def candidate_table(llr, nof_cce, sizes):
                     e.bits, e.rnti, e.flags = bits, rnti, 1
             li += 1
     return cand, pw
+
+
+# -------- uplink: transmitter + oracle bindings --------
+class TxgUlCell(C.Structure):
+    _fields_ = [("nof_prb", C.c_uint32), ("cell_id", C.c_uint32), ("cyclic_shift", C.c_uint32), ("delta_ss", C.c_uint32)]
+
+
+class TxgUlGrant(C.Structure):
+    _fields_ = [("rnti", C.c_uint16), ("n_dmrs", C.c_uint16), ("n_prb", C.c_uint32), ("L_prb", C.c_uint32), ("mod", C.c_uint32),
+                ("tbs", C.c_uint32), ("rv", C.c_uint32), ("gain_db", C.c_float), ("phase_rad", C.c_float), ("ta_samples", C.c_float)]
+
+
+class OUlCfg(C.Structure):
+    _fields_ = [("cyclic_shift", C.c_uint32), ("delta_ss", C.c_uint32)]
+
+
+class OPuschGrant(C.Structure):  # o_pusch_grant_t
+    _fields_ = [("L_prb", C.c_uint32), ("n_prb", C.c_uint32), ("mcs_idx", C.c_uint32), ("mod", C.c_int), ("tbs", C.c_int), ("rv", C.c_int)]
+
+
+VALID_UL_PRB = [n for n in range(1, 101) if (lambda m: all(m % p for p in (7, 11, 13)) and max([q for q in range(2, m + 1) if m % q == 0 and all(q % d for d in range(2, q))] or [1]) <= 5)(n)]
+
+
+def ul_mcs_to_mod_tbs(mcs, L, enable_64qam=True):
+    """Table 8.6.1-1 (ul_sniffer_fill_ra_mcs, ul_sniffer_pusch.c:176-200): -> (Qm, tbs)"""
+    o = oracle()
+    o.o_tbs_from_idx.restype = C.c_int
+    if mcs < 11:
+        return 2, o.o_tbs_from_idx(mcs, L)
+    if mcs < 21:
+        return 4, o.o_tbs_from_idx(mcs - 1, L)
+    return (6 if enable_64qam else 4), o.o_tbs_from_idx(mcs - 2, L)
+
+
+def ul_make_subframe(cell, tti, grants, snr_db=30.0, seed=1):
+    """grants: list of dict(rnti, n_dmrs, n_prb, L_prb, mod, tbs, rv, gain_db, phase_rad, ta_samples)
+    -> (iq complex64[15N], [payload bytes per grant])"""
+    lib = txgen()
+    lib.txg_ul_make.argtypes = [C.POINTER(TxgUlCell), C.c_uint32, C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+    N = {6: 128, 15: 256, 25: 512, 50: 1024, 100: 2048}[cell.nof_prb]
+    iq = np.zeros(15 * N, dtype=np.complex64)
+    arr = (TxgUlGrant * max(1, len(grants)))(*[TxgUlGrant(g["rnti"], g.get("n_dmrs", 0), g["n_prb"], g["L_prb"], g["mod"], g["tbs"], g.get("rv", 0),
+                                                           g.get("gain_db", 0.0), g.get("phase_rad", 0.0), g.get("ta_samples", 0.0)) for g in grants])
+    pbuf = np.zeros(sum(g["tbs"] // 8 for g in grants) + 16, dtype=np.uint8)
+    offs = (C.c_uint32 * max(1, len(grants)))()
+    n = lib.txg_ul_make(C.byref(cell), tti, arr, len(grants), snr_db, seed, iq.ctypes.data, pbuf.ctypes.data, offs)
+    assert n >= 0
+    return iq, [bytes(pbuf[offs[i]:offs[i] + g["tbs"] // 8]) for i, g in enumerate(grants)]
+
+
+def oracle_ul_api():
+    o = oracle()
+    o.o_ul_fft.argtypes = [C.POINTER(OCell), C.c_void_p, C.c_void_p]
+    o.o_pusch_demod.argtypes = [C.POINTER(OCell), C.POINTER(OUlCfg), C.c_uint32, C.c_uint16, C.POINTER(OPuschGrant), C.c_uint32, C.c_void_p, C.c_void_p,
+                                C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    o.o_pusch_decode.argtypes = [C.POINTER(OCell), C.POINTER(OUlCfg), C.c_uint32, C.c_uint16, C.POINTER(OPuschGrant), C.c_uint32, C.c_void_p, C.c_int,
+                                 C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float)]
+    o.o_ul_valid_prb.argtypes = [C.c_uint32]
+    return o

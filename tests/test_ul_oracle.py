@@ -1,0 +1,62 @@
+"""CPU tests of the uplink restatement: SC-FDMA transmitter (tools/txgen) -> oracle PUSCH receiver loop-back."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from lsn_testlib import (OCell, OPuschGrant, OUlCfg, TxgUlCell, VALID_UL_PRB, oracle_ul_api, ul_make_subframe, ul_mcs_to_mod_tbs)
+
+
+def test_valid_prb_set_matches_reference_table():
+    # UL_Sniffer_PUSCH.cc:3-10 lists exactly the 2^a 3^b 5^c sizes up to 100
+    o = oracle_ul_api()
+    ref = [1, 2, 3, 4, 5, 6, 8, 9, 10, 12, 15, 16, 18, 20, 24, 25, 27, 30, 32, 36, 40, 45, 48, 50, 54, 60, 64, 72, 75, 80, 81, 90, 96, 100]
+    assert [n for n in range(1, 101) if o.o_ul_valid_prb(n)] == ref == VALID_UL_PRB
+
+
+@pytest.mark.parametrize("nprb,cell_id", [(25, 7), (50, 101), (100, 1)])
+def test_pusch_loopback_all_modulations(nprb, cell_id):
+    o = oracle_ul_api()
+    rng = np.random.default_rng(nprb)
+    ocell, ucell, ucfg = OCell(nprb, 1, cell_id, 1), TxgUlCell(nprb, cell_id, 3, 5), OUlCfg(3, 5)
+    ok = 0
+    for it in range(6):
+        tti = int(rng.integers(0, 10240))
+        # pack a few non-overlapping grants into the band
+        grants, start = [], 0
+        while True:
+            L = int(rng.choice([n for n in VALID_UL_PRB if n >= 3 and n <= max(3, nprb // 3)]))
+            if start + L > nprb:
+                break
+            mcs = int(rng.integers(0, 29))
+            qm, tbs = ul_mcs_to_mod_tbs(mcs, L)
+            grants.append(dict(rnti=int(rng.integers(100, 60000)), n_dmrs=int(rng.integers(0, 8)), n_prb=start, L_prb=L, mod=qm, tbs=tbs, rv=0,
+                               gain_db=float(rng.uniform(-3, 3)), phase_rad=float(rng.uniform(0, 6.28)), ta_samples=float(rng.uniform(0, 4))))
+            start += L + int(rng.integers(0, 3))
+        iq, payloads = ul_make_subframe(ucell, tti, grants, snr_db=35.0, seed=it)
+        grid = np.zeros(14 * 12 * nprb, dtype=np.complex64)
+        o.o_ul_fft(C.byref(ocell), iq.ctypes.data, grid.ctypes.data)
+        for g, pl in zip(grants, payloads):
+            og = OPuschGrant(g["L_prb"], g["n_prb"], 0, g["mod"], g["tbs"], 0)
+            out = np.zeros(g["tbs"] // 8 + 8, dtype=np.uint8)
+            its, snr = C.c_int(0), C.c_float(0)
+            crc = o.o_pusch_decode(C.byref(ocell), C.byref(ucfg), tti % 10, g["rnti"], C.byref(og), g["n_dmrs"], grid.ctypes.data, 12, out.ctypes.data,
+                                   C.byref(its), C.byref(snr))
+            assert crc == 1, (nprb, it, g)
+            assert bytes(out[:g["tbs"] // 8]) == pl
+            assert snr.value > 15.0
+            ok += 1
+            # a wrong cyclic shift / RNTI must not decode
+            assert o.o_pusch_decode(C.byref(ocell), C.byref(ucfg), tti % 10, g["rnti"] ^ 1, C.byref(og), g["n_dmrs"], grid.ctypes.data, 4, out.ctypes.data,
+                                    C.byref(its), C.byref(snr)) == 0
+    assert ok >= 10
+
+
+def test_pusch_rejects_unsupported_grants():
+    o = oracle_ul_api()
+    ocell, ucfg = OCell(25, 1, 1, 1), OUlCfg(0, 0)
+    grid = np.zeros(14 * 300, dtype=np.complex64)
+    e = np.zeros(1 << 16, dtype=np.int16)
+    for L, n in ((1, 0), (2, 0), (7, 0), (10, 20), (0, 0)):
+        og = OPuschGrant(L, n, 0, 2, 104, 0)
+        assert o.o_pusch_demod(C.byref(ocell), C.byref(ucfg), 0, 70, C.byref(og), 0, grid.ctypes.data, e.ctypes.data, None, None) == -1

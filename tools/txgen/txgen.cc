@@ -676,3 +676,101 @@ extern "C" int txg_next(txg_t* g, float* iq, txg_pdu_t* pdus, int max_pdus, uint
   g->tti = (g->tti + 1) % 10240;
   return npdu;
 }
+
+// =====================================================================================================
+// Uplink: SC-FDMA transmitters of several UEs summed at the sniffer's uplink antenna (test tooling).
+// TS 36.212 5.2.2 (UL-SCH: CRC, segmentation, turbo code, rate matching, channel interleaver; no UCI),
+// TS 36.211 5.3 (scrambling, modulation, transform precoding), 5.5 (DMRS), 5.6 (7.5 kHz shifted SC-FDMA).
+typedef struct { uint32_t nof_prb, cell_id, cyclic_shift, delta_ss; } txg_ul_cell_t;
+typedef struct { uint16_t rnti; uint16_t n_dmrs; uint32_t n_prb, L_prb, mod, tbs, rv; float gain_db, phase_rad, ta_samples; } txg_ul_grant_t;
+
+static int ul_largest_prime_below(int n) { for (int p = n - 1; p >= 2; p--) { bool ok = true; for (int d = 2; d * d <= p; d++) if (p % d == 0) { ok = false; break; } if (ok) return p; } return 2; }
+
+// iq: 15*N cf32 (one antenna); payloads: concatenated tbs/8 bytes per grant at payload_off[i]; returns bytes used
+extern "C" int txg_ul_make(const txg_ul_cell_t* c, uint32_t tti, const txg_ul_grant_t* gr, int ngr, float snr_db, uint64_t seed, float* iq,
+                uint8_t* payloads, uint32_t* payload_off)
+{
+  Rng rng(seed * 7919ull + tti);
+  const int nprb = (int)c->nof_prb, nre = 12 * nprb;
+  int N = 0;
+  switch (nprb) { case 6: N = 128; break; case 15: N = 256; break; case 25: N = 512; break; case 50: N = 1024; break; case 100: N = 2048; break; default: return -1; }
+  const uint32_t sf = tti % 10;
+  std::vector<std::complex<double>> grid((size_t)14 * nre, 0.0);
+  static const uint32_t d1[8] = {0, 2, 3, 4, 6, 8, 9, 10}, d2[8] = {0, 6, 3, 4, 2, 8, 10, 9};
+  const uint32_t fss = ((c->cell_id % 30) + c->delta_ss) % 30;
+  bits_t cpn = gold(((c->cell_id / 30) << 5) + fss, 8 * 7 * 20 + 8);
+  uint32_t used = 0;
+  for (int gi = 0; gi < ngr; gi++) {
+    const txg_ul_grant_t& g = gr[gi];
+    const int M = 12 * (int)g.L_prb, Qm = (int)g.mod, G = 12 * M * Qm, k0 = 12 * (int)g.n_prb;
+    payload_off[gi] = used;
+    uint8_t* pl = payloads + used;
+    for (uint32_t i = 0; i < g.tbs / 8; i++) pl[i] = (uint8_t)rng.below(256);
+    used += g.tbs / 8;
+    bits_t f = dlsch_encode(pl, (int)g.tbs, G, Qm, 1, (int)g.rv);
+    bits_t h((size_t)G);
+    for (int col = 0; col < 12; col++)
+      for (int r = 0; r < M; r++)
+        for (int b = 0; b < Qm; b++) h[((size_t)col * M + r) * Qm + b] = f[((size_t)r * 12 + col) * Qm + b];
+    bits_t scr = gold(((uint32_t)g.rnti << 14) | (sf << 9) | c->cell_id, G);
+    for (int i = 0; i < G; i++) h[i] ^= scr[i];
+    std::vector<cf> sym;
+    modulate(h, Qm, sym);
+    const std::complex<double> chan = std::polar(std::pow(10.0, g.gain_db / 20.0), (double)g.phase_rad);
+    // base sequence
+    const int Nzc = ul_largest_prime_below(M);
+    const double qb = (double)Nzc * (double)(fss + 1) / 31.0;
+    const long long q = (long long)std::floor(qb + 0.5);
+    int col = 0;
+    for (int l = 0; l < 14; l++) {
+      std::vector<std::complex<double>> v((size_t)M);
+      if (l == 3 || l == 10) {
+        const uint32_t ns = 2 * sf + (l == 10 ? 1 : 0);
+        uint32_t npn = 0;
+        for (int i = 0; i < 8; i++) npn += (uint32_t)cpn[8 * 7 * ns + i] << i;
+        const uint32_t ncs = (d1[c->cyclic_shift & 7] + d2[g.n_dmrs & 7] + npn) % 12;
+        for (int n = 0; n < M; n++) {
+          const long long m = n % Nzc;
+          const double a = -M_PI * (double)((q * m * (m + 1)) % (2ll * Nzc)) / (double)Nzc + 2.0 * M_PI * (double)((ncs * (uint32_t)n) % 12) / 12.0;
+          v[n] = std::complex<double>(std::cos(a), std::sin(a));
+        }
+      } else {
+        for (int k = 0; k < M; k++) {  // transform precoding: (1/sqrt M) sum_r d[r] exp(-2 pi j r k / M)
+          std::complex<double> acc(0, 0);
+          for (int r = 0; r < M; r++) {
+            const double a = -2.0 * M_PI * (double)(((long long)r * k) % M) / (double)M;
+            acc += std::complex<double>(sym[(size_t)col * M + r]) * std::complex<double>(std::cos(a), std::sin(a));
+          }
+          v[k] = acc / std::sqrt((double)M);
+        }
+        col++;
+      }
+      for (int k = 0; k < M; k++) {
+        // timing advance error = linear phase over the carriers (carrier k sits at (k - nre/2 + 1/2) * 15 kHz)
+        const double fk = (double)(k0 + k) - nre / 2.0 + 0.5;
+        const double a = -2.0 * M_PI * fk * (double)g.ta_samples / (double)N;
+        grid[(size_t)l * nre + k0 + k] += chan * v[k] * std::complex<double>(std::cos(a), std::sin(a));
+      }
+    }
+  }
+  // SC-FDMA modulation with the half-subcarrier shift
+  const int sflen = 15 * N;
+  std::vector<std::complex<double>> buf(N);
+  const double sigma = std::sqrt(std::pow(10.0, -snr_db / 10.0) / (2.0 * N));
+  int pos = 0;
+  for (int l = 0; l < 14; l++) {
+    const int cp = ((l % 7) == 0 ? 160 : 144) * N / 2048;
+    for (auto& v : buf) v = 0;
+    for (int k = 0; k < nre; k++) buf[k < nre / 2 ? N - nre / 2 + k : k - nre / 2] = grid[(size_t)l * nre + k];
+    fft_d(buf, true);
+    for (int n = -cp; n < N; n++) {
+      const double a = M_PI * (double)n / (double)N;
+      const std::complex<double> y = buf[(size_t)((n + N) % N)] / (double)N * std::complex<double>(std::cos(a), std::sin(a));
+      iq[2 * (pos + cp + n)] = (float)(y.real() + sigma * rng.gauss());
+      iq[2 * (pos + cp + n) + 1] = (float)(y.imag() + sigma * rng.gauss());
+    }
+    pos += cp + N;
+  }
+  (void)sflen;
+  return (int)used;
+}
