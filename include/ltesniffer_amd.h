@@ -125,6 +125,31 @@ int lsn_phy_process_device(lsn_phy_t* phy, const void* d_iq, uint32_t n_subframe
 /* same, from host memory (copies through pinned staging) */
 int lsn_phy_process_host(lsn_phy_t* phy, const float* iq, uint32_t n_subframes, uint32_t start_tti, uint32_t update_meta_period);
 
+/* ---- uplink (PUSCH) ----
+ * lsn_phy_set_ul_config replaces srsran_enb_ul_set_cell(&enb_ul, cell, &ul_cfg.dmrs, ...) (SubframeWorker.cc:258-262); the two
+ * values come from SIB2 (ULSchedule::set_config, ULSchedule.cc:140-158: cyclicShift, groupAssignmentPUSCH).
+ * lsn_phy_pusch_decode runs srsran_enb_ul_fft + srsran_chest_ul_estimate_pusch + srsran_pusch_decode
+ * (UL_Sniffer_PUSCH.cc:392,256,262) for a whole list of grants on n_subframes of the uplink antenna.
+ * Round-1 scope: one antenna, no group/sequence/frequency hopping, no SRS, no UCI on PUSCH, L_prb >= 3 of the 2^a3^b5^c set
+ * (UL_Sniffer_PUSCH.cc:3-10); any other grant comes back with crc_ok = 0. */
+typedef struct { uint32_t cyclic_shift; uint32_t delta_ss; } lsn_ul_cfg_t;
+typedef struct {
+  uint32_t sf;       /* subframe index inside ul_iq (tti = start_tti + sf) */
+  uint16_t rnti;
+  uint16_t n_dmrs;   /* cyclic shift field of DCI 0 (0 for a RAR grant) */
+  uint32_t n_prb, L_prb;
+  uint32_t mod;      /* bits per symbol: 2, 4, 6, 8 */
+  uint32_t tbs;      /* bits */
+  int rv;
+} lsn_pusch_grant_t;
+typedef struct { uint32_t crc_ok; uint32_t iterations; float snr_db; uint32_t payload_off; } lsn_pusch_result_t;
+int lsn_phy_set_ul_config(lsn_phy_t* phy, const lsn_ul_cfg_t* cfg);
+/* ul_iq: [n_subframes][15*N] interleaved cf32 of the uplink antenna, host memory (iq_on_device = 0) or device memory (1).
+ * payloads (may be NULL): decoded transport blocks, tbs/8 bytes each at results[i].payload_off. */
+int lsn_phy_pusch_decode(lsn_phy_t* phy, const void* ul_iq, int iq_on_device, uint32_t n_subframes, uint32_t start_tti,
+                         const lsn_pusch_grant_t* grants, uint32_t n_grants, lsn_pusch_result_t* results, uint8_t* payloads, size_t payload_cap);
+long lsn_phy_tap_ul(lsn_phy_t* phy, int what /* 0: uplink grid of subframe `index` */, uint32_t index, void* out, size_t cap);
+
 /* ---- measurement + parity taps (not part of the reference surface) ---- */
 enum { LSN_TAP_GRID = 0, LSN_TAP_CE = 1, LSN_TAP_PDCCH_LLR = 2, LSN_TAP_CHEST = 3, LSN_TAP_CFI = 4, LSN_TAP_CANDIDATES = 5,
        LSN_TAP_CCE_POWER = 6, LSN_TAP_ACCEPTED = 7, LSN_TAP_RB_POWER = 8 };

@@ -29,7 +29,8 @@ EXPORTS = ["lsn_phy_create", "lsn_phy_destroy", "lsn_phy_set_cell", "lsn_phy_get
            "lsn_worker_sf_idx", "lsn_worker_sfn", "lsn_phy_process_device", "lsn_phy_process_host", "lsn_phy_tap",
            "lsn_phy_get_perf", "lsn_kernel_name", "lsn_version", "lsn_pcap_open", "lsn_pcap_open_mem",
            "lsn_pcap_set_wall_clock", "lsn_pcap_write", "lsn_pcap_sink", "lsn_pcap_mem", "lsn_pcap_nof_records",
-           "lsn_pcap_reset", "lsn_pcap_close", "lsn_phy_set_pcap_writer"]
+           "lsn_pcap_reset", "lsn_pcap_close", "lsn_phy_set_pcap_writer", "lsn_phy_set_ul_config", "lsn_phy_pusch_decode",
+           "lsn_phy_tap_ul"]
 
 
 class Cell(C.Structure):
@@ -65,6 +66,19 @@ class Perf(C.Structure):
                 ("nof_cb_decodes", C.c_uint64), ("nof_turbo_iterations", C.c_uint64), ("nof_candidates_decoded", C.c_uint64),
                 ("nof_ondemand_decodes", C.c_uint64), ("nof_pdus", C.c_uint64), ("ms_search_core", C.c_double), ("ms_rar", C.c_double), ("turbo_cyc_rm", C.c_uint64),
                 ("turbo_cyc_map", C.c_uint64), ("turbo_cyc_out", C.c_uint64)]
+
+
+class UlCfg(C.Structure):
+    _fields_ = [("cyclic_shift", C.c_uint32), ("delta_ss", C.c_uint32)]
+
+
+class PuschGrant(C.Structure):
+    _fields_ = [("sf", C.c_uint32), ("rnti", C.c_uint16), ("n_dmrs", C.c_uint16), ("n_prb", C.c_uint32), ("L_prb", C.c_uint32),
+                ("mod", C.c_uint32), ("tbs", C.c_uint32), ("rv", C.c_int)]
+
+
+class PuschResult(C.Structure):
+    _fields_ = [("crc_ok", C.c_uint32), ("iterations", C.c_uint32), ("snr_db", C.c_float), ("payload_off", C.c_uint32)]
 
 
 SINK_T = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(PduCtx), C.POINTER(C.c_uint8), C.c_uint32)
@@ -158,6 +172,11 @@ def lib():
         L.lsn_pcap_close.argtypes = [C.c_void_p]
         L.lsn_pcap_close.restype = None
         L.lsn_phy_set_pcap_writer.argtypes = [C.c_void_p, C.c_void_p]
+        L.lsn_phy_set_ul_config.argtypes = [C.c_void_p, C.POINTER(UlCfg)]
+        L.lsn_phy_pusch_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
+                                           C.c_void_p, C.c_size_t]
+        L.lsn_phy_tap_ul.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_size_t]
+        L.lsn_phy_tap_ul.restype = C.c_long
         _lib = L
     return _lib
 
@@ -289,6 +308,41 @@ class Phy:
     def process_device(self, dev_ptr, n_subframes, start_tti, update_meta_period=0, stream=None):
         _check(lib().lsn_phy_process_device(self._h, C.c_void_p(dev_ptr), n_subframes, start_tti, update_meta_period,
                                             C.c_void_p(stream or 0)), "process_device")
+
+    # ---- uplink ----
+    def setUlConfig(self, cyclic_shift, delta_ss):
+        u = UlCfg(cyclic_shift, delta_ss)
+        return lib().lsn_phy_set_ul_config(self._h, C.byref(u)) == LSN_SUCCESS
+
+    def pusch_decode(self, ul_iq, start_tti, grants):
+        """ul_iq: complex64 [n_subframes, 15*N]; grants: list of dict(sf, rnti, n_dmrs, n_prb, L_prb, mod, tbs, rv)
+        -> list of dict(crc_ok, iterations, snr_db, payload)"""
+        ul_iq = np.ascontiguousarray(ul_iq, dtype=np.complex64)
+        n = len(grants)
+        arr = (PuschGrant * max(1, n))(*[PuschGrant(g["sf"], g["rnti"], g.get("n_dmrs", 0), g["n_prb"], g["L_prb"], g["mod"], g["tbs"], g.get("rv", 0))
+                                         for g in grants])
+        res = (PuschResult * max(1, n))()
+        cap = sum(g["tbs"] // 8 for g in grants) + 64
+        pay = np.zeros(cap, dtype=np.uint8)
+        _check(lib().lsn_phy_pusch_decode(self._h, ul_iq.ctypes.data, 0, ul_iq.shape[0], start_tti, arr, n, res, pay.ctypes.data, cap), "pusch_decode")
+        return [dict(crc_ok=int(res[i].crc_ok), iterations=int(res[i].iterations), snr_db=float(res[i].snr_db),
+                     payload=bytes(pay[res[i].payload_off:res[i].payload_off + grants[i]["tbs"] // 8]) if res[i].crc_ok else b"")
+                for i in range(n)]
+
+    def tap_ul_grid(self, sf):
+        nre = 12 * self.cell.nof_prb
+        buf = np.zeros(14 * nre, dtype=np.complex64)
+        nb = lib().lsn_phy_tap_ul(self._h, 0, sf, buf.ctypes.data, buf.nbytes)
+        if nb < 0:
+            raise RuntimeError("tap_ul failed: %d" % nb)
+        return buf.reshape(14, nre)
+
+    def tap_ul_llr(self, grant_index, count):
+        buf = np.zeros(count, dtype=np.int16)
+        nb = lib().lsn_phy_tap_ul(self._h, 1, grant_index, buf.ctypes.data, buf.nbytes)
+        if nb < 0:
+            raise RuntimeError("tap_ul failed: %d" % nb)
+        return buf[: nb // 2]
 
     # ---- taps / stats ----
     def tap(self, what, sf, dtype, count):

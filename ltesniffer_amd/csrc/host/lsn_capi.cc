@@ -249,6 +249,23 @@ int lsn_phy_process_host(lsn_phy_t* phy, const float* iq, uint32_t n, uint32_t s
   return phy->engine->processHost(iq, n, start_tti, update_meta_period);
 }
 
+int lsn_phy_set_ul_config(lsn_phy_t* phy, const lsn_ul_cfg_t* cfg)
+{
+  if (!phy || !cfg) return LSN_ERROR_INVALID_INPUTS;
+  return phy->engine->setUlConfig(*cfg);
+}
+int lsn_phy_pusch_decode(lsn_phy_t* phy, const void* ul_iq, int iq_on_device, uint32_t n_subframes, uint32_t start_tti,
+                         const lsn_pusch_grant_t* grants, uint32_t n_grants, lsn_pusch_result_t* results, uint8_t* payloads, size_t payload_cap)
+{
+  if (!phy) return LSN_ERROR_INVALID_INPUTS;
+  return phy->engine->puschDecode(ul_iq, iq_on_device != 0, n_subframes, start_tti, grants, n_grants, results, payloads, payload_cap);
+}
+long lsn_phy_tap_ul(lsn_phy_t* phy, int what, uint32_t index, void* out, size_t cap)
+{
+  if (!phy || !out) return LSN_ERROR_INVALID_INPUTS;
+  return phy->engine->tapUl(what, index, out, cap);
+}
+
 long lsn_phy_tap(lsn_phy_t* phy, int what, uint32_t sf, void* out, size_t cap)
 {
   if (!phy || !out) return LSN_ERROR_INVALID_INPUTS;

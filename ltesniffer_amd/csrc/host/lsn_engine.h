@@ -85,6 +85,10 @@ public:
   uint32_t nofRx() const { return cfg.nof_rx_antennas; }
   uint32_t maxBatch() const { return max_batch; }
   void setupDefaultIntervals() { search->setupDefaultIntervals(); }
+  int setUlConfig(const lsn_ul_cfg_t& u);
+  int puschDecode(const void* ul_iq, bool on_device, uint32_t nsf, uint32_t start_tti, const lsn_pusch_grant_t* grants, uint32_t ngrants,
+                  lsn_pusch_result_t* results, uint8_t* payloads, size_t payload_cap);
+  long tapUl(int what, uint32_t index, void* out, size_t cap);
   void forceMetaUpdateNext() { force_meta_next = true; }
 
 private:
@@ -151,6 +155,15 @@ private:
   uint64_t sf_cnt = 0;
   Chunk* last_chunk = nullptr;
   bool force_meta_next = false;
+  // uplink
+  lsn_ul_cfg_t ul_cfg{};
+  bool ul_set = false;
+  std::vector<int> ul_off;       // allocation size L -> offset into ul_base / ul_idft (-1: unsupported)
+  uint32_t ul_npn[20] = {0};
+  std::vector<LsnUlGrantDev> ul_last_gd; std::vector<int> ul_last_idx;  // descriptors of the last puschDecode call (taps)
+  JobRunner runner_u;
+  cf32 *ul_d_iq = nullptr, *ul_d_grid = nullptr, *ul_d_hs = nullptr; float* ul_d_stat = nullptr; LsnUlGrantDev* ul_d_grants = nullptr;
+  size_t ul_iq_cap = 0, ul_grid_cap = 0, ul_hs_cap = 0, ul_stat_cap = 0, ul_grants_cap = 0;
   std::vector<int> numa_cpus;  // CPUs local to the GPU (empty: unknown, no pinning)
 };
 

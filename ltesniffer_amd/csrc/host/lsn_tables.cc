@@ -63,6 +63,13 @@ void Engine::freeDevice()
   for (auto& r : runner_c) freeRunner(r);
   freeRunner(runner_s);
   freeRunner(runner_f);
+  freeRunner(runner_u);
+  {
+    auto df = [](auto*& p) { if (p) (void)hipFree(p); p = nullptr; };
+    df(ul_d_iq); df(ul_d_grid); df(ul_d_hs); df(ul_d_stat); df(ul_d_grants);
+    ul_iq_cap = ul_grid_cap = ul_hs_cap = ul_stat_cap = ul_grants_cap = 0;
+    ul_set = false;
+  }
   d_dphi = nullptr; d_iq_staging = nullptr; staging_sf = 0;
   last_chunk = nullptr;
 }
@@ -84,7 +91,7 @@ void Engine::allocRunner(JobRunner& r)
   // the search thread's runner (on-demand RAR decodes) sits on the critical path of the sequential search: high priority
   int lo = 0, hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-  if (&r == &runner_s || &r == &runner_f) {
+  if (&r == &runner_s || &r == &runner_f || &r == &runner_u) {
     HIP_CHECK(hipStreamCreateWithPriority(&r.stream, hipStreamNonBlocking, hi));
   } else {
     // bulk decode streams leave a few CUs alone, so that the latency-critical launches (stage A, on-demand RAR decodes)

@@ -44,6 +44,11 @@ struct LsnCellDev {
   const uint32_t* gold_x2mask;     // [LSN_GOLD_LEN] x2(n+1600) = parity(mask & cinit)
   const uint32_t* crc_tab_a;       // [6144] x^j mod gCRC24A
   const uint32_t* crc_tab_b;       // [6144] x^j mod gCRC24B
+  // uplink (valid after lsn_phy_set_ul_config)
+  const cf32* ul_shift;            // [N] exp(-j pi n / N): 7.5 kHz shift
+  const cf32* ul_base;             // DMRS base sequences r_{u,0}(n) of every valid allocation size, concatenated
+  const cf32* ul_idft;             // exp(+2 pi j k / M) of every valid allocation size, concatenated
+  const cf32* ul_ph12;             // [12] exp(j 2 pi m / 12): cyclic-shift phasors
 };
 #define LSN_GOLD_LEN 115200
 
@@ -74,6 +79,18 @@ struct LsnCbDev {
   uint32_t max_iter;
   uint32_t res_idx;   // slot of this block's LsnCbRes (launch order is sorted by size, results are not)
 };
+// one PUSCH grant to decode
+struct LsnUlGrantDev {
+  uint32_t sf;          // subframe index inside the batch
+  uint32_t n_prb, L_prb, qm;
+  uint32_t ncs[2];      // DMRS cyclic shift n_cs of the two slots
+  uint32_t cinit;       // scrambling: rnti << 14 | sf_idx << 9 | cell id
+  uint32_t base_off, idft_off;  // offsets of this allocation size into ul_base / ul_idft
+  uint32_t hs_off;      // cf32 offset of the 2 M smoothed channel estimates
+  uint32_t llr_off;     // int16 offset of the 12 M Qm LLRs (UL-SCH order)
+  float scale;          // 1 / sqrt(M)
+};
+
 struct LsnCbRes { uint32_t ok, iters, rem_a, pad; uint32_t cyc_rm, cyc_map, cyc_out, cyc_all; };  // cyc_*: shader cycles per phase (s_memtime)
 
 // launchers (stage_a.hip / stage_c.hip)
@@ -85,6 +102,10 @@ void lsn_launch_pdcch_llr(const LsnCellDev& c, const cf32* grid, const cf32* ce,
 void lsn_launch_cce_power(const LsnCellDev& c, const float* llr, const uint32_t* cfi, float* pw, uint32_t nsf, hipStream_t s);
 void lsn_launch_viterbi(const LsnCellDev& c, const float* llr, const float* pw, const uint32_t* cfi, LsnCand* cand, uint32_t nsf, hipStream_t s);
 void lsn_launch_rb_power(const LsnCellDev& c, const cf32* grid, float* rbp, uint32_t nsf, hipStream_t s);
+void lsn_launch_ul_fft(const LsnCellDev& c, const cf32* iq, cf32* grid, uint32_t nsf, hipStream_t s);
+void lsn_launch_pusch_chest(const LsnCellDev& c, const LsnUlGrantDev* g, const cf32* grid, cf32* hs, float* stat, uint32_t ngrants, hipStream_t s);
+void lsn_launch_pusch_demod(const LsnCellDev& c, const LsnUlGrantDev* g, const cf32* grid, const cf32* hs, const float* stat, int16_t* llr,
+                            uint32_t ngrants, hipStream_t s);
 void lsn_launch_pdsch_prep(const LsnCellDev& c, const LsnGrantDev* g, uint16_t* prefix, uint32_t njobs, hipStream_t s);
 void lsn_launch_pdsch_demod(const LsnCellDev& c, const LsnGrantDev* g, const uint16_t* prefix, const cf32* grid, const cf32* ce, const LsnChest* ch, int16_t* llr, uint32_t njobs, hipStream_t s);
 void lsn_launch_turbo(const LsnCellDev& c, const LsnCbDev* cb, const int16_t* llr, uint8_t* payload, LsnCbRes* res, uint32_t n128, uint32_t kmax128,

@@ -1,0 +1,199 @@
+// stage_ul.hip - gfx950 kernels of the uplink receive chain: SC-FDMA demodulation of the uplink antenna and, per PUSCH
+// grant, DMRS channel estimation, 1-tap MMSE equalisation, transform de-precoding, soft demodulation, descrambling and
+// channel de-interleaving.  They replace srsran_enb_ul_fft (/root/reference/src/src/UL_Sniffer_PUSCH.cc:392),
+// srsran_chest_ul_estimate_pusch (:256) and the front half of srsran_pusch_decode (:262); the back half (rate
+// de-matching + turbo + CRC) is k_turbo of stage_c.hip.  Scope: one antenna, no hopping, no SRS, no UCI, L_prb >= 3.
+// Float arithmetic: one rounding per operation, fixed summation orders (bit-identical to the tests' CPU oracle).
+#include "lsn_dev.h"
+
+#define LLR_Q 180.0f
+
+__device__ __forceinline__ cf32 cmul(cf32 a, cf32 b) { cf32 c; c.r = a.r * b.r - a.i * b.i; c.i = a.r * b.i + a.i * b.r; return c; }
+__device__ __forceinline__ cf32 cmulconj(cf32 a, cf32 b) { cf32 c; c.r = a.r * b.r + a.i * b.i; c.i = a.i * b.r - a.r * b.i; return c; }
+
+// ------------------------------------------------------------------------------------------------ SC-FDMA demodulation
+template <int R>
+__device__ __forceinline__ void ul_fft_pass(cf32* a, const cf32* w, int s, int N, int lgN, int tid)
+{
+  constexpr int G = 1 << R;
+  const int h = 1 << s;
+#pragma unroll
+  for (int u = 0; u < (8 >> R); u++) {
+    int g = tid * (8 >> R) + u;
+    if (g >= (N >> R)) break;
+    int low = g & (h - 1), high = g >> s, base = (high << (s + R)) | low;
+    cf32 e[G];
+#pragma unroll
+    for (int j = 0; j < G; j++) e[j] = a[base + j * h];
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+#pragma unroll
+      for (int j = 0; j < G; j++) {
+        if (j & (1 << q)) continue;
+        int pos = low + (j & ((1 << q) - 1)) * h;
+        cf32 v = cmul(e[j + (1 << q)], w[pos << (lgN - (s + q + 1))]);
+        cf32 uu = e[j];
+        e[j].r = uu.r + v.r; e[j].i = uu.i + v.i;
+        e[j + (1 << q)].r = uu.r - v.r; e[j + (1 << q)].i = uu.i - v.i;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < G; j++) a[base + j * h] = e[j];
+  }
+}
+
+// one workgroup per (subframe, symbol): CP strip, 7.5 kHz shift, radix-8/4/2 DIT FFT in LDS, carrier extract (no DC gap)
+__global__ __launch_bounds__(256) void k_ul_fft(LsnCellDev c, const cf32* __restrict__ iq, cf32* __restrict__ grid)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int N = (int)c.N, lgN = (int)c.lgN, tid = threadIdx.x;
+  cf32* a = (cf32*)smem;
+  cf32* w = a + N;
+  const int l = blockIdx.x % 14, sf = blockIdx.x / 14;
+  const int cp0 = 160 * N / 2048, cp1 = 144 * N / 2048;
+  const int slot = l / 7, ls = l % 7;
+  const int pos = slot * (cp0 + 6 * cp1 + 7 * N) + cp0 + ls * (N + cp1);
+  const cf32* in = iq + (size_t)sf * c.sflen + pos;
+  for (int n = tid; n < N / 2; n += 256) w[n] = c.twiddle[n];
+  for (int n = tid; n < N; n += 256) a[__brev((unsigned)n) >> (32 - lgN)] = cmul(in[n], c.ul_shift[n]);
+  __syncthreads();
+  int s = 0;
+  while (s < lgN) {
+    int r = lgN - s;
+    if (r >= 3) { ul_fft_pass<3>(a, w, s, N, lgN, tid); s += 3; }
+    else if (r == 2) { ul_fft_pass<2>(a, w, s, N, lgN, tid); s += 2; }
+    else { ul_fft_pass<1>(a, w, s, N, lgN, tid); s += 1; }
+    __syncthreads();
+  }
+  const int nre = (int)c.nre;
+  cf32* out = grid + ((size_t)sf * 14 + l) * nre;
+  for (int k = tid; k < nre; k += 256) out[k] = a[(k < nre / 2) ? (N - nre / 2 + k) : (k - nre / 2)];
+}
+
+void lsn_launch_ul_fft(const LsnCellDev& c, const cf32* iq, cf32* grid, uint32_t nsf, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_ul_fft, dim3(nsf * 14), dim3(256), sizeof(cf32) * (c.N + c.N / 2), s, c, iq, grid);
+}
+
+// ------------------------------------------------------------------------------------------------ DMRS estimate
+// one workgroup per grant: LS on symbols 3 / 10, 3-tap smoothing per slot, noise = mean |smoothed - ls|^2,
+// signal = mean |smoothed|^2 (both over the 2 M values in the fixed 256-way order)
+__global__ __launch_bounds__(256) void k_pusch_chest(LsnCellDev c, const LsnUlGrantDev* __restrict__ grants, const cf32* __restrict__ grid,
+                                                     cf32* __restrict__ hs_out, float* __restrict__ stat)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const LsnUlGrantDev g = grants[blockIdx.x];
+  const int M = 12 * (int)g.L_prb, nre = (int)c.nre, tid = threadIdx.x;
+  cf32* ls = (cf32*)smem;            // [2 M]
+  float* part = (float*)(ls + 2 * M);  // [2][256]
+  const cf32* base = c.ul_base + g.base_off;
+  for (int i = tid; i < 2 * M; i += 256) {
+    const int s = i >= M ? 1 : 0, n = i - s * M;
+    const cf32 y = grid[((size_t)g.sf * 14 + 3 + 7 * s) * nre + 12 * g.n_prb + n];
+    const cf32 r = cmul(base[n], c.ul_ph12[(g.ncs[s] * (uint32_t)n) % 12u]);
+    ls[i] = cmulconj(y, r);
+  }
+  __syncthreads();
+  cf32* hs = hs_out + g.hs_off;
+  float p0 = 0.0f, p1 = 0.0f;
+  for (int i = tid; i < 2 * M; i += 256) {
+    const int s = i >= M ? 1 : 0, n = i - s * M;
+    const cf32* q = ls + s * M;
+    cf32 a;
+    if (n == 0) { a.r = (q[0].r + q[1].r) / 2.0f; a.i = (q[0].i + q[1].i) / 2.0f; }
+    else if (n == M - 1) { a.r = (q[n - 1].r + q[n].r) / 2.0f; a.i = (q[n - 1].i + q[n].i) / 2.0f; }
+    else { a.r = ((q[n - 1].r + q[n].r) + q[n + 1].r) / 3.0f; a.i = ((q[n - 1].i + q[n].i) + q[n + 1].i) / 3.0f; }
+    hs[i] = a;
+    const float dr = a.r - q[n].r, di = a.i - q[n].i;
+    p0 = p0 + (dr * dr + di * di);
+    p1 = p1 + (a.r * a.r + a.i * a.i);
+  }
+  part[tid] = p0; part[256 + tid] = p1;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) { part[tid] = part[tid] + part[tid + s]; part[256 + tid] = part[256 + tid] + part[256 + tid + s]; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    stat[2 * blockIdx.x] = part[0] / (float)(2 * M);
+    stat[2 * blockIdx.x + 1] = part[256] / (float)(2 * M);
+  }
+}
+
+void lsn_launch_pusch_chest(const LsnCellDev& c, const LsnUlGrantDev* g, const cf32* grid, cf32* hs, float* stat, uint32_t ngrants, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_pusch_chest, dim3(ngrants), dim3(256), sizeof(cf32) * 2 * 1200 + sizeof(float) * 512, s, c, g, grid, hs, stat);
+}
+
+// ------------------------------------------------------------------------------------------------ equalise + IDFT + demod
+__device__ __forceinline__ void ul_demod_llr(int Qm, float I, float Q, float* L)
+{
+  float aI = fabsf(I), aQ = fabsf(Q);
+  L[0] = -I; L[1] = -Q;
+  if (Qm == 4) {
+    const float a = 0.31622776601683794f;
+    L[2] = aI - 2.0f * a; L[3] = aQ - 2.0f * a;
+  } else if (Qm == 6) {
+    const float a = 0.15430334996209191f;
+    float tI = aI - 4.0f * a, tQ = aQ - 4.0f * a;
+    L[2] = tI; L[3] = tQ; L[4] = fabsf(tI) - 2.0f * a; L[5] = fabsf(tQ) - 2.0f * a;
+  } else if (Qm == 8) {
+    const float a = 0.07669649888473704f;
+    float tI = aI - 8.0f * a, tQ = aQ - 8.0f * a;
+    float uI = fabsf(tI) - 4.0f * a, uQ = fabsf(tQ) - 4.0f * a;
+    L[2] = tI; L[3] = tQ; L[4] = uI; L[5] = uQ; L[6] = fabsf(uI) - 2.0f * a; L[7] = fabsf(uQ) - 2.0f * a;
+  }
+}
+
+// one workgroup per (data symbol 0..11, grant): equalised carriers + the IDFT twiddles in LDS, one thread per output
+// sample of the transform de-precoding (direct IDFT, carriers summed in increasing order), LLRs written in UL-SCH order
+__global__ __launch_bounds__(256) void k_pusch_demod(LsnCellDev c, const LsnUlGrantDev* __restrict__ grants, const cf32* __restrict__ grid,
+                                                     const cf32* __restrict__ hs_all, const float* __restrict__ stat, int16_t* __restrict__ llr)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const LsnUlGrantDev g = grants[blockIdx.y];
+  const int col = blockIdx.x, l = col < 3 ? col : (col < 9 ? col + 1 : col + 2);
+  const int M = 12 * (int)g.L_prb, nre = (int)c.nre, Qm = (int)g.qm, tid = threadIdx.x;
+  cf32* x = (cf32*)smem;   // [M]
+  cf32* w = x + M;         // [M] exp(+2 pi j k / M)
+  const cf32* y = grid + ((size_t)g.sf * 14 + l) * nre + 12 * g.n_prb;
+  const cf32* h = hs_all + g.hs_off + (l / 7) * M;
+  const cf32* wt = c.ul_idft + g.idft_off;
+  const float noise = stat[2 * blockIdx.y];
+  for (int n = tid; n < M; n += 256) {
+    const cf32 hh = h[n], t = cmulconj(y[n], hh);
+    const float den = (hh.r * hh.r + hh.i * hh.i) + noise;
+    cf32 v; v.r = t.r / den; v.i = t.i / den;
+    x[n] = v;
+    w[n] = wt[n];
+  }
+  __syncthreads();
+  const float scale = g.scale;  // 1 / sqrt(M), from the host
+  int16_t* e = llr + g.llr_off;
+  for (int r = tid; r < M; r += 256) {
+    float ar = 0.0f, ai = 0.0f;
+    int idx = 0;
+    for (int n = 0; n < M; n++) {
+      const cf32 p = cmul(x[n], w[idx]);
+      ar = ar + p.r; ai = ai + p.i;
+      idx += r; idx = idx >= M ? idx - M : idx;
+    }
+    float Lb[8];
+    ul_demod_llr(Qm, ar * scale, ai * scale, Lb);
+    for (int b = 0; b < Qm; b++) {
+      float v = rintf(Lb[b] * LLR_Q);
+      v = v > (float)LSN_LLR_CLIP ? (float)LSN_LLR_CLIP : v;
+      v = v < (float)-LSN_LLR_CLIP ? (float)-LSN_LLR_CLIP : v;
+      int q = (int)v;
+      const uint32_t sidx = ((uint32_t)col * (uint32_t)M + (uint32_t)r) * (uint32_t)Qm + (uint32_t)b;  // scrambling: transmitted order
+      const uint32_t cbit = (uint32_t)c.gold_x1[sidx] ^ (uint32_t)(__popc(c.gold_x2mask[sidx] & g.cinit) & 1);
+      e[((uint32_t)r * 12u + (uint32_t)col) * (uint32_t)Qm + (uint32_t)b] = (int16_t)(cbit ? -q : q);  // UL-SCH (row-major) order
+    }
+  }
+}
+
+void lsn_launch_pusch_demod(const LsnCellDev& c, const LsnUlGrantDev* g, const cf32* grid, const cf32* hs, const float* stat, int16_t* llr,
+                            uint32_t ngrants, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_pusch_demod, dim3(12, ngrants), dim3(256), sizeof(cf32) * 2 * 1200, s, c, g, grid, hs, stat, llr);
+}
