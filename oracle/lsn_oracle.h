@@ -152,6 +152,7 @@ int o_dci_unpack_dl(const o_cell_t* cell, const uint8_t* payload, uint32_t nof_b
 int o_dci_unpack_ul(const o_cell_t* cell, const uint8_t* payload, uint32_t nof_bits, uint16_t rnti, o_dci_ul_t* dci);
 int o_ra_dl_dci_to_grant(const o_cell_t* cell, uint32_t sf_idx, uint32_t cfi, int use_256qam_table, const o_dci_dl_t* dci, o_pdsch_grant_t* g);
 int o_ra_ul_dci_to_grant(const o_cell_t* cell, const o_dci_ul_t* dci, o_pusch_grant_t* g);
+int o_ra_ul_dci_to_grant_256(const o_cell_t* cell, const o_dci_ul_t* dci, o_pusch_grant_t* g);
 int o_config_mimo(const o_cell_t* cell, int format, const o_dci_dl_t* dci, o_pdsch_grant_t* g);
 uint32_t o_ra_nof_re(const o_cell_t* cell, uint32_t sf_idx, uint32_t cfi, const o_pdsch_grant_t* g);
 int o_tbs_from_idx(int i_tbs, uint32_t n_prb);
@@ -230,6 +231,10 @@ void o_worker_free(o_worker_t*);
 void o_worker_set_pcap(o_worker_t*, o_pcap_t*);
 /* iq[rx] -> 15*N samples each; returns number of pcap records written for this subframe */
 int o_worker_work(o_worker_t*, const ocf_t* const* iq, uint32_t sf_idx, uint32_t sfn, int update_meta_formats, float cfo_correct_hz);
+/* UL_MODE (SubframeWorker.cc:184-199,236-345): iq[0] = downlink antenna, iq[1] = uplink antenna; worker created with nof_rx = 1.
+ * The SIB2-derived DMRS configuration is given instead of parsed (ASN.1 is out of scope). */
+void o_worker_set_ul_mode(o_worker_t*, const o_ul_cfg_t* ul);
+int o_worker_work_ul(o_worker_t*, const ocf_t* dl_iq, const ocf_t* ul_iq, uint32_t sf_idx, uint32_t sfn, int update_meta_formats);
 const o_stats_t* o_worker_stats(o_worker_t*);
 /* stage taps for parity tests (valid until the next work()) */
 const ocf_t* o_worker_grid(o_worker_t*);

@@ -528,3 +528,26 @@ int o_config_mimo(const o_cell_t* cell, int format, const o_dci_dl_t* d, o_pdsch
   }
   return 0;
 }
+
+/* ul_fill_ra_mcs_256 (ul_sniffer_pusch.c:91-136, Table 8.6.1-3 of 36.213 incl. the 32A row) on the grant of
+ * o_ra_ul_dci_to_grant: same PRB allocation, modulation / TBS of the 256QAM-capable table */
+int o_ra_ul_dci_to_grant_256(const o_cell_t* cell, const o_dci_ul_t* d, o_pusch_grant_t* g)
+{
+  if (o_ra_ul_dci_to_grant(cell, d, g)) return -1;
+  uint32_t m = d->mcs_idx, L = g->L_prb;
+  if (m <= 28) {
+    g->rv = 0;
+    if (m < 6) { g->mod = 2; g->tbs = o_tbs_from_idx((int)m * 2, L); }
+    else if (m < 14) { g->mod = 4; g->tbs = o_tbs_from_idx((int)m + (m < 10 ? 5 : 6), L); }
+    else if (m < 23) { g->mod = 6; g->tbs = o_tbs_from_idx((int)m + (m < 19 ? 6 : 7), L); }
+    else {
+      g->mod = 8;
+      if (m < 26) g->tbs = o_tbs_from_idx((int)m + 7, L);
+      else if (m == 26) g->tbs = (L > 0 && L < 111) ? lsn_tbs_table_32A[L - 1] : 0;
+      else g->tbs = o_tbs_from_idx((int)m + 6, L);
+    }
+  } else {
+    g->mod = 0; g->tbs = 0; g->rv = (int)m - 28; /* last_tb is empty without HARQ state */
+  }
+  return 0;
+}

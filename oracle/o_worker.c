@@ -15,6 +15,7 @@
  * evaluated on the grant that is actually used; RRC ConnectionSetup parsing (p_a feedback) is out of scope
  *  so p_a stays at the MCSTracking default 0 dB (MCSTracking.cc:1536). */
 #include "lsn_oracle.h"
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -30,7 +31,10 @@ typedef struct { /* DL_Sniffer_DCI_DL */
   o_dci_dl_t dci; uint16_t dci_rnti; /* ran_dci_dl->rnti, zeroed on grant failure */
   o_pdsch_grant_t g64, g256; int has64, has256;
 } dl_entry_t;
-typedef struct { uint16_t rnti; uint32_t nof_bits, L, ncce, histval; o_dci_ul_t dci; o_pusch_grant_t g; } ul_entry_t;
+typedef struct { uint16_t rnti; uint32_t nof_bits, L, ncce, histval; o_dci_ul_t dci; o_pusch_grant_t g, g256; int ok; } ul_entry_t;
+/* one entry of ULSchedule (DCI_UL): grants of both UL MCS tables */
+typedef struct { uint16_t rnti; o_pusch_grant_t g, g256; uint32_t n_dmrs, hopping; int is_rar; } ulg_t;
+typedef struct { uint32_t tti; int valid; int n; ulg_t g[96]; } ulslot_t;
 
 typedef struct { uint8_t present, has_rar; uint16_t nof_msg_after_rar; uint8_t table; } mcs_entry_t;
 
@@ -66,6 +70,14 @@ struct o_worker {
   uint8_t* payload;
   uint64_t total_iters, algo_bytes;
   int records;
+  /* UL mode */
+  int ul_mode;
+  o_ul_cfg_t ulcfg;
+  ocf_t* ul_grid;
+  ulslot_t* ul_sched;  /* [16] DCI-0 grants by tti % 16 (ULSchedule::pushULSche) */
+  ulslot_t* rar_sched; /* [16] RAR grants */
+  uint8_t* ulmod;      /* [65536] 0 absent, 1 unknown, 2 16QAM max, 3 64QAM max, 4 256QAM max (MCSTracking UL) */
+  uint32_t ulmod_count;
 };
 
 
@@ -137,6 +149,7 @@ void o_worker_free(o_worker_t* w)
   if (!w) return;
   o_rntiman_free(w->rm);
   free(w->grid); free(w->ce); free(w->llr); free(w->mcs); free(w->llr0); free(w->llr1); free(w->payload);
+  free(w->ul_grid); free(w->ul_sched); free(w->rar_sched); free(w->ulmod);
   free(w);
 }
 void o_worker_set_pcap(o_worker_t* w, o_pcap_t* p) { w->pcap = p; }
@@ -229,7 +242,9 @@ static void add_candidate(o_worker_t* w, const cand_t* c, uint32_t L, uint32_t n
     u->dci.L = L; u->dci.ncce = ncce;
     int ok = c->msg.payload[0] == 0 && o_dci_unpack_ul(cell, c->msg.payload, c->msg.nof_bits, c->rnti, &u->dci) == 0 &&
              o_ra_ul_dci_to_grant(cell, &u->dci, &u->g) == 0;
+    if (ok && o_ra_ul_dci_to_grant_256(cell, &u->dci, &u->g256)) { ok = 0; memset(&u->g256, 0, sizeof(u->g256)); } /* falcon_dci.c:222-231 */
     if (!ok) u->dci.rnti = 0;
+    u->ok = ok;
     if (ok) /* DCICollection.cc:275-280 */
       for (uint32_t i = 0; i < u->g.L_prb; i++) {
         if (w->rb_map_ul[u->g.n_prb + i] != 0) w->ul_collision = 1;
@@ -622,5 +637,208 @@ int o_worker_work(o_worker_t* w, const ocf_t* const* iq, uint32_t sf_idx, uint32
   } else {
     w->stats.nof_subframes++;
   }
+  return w->records;
+}
+
+
+/* ================================================================================================ UL mode */
+void o_worker_set_ul_mode(o_worker_t* w, const o_ul_cfg_t* ul)
+{
+  w->ul_mode = 1;
+  w->ulcfg = *ul;
+  if (!w->ul_grid) {
+    w->ul_grid = (ocf_t*)calloc(14u * 12u * w->cfg.cell.nof_prb, sizeof(ocf_t));
+    w->ul_sched = (ulslot_t*)calloc(16, sizeof(ulslot_t));
+    w->rar_sched = (ulslot_t*)calloc(16, sizeof(ulslot_t));
+    w->ulmod = (uint8_t*)calloc(65536, 1);
+  }
+}
+
+static void write_pcap_ul(o_worker_t* w, const uint8_t* pdu, uint32_t len, uint16_t rnti, uint32_t tti)
+{
+  if (!w->pcap) return;
+  w->records++;
+  o_pcap_write(w->pcap, pdu, len, tti, rnti, 0, O_PCAP_C_RNTI, 1, 0, 0); /* write_ul_crnti, PcapWriter.cc:172-175 */
+}
+
+/* unpack_rar_response_ul_mode, DL_Sniffer_PDSCH.cc:632-671: every sub-header activates its temporary C-RNTI; the UL grant
+ * that survives is the LAST one of the PDU (the result object is overwritten per sub-header) */
+static int unpack_rar_ul(o_worker_t* w, const uint8_t* p, int len, ulg_t* out)
+{
+  int nsub = 0, is_rapid[32], pos = 0, found = 0;
+  while (pos < len && nsub < 32) {
+    uint8_t b = p[pos++];
+    is_rapid[nsub++] = (b & 0x40) ? 1 : 0;
+    if (!(b & 0x80)) break;
+  }
+  for (int i = 0; i < nsub; i++) {
+    uint16_t t_crnti = 0;
+    uint32_t grant20 = 0;
+    if (is_rapid[i]) {
+      if (pos + 6 > len) break;
+      grant20 = ((uint32_t)(p[pos + 1] & 0x0F) << 16) | ((uint32_t)p[pos + 2] << 8) | p[pos + 3];
+      t_crnti = (uint16_t)((p[pos + 4] << 8) | p[pos + 5]);
+      pos += 6;
+    }
+    /* ul_sniffer_dci_rar_unpack / _rar_to_ul_dci, falcon_dci.c:648-683 */
+    o_dci_ul_t d;
+    memset(&d, 0, sizeof(d));
+    d.rnti = t_crnti;
+    d.freq_hop_fl = (grant20 >> 19) & 1u;
+    d.riv = (grant20 >> 9) & 0x3FFu;
+    d.mcs_idx = (grant20 >> 5) & 0xFu;
+    memset(out, 0, sizeof(*out));
+    out->rnti = t_crnti;
+    out->is_rar = 1;
+    out->hopping = d.freq_hop_fl;
+    if (o_ra_ul_dci_to_grant(&w->cfg.cell, &d, &out->g)) memset(&out->g, 0, sizeof(out->g)); /* ran_ul_grant_256 stays empty for RAR grants */
+    o_rntiman_activate_and_refresh(w->rm, t_crnti, 0, O_ACT_RAR);
+    found = 1;
+  }
+  return found;
+}
+
+/* PDSCH_Decoder::decode_ul_mode (DL_Sniffer_PDSCH.cc:362-457) with rnti == 0 (no target); RRC parsing is out of scope */
+static void decode_ul_mode_dl(o_worker_t* w, ulslot_t* rar_out)
+{
+  uint32_t tti = w->sfn * 10 + w->sf_idx;
+  for (uint32_t di = 0; di < w->ndl; di++) {
+    dl_entry_t* e = &w->dl[di];
+    int crc[2] = {0, 0};
+    if (e->rnti >= O_RARNTI_START && e->rnti <= O_RARNTI_END) { /* run_rar_decode, :673-740 */
+      o_pdsch_grant_t* cur = &e->g64;
+      if (o_config_mimo(&w->cfg.cell, e->format, &e->dci, cur) != 0) continue;
+      for (int i = 0; i < 2; i++)
+        if (cur->tb[i].enabled && cur->tb[i].rv < 0) cur->tb[i].rv = (int)((uint32_t)ceilf(1.5f * (float)((w->sfn / 2) % 4)) % 4u);
+      decode_grant(w, e, cur, crc);
+      for (int tb = 0; tb < 2; tb++)
+        if (crc[tb]) {
+          int len = cur->tb[tb].tbs / 8;
+          write_pcap(w, "RA_RNTI", w->payload + tb * 16384, (uint32_t)len, e->rnti, tti);
+          ulg_t g;
+          if (unpack_rar_ul(w, w->payload, len, &g) && rar_out->n < 96) rar_out->g[rar_out->n++] = g; /* pdsch_res->payload = TB 0 buffer */
+          break;
+        }
+    } else if (e->rnti > O_RARNTI_END) {
+      if ((e->format == O_FMT1 || e->format == O_FMT1A) && e->rnti != O_SIRNTI) { /* run_decode with the 64QAM table, :223-360 */
+        o_pdsch_grant_t* cur = &e->g64;
+        if (o_config_mimo(&w->cfg.cell, e->format, &e->dci, cur) != 0) continue;
+        decode_grant(w, e, cur, crc);
+        for (int tb = 0; tb < 2; tb++)
+          if (crc[tb]) write_pcap(w, rnti_name(e->rnti), w->payload + tb * 16384, (uint32_t)(cur->tb[tb].tbs / 8), e->rnti, tti);
+      }
+    }
+  }
+}
+
+/* one srsran_chest_ul_estimate_pusch + srsran_pusch_decode attempt (PUSCH_Decoder::decode_run, UL_Sniffer_PUSCH.cc:250-310) */
+static int pusch_attempt(o_worker_t* w, const ulg_t* m, const o_pusch_grant_t* g, int qm, uint32_t tti)
+{
+  if (m->hopping || g->tbs <= 0) return 0; /* frequency hopping is outside this restatement: the attempt fails */
+  o_pusch_grant_t gg = *g;
+  gg.mod = qm;
+  int its = 0;
+  float snr = 0;
+  int crc = o_pusch_decode(&w->cfg.cell, &w->ulcfg, tti % 10, m->rnti, &gg, m->n_dmrs, w->ul_grid, w->cfg.max_turbo_iter, w->payload, &its, &snr);
+  w->total_iters += (uint64_t)its;
+  if (crc) write_pcap_ul(w, w->payload, (uint32_t)(gg.tbs / 8), m->rnti, tti);
+  return crc;
+}
+
+static int ulmod_find(o_worker_t* w, uint16_t rnti) /* MCSTracking::find_tracking_info_RNTI_ul, MCSTracking.cc:32-57: 5 = FULL_BUFFER */
+{
+  if (!w->ulmod[rnti]) return w->ulmod_count < 250 ? 1 : 5;
+  return w->ulmod[rnti];
+}
+static void ulmod_update(o_worker_t* w, uint16_t rnti, int mod) /* update_RNTI_ul, :71-85 */
+{
+  if (w->ulmod[rnti]) w->ulmod[rnti] = (uint8_t)mod;
+  else { w->ulmod[rnti] = 1; w->ulmod_count++; }
+}
+
+/* PUSCH_Decoder::decode, UL_Sniffer_PUSCH.cc:389-583 (statistics / debug printing dropped) */
+static void decode_pusch(o_worker_t* w, uint32_t tti)
+{
+  uint32_t t4 = (tti + 10240 - 4) % 10240, t6 = (tti + 10240 - 6) % 10240;
+  ulslot_t* a = &w->ul_sched[t4 % 16];
+  ulslot_t* r = &w->rar_sched[t6 % 16];
+  int have_a = a->valid && a->tti == t4, have_r = r->valid && r->tti == t6;
+  ulg_t list[192];
+  int n = 0;
+  if (have_a) for (int i = 0; i < a->n; i++) list[n++] = a->g[i];
+  if (have_r) for (int i = 0; i < r->n; i++) list[n++] = r->g[i];
+  if (have_a) a->valid = 0;
+  if (have_r) r->valid = 0;
+  for (int i = 0; i < n; i++) {
+    ulg_t* m = &list[i];
+    int valid = 1; /* investigate_valid_ul_grant, :894-918 */
+    if (!m->is_rar) {
+      if (m->rnti == 0) valid = 0;
+      if (m->g.tbs == 0 || m->g256.tbs == 0) valid = 0;
+      if (!o_ul_valid_prb(m->g.L_prb) || m->g.L_prb > 100) valid = 0;
+    }
+    if (!valid || m->rnti == 0) continue;
+    uint32_t mcs = m->g.mcs_idx;
+    int mod = ulmod_find(w, m->rnti), mem_mod = 1 /* decoding_mem.mcs_mod, UNKNOWN unless set below */;
+    int ok256 = m->g256.L_prb < 110 && m->g256.L_prb > 0;
+    int qm_base = m->g.mod; /* modulation of Table 8.6.1-1 with 64QAM allowed */
+    int crc = 0;
+#define LEARN(newmod) do { if (crc && mcs > 20 && mem_mod == 1) ulmod_update(w, m->rnti, (newmod)); } while (0)
+    if (mcs > 20 && mcs < 29) {
+      if (mod == 2) { mem_mod = 2; crc = pusch_attempt(w, m, &m->g, 4, tti); LEARN(2); }
+      else if (mod == 3) { mem_mod = 3; crc = pusch_attempt(w, m, &m->g, qm_base, tti); LEARN(3); }
+      else if (mod == 4) { mem_mod = 4; if (ok256) { crc = pusch_attempt(w, m, &m->g256, m->g256.mod, tti); LEARN(4); } }
+      else if (mod == 1) {
+        crc = pusch_attempt(w, m, &m->g, 4, tti); LEARN(2);
+        if (!crc) {
+          crc = pusch_attempt(w, m, &m->g, qm_base, tti); LEARN(3);
+          if (!crc && ok256) { crc = pusch_attempt(w, m, &m->g256, m->g256.mod, tti); LEARN(4); }
+        }
+      }
+    } else if (mcs <= 20) {
+      if (mod == 2 || mod == 3) crc = pusch_attempt(w, m, &m->g, qm_base > 4 ? 4 : qm_base, tti);
+      else if (mod == 4) { if (ok256) crc = pusch_attempt(w, m, &m->g256, m->g256.mod, tti); }
+      else if (mod == 1) {
+        crc = pusch_attempt(w, m, &m->g, qm_base > 4 ? 4 : qm_base, tti);
+        if (!crc && ok256) crc = pusch_attempt(w, m, &m->g256, m->g256.mod, tti);
+      }
+    }
+#undef LEARN
+  }
+}
+
+int o_worker_work_ul(o_worker_t* w, const ocf_t* dl_iq, const ocf_t* ul_iq, uint32_t sf_idx, uint32_t sfn, int update_meta)
+{
+  const o_cell_t* cell = &w->cfg.cell;
+  if (!w->ul_mode || w->cfg.nof_rx != 1) return -1;
+  uint32_t tti = sfn * 10 + sf_idx;
+  w->sf_idx = sf_idx; w->sfn = sfn; w->records = 0;
+  w->ndl = w->nul = w->nacc = w->ntemp0 = 0;
+  w->dl_collision = w->ul_collision = 0;
+  memset(w->rb_map_dl, 0, sizeof(w->rb_map_dl));
+  memset(w->rb_map_ul, 0, sizeof(w->rb_map_ul));
+  if (update_meta) update_formats(w);
+  o_ofdm_rx(cell, dl_iq, 0, w->grid); /* DCISearch::prepareDCISearch: one rx antenna for the downlink, DCISearch.cc:592 */
+  o_chest(cell, 1, sf_idx, w->grid, w->ce, &w->chest);
+  w->cfi = o_pcfich_decode(cell, &w->regs, 1, sf_idx, w->grid, w->ce, w->chest.noise_avg, NULL);
+  o_pdcch_llr(cell, &w->regs, 1, sf_idx, w->cfi, w->grid, w->ce, w->chest.noise_avg, w->llr);
+  o_ul_fft(cell, ul_iq, w->ul_grid); /* srsran_enb_ul_fft, UL_Sniffer_PUSCH.cc:392 */
+  ulslot_t* cur = &w->ul_sched[tti % 16];
+  ulslot_t* rar = &w->rar_sched[tti % 16];
+  cur->tti = tti; cur->valid = 1; cur->n = 0;
+  rar->tti = tti; rar->valid = 1; rar->n = 0;
+  if (w->chest.snr_db > 6.0f) {
+    blind_search(w);
+    decode_ul_mode_dl(w, rar);
+    for (uint32_t i = 0; i < w->nul && cur->n < 96; i++) { /* ULSchedule::pushULSche(tti, dci_ul), SubframeWorker.cc:340 */
+      ulg_t* g = &cur->g[cur->n++];
+      memset(g, 0, sizeof(*g));
+      g->rnti = w->ul[i].rnti; g->g = w->ul[i].g; g->g256 = w->ul[i].g256;
+      g->n_dmrs = w->ul[i].dci.n_dmrs; g->hopping = w->ul[i].dci.freq_hop_fl;
+      if (!w->ul[i].ok) { memset(&g->g, 0, sizeof(g->g)); memset(&g->g256, 0, sizeof(g->g256)); }
+    }
+  }
+  w->stats.nof_subframes++;
+  decode_pusch(w, tti); /* SubframeWorker.cc:343-347 */
   return w->records;
 }

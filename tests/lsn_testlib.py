@@ -187,6 +187,7 @@ class TxGen:
             p = self._pdus[i]
             out.append(dict(rnti=p.rnti, format=p.format, L=p.L, ncce=p.ncce, tti=p.tti, tb=p.tb, mod=p.mod,
                             table256=p.table256, is_ul=p.is_ul, nof_prb=p.nof_prb, mcs=p.mcs,
+                            n_prb=p.offset if p.is_ul else 0,
                             payload=bytes(self._pbuf[p.offset:p.offset + p.nbytes]) if not p.is_ul else b""))
         return tti, iq, out
 
@@ -425,3 +426,46 @@ def oracle_ul_api():
                                  C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float)]
     o.o_ul_valid_prb.argtypes = [C.c_uint32]
     return o
+
+
+class OracleWorkerUl(OracleWorker):
+    """UL_MODE worker: one downlink antenna + the uplink antenna (SubframeWorker.cc:184-199)"""
+
+    def __init__(self, nof_prb, nof_ports, cell_id, cyclic_shift, delta_ss, **kw):
+        super().__init__(nof_prb, nof_ports, cell_id, 1, **kw)
+        self.lib.o_worker_set_ul_mode.argtypes = [C.c_void_p, C.POINTER(OUlCfg)]
+        self.lib.o_worker_work_ul.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]
+        self._ul = OUlCfg(cyclic_shift, delta_ss)
+        self.lib.o_worker_set_ul_mode(self.h, C.byref(self._ul))
+
+    def work_ul(self, dl_iq, ul_iq, tti, update_meta=0):
+        dl_iq = np.ascontiguousarray(dl_iq, dtype=np.complex64)
+        ul_iq = np.ascontiguousarray(ul_iq, dtype=np.complex64)
+        return self.lib.o_worker_work_ul(self.h, dl_iq.ctypes.data, ul_iq.ctypes.data, tti % 10, (tti // 10) % 1024, int(update_meta))
+
+
+def gen_ul_mode_subframes(sc, n, cyclic_shift=3, delta_ss=5, ul_snr_db=30.0):
+    """DL stream from the synthetic eNB (one rx antenna) + the matching UL stream: every DCI 0 of subframe t is answered by a
+    PUSCH in subframe t + 4 (UEs with an even RNTI are 64QAM-capable in the uplink).
+    -> (tti0, iq[n, 2, sf_len] (antenna 0 = DL, 1 = UL), list of sent UL payload dicts)"""
+    assert sc["nof_rx"] == 1
+    tx = TxGen(**sc)
+    ucell = TxgUlCell(sc["nof_prb"], sc["cell_id"], cyclic_shift, delta_ss)
+    iq = np.zeros((n, 2, tx.sf_len), dtype=np.complex64)
+    pending, sent, tti0 = {}, [], None
+    for i in range(n):
+        tti, x, pdus = tx.next()
+        if tti0 is None:
+            tti0 = tti
+        iq[i, 0] = x[0]
+        grants = pending.pop(tti, [])
+        ul, pl = ul_make_subframe(ucell, tti, grants, snr_db=ul_snr_db, seed=sc["seed"] * 1000 + i)
+        iq[i, 1] = ul
+        for g, p in zip(grants, pl):
+            sent.append(dict(tti=tti, rnti=g["rnti"], payload=p, L_prb=g["L_prb"], mod=g["mod"]))
+        for p in pdus:
+            if p["is_ul"] and p["nof_prb"] >= 3:
+                qm, tbs = ul_mcs_to_mod_tbs(p["mcs"], p["nof_prb"], enable_64qam=(p["rnti"] % 2 == 0))
+                if tbs > 0:
+                    pending.setdefault((tti + 4) % 10240, []).append(dict(rnti=p["rnti"], n_dmrs=0, n_prb=p["n_prb"], L_prb=p["nof_prb"], mod=qm, tbs=tbs, rv=0))
+    return tti0, iq, sent

@@ -575,7 +575,7 @@ extern "C" int txg_next(txg_t* g, float* iq, txg_pdu_t* pdus, int max_pdus, uint
     gr.mcs[0] = g->rng.below(25); gr.ndi[0] = g->rng.below(2);
     if (!place(gr, false)) continue;
     grants.push_back(gr);
-    if (npdu < max_pdus) { txg_pdu_t& pd = pdus[npdu++]; pd = txg_pdu_t{gr.rnti, 0, (uint8_t)gr.L, (uint16_t)gr.ncce, tti, 0, 0, 0, 0, 0, 1, (uint32_t)Lc, gr.mcs[0]}; }
+    if (npdu < max_pdus) { txg_pdu_t& pd = pdus[npdu++]; pd = txg_pdu_t{gr.rnti, 0, (uint8_t)gr.L, (uint16_t)gr.ncce, tti, 0, (uint32_t)start /* UL grants: offset = first PRB */, 0, 0, 0, 1, (uint32_t)Lc, gr.mcs[0]}; }
   }
 
   // ---- PDCCH ----
