@@ -59,6 +59,8 @@ typedef struct {
   int harq_mode;                    /* ArgManager.cc:50: always 0 in the reference; only 0 supported */
   int device;                       /* HIP device ordinal */
   int max_turbo_iterations;         /* SubframeWorker.cc:365, default 12 (0 = default) */
+  int sniffer_mode;                 /* 0 = DL_MODE, 1 = UL_MODE (SubframeWorker.cc:166-199): antenna 0 = downlink, antenna 1 = uplink,
+                                       nof_rx_antennas must be 2; call lsn_phy_set_ul_config after lsn_phy_set_cell */
 } lsn_phy_cfg_t;
 
 /* What LTESniffer_pcap_writer::pack_and_write receives (PcapWriter.cc:93-111) */

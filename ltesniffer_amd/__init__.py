@@ -45,7 +45,7 @@ class PhyCfg(C.Structure):
     _fields_ = [("nof_rx_antennas", C.c_uint32), ("nof_workers", C.c_uint32), ("max_batch", C.c_uint32),
                 ("skip_secondary_meta_formats", C.c_int), ("meta_format_split_ratio", C.c_double),
                 ("histogram_threshold", C.c_uint32), ("mcs_tracking_mode", C.c_int), ("harq_mode", C.c_int),
-                ("device", C.c_int), ("max_turbo_iterations", C.c_int)]
+                ("device", C.c_int), ("max_turbo_iterations", C.c_int), ("sniffer_mode", C.c_int)]
 
 
 class PduCtx(C.Structure):
@@ -253,10 +253,10 @@ class Phy:
 
     def __init__(self, nof_rx_antennas=2, nof_workers=20, skipSecondaryMetaFormats=False, metaFormatSplitRatio=0.99,
                  histogramThreshold=5, sink=None, mcs_tracking_mode=1, harq_mode=0, device=0, max_batch=64,
-                 max_turbo_iterations=12, default_rnti_intervals=True, pcapwriter=None):
+                 max_turbo_iterations=12, default_rnti_intervals=True, pcapwriter=None, sniffer_mode=0):
         self.nof_rx_antennas = nof_rx_antennas
         self._cfg = PhyCfg(nof_rx_antennas, nof_workers, max_batch, int(skipSecondaryMetaFormats), metaFormatSplitRatio,
-                           histogramThreshold, mcs_tracking_mode, harq_mode, device, max_turbo_iterations)
+                           histogramThreshold, mcs_tracking_mode, harq_mode, device, max_turbo_iterations, sniffer_mode)
         self._h = C.c_void_p()
         _check(lib().lsn_phy_create(C.byref(self._cfg), C.byref(self._h)), "lsn_phy_create")
         self.pdus = []

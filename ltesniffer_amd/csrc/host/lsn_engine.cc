@@ -80,6 +80,8 @@ void Engine::unpinThisThread(const void* saved) { (void)sched_setaffinity(0, siz
 Engine::Engine(const lsn_phy_cfg_t& c) : cfg(c)
 {
   if (cfg.nof_rx_antennas < 1 || cfg.nof_rx_antennas > LSN_MAX_RX) throw std::invalid_argument("nof_rx_antennas");
+  if (cfg.sniffer_mode != 0 && cfg.sniffer_mode != 1) throw std::invalid_argument("sniffer_mode");
+  if (cfg.sniffer_mode == 1 && cfg.nof_rx_antennas != 2) throw std::invalid_argument("UL_MODE needs two antenna buffers");
   if (cfg.harq_mode != 0) throw std::invalid_argument("harq_mode");  // ArgManager.cc:50: always 0 in the reference
   max_batch = cfg.max_batch ? cfg.max_batch : 64;
   if (cfg.max_turbo_iterations <= 0) cfg.max_turbo_iterations = 12;  // SubframeWorker.cc:365
@@ -183,6 +185,7 @@ void Engine::launchStageA(Chunk& ch, const void* d_iq)
   timed([&] { lsn_launch_cce_power(cd, ch.d_llr, ch.d_cfi, ch.d_ccepow, nsf, st); });
   timed([&] { lsn_launch_viterbi(cd, ch.d_llr, ch.d_ccepow, ch.d_cfi, ch.d_cand, nsf, st); });
   timed([&] { lsn_launch_rb_power(cd, ch.d_grid, ch.d_rbp, nsf, st); });
+  if (cfg.sniffer_mode == 1) lsn_launch_ul_fft(cd, iq, cd.iq_nant, 1, ch.d_ul_grid, nsf, st);  // srsran_enb_ul_fft on antenna 1, UL_Sniffer_PUSCH.cc:391-392
   HIP_CHECK(hipMemcpyAsync(ch.h_cand, ch.d_cand, (size_t)nsf * LSN_MAX_LOC * LSN_MAX_SIZES * sizeof(LsnCand), hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipMemcpyAsync(ch.h_ccepow, ch.d_ccepow, (size_t)nsf * LSN_CCE_STRIDE * sizeof(float), hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipMemcpyAsync(ch.h_chest, ch.d_chest, (size_t)nsf * sizeof(LsnChest), hipMemcpyDeviceToHost, st));
@@ -199,7 +202,7 @@ void Engine::finishStageA(Chunk& ch)
     if (hipEventElapsedTime(&ms, ch.ev_a[2 * n], ch.ev_a[2 * n + 1]) == hipSuccess) perf_front.kernel_ms[kStageA[n]] += ms;
     perf_front.kernel_launches[kStageA[n]]++;
   }
-  const uint64_t A = cfg.nof_rx_antennas, P = cell.nof_ports;
+  const uint64_t A = dlRx(), P = cell.nof_ports;
   for (uint32_t i = 0; i < ch.nsf; i++) {
     SubframeCtx& c = ch.ctx[i];
     c.cfi = ch.h_cfi[i];
@@ -231,14 +234,14 @@ void Engine::speculateRar(Chunk& ch)
         if (L * (i % (ncce / L)) >= 16) continue;  // common search space: first 16 CCEs
         for (DciFormat f : fmts) {
           const LsnCand& q = ch.h_cand[((size_t)sf * LSN_MAX_LOC + li) * LSN_MAX_SIZES + search->sizeIndexOfFormat(f)];
-          if (!q.flags || !(q.rnti > RARNTI_START && q.rnti < RARNTI_END)) continue;
+          if (!q.flags || !isRarFeedbackRnti((uint16_t)q.rnti)) continue;
           if (f == FORMAT1A && (q.bits >> 63) == 0) continue;  // that payload is a format 0
           bool dup = false;
           for (auto& s : ch.spec_rar) dup = dup || (s.sf == sf && s.rnti == q.rnti && s.format == f && s.bits == q.bits);
           if (dup) continue;
           DlEntry e;
           if (!search->buildDlEntry(c, (uint16_t)q.rnti, f, q.bits, e) || !e.ok64) continue;
-          if (!(e.grant64.tb[0].tbs > 0) || (cfg.nof_rx_antennas == 1 && e.grant64.nof_tb == 2)) continue;
+          if (cfg.sniffer_mode == 0 && (!(e.grant64.tb[0].tbs > 0) || (dlRx() == 1 && e.grant64.nof_tb == 2))) continue;
           const int j = newJob(ch, sf, e, 0);
           if (j < 0) continue;
           ch.spec_rar.push_back({sf, (uint16_t)q.rnti, f, q.bits, j});
@@ -277,10 +280,11 @@ void Engine::searchChunk(Chunk& ch, uint32_t update_meta_period)
     if (!c.searched) continue;
     // RAR grants feed the RNTI manager before the next subframe is searched (DL_Sniffer_PDSCH.cc:782-797): decode them now
     for (auto& e : c.dl) {
-      if (rnti_name(e.rnti)[0] != 'R') continue;
+      if (!isRarFeedbackRnti(e.rnti)) continue;
       const bool dci_ok = e.unpack_ok && e.ok64;
       const bool two_tb = e.grant64.nof_tb == 2;
-      if (!(e.grant64.tb[0].tbs > 0 && dci_ok && !(cfg.nof_rx_antennas == 1 && two_tb))) continue;
+      if (cfg.sniffer_mode == 0 && !(e.grant64.tb[0].tbs > 0 && dci_ok && !(dlRx() == 1 && two_tb))) continue;
+      if (cfg.sniffer_mode == 1 && !e.unpack_ok) continue;
       int j = -1;
       for (auto& s : ch.spec_rar)  // decoded ahead by the front thread?
         if (s.sf == sf && s.rnti == e.rnti && s.format == e.format && s.bits == e.bits && ch.jobs[s.job].done) { j = s.job; break; }
@@ -295,7 +299,11 @@ void Engine::searchChunk(Chunk& ch, uint32_t update_meta_period)
       e.job[0] = j;
       for (int tb = 0; tb < 2; tb++) {
         const int len = ch.jobs[j].grant.tb[tb].tbs / 8;
-        if (ch.jobs[j].crc[tb] && len > 0) unpackRar(ch.h_payload.data() + ch.jobs[j].payload_off[tb], len, true);
+        if (cfg.sniffer_mode == 1) {  // run_rar_decode parses pdsch_res->payload (TB 0) at the first CRC-ok TB and returns
+          if (ch.jobs[j].crc[tb]) { unpackRar(ch.h_payload.data() + ch.jobs[j].payload_off[0], len, true); break; }
+        } else if (ch.jobs[j].crc[tb] && len > 0) {
+          unpackRar(ch.h_payload.data() + ch.jobs[j].payload_off[tb], len, true);
+        }
       }
     }
   }
@@ -331,7 +339,11 @@ int Engine::newJob(Chunk& ch, uint32_t sf, const DlEntry& e, int table)
   j.sf = sf; j.rnti = e.rnti;
   j.grant = table ? e.grant256 : e.grant64;
   if (dl_sniffer_config_mimo(cell, e.format, e.dci, j.grant) != 0) return -1;
-  if (e.dci.tb[0].rv < 0 && e.rnti == SIRNTI) j.grant.tb[0].rv = 0;  // DL_Sniffer_PDSCH.cc:891-897
+  if (cfg.sniffer_mode == 1) {  // run_decode / run_rar_decode, DL_Sniffer_PDSCH.cc:240-247,694-701
+    const uint32_t sfn = ch.ctx[sf].sfn;
+    for (auto& tb : j.grant.tb)
+      if (tb.enabled && tb.rv < 0) tb.rv = (int)((uint32_t)ceilf(1.5f * (float)((sfn / 2) % 4)) % 4u);
+  } else if (e.dci.tb[0].rv < 0 && e.rnti == SIRNTI) j.grant.tb[0].rv = 0;  // DL_Sniffer_PDSCH.cc:891-897
   ch.jobs.push_back(j);
   return (int)ch.jobs.size() - 1;
 }
@@ -386,7 +398,7 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
     bool demod_ok = (g.tb[0].enabled || g.tb[1].enabled) && g.nof_re > 0;
     if (g.tx_scheme == TXSCHEME_SPATIALMUX || g.tx_scheme == TXSCHEME_CDD) {
       if (cell.nof_ports < 2) demod_ok = false;
-      if (g.nof_layers != 1 && cfg.nof_rx_antennas < 2) demod_ok = false;
+      if (g.nof_layers != 1 && dlRx() < 2) demod_ok = false;
     }
     if (g.tx_scheme == TXSCHEME_DIVERSITY && cell.nof_ports < 2) demod_ok = false;
     if (!demod_ok) continue;
@@ -545,6 +557,12 @@ void Engine::planJobs(Chunk& ch, JobRunner& r)
     for (size_t di = 0; di < c.dl.size(); di++) {
       DlEntry& e = c.dl[di];
       if (!e.unpack_ok) continue;
+      if (cfg.sniffer_mode == 1) {  // decode_ul_mode: RAR + format 1 / 1A (not SI) with the 64QAM table only
+        if (!ulModeDecodesDl(e)) continue;
+        if (e.job[0] < 0) e.job[0] = newJob(ch, sf, e, 0);
+        if (e.job[0] >= 0) wave.push_back(e.job[0]);
+        continue;
+      }
       McsTable table;
       if (cfg.mcs_tracking_mode == 1)
         table = (e.rnti == SIRNTI || e.rnti == PRNTI || rnti_israr(e.rnti) || e.format == FORMAT1A) ? TABLE_64QAM : mcs_tracking.peek(e.rnti);
@@ -554,7 +572,7 @@ void Engine::planJobs(Chunk& ch, JobRunner& r)
       const PdschGrant& g = first ? e.grant256 : e.grant64;
       const bool ok = first ? e.ok256 : e.ok64;
       if (!ok || !(g.tb[0].tbs > 0)) continue;
-      if (cfg.nof_rx_antennas == 1 && (e.grant64.nof_tb == 2 || e.grant256.nof_tb == 2)) continue;
+      if (dlRx() == 1 && (e.grant64.nof_tb == 2 || e.grant256.nof_tb == 2)) continue;
       if (e.job[first] < 0) e.job[first] = newJob(ch, sf, e, first);
       if (e.job[first] >= 0) wave.push_back(e.job[first]);
       if (table >= TABLE_UNKNOWN && e.ok256) retry.push_back({sf, di});
@@ -616,7 +634,7 @@ void Engine::commitChunk(Chunk& ch, JobRunner& r)
       static const PdschGrant empty_grant;
       const PdschGrant& cur = cur_t ? (has256 ? e.grant256 : empty_grant) : (has64 ? e.grant64 : empty_grant);
       const bool two_tb = (has64 && e.grant64.nof_tb == 2) || (has256 && e.grant256.nof_tb == 2);
-      const bool gate = (cur.tb[0].tbs > 0 && dci_rnti_ok && !(cfg.nof_rx_antennas == 1 && two_tb)) || e.rnti == PRNTI;  // :887-889
+      const bool gate = (cur.tb[0].tbs > 0 && dci_rnti_ok && !(dlRx() == 1 && two_tb)) || e.rnti == PRNTI;  // :887-889
       if (!gate) continue;
       const char* name = rnti_name(e.rnti);
       auto run = [&](int t) -> int {
@@ -697,7 +715,7 @@ void Engine::decodeLoop(int idx)
     }
     try {
       const double t1 = now_ms();
-      if (err.empty()) commitChunk(*ch, r);
+      if (err.empty()) { if (cfg.sniffer_mode == 1) commitChunkUl(*ch, r); else commitChunk(*ch, r); }
       r.perf.ms_commit += now_ms() - t1;
     } catch (const std::exception& ex) {
       err = ex.what();
@@ -874,7 +892,7 @@ long Engine::tap(int what, uint32_t sf, void* out, size_t cap)
 {
   if (!cell_set || !last_chunk || sf >= last_chunk->nsf) return LSN_ERROR_INVALID_INPUTS;
   Chunk& ch = *last_chunk;
-  const size_t A = cfg.nof_rx_antennas, P = cell.nof_ports, nre = cd.nre;
+  const size_t A = dlRx(), P = cell.nof_ports, nre = cd.nre;
   auto d2h = [&](const void* src, size_t n) -> long {
     if (n > cap) return LSN_ERROR_INVALID_INPUTS;
     if (hipMemcpy(out, src, n, hipMemcpyDeviceToHost) != hipSuccess) return LSN_ERROR;

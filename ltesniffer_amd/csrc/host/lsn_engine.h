@@ -13,6 +13,7 @@
 #include "lsn_search.h"
 #include <condition_variable>
 #include <deque>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -32,7 +33,7 @@ struct DecodeJob {
 // everything one chunk of subframes owns while it travels through the pipeline
 struct Chunk {
   uint32_t nsf = 0, start_tti = 0;
-  cf32 *d_grid = nullptr, *d_ce = nullptr;
+  cf32 *d_grid = nullptr, *d_ce = nullptr, *d_ul_grid = nullptr;
   float *d_chest_raw = nullptr, *d_llr = nullptr, *d_ccepow = nullptr, *d_pcfich_corr = nullptr, *d_rbp = nullptr;
   LsnChest* d_chest = nullptr;
   uint32_t *d_cfi = nullptr, *d_sfidx = nullptr;
@@ -83,6 +84,7 @@ public:
   RNTIManager& rntiManager() { return search->rntiManager(); }
   uint32_t sfLen() const { return cd.sflen; }
   uint32_t nofRx() const { return cfg.nof_rx_antennas; }
+  uint32_t dlRx() const { return cfg.sniffer_mode == 1 ? 1u : cfg.nof_rx_antennas; }  // DCISearch::prepareDCISearch, DCISearch.cc:592
   uint32_t maxBatch() const { return max_batch; }
   void setupDefaultIntervals() { search->setupDefaultIntervals(); }
   int setUlConfig(const lsn_ul_cfg_t& u);
@@ -108,6 +110,16 @@ private:
   void runJobs(Chunk& ch, JobRunner& r, std::vector<int>& job_ids);
   void ensureJob(Chunk& ch, JobRunner& r, int j);
   void commitChunk(Chunk& ch, JobRunner& r);
+  void commitChunkUl(Chunk& ch, JobRunner& r);
+  void puschDecodeGrid(const cf32* d_grid, uint32_t nsf, uint32_t start_tti, const lsn_pusch_grant_t* grants, uint32_t ngrants,
+                       lsn_pusch_result_t* results, std::vector<uint8_t>& payload_out);
+  // RA-RNTI grants whose content feeds the RNTI manager: DL mode 2..9 (rnti_name == RA_RNTI, DL_Sniffer_PDSCH.cc:1409), UL mode 1..10 (:373)
+  bool isRarFeedbackRnti(uint16_t r) const { return cfg.sniffer_mode == 1 ? (r >= RARNTI_START && r <= RARNTI_END) : (r > RARNTI_START && r < RARNTI_END); }
+  bool ulModeDecodesDl(const DlEntry& e) const
+  {
+    if (e.rnti >= RARNTI_START && e.rnti <= RARNTI_END) return true;
+    return e.rnti > RARNTI_END && (e.format == FORMAT1 || e.format == FORMAT1A) && e.rnti != SIRNTI;
+  }
   int newJob(Chunk& ch, uint32_t sf, const DlEntry& e, int table);
   void unpackRar(const uint8_t* p, int len, bool at_search);
   void emitPdu(JobRunner& r, const char* name, const uint8_t* pdu, uint32_t len, uint16_t rnti, uint32_t tti, uint8_t tb);
@@ -160,6 +172,9 @@ private:
   bool ul_set = false;
   std::vector<int> ul_off;       // allocation size L -> offset into ul_base / ul_idft (-1: unsupported)
   uint32_t ul_npn[20] = {0};
+  struct UlSchedGrant { uint16_t rnti = 0; PuschGrant g, g256; uint32_t n_dmrs = 0; bool hopping = false, is_rar = false; };
+  std::map<uint32_t, std::vector<UlSchedGrant>> ul_sched, rar_sched;  // ULSchedule databases (touched in the commit turn only)
+  std::vector<uint8_t> ulmod; uint32_t ulmod_count = 0;               // MCSTracking UL: 0 absent, 1 unknown, 2/3/4 = 16/64/256QAM max
   std::vector<LsnUlGrantDev> ul_last_gd; std::vector<int> ul_last_idx;  // descriptors of the last puschDecode call (taps)
   JobRunner runner_u;
   cf32 *ul_d_iq = nullptr, *ul_d_grid = nullptr, *ul_d_hs = nullptr; float* ul_d_stat = nullptr; LsnUlGrantDev* ul_d_grants = nullptr;

@@ -372,6 +372,37 @@ bool ra_ul_dci_to_grant(const Cell& cell, const DciUl& d, PuschGrant& g)
   return true;
 }
 
+// ul_fill_ra_mcs_256 (ul_sniffer_pusch.c:91-136): Table 8.6.1-3 of 36.213 incl. the 32A row
+bool ra_ul_dci_to_grant_256(const Cell& cell, const DciUl& d, PuschGrant& g)
+{
+  if (!ra_ul_dci_to_grant(cell, d, g)) return false;
+  const uint32_t m = d.mcs_idx, L = g.L_prb;
+  if (m <= 28) {
+    g.rv = 0;
+    if (m < 6) { g.mod = 2; g.tbs = ra_tbs_from_idx((int)m * 2, L); }
+    else if (m < 14) { g.mod = 4; g.tbs = ra_tbs_from_idx((int)m + (m < 10 ? 5 : 6), L); }
+    else if (m < 23) { g.mod = 6; g.tbs = ra_tbs_from_idx((int)m + (m < 19 ? 6 : 7), L); }
+    else {
+      g.mod = 8;
+      if (m < 26) g.tbs = ra_tbs_from_idx((int)m + 7, L);
+      else if (m == 26) g.tbs = (L > 0 && L < 111) ? lsn_tbs_table_32A[L - 1] : 0;
+      else g.tbs = ra_tbs_from_idx((int)m + 6, L);
+    }
+  } else {
+    g.mod = 0; g.tbs = 0; g.rv = (int)m - 28;  // last_tb is empty without HARQ state
+  }
+  return true;
+}
+
+bool ul_valid_prb(uint32_t L)
+{
+  if (L == 0 || L > 110) return false;
+  while (L % 2 == 0) L /= 2;
+  while (L % 3 == 0) L /= 3;
+  while (L % 5 == 0) L /= 5;
+  return L == 1;
+}
+
 // dl_sniffer_config_mimo, dl_sniffer_pdsch.c:134-276
 int dl_sniffer_config_mimo(const Cell& cell, DciFormat f, const DciDl& dci, PdschGrant& g)
 {

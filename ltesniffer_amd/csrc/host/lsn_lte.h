@@ -59,6 +59,8 @@ bool dl_sniffer_ra_dl_dci_to_grant(const Cell& cell, uint32_t sf_idx, uint32_t c
 void dl_sniffer_ra_dl_dci_to_grant_both(const Cell& cell, uint32_t sf_idx, uint32_t cfi, const DciDl& dci, PdschGrant& g64, bool& ok64,
                                         PdschGrant& g256, bool& ok256);
 bool ra_ul_dci_to_grant(const Cell& cell, const DciUl& dci, PuschGrant& g);
+bool ra_ul_dci_to_grant_256(const Cell& cell, const DciUl& dci, PuschGrant& g);  // ulsniffer_ra_ul_dci_to_grant_256, ul_sniffer_pusch.c:138-172
+bool ul_valid_prb(uint32_t L);                                                    // valid_prb_ul, UL_Sniffer_PUSCH.cc:3-10
 int dl_sniffer_config_mimo(const Cell& cell, DciFormat f, const DciDl& dci, PdschGrant& g);  // 0 ok
 bool pdsch_re_usable(const Cell& cell, uint32_t sf_idx, uint32_t l, uint32_t k);
 int ra_tbs_from_idx(int i_tbs, uint32_t n_prb);

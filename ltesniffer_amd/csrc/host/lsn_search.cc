@@ -131,7 +131,8 @@ void FalconSearch::addCandidate(SubframeCtx& c, const DciCandidate& cand, uint32
     u.rnti = cand.rnti; u.nof_bits = cand.msg.nof_bits; u.L = L; u.ncce = ncce; u.histval = histval;
     u.dci.L = L; u.dci.ncce = ncce;
     u.ok = payload[0] == 0 && dci_msg_unpack_pusch(cell, payload, cand.msg.nof_bits, cand.rnti, u.dci) && ra_ul_dci_to_grant(cell, u.dci, u.grant);
-    if (u.ok)
+    if (u.ok && !ra_ul_dci_to_grant_256(cell, u.dci, u.grant256)) { u.ok = false; u.grant256 = PuschGrant(); }  // falcon_dci.c:222-231
+    if (u.ok)  // convert_ul_grant runs only after both conversions succeeded (falcon_dci.c:222-232)
       for (uint32_t i = 0; i < u.grant.L_prb; i++) {  // DCICollection.cc:275-280
         if (rb_map_ul[u.grant.n_prb + i] != 0) ul_collision = true;
         rb_map_ul[u.grant.n_prb + i] = cand.rnti;

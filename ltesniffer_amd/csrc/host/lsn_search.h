@@ -28,7 +28,7 @@ struct DlEntry {  // DL_Sniffer_DCI_DL (Sniffer_dependency.h:90)
   PdschGrant grant64, grant256; bool ok64 = false, ok256 = false;  // both tables computed; selection happens at commit
   int job[2] = {-1, -1};                                          // decode job index per table
 };
-struct UlEntry { uint16_t rnti = 0; uint32_t nof_bits = 0, L = 0, ncce = 0, histval = 0; DciUl dci; PuschGrant grant; bool ok = false; };
+struct UlEntry { uint16_t rnti = 0; uint32_t nof_bits = 0, L = 0, ncce = 0, histval = 0; DciUl dci; PuschGrant grant, grant256; bool ok = false; };
 
 struct SubframeCtx {
   uint32_t tti = 0, sf_idx = 0, sfn = 0, cfi = 0;

@@ -121,7 +121,8 @@ static T* halloc(std::vector<void*>& allocs, size_t n)
 
 void Engine::allocChunk(Chunk& ch)
 {
-  const size_t B = max_batch, A = cfg.nof_rx_antennas, P = cell.nof_ports;
+  const size_t B = max_batch, A = dlRx(), P = cell.nof_ports;
+  if (cfg.sniffer_mode == 1) ch.d_ul_grid = dalloc<cf32>(dev_allocs, B * 14 * cd.nre);
   ch.d_grid = dalloc<cf32>(dev_allocs, B * A * 14 * cd.nre);
   ch.d_ce = dalloc<cf32>(dev_allocs, B * P * A * 14 * cd.nre);
   ch.d_chest_raw = dalloc<float>(dev_allocs, B * A * P * 8);
@@ -148,7 +149,7 @@ void Engine::buildTables()
   const uint32_t nprb = cell.nof_prb, P = cell.nof_ports, id = cell.id;
   const int N = fft_size_for(nprb);
   cd = LsnCellDev{};
-  cd.nof_prb = nprb; cd.nof_ports = P; cd.id = id; cd.nof_rx = cfg.nof_rx_antennas;
+  cd.nof_prb = nprb; cd.nof_ports = P; cd.id = id; cd.nof_rx = dlRx(); cd.iq_nant = cfg.nof_rx_antennas;
   cd.N = (uint32_t)N; cd.lgN = 0; while ((1 << cd.lgN) < N) cd.lgN++;
   cd.nre = 12 * nprb; cd.nref = 2 * nprb; cd.sflen = 15u * (uint32_t)N;
   // FFT twiddles and NCO tables (double -> float, same generation as the oracle's definition)

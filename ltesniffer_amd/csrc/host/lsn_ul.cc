@@ -18,14 +18,6 @@
 
 namespace lsn {
 
-static bool ul_valid_prb(uint32_t L)  // UL_Sniffer_PUSCH.cc:3-10: 2^a 3^b 5^c
-{
-  if (L == 0 || L > 110) return false;
-  while (L % 2 == 0) L /= 2;
-  while (L % 3 == 0) L /= 3;
-  while (L % 5 == 0) L /= 5;
-  return L == 1;
-}
 static int largest_prime_below(int n)
 {
   for (int p = n - 1; p >= 2; p--) {
@@ -108,140 +100,145 @@ int Engine::puschDecode(const void* ul_iq, bool on_device, uint32_t nsf, uint32_
 {
   if (!cell_set || !ul_set) return LSN_ERROR;
   if ((!ul_iq && nsf) || (!grants && ngrants) || (!results && ngrants)) return LSN_ERROR_INVALID_INPUTS;
-  static const uint32_t n_dmrs1[8] = {0, 2, 3, 4, 6, 8, 9, 10};  // 36.211 Table 5.5.2.1.1-2
-  static const uint32_t n_dmrs2[8] = {0, 6, 3, 4, 2, 8, 10, 9};  // Table 5.5.2.1.1-1
   try {
     HIP_CHECK(hipSetDevice(cfg.device));
-    JobRunner& r = runner_u;
-    hipStream_t st = r.stream;
-    const size_t sfbytes = (size_t)cd.sflen * sizeof(cf32);
+    hipStream_t st = runner_u.stream;
     const cf32* d_iq = (const cf32*)ul_iq;
     if (!on_device) {
       grow_d(ul_d_iq, ul_iq_cap, (size_t)nsf * cd.sflen);
-      HIP_CHECK(hipMemcpyAsync(ul_d_iq, ul_iq, (size_t)nsf * sfbytes, hipMemcpyHostToDevice, st));
+      HIP_CHECK(hipMemcpyAsync(ul_d_iq, ul_iq, (size_t)nsf * cd.sflen * sizeof(cf32), hipMemcpyHostToDevice, st));
       d_iq = ul_d_iq;
     }
     grow_d(ul_d_grid, ul_grid_cap, (size_t)nsf * 14 * cd.nre);
-    lsn_launch_ul_fft(cd, d_iq, ul_d_grid, nsf, st);
-    // grants -> device descriptors + code blocks
-    std::vector<LsnUlGrantDev> gd;
-    std::vector<int> gidx;
-    r.h_cbs.clear();
-    struct TbRef { uint32_t grant, cb_first, cb_count, pay_off; int tbs; };
-    std::vector<TbRef> tbs;
-    size_t hs_n = 0, llr_n = 0, pay_n = 0;
-    for (uint32_t i = 0; i < ngrants; i++) {
-      const lsn_pusch_grant_t& g = grants[i];
-      results[i] = lsn_pusch_result_t{};
-      const bool ok = g.sf < nsf && g.L_prb >= 3 && ul_valid_prb(g.L_prb) && g.n_prb + g.L_prb <= cell.nof_prb && g.tbs > 0 && (g.tbs % 8) == 0 &&
-                      (g.mod == 2 || g.mod == 4 || g.mod == 6 || g.mod == 8) && ul_off[g.L_prb] >= 0 && g.rv >= 0 && g.rv < 4;
-      if (!ok) continue;
-      const uint32_t M = 12 * g.L_prb, sf_idx = (start_tti + g.sf) % 10;
-      CbSegm s;
-      const int G = (int)(12 * M * g.mod);
-      if (!cbsegm((int)g.tbs, s)) continue;
-      LsnUlGrantDev d{};
-      d.sf = g.sf; d.n_prb = g.n_prb; d.L_prb = g.L_prb; d.qm = g.mod;
-      for (uint32_t sl = 0; sl < 2; sl++) d.ncs[sl] = (n_dmrs1[ul_cfg.cyclic_shift & 7] + n_dmrs2[g.n_dmrs & 7] + ul_npn[2 * sf_idx + sl]) % 12u;
-      d.cinit = ((uint32_t)g.rnti << 14) | (sf_idx << 9) | cell.id;
-      d.base_off = (uint32_t)ul_off[g.L_prb]; d.idft_off = d.base_off;
-      d.hs_off = (uint32_t)hs_n; hs_n += 2 * M;
-      d.llr_off = (uint32_t)llr_n; llr_n += ((size_t)G + 7) & ~(size_t)7;
-      d.scale = 1.0f / sqrtf((float)M);
-      // UL-SCH: one transport block, one layer (36.212 5.2.2.6)
-      const int Qm = (int)g.mod, Gp = G / Qm, gamma = Gp % s.C;
-      TbRef ref{i, (uint32_t)r.h_cbs.size(), (uint32_t)s.C, (uint32_t)pay_n, (int)g.tbs};
-      int rp = 0;
-      uint32_t wp = 0;
-      for (int q = 0; q < s.C; q++) {
-        LsnCbDev cb{};
-        const int K = q < s.Cm ? s.Km : s.Kp, F = q == 0 ? s.F : 0;
-        int E = (q <= s.C - gamma - 1) ? Qm * (Gp / s.C) : Qm * ((Gp + s.C - 1) / s.C);
-        if (rp + E > G) E = G - rp;
-        cb.e_off = d.llr_off + (uint32_t)rp; cb.E = (uint32_t)E; cb.K = (uint32_t)K; cb.F = (uint32_t)F; cb.rv = (uint32_t)g.rv;
-        cb.crc_b = s.C > 1 ? 1u : 0u;
-        cb.out_bytes = (uint32_t)(K - F - (s.C > 1 ? 24 : 0)) / 8;
-        cb.out_off = (uint32_t)pay_n + wp;
-        qpp_params(K, cb.f1, cb.f2);
-        cb.max_iter = (uint32_t)cfg.max_turbo_iterations;
-        wp += cb.out_bytes;
-        rp += E;
-        r.h_cbs.push_back(cb);
-      }
-      pay_n += (wp + 15) & ~15u;
-      tbs.push_back(ref);
-      gd.push_back(d);
-      gidx.push_back((int)i);
-    }
-    ul_last_gd = gd; ul_last_idx = gidx;
-    const uint32_t ng = (uint32_t)gd.size(), ncb = (uint32_t)r.h_cbs.size();
-    if (ng) {
-      grow_d(ul_d_grants, ul_grants_cap, ng);
-      grow_d(ul_d_hs, ul_hs_cap, hs_n);
-      grow_d(ul_d_stat, ul_stat_cap, (size_t)2 * ng);
-      grow_d(r.d_llr16, r.llr16_cap, llr_n + 8);
-      grow_d(r.d_cbs, r.cbs_cap, ncb);
-      grow_d(r.d_cbres, r.cbres_cap, ncb);
-      grow_d(r.d_payload, r.payload_cap, pay_n + 16);
-      std::vector<uint32_t> order(ncb);
-      uint32_t n128 = 0, kmax128 = 0, kmax64 = 0;
-      for (uint32_t i = 0; i < ncb; i++) { r.h_cbs[i].res_idx = i; order[i] = i; }
-      std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
-        const uint32_t kx = r.h_cbs[x].K, ky = r.h_cbs[y].K;
-        const bool bx = lsn_turbo_nwin((int)kx) > 64, by = lsn_turbo_nwin((int)ky) > 64;
-        if (bx != by) return bx;
-        if (kx != ky) return kx > ky;
-        return x < y;
-      });
-      std::vector<LsnCbDev> sorted(ncb);
-      for (uint32_t i = 0; i < ncb; i++) {
-        sorted[i] = r.h_cbs[order[i]];
-        if (lsn_turbo_nwin((int)sorted[i].K) > 64) { n128++; kmax128 = std::max(kmax128, sorted[i].K); } else kmax64 = std::max(kmax64, sorted[i].K);
-      }
-      HIP_CHECK(hipMemcpyAsync(ul_d_grants, gd.data(), ng * sizeof(LsnUlGrantDev), hipMemcpyHostToDevice, st));
-      HIP_CHECK(hipMemcpyAsync(r.d_cbs, sorted.data(), ncb * sizeof(LsnCbDev), hipMemcpyHostToDevice, st));
-      HIP_CHECK(hipMemsetAsync(r.d_llr16, 0, llr_n * sizeof(int16_t), st));
-      HIP_CHECK(hipStreamSynchronize(st));  // gd / sorted are pageable host vectors
-      lsn_launch_pusch_chest(cd, ul_d_grants, ul_d_grid, ul_d_hs, ul_d_stat, ng, st);
-      lsn_launch_pusch_demod(cd, ul_d_grants, ul_d_grid, ul_d_hs, ul_d_stat, r.d_llr16, ng, st);
-      lsn_launch_turbo(cd, r.d_cbs, r.d_llr16, r.d_payload, r.d_cbres, n128, kmax128, ncb - n128, kmax64, st, nullptr);
-      std::vector<LsnCbRes> cbres(ncb);
-      std::vector<uint8_t> pay(pay_n);
-      std::vector<float> stat((size_t)2 * ng);
-      HIP_CHECK(hipMemcpyAsync(cbres.data(), r.d_cbres, ncb * sizeof(LsnCbRes), hipMemcpyDeviceToHost, st));
-      HIP_CHECK(hipMemcpyAsync(pay.data(), r.d_payload, pay_n, hipMemcpyDeviceToHost, st));
-      HIP_CHECK(hipMemcpyAsync(stat.data(), ul_d_stat, stat.size() * sizeof(float), hipMemcpyDeviceToHost, st));
-      HIP_CHECK(hipStreamSynchronize(st));
-      size_t out_used = 0;
-      for (size_t t = 0; t < tbs.size(); t++) {
-        const TbRef& ref = tbs[t];
-        bool all_ok = true;
-        uint32_t rem = 0, iters = 0;
-        uint64_t bits_after = 0;
-        for (int q = (int)ref.cb_count - 1; q >= 0; q--) {
-          const LsnCbRes& cr = cbres[ref.cb_first + q];
-          all_ok = all_ok && cr.ok != 0;
-          iters += cr.iters;
-          rem ^= crc24a_mulmod(cr.rem_a, crc24a_xpow(bits_after));
-          bits_after += 8ull * r.h_cbs[ref.cb_first + q].out_bytes;
-        }
-        const uint8_t* pl = pay.data() + ref.pay_off;
-        const uint32_t par = ((uint32_t)pl[ref.tbs / 8] << 16) | ((uint32_t)pl[ref.tbs / 8 + 1] << 8) | pl[ref.tbs / 8 + 2];
-        lsn_pusch_result_t& res = results[ref.grant];
-        res.crc_ok = all_ok && rem == 0 && par != 0 && bits_after == (uint64_t)ref.tbs + 24;
-        res.iterations = iters;
-        res.snr_db = 10.0f * log10f(stat[2 * t + 1] / stat[2 * t]);
-        res.payload_off = (uint32_t)out_used;
-        if (payloads && out_used + (size_t)ref.tbs / 8 <= payload_cap) std::memcpy(payloads + out_used, pl, (size_t)ref.tbs / 8);
-        out_used += (size_t)ref.tbs / 8;
-      }
-    } else {
-      HIP_CHECK(hipStreamSynchronize(st));
-    }
+    lsn_launch_ul_fft(cd, d_iq, 1, 0, ul_d_grid, nsf, st);
+    std::vector<uint8_t> pay;
+    puschDecodeGrid(ul_d_grid, nsf, start_tti, grants, ngrants, results, pay);
+    if (payloads) std::memcpy(payloads, pay.data(), std::min(pay.size(), payload_cap));
     return LSN_SUCCESS;
   } catch (const std::exception& ex) {
     fprintf(stderr, "ltesniffer_amd: %s\n", ex.what());
     return LSN_ERROR;
+  }
+}
+
+// srsran_chest_ul_estimate_pusch + srsran_pusch_decode for a list of grants on an uplink grid that is already on the device
+// (stream runner_u).  payload_out: tbs/8 bytes per valid grant at results[i].payload_off.  Throws on HIP errors.
+void Engine::puschDecodeGrid(const cf32* d_grid, uint32_t nsf, uint32_t start_tti, const lsn_pusch_grant_t* grants, uint32_t ngrants,
+                             lsn_pusch_result_t* results, std::vector<uint8_t>& payload_out)
+{
+  static const uint32_t n_dmrs1[8] = {0, 2, 3, 4, 6, 8, 9, 10};  // 36.211 Table 5.5.2.1.1-2
+  static const uint32_t n_dmrs2[8] = {0, 6, 3, 4, 2, 8, 10, 9};  // Table 5.5.2.1.1-1
+  JobRunner& r = runner_u;
+  hipStream_t st = r.stream;
+  payload_out.clear();
+  std::vector<LsnUlGrantDev> gd;
+  std::vector<int> gidx;
+  r.h_cbs.clear();
+  struct TbRef { uint32_t grant, cb_first, cb_count, pay_off; int tbs; };
+  std::vector<TbRef> tbs;
+  size_t hs_n = 0, llr_n = 0, pay_n = 0;
+  for (uint32_t i = 0; i < ngrants; i++) {
+    const lsn_pusch_grant_t& g = grants[i];
+    results[i] = lsn_pusch_result_t{};
+    const bool ok = g.sf < nsf && g.L_prb >= 3 && ul_valid_prb(g.L_prb) && g.n_prb + g.L_prb <= cell.nof_prb && g.tbs > 0 && (g.tbs % 8) == 0 &&
+                    (g.mod == 2 || g.mod == 4 || g.mod == 6 || g.mod == 8) && ul_off[g.L_prb] >= 0 && g.rv >= 0 && g.rv < 4;
+    if (!ok) continue;
+    const uint32_t M = 12 * g.L_prb, sf_idx = (start_tti + g.sf) % 10;
+    CbSegm s;
+    const int G = (int)(12 * M * g.mod);
+    if (!cbsegm((int)g.tbs, s)) continue;
+    LsnUlGrantDev d{};
+    d.sf = g.sf; d.n_prb = g.n_prb; d.L_prb = g.L_prb; d.qm = g.mod;
+    for (uint32_t sl = 0; sl < 2; sl++) d.ncs[sl] = (n_dmrs1[ul_cfg.cyclic_shift & 7] + n_dmrs2[g.n_dmrs & 7] + ul_npn[2 * sf_idx + sl]) % 12u;
+    d.cinit = ((uint32_t)g.rnti << 14) | (sf_idx << 9) | cell.id;
+    d.base_off = (uint32_t)ul_off[g.L_prb]; d.idft_off = d.base_off;
+    d.hs_off = (uint32_t)hs_n; hs_n += 2 * M;
+    d.llr_off = (uint32_t)llr_n; llr_n += ((size_t)G + 7) & ~(size_t)7;
+    d.scale = 1.0f / sqrtf((float)M);
+    // UL-SCH: one transport block, one layer (36.212 5.2.2.6)
+    const int Qm = (int)g.mod, Gp = G / Qm, gamma = Gp % s.C;
+    TbRef ref{i, (uint32_t)r.h_cbs.size(), (uint32_t)s.C, (uint32_t)pay_n, (int)g.tbs};
+    int rp = 0;
+    uint32_t wp = 0;
+    for (int q = 0; q < s.C; q++) {
+      LsnCbDev cb{};
+      const int K = q < s.Cm ? s.Km : s.Kp, F = q == 0 ? s.F : 0;
+      int E = (q <= s.C - gamma - 1) ? Qm * (Gp / s.C) : Qm * ((Gp + s.C - 1) / s.C);
+      if (rp + E > G) E = G - rp;
+      cb.e_off = d.llr_off + (uint32_t)rp; cb.E = (uint32_t)E; cb.K = (uint32_t)K; cb.F = (uint32_t)F; cb.rv = (uint32_t)g.rv;
+      cb.crc_b = s.C > 1 ? 1u : 0u;
+      cb.out_bytes = (uint32_t)(K - F - (s.C > 1 ? 24 : 0)) / 8;
+      cb.out_off = (uint32_t)pay_n + wp;
+      qpp_params(K, cb.f1, cb.f2);
+      cb.max_iter = (uint32_t)cfg.max_turbo_iterations;
+      wp += cb.out_bytes;
+      rp += E;
+      r.h_cbs.push_back(cb);
+    }
+    pay_n += (wp + 15) & ~15u;
+    tbs.push_back(ref);
+    gd.push_back(d);
+    gidx.push_back((int)i);
+  }
+  ul_last_gd = gd; ul_last_idx = gidx;
+  const uint32_t ng = (uint32_t)gd.size(), ncb = (uint32_t)r.h_cbs.size();
+  if (!ng) { HIP_CHECK(hipStreamSynchronize(st)); return; }
+  grow_d(ul_d_grants, ul_grants_cap, ng);
+  grow_d(ul_d_hs, ul_hs_cap, hs_n);
+  grow_d(ul_d_stat, ul_stat_cap, (size_t)2 * ng);
+  grow_d(r.d_llr16, r.llr16_cap, llr_n + 8);
+  grow_d(r.d_cbs, r.cbs_cap, ncb);
+  grow_d(r.d_cbres, r.cbres_cap, ncb);
+  grow_d(r.d_payload, r.payload_cap, pay_n + 16);
+  std::vector<uint32_t> order(ncb);
+  uint32_t n128 = 0, kmax128 = 0, kmax64 = 0;
+  for (uint32_t i = 0; i < ncb; i++) { r.h_cbs[i].res_idx = i; order[i] = i; }
+  std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+    const uint32_t kx = r.h_cbs[x].K, ky = r.h_cbs[y].K;
+    const bool bx = lsn_turbo_nwin((int)kx) > 64, by = lsn_turbo_nwin((int)ky) > 64;
+    if (bx != by) return bx;
+    if (kx != ky) return kx > ky;
+    return x < y;
+  });
+  std::vector<LsnCbDev> sorted(ncb);
+  for (uint32_t i = 0; i < ncb; i++) {
+    sorted[i] = r.h_cbs[order[i]];
+    if (lsn_turbo_nwin((int)sorted[i].K) > 64) { n128++; kmax128 = std::max(kmax128, sorted[i].K); } else kmax64 = std::max(kmax64, sorted[i].K);
+  }
+  HIP_CHECK(hipMemcpyAsync(ul_d_grants, gd.data(), ng * sizeof(LsnUlGrantDev), hipMemcpyHostToDevice, st));
+  HIP_CHECK(hipMemcpyAsync(r.d_cbs, sorted.data(), ncb * sizeof(LsnCbDev), hipMemcpyHostToDevice, st));
+  HIP_CHECK(hipMemsetAsync(r.d_llr16, 0, llr_n * sizeof(int16_t), st));
+  HIP_CHECK(hipStreamSynchronize(st));  // gd / sorted are pageable host vectors
+  lsn_launch_pusch_chest(cd, ul_d_grants, d_grid, ul_d_hs, ul_d_stat, ng, st);
+  lsn_launch_pusch_demod(cd, ul_d_grants, d_grid, ul_d_hs, ul_d_stat, r.d_llr16, ng, st);
+  lsn_launch_turbo(cd, r.d_cbs, r.d_llr16, r.d_payload, r.d_cbres, n128, kmax128, ncb - n128, kmax64, st, nullptr);
+  std::vector<LsnCbRes> cbres(ncb);
+  std::vector<uint8_t> pay(pay_n);
+  std::vector<float> stat((size_t)2 * ng);
+  HIP_CHECK(hipMemcpyAsync(cbres.data(), r.d_cbres, ncb * sizeof(LsnCbRes), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipMemcpyAsync(pay.data(), r.d_payload, pay_n, hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipMemcpyAsync(stat.data(), ul_d_stat, stat.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+  HIP_CHECK(hipStreamSynchronize(st));
+  for (size_t t = 0; t < tbs.size(); t++) {
+    const TbRef& ref = tbs[t];
+    bool all_ok = true;
+    uint32_t rem = 0, iters = 0;
+    uint64_t bits_after = 0;
+    for (int q = (int)ref.cb_count - 1; q >= 0; q--) {
+      const LsnCbRes& cr = cbres[ref.cb_first + q];
+      all_ok = all_ok && cr.ok != 0;
+      iters += cr.iters;
+      rem ^= crc24a_mulmod(cr.rem_a, crc24a_xpow(bits_after));
+      bits_after += 8ull * r.h_cbs[ref.cb_first + q].out_bytes;
+    }
+    const uint8_t* pl = pay.data() + ref.pay_off;
+    const uint32_t par = ((uint32_t)pl[ref.tbs / 8] << 16) | ((uint32_t)pl[ref.tbs / 8 + 1] << 8) | pl[ref.tbs / 8 + 2];
+    lsn_pusch_result_t& res = results[ref.grant];
+    res.crc_ok = all_ok && rem == 0 && par != 0 && bits_after == (uint64_t)ref.tbs + 24;
+    res.iterations = iters;
+    res.snr_db = 10.0f * log10f(stat[2 * t + 1] / stat[2 * t]);
+    res.payload_off = (uint32_t)payload_out.size();
+    payload_out.insert(payload_out.end(), pl, pl + ref.tbs / 8);
   }
 }
 

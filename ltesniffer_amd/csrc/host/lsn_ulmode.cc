@@ -1,0 +1,207 @@
+// lsn_ulmode.cc - UL_MODE commit stage: what SubframeWorker::run_ul_mode does after the DCI search
+// (/root/reference/src/src/SubframeWorker.cc:236-347):
+//   PDSCH_Decoder::decode_ul_mode      /root/reference/src/src/DL_Sniffer_PDSCH.cc:362-457   (RAR + format 1 / 1A, 64QAM table)
+//   unpack_rar_response_ul_mode        /root/reference/src/src/DL_Sniffer_PDSCH.cc:632-671   (Msg3 grant of the RAR)
+//   ULSchedule push / get              /root/reference/src/src/ULSchedule.cc:11-138          (DCI 0 -> PUSCH 4 subframes later, RAR grant 6)
+//   PUSCH_Decoder::decode / decode_run /root/reference/src/src/UL_Sniffer_PUSCH.cc:250-310,389-583 (modulation-table trials, UL MCS tracking)
+// SIB2 is not parsed (ASN.1 is out of scope): the DMRS configuration comes from lsn_phy_set_ul_config.
+// The whole function runs in the chunk's commit turn, i.e. strictly in TTI order; PUSCH attempts of a chunk are decoded in
+// up to three batched waves (first / second / third attempt of the reference's trial order) and looked up by the sequential
+// logic, which falls back to an on-demand decode when the MCS-tracking state moved inside the chunk.
+#include "lsn_engine.h"
+#include <map>
+#include <tuple>
+
+namespace lsn {
+
+namespace {
+struct Attempt { uint32_t sf; uint32_t idx; bool use256; int qm; };
+inline bool operator<(const Attempt& a, const Attempt& b) { return std::tie(a.sf, a.idx, a.use256, a.qm) < std::tie(b.sf, b.idx, b.use256, b.qm); }
+struct AttemptResult { bool crc = false; std::vector<uint8_t> payload; };
+struct PendingPdu { bool ul; char name; uint16_t rnti; uint8_t tb; const uint8_t* data; std::vector<uint8_t> own; uint32_t len; };
+}  // namespace
+
+void Engine::commitChunkUl(Chunk& ch, JobRunner& r)
+{
+  if (ulmod.empty()) ulmod.assign(65536, 0);
+  if (!ul_set) throw std::runtime_error("UL_MODE: lsn_phy_set_ul_config has not been called");
+  const uint32_t nsf = ch.nsf;
+  std::vector<std::vector<PendingPdu>> out(nsf);            // records per subframe: downlink first, then uplink
+  std::vector<std::vector<UlSchedGrant>> lists(nsf);        // PUSCH grants to try in each subframe
+
+  // ---- phase 1 (sequential): downlink part + schedule bookkeeping ----
+  for (uint32_t sf = 0; sf < nsf; sf++) {
+    SubframeCtx& c = ch.ctx[sf];
+    const uint32_t tti = c.tti % 10240;
+    std::vector<UlSchedGrant> rar_now;
+    if (c.searched) {
+      for (auto& e : c.dl) {
+        if (!e.unpack_ok || !ulModeDecodesDl(e)) continue;
+        if (e.job[0] < 0) e.job[0] = newJob(ch, sf, e, 0);
+        const int j = e.job[0];
+        if (j < 0) continue;
+        if (!ch.jobs[j].done) { ensureJob(ch, r, j); r.perf.nof_ondemand_decodes++; }
+        const DecodeJob& job = ch.jobs[j];
+        const bool is_ra = e.rnti >= RARNTI_START && e.rnti <= RARNTI_END;
+        for (int tb = 0; tb < 2; tb++) {
+          if (!job.crc[tb]) continue;
+          const uint32_t len = (uint32_t)(job.grant.tb[tb].tbs / 8);
+          const uint8_t* pl = ch.h_payload.data() + job.payload_off[tb];
+          out[sf].push_back({false, is_ra ? 'R' : rnti_name(e.rnti)[0], e.rnti, (uint8_t)tb, pl, {}, len});
+          if (is_ra) {  // unpack_rar_response_ul_mode on TB 0's buffer; the grant of the LAST sub-header survives; then return
+            const uint8_t* p = ch.h_payload.data() + job.payload_off[0];
+            int nsub = 0, pos = 0;
+            bool is_rapid[32];
+            while (pos < (int)len && nsub < 32) { const uint8_t b = p[pos++]; is_rapid[nsub++] = (b & 0x40) != 0; if (!(b & 0x80)) break; }
+            UlSchedGrant last; bool found = false;
+            for (int i = 0; i < nsub; i++) {
+              uint16_t t_crnti = 0; uint32_t grant20 = 0;
+              if (is_rapid[i]) {
+                if (pos + 6 > (int)len) break;
+                grant20 = ((uint32_t)(p[pos + 1] & 0x0F) << 16) | ((uint32_t)p[pos + 2] << 8) | p[pos + 3];
+                t_crnti = (uint16_t)((p[pos + 4] << 8) | p[pos + 5]);
+                pos += 6;
+              }
+              DciUl d;  // ul_sniffer_dci_rar_unpack / _rar_to_ul_dci, falcon_dci.c:648-683
+              d.rnti = t_crnti; d.hopping = (grant20 >> 19) & 1u; d.riv = (grant20 >> 9) & 0x3FFu; d.mcs_idx = (grant20 >> 5) & 0xFu;
+              last = UlSchedGrant();
+              last.rnti = t_crnti; last.is_rar = true; last.hopping = d.hopping != 0;
+              if (!ra_ul_dci_to_grant(cell, d, last.g)) last.g = PuschGrant();  // ran_ul_grant_256 stays empty for RAR grants
+              found = true;  // (the RNTI activation of this sub-header already happened at search time)
+            }
+            if (found) rar_now.push_back(last);
+            break;
+          }
+        }
+      }
+      // ULSchedule::pushULSche(tti, dci_ul): every accepted DCI 0, also those whose grant conversion failed
+      std::vector<UlSchedGrant>& cur = ul_sched[tti];
+      for (auto& u : c.ul) {
+        UlSchedGrant g;
+        g.rnti = u.rnti; g.n_dmrs = u.dci.n_dmrs; g.hopping = u.dci.hopping != 0;
+        if (u.ok) { g.g = u.grant; g.g256 = u.grant256; }
+        cur.push_back(g);
+      }
+    } else {
+      ul_sched[tti];
+    }
+    rar_sched[tti] = rar_now;
+    // PUSCH_Decoder::decode: grants of tti - 4 followed by the RAR grants of tti - 6
+    const uint32_t t4 = (tti + 10240 - 4) % 10240, t6 = (tti + 10240 - 6) % 10240;
+    auto ia = ul_sched.find(t4);
+    if (ia != ul_sched.end()) { lists[sf] = ia->second; ul_sched.erase(ia); }
+    auto ir = rar_sched.find(t6);
+    if (ir != rar_sched.end()) { lists[sf].insert(lists[sf].end(), ir->second.begin(), ir->second.end()); rar_sched.erase(ir); }
+  }
+  // stale schedule entries (a gap in the TTI sequence) must not accumulate
+  while (ul_sched.size() > 64) ul_sched.erase(ul_sched.begin());
+  while (rar_sched.size() > 64) rar_sched.erase(rar_sched.begin());
+
+  // ---- the reference's trial order as a list of attempts, given the tracked maximum modulation ----
+  auto valid_grant = [&](const UlSchedGrant& m) {  // investigate_valid_ul_grant, UL_Sniffer_PUSCH.cc:894-918 (+ rnti != 0, :419)
+    if (m.rnti == 0) return false;
+    if (m.is_rar) return true;
+    if (m.g.tbs == 0 || m.g256.tbs == 0) return false;
+    return ul_valid_prb(m.g.L_prb) && m.g.L_prb <= 100;
+  };
+  auto mod_of = [&](uint16_t rnti) -> int { return ulmod[rnti] ? ulmod[rnti] : (ulmod_count < 250 ? 1 : 5); };  // 5 = FULL_BUFFER
+  auto trial = [&](const UlSchedGrant& m, int mod, Attempt* a, int* learn) -> int {
+    // returns the number of attempts (tried in order until one passes); learn[i]: modulation learnt if attempt i passes (0: none)
+    const uint32_t mcs = m.g.mcs_idx;
+    const bool ok256 = m.g256.L_prb < 110 && m.g256.L_prb > 0;
+    const int qb = m.g.mod, q16 = qb > 4 ? 4 : qb;
+    int n = 0;
+    auto add = [&](bool use256, int qm, int l) { a[n].use256 = use256; a[n].qm = qm; learn[n] = l; n++; };
+    if (mcs > 20 && mcs < 29) {
+      if (mod == 2) add(false, 4, 0);
+      else if (mod == 3) add(false, qb, 0);
+      else if (mod == 4) { if (ok256) add(true, m.g256.mod, 0); }
+      else if (mod == 1) { add(false, 4, 2); add(false, qb, 3); if (ok256) add(true, m.g256.mod, 4); }
+    } else if (mcs <= 20) {
+      if (mod == 2 || mod == 3) add(false, q16, 0);
+      else if (mod == 4) { if (ok256) add(true, m.g256.mod, 0); }
+      else if (mod == 1) { add(false, q16, 0); if (ok256) add(true, m.g256.mod, 0); }
+    }
+    return n;
+  };
+  std::map<Attempt, AttemptResult> results;
+  auto run_batch = [&](const std::vector<Attempt>& batch) {
+    std::vector<lsn_pusch_grant_t> gl;
+    std::vector<Attempt> keys;
+    for (const Attempt& a : batch) {
+      if (results.count(a)) continue;
+      const UlSchedGrant& m = lists[a.sf][a.idx];
+      const PuschGrant& g = a.use256 ? m.g256 : m.g;
+      results[a];  // default: failed
+      if (m.hopping || g.tbs <= 0) continue;  // frequency hopping is outside the round-1 scope: the attempt fails
+      lsn_pusch_grant_t q{};
+      q.sf = a.sf; q.rnti = m.rnti; q.n_dmrs = (uint16_t)m.n_dmrs; q.n_prb = g.n_prb; q.L_prb = g.L_prb; q.mod = (uint32_t)a.qm; q.tbs = (uint32_t)g.tbs; q.rv = g.rv;
+      gl.push_back(q);
+      keys.push_back(a);
+    }
+    if (gl.empty()) return;
+    std::vector<lsn_pusch_result_t> res(gl.size());
+    std::vector<uint8_t> pay;
+    puschDecodeGrid(ch.d_ul_grid, ch.nsf, ch.start_tti, gl.data(), (uint32_t)gl.size(), res.data(), pay);
+    for (size_t i = 0; i < gl.size(); i++) {
+      AttemptResult& ar = results[keys[i]];
+      ar.crc = res[i].crc_ok != 0;
+      if (ar.crc) ar.payload.assign(pay.begin() + res[i].payload_off, pay.begin() + res[i].payload_off + gl[i].tbs / 8);
+      r.perf.nof_tb_decodes++;
+      r.perf.nof_turbo_iterations += res[i].iterations;
+    }
+  };
+  // ---- phase 2: three waves, predicted with the tracking state as of now ----
+  for (int wave = 0; wave < 3; wave++) {
+    std::vector<Attempt> batch;
+    for (uint32_t sf = 0; sf < nsf; sf++)
+      for (uint32_t i = 0; i < lists[sf].size(); i++) {
+        const UlSchedGrant& m = lists[sf][i];
+        if (!valid_grant(m)) continue;
+        Attempt a[3]; int learn[3];
+        const int n = trial(m, mod_of(m.rnti), a, learn);
+        if (wave >= n) continue;
+        bool earlier_passed = false;
+        for (int k = 0; k < wave; k++) { a[k].sf = sf; a[k].idx = i; auto it = results.find(a[k]); earlier_passed = earlier_passed || (it != results.end() && it->second.crc); }
+        if (earlier_passed) continue;
+        a[wave].sf = sf; a[wave].idx = i;
+        batch.push_back(a[wave]);
+      }
+    run_batch(batch);
+  }
+  // ---- phase 3 (sequential): the exact decision logic, records in (tti, downlink, uplink) order ----
+  for (uint32_t sf = 0; sf < nsf; sf++) {
+    const uint32_t tti = ch.ctx[sf].tti;
+    for (uint32_t i = 0; i < lists[sf].size(); i++) {
+      const UlSchedGrant& m = lists[sf][i];
+      if (!valid_grant(m)) continue;
+      Attempt a[3]; int learn[3];
+      const int n = trial(m, mod_of(m.rnti), a, learn);
+      for (int k = 0; k < n; k++) {
+        a[k].sf = sf; a[k].idx = i;
+        if (!results.count(a[k])) { run_batch({a[k]}); r.perf.nof_ondemand_decodes++; }
+        const AttemptResult& ar = results[a[k]];
+        if (!ar.crc) continue;
+        PendingPdu p{true, 'C', m.rnti, 0, nullptr, ar.payload, (uint32_t)ar.payload.size()};
+        out[sf].push_back(std::move(p));
+        if (learn[k] && m.g.mcs_idx > 20) {  // decode_run: update_RNTI_ul when the maximum modulation was still unknown
+          if (ulmod[m.rnti]) ulmod[m.rnti] = (uint8_t)learn[k];
+          else { ulmod[m.rnti] = 1; ulmod_count++; }
+        }
+        break;
+      }
+    }
+    for (auto& p : out[sf]) {
+      const uint8_t* data = p.ul ? p.own.data() : p.data;
+      if (p.ul) {  // write_ul_crnti, PcapWriter.cc:172-175
+        r.perf.nof_pdus++;
+        if (sink) { lsn_pdu_ctx_t c{}; c.tti = tti; c.rnti = p.rnti; c.direction = 0; c.rnti_type = 3; c.crc_ok = 1; sink(sink_user, &c, data, p.len); }
+      } else {
+        const char name[2] = {p.name, 0};
+        emitPdu(r, name, data, p.len, p.rnti, tti, p.tb);
+      }
+    }
+  }
+}
+
+}  // namespace lsn

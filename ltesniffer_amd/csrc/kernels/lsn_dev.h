@@ -24,6 +24,7 @@ struct LsnChest {
 // cell-constant tables, passed to kernels by value
 struct LsnCellDev {
   uint32_t nof_prb, nof_ports, id, nof_rx, N, lgN, nre, nref, sflen;
+  uint32_t iq_nant;         // antennas interleaved in the IQ buffer ([sf][antenna][sflen]); nof_rx of them carry the downlink
   const cf32* twiddle;      // [N/2] exp(-2 pi i k/N)
   const cf32* nco_coarse;   // [4096]
   const cf32* nco_fine;     // [1024]
@@ -102,7 +103,7 @@ void lsn_launch_pdcch_llr(const LsnCellDev& c, const cf32* grid, const cf32* ce,
 void lsn_launch_cce_power(const LsnCellDev& c, const float* llr, const uint32_t* cfi, float* pw, uint32_t nsf, hipStream_t s);
 void lsn_launch_viterbi(const LsnCellDev& c, const float* llr, const float* pw, const uint32_t* cfi, LsnCand* cand, uint32_t nsf, hipStream_t s);
 void lsn_launch_rb_power(const LsnCellDev& c, const cf32* grid, float* rbp, uint32_t nsf, hipStream_t s);
-void lsn_launch_ul_fft(const LsnCellDev& c, const cf32* iq, cf32* grid, uint32_t nsf, hipStream_t s);
+void lsn_launch_ul_fft(const LsnCellDev& c, const cf32* iq, uint32_t nant, uint32_t ant, cf32* grid, uint32_t nsf, hipStream_t s);
 void lsn_launch_pusch_chest(const LsnCellDev& c, const LsnUlGrantDev* g, const cf32* grid, cf32* hs, float* stat, uint32_t ngrants, hipStream_t s);
 void lsn_launch_pusch_demod(const LsnCellDev& c, const LsnUlGrantDev* g, const cf32* grid, const cf32* hs, const float* stat, int16_t* llr,
                             uint32_t ngrants, hipStream_t s);

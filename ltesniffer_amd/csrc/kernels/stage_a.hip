@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void k_ofdm(LsnCellDev c, const cf32* __restri
   const int cp0 = 160 * N / 2048, cp1 = 144 * N / 2048;
   const int slot = l / 7, ls = l % 7;
   const int pos = slot * (cp0 + 6 * cp1 + 7 * N) + cp0 + ls * (N + cp1);
-  const cf32* in = iq + ((size_t)sf * c.nof_rx + rx) * c.sflen + pos;
+  const cf32* in = iq + ((size_t)sf * c.iq_nant + rx) * c.sflen + pos;
   const uint32_t dphi = dphi_sf ? dphi_sf[sf] : 0u;
   for (int n = tid; n < N / 2; n += 256) w[n] = c.twiddle[n];
   for (int n = tid; n < N; n += 256) {

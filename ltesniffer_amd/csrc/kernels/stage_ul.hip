@@ -43,7 +43,7 @@ __device__ __forceinline__ void ul_fft_pass(cf32* a, const cf32* w, int s, int N
 }
 
 // one workgroup per (subframe, symbol): CP strip, 7.5 kHz shift, radix-8/4/2 DIT FFT in LDS, carrier extract (no DC gap)
-__global__ __launch_bounds__(256) void k_ul_fft(LsnCellDev c, const cf32* __restrict__ iq, cf32* __restrict__ grid)
+__global__ __launch_bounds__(256) void k_ul_fft(LsnCellDev c, const cf32* __restrict__ iq, uint32_t nant, uint32_t ant, cf32* __restrict__ grid)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int N = (int)c.N, lgN = (int)c.lgN, tid = threadIdx.x;
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void k_ul_fft(LsnCellDev c, const cf32* __rest
   const int cp0 = 160 * N / 2048, cp1 = 144 * N / 2048;
   const int slot = l / 7, ls = l % 7;
   const int pos = slot * (cp0 + 6 * cp1 + 7 * N) + cp0 + ls * (N + cp1);
-  const cf32* in = iq + (size_t)sf * c.sflen + pos;
+  const cf32* in = iq + ((size_t)sf * nant + ant) * c.sflen + pos;
   for (int n = tid; n < N / 2; n += 256) w[n] = c.twiddle[n];
   for (int n = tid; n < N; n += 256) a[__brev((unsigned)n) >> (32 - lgN)] = cmul(in[n], c.ul_shift[n]);
   __syncthreads();
@@ -70,9 +70,9 @@ __global__ __launch_bounds__(256) void k_ul_fft(LsnCellDev c, const cf32* __rest
   for (int k = tid; k < nre; k += 256) out[k] = a[(k < nre / 2) ? (N - nre / 2 + k) : (k - nre / 2)];
 }
 
-void lsn_launch_ul_fft(const LsnCellDev& c, const cf32* iq, cf32* grid, uint32_t nsf, hipStream_t s)
+void lsn_launch_ul_fft(const LsnCellDev& c, const cf32* iq, uint32_t nant, uint32_t ant, cf32* grid, uint32_t nsf, hipStream_t s)
 {
-  hipLaunchKernelGGL(k_ul_fft, dim3(nsf * 14), dim3(256), sizeof(cf32) * (c.N + c.N / 2), s, c, iq, grid);
+  hipLaunchKernelGGL(k_ul_fft, dim3(nsf * 14), dim3(256), sizeof(cf32) * (c.N + c.N / 2), s, c, iq, nant, ant, grid);
 }
 
 // ------------------------------------------------------------------------------------------------ DMRS estimate

@@ -102,3 +102,37 @@ def test_pusch_unsupported_grants_fail_cleanly():
     res = phy.pusch_decode(iq, 0, bad)
     assert all(r["crc_ok"] == 0 for r in res)
     phy.close()
+
+
+def _run_ul_mode(nsf, seed, batch, **over):
+    from lsn_testlib import OracleWorkerUl, gen_ul_mode_subframes, parse_pcap, scenario
+    from parity import gpu_records, oracle_records
+    sc = scenario("cfg2", seed=seed, nof_rx=1, n_rnti=12, dl_min=2, dl_max=3, ul_min=2, ul_max=4, **over)
+    tti0, iq, sent = gen_ul_mode_subframes(sc, nsf)
+    ow = OracleWorkerUl(sc["nof_prb"], sc["nof_ports"], sc["cell_id"], 3, 5)
+    for i in range(nsf):
+        ow.work_ul(iq[i, 0], iq[i, 1], tti0 + i, update_meta=1 if i % 25 == 0 else 0)
+    orecs = parse_pcap(ow.pcap_bytes())
+    phy = la.Phy(nof_rx_antennas=2, sniffer_mode=1, max_batch=batch, pcapwriter=la.PcapWriter(None))
+    assert phy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"]) and phy.setUlConfig(3, 5)
+    phy.process_host(iq, tti0, 25)
+    g, o = gpu_records(phy), oracle_records(orecs)
+    assert g == o, "UL_MODE record streams differ: gpu %d vs oracle %d" % (len(g), len(o))
+    st, ost = phy.getStats(), ow.stats()
+    assert st.nof_decoded_locations == ost.nof_decoded_locations and st.nof_subframes == ost.nof_subframes
+    phy.close()
+    ul = [r for r in orecs if r["direction"] == 0]
+    dl = [r for r in orecs if r["direction"] == 1]
+    return len(ul), len(dl)
+
+
+def test_ul_mode_end_to_end_matches_oracle():
+    """UL_MODE through the C ABI: antenna 0 = downlink, antenna 1 = uplink; DCI 0 at t -> PUSCH at t + 4; uplink MCS-table trials;
+    pcap records (downlink RAR / format 1-1A PDUs + uplink PDUs) identical to the oracle's UL_MODE worker"""
+    n_ul, n_dl = _run_ul_mode(60, seed=5, batch=16, mcs_max=20)
+    assert n_ul >= 10 and n_dl >= 5
+
+
+def test_ul_mode_with_rar_and_single_chunk():
+    n_ul, n_dl = _run_ul_mode(48, seed=9, batch=64, rar_period=10, mcs_max=20)
+    assert n_ul >= 5
