@@ -24,11 +24,12 @@ import torch
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--nsf", type=int, default=1600, help="subframes per step (multiple of 20)")
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--nsf", type=int, default=6400, help="subframes per step = length of the resident capture (multiple of --gen)")
+    ap.add_argument("--gen", type=int, default=1600, help="distinct synthetic subframes generated (multiple of 20); the capture is this block tiled")
     ap.add_argument("--config", default="cfg3", help="scenario preset: cfg3 = 20 MHz, 150 RNTIs, TM3/TM4 up to 256QAM")
-    ap.add_argument("--batch", type=int, default=100, help="subframes per pipeline chunk inside a step")
+    ap.add_argument("--batch", type=int, default=200, help="subframes per pipeline chunk inside a step")
     ap.add_argument("--cpu-sample", type=int, default=120, help="subframes timed on the CPU oracle (rank 0, N=1 only)")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -54,12 +55,15 @@ def main():
     from lsn_testlib import scenario
     from parity import gen_subframes, gpu_records, oracle_records, run_oracle
 
-    nsf = max(20, (args.nsf // 20) * 20)
+    gen = max(20, (min(args.gen, args.nsf) // 20) * 20)
+    nsf = max(gen, (args.nsf // gen) * gen)
     batch = min(args.batch or nsf, nsf)
     from ltesniffer_amd import dist as ld
     sc = scenario(args.config, **ld.rank_workload(args.config, rank))  # one synthetic cell per rank (SURVEY 8d config 5 style)
-    tti0, iq, truth = gen_subframes(sc, nsf)
-    d_iq = torch.from_numpy(iq.view(np.float32)).to(dev)  # [nsf][rx][15*N] interleaved cf32, resident in HBM
+    tti0, iq, truth = gen_subframes(sc, gen)
+    # resident capture [nsf][rx][15*N] interleaved cf32 in HBM: the generated block tiled nsf/gen times (its length is a
+    # multiple of 20 subframes, so subframe indices and the SIB pattern stay consistent while the TTI keeps advancing)
+    d_iq = torch.from_numpy(iq.view(np.float32)).to(dev).repeat(nsf // gen, 1, 1).contiguous()
     torch.cuda.synchronize()
 
     pcap = la.PcapWriter(None)  # native MAC-LTE writer (in-memory capture), the reference's pcap-emit surface
@@ -73,7 +77,7 @@ def main():
     # ---- parity gate on the first (cold-state) pass: MAC-LTE record stream vs the CPU oracle on the same subframes ----
     cpu = None
     pcap_diff = None
-    ns = min(args.cpu_sample, nsf)
+    ns = min(args.cpu_sample, gen)
     if rank == 0 and not args.no_cpu:
         t = time.perf_counter()
         ow, _, orecs = run_oracle(sc, tti0, iq[:ns], update_meta_period=500, taps=False)
@@ -154,7 +158,7 @@ def main():
             "config": {"workload": "%s: 20 MHz DL (100 PRB, 2 CRS ports, 2 rx), 150 active RNTIs, TM2/TM3/TM4 mix up to 256QAM, "
                                    "CFI 3, 8-14 DL + 3-6 UL DCIs per subframe (BASELINE.json configs[2])" % args.config
                        if args.config == "cfg3" else args.config,
-                       "subframes_per_step": nsf, "gpu_batch": batch, "cells": world, "parallelism": "cell/subframe shards, no collective"},
+                       "subframes_per_step": nsf, "distinct_subframes": gen, "gpu_batch": batch, "cells": world, "parallelism": "cell/subframe shards, no collective"},
             "roofline": {"bound": "hbm", "kernel": la.KERNELS[kt], "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(ach / 8000.0, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": round(kms[kt] / max(1, klaunch[kt]), 4), "launches": int(klaunch[kt]),
