@@ -183,7 +183,7 @@ void Engine::launchStageA(Chunk& ch, const void* d_iq)
   timed([&] { lsn_launch_pcfich(cd, ch.d_grid, ch.d_ce, ch.d_chest, ch.d_sfidx, ch.d_cfi, ch.d_pcfich_corr, nsf, st); });
   timed([&] { lsn_launch_pdcch_llr(cd, ch.d_grid, ch.d_ce, ch.d_chest, ch.d_sfidx, ch.d_cfi, ch.d_llr, nsf, st); });
   timed([&] { lsn_launch_cce_power(cd, ch.d_llr, ch.d_cfi, ch.d_ccepow, nsf, st); });
-  timed([&] { lsn_launch_viterbi(cd, ch.d_llr, ch.d_ccepow, ch.d_cfi, ch.d_cand, nsf, st); });
+  timed([&] { lsn_launch_viterbi(cd, ch.d_llr, ch.d_ccepow, ch.d_cfi, ch.d_sfidx, ch.d_cand, nsf, st); });
   timed([&] { lsn_launch_rb_power(cd, ch.d_grid, ch.d_rbp, nsf, st); });
   if (cfg.sniffer_mode == 1) lsn_launch_ul_fft(cd, iq, cd.iq_nant, 1, ch.d_ul_grid, nsf, st);  // srsran_enb_ul_fft on antenna 1, UL_Sniffer_PUSCH.cc:391-392
   HIP_CHECK(hipMemcpyAsync(ch.h_cand, ch.d_cand, (size_t)nsf * LSN_MAX_LOC * LSN_MAX_SIZES * sizeof(LsnCand), hipMemcpyDeviceToHost, st));

@@ -97,6 +97,23 @@ void FalconSearch::setCell(const Cell& c, const uint32_t n[3])
   for (int f = 0; f < NOF_FORMATS; f++) size_index_of_format[f] = (int)(std::find(sizes.begin(), sizes.end(), size_of_format[f]) - sizes.begin());
   rb_map_dl.assign(cell.nof_prb, 0);
   rb_map_ul.assign(cell.nof_prb, 0);
+  for (int cfi = 0; cfi < 3; cfi++) {
+    LocTemplate& tp = loc_template[cfi];
+    const uint32_t ncce = nof_cce[cfi], lim = std::min<uint32_t>(ncce, LSN_MAX_NUM_OF_CCE);
+    for (auto& row : tp.map) for (auto& v : row) v = -1;
+    uint32_t k = 0;
+    for (int l = 3; l >= 0; l--) {
+      const uint32_t L = 1u << l;
+      if (ncce < L) continue;
+      for (uint32_t i = 0; i < lim / L; i++)
+        if (k < LSN_MAX_LOC) {
+          tp.locations[k] = FalconLocation{(uint32_t)l, L * (i % (ncce / L)), false, false, false, true, k};
+          for (uint32_t m = tp.locations[k].ncce; m < tp.locations[k].ncce + L && m < LSN_MAX_NUM_OF_CCE; m++) tp.map[m][l] = (int16_t)k;
+          k++;
+        }
+    }
+    tp.nloc = k;
+  }
 }
 
 // srsran_pdcch_decode_msg_limit_avg_llr_power (falcon_pdcch.c:110-170) as a lookup in the exhaustive candidate table
@@ -104,7 +121,8 @@ void FalconSearch::decodeCandidate(const FalconLocation& loc, DciFormat format, 
 {
   const LsnCand& c = cur_cand[(size_t)loc.index * LSN_MAX_SIZES + size_index_of_format[format]];
   nof_lookups++;
-  if (!c.flags) return;
+  if (!(c.flags & 1u)) return;
+  cand.search_space_match_result = (c.flags >> 1) & 3u;  // srsran_pdcch_validate_location, computed with the candidate
   cand.msg.bits = c.bits;
   cand.msg.nof_bits = size_of_format[format];
   cand.rnti = (uint16_t)c.rnti;
@@ -196,14 +214,14 @@ int FalconSearch::inspect_dci_location_recursively(SubframeCtx& c, CceMap* cce_m
         if (t.format == cand[fi].msg.format && t.rnti == cand[fi].rnti && t.ncce == ncce) add = false;
       if (add && temp_dci0.size() < 64) temp_dci0.push_back({cand[fi].rnti, L, ncce, cand[fi].msg.format, cand[fi]});
     }
-    if (metas[fi]->format != cand[fi].msg.format) { cand[fi].rnti = 0; continue; }  // :163
-    if (metas[fi]->format == FORMAT1C && cand[fi].rnti > RARNTI_END && cand[fi].rnti < PRNTI) { cand[fi].rnti = 0; continue; }  // :174
+    if (metas[fi]->format != cand[fi].msg.format) { cand[fi].rnti = 0; cand[fi].search_space_match_result = 0; continue; }  // :163
+    if (metas[fi]->format == FORMAT1C && cand[fi].rnti > RARNTI_END && cand[fi].rnti < PRNTI) { cand[fi].rnti = 0; cand[fi].search_space_match_result = 0; continue; }  // :174
     if (cand[fi].rnti > RARNTI_START && cand[fi].rnti < RARNTI_END)  // :181-197
-      if (metas[fi]->format != FORMAT1A && metas[fi]->format != FORMAT1C) { cand[fi].rnti = 0; continue; }
+      if (metas[fi]->format != FORMAT1A && metas[fi]->format != FORMAT1C) { cand[fi].rnti = 0; cand[fi].search_space_match_result = 0; continue; }
     if (enable_discovery && parent_cand != nullptr && parent_cand[fi].rnti == cand[fi].rnti &&
         !rnti_manager->isForbidden(cand[fi].rnti, metas[fi]->global_index))  // :200-211 (shortcut discovery)
       return -((int)fi + 1);
-    cand[fi].search_space_match_result = sspace.validate(c.cfi, ncce, L, c.sf_idx, cand[fi].rnti);  // :214
+    // :214 srsran_pdcch_validate_location: the verdict travels with the candidate (decodeCandidate)
     if (cand[fi].search_space_match_result == 0) { cand[fi].rnti = 0; continue; }
     if (rnti_manager->validateAndRefresh(cand[fi].rnti, metas[fi]->global_index)) {  // :245-250
       nof_cand_above_threshold++;
@@ -280,22 +298,17 @@ int FalconSearch::inspect_dci_location_recursively(SubframeCtx& c, CceMap* cce_m
 void FalconSearch::recursive_blind_dci_search(SubframeCtx& c)
 {
   CceMap cce_map[LSN_MAX_NUM_OF_CCE];
-  std::memset(cce_map, 0, sizeof(cce_map));
   const uint32_t ncce = nof_cce[c.cfi - 1];
   const uint32_t lim = std::min<uint32_t>(ncce, LSN_MAX_NUM_OF_CCE);
   stats.nof_cce += ncce;
-  uint32_t k = 0;
-  for (int l = 3; l >= 0; l--) {  // srsran_pdcch_ue_locations_all_map, falcon_pdcch.c:321-356
-    const uint32_t L = 1u << l;
-    for (uint32_t i = 0; i < lim / L; i++)
-      if (k < LSN_MAX_LOC) {
-        FalconLocation& f = locations[k];
-        f = FalconLocation{(uint32_t)l, L * (i % (ncce / L)), false, false, false, true, k};
-        for (uint32_t m = f.ncce; m < f.ncce + L; m++) cce_map[m].location[l] = &f;
-        k++;
-      }
+  // srsran_pdcch_ue_locations_all_map (falcon_pdcch.c:321-356): the enumeration only depends on the CFI -> copied from a template
+  const LocTemplate& tp = loc_template[c.cfi - 1];
+  const uint32_t nloc = tp.nloc;
+  std::memcpy(locations, tp.locations, sizeof(FalconLocation) * nloc);
+  for (uint32_t m = 0; m < lim; m++) {
+    for (int a = 0; a < 4; a++) cce_map[m].location[a] = tp.map[m][a] >= 0 ? &locations[tp.map[m][a]] : nullptr;
+    cce_map[m].power = 0.0f;
   }
-  const uint32_t nloc = k;
   stats.nof_locations += nloc;
   for (uint32_t cc = 0; cc < lim; cc++) {  // srsran_pdcch_cce_avg_llr_power, falcon_pdcch.c:595-620
     cce_map[cc].power = cur_ccepow[cc];

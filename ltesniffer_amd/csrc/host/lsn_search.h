@@ -74,6 +74,7 @@ public:
 private:
   struct FalconLocation { uint32_t L, ncce; bool used, occupied, checked, sufficient_power; uint32_t index; };
   struct CceMap { FalconLocation* location[4]; float power; };
+  struct LocTemplate { FalconLocation locations[LSN_MAX_LOC]; int16_t map[LSN_MAX_NUM_OF_CCE][4]; uint32_t nloc = 0; };
   struct TempDci0 { uint16_t rnti; uint32_t L, ncce; DciFormat format; DciCandidate cand; };
   int inspect_dci_location_recursively(SubframeCtx& c, CceMap* cce_map, uint32_t ncce, uint32_t L, uint32_t max_depth, MetaFormat** meta_formats_,
                                        uint32_t nof_formats, uint32_t enable_discovery, const DciCandidate* parent_cand);
@@ -93,6 +94,7 @@ private:
   std::vector<uint16_t> rb_map_dl, rb_map_ul;
   bool dl_collision = false, ul_collision = false;
   FalconLocation locations[LSN_MAX_LOC];
+  LocTemplate loc_template[3];
   const LsnCand* cur_cand = nullptr;
   const float* cur_ccepow = nullptr;
   BlindStats stats;

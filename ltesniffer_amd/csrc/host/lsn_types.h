@@ -11,5 +11,6 @@
 struct LsnCand {
   unsigned long long bits;  // payload bit i at position 63-i
   uint32_t rnti;            // CRC remainder = RNTI (falcon_pdcch.c:399-402)
-  uint32_t flags;           // 1 = decoded, 0 = skipped (location out of range / insufficient power / all-zero LLRs)
+  uint32_t flags;           // bit 0: decoded (0 = skipped: location out of range / insufficient power / all-zero LLRs);
+                            // bits 1-2: search-space verdict of (location, rnti): 0 invalid, 1 ambiguous with L-1, 2 valid
 };

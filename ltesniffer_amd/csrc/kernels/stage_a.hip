@@ -351,11 +351,43 @@ void lsn_launch_cce_power(const LsnCellDev& c, const float* llr, const uint32_t*
   hipLaunchKernelGGL(k_cce_power, dim3(nsf), dim3(128), 0, s, c, llr, cfi, pw);
 }
 
+// ------------------------------------------------------------------------------------------------ search space
+// srsran_pdcch_validate_location (falcon_pdcch.c:223-250) in closed form (36.213 9.1.1): 0 invalid, 1 valid but ambiguous
+// with aggregation level l-1 at the same CCE, 2 valid.  Same arithmetic as lsn::SearchSpace::validate on the host.
+__device__ __forceinline__ uint32_t ss_validate(uint32_t n, uint32_t ncce, uint32_t l, uint32_t nsubframe, uint32_t rnti)
+{
+  const bool ue = rnti >= 0x000Bu && rnti <= 0xFFF3u;
+  if (!ue && !((rnti >= 1u && rnti <= 10u) || rnti >= 0xFFFDu)) return 0;
+  uint32_t Yk = rnti;
+  if (ue)
+    for (uint32_t m = 0; m <= nsubframe; m++) {
+      const uint32_t x = 39827u * Yk;
+      const int t = (int)(x & 0xFFFFu) - (int)(x >> 16);
+      Yk = (uint32_t)(t < 0 ? t + 65537 : t);
+    }
+  auto member = [&](uint32_t lv) -> bool {
+    const uint32_t L = 1u << lv;
+    if (n < L) return false;
+    if (lv >= 2) {  // common search space: L = 4, 8 inside the first 16 CCEs
+      const uint32_t lim = (n < 16u ? n : 16u) / L;
+      if ((ncce & (L - 1)) == 0 && ncce / L < lim && ncce + L <= n) return true;
+    }
+    if (!ue || (ncce & (L - 1))) return false;
+    const uint32_t M = n / L, q = ncce / L, nc = lv < 2 ? 6u : 2u;
+    if (q >= M) return false;
+    return (q + M - Yk % M) % M < nc;
+  };
+  if (!member(l)) return 0;
+  if (l > 0 && member(l - 1)) return 1;
+  return 2;
+}
+
 // ------------------------------------------------------------------------------------------------ PDCCH Viterbi
 // One wavefront per (location, size, subframe).  Rate de-matching is a gather through a host-built rank table;
 // u8 quantisation 127.5 + 32*llr (truncated); 32-bit path metrics; 3 passes over the tail-biting block, middle pass kept.
 __global__ __launch_bounds__(64) void k_viterbi(LsnCellDev c, const float* __restrict__ llr, const float* __restrict__ pw,
-                                                const uint32_t* __restrict__ cfi_arr, LsnCand* __restrict__ cand)
+                                                const uint32_t* __restrict__ cfi_arr, const uint32_t* __restrict__ sf_idx_arr,
+                                                LsnCand* __restrict__ cand)
 {
   __shared__ unsigned char sym[3 * LSN_MAX_DCI_D];
   __shared__ unsigned long long dec[3 * LSN_MAX_DCI_D];
@@ -446,14 +478,16 @@ __global__ __launch_bounds__(64) void k_viterbi(LsnCellDev c, const float* __res
       reg = (reg << 1) | bit;
       if (reg & 0x10000u) reg ^= 0x11021u;
     }
+    const uint32_t rnti = (tailcrc ^ reg) & 0xFFFFu;
     out->bits = bits;
-    out->rnti = (tailcrc ^ reg) & 0xFFFFu;
-    out->flags = 1;
+    out->rnti = rnti;
+    out->flags = 1u | (ss_validate(ncce_tot, ncce, (uint32_t)L, sf_idx_arr[sf], rnti) << 1);  // bit 0: decoded, bits 1-2: search-space match
   }
 }
-void lsn_launch_viterbi(const LsnCellDev& c, const float* llr, const float* pw, const uint32_t* cfi, LsnCand* cand, uint32_t nsf, hipStream_t s)
+void lsn_launch_viterbi(const LsnCellDev& c, const float* llr, const float* pw, const uint32_t* cfi, const uint32_t* sf_idx, LsnCand* cand, uint32_t nsf,
+                        hipStream_t s)
 {
-  hipLaunchKernelGGL(k_viterbi, dim3(LSN_MAX_LOC, c.nsizes, nsf), dim3(64), 0, s, c, llr, pw, cfi, cand);
+  hipLaunchKernelGGL(k_viterbi, dim3(LSN_MAX_LOC, c.nsizes, nsf), dim3(64), 0, s, c, llr, pw, cfi, sf_idx, cand);
 }
 
 // SubframePower::computePower (SubframePower.cc:18-42) linear part: sum over 14 symbols of mean |x|^2 per PRB (antenna 0)

@@ -333,7 +333,7 @@ def hosttest():
 MAX_LOC, MAX_SIZES, CCE_STRIDE = 160, 8, 96
 
 
-def candidate_table(llr, nof_cce, sizes):
+def candidate_table(llr, nof_cce, sizes, sf_idx=0):
     """What k_viterbi + k_cce_power produce for one subframe, computed with the ORACLE's candidate decoder:
     -> (cand[MAX_LOC*MAX_SIZES] LsnCand array, ccepow float32[CCE_STRIDE])."""
     lib = oracle()
@@ -364,7 +364,7 @@ def candidate_table(llr, nof_cce, sizes):
                     for b in range(nb):
                         bits |= int(payload[b]) << (63 - b)
                     e = cand[li * MAX_SIZES + si]
-                    e.bits, e.rnti, e.flags = bits, rnti, 1
+                    e.bits, e.rnti, e.flags = bits, rnti, 1 | (lib.o_validate_location(nof_cce, ncce, l, sf_idx, rnti) << 1)
             li += 1
     return cand, pw
 

@@ -161,7 +161,7 @@ def _search_parity(scn, nsf, seed, update_meta_period=0, **over):
             hs = h.lsnh_search_new(sc["nof_prb"], sc["nof_ports"], sc["cell_id"], regs_cce, 5, 0.99, 0)
             sizes = [h.lsnh_search_size(hs, k) for k in range(h.lsnh_search_nof_sizes(hs))]
         cfi = ow.cfi()
-        cand, pw = candidate_table(ow.llr(), regs_cce[cfi - 1], sizes)
+        cand, pw = candidate_table(ow.llr(), regs_cce[cfi - 1], sizes, tti % 10)
         out = (C.c_uint32 * (64 * 6))()
         n = h.lsnh_search_run(hs, tti, cfi, float(ow.chest().snr_db), cand, pw.ctypes.data, upd, out, 64 * 6)
         got = [tuple(out[6 * k:6 * k + 6]) for k in range(n)]

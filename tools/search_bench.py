@@ -5,7 +5,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 import numpy as np
 from lsn_testlib import *
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-cache = "/tmp/search_bench_%d.pkl" % n
+cache = "/tmp/search_bench_v2_%d.pkl" % n
 h = hosttest()
 sc = scenario("cfg3", seed=3)
 cce = (C.c_uint32 * 3)(20, 54, 87)
@@ -18,7 +18,7 @@ else:
     ttis, cfis, cands, pws = [], [], [], []
     for i in range(n):
         tti, iq, _ = tx.next(); ow.work(iq, tti)
-        cand, pw = candidate_table(ow.llr(), 87, sizes)
+        cand, pw = candidate_table(ow.llr(), 87, sizes, tti % 10)
         ttis.append(tti); cfis.append(ow.cfi()); cands.append(bytes(cand)); pws.append(pw.tobytes())
     pickle.dump((ttis, cfis, cands, pws), open(cache, "wb"))
 T = (C.c_uint32 * n)(*ttis); F = (C.c_uint32 * n)(*cfis)

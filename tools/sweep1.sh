@@ -1,1 +1,2 @@
-python bench.py > gpurun_out/bench_r01c.json 2> gpurun_out/bench_r01c.err; tail -2 gpurun_out/bench_r01c.err; cut -c1-900 gpurun_out/bench_r01c.json
+python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+TAG=default python tools/bench_show.py --no-cpu
