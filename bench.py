@@ -30,7 +30,7 @@ def main():
     ap.add_argument("--gen", type=int, default=1600, help="distinct synthetic subframes generated (multiple of 20); the capture is this block tiled")
     ap.add_argument("--config", default="cfg3", help="scenario preset: cfg3 = 20 MHz, 150 RNTIs, TM3/TM4 up to 256QAM")
     ap.add_argument("--batch", type=int, default=200, help="subframes per pipeline chunk inside a step")
-    ap.add_argument("--cpu-sample", type=int, default=120, help="subframes timed on the CPU oracle (rank 0, N=1 only)")
+    ap.add_argument("--cpu-sample", type=int, default=600, help="subframes timed on the CPU oracle (rank 0, N=1 only)")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 

@@ -259,17 +259,18 @@ void Engine::speculateRar(Chunk& ch)
 static inline void prefetch_cand(const LsnCand* cand, const float* ccepow)
 {
   const char* p = (const char*)cand;
-  for (size_t off = 0; off < (size_t)LSN_MAX_LOC * LSN_MAX_SIZES * sizeof(LsnCand); off += 64) __builtin_prefetch(p + off, 0, 1);
+  for (size_t off = 0; off < (size_t)LSN_MAX_LOC * LSN_MAX_SIZES * sizeof(LsnCand); off += 64) __builtin_prefetch(p + off, 0, 3);
   const char* q = (const char*)ccepow;
-  for (size_t off = 0; off < LSN_CCE_STRIDE * sizeof(float); off += 64) __builtin_prefetch(q + off, 0, 1);
+  for (size_t off = 0; off < LSN_CCE_STRIDE * sizeof(float); off += 64) __builtin_prefetch(q + off, 0, 3);
 }
 
 void Engine::searchChunk(Chunk& ch, uint32_t update_meta_period)
 {
   prefetch_cand(ch.h_cand, ch.h_ccepow);
+  if (ch.nsf > 1) prefetch_cand(ch.h_cand + (size_t)LSN_MAX_LOC * LSN_MAX_SIZES, ch.h_ccepow + LSN_CCE_STRIDE);
   for (uint32_t sf = 0; sf < ch.nsf; sf++) {
     SubframeCtx& c = ch.ctx[sf];
-    if (sf + 1 < ch.nsf) prefetch_cand(ch.h_cand + (size_t)(sf + 1) * LSN_MAX_LOC * LSN_MAX_SIZES, ch.h_ccepow + (size_t)(sf + 1) * LSN_CCE_STRIDE);
+    if (sf + 2 < ch.nsf) prefetch_cand(ch.h_cand + (size_t)(sf + 2) * LSN_MAX_LOC * LSN_MAX_SIZES, ch.h_ccepow + (size_t)(sf + 2) * LSN_CCE_STRIDE);
     const bool upd = (update_meta_period && (sf_cnt % update_meta_period) == 0) || force_meta_next;  // LTESniffer_Core.cc:434
     force_meta_next = false;
     sf_cnt++;
@@ -389,7 +390,7 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
     LsnGrantDev d{};
     d.sf = j.sf; d.sf_idx = c.sf_idx; d.l0 = c.cfi + (nprb <= 10 ? 1u : 0u);
     for (int s = 0; s < 2; s++)
-      for (uint32_t rb = 0; rb < nprb; rb++)
+      for (uint32_t rb = g.prb_lo; rb <= g.prb_hi && rb < nprb; rb++)
         if (g.prb_idx[s][rb]) d.prb_mask[s][rb >> 5] |= 1u << (rb & 31);
     d.nof_re = g.nof_re; d.tx_scheme = (uint32_t)g.tx_scheme; d.pmi = g.pmi; d.nof_layers = g.nof_layers;
     for (int i = 0; i < 2; i++)

@@ -190,7 +190,8 @@ static void distributed_vrb_to_prb(uint32_t nprb, bool gap2, uint32_t vrb, uint3
 static bool ra_dl_grant_to_grant_prb_allocation(const Cell& cell, const DciDl& d, PdschGrant& g)
 {
   const uint32_t n = cell.nof_prb, P = ra_type0_P(n);
-  auto set_both = [&](uint32_t prb) { if (prb < n && !g.prb_idx[0][prb]) { g.prb_idx[0][prb] = g.prb_idx[1][prb] = true; g.nof_prb++; } };
+  auto mark = [&](uint32_t prb) { if (prb < g.prb_lo) g.prb_lo = prb; if (prb > g.prb_hi) g.prb_hi = prb; };
+  auto set_both = [&](uint32_t prb) { if (prb < n && !g.prb_idx[0][prb]) { g.prb_idx[0][prb] = g.prb_idx[1][prb] = true; g.nof_prb++; mark(prb); } };
   if (d.alloc_type == 0) {
     const uint32_t nb = (n + P - 1) / P;
     for (uint32_t i = 0; i < nb; i++)
@@ -222,7 +223,7 @@ static bool ra_dl_grant_to_grant_prb_allocation(const Cell& cell, const DciDl& d
         uint32_t v = start + i, pe, po;
         if (v >= nv) continue;
         distributed_vrb_to_prb(n, d.ngap2, v, pe, po);
-        if (pe < n && po < n) { g.prb_idx[0][pe] = true; g.prb_idx[1][po] = true; g.nof_prb++; }
+        if (pe < n && po < n) { g.prb_idx[0][pe] = true; g.prb_idx[1][po] = true; g.nof_prb++; mark(pe); mark(po); }
       }
     }
   } else {
@@ -280,7 +281,7 @@ static uint32_t ra_dl_compute_nof_re(const Cell& cell, uint32_t sf_idx, uint32_t
     const uint32_t cl = sf_idx == 0 ? 0 : (sf_idx == 5 ? 1 : 2);
     const uint16_t* t0 = cell.re_count->data() + ((size_t)(cl * 5 + l0) * 2) * cell.nof_prb;
     const uint16_t* t1 = t0 + cell.nof_prb;
-    for (uint32_t prb = 0; prb < cell.nof_prb; prb++) n += (g.prb_idx[0][prb] ? t0[prb] : 0u) + (g.prb_idx[1][prb] ? t1[prb] : 0u);
+    for (uint32_t prb = g.prb_lo; prb <= g.prb_hi && prb < cell.nof_prb; prb++) n += (g.prb_idx[0][prb] ? t0[prb] : 0u) + (g.prb_idx[1][prb] ? t1[prb] : 0u);
     return n;
   }
   for (uint32_t l = l0; l < 14; l++)
@@ -519,6 +520,14 @@ void Histogram::add(uint16_t item, uint32_t nTimes)
 void Histogram::addZeros(uint32_t nTimes)
 {
   uint32_t gained = 0;  // net increase of the count of item 0
+  // fast path: the window is full and the next nTimes slots hold 0 already (the usual case: most of the history is padding)
+  while (rnti_histogram_ready && nTimes >= 4 && rnti_history_current + 4 <= rnti_history_end) {
+    uint64_t w;
+    std::memcpy(&w, &rnti_history[rnti_history_current], 8);
+    if (w != 0) break;
+    rnti_history_current += 4; nTimes -= 4;
+    if (rnti_history_current == rnti_history_end) rnti_history_current = 0;
+  }
   while (nTimes-- > 0) {
     if (rnti_histogram_ready) {
       const uint16_t old = rnti_history[rnti_history_current];

@@ -48,6 +48,7 @@ struct GrantTb { uint32_t mcs_idx = 0; int rv = 0; uint32_t cw_idx = 0; bool ena
 struct PdschGrant {
   bool prb_idx[2][110]; uint32_t nof_prb = 0, nof_re = 0, nof_tb = 0; GrantTb tb[2]; TxScheme tx_scheme = TXSCHEME_PORT0;
   uint32_t pmi = 0, nof_layers = 0;
+  uint32_t prb_lo = 110, prb_hi = 0;  // allocated PRBs (either slot) lie in [prb_lo, prb_hi]; lo > hi: none
   PdschGrant() { std::memset(prb_idx, 0, sizeof(prb_idx)); }
 };
 struct PuschGrant { uint32_t L_prb = 0, n_prb = 0, mcs_idx = 0; int mod = 0, tbs = 0, rv = 0; };

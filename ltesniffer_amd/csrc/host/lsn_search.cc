@@ -165,7 +165,7 @@ void FalconSearch::addCandidate(SubframeCtx& c, const DciCandidate& cand, uint32
   e.unpack_ok = dci_msg_unpack_pdsch(cell, payload, cand.msg.nof_bits, fmt, cand.rnti, e.dci);
   if (e.unpack_ok) {
     dl_sniffer_ra_dl_dci_to_grant_both(cell, c.sf_idx, c.cfi, e.dci, e.grant64, e.ok64, e.grant256, e.ok256);
-    for (uint32_t rb = 0; rb < cell.nof_prb; rb++)  // DCICollection.cc:215-223 (the PRB set does not depend on the MCS table)
+    for (uint32_t rb = e.grant64.prb_lo; rb <= e.grant64.prb_hi && rb < cell.nof_prb; rb++)  // DCICollection.cc:215-223 (the PRB set does not depend on the MCS table)
       if (e.grant64.prb_idx[0][rb]) {
         if (rb_map_dl[rb] != 0) dl_collision = true;
         rb_map_dl[rb] = cand.rnti;

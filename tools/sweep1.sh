@@ -1,2 +1,2 @@
-python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-TAG=default python tools/bench_show.py --no-cpu
+TAG=prefetch3 python tools/bench_show.py --no-cpu
+python tools/search_bench.py 400 | tail -3
