@@ -242,6 +242,7 @@ const ocf_t* o_worker_ce(o_worker_t*);
 const float* o_worker_llr(o_worker_t*, uint32_t* n);
 const o_chest_res_t* o_worker_chest(o_worker_t*);
 uint32_t o_worker_cfi(o_worker_t*);
+const float* o_worker_rb_power(o_worker_t*); /* SubframePower::computePower of antenna 0, dB per PRB */
 /* accepted DCIs of the last subframe, flat: {rnti, format, L, ncce, nof_bits, histval} x n */
 uint32_t o_worker_accepted(o_worker_t*, uint32_t* out6, uint32_t max);
 o_rntiman_t* o_worker_rntiman(o_worker_t*);

@@ -159,6 +159,7 @@ const ocf_t* o_worker_ce(o_worker_t* w) { return w->ce; }
 const float* o_worker_llr(o_worker_t* w, uint32_t* n) { if (n) *n = w->regs.nof_cce[w->cfi - 1] * 72; return w->llr; }
 const o_chest_res_t* o_worker_chest(o_worker_t* w) { return &w->chest; }
 uint32_t o_worker_cfi(o_worker_t* w) { return w->cfi; }
+const float* o_worker_rb_power(o_worker_t* w) { return w->rb_power; }
 o_rntiman_t* o_worker_rntiman(o_worker_t* w) { return w->rm; }
 uint64_t o_worker_total_iters(o_worker_t* w) { return w->total_iters; }
 uint64_t o_worker_algo_bytes(o_worker_t* w) { return w->algo_bytes; }

@@ -240,6 +240,11 @@ class OracleWorker:
     def cfi(self):
         return self.lib.o_worker_cfi(self.h)
 
+    def rb_power(self):
+        self.lib.o_worker_rb_power.restype = C.POINTER(C.c_float)
+        self.lib.o_worker_rb_power.argtypes = [C.c_void_p]
+        return np.ctypeslib.as_array(self.lib.o_worker_rb_power(self.h), shape=(self.nre // 12,)).copy()
+
     def accepted(self):
         buf = (C.c_uint32 * (64 * 6))()
         n = self.lib.o_worker_accepted(self.h, buf, 64)

@@ -28,7 +28,7 @@ def run_oracle(sc, tti0, iq, update_meta_period=0, taps=True, **okw):
         ow.work(iq[i], tti0 + i, update_meta=upd)
         if taps:
             ch = ow.chest()
-            per_sf.append(dict(grid=ow.grid(), ce=ow.ce(), llr=ow.llr(), cfi=ow.cfi(), accepted=ow.accepted(),
+            per_sf.append(dict(grid=ow.grid(), ce=ow.ce(), llr=ow.llr(), cfi=ow.cfi(), accepted=ow.accepted(), rb_power=ow.rb_power(),
                                chest=np.array(list(ch.noise) + list(ch.rsrp) + list(ch.cepow) + list(ch.cfo_corr) +
                                               [ch.noise_avg, ch.rsrp_avg, ch.snr_db, ch.cfo_hz, ch.chan_ref], dtype=np.float32)))
     recs = parse_pcap(ow.pcap_bytes())
@@ -68,7 +68,37 @@ def compare_taps(phy, per_sf, sc, base=0, nsf=None):
         ch = phy.tap(la.TAP_CHEST, i, np.float32, 19)
         if not np.array_equal(ch.view(np.uint32), o["chest"].view(np.uint32)):
             bad.append((i, "chest", ch.tolist(), o["chest"].tolist()))
+        rbp = phy.tap(la.TAP_RB_POWER, i, np.float32, 110)
+        if not np.array_equal(rbp.view(np.uint32), o["rb_power"].view(np.uint32)):
+            bad.append((i, "rb_power", float(np.abs(rbp - o["rb_power"]).max())))
         acc = phy.tap(la.TAP_ACCEPTED, i, np.uint32, 64 * 6).reshape(-1, 6)
         if [tuple(int(v) for v in r) for r in acc] != [tuple(r) for r in o["accepted"]]:
             bad.append((i, "accepted", acc.tolist(), o["accepted"]))
+    return bad
+
+
+def compare_candidate_tables(phy, per_sf, sc, tti0, base=0, nsf=None):
+    """the exhaustive blind-decode table of the GPU (every location x every DCI size: payload bits, CRC remainder = RNTI,
+    search-space verdict) and the per-CCE LLR power against the oracle's candidate decoder run over the same LLRs"""
+    import ctypes as C
+    from lsn_testlib import MAX_LOC, MAX_SIZES, CCE_STRIDE, LsnCand, OCell, candidate_table, hosttest, oracle
+    h = hosttest()
+    cell = OCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"], sc["phich_ng_x6"])
+    sizes = sorted({oracle().o_dci_format_sizeof(C.byref(cell), f) for f in range(9)})
+    bad = []
+    n = nsf if nsf is not None else len(per_sf) - base
+    for i in range(n):
+        o = per_sf[base + i]
+        nof_cce = len(o["llr"]) // 72
+        cand, pw = candidate_table(o["llr"], nof_cce, sizes, (tti0 + base + i) % 10)
+        ref = np.frombuffer(bytes(cand), dtype=np.dtype([("bits", "<u8"), ("rnti", "<u4"), ("flags", "<u4")]))
+        got = phy.tap(la.TAP_CANDIDATES, i, np.uint8, MAX_LOC * MAX_SIZES * 16).view(ref.dtype)
+        gpw = phy.tap(la.TAP_CCE_POWER, i, np.float32, CCE_STRIDE)
+        if not np.array_equal(gpw[:nof_cce].view(np.uint32), pw[:nof_cce].view(np.uint32)):
+            bad.append((i, "cce_power"))
+        for li in range(MAX_LOC):
+            for si in range(len(sizes)):
+                a, b = got[li * MAX_SIZES + si], ref[li * MAX_SIZES + si]
+                if (a["flags"] & 1) != (b["flags"] & 1) or ((b["flags"] & 1) and (a["bits"] != b["bits"] or a["rnti"] != b["rnti"] or a["flags"] != b["flags"])):
+                    bad.append((i, "cand", li, si, int(a["bits"]), int(b["bits"]), int(a["rnti"]), int(b["rnti"]), int(a["flags"]), int(b["flags"])))
     return bad

@@ -4,7 +4,7 @@ import pytest
 
 import ltesniffer_amd as la
 from lsn_testlib import scenario
-from parity import compare_taps, gen_subframes, gpu_records, oracle_records, run_oracle
+from parity import compare_candidate_tables, compare_taps, gen_subframes, gpu_records, oracle_records, run_oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -101,6 +101,20 @@ def test_invalid_inputs_are_rejected():
     with pytest.raises(RuntimeError):
         phy.process_host(np.zeros((1, 2, 30720), dtype=np.complex64), 0)  # no cell set
     phy.close()
+
+
+def test_exhaustive_candidate_table_matches_oracle_decoder():
+    """k_viterbi / k_cce_power alone: all 157 locations x all DCI sizes, not only the entries the search happens to look at"""
+    for scn, n, over in (("small", 6, {}), ("cfg3", 4, {}), ("cfg1", 4, {})):
+        sc = scenario(scn, seed=51, **over)
+        tti0, iq, _ = gen_subframes(sc, n)
+        _, per_sf, _ = run_oracle(sc, tti0, iq)
+        phy = la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=n)
+        assert phy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"])
+        phy.process_host(iq, tti0, 0)
+        bad = compare_candidate_tables(phy, per_sf, sc, tti0, 0, n)
+        assert not bad, (scn, bad[:3])
+        phy.close()
 
 
 # ---------------------------------------------------------------------------------------------- edge cases
