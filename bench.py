@@ -103,7 +103,7 @@ def main():
     turbo128_bytes = 0
     algo_bytes = 0
     npdus = 0
-    acc = {k: 0 for k in ("nof_tb_decodes", "nof_cb_decodes", "nof_turbo_iterations", "nof_ondemand_decodes", "turbo_cyc_rm",
+    acc = {k: 0 for k in ("nof_tb_decodes", "nof_cb_decodes", "nof_turbo_iterations", "nof_turbo_iterations_run", "nof_ondemand_decodes", "turbo_cyc_rm",
                           "turbo_cyc_map", "turbo_cyc_out", "ms_stage_a", "ms_search", "ms_search_core", "ms_rar", "ms_stage_c", "ms_commit")}
     t0 = time.perf_counter()
     for i in range(args.steps):

@@ -157,7 +157,7 @@ void Engine::mergePerf(const lsn_perf_t& p)
   perf.algo_bytes += p.algo_bytes; perf.turbo_algo_bytes += p.turbo_algo_bytes; perf.turbo128_algo_bytes += p.turbo128_algo_bytes;
   perf.nof_tb_decodes += p.nof_tb_decodes; perf.nof_cb_decodes += p.nof_cb_decodes; perf.nof_turbo_iterations += p.nof_turbo_iterations;
   perf.ms_search_core += p.ms_search_core; perf.ms_rar += p.ms_rar;
-  perf.turbo_cyc_rm += p.turbo_cyc_rm; perf.turbo_cyc_map += p.turbo_cyc_map; perf.turbo_cyc_out += p.turbo_cyc_out;
+  perf.turbo_cyc_rm += p.turbo_cyc_rm; perf.turbo_cyc_map += p.turbo_cyc_map; perf.turbo_cyc_out += p.turbo_cyc_out; perf.nof_turbo_iterations_run += p.nof_turbo_iterations_run;
   perf.nof_candidates_decoded += p.nof_candidates_decoded; perf.nof_ondemand_decodes += p.nof_ondemand_decodes; perf.nof_pdus += p.nof_pdus;
   for (int k = 0; k < 16; k++) { perf.kernel_ms[k] += p.kernel_ms[k]; perf.kernel_launches[k] += p.kernel_launches[k]; }
 }
@@ -522,7 +522,7 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
         const LsnCbRes& cr = r.h_cbres_pinned[t.cb_first + q];
         all_ok = all_ok && cr.ok != 0;
         j.iters += cr.iters;
-        pf.nof_turbo_iterations += cr.iters;
+        pf.nof_turbo_iterations += cr.iters; pf.nof_turbo_iterations_run += cr.iters_run;
         pf.turbo_cyc_rm += cr.cyc_rm; pf.turbo_cyc_map += cr.cyc_map; pf.turbo_cyc_out += cr.cyc_out;
         rem ^= crc24a_mulmod(cr.rem_a, crc24a_xpow(bits_after));
         bits_after += 8ull * r.h_cbs[t.cb_first + q].out_bytes;

@@ -92,7 +92,7 @@ struct LsnUlGrantDev {
   float scale;          // 1 / sqrt(M)
 };
 
-struct LsnCbRes { uint32_t ok, iters, rem_a, pad; uint32_t cyc_rm, cyc_map, cyc_out, cyc_all; };  // cyc_*: shader cycles per phase (s_memtime)
+struct LsnCbRes { uint32_t ok, iters, rem_a, iters_run; uint32_t cyc_rm, cyc_map, cyc_out, cyc_all; };  // cyc_*: shader cycles per phase (s_memtime)
 
 // launchers (stage_a.hip / stage_c.hip)
 void lsn_launch_ofdm(const LsnCellDev& c, const cf32* iq, const uint32_t* dphi, cf32* grid, uint32_t nsf, hipStream_t s);

@@ -441,8 +441,7 @@ __global__ __launch_bounds__(64) void k_viterbi(LsnCellDev c, const float* __res
   const int c0 = b ^ (__popc(s0 & 0x36) & 1), c1 = b ^ (__popc(s0 & 0x27) & 1), c2 = b ^ (__popc(s0 & 0x2B) & 1);
   int m = 0;
   const int T = (int)D3;  // 3 passes of D steps
-  for (int t = 0; t < T; t++) {
-    int tt = t % (int)D;
+  for (int t = 0, tt = 0; t < T; t++, tt = (tt + 1 == (int)D) ? 0 : tt + 1) {
     int q0 = sym[3 * tt], q1 = sym[3 * tt + 1], q2 = sym[3 * tt + 2];
     int bm0 = (c0 ? 255 - q0 : q0) + (c1 ? 255 - q1 : q1) + (c2 ? 255 - q2 : q2);
     int a0 = __shfl(m, s0) + bm0, a1 = __shfl(m, s0 | 32) + (765 - bm0);

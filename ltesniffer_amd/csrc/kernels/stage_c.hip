@@ -544,23 +544,46 @@ __global__ __launch_bounds__(NT) void k_turbo(const uint32_t* __restrict__ crc_t
 #pragma unroll
   for (int s = 0; s < 7; s++) { na1[s] = 0; nb1[s] = 0; na2[s] = 0; nb2[s] = 0; }
   int it = 0;
-  bool ok = false;
-  while (it < (int)cb.max_iter && !ok) {
+  bool ok = false, stuck = false;
+  uint32_t hp0 = 0, hp1 = 0;
+  while (it < (int)cb.max_iter && !ok && !stuck) {
     map_pass<false, NT>(m, lane, active, K, P, W, magicW, (int)cb.f1, (int)cb.f2, na1, nb1, bt1);
     map_pass<true, NT>(m, lane, active, K, P, W, magicW, (int)cb.f1, (int)cb.f2, na2, nb2, bt2);
     it++;
     // CRC over all K decided bits == 0  <=>  data || parity divisible by g(x): Horner over the thread's own window,
-    // then weighting with x^((P-1-window) W) and an XOR reduction over the windows
-    uint32_t rem = 0;
+    // then weighting with x^((P-1-window) W) and an XOR reduction over the windows.
+    // The same sweep fingerprints the decoder state that the next iteration starts from (all extrinsics + the
+    // window-boundary metrics): an iteration that reproduces its own input state is a fixed point of a deterministic
+    // map, every later iteration would return the same decisions, so a failing block can stop there with the result
+    // (and the reported iteration count) of the full max_iter run.
+    uint32_t rem = 0, h0 = 0, h1 = 0;
     if (active) {
       for (int t = 0; t < W; t++) {
-        rem = (rem << 1) | ((uint32_t)m.ext[t * P + lane] & 1u);
+        const uint32_t v = (uint32_t)(uint16_t)m.ext[t * P + lane];
+        rem = (rem << 1) | (v & 1u);
         rem ^= (rem & 0x1000000u) ? poly : 0u;
+        h0 = (h0 ^ v) * 0x9E3779B1u;
+        h1 = ((h1 << 7) | (h1 >> 25)) + (v ^ 0x5bd1e995u) * 0x85EBCA6Bu;
       }
       rem = mulmod24(rem, cw, poly);
+#pragma unroll
+      for (int s = 0; s < 7; s++) {
+        const uint32_t v0 = ((uint32_t)na1[s] & 0xFFFFu) | ((uint32_t)nb1[s] << 16), v1 = ((uint32_t)na2[s] & 0xFFFFu) | ((uint32_t)nb2[s] << 16);
+        h0 = (h0 ^ v0) * 0x9E3779B1u; h0 = (h0 ^ v1) * 0x9E3779B1u;
+        h1 = ((h1 << 7) | (h1 >> 25)) + (v0 ^ 0x5bd1e995u) * 0x85EBCA6Bu; h1 = ((h1 << 7) | (h1 >> 25)) + (v1 ^ 0x5bd1e995u) * 0x85EBCA6Bu;
+      }
+      h0 = (h0 ^ ((uint32_t)lane * 0xC2B2AE35u)) * 0x27D4EB2Fu; h0 ^= h0 >> 15;
+      h1 = (h1 + (uint32_t)lane * 0x165667B1u) * 0x9E3779B1u; h1 ^= h1 >> 13;
     }
     ok = wg_xor<NT>(rem, m.ckpt, lane) == 0;
+    if (!ok) {
+      h0 = wg_xor<NT>(h0, m.ckpt, lane); h1 = wg_xor<NT>(h1, m.ckpt, lane);
+      stuck = it > 1 && h0 == hp0 && h1 == hp1;
+      hp0 = h0; hp1 = h1;
+    }
   }
+  const int it_run = it;
+  if (stuck) it = (int)cb.max_iter;  // what the plain loop would have counted
   const long long tc2 = clock64();
   // ---- output: payload bytes of this code block + its CRC24A remainder contribution (each thread a contiguous run) ----
   const int nout = (int)cb.out_bytes;
@@ -582,7 +605,7 @@ __global__ __launch_bounds__(NT) void k_turbo(const uint32_t* __restrict__ crc_t
   rema = wg_xor<NT>(rema, m.ckpt, lane);
   if (lane == 0) {
     const long long tc3 = clock64();
-    LsnCbRes r; r.ok = ok ? 1u : 0u; r.iters = (uint32_t)it; r.rem_a = rema; r.pad = 0;
+    LsnCbRes r; r.ok = ok ? 1u : 0u; r.iters = (uint32_t)it; r.rem_a = rema; r.iters_run = (uint32_t)it_run;
     r.cyc_rm = (uint32_t)(tc1 - tc0); r.cyc_map = (uint32_t)(tc2 - tc1); r.cyc_out = (uint32_t)(tc3 - tc2); r.cyc_all = (uint32_t)(tc3 - tc0);
     res[cb.res_idx] = r;
   }
