@@ -150,7 +150,43 @@ int lsn_phy_set_ul_config(lsn_phy_t* phy, const lsn_ul_cfg_t* cfg);
  * payloads (may be NULL): decoded transport blocks, tbs/8 bytes each at results[i].payload_off. */
 int lsn_phy_pusch_decode(lsn_phy_t* phy, const void* ul_iq, int iq_on_device, uint32_t n_subframes, uint32_t start_tti,
                          const lsn_pusch_grant_t* grants, uint32_t n_grants, lsn_pusch_result_t* results, uint8_t* payloads, size_t payload_cap);
-long lsn_phy_tap_ul(lsn_phy_t* phy, int what /* 0: uplink grid of subframe `index` */, uint32_t index, void* out, size_t cap);
+long lsn_phy_tap_ul(lsn_phy_t* phy, int what /* 0: uplink grid of subframe `index`, 1: LLRs of grant `index`, 2: PRACH correlation power of occasion `index` */,
+                    uint32_t index, void* out, size_t cap);
+
+/* ---- uplink (PRACH) ----
+ * lsn_phy_set_prach_config replaces PUSCH_Decoder::set_rach_config (UL_Sniffer_PUSCH.cc:640-653: srsran_prach_init,
+ * srsran_prach_set_cfg, srsran_prach_set_detect_factor(60)); the fields are SIB2's prach-ConfigInfo as the reference copies
+ * them in ULSchedule::set_config (ULSchedule.cc:149-154).  lsn_phy_prach_detect replaces PUSCH_Decoder::work_prach
+ * (UL_Sniffer_PUSCH.cc:656-713: srsran_prach_tti_opportunity + srsran_prach_detect_offset on one uplink subframe) for a
+ * block of uplink subframes.  Scope: preamble format 0 (config_idx 0..15, the format that fits the one subframe the
+ * reference hands over), unrestricted cyclic shifts (hs_flag = 0); anything else is LSN_ERROR_INVALID_INPUTS.
+ * The logical->physical root map (TS 36.211 Table 5.7.2-4, srsRAN's prach_zc_roots[838]) is passed in by the caller;
+ * with zc_roots = NULL the numbers root_seq_idx + i (+1) are used as physical roots.
+ * In UL_MODE (sniffer_mode = 1) a configured detector also runs on the uplink antenna of every processed PRACH occasion
+ * and reports through the sink (the reference prints the strongest preamble there). */
+typedef struct {
+  uint32_t config_idx;       /* prach-ConfigIndex */
+  uint32_t root_seq_idx;     /* rootSequenceIndex 0..837 */
+  uint32_t zero_corr_zone;   /* zeroCorrelationZoneConfig 0..15 */
+  uint32_t freq_offset;      /* prach-FreqOffset: first of the 6 PRBs */
+  uint32_t hs_flag;          /* highSpeedFlag, must be 0 */
+  float detect_factor;       /* peak / mean threshold, 0 = 60 (UL_Sniffer_PUSCH.cc:651) */
+  const uint16_t* zc_roots;  /* 838 entries or NULL (only read during the call) */
+} lsn_prach_cfg_t;
+typedef struct {
+  uint32_t sf;        /* subframe index inside the block (tti = start_tti + sf) */
+  uint32_t preamble;  /* 0..63 */
+  uint32_t offset;    /* peak lag inside the cyclic-shift window, units of T_SEQ / 839 */
+  float offset_sec;   /* the same in seconds (srsran_prach_detect_offset's t_offsets) */
+  float p2avg;        /* peak / mean correlation power */
+} lsn_prach_det_t;
+typedef void (*lsn_prach_sink_t)(void* user, uint32_t tti, const lsn_prach_det_t* det, uint32_t n_det);
+int lsn_phy_set_prach_config(lsn_phy_t* phy, const lsn_prach_cfg_t* cfg);
+/* returns the number of detections written to out (<= cap), in (subframe, root, cyclic shift) order, or < 0 */
+int lsn_phy_prach_detect(lsn_phy_t* phy, const void* ul_iq, int iq_on_device, uint32_t n_subframes, uint32_t start_tti, lsn_prach_det_t* out,
+                         uint32_t cap);
+void lsn_phy_set_prach_sink(lsn_phy_t* phy, lsn_prach_sink_t cb, void* user);
+int lsn_prach_tti_opportunity(uint32_t config_idx, uint32_t tti); /* srsran_prach_tti_opportunity(p, tti, -1), format 0 */
 
 /* ---- measurement + parity taps (not part of the reference surface) ---- */
 enum { LSN_TAP_GRID = 0, LSN_TAP_CE = 1, LSN_TAP_PDCCH_LLR = 2, LSN_TAP_CHEST = 3, LSN_TAP_CFI = 4, LSN_TAP_CANDIDATES = 5,

@@ -37,12 +37,12 @@ class Phy {
 public:
   // Phy.h:24-36.  dciFileName / statsFileName / HARQ* / ULSchedule* of the reference are not consumed by this path.
   Phy(uint32_t nof_rx_antennas, uint32_t nof_workers, bool skipSecondaryMetaFormats, double metaFormatSplitRatio, uint32_t histogramThreshold,
-      lsn_pcap_t* pcapwriter, int mcs_tracking_mode = 1, int harq_mode = 0, int device = 0)
+      lsn_pcap_t* pcapwriter, int mcs_tracking_mode = 1, int harq_mode = 0, int device = 0, int sniffer_mode = 0 /* DL_MODE; 1 = UL_MODE */)
   {
     lsn_phy_cfg_t cfg{};
     cfg.nof_rx_antennas = nof_rx_antennas; cfg.nof_workers = nof_workers; cfg.skip_secondary_meta_formats = skipSecondaryMetaFormats;
     cfg.meta_format_split_ratio = metaFormatSplitRatio; cfg.histogram_threshold = histogramThreshold;
-    cfg.mcs_tracking_mode = mcs_tracking_mode; cfg.harq_mode = harq_mode; cfg.device = device;
+    cfg.mcs_tracking_mode = mcs_tracking_mode; cfg.harq_mode = harq_mode; cfg.device = device; cfg.sniffer_mode = sniffer_mode;
     const int r = lsn_phy_create(&cfg, &h);
     if (r == LSN_ERROR_NO_DEVICE) throw std::runtime_error("ltesniffer_amd: no HIP device (this library has no CPU path)");
     if (r != LSN_SUCCESS) throw std::runtime_error("lsn_phy_create failed");
@@ -60,6 +60,14 @@ public:
   void setPduSink(lsn_pdu_sink_t cb, void* user) { lsn_phy_set_pdu_sink(h, cb, user); }
   lsn_blind_stats_t getStats() { lsn_blind_stats_t s{}; lsn_phy_get_stats(h, &s); return s; }              // PhyCommon::getStats
   float getEstCfo() { return lsn_phy_get_est_cfo(h); }                                                      // SubframeWorker.cc:203
+  // UL_MODE: what ULSchedule::set_config hands to the workers once SIB2 is known (ULSchedule.cc:140-158)
+  bool setUlConfig(uint32_t cyclicShift, uint32_t groupAssignmentPUSCH)                                    // SubframeWorker.cc:258-262
+  {
+    lsn_ul_cfg_t u{cyclicShift, groupAssignmentPUSCH};
+    return lsn_phy_set_ul_config(h, &u) == LSN_SUCCESS;
+  }
+  bool setRachConfig(const lsn_prach_cfg_t& p) { return lsn_phy_set_prach_config(h, &p) == LSN_SUCCESS; }    // PUSCH_Decoder::set_rach_config
+  void setPrachSink(lsn_prach_sink_t cb, void* user) { lsn_phy_set_prach_sink(h, cb, user); }               // work_prach's report
   lsn_phy_t* handle() { return h; }
 private:
   static std::shared_ptr<SubframeWorker> wrap(lsn_worker_t* w) { return w ? std::shared_ptr<SubframeWorker>(new SubframeWorker(w)) : nullptr; }

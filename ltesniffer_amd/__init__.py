@@ -30,7 +30,22 @@ EXPORTS = ["lsn_phy_create", "lsn_phy_destroy", "lsn_phy_set_cell", "lsn_phy_get
            "lsn_phy_get_perf", "lsn_kernel_name", "lsn_version", "lsn_pcap_open", "lsn_pcap_open_mem",
            "lsn_pcap_set_wall_clock", "lsn_pcap_write", "lsn_pcap_sink", "lsn_pcap_mem", "lsn_pcap_nof_records",
            "lsn_pcap_reset", "lsn_pcap_close", "lsn_phy_set_pcap_writer", "lsn_phy_set_ul_config", "lsn_phy_pusch_decode",
-           "lsn_phy_tap_ul"]
+           "lsn_phy_tap_ul", "lsn_phy_set_prach_config", "lsn_phy_prach_detect", "lsn_phy_set_prach_sink", "lsn_prach_tti_opportunity"]
+
+
+PRACH_NCS = [0, 13, 15, 18, 22, 26, 32, 38, 46, 59, 76, 93, 119, 167, 279, 419]  # 36.211 Table 5.7.2-2
+
+
+class PrachCfg(C.Structure):
+    _fields_ = [("config_idx", C.c_uint32), ("root_seq_idx", C.c_uint32), ("zero_corr_zone", C.c_uint32), ("freq_offset", C.c_uint32),
+                ("hs_flag", C.c_uint32), ("detect_factor", C.c_float), ("zc_roots", C.POINTER(C.c_uint16))]
+
+
+class PrachDet(C.Structure):
+    _fields_ = [("sf", C.c_uint32), ("preamble", C.c_uint32), ("offset", C.c_uint32), ("offset_sec", C.c_float), ("p2avg", C.c_float)]
+
+
+PRACH_SINK = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.POINTER(PrachDet), C.c_uint32)
 
 
 class Cell(C.Structure):
@@ -177,6 +192,11 @@ def lib():
                                            C.c_void_p, C.c_size_t]
         L.lsn_phy_tap_ul.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_size_t]
         L.lsn_phy_tap_ul.restype = C.c_long
+        L.lsn_phy_set_prach_config.argtypes = [C.c_void_p, C.POINTER(PrachCfg)]
+        L.lsn_phy_prach_detect.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(PrachDet), C.c_uint32]
+        L.lsn_phy_set_prach_sink.argtypes = [C.c_void_p, PRACH_SINK, C.c_void_p]
+        L.lsn_phy_set_prach_sink.restype = None
+        L.lsn_prach_tti_opportunity.argtypes = [C.c_uint32, C.c_uint32]
         _lib = L
     return _lib
 
@@ -185,6 +205,12 @@ def _check(rc, what):
     if rc != LSN_SUCCESS:
         raise RuntimeError("%s failed: %d%s" % (what, rc, " (no HIP device: this library has no CPU path)"
                                                 if rc == LSN_ERROR_NO_DEVICE else ""))
+
+
+def _check_n(rc, what):
+    if rc < 0:
+        _check(rc, what)
+    return rc
 
 
 class PcapWriter:
@@ -343,6 +369,38 @@ class Phy:
         if nb < 0:
             raise RuntimeError("tap_ul failed: %d" % nb)
         return buf[: nb // 2]
+
+    # ---- PRACH ----
+    def setPrachConfig(self, config_idx, root_seq_idx, zero_corr_zone, freq_offset, hs_flag=0, detect_factor=0.0, zc_roots=None):
+        """PUSCH_Decoder::set_rach_config; zc_roots: 838 uint16 (36.211 Table 5.7.2-4) or None"""
+        zc = np.ascontiguousarray(zc_roots, dtype=np.uint16) if zc_roots is not None else None
+        p = PrachCfg(config_idx, root_seq_idx, zero_corr_zone, freq_offset, hs_flag, detect_factor,
+                     zc.ctypes.data_as(C.POINTER(C.c_uint16)) if zc is not None else None)
+        nwin = 839 // PRACH_NCS[zero_corr_zone] if 0 < zero_corr_zone < 16 else 1
+        self._prach_nroots = (64 + nwin - 1) // nwin
+        return lib().lsn_phy_set_prach_config(self._h, C.byref(p)) == LSN_SUCCESS
+
+    def prach_detect(self, ul_iq, start_tti, cap=256):
+        """PUSCH_Decoder::work_prach over ul_iq complex64 [n_subframes, 15*N] -> list of dict(sf, preamble, offset, offset_sec, p2avg)"""
+        ul_iq = np.ascontiguousarray(ul_iq, dtype=np.complex64)
+        det = (PrachDet * cap)()
+        n = _check_n(lib().lsn_phy_prach_detect(self._h, ul_iq.ctypes.data, 0, ul_iq.shape[0], start_tti, det, cap), "prach_detect")
+        return [dict(sf=int(d.sf), preamble=int(d.preamble), offset=int(d.offset), offset_sec=float(d.offset_sec), p2avg=float(d.p2avg)) for d in det[:n]]
+
+    def set_prach_sink(self, fn):
+        """fn(tti, [dict(...)]) for every PRACH occasion with detections while UL_MODE batches are processed"""
+        def tramp(_user, tti, det, n):
+            fn(int(tti), [dict(sf=int(det[i].sf), preamble=int(det[i].preamble), offset=int(det[i].offset), offset_sec=float(det[i].offset_sec),
+                               p2avg=float(det[i].p2avg)) for i in range(n)])
+        self._prach_cb = PRACH_SINK(tramp) if fn else PRACH_SINK()
+        lib().lsn_phy_set_prach_sink(self._h, self._prach_cb, None)
+
+    def tap_prach_corr(self, occasion):
+        buf = np.zeros(self._prach_nroots * 839, dtype=np.float32)
+        nb = lib().lsn_phy_tap_ul(self._h, 2, occasion, buf.ctypes.data, buf.nbytes)
+        if nb < 0:
+            raise RuntimeError("tap_ul failed: %d" % nb)
+        return buf.reshape(self._prach_nroots, 839)
 
     # ---- taps / stats ----
     def tap(self, what, sf, dtype, count):

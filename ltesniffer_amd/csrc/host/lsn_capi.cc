@@ -263,8 +263,24 @@ int lsn_phy_pusch_decode(lsn_phy_t* phy, const void* ul_iq, int iq_on_device, ui
 long lsn_phy_tap_ul(lsn_phy_t* phy, int what, uint32_t index, void* out, size_t cap)
 {
   if (!phy || !out) return LSN_ERROR_INVALID_INPUTS;
+  if (what == 2) return phy->engine->tapPrach(index, out, cap);
   return phy->engine->tapUl(what, index, out, cap);
 }
+int lsn_phy_set_prach_config(lsn_phy_t* phy, const lsn_prach_cfg_t* cfg)
+{
+  if (!phy || !cfg) return LSN_ERROR_INVALID_INPUTS;
+  return phy->engine->setPrachConfig(*cfg);
+}
+int lsn_phy_prach_detect(lsn_phy_t* phy, const void* ul_iq, int iq_on_device, uint32_t n_subframes, uint32_t start_tti, lsn_prach_det_t* out, uint32_t cap)
+{
+  if (!phy) return LSN_ERROR_INVALID_INPUTS;
+  return phy->engine->prachDetect(ul_iq, iq_on_device != 0, n_subframes, start_tti, out, cap);
+}
+void lsn_phy_set_prach_sink(lsn_phy_t* phy, lsn_prach_sink_t cb, void* user)
+{
+  if (phy) phy->engine->setPrachSink(cb, user);
+}
+int lsn_prach_tti_opportunity(uint32_t config_idx, uint32_t tti) { return lsn::prach_tti_opportunity(config_idx, tti) ? 1 : 0; }
 
 long lsn_phy_tap(lsn_phy_t* phy, int what, uint32_t sf, void* out, size_t cap)
 {

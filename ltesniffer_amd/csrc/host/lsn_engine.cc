@@ -170,6 +170,7 @@ void Engine::launchStageA(Chunk& ch, const void* d_iq)
   for (uint32_t i = 0; i < nsf; i++) ch.h_sfidx[i] = ch.ctx[i].sf_idx;
   HIP_CHECK(hipMemcpyAsync(ch.d_sfidx, ch.h_sfidx, nsf * sizeof(uint32_t), hipMemcpyHostToDevice, st));
   const cf32* iq = (const cf32*)d_iq;
+  ch.d_iq_src = iq;
   int n = 0;
   auto timed = [&](auto&& fn) {
     HIP_CHECK(hipEventRecord(ch.ev_a[2 * n], st));

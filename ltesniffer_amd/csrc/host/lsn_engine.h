@@ -34,6 +34,7 @@ struct DecodeJob {
 struct Chunk {
   uint32_t nsf = 0, start_tti = 0;
   cf32 *d_grid = nullptr, *d_ce = nullptr, *d_ul_grid = nullptr;
+  const cf32* d_iq_src = nullptr;    // the caller's samples of this chunk ([sf][antenna][sflen]), valid until the call returns
   float *d_chest_raw = nullptr, *d_llr = nullptr, *d_ccepow = nullptr, *d_pcfich_corr = nullptr, *d_rbp = nullptr;
   LsnChest* d_chest = nullptr;
   uint32_t *d_cfi = nullptr, *d_sfidx = nullptr;
@@ -91,6 +92,10 @@ public:
   int puschDecode(const void* ul_iq, bool on_device, uint32_t nsf, uint32_t start_tti, const lsn_pusch_grant_t* grants, uint32_t ngrants,
                   lsn_pusch_result_t* results, uint8_t* payloads, size_t payload_cap);
   long tapUl(int what, uint32_t index, void* out, size_t cap);
+  int setPrachConfig(const lsn_prach_cfg_t& p);
+  int prachDetect(const void* ul_iq, bool on_device, uint32_t nsf, uint32_t start_tti, lsn_prach_det_t* out, uint32_t cap);
+  long tapPrach(uint32_t index, void* out, size_t cap);
+  void setPrachSink(lsn_prach_sink_t cb, void* user) { prach_sink = cb; prach_sink_user = user; }
   void forceMetaUpdateNext() { force_meta_next = true; }
 
 private:
@@ -111,6 +116,7 @@ private:
   void ensureJob(Chunk& ch, JobRunner& r, int j);
   void commitChunk(Chunk& ch, JobRunner& r);
   void commitChunkUl(Chunk& ch, JobRunner& r);
+  void prachDetectDev(const cf32* d_iq, uint32_t nant, uint32_t ant, uint32_t nsf, uint32_t start_tti, std::vector<lsn_prach_det_t>& out);
   void puschDecodeGrid(const cf32* d_grid, uint32_t nsf, uint32_t start_tti, const lsn_pusch_grant_t* grants, uint32_t ngrants,
                        lsn_pusch_result_t* results, std::vector<uint8_t>& payload_out);
   // RA-RNTI grants whose content feeds the RNTI manager: DL mode 2..9 (rnti_name == RA_RNTI, DL_Sniffer_PDSCH.cc:1409), UL mode 1..10 (:373)
@@ -179,9 +185,22 @@ private:
   JobRunner runner_u;
   cf32 *ul_d_iq = nullptr, *ul_d_grid = nullptr, *ul_d_hs = nullptr; float* ul_d_stat = nullptr; LsnUlGrantDev* ul_d_grants = nullptr;
   size_t ul_iq_cap = 0, ul_grid_cap = 0, ul_hs_cap = 0, ul_stat_cap = 0, ul_grants_cap = 0;
+  struct Prach {
+    bool set = false;
+    lsn_prach_cfg_t cfg{};
+    float factor = 60.0f;
+    uint32_t ncs = 0, nwin = 1, nroots = 1, last_nocc = 0;
+    int N12 = 0, Ncp = 0, b0 = 0;
+    cf32 *d_W = nullptr, *d_V = nullptr, *d_D = nullptr, *d_Y = nullptr;
+    float *d_corr = nullptr, *d_out = nullptr;
+    uint64_t* d_off = nullptr;
+    size_t off_cap = 0, y_cap = 0, corr_cap = 0, out_cap = 0;
+  } prach;
+  lsn_prach_sink_t prach_sink = nullptr; void* prach_sink_user = nullptr;
   std::vector<int> numa_cpus;  // CPUs local to the GPU (empty: unknown, no pinning)
 };
 
+bool prach_tti_opportunity(uint32_t config_idx, uint32_t tti);  // lsn_prach.cc
 // table builders (lsn_tables.cc)
 void gold_sequence(uint32_t cinit, uint8_t* c, int len);
 

@@ -69,6 +69,8 @@ void Engine::freeDevice()
     df(ul_d_iq); df(ul_d_grid); df(ul_d_hs); df(ul_d_stat); df(ul_d_grants);
     ul_iq_cap = ul_grid_cap = ul_hs_cap = ul_stat_cap = ul_grants_cap = 0;
     ul_set = false;
+    df(prach.d_W); df(prach.d_V); df(prach.d_D); df(prach.d_Y); df(prach.d_corr); df(prach.d_out); df(prach.d_off);
+    prach = Prach();
   }
   d_dphi = nullptr; d_iq_staging = nullptr; staging_sf = 0;
   last_chunk = nullptr;

@@ -29,6 +29,18 @@ void Engine::commitChunkUl(Chunk& ch, JobRunner& r)
   std::vector<std::vector<PendingPdu>> out(nsf);            // records per subframe: downlink first, then uplink
   std::vector<std::vector<UlSchedGrant>> lists(nsf);        // PUSCH grants to try in each subframe
 
+  // ---- PRACH occasions of this chunk (PUSCH_Decoder::work_prach, UL_Sniffer_PUSCH.cc:656-713; no effect on the pcap) ----
+  if (prach.set && ch.d_iq_src) {
+    std::vector<lsn_prach_det_t> det;
+    prachDetectDev(ch.d_iq_src, cd.iq_nant, 1, nsf, ch.start_tti, det);
+    for (size_t a = 0; a < det.size();) {
+      size_t b = a;
+      while (b < det.size() && det[b].sf == det[a].sf) b++;
+      if (prach_sink) prach_sink(prach_sink_user, (ch.start_tti + det[a].sf) % 10240u, det.data() + a, (uint32_t)(b - a));
+      a = b;
+    }
+  }
+
   // ---- phase 1 (sequential): downlink part + schedule bookkeeping ----
   for (uint32_t sf = 0; sf < nsf; sf++) {
     SubframeCtx& c = ch.ctx[sf];

@@ -197,3 +197,93 @@ void lsn_launch_pusch_demod(const LsnCellDev& c, const LsnUlGrantDev* g, const c
 {
   hipLaunchKernelGGL(k_pusch_demod, dim3(12, ngrants), dim3(256), sizeof(cf32) * 2 * 1200, s, c, g, grid, hs, stat, llr);
 }
+
+// ------------------------------------------------------------------------------------------------ PRACH detection
+// srsran_prach_detect_offset (/root/reference/src/src/UL_Sniffer_PUSCH.cc:690) for preamble format 0, three kernels:
+//   k_prach_bins : the 839 PRACH bins of the 12N-point DFT of the samples behind the CP (one workgroup per bin: 256
+//                  interleaved partial sums, fixed tree) - only 839 of the 12N outputs are needed, so no full FFT
+//   k_prach_corr : bins x conj(root spectrum), 839-point inverse DFT (one workgroup per lag), |.|^2
+//   k_prach_peaks: mean of the correlation power + the peak of every cyclic-shift window
+// The threshold test and the result list are host work (a few dozen floats per occasion).
+#define LSN_NZC 839
+
+// fixed 256-leaf tree of the oracle's o_reduce256 on two arrays at once; result valid in thread 0
+__device__ __forceinline__ void tree256_2(float* pr, float* pi, int tid)
+{
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) { pr[tid] = pr[tid] + pr[tid + s]; pi[tid] = pi[tid] + pi[tid + s]; }
+    __syncthreads();
+  }
+}
+
+// grid (839, nocc).  occ_off[o]: cf32 offset of the uplink subframe of occasion o inside iq; W[i] = exp(-2 pi j i / N12)
+__global__ __launch_bounds__(256) void k_prach_bins(const cf32* __restrict__ iq, const uint64_t* __restrict__ occ_off, const cf32* __restrict__ W,
+                                                    int N12, int Ncp, int b0, cf32* __restrict__ Y)
+{
+  __shared__ float pr[256], pi[256];
+  const int j = blockIdx.x, o = blockIdx.y, tid = threadIdx.x;
+  const cf32* x = iq + occ_off[o] + Ncp;
+  const int b = ((b0 + j) % N12 + N12) % N12;
+  int idx = (int)((long long)b * tid % N12);
+  const int step = (int)((long long)b * 256 % N12);
+  float ar = 0.0f, ai = 0.0f;
+  for (int n = tid; n < N12; n += 256) {
+    const cf32 p = cmul(x[n], W[idx]);
+    ar = ar + p.r; ai = ai + p.i;
+    idx += step; idx = idx >= N12 ? idx - N12 : idx;
+  }
+  pr[tid] = ar; pi[tid] = ai;
+  tree256_2(pr, pi, tid);
+  if (tid == 0) { cf32 y; y.r = pr[0]; y.i = pi[0]; Y[(size_t)o * LSN_NZC + j] = y; }
+}
+
+// grid (839 lags, nroots, nocc).  D[root][839]: DFT of the root sequence, V[m] = exp(+2 pi j m / 839)
+__global__ __launch_bounds__(256) void k_prach_corr(const cf32* __restrict__ Y, const cf32* __restrict__ D, const cf32* __restrict__ V, int nroots,
+                                                    float* __restrict__ corr)
+{
+  __shared__ float pr[256], pi[256];
+  const int k = blockIdx.x, root = blockIdx.y, o = blockIdx.z, tid = threadIdx.x;
+  const cf32* y = Y + (size_t)o * LSN_NZC;
+  const cf32* d = D + (size_t)root * LSN_NZC;
+  float ar = 0.0f, ai = 0.0f;
+  for (int j = tid; j < LSN_NZC; j += 256) {
+    const cf32 p = cmul(cmulconj(y[j], d[j]), V[(j * k) % LSN_NZC]);
+    ar = ar + p.r; ai = ai + p.i;
+  }
+  pr[tid] = ar; pi[tid] = ai;
+  tree256_2(pr, pi, tid);
+  if (tid == 0) corr[((size_t)o * nroots + root) * LSN_NZC + k] = pr[0] * pr[0] + pi[0] * pi[0];
+}
+
+// grid (nroots, nocc).  out[(o * nroots + root) * 130 + {0: mean, 1: unused, 2 + 2 w: peak of window w, 3 + 2 w: its lag}]
+__global__ __launch_bounds__(256) void k_prach_peaks(const float* __restrict__ corr, int nroots, int ncs, int nwin, float* __restrict__ out)
+{
+  __shared__ float pr[256], pi[256];
+  const int root = blockIdx.x, o = blockIdx.y, tid = threadIdx.x;
+  const float* c = corr + ((size_t)o * nroots + root) * LSN_NZC;
+  float* res = out + ((size_t)o * nroots + root) * 130;
+  float p = 0.0f;
+  for (int i = tid; i < LSN_NZC; i += 256) p = p + c[i];
+  pr[tid] = p; pi[tid] = 0.0f;
+  tree256_2(pr, pi, tid);
+  if (tid == 0) { res[0] = pr[0] / (float)LSN_NZC; res[1] = 0.0f; }
+  if (tid < nwin && tid < 64) {
+    const int start = (LSN_NZC - tid * ncs) % LSN_NZC, win = ncs ? ncs : LSN_NZC;
+    float peak = 0.0f; int off = 0;
+    for (int k = 0; k < win; k++) {
+      const float v = c[start + k];
+      if (v > peak) { peak = v; off = k; }
+    }
+    res[2 + 2 * tid] = peak; res[3 + 2 * tid] = (float)off;
+  }
+}
+
+void lsn_launch_prach(const cf32* iq, const uint64_t* occ_off, uint32_t nocc, const cf32* W, const cf32* D, const cf32* V, int N12, int Ncp, int b0,
+                      int nroots, int ncs, int nwin, cf32* Y, float* corr, float* out, hipStream_t s)
+{
+  if (!nocc) return;
+  hipLaunchKernelGGL(k_prach_bins, dim3(LSN_NZC, nocc), dim3(256), 0, s, iq, occ_off, W, N12, Ncp, b0, Y);
+  hipLaunchKernelGGL(k_prach_corr, dim3(LSN_NZC, nroots, nocc), dim3(256), 0, s, Y, D, V, nroots, corr);
+  hipLaunchKernelGGL(k_prach_peaks, dim3(nroots, nocc), dim3(256), 0, s, corr, nroots, ncs, nwin, out);
+}

@@ -193,6 +193,20 @@ int o_pdsch_decode_tb(const int16_t* e, int G, int tbs, int Qm, int nof_layers_r
                       uint8_t* payload, int* iters_total);
 int o_turbo_nwin(int K);
 
+/* ---------- uplink: PRACH detection (o_prach.c) ---------- */
+typedef struct {
+  uint32_t config_idx, root_seq_idx, zero_corr_zone, freq_offset, hs_flag; /* SIB2 prach-ConfigInfo (ULSchedule.cc:149-154) */
+  float detect_factor;                                                     /* 0 -> 60 (UL_Sniffer_PUSCH.cc:651) */
+  const uint16_t* zc_roots;                                                /* 36.211 Table 5.7.2-4 (838 entries) or NULL */
+} o_prach_cfg_t;
+typedef struct { uint32_t preamble, offset; float offset_sec, p2avg; } o_prach_det_t;
+uint32_t o_prach_ncs(uint32_t zero_corr_zone);
+uint32_t o_prach_nof_roots(uint32_t zero_corr_zone);
+int o_prach_tti_opportunity(uint32_t config_idx, uint32_t tti);
+int o_prach_first_bin(uint32_t nof_prb, uint32_t freq_offset);
+void o_prach_root_spectrum(uint32_t u, ocf_t* D);
+int o_prach_detect(const o_cell_t* cell, const o_prach_cfg_t* cfg, const ocf_t* samples, o_prach_det_t* out, int cap, float* corr_out);
+
 /* ---------- uplink: SC-FDMA demodulation + PUSCH (o_pusch.c) ---------- */
 typedef struct { uint32_t cyclic_shift; /* SIB2 cyclicShift 0..7 */ uint32_t delta_ss; /* SIB2 groupAssignmentPUSCH 0..29 */ } o_ul_cfg_t;
 int o_ul_valid_prb(uint32_t L);

@@ -474,3 +474,58 @@ def gen_ul_mode_subframes(sc, n, cyclic_shift=3, delta_ss=5, ul_snr_db=30.0):
                 if tbs > 0:
                     pending.setdefault((tti + 4) % 10240, []).append(dict(rnti=p["rnti"], n_dmrs=0, n_prb=p["n_prb"], L_prb=p["nof_prb"], mod=qm, tbs=tbs, rv=0))
     return tti0, iq, sent
+
+
+# ---------------------------------------------------------------------------------------------------- PRACH
+PRACH_NCS = [0, 13, 15, 18, 22, 26, 32, 38, 46, 59, 76, 93, 119, 167, 279, 419]  # 36.211 Table 5.7.2-2 (unrestricted)
+
+
+class OPrachCfg(C.Structure):
+    _fields_ = [("config_idx", C.c_uint32), ("root_seq_idx", C.c_uint32), ("zero_corr_zone", C.c_uint32), ("freq_offset", C.c_uint32),
+                ("hs_flag", C.c_uint32), ("detect_factor", C.c_float), ("zc_roots", C.POINTER(C.c_uint16))]
+
+
+class OPrachDet(C.Structure):
+    _fields_ = [("preamble", C.c_uint32), ("offset", C.c_uint32), ("offset_sec", C.c_float), ("p2avg", C.c_float)]
+
+
+def oracle_prach_api():
+    o = oracle()
+    o.o_prach_detect.argtypes = [C.POINTER(OCell), C.POINTER(OPrachCfg), C.c_void_p, C.POINTER(OPrachDet), C.c_int, C.c_void_p]
+    o.o_prach_tti_opportunity.argtypes = [C.c_uint32, C.c_uint32]
+    o.o_prach_nof_roots.argtypes = [C.c_uint32]
+    o.o_prach_nof_roots.restype = C.c_uint32
+    return o
+
+
+def prach_preamble(nof_prb, u, cv, freq_offset):
+    """36.211 5.7.3 baseband PRACH signal, preamble format 0, physical root u, cyclic shift C_v = cv, at the cell's sample
+    rate (N_cp + 12 N samples, unit mean power) - an independent transmitter (numpy FFTs in double)"""
+    nsym = oracle().o_fft_size(nof_prb)
+    n_seq, n_cp = 12 * nsym, 3168 * nsym // 2048
+    n = np.arange(839, dtype=np.int64)
+    x = np.exp(-1j * np.pi * ((u * n * (n + 1)) % (2 * 839)) / 839.0)
+    spec = np.fft.fft(x[(n + cv) % 839])
+    b0 = 7 + 12 * (12 * freq_offset - 6 * nof_prb) + 6
+    full = np.zeros(n_seq, dtype=np.complex128)
+    full[(b0 + n) % n_seq] = spec
+    s = np.fft.ifft(full)
+    s /= np.sqrt(np.mean(np.abs(s) ** 2))
+    return np.concatenate([s[-n_cp:], s])
+
+
+def prach_subframe(nof_prb, ues, snr_db=10.0, seed=1, zero_corr_zone=5, root_seq_idx=10, freq_offset=4, zc_roots=None):
+    """one uplink subframe (15 N samples) with the PRACH preambles of `ues` = [(preamble index, delay in samples, gain dB)]
+    on top of unit-power noise scaled to snr_db below a 0 dB preamble"""
+    sf_len = 15 * oracle().o_fft_size(nof_prb)
+    rng = np.random.default_rng(seed)
+    sigma = 10.0 ** (-snr_db / 20.0)
+    iq = (rng.standard_normal(sf_len) + 1j * rng.standard_normal(sf_len)) * (sigma / np.sqrt(2.0))
+    ncs = PRACH_NCS[zero_corr_zone]
+    nwin = 839 // ncs if ncs else 1
+    for idx, delay, gain_db in ues:
+        lr = (root_seq_idx + idx // nwin) % 838
+        u = int(zc_roots[lr]) if zc_roots is not None else lr + 1
+        p = prach_preamble(nof_prb, u, (idx % nwin) * ncs, freq_offset) * 10.0 ** (gain_db / 20.0)
+        iq[delay:delay + len(p)] += p[:sf_len - delay]
+    return iq.astype(np.complex64)
