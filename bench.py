@@ -104,7 +104,7 @@ def main():
     algo_bytes = 0
     npdus = 0
     acc = {k: 0 for k in ("nof_tb_decodes", "nof_cb_decodes", "nof_turbo_iterations", "nof_turbo_iterations_run", "nof_ondemand_decodes", "turbo_cyc_rm",
-                          "turbo_cyc_map", "turbo_cyc_out", "ms_stage_a", "ms_search", "ms_search_core", "ms_rar", "ms_stage_c", "ms_commit")}
+                          "turbo_cyc_map", "turbo_cyc_out", "ms_stage_a", "ms_search", "ms_search_core", "ms_rar", "ms_stage_c", "ms_commit", "ms_wait_front", "ms_wait_slot", "ms_drain")}
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)
@@ -150,6 +150,24 @@ def main():
                     traffic_src = os.path.relpath(cand[-1], ROOT)
         except Exception:
             pass
+        # secondary view (the recursions are integer-VALU work, not HBM work): wave-level VALU instructions per launch from a
+        # separate rocprofv3 --pmc SQ_INSTS_VALU pass (tools/pmc_valu_summary.py -> profiles/*_pmc_valu.json) over this run's launch time,
+        # against the plain-VOP2 issue peak measured on this chip by tools/ubench/valu_rate (profiles/*_valu_ubench.txt)
+        valu = None
+        try:
+            cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_valu.json")))
+            if cand:
+                vj = json.load(open(cand[-1]))
+                pj = vj.get(la.KERNELS[kt])
+                if pj and klaunch[kt] > 0 and kms[kt] > 0:
+                    g = pj["valu_insts_per_launch"] / (kms[kt] / klaunch[kt] * 1e6)
+                    valu = {"wave_insts_per_launch": int(pj["valu_insts_per_launch"]), "achieved_G_per_s": round(g, 1),
+                            "peak_G_per_s": vj.get("_peak_G_wave_insts_per_s", 740.0), "frac": round(g / vj.get("_peak_G_wave_insts_per_s", 740.0), 4),
+                            "all_kernels_wave_insts_per_subframe": int(sum(v["valu_insts_total"] for k, v in vj.items() if not k.startswith("_") and (k.startswith("k_"))) /
+                                                                       max(1, vj.get("_subframes", 3 * 6400))),
+                            "source": os.path.relpath(cand[-1], ROOT)}
+        except Exception:
+            pass
         out = {
             "metric": "subframes/s (20 MHz, 150 RNTIs)", "value": round(value, 1), "unit": "subframes/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
@@ -163,7 +181,7 @@ def main():
                          "frac": round(ach / 8000.0, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": round(kms[kt] / max(1, klaunch[kt]), 4), "launches": int(klaunch[kt]),
                          "algo_bytes_per_launch": int(kbytes / max(1, klaunch[kt])),
-                         "dominant_by_time": la.KERNELS[dom]},
+                         "dominant_by_time": la.KERNELS[dom], "valu": valu},
             "cpu_baseline": cpu, "host": {"cpu_count": os.cpu_count()},
             "detail": {"pdus_per_step": npdus / args.steps, "algo_bytes_per_subframe": int(algo_bytes / (args.steps * nsf)),
                        "whole_path_GBps": round(algo_bytes / 1e9 / dt, 2),

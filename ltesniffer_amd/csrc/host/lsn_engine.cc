@@ -94,11 +94,11 @@ Engine::Engine(const lsn_phy_cfg_t& c) : cfg(c)
   {
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    HIP_CHECK(hipStreamCreateWithPriority(&stream_a, hipStreamNonBlocking, hi));  // stage A feeds the sequential search
+    for (auto& sa : stream_a) HIP_CHECK(hipStreamCreateWithPriority(&sa, hipStreamNonBlocking, hi));  // stage A feeds the sequential search
   }
   HIP_CHECK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
   if (const char* e = getenv("LSN_DECODE_THREADS")) ndec = std::max(1, std::min((int)NDEC, atoi(e)));
-  nslots = ndec + 3;
+  nslots = ndec + 5;
   front_thread = std::thread([this] { frontLoop(); });
   for (int i = 0; i < ndec; i++) decode_threads[i] = std::thread([this, i] { decodeLoop(i); });
 }
@@ -116,7 +116,8 @@ Engine::~Engine()
     if (t.joinable()) t.join();
   (void)hipDeviceSynchronize();
   freeDevice();
-  if (stream_a) (void)hipStreamDestroy(stream_a);
+  for (auto& sa : stream_a)
+    if (sa) (void)hipStreamDestroy(sa);
   if (ev_in) (void)hipEventDestroy(ev_in);
 }
 
@@ -157,7 +158,7 @@ void Engine::mergePerf(const lsn_perf_t& p)
   perf.algo_bytes += p.algo_bytes; perf.turbo_algo_bytes += p.turbo_algo_bytes; perf.turbo128_algo_bytes += p.turbo128_algo_bytes;
   perf.nof_tb_decodes += p.nof_tb_decodes; perf.nof_cb_decodes += p.nof_cb_decodes; perf.nof_turbo_iterations += p.nof_turbo_iterations;
   perf.ms_search_core += p.ms_search_core; perf.ms_rar += p.ms_rar;
-  perf.turbo_cyc_rm += p.turbo_cyc_rm; perf.turbo_cyc_map += p.turbo_cyc_map; perf.turbo_cyc_out += p.turbo_cyc_out; perf.nof_turbo_iterations_run += p.nof_turbo_iterations_run;
+  perf.turbo_cyc_rm += p.turbo_cyc_rm; perf.turbo_cyc_map += p.turbo_cyc_map; perf.turbo_cyc_out += p.turbo_cyc_out; perf.nof_turbo_iterations_run += p.nof_turbo_iterations_run; perf.ms_wait_slot += p.ms_wait_slot;
   perf.nof_candidates_decoded += p.nof_candidates_decoded; perf.nof_ondemand_decodes += p.nof_ondemand_decodes; perf.nof_pdus += p.nof_pdus;
   for (int k = 0; k < 16; k++) { perf.kernel_ms[k] += p.kernel_ms[k]; perf.kernel_launches[k] += p.kernel_launches[k]; }
 }
@@ -165,7 +166,7 @@ void Engine::mergePerf(const lsn_perf_t& p)
 // ------------------------------------------------------------------------------------------------ stage A
 void Engine::launchStageA(Chunk& ch, const void* d_iq)
 {
-  hipStream_t st = stream_a;
+  hipStream_t st = ch.st_a;
   const uint32_t nsf = ch.nsf;
   for (uint32_t i = 0; i < nsf; i++) ch.h_sfidx[i] = ch.ctx[i].sf_idx;
   HIP_CHECK(hipMemcpyAsync(ch.d_sfidx, ch.h_sfidx, nsf * sizeof(uint32_t), hipMemcpyHostToDevice, st));
@@ -754,21 +755,28 @@ void Engine::frontLoop()
       auto acquire = [&](uint32_t ci) -> Chunk* {
         Chunk& ch = chunks[ci % (uint32_t)nslots];
         {
+          const double tw = now_ms();
           std::unique_lock<std::mutex> lk(mtx);
           cv_done.wait(lk, [&] { return !ch.busy; });
           ch.busy = true;
+          perf_front.ms_wait_slot += now_ms() - tw;
         }
         const uint32_t base = ci * max_batch;
         ch.nsf = std::min(max_batch, job.nsf_total - base);
         ch.start_tti = job.start_tti + base;
         ch.jobs.clear(); ch.h_payload.clear();
         for (uint32_t i = 0; i < ch.nsf; i++) ch.ctx[i].reset(ch.start_tti + i);
+        ch.st_a = stream_a[ci % NSTREAM_A];
         launchStageA(ch, (const uint8_t*)job.d_iq + (size_t)base * sf_stride);
         return &ch;
       };
-      Chunk* cur = nchunks ? acquire(0) : nullptr;
+      // stage A of up to NSTREAM_A chunks is in flight (one stream each) while the oldest one is finished and handed on
+      std::deque<Chunk*> inflight;
+      uint32_t launched = 0;
       for (uint32_t ci = 0; ci < nchunks; ci++) {
-        Chunk* next = (ci + 1 < nchunks) ? acquire(ci + 1) : nullptr;
+        while (launched < nchunks && launched < ci + NSTREAM_A) inflight.push_back(acquire(launched++));
+        Chunk* cur = inflight.front();
+        inflight.pop_front();
         const double t0 = now_ms();
         finishStageA(*cur);
         speculateRar(*cur);
@@ -778,7 +786,6 @@ void Engine::frontLoop()
           search_queue.push_back(cur);
         }
         cv_search.notify_one();
-        cur = next;
       }
     } catch (const std::exception& ex) {
       err = ex.what();
@@ -809,7 +816,7 @@ int Engine::process(const void* d_iq, uint32_t nsf_total, uint32_t start_tti, ui
     const double t_all = now_ms();
     // the caller's stream orders the IQ buffer: stage A starts after everything queued on it so far
     HIP_CHECK(hipEventRecord(ev_in, stream));
-    HIP_CHECK(hipStreamWaitEvent(stream_a, ev_in, 0));
+    for (auto& sa : stream_a) HIP_CHECK(hipStreamWaitEvent(sa, ev_in, 0));
     const uint32_t nchunks = (nsf_total + max_batch - 1) / max_batch;
     {
       std::unique_lock<std::mutex> lk(mtx);
@@ -820,8 +827,10 @@ int Engine::process(const void* d_iq, uint32_t nsf_total, uint32_t start_tti, ui
     for (uint32_t ci = 0; ci < nchunks; ci++) {
       Chunk* cur = nullptr;
       {
+        const double tw = now_ms();
         std::unique_lock<std::mutex> lk(mtx);
         cv_search.wait(lk, [&] { return !search_queue.empty(); });
+        perf.ms_wait_front += now_ms() - tw;
         cur = search_queue.front();
         search_queue.pop_front();
         if (!cur) { err = front_error; front_error.clear(); }
@@ -839,8 +848,10 @@ int Engine::process(const void* d_iq, uint32_t nsf_total, uint32_t start_tti, ui
       last_chunk = cur;
     }
     {
+      const double tw = now_ms();
       std::unique_lock<std::mutex> lk(mtx);
       cv_done.wait(lk, [&] { return seq_committed == seq_pushed; });
+      perf.ms_drain += now_ms() - tw;
       if (err.empty() && !commit_error.empty()) err = commit_error;
       commit_error.clear();
     }

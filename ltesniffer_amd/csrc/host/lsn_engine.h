@@ -34,6 +34,7 @@ struct DecodeJob {
 struct Chunk {
   uint32_t nsf = 0, start_tti = 0;
   cf32 *d_grid = nullptr, *d_ce = nullptr, *d_ul_grid = nullptr;
+  hipStream_t st_a = nullptr;        // stage-A stream of this trip through the pipeline
   const cf32* d_iq_src = nullptr;    // the caller's samples of this chunk ([sf][antenna][sflen]), valid until the call returns
   float *d_chest_raw = nullptr, *d_llr = nullptr, *d_ccepow = nullptr, *d_pcfich_corr = nullptr, *d_rbp = nullptr;
   LsnChest* d_chest = nullptr;
@@ -99,8 +100,8 @@ public:
   void forceMetaUpdateNext() { force_meta_next = true; }
 
 private:
-  static constexpr int NDEC = 8;             // max decode threads (each: plan + stage-C launches of one chunk; commits stay in order)
-  static constexpr int NSLOTS = NDEC + 2;
+  static constexpr int NDEC = 12;            // max decode threads (each: plan + stage-C launches of one chunk; commits stay in order)
+  static constexpr int NSLOTS = NDEC + 5;
   int ndec = 6, nslots = 9;                  // in use (LSN_DECODE_THREADS)
   void freeDevice();
   void buildTables();
@@ -147,7 +148,8 @@ private:
   size_t staging_sf = 0;
   Chunk chunks[NSLOTS];
   JobRunner runner_c[NDEC], runner_s, runner_f;  // decode threads / search thread (on-demand RAR decodes) / front thread (speculative RAR decodes)
-  hipStream_t stream_a = nullptr;
+  static constexpr int NSTREAM_A = 3;        // stage A of consecutive chunks overlaps on the GPU (kernels of one stream serialise)
+  hipStream_t stream_a[NSTREAM_A] = {};
   hipEvent_t ev_in = nullptr;
   std::unique_ptr<FalconSearch> search;
   MCSTracking mcs_tracking;

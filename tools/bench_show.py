@@ -10,6 +10,7 @@ if not line:
 d = json.loads(line[-1])
 ps = d["detail"]["per_step"]
 km = d["detail"]["kernel_ms_per_step"]
+print("waits: front %.1f slot %.1f drain %.1f" % (ps.get("ms_wait_front", 0), ps.get("ms_wait_slot", 0), ps.get("ms_drain", 0)), end=" ")
 print("%s | %.0f sf/s | %.2f ms/step | search %.1f (core %.1f rar %.1f) stageC %.1f commit %.1f | turbo %.2f vit %.2f demod %.2f | rm/map Gcyc %.2f/%.2f | cb %d it %d" % (
     os.environ.get("TAG", ""), d["value"], d["ms_per_step"], ps["ms_search"], ps["ms_search_core"], ps["ms_rar"], ps["ms_stage_c"], ps["ms_commit"],
     km["k_turbo<64>"] + km["k_turbo<128>"], km["k_viterbi"], km["k_pdsch_demod"], ps["turbo_cyc_rm"] / 1e9, ps["turbo_cyc_map"] / 1e9, ps["nof_cb_decodes"], ps.get("nof_turbo_iterations_run", ps["nof_turbo_iterations"])))

@@ -1,2 +1,1 @@
-python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-python tools/bench_show.py --no-cpu
+for nd in 6 8; do TAG="ndec=$nd" LSN_DECODE_THREADS=$nd python tools/bench_show.py --no-cpu; done
