@@ -284,6 +284,7 @@ void Engine::searchChunk(Chunk& ch, uint32_t update_meta_period)
     // RAR grants feed the RNTI manager before the next subframe is searched (DL_Sniffer_PDSCH.cc:782-797): decode them now
     for (auto& e : c.dl) {
       if (!isRarFeedbackRnti(e.rnti)) continue;
+      search->finishDlEntry(e, c.sf_idx, c.cfi);
       const bool dci_ok = e.unpack_ok && e.ok64;
       const bool two_tb = e.grant64.nof_tb == 2;
       if (cfg.sniffer_mode == 0 && !(e.grant64.tb[0].tbs > 0 && dci_ok && !(dlRx() == 1 && two_tb))) continue;
@@ -553,6 +554,8 @@ void Engine::planJobs(Chunk& ch, JobRunner& r)
   std::vector<int> wave;
   struct Pending { uint32_t sf; size_t di; };
   std::vector<Pending> retry;
+  for (uint32_t sf = 0; sf < ch.nsf; sf++)  // MCS / TBS / RE counts of every accepted downlink DCI (deferred from the sequential search)
+    for (auto& e : ch.ctx[sf].dl) search->finishDlEntry(e, ch.ctx[sf].sf_idx, ch.ctx[sf].cfi);
   std::unique_lock<std::mutex> mcs_lk(mcs_mtx);
   for (uint32_t sf = 0; sf < ch.nsf; sf++) {
     SubframeCtx& c = ch.ctx[sf];

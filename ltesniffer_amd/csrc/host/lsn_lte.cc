@@ -187,7 +187,7 @@ static void distributed_vrb_to_prb(uint32_t nprb, bool gap2, uint32_t vrb, uint3
   prb_odd = (ob < Nt / 2 ? ob : ob + G - Nt / 2) + Nt * blk;
 }
 
-static bool ra_dl_grant_to_grant_prb_allocation(const Cell& cell, const DciDl& d, PdschGrant& g)
+bool ra_dl_grant_to_grant_prb_allocation(const Cell& cell, const DciDl& d, PdschGrant& g)
 {
   const uint32_t n = cell.nof_prb, P = ra_type0_P(n);
   auto mark = [&](uint32_t prb) { if (prb < g.prb_lo) g.prb_lo = prb; if (prb > g.prb_hi) g.prb_hi = prb; };
@@ -340,12 +340,11 @@ bool dl_sniffer_ra_dl_dci_to_grant(const Cell& cell, uint32_t sf_idx, uint32_t c
   return true;
 }
 
-void dl_sniffer_ra_dl_dci_to_grant_both(const Cell& cell, uint32_t sf_idx, uint32_t cfi, const DciDl& dci, PdschGrant& g64, bool& ok64,
-                                        PdschGrant& g256, bool& ok256)
+// second half of dl_sniffer_ra_dl_dci_to_grant_both: g64 holds the PRB allocation (ra_dl_grant_to_grant_prb_allocation succeeded);
+// fills the MCS / TBS / RE-count dependent fields for both MCS tables
+void dl_sniffer_grant_finish_both(const Cell& cell, uint32_t sf_idx, uint32_t cfi, const DciDl& dci, PdschGrant& g64, bool& ok64, PdschGrant& g256,
+                                  bool& ok256)
 {
-  g64 = PdschGrant();
-  ok64 = ok256 = false;
-  if (!ra_dl_grant_to_grant_prb_allocation(cell, dci, g64)) { g256 = g64; return; }
   g256 = g64;  // the PRB set does not depend on the MCS table
   ok64 = dl_sniffer_compute_tb(false, dci, g64);
   ok256 = dl_sniffer_compute_tb(true, dci, g256);
@@ -358,6 +357,15 @@ void dl_sniffer_ra_dl_dci_to_grant_both(const Cell& cell, uint32_t sf_idx, uint3
     g.nof_re = nof_re;
     for (auto& tb : g.tb) { tb.nof_bits = tb.enabled ? (int)nof_re * tb.mod : 0; if (rv0) tb.rv = 0; }
   }
+}
+
+void dl_sniffer_ra_dl_dci_to_grant_both(const Cell& cell, uint32_t sf_idx, uint32_t cfi, const DciDl& dci, PdschGrant& g64, bool& ok64,
+                                        PdschGrant& g256, bool& ok256)
+{
+  g64 = PdschGrant();
+  ok64 = ok256 = false;
+  if (!ra_dl_grant_to_grant_prb_allocation(cell, dci, g64)) { g256 = g64; return; }
+  dl_sniffer_grant_finish_both(cell, sf_idx, cfi, dci, g64, ok64, g256, ok256);
 }
 
 bool ra_ul_dci_to_grant(const Cell& cell, const DciUl& d, PuschGrant& g)

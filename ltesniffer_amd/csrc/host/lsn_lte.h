@@ -59,6 +59,9 @@ bool dl_sniffer_ra_dl_dci_to_grant(const Cell& cell, uint32_t sf_idx, uint32_t c
 // both MCS tables at once (falcon_dci.c:284-310 calls the function above twice): same results as two separate calls
 void dl_sniffer_ra_dl_dci_to_grant_both(const Cell& cell, uint32_t sf_idx, uint32_t cfi, const DciDl& dci, PdschGrant& g64, bool& ok64,
                                         PdschGrant& g256, bool& ok256);
+void dl_sniffer_grant_finish_both(const Cell& cell, uint32_t sf_idx, uint32_t cfi, const DciDl& dci, PdschGrant& g64, bool& ok64, PdschGrant& g256,
+                                  bool& ok256);
+bool ra_dl_grant_to_grant_prb_allocation(const Cell& cell, const DciDl& dci, PdschGrant& g);
 bool ra_ul_dci_to_grant(const Cell& cell, const DciUl& dci, PuschGrant& g);
 bool ra_ul_dci_to_grant_256(const Cell& cell, const DciUl& dci, PuschGrant& g);  // ulsniffer_ra_ul_dci_to_grant_256, ul_sniffer_pusch.c:138-172
 bool ul_valid_prb(uint32_t L);                                                    // valid_prb_ul, UL_Sniffer_PUSCH.cc:3-10

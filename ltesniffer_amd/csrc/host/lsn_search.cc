@@ -164,16 +164,29 @@ void FalconSearch::addCandidate(SubframeCtx& c, const DciCandidate& cand, uint32
   e.dci.L = L; e.dci.ncce = ncce;
   e.unpack_ok = dci_msg_unpack_pdsch(cell, payload, cand.msg.nof_bits, fmt, cand.rnti, e.dci);
   if (e.unpack_ok) {
-    dl_sniffer_ra_dl_dci_to_grant_both(cell, c.sf_idx, c.cfi, e.dci, e.grant64, e.ok64, e.grant256, e.ok256);
-    for (uint32_t rb = e.grant64.prb_lo; rb <= e.grant64.prb_hi && rb < cell.nof_prb; rb++)  // DCICollection.cc:215-223 (the PRB set does not depend on the MCS table)
-      if (e.grant64.prb_idx[0][rb]) {
-        if (rb_map_dl[rb] != 0) dl_collision = true;
-        rb_map_dl[rb] = cand.rnti;
-      }
-    for (int i = 0; i < 2; i++) {  // DCICollection.cc:252-259
-      if (e.grant64.tb[i].nof_bits <= 0) e.grant64.tb[i].enabled = false;
-      if (e.grant256.tb[i].nof_bits <= 0) e.grant256.tb[i].enabled = false;
-    }
+    // the sequential search needs the PRB set only (collision statistics); the MCS-table dependent half of
+    // dl_sniffer_ra_dl_dci_to_grant_both runs later, off this thread (finishDlEntry)
+    e.alloc_ok = ra_dl_grant_to_grant_prb_allocation(cell, e.dci, e.grant64);
+    if (e.alloc_ok)
+      for (uint32_t rb = e.grant64.prb_lo; rb <= e.grant64.prb_hi && rb < cell.nof_prb; rb++)  // DCICollection.cc:215-223 (the PRB set does not depend on the MCS table)
+        if (e.grant64.prb_idx[0][rb]) {
+          if (rb_map_dl[rb] != 0) dl_collision = true;
+          rb_map_dl[rb] = cand.rnti;
+        }
+  } else {
+    e.finished = true;
+  }
+}
+
+void FalconSearch::finishDlEntry(DlEntry& e, uint32_t sf_idx, uint32_t cfi) const
+{
+  if (e.finished) return;
+  e.finished = true;
+  if (!e.alloc_ok) { e.grant256 = e.grant64; return; }
+  dl_sniffer_grant_finish_both(cell, sf_idx, cfi, e.dci, e.grant64, e.ok64, e.grant256, e.ok256);
+  for (int i = 0; i < 2; i++) {  // DCICollection.cc:252-259
+    if (e.grant64.tb[i].nof_bits <= 0) e.grant64.tb[i].enabled = false;
+    if (e.grant256.tb[i].nof_bits <= 0) e.grant256.tb[i].enabled = false;
   }
 }
 
@@ -186,6 +199,7 @@ bool FalconSearch::buildDlEntry(const SubframeCtx& c, uint16_t rnti, DciFormat f
   e = DlEntry();
   e.rnti = rnti; e.format = fmt; e.nof_bits = msg.nof_bits; e.bits = bits;
   e.unpack_ok = dci_msg_unpack_pdsch(cell, payload, msg.nof_bits, fmt, rnti, e.dci);
+  e.finished = true;
   if (!e.unpack_ok) return false;
   dl_sniffer_ra_dl_dci_to_grant_both(cell, c.sf_idx, c.cfi, e.dci, e.grant64, e.ok64, e.grant256, e.ok256);
   for (int i = 0; i < 2; i++) {

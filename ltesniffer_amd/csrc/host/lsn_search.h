@@ -26,6 +26,7 @@ struct DlEntry {  // DL_Sniffer_DCI_DL (Sniffer_dependency.h:90)
   unsigned long long bits = 0;  // DCI payload as decoded (bit i at position 63-i)
   DciDl dci; bool unpack_ok = false;
   PdschGrant grant64, grant256; bool ok64 = false, ok256 = false;  // both tables computed; selection happens at commit
+  bool alloc_ok = false, finished = false;  // the search only needs the PRB allocation; MCS/TBS/RE counts are filled by finishDlEntry (decode threads)
   int job[2] = {-1, -1};                                          // decode job index per table
 };
 struct UlEntry { uint16_t rnti = 0; uint32_t nof_bits = 0, L = 0, ncce = 0, histval = 0; DciUl dci; PuschGrant grant, grant256; bool ok = false; };
@@ -68,6 +69,7 @@ public:
   const uint32_t* sizes() const { return size_list; }
   void setupDefaultIntervals();  // LTESniffer_Core.cc:398-417
   // the DL entry addCandidate() would build for this candidate (no state is touched): used to decode RA-RNTI grants ahead
+  void finishDlEntry(DlEntry& e, uint32_t sf_idx, uint32_t cfi) const;  // idempotent second half of addCandidate's grant conversion
   bool buildDlEntry(const SubframeCtx& c, uint16_t rnti, DciFormat fmt, unsigned long long bits, DlEntry& e) const;
   uint64_t nof_lookups = 0;
 

@@ -385,11 +385,17 @@ __device__ __forceinline__ uint32_t ss_validate(uint32_t n, uint32_t ncce, uint3
 // ------------------------------------------------------------------------------------------------ PDCCH Viterbi
 // One wavefront per (location, size, subframe).  Rate de-matching is a gather through a host-built rank table;
 // u8 quantisation 127.5 + 32*llr (truncated); 32-bit path metrics; 3 passes over the tail-biting block, middle pass kept.
+// Issue-cost shaping (VALU instructions are what this kernel is made of, 55 % of the whole path's): the three symbols of
+// a step are stored as one word of signed bytes (q - 128), so the branch metric of a lane is ONE v_dot4_i32_i8 with the
+// lane's constant sign word (sum of c_i ? 255 - q_i : q_i  ==  dot(sign, q - 128) + sum of c_i ? 127 : 128); the decision
+// ballots are stored by a uniform, branch-free LDS write; the trace-back covers only passes 2 and 3, fetches 64 ballot
+// words per LDS read (one per lane) and then walks them with v_readlane + scalar shifts instead of one dependent LDS
+// round trip per step.
 __global__ __launch_bounds__(64) void k_viterbi(LsnCellDev c, const float* __restrict__ llr, const float* __restrict__ pw,
                                                 const uint32_t* __restrict__ cfi_arr, const uint32_t* __restrict__ sf_idx_arr,
                                                 LsnCand* __restrict__ cand)
 {
-  __shared__ unsigned char sym[3 * LSN_MAX_DCI_D];
+  __shared__ int symw[LSN_MAX_DCI_D];                  // per step: (q0 - 128) | (q1 - 128) << 8 | (q2 - 128) << 16, signed bytes
   __shared__ unsigned long long dec[3 * LSN_MAX_DCI_D];
   const int lane = threadIdx.x, sf = blockIdx.z, sz = blockIdx.y;
   int li = blockIdx.x;
@@ -418,18 +424,23 @@ __global__ __launch_bounds__(64) void k_viterbi(LsnCellDev c, const float* __res
   const uint32_t nbits = c.sizes[sz], D = nbits + 16, D3 = 3 * D;
   const uint16_t* rank = c.rankmap + sz * 3 * LSN_MAX_DCI_D;
   bool nz = false;
-  for (uint32_t o = lane; o < D3; o += 64) {
-    float acc = 0.0f;
-    bool first = true;
-    for (uint32_t k = rank[o]; k < E; k += D3) {
-      float v = e[k];
-      if (v != 0.0f) nz = true;
-      if (first) { acc = v; first = false; } else acc = acc + v;
+  for (uint32_t t = lane; t < D; t += 64) {
+    uint32_t word = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 3; j++) {
+      float acc = 0.0f;
+      bool first = true;
+      for (uint32_t k = rank[3 * t + j]; k < E; k += D3) {
+        float v = e[k];
+        if (v != 0.0f) nz = true;
+        if (first) { acc = v; first = false; } else acc = acc + v;
+      }
+      float q = 127.5f + 32.0f * acc;
+      q = q < 0.0f ? 0.0f : q;
+      q = q > 255.0f ? 255.0f : q;
+      word |= (((uint32_t)(unsigned char)q - 128u) & 0xFFu) << (8 * j);
     }
-    float q = 127.5f + 32.0f * acc;
-    q = q < 0.0f ? 0.0f : q;
-    q = q > 255.0f ? 255.0f : q;
-    sym[o] = (unsigned char)q;
+    symw[t] = (int)word;
   }
   if (__ballot(nz) == 0ull) {  // mean |llr| == 0: the reference skips the decode (falcon_pdcch.c:141)
     if (lane == 0) { out->bits = 0; out->rnti = 0; out->flags = 0; }
@@ -439,17 +450,19 @@ __global__ __launch_bounds__(64) void k_viterbi(LsnCellDev c, const float* __res
   // lane = new state j: input bit b = j&1, predecessors j>>1 and (j>>1)|32; generator masks on the old state
   const int b = lane & 1, s0 = lane >> 1;
   const int c0 = b ^ (__popc(s0 & 0x36) & 1), c1 = b ^ (__popc(s0 & 0x27) & 1), c2 = b ^ (__popc(s0 & 0x2B) & 1);
+  const int signs = (c0 ? 0xFF : 0x01) | (c1 ? 0xFF00 : 0x0100) | (c2 ? 0xFF0000 : 0x010000);
+  const int kconst = (c0 ? 127 : 128) + (c1 ? 127 : 128) + (c2 ? 127 : 128);
+  const int pa = s0 << 2, pb = (s0 | 32) << 2;  // ds_bpermute byte addresses of the two predecessors
   int m = 0;
   const int T = (int)D3;  // 3 passes of D steps
-  for (int t = 0, tt = 0; t < T; t++, tt = (tt + 1 == (int)D) ? 0 : tt + 1) {
-    int q0 = sym[3 * tt], q1 = sym[3 * tt + 1], q2 = sym[3 * tt + 2];
-    int bm0 = (c0 ? 255 - q0 : q0) + (c1 ? 255 - q1 : q1) + (c2 ? 255 - q2 : q2);
-    int a0 = __shfl(m, s0) + bm0, a1 = __shfl(m, s0 | 32) + (765 - bm0);
-    bool d = a1 < a0;
-    m = d ? a1 : a0;
-    unsigned long long dw = __ballot(d);
-    if (lane == 0) dec[t] = dw;
-  }
+  for (int pass = 0, t = 0; pass < 3; pass++)
+    for (int tt = 0; tt < (int)D; tt++, t++) {
+      const int bm0 = __builtin_amdgcn_sdot4(symw[tt], signs, kconst, false);
+      const int a0 = __builtin_amdgcn_ds_bpermute(pa, m) + bm0, a1 = __builtin_amdgcn_ds_bpermute(pb, m) + (765 - bm0);
+      const bool d = a1 < a0;
+      m = d ? a1 : a0;
+      dec[t] = __ballot(d);  // same value, same address from every lane
+    }
   // best end state: minimum metric, lowest index on ties
   unsigned long long key = ((unsigned long long)(unsigned)m << 6) | (unsigned)lane;
   for (int off = 32; off > 0; off >>= 1) {
@@ -457,19 +470,27 @@ __global__ __launch_bounds__(64) void k_viterbi(LsnCellDev c, const float* __res
     key = o2 < key ? o2 : key;
   }
   __syncthreads();
-  if (lane == 0) {
-    int st = (int)(key & 63ull);
-    unsigned long long bits = 0;  // decoded bit i of the middle pass at position 63-i (payload then 16 CRC bits handled below)
-    unsigned int tailcrc = 0;
-    for (int t = T - 1; t >= 0; t--) {
-      if (t >= (int)D && t < 2 * (int)D) {
-        int i = t - (int)D;
+  // trace-back over passes 3 and 2 (t = T-1 .. D): the state walks in scalar registers
+  int st = __builtin_amdgcn_readfirstlane((int)(key & 63ull));
+  unsigned long long bits = 0;  // decoded bit i of the middle pass at position 63-i (payload); the 16 CRC bits go to tailcrc
+  unsigned int tailcrc = 0;
+  for (int hi = T; hi > (int)D; hi -= 64) {
+    const int lo = hi - 64 > (int)D ? hi - 64 : (int)D;
+    const unsigned long long mine = (lo + lane < hi) ? dec[lo + lane] : 0ull;
+    const int mlo = (int)(unsigned)mine, mhi = (int)(unsigned)(mine >> 32);
+    for (int t = hi - 1; t >= lo; t--) {
+      if (t < 2 * (int)D) {
+        const int i = t - (int)D;
         if (i < (int)nbits) bits |= (unsigned long long)(st & 1) << (63 - i);
         else tailcrc |= (unsigned)(st & 1) << (15 - (i - (int)nbits));
       }
-      int dd = (int)((dec[t] >> st) & 1ull);
+      const unsigned wlo = (unsigned)__builtin_amdgcn_readlane(mlo, t - lo), whi = (unsigned)__builtin_amdgcn_readlane(mhi, t - lo);
+      const unsigned long long w = ((unsigned long long)whi << 32) | wlo;
+      const int dd = (int)((w >> st) & 1ull);
       st = (st >> 1) | (dd << 5);
     }
+  }
+  if (lane == 0) {
     // CRC16 (x^16+x^12+x^5+1) over the payload, zero-augmented long division
     unsigned int reg = 0;
     for (int i = 0; i < (int)nbits + 16; i++) {
