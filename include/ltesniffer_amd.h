@@ -127,6 +127,23 @@ int lsn_phy_process_device(lsn_phy_t* phy, const void* d_iq, uint32_t n_subframe
 /* same, from host memory (copies through pinned staging) */
 int lsn_phy_process_host(lsn_phy_t* phy, const float* iq, uint32_t n_subframes, uint32_t start_tti, uint32_t update_meta_period);
 
+/* ---- IQ capture file replay ----
+ * Replaces the file source of the reference's file mode: srsran_ue_sync_init_file_multi(&ue_sync, nof_prb, file, offset_time,
+ * offset_freq, nof_rx_antennas) + one srsran_ue_sync_zerocopy per subframe (LTESniffer_Core.cc:252-258,365; options -O / -o,
+ * ArgManager.cc:144-149).  File format: complex float32, antennas interleaved sample by sample, subframe aligned after the
+ * offset (file mode has no PSS tracking); every 15*N samples per antenna are one subframe, counted from start_tti.
+ * offset_freq_hz != 0: every subframe is multiplied by exp(-j 2 pi offset_freq n / fs) with n restarting per subframe.
+ * The SFN the reference takes from the MIB (LTESniffer_Core.cc:382-420) is an input here (start_tti).
+ * Blocks of LSN_FILE_BLOCK (default 3200) subframes are read, copied and re-laid-out on the GPU while the previous block is
+ * processed. */
+typedef struct {
+  uint32_t nof_antennas;        /* interleaved antennas in the file = nof_rx_antennas of the Phy */
+  int64_t offset_time_samples;  /* -O: samples (per antenna) skipped at the start */
+  float offset_freq_hz;         /* -o: frequency offset correction */
+} lsn_file_cfg_t;
+int lsn_phy_process_file(lsn_phy_t* phy, const char* path, const lsn_file_cfg_t* cfg, uint32_t start_tti, uint64_t max_subframes /* 0 = to the end */,
+                         uint32_t update_meta_period, uint64_t* subframes_done);
+
 /* ---- uplink (PUSCH) ----
  * lsn_phy_set_ul_config replaces srsran_enb_ul_set_cell(&enb_ul, cell, &ul_cfg.dmrs, ...) (SubframeWorker.cc:258-262); the two
  * values come from SIB2 (ULSchedule::set_config, ULSchedule.cc:140-158: cyclicShift, groupAssignmentPUSCH).

@@ -249,6 +249,12 @@ int lsn_phy_process_host(lsn_phy_t* phy, const float* iq, uint32_t n, uint32_t s
   return phy->engine->processHost(iq, n, start_tti, update_meta_period);
 }
 
+int lsn_phy_process_file(lsn_phy_t* phy, const char* path, const lsn_file_cfg_t* cfg, uint32_t start_tti, uint64_t max_subframes, uint32_t update_meta_period,
+                         uint64_t* subframes_done)
+{
+  if (!phy || !path || !cfg) return LSN_ERROR_INVALID_INPUTS;
+  return phy->engine->processFile(path, *cfg, start_tti, max_subframes, update_meta_period, subframes_done);
+}
 int lsn_phy_set_ul_config(lsn_phy_t* phy, const lsn_ul_cfg_t* cfg)
 {
   if (!phy || !cfg) return LSN_ERROR_INVALID_INPUTS;

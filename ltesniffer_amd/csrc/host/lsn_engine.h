@@ -77,6 +77,8 @@ public:
   int setCell(const lsn_cell_t& cell);
   bool hasCell() const { return cell_set; }
   int process(const void* d_iq, uint32_t nsf, uint32_t start_tti, uint32_t update_meta_period, hipStream_t stream);
+  int processFile(const char* path, const lsn_file_cfg_t& fc, uint32_t start_tti, uint64_t max_subframes, uint32_t update_meta_period,
+                  uint64_t* subframes_done);
   int processHost(const float* iq, uint32_t nsf, uint32_t start_tti, uint32_t update_meta_period);
   void setSink(lsn_pdu_sink_t cb, void* user) { sink = cb; sink_user = user; }
   long tap(int what, uint32_t sf, void* out, size_t cap);

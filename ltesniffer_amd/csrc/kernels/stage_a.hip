@@ -528,3 +528,26 @@ void lsn_launch_rb_power(const LsnCellDev& c, const cf32* grid, float* rbp, uint
 {
   hipLaunchKernelGGL(k_rb_power, dim3(nsf), dim3(128), 0, s, c, grid, rbp);
 }
+
+// ------------------------------------------------------------------------------------------------ IQ capture file source
+// srsran_ue_sync_zerocopy in file mode (LTESniffer_Core.cc:365): de-interleave the antennas of a block of raw file samples
+// ([subframe][sample][antenna] cf32) into the engine's [subframe][antenna][sample] layout and, with a frequency offset,
+// multiply every subframe by rot[n] = exp(-j 2 pi offset_freq n / fs) (the phase restarts in every subframe).  HBM-bound copy.
+__global__ __launch_bounds__(256) void k_file_unpack(const cf32* __restrict__ raw, const cf32* __restrict__ rot, uint32_t sflen, uint32_t nant,
+                                                     cf32* __restrict__ out)
+{
+  const uint32_t n = blockIdx.x * 256 + threadIdx.x, a = blockIdx.y, sf = blockIdx.z;
+  if (n >= sflen) return;
+  cf32 x = raw[((size_t)sf * sflen + n) * nant + a];
+  if (rot) {
+    const cf32 w = rot[n];
+    cf32 y; y.r = x.r * w.r - x.i * w.i; y.i = x.r * w.i + x.i * w.r;
+    x = y;
+  }
+  out[((size_t)sf * nant + a) * sflen + n] = x;
+}
+void lsn_launch_file_unpack(const cf32* raw, const cf32* rot, uint32_t sflen, uint32_t nant, cf32* out, uint32_t nsf, hipStream_t s)
+{
+  if (!nsf) return;
+  hipLaunchKernelGGL(k_file_unpack, dim3((sflen + 255) / 256, nant, nsf), dim3(256), 0, s, raw, rot, sflen, nant, out);
+}

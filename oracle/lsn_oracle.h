@@ -193,6 +193,9 @@ int o_pdsch_decode_tb(const int16_t* e, int G, int tbs, int Qm, int nof_layers_r
                       uint8_t* payload, int* iters_total);
 int o_turbo_nwin(int K);
 
+/* ---------- IQ capture file source (o_file.c) ---------- */
+long o_file_read(const char* path, uint32_t nof_prb, uint32_t nant, long offset_time, float offset_freq, uint32_t first_sf, uint32_t nsf, ocf_t* out);
+
 /* ---------- uplink: PRACH detection (o_prach.c) ---------- */
 typedef struct {
   uint32_t config_idx, root_seq_idx, zero_corr_zone, freq_offset, hs_flag; /* SIB2 prach-ConfigInfo (ULSchedule.cc:149-154) */

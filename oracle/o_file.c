@@ -1,0 +1,46 @@
+/* o_file.c - ORACLE (test infrastructure only): the IQ capture file source in front of the worker.
+ * Restates srsran_ue_sync_init_file_multi + srsran_ue_sync_zerocopy in file mode
+ * (/root/reference/src/src/LTESniffer_Core.cc:252-258,365; -O / -o options ArgManager.cc:144-149) [srsRAN ue_sync.c /
+ * filesource.c, not in tree]: the file holds complex float32 samples, the antennas interleaved sample by sample; the
+ * first `offset_time` samples (per antenna) are skipped once; every call delivers one subframe (15 N samples per antenna),
+ * no PSS tracking in file mode - the file is taken as subframe aligned, the subframe counter just increments; with a
+ * non-zero frequency offset every subframe is multiplied by exp(-j 2 pi offset_freq n / fs), n restarting at 0 in each
+ * subframe (srsran_cfo_correct is called per subframe with freq = -offset_freq / 15000 / N).
+ * Parity unpinned against srsRAN itself; arithmetic contract as in lsn_oracle.h (table in double on the "host" side, one
+ * float rounding per operation). */
+#include "lsn_oracle.h"
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+/* out: [nsf][nant][15 N]; returns the number of complete subframes delivered (<= nsf), or -1 */
+long o_file_read(const char* path, uint32_t nof_prb, uint32_t nant, long offset_time, float offset_freq, uint32_t first_sf, uint32_t nsf, ocf_t* out)
+{
+  FILE* f = fopen(path, "rb");
+  if (!f || nant == 0) { if (f) fclose(f); return -1; }
+  const int N = o_fft_size(nof_prb), sflen = 15 * N;
+  const double fs = 15000.0 * (double)N;
+  if (fseek(f, ((long)offset_time + (long)first_sf * sflen) * (long)nant * (long)sizeof(ocf_t), SEEK_SET)) { fclose(f); return -1; }
+  ocf_t* raw = (ocf_t*)malloc(sizeof(ocf_t) * (size_t)sflen * nant);
+  ocf_t* rot = NULL;
+  if (offset_freq != 0.0f) {
+    rot = (ocf_t*)malloc(sizeof(ocf_t) * (size_t)sflen);
+    for (int n = 0; n < sflen; n++) {
+      double a = -2.0 * M_PI * (double)offset_freq * (double)n / fs;
+      rot[n].r = (float)cos(a); rot[n].i = (float)sin(a);
+    }
+  }
+  long done = 0;
+  for (uint32_t s = 0; s < nsf; s++) {
+    if (fread(raw, sizeof(ocf_t), (size_t)sflen * nant, f) != (size_t)sflen * nant) break;
+    for (uint32_t a = 0; a < nant; a++)
+      for (int n = 0; n < sflen; n++) {
+        ocf_t x = raw[(size_t)n * nant + a];
+        if (rot) { ocf_t y = {x.r * rot[n].r - x.i * rot[n].i, x.r * rot[n].i + x.i * rot[n].r}; x = y; }
+        out[((size_t)s * nant + a) * sflen + n] = x;
+      }
+    done++;
+  }
+  free(raw); free(rot); fclose(f);
+  return done;
+}

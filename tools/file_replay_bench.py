@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""File-mode replay rate (host file -> pinned blocks -> PCIe -> k_file_unpack -> engine), the PCIe/IO-inclusive companion of
+bench.py's resident-capture number.  usage: file_replay_bench.py [nsf=6400] [gen=800]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import numpy as np
+import ltesniffer_amd as la
+from lsn_testlib import scenario
+from parity import gen_subframes
+
+nsf = int(sys.argv[1]) if len(sys.argv) > 1 else 6400
+gen = int(sys.argv[2]) if len(sys.argv) > 2 else 800
+sc = scenario("cfg3", seed=3)
+tti0, iq, _ = gen_subframes(sc, gen)
+path = "/tmp/lsn_capture.cf32"
+blockdata = np.ascontiguousarray(np.transpose(iq, (0, 2, 1)))
+with open(path, "wb") as f:
+    for _ in range(nsf // gen):
+        blockdata.tofile(f)
+size = os.path.getsize(path)
+phy = la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=200, pcapwriter=la.PcapWriter(None))
+assert phy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"])
+for rep in range(3):
+    phy.pcapwriter.reset()
+    t0 = time.perf_counter()
+    done = phy.process_file(path, start_tti=tti0, update_meta_period=500)
+    dt = time.perf_counter() - t0
+    print("replay %d: %d subframes in %.3f s = %.0f subframes/s (%.2f GB/s from the file, page cache)" % (rep, done, dt, done / dt, size / dt / 1e9), flush=True)
+phy.close()
+os.remove(path)
