@@ -127,6 +127,25 @@ int lsn_phy_process_device(lsn_phy_t* phy, const void* d_iq, uint32_t n_subframe
 /* same, from host memory (copies through pinned staging) */
 int lsn_phy_process_host(lsn_phy_t* phy, const float* iq, uint32_t n_subframes, uint32_t start_tti, uint32_t update_meta_period);
 
+/* ---- PBCH / MIB ----
+ * Replaces srsran_ue_mib_decode + srsran_pbch_mib_unpack of the reference's DECODE_MIB state (LTESniffer_Core.cc:382-395): decode
+ * the MIB on a subframe 0 and return the SFN of that subframe (MIB SFN + position of the radio frame in the 40 ms BCH period,
+ * "sfn = (sfn + sfn_offset) % 1024").  The cell (bandwidth, id, number of CRS ports for the channel estimate) must have been set;
+ * nof_ports is what the CRC mask says (1 / 2 / 4).  Returns 1 = found, 0 = no MIB in this subframe, < 0 = error. */
+typedef struct {
+  uint32_t found;
+  uint32_t sfn;                 /* SFN of the subframe that was handed in */
+  uint32_t sfn_offset;          /* radio-frame position inside the BCH period, 0..3 */
+  uint32_t nof_prb, nof_ports;  /* dl-Bandwidth, CRC mask */
+  uint32_t phich_length;        /* 0 normal, 1 extended */
+  uint32_t phich_resources_x6;  /* Ng * 6: 1, 3, 6, 12 */
+  uint32_t mib_bits;            /* the 24 MIB bits, first bit = MSB */
+} lsn_mib_t;
+/* iq: ONE subframe, [nof_rx_antennas][15*N] cf32 (host memory unless iq_on_device) */
+int lsn_phy_mib_decode(lsn_phy_t* phy, const void* iq, int iq_on_device, lsn_mib_t* out);
+#define LSN_TTI_FROM_MIB 0xFFFFFFFFu /* start_tti of lsn_phy_process_file: take the SFN from the first MIB that decodes (subframes 0, 10, 20, ...
+                                        of the file; the subframes in front of it are dropped, as in the reference's DECODE_MIB state) */
+
 /* ---- IQ capture file replay ----
  * Replaces the file source of the reference's file mode: srsran_ue_sync_init_file_multi(&ue_sync, nof_prb, file, offset_time,
  * offset_freq, nof_rx_antennas) + one srsran_ue_sync_zerocopy per subframe (LTESniffer_Core.cc:252-258,365; options -O / -o,
@@ -210,6 +229,8 @@ enum { LSN_TAP_GRID = 0, LSN_TAP_CE = 1, LSN_TAP_PDCCH_LLR = 2, LSN_TAP_CHEST = 
        LSN_TAP_CCE_POWER = 6, LSN_TAP_ACCEPTED = 7, LSN_TAP_RB_POWER = 8 };
 /* copies tap `what` of subframe `sf_in_batch` of the LAST processed batch into out (host); returns bytes written or <0 */
 long lsn_phy_tap(lsn_phy_t* phy, int what, uint32_t sf_in_batch, void* out, size_t cap);
+/* lsn_phy_mib_decode + the 480 raw (not descrambled) PBCH soft bits of the subframe */
+int lsn_phy_mib_decode_llr(lsn_phy_t* phy, const void* iq, int iq_on_device, lsn_mib_t* out, float* llr_raw480);
 typedef struct {
   double ms_stage_a, ms_search, ms_stage_c, ms_commit, ms_total; /* wall clock of the last process call */
   double kernel_ms[16];                                          /* HIP-event time per kernel class, last call */

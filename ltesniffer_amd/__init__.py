@@ -30,10 +30,17 @@ EXPORTS = ["lsn_phy_create", "lsn_phy_destroy", "lsn_phy_set_cell", "lsn_phy_get
            "lsn_phy_get_perf", "lsn_kernel_name", "lsn_version", "lsn_pcap_open", "lsn_pcap_open_mem",
            "lsn_pcap_set_wall_clock", "lsn_pcap_write", "lsn_pcap_sink", "lsn_pcap_mem", "lsn_pcap_nof_records",
            "lsn_pcap_reset", "lsn_pcap_close", "lsn_phy_set_pcap_writer", "lsn_phy_set_ul_config", "lsn_phy_pusch_decode",
-           "lsn_phy_tap_ul", "lsn_phy_set_prach_config", "lsn_phy_prach_detect", "lsn_phy_set_prach_sink", "lsn_prach_tti_opportunity", "lsn_phy_process_file"]
+           "lsn_phy_tap_ul", "lsn_phy_set_prach_config", "lsn_phy_prach_detect", "lsn_phy_set_prach_sink", "lsn_prach_tti_opportunity", "lsn_phy_process_file", "lsn_phy_mib_decode", "lsn_phy_mib_decode_llr"]
 
 
 PRACH_NCS = [0, 13, 15, 18, 22, 26, 32, 38, 46, 59, 76, 93, 119, 167, 279, 419]  # 36.211 Table 5.7.2-2
+
+
+class Mib(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("found", "sfn", "sfn_offset", "nof_prb", "nof_ports", "phich_length", "phich_resources_x6", "mib_bits")]
+
+
+TTI_FROM_MIB = 0xFFFFFFFF
 
 
 class FileCfg(C.Structure):
@@ -197,6 +204,8 @@ def lib():
                                            C.c_void_p, C.c_size_t]
         L.lsn_phy_tap_ul.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_size_t]
         L.lsn_phy_tap_ul.restype = C.c_long
+        L.lsn_phy_mib_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Mib)]
+        L.lsn_phy_mib_decode_llr.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Mib), C.c_void_p]
         L.lsn_phy_process_file.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(FileCfg), C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64)]
         L.lsn_phy_set_prach_config.argtypes = [C.c_void_p, C.POINTER(PrachCfg)]
         L.lsn_phy_prach_detect.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(PrachDet), C.c_uint32]
@@ -341,12 +350,23 @@ class Phy:
         _check(lib().lsn_phy_process_device(self._h, C.c_void_p(dev_ptr), n_subframes, start_tti, update_meta_period,
                                             C.c_void_p(stream or 0)), "process_device")
 
+    def mib_decode(self, iq, with_llr=False):
+        """srsran_ue_mib_decode on ONE subframe iq[nof_rx, 15*N] -> dict (found, sfn, sfn_offset, nof_prb, nof_ports, ...) [, raw PBCH soft bits]"""
+        iq = np.ascontiguousarray(iq, dtype=np.complex64)
+        m = Mib()
+        llr = np.zeros(480, dtype=np.float32)
+        r = lib().lsn_phy_mib_decode_llr(self._h, iq.ctypes.data, 0, C.byref(m), llr.ctypes.data)
+        if r < 0:
+            _check(r, "mib_decode")
+        d = {n: int(getattr(m, n)) for n, _ in Mib._fields_}
+        return (d, llr) if with_llr else d
+
     def process_file(self, path, start_tti=0, offset_time=0, offset_freq=0.0, max_subframes=0, update_meta_period=0):
         """file mode of the reference (-i file -O offset_time -o offset_freq): replay a cf32 capture (antennas interleaved per sample);
         returns the number of subframes processed"""
         fc = FileCfg(self.nof_rx_antennas, int(offset_time), float(offset_freq))
         done = C.c_uint64(0)
-        _check(lib().lsn_phy_process_file(self._h, os.fsencode(path), C.byref(fc), start_tti % 10240, max_subframes, update_meta_period, C.byref(done)),
+        _check(lib().lsn_phy_process_file(self._h, os.fsencode(path), C.byref(fc), start_tti if start_tti == TTI_FROM_MIB else start_tti % 10240, max_subframes, update_meta_period, C.byref(done)),
                "process_file")
         return int(done.value)
 

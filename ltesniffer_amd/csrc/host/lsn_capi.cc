@@ -249,6 +249,16 @@ int lsn_phy_process_host(lsn_phy_t* phy, const float* iq, uint32_t n, uint32_t s
   return phy->engine->processHost(iq, n, start_tti, update_meta_period);
 }
 
+int lsn_phy_mib_decode(lsn_phy_t* phy, const void* iq, int iq_on_device, lsn_mib_t* out)
+{
+  if (!phy) return LSN_ERROR_INVALID_INPUTS;
+  return phy->engine->mibDecode(iq, iq_on_device != 0, out, nullptr);
+}
+int lsn_phy_mib_decode_llr(lsn_phy_t* phy, const void* iq, int iq_on_device, lsn_mib_t* out, float* llr_raw480)
+{
+  if (!phy) return LSN_ERROR_INVALID_INPUTS;
+  return phy->engine->mibDecode(iq, iq_on_device != 0, out, llr_raw480);
+}
 int lsn_phy_process_file(lsn_phy_t* phy, const char* path, const lsn_file_cfg_t* cfg, uint32_t start_tti, uint64_t max_subframes, uint32_t update_meta_period,
                          uint64_t* subframes_done)
 {

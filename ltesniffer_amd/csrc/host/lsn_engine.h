@@ -77,6 +77,7 @@ public:
   int setCell(const lsn_cell_t& cell);
   bool hasCell() const { return cell_set; }
   int process(const void* d_iq, uint32_t nsf, uint32_t start_tti, uint32_t update_meta_period, hipStream_t stream);
+  int mibDecode(const void* iq, bool on_device, lsn_mib_t* out, float* llr_raw480);
   int processFile(const char* path, const lsn_file_cfg_t& fc, uint32_t start_tti, uint64_t max_subframes, uint32_t update_meta_period,
                   uint64_t* subframes_done);
   int processHost(const float* iq, uint32_t nsf, uint32_t start_tti, uint32_t update_meta_period);
@@ -200,6 +201,7 @@ private:
     uint64_t* d_off = nullptr;
     size_t off_cap = 0, y_cap = 0, corr_cap = 0, out_cap = 0;
   } prach;
+  cf32* mib_d_iq = nullptr; float* mib_d_llr = nullptr; LsnCand* mib_d_cand = nullptr;
   lsn_prach_sink_t prach_sink = nullptr; void* prach_sink_user = nullptr;
   std::vector<int> numa_cpus;  // CPUs local to the GPU (empty: unknown, no pinning)
 };

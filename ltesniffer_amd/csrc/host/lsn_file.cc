@@ -68,11 +68,26 @@ int Engine::processFile(const char* path, const lsn_file_cfg_t& fc, uint32_t sta
       HIP_CHECK(hipMalloc((void**)&d_rot, sflen * sizeof(cf32)));
       HIP_CHECK(hipMemcpy(d_rot, rot.data(), sflen * sizeof(cf32), hipMemcpyHostToDevice));
     }
+    uint64_t first_sf = 0;  // subframes of the file in front of the replay (DECODE_MIB state of the reference)
+    if (start_tti == LSN_TTI_FROM_MIB) {
+      bool found = false;
+      for (uint64_t i = 0; i < sf_in_file && i < 10 * 64; i += 10) {  // the file starts at subframe 0 of a radio frame (file mode has no sync)
+        if (pread(fd, slot[0].h_raw, sf_bytes, (off_t)(file_off0 + i * sf_bytes)) != (ssize_t)sf_bytes) break;
+        HIP_CHECK(hipMemcpyAsync(slot[0].d_raw, slot[0].h_raw, sf_bytes, hipMemcpyHostToDevice, st));
+        lsn_launch_file_unpack(slot[0].d_raw, d_rot, sflen, nant, slot[0].d_iq, 1, st);
+        HIP_CHECK(hipStreamSynchronize(st));
+        lsn_mib_t mib;
+        const int r = mibDecode(slot[0].d_iq, true, &mib, nullptr);
+        if (r < 0) throw std::runtime_error("MIB decode failed");
+        if (r == 1) { found = true; first_sf = i; start_tti = mib.sfn * 10u; break; }
+      }
+      if (!found) { rc = LSN_ERROR; throw std::runtime_error("no MIB found in the first 64 radio frames of the file"); }
+    }
     reader = std::thread([&] {
       try {
         (void)hipSetDevice(cfg.device);
         pinThisThread(nullptr);
-        uint64_t left = max_subframes ? std::min<uint64_t>(max_subframes, sf_in_file) : sf_in_file, pos = 0;
+        uint64_t avail = sf_in_file - first_sf, left = max_subframes ? std::min<uint64_t>(max_subframes, avail) : avail, pos = first_sf;
         for (int i = 0;; i ^= 1) {
           Slot& s = slot[i];
           {

@@ -71,6 +71,7 @@ void Engine::freeDevice()
     ul_set = false;
     df(prach.d_W); df(prach.d_V); df(prach.d_D); df(prach.d_Y); df(prach.d_corr); df(prach.d_out); df(prach.d_off);
     prach = Prach();
+    df(mib_d_iq); df(mib_d_llr); df(mib_d_cand);
   }
   d_dphi = nullptr; d_iq_staging = nullptr; staging_sf = 0;
   last_chunk = nullptr;
@@ -246,6 +247,18 @@ void Engine::buildTables()
           }
     }
     cd.rankmap = upload(dev_allocs, rank);
+    std::vector<uint16_t> prank(120, 0);  // PBCH block: 24 + 16 bits
+    {
+      const int D = 40, R = 2, KP = 64, ND = KP - D;
+      int nonnull = 0;
+      for (int s = 0; s < 3; s++)
+        for (int col = 0; col < 32; col++)
+          for (int r = 0; r < R; r++) {
+            const int idx = r * 32 + lsn_perm_cc[col];
+            if (idx >= ND) prank[3 * (idx - ND) + s] = (uint16_t)nonnull++;
+          }
+    }
+    cd.pbch_rank = upload(dev_allocs, prank);
   }
   // PDSCH-capable RE masks per (subframe class, symbol, PRB)
   {

@@ -38,6 +38,7 @@ struct LsnCellDev {
   float taps[5];
   uint32_t nsizes;
   uint32_t sizes[LSN_MAX_SIZES];   // distinct DCI payload sizes, ascending
+  const uint16_t* pbch_rank;       // [120] the same for the PBCH block (D = 40)
   const uint16_t* rankmap;         // [LSN_MAX_SIZES][3*LSN_MAX_DCI_D]: output position -> rank in the circular buffer
   // PDSCH
   const uint16_t* validmask;       // [3][14][nof_prb]: 12-bit mask of PDSCH-capable REs (class 0: sf0, 1: sf5, 2: other)
@@ -105,6 +106,7 @@ void lsn_launch_viterbi(const LsnCellDev& c, const float* llr, const float* pw, 
                         hipStream_t s);
 void lsn_launch_rb_power(const LsnCellDev& c, const cf32* grid, float* rbp, uint32_t nsf, hipStream_t s);
 void lsn_launch_ul_fft(const LsnCellDev& c, const cf32* iq, uint32_t nant, uint32_t ant, cf32* grid, uint32_t nsf, hipStream_t s);
+void lsn_launch_pbch(const LsnCellDev& c, const cf32* grid, const cf32* ce, const LsnChest* ch, float* llr5, LsnCand* out4, hipStream_t s);
 void lsn_launch_file_unpack(const cf32* raw, const cf32* rot, uint32_t sflen, uint32_t nant, cf32* out, uint32_t nsf, hipStream_t s);
 void lsn_launch_prach(const cf32* iq, const uint64_t* occ_off, uint32_t nocc, const cf32* W, const cf32* D, const cf32* V, int N12, int Ncp, int b0,
                       int nroots, int ncs, int nwin, cf32* Y, float* corr, float* out, hipStream_t s);

@@ -383,6 +383,71 @@ __device__ __forceinline__ uint32_t ss_validate(uint32_t n, uint32_t ncce, uint3
 }
 
 // ------------------------------------------------------------------------------------------------ PDCCH Viterbi
+// tail-biting Viterbi over D = nbits + 16 steps whose symbols are in symw (LDS, signed-byte triples); one wavefront.
+// Returns the nbits decoded bits (bit i at position 63 - i) and, in lane 0, the CRC16 remainder XOR the received parity
+// (the RNTI of a DCI / the antenna-port mask of the PBCH).
+__device__ __forceinline__ void viterbi_tb(const int* symw, unsigned long long* dec, uint32_t D, uint32_t nbits, int lane, unsigned long long& bits_out,
+                                           uint32_t& rem_out)
+{
+  __syncthreads();
+  // lane = new state j: input bit b = j&1, predecessors j>>1 and (j>>1)|32; generator masks on the old state
+  const int b = lane & 1, s0 = lane >> 1;
+  const int c0 = b ^ (__popc(s0 & 0x36) & 1), c1 = b ^ (__popc(s0 & 0x27) & 1), c2 = b ^ (__popc(s0 & 0x2B) & 1);
+  const int signs = (c0 ? 0xFF : 0x01) | (c1 ? 0xFF00 : 0x0100) | (c2 ? 0xFF0000 : 0x010000);
+  const int kconst = (c0 ? 127 : 128) + (c1 ? 127 : 128) + (c2 ? 127 : 128);
+  const int pa = s0 << 2, pb = (s0 | 32) << 2;  // ds_bpermute byte addresses of the two predecessors
+  int m = 0;
+  const int T = 3 * (int)D;  // 3 passes of D steps
+  for (int pass = 0, t = 0; pass < 3; pass++)
+    for (int tt = 0; tt < (int)D; tt++, t++) {
+      const int bm0 = __builtin_amdgcn_sdot4(symw[tt], signs, kconst, false);
+      const int a0 = __builtin_amdgcn_ds_bpermute(pa, m) + bm0, a1 = __builtin_amdgcn_ds_bpermute(pb, m) + (765 - bm0);
+      const bool d = a1 < a0;
+      m = d ? a1 : a0;
+      dec[t] = __ballot(d);  // same value, same address from every lane
+    }
+  // best end state: minimum metric, lowest index on ties
+  unsigned long long key = ((unsigned long long)(unsigned)m << 6) | (unsigned)lane;
+  for (int off = 32; off > 0; off >>= 1) {
+    unsigned long long o2 = __shfl_xor(key, off);
+    key = o2 < key ? o2 : key;
+  }
+  __syncthreads();
+  // trace-back over passes 3 and 2 (t = T-1 .. D): the state walks in scalar registers
+  int st = __builtin_amdgcn_readfirstlane((int)(key & 63ull));
+  rem_out = 0;
+  unsigned long long bits = 0;  // decoded bit i of the middle pass at position 63-i (payload); the 16 CRC bits go to tailcrc
+  unsigned int tailcrc = 0;
+  for (int hi = T; hi > (int)D; hi -= 64) {
+    const int lo = hi - 64 > (int)D ? hi - 64 : (int)D;
+    const unsigned long long mine = (lo + lane < hi) ? dec[lo + lane] : 0ull;
+    const int mlo = (int)(unsigned)mine, mhi = (int)(unsigned)(mine >> 32);
+    for (int t = hi - 1; t >= lo; t--) {
+      if (t < 2 * (int)D) {
+        const int i = t - (int)D;
+        if (i < (int)nbits) bits |= (unsigned long long)(st & 1) << (63 - i);
+        else tailcrc |= (unsigned)(st & 1) << (15 - (i - (int)nbits));
+      }
+      const unsigned wlo = (unsigned)__builtin_amdgcn_readlane(mlo, t - lo), whi = (unsigned)__builtin_amdgcn_readlane(mhi, t - lo);
+      const unsigned long long w = ((unsigned long long)whi << 32) | wlo;
+      const int dd = (int)((w >> st) & 1ull);
+      st = (st >> 1) | (dd << 5);
+    }
+  }
+  if (lane == 0) {
+    // CRC16 (x^16+x^12+x^5+1) over the payload, zero-augmented long division
+    unsigned int reg = 0;
+    for (int i = 0; i < (int)nbits + 16; i++) {
+      unsigned int bit = i < (int)nbits ? (unsigned)((bits >> (63 - i)) & 1ull) : 0u;
+      reg = (reg << 1) | bit;
+      if (reg & 0x10000u) reg ^= 0x11021u;
+    }
+    const uint32_t rnti = (tailcrc ^ reg) & 0xFFFFu;
+    rem_out = rnti;
+  }
+  bits_out = bits;
+}
+
 // One wavefront per (location, size, subframe).  Rate de-matching is a gather through a host-built rank table;
 // u8 quantisation 127.5 + 32*llr (truncated); 32-bit path metrics; 3 passes over the tail-biting block, middle pass kept.
 // Issue-cost shaping (VALU instructions are what this kernel is made of, 55 % of the whole path's): the three symbols of
@@ -446,64 +511,121 @@ __global__ __launch_bounds__(64) void k_viterbi(LsnCellDev c, const float* __res
     if (lane == 0) { out->bits = 0; out->rnti = 0; out->flags = 0; }
     return;
   }
-  __syncthreads();
-  // lane = new state j: input bit b = j&1, predecessors j>>1 and (j>>1)|32; generator masks on the old state
-  const int b = lane & 1, s0 = lane >> 1;
-  const int c0 = b ^ (__popc(s0 & 0x36) & 1), c1 = b ^ (__popc(s0 & 0x27) & 1), c2 = b ^ (__popc(s0 & 0x2B) & 1);
-  const int signs = (c0 ? 0xFF : 0x01) | (c1 ? 0xFF00 : 0x0100) | (c2 ? 0xFF0000 : 0x010000);
-  const int kconst = (c0 ? 127 : 128) + (c1 ? 127 : 128) + (c2 ? 127 : 128);
-  const int pa = s0 << 2, pb = (s0 | 32) << 2;  // ds_bpermute byte addresses of the two predecessors
-  int m = 0;
-  const int T = (int)D3;  // 3 passes of D steps
-  for (int pass = 0, t = 0; pass < 3; pass++)
-    for (int tt = 0; tt < (int)D; tt++, t++) {
-      const int bm0 = __builtin_amdgcn_sdot4(symw[tt], signs, kconst, false);
-      const int a0 = __builtin_amdgcn_ds_bpermute(pa, m) + bm0, a1 = __builtin_amdgcn_ds_bpermute(pb, m) + (765 - bm0);
-      const bool d = a1 < a0;
-      m = d ? a1 : a0;
-      dec[t] = __ballot(d);  // same value, same address from every lane
-    }
-  // best end state: minimum metric, lowest index on ties
-  unsigned long long key = ((unsigned long long)(unsigned)m << 6) | (unsigned)lane;
-  for (int off = 32; off > 0; off >>= 1) {
-    unsigned long long o2 = __shfl_xor(key, off);
-    key = o2 < key ? o2 : key;
-  }
-  __syncthreads();
-  // trace-back over passes 3 and 2 (t = T-1 .. D): the state walks in scalar registers
-  int st = __builtin_amdgcn_readfirstlane((int)(key & 63ull));
-  unsigned long long bits = 0;  // decoded bit i of the middle pass at position 63-i (payload); the 16 CRC bits go to tailcrc
-  unsigned int tailcrc = 0;
-  for (int hi = T; hi > (int)D; hi -= 64) {
-    const int lo = hi - 64 > (int)D ? hi - 64 : (int)D;
-    const unsigned long long mine = (lo + lane < hi) ? dec[lo + lane] : 0ull;
-    const int mlo = (int)(unsigned)mine, mhi = (int)(unsigned)(mine >> 32);
-    for (int t = hi - 1; t >= lo; t--) {
-      if (t < 2 * (int)D) {
-        const int i = t - (int)D;
-        if (i < (int)nbits) bits |= (unsigned long long)(st & 1) << (63 - i);
-        else tailcrc |= (unsigned)(st & 1) << (15 - (i - (int)nbits));
-      }
-      const unsigned wlo = (unsigned)__builtin_amdgcn_readlane(mlo, t - lo), whi = (unsigned)__builtin_amdgcn_readlane(mhi, t - lo);
-      const unsigned long long w = ((unsigned long long)whi << 32) | wlo;
-      const int dd = (int)((w >> st) & 1ull);
-      st = (st >> 1) | (dd << 5);
-    }
-  }
+  unsigned long long bits; uint32_t rnti;
+  viterbi_tb(symw, dec, D, nbits, lane, bits, rnti);
   if (lane == 0) {
-    // CRC16 (x^16+x^12+x^5+1) over the payload, zero-augmented long division
-    unsigned int reg = 0;
-    for (int i = 0; i < (int)nbits + 16; i++) {
-      unsigned int bit = i < (int)nbits ? (unsigned)((bits >> (63 - i)) & 1ull) : 0u;
-      reg = (reg << 1) | bit;
-      if (reg & 0x10000u) reg ^= 0x11021u;
-    }
-    const uint32_t rnti = (tailcrc ^ reg) & 0xFFFFu;
     out->bits = bits;
     out->rnti = rnti;
     out->flags = 1u | (ss_validate(ncce_tot, ncce, (uint32_t)L, sf_idx_arr[sf], rnti) << 1);  // bit 0: decoded, bits 1-2: search-space match
   }
 }
+// ------------------------------------------------------------------------------------------------ PBCH / MIB
+// srsran_ue_mib_decode on subframe 0 (LTESniffer_Core.cc:382-395).  k_pbch_llr: one workgroup; the 240 PBCH symbols
+// (72 centre carriers of symbols 7-10, CRS positions of four ports left out) are equalised like a REG (MRC or SFBC pairs),
+// turned into QPSK soft bits and written once raw and once descrambled for each of the four radio-frame positions of the
+// 40 ms BCH period (c_init = N_cell_ID).  k_pbch_viterbi: one wavefront per hypothesis, the DCI decoder's tail-biting
+// Viterbi on 40 steps (24 MIB bits + CRC16 whose mask tells the number of CRS ports).
+__device__ __forceinline__ void pbch_pos(const LsnCellDev& c, int i, int& l, int& k)
+{
+  const int k0 = (int)c.nre / 2 - 36;
+  if (i < 96) {
+    l = 7 + i / 48;
+    const int j = i % 48, r = (int)(c.id % 3);
+    const int d0 = r == 0 ? 1 : 0, d1 = r == 2 ? 1 : 2;  // the two carriers of a group of three that carry data
+    k = k0 + 3 * (j >> 1) + ((j & 1) ? d1 : d0);
+  } else {
+    l = 9 + (i - 96) / 72;
+    k = k0 + (i - 96) % 72;
+  }
+}
+__global__ __launch_bounds__(256) void k_pbch_llr(LsnCellDev c, const cf32* __restrict__ g, const cf32* __restrict__ ce, const LsnChest* __restrict__ ch,
+                                                  float* __restrict__ out /* [5][480]: raw, then 4 descrambled */)
+{
+  const int tid = threadIdx.x, nre = (int)c.nre, A = (int)c.nof_rx;
+  const float noise = ch[0].noise_avg;
+  cf32 x0, x1;
+  int i0 = -1;
+  if (c.nof_ports == 1) {
+    if (tid < 240) {
+      i0 = tid;
+      int l, k; pbch_pos(c, tid, l, k);
+      float nr = 0.0f, ni = 0.0f, den = 0.0f;
+      for (int rx = 0; rx < A; rx++) {
+        const size_t b = ((size_t)rx * 14 + l) * nre + k;
+        const cf32 t = cmulconj(g[b], ce[b]);
+        const float hp = ce[b].r * ce[b].r + ce[b].i * ce[b].i;
+        if (rx == 0) { nr = t.r; ni = t.i; den = hp; } else { nr = nr + t.r; ni = ni + t.i; den = den + hp; }
+      }
+      den = den + noise;
+      x0.r = nr / den; x0.i = ni / den;
+    }
+  } else if (tid < 120) {
+    i0 = 2 * tid;
+    int l, ka, kb, l2; pbch_pos(c, i0, l, ka); pbch_pos(c, i0 + 1, l2, kb);
+    float x0r = 0, x0i = 0, x1r = 0, x1i = 0, hh = 0;
+    for (int rx = 0; rx < A; rx++) {
+      const size_t b0 = ((size_t)rx * 14 + l) * nre, b1 = (((size_t)A + rx) * 14 + l) * nre;
+      const cf32 r0 = g[b0 + ka], r1 = g[b0 + kb];
+      const cf32 h00 = ce[b0 + ka], h01 = ce[b0 + kb], h10 = ce[b1 + ka], h11 = ce[b1 + kb];
+      const float hp = (h00.r * h00.r + h00.i * h00.i) + (h11.r * h11.r + h11.i * h11.i);
+      const cf32 a = cmulconj(r0, h00), b = cmulconj(h11, r1), cc = cmulconj(h10, r0), d = cmulconj(r1, h01);
+      const float t0r = a.r + b.r, t0i = a.i + b.i, t1r = d.r - cc.r, t1i = d.i - cc.i;
+      if (rx == 0) { x0r = t0r; x0i = t0i; x1r = t1r; x1i = t1i; hh = hp; }
+      else { x0r = x0r + t0r; x0i = x0i + t0i; x1r = x1r + t1r; x1i = x1i + t1i; hh = hh + hp; }
+    }
+    x0.r = x0r / hh * SQRT2F; x0.i = x0i / hh * SQRT2F;
+    x1.r = x1r / hh * SQRT2F; x1.i = x1i / hh * SQRT2F;
+  }
+  if (i0 < 0) return;
+  const int nsym = c.nof_ports == 1 ? 1 : 2;
+  for (int s = 0; s < nsym; s++) {
+    const cf32 x = s ? x1 : x0;
+    const float v[2] = {-(x.r * SQRT2F), -(x.i * SQRT2F)};
+    for (int j = 0; j < 2; j++) {
+      const int n = 2 * (i0 + s) + j;
+      out[n] = v[j];
+      for (int q = 0; q < 4; q++) {
+        const uint32_t m = 480u * (uint32_t)q + (uint32_t)n;
+        const uint32_t cbit = (uint32_t)c.gold_x1[m] ^ (uint32_t)(__popc(c.gold_x2mask[m] & c.id) & 1);
+        out[480 * (q + 1) + n] = cbit ? -v[j] : v[j];
+      }
+    }
+  }
+}
+__global__ __launch_bounds__(64) void k_pbch_viterbi(LsnCellDev c, const float* __restrict__ llr5, LsnCand* __restrict__ out4)
+{
+  __shared__ int symw[LSN_MAX_DCI_D];
+  __shared__ unsigned long long dec[3 * LSN_MAX_DCI_D];
+  const int lane = threadIdx.x, q = blockIdx.x;
+  const float* e = llr5 + 480 * (q + 1);
+  const uint32_t D = 40, D3 = 120, E = 480;
+  for (uint32_t t = lane; t < D; t += 64) {
+    uint32_t word = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 3; j++) {
+      float acc = 0.0f;
+      bool first = true;
+      for (uint32_t k = c.pbch_rank[3 * t + j]; k < E; k += D3) {
+        const float v = e[k];
+        if (first) { acc = v; first = false; } else acc = acc + v;
+      }
+      float qv = 127.5f + 32.0f * acc;
+      qv = qv < 0.0f ? 0.0f : qv;
+      qv = qv > 255.0f ? 255.0f : qv;
+      word |= (((uint32_t)(unsigned char)qv - 128u) & 0xFFu) << (8 * j);
+    }
+    symw[t] = (int)word;
+  }
+  unsigned long long bits; uint32_t rem;
+  viterbi_tb(symw, dec, D, 24, lane, bits, rem);
+  if (lane == 0) { out4[q].bits = bits; out4[q].rnti = rem; out4[q].flags = 1u; }
+}
+void lsn_launch_pbch(const LsnCellDev& c, const cf32* grid, const cf32* ce, const LsnChest* ch, float* llr5, LsnCand* out4, hipStream_t s)
+{
+  hipLaunchKernelGGL(k_pbch_llr, dim3(1), dim3(256), 0, s, c, grid, ce, ch, llr5);
+  hipLaunchKernelGGL(k_pbch_viterbi, dim3(4), dim3(64), 0, s, c, llr5, out4);
+}
+
 void lsn_launch_viterbi(const LsnCellDev& c, const float* llr, const float* pw, const uint32_t* cfi, const uint32_t* sf_idx, LsnCand* cand, uint32_t nsf,
                         hipStream_t s)
 {

@@ -193,6 +193,13 @@ int o_pdsch_decode_tb(const int16_t* e, int G, int tbs, int Qm, int nof_layers_r
                       uint8_t* payload, int* iters_total);
 int o_turbo_nwin(int K);
 
+/* ---------- PBCH / MIB (o_pbch.c) ---------- */
+typedef struct { int found; uint32_t sfn /* MIB SFN + radio-frame position */, sfn_offset, nof_prb, nof_ports, phich_length, phich_ng_x6, mib_bits; } o_mib_t;
+void o_pbch_positions(const o_cell_t* cell, uint8_t* l, uint16_t* k);
+void o_pbch_llr(const o_cell_t* cell, uint32_t nof_rx, const ocf_t* grid, const ocf_t* ce, float noise, float* llr);
+int o_pbch_decode(const o_cell_t* cell, uint32_t nof_rx, const ocf_t* grid, const ocf_t* ce, float noise, o_mib_t* out, float* llr_out);
+int o_mib_decode_subframe(const o_cell_t* cell, uint32_t nof_rx, const ocf_t* iq, o_mib_t* out, float* llr_out);
+
 /* ---------- IQ capture file source (o_file.c) ---------- */
 long o_file_read(const char* path, uint32_t nof_prb, uint32_t nant, long offset_time, float offset_freq, uint32_t first_sf, uint32_t nsf, ocf_t* out);
 

@@ -429,6 +429,31 @@ extern "C" int txg_next(txg_t* g, float* iq, txg_pdu_t* pdus, int max_pdus, uint
     for (int i = 0; i < 4; i++) map_quad(g->regs.pcfich_k0[i], 0, &sy[4 * i]);
   }
 
+  // ---- PBCH (36.211 6.6, 36.212 5.3.1): MIB of this radio frame's 40 ms period, quarter sfn % 4, on subframe 0 ----
+  if (sf == 0) {
+    bits_t mib;
+    static const int bwidx[6] = {6, 15, 25, 50, 75, 100};
+    int bi = 0; for (int i = 0; i < 6; i++) if (bwidx[i] == nprb) bi = i;
+    put(mib, (uint32_t)bi, 3);
+    put(mib, 0, 1);  // phich-Duration normal
+    put(mib, c.phich_ng_x6 == 1 ? 0u : c.phich_ng_x6 == 3 ? 1u : c.phich_ng_x6 == 6 ? 2u : 3u, 2);
+    put(mib, (sfn >> 2) & 0xFF, 8);
+    put(mib, 0, 10);
+    crc_attach(mib, 0x11021, 16, P == 1 ? 0x0000u : (P == 2 ? 0xFFFFu : 0x5555u));
+    bits_t e = rm_conv_tx(conv_encode(mib), 1920), scr = gold((uint32_t)id, 1920), q(480);
+    for (int i = 0; i < 480; i++) q[i] = e[480 * (sfn & 3) + i] ^ scr[480 * (sfn & 3) + i];
+    std::vector<cf> sy; modulate(q, 2, sy);
+    std::vector<std::pair<int, int>> pos;
+    for (int l = 7; l <= 10; l++)
+      for (int k = 6 * nprb - 36; k < 6 * nprb + 36; k++)
+        if (!(l <= 8 && k % 3 == id % 3)) pos.push_back({l, k});
+    if (P == 1) { for (int i = 0; i < 240; i++) grid[0][pos[i].first * nre + pos[i].second] = sy[i]; }
+    else for (int i = 0; i < 240; i += 2) {
+      cf p0[2], p1[2]; sfbc_pair(sy[i], sy[i + 1], p0, p1);
+      for (int j = 0; j < 2; j++) { grid[0][pos[i + j].first * nre + pos[i + j].second] = p0[j]; grid[1][pos[i + j].first * nre + pos[i + j].second] = p1[j]; }
+    }
+  }
+
   // ---- schedule ----
   std::vector<Grant> grants;
   std::vector<uint8_t> cce_used(ncce, 0);
