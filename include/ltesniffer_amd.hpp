@@ -69,7 +69,7 @@ public:
   bool setRachConfig(const lsn_prach_cfg_t& p) { return lsn_phy_set_prach_config(h, &p) == LSN_SUCCESS; }    // PUSCH_Decoder::set_rach_config
   void setPrachSink(lsn_prach_sink_t cb, void* user) { lsn_phy_set_prach_sink(h, cb, user); }               // work_prach's report
   // srsran_ue_mib_decode + srsran_pbch_mib_unpack on one subframe 0 (LTESniffer_Core.cc:386-391); true when a MIB was found
-  bool mibDecode(cf_t* const* subframe_iq_contiguous, lsn_mib_t& mib) { return lsn_phy_mib_decode(h, subframe_iq_contiguous[0], 0, &mib) == 1; }
+  bool mibDecode(const cf_t* subframe_iq /* [nof_rx_antennas][SF_LEN] */, lsn_mib_t& mib) { return lsn_phy_mib_decode(h, subframe_iq, 0, &mib) == 1; }
   lsn_phy_t* handle() { return h; }
 private:
   static std::shared_ptr<SubframeWorker> wrap(lsn_worker_t* w) { return w ? std::shared_ptr<SubframeWorker>(new SubframeWorker(w)) : nullptr; }
