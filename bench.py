@@ -143,6 +143,9 @@ def main():
         try:
             import glob
             cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json")))
+            cur = os.path.join(ROOT, "profiles", "current.json")
+            if os.path.exists(cur) and json.load(open(cur)).get("pmc_hbm"):
+                cand = [os.path.join(ROOT, "profiles", json.load(open(cur))["pmc_hbm"])]
             if cand:
                 pj = json.load(open(cand[-1])).get(la.KERNELS[kt])
                 if pj:
@@ -156,6 +159,8 @@ def main():
         valu = None
         try:
             cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_valu.json")))
+            if os.path.exists(cur) and json.load(open(cur)).get("pmc_valu"):
+                cand = [os.path.join(ROOT, "profiles", json.load(open(cur))["pmc_valu"])]
             if cand:
                 vj = json.load(open(cand[-1]))
                 pj = vj.get(la.KERNELS[kt])
