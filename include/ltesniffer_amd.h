@@ -168,7 +168,8 @@ int lsn_phy_process_file(lsn_phy_t* phy, const char* path, const lsn_file_cfg_t*
  * values come from SIB2 (ULSchedule::set_config, ULSchedule.cc:140-158: cyclicShift, groupAssignmentPUSCH).
  * lsn_phy_pusch_decode runs srsran_enb_ul_fft + srsran_chest_ul_estimate_pusch + srsran_pusch_decode
  * (UL_Sniffer_PUSCH.cc:392,256,262) for a whole list of grants on n_subframes of the uplink antenna.
- * Round-1 scope: one antenna, no group/sequence/frequency hopping, no SRS, no UCI on PUSCH, L_prb >= 3 of the 2^a3^b5^c set
+ * Round-1 scope: one antenna, no group/sequence/frequency hopping, no SRS, L_prb >= 3 of the 2^a3^b5^c set; control information on the
+ * PUSCH is located and skipped / erased, not decoded
  * (UL_Sniffer_PUSCH.cc:3-10); any other grant comes back with crc_ok = 0. */
 typedef struct { uint32_t cyclic_shift; uint32_t delta_ss; } lsn_ul_cfg_t;
 typedef struct {
@@ -179,6 +180,12 @@ typedef struct {
   uint32_t mod;      /* bits per symbol: 2, 4, 6, 8 */
   uint32_t tbs;      /* bits */
   int rv;
+  /* control information multiplexed into the PUSCH (TS 36.212 5.2.2.6-8), located so that the UL-SCH bits are de-multiplexed
+   * correctly; the reference's settings are UL_Sniffer_PUSCH.cc:429-450 with the offsets I_ack = 10, I_cqi = 8, I_ri = 11 of
+   * MCSTracking.cc:1534-1538 */
+  uint32_t nof_ack;  /* HARQ-ACK bits 0..2 (uci_cfg.ack[0].nof_acks) */
+  uint32_t cqi_bits; /* size of the CQI report, 0 = none (aperiodic request: 4 + 2 N, higher-layer sub-band) */
+  uint32_t ri_bits;  /* rank indication bits (1 with a CQI request) */
 } lsn_pusch_grant_t;
 typedef struct { uint32_t crc_ok; uint32_t iterations; float snr_db; uint32_t payload_off; } lsn_pusch_result_t;
 int lsn_phy_set_ul_config(lsn_phy_t* phy, const lsn_ul_cfg_t* cfg);

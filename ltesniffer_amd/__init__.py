@@ -101,7 +101,7 @@ class UlCfg(C.Structure):
 
 class PuschGrant(C.Structure):
     _fields_ = [("sf", C.c_uint32), ("rnti", C.c_uint16), ("n_dmrs", C.c_uint16), ("n_prb", C.c_uint32), ("L_prb", C.c_uint32),
-                ("mod", C.c_uint32), ("tbs", C.c_uint32), ("rv", C.c_int)]
+                ("mod", C.c_uint32), ("tbs", C.c_uint32), ("rv", C.c_int), ("nof_ack", C.c_uint32), ("cqi_bits", C.c_uint32), ("ri_bits", C.c_uint32)]
 
 
 class PuschResult(C.Structure):
@@ -380,7 +380,8 @@ class Phy:
         -> list of dict(crc_ok, iterations, snr_db, payload)"""
         ul_iq = np.ascontiguousarray(ul_iq, dtype=np.complex64)
         n = len(grants)
-        arr = (PuschGrant * max(1, n))(*[PuschGrant(g["sf"], g["rnti"], g.get("n_dmrs", 0), g["n_prb"], g["L_prb"], g["mod"], g["tbs"], g.get("rv", 0))
+        arr = (PuschGrant * max(1, n))(*[PuschGrant(g["sf"], g["rnti"], g.get("n_dmrs", 0), g["n_prb"], g["L_prb"], g["mod"], g["tbs"], g.get("rv", 0),
+                                                    g.get("nof_ack", 0), g.get("cqi_bits", 0), g.get("ri_bits", 0))
                                          for g in grants])
         res = (PuschResult * max(1, n))()
         cap = sum(g["tbs"] // 8 for g in grants) + 64

@@ -145,8 +145,19 @@ void Engine::puschDecodeGrid(const cf32* d_grid, uint32_t nsf, uint32_t start_tt
     if (!ok) continue;
     const uint32_t M = 12 * g.L_prb, sf_idx = (start_tti + g.sf) % 10;
     CbSegm s;
-    const int G = (int)(12 * M * g.mod);
     if (!cbsegm((int)g.tbs, s)) continue;
+    // control resources Q' = min(ceil(O M_sc N_symb beta / sum K_r), cap) (36.212 5.2.2.6), beta in eighths: 20, 15.875, 2.25
+    const long long sumK = (long long)s.Cp * s.Kp + (long long)s.Cm * s.Km;
+    auto qprime = [&](uint32_t O, long long beta8, uint32_t cap) -> uint32_t {
+      if (!O) return 0u;
+      const long long q = ((long long)O * M * 12 * beta8 + 8 * sumK - 1) / (8 * sumK);
+      return (uint32_t)std::min<long long>(q, cap);
+    };
+    if (g.nof_ack > 2 || g.ri_bits > 2 || g.cqi_bits > 64) continue;
+    const uint32_t q_ack = qprime(g.nof_ack, 160, 4 * M), q_ri = qprime(g.ri_bits, 127, 4 * M);
+    const uint32_t q_cqi = g.cqi_bits ? qprime(g.cqi_bits + (g.cqi_bits > 11 ? 8u : 0u), 18, 12 * M - q_ri) : 0u;
+    if (q_ri + q_cqi >= 12 * M) continue;
+    const int G = (int)((12 * M - q_ri - q_cqi) * g.mod);
     LsnUlGrantDev d{};
     d.sf = g.sf; d.n_prb = g.n_prb; d.L_prb = g.L_prb; d.qm = g.mod;
     for (uint32_t sl = 0; sl < 2; sl++) d.ncs[sl] = (n_dmrs1[ul_cfg.cyclic_shift & 7] + n_dmrs2[g.n_dmrs & 7] + ul_npn[2 * sf_idx + sl]) % 12u;
@@ -155,6 +166,7 @@ void Engine::puschDecodeGrid(const cf32* d_grid, uint32_t nsf, uint32_t start_tt
     d.hs_off = (uint32_t)hs_n; hs_n += 2 * M;
     d.llr_off = (uint32_t)llr_n; llr_n += ((size_t)G + 7) & ~(size_t)7;
     d.scale = 1.0f / sqrtf((float)M);
+    d.q_ack = q_ack; d.q_ri = q_ri; d.q_cqi = q_cqi;
     // UL-SCH: one transport block, one layer (36.212 5.2.2.6)
     const int Qm = (int)g.mod, Gp = G / Qm, gamma = Gp % s.C;
     TbRef ref{i, (uint32_t)r.h_cbs.size(), (uint32_t)s.C, (uint32_t)pay_n, (int)g.tbs};
@@ -253,7 +265,7 @@ long Engine::tapUl(int what, uint32_t index, void* out, size_t cap)
     for (size_t i = 0; i < ul_last_idx.size(); i++)
       if ((uint32_t)ul_last_idx[i] == index) d = &ul_last_gd[i];
     if (!d) return LSN_ERROR_INVALID_INPUTS;
-    n = (size_t)12 * 12 * d->L_prb * d->qm * sizeof(int16_t); src = runner_u.d_llr16 + d->llr_off;
+    n = ((size_t)12 * 12 * d->L_prb - d->q_ri - d->q_cqi) * d->qm * sizeof(int16_t); src = runner_u.d_llr16 + d->llr_off;
   } else return LSN_ERROR_INVALID_INPUTS;
   if (n > cap) return LSN_ERROR_INVALID_INPUTS;
   if (hipMemcpy(out, src, n, hipMemcpyDeviceToHost) != hipSuccess) return LSN_ERROR;

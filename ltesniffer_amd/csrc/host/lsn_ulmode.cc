@@ -91,6 +91,12 @@ void Engine::commitChunkUl(Chunk& ch, JobRunner& r)
       for (auto& u : c.ul) {
         UlSchedGrant g;
         g.rnti = u.rnti; g.n_dmrs = u.dci.n_dmrs; g.hopping = u.dci.hopping != 0;
+        g.cqi_req = u.dci.cqi_req != 0;
+        for (auto& e : c.dl)  // "check nof_ack for uplink pusch decoder", SubframeWorker.cc:318-336
+          if (e.rnti == u.rnti) {
+            if (e.grant64.nof_tb == 1) g.nof_ack = 1;
+            else if (e.grant64.nof_tb == 2) g.nof_ack = 2;
+          }
         if (u.ok) { g.g = u.grant; g.g256 = u.grant256; }
         cur.push_back(g);
       }
@@ -148,6 +154,13 @@ void Engine::commitChunkUl(Chunk& ch, JobRunner& r)
       if (m.hopping || g.tbs <= 0) continue;  // frequency hopping is outside the round-1 scope: the attempt fails
       lsn_pusch_grant_t q{};
       q.sf = a.sf; q.rnti = m.rnti; q.n_dmrs = (uint16_t)m.n_dmrs; q.n_prb = g.n_prb; q.L_prb = g.L_prb; q.mod = (uint32_t)a.qm; q.tbs = (uint32_t)g.tbs; q.rv = g.rv;
+      // uci_cfg of the attempt, UL_Sniffer_PUSCH.cc:429-450: HARQ-ACK bits, aperiodic higher-layer sub-band CQI (4 + 2 N bits) + one RI bit on request
+      q.nof_ack = m.nof_ack;
+      if (m.cqi_req) {
+        const uint32_t k = cell.nof_prb <= 7 ? 0u : (cell.nof_prb <= 26 ? 4u : (cell.nof_prb <= 63 ? 6u : 8u));  // dl_sniffer_pdsch.c:276-305
+        q.cqi_bits = k ? 4u + 2u * ((cell.nof_prb + k - 1) / k) : 0u;
+        q.ri_bits = 1;
+      }
       gl.push_back(q);
       keys.push_back(a);
     }

@@ -91,6 +91,7 @@ struct LsnUlGrantDev {
   uint32_t hs_off;      // cf32 offset of the 2 M smoothed channel estimates
   uint32_t llr_off;     // int16 offset of the 12 M Qm LLRs (UL-SCH order)
   float scale;          // 1 / sqrt(M)
+  uint32_t q_ack, q_ri, q_cqi;  // control symbols multiplexed into the allocation (36.212 5.2.2.6): HARQ-ACK punctures, RI / CQI are skipped
 };
 
 struct LsnCbRes { uint32_t ok, iters, rem_a, iters_run; uint32_t cyc_rm, cyc_map, cyc_out, cyc_all; };  // cyc_*: shader cycles per phase (s_memtime)

@@ -178,6 +178,25 @@ __global__ __launch_bounds__(256) void k_pusch_demod(LsnCellDev c, const LsnUlGr
       ar = ar + p.r; ai = ai + p.i;
       idx += r; idx = idx >= M ? idx - M : idx;
     }
+    // cell (r, col) of the M x 12 channel-interleaver matrix (36.212 5.2.2.8) in closed form: the i-th RI / HARQ-ACK symbol sits
+    // in row M - 1 - i / 4, column set[(-i) mod 4]; CQI then data fill the other cells row by row
+    int dcell; bool is_ack = false;
+    {
+      const int qri = (int)g.q_ri, qack = (int)g.q_ack, qcqi = (int)g.q_cqi;
+      auto in_col = [&](int q, int slot) { const int i0 = (4 - slot) & 3; return q > i0 ? (q - 1 - i0) / 4 + 1 : 0; };  // symbols of a column slot
+      int before = 0; bool is_ri = false;
+#pragma unroll
+      for (int slot = 0; slot < 4; slot++) {
+        const int cc = slot == 0 ? 1 : (slot == 1 ? 4 : (slot == 2 ? 7 : 10)), n = in_col(qri, slot), top = M - n;
+        before += r > top ? r - top : 0;             // RI cells of this column in the rows above r
+        if (n && r >= top && cc < col) before += 1;  // ... and to the left in row r
+        if (n && r >= top && cc == col) is_ri = true;
+        const int ca = slot == 0 ? 2 : (slot == 1 ? 3 : (slot == 2 ? 8 : 9));
+        if (ca == col && r >= M - in_col(qack, slot) && in_col(qack, slot)) is_ack = true;
+      }
+      const int rank = r * 12 + col - before;
+      dcell = (is_ri || rank < qcqi) ? -1 : rank - qcqi;
+    }
     float Lb[8];
     ul_demod_llr(Qm, ar * scale, ai * scale, Lb);
     for (int b = 0; b < Qm; b++) {
@@ -187,7 +206,7 @@ __global__ __launch_bounds__(256) void k_pusch_demod(LsnCellDev c, const LsnUlGr
       int q = (int)v;
       const uint32_t sidx = ((uint32_t)col * (uint32_t)M + (uint32_t)r) * (uint32_t)Qm + (uint32_t)b;  // scrambling: transmitted order
       const uint32_t cbit = (uint32_t)c.gold_x1[sidx] ^ (uint32_t)(__popc(c.gold_x2mask[sidx] & g.cinit) & 1);
-      e[((uint32_t)r * 12u + (uint32_t)col) * (uint32_t)Qm + (uint32_t)b] = (int16_t)(cbit ? -q : q);  // UL-SCH (row-major) order
+      if (dcell >= 0) e[(uint32_t)dcell * (uint32_t)Qm + (uint32_t)b] = is_ack ? (int16_t)0 : (int16_t)(cbit ? -q : q);  // UL-SCH (row-major) order
     }
   }
 }

@@ -219,6 +219,9 @@ int o_prach_detect(const o_cell_t* cell, const o_prach_cfg_t* cfg, const ocf_t* 
 
 /* ---------- uplink: SC-FDMA demodulation + PUSCH (o_pusch.c) ---------- */
 typedef struct { uint32_t cyclic_shift; /* SIB2 cyclicShift 0..7 */ uint32_t delta_ss; /* SIB2 groupAssignmentPUSCH 0..29 */ } o_ul_cfg_t;
+typedef struct { uint32_t nof_ack; uint32_t cqi_bits; uint32_t ri_bits; } o_uci_t; /* HARQ-ACK bits 0..2, CQI report size (0 = none), RI bits */
+int o_uci_cqi_bits(uint32_t nof_prb);
+int o_uci_layout(int M, int tbs, const o_uci_t* uci, uint8_t* cls, int* didx, int* q_ack, int* q_ri, int* q_cqi);
 int o_ul_valid_prb(uint32_t L);
 void o_ul_shift_table(int N, ocf_t* t);
 void o_ul_fft(const o_cell_t* cell, const ocf_t* in, ocf_t* grid);
@@ -229,6 +232,10 @@ int o_pusch_demod(const o_cell_t* cell, const o_ul_cfg_t* ul, uint32_t sf_idx, u
                   const ocf_t* grid, int16_t* e, float* noise_out, float* sigpow_out);
 int o_pusch_decode(const o_cell_t* cell, const o_ul_cfg_t* ul, uint32_t sf_idx, uint16_t rnti, const o_pusch_grant_t* g, uint32_t n_dmrs_dci,
                    const ocf_t* grid, int max_iter, uint8_t* payload, int* iters, float* snr_db);
+int o_pusch_demod_uci(const o_cell_t* cell, const o_ul_cfg_t* ul, uint32_t sf_idx, uint16_t rnti, const o_pusch_grant_t* g, uint32_t n_dmrs_dci,
+                      const o_uci_t* uci, const ocf_t* grid, int16_t* e, float* noise_out, float* sigpow_out);
+int o_pusch_decode_uci(const o_cell_t* cell, const o_ul_cfg_t* ul, uint32_t sf_idx, uint16_t rnti, const o_pusch_grant_t* g, uint32_t n_dmrs_dci,
+                       const o_uci_t* uci, const ocf_t* grid, int max_iter, uint8_t* payload, int* iters, float* snr_db);
 
 /* ---------- pcap (o_pcap.c) ---------- */
 typedef struct o_pcap o_pcap_t;

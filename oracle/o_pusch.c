@@ -132,12 +132,78 @@ void o_idft_table(int M, ocf_t* w)
   }
 }
 
+/* ---- UCI multiplexed into the PUSCH (36.212 5.2.2.6-5.2.2.8), as far as the data decoder needs it ----
+ * What the reference configures (UL_Sniffer_PUSCH.cc:429-450, defaults MCSTracking.cc:1534-1538): HARQ-ACK bits of the
+ * downlink grants seen together with the DCI 0 (nof_ack 0/1/2, SubframeWorker.cc:318-336), and for an aperiodic CSI
+ * request a higher-layer sub-band CQI report of 4 + 2 N bits plus one RI bit; offsets I_ack = 10, I_cqi = 8, I_ri = 11
+ * (beta = 20, 2.25, 15.875).  The control information itself is not decoded here; its resource elements are located so
+ * that the UL-SCH bits are de-multiplexed correctly: RI cells are skipped, the first Q'_CQI cells of the row-major
+ * fill are CQI, HARQ-ACK cells puncture the data and come back as erasures. */
+int o_uci_cqi_bits(uint32_t nof_prb) /* srsran_cqi_size for SRSRAN_CQI_TYPE_SUBBAND_HL, one codeword, no PMI */
+{
+  int k = nof_prb <= 7 ? 0 : (nof_prb <= 26 ? 4 : (nof_prb <= 63 ? 6 : 8)); /* ul_cqi_hl_get_subband_size, dl_sniffer_pdsch.c:276-292 */
+  if (!k) return 0;
+  return 4 + 2 * (((int)nof_prb + k - 1) / k);
+}
+
+static int uci_qprime(int O, int M, int beta8, int sumK, int cap)
+{
+  if (O <= 0) return 0;
+  long long num = (long long)O * M * 12 * beta8, den = 8ll * sumK;
+  int q = (int)((num + den - 1) / den);
+  return q < cap ? q : cap;
+}
+
+/* cls[r * 12 + c]: 0 data, 1 CQI, 2 RI, 3 HARQ-ACK; didx: UL-SCH symbol index of a data / ACK-punctured cell.
+ * Built by running the standard's procedure literally. Returns the number of UL-SCH symbols (G / Qm), -1 on error. */
+int o_uci_layout(int M, int tbs, const o_uci_t* uci, uint8_t* cls, int* didx, int* q_ack, int* q_ri, int* q_cqi)
+{
+  o_cbsegm_t sg;
+  int sumK = 0;
+  if (o_cbsegm(&sg, tbs)) return -1;
+  sumK = sg.Cp * sg.Kp + sg.Cm * sg.Km;
+  const int Qa = uci ? uci_qprime((int)uci->nof_ack, M, 160, sumK, 4 * M) : 0;
+  const int Qr = uci ? uci_qprime((int)uci->ri_bits, M, 127, sumK, 4 * M) : 0;
+  int Oc = uci ? (int)uci->cqi_bits : 0;
+  const int Qc = Oc ? uci_qprime(Oc + (Oc > 11 ? 8 : 0), M, 18, sumK, 12 * M - Qr) : 0;
+  static const int ri_cols[4] = {1, 4, 7, 10}, ack_cols[4] = {2, 3, 8, 9};
+  memset(cls, 0, (size_t)(12 * M));
+  for (int i = 0, j = 0, r = M - 1; i < Qr;) { /* 5.2.2.8: rank indication first, bottom row upwards */
+    cls[r * 12 + ri_cols[j]] = 2;
+    i++; r = M - 1 - i / 4; j = (j + 3) % 4;
+  }
+  int k = 0; /* then CQI followed by data, row by row, skipping the RI cells */
+  for (int r = 0; r < M; r++)
+    for (int c = 0; c < 12; c++) {
+      if (cls[r * 12 + c] == 2) { didx[r * 12 + c] = -1; continue; }
+      if (k < Qc) { cls[r * 12 + c] = 1; didx[r * 12 + c] = -1; }
+      else didx[r * 12 + c] = k - Qc;
+      k++;
+    }
+  for (int i = 0, j = 0, r = M - 1; i < Qa;) { /* HARQ-ACK overwrites */
+    cls[r * 12 + ack_cols[j]] = 3;
+    i++; r = M - 1 - i / 4; j = (j + 3) % 4;
+  }
+  if (q_ack) *q_ack = Qa;
+  if (q_ri) *q_ri = Qr;
+  if (q_cqi) *q_cqi = Qc;
+  return 12 * M - Qr - Qc;
+}
+
 /* One grant: DMRS channel estimate (LS on symbols 3 and 10, 3-tap frequency smoothing, one estimate per slot), 1-tap
  * MMSE equaliser, transform de-precoding (direct IDFT of size M_sc, summation in increasing carrier order, scale
  * 1/sqrt(M_sc)), soft demodulation, descrambling and channel de-interleaving -> e[nof_re * Qm] int16 (UL-SCH order).
  * noise_out / sigpow_out: scalar estimates (mean |ls - smoothed|^2, mean |smoothed|^2). Returns 0 or -1. */
+int o_pusch_demod_uci(const o_cell_t* cell, const o_ul_cfg_t* ul, uint32_t sf_idx, uint16_t rnti, const o_pusch_grant_t* g, uint32_t n_dmrs_dci,
+                      const o_uci_t* uci, const ocf_t* grid, int16_t* e, float* noise_out, float* sigpow_out);
 int o_pusch_demod(const o_cell_t* cell, const o_ul_cfg_t* ul, uint32_t sf_idx, uint16_t rnti, const o_pusch_grant_t* g, uint32_t n_dmrs_dci,
                   const ocf_t* grid, int16_t* e, float* noise_out, float* sigpow_out)
+{
+  return o_pusch_demod_uci(cell, ul, sf_idx, rnti, g, n_dmrs_dci, NULL, grid, e, noise_out, sigpow_out);
+}
+/* the same with multiplexed control information: e holds G = Qm * (12 M - Q'_RI - Q'_CQI) values, HARQ-ACK cells as zeros */
+int o_pusch_demod_uci(const o_cell_t* cell, const o_ul_cfg_t* ul, uint32_t sf_idx, uint16_t rnti, const o_pusch_grant_t* g, uint32_t n_dmrs_dci,
+                      const o_uci_t* uci, const ocf_t* grid, int16_t* e, float* noise_out, float* sigpow_out)
 {
   int L = (int)g->L_prb, M = 12 * L, nre = 12 * (int)cell->nof_prb, Qm = g->mod;
   if (L < 3 || !o_ul_valid_prb(g->L_prb) || g->n_prb + g->L_prb > cell->nof_prb || Qm <= 0) return -1;
@@ -149,6 +215,9 @@ int o_pusch_demod(const o_cell_t* cell, const o_ul_cfg_t* ul, uint32_t sf_idx, u
   ocf_t* x = (ocf_t*)malloc(sizeof(ocf_t) * (size_t)M);
   ocf_t* w = (ocf_t*)malloc(sizeof(ocf_t) * (size_t)M);
   uint8_t* c = (uint8_t*)malloc((size_t)(12 * M * Qm));
+  uint8_t* cls = (uint8_t*)malloc((size_t)(12 * M));
+  int* didx = (int*)malloc(sizeof(int) * (size_t)(12 * M));
+  if (o_uci_layout(M, g->tbs > 0 ? g->tbs : 16, uci, cls, didx, NULL, NULL, NULL) < 0) { free(cls); free(didx); free(c); free(base); free(ls); free(hs); free(tmp); free(x); free(w); return -1; }
   uint32_t u = (((cell->id % 30u) + ul->delta_ss) % 30u) % 30u; /* group hopping off: u = f_ss^PUSCH */
   o_dmrs_base(u, M, base);
   o_idft_table(M, w);
@@ -213,12 +282,14 @@ int o_pusch_demod(const o_cell_t* cell, const o_ul_cfg_t* ul, uint32_t sf_idx, u
         /* scrambling runs over the transmitted (column-major) order, the decoder wants the row-major UL-SCH order
          * (36.212 5.2.2.8: R_mux x 12 matrix written row by row, read column by column) */
         if (c[((size_t)col * (size_t)M + (size_t)r) * (size_t)Qm + (size_t)b]) q = (int16_t)-q;
-        e[((size_t)r * 12 + (size_t)col) * (size_t)Qm + (size_t)b] = q;
+        const int cell_cls = cls[r * 12 + col];
+        if (cell_cls == 1 || cell_cls == 2) continue;          /* CQI / RI: not part of the UL-SCH stream */
+        e[(size_t)didx[r * 12 + col] * (size_t)Qm + (size_t)b] = cell_cls == 3 ? (int16_t)0 : q; /* HARQ-ACK punctures */
       }
     }
     col++;
   }
-  free(base); free(ls); free(hs); free(tmp); free(x); free(w); free(c);
+  free(base); free(ls); free(hs); free(tmp); free(x); free(w); free(c); free(cls); free(didx);
   return 0;
 }
 
@@ -226,12 +297,25 @@ int o_pusch_demod(const o_cell_t* cell, const o_ul_cfg_t* ul, uint32_t sf_idx, u
 int o_pusch_decode(const o_cell_t* cell, const o_ul_cfg_t* ul, uint32_t sf_idx, uint16_t rnti, const o_pusch_grant_t* g, uint32_t n_dmrs_dci,
                    const ocf_t* grid, int max_iter, uint8_t* payload, int* iters, float* snr_db)
 {
+  return o_pusch_decode_uci(cell, ul, sf_idx, rnti, g, n_dmrs_dci, NULL, grid, max_iter, payload, iters, snr_db);
+}
+int o_pusch_decode_uci(const o_cell_t* cell, const o_ul_cfg_t* ul, uint32_t sf_idx, uint16_t rnti, const o_pusch_grant_t* g, uint32_t n_dmrs_dci,
+                       const o_uci_t* uci, const ocf_t* grid, int max_iter, uint8_t* payload, int* iters, float* snr_db)
+{
   if (g->tbs <= 0) return 0;
   int M = 12 * (int)g->L_prb, G = 12 * M * g->mod;
-  int16_t* e = (int16_t*)malloc(sizeof(int16_t) * (size_t)(G > 0 ? G : 1));
+  if (uci && M >= 36) {
+    uint8_t* cls = (uint8_t*)malloc((size_t)(12 * M));
+    int* didx = (int*)malloc(sizeof(int) * (size_t)(12 * M));
+    int nsym = o_uci_layout(M, g->tbs, uci, cls, didx, NULL, NULL, NULL);
+    free(cls); free(didx);
+    if (nsym <= 0) return 0;
+    G = nsym * g->mod;
+  }
+  int16_t* e = (int16_t*)malloc(sizeof(int16_t) * (size_t)(12 * M * g->mod > 0 ? 12 * M * g->mod : 1));
   float noise = 0, sig = 0;
   int ok = 0;
-  if (o_pusch_demod(cell, ul, sf_idx, rnti, g, n_dmrs_dci, grid, e, &noise, &sig) == 0) {
+  if (o_pusch_demod_uci(cell, ul, sf_idx, rnti, g, n_dmrs_dci, uci, grid, e, &noise, &sig) == 0) {
     ok = o_pdsch_decode_tb(e, G, g->tbs, g->mod, 1, g->rv, max_iter, payload, iters);
     if (snr_db) *snr_db = 10.0f * log10f(sig / noise);
   }

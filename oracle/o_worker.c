@@ -33,7 +33,7 @@ typedef struct { /* DL_Sniffer_DCI_DL */
 } dl_entry_t;
 typedef struct { uint16_t rnti; uint32_t nof_bits, L, ncce, histval; o_dci_ul_t dci; o_pusch_grant_t g, g256; int ok; } ul_entry_t;
 /* one entry of ULSchedule (DCI_UL): grants of both UL MCS tables */
-typedef struct { uint16_t rnti; o_pusch_grant_t g, g256; uint32_t n_dmrs, hopping; int is_rar; } ulg_t;
+typedef struct { uint16_t rnti; o_pusch_grant_t g, g256; uint32_t n_dmrs, hopping; int is_rar; uint32_t nof_ack, cqi_req; } ulg_t;
 typedef struct { uint32_t tti; int valid; int n; ulg_t g[96]; } ulslot_t;
 
 typedef struct { uint8_t present, has_rar; uint16_t nof_msg_after_rar; uint8_t table; } mcs_entry_t;
@@ -740,7 +740,9 @@ static int pusch_attempt(o_worker_t* w, const ulg_t* m, const o_pusch_grant_t* g
   gg.mod = qm;
   int its = 0;
   float snr = 0;
-  int crc = o_pusch_decode(&w->cfg.cell, &w->ulcfg, tti % 10, m->rnti, &gg, m->n_dmrs, w->ul_grid, w->cfg.max_turbo_iter, w->payload, &its, &snr);
+  /* uci_cfg of this attempt, UL_Sniffer_PUSCH.cc:429-450: HARQ-ACK bits counted 4 ms earlier, aperiodic CQI (higher-layer sub-band) + 1 RI bit on request */
+  o_uci_t uci = {m->nof_ack, m->cqi_req ? (uint32_t)o_uci_cqi_bits(w->cfg.cell.nof_prb) : 0u, m->cqi_req ? 1u : 0u};
+  int crc = o_pusch_decode_uci(&w->cfg.cell, &w->ulcfg, tti % 10, m->rnti, &gg, m->n_dmrs, &uci, w->ul_grid, w->cfg.max_turbo_iter, w->payload, &its, &snr);
   w->total_iters += (uint64_t)its;
   if (crc) write_pcap_ul(w, w->payload, (uint32_t)(gg.tbs / 8), m->rnti, tti);
   return crc;
@@ -836,6 +838,12 @@ int o_worker_work_ul(o_worker_t* w, const ocf_t* dl_iq, const ocf_t* ul_iq, uint
       memset(g, 0, sizeof(*g));
       g->rnti = w->ul[i].rnti; g->g = w->ul[i].g; g->g256 = w->ul[i].g256;
       g->n_dmrs = w->ul[i].dci.n_dmrs; g->hopping = w->ul[i].dci.freq_hop_fl;
+      g->cqi_req = w->ul[i].dci.cqi_req;
+      for (uint32_t di = 0; di < w->ndl; di++) /* "check nof_ack for uplink pusch decoder", SubframeWorker.cc:318-336 */
+        if (w->dl[di].rnti == g->rnti) {
+          if (w->dl[di].g64.nof_tb == 1) g->nof_ack = 1;
+          else if (w->dl[di].g64.nof_tb == 2) g->nof_ack = 2;
+        }
       if (!w->ul[i].ok) { memset(&g->g, 0, sizeof(g->g)); memset(&g->g256, 0, sizeof(g->g256)); }
     }
   }

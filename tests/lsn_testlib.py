@@ -48,13 +48,13 @@ class TxgCfg(C.Structure):
                 ("ul_min", C.c_uint32), ("ul_max", C.c_uint32), ("cfi", C.c_uint32), ("mix_tm3_pct", C.c_uint32),
                 ("mix_tm4_pct", C.c_uint32), ("pct_256qam", C.c_uint32), ("mcs_min", C.c_uint32), ("mcs_max", C.c_uint32),
                 ("sib_period", C.c_uint32), ("rar_period", C.c_uint32), ("paging_period", C.c_uint32),
-                ("start_tti", C.c_uint32), ("fixed_L", C.c_uint32), ("pct_rv", C.c_uint32)]
+                ("start_tti", C.c_uint32), ("fixed_L", C.c_uint32), ("pct_rv", C.c_uint32), ("pct_cqi_req", C.c_uint32)]
 
 
 class TxgPdu(C.Structure):
     _fields_ = [("rnti", C.c_uint16), ("format", C.c_uint8), ("L", C.c_uint8), ("ncce", C.c_uint16), ("tti", C.c_uint32),
                 ("nbytes", C.c_uint32), ("offset", C.c_uint32), ("tb", C.c_uint8), ("mod", C.c_uint8),
-                ("table256", C.c_uint8), ("is_ul", C.c_uint8), ("nof_prb", C.c_uint32), ("mcs", C.c_uint32)]
+                ("table256", C.c_uint8), ("is_ul", C.c_uint8), ("nof_prb", C.c_uint32), ("mcs", C.c_uint32), ("cqi_req", C.c_uint32)]
 
 
 _oracle = None
@@ -147,7 +147,7 @@ def txgen():
 def scenario(name, seed=1, **over):
     base = dict(nof_prb=100, nof_ports=2, cell_id=1, phich_ng_x6=1, nof_rx=2, snr_db=30.0, cfo_hz=0.0, delay_samples=0,
                 seed=seed, n_rnti=32, dl_min=6, dl_max=6, ul_min=2, ul_max=2, cfi=3, mix_tm3_pct=0, mix_tm4_pct=0,
-                pct_256qam=0, mcs_min=0, mcs_max=28, sib_period=1, rar_period=0, paging_period=0, start_tti=0, fixed_L=0, pct_rv=0)
+                pct_256qam=0, mcs_min=0, mcs_max=28, sib_period=1, rar_period=0, paging_period=0, start_tti=0, fixed_L=0, pct_rv=0, pct_cqi_req=0)
     presets = {
         # config 1: 10 MHz, single RNTI, TM1 QPSK, 1 port / 1 rx
         "cfg1": dict(nof_prb=50, nof_ports=1, nof_rx=1, snr_db=20.0, cfo_hz=300.0, n_rnti=1, dl_min=1, dl_max=1, ul_min=0,
@@ -186,7 +186,7 @@ class TxGen:
         for i in range(n):
             p = self._pdus[i]
             out.append(dict(rnti=p.rnti, format=p.format, L=p.L, ncce=p.ncce, tti=p.tti, tb=p.tb, mod=p.mod,
-                            table256=p.table256, is_ul=p.is_ul, nof_prb=p.nof_prb, mcs=p.mcs,
+                            table256=p.table256, is_ul=p.is_ul, nof_prb=p.nof_prb, mcs=p.mcs, cqi_req=p.cqi_req,
                             n_prb=p.offset if p.is_ul else 0,
                             payload=bytes(self._pbuf[p.offset:p.offset + p.nbytes]) if not p.is_ul else b""))
         return tti, iq, out
@@ -381,7 +381,12 @@ class TxgUlCell(C.Structure):
 
 class TxgUlGrant(C.Structure):
     _fields_ = [("rnti", C.c_uint16), ("n_dmrs", C.c_uint16), ("n_prb", C.c_uint32), ("L_prb", C.c_uint32), ("mod", C.c_uint32),
-                ("tbs", C.c_uint32), ("rv", C.c_uint32), ("gain_db", C.c_float), ("phase_rad", C.c_float), ("ta_samples", C.c_float)]
+                ("tbs", C.c_uint32), ("rv", C.c_uint32), ("gain_db", C.c_float), ("phase_rad", C.c_float), ("ta_samples", C.c_float),
+                ("nof_ack", C.c_uint32), ("cqi_bits", C.c_uint32), ("ri_bits", C.c_uint32)]
+
+
+class OUci(C.Structure):
+    _fields_ = [("nof_ack", C.c_uint32), ("cqi_bits", C.c_uint32), ("ri_bits", C.c_uint32)]
 
 
 class OUlCfg(C.Structure):
@@ -414,7 +419,8 @@ def ul_make_subframe(cell, tti, grants, snr_db=30.0, seed=1):
     N = {6: 128, 15: 256, 25: 512, 50: 1024, 100: 2048}[cell.nof_prb]
     iq = np.zeros(15 * N, dtype=np.complex64)
     arr = (TxgUlGrant * max(1, len(grants)))(*[TxgUlGrant(g["rnti"], g.get("n_dmrs", 0), g["n_prb"], g["L_prb"], g["mod"], g["tbs"], g.get("rv", 0),
-                                                           g.get("gain_db", 0.0), g.get("phase_rad", 0.0), g.get("ta_samples", 0.0)) for g in grants])
+                                                           g.get("gain_db", 0.0), g.get("phase_rad", 0.0), g.get("ta_samples", 0.0),
+                                                           g.get("nof_ack", 0), g.get("cqi_bits", 0), g.get("ri_bits", 0)) for g in grants])
     pbuf = np.zeros(sum(g["tbs"] // 8 for g in grants) + 16, dtype=np.uint8)
     offs = (C.c_uint32 * max(1, len(grants)))()
     n = lib.txg_ul_make(C.byref(cell), tti, arr, len(grants), snr_db, seed, iq.ctypes.data, pbuf.ctypes.data, offs)
@@ -430,6 +436,12 @@ def oracle_ul_api():
     o.o_pusch_decode.argtypes = [C.POINTER(OCell), C.POINTER(OUlCfg), C.c_uint32, C.c_uint16, C.POINTER(OPuschGrant), C.c_uint32, C.c_void_p, C.c_int,
                                  C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float)]
     o.o_ul_valid_prb.argtypes = [C.c_uint32]
+    o.o_pusch_demod_uci.argtypes = [C.POINTER(OCell), C.POINTER(OUlCfg), C.c_uint32, C.c_uint16, C.POINTER(OPuschGrant), C.c_uint32, C.POINTER(OUci), C.c_void_p,
+                                    C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    o.o_pusch_decode_uci.argtypes = [C.POINTER(OCell), C.POINTER(OUlCfg), C.c_uint32, C.c_uint16, C.POINTER(OPuschGrant), C.c_uint32, C.POINTER(OUci), C.c_void_p,
+                                     C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float)]
+    o.o_uci_layout.argtypes = [C.c_int, C.c_int, C.POINTER(OUci), C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    o.o_uci_cqi_bits.argtypes = [C.c_uint32]
     return o
 
 
@@ -472,7 +484,12 @@ def gen_ul_mode_subframes(sc, n, cyclic_shift=3, delta_ss=5, ul_snr_db=30.0):
             if p["is_ul"] and p["nof_prb"] >= 3:
                 qm, tbs = ul_mcs_to_mod_tbs(p["mcs"], p["nof_prb"], enable_64qam=(p["rnti"] % 2 == 0))
                 if tbs > 0:
-                    pending.setdefault((tti + 4) % 10240, []).append(dict(rnti=p["rnti"], n_dmrs=0, n_prb=p["n_prb"], L_prb=p["nof_prb"], mod=qm, tbs=tbs, rv=0))
+                    # the UE acknowledges the downlink transport blocks it was sent in this subframe on the PUSCH 4 ms later and adds the
+                    # aperiodic CSI report (higher-layer sub-band CQI + RI) when the DCI 0 asks for one (36.212 5.2.2.6)
+                    ntb = len([q for q in pdus if not q["is_ul"] and q["rnti"] == p["rnti"]])
+                    cqi = oracle().o_uci_cqi_bits(sc["nof_prb"]) if p["cqi_req"] else 0
+                    pending.setdefault((tti + 4) % 10240, []).append(dict(rnti=p["rnti"], n_dmrs=0, n_prb=p["n_prb"], L_prb=p["nof_prb"], mod=qm, tbs=tbs, rv=0,
+                                                                          nof_ack=min(ntb, 2), cqi_bits=cqi, ri_bits=1 if cqi else 0))
     return tti0, iq, sent
 
 

@@ -6,13 +6,14 @@ import numpy as np
 import pytest
 
 import ltesniffer_amd as la
-from lsn_testlib import (OCell, OPuschGrant, OUlCfg, TxgUlCell, VALID_UL_PRB, oracle_ul_api, ul_make_subframe, ul_mcs_to_mod_tbs)
+from lsn_testlib import (OCell, OPuschGrant, OUci, OUlCfg, TxgUlCell, VALID_UL_PRB, oracle_ul_api, ul_make_subframe, ul_mcs_to_mod_tbs)
 
 pytestmark = pytest.mark.gpu
 
 
-def _scenario(nprb, cell_id, nsf, seed, snr_db=32.0, max_share=3, rvs=(0,)):
+def _scenario(nprb, cell_id, nsf, seed, snr_db=32.0, max_share=3, rvs=(0,), uci=False):
     rng = np.random.default_rng(seed)
+    cqi_bits = oracle_ul_api().o_uci_cqi_bits(nprb)
     ucell = TxgUlCell(nprb, cell_id, 3, 5)
     N = {25: 512, 50: 1024, 100: 2048}[nprb]
     iq = np.zeros((nsf, 15 * N), dtype=np.complex64)
@@ -30,6 +31,9 @@ def _scenario(nprb, cell_id, nsf, seed, snr_db=32.0, max_share=3, rvs=(0,)):
                 qm = 8  # exercise the 256QAM demapper with the same TBS
             gl.append(dict(sf=sf, rnti=int(rng.integers(100, 60000)), n_dmrs=int(rng.integers(0, 8)), n_prb=start, L_prb=L, mod=qm, tbs=tbs,
                            rv=int(rng.choice(rvs)), gain_db=float(rng.uniform(-3, 3)), phase_rad=float(rng.uniform(0, 6.28)), ta_samples=float(rng.uniform(0, 3))))
+            if uci:  # control information multiplexed into the PUSCH: HARQ-ACK bits, aperiodic CQI report + RI
+                cq = int(rng.integers(0, 2)) * cqi_bits
+                gl[-1].update(nof_ack=int(rng.integers(0, 3)), cqi_bits=cq, ri_bits=1 if cq else 0)
             start += L + int(rng.integers(0, 2))
         iq[sf], pl = ul_make_subframe(ucell, tti0 + sf, gl, snr_db=snr_db, seed=seed * 100 + sf)
         grants += gl
@@ -54,16 +58,20 @@ def _run(nprb, cell_id, nsf, seed, **kw):
     n_ok = 0
     for i, (g, pl, r) in enumerate(zip(grants, payloads, res)):
         og = OPuschGrant(g["L_prb"], g["n_prb"], 0, g["mod"], g["tbs"], g["rv"])
-        G = 144 * g["L_prb"] * g["mod"]
-        e = np.zeros(G, dtype=np.int16)
+        uci = OUci(g.get("nof_ack", 0), g.get("cqi_bits", 0), g.get("ri_bits", 0))
+        M = 12 * g["L_prb"]
+        cls_buf, idx_buf = np.zeros(12 * M, np.uint8), np.zeros(12 * M, np.int32)
+        nsym = o.o_uci_layout(M, g["tbs"], C.byref(uci), cls_buf.ctypes.data, idx_buf.ctypes.data, None, None, None)
+        G = nsym * g["mod"]
+        e = np.zeros(144 * g["L_prb"] * g["mod"], dtype=np.int16)
         noise, sig = C.c_float(), C.c_float()
-        assert o.o_pusch_demod(C.byref(ocell), C.byref(ucfg), (tti0 + g["sf"]) % 10, g["rnti"], C.byref(og), g["n_dmrs"], grids[g["sf"]].ctypes.data,
-                               e.ctypes.data, C.byref(noise), C.byref(sig)) == 0
-        assert np.array_equal(phy.tap_ul_llr(i, G), e), (i, g)
+        assert o.o_pusch_demod_uci(C.byref(ocell), C.byref(ucfg), (tti0 + g["sf"]) % 10, g["rnti"], C.byref(og), g["n_dmrs"], C.byref(uci),
+                                   grids[g["sf"]].ctypes.data, e.ctypes.data, C.byref(noise), C.byref(sig)) == 0
+        assert np.array_equal(phy.tap_ul_llr(i, G), e[:G]), (i, g)
         out = np.zeros(g["tbs"] // 8 + 8, dtype=np.uint8)
         its, snr = C.c_int(0), C.c_float(0)
-        crc = o.o_pusch_decode(C.byref(ocell), C.byref(ucfg), (tti0 + g["sf"]) % 10, g["rnti"], C.byref(og), g["n_dmrs"], grids[g["sf"]].ctypes.data, 12,
-                               out.ctypes.data, C.byref(its), C.byref(snr))
+        crc = o.o_pusch_decode_uci(C.byref(ocell), C.byref(ucfg), (tti0 + g["sf"]) % 10, g["rnti"], C.byref(og), g["n_dmrs"], C.byref(uci),
+                                   grids[g["sf"]].ctypes.data, 12, out.ctypes.data, C.byref(its), C.byref(snr))
         assert r["crc_ok"] == crc and r["iterations"] == its.value, (i, g, r, crc, its.value)
         assert np.float32(r["snr_db"]).view(np.uint32) == np.float32(snr.value).view(np.uint32)
         if crc:
@@ -87,6 +95,13 @@ def test_pusch_100prb_wideband_and_low_snr():
     ok, n = _run(100, 1, 4, seed=3, max_share=1)      # allocations up to 100 PRB (M = 1200, 13+ code blocks)
     assert ok >= 1
     _run(100, 1, 3, seed=4, snr_db=8.0, max_share=4)   # many CRC failures: verdicts and iteration counts still identical
+
+
+def test_pusch_with_uci_multiplexing():
+    """HARQ-ACK puncturing, RI and CQI cells (36.212 5.2.2.6-8) located by the closed form of k_pusch_demod = the oracle's literal matrix"""
+    for nprb, seed in ((25, 41), (100, 42)):
+        n_ok, n = _run(nprb, 7, 4, seed, uci=True)
+        assert n >= 8 and n_ok >= n - 1, (nprb, n_ok, n)
 
 
 def test_pusch_unsupported_grants_fail_cleanly():
@@ -134,5 +149,5 @@ def test_ul_mode_end_to_end_matches_oracle():
 
 
 def test_ul_mode_with_rar_and_single_chunk():
-    n_ul, n_dl = _run_ul_mode(48, seed=9, batch=64, rar_period=10, mcs_max=20)
+    n_ul, n_dl = _run_ul_mode(48, seed=9, batch=64, rar_period=10, mcs_max=20, pct_cqi_req=50)
     assert n_ul >= 5

@@ -66,7 +66,7 @@ def test_ul_mode_worker_loopback():
     """UL_MODE: DCI 0 found on the downlink antenna at t -> PUSCH decoded from the uplink antenna at t + 4, MCS > 20 learns the
     UE's maximum modulation; every emitted uplink record equals a transmitted payload"""
     from lsn_testlib import OracleWorkerUl, gen_ul_mode_subframes, parse_pcap, scenario
-    sc = scenario("cfg2", seed=5, nof_rx=1, n_rnti=12, dl_min=2, dl_max=3, ul_min=2, ul_max=4, mcs_max=20)
+    sc = scenario("cfg2", seed=5, nof_rx=1, n_rnti=12, dl_min=2, dl_max=3, ul_min=2, ul_max=4, mcs_max=20, pct_cqi_req=40)
     tti0, iq, sent = gen_ul_mode_subframes(sc, 60)
     ow = OracleWorkerUl(sc["nof_prb"], sc["nof_ports"], sc["cell_id"], 3, 5)
     for i in range(iq.shape[0]):
@@ -83,3 +83,63 @@ def test_ul_mode_worker_loopback():
     late = [s for s in sent if s["tti"] >= tti0 + 30 and s["L_prb"] in valid_sizes]
     got = {(r["sfn"] * 10 + r["sf"], r["rnti"]) for r in ul}
     assert sum((s["tti"], s["rnti"]) in got for s in late) >= 0.6 * len(late)
+
+
+@pytest.mark.parametrize("nprb,cell_id", [(25, 9), (100, 3)])
+def test_pusch_loopback_with_uci_multiplexing(nprb, cell_id):
+    """HARQ-ACK / RI / CQI multiplexed into the PUSCH (36.212 5.2.2.6-8): the transmitter fills the control cells with random bits,
+    the receiver locates them, skips RI + CQI and erases the ACK cells; the payload must come back, and ignoring a CQI report
+    (different rate matching) must fail"""
+    from lsn_testlib import OUci
+    o = oracle_ul_api()
+    rng = np.random.default_rng(nprb + 1)
+    ocell, ucell, ucfg = OCell(nprb, 1, cell_id, 1), TxgUlCell(nprb, cell_id, 3, 5), OUlCfg(3, 5)
+    cqi_bits = o.o_uci_cqi_bits(nprb)
+    assert cqi_bits == {25: 18, 100: 30}[nprb]
+    tried = 0
+    for it, (nof_ack, cqi, ri) in enumerate([(1, 0, 0), (2, 0, 0), (0, cqi_bits, 1), (2, cqi_bits, 1), (1, cqi_bits, 0)]):
+        tti = int(rng.integers(0, 10240))
+        grants, start = [], 0
+        for L in (3, 6, 10):
+            mcs = int(rng.integers(2, 26))
+            qm, tbs = ul_mcs_to_mod_tbs(mcs, L)
+            grants.append(dict(rnti=int(rng.integers(100, 60000)), n_dmrs=int(rng.integers(0, 8)), n_prb=start, L_prb=L, mod=qm, tbs=tbs, rv=0,
+                               nof_ack=nof_ack, cqi_bits=cqi, ri_bits=ri))
+            start += L + 1
+        iq, payloads = ul_make_subframe(ucell, tti, grants, snr_db=35.0, seed=it)
+        grid = np.zeros(14 * 12 * nprb, dtype=np.complex64)
+        o.o_ul_fft(C.byref(ocell), iq.ctypes.data, grid.ctypes.data)
+        for g, pl in zip(grants, payloads):
+            og = OPuschGrant(g["L_prb"], g["n_prb"], 0, g["mod"], g["tbs"], 0)
+            uci = OUci(nof_ack, cqi, ri)
+            out = np.zeros(g["tbs"] // 8 + 8, dtype=np.uint8)
+            its, snr = C.c_int(0), C.c_float(0)
+            crc = o.o_pusch_decode_uci(C.byref(ocell), C.byref(ucfg), tti % 10, g["rnti"], C.byref(og), g["n_dmrs"], C.byref(uci), grid.ctypes.data, 12,
+                                       out.ctypes.data, C.byref(its), C.byref(snr))
+            assert crc == 1 and bytes(out[:g["tbs"] // 8]) == pl, (nprb, it, g)
+            if cqi:  # the same samples decoded as if there were no control information: rate matching is off by Q_CQI + Q_RI
+                assert o.o_pusch_decode(C.byref(ocell), C.byref(ucfg), tti % 10, g["rnti"], C.byref(og), g["n_dmrs"], grid.ctypes.data, 4, out.ctypes.data,
+                                        C.byref(its), C.byref(snr)) == 0
+            tried += 1
+    assert tried == 15
+
+
+def test_uci_layout_counts_and_positions():
+    from lsn_testlib import OUci
+    o = oracle_ul_api()
+    M, tbs = 72, 1544  # 6 PRB
+    cls = np.zeros(12 * M, dtype=np.uint8)
+    didx = np.zeros(12 * M, dtype=np.int32)
+    qa, qr, qc = C.c_int(), C.c_int(), C.c_int()
+    n = o.o_uci_layout(M, tbs, C.byref(OUci(2, 30, 1)), cls.ctypes.data, didx.ctypes.data, C.byref(qa), C.byref(qr), C.byref(qc))
+    sumk = 1568  # one code block: 1544 + 24 -> K = 1568
+    assert qa.value == min(-(-2 * M * 12 * 160 // (8 * sumk)), 4 * M) and qr.value == -(-1 * M * 12 * 127 // (8 * sumk)) and qc.value == -(-38 * M * 12 * 18 // (8 * sumk))
+    m = cls.reshape(M, 12)
+    assert n == 12 * M - qr.value - qc.value
+    assert (m == 2).sum() == qr.value and set(np.nonzero((m == 2).any(axis=0))[0]) <= {1, 4, 7, 10}
+    assert (m == 3).sum() == qa.value and set(np.nonzero((m == 3).any(axis=0))[0]) <= {2, 3, 8, 9}
+    assert (m == 1).sum() == qc.value and m[0, 0] == 1                      # CQI starts the row-major fill
+    assert m[M - 1, 1] == 2 and m[M - 1, 10] == 2 and m[M - 1, 2] == 3      # first symbols sit in the bottom row
+    d = didx.reshape(M, 12)
+    data = np.sort(d[(m == 0) | (m == 3)])
+    assert np.array_equal(data, np.arange(n))                              # every UL-SCH symbol index exactly once

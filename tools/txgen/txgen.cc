@@ -217,9 +217,10 @@ typedef struct {
   uint32_t start_tti;
   uint32_t fixed_L;       // 0 = random aggregation level
   uint32_t pct_rv;        // share of C-RNTI transport blocks sent with a random redundancy version (else rv 0)
+  uint32_t pct_cqi_req;   // share of DCI 0 that request an aperiodic CSI report
 } txg_cfg_t;
 
-typedef struct { uint16_t rnti; uint8_t format, L; uint16_t ncce; uint32_t tti; uint32_t nbytes; uint32_t offset; uint8_t tb, mod, table256, is_ul; uint32_t nof_prb; uint32_t mcs; } txg_pdu_t;
+typedef struct { uint16_t rnti; uint8_t format, L; uint16_t ncce; uint32_t tti; uint32_t nbytes; uint32_t offset; uint8_t tb, mod, table256, is_ul; uint32_t nof_prb; uint32_t mcs; uint32_t cqi_req; } txg_pdu_t;
 
 struct txg;
 typedef struct txg txg_t;
@@ -316,6 +317,7 @@ struct Grant {
   int scheme;  // 0 port0, 1 div, 2 SM, 3 CDD
   int pmi, nlayers;
   bool is_ul;
+  uint32_t cqi_req = 0;
 };
 
 static bits_t dci_pack(const txg* g, const Grant& gr) {
@@ -324,7 +326,7 @@ static bits_t dci_pack(const txg* g, const Grant& gr) {
   bool user = gr.rnti >= 0x000B && gr.rnti <= 0xFFF3;
   switch (gr.format) {
     case TXG_FMT0:
-      put(b, 0, 1); put(b, 0, 1); put(b, gr.riv, riv_nbits(n)); put(b, gr.mcs[0], 5); put(b, gr.ndi[0], 1); put(b, 1, 2); put(b, 0, 3); put(b, 0, 1);
+      put(b, 0, 1); put(b, 0, 1); put(b, gr.riv, riv_nbits(n)); put(b, gr.mcs[0], 5); put(b, gr.ndi[0], 1); put(b, 1, 2); put(b, 0, 3); put(b, gr.cqi_req, 1);
       while (b.size() < f0_sz(n)) b.push_back(0);
       break;
     case TXG_FMT1A:
@@ -598,9 +600,10 @@ extern "C" int txg_next(txg_t* g, float* iq, txg_pdu_t* pdus, int max_pdus, uint
     if (start + Lc > nprb) break;
     gr.riv = (Lc - 1 <= nprb / 2) ? (uint32_t)(nprb * (Lc - 1) + start) : (uint32_t)(nprb * (nprb - Lc + 1) + (nprb - 1 - start));
     gr.mcs[0] = g->rng.below(25); gr.ndi[0] = g->rng.below(2);
+    if (c.pct_cqi_req) gr.cqi_req = g->rng.below(100) < c.pct_cqi_req ? 1u : 0u;
     if (!place(gr, false)) continue;
     grants.push_back(gr);
-    if (npdu < max_pdus) { txg_pdu_t& pd = pdus[npdu++]; pd = txg_pdu_t{gr.rnti, 0, (uint8_t)gr.L, (uint16_t)gr.ncce, tti, 0, (uint32_t)start /* UL grants: offset = first PRB */, 0, 0, 0, 1, (uint32_t)Lc, gr.mcs[0]}; }
+    if (npdu < max_pdus) { txg_pdu_t& pd = pdus[npdu++]; pd = txg_pdu_t{gr.rnti, 0, (uint8_t)gr.L, (uint16_t)gr.ncce, tti, 0, (uint32_t)start /* UL grants: offset = first PRB */, 0, 0, 0, 1, (uint32_t)Lc, gr.mcs[0], gr.cqi_req}; }
   }
 
   // ---- PDCCH ----
@@ -704,10 +707,11 @@ extern "C" int txg_next(txg_t* g, float* iq, txg_pdu_t* pdus, int max_pdus, uint
 
 // =====================================================================================================
 // Uplink: SC-FDMA transmitters of several UEs summed at the sniffer's uplink antenna (test tooling).
-// TS 36.212 5.2.2 (UL-SCH: CRC, segmentation, turbo code, rate matching, channel interleaver; no UCI),
+// TS 36.212 5.2.2 (UL-SCH: CRC, segmentation, turbo code, rate matching, control multiplexing with random control bits, channel interleaver),
 // TS 36.211 5.3 (scrambling, modulation, transform precoding), 5.5 (DMRS), 5.6 (7.5 kHz shifted SC-FDMA).
 typedef struct { uint32_t nof_prb, cell_id, cyclic_shift, delta_ss; } txg_ul_cell_t;
-typedef struct { uint16_t rnti; uint16_t n_dmrs; uint32_t n_prb, L_prb, mod, tbs, rv; float gain_db, phase_rad, ta_samples; } txg_ul_grant_t;
+typedef struct { uint16_t rnti; uint16_t n_dmrs; uint32_t n_prb, L_prb, mod, tbs, rv; float gain_db, phase_rad, ta_samples;
+                 uint32_t nof_ack, cqi_bits, ri_bits; /* UCI multiplexed into the PUSCH (36.212 5.2.2.6-8): HARQ-ACK bits, CQI report size, RI bits */ } txg_ul_grant_t;
 
 static int ul_largest_prime_below(int n) { for (int p = n - 1; p >= 2; p--) { bool ok = true; for (int d = 2; d * d <= p; d++) if (p % d == 0) { ok = false; break; } if (ok) return p; } return 2; }
 
@@ -727,18 +731,45 @@ extern "C" int txg_ul_make(const txg_ul_cell_t* c, uint32_t tti, const txg_ul_gr
   uint32_t used = 0;
   for (int gi = 0; gi < ngr; gi++) {
     const txg_ul_grant_t& g = gr[gi];
-    const int M = 12 * (int)g.L_prb, Qm = (int)g.mod, G = 12 * M * Qm, k0 = 12 * (int)g.n_prb;
+    const int M = 12 * (int)g.L_prb, Qm = (int)g.mod, H = 12 * M * Qm, k0 = 12 * (int)g.n_prb;
     payload_off[gi] = used;
     uint8_t* pl = payloads + used;
     for (uint32_t i = 0; i < g.tbs / 8; i++) pl[i] = (uint8_t)rng.below(256);
     used += g.tbs / 8;
+    // control resources, 36.212 5.2.2.6: Q' = min(ceil(O M_sc N_symb beta / sum K_r), cap), beta_ack = 20, beta_ri = 15.875, beta_cqi = 2.25
+    Segm sg; cbsegm((int)g.tbs, sg);
+    const double sumK = (double)sg.Cp * sg.Kp + (double)sg.Cm * sg.Km;
+    auto qprime = [&](int O, double beta, int cap) { if (O <= 0) return 0; int q = (int)std::ceil((double)O * M * 12.0 * beta / sumK - 1e-9); return q < cap ? q : cap; };
+    const int Qa = qprime((int)g.nof_ack, 20.0, 4 * M), Qr = qprime((int)g.ri_bits, 15.875, 4 * M);
+    const int Oc = (int)g.cqi_bits, Qc = Oc ? qprime(Oc + (Oc > 11 ? 8 : 0), 2.25, 12 * M - Qr) : 0;
+    const int G = (12 * M - Qr - Qc) * Qm;
     bits_t f = dlsch_encode(pl, (int)g.tbs, G, Qm, 1, (int)g.rv);
-    bits_t h((size_t)G);
+    // channel interleaver 5.2.2.8: M rows x 12 columns of Qm-bit cells; RI first (bottom rows, columns 1,4,7,10), then CQI + data row by
+    // row, then HARQ-ACK overwriting (bottom rows, columns 2,3,8,9); control bits are random here
+    std::vector<int> owner((size_t)12 * M, 0);  // 0 free, 2 RI
+    bits_t mat((size_t)H);
+    static const int ri_cols[4] = {1, 4, 7, 10}, ack_cols[4] = {2, 3, 8, 9};
+    for (int i = 0, j = 0, r = M - 1; i < Qr; i++, r = M - 1 - i / 4, j = (j + 3) % 4) {
+      owner[(size_t)r * 12 + ri_cols[j]] = 2;
+      for (int b = 0; b < Qm; b++) mat[((size_t)r * 12 + ri_cols[j]) * Qm + b] = (uint8_t)rng.below(2);
+    }
+    {
+      int k = 0;
+      for (int r = 0; r < M; r++)
+        for (int cc = 0; cc < 12; cc++) {
+          if (owner[(size_t)r * 12 + cc] == 2) continue;
+          for (int b = 0; b < Qm; b++) mat[((size_t)r * 12 + cc) * Qm + b] = k < Qc ? (uint8_t)rng.below(2) : f[(size_t)(k - Qc) * Qm + b];
+          k++;
+        }
+    }
+    for (int i = 0, j = 0, r = M - 1; i < Qa; i++, r = M - 1 - i / 4, j = (j + 3) % 4)
+      for (int b = 0; b < Qm; b++) mat[((size_t)r * 12 + ack_cols[j]) * Qm + b] = (uint8_t)rng.below(2);
+    bits_t h((size_t)H);
     for (int col = 0; col < 12; col++)
       for (int r = 0; r < M; r++)
-        for (int b = 0; b < Qm; b++) h[((size_t)col * M + r) * Qm + b] = f[((size_t)r * 12 + col) * Qm + b];
-    bits_t scr = gold(((uint32_t)g.rnti << 14) | (sf << 9) | c->cell_id, G);
-    for (int i = 0; i < G; i++) h[i] ^= scr[i];
+        for (int b = 0; b < Qm; b++) h[((size_t)col * M + r) * Qm + b] = mat[((size_t)r * 12 + col) * Qm + b];
+    bits_t scr = gold(((uint32_t)g.rnti << 14) | (sf << 9) | c->cell_id, H);
+    for (int i = 0; i < H; i++) h[i] ^= scr[i];
     std::vector<cf> sym;
     modulate(h, Qm, sym);
     const std::complex<double> chan = std::polar(std::pow(10.0, g.gain_db / 20.0), (double)g.phase_rad);
