@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--config", default="cfg3", help="scenario preset: cfg3 = 20 MHz, 150 RNTIs, TM3/TM4 up to 256QAM")
     ap.add_argument("--batch", type=int, default=200, help="subframes per pipeline chunk inside a step")
     ap.add_argument("--cpu-sample", type=int, default=600, help="subframes timed on the CPU oracle (rank 0, N=1 only)")
+    ap.add_argument("--sync-steps", action="store_true", help="complete every step (lsn_phy_process_device) before the next one starts")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -106,18 +107,27 @@ def main():
     acc = {k: 0 for k in ("nof_tb_decodes", "nof_cb_decodes", "nof_turbo_iterations", "nof_turbo_iterations_run", "nof_ondemand_decodes", "turbo_cyc_rm",
                           "turbo_cyc_map", "turbo_cyc_out", "ms_stage_a", "ms_search", "ms_search_core", "ms_rar", "ms_stage_c", "ms_commit", "ms_wait_front", "ms_wait_slot", "ms_drain")}
     t0 = time.perf_counter()
+    # the K steps are submitted back to back (lsn_phy_submit_device: a step returns once its subframes are searched and queued, its
+    # decode / commit tail overlaps the next step's front) and completed by one lsn_phy_wait inside the timed region
     for i in range(args.steps):
-        step(args.warmup + i)
-        p = phy.perf()
-        kms += np.array(p.kernel_ms[:])
-        klaunch += np.array(p.kernel_launches[:])
-        turbo_bytes += p.turbo_algo_bytes
-        turbo128_bytes += p.turbo128_algo_bytes
-        algo_bytes += p.algo_bytes
-        npdus += p.nof_pdus
-        for k in acc:
-            acc[k] += getattr(p, k)
-        pcap.reset()
+        if args.sync_steps:
+            step(args.warmup + i)
+        else:
+            phy.submit_device(d_iq.data_ptr(), nsf, tti0 + (args.warmup + i) * nsf, 500, stream)
+        if args.sync_steps or i == args.steps - 1:
+            if not args.sync_steps:
+                phy.wait()
+            p = phy.perf()
+            kms += np.array(p.kernel_ms[:])
+            klaunch += np.array(p.kernel_launches[:])
+            turbo_bytes += p.turbo_algo_bytes
+            turbo128_bytes += p.turbo128_algo_bytes
+            algo_bytes += p.algo_bytes
+            npdus += p.nof_pdus
+            for k in acc:
+                acc[k] += getattr(p, k)
+            if args.sync_steps:
+                pcap.reset()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -181,7 +191,7 @@ def main():
             "config": {"workload": "%s: 20 MHz DL (100 PRB, 2 CRS ports, 2 rx), 150 active RNTIs, TM2/TM3/TM4 mix up to 256QAM, "
                                    "CFI 3, 8-14 DL + 3-6 UL DCIs per subframe (BASELINE.json configs[2])" % args.config
                        if args.config == "cfg3" else args.config,
-                       "subframes_per_step": nsf, "distinct_subframes": gen, "gpu_batch": batch, "cells": world, "parallelism": "cell/subframe shards, no collective"},
+                       "subframes_per_step": nsf, "steps_pipelined": not args.sync_steps, "distinct_subframes": gen, "gpu_batch": batch, "cells": world, "parallelism": "cell/subframe shards, no collective"},
             "roofline": {"bound": "hbm", "kernel": la.KERNELS[kt], "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(ach / 8000.0, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": round(kms[kt] / max(1, klaunch[kt]), 4), "launches": int(klaunch[kt]),

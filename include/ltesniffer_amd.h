@@ -126,6 +126,12 @@ int lsn_phy_process_device(lsn_phy_t* phy, const void* d_iq, uint32_t n_subframe
                            uint32_t update_meta_period, void* stream);
 /* same, from host memory (copies through pinned staging) */
 int lsn_phy_process_host(lsn_phy_t* phy, const float* iq, uint32_t n_subframes, uint32_t start_tti, uint32_t update_meta_period);
+/* Pipelined form of lsn_phy_process_device: submit returns as soon as every subframe of the block has been searched and queued for
+ * decoding, so the decode / commit tail of one block overlaps the front of the next; lsn_phy_wait returns when everything submitted
+ * has been committed (PDUs delivered, in order).  The IQ buffer of a submit must stay valid until the next lsn_phy_wait.
+ * lsn_phy_get_perf then describes the whole submit ... wait span.  process_device == submit + wait. */
+int lsn_phy_submit_device(lsn_phy_t* phy, const void* d_iq, uint32_t n_subframes, uint32_t start_tti, uint32_t update_meta_period, void* hip_stream);
+int lsn_phy_wait(lsn_phy_t* phy);
 
 /* ---- PBCH / MIB ----
  * Replaces srsran_ue_mib_decode + srsran_pbch_mib_unpack of the reference's DECODE_MIB state (LTESniffer_Core.cc:382-395): decode

@@ -30,7 +30,7 @@ EXPORTS = ["lsn_phy_create", "lsn_phy_destroy", "lsn_phy_set_cell", "lsn_phy_get
            "lsn_phy_get_perf", "lsn_kernel_name", "lsn_version", "lsn_pcap_open", "lsn_pcap_open_mem",
            "lsn_pcap_set_wall_clock", "lsn_pcap_write", "lsn_pcap_sink", "lsn_pcap_mem", "lsn_pcap_nof_records",
            "lsn_pcap_reset", "lsn_pcap_close", "lsn_phy_set_pcap_writer", "lsn_phy_set_ul_config", "lsn_phy_pusch_decode",
-           "lsn_phy_tap_ul", "lsn_phy_set_prach_config", "lsn_phy_prach_detect", "lsn_phy_set_prach_sink", "lsn_prach_tti_opportunity", "lsn_phy_process_file", "lsn_phy_mib_decode", "lsn_phy_mib_decode_llr"]
+           "lsn_phy_tap_ul", "lsn_phy_set_prach_config", "lsn_phy_prach_detect", "lsn_phy_set_prach_sink", "lsn_prach_tti_opportunity", "lsn_phy_process_file", "lsn_phy_mib_decode", "lsn_phy_mib_decode_llr", "lsn_phy_submit_device", "lsn_phy_wait"]
 
 
 PRACH_NCS = [0, 13, 15, 18, 22, 26, 32, 38, 46, 59, 76, 93, 119, 167, 279, 419]  # 36.211 Table 5.7.2-2
@@ -204,6 +204,8 @@ def lib():
                                            C.c_void_p, C.c_size_t]
         L.lsn_phy_tap_ul.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_size_t]
         L.lsn_phy_tap_ul.restype = C.c_long
+        L.lsn_phy_submit_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.lsn_phy_wait.argtypes = [C.c_void_p]
         L.lsn_phy_mib_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Mib)]
         L.lsn_phy_mib_decode_llr.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Mib), C.c_void_p]
         L.lsn_phy_process_file.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(FileCfg), C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64)]
@@ -349,6 +351,13 @@ class Phy:
     def process_device(self, dev_ptr, n_subframes, start_tti, update_meta_period=0, stream=None):
         _check(lib().lsn_phy_process_device(self._h, C.c_void_p(dev_ptr), n_subframes, start_tti, update_meta_period,
                                             C.c_void_p(stream or 0)), "process_device")
+
+    def submit_device(self, d_ptr, n_subframes, start_tti, update_meta_period=0, stream=None):
+        """pipelined process_device: returns once the block is searched and queued; call wait() before reusing the buffer / reading results"""
+        _check(lib().lsn_phy_submit_device(self._h, C.c_void_p(d_ptr), n_subframes, start_tti, update_meta_period, C.c_void_p(stream or 0)), "submit_device")
+
+    def wait(self):
+        _check(lib().lsn_phy_wait(self._h), "wait")
 
     def mib_decode(self, iq, with_llr=False):
         """srsran_ue_mib_decode on ONE subframe iq[nof_rx, 15*N] -> dict (found, sfn, sfn_offset, nof_prb, nof_ports, ...) [, raw PBCH soft bits]"""

@@ -243,6 +243,16 @@ int lsn_phy_process_device(lsn_phy_t* phy, const void* d_iq, uint32_t n, uint32_
   if (!phy) return LSN_ERROR_INVALID_INPUTS;
   return phy->engine->process(d_iq, n, start_tti, update_meta_period, (hipStream_t)stream);
 }
+int lsn_phy_submit_device(lsn_phy_t* phy, const void* d_iq, uint32_t n, uint32_t start_tti, uint32_t update_meta_period, void* stream)
+{
+  if (!phy) return LSN_ERROR_INVALID_INPUTS;
+  return phy->engine->submit(d_iq, n, start_tti, update_meta_period, (hipStream_t)stream);
+}
+int lsn_phy_wait(lsn_phy_t* phy)
+{
+  if (!phy) return LSN_ERROR_INVALID_INPUTS;
+  return phy->engine->wait();
+}
 int lsn_phy_process_host(lsn_phy_t* phy, const float* iq, uint32_t n, uint32_t start_tti, uint32_t update_meta_period)
 {
   if (!phy || (!iq && n)) return LSN_ERROR_INVALID_INPUTS;

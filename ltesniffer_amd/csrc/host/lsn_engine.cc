@@ -802,7 +802,16 @@ void Engine::frontLoop()
   }
 }
 
+// process = submit + wait.  submit() returns once every chunk of the call has been searched and handed to the decode threads;
+// their decode / commit tail overlaps the next submit (the caller keeps the IQ buffer alive until wait()).
 int Engine::process(const void* d_iq, uint32_t nsf_total, uint32_t start_tti, uint32_t update_meta_period, hipStream_t stream)
+{
+  const int r = submit(d_iq, nsf_total, start_tti, update_meta_period, stream);
+  const int w = wait();
+  return r != LSN_SUCCESS ? r : w;
+}
+
+int Engine::submit(const void* d_iq, uint32_t nsf_total, uint32_t start_tti, uint32_t update_meta_period, hipStream_t stream)
 {
   if (!cell_set) return LSN_ERROR;
   if (!d_iq && nsf_total) return LSN_ERROR_INVALID_INPUTS;
@@ -811,12 +820,15 @@ int Engine::process(const void* d_iq, uint32_t nsf_total, uint32_t start_tti, ui
   struct Unpin { Engine* e; bool on; cpu_set_t* m; ~Unpin() { if (on) e->unpinThisThread(m); } } unpin{this, pinned, &saved_mask};
   try {
     HIP_CHECK(hipSetDevice(cfg.device));
-    perf = lsn_perf_t{};
-    perf_front = lsn_perf_t{};
-    for (auto& r : runner_c) r.perf = lsn_perf_t{};
-    runner_s.perf = lsn_perf_t{};
-    runner_f.perf = lsn_perf_t{};
-    const double t_all = now_ms();
+    if (!batch_open) {  // first submit since the last wait: the counters describe one submit ... wait span
+      perf = lsn_perf_t{};
+      perf_front = lsn_perf_t{};
+      for (auto& r : runner_c) r.perf = lsn_perf_t{};
+      runner_s.perf = lsn_perf_t{};
+      runner_f.perf = lsn_perf_t{};
+      t_batch = now_ms();
+      batch_open = true;
+    }
     // the caller's stream orders the IQ buffer: stage A starts after everything queued on it so far
     HIP_CHECK(hipEventRecord(ev_in, stream));
     for (auto& sa : stream_a) HIP_CHECK(hipStreamWaitEvent(sa, ev_in, 0));
@@ -826,7 +838,6 @@ int Engine::process(const void* d_iq, uint32_t nsf_total, uint32_t start_tti, ui
       front_job.d_iq = d_iq; front_job.nsf_total = nsf_total; front_job.start_tti = start_tti; front_job.pending = true;
     }
     cv_front.notify_one();
-    std::string err;
     for (uint32_t ci = 0; ci < nchunks; ci++) {
       Chunk* cur = nullptr;
       {
@@ -836,7 +847,7 @@ int Engine::process(const void* d_iq, uint32_t nsf_total, uint32_t start_tti, ui
         perf.ms_wait_front += now_ms() - tw;
         cur = search_queue.front();
         search_queue.pop_front();
-        if (!cur) { err = front_error; front_error.clear(); }
+        if (!cur) { submit_error = front_error; front_error.clear(); }
       }
       if (!cur) break;
       const double t1 = now_ms();
@@ -850,6 +861,20 @@ int Engine::process(const void* d_iq, uint32_t nsf_total, uint32_t start_tti, ui
       cv_work.notify_one();
       last_chunk = cur;
     }
+    return submit_error.empty() ? LSN_SUCCESS : LSN_ERROR;
+  } catch (const std::exception& ex) {
+    fprintf(stderr, "ltesniffer_amd: %s\n", ex.what());
+    submit_error = ex.what();
+    return LSN_ERROR;
+  }
+}
+
+int Engine::wait()
+{
+  if (!batch_open) return LSN_SUCCESS;
+  try {
+    std::string err = submit_error;
+    submit_error.clear();
     {
       const double tw = now_ms();
       std::unique_lock<std::mutex> lk(mtx);
@@ -858,6 +883,7 @@ int Engine::process(const void* d_iq, uint32_t nsf_total, uint32_t start_tti, ui
       if (err.empty() && !commit_error.empty()) err = commit_error;
       commit_error.clear();
     }
+    batch_open = false;
     if (!err.empty()) {
       std::unique_lock<std::mutex> lk(mtx);
       for (auto& ch : chunks) ch.busy = false;
@@ -868,7 +894,7 @@ int Engine::process(const void* d_iq, uint32_t nsf_total, uint32_t start_tti, ui
     for (auto& r : runner_c) mergePerf(r.perf);
     mergePerf(runner_s.perf);
     mergePerf(runner_f.perf);
-    perf.ms_total = now_ms() - t_all;
+    perf.ms_total = now_ms() - t_batch;
     return LSN_SUCCESS;
   } catch (const std::exception& ex) {
     fprintf(stderr, "ltesniffer_amd: %s\n", ex.what());

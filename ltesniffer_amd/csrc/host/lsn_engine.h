@@ -77,6 +77,10 @@ public:
   int setCell(const lsn_cell_t& cell);
   bool hasCell() const { return cell_set; }
   int process(const void* d_iq, uint32_t nsf, uint32_t start_tti, uint32_t update_meta_period, hipStream_t stream);
+  int submit(const void* d_iq, uint32_t nsf, uint32_t start_tti, uint32_t update_meta_period, hipStream_t stream);
+  int wait();
+  uint64_t submitMark() { std::unique_lock<std::mutex> lk(mtx); return seq_pushed; }                 // position of the last submitted chunk
+  void waitMark(uint64_t mark) { std::unique_lock<std::mutex> lk(mtx); cv_done.wait(lk, [&] { return seq_committed >= mark || !commit_error.empty(); }); }
   int mibDecode(const void* iq, bool on_device, lsn_mib_t* out, float* llr_raw480);
   int processFile(const char* path, const lsn_file_cfg_t& fc, uint32_t start_tti, uint64_t max_subframes, uint32_t update_meta_period,
                   uint64_t* subframes_done);
@@ -171,7 +175,9 @@ private:
   std::condition_variable cv_work, cv_done;
   std::deque<Chunk*> commit_queue;
   bool stop = false;
-  std::string commit_error;
+  std::string commit_error, submit_error;
+  bool batch_open = false;  // submits since the last wait()
+  double t_batch = 0;
   lsn_perf_t perf{};
   float est_cfo = 0;
   lsn_pdu_sink_t sink = nullptr; void* sink_user = nullptr;

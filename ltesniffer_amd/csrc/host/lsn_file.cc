@@ -40,7 +40,7 @@ int Engine::processFile(const char* path, const lsn_file_cfg_t& fc, uint32_t sta
   if (const char* e = getenv("LSN_FILE_READERS")) nrd = (uint32_t)std::max(1, std::min(32, atoi(e)));
   const uint64_t file_off0 = (uint64_t)fc.offset_time_samples * nant * sizeof(cf32);
   const uint64_t sf_in_file = (uint64_t)sb.st_size > file_off0 ? ((uint64_t)sb.st_size - file_off0) / sf_bytes : 0;  // complete subframes only
-  struct Slot { cf32* h_raw = nullptr; cf32* d_raw = nullptr; cf32* d_iq = nullptr; uint32_t nsf = 0; int state = 0; /* 0 free, 1 ready, 2 eof */ } slot[2];
+  struct Slot { cf32* h_raw = nullptr; cf32* d_raw = nullptr; cf32* d_iq = nullptr; uint32_t nsf = 0; int state = 0; /* 0 free, 1 ready, 2 eof */ uint64_t mark = 0; } slot[3];
   cf32* d_rot = nullptr;
   hipStream_t st = nullptr;
   std::mutex fm;
@@ -88,7 +88,7 @@ int Engine::processFile(const char* path, const lsn_file_cfg_t& fc, uint32_t sta
         (void)hipSetDevice(cfg.device);
         pinThisThread(nullptr);
         uint64_t avail = sf_in_file - first_sf, left = max_subframes ? std::min<uint64_t>(max_subframes, avail) : avail, pos = first_sf;
-        for (int i = 0;; i ^= 1) {
+        for (int i = 0;; i = (i + 1) % 3) {
           Slot& s = slot[i];
           {
             std::unique_lock<std::mutex> lk(fm);
@@ -136,21 +136,30 @@ int Engine::processFile(const char* path, const lsn_file_cfg_t& fc, uint32_t sta
         fcv.notify_all();
       }
     });
-    for (int i = 0;; i ^= 1) {
+    // block i is submitted (searched, queued for decoding) while block i-1 drains; its slot goes back to the reader once every chunk
+    // of it has been committed
+    int prev = -1;
+    for (int i = 0;; i = (i + 1) % 3) {
       Slot& s = slot[i];
       {
         std::unique_lock<std::mutex> lk(fm);
         fcv.wait(lk, [&] { return s.state != 0; });
         if (s.state == 2) break;
       }
-      rc = process(s.d_iq, s.nsf, (uint32_t)((start_tti + done) % 10240u), update_meta_period, nullptr);
-      if (rc != LSN_SUCCESS) break;
+      rc = submit(s.d_iq, s.nsf, (uint32_t)((start_tti + done) % 10240u), update_meta_period, nullptr);
+      s.mark = submitMark();
       done += s.nsf;
-      {
-        std::unique_lock<std::mutex> lk(fm);
-        s.state = 0;
+      if (prev >= 0) {
+        waitMark(slot[prev].mark);
+        { std::unique_lock<std::mutex> lk(fm); slot[prev].state = 0; }
+        fcv.notify_all();
       }
-      fcv.notify_all();
+      prev = i;
+      if (rc != LSN_SUCCESS) break;
+    }
+    {
+      const int w = wait();
+      if (rc == LSN_SUCCESS) rc = w;
     }
     if (!rerr.empty()) throw std::runtime_error(rerr);
   } catch (const std::exception& ex) {

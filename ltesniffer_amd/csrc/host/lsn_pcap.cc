@@ -44,6 +44,7 @@ lsn_pcap_t* lsn_pcap_open_mem(void)
 {
   lsn_pcap* p = new lsn_pcap();
   p->to_mem = true;
+  p->mem.reserve((size_t)256 << 20);  // address space only: no re-allocation copies in the commit turn while a capture grows
   p->wall_clock = false;  // deterministic captures: timestamps are zero
   p->header();
   return p;
