@@ -316,22 +316,11 @@ void Engine::searchChunk(Chunk& ch, uint32_t update_meta_period)
 // MAC RAR PDU (TS 36.321 6.1.5) walked like srsran::rar_pdu; DL_Sniffer_PDSCH.cc:782-797
 void Engine::unpackRar(const uint8_t* p, int len, bool at_search)
 {
-  int nsub = 0, pos = 0;
-  bool is_rapid[32];
-  while (pos < len && nsub < 32) {
-    const uint8_t b = p[pos++];
-    is_rapid[nsub++] = (b & 0x40) != 0;
-    if (!(b & 0x80)) break;
-  }
-  for (int i = 0; i < nsub; i++) {
-    uint16_t t_crnti = 0;
-    if (is_rapid[i]) {
-      if (pos + 6 > len) break;
-      t_crnti = (uint16_t)((p[pos + 4] << 8) | p[pos + 5]);
-      pos += 6;
-    }
-    if (at_search) search->rntiManager().activateAndRefresh(t_crnti, 0, RM_ACT_RAR);  // search thread owns the RNTI manager
-    else mcs_tracking.update_rar_time_crnti(t_crnti);                                // commit thread owns the MCS tracking
+  RarEntry r[32];
+  const int n = rar_parse(cell, p, len, r, 32);
+  for (int i = 0; i < n; i++) {
+    if (at_search) search->rntiManager().activateAndRefresh(r[i].t_crnti, 0, RM_ACT_RAR);  // search thread owns the RNTI manager
+    else mcs_tracking.update_rar_time_crnti(r[i].t_crnti);                                // commit thread owns the MCS tracking
   }
 }
 

@@ -381,6 +381,39 @@ bool ra_ul_dci_to_grant(const Cell& cell, const DciUl& d, PuschGrant& g)
   return true;
 }
 
+int rar_parse(const Cell& cell, const uint8_t* p, int len, RarEntry* out, int cap)
+{
+  int nsub = 0, pos = 0, n = 0;
+  bool is_rapid[32];
+  uint8_t rapid[32];
+  while (pos < len && nsub < 32) {
+    const uint8_t b = p[pos++];
+    is_rapid[nsub] = (b & 0x40) != 0;
+    rapid[nsub] = b & 0x3F;
+    nsub++;
+    if (!(b & 0x80)) break;
+  }
+  for (int i = 0; i < nsub && n < cap; i++) {
+    RarEntry r;
+    uint32_t grant20 = 0;
+    if (is_rapid[i]) {
+      if (pos + 6 > len) break;
+      r.rapid = rapid[i];
+      r.ta = ((uint32_t)(p[pos] & 0x7F) << 4) | (p[pos + 1] >> 4);
+      grant20 = ((uint32_t)(p[pos + 1] & 0x0F) << 16) | ((uint32_t)p[pos + 2] << 8) | p[pos + 3];
+      r.t_crnti = (uint16_t)((p[pos + 4] << 8) | p[pos + 5]);
+      pos += 6;
+    }
+    DciUl d;
+    d.rnti = r.t_crnti; d.hopping = (grant20 >> 19) & 1u; d.riv = (grant20 >> 9) & 0x3FFu; d.mcs_idx = (grant20 >> 5) & 0xFu;
+    r.hopping = d.hopping; r.riv = d.riv; r.mcs = d.mcs_idx; r.tpc = (grant20 >> 2) & 7u; r.ul_delay = (grant20 >> 1) & 1u; r.csi_req = grant20 & 1u;
+    r.grant_ok = ra_ul_dci_to_grant(cell, d, r.grant);
+    if (!r.grant_ok) r.grant = PuschGrant();
+    out[n++] = r;
+  }
+  return n;
+}
+
 // ul_fill_ra_mcs_256 (ul_sniffer_pusch.c:91-136): Table 8.6.1-3 of 36.213 incl. the 32A row
 bool ra_ul_dci_to_grant_256(const Cell& cell, const DciUl& d, PuschGrant& g)
 {

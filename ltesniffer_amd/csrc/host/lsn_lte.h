@@ -63,6 +63,10 @@ void dl_sniffer_grant_finish_both(const Cell& cell, uint32_t sf_idx, uint32_t cf
                                   bool& ok256);
 bool ra_dl_grant_to_grant_prb_allocation(const Cell& cell, const DciDl& dci, PdschGrant& g);
 bool ra_ul_dci_to_grant(const Cell& cell, const DciUl& dci, PuschGrant& g);
+// MAC RAR PDU (TS 36.321 6.1.5, 6.2.2, 6.2.3) -> one entry per sub-header (a sub-header without a body - backoff indicator - gives T-CRNTI 0,
+// like the reference's loop, DL_Sniffer_PDSCH.cc:632-671); the 20-bit grant as ul_sniffer_dci_rar_unpack reads it (falcon_dci.c:648-683)
+struct RarEntry { uint32_t rapid = 0, ta = 0, hopping = 0, riv = 0, mcs = 0, tpc = 0, ul_delay = 0, csi_req = 0; uint16_t t_crnti = 0; bool grant_ok = false; PuschGrant grant; };
+int rar_parse(const Cell& cell, const uint8_t* p, int len, RarEntry* out, int cap);
 bool ra_ul_dci_to_grant_256(const Cell& cell, const DciUl& dci, PuschGrant& g);  // ulsniffer_ra_ul_dci_to_grant_256, ul_sniffer_pusch.c:138-172
 bool ul_valid_prb(uint32_t L);                                                    // valid_prb_ul, UL_Sniffer_PUSCH.cc:3-10
 int dl_sniffer_config_mimo(const Cell& cell, DciFormat f, const DciDl& dci, PdschGrant& g);  // 0 ok

@@ -61,25 +61,14 @@ void Engine::commitChunkUl(Chunk& ch, JobRunner& r)
           const uint8_t* pl = ch.h_payload.data() + job.payload_off[tb];
           out[sf].push_back({false, is_ra ? 'R' : rnti_name(e.rnti)[0], e.rnti, (uint8_t)tb, pl, {}, len});
           if (is_ra) {  // unpack_rar_response_ul_mode on TB 0's buffer; the grant of the LAST sub-header survives; then return
-            const uint8_t* p = ch.h_payload.data() + job.payload_off[0];
-            int nsub = 0, pos = 0;
-            bool is_rapid[32];
-            while (pos < (int)len && nsub < 32) { const uint8_t b = p[pos++]; is_rapid[nsub++] = (b & 0x40) != 0; if (!(b & 0x80)) break; }
-            UlSchedGrant last; bool found = false;
-            for (int i = 0; i < nsub; i++) {
-              uint16_t t_crnti = 0; uint32_t grant20 = 0;
-              if (is_rapid[i]) {
-                if (pos + 6 > (int)len) break;
-                grant20 = ((uint32_t)(p[pos + 1] & 0x0F) << 16) | ((uint32_t)p[pos + 2] << 8) | p[pos + 3];
-                t_crnti = (uint16_t)((p[pos + 4] << 8) | p[pos + 5]);
-                pos += 6;
-              }
-              DciUl d;  // ul_sniffer_dci_rar_unpack / _rar_to_ul_dci, falcon_dci.c:648-683
-              d.rnti = t_crnti; d.hopping = (grant20 >> 19) & 1u; d.riv = (grant20 >> 9) & 0x3FFu; d.mcs_idx = (grant20 >> 5) & 0xFu;
-              last = UlSchedGrant();
-              last.rnti = t_crnti; last.is_rar = true; last.hopping = d.hopping != 0;
-              if (!ra_ul_dci_to_grant(cell, d, last.g)) last.g = PuschGrant();  // ran_ul_grant_256 stays empty for RAR grants
-              found = true;  // (the RNTI activation of this sub-header already happened at search time)
+            RarEntry re[32];
+            const int nre = rar_parse(cell, ch.h_payload.data() + job.payload_off[0], (int)len, re, 32);
+            UlSchedGrant last; const bool found = nre > 0;
+            if (found) {
+              const RarEntry& e = re[nre - 1];
+              last.rnti = e.t_crnti; last.is_rar = true; last.hopping = e.hopping != 0;
+              if (e.grant_ok) last.g = e.grant;  // ran_ul_grant_256 stays empty for RAR grants
+              // (the RNTI activation of every sub-header already happened at search time)
             }
             if (found) rar_now.push_back(last);
             break;

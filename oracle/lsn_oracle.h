@@ -264,6 +264,8 @@ void o_worker_set_pcap(o_worker_t*, o_pcap_t*);
 int o_worker_work(o_worker_t*, const ocf_t* const* iq, uint32_t sf_idx, uint32_t sfn, int update_meta_formats, float cfo_correct_hz);
 /* UL_MODE (SubframeWorker.cc:184-199,236-345): iq[0] = downlink antenna, iq[1] = uplink antenna; worker created with nof_rx = 1.
  * The SIB2-derived DMRS configuration is given instead of parsed (ASN.1 is out of scope). */
+typedef struct { uint32_t rapid, ta, hopping, riv, mcs, tpc, ul_delay, csi_req; uint16_t t_crnti; int grant_ok; o_pusch_grant_t grant; } o_rar_t;
+int o_rar_parse(const o_cell_t* cell, const uint8_t* p, int len, o_rar_t* out, int cap); /* MAC RAR PDU -> RAR entries (o_worker.c) */
 void o_worker_set_ul_mode(o_worker_t*, const o_ul_cfg_t* ul);
 int o_worker_work_ul(o_worker_t*, const ocf_t* dl_iq, const ocf_t* ul_iq, uint32_t sf_idx, uint32_t sfn, int update_meta_formats);
 const o_stats_t* o_worker_stats(o_worker_t*);

@@ -507,6 +507,46 @@ static const char* rnti_name(uint16_t r) /* DL_Sniffer_PDSCH.cc:1398-1418 */
   return "C_RNTI";
 }
 
+/* MAC RAR PDU (TS 36.321 6.1.5, 6.2.2, 6.2.3): E/T/RAPID sub-headers (a T = 0 sub-header is the backoff indicator and has no body),
+ * then one 6-byte RAR per RAPID sub-header: R(1) TA(11) UL grant(20) T-CRNTI(16); the grant as ul_sniffer_dci_rar_unpack /
+ * _rar_to_ul_dci read it (falcon_dci.c:648-683: hopping(1) RIV(10) MCS(4) TPC(3) UL delay(1) CSI request(1)) and convert it
+ * with srsran_ra_ul_dci_to_grant.  A sub-header without a body yields an entry with T-CRNTI 0, like the reference's loop. */
+int o_rar_parse(const o_cell_t* cell, const uint8_t* p, int len, o_rar_t* out, int cap)
+{
+  int nsub = 0, is_rapid[32], rapid[32], pos = 0, n = 0;
+  while (pos < len && nsub < 32) {
+    uint8_t b = p[pos++];
+    is_rapid[nsub] = (b & 0x40) ? 1 : 0;
+    rapid[nsub] = b & 0x3F;
+    nsub++;
+    if (!(b & 0x80)) break;
+  }
+  for (int i = 0; i < nsub && n < cap; i++) {
+    o_rar_t* r = &out[n];
+    memset(r, 0, sizeof(*r));
+    uint32_t grant20 = 0;
+    if (is_rapid[i]) {
+      if (pos + 6 > len) break;
+      r->rapid = (uint32_t)rapid[i];
+      r->ta = ((uint32_t)(p[pos] & 0x7F) << 4) | (p[pos + 1] >> 4);
+      grant20 = ((uint32_t)(p[pos + 1] & 0x0F) << 16) | ((uint32_t)p[pos + 2] << 8) | p[pos + 3];
+      r->t_crnti = (uint16_t)((p[pos + 4] << 8) | p[pos + 5]);
+      pos += 6;
+    }
+    o_dci_ul_t d;
+    memset(&d, 0, sizeof(d));
+    d.rnti = r->t_crnti;
+    d.freq_hop_fl = (grant20 >> 19) & 1u;
+    d.riv = (grant20 >> 9) & 0x3FFu;
+    d.mcs_idx = (grant20 >> 5) & 0xFu;
+    r->hopping = d.freq_hop_fl; r->riv = d.riv; r->mcs = d.mcs_idx; r->tpc = (grant20 >> 2) & 7u; r->ul_delay = (grant20 >> 1) & 1u; r->csi_req = grant20 & 1u;
+    r->grant_ok = o_ra_ul_dci_to_grant(cell, &d, &r->grant) == 0;
+    if (!r->grant_ok) memset(&r->grant, 0, sizeof(r->grant));
+    n++;
+  }
+  return n;
+}
+
 /* MAC RAR PDU (TS 36.321 6.1.5 / 6.2.2-6.2.3) walked like srsran::rar_pdu; DL_Sniffer_PDSCH.cc:782-797 */
 static void unpack_rar(o_worker_t* w, const uint8_t* p, int len)
 {
@@ -666,37 +706,17 @@ static void write_pcap_ul(o_worker_t* w, const uint8_t* pdu, uint32_t len, uint1
  * that survives is the LAST one of the PDU (the result object is overwritten per sub-header) */
 static int unpack_rar_ul(o_worker_t* w, const uint8_t* p, int len, ulg_t* out)
 {
-  int nsub = 0, is_rapid[32], pos = 0, found = 0;
-  while (pos < len && nsub < 32) {
-    uint8_t b = p[pos++];
-    is_rapid[nsub++] = (b & 0x40) ? 1 : 0;
-    if (!(b & 0x80)) break;
-  }
-  for (int i = 0; i < nsub; i++) {
-    uint16_t t_crnti = 0;
-    uint32_t grant20 = 0;
-    if (is_rapid[i]) {
-      if (pos + 6 > len) break;
-      grant20 = ((uint32_t)(p[pos + 1] & 0x0F) << 16) | ((uint32_t)p[pos + 2] << 8) | p[pos + 3];
-      t_crnti = (uint16_t)((p[pos + 4] << 8) | p[pos + 5]);
-      pos += 6;
-    }
-    /* ul_sniffer_dci_rar_unpack / _rar_to_ul_dci, falcon_dci.c:648-683 */
-    o_dci_ul_t d;
-    memset(&d, 0, sizeof(d));
-    d.rnti = t_crnti;
-    d.freq_hop_fl = (grant20 >> 19) & 1u;
-    d.riv = (grant20 >> 9) & 0x3FFu;
-    d.mcs_idx = (grant20 >> 5) & 0xFu;
+  o_rar_t r[32];
+  int n = o_rar_parse(&w->cfg.cell, p, len, r, 32);
+  for (int i = 0; i < n; i++) {
     memset(out, 0, sizeof(*out));
-    out->rnti = t_crnti;
+    out->rnti = r[i].t_crnti;
     out->is_rar = 1;
-    out->hopping = d.freq_hop_fl;
-    if (o_ra_ul_dci_to_grant(&w->cfg.cell, &d, &out->g)) memset(&out->g, 0, sizeof(out->g)); /* ran_ul_grant_256 stays empty for RAR grants */
-    o_rntiman_activate_and_refresh(w->rm, t_crnti, 0, O_ACT_RAR);
-    found = 1;
+    out->hopping = r[i].hopping;
+    if (r[i].grant_ok) out->g = r[i].grant; /* ran_ul_grant_256 stays empty for RAR grants */
+    o_rntiman_activate_and_refresh(w->rm, r[i].t_crnti, 0, O_ACT_RAR);
   }
-  return found;
+  return n > 0;
 }
 
 /* PDSCH_Decoder::decode_ul_mode (DL_Sniffer_PDSCH.cc:362-457) with rnti == 0 (no target); RRC parsing is out of scope */

@@ -20,5 +20,17 @@ for name in ("ltesniffer_dl_mode.pcap", "ltesniffer_ul_mode.pcap", "api_collecto
             seen.add(key); keep.append(r)
     out[name] = {"global_header": data[:24].hex(), "nof_records": len(recs),
                  "records": [r[:19 + 48].hex() for r in keep], "record_lens": [len(r) for r in keep]}
+    # procedure-level golden data (real captures of the reference): every random-access response with the records that follow it, and the
+    # PDU length of every record (= transport block sizes the reference's grant conversion produced)
+    full = [dict(direction=r[1], rnti_type=r[2], rnti=(r[4] << 8) | r[5], tti=(((r[10] << 8) | r[11]) >> 4) * 10 + (((r[10] << 8) | r[11]) & 15), pdu=r[19:]) for r in recs]
+    proc = []
+    for i, r in enumerate(full):
+        if r["rnti_type"] == 2:
+            proc.append({"rar_tti": r["tti"], "ra_rnti": r["rnti"], "rar_pdu": r["pdu"].hex(),
+                         "following": [dict(direction=q["direction"], rnti_type=q["rnti_type"], rnti=q["rnti"], dtti=(q["tti"] - r["tti"]) % 10240, pdu=q["pdu"].hex())
+                                       for q in full[i + 1:i + 4]]})
+    out[name]["random_access"] = proc
+    out[name]["pdu_lengths"] = {"%d/%d" % (d, t): sorted({len(q["pdu"]) for q in full if q["direction"] == d and q["rnti_type"] == t})
+                                for d, t in sorted({(q["direction"], q["rnti_type"]) for q in full})}
 json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "pcap_records.json"), "w"), indent=0)
 print({k: (v["nof_records"], len(v["records"])) for k, v in out.items()})

@@ -142,4 +142,19 @@ double lsnh_search_bench(hsearch* h, uint32_t n, uint32_t reps, const uint32_t* 
   return us / ((double)n * reps);
 }
 
+int lsnh_tbs(int i_tbs, uint32_t n_prb) { return ra_tbs_from_idx(i_tbs, n_prb); }
+// MAC RAR PDU -> up to cap entries of 8 words: t_crnti, rapid, ta, riv, mcs, grant_ok, n_prb, L_prb | tbs in the high half of word 7 is not needed: word 7 = L_prb, word 6 = n_prb; tbs returned via tbs_out
+int lsnh_rar_parse(uint32_t nof_prb, const uint8_t* p, int len, uint32_t* out, int* tbs_out, int cap)
+{
+  Cell c; c.nof_prb = nof_prb; c.nof_ports = 1; c.id = 0;
+  RarEntry r[32];
+  const int n = rar_parse(c, p, len, r, cap < 32 ? cap : 32);
+  for (int i = 0; i < n; i++) {
+    uint32_t* o = out + 8 * i;
+    o[0] = r[i].t_crnti; o[1] = r[i].rapid; o[2] = r[i].ta; o[3] = r[i].riv; o[4] = r[i].mcs; o[5] = r[i].grant_ok ? 1u : 0u; o[6] = r[i].grant.n_prb; o[7] = r[i].grant.L_prb;
+    tbs_out[i] = r[i].grant.tbs;
+  }
+  return n;
+}
+
 }  // extern "C"
