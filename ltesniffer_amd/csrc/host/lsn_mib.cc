@@ -21,6 +21,7 @@ int Engine::mibDecode(const void* iq, bool on_device, lsn_mib_t* out, float* llr
 {
   if (!cell_set) return LSN_ERROR;
   if (!iq || !out) return LSN_ERROR_INVALID_INPUTS;
+  if (batch_open) return LSN_ERROR;  // borrows a chunk slot: not while submitted blocks are in flight (call lsn_phy_wait first)
   std::memset(out, 0, sizeof(*out));
   try {
     HIP_CHECK(hipSetDevice(cfg.device));
