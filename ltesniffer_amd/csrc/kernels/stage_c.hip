@@ -67,14 +67,16 @@ __device__ __forceinline__ void demod_llr(int Qm, float I, float Q, float* L)
   }
 }
 
-__device__ __forceinline__ void emit(const LsnCellDev& c, int Qm, cf32 x, float w, float inv_amp, uint32_t cinit, uint32_t idx,
-                                     int16_t* __restrict__ out)
+// QM is a compile-time constant so that the soft-bit array stays in registers (a run-time loop bound puts it in scratch memory)
+template <int QM>
+__device__ __forceinline__ void emit_q(const LsnCellDev& c, cf32 x, float w, float inv_amp, uint32_t cinit, uint32_t idx, int16_t* __restrict__ out)
 {
   float L[8];
   float wq = w * LLR_Q;
-  demod_llr(Qm, x.r * inv_amp, x.i * inv_amp, L);
-  const uint32_t n0 = idx * (uint32_t)Qm;
-  for (int b = 0; b < Qm; b++) {
+  demod_llr(QM, x.r * inv_amp, x.i * inv_amp, L);
+  const uint32_t n0 = idx * (uint32_t)QM;
+#pragma unroll
+  for (int b = 0; b < QM; b++) {
     float r = rintf(L[b] * wq);
     r = r > (float)LSN_LLR_CLIP ? (float)LSN_LLR_CLIP : r;
     r = r < (float)-LSN_LLR_CLIP ? (float)-LSN_LLR_CLIP : r;
@@ -82,6 +84,17 @@ __device__ __forceinline__ void emit(const LsnCellDev& c, int Qm, cf32 x, float 
     uint32_t n = n0 + (uint32_t)b;
     uint32_t cbit = (uint32_t)c.gold_x1[n] ^ (uint32_t)(__popc(c.gold_x2mask[n] & cinit) & 1);
     out[n] = (int16_t)(cbit ? -q : q);
+  }
+}
+__device__ __forceinline__ void emit(const LsnCellDev& c, int Qm, cf32 x, float w, float inv_amp, uint32_t cinit, uint32_t idx,
+                                     int16_t* __restrict__ out)
+{
+  switch (Qm) {
+    case 2: emit_q<2>(c, x, w, inv_amp, cinit, idx, out); break;
+    case 4: emit_q<4>(c, x, w, inv_amp, cinit, idx, out); break;
+    case 6: emit_q<6>(c, x, w, inv_amp, cinit, idx, out); break;
+    case 8: emit_q<8>(c, x, w, inv_amp, cinit, idx, out); break;
+    default: break;
   }
 }
 

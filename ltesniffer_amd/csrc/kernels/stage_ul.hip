@@ -199,7 +199,9 @@ __global__ __launch_bounds__(256) void k_pusch_demod(LsnCellDev c, const LsnUlGr
     }
     float Lb[8];
     ul_demod_llr(Qm, ar * scale, ai * scale, Lb);
-    for (int b = 0; b < Qm; b++) {
+#pragma unroll
+    for (int b = 0; b < 8; b++) {  // fixed trip count keeps Lb in registers (a run-time bound would put it in scratch memory)
+      if (b >= Qm) break;
       float v = rintf(Lb[b] * LLR_Q);
       v = v > (float)LSN_LLR_CLIP ? (float)LSN_LLR_CLIP : v;
       v = v < (float)-LSN_LLR_CLIP ? (float)-LSN_LLR_CLIP : v;
