@@ -133,6 +133,8 @@ def main():
     npdus = 0
     acc = {k: 0 for k in ("nof_tb_decodes", "nof_cb_decodes", "nof_turbo_iterations", "nof_turbo_iterations_run", "nof_ondemand_decodes", "turbo_cyc_rm",
                           "turbo_cyc_map", "turbo_cyc_out", "ms_stage_a", "ms_search", "ms_search_core", "ms_rar", "ms_stage_c", "ms_commit", "ms_wait_front", "ms_wait_slot", "ms_drain")}
+    import resource
+    ru0 = resource.getrusage(resource.RUSAGE_SELF)
     t0 = time.perf_counter()
     # the K steps are submitted back to back (lsn_phy_submit_device: a step returns once its subframes are searched and queued, its
     # decode / commit tail overlaps the next step's front) and completed by one lsn_phy_wait inside the timed region
@@ -159,6 +161,8 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    host_cores_busy = ((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) / dt  # CPU cores this rank kept busy in the timed region
     if world > 1:
         rdev = dev if dist.get_backend() == "nccl" else None
         dt, total = ld.reduce_max_sum(dt, args.steps * nsf, rdev)
@@ -224,7 +228,7 @@ def main():
                          "avg_launch_ms": round(kms[kt] / max(1, klaunch[kt]), 4), "launches": int(klaunch[kt]),
                          "algo_bytes_per_launch": int(kbytes / max(1, klaunch[kt])),
                          "dominant_by_time": la.KERNELS[dom], "valu": valu},
-            "cpu_baseline": cpu, "host": {"cpu_count": os.cpu_count()},
+            "cpu_baseline": cpu, "host": {"cpu_count": os.cpu_count(), "cores_busy_in_timed_region": round(host_cores_busy, 2)},
             "detail": {"pdus_per_step": npdus / args.steps, "algo_bytes_per_subframe": int(algo_bytes / (args.steps * nsf)),
                        "whole_path_GBps": round(algo_bytes / 1e9 / dt, 2),
                        "per_step": {k: round(v / args.steps, 3) for k, v in acc.items()},

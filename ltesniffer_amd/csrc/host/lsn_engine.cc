@@ -491,7 +491,8 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
       HIP_CHECK(hipMemcpyAsync(r.h_cbres_pinned, r.d_cbres, ncb * sizeof(LsnCbRes), hipMemcpyDeviceToHost, st));
       HIP_CHECK(hipMemcpyAsync(r.h_payload_pinned, r.d_payload, pay_n - pay0, hipMemcpyDeviceToHost, st));
     }
-    HIP_CHECK(hipStreamSynchronize(st));
+    HIP_CHECK(hipEventRecord(r.ev_done, st));
+    HIP_CHECK(hipEventSynchronize(r.ev_done));
     float ms = 0;
     if (hipEventElapsedTime(&ms, r.ev[0], r.ev[1]) == hipSuccess) pf.kernel_ms[LSN_K_PDSCH_PREP] += ms;
     if (hipEventElapsedTime(&ms, r.ev[1], r.ev[2]) == hipSuccess) pf.kernel_ms[LSN_K_PDSCH_DEMOD] += ms;

@@ -67,6 +67,7 @@ struct JobRunner {
   LsnCbDev* h_cbs_pinned = nullptr; size_t h_cbs_cap = 0;
   std::vector<LsnGrantDev> h_jobs; std::vector<LsnCbDev> h_cbs;
   hipEvent_t ev[8] = {};
+  hipEvent_t ev_done = nullptr;  // blocking-sync event the owning thread waits on
   lsn_perf_t perf{};
 };
 

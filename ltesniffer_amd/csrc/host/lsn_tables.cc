@@ -86,6 +86,7 @@ void Engine::freeRunner(JobRunner& r)
   r.jobs_cap = r.cbs_cap = r.cbres_cap = r.prefix_cap = r.llr16_cap = r.payload_cap = r.h_payload_cap = r.h_cbres_cap = r.h_jobs_cap = r.h_cbs_cap = 0;
   for (auto& e : r.ev)
     if (e) { (void)hipEventDestroy(e); e = nullptr; }
+  if (r.ev_done) { (void)hipEventDestroy(r.ev_done); r.ev_done = nullptr; }
   if (r.stream) { (void)hipStreamDestroy(r.stream); r.stream = nullptr; }
 }
 
@@ -111,6 +112,8 @@ void Engine::allocRunner(JobRunner& r)
       HIP_CHECK(hipStreamCreateWithPriority(&r.stream, hipStreamNonBlocking, lo));
   }
   for (auto& e : r.ev) HIP_CHECK(hipEventCreate(&e));
+  // the thread that waits for this runner's stream sleeps on an interrupt instead of spinning on a core (LSN_SPIN_WAIT=1: spin)
+  HIP_CHECK(hipEventCreateWithFlags(&r.ev_done, (getenv("LSN_SPIN_WAIT") && atoi(getenv("LSN_SPIN_WAIT"))) ? hipEventDisableTiming : (hipEventBlockingSync | hipEventDisableTiming)));
 }
 
 template <typename T>
@@ -145,6 +148,8 @@ void Engine::allocChunk(Chunk& ch)
   ch.h_sfidx = halloc<uint32_t>(host_allocs, B);
   ch.ctx.assign(B, SubframeCtx());
   for (auto& e : ch.ev_a) HIP_CHECK(hipEventCreate(&e));
+  (void)hipEventDestroy(ch.ev_a[16]);  // the "stage A results are on the host" marker is only waited for, never timed
+  HIP_CHECK(hipEventCreateWithFlags(&ch.ev_a[16], (getenv("LSN_SPIN_WAIT") && atoi(getenv("LSN_SPIN_WAIT"))) ? hipEventDisableTiming : (hipEventBlockingSync | hipEventDisableTiming)));
 }
 
 void Engine::buildTables()
