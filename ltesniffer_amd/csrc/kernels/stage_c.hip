@@ -245,6 +245,15 @@ __device__ __forceinline__ int ext_scale(int x)
   a = a > LSN_EXT_CLIP ? LSN_EXT_CLIP : a;
   return x < 0 ? -a : a;
 }
+// forward step without the per-step normalisation (metrics only ever enter differences and maxima, so a common offset is
+// harmless as long as it fits: callers re-normalise every TB_S steps, growth <= 16 * 3069)
+__device__ __forceinline__ void step_fwd_raw(int* a, int lsa, int lp)
+{
+  const int g01 = lp, g10 = lsa, g11 = lsa + lp;
+  int n0 = imax(a[0], a[1] + g11), n1 = imax(a[2] + g10, a[3] + g01), n2 = imax(a[4] + g01, a[5] + g10), n3 = imax(a[6] + g11, a[7]);
+  int n4 = imax(a[0] + g11, a[1]), n5 = imax(a[2] + g01, a[3] + g10), n6 = imax(a[4] + g10, a[5] + g01), n7 = imax(a[6], a[7] + g11);
+  a[0] = n0; a[1] = n1; a[2] = n2; a[3] = n3; a[4] = n4; a[5] = n5; a[6] = n6; a[7] = n7;
+}
 // a[0] is always 0 after normalisation
 __device__ __forceinline__ void step_fwd(int* a, int lsa, int lp)
 {
@@ -323,7 +332,9 @@ __device__ __forceinline__ void map_pass(const TurboLds& m, int lane, bool activ
       }
     }
 #pragma unroll
-    for (int u = 0; u < TB_S; u++) step_fwd(a, (int)(g[u] << 16) >> 16, g[u] >> 16);
+    for (int u = 0; u < TB_S; u++) step_fwd_raw(a, (int)(g[u] << 16) >> 16, g[u] >> 16);
+#pragma unroll
+    for (int s = 7; s >= 0; s--) a[s] -= a[0];  // one normalisation per sub-block (exactly what 16 normalised steps would leave)
   }
   if (IL) {  // interleaver state -> end of the window
     for (int t = (nsb - 1) * TB_S; t < W; t++) { pi += gq; pi = pi >= K ? pi - K : pi; gq += twof2; gq = gq >= K ? gq - K : gq; }
@@ -403,12 +414,13 @@ __device__ __forceinline__ void map_pass(const TurboLds& m, int lane, bool activ
         const int m1 = imax(imax(imax(x01, al1 + x11), imax(al2 + x21, al3 + x31)), imax(imax(al4 + x41, al5 + x51), imax(al6 + x61, al7 + x71)));
         const int L = m1 - m0;
         m.ext[ix[u]] = (int16_t)((ext_scale(L - lsa) << 1) | (L > 0 ? 1 : 0));  // idle lanes: spare slot ext[K]
-        const int n0 = imax(x00, x01);
-        b[1] = imax(x10, x11) - n0; b[2] = imax(x20, x21) - n0; b[3] = imax(x30, x31) - n0; b[4] = imax(x40, x41) - n0;
-        b[5] = imax(x50, x51) - n0; b[6] = imax(x60, x61) - n0; b[7] = imax(x70, x71) - n0;
-        b[0] = 0;
+        b[0] = imax(x00, x01);  // no per-step normalisation (see step_fwd_raw): once per sub-block below
+        b[1] = imax(x10, x11); b[2] = imax(x20, x21); b[3] = imax(x30, x31); b[4] = imax(x40, x41);
+        b[5] = imax(x50, x51); b[6] = imax(x60, x61); b[7] = imax(x70, x71);
       }
     }
+#pragma unroll
+    for (int s = 7; s >= 0; s--) b[s] -= b[0];
       };
     if (n == TB_S) subblock(std::true_type{}); else subblock(std::false_type{});
   }
@@ -557,46 +569,24 @@ __global__ __launch_bounds__(NT) void k_turbo(const uint32_t* __restrict__ crc_t
 #pragma unroll
   for (int s = 0; s < 7; s++) { na1[s] = 0; nb1[s] = 0; na2[s] = 0; nb2[s] = 0; }
   int it = 0;
-  bool ok = false, stuck = false;
-  uint32_t hp0 = 0, hp1 = 0;
-  while (it < (int)cb.max_iter && !ok && !stuck) {
+  bool ok = false;
+  while (it < (int)cb.max_iter && !ok) {
     map_pass<false, NT>(m, lane, active, K, P, W, magicW, (int)cb.f1, (int)cb.f2, na1, nb1, bt1);
     map_pass<true, NT>(m, lane, active, K, P, W, magicW, (int)cb.f1, (int)cb.f2, na2, nb2, bt2);
     it++;
     // CRC over all K decided bits == 0  <=>  data || parity divisible by g(x): Horner over the thread's own window,
-    // then weighting with x^((P-1-window) W) and an XOR reduction over the windows.
-    // The same sweep fingerprints the decoder state that the next iteration starts from (all extrinsics + the
-    // window-boundary metrics): an iteration that reproduces its own input state is a fixed point of a deterministic
-    // map, every later iteration would return the same decisions, so a failing block can stop there with the result
-    // (and the reported iteration count) of the full max_iter run.
-    uint32_t rem = 0, h0 = 0, h1 = 0;
+    // then weighting with x^((P-1-window) W) and an XOR reduction over the windows
+    uint32_t rem = 0;
     if (active) {
       for (int t = 0; t < W; t++) {
-        const uint32_t v = (uint32_t)(uint16_t)m.ext[t * P + lane];
-        rem = (rem << 1) | (v & 1u);
+        rem = (rem << 1) | ((uint32_t)m.ext[t * P + lane] & 1u);
         rem ^= (rem & 0x1000000u) ? poly : 0u;
-        h0 = (h0 ^ v) * 0x9E3779B1u;
-        h1 = ((h1 << 7) | (h1 >> 25)) + (v ^ 0x5bd1e995u) * 0x85EBCA6Bu;
       }
       rem = mulmod24(rem, cw, poly);
-#pragma unroll
-      for (int s = 0; s < 7; s++) {
-        const uint32_t v0 = ((uint32_t)na1[s] & 0xFFFFu) | ((uint32_t)nb1[s] << 16), v1 = ((uint32_t)na2[s] & 0xFFFFu) | ((uint32_t)nb2[s] << 16);
-        h0 = (h0 ^ v0) * 0x9E3779B1u; h0 = (h0 ^ v1) * 0x9E3779B1u;
-        h1 = ((h1 << 7) | (h1 >> 25)) + (v0 ^ 0x5bd1e995u) * 0x85EBCA6Bu; h1 = ((h1 << 7) | (h1 >> 25)) + (v1 ^ 0x5bd1e995u) * 0x85EBCA6Bu;
-      }
-      h0 = (h0 ^ ((uint32_t)lane * 0xC2B2AE35u)) * 0x27D4EB2Fu; h0 ^= h0 >> 15;
-      h1 = (h1 + (uint32_t)lane * 0x165667B1u) * 0x9E3779B1u; h1 ^= h1 >> 13;
     }
     ok = wg_xor<NT>(rem, m.ckpt, lane) == 0;
-    if (!ok) {
-      h0 = wg_xor<NT>(h0, m.ckpt, lane); h1 = wg_xor<NT>(h1, m.ckpt, lane);
-      stuck = it > 1 && h0 == hp0 && h1 == hp1;
-      hp0 = h0; hp1 = h1;
-    }
   }
   const int it_run = it;
-  if (stuck) it = (int)cb.max_iter;  // what the plain loop would have counted
   const long long tc2 = clock64();
   // ---- output: payload bytes of this code block + its CRC24A remainder contribution (each thread a contiguous run) ----
   const int nout = (int)cb.out_bytes;
