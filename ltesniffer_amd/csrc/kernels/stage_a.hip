@@ -398,14 +398,16 @@ __device__ __forceinline__ void viterbi_tb(const int* symw, unsigned long long* 
   const int pa = s0 << 2, pb = (s0 | 32) << 2;  // ds_bpermute byte addresses of the two predecessors
   int m = 0;
   const int T = 3 * (int)D;  // 3 passes of D steps
-  for (int pass = 0, t = 0; pass < 3; pass++)
-    for (int tt = 0; tt < (int)D; tt++, t++) {
-      const int bm0 = __builtin_amdgcn_sdot4(symw[tt], signs, kconst, false);
-      const int a0 = __builtin_amdgcn_ds_bpermute(pa, m) + bm0, a1 = __builtin_amdgcn_ds_bpermute(pb, m) + (765 - bm0);
-      const bool d = a1 < a0;
-      m = d ? a1 : a0;
-      dec[t] = __ballot(d);  // same value, same address from every lane
-    }
+  auto step = [&](int t) {
+    const int bm0 = __builtin_amdgcn_sdot4(symw[t], signs, kconst, false);
+    const int a0 = __builtin_amdgcn_ds_bpermute(pa, m) + bm0, a1 = __builtin_amdgcn_ds_bpermute(pb, m) + (765 - bm0);
+    const bool d = a1 < a0;
+    m = d ? a1 : a0;
+    dec[t] = __ballot(d);  // same value, same address from every lane
+  };
+  int t = 0;
+  for (; t + 4 <= T; t += 4) { step(t); step(t + 1); step(t + 2); step(t + 3); }  // four steps share one symbol fetch and two ballot stores
+  for (; t < T; t++) step(t);
   // best end state: minimum metric, lowest index on ties
   unsigned long long key = ((unsigned long long)(unsigned)m << 6) | (unsigned)lane;
   for (int off = 32; off > 0; off >>= 1) {
@@ -460,8 +462,8 @@ __global__ __launch_bounds__(64) void k_viterbi(LsnCellDev c, const float* __res
                                                 const uint32_t* __restrict__ cfi_arr, const uint32_t* __restrict__ sf_idx_arr,
                                                 LsnCand* __restrict__ cand)
 {
-  __shared__ int symw[LSN_MAX_DCI_D];                  // per step: (q0 - 128) | (q1 - 128) << 8 | (q2 - 128) << 16, signed bytes
-  __shared__ unsigned long long dec[3 * LSN_MAX_DCI_D];
+  __shared__ __attribute__((aligned(16))) int symw[3 * LSN_MAX_DCI_D + 4];  // per step of the three passes: (q0 - 128) | (q1 - 128) << 8 | (q2 - 128) << 16, signed bytes
+  __shared__ __attribute__((aligned(16))) unsigned long long dec[3 * LSN_MAX_DCI_D];
   const int lane = threadIdx.x, sf = blockIdx.z, sz = blockIdx.y;
   int li = blockIdx.x;
   LsnCand* out = cand + ((size_t)sf * LSN_MAX_LOC + blockIdx.x) * LSN_MAX_SIZES + sz;
@@ -505,7 +507,7 @@ __global__ __launch_bounds__(64) void k_viterbi(LsnCellDev c, const float* __res
       q = q > 255.0f ? 255.0f : q;
       word |= (((uint32_t)(unsigned char)q - 128u) & 0xFFu) << (8 * j);
     }
-    symw[t] = (int)word;
+    symw[t] = (int)word; symw[D + t] = (int)word; symw[2 * D + t] = (int)word;  // one copy per pass: the sweep reads straight through
   }
   if (__ballot(nz) == 0ull) {  // mean |llr| == 0: the reference skips the decode (falcon_pdcch.c:141)
     if (lane == 0) { out->bits = 0; out->rnti = 0; out->flags = 0; }
@@ -594,8 +596,8 @@ __global__ __launch_bounds__(256) void k_pbch_llr(LsnCellDev c, const cf32* __re
 }
 __global__ __launch_bounds__(64) void k_pbch_viterbi(LsnCellDev c, const float* __restrict__ llr5, LsnCand* __restrict__ out4)
 {
-  __shared__ int symw[LSN_MAX_DCI_D];
-  __shared__ unsigned long long dec[3 * LSN_MAX_DCI_D];
+  __shared__ __attribute__((aligned(16))) int symw[3 * LSN_MAX_DCI_D + 4];
+  __shared__ __attribute__((aligned(16))) unsigned long long dec[3 * LSN_MAX_DCI_D];
   const int lane = threadIdx.x, q = blockIdx.x;
   const float* e = llr5 + 480 * (q + 1);
   const uint32_t D = 40, D3 = 120, E = 480;
@@ -614,7 +616,7 @@ __global__ __launch_bounds__(64) void k_pbch_viterbi(LsnCellDev c, const float* 
       qv = qv > 255.0f ? 255.0f : qv;
       word |= (((uint32_t)(unsigned char)qv - 128u) & 0xFFu) << (8 * j);
     }
-    symw[t] = (int)word;
+    symw[t] = (int)word; symw[D + t] = (int)word; symw[2 * D + t] = (int)word;  // one copy per pass: the sweep reads straight through
   }
   unsigned long long bits; uint32_t rem;
   viterbi_tb(symw, dec, D, 24, lane, bits, rem);
