@@ -330,14 +330,19 @@ void FalconSearch::recursive_blind_dci_search(SubframeCtx& c)
       for (int a = 0; a < 4; a++)
         if (cce_map[cc].location[a]) cce_map[cc].location[a]->sufficient_power = false;
   }
-  for (uint32_t i = 0; i < nloc; i++)
-    inspect_dci_location_recursively(c, cce_map, locations[i].ncce, locations[i].L, 99, meta_formats->getPrimaryMetaFormats(),
-                                     meta_formats->getNofPrimaryMetaFormats(), 1, nullptr);
+  // (the entry test of inspect_dci_location_recursively, DCISearch.cc:124-127, is repeated here so that dead locations cost no call)
+  for (uint32_t i = 0; i < nloc; i++) {
+    const FalconLocation& l = locations[i];
+    if (l.occupied || l.checked || !l.sufficient_power) continue;
+    inspect_dci_location_recursively(c, cce_map, l.ncce, l.L, 99, meta_formats->getPrimaryMetaFormats(), meta_formats->getNofPrimaryMetaFormats(), 1, nullptr);
+  }
   if (!meta_formats->skipSecondaryMetaFormats()) {
     for (uint32_t i = 0; i < nloc; i++) locations[i].checked = false;
-    for (uint32_t i = 0; i < nloc; i++)
-      inspect_dci_location_recursively(c, cce_map, locations[i].ncce, locations[i].L, 99, meta_formats->getSecondaryMetaFormats(),
-                                       meta_formats->getNofSecondaryMetaFormats(), 1, nullptr);
+    for (uint32_t i = 0; i < nloc; i++) {
+      const FalconLocation& l = locations[i];
+      if (l.occupied || l.checked || !l.sufficient_power) continue;
+      inspect_dci_location_recursively(c, cce_map, l.ncce, l.L, 99, meta_formats->getSecondaryMetaFormats(), meta_formats->getNofSecondaryMetaFormats(), 1, nullptr);
+    }
   }
   if (dl_collision) stats.nof_subframe_collisions_dw++;
   if (ul_collision) stats.nof_subframe_collisions_up++;
