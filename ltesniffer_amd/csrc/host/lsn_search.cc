@@ -210,12 +210,12 @@ bool FalconSearch::buildDlEntry(const SubframeCtx& c, uint16_t rnti, DciFormat f
 }
 
 // DCISearch::inspect_dci_location_recursively, DCISearch.cc:102-447
-int FalconSearch::inspect_dci_location_recursively(SubframeCtx& c, CceMap* cce_map, uint32_t ncce, uint32_t L, uint32_t max_depth, MetaFormat** metas,
+int FalconSearch::inspect_dci_location_recursively(SubframeCtx& c, const int16_t (*cce_map)[4], uint32_t ncce, uint32_t L, uint32_t max_depth, MetaFormat** metas,
                                                    uint32_t nof_formats, uint32_t enable_discovery, const DciCandidate* parent_cand)
 {
   int hist_max_format_idx = -1;
   uint32_t hist_max_format_value = 0, nof_cand_above_threshold = 0;
-  FalconLocation* loc = cce_map[ncce].location[L];
+  FalconLocation* loc = cce_map[ncce][L] >= 0 ? &locations[cce_map[ncce][L]] : nullptr;  // the level-L location that covers this CCE
   if (!(loc && !loc->occupied && !loc->checked && loc->sufficient_power)) return 0;  // :124-127
   DciCandidate cand[NOF_FORMATS];
 
@@ -288,7 +288,7 @@ int FalconSearch::inspect_dci_location_recursively(SubframeCtx& c, CceMap* cce_m
     loc->used = true;
     for (uint32_t ci = ncce; ci < ncce + (1u << L); ci++)
       for (int a = 0; a < 4; a++)
-        if (cce_map[ci].location[a]) { cce_map[ci].location[a]->occupied = true; cce_map[ci].location[a]->checked = true; }
+        if (cce_map[ci][a] >= 0) { locations[cce_map[ci][a]].occupied = true; locations[cce_map[ci][a]].checked = true; }
     DciCandidate& best = cand[hist_max_format_idx];
     rnti_manager->addCandidate(best.rnti, metas[hist_max_format_idx]->global_index);
     metas[hist_max_format_idx]->hits++;
@@ -311,25 +311,20 @@ int FalconSearch::inspect_dci_location_recursively(SubframeCtx& c, CceMap* cce_m
 // DCISearch::recursive_blind_dci_search, DCISearch.cc:449-528
 void FalconSearch::recursive_blind_dci_search(SubframeCtx& c)
 {
-  CceMap cce_map[LSN_MAX_NUM_OF_CCE];
   const uint32_t ncce = nof_cce[c.cfi - 1];
   const uint32_t lim = std::min<uint32_t>(ncce, LSN_MAX_NUM_OF_CCE);
   stats.nof_cce += ncce;
-  // srsran_pdcch_ue_locations_all_map (falcon_pdcch.c:321-356): the enumeration only depends on the CFI -> copied from a template
+  // srsran_pdcch_ue_locations_all_map (falcon_pdcch.c:321-356): the enumeration and the CCE -> covering-location map only depend on
+  // the CFI: the map is used straight from the template (indices instead of pointers), the per-subframe flags are copied
   const LocTemplate& tp = loc_template[c.cfi - 1];
+  const int16_t (*cce_map)[4] = tp.map;
   const uint32_t nloc = tp.nloc;
   std::memcpy(locations, tp.locations, sizeof(FalconLocation) * nloc);
-  for (uint32_t m = 0; m < lim; m++) {
-    for (int a = 0; a < 4; a++) cce_map[m].location[a] = tp.map[m][a] >= 0 ? &locations[tp.map[m][a]] : nullptr;
-    cce_map[m].power = 0.0f;
-  }
   stats.nof_locations += nloc;
-  for (uint32_t cc = 0; cc < lim; cc++) {  // srsran_pdcch_cce_avg_llr_power, falcon_pdcch.c:595-620
-    cce_map[cc].power = cur_ccepow[cc];
-    if (cce_map[cc].power < 0.7f)
+  for (uint32_t cc = 0; cc < lim; cc++)  // srsran_pdcch_cce_avg_llr_power, falcon_pdcch.c:595-620
+    if (cur_ccepow[cc] < 0.7f)
       for (int a = 0; a < 4; a++)
-        if (cce_map[cc].location[a]) cce_map[cc].location[a]->sufficient_power = false;
-  }
+        if (cce_map[cc][a] >= 0) locations[cce_map[cc][a]].sufficient_power = false;
   // (the entry test of inspect_dci_location_recursively, DCISearch.cc:124-127, is repeated here so that dead locations cost no call)
   for (uint32_t i = 0; i < nloc; i++) {
     const FalconLocation& l = locations[i];
@@ -348,10 +343,10 @@ void FalconSearch::recursive_blind_dci_search(SubframeCtx& c)
   if (ul_collision) stats.nof_subframe_collisions_up++;
   uint32_t missed = 0;  // falcon_pdcch.c:561-593
   for (uint32_t cc = 0; cc < lim; cc++) {
-    if (cce_map[cc].power < 0.7f) continue;
+    if (cur_ccepow[cc] < 0.7f) continue;
     bool m = true;
     for (int a = 0; a < 4; a++)
-      if (cce_map[cc].location[a] && cce_map[cc].location[a]->used) { m = false; break; }
+      if (cce_map[cc][a] >= 0 && locations[cce_map[cc][a]].used) { m = false; break; }
     if (m) missed++;
   }
   stats.nof_missed_cce += missed;

@@ -75,10 +75,9 @@ public:
 
 private:
   struct FalconLocation { uint32_t L, ncce; bool used, occupied, checked, sufficient_power; uint32_t index; };
-  struct CceMap { FalconLocation* location[4]; float power; };
   struct LocTemplate { FalconLocation locations[LSN_MAX_LOC]; int16_t map[LSN_MAX_NUM_OF_CCE][4]; uint32_t nloc = 0; };
   struct TempDci0 { uint16_t rnti; uint32_t L, ncce; DciFormat format; DciCandidate cand; };
-  int inspect_dci_location_recursively(SubframeCtx& c, CceMap* cce_map, uint32_t ncce, uint32_t L, uint32_t max_depth, MetaFormat** meta_formats_,
+  int inspect_dci_location_recursively(SubframeCtx& c, const int16_t (*cce_map)[4], uint32_t ncce, uint32_t L, uint32_t max_depth, MetaFormat** meta_formats_,
                                        uint32_t nof_formats, uint32_t enable_discovery, const DciCandidate* parent_cand);
   void recursive_blind_dci_search(SubframeCtx& c);
   void decodeCandidate(const FalconLocation& loc, DciFormat format, DciCandidate& cand);
