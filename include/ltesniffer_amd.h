@@ -174,10 +174,14 @@ int lsn_phy_process_file(lsn_phy_t* phy, const char* path, const lsn_file_cfg_t*
  * values come from SIB2 (ULSchedule::set_config, ULSchedule.cc:140-158: cyclicShift, groupAssignmentPUSCH).
  * lsn_phy_pusch_decode runs srsran_enb_ul_fft + srsran_chest_ul_estimate_pusch + srsran_pusch_decode
  * (UL_Sniffer_PUSCH.cc:392,256,262) for a whole list of grants on n_subframes of the uplink antenna.
- * Round-1 scope: one antenna, no group/sequence/frequency hopping, no SRS, L_prb >= 3 of the 2^a3^b5^c set; control information on the
+ * Round-1 scope: one antenna, no group/sequence hopping, type-1 frequency hopping only (type 2 grants come back with crc_ok = 0), no SRS, L_prb >= 3 of the 2^a3^b5^c set; control information on the
  * PUSCH is located and skipped / erased, not decoded
  * (UL_Sniffer_PUSCH.cc:3-10); any other grant comes back with crc_ok = 0. */
-typedef struct { uint32_t cyclic_shift; uint32_t delta_ss; } lsn_ul_cfg_t;
+typedef struct {
+  uint32_t cyclic_shift;    /* SIB2 cyclicShift */
+  uint32_t delta_ss;        /* SIB2 groupAssignmentPUSCH */
+  uint32_t hopping_offset;  /* SIB2 pusch-HoppingOffset (ul_cfg.hopping.n_rb_ho, SubframeWorker.cc:271-273): second-slot position of type-1 hopping grants */
+} lsn_ul_cfg_t;
 typedef struct {
   uint32_t sf;       /* subframe index inside ul_iq (tti = start_tti + sf) */
   uint16_t rnti;
@@ -192,6 +196,8 @@ typedef struct {
   uint32_t nof_ack;  /* HARQ-ACK bits 0..2 (uci_cfg.ack[0].nof_acks) */
   uint32_t cqi_bits; /* size of the CQI report, 0 = none (aperiodic request: 4 + 2 N, higher-layer sub-band) */
   uint32_t ri_bits;  /* rank indication bits (1 with a CQI request) */
+  uint32_t hop;      /* 0: both slots on n_prb; 1: type-1 frequency hopping, slot 1 starts at n_prb_slot1 (36.213 8.4.1) */
+  uint32_t n_prb_slot1;
 } lsn_pusch_grant_t;
 typedef struct { uint32_t crc_ok; uint32_t iterations; float snr_db; uint32_t payload_off; } lsn_pusch_result_t;
 int lsn_phy_set_ul_config(lsn_phy_t* phy, const lsn_ul_cfg_t* cfg);

@@ -61,9 +61,9 @@ public:
   lsn_blind_stats_t getStats() { lsn_blind_stats_t s{}; lsn_phy_get_stats(h, &s); return s; }              // PhyCommon::getStats
   float getEstCfo() { return lsn_phy_get_est_cfo(h); }                                                      // SubframeWorker.cc:203
   // UL_MODE: what ULSchedule::set_config hands to the workers once SIB2 is known (ULSchedule.cc:140-158)
-  bool setUlConfig(uint32_t cyclicShift, uint32_t groupAssignmentPUSCH)                                    // SubframeWorker.cc:258-262
+  bool setUlConfig(uint32_t cyclicShift, uint32_t groupAssignmentPUSCH, uint32_t puschHoppingOffset = 0)    // SubframeWorker.cc:258-277
   {
-    lsn_ul_cfg_t u{cyclicShift, groupAssignmentPUSCH};
+    lsn_ul_cfg_t u{cyclicShift, groupAssignmentPUSCH, puschHoppingOffset};
     return lsn_phy_set_ul_config(h, &u) == LSN_SUCCESS;
   }
   bool setRachConfig(const lsn_prach_cfg_t& p) { return lsn_phy_set_prach_config(h, &p) == LSN_SUCCESS; }    // PUSCH_Decoder::set_rach_config

@@ -96,12 +96,13 @@ class Perf(C.Structure):
 
 
 class UlCfg(C.Structure):
-    _fields_ = [("cyclic_shift", C.c_uint32), ("delta_ss", C.c_uint32)]
+    _fields_ = [("cyclic_shift", C.c_uint32), ("delta_ss", C.c_uint32), ("hopping_offset", C.c_uint32)]
 
 
 class PuschGrant(C.Structure):
     _fields_ = [("sf", C.c_uint32), ("rnti", C.c_uint16), ("n_dmrs", C.c_uint16), ("n_prb", C.c_uint32), ("L_prb", C.c_uint32),
-                ("mod", C.c_uint32), ("tbs", C.c_uint32), ("rv", C.c_int), ("nof_ack", C.c_uint32), ("cqi_bits", C.c_uint32), ("ri_bits", C.c_uint32)]
+                ("mod", C.c_uint32), ("tbs", C.c_uint32), ("rv", C.c_int), ("nof_ack", C.c_uint32), ("cqi_bits", C.c_uint32), ("ri_bits", C.c_uint32),
+                ("hop", C.c_uint32), ("n_prb_slot1", C.c_uint32)]
 
 
 class PuschResult(C.Structure):
@@ -380,8 +381,8 @@ class Phy:
         return int(done.value)
 
     # ---- uplink ----
-    def setUlConfig(self, cyclic_shift, delta_ss):
-        u = UlCfg(cyclic_shift, delta_ss)
+    def setUlConfig(self, cyclic_shift, delta_ss, hopping_offset=0):
+        u = UlCfg(cyclic_shift, delta_ss, hopping_offset)
         return lib().lsn_phy_set_ul_config(self._h, C.byref(u)) == LSN_SUCCESS
 
     def pusch_decode(self, ul_iq, start_tti, grants):
@@ -390,7 +391,7 @@ class Phy:
         ul_iq = np.ascontiguousarray(ul_iq, dtype=np.complex64)
         n = len(grants)
         arr = (PuschGrant * max(1, n))(*[PuschGrant(g["sf"], g["rnti"], g.get("n_dmrs", 0), g["n_prb"], g["L_prb"], g["mod"], g["tbs"], g.get("rv", 0),
-                                                    g.get("nof_ack", 0), g.get("cqi_bits", 0), g.get("ri_bits", 0))
+                                                    g.get("nof_ack", 0), g.get("cqi_bits", 0), g.get("ri_bits", 0), g.get("hop", 0), g.get("n_prb2", 0))
                                          for g in grants])
         res = (PuschResult * max(1, n))()
         cap = sum(g["tbs"] // 8 for g in grants) + 64

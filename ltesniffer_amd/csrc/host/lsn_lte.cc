@@ -157,7 +157,14 @@ bool dci_msg_unpack_pusch(const Cell& cell, const uint8_t* bits, uint32_t nof_bi
   if (nof_bits != dci_format_sizeof(cell, FORMAT0)) return false;
   BitReader br{bits};
   if (br.get(1) != 0) return false;
-  d.hopping = br.get(1); d.riv = br.get(riv_nbits(cell.nof_prb)); d.mcs_idx = br.get(5); d.ndi = br.get(1);
+  d.hopping = br.get(1);
+  if (d.hopping) {  // 36.213 8.4: the N_UL_hop most significant bits of the allocation field are the hopping bits (Tables 8.4-1, 8.4-2)
+    if (cell.nof_prb < 50) { d.hop_type = br.get(1) ? 3 : 2; d.riv = br.get(riv_nbits(cell.nof_prb) - 1); }
+    else { d.hop_type = (int)br.get(2); d.riv = br.get(riv_nbits(cell.nof_prb) - 2); }
+  } else {
+    d.riv = br.get(riv_nbits(cell.nof_prb));
+  }
+  d.mcs_idx = br.get(5); d.ndi = br.get(1);
   d.tpc = br.get(2); d.n_dmrs = br.get(3); d.cqi_req = br.get(1);
   return true;
 }
@@ -368,13 +375,31 @@ void dl_sniffer_ra_dl_dci_to_grant_both(const Cell& cell, uint32_t sf_idx, uint3
   dl_sniffer_grant_finish_both(cell, sf_idx, cfi, dci, g64, ok64, g256, ok256);
 }
 
+// ul_sniffer_ra_ul_grant_to_grant_prb_allocation (ul_sniffer_pusch.c:19-87) + the 64QAM MCS table
 bool ra_ul_dci_to_grant(const Cell& cell, const DciUl& d, PuschGrant& g)
 {
   g = PuschGrant();
   uint32_t L, start;
-  ra_type2_from_riv(d.riv, L, start, cell.nof_prb, cell.nof_prb);
-  if (L == 0 || start + L > cell.nof_prb) return false;
-  g.L_prb = L; g.n_prb = start; g.mcs_idx = d.mcs_idx;
+  const uint32_t nprb = cell.nof_prb;
+  ra_type2_from_riv(d.riv, L, start, nprb, nprb);
+  if (L == 0 || start + L > nprb) return false;
+  g.L_prb = L; g.n_prb = start; g.n_prb2 = start;
+  const int hop = d.hopping ? d.hop_type : -1;
+  if (hop == 3) {
+    g.hop = 2;  // type 2: same PRBs in the grant, hopped / mirrored at resource mapping (not decoded)
+  } else if (hop >= 0) {  // type 1 (36.213 8.4.1): fixed offset between the two slots
+    uint32_t n_rb_ho = cell.pusch_hop_offset;
+    if (n_rb_ho % 2) n_rb_ho++;
+    if (n_rb_ho + (nprb % 2) >= nprb) return false;
+    const uint32_t n_rb_pusch = nprb - n_rb_ho - (nprb % 2);
+    if (start < n_rb_ho / 2) return false;
+    if (hop == 0) g.n_prb2 = (n_rb_pusch / 4 + start) % n_rb_pusch;
+    else if (hop == 1) g.n_prb2 = start < n_rb_pusch / 4 ? n_rb_pusch + start - n_rb_pusch / 4 : start - n_rb_pusch / 4;
+    else g.n_prb2 = (n_rb_pusch / 2 + start) % n_rb_pusch;
+    g.hop = 1;
+    if (g.n_prb2 + L > nprb) return false;
+  }
+  g.mcs_idx = d.mcs_idx;
   g.mod = lsn_mcs_ul_64qam[d.mcs_idx & 31][0];
   const int i_tbs = lsn_mcs_ul_64qam[d.mcs_idx & 31][1];
   if (i_tbs >= 0) g.tbs = ra_tbs_from_idx(i_tbs, L); else g.rv = (int)d.mcs_idx - 28;
@@ -406,6 +431,7 @@ int rar_parse(const Cell& cell, const uint8_t* p, int len, RarEntry* out, int ca
     }
     DciUl d;
     d.rnti = r.t_crnti; d.hopping = (grant20 >> 19) & 1u; d.riv = (grant20 >> 9) & 0x3FFu; d.mcs_idx = (grant20 >> 5) & 0xFu;
+    d.hop_type = d.hopping ? 3 : -1;  // a hopping RAR grant (36.213 6.2) is not decoded
     r.hopping = d.hopping; r.riv = d.riv; r.mcs = d.mcs_idx; r.tpc = (grant20 >> 2) & 7u; r.ul_delay = (grant20 >> 1) & 1u; r.csi_req = grant20 & 1u;
     r.grant_ok = ra_ul_dci_to_grant(cell, d, r.grant);
     if (!r.grant_ok) r.grant = PuschGrant();

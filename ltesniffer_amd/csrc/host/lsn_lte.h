@@ -27,6 +27,7 @@ inline bool rnti_israr(uint16_t r) { return r >= RARNTI_START && r <= RARNTI_END
 
 struct Cell {
   uint32_t nof_prb = 0, nof_ports = 0, id = 0, phich_ng_x6 = 1;
+  uint32_t pusch_hop_offset = 0;  // SIB2 pusch-HoppingOffset = n_rb_ho of the uplink grant conversion (SubframeWorker.cc:271-273); 0 until known
   // optional acceleration table built by cell_build_re_tables(): PDSCH-capable REs per (subframe class, first PDSCH
   // symbol l0 0..4, slot, PRB); class 0: subframe 0, 1: subframe 5, 2: any other (srsran_ra_dl_compute_nof_re [srsRAN])
   std::shared_ptr<std::vector<uint16_t>> re_count;
@@ -43,7 +44,10 @@ struct DciDl {
   uint32_t riv = 0; bool distributed = false, ngap2 = false, nprb1a_is2 = false;
   uint32_t pid = 0; DciTb tb[2]; uint32_t tb_cw_swap = 0, pinfo = 0, tpc = 0;
 };
-struct DciUl { uint16_t rnti = 0; uint32_t L = 0, ncce = 0, hopping = 0, riv = 0, mcs_idx = 0, ndi = 0, tpc = 0, n_dmrs = 0, cqi_req = 0; };
+struct DciUl {
+  uint16_t rnti = 0; uint32_t L = 0, ncce = 0, hopping = 0, riv = 0, mcs_idx = 0, ndi = 0, tpc = 0, n_dmrs = 0, cqi_req = 0;
+  int hop_type = -1;  // -1 no hopping; 36.213 Table 8.4-2: 0 = +N/4, 1 = -N/4, 2 = +N/2 (type 1), 3 = type 2
+};
 struct GrantTb { uint32_t mcs_idx = 0; int rv = 0; uint32_t cw_idx = 0; bool enabled = false; int mod = 0; int tbs = 0; int nof_bits = 0; };
 struct PdschGrant {
   bool prb_idx[2][110]; uint32_t nof_prb = 0, nof_re = 0, nof_tb = 0; GrantTb tb[2]; TxScheme tx_scheme = TXSCHEME_PORT0;
@@ -51,7 +55,10 @@ struct PdschGrant {
   uint32_t prb_lo = 110, prb_hi = 0;  // allocated PRBs (either slot) lie in [prb_lo, prb_hi]; lo > hi: none
   PdschGrant() { std::memset(prb_idx, 0, sizeof(prb_idx)); }
 };
-struct PuschGrant { uint32_t L_prb = 0, n_prb = 0, mcs_idx = 0; int mod = 0, tbs = 0, rv = 0; };
+struct PuschGrant {
+  uint32_t L_prb = 0, n_prb = 0, mcs_idx = 0; int mod = 0, tbs = 0, rv = 0;
+  uint32_t n_prb2 = 0, hop = 0;  // first PRB of slot 1 when hop == 1 (type-1 hopping); hop == 2: type 2 (not decoded)
+};
 
 bool dci_msg_unpack_pdsch(const Cell& cell, const uint8_t* bits, uint32_t nof_bits, DciFormat f, uint16_t rnti, DciDl& out);
 bool dci_msg_unpack_pusch(const Cell& cell, const uint8_t* bits, uint32_t nof_bits, uint16_t rnti, DciUl& out);

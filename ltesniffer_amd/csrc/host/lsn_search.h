@@ -58,6 +58,7 @@ class FalconSearch {
 public:
   FalconSearch(uint32_t histogram_threshold, double split_ratio, bool skip_secondary);
   void setCell(const Cell& cell, const uint32_t nof_cce_per_cfi[3]);
+  void setPuschHopOffset(uint32_t n_rb_ho) { cell.pusch_hop_offset = n_rb_ho; }  // SIB2 pusch-HoppingOffset, once known
   // cand: [LSN_MAX_LOC][LSN_MAX_SIZES] of this subframe, ccepow: [LSN_CCE_STRIDE]; c.cfi / c.snr_db / c.sf_idx must be set
   void search(SubframeCtx& c, const LsnCand* cand, const float* ccepow, bool update_meta);
   RNTIManager& rntiManager() { return *rnti_manager; }

@@ -76,6 +76,8 @@ int Engine::setUlConfig(const lsn_ul_cfg_t& u)
       ul_npn[ns] = npn;
     }
     ul_cfg = u;
+    cell.pusch_hop_offset = u.hopping_offset;  // n_rb_ho of the DCI 0 -> grant conversion from now on (SubframeWorker.cc:271-277)
+    search->setPuschHopOffset(u.hopping_offset);
     ul_set = true;
     if (!runner_u.stream) allocRunner(runner_u);
     return LSN_SUCCESS;
@@ -140,7 +142,9 @@ void Engine::puschDecodeGrid(const cf32* d_grid, uint32_t nsf, uint32_t start_tt
   for (uint32_t i = 0; i < ngrants; i++) {
     const lsn_pusch_grant_t& g = grants[i];
     results[i] = lsn_pusch_result_t{};
-    const bool ok = g.sf < nsf && g.L_prb >= 3 && ul_valid_prb(g.L_prb) && g.n_prb + g.L_prb <= cell.nof_prb && g.tbs > 0 && (g.tbs % 8) == 0 &&
+    const uint32_t n_prb2 = g.hop == 1 ? g.n_prb_slot1 : g.n_prb;
+    const bool ok = g.sf < nsf && g.L_prb >= 3 && ul_valid_prb(g.L_prb) && g.n_prb + g.L_prb <= cell.nof_prb && n_prb2 + g.L_prb <= cell.nof_prb && g.hop <= 1 &&
+                    g.tbs > 0 && (g.tbs % 8) == 0 &&
                     (g.mod == 2 || g.mod == 4 || g.mod == 6 || g.mod == 8) && ul_off[g.L_prb] >= 0 && g.rv >= 0 && g.rv < 4;
     if (!ok) continue;
     const uint32_t M = 12 * g.L_prb, sf_idx = (start_tti + g.sf) % 10;
@@ -159,7 +163,7 @@ void Engine::puschDecodeGrid(const cf32* d_grid, uint32_t nsf, uint32_t start_tt
     if (q_ri + q_cqi >= 12 * M) continue;
     const int G = (int)((12 * M - q_ri - q_cqi) * g.mod);
     LsnUlGrantDev d{};
-    d.sf = g.sf; d.n_prb = g.n_prb; d.L_prb = g.L_prb; d.qm = g.mod;
+    d.sf = g.sf; d.n_prb = g.n_prb; d.n_prb2 = n_prb2; d.L_prb = g.L_prb; d.qm = g.mod;
     for (uint32_t sl = 0; sl < 2; sl++) d.ncs[sl] = (n_dmrs1[ul_cfg.cyclic_shift & 7] + n_dmrs2[g.n_dmrs & 7] + ul_npn[2 * sf_idx + sl]) % 12u;
     d.cinit = ((uint32_t)g.rnti << 14) | (sf_idx << 9) | cell.id;
     d.base_off = (uint32_t)ul_off[g.L_prb]; d.idft_off = d.base_off;

@@ -79,7 +79,7 @@ void Engine::commitChunkUl(Chunk& ch, JobRunner& r)
       std::vector<UlSchedGrant>& cur = ul_sched[tti];
       for (auto& u : c.ul) {
         UlSchedGrant g;
-        g.rnti = u.rnti; g.n_dmrs = u.dci.n_dmrs; g.hopping = u.dci.hopping != 0;
+        g.rnti = u.rnti; g.n_dmrs = u.dci.n_dmrs; g.hopping = false;  // DCI 0 hopping lives in the grants (hop = 1 decoded, 2 not)
         g.cqi_req = u.dci.cqi_req != 0;
         for (auto& e : c.dl)  // "check nof_ack for uplink pusch decoder", SubframeWorker.cc:318-336
           if (e.rnti == u.rnti) {
@@ -140,9 +140,10 @@ void Engine::commitChunkUl(Chunk& ch, JobRunner& r)
       const UlSchedGrant& m = lists[a.sf][a.idx];
       const PuschGrant& g = a.use256 ? m.g256 : m.g;
       results[a];  // default: failed
-      if (m.hopping || g.tbs <= 0) continue;  // frequency hopping is outside the round-1 scope: the attempt fails
+      if (m.hopping || g.hop == 2 || g.tbs <= 0) continue;  // type-2 hopping and hopping RAR grants are not decoded: the attempt fails
       lsn_pusch_grant_t q{};
       q.sf = a.sf; q.rnti = m.rnti; q.n_dmrs = (uint16_t)m.n_dmrs; q.n_prb = g.n_prb; q.L_prb = g.L_prb; q.mod = (uint32_t)a.qm; q.tbs = (uint32_t)g.tbs; q.rv = g.rv;
+      q.hop = g.hop; q.n_prb_slot1 = g.n_prb2;
       // uci_cfg of the attempt, UL_Sniffer_PUSCH.cc:429-450: HARQ-ACK bits, aperiodic higher-layer sub-band CQI (4 + 2 N bits) + one RI bit on request
       q.nof_ack = m.nof_ack;
       if (m.cqi_req) {

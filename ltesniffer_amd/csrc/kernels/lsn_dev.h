@@ -85,6 +85,7 @@ struct LsnCbDev {
 struct LsnUlGrantDev {
   uint32_t sf;          // subframe index inside the batch
   uint32_t n_prb, L_prb, qm;
+  uint32_t n_prb2;      // first PRB in slot 1 (== n_prb unless the grant hops, 36.213 8.4.1)
   uint32_t ncs[2];      // DMRS cyclic shift n_cs of the two slots
   uint32_t cinit;       // scrambling: rnti << 14 | sf_idx << 9 | cell id
   uint32_t base_off, idft_off;  // offsets of this allocation size into ul_base / ul_idft

@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void k_pusch_chest(LsnCellDev c, const LsnUlGr
   const cf32* base = c.ul_base + g.base_off;
   for (int i = tid; i < 2 * M; i += 256) {
     const int s = i >= M ? 1 : 0, n = i - s * M;
-    const cf32 y = grid[((size_t)g.sf * 14 + 3 + 7 * s) * nre + 12 * g.n_prb + n];
+    const cf32 y = grid[((size_t)g.sf * 14 + 3 + 7 * s) * nre + 12 * (s ? g.n_prb2 : g.n_prb) + n];
     const cf32 r = cmul(base[n], c.ul_ph12[(g.ncs[s] * (uint32_t)n) % 12u]);
     ls[i] = cmulconj(y, r);
   }
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256) void k_pusch_demod(LsnCellDev c, const LsnUlGr
   const int M = 12 * (int)g.L_prb, nre = (int)c.nre, Qm = (int)g.qm, tid = threadIdx.x;
   cf32* x = (cf32*)smem;   // [M]
   cf32* w = x + M;         // [M] exp(+2 pi j k / M)
-  const cf32* y = grid + ((size_t)g.sf * 14 + l) * nre + 12 * g.n_prb;
+  const cf32* y = grid + ((size_t)g.sf * 14 + l) * nre + 12 * (l >= 7 ? g.n_prb2 : g.n_prb);
   const cf32* h = hs_all + g.hs_off + (l / 7) * M;
   const cf32* wt = c.ul_idft + g.idft_off;
   const float noise = stat[2 * blockIdx.y];

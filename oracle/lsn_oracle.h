@@ -66,6 +66,7 @@ typedef struct {
   uint32_t nof_ports; /* 1 or 2 CRS ports */
   uint32_t id;        /* physical cell id 0..503 */
   uint32_t phich_ng_x6; /* Ng*6: 1 (=1/6), 3, 6, 12 ; LTESniffer_Core.cc:211-212 forces 1/6 */
+  uint32_t pusch_hop_offset; /* SIB2 pusch-HoppingOffset = n_rb_ho of the uplink grant conversion (SubframeWorker.cc:271-273); 0 until SIB2 is known */
 } o_cell_t;
 
 /* ---------- bit-level primitives (o_bits.c) ---------- */
@@ -140,13 +141,15 @@ typedef struct {
 typedef struct {
   uint16_t rnti; uint32_t L, ncce;
   uint32_t freq_hop_fl; uint32_t riv; uint32_t mcs_idx; int rv; uint32_t ndi; uint32_t tpc; uint32_t n_dmrs; uint32_t cqi_req;
+  int hop_type; /* -1 no hopping; 36.213 Table 8.4-2: 0 = +N/4, 1 = -N/4, 2 = +N/2 (type 1), 3 = type 2 */
 } o_dci_ul_t;
 typedef struct { uint32_t mcs_idx; int rv; uint32_t cw_idx; int enabled; int mod; int tbs; int nof_bits; } o_tb_t;
 typedef struct {
   uint8_t prb_idx[2][O_MAX_PRB]; uint32_t nof_prb; uint32_t nof_re; uint32_t nof_tb;
   o_tb_t tb[2]; int tx_scheme; uint32_t pmi; uint32_t nof_layers;
 } o_pdsch_grant_t;
-typedef struct { uint32_t L_prb, n_prb; uint32_t mcs_idx; int mod; int tbs; int rv; } o_pusch_grant_t;
+typedef struct { uint32_t L_prb, n_prb; uint32_t mcs_idx; int mod; int tbs; int rv;
+                 uint32_t n_prb2; /* first PRB in slot 1 when hop == 1 */ uint32_t hop; /* 0 none, 1 type-1 hopping, 2 type-2 (not decoded) */ } o_pusch_grant_t;
 
 int o_dci_unpack_dl(const o_cell_t* cell, const uint8_t* payload, uint32_t nof_bits, int format, uint16_t rnti, o_dci_dl_t* dci);
 int o_dci_unpack_ul(const o_cell_t* cell, const uint8_t* payload, uint32_t nof_bits, uint16_t rnti, o_dci_ul_t* dci);
@@ -218,7 +221,8 @@ void o_prach_root_spectrum(uint32_t u, ocf_t* D);
 int o_prach_detect(const o_cell_t* cell, const o_prach_cfg_t* cfg, const ocf_t* samples, o_prach_det_t* out, int cap, float* corr_out);
 
 /* ---------- uplink: SC-FDMA demodulation + PUSCH (o_pusch.c) ---------- */
-typedef struct { uint32_t cyclic_shift; /* SIB2 cyclicShift 0..7 */ uint32_t delta_ss; /* SIB2 groupAssignmentPUSCH 0..29 */ } o_ul_cfg_t;
+typedef struct { uint32_t cyclic_shift; /* SIB2 cyclicShift 0..7 */ uint32_t delta_ss; /* SIB2 groupAssignmentPUSCH 0..29 */
+                 uint32_t hopping_offset; /* SIB2 pusch-HoppingOffset */ } o_ul_cfg_t;
 typedef struct { uint32_t nof_ack; uint32_t cqi_bits; uint32_t ri_bits; } o_uci_t; /* HARQ-ACK bits 0..2, CQI report size (0 = none), RI bits */
 int o_uci_cqi_bits(uint32_t nof_prb);
 int o_uci_layout(int M, int tbs, const o_uci_t* uci, uint8_t* cls, int* didx, int* q_ack, int* q_ri, int* q_cqi);

@@ -229,7 +229,18 @@ int o_dci_unpack_ul(const o_cell_t* cell, const uint8_t* payload, uint32_t nof_b
   if (nof_bits != f0_size(cell->nof_prb)) return -1;
   if (take(&y, 1) != 0) return -1;
   d->freq_hop_fl = take(&y, 1);
-  d->riv = take(&y, riv_nbits(cell->nof_prb));
+  d->hop_type = -1;
+  if (d->freq_hop_fl) { /* 36.213 8.4: the N_UL_hop most significant bits of the allocation field are the hopping bits (Table 8.4-1 / 8.4-2) */
+    if (cell->nof_prb < 50) {
+      d->hop_type = take(&y, 1) ? 3 : 2;
+      d->riv = take(&y, riv_nbits(cell->nof_prb) - 1);
+    } else {
+      d->hop_type = (int)take(&y, 2);
+      d->riv = take(&y, riv_nbits(cell->nof_prb) - 2);
+    }
+  } else {
+    d->riv = take(&y, riv_nbits(cell->nof_prb));
+  }
   d->mcs_idx = take(&y, 5);
   d->ndi = take(&y, 1);
   d->tpc = take(&y, 2);
@@ -461,14 +472,31 @@ int o_ra_dl_dci_to_grant(const o_cell_t* cell, uint32_t sf_idx, uint32_t cfi, in
   return 0;
 }
 
+/* ul_sniffer_ra_ul_grant_to_grant_prb_allocation (ul_sniffer_pusch.c:19-87) + the 64QAM MCS table */
 int o_ra_ul_dci_to_grant(const o_cell_t* cell, const o_dci_ul_t* d, o_pusch_grant_t* g)
 {
   memset(g, 0, sizeof(*g));
-  uint32_t L, start;
-  type2_from_riv(d->riv, &L, &start, cell->nof_prb, cell->nof_prb);
-  if (L == 0 || start + L > cell->nof_prb) return -1;
+  uint32_t L, start, nprb = cell->nof_prb;
+  type2_from_riv(d->riv, &L, &start, nprb, nprb);
+  if (L == 0 || start + L > nprb) return -1;
   g->L_prb = L;
   g->n_prb = start;
+  g->n_prb2 = start;
+  const int hop = d->freq_hop_fl ? d->hop_type : -1;
+  if (hop == 3) {
+    g->hop = 2; /* type 2: same PRBs in the grant, mirrored / hopped during resource mapping (not decoded here) */
+  } else if (hop >= 0) { /* type 1, 36.213 8.4.1: fixed offset between the slots */
+    uint32_t n_rb_ho = cell->pusch_hop_offset;
+    if (n_rb_ho % 2) n_rb_ho++;
+    if (n_rb_ho + (nprb % 2) >= nprb) return -1;
+    const uint32_t n_rb_pusch = nprb - n_rb_ho - (nprb % 2);
+    if (start < n_rb_ho / 2) return -1;
+    if (hop == 0) g->n_prb2 = (n_rb_pusch / 4 + start) % n_rb_pusch;
+    else if (hop == 1) g->n_prb2 = start < n_rb_pusch / 4 ? n_rb_pusch + start - n_rb_pusch / 4 : start - n_rb_pusch / 4;
+    else g->n_prb2 = (n_rb_pusch / 2 + start) % n_rb_pusch;
+    g->hop = 1;
+    if (g->n_prb2 + L > nprb) return -1;
+  }
   g->mcs_idx = d->mcs_idx;
   int itbs = lsn_mcs_ul_64qam[d->mcs_idx & 31][1];
   g->mod = lsn_mcs_ul_64qam[d->mcs_idx & 31][0];

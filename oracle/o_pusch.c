@@ -206,8 +206,9 @@ int o_pusch_demod_uci(const o_cell_t* cell, const o_ul_cfg_t* ul, uint32_t sf_id
                       const o_uci_t* uci, const ocf_t* grid, int16_t* e, float* noise_out, float* sigpow_out)
 {
   int L = (int)g->L_prb, M = 12 * L, nre = 12 * (int)cell->nof_prb, Qm = g->mod;
-  if (L < 3 || !o_ul_valid_prb(g->L_prb) || g->n_prb + g->L_prb > cell->nof_prb || Qm <= 0) return -1;
-  int k0 = 12 * (int)g->n_prb;
+  if (L < 3 || !o_ul_valid_prb(g->L_prb) || g->n_prb + g->L_prb > cell->nof_prb || Qm <= 0 || g->hop > 1) return -1;
+  if (g->hop == 1 && g->n_prb2 + g->L_prb > cell->nof_prb) return -1;
+  const int k0s[2] = {12 * (int)g->n_prb, 12 * (int)(g->hop == 1 ? g->n_prb2 : g->n_prb)}; /* first carrier per slot (type-1 hopping: two places) */
   ocf_t* base = (ocf_t*)malloc(sizeof(ocf_t) * (size_t)M);
   ocf_t* ls = (ocf_t*)malloc(sizeof(ocf_t) * (size_t)(2 * M));
   ocf_t* hs = (ocf_t*)malloc(sizeof(ocf_t) * (size_t)(2 * M));
@@ -231,7 +232,7 @@ int o_pusch_demod_uci(const o_cell_t* cell, const o_ul_cfg_t* ul, uint32_t sf_id
   }
   for (int s = 0; s < 2; s++) {
     uint32_t ncs = o_dmrs_ncs(cell, ul, 2 * sf_idx + (uint32_t)s, n_dmrs_dci);
-    const ocf_t* y = grid + (size_t)(3 + 7 * s) * (size_t)nre + (size_t)k0;
+    const ocf_t* y = grid + (size_t)(3 + 7 * s) * (size_t)nre + (size_t)k0s[s];
     for (int n = 0; n < M; n++) {
       ocf_t r = cmul(base[n], ph12[(ncs * (uint32_t)n) % 12u]);
       ls[s * M + n] = cmulconj(y[n], r);
@@ -254,7 +255,7 @@ int o_pusch_demod_uci(const o_cell_t* cell, const o_ul_cfg_t* ul, uint32_t sf_id
   int col = 0;
   for (int l = 0; l < 14; l++) {
     if (l == 3 || l == 10) continue;
-    const ocf_t* y = grid + (size_t)l * (size_t)nre + (size_t)k0;
+    const ocf_t* y = grid + (size_t)l * (size_t)nre + (size_t)k0s[l / 7];
     const ocf_t* h = hs + (l / 7) * M;
     for (int n = 0; n < M; n++) {
       ocf_t t = cmulconj(y[n], h[n]);

@@ -537,6 +537,7 @@ int o_rar_parse(const o_cell_t* cell, const uint8_t* p, int len, o_rar_t* out, i
     memset(&d, 0, sizeof(d));
     d.rnti = r->t_crnti;
     d.freq_hop_fl = (grant20 >> 19) & 1u;
+    d.hop_type = d.freq_hop_fl ? 3 : -1; /* a hopping RAR grant (36.213 6.2) is not decoded by this restatement */
     d.riv = (grant20 >> 9) & 0x3FFu;
     d.mcs_idx = (grant20 >> 5) & 0xFu;
     r->hopping = d.freq_hop_fl; r->riv = d.riv; r->mcs = d.mcs_idx; r->tpc = (grant20 >> 2) & 7u; r->ul_delay = (grant20 >> 1) & 1u; r->csi_req = grant20 & 1u;
@@ -687,6 +688,7 @@ void o_worker_set_ul_mode(o_worker_t* w, const o_ul_cfg_t* ul)
 {
   w->ul_mode = 1;
   w->ulcfg = *ul;
+  w->cfg.cell.pusch_hop_offset = ul->hopping_offset; /* ul_cfg.hopping.n_rb_ho, SubframeWorker.cc:271-273 */
   if (!w->ul_grid) {
     w->ul_grid = (ocf_t*)calloc(14u * 12u * w->cfg.cell.nof_prb, sizeof(ocf_t));
     w->ul_sched = (ulslot_t*)calloc(16, sizeof(ulslot_t));
@@ -755,7 +757,7 @@ static void decode_ul_mode_dl(o_worker_t* w, ulslot_t* rar_out)
 /* one srsran_chest_ul_estimate_pusch + srsran_pusch_decode attempt (PUSCH_Decoder::decode_run, UL_Sniffer_PUSCH.cc:250-310) */
 static int pusch_attempt(o_worker_t* w, const ulg_t* m, const o_pusch_grant_t* g, int qm, uint32_t tti)
 {
-  if (m->hopping || g->tbs <= 0) return 0; /* frequency hopping is outside this restatement: the attempt fails */
+  if (m->hopping || g->hop == 2 || g->tbs <= 0) return 0; /* type-2 hopping and hopping RAR grants are outside this restatement: the attempt fails */
   o_pusch_grant_t gg = *g;
   gg.mod = qm;
   int its = 0;
@@ -857,7 +859,7 @@ int o_worker_work_ul(o_worker_t* w, const ocf_t* dl_iq, const ocf_t* ul_iq, uint
       ulg_t* g = &cur->g[cur->n++];
       memset(g, 0, sizeof(*g));
       g->rnti = w->ul[i].rnti; g->g = w->ul[i].g; g->g256 = w->ul[i].g256;
-      g->n_dmrs = w->ul[i].dci.n_dmrs; g->hopping = w->ul[i].dci.freq_hop_fl;
+      g->n_dmrs = w->ul[i].dci.n_dmrs; g->hopping = 0; /* DCI 0 hopping lives in the grants (hop = 1 decoded, 2 not) */
       g->cqi_req = w->ul[i].dci.cqi_req;
       for (uint32_t di = 0; di < w->ndl; di++) /* "check nof_ack for uplink pusch decoder", SubframeWorker.cc:318-336 */
         if (w->dl[di].rnti == g->rnti) {

@@ -21,7 +21,7 @@ def _ensure(path, mkdir):
 
 
 class OCell(C.Structure):
-    _fields_ = [("nof_prb", C.c_uint32), ("nof_ports", C.c_uint32), ("id", C.c_uint32), ("phich_ng_x6", C.c_uint32)]
+    _fields_ = [("nof_prb", C.c_uint32), ("nof_ports", C.c_uint32), ("id", C.c_uint32), ("phich_ng_x6", C.c_uint32), ("pusch_hop_offset", C.c_uint32)]
 
 
 class OWorkerCfg(C.Structure):
@@ -48,13 +48,13 @@ class TxgCfg(C.Structure):
                 ("ul_min", C.c_uint32), ("ul_max", C.c_uint32), ("cfi", C.c_uint32), ("mix_tm3_pct", C.c_uint32),
                 ("mix_tm4_pct", C.c_uint32), ("pct_256qam", C.c_uint32), ("mcs_min", C.c_uint32), ("mcs_max", C.c_uint32),
                 ("sib_period", C.c_uint32), ("rar_period", C.c_uint32), ("paging_period", C.c_uint32),
-                ("start_tti", C.c_uint32), ("fixed_L", C.c_uint32), ("pct_rv", C.c_uint32), ("pct_cqi_req", C.c_uint32)]
+                ("start_tti", C.c_uint32), ("fixed_L", C.c_uint32), ("pct_rv", C.c_uint32), ("pct_cqi_req", C.c_uint32), ("pct_hop", C.c_uint32), ("pusch_hop_offset", C.c_uint32)]
 
 
 class TxgPdu(C.Structure):
     _fields_ = [("rnti", C.c_uint16), ("format", C.c_uint8), ("L", C.c_uint8), ("ncce", C.c_uint16), ("tti", C.c_uint32),
                 ("nbytes", C.c_uint32), ("offset", C.c_uint32), ("tb", C.c_uint8), ("mod", C.c_uint8),
-                ("table256", C.c_uint8), ("is_ul", C.c_uint8), ("nof_prb", C.c_uint32), ("mcs", C.c_uint32), ("cqi_req", C.c_uint32)]
+                ("table256", C.c_uint8), ("is_ul", C.c_uint8), ("nof_prb", C.c_uint32), ("mcs", C.c_uint32), ("cqi_req", C.c_uint32), ("hop_bits_plus1", C.c_uint32)]
 
 
 _oracle = None
@@ -147,7 +147,7 @@ def txgen():
 def scenario(name, seed=1, **over):
     base = dict(nof_prb=100, nof_ports=2, cell_id=1, phich_ng_x6=1, nof_rx=2, snr_db=30.0, cfo_hz=0.0, delay_samples=0,
                 seed=seed, n_rnti=32, dl_min=6, dl_max=6, ul_min=2, ul_max=2, cfi=3, mix_tm3_pct=0, mix_tm4_pct=0,
-                pct_256qam=0, mcs_min=0, mcs_max=28, sib_period=1, rar_period=0, paging_period=0, start_tti=0, fixed_L=0, pct_rv=0, pct_cqi_req=0)
+                pct_256qam=0, mcs_min=0, mcs_max=28, sib_period=1, rar_period=0, paging_period=0, start_tti=0, fixed_L=0, pct_rv=0, pct_cqi_req=0, pct_hop=0, pusch_hop_offset=0)
     presets = {
         # config 1: 10 MHz, single RNTI, TM1 QPSK, 1 port / 1 rx
         "cfg1": dict(nof_prb=50, nof_ports=1, nof_rx=1, snr_db=20.0, cfo_hz=300.0, n_rnti=1, dl_min=1, dl_max=1, ul_min=0,
@@ -186,7 +186,7 @@ class TxGen:
         for i in range(n):
             p = self._pdus[i]
             out.append(dict(rnti=p.rnti, format=p.format, L=p.L, ncce=p.ncce, tti=p.tti, tb=p.tb, mod=p.mod,
-                            table256=p.table256, is_ul=p.is_ul, nof_prb=p.nof_prb, mcs=p.mcs, cqi_req=p.cqi_req,
+                            table256=p.table256, is_ul=p.is_ul, nof_prb=p.nof_prb, mcs=p.mcs, cqi_req=p.cqi_req, hop_bits_plus1=p.hop_bits_plus1,
                             n_prb=p.offset if p.is_ul else 0,
                             payload=bytes(self._pbuf[p.offset:p.offset + p.nbytes]) if not p.is_ul else b""))
         return tti, iq, out
@@ -382,7 +382,22 @@ class TxgUlCell(C.Structure):
 class TxgUlGrant(C.Structure):
     _fields_ = [("rnti", C.c_uint16), ("n_dmrs", C.c_uint16), ("n_prb", C.c_uint32), ("L_prb", C.c_uint32), ("mod", C.c_uint32),
                 ("tbs", C.c_uint32), ("rv", C.c_uint32), ("gain_db", C.c_float), ("phase_rad", C.c_float), ("ta_samples", C.c_float),
-                ("nof_ack", C.c_uint32), ("cqi_bits", C.c_uint32), ("ri_bits", C.c_uint32)]
+                ("nof_ack", C.c_uint32), ("cqi_bits", C.c_uint32), ("ri_bits", C.c_uint32), ("hop", C.c_uint32), ("n_prb2", C.c_uint32)]
+
+
+def pusch_hop_slot1(nof_prb, hop_offset, hop_bits, n_prb):
+    """36.213 8.4.1 / Table 8.4-2, type-1 PUSCH hopping: first PRB of slot 1 (written from the specification, independent of oracle and product);
+    None for type 2"""
+    ho = hop_offset + (hop_offset % 2)
+    n = nof_prb - ho - (nof_prb % 2)
+    kind = {0: "half", 1: None}[hop_bits] if nof_prb < 50 else {0: "quart", 1: "quart_neg", 2: "half", 3: None}[hop_bits]
+    if kind is None:
+        return None
+    if kind == "quart":
+        return (n // 4 + n_prb) % n
+    if kind == "half":
+        return (n // 2 + n_prb) % n
+    return n_prb - n // 4 if n_prb >= n // 4 else n + n_prb - n // 4
 
 
 class OUci(C.Structure):
@@ -390,11 +405,12 @@ class OUci(C.Structure):
 
 
 class OUlCfg(C.Structure):
-    _fields_ = [("cyclic_shift", C.c_uint32), ("delta_ss", C.c_uint32)]
+    _fields_ = [("cyclic_shift", C.c_uint32), ("delta_ss", C.c_uint32), ("hopping_offset", C.c_uint32)]
 
 
-class OPuschGrant(C.Structure):  # o_pusch_grant_t
-    _fields_ = [("L_prb", C.c_uint32), ("n_prb", C.c_uint32), ("mcs_idx", C.c_uint32), ("mod", C.c_int), ("tbs", C.c_int), ("rv", C.c_int)]
+class OPuschGrant(C.Structure):  # o_pusch_grant_t (n_prb2 / hop: type-1 frequency hopping, slot 1 on other PRBs)
+    _fields_ = [("L_prb", C.c_uint32), ("n_prb", C.c_uint32), ("mcs_idx", C.c_uint32), ("mod", C.c_int), ("tbs", C.c_int), ("rv", C.c_int),
+                ("n_prb2", C.c_uint32), ("hop", C.c_uint32)]
 
 
 VALID_UL_PRB = [n for n in range(1, 101) if (lambda m: all(m % p for p in (7, 11, 13)) and max([q for q in range(2, m + 1) if m % q == 0 and all(q % d for d in range(2, q))] or [1]) <= 5)(n)]
@@ -420,7 +436,8 @@ def ul_make_subframe(cell, tti, grants, snr_db=30.0, seed=1):
     iq = np.zeros(15 * N, dtype=np.complex64)
     arr = (TxgUlGrant * max(1, len(grants)))(*[TxgUlGrant(g["rnti"], g.get("n_dmrs", 0), g["n_prb"], g["L_prb"], g["mod"], g["tbs"], g.get("rv", 0),
                                                            g.get("gain_db", 0.0), g.get("phase_rad", 0.0), g.get("ta_samples", 0.0),
-                                                           g.get("nof_ack", 0), g.get("cqi_bits", 0), g.get("ri_bits", 0)) for g in grants])
+                                                           g.get("nof_ack", 0), g.get("cqi_bits", 0), g.get("ri_bits", 0), g.get("hop", 0), g.get("n_prb2", 0))
+                                               for g in grants])
     pbuf = np.zeros(sum(g["tbs"] // 8 for g in grants) + 16, dtype=np.uint8)
     offs = (C.c_uint32 * max(1, len(grants)))()
     n = lib.txg_ul_make(C.byref(cell), tti, arr, len(grants), snr_db, seed, iq.ctypes.data, pbuf.ctypes.data, offs)
@@ -448,11 +465,11 @@ def oracle_ul_api():
 class OracleWorkerUl(OracleWorker):
     """UL_MODE worker: one downlink antenna + the uplink antenna (SubframeWorker.cc:184-199)"""
 
-    def __init__(self, nof_prb, nof_ports, cell_id, cyclic_shift, delta_ss, **kw):
+    def __init__(self, nof_prb, nof_ports, cell_id, cyclic_shift, delta_ss, hopping_offset=0, **kw):
         super().__init__(nof_prb, nof_ports, cell_id, 1, **kw)
         self.lib.o_worker_set_ul_mode.argtypes = [C.c_void_p, C.POINTER(OUlCfg)]
         self.lib.o_worker_work_ul.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]
-        self._ul = OUlCfg(cyclic_shift, delta_ss)
+        self._ul = OUlCfg(cyclic_shift, delta_ss, hopping_offset)
         self.lib.o_worker_set_ul_mode(self.h, C.byref(self._ul))
 
     def work_ul(self, dl_iq, ul_iq, tti, update_meta=0):
@@ -461,7 +478,7 @@ class OracleWorkerUl(OracleWorker):
         return self.lib.o_worker_work_ul(self.h, dl_iq.ctypes.data, ul_iq.ctypes.data, tti % 10, (tti // 10) % 1024, int(update_meta))
 
 
-def gen_ul_mode_subframes(sc, n, cyclic_shift=3, delta_ss=5, ul_snr_db=30.0):
+def gen_ul_mode_subframes(sc, n, cyclic_shift=3, delta_ss=5, ul_snr_db=30.0):  # sc['pusch_hop_offset'] = SIB2 pusch-HoppingOffset of the cell
     """DL stream from the synthetic eNB (one rx antenna) + the matching UL stream: every DCI 0 of subframe t is answered by a
     PUSCH in subframe t + 4 (UEs with an even RNTI are 64QAM-capable in the uplink).
     -> (tti0, iq[n, 2, sf_len] (antenna 0 = DL, 1 = UL), list of sent UL payload dicts)"""
@@ -479,7 +496,7 @@ def gen_ul_mode_subframes(sc, n, cyclic_shift=3, delta_ss=5, ul_snr_db=30.0):
         ul, pl = ul_make_subframe(ucell, tti, grants, snr_db=ul_snr_db, seed=sc["seed"] * 1000 + i)
         iq[i, 1] = ul
         for g, p in zip(grants, pl):
-            sent.append(dict(tti=tti, rnti=g["rnti"], payload=p, L_prb=g["L_prb"], mod=g["mod"]))
+            sent.append(dict(tti=tti, rnti=g["rnti"], payload=p, L_prb=g["L_prb"], mod=g["mod"], hop=g.get("hop", 0)))
         for p in pdus:
             if p["is_ul"] and p["nof_prb"] >= 3:
                 qm, tbs = ul_mcs_to_mod_tbs(p["mcs"], p["nof_prb"], enable_64qam=(p["rnti"] % 2 == 0))
@@ -488,8 +505,12 @@ def gen_ul_mode_subframes(sc, n, cyclic_shift=3, delta_ss=5, ul_snr_db=30.0):
                     # aperiodic CSI report (higher-layer sub-band CQI + RI) when the DCI 0 asks for one (36.212 5.2.2.6)
                     ntb = len([q for q in pdus if not q["is_ul"] and q["rnti"] == p["rnti"]])
                     cqi = oracle().o_uci_cqi_bits(sc["nof_prb"]) if p["cqi_req"] else 0
+                    hop, n2 = 0, 0
+                    if p["hop_bits_plus1"]:
+                        n2 = pusch_hop_slot1(sc["nof_prb"], sc["pusch_hop_offset"], p["hop_bits_plus1"] - 1, p["n_prb"])
+                        hop = 1
                     pending.setdefault((tti + 4) % 10240, []).append(dict(rnti=p["rnti"], n_dmrs=0, n_prb=p["n_prb"], L_prb=p["nof_prb"], mod=qm, tbs=tbs, rv=0,
-                                                                          nof_ack=min(ntb, 2), cqi_bits=cqi, ri_bits=1 if cqi else 0))
+                                                                          nof_ack=min(ntb, 2), cqi_bits=cqi, ri_bits=1 if cqi else 0, hop=hop, n_prb2=n2 or 0))
     return tti0, iq, sent
 
 

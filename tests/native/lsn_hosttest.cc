@@ -77,6 +77,16 @@ int lsnh_dl_grant(uint32_t nof_prb, uint32_t nof_ports, uint32_t cell_id, uint32
   return r;
 }
 
+int lsnh_ul_grant_hop(uint32_t nof_prb, uint32_t nof_ports, uint32_t hop_offset, const uint8_t* payload, uint32_t nof_bits, uint16_t rnti, uint32_t* out8)
+{
+  Cell c; c.nof_prb = nof_prb; c.nof_ports = nof_ports; c.pusch_hop_offset = hop_offset;
+  DciUl d;
+  if (!dci_msg_unpack_pusch(c, payload, nof_bits, rnti, d)) return 0;
+  PuschGrant g;
+  if (!ra_ul_dci_to_grant(c, d, g)) return 1;
+  out8[0] = g.L_prb; out8[1] = g.n_prb; out8[2] = g.mcs_idx; out8[3] = (uint32_t)g.mod; out8[4] = (uint32_t)g.tbs; out8[5] = (uint32_t)g.rv; out8[6] = g.n_prb2; out8[7] = g.hop;
+  return 3;
+}
 int lsnh_ul_grant(uint32_t nof_prb, uint32_t nof_ports, const uint8_t* payload, uint32_t nof_bits, uint16_t rnti, uint32_t* out6)
 {
   Cell c; c.nof_prb = nof_prb; c.nof_ports = nof_ports;

@@ -57,7 +57,7 @@ def _run(nprb, cell_id, nsf, seed, **kw):
         assert np.array_equal(phy.tap_ul_grid(sf).reshape(-1).view(np.uint32), g.view(np.uint32)), sf
     n_ok = 0
     for i, (g, pl, r) in enumerate(zip(grants, payloads, res)):
-        og = OPuschGrant(g["L_prb"], g["n_prb"], 0, g["mod"], g["tbs"], g["rv"])
+        og = OPuschGrant(g["L_prb"], g["n_prb"], 0, g["mod"], g["tbs"], g["rv"], g.get("n_prb2", 0), g.get("hop", 0))
         uci = OUci(g.get("nof_ack", 0), g.get("cqi_bits", 0), g.get("ri_bits", 0))
         M = 12 * g["L_prb"]
         cls_buf, idx_buf = np.zeros(12 * M, np.uint8), np.zeros(12 * M, np.int32)
@@ -104,6 +104,41 @@ def test_pusch_with_uci_multiplexing():
         assert n >= 8 and n_ok >= n - 1, (nprb, n_ok, n)
 
 
+def test_pusch_type1_frequency_hopping():
+    """slot 1 on other PRBs (36.213 8.4.1): k_pusch_chest / k_pusch_demod read each slot at its own offset"""
+    from lsn_testlib import pusch_hop_slot1
+    o = oracle_ul_api()
+    nprb, cell_id, off = 100, 5, 10
+    ocell, ucell, ucfg = OCell(nprb, 1, cell_id, 1, off), TxgUlCell(nprb, cell_id, 3, 5), OUlCfg(3, 5, off)
+    rng = np.random.default_rng(3)
+    grants, tti0 = [], 4321
+    iq = np.zeros((3, 15 * 2048), dtype=np.complex64)
+    payloads = []
+    for sf in range(3):
+        hop_bits = [0, 1, 2][sf]
+        n_prb = [6, 40, 9][sf]
+        L = [5, 4, 12][sf]
+        qm, tbs = ul_mcs_to_mod_tbs(int(rng.integers(4, 20)), L)
+        g = dict(sf=sf, rnti=int(rng.integers(100, 60000)), n_dmrs=int(rng.integers(0, 8)), n_prb=n_prb, L_prb=L, mod=qm, tbs=tbs, rv=0, hop=1,
+                 n_prb2=pusch_hop_slot1(nprb, off, hop_bits, n_prb), nof_ack=sf % 3)
+        iq[sf], pl = ul_make_subframe(ucell, tti0 + sf, [g], snr_db=30.0, seed=sf)
+        grants.append(g); payloads += pl
+    phy = la.Phy(nof_rx_antennas=1)
+    assert phy.setCell(nprb, 1, cell_id) and phy.setUlConfig(3, 5, off)
+    res = phy.pusch_decode(iq, tti0, grants)
+    for i, (g, pl, r) in enumerate(zip(grants, payloads, res)):
+        grid = np.zeros(14 * 12 * nprb, dtype=np.complex64)
+        o.o_ul_fft(C.byref(ocell), iq[g["sf"]].ctypes.data, grid.ctypes.data)
+        og = OPuschGrant(g["L_prb"], g["n_prb"], 0, g["mod"], g["tbs"], 0, g["n_prb2"], 1)
+        uci = OUci(g["nof_ack"], 0, 0)
+        e = np.zeros(144 * g["L_prb"] * g["mod"], dtype=np.int16)
+        assert o.o_pusch_demod_uci(C.byref(ocell), C.byref(ucfg), (tti0 + g["sf"]) % 10, g["rnti"], C.byref(og), g["n_dmrs"], C.byref(uci), grid.ctypes.data,
+                                   e.ctypes.data, None, None) == 0
+        assert np.array_equal(phy.tap_ul_llr(i, e.size), e), i
+        assert r["crc_ok"] == 1 and r["payload"] == pl, (i, g)
+    phy.close()
+
+
 def test_pusch_unsupported_grants_fail_cleanly():
     phy = la.Phy(nof_rx_antennas=1)
     assert phy.setCell(25, 1, 3)
@@ -119,17 +154,17 @@ def test_pusch_unsupported_grants_fail_cleanly():
     phy.close()
 
 
-def _run_ul_mode(nsf, seed, batch, **over):
+def _run_ul_mode(nsf, seed, batch, hopping_offset=0, **over):
     from lsn_testlib import OracleWorkerUl, gen_ul_mode_subframes, parse_pcap, scenario
     from parity import gpu_records, oracle_records
     sc = scenario("cfg2", seed=seed, nof_rx=1, n_rnti=12, dl_min=2, dl_max=3, ul_min=2, ul_max=4, **over)
     tti0, iq, sent = gen_ul_mode_subframes(sc, nsf)
-    ow = OracleWorkerUl(sc["nof_prb"], sc["nof_ports"], sc["cell_id"], 3, 5)
+    ow = OracleWorkerUl(sc["nof_prb"], sc["nof_ports"], sc["cell_id"], 3, 5, hopping_offset)
     for i in range(nsf):
         ow.work_ul(iq[i, 0], iq[i, 1], tti0 + i, update_meta=1 if i % 25 == 0 else 0)
     orecs = parse_pcap(ow.pcap_bytes())
     phy = la.Phy(nof_rx_antennas=2, sniffer_mode=1, max_batch=batch, pcapwriter=la.PcapWriter(None))
-    assert phy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"]) and phy.setUlConfig(3, 5)
+    assert phy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"]) and phy.setUlConfig(3, 5, hopping_offset)
     phy.process_host(iq, tti0, 25)
     g, o = gpu_records(phy), oracle_records(orecs)
     assert g == o, "UL_MODE record streams differ: gpu %d vs oracle %d" % (len(g), len(o))
@@ -151,3 +186,9 @@ def test_ul_mode_end_to_end_matches_oracle():
 def test_ul_mode_with_rar_and_single_chunk():
     n_ul, n_dl = _run_ul_mode(48, seed=9, batch=64, rar_period=10, mcs_max=20, pct_cqi_req=50)
     assert n_ul >= 5
+
+
+def test_ul_mode_with_frequency_hopping_grants():
+    """DCI 0 with the hopping flag: type-1 grants are decoded from both slot positions, like the oracle's UL_MODE worker"""
+    n_ul, n_dl = _run_ul_mode(60, seed=15, batch=32, hopping_offset=8, mcs_max=18, pct_hop=50, pusch_hop_offset=8, pct_cqi_req=20)
+    assert n_ul >= 8

@@ -111,6 +111,45 @@ def test_ul_grants_random_payloads():
                 assert list(hg) == list(og)[:6]
 
 
+def test_ul_grants_with_frequency_hopping_offsets():
+    """DCI 0 with the hopping flag: hop bits (36.213 Tables 8.4-1/2), type-1 second-slot position for several pusch-HoppingOffset values,
+    type 2 flagged - product == oracle on random payloads, and a hand-computed case"""
+    h, o = hosttest(), _oracle_grant_api()
+    h.lsnh_ul_grant_hop.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint16, C.c_void_p]
+    rng = np.random.default_rng(19)
+    seen = set()
+    for nprb in (25, 50, 100):
+        nb = h.lsnh_dci_format_sizeof(nprb, 2, 0)
+        for off in (0, 3, 8, 20):
+            cell = OCell(nprb, 2, 1, 1, off)
+            for it in range(400):
+                payload = rng.integers(0, 2, nb).astype(np.uint8)
+                payload[0] = 0
+                payload[1] = 1  # hopping flag
+                dci = (C.c_uint8 * 256)()
+                og = (C.c_uint32 * 8)()
+                hg = (C.c_uint32 * 8)()
+                r_o = 0
+                if o.o_dci_unpack_ul(C.byref(cell), payload.ctypes.data, nb, 0x100, dci) == 0:
+                    r_o = 1
+                    if o.o_ra_ul_dci_to_grant(C.byref(cell), dci, og) == 0:
+                        r_o = 3
+                assert h.lsnh_ul_grant_hop(nprb, 2, off, payload.ctypes.data, nb, 0x100, hg) == r_o
+                if r_o == 3:
+                    assert list(hg) == list(og)
+                    seen.add((nprb, int(og[7])))
+                    if og[7] == 1:
+                        assert og[6] + og[0] <= nprb and og[6] != og[1] or og[0] == 0
+    assert {(25, 1), (25, 2), (100, 1), (100, 2)} <= seen
+    # 100 PRB, offset 10: n_rb_pusch = 90; hop bits 10 (= +N/2), L = 4 at PRB 12 -> slot 1 at (45 + 12) % 90 = 57
+    nb = h.lsnh_dci_format_sizeof(100, 2, 0)
+    riv = 100 * (4 - 1) + 12
+    bits = [0, 1, 1, 0] + [int(b) for b in format(riv, "011b")] + [0] * (nb - 15)
+    hg = (C.c_uint32 * 8)()
+    pl = np.array(bits, dtype=np.uint8)
+    assert h.lsnh_ul_grant_hop(100, 2, 10, pl.ctypes.data, nb, 0x100, hg) == 3 and (hg[0], hg[1], hg[6], hg[7]) == (4, 12, 57, 1)
+
+
 def test_cbsegm_all_tbs():
     h, o = hosttest(), oracle()
 

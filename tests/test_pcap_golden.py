@@ -91,7 +91,7 @@ def test_real_rar_pdu_gives_the_rnti_and_the_msg3_the_reference_then_decoded(nam
     class ORar(C.Structure):
         _fields_ = [(n, C.c_uint32) for n in ("rapid", "ta", "hopping", "riv", "mcs", "tpc", "ul_delay", "csi_req")] + \
                    [("t_crnti", C.c_uint16), ("grant_ok", C.c_int)] + [(n, C.c_uint32) for n in ("L_prb", "n_prb", "mcs_idx")] + \
-                   [("mod", C.c_int), ("tbs", C.c_int), ("rv", C.c_int)]
+                   [("mod", C.c_int), ("tbs", C.c_int), ("rv", C.c_int), ("n_prb2", C.c_uint32), ("hop", C.c_uint32)]
     o.o_rar_parse.argtypes = [C.POINTER(OCell), C.c_char_p, C.c_int, C.POINTER(ORar), C.c_int]
     cell = OCell(100, 2, 1, 1)  # the capture is a 20 MHz cell: RIV 202 = 100 * (3 - 1) + 2
     r = (ORar * 8)()

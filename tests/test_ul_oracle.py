@@ -143,3 +143,39 @@ def test_uci_layout_counts_and_positions():
     d = didx.reshape(M, 12)
     data = np.sort(d[(m == 0) | (m == 3)])
     assert np.array_equal(data, np.arange(n))                              # every UL-SCH symbol index exactly once
+
+
+def test_pusch_loopback_type1_frequency_hopping():
+    """slot 0 and slot 1 of a grant on different PRBs (36.213 8.4.1): DMRS of slot 1 and the last six data symbols are taken from n_prb2"""
+    from lsn_testlib import pusch_hop_slot1
+    o = oracle_ul_api()
+    nprb, cell_id = 50, 11
+    ocell, ucell, ucfg = OCell(nprb, 1, cell_id, 1, 6), TxgUlCell(nprb, cell_id, 3, 5), OUlCfg(3, 5, 6)
+    for hop_bits, n_prb, L in ((0, 3, 4), (2, 5, 6), (1, 30, 3)):
+        n2 = pusch_hop_slot1(nprb, 6, hop_bits, n_prb)
+        qm, tbs = ul_mcs_to_mod_tbs(12, L)
+        g = dict(rnti=4242, n_dmrs=2, n_prb=n_prb, L_prb=L, mod=qm, tbs=tbs, rv=0, hop=1, n_prb2=n2)
+        iq, payloads = ul_make_subframe(ucell, 77, [g], snr_db=30.0, seed=hop_bits)
+        grid = np.zeros(14 * 12 * nprb, dtype=np.complex64)
+        o.o_ul_fft(C.byref(ocell), iq.ctypes.data, grid.ctypes.data)
+        out = np.zeros(tbs // 8 + 8, dtype=np.uint8)
+        its, snr = C.c_int(0), C.c_float(0)
+        og = OPuschGrant(L, n_prb, 0, qm, tbs, 0, n2, 1)
+        assert o.o_pusch_decode(C.byref(ocell), C.byref(ucfg), 7, 4242, C.byref(og), 2, grid.ctypes.data, 12, out.ctypes.data, C.byref(its), C.byref(snr)) == 1
+        assert bytes(out[:tbs // 8]) == payloads[0]
+        og0 = OPuschGrant(L, n_prb, 0, qm, tbs, 0, n_prb, 0)  # the same samples read without hopping: slot 1 is elsewhere
+        assert o.o_pusch_decode(C.byref(ocell), C.byref(ucfg), 7, 4242, C.byref(og0), 2, grid.ctypes.data, 4, out.ctypes.data, C.byref(its), C.byref(snr)) == 0
+
+
+def test_ul_mode_worker_with_hopping_grants():
+    from lsn_testlib import OracleWorkerUl, gen_ul_mode_subframes, parse_pcap, scenario
+    sc = scenario("cfg2", seed=15, nof_rx=1, n_rnti=10, dl_min=2, dl_max=3, ul_min=2, ul_max=3, mcs_max=18, pct_hop=50, pusch_hop_offset=8)
+    tti0, iq, sent = gen_ul_mode_subframes(sc, 60)
+    assert sum(1 for s in sent if s.get("hop")) >= 5
+    ow = OracleWorkerUl(sc["nof_prb"], sc["nof_ports"], sc["cell_id"], 3, 5, 8)
+    for i in range(iq.shape[0]):
+        ow.work_ul(iq[i, 0], iq[i, 1], tti0 + i)
+    ul = [r for r in parse_pcap(ow.pcap_bytes()) if r["direction"] == 0]
+    got = {(r["sfn"] * 10 + r["sf"], r["rnti"], r["pdu"]) for r in ul}
+    hop_sent = [s for s in sent if s.get("hop") and s["tti"] >= tti0 + 30]
+    assert hop_sent and sum((s["tti"], s["rnti"], s["payload"]) in got for s in hop_sent) >= 0.6 * len(hop_sent)

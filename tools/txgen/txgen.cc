@@ -218,9 +218,11 @@ typedef struct {
   uint32_t fixed_L;       // 0 = random aggregation level
   uint32_t pct_rv;        // share of C-RNTI transport blocks sent with a random redundancy version (else rv 0)
   uint32_t pct_cqi_req;   // share of DCI 0 that request an aperiodic CSI report
+  uint32_t pct_hop;       // share of subframes whose (then only) DCI 0 uses type-1 PUSCH frequency hopping (36.213 8.4.1)
+  uint32_t pusch_hop_offset;  // SIB2 pusch-HoppingOffset of the cell
 } txg_cfg_t;
 
-typedef struct { uint16_t rnti; uint8_t format, L; uint16_t ncce; uint32_t tti; uint32_t nbytes; uint32_t offset; uint8_t tb, mod, table256, is_ul; uint32_t nof_prb; uint32_t mcs; uint32_t cqi_req; } txg_pdu_t;
+typedef struct { uint16_t rnti; uint8_t format, L; uint16_t ncce; uint32_t tti; uint32_t nbytes; uint32_t offset; uint8_t tb, mod, table256, is_ul; uint32_t nof_prb; uint32_t mcs; uint32_t cqi_req; uint32_t hop_bits_plus1; /* DCI 0: 0 = no hopping, else 1 + hopping bits */ } txg_pdu_t;
 
 struct txg;
 typedef struct txg txg_t;
@@ -318,6 +320,7 @@ struct Grant {
   int pmi, nlayers;
   bool is_ul;
   uint32_t cqi_req = 0;
+  int hop_bits = -1;  // DCI 0: hopping bits (36.213 Table 8.4-2), -1 = no hopping
 };
 
 static bits_t dci_pack(const txg* g, const Grant& gr) {
@@ -326,7 +329,10 @@ static bits_t dci_pack(const txg* g, const Grant& gr) {
   bool user = gr.rnti >= 0x000B && gr.rnti <= 0xFFF3;
   switch (gr.format) {
     case TXG_FMT0:
-      put(b, 0, 1); put(b, 0, 1); put(b, gr.riv, riv_nbits(n)); put(b, gr.mcs[0], 5); put(b, gr.ndi[0], 1); put(b, 1, 2); put(b, 0, 3); put(b, gr.cqi_req, 1);
+      put(b, 0, 1);
+      if (gr.hop_bits < 0) { put(b, 0, 1); put(b, gr.riv, riv_nbits(n)); }
+      else { const uint32_t nh = n < 50 ? 1 : 2; put(b, 1, 1); put(b, (uint32_t)gr.hop_bits, nh); put(b, gr.riv, riv_nbits(n) - nh); }
+      put(b, gr.mcs[0], 5); put(b, gr.ndi[0], 1); put(b, 1, 2); put(b, 0, 3); put(b, gr.cqi_req, 1);
       while (b.size() < f0_sz(n)) b.push_back(0);
       break;
     case TXG_FMT1A:
@@ -597,13 +603,23 @@ extern "C" int txg_next(txg_t* g, float* iq, txg_pdu_t* pdus, int max_pdus, uint
     if (dupl) continue;
     Grant gr{}; gr.rnti = u.rnti; gr.format = TXG_FMT0; gr.L = pickL(); gr.is_ul = true; gr.ntb = 0;
     int Lc = 2 + (int)g->rng.below(8), start = ul_next; ul_next += Lc;
+    if (q == 0 && c.pct_hop && g->rng.below(100) < c.pct_hop) {
+      // a hopping grant: the only uplink grant of this subframe, allocation in the lower quarter so that both slots fit and the
+      // shortened RIV field holds it; hopping bits: 1-bit field 0 = +N/2, 2-bit field 0 / 2 = +N/4 / +N/2 (type 1)
+      const uint32_t nh = nprb < 50 ? 1 : 2;
+      Lc = 3 + (int)g->rng.below(4);
+      start = (int)((c.pusch_hop_offset + 1) / 2) + (int)g->rng.below(4);
+      gr.hop_bits = nh == 1 ? 0 : (g->rng.below(2) ? 2 : 0);
+      kul = 1;
+      if ((uint32_t)(nprb * (Lc - 1) + start) >= (1u << (riv_nbits((uint32_t)nprb) - nh))) gr.hop_bits = -1;
+    }
     if (start + Lc > nprb) break;
     gr.riv = (Lc - 1 <= nprb / 2) ? (uint32_t)(nprb * (Lc - 1) + start) : (uint32_t)(nprb * (nprb - Lc + 1) + (nprb - 1 - start));
     gr.mcs[0] = g->rng.below(25); gr.ndi[0] = g->rng.below(2);
     if (c.pct_cqi_req) gr.cqi_req = g->rng.below(100) < c.pct_cqi_req ? 1u : 0u;
     if (!place(gr, false)) continue;
     grants.push_back(gr);
-    if (npdu < max_pdus) { txg_pdu_t& pd = pdus[npdu++]; pd = txg_pdu_t{gr.rnti, 0, (uint8_t)gr.L, (uint16_t)gr.ncce, tti, 0, (uint32_t)start /* UL grants: offset = first PRB */, 0, 0, 0, 1, (uint32_t)Lc, gr.mcs[0], gr.cqi_req}; }
+    if (npdu < max_pdus) { txg_pdu_t& pd = pdus[npdu++]; pd = txg_pdu_t{gr.rnti, 0, (uint8_t)gr.L, (uint16_t)gr.ncce, tti, 0, (uint32_t)start /* UL grants: offset = first PRB */, 0, 0, 0, 1, (uint32_t)Lc, gr.mcs[0], gr.cqi_req, (uint32_t)(gr.hop_bits + 1)}; }
   }
 
   // ---- PDCCH ----
@@ -711,7 +727,8 @@ extern "C" int txg_next(txg_t* g, float* iq, txg_pdu_t* pdus, int max_pdus, uint
 // TS 36.211 5.3 (scrambling, modulation, transform precoding), 5.5 (DMRS), 5.6 (7.5 kHz shifted SC-FDMA).
 typedef struct { uint32_t nof_prb, cell_id, cyclic_shift, delta_ss; } txg_ul_cell_t;
 typedef struct { uint16_t rnti; uint16_t n_dmrs; uint32_t n_prb, L_prb, mod, tbs, rv; float gain_db, phase_rad, ta_samples;
-                 uint32_t nof_ack, cqi_bits, ri_bits; /* UCI multiplexed into the PUSCH (36.212 5.2.2.6-8): HARQ-ACK bits, CQI report size, RI bits */ } txg_ul_grant_t;
+                 uint32_t nof_ack, cqi_bits, ri_bits; /* UCI multiplexed into the PUSCH (36.212 5.2.2.6-8): HARQ-ACK bits, CQI report size, RI bits */
+                 uint32_t hop, n_prb2; /* hop = 1: slot 1 is sent on n_prb2 .. n_prb2 + L_prb - 1 (type-1 frequency hopping) */ } txg_ul_grant_t;
 
 static int ul_largest_prime_below(int n) { for (int p = n - 1; p >= 2; p--) { bool ok = true; for (int d = 2; d * d <= p; d++) if (p % d == 0) { ok = false; break; } if (ok) return p; } return 2; }
 
@@ -731,7 +748,8 @@ extern "C" int txg_ul_make(const txg_ul_cell_t* c, uint32_t tti, const txg_ul_gr
   uint32_t used = 0;
   for (int gi = 0; gi < ngr; gi++) {
     const txg_ul_grant_t& g = gr[gi];
-    const int M = 12 * (int)g.L_prb, Qm = (int)g.mod, H = 12 * M * Qm, k0 = 12 * (int)g.n_prb;
+    const int M = 12 * (int)g.L_prb, Qm = (int)g.mod, H = 12 * M * Qm;
+    const int k0s[2] = {12 * (int)g.n_prb, 12 * (int)(g.hop == 1 ? g.n_prb2 : g.n_prb)};
     payload_off[gi] = used;
     uint8_t* pl = payloads + used;
     for (uint32_t i = 0; i < g.tbs / 8; i++) pl[i] = (uint8_t)rng.below(256);
@@ -801,6 +819,7 @@ extern "C" int txg_ul_make(const txg_ul_cell_t* c, uint32_t tti, const txg_ul_gr
         }
         col++;
       }
+      const int k0 = k0s[l / 7];
       for (int k = 0; k < M; k++) {
         // timing advance error = linear phase over the carriers (carrier k sits at (k - nre/2 + 1/2) * 15 kHz)
         const double fk = (double)(k0 + k) - nre / 2.0 + 0.5;
