@@ -431,7 +431,7 @@ int rar_parse(const Cell& cell, const uint8_t* p, int len, RarEntry* out, int ca
     }
     DciUl d;
     d.rnti = r.t_crnti; d.hopping = (grant20 >> 19) & 1u; d.riv = (grant20 >> 9) & 0x3FFu; d.mcs_idx = (grant20 >> 5) & 0xFu;
-    d.hop_type = d.hopping ? 3 : -1;  // a hopping RAR grant (36.213 6.2) is not decoded
+    d.hop_type = d.hopping ? 1 : -1;  // ul_sniffer_dci_rar_to_ul_dci, falcon_dci.c:665-670: "freq_hop_fl = 1" = the -N/4 type-1 pattern on the full RIV
     r.hopping = d.hopping; r.riv = d.riv; r.mcs = d.mcs_idx; r.tpc = (grant20 >> 2) & 7u; r.ul_delay = (grant20 >> 1) & 1u; r.csi_req = grant20 & 1u;
     r.grant_ok = ra_ul_dci_to_grant(cell, d, r.grant);
     if (!r.grant_ok) r.grant = PuschGrant();

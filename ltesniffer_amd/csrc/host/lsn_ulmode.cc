@@ -66,7 +66,7 @@ void Engine::commitChunkUl(Chunk& ch, JobRunner& r)
             UlSchedGrant last; const bool found = nre > 0;
             if (found) {
               const RarEntry& e = re[nre - 1];
-              last.rnti = e.t_crnti; last.is_rar = true; last.hopping = e.hopping != 0;
+              last.rnti = e.t_crnti; last.is_rar = true; last.hopping = false;  // a hopping RAR grant is a type-1 grant (rar_parse)
               if (e.grant_ok) last.g = e.grant;  // ran_ul_grant_256 stays empty for RAR grants
               // (the RNTI activation of every sub-header already happened at search time)
             }
@@ -140,7 +140,7 @@ void Engine::commitChunkUl(Chunk& ch, JobRunner& r)
       const UlSchedGrant& m = lists[a.sf][a.idx];
       const PuschGrant& g = a.use256 ? m.g256 : m.g;
       results[a];  // default: failed
-      if (m.hopping || g.hop == 2 || g.tbs <= 0) continue;  // type-2 hopping and hopping RAR grants are not decoded: the attempt fails
+      if (m.hopping || g.hop == 2 || g.tbs <= 0) continue;  // type-2 hopping is not applied by the reference either (hopping_enabled stays false, SubframeWorker.cc:269)
       lsn_pusch_grant_t q{};
       q.sf = a.sf; q.rnti = m.rnti; q.n_dmrs = (uint16_t)m.n_dmrs; q.n_prb = g.n_prb; q.L_prb = g.L_prb; q.mod = (uint32_t)a.qm; q.tbs = (uint32_t)g.tbs; q.rv = g.rv;
       q.hop = g.hop; q.n_prb_slot1 = g.n_prb2;

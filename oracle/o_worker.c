@@ -537,7 +537,7 @@ int o_rar_parse(const o_cell_t* cell, const uint8_t* p, int len, o_rar_t* out, i
     memset(&d, 0, sizeof(d));
     d.rnti = r->t_crnti;
     d.freq_hop_fl = (grant20 >> 19) & 1u;
-    d.hop_type = d.freq_hop_fl ? 3 : -1; /* a hopping RAR grant (36.213 6.2) is not decoded by this restatement */
+    d.hop_type = d.freq_hop_fl ? 1 : -1; /* ul_sniffer_dci_rar_to_ul_dci, falcon_dci.c:665-670: "freq_hop_fl = 1" = the -N/4 type-1 pattern on the full RIV */
     d.riv = (grant20 >> 9) & 0x3FFu;
     d.mcs_idx = (grant20 >> 5) & 0xFu;
     r->hopping = d.freq_hop_fl; r->riv = d.riv; r->mcs = d.mcs_idx; r->tpc = (grant20 >> 2) & 7u; r->ul_delay = (grant20 >> 1) & 1u; r->csi_req = grant20 & 1u;
@@ -714,7 +714,7 @@ static int unpack_rar_ul(o_worker_t* w, const uint8_t* p, int len, ulg_t* out)
     memset(out, 0, sizeof(*out));
     out->rnti = r[i].t_crnti;
     out->is_rar = 1;
-    out->hopping = r[i].hopping;
+    out->hopping = 0; /* a hopping RAR grant is a type-1 grant (see o_rar_parse) */
     if (r[i].grant_ok) out->g = r[i].grant; /* ran_ul_grant_256 stays empty for RAR grants */
     o_rntiman_activate_and_refresh(w->rm, r[i].t_crnti, 0, O_ACT_RAR);
   }
@@ -757,7 +757,7 @@ static void decode_ul_mode_dl(o_worker_t* w, ulslot_t* rar_out)
 /* one srsran_chest_ul_estimate_pusch + srsran_pusch_decode attempt (PUSCH_Decoder::decode_run, UL_Sniffer_PUSCH.cc:250-310) */
 static int pusch_attempt(o_worker_t* w, const ulg_t* m, const o_pusch_grant_t* g, int qm, uint32_t tti)
 {
-  if (m->hopping || g->hop == 2 || g->tbs <= 0) return 0; /* type-2 hopping and hopping RAR grants are outside this restatement: the attempt fails */
+  if (m->hopping || g->hop == 2 || g->tbs <= 0) return 0; /* type-2 hopping is not applied by the reference either (hopping_enabled stays false, SubframeWorker.cc:269): the attempt fails */
   o_pusch_grant_t gg = *g;
   gg.mod = qm;
   int its = 0;
