@@ -31,6 +31,32 @@ def test_no_cpu_fallback():
         la.Phy(nof_rx_antennas=1)
 
 
+def _run_hpp_program():
+    import subprocess
+    la.lib()  # the product library must exist before the C++ program links against it
+    d = os.path.join(ROOT, "tests", "native")
+    subprocess.check_call(["make", "-C", d, "_build/test_hpp"], stdout=subprocess.DEVNULL)
+    r = subprocess.run([os.path.join(d, "_build", "test_hpp")], capture_output=True, text=True, timeout=120)
+    return r.returncode, r.stdout
+
+
+def test_cpp_mirror_compiles_links_and_fails_loudly_without_a_device():
+    """include/ltesniffer_amd.hpp (the drop-in Phy / SubframeWorker classes) against the shared library from plain g++; on a box without a
+    HIP device the constructor throws - there is no CPU path"""
+    import torch
+    rc, out = _run_hpp_program()
+    if torch.cuda.is_available():
+        assert rc == 0 and "device path ok" in out, out
+    else:
+        assert rc == 10 and "no HIP device" in out, out
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_worker_pool_round_trip_on_the_gpu():
+    rc, out = _run_hpp_program()
+    assert rc == 0 and "device path ok: 1 subframes" in out, out
+
+
 def test_product_does_not_link_or_include_the_oracle():
     bad = []
     for dp, _, fs in os.walk(os.path.join(ROOT, "ltesniffer_amd")):
