@@ -1,5 +1,6 @@
 // lsn_search.cc - see lsn_search.h.  Product code (HIP-free): must not include anything from oracle/.
 #include "lsn_search.h"
+#include <new>
 #include <algorithm>
 #include <cstring>
 #include <stdexcept>
@@ -217,7 +218,10 @@ int FalconSearch::inspect_dci_location_recursively(SubframeCtx& c, const int16_t
   uint32_t hist_max_format_value = 0, nof_cand_above_threshold = 0;
   FalconLocation* loc = cce_map[ncce][L] >= 0 ? &locations[cce_map[ncce][L]] : nullptr;  // the level-L location that covers this CCE
   if (!(loc && !loc->occupied && !loc->checked && loc->sufficient_power)) return 0;  // :124-127
-  DciCandidate cand[NOF_FORMATS];
+  // only the first nof_formats entries exist (children index their parent's candidates with the same format list)
+  alignas(DciCandidate) unsigned char cand_raw[sizeof(DciCandidate) * NOF_FORMATS];
+  DciCandidate* cand = reinterpret_cast<DciCandidate*>(cand_raw);
+  for (uint32_t fi = 0; fi < nof_formats; fi++) new (&cand[fi]) DciCandidate();
 
   for (uint32_t fi = 0; fi < nof_formats; fi++) {
     decodeCandidate(*loc, metas[fi]->format, cand[fi]);
