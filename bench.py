@@ -24,6 +24,21 @@ import torch
 _CPU_CTX = None
 
 
+def _thread_cpu():
+    """CPU seconds (user+system) of every thread of this process, keyed by (tid, name)"""
+    out = {}
+    tck = os.sysconf("SC_CLK_TCK")
+    for tid in os.listdir("/proc/self/task"):
+        try:
+            st = open(f"/proc/self/task/{tid}/stat").read()
+        except OSError:
+            continue
+        name = st[st.index("(") + 1:st.rindex(")")]
+        f = st[st.rindex(")") + 2:].split()
+        out[(int(tid), name)] = (int(f[11]) + int(f[12])) / tck
+    return out
+
+
 def _cpu_slice(k):
     sc, tti0, iq, gen, per, run_oracle = _CPU_CTX
     a = (k * per) % max(1, gen - per)
@@ -135,6 +150,7 @@ def main():
                           "turbo_cyc_map", "turbo_cyc_out", "ms_stage_a", "ms_search", "ms_search_core", "ms_rar", "ms_stage_c", "ms_commit", "ms_wait_front", "ms_wait_slot", "ms_drain")}
     import resource
     ru0 = resource.getrusage(resource.RUSAGE_SELF)
+    thr0 = _thread_cpu()
     t0 = time.perf_counter()
     # the K steps are submitted back to back (lsn_phy_submit_device: a step returns once its subframes are searched and queued, its
     # decode / commit tail overlaps the next step's front) and completed by one lsn_phy_wait inside the timed region
@@ -162,6 +178,7 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
+    thr1 = _thread_cpu()
     host_cores_busy = ((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) / dt  # CPU cores this rank kept busy in the timed region
     if world > 1:
         rdev = dev if dist.get_backend() == "nccl" else None
@@ -171,6 +188,10 @@ def main():
     value = total_sf / dt
 
     if rank == 0:
+        per_thr = {}
+        for k, v in thr1.items():
+            per_thr[k[1]] = per_thr.get(k[1], 0.0) + (v - thr0.get(k, 0.0)) / dt
+        busiest = {k: round(v, 2) for k, v in sorted(per_thr.items(), key=lambda kv: -kv[1])[:8] if v >= 0.01}
         dom = int(np.argmax(kms[:len(la.KERNELS)]))
         # roofline of the dominant kernel (one of the two turbo-decoder variants): algorithmic bytes = rate-matched int16
         # LLRs read (E * 2 per code block) + payload bytes written, per launch; duration from HIP events on the launch stream
@@ -228,7 +249,8 @@ def main():
                          "avg_launch_ms": round(kms[kt] / max(1, klaunch[kt]), 4), "launches": int(klaunch[kt]),
                          "algo_bytes_per_launch": int(kbytes / max(1, klaunch[kt])),
                          "dominant_by_time": la.KERNELS[dom], "valu": valu},
-            "cpu_baseline": cpu, "host": {"cpu_count": os.cpu_count(), "cores_busy_in_timed_region": round(host_cores_busy, 2)},
+            "cpu_baseline": cpu, "host": {"cpu_count": os.cpu_count(), "cores_busy_in_timed_region": round(host_cores_busy, 2),
+                                             "busiest_threads": busiest},
             "detail": {"pdus_per_step": npdus / args.steps, "algo_bytes_per_subframe": int(algo_bytes / (args.steps * nsf)),
                        "whole_path_GBps": round(algo_bytes / 1e9 / dt, 2),
                        "per_step": {k: round(v / args.steps, 3) for k, v in acc.items()},

@@ -5,6 +5,10 @@
 //   PDSCH_Decoder::decode_dl_mode           /root/reference/src/src/DL_Sniffer_PDSCH.cc:881-1291
 // Product code: no CPU fallback, nothing from oracle/ is included or linked.
 #include "lsn_engine.h"
+#include <pthread.h>
+#include <atomic>
+#include <time.h>
+#include <sys/prctl.h>
 #include "../kernels/lsn_rm.h"
 #include <algorithm>
 #include <chrono>
@@ -22,6 +26,27 @@
   } while (0)
 
 namespace lsn {
+
+// Host wait for a pipeline event.  hipEventSynchronize keeps the calling core busy for the whole wait on this runtime even
+// for hipEventBlockingSync events (measured: thread CPU time == wall time in the wait, six decode threads = four cores of
+// polling per rank), which starves the search thread when several ranks share a CPU quota.  Poll-and-sleep instead: the
+// waits are 2-15 ms long; the decode threads nap 50 us, the front thread (which feeds the sequential search) 15 us, with the
+// threads' timer slack set to 1 us so the naps are that short.  LSN_SPIN_WAIT=1 spins.
+static const bool g_spin_wait = getenv("LSN_SPIN_WAIT") && atoi(getenv("LSN_SPIN_WAIT"));
+static void waitEvent(hipEvent_t ev, long nap_ns = 50000)
+{
+  if (g_spin_wait) {
+    HIP_CHECK(hipEventSynchronize(ev));
+    return;
+  }
+  for (;;) {
+    const hipError_t e = hipEventQuery(ev);
+    if (e == hipSuccess) return;
+    if (e != hipErrorNotReady) HIP_CHECK(e);
+    timespec ts{0, nap_ns};
+    nanosleep(&ts, nullptr);
+  }
+}
 
 static double now_ms()
 {
@@ -99,8 +124,14 @@ Engine::Engine(const lsn_phy_cfg_t& c) : cfg(c)
   HIP_CHECK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
   if (const char* e = getenv("LSN_DECODE_THREADS")) ndec = std::max(1, std::min((int)NDEC, atoi(e)));
   nslots = ndec + 5;
-  front_thread = std::thread([this] { frontLoop(); });
-  for (int i = 0; i < ndec; i++) decode_threads[i] = std::thread([this, i] { decodeLoop(i); });
+  front_thread = std::thread([this] { pthread_setname_np(pthread_self(), "lsn-front"); frontLoop(); });
+  for (int i = 0; i < ndec; i++)
+    decode_threads[i] = std::thread([this, i] {
+      char nm[16];
+      snprintf(nm, sizeof nm, "lsn-dec%d", i);
+      pthread_setname_np(pthread_self(), nm);
+      decodeLoop(i);
+    });
 }
 
 Engine::~Engine()
@@ -198,7 +229,7 @@ void Engine::launchStageA(Chunk& ch, const void* d_iq)
 
 void Engine::finishStageA(Chunk& ch)
 {
-  HIP_CHECK(hipEventSynchronize(ch.ev_a[16]));
+  waitEvent(ch.ev_a[16], 15000);
   for (int n = 0; n < 8; n++) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, ch.ev_a[2 * n], ch.ev_a[2 * n + 1]) == hipSuccess) perf_front.kernel_ms[kStageA[n]] += ms;
@@ -492,7 +523,7 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
       HIP_CHECK(hipMemcpyAsync(r.h_payload_pinned, r.d_payload, pay_n - pay0, hipMemcpyDeviceToHost, st));
     }
     HIP_CHECK(hipEventRecord(r.ev_done, st));
-    HIP_CHECK(hipEventSynchronize(r.ev_done));
+    waitEvent(r.ev_done);
     float ms = 0;
     if (hipEventElapsedTime(&ms, r.ev[0], r.ev[1]) == hipSuccess) pf.kernel_ms[LSN_K_PDSCH_PREP] += ms;
     if (hipEventElapsedTime(&ms, r.ev[1], r.ev[2]) == hipSuccess) pf.kernel_ms[LSN_K_PDSCH_DEMOD] += ms;
@@ -687,6 +718,7 @@ void Engine::decodeLoop(int idx)
 {
   JobRunner& r = runner_c[idx];
   pinThisThread(nullptr);
+  prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0);
   for (;;) {
     Chunk* ch = nullptr;
     {
@@ -731,6 +763,7 @@ void Engine::decodeLoop(int idx)
 void Engine::frontLoop()
 {
   pinThisThread(nullptr);
+  prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0);
   for (;;) {
     FrontJob job;
     {

@@ -112,8 +112,7 @@ void Engine::allocRunner(JobRunner& r)
       HIP_CHECK(hipStreamCreateWithPriority(&r.stream, hipStreamNonBlocking, lo));
   }
   for (auto& e : r.ev) HIP_CHECK(hipEventCreate(&e));
-  // the thread that waits for this runner's stream sleeps on an interrupt instead of spinning on a core (LSN_SPIN_WAIT=1: spin)
-  HIP_CHECK(hipEventCreateWithFlags(&r.ev_done, (getenv("LSN_SPIN_WAIT") && atoi(getenv("LSN_SPIN_WAIT"))) ? hipEventDisableTiming : (hipEventBlockingSync | hipEventDisableTiming)));
+  HIP_CHECK(hipEventCreateWithFlags(&r.ev_done, hipEventDisableTiming));  // waited for with Engine's poll-and-sleep waitEvent()
 }
 
 template <typename T>
@@ -149,7 +148,7 @@ void Engine::allocChunk(Chunk& ch)
   ch.ctx.assign(B, SubframeCtx());
   for (auto& e : ch.ev_a) HIP_CHECK(hipEventCreate(&e));
   (void)hipEventDestroy(ch.ev_a[16]);  // the "stage A results are on the host" marker is only waited for, never timed
-  HIP_CHECK(hipEventCreateWithFlags(&ch.ev_a[16], (getenv("LSN_SPIN_WAIT") && atoi(getenv("LSN_SPIN_WAIT"))) ? hipEventDisableTiming : (hipEventBlockingSync | hipEventDisableTiming)));
+  HIP_CHECK(hipEventCreateWithFlags(&ch.ev_a[16], hipEventDisableTiming));
 }
 
 void Engine::buildTables()
