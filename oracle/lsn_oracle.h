@@ -203,6 +203,22 @@ void o_pbch_llr(const o_cell_t* cell, uint32_t nof_rx, const ocf_t* grid, const 
 int o_pbch_decode(const o_cell_t* cell, uint32_t nof_rx, const ocf_t* grid, const ocf_t* ce, float noise, o_mib_t* out, float* llr_out);
 int o_mib_decode_subframe(const o_cell_t* cell, uint32_t nof_rx, const ocf_t* iq, o_mib_t* out, float* llr_out);
 
+/* ---------- PSS / SSS cell search (o_sync.c) ---------- */
+typedef struct { uint32_t nof_periods; int32_t force_n_id_2 /* -1: all three roots */; float threshold /* peak / mean of the PSS correlation power */; } o_sync_cfg_t;
+typedef struct {
+  uint32_t found, cell_id, n_id_2, n_id_1;
+  uint32_t sf_idx;   /* 0 or 5: index of the subframe that starts at sample sf_start */
+  uint32_t pss_pos;  /* first sample of the PSS symbol's useful part, 0 <= pss_pos < 5 ms */
+  uint32_t sf_start; /* 0 <= sf_start < 5 ms */
+  float pss_peak, pss_p2avg, sss_metric, sss_second, cfo_hz, cfo_coarse_hz;
+} o_sync_t;
+void o_pss_seq(uint32_t n_id_2, ocf_t* d);
+void o_sss_m0m1(uint32_t n_id_1, uint32_t* m0, uint32_t* m1);
+void o_sss_seq(uint32_t n_id_1, uint32_t n_id_2, int sf5, int8_t* d);
+void o_pss_time(uint32_t n_id_2, uint32_t N, ocf_t* p);
+uint32_t o_sync_min_samples(uint32_t nof_prb, uint32_t nof_periods);
+int o_cell_search(const ocf_t* x, uint64_t nsamples, uint32_t nof_prb, const o_sync_cfg_t* cfg, o_sync_t* out, float* corr_out);
+
 /* ---------- IQ capture file source (o_file.c) ---------- */
 long o_file_read(const char* path, uint32_t nof_prb, uint32_t nant, long offset_time, float offset_freq, uint32_t first_sf, uint32_t nsf, ocf_t* out);
 

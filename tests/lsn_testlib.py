@@ -567,3 +567,42 @@ def prach_subframe(nof_prb, ues, snr_db=10.0, seed=1, zero_corr_zone=5, root_seq
         p = prach_preamble(nof_prb, u, (idx % nwin) * ncs, freq_offset) * 10.0 ** (gain_db / 20.0)
         iq[delay:delay + len(p)] += p[:sf_len - delay]
     return iq.astype(np.complex64)
+
+
+# -------- PSS / SSS cell search (oracle/o_sync.c) --------
+class OSyncCfg(C.Structure):
+    _fields_ = [("nof_periods", C.c_uint32), ("force_n_id_2", C.c_int32), ("threshold", C.c_float)]
+
+
+class OSync(C.Structure):
+    _fields_ = [("found", C.c_uint32), ("cell_id", C.c_uint32), ("n_id_2", C.c_uint32), ("n_id_1", C.c_uint32), ("sf_idx", C.c_uint32),
+                ("pss_pos", C.c_uint32), ("sf_start", C.c_uint32), ("pss_peak", C.c_float), ("pss_p2avg", C.c_float),
+                ("sss_metric", C.c_float), ("sss_second", C.c_float), ("cfo_hz", C.c_float), ("cfo_coarse_hz", C.c_float)]
+
+
+def oracle_sync_api():
+    o = oracle()
+    o.o_pss_seq.argtypes = [C.c_uint32, C.c_void_p]
+    o.o_sss_m0m1.argtypes = [C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    o.o_sss_seq.argtypes = [C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
+    o.o_pss_time.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p]
+    o.o_sync_min_samples.argtypes = [C.c_uint32, C.c_uint32]
+    o.o_sync_min_samples.restype = C.c_uint32
+    o.o_cell_search.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(OSyncCfg), C.POINTER(OSync), C.c_void_p]
+    return o
+
+
+def sync_capture(sc, lead, periods, seed=11):
+    """antenna 0 of a txgen capture behind `lead` samples of receiver noise -> (samples, tti of the first whole subframe)"""
+    tx = TxGen(**sc)
+    need = oracle_sync_api().o_sync_min_samples(sc["nof_prb"], periods)
+    rng = np.random.default_rng(seed)
+    parts = [(0.02 * (rng.standard_normal(lead) + 1j * rng.standard_normal(lead))).astype(np.complex64)]
+    first_tti, have = None, lead
+    while have < need:
+        tti, iq, _ = tx.next()
+        if first_tti is None:
+            first_tti = tti
+        parts.append(iq[0])
+        have += iq.shape[1]
+    return np.ascontiguousarray(np.concatenate(parts)), first_tti

@@ -462,6 +462,35 @@ extern "C" int txg_next(txg_t* g, float* iq, txg_pdu_t* pdus, int max_pdus, uint
     }
   }
 
+  // ---- PSS / SSS (36.211 6.11, FDD): symbols 6 / 5 of subframes 0 and 5, 62 carriers around DC, antenna port 0 ----
+  if (sf == 0 || sf == 5) {
+    static const int root[3] = {25, 29, 34};
+    const int n2 = id % 3, n1 = id / 3, u = root[n2];
+    int xs[31], xc[31], xz[31];
+    for (int i = 0; i < 5; i++) xs[i] = xc[i] = xz[i] = (i == 4);
+    for (int i = 0; i < 26; i++) {
+      xs[i + 5] = (xs[i + 2] + xs[i]) & 1;
+      xc[i + 5] = (xc[i + 3] + xc[i]) & 1;
+      xz[i + 5] = (xz[i + 4] + xz[i + 2] + xz[i + 1] + xz[i]) & 1;
+    }
+    const int qp = n1 / 30, q = (n1 + qp * (qp + 1) / 2) / 30, mp = n1 + q * (q + 1) / 2;
+    const int m0 = mp % 31, m1 = (m0 + mp / 31 + 1) % 31;
+    for (int n = 0; n < 62; n++) {
+      const int k = 6 * nprb - 31 + n;
+      const int a = n < 31 ? n * (n + 1) : (n + 1) * (n + 2);
+      const double ph = -M_PI * u * (double)(a % 126) / 63.0;
+      grid[0][6 * nre + k] = cf((float)std::cos(ph), (float)std::sin(ph));
+      const int i = n / 2;
+      const int s0 = 1 - 2 * xs[(i + m0) % 31], s1 = 1 - 2 * xs[(i + m1) % 31];
+      const int c0 = 1 - 2 * xc[(i + n2) % 31], c1 = 1 - 2 * xc[(i + n2 + 3) % 31];
+      const int z0 = 1 - 2 * xz[(i + m0 % 8) % 31], z1 = 1 - 2 * xz[(i + m1 % 8) % 31];
+      int d;
+      if (n % 2 == 0) d = (sf == 0 ? s0 : s1) * c0;
+      else d = sf == 0 ? s1 * c1 * z0 : s0 * c1 * z1;
+      grid[0][5 * nre + k] = cf((float)d, 0.0f);
+    }
+  }
+
   // ---- schedule ----
   std::vector<Grant> grants;
   std::vector<uint8_t> cce_used(ncce, 0);
