@@ -152,6 +152,32 @@ int lsn_phy_mib_decode(lsn_phy_t* phy, const void* iq, int iq_on_device, lsn_mib
 #define LSN_TTI_FROM_MIB 0xFFFFFFFFu /* start_tti of lsn_phy_process_file: take the SFN from the first MIB that decodes (subframes 0, 10, 20, ...
                                         of the file; the subframes in front of it are dropped, as in the reference's DECODE_MIB state) */
 
+/* ---- PSS / SSS cell search ----
+ * Replaces rf_search_and_decode_mib(&rf, nof_rx_ant, &cell_detect_config, force_N_id_2, &cell, &search_cell_cfo)
+ * (LTESniffer_Core.cc:195-204, configuration :108-112) on a block of samples instead of a radio: physical cell id, the position
+ * of the subframe-0/5 boundaries and the carrier offset - for a recording also the -O offset and -c cell id that the
+ * reference's file mode asks the user for.  The MIB (bandwidth, ports, PHICH, SFN) then comes from lsn_phy_mib_decode.
+ * Needs no Phy.  iq: one antenna, contiguous cf32 at the sampling rate of nof_prb (15 kHz * N), at least
+ * (nof_periods + 1) * 75 * N + N samples.  FDD, normal cyclic prefix.
+ * Returns 1 when a cell was found (pss_p2avg >= threshold), 0 when not (out still holds the best guess), < 0 on error. */
+typedef struct {
+  uint32_t nof_periods;  /* 5 ms periods whose PSS correlation powers are added (1..16; 0 = 1) */
+  int32_t force_n_id_2;  /* -1: search the three PSS roots (args.force_N_id_2 of the reference) */
+  float threshold;       /* on peak / mean of the PSS correlation power; 20 is a safe floor (noise alone stays below 15) */
+} lsn_cell_search_cfg_t;
+typedef struct {
+  uint32_t found, cell_id, n_id_2, n_id_1;
+  uint32_t sf_idx;    /* 0 or 5: index of the subframe that starts at sample sf_start */
+  uint32_t pss_pos;   /* first sample of the useful part of the PSS symbol, 0 <= pss_pos < 75 N */
+  uint32_t sf_start;  /* 0 <= sf_start < 75 N: lsn_file_cfg_t.offset_time_samples for a recording */
+  float pss_peak, pss_p2avg;
+  float sss_metric, sss_second;  /* best and second best of the 336 SSS hypotheses */
+  float cfo_hz;                  /* from the phase turn between the SSS and PSS symbols (+-7 kHz) */
+  float cfo_coarse_hz;           /* from the two halves of the PSS symbol (+-15 kHz; disturbed by the other carriers of a loaded cell) */
+} lsn_cell_search_t;
+int lsn_cell_search(int device, const void* iq, int iq_on_device, uint64_t nof_samples, uint32_t nof_prb, const lsn_cell_search_cfg_t* cfg,
+                    lsn_cell_search_t* out, float* corr_out /* optional, host: [3][75 N] accumulated PSS correlation powers */);
+
 /* ---- IQ capture file replay ----
  * Replaces the file source of the reference's file mode: srsran_ue_sync_init_file_multi(&ue_sync, nof_prb, file, offset_time,
  * offset_freq, nof_rx_antennas) + one srsran_ue_sync_zerocopy per subframe (LTESniffer_Core.cc:252-258,365; options -O / -o,

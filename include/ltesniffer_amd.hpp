@@ -76,4 +76,12 @@ private:
   lsn_phy_t* h = nullptr;
 };
 
+// rf_search_and_decode_mib's cell search on a block of samples of one antenna (LTESniffer_Core.cc:195-204): 1 found, 0 not, < 0 error
+inline int cellSearch(const cf_t* iq, uint64_t nof_samples, uint32_t nof_prb, lsn_cell_search_t& out, int force_N_id_2 = -1,
+                      uint32_t nof_periods = 2, float threshold = 20.0f, int device = 0)
+{
+  lsn_cell_search_cfg_t c{nof_periods, force_N_id_2, threshold};
+  return lsn_cell_search(device, iq, 0, nof_samples, nof_prb, &c, &out, nullptr);
+}
+
 }  // namespace lsn_amd

@@ -30,7 +30,7 @@ EXPORTS = ["lsn_phy_create", "lsn_phy_destroy", "lsn_phy_set_cell", "lsn_phy_get
            "lsn_phy_get_perf", "lsn_kernel_name", "lsn_version", "lsn_pcap_open", "lsn_pcap_open_mem",
            "lsn_pcap_set_wall_clock", "lsn_pcap_write", "lsn_pcap_sink", "lsn_pcap_mem", "lsn_pcap_nof_records",
            "lsn_pcap_reset", "lsn_pcap_close", "lsn_phy_set_pcap_writer", "lsn_phy_set_ul_config", "lsn_phy_pusch_decode",
-           "lsn_phy_tap_ul", "lsn_phy_set_prach_config", "lsn_phy_prach_detect", "lsn_phy_set_prach_sink", "lsn_prach_tti_opportunity", "lsn_phy_process_file", "lsn_phy_mib_decode", "lsn_phy_mib_decode_llr", "lsn_phy_submit_device", "lsn_phy_wait"]
+           "lsn_phy_tap_ul", "lsn_phy_set_prach_config", "lsn_phy_prach_detect", "lsn_phy_set_prach_sink", "lsn_prach_tti_opportunity", "lsn_phy_process_file", "lsn_phy_mib_decode", "lsn_phy_mib_decode_llr", "lsn_phy_submit_device", "lsn_phy_wait", "lsn_cell_search"]
 
 
 PRACH_NCS = [0, 13, 15, 18, 22, 26, 32, 38, 46, 59, 76, 93, 119, 167, 279, 419]  # 36.211 Table 5.7.2-2
@@ -41,6 +41,16 @@ class Mib(C.Structure):
 
 
 TTI_FROM_MIB = 0xFFFFFFFF
+
+
+class CellSearchCfg(C.Structure):
+    _fields_ = [("nof_periods", C.c_uint32), ("force_n_id_2", C.c_int32), ("threshold", C.c_float)]
+
+
+class CellSearch(C.Structure):
+    _fields_ = [("found", C.c_uint32), ("cell_id", C.c_uint32), ("n_id_2", C.c_uint32), ("n_id_1", C.c_uint32), ("sf_idx", C.c_uint32),
+                ("pss_pos", C.c_uint32), ("sf_start", C.c_uint32), ("pss_peak", C.c_float), ("pss_p2avg", C.c_float),
+                ("sss_metric", C.c_float), ("sss_second", C.c_float), ("cfo_hz", C.c_float), ("cfo_coarse_hz", C.c_float)]
 
 
 class FileCfg(C.Structure):
@@ -215,6 +225,7 @@ def lib():
         L.lsn_phy_set_prach_sink.argtypes = [C.c_void_p, PRACH_SINK, C.c_void_p]
         L.lsn_phy_set_prach_sink.restype = None
         L.lsn_prach_tti_opportunity.argtypes = [C.c_uint32, C.c_uint32]
+        L.lsn_cell_search.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_uint64, C.c_uint32, C.POINTER(CellSearchCfg), C.POINTER(CellSearch), C.c_void_p]
         _lib = L
     return _lib
 
@@ -482,6 +493,23 @@ class Phy:
             self.close()
         except Exception:
             pass
+
+
+def cell_search(iq, nof_prb, nof_periods=2, force_n_id_2=-1, threshold=20.0, device=0, with_corr=False):
+    """rf_search_and_decode_mib of the reference (LTESniffer_Core.cc:195-204) on a block of samples of one antenna:
+    -> (rc, CellSearch[, corr[3, 75 N]]); rc 1 found / 0 not found; iq: numpy complex64 (host) or a torch cuda tensor"""
+    import numpy as np
+    N = {6: 128, 15: 256, 25: 512, 50: 1024, 100: 2048}.get(nof_prb, 128)
+    cfg = CellSearchCfg(nof_periods, force_n_id_2, threshold)
+    out = CellSearch()
+    corr = np.zeros((3, 75 * N), dtype=np.float32) if with_corr else None
+    if hasattr(iq, "data_ptr"):
+        ptr, n, on_dev = iq.data_ptr(), iq.numel(), 1
+    else:
+        iq = np.ascontiguousarray(iq, dtype=np.complex64)
+        ptr, n, on_dev = iq.ctypes.data, iq.size, 0
+    rc = _check_n(lib().lsn_cell_search(device, ptr, on_dev, n, nof_prb, C.byref(cfg), C.byref(out), corr.ctypes.data if with_corr else None), "lsn_cell_search")
+    return (rc, out, corr) if with_corr else (rc, out)
 
 
 def mac_lte_record(ctx, pdu):

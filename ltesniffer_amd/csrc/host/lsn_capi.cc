@@ -308,6 +308,18 @@ void lsn_phy_set_prach_sink(lsn_phy_t* phy, lsn_prach_sink_t cb, void* user)
 }
 int lsn_prach_tti_opportunity(uint32_t config_idx, uint32_t tti) { return lsn::prach_tti_opportunity(config_idx, tti) ? 1 : 0; }
 
+int lsn_cell_search(int device, const void* iq, int iq_on_device, uint64_t nof_samples, uint32_t nof_prb, const lsn_cell_search_cfg_t* cfg,
+                    lsn_cell_search_t* out, float* corr_out)
+{
+  if (!iq || !cfg || !out) return LSN_ERROR_INVALID_INPUTS;
+  try {
+    return lsn::cell_search(device, (const cf32*)iq, iq_on_device != 0, nof_samples, nof_prb, *cfg, *out, corr_out);
+  } catch (const std::exception& ex) {
+    fprintf(stderr, "ltesniffer_amd: cell search: %s\n", ex.what());
+    return LSN_ERROR;
+  }
+}
+
 long lsn_phy_tap(lsn_phy_t* phy, int what, uint32_t sf, void* out, size_t cap)
 {
   if (!phy || !out) return LSN_ERROR_INVALID_INPUTS;

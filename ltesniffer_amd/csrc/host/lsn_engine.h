@@ -214,6 +214,8 @@ private:
 };
 
 bool prach_tti_opportunity(uint32_t config_idx, uint32_t tti);  // lsn_prach.cc
+int cell_search(int device, const cf32* iq, bool on_device, uint64_t nsamples, uint32_t nof_prb, const lsn_cell_search_cfg_t& cfg, lsn_cell_search_t& out,
+                float* corr_out);  // lsn_sync.cc
 // table builders (lsn_tables.cc)
 void gold_sequence(uint32_t cinit, uint8_t* c, int len);
 

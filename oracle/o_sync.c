@@ -7,9 +7,10 @@
  *   PSS  d_u(n), u = 25/29/34, 62 carriers around DC, last symbol of slots 0 and 10;
  *   SSS  two interleaved length-31 m-sequences (m0, m1 from N_id_1), scrambled by c0/c1 (N_id_2) and z1, one symbol earlier,
  *        different in subframes 0 and 5.
- * Detector: full-rate matched filter of the three time-domain PSS replicas over one 5 ms period, powers of `nof_periods`
- * consecutive periods added (srsRAN averages the peak over nof_valid_pss_frames), argmax over (root, lag); accepted when
- * peak / mean of the winning root's correlation power >= threshold.  The channel on the 62 carriers is taken from the PSS
+ * Detector: full-rate matched filter of the three time-domain PSS replicas over one 5 ms period, each output power divided by
+ * the energy of its N-sample window (a burst of strong samples - AGC settling, junk in front of a recording - cannot win),
+ * the ratios of `nof_periods` consecutive periods added (srsRAN averages the peak over nof_valid_pss_frames), argmax over
+ * (root, lag); accepted when peak / mean of the winning root's metric >= threshold.  The channel on the 62 carriers is taken from the PSS
  * symbol, the SSS symbol is matched against all 168 x 2 sequences (|.|^2 of the coherent sum, so that a common phase turn
  * from the carrier offset does not matter) - an exhaustive search instead of srsRAN's m0/m1 partial correlations, which is
  * what one launch on a GPU does anyway.  CFO: coarse from the two halves of the PSS
@@ -122,13 +123,14 @@ int o_cell_search(const ocf_t* x, uint64_t nsamples, uint32_t nof_prb, const o_s
       float c = 0.0f;
       for (uint32_t q = 0; q < P; q++) {
         const ocf_t* xs = x + (size_t)q * W5 + n;
-        float ar = 0.0f, ai = 0.0f;
-        for (uint32_t k = 0; k < N; k++) { /* x * conj(p), one rounding per operation */
+        float ar = 0.0f, ai = 0.0f, e = 0.0f;
+        for (uint32_t k = 0; k < N; k++) { /* x * conj(p) and the energy of the window, one rounding per operation */
           const float t1 = xs[k].r * p[k].r, t2 = xs[k].i * p[k].i, t3 = xs[k].i * p[k].r, t4 = xs[k].r * p[k].i;
           ar = ar + (t1 + t2);
           ai = ai + (t3 - t4);
+          e = e + (xs[k].r * xs[k].r + xs[k].i * xs[k].i);
         }
-        c = c + (ar * ar + ai * ai);
+        if (e > 0.0f) c = c + (ar * ar + ai * ai) / e; /* in [0, 1]: the replica has unit energy */
       }
       C[(size_t)u * W5 + n] = c;
       if (c > best) { best = c; bu = u; bn = n; } /* first maximum in (root, lag) order */
@@ -155,18 +157,21 @@ int o_cell_search(const ocf_t* x, uint64_t nsamples, uint32_t nof_prb, const o_s
   for (uint32_t j = bn >= N + cp ? 0u : 1u; j <= P; j++) {
     const ocf_t* xj = x + (size_t)j * W5 + bn;
     ocf_t y[2];
+    float eh[2];
     for (int h = 0; h < 2; h++) {
-      float ar = 0.0f, ai = 0.0f;
+      float ar = 0.0f, ai = 0.0f, e = 0.0f;
       for (uint32_t k = h * (N / 2); k < (h + 1) * (N / 2); k++) {
         const float t1 = xj[k].r * pbest[k].r, t2 = xj[k].i * pbest[k].i, t3 = xj[k].i * pbest[k].r, t4 = xj[k].r * pbest[k].i;
         ar = ar + (t1 + t2);
         ai = ai + (t3 - t4);
+        e = e + (xj[k].r * xj[k].r + xj[k].i * xj[k].i);
       }
       y[h].r = ar;
       y[h].i = ai;
+      eh[h] = e;
     }
-    const float sr = y[0].r + y[1].r, si = y[0].i + y[1].i;
-    const float cj = sr * sr + si * si;
+    const float sr = y[0].r + y[1].r, si = y[0].i + y[1].i, et = eh[0] + eh[1];
+    const float cj = et > 0.0f ? (sr * sr + si * si) / et : 0.0f;
     if (cj > cjb) { cjb = cj; jb = j; yb[0] = y[0]; yb[1] = y[1]; }
   }
   const uint32_t q0 = bn + jb * W5;

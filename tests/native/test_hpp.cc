@@ -6,6 +6,8 @@
 
 int main()
 {
+  lsn_cell_search_t cs;
+  if (lsn_amd::cellSearch(nullptr, 0, 6, cs) != LSN_ERROR_INVALID_INPUTS) { printf("cellSearch accepted a null buffer\n"); return 4; }
   try {
     lsn_amd::Phy phy(/*nof_rx_antennas*/ 1, /*nof_workers*/ 4, /*skipSecondaryMetaFormats*/ false, /*metaFormatSplitRatio*/ 0.99, /*histogramThreshold*/ 5,
                      /*pcapwriter*/ nullptr);

@@ -1,0 +1,88 @@
+"""GPU parity of the PSS / SSS cell search (k_pss_corr + k_sync_fin behind lsn_cell_search) against the oracle - bit-exact
+correlation powers and metrics, identical decisions - and the chain a recording needs: search -> MIB -> file replay at the
+offset, cell id and SFN that were found."""
+import numpy as np
+import pytest
+
+import ltesniffer_amd as la
+from lsn_testlib import OracleWorker, parse_pcap, scenario, sync_capture
+from parity import gen_subframes, gpu_records, oracle_records
+from test_file_source import write_capture
+from test_sync_oracle import oracle_cell_search
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ("found", "cell_id", "n_id_2", "n_id_1", "sf_idx", "pss_pos", "sf_start")
+FLOATS = ("pss_peak", "pss_p2avg", "sss_metric", "sss_second", "cfo_hz", "cfo_coarse_hz")
+
+
+def same(g, o):
+    assert [getattr(g, f) for f in FIELDS] == [getattr(o, f) for f in FIELDS], ([getattr(g, f) for f in FIELDS], [getattr(o, f) for f in FIELDS])
+    a = np.array([getattr(g, f) for f in FLOATS], dtype=np.float32)
+    b = np.array([getattr(o, f) for f in FLOATS], dtype=np.float32)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (a, b)
+
+
+@pytest.mark.parametrize("scn,over,lead,cfo,periods,force", [
+    ("small", dict(cell_id=301), 1234, 0.0, 1, -1),
+    ("small", dict(cell_id=2, nof_ports=1, nof_rx=1, snr_db=5.0), 38000, 900.0, 2, -1),
+    ("small", dict(cell_id=503, nof_prb=6), 77, -2500.0, 3, -1),
+    ("small", dict(cell_id=100, nof_prb=15), 5000, 400.0, 1, 1),
+    ("cfg1", dict(cell_id=150), 60001, 0.0, 2, 0),
+    ("cfg3", dict(cell_id=37, dl_min=2, dl_max=3), 20000, -700.0, 1, 1),
+])
+def test_cell_search_matches_oracle(scn, over, lead, cfo, periods, force):
+    sc = scenario(scn, seed=5, start_tti=10 * 77 + 3, cfo_hz=cfo, **over)
+    x, _ = sync_capture(sc, lead, periods)
+    ro, so, ocorr = oracle_cell_search(x, sc["nof_prb"], periods, force, 20.0)
+    rg, sg, gcorr = la.cell_search(x, sc["nof_prb"], nof_periods=periods, force_n_id_2=force, threshold=20.0, with_corr=True)
+    assert np.array_equal(gcorr.view(np.uint32), ocorr.view(np.uint32)), float(np.abs(gcorr - ocorr).max())
+    assert rg == ro == 1
+    same(sg, so)
+    assert sg.cell_id == sc["cell_id"]
+
+
+def test_cell_search_on_noise_device_input_and_invalid_arguments():
+    import torch
+    rng = np.random.default_rng(3)
+    n = 3 * 75 * 128 + 128
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    ro, so, _ = oracle_cell_search(x, 6, 2, -1, 20.0)
+    rg, sg = la.cell_search(x, 6, nof_periods=2)
+    assert rg == ro == 0 and not sg.found
+    same(sg, so)
+    xd = torch.from_numpy(x.view(np.float32)).to("cuda:0")  # samples already in HBM
+    rg2, sg2 = la.cell_search(xd.view(torch.complex64), 6, nof_periods=2)
+    assert rg2 == 0
+    same(sg2, so)
+    for bad in (dict(nof_prb=75), dict(nof_periods=17), dict(force_n_id_2=3), dict(nof_periods=3)):  # the last one: buffer too short
+        kw = dict(nof_prb=6, nof_periods=2)
+        kw.update(bad)
+        with pytest.raises(RuntimeError):
+            la.cell_search(x, kw.pop("nof_prb"), **kw)
+
+
+def test_recording_with_unknown_offset_cell_and_sfn_is_replayed_like_the_oracle(tmp_path):
+    sc = scenario("small", seed=8, start_tti=10 * 700 + 4, cell_id=215)
+    tti0, iq, _ = gen_subframes(sc, 50)
+    lead = 4321
+    p = str(tmp_path / "cap.cf32")
+    write_capture(p, iq, lead=lead)
+    raw = np.fromfile(p, dtype=np.complex64).reshape(-1, sc["nof_rx"])
+    rc, s = la.cell_search(raw[:, 0], sc["nof_prb"], nof_periods=2)
+    assert rc == 1 and s.cell_id == sc["cell_id"]
+    sflen = iq.shape[2]
+    # the first subframe-0/5 boundary of the recording: subframe 5 of SFN 700 is the second whole subframe
+    assert s.sf_start == lead + sflen and s.sf_idx == 5
+    # replay from the first subframe 0 (MIB): 5 more subframes on
+    off = s.sf_start + (5 * sflen if s.sf_idx == 5 else 0)
+    first = (off - lead) // sflen
+    ow = OracleWorker(sc["nof_prb"], sc["nof_ports"], s.cell_id, sc["nof_rx"])
+    for i in range(first, 50):
+        ow.work(iq[i], tti0 + i, update_meta=1 if (i - first) % 20 == 0 else 0)
+    orecs = oracle_records(parse_pcap(ow.pcap_bytes()))
+    phy = la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=8, pcapwriter=la.PcapWriter(None))
+    assert phy.setCell(sc["nof_prb"], sc["nof_ports"], s.cell_id)
+    assert phy.process_file(p, start_tti=la.TTI_FROM_MIB, offset_time=off, update_meta_period=20) == 50 - first
+    assert gpu_records(phy) == orecs and orecs
+    phy.close()
