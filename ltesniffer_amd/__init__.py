@@ -499,7 +499,7 @@ def cell_search(iq, nof_prb, nof_periods=2, force_n_id_2=-1, threshold=20.0, dev
     """rf_search_and_decode_mib of the reference (LTESniffer_Core.cc:195-204) on a block of samples of one antenna:
     -> (rc, CellSearch[, corr[3, 75 N]]); rc 1 found / 0 not found; iq: numpy complex64 (host) or a torch cuda tensor"""
     import numpy as np
-    N = {6: 128, 15: 256, 25: 512, 50: 1024, 100: 2048}.get(nof_prb, 128)
+    N = {6: 128, 15: 256, 25: 512, 50: 1024, 75: 1536, 100: 2048}.get(nof_prb, 128)
     cfg = CellSearchCfg(nof_periods, force_n_id_2, threshold)
     out = CellSearch()
     corr = np.zeros((3, 75 * N), dtype=np.float32) if with_corr else None

@@ -157,7 +157,7 @@ int Engine::setCell(const lsn_cell_t& c)
   static const uint32_t ng_x6[4] = {1, 3, 6, 12};
   if (c.cp != 0 || c.frame_type != 0 || c.phich_length != 0 || c.phich_resources > 3) return LSN_ERROR_INVALID_INPUTS;
   if (c.nof_ports < 1 || c.nof_ports > 2 || c.id > 503) return LSN_ERROR_INVALID_INPUTS;
-  switch (c.nof_prb) { case 6: case 15: case 25: case 50: case 100: break; default: return LSN_ERROR_INVALID_INPUTS; }
+  switch (c.nof_prb) { case 6: case 15: case 25: case 50: case 75: case 100: break; default: return LSN_ERROR_INVALID_INPUTS; }
   cpu_set_t saved_mask;
   const bool pinned = pinThisThread(&saved_mask);  // pinned host buffers are first touched on the GPU's node
   struct Unpin { Engine* e; bool on; cpu_set_t* m; ~Unpin() { if (on) e->unpinThisThread(m); } } unpin{this, pinned, &saved_mask};

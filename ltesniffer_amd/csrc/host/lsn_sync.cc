@@ -38,6 +38,7 @@ static uint32_t sync_fft_size(uint32_t nof_prb)
     case 15: return 256;
     case 25: return 512;
     case 50: return 1024;
+    case 75: return 1536;
     case 100: return 2048;
     default: return 0;
   }

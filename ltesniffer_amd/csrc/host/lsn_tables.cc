@@ -27,7 +27,7 @@ void gold_sequence(uint32_t cinit, uint8_t* c, int len)
 
 static int fft_size_for(uint32_t nprb)
 {
-  switch (nprb) { case 6: return 128; case 15: return 256; case 25: return 512; case 50: return 1024; case 100: return 2048; default: return -1; }
+  switch (nprb) { case 6: return 128; case 15: return 256; case 25: return 512; case 50: return 1024; case 75: return 1536; case 100: return 2048; default: return -1; }
 }
 
 template <typename T>
@@ -157,11 +157,17 @@ void Engine::buildTables()
   const int N = fft_size_for(nprb);
   cd = LsnCellDev{};
   cd.nof_prb = nprb; cd.nof_ports = P; cd.id = id; cd.nof_rx = dlRx(); cd.iq_nant = cfg.nof_rx_antennas;
-  cd.N = (uint32_t)N; cd.lgN = 0; while ((1 << cd.lgN) < N) cd.lgN++;
+  const int Nsub = N == 1536 ? 512 : N;  // 15 MHz: three interleaved 512-point transforms + a radix-3 combination
+  cd.N = (uint32_t)N; cd.nsub = (uint32_t)Nsub; cd.lgN = 0; while ((1 << cd.lgN) < Nsub) cd.lgN++;
   cd.nre = 12 * nprb; cd.nref = 2 * nprb; cd.sflen = 15u * (uint32_t)N;
   // FFT twiddles and NCO tables (double -> float, same generation as the oracle's definition)
-  std::vector<cf32> tw((size_t)N / 2), coarse(4096), fine(1024);
-  for (int k = 0; k < N / 2; k++) { double a = 2.0 * M_PI * k / N; tw[k] = {(float)std::cos(a), (float)(-std::sin(a))}; }
+  std::vector<cf32> tw((size_t)Nsub / 2), coarse(4096), fine(1024);
+  for (int k = 0; k < Nsub / 2; k++) { double a = 2.0 * M_PI * k / Nsub; tw[k] = {(float)std::cos(a), (float)(-std::sin(a))}; }
+  if (N != Nsub) {
+    std::vector<cf32> t3((size_t)N);
+    for (int k = 0; k < N; k++) { double a = 2.0 * M_PI * k / N; t3[k] = {(float)std::cos(a), (float)(-std::sin(a))}; }
+    cd.twiddle3 = upload(dev_allocs, t3);
+  }
   for (int k = 0; k < 4096; k++) { double a = 2.0 * M_PI * k / 4096.0; coarse[k] = {(float)std::cos(a), (float)std::sin(a)}; }
   for (int k = 0; k < 1024; k++) { double a = 2.0 * M_PI * k / 4194304.0; fine[k] = {(float)std::cos(a), (float)std::sin(a)}; }
   cd.twiddle = upload(dev_allocs, tw); cd.nco_coarse = upload(dev_allocs, coarse); cd.nco_fine = upload(dev_allocs, fine);

@@ -25,7 +25,9 @@ struct LsnChest {
 struct LsnCellDev {
   uint32_t nof_prb, nof_ports, id, nof_rx, N, lgN, nre, nref, sflen;
   uint32_t iq_nant;         // antennas interleaved in the IQ buffer ([sf][antenna][sflen]); nof_rx of them carry the downlink
-  const cf32* twiddle;      // [N/2] exp(-2 pi i k/N)
+  uint32_t nsub;            // power-of-two transform length: N, or 512 when N = 1536 = 3 x 512 (15 MHz); lgN = log2(nsub)
+  const cf32* twiddle;      // [nsub/2] exp(-2 pi i k/nsub)
+  const cf32* twiddle3;     // N = 1536 only: [1536] exp(-2 pi i k/1536) of the radix-3 combination, else null
   const cf32* nco_coarse;   // [4096]
   const cf32* nco_fine;     // [1024]
   const cf32* crs;          // [10][ports][4][nref]

@@ -59,6 +59,42 @@ __global__ __launch_bounds__(256) void k_ofdm(LsnCellDev c, const cf32* __restri
   const int pos = slot * (cp0 + 6 * cp1 + 7 * N) + cp0 + ls * (N + cp1);
   const cf32* in = iq + ((size_t)sf * c.iq_nant + rx) * c.sflen + pos;
   const uint32_t dphi = dphi_sf ? dphi_sf[sf] : 0u;
+  const int nre = (int)c.nre;
+  cf32* out = grid + (((size_t)sf * c.nof_rx + rx) * 14 + l) * nre;
+  if (c.twiddle3) {
+    // 15 MHz, N = 1536 = 3 x 512: x_r[m] = x[3 m + r] -> three 512-point transforms side by side in LDS, then
+    // X[k] = (F_0[k % 512] + F_1[k % 512] T[k]) + F_2[k % 512] T[2 k mod N] for the 900 carriers that are kept
+    const int M = (int)c.nsub;
+    for (int n = tid; n < M / 2; n += 256) w[n] = c.twiddle[n];
+    for (int n = tid; n < N; n += 256) {
+      cf32 x = in[n];
+      if (dphi != 0u) {
+        uint32_t ph = (uint32_t)(pos + n) * dphi;
+        cf32 rot = cmul(c.nco_coarse[ph >> 20], c.nco_fine[(ph >> 10) & 1023u]);
+        x = cmul(x, rot);
+      }
+      const int m = n / 3, r = n - 3 * m;
+      a[r * M + (int)(__brev((unsigned)m) >> (32 - lgN))] = x;
+    }
+    __syncthreads();
+    for (int s = 0; s < lgN; s += 3) {  // lgN = 9: three radix-8 passes per block
+      for (int r = 0; r < 3; r++) fft_pass<3>(a + r * M, w, s, M, lgN, tid);
+      __syncthreads();
+    }
+    const cf32* __restrict__ T = c.twiddle3;
+    for (int k = tid; k < nre; k += 256) {
+      const int bin = (k < nre / 2) ? (N - nre / 2 + k) : (k - nre / 2 + 1), kq = bin & (M - 1);
+      int b2 = 2 * bin;
+      b2 = b2 >= N ? b2 - N : b2;
+      const cf32 t1 = cmul(a[M + kq], T[bin]), t2 = cmul(a[2 * M + kq], T[b2]);
+      const float sr = a[kq].r + t1.r, si = a[kq].i + t1.i;
+      cf32 X;
+      X.r = sr + t2.r;
+      X.i = si + t2.i;
+      out[k] = X;
+    }
+    return;
+  }
   for (int n = tid; n < N / 2; n += 256) w[n] = c.twiddle[n];
   for (int n = tid; n < N; n += 256) {
     cf32 x = in[n];
@@ -78,8 +114,6 @@ __global__ __launch_bounds__(256) void k_ofdm(LsnCellDev c, const cf32* __restri
     else { fft_pass<1>(a, w, s, N, lgN, tid); s += 1; }
     __syncthreads();
   }
-  const int nre = (int)c.nre;
-  cf32* out = grid + (((size_t)sf * c.nof_rx + rx) * 14 + l) * nre;
   for (int k = tid; k < nre; k += 256) {
     int bin = (k < nre / 2) ? (N - nre / 2 + k) : (k - nre / 2 + 1);
     out[k] = a[bin];

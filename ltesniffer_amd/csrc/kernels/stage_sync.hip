@@ -114,12 +114,13 @@ __global__ __launch_bounds__(512) void k_sync_fin(const cf32* __restrict__ x, co
     const uint32_t kb = m < 31 ? N - 31 + m : m - 30;
     const cf32* xx = s ? x + q0 - (N + cp) : x + q0;
     float ar = 0.0f, ai = 0.0f;
-    uint32_t idx = 0;  // (kb * n) mod N, N a power of two
+    uint32_t idx = 0;  // (kb * n) mod N
     for (uint32_t n = 0; n < N; n++) {
       const cf32 v = xx[n], ww = w[idx];
       ar = ar + (v.r * ww.r - v.i * ww.i);
       ai = ai + (v.r * ww.i + v.i * ww.r);
-      idx = (idx + kb) & (N - 1);
+      idx += kb;
+      idx = idx >= N ? idx - N : idx;
     }
     Y[s][m].r = ar;
     Y[s][m].i = ai;

@@ -54,6 +54,34 @@ __global__ __launch_bounds__(256) void k_ul_fft(LsnCellDev c, const cf32* __rest
   const int slot = l / 7, ls = l % 7;
   const int pos = slot * (cp0 + 6 * cp1 + 7 * N) + cp0 + ls * (N + cp1);
   const cf32* in = iq + ((size_t)sf * nant + ant) * c.sflen + pos;
+  const int nre = (int)c.nre;
+  cf32* out = grid + ((size_t)sf * 14 + l) * nre;
+  if (c.twiddle3) {  // 15 MHz, N = 1536 = 3 x 512 (see k_ofdm)
+    const int M = (int)c.nsub;
+    for (int n = tid; n < M / 2; n += 256) w[n] = c.twiddle[n];
+    for (int n = tid; n < N; n += 256) {
+      const int m = n / 3, r = n - 3 * m;
+      a[r * M + (int)(__brev((unsigned)m) >> (32 - lgN))] = cmul(in[n], c.ul_shift[n]);
+    }
+    __syncthreads();
+    for (int s = 0; s < lgN; s += 3) {
+      for (int r = 0; r < 3; r++) ul_fft_pass<3>(a + r * M, w, s, M, lgN, tid);
+      __syncthreads();
+    }
+    const cf32* __restrict__ T = c.twiddle3;
+    for (int k = tid; k < nre; k += 256) {
+      const int bin = (k < nre / 2) ? (N - nre / 2 + k) : (k - nre / 2), kq = bin & (M - 1);
+      int b2 = 2 * bin;
+      b2 = b2 >= N ? b2 - N : b2;
+      const cf32 t1 = cmul(a[M + kq], T[bin]), t2 = cmul(a[2 * M + kq], T[b2]);
+      const float sr = a[kq].r + t1.r, si = a[kq].i + t1.i;
+      cf32 X;
+      X.r = sr + t2.r;
+      X.i = si + t2.i;
+      out[k] = X;
+    }
+    return;
+  }
   for (int n = tid; n < N / 2; n += 256) w[n] = c.twiddle[n];
   for (int n = tid; n < N; n += 256) a[__brev((unsigned)n) >> (32 - lgN)] = cmul(in[n], c.ul_shift[n]);
   __syncthreads();
@@ -65,8 +93,6 @@ __global__ __launch_bounds__(256) void k_ul_fft(LsnCellDev c, const cf32* __rest
     else { ul_fft_pass<1>(a, w, s, N, lgN, tid); s += 1; }
     __syncthreads();
   }
-  const int nre = (int)c.nre;
-  cf32* out = grid + ((size_t)sf * 14 + l) * nre;
   for (int k = tid; k < nre; k += 256) out[k] = a[(k < nre / 2) ? (N - nre / 2 + k) : (k - nre / 2)];
 }
 

@@ -82,6 +82,7 @@ float o_reduce256(const float* v, int n);
 
 /* ---------- OFDM + channel estimation + control region (o_phy.c) ---------- */
 int o_fft_size(uint32_t nof_prb);
+int o_fft_twiddle_len(int N);
 void o_fft_twiddles(int N, ocf_t* w /* N/2 */);
 void o_fft(int N, const ocf_t* w, ocf_t* a /* in place, natural order in and out */);
 /* in: 15*N samples of one subframe, cfo_phase_inc: NCO increment (0 = no correction); out: grid[14][12*nprb] */

@@ -24,17 +24,29 @@ int o_fft_size(uint32_t nof_prb)
     case 25: return 512;
     case 50: return 1024;
     case 100: return 2048;
-    default: return -1; /* 75 PRB (1536-point) not supported */
+    case 75: return 1536;
+    default: return -1;
   }
 }
 
+/* table length for o_fft_twiddles: N/2 for the power-of-two sizes; 1536 = 3 x 512: the 256 twiddles of the 512-point
+ * transform followed by the full circle exp(-2 pi i k / 1536), k < 1536, of the radix-3 combination */
+int o_fft_twiddle_len(int N) { return N == 1536 ? 256 + 1536 : N / 2; }
+
 void o_fft_twiddles(int N, ocf_t* w)
 {
-  for (int k = 0; k < N / 2; k++) {
-    double a = 2.0 * M_PI * (double)k / (double)N;
+  const int M = N == 1536 ? 512 : N;
+  for (int k = 0; k < M / 2; k++) {
+    double a = 2.0 * M_PI * (double)k / (double)M;
     w[k].r = (float)cos(a);
     w[k].i = (float)(-sin(a));
   }
+  if (N == 1536)
+    for (int k = 0; k < 1536; k++) {
+      double a = 2.0 * M_PI * (double)k / 1536.0;
+      w[256 + k].r = (float)cos(a);
+      w[256 + k].i = (float)(-sin(a));
+    }
 }
 
 static inline ocf_t cmul(ocf_t a, ocf_t b)
@@ -56,6 +68,24 @@ static inline ocf_t cmulconj(ocf_t a, ocf_t b) /* a * conj(b) */
  * v = b*w (4 mul, 1 sub, 1 add), a' = a+v, b' = a-v, including the trivial twiddles. */
 void o_fft(int N, const ocf_t* w, ocf_t* a)
 {
+  if (N == 1536) {
+    /* 15 MHz: decimation in time by three, x_r[m] = x[3 m + r] -> F_r = FFT512(x_r), then
+     * X[k] = (F_0[k % 512] + F_1[k % 512] T[k]) + F_2[k % 512] T[2 k mod 1536], T[k] = exp(-2 pi i k / 1536) */
+    static _Thread_local ocf_t sub[3][512];
+    const ocf_t* T = w + 256;
+    for (int r = 0; r < 3; r++) {
+      for (int m = 0; m < 512; m++) sub[r][m] = a[3 * m + r];
+      o_fft(512, w, sub[r]);
+    }
+    for (int k = 0; k < 1536; k++) {
+      const int kq = k % 512;
+      const ocf_t t1 = cmul(sub[1][kq], T[k]), t2 = cmul(sub[2][kq], T[(2 * k) % 1536]);
+      const float sr = sub[0][kq].r + t1.r, si = sub[0][kq].i + t1.i;
+      a[k].r = sr + t2.r;
+      a[k].i = si + t2.i;
+    }
+    return;
+  }
   int lg = 0;
   while ((1 << lg) < N) lg++;
   for (int i = 0; i < N; i++) {
@@ -111,7 +141,7 @@ void o_ofdm_rx(const o_cell_t* cell, const ocf_t* in, uint32_t dphi, ocf_t* grid
 {
   int N = o_fft_size(cell->nof_prb);
   int nre = 12 * (int)cell->nof_prb;
-  ocf_t* w = (ocf_t*)malloc(sizeof(ocf_t) * (size_t)(N / 2));
+  ocf_t* w = (ocf_t*)malloc(sizeof(ocf_t) * (size_t)o_fft_twiddle_len(N));
   ocf_t* buf = (ocf_t*)malloc(sizeof(ocf_t) * (size_t)N);
   static ocf_t coarse[4096], fine[1024];
   static int nco_init = 0;

@@ -44,7 +44,7 @@ void o_ul_shift_table(int N, ocf_t* t)
 void o_ul_fft(const o_cell_t* cell, const ocf_t* in, ocf_t* grid)
 {
   int N = o_fft_size(cell->nof_prb), nre = 12 * (int)cell->nof_prb;
-  ocf_t* w = (ocf_t*)malloc(sizeof(ocf_t) * (size_t)(N / 2));
+  ocf_t* w = (ocf_t*)malloc(sizeof(ocf_t) * (size_t)o_fft_twiddle_len(N));
   ocf_t* sh = (ocf_t*)malloc(sizeof(ocf_t) * (size_t)N);
   ocf_t* buf = (ocf_t*)malloc(sizeof(ocf_t) * (size_t)N);
   o_fft_twiddles(N, w);

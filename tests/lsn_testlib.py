@@ -432,7 +432,7 @@ def ul_make_subframe(cell, tti, grants, snr_db=30.0, seed=1):
     -> (iq complex64[15N], [payload bytes per grant])"""
     lib = txgen()
     lib.txg_ul_make.argtypes = [C.POINTER(TxgUlCell), C.c_uint32, C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
-    N = {6: 128, 15: 256, 25: 512, 50: 1024, 100: 2048}[cell.nof_prb]
+    N = {6: 128, 15: 256, 25: 512, 50: 1024, 75: 1536, 100: 2048}[cell.nof_prb]
     iq = np.zeros(15 * N, dtype=np.complex64)
     arr = (TxgUlGrant * max(1, len(grants)))(*[TxgUlGrant(g["rnti"], g.get("n_dmrs", 0), g["n_prb"], g["L_prb"], g["mod"], g["tbs"], g.get("rv", 0),
                                                            g.get("gain_db", 0.0), g.get("phase_rad", 0.0), g.get("ta_samples", 0.0),

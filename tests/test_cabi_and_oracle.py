@@ -136,8 +136,10 @@ def test_qpp_table_is_a_permutation_and_contention_free():
 def test_fft_matches_numpy():
     o = oracle()
     rng = np.random.default_rng(3)
-    for N in (128, 512, 2048):
-        w = np.zeros(N // 2, dtype=np.complex64)
+    o.o_fft_twiddle_len.argtypes = [C.c_int]
+    for N in (128, 512, 1536, 2048):  # 1536 (15 MHz) = 3 x 512 with a radix-3 combination
+        w = np.zeros(o.o_fft_twiddle_len(N), dtype=np.complex64)
+        assert w.size == (256 + 1536 if N == 1536 else N // 2)
         o.o_fft_twiddles(N, w.ctypes.data)
         x = (rng.standard_normal(N) + 1j * rng.standard_normal(N)).astype(np.complex64)
         y = x.copy()
@@ -165,8 +167,8 @@ def test_dci_conv_round_trip_noise_free():
 
 def test_transmitter_oracle_loopback_payload_equality():
     """every MAC PDU the oracle emits equals the transmitted one (high SNR); nothing spurious"""
-    for scn, n, seed in (("small", 40, 2), ("cfg1", 40, 1), ("cfg3", 24, 3)):
-        sc = scenario(scn, seed=seed)
+    for scn, n, seed, over in (("small", 40, 2, {}), ("cfg1", 40, 1, {}), ("cfg3", 24, 3, {}), ("cfg2", 16, 6, dict(nof_prb=75, cell_id=77, n_rnti=20))):
+        sc = scenario(scn, seed=seed, **over)
         tx = TxGen(**sc)
         ow = OracleWorker(sc["nof_prb"], sc["nof_ports"], sc["cell_id"], sc["nof_rx"], sc["phich_ng_x6"])
         sent = {}

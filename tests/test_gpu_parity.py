@@ -95,7 +95,7 @@ def test_device_resident_path_and_sink_callback():
 
 def test_invalid_inputs_are_rejected():
     phy = la.Phy(nof_rx_antennas=2)
-    assert not phy.setCell(75, 2, 1)       # 1536-point FFT not supported
+    assert not phy.setCell(70, 2, 1)       # not an LTE bandwidth
     assert not phy.setCell(100, 4, 1)      # 4 CRS ports not supported
     assert not phy.setCell(100, 2, 504)
     with pytest.raises(RuntimeError):

@@ -55,7 +55,7 @@ def test_cell_search_on_noise_device_input_and_invalid_arguments():
     rg2, sg2 = la.cell_search(xd.view(torch.complex64), 6, nof_periods=2)
     assert rg2 == 0
     same(sg2, so)
-    for bad in (dict(nof_prb=75), dict(nof_periods=17), dict(force_n_id_2=3), dict(nof_periods=3)):  # the last one: buffer too short
+    for bad in (dict(nof_prb=70), dict(nof_periods=17), dict(force_n_id_2=3), dict(nof_periods=3)):  # the last one: buffer too short
         kw = dict(nof_prb=6, nof_periods=2)
         kw.update(bad)
         with pytest.raises(RuntimeError):

@@ -15,7 +15,7 @@ def _scenario(nprb, cell_id, nsf, seed, snr_db=32.0, max_share=3, rvs=(0,), uci=
     rng = np.random.default_rng(seed)
     cqi_bits = oracle_ul_api().o_uci_cqi_bits(nprb)
     ucell = TxgUlCell(nprb, cell_id, 3, 5)
-    N = {25: 512, 50: 1024, 100: 2048}[nprb]
+    N = {25: 512, 50: 1024, 75: 1536, 100: 2048}[nprb]
     iq = np.zeros((nsf, 15 * N), dtype=np.complex64)
     grants, payloads = [], []
     tti0 = int(rng.integers(0, 10000))

@@ -17,7 +17,7 @@ def test_rm_index_closed_form():
     assert out.startswith("OK")
 
 
-@pytest.mark.parametrize("nprb,ports", [(6, 1), (15, 2), (25, 1), (25, 2), (50, 1), (50, 2), (100, 1), (100, 2)])
+@pytest.mark.parametrize("nprb,ports", [(6, 1), (15, 2), (25, 1), (25, 2), (50, 1), (50, 2), (75, 1), (75, 2), (100, 1), (100, 2)])
 def test_dci_sizes(nprb, ports):
     h, o = hosttest(), oracle()
     cell = OCell(nprb, ports, 1, 1)
@@ -54,7 +54,7 @@ def _oracle_grant_api():
     return o
 
 
-@pytest.mark.parametrize("nprb,ports", [(100, 2), (50, 1), (25, 2), (6, 1), (15, 2)])
+@pytest.mark.parametrize("nprb,ports", [(100, 2), (75, 2), (50, 1), (25, 2), (6, 1), (15, 2)])
 def test_dl_grants_random_payloads(nprb, ports):
     """random DCI payloads of every DL format -> identical unpack verdict, PRB set, TBS/modulation, nof_re, MIMO config"""
     h, o = hosttest(), _oracle_grant_api()
@@ -91,7 +91,7 @@ def test_dl_grants_random_payloads(nprb, ports):
 def test_ul_grants_random_payloads():
     h, o = hosttest(), _oracle_grant_api()
     rng = np.random.default_rng(9)
-    for nprb in (25, 50, 100):
+    for nprb in (25, 50, 75, 100):
         cell = OCell(nprb, 2, 1, 1)
         nb = h.lsnh_dci_format_sizeof(nprb, 2, 0)
         for it in range(500):
@@ -225,6 +225,10 @@ def test_falcon_search_small_cell():
 
 def test_falcon_search_cfg1():
     _search_parity("cfg1", 25, seed=1)
+
+
+def test_falcon_search_15mhz_cell():
+    _search_parity("cfg2", 12, seed=6, nof_prb=75, cell_id=77, n_rnti=20)
 
 
 def test_falcon_search_cfg3_meta_update():

@@ -78,7 +78,7 @@ def test_cell_search_finds_id_timing_and_cfo(scn, over, lead, cfo, periods, forc
     sc = scenario(scn, seed=5, start_tti=10 * 77 + 3, cfo_hz=cfo, **over)
     x, first_tti = sync_capture(sc, lead, periods)
     r, s, corr = oracle_cell_search(x, sc["nof_prb"], periods, force, 20.0)
-    N = {6: 128, 15: 256, 25: 512, 50: 1024, 100: 2048}[sc["nof_prb"]]
+    N = {6: 128, 15: 256, 25: 512, 50: 1024, 75: 1536, 100: 2048}[sc["nof_prb"]]
     sflen, w5 = 15 * N, 75 * N
     assert r == 1 and s.found and s.cell_id == sc["cell_id"] and s.n_id_2 == sc["cell_id"] % 3 and s.n_id_1 == sc["cell_id"] // 3
     # subframe first_tti starts at sample `lead`; the reported boundary is the first sf-0/5 start in the buffer
@@ -99,7 +99,7 @@ def test_cell_search_rejects_noise_and_short_buffers():
     assert r == 0 and not s.found and s.pss_p2avg < 20.0
     r, _, _ = oracle_cell_search(x[:-1], 6, 1, -1, 20.0)
     assert r == -1
-    r, _, _ = oracle_cell_search(x, 75, 1, -1, 20.0)
+    r, _, _ = oracle_cell_search(x, 70, 1, -1, 20.0)
     assert r == -1
     r, _, _ = oracle_cell_search(x, 6, 1, 3, 20.0)
     assert r == -1
@@ -107,7 +107,7 @@ def test_cell_search_rejects_noise_and_short_buffers():
 
 def oracle_cell_search(x, nof_prb, periods, force, threshold):
     o = oracle_sync_api()
-    N = {6: 128, 15: 256, 25: 512, 50: 1024, 100: 2048}.get(nof_prb, 128)
+    N = {6: 128, 15: 256, 25: 512, 50: 1024, 75: 1536, 100: 2048}.get(nof_prb, 128)
     corr = np.zeros((3, 75 * N), dtype=np.float32)
     cfg = OSyncCfg(periods, force, threshold)
     s = OSync()

@@ -174,6 +174,17 @@ void modulate(const bits_t& b, int Qm, std::vector<cf>& out) {
 
 // ---------------- fft (double) ----------------
 void fft_d(std::vector<std::complex<double>>& a, bool inv) {
+  if (a.size() % 3 == 0) {  // 1536 = 3 x 512 (15 MHz): three interleaved power-of-two transforms, then the radix-3 combination
+    const int N = (int)a.size(), M = N / 3;
+    std::vector<std::complex<double>> f[3];
+    for (int r = 0; r < 3; r++) { f[r].resize(M); for (int m = 0; m < M; m++) f[r][m] = a[3 * m + r]; fft_d(f[r], inv); }
+    const double ang = 2 * M_PI / N * (inv ? 1 : -1);
+    for (int k = 0; k < N; k++) {
+      std::complex<double> w1(std::cos(ang * k), std::sin(ang * k)), w2(std::cos(ang * 2 * k), std::sin(ang * 2 * k));
+      a[k] = f[0][k % M] + w1 * f[1][k % M] + w2 * f[2][k % M];
+    }
+    return;
+  }
   int N = (int)a.size(), lg = 0;
   while ((1 << lg) < N) lg++;
   for (int i = 0; i < N; i++) { int j = 0; for (int b = 0; b < lg; b++) if (i & (1 << b)) j |= 1 << (lg - 1 - b); if (j > i) std::swap(a[i], a[j]); }
@@ -247,7 +258,7 @@ struct txg {
   explicit txg(const txg_cfg_t& cfg) : c(cfg), rng(cfg.seed) {}
 };
 
-static int fft_size(uint32_t nprb) { switch (nprb) { case 6: return 128; case 15: return 256; case 25: return 512; case 50: return 1024; case 100: return 2048; default: return -1; } }
+static int fft_size(uint32_t nprb) { switch (nprb) { case 6: return 128; case 15: return 256; case 25: return 512; case 50: return 1024; case 75: return 1536; case 100: return 2048; default: return -1; } }
 
 static void build_regs(txg* g) {
   int nprb = g->c.nof_prb, nre = 12 * nprb, n0 = nre / 6, id = g->c.cell_id;
@@ -768,7 +779,7 @@ extern "C" int txg_ul_make(const txg_ul_cell_t* c, uint32_t tti, const txg_ul_gr
   Rng rng(seed * 7919ull + tti);
   const int nprb = (int)c->nof_prb, nre = 12 * nprb;
   int N = 0;
-  switch (nprb) { case 6: N = 128; break; case 15: N = 256; break; case 25: N = 512; break; case 50: N = 1024; break; case 100: N = 2048; break; default: return -1; }
+  switch (nprb) { case 6: N = 128; break; case 15: N = 256; break; case 25: N = 512; break; case 50: N = 1024; break; case 75: N = 1536; break; case 100: N = 2048; break; default: return -1; }
   const uint32_t sf = tti % 10;
   std::vector<std::complex<double>> grid((size_t)14 * nre, 0.0);
   static const uint32_t d1[8] = {0, 2, 3, 4, 6, 8, 9, 10}, d2[8] = {0, 6, 3, 4, 2, 8, 10, 9};
