@@ -204,6 +204,18 @@ void o_pbch_llr(const o_cell_t* cell, uint32_t nof_rx, const ocf_t* grid, const 
 int o_pbch_decode(const o_cell_t* cell, uint32_t nof_rx, const ocf_t* grid, const ocf_t* ce, float noise, o_mib_t* out, float* llr_out);
 int o_mib_decode_subframe(const o_cell_t* cell, uint32_t nof_rx, const ocf_t* iq, o_mib_t* out, float* llr_out);
 
+/* ---------- MAC DL-SCH walk + RRCConnectionSetup (o_rrc.c) ---------- */
+typedef struct { uint32_t lcid, is_sdu, off, len; } o_mac_subh_t;
+typedef struct { /* ltesniffer_ue_spec_config_t, MCSTracking.h:37-43 */
+  uint32_t has_ue_config;
+  float p_a;                                     /* dB */
+  uint32_t i_offset_ack, i_offset_cqi, i_offset_ri; /* betaOffset-*-Index */
+  uint32_t cqi_type;                             /* 0 wideband, 1 UE-selected sub-band, 2 higher-layer sub-band */
+  uint32_t bits_used;                            /* bits of the DL-CCCH message consumed by the decoder (test aid) */
+} o_ue_cfg_t;
+int o_mac_dlsch_parse(const uint8_t* pdu, int len, o_mac_subh_t* out, int cap);
+int o_rrc_conn_setup_decode(const uint8_t* sdu, int len, o_ue_cfg_t* out);
+
 /* ---------- PSS / SSS cell search (o_sync.c) ---------- */
 typedef struct { uint32_t nof_periods; int32_t force_n_id_2 /* -1: all three roots */; float threshold /* peak / mean of the PSS correlation power */; } o_sync_cfg_t;
 typedef struct {

@@ -1,0 +1,247 @@
+/* o_rrc.c - ORACLE (test infrastructure only): what the decode loop learns from a decoded C-RNTI transport block.
+ * Restates (a) the MAC DL-SCH PDU walk the reference does with srsran::sch_pdu::parse_packet / next / get
+ * (/root/reference/src/src/DL_Sniffer_PDSCH.cc:1041-1070, 1133-1160, 279-310) [srsRAN lib/src/mac/pdu.cc, not in tree;
+ * TS 36.321 6.1.2 / 6.2.1] and (b) PDSCH_Decoder::decode_rrc_connection_setup (DL_Sniffer_PDSCH.cc:129-181), which unpacks a
+ * DL-CCCH-Message with srsRAN's ASN.1 code [not in tree] and keeps four things of an RRCConnectionSetup: p-a, the three
+ * betaOffset indices and the aperiodic CQI report mode.  The UPER walk below follows TS 36.331 6.2.2 / 6.3.2 (Rel-8 root
+ * components; extension additions of any release are skipped through their length determinants, X.691 10.9 / 18).
+ * Pinned by the five RRCConnectionSetup messages in the reference's own capture (pcap_file_example/api_collector.pcap,
+ * committed as tests/golden/msg4_conn_setup.json): every field decodes to a legal value, the walk ends on the last octet.
+ * Not restated: DRB / SPS components (never part of a connection setup: SRB1 only) - such a message is reported as
+ * "not a connection setup", where srsRAN would decode it. */
+#include "lsn_oracle.h"
+#include <string.h>
+
+/* ---------------- MAC DL-SCH PDU ---------------- */
+static int dl_ce_size(uint32_t lcid) /* sch_subh::sizeof_ce, downlink */
+{
+  switch (lcid) {
+    case 28: return 6; /* UE contention resolution identity */
+    case 29: return 1; /* timing advance command */
+    case 27: return 1; /* SCell activation */
+    default: return 0; /* DRX command, padding, reserved */
+  }
+}
+
+/* returns the number of subheaders, 0 when the PDU does not parse (sch_pdu::parse_packet fails -> next() yields nothing) */
+int o_mac_dlsch_parse(const uint8_t* pdu, int len, o_mac_subh_t* out, int cap)
+{
+  int pos = 0, n = 0, more = 1;
+  if (len <= 0) return 0;
+  while (more && n < cap && pos < len) {
+    const uint8_t b = pdu[pos++];
+    o_mac_subh_t* s = &out[n++];
+    s->lcid = b & 0x1Fu;
+    s->is_sdu = s->lcid < 26; /* sch_subh::is_sdu: everything below the control-element LCIDs */
+    s->len = 0;
+    more = (b >> 5) & 1;
+    if (s->is_sdu && more) { /* F / L: only when another subheader follows */
+      if (pos >= len) return 0;
+      const uint8_t l = pdu[pos++];
+      s->len = l & 0x7Fu;
+      if (l & 0x80u) {
+        if (pos >= len) return 0;
+        s->len = (s->len << 8) | pdu[pos++];
+      }
+    }
+    if (more && pos >= len) return 0; /* a further subheader is announced but the PDU is used up */
+  }
+  if (more && n == cap) return 0;
+  for (int i = 0; i < n; i++) {
+    o_mac_subh_t* s = &out[i];
+    if (!s->is_sdu) s->len = (uint32_t)dl_ce_size(s->lcid);
+    s->off = (uint32_t)pos;
+    if (i == n - 1 && s->is_sdu) s->len = (uint32_t)(len - pos); /* the last SDU takes what is left */
+    pos += (int)s->len;
+    if (pos > len) return 0;
+  }
+  return n;
+}
+
+/* ---------------- UPER bit reader ---------------- */
+typedef struct { const uint8_t* p; uint32_t nbits, pos; int err; } br_t;
+static uint32_t rd(br_t* b, uint32_t n)
+{
+  uint32_t v = 0;
+  for (uint32_t i = 0; i < n; i++) {
+    if (b->pos >= b->nbits) { b->err = 1; return 0; }
+    v = (v << 1) | ((b->p[b->pos >> 3] >> (7 - (b->pos & 7))) & 1u);
+    b->pos++;
+  }
+  return v;
+}
+/* constrained whole number lb..ub in the minimum number of bits; a value above ub is a decode error */
+static uint32_t rd_int(br_t* b, uint32_t lb, uint32_t ub)
+{
+  uint32_t range = ub - lb + 1, nb = 0;
+  while ((1u << nb) < range) nb++;
+  uint32_t v = rd(b, nb);
+  if (v >= range) { b->err = 1; return lb; }
+  return lb + v;
+}
+/* general length determinant (X.691 10.9.3.5-7, unaligned) */
+static uint32_t rd_len(br_t* b)
+{
+  if (!rd(b, 1)) return rd(b, 7);
+  if (!rd(b, 1)) return rd(b, 14);
+  b->err = 1; /* fragmented lengths do not occur in these messages */
+  return 0;
+}
+/* extension additions of a SEQUENCE whose extension bit was set (X.691 18.7-9): a "normally small" count, the presence
+ * bitmap, then one open type (length in octets + content) per addition present */
+static void skip_ext(br_t* b)
+{
+  uint32_t n;
+  if (!rd(b, 1)) n = rd(b, 6) + 1; else n = rd_len(b);
+  uint32_t present = 0;
+  for (uint32_t i = 0; i < n && !b->err; i++) present += rd(b, 1);
+  for (uint32_t i = 0; i < present && !b->err; i++) {
+    const uint32_t octets = rd_len(b);
+    if (b->pos + 8u * octets > b->nbits) { b->err = 1; return; }
+    b->pos += 8u * octets;
+  }
+}
+
+static void rlc_config(br_t* b)
+{
+  if (rd(b, 1)) { b->err = 1; return; } /* a choice outside the root */
+  switch (rd(b, 2)) {
+    case 0: rd(b, 6); rd(b, 3); rd(b, 4); rd(b, 3); rd(b, 5); rd(b, 6); break; /* am: ul-AM-RLC, dl-AM-RLC */
+    case 1: rd(b, 1); rd(b, 1); rd(b, 5); break;                               /* um-Bi-Directional */
+    case 2: rd(b, 1); break;                                                   /* um-Uni-Directional-UL */
+    default: rd(b, 1); rd(b, 5); break;                                        /* um-Uni-Directional-DL */
+  }
+}
+static void logical_channel_config(br_t* b)
+{
+  const uint32_t ext = rd(b, 1), ul = rd(b, 1);
+  if (ul) {
+    const uint32_t grp = rd(b, 1);
+    rd(b, 4); rd(b, 4); rd(b, 3);
+    if (grp) rd(b, 2);
+  }
+  if (ext) skip_ext(b);
+}
+static void mac_main_config(br_t* b)
+{
+  const uint32_t ext = rd(b, 1), ulsch = rd(b, 1), drx = rd(b, 1), phr = rd(b, 1);
+  if (ulsch) {
+    const uint32_t harq = rd(b, 1), bsr = rd(b, 1);
+    if (harq) rd(b, 4);
+    if (bsr) rd(b, 4);
+    rd(b, 3); rd(b, 1);
+  }
+  if (drx && rd(b, 1)) { /* setup */
+    static const uint16_t cyc[16] = {10, 20, 32, 40, 64, 80, 128, 160, 256, 320, 512, 640, 1024, 1280, 2048, 2560};
+    const uint32_t shortdrx = rd(b, 1);
+    rd(b, 4); rd(b, 5); rd(b, 3);
+    rd_int(b, 0, cyc[rd(b, 4)] - 1u);
+    if (shortdrx) { rd(b, 4); rd(b, 4); }
+  }
+  rd(b, 3); /* timeAlignmentTimerDedicated */
+  if (phr && rd(b, 1)) { rd(b, 3); rd(b, 3); rd(b, 2); }
+  if (ext) skip_ext(b);
+}
+static void tpc_pdcch_config(br_t* b)
+{
+  if (!rd(b, 1)) return; /* release */
+  rd(b, 16);
+  if (rd(b, 1)) rd_int(b, 1, 31); else rd_int(b, 1, 15);
+}
+
+/* 1: an RRCConnectionSetup, *out filled; 0: anything else (decode_rrc_connection_setup returns SRSRAN_ERROR) */
+int o_rrc_conn_setup_decode(const uint8_t* sdu, int len, o_ue_cfg_t* out)
+{
+  static const float p_a_db[8] = {-6.0f, -4.77f, -3.0f, -1.77f, 0.0f, 1.0f, 2.0f, 3.0f}; /* DL_Sniffer_PDSCH.cc:3 */
+  br_t br = {sdu, len > 0 ? 8u * (uint32_t)len : 0u, 0, 0};
+  br_t* b = &br;
+  memset(out, 0, sizeof *out); /* ltesniffer_ue_spec_config_t ue_config = {}: p_a 0 dB, offsets 0, CQI type 0 = wideband */
+  if (rd(b, 1)) return 0;      /* DL-CCCH-MessageType: c1 */
+  if (rd(b, 2) != 3) return 0; /* c1: reestablishment, reestablishmentReject, reject, setup */
+  rd(b, 2);                    /* rrc-TransactionIdentifier */
+  if (rd(b, 1)) return 0;      /* criticalExtensions: c1 */
+  if (rd(b, 3) != 0) return 0; /* c1: rrcConnectionSetup-r8 */
+  const uint32_t noncrit = rd(b, 1);
+  /* RadioResourceConfigDedicated */
+  const uint32_t rr_ext = rd(b, 1), srb = rd(b, 1), drb_add = rd(b, 1), drb_rel = rd(b, 1), mac = rd(b, 1), sps = rd(b, 1), phy = rd(b, 1);
+  if (drb_add || sps) return 0; /* see the header: not part of a connection setup */
+  if (srb) {
+    const uint32_t n = rd(b, 1) + 1;
+    for (uint32_t i = 0; i < n && !b->err; i++) {
+      const uint32_t ext = rd(b, 1), rlc = rd(b, 1), lc = rd(b, 1);
+      rd(b, 1); /* srb-Identity */
+      if (rlc && !rd(b, 1)) rlc_config(b);
+      if (lc && !rd(b, 1)) logical_channel_config(b);
+      if (ext) skip_ext(b);
+    }
+  }
+  if (drb_rel) {
+    const uint32_t n = rd_int(b, 1, 11);
+    for (uint32_t i = 0; i < n; i++) rd(b, 5);
+  }
+  if (mac && !rd(b, 1)) mac_main_config(b);
+  if (phy) {
+    const uint32_t ext = rd(b, 1);
+    uint32_t f[10];
+    for (int i = 0; i < 10; i++) f[i] = rd(b, 1);
+    if (f[0]) out->p_a = p_a_db[rd(b, 3)]; /* pdsch-ConfigDedicated */
+    if (f[1]) {                            /* pucch-ConfigDedicated */
+      const uint32_t tdd = rd(b, 1);
+      if (rd(b, 1)) { rd(b, 2); rd(b, 11); }
+      if (tdd) rd(b, 1);
+    }
+    if (f[2]) { /* pusch-ConfigDedicated: betaOffset-ACK-Index, betaOffset-RI-Index, betaOffset-CQI-Index */
+      out->i_offset_ack = rd(b, 4);
+      out->i_offset_ri = rd(b, 4);
+      out->i_offset_cqi = rd(b, 4);
+    }
+    if (f[3]) { /* uplinkPowerControlDedicated */
+      const uint32_t fc = rd(b, 1);
+      rd(b, 4); rd(b, 1); rd(b, 1); rd(b, 4); rd(b, 4);
+      if (fc) { if (rd(b, 1)) b->err = 1; rd(b, 4); }
+    }
+    if (f[4]) tpc_pdcch_config(b);
+    if (f[5]) tpc_pdcch_config(b);
+    if (f[6]) { /* cqi-ReportConfig */
+      const uint32_t aper = rd(b, 1), per = rd(b, 1);
+      if (aper) {
+        const uint32_t m = rd(b, 3); /* rm12, rm20, rm22, rm30, rm31, spare */
+        if (m == 0) out->cqi_type = 0;                 /* SRSRAN_CQI_TYPE_WIDEBAND */
+        else if (m == 1 || m == 2) out->cqi_type = 1;  /* SUBBAND_UE */
+        else if (m == 3 || m == 4) out->cqi_type = 2;  /* SUBBAND_HL */
+      }
+      rd(b, 3); /* nomPDSCH-RS-EPRE-Offset */
+      if (per && rd(b, 1)) {
+        const uint32_t ri = rd(b, 1);
+        rd_int(b, 0, 1185);
+        rd(b, 10);
+        if (rd(b, 1)) rd(b, 2);
+        if (ri) rd(b, 10);
+        rd(b, 1);
+      }
+    }
+    if (f[7] && rd(b, 1)) { rd(b, 2); rd(b, 2); rd_int(b, 0, 23); rd(b, 1); rd(b, 10); rd(b, 1); rd(b, 3); } /* soundingRS-UL-ConfigDedicated */
+    if (f[8] && !rd(b, 1)) { /* antennaInfo: explicitValue */
+      static const uint8_t cbsr_bits[8] = {2, 4, 6, 64, 4, 16, 4, 16};
+      const uint32_t cb = rd(b, 1);
+      rd(b, 3);
+      if (cb) {
+        uint32_t nb = cbsr_bits[rd(b, 3)];
+        while (nb) { const uint32_t k = nb > 16 ? 16 : nb; rd(b, k); nb -= k; }
+      }
+      if (rd(b, 1)) rd(b, 1);
+    }
+    if (f[9] && rd(b, 1)) { rd(b, 11); rd_int(b, 0, 157); rd(b, 3); } /* schedulingRequestConfig */
+    if (ext) skip_ext(b);
+  }
+  if (rr_ext) skip_ext(b);
+  if (noncrit) { /* RRCConnectionSetup-v8a0-IEs: lateNonCriticalExtension OCTET STRING, empty nonCriticalExtension */
+    const uint32_t late = rd(b, 1), more = rd(b, 1);
+    if (late) { const uint32_t octets = rd_len(b); if (b->pos + 8u * octets > b->nbits) b->err = 1; else b->pos += 8u * octets; }
+    (void)more;
+  }
+  if (b->err) return 0;
+  out->has_ue_config = 1;
+  out->bits_used = b->pos;
+  return 1;
+}

@@ -32,5 +32,27 @@ for name in ("ltesniffer_dl_mode.pcap", "ltesniffer_ul_mode.pcap", "api_collecto
     out[name]["random_access"] = proc
     out[name]["pdu_lengths"] = {"%d/%d" % (d, t): sorted({len(q["pdu"]) for q in full if q["direction"] == d and q["rnti_type"] == t})
                                 for d, t in sorted({(q["direction"], q["rnti_type"]) for q in full})}
+    # downlink C-RNTI MAC PDUs: the contention-resolution messages (a CCCH SDU = RRCConnectionSetup behind a contention resolution
+    # identity) in full, and (lcid, length) lists of a sample of the others, walked by the independent parser below
+    def walk(p):
+        pos, subs, more = 0, [], True
+        while more:
+            b = p[pos]; pos += 1
+            lcid, more, ln = b & 31, bool(b & 32), None
+            if lcid < 26 and more:
+                ln = p[pos] & 127
+                if p[pos] & 128:
+                    ln = (ln << 8) | p[pos + 1]; pos += 1
+                pos += 1
+            subs.append([lcid, ln])
+        for s_ in subs:
+            if s_[0] >= 26:
+                s_[1] = {28: 6, 29: 1, 27: 1}.get(s_[0], 0)
+        if subs[-1][1] is None:
+            subs[-1][1] = len(p) - pos - sum(x[1] for x in subs[:-1])
+        return subs
+    dl = [q for q in full if q["direction"] == 1 and q["rnti_type"] == 3]
+    out[name]["dl_crnti_walks"] = [dict(pdu_head=q["pdu"][:24].hex(), length=len(q["pdu"]), subheaders=walk(q["pdu"])) for q in dl[:60]]
+    out[name]["conn_setup"] = [dict(rnti=q["rnti"], pdu=q["pdu"].hex()) for q in dl if len(q["pdu"]) > 8 and q["pdu"][0] == 0x3C and (q["pdu"][1] & 31) == 0]
 json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "pcap_records.json"), "w"), indent=0)
 print({k: (v["nof_records"], len(v["records"])) for k, v in out.items()})
