@@ -690,7 +690,42 @@ McsTable MCSTracking::find_tracking_info_RNTI_dl(uint16_t rnti) const
   if (!db[rnti].present) return count < max_size ? TABLE_UNKNOWN : TABLE_FULL_BUFFER;
   return (McsTable)db[rnti].table;
 }
-void MCSTracking::add_RNTI_dl(uint16_t rnti) { if (!db[rnti].present) { db[rnti] = Entry(); db[rnti].present = 1; count++; } }
+void MCSTracking::add_RNTI_dl(uint16_t rnti)
+{
+  if (db[rnti].present) return;
+  db[rnti] = Entry();
+  db[rnti].present = 1;
+  count++;
+  ue_cfg[rnti] = default_cfg;  // MCSTracking.cc:791-792
+  ue_cfg[rnti].has_ue_config = false;
+}
+UeSpecConfig MCSTracking::get_ue_config_rnti(uint16_t rnti) const
+{
+  if (db[rnti].present) return ue_cfg[rnti];
+  UeSpecConfig c = default_cfg;
+  c.has_ue_config = false;
+  return c;
+}
+void MCSTracking::update_ue_config_rnti(uint16_t rnti, const UeSpecConfig& c)
+{
+  add_RNTI_dl(rnti);
+  ue_cfg[rnti] = c;
+}
+bool MCSTracking::learn_from_pdu(const uint8_t* pdu, int len, uint16_t rnti)
+{
+  MacSubheader sub[20];
+  const int n = mac_dlsch_parse(pdu, len, sub, 20);
+  bool any = false;
+  for (int i = 0; i < n; i++) {
+    if (!(sub[i].is_sdu && sub[i].lcid == 0)) continue;
+    UeSpecConfig c;
+    if (!rrc_conn_setup_decode(pdu + sub[i].off, (int)sub[i].len, c)) continue;
+    if (!has_default) update_default_ue_config(c);  // the first connection setup seen, DL_Sniffer_PDSCH.cc:1061-1065
+    update_ue_config_rnti(rnti, c);
+    any = true;
+  }
+  return any;
+}
 void MCSTracking::update_RNTI_dl(uint16_t rnti, McsTable t)
 {
   Entry& e = db[rnti];

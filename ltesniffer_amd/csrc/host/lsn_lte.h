@@ -150,19 +150,41 @@ private:
   double split_ratio;
 };
 
-// ---- MCSTracking (DL table learning only; MCSTracking.cc:758-848,1269-1291) ----
+// ---- MAC DL-SCH walk and RRCConnectionSetup (lsn_rrc.cc) ----
+struct MacSubheader { uint32_t lcid = 0; bool is_sdu = false; uint32_t off = 0, len = 0; };
+// sch_pdu::parse_packet: number of subheaders with payload offsets / lengths, 0 when the PDU does not parse
+int mac_dlsch_parse(const uint8_t* pdu, int len, MacSubheader* out, int cap);
+struct UeSpecConfig {  // ltesniffer_ue_spec_config_t, MCSTracking.h:37-43
+  bool has_ue_config = false;
+  float p_a = 0.0f;                                         // dB
+  uint32_t i_offset_ack = 10, i_offset_cqi = 8, i_offset_ri = 11;  // MCSTracking::set_default_of_default_config, MCSTracking.cc:1531-1540
+  uint32_t cqi_type = 2;                                    // 0 wideband, 1 UE-selected sub-band, 2 higher-layer sub-band
+};
+// PDSCH_Decoder::decode_rrc_connection_setup: true when the CCCH SDU is an RRCConnectionSetup (out filled)
+bool rrc_conn_setup_decode(const uint8_t* sdu, int len, UeSpecConfig& out);
+
+// ---- MCSTracking (DL table learning + UE-specific configuration; MCSTracking.cc:758-848,1269-1291,1444-1540) ----
 class MCSTracking {
 public:
+  UeSpecConfig get_ue_config_rnti(uint16_t rnti) const;         // the entry's configuration, else the default
+  void update_ue_config_rnti(uint16_t rnti, const UeSpecConfig& c);
+  bool check_default_config() const { return has_default; }
+  void update_default_ue_config(const UeSpecConfig& c) { default_cfg = c; has_default = true; }
+  // one decoded C-RNTI transport block: every CCCH SDU is tried as RRCConnectionSetup (DL_Sniffer_PDSCH.cc:1041-1070); true when one was
+  bool learn_from_pdu(const uint8_t* pdu, int len, uint16_t rnti);
   McsTable find_tracking_info_RNTI_dl(uint16_t rnti) const;
   void update_RNTI_dl(uint16_t rnti, McsTable t);
   void update_rar_time_crnti(uint16_t crnti);
   void update_statistic_dl(uint16_t rnti, DciFormat f);
   McsTable peek(uint16_t rnti) const { return db[rnti].present ? (McsTable)db[rnti].table : TABLE_UNKNOWN; }
-  MCSTracking() : db(65536) {}
+  MCSTracking() : db(65536), ue_cfg(65536) {}
 private:
   struct Entry { uint8_t present = 0, has_rar = 0, table = TABLE_UNKNOWN; uint16_t nof_msg_after_rar = 0; };
   void add_RNTI_dl(uint16_t rnti);
   std::vector<Entry> db;
+  std::vector<UeSpecConfig> ue_cfg;  // [65536], valid where db[].present
+  UeSpecConfig default_cfg;
+  bool has_default = false;
   uint32_t count = 0;
   static constexpr uint32_t max_size = 250;  // MCSTracking.h:30
   static constexpr uint16_t rar_thresold = 3;

@@ -1,0 +1,237 @@
+// lsn_rrc.cc - what the decode loop reads out of a decoded C-RNTI transport block before the next grant is decoded:
+//  * the MAC DL-SCH PDU walk the reference does with srsran::sch_pdu (parse_packet / next / get:
+//    /root/reference/src/src/DL_Sniffer_PDSCH.cc:1041-1070, 1133-1160, 279-310; TS 36.321 6.1.2, 6.2.1), and
+//  * PDSCH_Decoder::decode_rrc_connection_setup (DL_Sniffer_PDSCH.cc:129-181): an RRCConnectionSetup on the CCCH gives the UE's
+//    p-a (PDSCH power offset used by every later decode of that RNTI, :926-927), the betaOffset indices and the aperiodic CQI
+//    report mode (used by the PUSCH decoder in UL mode, UL_Sniffer_PUSCH.cc:433-435).
+// The reference unpacks the whole DL-CCCH-Message with srsRAN's generated ASN.1 code; here the UPER encoding (TS 36.331 6.2.2 /
+// 6.3.2, X.691) is walked directly: Rel-8 root components are read, extension additions are skipped by their length
+// determinants.  Messages that carry DRB or SPS components (never the case for a connection setup) are not accepted.
+// HIP-free host code: built into the product library and, for the CPU tests, into tests/native.
+#include "lsn_lte.h"
+#include <cstring>
+
+namespace lsn {
+
+int mac_dlsch_parse(const uint8_t* pdu, int len, MacSubheader* out, int cap)
+{
+  if (len <= 0) return 0;
+  int pos = 0, n = 0;
+  bool more = true;
+  while (more && n < cap && pos < len) {
+    const uint8_t b = pdu[pos++];
+    MacSubheader& s = out[n++];
+    s.lcid = b & 0x1Fu;
+    s.is_sdu = s.lcid < 26;  // LCIDs below the control elements (sch_subh::is_sdu)
+    s.len = 0;
+    more = (b & 0x20u) != 0;
+    if (s.is_sdu && more) {  // F / L exist only when another subheader follows
+      if (pos >= len) return 0;
+      const uint8_t l = pdu[pos++];
+      s.len = l & 0x7Fu;
+      if (l & 0x80u) {
+        if (pos >= len) return 0;
+        s.len = (s.len << 8) | pdu[pos++];
+      }
+    }
+    if (more && pos >= len) return 0;
+  }
+  if (more && n == cap) return 0;
+  for (int i = 0; i < n; i++) {
+    MacSubheader& s = out[i];
+    if (!s.is_sdu) s.len = s.lcid == 28 ? 6u : (s.lcid == 29 || s.lcid == 27) ? 1u : 0u;  // contention resolution id, TA command, SCell activation
+    s.off = (uint32_t)pos;
+    if (i == n - 1 && s.is_sdu) s.len = (uint32_t)(len - pos);  // the last SDU has no length field
+    pos += (int)s.len;
+    if (pos > len) return 0;
+  }
+  return n;
+}
+
+namespace {
+struct BitReader {
+  const uint8_t* p;
+  uint32_t nbits, pos = 0;
+  bool err = false;
+  uint32_t get(uint32_t n)
+  {
+    uint32_t v = 0;
+    for (uint32_t i = 0; i < n; i++) {
+      if (pos >= nbits) { err = true; return 0; }
+      v = (v << 1) | ((p[pos >> 3] >> (7 - (pos & 7))) & 1u);
+      pos++;
+    }
+    return v;
+  }
+  bool flag() { return get(1) != 0; }
+  uint32_t integer(uint32_t lb, uint32_t ub)  // constrained whole number
+  {
+    const uint32_t range = ub - lb + 1;
+    uint32_t nb = 0;
+    while ((1u << nb) < range) nb++;
+    const uint32_t v = get(nb);
+    if (v >= range) { err = true; return lb; }
+    return lb + v;
+  }
+  uint32_t length()  // general length determinant, unaligned
+  {
+    if (!flag()) return get(7);
+    if (!flag()) return get(14);
+    err = true;
+    return 0;
+  }
+  void skipOctets(uint32_t n)
+  {
+    if (pos + 8u * n > nbits) { err = true; return; }
+    pos += 8u * n;
+  }
+  void skipExtensions()  // extension additions of a SEQUENCE whose extension bit is set
+  {
+    const uint32_t n = !flag() ? get(6) + 1 : length();
+    uint32_t present = 0;
+    for (uint32_t i = 0; i < n && !err; i++) present += get(1);
+    for (uint32_t i = 0; i < present && !err; i++) skipOctets(length());
+  }
+};
+
+void rlcConfig(BitReader& b)
+{
+  if (b.flag()) { b.err = true; return; }
+  switch (b.get(2)) {
+    case 0: b.get(6); b.get(3); b.get(4); b.get(3); b.get(5); b.get(6); break;  // am
+    case 1: b.get(1); b.get(1); b.get(5); break;                                // um-Bi-Directional
+    case 2: b.get(1); break;                                                    // um-Uni-Directional-UL
+    default: b.get(1); b.get(5); break;                                         // um-Uni-Directional-DL
+  }
+}
+void logicalChannelConfig(BitReader& b)
+{
+  const bool ext = b.flag(), ul = b.flag();
+  if (ul) {
+    const bool grp = b.flag();
+    b.get(4); b.get(4); b.get(3);
+    if (grp) b.get(2);
+  }
+  if (ext) b.skipExtensions();
+}
+void macMainConfig(BitReader& b)
+{
+  const bool ext = b.flag(), ulsch = b.flag(), drx = b.flag(), phr = b.flag();
+  if (ulsch) {
+    const bool harq = b.flag(), bsr = b.flag();
+    if (harq) b.get(4);
+    if (bsr) b.get(4);
+    b.get(3); b.get(1);
+  }
+  if (drx && b.flag()) {
+    static const uint16_t kCycle[16] = {10, 20, 32, 40, 64, 80, 128, 160, 256, 320, 512, 640, 1024, 1280, 2048, 2560};
+    const bool shortDrx = b.flag();
+    b.get(4); b.get(5); b.get(3);
+    b.integer(0, kCycle[b.get(4)] - 1u);
+    if (shortDrx) { b.get(4); b.get(4); }
+  }
+  b.get(3);
+  if (phr && b.flag()) { b.get(3); b.get(3); b.get(2); }
+  if (ext) b.skipExtensions();
+}
+void tpcPdcchConfig(BitReader& b)
+{
+  if (!b.flag()) return;
+  b.get(16);
+  if (b.flag()) b.integer(1, 31); else b.integer(1, 15);
+}
+}  // namespace
+
+bool rrc_conn_setup_decode(const uint8_t* sdu, int len, UeSpecConfig& out)
+{
+  static const float kPaDb[8] = {-6.0f, -4.77f, -3.0f, -1.77f, 0.0f, 1.0f, 2.0f, 3.0f};  // DL_Sniffer_PDSCH.cc:3
+  BitReader b{sdu, len > 0 ? 8u * (uint32_t)len : 0u};
+  out = UeSpecConfig();  // ltesniffer_ue_spec_config_t ue_config = {}
+  out.p_a = 0.0f; out.i_offset_ack = out.i_offset_cqi = out.i_offset_ri = 0; out.cqi_type = 0;
+  if (b.flag()) return false;        // DL-CCCH-MessageType c1
+  if (b.get(2) != 3) return false;   // rrcConnectionSetup
+  b.get(2);                          // rrc-TransactionIdentifier
+  if (b.flag()) return false;        // criticalExtensions c1
+  if (b.get(3) != 0) return false;   // rrcConnectionSetup-r8
+  const bool noncrit = b.flag();
+  const bool rrExt = b.flag(), srb = b.flag(), drbAdd = b.flag(), drbRel = b.flag(), mac = b.flag(), sps = b.flag(), phy = b.flag();
+  if (drbAdd || sps) return false;
+  if (srb) {
+    const uint32_t n = b.get(1) + 1;
+    for (uint32_t i = 0; i < n && !b.err; i++) {
+      const bool ext = b.flag(), rlc = b.flag(), lc = b.flag();
+      b.get(1);
+      if (rlc && !b.flag()) rlcConfig(b);
+      if (lc && !b.flag()) logicalChannelConfig(b);
+      if (ext) b.skipExtensions();
+    }
+  }
+  if (drbRel) {
+    const uint32_t n = b.integer(1, 11);
+    for (uint32_t i = 0; i < n; i++) b.get(5);
+  }
+  if (mac && !b.flag()) macMainConfig(b);
+  if (phy) {
+    const bool ext = b.flag();
+    bool f[10];
+    for (bool& x : f) x = b.flag();
+    if (f[0]) out.p_a = kPaDb[b.get(3)];
+    if (f[1]) {
+      const bool tdd = b.flag();
+      if (b.flag()) { b.get(2); b.get(11); }
+      if (tdd) b.get(1);
+    }
+    if (f[2]) {
+      out.i_offset_ack = b.get(4);
+      out.i_offset_ri = b.get(4);
+      out.i_offset_cqi = b.get(4);
+    }
+    if (f[3]) {
+      const bool fc = b.flag();
+      b.get(4); b.get(1); b.get(1); b.get(4); b.get(4);
+      if (fc) { if (b.flag()) b.err = true; b.get(4); }
+    }
+    if (f[4]) tpcPdcchConfig(b);
+    if (f[5]) tpcPdcchConfig(b);
+    if (f[6]) {
+      const bool aper = b.flag(), per = b.flag();
+      if (aper) {
+        const uint32_t m = b.get(3);  // rm12, rm20, rm22, rm30, rm31
+        if (m == 0) out.cqi_type = 0; else if (m <= 2) out.cqi_type = 1; else if (m <= 4) out.cqi_type = 2;
+      }
+      b.get(3);
+      if (per && b.flag()) {
+        const bool ri = b.flag();
+        b.integer(0, 1185);
+        b.get(10);
+        if (b.flag()) b.get(2);
+        if (ri) b.get(10);
+        b.get(1);
+      }
+    }
+    if (f[7] && b.flag()) { b.get(2); b.get(2); b.integer(0, 23); b.get(1); b.get(10); b.get(1); b.get(3); }
+    if (f[8] && !b.flag()) {
+      static const uint8_t kCbsrBits[8] = {2, 4, 6, 64, 4, 16, 4, 16};
+      const bool cb = b.flag();
+      b.get(3);
+      if (cb) {
+        uint32_t nb = kCbsrBits[b.get(3)];
+        while (nb) { const uint32_t k = nb > 16 ? 16 : nb; b.get(k); nb -= k; }
+      }
+      if (b.flag()) b.get(1);
+    }
+    if (f[9] && b.flag()) { b.get(11); b.integer(0, 157); b.get(3); }
+    if (ext) b.skipExtensions();
+  }
+  if (rrExt) b.skipExtensions();
+  if (noncrit) {
+    const bool late = b.flag();
+    b.flag();
+    if (late) b.skipOctets(b.length());
+  }
+  if (b.err) return false;
+  out.has_ue_config = true;
+  return true;
+}
+
+}  // namespace lsn

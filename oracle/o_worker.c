@@ -12,8 +12,8 @@
  * Deviations that any deterministic restatement needs (DESIGN.md "determinism"): wall-clock / clock() fields are
  * dropped; grants that the reference leaves uninitialised (new srsran_pdsch_grant_t without the table's
  * dci_to_grant call, DL_Sniffer_PDSCH.cc:887 reads them) are defined as "not computed" and the decode gate is
- * evaluated on the grant that is actually used; RRC ConnectionSetup parsing (p_a feedback) is out of scope
- *  so p_a stays at the MCSTracking default 0 dB (MCSTracking.cc:1536). */
+ * evaluated on the grant that is actually used; the p-a of a UE comes from its RRCConnectionSetup (o_rrc.c), until then the
+ * MCSTracking default 0 dB (MCSTracking.cc:1536). */
 #include "lsn_oracle.h"
 #include <math.h>
 #include <stdlib.h>
@@ -50,6 +50,9 @@ struct o_worker {
   o_stats_t stats;
   mcs_entry_t* mcs; /* [65536] */
   uint32_t mcs_count;
+  o_ue_cfg_t* uecfg; /* [65536] ue_spec_config of the tracking-database entries (MCSTracking.h:37-43) */
+  o_ue_cfg_t default_cfg;
+  int has_default_cfg;
   /* per-subframe state */
   ocf_t *grid, *ce;
   float* llr;
@@ -138,6 +141,13 @@ o_worker_t* o_worker_new(const o_worker_cfg_t* cfg)
   w->ce = (ocf_t*)calloc((size_t)cfg->cell.nof_ports * cfg->nof_rx * 14u * nre, sizeof(ocf_t));
   w->llr = (float*)calloc(8 * 800, sizeof(float));
   w->mcs = (mcs_entry_t*)calloc(65536, sizeof(mcs_entry_t));
+  w->uecfg = (o_ue_cfg_t*)calloc(65536, sizeof(o_ue_cfg_t));
+  /* MCSTracking::set_default_of_default_config (:1531-1540) */
+  w->default_cfg.p_a = 0.0f;
+  w->default_cfg.i_offset_ack = 10;
+  w->default_cfg.i_offset_cqi = 8;
+  w->default_cfg.i_offset_ri = 11;
+  w->default_cfg.cqi_type = 2;
   w->llr0 = (int16_t*)calloc(14u * nre * 8u, sizeof(int16_t));
   w->llr1 = (int16_t*)calloc(14u * nre * 8u, sizeof(int16_t));
   w->payload = (uint8_t*)calloc(32768, 1);
@@ -148,7 +158,7 @@ void o_worker_free(o_worker_t* w)
 {
   if (!w) return;
   o_rntiman_free(w->rm);
-  free(w->grid); free(w->ce); free(w->llr); free(w->mcs); free(w->llr0); free(w->llr1); free(w->payload);
+  free(w->grid); free(w->ce); free(w->llr); free(w->mcs); free(w->uecfg); free(w->llr0); free(w->llr1); free(w->payload);
   free(w->ul_grid); free(w->ul_sched); free(w->rar_sched); free(w->ulmod);
   free(w);
 }
@@ -183,6 +193,34 @@ static void mcs_add(o_worker_t* w, uint16_t rnti)
     w->mcs[rnti].present = 1;
     w->mcs[rnti].table = O_TABLE_UNKNOWN;
     w->mcs_count++;
+    w->uecfg[rnti] = w->default_cfg; /* add_RNTI_dl, MCSTracking.cc:785-795 */
+    w->uecfg[rnti].has_ue_config = 0;
+  }
+}
+/* MCSTracking::get_ue_config_rnti (:1482-1516): the entry's configuration, or the default for an RNTI without entry */
+static o_ue_cfg_t ue_cfg_get(o_worker_t* w, uint16_t rnti)
+{
+  if (w->mcs[rnti].present) return w->uecfg[rnti];
+  o_ue_cfg_t c = w->default_cfg;
+  c.has_ue_config = 0;
+  return c;
+}
+/* a decoded C-RNTI transport block: sch_pdu walk, every CCCH SDU (LCID 0) is tried as RRCConnectionSetup; the first one ever
+ * seen also becomes the default of RNTIs without entry (DL_Sniffer_PDSCH.cc:1041-1070, 1133-1160) */
+static void learn_conn_setup(o_worker_t* w, const uint8_t* pdu, int len, uint16_t rnti)
+{
+  o_mac_subh_t sub[20];
+  const int n = o_mac_dlsch_parse(pdu, len, sub, 20);
+  for (int i = 0; i < n; i++) {
+    if (!(sub[i].is_sdu && sub[i].lcid == 0)) continue;
+    o_ue_cfg_t c;
+    if (!o_rrc_conn_setup_decode(pdu + sub[i].off, (int)sub[i].len, &c)) continue;
+    if (!w->has_default_cfg) {
+      w->default_cfg = c; /* update_default_ue_config, :1518-1529 */
+      w->has_default_cfg = 1;
+    }
+    mcs_add(w, rnti); /* update_ue_config_rnti, :1446-1480 */
+    w->uecfg[rnti] = c;
   }
 }
 static void mcs_update(o_worker_t* w, uint16_t rnti, int table) /* MCSTracking.cc:797-825 */
@@ -576,8 +614,11 @@ static void decode_grant(o_worker_t* w, const dl_entry_t* e, const o_pdsch_grant
   if (!(g->tb[0].enabled || g->tb[1].enabled)) return;
   memset(w->llr0, 0, sizeof(int16_t) * g->nof_re * 8);
   memset(w->llr1, 0, sizeof(int16_t) * g->nof_re * 8);
+  /* pdsch_cfg->p_a: the UE's p-a from its RRCConnectionSetup (or the default) in DL mode, DL_Sniffer_PDSCH.cc:926-927; the UL-mode
+   * decoders never set it and run with the initial -3 dB of SubframeWorker::set_pdsch_uecfg (SubframeWorker.cc:370) */
+  const float p_a = w->ul_mode ? -3.0f : ue_cfg_get(w, e->rnti).p_a;
   if (o_pdsch_demod(&w->cfg.cell, w->cfg.nof_rx, w->sf_idx, w->cfi, e->rnti, g, w->grid, w->ce, w->chest.noise_avg,
-                    w->chest.chan_ref, 0.0f, w->llr0, w->llr1))
+                    w->chest.chan_ref, p_a, w->llr0, w->llr1))
     return;
   for (int i = 0; i < 2; i++)
     if (g->tb[i].enabled && g->tb[i].tbs > 0) {
@@ -614,6 +655,7 @@ static void decode_dl_mode(o_worker_t* w)
           if (crc[tb] && len > 0) {
             write_pcap(w, name, w->payload + tb * 16384, (uint32_t)len, e->rnti, tti);
             if (name[0] == 'R') unpack_rar(w, w->payload + tb * 16384, len);
+            if (name[0] == 'C') learn_conn_setup(w, w->payload + tb * 16384, len, e->rnti);
           }
         }
       }
@@ -626,6 +668,7 @@ static void decode_dl_mode(o_worker_t* w)
           if (crc[tb] && len > 0) {
             write_pcap(w, name, w->payload + tb * 16384, (uint32_t)len, e->rnti, tti);
             if (name[0] == 'R') unpack_rar(w, w->payload + tb * 16384, len);
+            if (name[0] == 'C') learn_conn_setup(w, w->payload + tb * 16384, len, e->rnti);
             if (e->dci.tb[tb].mcs_idx > 0 && e->dci.tb[tb].mcs_idx < 29 && e->format > O_FMT1A) mcs_update(w, e->rnti, O_TABLE_64QAM);
           }
         }

@@ -48,7 +48,8 @@ class TxgCfg(C.Structure):
                 ("ul_min", C.c_uint32), ("ul_max", C.c_uint32), ("cfi", C.c_uint32), ("mix_tm3_pct", C.c_uint32),
                 ("mix_tm4_pct", C.c_uint32), ("pct_256qam", C.c_uint32), ("mcs_min", C.c_uint32), ("mcs_max", C.c_uint32),
                 ("sib_period", C.c_uint32), ("rar_period", C.c_uint32), ("paging_period", C.c_uint32),
-                ("start_tti", C.c_uint32), ("fixed_L", C.c_uint32), ("pct_rv", C.c_uint32), ("pct_cqi_req", C.c_uint32), ("pct_hop", C.c_uint32), ("pusch_hop_offset", C.c_uint32)]
+                ("start_tti", C.c_uint32), ("fixed_L", C.c_uint32), ("pct_rv", C.c_uint32), ("pct_cqi_req", C.c_uint32), ("pct_hop", C.c_uint32), ("pusch_hop_offset", C.c_uint32),
+                ("msg4_period", C.c_uint32), ("msg4_p_a_idx", C.c_uint32)]
 
 
 class TxgPdu(C.Structure):
@@ -147,7 +148,7 @@ def txgen():
 def scenario(name, seed=1, **over):
     base = dict(nof_prb=100, nof_ports=2, cell_id=1, phich_ng_x6=1, nof_rx=2, snr_db=30.0, cfo_hz=0.0, delay_samples=0,
                 seed=seed, n_rnti=32, dl_min=6, dl_max=6, ul_min=2, ul_max=2, cfi=3, mix_tm3_pct=0, mix_tm4_pct=0,
-                pct_256qam=0, mcs_min=0, mcs_max=28, sib_period=1, rar_period=0, paging_period=0, start_tti=0, fixed_L=0, pct_rv=0, pct_cqi_req=0, pct_hop=0, pusch_hop_offset=0)
+                pct_256qam=0, mcs_min=0, mcs_max=28, sib_period=1, rar_period=0, paging_period=0, start_tti=0, fixed_L=0, pct_rv=0, pct_cqi_req=0, pct_hop=0, pusch_hop_offset=0, msg4_period=0, msg4_p_a_idx=4)
     presets = {
         # config 1: 10 MHz, single RNTI, TM1 QPSK, 1 port / 1 rx
         "cfg1": dict(nof_prb=50, nof_ports=1, nof_rx=1, snr_db=20.0, cfo_hz=300.0, n_rnti=1, dl_min=1, dl_max=1, ul_min=0,

@@ -167,4 +167,33 @@ int lsnh_rar_parse(uint32_t nof_prb, const uint8_t* p, int len, uint32_t* out, i
   return n;
 }
 
+// MAC DL-SCH walk: out = n x {lcid, is_sdu, off, len}
+int lsnh_mac_dlsch_parse(const uint8_t* pdu, int len, uint32_t* out, int cap)
+{
+  MacSubheader sub[32];
+  const int n = mac_dlsch_parse(pdu, len, sub, cap < 32 ? cap : 32);
+  for (int i = 0; i < n; i++) { out[4 * i] = sub[i].lcid; out[4 * i + 1] = sub[i].is_sdu; out[4 * i + 2] = sub[i].off; out[4 * i + 3] = sub[i].len; }
+  return n;
+}
+// RRCConnectionSetup decode: out = {p_a (float bits), i_offset_ack, i_offset_cqi, i_offset_ri, cqi_type}
+int lsnh_rrc_conn_setup(const uint8_t* sdu, int len, uint32_t* out)
+{
+  UeSpecConfig c;
+  if (!rrc_conn_setup_decode(sdu, len, c)) return 0;
+  std::memcpy(&out[0], &c.p_a, 4);
+  out[1] = c.i_offset_ack; out[2] = c.i_offset_cqi; out[3] = c.i_offset_ri; out[4] = c.cqi_type;
+  return 1;
+}
+// MCSTracking UE-configuration database driven by a sequence of (rnti, pdu) events; returns the configuration get_ue_config_rnti(query) ends with
+void* lsnh_mcs_new() { return new MCSTracking(); }
+void lsnh_mcs_free(void* m) { delete (MCSTracking*)m; }
+int lsnh_mcs_learn(void* m, const uint8_t* pdu, int len, uint16_t rnti) { return ((MCSTracking*)m)->learn_from_pdu(pdu, len, rnti) ? 1 : 0; }
+void lsnh_mcs_touch(void* m, uint16_t rnti) { ((MCSTracking*)m)->update_statistic_dl(rnti, FORMAT1); }
+void lsnh_mcs_get(void* m, uint16_t rnti, uint32_t* out)
+{
+  const UeSpecConfig c = ((MCSTracking*)m)->get_ue_config_rnti(rnti);
+  std::memcpy(&out[0], &c.p_a, 4);
+  out[1] = c.i_offset_ack; out[2] = c.i_offset_cqi; out[3] = c.i_offset_ri; out[4] = c.cqi_type; out[5] = c.has_ue_config;
+}
+
 }  // extern "C"

@@ -231,6 +231,8 @@ typedef struct {
   uint32_t pct_cqi_req;   // share of DCI 0 that request an aperiodic CSI report
   uint32_t pct_hop;       // share of subframes whose (then only) DCI 0 uses type-1 PUSCH frequency hopping (36.213 8.4.1)
   uint32_t pusch_hop_offset;  // SIB2 pusch-HoppingOffset of the cell
+  uint32_t msg4_period;   // every n subframes one scheduled UE gets a contention-resolution PDU with an RRCConnectionSetup (0 = never)
+  uint32_t msg4_p_a_idx;  // its pdsch-ConfigDedicated.p-a (0..7 = dB-6 .. dB3), 8 = random; the UE's PDSCH is sent with that power offset from the next subframe on
 } txg_cfg_t;
 
 typedef struct { uint16_t rnti; uint8_t format, L; uint16_t ncce; uint32_t tti; uint32_t nbytes; uint32_t offset; uint8_t tb, mod, table256, is_ul; uint32_t nof_prb; uint32_t mcs; uint32_t cqi_req; uint32_t hop_bits_plus1; /* DCI 0: 0 = no hopping, else 1 + hopping bits */ } txg_pdu_t;
@@ -244,7 +246,7 @@ uint32_t txg_sf_len(const txg_t*);
 uint32_t txg_tti(const txg_t*);
 }
 
-struct Ue { uint16_t rnti; int tm; bool t256; };
+struct Ue { uint16_t rnti; int tm; bool t256; float p_a_db = 0.0f; };
 struct RegInfo { std::vector<uint16_t> k0[3]; std::vector<uint8_t> l[3]; uint32_t nregs[3], ncce[3]; uint16_t pcfich_k0[4]; };
 
 struct txg {
@@ -321,6 +323,52 @@ static uint32_t alloc_bits(uint32_t n) { return (n > 10 ? 1 : 0) + (n + ra_P(n) 
 static uint32_t f1_sz(uint32_t n) { uint32_t s = alloc_bits(n) + 5 + 3 + 1 + 2 + 2; while (s == f0_sz(n) || s == f1a_sz(n) || amb(s)) s++; return s; }
 static uint32_t f2_sz(uint32_t n, uint32_t ports) { uint32_t s = alloc_bits(n) + 2 + 3 + 1 + 16 + (ports == 2 ? 3 : ports == 4 ? 6 : 0); while (amb(s)) s++; return s; }
 static uint32_t f2a_sz(uint32_t n, uint32_t ports) { uint32_t s = alloc_bits(n) + 2 + 3 + 1 + 16 + (ports == 4 ? 2 : 0); while (amb(s)) s++; return s; }
+
+// RRCConnectionSetup (TS 36.331 6.2.2, UPER) as an eNB sends it in message 4: SRB1 with default RLC / logical channel configuration,
+// explicit mac-MainConfig (optionally with the Rel-9 sr-ProhibitTimer extension group) and physicalConfigDedicated
+static std::vector<uint8_t> rrc_conn_setup(Rng& rng, uint32_t p_a_idx, uint32_t b_ack, uint32_t b_ri, uint32_t b_cqi, int aper_mode /* -1 none */) {
+  bits_t b;
+  put(b, 0, 1); put(b, 3, 2);            // DL-CCCH-Message: c1, rrcConnectionSetup
+  put(b, rng.below(4), 2);               // rrc-TransactionIdentifier
+  put(b, 0, 1); put(b, 0, 3);            // criticalExtensions c1, rrcConnectionSetup-r8
+  put(b, 0, 1);                          // no nonCriticalExtension
+  put(b, 0, 1);                          // RadioResourceConfigDedicated: no extension
+  put(b, 1, 1); put(b, 0, 1); put(b, 0, 1); put(b, 1, 1); put(b, 0, 1); put(b, 1, 1);  // srb list, -, -, mac-MainConfig, -, physicalConfigDedicated
+  put(b, 0, 1);                          // one SRB
+  const bool explicit_rlc = rng.below(2);
+  put(b, 0, 1); put(b, 1, 1); put(b, 1, 1); put(b, 0, 1);  // SRB-ToAddMod: no ext, rlc-Config, logicalChannelConfig, srb-Identity 1
+  if (explicit_rlc) { put(b, 0, 1); put(b, 0, 1); put(b, 0, 2); put(b, rng.below(55), 6); put(b, rng.below(8), 3); put(b, rng.below(15), 4); put(b, rng.below(8), 3); put(b, rng.below(31), 5); put(b, rng.below(56), 6); }
+  else put(b, 1, 1);
+  if (rng.below(2)) { put(b, 0, 1); put(b, 0, 1); put(b, 1, 1); put(b, 1, 1); put(b, rng.below(16), 4); put(b, rng.below(8), 4); put(b, rng.below(6), 3); put(b, rng.below(4), 2); }  // explicit: ul-SpecificParameters with group
+  else put(b, 1, 1);
+  const bool mac_ext = rng.below(2), drx = rng.below(2);
+  put(b, 0, 1);                          // mac-MainConfig explicitValue
+  put(b, mac_ext, 1); put(b, 1, 1); put(b, drx, 1); put(b, 1, 1);  // ext, ul-SCH-Config, drx-Config, phr-Config
+  put(b, 1, 1); put(b, 1, 1); put(b, rng.below(14), 4); put(b, rng.below(14), 4); put(b, rng.below(6), 3); put(b, 0, 1);
+  if (drx) { put(b, 1, 1); put(b, 1, 1); put(b, rng.below(16), 4); put(b, rng.below(22), 5); put(b, rng.below(8), 3); put(b, 7, 4); put(b, rng.below(160), 8); put(b, rng.below(16), 4); put(b, rng.below(16), 4); }  // setup with shortDRX, longDRX sf160
+  put(b, rng.below(8), 3);               // timeAlignmentTimerDedicated
+  put(b, 1, 1); put(b, rng.below(8), 3); put(b, rng.below(8), 3); put(b, rng.below(4), 2);  // phr-Config setup
+  if (mac_ext) { put(b, 0, 1); put(b, 0, 6); put(b, 1, 1); put(b, 1, 8); put(b, 1, 1); put(b, rng.below(8), 3); put(b, 0, 4); }  // one addition group: [[ sr-ProhibitTimer-r9 ]] in one octet
+  put(b, 0, 1);                          // PhysicalConfigDedicated: no extension
+  const bool tpc = rng.below(2), srs = rng.below(2);
+  put(b, 1, 1); put(b, 1, 1); put(b, 1, 1); put(b, 1, 1); put(b, tpc, 1); put(b, 0, 1); put(b, 1, 1); put(b, srs, 1); put(b, 1, 1); put(b, 1, 1);
+  put(b, p_a_idx, 3);                    // pdsch-ConfigDedicated
+  put(b, 0, 1); put(b, 0, 1);            // pucch-ConfigDedicated: no tdd mode, ackNackRepetition release
+  put(b, b_ack, 4); put(b, b_ri, 4); put(b, b_cqi, 4);  // pusch-ConfigDedicated
+  put(b, 0, 1); put(b, 8, 4); put(b, 0, 1); put(b, 1, 1); put(b, 8, 4); put(b, 3, 4);  // uplinkPowerControlDedicated, filterCoefficient default
+  if (tpc) { put(b, 1, 1); put(b, rng.below(65536), 16); put(b, 0, 1); put(b, rng.below(15), 4); }  // tpc-PDCCH-ConfigPUCCH setup, indexOfFormat3
+  put(b, aper_mode >= 0, 1); put(b, 1, 1);  // cqi-ReportConfig: aperiodic mode?, periodic
+  if (aper_mode >= 0) put(b, (uint32_t)aper_mode, 3);
+  put(b, 1, 3);                          // nomPDSCH-RS-EPRE-Offset 0
+  put(b, 1, 1); put(b, 0, 1); put(b, rng.below(1186), 11); put(b, 38, 10); put(b, 0, 1); put(b, 1, 1);  // periodic setup
+  if (srs) { put(b, 1, 1); put(b, rng.below(4), 2); put(b, rng.below(4), 2); put(b, rng.below(24), 5); put(b, 1, 1); put(b, rng.below(1024), 10); put(b, rng.below(2), 1); put(b, rng.below(8), 3); }
+  put(b, 0, 1); put(b, 0, 1); put(b, 1, 3); put(b, 0, 1);  // antennaInfo explicit: tm2, no codebook restriction, antenna selection release
+  put(b, 1, 1); put(b, rng.below(2048), 11); put(b, 15, 8); put(b, 4, 3);  // schedulingRequestConfig setup
+  while (b.size() % 8) b.push_back(0);
+  std::vector<uint8_t> out(b.size() / 8, 0);
+  for (size_t i = 0; i < b.size(); i++) out[i / 8] |= (uint8_t)(b[i] << (7 - i % 8));
+  return out;
+}
 
 struct Grant {
   uint16_t rnti; int format; int L; int ncce;
@@ -577,6 +625,8 @@ extern "C" int txg_next(txg_t* g, float* iq, txg_pdu_t* pdus, int max_pdus, uint
     }
   }
   // unicast DL
+  int msg4_ue = -1;
+  float msg4_p_a = 0.0f;
   uint32_t kdl = c.dl_min + g->rng.below(c.dl_max - c.dl_min + 1);
   std::vector<int> picked;
   int rbg_left = (int)nrbg - next_rbg;
@@ -628,6 +678,21 @@ extern "C" int txg_next(txg_t* g, float* iq, txg_pdu_t* pdus, int max_pdus, uint
       if (npdu < max_pdus && poff + nb <= pcap) {
         for (int b = 0; b < nb; b++) pbuf[poff + b] = (uint8_t)g->rng.u32();
         pbuf[poff] |= 0x20;  // never an all-zero TB; avoid LCID-0 looking headers
+        if (i == 0 && q == 0 && c.msg4_period && (tti % c.msg4_period) == 5 % c.msg4_period && msg4_ue < 0) {
+          // message 4: UE contention resolution identity + CCCH SDU (RRCConnectionSetup) + padding (TS 36.321 6.1.2), sent with the
+          // power offset in force so far; the new p-a applies to this UE from the next subframe on
+          static const float p_a_db[8] = {-6.0f, -4.77f, -3.0f, -1.77f, 0.0f, 1.0f, 2.0f, 3.0f};
+          const uint32_t pi = c.msg4_p_a_idx < 8 ? c.msg4_p_a_idx : g->rng.below(8);
+          const int am = g->rng.below(3) == 0 ? -1 : (int)g->rng.below(5);
+          std::vector<uint8_t> rrc = rrc_conn_setup(g->rng, pi, g->rng.below(15), g->rng.below(13), 2 + g->rng.below(14), am);
+          if ((int)rrc.size() + 10 <= nb && rrc.size() < 128) {
+            memset(pbuf + poff, 0, (size_t)nb);
+            pbuf[poff] = 0x3C; pbuf[poff + 1] = 0x20; pbuf[poff + 2] = (uint8_t)rrc.size(); pbuf[poff + 3] = 0x1F;
+            for (int b = 0; b < 6; b++) pbuf[poff + 4 + b] = (uint8_t)g->rng.u32();
+            memcpy(pbuf + poff + 10, rrc.data(), rrc.size());
+            msg4_ue = ui; msg4_p_a = p_a_db[pi];
+          }
+        }
         txg_pdu_t& pd = pdus[npdu++];
         pd = txg_pdu_t{gr.rnti, (uint8_t)gr.format, (uint8_t)gr.L, (uint16_t)gr.ncce, tti, (uint32_t)nb, (uint32_t)poff, (uint8_t)i, (uint8_t)gr.qm[i], (uint8_t)gr.t256, 0, (uint32_t)gr.prbs.size(), gr.mcs[i]};
         poff += nb;
@@ -695,6 +760,8 @@ extern "C" int txg_next(txg_t* g, float* iq, txg_pdu_t* pdus, int max_pdus, uint
     std::vector<std::pair<int, int>> res;
     for (int l = l0; l < 14; l++) for (int p : gr.prbs) for (int k = 12 * p; k < 12 * p + 12; k++) if (pdsch_re_ok(g, sf, l, k)) res.push_back({l, k});
     int nre_g = (int)res.size();
+    float rho_a = 1.0f;
+    for (auto& u : g->ues) if (u.rnti == gr.rnti) rho_a = std::pow(10.0f, u.p_a_db / 20.0f);
     std::vector<cf> sym[2];
     for (int i = 0; i < gr.ntb; i++) {
       if (pdu_i + i >= npdu) break;
@@ -708,7 +775,7 @@ extern "C" int txg_next(txg_t* g, float* iq, txg_pdu_t* pdus, int max_pdus, uint
     pdu_i += gr.ntb;
     for (int i = 0; i < nre_g; i++) {
       int l = res[i].first, k = res[i].second;
-      float amp = (l == 0 || l == 4 || l == 7 || l == 11) ? rho_b : 1.0f;
+      float amp = rho_a * ((l == 0 || l == 4 || l == 7 || l == 11) ? rho_b : 1.0f);  // 36.213 5.2: rho_A from the UE's p-a, rho_B / rho_A from p-b = 1
       cf* g0 = &grid[0][l * nre + k];
       cf* g1 = P > 1 ? &grid[1][l * nre + k] : nullptr;
       switch (gr.scheme) {
@@ -727,6 +794,8 @@ extern "C" int txg_next(txg_t* g, float* iq, txg_pdu_t* pdus, int max_pdus, uint
       }
     }
   }
+
+  if (msg4_ue >= 0) g->ues[msg4_ue].p_a_db = msg4_p_a;
 
   // ---- OFDM + channel ----
   int sflen = 15 * N;
