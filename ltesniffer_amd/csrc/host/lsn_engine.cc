@@ -275,7 +275,7 @@ void Engine::speculateRar(Chunk& ch)
           DlEntry e;
           if (!search->buildDlEntry(c, (uint16_t)q.rnti, f, q.bits, e) || !e.ok64) continue;
           if (cfg.sniffer_mode == 0 && (!(e.grant64.tb[0].tbs > 0) || (dlRx() == 1 && e.grant64.nof_tb == 2))) continue;
-          const int j = newJob(ch, sf, e, 0);
+          const int j = newJob(ch, sf, e, 0, default_p_a.load(std::memory_order_relaxed));
           if (j < 0) continue;
           ch.spec_rar.push_back({sf, (uint16_t)q.rnti, f, q.bits, j});
           ids.push_back(j);
@@ -324,7 +324,7 @@ void Engine::searchChunk(Chunk& ch, uint32_t update_meta_period)
       for (auto& s : ch.spec_rar)  // decoded ahead by the front thread?
         if (s.sf == sf && s.rnti == e.rnti && s.format == e.format && s.bits == e.bits && ch.jobs[s.job].done) { j = s.job; break; }
       if (j < 0) {
-        j = newJob(ch, sf, e, 0);
+        j = newJob(ch, sf, e, 0, default_p_a.load(std::memory_order_relaxed));
         if (j < 0) continue;
         const double tr0 = now_ms();
         ensureJob(ch, runner_s, j);
@@ -357,10 +357,13 @@ void Engine::unpackRar(const uint8_t* p, int len, bool at_search)
 
 // ------------------------------------------------------------------------------------------------ stage C planning
 // one srsran_ue_dl_decode_pdsch call = one job; returns -1 when dl_sniffer_config_mimo rejects the grant
-int Engine::newJob(Chunk& ch, uint32_t sf, const DlEntry& e, int table)
+int Engine::newJob(Chunk& ch, uint32_t sf, const DlEntry& e, int table, float p_a)
 {
   DecodeJob j;
   j.sf = sf; j.rnti = e.rnti;
+  // pdsch_cfg->p_a: DL mode looks the UE's p-a up before every decode (DL_Sniffer_PDSCH.cc:926-927); the UL-mode decoders never set
+  // it and run with the -3 dB of SubframeWorker::set_pdsch_uecfg (SubframeWorker.cc:370)
+  j.p_a = cfg.sniffer_mode == 1 ? -3.0f : p_a;
   j.grant = table ? e.grant256 : e.grant64;
   if (dl_sniffer_config_mimo(cell, e.format, e.dci, j.grant) != 0) return -1;
   if (cfg.sniffer_mode == 1) {  // run_decode / run_rar_decode, DL_Sniffer_PDSCH.cc:240-247,694-701
@@ -433,8 +436,8 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
     }
     d.prefix_off = (uint32_t)prefix_n;
     prefix_n += 14 * nprb + 16;
-    // power allocation 36.213 5.2 with p_a = 0 dB (MCSTracking.cc:1536), p_b = 1 (SubframeWorker.cc:372)
-    const float rho_a = powf(10.0f, 0.0f / 20.0f);
+    // power allocation 36.213 5.2: rho_A from the job's p_a, p_b = 1 (SubframeWorker.cc:372)
+    const float rho_a = powf(10.0f, j.p_a / 20.0f);
     const float rho_b = cell.nof_ports == 1 ? rho_a * sqrtf(0.8f) : rho_a;
     d.inv_amp_a = 1.0f / rho_a; d.inv_amp_b = 1.0f / rho_b;
     // transport blocks -> code blocks (36.212 5.1.2, 5.1.4.1.2)
@@ -600,7 +603,7 @@ void Engine::planJobs(Chunk& ch, JobRunner& r)
       const bool ok = first ? e.ok256 : e.ok64;
       if (!ok || !(g.tb[0].tbs > 0)) continue;
       if (dlRx() == 1 && (e.grant64.nof_tb == 2 || e.grant256.nof_tb == 2)) continue;
-      if (e.job[first] < 0) e.job[first] = newJob(ch, sf, e, first);
+      if (e.job[first] < 0) e.job[first] = newJob(ch, sf, e, first, mcs_tracking.get_ue_config_rnti(e.rnti).p_a);  // as of now; commit checks it
       if (e.job[first] >= 0) wave.push_back(e.job[first]);
       if (table >= TABLE_UNKNOWN && e.ok256) retry.push_back({sf, di});
     }
@@ -612,7 +615,7 @@ void Engine::planJobs(Chunk& ch, JobRunner& r)
     DlEntry& e = ch.ctx[p.sf].dl[p.di];
     if (e.job[0] < 0 || !ch.jobs[e.job[0]].done) continue;
     if (ch.jobs[e.job[0]].crc[0] || ch.jobs[e.job[0]].crc[1]) continue;
-    if (e.job[1] < 0) e.job[1] = newJob(ch, p.sf, e, 1);
+    if (e.job[1] < 0) e.job[1] = newJob(ch, p.sf, e, 1, ch.jobs[e.job[0]].p_a);
     if (e.job[1] >= 0) wave.push_back(e.job[1]);
   }
   runJobs(ch, r, wave);
@@ -631,6 +634,12 @@ void Engine::emitPdu(JobRunner& r, const char* name, const uint8_t* pdu, uint32_
   else if (name[0] == 'R') { c.rnti = rnti; c.rnti_type = 2; }
   else { c.rnti = rnti; c.rnti_type = 3; }
   sink(sink_user, &c, pdu, len);
+}
+
+// a decoded C-RNTI transport block: RRCConnectionSetup -> UE configuration database (caller holds mcs_mtx)
+void Engine::learnUeConfig(const uint8_t* pdu, int len, uint16_t rnti)
+{
+  if (mcs_tracking.learn_from_pdu(pdu, len, rnti)) default_p_a.store(mcs_tracking.default_p_a(), std::memory_order_relaxed);
 }
 
 // PDSCH_Decoder::decode_dl_mode (DL_Sniffer_PDSCH.cc:881-1291) over the decode results of every subframe of the chunk
@@ -664,9 +673,13 @@ void Engine::commitChunk(Chunk& ch, JobRunner& r)
       const bool gate = (cur.tb[0].tbs > 0 && dci_rnti_ok && !(dlRx() == 1 && two_tb)) || e.rnti == PRNTI;  // :887-889
       if (!gate) continue;
       const char* name = rnti_name(e.rnti);
+      // :926-927: the p-a in force when this DCI is decoded.  A job planned (or speculated) with another value - a connection setup
+      // was committed in between - is dropped and decoded again, so results do not depend on how far ahead the pipeline planned
+      const float p_a_now = mcs_tracking.get_ue_config_rnti(e.rnti).p_a;
       auto run = [&](int t) -> int {
         if (!(t ? has256 : has64)) return -1;
-        if (e.job[t] < 0) e.job[t] = newJob(ch, sf, e, t);
+        if (e.job[t] >= 0 && ch.jobs[e.job[t]].p_a != p_a_now) e.job[t] = -1;
+        if (e.job[t] < 0) e.job[t] = newJob(ch, sf, e, t, p_a_now);
         if (e.job[t] >= 0 && !ch.jobs[e.job[t]].done) { ensureJob(ch, r, e.job[t]); r.perf.nof_ondemand_decodes++; }
         return e.job[t];
       };
@@ -680,6 +693,7 @@ void Engine::commitChunk(Chunk& ch, JobRunner& r)
             if (ch.jobs[j].crc[tb] && len > 0) {
               emitPdu(r, name, payload_of(j, tb), (uint32_t)len, e.rnti, c.tti, (uint8_t)tb);
               if (name[0] == 'R') unpackRar(payload_of(j, tb), len, false);
+              if (name[0] == 'C') learnUeConfig(payload_of(j, tb), len, e.rnti);  // :1041-1070
             }
           }
       } else {  // unknown table: 64QAM table first, the 256QAM table only if both TBs failed, :1089-1243
@@ -691,6 +705,7 @@ void Engine::commitChunk(Chunk& ch, JobRunner& r)
             if (crc[tb] && len > 0) {
               emitPdu(r, name, payload_of(j, tb), (uint32_t)len, e.rnti, c.tti, (uint8_t)tb);
               if (name[0] == 'R') unpackRar(payload_of(j, tb), len, false);
+              if (name[0] == 'C') learnUeConfig(payload_of(j, tb), len, e.rnti);  // :1133-1160
               if (e.dci.tb[tb].mcs_idx > 0 && e.dci.tb[tb].mcs_idx < 29 && e.format > FORMAT1A) mcs_tracking.update_RNTI_dl(e.rnti, TABLE_64QAM);
             }
           }

@@ -11,6 +11,7 @@
 #include "../../../include/ltesniffer_amd.h"
 #include "../kernels/lsn_dev.h"
 #include "lsn_search.h"
+#include <atomic>
 #include <condition_variable>
 #include <deque>
 #include <map>
@@ -23,6 +24,7 @@ namespace lsn {
 
 struct DecodeJob {
   uint32_t sf = 0; PdschGrant grant; uint16_t rnti = 0;
+  float p_a = 0.0f;  // pdsch_cfg->p_a this decode runs with (dB)
   bool planned = false, done = false;
   uint32_t cb_first = 0, cb_count[2] = {0, 0};
   uint32_t payload_off[2] = {0, 0};
@@ -135,7 +137,8 @@ private:
     if (e.rnti >= RARNTI_START && e.rnti <= RARNTI_END) return true;
     return e.rnti > RARNTI_END && (e.format == FORMAT1 || e.format == FORMAT1A) && e.rnti != SIRNTI;
   }
-  int newJob(Chunk& ch, uint32_t sf, const DlEntry& e, int table);
+  int newJob(Chunk& ch, uint32_t sf, const DlEntry& e, int table, float p_a = 0.0f);
+  void learnUeConfig(const uint8_t* pdu, int len, uint16_t rnti);
   void unpackRar(const uint8_t* p, int len, bool at_search);
   void emitPdu(JobRunner& r, const char* name, const uint8_t* pdu, uint32_t len, uint16_t rnti, uint32_t tti, uint8_t tb);
   void decodeLoop(int idx);
@@ -161,6 +164,7 @@ private:
   hipEvent_t ev_in = nullptr;
   std::unique_ptr<FalconSearch> search;
   MCSTracking mcs_tracking;
+  std::atomic<float> default_p_a{0.0f};  // p-a of RNTIs without tracking entry (RA-RNTIs): readable by the search / front thread without mcs_mtx
   std::mutex mcs_mtx;  // planJobs (prediction) vs commitChunk (authoritative updates)
   // front thread: launches stage A chunk after chunk, hands finished chunks to the search (caller) thread
   std::thread front_thread;

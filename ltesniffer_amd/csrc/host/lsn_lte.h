@@ -169,6 +169,7 @@ public:
   UeSpecConfig get_ue_config_rnti(uint16_t rnti) const;         // the entry's configuration, else the default
   void update_ue_config_rnti(uint16_t rnti, const UeSpecConfig& c);
   bool check_default_config() const { return has_default; }
+  float default_p_a() const { return default_cfg.p_a; }
   void update_default_ue_config(const UeSpecConfig& c) { default_cfg = c; has_default = true; }
   // one decoded C-RNTI transport block: every CCCH SDU is tried as RRCConnectionSetup (DL_Sniffer_PDSCH.cc:1041-1070); true when one was
   bool learn_from_pdu(const uint8_t* pdu, int len, uint16_t rnti);
