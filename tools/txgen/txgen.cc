@@ -677,7 +677,7 @@ extern "C" int txg_next(txg_t* g, float* iq, txg_pdu_t* pdus, int max_pdus, uint
       int nb = gr.tbs[i] / 8;
       if (npdu < max_pdus && poff + nb <= pcap) {
         for (int b = 0; b < nb; b++) pbuf[poff + b] = (uint8_t)g->rng.u32();
-        pbuf[poff] |= 0x20;  // never an all-zero TB; avoid LCID-0 looking headers
+        pbuf[poff] = 0x03;  // a well-formed MAC PDU: one subheader (E = 0, LCID 3 = a DTCH), the SDU takes the rest; never an all-zero TB
         if (i == 0 && q == 0 && c.msg4_period && (tti % c.msg4_period) == 5 % c.msg4_period && msg4_ue < 0) {
           // message 4: UE contention resolution identity + CCCH SDU (RRCConnectionSetup) + padding (TS 36.321 6.1.2), sent with the
           // power offset in force so far; the new p-a applies to this UE from the next subframe on
