@@ -96,6 +96,17 @@ int lsn_phy_add_evergreen(lsn_phy_t* phy, uint16_t rnti_start, uint16_t rnti_end
 int lsn_phy_add_forbidden(lsn_phy_t* phy, uint16_t rnti_start, uint16_t rnti_end, uint32_t format_idx); /* RNTIManager::addForbidden */
 int lsn_phy_setup_default_rnti_intervals(lsn_phy_t* phy);                 /* LTESniffer_Core.cc:398-417 in one call */
 uint32_t lsn_phy_nof_active_rnti(lsn_phy_t* phy);
+/* UE-specific configuration learned from RRCConnectionSetup messages on the downlink (MCSTracking::get_ue_config_rnti,
+ * MCSTracking.cc:1482-1516; filled by PDSCH_Decoder::decode_rrc_connection_setup, DL_Sniffer_PDSCH.cc:129-181): the entry of the
+ * RNTI, or the default (the first connection setup seen; before that p_a 0 dB, offsets 10 / 8 / 11, higher-layer sub-band CQI).
+ * p_a_db is the PDSCH power offset every later decode of that RNTI runs with (DL_Sniffer_PDSCH.cc:926-927). */
+typedef struct {
+  uint32_t has_ue_config;                           /* 1: from this UE's own connection setup */
+  float p_a_db;
+  uint32_t i_offset_ack, i_offset_cqi, i_offset_ri; /* betaOffset-ACK / CQI / RI-Index */
+  uint32_t cqi_type;                                /* 0 wideband, 1 UE-selected sub-band, 2 higher-layer sub-band (srsran_cqi_type_t) */
+} lsn_ue_config_t;
+int lsn_phy_get_ue_config(lsn_phy_t* phy, uint16_t rnti, lsn_ue_config_t* out);
 
 /* ---- SubframeWorker ---- */
 float** lsn_worker_buffers(lsn_worker_t* w);         /* SubframeWorker::getBuffers: [antenna] -> interleaved cf32, pinned host */

@@ -70,6 +70,7 @@ public:
   void setPrachSink(lsn_prach_sink_t cb, void* user) { lsn_phy_set_prach_sink(h, cb, user); }               // work_prach's report
   // srsran_ue_mib_decode + srsran_pbch_mib_unpack on one subframe 0 (LTESniffer_Core.cc:386-391); true when a MIB was found
   bool mibDecode(const cf_t* subframe_iq /* [nof_rx_antennas][SF_LEN] */, lsn_mib_t& mib) { return lsn_phy_mib_decode(h, subframe_iq, 0, &mib) == 1; }
+  lsn_ue_config_t getUeConfig(uint16_t rnti) { lsn_ue_config_t c{}; lsn_phy_get_ue_config(h, rnti, &c); return c; }  // MCSTracking::get_ue_config_rnti
   lsn_phy_t* handle() { return h; }
 private:
   static std::shared_ptr<SubframeWorker> wrap(lsn_worker_t* w) { return w ? std::shared_ptr<SubframeWorker>(new SubframeWorker(w)) : nullptr; }

@@ -25,7 +25,7 @@ KERNELS = ["k_ofdm", "k_chest", "k_chest_fin", "k_pcfich", "k_pdcch_llr", "k_cce
 EXPORTS = ["lsn_phy_create", "lsn_phy_destroy", "lsn_phy_set_cell", "lsn_phy_get_avail", "lsn_phy_put_pending",
            "lsn_phy_join_pending", "lsn_phy_set_pdu_sink", "lsn_phy_get_stats", "lsn_phy_get_est_cfo",
            "lsn_phy_add_evergreen", "lsn_phy_add_forbidden", "lsn_phy_setup_default_rnti_intervals",
-           "lsn_phy_nof_active_rnti", "lsn_worker_buffers", "lsn_worker_buffer_len", "lsn_worker_prepare",
+           "lsn_phy_nof_active_rnti", "lsn_phy_get_ue_config", "lsn_worker_buffers", "lsn_worker_buffer_len", "lsn_worker_prepare",
            "lsn_worker_sf_idx", "lsn_worker_sfn", "lsn_phy_process_device", "lsn_phy_process_host", "lsn_phy_tap",
            "lsn_phy_get_perf", "lsn_kernel_name", "lsn_version", "lsn_pcap_open", "lsn_pcap_open_mem",
            "lsn_pcap_set_wall_clock", "lsn_pcap_write", "lsn_pcap_sink", "lsn_pcap_mem", "lsn_pcap_nof_records",
@@ -41,6 +41,11 @@ class Mib(C.Structure):
 
 
 TTI_FROM_MIB = 0xFFFFFFFF
+
+
+class UeConfig(C.Structure):
+    _fields_ = [("has_ue_config", C.c_uint32), ("p_a_db", C.c_float), ("i_offset_ack", C.c_uint32), ("i_offset_cqi", C.c_uint32),
+                ("i_offset_ri", C.c_uint32), ("cqi_type", C.c_uint32)]
 
 
 class CellSearchCfg(C.Structure):
@@ -178,6 +183,7 @@ def lib():
         L.lsn_phy_setup_default_rnti_intervals.argtypes = [C.c_void_p]
         L.lsn_phy_nof_active_rnti.argtypes = [C.c_void_p]
         L.lsn_phy_nof_active_rnti.restype = C.c_uint32
+        L.lsn_phy_get_ue_config.argtypes = [C.c_void_p, C.c_uint16, C.POINTER(UeConfig)]
         L.lsn_worker_buffers.argtypes = [C.c_void_p]
         L.lsn_worker_buffers.restype = C.POINTER(C.POINTER(C.c_float))
         L.lsn_worker_buffer_len.argtypes = [C.c_void_p]
@@ -482,6 +488,12 @@ class Phy:
 
     def nof_active_rnti(self):
         return lib().lsn_phy_nof_active_rnti(self._h)
+
+    def ue_config(self, rnti):
+        """MCSTracking::get_ue_config_rnti: what RRCConnectionSetup messages taught about this RNTI (or the default)"""
+        c = UeConfig()
+        _check(lib().lsn_phy_get_ue_config(self._h, rnti, C.byref(c)), "get_ue_config")
+        return c
 
     def close(self):
         if self._h:

@@ -225,6 +225,16 @@ int lsn_phy_setup_default_rnti_intervals(lsn_phy_t* phy)
   return LSN_SUCCESS;
 }
 uint32_t lsn_phy_nof_active_rnti(lsn_phy_t* phy) { return phy ? phy->engine->rntiManager().nofActive() : 0; }
+int lsn_phy_get_ue_config(lsn_phy_t* phy, uint16_t rnti, lsn_ue_config_t* out)
+{
+  if (!phy || !out) return LSN_ERROR_INVALID_INPUTS;
+  const lsn::UeSpecConfig c = phy->engine->ueConfig(rnti);
+  out->has_ue_config = c.has_ue_config ? 1u : 0u;
+  out->p_a_db = c.p_a;
+  out->i_offset_ack = c.i_offset_ack; out->i_offset_cqi = c.i_offset_cqi; out->i_offset_ri = c.i_offset_ri;
+  out->cqi_type = c.cqi_type;
+  return LSN_SUCCESS;
+}
 
 float** lsn_worker_buffers(lsn_worker_t* w) { return w ? w->buf : nullptr; }
 uint32_t lsn_worker_buffer_len(lsn_worker_t* w) { return w ? w->buf_len : 0; }

@@ -139,6 +139,9 @@ private:
   }
   int newJob(Chunk& ch, uint32_t sf, const DlEntry& e, int table, float p_a = 0.0f);
   void learnUeConfig(const uint8_t* pdu, int len, uint16_t rnti);
+public:
+  UeSpecConfig ueConfig(uint16_t rnti) { std::lock_guard<std::mutex> lk(mcs_mtx); return mcs_tracking.get_ue_config_rnti(rnti); }
+private:
   void unpackRar(const uint8_t* p, int len, bool at_search);
   void emitPdu(JobRunner& r, const char* name, const uint8_t* pdu, uint32_t len, uint16_t rnti, uint32_t tti, uint8_t tb);
   void decodeLoop(int idx);

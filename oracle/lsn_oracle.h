@@ -302,6 +302,7 @@ int o_rar_parse(const o_cell_t* cell, const uint8_t* p, int len, o_rar_t* out, i
 void o_worker_set_ul_mode(o_worker_t*, const o_ul_cfg_t* ul);
 int o_worker_work_ul(o_worker_t*, const ocf_t* dl_iq, const ocf_t* ul_iq, uint32_t sf_idx, uint32_t sfn, int update_meta_formats);
 const o_stats_t* o_worker_stats(o_worker_t*);
+void o_worker_ue_cfg(o_worker_t* w, uint16_t rnti, o_ue_cfg_t* out); /* MCSTracking::get_ue_config_rnti */
 /* stage taps for parity tests (valid until the next work()) */
 const ocf_t* o_worker_grid(o_worker_t*);
 const ocf_t* o_worker_ce(o_worker_t*);

@@ -693,6 +693,8 @@ static void decode_dl_mode(o_worker_t* w)
   }
 }
 
+void o_worker_ue_cfg(o_worker_t* w, uint16_t rnti, o_ue_cfg_t* out) { *out = ue_cfg_get(w, rnti); }
+
 int o_worker_work(o_worker_t* w, const ocf_t* const* iq, uint32_t sf_idx, uint32_t sfn, int update_meta, float cfo_hz)
 {
   const o_cell_t* cell = &w->cfg.cell;

@@ -241,6 +241,15 @@ class OracleWorker:
     def cfi(self):
         return self.lib.o_worker_cfi(self.h)
 
+    def ue_cfg(self, rnti):
+        """MCSTracking::get_ue_config_rnti -> (has_ue_config, p_a, i_offset_ack, i_offset_cqi, i_offset_ri, cqi_type)"""
+        class _Cfg(C.Structure):
+            _fields_ = [("has", C.c_uint32), ("p_a", C.c_float), ("ack", C.c_uint32), ("cqi", C.c_uint32), ("ri", C.c_uint32), ("typ", C.c_uint32), ("bits", C.c_uint32)]
+        c = _Cfg()
+        self.lib.o_worker_ue_cfg.argtypes = [C.c_void_p, C.c_uint16, C.c_void_p]
+        self.lib.o_worker_ue_cfg(self.h, rnti, C.byref(c))
+        return (c.has, np.float32(c.p_a).item(), c.ack, c.cqi, c.ri, c.typ)
+
     def rb_power(self):
         self.lib.o_worker_rb_power.restype = C.POINTER(C.c_float)
         self.lib.o_worker_rb_power.argtypes = [C.c_void_p]

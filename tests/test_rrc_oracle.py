@@ -192,3 +192,8 @@ def test_oracle_worker_follows_p_a_of_the_connection_setup(p_a_idx):
     got = {(r["sfn"] * 10 + r["sf"], r["rnti"]) for r in recs}
     hit = sum((k[0], k[1]) in got for k in after)
     assert len(configured) == 3 and len(after) > 60 and hit >= 0.9 * len(after), (len(after), hit)
+    p_a_db = [-6.0, -4.77, -3.0, -1.77, 0.0, 1.0, 2.0, 3.0][p_a_idx]
+    for rnti in configured:
+        c = ow.ue_cfg(rnti)
+        assert c[0] == 1 and abs(c[1] - p_a_db) < 1e-6
+    assert ow.ue_cfg(0x0BAD)[0] == 0 and abs(ow.ue_cfg(0x0BAD)[1] - p_a_db) < 1e-6  # no entry: the default = the first connection setup
