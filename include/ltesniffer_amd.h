@@ -107,9 +107,26 @@ typedef struct {
   uint32_t cqi_type;                                /* 0 wideband, 1 UE-selected sub-band, 2 higher-layer sub-band (srsran_cqi_type_t) */
 } lsn_ue_config_t;
 int lsn_phy_get_ue_config(lsn_phy_t* phy, uint16_t rnti, lsn_ue_config_t* out);
+/* PhyCommon::setShortcutDiscovery (PhyCommon.cc:69-71; LTESniffer_Core.cc:87,616): the parent/child shortcut of the recursive blind
+ * search (DCISearch.cc:200-211).  Default on, like ArgManager.cc:47. */
+int lsn_phy_set_shortcut_discovery(lsn_phy_t* phy, int enable);
+int lsn_phy_get_shortcut_discovery(lsn_phy_t* phy);
+/* RNTIManager::setHistogramThreshold (RNTIManager.cc:442-444; LTESniffer_Core.cc:620) */
+int lsn_phy_set_histogram_threshold(lsn_phy_t* phy, uint32_t threshold);
+/* PhyCommon::printStats -> DCIBlindSearchStats::print (PhyCommon.cc:65-67,102-114; LTESniffer_Core.cc:561): the two CSV lines of the
+ * reference's stats file; `file` is a FILE* (NULL: stdout).  The blind-search time column is the search thread's time. */
+int lsn_phy_print_stats(lsn_phy_t* phy, void* file);
+/* MCSTracking database ageing (MCSTracking::update_database_dl, MCSTracking.cc:850-927, driven every get_interval() x 1000 subframes
+ * by LTESniffer_Core.cc:473-499).  The library ages its database by itself on the SUBFRAME count of the stream it commits (one subframe
+ * = 1 ms; the reference uses clock(), i.e. replay speed): interval in seconds, 0 = never, default 5 (MCSTracking.h:162).
+ * lsn_phy_update_mcs_database runs one update now (between process calls), for callers that keep the reference's own timer. */
+int lsn_phy_set_mcs_update_interval(lsn_phy_t* phy, uint32_t seconds);
+int lsn_phy_update_mcs_database(lsn_phy_t* phy);
+uint32_t lsn_phy_nof_tracked_rnti(lsn_phy_t* phy);   /* MCSTracking::nof_RNTI_member_dl */
 
 /* ---- SubframeWorker ---- */
 float** lsn_worker_buffers(lsn_worker_t* w);         /* SubframeWorker::getBuffers: [antenna] -> interleaved cf32, pinned host */
+float** lsn_worker_buffers_offset(lsn_worker_t* w);  /* SubframeWorker::getBuffers_offset (SubframeWorker.h:37): the two 3 * SF_LEN scratch buffers of SubframeBuffer.cc:28 */
 uint32_t lsn_worker_buffer_len(lsn_worker_t* w);     /* complex samples per antenna buffer (3 * SF_LEN, SubframeBuffer.cc:25) */
 int lsn_worker_prepare(lsn_worker_t* w, uint32_t sf_idx, uint32_t sfn, int update_meta_formats, const lsn_dl_sf_cfg_t* sf); /* SubframeWorker::prepare */
 uint32_t lsn_worker_sf_idx(lsn_worker_t* w);
@@ -126,6 +143,10 @@ void lsn_pcap_sink(void* user /* lsn_pcap_t* */, const lsn_pdu_ctx_t* ctx, const
 const uint8_t* lsn_pcap_mem(lsn_pcap_t* p, size_t* len);
 uint32_t lsn_pcap_nof_records(lsn_pcap_t* p);
 void lsn_pcap_reset(lsn_pcap_t* p);
+/* order-sensitive 64-bit digest + byte count of all records since open / reset, timestamps excluded (two writers fed the same record
+ * sequence agree); lsn_pcap_set_store(p, 0) keeps only the count and the digest (long streams that need not be kept) */
+int lsn_pcap_digest(lsn_pcap_t* p, uint64_t* digest, uint64_t* nbytes);
+void lsn_pcap_set_store(lsn_pcap_t* p, int on);
 void lsn_pcap_close(lsn_pcap_t* p);                          /* LTESniffer_pcap_writer::close */
 int lsn_phy_set_pcap_writer(lsn_phy_t* phy, lsn_pcap_t* p);  /* Phy ctor argument `LTESniffer_pcap_writer*` (Phy.h:31) */
 
@@ -303,8 +324,8 @@ typedef struct {
 } lsn_perf_t;
 int lsn_phy_get_perf(lsn_phy_t* phy, lsn_perf_t* out);
 enum { LSN_K_OFDM = 0, LSN_K_CHEST, LSN_K_CHEST_FIN, LSN_K_PCFICH, LSN_K_PDCCH_LLR, LSN_K_CCE_POWER, LSN_K_VITERBI,
-       LSN_K_PDSCH_PREP, LSN_K_PDSCH_DEMOD, LSN_K_TURBO, LSN_K_RB_POWER, LSN_K_TURBO128, LSN_K_COUNT };
-/* LSN_K_TURBO = k_turbo<64> (one wavefront per code block), LSN_K_TURBO128 = k_turbo<128> (two) */
+       LSN_K_PDSCH_PREP, LSN_K_PDSCH_DEMOD, LSN_K_TURBO, LSN_K_RB_POWER, LSN_K_TURBO128, LSN_K_RM, LSN_K_COUNT };
+/* LSN_K_TURBO = k_turbo<64> (one wavefront per code block), LSN_K_TURBO128 = k_turbo<128> (two), LSN_K_RM = k_rm (rate de-matching in front of both) */
 const char* lsn_kernel_name(int k);
 const char* lsn_version(void);
 

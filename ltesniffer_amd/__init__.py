@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libltesniffer_amd.so")
 LSN_SUCCESS, LSN_ERROR, LSN_ERROR_INVALID_INPUTS, LSN_ERROR_NO_DEVICE = 0, -1, -2, -3
 TAP_GRID, TAP_CE, TAP_PDCCH_LLR, TAP_CHEST, TAP_CFI, TAP_CANDIDATES, TAP_CCE_POWER, TAP_ACCEPTED, TAP_RB_POWER = range(9)
 KERNELS = ["k_ofdm", "k_chest", "k_chest_fin", "k_pcfich", "k_pdcch_llr", "k_cce_power", "k_viterbi", "k_pdsch_prep",
-           "k_pdsch_demod", "k_turbo<64>", "k_rb_power", "k_turbo<128>"]
+           "k_pdsch_demod", "k_turbo<64>", "k_rb_power", "k_turbo<128>", "k_rm"]
 
 # every symbol include/ltesniffer_amd.h declares
 EXPORTS = ["lsn_phy_create", "lsn_phy_destroy", "lsn_phy_set_cell", "lsn_phy_get_avail", "lsn_phy_put_pending",
@@ -30,7 +30,9 @@ EXPORTS = ["lsn_phy_create", "lsn_phy_destroy", "lsn_phy_set_cell", "lsn_phy_get
            "lsn_phy_get_perf", "lsn_kernel_name", "lsn_version", "lsn_pcap_open", "lsn_pcap_open_mem",
            "lsn_pcap_set_wall_clock", "lsn_pcap_write", "lsn_pcap_sink", "lsn_pcap_mem", "lsn_pcap_nof_records",
            "lsn_pcap_reset", "lsn_pcap_close", "lsn_phy_set_pcap_writer", "lsn_phy_set_ul_config", "lsn_phy_pusch_decode",
-           "lsn_phy_tap_ul", "lsn_phy_set_prach_config", "lsn_phy_prach_detect", "lsn_phy_set_prach_sink", "lsn_prach_tti_opportunity", "lsn_phy_process_file", "lsn_phy_mib_decode", "lsn_phy_mib_decode_llr", "lsn_phy_submit_device", "lsn_phy_wait", "lsn_cell_search"]
+           "lsn_phy_tap_ul", "lsn_phy_set_prach_config", "lsn_phy_prach_detect", "lsn_phy_set_prach_sink", "lsn_prach_tti_opportunity", "lsn_phy_process_file", "lsn_phy_mib_decode", "lsn_phy_mib_decode_llr", "lsn_phy_submit_device", "lsn_phy_wait", "lsn_cell_search",
+           "lsn_phy_set_shortcut_discovery", "lsn_phy_get_shortcut_discovery", "lsn_phy_set_histogram_threshold", "lsn_phy_print_stats",
+           "lsn_phy_set_mcs_update_interval", "lsn_phy_update_mcs_database", "lsn_phy_nof_tracked_rnti", "lsn_worker_buffers_offset", "lsn_pcap_digest", "lsn_pcap_set_store"]
 
 
 PRACH_NCS = [0, 13, 15, 18, 22, 26, 32, 38, 46, 59, 76, 93, 119, 167, 279, 419]  # 36.211 Table 5.7.2-2
@@ -214,6 +216,9 @@ def lib():
         L.lsn_pcap_reset.argtypes = [C.c_void_p]
         L.lsn_pcap_reset.restype = None
         L.lsn_pcap_close.argtypes = [C.c_void_p]
+        L.lsn_pcap_digest.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.lsn_pcap_set_store.argtypes = [C.c_void_p, C.c_int]
+        L.lsn_pcap_set_store.restype = None
         L.lsn_pcap_close.restype = None
         L.lsn_phy_set_pcap_writer.argtypes = [C.c_void_p, C.c_void_p]
         L.lsn_phy_set_ul_config.argtypes = [C.c_void_p, C.POINTER(UlCfg)]
@@ -231,6 +236,16 @@ def lib():
         L.lsn_phy_set_prach_sink.argtypes = [C.c_void_p, PRACH_SINK, C.c_void_p]
         L.lsn_phy_set_prach_sink.restype = None
         L.lsn_prach_tti_opportunity.argtypes = [C.c_uint32, C.c_uint32]
+        L.lsn_phy_set_shortcut_discovery.argtypes = [C.c_void_p, C.c_int]
+        L.lsn_phy_get_shortcut_discovery.argtypes = [C.c_void_p]
+        L.lsn_phy_set_histogram_threshold.argtypes = [C.c_void_p, C.c_uint32]
+        L.lsn_phy_print_stats.argtypes = [C.c_void_p, C.c_void_p]
+        L.lsn_phy_set_mcs_update_interval.argtypes = [C.c_void_p, C.c_uint32]
+        L.lsn_phy_update_mcs_database.argtypes = [C.c_void_p]
+        L.lsn_phy_nof_tracked_rnti.argtypes = [C.c_void_p]
+        L.lsn_phy_nof_tracked_rnti.restype = C.c_uint32
+        L.lsn_worker_buffers_offset.argtypes = [C.c_void_p]
+        L.lsn_worker_buffers_offset.restype = C.POINTER(C.POINTER(C.c_float))
         L.lsn_cell_search.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_uint64, C.c_uint32, C.POINTER(CellSearchCfg), C.POINTER(CellSearch), C.c_void_p]
         _lib = L
     return _lib
@@ -270,6 +285,15 @@ class PcapWriter:
 
     def nof_records(self):
         return lib().lsn_pcap_nof_records(self._h)
+
+    def digest(self):
+        """(64-bit digest, bytes) of the record stream since open / reset, timestamps excluded"""
+        d, n = C.c_uint64(), C.c_uint64()
+        _check(lib().lsn_pcap_digest(self._h, C.byref(d), C.byref(n)), "pcap_digest")
+        return int(d.value), int(n.value)
+
+    def set_store(self, on):
+        lib().lsn_pcap_set_store(self._h, int(bool(on)))
 
     def reset(self):
         lib().lsn_pcap_reset(self._h)
@@ -359,6 +383,38 @@ class Phy:
 
     def joinPending(self):
         _check(lib().lsn_phy_join_pending(self._h), "joinPending")
+
+    # ---- the calls LTESniffer_Core makes on PhyCommon / RNTIManager / MCSTracking (LTESniffer_Core.cc:87,473-499,561,616-620) ----
+    def setShortcutDiscovery(self, enable):
+        _check(lib().lsn_phy_set_shortcut_discovery(self._h, int(bool(enable))), "setShortcutDiscovery")
+
+    def getShortcutDiscovery(self):
+        return bool(lib().lsn_phy_get_shortcut_discovery(self._h))
+
+    def setHistogramThreshold(self, threshold):
+        _check(lib().lsn_phy_set_histogram_threshold(self._h, int(threshold)), "setHistogramThreshold")
+
+    def printStats(self):
+        """PhyCommon::printStats: the two CSV lines, returned as text (written through a FILE* by the library)"""
+        import tempfile
+        libc = C.CDLL(None)
+        libc.fopen.restype = C.c_void_p
+        libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+        libc.fclose.argtypes = [C.c_void_p]
+        with tempfile.NamedTemporaryFile() as t:
+            f = libc.fopen(t.name.encode(), b"w")
+            _check(lib().lsn_phy_print_stats(self._h, C.c_void_p(f)), "printStats")
+            libc.fclose(f)
+            return open(t.name).read()
+
+    def setMcsUpdateInterval(self, seconds):
+        _check(lib().lsn_phy_set_mcs_update_interval(self._h, int(seconds)), "setMcsUpdateInterval")
+
+    def updateMcsDatabase(self):
+        _check(lib().lsn_phy_update_mcs_database(self._h), "updateMcsDatabase")
+
+    def nofTrackedRnti(self):
+        return int(lib().lsn_phy_nof_tracked_rnti(self._h))
 
     # ---- offline / file-replay path ----
     def process_host(self, iq, start_tti, update_meta_period=0):

@@ -14,6 +14,7 @@
 struct lsn_worker {
   lsn_phy* phy = nullptr;
   float* buf[LSN_MAX_RX] = {nullptr, nullptr};
+  float* buf_offset[2] = {nullptr, nullptr};  // SubframeBuffer::sf_buffer_offset (allocated on first use)
   uint32_t buf_len = 0;  // complex samples per antenna
   uint32_t sf_idx = 0, sfn = 0;
   int update_meta = 0;
@@ -109,9 +110,11 @@ void lsn_phy_destroy(lsn_phy_t* phy)
   }
   phy->cv_pending.notify_all();
   if (phy->dispatcher.joinable()) phy->dispatcher.join();
-  for (auto& w : phy->workers)
+  for (auto& w : phy->workers) {
     for (auto& b : w->buf)
       if (b) (void)hipHostFree(b);
+    for (auto& b : w->buf_offset) free(b);
+  }
   if (phy->staging) (void)hipHostFree(phy->staging);
   delete phy;
 }
@@ -132,9 +135,11 @@ int lsn_phy_set_cell(lsn_phy_t* phy, const lsn_cell_t* cell)
   const int r = phy->engine->setCell(*cell);
   if (r != LSN_SUCCESS) return r;
   // worker pool: SubframeBuffer allocates 3 * SF_LEN per antenna (SubframeBuffer.cc:25)
-  for (auto& w : phy->workers)
+  for (auto& w : phy->workers) {
     for (auto& b : w->buf)
       if (b) { (void)hipHostFree(b); b = nullptr; }
+    for (auto& b : w->buf_offset) { free(b); b = nullptr; }
+  }
   phy->workers.clear(); phy->avail.clear(); phy->pending.clear();
   if (phy->staging) { (void)hipHostFree(phy->staging); phy->staging = nullptr; }
   const uint32_t sflen = phy->engine->sfLen(), A = phy->engine->nofRx();
@@ -224,6 +229,44 @@ int lsn_phy_setup_default_rnti_intervals(lsn_phy_t* phy)
   phy->engine->setupDefaultIntervals();
   return LSN_SUCCESS;
 }
+int lsn_phy_set_shortcut_discovery(lsn_phy_t* phy, int enable)
+{
+  if (!phy) return LSN_ERROR_INVALID_INPUTS;
+  phy->engine->searchRef().setShortcutDiscovery(enable != 0);
+  return LSN_SUCCESS;
+}
+int lsn_phy_get_shortcut_discovery(lsn_phy_t* phy) { return phy && phy->engine->searchRef().getShortcutDiscovery() ? 1 : 0; }
+int lsn_phy_set_histogram_threshold(lsn_phy_t* phy, uint32_t threshold)
+{
+  if (!phy) return LSN_ERROR_INVALID_INPUTS;
+  phy->engine->rntiManager().setHistogramThreshold(threshold);
+  return LSN_SUCCESS;
+}
+int lsn_phy_print_stats(lsn_phy_t* phy, void* file)
+{
+  if (!phy) return LSN_ERROR_INVALID_INPUTS;
+  FILE* f = file ? (FILE*)file : stdout;
+  lsn_blind_stats_t s;
+  phy->engine->getStats(&s);
+  const double us = phy->engine->searchTimeUs();
+  fprintf(f, "nof_decoded_locations, nof_cce, nof_missed_cce, nof_subframes, nof_subframe_collisions_dw, nof_subframe_collisions_up, time, nof_locations\n");
+  fprintf(f, "%u, %u, %u, %u, %u, %u, %ld.%06ld, %u\n", s.nof_decoded_locations, s.nof_cce, s.nof_missed_cce, s.nof_subframes, s.nof_subframe_collisions_dw,
+          s.nof_subframe_collisions_up, (long)(us / 1e6), (long)us % 1000000L, s.nof_locations);
+  return LSN_SUCCESS;
+}
+int lsn_phy_set_mcs_update_interval(lsn_phy_t* phy, uint32_t seconds)
+{
+  if (!phy || seconds > 4000000u) return LSN_ERROR_INVALID_INPUTS;
+  phy->engine->setMcsUpdateInterval(seconds);
+  return LSN_SUCCESS;
+}
+int lsn_phy_update_mcs_database(lsn_phy_t* phy)
+{
+  if (!phy) return LSN_ERROR_INVALID_INPUTS;
+  phy->engine->updateMcsDatabase();
+  return LSN_SUCCESS;
+}
+uint32_t lsn_phy_nof_tracked_rnti(lsn_phy_t* phy) { return phy ? phy->engine->nofTrackedRnti() : 0; }
 uint32_t lsn_phy_nof_active_rnti(lsn_phy_t* phy) { return phy ? phy->engine->rntiManager().nofActive() : 0; }
 int lsn_phy_get_ue_config(lsn_phy_t* phy, uint16_t rnti, lsn_ue_config_t* out)
 {
@@ -237,6 +280,13 @@ int lsn_phy_get_ue_config(lsn_phy_t* phy, uint16_t rnti, lsn_ue_config_t* out)
 }
 
 float** lsn_worker_buffers(lsn_worker_t* w) { return w ? w->buf : nullptr; }
+float** lsn_worker_buffers_offset(lsn_worker_t* w)
+{
+  if (!w) return nullptr;
+  for (auto& b : w->buf_offset)
+    if (!b) b = (float*)calloc((size_t)w->buf_len * 2, sizeof(float));
+  return w->buf_offset;
+}
 uint32_t lsn_worker_buffer_len(lsn_worker_t* w) { return w ? w->buf_len : 0; }
 int lsn_worker_prepare(lsn_worker_t* w, uint32_t sf_idx, uint32_t sfn, int update_meta_formats, const lsn_dl_sf_cfg_t* sf)
 {
@@ -344,7 +394,7 @@ int lsn_phy_get_perf(lsn_phy_t* phy, lsn_perf_t* out)
 const char* lsn_kernel_name(int k)
 {
   static const char* names[LSN_K_COUNT] = {"k_ofdm", "k_chest", "k_chest_fin", "k_pcfich", "k_pdcch_llr", "k_cce_power", "k_viterbi",
-                                           "k_pdsch_prep", "k_pdsch_demod", "k_turbo<64>", "k_rb_power", "k_turbo<128>"};
+                                           "k_pdsch_prep", "k_pdsch_demod", "k_turbo<64>", "k_rb_power", "k_turbo<128>", "k_rm"};
   return (k >= 0 && k < LSN_K_COUNT) ? names[k] : "";
 }
 const char* lsn_version(void) { return "ltesniffer_amd 0.1 (gfx950)"; }

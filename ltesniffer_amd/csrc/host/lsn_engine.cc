@@ -33,6 +33,8 @@ namespace lsn {
 // waits are 2-15 ms long; the decode threads nap 50 us, the front thread (which feeds the sequential search) 15 us, with the
 // threads' timer slack set to 1 us so the naps are that short.  LSN_SPIN_WAIT=1 spins.
 static const bool g_spin_wait = getenv("LSN_SPIN_WAIT") && atoi(getenv("LSN_SPIN_WAIT"));
+// LSN_TURBO_FORK=1: k_turbo<64> on a second stream per runner next to k_turbo<128> (more HSA queues: measured slower beyond 6 decode threads)
+static const bool g_turbo_fork = getenv("LSN_TURBO_FORK") && atoi(getenv("LSN_TURBO_FORK"));
 static void waitEvent(hipEvent_t ev, long nap_ns = 50000)
 {
   if (g_spin_wait) {
@@ -51,6 +53,31 @@ static void waitEvent(hipEvent_t ev, long nap_ns = 50000)
 static double now_ms()
 {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// pipeline event log (LSN_TRACE): thread 0 = caller/search, 1 = front, 2.. = decode threads
+enum { TR_ACQ_BEGIN = 0, TR_ACQ_END, TR_A_DONE, TR_SPEC_DONE, TR_SEARCH_BEGIN, TR_SEARCH_END, TR_DEC_BEGIN, TR_W1_LAUNCHED, TR_W1_DONE, TR_W2_DONE,
+       TR_COMMIT_BEGIN, TR_COMMIT_END };
+void Engine::trace(uint8_t thr, uint8_t ev, uint32_t chunk)
+{
+  if (!trace_path) return;
+  const double t = now_ms();
+  std::lock_guard<std::mutex> lk(trace_mtx);
+  trace_log.push_back({t, thr, ev, chunk});
+}
+void Engine::traceDump()
+{
+  if (!trace_path) return;
+  std::lock_guard<std::mutex> lk(trace_mtx);
+  if (trace_log.empty()) return;
+  static const char* nm[] = {"acq_begin", "acq_end", "stage_a_done", "spec_done", "search_begin", "search_end", "dec_begin", "w1_launched", "w1_done",
+                             "w2_done", "commit_begin", "commit_end"};
+  if (FILE* f = fopen(trace_path, "w")) {
+    const double t0 = trace_log[0].t;
+    for (auto& e : trace_log) fprintf(f, "%u %s %u %.4f\n", (unsigned)e.thr, nm[e.ev], e.chunk, e.t - t0);
+    fclose(f);
+  }
+  trace_log.clear();
 }
 
 static const int kStageA[8] = {LSN_K_OFDM, LSN_K_CHEST, LSN_K_CHEST_FIN, LSN_K_PCFICH, LSN_K_PDCCH_LLR, LSN_K_CCE_POWER, LSN_K_VITERBI, LSN_K_RB_POWER};
@@ -122,9 +149,12 @@ Engine::Engine(const lsn_phy_cfg_t& c) : cfg(c)
     for (auto& sa : stream_a) HIP_CHECK(hipStreamCreateWithPriority(&sa, hipStreamNonBlocking, hi));  // stage A feeds the sequential search
   }
   HIP_CHECK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
+  trace_path = getenv("LSN_TRACE");
+  for (uint32_t i = 0; i < 65536; i++) { pred_table[i].store(0xFF, std::memory_order_relaxed); pred_p_a[i].store(0.0f, std::memory_order_relaxed); }
   if (const char* e = getenv("LSN_DECODE_THREADS")) ndec = std::max(1, std::min((int)NDEC, atoi(e)));
   nslots = ndec + 5;
   front_thread = std::thread([this] { pthread_setname_np(pthread_self(), "lsn-front"); frontLoop(); });
+  commit_thread = std::thread([this] { pthread_setname_np(pthread_self(), "lsn-commit"); commitLoop(); });
   for (int i = 0; i < ndec; i++)
     decode_threads[i] = std::thread([this, i] {
       char nm[16];
@@ -142,7 +172,9 @@ Engine::~Engine()
   }
   cv_work.notify_all();
   cv_front.notify_all();
+  cv_commit.notify_all();
   if (front_thread.joinable()) front_thread.join();
+  if (commit_thread.joinable()) commit_thread.join();
   for (auto& t : decode_threads)
     if (t.joinable()) t.join();
   (void)hipDeviceSynchronize();
@@ -309,7 +341,7 @@ void Engine::searchChunk(Chunk& ch, uint32_t update_meta_period)
     sf_cnt++;
     const double ts0 = now_ms();
     search->search(c, ch.h_cand + (size_t)sf * LSN_MAX_LOC * LSN_MAX_SIZES, ch.h_ccepow + (size_t)sf * LSN_CCE_STRIDE, upd);
-    perf.ms_search_core += now_ms() - ts0;
+    { const double dt = now_ms() - ts0; perf.ms_search_core += dt; search_time_us += dt * 1e3; }
     est_cfo = c.cfo_hz;  // SubframeWorker.cc:203
     if (!c.searched) continue;
     // RAR grants feed the RNTI manager before the next subframe is searched (DL_Sniffer_PDSCH.cc:782-797): decode them now
@@ -351,7 +383,7 @@ void Engine::unpackRar(const uint8_t* p, int len, bool at_search)
   const int n = rar_parse(cell, p, len, r, 32);
   for (int i = 0; i < n; i++) {
     if (at_search) search->rntiManager().activateAndRefresh(r[i].t_crnti, 0, RM_ACT_RAR);  // search thread owns the RNTI manager
-    else mcs_tracking.update_rar_time_crnti(r[i].t_crnti);                                // commit thread owns the MCS tracking
+    else { mcs_tracking.update_rar_time_crnti(r[i].t_crnti, commit_sf_cnt); publishPrediction(r[i].t_crnti); }  // commit thread owns the MCS tracking
   }
 }
 
@@ -480,7 +512,8 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
     r.h_jobs.push_back(d);
   }
   const uint32_t njobs = (uint32_t)r.h_jobs.size(), ncb = (uint32_t)r.h_cbs.size();
-  uint32_t n128 = 0, kmax128 = 0, kmax64 = 0;
+  uint32_t n128 = 0, kmax128 = 0, kmax64 = 0, emax = 0;
+  size_t spp_n = 0;
   std::vector<uint32_t> order;
   if (njobs) {
     grow_dev(r.d_jobs, r.jobs_cap, njobs, st);
@@ -507,10 +540,13 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
         return x < y;
       });
       for (uint32_t i = 0; i < ncb; i++) {
-        const LsnCbDev& q = r.h_cbs[order[i]];
+        LsnCbDev q = r.h_cbs[order[i]];
+        q.spp_off = (uint32_t)spp_n; spp_n += LSN_SPP_WORDS(q.K);
+        emax = std::max(emax, q.E);
         r.h_cbs_pinned[i] = q;
         if (lsn_turbo_nwin((int)q.K) > 64) { n128++; kmax128 = std::max(kmax128, q.K); } else kmax64 = std::max(kmax64, q.K);
       }
+      grow_dev(r.d_spp, r.spp_cap, spp_n + 16, st);
       HIP_CHECK(hipMemcpyAsync(r.d_cbs, r.h_cbs_pinned, ncb * sizeof(LsnCbDev), hipMemcpyHostToDevice, st));
     }
     HIP_CHECK(hipMemsetAsync(r.d_llr16, 0, llr_n * sizeof(int16_t), st));
@@ -520,7 +556,23 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
     lsn_launch_pdsch_demod(cd, r.d_jobs, r.d_prefix, ch.d_grid, ch.d_ce, ch.d_chest, r.d_llr16, njobs, st);
     HIP_CHECK(hipEventRecord(r.ev[2], st));
     if (ncb) {
-      lsn_launch_turbo(cd, r.d_cbs, r.d_llr16, r.d_payload, r.d_cbres, n128, kmax128, ncb - n128, kmax64, st, r.ev[4]);
+      lsn_launch_rm(r.d_cbs, r.d_llr16, r.d_spp, ncb, emax, st);
+      HIP_CHECK(hipEventRecord(r.ev[5], st));
+      // the two decoder variants run side by side (one stream each): neither waits for the other's slowest code block
+      const bool fork = g_turbo_fork && n128 && ncb > n128 && r.stream2;
+      if (fork) {
+        HIP_CHECK(hipEventRecord(r.ev_fork, st));
+        HIP_CHECK(hipStreamWaitEvent(r.stream2, r.ev_fork, 0));
+        HIP_CHECK(hipEventRecord(r.ev[6], r.stream2));
+        lsn_launch_turbo(cd, r.d_cbs + n128, r.d_spp, r.d_payload, r.d_cbres, 0, 0, ncb - n128, kmax64, r.stream2, nullptr);
+        HIP_CHECK(hipEventRecord(r.ev[7], r.stream2));
+        HIP_CHECK(hipEventRecord(r.ev_join, r.stream2));
+        lsn_launch_turbo(cd, r.d_cbs, r.d_spp, r.d_payload, r.d_cbres, n128, kmax128, 0, 0, st, nullptr);
+        HIP_CHECK(hipEventRecord(r.ev[4], st));
+        HIP_CHECK(hipStreamWaitEvent(st, r.ev_join, 0));
+      } else {
+        lsn_launch_turbo(cd, r.d_cbs, r.d_spp, r.d_payload, r.d_cbres, n128, kmax128, ncb - n128, kmax64, st, r.ev[4]);
+      }
       HIP_CHECK(hipEventRecord(r.ev[3], st));
       HIP_CHECK(hipMemcpyAsync(r.h_cbres_pinned, r.d_cbres, ncb * sizeof(LsnCbRes), hipMemcpyDeviceToHost, st));
       HIP_CHECK(hipMemcpyAsync(r.h_payload_pinned, r.d_payload, pay_n - pay0, hipMemcpyDeviceToHost, st));
@@ -532,8 +584,10 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
     if (hipEventElapsedTime(&ms, r.ev[1], r.ev[2]) == hipSuccess) pf.kernel_ms[LSN_K_PDSCH_DEMOD] += ms;
     pf.kernel_launches[LSN_K_PDSCH_PREP]++; pf.kernel_launches[LSN_K_PDSCH_DEMOD]++;
     if (ncb) {
-      if (n128 && hipEventElapsedTime(&ms, r.ev[2], r.ev[4]) == hipSuccess) { pf.kernel_ms[LSN_K_TURBO128] += ms; pf.kernel_launches[LSN_K_TURBO128]++; }
-      if (ncb > n128 && hipEventElapsedTime(&ms, r.ev[4], r.ev[3]) == hipSuccess) { pf.kernel_ms[LSN_K_TURBO] += ms; pf.kernel_launches[LSN_K_TURBO]++; }
+      if (hipEventElapsedTime(&ms, r.ev[2], r.ev[5]) == hipSuccess) { pf.kernel_ms[LSN_K_RM] += ms; pf.kernel_launches[LSN_K_RM]++; }
+      if (n128 && hipEventElapsedTime(&ms, r.ev[5], r.ev[4]) == hipSuccess) { pf.kernel_ms[LSN_K_TURBO128] += ms; pf.kernel_launches[LSN_K_TURBO128]++; }
+      const bool forked = g_turbo_fork && n128 && ncb > n128 && r.stream2;
+      if (ncb > n128 && hipEventElapsedTime(&ms, forked ? r.ev[6] : r.ev[4], forked ? r.ev[7] : r.ev[3]) == hipSuccess) { pf.kernel_ms[LSN_K_TURBO] += ms; pf.kernel_launches[LSN_K_TURBO]++; }
       for (uint32_t i = 0; i < n128; i++) pf.turbo128_algo_bytes += (uint64_t)r.h_cbs_pinned[i].E * 2ull + r.h_cbs_pinned[i].out_bytes;
     }
     ch.h_payload.resize(pay_n);
@@ -580,7 +634,6 @@ void Engine::planJobs(Chunk& ch, JobRunner& r)
   std::vector<Pending> retry;
   for (uint32_t sf = 0; sf < ch.nsf; sf++)  // MCS / TBS / RE counts of every accepted downlink DCI (deferred from the sequential search)
     for (auto& e : ch.ctx[sf].dl) search->finishDlEntry(e, ch.ctx[sf].sf_idx, ch.ctx[sf].cfi);
-  std::unique_lock<std::mutex> mcs_lk(mcs_mtx);
   for (uint32_t sf = 0; sf < ch.nsf; sf++) {
     SubframeCtx& c = ch.ctx[sf];
     if (!c.searched) continue;
@@ -595,7 +648,7 @@ void Engine::planJobs(Chunk& ch, JobRunner& r)
       }
       McsTable table;
       if (cfg.mcs_tracking_mode == 1)
-        table = (e.rnti == SIRNTI || e.rnti == PRNTI || rnti_israr(e.rnti) || e.format == FORMAT1A) ? TABLE_64QAM : mcs_tracking.peek(e.rnti);
+        table = (e.rnti == SIRNTI || e.rnti == PRNTI || rnti_israr(e.rnti) || e.format == FORMAT1A) ? TABLE_64QAM : predictedTable(e.rnti);
       else
         table = cfg.mcs_tracking_mode == 2 ? TABLE_UNKNOWN : TABLE_64QAM;
       const int first = table == TABLE_256QAM ? 1 : 0;
@@ -603,13 +656,15 @@ void Engine::planJobs(Chunk& ch, JobRunner& r)
       const bool ok = first ? e.ok256 : e.ok64;
       if (!ok || !(g.tb[0].tbs > 0)) continue;
       if (dlRx() == 1 && (e.grant64.nof_tb == 2 || e.grant256.nof_tb == 2)) continue;
-      if (e.job[first] < 0) e.job[first] = newJob(ch, sf, e, first, mcs_tracking.get_ue_config_rnti(e.rnti).p_a);  // as of now; commit checks it
+      if (e.job[first] < 0) e.job[first] = newJob(ch, sf, e, first, predictedPa(e.rnti));  // as of now; commit checks it
       if (e.job[first] >= 0) wave.push_back(e.job[first]);
       if (table >= TABLE_UNKNOWN && e.ok256) retry.push_back({sf, di});
     }
   }
-  mcs_lk.unlock();
+  const uint8_t trk = (uint8_t)(2 + (&r - runner_c));
+  trace(trk, TR_W1_LAUNCHED, ch.trace_id);  // host-side planning done
   runJobs(ch, r, wave);
+  trace(trk, TR_W1_DONE, ch.trace_id);
   wave.clear();
   for (auto& p : retry) {
     DlEntry& e = ch.ctx[p.sf].dl[p.di];
@@ -636,19 +691,39 @@ void Engine::emitPdu(JobRunner& r, const char* name, const uint8_t* pdu, uint32_
   sink(sink_user, &c, pdu, len);
 }
 
-// a decoded C-RNTI transport block: RRCConnectionSetup -> UE configuration database (caller holds mcs_mtx)
+// a decoded C-RNTI transport block: RRCConnectionSetup -> UE configuration database (commit thread)
 void Engine::learnUeConfig(const uint8_t* pdu, int len, uint16_t rnti)
 {
-  if (mcs_tracking.learn_from_pdu(pdu, len, rnti)) default_p_a.store(mcs_tracking.default_p_a(), std::memory_order_relaxed);
+  if (mcs_tracking.learn_from_pdu(pdu, len, rnti, commit_sf_cnt)) default_p_a.store(mcs_tracking.default_p_a(), std::memory_order_relaxed);
+}
+
+// what the decode threads may read of the tracking database while they plan a chunk (a prediction: commit re-derives everything)
+void Engine::publishPrediction(uint16_t rnti)
+{
+  pred_table[rnti].store(mcs_tracking.present(rnti) ? (uint8_t)mcs_tracking.peek(rnti) : (uint8_t)0xFF, std::memory_order_relaxed);
+  pred_p_a[rnti].store(mcs_tracking.get_ue_config_rnti(rnti).p_a, std::memory_order_relaxed);
+}
+
+// MCSTracking::update_database_dl as LTESniffer_Core drives it (LTESniffer_Core.cc:473-499): every get_interval() x 1000 subframes
+void Engine::ageTrackingDatabase()
+{
+  std::vector<uint16_t> changed;
+  mcs_tracking.update_database_dl(commit_sf_cnt, &changed);
+  for (uint16_t r : changed) publishPrediction(r);
+  nof_mcs_db_updates++;
 }
 
 // PDSCH_Decoder::decode_dl_mode (DL_Sniffer_PDSCH.cc:881-1291) over the decode results of every subframe of the chunk
 void Engine::commitChunk(Chunk& ch, JobRunner& r)
 {
-  std::unique_lock<std::mutex> mcs_lk(mcs_mtx);
   std::vector<McsTable> tables;
-  for (uint32_t sf = 0; sf < ch.nsf; sf++) {
+  for (uint32_t sf = 0; sf < ch.nsf; sf++, commit_sf_cnt++) {
     SubframeCtx& c = ch.ctx[sf];
+    // the tracking database is only WRITTEN here (commit thread); decode threads read the published prediction arrays, the API getter
+    // (lsn_phy_get_ue_config) takes this lock
+    std::unique_lock<std::mutex> mcs_lk(mcs_mtx);
+    const uint32_t now = commit_sf_cnt;
+    if (cfg.mcs_tracking_mode && mcs_update_period && commit_sf_cnt && (commit_sf_cnt % mcs_update_period) == 0) ageTrackingDatabase();
     if (!c.searched) continue;
     // DCICollection.cc:107-134: the table of every DCI of this subframe is fixed before any of them is decoded
     tables.resize(c.dl.size());
@@ -656,7 +731,7 @@ void Engine::commitChunk(Chunk& ch, JobRunner& r)
       const DlEntry& e = c.dl[di];
       if (cfg.mcs_tracking_mode == 1)
         tables[di] = (e.rnti == SIRNTI || e.rnti == PRNTI || rnti_israr(e.rnti) || e.format == FORMAT1A) ? TABLE_64QAM
-                                                                                                        : mcs_tracking.find_tracking_info_RNTI_dl(e.rnti);
+                                                                                                        : mcs_tracking.find_tracking_info_RNTI_dl(e.rnti, now);
       else
         tables[di] = cfg.mcs_tracking_mode == 2 ? TABLE_UNKNOWN : TABLE_64QAM;
     }
@@ -684,12 +759,16 @@ void Engine::commitChunk(Chunk& ch, JobRunner& r)
         return e.job[t];
       };
       auto payload_of = [&](int j, int tb) { return ch.h_payload.data() + ch.jobs[j].payload_off[tb]; };
-      bool crc[2] = {false, false};
+      auto mimo_of = [&](const PdschGrant& g) { PdschGrant t = g; return -dl_sniffer_config_mimo(cell, e.format, e.dci, t); };  // 0 / -1 / -2 / -3
+      bool crc[2] = {false, false};   // pdsch_res[].crc as the statistics see it at the end of the iteration
+      int mimo_ret = 0;
       if (table == TABLE_64QAM || table == TABLE_256QAM) {  // :932-1083
+        mimo_ret = mimo_of(cur);
         const int j = run(cur_t);
         if (j >= 0)
           for (int tb = 0; tb < 2; tb++) {
             const int len = ch.jobs[j].grant.tb[tb].tbs / 8;
+            crc[tb] = ch.jobs[j].crc[tb];
             if (ch.jobs[j].crc[tb] && len > 0) {
               emitPdu(r, name, payload_of(j, tb), (uint32_t)len, e.rnti, c.tti, (uint8_t)tb);
               if (name[0] == 'R') unpackRar(payload_of(j, tb), len, false);
@@ -697,6 +776,7 @@ void Engine::commitChunk(Chunk& ch, JobRunner& r)
             }
           }
       } else {  // unknown table: 64QAM table first, the 256QAM table only if both TBs failed, :1089-1243
+        mimo_ret = has64 ? mimo_of(e.grant64) : -1;
         const int j = run(0);
         if (j >= 0) {
           for (int tb = 0; tb < 2; tb++) {
@@ -706,29 +786,35 @@ void Engine::commitChunk(Chunk& ch, JobRunner& r)
               emitPdu(r, name, payload_of(j, tb), (uint32_t)len, e.rnti, c.tti, (uint8_t)tb);
               if (name[0] == 'R') unpackRar(payload_of(j, tb), len, false);
               if (name[0] == 'C') learnUeConfig(payload_of(j, tb), len, e.rnti);  // :1133-1160
-              if (e.dci.tb[tb].mcs_idx > 0 && e.dci.tb[tb].mcs_idx < 29 && e.format > FORMAT1A) mcs_tracking.update_RNTI_dl(e.rnti, TABLE_64QAM);
+              if (e.dci.tb[tb].mcs_idx > 0 && e.dci.tb[tb].mcs_idx < 29 && e.format > FORMAT1A) mcs_tracking.update_RNTI_dl(e.rnti, TABLE_64QAM, now);
             }
           }
-          if (!crc[0] && !crc[1]) {
-            const int j2 = run(1);
-            if (j2 >= 0)
-              for (int tb = 0; tb < 2; tb++) {
-                const int len = ch.jobs[j2].grant.tb[tb].tbs / 8;
-                if (ch.jobs[j2].crc[tb] && len > 0) {
-                  emitPdu(r, name, payload_of(j2, tb), (uint32_t)len, e.rnti, c.tti, (uint8_t)tb);
-                  if (e.dci.tb[tb].mcs_idx > 0 && e.dci.tb[tb].mcs_idx < 28 && e.format > FORMAT1A) mcs_tracking.update_RNTI_dl(e.rnti, TABLE_256QAM);
-                }
+        }
+        if (!crc[0] && !crc[1] && mimo_ret == 0) {
+          mimo_ret = has256 ? mimo_of(e.grant256) : -1;
+          const int j2 = run(1);
+          if (j2 >= 0)
+            for (int tb = 0; tb < 2; tb++) {
+              const int len = ch.jobs[j2].grant.tb[tb].tbs / 8;
+              if (ch.jobs[j2].grant.tb[tb].enabled) crc[tb] = ch.jobs[j2].crc[tb];
+              if (ch.jobs[j2].crc[tb] && len > 0) {
+                emitPdu(r, name, payload_of(j2, tb), (uint32_t)len, e.rnti, c.tti, (uint8_t)tb);
+                if (e.dci.tb[tb].mcs_idx > 0 && e.dci.tb[tb].mcs_idx < 28 && e.format > FORMAT1A) mcs_tracking.update_RNTI_dl(e.rnti, TABLE_256QAM, now);
               }
-          }
+            }
         }
       }
-      if (name[0] == 'C' && cfg.mcs_tracking_mode) mcs_tracking.update_statistic_dl(e.rnti, e.format);  // :1268-1285
+      if (name[0] == 'C' && cfg.mcs_tracking_mode) {  // :1268-1285
+        const bool tb_en[2] = {cur.tb[0].enabled, cur.tb[1].enabled};
+        mcs_tracking.update_statistic_dl(e.rnti, e.format, table, tb_en, crc, mimo_ret, now);
+      }
+      publishPrediction(e.rnti);
     }
   }
 }
 
-// decode threads: each takes the next chunk of the queue, plans and runs its PDSCH decodes on its own stream, then commits
-// when every earlier chunk has been committed (PDU order and MCS-table learning stay in TTI order)
+// decode threads: each takes the next chunk of the queue, plans and runs its PDSCH decodes on its own streams and hands the chunk
+// to the commit thread; commits happen in queue order (PDU order and MCS-table learning stay in TTI order)
 void Engine::decodeLoop(int idx)
 {
   JobRunner& r = runner_c[idx];
@@ -747,18 +833,43 @@ void Engine::decodeLoop(int idx)
     try {
       (void)hipSetDevice(cfg.device);
       const double t0 = now_ms();
+      trace((uint8_t)(2 + idx), TR_DEC_BEGIN, ch->trace_id);
       planJobs(*ch, r);
+      trace((uint8_t)(2 + idx), TR_W2_DONE, ch->trace_id);
       r.perf.ms_stage_c += now_ms() - t0;
     } catch (const std::exception& ex) {
       err = ex.what();
     }
     {
       std::unique_lock<std::mutex> lk(mtx);
-      cv_done.wait(lk, [&] { return seq_committed == ch->seq; });
+      decoded[ch->seq] = {ch, err};
+    }
+    cv_commit.notify_one();
+  }
+}
+
+void Engine::commitLoop()
+{
+  JobRunner& r = runner_k;
+  pinThisThread(nullptr);
+  prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0);
+  for (;;) {
+    Chunk* ch = nullptr;
+    std::string err;
+    {
+      std::unique_lock<std::mutex> lk(mtx);
+      cv_commit.wait(lk, [&] { return stop || decoded.count(seq_committed); });
+      auto it = decoded.find(seq_committed);
+      if (it == decoded.end()) return;  // stop
+      ch = it->second.first; err = it->second.second;
+      decoded.erase(it);
     }
     try {
+      (void)hipSetDevice(cfg.device);
       const double t1 = now_ms();
+      trace(15, TR_COMMIT_BEGIN, ch->trace_id);
       if (err.empty()) { if (cfg.sniffer_mode == 1) commitChunkUl(*ch, r); else commitChunk(*ch, r); }
+      trace(15, TR_COMMIT_END, ch->trace_id);
       r.perf.ms_commit += now_ms() - t1;
     } catch (const std::exception& ex) {
       err = ex.what();
@@ -770,6 +881,7 @@ void Engine::decodeLoop(int idx)
       ch->busy = false;
     }
     cv_done.notify_all();
+    cv_commit.notify_one();
   }
 }
 
@@ -795,6 +907,7 @@ void Engine::frontLoop()
       const size_t sf_stride = (size_t)cfg.nof_rx_antennas * cd.sflen * sizeof(cf32);
       auto acquire = [&](uint32_t ci) -> Chunk* {
         Chunk& ch = chunks[ci % (uint32_t)nslots];
+        trace(1, TR_ACQ_BEGIN, ci);
         {
           const double tw = now_ms();
           std::unique_lock<std::mutex> lk(mtx);
@@ -808,6 +921,8 @@ void Engine::frontLoop()
         ch.jobs.clear(); ch.h_payload.clear();
         for (uint32_t i = 0; i < ch.nsf; i++) ch.ctx[i].reset(ch.start_tti + i);
         ch.st_a = stream_a[ci % NSTREAM_A];
+        ch.trace_id = ci;
+        trace(1, TR_ACQ_END, ci);
         launchStageA(ch, (const uint8_t*)job.d_iq + (size_t)base * sf_stride);
         return &ch;
       };
@@ -820,7 +935,9 @@ void Engine::frontLoop()
         inflight.pop_front();
         const double t0 = now_ms();
         finishStageA(*cur);
+        trace(1, TR_A_DONE, cur->trace_id);
         speculateRar(*cur);
+        trace(1, TR_SPEC_DONE, cur->trace_id);
         perf_front.ms_stage_a += now_ms() - t0;
         {
           std::unique_lock<std::mutex> lk(mtx);
@@ -864,6 +981,7 @@ int Engine::submit(const void* d_iq, uint32_t nsf_total, uint32_t start_tti, uin
       for (auto& r : runner_c) r.perf = lsn_perf_t{};
       runner_s.perf = lsn_perf_t{};
       runner_f.perf = lsn_perf_t{};
+      runner_k.perf = lsn_perf_t{};
       t_batch = now_ms();
       batch_open = true;
     }
@@ -889,7 +1007,9 @@ int Engine::submit(const void* d_iq, uint32_t nsf_total, uint32_t start_tti, uin
       }
       if (!cur) break;
       const double t1 = now_ms();
+      trace(0, TR_SEARCH_BEGIN, cur->trace_id);
       searchChunk(*cur, update_meta_period);
+      trace(0, TR_SEARCH_END, cur->trace_id);
       perf.ms_search += now_ms() - t1;
       {
         std::unique_lock<std::mutex> lk(mtx);
@@ -932,7 +1052,9 @@ int Engine::wait()
     for (auto& r : runner_c) mergePerf(r.perf);
     mergePerf(runner_s.perf);
     mergePerf(runner_f.perf);
+    mergePerf(runner_k.perf);
     perf.ms_total = now_ms() - t_batch;
+    traceDump();
     return LSN_SUCCESS;
   } catch (const std::exception& ex) {
     fprintf(stderr, "ltesniffer_amd: %s\n", ex.what());

@@ -52,23 +52,27 @@ struct Chunk {
   std::vector<SpecRar> spec_rar;     // RA-RNTI grants decoded ahead of the search (front thread)
   bool busy = false;                 // owned by the pipeline (slot not reusable yet)
   uint64_t seq = 0;                  // position in the commit order
+  uint32_t trace_id = 0;             // chunk number inside its submit (LSN_TRACE)
 };
 
 // one stream + its device/host arenas for PDSCH decode launches
 struct JobRunner {
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;     // k_turbo<64> runs here, next to k_turbo<128> on `stream` (fork / join by events)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   LsnGrantDev* d_jobs = nullptr; size_t jobs_cap = 0;
   LsnCbDev* d_cbs = nullptr; size_t cbs_cap = 0;
   LsnCbRes* d_cbres = nullptr; size_t cbres_cap = 0;
   uint16_t* d_prefix = nullptr; size_t prefix_cap = 0;
   int16_t* d_llr16 = nullptr; size_t llr16_cap = 0;
+  uint32_t* d_spp = nullptr; size_t spp_cap = 0;   // de-rate-matched soft data of every code block of the launch (k_rm -> k_turbo)
   uint8_t* d_payload = nullptr; size_t payload_cap = 0;
   uint8_t* h_payload_pinned = nullptr; size_t h_payload_cap = 0;
   LsnCbRes* h_cbres_pinned = nullptr; size_t h_cbres_cap = 0;
   LsnGrantDev* h_jobs_pinned = nullptr; size_t h_jobs_cap = 0;
   LsnCbDev* h_cbs_pinned = nullptr; size_t h_cbs_cap = 0;
   std::vector<LsnGrantDev> h_jobs; std::vector<LsnCbDev> h_cbs;
-  hipEvent_t ev[8] = {};
+  hipEvent_t ev[10] = {};
   hipEvent_t ev_done = nullptr;  // blocking-sync event the owning thread waits on
   lsn_perf_t perf{};
 };
@@ -94,6 +98,8 @@ public:
   void getStats(lsn_blind_stats_t* s) const;
   float estCfo() const { return est_cfo; }
   RNTIManager& rntiManager() { return search->rntiManager(); }
+  FalconSearch& searchRef() { return *search; }
+  double searchTimeUs() const { return search_time_us; }
   uint32_t sfLen() const { return cd.sflen; }
   uint32_t nofRx() const { return cfg.nof_rx_antennas; }
   uint32_t dlRx() const { return cfg.sniffer_mode == 1 ? 1u : cfg.nof_rx_antennas; }  // DCISearch::prepareDCISearch, DCISearch.cc:592
@@ -145,6 +151,7 @@ private:
   void unpackRar(const uint8_t* p, int len, bool at_search);
   void emitPdu(JobRunner& r, const char* name, const uint8_t* pdu, uint32_t len, uint16_t rnti, uint32_t tti, uint8_t tb);
   void decodeLoop(int idx);
+  void commitLoop();
   void frontLoop();
   void mergePerf(const lsn_perf_t& p);
   void detectNumaCpus();
@@ -161,14 +168,29 @@ private:
   void* d_iq_staging = nullptr;
   size_t staging_sf = 0;
   Chunk chunks[NSLOTS];
-  JobRunner runner_c[NDEC], runner_s, runner_f;  // decode threads / search thread (on-demand RAR decodes) / front thread (speculative RAR decodes)
+  JobRunner runner_c[NDEC], runner_s, runner_f, runner_k;  // decode threads / search thread (on-demand RAR decodes) / front thread (speculative RAR decodes) / commit thread (on-demand decodes)
   static constexpr int NSTREAM_A = 3;        // stage A of consecutive chunks overlaps on the GPU (kernels of one stream serialise)
   hipStream_t stream_a[NSTREAM_A] = {};
   hipEvent_t ev_in = nullptr;
   std::unique_ptr<FalconSearch> search;
   MCSTracking mcs_tracking;
   std::atomic<float> default_p_a{0.0f};  // p-a of RNTIs without tracking entry (RA-RNTIs): readable by the search / front thread without mcs_mtx
-  std::mutex mcs_mtx;  // planJobs (prediction) vs commitChunk (authoritative updates)
+  std::mutex mcs_mtx;  // commit thread (authoritative updates) vs the API getter; the decode threads read the prediction arrays below
+  // per RNTI: tracked table (0xFF: no entry) and p-a as of the last commit that touched the RNTI; relaxed atomics, prediction only
+  std::unique_ptr<std::atomic<uint8_t>[]> pred_table{new std::atomic<uint8_t>[65536]};
+  std::unique_ptr<std::atomic<float>[]> pred_p_a{new std::atomic<float>[65536]};
+  McsTable predictedTable(uint16_t rnti) const { const uint8_t t = pred_table[rnti].load(std::memory_order_relaxed); return t == 0xFF ? TABLE_UNKNOWN : (McsTable)t; }
+  float predictedPa(uint16_t rnti) const { return pred_table[rnti].load(std::memory_order_relaxed) == 0xFF ? default_p_a.load(std::memory_order_relaxed) : pred_p_a[rnti].load(std::memory_order_relaxed); }
+  void publishPrediction(uint16_t rnti);
+  void ageTrackingDatabase();
+  uint32_t commit_sf_cnt = 0;        // subframes committed so far = the tracking database's clock (1 subframe = 1 ms)
+  uint32_t mcs_update_period = 5000; // MCSTracking::get_interval() x 1000 subframes (LTESniffer_Core.cc:473-485); 0: never
+  uint64_t nof_mcs_db_updates = 0;
+public:
+  void setMcsUpdateInterval(uint32_t seconds) { mcs_tracking.set_interval(seconds); mcs_update_period = seconds * 1000u; }
+  void updateMcsDatabase() { std::lock_guard<std::mutex> lk(mcs_mtx); ageTrackingDatabase(); }  // between process calls only
+  uint32_t nofTrackedRnti() { std::lock_guard<std::mutex> lk(mcs_mtx); return mcs_tracking.nof_RNTI_member_dl(); }
+private:
   // front thread: launches stage A chunk after chunk, hands finished chunks to the search (caller) thread
   std::thread front_thread;
   struct FrontJob { const void* d_iq = nullptr; uint32_t nsf_total = 0, start_tti = 0; bool pending = false; } front_job;
@@ -178,6 +200,9 @@ private:
   lsn_perf_t perf_front{};
   // decode threads
   std::thread decode_threads[NDEC];
+  std::thread commit_thread;                    // commits decoded chunks in queue order (PDU order and MCS-table learning stay in TTI order)
+  std::map<uint64_t, std::pair<Chunk*, std::string>> decoded;  // seq -> chunk whose decode launches have completed (+ error text)
+  std::condition_variable cv_commit;
   uint64_t seq_pushed = 0, seq_committed = 0;  // chunks queued / committed (commit order = queue order)
   std::mutex mtx;
   std::condition_variable cv_work, cv_done;
@@ -190,6 +215,7 @@ private:
   float est_cfo = 0;
   lsn_pdu_sink_t sink = nullptr; void* sink_user = nullptr;
   uint64_t sf_cnt = 0;
+  double search_time_us = 0;  // time_blindsearch of the statistics (PhyCommon.cc:111-112)
   Chunk* last_chunk = nullptr;
   bool force_meta_next = false;
   // uplink
@@ -218,6 +244,13 @@ private:
   cf32* mib_d_iq = nullptr; float* mib_d_llr = nullptr; LsnCand* mib_d_cand = nullptr;
   lsn_prach_sink_t prach_sink = nullptr; void* prach_sink_user = nullptr;
   std::vector<int> numa_cpus;  // CPUs local to the GPU (empty: unknown, no pinning)
+  // LSN_TRACE=<file>: pipeline event log (thread, event, chunk, ms since the first event), written by wait(); tools/trace_gantt.py reads it
+  struct TraceEv { double t; uint8_t thr, ev; uint32_t chunk; };
+  std::vector<TraceEv> trace_log;
+  std::mutex trace_mtx;
+  const char* trace_path = nullptr;
+  void trace(uint8_t thr, uint8_t ev, uint32_t chunk);
+  void traceDump();
 };
 
 bool prach_tti_opportunity(uint32_t config_idx, uint32_t tti);  // lsn_prach.cc

@@ -685,16 +685,18 @@ void DCIMetaFormats::update_formats()
 }
 
 // ---------------------------------------------------------------------------------------------- MCSTracking
-McsTable MCSTracking::find_tracking_info_RNTI_dl(uint16_t rnti) const
+McsTable MCSTracking::find_tracking_info_RNTI_dl(uint16_t rnti, uint32_t now)
 {
   if (!db[rnti].present) return count < max_size ? TABLE_UNKNOWN : TABLE_FULL_BUFFER;
+  db[rnti].time = now;
   return (McsTable)db[rnti].table;
 }
-void MCSTracking::add_RNTI_dl(uint16_t rnti)
+void MCSTracking::add_RNTI_dl(uint16_t rnti, uint32_t now)
 {
   if (db[rnti].present) return;
   db[rnti] = Entry();
   db[rnti].present = 1;
+  db[rnti].time = now;
   count++;
   ue_cfg[rnti] = default_cfg;  // MCSTracking.cc:791-792
   ue_cfg[rnti].has_ue_config = false;
@@ -706,12 +708,12 @@ UeSpecConfig MCSTracking::get_ue_config_rnti(uint16_t rnti) const
   c.has_ue_config = false;
   return c;
 }
-void MCSTracking::update_ue_config_rnti(uint16_t rnti, const UeSpecConfig& c)
+void MCSTracking::update_ue_config_rnti(uint16_t rnti, const UeSpecConfig& c, uint32_t now)
 {
-  add_RNTI_dl(rnti);
+  add_RNTI_dl(rnti, now);
   ue_cfg[rnti] = c;
 }
-bool MCSTracking::learn_from_pdu(const uint8_t* pdu, int len, uint16_t rnti)
+bool MCSTracking::learn_from_pdu(const uint8_t* pdu, int len, uint16_t rnti, uint32_t now)
 {
   MacSubheader sub[20];
   const int n = mac_dlsch_parse(pdu, len, sub, 20);
@@ -721,15 +723,15 @@ bool MCSTracking::learn_from_pdu(const uint8_t* pdu, int len, uint16_t rnti)
     UeSpecConfig c;
     if (!rrc_conn_setup_decode(pdu + sub[i].off, (int)sub[i].len, c)) continue;
     if (!has_default) update_default_ue_config(c);  // the first connection setup seen, DL_Sniffer_PDSCH.cc:1061-1065
-    update_ue_config_rnti(rnti, c);
+    update_ue_config_rnti(rnti, c, now);
     any = true;
   }
   return any;
 }
-void MCSTracking::update_RNTI_dl(uint16_t rnti, McsTable t)
+void MCSTracking::update_RNTI_dl(uint16_t rnti, McsTable t, uint32_t now)
 {
   Entry& e = db[rnti];
-  if (!e.present) { add_RNTI_dl(rnti); return; }
+  if (!e.present) { add_RNTI_dl(rnti, now); return; }
   if (e.has_rar) {
     if (e.nof_msg_after_rar > rar_thresold) { e.table = (uint8_t)t; e.has_rar = 0; }
     else e.table = TABLE_UNKNOWN;
@@ -737,8 +739,38 @@ void MCSTracking::update_RNTI_dl(uint16_t rnti, McsTable t)
     e.table = (uint8_t)t;
   }
 }
-void MCSTracking::update_rar_time_crnti(uint16_t crnti) { add_RNTI_dl(crnti); db[crnti].has_rar = 1; db[crnti].table = TABLE_UNKNOWN; }
-void MCSTracking::update_statistic_dl(uint16_t rnti, DciFormat f) { add_RNTI_dl(rnti); if (f > FORMAT1A && db[rnti].has_rar) db[rnti].nof_msg_after_rar++; }
+void MCSTracking::update_rar_time_crnti(uint16_t crnti, uint32_t now) { add_RNTI_dl(crnti, now); db[crnti].has_rar = 1; db[crnti].table = TABLE_UNKNOWN; }
+void MCSTracking::update_statistic_dl(uint16_t rnti, DciFormat f, McsTable table, const bool tb_en[2], const bool success[2], int mimo_ret, uint32_t now)
+{
+  add_RNTI_dl(rnti, now);
+  Entry& e = db[rnti];
+  if (f > FORMAT1A && e.has_rar) e.nof_msg_after_rar++;
+  if (table == TABLE_64QAM || table == TABLE_256QAM || table == TABLE_UNKNOWN)  // :1292-1384, transmission_type = NEW_TX throughout
+    for (int i = 0; i < 2; i++) {
+      if (tb_en[i]) e.nof_active++;
+      if (success[i]) e.nof_success_mgs++;
+      if (mimo_ret == -1 && tb_en[i]) e.nof_unsupport_mimo++;
+      else if (mimo_ret == -2 && tb_en[i]) e.nof_pinfo++;
+      else if (mimo_ret == -3 && tb_en[i]) e.nof_other_mimo++;
+    }
+}
+void MCSTracking::update_database_dl(uint32_t now, std::vector<uint16_t>* changed)
+{
+  for (uint32_t r = 0; r < 65536; r++) {
+    Entry& e = db[r];
+    if (!e.present) continue;
+    const uint32_t cur_interval = (now - e.time) / 1000u;  // whole seconds, like (cur_time - last_time) / CLOCKS_PER_SEC
+    const bool wrong_detect = e.nof_active == 0 || (e.nof_active <= 10 && e.nof_success_mgs == 0 && (e.nof_unsupport_mimo > 0 || e.nof_pinfo > 0 || e.nof_other_mimo > 0));
+    if (cur_interval > interval || wrong_detect || e.nof_active == 0) {
+      e = Entry();
+      count--;
+      if (changed) changed->push_back((uint16_t)r);
+    } else if ((float)e.nof_success_mgs / (float)e.nof_active < 0.15f && e.table != TABLE_UNKNOWN) {
+      e.table = TABLE_UNKNOWN;
+      if (changed) changed->push_back((uint16_t)r);
+    }
+  }
+}
 
 // ---------------------------------------------------------------------------------------------- CRC helpers
 uint32_t crc_bits(uint32_t poly, int order, const uint8_t* bits, int n)

@@ -117,6 +117,7 @@ public:
   uint32_t getFrequency(uint16_t rnti, uint32_t formatIdx) const { return histograms[formatIdx].getFrequency(rnti); }
   ActivationReason getActivationReason(uint16_t rnti) const { return active[rnti] ? (ActivationReason)reason[rnti] : RM_ACT_UNSET; }
   uint32_t nofActive() const { return nactive; }
+  void setHistogramThreshold(uint32_t t) { threshold = t; }  // RNTIManager.cc:442-444
 private:
   uint32_t getLikelyDlFormatIdx(uint16_t rnti) const;
   void activateRNTI(uint16_t rnti, ActivationReason r);
@@ -163,30 +164,45 @@ struct UeSpecConfig {  // ltesniffer_ue_spec_config_t, MCSTracking.h:37-43
 // PDSCH_Decoder::decode_rrc_connection_setup: true when the CCCH SDU is an RRCConnectionSetup (out filled)
 bool rrc_conn_setup_decode(const uint8_t* sdu, int len, UeSpecConfig& out);
 
-// ---- MCSTracking (DL table learning + UE-specific configuration; MCSTracking.cc:758-848,1269-1291,1444-1540) ----
+// ---- MCSTracking (DL table learning + UE-specific configuration + database ageing; MCSTracking.cc:758-927,1269-1400,1444-1540) ----
+// Time is counted in SUBFRAMES processed so far (`now`), not in clock() ticks: the reference ages its database by CPU time consumed
+// (MCSTracking.cc:778,854-858), i.e. by replay speed; one subframe = 1 ms of air time is the deterministic equivalent.
 class MCSTracking {
 public:
   UeSpecConfig get_ue_config_rnti(uint16_t rnti) const;         // the entry's configuration, else the default
-  void update_ue_config_rnti(uint16_t rnti, const UeSpecConfig& c);
+  void update_ue_config_rnti(uint16_t rnti, const UeSpecConfig& c, uint32_t now);
   bool check_default_config() const { return has_default; }
   float default_p_a() const { return default_cfg.p_a; }
   void update_default_ue_config(const UeSpecConfig& c) { default_cfg = c; has_default = true; }
   // one decoded C-RNTI transport block: every CCCH SDU is tried as RRCConnectionSetup (DL_Sniffer_PDSCH.cc:1041-1070); true when one was
-  bool learn_from_pdu(const uint8_t* pdu, int len, uint16_t rnti);
-  McsTable find_tracking_info_RNTI_dl(uint16_t rnti) const;
-  void update_RNTI_dl(uint16_t rnti, McsTable t);
-  void update_rar_time_crnti(uint16_t crnti);
-  void update_statistic_dl(uint16_t rnti, DciFormat f);
+  bool learn_from_pdu(const uint8_t* pdu, int len, uint16_t rnti, uint32_t now);
+  McsTable find_tracking_info_RNTI_dl(uint16_t rnti, uint32_t now);  // refreshes the entry's time stamp (:778-779)
+  void update_RNTI_dl(uint16_t rnti, McsTable t, uint32_t now);
+  void update_rar_time_crnti(uint16_t crnti, uint32_t now);
+  // update_statistic_dl (:1269-1400) without the HARQ branches (harq_mode is 0): table = the table fixed when the DCI was collected,
+  // tb_en = enabled flags of the statistic grant, success = final CRC verdicts, mimo_ret = 0 / -1 / -2 / -3 of dl_sniffer_config_mimo
+  void update_statistic_dl(uint16_t rnti, DciFormat f, McsTable table, const bool tb_en[2], const bool success[2], int mimo_ret, uint32_t now);
+  // update_database_dl (:850-927): entries idle for more than `interval` whole seconds, never active, or wrongly detected are deleted;
+  // a known table with a success rate under 15 % is reset.  Appends the RNTIs it touched to `changed`.
+  void update_database_dl(uint32_t now, std::vector<uint16_t>* changed = nullptr);
+  uint32_t get_interval() const { return interval; }   // seconds (MCSTracking.h:162: 5)
+  void set_interval(uint32_t seconds) { interval = seconds; }
+  uint32_t nof_RNTI_member_dl() const { return count; }
   McsTable peek(uint16_t rnti) const { return db[rnti].present ? (McsTable)db[rnti].table : TABLE_UNKNOWN; }
+  bool present(uint16_t rnti) const { return db[rnti].present != 0; }
   MCSTracking() : db(65536), ue_cfg(65536) {}
 private:
-  struct Entry { uint8_t present = 0, has_rar = 0, table = TABLE_UNKNOWN; uint16_t nof_msg_after_rar = 0; };
-  void add_RNTI_dl(uint16_t rnti);
+  struct Entry {
+    uint8_t present = 0, has_rar = 0, table = TABLE_UNKNOWN; uint16_t nof_msg_after_rar = 0;
+    uint32_t time = 0, nof_active = 0, nof_success_mgs = 0, nof_unsupport_mimo = 0, nof_pinfo = 0, nof_other_mimo = 0;
+  };
+  void add_RNTI_dl(uint16_t rnti, uint32_t now);
   std::vector<Entry> db;
   std::vector<UeSpecConfig> ue_cfg;  // [65536], valid where db[].present
   UeSpecConfig default_cfg;
   bool has_default = false;
   uint32_t count = 0;
+  uint32_t interval = 5;
   static constexpr uint32_t max_size = 250;  // MCSTracking.h:30
   static constexpr uint16_t rar_thresold = 3;
 };

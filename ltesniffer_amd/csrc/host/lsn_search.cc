@@ -236,7 +236,7 @@ int FalconSearch::inspect_dci_location_recursively(SubframeCtx& c, const int16_t
     if (metas[fi]->format == FORMAT1C && cand[fi].rnti > RARNTI_END && cand[fi].rnti < PRNTI) { cand[fi].rnti = 0; cand[fi].search_space_match_result = 0; continue; }  // :174
     if (cand[fi].rnti > RARNTI_START && cand[fi].rnti < RARNTI_END)  // :181-197
       if (metas[fi]->format != FORMAT1A && metas[fi]->format != FORMAT1C) { cand[fi].rnti = 0; cand[fi].search_space_match_result = 0; continue; }
-    if (enable_discovery && parent_cand != nullptr && parent_cand[fi].rnti == cand[fi].rnti &&
+    if (shortcut_discovery && enable_discovery && parent_cand != nullptr && parent_cand[fi].rnti == cand[fi].rnti &&
         !rnti_manager->isForbidden(cand[fi].rnti, metas[fi]->global_index))  // :200-211 (shortcut discovery)
       return -((int)fi + 1);
     // :214 srsran_pdcch_validate_location: the verdict travels with the candidate (decodeCandidate)

@@ -38,7 +38,8 @@ struct SubframeCtx {
   std::vector<DlEntry> dl;
   std::vector<UlEntry> ul;
   std::vector<uint32_t> accepted;  // 6 words per accepted DCI: rnti, format, L, ncce, nof_bits, histval
-  void reset(uint32_t tti_) { tti = tti_; sf_idx = tti_ % 10; sfn = (tti_ / 10) % 1024; cfi = 0; snr_db = cfo_hz = 0; searched = false; dl.clear(); ul.clear(); accepted.clear(); }
+  // the TTI counter wraps with the SFN (10 * 1024 subframes): records carry sfn 0..1023 like PcapWriter.cc:102-103, also when a call crosses the wrap
+  void reset(uint32_t tti_) { tti_ %= 10240u; tti = tti_; sf_idx = tti_ % 10; sfn = (tti_ / 10) % 1024; cfi = 0; snr_db = cfo_hz = 0; searched = false; dl.clear(); ul.clear(); accepted.clear(); }
 };
 
 struct BlindStats { uint32_t nof_locations = 0, nof_decoded_locations = 0, nof_cce = 0, nof_missed_cce = 0, nof_subframes = 0, nof_subframe_collisions_dw = 0, nof_subframe_collisions_up = 0; };
@@ -69,6 +70,8 @@ public:
   uint32_t nofSizes() const { return nsizes; }
   const uint32_t* sizes() const { return size_list; }
   void setupDefaultIntervals();  // LTESniffer_Core.cc:398-417
+  void setShortcutDiscovery(bool enable) { shortcut_discovery = enable; }  // PhyCommon::setShortcutDiscovery, PhyCommon.cc:69-71
+  bool getShortcutDiscovery() const { return shortcut_discovery; }
   // the DL entry addCandidate() would build for this candidate (no state is touched): used to decode RA-RNTI grants ahead
   void finishDlEntry(DlEntry& e, uint32_t sf_idx, uint32_t cfi) const;  // idempotent second half of addCandidate's grant conversion
   bool buildDlEntry(const SubframeCtx& c, uint16_t rnti, DciFormat fmt, unsigned long long bits, DlEntry& e) const;
@@ -100,6 +103,7 @@ private:
   const LsnCand* cur_cand = nullptr;
   const float* cur_ccepow = nullptr;
   BlindStats stats;
+  bool shortcut_discovery = true;  // Settings.h / ArgManager default (DCISearch.cc:200: enableShortcutDiscovery)
 };
 
 const char* rnti_name(uint16_t r);  // DL_Sniffer_PDSCH.cc:1398-1418

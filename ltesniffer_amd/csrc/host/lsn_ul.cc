@@ -217,17 +217,23 @@ void Engine::puschDecodeGrid(const cf32* d_grid, uint32_t nsf, uint32_t start_tt
     return x < y;
   });
   std::vector<LsnCbDev> sorted(ncb);
+  size_t spp_n = 0;
+  uint32_t emax = 0;
   for (uint32_t i = 0; i < ncb; i++) {
     sorted[i] = r.h_cbs[order[i]];
+    sorted[i].spp_off = (uint32_t)spp_n; spp_n += LSN_SPP_WORDS(sorted[i].K);
+    emax = std::max(emax, sorted[i].E);
     if (lsn_turbo_nwin((int)sorted[i].K) > 64) { n128++; kmax128 = std::max(kmax128, sorted[i].K); } else kmax64 = std::max(kmax64, sorted[i].K);
   }
+  grow_d(r.d_spp, r.spp_cap, spp_n + 16);
   HIP_CHECK(hipMemcpyAsync(ul_d_grants, gd.data(), ng * sizeof(LsnUlGrantDev), hipMemcpyHostToDevice, st));
   HIP_CHECK(hipMemcpyAsync(r.d_cbs, sorted.data(), ncb * sizeof(LsnCbDev), hipMemcpyHostToDevice, st));
   HIP_CHECK(hipMemsetAsync(r.d_llr16, 0, llr_n * sizeof(int16_t), st));
   HIP_CHECK(hipStreamSynchronize(st));  // gd / sorted are pageable host vectors
   lsn_launch_pusch_chest(cd, ul_d_grants, d_grid, ul_d_hs, ul_d_stat, ng, st);
   lsn_launch_pusch_demod(cd, ul_d_grants, d_grid, ul_d_hs, ul_d_stat, r.d_llr16, ng, st);
-  lsn_launch_turbo(cd, r.d_cbs, r.d_llr16, r.d_payload, r.d_cbres, n128, kmax128, ncb - n128, kmax64, st, nullptr);
+  lsn_launch_rm(r.d_cbs, r.d_llr16, r.d_spp, ncb, emax, st);
+  lsn_launch_turbo(cd, r.d_cbs, r.d_spp, r.d_payload, r.d_cbres, n128, kmax128, ncb - n128, kmax64, st, nullptr);
   std::vector<LsnCbRes> cbres(ncb);
   std::vector<uint8_t> pay(pay_n);
   std::vector<float> stat((size_t)2 * ng);

@@ -18,7 +18,9 @@ namespace {
 struct Attempt { uint32_t sf; uint32_t idx; bool use256; int qm; };
 inline bool operator<(const Attempt& a, const Attempt& b) { return std::tie(a.sf, a.idx, a.use256, a.qm) < std::tie(b.sf, b.idx, b.use256, b.qm); }
 struct AttemptResult { bool crc = false; std::vector<uint8_t> payload; };
-struct PendingPdu { bool ul; char name; uint16_t rnti; uint8_t tb; const uint8_t* data; std::vector<uint8_t> own; uint32_t len; };
+// downlink records keep the OFFSET of their payload in ch.h_payload: a later on-demand decode of the same loop may grow (reallocate) that
+// arena, so the pointer is only formed when the record is emitted
+struct PendingPdu { bool ul; char name; uint16_t rnti; uint8_t tb; size_t off; std::vector<uint8_t> own; uint32_t len; };
 }  // namespace
 
 void Engine::commitChunkUl(Chunk& ch, JobRunner& r)
@@ -58,8 +60,7 @@ void Engine::commitChunkUl(Chunk& ch, JobRunner& r)
         for (int tb = 0; tb < 2; tb++) {
           if (!job.crc[tb]) continue;
           const uint32_t len = (uint32_t)(job.grant.tb[tb].tbs / 8);
-          const uint8_t* pl = ch.h_payload.data() + job.payload_off[tb];
-          out[sf].push_back({false, is_ra ? 'R' : rnti_name(e.rnti)[0], e.rnti, (uint8_t)tb, pl, {}, len});
+          out[sf].push_back({false, is_ra ? 'R' : rnti_name(e.rnti)[0], e.rnti, (uint8_t)tb, (size_t)job.payload_off[tb], {}, len});
           if (is_ra) {  // unpack_rar_response_ul_mode on TB 0's buffer; the grant of the LAST sub-header survives; then return
             RarEntry re[32];
             const int nre = rar_parse(cell, ch.h_payload.data() + job.payload_off[0], (int)len, re, 32);
@@ -186,7 +187,7 @@ void Engine::commitChunkUl(Chunk& ch, JobRunner& r)
   }
   // ---- phase 3 (sequential): the exact decision logic, records in (tti, downlink, uplink) order ----
   for (uint32_t sf = 0; sf < nsf; sf++) {
-    const uint32_t tti = ch.ctx[sf].tti;
+    const uint32_t tti = ch.ctx[sf].tti;  // already reduced mod 10240 (SubframeCtx::reset)
     for (uint32_t i = 0; i < lists[sf].size(); i++) {
       const UlSchedGrant& m = lists[sf][i];
       if (!valid_grant(m)) continue;
@@ -197,7 +198,7 @@ void Engine::commitChunkUl(Chunk& ch, JobRunner& r)
         if (!results.count(a[k])) { run_batch({a[k]}); r.perf.nof_ondemand_decodes++; }
         const AttemptResult& ar = results[a[k]];
         if (!ar.crc) continue;
-        PendingPdu p{true, 'C', m.rnti, 0, nullptr, ar.payload, (uint32_t)ar.payload.size()};
+        PendingPdu p{true, 'C', m.rnti, 0, 0, ar.payload, (uint32_t)ar.payload.size()};
         out[sf].push_back(std::move(p));
         if (learn[k] && m.g.mcs_idx > 20) {  // decode_run: update_RNTI_ul when the maximum modulation was still unknown
           if (ulmod[m.rnti]) ulmod[m.rnti] = (uint8_t)learn[k];
@@ -207,7 +208,7 @@ void Engine::commitChunkUl(Chunk& ch, JobRunner& r)
       }
     }
     for (auto& p : out[sf]) {
-      const uint8_t* data = p.ul ? p.own.data() : p.data;
+      const uint8_t* data = p.ul ? p.own.data() : ch.h_payload.data() + p.off;
       if (p.ul) {  // write_ul_crnti, PcapWriter.cc:172-175
         r.perf.nof_pdus++;
         if (sink) { lsn_pdu_ctx_t c{}; c.tti = tti; c.rnti = p.rnti; c.direction = 0; c.rnti_type = 3; c.crc_ok = 1; sink(sink_user, &c, data, p.len); }

@@ -82,7 +82,9 @@ struct LsnCbDev {
   uint32_t f1, f2;
   uint32_t max_iter;
   uint32_t res_idx;   // slot of this block's LsnCbRes (launch order is sorted by size, results are not)
+  uint32_t spp_off;   // u32 word offset (multiple of 4) of the block's de-rate-matched soft data: K packed words + 12 termination values (k_rm -> k_turbo)
 };
+#define LSN_SPP_WORDS(K) (((K) + 12u + 3u) & ~3u)
 // one PUSCH grant to decode
 struct LsnUlGrantDev {
   uint32_t sf;          // subframe index inside the batch
@@ -119,5 +121,6 @@ void lsn_launch_pusch_demod(const LsnCellDev& c, const LsnUlGrantDev* g, const c
                             uint32_t ngrants, hipStream_t s);
 void lsn_launch_pdsch_prep(const LsnCellDev& c, const LsnGrantDev* g, uint16_t* prefix, uint32_t njobs, hipStream_t s);
 void lsn_launch_pdsch_demod(const LsnCellDev& c, const LsnGrantDev* g, const uint16_t* prefix, const cf32* grid, const cf32* ce, const LsnChest* ch, int16_t* llr, uint32_t njobs, hipStream_t s);
-void lsn_launch_turbo(const LsnCellDev& c, const LsnCbDev* cb, const int16_t* llr, uint8_t* payload, LsnCbRes* res, uint32_t n128, uint32_t kmax128,
+void lsn_launch_rm(const LsnCbDev* cb, const int16_t* llr, uint32_t* spp, uint32_t ncb, uint32_t emax, hipStream_t s);
+void lsn_launch_turbo(const LsnCellDev& c, const LsnCbDev* cb, const uint32_t* spp, uint8_t* payload, LsnCbRes* res, uint32_t n128, uint32_t kmax128,
                       uint32_t n64, uint32_t kmax64, hipStream_t s, hipEvent_t between);

@@ -220,6 +220,80 @@ void lsn_launch_pdsch_demod(const LsnCellDev& c, const LsnGrantDev* g, const uin
   hipLaunchKernelGGL(k_pdsch_demod, dim3((c.nof_prb + 15) / 16, 14, njobs), dim3(192), 0, s, c, g, prefix, grid, ce, ch, llr);
 }
 
+// ------------------------------------------------------------------------------------------------ rate de-matching
+// 36.212 5.1.4.1.2 inverted, as a kernel of its own in front of the turbo decoder: the gather over the circular buffer is
+// memory-latency work that wants many resident wavefronts, the decoder is register-bound and runs one wavefront per SIMD.
+// Workgroup per code block.  The block's rate-matched soft bits e[0 .. E) are staged in LDS with coalesced 16-byte loads;
+// thread t then builds word t of the decoder's TRANSPOSED layout (t = (x % W) * P + x / W  <=>  x = (t % P) * W + t / P):
+// the three streams of trellis position x are looked up through the closed-form rank of lsn_rm.h (first e index of a
+// circular-buffer entry), repetitions e[rank + m * nn] are added, the sum is clipped to +-511 and the three 10-bit fields
+// are packed (systematic | parity 1 << 10 | parity 2 << 20; filler bits are known zeros: -511).  Words K .. K+11 carry the
+// twelve termination values (stream s, position K + j at K + 4 s + j) as int32.  Blocks whose E exceeds the staging
+// area read e[] from global memory instead (same arithmetic).
+#define RM_NT 256
+template <bool STAGED>
+__device__ __forceinline__ int rm_sum(const int16_t* __restrict__ e, const int16_t* es, int rank, int E, int nn)
+{
+  int acc = 0;
+  if (rank < 0) return 0;
+  for (int k = rank; k < E; k += nn) acc += STAGED ? (int)es[k] : (int)e[k];
+  return acc > LSN_LLR_CLIP ? LSN_LLR_CLIP : (acc < -LSN_LLR_CLIP ? -LSN_LLR_CLIP : acc);
+}
+__global__ __launch_bounds__(RM_NT) void k_rm(const LsnCbDev* __restrict__ cbs, const int16_t* __restrict__ llr, uint32_t* __restrict__ spp_g, uint32_t seg)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char rm_smem[];
+  __shared__ LsnRmGeom geom;
+  int16_t* es = (int16_t*)rm_smem;
+  const LsnCbDev cb = cbs[blockIdx.x];
+  const int tid = threadIdx.x, K = (int)cb.K, F = (int)cb.F, E = (int)cb.E;
+  const int P = lsn_turbo_nwin(K), W = K / P;
+  const int16_t* e = llr + cb.e_off;  // e_off is a multiple of 8 entries (16 bytes) for the first block of a codeword only
+  const bool staged = (uint32_t)E <= seg;
+  if (tid == 0) lsn_rm_geom(geom, K, F, (int)cb.rv);
+  if (staged) {
+    // 16-byte loads from the aligned address at or below e
+    const uintptr_t a0 = (uintptr_t)e & ~(uintptr_t)15;
+    const int skew = (int)(((uintptr_t)e - a0) >> 1);  // entries between the aligned address and e[0]
+    const uint4* src = (const uint4*)a0;
+    const int nv = (skew + E + 7) >> 3;
+    for (int v = tid; v < nv; v += RM_NT) ((uint4*)es)[v] = src[v];
+    es += skew;
+  }
+  __syncthreads();
+  const int nn = geom.nn;
+  uint32_t* out = spp_g + cb.spp_off;
+  for (int t = tid; t < K + 12; t += RM_NT) {
+    if (t < K) {
+      const int x = (t % P) * W + t / P;
+      int v0, v1, v2;
+      if (staged) {
+        v0 = x < F ? -LSN_LLR_CLIP : rm_sum<true>(e, es, lsn_rm_rank(geom, 0, x), E, nn);
+        v1 = x < F ? -LSN_LLR_CLIP : rm_sum<true>(e, es, lsn_rm_rank(geom, 1, x), E, nn);
+        v2 = rm_sum<true>(e, es, lsn_rm_rank(geom, 2, x), E, nn);
+      } else {
+        v0 = x < F ? -LSN_LLR_CLIP : rm_sum<false>(e, es, lsn_rm_rank(geom, 0, x), E, nn);
+        v1 = x < F ? -LSN_LLR_CLIP : rm_sum<false>(e, es, lsn_rm_rank(geom, 1, x), E, nn);
+        v2 = rm_sum<false>(e, es, lsn_rm_rank(geom, 2, x), E, nn);
+      }
+      out[t] = ((uint32_t)v0 & 0x3FFu) | (((uint32_t)v1 & 0x3FFu) << 10) | (((uint32_t)v2 & 0x3FFu) << 20);
+    } else {
+      const int s = (t - K) >> 2, x = K + ((t - K) & 3);
+      const int r = lsn_rm_rank(geom, s, x);
+      out[t] = (uint32_t)(staged ? rm_sum<true>(e, es, r, E, nn) : rm_sum<false>(e, es, r, E, nn));
+    }
+  }
+}
+// the staging area is sized by the largest E of the launch, capped at 64 KiB (two workgroups per CU at least)
+void lsn_launch_rm(const LsnCbDev* cb, const int16_t* llr, uint32_t* spp, uint32_t ncb, uint32_t emax, hipStream_t s)
+{
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_rm, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); attr_set = true; }
+  const uint32_t cap = (65536 - 32) / 2;
+  const uint32_t seg = emax < cap ? emax : cap;
+  const size_t lds = (((size_t)seg + 16) * 2 + 15) & ~(size_t)15;  // + the skew in front of e[0] and the tail of the last 16-byte load
+  if (ncb) hipLaunchKernelGGL(k_rm, dim3(ncb), dim3(RM_NT), lds, s, cb, llr, spp, seg);
+}
+
 // ------------------------------------------------------------------------------------------------ turbo decoder
 // One workgroup per code block, thread = trellis window (P = lsn_turbo_nwin(K) windows of W = K/P steps): one
 // wavefront when P <= 64, two when 96 <= P <= 128; four code blocks per CU (<= 40 KiB of LDS each).
@@ -474,7 +548,7 @@ __device__ __forceinline__ uint32_t wg_xor(uint32_t v, int16_t* scratch, int tid
 
 template <int NT>
 __global__ __launch_bounds__(NT) void k_turbo(const uint32_t* __restrict__ crc_tab_a, const uint32_t* __restrict__ crc_tab_b,
-                                              const LsnCbDev* __restrict__ cbs, const int16_t* __restrict__ llr,
+                                              const LsnCbDev* __restrict__ cbs, const uint32_t* __restrict__ spp_g,
                                               uint8_t* __restrict__ payload, LsnCbRes* __restrict__ res, uint32_t kmax)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -486,69 +560,14 @@ __global__ __launch_bounds__(NT) void k_turbo(const uint32_t* __restrict__ crc_t
   const bool active = lane < P;
   TurboLds m;
   m.spp = (uint32_t*)smem; m.ext = (int16_t*)(m.spp + kmax); m.ckpt = m.ext + kmax + 8;  // ext[K] = spare slot for idle lanes
-  // the check-point area doubles as scratch for the rate-matcher geometry and the 12 termination values
-  LsnRmGeom& geom = *(LsnRmGeom*)m.ckpt;
+  // the check-point area doubles as scratch for the 12 termination values
   int* tail = (int*)(m.ckpt + 1024);
-  if (lane == 0) lsn_rm_geom(geom, K, F, (int)cb.rv);
-  for (int i = lane; i < K; i += NT) { m.spp[i] = 0u; m.ext[i] = 0; }
-  __syncthreads();
-  // ---- rate de-matching as a gather over the circular buffer (36.212 5.1.4.1.2): threads walk the rows of one
-  //      sub-block column, so the e[] reads are contiguous; repeated bits are soft-combined, results clipped to +-511 ----
+  // ---- soft data of the block: K packed words (already in the transposed layout) + 12 termination values, written by k_rm ----
   {
-    const int16_t* e = llr + cb.e_off;
-    const int E = (int)cb.E, nn = geom.nn, R = geom.R, ND = geom.ND, KP = geom.KP, nn0 = geom.nn0;
-    auto put = [&](int s, int i, int v) {
-      if (i < K) atomicOr(&m.spp[tr_idx(i, W, P, magicW)], ((uint32_t)v & 0x3FFu) << (10 * s)); else tail[s * 4 + (i - K)] = v;
-    };
-    for (int i = lane; i < F; i += NT) { put(0, i, -LSN_LLR_CLIP); put(1, i, -LSN_LLR_CLIP); }  // filler bits are known zeros
-    // threads own rows, eight sub-block columns (24 buffer entries) are gathered per batch so that the global loads of a
-    // batch are all in flight together; entry j of the batch adds e[first_j + r * nn] for r = 0 .. nrep-1 (repetition)
-    const int nrep = E > 0 ? (E + nn - 1) / nn : 0;
-    for (int cb8 = 0; cb8 < 32; cb8 += 8) {
-      // per-column constants of the batch (registers: the LDS copy cannot be hoisted past the atomics below)
-      int c01[8], b01[8], b2[8], f2c[8];
-#pragma unroll
-      for (int q = 0; q < 8; q++) {
-        c01[q] = (int)geom.cnt01[cb8 + q]; b01[q] = geom.pre01[cb8 + q]; b2[q] = geom.pre2[cb8 + q]; f2c[q] = (int)geom.first2[cb8 + q];
-      }
-      for (int row = lane; row < R; row += NT) {
-        int first[24], acc[24];
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-          const int col = cb8 + q, p = lsn_perm_tc_f(col);
-          const int k = col * R + row, y = row * 32 + p;
-          const int nb01 = b01[q] + (row < c01[q] ? row : c01[q]), nb2 = b2[q] + (row > 0 ? f2c[q] : 0);
-          const bool null01 = row < c01[q];
-          const int cum1 = nn0 + (k - nb01) + (k - nb2);
-          const int i2 = (y + 1 == KP ? 0 : y + 1) - ND;
-          first[3 * q + 0] = null01 ? E : lsn_rm_eidx(geom, k - nb01);
-          first[3 * q + 1] = null01 ? E : lsn_rm_eidx(geom, cum1);
-          first[3 * q + 2] = i2 < 0 ? E : lsn_rm_eidx(geom, cum1 + (null01 ? 0 : 1));
-          acc[3 * q + 0] = 0; acc[3 * q + 1] = 0; acc[3 * q + 2] = 0;
-        }
-        for (int r = 0; r < nrep; r++) {
-#pragma unroll
-          for (int j = 0; j < 24; j++) {
-            const int k = first[j] + r * nn;
-            const int v = (int)e[k < E ? k : E - 1];
-            acc[j] += k < E ? v : 0;
-          }
-        }
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-          const int col = cb8 + q, p = lsn_perm_tc_f(col), y = row * 32 + p;
-          const bool null01 = row < c01[q];
-          const int i2 = (y + 1 == KP ? 0 : y + 1) - ND;
-#pragma unroll
-          for (int j = 0; j < 3; j++) {
-            int v = acc[3 * q + j];
-            v = v > LSN_LLR_CLIP ? LSN_LLR_CLIP : (v < -LSN_LLR_CLIP ? -LSN_LLR_CLIP : v);
-            if (j < 2) { if (!null01) put(j, y - ND, v); }
-            else if (i2 >= 0) put(2, i2, v);
-          }
-        }
-      }
-    }
+    const uint32_t* src = spp_g + cb.spp_off;  // 16-byte aligned, K is a multiple of 8
+    for (int i = 4 * lane; i < K; i += 4 * NT) *(uint4*)&m.spp[i] = *(const uint4*)&src[i];
+    for (int i = 8 * lane; i < K; i += 8 * NT) *(uint4*)&m.ext[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (lane < 12) tail[lane] = (int)src[K + lane];
   }
   __syncthreads();
   // ---- termination (36.212 5.1.3.2.2): tail[s*4 + j] = stream s at position K + j ----
@@ -618,7 +637,7 @@ size_t lsn_turbo_lds_bytes(uint32_t kmax) { return 6 * (size_t)kmax + 16 + sizeo
 
 // cb[0 .. n128) use two wavefronts per code block (P > 64), cb[n128 .. ncb) one; each range is launched with the LDS
 // size of its largest block (40 KiB at K = 6144 -> four code blocks per CU)
-void lsn_launch_turbo(const LsnCellDev& c, const LsnCbDev* cb, const int16_t* llr, uint8_t* payload, LsnCbRes* res, uint32_t n128, uint32_t kmax128,
+void lsn_launch_turbo(const LsnCellDev& c, const LsnCbDev* cb, const uint32_t* spp, uint8_t* payload, LsnCbRes* res, uint32_t n128, uint32_t kmax128,
                       uint32_t n64, uint32_t kmax64, hipStream_t s, hipEvent_t between)
 {
   static bool attr_set = false;
@@ -628,7 +647,7 @@ void lsn_launch_turbo(const LsnCellDev& c, const LsnCbDev* cb, const int16_t* ll
     attr_set = true;
   }
   auto fix = [](uint32_t k) { return ((k < 512 ? 512u : k) + 7u) & ~7u; };  // the scratch in the check-point area needs room
-  if (n128) hipLaunchKernelGGL(k_turbo<128>, dim3(n128), dim3(128), lsn_turbo_lds_bytes(fix(kmax128)), s, c.crc_tab_a, c.crc_tab_b, cb, llr, payload, res, fix(kmax128));
+  if (n128) hipLaunchKernelGGL(k_turbo<128>, dim3(n128), dim3(128), lsn_turbo_lds_bytes(fix(kmax128)), s, c.crc_tab_a, c.crc_tab_b, cb, spp, payload, res, fix(kmax128));
   if (between) (void)hipEventRecord(between, s);
-  if (n64) hipLaunchKernelGGL(k_turbo<64>, dim3(n64), dim3(64), lsn_turbo_lds_bytes(fix(kmax64)), s, c.crc_tab_a, c.crc_tab_b, cb + n128, llr, payload, res, fix(kmax64));
+  if (n64) hipLaunchKernelGGL(k_turbo<64>, dim3(n64), dim3(64), lsn_turbo_lds_bytes(fix(kmax64)), s, c.crc_tab_a, c.crc_tab_b, cb + n128, spp, payload, res, fix(kmax64));
 }

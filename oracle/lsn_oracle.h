@@ -303,6 +303,9 @@ void o_worker_set_ul_mode(o_worker_t*, const o_ul_cfg_t* ul);
 int o_worker_work_ul(o_worker_t*, const ocf_t* dl_iq, const ocf_t* ul_iq, uint32_t sf_idx, uint32_t sfn, int update_meta_formats);
 const o_stats_t* o_worker_stats(o_worker_t*);
 void o_worker_ue_cfg(o_worker_t* w, uint16_t rnti, o_ue_cfg_t* out); /* MCSTracking::get_ue_config_rnti */
+void o_worker_set_mcs_update_interval(o_worker_t* w, uint32_t seconds); /* MCSTracking::interval (5 s): ageing every interval x 1000 subframes, 0 = never */
+uint32_t o_worker_nof_tracked(o_worker_t* w);                         /* MCSTracking::nof_RNTI_member_dl */
+int o_worker_tracked_table(o_worker_t* w, uint16_t rnti);            /* tracked table of an RNTI, -1 without entry */
 /* stage taps for parity tests (valid until the next work()) */
 const ocf_t* o_worker_grid(o_worker_t*);
 const ocf_t* o_worker_ce(o_worker_t*);

@@ -36,7 +36,11 @@ typedef struct { uint16_t rnti; uint32_t nof_bits, L, ncce, histval; o_dci_ul_t 
 typedef struct { uint16_t rnti; o_pusch_grant_t g, g256; uint32_t n_dmrs, hopping; int is_rar; uint32_t nof_ack, cqi_req; } ulg_t;
 typedef struct { uint32_t tti; int valid; int n; ulg_t g[96]; } ulslot_t;
 
-typedef struct { uint8_t present, has_rar; uint16_t nof_msg_after_rar; uint8_t table; } mcs_entry_t;
+typedef struct {
+  uint8_t present, has_rar; uint16_t nof_msg_after_rar; uint8_t table;
+  /* database ageing (MCSTracking.cc:850-927): last look-up in subframes processed, activity / success / MIMO-error counters */
+  uint32_t time, nof_active, nof_success_mgs, nof_unsupport_mimo, nof_pinfo, nof_other_mimo;
+} mcs_entry_t;
 
 struct o_worker {
   o_worker_cfg_t cfg;
@@ -50,6 +54,10 @@ struct o_worker {
   o_stats_t stats;
   mcs_entry_t* mcs; /* [65536] */
   uint32_t mcs_count;
+  uint32_t sf_count;          /* subframes worked so far = the database's clock (1 subframe = 1 ms instead of clock()) */
+  uint32_t mcs_update_period; /* get_interval() x 1000 subframes (LTESniffer_Core.cc:473-485), 0 = never */
+  uint32_t mcs_interval;      /* seconds, MCSTracking.h:162 */
+  uint32_t nof_mcs_updates;
   o_ue_cfg_t* uecfg; /* [65536] ue_spec_config of the tracking-database entries (MCSTracking.h:37-43) */
   o_ue_cfg_t default_cfg;
   int has_default_cfg;
@@ -148,6 +156,8 @@ o_worker_t* o_worker_new(const o_worker_cfg_t* cfg)
   w->default_cfg.i_offset_cqi = 8;
   w->default_cfg.i_offset_ri = 11;
   w->default_cfg.cqi_type = 2;
+  w->mcs_interval = 5; /* MCSTracking.h:162 */
+  w->mcs_update_period = 5000;
   w->llr0 = (int16_t*)calloc(14u * nre * 8u, sizeof(int16_t));
   w->llr1 = (int16_t*)calloc(14u * nre * 8u, sizeof(int16_t));
   w->payload = (uint8_t*)calloc(32768, 1);
@@ -184,6 +194,7 @@ uint32_t o_worker_accepted(o_worker_t* w, uint32_t* out6, uint32_t max)
 static int mcs_find(o_worker_t* w, uint16_t rnti) /* MCSTracking.cc:758-782 */
 {
   if (!w->mcs[rnti].present) return w->mcs_count < 250 ? O_TABLE_UNKNOWN : O_TABLE_FULL;
+  w->mcs[rnti].time = w->sf_count; /* :778-779 */
   return w->mcs[rnti].table;
 }
 static void mcs_add(o_worker_t* w, uint16_t rnti)
@@ -191,6 +202,7 @@ static void mcs_add(o_worker_t* w, uint16_t rnti)
   if (!w->mcs[rnti].present) {
     memset(&w->mcs[rnti], 0, sizeof(mcs_entry_t));
     w->mcs[rnti].present = 1;
+    w->mcs[rnti].time = w->sf_count;
     w->mcs[rnti].table = O_TABLE_UNKNOWN;
     w->mcs_count++;
     w->uecfg[rnti] = w->default_cfg; /* add_RNTI_dl, MCSTracking.cc:785-795 */
@@ -247,11 +259,43 @@ static void mcs_rar(o_worker_t* w, uint16_t crnti) /* MCSTracking.cc:827-848 */
   w->mcs[crnti].has_rar = 1;
   w->mcs[crnti].table = O_TABLE_UNKNOWN;
 }
-static void mcs_statistic(o_worker_t* w, uint16_t rnti, int format) /* MCSTracking.cc:1269-1291 */
+/* MCSTracking::update_statistic_dl, MCSTracking.cc:1269-1400, without the HARQ branches (harq_mode 0: every transmission is NEW_TX) */
+static void mcs_statistic(o_worker_t* w, uint16_t rnti, int format, int table, const int* tb_en, const int* success, int mimo_ret)
 {
   mcs_add(w, rnti);
-  if (format > O_FMT1A && w->mcs[rnti].has_rar) w->mcs[rnti].nof_msg_after_rar++;
+  mcs_entry_t* e = &w->mcs[rnti];
+  if (format > O_FMT1A && e->has_rar) e->nof_msg_after_rar++;
+  if (table == O_TABLE_64QAM || table == O_TABLE_256QAM || table == O_TABLE_UNKNOWN)
+    for (int i = 0; i < 2; i++) {
+      if (tb_en[i]) e->nof_active++;
+      if (success[i]) e->nof_success_mgs++;
+      if (mimo_ret == -1 && tb_en[i]) e->nof_unsupport_mimo++;
+      else if (mimo_ret == -2 && tb_en[i]) e->nof_pinfo++;
+      else if (mimo_ret == -3 && tb_en[i]) e->nof_other_mimo++;
+    }
 }
+/* MCSTracking::update_database_dl, MCSTracking.cc:850-927 (the all_database copies are statistics only) */
+static void mcs_update_database(o_worker_t* w)
+{
+  const uint32_t now = w->sf_count;
+  for (uint32_t r = 0; r < 65536; r++) {
+    mcs_entry_t* e = &w->mcs[r];
+    if (!e->present) continue;
+    const uint32_t cur_interval = (now - e->time) / 1000u; /* whole seconds */
+    const int wrong_detect = e->nof_active == 0 ||
+                             (e->nof_active <= 10 && e->nof_success_mgs == 0 && (e->nof_unsupport_mimo > 0 || e->nof_pinfo > 0 || e->nof_other_mimo > 0));
+    if (cur_interval > w->mcs_interval || wrong_detect || e->nof_active == 0) {
+      memset(e, 0, sizeof(*e));
+      w->mcs_count--;
+    } else if ((float)e->nof_success_mgs / (float)e->nof_active < 0.15f && e->table != O_TABLE_UNKNOWN) {
+      e->table = O_TABLE_UNKNOWN;
+    }
+  }
+  w->nof_mcs_updates++;
+}
+void o_worker_set_mcs_update_interval(o_worker_t* w, uint32_t seconds) { w->mcs_interval = seconds; w->mcs_update_period = seconds * 1000u; }
+uint32_t o_worker_nof_tracked(o_worker_t* w) { return w->mcs_count; }
+int o_worker_tracked_table(o_worker_t* w, uint16_t rnti) { return w->mcs[rnti].present ? (int)w->mcs[rnti].table : -1; }
 
 /* ---------------- DCICollection::addCandidate ---------------- */
 static void add_candidate(o_worker_t* w, const cand_t* c, uint32_t L, uint32_t ncce, uint32_t histval)
@@ -689,7 +733,10 @@ static void decode_dl_mode(o_worker_t* w)
         }
       }
     }
-    if (name[0] == 'C' && w->cfg.mcs_tracking_mode) mcs_statistic(w, e->rnti, e->format); /* :1268-1285 */
+    if (name[0] == 'C' && w->cfg.mcs_tracking_mode) { /* :1268-1285 */
+      const int tb_en[2] = {cur->tb[0].enabled, cur->tb[1].enabled};
+      mcs_statistic(w, e->rnti, e->format, e->mcs_table, tb_en, crc, mimo_ret ? -mimo_ret : 0);
+    }
   }
 }
 
@@ -707,6 +754,8 @@ int o_worker_work(o_worker_t* w, const ocf_t* const* iq, uint32_t sf_idx, uint32
   memset(w->rb_map_dl, 0, sizeof(w->rb_map_dl));
   memset(w->rb_map_ul, 0, sizeof(w->rb_map_ul));
   if (update_meta) update_formats(w); /* SubframeWorker.cc:148-151 */
+  /* LTESniffer_Core.cc:473-499: every get_interval() x 1000 subframes the tracking database is aged (DL mode, mcs_tracking_mode on) */
+  if (w->cfg.mcs_tracking_mode && w->mcs_update_period && w->sf_count && (w->sf_count % w->mcs_update_period) == 0) mcs_update_database(w);
   uint32_t dphi = cfo_hz != 0.0f ? o_nco_dphi(cfo_hz, o_fft_size(cell->nof_prb)) : 0;
   /* srsran_ue_dl_decode_fft_estimate, DCISearch.cc:562 */
   for (uint32_t rx = 0; rx < w->cfg.nof_rx; rx++) o_ofdm_rx(cell, iq[rx], dphi, w->grid + rx * 14u * nre);
@@ -724,6 +773,7 @@ int o_worker_work(o_worker_t* w, const ocf_t* const* iq, uint32_t sf_idx, uint32
   } else {
     w->stats.nof_subframes++;
   }
+  w->sf_count++;
   return w->records;
 }
 

@@ -250,6 +250,15 @@ class OracleWorker:
         self.lib.o_worker_ue_cfg(self.h, rnti, C.byref(c))
         return (c.has, np.float32(c.p_a).item(), c.ack, c.cqi, c.ri, c.typ)
 
+    def set_mcs_update_interval(self, seconds):
+        self.lib.o_worker_set_mcs_update_interval.argtypes = [C.c_void_p, C.c_uint32]
+        self.lib.o_worker_set_mcs_update_interval(self.h, seconds)
+
+    def nof_tracked(self):
+        self.lib.o_worker_nof_tracked.argtypes = [C.c_void_p]
+        self.lib.o_worker_nof_tracked.restype = C.c_uint32
+        return self.lib.o_worker_nof_tracked(self.h)
+
     def rb_power(self):
         self.lib.o_worker_rb_power.restype = C.POINTER(C.c_float)
         self.lib.o_worker_rb_power.argtypes = [C.c_void_p]

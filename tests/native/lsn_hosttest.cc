@@ -187,8 +187,24 @@ int lsnh_rrc_conn_setup(const uint8_t* sdu, int len, uint32_t* out)
 // MCSTracking UE-configuration database driven by a sequence of (rnti, pdu) events; returns the configuration get_ue_config_rnti(query) ends with
 void* lsnh_mcs_new() { return new MCSTracking(); }
 void lsnh_mcs_free(void* m) { delete (MCSTracking*)m; }
-int lsnh_mcs_learn(void* m, const uint8_t* pdu, int len, uint16_t rnti) { return ((MCSTracking*)m)->learn_from_pdu(pdu, len, rnti) ? 1 : 0; }
-void lsnh_mcs_touch(void* m, uint16_t rnti) { ((MCSTracking*)m)->update_statistic_dl(rnti, FORMAT1); }
+int lsnh_mcs_learn(void* m, const uint8_t* pdu, int len, uint16_t rnti) { return ((MCSTracking*)m)->learn_from_pdu(pdu, len, rnti, 0) ? 1 : 0; }
+void lsnh_mcs_touch(void* m, uint16_t rnti)
+{
+  const bool none[2] = {false, false};
+  ((MCSTracking*)m)->update_statistic_dl(rnti, FORMAT1, TABLE_FULL_BUFFER, none, none, 0, 0);
+}
+// database ageing (MCSTracking.cc:758-927) driven event by event; `now` = subframes processed so far
+int lsnh_mcs_find(void* m, uint16_t rnti, uint32_t now) { return (int)((MCSTracking*)m)->find_tracking_info_RNTI_dl(rnti, now); }
+void lsnh_mcs_update(void* m, uint16_t rnti, int table, uint32_t now) { ((MCSTracking*)m)->update_RNTI_dl(rnti, (McsTable)table, now); }
+void lsnh_mcs_rar(void* m, uint16_t rnti, uint32_t now) { ((MCSTracking*)m)->update_rar_time_crnti(rnti, now); }
+void lsnh_mcs_stat(void* m, uint16_t rnti, int format, int table, int en0, int en1, int ok0, int ok1, int mimo_ret, uint32_t now)
+{
+  const bool en[2] = {en0 != 0, en1 != 0}, ok[2] = {ok0 != 0, ok1 != 0};
+  ((MCSTracking*)m)->update_statistic_dl(rnti, (DciFormat)format, (McsTable)table, en, ok, mimo_ret, now);
+}
+void lsnh_mcs_update_database(void* m, uint32_t now) { ((MCSTracking*)m)->update_database_dl(now); }
+uint32_t lsnh_mcs_count(void* m) { return ((MCSTracking*)m)->nof_RNTI_member_dl(); }
+int lsnh_mcs_peek(void* m, uint16_t rnti) { return ((MCSTracking*)m)->present(rnti) ? (int)((MCSTracking*)m)->peek(rnti) : -1; }
 void lsnh_mcs_get(void* m, uint16_t rnti, uint32_t* out)
 {
   const UeSpecConfig c = ((MCSTracking*)m)->get_ue_config_rnti(rnti);

@@ -20,8 +20,10 @@ def gen_subframes(sc, n):
     return tti0, iq, truth
 
 
-def run_oracle(sc, tti0, iq, update_meta_period=0, taps=True, **okw):
+def run_oracle(sc, tti0, iq, update_meta_period=0, taps=True, mcs_update_interval=None, **okw):
     ow = OracleWorker(sc["nof_prb"], sc["nof_ports"], sc["cell_id"], sc["nof_rx"], sc["phich_ng_x6"], **okw)
+    if mcs_update_interval is not None:
+        ow.set_mcs_update_interval(mcs_update_interval)
     per_sf = []
     for i in range(iq.shape[0]):
         upd = 1 if (update_meta_period and i % update_meta_period == 0) else 0

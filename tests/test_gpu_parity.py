@@ -233,3 +233,98 @@ def test_full_load_properties_round_trip_and_pipeline_invariance():
     late = [(k, pl) for k, v in sent.items() for pl in v if (k[0] - tti0) % 10240 >= 120 and 0x000B <= k[1] <= 0xFFF3]
     got = {(((r["sfn"] * 10 + r["sf"]) % 10240, r["rnti"]), r["pdu"]) for r in dl}
     assert sum(x in got for x in late) >= 0.85 * len(late), (sum(x in got for x in late), len(late))
+
+
+# ---------------------------------------------------------------------------------------------- BASELINE.json sizes
+def _run_stream(scn, nsf, seed, batch, update_meta_period=0, submit=False, **over):
+    """record stream + learned state of a long stream at the scenario's full RNTI count (no per-subframe taps: the tap comparisons
+    above cover the stages; here the sequential state - RNTI manager, MCS tables, p-a - runs for hundreds of subframes)"""
+    import torch
+    sc = scenario(scn, seed=seed, **over)
+    tti0, iq, _ = gen_subframes(sc, nsf)
+    ow, _, orecs = run_oracle(sc, tti0, iq, update_meta_period=update_meta_period, taps=False)
+    phy = la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=batch, pcapwriter=la.PcapWriter(None))
+    assert phy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"])
+    if submit:  # the pipelined entry point bench.py times: resident capture, several submits, one wait
+        d = torch.from_numpy(iq.view(np.float32)).to("cuda:0")
+        stride = iq[0].size * 8
+        torch.cuda.synchronize()
+        cuts = list(range(0, nsf, 3 * batch + 11)) + [nsf]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            phy.submit_device(d.data_ptr() + a * stride, b - a, tti0 + a, update_meta_period, torch.cuda.current_stream().cuda_stream)
+        phy.wait()
+    else:
+        phy.process_host(iq, tti0, update_meta_period)
+    g, o = gpu_records(phy), oracle_records(orecs)
+    assert len(o) > 5 * nsf
+    assert g == o, "record streams differ: gpu %d vs oracle %d" % (len(g), len(o))
+    st, ost = phy.getStats(), ow.stats()
+    for f in ("nof_locations", "nof_decoded_locations", "nof_cce", "nof_missed_cce", "nof_subframes", "nof_subframe_collisions_dw", "nof_subframe_collisions_up"):
+        assert getattr(st, f) == getattr(ost, f), f
+    assert phy.nofTrackedRnti() == ow.nof_tracked()
+    assert phy.nof_active_rnti() == ow.nof_active()
+    phy.close()
+
+
+def test_baseline_cfg2_32_rnti_400_subframes():
+    """BASELINE.json configs[1]: 20 MHz, 32 active RNTIs, TM2 64QAM"""
+    _run_stream("cfg2", 400, seed=202, batch=64, update_meta_period=100)
+
+
+def test_baseline_cfg3_150_rnti_400_subframes_pipelined():
+    """BASELINE.json configs[2] (the metric's config): 20 MHz, 150 active RNTIs, TM3/TM4 up to 256QAM, through lsn_phy_submit_device"""
+    _run_stream("cfg3", 400, seed=203, batch=50, update_meta_period=100, submit=True)
+
+
+def test_tti_wrap_inside_a_call():
+    """a call that crosses TTI 10239 -> 0: records carry SFN 0..1023 (PcapWriter.cc:102-103), raw pcap bytes equal to the oracle's"""
+    sc = scenario("small", seed=61, start_tti=10240 - 13)
+    tti0, iq, _ = gen_subframes(sc, 30)
+    assert tti0 == 10240 - 13
+    _, _, orecs = run_oracle(sc, tti0, iq, taps=False)
+    phy = la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=8, pcapwriter=la.PcapWriter(None))
+    assert phy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"])
+    phy.process_host(iq, tti0, 0)
+    from lsn_testlib import parse_pcap
+    recs = parse_pcap(phy.pcapwriter.bytes())
+    assert [r["ctx"] + r["pdu"] for r in recs] == oracle_records(orecs) and len(orecs) > 0
+    assert all(r["sfn"] < 1024 for r in recs) and any(r["sfn"] == 1023 for r in recs) and any(r["sfn"] == 0 for r in recs)
+    phy.close()
+
+
+def test_shortcut_discovery_off_and_histogram_threshold_setter():
+    """PhyCommon::setShortcutDiscovery(false) (LTESniffer_Core.cc:87,616) and RNTIManager::setHistogramThreshold (:620) after construction"""
+    sc = scenario("cfg3", seed=63, n_rnti=40)
+    tti0, iq, _ = gen_subframes(sc, 60)
+    for setup, okw in ((lambda p: p.setShortcutDiscovery(False), dict(enable_shortcut=0)), (lambda p: p.setHistogramThreshold(3), dict(threshold=3))):
+        ow, _, orecs = run_oracle(sc, tti0, iq, taps=False, **okw)
+        phy = la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=20, pcapwriter=la.PcapWriter(None))
+        assert phy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"])
+        setup(phy)
+        phy.process_host(iq, tti0, 0)
+        assert gpu_records(phy) == oracle_records(orecs) and len(orecs) > 0
+        st, ost = phy.getStats(), ow.stats()
+        assert st.nof_decoded_locations == ost.nof_decoded_locations and st.nof_locations == ost.nof_locations
+        txt = phy.printStats().splitlines()
+        assert txt[0].startswith("nof_decoded_locations, nof_cce") and txt[1].split(", ")[0] == str(ost.nof_decoded_locations)
+        phy.close()
+    assert la.Phy(nof_rx_antennas=2).getShortcutDiscovery()
+
+
+def test_mcs_database_ageing_matches_oracle():
+    """MCSTracking::update_database_dl every interval x 1000 subframes (LTESniffer_Core.cc:473-499): RNTIs that appeared through a
+    RAR and went idle leave the database, the record stream and the database size stay identical to the oracle's"""
+    sc = scenario("small", seed=65, n_rnti=6, rar_period=40, pct_256qam=50, mix_tm3_pct=40, dl_min=1, dl_max=2)
+    nsf = 3300
+    tti0, iq, _ = gen_subframes(sc, nsf)
+    ow, _, orecs = run_oracle(sc, tti0, iq, taps=False, mcs_update_interval=1)
+    never, _, _ = run_oracle(sc, tti0, iq[:1], taps=False)
+    phy = la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=100, pcapwriter=la.PcapWriter(None))
+    assert phy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"])
+    phy.setMcsUpdateInterval(1)
+    phy.process_host(iq, tti0, 0)
+    assert gpu_records(phy) == oracle_records(orecs) and len(orecs) > nsf
+    assert phy.nofTrackedRnti() == ow.nof_tracked()
+    # the test must exercise deletions: far more RNTIs were introduced (one per RAR) than the database holds at the end
+    assert ow.nof_tracked() < nsf // 40 // 2, ow.nof_tracked()
+    phy.close()

@@ -1,0 +1,171 @@
+"""MCS-tracking database ageing (MCSTracking::update_database_dl, /root/reference/src/src/MCSTracking.cc:850-927, with the look-up /
+statistics functions that feed it, :758-848 and :1269-1400; driven every get_interval() x 1000 subframes by
+/root/reference/src/src/LTESniffer_Core.cc:473-499).
+
+The product's MCSTracking (ltesniffer_amd/csrc/host/lsn_lte.cc, HIP-free) is driven through the host test glue with random event
+sequences and compared, after every event, with a dict-based restatement of the reference's std::map logic written here from the
+reference source - with the one deliberate difference the whole repo makes: time is the number of subframes processed (1 ms each)
+instead of clock()."""
+import ctypes as C
+import random
+
+import pytest
+
+from lsn_testlib import hosttest
+
+T64, T256, TUNK, TBOTH, TFULL = 0, 1, 2, 3, 4
+MAX_SIZE, RAR_THRESHOLD = 250, 3
+
+
+class RefModel:
+    """tracking_database_dl_mode as the reference keeps it (only the fields that influence a decision)"""
+
+    def __init__(self, interval=5):
+        self.db = {}
+        self.interval = interval
+
+    def _new(self, now):
+        return dict(time=now, table=TUNK, has_rar=False, after_rar=0, active=0, success=0, unsup=0, pinfo=0, other=0)
+
+    def find(self, rnti, now):  # :758-782
+        e = self.db.get(rnti)
+        if e is None:
+            return TUNK if len(self.db) < MAX_SIZE else TFULL
+        e["time"] = now
+        return e["table"]
+
+    def add(self, rnti, now):  # :784-795
+        self.db.setdefault(rnti, self._new(now))
+
+    def update(self, rnti, table, now):  # :797-825
+        e = self.db.get(rnti)
+        if e is None:
+            self.add(rnti, now)
+        elif e["has_rar"]:
+            if e["after_rar"] > RAR_THRESHOLD:
+                e["table"], e["has_rar"] = table, False
+            else:
+                e["table"] = TUNK
+        else:
+            e["table"] = table
+
+    def rar(self, rnti, now):  # :827-848
+        self.add(rnti, now)
+        self.db[rnti]["has_rar"] = True
+        self.db[rnti]["table"] = TUNK
+
+    def statistic(self, rnti, fmt, table, en, ok, mimo, now):  # :1269-1384, harq_mode 0
+        self.add(rnti, now)
+        e = self.db[rnti]
+        if fmt > 2 and e["has_rar"]:  # format > 1A
+            e["after_rar"] += 1
+        if table in (T64, T256, TUNK):
+            for i in range(2):
+                if en[i]:
+                    e["active"] += 1
+                if ok[i]:
+                    e["success"] += 1
+                if en[i] and mimo == -1:
+                    e["unsup"] += 1
+                elif en[i] and mimo == -2:
+                    e["pinfo"] += 1
+                elif en[i] and mimo == -3:
+                    e["other"] += 1
+
+    def update_database(self, now):  # :850-927
+        dele = []
+        for rnti in sorted(self.db):
+            e = self.db[rnti]
+            cur_interval = (now - e["time"]) // 1000
+            wrong = e["active"] == 0 or (e["active"] <= 10 and e["success"] == 0 and (e["unsup"] > 0 or e["pinfo"] > 0 or e["other"] > 0))
+            if cur_interval > self.interval or wrong or e["active"] == 0:
+                dele.append(rnti)
+            elif e["success"] / e["active"] < 0.15 and e["table"] != TUNK:
+                e["table"] = TUNK
+        for r in dele:
+            del self.db[r]
+
+
+def _bind(h):
+    h.lsnh_mcs_new.restype = C.c_void_p
+    h.lsnh_mcs_free.argtypes = [C.c_void_p]
+    h.lsnh_mcs_find.argtypes = [C.c_void_p, C.c_uint16, C.c_uint32]
+    h.lsnh_mcs_update.argtypes = [C.c_void_p, C.c_uint16, C.c_int, C.c_uint32]
+    h.lsnh_mcs_rar.argtypes = [C.c_void_p, C.c_uint16, C.c_uint32]
+    h.lsnh_mcs_stat.argtypes = [C.c_void_p, C.c_uint16] + [C.c_int] * 7 + [C.c_uint32]
+    h.lsnh_mcs_update_database.argtypes = [C.c_void_p, C.c_uint32]
+    h.lsnh_mcs_count.argtypes = [C.c_void_p]
+    h.lsnh_mcs_count.restype = C.c_uint32
+    h.lsnh_mcs_peek.argtypes = [C.c_void_p, C.c_uint16]
+    return h
+
+
+def _same(h, m, ref, rntis):
+    assert h.lsnh_mcs_count(m) == len(ref.db)
+    for r in rntis:
+        want = ref.db[r]["table"] if r in ref.db else -1
+        assert h.lsnh_mcs_peek(m, r) == want, (r, want)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_database_ageing_matches_the_reference_logic(seed):
+    h = _bind(hosttest())
+    m = h.lsnh_mcs_new()
+    ref = RefModel()
+    rng = random.Random(seed)
+    pool = [rng.randrange(11, 0xFFF4) for _ in range(400)]  # more RNTIs than max_size: FULL_BUFFER answers and unbounded growth both occur
+    now = 0
+    try:
+        for step in range(30000):
+            now += rng.choice((1, 1, 1, 2, 5))
+            r = rng.choice(pool[:60]) if rng.random() < 0.7 else rng.choice(pool)  # a busy core of UEs + a long tail that goes idle
+            ev = rng.random()
+            if ev < 0.45:
+                t = ref.find(r, now)
+                assert h.lsnh_mcs_find(m, r, now) == t
+                en = (1, rng.random() < 0.4)
+                ok = tuple(int(e and rng.random() < (0.05 if r % 7 == 0 else 0.9)) for e in en)
+                mimo = rng.choice((0, 0, 0, 0, -1, -2, -3)) if r % 11 == 0 else 0
+                fmt = rng.choice((1, 2, 6, 7))
+                ref.statistic(r, fmt, t, en, ok, mimo, now)
+                h.lsnh_mcs_stat(m, r, fmt, t, int(en[0]), int(en[1]), ok[0], ok[1], mimo, now)
+            elif ev < 0.75:
+                t = rng.choice((T64, T256))
+                ref.update(r, t, now)
+                h.lsnh_mcs_update(m, r, t, now)
+            elif ev < 0.80:
+                ref.rar(r, now)
+                h.lsnh_mcs_rar(m, r, now)
+            if now // 5000 != (now - 5) // 5000 and rng.random() < 0.9:  # roughly every 5000 "subframes"
+                ref.update_database(now)
+                h.lsnh_mcs_update_database(m, now)
+                _same(h, m, ref, pool)
+        _same(h, m, ref, pool)
+        assert len(ref.db) < len(set(pool)), "the sequence never aged anything out"
+    finally:
+        h.lsnh_mcs_free(m)
+
+
+def test_idle_entries_leave_after_more_than_interval_whole_seconds():
+    h = _bind(hosttest())
+    m = h.lsnh_mcs_new()
+    try:
+        for r in (100, 200):
+            h.lsnh_mcs_find(m, r, 0)
+            h.lsnh_mcs_stat(m, r, 2, TUNK, 1, 0, 1, 0, 0, 0)  # active once, success once
+        h.lsnh_mcs_find(m, 200, 4000)                          # 200 is looked up again later
+        h.lsnh_mcs_update_database(m, 5999)                    # 100 idle for 5.999 s: (5999 - 0) / 1000 = 5, not > 5
+        assert h.lsnh_mcs_count(m) == 2
+        h.lsnh_mcs_update_database(m, 6000)                    # 6 whole seconds > 5: gone; 200 was seen 2 s ago
+        assert h.lsnh_mcs_peek(m, 100) == -1 and h.lsnh_mcs_peek(m, 200) == TUNK
+        h.lsnh_mcs_update(m, 200, T256, 6001)
+        assert h.lsnh_mcs_peek(m, 200) == T256
+        for _ in range(9):                                     # success rate 1 / 10 < 15 %: the learned table is dropped
+            h.lsnh_mcs_stat(m, 200, 7, T256, 1, 0, 0, 0, 0, 6002)
+        h.lsnh_mcs_update_database(m, 6500)
+        assert h.lsnh_mcs_peek(m, 200) == TUNK
+        h.lsnh_mcs_rar(m, 300, 6600)                           # an entry that was never active is deleted at the next update
+        h.lsnh_mcs_update_database(m, 6700)
+        assert h.lsnh_mcs_peek(m, 300) == -1
+    finally:
+        h.lsnh_mcs_free(m)
