@@ -1,25 +1,57 @@
 #!/usr/bin/env python3
 """bench.py - subframes/s of the MI355X-native LTESniffer worker on BASELINE.json's metric config.
 
-A "step" is one pass of the hot path (OFDM -> chest -> PCFICH/PDCCH -> exhaustive Viterbi -> FALCON search ->
-PDSCH demod -> turbo -> MAC PDUs) over one resident batch of synthetic subframes.  IQ is already in HBM when the timed
-region starts.  N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), every rank replays its own
-synthetic cell (subframes/cells shard with no data-path exchange) -> weak scaling; value = all ranks' subframes / max time.
+A "step" is one pass of the hot path (OFDM -> chest -> PCFICH/PDCCH -> exhaustive Viterbi -> FALCON search -> PDSCH demod ->
+rate de-matching -> turbo -> MAC PDUs into the MAC-LTE pcap writer) over `--reps` replays of a resident capture of `--nsf` synthetic
+subframes (the TTI keeps advancing, the sequential RNTI / MCS-table state carries across replays).  IQ is in HBM before the timed
+region starts.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--nsf 200] [--config cfg3] [--cpu-sample 120]
-"""
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--nsf 6400] [--reps 10] [--config cfg3] [--cpu-sample 1600]
+
+N > 1: `--gpus N` launches N ranks itself (python -m torch.distributed.run, one process per GPU, backend nccl = RCCL) unless it already
+runs under one (RANK / WORLD_SIZE set, which is how the driver starts it).  Every rank replays its own synthetic cell (BASELINE
+configs[4]: cells shard with no data-path exchange) -> weak scaling; value = all ranks' subframes / max-over-ranks time.
+
+Parity gate (rank 0): `pcap_diff` describes the TIMED stream.  (1) the first `--cpu-sample` subframes of the capture from cold state:
+record stream == the CPU oracle's, record by record; (2) the records of the K timed steps (pipelined lsn_phy_submit_device, chunk size
+--batch) hash to the same digest as a second Phy that walks the same W + K steps synchronously (lsn_phy_process_device, another chunk
+size) - the stream the oracle comparison anchors."""
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
 
-import numpy as np
-import torch
 
+def _maybe_spawn(argv):
+    """--gpus N without a launcher: start N ranks (one per GPU) and relay rank 0's line"""
+    n = 1
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            n = int(argv[i + 1])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+    if n <= 1 or "WORLD_SIZE" in os.environ or "RANK" in os.environ:
+        return
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+_maybe_spawn(sys.argv[1:])
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 _CPU_CTX = None
 
@@ -46,18 +78,28 @@ def _cpu_slice(k):
     return 0
 
 
+def _profile_json(key):
+    """profiles/current.json names the rocprofv3 summaries of this tree (tools/gpu_profile.sh); None when absent"""
+    try:
+        cur = json.load(open(os.path.join(ROOT, "profiles", "current.json")))
+        return json.load(open(os.path.join(ROOT, "profiles", cur[key]))), cur[key]
+    except Exception:
+        return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--nsf", type=int, default=6400, help="subframes per step = length of the resident capture (multiple of --gen)")
+    ap.add_argument("--nsf", type=int, default=6400, help="length of the resident capture in subframes (multiple of --gen)")
+    ap.add_argument("--reps", type=int, default=10, help="replays of the resident capture per step (a step = nsf * reps subframes)")
     ap.add_argument("--gen", type=int, default=1600, help="distinct synthetic subframes generated (multiple of 20); the capture is this block tiled")
     ap.add_argument("--config", default="cfg3", help="scenario preset: cfg3 = 20 MHz, 150 RNTIs, TM3/TM4 up to 256QAM")
-    ap.add_argument("--batch", type=int, default=200, help="subframes per pipeline chunk inside a step")
-    ap.add_argument("--cpu-sample", type=int, default=600, help="subframes timed on the CPU oracle (rank 0, N=1 only)")
-    ap.add_argument("--sync-steps", action="store_true", help="complete every step (lsn_phy_process_device) before the next one starts")
-    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--batch", type=int, default=200, help="subframes per pipeline chunk inside a submit")
+    ap.add_argument("--cpu-sample", type=int, default=1600, help="subframes of the capture decoded by the CPU oracle from cold state (rank 0): parity gate + cpu_baseline")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the oracle leg (parity gate part 1 and cpu_baseline)")
+    ap.add_argument("--no-check", action="store_true", help="skip the synchronous second pass (parity gate part 2)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -80,170 +122,183 @@ def main():
     import ltesniffer_amd as la
     from lsn_testlib import scenario
     from parity import gen_subframes, gpu_records, oracle_records, run_oracle
+    from ltesniffer_amd import dist as ld
 
     gen = max(20, (min(args.gen, args.nsf) // 20) * 20)
     nsf = max(gen, (args.nsf // gen) * gen)
+    reps = max(1, args.reps)
     batch = min(args.batch or nsf, nsf)
-    from ltesniffer_amd import dist as ld
-    sc = scenario(args.config, **ld.rank_workload(args.config, rank))  # one synthetic cell per rank (SURVEY 8d config 5 style)
-    tti0, iq, truth = gen_subframes(sc, gen)
-    # resident capture [nsf][rx][15*N] interleaved cf32 in HBM: the generated block tiled nsf/gen times (its length is a
-    # multiple of 20 subframes, so subframe indices and the SIB pattern stay consistent while the TTI keeps advancing)
+    sc = scenario(args.config, **ld.rank_workload(args.config, rank))  # one synthetic cell per rank
+    tti0, iq, _ = gen_subframes(sc, gen)
+    # resident capture [nsf][rx][15*N] interleaved cf32 in HBM: the generated block tiled nsf/gen times (its length is a multiple of 20
+    # subframes, so subframe indices and the SIB pattern stay consistent while the TTI keeps advancing)
     d_iq = torch.from_numpy(iq.view(np.float32)).to(dev).repeat(nsf // gen, 1, 1).contiguous()
     torch.cuda.synchronize()
+    stream = torch.cuda.current_stream().cuda_stream
+    sf_per_step = nsf * reps
 
-    pcap = la.PcapWriter(None)  # native MAC-LTE writer (in-memory capture), the reference's pcap-emit surface
+    pcap = la.PcapWriter(None)  # native MAC-LTE writer, the reference's pcap-emit surface; the timed stream is digested, not kept
+    pcap.set_store(False)
     phy = la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=batch, device=local, pcapwriter=pcap)
     assert phy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"])
-    stream = torch.cuda.current_stream().cuda_stream
 
-    def step(i):
-        phy.process_device(d_iq.data_ptr(), nsf, tti0 + i * nsf, 500, stream)  # LTESniffer_Core.cc:434: meta update / 500 sf
-
-    # ---- parity gate on the first (cold-state) pass: MAC-LTE record stream vs the CPU oracle on the same subframes ----
-    cpu = None
-    pcap_diff = None
-    ns = min(args.cpu_sample, gen)
-    if rank == 0 and not args.no_cpu:
-        t = time.perf_counter()
-        ow, _, orecs = run_oracle(sc, tti0, iq[:ns], update_meta_period=500, taps=False)
-        dt = time.perf_counter() - t
-        cpu = {"value": round(ns / dt, 2), "unit": "subframes/s", "cores": 1, "kind": "port",
-               "sample": "%d subframes of the same workload (cold RNTI state), scalar C oracle, 1 thread" % ns}
-        # the same restatement on many cores: W forked workers, each decoding its own 100-subframe slice with its own (cold) RNTI state -
-        # an upper bound for a subframe-parallel CPU run of this code (the sequential RNTI state is not shared), informational only
-        try:
-            import multiprocessing as mp
-            W = max(1, min(16, (os.cpu_count() or 2) // 2))
-            per = min(200, gen)
-
-            global _CPU_CTX
-            _CPU_CTX = (sc, tti0, iq, gen, per, run_oracle)  # inherited by the forked workers
-            with mp.get_context("fork").Pool(W) as pool:
-                t = time.perf_counter()
-                pool.map(_cpu_slice, range(W))
-                dtp = time.perf_counter() - t
-            cpu["parallel"] = {"value": round(W * per / dtp, 1), "unit": "subframes/s", "cores": W,
-                               "sample": "%d forked workers x %d subframes, independent cold RNTI state each" % (W, per)}
-        except Exception as ex:  # the single-core figure above is the contract; this one is optional
-            cpu["parallel"] = {"error": str(ex)[:200]}
-        chk = la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=min(batch, 64), device=local, pcapwriter=la.PcapWriter(None))
-        chk.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"])
-        chk.process_host(iq[:ns], tti0, 500)
-        g, o = gpu_records(chk), oracle_records(orecs)
-        pcap_diff = 0 if g == o else max(1, abs(len(g) - len(o)) + sum(1 for a, b in zip(g, o) if a != b))
-        chk.close()
+    def submit_step(p, i, sync=False):
+        for r in range(reps):
+            t = (tti0 + (i * reps + r) * nsf) % 10240
+            if sync:
+                p.process_device(d_iq.data_ptr(), nsf, t, 500, stream)  # LTESniffer_Core.cc:434: meta-format update every 500 subframes
+            else:
+                p.submit_device(d_iq.data_ptr(), nsf, t, 500, stream)
 
     for i in range(args.warmup):
-        step(i)
-        pcap.reset()
+        submit_step(phy, i)
+    phy.wait()
+    pcap.reset()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    kms = np.zeros(16)
-    klaunch = np.zeros(16)
-    turbo_bytes = 0
-    turbo128_bytes = 0
-    algo_bytes = 0
-    npdus = 0
-    acc = {k: 0 for k in ("nof_tb_decodes", "nof_cb_decodes", "nof_turbo_iterations", "nof_turbo_iterations_run", "nof_ondemand_decodes", "turbo_cyc_rm",
-                          "turbo_cyc_map", "turbo_cyc_out", "ms_stage_a", "ms_search", "ms_search_core", "ms_rar", "ms_stage_c", "ms_commit", "ms_wait_front", "ms_wait_slot", "ms_drain")}
     import resource
     ru0 = resource.getrusage(resource.RUSAGE_SELF)
     thr0 = _thread_cpu()
     t0 = time.perf_counter()
-    # the K steps are submitted back to back (lsn_phy_submit_device: a step returns once its subframes are searched and queued, its
-    # decode / commit tail overlaps the next step's front) and completed by one lsn_phy_wait inside the timed region
+    # the K steps are submitted back to back (lsn_phy_submit_device: a submit returns once its subframes are searched and queued, the
+    # decode / commit tail overlaps the next submit) and completed by one lsn_phy_wait inside the timed region
     for i in range(args.steps):
-        if args.sync_steps:
-            step(args.warmup + i)
-        else:
-            phy.submit_device(d_iq.data_ptr(), nsf, tti0 + (args.warmup + i) * nsf, 500, stream)
-        if args.sync_steps or i == args.steps - 1:
-            if not args.sync_steps:
-                phy.wait()
-            p = phy.perf()
-            kms += np.array(p.kernel_ms[:])
-            klaunch += np.array(p.kernel_launches[:])
-            turbo_bytes += p.turbo_algo_bytes
-            turbo128_bytes += p.turbo128_algo_bytes
-            algo_bytes += p.algo_bytes
-            npdus += p.nof_pdus
-            for k in acc:
-                acc[k] += getattr(p, k)
-            if args.sync_steps:
-                pcap.reset()
+        submit_step(phy, args.warmup + i)
+    phy.wait()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
     thr1 = _thread_cpu()
-    host_cores_busy = ((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) / dt  # CPU cores this rank kept busy in the timed region
+    p = phy.perf()
+    timed_digest, timed_bytes = pcap.digest()
+    timed_records = pcap.nof_records()
+    host_cores_busy = ((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) / dt
     if world > 1:
         rdev = dev if dist.get_backend() == "nccl" else None
-        dt, total = ld.reduce_max_sum(dt, args.steps * nsf, rdev)
-        assert total == args.steps * nsf * world
-    total_sf = args.steps * nsf * world
+        dt, total = ld.reduce_max_sum(dt, args.steps * sf_per_step, rdev)
+        assert total == args.steps * sf_per_step * world
+    total_sf = args.steps * sf_per_step * world
     value = total_sf / dt
+    phy.close()
+
+    # ---------------------------------------------------------------- parity gate + CPU baseline (rank 0, outside the timed region)
+    cpu, parity, pcap_diff = None, None, None
+    if rank == 0:
+        parity = {"timed_records": timed_records, "timed_bytes": timed_bytes, "timed_digest": "%016x" % timed_digest}
+        ns = max(20, min(args.cpu_sample, gen))
+        orecs = None
+        if not args.no_cpu:
+            t = time.perf_counter()
+            _, _, orecs = run_oracle(sc, tti0, iq[:ns], update_meta_period=500, taps=False)
+            dto = time.perf_counter() - t
+            cpu = {"value": round(ns / dto, 2), "unit": "subframes/s", "cores": 1, "kind": "port",
+                   "sample": "the first %d subframes of the same capture (cold RNTI state), scalar C oracle, 1 thread" % ns}
+            if world == 1:
+                # the same restatement on many cores: forked workers on independent 200-subframe slices, each with its own (cold) state - an
+                # upper bound for a subframe-parallel CPU run of this code (the sequential RNTI state is not shared), informational only
+                try:
+                    import multiprocessing as mp
+                    W = max(1, min(16, (os.cpu_count() or 2) // 2))
+                    per = min(200, gen)
+                    global _CPU_CTX
+                    _CPU_CTX = (sc, tti0, iq, gen, per, run_oracle)
+                    with mp.get_context("fork").Pool(W) as pool:
+                        t = time.perf_counter()
+                        pool.map(_cpu_slice, range(W))
+                        dtp = time.perf_counter() - t
+                    cpu["parallel"] = {"value": round(W * per / dtp, 1), "unit": "subframes/s", "cores": W,
+                                       "sample": "%d forked workers x %d subframes, independent cold RNTI state each" % (W, per)}
+                except Exception as ex:
+                    cpu["parallel"] = {"error": str(ex)[:200]}
+        if not args.no_check:
+            cw = la.PcapWriter(None)
+            chk = la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=96, device=local, pcapwriter=cw)
+            chk.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"])
+            # the walk below is the SAME subframe sequence the timed Phy saw (W + K steps from cold state), cut differently: first the
+            # oracle's sample as a call of its own (records kept and compared one by one), then the rest with only the digest kept
+            chk.process_device(d_iq.data_ptr(), ns, tti0 % 10240, 500, stream)
+            diff_oracle = None
+            if orecs is not None:
+                g, o = gpu_records(chk), oracle_records(orecs)
+                diff_oracle = 0 if g == o else max(1, abs(len(g) - len(o)) + sum(1 for a, b in zip(g, o) if a != b))
+                parity.update({"oracle_subframes": ns, "oracle_records": len(o), "oracle_mismatches": diff_oracle})
+            cw.set_store(False)
+            stride = d_iq[0].numel() * 4
+            first = True
+            for i in range(args.warmup + args.steps):
+                if i == args.warmup:
+                    cw.reset()
+                for r in range(reps):
+                    t = (tti0 + (i * reps + r) * nsf) % 10240
+                    if first:  # the part of the first replay behind the oracle's sample
+                        first = False
+                        if nsf > ns:
+                            chk.process_device(d_iq.data_ptr() + ns * stride, nsf - ns, (t + ns) % 10240, 500, stream)
+                    else:
+                        chk.process_device(d_iq.data_ptr(), nsf, t, 500, stream)
+            if args.warmup == 0:
+                parity["note"] = "warmup 0: the synchronous pass kept the oracle's sample out of its digest; digests are not comparable"
+            sd, sb = cw.digest()
+            same = (sd == timed_digest and sb == timed_bytes and cw.nof_records() == timed_records) if args.warmup > 0 else None
+            parity.update({"sync_records": cw.nof_records(), "sync_digest": "%016x" % sd, "timed_equals_sync": same})
+            chk.close()
+            if diff_oracle is not None and same is not None:
+                pcap_diff = diff_oracle + (0 if same else max(1, abs(cw.nof_records() - timed_records)))
 
     if rank == 0:
+        kms = np.array(p.kernel_ms[:])
+        klaunch = np.array(p.kernel_launches[:])
         per_thr = {}
         for k, v in thr1.items():
             per_thr[k[1]] = per_thr.get(k[1], 0.0) + (v - thr0.get(k, 0.0)) / dt
         busiest = {k: round(v, 2) for k, v in sorted(per_thr.items(), key=lambda kv: -kv[1])[:8] if v >= 0.01}
-        dom = int(np.argmax(kms[:len(la.KERNELS)]))
-        # roofline of the dominant kernel (one of the two turbo-decoder variants): algorithmic bytes = rate-matched int16
-        # LLRs read (E * 2 per code block) + payload bytes written, per launch; duration from HIP events on the launch stream
+        nk = len(la.KERNELS)
+        dom = int(np.argmax(kms[:nk]))
+        sf_rank = args.steps * sf_per_step  # subframes this rank processed in the timed region
+        # roofline of the dominant kernel (one of the two turbo-decoder variants).  Algorithmic bytes = what the decoder must move per code
+        # block: its K + 12 packed soft words (4 B each, written by k_rm) in, payload bytes out.  Duration: HIP events on the launch stream.
         k64, k128 = la.KERNELS.index("k_turbo<64>"), la.KERNELS.index("k_turbo<128>")
         kt = k128 if kms[k128] >= kms[k64] else k64
-        kbytes = turbo128_bytes if kt == k128 else turbo_bytes - turbo128_bytes
+        kbytes = p.turbo128_algo_bytes if kt == k128 else p.turbo_algo_bytes - p.turbo128_algo_bytes
         ach = (kbytes / 1e9) / (kms[kt] / 1e3) if kms[kt] > 0 else 0.0
-        # HBM traffic of the same kernel from the PMC counters: collected by SEPARATE rocprofv3 --pmc passes of this command
-        # (tools/pmc_summary.py -> profiles/*_pmc_hbm.json); FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md
+        # HBM traffic of the same kernel from the PMC counters: SEPARATE rocprofv3 --pmc passes of this command (tools/gpu_profile.sh ->
+        # profiles/*_pmc_hbm.json), FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md; per launch like `achieved`
         traffic, traffic_src = None, None
-        try:
-            import glob
-            cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json")))
-            cur = os.path.join(ROOT, "profiles", "current.json")
-            if os.path.exists(cur) and json.load(open(cur)).get("pmc_hbm"):
-                cand = [os.path.join(ROOT, "profiles", json.load(open(cur))["pmc_hbm"])]
-            if cand:
-                pj = json.load(open(cand[-1])).get(la.KERNELS[kt])
-                if pj:
-                    traffic = int(pj["fetch_corrected_bytes_per_launch"] + pj["write_bytes_per_launch"])
-                    traffic_src = os.path.relpath(cand[-1], ROOT)
-        except Exception:
-            pass
-        # secondary view (the recursions are integer-VALU work, not HBM work): wave-level VALU instructions per launch from a
-        # separate rocprofv3 --pmc SQ_INSTS_VALU pass (tools/pmc_valu_summary.py -> profiles/*_pmc_valu.json) over this run's launch time,
-        # against the plain-VOP2 issue peak measured on this chip by tools/ubench/valu_rate (profiles/*_valu_ubench.txt)
+        hj, hname = _profile_json("pmc_hbm")
+        if hj and hj.get(la.KERNELS[kt]):
+            e = hj[la.KERNELS[kt]]
+            traffic = int(e["fetch_corrected_bytes_per_launch"] + e["write_bytes_per_launch"])
+            traffic_src = "profiles/" + hname
+        # secondary view (the recursions are integer-VALU work): wave-level VALU instructions per SUBFRAME from a separate
+        # --pmc pass (a property of the workload), over this run's kernel time per subframe = instruction rate while the kernel is resident;
+        # peak = 256 CUs x 4 SIMDs x 2.4 GHz / cycles per wave64 VALU instruction as measured by tools/ubench/valu_rate on this chip
         valu = None
+        vj, vname = _profile_json("pmc_sq")
         try:
-            cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_valu.json")))
-            if os.path.exists(cur) and json.load(open(cur)).get("pmc_valu"):
-                cand = [os.path.join(ROOT, "profiles", json.load(open(cur))["pmc_valu"])]
-            if cand:
-                vj = json.load(open(cand[-1]))
-                pj = vj.get(la.KERNELS[kt])
-                if pj and klaunch[kt] > 0 and kms[kt] > 0:
-                    g = pj["valu_insts_per_launch"] / (kms[kt] / klaunch[kt] * 1e6)
-                    valu = {"wave_insts_per_launch": int(pj["valu_insts_per_launch"]), "achieved_G_per_s": round(g, 1),
-                            "peak_G_per_s": vj.get("_peak_G_wave_insts_per_s", 740.0), "frac": round(g / vj.get("_peak_G_wave_insts_per_s", 740.0), 4),
-                            "all_kernels_wave_insts_per_subframe": int(sum(v["valu_insts_total"] for k, v in vj.items() if not k.startswith("_") and (k.startswith("k_"))) /
-                                                                       max(1, vj.get("_subframes", 3 * 6400))),
-                            "source": os.path.relpath(cand[-1], ROOT)}
+            if vj and vj.get(la.KERNELS[kt]) and kms[kt] > 0:
+                sub = float(vj["_subframes"])
+                peak = float(vj.get("_peak_G_wave_insts_per_s", 1228.8))
+                ins = vj[la.KERNELS[kt]]["SQ_INSTS_VALU"]["total"] / sub
+                g = ins / (kms[kt] / sf_rank * 1e6)
+                allk = sum(v["SQ_INSTS_VALU"]["total"] for k, v in vj.items() if not k.startswith("_") and "SQ_INSTS_VALU" in v and k.startswith("k_")) / sub
+                valu = {"kernel_wave_insts_per_subframe": int(ins), "achieved_G_per_s": round(g, 1), "peak_G_per_s": peak, "frac": round(g / peak, 4),
+                        "all_kernels_wave_insts_per_subframe": int(allk), "chip_G_per_s_at_this_rate": round(allk * value / world / 1e9, 1),
+                        "chip_frac": round(allk * value / world / 1e9 / peak, 4), "source": "profiles/" + vname}
         except Exception:
-            pass
+            valu = None
         out = {
             "metric": "subframes/s (20 MHz, 150 RNTIs)", "value": round(value, 1), "unit": "subframes/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32+int16", "data": "synthetic",
-            "x_realtime": round(value / 1000.0, 2), "pcap_diff": pcap_diff,
+            "x_realtime": round(value / 1000.0 / world, 2), "pcap_diff": pcap_diff, "parity": parity,
             "config": {"workload": "%s: 20 MHz DL (100 PRB, 2 CRS ports, 2 rx), 150 active RNTIs, TM2/TM3/TM4 mix up to 256QAM, "
                                    "CFI 3, 8-14 DL + 3-6 UL DCIs per subframe (BASELINE.json configs[2])" % args.config
                        if args.config == "cfg3" else args.config,
-                       "subframes_per_step": nsf, "steps_pipelined": not args.sync_steps, "distinct_subframes": gen, "gpu_batch": batch, "cells": world, "parallelism": "cell/subframe shards, no collective"},
+                       "subframes_per_step": sf_per_step, "resident_capture_subframes": nsf, "replays_per_step": reps, "steps_pipelined": True,
+                       "distinct_subframes": gen, "gpu_batch": batch, "cells": world, "parallelism": "one cell per GPU, no collective"},
             "roofline": {"bound": "hbm", "kernel": la.KERNELS[kt], "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(ach / 8000.0, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": round(kms[kt] / max(1, klaunch[kt]), 4), "launches": int(klaunch[kt]),
@@ -251,13 +306,15 @@ def main():
                          "dominant_by_time": la.KERNELS[dom], "valu": valu},
             "cpu_baseline": cpu, "host": {"cpu_count": os.cpu_count(), "cores_busy_in_timed_region": round(host_cores_busy, 2),
                                              "busiest_threads": busiest},
-            "detail": {"pdus_per_step": npdus / args.steps, "algo_bytes_per_subframe": int(algo_bytes / (args.steps * nsf)),
-                       "whole_path_GBps": round(algo_bytes / 1e9 / dt, 2),
-                       "per_step": {k: round(v / args.steps, 3) for k, v in acc.items()},
-                       "kernel_ms_per_step": {la.KERNELS[k]: round(kms[k] / args.steps, 4) for k in range(len(la.KERNELS))}},
+            "detail": {"pdus_per_subframe": round(p.nof_pdus / sf_rank, 3), "algo_bytes_per_subframe": int(p.algo_bytes / sf_rank),
+                       "whole_path_GBps": round(p.algo_bytes * world / 1e9 / dt, 2), "timed_region_s": round(dt, 3),
+                       "per_6400_subframes": {k: round(getattr(p, k) * 6400.0 / sf_rank, 3) for k in
+                                              ("nof_tb_decodes", "nof_cb_decodes", "nof_turbo_iterations", "nof_ondemand_decodes", "turbo_cyc_rm", "turbo_cyc_map",
+                                               "turbo_cyc_out", "ms_stage_a", "ms_search", "ms_search_core", "ms_rar", "ms_stage_c", "ms_commit", "ms_wait_front",
+                                               "ms_wait_slot", "ms_drain")},
+                       "kernel_ms_per_6400_subframes": {la.KERNELS[k]: round(kms[k] * 6400.0 / sf_rank, 4) for k in range(nk)}},
         }
         print(json.dumps(out), flush=True)
-    phy.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -507,7 +507,6 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
       pf.nof_tb_decodes++;
       pf.nof_cb_decodes += (uint64_t)s.C;
       pf.algo_bytes += 2ull * (uint64_t)tb.nof_bits * 2ull + (uint64_t)tb.tbs / 8ull;
-      pf.turbo_algo_bytes += (uint64_t)tb.nof_bits * 2ull + (uint64_t)tb.tbs / 8ull;
     }
     r.h_jobs.push_back(d);
   }
@@ -588,7 +587,12 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
       if (n128 && hipEventElapsedTime(&ms, r.ev[5], r.ev[4]) == hipSuccess) { pf.kernel_ms[LSN_K_TURBO128] += ms; pf.kernel_launches[LSN_K_TURBO128]++; }
       const bool forked = g_turbo_fork && n128 && ncb > n128 && r.stream2;
       if (ncb > n128 && hipEventElapsedTime(&ms, forked ? r.ev[6] : r.ev[4], forked ? r.ev[7] : r.ev[3]) == hipSuccess) { pf.kernel_ms[LSN_K_TURBO] += ms; pf.kernel_launches[LSN_K_TURBO]++; }
-      for (uint32_t i = 0; i < n128; i++) pf.turbo128_algo_bytes += (uint64_t)r.h_cbs_pinned[i].E * 2ull + r.h_cbs_pinned[i].out_bytes;
+      // algorithmic bytes of the decoder kernels: every code block reads its K + 12 packed soft words (k_rm's output) and writes its payload
+      for (uint32_t i = 0; i < ncb; i++) {
+        const uint64_t b = 4ull * (r.h_cbs_pinned[i].K + 12u) + r.h_cbs_pinned[i].out_bytes;
+        pf.turbo_algo_bytes += b;
+        if (i < n128) pf.turbo128_algo_bytes += b;
+      }
     }
     ch.h_payload.resize(pay_n);
     if (pay_n > pay0) std::memcpy(ch.h_payload.data() + pay0, r.h_payload_pinned, pay_n - pay0);
@@ -735,6 +739,10 @@ void Engine::commitChunk(Chunk& ch, JobRunner& r)
       else
         tables[di] = cfg.mcs_tracking_mode == 2 ? TABLE_UNKNOWN : TABLE_64QAM;
     }
+    // addCandidate looks the table up for EVERY accepted DCI, format 0 included: an uplink grant refreshes the entry's time stamp too
+    if (cfg.mcs_tracking_mode == 1)
+      for (const UlEntry& u : c.ul)
+        if (!(u.rnti == SIRNTI || u.rnti == PRNTI || rnti_israr(u.rnti))) (void)mcs_tracking.find_tracking_info_RNTI_dl(u.rnti, now);
     for (size_t di = 0; di < c.dl.size(); di++) {
       DlEntry& e = c.dl[di];
       const McsTable table = tables[di];
@@ -759,12 +767,14 @@ void Engine::commitChunk(Chunk& ch, JobRunner& r)
         return e.job[t];
       };
       auto payload_of = [&](int j, int tb) { return ch.h_payload.data() + ch.jobs[j].payload_off[tb]; };
-      auto mimo_of = [&](const PdschGrant& g) { PdschGrant t = g; return -dl_sniffer_config_mimo(cell, e.format, e.dci, t); };  // 0 / -1 / -2 / -3
+      // dl_sniffer_config_mimo's verdict 0 / -1 / -2 / -3 for the statistics: a job exists exactly when it was 0 (newJob), so the
+      // function itself only runs again for the rare rejected grant
+      auto mimo_of = [&](const PdschGrant& g, int job) { if (job >= 0) return 0; PdschGrant t = g; return -dl_sniffer_config_mimo(cell, e.format, e.dci, t); };
       bool crc[2] = {false, false};   // pdsch_res[].crc as the statistics see it at the end of the iteration
       int mimo_ret = 0;
       if (table == TABLE_64QAM || table == TABLE_256QAM) {  // :932-1083
-        mimo_ret = mimo_of(cur);
         const int j = run(cur_t);
+        mimo_ret = mimo_of(cur, j);
         if (j >= 0)
           for (int tb = 0; tb < 2; tb++) {
             const int len = ch.jobs[j].grant.tb[tb].tbs / 8;
@@ -776,8 +786,8 @@ void Engine::commitChunk(Chunk& ch, JobRunner& r)
             }
           }
       } else {  // unknown table: 64QAM table first, the 256QAM table only if both TBs failed, :1089-1243
-        mimo_ret = has64 ? mimo_of(e.grant64) : -1;
         const int j = run(0);
+        mimo_ret = has64 ? mimo_of(e.grant64, j) : -1;
         if (j >= 0) {
           for (int tb = 0; tb < 2; tb++) {
             const int len = ch.jobs[j].grant.tb[tb].tbs / 8;
@@ -791,8 +801,8 @@ void Engine::commitChunk(Chunk& ch, JobRunner& r)
           }
         }
         if (!crc[0] && !crc[1] && mimo_ret == 0) {
-          mimo_ret = has256 ? mimo_of(e.grant256) : -1;
           const int j2 = run(1);
+          mimo_ret = has256 ? mimo_of(e.grant256, j2) : -1;
           if (j2 >= 0)
             for (int tb = 0; tb < 2; tb++) {
               const int len = ch.jobs[j2].grant.tb[tb].tbs / 8;

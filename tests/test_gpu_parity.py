@@ -325,6 +325,7 @@ def test_mcs_database_ageing_matches_oracle():
     phy.process_host(iq, tti0, 0)
     assert gpu_records(phy) == oracle_records(orecs) and len(orecs) > nsf
     assert phy.nofTrackedRnti() == ow.nof_tracked()
-    # the test must exercise deletions: far more RNTIs were introduced (one per RAR) than the database holds at the end
-    assert ow.nof_tracked() < nsf // 40 // 2, ow.nof_tracked()
+    # the test must exercise deletions: more RNTIs were introduced (one per RAR, 82 + the 6 of the cell) than the database holds at the
+    # end (the ones that went idle more than one whole second before the last update are gone)
+    assert ow.nof_tracked() < nsf // 40 - 10, ow.nof_tracked()
     phy.close()

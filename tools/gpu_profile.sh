@@ -5,7 +5,8 @@
 # --pmc passes (SQ instruction/occupancy counters, FETCH_SIZE, WRITE_SIZE; never combined with other trace domains).
 set -u
 TAG=${1:-prof}; shift || true
-ARGS=${*:---no-cpu --steps 3 --warmup 1}
+ARGS=${*:---no-cpu --no-check --steps 1 --warmup 1 --reps 2}
+SUBFRAMES=${LSN_PROFILE_SUBFRAMES:-25600}   # subframes the profiled command processes: (steps + warmup) * nsf * reps
 OUT=gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -25,6 +26,6 @@ P1=$(run_prof pmc_sq1 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS S
 P2=$(run_prof pmc_sq2 --kernel-trace --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_IFETCH)
 P3=$(run_prof pmc_fetch --kernel-trace --pmc FETCH_SIZE)
 P4=$(run_prof pmc_write --kernel-trace --pmc WRITE_SIZE)
-[ -n "$P1$P2" ] && python tools/pmc_generic_summary.py $OUT/${TAG}_pmc_sq.json $P1 $P2 > $OUT/${TAG}_pmc_sq.txt 2>&1
+[ -n "$P1$P2" ] && python tools/pmc_generic_summary.py $OUT/${TAG}_pmc_sq.json $P1 $P2 --subframes $SUBFRAMES > $OUT/${TAG}_pmc_sq.txt 2>&1
 [ -n "$P3" ] && [ -n "$P4" ] && python tools/pmc_summary.py $P3 $P4 $OUT/${TAG}_pmc_hbm.json > $OUT/${TAG}_pmc_hbm.txt 2>&1
 ls -la $OUT | tail -20

@@ -12,6 +12,8 @@ for line in open(sys.argv[1]):
     ev.append((float(t), int(thr), name, int(chunk)))
 ev.sort()
 t_end = ev[-1][0]
+if skip >= t_end - ev[0][0]:
+    skip = 0.0
 ev = [e for e in ev if e[0] >= skip]
 span = t_end - ev[0][0]
 pairs = [("front: wait slot", "acq_begin", "acq_end"), ("front: spec RAR", "stage_a_done", "spec_done"), ("search", "search_begin", "search_end"),
