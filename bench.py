@@ -96,7 +96,7 @@ def main():
     ap.add_argument("--reps", type=int, default=10, help="replays of the resident capture per step (a step = nsf * reps subframes)")
     ap.add_argument("--gen", type=int, default=1600, help="distinct synthetic subframes generated (multiple of 20); the capture is this block tiled")
     ap.add_argument("--config", default="cfg3", help="scenario preset: cfg3 = 20 MHz, 150 RNTIs, TM3/TM4 up to 256QAM")
-    ap.add_argument("--batch", type=int, default=200, help="subframes per pipeline chunk inside a submit")
+    ap.add_argument("--batch", type=int, default=800, help="subframes per pipeline chunk inside a submit")
     ap.add_argument("--cpu-sample", type=int, default=1600, help="subframes of the capture decoded by the CPU oracle from cold state (rank 0): parity gate + cpu_baseline")
     ap.add_argument("--no-cpu", action="store_true", help="skip the oracle leg (parity gate part 1 and cpu_baseline)")
     ap.add_argument("--no-check", action="store_true", help="skip the synchronous second pass (parity gate part 2)")
@@ -310,8 +310,9 @@ def main():
                        "whole_path_GBps": round(p.algo_bytes * world / 1e9 / dt, 2), "timed_region_s": round(dt, 3),
                        "per_6400_subframes": {k: round(getattr(p, k) * 6400.0 / sf_rank, 3) for k in
                                               ("nof_tb_decodes", "nof_cb_decodes", "nof_turbo_iterations", "nof_ondemand_decodes", "turbo_cyc_rm", "turbo_cyc_map",
-                                               "turbo_cyc_out", "ms_stage_a", "ms_search", "ms_search_core", "ms_rar", "ms_stage_c", "ms_commit", "ms_wait_front",
+                                               "turbo_cyc_out", "ms_ondemand_commit", "ms_stage_a", "ms_search", "ms_search_core", "ms_rar", "ms_stage_c", "ms_commit", "ms_wait_front",
                                                "ms_wait_slot", "ms_drain")},
+                       "ondemand_at_commit_per_6400": [round(p.nof_ondemand_commit[k] * 6400.0 / sf_rank, 2) for k in range(4)],
                        "kernel_ms_per_6400_subframes": {la.KERNELS[k]: round(kms[k] * 6400.0 / sf_rank, 4) for k in range(nk)}},
         }
         print(json.dumps(out), flush=True)

@@ -321,6 +321,8 @@ typedef struct {
   uint64_t turbo_cyc_rm, turbo_cyc_map, turbo_cyc_out;  /* shader cycles summed over code blocks: rate-dematch / MAP iterations / output */
   double ms_wait_front, ms_wait_slot, ms_drain;          /* search thread waiting for stage A / front thread waiting for a free chunk slot / final wait for the commits */
   uint64_t nof_turbo_iterations_run;                     /* iterations executed (equals nof_turbo_iterations) */
+  uint64_t nof_ondemand_commit[4];                       /* decodes created at commit: [0] p-a changed, [1] table known at commit but unknown when planned or vice versa, [2] no job planned at all, [3] other */
+  double ms_ondemand_commit;                             /* commit-thread time inside those decodes */
 } lsn_perf_t;
 int lsn_phy_get_perf(lsn_phy_t* phy, lsn_perf_t* out);
 enum { LSN_K_OFDM = 0, LSN_K_CHEST, LSN_K_CHEST_FIN, LSN_K_PCFICH, LSN_K_PDCCH_LLR, LSN_K_CCE_POWER, LSN_K_VITERBI,

@@ -150,11 +150,13 @@ Engine::Engine(const lsn_phy_cfg_t& c) : cfg(c)
   }
   HIP_CHECK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
   trace_path = getenv("LSN_TRACE");
-  for (uint32_t i = 0; i < 65536; i++) { pred_table[i].store(0xFF, std::memory_order_relaxed); pred_p_a[i].store(0.0f, std::memory_order_relaxed); }
+  for (uint32_t i = 0; i < 65536; i++) { pred_table[i].store(0xFF, std::memory_order_relaxed); pred_p_a[i].store(0.0f, std::memory_order_relaxed); pred_rar_at[i].store(0, std::memory_order_relaxed); }
   if (const char* e = getenv("LSN_DECODE_THREADS")) ndec = std::max(1, std::min((int)NDEC, atoi(e)));
-  nslots = ndec + 5;
+  nslots = ndec + 8;
   front_thread = std::thread([this] { pthread_setname_np(pthread_self(), "lsn-front"); frontLoop(); });
   commit_thread = std::thread([this] { pthread_setname_np(pthread_self(), "lsn-commit"); commitLoop(); });
+  spec_thread = std::thread([this] { pthread_setname_np(pthread_self(), "lsn-spec"); specLoop(); });
+  writer_thread = std::thread([this] { pthread_setname_np(pthread_self(), "lsn-writer"); writerLoop(); });
   for (int i = 0; i < ndec; i++)
     decode_threads[i] = std::thread([this, i] {
       char nm[16];
@@ -173,7 +175,11 @@ Engine::~Engine()
   cv_work.notify_all();
   cv_front.notify_all();
   cv_commit.notify_all();
+  cv_spec.notify_all();
+  cv_write.notify_all();
+  if (writer_thread.joinable()) writer_thread.join();
   if (front_thread.joinable()) front_thread.join();
+  if (spec_thread.joinable()) spec_thread.join();
   if (commit_thread.joinable()) commit_thread.join();
   for (auto& t : decode_threads)
     if (t.joinable()) t.join();
@@ -209,7 +215,7 @@ int Engine::setCell(const lsn_cell_t& c)
 
 void Engine::getStats(lsn_blind_stats_t* s) const
 {
-  const BlindStats& b = search->getStats();
+  const BlindStats b = search->getStats();
   s->nof_locations = b.nof_locations; s->nof_decoded_locations = b.nof_decoded_locations; s->nof_cce = b.nof_cce;
   s->nof_missed_cce = b.nof_missed_cce; s->nof_subframes = b.nof_subframes;
   s->nof_subframe_collisions_dw = b.nof_subframe_collisions_dw; s->nof_subframe_collisions_up = b.nof_subframe_collisions_up;
@@ -223,6 +229,8 @@ void Engine::mergePerf(const lsn_perf_t& p)
   perf.ms_search_core += p.ms_search_core; perf.ms_rar += p.ms_rar;
   perf.turbo_cyc_rm += p.turbo_cyc_rm; perf.turbo_cyc_map += p.turbo_cyc_map; perf.turbo_cyc_out += p.turbo_cyc_out; perf.nof_turbo_iterations_run += p.nof_turbo_iterations_run; perf.ms_wait_slot += p.ms_wait_slot;
   perf.nof_candidates_decoded += p.nof_candidates_decoded; perf.nof_ondemand_decodes += p.nof_ondemand_decodes; perf.nof_pdus += p.nof_pdus;
+  for (int k = 0; k < 4; k++) perf.nof_ondemand_commit[k] += p.nof_ondemand_commit[k];
+  perf.ms_ondemand_commit += p.ms_ondemand_commit;
   for (int k = 0; k < 16; k++) { perf.kernel_ms[k] += p.kernel_ms[k]; perf.kernel_launches[k] += p.kernel_launches[k]; }
 }
 
@@ -382,7 +390,10 @@ void Engine::unpackRar(const uint8_t* p, int len, bool at_search)
   RarEntry r[32];
   const int n = rar_parse(cell, p, len, r, 32);
   for (int i = 0; i < n; i++) {
-    if (at_search) search->rntiManager().activateAndRefresh(r[i].t_crnti, 0, RM_ACT_RAR);  // search thread owns the RNTI manager
+    if (at_search) {  // search thread owns the RNTI manager
+      search->rntiManager().activateAndRefresh(r[i].t_crnti, 0, RM_ACT_RAR);
+      pred_rar_at[r[i].t_crnti].store((uint32_t)sf_cnt, std::memory_order_relaxed);  // sf_cnt already counts the subframe being searched (+1 form)
+    }
     else { mcs_tracking.update_rar_time_crnti(r[i].t_crnti, commit_sf_cnt); publishPrediction(r[i].t_crnti); }  // commit thread owns the MCS tracking
   }
 }
@@ -404,6 +415,10 @@ int Engine::newJob(Chunk& ch, uint32_t sf, const DlEntry& e, int table, float p_
       if (tb.enabled && tb.rv < 0) tb.rv = (int)((uint32_t)ceilf(1.5f * (float)((sfn / 2) % 4)) % 4u);
   } else if (e.dci.tb[0].rv < 0 && e.rnti == SIRNTI) j.grant.tb[0].rv = 0;  // DL_Sniffer_PDSCH.cc:891-897
   ch.jobs.push_back(j);
+  JobRes jr;
+  jr.p_a = j.p_a;
+  for (int i = 0; i < 2; i++) { jr.enabled[i] = j.grant.tb[i].enabled ? 1 : 0; jr.len[i] = j.grant.tb[i].tbs / 8; }
+  ch.jres.push_back(jr);
   return (int)ch.jobs.size() - 1;
 }
 
@@ -616,9 +631,23 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
       const uint8_t* pl = ch.h_payload.data() + j.payload_off[t.tb];
       const uint32_t par = ((uint32_t)pl[tbs / 8] << 16) | ((uint32_t)pl[tbs / 8 + 1] << 8) | pl[tbs / 8 + 2];
       j.crc[t.tb] = all_ok && rem == 0 && par != 0 && bits_after == (uint64_t)tbs + 24;
+      JobRes& jr = ch.jres[t.job];
+      jr.crc[t.tb] = j.crc[t.tb] ? 1 : 0;
+      jr.payload_off[t.tb] = j.payload_off[t.tb];
+      // DL_Sniffer_PDSCH.cc:1041-1070: a decoded C-RNTI block is walked for RRCConnectionSetups - here, by the thread that ran the decode,
+      // so that the commit thread never touches the payload
+      if (j.crc[t.tb] && tbs >= 8 && cfg.sniffer_mode == 0 && rnti_name(j.rnti)[0] == 'C') {
+        UeSpecConfig sc[20];
+        const int n = MCSTracking::setups_of_pdu(pl, tbs / 8, sc, 20);
+        if (n > 0) {
+          jr.setup_first[t.tb] = (uint32_t)ch.setup_cfgs.size();
+          jr.nsetup[t.tb] = (uint8_t)n;
+          ch.setup_cfgs.insert(ch.setup_cfgs.end(), sc, sc + n);
+        }
+      }
     }
   }
-  for (int jid : todo) ch.jobs[jid].done = true;
+  for (int jid : todo) { ch.jobs[jid].done = true; ch.jres[jid].done = 1; }
 }
 
 void Engine::ensureJob(Chunk& ch, JobRunner& r, int j)
@@ -634,10 +663,9 @@ void Engine::ensureJob(Chunk& ch, JobRunner& r, int j)
 void Engine::planJobs(Chunk& ch, JobRunner& r)
 {
   std::vector<int> wave;
-  struct Pending { uint32_t sf; size_t di; };
+  struct Pending { uint32_t sf; size_t di; bool always; };
   std::vector<Pending> retry;
-  for (uint32_t sf = 0; sf < ch.nsf; sf++)  // MCS / TBS / RE counts of every accepted downlink DCI (deferred from the sequential search)
-    for (auto& e : ch.ctx[sf].dl) search->finishDlEntry(e, ch.ctx[sf].sf_idx, ch.ctx[sf].cfi);
+  for (uint32_t sf = 0; sf < ch.nsf; sf++) search->finishSubframe(ch.ctx[sf]);  // DCI unpack, grants and collision statistics of every accepted DCI (deferred from the sequential search)
   for (uint32_t sf = 0; sf < ch.nsf; sf++) {
     SubframeCtx& c = ch.ctx[sf];
     if (!c.searched) continue;
@@ -662,7 +690,11 @@ void Engine::planJobs(Chunk& ch, JobRunner& r)
       if (dlRx() == 1 && (e.grant64.nof_tb == 2 || e.grant256.nof_tb == 2)) continue;
       if (e.job[first] < 0) e.job[first] = newJob(ch, sf, e, first, predictedPa(e.rnti));  // as of now; commit checks it
       if (e.job[first] >= 0) wave.push_back(e.job[first]);
-      if (table >= TABLE_UNKNOWN && e.ok256) retry.push_back({sf, di});
+      // the 256QAM-table attempt: the reference makes it when both TBs failed with the 64QAM table.  A DCI of a format that can teach the
+      // table (> 1A, DL_Sniffer_PDSCH.cc:1168-1171) may find its RNTI's table KNOWN by the time it is committed (the plan runs thousands of
+      // subframes ahead of the commit while a new UE is being learned), and then commit wants exactly that attempt: decode it now rather
+      // than as a GPU round trip of the sequential commit thread
+      if (table >= TABLE_UNKNOWN && e.ok256) retry.push_back({sf, di, e.format > FORMAT1A});
     }
   }
   const uint8_t trk = (uint8_t)(2 + (&r - runner_c));
@@ -673,15 +705,42 @@ void Engine::planJobs(Chunk& ch, JobRunner& r)
   for (auto& p : retry) {
     DlEntry& e = ch.ctx[p.sf].dl[p.di];
     if (e.job[0] < 0 || !ch.jobs[e.job[0]].done) continue;
-    if (ch.jobs[e.job[0]].crc[0] || ch.jobs[e.job[0]].crc[1]) continue;
+    if (!p.always && (ch.jobs[e.job[0]].crc[0] || ch.jobs[e.job[0]].crc[1])) continue;
     if (e.job[1] < 0) e.job[1] = newJob(ch, p.sf, e, 1, ch.jobs[e.job[0]].p_a);
     if (e.job[1] >= 0) wave.push_back(e.job[1]);
   }
   runJobs(ch, r, wave);
+  buildCommitView(ch);
+}
+
+void Engine::buildCommitView(Chunk& ch)
+{
+  ch.cdci.clear();
+  ch.cdci_first.assign(ch.nsf + 1, 0);
+  for (uint32_t sf = 0; sf < ch.nsf; sf++) {
+    ch.cdci_first[sf] = (uint32_t)ch.cdci.size();
+    const SubframeCtx& c = ch.ctx[sf];
+    if (!c.searched) continue;
+    for (size_t di = 0; di < c.dl.size(); di++) {
+      const DlEntry& e = c.dl[di];
+      CommitDci d;
+      d.rnti = e.rnti; d.format = (uint8_t)e.format; d.di = (uint32_t)di;
+      d.flags = (uint8_t)((e.unpack_ok ? 1 : 0) | (e.ok64 ? 2 : 0) | (e.ok256 ? 4 : 0) | (e.grant64.nof_tb == 2 ? 8 : 0) | (e.grant256.nof_tb == 2 ? 16 : 0));
+      for (int i = 0; i < 2; i++) {
+        if (e.grant64.tb[i].enabled) d.en64 |= (uint8_t)(1u << i);
+        if (e.grant256.tb[i].enabled) d.en256 |= (uint8_t)(1u << i);
+        d.mcs_idx[i] = (uint8_t)e.dci.tb[i].mcs_idx;
+        d.job[i] = e.job[i];
+      }
+      d.tbs0_64 = e.grant64.tb[0].tbs; d.tbs0_256 = e.grant256.tb[0].tbs;
+      ch.cdci.push_back(d);
+    }
+  }
+  ch.cdci_first[ch.nsf] = (uint32_t)ch.cdci.size();
 }
 
 // ------------------------------------------------------------------------------------------------ commit
-void Engine::emitPdu(JobRunner& r, const char* name, const uint8_t* pdu, uint32_t len, uint16_t rnti, uint32_t tti, uint8_t tb)
+void Engine::emitPdu(Chunk& ch, JobRunner& r, const char* name, size_t payload_off, uint32_t len, uint16_t rnti, uint32_t tti, uint8_t tb)
 {
   r.perf.nof_pdus++;
   if (!sink) return;
@@ -692,7 +751,7 @@ void Engine::emitPdu(JobRunner& r, const char* name, const uint8_t* pdu, uint32_
   else if (name[0] == 'P') { c.rnti = PRNTI; c.rnti_type = 1; }
   else if (name[0] == 'R') { c.rnti = rnti; c.rnti_type = 2; }
   else { c.rnti = rnti; c.rnti_type = 3; }
-  sink(sink_user, &c, pdu, len);
+  ch.recs.push_back({c, payload_off, len});  // written by the writer thread, in commit order
 }
 
 // a decoded C-RNTI transport block: RRCConnectionSetup -> UE configuration database (commit thread)
@@ -717,7 +776,9 @@ void Engine::ageTrackingDatabase()
   nof_mcs_db_updates++;
 }
 
-// PDSCH_Decoder::decode_dl_mode (DL_Sniffer_PDSCH.cc:881-1291) over the decode results of every subframe of the chunk
+// PDSCH_Decoder::decode_dl_mode (DL_Sniffer_PDSCH.cc:881-1291) over the decode results of every subframe of the chunk.
+// The loop reads the compact CommitDci / JobRes views (buildCommitView, runJobs); the wide DlEntry / DecodeJob records are only touched
+// on the slow path (a decode that has to be created here because the plan-time prediction of table or p-a was wrong).
 void Engine::commitChunk(Chunk& ch, JobRunner& r)
 {
   std::vector<McsTable> tables;
@@ -727,98 +788,124 @@ void Engine::commitChunk(Chunk& ch, JobRunner& r)
     // (lsn_phy_get_ue_config) takes this lock
     std::unique_lock<std::mutex> mcs_lk(mcs_mtx);
     const uint32_t now = commit_sf_cnt;
+    commit_pos.store(commit_sf_cnt, std::memory_order_relaxed);
     if (cfg.mcs_tracking_mode && mcs_update_period && commit_sf_cnt && (commit_sf_cnt % mcs_update_period) == 0) ageTrackingDatabase();
     if (!c.searched) continue;
+    const uint32_t k0 = ch.cdci_first[sf], k1 = ch.cdci_first[sf + 1];
     // DCICollection.cc:107-134: the table of every DCI of this subframe is fixed before any of them is decoded
-    tables.resize(c.dl.size());
-    for (size_t di = 0; di < c.dl.size(); di++) {
-      const DlEntry& e = c.dl[di];
+    tables.resize(k1 - k0);
+    for (uint32_t k = k0; k < k1; k++) {
+      const CommitDci& d = ch.cdci[k];
       if (cfg.mcs_tracking_mode == 1)
-        tables[di] = (e.rnti == SIRNTI || e.rnti == PRNTI || rnti_israr(e.rnti) || e.format == FORMAT1A) ? TABLE_64QAM
-                                                                                                        : mcs_tracking.find_tracking_info_RNTI_dl(e.rnti, now);
+        tables[k - k0] = (d.rnti == SIRNTI || d.rnti == PRNTI || rnti_israr(d.rnti) || d.format == FORMAT1A) ? TABLE_64QAM
+                                                                                                           : mcs_tracking.find_tracking_info_RNTI_dl(d.rnti, now);
       else
-        tables[di] = cfg.mcs_tracking_mode == 2 ? TABLE_UNKNOWN : TABLE_64QAM;
+        tables[k - k0] = cfg.mcs_tracking_mode == 2 ? TABLE_UNKNOWN : TABLE_64QAM;
     }
     // addCandidate looks the table up for EVERY accepted DCI, format 0 included: an uplink grant refreshes the entry's time stamp too
     if (cfg.mcs_tracking_mode == 1)
       for (const UlEntry& u : c.ul)
         if (!(u.rnti == SIRNTI || u.rnti == PRNTI || rnti_israr(u.rnti))) (void)mcs_tracking.find_tracking_info_RNTI_dl(u.rnti, now);
-    for (size_t di = 0; di < c.dl.size(); di++) {
-      DlEntry& e = c.dl[di];
-      const McsTable table = tables[di];
-      const bool has64 = e.unpack_ok && (table == TABLE_64QAM || table >= TABLE_UNKNOWN);
-      const bool has256 = e.unpack_ok && (table == TABLE_256QAM || table >= TABLE_UNKNOWN);
-      const bool dci_rnti_ok = e.rnti > 0 && !(has64 && !e.ok64) && !(has256 && !e.ok256);  // falcon_dci.c:286,293,300,305
+    for (uint32_t k = k0; k < k1; k++) {
+      CommitDci& d = ch.cdci[k];
+      const McsTable table = tables[k - k0];
+      const bool unpack_ok = d.flags & 1, ok64 = d.flags & 2, ok256 = d.flags & 4;
+      const bool has64 = unpack_ok && (table == TABLE_64QAM || table >= TABLE_UNKNOWN);
+      const bool has256 = unpack_ok && (table == TABLE_256QAM || table >= TABLE_UNKNOWN);
+      const bool dci_rnti_ok = d.rnti > 0 && !(has64 && !ok64) && !(has256 && !ok256);  // falcon_dci.c:286,293,300,305
       const int cur_t = table == TABLE_256QAM ? 1 : 0;
-      static const PdschGrant empty_grant;
-      const PdschGrant& cur = cur_t ? (has256 ? e.grant256 : empty_grant) : (has64 ? e.grant64 : empty_grant);
-      const bool two_tb = (has64 && e.grant64.nof_tb == 2) || (has256 && e.grant256.nof_tb == 2);
-      const bool gate = (cur.tb[0].tbs > 0 && dci_rnti_ok && !(dlRx() == 1 && two_tb)) || e.rnti == PRNTI;  // :887-889
+      const bool cur_has = cur_t ? has256 : has64;
+      const int32_t cur_tbs0 = cur_has ? (cur_t ? d.tbs0_256 : d.tbs0_64) : 0;
+      const uint8_t cur_en = cur_has ? (cur_t ? d.en256 : d.en64) : 0;
+      const bool two_tb = (has64 && (d.flags & 8)) || (has256 && (d.flags & 16));
+      const bool gate = (cur_tbs0 > 0 && dci_rnti_ok && !(dlRx() == 1 && two_tb)) || d.rnti == PRNTI;  // :887-889
       if (!gate) continue;
-      const char* name = rnti_name(e.rnti);
+      const char* name = rnti_name(d.rnti);
       // :926-927: the p-a in force when this DCI is decoded.  A job planned (or speculated) with another value - a connection setup
       // was committed in between - is dropped and decoded again, so results do not depend on how far ahead the pipeline planned
-      const float p_a_now = mcs_tracking.get_ue_config_rnti(e.rnti).p_a;
+      const float p_a_now = mcs_tracking.get_ue_config_rnti(d.rnti).p_a;
       auto run = [&](int t) -> int {
         if (!(t ? has256 : has64)) return -1;
-        if (e.job[t] >= 0 && ch.jobs[e.job[t]].p_a != p_a_now) e.job[t] = -1;
+        if (d.job[t] >= 0 && ch.jres[d.job[t]].p_a != p_a_now) d.job[t] = -1;
+        if (d.job[t] >= 0 && ch.jres[d.job[t]].done) return d.job[t];
+        DlEntry& e = c.dl[d.di];  // slow path
+        const int why = (e.job[t] >= 0 && d.job[t] < 0) ? 0 : (e.job[t] < 0 ? (e.job[1 - t] >= 0 ? 1 : 2) : 3);
+        e.job[t] = d.job[t];
         if (e.job[t] < 0) e.job[t] = newJob(ch, sf, e, t, p_a_now);
-        if (e.job[t] >= 0 && !ch.jobs[e.job[t]].done) { ensureJob(ch, r, e.job[t]); r.perf.nof_ondemand_decodes++; }
-        return e.job[t];
+        if (e.job[t] >= 0 && !ch.jobs[e.job[t]].done) {
+          const double t0 = now_ms();
+          static const bool dbg = getenv("LSN_DEBUG_ONDEMAND") != nullptr;
+          if (dbg) fprintf(stderr, "ondemand: sf_cnt %u tti %u rnti %u fmt %d table %d t %d job0 %d job1 %d pred %d mcs %u/%u crc0job %d%d\n", commit_sf_cnt, c.tti, d.rnti, (int)d.format, (int)table, t,
+                           e.job[0], e.job[1], (int)pred_table[d.rnti].load(), d.mcs_idx[0], d.mcs_idx[1], e.job[1 - t] >= 0 ? (int)ch.jres[e.job[1 - t]].crc[0] : -1, e.job[1 - t] >= 0 ? (int)ch.jres[e.job[1 - t]].crc[1] : -1);
+          ensureJob(ch, r, e.job[t]);
+          r.perf.nof_ondemand_decodes++; r.perf.nof_ondemand_commit[why]++; r.perf.ms_ondemand_commit += now_ms() - t0;
+        }
+        d.job[t] = e.job[t];
+        return d.job[t];
       };
-      auto payload_of = [&](int j, int tb) { return ch.h_payload.data() + ch.jobs[j].payload_off[tb]; };
       // dl_sniffer_config_mimo's verdict 0 / -1 / -2 / -3 for the statistics: a job exists exactly when it was 0 (newJob), so the
       // function itself only runs again for the rare rejected grant
-      auto mimo_of = [&](const PdschGrant& g, int job) { if (job >= 0) return 0; PdschGrant t = g; return -dl_sniffer_config_mimo(cell, e.format, e.dci, t); };
+      auto mimo_of = [&](int t, int job) {
+        if (job >= 0) return 0;
+        const DlEntry& e = c.dl[d.di];
+        PdschGrant g = t ? e.grant256 : e.grant64;
+        return -dl_sniffer_config_mimo(cell, e.format, e.dci, g);
+      };
+      auto learn = [&](const JobRes& jr, int tb) {  // :1041-1070 with the PDU walked ahead of time (runJobs)
+        if (jr.nsetup[tb] && mcs_tracking.learn_setups(ch.setup_cfgs.data() + jr.setup_first[tb], jr.nsetup[tb], d.rnti, now))
+          default_p_a.store(mcs_tracking.default_p_a(), std::memory_order_relaxed);
+      };
       bool crc[2] = {false, false};   // pdsch_res[].crc as the statistics see it at the end of the iteration
       int mimo_ret = 0;
       if (table == TABLE_64QAM || table == TABLE_256QAM) {  // :932-1083
         const int j = run(cur_t);
-        mimo_ret = mimo_of(cur, j);
-        if (j >= 0)
+        mimo_ret = cur_has ? mimo_of(cur_t, j) : -1;
+        if (j >= 0) {
+          const JobRes& jr = ch.jres[j];
           for (int tb = 0; tb < 2; tb++) {
-            const int len = ch.jobs[j].grant.tb[tb].tbs / 8;
-            crc[tb] = ch.jobs[j].crc[tb];
-            if (ch.jobs[j].crc[tb] && len > 0) {
-              emitPdu(r, name, payload_of(j, tb), (uint32_t)len, e.rnti, c.tti, (uint8_t)tb);
-              if (name[0] == 'R') unpackRar(payload_of(j, tb), len, false);
-              if (name[0] == 'C') learnUeConfig(payload_of(j, tb), len, e.rnti);  // :1041-1070
+            crc[tb] = jr.crc[tb] != 0;
+            if (crc[tb] && jr.len[tb] > 0) {
+              emitPdu(ch, r, name, jr.payload_off[tb], (uint32_t)jr.len[tb], d.rnti, c.tti, (uint8_t)tb);
+              if (name[0] == 'R') unpackRar(ch.h_payload.data() + jr.payload_off[tb], jr.len[tb], false);
+              if (name[0] == 'C') learn(jr, tb);
             }
           }
+        }
       } else {  // unknown table: 64QAM table first, the 256QAM table only if both TBs failed, :1089-1243
         const int j = run(0);
-        mimo_ret = has64 ? mimo_of(e.grant64, j) : -1;
+        mimo_ret = has64 ? mimo_of(0, j) : -1;
         if (j >= 0) {
+          const JobRes& jr = ch.jres[j];
           for (int tb = 0; tb < 2; tb++) {
-            const int len = ch.jobs[j].grant.tb[tb].tbs / 8;
-            crc[tb] = ch.jobs[j].crc[tb];
-            if (crc[tb] && len > 0) {
-              emitPdu(r, name, payload_of(j, tb), (uint32_t)len, e.rnti, c.tti, (uint8_t)tb);
-              if (name[0] == 'R') unpackRar(payload_of(j, tb), len, false);
-              if (name[0] == 'C') learnUeConfig(payload_of(j, tb), len, e.rnti);  // :1133-1160
-              if (e.dci.tb[tb].mcs_idx > 0 && e.dci.tb[tb].mcs_idx < 29 && e.format > FORMAT1A) mcs_tracking.update_RNTI_dl(e.rnti, TABLE_64QAM, now);
+            crc[tb] = jr.crc[tb] != 0;
+            if (crc[tb] && jr.len[tb] > 0) {
+              emitPdu(ch, r, name, jr.payload_off[tb], (uint32_t)jr.len[tb], d.rnti, c.tti, (uint8_t)tb);
+              if (name[0] == 'R') unpackRar(ch.h_payload.data() + jr.payload_off[tb], jr.len[tb], false);
+              if (name[0] == 'C') learn(jr, tb);  // :1133-1160
+              if (d.mcs_idx[tb] > 0 && d.mcs_idx[tb] < 29 && d.format > FORMAT1A) mcs_tracking.update_RNTI_dl(d.rnti, TABLE_64QAM, now);
             }
           }
         }
         if (!crc[0] && !crc[1] && mimo_ret == 0) {
           const int j2 = run(1);
-          mimo_ret = has256 ? mimo_of(e.grant256, j2) : -1;
-          if (j2 >= 0)
+          mimo_ret = has256 ? mimo_of(1, j2) : -1;
+          if (j2 >= 0) {
+            const JobRes& jr = ch.jres[j2];
             for (int tb = 0; tb < 2; tb++) {
-              const int len = ch.jobs[j2].grant.tb[tb].tbs / 8;
-              if (ch.jobs[j2].grant.tb[tb].enabled) crc[tb] = ch.jobs[j2].crc[tb];
-              if (ch.jobs[j2].crc[tb] && len > 0) {
-                emitPdu(r, name, payload_of(j2, tb), (uint32_t)len, e.rnti, c.tti, (uint8_t)tb);
-                if (e.dci.tb[tb].mcs_idx > 0 && e.dci.tb[tb].mcs_idx < 28 && e.format > FORMAT1A) mcs_tracking.update_RNTI_dl(e.rnti, TABLE_256QAM, now);
+              if (jr.enabled[tb]) crc[tb] = jr.crc[tb] != 0;
+              if (jr.crc[tb] && jr.len[tb] > 0) {
+                emitPdu(ch, r, name, jr.payload_off[tb], (uint32_t)jr.len[tb], d.rnti, c.tti, (uint8_t)tb);
+                if (d.mcs_idx[tb] > 0 && d.mcs_idx[tb] < 28 && d.format > FORMAT1A) mcs_tracking.update_RNTI_dl(d.rnti, TABLE_256QAM, now);
               }
             }
+          }
         }
       }
       if (name[0] == 'C' && cfg.mcs_tracking_mode) {  // :1268-1285
-        const bool tb_en[2] = {cur.tb[0].enabled, cur.tb[1].enabled};
-        mcs_tracking.update_statistic_dl(e.rnti, e.format, table, tb_en, crc, mimo_ret, now);
+        const bool tb_en[2] = {(cur_en & 1) != 0, (cur_en & 2) != 0};
+        mcs_tracking.update_statistic_dl(d.rnti, (DciFormat)d.format, table, tb_en, crc, mimo_ret, now);
       }
-      publishPrediction(e.rnti);
+      publishPrediction(d.rnti);
     }
   }
 }
@@ -886,12 +973,45 @@ void Engine::commitLoop()
     }
     {
       std::unique_lock<std::mutex> lk(mtx);
-      if (!err.empty()) commit_error = err;
+      ch->err = err;
       seq_committed++;
+      write_queue.push_back(ch);
+    }
+    cv_write.notify_one();
+    cv_commit.notify_one();
+  }
+}
+
+// writer thread: the records of committed chunks go to the PDU sink (pcap writer / callback) in commit order; the chunk's slot is free
+// again when its last record is out
+void Engine::writerLoop()
+{
+  pinThisThread(nullptr);
+  for (;;) {
+    Chunk* ch = nullptr;
+    {
+      std::unique_lock<std::mutex> lk(mtx);
+      cv_write.wait(lk, [&] { return stop || !write_queue.empty(); });
+      if (write_queue.empty()) return;
+      ch = write_queue.front();
+      write_queue.pop_front();
+    }
+    std::string err = ch->err;
+    if (err.empty() && sink) {
+      try {
+        const uint8_t* base = ch->h_payload.data();
+        for (const auto& rec : ch->recs) sink(sink_user, &rec.ctx, base + rec.off, rec.len);
+      } catch (const std::exception& ex) {
+        err = ex.what();
+      }
+    }
+    {
+      std::unique_lock<std::mutex> lk(mtx);
+      if (!err.empty() && commit_error.empty()) commit_error = err;
+      seq_written++;
       ch->busy = false;
     }
     cv_done.notify_all();
-    cv_commit.notify_one();
   }
 }
 
@@ -916,7 +1036,7 @@ void Engine::frontLoop()
       (void)hipSetDevice(cfg.device);
       const size_t sf_stride = (size_t)cfg.nof_rx_antennas * cd.sflen * sizeof(cf32);
       auto acquire = [&](uint32_t ci) -> Chunk* {
-        Chunk& ch = chunks[ci % (uint32_t)nslots];
+        Chunk& ch = chunks[slot_counter++ % (uint64_t)nslots];  // slots rotate across submits (a short submit must not pin the pipeline to its first few slots)
         trace(1, TR_ACQ_BEGIN, ci);
         {
           const double tw = now_ms();
@@ -928,9 +1048,9 @@ void Engine::frontLoop()
         const uint32_t base = ci * max_batch;
         ch.nsf = std::min(max_batch, job.nsf_total - base);
         ch.start_tti = job.start_tti + base;
-        ch.jobs.clear(); ch.h_payload.clear();
+        ch.jobs.clear(); ch.jres.clear(); ch.cdci.clear(); ch.setup_cfgs.clear(); ch.h_payload.clear(); ch.recs.clear(); ch.err.clear();
         for (uint32_t i = 0; i < ch.nsf; i++) ch.ctx[i].reset(ch.start_tti + i);
-        ch.st_a = stream_a[ci % NSTREAM_A];
+        ch.st_a = stream_a[(slot_counter - 1) % NSTREAM_A];
         ch.trace_id = ci;
         trace(1, TR_ACQ_END, ci);
         launchStageA(ch, (const uint8_t*)job.d_iq + (size_t)base * sf_stride);
@@ -946,14 +1066,12 @@ void Engine::frontLoop()
         const double t0 = now_ms();
         finishStageA(*cur);
         trace(1, TR_A_DONE, cur->trace_id);
-        speculateRar(*cur);
-        trace(1, TR_SPEC_DONE, cur->trace_id);
         perf_front.ms_stage_a += now_ms() - t0;
         {
           std::unique_lock<std::mutex> lk(mtx);
-          search_queue.push_back(cur);
+          spec_queue.push_back(cur);
         }
-        cv_search.notify_one();
+        cv_spec.notify_one();
       }
     } catch (const std::exception& ex) {
       err = ex.what();
@@ -961,9 +1079,46 @@ void Engine::frontLoop()
     if (!err.empty()) {
       std::unique_lock<std::mutex> lk(mtx);
       front_error = err;
-      search_queue.push_back(nullptr);
-      cv_search.notify_one();
+      spec_queue.push_back(nullptr);
+      cv_spec.notify_one();
     }
+  }
+}
+
+// speculative RA-RNTI decodes of finished stage-A chunks (a GPU round trip per chunk), off the front thread so that stage A of the
+// following chunks keeps being launched and collected meanwhile; chunks reach the search thread in order
+void Engine::specLoop()
+{
+  pinThisThread(nullptr);
+  prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0);
+  for (;;) {
+    Chunk* cur = nullptr;
+    {
+      std::unique_lock<std::mutex> lk(mtx);
+      cv_spec.wait(lk, [&] { return stop || !spec_queue.empty(); });
+      if (spec_queue.empty()) return;
+      cur = spec_queue.front();
+      spec_queue.pop_front();
+    }
+    if (cur) {
+      try {
+        (void)hipSetDevice(cfg.device);
+        const double t0 = now_ms();
+        speculateRar(*cur);
+        trace(14, TR_SPEC_DONE, cur->trace_id);
+        runner_f.perf.ms_rar += 0.0;
+        (void)t0;
+      } catch (const std::exception& ex) {
+        std::unique_lock<std::mutex> lk(mtx);
+        front_error = ex.what();
+        cur = nullptr;
+      }
+    }
+    {
+      std::unique_lock<std::mutex> lk(mtx);
+      search_queue.push_back(cur);
+    }
+    cv_search.notify_one();
   }
 }
 
@@ -1046,7 +1201,7 @@ int Engine::wait()
     {
       const double tw = now_ms();
       std::unique_lock<std::mutex> lk(mtx);
-      cv_done.wait(lk, [&] { return seq_committed == seq_pushed; });
+      cv_done.wait(lk, [&] { return seq_written == seq_pushed; });
       perf.ms_drain += now_ms() - tw;
       if (err.empty() && !commit_error.empty()) err = commit_error;
       commit_error.clear();

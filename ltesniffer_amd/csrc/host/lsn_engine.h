@@ -32,6 +32,24 @@ struct DecodeJob {
   uint32_t iters = 0;
 };
 
+// Compact views for the sequential commit thread (it walks them linearly instead of chasing the wide DlEntry / DecodeJob records that
+// other threads wrote): one JobRes per decode job (same index), one CommitDci per accepted downlink DCI in (subframe, acceptance) order.
+struct JobRes {
+  uint8_t done = 0, crc[2] = {0, 0}, enabled[2] = {0, 0};
+  uint8_t nsetup[2] = {0, 0};          // RRCConnectionSetups found in a CRC-ok transport block (pre-parsed by the thread that ran the decode)
+  float p_a = 0.0f;
+  uint32_t payload_off[2] = {0, 0};
+  int32_t len[2] = {0, 0};             // tbs / 8
+  uint32_t setup_first[2] = {0, 0};    // into Chunk::setup_cfgs
+};
+struct CommitDci {
+  uint16_t rnti = 0; uint8_t format = 0, flags = 0;   // flags: 1 unpack_ok, 2 ok64, 4 ok256, 8 grant64 has two TBs, 16 grant256 has two TBs
+  uint8_t en64 = 0, en256 = 0, mcs_idx[2] = {0, 0};   // en*: bit i = tb[i].enabled of that table's grant
+  int32_t tbs0_64 = 0, tbs0_256 = 0;                  // tb[0].tbs of the two grants
+  int32_t job[2] = {-1, -1};
+  uint32_t di = 0;                                    // index in SubframeCtx::dl (slow path: a decode has to be created at commit)
+};
+
 // everything one chunk of subframes owns while it travels through the pipeline
 struct Chunk {
   uint32_t nsf = 0, start_tti = 0;
@@ -46,7 +64,14 @@ struct Chunk {
   uint32_t* h_sfidx = nullptr;
   std::vector<SubframeCtx> ctx;
   std::vector<DecodeJob> jobs;
+  std::vector<JobRes> jres;            // per job, same index as jobs
+  std::vector<CommitDci> cdci;         // built by planJobs
+  std::vector<uint32_t> cdci_first;    // [nsf + 1] first CommitDci of each subframe
+  std::vector<UeSpecConfig> setup_cfgs;
   std::vector<uint8_t> h_payload;
+  struct PduRec { lsn_pdu_ctx_t ctx; size_t off; uint32_t len; };  // payload at h_payload[off .. off + len)
+  std::vector<PduRec> recs;          // records of this chunk in emission order (commit thread -> writer thread)
+  std::string err;                   // first error on this chunk's way through the pipeline
   hipEvent_t ev_a[2 * 8 + 1] = {};  // per stage-A kernel class start/stop + "mirrors on host"
   struct SpecRar { uint32_t sf; uint16_t rnti; DciFormat format; unsigned long long bits; int job; };
   std::vector<SpecRar> spec_rar;     // RA-RNTI grants decoded ahead of the search (front thread)
@@ -87,7 +112,7 @@ public:
   int submit(const void* d_iq, uint32_t nsf, uint32_t start_tti, uint32_t update_meta_period, hipStream_t stream);
   int wait();
   uint64_t submitMark() { std::unique_lock<std::mutex> lk(mtx); return seq_pushed; }                 // position of the last submitted chunk
-  void waitMark(uint64_t mark) { std::unique_lock<std::mutex> lk(mtx); cv_done.wait(lk, [&] { return seq_committed >= mark || !commit_error.empty(); }); }
+  void waitMark(uint64_t mark) { std::unique_lock<std::mutex> lk(mtx); cv_done.wait(lk, [&] { return seq_written >= mark || !commit_error.empty(); }); }
   int mibDecode(const void* iq, bool on_device, lsn_mib_t* out, float* llr_raw480);
   int processFile(const char* path, const lsn_file_cfg_t& fc, uint32_t start_tti, uint64_t max_subframes, uint32_t update_meta_period,
                   uint64_t* subframes_done);
@@ -117,8 +142,8 @@ public:
 
 private:
   static constexpr int NDEC = 12;            // max decode threads (each: plan + stage-C launches of one chunk; commits stay in order)
-  static constexpr int NSLOTS = NDEC + 5;
-  int ndec = 6, nslots = 9;                  // in use (LSN_DECODE_THREADS)
+  static constexpr int NSLOTS = NDEC + 8;
+  int ndec = 8, nslots = 16;                  // in use (LSN_DECODE_THREADS)
   void freeDevice();
   void buildTables();
   void allocChunk(Chunk& ch);
@@ -129,6 +154,7 @@ private:
   void searchChunk(Chunk& ch, uint32_t update_meta_period);
   void speculateRar(Chunk& ch);
   void planJobs(Chunk& ch, JobRunner& r);
+  void buildCommitView(Chunk& ch);
   void runJobs(Chunk& ch, JobRunner& r, std::vector<int>& job_ids);
   void ensureJob(Chunk& ch, JobRunner& r, int j);
   void commitChunk(Chunk& ch, JobRunner& r);
@@ -149,10 +175,12 @@ public:
   UeSpecConfig ueConfig(uint16_t rnti) { std::lock_guard<std::mutex> lk(mcs_mtx); return mcs_tracking.get_ue_config_rnti(rnti); }
 private:
   void unpackRar(const uint8_t* p, int len, bool at_search);
-  void emitPdu(JobRunner& r, const char* name, const uint8_t* pdu, uint32_t len, uint16_t rnti, uint32_t tti, uint8_t tb);
+  void emitPdu(Chunk& ch, JobRunner& r, const char* name, size_t payload_off, uint32_t len, uint16_t rnti, uint32_t tti, uint8_t tb);
+  void writerLoop();
   void decodeLoop(int idx);
   void commitLoop();
   void frontLoop();
+  void specLoop();
   void mergePerf(const lsn_perf_t& p);
   void detectNumaCpus();
   bool pinThisThread(void* saved_mask);   // bind the calling thread to the CPUs of the GPU's NUMA node
@@ -179,7 +207,16 @@ private:
   // per RNTI: tracked table (0xFF: no entry) and p-a as of the last commit that touched the RNTI; relaxed atomics, prediction only
   std::unique_ptr<std::atomic<uint8_t>[]> pred_table{new std::atomic<uint8_t>[65536]};
   std::unique_ptr<std::atomic<float>[]> pred_p_a{new std::atomic<float>[65536]};
-  McsTable predictedTable(uint16_t rnti) const { const uint8_t t = pred_table[rnti].load(std::memory_order_relaxed); return t == 0xFF ? TABLE_UNKNOWN : (McsTable)t; }
+  // a RAR the search has seen for this RNTI but the commit has not reached yet will reset the RNTI's table (update_rar_time_crnti): predict that
+  std::unique_ptr<std::atomic<uint32_t>[]> pred_rar_at{new std::atomic<uint32_t>[65536]};  // 1 + subframe count (search side) of the latest RAR naming the RNTI, 0 = none
+  std::atomic<uint32_t> commit_pos{0};                                                      // subframes committed so far, published
+  McsTable predictedTable(uint16_t rnti) const
+  {
+    const uint32_t ra = pred_rar_at[rnti].load(std::memory_order_relaxed);
+    if (ra && ra > commit_pos.load(std::memory_order_relaxed)) return TABLE_UNKNOWN;
+    const uint8_t t = pred_table[rnti].load(std::memory_order_relaxed);
+    return t == 0xFF ? TABLE_UNKNOWN : (McsTable)t;
+  }
   float predictedPa(uint16_t rnti) const { return pred_table[rnti].load(std::memory_order_relaxed) == 0xFF ? default_p_a.load(std::memory_order_relaxed) : pred_p_a[rnti].load(std::memory_order_relaxed); }
   void publishPrediction(uint16_t rnti);
   void ageTrackingDatabase();
@@ -194,7 +231,9 @@ private:
   // front thread: launches stage A chunk after chunk, hands finished chunks to the search (caller) thread
   std::thread front_thread;
   struct FrontJob { const void* d_iq = nullptr; uint32_t nsf_total = 0, start_tti = 0; bool pending = false; } front_job;
-  std::deque<Chunk*> search_queue;
+  std::deque<Chunk*> search_queue, spec_queue;   // front -> spec (speculative RA-RNTI decodes) -> search
+  std::thread spec_thread;
+  std::condition_variable cv_spec;
   std::condition_variable cv_front, cv_search;
   std::string front_error;
   lsn_perf_t perf_front{};
@@ -203,6 +242,11 @@ private:
   std::thread commit_thread;                    // commits decoded chunks in queue order (PDU order and MCS-table learning stay in TTI order)
   std::map<uint64_t, std::pair<Chunk*, std::string>> decoded;  // seq -> chunk whose decode launches have completed (+ error text)
   std::condition_variable cv_commit;
+  std::thread writer_thread;                    // hands the committed records to the PDU sink / pcap writer, chunk by chunk in commit order
+  std::deque<Chunk*> write_queue;
+  std::condition_variable cv_write;
+  uint64_t seq_written = 0;
+  uint64_t slot_counter = 0;                    // chunks acquired so far (front thread)
   uint64_t seq_pushed = 0, seq_committed = 0;  // chunks queued / committed (commit order = queue order)
   std::mutex mtx;
   std::condition_variable cv_work, cv_done;

@@ -713,20 +713,30 @@ void MCSTracking::update_ue_config_rnti(uint16_t rnti, const UeSpecConfig& c, ui
   add_RNTI_dl(rnti, now);
   ue_cfg[rnti] = c;
 }
-bool MCSTracking::learn_from_pdu(const uint8_t* pdu, int len, uint16_t rnti, uint32_t now)
+int MCSTracking::setups_of_pdu(const uint8_t* pdu, int len, UeSpecConfig* out, int cap)
 {
   MacSubheader sub[20];
   const int n = mac_dlsch_parse(pdu, len, sub, 20);
-  bool any = false;
-  for (int i = 0; i < n; i++) {
+  int k = 0;
+  for (int i = 0; i < n && k < cap; i++) {
     if (!(sub[i].is_sdu && sub[i].lcid == 0)) continue;
     UeSpecConfig c;
-    if (!rrc_conn_setup_decode(pdu + sub[i].off, (int)sub[i].len, c)) continue;
-    if (!has_default) update_default_ue_config(c);  // the first connection setup seen, DL_Sniffer_PDSCH.cc:1061-1065
-    update_ue_config_rnti(rnti, c, now);
-    any = true;
+    if (rrc_conn_setup_decode(pdu + sub[i].off, (int)sub[i].len, c)) out[k++] = c;
   }
-  return any;
+  return k;
+}
+bool MCSTracking::learn_setups(const UeSpecConfig* c, int n, uint16_t rnti, uint32_t now)
+{
+  for (int i = 0; i < n; i++) {
+    if (!has_default) update_default_ue_config(c[i]);  // the first connection setup seen, DL_Sniffer_PDSCH.cc:1061-1065
+    update_ue_config_rnti(rnti, c[i], now);
+  }
+  return n > 0;
+}
+bool MCSTracking::learn_from_pdu(const uint8_t* pdu, int len, uint16_t rnti, uint32_t now)
+{
+  UeSpecConfig c[20];
+  return learn_setups(c, setups_of_pdu(pdu, len, c, 20), rnti, now);
 }
 void MCSTracking::update_RNTI_dl(uint16_t rnti, McsTable t, uint32_t now)
 {

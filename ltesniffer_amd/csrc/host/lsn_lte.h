@@ -176,6 +176,9 @@ public:
   void update_default_ue_config(const UeSpecConfig& c) { default_cfg = c; has_default = true; }
   // one decoded C-RNTI transport block: every CCCH SDU is tried as RRCConnectionSetup (DL_Sniffer_PDSCH.cc:1041-1070); true when one was
   bool learn_from_pdu(const uint8_t* pdu, int len, uint16_t rnti, uint32_t now);
+  // the same with the PDU already walked (setups_of_pdu): the commit thread applies what a decode thread parsed
+  bool learn_setups(const UeSpecConfig* c, int n, uint16_t rnti, uint32_t now);
+  static int setups_of_pdu(const uint8_t* pdu, int len, UeSpecConfig* out, int cap);  // RRCConnectionSetups among the CCCH SDUs, in order
   McsTable find_tracking_info_RNTI_dl(uint16_t rnti, uint32_t now);  // refreshes the entry's time stamp (:778-779)
   void update_RNTI_dl(uint16_t rnti, McsTable t, uint32_t now);
   void update_rar_time_crnti(uint16_t crnti, uint32_t now);

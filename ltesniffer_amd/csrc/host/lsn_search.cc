@@ -96,8 +96,6 @@ void FalconSearch::setCell(const Cell& c, const uint32_t n[3])
   nsizes = (uint32_t)sizes.size();
   for (size_t i = 0; i < sizes.size(); i++) size_list[i] = sizes[i];
   for (int f = 0; f < NOF_FORMATS; f++) size_index_of_format[f] = (int)(std::find(sizes.begin(), sizes.end(), size_of_format[f]) - sizes.begin());
-  rb_map_dl.assign(cell.nof_prb, 0);
-  rb_map_ul.assign(cell.nof_prb, 0);
   for (int cfi = 0; cfi < 3; cfi++) {
     LocTemplate& tp = loc_template[cfi];
     const uint32_t ncce = nof_cce[cfi], lim = std::min<uint32_t>(ncce, LSN_MAX_NUM_OF_CCE);
@@ -132,8 +130,9 @@ void FalconSearch::decodeCandidate(const FalconLocation& loc, DciFormat format, 
 }
 
 // DCICollection::addCandidate (DCICollection.cc:97-298) + srsran_dci_msg_to_trace_timestamp (falcon_dci.c:148-352).
-// Both MCS tables' grants are computed here; which of them "exists" for the reference is resolved at commit time,
-// when the MCS-tracking state of this subframe is known.
+// The sequential search only RECORDS the accepted DCI (nothing it decides later depends on the unpacked fields); unpacking, the grant
+// conversion for both MCS tables and the PRB collision statistics happen in finishSubframe, on the decode threads.  Which table's grant
+// "exists" for the reference is resolved at commit time, when the MCS-tracking state of the subframe is known.
 void FalconSearch::addCandidate(SubframeCtx& c, const DciCandidate& cand, uint32_t L, uint32_t ncce, uint32_t histval)
 {
   const DciFormat fmt = cand.msg.format;
@@ -141,54 +140,81 @@ void FalconSearch::addCandidate(SubframeCtx& c, const DciCandidate& cand, uint32
     const uint32_t a[6] = {cand.rnti, (uint32_t)fmt, L, ncce, cand.msg.nof_bits, histval};
     c.accepted.insert(c.accepted.end(), a, a + 6);
   }
-  uint8_t payload[64] = {0};
-  cand.msg.unpack(payload);
   if (fmt == FORMAT0) {
     if (c.ul.size() >= 64) return;
     c.ul.emplace_back();
     UlEntry& u = c.ul.back();
-    u.rnti = cand.rnti; u.nof_bits = cand.msg.nof_bits; u.L = L; u.ncce = ncce; u.histval = histval;
-    u.dci.L = L; u.dci.ncce = ncce;
-    u.ok = payload[0] == 0 && dci_msg_unpack_pusch(cell, payload, cand.msg.nof_bits, cand.rnti, u.dci) && ra_ul_dci_to_grant(cell, u.dci, u.grant);
-    if (u.ok && !ra_ul_dci_to_grant_256(cell, u.dci, u.grant256)) { u.ok = false; u.grant256 = PuschGrant(); }  // falcon_dci.c:222-231
-    if (u.ok)  // convert_ul_grant runs only after both conversions succeeded (falcon_dci.c:222-232)
-      for (uint32_t i = 0; i < u.grant.L_prb; i++) {  // DCICollection.cc:275-280
-        if (rb_map_ul[u.grant.n_prb + i] != 0) ul_collision = true;
-        rb_map_ul[u.grant.n_prb + i] = cand.rnti;
-      }
+    u.rnti = cand.rnti; u.nof_bits = cand.msg.nof_bits; u.L = L; u.ncce = ncce; u.histval = histval; u.bits = cand.msg.bits;
     return;
   }
   if (c.dl.size() >= 64) return;
   c.dl.emplace_back();
   DlEntry& e = c.dl.back();
   e.rnti = cand.rnti; e.format = fmt; e.nof_bits = cand.msg.nof_bits; e.L = L; e.ncce = ncce; e.histval = histval; e.bits = cand.msg.bits;
-  e.dci.L = L; e.dci.ncce = ncce;
-  e.unpack_ok = dci_msg_unpack_pdsch(cell, payload, cand.msg.nof_bits, fmt, cand.rnti, e.dci);
-  if (e.unpack_ok) {
-    // the sequential search needs the PRB set only (collision statistics); the MCS-table dependent half of
-    // dl_sniffer_ra_dl_dci_to_grant_both runs later, off this thread (finishDlEntry)
-    e.alloc_ok = ra_dl_grant_to_grant_prb_allocation(cell, e.dci, e.grant64);
-    if (e.alloc_ok)
-      for (uint32_t rb = e.grant64.prb_lo; rb <= e.grant64.prb_hi && rb < cell.nof_prb; rb++)  // DCICollection.cc:215-223 (the PRB set does not depend on the MCS table)
-        if (e.grant64.prb_idx[0][rb]) {
-          if (rb_map_dl[rb] != 0) dl_collision = true;
-          rb_map_dl[rb] = cand.rnti;
-        }
-  } else {
-    e.finished = true;
-  }
+}
+
+void FalconSearch::finishUlEntry(UlEntry& u) const
+{
+  if (u.finished) return;
+  u.finished = true;
+  DciMsg msg;
+  msg.bits = u.bits; msg.nof_bits = u.nof_bits;
+  uint8_t payload[64] = {0};
+  msg.unpack(payload);
+  u.dci.L = u.L; u.dci.ncce = u.ncce;
+  u.ok = payload[0] == 0 && dci_msg_unpack_pusch(cell, payload, u.nof_bits, u.rnti, u.dci) && ra_ul_dci_to_grant(cell, u.dci, u.grant);
+  if (u.ok && !ra_ul_dci_to_grant_256(cell, u.dci, u.grant256)) { u.ok = false; u.grant256 = PuschGrant(); }  // falcon_dci.c:222-231
 }
 
 void FalconSearch::finishDlEntry(DlEntry& e, uint32_t sf_idx, uint32_t cfi) const
 {
   if (e.finished) return;
   e.finished = true;
+  if (!e.unpacked) {
+    e.unpacked = true;
+    DciMsg msg;
+    msg.bits = e.bits; msg.nof_bits = e.nof_bits;
+    uint8_t payload[64] = {0};
+    msg.unpack(payload);
+    e.dci.L = e.L; e.dci.ncce = e.ncce;
+    e.unpack_ok = dci_msg_unpack_pdsch(cell, payload, e.nof_bits, e.format, e.rnti, e.dci);
+    if (!e.unpack_ok) return;
+    e.alloc_ok = ra_dl_grant_to_grant_prb_allocation(cell, e.dci, e.grant64);
+  }
+  if (!e.unpack_ok) return;
   if (!e.alloc_ok) { e.grant256 = e.grant64; return; }
   dl_sniffer_grant_finish_both(cell, sf_idx, cfi, e.dci, e.grant64, e.ok64, e.grant256, e.ok256);
   for (int i = 0; i < 2; i++) {  // DCICollection.cc:252-259
     if (e.grant64.tb[i].nof_bits <= 0) e.grant64.tb[i].enabled = false;
     if (e.grant256.tb[i].nof_bits <= 0) e.grant256.tb[i].enabled = false;
   }
+}
+
+void FalconSearch::finishSubframe(SubframeCtx& c)
+{
+  if (c.finished) return;
+  c.finished = true;
+  uint16_t rb_dl[110] = {0}, rb_ul[110] = {0};
+  bool dl_collision = false, ul_collision = false;
+  for (auto& e : c.dl) {
+    finishDlEntry(e, c.sf_idx, c.cfi);
+    if (e.unpack_ok && e.alloc_ok)
+      for (uint32_t rb = e.grant64.prb_lo; rb <= e.grant64.prb_hi && rb < cell.nof_prb; rb++)  // DCICollection.cc:215-223 (the PRB set does not depend on the MCS table)
+        if (e.grant64.prb_idx[0][rb]) {
+          if (rb_dl[rb] != 0) dl_collision = true;
+          rb_dl[rb] = e.rnti;
+        }
+  }
+  for (auto& u : c.ul) {
+    finishUlEntry(u);
+    if (u.ok)  // convert_ul_grant runs only after both conversions succeeded (falcon_dci.c:222-232); DCICollection.cc:275-280
+      for (uint32_t i = 0; i < u.grant.L_prb && u.grant.n_prb + i < 110; i++) {
+        if (rb_ul[u.grant.n_prb + i] != 0) ul_collision = true;
+        rb_ul[u.grant.n_prb + i] = u.rnti;
+      }
+  }
+  if (dl_collision) coll_dw.fetch_add(1, std::memory_order_relaxed);
+  if (ul_collision) coll_up.fetch_add(1, std::memory_order_relaxed);
 }
 
 bool FalconSearch::buildDlEntry(const SubframeCtx& c, uint16_t rnti, DciFormat fmt, unsigned long long bits, DlEntry& e) const
@@ -200,7 +226,7 @@ bool FalconSearch::buildDlEntry(const SubframeCtx& c, uint16_t rnti, DciFormat f
   e = DlEntry();
   e.rnti = rnti; e.format = fmt; e.nof_bits = msg.nof_bits; e.bits = bits;
   e.unpack_ok = dci_msg_unpack_pdsch(cell, payload, msg.nof_bits, fmt, rnti, e.dci);
-  e.finished = true;
+  e.finished = true; e.unpacked = true;
   if (!e.unpack_ok) return false;
   dl_sniffer_ra_dl_dci_to_grant_both(cell, c.sf_idx, c.cfi, e.dci, e.grant64, e.ok64, e.grant256, e.ok256);
   for (int i = 0; i < 2; i++) {
@@ -343,8 +369,6 @@ void FalconSearch::recursive_blind_dci_search(SubframeCtx& c)
       inspect_dci_location_recursively(c, cce_map, l.ncce, l.L, 99, meta_formats->getSecondaryMetaFormats(), meta_formats->getNofSecondaryMetaFormats(), 1, nullptr);
     }
   }
-  if (dl_collision) stats.nof_subframe_collisions_dw++;
-  if (ul_collision) stats.nof_subframe_collisions_up++;
   uint32_t missed = 0;  // falcon_pdcch.c:561-593
   for (uint32_t cc = 0; cc < lim; cc++) {
     if (cur_ccepow[cc] < 0.7f) continue;
@@ -361,9 +385,6 @@ void FalconSearch::search(SubframeCtx& c, const LsnCand* cand, const float* ccep
 {
   cur_cand = cand; cur_ccepow = ccepow;
   temp_dci0.clear();
-  dl_collision = ul_collision = false;
-  std::fill(rb_map_dl.begin(), rb_map_dl.end(), 0);
-  std::fill(rb_map_ul.begin(), rb_map_ul.end(), 0);
   if (update_meta) meta_formats->update_formats();  // SubframeWorker.cc:148-151
   c.searched = c.snr_db > 6.0f;                     // DCISearch.cc:568-574
   if (c.searched) recursive_blind_dci_search(c);

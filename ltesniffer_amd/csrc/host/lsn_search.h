@@ -8,6 +8,7 @@
 #include "lsn_lte.h"
 #include "lsn_types.h"
 #include <functional>
+#include <atomic>
 #include <memory>
 #include <vector>
 
@@ -26,20 +27,22 @@ struct DlEntry {  // DL_Sniffer_DCI_DL (Sniffer_dependency.h:90)
   unsigned long long bits = 0;  // DCI payload as decoded (bit i at position 63-i)
   DciDl dci; bool unpack_ok = false;
   PdschGrant grant64, grant256; bool ok64 = false, ok256 = false;  // both tables computed; selection happens at commit
-  bool alloc_ok = false, finished = false;  // the search only needs the PRB allocation; MCS/TBS/RE counts are filled by finishDlEntry (decode threads)
+  bool alloc_ok = false, finished = false, unpacked = false;  // the sequential search only records (rnti, format, location, payload bits); unpacking, PRB allocation
+                                                              // and MCS/TBS/RE counts are filled in by finishDlEntry / finishSubframe, off the search thread
   int job[2] = {-1, -1};                                          // decode job index per table
 };
-struct UlEntry { uint16_t rnti = 0; uint32_t nof_bits = 0, L = 0, ncce = 0, histval = 0; DciUl dci; PuschGrant grant, grant256; bool ok = false; };
+struct UlEntry { uint16_t rnti = 0; uint32_t nof_bits = 0, L = 0, ncce = 0, histval = 0; unsigned long long bits = 0; DciUl dci; PuschGrant grant, grant256; bool ok = false, finished = false; };
 
 struct SubframeCtx {
   uint32_t tti = 0, sf_idx = 0, sfn = 0, cfi = 0;
   float snr_db = 0, cfo_hz = 0;
   bool searched = false;
+  bool finished = false;           // finishSubframe has run (grants converted, collision statistics counted)
   std::vector<DlEntry> dl;
   std::vector<UlEntry> ul;
   std::vector<uint32_t> accepted;  // 6 words per accepted DCI: rnti, format, L, ncce, nof_bits, histval
   // the TTI counter wraps with the SFN (10 * 1024 subframes): records carry sfn 0..1023 like PcapWriter.cc:102-103, also when a call crosses the wrap
-  void reset(uint32_t tti_) { tti_ %= 10240u; tti = tti_; sf_idx = tti_ % 10; sfn = (tti_ / 10) % 1024; cfi = 0; snr_db = cfo_hz = 0; searched = false; dl.clear(); ul.clear(); accepted.clear(); }
+  void reset(uint32_t tti_) { tti_ %= 10240u; tti = tti_; sf_idx = tti_ % 10; sfn = (tti_ / 10) % 1024; cfi = 0; snr_db = cfo_hz = 0; searched = false; finished = false; dl.clear(); ul.clear(); accepted.clear(); }
 };
 
 struct BlindStats { uint32_t nof_locations = 0, nof_decoded_locations = 0, nof_cce = 0, nof_missed_cce = 0, nof_subframes = 0, nof_subframe_collisions_dw = 0, nof_subframe_collisions_up = 0; };
@@ -64,7 +67,7 @@ public:
   void search(SubframeCtx& c, const LsnCand* cand, const float* ccepow, bool update_meta);
   RNTIManager& rntiManager() { return *rnti_manager; }
   DCIMetaFormats& metaFormats() { return *meta_formats; }
-  const BlindStats& getStats() const { return stats; }
+  BlindStats getStats() const { BlindStats b = stats; b.nof_subframe_collisions_dw = coll_dw.load(); b.nof_subframe_collisions_up = coll_up.load(); return b; }
   uint32_t sizeOfFormat(int f) const { return size_of_format[f]; }
   int sizeIndexOfFormat(int f) const { return size_index_of_format[f]; }
   uint32_t nofSizes() const { return nsizes; }
@@ -73,7 +76,11 @@ public:
   void setShortcutDiscovery(bool enable) { shortcut_discovery = enable; }  // PhyCommon::setShortcutDiscovery, PhyCommon.cc:69-71
   bool getShortcutDiscovery() const { return shortcut_discovery; }
   // the DL entry addCandidate() would build for this candidate (no state is touched): used to decode RA-RNTI grants ahead
-  void finishDlEntry(DlEntry& e, uint32_t sf_idx, uint32_t cfi) const;  // idempotent second half of addCandidate's grant conversion
+  void finishDlEntry(DlEntry& e, uint32_t sf_idx, uint32_t cfi) const;  // idempotent: the rest of addCandidate's DCI unpack + grant conversion (falcon_dci.c:148-352)
+  void finishUlEntry(UlEntry& u) const;
+  // everything of DCICollection::addCandidate the decisions of the search do not depend on, for all accepted DCIs of a subframe:
+  // unpack + grant conversion + the PRB collision statistics (DCICollection.cc:215-223,275-280).  Thread-safe (decode threads).
+  void finishSubframe(SubframeCtx& c);
   bool buildDlEntry(const SubframeCtx& c, uint16_t rnti, DciFormat fmt, unsigned long long bits, DlEntry& e) const;
   uint64_t nof_lookups = 0;
 
@@ -96,8 +103,7 @@ private:
   int size_index_of_format[NOF_FORMATS] = {0};
   uint32_t size_list[LSN_MAX_SIZES] = {0}, nsizes = 0;
   std::vector<TempDci0> temp_dci0;
-  std::vector<uint16_t> rb_map_dl, rb_map_ul;
-  bool dl_collision = false, ul_collision = false;
+  std::atomic<uint32_t> coll_dw{0}, coll_up{0};  // nof_subframe_collisions_dw / _up, counted by finishSubframe
   FalconLocation locations[LSN_MAX_LOC];
   LocTemplate loc_template[3];
   const LsnCand* cur_cand = nullptr;

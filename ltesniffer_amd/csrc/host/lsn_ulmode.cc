@@ -208,13 +208,17 @@ void Engine::commitChunkUl(Chunk& ch, JobRunner& r)
       }
     }
     for (auto& p : out[sf]) {
-      const uint8_t* data = p.ul ? p.own.data() : ch.h_payload.data() + p.off;
-      if (p.ul) {  // write_ul_crnti, PcapWriter.cc:172-175
+      if (p.ul) {  // write_ul_crnti, PcapWriter.cc:172-175: the payload joins the chunk's arena so that the writer thread finds it there
         r.perf.nof_pdus++;
-        if (sink) { lsn_pdu_ctx_t c{}; c.tti = tti; c.rnti = p.rnti; c.direction = 0; c.rnti_type = 3; c.crc_ok = 1; sink(sink_user, &c, data, p.len); }
+        if (sink) {
+          lsn_pdu_ctx_t c{}; c.tti = tti; c.rnti = p.rnti; c.direction = 0; c.rnti_type = 3; c.crc_ok = 1;
+          const size_t off = ch.h_payload.size();
+          ch.h_payload.insert(ch.h_payload.end(), p.own.begin(), p.own.end());
+          ch.recs.push_back({c, off, p.len});
+        }
       } else {
         const char name[2] = {p.name, 0};
-        emitPdu(r, name, data, p.len, p.rnti, tti, p.tb);
+        emitPdu(ch, r, name, p.off, p.len, p.rnti, tti, p.tb);
       }
     }
   }

@@ -126,6 +126,7 @@ uint32_t lsnh_search_run(hsearch* h, uint32_t tti, uint32_t cfi, float snr_db, c
   h->ctx.reset(tti);
   h->ctx.cfi = cfi; h->ctx.snr_db = snr_db;
   h->s->search(h->ctx, cand, ccepow, update_meta != 0);
+  h->s->finishSubframe(h->ctx);  // what the engine's decode threads do with the accepted DCIs (grants + collision statistics)
   const uint32_t n = (uint32_t)h->ctx.accepted.size();
   std::memcpy(out, h->ctx.accepted.data(), sizeof(uint32_t) * (n < max_words ? n : max_words));
   return n / 6;
@@ -133,7 +134,7 @@ uint32_t lsnh_search_run(hsearch* h, uint32_t tti, uint32_t cfi, float snr_db, c
 void lsnh_search_activate_rar(hsearch* h, uint16_t rnti) { h->s->rntiManager().activateAndRefresh(rnti, 0, RM_ACT_RAR); }
 void lsnh_search_stats(hsearch* h, uint32_t* out7)
 {
-  const BlindStats& b = h->s->getStats();
+  const BlindStats b = h->s->getStats();
   out7[0] = b.nof_decoded_locations; out7[1] = b.nof_cce; out7[2] = b.nof_missed_cce; out7[3] = b.nof_subframes;
   out7[4] = b.nof_subframe_collisions_dw; out7[5] = b.nof_subframe_collisions_up; out7[6] = b.nof_locations;
 }
