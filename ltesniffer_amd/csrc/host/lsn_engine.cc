@@ -156,6 +156,7 @@ Engine::Engine(const lsn_phy_cfg_t& c) : cfg(c)
   front_thread = std::thread([this] { pthread_setname_np(pthread_self(), "lsn-front"); frontLoop(); });
   commit_thread = std::thread([this] { pthread_setname_np(pthread_self(), "lsn-commit"); commitLoop(); });
   spec_thread = std::thread([this] { pthread_setname_np(pthread_self(), "lsn-spec"); specLoop(); });
+  search_thread = std::thread([this] { pthread_setname_np(pthread_self(), "lsn-search"); searchLoop(); });
   writer_thread = std::thread([this] { pthread_setname_np(pthread_self(), "lsn-writer"); writerLoop(); });
   for (int i = 0; i < ndec; i++)
     decode_threads[i] = std::thread([this, i] {
@@ -177,6 +178,9 @@ Engine::~Engine()
   cv_commit.notify_all();
   cv_spec.notify_all();
   cv_write.notify_all();
+  cv_search.notify_all();
+  cv_done.notify_all();
+  if (search_thread.joinable()) search_thread.join();
   if (writer_thread.joinable()) writer_thread.join();
   if (front_thread.joinable()) front_thread.join();
   if (spec_thread.joinable()) spec_thread.join();
@@ -349,7 +353,7 @@ void Engine::searchChunk(Chunk& ch, uint32_t update_meta_period)
     sf_cnt++;
     const double ts0 = now_ms();
     search->search(c, ch.h_cand + (size_t)sf * LSN_MAX_LOC * LSN_MAX_SIZES, ch.h_ccepow + (size_t)sf * LSN_CCE_STRIDE, upd);
-    { const double dt = now_ms() - ts0; perf.ms_search_core += dt; search_time_us += dt * 1e3; }
+    { const double dt = now_ms() - ts0; perf_search.ms_search_core += dt; search_time_us += dt * 1e3; }
     est_cfo = c.cfo_hz;  // SubframeWorker.cc:203
     if (!c.searched) continue;
     // RAR grants feed the RNTI manager before the next subframe is searched (DL_Sniffer_PDSCH.cc:782-797): decode them now
@@ -1016,72 +1020,108 @@ void Engine::writerLoop()
 }
 
 // ------------------------------------------------------------------------------------------------ batch driver
-// front thread: stage A of chunk i+1 is launched before chunk i is waited for, finished chunks go to the search thread
+// front thread: cuts the submitted blocks into chunks and keeps stage A of up to NSTREAM_A chunks in flight (one stream each), also
+// across submits (a new submit does not wait for the previous one's chunks to drain); finished chunks go on to the spec thread
 void Engine::frontLoop()
 {
   pinThisThread(nullptr);
   prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0);
-  for (;;) {
-    FrontJob job;
+  std::deque<Chunk*> inflight;
+  auto finish_oldest = [&] {
+    Chunk* cur = inflight.front();
+    inflight.pop_front();
+    const double t0 = now_ms();
+    finishStageA(*cur);
+    trace(1, TR_A_DONE, cur->trace_id);
+    perf_front.ms_stage_a += now_ms() - t0;
     {
       std::unique_lock<std::mutex> lk(mtx);
-      cv_front.wait(lk, [&] { return stop || front_job.pending; });
-      if (!front_job.pending) return;
-      job = front_job;
-      front_job.pending = false;
+      spec_queue.push_back(cur);
     }
-    const uint32_t nchunks = (job.nsf_total + max_batch - 1) / max_batch;
-    std::string err;
+    cv_spec.notify_one();
+  };
+  for (;;) {
+    FrontJob job;
+    bool have = false;
+    {
+      std::unique_lock<std::mutex> lk(mtx);
+      if (inflight.empty()) cv_front.wait(lk, [&] { return stop || !front_jobs.empty(); });
+      if (front_jobs.empty() && inflight.empty()) return;  // stop
+      if (!front_jobs.empty()) { job = front_jobs.front(); front_jobs.pop_front(); have = true; }
+    }
     try {
       (void)hipSetDevice(cfg.device);
+      if (!have) { finish_oldest(); continue; }
+      const uint32_t nchunks = (job.nsf_total + max_batch - 1) / max_batch;
       const size_t sf_stride = (size_t)cfg.nof_rx_antennas * cd.sflen * sizeof(cf32);
-      auto acquire = [&](uint32_t ci) -> Chunk* {
-        Chunk& ch = chunks[slot_counter++ % (uint64_t)nslots];  // slots rotate across submits (a short submit must not pin the pipeline to its first few slots)
+      for (uint32_t ci = 0; ci < nchunks; ci++) {
+        while (inflight.size() >= (size_t)NSTREAM_A) finish_oldest();
+        Chunk& ch = chunks[slot_counter++ % (uint64_t)nslots];  // slots rotate across submits
         trace(1, TR_ACQ_BEGIN, ci);
         {
           const double tw = now_ms();
           std::unique_lock<std::mutex> lk(mtx);
-          cv_done.wait(lk, [&] { return !ch.busy; });
+          cv_done.wait(lk, [&] { return !ch.busy || stop; });
+          if (stop) return;
           ch.busy = true;
           perf_front.ms_wait_slot += now_ms() - tw;
         }
         const uint32_t base = ci * max_batch;
         ch.nsf = std::min(max_batch, job.nsf_total - base);
         ch.start_tti = job.start_tti + base;
+        ch.update_meta_period = job.update_meta_period;
         ch.jobs.clear(); ch.jres.clear(); ch.cdci.clear(); ch.setup_cfgs.clear(); ch.h_payload.clear(); ch.recs.clear(); ch.err.clear();
         for (uint32_t i = 0; i < ch.nsf; i++) ch.ctx[i].reset(ch.start_tti + i);
         ch.st_a = stream_a[(slot_counter - 1) % NSTREAM_A];
         ch.trace_id = ci;
         trace(1, TR_ACQ_END, ci);
         launchStageA(ch, (const uint8_t*)job.d_iq + (size_t)base * sf_stride);
-        return &ch;
-      };
-      // stage A of up to NSTREAM_A chunks is in flight (one stream each) while the oldest one is finished and handed on
-      std::deque<Chunk*> inflight;
-      uint32_t launched = 0;
-      for (uint32_t ci = 0; ci < nchunks; ci++) {
-        while (launched < nchunks && launched < ci + NSTREAM_A) inflight.push_back(acquire(launched++));
-        Chunk* cur = inflight.front();
-        inflight.pop_front();
-        const double t0 = now_ms();
-        finishStageA(*cur);
-        trace(1, TR_A_DONE, cur->trace_id);
-        perf_front.ms_stage_a += now_ms() - t0;
-        {
-          std::unique_lock<std::mutex> lk(mtx);
-          spec_queue.push_back(cur);
-        }
-        cv_spec.notify_one();
+        inflight.push_back(&ch);
       }
     } catch (const std::exception& ex) {
-      err = ex.what();
-    }
-    if (!err.empty()) {
       std::unique_lock<std::mutex> lk(mtx);
-      front_error = err;
-      spec_queue.push_back(nullptr);
-      cv_spec.notify_one();
+      if (commit_error.empty()) commit_error = ex.what();
+      inflight.clear();
+      cv_done.notify_all();
     }
+  }
+}
+
+// search thread (stage B): the FALCON decision tree over every subframe of every chunk, strictly in order
+void Engine::searchLoop()
+{
+  pinThisThread(nullptr);
+  for (;;) {
+    Chunk* cur = nullptr;
+    {
+      const double tw = now_ms();
+      std::unique_lock<std::mutex> lk(mtx);
+      cv_search.wait(lk, [&] { return stop || !search_queue.empty(); });
+      if (search_queue.empty()) return;
+      perf_search.ms_wait_front += now_ms() - tw;
+      cur = search_queue.front();
+      search_queue.pop_front();
+    }
+    if (!cur) continue;  // a chunk the spec thread gave up on: its error is already recorded
+    try {
+      (void)hipSetDevice(cfg.device);
+      const double t1 = now_ms();
+      trace(0, TR_SEARCH_BEGIN, cur->trace_id);
+      searchChunk(*cur, cur->update_meta_period);
+      trace(0, TR_SEARCH_END, cur->trace_id);
+      perf_search.ms_search += now_ms() - t1;
+    } catch (const std::exception& ex) {
+      std::unique_lock<std::mutex> lk(mtx);
+      if (commit_error.empty()) commit_error = ex.what();
+      cv_done.notify_all();
+    }
+    {
+      std::unique_lock<std::mutex> lk(mtx);
+      cur->seq = seq_pushed++;
+      commit_queue.push_back(cur);
+      last_chunk = cur;
+    }
+    cv_work.notify_one();
   }
 }
 
@@ -1110,8 +1150,9 @@ void Engine::specLoop()
         (void)t0;
       } catch (const std::exception& ex) {
         std::unique_lock<std::mutex> lk(mtx);
-        front_error = ex.what();
+        if (commit_error.empty()) commit_error = ex.what();
         cur = nullptr;
+        cv_done.notify_all();
       }
     }
     {
@@ -1122,8 +1163,8 @@ void Engine::specLoop()
   }
 }
 
-// process = submit + wait.  submit() returns once every chunk of the call has been searched and handed to the decode threads;
-// their decode / commit tail overlaps the next submit (the caller keeps the IQ buffer alive until wait()).
+// process = submit + wait.  submit() only queues the block (the caller keeps the IQ buffer alive until wait() / waitMark()); the front,
+// spec, search, decode, commit and writer threads take it from there, so consecutive submits flow through the pipeline without a gap.
 int Engine::process(const void* d_iq, uint32_t nsf_total, uint32_t start_tti, uint32_t update_meta_period, hipStream_t stream)
 {
   const int r = submit(d_iq, nsf_total, start_tti, update_meta_period, stream);
@@ -1135,14 +1176,12 @@ int Engine::submit(const void* d_iq, uint32_t nsf_total, uint32_t start_tti, uin
 {
   if (!cell_set) return LSN_ERROR;
   if (!d_iq && nsf_total) return LSN_ERROR_INVALID_INPUTS;
-  cpu_set_t saved_mask;
-  const bool pinned = pinThisThread(&saved_mask);
-  struct Unpin { Engine* e; bool on; cpu_set_t* m; ~Unpin() { if (on) e->unpinThisThread(m); } } unpin{this, pinned, &saved_mask};
   try {
     HIP_CHECK(hipSetDevice(cfg.device));
     if (!batch_open) {  // first submit since the last wait: the counters describe one submit ... wait span
       perf = lsn_perf_t{};
       perf_front = lsn_perf_t{};
+      perf_search = lsn_perf_t{};
       for (auto& r : runner_c) r.perf = lsn_perf_t{};
       runner_s.perf = lsn_perf_t{};
       runner_f.perf = lsn_perf_t{};
@@ -1156,38 +1195,13 @@ int Engine::submit(const void* d_iq, uint32_t nsf_total, uint32_t start_tti, uin
     const uint32_t nchunks = (nsf_total + max_batch - 1) / max_batch;
     {
       std::unique_lock<std::mutex> lk(mtx);
-      front_job.d_iq = d_iq; front_job.nsf_total = nsf_total; front_job.start_tti = start_tti; front_job.pending = true;
+      front_jobs.push_back({d_iq, nsf_total, start_tti, update_meta_period});
+      chunks_expected += nchunks;
     }
     cv_front.notify_one();
-    for (uint32_t ci = 0; ci < nchunks; ci++) {
-      Chunk* cur = nullptr;
-      {
-        const double tw = now_ms();
-        std::unique_lock<std::mutex> lk(mtx);
-        cv_search.wait(lk, [&] { return !search_queue.empty(); });
-        perf.ms_wait_front += now_ms() - tw;
-        cur = search_queue.front();
-        search_queue.pop_front();
-        if (!cur) { submit_error = front_error; front_error.clear(); }
-      }
-      if (!cur) break;
-      const double t1 = now_ms();
-      trace(0, TR_SEARCH_BEGIN, cur->trace_id);
-      searchChunk(*cur, update_meta_period);
-      trace(0, TR_SEARCH_END, cur->trace_id);
-      perf.ms_search += now_ms() - t1;
-      {
-        std::unique_lock<std::mutex> lk(mtx);
-        cur->seq = seq_pushed++;
-        commit_queue.push_back(cur);
-      }
-      cv_work.notify_one();
-      last_chunk = cur;
-    }
-    return submit_error.empty() ? LSN_SUCCESS : LSN_ERROR;
+    return LSN_SUCCESS;
   } catch (const std::exception& ex) {
     fprintf(stderr, "ltesniffer_amd: %s\n", ex.what());
-    submit_error = ex.what();
     return LSN_ERROR;
   }
 }
@@ -1196,23 +1210,25 @@ int Engine::wait()
 {
   if (!batch_open) return LSN_SUCCESS;
   try {
-    std::string err = submit_error;
-    submit_error.clear();
+    std::string err;
     {
       const double tw = now_ms();
       std::unique_lock<std::mutex> lk(mtx);
-      cv_done.wait(lk, [&] { return seq_written == seq_pushed; });
+      cv_done.wait(lk, [&] { return seq_written == chunks_expected || !commit_error.empty(); });
       perf.ms_drain += now_ms() - tw;
-      if (err.empty() && !commit_error.empty()) err = commit_error;
-      commit_error.clear();
+      err = commit_error;
+      if (!err.empty()) {  // give up on whatever is still in flight: the pipeline starts clean with the next submit
+        commit_error.clear();
+        front_jobs.clear();
+        chunks_expected = seq_written;
+      }
     }
     batch_open = false;
-    if (!err.empty()) {
-      std::unique_lock<std::mutex> lk(mtx);
-      for (auto& ch : chunks) ch.busy = false;
-      throw std::runtime_error(err);
-    }
+    if (!err.empty()) throw std::runtime_error(err);
     perf.nof_candidates_decoded = search->nof_lookups; search->nof_lookups = 0;
+    perf.ms_search_core = 0;
+    mergePerf(perf_search);
+    perf.ms_wait_front += perf_search.ms_wait_front;
     mergePerf(perf_front);
     for (auto& r : runner_c) mergePerf(r.perf);
     mergePerf(runner_s.perf);

@@ -78,6 +78,7 @@ struct Chunk {
   bool busy = false;                 // owned by the pipeline (slot not reusable yet)
   uint64_t seq = 0;                  // position in the commit order
   uint32_t trace_id = 0;             // chunk number inside its submit (LSN_TRACE)
+  uint32_t update_meta_period = 0;   // of the submit this chunk belongs to
 };
 
 // one stream + its device/host arenas for PDSCH decode launches
@@ -111,7 +112,7 @@ public:
   int process(const void* d_iq, uint32_t nsf, uint32_t start_tti, uint32_t update_meta_period, hipStream_t stream);
   int submit(const void* d_iq, uint32_t nsf, uint32_t start_tti, uint32_t update_meta_period, hipStream_t stream);
   int wait();
-  uint64_t submitMark() { std::unique_lock<std::mutex> lk(mtx); return seq_pushed; }                 // position of the last submitted chunk
+  uint64_t submitMark() { std::unique_lock<std::mutex> lk(mtx); return chunks_expected; }            // position of the last submitted chunk
   void waitMark(uint64_t mark) { std::unique_lock<std::mutex> lk(mtx); cv_done.wait(lk, [&] { return seq_written >= mark || !commit_error.empty(); }); }
   int mibDecode(const void* iq, bool on_device, lsn_mib_t* out, float* llr_raw480);
   int processFile(const char* path, const lsn_file_cfg_t& fc, uint32_t start_tti, uint64_t max_subframes, uint32_t update_meta_period,
@@ -197,7 +198,7 @@ private:
   size_t staging_sf = 0;
   Chunk chunks[NSLOTS];
   JobRunner runner_c[NDEC], runner_s, runner_f, runner_k;  // decode threads / search thread (on-demand RAR decodes) / front thread (speculative RAR decodes) / commit thread (on-demand decodes)
-  static constexpr int NSTREAM_A = 3;        // stage A of consecutive chunks overlaps on the GPU (kernels of one stream serialise)
+  static constexpr int NSTREAM_A = 4;        // stage A of consecutive chunks overlaps on the GPU (kernels of one stream serialise)
   hipStream_t stream_a[NSTREAM_A] = {};
   hipEvent_t ev_in = nullptr;
   std::unique_ptr<FalconSearch> search;
@@ -230,7 +231,12 @@ public:
 private:
   // front thread: launches stage A chunk after chunk, hands finished chunks to the search (caller) thread
   std::thread front_thread;
-  struct FrontJob { const void* d_iq = nullptr; uint32_t nsf_total = 0, start_tti = 0; bool pending = false; } front_job;
+  struct FrontJob { const void* d_iq = nullptr; uint32_t nsf_total = 0, start_tti = 0, update_meta_period = 0; };
+  std::deque<FrontJob> front_jobs;            // submits not yet cut into chunks (front thread)
+  uint64_t chunks_expected = 0;               // chunks of all submits so far; wait() returns when as many have been written
+  std::thread search_thread;                  // stage B: the sequential FALCON search, chunk after chunk
+  lsn_perf_t perf_search{};
+  void searchLoop();
   std::deque<Chunk*> search_queue, spec_queue;   // front -> spec (speculative RA-RNTI decodes) -> search
   std::thread spec_thread;
   std::condition_variable cv_spec;

@@ -18,29 +18,34 @@ __device__ __forceinline__ cf32 cmulconj(cf32 a, cf32 b) { cf32 c; c.r = a.r * b
 __device__ __forceinline__ float cabs2(cf32 a) { return a.r * a.r + a.i * a.i; }
 
 // ------------------------------------------------------------------------------------------------ RE bookkeeping
-// prefix[l][prb] = number of PDSCH REs of this grant in symbol l before PRB prb; prefix[14*nprb + l] = REs before symbol l
+// prefix[l][prb] = number of PDSCH REs of this grant in symbol l before PRB prb; prefix[14*nprb + l] = REs before symbol l.
+// One wavefront per job: lanes are PRBs (two rounds cover 110), the exclusive prefix over the PRBs of a symbol is a shuffle scan.
 __global__ __launch_bounds__(64) void k_pdsch_prep(LsnCellDev c, const LsnGrantDev* __restrict__ jobs, uint16_t* __restrict__ prefix)
 {
-  __shared__ uint32_t tot[16];
   const LsnGrantDev& g = jobs[blockIdx.x];
-  const int l = threadIdx.x, nprb = (int)c.nof_prb;
+  const int lane = threadIdx.x, nprb = (int)c.nof_prb;
   uint16_t* pf = prefix + g.prefix_off;
   const int cls = g.sf_idx == 0 ? 0 : (g.sf_idx == 5 ? 1 : 2);
-  if (l < 14) {
-    uint32_t run = 0;
-    for (int prb = 0; prb < nprb; prb++) {
-      pf[l * nprb + prb] = (uint16_t)run;
-      if (l >= (int)g.l0 && ((g.prb_mask[l / 7][prb >> 5] >> (prb & 31)) & 1u))
-        run += __popc((unsigned)c.validmask[(cls * 14 + l) * nprb + prb]);
+  uint32_t before = 0;  // REs of the symbols in front of l (wave-uniform)
+  for (int l = 0; l < 14; l++) {
+    uint32_t run = 0;   // REs of this symbol in front of the current round
+    for (int base = 0; base < nprb; base += 64) {
+      const int prb = base + lane;
+      uint32_t v = 0;
+      if (prb < nprb && l >= (int)g.l0 && ((g.prb_mask[l / 7][prb >> 5] >> (prb & 31)) & 1u)) v = (uint32_t)__popc((unsigned)c.validmask[(cls * 14 + l) * nprb + prb]);
+      uint32_t inc = v;  // inclusive scan over the 64 lanes
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(inc, off);
+        if (lane >= off) inc += t;
+      }
+      if (prb < nprb) pf[l * nprb + prb] = (uint16_t)(run + inc - v);
+      run += __shfl(inc, 63);
     }
-    tot[l] = run;
+    if (lane == 0) pf[14 * nprb + l] = (uint16_t)before;
+    before += run;
   }
-  __syncthreads();
-  if (l == 0) {
-    uint32_t run = 0;
-    for (int i = 0; i < 14; i++) { pf[14 * nprb + i] = (uint16_t)run; run += tot[i]; }
-    pf[14 * nprb + 14] = (uint16_t)run;
-  }
+  if (lane == 0) pf[14 * nprb + 14] = (uint16_t)before;
 }
 void lsn_launch_pdsch_prep(const LsnCellDev& c, const LsnGrantDev* g, uint16_t* prefix, uint32_t njobs, hipStream_t s)
 {
