@@ -196,6 +196,11 @@ int o_turbo_decode_cb(const int16_t* d3, int K, int max_iter, uint32_t crc_poly,
 int o_pdsch_decode_tb(const int16_t* e, int G, int tbs, int Qm, int nof_layers_rm, int rv, int max_iter,
                       uint8_t* payload, int* iters_total);
 int o_turbo_nwin(int K);
+/* ---------- second-opinion decoders (o_second.c): full-trellis 16-bit-input turbo, float tail-biting Viterbi ---------- */
+void o_pdsch_set_llr_clip(int clip); /* demodulator soft-bit clip, 511 by contract */
+int o_turbo_decode_cb_second(const int32_t* d3, int K, int max_iter, uint32_t crc_poly, uint8_t* bits, int* crc_ok);
+int o_pdsch_decode_tb_second(const int16_t* e, int G, int tbs, int Qm, int nof_layers_rm, int rv, int max_iter, uint8_t* payload, int* iters_total);
+uint16_t o_dci_decode_second(const float* llr, int E, int nof_bits, uint8_t* payload);
 
 /* ---------- PBCH / MIB (o_pbch.c) ---------- */
 typedef struct { int found; uint32_t sfn /* MIB SFN + radio-frame position */, sfn_offset, nof_prb, nof_ports, phich_length, phich_ng_x6, mib_bits; } o_mib_t;
@@ -303,6 +308,7 @@ void o_worker_set_ul_mode(o_worker_t*, const o_ul_cfg_t* ul);
 int o_worker_work_ul(o_worker_t*, const ocf_t* dl_iq, const ocf_t* ul_iq, uint32_t sf_idx, uint32_t sfn, int update_meta_formats);
 const o_stats_t* o_worker_stats(o_worker_t*);
 void o_worker_ue_cfg(o_worker_t* w, uint16_t rnti, o_ue_cfg_t* out); /* MCSTracking::get_ue_config_rnti */
+void o_worker_set_second_opinion(o_worker_t* w, int turbo, int viterbi); /* decode transport blocks / DCI candidates with o_second.c */
 void o_worker_set_mcs_update_interval(o_worker_t* w, uint32_t seconds); /* MCSTracking::interval (5 s): ageing every interval x 1000 subframes, 0 = never */
 uint32_t o_worker_nof_tracked(o_worker_t* w);                         /* MCSTracking::nof_RNTI_member_dl */
 int o_worker_tracked_table(o_worker_t* w, uint16_t rnti);            /* tracked table of an RNTI, -1 without entry */

@@ -107,11 +107,14 @@ static void demod_llr(int Qm, float I, float Q, float* L)
   }
 }
 
+/* soft-bit clip of the demodulator: 511 (10-bit soft values, the production contract); the second-opinion chain (o_second.c) lifts it */
+static int g_llr_clip = LLR_CLIP;
+void o_pdsch_set_llr_clip(int clip) { g_llr_clip = clip > 0 && clip < 32768 ? clip : LLR_CLIP; }
 static inline int16_t quant_llr(float v)
 {
   float r = rintf(v);
-  if (r > (float)LLR_CLIP) r = (float)LLR_CLIP;
-  if (r < (float)-LLR_CLIP) r = (float)-LLR_CLIP;
+  if (r > (float)g_llr_clip) r = (float)g_llr_clip;
+  if (r < (float)-g_llr_clip) r = (float)-g_llr_clip;
   return (int16_t)r;
 }
 

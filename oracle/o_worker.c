@@ -58,6 +58,7 @@ struct o_worker {
   uint32_t mcs_update_period; /* get_interval() x 1000 subframes (LTESniffer_Core.cc:473-485), 0 = never */
   uint32_t mcs_interval;      /* seconds, MCSTracking.h:162 */
   uint32_t nof_mcs_updates;
+  int second_turbo, second_viterbi; /* second-opinion decoders (o_second.c) instead of the production restatement */
   o_ue_cfg_t* uecfg; /* [65536] ue_spec_config of the tracking-database entries (MCSTracking.h:37-43) */
   o_ue_cfg_t default_cfg;
   int has_default_cfg;
@@ -293,6 +294,7 @@ static void mcs_update_database(o_worker_t* w)
   }
   w->nof_mcs_updates++;
 }
+void o_worker_set_second_opinion(o_worker_t* w, int turbo, int viterbi) { w->second_turbo = turbo; w->second_viterbi = viterbi; }
 void o_worker_set_mcs_update_interval(o_worker_t* w, uint32_t seconds) { w->mcs_interval = seconds; w->mcs_update_period = seconds * 1000u; }
 uint32_t o_worker_nof_tracked(o_worker_t* w) { return w->mcs_count; }
 int o_worker_tracked_table(o_worker_t* w, uint16_t rnti) { return w->mcs[rnti].present ? (int)w->mcs[rnti].table : -1; }
@@ -378,7 +380,7 @@ static void decode_msg(o_worker_t* w, const floc_t* loc, int format, cand_t* c)
   for (uint32_t i = 0; i < E; i++) mean += (l[i] < 0 ? -l[i] : l[i]);
   mean /= E;
   if (mean > 0.0) {
-    c->rnti = o_dci_decode(l, (int)E, (int)nof_bits, c->msg.payload);
+    c->rnti = w->second_viterbi ? o_dci_decode_second(l, (int)E, (int)nof_bits, c->msg.payload) : o_dci_decode(l, (int)E, (int)nof_bits, c->msg.payload);
     c->msg.nof_bits = nof_bits;
     if (format == O_FMT0 || format == O_FMT1A)
       c->msg.format = c->msg.payload[0] == 0 ? O_FMT0 : O_FMT1A;
@@ -661,14 +663,16 @@ static void decode_grant(o_worker_t* w, const dl_entry_t* e, const o_pdsch_grant
   /* pdsch_cfg->p_a: the UE's p-a from its RRCConnectionSetup (or the default) in DL mode, DL_Sniffer_PDSCH.cc:926-927; the UL-mode
    * decoders never set it and run with the initial -3 dB of SubframeWorker::set_pdsch_uecfg (SubframeWorker.cc:370) */
   const float p_a = w->ul_mode ? -3.0f : ue_cfg_get(w, e->rnti).p_a;
-  if (o_pdsch_demod(&w->cfg.cell, w->cfg.nof_rx, w->sf_idx, w->cfi, e->rnti, g, w->grid, w->ce, w->chest.noise_avg,
-                    w->chest.chan_ref, p_a, w->llr0, w->llr1))
-    return;
+  if (w->second_turbo) o_pdsch_set_llr_clip(32767);
+  const int demod_rc = o_pdsch_demod(&w->cfg.cell, w->cfg.nof_rx, w->sf_idx, w->cfi, e->rnti, g, w->grid, w->ce, w->chest.noise_avg,
+                                     w->chest.chan_ref, p_a, w->llr0, w->llr1);
+  if (w->second_turbo) o_pdsch_set_llr_clip(511);
+  if (demod_rc) return;
   for (int i = 0; i < 2; i++)
     if (g->tb[i].enabled && g->tb[i].tbs > 0) {
       const int16_t* llr = (g->tb[i].cw_idx & 1) ? w->llr1 : w->llr0;
       int its = 0;
-      crc[i] = o_pdsch_decode_tb(llr, g->tb[i].nof_bits, g->tb[i].tbs, g->tb[i].mod, g->tx_scheme == O_TX_DIVERSITY ? 2 : 1,
+      crc[i] = (w->second_turbo ? o_pdsch_decode_tb_second : o_pdsch_decode_tb)(llr, g->tb[i].nof_bits, g->tb[i].tbs, g->tb[i].mod, g->tx_scheme == O_TX_DIVERSITY ? 2 : 1,
                                  g->tb[i].rv, w->cfg.max_turbo_iter, w->payload + i * 8192 * 2, &its);
       w->total_iters += (uint64_t)its;
       w->algo_bytes += 2ull * (uint64_t)g->tb[i].nof_bits * 2ull + (uint64_t)g->tb[i].tbs / 8ull;

@@ -1,0 +1,107 @@
+"""spec/lte_tables.h is shared by the oracle, the product and the synthetic transmitter, so an error in it would be common-mode and
+invisible to every GPU-vs-oracle comparison.  These checks pin it INDEPENDENTLY of all three:
+  * structure the 3GPP tables have by construction: every TBS (36.213 Table 7.1.7.2.1-1) is byte aligned, belongs to the closed value set,
+    needs NO filler bits in code-block segmentation (36.212 5.1.2: the table was built from the interleaver sizes), rows and columns are
+    monotone except the one famous entry (I_TBS 6, 1 PRB = 328);
+  * the QPP interleaver parameters (36.212 Table 5.1.3-3): f1 coprime to K, every prime factor of K divides f2, (4 | K => 4 | f2 is NOT
+    required), and f1*i + f2*i^2 is a permutation for all 188 sizes;
+  * literal data the REFERENCE carries in-tree: row 32A (/root/reference/lib/src/phy/falcon_phch/ul_sniffer_pusch.c:7-17) lies between the
+    derived rows 32 and 33 for every PRB count, the format-1C table (dl_sniffer_pdsch.c:8-10) is a subset of the value set, valid_prb_ul
+    (UL_Sniffer_PUSCH.cc:3-10) is the 2^a 3^b 5^c set;
+  * data the reference DECODED: every C-RNTI PDU length in its three example captures is a table value (tests/golden/pcap_records.json)."""
+import json
+import math
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = open(os.path.join(ROOT, "spec", "lte_tables.h")).read()
+
+
+def _arr(name):
+    m = re.search(name + r"\[[^\]]*\](?:\[[^\]]*\])?\s*=\s*\{(.*?)\};", SRC, re.S)
+    assert m, name
+    return m.group(1)
+
+
+def _rows(name):
+    return [[int(x) for x in r.split(",")] for r in re.findall(r"\{([^{}]*)\}", _arr(name))]
+
+
+TBS = _rows("lsn_tbs_table")
+QPP = [tuple(r) for r in _rows("lsn_qpp_table")]
+KS = sorted(k for k, _, _ in QPP)
+ALLOWED = sorted(int(x) for x in _arr("lsn_tbs_allowed").split(","))
+ROW32A = [int(x) for x in _arr("lsn_tbs_table_32A").split(",")]
+F1C = [int(x) for x in _arr("lsn_tbs_format1c_table").split(",")]
+
+
+def _filler(tbs):
+    """36.212 5.1.2 written out here: number of filler bits of a transport block of `tbs` bits"""
+    B = tbs + 24
+    if B <= 6144:
+        return min(k for k in KS if k >= B) - B
+    C = -(-B // (6144 - 24))
+    Bp = B + 24 * C
+    Kp = min(k for k in KS if C * k >= Bp)
+    Km = max(k for k in KS if k < Kp)
+    Cm = (C * Kp - Bp) // (Kp - Km)
+    return (C - Cm) * Kp + Cm * Km - Bp
+
+
+def test_tbs_table_structure():
+    assert len(TBS) == 34 and all(len(r) == 110 for r in TBS)
+    assert ALLOWED == sorted(set(ALLOWED)) and all(v % 8 == 0 for v in ALLOWED)
+    allowed = set(ALLOWED)
+    for i, r in enumerate(TBS):
+        for n, v in enumerate(r, 1):
+            assert v in allowed, (i, n, v)
+            assert _filler(v) == 0, (i, n, v, _filler(v))
+    assert all(_filler(v) == 0 for v in ALLOWED)
+    assert TBS[6][0] == 328 and TBS[0][0] == 16 and TBS[26][109] == 75376 and TBS[26][99] == 75376 and TBS[25][99] == 63776 and TBS[9][99] == 15840
+    for i, r in enumerate(TBS):
+        for n in range(109):
+            assert r[n + 1] >= r[n] or (i, n + 1) == (6, 1), (i, n + 1)
+    for n in range(110):
+        for i in range(33):
+            assert TBS[i + 1][n] >= TBS[i][n] or (i, n + 1) == (6, 1), (i, n + 1)
+
+
+def test_rows_the_reference_carries_literally():
+    # 36.213 row 32A (256QAM, the reference's only in-tree TBS row) sits between rows 32 and 33 of the restated table for every PRB count
+    assert len(ROW32A) == 110 and all(v in set(ALLOWED) for v in ROW32A)
+    for n in range(110):
+        assert TBS[31][n] <= ROW32A[n] <= TBS[33][n], (n + 1, TBS[31][n], ROW32A[n], TBS[33][n])
+    assert TBS[33][99] == 97896 and ROW32A[99] in (93800, 97896)
+    assert len(F1C) == 32 and F1C == sorted(F1C) and all(v in set(ALLOWED) for v in F1C) and F1C[0] == 40 and F1C[-1] == 1736
+
+
+def test_qpp_parameters():
+    assert len(QPP) == 188 and KS[0] == 40 and KS[-1] == 6144
+    assert all(b - a == (8 if a < 512 else 16 if a < 1024 else 32 if a < 2048 else 64) for a, b in zip(KS, KS[1:]))
+    for K, f1, f2 in QPP:
+        assert math.gcd(f1, K) == 1, K
+        k, p = K, 2
+        while k > 1:  # every prime factor of K divides f2 (36.212 5.1.3.2.3: necessary and sufficient with gcd(f1, K) = 1 for these K)
+            if k % p == 0:
+                assert f2 % p == 0, (K, p)
+                while k % p == 0:
+                    k //= p
+            p += 1
+        if K in (40, 1008, 3136, 6144):
+            assert len({(f1 * i + f2 * i * i) % K for i in range(K)}) == K
+
+
+def test_lengths_the_reference_decoded_are_table_values():
+    """pdu_lengths of the fixture: {"direction/rnti_type": [distinct PDU lengths in bytes]} extracted from the reference's example captures"""
+    recs = json.load(open(os.path.join(ROOT, "tests", "golden", "pcap_records.json")))
+    dl = {v for r in TBS for v in r}
+    n = 0
+    for cap in recs.values():
+        for key, lens in cap["pdu_lengths"].items():
+            if key.split("/")[1] != "3":  # C-RNTI records only: SI / paging / RAR sizes come from format 1A / 1C rules
+                continue
+            for ln in lens:
+                assert ln * 8 in dl, (key, ln)
+                n += 1
+    assert n > 40
