@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1600, help="subframes of the capture decoded by the CPU oracle from cold state (rank 0): parity gate + cpu_baseline")
     ap.add_argument("--no-cpu", action="store_true", help="skip the oracle leg (parity gate part 1 and cpu_baseline)")
     ap.add_argument("--no-check", action="store_true", help="skip the synchronous second pass (parity gate part 2)")
+    ap.add_argument("--no-legs", action="store_true", help="skip the PCIe-inclusive legs (host buffers, capture file)")
+    ap.add_argument("--leg-nsf", type=int, default=12800, help="subframes of the capture file / host buffer of the PCIe-inclusive legs")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -118,6 +120,23 @@ def main():
         raise SystemExit("bench.py needs a HIP device (the library has no CPU path)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+
+    # host threads and host buffers next to the GPU: pinned staging, the page-cache pages of the capture file and the caller's own arrays are
+    # first touched by this process, and a far-socket source halves the PCIe rate (the engine pins its own threads the same way)
+    try:
+        pr = torch.cuda.get_device_properties(local)
+        bus = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        node = int(open("/sys/bus/pci/devices/%s/numa_node" % bus).read())
+        if node >= 0:
+            cpus = set()
+            for tok in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+                a, _, b = tok.partition("-")
+                cpus.update(range(int(a), int(b or a) + 1))
+            cpus &= os.sched_getaffinity(0)
+            if cpus:
+                os.sched_setaffinity(0, cpus)
+    except Exception:
+        pass
 
     import ltesniffer_amd as la
     from lsn_testlib import scenario
@@ -248,6 +267,46 @@ def main():
             if diff_oracle is not None and same is not None:
                 pcap_diff = diff_oracle + (0 if same else max(1, abs(cw.nof_records() - timed_records)))
 
+    # ---------------------------------------------------------------- PCIe-inclusive legs ("first H2D -> last PDU on host")
+    # Never `value`: the same capture (a) handed over as host buffers (lsn_phy_process_host: PCIe copies overlapped with the pipeline) and
+    # (b) replayed from a cf32 file in the page cache (lsn_phy_process_file, the reference's file mode, LTESniffer_Core.cc:240-262,365).
+    legs = None
+    if rank == 0 and world == 1 and not args.no_legs:
+        legs = {}
+        try:
+            ln = max(nsf, (args.leg_nsf // nsf) * nsf)
+            sf_bytes = iq[0].nbytes
+            host = torch.from_numpy(np.tile(iq, (ln // gen, 1, 1))).pin_memory()
+            lp = la.PcapWriter(None)
+            lp.set_store(False)
+            lphy = la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=batch, device=local, pcapwriter=lp)
+            lphy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"])
+            for name, arr in (("host_pinned", host.numpy()), ("host_pageable", np.array(host.numpy()[:nsf]))):
+                lphy.process_host(arr, tti0 % 10240, 500)  # warm state / first-touch
+                t = time.perf_counter()
+                lphy.process_host(arr, tti0 % 10240, 500)
+                dtl = time.perf_counter() - t
+                legs[name] = {"subframes_per_s": round(arr.shape[0] / dtl, 1), "GB_per_s_over_pcie": round(arr.shape[0] * sf_bytes / dtl / 1e9, 2),
+                              "subframes": int(arr.shape[0]), "pcie_gen5_x16_GB_per_s": 63.0}
+            path = "/dev/shm/lsn_bench_capture_%d.cf32" % os.getpid()
+            block = np.ascontiguousarray(np.transpose(iq, (0, 2, 1)))  # file mode: antennas interleaved per sample
+            with open(path, "wb") as f:
+                for _ in range(ln // gen):
+                    block.tofile(f)
+            try:
+                lphy.process_file(path, start_tti=tti0 % 10240, update_meta_period=500)  # warm page cache + state
+                t = time.perf_counter()
+                done = lphy.process_file(path, start_tti=tti0 % 10240, update_meta_period=500)
+                dtl = time.perf_counter() - t
+                legs["file_replay"] = {"subframes_per_s": round(done / dtl, 1), "GB_per_s_from_file": round(done * sf_bytes / dtl / 1e9, 2), "subframes": int(done),
+                                       "x_realtime": round(done / dtl / 1000.0, 1), "storage": "tmpfs (/dev/shm) = page cache; pread threads -> pinned blocks -> PCIe"}
+            finally:
+                os.remove(path)
+            lphy.close()
+            del host
+        except Exception as ex:
+            legs["error"] = str(ex)[:300]
+
     if rank == 0:
         kms = np.array(p.kernel_ms[:])
         klaunch = np.array(p.kernel_launches[:])
@@ -304,7 +363,7 @@ def main():
                          "avg_launch_ms": round(kms[kt] / max(1, klaunch[kt]), 4), "launches": int(klaunch[kt]),
                          "algo_bytes_per_launch": int(kbytes / max(1, klaunch[kt])),
                          "dominant_by_time": la.KERNELS[dom], "valu": valu},
-            "cpu_baseline": cpu, "host": {"cpu_count": os.cpu_count(), "cores_busy_in_timed_region": round(host_cores_busy, 2),
+            "legs": legs, "cpu_baseline": cpu, "host": {"cpu_count": os.cpu_count(), "cores_busy_in_timed_region": round(host_cores_busy, 2),
                                              "busiest_threads": busiest},
             "detail": {"pdus_per_subframe": round(p.nof_pdus / sf_rank, 3), "algo_bytes_per_subframe": int(p.algo_bytes / sf_rank),
                        "whole_path_GBps": round(p.algo_bytes * world / 1e9 / dt, 2), "timed_region_s": round(dt, 3),

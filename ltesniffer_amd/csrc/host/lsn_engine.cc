@@ -192,6 +192,8 @@ Engine::~Engine()
   for (auto& sa : stream_a)
     if (sa) (void)hipStreamDestroy(sa);
   if (ev_in) (void)hipEventDestroy(ev_in);
+  if (copy_stream) (void)hipStreamDestroy(copy_stream);
+  for (auto& e : copy_done) if (e) (void)hipEventDestroy(e);
 }
 
 int Engine::setCell(const lsn_cell_t& c)
@@ -1243,27 +1245,46 @@ int Engine::wait()
   }
 }
 
+// Host buffers (the worker pool's pinned staging, or any caller memory): blocks travel over PCIe into a ring of device staging buffers on a
+// copy stream of their own while the pipeline works on the blocks before them (submit() only queues).  Caller memory that is not pinned
+// yet is registered for the duration of the call so that the copies are real DMA transfers; if the registration is refused the copies
+// fall back to the runtime's bounce buffers (still overlapped with the compute of earlier blocks).
 int Engine::processHost(const float* iq, uint32_t nsf_total, uint32_t start_tti, uint32_t update_meta_period)
 {
   if (!cell_set) return LSN_ERROR;
+  if (!iq && nsf_total) return LSN_ERROR_INVALID_INPUTS;
+  bool registered = false;
   try {
     HIP_CHECK(hipSetDevice(cfg.device));
     const size_t sf_stride = (size_t)cfg.nof_rx_antennas * cd.sflen * sizeof(cf32);
-    lsn_perf_t acc{};
-    for (uint32_t base = 0; base < nsf_total; base += (uint32_t)staging_sf) {
-      const uint32_t nsf = std::min((uint32_t)staging_sf, nsf_total - base);
-      HIP_CHECK(hipMemcpy(d_iq_staging, (const uint8_t*)iq + (size_t)base * sf_stride, (size_t)nsf * sf_stride, hipMemcpyHostToDevice));
-      const int r = process(d_iq_staging, nsf, start_tti + base, update_meta_period, nullptr);
-      if (r != LSN_SUCCESS) return r;
-      const lsn_perf_t p = perf;
-      perf = acc;
-      mergePerf(p);
-      perf.ms_total += p.ms_total;
-      acc = perf;
+    const uint32_t nring = 3;
+    const uint32_t blk = (uint32_t)std::max<size_t>(1, staging_sf / nring);  // subframes per staging block
+    if (!copy_stream) {
+      HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+      for (auto& e : copy_done) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
-    perf = acc;
-    return LSN_SUCCESS;
+    hipPointerAttribute_t attr{};
+    const bool pinned = hipPointerGetAttributes(&attr, iq) == hipSuccess && attr.type == hipMemoryTypeHost;
+    if (!pinned && (size_t)nsf_total * sf_stride >= ((size_t)8 << 20))
+      registered = hipHostRegister((void*)iq, (size_t)nsf_total * sf_stride, hipHostRegisterDefault) == hipSuccess;
+    (void)hipGetLastError();
+    uint64_t marks[3] = {0, 0, 0};
+    uint32_t k = 0;
+    int rc = LSN_SUCCESS;
+    for (uint32_t base = 0; base < nsf_total && rc == LSN_SUCCESS; base += blk, k++) {
+      const uint32_t nsf = std::min(blk, nsf_total - base), slot = k % nring;
+      if (k >= nring) waitMark(marks[slot]);  // the block that used this staging buffer three blocks ago has left the pipeline
+      uint8_t* dst = (uint8_t*)d_iq_staging + (size_t)slot * blk * sf_stride;
+      HIP_CHECK(hipMemcpyAsync(dst, (const uint8_t*)iq + (size_t)base * sf_stride, (size_t)nsf * sf_stride, hipMemcpyHostToDevice, copy_stream));
+      rc = submit(dst, nsf, start_tti + base, update_meta_period, copy_stream);  // stage A of the block waits for the copy on the device
+      marks[slot] = submitMark();
+    }
+    const int w = wait();
+    if (registered) (void)hipHostUnregister((void*)iq);
+    return rc != LSN_SUCCESS ? rc : w;
   } catch (const std::exception& ex) {
+    if (registered) (void)hipHostUnregister((void*)iq);
+    (void)wait();
     fprintf(stderr, "ltesniffer_amd: %s\n", ex.what());
     return LSN_ERROR;
   }

@@ -195,6 +195,8 @@ private:
   std::vector<void*> dev_allocs, host_allocs;
   uint32_t* d_dphi = nullptr;
   void* d_iq_staging = nullptr;
+  hipStream_t copy_stream = nullptr;          // host -> staging copies of processHost
+  hipEvent_t copy_done[3] = {};
   size_t staging_sf = 0;
   Chunk chunks[NSLOTS];
   JobRunner runner_c[NDEC], runner_s, runner_f, runner_k;  // decode threads / search thread (on-demand RAR decodes) / front thread (speculative RAR decodes) / commit thread (on-demand decodes)

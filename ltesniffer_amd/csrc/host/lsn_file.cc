@@ -7,6 +7,7 @@
 // processes the previous block, so the file / PCIe leg overlaps the compute.
 // Product code: no CPU fallback, nothing from oracle/ is included or linked.
 #include "lsn_engine.h"
+#include <deque>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -35,12 +36,13 @@ int Engine::processFile(const char* path, const lsn_file_cfg_t& fc, uint32_t sta
   if (fstat(fd, &sb)) { close(fd); return LSN_ERROR_INVALID_INPUTS; }
   const uint32_t nant = fc.nof_antennas, sflen = cd.sflen;
   const size_t sf_bytes = (size_t)sflen * nant * sizeof(cf32);
-  uint32_t blk = 800, nrd = 6;
+  uint32_t blk = 1600, nrd = 12;  // subframes per block (786 MB at 20 MHz / 2 antennas), pread threads per block
   if (const char* e = getenv("LSN_FILE_BLOCK")) blk = (uint32_t)std::max(1, atoi(e));
   if (const char* e = getenv("LSN_FILE_READERS")) nrd = (uint32_t)std::max(1, std::min(32, atoi(e)));
   const uint64_t file_off0 = (uint64_t)fc.offset_time_samples * nant * sizeof(cf32);
   const uint64_t sf_in_file = (uint64_t)sb.st_size > file_off0 ? ((uint64_t)sb.st_size - file_off0) / sf_bytes : 0;  // complete subframes only
-  struct Slot { cf32* h_raw = nullptr; cf32* d_raw = nullptr; cf32* d_iq = nullptr; uint32_t nsf = 0; int state = 0; /* 0 free, 1 ready, 2 eof */ uint64_t mark = 0; } slot[3];
+  constexpr int NSLOT = 5;  // blocks in flight: one being read, one crossing PCIe, the others inside the decode pipeline
+  struct Slot { cf32* h_raw = nullptr; cf32* d_raw = nullptr; cf32* d_iq = nullptr; uint32_t nsf = 0; int state = 0; /* 0 free, 1 ready, 2 eof */ uint64_t mark = 0; } slot[NSLOT];
   cf32* d_rot = nullptr;
   hipStream_t st = nullptr;
   std::mutex fm;
@@ -88,7 +90,7 @@ int Engine::processFile(const char* path, const lsn_file_cfg_t& fc, uint32_t sta
         (void)hipSetDevice(cfg.device);
         pinThisThread(nullptr);
         uint64_t avail = sf_in_file - first_sf, left = max_subframes ? std::min<uint64_t>(max_subframes, avail) : avail, pos = first_sf;
-        for (int i = 0;; i = (i + 1) % 3) {
+        for (int i = 0;; i = (i + 1) % NSLOT) {
           Slot& s = slot[i];
           {
             std::unique_lock<std::mutex> lk(fm);
@@ -116,9 +118,10 @@ int Engine::processFile(const char* path, const lsn_file_cfg_t& fc, uint32_t sta
             for (auto& t : rd) t.join();
             for (int b : bad) if (b) throw std::runtime_error("read failed");
             pos += got;
+            // the copy and the de-interleave are only QUEUED here (stream st); the submit below is ordered behind them on the device, so
+            // the reader goes straight on to the next block while this one crosses PCIe
             HIP_CHECK(hipMemcpyAsync(s.d_raw, s.h_raw, got * sf_bytes, hipMemcpyHostToDevice, st));
             lsn_launch_file_unpack(s.d_raw, d_rot, sflen, nant, s.d_iq, (uint32_t)got, st);
-            HIP_CHECK(hipStreamSynchronize(st));
           }
           left -= got;
           {
@@ -138,23 +141,25 @@ int Engine::processFile(const char* path, const lsn_file_cfg_t& fc, uint32_t sta
     });
     // block i is submitted (searched, queued for decoding) while block i-1 drains; its slot goes back to the reader once every chunk
     // of it has been committed
-    int prev = -1;
-    for (int i = 0;; i = (i + 1) % 3) {
+    std::deque<int> inflight;  // submitted blocks whose slot the reader may not touch yet (pinned source + device buffers still in use)
+    for (int i = 0;; i = (i + 1) % NSLOT) {
       Slot& s = slot[i];
       {
         std::unique_lock<std::mutex> lk(fm);
         fcv.wait(lk, [&] { return s.state != 0; });
         if (s.state == 2) break;
       }
-      rc = submit(s.d_iq, s.nsf, (uint32_t)((start_tti + done) % 10240u), update_meta_period, nullptr);
+      rc = submit(s.d_iq, s.nsf, (uint32_t)((start_tti + done) % 10240u), update_meta_period, st);
       s.mark = submitMark();
       done += s.nsf;
-      if (prev >= 0) {
-        waitMark(slot[prev].mark);
-        { std::unique_lock<std::mutex> lk(fm); slot[prev].state = 0; }
+      inflight.push_back(i);
+      while ((int)inflight.size() > NSLOT - 2) {  // keep two slots for the reader, hand the oldest one back once its chunks are written
+        const int o = inflight.front();
+        inflight.pop_front();
+        waitMark(slot[o].mark);
+        { std::unique_lock<std::mutex> lk(fm); slot[o].state = 0; }
         fcv.notify_all();
       }
-      prev = i;
       if (rc != LSN_SUCCESS) break;
     }
     {

@@ -328,7 +328,7 @@ void Engine::buildTables()
   allocRunner(runner_s);
   allocRunner(runner_f);
   allocRunner(runner_k);
-  staging_sf = (size_t)max_batch * nslots;
+  staging_sf = (size_t)max_batch * 12;  // three staging blocks of four chunks each (processHost)
   d_iq_staging = dalloc<cf32>(dev_allocs, staging_sf * cfg.nof_rx_antennas * cd.sflen);
 }
 
