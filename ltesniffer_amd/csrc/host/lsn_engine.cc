@@ -34,6 +34,8 @@ namespace lsn {
 // threads' timer slack set to 1 us so the naps are that short.  LSN_SPIN_WAIT=1 spins.
 static const bool g_spin_wait = getenv("LSN_SPIN_WAIT") && atoi(getenv("LSN_SPIN_WAIT"));
 // LSN_TURBO_FORK=1: k_turbo<64> on a second stream per runner next to k_turbo<128> (more HSA queues: measured slower beyond 6 decode threads)
+// LSN_NO_CB_SKIP=1: decode every code block even when the first block of its transport block has already failed (iteration counts then equal the oracle's)
+static const bool g_cb_skip = !(getenv("LSN_NO_CB_SKIP") && atoi(getenv("LSN_NO_CB_SKIP")));
 static const bool g_turbo_fork = getenv("LSN_TURBO_FORK") && atoi(getenv("LSN_TURBO_FORK"));
 static void waitEvent(hipEvent_t ev, long nap_ns = 50000)
 {
@@ -456,7 +458,7 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
   hipStream_t st = r.stream;
   lsn_perf_t& pf = r.perf;
   const uint32_t nprb = cell.nof_prb;
-  r.h_jobs.clear(); r.h_cbs.clear();
+  r.h_jobs.clear(); r.h_cbs.clear(); r.h_items.clear();
   size_t llr_n = 0, prefix_n = 0;
   const size_t pay0 = ch.h_payload.size();
   size_t pay_n = pay0;
@@ -518,6 +520,8 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
         cb.out_off = (uint32_t)(pay_n - pay0) + wp;
         qpp_params(K, cb.f1, cb.f2);
         cb.max_iter = (uint32_t)cfg.max_turbo_iterations;
+        // code blocks 1 .. C-1 are launched behind block 0 and skipped when it failed (the TB CRC verdict needs every block)
+        cb.dep = (q > 0 && g_cb_skip) ? (uint32_t)(r.h_cbs.size() - (size_t)q) : LSN_CB_NODEP;
         wp += cb.out_bytes;
         rp += E;
         r.h_cbs.push_back(cb);
@@ -529,10 +533,12 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
       pf.nof_cb_decodes += (uint64_t)s.C;
       pf.algo_bytes += 2ull * (uint64_t)tb.nof_bits * 2ull + (uint64_t)tb.tbs / 8ull;
     }
+    if (g.prb_lo <= g.prb_hi)
+      for (uint32_t grp = g.prb_lo / 16; grp <= std::min<uint32_t>(g.prb_hi, nprb - 1) / 16; grp++) r.h_items.push_back(((uint32_t)r.h_jobs.size() << 8) | grp);
     r.h_jobs.push_back(d);
   }
   const uint32_t njobs = (uint32_t)r.h_jobs.size(), ncb = (uint32_t)r.h_cbs.size();
-  uint32_t n128 = 0, kmax128 = 0, kmax64 = 0, emax = 0;
+  uint32_t n128 = 0, kmax128 = 0, kmax64 = 0, emax = 0, n128p[2] = {0, 0}, n64p[2] = {0, 0};
   size_t spp_n = 0;
   std::vector<uint32_t> order;
   if (njobs) {
@@ -546,13 +552,21 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
     grow_host(r.h_payload_pinned, r.h_payload_cap, pay_n - pay0 + 16, st);
     grow_host(r.h_jobs_pinned, r.h_jobs_cap, njobs, st);
     grow_host(r.h_cbs_pinned, r.h_cbs_cap, ncb, st);
+    const uint32_t nitems = (uint32_t)r.h_items.size();
+    grow_dev(r.d_items, r.items_cap, nitems + 1, st);
+    grow_host(r.h_items_pinned, r.h_items_cap, nitems + 1, st);
+    std::memcpy(r.h_items_pinned, r.h_items.data(), nitems * sizeof(uint32_t));
+    HIP_CHECK(hipMemcpyAsync(r.d_items, r.h_items_pinned, nitems * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     std::memcpy(r.h_jobs_pinned, r.h_jobs.data(), njobs * sizeof(LsnGrantDev));
     HIP_CHECK(hipMemcpyAsync(r.d_jobs, r.h_jobs_pinned, njobs * sizeof(LsnGrantDev), hipMemcpyHostToDevice, st));
     if (ncb) {
       // launch order: two-wavefront blocks first, each class by descending size (longest jobs first)
       order.resize(ncb);
       for (uint32_t i = 0; i < ncb; i++) { r.h_cbs[i].res_idx = i; order[i] = i; }
+      // two phases: first every block that nothing depends on having passed (block 0 of each transport block), then the dependants
       std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
+        const bool dx = r.h_cbs[x].dep != LSN_CB_NODEP, dy = r.h_cbs[y].dep != LSN_CB_NODEP;
+        if (dx != dy) return dy;
         const uint32_t kx = r.h_cbs[x].K, ky = r.h_cbs[y].K;
         const bool bx = lsn_turbo_nwin((int)kx) > 64, by = lsn_turbo_nwin((int)ky) > 64;
         if (bx != by) return bx;
@@ -564,8 +578,10 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
         q.spp_off = (uint32_t)spp_n; spp_n += LSN_SPP_WORDS(q.K);
         emax = std::max(emax, q.E);
         r.h_cbs_pinned[i] = q;
-        if (lsn_turbo_nwin((int)q.K) > 64) { n128++; kmax128 = std::max(kmax128, q.K); } else kmax64 = std::max(kmax64, q.K);
+        const int ph = q.dep != LSN_CB_NODEP ? 1 : 0;
+        if (lsn_turbo_nwin((int)q.K) > 64) { n128p[ph]++; kmax128 = std::max(kmax128, q.K); } else { n64p[ph]++; kmax64 = std::max(kmax64, q.K); }
       }
+      n128 = n128p[0] + n128p[1];
       grow_dev(r.d_spp, r.spp_cap, spp_n + 16, st);
       HIP_CHECK(hipMemcpyAsync(r.d_cbs, r.h_cbs_pinned, ncb * sizeof(LsnCbDev), hipMemcpyHostToDevice, st));
     }
@@ -573,25 +589,19 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
     HIP_CHECK(hipEventRecord(r.ev[0], st));
     lsn_launch_pdsch_prep(cd, r.d_jobs, r.d_prefix, njobs, st);
     HIP_CHECK(hipEventRecord(r.ev[1], st));
-    lsn_launch_pdsch_demod(cd, r.d_jobs, r.d_prefix, ch.d_grid, ch.d_ce, ch.d_chest, r.d_llr16, njobs, st);
+    lsn_launch_pdsch_demod(cd, r.d_jobs, r.d_items, nitems, r.d_prefix, ch.d_grid, ch.d_ce, ch.d_chest, r.d_llr16, st);
     HIP_CHECK(hipEventRecord(r.ev[2], st));
     if (ncb) {
       lsn_launch_rm(r.d_cbs, r.d_llr16, r.d_spp, ncb, emax, st);
       HIP_CHECK(hipEventRecord(r.ev[5], st));
-      // the two decoder variants run side by side (one stream each): neither waits for the other's slowest code block
-      const bool fork = g_turbo_fork && n128 && ncb > n128 && r.stream2;
-      if (fork) {
-        HIP_CHECK(hipEventRecord(r.ev_fork, st));
-        HIP_CHECK(hipStreamWaitEvent(r.stream2, r.ev_fork, 0));
-        HIP_CHECK(hipEventRecord(r.ev[6], r.stream2));
-        lsn_launch_turbo(cd, r.d_cbs + n128, r.d_spp, r.d_payload, r.d_cbres, 0, 0, ncb - n128, kmax64, r.stream2, nullptr);
-        HIP_CHECK(hipEventRecord(r.ev[7], r.stream2));
-        HIP_CHECK(hipEventRecord(r.ev_join, r.stream2));
-        lsn_launch_turbo(cd, r.d_cbs, r.d_spp, r.d_payload, r.d_cbres, n128, kmax128, 0, 0, st, nullptr);
-        HIP_CHECK(hipEventRecord(r.ev[4], st));
-        HIP_CHECK(hipStreamWaitEvent(st, r.ev_join, 0));
-      } else {
-        lsn_launch_turbo(cd, r.d_cbs, r.d_spp, r.d_payload, r.d_cbres, n128, kmax128, ncb - n128, kmax64, st, r.ev[4]);
+      {
+        // phase 0: [128-class | 64-class] of the independent blocks, phase 1: the same of the dependants (descriptor order = launch order)
+        lsn_launch_turbo(cd, r.d_cbs, r.d_spp, r.d_payload, r.d_cbres, n128p[0], kmax128, n64p[0], kmax64, st, r.ev[4]);
+        const uint32_t o1 = n128p[0] + n64p[0];
+        if (ncb > o1) {
+          HIP_CHECK(hipEventRecord(r.ev[8], st));
+          lsn_launch_turbo(cd, r.d_cbs + o1, r.d_spp, r.d_payload, r.d_cbres, n128p[1], kmax128, n64p[1], kmax64, st, r.ev[9]);
+        }
       }
       HIP_CHECK(hipEventRecord(r.ev[3], st));
       HIP_CHECK(hipMemcpyAsync(r.h_cbres_pinned, r.d_cbres, ncb * sizeof(LsnCbRes), hipMemcpyDeviceToHost, st));
@@ -605,14 +615,19 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
     pf.kernel_launches[LSN_K_PDSCH_PREP]++; pf.kernel_launches[LSN_K_PDSCH_DEMOD]++;
     if (ncb) {
       if (hipEventElapsedTime(&ms, r.ev[2], r.ev[5]) == hipSuccess) { pf.kernel_ms[LSN_K_RM] += ms; pf.kernel_launches[LSN_K_RM]++; }
-      if (n128 && hipEventElapsedTime(&ms, r.ev[5], r.ev[4]) == hipSuccess) { pf.kernel_ms[LSN_K_TURBO128] += ms; pf.kernel_launches[LSN_K_TURBO128]++; }
-      const bool forked = g_turbo_fork && n128 && ncb > n128 && r.stream2;
-      if (ncb > n128 && hipEventElapsedTime(&ms, forked ? r.ev[6] : r.ev[4], forked ? r.ev[7] : r.ev[3]) == hipSuccess) { pf.kernel_ms[LSN_K_TURBO] += ms; pf.kernel_launches[LSN_K_TURBO]++; }
+      {
+        const bool ph1 = ncb > n128p[0] + n64p[0];
+        auto acc = [&](int k, hipEvent_t a, hipEvent_t b) { if (hipEventElapsedTime(&ms, a, b) == hipSuccess) { pf.kernel_ms[k] += ms; pf.kernel_launches[k]++; } };
+        if (n128p[0]) acc(LSN_K_TURBO128, r.ev[5], r.ev[4]);
+        if (n64p[0]) acc(LSN_K_TURBO, r.ev[4], ph1 ? r.ev[8] : r.ev[3]);
+        if (ph1 && n128p[1]) acc(LSN_K_TURBO128, r.ev[8], r.ev[9]);
+        if (ph1 && n64p[1]) acc(LSN_K_TURBO, r.ev[9], r.ev[3]);
+      }
       // algorithmic bytes of the decoder kernels: every code block reads its K + 12 packed soft words (k_rm's output) and writes its payload
       for (uint32_t i = 0; i < ncb; i++) {
         const uint64_t b = 4ull * (r.h_cbs_pinned[i].K + 12u) + r.h_cbs_pinned[i].out_bytes;
         pf.turbo_algo_bytes += b;
-        if (i < n128) pf.turbo128_algo_bytes += b;
+        if (lsn_turbo_nwin((int)r.h_cbs_pinned[i].K) > 64) pf.turbo128_algo_bytes += b;
       }
     }
     ch.h_payload.resize(pay_n);

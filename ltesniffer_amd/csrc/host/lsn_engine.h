@@ -84,13 +84,14 @@ struct Chunk {
 // one stream + its device/host arenas for PDSCH decode launches
 struct JobRunner {
   hipStream_t stream = nullptr;
-  hipStream_t stream2 = nullptr;     // k_turbo<64> runs here, next to k_turbo<128> on `stream` (fork / join by events)
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   LsnGrantDev* d_jobs = nullptr; size_t jobs_cap = 0;
   LsnCbDev* d_cbs = nullptr; size_t cbs_cap = 0;
   LsnCbRes* d_cbres = nullptr; size_t cbres_cap = 0;
   uint16_t* d_prefix = nullptr; size_t prefix_cap = 0;
   int16_t* d_llr16 = nullptr; size_t llr16_cap = 0;
+  uint32_t* d_items = nullptr; size_t items_cap = 0;   // demodulator work items: job << 8 | group of 16 PRBs
+  uint32_t* h_items_pinned = nullptr; size_t h_items_cap = 0;
+  std::vector<uint32_t> h_items;
   uint32_t* d_spp = nullptr; size_t spp_cap = 0;   // de-rate-matched soft data of every code block of the launch (k_rm -> k_turbo)
   uint8_t* d_payload = nullptr; size_t payload_cap = 0;
   uint8_t* h_payload_pinned = nullptr; size_t h_payload_cap = 0;

@@ -82,16 +82,13 @@ void Engine::freeRunner(JobRunner& r)
 {
   auto df = [](auto*& p) { if (p) (void)hipFree(p); p = nullptr; };
   auto hf = [](auto*& p) { if (p) (void)hipHostFree(p); p = nullptr; };
-  df(r.d_jobs); df(r.d_cbs); df(r.d_cbres); df(r.d_prefix); df(r.d_llr16); df(r.d_payload); df(r.d_spp);
-  hf(r.h_payload_pinned); hf(r.h_cbres_pinned); hf(r.h_jobs_pinned); hf(r.h_cbs_pinned);
-  r.spp_cap = r.jobs_cap = r.cbs_cap = r.cbres_cap = r.prefix_cap = r.llr16_cap = r.payload_cap = r.h_payload_cap = r.h_cbres_cap = r.h_jobs_cap = r.h_cbs_cap = 0;
+  df(r.d_jobs); df(r.d_cbs); df(r.d_cbres); df(r.d_prefix); df(r.d_llr16); df(r.d_payload); df(r.d_spp); df(r.d_items);
+  hf(r.h_items_pinned); hf(r.h_payload_pinned); hf(r.h_cbres_pinned); hf(r.h_jobs_pinned); hf(r.h_cbs_pinned);
+  r.items_cap = r.h_items_cap = r.spp_cap = r.jobs_cap = r.cbs_cap = r.cbres_cap = r.prefix_cap = r.llr16_cap = r.payload_cap = r.h_payload_cap = r.h_cbres_cap = r.h_jobs_cap = r.h_cbs_cap = 0;
   for (auto& e : r.ev)
     if (e) { (void)hipEventDestroy(e); e = nullptr; }
   if (r.ev_done) { (void)hipEventDestroy(r.ev_done); r.ev_done = nullptr; }
-  if (r.ev_fork) { (void)hipEventDestroy(r.ev_fork); r.ev_fork = nullptr; }
-  if (r.ev_join) { (void)hipEventDestroy(r.ev_join); r.ev_join = nullptr; }
   if (r.stream) { (void)hipStreamDestroy(r.stream); r.stream = nullptr; }
-  if (r.stream2) { (void)hipStreamDestroy(r.stream2); r.stream2 = nullptr; }
 }
 
 void Engine::allocRunner(JobRunner& r)
@@ -99,10 +96,8 @@ void Engine::allocRunner(JobRunner& r)
   // the search thread's runner (on-demand RAR decodes) sits on the critical path of the sequential search: high priority
   int lo = 0, hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-  const bool fork2 = getenv("LSN_TURBO_FORK") && atoi(getenv("LSN_TURBO_FORK"));  // second stream per runner (every stream is an HSA queue)
   if (&r == &runner_s || &r == &runner_f || &r == &runner_u || &r == &runner_k) {
     HIP_CHECK(hipStreamCreateWithPriority(&r.stream, hipStreamNonBlocking, hi));
-    if (fork2) HIP_CHECK(hipStreamCreateWithPriority(&r.stream2, hipStreamNonBlocking, hi));
   } else {
     // bulk decode streams leave a few CUs alone, so that the latency-critical launches (stage A, on-demand RAR decodes)
     // never queue behind thousands of resident turbo workgroups
@@ -116,13 +111,8 @@ void Engine::allocRunner(JobRunner& r)
       if (!(reserve > 0 && i % (ncu / (reserve > 0 ? reserve : 1)) == 0)) mask[i / 32] |= 1u << (i % 32);
     if (reserve <= 0 || reserve >= ncu || hipExtStreamCreateWithCUMask(&r.stream, (uint32_t)mask.size(), mask.data()) != hipSuccess)
       HIP_CHECK(hipStreamCreateWithPriority(&r.stream, hipStreamNonBlocking, lo));
-    if (!fork2) {
-    } else if (reserve <= 0 || reserve >= ncu || hipExtStreamCreateWithCUMask(&r.stream2, (uint32_t)mask.size(), mask.data()) != hipSuccess)
-      HIP_CHECK(hipStreamCreateWithPriority(&r.stream2, hipStreamNonBlocking, lo));
   }
   for (auto& e : r.ev) HIP_CHECK(hipEventCreate(&e));
-  HIP_CHECK(hipEventCreateWithFlags(&r.ev_fork, hipEventDisableTiming));
-  HIP_CHECK(hipEventCreateWithFlags(&r.ev_join, hipEventDisableTiming));
   HIP_CHECK(hipEventCreateWithFlags(&r.ev_done, hipEventDisableTiming));  // waited for with Engine's poll-and-sleep waitEvent()
 }
 

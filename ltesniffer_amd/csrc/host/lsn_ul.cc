@@ -187,6 +187,7 @@ void Engine::puschDecodeGrid(const cf32* d_grid, uint32_t nsf, uint32_t start_tt
       cb.out_off = (uint32_t)pay_n + wp;
       qpp_params(K, cb.f1, cb.f2);
       cb.max_iter = (uint32_t)cfg.max_turbo_iterations;
+      cb.dep = LSN_CB_NODEP;  // every code block is decoded: the iteration count of a grant is part of what lsn_phy_pusch_decode reports
       wp += cb.out_bytes;
       rp += E;
       r.h_cbs.push_back(cb);

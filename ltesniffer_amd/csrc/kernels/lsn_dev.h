@@ -82,6 +82,8 @@ struct LsnCbDev {
   uint32_t f1, f2;
   uint32_t max_iter;
   uint32_t res_idx;   // slot of this block's LsnCbRes (launch order is sorted by size, results are not)
+  uint32_t dep;       // res_idx of the FIRST code block of the same transport block when this one may be skipped once that one has failed
+                      // (a transport block fails as soon as any of its code blocks fails); 0xFFFFFFFF: always decode
   uint32_t spp_off;   // u32 word offset (multiple of 4) of the block's de-rate-matched soft data: K packed words + 12 termination values (k_rm -> k_turbo)
 };
 #define LSN_SPP_WORDS(K) (((K) + 12u + 3u) & ~3u)
@@ -120,7 +122,9 @@ void lsn_launch_pusch_chest(const LsnCellDev& c, const LsnUlGrantDev* g, const c
 void lsn_launch_pusch_demod(const LsnCellDev& c, const LsnUlGrantDev* g, const cf32* grid, const cf32* hs, const float* stat, int16_t* llr,
                             uint32_t ngrants, hipStream_t s);
 void lsn_launch_pdsch_prep(const LsnCellDev& c, const LsnGrantDev* g, uint16_t* prefix, uint32_t njobs, hipStream_t s);
-void lsn_launch_pdsch_demod(const LsnCellDev& c, const LsnGrantDev* g, const uint16_t* prefix, const cf32* grid, const cf32* ce, const LsnChest* ch, int16_t* llr, uint32_t njobs, hipStream_t s);
+void lsn_launch_pdsch_demod(const LsnCellDev& c, const LsnGrantDev* g, const uint32_t* items, uint32_t nitems, const uint16_t* prefix, const cf32* grid, const cf32* ce,
+                            const LsnChest* ch, int16_t* llr, hipStream_t s);
 void lsn_launch_rm(const LsnCbDev* cb, const int16_t* llr, uint32_t* spp, uint32_t ncb, uint32_t emax, hipStream_t s);
+#define LSN_CB_NODEP 0xFFFFFFFFu
 void lsn_launch_turbo(const LsnCellDev& c, const LsnCbDev* cb, const uint32_t* spp, uint8_t* payload, LsnCbRes* res, uint32_t n128, uint32_t kmax128,
                       uint32_t n64, uint32_t kmax64, hipStream_t s, hipEvent_t between);

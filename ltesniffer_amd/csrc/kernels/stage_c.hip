@@ -103,13 +103,17 @@ __device__ __forceinline__ void emit(const LsnCellDev& c, int Qm, cf32 x, float 
   }
 }
 
-__global__ __launch_bounds__(192) void k_pdsch_demod(LsnCellDev c, const LsnGrantDev* __restrict__ jobs, const uint16_t* __restrict__ prefix,
+// grid = (work items, 14 symbols): an item is one group of 16 PRBs inside the PRB span of one job (items[i] = job << 8 | group), listed by the
+// host - a grid over all groups of all jobs would be mostly empty workgroups (a grant covers a few PRBs of the 100)
+__global__ __launch_bounds__(192) void k_pdsch_demod(LsnCellDev c, const LsnGrantDev* __restrict__ jobs, const uint32_t* __restrict__ items,
+                                                     const uint16_t* __restrict__ prefix,
                                                      const cf32* __restrict__ grid, const cf32* __restrict__ ce,
                                                      const LsnChest* __restrict__ chest, int16_t* __restrict__ llr)
 {
-  const LsnGrantDev& g = jobs[blockIdx.z];
+  const uint32_t item = items[blockIdx.x];
+  const LsnGrantDev& g = jobs[item >> 8];
   const int nprb = (int)c.nof_prb, nre = (int)c.nre, A = (int)c.nof_rx;
-  const int l = blockIdx.y, prb = blockIdx.x * 16 + (int)threadIdx.x / 12, kk = (int)threadIdx.x % 12;
+  const int l = blockIdx.y, prb = (int)(item & 255u) * 16 + (int)threadIdx.x / 12, kk = (int)threadIdx.x % 12;
   if (l < (int)g.l0 || prb >= nprb) return;
   if (!((g.prb_mask[l / 7][prb >> 5] >> (prb & 31)) & 1u)) return;
   const int cls = g.sf_idx == 0 ? 0 : (g.sf_idx == 5 ? 1 : 2);
@@ -219,10 +223,10 @@ __global__ __launch_bounds__(192) void k_pdsch_demod(LsnCellDev c, const LsnGran
 #undef GRID
 #undef CE
 }
-void lsn_launch_pdsch_demod(const LsnCellDev& c, const LsnGrantDev* g, const uint16_t* prefix, const cf32* grid, const cf32* ce,
-                            const LsnChest* ch, int16_t* llr, uint32_t njobs, hipStream_t s)
+void lsn_launch_pdsch_demod(const LsnCellDev& c, const LsnGrantDev* g, const uint32_t* items, uint32_t nitems, const uint16_t* prefix, const cf32* grid,
+                            const cf32* ce, const LsnChest* ch, int16_t* llr, hipStream_t s)
 {
-  hipLaunchKernelGGL(k_pdsch_demod, dim3((c.nof_prb + 15) / 16, 14, njobs), dim3(192), 0, s, c, g, prefix, grid, ce, ch, llr);
+  if (nitems) hipLaunchKernelGGL(k_pdsch_demod, dim3(nitems, 14), dim3(192), 0, s, c, g, items, prefix, grid, ce, ch, llr);
 }
 
 // ------------------------------------------------------------------------------------------------ rate de-matching
@@ -312,8 +316,13 @@ void lsn_launch_rm(const LsnCbDev* cb, const int16_t* llr, uint32_t* spp, uint32
 // The interleaver addresses of the backward phase are generated by stepping the QPP recursion in reverse.
 // Window-boundary metrics of the previous iteration (next-iteration initialisation) stay in registers and move
 // between lanes with shuffles.
+#ifndef TB_S
 #define TB_S 16      // sub-block length
-#define TB_CKPT_I16 (4 * 7 * 64)  // check-point store (int16): sub-blocks 1 .. nsb-2, [slot][state][thread];
+#endif
+// check-point store (int16): sub-blocks 1 .. nsb-2, [slot][state][thread]; 64 threads: W <= 96, 128 threads: W <= 64
+#define TB_CKPT_SLOTS(NT) ((((NT) == 64 ? 96 : 64) + TB_S - 1) / TB_S - 2)
+#define TB_CKPT_I16_NT(NT) ((TB_CKPT_SLOTS(NT) < 2 ? 2 : TB_CKPT_SLOTS(NT)) * 7 * (NT) < 1100 ? 1100 : (TB_CKPT_SLOTS(NT) < 2 ? 2 : TB_CKPT_SLOTS(NT)) * 7 * (NT))
+#define TB_CKPT_I16 (4 * 7 * 64)  // (legacy size: TB_S = 16)
                                  // 64 threads: W <= 96 -> 4 slots, 128 threads: W <= 64 -> 2 slots
 
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
@@ -551,14 +560,23 @@ __device__ __forceinline__ uint32_t wg_xor(uint32_t v, int16_t* scratch, int tid
   return v;
 }
 
+#ifndef TB_WAVES_ATTR
+#define TB_WAVES_ATTR
+#endif
 template <int NT>
-__global__ __launch_bounds__(NT) void k_turbo(const uint32_t* __restrict__ crc_tab_a, const uint32_t* __restrict__ crc_tab_b,
+__global__ __launch_bounds__(NT) TB_WAVES_ATTR void k_turbo(const uint32_t* __restrict__ crc_tab_a, const uint32_t* __restrict__ crc_tab_b,
                                               const LsnCbDev* __restrict__ cbs, const uint32_t* __restrict__ spp_g,
-                                              uint8_t* __restrict__ payload, LsnCbRes* __restrict__ res, uint32_t kmax)
+                                              uint8_t* __restrict__ payload, LsnCbRes* res, uint32_t kmax)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const long long tc0 = clock64();
   const LsnCbDev cb = cbs[blockIdx.x];
+  // The transport block of this code block is already lost when its first code block (decoded by an EARLIER launch on this stream)
+  // failed: nothing this block could decode would reach the record stream, so it is not decoded at all
+  if (cb.dep != LSN_CB_NODEP && res[cb.dep].ok == 0u) {
+    if (threadIdx.x == 0) { LsnCbRes r{}; res[cb.res_idx] = r; }
+    return;
+  }
   const int lane = threadIdx.x, K = (int)cb.K, F = (int)cb.F;
   const int P = lsn_turbo_nwin(K), W = K / P;
   const uint32_t magicW = ((1u << 20) + (uint32_t)W - 1u) / (uint32_t)W;
@@ -638,7 +656,8 @@ __global__ __launch_bounds__(NT) void k_turbo(const uint32_t* __restrict__ crc_t
   }
 }
 
-size_t lsn_turbo_lds_bytes(uint32_t kmax) { return 6 * (size_t)kmax + 16 + sizeof(int16_t) * TB_CKPT_I16; }
+size_t lsn_turbo_lds_bytes(uint32_t kmax) { return 6 * (size_t)kmax + 16 + sizeof(int16_t) * TB_CKPT_I16_NT(64); }
+static size_t turbo_lds_bytes_nt(uint32_t kmax, int nt) { return 6 * (size_t)kmax + 16 + sizeof(int16_t) * (size_t)(nt == 64 ? TB_CKPT_I16_NT(64) : TB_CKPT_I16_NT(128)); }
 
 // cb[0 .. n128) use two wavefronts per code block (P > 64), cb[n128 .. ncb) one; each range is launched with the LDS
 // size of its largest block (40 KiB at K = 6144 -> four code blocks per CU)
@@ -647,12 +666,12 @@ void lsn_launch_turbo(const LsnCellDev& c, const LsnCbDev* cb, const uint32_t* s
 {
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)k_turbo<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lsn_turbo_lds_bytes(6144));
-    (void)hipFuncSetAttribute((const void*)k_turbo<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lsn_turbo_lds_bytes(6144));
+    (void)hipFuncSetAttribute((const void*)k_turbo<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)turbo_lds_bytes_nt(6144, 64));
+    (void)hipFuncSetAttribute((const void*)k_turbo<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)turbo_lds_bytes_nt(6144, 128));
     attr_set = true;
   }
   auto fix = [](uint32_t k) { return ((k < 512 ? 512u : k) + 7u) & ~7u; };  // the scratch in the check-point area needs room
-  if (n128) hipLaunchKernelGGL(k_turbo<128>, dim3(n128), dim3(128), lsn_turbo_lds_bytes(fix(kmax128)), s, c.crc_tab_a, c.crc_tab_b, cb, spp, payload, res, fix(kmax128));
+  if (n128) hipLaunchKernelGGL(k_turbo<128>, dim3(n128), dim3(128), turbo_lds_bytes_nt(fix(kmax128), 128), s, c.crc_tab_a, c.crc_tab_b, cb, spp, payload, res, fix(kmax128));
   if (between) (void)hipEventRecord(between, s);
-  if (n64) hipLaunchKernelGGL(k_turbo<64>, dim3(n64), dim3(64), lsn_turbo_lds_bytes(fix(kmax64)), s, c.crc_tab_a, c.crc_tab_b, cb + n128, spp, payload, res, fix(kmax64));
+  if (n64) hipLaunchKernelGGL(k_turbo<64>, dim3(n64), dim3(64), turbo_lds_bytes_nt(fix(kmax64), 64), s, c.crc_tab_a, c.crc_tab_b, cb + n128, spp, payload, res, fix(kmax64));
 }
