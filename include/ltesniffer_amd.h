@@ -323,6 +323,7 @@ typedef struct {
   uint64_t nof_turbo_iterations_run;                     /* iterations executed (equals nof_turbo_iterations) */
   uint64_t nof_ondemand_commit[4];                       /* decodes created at commit: [0] p-a changed, [1] table known at commit but unknown when planned or vice versa, [2] no job planned at all, [3] other */
   double ms_ondemand_commit;                             /* commit-thread time inside those decodes */
+  uint64_t nof_pusch_2prb_skipped;                       /* UL_MODE: valid 2-PRB PUSCH grants that could not be attempted (36.211 Table 5.5.1.2-2 not built in) */
 } lsn_perf_t;
 int lsn_phy_get_perf(lsn_phy_t* phy, lsn_perf_t* out);
 enum { LSN_K_OFDM = 0, LSN_K_CHEST, LSN_K_CHEST_FIN, LSN_K_PCFICH, LSN_K_PDCCH_LLR, LSN_K_CCE_POWER, LSN_K_VITERBI,

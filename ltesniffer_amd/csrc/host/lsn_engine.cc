@@ -239,6 +239,7 @@ void Engine::mergePerf(const lsn_perf_t& p)
   perf.nof_candidates_decoded += p.nof_candidates_decoded; perf.nof_ondemand_decodes += p.nof_ondemand_decodes; perf.nof_pdus += p.nof_pdus;
   for (int k = 0; k < 4; k++) perf.nof_ondemand_commit[k] += p.nof_ondemand_commit[k];
   perf.ms_ondemand_commit += p.ms_ondemand_commit;
+  perf.nof_pusch_2prb_skipped += p.nof_pusch_2prb_skipped;
   for (int k = 0; k < 16; k++) { perf.kernel_ms[k] += p.kernel_ms[k]; perf.kernel_launches[k] += p.kernel_launches[k]; }
 }
 

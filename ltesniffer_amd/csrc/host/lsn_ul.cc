@@ -5,6 +5,7 @@
 // Product code: no CPU fallback, nothing from oracle/ is included or linked.
 #include "lsn_engine.h"
 #include "../kernels/lsn_rm.h"
+#include "../../../spec/lte_tables.h"
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -51,12 +52,17 @@ int Engine::setUlConfig(const lsn_ul_cfg_t& u)
     for (int m = 0; m < 12; m++) { const double a = 2.0 * M_PI * m / 12.0; ph[m] = {(float)std::cos(a), (float)std::sin(a)}; }
     const uint32_t fss = ((cell.id % 30u) + u.delta_ss) % 30u;  // group hopping off: u = f_ss^PUSCH, v = 0
     ul_off.assign(111, -1);
-    for (uint32_t L = 3; L <= cell.nof_prb; L++) {
-      if (!ul_valid_prb(L)) continue;
+    for (uint32_t L = 1; L <= cell.nof_prb; L++) {
+      if (!ul_valid_prb(L) || L == 2) continue;  // two PRB: 36.211 Table 5.5.1.2-2 is not reproduced
       const int M = 12 * (int)L, Nzc = largest_prime_below(M);
       ul_off[L] = (int)base.size();
       const long long q = (long long)std::floor((double)Nzc * (double)(fss + 1) / 31.0 + 0.5);
       for (int n = 0; n < M; n++) {
+        if (L == 1) {  // one PRB: the tabulated sequence exp(j phi(n) pi / 4) (Table 5.5.1.2-1, spec/lte_tables.h)
+          const double a = M_PI * (double)lsn_dmrs_phi12[fss % 30][n] / 4.0;
+          base.push_back({(float)std::cos(a), (float)std::sin(a)});
+          continue;
+        }
         const long long m = n % Nzc;
         const double a = M_PI * (double)((q * m * (m + 1)) % (2ll * Nzc)) / (double)Nzc;
         base.push_back({(float)std::cos(a), (float)(-std::sin(a))});
@@ -115,7 +121,8 @@ int Engine::puschDecode(const void* ul_iq, bool on_device, uint32_t nsf, uint32_
     lsn_launch_ul_fft(cd, d_iq, 1, 0, ul_d_grid, nsf, st);
     std::vector<uint8_t> pay;
     puschDecodeGrid(ul_d_grid, nsf, start_tti, grants, ngrants, results, pay);
-    if (payloads) std::memcpy(payloads, pay.data(), std::min(pay.size(), payload_cap));
+    if (payloads && pay.size() > payload_cap) return LSN_ERROR_INVALID_INPUTS;  // results[].payload_off would point past the caller's buffer
+    if (payloads) std::memcpy(payloads, pay.data(), pay.size());
     return LSN_SUCCESS;
   } catch (const std::exception& ex) {
     fprintf(stderr, "ltesniffer_amd: %s\n", ex.what());
@@ -143,7 +150,8 @@ void Engine::puschDecodeGrid(const cf32* d_grid, uint32_t nsf, uint32_t start_tt
     const lsn_pusch_grant_t& g = grants[i];
     results[i] = lsn_pusch_result_t{};
     const uint32_t n_prb2 = g.hop == 1 ? g.n_prb_slot1 : g.n_prb;
-    const bool ok = g.sf < nsf && g.L_prb >= 3 && ul_valid_prb(g.L_prb) && g.n_prb + g.L_prb <= cell.nof_prb && n_prb2 + g.L_prb <= cell.nof_prb && g.hop <= 1 &&
+    // (no uint32 wrap-around in the range checks: n_prb <= nof_prb first, then L_prb against what is left)
+    const bool ok = g.sf < nsf && g.L_prb >= 1 && g.L_prb <= cell.nof_prb && ul_valid_prb(g.L_prb) && g.n_prb <= cell.nof_prb - g.L_prb && n_prb2 <= cell.nof_prb - g.L_prb && g.hop <= 1 &&
                     g.tbs > 0 && (g.tbs % 8) == 0 &&
                     (g.mod == 2 || g.mod == 4 || g.mod == 6 || g.mod == 8) && ul_off[g.L_prb] >= 0 && g.rv >= 0 && g.rv < 4;
     if (!ok) continue;

@@ -141,6 +141,7 @@ void Engine::commitChunkUl(Chunk& ch, JobRunner& r)
       const UlSchedGrant& m = lists[a.sf][a.idx];
       const PuschGrant& g = a.use256 ? m.g256 : m.g;
       results[a];  // default: failed
+      if (g.L_prb == 2) r.perf.nof_pusch_2prb_skipped++;  // reported, not decoded (no 24-entry DMRS table)
       if (m.hopping || g.hop == 2 || g.tbs <= 0) continue;  // type-2 hopping is not applied by the reference either (hopping_enabled stays false, SubframeWorker.cc:269)
       lsn_pusch_grant_t q{};
       q.sf = a.sf; q.rnti = m.rnti; q.n_dmrs = (uint16_t)m.n_dmrs; q.n_prb = g.n_prb; q.L_prb = g.L_prb; q.mod = (uint32_t)a.qm; q.tbs = (uint32_t)g.tbs; q.rv = g.rv;

@@ -5,10 +5,11 @@
  * modulation, transform precoding) and TS 36.212 5.2.2 (UL-SCH coding, channel interleaver).
  * Scope of this restatement: one receive antenna (the reference uses antenna 1 for the uplink,
  * UL_Sniffer_PUSCH.cc:391), no group / sequence hopping, no frequency hopping, no SRS, no UCI multiplexed into the
- * PUSCH, allocations of >= 3 PRB (the 1- and 2-PRB base sequences are tabulated phases that are not reproduced here).
+ * PUSCH, allocations of 1 PRB (tabulated sequence, spec/lte_tables.h) and >= 3 PRB (Zadoff-Chu); the 2-PRB table (5.5.1.2-2) is not reproduced.
  * Arithmetic contract as in lsn_oracle.h: one float rounding per operation, fixed summation orders, all cos/sin on the
  * "host" side (tables). */
 #include "lsn_oracle.h"
+#include "../spec/lte_tables.h"
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -74,7 +75,15 @@ static int largest_prime_below(int n)
 /* base sequence r_{u,0}(n), n < M_sc = 12 L, L >= 3 (36.211 5.5.1.1) */
 int o_dmrs_base(uint32_t u, int M_sc, ocf_t* r)
 {
-  if (M_sc < 36) return -1;
+  if (M_sc == 12) { /* one PRB: the tabulated sequence exp(j phi(n) pi / 4), 36.211 5.5.1.2 Table 5.5.1.2-1 */
+    for (int n = 0; n < 12; n++) {
+      double a = M_PI * (double)lsn_dmrs_phi12[u % 30][n] / 4.0;
+      r[n].r = (float)cos(a);
+      r[n].i = (float)sin(a);
+    }
+    return 0;
+  }
+  if (M_sc < 36) return -1; /* two PRB: Table 5.5.1.2-2 is not reproduced */
   int Nzc = largest_prime_below(M_sc);
   double qb = (double)Nzc * (double)(u + 1) / 31.0;
   int q = (int)floor(qb + 0.5); /* v = 0 */
@@ -206,7 +215,7 @@ int o_pusch_demod_uci(const o_cell_t* cell, const o_ul_cfg_t* ul, uint32_t sf_id
                       const o_uci_t* uci, const ocf_t* grid, int16_t* e, float* noise_out, float* sigpow_out)
 {
   int L = (int)g->L_prb, M = 12 * L, nre = 12 * (int)cell->nof_prb, Qm = g->mod;
-  if (L < 3 || !o_ul_valid_prb(g->L_prb) || g->n_prb + g->L_prb > cell->nof_prb || Qm <= 0 || g->hop > 1) return -1;
+  if ((L < 3 && L != 1) || !o_ul_valid_prb(g->L_prb) || g->n_prb + g->L_prb > cell->nof_prb || Qm <= 0 || g->hop > 1) return -1;
   if (g->hop == 1 && g->n_prb2 + g->L_prb > cell->nof_prb) return -1;
   const int k0s[2] = {12 * (int)g->n_prb, 12 * (int)(g->hop == 1 ? g->n_prb2 : g->n_prb)}; /* first carrier per slot (type-1 hopping: two places) */
   ocf_t* base = (ocf_t*)malloc(sizeof(ocf_t) * (size_t)M);
@@ -305,7 +314,7 @@ int o_pusch_decode_uci(const o_cell_t* cell, const o_ul_cfg_t* ul, uint32_t sf_i
 {
   if (g->tbs <= 0) return 0;
   int M = 12 * (int)g->L_prb, G = 12 * M * g->mod;
-  if (uci && M >= 36) {
+  if (uci) {
     uint8_t* cls = (uint8_t*)malloc((size_t)(12 * M));
     int* didx = (int*)malloc(sizeof(int) * (size_t)(12 * M));
     int nsym = o_uci_layout(M, g->tbs, uci, cls, didx, NULL, NULL, NULL);

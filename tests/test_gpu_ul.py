@@ -22,7 +22,7 @@ def _scenario(nprb, cell_id, nsf, seed, snr_db=32.0, max_share=3, rvs=(0,), uci=
     for sf in range(nsf):
         gl, start = [], 0
         while True:
-            L = int(rng.choice([n for n in VALID_UL_PRB if 3 <= n <= max(3, nprb // max_share)]))
+            L = int(rng.choice([n for n in VALID_UL_PRB if n != 2 and n <= max(3, nprb // max_share)]))  # 1 PRB: tabulated DMRS; 2 PRB unsupported
             if start + L > nprb:
                 break
             mcs = int(rng.integers(0, 29))
@@ -63,6 +63,12 @@ def _run(nprb, cell_id, nsf, seed, **kw):
         cls_buf, idx_buf = np.zeros(12 * M, np.uint8), np.zeros(12 * M, np.int32)
         nsym = o.o_uci_layout(M, g["tbs"], C.byref(uci), cls_buf.ctypes.data, idx_buf.ctypes.data, None, None, None)
         G = nsym * g["mod"]
+        if G <= 0:  # the control information takes every resource of the allocation (one PRB with a CQI report): nothing to decode, on both sides
+            assert r["crc_ok"] == 0
+            out = np.zeros(g["tbs"] // 8 + 8, dtype=np.uint8)
+            assert o.o_pusch_decode_uci(C.byref(ocell), C.byref(ucfg), (tti0 + g["sf"]) % 10, g["rnti"], C.byref(og), g["n_dmrs"], C.byref(uci),
+                                        grids[g["sf"]].ctypes.data, 12, out.ctypes.data, None, None) == 0
+            continue
         e = np.zeros(144 * g["L_prb"] * g["mod"], dtype=np.int16)
         noise, sig = C.c_float(), C.c_float()
         assert o.o_pusch_demod_uci(C.byref(ocell), C.byref(ucfg), (tti0 + g["sf"]) % 10, g["rnti"], C.byref(og), g["n_dmrs"], C.byref(uci),
@@ -146,7 +152,8 @@ def test_pusch_unsupported_grants_fail_cleanly():
         phy.pusch_decode(np.zeros((1, 15 * 512), dtype=np.complex64), 0, [])  # no UL config yet
     assert phy.setUlConfig(0, 0) and not phy.setUlConfig(9, 0)
     iq = np.zeros((2, 15 * 512), dtype=np.complex64)
-    bad = [dict(sf=0, rnti=70, n_prb=0, L_prb=1, mod=2, tbs=104), dict(sf=0, rnti=70, n_prb=0, L_prb=7, mod=2, tbs=104),
+    bad = [dict(sf=0, rnti=70, n_prb=0, L_prb=2, mod=2, tbs=104), dict(sf=0, rnti=70, n_prb=0, L_prb=7, mod=2, tbs=104),
+           dict(sf=0, rnti=70, n_prb=0xFFFFFFFD, L_prb=3, mod=2, tbs=104),  # n_prb + L_prb wraps around in 32 bits
            dict(sf=5, rnti=70, n_prb=0, L_prb=3, mod=2, tbs=104), dict(sf=0, rnti=70, n_prb=24, L_prb=3, mod=2, tbs=104),
            dict(sf=1, rnti=70, n_prb=0, L_prb=3, mod=3, tbs=104), dict(sf=1, rnti=70, n_prb=0, L_prb=3, mod=2, tbs=0)]
     res = phy.pusch_decode(iq, 0, bad)

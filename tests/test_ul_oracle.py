@@ -25,7 +25,8 @@ def test_pusch_loopback_all_modulations(nprb, cell_id):
         # pack a few non-overlapping grants into the band
         grants, start = [], 0
         while True:
-            L = int(rng.choice([n for n in VALID_UL_PRB if n >= 3 and n <= max(3, nprb // 3)]))
+            # one PRB (tabulated DMRS sequence, 36.211 Table 5.5.1.2-1) and >= 3 PRB (Zadoff-Chu); two PRB is not supported
+            L = int(rng.choice([n for n in VALID_UL_PRB if n != 2 and n <= max(3, nprb // 3)]))
             if start + L > nprb:
                 break
             mcs = int(rng.integers(0, 29))
@@ -57,7 +58,7 @@ def test_pusch_rejects_unsupported_grants():
     ocell, ucfg = OCell(25, 1, 1, 1), OUlCfg(0, 0)
     grid = np.zeros(14 * 300, dtype=np.complex64)
     e = np.zeros(1 << 16, dtype=np.int16)
-    for L, n in ((1, 0), (2, 0), (7, 0), (10, 20), (0, 0)):
+    for L, n in ((2, 0), (7, 0), (10, 20), (0, 0)):
         og = OPuschGrant(L, n, 0, 2, 104, 0)
         assert o.o_pusch_demod(C.byref(ocell), C.byref(ucfg), 0, 70, C.byref(og), 0, grid.ctypes.data, e.ctypes.data, None, None) == -1
 

@@ -914,7 +914,9 @@ extern "C" int txg_ul_make(const txg_ul_cell_t* c, uint32_t tti, const txg_ul_gr
         const uint32_t ncs = (d1[c->cyclic_shift & 7] + d2[g.n_dmrs & 7] + npn) % 12;
         for (int n = 0; n < M; n++) {
           const long long m = n % Nzc;
-          const double a = -M_PI * (double)((q * m * (m + 1)) % (2ll * Nzc)) / (double)Nzc + 2.0 * M_PI * (double)((ncs * (uint32_t)n) % 12) / 12.0;
+          const double base = M == 12 ? M_PI * (double)lsn_dmrs_phi12[fss % 30][n] / 4.0  // one PRB: 36.211 Table 5.5.1.2-1
+                                      : -M_PI * (double)((q * m * (m + 1)) % (2ll * Nzc)) / (double)Nzc;
+          const double a = base + 2.0 * M_PI * (double)((ncs * (uint32_t)n) % 12) / 12.0;
           v[n] = std::complex<double>(std::cos(a), std::sin(a));
         }
       } else {
