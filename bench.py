@@ -100,6 +100,10 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1600, help="subframes of the capture decoded by the CPU oracle from cold state (rank 0): parity gate + cpu_baseline")
     ap.add_argument("--no-cpu", action="store_true", help="skip the oracle leg (parity gate part 1 and cpu_baseline)")
     ap.add_argument("--no-check", action="store_true", help="skip the synchronous second pass (parity gate part 2)")
+    ap.add_argument("--shard", choices=("cells", "capture"), default="cells",
+                    help="N > 1: 'cells' = one synthetic cell per rank (weak scaling, the default and what BASELINE configs[4] asks for); 'capture' = ONE capture "
+                         "whose chunks go round-robin to the N GPUs (lsn_phy_create_multi on rank 0; the other ranks only hold their GPU) - strong scaling, "
+                         "bounded by the sequential FALCON search on one host thread")
     ap.add_argument("--no-legs", action="store_true", help="skip the PCIe-inclusive legs (host buffers, capture file)")
     ap.add_argument("--leg-nsf", type=int, default=12800, help="subframes of the capture file / host buffer of the PCIe-inclusive legs")
     args = ap.parse_args()
@@ -156,9 +160,18 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     sf_per_step = nsf * reps
 
+    capture_mode = args.shard == "capture" and (world > 1 or os.environ.get("LSN_BENCH_DEVICES"))
+    devices = None
+    if capture_mode:
+        devices = [int(x) for x in os.environ["LSN_BENCH_DEVICES"].split(",")] if os.environ.get("LSN_BENCH_DEVICES") else list(range(world))
+    if capture_mode and rank != 0:  # the capture is driven by rank 0's process (one search thread, one record stream); this rank's GPU is one of its devices
+        dist.barrier()
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     pcap = la.PcapWriter(None)  # native MAC-LTE writer, the reference's pcap-emit surface; the timed stream is digested, not kept
     pcap.set_store(False)
-    phy = la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=batch, device=local, pcapwriter=pcap)
+    phy = la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=batch, device=local, pcapwriter=pcap, devices=devices)
     assert phy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"])
 
     def submit_step(p, i, sync=False):
@@ -195,11 +208,11 @@ def main():
     timed_digest, timed_bytes = pcap.digest()
     timed_records = pcap.nof_records()
     host_cores_busy = ((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) / dt
-    if world > 1:
+    if world > 1 and not capture_mode:
         rdev = dev if dist.get_backend() == "nccl" else None
         dt, total = ld.reduce_max_sum(dt, args.steps * sf_per_step, rdev)
         assert total == args.steps * sf_per_step * world
-    total_sf = args.steps * sf_per_step * world
+    total_sf = args.steps * sf_per_step * (1 if capture_mode else world)
     value = total_sf / dt
     phy.close()
 
@@ -349,15 +362,16 @@ def main():
         except Exception:
             valu = None
         out = {
-            "metric": "subframes/s (20 MHz, 150 RNTIs)", "value": round(value, 1), "unit": "subframes/s", "n_gpus": world,
+            "metric": "subframes/s (20 MHz, 150 RNTIs)", "value": round(value, 1), "unit": "subframes/s", "n_gpus": world if not capture_mode or world > 1 else len(devices),
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32+int16", "data": "synthetic",
-            "x_realtime": round(value / 1000.0 / world, 2), "pcap_diff": pcap_diff, "parity": parity,
+            "higher_is_better": True, "scaling": "strong" if capture_mode else "weak", "vs_baseline": None, "dtype": "f32+int16", "data": "synthetic",
+            "x_realtime": round(value / 1000.0 / (1 if capture_mode else world), 2), "pcap_diff": pcap_diff, "parity": parity,
             "config": {"workload": "%s: 20 MHz DL (100 PRB, 2 CRS ports, 2 rx), 150 active RNTIs, TM2/TM3/TM4 mix up to 256QAM, "
                                    "CFI 3, 8-14 DL + 3-6 UL DCIs per subframe (BASELINE.json configs[2])" % args.config
                        if args.config == "cfg3" else args.config,
                        "subframes_per_step": sf_per_step, "resident_capture_subframes": nsf, "replays_per_step": reps, "steps_pipelined": True,
-                       "distinct_subframes": gen, "gpu_batch": batch, "cells": world, "parallelism": "one cell per GPU, no collective"},
+                       "distinct_subframes": gen, "gpu_batch": batch, "cells": 1 if capture_mode else world,
+                       "parallelism": ("one capture, chunks round-robin over devices %s, shared sequential search" % devices) if capture_mode else "one cell per GPU, no collective"},
             "roofline": {"bound": "hbm", "kernel": la.KERNELS[kt], "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(ach / 8000.0, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": round(kms[kt] / max(1, klaunch[kt]), 4), "launches": int(klaunch[kt]),
@@ -366,7 +380,7 @@ def main():
             "legs": legs, "cpu_baseline": cpu, "host": {"cpu_count": os.cpu_count(), "cores_busy_in_timed_region": round(host_cores_busy, 2),
                                              "busiest_threads": busiest},
             "detail": {"pdus_per_subframe": round(p.nof_pdus / sf_rank, 3), "algo_bytes_per_subframe": int(p.algo_bytes / sf_rank),
-                       "whole_path_GBps": round(p.algo_bytes * world / 1e9 / dt, 2), "timed_region_s": round(dt, 3),
+                       "whole_path_GBps": round(p.algo_bytes * (1 if capture_mode else world) / 1e9 / dt, 2), "timed_region_s": round(dt, 3),
                        "per_6400_subframes": {k: round(getattr(p, k) * 6400.0 / sf_rank, 3) for k in
                                               ("nof_tb_decodes", "nof_cb_decodes", "nof_turbo_iterations", "nof_ondemand_decodes", "turbo_cyc_rm", "turbo_cyc_map",
                                                "turbo_cyc_out", "ms_ondemand_commit", "ms_stage_a", "ms_search", "ms_search_core", "ms_rar", "ms_stage_c", "ms_commit", "ms_wait_front",

@@ -85,6 +85,14 @@ typedef struct {
 /* ---- Phy ---- */
 int lsn_phy_create(const lsn_phy_cfg_t* cfg, lsn_phy_t** out);          /* Phy::Phy, Phy.cc:5 */
 void lsn_phy_destroy(lsn_phy_t* phy);                                     /* Phy::~Phy */
+/* ONE capture spread over several GPUs of the node: a Phy whose chunks of max_batch subframes go round-robin to one
+ * engine per listed device.  Stage A, the exhaustive candidate decode and the PDSCH decodes of a chunk run on its device; the sequential
+ * host state (FALCON search / RNTI manager, MCS tracking, record order) is shared and taken in turns, so the record stream is the one a
+ * single device produces.  IQ blocks that live on another device travel by peer copies (xGMI).  devices[0] is the primary device (MIB,
+ * uplink, taps); listing a device twice is allowed (two engines on one GPU).  Supported entry points in this mode: lsn_phy_process_device,
+ * lsn_phy_submit_device, lsn_phy_wait and the getters; DL mode only.  Several CELLS are several Phys - one process per GPU, no exchange. */
+int lsn_phy_create_multi(const lsn_phy_cfg_t* cfg, const int* devices, uint32_t n_devices, lsn_phy_t** out);
+uint32_t lsn_phy_nof_devices(lsn_phy_t* phy);
 int lsn_phy_set_cell(lsn_phy_t* phy, const lsn_cell_t* cell);             /* Phy::setCell, Phy.cc:111 */
 lsn_worker_t* lsn_phy_get_avail(lsn_phy_t* phy, int blocking);            /* Phy::getAvail / getAvailImmediate, Phy.cc:79-89 */
 int lsn_phy_put_pending(lsn_phy_t* phy, lsn_worker_t* w);                 /* Phy::putPending, Phy.cc:95 */

@@ -32,7 +32,7 @@ EXPORTS = ["lsn_phy_create", "lsn_phy_destroy", "lsn_phy_set_cell", "lsn_phy_get
            "lsn_pcap_reset", "lsn_pcap_close", "lsn_phy_set_pcap_writer", "lsn_phy_set_ul_config", "lsn_phy_pusch_decode",
            "lsn_phy_tap_ul", "lsn_phy_set_prach_config", "lsn_phy_prach_detect", "lsn_phy_set_prach_sink", "lsn_prach_tti_opportunity", "lsn_phy_process_file", "lsn_phy_mib_decode", "lsn_phy_mib_decode_llr", "lsn_phy_submit_device", "lsn_phy_wait", "lsn_cell_search",
            "lsn_phy_set_shortcut_discovery", "lsn_phy_get_shortcut_discovery", "lsn_phy_set_histogram_threshold", "lsn_phy_print_stats",
-           "lsn_phy_set_mcs_update_interval", "lsn_phy_update_mcs_database", "lsn_phy_nof_tracked_rnti", "lsn_worker_buffers_offset", "lsn_pcap_digest", "lsn_pcap_set_store"]
+           "lsn_phy_set_mcs_update_interval", "lsn_phy_update_mcs_database", "lsn_phy_nof_tracked_rnti", "lsn_worker_buffers_offset", "lsn_pcap_digest", "lsn_pcap_set_store", "lsn_phy_create_multi", "lsn_phy_nof_devices"]
 
 
 PRACH_NCS = [0, 13, 15, 18, 22, 26, 32, 38, 46, 59, 76, 93, 119, 167, 279, 419]  # 36.211 Table 5.7.2-2
@@ -170,6 +170,9 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.lsn_phy_create.argtypes = [C.POINTER(PhyCfg), C.POINTER(C.c_void_p)]
         L.lsn_phy_destroy.argtypes = [C.c_void_p]
+        L.lsn_phy_create_multi.argtypes = [C.POINTER(PhyCfg), C.POINTER(C.c_int), C.c_uint32, C.POINTER(C.c_void_p)]
+        L.lsn_phy_nof_devices.argtypes = [C.c_void_p]
+        L.lsn_phy_nof_devices.restype = C.c_uint32
         L.lsn_phy_destroy.restype = None
         L.lsn_phy_set_cell.argtypes = [C.c_void_p, C.POINTER(Cell)]
         L.lsn_phy_get_avail.argtypes = [C.c_void_p, C.c_int]
@@ -338,12 +341,17 @@ class Phy:
 
     def __init__(self, nof_rx_antennas=2, nof_workers=20, skipSecondaryMetaFormats=False, metaFormatSplitRatio=0.99,
                  histogramThreshold=5, sink=None, mcs_tracking_mode=1, harq_mode=0, device=0, max_batch=64,
-                 max_turbo_iterations=12, default_rnti_intervals=True, pcapwriter=None, sniffer_mode=0):
+                 max_turbo_iterations=12, default_rnti_intervals=True, pcapwriter=None, sniffer_mode=0, devices=None):
+        """devices: list of HIP devices that share ONE capture (lsn_phy_create_multi); None: the single `device`"""
         self.nof_rx_antennas = nof_rx_antennas
         self._cfg = PhyCfg(nof_rx_antennas, nof_workers, max_batch, int(skipSecondaryMetaFormats), metaFormatSplitRatio,
-                           histogramThreshold, mcs_tracking_mode, harq_mode, device, max_turbo_iterations, sniffer_mode)
+                           histogramThreshold, mcs_tracking_mode, harq_mode, devices[0] if devices else device, max_turbo_iterations, sniffer_mode)
         self._h = C.c_void_p()
-        _check(lib().lsn_phy_create(C.byref(self._cfg), C.byref(self._h)), "lsn_phy_create")
+        if devices:
+            arr = (C.c_int * len(devices))(*devices)
+            _check(lib().lsn_phy_create_multi(C.byref(self._cfg), arr, len(devices), C.byref(self._h)), "lsn_phy_create_multi")
+        else:
+            _check(lib().lsn_phy_create(C.byref(self._cfg), C.byref(self._h)), "lsn_phy_create")
         self.pdus = []
         self._user_sink = sink
         self._cb = SINK_T(self._on_pdu)

@@ -23,6 +23,11 @@ struct lsn_worker {
 
 struct lsn_phy {
   std::unique_ptr<lsn::Engine> engine;
+  // lsn_phy_create_multi: further engines (one per additional GPU) that share engine's sequential state; chunk g of a submit goes to engine g mod G
+  std::vector<std::unique_ptr<lsn::Engine>> more;
+  uint64_t multi_next = 0;  // round-robin position
+  lsn::Engine* eng(size_t i) { return i == 0 ? engine.get() : more[i - 1].get(); }
+  size_t neng() const { return 1 + more.size(); }
   lsn_phy_cfg_t cfg{};
   std::vector<std::unique_ptr<lsn_worker>> workers;
   std::deque<lsn_worker*> avail, pending;
@@ -101,6 +106,37 @@ int lsn_phy_create(const lsn_phy_cfg_t* cfg, lsn_phy_t** out)
   }
 }
 
+int lsn_phy_create_multi(const lsn_phy_cfg_t* cfg, const int* devices, uint32_t n_devices, lsn_phy_t** out)
+{
+  if (!cfg || !out || !devices || n_devices < 1 || n_devices > 16) return LSN_ERROR_INVALID_INPUTS;
+  lsn_phy_cfg_t c0 = *cfg;
+  c0.device = devices[0];
+  const int r = lsn_phy_create(&c0, out);
+  if (r != LSN_SUCCESS) return r;
+  if (cfg->sniffer_mode != 0 && n_devices > 1) { lsn_phy_destroy(*out); *out = nullptr; return LSN_ERROR_INVALID_INPUTS; }  // UL_MODE keeps per-chunk uplink state
+  int ndev = 0;
+  (void)hipGetDeviceCount(&ndev);
+  try {
+    for (uint32_t i = 1; i < n_devices; i++) {
+      if (devices[i] < 0 || devices[i] >= ndev) throw std::invalid_argument("device");
+      lsn_phy_cfg_t ci = (*out)->cfg;
+      ci.device = devices[i];
+      (*out)->more.emplace_back(new lsn::Engine(ci, (*out)->engine->sharedState()));
+      if (devices[i] != devices[0]) {  // peer copies of the IQ blocks (xGMI); harmless when already enabled
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, devices[i], devices[0]) == hipSuccess && can) { (void)hipSetDevice(devices[i]); (void)hipDeviceEnablePeerAccess(devices[0], 0); (void)hipGetLastError(); }
+      }
+    }
+    return LSN_SUCCESS;
+  } catch (const std::exception& ex) {
+    fprintf(stderr, "ltesniffer_amd: %s\n", ex.what());
+    lsn_phy_destroy(*out);
+    *out = nullptr;
+    return LSN_ERROR_INVALID_INPUTS;
+  }
+}
+uint32_t lsn_phy_nof_devices(lsn_phy_t* phy) { return phy ? (uint32_t)phy->neng() : 0; }
+
 void lsn_phy_destroy(lsn_phy_t* phy)
 {
   if (!phy) return;
@@ -134,6 +170,7 @@ int lsn_phy_set_cell(lsn_phy_t* phy, const lsn_cell_t* cell)
   }
   const int r = phy->engine->setCell(*cell);
   if (r != LSN_SUCCESS) return r;
+  for (auto& e : phy->more) { const int re = e->setCell(*cell); if (re != LSN_SUCCESS) return re; }
   // worker pool: SubframeBuffer allocates 3 * SF_LEN per antenna (SubframeBuffer.cc:25)
   for (auto& w : phy->workers) {
     for (auto& b : w->buf)
@@ -192,6 +229,7 @@ int lsn_phy_set_pdu_sink(lsn_phy_t* phy, lsn_pdu_sink_t cb, void* user)
 {
   if (!phy) return LSN_ERROR_INVALID_INPUTS;
   phy->engine->setSink(cb, user);
+  for (auto& e : phy->more) e->setSink(cb, user);  // the writer turns keep the records of all engines in one order
   return LSN_SUCCESS;
 }
 
@@ -199,6 +237,7 @@ int lsn_phy_set_pcap_writer(lsn_phy_t* phy, lsn_pcap_t* p)
 {
   if (!phy) return LSN_ERROR_INVALID_INPUTS;
   phy->engine->setSink(p ? lsn_pcap_sink : nullptr, p);
+  for (auto& e : phy->more) e->setSink(p ? lsn_pcap_sink : nullptr, p);
   return LSN_SUCCESS;
 }
 
@@ -298,19 +337,45 @@ int lsn_worker_prepare(lsn_worker_t* w, uint32_t sf_idx, uint32_t sfn, int updat
 uint32_t lsn_worker_sf_idx(lsn_worker_t* w) { return w ? w->sf_idx : 0; }
 uint32_t lsn_worker_sfn(lsn_worker_t* w) { return w ? w->sfn : 0; }
 
+// one capture over several GPUs: the block is cut into chunks of max_batch subframes, chunk g goes to engine g mod G
+static int multi_submit(lsn_phy_t* phy, const void* d_iq, uint32_t n, uint32_t start_tti, uint32_t update_meta_period, void* stream)
+{
+  hipPointerAttribute_t attr{};
+  int src = phy->engine->device();
+  if (hipPointerGetAttributes(&attr, d_iq) == hipSuccess && attr.type == hipMemoryTypeDevice) src = attr.device;
+  (void)hipGetLastError();
+  const uint32_t mb = phy->engine->maxBatch();
+  const size_t sf_stride = (size_t)phy->engine->nofRx() * phy->engine->sfLen() * 2 * sizeof(float);
+  for (uint32_t base = 0; base < n; base += mb) {
+    lsn::Engine* e = phy->eng((size_t)(phy->multi_next++ % phy->neng()));
+    const int r = e->submitFrom((const uint8_t*)d_iq + (size_t)base * sf_stride, src, std::min(mb, n - base), start_tti + base, update_meta_period, (hipStream_t)stream);
+    if (r != LSN_SUCCESS) return r;
+  }
+  return LSN_SUCCESS;
+}
+static int multi_wait(lsn_phy_t* phy)
+{
+  int rc = LSN_SUCCESS;
+  for (size_t i = 0; i < phy->neng(); i++) { const int r = phy->eng(i)->wait(); if (r != LSN_SUCCESS) rc = r; }
+  return rc;
+}
+
 int lsn_phy_process_device(lsn_phy_t* phy, const void* d_iq, uint32_t n, uint32_t start_tti, uint32_t update_meta_period, void* stream)
 {
   if (!phy) return LSN_ERROR_INVALID_INPUTS;
+  if (!phy->more.empty()) { const int r = multi_submit(phy, d_iq, n, start_tti, update_meta_period, stream); const int w = multi_wait(phy); return r != LSN_SUCCESS ? r : w; }
   return phy->engine->process(d_iq, n, start_tti, update_meta_period, (hipStream_t)stream);
 }
 int lsn_phy_submit_device(lsn_phy_t* phy, const void* d_iq, uint32_t n, uint32_t start_tti, uint32_t update_meta_period, void* stream)
 {
   if (!phy) return LSN_ERROR_INVALID_INPUTS;
+  if (!phy->more.empty()) return multi_submit(phy, d_iq, n, start_tti, update_meta_period, stream);
   return phy->engine->submit(d_iq, n, start_tti, update_meta_period, (hipStream_t)stream);
 }
 int lsn_phy_wait(lsn_phy_t* phy)
 {
   if (!phy) return LSN_ERROR_INVALID_INPUTS;
+  if (!phy->more.empty()) return multi_wait(phy);
   return phy->engine->wait();
 }
 int lsn_phy_process_host(lsn_phy_t* phy, const float* iq, uint32_t n, uint32_t start_tti, uint32_t update_meta_period)
@@ -389,6 +454,20 @@ int lsn_phy_get_perf(lsn_phy_t* phy, lsn_perf_t* out)
 {
   if (!phy || !out) return LSN_ERROR_INVALID_INPUTS;
   phy->engine->getPerf(out);
+  for (auto& e : phy->more) {  // counters and times of the other GPUs' engines add up (wall-clock fields: the longest one)
+    lsn_perf_t p;
+    e->getPerf(&p);
+    out->ms_stage_a += p.ms_stage_a; out->ms_search += p.ms_search; out->ms_stage_c += p.ms_stage_c; out->ms_commit += p.ms_commit;
+    out->ms_total = std::max(out->ms_total, p.ms_total);
+    for (int k = 0; k < 16; k++) { out->kernel_ms[k] += p.kernel_ms[k]; out->kernel_launches[k] += p.kernel_launches[k]; }
+    out->algo_bytes += p.algo_bytes; out->turbo_algo_bytes += p.turbo_algo_bytes; out->turbo128_algo_bytes += p.turbo128_algo_bytes;
+    out->nof_tb_decodes += p.nof_tb_decodes; out->nof_cb_decodes += p.nof_cb_decodes; out->nof_turbo_iterations += p.nof_turbo_iterations;
+    out->nof_candidates_decoded += p.nof_candidates_decoded; out->nof_ondemand_decodes += p.nof_ondemand_decodes; out->nof_pdus += p.nof_pdus;
+    out->ms_search_core += p.ms_search_core; out->ms_rar += p.ms_rar; out->turbo_cyc_rm += p.turbo_cyc_rm; out->turbo_cyc_map += p.turbo_cyc_map;
+    out->turbo_cyc_out += p.turbo_cyc_out; out->ms_wait_front += p.ms_wait_front; out->ms_wait_slot += p.ms_wait_slot; out->ms_drain = std::max(out->ms_drain, p.ms_drain);
+    out->nof_turbo_iterations_run += p.nof_turbo_iterations_run; out->ms_ondemand_commit += p.ms_ondemand_commit;
+    for (int k = 0; k < 4; k++) out->nof_ondemand_commit[k] += p.nof_ondemand_commit[k];
+  }
   return LSN_SUCCESS;
 }
 const char* lsn_kernel_name(int k)

@@ -131,7 +131,7 @@ bool Engine::pinThisThread(void* saved)
 void Engine::unpinThisThread(const void* saved) { (void)sched_setaffinity(0, sizeof(cpu_set_t), (const cpu_set_t*)saved); }
 
 // ------------------------------------------------------------------------------------------------ life cycle
-Engine::Engine(const lsn_phy_cfg_t& c) : cfg(c)
+Engine::Engine(const lsn_phy_cfg_t& c, std::shared_ptr<SharedSeq> shared) : sh(shared ? shared : std::make_shared<SharedSeq>()), cfg(c)
 {
   if (cfg.nof_rx_antennas < 1 || cfg.nof_rx_antennas > LSN_MAX_RX) throw std::invalid_argument("nof_rx_antennas");
   if (cfg.sniffer_mode != 0 && cfg.sniffer_mode != 1) throw std::invalid_argument("sniffer_mode");
@@ -144,7 +144,7 @@ Engine::Engine(const lsn_phy_cfg_t& c) : cfg(c)
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) throw std::runtime_error("no HIP device");
   HIP_CHECK(hipSetDevice(cfg.device));
   detectNumaCpus();
-  search.reset(new FalconSearch(cfg.histogram_threshold, cfg.meta_format_split_ratio, cfg.skip_secondary_meta_formats != 0));
+  if (!search) search.reset(new FalconSearch(cfg.histogram_threshold, cfg.meta_format_split_ratio, cfg.skip_secondary_meta_formats != 0));  // (shared: the first engine of a group makes it)
   {
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
@@ -152,7 +152,6 @@ Engine::Engine(const lsn_phy_cfg_t& c) : cfg(c)
   }
   HIP_CHECK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
   trace_path = getenv("LSN_TRACE");
-  for (uint32_t i = 0; i < 65536; i++) { pred_table[i].store(0xFF, std::memory_order_relaxed); pred_p_a[i].store(0.0f, std::memory_order_relaxed); pred_rar_at[i].store(0, std::memory_order_relaxed); }
   if (const char* e = getenv("LSN_DECODE_THREADS")) ndec = std::max(1, std::min((int)NDEC, atoi(e)));
   nslots = ndec + 8;
   front_thread = std::thread([this] { pthread_setname_np(pthread_self(), "lsn-front"); frontLoop(); });
@@ -182,6 +181,7 @@ Engine::~Engine()
   cv_write.notify_all();
   cv_search.notify_all();
   cv_done.notify_all();
+  sh->turn_cv.notify_all();
   if (search_thread.joinable()) search_thread.join();
   if (writer_thread.joinable()) writer_thread.join();
   if (front_thread.joinable()) front_thread.join();
@@ -983,6 +983,10 @@ void Engine::commitLoop()
       ch = it->second.first; err = it->second.second;
       decoded.erase(it);
     }
+    {
+      std::unique_lock<std::mutex> tl(sh->turn_mtx);
+      sh->turn_cv.wait(tl, [&] { return sh->commit_turn == ch->gseq || stop; });
+    }
     try {
       (void)hipSetDevice(cfg.device);
       const double t1 = now_ms();
@@ -993,6 +997,11 @@ void Engine::commitLoop()
     } catch (const std::exception& ex) {
       err = ex.what();
     }
+    {
+      std::unique_lock<std::mutex> tl(sh->turn_mtx);
+      sh->commit_turn = ch->gseq + 1;
+    }
+    sh->turn_cv.notify_all();
     {
       std::unique_lock<std::mutex> lk(mtx);
       ch->err = err;
@@ -1019,6 +1028,10 @@ void Engine::writerLoop()
       write_queue.pop_front();
     }
     std::string err = ch->err;
+    {
+      std::unique_lock<std::mutex> tl(sh->turn_mtx);
+      sh->turn_cv.wait(tl, [&] { return sh->write_turn == ch->gseq || stop; });
+    }
     if (err.empty() && sink) {
       try {
         const uint8_t* base = ch->h_payload.data();
@@ -1027,6 +1040,11 @@ void Engine::writerLoop()
         err = ex.what();
       }
     }
+    {
+      std::unique_lock<std::mutex> tl(sh->turn_mtx);
+      sh->write_turn = ch->gseq + 1;
+    }
+    sh->turn_cv.notify_all();
     {
       std::unique_lock<std::mutex> lk(mtx);
       if (!err.empty() && commit_error.empty()) commit_error = err;
@@ -1088,6 +1106,7 @@ void Engine::frontLoop()
         ch.nsf = std::min(max_batch, job.nsf_total - base);
         ch.start_tti = job.start_tti + base;
         ch.update_meta_period = job.update_meta_period;
+        ch.gseq = job.gseq0 + ci;
         ch.jobs.clear(); ch.jres.clear(); ch.cdci.clear(); ch.setup_cfgs.clear(); ch.h_payload.clear(); ch.recs.clear(); ch.err.clear();
         for (uint32_t i = 0; i < ch.nsf; i++) ch.ctx[i].reset(ch.start_tti + i);
         ch.st_a = stream_a[(slot_counter - 1) % NSTREAM_A];
@@ -1121,6 +1140,10 @@ void Engine::searchLoop()
       search_queue.pop_front();
     }
     if (!cur) continue;  // a chunk the spec thread gave up on: its error is already recorded
+    {  // the sequential search state may be shared with the engines of other GPUs: chunk g is searched when chunks 0 .. g-1 have been
+      std::unique_lock<std::mutex> tl(sh->turn_mtx);
+      sh->turn_cv.wait(tl, [&] { return sh->search_turn == cur->gseq || stop; });
+    }
     try {
       (void)hipSetDevice(cfg.device);
       const double t1 = now_ms();
@@ -1133,6 +1156,11 @@ void Engine::searchLoop()
       if (commit_error.empty()) commit_error = ex.what();
       cv_done.notify_all();
     }
+    {
+      std::unique_lock<std::mutex> tl(sh->turn_mtx);
+      sh->search_turn = cur->gseq + 1;
+    }
+    sh->turn_cv.notify_all();
     {
       std::unique_lock<std::mutex> lk(mtx);
       cur->seq = seq_pushed++;
@@ -1213,11 +1241,39 @@ int Engine::submit(const void* d_iq, uint32_t nsf_total, uint32_t start_tti, uin
     const uint32_t nchunks = (nsf_total + max_batch - 1) / max_batch;
     {
       std::unique_lock<std::mutex> lk(mtx);
-      front_jobs.push_back({d_iq, nsf_total, start_tti, update_meta_period});
+      front_jobs.push_back({d_iq, nsf_total, start_tti, update_meta_period, sh->next_gseq.fetch_add(nchunks)});
       chunks_expected += nchunks;
     }
     cv_front.notify_one();
     return LSN_SUCCESS;
+  } catch (const std::exception& ex) {
+    fprintf(stderr, "ltesniffer_amd: %s\n", ex.what());
+    return LSN_ERROR;
+  }
+}
+
+int Engine::submitFrom(const void* d_iq, int src_device, uint32_t nsf, uint32_t start_tti, uint32_t update_meta_period, hipStream_t stream)
+{
+  static const bool force_copy = getenv("LSN_FORCE_PEER_COPY") && atoi(getenv("LSN_FORCE_PEER_COPY"));  // tests: take the staging path on one GPU too
+  if (src_device == cfg.device && !force_copy) return submit(d_iq, nsf, start_tti, update_meta_period, stream);
+  if (!cell_set || nsf > max_batch) return LSN_ERROR_INVALID_INPUTS;
+  try {
+    HIP_CHECK(hipSetDevice(cfg.device));
+    if (!copy_stream) {
+      HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+      for (auto& e : copy_done) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    const size_t sf_stride = (size_t)cfg.nof_rx_antennas * cd.sflen * sizeof(cf32);
+    const uint32_t slot = peer_slot++ % 12u;  // the staging area holds twelve chunks
+    if (peer_marks[slot]) waitMark(peer_marks[slot]);
+    uint8_t* dst = (uint8_t*)d_iq_staging + (size_t)slot * max_batch * sf_stride;
+    // the copy is ordered behind the caller's stream (the source block) and in front of this engine's stage A
+    HIP_CHECK(hipEventRecord(ev_in, stream));
+    HIP_CHECK(hipStreamWaitEvent(copy_stream, ev_in, 0));
+    HIP_CHECK(hipMemcpyPeerAsync(dst, cfg.device, d_iq, src_device, (size_t)nsf * sf_stride, copy_stream));
+    const int rc = submit(dst, nsf, start_tti, update_meta_period, copy_stream);
+    peer_marks[slot] = submitMark();
+    return rc;
   } catch (const std::exception& ex) {
     fprintf(stderr, "ltesniffer_amd: %s\n", ex.what());
     return LSN_ERROR;
@@ -1239,6 +1295,8 @@ int Engine::wait()
         commit_error.clear();
         front_jobs.clear();
         chunks_expected = seq_written;
+        std::unique_lock<std::mutex> tl(sh->turn_mtx);
+        sh->search_turn = sh->commit_turn = sh->write_turn = sh->next_gseq.load();
       }
     }
     batch_open = false;

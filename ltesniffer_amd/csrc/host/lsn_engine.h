@@ -77,6 +77,7 @@ struct Chunk {
   std::vector<SpecRar> spec_rar;     // RA-RNTI grants decoded ahead of the search (front thread)
   bool busy = false;                 // owned by the pipeline (slot not reusable yet)
   uint64_t seq = 0;                  // position in the commit order
+  uint64_t gseq = 0;                 // global chunk number (SharedSeq turn taking)
   uint32_t trace_id = 0;             // chunk number inside its submit (LSN_TRACE)
   uint32_t update_meta_period = 0;   // of the submit this chunk belongs to
 };
@@ -104,9 +105,46 @@ struct JobRunner {
   lsn_perf_t perf{};
 };
 
+// The SEQUENTIAL host state of one cell: the FALCON search with its RNTI manager, the MCS-tracking database and the clocks both run on.
+// One engine owns one of these; the engines of a capture that is spread over several GPUs (lsn_phy_create_multi: chunk g goes to engine
+// g mod G) share one and take turns on it - chunk g is searched, committed and written when chunks 0 .. g-1 have been, whichever engine
+// holds them - so the record stream is the one a single engine would produce.
+struct SharedSeq {
+  std::unique_ptr<FalconSearch> search;
+  MCSTracking mcs_tracking;
+  std::atomic<float> default_p_a{0.0f};  // p-a of RNTIs without tracking entry (RA-RNTIs): readable by the search / front thread without mcs_mtx
+  std::mutex mcs_mtx;                     // commit thread (authoritative updates) vs the API getter; the decode threads read the prediction arrays below
+  // per RNTI: tracked table (0xFF: no entry) and p-a as of the last commit that touched the RNTI; relaxed atomics, prediction only
+  std::unique_ptr<std::atomic<uint8_t>[]> pred_table{new std::atomic<uint8_t>[65536]};
+  std::unique_ptr<std::atomic<float>[]> pred_p_a{new std::atomic<float>[65536]};
+  // a RAR the search has seen for this RNTI but the commit has not reached yet will reset the RNTI's table (update_rar_time_crnti): predict that
+  std::unique_ptr<std::atomic<uint32_t>[]> pred_rar_at{new std::atomic<uint32_t>[65536]};  // 1 + subframe count (search side) of the latest RAR naming the RNTI, 0 = none
+  std::atomic<uint32_t> commit_pos{0};    // subframes committed so far, published
+  uint32_t commit_sf_cnt = 0;             // subframes committed so far = the tracking database's clock (1 subframe = 1 ms)
+  uint32_t mcs_update_period = 5000;      // MCSTracking::get_interval() x 1000 subframes (LTESniffer_Core.cc:473-485); 0: never
+  uint64_t nof_mcs_db_updates = 0;
+  uint64_t sf_cnt = 0;                    // subframes searched so far
+  double search_time_us = 0;              // time_blindsearch of the statistics (PhyCommon.cc:111-112)
+  float est_cfo = 0;
+  bool force_meta_next = false;
+  // turn taking
+  std::atomic<uint64_t> next_gseq{0};     // global chunk numbers in submission order
+  std::mutex turn_mtx;
+  std::condition_variable turn_cv;
+  uint64_t search_turn = 0, commit_turn = 0, write_turn = 0;
+  SharedSeq()
+  {
+    for (uint32_t i = 0; i < 65536; i++) { pred_table[i].store(0xFF, std::memory_order_relaxed); pred_p_a[i].store(0.0f, std::memory_order_relaxed); pred_rar_at[i].store(0, std::memory_order_relaxed); }
+  }
+};
+
 class Engine {
 public:
-  explicit Engine(const lsn_phy_cfg_t& cfg);
+  explicit Engine(const lsn_phy_cfg_t& cfg, std::shared_ptr<SharedSeq> shared = nullptr);
+  std::shared_ptr<SharedSeq> sharedState() { return sh; }
+  int device() const { return cfg.device; }
+  // a block that lives on ANOTHER device (one capture spread over several GPUs): copied over the peer link into this engine's staging ring
+  int submitFrom(const void* d_iq, int src_device, uint32_t nsf, uint32_t start_tti, uint32_t update_meta_period, hipStream_t stream);
   ~Engine();
   int setCell(const lsn_cell_t& cell);
   bool hasCell() const { return cell_set; }
@@ -188,6 +226,7 @@ private:
   bool pinThisThread(void* saved_mask);   // bind the calling thread to the CPUs of the GPU's NUMA node
   void unpinThisThread(const void* saved_mask);
 
+  std::shared_ptr<SharedSeq> sh;  // (declared first: the reference members below bind to it)
   lsn_phy_cfg_t cfg;
   Cell cell;
   bool cell_set = false;
@@ -198,22 +237,22 @@ private:
   void* d_iq_staging = nullptr;
   hipStream_t copy_stream = nullptr;          // host -> staging copies of processHost
   hipEvent_t copy_done[3] = {};
+  uint64_t peer_marks[12] = {};               // submitFrom: staging slot -> mark of the chunk that used it last
+  uint32_t peer_slot = 0;
   size_t staging_sf = 0;
   Chunk chunks[NSLOTS];
   JobRunner runner_c[NDEC], runner_s, runner_f, runner_k;  // decode threads / search thread (on-demand RAR decodes) / front thread (speculative RAR decodes) / commit thread (on-demand decodes)
   static constexpr int NSTREAM_A = 4;        // stage A of consecutive chunks overlaps on the GPU (kernels of one stream serialise)
   hipStream_t stream_a[NSTREAM_A] = {};
   hipEvent_t ev_in = nullptr;
-  std::unique_ptr<FalconSearch> search;
-  MCSTracking mcs_tracking;
-  std::atomic<float> default_p_a{0.0f};  // p-a of RNTIs without tracking entry (RA-RNTIs): readable by the search / front thread without mcs_mtx
-  std::mutex mcs_mtx;  // commit thread (authoritative updates) vs the API getter; the decode threads read the prediction arrays below
-  // per RNTI: tracked table (0xFF: no entry) and p-a as of the last commit that touched the RNTI; relaxed atomics, prediction only
-  std::unique_ptr<std::atomic<uint8_t>[]> pred_table{new std::atomic<uint8_t>[65536]};
-  std::unique_ptr<std::atomic<float>[]> pred_p_a{new std::atomic<float>[65536]};
-  // a RAR the search has seen for this RNTI but the commit has not reached yet will reset the RNTI's table (update_rar_time_crnti): predict that
-  std::unique_ptr<std::atomic<uint32_t>[]> pred_rar_at{new std::atomic<uint32_t>[65536]};  // 1 + subframe count (search side) of the latest RAR naming the RNTI, 0 = none
-  std::atomic<uint32_t> commit_pos{0};                                                      // subframes committed so far, published
+  std::unique_ptr<FalconSearch>& search = sh->search;
+  MCSTracking& mcs_tracking = sh->mcs_tracking;
+  std::atomic<float>& default_p_a = sh->default_p_a;
+  std::mutex& mcs_mtx = sh->mcs_mtx;
+  std::unique_ptr<std::atomic<uint8_t>[]>& pred_table = sh->pred_table;
+  std::unique_ptr<std::atomic<float>[]>& pred_p_a = sh->pred_p_a;
+  std::unique_ptr<std::atomic<uint32_t>[]>& pred_rar_at = sh->pred_rar_at;
+  std::atomic<uint32_t>& commit_pos = sh->commit_pos;
   McsTable predictedTable(uint16_t rnti) const
   {
     const uint32_t ra = pred_rar_at[rnti].load(std::memory_order_relaxed);
@@ -224,9 +263,9 @@ private:
   float predictedPa(uint16_t rnti) const { return pred_table[rnti].load(std::memory_order_relaxed) == 0xFF ? default_p_a.load(std::memory_order_relaxed) : pred_p_a[rnti].load(std::memory_order_relaxed); }
   void publishPrediction(uint16_t rnti);
   void ageTrackingDatabase();
-  uint32_t commit_sf_cnt = 0;        // subframes committed so far = the tracking database's clock (1 subframe = 1 ms)
-  uint32_t mcs_update_period = 5000; // MCSTracking::get_interval() x 1000 subframes (LTESniffer_Core.cc:473-485); 0: never
-  uint64_t nof_mcs_db_updates = 0;
+  uint32_t& commit_sf_cnt = sh->commit_sf_cnt;
+  uint32_t& mcs_update_period = sh->mcs_update_period;
+  uint64_t& nof_mcs_db_updates = sh->nof_mcs_db_updates;
 public:
   void setMcsUpdateInterval(uint32_t seconds) { mcs_tracking.set_interval(seconds); mcs_update_period = seconds * 1000u; }
   void updateMcsDatabase() { std::lock_guard<std::mutex> lk(mcs_mtx); ageTrackingDatabase(); }  // between process calls only
@@ -234,7 +273,7 @@ public:
 private:
   // front thread: launches stage A chunk after chunk, hands finished chunks to the search (caller) thread
   std::thread front_thread;
-  struct FrontJob { const void* d_iq = nullptr; uint32_t nsf_total = 0, start_tti = 0, update_meta_period = 0; };
+  struct FrontJob { const void* d_iq = nullptr; uint32_t nsf_total = 0, start_tti = 0, update_meta_period = 0; uint64_t gseq0 = 0; };
   std::deque<FrontJob> front_jobs;            // submits not yet cut into chunks (front thread)
   uint64_t chunks_expected = 0;               // chunks of all submits so far; wait() returns when as many have been written
   std::thread search_thread;                  // stage B: the sequential FALCON search, chunk after chunk
@@ -265,12 +304,12 @@ private:
   bool batch_open = false;  // submits since the last wait()
   double t_batch = 0;
   lsn_perf_t perf{};
-  float est_cfo = 0;
+  float& est_cfo = sh->est_cfo;
   lsn_pdu_sink_t sink = nullptr; void* sink_user = nullptr;
-  uint64_t sf_cnt = 0;
-  double search_time_us = 0;  // time_blindsearch of the statistics (PhyCommon.cc:111-112)
+  uint64_t& sf_cnt = sh->sf_cnt;
+  double& search_time_us = sh->search_time_us;
   Chunk* last_chunk = nullptr;
-  bool force_meta_next = false;
+  bool& force_meta_next = sh->force_meta_next;
   // uplink
   lsn_ul_cfg_t ul_cfg{};
   bool ul_set = false;
