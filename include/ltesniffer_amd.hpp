@@ -7,8 +7,10 @@
 #pragma once
 #include "ltesniffer_amd.h"
 #include <complex>
+#include <cstdio>
 #include <memory>
 #include <stdexcept>
+#include <string>
 
 namespace lsn_amd {
 
@@ -18,7 +20,8 @@ class Phy;
 
 class SubframeWorker {
 public:
-  cf_t** getBuffers() { return reinterpret_cast<cf_t**>(lsn_worker_buffers(h)); }   // SubframeWorker.h:37
+  cf_t** getBuffers() { return reinterpret_cast<cf_t**>(lsn_worker_buffers(h)); }   // SubframeWorker.h:36
+  cf_t** getBuffers_offset() { return reinterpret_cast<cf_t**>(lsn_worker_buffers_offset(h)); }  // SubframeWorker.h:37
   uint32_t getBufferLen() const { return lsn_worker_buffer_len(h); }                // 3 * SF_LEN samples per antenna
   void prepare(uint32_t sf_idx, uint32_t sfn, bool updateMetaFormats, const lsn_dl_sf_cfg_t& dl_sf)  // SubframeWorker.h:32
   {
@@ -33,23 +36,75 @@ private:
   lsn_worker_t* h;
 };
 
+// Facades for the objects LTESniffer_Core still talks to after the swap.  Their state lives behind lsn_phy_t now; the facades forward the
+// calls the unchanged caller makes (LTESniffer_Core.cc:87,422-426,473-499,535-540,561,616,620).
+class RNTIManagerFacade {   // phy->getCommon().getRNTIManager()
+public:
+  void setHistogramThreshold(uint32_t threshold) { lsn_phy_set_histogram_threshold(h, threshold); }        // RNTIManager.cc:442-444
+  void addEvergreen(uint16_t a, uint16_t b, uint32_t formatIdx) { lsn_phy_add_evergreen(h, a, b, formatIdx); }
+  void addForbidden(uint16_t a, uint16_t b, uint32_t formatIdx) { lsn_phy_add_forbidden(h, a, b, formatIdx); }
+  uint32_t nofActive() { return lsn_phy_nof_active_rnti(h); }
+private:
+  friend class PhyCommonFacade;
+  friend class Phy;
+  lsn_phy_t* h = nullptr;
+};
+class PhyCommonFacade {     // phy->getCommon()
+public:
+  void setShortcutDiscovery(bool enable) { lsn_phy_set_shortcut_discovery(h, enable ? 1 : 0); }           // PhyCommon.cc:69-71
+  bool getShortcutDiscovery() const { return lsn_phy_get_shortcut_discovery(h) != 0; }
+  void printStats() { lsn_phy_print_stats(h, stats_file); }                                                // PhyCommon.cc:65-67
+  lsn_blind_stats_t getStats() { lsn_blind_stats_t s{}; lsn_phy_get_stats(h, &s); return s; }
+  RNTIManagerFacade& getRNTIManager() { return rm; }
+  FILE* getStatsFile() { return stats_file; }
+private:
+  friend class Phy;
+  lsn_phy_t* h = nullptr;
+  FILE* stats_file = nullptr;
+  RNTIManagerFacade rm;
+};
+// The caller's MCSTracking object (LTESniffer_Core.cc:422-426,473-499): the database it used to own is inside the library; what the main
+// loop calls on it keeps working.  The library ages the database by itself on the subframe count (lsn_phy_set_mcs_update_interval), so
+// update_database_dl() from the caller's wall-clock timer is an extra, idempotent update.
+class MCSTracking {
+public:
+  void attach(lsn_phy_t* phy) { h = phy; }
+  double get_interval() const { return interval; }
+  void set_interval(double seconds) { interval = seconds; if (h) lsn_phy_set_mcs_update_interval(h, (uint32_t)seconds); }
+  void update_database_dl() { if (h) lsn_phy_update_mcs_database(h); }
+  void update_database_ul() {}                         // UL tracking is aged inside the UL_MODE commit turn
+  uint32_t nof_RNTI_member_dl() { return h ? lsn_phy_nof_tracked_rnti(h) : 0; }
+  lsn_ue_config_t get_ue_config_rnti(uint16_t rnti) { lsn_ue_config_t c{}; if (h) lsn_phy_get_ue_config(h, rnti, &c); return c; }
+private:
+  lsn_phy_t* h = nullptr;
+  double interval = 5.0;                               // MCSTracking.h:162
+};
+class HARQ;        // HARQ.h: harq_mode is 0 in the reference (ArgManager.cc:50); accepted and ignored
+class ULSchedule;  // ULSchedule.h: the schedule lives inside the library; SIB2 values arrive through Phy::setUlConfig
+
 class Phy {
 public:
-  // Phy.h:24-36.  dciFileName / statsFileName / HARQ* / ULSchedule* of the reference are not consumed by this path.
-  Phy(uint32_t nof_rx_antennas, uint32_t nof_workers, bool skipSecondaryMetaFormats, double metaFormatSplitRatio, uint32_t histogramThreshold,
-      lsn_pcap_t* pcapwriter, int mcs_tracking_mode = 1, int harq_mode = 0, int device = 0, int sniffer_mode = 0 /* DL_MODE; 1 = UL_MODE */)
+  // Phy.h:24-36 - the reference's argument list, in its order.  dciFileName is not consumed (the DCI text log belongs to DCIToFile on the
+  // caller's side of the boundary), statsFileName receives printStats(); `pcapwriter` is this library's writer (lsn_pcap_open) or nullptr
+  // when the original LTESniffer_pcap_writer stays in use through setPduSink().  Trailing arguments are this library's own.
+  Phy(uint32_t nof_rx_antennas, uint32_t nof_workers, const std::string& dciFileName, const std::string& statsFileName, bool skipSecondaryMetaFormats,
+      double metaFormatSplitRatio, uint32_t histogramThreshold, lsn_pcap_t* pcapwriter, MCSTracking* mcs_tracking, HARQ* harq, int mcs_tracking_mode,
+      int harq_mode, ULSchedule* ulsche, int device = 0, int sniffer_mode = 0 /* DL_MODE; 1 = UL_MODE */, uint32_t max_batch = 0)
+      : nof_rx_antennas(nof_rx_antennas), nof_workers(nof_workers)
   {
-    lsn_phy_cfg_t cfg{};
-    cfg.nof_rx_antennas = nof_rx_antennas; cfg.nof_workers = nof_workers; cfg.skip_secondary_meta_formats = skipSecondaryMetaFormats;
-    cfg.meta_format_split_ratio = metaFormatSplitRatio; cfg.histogram_threshold = histogramThreshold;
-    cfg.mcs_tracking_mode = mcs_tracking_mode; cfg.harq_mode = harq_mode; cfg.device = device; cfg.sniffer_mode = sniffer_mode;
-    const int r = lsn_phy_create(&cfg, &h);
-    if (r == LSN_ERROR_NO_DEVICE) throw std::runtime_error("ltesniffer_amd: no HIP device (this library has no CPU path)");
-    if (r != LSN_SUCCESS) throw std::runtime_error("lsn_phy_create failed");
-    lsn_phy_setup_default_rnti_intervals(h);  // LTESniffer_Core.cc:398-417
-    if (pcapwriter) lsn_phy_set_pcap_writer(h, pcapwriter);
+    (void)dciFileName; (void)harq; (void)ulsche;
+    init(skipSecondaryMetaFormats, metaFormatSplitRatio, histogramThreshold, pcapwriter, mcs_tracking_mode, harq_mode, device, sniffer_mode, max_batch);
+    if (!statsFileName.empty()) common.stats_file = fopen(statsFileName.c_str(), "w");
+    if (mcs_tracking) mcs_tracking->attach(h);
   }
-  ~Phy() { lsn_phy_destroy(h); }
+  // short form (tests, new callers)
+  Phy(uint32_t nof_rx_antennas, uint32_t nof_workers, bool skipSecondaryMetaFormats, double metaFormatSplitRatio, uint32_t histogramThreshold,
+      lsn_pcap_t* pcapwriter, int mcs_tracking_mode = 1, int harq_mode = 0, int device = 0, int sniffer_mode = 0)
+      : nof_rx_antennas(nof_rx_antennas), nof_workers(nof_workers)
+  {
+    init(skipSecondaryMetaFormats, metaFormatSplitRatio, histogramThreshold, pcapwriter, mcs_tracking_mode, harq_mode, device, sniffer_mode, 0);
+  }
+  ~Phy() { lsn_phy_destroy(h); if (common.stats_file) fclose(common.stats_file); }
   Phy(const Phy&) = delete;
   Phy& operator=(const Phy&) = delete;
   bool setCell(const lsn_cell_t& cell) { return lsn_phy_set_cell(h, &cell) == LSN_SUCCESS; }               // Phy.cc:111
@@ -59,6 +114,12 @@ public:
   void joinPending() { lsn_phy_join_pending(h); }                                                           // Phy.cc:100
   void setPduSink(lsn_pdu_sink_t cb, void* user) { lsn_phy_set_pdu_sink(h, cb, user); }
   lsn_blind_stats_t getStats() { lsn_blind_stats_t s{}; lsn_phy_get_stats(h, &s); return s; }              // PhyCommon::getStats
+  PhyCommonFacade& getCommon() { return common; }                                                           // Phy.h:44
+  void printStats() { common.printStats(); }                                                               // Phy.cc:144
+  void setChestCFOEstimateEnable(bool, uint32_t) {}   // Phy.h:49-50: the estimator of this path always reports its CFO (getEstCfo)
+  void setChestAverageSubframe(bool) {}
+  void setRNTI(uint16_t) {}                           // Phy.h:48 (single-RNTI filter of the legacy path; unused by LTESniffer_Core)
+  uint32_t nof_rx_antennas, nof_workers;              // Phy.h:54-55
   float getEstCfo() { return lsn_phy_get_est_cfo(h); }                                                      // SubframeWorker.cc:203
   // UL_MODE: what ULSchedule::set_config hands to the workers once SIB2 is known (ULSchedule.cc:140-158)
   bool setUlConfig(uint32_t cyclicShift, uint32_t groupAssignmentPUSCH, uint32_t puschHoppingOffset = 0)    // SubframeWorker.cc:258-277
@@ -73,6 +134,21 @@ public:
   lsn_ue_config_t getUeConfig(uint16_t rnti) { lsn_ue_config_t c{}; lsn_phy_get_ue_config(h, rnti, &c); return c; }  // MCSTracking::get_ue_config_rnti
   lsn_phy_t* handle() { return h; }
 private:
+  void init(bool skipSecondaryMetaFormats, double metaFormatSplitRatio, uint32_t histogramThreshold, lsn_pcap_t* pcapwriter, int mcs_tracking_mode, int harq_mode,
+            int device, int sniffer_mode, uint32_t max_batch)
+  {
+    lsn_phy_cfg_t cfg{};
+    cfg.nof_rx_antennas = nof_rx_antennas; cfg.nof_workers = nof_workers; cfg.skip_secondary_meta_formats = skipSecondaryMetaFormats;
+    cfg.meta_format_split_ratio = metaFormatSplitRatio; cfg.histogram_threshold = histogramThreshold; cfg.max_batch = max_batch;
+    cfg.mcs_tracking_mode = mcs_tracking_mode; cfg.harq_mode = harq_mode; cfg.device = device; cfg.sniffer_mode = sniffer_mode;
+    const int r = lsn_phy_create(&cfg, &h);
+    if (r == LSN_ERROR_NO_DEVICE) throw std::runtime_error("ltesniffer_amd: no HIP device (this library has no CPU path)");
+    if (r != LSN_SUCCESS) throw std::runtime_error("lsn_phy_create failed");
+    lsn_phy_setup_default_rnti_intervals(h);  // LTESniffer_Core.cc:398-417
+    if (pcapwriter) lsn_phy_set_pcap_writer(h, pcapwriter);
+    common.h = h; common.rm.h = h;
+  }
+  PhyCommonFacade common;
   static std::shared_ptr<SubframeWorker> wrap(lsn_worker_t* w) { return w ? std::shared_ptr<SubframeWorker>(new SubframeWorker(w)) : nullptr; }
   lsn_phy_t* h = nullptr;
 };

@@ -9,8 +9,14 @@ int main()
   lsn_cell_search_t cs;
   if (lsn_amd::cellSearch(nullptr, 0, 6, cs) != LSN_ERROR_INVALID_INPUTS) { printf("cellSearch accepted a null buffer\n"); return 4; }
   try {
-    lsn_amd::Phy phy(/*nof_rx_antennas*/ 1, /*nof_workers*/ 4, /*skipSecondaryMetaFormats*/ false, /*metaFormatSplitRatio*/ 0.99, /*histogramThreshold*/ 5,
-                     /*pcapwriter*/ nullptr);
+    // the reference's own constructor call (LTESniffer_Core.cc:63-86), argument for argument
+    lsn_amd::MCSTracking mcs_tracking;
+    lsn_amd::Phy phy(/*nof_rx_antennas*/ 1, /*nof_workers*/ 4, /*dciFileName*/ "", /*statsFileName*/ "", /*skipSecondaryMetaFormats*/ false,
+                     /*metaFormatSplitRatio*/ 0.99, /*histogramThreshold*/ 5, /*pcapwriter*/ nullptr, &mcs_tracking, /*harq*/ nullptr, /*mcs_tracking_mode*/ 1,
+                     /*harq_mode*/ 0, /*ulsche*/ nullptr);
+    phy.getCommon().setShortcutDiscovery(true);                  // LTESniffer_Core.cc:87
+    phy.getCommon().getRNTIManager().setHistogramThreshold(5);   // :620
+    if (mcs_tracking.get_interval() != 5.0) return 5;
     lsn_cell_t c{25, 1, 7, 0, 0, 0, 0};
     if (!phy.setCell(c)) { printf("setCell failed\n"); return 2; }
     auto w = phy.getAvail();
@@ -21,6 +27,8 @@ int main()
     w->prepare(0, 0, true, sf);
     phy.putPending(w);
     phy.joinPending();
+    mcs_tracking.update_database_dl();                           // :473-499
+    phy.getCommon().printStats();                                // :561
     lsn_blind_stats_t st = phy.getStats();
     printf("device path ok: %u subframes\n", st.nof_subframes);
     return 0;

@@ -1,0 +1,28 @@
+"""`bench.py --gpus 2` launches its own two ranks (python -m torch.distributed.run, one process per rank) and reports n_gpus = 2: the
+multi-process path of BASELINE configs[4] (one cell per GPU, no data-path exchange) with the PRODUCT engine in every rank - two engines, two
+HIP contexts and two sets of pinned threads on one box.  On a one-GPU box both ranks share the GPU (LSN_DIST_BACKEND=gloo: RCCL needs one
+device per rank); the numbers are not a scaling result, the test checks the launch contract and that rank 0's stream still passes the parity
+gate while another rank loads the same GPU."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_spawns_two_product_ranks():
+    env = dict(os.environ, LSN_DIST_BACKEND="gloo")
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--reps", "1", "--nsf", "1600",
+                          "--gen", "400", "--cpu-sample", "200", "--batch", "100", "--no-legs"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stdout[-1500:] + out.stderr[-1500:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["cells"] == 2
+    assert j["value"] > 0 and j["pcap_diff"] == 0, j["parity"]
+    assert j["parity"]["oracle_records"] > 1000 and j["parity"]["timed_equals_sync"] is True
