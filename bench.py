@@ -320,6 +320,48 @@ def main():
         except Exception as ex:
             legs["error"] = str(ex)[:300]
 
+    # ---------------------------------------------------------------- the other BASELINE.json configurations, one short resident pass each
+    # (configs[1]: 20 MHz, 32 RNTIs, TM2 64QAM; configs[3]: 20 MHz UL+DL, 64 RNTIs, PUSCH at n + 4 with 16/64QAM turbo decodes) - context
+    # numbers next to the headline, never `value`; their parity is covered by tests/test_gpu_parity.py and tests/test_gpu_ul.py
+    if legs is not None and "error" not in legs:
+        try:
+            sc2 = scenario("cfg2", seed=2)
+            t2, iq2, _ = gen_subframes(sc2, 400)
+            d2 = torch.from_numpy(iq2.view(np.float32)).to(dev).repeat(8, 1, 1).contiguous()
+            w2 = la.PcapWriter(None)
+            w2.set_store(False)
+            p2 = la.Phy(nof_rx_antennas=sc2["nof_rx"], max_batch=batch, device=local, pcapwriter=w2)
+            p2.setCell(sc2["nof_prb"], sc2["nof_ports"], sc2["cell_id"])
+            n2 = d2.shape[0]
+            p2.process_device(d2.data_ptr(), n2, t2 % 10240, 500, stream)
+            t = time.perf_counter()
+            for r in range(4):
+                p2.submit_device(d2.data_ptr(), n2, (t2 + (r + 1) * n2) % 10240, 500, stream)
+            p2.wait()
+            dtl = time.perf_counter() - t
+            legs["cfg2_32_rnti_tm2_64qam"] = {"subframes_per_s": round(4 * n2 / dtl, 1), "subframes": 4 * n2, "records": w2.nof_records()}
+            p2.close()
+            del d2
+            from lsn_testlib import gen_ul_mode_subframes
+            sc4 = scenario("cfg2", seed=4, nof_rx=1, n_rnti=64, ul_min=2, ul_max=4, mcs_min=0, mcs_max=28, snr_db=28.0)
+            t4, iq4, sent4 = gen_ul_mode_subframes(sc4, 200, ul_snr_db=22.0)
+            h4 = torch.from_numpy(np.tile(iq4, (16, 1, 1))).pin_memory()
+            w4 = la.PcapWriter(None)
+            w4.set_store(False)
+            p4 = la.Phy(nof_rx_antennas=2, sniffer_mode=1, max_batch=200, device=local, pcapwriter=w4)
+            p4.setCell(sc4["nof_prb"], sc4["nof_ports"], sc4["cell_id"])
+            p4.setUlConfig(3, 5)
+            p4.process_host(h4.numpy(), t4 % 10240, 500)
+            w4.reset()
+            t = time.perf_counter()
+            p4.process_host(h4.numpy(), t4 % 10240, 500)
+            dtl = time.perf_counter() - t
+            legs["cfg4_ul_mode_64_rnti"] = {"subframes_per_s": round(h4.shape[0] / dtl, 1), "subframes": int(h4.shape[0]), "records": w4.nof_records(),
+                                            "pusch_sent_per_subframe": round(len(sent4) / 200.0, 2), "input": "host buffers (two antenna streams), PCIe included"}
+            p4.close()
+        except Exception as ex:
+            legs["other_configs_error"] = str(ex)[:300]
+
     if rank == 0:
         kms = np.array(p.kernel_ms[:])
         klaunch = np.array(p.kernel_launches[:])

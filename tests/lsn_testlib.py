@@ -517,7 +517,7 @@ def gen_ul_mode_subframes(sc, n, cyclic_shift=3, delta_ss=5, ul_snr_db=30.0):  #
         for g, p in zip(grants, pl):
             sent.append(dict(tti=tti, rnti=g["rnti"], payload=p, L_prb=g["L_prb"], mod=g["mod"], hop=g.get("hop", 0)))
         for p in pdus:
-            if p["is_ul"] and p["nof_prb"] >= 3:
+            if p["is_ul"] and p["nof_prb"] != 2:  # 2 PRB: no DMRS table (36.211 Table 5.5.1.2-2), the grant stays unanswered
                 qm, tbs = ul_mcs_to_mod_tbs(p["mcs"], p["nof_prb"], enable_64qam=(p["rnti"] % 2 == 0))
                 if tbs > 0:
                     # the UE acknowledges the downlink transport blocks it was sent in this subframe on the PUSCH 4 ms later and adds the
