@@ -60,7 +60,8 @@ typedef struct {
   int device;                       /* HIP device ordinal */
   int max_turbo_iterations;         /* SubframeWorker.cc:365, default 12 (0 = default) */
   int sniffer_mode;                 /* 0 = DL_MODE, 1 = UL_MODE (SubframeWorker.cc:166-199): antenna 0 = downlink, antenna 1 = uplink,
-                                       nof_rx_antennas must be 2; call lsn_phy_set_ul_config after lsn_phy_set_cell */
+                                       nof_rx_antennas must be 2; the uplink configuration comes from lsn_phy_set_ul_config (+ lsn_phy_set_prach_config)
+                                       or, when those are not called, from the first SIB2 decoded (PDSCH_Decoder::decode_SIB) */
 } lsn_phy_cfg_t;
 
 /* What LTESniffer_pcap_writer::pack_and_write receives (PcapWriter.cc:93-111) */
@@ -267,6 +268,20 @@ typedef struct {
 } lsn_pusch_grant_t;
 typedef struct { uint32_t crc_ok; uint32_t iterations; float snr_db; uint32_t payload_off; } lsn_pusch_result_t;
 int lsn_phy_set_ul_config(lsn_phy_t* phy, const lsn_ul_cfg_t* cfg);
+/* The SIB2 fields the sniffer reads (ULSchedule::set_config, ULSchedule.cc:140-158; SubframeWorker.cc:271-273). */
+typedef struct {
+  uint32_t n_sb, hopping_mode, pusch_hop_offset, enable_64qam;                                                  /* pusch-ConfigBasic */
+  uint32_t group_hopping_enabled, group_assignment_pusch, sequence_hopping_enabled, cyclic_shift;                /* ul-ReferenceSignalsPUSCH */
+  uint32_t root_seq_idx, prach_config_idx, high_speed_flag, zero_corr_zone, prach_freq_offset;                   /* prach-Config */
+} lsn_sib2_t;
+/* ULSchedule::get_config / getSIB2 (ULSchedule.h:90-93, DL_Sniffer_PDSCH.h:137): in UL_MODE without lsn_phy_set_ul_config the commit stage
+ * runs PDSCH_Decoder::decode_SIB (DL_Sniffer_PDSCH.cc:459-560) on every subframe until a SystemInformation with SIB2 decodes, writes
+ * that one SI-RNTI record, configures DMRS / hopping offset / PRACH detector from it and decodes PUSCH from the next subframe on.
+ * Returns 1 when an uplink configuration is in use (ul filled; *from_sib2 = 1 and sib2 filled when it was learned from SIB2), else 0.
+ * Any output pointer may be NULL.  Call between lsn_phy_wait and the next submit. */
+int lsn_phy_get_ul_config(lsn_phy_t* phy, lsn_ul_cfg_t* ul, lsn_sib2_t* sib2, uint32_t* from_sib2);
+/* BCCH-DL-SCH-Message -> SIB2 (the parser behind decode_SIB): 0 = does not unpack, 1 = unpacks without SIB2 in front, 2 = SIB2 (out filled) */
+int lsn_sib2_decode(const uint8_t* pdu, uint32_t len, lsn_sib2_t* out);
 /* ul_iq: [n_subframes][15*N] interleaved cf32 of the uplink antenna, host memory (iq_on_device = 0) or device memory (1).
  * payloads (may be NULL): decoded transport blocks, tbs/8 bytes each at results[i].payload_off. */
 int lsn_phy_pusch_decode(lsn_phy_t* phy, const void* ul_iq, int iq_on_device, uint32_t n_subframes, uint32_t start_tti,

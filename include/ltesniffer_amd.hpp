@@ -127,6 +127,14 @@ public:
     lsn_ul_cfg_t u{cyclicShift, groupAssignmentPUSCH, puschHoppingOffset};
     return lsn_phy_set_ul_config(h, &u) == LSN_SUCCESS;
   }
+  // ULSchedule::get_config + getSIB2: true once a configuration is in use (given, or learned from the first SIB2 in UL_MODE)
+  bool getUlConfig(lsn_ul_cfg_t* ul = nullptr, lsn_sib2_t* sib2 = nullptr, bool* fromSib2 = nullptr)
+  {
+    uint32_t f = 0;
+    const bool ok = lsn_phy_get_ul_config(h, ul, sib2, &f) == 1;
+    if (fromSib2) *fromSib2 = f != 0;
+    return ok;
+  }
   bool setRachConfig(const lsn_prach_cfg_t& p) { return lsn_phy_set_prach_config(h, &p) == LSN_SUCCESS; }    // PUSCH_Decoder::set_rach_config
   void setPrachSink(lsn_prach_sink_t cb, void* user) { lsn_phy_set_prach_sink(h, cb, user); }               // work_prach's report
   // srsran_ue_mib_decode + srsran_pbch_mib_unpack on one subframe 0 (LTESniffer_Core.cc:386-391); true when a MIB was found

@@ -29,7 +29,7 @@ EXPORTS = ["lsn_phy_create", "lsn_phy_destroy", "lsn_phy_set_cell", "lsn_phy_get
            "lsn_worker_sf_idx", "lsn_worker_sfn", "lsn_phy_process_device", "lsn_phy_process_host", "lsn_phy_tap",
            "lsn_phy_get_perf", "lsn_kernel_name", "lsn_version", "lsn_pcap_open", "lsn_pcap_open_mem",
            "lsn_pcap_set_wall_clock", "lsn_pcap_write", "lsn_pcap_sink", "lsn_pcap_mem", "lsn_pcap_nof_records",
-           "lsn_pcap_reset", "lsn_pcap_close", "lsn_phy_set_pcap_writer", "lsn_phy_set_ul_config", "lsn_phy_pusch_decode",
+           "lsn_pcap_reset", "lsn_pcap_close", "lsn_phy_set_pcap_writer", "lsn_phy_set_ul_config", "lsn_phy_get_ul_config", "lsn_sib2_decode", "lsn_phy_pusch_decode",
            "lsn_phy_tap_ul", "lsn_phy_set_prach_config", "lsn_phy_prach_detect", "lsn_phy_set_prach_sink", "lsn_prach_tti_opportunity", "lsn_phy_process_file", "lsn_phy_mib_decode", "lsn_phy_mib_decode_llr", "lsn_phy_submit_device", "lsn_phy_wait", "lsn_cell_search",
            "lsn_phy_set_shortcut_discovery", "lsn_phy_get_shortcut_discovery", "lsn_phy_set_histogram_threshold", "lsn_phy_print_stats",
            "lsn_phy_set_mcs_update_interval", "lsn_phy_update_mcs_database", "lsn_phy_nof_tracked_rnti", "lsn_worker_buffers_offset", "lsn_pcap_digest", "lsn_pcap_set_store", "lsn_phy_create_multi", "lsn_phy_nof_devices"]
@@ -62,6 +62,22 @@ class CellSearch(C.Structure):
 
 class FileCfg(C.Structure):
     _fields_ = [("nof_antennas", C.c_uint32), ("offset_time_samples", C.c_int64), ("offset_freq_hz", C.c_float)]
+
+
+class Sib2(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("n_sb", "hopping_mode", "pusch_hop_offset", "enable_64qam", "group_hopping_enabled", "group_assignment_pusch",
+                                          "sequence_hopping_enabled", "cyclic_shift", "root_seq_idx", "prach_config_idx", "high_speed_flag",
+                                          "zero_corr_zone", "prach_freq_offset")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+def sib2_decode(pdu):
+    """BCCH-DL-SCH-Message -> (verdict 0 / 1 / 2, dict of the SIB2 fields or None)"""
+    s = Sib2()
+    r = lib().lsn_sib2_decode(bytes(pdu), len(pdu), C.byref(s))
+    return r, (s.as_dict() if r == 2 else None)
 
 
 class PrachCfg(C.Structure):
@@ -225,6 +241,8 @@ def lib():
         L.lsn_pcap_close.restype = None
         L.lsn_phy_set_pcap_writer.argtypes = [C.c_void_p, C.c_void_p]
         L.lsn_phy_set_ul_config.argtypes = [C.c_void_p, C.POINTER(UlCfg)]
+        L.lsn_phy_get_ul_config.argtypes = [C.c_void_p, C.POINTER(UlCfg), C.POINTER(Sib2), C.POINTER(C.c_uint32)]
+        L.lsn_sib2_decode.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(Sib2)]
         L.lsn_phy_pusch_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
                                            C.c_void_p, C.c_size_t]
         L.lsn_phy_tap_ul.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_size_t]
@@ -465,6 +483,14 @@ class Phy:
     def setUlConfig(self, cyclic_shift, delta_ss, hopping_offset=0):
         u = UlCfg(cyclic_shift, delta_ss, hopping_offset)
         return lib().lsn_phy_set_ul_config(self._h, C.byref(u)) == LSN_SUCCESS
+
+    def getUlConfig(self):
+        """None until an uplink configuration is in use, else dict(cyclic_shift, delta_ss, hopping_offset, from_sib2, sib2 = dict or None)"""
+        u, s, f = UlCfg(), Sib2(), C.c_uint32(0)
+        if lib().lsn_phy_get_ul_config(self._h, C.byref(u), C.byref(s), C.byref(f)) != 1:
+            return None
+        return dict(cyclic_shift=u.cyclic_shift, delta_ss=u.delta_ss, hopping_offset=u.hopping_offset, from_sib2=bool(f.value),
+                    sib2=s.as_dict() if f.value else None)
 
     def pusch_decode(self, ul_iq, start_tti, grants):
         """ul_iq: complex64 [n_subframes, 15*N]; grants: list of dict(sf, rnti, n_dmrs, n_prb, L_prb, mod, tbs, rv)

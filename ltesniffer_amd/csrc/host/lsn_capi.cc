@@ -405,6 +405,31 @@ int lsn_phy_set_ul_config(lsn_phy_t* phy, const lsn_ul_cfg_t* cfg)
   if (!phy || !cfg) return LSN_ERROR_INVALID_INPUTS;
   return phy->engine->setUlConfig(*cfg);
 }
+static void sib2_to_c(const lsn::Sib2Config& c, lsn_sib2_t* o)
+{
+  o->n_sb = c.n_sb; o->hopping_mode = c.hopping_mode; o->pusch_hop_offset = c.pusch_hop_offset; o->enable_64qam = c.enable_64qam;
+  o->group_hopping_enabled = c.group_hopping_enabled; o->group_assignment_pusch = c.group_assignment_pusch;
+  o->sequence_hopping_enabled = c.sequence_hopping_enabled; o->cyclic_shift = c.cyclic_shift;
+  o->root_seq_idx = c.root_seq_idx; o->prach_config_idx = c.prach_config_idx; o->high_speed_flag = c.high_speed_flag;
+  o->zero_corr_zone = c.zero_corr_zone; o->prach_freq_offset = c.prach_freq_offset;
+}
+int lsn_phy_get_ul_config(lsn_phy_t* phy, lsn_ul_cfg_t* ul, lsn_sib2_t* sib2, uint32_t* from_sib2)
+{
+  if (!phy) return LSN_ERROR_INVALID_INPUTS;
+  lsn::Sib2Config s;
+  if (!phy->engine->getUlConfig(ul, nullptr, &s)) return 0;
+  if (sib2) sib2_to_c(s, sib2);
+  if (from_sib2) *from_sib2 = phy->engine->sib2Learned() ? 1u : 0u;
+  return 1;
+}
+int lsn_sib2_decode(const uint8_t* pdu, uint32_t len, lsn_sib2_t* out)
+{
+  if (!pdu || !out) return LSN_ERROR_INVALID_INPUTS;
+  lsn::Sib2Config s;
+  const int r = lsn::sib2_decode(pdu, (int)len, s);
+  if (r == 2) sib2_to_c(s, out);
+  return r;
+}
 int lsn_phy_pusch_decode(lsn_phy_t* phy, const void* ul_iq, int iq_on_device, uint32_t n_subframes, uint32_t start_tti,
                          const lsn_pusch_grant_t* grants, uint32_t n_grants, lsn_pusch_result_t* results, uint8_t* payloads, size_t payload_cap)
 {

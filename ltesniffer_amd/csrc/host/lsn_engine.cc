@@ -213,6 +213,8 @@ int Engine::setCell(const lsn_cell_t& c)
     freeDevice();
     cell.nof_prb = c.nof_prb; cell.nof_ports = c.nof_ports; cell.id = c.id; cell.phich_ng_x6 = ng_x6[c.phich_resources];
     buildTables();
+    sib2_learned = false;
+    if (cfg.sniffer_mode == 1) uploadUlStatic();
   } catch (const std::exception& ex) {
     fprintf(stderr, "ltesniffer_amd: %s\n", ex.what());
     return LSN_ERROR;
@@ -687,6 +689,7 @@ void Engine::planJobs(Chunk& ch, JobRunner& r)
   std::vector<int> wave;
   struct Pending { uint32_t sf; size_t di; bool always; };
   std::vector<Pending> retry;
+  ch.ul_epoch = ul_cfg_epoch.load(std::memory_order_acquire);
   for (uint32_t sf = 0; sf < ch.nsf; sf++) search->finishSubframe(ch.ctx[sf]);  // DCI unpack, grants and collision statistics of every accepted DCI (deferred from the sequential search)
   for (uint32_t sf = 0; sf < ch.nsf; sf++) {
     SubframeCtx& c = ch.ctx[sf];
@@ -695,7 +698,7 @@ void Engine::planJobs(Chunk& ch, JobRunner& r)
       DlEntry& e = c.dl[di];
       if (!e.unpack_ok) continue;
       if (cfg.sniffer_mode == 1) {  // decode_ul_mode: RAR + format 1 / 1A (not SI) with the 64QAM table only
-        if (!ulModeDecodesDl(e)) continue;
+        if (!(ul_set ? ulModeDecodesDl(e) : e.rnti == SIRNTI)) continue;  // before the SIB2 configuration: decode_SIB (a prediction, commit decides)
         if (e.job[0] < 0) e.job[0] = newJob(ch, sf, e, 0);
         if (e.job[0] >= 0) wave.push_back(e.job[0]);
         continue;

@@ -63,6 +63,7 @@ struct Chunk {
   LsnCand* h_cand = nullptr; float* h_ccepow = nullptr; LsnChest* h_chest = nullptr; uint32_t* h_cfi = nullptr; float* h_rbp = nullptr;
   uint32_t* h_sfidx = nullptr;
   std::vector<SubframeCtx> ctx;
+  uint32_t ul_epoch = 0;             // Engine::ul_cfg_epoch when the DCI 0 grants of this chunk were converted
   std::vector<DecodeJob> jobs;
   std::vector<JobRes> jres;            // per job, same index as jobs
   std::vector<CommitDci> cdci;         // built by planJobs
@@ -171,6 +172,9 @@ public:
   uint32_t maxBatch() const { return max_batch; }
   void setupDefaultIntervals() { search->setupDefaultIntervals(); }
   int setUlConfig(const lsn_ul_cfg_t& u);
+  void uploadUlStatic();   // tables of the uplink OFDM demodulator that do not depend on SIB2
+  bool getUlConfig(lsn_ul_cfg_t* u, lsn_prach_cfg_t* p, Sib2Config* sib) const;
+  bool sib2Learned() const { return sib2_learned; }
   int puschDecode(const void* ul_iq, bool on_device, uint32_t nsf, uint32_t start_tti, const lsn_pusch_grant_t* grants, uint32_t ngrants,
                   lsn_pusch_result_t* results, uint8_t* payloads, size_t payload_cap);
   long tapUl(int what, uint32_t index, void* out, size_t cap);
@@ -199,7 +203,7 @@ private:
   void ensureJob(Chunk& ch, JobRunner& r, int j);
   void commitChunk(Chunk& ch, JobRunner& r);
   void commitChunkUl(Chunk& ch, JobRunner& r);
-  void prachDetectDev(const cf32* d_iq, uint32_t nant, uint32_t ant, uint32_t nsf, uint32_t start_tti, std::vector<lsn_prach_det_t>& out);
+  void prachDetectDev(const cf32* d_iq, uint32_t nant, uint32_t ant, uint32_t nsf, uint32_t start_tti, std::vector<lsn_prach_det_t>& out, uint32_t first_sf = 0);
   void puschDecodeGrid(const cf32* d_grid, uint32_t nsf, uint32_t start_tti, const lsn_pusch_grant_t* grants, uint32_t ngrants,
                        lsn_pusch_result_t* results, std::vector<uint8_t>& payload_out);
   // RA-RNTI grants whose content feeds the RNTI manager: DL mode 2..9 (rnti_name == RA_RNTI, DL_Sniffer_PDSCH.cc:1409), UL mode 1..10 (:373)
@@ -313,6 +317,9 @@ private:
   // uplink
   lsn_ul_cfg_t ul_cfg{};
   bool ul_set = false;
+  std::atomic<uint32_t> ul_cfg_epoch{0};  // bumped by every (re)configuration: chunks whose DCI 0 grants were converted earlier are converted again at commit
+  bool sib2_learned = false; Sib2Config sib2;  // the SIB2 the UL-mode commit stage configured itself from (decode_SIB), if any
+  bool decodeSib(Chunk& ch, JobRunner& r, uint32_t sf, Sib2Config& out, size_t& payload_off, uint32_t& len, uint8_t& tb);
   std::vector<int> ul_off;       // allocation size L -> offset into ul_base / ul_idft (-1: unsupported)
   uint32_t ul_npn[20] = {0};
   struct UlSchedGrant { uint16_t rnti = 0; PuschGrant g, g256; uint32_t n_dmrs = 0; bool hopping = false, is_rar = false; uint32_t nof_ack = 0; bool cqi_req = false; };

@@ -164,6 +164,16 @@ struct UeSpecConfig {  // ltesniffer_ue_spec_config_t, MCSTracking.h:37-43
 // PDSCH_Decoder::decode_rrc_connection_setup: true when the CCCH SDU is an RRCConnectionSetup (out filled)
 bool rrc_conn_setup_decode(const uint8_t* sdu, int len, UeSpecConfig& out);
 
+// SystemInformationBlockType2 as far as the sniffer uses it (ULSchedule::set_config, ULSchedule.cc:140-158; SubframeWorker.cc:271-273)
+struct Sib2Config {
+  uint32_t n_sb = 1, hopping_mode = 0, pusch_hop_offset = 0, enable_64qam = 0;            // pusch-ConfigBasic
+  uint32_t group_hopping_enabled = 0, group_assignment_pusch = 0, sequence_hopping_enabled = 0, cyclic_shift = 0;  // ul-ReferenceSignalsPUSCH
+  uint32_t root_seq_idx = 0, prach_config_idx = 0, high_speed_flag = 0, zero_corr_zone = 0, prach_freq_offset = 0;  // prach-Config
+};
+// PDSCH_Decoder::decode_SIB, DL_Sniffer_PDSCH.cc:531-557: 0 = not a BCCH-DL-SCH message that unpacks, 1 = unpacks but carries no SIB2
+// (SystemInformationBlockType1, or a SystemInformation whose first entry is another block), 2 = SIB2 found (out filled)
+int sib2_decode(const uint8_t* pdu, int len, Sib2Config& out);
+
 // ---- MCSTracking (DL table learning + UE-specific configuration + database ageing; MCSTracking.cc:758-927,1269-1400,1444-1540) ----
 // Time is counted in SUBFRAMES processed so far (`now`), not in clock() ticks: the reference ages its database by CPU time consumed
 // (MCSTracking.cc:778,854-858), i.e. by replay speed; one subframe = 1 ms of air time is the deterministic equivalent.

@@ -103,12 +103,12 @@ int Engine::setPrachConfig(const lsn_prach_cfg_t& p)
 }
 
 // detection on the subframes of d_iq ([sf][nant][sflen], antenna `ant`) that are PRACH occasions; stream runner_u.  Throws on HIP errors.
-void Engine::prachDetectDev(const cf32* d_iq, uint32_t nant, uint32_t ant, uint32_t nsf, uint32_t start_tti, std::vector<lsn_prach_det_t>& out)
+void Engine::prachDetectDev(const cf32* d_iq, uint32_t nant, uint32_t ant, uint32_t nsf, uint32_t start_tti, std::vector<lsn_prach_det_t>& out, uint32_t first_sf)
 {
   out.clear();
   std::vector<uint64_t> off;
   std::vector<uint32_t> occ_sf;
-  for (uint32_t s = 0; s < nsf; s++)
+  for (uint32_t s = first_sf; s < nsf; s++)
     if (prach_tti_opportunity(prach.cfg.config_idx, (start_tti + s) % 10240u)) { off.push_back(((uint64_t)s * nant + ant) * cd.sflen); occ_sf.push_back(s); }
   const uint32_t nocc = (uint32_t)off.size();
   prach.last_nocc = nocc;

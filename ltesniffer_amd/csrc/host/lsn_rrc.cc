@@ -234,4 +234,84 @@ bool rrc_conn_setup_decode(const uint8_t* sdu, int len, UeSpecConfig& out)
   return true;
 }
 
+// BCCH-DL-SCH-Message (TS 36.331 6.2.1 / 6.2.2 / 6.3.1 / 6.3.2, UPER).  The reference unpacks the whole message with srsRAN's generated
+// code and then looks for a sib2 entry in sib-TypeAndInfo (DL_Sniffer_PDSCH.cc:531-557).  Here the walk covers the message head and a
+// complete SystemInformationBlockType2 (root components read, extension additions skipped by their length determinants).  SIB2 is always
+// the first entry of the SI message that carries it (36.331 5.2.1.2 / 6.2.2: schedulingInfoList's first SI message implicitly starts with
+// it); entries behind it are not unpacked (the reference would also reject a message whose LATER blocks do not unpack).
+int sib2_decode(const uint8_t* pdu, int len, Sib2Config& out)
+{
+  BitReader b{pdu, len > 0 ? 8u * (uint32_t)len : 0u};
+  if (b.flag()) return 0;                    // BCCH-DL-SCH-MessageType: c1
+  if (b.flag()) return b.err ? 0 : 1;        // c1: systemInformationBlockType1 ("do nothing")
+  if (b.flag()) return 0;                    // criticalExtensions: systemInformation-r8
+  b.flag();                                  // nonCriticalExtension present
+  b.get(5);                                  // sib-TypeAndInfo: SIZE (1..32)
+  if (b.flag()) return 0;                    // entry CHOICE: extension alternative (sib12 ...) never in front of SIB2
+  const uint32_t alt = b.get(4);             // sib2, sib3, ... sib11
+  if (b.err || alt > 9) return 0;
+  if (alt != 0) return 1;
+  Sib2Config o;
+  // ---- SystemInformationBlockType2 ----
+  const bool sibExt = b.flag(), acBarring = b.flag(), mbsfn = b.flag();
+  if (acBarring) {
+    const bool sig = b.flag(), data = b.flag();
+    b.get(1);                                // ac-BarringForEmergency
+    if (sig) { b.get(4); b.get(3); b.get(5); }
+    if (data) { b.get(4); b.get(3); b.get(5); }
+  }
+  // RadioResourceConfigCommonSIB
+  const bool rrExt = b.flag();
+  {  // rach-ConfigCommon
+    const bool ext = b.flag(), groupA = b.flag();
+    b.get(4);                                // numberOfRA-Preambles
+    if (groupA) {
+      const bool gext = b.flag();
+      b.integer(0, 14); b.get(2); b.get(3);  // sizeOfRA-PreamblesGroupA, messageSizeGroupA, messagePowerOffsetGroupB
+      if (gext) b.skipExtensions();
+    }
+    b.get(2); b.get(4);                      // powerRampingParameters
+    b.integer(0, 10); b.get(3); b.get(3);    // ra-SupervisionInfo
+    b.get(3);                                // maxHARQ-Msg3Tx
+    if (ext) b.skipExtensions();
+  }
+  b.get(2);                                  // bcch-Config
+  b.get(2); b.get(3);                        // pcch-Config
+  o.root_seq_idx = b.integer(0, 837);        // prach-Config
+  o.prach_config_idx = b.get(6); o.high_speed_flag = b.get(1); o.zero_corr_zone = b.get(4); o.prach_freq_offset = b.integer(0, 94);
+  b.integer(0, 110); b.get(2);               // pdsch-ConfigCommon: referenceSignalPower (-60..50), p-b
+  o.n_sb = b.get(2) + 1; o.hopping_mode = b.get(1); o.pusch_hop_offset = b.integer(0, 98); o.enable_64qam = b.get(1);
+  o.group_hopping_enabled = b.get(1); o.group_assignment_pusch = b.integer(0, 29); o.sequence_hopping_enabled = b.get(1); o.cyclic_shift = b.get(3);
+  b.integer(0, 2); b.integer(0, 98); b.get(3); b.get(11);  // pucch-ConfigCommon
+  if (b.flag()) {                            // soundingRS-UL-ConfigCommon: setup
+    b.flag();                                // srs-MaxUpPts present (one enumeration value: no bits)
+    b.get(3); b.get(4); b.get(1);
+  }
+  b.integer(0, 150); b.get(3); b.get(5);     // uplinkPowerControlCommon: p0-NominalPUSCH (-126..24), alpha, p0-NominalPUCCH
+  b.integer(0, 2); b.integer(0, 2); b.get(2); b.integer(0, 2); b.integer(0, 2);  // deltaFList-PUCCH
+  b.get(3);                                  // deltaPreambleMsg3
+  b.get(1);                                  // ul-CyclicPrefixLength
+  if (rrExt) b.skipExtensions();
+  {  // ue-TimersAndConstants
+    const bool ext = b.flag();
+    b.get(3); b.get(3); b.integer(0, 6); b.get(3); b.integer(0, 6); b.get(3);
+    if (ext) b.skipExtensions();
+  }
+  {  // freqInfo
+    const bool carrier = b.flag(), bw = b.flag();
+    if (carrier) b.get(16);
+    if (bw) b.integer(0, 5);
+    b.get(5);
+  }
+  if (mbsfn) {
+    const uint32_t n = b.get(3) + 1;
+    for (uint32_t i = 0; i < n && !b.err; i++) { b.integer(0, 5); b.get(3); if (b.flag()) b.get(24); else b.get(6); }
+  }
+  b.get(3);                                  // timeAlignmentTimerCommon
+  if (sibExt) b.skipExtensions();
+  if (b.err) return 0;
+  out = o;
+  return 2;
+}
+
 }  // namespace lsn

@@ -40,6 +40,25 @@ static T* upload_vec(std::vector<void*>& allocs, const std::vector<T>& v)
   return (T*)d;
 }
 
+// 7.5 kHz shift of the SC-FDMA demodulator: needed by the uplink OFDM stage of every chunk, also before SIB2 is known
+void Engine::uploadUlStatic()
+{
+  if (cd.ul_shift) return;
+  const int N = (int)cd.N;
+  std::vector<cf32> sh((size_t)N);
+  for (int n = 0; n < N; n++) { const double a = M_PI * n / N; sh[n] = {(float)std::cos(a), (float)(-std::sin(a))}; }
+  cd.ul_shift = upload_vec(dev_allocs, sh);
+}
+
+bool Engine::getUlConfig(lsn_ul_cfg_t* u, lsn_prach_cfg_t* p, Sib2Config* sib) const
+{
+  if (!ul_set) return false;
+  if (u) *u = ul_cfg;
+  if (p) { *p = prach.cfg; if (!prach.set) p->config_idx = 0xFFFFFFFFu; }
+  if (sib) *sib = sib2;
+  return true;
+}
+
 // srsran_enb_ul_set_cell with the DMRS configuration of SIB2 (SubframeWorker.cc:258-262, ULSchedule.cc:140-158)
 int Engine::setUlConfig(const lsn_ul_cfg_t& u)
 {
@@ -47,8 +66,8 @@ int Engine::setUlConfig(const lsn_ul_cfg_t& u)
   try {
     HIP_CHECK(hipSetDevice(cfg.device));
     const int N = (int)cd.N;
-    std::vector<cf32> sh((size_t)N), ph(12), base, idft;
-    for (int n = 0; n < N; n++) { const double a = M_PI * n / N; sh[n] = {(float)std::cos(a), (float)(-std::sin(a))}; }
+    (void)N;
+    std::vector<cf32> ph(12), base, idft;
     for (int m = 0; m < 12; m++) { const double a = 2.0 * M_PI * m / 12.0; ph[m] = {(float)std::cos(a), (float)std::sin(a)}; }
     const uint32_t fss = ((cell.id % 30u) + u.delta_ss) % 30u;  // group hopping off: u = f_ss^PUSCH, v = 0
     ul_off.assign(111, -1);
@@ -69,7 +88,7 @@ int Engine::setUlConfig(const lsn_ul_cfg_t& u)
       }
       for (int k = 0; k < M; k++) { const double a = 2.0 * M_PI * k / M; idft.push_back({(float)std::cos(a), (float)std::sin(a)}); }
     }
-    cd.ul_shift = upload_vec(dev_allocs, sh);
+    uploadUlStatic();
     cd.ul_ph12 = upload_vec(dev_allocs, ph);
     cd.ul_base = upload_vec(dev_allocs, base);
     cd.ul_idft = upload_vec(dev_allocs, idft);
@@ -85,6 +104,8 @@ int Engine::setUlConfig(const lsn_ul_cfg_t& u)
     cell.pusch_hop_offset = u.hopping_offset;  // n_rb_ho of the DCI 0 -> grant conversion from now on (SubframeWorker.cc:271-277)
     search->setPuschHopOffset(u.hopping_offset);
     ul_set = true;
+    sib2_learned = false;
+    ul_cfg_epoch.fetch_add(1, std::memory_order_release);
     if (!runner_u.stream) allocRunner(runner_u);
     return LSN_SUCCESS;
   } catch (const std::exception& ex) {

@@ -4,7 +4,8 @@
 //   unpack_rar_response_ul_mode        /root/reference/src/src/DL_Sniffer_PDSCH.cc:632-671   (Msg3 grant of the RAR)
 //   ULSchedule push / get              /root/reference/src/src/ULSchedule.cc:11-138          (DCI 0 -> PUSCH 4 subframes later, RAR grant 6)
 //   PUSCH_Decoder::decode / decode_run /root/reference/src/src/UL_Sniffer_PUSCH.cc:250-310,389-583 (modulation-table trials, UL MCS tracking)
-// SIB2 is not parsed (ASN.1 is out of scope): the DMRS configuration comes from lsn_phy_set_ul_config.
+//   PDSCH_Decoder::decode_SIB          /root/reference/src/src/DL_Sniffer_PDSCH.cc:459-560   (until the uplink configuration is known)
+// The uplink configuration comes from lsn_phy_set_ul_config / lsn_phy_set_prach_config or, like in the reference, from the first SIB2 seen.
 // The whole function runs in the chunk's commit turn, i.e. strictly in TTI order; PUSCH attempts of a chunk are decoded in
 // up to three batched waves (first / second / third attempt of the reference's trial order) and looked up by the sequential
 // logic, which falls back to an on-demand decode when the MCS-tracking state moved inside the chunk.
@@ -23,30 +24,63 @@ struct AttemptResult { bool crc = false; std::vector<uint8_t> payload; };
 struct PendingPdu { bool ul; char name; uint16_t rnti; uint8_t tb; size_t off; std::vector<uint8_t> own; uint32_t len; };
 }  // namespace
 
+// PDSCH_Decoder::decode_SIB (DL_Sniffer_PDSCH.cc:459-560): every SI-RNTI grant of the subframe is decoded with the 64QAM table until a
+// transport block carries a SystemInformation with SIB2; that block is the only record the subframe writes
+bool Engine::decodeSib(Chunk& ch, JobRunner& r, uint32_t sf, Sib2Config& out, size_t& payload_off, uint32_t& len, uint8_t& tb_out)
+{
+  SubframeCtx& c = ch.ctx[sf];
+  for (auto& e : c.dl) {
+    if (e.rnti != SIRNTI || !e.unpack_ok) continue;
+    if (e.job[0] < 0) e.job[0] = newJob(ch, sf, e, 0);
+    const int j = e.job[0];
+    if (j < 0) continue;
+    if (!ch.jobs[j].done) { ensureJob(ch, r, j); r.perf.nof_ondemand_decodes++; }
+    const DecodeJob& job = ch.jobs[j];
+    for (int tb = 0; tb < 2; tb++) {
+      if (!job.crc[tb]) continue;
+      const uint32_t n = (uint32_t)(job.grant.tb[tb].tbs / 8);
+      if (sib2_decode(ch.h_payload.data() + job.payload_off[tb], (int)n, out) == 2) { payload_off = (size_t)job.payload_off[tb]; len = n; tb_out = (uint8_t)tb; return true; }
+    }
+  }
+  return false;
+}
+
 void Engine::commitChunkUl(Chunk& ch, JobRunner& r)
 {
   if (ulmod.empty()) ulmod.assign(65536, 0);
-  if (!ul_set) throw std::runtime_error("UL_MODE: lsn_phy_set_ul_config has not been called");
   const uint32_t nsf = ch.nsf;
   std::vector<std::vector<PendingPdu>> out(nsf);            // records per subframe: downlink first, then uplink
   std::vector<std::vector<UlSchedGrant>> lists(nsf);        // PUSCH grants to try in each subframe
-
-  // ---- PRACH occasions of this chunk (PUSCH_Decoder::work_prach, UL_Sniffer_PUSCH.cc:656-713; no effect on the pcap) ----
-  if (prach.set && ch.d_iq_src) {
-    std::vector<lsn_prach_det_t> det;
-    prachDetectDev(ch.d_iq_src, cd.iq_nant, 1, nsf, ch.start_tti, det);
-    for (size_t a = 0; a < det.size();) {
-      size_t b = a;
-      while (b < det.size() && det[b].sf == det[a].sf) b++;
-      if (prach_sink) prach_sink(prach_sink_user, (ch.start_tti + det[a].sf) % 10240u, det.data() + a, (uint32_t)(b - a));
-      a = b;
-    }
-  }
+  auto reconvert = [&](uint32_t from) {  // DCI 0 -> grant conversions done before the (re)configuration used another pusch-HoppingOffset
+    for (uint32_t s = from; s < nsf; s++)
+      for (auto& u : ch.ctx[s].ul) { u.finished = false; search->finishUlEntry(u); }
+  };
+  if (ch.ul_epoch != ul_cfg_epoch.load(std::memory_order_acquire)) reconvert(0);
+  uint32_t prach_from = ul_set ? 0 : nsf;  // first subframe of this chunk that runs with a configuration
 
   // ---- phase 1 (sequential): downlink part + schedule bookkeeping ----
   for (uint32_t sf = 0; sf < nsf; sf++) {
     SubframeCtx& c = ch.ctx[sf];
     const uint32_t tti = c.tti % 10240;
+    if (!ul_set) {  // SubframeWorker::run_ul_mode without a configuration (SubframeWorker.cc:238-252): decode_SIB and nothing else
+      Sib2Config s2; size_t off = 0; uint32_t len = 0; uint8_t tb = 0;
+      if (c.searched && decodeSib(ch, r, sf, s2, off, len, tb)) {
+        out[sf].push_back({false, 'S', SIRNTI, tb, off, {}, len});
+        // ULSchedule::set_config (ULSchedule.cc:140-158) + SubframeWorker.cc:256-282: DMRS, hopping offset, PRACH detector
+        if (s2.group_hopping_enabled || s2.sequence_hopping_enabled)
+          fprintf(stderr, "ltesniffer_amd: SIB2 enables group / sequence hopping of the PUSCH reference signal - not supported, PUSCH decodes will fail\n");
+        lsn_ul_cfg_t u{}; u.cyclic_shift = s2.cyclic_shift; u.delta_ss = s2.group_assignment_pusch; u.hopping_offset = s2.pusch_hop_offset;
+        if (setUlConfig(u) != LSN_SUCCESS) throw std::runtime_error("UL_MODE: the uplink configuration of SIB2 could not be applied");
+        sib2 = s2; sib2_learned = true;
+        lsn_prach_cfg_t pc{}; pc.config_idx = s2.prach_config_idx; pc.root_seq_idx = s2.root_seq_idx; pc.zero_corr_zone = s2.zero_corr_zone;
+        pc.freq_offset = s2.prach_freq_offset; pc.hs_flag = s2.high_speed_flag;
+        if (setPrachConfig(pc) != LSN_SUCCESS)
+          fprintf(stderr, "ltesniffer_amd: the PRACH configuration of SIB2 (index %u, high-speed %u) is outside the supported set - no PRACH detection\n", s2.prach_config_idx, s2.high_speed_flag);
+        reconvert(sf + 1);
+        prach_from = sf + 1;
+      }
+      continue;
+    }
     std::vector<UlSchedGrant> rar_now;
     if (c.searched) {
       for (auto& e : c.dl) {
@@ -100,6 +134,17 @@ void Engine::commitChunkUl(Chunk& ch, JobRunner& r)
     if (ia != ul_sched.end()) { lists[sf] = ia->second; ul_sched.erase(ia); }
     auto ir = rar_sched.find(t6);
     if (ir != rar_sched.end()) { lists[sf].insert(lists[sf].end(), ir->second.begin(), ir->second.end()); rar_sched.erase(ir); }
+  }
+  // ---- PRACH occasions of the configured part of this chunk (PUSCH_Decoder::work_prach, UL_Sniffer_PUSCH.cc:656-713; no effect on the pcap) ----
+  if (prach.set && ch.d_iq_src && prach_from < nsf) {
+    std::vector<lsn_prach_det_t> det;
+    prachDetectDev(ch.d_iq_src, cd.iq_nant, 1, nsf, ch.start_tti, det, prach_from);
+    for (size_t a = 0; a < det.size();) {
+      size_t b = a;
+      while (b < det.size() && det[b].sf == det[a].sf) b++;
+      if (prach_sink) prach_sink(prach_sink_user, (ch.start_tti + det[a].sf) % 10240u, det.data() + a, (uint32_t)(b - a));
+      a = b;
+    }
   }
   // stale schedule entries (a gap in the TTI sequence) must not accumulate
   while (ul_sched.size() > 64) ul_sched.erase(ul_sched.begin());

@@ -258,10 +258,12 @@ void lsn_launch_chest_fin(const LsnCellDev& c, const float* raw, LsnChest* out, 
 
 // ------------------------------------------------------------------------------------------------ control region
 // equalise the 4 data REs of one REG (36.211 6.2.4) -> 4 QPSK symbols; single port: MRC/(|h|^2+noise), two ports: SFBC
+// g / ce point at symbol l of antenna 0 (port 0); rs = distance between antennas, ps = distance between ports (in REs), so the
+// same arithmetic runs on the global grids (rs = 14 nre, ps = A 14 nre) and on rows staged in LDS (rs = nre, ps = A nre)
 __device__ __forceinline__ void reg_equalise(const LsnCellDev& c, const cf32* __restrict__ g, const cf32* __restrict__ ce, float noise,
-                                             int l, int k0, cf32* x)
+                                             int l, int k0, cf32* x, int rs, int ps)
 {
-  const int nre = (int)c.nre, A = (int)c.nof_rx;
+  const int A = (int)c.nof_rx;
   int kk[4], n = 0;
   if (l == 0) {
     for (int k = k0; k < k0 + 6; k++)
@@ -274,8 +276,8 @@ __device__ __forceinline__ void reg_equalise(const LsnCellDev& c, const cf32* __
     for (int i = 0; i < 4; i++) {
       float nr = 0.0f, ni = 0.0f, den = 0.0f;
       for (int rx = 0; rx < A; rx++) {
-        cf32 y = g[((size_t)rx * 14 + l) * nre + kk[i]];
-        cf32 h = ce[((size_t)rx * 14 + l) * nre + kk[i]];
+        cf32 y = g[rx * rs + kk[i]];
+        cf32 h = ce[rx * rs + kk[i]];
         cf32 t = cmulconj(y, h);
         float hp = h.r * h.r + h.i * h.i;
         if (rx == 0) { nr = t.r; ni = t.i; den = hp; } else { nr = nr + t.r; ni = ni + t.i; den = den + hp; }
@@ -288,7 +290,7 @@ __device__ __forceinline__ void reg_equalise(const LsnCellDev& c, const cf32* __
     for (int i = 0; i < 4; i += 2) {
       float x0r = 0, x0i = 0, x1r = 0, x1i = 0, hh = 0;
       for (int rx = 0; rx < A; rx++) {
-        size_t b0 = ((size_t)rx * 14 + l) * nre, b1 = (((size_t)A + rx) * 14 + l) * nre;
+        const int b0 = rx * rs, b1 = ps + rx * rs;
         cf32 r0 = g[b0 + kk[i]], r1 = g[b0 + kk[i + 1]];
         cf32 h00 = ce[b0 + kk[i]], h01 = ce[b0 + kk[i + 1]], h10 = ce[b1 + kk[i]], h11 = ce[b1 + kk[i + 1]];
         float hp = (h00.r * h00.r + h00.i * h00.i) + (h11.r * h11.r + h11.i * h11.i);
@@ -314,7 +316,7 @@ __global__ __launch_bounds__(64) void k_pcfich(LsnCellDev c, const cf32* __restr
   const uint8_t* scr = c.pcfich_scr + sf_idx_arr[sf] * 32;
   if (lane < 4) {
     cf32 x[4];
-    reg_equalise(c, g, e, ch[sf].noise_avg, 0, (int)c.pcfich_k0[lane], x);
+    reg_equalise(c, g, e, ch[sf].noise_avg, 0, (int)c.pcfich_k0[lane], x, 14 * (int)c.nre, (int)c.nof_rx * 14 * (int)c.nre);
     for (int j = 0; j < 4; j++) {
       float a = -(x[j].r * SQRT2F), b = -(x[j].i * SQRT2F);
       llr[8 * lane + 2 * j] = scr[8 * lane + 2 * j] ? -a : a;
@@ -339,30 +341,56 @@ void lsn_launch_pcfich(const LsnCellDev& c, const cf32* grid, const cf32* ce, co
   hipLaunchKernelGGL(k_pcfich, dim3(nsf), dim3(64), 0, s, c, grid, ce, ch, sf_idx, cfi, corr);
 }
 
-__global__ __launch_bounds__(64) void k_pdcch_llr(LsnCellDev c, const cf32* __restrict__ grid, const cf32* __restrict__ ce,
-                                                  const LsnChest* __restrict__ ch, const uint32_t* __restrict__ sf_idx_arr,
-                                                  const uint32_t* __restrict__ cfi_arr, float* __restrict__ llr)
+// One workgroup per (control symbol l, subframe): the (1 + ports) x nof_rx rows of that symbol (received grid and channel
+// estimates, <= 57.6 KB at 100 PRB) are staged in LDS with coalesced 16-byte loads, then every REG quadruplet that lives on
+// the symbol is equalised from LDS and written to its place in the PDCCH order (8 consecutive floats per quadruplet).
+__global__ __launch_bounds__(256) void k_pdcch_llr(LsnCellDev c, const cf32* __restrict__ grid, const cf32* __restrict__ ce,
+                                                   const LsnChest* __restrict__ ch, const uint32_t* __restrict__ sf_idx_arr,
+                                                   const uint32_t* __restrict__ cfi_arr, float* __restrict__ llr)
 {
-  const int sf = blockIdx.y;
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  cf32* rows = reinterpret_cast<cf32*>(lds_raw);
+  const int sf = blockIdx.y, l = blockIdx.x;
   const uint32_t cfi = cfi_arr[sf];
-  const uint32_t q = blockIdx.x * 64 + threadIdx.x;
-  if (q >= c.nof_cce[cfi - 1] * 9) return;
-  const cf32* g = grid + (size_t)sf * c.nof_rx * 14 * c.nre;
-  const cf32* e = ce + (size_t)sf * c.nof_ports * c.nof_rx * 14 * c.nre;
+  if ((uint32_t)l >= cfi + (c.nof_prb <= 10 ? 1u : 0u)) return;  // 36.211 6.7: one more control symbol at <= 10 PRB
+  const int nre = (int)c.nre, A = (int)c.nof_rx, P = (int)c.nof_ports;
+  const cf32* g = grid + (size_t)sf * A * 14 * nre;
+  const cf32* e = ce + (size_t)sf * P * A * 14 * nre;
+  // rows [0, A): grid; rows [A, A + P A): estimates, port-major like the global layout
+  const int nrow = A + P * A, n2 = nre / 2;   // nre is a multiple of 12: rows are 16-byte aligned
+  for (int i = threadIdx.x; i < nrow * n2; i += 256) {
+    const int r = i / n2, k2 = i - r * n2;
+    const cf32* src = (r < A) ? g + ((size_t)r * 14 + l) * nre : e + ((size_t)(r - A) * 14 + l) * nre;
+    reinterpret_cast<float4*>(rows + (size_t)r * nre)[k2] = reinterpret_cast<const float4*>(src)[k2];
+  }
+  __syncthreads();
   const uint8_t* scr = c.pdcch_scr + (size_t)sf_idx_arr[sf] * LSN_LLR_STRIDE;
-  cf32 x[4];
-  reg_equalise(c, g, e, ch[sf].noise_avg, (int)c.reg_l[(cfi - 1) * 800 + q], (int)c.reg_k0[(cfi - 1) * 800 + q], x);
-  float* o = llr + (size_t)sf * LSN_LLR_STRIDE + 8 * q;
+  const float noise = ch[sf].noise_avg;
+  const uint32_t nq = c.nof_cce[cfi - 1] * 9;
+  const uint8_t* rl = c.reg_l + (cfi - 1) * 800;
+  const uint16_t* rk = c.reg_k0 + (cfi - 1) * 800;
+  for (uint32_t q = threadIdx.x; q < nq; q += 256) {
+    if ((int)rl[q] != l) continue;
+    cf32 x[4];
+    reg_equalise(c, rows, rows + (size_t)A * nre, noise, l, (int)rk[q], x, nre, A * nre);
+    float4 o0, o1;
+    const uint8_t* sc = scr + 8 * q;
+    float v[8];
 #pragma unroll
-  for (int j = 0; j < 4; j++) {
-    float a = -(x[j].r * SQRT2F), b = -(x[j].i * SQRT2F);
-    o[2 * j] = scr[8 * q + 2 * j] ? -a : a;
-    o[2 * j + 1] = scr[8 * q + 2 * j + 1] ? -b : b;
+    for (int j = 0; j < 4; j++) {
+      float a = -(x[j].r * SQRT2F), b = -(x[j].i * SQRT2F);
+      v[2 * j] = sc[2 * j] ? -a : a;
+      v[2 * j + 1] = sc[2 * j + 1] ? -b : b;
+    }
+    o0.x = v[0]; o0.y = v[1]; o0.z = v[2]; o0.w = v[3]; o1.x = v[4]; o1.y = v[5]; o1.z = v[6]; o1.w = v[7];
+    float4* o = reinterpret_cast<float4*>(llr + (size_t)sf * LSN_LLR_STRIDE + 8 * q);
+    o[0] = o0; o[1] = o1;
   }
 }
 void lsn_launch_pdcch_llr(const LsnCellDev& c, const cf32* grid, const cf32* ce, const LsnChest* ch, const uint32_t* sf_idx, const uint32_t* cfi, float* llr, uint32_t nsf, hipStream_t s)
 {
-  hipLaunchKernelGGL(k_pdcch_llr, dim3((87 * 9 + 63) / 64, nsf), dim3(64), 0, s, c, grid, ce, ch, sf_idx, cfi, llr);
+  const size_t lds = (size_t)(c.nof_rx + c.nof_ports * c.nof_rx) * c.nre * sizeof(cf32);
+  hipLaunchKernelGGL(k_pdcch_llr, dim3(c.nof_prb <= 10 ? 4 : 3, nsf), dim3(256), lds, s, c, grid, ce, ch, sf_idx, cfi, llr);
 }
 
 // falcon_pdcch.c:595-620: mean |llr| over the 72 LLRs of each CCE, accumulated in double in index order

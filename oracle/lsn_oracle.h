@@ -220,6 +220,13 @@ typedef struct { /* ltesniffer_ue_spec_config_t, MCSTracking.h:37-43 */
 } o_ue_cfg_t;
 int o_mac_dlsch_parse(const uint8_t* pdu, int len, o_mac_subh_t* out, int cap);
 int o_rrc_conn_setup_decode(const uint8_t* sdu, int len, o_ue_cfg_t* out);
+typedef struct { /* the SIB2 fields ULSchedule::set_config and SubframeWorker.cc:271-273 read */
+  uint32_t n_sb, hopping_mode, pusch_hop_offset, enable_64qam;
+  uint32_t group_hopping_enabled, group_assignment_pusch, sequence_hopping_enabled, cyclic_shift;
+  uint32_t root_seq_idx, prach_config_idx, high_speed_flag, zero_corr_zone, prach_freq_offset;
+  uint32_t bits_used; /* test aid */
+} o_sib2_t;
+int o_sib2_decode(const uint8_t* pdu, int len, o_sib2_t* out);
 
 /* ---------- PSS / SSS cell search (o_sync.c) ---------- */
 typedef struct { uint32_t nof_periods; int32_t force_n_id_2 /* -1: all three roots */; float threshold /* peak / mean of the PSS correlation power */; } o_sync_cfg_t;
@@ -304,7 +311,8 @@ int o_worker_work(o_worker_t*, const ocf_t* const* iq, uint32_t sf_idx, uint32_t
  * The SIB2-derived DMRS configuration is given instead of parsed (ASN.1 is out of scope). */
 typedef struct { uint32_t rapid, ta, hopping, riv, mcs, tpc, ul_delay, csi_req; uint16_t t_crnti; int grant_ok; o_pusch_grant_t grant; } o_rar_t;
 int o_rar_parse(const o_cell_t* cell, const uint8_t* p, int len, o_rar_t* out, int cap); /* MAC RAR PDU -> RAR entries (o_worker.c) */
-void o_worker_set_ul_mode(o_worker_t*, const o_ul_cfg_t* ul);
+void o_worker_set_ul_mode(o_worker_t*, const o_ul_cfg_t* ul); /* ul == NULL: configure from the first SIB2 (decode_SIB) */
+int o_worker_ul_config(o_worker_t* w, o_ul_cfg_t* ul, o_sib2_t* sib2); /* 0 not configured, 1 given, 2 learned from SIB2 */
 int o_worker_work_ul(o_worker_t*, const ocf_t* dl_iq, const ocf_t* ul_iq, uint32_t sf_idx, uint32_t sfn, int update_meta_formats);
 const o_stats_t* o_worker_stats(o_worker_t*);
 void o_worker_ue_cfg(o_worker_t* w, uint16_t rnti, o_ue_cfg_t* out); /* MCSTracking::get_ue_config_rnti */

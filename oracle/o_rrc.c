@@ -245,3 +245,92 @@ int o_rrc_conn_setup_decode(const uint8_t* sdu, int len, o_ue_cfg_t* out)
   out->bits_used = b->pos;
   return 1;
 }
+
+/* ---------------- BCCH-DL-SCH-Message: SystemInformationBlockType2 ----------------
+ * PDSCH_Decoder::decode_SIB (/root/reference/src/src/DL_Sniffer_PDSCH.cc:531-557) unpacks a BCCH-DL-SCH-Message with srsRAN's
+ * ASN.1 code [not in tree] and keeps the sib2 entry of a SystemInformation; ULSchedule::set_config (ULSchedule.cc:140-158) and
+ * SubframeWorker.cc:271-273 read the PUSCH hopping / reference-signal and PRACH fields out of it.  UPER walk after TS 36.331
+ * 6.2.1 / 6.2.2 / 6.3.1 / 6.3.2.  Pinned by the SIB2 message the reference itself wrote into pcap_file_example/ltesniffer_ul_mode.pcap
+ * (tests/golden/pcap_records.json "si_pdus"): the walk ends inside the message and yields srsENB's stock sib.conf values.
+ * Returns 0: does not unpack, 1: unpacks, no SIB2 in front (SIB1 or another block), 2: SIB2 (out filled).
+ * Not restated: blocks BEHIND SIB2 in the same SystemInformation are not unpacked. */
+int o_sib2_decode(const uint8_t* pdu, int len, o_sib2_t* out)
+{
+  br_t b = {pdu, len > 0 ? 8u * (uint32_t)len : 0u, 0, 0};
+  o_sib2_t o;
+  memset(&o, 0, sizeof(o));
+  if (rd(&b, 1)) return 0;                /* messageClassExtension */
+  if (rd(&b, 1)) return b.err ? 0 : 1;    /* systemInformationBlockType1 */
+  if (rd(&b, 1)) return 0;                /* criticalExtensionsFuture */
+  rd(&b, 1);                              /* nonCriticalExtension present */
+  rd(&b, 5);                              /* number of blocks - 1 */
+  if (rd(&b, 1)) return 0;                /* extension alternative of the block CHOICE */
+  uint32_t alt = rd(&b, 4);
+  if (b.err || alt > 9) return 0;
+  if (alt != 0) return 1;
+  int sib_ext = (int)rd(&b, 1), ac = (int)rd(&b, 1), mbsfn = (int)rd(&b, 1);
+  if (ac) {
+    int sig = (int)rd(&b, 1), dat = (int)rd(&b, 1);
+    rd(&b, 1);
+    if (sig) rd(&b, 12);
+    if (dat) rd(&b, 12);
+  }
+  int rr_ext = (int)rd(&b, 1);
+  { /* RACH-ConfigCommon */
+    int ext = (int)rd(&b, 1), grp = (int)rd(&b, 1);
+    rd(&b, 4);
+    if (grp) {
+      int gext = (int)rd(&b, 1);
+      rd_int(&b, 0, 14); rd(&b, 2); rd(&b, 3);
+      if (gext) skip_ext(&b);
+    }
+    rd(&b, 2); rd(&b, 4);
+    rd_int(&b, 0, 10); rd(&b, 3); rd(&b, 3);
+    rd(&b, 3);
+    if (ext) skip_ext(&b);
+  }
+  rd(&b, 2);          /* BCCH-Config */
+  rd(&b, 5);          /* PCCH-Config */
+  o.root_seq_idx = rd_int(&b, 0, 837);
+  o.prach_config_idx = rd(&b, 6);
+  o.high_speed_flag = rd(&b, 1);
+  o.zero_corr_zone = rd(&b, 4);
+  o.prach_freq_offset = rd_int(&b, 0, 94);
+  rd_int(&b, 0, 110); rd(&b, 2); /* PDSCH-ConfigCommon */
+  o.n_sb = rd(&b, 2) + 1;
+  o.hopping_mode = rd(&b, 1);
+  o.pusch_hop_offset = rd_int(&b, 0, 98);
+  o.enable_64qam = rd(&b, 1);
+  o.group_hopping_enabled = rd(&b, 1);
+  o.group_assignment_pusch = rd_int(&b, 0, 29);
+  o.sequence_hopping_enabled = rd(&b, 1);
+  o.cyclic_shift = rd(&b, 3);
+  rd_int(&b, 0, 2); rd_int(&b, 0, 98); rd(&b, 3); rd(&b, 11); /* PUCCH-ConfigCommon */
+  if (rd(&b, 1)) { rd(&b, 1); rd(&b, 8); }                     /* SoundingRS-UL-ConfigCommon setup */
+  rd_int(&b, 0, 150); rd(&b, 3); rd(&b, 5);                    /* UplinkPowerControlCommon */
+  rd_int(&b, 0, 2); rd_int(&b, 0, 2); rd(&b, 2); rd_int(&b, 0, 2); rd_int(&b, 0, 2);
+  rd(&b, 3);
+  rd(&b, 1);                                                   /* UL-CyclicPrefixLength */
+  if (rr_ext) skip_ext(&b);
+  { /* UE-TimersAndConstants */
+    int ext = (int)rd(&b, 1);
+    rd(&b, 3); rd(&b, 3); rd_int(&b, 0, 6); rd(&b, 3); rd_int(&b, 0, 6); rd(&b, 3);
+    if (ext) skip_ext(&b);
+  }
+  { /* freqInfo */
+    int carrier = (int)rd(&b, 1), bw = (int)rd(&b, 1);
+    if (carrier) rd(&b, 16);
+    if (bw) rd_int(&b, 0, 5);
+    rd(&b, 5);
+  }
+  if (mbsfn) {
+    uint32_t n = rd(&b, 3) + 1;
+    for (uint32_t i = 0; i < n && !b.err; i++) { rd_int(&b, 0, 5); rd(&b, 3); if (rd(&b, 1)) rd(&b, 24); else rd(&b, 6); }
+  }
+  rd(&b, 3); /* TimeAlignmentTimer */
+  if (sib_ext) skip_ext(&b);
+  if (b.err) return 0;
+  o.bits_used = b.pos;
+  *out = o;
+  return 2;
+}

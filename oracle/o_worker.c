@@ -85,6 +85,9 @@ struct o_worker {
   /* UL mode */
   int ul_mode;
   o_ul_cfg_t ulcfg;
+  int ul_configured;   /* ULSchedule::get_config */
+  o_sib2_t sib2;       /* ULSchedule::sib2, valid when the configuration was learned */
+  int sib2_learned;
   ocf_t* ul_grid;
   ulslot_t* ul_sched;  /* [16] DCI-0 grants by tti % 16 (ULSchedule::pushULSche) */
   ulslot_t* rar_sched; /* [16] RAR grants */
@@ -783,11 +786,16 @@ int o_worker_work(o_worker_t* w, const ocf_t* const* iq, uint32_t sf_idx, uint32
 
 
 /* ================================================================================================ UL mode */
+/* ul == NULL: no configuration yet - the worker runs PDSCH_Decoder::decode_SIB until a SIB2 configures it (SubframeWorker.cc:238-252) */
 void o_worker_set_ul_mode(o_worker_t* w, const o_ul_cfg_t* ul)
 {
   w->ul_mode = 1;
-  w->ulcfg = *ul;
-  w->cfg.cell.pusch_hop_offset = ul->hopping_offset; /* ul_cfg.hopping.n_rb_ho, SubframeWorker.cc:271-273 */
+  w->ul_configured = ul != NULL;
+  w->sib2_learned = 0;
+  if (ul) {
+    w->ulcfg = *ul;
+    w->cfg.cell.pusch_hop_offset = ul->hopping_offset; /* ul_cfg.hopping.n_rb_ho, SubframeWorker.cc:271-273 */
+  }
   if (!w->ul_grid) {
     w->ul_grid = (ocf_t*)calloc(14u * 12u * w->cfg.cell.nof_prb, sizeof(ocf_t));
     w->ul_sched = (ulslot_t*)calloc(16, sizeof(ulslot_t));
@@ -851,6 +859,41 @@ static void decode_ul_mode_dl(o_worker_t* w, ulslot_t* rar_out)
       }
     }
   }
+}
+
+/* PDSCH_Decoder::decode_SIB, DL_Sniffer_PDSCH.cc:459-560: SI-RNTI grants with the 64QAM table; the first transport block that carries a
+ * SystemInformation with SIB2 is written to the pcap and ends the subframe */
+static int decode_sib(o_worker_t* w)
+{
+  uint32_t tti = w->sfn * 10 + w->sf_idx;
+  for (uint32_t di = 0; di < w->ndl; di++) {
+    dl_entry_t* e = &w->dl[di];
+    int crc[2] = {0, 0};
+    if (e->rnti != O_SIRNTI) continue;
+    o_pdsch_grant_t* cur = &e->g64;
+    if (o_config_mimo(&w->cfg.cell, e->format, &e->dci, cur) != 0) continue;
+    for (int i = 0; i < 2; i++)
+      if (cur->tb[i].enabled && cur->tb[i].rv < 0) cur->tb[i].rv = (int)((uint32_t)ceilf(1.5f * (float)((w->sfn / 2) % 4)) % 4u);
+    decode_grant(w, e, cur, crc);
+    for (int tb = 0; tb < 2; tb++)
+      if (crc[tb]) {
+        int len = cur->tb[tb].tbs / 8;
+        o_sib2_t s;
+        if (o_sib2_decode(w->payload + tb * 16384, len, &s) == 2) {
+          w->sib2 = s;
+          write_pcap(w, "SI_RNTI", w->payload + tb * 16384, (uint32_t)len, e->rnti, tti);
+          return 1;
+        }
+      }
+  }
+  return 0;
+}
+int o_worker_ul_config(o_worker_t* w, o_ul_cfg_t* ul, o_sib2_t* sib2) /* ULSchedule::get_config / getSIB2: 0 none, 1 given, 2 learned from SIB2 */
+{
+  if (!w->ul_configured) return 0;
+  if (ul) *ul = w->ulcfg;
+  if (sib2 && w->sib2_learned) *sib2 = w->sib2;
+  return w->sib2_learned ? 2 : 1;
 }
 
 /* one srsran_chest_ul_estimate_pusch + srsran_pusch_decode attempt (PUSCH_Decoder::decode_run, UL_Sniffer_PUSCH.cc:250-310) */
@@ -951,6 +994,21 @@ int o_worker_work_ul(o_worker_t* w, const ocf_t* dl_iq, const ocf_t* ul_iq, uint
   ulslot_t* rar = &w->rar_sched[tti % 16];
   cur->tti = tti; cur->valid = 1; cur->n = 0;
   rar->tti = tti; rar->valid = 1; rar->n = 0;
+  if (!w->ul_configured) { /* run_ul_mode without a configuration: decode_SIB, then ULSchedule::set_SIB2 + set_config; nothing else this subframe */
+    if (w->chest.snr_db > 6.0f) {
+      blind_search(w);
+      if (decode_sib(w)) {
+        w->ulcfg.cyclic_shift = w->sib2.cyclic_shift;           /* ULSchedule.cc:143-146 */
+        w->ulcfg.delta_ss = w->sib2.group_assignment_pusch;
+        w->ulcfg.hopping_offset = w->sib2.pusch_hop_offset;     /* SubframeWorker.cc:271-273 */
+        w->cfg.cell.pusch_hop_offset = w->sib2.pusch_hop_offset;
+        w->ul_configured = 1;
+        w->sib2_learned = 1;
+      }
+    }
+    w->stats.nof_subframes++;
+    return w->records;
+  }
   if (w->chest.snr_db > 6.0f) {
     blind_search(w);
     decode_ul_mode_dl(w, rar);

@@ -49,7 +49,7 @@ class TxgCfg(C.Structure):
                 ("mix_tm4_pct", C.c_uint32), ("pct_256qam", C.c_uint32), ("mcs_min", C.c_uint32), ("mcs_max", C.c_uint32),
                 ("sib_period", C.c_uint32), ("rar_period", C.c_uint32), ("paging_period", C.c_uint32),
                 ("start_tti", C.c_uint32), ("fixed_L", C.c_uint32), ("pct_rv", C.c_uint32), ("pct_cqi_req", C.c_uint32), ("pct_hop", C.c_uint32), ("pusch_hop_offset", C.c_uint32),
-                ("msg4_period", C.c_uint32), ("msg4_p_a_idx", C.c_uint32)]
+                ("msg4_period", C.c_uint32), ("msg4_p_a_idx", C.c_uint32), ("si_len", C.c_uint32 * 2), ("si_msg", (C.c_uint8 * 96) * 2)]
 
 
 class TxgPdu(C.Structure):
@@ -168,9 +168,14 @@ def scenario(name, seed=1, **over):
 
 
 class TxGen:
-    def __init__(self, **kw):
+    def __init__(self, si_msgs=None, **kw):
         self.lib = txgen()
         self.cfg = TxgCfg(**kw)
+        for i, m in enumerate(si_msgs or []):  # BCCH-DL-SCH messages of the SI-RNTI transmissions (alternating), None / b"" = random bytes
+            if m:
+                self.cfg.si_len[i] = len(m)
+                for j, b in enumerate(bytes(m)[:96]):
+                    self.cfg.si_msg[i][j] = b
         self.h = self.lib.txg_new(C.byref(self.cfg))
         assert self.h, "txg_new failed"
         self.sf_len = self.lib.txg_sf_len(self.h)
@@ -423,6 +428,34 @@ class OUci(C.Structure):
     _fields_ = [("nof_ack", C.c_uint32), ("cqi_bits", C.c_uint32), ("ri_bits", C.c_uint32)]
 
 
+SIB2_FIELDS = ("n_sb", "hopping_mode", "pusch_hop_offset", "enable_64qam", "group_hopping_enabled", "group_assignment_pusch",
+               "sequence_hopping_enabled", "cyclic_shift", "root_seq_idx", "prach_config_idx", "high_speed_flag", "zero_corr_zone", "prach_freq_offset")
+
+
+class OSib2(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in SIB2_FIELDS + ("bits_used",)]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n in SIB2_FIELDS}
+
+
+def oracle_sib2_decode(pdu):
+    """-> (verdict, dict | None, bits_used)"""
+    o = oracle()
+    o.o_sib2_decode.argtypes = [C.c_char_p, C.c_int, C.POINTER(OSib2)]
+    s = OSib2()
+    r = o.o_sib2_decode(bytes(pdu), len(pdu), C.byref(s))
+    return r, (s.as_dict() if r == 2 else None), int(s.bits_used)
+
+
+def host_sib2_decode(pdu):
+    """the product's parser (tests/native build of lsn_rrc.cc) -> (verdict, dict | None)"""
+    h = hosttest()
+    out = np.zeros(13, np.uint32)
+    r = h.lsnh_sib2_decode(bytes(pdu), len(pdu), out.ctypes.data_as(C.c_void_p))
+    return r, (dict(zip(SIB2_FIELDS, (int(v) for v in out))) if r == 2 else None)
+
+
 class OUlCfg(C.Structure):
     _fields_ = [("cyclic_shift", C.c_uint32), ("delta_ss", C.c_uint32), ("hopping_offset", C.c_uint32)]
 
@@ -485,11 +518,25 @@ class OracleWorkerUl(OracleWorker):
     """UL_MODE worker: one downlink antenna + the uplink antenna (SubframeWorker.cc:184-199)"""
 
     def __init__(self, nof_prb, nof_ports, cell_id, cyclic_shift, delta_ss, hopping_offset=0, **kw):
+        """cyclic_shift None: no configuration given - the worker configures itself from the first SIB2 (decode_SIB)"""
         super().__init__(nof_prb, nof_ports, cell_id, 1, **kw)
         self.lib.o_worker_set_ul_mode.argtypes = [C.c_void_p, C.POINTER(OUlCfg)]
         self.lib.o_worker_work_ul.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_int]
-        self._ul = OUlCfg(cyclic_shift, delta_ss, hopping_offset)
-        self.lib.o_worker_set_ul_mode(self.h, C.byref(self._ul))
+        self.lib.o_worker_ul_config.argtypes = [C.c_void_p, C.POINTER(OUlCfg), C.POINTER(OSib2)]
+        if cyclic_shift is None:
+            self.lib.o_worker_set_ul_mode(self.h, None)
+        else:
+            self._ul = OUlCfg(cyclic_shift, delta_ss, hopping_offset)
+            self.lib.o_worker_set_ul_mode(self.h, C.byref(self._ul))
+
+    def ul_config(self):
+        """-> None | dict(cyclic_shift, delta_ss, hopping_offset, from_sib2, sib2)"""
+        u, s = OUlCfg(), OSib2()
+        r = self.lib.o_worker_ul_config(self.h, C.byref(u), C.byref(s))
+        if r == 0:
+            return None
+        return dict(cyclic_shift=u.cyclic_shift, delta_ss=u.delta_ss, hopping_offset=u.hopping_offset, from_sib2=r == 2,
+                    sib2=s.as_dict() if r == 2 else None)
 
     def work_ul(self, dl_iq, ul_iq, tti, update_meta=0):
         dl_iq = np.ascontiguousarray(dl_iq, dtype=np.complex64)
@@ -497,12 +544,95 @@ class OracleWorkerUl(OracleWorker):
         return self.lib.o_worker_work_ul(self.h, dl_iq.ctypes.data, ul_iq.ctypes.data, tti % 10, (tti // 10) % 1024, int(update_meta))
 
 
-def gen_ul_mode_subframes(sc, n, cyclic_shift=3, delta_ss=5, ul_snr_db=30.0):  # sc['pusch_hop_offset'] = SIB2 pusch-HoppingOffset of the cell
+# the two BCCH-DL-SCH messages of the reference's own UL_MODE / DL_MODE captures (tests/golden/pcap_records.json "si_pdus")
+REAL_SIB1 = bytes.fromhex("406404ab00070019b0181460108280000000")
+REAL_SIB2 = bytes.fromhex("00800ce1bf788800ca11e20140000801829945ab9c30c6a73141c21462d84ea5a40000000000000000")
+
+
+def encode_sib2(n_sb=1, hopping_mode=0, pusch_hop_offset=0, enable_64qam=1, group_hopping_enabled=0, group_assignment_pusch=0,
+                sequence_hopping_enabled=0, cyclic_shift=0, root_seq_idx=128, prach_config_idx=3, high_speed_flag=0, zero_corr_zone=5,
+                prach_freq_offset=4, ac_barring=0, group_a=0, srs=0, mbsfn=0, ul_carrier=0, ul_bw=0, rach_ext=0, rr_ext=0, timers_ext=0,
+                sib_ext=0, nblocks=1, fill=0):
+    """BCCH-DL-SCH-Message { systemInformation { sib2 ... } } in unaligned PER (TS 36.331 6.2.2 / 6.3.1 / 6.3.2) - an independent
+    encoder for the tests: optional components / extension additions can be switched on, `fill` seeds the don't-care fields"""
+    bits = []
+    rnd = np.random.RandomState(fill)
+
+    def put(v, n):
+        bits.extend((int(v) >> (n - 1 - i)) & 1 for i in range(n))
+
+    def dc(n, lim=None):  # a don't-care field
+        put(rnd.randint(0, lim if lim is not None else (1 << n)) if fill else 0, n)
+
+    def ext_additions(octets):  # one extension addition group, `octets` bytes of open type
+        put(0, 1); put(0, 6)    # normally small number: 1 addition
+        put(1, 1)               # present
+        put(octets, 8)          # length determinant < 128
+        for _ in range(octets):
+            dc(8)
+
+    put(0, 1); put(0, 1); put(0, 1); put(0, 1)  # c1, systemInformation, systemInformation-r8, no nonCriticalExtension
+    put(nblocks - 1, 5)
+    put(0, 1); put(0, 4)                         # sib2
+    put(sib_ext, 1); put(1 if ac_barring else 0, 1); put(1 if mbsfn else 0, 1)
+    if ac_barring:
+        put(1, 1); put(ac_barring > 1, 1); dc(1)
+        dc(4); dc(3); dc(5)
+        if ac_barring > 1:
+            dc(4); dc(3); dc(5)
+    put(rr_ext, 1)
+    put(rach_ext, 1); put(group_a, 1); dc(4)     # rach-ConfigCommon
+    if group_a:
+        put(0, 1); dc(4, 15); dc(2); dc(3)
+    dc(2); dc(4); dc(4, 11); dc(3); dc(3); dc(3)
+    if rach_ext:
+        ext_additions(2)
+    dc(2)                                        # bcch-Config
+    dc(2); dc(3)                                 # pcch-Config
+    put(root_seq_idx, 10); put(prach_config_idx, 6); put(high_speed_flag, 1); put(zero_corr_zone, 4); put(prach_freq_offset, 7)
+    dc(7, 111); dc(2)                            # pdsch-ConfigCommon
+    put(n_sb - 1, 2); put(hopping_mode, 1); put(pusch_hop_offset, 7); put(enable_64qam, 1)
+    put(group_hopping_enabled, 1); put(group_assignment_pusch, 5); put(sequence_hopping_enabled, 1); put(cyclic_shift, 3)
+    dc(2, 3); dc(7, 99); dc(3); dc(11)           # pucch-ConfigCommon
+    put(1 if srs else 0, 1)
+    if srs:
+        put(srs > 1, 1); dc(3); dc(4); dc(1)
+    dc(8, 151); dc(3); dc(5)                     # uplinkPowerControlCommon
+    dc(2, 3); dc(2, 3); dc(2); dc(2, 3); dc(2, 3)
+    dc(3)
+    dc(1)                                        # ul-CyclicPrefixLength
+    if rr_ext:
+        ext_additions(3)
+    put(timers_ext, 1); dc(3); dc(3); dc(3, 7); dc(3); dc(3, 7); dc(3)
+    if timers_ext:
+        ext_additions(1)
+    put(ul_carrier, 1); put(ul_bw, 1)
+    if ul_carrier:
+        dc(16)
+    if ul_bw:
+        dc(3, 6)
+    dc(5)
+    if mbsfn:
+        put(mbsfn - 1, 3)
+        for i in range(mbsfn):
+            dc(3, 6); dc(3); put(i & 1, 1); dc(24 if i & 1 else 6)
+    dc(3)                                        # timeAlignmentTimerCommon
+    if sib_ext:
+        ext_additions(4)
+    for _ in range(nblocks - 1):                 # further blocks: not read by the decoders under test
+        for _ in range(5):
+            dc(8)
+    while len(bits) % 8:
+        bits.append(0)
+    return bytes(int("".join(map(str, bits[i:i + 8])), 2) for i in range(0, len(bits), 8))
+
+
+def gen_ul_mode_subframes(sc, n, cyclic_shift=3, delta_ss=5, ul_snr_db=30.0, si_msgs=None):  # sc['pusch_hop_offset'] = SIB2 pusch-HoppingOffset of the cell
     """DL stream from the synthetic eNB (one rx antenna) + the matching UL stream: every DCI 0 of subframe t is answered by a
     PUSCH in subframe t + 4 (UEs with an even RNTI are 64QAM-capable in the uplink).
     -> (tti0, iq[n, 2, sf_len] (antenna 0 = DL, 1 = UL), list of sent UL payload dicts)"""
     assert sc["nof_rx"] == 1
-    tx = TxGen(**sc)
+    tx = TxGen(si_msgs=si_msgs, **sc)
     ucell = TxgUlCell(sc["nof_prb"], sc["cell_id"], cyclic_shift, delta_ss)
     iq = np.zeros((n, 2, tx.sf_len), dtype=np.complex64)
     pending, sent, tti0 = {}, [], None

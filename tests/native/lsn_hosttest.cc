@@ -185,6 +185,18 @@ int lsnh_rrc_conn_setup(const uint8_t* sdu, int len, uint32_t* out)
   out[1] = c.i_offset_ack; out[2] = c.i_offset_cqi; out[3] = c.i_offset_ri; out[4] = c.cqi_type;
   return 1;
 }
+// SIB2 decode: out[13] = Sib2Config fields in declaration order; returns sib2_decode's verdict (0 / 1 / 2)
+int lsnh_sib2_decode(const uint8_t* pdu, int len, uint32_t* out)
+{
+  Sib2Config c;
+  const int r = sib2_decode(pdu, len, c);
+  if (r == 2) {
+    const uint32_t v[13] = {c.n_sb, c.hopping_mode, c.pusch_hop_offset, c.enable_64qam, c.group_hopping_enabled, c.group_assignment_pusch,
+                            c.sequence_hopping_enabled, c.cyclic_shift, c.root_seq_idx, c.prach_config_idx, c.high_speed_flag, c.zero_corr_zone, c.prach_freq_offset};
+    std::memcpy(out, v, sizeof(v));
+  }
+  return r;
+}
 // MCSTracking UE-configuration database driven by a sequence of (rnti, pdu) events; returns the configuration get_ue_config_rnti(query) ends with
 void* lsnh_mcs_new() { return new MCSTracking(); }
 void lsnh_mcs_free(void* m) { delete (MCSTracking*)m; }

@@ -199,3 +199,35 @@ def test_ul_mode_with_frequency_hopping_grants():
     """DCI 0 with the hopping flag: type-1 grants are decoded from both slot positions, like the oracle's UL_MODE worker"""
     n_ul, n_dl = _run_ul_mode(60, seed=15, batch=32, hopping_offset=8, mcs_max=18, pct_hop=50, pusch_hop_offset=8, pct_cqi_req=20)
     assert n_ul >= 8
+
+
+@pytest.mark.parametrize("batch", [16, 64])
+def test_ul_mode_configures_itself_from_sib2(batch):
+    """UL_MODE without lsn_phy_set_ul_config: PDSCH_Decoder::decode_SIB on every subframe until the SystemInformation with SIB2 (here in
+    the middle of a chunk), that one SI-RNTI record, then DMRS / hopping offset / PRACH from it - records, learned configuration and
+    search statistics identical to the oracle's worker that started without a configuration"""
+    from lsn_testlib import REAL_SIB1, OracleWorkerUl, encode_sib2, gen_ul_mode_subframes, parse_pcap, scenario
+    from parity import gpu_records, oracle_records
+    sc = scenario("cfg2", seed=21, nof_rx=1, n_rnti=10, dl_min=2, dl_max=3, ul_min=2, ul_max=4, nof_prb=25, mcs_max=18, pusch_hop_offset=4, pct_hop=30)
+    sib2 = encode_sib2(cyclic_shift=3, group_assignment_pusch=5, pusch_hop_offset=4, root_seq_idx=22, prach_config_idx=3, zero_corr_zone=1,
+                       prach_freq_offset=2, ac_barring=1, srs=1, rr_ext=1, nblocks=2, fill=5)
+    nsf = 70
+    tti0, iq, sent = gen_ul_mode_subframes(sc, nsf, si_msgs=[REAL_SIB1, sib2])
+    ow = OracleWorkerUl(sc["nof_prb"], sc["nof_ports"], sc["cell_id"], None, None)
+    for i in range(nsf):
+        ow.work_ul(iq[i, 0], iq[i, 1], tti0 + i, update_meta=1 if i % 25 == 0 else 0)
+    orecs = parse_pcap(ow.pcap_bytes())
+    assert orecs[0]["rnti_type"] == 4 and len([r for r in orecs if r["direction"] == 0]) >= 5
+    phy = la.Phy(nof_rx_antennas=2, sniffer_mode=1, max_batch=batch, pcapwriter=la.PcapWriter(None))
+    assert phy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"])
+    assert phy.getUlConfig() is None
+    phy.process_host(iq, tti0, 25)
+    g, o = gpu_records(phy), oracle_records(orecs)
+    assert g == o, "UL_MODE (self-configured) record streams differ: gpu %d vs oracle %d" % (len(g), len(o))
+    assert phy.getUlConfig() == ow.ul_config()
+    st, ost = phy.getStats(), ow.stats()
+    assert st.nof_decoded_locations == ost.nof_decoded_locations and st.nof_subframes == ost.nof_subframes
+    # a configuration given by hand afterwards replaces the learned one
+    assert phy.setUlConfig(1, 2, 0) and phy.getUlConfig() == dict(cyclic_shift=1, delta_ss=2, hopping_offset=0, from_sib2=False, sib2=None)
+    assert la.sib2_decode(sib2)[1]["root_seq_idx"] == 22 and la.sib2_decode(REAL_SIB1) == (1, None)
+    phy.close()

@@ -5,7 +5,7 @@
 # --pmc passes (SQ instruction/occupancy counters, FETCH_SIZE, WRITE_SIZE; never combined with other trace domains).
 set -u
 TAG=${1:-prof}; shift || true
-ARGS=${*:---no-cpu --no-check --steps 1 --warmup 1 --reps 2}
+ARGS=${*:---no-cpu --no-check --no-legs --steps 1 --warmup 1 --reps 2}
 SUBFRAMES=${LSN_PROFILE_SUBFRAMES:-25600}   # subframes the profiled command processes: (steps + warmup) * nsf * reps
 OUT=gpurun_out
 mkdir -p $OUT

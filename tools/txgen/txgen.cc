@@ -233,6 +233,9 @@ typedef struct {
   uint32_t pusch_hop_offset;  // SIB2 pusch-HoppingOffset of the cell
   uint32_t msg4_period;   // every n subframes one scheduled UE gets a contention-resolution PDU with an RRCConnectionSetup (0 = never)
   uint32_t msg4_p_a_idx;  // its pdsch-ConfigDedicated.p-a (0..7 = dB-6 .. dB3), 8 = random; the UE's PDSCH is sent with that power offset from the next subframe on
+  // BCCH-DL-SCH messages sent with the SI-RNTI (sib_period != 0): message (sfn / 2) % 2 when its length is not 0, else random bytes
+  uint32_t si_len[2];
+  uint8_t si_msg[2][96];
 } txg_cfg_t;
 
 typedef struct { uint16_t rnti; uint8_t format, L; uint16_t ncce; uint32_t tti; uint32_t nbytes; uint32_t offset; uint8_t tb, mod, table256, is_ul; uint32_t nof_prb; uint32_t mcs; uint32_t cqi_req; uint32_t hop_bits_plus1; /* DCI 0: 0 = no hopping, else 1 + hopping bits */ } txg_pdu_t;
@@ -597,6 +600,8 @@ extern "C" int txg_next(txg_t* g, float* iq, txg_pdu_t* pdus, int max_pdus, uint
     if (Lcrb - 1 > nprb / 2) gr.riv = (uint32_t)(nprb * (nprb - Lcrb + 1) + (nprb - 1 - start));
     for (int i = 0; i < Lcrb; i++) gr.prbs.push_back(start + i);
     gr.nprb1a_is2 = false; gr.mcs[0] = 2 + g->rng.below(6); gr.rv[0] = 0; gr.t256 = false;
+    if (fixed_payload)  // the block must hold the whole message
+      while (gr.mcs[0] < 26 && lsn_tbs_table[gr.mcs[0]][2] < 8 * fixed_len) gr.mcs[0]++;
     gr.tbs[0] = lsn_tbs_table[gr.mcs[0]][2]; gr.qm[0] = 2; gr.scheme = P == 1 ? 0 : 1; gr.nlayers = P;
     (void)nbytes_hint;
     if (!place(gr, true)) return;
@@ -612,7 +617,11 @@ extern "C" int txg_next(txg_t* g, float* iq, txg_pdu_t* pdus, int max_pdus, uint
       poff += nb;
     }
   };
-  if (c.sib_period && sf == 5 && (sfn % 2) == 0) add_common(0xFFFF, 0, nullptr, 0);
+  if (c.sib_period && sf == 5 && (sfn % 2) == 0) {
+    const uint32_t mi = (sfn / 2) % 2;
+    if (c.si_len[mi]) add_common(0xFFFF, 0, c.si_msg[mi], (int)std::min<uint32_t>(c.si_len[mi], 96));
+    else add_common(0xFFFF, 0, nullptr, 0);
+  }
   if (c.paging_period && (tti % c.paging_period) == 3) add_common(0xFFFE, 0, nullptr, 0);
   if (c.rar_period && (tti % c.rar_period) == 7) {
     // MAC RAR PDU: one RAPID subheader + one RAR with a fresh temporary C-RNTI
