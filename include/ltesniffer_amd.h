@@ -236,6 +236,22 @@ typedef struct {
 int lsn_phy_process_file(lsn_phy_t* phy, const char* path, const lsn_file_cfg_t* cfg, uint32_t start_tti, uint64_t max_subframes /* 0 = to the end */,
                          uint32_t update_meta_period, uint64_t* subframes_done);
 
+/* ---- security-API sink (the step behind the path: PDSCH_Decoder::run_api_dl_mode, DL_Sniffer_PDSCH.cc:804-879) ----
+ * api_mode as ArgManager's -a (ArgManager.cc:63,218): -1 off (default), 0 identity mapping, 2 IMSI catching, 3 all.  For every CRC-ok
+ * downlink block the writer thread reports, in record order: paging records (modes 2, 3; decode_imsi_tmsi_paging :84-127: IMSI as 15
+ * digits, S-TMSI as 8 hex digits of the m-TMSI, rnti 65534) and the contention resolution identity next to an RRCConnectionSetup
+ * (modes 0, 3; :813-877: characters 3..10 of the identity printed in hex).  Blocks that produced an identity are also written to
+ * api_pcap (write_dl_paging_api / write_dl_crnti_api, PcapWriter.cc:120-145,177-190) when it is not NULL.
+ * Not covered: RRCConnectionReconfiguration / NAS identities (LCID 1) and the uplink parsers (UL_Sniffer_PUSCH.cc:47-247). */
+typedef struct {
+  uint32_t tti; uint16_t rnti;
+  uint32_t id_type;   /* Sniffer_dependency.h:43-45: 1 ID_TMSI, 2 ID_CON_RES, 3 ID_IMSI */
+  uint32_t msg_type;  /* Sniffer_dependency.h:50-55: 1 MSG_CON_SET, 5 MSG_PAGING */
+  char value[24];     /* the string print_api_dl receives */
+} lsn_api_event_t;
+typedef void (*lsn_api_sink_t)(void* user, const lsn_api_event_t* ev);
+int lsn_phy_set_api_mode(lsn_phy_t* phy, int api_mode, lsn_api_sink_t cb, void* user, lsn_pcap_t* api_pcap);
+
 /* ---- uplink (PUSCH) ----
  * lsn_phy_set_ul_config replaces srsran_enb_ul_set_cell(&enb_ul, cell, &ul_cfg.dmrs, ...) (SubframeWorker.cc:258-262); the two
  * values come from SIB2 (ULSchedule::set_config, ULSchedule.cc:140-158: cyclicShift, groupAssignmentPUSCH).
@@ -261,10 +277,14 @@ typedef struct {
    * correctly; the reference's settings are UL_Sniffer_PUSCH.cc:429-450 with the offsets I_ack = 10, I_cqi = 8, I_ri = 11 of
    * MCSTracking.cc:1534-1538 */
   uint32_t nof_ack;  /* HARQ-ACK bits 0..2 (uci_cfg.ack[0].nof_acks) */
-  uint32_t cqi_bits; /* size of the CQI report, 0 = none (aperiodic request: 4 + 2 N, higher-layer sub-band) */
+  uint32_t cqi_bits; /* size of the CQI report, 0 = none (aperiodic request: wideband 4, UE-selected sub-band 5, higher-layer sub-band 4 + 2 N) */
   uint32_t ri_bits;  /* rank indication bits (1 with a CQI request) */
   uint32_t hop;      /* 0: both slots on n_prb; 1: type-1 frequency hopping, slot 1 starts at n_prb_slot1 (36.213 8.4.1) */
   uint32_t n_prb_slot1;
+  /* 1 + betaOffset-ACK-Index / betaOffset-CQI-Index / betaOffset-RI-Index of the UE (ul_cfg.pusch.uci_offset = ue_config.uci_config,
+   * UL_Sniffer_PUSCH.cc:433-435; 36.213 Tables 8.6.3-1/-2/-3); 0 = the reference's defaults 10 / 8 / 11.  A reserved index makes the
+   * grant undecodable (crc_ok = 0). */
+  uint32_t beta_offset_ack_idx_p1, beta_offset_cqi_idx_p1, beta_offset_ri_idx_p1;
 } lsn_pusch_grant_t;
 typedef struct { uint32_t crc_ok; uint32_t iterations; float snr_db; uint32_t payload_off; } lsn_pusch_result_t;
 int lsn_phy_set_ul_config(lsn_phy_t* phy, const lsn_ul_cfg_t* cfg);

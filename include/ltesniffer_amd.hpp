@@ -127,6 +127,8 @@ public:
     lsn_ul_cfg_t u{cyclicShift, groupAssignmentPUSCH, puschHoppingOffset};
     return lsn_phy_set_ul_config(h, &u) == LSN_SUCCESS;
   }
+  // -a api_mode of LTESniffer_Core (run_api_dl_mode): identities of decoded downlink blocks go to cb, their blocks to apiPcap
+  bool setApiMode(int apiMode, lsn_api_sink_t cb, void* user, lsn_pcap_t* apiPcap = nullptr) { return lsn_phy_set_api_mode(h, apiMode, cb, user, apiPcap) == LSN_SUCCESS; }
   // ULSchedule::get_config + getSIB2: true once a configuration is in use (given, or learned from the first SIB2 in UL_MODE)
   bool getUlConfig(lsn_ul_cfg_t* ul = nullptr, lsn_sib2_t* sib2 = nullptr, bool* fromSib2 = nullptr)
   {

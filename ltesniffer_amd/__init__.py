@@ -29,7 +29,7 @@ EXPORTS = ["lsn_phy_create", "lsn_phy_destroy", "lsn_phy_set_cell", "lsn_phy_get
            "lsn_worker_sf_idx", "lsn_worker_sfn", "lsn_phy_process_device", "lsn_phy_process_host", "lsn_phy_tap",
            "lsn_phy_get_perf", "lsn_kernel_name", "lsn_version", "lsn_pcap_open", "lsn_pcap_open_mem",
            "lsn_pcap_set_wall_clock", "lsn_pcap_write", "lsn_pcap_sink", "lsn_pcap_mem", "lsn_pcap_nof_records",
-           "lsn_pcap_reset", "lsn_pcap_close", "lsn_phy_set_pcap_writer", "lsn_phy_set_ul_config", "lsn_phy_get_ul_config", "lsn_sib2_decode", "lsn_phy_pusch_decode",
+           "lsn_pcap_reset", "lsn_pcap_close", "lsn_phy_set_pcap_writer", "lsn_phy_set_api_mode", "lsn_phy_set_ul_config", "lsn_phy_get_ul_config", "lsn_sib2_decode", "lsn_phy_pusch_decode",
            "lsn_phy_tap_ul", "lsn_phy_set_prach_config", "lsn_phy_prach_detect", "lsn_phy_set_prach_sink", "lsn_prach_tti_opportunity", "lsn_phy_process_file", "lsn_phy_mib_decode", "lsn_phy_mib_decode_llr", "lsn_phy_submit_device", "lsn_phy_wait", "lsn_cell_search",
            "lsn_phy_set_shortcut_discovery", "lsn_phy_get_shortcut_discovery", "lsn_phy_set_histogram_threshold", "lsn_phy_print_stats",
            "lsn_phy_set_mcs_update_interval", "lsn_phy_update_mcs_database", "lsn_phy_nof_tracked_rnti", "lsn_worker_buffers_offset", "lsn_pcap_digest", "lsn_pcap_set_store", "lsn_phy_create_multi", "lsn_phy_nof_devices"]
@@ -62,6 +62,13 @@ class CellSearch(C.Structure):
 
 class FileCfg(C.Structure):
     _fields_ = [("nof_antennas", C.c_uint32), ("offset_time_samples", C.c_int64), ("offset_freq_hz", C.c_float)]
+
+
+class ApiEvent(C.Structure):
+    _fields_ = [("tti", C.c_uint32), ("rnti", C.c_uint16), ("id_type", C.c_uint32), ("msg_type", C.c_uint32), ("value", C.c_char * 24)]
+
+
+API_SINK = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(ApiEvent))
 
 
 class Sib2(C.Structure):
@@ -135,7 +142,8 @@ class UlCfg(C.Structure):
 class PuschGrant(C.Structure):
     _fields_ = [("sf", C.c_uint32), ("rnti", C.c_uint16), ("n_dmrs", C.c_uint16), ("n_prb", C.c_uint32), ("L_prb", C.c_uint32),
                 ("mod", C.c_uint32), ("tbs", C.c_uint32), ("rv", C.c_int), ("nof_ack", C.c_uint32), ("cqi_bits", C.c_uint32), ("ri_bits", C.c_uint32),
-                ("hop", C.c_uint32), ("n_prb_slot1", C.c_uint32)]
+                ("hop", C.c_uint32), ("n_prb_slot1", C.c_uint32),
+                ("beta_offset_ack_idx_p1", C.c_uint32), ("beta_offset_cqi_idx_p1", C.c_uint32), ("beta_offset_ri_idx_p1", C.c_uint32)]
 
 
 class PuschResult(C.Structure):
@@ -241,6 +249,7 @@ def lib():
         L.lsn_pcap_close.restype = None
         L.lsn_phy_set_pcap_writer.argtypes = [C.c_void_p, C.c_void_p]
         L.lsn_phy_set_ul_config.argtypes = [C.c_void_p, C.POINTER(UlCfg)]
+        L.lsn_phy_set_api_mode.argtypes = [C.c_void_p, C.c_int, API_SINK, C.c_void_p, C.c_void_p]
         L.lsn_phy_get_ul_config.argtypes = [C.c_void_p, C.POINTER(UlCfg), C.POINTER(Sib2), C.POINTER(C.c_uint32)]
         L.lsn_sib2_decode.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(Sib2)]
         L.lsn_phy_pusch_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p,
@@ -484,6 +493,18 @@ class Phy:
         u = UlCfg(cyclic_shift, delta_ss, hopping_offset)
         return lib().lsn_phy_set_ul_config(self._h, C.byref(u)) == LSN_SUCCESS
 
+    def setApiMode(self, api_mode, api_pcapwriter=None):
+        """-a of the reference: identities found in decoded downlink blocks are collected in self.api_events as
+        (tti, rnti, id_type, msg_type, value); blocks that carried one also go to api_pcapwriter"""
+        self.api_events = []
+        self._api_pcap = api_pcapwriter
+
+        def _cb(user, ev):
+            e = ev.contents
+            self.api_events.append((int(e.tti), int(e.rnti), int(e.id_type), int(e.msg_type), e.value.decode()))
+        self._api_cb = API_SINK(_cb)
+        return lib().lsn_phy_set_api_mode(self._h, int(api_mode), self._api_cb, None, api_pcapwriter._h if api_pcapwriter else None) == LSN_SUCCESS
+
     def getUlConfig(self):
         """None until an uplink configuration is in use, else dict(cyclic_shift, delta_ss, hopping_offset, from_sib2, sib2 = dict or None)"""
         u, s, f = UlCfg(), Sib2(), C.c_uint32(0)
@@ -498,7 +519,8 @@ class Phy:
         ul_iq = np.ascontiguousarray(ul_iq, dtype=np.complex64)
         n = len(grants)
         arr = (PuschGrant * max(1, n))(*[PuschGrant(g["sf"], g["rnti"], g.get("n_dmrs", 0), g["n_prb"], g["L_prb"], g["mod"], g["tbs"], g.get("rv", 0),
-                                                    g.get("nof_ack", 0), g.get("cqi_bits", 0), g.get("ri_bits", 0), g.get("hop", 0), g.get("n_prb2", 0))
+                                                    g.get("nof_ack", 0), g.get("cqi_bits", 0), g.get("ri_bits", 0), g.get("hop", 0), g.get("n_prb2", 0),
+                                                    g.get("i_ack_p1", 0), g.get("i_cqi_p1", 0), g.get("i_ri_p1", 0))
                                          for g in grants])
         res = (PuschResult * max(1, n))()
         cap = sum(g["tbs"] // 8 for g in grants) + 64

@@ -241,6 +241,14 @@ int lsn_phy_set_pcap_writer(lsn_phy_t* phy, lsn_pcap_t* p)
   return LSN_SUCCESS;
 }
 
+int lsn_phy_set_api_mode(lsn_phy_t* phy, int api_mode, lsn_api_sink_t cb, void* user, lsn_pcap_t* api_pcap)
+{
+  if (!phy || api_mode < -1 || api_mode > 3) return LSN_ERROR_INVALID_INPUTS;
+  phy->engine->setApi(api_mode, cb, user, api_pcap ? lsn_pcap_sink : nullptr, api_pcap);
+  for (auto& e : phy->more) e->setApi(api_mode, cb, user, api_pcap ? lsn_pcap_sink : nullptr, api_pcap);
+  return LSN_SUCCESS;
+}
+
 int lsn_phy_get_stats(lsn_phy_t* phy, lsn_blind_stats_t* out)
 {
   if (!phy || !out) return LSN_ERROR_INVALID_INPUTS;

@@ -364,6 +364,9 @@ void Engine::searchChunk(Chunk& ch, uint32_t update_meta_period)
     est_cfo = c.cfo_hz;  // SubframeWorker.cc:203
     if (!c.searched) continue;
     // RAR grants feed the RNTI manager before the next subframe is searched (DL_Sniffer_PDSCH.cc:782-797): decode them now
+    // (the entry objects of the accepted DCIs are otherwise built by the decode threads, FalconSearch::finishSubframe)
+    for (const AcceptedDci& a : c.raw)
+      if ((DciFormat)a.format != FORMAT0 && isRarFeedbackRnti(a.rnti)) { FalconSearch::materialize(c); break; }
     for (auto& e : c.dl) {
       if (!isRarFeedbackRnti(e.rnti)) continue;
       search->finishDlEntry(e, c.sf_idx, c.cfi);
@@ -1038,7 +1041,21 @@ void Engine::writerLoop()
     if (err.empty() && sink) {
       try {
         const uint8_t* base = ch->h_payload.data();
-        for (const auto& rec : ch->recs) sink(sink_user, &rec.ctx, base + rec.off, rec.len);
+        for (const auto& rec : ch->recs) {
+          sink(sink_user, &rec.ctx, base + rec.off, rec.len);
+          if (api_mode >= 0 && rec.ctx.direction == 1 && (rec.ctx.rnti_type == 1 || rec.ctx.rnti_type == 3)) {  // run_api_dl_mode, DL_Sniffer_PDSCH.cc:804-879
+            ApiEvent ev[20];
+            int nev = 0;
+            const bool keep = api_dl_events(api_mode, rec.ctx.rnti_type == 1 ? 'P' : 'C', base + rec.off, (int)rec.len, rec.ctx.rnti, rec.ctx.tti, ev, 20, &nev);
+            for (int i = 0; i < nev && api_sink; i++) {
+              lsn_api_event_t e{};
+              e.tti = ev[i].tti; e.rnti = ev[i].rnti; e.id_type = ev[i].id_type; e.msg_type = ev[i].msg_type;
+              std::memcpy(e.value, ev[i].value, sizeof(e.value));
+              api_sink(api_user, &e);
+            }
+            if (keep && api_pcap_sink) api_pcap_sink(api_pcap, &rec.ctx, base + rec.off, rec.len);
+          }
+        }
       } catch (const std::exception& ex) {
         err = ex.what();
       }

@@ -159,6 +159,7 @@ public:
                   uint64_t* subframes_done);
   int processHost(const float* iq, uint32_t nsf, uint32_t start_tti, uint32_t update_meta_period);
   void setSink(lsn_pdu_sink_t cb, void* user) { sink = cb; sink_user = user; }
+  void setApi(int mode, lsn_api_sink_t cb, void* user, lsn_pdu_sink_t pcap_cb, void* pcap) { api_mode = mode; api_sink = cb; api_user = user; api_pcap_sink = pcap_cb; api_pcap = pcap; }
   long tap(int what, uint32_t sf, void* out, size_t cap);
   void getPerf(lsn_perf_t* p) const { *p = perf; }
   void getStats(lsn_blind_stats_t* s) const;
@@ -216,7 +217,7 @@ private:
   int newJob(Chunk& ch, uint32_t sf, const DlEntry& e, int table, float p_a = 0.0f);
   void learnUeConfig(const uint8_t* pdu, int len, uint16_t rnti);
 public:
-  UeSpecConfig ueConfig(uint16_t rnti) { std::lock_guard<std::mutex> lk(mcs_mtx); return mcs_tracking.get_ue_config_rnti(rnti); }
+  UeSpecConfig ueConfig(uint16_t rnti) { std::lock_guard<std::mutex> lk(mcs_mtx); return cfg.sniffer_mode == 1 ? ulUeConfig(rnti) : mcs_tracking.get_ue_config_rnti(rnti); }
 private:
   void unpackRar(const uint8_t* p, int len, bool at_search);
   void emitPdu(Chunk& ch, JobRunner& r, const char* name, size_t payload_off, uint32_t len, uint16_t rnti, uint32_t tti, uint8_t tb);
@@ -310,6 +311,7 @@ private:
   lsn_perf_t perf{};
   float& est_cfo = sh->est_cfo;
   lsn_pdu_sink_t sink = nullptr; void* sink_user = nullptr;
+  int api_mode = -1; lsn_api_sink_t api_sink = nullptr; void* api_user = nullptr; lsn_pdu_sink_t api_pcap_sink = nullptr; void* api_pcap = nullptr;  // run_api_dl_mode
   uint64_t& sf_cnt = sh->sf_cnt;
   double& search_time_us = sh->search_time_us;
   Chunk* last_chunk = nullptr;
@@ -325,6 +327,9 @@ private:
   struct UlSchedGrant { uint16_t rnti = 0; PuschGrant g, g256; uint32_t n_dmrs = 0; bool hopping = false, is_rar = false; uint32_t nof_ack = 0; bool cqi_req = false; };
   std::map<uint32_t, std::vector<UlSchedGrant>> ul_sched, rar_sched;  // ULSchedule databases (touched in the commit turn only)
   std::vector<uint8_t> ulmod; uint32_t ulmod_count = 0;               // MCSTracking UL: 0 absent, 1 unknown, 2/3/4 = 16/64/256QAM max
+  std::vector<UeSpecConfig> ul_uecfg;                                 // ue_spec_config of the UL tracking entries (valid where ulmod != 0)
+  void ulTrackAdd(uint16_t rnti);                                     // add_RNTI_ul(UNKNOWN_MOD), MCSTracking.cc:57-69
+  UeSpecConfig ulUeConfig(uint16_t rnti) const { return (!ulmod.empty() && ulmod[rnti]) ? ul_uecfg[rnti] : mcs_tracking.default_config(); }
   std::vector<LsnUlGrantDev> ul_last_gd; std::vector<int> ul_last_idx;  // descriptors of the last puschDecode call (taps)
   JobRunner runner_u;
   cf32 *ul_d_iq = nullptr, *ul_d_grid = nullptr, *ul_d_hs = nullptr; float* ul_d_stat = nullptr; LsnUlGrantDev* ul_d_grants = nullptr;

@@ -588,6 +588,13 @@ void Histogram::addZeros(uint32_t nTimes)
 {
   uint32_t gained = 0;  // net increase of the count of item 0
   // fast path: the window is full and the next nTimes slots hold 0 already (the usual case: most of the history is padding)
+  while (rnti_histogram_ready && nTimes >= 16 && rnti_history_current + 16 <= rnti_history_end) {
+    uint64_t w[4];
+    std::memcpy(w, &rnti_history[rnti_history_current], 32);
+    if ((w[0] | w[1] | w[2] | w[3]) != 0) break;
+    rnti_history_current += 16; nTimes -= 16;
+    if (rnti_history_current == rnti_history_end) rnti_history_current = 0;
+  }
   while (rnti_histogram_ready && nTimes >= 4 && rnti_history_current + 4 <= rnti_history_end) {
     uint64_t w;
     std::memcpy(&w, &rnti_history[rnti_history_current], 8);

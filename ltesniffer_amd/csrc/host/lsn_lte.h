@@ -174,6 +174,16 @@ struct Sib2Config {
 // (SystemInformationBlockType1, or a SystemInformation whose first entry is another block), 2 = SIB2 found (out filled)
 int sib2_decode(const uint8_t* pdu, int len, Sib2Config& out);
 
+// ---- security-API view of decoded downlink blocks (PDSCH_Decoder::run_api_dl_mode, DL_Sniffer_PDSCH.cc:804-879) ----
+struct PagingId { bool is_imsi = false; uint32_t nof_digits = 0; uint8_t digits[21] = {0}; uint32_t mmec = 0, m_tmsi = 0; };
+// PCCH-Message -> paging records (decode_imsi_tmsi_paging, DL_Sniffer_PDSCH.cc:84-127): number of records, -1 when the message does not unpack
+int paging_decode(const uint8_t* pdu, int len, PagingId* out, int cap);
+struct ApiEvent { uint32_t tti = 0; uint16_t rnti = 0; uint32_t id_type = 0, msg_type = 0; char value[24] = {0}; };  // print_api_dl's arguments
+enum { API_ID_TMSI = 1, API_ID_CON_RES = 2, API_ID_IMSI = 3, API_MSG_CON_SET = 1, API_MSG_PAGING = 5 };  // Sniffer_dependency.h:43-55
+// what run_api_dl_mode reports for one CRC-ok downlink block (name = first letter of the reference's RNTI name, api_mode 0 / 2 / 3):
+// events appended to ev (at most cap), return value = true when the block also goes to the API pcap (write_dl_paging_api / write_dl_crnti_api)
+bool api_dl_events(int api_mode, char name, const uint8_t* pdu, int len, uint16_t rnti, uint32_t tti, ApiEvent* ev, int cap, int* nev);
+
 // ---- MCSTracking (DL table learning + UE-specific configuration + database ageing; MCSTracking.cc:758-927,1269-1400,1444-1540) ----
 // Time is counted in SUBFRAMES processed so far (`now`), not in clock() ticks: the reference ages its database by CPU time consumed
 // (MCSTracking.cc:778,854-858), i.e. by replay speed; one subframe = 1 ms of air time is the deterministic equivalent.
@@ -183,6 +193,7 @@ public:
   void update_ue_config_rnti(uint16_t rnti, const UeSpecConfig& c, uint32_t now);
   bool check_default_config() const { return has_default; }
   float default_p_a() const { return default_cfg.p_a; }
+  UeSpecConfig default_config() const { UeSpecConfig c = default_cfg; c.has_ue_config = false; return c; }
   void update_default_ue_config(const UeSpecConfig& c) { default_cfg = c; has_default = true; }
   // one decoded C-RNTI transport block: every CCCH SDU is tried as RRCConnectionSetup (DL_Sniffer_PDSCH.cc:1041-1070); true when one was
   bool learn_from_pdu(const uint8_t* pdu, int len, uint16_t rnti, uint32_t now);

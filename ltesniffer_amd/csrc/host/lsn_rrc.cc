@@ -9,6 +9,7 @@
 // determinants.  Messages that carry DRB or SPS components (never the case for a connection setup) are not accepted.
 // HIP-free host code: built into the product library and, for the CPU tests, into tests/native.
 #include "lsn_lte.h"
+#include <cstdio>
 #include <cstring>
 
 namespace lsn {
@@ -312,6 +313,100 @@ int sib2_decode(const uint8_t* pdu, int len, Sib2Config& out)
   if (b.err) return 0;
   out = o;
   return 2;
+}
+
+// PCCH-Message (TS 36.331 6.2.1 / 6.2.2): c1 { paging { pagingRecordList OPTIONAL, systemInfoModification OPTIONAL, etws-Indication OPTIONAL,
+// nonCriticalExtension OPTIONAL } }; PagingRecord { ue-Identity CHOICE { s-TMSI { mmec BIT STRING (8), m-TMSI BIT STRING (32) }, imsi SEQUENCE
+// (SIZE (6..21)) OF INTEGER (0..9), ... }, cn-Domain, ... }.  Only the record list is read (the reference reads nothing else).
+int paging_decode(const uint8_t* pdu, int len, PagingId* out, int cap)
+{
+  BitReader b{pdu, len > 0 ? 8u * (uint32_t)len : 0u};
+  if (b.flag()) return -1;  // messageClassExtension
+  const bool list = b.flag();
+  b.flag(); b.flag(); b.flag();  // systemInfoModification, etws-Indication, nonCriticalExtension: behind the list, not read
+  if (b.err) return -1;
+  int n = 0;
+  if (list) {
+    const uint32_t cnt = b.get(4) + 1;
+    for (uint32_t i = 0; i < cnt && !b.err; i++) {
+      const bool ext = b.flag();
+      PagingId id;
+      if (b.flag()) return -1;  // an identity outside the root alternatives
+      if (!b.flag()) {
+        id.mmec = b.get(8); id.m_tmsi = b.get(32);
+      } else {
+        id.is_imsi = true;
+        id.nof_digits = b.get(4) + 6;
+        if (id.nof_digits > 21) return -1;
+        for (uint32_t k = 0; k < id.nof_digits; k++) { id.digits[k] = (uint8_t)b.get(4); if (id.digits[k] > 9) b.err = true; }
+      }
+      b.get(1);  // cn-Domain
+      if (ext) b.skipExtensions();
+      if (b.err) return -1;
+      if (n < cap) out[n++] = id;
+    }
+  }
+  return b.err ? -1 : n;
+}
+
+bool api_dl_events(int api_mode, char name, const uint8_t* pdu, int len, uint16_t rnti, uint32_t tti, ApiEvent* ev, int cap, int* nev)
+{
+  int n = 0;
+  bool to_pcap = false;
+  auto add = [&](uint16_t r, uint32_t id, uint32_t msg, const char* v) {
+    if (n >= cap) return;
+    ApiEvent& e = ev[n++];
+    e.tti = tti; e.rnti = r; e.id_type = id; e.msg_type = msg;
+    std::snprintf(e.value, sizeof(e.value), "%s", v);
+  };
+  if (name == 'P' && (api_mode == 2 || api_mode == 3)) {  // IMSI catching from paging, :805-812 + :84-127
+    PagingId rec[16];
+    const int nr = paging_decode(pdu, len, rec, 16);
+    for (int i = 0; i < nr; i++) {
+      char v[24] = {0};
+      if (rec[i].is_imsi) {  // the reference prints the first 15 digits
+        for (uint32_t k = 0; k < 15 && k < rec[i].nof_digits; k++) v[k] = (char)('0' + rec[i].digits[k]);
+        add(65534, API_ID_IMSI, API_MSG_PAGING, v);
+      } else {
+        std::snprintf(v, sizeof(v), "%08x", rec[i].m_tmsi);
+        add(65534, API_ID_TMSI, API_MSG_PAGING, v);
+      }
+      to_pcap = true;
+    }
+  }
+  if (name == 'C' && (api_mode == 0 || api_mode == 3)) {  // identity mapping: contention resolution identity next to an RRCConnectionSetup, :813-877
+    MacSubheader sub[20];
+    const int ns = mac_dlsch_parse(pdu, len, sub, 20);
+    bool setup = false, found = false;
+    int seen[10], nseen = 0;
+    for (int i = 0; i < ns; i++) {
+      if (sub[i].is_sdu && sub[i].lcid == 0) {
+        UeSpecConfig c;
+        if (rrc_conn_setup_decode(pdu + sub[i].off, (int)sub[i].len, c)) setup = true;
+      } else if (sub[i].is_sdu && sub[i].lcid == 1) {
+        // RRCConnectionReconfiguration / NAS identities: not restated
+      } else {
+        if (nseen < 10) seen[nseen++] = i; else break;
+      }
+      if (setup) {
+        for (int h = 0; h < nseen && !found; h++)
+          if (sub[seen[h]].lcid == 28 && sub[seen[h]].len == 6) {
+            unsigned long long id = 0;
+            for (int k = 0; k < 6; k++) id = (id << 8) | pdu[sub[seen[h]].off + k];
+            char hex[24];
+            std::snprintf(hex, sizeof(hex), "%llx", id);  // printed without leading zeros; characters 3..10 are reported (:865-866)
+            const size_t L = std::strlen(hex);
+            char v[24] = {0};
+            if (L >= 3) std::snprintf(v, sizeof(v), "%.8s", hex + 3);
+            add(rnti, API_ID_CON_RES, API_MSG_CON_SET, v);
+            found = true;
+          }
+        to_pcap = true;  // write_dl_crnti_api (once per block here)
+      }
+    }
+  }
+  if (nev) *nev = n;
+  return to_pcap;
 }
 
 }  // namespace lsn

@@ -100,33 +100,23 @@ void FalconSearch::setCell(const Cell& c, const uint32_t n[3])
     LocTemplate& tp = loc_template[cfi];
     const uint32_t ncce = nof_cce[cfi], lim = std::min<uint32_t>(ncce, LSN_MAX_NUM_OF_CCE);
     for (auto& row : tp.map) for (auto& v : row) v = -1;
+    for (auto& cs : tp.cover) cs.clear();
     uint32_t k = 0;
     for (int l = 3; l >= 0; l--) {
       const uint32_t L = 1u << l;
       if (ncce < L) continue;
       for (uint32_t i = 0; i < lim / L; i++)
         if (k < LSN_MAX_LOC) {
-          tp.locations[k] = FalconLocation{(uint32_t)l, L * (i % (ncce / L)), false, false, false, true, k};
+          tp.locations[k] = FalconLocation{(uint32_t)l, L * (i % (ncce / L))};
           for (uint32_t m = tp.locations[k].ncce; m < tp.locations[k].ncce + L && m < LSN_MAX_NUM_OF_CCE; m++) tp.map[m][l] = (int16_t)k;
           k++;
         }
     }
     tp.nloc = k;
+    for (uint32_t m = 0; m < LSN_MAX_NUM_OF_CCE; m++)  // (a later location of the same level overwrites an earlier one in the map, like the reference's pointer map)
+      for (int a = 0; a < 4; a++)
+        if (tp.map[m][a] >= 0) tp.cover[m].set((uint32_t)tp.map[m][a]);
   }
-}
-
-// srsran_pdcch_decode_msg_limit_avg_llr_power (falcon_pdcch.c:110-170) as a lookup in the exhaustive candidate table
-void FalconSearch::decodeCandidate(const FalconLocation& loc, DciFormat format, DciCandidate& cand)
-{
-  const LsnCand& c = cur_cand[(size_t)loc.index * LSN_MAX_SIZES + size_index_of_format[format]];
-  nof_lookups++;
-  if (!(c.flags & 1u)) return;
-  cand.search_space_match_result = (c.flags >> 1) & 3u;  // srsran_pdcch_validate_location, computed with the candidate
-  cand.msg.bits = c.bits;
-  cand.msg.nof_bits = size_of_format[format];
-  cand.rnti = (uint16_t)c.rnti;
-  if (format == FORMAT0 || format == FORMAT1A) cand.msg.format = (c.bits >> 63) == 0 ? FORMAT0 : FORMAT1A;  // falcon_pdcch.c:147-148
-  else cand.msg.format = format;
 }
 
 // DCICollection::addCandidate (DCICollection.cc:97-298) + srsran_dci_msg_to_trace_timestamp (falcon_dci.c:148-352).
@@ -135,22 +125,30 @@ void FalconSearch::decodeCandidate(const FalconLocation& loc, DciFormat format, 
 // "exists" for the reference is resolved at commit time, when the MCS-tracking state of the subframe is known.
 void FalconSearch::addCandidate(SubframeCtx& c, const DciCandidate& cand, uint32_t L, uint32_t ncce, uint32_t histval)
 {
-  const DciFormat fmt = cand.msg.format;
-  if (c.accepted.size() < 64 * 6) {
-    const uint32_t a[6] = {cand.rnti, (uint32_t)fmt, L, ncce, cand.msg.nof_bits, histval};
-    c.accepted.insert(c.accepted.end(), a, a + 6);
+  c.raw.push_back(AcceptedDci{cand.rnti, (uint8_t)cand.msg.format, (uint8_t)L, (uint16_t)ncce, (uint16_t)cand.msg.nof_bits, histval, cand.msg.bits});
+}
+
+void FalconSearch::materialize(SubframeCtx& c)
+{
+  if (c.materialized) return;
+  c.materialized = true;
+  for (const AcceptedDci& r : c.raw) {
+    if (c.accepted.size() < 64 * 6) {
+      const uint32_t a[6] = {r.rnti, (uint32_t)r.format, r.L, r.ncce, r.nof_bits, r.histval};
+      c.accepted.insert(c.accepted.end(), a, a + 6);
+    }
+    if ((DciFormat)r.format == FORMAT0) {
+      if (c.ul.size() >= 64) continue;
+      c.ul.emplace_back();
+      UlEntry& u = c.ul.back();
+      u.rnti = r.rnti; u.nof_bits = r.nof_bits; u.L = r.L; u.ncce = r.ncce; u.histval = r.histval; u.bits = r.bits;
+      continue;
+    }
+    if (c.dl.size() >= 64) continue;
+    c.dl.emplace_back();
+    DlEntry& e = c.dl.back();
+    e.rnti = r.rnti; e.format = (DciFormat)r.format; e.nof_bits = r.nof_bits; e.L = r.L; e.ncce = r.ncce; e.histval = r.histval; e.bits = r.bits;
   }
-  if (fmt == FORMAT0) {
-    if (c.ul.size() >= 64) return;
-    c.ul.emplace_back();
-    UlEntry& u = c.ul.back();
-    u.rnti = cand.rnti; u.nof_bits = cand.msg.nof_bits; u.L = L; u.ncce = ncce; u.histval = histval; u.bits = cand.msg.bits;
-    return;
-  }
-  if (c.dl.size() >= 64) return;
-  c.dl.emplace_back();
-  DlEntry& e = c.dl.back();
-  e.rnti = cand.rnti; e.format = fmt; e.nof_bits = cand.msg.nof_bits; e.L = L; e.ncce = ncce; e.histval = histval; e.bits = cand.msg.bits;
 }
 
 void FalconSearch::finishUlEntry(UlEntry& u) const
@@ -194,6 +192,7 @@ void FalconSearch::finishSubframe(SubframeCtx& c)
 {
   if (c.finished) return;
   c.finished = true;
+  materialize(c);
   uint16_t rb_dl[110] = {0}, rb_ul[110] = {0};
   bool dl_collision = false, ul_collision = false;
   for (auto& e : c.dl) {
@@ -242,16 +241,30 @@ int FalconSearch::inspect_dci_location_recursively(SubframeCtx& c, const int16_t
 {
   int hist_max_format_idx = -1;
   uint32_t hist_max_format_value = 0, nof_cand_above_threshold = 0;
-  FalconLocation* loc = cce_map[ncce][L] >= 0 ? &locations[cce_map[ncce][L]] : nullptr;  // the level-L location that covers this CCE
-  if (!(loc && !loc->occupied && !loc->checked && loc->sufficient_power)) return 0;  // :124-127
+  const int li = cce_map[ncce][L];  // the level-L location that covers this CCE
+  if (li < 0 || f_occupied.test((uint32_t)li) || f_checked.test((uint32_t)li) || f_nopower.test((uint32_t)li)) return 0;  // :124-127
   // only the first nof_formats entries exist (children index their parent's candidates with the same format list)
   alignas(DciCandidate) unsigned char cand_raw[sizeof(DciCandidate) * NOF_FORMATS];
   DciCandidate* cand = reinterpret_cast<DciCandidate*>(cand_raw);
-  for (uint32_t fi = 0; fi < nof_formats; fi++) new (&cand[fi]) DciCandidate();
+  const LsnCand* row = cur_cand + (size_t)li * LSN_MAX_SIZES;
+  stats.nof_decoded_locations += nof_formats;
+  nof_lookups += nof_formats;
 
   for (uint32_t fi = 0; fi < nof_formats; fi++) {
-    decodeCandidate(*loc, metas[fi]->format, cand[fi]);
-    stats.nof_decoded_locations++;
+    {  // srsran_pdcch_decode_msg_limit_avg_llr_power (falcon_pdcch.c:110-170) as a lookup in the exhaustive candidate table (decodeCandidate)
+      const DciFormat format = metas[fi]->format;
+      const LsnCand& t = row[size_index_of_format[format]];
+      DciCandidate& d = cand[fi];
+      if (t.flags & 1u) {
+        d.rnti = (uint16_t)t.rnti;
+        d.search_space_match_result = (t.flags >> 1) & 3u;
+        d.msg.bits = t.bits;
+        d.msg.nof_bits = size_of_format[format];
+        d.msg.format = (format == FORMAT0 || format == FORMAT1A) ? ((t.bits >> 63) == 0 ? FORMAT0 : FORMAT1A) : format;  // falcon_pdcch.c:147-148
+      } else {
+        d.rnti = 0; d.search_space_match_result = 0; d.msg.bits = 0; d.msg.nof_bits = 0; d.msg.format = FORMAT0;
+      }
+    }
     if (cand[fi].msg.format == FORMAT0 && rnti_manager->getActivationReason(cand[fi].rnti) == RM_ACT_RAR) {  // :139-158
       bool add = true;
       for (auto& t : temp_dci0)
@@ -263,8 +276,11 @@ int FalconSearch::inspect_dci_location_recursively(SubframeCtx& c, const int16_t
     if (cand[fi].rnti > RARNTI_START && cand[fi].rnti < RARNTI_END)  // :181-197
       if (metas[fi]->format != FORMAT1A && metas[fi]->format != FORMAT1C) { cand[fi].rnti = 0; cand[fi].search_space_match_result = 0; continue; }
     if (shortcut_discovery && enable_discovery && parent_cand != nullptr && parent_cand[fi].rnti == cand[fi].rnti &&
-        !rnti_manager->isForbidden(cand[fi].rnti, metas[fi]->global_index))  // :200-211 (shortcut discovery)
+        !rnti_manager->isForbidden(cand[fi].rnti, metas[fi]->global_index)) {  // :200-211 (shortcut discovery)
+      stats.nof_decoded_locations -= nof_formats - fi - 1;  // the formats behind fi are not decoded
+      nof_lookups -= nof_formats - fi - 1;
       return -((int)fi + 1);
+    }
     // :214 srsran_pdcch_validate_location: the verdict travels with the candidate (decodeCandidate)
     if (cand[fi].search_space_match_result == 0) { cand[fi].rnti = 0; continue; }
     if (rnti_manager->validateAndRefresh(cand[fi].rnti, metas[fi]->global_index)) {  // :245-250
@@ -283,7 +299,7 @@ int FalconSearch::inspect_dci_location_recursively(SubframeCtx& c, const int16_t
       }
     if (hist_max_format_idx == -1) nof_cand_above_threshold = 0;
   }
-  loc->checked = true;  // :282
+  f_checked.set((uint32_t)li);  // :282
   int disamb = 0;
   if (nof_cand_above_threshold > 0 && cand[hist_max_format_idx].search_space_match_result == 1) {  // :288-298
     if (L > 0 && max_depth > 0)
@@ -315,10 +331,8 @@ int FalconSearch::inspect_dci_location_recursively(SubframeCtx& c, const int16_t
     }
   }
   if (nof_cand_above_threshold > 0) {  // :371-439
-    loc->used = true;
-    for (uint32_t ci = ncce; ci < ncce + (1u << L); ci++)
-      for (int a = 0; a < 4; a++)
-        if (cce_map[ci][a] >= 0) { locations[cce_map[ci][a]].occupied = true; locations[cce_map[ci][a]].checked = true; }
+    f_used.set((uint32_t)li);
+    for (uint32_t ci = ncce; ci < ncce + (1u << L); ci++) { f_occupied |= cur_tp->cover[ci]; f_checked |= cur_tp->cover[ci]; }
     DciCandidate& best = cand[hist_max_format_idx];
     rnti_manager->addCandidate(best.rnti, metas[hist_max_format_idx]->global_index);
     metas[hist_max_format_idx]->hits++;
@@ -347,36 +361,39 @@ void FalconSearch::recursive_blind_dci_search(SubframeCtx& c)
   // srsran_pdcch_ue_locations_all_map (falcon_pdcch.c:321-356): the enumeration and the CCE -> covering-location map only depend on
   // the CFI: the map is used straight from the template (indices instead of pointers), the per-subframe flags are copied
   const LocTemplate& tp = loc_template[c.cfi - 1];
+  cur_tp = &tp;
   const int16_t (*cce_map)[4] = tp.map;
   const uint32_t nloc = tp.nloc;
-  std::memcpy(locations, tp.locations, sizeof(FalconLocation) * nloc);
+  f_used.clear(); f_occupied.clear(); f_checked.clear(); f_nopower.clear();
   stats.nof_locations += nloc;
-  for (uint32_t cc = 0; cc < lim; cc++)  // srsran_pdcch_cce_avg_llr_power, falcon_pdcch.c:595-620
-    if (cur_ccepow[cc] < 0.7f)
-      for (int a = 0; a < 4; a++)
-        if (cce_map[cc][a] >= 0) locations[cce_map[cc][a]].sufficient_power = false;
-  // (the entry test of inspect_dci_location_recursively, DCISearch.cc:124-127, is repeated here so that dead locations cost no call)
-  for (uint32_t i = 0; i < nloc; i++) {
-    const FalconLocation& l = locations[i];
-    if (l.occupied || l.checked || !l.sufficient_power) continue;
-    inspect_dci_location_recursively(c, cce_map, l.ncce, l.L, 99, meta_formats->getPrimaryMetaFormats(), meta_formats->getNofPrimaryMetaFormats(), 1, nullptr);
-  }
-  if (!meta_formats->skipSecondaryMetaFormats()) {
-    for (uint32_t i = 0; i < nloc; i++) locations[i].checked = false;
-    for (uint32_t i = 0; i < nloc; i++) {
-      const FalconLocation& l = locations[i];
-      if (l.occupied || l.checked || !l.sufficient_power) continue;
-      inspect_dci_location_recursively(c, cce_map, l.ncce, l.L, 99, meta_formats->getSecondaryMetaFormats(), meta_formats->getNofSecondaryMetaFormats(), 1, nullptr);
+  // srsran_pdcch_cce_avg_llr_power, falcon_pdcch.c:595-620: CCEs below the power bound switch off every location that covers them
+  static_assert(LSN_MAX_NUM_OF_CCE <= 128, "two words of CCE flags");
+  uint64_t low[2] = {0, 0};  // bit cc: CCE cc is below the bound
+  for (uint32_t cc = 0; cc < lim; cc++) low[cc >> 6] |= (uint64_t)(cur_ccepow[cc] < 0.7f) << (cc & 63);
+  for (int k = 0; k < 2; k++)
+    for (uint64_t m = low[k]; m; m &= m - 1) f_nopower |= tp.cover[64 * k + __builtin_ctzll(m)];
+  // (the entry test of inspect_dci_location_recursively, DCISearch.cc:124-127, is repeated here so that dead locations cost no call:
+  // the next location in index order that is neither occupied nor checked nor without power, re-evaluated after every call)
+  auto pass = [&](MetaFormat** metas, uint32_t nmetas) {
+    for (uint32_t i = 0; i < nloc;) {
+      const uint32_t w = i >> 6;
+      const uint64_t alive = ~(f_occupied.w[w] | f_checked.w[w] | f_nopower.w[w]) & (~0ull << (i & 63));
+      if (!alive) { i = (w + 1) << 6; continue; }
+      i = (w << 6) + (uint32_t)__builtin_ctzll(alive);
+      if (i >= nloc) break;
+      const FalconLocation& l = tp.locations[i];
+      inspect_dci_location_recursively(c, cce_map, l.ncce, l.L, 99, metas, nmetas, 1, nullptr);
+      i++;
     }
+  };
+  pass(meta_formats->getPrimaryMetaFormats(), meta_formats->getNofPrimaryMetaFormats());
+  if (!meta_formats->skipSecondaryMetaFormats()) {
+    f_checked.clear();
+    pass(meta_formats->getSecondaryMetaFormats(), meta_formats->getNofSecondaryMetaFormats());
   }
   uint32_t missed = 0;  // falcon_pdcch.c:561-593
-  for (uint32_t cc = 0; cc < lim; cc++) {
-    if (cur_ccepow[cc] < 0.7f) continue;
-    bool m = true;
-    for (int a = 0; a < 4; a++)
-      if (cce_map[cc][a] >= 0 && locations[cce_map[cc][a]].used) { m = false; break; }
-    if (m) missed++;
-  }
+  for (uint32_t cc = 0; cc < lim; cc++)
+    missed += (uint32_t)(!((low[cc >> 6] >> (cc & 63)) & 1ull) & !f_used.intersects(tp.cover[cc]));
   stats.nof_missed_cce += missed;
   rnti_manager->stepTime();
 }

@@ -33,16 +33,21 @@ struct DlEntry {  // DL_Sniffer_DCI_DL (Sniffer_dependency.h:90)
 };
 struct UlEntry { uint16_t rnti = 0; uint32_t nof_bits = 0, L = 0, ncce = 0, histval = 0; unsigned long long bits = 0; DciUl dci; PuschGrant grant, grant256; bool ok = false, finished = false; };
 
+// what the sequential search records of an accepted DCI; the DlEntry / UlEntry objects are built from it off the search thread
+struct AcceptedDci { uint16_t rnti; uint8_t format, L; uint16_t ncce, nof_bits; uint32_t histval; unsigned long long bits; };
+
 struct SubframeCtx {
   uint32_t tti = 0, sf_idx = 0, sfn = 0, cfi = 0;
   float snr_db = 0, cfo_hz = 0;
   bool searched = false;
   bool finished = false;           // finishSubframe has run (grants converted, collision statistics counted)
+  bool materialized = false;       // dl / ul / accepted have been built from raw (FalconSearch::materialize)
+  std::vector<AcceptedDci> raw;    // accepted DCIs in acceptance order
   std::vector<DlEntry> dl;
   std::vector<UlEntry> ul;
   std::vector<uint32_t> accepted;  // 6 words per accepted DCI: rnti, format, L, ncce, nof_bits, histval
   // the TTI counter wraps with the SFN (10 * 1024 subframes): records carry sfn 0..1023 like PcapWriter.cc:102-103, also when a call crosses the wrap
-  void reset(uint32_t tti_) { tti_ %= 10240u; tti = tti_; sf_idx = tti_ % 10; sfn = (tti_ / 10) % 1024; cfi = 0; snr_db = cfo_hz = 0; searched = false; finished = false; dl.clear(); ul.clear(); accepted.clear(); }
+  void reset(uint32_t tti_) { tti_ %= 10240u; tti = tti_; sf_idx = tti_ % 10; sfn = (tti_ / 10) % 1024; cfi = 0; snr_db = cfo_hz = 0; searched = false; finished = false; materialized = false; raw.clear(); dl.clear(); ul.clear(); accepted.clear(); }
 };
 
 struct BlindStats { uint32_t nof_locations = 0, nof_decoded_locations = 0, nof_cce = 0, nof_missed_cce = 0, nof_subframes = 0, nof_subframe_collisions_dw = 0, nof_subframe_collisions_up = 0; };
@@ -81,17 +86,34 @@ public:
   // everything of DCICollection::addCandidate the decisions of the search do not depend on, for all accepted DCIs of a subframe:
   // unpack + grant conversion + the PRB collision statistics (DCICollection.cc:215-223,275-280).  Thread-safe (decode threads).
   void finishSubframe(SubframeCtx& c);
+  // DCICollection::addCandidate's bookkeeping for the DCIs the search accepted: c.raw -> c.accepted / c.dl / c.ul (idempotent)
+  static void materialize(SubframeCtx& c);
   bool buildDlEntry(const SubframeCtx& c, uint16_t rnti, DciFormat fmt, unsigned long long bits, DlEntry& e) const;
   uint64_t nof_lookups = 0;
 
 private:
-  struct FalconLocation { uint32_t L, ncce; bool used, occupied, checked, sufficient_power; uint32_t index; };
-  struct LocTemplate { FalconLocation locations[LSN_MAX_LOC]; int16_t map[LSN_MAX_NUM_OF_CCE][4]; uint32_t nloc = 0; };
+  // falcon_dci_location_t (falcon_dci.h:91-99): the static part (L, ncce) lives in the per-CFI template, the four per-subframe flags
+  // (used / occupied / checked / !sufficient_power) are bit sets over the location index
+  static constexpr int LOCW = (LSN_MAX_LOC + 63) / 64;
+  struct LocSet {
+    uint64_t w[LOCW] = {0};
+    bool test(uint32_t i) const { return (w[i >> 6] >> (i & 63)) & 1ull; }
+    void set(uint32_t i) { w[i >> 6] |= 1ull << (i & 63); }
+    void operator|=(const LocSet& o) { for (int k = 0; k < LOCW; k++) w[k] |= o.w[k]; }
+    bool intersects(const LocSet& o) const { uint64_t a = 0; for (int k = 0; k < LOCW; k++) a |= w[k] & o.w[k]; return a != 0; }
+    void clear() { for (int k = 0; k < LOCW; k++) w[k] = 0; }
+  };
+  struct FalconLocation { uint32_t L, ncce; };
+  struct LocTemplate {
+    FalconLocation locations[LSN_MAX_LOC];
+    int16_t map[LSN_MAX_NUM_OF_CCE][4];   // CCE -> the location of every aggregation level that covers it (-1: none)
+    LocSet cover[LSN_MAX_NUM_OF_CCE];     // the same as a set
+    uint32_t nloc = 0;
+  };
   struct TempDci0 { uint16_t rnti; uint32_t L, ncce; DciFormat format; DciCandidate cand; };
   int inspect_dci_location_recursively(SubframeCtx& c, const int16_t (*cce_map)[4], uint32_t ncce, uint32_t L, uint32_t max_depth, MetaFormat** meta_formats_,
                                        uint32_t nof_formats, uint32_t enable_discovery, const DciCandidate* parent_cand);
   void recursive_blind_dci_search(SubframeCtx& c);
-  void decodeCandidate(const FalconLocation& loc, DciFormat format, DciCandidate& cand);
   void addCandidate(SubframeCtx& c, const DciCandidate& cand, uint32_t L, uint32_t ncce, uint32_t histval);
 
   Cell cell;
@@ -104,7 +126,8 @@ private:
   uint32_t size_list[LSN_MAX_SIZES] = {0}, nsizes = 0;
   std::vector<TempDci0> temp_dci0;
   std::atomic<uint32_t> coll_dw{0}, coll_up{0};  // nof_subframe_collisions_dw / _up, counted by finishSubframe
-  FalconLocation locations[LSN_MAX_LOC];
+  LocSet f_used, f_occupied, f_checked, f_nopower;
+  const LocTemplate* cur_tp = nullptr;
   LocTemplate loc_template[3];
   const LsnCand* cur_cand = nullptr;
   const float* cur_ccepow = nullptr;

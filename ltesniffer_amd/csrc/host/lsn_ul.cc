@@ -179,7 +179,7 @@ void Engine::puschDecodeGrid(const cf32* d_grid, uint32_t nsf, uint32_t start_tt
     const uint32_t M = 12 * g.L_prb, sf_idx = (start_tti + g.sf) % 10;
     CbSegm s;
     if (!cbsegm((int)g.tbs, s)) continue;
-    // control resources Q' = min(ceil(O M_sc N_symb beta / sum K_r), cap) (36.212 5.2.2.6), beta in eighths: 20, 15.875, 2.25
+    // control resources Q' = min(ceil(O M_sc N_symb beta / sum K_r), cap) (36.212 5.2.2.6), beta in eighths
     const long long sumK = (long long)s.Cp * s.Kp + (long long)s.Cm * s.Km;
     auto qprime = [&](uint32_t O, long long beta8, uint32_t cap) -> uint32_t {
       if (!O) return 0u;
@@ -187,8 +187,13 @@ void Engine::puschDecodeGrid(const cf32* d_grid, uint32_t nsf, uint32_t start_tt
       return (uint32_t)std::min<long long>(q, cap);
     };
     if (g.nof_ack > 2 || g.ri_bits > 2 || g.cqi_bits > 64) continue;
-    const uint32_t q_ack = qprime(g.nof_ack, 160, 4 * M), q_ri = qprime(g.ri_bits, 127, 4 * M);
-    const uint32_t q_cqi = g.cqi_bits ? qprime(g.cqi_bits + (g.cqi_bits > 11 ? 8u : 0u), 18, 12 * M - q_ri) : 0u;
+    // beta offsets of the UE (36.213 Tables 8.6.3-1/-2/-3, spec/lte_tables.h), the reference's defaults when the grant does not name them
+    const uint32_t ia = g.beta_offset_ack_idx_p1 ? g.beta_offset_ack_idx_p1 - 1 : 10u, ic = g.beta_offset_cqi_idx_p1 ? g.beta_offset_cqi_idx_p1 - 1 : 8u,
+                   ir = g.beta_offset_ri_idx_p1 ? g.beta_offset_ri_idx_p1 - 1 : 11u;
+    if (ia > 15 || ic > 15 || ir > 15) continue;
+    if ((g.nof_ack && !lsn_beta_ack8[ia]) || (g.ri_bits && !lsn_beta_ri8[ir]) || (g.cqi_bits && !lsn_beta_cqi8[ic])) continue;  // reserved index
+    const uint32_t q_ack = qprime(g.nof_ack, lsn_beta_ack8[ia], 4 * M), q_ri = qprime(g.ri_bits, lsn_beta_ri8[ir], 4 * M);
+    const uint32_t q_cqi = g.cqi_bits ? qprime(g.cqi_bits + (g.cqi_bits > 11 ? 8u : 0u), lsn_beta_cqi8[ic], 12 * M - q_ri) : 0u;
     if (q_ri + q_cqi >= 12 * M) continue;
     const int G = (int)((12 * M - q_ri - q_cqi) * g.mod);
     LsnUlGrantDev d{};

@@ -16,8 +16,10 @@
 namespace lsn {
 
 namespace {
-struct Attempt { uint32_t sf; uint32_t idx; bool use256; int qm; };
-inline bool operator<(const Attempt& a, const Attempt& b) { return std::tie(a.sf, a.idx, a.use256, a.qm) < std::tie(b.sf, b.idx, b.use256, b.qm); }
+// one srsran_pusch_decode call: the grant (sf, idx), the MCS table / modulation tried and the control-information layout it was tried with
+// (uci: CQI report size | 1 + betaOffset indices << 8 / 13 / 18 - they move the UL-SCH resource elements, UL_Sniffer_PUSCH.cc:429-450)
+struct Attempt { uint32_t sf; uint32_t idx; bool use256; int qm; uint32_t uci; };
+inline bool operator<(const Attempt& a, const Attempt& b) { return std::tie(a.sf, a.idx, a.use256, a.qm, a.uci) < std::tie(b.sf, b.idx, b.use256, b.qm, b.uci); }
 struct AttemptResult { bool crc = false; std::vector<uint8_t> payload; };
 // downlink records keep the OFFSET of their payload in ch.h_payload: a later on-demand decode of the same loop may grow (reallocate) that
 // arena, so the pointer is only formed when the record is emitted
@@ -45,12 +47,21 @@ bool Engine::decodeSib(Chunk& ch, JobRunner& r, uint32_t sf, Sib2Config& out, si
   return false;
 }
 
+// MCSTracking::add_RNTI_ul (MCSTracking.cc:57-69): a new entry starts with unknown modulation and a copy of the default configuration
+void Engine::ulTrackAdd(uint16_t rnti)
+{
+  if (ulmod[rnti]) return;
+  ulmod[rnti] = 1; ulmod_count++;
+  ul_uecfg[rnti] = mcs_tracking.default_config();
+}
+
 void Engine::commitChunkUl(Chunk& ch, JobRunner& r)
 {
-  if (ulmod.empty()) ulmod.assign(65536, 0);
+  if (ulmod.empty()) { ulmod.assign(65536, 0); ul_uecfg.assign(65536, UeSpecConfig()); }
   const uint32_t nsf = ch.nsf;
   std::vector<std::vector<PendingPdu>> out(nsf);            // records per subframe: downlink first, then uplink
   std::vector<std::vector<UlSchedGrant>> lists(nsf);        // PUSCH grants to try in each subframe
+  std::vector<std::vector<std::pair<uint16_t, UeSpecConfig>>> setups(nsf);  // RRCConnectionSetups decoded in each subframe (run_decode, DL_Sniffer_PDSCH.cc:279-306)
   auto reconvert = [&](uint32_t from) {  // DCI 0 -> grant conversions done before the (re)configuration used another pusch-HoppingOffset
     for (uint32_t s = from; s < nsf; s++)
       for (auto& u : ch.ctx[s].ul) { u.finished = false; search->finishUlEntry(u); }
@@ -95,6 +106,11 @@ void Engine::commitChunkUl(Chunk& ch, JobRunner& r)
           if (!job.crc[tb]) continue;
           const uint32_t len = (uint32_t)(job.grant.tb[tb].tbs / 8);
           out[sf].push_back({false, is_ra ? 'R' : rnti_name(e.rnti)[0], e.rnti, (uint8_t)tb, (size_t)job.payload_off[tb], {}, len});
+          if (!is_ra) {  // betaOffset indices + aperiodic CQI mode of the UE, used by the PUSCH decoder from this subframe on
+            UeSpecConfig sc[8];
+            const int ns = MCSTracking::setups_of_pdu(ch.h_payload.data() + job.payload_off[tb], (int)len, sc, 8);
+            for (int k = 0; k < ns; k++) setups[sf].push_back({e.rnti, sc[k]});
+          }
           if (is_ra) {  // unpack_rar_response_ul_mode on TB 0's buffer; the grant of the LAST sub-header survives; then return
             RarEntry re[32];
             const int nre = rar_parse(cell, ch.h_payload.data() + job.payload_off[0], (int)len, re, 32);
@@ -177,6 +193,17 @@ void Engine::commitChunkUl(Chunk& ch, JobRunner& r)
     }
     return n;
   };
+  // uci_cfg of an attempt, UL_Sniffer_PUSCH.cc:429-450: HARQ-ACK bits come with the grant; an aperiodic CSI request adds a CQI report of the
+  // UE's configured type (srsran_cqi_size: wideband 4, UE-selected sub-band 4 + 1, higher-layer sub-band 4 + 2 N bits) and one RI bit
+  auto uci_of = [&](const UlSchedGrant& m) -> uint32_t {
+    const UeSpecConfig uc = ulUeConfig(m.rnti);
+    uint32_t cqi = 0;
+    if (m.cqi_req) {
+      const uint32_t k = cell.nof_prb <= 7 ? 0u : (cell.nof_prb <= 26 ? 4u : (cell.nof_prb <= 63 ? 6u : 8u));  // dl_sniffer_pdsch.c:276-305
+      cqi = uc.cqi_type == 0 ? 4u : (uc.cqi_type == 1 ? 5u : (k ? 4u + 2u * ((cell.nof_prb + k - 1) / k) : 0u));
+    }
+    return cqi | ((uc.i_offset_ack + 1u) & 31u) << 8 | ((uc.i_offset_cqi + 1u) & 31u) << 13 | ((uc.i_offset_ri + 1u) & 31u) << 18;
+  };
   std::map<Attempt, AttemptResult> results;
   auto run_batch = [&](const std::vector<Attempt>& batch) {
     std::vector<lsn_pusch_grant_t> gl;
@@ -191,13 +218,9 @@ void Engine::commitChunkUl(Chunk& ch, JobRunner& r)
       lsn_pusch_grant_t q{};
       q.sf = a.sf; q.rnti = m.rnti; q.n_dmrs = (uint16_t)m.n_dmrs; q.n_prb = g.n_prb; q.L_prb = g.L_prb; q.mod = (uint32_t)a.qm; q.tbs = (uint32_t)g.tbs; q.rv = g.rv;
       q.hop = g.hop; q.n_prb_slot1 = g.n_prb2;
-      // uci_cfg of the attempt, UL_Sniffer_PUSCH.cc:429-450: HARQ-ACK bits, aperiodic higher-layer sub-band CQI (4 + 2 N bits) + one RI bit on request
       q.nof_ack = m.nof_ack;
-      if (m.cqi_req) {
-        const uint32_t k = cell.nof_prb <= 7 ? 0u : (cell.nof_prb <= 26 ? 4u : (cell.nof_prb <= 63 ? 6u : 8u));  // dl_sniffer_pdsch.c:276-305
-        q.cqi_bits = k ? 4u + 2u * ((cell.nof_prb + k - 1) / k) : 0u;
-        q.ri_bits = 1;
-      }
+      q.cqi_bits = a.uci & 255u; q.ri_bits = m.cqi_req ? 1u : 0u;
+      q.beta_offset_ack_idx_p1 = (a.uci >> 8) & 31u; q.beta_offset_cqi_idx_p1 = (a.uci >> 13) & 31u; q.beta_offset_ri_idx_p1 = (a.uci >> 18) & 31u;
       gl.push_back(q);
       keys.push_back(a);
     }
@@ -223,10 +246,11 @@ void Engine::commitChunkUl(Chunk& ch, JobRunner& r)
         Attempt a[3]; int learn[3];
         const int n = trial(m, mod_of(m.rnti), a, learn);
         if (wave >= n) continue;
+        const uint32_t uci = uci_of(m);
         bool earlier_passed = false;
-        for (int k = 0; k < wave; k++) { a[k].sf = sf; a[k].idx = i; auto it = results.find(a[k]); earlier_passed = earlier_passed || (it != results.end() && it->second.crc); }
+        for (int k = 0; k < wave; k++) { a[k].sf = sf; a[k].idx = i; a[k].uci = uci; auto it = results.find(a[k]); earlier_passed = earlier_passed || (it != results.end() && it->second.crc); }
         if (earlier_passed) continue;
-        a[wave].sf = sf; a[wave].idx = i;
+        a[wave].sf = sf; a[wave].idx = i; a[wave].uci = uci;
         batch.push_back(a[wave]);
       }
     run_batch(batch);
@@ -234,13 +258,19 @@ void Engine::commitChunkUl(Chunk& ch, JobRunner& r)
   // ---- phase 3 (sequential): the exact decision logic, records in (tti, downlink, uplink) order ----
   for (uint32_t sf = 0; sf < nsf; sf++) {
     const uint32_t tti = ch.ctx[sf].tti;  // already reduced mod 10240 (SubframeCtx::reset)
+    for (auto& su : setups[sf]) {  // the downlink part of the subframe ran first (SubframeWorker.cc:299-347): update_default_ue_config / update_ue_config_rnti
+      if (!mcs_tracking.check_default_config()) mcs_tracking.update_default_ue_config(su.second);
+      ulTrackAdd(su.first);
+      ul_uecfg[su.first] = su.second;
+    }
     for (uint32_t i = 0; i < lists[sf].size(); i++) {
       const UlSchedGrant& m = lists[sf][i];
       if (!valid_grant(m)) continue;
       Attempt a[3]; int learn[3];
       const int n = trial(m, mod_of(m.rnti), a, learn);
+      const uint32_t uci = uci_of(m);
       for (int k = 0; k < n; k++) {
-        a[k].sf = sf; a[k].idx = i;
+        a[k].sf = sf; a[k].idx = i; a[k].uci = uci;
         if (!results.count(a[k])) { run_batch({a[k]}); r.perf.nof_ondemand_decodes++; }
         const AttemptResult& ar = results[a[k]];
         if (!ar.crc) continue;
@@ -248,7 +278,7 @@ void Engine::commitChunkUl(Chunk& ch, JobRunner& r)
         out[sf].push_back(std::move(p));
         if (learn[k] && m.g.mcs_idx > 20) {  // decode_run: update_RNTI_ul when the maximum modulation was still unknown
           if (ulmod[m.rnti]) ulmod[m.rnti] = (uint8_t)learn[k];
-          else { ulmod[m.rnti] = 1; ulmod_count++; }
+          else ulTrackAdd(m.rnti);
         }
         break;
       }

@@ -227,6 +227,10 @@ typedef struct { /* the SIB2 fields ULSchedule::set_config and SubframeWorker.cc
   uint32_t bits_used; /* test aid */
 } o_sib2_t;
 int o_sib2_decode(const uint8_t* pdu, int len, o_sib2_t* out);
+typedef struct { uint32_t is_imsi, nof_digits; uint8_t digits[24]; uint32_t mmec, m_tmsi; } o_paging_id_t;
+int o_paging_decode(const uint8_t* pdu, int len, o_paging_id_t* out, int cap); /* PCCH-Message -> paging records, -1: does not unpack */
+typedef struct { uint32_t tti; uint16_t rnti; uint32_t id_type /* 1 TMSI, 2 contention resolution, 3 IMSI */, msg_type /* 1 connection setup, 5 paging */; char value[24]; } o_api_event_t;
+int o_api_dl_events(int api_mode, char name, const uint8_t* pdu, int len, uint16_t rnti, uint32_t tti, o_api_event_t* ev, int cap, int* nev);
 
 /* ---------- PSS / SSS cell search (o_sync.c) ---------- */
 typedef struct { uint32_t nof_periods; int32_t force_n_id_2 /* -1: all three roots */; float threshold /* peak / mean of the PSS correlation power */; } o_sync_cfg_t;
@@ -264,7 +268,9 @@ int o_prach_detect(const o_cell_t* cell, const o_prach_cfg_t* cfg, const ocf_t* 
 /* ---------- uplink: SC-FDMA demodulation + PUSCH (o_pusch.c) ---------- */
 typedef struct { uint32_t cyclic_shift; /* SIB2 cyclicShift 0..7 */ uint32_t delta_ss; /* SIB2 groupAssignmentPUSCH 0..29 */
                  uint32_t hopping_offset; /* SIB2 pusch-HoppingOffset */ } o_ul_cfg_t;
-typedef struct { uint32_t nof_ack; uint32_t cqi_bits; uint32_t ri_bits; } o_uci_t; /* HARQ-ACK bits 0..2, CQI report size (0 = none), RI bits */
+typedef struct { uint32_t nof_ack; uint32_t cqi_bits; uint32_t ri_bits; /* HARQ-ACK bits 0..2, CQI report size (0 = none), RI bits */
+                 uint32_t i_ack_p1, i_cqi_p1, i_ri_p1; /* 1 + betaOffset-ACK / -CQI / -RI-Index of the UE (uci_offset, UL_Sniffer_PUSCH.cc:435); 0 = the defaults 10 / 8 / 11 of MCSTracking.cc:1534-1538 */ } o_uci_t;
+int o_uci_cqi_bits_type(uint32_t nof_prb, uint32_t cqi_type); /* srsran_cqi_size: 0 wideband (4), 1 UE-selected sub-band (4 + 1), 2 higher-layer sub-band (4 + 2 N) */
 int o_uci_cqi_bits(uint32_t nof_prb);
 int o_uci_layout(int M, int tbs, const o_uci_t* uci, uint8_t* cls, int* didx, int* q_ack, int* q_ri, int* q_cqi);
 int o_ul_valid_prb(uint32_t L);
@@ -316,6 +322,8 @@ int o_worker_ul_config(o_worker_t* w, o_ul_cfg_t* ul, o_sib2_t* sib2); /* 0 not 
 int o_worker_work_ul(o_worker_t*, const ocf_t* dl_iq, const ocf_t* ul_iq, uint32_t sf_idx, uint32_t sfn, int update_meta_formats);
 const o_stats_t* o_worker_stats(o_worker_t*);
 void o_worker_ue_cfg(o_worker_t* w, uint16_t rnti, o_ue_cfg_t* out); /* MCSTracking::get_ue_config_rnti */
+void o_worker_set_api(o_worker_t* w, int api_mode, o_pcap_t* api_pcap); /* -a: -1 off, 0 identity mapping, 2 IMSI catching, 3 all */
+int o_worker_api_events(o_worker_t* w, o_api_event_t* out, int cap);     /* events reported so far (print_api_dl) */
 void o_worker_set_second_opinion(o_worker_t* w, int turbo, int viterbi); /* decode transport blocks / DCI candidates with o_second.c */
 void o_worker_set_mcs_update_interval(o_worker_t* w, uint32_t seconds); /* MCSTracking::interval (5 s): ageing every interval x 1000 subframes, 0 = never */
 uint32_t o_worker_nof_tracked(o_worker_t* w);                         /* MCSTracking::nof_RNTI_member_dl */

@@ -155,6 +155,15 @@ int o_uci_cqi_bits(uint32_t nof_prb) /* srsran_cqi_size for SRSRAN_CQI_TYPE_SUBB
   return 4 + 2 * (((int)nof_prb + k - 1) / k);
 }
 
+/* srsran_cqi_size [srsRAN lib/src/phy/phch/cqi.c] for the three report types the reference configures (DL_Sniffer_PDSCH.cc:150-163),
+ * one codeword, no PMI, one-bit sub-band label: wideband 4 bits, UE-selected sub-band 4 + 1, higher-layer sub-band 4 + 2 N */
+int o_uci_cqi_bits_type(uint32_t nof_prb, uint32_t cqi_type)
+{
+  if (cqi_type == 0) return 4;
+  if (cqi_type == 1) return 5;
+  return o_uci_cqi_bits(nof_prb);
+}
+
 static int uci_qprime(int O, int M, int beta8, int sumK, int cap)
 {
   if (O <= 0) return 0;
@@ -171,10 +180,15 @@ int o_uci_layout(int M, int tbs, const o_uci_t* uci, uint8_t* cls, int* didx, in
   int sumK = 0;
   if (o_cbsegm(&sg, tbs)) return -1;
   sumK = sg.Cp * sg.Kp + sg.Cm * sg.Km;
-  const int Qa = uci ? uci_qprime((int)uci->nof_ack, M, 160, sumK, 4 * M) : 0;
-  const int Qr = uci ? uci_qprime((int)uci->ri_bits, M, 127, sumK, 4 * M) : 0;
+  /* beta offsets of 36.213 Tables 8.6.3-1/-2/-3 in eighths (spec/lte_tables.h); a reserved index makes the grant undecodable */
+  const int ia = uci && uci->i_ack_p1 ? (int)uci->i_ack_p1 - 1 : 10, ic = uci && uci->i_cqi_p1 ? (int)uci->i_cqi_p1 - 1 : 8,
+            ir = uci && uci->i_ri_p1 ? (int)uci->i_ri_p1 - 1 : 11;
+  if (ia > 15 || ic > 15 || ir > 15) return -1;
   int Oc = uci ? (int)uci->cqi_bits : 0;
-  const int Qc = Oc ? uci_qprime(Oc + (Oc > 11 ? 8 : 0), M, 18, sumK, 12 * M - Qr) : 0;
+  if (uci && ((uci->nof_ack && !lsn_beta_ack8[ia]) || (uci->ri_bits && !lsn_beta_ri8[ir]) || (Oc && !lsn_beta_cqi8[ic]))) return -1;
+  const int Qa = uci ? uci_qprime((int)uci->nof_ack, M, lsn_beta_ack8[ia], sumK, 4 * M) : 0;
+  const int Qr = uci ? uci_qprime((int)uci->ri_bits, M, lsn_beta_ri8[ir], sumK, 4 * M) : 0;
+  const int Qc = Oc ? uci_qprime(Oc + (Oc > 11 ? 8 : 0), M, lsn_beta_cqi8[ic], sumK, 12 * M - Qr) : 0;
   static const int ri_cols[4] = {1, 4, 7, 10}, ack_cols[4] = {2, 3, 8, 9};
   memset(cls, 0, (size_t)(12 * M));
   for (int i = 0, j = 0, r = M - 1; i < Qr;) { /* 5.2.2.8: rank indication first, bottom row upwards */

@@ -334,3 +334,98 @@ int o_sib2_decode(const uint8_t* pdu, int len, o_sib2_t* out)
   *out = o;
   return 2;
 }
+
+/* ---------------- security-API view of a decoded downlink block ----------------
+ * PDSCH_Decoder::run_api_dl_mode (DL_Sniffer_PDSCH.cc:804-879) and decode_imsi_tmsi_paging (:84-127): paging records (IMSI / S-TMSI) and
+ * the contention resolution identity next to an RRCConnectionSetup.  PCCH-Message per TS 36.331 6.2.1 / 6.2.2.  parity unpinned: the
+ * reference's captures hold no paging record; the connection-setup side is pinned by api_collector.pcap (one API record per setup).
+ * Not restated: RRCConnectionReconfiguration / NAS identities (LCID 1), the uplink API parsers. */
+int o_paging_decode(const uint8_t* pdu, int len, o_paging_id_t* out, int cap)
+{
+  br_t b = {pdu, len > 0 ? 8u * (uint32_t)len : 0u, 0, 0};
+  if (rd(&b, 1)) return -1;
+  int list = (int)rd(&b, 1);
+  rd(&b, 3);
+  if (b.err) return -1;
+  int n = 0;
+  if (list) {
+    uint32_t cnt = rd(&b, 4) + 1;
+    for (uint32_t i = 0; i < cnt && !b.err; i++) {
+      int ext = (int)rd(&b, 1);
+      o_paging_id_t id;
+      memset(&id, 0, sizeof(id));
+      if (rd(&b, 1)) return -1;
+      if (!rd(&b, 1)) {
+        id.mmec = rd(&b, 8);
+        id.m_tmsi = rd(&b, 32);
+      } else {
+        id.is_imsi = 1;
+        id.nof_digits = rd(&b, 4) + 6;
+        if (id.nof_digits > 21) return -1;
+        for (uint32_t k = 0; k < id.nof_digits; k++) { id.digits[k] = (uint8_t)rd(&b, 4); if (id.digits[k] > 9) b.err = 1; }
+      }
+      rd(&b, 1);
+      if (ext) skip_ext(&b);
+      if (b.err) return -1;
+      if (n < cap) out[n++] = id;
+    }
+  }
+  return b.err ? -1 : n;
+}
+
+#include <stdio.h>
+int o_api_dl_events(int api_mode, char name, const uint8_t* pdu, int len, uint16_t rnti, uint32_t tti, o_api_event_t* ev, int cap, int* nev)
+{
+  int n = 0, to_pcap = 0;
+  if (name == 'P' && (api_mode == 2 || api_mode == 3)) {
+    o_paging_id_t rec[16];
+    int nr = o_paging_decode(pdu, len, rec, 16);
+    for (int i = 0; i < nr; i++) {
+      if (n < cap) {
+        o_api_event_t* e = &ev[n++];
+        memset(e, 0, sizeof(*e));
+        e->tti = tti; e->rnti = 65534; e->msg_type = 5;
+        if (rec[i].is_imsi) {
+          e->id_type = 3;
+          for (uint32_t k = 0; k < 15 && k < rec[i].nof_digits; k++) e->value[k] = (char)('0' + rec[i].digits[k]);
+        } else {
+          e->id_type = 1;
+          snprintf(e->value, sizeof(e->value), "%08x", rec[i].m_tmsi);
+        }
+      }
+      to_pcap = 1;
+    }
+  }
+  if (name == 'C' && (api_mode == 0 || api_mode == 3)) {
+    o_mac_subh_t sub[20];
+    int ns = o_mac_dlsch_parse(pdu, len, sub, 20), setup = 0, found = 0, seen[10], nseen = 0;
+    for (int i = 0; i < ns; i++) {
+      if (sub[i].is_sdu && sub[i].lcid == 0) {
+        o_ue_cfg_t c;
+        if (o_rrc_conn_setup_decode(pdu + sub[i].off, (int)sub[i].len, &c)) setup = 1;
+      } else if (sub[i].is_sdu && sub[i].lcid == 1) {
+      } else {
+        if (nseen < 10) seen[nseen++] = i; else break;
+      }
+      if (setup) {
+        for (int h = 0; h < nseen && !found; h++)
+          if (sub[seen[h]].lcid == 28 && sub[seen[h]].len == 6) {
+            unsigned long long id = 0;
+            char hex[24];
+            for (int k = 0; k < 6; k++) id = (id << 8) | pdu[sub[seen[h]].off + k];
+            snprintf(hex, sizeof(hex), "%llx", id);
+            if (n < cap) {
+              o_api_event_t* e = &ev[n++];
+              memset(e, 0, sizeof(*e));
+              e->tti = tti; e->rnti = rnti; e->id_type = 2; e->msg_type = 1;
+              if (strlen(hex) >= 3) snprintf(e->value, sizeof(e->value), "%.8s", hex + 3);
+            }
+            found = 1;
+          }
+        to_pcap = 1;
+      }
+    }
+  }
+  if (nev) *nev = n;
+  return to_pcap;
+}

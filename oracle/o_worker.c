@@ -85,6 +85,7 @@ struct o_worker {
   /* UL mode */
   int ul_mode;
   o_ul_cfg_t ulcfg;
+  int api_mode; o_pcap_t* api_pcap; o_api_event_t* api_ev; int api_n, api_cap; /* security-API sink (run_api_dl_mode) */
   int ul_configured;   /* ULSchedule::get_config */
   o_sib2_t sib2;       /* ULSchedule::sib2, valid when the configuration was learned */
   int sib2_learned;
@@ -160,6 +161,7 @@ o_worker_t* o_worker_new(const o_worker_cfg_t* cfg)
   w->default_cfg.i_offset_cqi = 8;
   w->default_cfg.i_offset_ri = 11;
   w->default_cfg.cqi_type = 2;
+  w->api_mode = -1; /* ArgManager.cc:63 */
   w->mcs_interval = 5; /* MCSTracking.h:162 */
   w->mcs_update_period = 5000;
   w->llr0 = (int16_t*)calloc(14u * nre * 8u, sizeof(int16_t));
@@ -172,7 +174,7 @@ void o_worker_free(o_worker_t* w)
 {
   if (!w) return;
   o_rntiman_free(w->rm);
-  free(w->grid); free(w->ce); free(w->llr); free(w->mcs); free(w->uecfg); free(w->llr0); free(w->llr1); free(w->payload);
+  free(w->grid); free(w->ce); free(w->llr); free(w->mcs); free(w->uecfg); free(w->api_ev); free(w->llr0); free(w->llr1); free(w->payload);
   free(w->ul_grid); free(w->ul_sched); free(w->rar_sched); free(w->ulmod);
   free(w);
 }
@@ -216,7 +218,7 @@ static void mcs_add(o_worker_t* w, uint16_t rnti)
 /* MCSTracking::get_ue_config_rnti (:1482-1516): the entry's configuration, or the default for an RNTI without entry */
 static o_ue_cfg_t ue_cfg_get(o_worker_t* w, uint16_t rnti)
 {
-  if (w->mcs[rnti].present) return w->uecfg[rnti];
+  if (w->ul_mode ? (w->ulmod && w->ulmod[rnti]) : w->mcs[rnti].present) return w->uecfg[rnti]; /* UL_MODE: tracking_database_ul_mode, :1466-1479,1503-1513 */
   o_ue_cfg_t c = w->default_cfg;
   c.has_ue_config = 0;
   return c;
@@ -235,7 +237,11 @@ static void learn_conn_setup(o_worker_t* w, const uint8_t* pdu, int len, uint16_
       w->default_cfg = c; /* update_default_ue_config, :1518-1529 */
       w->has_default_cfg = 1;
     }
-    mcs_add(w, rnti); /* update_ue_config_rnti, :1446-1480 */
+    if (w->ul_mode) { /* update_ue_config_rnti, UL_MODE branch (:1464-1479): add_RNTI_ul(UNKNOWN_MOD) copies the default first */
+      if (!w->ulmod[rnti]) { w->ulmod[rnti] = 1; w->ulmod_count++; }
+    } else {
+      mcs_add(w, rnti); /* update_ue_config_rnti, :1446-1463 */
+    }
     w->uecfg[rnti] = c;
   }
 }
@@ -584,6 +590,23 @@ static void write_pcap(o_worker_t* w, const char* name, const uint8_t* pdu, uint
   else if (name[0] == 'P') o_pcap_write(w->pcap, pdu, len, tti, O_PRNTI, 1, O_PCAP_P_RNTI, 1, 0, 0);
   else if (name[0] == 'R') o_pcap_write(w->pcap, pdu, len, tti, rnti, 1, O_PCAP_RA_RNTI, 1, 0, 0);
   else o_pcap_write(w->pcap, pdu, len, tti, rnti, 1, O_PCAP_C_RNTI, 1, 0, 0);
+  if (w->api_mode >= 0 && (name[0] == 'P' || name[0] == 'C')) { /* run_api_dl_mode, DL_Sniffer_PDSCH.cc:804-879 */
+    o_api_event_t ev[20];
+    int nev = 0;
+    if (o_api_dl_events(w->api_mode, name[0], pdu, (int)len, rnti, tti, ev, 20, &nev) && w->api_pcap)
+      o_pcap_write(w->api_pcap, pdu, len, tti, name[0] == 'P' ? O_PRNTI : rnti, 1, name[0] == 'P' ? O_PCAP_P_RNTI : O_PCAP_C_RNTI, 1, 0, 0);
+    for (int i = 0; i < nev; i++) {
+      if (w->api_n == w->api_cap) { w->api_cap = w->api_cap ? 2 * w->api_cap : 64; w->api_ev = (o_api_event_t*)realloc(w->api_ev, sizeof(o_api_event_t) * (size_t)w->api_cap); }
+      w->api_ev[w->api_n++] = ev[i];
+    }
+  }
+}
+void o_worker_set_api(o_worker_t* w, int api_mode, o_pcap_t* api_pcap) { w->api_mode = api_mode; w->api_pcap = api_pcap; }
+int o_worker_api_events(o_worker_t* w, o_api_event_t* out, int cap)
+{
+  int n = w->api_n < cap ? w->api_n : cap;
+  if (out) memcpy(out, w->api_ev, sizeof(o_api_event_t) * (size_t)n);
+  return w->api_n;
 }
 
 static const char* rnti_name(uint16_t r) /* DL_Sniffer_PDSCH.cc:1398-1418 */
@@ -855,7 +878,10 @@ static void decode_ul_mode_dl(o_worker_t* w, ulslot_t* rar_out)
         if (o_config_mimo(&w->cfg.cell, e->format, &e->dci, cur) != 0) continue;
         decode_grant(w, e, cur, crc);
         for (int tb = 0; tb < 2; tb++)
-          if (crc[tb]) write_pcap(w, rnti_name(e->rnti), w->payload + tb * 16384, (uint32_t)(cur->tb[tb].tbs / 8), e->rnti, tti);
+          if (crc[tb]) {
+            write_pcap(w, rnti_name(e->rnti), w->payload + tb * 16384, (uint32_t)(cur->tb[tb].tbs / 8), e->rnti, tti);
+            learn_conn_setup(w, w->payload + tb * 16384, cur->tb[tb].tbs / 8, e->rnti); /* run_decode, :279-306: betaOffset indices + CQI mode for the PUSCH decoder */
+          }
       }
     }
   }
@@ -905,7 +931,10 @@ static int pusch_attempt(o_worker_t* w, const ulg_t* m, const o_pusch_grant_t* g
   int its = 0;
   float snr = 0;
   /* uci_cfg of this attempt, UL_Sniffer_PUSCH.cc:429-450: HARQ-ACK bits counted 4 ms earlier, aperiodic CQI (higher-layer sub-band) + 1 RI bit on request */
-  o_uci_t uci = {m->nof_ack, m->cqi_req ? (uint32_t)o_uci_cqi_bits(w->cfg.cell.nof_prb) : 0u, m->cqi_req ? 1u : 0u};
+  /* ... with the UE's report type and betaOffset indices from the tracking database (get_ue_config_rnti, :433-435) */
+  const o_ue_cfg_t uc = ue_cfg_get(w, m->rnti);
+  o_uci_t uci = {m->nof_ack, m->cqi_req ? (uint32_t)o_uci_cqi_bits_type(w->cfg.cell.nof_prb, uc.cqi_type) : 0u, m->cqi_req ? 1u : 0u,
+                 uc.i_offset_ack + 1u, uc.i_offset_cqi + 1u, uc.i_offset_ri + 1u};
   int crc = o_pusch_decode_uci(&w->cfg.cell, &w->ulcfg, tti % 10, m->rnti, &gg, m->n_dmrs, &uci, w->ul_grid, w->cfg.max_turbo_iter, w->payload, &its, &snr);
   w->total_iters += (uint64_t)its;
   if (crc) write_pcap_ul(w, w->payload, (uint32_t)(gg.tbs / 8), m->rnti, tti);
@@ -917,10 +946,10 @@ static int ulmod_find(o_worker_t* w, uint16_t rnti) /* MCSTracking::find_trackin
   if (!w->ulmod[rnti]) return w->ulmod_count < 250 ? 1 : 5;
   return w->ulmod[rnti];
 }
-static void ulmod_update(o_worker_t* w, uint16_t rnti, int mod) /* update_RNTI_ul, :71-85 */
+static void ulmod_update(o_worker_t* w, uint16_t rnti, int mod) /* update_RNTI_ul, :71-85; add_RNTI_ul (:57-69) copies the default configuration */
 {
   if (w->ulmod[rnti]) w->ulmod[rnti] = (uint8_t)mod;
-  else { w->ulmod[rnti] = 1; w->ulmod_count++; }
+  else { w->ulmod[rnti] = 1; w->ulmod_count++; w->uecfg[rnti] = w->default_cfg; w->uecfg[rnti].has_ue_config = 0; }
 }
 
 /* PUSCH_Decoder::decode, UL_Sniffer_PUSCH.cc:389-583 (statistics / debug printing dropped) */

@@ -49,7 +49,8 @@ class TxgCfg(C.Structure):
                 ("mix_tm4_pct", C.c_uint32), ("pct_256qam", C.c_uint32), ("mcs_min", C.c_uint32), ("mcs_max", C.c_uint32),
                 ("sib_period", C.c_uint32), ("rar_period", C.c_uint32), ("paging_period", C.c_uint32),
                 ("start_tti", C.c_uint32), ("fixed_L", C.c_uint32), ("pct_rv", C.c_uint32), ("pct_cqi_req", C.c_uint32), ("pct_hop", C.c_uint32), ("pusch_hop_offset", C.c_uint32),
-                ("msg4_period", C.c_uint32), ("msg4_p_a_idx", C.c_uint32), ("si_len", C.c_uint32 * 2), ("si_msg", (C.c_uint8 * 96) * 2)]
+                ("msg4_period", C.c_uint32), ("msg4_p_a_idx", C.c_uint32), ("si_len", C.c_uint32 * 2), ("si_msg", (C.c_uint8 * 96) * 2),
+                ("pg_len", C.c_uint32), ("pg_msg", C.c_uint8 * 96)]
 
 
 class TxgPdu(C.Structure):
@@ -168,9 +169,13 @@ def scenario(name, seed=1, **over):
 
 
 class TxGen:
-    def __init__(self, si_msgs=None, **kw):
+    def __init__(self, si_msgs=None, paging_msg=None, **kw):
         self.lib = txgen()
         self.cfg = TxgCfg(**kw)
+        if paging_msg:  # PCCH message of every P-RNTI transmission
+            self.cfg.pg_len = len(paging_msg)
+            for j, b in enumerate(bytes(paging_msg)[:96]):
+                self.cfg.pg_msg[j] = b
         for i, m in enumerate(si_msgs or []):  # BCCH-DL-SCH messages of the SI-RNTI transmissions (alternating), None / b"" = random bytes
             if m:
                 self.cfg.si_len[i] = len(m)
@@ -406,7 +411,8 @@ class TxgUlCell(C.Structure):
 class TxgUlGrant(C.Structure):
     _fields_ = [("rnti", C.c_uint16), ("n_dmrs", C.c_uint16), ("n_prb", C.c_uint32), ("L_prb", C.c_uint32), ("mod", C.c_uint32),
                 ("tbs", C.c_uint32), ("rv", C.c_uint32), ("gain_db", C.c_float), ("phase_rad", C.c_float), ("ta_samples", C.c_float),
-                ("nof_ack", C.c_uint32), ("cqi_bits", C.c_uint32), ("ri_bits", C.c_uint32), ("hop", C.c_uint32), ("n_prb2", C.c_uint32)]
+                ("nof_ack", C.c_uint32), ("cqi_bits", C.c_uint32), ("ri_bits", C.c_uint32), ("hop", C.c_uint32), ("n_prb2", C.c_uint32),
+                ("i_ack_p1", C.c_uint32), ("i_cqi_p1", C.c_uint32), ("i_ri_p1", C.c_uint32)]
 
 
 def pusch_hop_slot1(nof_prb, hop_offset, hop_bits, n_prb):
@@ -425,7 +431,13 @@ def pusch_hop_slot1(nof_prb, hop_offset, hop_bits, n_prb):
 
 
 class OUci(C.Structure):
-    _fields_ = [("nof_ack", C.c_uint32), ("cqi_bits", C.c_uint32), ("ri_bits", C.c_uint32)]
+    _fields_ = [("nof_ack", C.c_uint32), ("cqi_bits", C.c_uint32), ("ri_bits", C.c_uint32),
+                ("i_ack_p1", C.c_uint32), ("i_cqi_p1", C.c_uint32), ("i_ri_p1", C.c_uint32)]
+
+
+class OUeCfg(C.Structure):  # o_ue_cfg_t
+    _fields_ = [("has_ue_config", C.c_uint32), ("p_a", C.c_float), ("i_offset_ack", C.c_uint32), ("i_offset_cqi", C.c_uint32),
+                ("i_offset_ri", C.c_uint32), ("cqi_type", C.c_uint32), ("bits_used", C.c_uint32)]
 
 
 SIB2_FIELDS = ("n_sb", "hopping_mode", "pusch_hop_offset", "enable_64qam", "group_hopping_enabled", "group_assignment_pusch",
@@ -454,6 +466,53 @@ def host_sib2_decode(pdu):
     out = np.zeros(13, np.uint32)
     r = h.lsnh_sib2_decode(bytes(pdu), len(pdu), out.ctypes.data_as(C.c_void_p))
     return r, (dict(zip(SIB2_FIELDS, (int(v) for v in out))) if r == 2 else None)
+
+
+class OApiEvent(C.Structure):
+    _fields_ = [("tti", C.c_uint32), ("rnti", C.c_uint16), ("id_type", C.c_uint32), ("msg_type", C.c_uint32), ("value", C.c_char * 24)]
+
+
+class OPagingId(C.Structure):
+    _fields_ = [("is_imsi", C.c_uint32), ("nof_digits", C.c_uint32), ("digits", C.c_uint8 * 24), ("mmec", C.c_uint32), ("m_tmsi", C.c_uint32)]
+
+
+def oracle_paging_decode(pdu):
+    """-> list of ("imsi", digits) / ("tmsi", mmec, m_tmsi), or None when the message does not unpack"""
+    o = oracle()
+    o.o_paging_decode.argtypes = [C.c_char_p, C.c_int, C.POINTER(OPagingId), C.c_int]
+    rec = (OPagingId * 16)()
+    n = o.o_paging_decode(bytes(pdu), len(pdu), rec, 16)
+    if n < 0:
+        return None
+    return [("imsi", "".join(str(d) for d in r.digits[:r.nof_digits])) if r.is_imsi else ("tmsi", int(r.mmec), int(r.m_tmsi)) for r in rec[:n]]
+
+
+def host_paging_decode(pdu):
+    h = hosttest()
+    out = np.zeros(25 * 16, np.uint32)
+    n = h.lsnh_paging_decode(bytes(pdu), len(pdu), out.ctypes.data_as(C.c_void_p), 16)
+    if n < 0:
+        return None
+    return [("imsi", "".join(str(int(d)) for d in out[25 * i + 4:25 * i + 4 + out[25 * i + 1]])) if out[25 * i] else ("tmsi", int(out[25 * i + 2]), int(out[25 * i + 3]))
+            for i in range(n)]
+
+
+def oracle_api_events(api_mode, name, pdu, rnti, tti):
+    """-> (events [(tti, rnti, id_type, msg_type, value)], to_pcap)"""
+    o = oracle()
+    o.o_api_dl_events.argtypes = [C.c_int, C.c_char, C.c_char_p, C.c_int, C.c_uint16, C.c_uint32, C.POINTER(OApiEvent), C.c_int, C.POINTER(C.c_int)]
+    ev, n = (OApiEvent * 20)(), C.c_int(0)
+    keep = o.o_api_dl_events(api_mode, name.encode(), bytes(pdu), len(pdu), rnti, tti, ev, 20, C.byref(n))
+    return [(e.tti, e.rnti, e.id_type, e.msg_type, e.value.decode()) for e in ev[:n.value]], bool(keep)
+
+
+def host_api_events(api_mode, name, pdu, rnti, tti):
+    h = hosttest()
+    out = np.zeros(10 * 20, np.uint32)
+    r = h.lsnh_api_dl_events(api_mode, ord(name), bytes(pdu), len(pdu), rnti, tti, out.ctypes.data_as(C.c_void_p), 20)
+    n = r & 0xFFFF
+    return [(int(out[10 * i]), int(out[10 * i + 1]), int(out[10 * i + 2]), int(out[10 * i + 3]), out[10 * i + 4:10 * i + 10].tobytes().split(b"\0")[0].decode())
+            for i in range(n)], bool(r >> 16)
 
 
 class OUlCfg(C.Structure):
@@ -488,7 +547,8 @@ def ul_make_subframe(cell, tti, grants, snr_db=30.0, seed=1):
     iq = np.zeros(15 * N, dtype=np.complex64)
     arr = (TxgUlGrant * max(1, len(grants)))(*[TxgUlGrant(g["rnti"], g.get("n_dmrs", 0), g["n_prb"], g["L_prb"], g["mod"], g["tbs"], g.get("rv", 0),
                                                            g.get("gain_db", 0.0), g.get("phase_rad", 0.0), g.get("ta_samples", 0.0),
-                                                           g.get("nof_ack", 0), g.get("cqi_bits", 0), g.get("ri_bits", 0), g.get("hop", 0), g.get("n_prb2", 0))
+                                                           g.get("nof_ack", 0), g.get("cqi_bits", 0), g.get("ri_bits", 0), g.get("hop", 0), g.get("n_prb2", 0),
+                                                           g.get("i_ack_p1", 0), g.get("i_cqi_p1", 0), g.get("i_ri_p1", 0))
                                                for g in grants])
     pbuf = np.zeros(sum(g["tbs"] // 8 for g in grants) + 16, dtype=np.uint8)
     offs = (C.c_uint32 * max(1, len(grants)))()
@@ -512,6 +572,23 @@ def oracle_ul_api():
     o.o_uci_layout.argtypes = [C.c_int, C.c_int, C.POINTER(OUci), C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     o.o_uci_cqi_bits.argtypes = [C.c_uint32]
     return o
+
+
+def oracle_worker_set_api(ow, api_mode):
+    """-a of the reference on an oracle worker; -> the in-memory API pcap handle (read with ow.lib.o_pcap_* like ow.pcap)"""
+    ow.lib.o_worker_set_api.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    ow.lib.o_worker_api_events.argtypes = [C.c_void_p, C.POINTER(OApiEvent), C.c_int]
+    ow.lib.o_pcap_open_mem.restype = C.c_void_p
+    ow.api_pcap = ow.lib.o_pcap_open_mem()
+    ow.lib.o_worker_set_api(ow.h, api_mode, ow.api_pcap)
+    return ow.api_pcap
+
+
+def oracle_worker_api_events(ow):
+    n = ow.lib.o_worker_api_events(ow.h, None, 0)
+    ev = (OApiEvent * max(1, n))()
+    ow.lib.o_worker_api_events(ow.h, ev, n)
+    return [(e.tti, e.rnti, e.id_type, e.msg_type, e.value.decode()) for e in ev[:n]]
 
 
 class OracleWorkerUl(OracleWorker):
@@ -627,6 +704,34 @@ def encode_sib2(n_sb=1, hopping_mode=0, pusch_hop_offset=0, enable_64qam=1, grou
     return bytes(int("".join(map(str, bits[i:i + 8])), 2) for i in range(0, len(bits), 8))
 
 
+def encode_paging(records, sys_info_mod=0, etws=0, ext_record=None):
+    """PCCH-Message { paging { pagingRecordList } } in unaligned PER (TS 36.331 6.2.2); records: ("imsi", "262011234567890") or
+    ("tmsi", mmec, m_tmsi); ext_record: index of a record sent with an (empty-content) extension addition"""
+    bits = []
+
+    def put(v, n):
+        bits.extend((int(v) >> (n - 1 - i)) & 1 for i in range(n))
+    put(0, 1)
+    put(1 if records else 0, 1); put(sys_info_mod, 1); put(etws, 1); put(0, 1)
+    if records:
+        put(len(records) - 1, 4)
+        for i, r in enumerate(records):
+            ext = ext_record == i
+            put(ext, 1); put(0, 1)
+            if r[0] == "tmsi":
+                put(0, 1); put(r[1], 8); put(r[2], 32)
+            else:
+                put(1, 1); put(len(r[1]) - 6, 4)
+                for d in r[1]:
+                    put(int(d), 4)
+            put(i & 1, 1)
+            if ext:
+                put(0, 1); put(0, 6); put(1, 1); put(1, 8); put(0xA5, 8)
+    while len(bits) % 8:
+        bits.append(0)
+    return bytes(int("".join(map(str, bits[i:i + 8])), 2) for i in range(0, len(bits), 8))
+
+
 def gen_ul_mode_subframes(sc, n, cyclic_shift=3, delta_ss=5, ul_snr_db=30.0, si_msgs=None):  # sc['pusch_hop_offset'] = SIB2 pusch-HoppingOffset of the cell
     """DL stream from the synthetic eNB (one rx antenna) + the matching UL stream: every DCI 0 of subframe t is answered by a
     PUSCH in subframe t + 4 (UEs with an even RNTI are 64QAM-capable in the uplink).
@@ -636,12 +741,40 @@ def gen_ul_mode_subframes(sc, n, cyclic_shift=3, delta_ss=5, ul_snr_db=30.0, si_
     ucell = TxgUlCell(sc["nof_prb"], sc["cell_id"], cyclic_shift, delta_ss)
     iq = np.zeros((n, 2, tx.sf_len), dtype=np.complex64)
     pending, sent, tti0 = {}, [], None
+    # the uplink control configuration every UE transmits with: its own RRCConnectionSetup once it got one, else what a sniffer that
+    # follows the cell assumes - the first connection setup ever seen (update_default_ue_config), before that 10 / 8 / 11, sub-band reports
+    o = oracle()
+    o.o_mac_dlsch_parse.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_int]
+    o.o_rrc_conn_setup_decode.argtypes = [C.c_char_p, C.c_int, C.c_void_p]
+    o.o_uci_cqi_bits_type.argtypes = [C.c_uint32, C.c_uint32]
+    default_cfg, ue_cfg = (10, 8, 11, 2), {}
+
+    def setups(pdu):
+        sub = (C.c_uint32 * (4 * 20))()
+        ns = o.o_mac_dlsch_parse(pdu, len(pdu), sub, 20)
+        for k in range(ns):
+            lcid, is_sdu, off, ln = sub[4 * k:4 * k + 4]
+            if is_sdu and lcid == 0:
+                out = (C.c_uint32 * 7)()
+                if o.o_rrc_conn_setup_decode(pdu[off:off + ln], ln, out):
+                    yield (out[2], out[3], out[4], out[5])  # i_offset_ack, i_offset_cqi, i_offset_ri, cqi_type
+    nsetup = 0
     for i in range(n):
         tti, x, pdus = tx.next()
         if tti0 is None:
             tti0 = tti
         iq[i, 0] = x[0]
+        for p in pdus:  # the downlink of a subframe is handled before its uplink (SubframeWorker.cc:299-347)
+            if not p["is_ul"] and 10 < p["rnti"] < 0xFFF4 and p["format"] in (1, 2):  # TXG_FMT1 / TXG_FMT1A: what decode_ul_mode decodes
+                for c in setups(p["payload"]):
+                    if nsetup == 0:
+                        default_cfg = c
+                    ue_cfg[p["rnti"]] = c
+                    nsetup += 1
         grants = pending.pop(tti, [])
+        for g in grants:
+            ia, ic, ir, ct = ue_cfg.get(g["rnti"], default_cfg)
+            g.update(i_ack_p1=ia + 1, i_cqi_p1=ic + 1, i_ri_p1=ir + 1, cqi_bits=o.o_uci_cqi_bits_type(sc["nof_prb"], ct) if g["cqi_req"] else 0)
         ul, pl = ul_make_subframe(ucell, tti, grants, snr_db=ul_snr_db, seed=sc["seed"] * 1000 + i)
         iq[i, 1] = ul
         for g, p in zip(grants, pl):
@@ -651,15 +784,15 @@ def gen_ul_mode_subframes(sc, n, cyclic_shift=3, delta_ss=5, ul_snr_db=30.0, si_
                 qm, tbs = ul_mcs_to_mod_tbs(p["mcs"], p["nof_prb"], enable_64qam=(p["rnti"] % 2 == 0))
                 if tbs > 0:
                     # the UE acknowledges the downlink transport blocks it was sent in this subframe on the PUSCH 4 ms later and adds the
-                    # aperiodic CSI report (higher-layer sub-band CQI + RI) when the DCI 0 asks for one (36.212 5.2.2.6)
+                    # aperiodic CSI report (type per its configuration + RI) when the DCI 0 asks for one (36.212 5.2.2.6)
                     ntb = len([q for q in pdus if not q["is_ul"] and q["rnti"] == p["rnti"]])
-                    cqi = oracle().o_uci_cqi_bits(sc["nof_prb"]) if p["cqi_req"] else 0
                     hop, n2 = 0, 0
                     if p["hop_bits_plus1"]:
                         n2 = pusch_hop_slot1(sc["nof_prb"], sc["pusch_hop_offset"], p["hop_bits_plus1"] - 1, p["n_prb"])
                         hop = 1
                     pending.setdefault((tti + 4) % 10240, []).append(dict(rnti=p["rnti"], n_dmrs=0, n_prb=p["n_prb"], L_prb=p["nof_prb"], mod=qm, tbs=tbs, rv=0,
-                                                                          nof_ack=min(ntb, 2), cqi_bits=cqi, ri_bits=1 if cqi else 0, hop=hop, n_prb2=n2 or 0))
+                                                                          nof_ack=min(ntb, 2), cqi_req=bool(p["cqi_req"]), ri_bits=1 if p["cqi_req"] else 0,
+                                                                          hop=hop, n_prb2=n2 or 0))
     return tti0, iq, sent
 
 

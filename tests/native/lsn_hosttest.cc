@@ -147,7 +147,7 @@ double lsnh_search_bench(hsearch* h, uint32_t n, uint32_t reps, const uint32_t* 
     for (uint32_t i = 0; i < n; i++) {
       h->ctx.reset(tti[i] + r * n);
       h->ctx.cfi = cfi[i]; h->ctx.snr_db = 20.0f;
-      h->s->search(h->ctx, cand + (size_t)i * LSN_MAX_LOC * LSN_MAX_SIZES, ccepow + (size_t)i * LSN_CCE_STRIDE, false);
+      h->s->search(h->ctx, cand + (size_t)i * LSN_MAX_LOC * LSN_MAX_SIZES, ccepow + (size_t)i * LSN_CCE_STRIDE, (r * n + i) % 500 == 0 && (r || i));  // LTESniffer_Core.cc:434
     }
   const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
   return us / ((double)n * reps);
@@ -196,6 +196,31 @@ int lsnh_sib2_decode(const uint8_t* pdu, int len, uint32_t* out)
     std::memcpy(out, v, sizeof(v));
   }
   return r;
+}
+// paging records: out = n x {is_imsi, nof_digits, mmec, m_tmsi, digits[21] packed one per word} (25 words per record); returns paging_decode's value
+int lsnh_paging_decode(const uint8_t* pdu, int len, uint32_t* out, int cap)
+{
+  PagingId rec[16];
+  const int n = paging_decode(pdu, len, rec, cap < 16 ? cap : 16);
+  for (int i = 0; i < n; i++) {
+    uint32_t* o = out + 25 * i;
+    o[0] = rec[i].is_imsi; o[1] = rec[i].nof_digits; o[2] = rec[i].mmec; o[3] = rec[i].m_tmsi;
+    for (int k = 0; k < 21; k++) o[4 + k] = rec[i].digits[k];
+  }
+  return n;
+}
+// run_api_dl_mode's report for one block: events as {tti, rnti, id_type, msg_type} + value[24] (10 words each); returns nev | to_pcap << 16
+int lsnh_api_dl_events(int api_mode, int name, const uint8_t* pdu, int len, uint16_t rnti, uint32_t tti, uint32_t* out, int cap)
+{
+  ApiEvent ev[20];
+  int nev = 0;
+  const bool keep = api_dl_events(api_mode, (char)name, pdu, len, rnti, tti, ev, cap < 20 ? cap : 20, &nev);
+  for (int i = 0; i < nev; i++) {
+    uint32_t* o = out + 10 * i;
+    o[0] = ev[i].tti; o[1] = ev[i].rnti; o[2] = ev[i].id_type; o[3] = ev[i].msg_type;
+    std::memcpy(o + 4, ev[i].value, 24);
+  }
+  return nev | (keep ? 1 << 16 : 0);
 }
 // MCSTracking UE-configuration database driven by a sequence of (rnti, pdu) events; returns the configuration get_ue_config_rnti(query) ends with
 void* lsnh_mcs_new() { return new MCSTracking(); }

@@ -6,8 +6,8 @@ import ltesniffer_amd as la
 from lsn_testlib import OracleWorker, TxGen, parse_pcap, scenario
 
 
-def gen_subframes(sc, n):
-    tx = TxGen(**sc)
+def gen_subframes(sc, n, **txkw):
+    tx = TxGen(**txkw, **sc)
     iq = np.zeros((n, sc["nof_rx"], tx.sf_len), dtype=np.complex64)
     truth = []
     tti0 = None

@@ -231,3 +231,37 @@ def test_ul_mode_configures_itself_from_sib2(batch):
     assert phy.setUlConfig(1, 2, 0) and phy.getUlConfig() == dict(cyclic_shift=1, delta_ss=2, hopping_offset=0, from_sib2=False, sib2=None)
     assert la.sib2_decode(sib2)[1]["root_seq_idx"] == 22 and la.sib2_decode(REAL_SIB1) == (1, None)
     phy.close()
+
+
+def test_ul_mode_learns_beta_offsets_and_cqi_mode():
+    """RRCConnectionSetups decoded in UL_MODE feed the PUSCH decoder's control-information layout (betaOffset indices, aperiodic CQI
+    mode; UL_Sniffer_PUSCH.cc:433-435): records and learned configurations identical to the oracle's, chunked so that setups fall inside
+    and between chunks"""
+    import ctypes as C
+    from lsn_testlib import OracleWorkerUl, OUeCfg, gen_ul_mode_subframes, parse_pcap, scenario
+    from parity import gpu_records, oracle_records
+    sc = scenario("cfg2", seed=33, nof_rx=1, n_rnti=6, dl_min=3, dl_max=4, ul_min=2, ul_max=3, nof_prb=25, mcs_max=16, msg4_period=6, msg4_p_a_idx=4, pct_cqi_req=60)
+    nsf = 90
+    tti0, iq, sent = gen_ul_mode_subframes(sc, nsf)
+    ow = OracleWorkerUl(sc["nof_prb"], sc["nof_ports"], sc["cell_id"], 3, 5)
+    for i in range(nsf):
+        ow.work_ul(iq[i, 0], iq[i, 1], tti0 + i, update_meta=1 if i % 25 == 0 else 0)
+    orecs = parse_pcap(ow.pcap_bytes())
+    ow.lib.o_worker_ue_cfg.argtypes = [C.c_void_p, C.c_uint16, C.POINTER(OUeCfg)]
+    for batch in (16, 90):
+        phy = la.Phy(nof_rx_antennas=2, sniffer_mode=1, max_batch=batch, pcapwriter=la.PcapWriter(None))
+        assert phy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"]) and phy.setUlConfig(3, 5)
+        phy.process_host(iq, tti0, 25)
+        g, o = gpu_records(phy), oracle_records(orecs)
+        assert g == o, "batch %d: UL_MODE record streams differ: gpu %d vs oracle %d" % (batch, len(g), len(o))
+        nlearn = 0
+        for rnti in sorted({r["rnti"] for r in orecs if r["rnti_type"] == 3}):
+            c = OUeCfg()
+            ow.lib.o_worker_ue_cfg(ow.h, rnti, C.byref(c))
+            u = phy.ue_config(rnti)
+            assert (u.has_ue_config, u.i_offset_ack, u.i_offset_cqi, u.i_offset_ri, u.cqi_type) == \
+                (c.has_ue_config, c.i_offset_ack, c.i_offset_cqi, c.i_offset_ri, c.cqi_type), rnti
+            nlearn += c.has_ue_config
+        assert nlearn >= 3
+        phy.close()
+    assert len([r for r in orecs if r["direction"] == 0]) >= 20

@@ -180,3 +180,33 @@ def test_ul_mode_worker_with_hopping_grants():
     got = {(r["sfn"] * 10 + r["sf"], r["rnti"], r["pdu"]) for r in ul}
     hop_sent = [s for s in sent if s.get("hop") and s["tti"] >= tti0 + 30]
     assert hop_sent and sum((s["tti"], s["rnti"], s["payload"]) in got for s in hop_sent) >= 0.6 * len(hop_sent)
+
+
+def test_ul_mode_worker_learns_beta_offsets_and_cqi_mode():
+    """UEs that received an RRCConnectionSetup transmit their PUSCH control information with their own betaOffset indices and aperiodic
+    CQI mode (UL_Sniffer_PUSCH.cc:433-435): the worker that learns them from the downlink keeps decoding, a worker that is kept on the
+    defaults (10 / 8 / 11, sub-band reports) loses the grants that carry control information"""
+    import ctypes as C
+    from lsn_testlib import OracleWorkerUl, OUeCfg, gen_ul_mode_subframes, parse_pcap, scenario
+    sc = scenario("cfg2", seed=33, nof_rx=1, n_rnti=6, dl_min=3, dl_max=4, ul_min=2, ul_max=3, nof_prb=25, mcs_max=16, msg4_period=6, msg4_p_a_idx=4, pct_cqi_req=60)
+    nsf = 90
+    tti0, iq, sent = gen_ul_mode_subframes(sc, nsf)
+    ow = OracleWorkerUl(sc["nof_prb"], sc["nof_ports"], sc["cell_id"], 3, 5)
+    for i in range(nsf):
+        ow.work_ul(iq[i, 0], iq[i, 1], tti0 + i)
+    recs = parse_pcap(ow.pcap_bytes())
+    ul = {(r["sfn"] * 10 + r["sf"], r["rnti"], r["pdu"]) for r in recs if r["direction"] == 0}
+    setups = [r for r in recs if r["direction"] == 1 and r["rnti_type"] == 3 and r["pdu"][:1] == b"\x3c"]
+    assert len(setups) >= 4
+    late = [s for s in sent if s["tti"] >= tti0 + 40]
+    hit = sum((s["tti"] % 10240, s["rnti"], s["payload"]) in ul for s in late)
+    assert late and hit >= 0.7 * len(late), (hit, len(late))
+    # the learned configurations differ from the defaults for at least one UE
+    ow.lib.o_worker_ue_cfg.argtypes = [C.c_void_p, C.c_uint16, C.POINTER(OUeCfg)]
+    learned = set()
+    for r in setups:
+        c = OUeCfg()
+        ow.lib.o_worker_ue_cfg(ow.h, r["rnti"], C.byref(c))
+        assert c.has_ue_config == 1
+        learned.add((c.i_offset_ack, c.i_offset_cqi, c.i_offset_ri, c.cqi_type))
+    assert any(x != (10, 8, 11, 2) for x in learned)

@@ -236,6 +236,8 @@ typedef struct {
   // BCCH-DL-SCH messages sent with the SI-RNTI (sib_period != 0): message (sfn / 2) % 2 when its length is not 0, else random bytes
   uint32_t si_len[2];
   uint8_t si_msg[2][96];
+  uint32_t pg_len;        // PCCH message sent with the P-RNTI (paging_period != 0) when not 0, else random bytes
+  uint8_t pg_msg[96];
 } txg_cfg_t;
 
 typedef struct { uint16_t rnti; uint8_t format, L; uint16_t ncce; uint32_t tti; uint32_t nbytes; uint32_t offset; uint8_t tb, mod, table256, is_ul; uint32_t nof_prb; uint32_t mcs; uint32_t cqi_req; uint32_t hop_bits_plus1; /* DCI 0: 0 = no hopping, else 1 + hopping bits */ } txg_pdu_t;
@@ -622,7 +624,10 @@ extern "C" int txg_next(txg_t* g, float* iq, txg_pdu_t* pdus, int max_pdus, uint
     if (c.si_len[mi]) add_common(0xFFFF, 0, c.si_msg[mi], (int)std::min<uint32_t>(c.si_len[mi], 96));
     else add_common(0xFFFF, 0, nullptr, 0);
   }
-  if (c.paging_period && (tti % c.paging_period) == 3) add_common(0xFFFE, 0, nullptr, 0);
+  if (c.paging_period && (tti % c.paging_period) == 3) {
+    if (c.pg_len) add_common(0xFFFE, 0, c.pg_msg, (int)std::min<uint32_t>(c.pg_len, 96));
+    else add_common(0xFFFE, 0, nullptr, 0);
+  }
   if (c.rar_period && (tti % c.rar_period) == 7) {
     // MAC RAR PDU: one RAPID subheader + one RAR with a fresh temporary C-RNTI
     uint16_t t_crnti = (uint16_t)(0x0100 + g->rng.below(0xFFF3 - 0x0100));
@@ -846,7 +851,8 @@ extern "C" int txg_next(txg_t* g, float* iq, txg_pdu_t* pdus, int max_pdus, uint
 typedef struct { uint32_t nof_prb, cell_id, cyclic_shift, delta_ss; } txg_ul_cell_t;
 typedef struct { uint16_t rnti; uint16_t n_dmrs; uint32_t n_prb, L_prb, mod, tbs, rv; float gain_db, phase_rad, ta_samples;
                  uint32_t nof_ack, cqi_bits, ri_bits; /* UCI multiplexed into the PUSCH (36.212 5.2.2.6-8): HARQ-ACK bits, CQI report size, RI bits */
-                 uint32_t hop, n_prb2; /* hop = 1: slot 1 is sent on n_prb2 .. n_prb2 + L_prb - 1 (type-1 frequency hopping) */ } txg_ul_grant_t;
+                 uint32_t hop, n_prb2; /* hop = 1: slot 1 is sent on n_prb2 .. n_prb2 + L_prb - 1 (type-1 frequency hopping) */
+                 uint32_t i_ack_p1, i_cqi_p1, i_ri_p1; /* 1 + betaOffset-ACK / -CQI / -RI-Index the UE was configured with, 0 = 10 / 8 / 11 */ } txg_ul_grant_t;
 
 static int ul_largest_prime_below(int n) { for (int p = n - 1; p >= 2; p--) { bool ok = true; for (int d = 2; d * d <= p; d++) if (p % d == 0) { ok = false; break; } if (ok) return p; } return 2; }
 
@@ -872,12 +878,18 @@ extern "C" int txg_ul_make(const txg_ul_cell_t* c, uint32_t tti, const txg_ul_gr
     uint8_t* pl = payloads + used;
     for (uint32_t i = 0; i < g.tbs / 8; i++) pl[i] = (uint8_t)rng.below(256);
     used += g.tbs / 8;
-    // control resources, 36.212 5.2.2.6: Q' = min(ceil(O M_sc N_symb beta / sum K_r), cap), beta_ack = 20, beta_ri = 15.875, beta_cqi = 2.25
+    // control resources, 36.212 5.2.2.6: Q' = min(ceil(O M_sc N_symb beta / sum K_r), cap), beta from the UE's betaOffset indices
     Segm sg; cbsegm((int)g.tbs, sg);
     const double sumK = (double)sg.Cp * sg.Kp + (double)sg.Cm * sg.Km;
     auto qprime = [&](int O, double beta, int cap) { if (O <= 0) return 0; int q = (int)std::ceil((double)O * M * 12.0 * beta / sumK - 1e-9); return q < cap ? q : cap; };
-    const int Qa = qprime((int)g.nof_ack, 20.0, 4 * M), Qr = qprime((int)g.ri_bits, 15.875, 4 * M);
-    const int Oc = (int)g.cqi_bits, Qc = Oc ? qprime(Oc + (Oc > 11 ? 8 : 0), 2.25, 12 * M - Qr) : 0;
+    // 36.213 Tables 8.6.3-1/-2/-3
+    static const double b_ack[16] = {2.0, 2.5, 3.125, 4.0, 5.0, 6.25, 8.0, 10.0, 12.625, 15.875, 20.0, 31.0, 50.0, 80.0, 126.0, 0.0};
+    static const double b_ri[16] = {1.25, 1.625, 2.0, 2.5, 3.125, 4.0, 5.0, 6.25, 8.0, 10.0, 12.625, 15.875, 20.0, 0.0, 0.0, 0.0};
+    static const double b_cqi[16] = {0.0, 0.0, 1.125, 1.25, 1.375, 1.625, 1.75, 2.0, 2.25, 2.5, 2.875, 3.125, 3.5, 4.0, 5.0, 6.25};
+    const double beta_ack = b_ack[g.i_ack_p1 ? (g.i_ack_p1 - 1) & 15 : 10], beta_ri = b_ri[g.i_ri_p1 ? (g.i_ri_p1 - 1) & 15 : 11],
+                 beta_cqi = b_cqi[g.i_cqi_p1 ? (g.i_cqi_p1 - 1) & 15 : 8];
+    const int Qa = qprime((int)g.nof_ack, beta_ack, 4 * M), Qr = qprime((int)g.ri_bits, beta_ri, 4 * M);
+    const int Oc = (int)g.cqi_bits, Qc = Oc ? qprime(Oc + (Oc > 11 ? 8 : 0), beta_cqi, 12 * M - Qr) : 0;
     const int G = (12 * M - Qr - Qc) * Qm;
     bits_t f = dlsch_encode(pl, (int)g.tbs, G, Qm, 1, (int)g.rv);
     // channel interleaver 5.2.2.8: M rows x 12 columns of Qm-bit cells; RI first (bottom rows, columns 1,4,7,10), then CQI + data row by
