@@ -203,6 +203,7 @@ void Engine::buildTables()
     for (int m = 0; m < ng; m++) for (int i = 0; i < 3; i++) used0[avail[((int)id + m + (i * na) / 3) % na]] = 1;
     std::vector<uint16_t> rk(3 * 800, 0);
     std::vector<uint8_t> rl(3 * 800, 0);
+    std::vector<uint16_t> rq(3 * 800, 0xFFFFu);  // natural REG index: symbol 0 has nre / 6 REGs, every later control symbol nre / 4
     for (int cfi = 1; cfi <= 3; cfi++) {
       const int nsym = cfi + (nprb <= 10 ? 1 : 0);
       std::vector<std::pair<uint16_t, uint8_t>> regs;
@@ -218,10 +219,14 @@ void Engine::buildTables()
       cd.nof_regs[cfi - 1] = (uint32_t)M; cd.nof_cce[cfi - 1] = (uint32_t)(M / 9);
       for (int mp = 0; mp < M; mp++) {
         const int q = perm[(mp + (int)id) % M];
-        if (q < 800) { rk[(cfi - 1) * 800 + q] = regs[mp].first; rl[(cfi - 1) * 800 + q] = regs[mp].second; }
+        if (q < 800) {
+          rk[(cfi - 1) * 800 + q] = regs[mp].first; rl[(cfi - 1) * 800 + q] = regs[mp].second;
+          const int l = regs[mp].second, nat = l == 0 ? regs[mp].first / 6 : n0 + (l - 1) * (nre / 4) + regs[mp].first / 4;
+          if (nat < 800) rq[(cfi - 1) * 800 + nat] = (uint16_t)q;
+        }
       }
     }
-    cd.reg_k0 = upload(dev_allocs, rk); cd.reg_l = upload(dev_allocs, rl);
+    cd.reg_k0 = upload(dev_allocs, rk); cd.reg_l = upload(dev_allocs, rl); cd.reg_q = upload(dev_allocs, rq);
   }
   // scrambling sequences of the control region
   {

@@ -33,6 +33,7 @@ struct LsnCellDev {
   const cf32* crs;          // [10][ports][4][nref]
   const uint16_t* reg_k0;   // [3][800] quadruplet -> first RE of its REG
   const uint8_t* reg_l;     // [3][800]
+  const uint16_t* reg_q;    // [3][800] inverse map: REG in (symbol, frequency) order -> quadruplet of the PDCCH order, 0xFFFF = PCFICH / PHICH
   const uint8_t* pdcch_scr; // [10][LSN_LLR_STRIDE] scrambling bits
   const uint8_t* pcfich_scr;// [10][32]
   uint32_t nof_cce[3], nof_regs[3];

@@ -341,56 +341,44 @@ void lsn_launch_pcfich(const LsnCellDev& c, const cf32* grid, const cf32* ce, co
   hipLaunchKernelGGL(k_pcfich, dim3(nsf), dim3(64), 0, s, c, grid, ce, ch, sf_idx, cfi, corr);
 }
 
-// One workgroup per (control symbol l, subframe): the (1 + ports) x nof_rx rows of that symbol (received grid and channel
-// estimates, <= 57.6 KB at 100 PRB) are staged in LDS with coalesced 16-byte loads, then every REG quadruplet that lives on
-// the symbol is equalised from LDS and written to its place in the PDCCH order (8 consecutive floats per quadruplet).
+// One thread per REG in (symbol, frequency) order: consecutive lanes read consecutive REGs of the received grid and of the channel
+// estimates (32 / 48 contiguous bytes each, so a wavefront reads whole rows segments), equalise and write the 8 LLRs of the quadruplet to
+// its place in the PDCCH order (reg_q: inverse of the REG interleaver, 36.211 6.8.5).  Same arithmetic as the gather form.
 __global__ __launch_bounds__(256) void k_pdcch_llr(LsnCellDev c, const cf32* __restrict__ grid, const cf32* __restrict__ ce,
                                                    const LsnChest* __restrict__ ch, const uint32_t* __restrict__ sf_idx_arr,
                                                    const uint32_t* __restrict__ cfi_arr, float* __restrict__ llr)
 {
-  extern __shared__ __align__(16) unsigned char lds_raw[];
-  cf32* rows = reinterpret_cast<cf32*>(lds_raw);
-  const int sf = blockIdx.y, l = blockIdx.x;
+  const int sf = blockIdx.y;
   const uint32_t cfi = cfi_arr[sf];
-  if ((uint32_t)l >= cfi + (c.nof_prb <= 10 ? 1u : 0u)) return;  // 36.211 6.7: one more control symbol at <= 10 PRB
-  const int nre = (int)c.nre, A = (int)c.nof_rx, P = (int)c.nof_ports;
-  const cf32* g = grid + (size_t)sf * A * 14 * nre;
-  const cf32* e = ce + (size_t)sf * P * A * 14 * nre;
-  // rows [0, A): grid; rows [A, A + P A): estimates, port-major like the global layout
-  const int nrow = A + P * A, n2 = nre / 2;   // nre is a multiple of 12: rows are 16-byte aligned
-  for (int i = threadIdx.x; i < nrow * n2; i += 256) {
-    const int r = i / n2, k2 = i - r * n2;
-    const cf32* src = (r < A) ? g + ((size_t)r * 14 + l) * nre : e + ((size_t)(r - A) * 14 + l) * nre;
-    reinterpret_cast<float4*>(rows + (size_t)r * nre)[k2] = reinterpret_cast<const float4*>(src)[k2];
-  }
-  __syncthreads();
-  const uint8_t* scr = c.pdcch_scr + (size_t)sf_idx_arr[sf] * LSN_LLR_STRIDE;
-  const float noise = ch[sf].noise_avg;
-  const uint32_t nq = c.nof_cce[cfi - 1] * 9;
-  const uint8_t* rl = c.reg_l + (cfi - 1) * 800;
-  const uint16_t* rk = c.reg_k0 + (cfi - 1) * 800;
-  for (uint32_t q = threadIdx.x; q < nq; q += 256) {
-    if ((int)rl[q] != l) continue;
-    cf32 x[4];
-    reg_equalise(c, rows, rows + (size_t)A * nre, noise, l, (int)rk[q], x, nre, A * nre);
-    float4 o0, o1;
-    const uint8_t* sc = scr + 8 * q;
-    float v[8];
+  const int nre = (int)c.nre, A = (int)c.nof_rx, n0 = nre / 6, n1 = nre / 4;
+  const int nat = blockIdx.x * 256 + threadIdx.x;
+  int l, k0;
+  if (nat < n0) { l = 0; k0 = 6 * nat; }
+  else { const int r = nat - n0; l = 1 + r / n1; k0 = 4 * (r - (l - 1) * n1); }
+  if ((uint32_t)l >= cfi + (c.nof_prb <= 10 ? 1u : 0u) || nat >= 800) return;  // 36.211 6.7: one more control symbol at <= 10 PRB
+  const uint32_t q = c.reg_q[(cfi - 1) * 800 + nat];
+  if (q >= c.nof_cce[cfi - 1] * 9) return;  // PCFICH / PHICH REG (0xFFFF) or behind the last whole CCE
+  const cf32* g = grid + ((size_t)sf * A * 14 + l) * nre;
+  const cf32* e = ce + ((size_t)sf * c.nof_ports * A * 14 + l) * nre;
+  const uint8_t* sc = c.pdcch_scr + (size_t)sf_idx_arr[sf] * LSN_LLR_STRIDE + 8 * q;
+  cf32 x[4];
+  reg_equalise(c, g, e, ch[sf].noise_avg, l, k0, x, 14 * nre, A * 14 * nre);
+  float v[8];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      float a = -(x[j].r * SQRT2F), b = -(x[j].i * SQRT2F);
-      v[2 * j] = sc[2 * j] ? -a : a;
-      v[2 * j + 1] = sc[2 * j + 1] ? -b : b;
-    }
-    o0.x = v[0]; o0.y = v[1]; o0.z = v[2]; o0.w = v[3]; o1.x = v[4]; o1.y = v[5]; o1.z = v[6]; o1.w = v[7];
-    float4* o = reinterpret_cast<float4*>(llr + (size_t)sf * LSN_LLR_STRIDE + 8 * q);
-    o[0] = o0; o[1] = o1;
+  for (int j = 0; j < 4; j++) {
+    float a = -(x[j].r * SQRT2F), b = -(x[j].i * SQRT2F);
+    v[2 * j] = sc[2 * j] ? -a : a;
+    v[2 * j + 1] = sc[2 * j + 1] ? -b : b;
   }
+  float4 o0, o1;
+  o0.x = v[0]; o0.y = v[1]; o0.z = v[2]; o0.w = v[3]; o1.x = v[4]; o1.y = v[5]; o1.z = v[6]; o1.w = v[7];
+  float4* o = reinterpret_cast<float4*>(llr + (size_t)sf * LSN_LLR_STRIDE + 8 * q);
+  o[0] = o0; o[1] = o1;
 }
 void lsn_launch_pdcch_llr(const LsnCellDev& c, const cf32* grid, const cf32* ce, const LsnChest* ch, const uint32_t* sf_idx, const uint32_t* cfi, float* llr, uint32_t nsf, hipStream_t s)
 {
-  const size_t lds = (size_t)(c.nof_rx + c.nof_ports * c.nof_rx) * c.nre * sizeof(cf32);
-  hipLaunchKernelGGL(k_pdcch_llr, dim3(c.nof_prb <= 10 ? 4 : 3, nsf), dim3(256), lds, s, c, grid, ce, ch, sf_idx, cfi, llr);
+  const uint32_t nreg = c.nre / 6 + (c.nof_prb <= 10 ? 3u : 2u) * (c.nre / 4);  // REGs of the widest control region
+  hipLaunchKernelGGL(k_pdcch_llr, dim3((nreg + 255) / 256, nsf), dim3(256), 0, s, c, grid, ce, ch, sf_idx, cfi, llr);
 }
 
 // falcon_pdcch.c:595-620: mean |llr| over the 72 LLRs of each CCE, accumulated in double in index order
