@@ -131,7 +131,9 @@ int lsn_phy_print_stats(lsn_phy_t* phy, void* file);
  * lsn_phy_update_mcs_database runs one update now (between process calls), for callers that keep the reference's own timer. */
 int lsn_phy_set_mcs_update_interval(lsn_phy_t* phy, uint32_t seconds);
 int lsn_phy_update_mcs_database(lsn_phy_t* phy);
-uint32_t lsn_phy_nof_tracked_rnti(lsn_phy_t* phy);   /* MCSTracking::nof_RNTI_member_dl */
+uint32_t lsn_phy_nof_tracked_rnti(lsn_phy_t* phy);   /* MCSTracking::nof_RNTI_member_dl; in UL_MODE nof_RNTI_member_ul (the uplink database is aged the
+                                                         same way: update_database_ul, MCSTracking.cc:86-176, fed by update_statistic_ul :729-754) */
+int lsn_phy_tracked_ul_modulation(lsn_phy_t* phy, uint16_t rnti); /* UL_MODE: 0 no entry, 1 unknown, 2 / 3 / 4 = 16 / 64 / 256QAM maximum (find_tracking_info_RNTI_ul without the time stamp) */
 
 /* ---- SubframeWorker ---- */
 float** lsn_worker_buffers(lsn_worker_t* w);         /* SubframeWorker::getBuffers: [antenna] -> interleaved cf32, pinned host */

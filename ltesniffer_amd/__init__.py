@@ -29,7 +29,7 @@ EXPORTS = ["lsn_phy_create", "lsn_phy_destroy", "lsn_phy_set_cell", "lsn_phy_get
            "lsn_worker_sf_idx", "lsn_worker_sfn", "lsn_phy_process_device", "lsn_phy_process_host", "lsn_phy_tap",
            "lsn_phy_get_perf", "lsn_kernel_name", "lsn_version", "lsn_pcap_open", "lsn_pcap_open_mem",
            "lsn_pcap_set_wall_clock", "lsn_pcap_write", "lsn_pcap_sink", "lsn_pcap_mem", "lsn_pcap_nof_records",
-           "lsn_pcap_reset", "lsn_pcap_close", "lsn_phy_set_pcap_writer", "lsn_phy_set_api_mode", "lsn_phy_set_ul_config", "lsn_phy_get_ul_config", "lsn_sib2_decode", "lsn_phy_pusch_decode",
+           "lsn_pcap_reset", "lsn_pcap_close", "lsn_phy_set_pcap_writer", "lsn_phy_set_api_mode", "lsn_phy_tracked_ul_modulation", "lsn_phy_set_ul_config", "lsn_phy_get_ul_config", "lsn_sib2_decode", "lsn_phy_pusch_decode",
            "lsn_phy_tap_ul", "lsn_phy_set_prach_config", "lsn_phy_prach_detect", "lsn_phy_set_prach_sink", "lsn_prach_tti_opportunity", "lsn_phy_process_file", "lsn_phy_mib_decode", "lsn_phy_mib_decode_llr", "lsn_phy_submit_device", "lsn_phy_wait", "lsn_cell_search",
            "lsn_phy_set_shortcut_discovery", "lsn_phy_get_shortcut_discovery", "lsn_phy_set_histogram_threshold", "lsn_phy_print_stats",
            "lsn_phy_set_mcs_update_interval", "lsn_phy_update_mcs_database", "lsn_phy_nof_tracked_rnti", "lsn_worker_buffers_offset", "lsn_pcap_digest", "lsn_pcap_set_store", "lsn_phy_create_multi", "lsn_phy_nof_devices"]
@@ -249,6 +249,7 @@ def lib():
         L.lsn_pcap_close.restype = None
         L.lsn_phy_set_pcap_writer.argtypes = [C.c_void_p, C.c_void_p]
         L.lsn_phy_set_ul_config.argtypes = [C.c_void_p, C.POINTER(UlCfg)]
+        L.lsn_phy_tracked_ul_modulation.argtypes = [C.c_void_p, C.c_uint16]
         L.lsn_phy_set_api_mode.argtypes = [C.c_void_p, C.c_int, API_SINK, C.c_void_p, C.c_void_p]
         L.lsn_phy_get_ul_config.argtypes = [C.c_void_p, C.POINTER(UlCfg), C.POINTER(Sib2), C.POINTER(C.c_uint32)]
         L.lsn_sib2_decode.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(Sib2)]
@@ -504,6 +505,9 @@ class Phy:
             self.api_events.append((int(e.tti), int(e.rnti), int(e.id_type), int(e.msg_type), e.value.decode()))
         self._api_cb = API_SINK(_cb)
         return lib().lsn_phy_set_api_mode(self._h, int(api_mode), self._api_cb, None, api_pcapwriter._h if api_pcapwriter else None) == LSN_SUCCESS
+
+    def trackedUlModulation(self, rnti):
+        return int(lib().lsn_phy_tracked_ul_modulation(self._h, rnti))
 
     def getUlConfig(self):
         """None until an uplink configuration is in use, else dict(cyclic_shift, delta_ss, hopping_offset, from_sib2, sib2 = dict or None)"""

@@ -314,6 +314,7 @@ int lsn_phy_update_mcs_database(lsn_phy_t* phy)
   return LSN_SUCCESS;
 }
 uint32_t lsn_phy_nof_tracked_rnti(lsn_phy_t* phy) { return phy ? phy->engine->nofTrackedRnti() : 0; }
+int lsn_phy_tracked_ul_modulation(lsn_phy_t* phy, uint16_t rnti) { return phy ? phy->engine->trackedModUl(rnti) : 0; }
 uint32_t lsn_phy_nof_active_rnti(lsn_phy_t* phy) { return phy ? phy->engine->rntiManager().nofActive() : 0; }
 int lsn_phy_get_ue_config(lsn_phy_t* phy, uint16_t rnti, lsn_ue_config_t* out)
 {

@@ -176,6 +176,7 @@ public:
   void uploadUlStatic();   // tables of the uplink OFDM demodulator that do not depend on SIB2
   bool getUlConfig(lsn_ul_cfg_t* u, lsn_prach_cfg_t* p, Sib2Config* sib) const;
   bool sib2Learned() const { return sib2_learned; }
+  int trackedModUl(uint16_t rnti) const { return ulmod.empty() ? 0 : (int)ulmod[rnti]; }
   int puschDecode(const void* ul_iq, bool on_device, uint32_t nsf, uint32_t start_tti, const lsn_pusch_grant_t* grants, uint32_t ngrants,
                   lsn_pusch_result_t* results, uint8_t* payloads, size_t payload_cap);
   long tapUl(int what, uint32_t index, void* out, size_t cap);
@@ -273,8 +274,8 @@ private:
   uint64_t& nof_mcs_db_updates = sh->nof_mcs_db_updates;
 public:
   void setMcsUpdateInterval(uint32_t seconds) { mcs_tracking.set_interval(seconds); mcs_update_period = seconds * 1000u; }
-  void updateMcsDatabase() { std::lock_guard<std::mutex> lk(mcs_mtx); ageTrackingDatabase(); }  // between process calls only
-  uint32_t nofTrackedRnti() { std::lock_guard<std::mutex> lk(mcs_mtx); return mcs_tracking.nof_RNTI_member_dl(); }
+  void updateMcsDatabase() { std::lock_guard<std::mutex> lk(mcs_mtx); if (cfg.sniffer_mode == 1) ulAgeDatabase(); else ageTrackingDatabase(); }  // between process calls only
+  uint32_t nofTrackedRnti() { std::lock_guard<std::mutex> lk(mcs_mtx); return cfg.sniffer_mode == 1 ? ulmod_count : mcs_tracking.nof_RNTI_member_dl(); }  // nof_RNTI_member_dl / _ul
 private:
   // front thread: launches stage A chunk after chunk, hands finished chunks to the search (caller) thread
   std::thread front_thread;
@@ -328,7 +329,11 @@ private:
   std::map<uint32_t, std::vector<UlSchedGrant>> ul_sched, rar_sched;  // ULSchedule databases (touched in the commit turn only)
   std::vector<uint8_t> ulmod; uint32_t ulmod_count = 0;               // MCSTracking UL: 0 absent, 1 unknown, 2/3/4 = 16/64/256QAM max
   std::vector<UeSpecConfig> ul_uecfg;                                 // ue_spec_config of the UL tracking entries (valid where ulmod != 0)
-  void ulTrackAdd(uint16_t rnti);                                     // add_RNTI_ul(UNKNOWN_MOD), MCSTracking.cc:57-69
+  std::vector<uint32_t> ul_time, ul_active, ul_success;               // ul_sniffer_tracking_t::time (in subframes), nof_active, nof_success_mgs
+  float last_ul_snr = 0.0f;                                           // enb_ul.chest_res.snr_db of the most recent PUSCH attempt (UL_Sniffer_PUSCH.cc:572)
+  void ulTrackAdd(uint16_t rnti, int mod = 1);                        // add_RNTI_ul, MCSTracking.cc:57-69
+  void ulAgeDatabase();                                               // update_database_ul, MCSTracking.cc:86-176
+
   UeSpecConfig ulUeConfig(uint16_t rnti) const { return (!ulmod.empty() && ulmod[rnti]) ? ul_uecfg[rnti] : mcs_tracking.default_config(); }
   std::vector<LsnUlGrantDev> ul_last_gd; std::vector<int> ul_last_idx;  // descriptors of the last puschDecode call (taps)
   JobRunner runner_u;

@@ -20,7 +20,7 @@ namespace {
 // (uci: CQI report size | 1 + betaOffset indices << 8 / 13 / 18 - they move the UL-SCH resource elements, UL_Sniffer_PUSCH.cc:429-450)
 struct Attempt { uint32_t sf; uint32_t idx; bool use256; int qm; uint32_t uci; };
 inline bool operator<(const Attempt& a, const Attempt& b) { return std::tie(a.sf, a.idx, a.use256, a.qm, a.uci) < std::tie(b.sf, b.idx, b.use256, b.qm, b.uci); }
-struct AttemptResult { bool crc = false; std::vector<uint8_t> payload; };
+struct AttemptResult { bool crc = false; bool ran = false; float snr = 0.0f; std::vector<uint8_t> payload; };  // ran: the channel estimate of the attempt was computed
 // downlink records keep the OFFSET of their payload in ch.h_payload: a later on-demand decode of the same loop may grow (reallocate) that
 // arena, so the pointer is only formed when the record is emitted
 struct PendingPdu { bool ul; char name; uint16_t rnti; uint8_t tb; size_t off; std::vector<uint8_t> own; uint32_t len; };
@@ -48,16 +48,29 @@ bool Engine::decodeSib(Chunk& ch, JobRunner& r, uint32_t sf, Sib2Config& out, si
 }
 
 // MCSTracking::add_RNTI_ul (MCSTracking.cc:57-69): a new entry starts with unknown modulation and a copy of the default configuration
-void Engine::ulTrackAdd(uint16_t rnti)
+void Engine::ulTrackAdd(uint16_t rnti, int mod)
 {
-  if (ulmod[rnti]) return;
-  ulmod[rnti] = 1; ulmod_count++;
+  if (ulmod[rnti]) return;  // std::map::insert keeps an existing entry
+  ulmod[rnti] = (uint8_t)mod; ulmod_count++;
+  ul_time[rnti] = commit_sf_cnt; ul_active[rnti] = ul_success[rnti] = 0;
   ul_uecfg[rnti] = mcs_tracking.default_config();
+}
+
+// MCSTracking::update_database_ul as LTESniffer_Core drives it (LTESniffer_Core.cc:473-499): entries idle for more than `interval` whole
+// seconds (1 subframe = 1 ms) or without a counted decode are dropped
+void Engine::ulAgeDatabase()
+{
+  if (ulmod.empty()) return;
+  const uint32_t interval = mcs_update_period / 1000u;
+  for (uint32_t r = 0; r < 65536; r++) {
+    if (!ulmod[r]) continue;
+    if ((commit_sf_cnt - ul_time[r]) / 1000u > interval || ul_active[r] == 0) { ulmod[r] = 0; ulmod_count--; }
+  }
 }
 
 void Engine::commitChunkUl(Chunk& ch, JobRunner& r)
 {
-  if (ulmod.empty()) { ulmod.assign(65536, 0); ul_uecfg.assign(65536, UeSpecConfig()); }
+  if (ulmod.empty()) { ulmod.assign(65536, 0); ul_uecfg.assign(65536, UeSpecConfig()); ul_time.assign(65536, 0); ul_active.assign(65536, 0); ul_success.assign(65536, 0); }
   const uint32_t nsf = ch.nsf;
   std::vector<std::vector<PendingPdu>> out(nsf);            // records per subframe: downlink first, then uplink
   std::vector<std::vector<UlSchedGrant>> lists(nsf);        // PUSCH grants to try in each subframe
@@ -173,7 +186,7 @@ void Engine::commitChunkUl(Chunk& ch, JobRunner& r)
     if (m.g.tbs == 0 || m.g256.tbs == 0) return false;
     return ul_valid_prb(m.g.L_prb) && m.g.L_prb <= 100;
   };
-  auto mod_of = [&](uint16_t rnti) -> int { return ulmod[rnti] ? ulmod[rnti] : (ulmod_count < 250 ? 1 : 5); };  // 5 = FULL_BUFFER
+  auto mod_of = [&](uint16_t rnti) -> int { return ulmod[rnti] ? ulmod[rnti] : (ulmod_count < 250 ? 1 : 5); };  // find_tracking_info_RNTI_ul; 5 = FULL_BUFFER
   auto trial = [&](const UlSchedGrant& m, int mod, Attempt* a, int* learn) -> int {
     // returns the number of attempts (tried in order until one passes); learn[i]: modulation learnt if attempt i passes (0: none)
     const uint32_t mcs = m.g.mcs_idx;
@@ -231,6 +244,7 @@ void Engine::commitChunkUl(Chunk& ch, JobRunner& r)
     for (size_t i = 0; i < gl.size(); i++) {
       AttemptResult& ar = results[keys[i]];
       ar.crc = res[i].crc_ok != 0;
+      ar.ran = res[i].iterations > 0; ar.snr = res[i].snr_db;
       if (ar.crc) ar.payload.assign(pay.begin() + res[i].payload_off, pay.begin() + res[i].payload_off + gl[i].tbs / 8);
       r.perf.nof_tb_decodes++;
       r.perf.nof_turbo_iterations += res[i].iterations;
@@ -258,6 +272,7 @@ void Engine::commitChunkUl(Chunk& ch, JobRunner& r)
   // ---- phase 3 (sequential): the exact decision logic, records in (tti, downlink, uplink) order ----
   for (uint32_t sf = 0; sf < nsf; sf++) {
     const uint32_t tti = ch.ctx[sf].tti;  // already reduced mod 10240 (SubframeCtx::reset)
+    if (cfg.mcs_tracking_mode && mcs_update_period && commit_sf_cnt && (commit_sf_cnt % mcs_update_period) == 0) ulAgeDatabase();  // LTESniffer_Core.cc:473-499
     for (auto& su : setups[sf]) {  // the downlink part of the subframe ran first (SubframeWorker.cc:299-347): update_default_ue_config / update_ue_config_rnti
       if (!mcs_tracking.check_default_config()) mcs_tracking.update_default_ue_config(su.second);
       ulTrackAdd(su.first);
@@ -267,13 +282,19 @@ void Engine::commitChunkUl(Chunk& ch, JobRunner& r)
       const UlSchedGrant& m = lists[sf][i];
       if (!valid_grant(m)) continue;
       Attempt a[3]; int learn[3];
-      const int n = trial(m, mod_of(m.rnti), a, learn);
-      const uint32_t uci = uci_of(m);
+      const int mod = mod_of(m.rnti);
+      if (ulmod[m.rnti]) ul_time[m.rnti] = commit_sf_cnt;  // find_tracking_info_RNTI_ul refreshes the entry's time stamp (MCSTracking.cc:52-53)
+      const int n = trial(m, mod, a, learn);
+      const uint32_t uci = uci_of(m), mcs = m.g.mcs_idx;
+      const int mem_mod = (mcs > 20 && mcs < 29 && mod >= 2 && mod <= 4) ? mod : 1;  // decoding_mem.mcs_mod, UL_Sniffer_PUSCH.cc:456-570
+      bool crc = false;
       for (int k = 0; k < n; k++) {
         a[k].sf = sf; a[k].idx = i; a[k].uci = uci;
         if (!results.count(a[k])) { run_batch({a[k]}); r.perf.nof_ondemand_decodes++; }
         const AttemptResult& ar = results[a[k]];
+        if (ar.ran) last_ul_snr = ar.snr;
         if (!ar.crc) continue;
+        crc = true;
         PendingPdu p{true, 'C', m.rnti, 0, 0, ar.payload, (uint32_t)ar.payload.size()};
         out[sf].push_back(std::move(p));
         if (learn[k] && m.g.mcs_idx > 20) {  // decode_run: update_RNTI_ul when the maximum modulation was still unknown
@@ -281,6 +302,11 @@ void Engine::commitChunkUl(Chunk& ch, JobRunner& r)
           else ulTrackAdd(m.rnti);
         }
         break;
+      }
+      if (last_ul_snr >= 1.0f) {  // update_statistic_ul (MCSTracking.cc:729-754) behind the SNR gate of UL_Sniffer_PUSCH.cc:571-575
+        ulTrackAdd(m.rnti, mem_mod);
+        ul_active[m.rnti]++;
+        if (crc) ul_success[m.rnti]++;
       }
     }
     for (auto& p : out[sf]) {
@@ -297,6 +323,7 @@ void Engine::commitChunkUl(Chunk& ch, JobRunner& r)
         emitPdu(ch, r, name, p.off, p.len, p.rnti, tti, p.tb);
       }
     }
+    commit_sf_cnt++;
   }
 }
 

@@ -326,6 +326,8 @@ void o_worker_set_api(o_worker_t* w, int api_mode, o_pcap_t* api_pcap); /* -a: -
 int o_worker_api_events(o_worker_t* w, o_api_event_t* out, int cap);     /* events reported so far (print_api_dl) */
 void o_worker_set_second_opinion(o_worker_t* w, int turbo, int viterbi); /* decode transport blocks / DCI candidates with o_second.c */
 void o_worker_set_mcs_update_interval(o_worker_t* w, uint32_t seconds); /* MCSTracking::interval (5 s): ageing every interval x 1000 subframes, 0 = never */
+uint32_t o_worker_nof_tracked_ul(o_worker_t* w);                      /* MCSTracking::nof_RNTI_member_ul */
+int o_worker_tracked_mod_ul(o_worker_t* w, uint16_t rnti);            /* 0 no entry, 1 unknown, 2 / 3 / 4 = 16 / 64 / 256QAM max */
 uint32_t o_worker_nof_tracked(o_worker_t* w);                         /* MCSTracking::nof_RNTI_member_dl */
 int o_worker_tracked_table(o_worker_t* w, uint16_t rnti);            /* tracked table of an RNTI, -1 without entry */
 /* stage taps for parity tests (valid until the next work()) */

@@ -94,6 +94,9 @@ struct o_worker {
   ulslot_t* rar_sched; /* [16] RAR grants */
   uint8_t* ulmod;      /* [65536] 0 absent, 1 unknown, 2 16QAM max, 3 64QAM max, 4 256QAM max (MCSTracking UL) */
   uint32_t ulmod_count;
+  uint32_t *ul_time, *ul_active, *ul_success; /* [65536] ul_sniffer_tracking_t::time (subframes), nof_active, nof_success_mgs */
+  float last_ul_snr;  /* enb_ul.chest_res.snr_db: the estimate of the most recent PUSCH attempt (UL_Sniffer_PUSCH.cc:572) */
+  uint32_t nof_ul_updates;
 };
 
 
@@ -175,7 +178,7 @@ void o_worker_free(o_worker_t* w)
   if (!w) return;
   o_rntiman_free(w->rm);
   free(w->grid); free(w->ce); free(w->llr); free(w->mcs); free(w->uecfg); free(w->api_ev); free(w->llr0); free(w->llr1); free(w->payload);
-  free(w->ul_grid); free(w->ul_sched); free(w->rar_sched); free(w->ulmod);
+  free(w->ul_grid); free(w->ul_sched); free(w->rar_sched); free(w->ulmod); free(w->ul_time); free(w->ul_active); free(w->ul_success);
   free(w);
 }
 void o_worker_set_pcap(o_worker_t* w, o_pcap_t* p) { w->pcap = p; }
@@ -223,6 +226,17 @@ static o_ue_cfg_t ue_cfg_get(o_worker_t* w, uint16_t rnti)
   c.has_ue_config = 0;
   return c;
 }
+/* MCSTracking::add_RNTI_ul (MCSTracking.cc:57-69): time stamp, modulation, a copy of the default configuration, counters at zero */
+static void ul_add(o_worker_t* w, uint16_t rnti, int mod)
+{
+  if (w->ulmod[rnti]) return; /* std::map::insert keeps an existing entry */
+  w->ulmod[rnti] = (uint8_t)mod;
+  w->ulmod_count++;
+  w->ul_time[rnti] = w->sf_count;
+  w->ul_active[rnti] = w->ul_success[rnti] = 0;
+  w->uecfg[rnti] = w->default_cfg;
+  w->uecfg[rnti].has_ue_config = 0;
+}
 /* a decoded C-RNTI transport block: sch_pdu walk, every CCCH SDU (LCID 0) is tried as RRCConnectionSetup; the first one ever
  * seen also becomes the default of RNTIs without entry (DL_Sniffer_PDSCH.cc:1041-1070, 1133-1160) */
 static void learn_conn_setup(o_worker_t* w, const uint8_t* pdu, int len, uint16_t rnti)
@@ -238,7 +252,7 @@ static void learn_conn_setup(o_worker_t* w, const uint8_t* pdu, int len, uint16_
       w->has_default_cfg = 1;
     }
     if (w->ul_mode) { /* update_ue_config_rnti, UL_MODE branch (:1464-1479): add_RNTI_ul(UNKNOWN_MOD) copies the default first */
-      if (!w->ulmod[rnti]) { w->ulmod[rnti] = 1; w->ulmod_count++; }
+      ul_add(w, rnti, 1);
     } else {
       mcs_add(w, rnti); /* update_ue_config_rnti, :1446-1463 */
     }
@@ -824,6 +838,7 @@ void o_worker_set_ul_mode(o_worker_t* w, const o_ul_cfg_t* ul)
     w->ul_sched = (ulslot_t*)calloc(16, sizeof(ulslot_t));
     w->rar_sched = (ulslot_t*)calloc(16, sizeof(ulslot_t));
     w->ulmod = (uint8_t*)calloc(65536, 1);
+    w->ul_time = (uint32_t*)calloc(65536, 4); w->ul_active = (uint32_t*)calloc(65536, 4); w->ul_success = (uint32_t*)calloc(65536, 4);
   }
 }
 
@@ -937,6 +952,7 @@ static int pusch_attempt(o_worker_t* w, const ulg_t* m, const o_pusch_grant_t* g
                  uc.i_offset_ack + 1u, uc.i_offset_cqi + 1u, uc.i_offset_ri + 1u};
   int crc = o_pusch_decode_uci(&w->cfg.cell, &w->ulcfg, tti % 10, m->rnti, &gg, m->n_dmrs, &uci, w->ul_grid, w->cfg.max_turbo_iter, w->payload, &its, &snr);
   w->total_iters += (uint64_t)its;
+  if (its > 0) w->last_ul_snr = snr; /* the channel estimate ran (an invalid grant leaves the previous estimate in place) */
   if (crc) write_pcap_ul(w, w->payload, (uint32_t)(gg.tbs / 8), m->rnti, tti);
   return crc;
 }
@@ -944,13 +960,34 @@ static int pusch_attempt(o_worker_t* w, const ulg_t* m, const o_pusch_grant_t* g
 static int ulmod_find(o_worker_t* w, uint16_t rnti) /* MCSTracking::find_tracking_info_RNTI_ul, MCSTracking.cc:32-57: 5 = FULL_BUFFER */
 {
   if (!w->ulmod[rnti]) return w->ulmod_count < 250 ? 1 : 5;
+  w->ul_time[rnti] = w->sf_count; /* :52-53 */
   return w->ulmod[rnti];
 }
 static void ulmod_update(o_worker_t* w, uint16_t rnti, int mod) /* update_RNTI_ul, :71-85; add_RNTI_ul (:57-69) copies the default configuration */
 {
   if (w->ulmod[rnti]) w->ulmod[rnti] = (uint8_t)mod;
-  else { w->ulmod[rnti] = 1; w->ulmod_count++; w->uecfg[rnti] = w->default_cfg; w->uecfg[rnti].has_ue_config = 0; }
+  else ul_add(w, rnti, 1);
 }
+/* MCSTracking::update_statistic_ul, :729-754 (called when the last channel estimate reports >= 1 dB, UL_Sniffer_PUSCH.cc:571-575) */
+static void ul_statistic(o_worker_t* w, uint16_t rnti, int success, int mem_mod)
+{
+  ul_add(w, rnti, mem_mod);
+  w->ul_active[rnti]++;
+  if (success) w->ul_success[rnti]++;
+}
+/* MCSTracking::update_database_ul, :86-176: entries idle for more than `interval` whole seconds or without a counted decode are dropped
+ * (the all_database copies are statistics only) */
+static void ul_update_database(o_worker_t* w)
+{
+  for (uint32_t r = 0; r < 65536; r++) {
+    if (!w->ulmod[r]) continue;
+    const uint32_t cur_interval = (w->sf_count - w->ul_time[r]) / 1000u;
+    if (cur_interval > w->mcs_interval || w->ul_active[r] == 0) { w->ulmod[r] = 0; w->ulmod_count--; }
+  }
+  w->nof_ul_updates++;
+}
+uint32_t o_worker_nof_tracked_ul(o_worker_t* w) { return w->ulmod_count; }
+int o_worker_tracked_mod_ul(o_worker_t* w, uint16_t rnti) { return w->ulmod ? (int)w->ulmod[rnti] : 0; }
 
 /* PUSCH_Decoder::decode, UL_Sniffer_PUSCH.cc:389-583 (statistics / debug printing dropped) */
 static void decode_pusch(o_worker_t* w, uint32_t tti)
@@ -1000,6 +1037,7 @@ static void decode_pusch(o_worker_t* w, uint32_t tti)
       }
     }
 #undef LEARN
+    if (w->last_ul_snr >= 1.0f) ul_statistic(w, m->rnti, crc, mem_mod); /* UL_Sniffer_PUSCH.cc:571-575 */
   }
 }
 
@@ -1014,6 +1052,8 @@ int o_worker_work_ul(o_worker_t* w, const ocf_t* dl_iq, const ocf_t* ul_iq, uint
   memset(w->rb_map_dl, 0, sizeof(w->rb_map_dl));
   memset(w->rb_map_ul, 0, sizeof(w->rb_map_ul));
   if (update_meta) update_formats(w);
+  /* LTESniffer_Core.cc:473-499: every get_interval() x 1000 subframes the uplink tracking database is aged (UL mode, mcs_tracking_mode on) */
+  if (w->cfg.mcs_tracking_mode && w->mcs_update_period && w->sf_count && (w->sf_count % w->mcs_update_period) == 0) ul_update_database(w);
   o_ofdm_rx(cell, dl_iq, 0, w->grid); /* DCISearch::prepareDCISearch: one rx antenna for the downlink, DCISearch.cc:592 */
   o_chest(cell, 1, sf_idx, w->grid, w->ce, &w->chest);
   w->cfi = o_pcfich_decode(cell, &w->regs, 1, sf_idx, w->grid, w->ce, w->chest.noise_avg, NULL);
@@ -1036,6 +1076,7 @@ int o_worker_work_ul(o_worker_t* w, const ocf_t* dl_iq, const ocf_t* ul_iq, uint
       }
     }
     w->stats.nof_subframes++;
+    w->sf_count++;
     return w->records;
   }
   if (w->chest.snr_db > 6.0f) {
@@ -1057,5 +1098,6 @@ int o_worker_work_ul(o_worker_t* w, const ocf_t* dl_iq, const ocf_t* ul_iq, uint
   }
   w->stats.nof_subframes++;
   decode_pusch(w, tti); /* SubframeWorker.cc:343-347 */
+  w->sf_count++;
   return w->records;
 }
