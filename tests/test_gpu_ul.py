@@ -265,3 +265,32 @@ def test_ul_mode_learns_beta_offsets_and_cqi_mode():
         assert nlearn >= 3
         phy.close()
     assert len([r for r in orecs if r["direction"] == 0]) >= 20
+
+
+def test_ul_tracking_database_statistics_and_ageing_match_oracle():
+    """3150 UL_MODE subframes with UEs joining through random access: the uplink tracking database (entries from update_statistic_ul,
+    maximum modulation learnt at the first success above MCS 20, entries dropped by update_database_ul every 1000 subframes) evolves
+    like the oracle's - same records, same entry count, same modulation per RNTI"""
+    import ctypes as C
+    from lsn_testlib import OracleWorkerUl, parse_pcap
+    from parity import gpu_records, oracle_records
+    from test_ul_oracle import _ul_ageing_stream
+    sc, tti0, iq, sent = _ul_ageing_stream()
+    ow = OracleWorkerUl(sc["nof_prb"], sc["nof_ports"], sc["cell_id"], 3, 5)
+    ow.set_mcs_update_interval(1)
+    ow.lib.o_worker_nof_tracked_ul.argtypes = [C.c_void_p]
+    ow.lib.o_worker_tracked_mod_ul.argtypes = [C.c_void_p, C.c_uint16]
+    for i in range(iq.shape[0]):
+        ow.work_ul(iq[i, 0], iq[i, 1], tti0 + i, update_meta=1 if i % 500 == 0 else 0)
+    orecs = parse_pcap(ow.pcap_bytes())
+    phy = la.Phy(nof_rx_antennas=2, sniffer_mode=1, max_batch=200, pcapwriter=la.PcapWriter(None))
+    assert phy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"]) and phy.setUlConfig(3, 5)
+    phy.setMcsUpdateInterval(1)
+    phy.process_host(iq, tti0, 500)
+    g, o = gpu_records(phy), oracle_records(orecs)
+    assert g == o, "UL_MODE record streams differ: gpu %d vs oracle %d" % (len(g), len(o))
+    assert phy.nofTrackedRnti() == ow.lib.o_worker_nof_tracked_ul(ow.h) > 5
+    rntis = sorted({s["rnti"] for s in sent})
+    assert [phy.trackedUlModulation(r) for r in rntis] == [ow.lib.o_worker_tracked_mod_ul(ow.h, r) for r in rntis]
+    assert len([r for r in orecs if r["direction"] == 0]) > 1500
+    phy.close()

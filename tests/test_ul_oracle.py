@@ -210,3 +210,40 @@ def test_ul_mode_worker_learns_beta_offsets_and_cqi_mode():
         assert c.has_ue_config == 1
         learned.add((c.i_offset_ack, c.i_offset_cqi, c.i_offset_ri, c.cqi_type))
     assert any(x != (10, 8, 11, 2) for x in learned)
+
+
+def _ul_ageing_stream(nsf=3150):
+    from lsn_testlib import gen_ul_mode_subframes, scenario
+    sc = scenario("cfg2", seed=41, nof_rx=1, n_rnti=8, dl_min=1, dl_max=2, ul_min=1, ul_max=2, nof_prb=15, mcs_max=22, cfi=3, rar_period=180)
+    return (sc,) + gen_ul_mode_subframes(sc, nsf)
+
+
+def test_ul_tracking_database_statistics_and_ageing():
+    """MCSTracking's uplink database (update_statistic_ul :729-754 behind the 1 dB gate of UL_Sniffer_PUSCH.cc:571-575, update_database_ul
+    :86-176 every interval x 1000 subframes): every UE with a counted PUSCH decode gets an entry - so the first successful decode above
+    MCS 20 already fixes its maximum modulation -, entries of UEs that left the cell are dropped one interval later"""
+    import ctypes as C
+    from lsn_testlib import OracleWorkerUl, parse_pcap
+    sc, tti0, iq, sent = _ul_ageing_stream()
+    ow = OracleWorkerUl(sc["nof_prb"], sc["nof_ports"], sc["cell_id"], 3, 5)
+    ow.set_mcs_update_interval(1)
+    ow.lib.o_worker_nof_tracked_ul.argtypes = [C.c_void_p]
+    ow.lib.o_worker_tracked_mod_ul.argtypes = [C.c_void_p, C.c_uint16]
+    seen, counts = set(), []
+    last_tx = {}
+    for i in range(iq.shape[0]):
+        ow.work_ul(iq[i, 0], iq[i, 1], tti0 + i)
+        counts.append(ow.lib.o_worker_nof_tracked_ul(ow.h))
+    for s in sent:
+        seen.add(s["rnti"]); last_tx[s["rnti"]] = (s["tti"] - tti0) % 10240
+    n = iq.shape[0]
+    assert len(seen) > 20                     # random access brought new UEs in
+    # the passes at 1000 and 2000 subframes find nothing idle for more than one whole second, the one at 3000 drops the UEs that left early
+    assert counts[1001] >= counts[999] and counts[2001] >= counts[1999] and counts[3001] <= counts[2999] - 4
+    gone = [r for r in seen if last_tx[r] < 990]
+    live = [r for r in seen if last_tx[r] > n - 100]
+    assert gone and live
+    assert all(ow.lib.o_worker_tracked_mod_ul(ow.h, r) == 0 for r in gone)
+    assert sum(ow.lib.o_worker_tracked_mod_ul(ow.h, r) >= 2 for r in live) >= len(live) - 2   # 16QAM / 64QAM maximum learnt
+    ul = [r for r in parse_pcap(ow.pcap_bytes()) if r["direction"] == 0]
+    assert len(ul) > 0.7 * len([s for s in sent if (s["tti"] - tti0) % 10240 > 20])
