@@ -228,8 +228,10 @@ int lsn_cell_search(int device, const void* iq, int iq_on_device, uint64_t nof_s
  * offset (file mode has no PSS tracking); every 15*N samples per antenna are one subframe, counted from start_tti.
  * offset_freq_hz != 0: every subframe is multiplied by exp(-j 2 pi offset_freq n / fs) with n restarting per subframe.
  * The SFN the reference takes from the MIB (LTESniffer_Core.cc:382-420) is an input here (start_tti).
- * Blocks of LSN_FILE_BLOCK (default 3200) subframes are read, copied and re-laid-out on the GPU while the previous block is
- * processed. */
+ * Blocks of LSN_FILE_BLOCK (default 800) subframes go to the GPU and are re-laid-out there while the previous blocks are processed
+ * (LSN_FILE_SLOTS, default 8, blocks in flight): LSN_FILE_READERS (default 12) threads pread() a block into a pinned buffer;
+ * LSN_FILE_MMAP=1 page-locks the blocks in a mapping of the file instead (no CPU copy; slower on the boxes measured).  The block
+ * buffers stay allocated between calls, so the first call pays ~0.15 s of allocation. */
 typedef struct {
   uint32_t nof_antennas;        /* interleaved antennas in the file = nof_rx_antennas of the Phy */
   int64_t offset_time_samples;  /* -O: samples (per antenna) skipped at the start */

@@ -320,6 +320,9 @@ private:
   // uplink
   lsn_ul_cfg_t ul_cfg{};
   bool ul_set = false;
+  // device / pinned blocks of the file source, kept between lsn_phy_process_file calls (allocating them costs more than replaying a short capture)
+  struct FileBuf { cf32* h_raw = nullptr; cf32* d_raw = nullptr; cf32* d_iq = nullptr; size_t bytes = 0; };
+  FileBuf file_buf[8];
   std::atomic<uint32_t> ul_cfg_epoch{0};  // bumped by every (re)configuration: chunks whose DCI 0 grants were converted earlier are converted again at commit
   bool sib2_learned = false; Sib2Config sib2;  // the SIB2 the UL-mode commit stage configured itself from (decode_SIB), if any
   bool decodeSib(Chunk& ch, JobRunner& r, uint32_t sf, Sib2Config& out, size_t& payload_off, uint32_t& len, uint8_t& tb);

@@ -3,16 +3,21 @@
 // options -O / -o, ArgManager.cc:144-149).  cf32 samples, antennas interleaved sample by sample; `offset_time` samples per
 // antenna are skipped once; the stream is taken as subframe aligned (no PSS tracking in file mode), the subframe counter
 // starts at start_tti; a non-zero `offset_freq` rotates every subframe by exp(-j 2 pi f n / fs), n restarting per subframe.
-// A reader thread fills pinned blocks, copies them to the GPU and runs k_file_unpack on its own stream while the engine
-// processes the previous block, so the file / PCIe leg overlaps the compute.
+// A reader thread hands blocks of the file to the GPU and runs k_file_unpack on its own stream while the engine processes the
+// previous blocks, so the file / PCIe leg overlaps the compute.  Default source: LSN_FILE_READERS threads pread() the block into a pinned
+// buffer that lives in the engine (a 393 MB block from the page cache takes ~8 ms).  LSN_FILE_MMAP=1 selects the zero-copy variant: the
+// file is mapped read-only, the pages of a block are faulted in by the same threads, the block is page-locked in place (hipHostRegister)
+// and crosses PCIe straight from the page cache; on the boxes measured the lock / unlock per block costs more than the copy it saves.
 // Product code: no CPU fallback, nothing from oracle/ is included or linked.
 #include "lsn_engine.h"
+#include <chrono>
 #include <deque>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <fcntl.h>
 #include <stdexcept>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -36,13 +41,29 @@ int Engine::processFile(const char* path, const lsn_file_cfg_t& fc, uint32_t sta
   if (fstat(fd, &sb)) { close(fd); return LSN_ERROR_INVALID_INPUTS; }
   const uint32_t nant = fc.nof_antennas, sflen = cd.sflen;
   const size_t sf_bytes = (size_t)sflen * nant * sizeof(cf32);
-  uint32_t blk = 1600, nrd = 12;  // subframes per block (786 MB at 20 MHz / 2 antennas), pread threads per block
+  uint32_t blk = 800, nrd = 12;  // subframes per block (393 MB at 20 MHz / 2 antennas), page-touch / pread threads per block
   if (const char* e = getenv("LSN_FILE_BLOCK")) blk = (uint32_t)std::max(1, atoi(e));
   if (const char* e = getenv("LSN_FILE_READERS")) nrd = (uint32_t)std::max(1, std::min(32, atoi(e)));
   const uint64_t file_off0 = (uint64_t)fc.offset_time_samples * nant * sizeof(cf32);
   const uint64_t sf_in_file = (uint64_t)sb.st_size > file_off0 ? ((uint64_t)sb.st_size - file_off0) / sf_bytes : 0;  // complete subframes only
-  constexpr int NSLOT = 5;  // blocks in flight: one being read, one crossing PCIe, the others inside the decode pipeline
-  struct Slot { cf32* h_raw = nullptr; cf32* d_raw = nullptr; cf32* d_iq = nullptr; uint32_t nsf = 0; int state = 0; /* 0 free, 1 ready, 2 eof */ uint64_t mark = 0; } slot[NSLOT];
+  constexpr int NSLOT_MAX = 8;
+  int NSLOT = 8;  // blocks in flight: one being read, one crossing PCIe, the others inside the decode pipeline
+  if (const char* e = getenv("LSN_FILE_SLOTS")) NSLOT = std::max(3, std::min(NSLOT_MAX, atoi(e)));
+  const bool fdebug = getenv("LSN_FILE_DEBUG") != nullptr;
+  auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_begin = tnow();
+  struct Slot { cf32* h_raw = nullptr; cf32* d_raw = nullptr; cf32* d_iq = nullptr; uint32_t nsf = 0; int state = 0; /* 0 free, 1 ready, 2 eof */ uint64_t mark = 0;
+                void* reg = nullptr; /* page-locked range of the file mapping this block is copied from */ } slot[NSLOT_MAX];
+  bool use_mmap = false;  // measured on MI355X boxes (page-cache file): pread into pinned blocks 60 k subframes/s, in-place locking 26 k (lock / unlock per block)
+  if (const char* e = getenv("LSN_FILE_MMAP")) use_mmap = atoi(e) != 0;
+  uint8_t* map = nullptr;
+  const long page = sysconf(_SC_PAGESIZE);
+  if (use_mmap && sb.st_size > 0) {
+    void* m = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_SHARED, fd, 0);
+    if (m == MAP_FAILED) use_mmap = false; else map = (uint8_t*)m;
+  } else {
+    use_mmap = false;
+  }
   cf32* d_rot = nullptr;
   hipStream_t st = nullptr;
   std::mutex fm;
@@ -55,10 +76,20 @@ int Engine::processFile(const char* path, const lsn_file_cfg_t& fc, uint32_t sta
   try {
     HIP_CHECK(hipSetDevice(cfg.device));
     HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    for (auto& s : slot) {
-      HIP_CHECK(hipHostMalloc((void**)&s.h_raw, blk * sf_bytes, hipHostMallocDefault));
-      HIP_CHECK(hipMalloc((void**)&s.d_raw, blk * sf_bytes));
-      HIP_CHECK(hipMalloc((void**)&s.d_iq, blk * sf_bytes));
+    for (int si = 0; si < NSLOT; si++) {  // block buffers live in the engine and are reused by later calls
+      Slot& s = slot[si];
+      FileBuf& fb = file_buf[si];
+      if (fb.bytes < blk * sf_bytes) {
+        if (fb.h_raw) { (void)hipHostFree(fb.h_raw); fb.h_raw = nullptr; }
+        if (fb.d_raw) { (void)hipFree(fb.d_raw); fb.d_raw = nullptr; }
+        if (fb.d_iq) { (void)hipFree(fb.d_iq); fb.d_iq = nullptr; }
+        fb.bytes = 0;
+        HIP_CHECK(hipMalloc((void**)&fb.d_raw, blk * sf_bytes));
+        HIP_CHECK(hipMalloc((void**)&fb.d_iq, blk * sf_bytes));
+        fb.bytes = blk * sf_bytes;
+      }
+      if (!use_mmap && !fb.h_raw) HIP_CHECK(hipHostMalloc((void**)&fb.h_raw, fb.bytes, hipHostMallocDefault));
+      s.h_raw = fb.h_raw; s.d_raw = fb.d_raw; s.d_iq = fb.d_iq;
     }
     if (fc.offset_freq_hz != 0.0f) {
       std::vector<cf32> rot(sflen);
@@ -74,8 +105,10 @@ int Engine::processFile(const char* path, const lsn_file_cfg_t& fc, uint32_t sta
     if (start_tti == LSN_TTI_FROM_MIB) {
       bool found = false;
       for (uint64_t i = 0; i < sf_in_file && i < 10 * 64; i += 10) {  // the file starts at subframe 0 of a radio frame (file mode has no sync)
-        if (pread(fd, slot[0].h_raw, sf_bytes, (off_t)(file_off0 + i * sf_bytes)) != (ssize_t)sf_bytes) break;
-        HIP_CHECK(hipMemcpyAsync(slot[0].d_raw, slot[0].h_raw, sf_bytes, hipMemcpyHostToDevice, st));
+        std::vector<uint8_t> one(sf_bytes);
+        if (pread(fd, one.data(), sf_bytes, (off_t)(file_off0 + i * sf_bytes)) != (ssize_t)sf_bytes) break;
+        HIP_CHECK(hipMemcpyAsync(slot[0].d_raw, one.data(), sf_bytes, hipMemcpyHostToDevice, st));
+        HIP_CHECK(hipStreamSynchronize(st));
         lsn_launch_file_unpack(slot[0].d_raw, d_rot, sflen, nant, slot[0].d_iq, 1, st);
         HIP_CHECK(hipStreamSynchronize(st));
         lsn_mib_t mib;
@@ -85,6 +118,7 @@ int Engine::processFile(const char* path, const lsn_file_cfg_t& fc, uint32_t sta
       }
       if (!found) { rc = LSN_ERROR; throw std::runtime_error("no MIB found in the first 64 radio frames of the file"); }
     }
+    if (fdebug) fprintf(stderr, "lsn_file: setup %.1f ms, mmap %d, block %u subframes, %d slots, %u readers\n", tnow() - t_begin, (int)use_mmap, blk, NSLOT, nrd);
     reader = std::thread([&] {
       try {
         (void)hipSetDevice(cfg.device);
@@ -98,30 +132,60 @@ int Engine::processFile(const char* path, const lsn_file_cfg_t& fc, uint32_t sta
             if (abort_reader) return;
           }
           const size_t got = (size_t)std::min<uint64_t>(blk, left);
+          const double tb0 = tnow();
+          if (s.reg) { (void)hipHostUnregister(s.reg); s.reg = nullptr; }  // the block this slot carried last has been committed
           if (got) {
-            // the page-cache copy of one thread tops out near 9 GB/s: split the block over a few pread()ers
             const size_t total = got * sf_bytes, part = (total / nrd + 4095) & ~(size_t)4095;
-            std::vector<std::thread> rd;
-            std::vector<int> bad(nrd, 0);
-            for (uint32_t r = 0; r < nrd; r++) {
-              const size_t b0 = std::min(total, (size_t)r * part), b1 = std::min(total, b0 + part);
-              if (b0 == b1) continue;
-              rd.emplace_back([&, r, b0, b1] {
-                size_t o = b0;
-                while (o < b1) {
-                  const ssize_t k = pread(fd, (char*)s.h_raw + o, b1 - o, (off_t)(file_off0 + pos * sf_bytes + o));
-                  if (k <= 0) { bad[r] = 1; return; }
-                  o += (size_t)k;
-                }
-              });
+            const uint8_t* src = nullptr;
+            if (use_mmap) {
+              // fault the pages of the block in (page-cache hits: a page-table walk per page; otherwise this is the read-ahead), then lock them
+              const uint8_t* b = map + file_off0 + pos * sf_bytes;
+              uint8_t* lo = (uint8_t*)((uintptr_t)b & ~(uintptr_t)(page - 1));
+              const size_t len = (size_t)(b + total - lo);
+              (void)madvise(lo, len, MADV_WILLNEED);
+              std::vector<std::thread> rd;
+              std::vector<unsigned> sink(nrd, 0);
+              for (uint32_t r = 0; r < nrd; r++) {
+                const size_t b0 = std::min(len, (size_t)r * part), b1 = std::min(len, b0 + part);
+                if (b0 == b1) continue;
+                rd.emplace_back([&, r, b0, b1] { unsigned a = 0; for (size_t o = b0; o < b1; o += (size_t)page) a += lo[o]; sink[r] = a; });
+              }
+              for (auto& t : rd) t.join();
+              const double tr0 = tnow();
+              if (hipHostRegister(lo, len, hipHostRegisterDefault) == hipSuccess) { s.reg = lo; src = b; }
+              if (fdebug) fprintf(stderr, "lsn_file: block at %.1f ms: touch %.1f ms, register %.1f ms (%s)\n", tb0 - t_begin, tr0 - tb0, tnow() - tr0, src ? "ok" : "failed");
+              else {  // this mapping cannot be page-locked: copy through pinned buffers from here on
+                (void)hipGetLastError();
+                use_mmap = false;
+              }
             }
-            for (auto& t : rd) t.join();
-            for (int b : bad) if (b) throw std::runtime_error("read failed");
-            pos += got;
+            if (!src) {
+              if (!s.h_raw) { FileBuf& fb = file_buf[&s - slot]; HIP_CHECK(hipHostMalloc((void**)&fb.h_raw, fb.bytes, hipHostMallocDefault)); s.h_raw = fb.h_raw; }
+              // the page-cache copy of one thread tops out near 9 GB/s: split the block over a few pread()ers
+              std::vector<std::thread> rd;
+              std::vector<int> bad(nrd, 0);
+              for (uint32_t r = 0; r < nrd; r++) {
+                const size_t b0 = std::min(total, (size_t)r * part), b1 = std::min(total, b0 + part);
+                if (b0 == b1) continue;
+                rd.emplace_back([&, r, b0, b1] {
+                  size_t o = b0;
+                  while (o < b1) {
+                    const ssize_t k = pread(fd, (char*)s.h_raw + o, b1 - o, (off_t)(file_off0 + pos * sf_bytes + o));
+                    if (k <= 0) { bad[r] = 1; return; }
+                    o += (size_t)k;
+                  }
+                });
+              }
+              for (auto& t : rd) t.join();
+              for (int b : bad) if (b) throw std::runtime_error("read failed");
+              src = (const uint8_t*)s.h_raw;
+              if (fdebug) fprintf(stderr, "lsn_file: block at %.1f ms: pread %.1f ms\n", tb0 - t_begin, tnow() - tb0);
+            }
             // the copy and the de-interleave are only QUEUED here (stream st); the submit below is ordered behind them on the device, so
             // the reader goes straight on to the next block while this one crosses PCIe
-            HIP_CHECK(hipMemcpyAsync(s.d_raw, s.h_raw, got * sf_bytes, hipMemcpyHostToDevice, st));
+            HIP_CHECK(hipMemcpyAsync(s.d_raw, src, got * sf_bytes, hipMemcpyHostToDevice, st));
             lsn_launch_file_unpack(s.d_raw, d_rot, sflen, nant, s.d_iq, (uint32_t)got, st);
+            pos += got;
           }
           left -= got;
           {
@@ -166,6 +230,7 @@ int Engine::processFile(const char* path, const lsn_file_cfg_t& fc, uint32_t sta
       const int w = wait();
       if (rc == LSN_SUCCESS) rc = w;
     }
+    if (fdebug) fprintf(stderr, "lsn_file: %llu subframes done at %.1f ms\n", (unsigned long long)done, tnow() - t_begin);
     if (!rerr.empty()) throw std::runtime_error(rerr);
   } catch (const std::exception& ex) {
     fprintf(stderr, "ltesniffer_amd: %s\n", ex.what());
@@ -178,12 +243,11 @@ int Engine::processFile(const char* path, const lsn_file_cfg_t& fc, uint32_t sta
   fcv.notify_all();
   if (reader.joinable()) reader.join();
   for (auto& s : slot) {
-    if (s.h_raw) (void)hipHostFree(s.h_raw);
-    if (s.d_raw) (void)hipFree(s.d_raw);
-    if (s.d_iq) (void)hipFree(s.d_iq);
+    if (s.reg) (void)hipHostUnregister(s.reg);
   }
   if (d_rot) (void)hipFree(d_rot);
   if (st) (void)hipStreamDestroy(st);
+  if (map) munmap(map, (size_t)sb.st_size);
   close(fd);
   if (subframes_done) *subframes_done = done;
   return rc;

@@ -73,6 +73,7 @@ void Engine::freeDevice()
     df(prach.d_W); df(prach.d_V); df(prach.d_D); df(prach.d_Y); df(prach.d_corr); df(prach.d_out); df(prach.d_off);
     prach = Prach();
     df(mib_d_iq); df(mib_d_llr); df(mib_d_cand);
+    for (auto& fb : file_buf) { if (fb.h_raw) (void)hipHostFree(fb.h_raw); df(fb.d_raw); df(fb.d_iq); fb.h_raw = nullptr; fb.bytes = 0; }
   }
   d_dphi = nullptr; d_iq_staging = nullptr; staging_sf = 0;
   last_chunk = nullptr;

@@ -49,8 +49,11 @@ def test_oracle_reader_deinterleaves_skips_and_rotates(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("scn,nsf,lead,cfo,block", [("small", 50, 0, 0.0, 16), ("small", 45, 777, 2500.0, 7), ("cfg3", 24, 64, -800.0, 10)])
-def test_process_file_matches_oracle_worker(tmp_path, monkeypatch, scn, nsf, lead, cfo, block):
+@pytest.mark.parametrize("scn,nsf,lead,cfo,block,mm", [("small", 50, 0, 0.0, 16, 0), ("small", 45, 777, 2500.0, 7, 0), ("cfg3", 24, 64, -800.0, 10, 0),
+                                                       ("small", 45, 777, 2500.0, 7, 1)])
+def test_process_file_matches_oracle_worker(tmp_path, monkeypatch, scn, nsf, lead, cfo, block, mm):
+    """mm = 0 (default): pread() into pinned buffers; mm = 1: blocks are page-locked in the file mapping and cross PCIe from the page cache"""
+    monkeypatch.setenv("LSN_FILE_MMAP", str(mm))
     import ltesniffer_amd as la
     from parity import gpu_records
     sc = scenario(scn, seed=31)

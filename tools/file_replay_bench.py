@@ -9,17 +9,17 @@ import ltesniffer_amd as la
 from lsn_testlib import scenario
 from parity import gen_subframes
 
-nsf = int(sys.argv[1]) if len(sys.argv) > 1 else 6400
+nsf = int(sys.argv[1]) if len(sys.argv) > 1 else 12800
 gen = int(sys.argv[2]) if len(sys.argv) > 2 else 800
 sc = scenario("cfg3", seed=3)
 tti0, iq, _ = gen_subframes(sc, gen)
-path = "/tmp/lsn_capture.cf32"
+path = "/dev/shm/lsn_capture.cf32" if os.path.isdir("/dev/shm") else "/tmp/lsn_capture.cf32"
 blockdata = np.ascontiguousarray(np.transpose(iq, (0, 2, 1)))
 with open(path, "wb") as f:
     for _ in range(nsf // gen):
         blockdata.tofile(f)
 size = os.path.getsize(path)
-phy = la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=200, pcapwriter=la.PcapWriter(None))
+phy = la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=int(os.environ.get("LSN_BENCH_BATCH", "800")), pcapwriter=la.PcapWriter(None))
 assert phy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"])
 for rep in range(3):
     phy.pcapwriter.reset()
