@@ -142,6 +142,18 @@ def main():
     except Exception:
         pass
 
+    # N ranks share the host: a rank keeps ~3 cores busy with 8 decode threads (host.cores_busy_in_timed_region).  Under a CPU quota smaller
+    # than that (cgroup cpu.max; the 1-GPU boxes of this pool give 16 cores) the CFS throttle stalls whole ranks, so the pipeline is narrowed
+    # instead: fewer decode threads per rank (each costs ~0.3 core, search + front + commit + writer ~0.9).
+    host_quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        host_quota = float(q) / float(per) if q != "max" else float(len(os.sched_getaffinity(0)))
+    except Exception:
+        host_quota = float(len(os.sched_getaffinity(0)))
+    if world > 1 and "LSN_DECODE_THREADS" not in os.environ and host_quota / world < 3.4:
+        os.environ["LSN_DECODE_THREADS"] = str(max(3, min(8, int((host_quota / world - 0.9) / 0.3))))
+
     import ltesniffer_amd as la
     from lsn_testlib import scenario
     from parity import gen_subframes, gpu_records, oracle_records, run_oracle
@@ -419,7 +431,7 @@ def main():
                          "avg_launch_ms": round(kms[kt] / max(1, klaunch[kt]), 4), "launches": int(klaunch[kt]),
                          "algo_bytes_per_launch": int(kbytes / max(1, klaunch[kt])),
                          "dominant_by_time": la.KERNELS[dom], "valu": valu},
-            "legs": legs, "cpu_baseline": cpu, "host": {"cpu_count": os.cpu_count(), "cores_busy_in_timed_region": round(host_cores_busy, 2),
+            "legs": legs, "cpu_baseline": cpu, "host": {"cpu_count": os.cpu_count(), "cpu_quota_cores": host_quota, "decode_threads": int(os.environ.get("LSN_DECODE_THREADS", "8")), "cores_busy_in_timed_region": round(host_cores_busy, 2),
                                              "busiest_threads": busiest},
             "detail": {"pdus_per_subframe": round(p.nof_pdus / sf_rank, 3), "algo_bytes_per_subframe": int(p.algo_bytes / sf_rank),
                        "whole_path_GBps": round(p.algo_bytes * (1 if capture_mode else world) / 1e9 / dt, 2), "timed_region_s": round(dt, 3),
