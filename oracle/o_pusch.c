@@ -307,7 +307,7 @@ int o_pusch_demod_uci(const o_cell_t* cell, const o_ul_cfg_t* ul, uint32_t sf_id
          * (36.212 5.2.2.8: R_mux x 12 matrix written row by row, read column by column) */
         if (c[((size_t)col * (size_t)M + (size_t)r) * (size_t)Qm + (size_t)b]) q = (int16_t)-q;
         const int cell_cls = cls[r * 12 + col];
-        if (cell_cls == 1 || cell_cls == 2) continue;          /* CQI / RI: not part of the UL-SCH stream */
+        if (cell_cls == 1 || cell_cls == 2 || didx[r * 12 + col] < 0) continue; /* CQI / RI (also under a HARQ-ACK symbol that overwrote a CQI cell): not part of the UL-SCH stream */
         e[(size_t)didx[r * 12 + col] * (size_t)Qm + (size_t)b] = cell_cls == 3 ? (int16_t)0 : q; /* HARQ-ACK punctures */
       }
     }

@@ -201,6 +201,29 @@ def test_ul_mode_with_frequency_hopping_grants():
     assert n_ul >= 8
 
 
+def test_ul_mode_baseline_size_64_rnti_400_subframes():
+    """BASELINE configs[3]: 20 MHz, 64 RNTIs, every DCI 0 answered by a PUSCH 4 ms later (MCS 0-28, half of the UEs 64QAM-capable, uplink at
+    22 dB), 400 subframes in chunks of 128 - record stream identical to the oracle's UL_MODE worker"""
+    from lsn_testlib import OracleWorkerUl, gen_ul_mode_subframes, parse_pcap, scenario
+    from parity import gpu_records, oracle_records
+    sc = scenario("cfg2", seed=4, nof_rx=1, n_rnti=64, dl_min=4, dl_max=6, ul_min=2, ul_max=4, mcs_min=0, mcs_max=28, snr_db=28.0, pct_cqi_req=20, rar_period=90)
+    nsf = 400
+    tti0, iq, sent = gen_ul_mode_subframes(sc, nsf, ul_snr_db=22.0)
+    ow = OracleWorkerUl(sc["nof_prb"], sc["nof_ports"], sc["cell_id"], 3, 5)
+    for i in range(nsf):
+        ow.work_ul(iq[i, 0], iq[i, 1], tti0 + i, update_meta=1 if i % 100 == 0 else 0)
+    orecs = parse_pcap(ow.pcap_bytes())
+    phy = la.Phy(nof_rx_antennas=2, sniffer_mode=1, max_batch=128, pcapwriter=la.PcapWriter(None))
+    assert phy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"]) and phy.setUlConfig(3, 5)
+    phy.process_host(iq, tti0, 100)
+    g, o = gpu_records(phy), oracle_records(orecs)
+    assert g == o, "UL_MODE record streams differ: gpu %d vs oracle %d" % (len(g), len(o))
+    st, ost = phy.getStats(), ow.stats()
+    assert st.nof_decoded_locations == ost.nof_decoded_locations and st.nof_subframes == ost.nof_subframes
+    assert len({s_["rnti"] for s_ in sent}) >= 60 and len([r for r in orecs if r["direction"] == 0]) >= 500
+    phy.close()
+
+
 @pytest.mark.parametrize("batch", [16, 64])
 def test_ul_mode_configures_itself_from_sib2(batch):
     """UL_MODE without lsn_phy_set_ul_config: PDSCH_Decoder::decode_SIB on every subframe until the SystemInformation with SIB2 (here in
