@@ -244,13 +244,16 @@ int lsn_phy_process_file(lsn_phy_t* phy, const char* path, const lsn_file_cfg_t*
  * api_mode as ArgManager's -a (ArgManager.cc:63,218): -1 off (default), 0 identity mapping, 2 IMSI catching, 3 all.  For every CRC-ok
  * downlink block the writer thread reports, in record order: paging records (modes 2, 3; decode_imsi_tmsi_paging :84-127: IMSI as 15
  * digits, S-TMSI as 8 hex digits of the m-TMSI, rnti 65534) and the contention resolution identity next to an RRCConnectionSetup
- * (modes 0, 3; :813-877: characters 3..10 of the identity printed in hex).  Blocks that produced an identity are also written to
- * api_pcap (write_dl_paging_api / write_dl_crnti_api, PcapWriter.cc:120-145,177-190) when it is not NULL.
- * Not covered: RRCConnectionReconfiguration / NAS identities (LCID 1) and the uplink parsers (UL_Sniffer_PUSCH.cc:47-247). */
+ * (modes 0, 3; :813-877: characters 3..10 of the identity printed in hex).  In UL_MODE a decoded Msg3 (PUSCH of a RAR grant) reports the
+ * initial UE identity of its RRCConnectionRequest (modes 0, 3; UL_Sniffer_PUSCH.cc:47-93,306-327: m-TMSI in hex, or the last eight hex
+ * digits of the random value - the same characters the connection setup reports).  Blocks that produced an identity are also written
+ * to api_pcap (write_dl_paging_api / write_dl_crnti_api / write_ul_crnti_api, PcapWriter.cc:120-145,177-190) when it is not NULL.
+ * Not covered: RRCConnectionReconfiguration / NAS identities (LCID 1), the uplink DCCH parsers (UE capability, attach request, identity
+ * response: UL_Sniffer_PUSCH.cc:95-247,328-372). */
 typedef struct {
   uint32_t tti; uint16_t rnti;
-  uint32_t id_type;   /* Sniffer_dependency.h:43-45: 1 ID_TMSI, 2 ID_CON_RES, 3 ID_IMSI */
-  uint32_t msg_type;  /* Sniffer_dependency.h:50-55: 1 MSG_CON_SET, 5 MSG_PAGING */
+  uint32_t id_type;   /* Sniffer_dependency.h:42-45: 0 ID_RAN_VAL, 1 ID_TMSI, 2 ID_CON_RES, 3 ID_IMSI */
+  uint32_t msg_type;  /* Sniffer_dependency.h:49-55: 0 MSG_CON_REQ, 1 MSG_CON_SET, 5 MSG_PAGING */
   char value[24];     /* the string print_api_dl receives */
 } lsn_api_event_t;
 typedef void (*lsn_api_sink_t)(void* user, const lsn_api_event_t* ev);

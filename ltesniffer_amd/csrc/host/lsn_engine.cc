@@ -779,7 +779,7 @@ void Engine::emitPdu(Chunk& ch, JobRunner& r, const char* name, size_t payload_o
   else if (name[0] == 'P') { c.rnti = PRNTI; c.rnti_type = 1; }
   else if (name[0] == 'R') { c.rnti = rnti; c.rnti_type = 2; }
   else { c.rnti = rnti; c.rnti_type = 3; }
-  ch.recs.push_back({c, payload_off, len});  // written by the writer thread, in commit order
+  ch.recs.push_back({c, payload_off, len, 0});  // written by the writer thread, in commit order
 }
 
 // a decoded C-RNTI transport block: RRCConnectionSetup -> UE configuration database (commit thread)
@@ -1054,6 +1054,17 @@ void Engine::writerLoop()
               api_sink(api_user, &e);
             }
             if (keep && api_pcap_sink) api_pcap_sink(api_pcap, &rec.ctx, base + rec.off, rec.len);
+          } else if (api_mode >= 0 && rec.ctx.direction == 0 && rec.msg3) {  // decode_run's API part for a decoded Msg3, UL_Sniffer_PUSCH.cc:306-327
+            ApiEvent ev[10];
+            int nev = 0;
+            const bool keep = api_ul_msg3_events(api_mode, base + rec.off, (int)rec.len, rec.ctx.rnti, rec.ctx.tti, ev, 10, &nev);
+            for (int i = 0; i < nev && api_sink; i++) {
+              lsn_api_event_t e{};
+              e.tti = ev[i].tti; e.rnti = ev[i].rnti; e.id_type = ev[i].id_type; e.msg_type = ev[i].msg_type;
+              std::memcpy(e.value, ev[i].value, sizeof(e.value));
+              api_sink(api_user, &e);
+            }
+            if (keep && api_pcap_sink) api_pcap_sink(api_pcap, &rec.ctx, base + rec.off, rec.len);  // write_ul_crnti_api
           }
         }
       } catch (const std::exception& ex) {

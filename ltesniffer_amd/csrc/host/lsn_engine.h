@@ -70,7 +70,7 @@ struct Chunk {
   std::vector<uint32_t> cdci_first;    // [nsf + 1] first CommitDci of each subframe
   std::vector<UeSpecConfig> setup_cfgs;
   std::vector<uint8_t> h_payload;
-  struct PduRec { lsn_pdu_ctx_t ctx; size_t off; uint32_t len; };  // payload at h_payload[off .. off + len)
+  struct PduRec { lsn_pdu_ctx_t ctx; size_t off; uint32_t len; uint8_t msg3 = 0; };  // payload at h_payload[off .. off + len); msg3: uplink block of a RAR grant
   std::vector<PduRec> recs;          // records of this chunk in emission order (commit thread -> writer thread)
   std::string err;                   // first error on this chunk's way through the pipeline
   hipEvent_t ev_a[2 * 8 + 1] = {};  // per stage-A kernel class start/stop + "mirrors on host"

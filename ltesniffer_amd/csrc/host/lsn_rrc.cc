@@ -349,6 +349,80 @@ int paging_decode(const uint8_t* pdu, int len, PagingId* out, int cap)
   return b.err ? -1 : n;
 }
 
+// MAC UL-SCH PDU (TS 36.321 6.1.2, 6.2.1): sub-headers like the downlink; control elements: power headroom (26) 1 byte, C-RNTI (27) 2,
+// truncated / short BSR (28, 29) 1, long BSR (30) 3, padding (31) 0 [srsran::sch_subh::sizeof_ce, uplink branch]
+static int mac_ulsch_parse(const uint8_t* pdu, int len, MacSubheader* out, int cap)
+{
+  if (len <= 0) return 0;
+  int pos = 0, n = 0;
+  bool more = true;
+  while (more && n < cap && pos < len) {
+    const uint8_t b = pdu[pos++];
+    MacSubheader& s = out[n++];
+    s.lcid = b & 0x1Fu;
+    s.is_sdu = s.lcid < 26;
+    s.len = 0;
+    more = (b & 0x20u) != 0;
+    if (s.is_sdu && more) {
+      if (pos >= len) return 0;
+      const uint8_t l = pdu[pos++];
+      s.len = l & 0x7Fu;
+      if (l & 0x80u) {
+        if (pos >= len) return 0;
+        s.len = (s.len << 8) | pdu[pos++];
+      }
+    }
+    if (more && pos >= len) return 0;
+  }
+  if (more && n == cap) return 0;
+  for (int i = 0; i < n; i++) {
+    MacSubheader& s = out[i];
+    if (!s.is_sdu) s.len = s.lcid == 26 ? 1u : s.lcid == 27 ? 2u : (s.lcid == 28 || s.lcid == 29) ? 1u : s.lcid == 30 ? 3u : 0u;
+    s.off = (uint32_t)pos;
+    if (i == n - 1 && s.is_sdu) s.len = (uint32_t)(len - pos);
+    pos += (int)s.len;
+    if (pos > len) return 0;
+  }
+  return n;
+}
+
+bool api_ul_msg3_events(int api_mode, const uint8_t* pdu, int len, uint16_t rnti, uint32_t tti, ApiEvent* ev, int cap, int* nev)
+{
+  int n = 0;
+  if (nev) *nev = 0;
+  if (!(api_mode == 0 || api_mode == 3)) return false;
+  MacSubheader sub[10];
+  const int ns = mac_ulsch_parse(pdu, len, sub, 10);
+  bool ok = true;  // the reference tests the result of the LAST SDU; a PDU without SDU keeps the (successful) result of the PUSCH decode
+  for (int i = 0; i < ns; i++) {
+    if (!sub[i].is_sdu) continue;
+    ok = false;
+    // UL-CCCH-Message: c1 { rrcConnectionReestablishmentRequest | rrcConnectionRequest { rrcConnectionRequest-r8 { ue-Identity CHOICE
+    // { s-TMSI { mmec (8), m-TMSI (32) } | randomValue (40) }, establishmentCause (3), spare (1) } } }
+    BitReader b{pdu + sub[i].off, 8u * sub[i].len};
+    if (b.flag()) continue;                 // messageClassExtension
+    const bool req = b.flag();
+    if (b.flag()) continue;                 // criticalExtensionsFuture
+    if (!req) { b.get(16); b.get(9); b.get(16); b.get(2); b.get(2); continue; }  // reestablishment request: nothing is reported
+    const bool random = b.flag();
+    const uint32_t hi = b.get(8), lo = b.get(32);
+    b.get(3); b.get(1);
+    if (b.err) continue;
+    char v[24] = {0};
+    if (n < cap) {
+      ApiEvent& e = ev[n++];
+      e.tti = tti; e.rnti = rnti; e.msg_type = API_MSG_CON_REQ;
+      if (!random) { e.id_type = API_ID_TMSI; std::snprintf(v, sizeof(v), "%x", lo); }  // m-TMSI in hex without padding (:63-66)
+      else { e.id_type = API_ID_RAN_VAL; std::snprintf(v, sizeof(v), "%08x", lo); }  // ten hex digits, the first two (hi) dropped (:72-81)
+      (void)hi;
+      std::memcpy(e.value, v, sizeof(v));
+    }
+    ok = true;
+  }
+  if (nev) *nev = n;
+  return ok;
+}
+
 bool api_dl_events(int api_mode, char name, const uint8_t* pdu, int len, uint16_t rnti, uint32_t tti, ApiEvent* ev, int cap, int* nev)
 {
   int n = 0;

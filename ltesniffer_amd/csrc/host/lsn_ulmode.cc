@@ -23,7 +23,7 @@ inline bool operator<(const Attempt& a, const Attempt& b) { return std::tie(a.sf
 struct AttemptResult { bool crc = false; bool ran = false; float snr = 0.0f; std::vector<uint8_t> payload; };  // ran: the channel estimate of the attempt was computed
 // downlink records keep the OFFSET of their payload in ch.h_payload: a later on-demand decode of the same loop may grow (reallocate) that
 // arena, so the pointer is only formed when the record is emitted
-struct PendingPdu { bool ul; char name; uint16_t rnti; uint8_t tb; size_t off; std::vector<uint8_t> own; uint32_t len; };
+struct PendingPdu { bool ul; char name; uint16_t rnti; uint8_t tb; size_t off; std::vector<uint8_t> own; uint32_t len; bool msg3 = false; };
 }  // namespace
 
 // PDSCH_Decoder::decode_SIB (DL_Sniffer_PDSCH.cc:459-560): every SI-RNTI grant of the subframe is decoded with the 64QAM table until a
@@ -199,10 +199,11 @@ void Engine::commitChunkUl(Chunk& ch, JobRunner& r)
       else if (mod == 3) add(false, qb, 0);
       else if (mod == 4) { if (ok256) add(true, m.g256.mod, 0); }
       else if (mod == 1) { add(false, 4, 2); add(false, qb, 3); if (ok256) add(true, m.g256.mod, 4); }
-    } else if (mcs <= 20) {
+    } else if (mcs <= 20) {  // decode_run's second rule (UL_Sniffer_PUSCH.cc:300-303): a passing 256QAM-table attempt with MCS > 0 reports 256QAM_MAX
+      const int l256 = mcs > 0 ? 4 : 0;
       if (mod == 2 || mod == 3) add(false, q16, 0);
-      else if (mod == 4) { if (ok256) add(true, m.g256.mod, 0); }
-      else if (mod == 1) { add(false, q16, 0); if (ok256) add(true, m.g256.mod, 0); }
+      else if (mod == 4) { if (ok256) add(true, m.g256.mod, l256); }
+      else if (mod == 1) { add(false, q16, 0); if (ok256) add(true, m.g256.mod, l256); }
     }
     return n;
   };
@@ -295,9 +296,9 @@ void Engine::commitChunkUl(Chunk& ch, JobRunner& r)
         if (ar.ran) last_ul_snr = ar.snr;
         if (!ar.crc) continue;
         crc = true;
-        PendingPdu p{true, 'C', m.rnti, 0, 0, ar.payload, (uint32_t)ar.payload.size()};
+        PendingPdu p{true, 'C', m.rnti, 0, 0, ar.payload, (uint32_t)ar.payload.size(), m.is_rar};
         out[sf].push_back(std::move(p));
-        if (learn[k] && m.g.mcs_idx > 20) {  // decode_run: update_RNTI_ul when the maximum modulation was still unknown
+        if (learn[k]) {  // decode_run: update_RNTI_ul (above MCS 20 when the maximum modulation was still unknown; below, after a 256QAM-table success)
           if (ulmod[m.rnti]) ulmod[m.rnti] = (uint8_t)learn[k];
           else ulTrackAdd(m.rnti);
         }
@@ -316,7 +317,7 @@ void Engine::commitChunkUl(Chunk& ch, JobRunner& r)
           lsn_pdu_ctx_t c{}; c.tti = tti; c.rnti = p.rnti; c.direction = 0; c.rnti_type = 3; c.crc_ok = 1;
           const size_t off = ch.h_payload.size();
           ch.h_payload.insert(ch.h_payload.end(), p.own.begin(), p.own.end());
-          ch.recs.push_back({c, off, p.len});
+          ch.recs.push_back({c, off, p.len, (uint8_t)(p.msg3 ? 1 : 0)});
         }
       } else {
         const char name[2] = {p.name, 0};

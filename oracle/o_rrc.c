@@ -429,3 +429,63 @@ int o_api_dl_events(int api_mode, char name, const uint8_t* pdu, int len, uint16
   if (nev) *nev = n;
   return to_pcap;
 }
+
+/* Uplink side of the identity mapping: a decoded Msg3 (PUSCH of a RAR grant), PUSCH_Decoder::decode_run's API part (UL_Sniffer_PUSCH.cc:306-327)
+ * with decode_rrc_connection_request (:47-93).  MAC UL-SCH walk per TS 36.321 6.1.2 / 6.2.1 [srsran::sch_pdu, uplink], UL-CCCH-Message per
+ * TS 36.331 6.2.2.  Pinned by the five Msg3 blocks of the reference's api_collector.pcap: the value reported equals the characters the matching
+ * connection setup reports for its contention resolution identity.  Returns whether the block goes to the API pcap. */
+static int ul_ce_size(uint32_t lcid) { return lcid == 26 ? 1 : lcid == 27 ? 2 : (lcid == 28 || lcid == 29) ? 1 : lcid == 30 ? 3 : 0; }
+int o_api_ul_msg3_events(int api_mode, const uint8_t* pdu, int len, uint16_t rnti, uint32_t tti, o_api_event_t* ev, int cap, int* nev)
+{
+  int n = 0, ok = 1;
+  if (nev) *nev = 0;
+  if (!(api_mode == 0 || api_mode == 3)) return 0;
+  /* sub-headers */
+  struct { uint32_t lcid, is_sdu, off, len; } sub[10];
+  int ns = 0, pos = 0, more = 1, bad = len <= 0;
+  while (!bad && more && ns < 10 && pos < len) {
+    uint8_t b = pdu[pos++];
+    sub[ns].lcid = b & 0x1Fu; sub[ns].is_sdu = sub[ns].lcid < 26; sub[ns].len = 0;
+    more = (b >> 5) & 1;
+    if (sub[ns].is_sdu && more) {
+      if (pos >= len) { bad = 1; break; }
+      uint8_t l = pdu[pos++];
+      sub[ns].len = l & 0x7Fu;
+      if (l & 0x80u) { if (pos >= len) { bad = 1; break; } sub[ns].len = (sub[ns].len << 8) | pdu[pos++]; }
+    }
+    ns++;
+    if (more && pos >= len) bad = 1;
+  }
+  if (more && ns == 10) bad = 1;
+  for (int i = 0; i < ns && !bad; i++) {
+    if (!sub[i].is_sdu) sub[i].len = (uint32_t)ul_ce_size(sub[i].lcid);
+    sub[i].off = (uint32_t)pos;
+    if (i == ns - 1 && sub[i].is_sdu) sub[i].len = (uint32_t)(len - pos);
+    pos += (int)sub[i].len;
+    if (pos > len) bad = 1;
+  }
+  if (bad) ns = 0;
+  for (int i = 0; i < ns; i++) {
+    if (!sub[i].is_sdu) continue;
+    ok = 0;
+    br_t b = {pdu + sub[i].off, 8u * sub[i].len, 0, 0};
+    if (rd(&b, 1)) continue;
+    int req = (int)rd(&b, 1);
+    if (rd(&b, 1)) continue;
+    if (!req) continue; /* rrcConnectionReestablishmentRequest: "do nothing" */
+    int random = (int)rd(&b, 1);
+    rd(&b, 8);
+    uint32_t lo = rd(&b, 32);
+    rd(&b, 4);
+    if (b.err) continue;
+    if (n < cap) {
+      o_api_event_t* e = &ev[n++];
+      memset(e, 0, sizeof(*e));
+      e->tti = tti; e->rnti = rnti; e->msg_type = 0; e->id_type = random ? 0u : 1u;
+      if (random) snprintf(e->value, sizeof(e->value), "%08x", lo); else snprintf(e->value, sizeof(e->value), "%x", lo);
+    }
+    ok = 1;
+  }
+  if (nev) *nev = n;
+  return ok;
+}

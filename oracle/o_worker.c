@@ -842,11 +842,21 @@ void o_worker_set_ul_mode(o_worker_t* w, const o_ul_cfg_t* ul)
   }
 }
 
-static void write_pcap_ul(o_worker_t* w, const uint8_t* pdu, uint32_t len, uint16_t rnti, uint32_t tti)
+static void write_pcap_ul(o_worker_t* w, const uint8_t* pdu, uint32_t len, uint16_t rnti, uint32_t tti, int is_rar)
 {
   if (!w->pcap) return;
   w->records++;
   o_pcap_write(w->pcap, pdu, len, tti, rnti, 0, O_PCAP_C_RNTI, 1, 0, 0); /* write_ul_crnti, PcapWriter.cc:172-175 */
+  if (w->api_mode >= 0 && is_rar) { /* decode_run's API part, UL_Sniffer_PUSCH.cc:306-327 */
+    o_api_event_t ev[10];
+    int nev = 0;
+    if (o_api_ul_msg3_events(w->api_mode, pdu, (int)len, rnti, tti, ev, 10, &nev) && w->api_pcap)
+      o_pcap_write(w->api_pcap, pdu, len, tti, rnti, 0, O_PCAP_C_RNTI, 1, 0, 0); /* write_ul_crnti_api */
+    for (int i = 0; i < nev; i++) {
+      if (w->api_n == w->api_cap) { w->api_cap = w->api_cap ? 2 * w->api_cap : 64; w->api_ev = (o_api_event_t*)realloc(w->api_ev, sizeof(o_api_event_t) * (size_t)w->api_cap); }
+      w->api_ev[w->api_n++] = ev[i];
+    }
+  }
 }
 
 /* unpack_rar_response_ul_mode, DL_Sniffer_PDSCH.cc:632-671: every sub-header activates its temporary C-RNTI; the UL grant
@@ -953,7 +963,7 @@ static int pusch_attempt(o_worker_t* w, const ulg_t* m, const o_pusch_grant_t* g
   int crc = o_pusch_decode_uci(&w->cfg.cell, &w->ulcfg, tti % 10, m->rnti, &gg, m->n_dmrs, &uci, w->ul_grid, w->cfg.max_turbo_iter, w->payload, &its, &snr);
   w->total_iters += (uint64_t)its;
   if (its > 0) w->last_ul_snr = snr; /* the channel estimate ran (an invalid grant leaves the previous estimate in place) */
-  if (crc) write_pcap_ul(w, w->payload, (uint32_t)(gg.tbs / 8), m->rnti, tti);
+  if (crc) write_pcap_ul(w, w->payload, (uint32_t)(gg.tbs / 8), m->rnti, tti, m->is_rar);
   return crc;
 }
 
@@ -1029,11 +1039,13 @@ static void decode_pusch(o_worker_t* w, uint32_t tti)
         }
       }
     } else if (mcs <= 20) {
+      /* decode_run's second rule (UL_Sniffer_PUSCH.cc:300-303): below MCS 21 decoding_mem.mcs_mod is never set, so a passing
+       * "[PUSCH-256]" attempt with MCS > 0 calls update_RNTI_ul(256QAM_MAX) - whether the entry said 256QAM already or nothing */
       if (mod == 2 || mod == 3) crc = pusch_attempt(w, m, &m->g, qm_base > 4 ? 4 : qm_base, tti);
-      else if (mod == 4) { if (ok256) crc = pusch_attempt(w, m, &m->g256, m->g256.mod, tti); }
+      else if (mod == 4) { if (ok256) { crc = pusch_attempt(w, m, &m->g256, m->g256.mod, tti); if (crc && mcs > 0) ulmod_update(w, m->rnti, 4); } }
       else if (mod == 1) {
         crc = pusch_attempt(w, m, &m->g, qm_base > 4 ? 4 : qm_base, tti);
-        if (!crc && ok256) crc = pusch_attempt(w, m, &m->g256, m->g256.mod, tti);
+        if (!crc && ok256) { crc = pusch_attempt(w, m, &m->g256, m->g256.mod, tti); if (crc && mcs > 0) ulmod_update(w, m->rnti, 4); }
       }
     }
 #undef LEARN

@@ -55,6 +55,8 @@ for name in ("ltesniffer_dl_mode.pcap", "ltesniffer_ul_mode.pcap", "api_collecto
     out[name]["dl_crnti_walks"] = [dict(pdu_head=q["pdu"][:24].hex(), length=len(q["pdu"]), subheaders=walk(q["pdu"])) for q in dl[:60]]
     # BCCH-DL-SCH messages (SI-RNTI records): in UL_MODE the reference writes exactly the SystemInformation it took SIB2 from (decode_SIB)
     out[name]["si_pdus"] = sorted({q["pdu"].hex() for q in full if q["rnti_type"] == 4})
+    # uplink Msg3 blocks (7 bytes: CCCH sub-header + RRCConnectionRequest) the reference's API collected next to the connection setups
+    out[name]["msg3"] = [dict(rnti=q["rnti"], pdu=q["pdu"].hex()) for q in full if q["direction"] == 0 and len(q["pdu"]) == 7 and q["pdu"][0] == 0x00]
     out[name]["conn_setup"] = [dict(rnti=q["rnti"], pdu=q["pdu"].hex()) for q in dl if len(q["pdu"]) > 8 and q["pdu"][0] == 0x3C and (q["pdu"][1] & 31) == 0]
 json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "pcap_records.json"), "w"), indent=0)
 print({k: (v["nof_records"], len(v["records"])) for k, v in out.items()})

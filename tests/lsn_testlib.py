@@ -506,6 +506,23 @@ def oracle_api_events(api_mode, name, pdu, rnti, tti):
     return [(e.tti, e.rnti, e.id_type, e.msg_type, e.value.decode()) for e in ev[:n.value]], bool(keep)
 
 
+def oracle_api_ul_msg3(api_mode, pdu, rnti, tti):
+    o = oracle()
+    o.o_api_ul_msg3_events.argtypes = [C.c_int, C.c_char_p, C.c_int, C.c_uint16, C.c_uint32, C.POINTER(OApiEvent), C.c_int, C.POINTER(C.c_int)]
+    ev, n = (OApiEvent * 10)(), C.c_int(0)
+    keep = o.o_api_ul_msg3_events(api_mode, bytes(pdu), len(pdu), rnti, tti, ev, 10, C.byref(n))
+    return [(e.tti, e.rnti, e.id_type, e.msg_type, e.value.decode()) for e in ev[:n.value]], bool(keep)
+
+
+def host_api_ul_msg3(api_mode, pdu, rnti, tti):
+    h = hosttest()
+    out = np.zeros(10 * 10, np.uint32)
+    r = h.lsnh_api_ul_msg3_events(api_mode, bytes(pdu), len(pdu), rnti, tti, out.ctypes.data_as(C.c_void_p), 10)
+    n = r & 0xFFFF
+    return [(int(out[10 * i]), int(out[10 * i + 1]), int(out[10 * i + 2]), int(out[10 * i + 3]), out[10 * i + 4:10 * i + 10].tobytes().split(b"\0")[0].decode())
+            for i in range(n)], bool(r >> 16)
+
+
 def host_api_events(api_mode, name, pdu, rnti, tti):
     h = hosttest()
     out = np.zeros(10 * 20, np.uint32)
@@ -536,6 +553,24 @@ def ul_mcs_to_mod_tbs(mcs, L, enable_64qam=True):
     if mcs < 21:
         return 4, o.o_tbs_from_idx(mcs - 1, L)
     return (6 if enable_64qam else 4), o.o_tbs_from_idx(mcs - 2, L)
+
+
+def ul_mcs_to_mod_tbs_256(mcs, L):
+    """36.213 Table 8.6.1-3 (uplink MCS table with 256QAM), restated for the synthetic UE: -> (Qm, tbs); (0, 0) where the UE stays silent
+    (MCS 26 needs the 32A TBS row, MCS 29-31 are retransmissions)"""
+    o = oracle()
+    o.o_tbs_from_idx.restype = C.c_int
+    if mcs < 6:
+        return 2, o.o_tbs_from_idx(2 * mcs, L)
+    if mcs < 14:
+        return 4, o.o_tbs_from_idx(mcs + (5 if mcs < 10 else 6), L)
+    if mcs < 23:
+        return 6, o.o_tbs_from_idx(mcs + (6 if mcs < 19 else 7), L)
+    if mcs < 26:
+        return 8, o.o_tbs_from_idx(mcs + 7, L)
+    if mcs in (27, 28):
+        return 8, o.o_tbs_from_idx(mcs + 6, L)
+    return 0, 0
 
 
 def ul_make_subframe(cell, tti, grants, snr_db=30.0, seed=1):
@@ -732,9 +767,9 @@ def encode_paging(records, sys_info_mod=0, etws=0, ext_record=None):
     return bytes(int("".join(map(str, bits[i:i + 8])), 2) for i in range(0, len(bits), 8))
 
 
-def gen_ul_mode_subframes(sc, n, cyclic_shift=3, delta_ss=5, ul_snr_db=30.0, si_msgs=None):  # sc['pusch_hop_offset'] = SIB2 pusch-HoppingOffset of the cell
+def gen_ul_mode_subframes(sc, n, cyclic_shift=3, delta_ss=5, ul_snr_db=30.0, si_msgs=None, ul_256=False):  # sc['pusch_hop_offset'] = SIB2 pusch-HoppingOffset of the cell
     """DL stream from the synthetic eNB (one rx antenna) + the matching UL stream: every DCI 0 of subframe t is answered by a
-    PUSCH in subframe t + 4 (UEs with an even RNTI are 64QAM-capable in the uplink).
+    PUSCH in subframe t + 4 (UEs with an even RNTI are 64QAM-capable in the uplink; with ul_256 every fourth UE uses the 256QAM table).
     -> (tti0, iq[n, 2, sf_len] (antenna 0 = DL, 1 = UL), list of sent UL payload dicts)"""
     assert sc["nof_rx"] == 1
     tx = TxGen(si_msgs=si_msgs, **sc)
@@ -781,7 +816,10 @@ def gen_ul_mode_subframes(sc, n, cyclic_shift=3, delta_ss=5, ul_snr_db=30.0, si_
             sent.append(dict(tti=tti, rnti=g["rnti"], payload=p, L_prb=g["L_prb"], mod=g["mod"], hop=g.get("hop", 0)))
         for p in pdus:
             if p["is_ul"] and p["nof_prb"] != 2:  # 2 PRB: no DMRS table (36.211 Table 5.5.1.2-2), the grant stays unanswered
-                qm, tbs = ul_mcs_to_mod_tbs(p["mcs"], p["nof_prb"], enable_64qam=(p["rnti"] % 2 == 0))
+                if ul_256 and p["rnti"] % 4 == 0:  # every fourth UE is configured with the 256QAM uplink table
+                    qm, tbs = ul_mcs_to_mod_tbs_256(p["mcs"], p["nof_prb"])
+                else:
+                    qm, tbs = ul_mcs_to_mod_tbs(p["mcs"], p["nof_prb"], enable_64qam=(p["rnti"] % 2 == 0))
                 if tbs > 0:
                     # the UE acknowledges the downlink transport blocks it was sent in this subframe on the PUSCH 4 ms later and adds the
                     # aperiodic CSI report (type per its configuration + RI) when the DCI 0 asks for one (36.212 5.2.2.6)

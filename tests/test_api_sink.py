@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from lsn_testlib import (OracleWorker, TxGen, encode_paging, host_api_events, host_paging_decode, oracle_api_events, oracle_paging_decode,
+from lsn_testlib import (OracleWorker, TxGen, encode_paging, host_api_events, host_api_ul_msg3, host_paging_decode, oracle_api_events, oracle_api_ul_msg3, oracle_paging_decode,
                          oracle_worker_api_events, oracle_worker_set_api, parse_pcap, scenario)
 
 FIX = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "pcap_records.json")))
@@ -32,6 +32,31 @@ def test_recorded_connection_setups_report_the_contention_resolution_identity():
     assert FIX["api_collector.pcap"]["pdu_lengths"]["1/3"] == [32]
     # an ordinary downlink block reports nothing
     assert oracle_api_events(3, "C", bytes([0x03]) + bytes(40), 70, 5) == ([], False) == host_api_events(3, "C", bytes([0x03]) + bytes(40), 70, 5)
+
+
+def test_recorded_msg3_blocks_report_the_identity_the_connection_setup_echoes():
+    """identity mapping of -a 0 / 3: the random value of the RRCConnectionRequest (uplink) and the contention resolution identity of the
+    RRCConnectionSetup (downlink) are printed as the same eight hex characters - on the reference's own capture"""
+    msg3 = FIX["api_collector.pcap"]["msg3"]
+    setups = {m["rnti"]: bytes.fromhex(m["pdu"]) for m in FIX["api_collector.pcap"]["conn_setup"]}
+    assert len(msg3) == 5
+    for m in msg3:
+        pdu = bytes.fromhex(m["pdu"])
+        ev, keep = oracle_api_ul_msg3(3, pdu, m["rnti"], 77)
+        assert keep and len(ev) == 1 and ev[0][:4] == (77, m["rnti"], 0, 0)  # ID_RAN_VAL, MSG_CON_REQ
+        dl, _ = oracle_api_events(3, "C", setups[m["rnti"]], m["rnti"], 83)
+        assert ev[0][4] == dl[0][4] == pdu[1:7].hex()[3:11]
+        assert host_api_ul_msg3(3, pdu, m["rnti"], 77) == (ev, keep) == host_api_ul_msg3(0, pdu, m["rnti"], 77)
+        assert oracle_api_ul_msg3(2, pdu, m["rnti"], 77) == ([], False) == host_api_ul_msg3(2, pdu, m["rnti"], 77)
+    # an s-TMSI request reports the m-TMSI; truncated / random input: both walks agree
+    req = bytes([0x00]) + int("0" "1" "0" "0" + "{:08b}".format(0x5A) + "{:032b}".format(0x00C0FFEE) + "011" "0", 2).to_bytes(6, "big")
+    assert oracle_api_ul_msg3(0, req, 9, 1) == ([(1, 9, 1, 0, "c0ffee")], True) == host_api_ul_msg3(0, req, 9, 1)
+    rng = np.random.RandomState(5)
+    for i in range(3000):
+        m = bytes(rng.randint(0, 256, size=int(rng.randint(1, 24))).astype(np.uint8))
+        if i % 2:
+            m = bytes([m[0] & 0x3F]) + m[1:]
+        assert oracle_api_ul_msg3(3, m, 5, 2) == host_api_ul_msg3(3, m, 5, 2)
 
 
 def _records(rng):

@@ -161,11 +161,11 @@ def test_pusch_unsupported_grants_fail_cleanly():
     phy.close()
 
 
-def _run_ul_mode(nsf, seed, batch, hopping_offset=0, **over):
+def _run_ul_mode(nsf, seed, batch, hopping_offset=0, ul_256=False, ul_snr_db=30.0, **over):
     from lsn_testlib import OracleWorkerUl, gen_ul_mode_subframes, parse_pcap, scenario
     from parity import gpu_records, oracle_records
     sc = scenario("cfg2", seed=seed, nof_rx=1, n_rnti=12, dl_min=2, dl_max=3, ul_min=2, ul_max=4, **over)
-    tti0, iq, sent = gen_ul_mode_subframes(sc, nsf)
+    tti0, iq, sent = gen_ul_mode_subframes(sc, nsf, ul_256=ul_256, ul_snr_db=ul_snr_db)
     ow = OracleWorkerUl(sc["nof_prb"], sc["nof_ports"], sc["cell_id"], 3, 5, hopping_offset)
     for i in range(nsf):
         ow.work_ul(iq[i, 0], iq[i, 1], tti0 + i, update_meta=1 if i % 25 == 0 else 0)
@@ -199,6 +199,13 @@ def test_ul_mode_with_frequency_hopping_grants():
     """DCI 0 with the hopping flag: type-1 grants are decoded from both slot positions, like the oracle's UL_MODE worker"""
     n_ul, n_dl = _run_ul_mode(60, seed=15, batch=32, hopping_offset=8, mcs_max=18, pct_hop=50, pusch_hop_offset=8, pct_cqi_req=20)
     assert n_ul >= 8
+
+
+def test_ul_mode_with_256qam_uplink_ues():
+    """every fourth UE transmits with the 256QAM uplink table: the 16QAM- / 64QAM-table attempts fail, the 256QAM-table attempt passes and
+    fixes the UE's maximum modulation - above MCS 20 through decode_run's first rule, below through its second (UL_Sniffer_PUSCH.cc:287-303)"""
+    n_ul, n_dl = _run_ul_mode(160, seed=52, batch=32, ul_256=True, ul_snr_db=32.0, nof_prb=25, mcs_max=28, cfi=3, dl_min=1, dl_max=2, ul_max=3)
+    assert n_ul >= 120
 
 
 def test_ul_mode_baseline_size_64_rnti_400_subframes():

@@ -247,3 +247,26 @@ def test_ul_tracking_database_statistics_and_ageing():
     assert sum(ow.lib.o_worker_tracked_mod_ul(ow.h, r) >= 2 for r in live) >= len(live) - 2   # 16QAM / 64QAM maximum learnt
     ul = [r for r in parse_pcap(ow.pcap_bytes()) if r["direction"] == 0]
     assert len(ul) > 0.7 * len([s for s in sent if (s["tti"] - tti0) % 10240 > 20])
+
+
+def test_ul_mode_worker_learns_256qam_uplink_table():
+    """UEs on the 256QAM uplink table (every fourth RNTI): the worker's 16QAM / 64QAM-table attempts fail, the 256QAM-table attempt passes;
+    the tracking database then holds 256QAM_MAX for them (both rules of decode_run, UL_Sniffer_PUSCH.cc:287-303) and later grants decode at
+    the first attempt"""
+    import ctypes as C
+    from lsn_testlib import OracleWorkerUl, gen_ul_mode_subframes, parse_pcap, scenario
+    sc = scenario("cfg2", seed=52, nof_rx=1, n_rnti=12, dl_min=1, dl_max=2, ul_min=2, ul_max=3, nof_prb=25, mcs_max=28, cfi=3)
+    tti0, iq, sent = gen_ul_mode_subframes(sc, 300, ul_256=True, ul_snr_db=32.0)
+    ow = OracleWorkerUl(sc["nof_prb"], sc["nof_ports"], sc["cell_id"], 3, 5)
+    ow.lib.o_worker_tracked_mod_ul.argtypes = [C.c_void_p, C.c_uint16]
+    its = []
+    for i in range(300):
+        ow.work_ul(iq[i, 0], iq[i, 1], tti0 + i)
+    ul = {(r["sfn"] * 10 + r["sf"], r["rnti"], r["pdu"]) for r in parse_pcap(ow.pcap_bytes()) if r["direction"] == 0}
+    r256 = sorted({s["rnti"] for s in sent if s["rnti"] % 4 == 0})
+    assert len(r256) >= 3 and all(ow.lib.o_worker_tracked_mod_ul(ow.h, r) == 4 for r in r256)
+    assert all(ow.lib.o_worker_tracked_mod_ul(ow.h, r) in (2, 3) for r in {s["rnti"] for s in sent} - set(r256))
+    late = [s for s in sent if s["tti"] >= tti0 + 100 and s["rnti"] % 4 == 0]
+    hit = sum((s["tti"] % 10240, s["rnti"], s["payload"]) in ul for s in late)
+    assert len(late) > 30 and hit >= 0.7 * len(late), (hit, len(late))
+    assert any(s["mod"] == 8 for s in late)
