@@ -164,7 +164,9 @@ def test_pusch_unsupported_grants_fail_cleanly():
 def _run_ul_mode(nsf, seed, batch, hopping_offset=0, ul_256=False, ul_snr_db=30.0, **over):
     from lsn_testlib import OracleWorkerUl, gen_ul_mode_subframes, parse_pcap, scenario
     from parity import gpu_records, oracle_records
-    sc = scenario("cfg2", seed=seed, nof_rx=1, n_rnti=12, dl_min=2, dl_max=3, ul_min=2, ul_max=4, **over)
+    kw = dict(nof_rx=1, n_rnti=12, dl_min=2, dl_max=3, ul_min=2, ul_max=4)
+    kw.update(over)
+    sc = scenario("cfg2", seed=seed, **kw)
     tti0, iq, sent = gen_ul_mode_subframes(sc, nsf, ul_256=ul_256, ul_snr_db=ul_snr_db)
     ow = OracleWorkerUl(sc["nof_prb"], sc["nof_ports"], sc["cell_id"], 3, 5, hopping_offset)
     for i in range(nsf):
