@@ -246,14 +246,17 @@ int lsn_phy_process_file(lsn_phy_t* phy, const char* path, const lsn_file_cfg_t*
  * digits, S-TMSI as 8 hex digits of the m-TMSI, rnti 65534) and the contention resolution identity next to an RRCConnectionSetup
  * (modes 0, 3; :813-877: characters 3..10 of the identity printed in hex).  In UL_MODE a decoded Msg3 (PUSCH of a RAR grant) reports the
  * initial UE identity of its RRCConnectionRequest (modes 0, 3; UL_Sniffer_PUSCH.cc:47-93,306-327: m-TMSI in hex, or the last eight hex
- * digits of the random value - the same characters the connection setup reports).  Blocks that produced an identity are also written
- * to api_pcap (write_dl_paging_api / write_dl_crnti_api / write_ul_crnti_api, PcapWriter.cc:120-145,177-190) when it is not NULL.
- * Not covered: RRCConnectionReconfiguration / NAS identities (LCID 1), the uplink DCCH parsers (UE capability, attach request, identity
- * response: UL_Sniffer_PUSCH.cc:95-247,328-372). */
+ * digits of the random value - the same characters the connection setup reports); every other decoded uplink block is read as SRB
+ * traffic (modes 1-3; :95-247,328-372: MAC / RLC AM / PDCP walk, UL-DCCH head, NAS): UECapabilityInformation (modes 1, 3: id_type
+ * 0xFFFFFFFF, value "-"), attach request and identity response identities (modes 2, 3: IMSI / IMEI / IMEISV digits, m-TMSI of a GUTI).
+ * Blocks that produced an identity are also written to api_pcap (write_dl_paging_api / write_dl_crnti_api / write_ul_crnti_api,
+ * PcapWriter.cc:120-145,177-190) when it is not NULL.
+ * Not covered: RRCConnectionReconfiguration / NAS identities of the downlink (LCID 1, :837-850); the body of a UECapabilityInformation is
+ * not unpacked. */
 typedef struct {
   uint32_t tti; uint16_t rnti;
-  uint32_t id_type;   /* Sniffer_dependency.h:42-45: 0 ID_RAN_VAL, 1 ID_TMSI, 2 ID_CON_RES, 3 ID_IMSI */
-  uint32_t msg_type;  /* Sniffer_dependency.h:49-55: 0 MSG_CON_REQ, 1 MSG_CON_SET, 5 MSG_PAGING */
+  uint32_t id_type;   /* Sniffer_dependency.h:42-47: 0 ID_RAN_VAL, 1 ID_TMSI, 2 ID_CON_RES, 3 ID_IMSI, 4 ID_IMEI, 5 ID_IMEISV, 0xFFFFFFFF none */
+  uint32_t msg_type;  /* Sniffer_dependency.h:49-55: 0 MSG_CON_REQ, 1 MSG_CON_SET, 2 MSG_ATT_REQ, 3 MSG_ID_RES, 4 MSG_UE_CAP, 5 MSG_PAGING */
   char value[24];     /* the string print_api_dl receives */
 } lsn_api_event_t;
 typedef void (*lsn_api_sink_t)(void* user, const lsn_api_event_t* ev);

@@ -1054,10 +1054,12 @@ void Engine::writerLoop()
               api_sink(api_user, &e);
             }
             if (keep && api_pcap_sink) api_pcap_sink(api_pcap, &rec.ctx, base + rec.off, rec.len);
-          } else if (api_mode >= 0 && rec.ctx.direction == 0 && rec.msg3) {  // decode_run's API part for a decoded Msg3, UL_Sniffer_PUSCH.cc:306-327
+          } else if (api_mode >= 0 && rec.ctx.direction == 0) {  // decode_run's API part, UL_Sniffer_PUSCH.cc:306-372: Msg3 of a RAR grant (modes 0, 3), else SRB messages
             ApiEvent ev[10];
             int nev = 0;
-            const bool keep = api_ul_msg3_events(api_mode, base + rec.off, (int)rec.len, rec.ctx.rnti, rec.ctx.tti, ev, 10, &nev);
+            const bool msg3 = rec.msg3 && (api_mode == 0 || api_mode == 3);
+            const bool keep = msg3 ? api_ul_msg3_events(api_mode, base + rec.off, (int)rec.len, rec.ctx.rnti, rec.ctx.tti, ev, 10, &nev)
+                                   : api_ul_dcch_events(api_mode, base + rec.off, (int)rec.len, rec.ctx.rnti, rec.ctx.tti, ev, 10, &nev);
             for (int i = 0; i < nev && api_sink; i++) {
               lsn_api_event_t e{};
               e.tti = ev[i].tti; e.rnti = ev[i].rnti; e.id_type = ev[i].id_type; e.msg_type = ev[i].msg_type;

@@ -11,6 +11,7 @@
 #include "lsn_lte.h"
 #include <cstdio>
 #include <cstring>
+#include <vector>
 
 namespace lsn {
 
@@ -418,6 +419,166 @@ bool api_ul_msg3_events(int api_mode, const uint8_t* pdu, int len, uint16_t rnti
       std::memcpy(e.value, v, sizeof(v));
     }
     ok = true;
+  }
+  if (nev) *nev = n;
+  return ok;
+}
+
+namespace {
+// mobile identity digits (TS 24.008 10.5.1.4 / TS 24.301 9.9.3.12): first digit in the high nibble of the type octet, then low / high nibbles
+int bcd_digits(const uint8_t* v, int len, int ndig, char* out)
+{
+  if (len < 1) return 0;
+  int n = 0;
+  out[n++] = (char)('0' + (v[0] >> 4));
+  for (int i = 1; i < len && n < ndig; i++) {
+    out[n++] = (char)('0' + (v[i] & 0xF));
+    if (n < ndig) out[n++] = (char)('0' + (v[i] >> 4));
+  }
+  out[n] = 0;
+  return n;
+}
+
+// PUSCH_Decoder::decode_nas_ul (UL_Sniffer_PUSCH.cc:146-247) on a dedicatedInfoNAS: identity response and attach request without ciphering
+bool nas_ul_identity(const uint8_t* nas, int len, uint16_t rnti, uint32_t tti, ApiEvent* ev, int cap, int& n)
+{
+  if (len < 2) return false;
+  const uint32_t sec = nas[0] >> 4;
+  if (sec == 2 || sec == 4) return false;       // integrity protected and ciphered: nothing to read
+  const int body = sec == 0 ? 0 : 6;             // security header (1) + MAC (4) + sequence number (1) in front of the plain message
+  if (len < body + 2) return false;
+  const uint32_t msg_type = nas[body + 1];
+  const uint8_t* p = nas + body + 2;
+  int left = len - body - 2;
+  auto add = [&](uint32_t id, uint32_t msg, const char* v) {
+    if (n >= cap) return;
+    ApiEvent& e = ev[n++];
+    e.tti = tti; e.rnti = rnti; e.id_type = id; e.msg_type = msg;
+    std::snprintf(e.value, sizeof(e.value), "%s", v);
+  };
+  char v[24];
+  if (msg_type == 0x56) {                        // identity response: mobile identity LV
+    if (left < 2 || p[0] < 1 || p[0] > left - 1) return false;
+    const uint32_t type = p[1] & 7u;
+    if (type == 1) { bcd_digits(p + 1, p[0], 15, v); add(API_ID_IMSI, API_MSG_ID_RES, v); return true; }
+    if (type == 2) { bcd_digits(p + 1, p[0], 15, v); add(API_ID_IMEI, API_MSG_ID_RES, v); return true; }
+    if (type == 3) { bcd_digits(p + 1, p[0], 16, v); add(API_ID_IMEISV, API_MSG_ID_RES, v); return true; }
+    return false;
+  }
+  if (msg_type == 0x41) {                        // attach request: NAS key set identifier | attach type, EPS mobile identity LV
+    if (left < 3) return false;
+    p += 1; left -= 1;
+    if (p[0] < 1 || p[0] > left - 1) return false;
+    const uint32_t type = p[1] & 7u;
+    if (type == 1) { bcd_digits(p + 1, p[0], 15, v); add(API_ID_IMSI, API_MSG_ATT_REQ, v); return true; }
+    if (type == 6) {
+      if (p[0] < 11) return false;
+      const uint32_t m_tmsi = ((uint32_t)p[8] << 24) | ((uint32_t)p[9] << 16) | ((uint32_t)p[10] << 8) | p[11];
+      std::snprintf(v, sizeof(v), "%x", m_tmsi);
+      add(API_ID_TMSI, API_MSG_ATT_REQ, v);
+      return true;
+    }
+    if (type == 3) { bcd_digits(p + 1, p[0], 15, v); add(API_ID_IMEI, API_MSG_ATT_REQ, v); return true; }
+    return false;
+  }
+  return false;
+}
+
+// UPER OCTET STRING with an unconstrained length: -> pointer / length of the content when it is octet aligned in the buffer, else a copy
+bool octet_string(BitReader& b, std::vector<uint8_t>& out)
+{
+  const uint32_t n = b.length();
+  if (b.err || b.pos + 8u * n > b.nbits) return false;
+  out.resize(n);
+  for (uint32_t i = 0; i < n; i++) out[i] = (uint8_t)b.get(8);
+  return !b.err;
+}
+
+// PUSCH_Decoder::decode_ul_dcch (UL_Sniffer_PUSCH.cc:95-143): UL-DCCH-Message, TS 36.331 6.2.1 / 6.2.2.  The reference unpacks the whole message;
+// here the head is walked as far as the dedicatedInfoNAS (the body of a UECapabilityInformation is not unpacked)
+bool ul_dcch(int api_mode, const uint8_t* rrc, int len, uint16_t rnti, uint32_t tti, ApiEvent* ev, int cap, int& n)
+{
+  BitReader b{rrc, len > 0 ? 8u * (uint32_t)len : 0u};
+  if (b.flag()) return false;                    // messageClassExtension
+  const uint32_t type = b.get(4);
+  if (b.err) return false;
+  if (type == 7 && (api_mode == 1 || api_mode == 3)) {  // ueCapabilityInformation
+    b.get(2);
+    if (b.flag() || b.err) return false;         // criticalExtensions: c1
+    if (n < cap) {
+      ApiEvent& e = ev[n++];
+      e.tti = tti; e.rnti = rnti; e.id_type = API_ID_NONE; e.msg_type = API_MSG_UE_CAP;
+      std::snprintf(e.value, sizeof(e.value), "-");
+    }
+    return true;
+  }
+  std::vector<uint8_t> nas;
+  if (type == 4 && (api_mode == 2 || api_mode == 3)) {  // rrcConnectionSetupComplete
+    b.get(2);                                    // rrc-TransactionIdentifier
+    if (b.flag()) return false;                  // criticalExtensions: c1
+    if (b.get(2) != 0) return false;             // rrcConnectionSetupComplete-r8
+    const bool mme = b.flag();
+    b.flag();                                    // nonCriticalExtension (behind the NAS container)
+    b.integer(1, 6);                             // selectedPLMN-Identity
+    if (mme) {                                   // registeredMME
+      if (b.flag()) {                            // plmn-Identity
+        if (b.flag()) { for (int i = 0; i < 3; i++) b.integer(0, 9); }
+        const uint32_t nd = b.get(1) + 2;
+        for (uint32_t i = 0; i < nd; i++) b.integer(0, 9);
+      }
+      b.get(16); b.get(8);                       // mmegi, mmec
+    }
+    if (!octet_string(b, nas)) return false;
+    return nas_ul_identity(nas.data(), (int)nas.size(), rnti, tti, ev, cap, n);
+  }
+  if (type == 9 && (api_mode == 2 || api_mode == 3)) {  // ulInformationTransfer
+    if (b.flag()) return false;                  // criticalExtensions: c1
+    if (b.get(2) != 0) return false;             // ulInformationTransfer-r8
+    b.flag();                                    // nonCriticalExtension
+    if (b.get(2) != 0) return false;             // dedicatedInfoType: dedicatedInfoNAS
+    if (!octet_string(b, nas)) return false;
+    return nas_ul_identity(nas.data(), (int)nas.size(), rnti, tti, ev, cap, n);
+  }
+  return false;
+}
+}  // namespace
+
+bool api_ul_dcch_events(int api_mode, const uint8_t* pdu, int len, uint16_t rnti, uint32_t tti, ApiEvent* ev, int cap, int* nev)
+{
+  int n = 0;
+  if (nev) *nev = 0;
+  if (api_mode <= 0) return false;
+  MacSubheader sub[10];
+  const int ns = mac_ulsch_parse(pdu, len, sub, 10);
+  bool ok = false;  // api_ret: the verdict of the last SRB SDU that reached decode_ul_dcch
+  for (int i = 0; i < ns; i++) {
+    if (!(sub[i].is_sdu && (sub[i].lcid == 1 || sub[i].lcid == 2))) continue;
+    const uint8_t* p = pdu + sub[i].off;
+    int left = (int)sub[i].len;
+    if (left < 3 || !(p[0] & 0x80u)) continue;   // RLC AM control PDU (rlc_am_is_control_pdu)
+    // rlc_am_read_data_pdu_header [srsRAN lib/src/rlc/rlc_am_lte.cc]: D/C RF P FI(2) E SN(10); only whole, unsegmented SDUs are read
+    const bool rf = p[0] & 0x40u, ext = p[0] & 0x04u;
+    const uint32_t fi = (p[0] >> 3) & 3u;
+    int hdr = 2;
+    if (rf) continue;
+    if (ext) {                                   // E / LI chain, 12 bits per entry, padded to an octet
+      int bitpos = 16;
+      bool more = true;
+      while (more) {
+        if ((bitpos + 12 + 7) / 8 > left) { hdr = -1; break; }
+        more = (p[bitpos >> 3] >> (7 - (bitpos & 7))) & 1u;
+        bitpos += 12;
+      }
+      if (hdr < 0) continue;
+      hdr = (bitpos + 7) / 8;
+    }
+    if (fi != 0 || left < hdr + 2) continue;
+    p += hdr; left -= hdr;
+    // one PDCP header octet is dropped; the reference's NAS security-header test reads that octet (buffer-layout cast, :349-354): its high
+    // nibble must be 0, 1 or 3 - true for every SRB PDCP sequence number
+    const uint32_t nib = p[0] >> 4;
+    if (!(nib == 0 || nib == 1 || nib == 3)) continue;
+    ok = ul_dcch(api_mode, p + 1, left - 1, rnti, tti, ev, cap, n);
   }
   if (nev) *nev = n;
   return ok;

@@ -231,6 +231,7 @@ typedef struct { uint32_t is_imsi, nof_digits; uint8_t digits[24]; uint32_t mmec
 int o_paging_decode(const uint8_t* pdu, int len, o_paging_id_t* out, int cap); /* PCCH-Message -> paging records, -1: does not unpack */
 typedef struct { uint32_t tti; uint16_t rnti; uint32_t id_type /* 1 TMSI, 2 contention resolution, 3 IMSI */, msg_type /* 1 connection setup, 5 paging */; char value[24]; } o_api_event_t;
 int o_api_ul_msg3_events(int api_mode, const uint8_t* pdu, int len, uint16_t rnti, uint32_t tti, o_api_event_t* ev, int cap, int* nev); /* decoded Msg3 -> initial UE identity */
+int o_api_ul_dcch_events(int api_mode, const uint8_t* pdu, int len, uint16_t rnti, uint32_t tti, o_api_event_t* ev, int cap, int* nev); /* SRB messages: UE capability, attach request / identity response */
 int o_api_dl_events(int api_mode, char name, const uint8_t* pdu, int len, uint16_t rnti, uint32_t tti, o_api_event_t* ev, int cap, int* nev);
 
 /* ---------- PSS / SSS cell search (o_sync.c) ---------- */

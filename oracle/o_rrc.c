@@ -489,3 +489,172 @@ int o_api_ul_msg3_events(int api_mode, const uint8_t* pdu, int len, uint16_t rnt
   if (nev) *nev = n;
   return ok;
 }
+
+/* Uplink SRB messages (api_mode 1 / 2 / 3): PUSCH_Decoder::decode_run :328-372 (MAC UL-SCH walk, RLC AM data PDU header [srsRAN rlc_am_lte.cc],
+ * one PDCP octet), decode_ul_dcch :95-143 (UL-DCCH-Message, TS 36.331 6.2.1 / 6.2.2) and decode_nas_ul :146-247 (TS 24.301 8.2.4 attach request,
+ * 8.2.19 identity response; mobile identities TS 24.008 10.5.1.4 / TS 24.301 9.9.3.12).  Pinned by the reference's api_collector.pcap: its five
+ * 333-byte blocks are RRCConnectionSetupComplete + attach request with a GUTI, its five 533-byte blocks UECapabilityInformation - the blocks the
+ * reference's own parsers accepted.  The body of a UECapabilityInformation is not unpacked (the reference unpacks it and would reject a
+ * malformed one).  The "NAS security header" test of :349-354 reads the PDCP octet (buffer-layout cast): high nibble 0, 1 or 3. */
+static int o_bcd(const uint8_t* v, int len, int ndig, char* out)
+{
+  int n = 0;
+  if (len < 1) return 0;
+  out[n++] = (char)('0' + (v[0] >> 4));
+  for (int i = 1; i < len && n < ndig; i++) {
+    out[n++] = (char)('0' + (v[i] & 0xF));
+    if (n < ndig) out[n++] = (char)('0' + (v[i] >> 4));
+  }
+  out[n] = 0;
+  return n;
+}
+static void o_api_add(o_api_event_t* ev, int cap, int* n, uint32_t tti, uint16_t rnti, uint32_t id, uint32_t msg, const char* v)
+{
+  if (*n >= cap) return;
+  o_api_event_t* e = &ev[(*n)++];
+  memset(e, 0, sizeof(*e));
+  e->tti = tti; e->rnti = rnti; e->id_type = id; e->msg_type = msg;
+  snprintf(e->value, sizeof(e->value), "%s", v);
+}
+static int o_nas_ul_identity(const uint8_t* nas, int len, uint16_t rnti, uint32_t tti, o_api_event_t* ev, int cap, int* n)
+{
+  char v[24];
+  if (len < 2) return 0;
+  uint32_t sec = nas[0] >> 4;
+  if (sec == 2 || sec == 4) return 0;
+  int body = sec == 0 ? 0 : 6;
+  if (len < body + 2) return 0;
+  uint32_t msg_type = nas[body + 1];
+  const uint8_t* p = nas + body + 2;
+  int left = len - body - 2;
+  if (msg_type == 0x56) {
+    if (left < 2 || p[0] < 1 || p[0] > left - 1) return 0;
+    uint32_t type = p[1] & 7u;
+    if (type == 1) { o_bcd(p + 1, p[0], 15, v); o_api_add(ev, cap, n, tti, rnti, 3, 3, v); return 1; }
+    if (type == 2) { o_bcd(p + 1, p[0], 15, v); o_api_add(ev, cap, n, tti, rnti, 4, 3, v); return 1; }
+    if (type == 3) { o_bcd(p + 1, p[0], 16, v); o_api_add(ev, cap, n, tti, rnti, 5, 3, v); return 1; }
+    return 0;
+  }
+  if (msg_type == 0x41) {
+    if (left < 3) return 0;
+    p += 1; left -= 1;
+    if (p[0] < 1 || p[0] > left - 1) return 0;
+    uint32_t type = p[1] & 7u;
+    if (type == 1) { o_bcd(p + 1, p[0], 15, v); o_api_add(ev, cap, n, tti, rnti, 3, 2, v); return 1; }
+    if (type == 6) {
+      if (p[0] < 11) return 0;
+      uint32_t m_tmsi = ((uint32_t)p[8] << 24) | ((uint32_t)p[9] << 16) | ((uint32_t)p[10] << 8) | p[11];
+      snprintf(v, sizeof(v), "%x", m_tmsi);
+      o_api_add(ev, cap, n, tti, rnti, 1, 2, v);
+      return 1;
+    }
+    if (type == 3) { o_bcd(p + 1, p[0], 15, v); o_api_add(ev, cap, n, tti, rnti, 4, 2, v); return 1; }
+    return 0;
+  }
+  return 0;
+}
+static int o_octets(br_t* b, uint8_t* out, int cap)
+{
+  uint32_t n = rd_len(b);
+  if (b->err || b->pos + 8u * n > b->nbits || (int)n > cap) return -1;
+  for (uint32_t i = 0; i < n; i++) out[i] = (uint8_t)rd(b, 8);
+  return b->err ? -1 : (int)n;
+}
+static int o_ul_dcch(int api_mode, const uint8_t* rrc, int len, uint16_t rnti, uint32_t tti, o_api_event_t* ev, int cap, int* n)
+{
+  br_t b = {rrc, len > 0 ? 8u * (uint32_t)len : 0u, 0, 0};
+  uint8_t nas[2048];
+  if (rd(&b, 1)) return 0;
+  uint32_t type = rd(&b, 4);
+  if (b.err) return 0;
+  if (type == 7 && (api_mode == 1 || api_mode == 3)) {
+    rd(&b, 2);
+    if (rd(&b, 1) || b.err) return 0;
+    o_api_add(ev, cap, n, tti, rnti, 0xFFFFFFFFu, 4, "-");
+    return 1;
+  }
+  if (type == 4 && (api_mode == 2 || api_mode == 3)) {
+    rd(&b, 2);
+    if (rd(&b, 1)) return 0;
+    if (rd(&b, 2) != 0) return 0;
+    int mme = (int)rd(&b, 1);
+    rd(&b, 1);
+    rd_int(&b, 1, 6);
+    if (mme) {
+      if (rd(&b, 1)) {
+        if (rd(&b, 1)) { rd_int(&b, 0, 9); rd_int(&b, 0, 9); rd_int(&b, 0, 9); }
+        uint32_t nd = rd(&b, 1) + 2;
+        for (uint32_t i = 0; i < nd; i++) rd_int(&b, 0, 9);
+      }
+      rd(&b, 16); rd(&b, 8);
+    }
+    int nn = o_octets(&b, nas, (int)sizeof(nas));
+    if (nn < 0) return 0;
+    return o_nas_ul_identity(nas, nn, rnti, tti, ev, cap, n);
+  }
+  if (type == 9 && (api_mode == 2 || api_mode == 3)) {
+    if (rd(&b, 1)) return 0;
+    if (rd(&b, 2) != 0) return 0;
+    rd(&b, 1);
+    if (rd(&b, 2) != 0) return 0;
+    int nn = o_octets(&b, nas, (int)sizeof(nas));
+    if (nn < 0) return 0;
+    return o_nas_ul_identity(nas, nn, rnti, tti, ev, cap, n);
+  }
+  return 0;
+}
+int o_api_ul_dcch_events(int api_mode, const uint8_t* pdu, int len, uint16_t rnti, uint32_t tti, o_api_event_t* ev, int cap, int* nev)
+{
+  int n = 0, ok = 0;
+  if (nev) *nev = 0;
+  if (api_mode <= 0) return 0;
+  struct { uint32_t lcid, is_sdu, off, len; } sub[10];
+  int ns = 0, pos = 0, more = 1, bad = len <= 0;
+  while (!bad && more && ns < 10 && pos < len) {
+    uint8_t b = pdu[pos++];
+    sub[ns].lcid = b & 0x1Fu; sub[ns].is_sdu = sub[ns].lcid < 26; sub[ns].len = 0;
+    more = (b >> 5) & 1;
+    if (sub[ns].is_sdu && more) {
+      if (pos >= len) { bad = 1; break; }
+      uint8_t l = pdu[pos++];
+      sub[ns].len = l & 0x7Fu;
+      if (l & 0x80u) { if (pos >= len) { bad = 1; break; } sub[ns].len = (sub[ns].len << 8) | pdu[pos++]; }
+    }
+    ns++;
+    if (more && pos >= len) bad = 1;
+  }
+  if (more && ns == 10) bad = 1;
+  for (int i = 0; i < ns && !bad; i++) {
+    if (!sub[i].is_sdu) sub[i].len = (uint32_t)ul_ce_size(sub[i].lcid);
+    sub[i].off = (uint32_t)pos;
+    if (i == ns - 1 && sub[i].is_sdu) sub[i].len = (uint32_t)(len - pos);
+    pos += (int)sub[i].len;
+    if (pos > len) bad = 1;
+  }
+  if (bad) ns = 0;
+  for (int i = 0; i < ns; i++) {
+    if (!(sub[i].is_sdu && (sub[i].lcid == 1 || sub[i].lcid == 2))) continue;
+    const uint8_t* p = pdu + sub[i].off;
+    int left = (int)sub[i].len, hdr = 2;
+    if (left < 3 || !(p[0] & 0x80u)) continue;
+    if (p[0] & 0x40u) continue; /* re-segmentation */
+    uint32_t fi = (p[0] >> 3) & 3u;
+    if (p[0] & 0x04u) {
+      int bitpos = 16, m = 1;
+      while (m) {
+        if ((bitpos + 12 + 7) / 8 > left) { hdr = -1; break; }
+        m = (p[bitpos >> 3] >> (7 - (bitpos & 7))) & 1;
+        bitpos += 12;
+      }
+      if (hdr < 0) continue;
+      hdr = (bitpos + 7) / 8;
+    }
+    if (fi != 0 || left < hdr + 2) continue;
+    p += hdr; left -= hdr;
+    uint32_t nib = p[0] >> 4;
+    if (!(nib == 0 || nib == 1 || nib == 3)) continue;
+    ok = o_ul_dcch(api_mode, p + 1, left - 1, rnti, tti, ev, cap, &n);
+  }
+  if (nev) *nev = n;
+  return ok;
+}

@@ -847,10 +847,11 @@ static void write_pcap_ul(o_worker_t* w, const uint8_t* pdu, uint32_t len, uint1
   if (!w->pcap) return;
   w->records++;
   o_pcap_write(w->pcap, pdu, len, tti, rnti, 0, O_PCAP_C_RNTI, 1, 0, 0); /* write_ul_crnti, PcapWriter.cc:172-175 */
-  if (w->api_mode >= 0 && is_rar) { /* decode_run's API part, UL_Sniffer_PUSCH.cc:306-327 */
+  if (w->api_mode >= 0) { /* decode_run's API part, UL_Sniffer_PUSCH.cc:306-372: Msg3 of a RAR grant (modes 0, 3), else SRB messages (modes 1-3) */
     o_api_event_t ev[10];
     int nev = 0;
-    if (o_api_ul_msg3_events(w->api_mode, pdu, (int)len, rnti, tti, ev, 10, &nev) && w->api_pcap)
+    const int msg3 = is_rar && (w->api_mode == 0 || w->api_mode == 3);
+    if ((msg3 ? o_api_ul_msg3_events(w->api_mode, pdu, (int)len, rnti, tti, ev, 10, &nev) : o_api_ul_dcch_events(w->api_mode, pdu, (int)len, rnti, tti, ev, 10, &nev)) && w->api_pcap)
       o_pcap_write(w->api_pcap, pdu, len, tti, rnti, 0, O_PCAP_C_RNTI, 1, 0, 0); /* write_ul_crnti_api */
     for (int i = 0; i < nev; i++) {
       if (w->api_n == w->api_cap) { w->api_cap = w->api_cap ? 2 * w->api_cap : 64; w->api_ev = (o_api_event_t*)realloc(w->api_ev, sizeof(o_api_event_t) * (size_t)w->api_cap); }

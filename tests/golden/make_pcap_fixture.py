@@ -57,6 +57,9 @@ for name in ("ltesniffer_dl_mode.pcap", "ltesniffer_ul_mode.pcap", "api_collecto
     out[name]["si_pdus"] = sorted({q["pdu"].hex() for q in full if q["rnti_type"] == 4})
     # uplink Msg3 blocks (7 bytes: CCCH sub-header + RRCConnectionRequest) the reference's API collected next to the connection setups
     out[name]["msg3"] = [dict(rnti=q["rnti"], pdu=q["pdu"].hex()) for q in full if q["direction"] == 0 and len(q["pdu"]) == 7 and q["pdu"][0] == 0x00]
+    # the uplink SRB blocks the reference's API parsers accepted (api_collector.pcap only: UE capability information, attach requests)
+    if name == "api_collector.pcap":
+        out[name]["ul_dcch"] = [dict(rnti=q["rnti"], pdu=q["pdu"].hex()) for q in full if q["direction"] == 0 and len(q["pdu"]) > 7]
     out[name]["conn_setup"] = [dict(rnti=q["rnti"], pdu=q["pdu"].hex()) for q in dl if len(q["pdu"]) > 8 and q["pdu"][0] == 0x3C and (q["pdu"][1] & 31) == 0]
 json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "pcap_records.json"), "w"), indent=0)
 print({k: (v["nof_records"], len(v["records"])) for k, v in out.items()})

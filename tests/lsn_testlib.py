@@ -523,6 +523,23 @@ def host_api_ul_msg3(api_mode, pdu, rnti, tti):
             for i in range(n)], bool(r >> 16)
 
 
+def oracle_api_ul_dcch(api_mode, pdu, rnti, tti):
+    o = oracle()
+    o.o_api_ul_dcch_events.argtypes = [C.c_int, C.c_char_p, C.c_int, C.c_uint16, C.c_uint32, C.POINTER(OApiEvent), C.c_int, C.POINTER(C.c_int)]
+    ev, n = (OApiEvent * 10)(), C.c_int(0)
+    keep = o.o_api_ul_dcch_events(api_mode, bytes(pdu), len(pdu), rnti, tti, ev, 10, C.byref(n))
+    return [(e.tti, e.rnti, e.id_type, e.msg_type, e.value.decode()) for e in ev[:n.value]], bool(keep)
+
+
+def host_api_ul_dcch(api_mode, pdu, rnti, tti):
+    h = hosttest()
+    out = np.zeros(10 * 10, np.uint32)
+    r = h.lsnh_api_ul_dcch_events(api_mode, bytes(pdu), len(pdu), rnti, tti, out.ctypes.data_as(C.c_void_p), 10)
+    n = r & 0xFFFF
+    return [(int(out[10 * i]), int(out[10 * i + 1]), int(out[10 * i + 2]), int(out[10 * i + 3]), out[10 * i + 4:10 * i + 10].tobytes().split(b"\0")[0].decode())
+            for i in range(n)], bool(r >> 16)
+
+
 def host_api_events(api_mode, name, pdu, rnti, tti):
     h = hosttest()
     out = np.zeros(10 * 20, np.uint32)

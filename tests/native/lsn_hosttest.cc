@@ -222,6 +222,18 @@ int lsnh_api_dl_events(int api_mode, int name, const uint8_t* pdu, int len, uint
   }
   return nev | (keep ? 1 << 16 : 0);
 }
+int lsnh_api_ul_dcch_events(int api_mode, const uint8_t* pdu, int len, uint16_t rnti, uint32_t tti, uint32_t* out, int cap)
+{
+  ApiEvent ev[10];
+  int nev = 0;
+  const bool keep = api_ul_dcch_events(api_mode, pdu, len, rnti, tti, ev, cap < 10 ? cap : 10, &nev);
+  for (int i = 0; i < nev; i++) {
+    uint32_t* o = out + 10 * i;
+    o[0] = ev[i].tti; o[1] = ev[i].rnti; o[2] = ev[i].id_type; o[3] = ev[i].msg_type;
+    std::memcpy(o + 4, ev[i].value, 24);
+  }
+  return nev | (keep ? 1 << 16 : 0);
+}
 int lsnh_api_ul_msg3_events(int api_mode, const uint8_t* pdu, int len, uint16_t rnti, uint32_t tti, uint32_t* out, int cap)
 {
   ApiEvent ev[10];

@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from lsn_testlib import (OracleWorker, TxGen, encode_paging, host_api_events, host_api_ul_msg3, host_paging_decode, oracle_api_events, oracle_api_ul_msg3, oracle_paging_decode,
+from lsn_testlib import (OracleWorker, TxGen, encode_paging, host_api_events, host_api_ul_dcch, host_api_ul_msg3, host_paging_decode, oracle_api_events, oracle_api_ul_dcch, oracle_api_ul_msg3, oracle_paging_decode,
                          oracle_worker_api_events, oracle_worker_set_api, parse_pcap, scenario)
 
 FIX = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "pcap_records.json")))
@@ -57,6 +57,123 @@ def test_recorded_msg3_blocks_report_the_identity_the_connection_setup_echoes():
         if i % 2:
             m = bytes([m[0] & 0x3F]) + m[1:]
         assert oracle_api_ul_msg3(3, m, 5, 2) == host_api_ul_msg3(3, m, 5, 2)
+
+
+def _bits_to_bytes(bits):
+    while len(bits) % 8:
+        bits.append(0)
+    return bytes(int("".join(map(str, bits[i:i + 8])), 2) for i in range(0, len(bits), 8))
+
+
+def _mobile_id(type_, digits):
+    """TS 24.008 10.5.1.4 / TS 24.301 9.9.3.12 value part for a digit string identity (1 IMSI, 2 / 3 IMEI(SV))"""
+    d = [int(c) for c in digits]
+    odd = len(d) % 2
+    out = [(d[0] << 4) | (odd << 3) | type_]
+    rest = d[1:] + ([15] if not odd else [])
+    out += [rest[i] | (rest[i + 1] << 4) for i in range(0, len(rest), 2)]
+    return bytes(out)
+
+
+def _nas(msg_type, body, protected, rng):
+    plain = bytes([0x07, msg_type]) + body
+    return (bytes([0x17]) + bytes(rng.randint(0, 256, size=4).astype(np.uint8)) + bytes([int(rng.randint(256))]) + plain) if protected else plain
+
+
+def _ul_dcch_block(rrc_bits, nas, rng, sn=None):
+    """MAC UL-SCH PDU: short BSR + one SRB1 SDU (RLC AM data PDU, whole SDU) + padding; rrc_bits = UL-DCCH head up to the NAS container"""
+    bits = list(rrc_bits)
+    n = len(nas)
+    bits += [int(c) for c in ("{:08b}".format(n) if n < 128 else "10" + "{:014b}".format(n))]
+    for b in nas:
+        bits += [int(c) for c in "{:08b}".format(b)]
+    rrc = _bits_to_bytes(bits)
+    sn = int(rng.randint(1024)) if sn is None else sn
+    sdu = bytes([0x80 | (int(rng.randint(2)) << 5) | (sn >> 8), sn & 0xFF]) + bytes([int(rng.randint(32))]) + rrc
+    hdr = bytes([0x3D, 0x21]) + (bytes([len(sdu)]) if len(sdu) < 128 else bytes([0x80 | (len(sdu) >> 8), len(sdu) & 0xFF])) + bytes([0x1F])
+    return hdr + bytes([int(rng.randint(64))]) + sdu + bytes(int(rng.randint(0, 9)))
+
+
+def _setup_complete_head(rng, mme):
+    bits = [0, 0, 1, 0, 0] + [int(rng.randint(2)), int(rng.randint(2))] + [0] + [0, 0] + [mme, 0] + [int(c) for c in "{:03b}".format(int(rng.randint(6)))]
+    if mme:
+        plmn = int(rng.randint(2))
+        bits += [plmn]
+        if plmn:
+            mcc = int(rng.randint(2))
+            bits += [mcc]
+            if mcc:
+                for _ in range(3):
+                    bits += [int(c) for c in "{:04b}".format(int(rng.randint(10)))]
+            nd = int(rng.randint(2, 4))
+            bits += [nd - 2]
+            for _ in range(nd):
+                bits += [int(c) for c in "{:04b}".format(int(rng.randint(10)))]
+        bits += [int(rng.randint(2)) for _ in range(24)]
+    return bits
+
+
+def test_recorded_uplink_srb_blocks_are_what_the_reference_accepted():
+    """api_collector.pcap holds the blocks whose API parse succeeded in the reference: five RRCConnectionSetupComplete + attach request
+    (GUTI, consecutive m-TMSIs of one test network) and five UECapabilityInformation"""
+    blocks = FIX["api_collector.pcap"]["ul_dcch"]
+    assert sorted(len(b["pdu"]) // 2 for b in blocks) == [333] * 5 + [533] * 5
+    tmsi = []
+    for m in blocks:
+        pdu = bytes.fromhex(m["pdu"])
+        ev, keep = oracle_api_ul_dcch(3, pdu, m["rnti"], 9)
+        assert keep and len(ev) == 1 and host_api_ul_dcch(3, pdu, m["rnti"], 9) == (ev, keep)
+        if len(pdu) == 333:
+            assert ev[0][:4] == (9, m["rnti"], 1, 2)                      # ID_TMSI, MSG_ATT_REQ
+            tmsi.append(int(ev[0][4], 16))
+            assert oracle_api_ul_dcch(2, pdu, m["rnti"], 9) == (ev, True) and oracle_api_ul_dcch(1, pdu, m["rnti"], 9) == ([], False)
+        else:
+            assert ev[0] == (9, m["rnti"], 0xFFFFFFFF, 4, "-")             # print_api(..., -1, "-", MSG_UE_CAP)
+            assert oracle_api_ul_dcch(1, pdu, m["rnti"], 9) == (ev, True) and oracle_api_ul_dcch(2, pdu, m["rnti"], 9) == ([], False)
+        assert oracle_api_ul_dcch(0, pdu, m["rnti"], 9) == ([], False) == host_api_ul_dcch(-1, pdu, m["rnti"], 9)
+    assert tmsi == list(range(tmsi[0], tmsi[0] + 5))
+
+
+def test_uplink_identities_round_trip():
+    rng = np.random.RandomState(21)
+    kinds = 0
+    for i in range(400):
+        imsi = "".join(str(int(d)) for d in rng.randint(0, 10, size=15))
+        imei = "".join(str(int(d)) for d in rng.randint(0, 10, size=15))
+        imeisv = "".join(str(int(d)) for d in rng.randint(0, 10, size=16))
+        m_tmsi = int(rng.randint(1, 1 << 32, dtype=np.uint64))
+        guti = bytes([0xF6]) + bytes(rng.randint(0, 256, size=6).astype(np.uint8)) + m_tmsi.to_bytes(4, "big")
+        k = i % 7
+        prot = int(rng.randint(2))
+        if k < 4:  # attach request in an RRCConnectionSetupComplete
+            ident, want = [(_mobile_id(1, imsi), (3, 2, imsi)), (guti, (1, 2, "%x" % m_tmsi)), (_mobile_id(3, imei), (4, 2, imei)),
+                           (bytes([0xF0]) + bytes(4), None)][k]
+            nas = _nas(0x41, bytes([0x71, len(ident)]) + ident + bytes(rng.randint(0, 256, size=int(rng.randint(0, 30))).astype(np.uint8)), prot, rng)
+            head = _setup_complete_head(rng, int(rng.randint(2)))
+        else:      # identity response in an ULInformationTransfer
+            ident, want = [(_mobile_id(1, imsi), (3, 3, imsi)), (_mobile_id(2, imei), (4, 3, imei)), (_mobile_id(3, imeisv), (5, 3, imeisv))][k - 4]
+            nas = _nas(0x56, bytes([len(ident)]) + ident, prot, rng)
+            head = [0, 1, 0, 0, 1] + [0] + [0, 0] + [0] + [0, 0]
+        pdu = _ul_dcch_block(head, nas, rng)
+        ev, keep = oracle_api_ul_dcch(3, pdu, 61, 4)
+        assert (ev, keep) == (([(4, 61, want[0], want[1], want[2])], True) if want else ([], False)), (k, prot, pdu.hex(), ev)
+        assert host_api_ul_dcch(3, pdu, 61, 4) == (ev, keep) == host_api_ul_dcch(2, pdu, 61, 4)
+        assert oracle_api_ul_dcch(1, pdu, 61, 4) == ([], False)
+        kinds |= 1 << k
+        # a ciphered NAS message, an RLC control PDU, a segment (FI != 0) and a re-segment report nothing
+        ciphered = _ul_dcch_block(head, bytes([0x27]) + nas[1:], rng)
+        assert oracle_api_ul_dcch(3, ciphered, 61, 4) == ([], False)
+        for bad in (ciphered, pdu[:5] + bytes([pdu[5] & 0x7F]) + pdu[6:], pdu[:5] + bytes([pdu[5] | 0x08]) + pdu[6:], pdu[:5] + bytes([pdu[5] | 0x40]) + pdu[6:]):
+            assert oracle_api_ul_dcch(3, bad, 61, 4) == host_api_ul_dcch(3, bad, 61, 4)
+        assert oracle_api_ul_dcch(3, pdu[:5] + bytes([pdu[5] & 0x7F]) + pdu[6:], 61, 4) == ([], False)
+        for cut in range(0, len(pdu), 3):
+            assert oracle_api_ul_dcch(3, pdu[:cut], 61, 4) == host_api_ul_dcch(3, pdu[:cut], 61, 4)
+    assert kinds == 127
+    for i in range(3000):
+        m = bytes(rng.randint(0, 256, size=int(rng.randint(1, 60))).astype(np.uint8))
+        if i % 2:
+            m = bytes([0x21, min(len(m), 50), 0x1F, 0x80, 0x00, 0x00]) + m
+        assert oracle_api_ul_dcch(3, m, 5, 2) == host_api_ul_dcch(3, m, 5, 2)
 
 
 def _records(rng):
