@@ -72,7 +72,8 @@ public:
   double get_interval() const { return interval; }
   void set_interval(double seconds) { interval = seconds; if (h) lsn_phy_set_mcs_update_interval(h, (uint32_t)seconds); }
   void update_database_dl() { if (h) lsn_phy_update_mcs_database(h); }
-  void update_database_ul() {}                         // UL tracking is aged inside the UL_MODE commit turn
+  void update_database_ul() { if (h) lsn_phy_update_mcs_database(h); }   // UL_MODE: the uplink database (same call, the mode decides)
+  uint32_t nof_RNTI_member_ul() { return h ? lsn_phy_nof_tracked_rnti(h) : 0; }
   uint32_t nof_RNTI_member_dl() { return h ? lsn_phy_nof_tracked_rnti(h) : 0; }
   lsn_ue_config_t get_ue_config_rnti(uint16_t rnti) { lsn_ue_config_t c{}; if (h) lsn_phy_get_ue_config(h, rnti, &c); return c; }
 private:
@@ -80,7 +81,7 @@ private:
   double interval = 5.0;                               // MCSTracking.h:162
 };
 class HARQ;        // HARQ.h: harq_mode is 0 in the reference (ArgManager.cc:50); accepted and ignored
-class ULSchedule;  // ULSchedule.h: the schedule lives inside the library; SIB2 values arrive through Phy::setUlConfig
+class ULSchedule;  // ULSchedule.h: the schedule lives inside the library; the SIB2 values are learned there (decode_SIB) or given through Phy::setUlConfig
 
 class Phy {
 public:
