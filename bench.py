@@ -329,6 +329,22 @@ def main():
                 os.remove(path)
             lphy.close()
             del host
+            # cold state: a fresh engine (empty RNTI histograms, no MCS-table knowledge, default meta formats) on the resident capture - the
+            # start of a replay, where unknown-table grants are decoded twice and the search walks every format
+            cw0 = la.PcapWriter(None)
+            cw0.set_store(False)
+            cphy = la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=batch, device=local, pcapwriter=cw0)
+            cphy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"])
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            cphy.submit_device(d_iq.data_ptr(), nsf, tti0 % 10240, 500)
+            cphy.wait()
+            dtl = time.perf_counter() - t
+            cp = cphy.perf()
+            legs["cold_state_first_pass"] = {"subframes_per_s": round(nsf / dtl, 1), "subframes": int(nsf), "tb_decodes_per_subframe": round(cp.nof_tb_decodes / nsf, 2),
+                                             "turbo_iterations_per_subframe": round(cp.nof_turbo_iterations / nsf, 1),
+                                             "note": "includes pipeline fill and drain of one %d-subframe block" % nsf}
+            cphy.close()
         except Exception as ex:
             legs["error"] = str(ex)[:300]
 
