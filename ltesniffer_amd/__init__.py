@@ -14,7 +14,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libltesniffer_amd.so")
+LIB_PATH = os.environ.get("LSN_LIB_PATH") or os.path.join(_HERE, "lib", "libltesniffer_amd.so")  # LSN_LIB_PATH: A/B builds of the same library (tools/)
 
 LSN_SUCCESS, LSN_ERROR, LSN_ERROR_INVALID_INPUTS, LSN_ERROR_NO_DEVICE = 0, -1, -2, -3
 TAP_GRID, TAP_CE, TAP_PDCCH_LLR, TAP_CHEST, TAP_CFI, TAP_CANDIDATES, TAP_CCE_POWER, TAP_ACCEPTED, TAP_RB_POWER = range(9)

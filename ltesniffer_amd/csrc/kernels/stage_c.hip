@@ -316,13 +316,20 @@ void lsn_launch_rm(const LsnCbDev* cb, const int16_t* llr, uint32_t* spp, uint32
 // The interleaver addresses of the backward phase are generated by stepping the QPP recursion in reverse.
 // Window-boundary metrics of the previous iteration (next-iteration initialisation) stay in registers and move
 // between lanes with shuffles.
-#ifndef TB_S
-#define TB_S 16      // sub-block length
+// Sub-block length per kernel variant.  Build options kept from a measured experiment (MI355X, bit-identical results, interleaved A/B runs of
+// bench.py): -DTB_S128=8 with TB_WAVES_ATTR = amdgpu_waves_per_eu(2, 2) on k_turbo<128> fits 256 registers (20 spilled) = two waves per SIMD;
+// its own launches get shorter, the k_turbo<64> launches sharing the GPU get longer, the pipeline rate stays within run-to-run noise
+// (136.6 / 138.3 k vs 136.6 / 135.1 k subframes/s) - the instruction mix is dominated by half-rate VALU forms either way.
+#ifndef TB_S64
+#define TB_S64 16
 #endif
+#ifndef TB_S128
+#define TB_S128 16
+#endif
+#define TB_S_OF(NT) ((NT) == 128 ? TB_S128 : TB_S64)
 // check-point store (int16): sub-blocks 1 .. nsb-2, [slot][state][thread]; 64 threads: W <= 96, 128 threads: W <= 64
-#define TB_CKPT_SLOTS(NT) ((((NT) == 64 ? 96 : 64) + TB_S - 1) / TB_S - 2)
+#define TB_CKPT_SLOTS(NT) ((((NT) == 64 ? 96 : 64) + TB_S_OF(NT) - 1) / TB_S_OF(NT) - 2)
 #define TB_CKPT_I16_NT(NT) ((TB_CKPT_SLOTS(NT) < 2 ? 2 : TB_CKPT_SLOTS(NT)) * 7 * (NT) < 1100 ? 1100 : (TB_CKPT_SLOTS(NT) < 2 ? 2 : TB_CKPT_SLOTS(NT)) * 7 * (NT))
-#define TB_CKPT_I16 (4 * 7 * 64)  // (legacy size: TB_S = 16)
                                  // 64 threads: W <= 96 -> 4 slots, 128 threads: W <= 64 -> 2 slots
 
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
@@ -386,6 +393,7 @@ template <bool IL, int NT>
 __device__ __forceinline__ void map_pass(const TurboLds& m, int lane, bool active, int K, int P, int W, uint32_t magicW, int f1, int f2,
                                          int* nii_a, int* nii_b, const int* beta_tail)
 {
+  constexpr int TB_S = TB_S_OF(NT);  // sub-block length of this variant
   const int wl = active ? lane : 0;  // window this lane computes (idle lanes shadow window 0 and never store soft data)
   const int t0 = wl * W;
   const int nsb = (W + TB_S - 1) / TB_S;
@@ -561,7 +569,7 @@ __device__ __forceinline__ uint32_t wg_xor(uint32_t v, int16_t* scratch, int tid
 }
 
 #ifndef TB_WAVES_ATTR
-#define TB_WAVES_ATTR
+#define TB_WAVES_ATTR  // e.g. __attribute__((amdgpu_waves_per_eu(NT == 128 ? 2 : 1, NT == 128 ? 2 : 8))) together with -DTB_S128=8
 #endif
 template <int NT>
 __global__ __launch_bounds__(NT) TB_WAVES_ATTR void k_turbo(const uint32_t* __restrict__ crc_tab_a, const uint32_t* __restrict__ crc_tab_b,
