@@ -171,8 +171,10 @@ __device__ __forceinline__ void ul_demod_llr(int Qm, float I, float Q, float* L)
   }
 }
 
-// one workgroup per (data symbol 0..11, grant): equalised carriers + the IDFT twiddles in LDS, one thread per output
-// sample of the transform de-precoding (direct IDFT, carriers summed in increasing order), LLRs written in UL-SCH order
+// one workgroup per (data symbol 0..11, grant): equalised carriers, a ping-pong buffer and the IDFT twiddles in LDS; transform de-precoding as
+// an autosort (Stockham) decimation-in-frequency IDFT over the radices 4 (while the remaining length divides by 4), 2, 3, 5 - one thread per
+// output of a stage, terms added in index order: the operation order of the oracle's o_idft_mixed (M = 1200: 21 complex MACs per output
+// instead of 1200); LLRs written in UL-SCH order
 __global__ __launch_bounds__(256) void k_pusch_demod(LsnCellDev c, const LsnUlGrantDev* __restrict__ grants, const cf32* __restrict__ grid,
                                                      const cf32* __restrict__ hs_all, const float* __restrict__ stat, int16_t* __restrict__ llr)
 {
@@ -180,8 +182,9 @@ __global__ __launch_bounds__(256) void k_pusch_demod(LsnCellDev c, const LsnUlGr
   const LsnUlGrantDev g = grants[blockIdx.y];
   const int col = blockIdx.x, l = col < 3 ? col : (col < 9 ? col + 1 : col + 2);
   const int M = 12 * (int)g.L_prb, nre = (int)c.nre, Qm = (int)g.qm, tid = threadIdx.x;
-  cf32* x = (cf32*)smem;   // [M]
-  cf32* w = x + M;         // [M] exp(+2 pi j k / M)
+  cf32* xa = (cf32*)smem;  // [M]
+  cf32* xb = xa + M;       // [M]
+  cf32* w = xb + M;        // [M] exp(+2 pi j k / M)
   const cf32* y = grid + ((size_t)g.sf * 14 + l) * nre + 12 * (l >= 7 ? g.n_prb2 : g.n_prb);
   const cf32* h = hs_all + g.hs_off + (l / 7) * M;
   const cf32* wt = c.ul_idft + g.idft_off;
@@ -190,20 +193,33 @@ __global__ __launch_bounds__(256) void k_pusch_demod(LsnCellDev c, const LsnUlGr
     const cf32 hh = h[n], t = cmulconj(y[n], hh);
     const float den = (hh.r * hh.r + hh.i * hh.i) + noise;
     cf32 v; v.r = t.r / den; v.i = t.i / den;
-    x[n] = v;
+    xa[n] = v;
     w[n] = wt[n];
   }
   __syncthreads();
+  cf32 *in = xa, *out = xb;
+  for (int n = M, s = 1; n > 1;) {
+    const int r = (n % 4 == 0) ? 4 : (n % 2 == 0) ? 2 : (n % 3 == 0) ? 3 : 5;
+    const int m = n / r, wr = M / r;
+    for (int o = tid; o < M; o += 256) {
+      const int q = o % s, rest = o / s, t = rest % r, p = rest / r;
+      cf32 acc = cmul(in[q + s * p], w[0]);
+      int wi = 0;
+      for (int i = 1; i < r; i++) {
+        wi += t * wr; wi = wi >= M ? wi - M : wi;            // (i t M / r) mod M
+        const cf32 term = cmul(in[q + s * (p + m * i)], w[wi]);
+        acc.r = acc.r + term.r; acc.i = acc.i + term.i;
+      }
+      out[o] = cmul(acc, w[(int)(((unsigned)p * (unsigned)t * (unsigned)s) % (unsigned)M)]);
+    }
+    __syncthreads();
+    cf32* sw = in; in = out; out = sw;
+    n = m; s *= r;
+  }
   const float scale = g.scale;  // 1 / sqrt(M), from the host
   int16_t* e = llr + g.llr_off;
   for (int r = tid; r < M; r += 256) {
-    float ar = 0.0f, ai = 0.0f;
-    int idx = 0;
-    for (int n = 0; n < M; n++) {
-      const cf32 p = cmul(x[n], w[idx]);
-      ar = ar + p.r; ai = ai + p.i;
-      idx += r; idx = idx >= M ? idx - M : idx;
-    }
+    const float ar = in[r].r, ai = in[r].i;
     // cell (r, col) of the M x 12 channel-interleaver matrix (36.212 5.2.2.8) in closed form: the i-th RI / HARQ-ACK symbol sits
     // in row M - 1 - i / 4, column set[(-i) mod 4]; CQI then data fill the other cells row by row
     int dcell; bool is_ack = false;
@@ -242,7 +258,7 @@ __global__ __launch_bounds__(256) void k_pusch_demod(LsnCellDev c, const LsnUlGr
 void lsn_launch_pusch_demod(const LsnCellDev& c, const LsnUlGrantDev* g, const cf32* grid, const cf32* hs, const float* stat, int16_t* llr,
                             uint32_t ngrants, hipStream_t s)
 {
-  hipLaunchKernelGGL(k_pusch_demod, dim3(12, ngrants), dim3(256), sizeof(cf32) * 2 * 1200, s, c, g, grid, hs, stat, llr);
+  hipLaunchKernelGGL(k_pusch_demod, dim3(12, ngrants), dim3(256), sizeof(cf32) * 3 * 1200, s, c, g, grid, hs, stat, llr);
 }
 
 // ------------------------------------------------------------------------------------------------ PRACH detection

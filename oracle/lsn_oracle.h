@@ -281,6 +281,7 @@ void o_ul_fft(const o_cell_t* cell, const ocf_t* in, ocf_t* grid);
 int o_dmrs_base(uint32_t u, int M_sc, ocf_t* r);
 uint32_t o_dmrs_ncs(const o_cell_t* cell, const o_ul_cfg_t* ul, uint32_t ns, uint32_t n_dmrs_dci);
 void o_idft_table(int M, ocf_t* w);
+void o_idft_mixed(int M, const ocf_t* w, ocf_t* x, ocf_t* tmp); /* in-place (via tmp) mixed-radix IDFT, radices 4, 2, 3, 5; defines the operation order of the product */
 int o_pusch_demod(const o_cell_t* cell, const o_ul_cfg_t* ul, uint32_t sf_idx, uint16_t rnti, const o_pusch_grant_t* g, uint32_t n_dmrs_dci,
                   const ocf_t* grid, int16_t* e, float* noise_out, float* sigpow_out);
 int o_pusch_decode(const o_cell_t* cell, const o_ul_cfg_t* ul, uint32_t sf_idx, uint16_t rnti, const o_pusch_grant_t* g, uint32_t n_dmrs_dci,

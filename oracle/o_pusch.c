@@ -141,6 +141,35 @@ void o_idft_table(int M, ocf_t* w)
   }
 }
 
+/* Transform de-precoding: z[n] = sum_k x[k] exp(+2 pi j n k / M), M = 12 L = 2^a 3^b 5^c, as an autosort (Stockham) decimation-in-frequency
+ * transform.  Radices: 4 while the remaining length divides by 4, then 2, 3, 5.  A stage of radix r on remaining length n (m = n / r, s = M / n):
+ *   y[q + s (r p + t)] = W_n^(p t) * ( ((x_0 W_r^0) + x_1 W_r^t) + ... + x_(r-1) W_r^((r-1) t) ),  x_i = x[q + s (p + m i)],  0 <= p < m, 0 <= q < s, 0 <= t < r
+ * with both twiddles read from the size-M table w (W_n^(p t) = w[(p t s) mod M], W_r^(i t) = w[(i t M / r) mod M]) and the sum taken in the order
+ * written: one complex multiply per term, terms added left to right, one final complex multiply.  This operation order IS the definition the
+ * HIP kernel (k_pusch_demod) reproduces bit for bit.  x is overwritten (ping-pong with tmp); the result is returned in x. */
+void o_idft_mixed(int M, const ocf_t* w, ocf_t* x, ocf_t* tmp)
+{
+  int n = M, s = 1;
+  ocf_t *in = x, *out = tmp;
+  while (n > 1) {
+    int r = (n % 4 == 0) ? 4 : (n % 2 == 0) ? 2 : (n % 3 == 0) ? 3 : 5;
+    int m = n / r;
+    for (int o = 0; o < M; o++) {
+      int q = o % s, rest = o / s, t = rest % r, p = rest / r;
+      ocf_t acc = cmul(in[q + s * p], w[0]);
+      for (int i = 1; i < r; i++) {
+        ocf_t term = cmul(in[q + s * (p + m * i)], w[(int)(((long long)i * t * (M / r)) % M)]);
+        acc.r = acc.r + term.r;
+        acc.i = acc.i + term.i;
+      }
+      out[o] = cmul(acc, w[(int)(((long long)p * t * s) % M)]);
+    }
+    ocf_t* sw = in; in = out; out = sw;
+    n = m; s *= r;
+  }
+  if (in != x) memcpy(x, in, sizeof(ocf_t) * (size_t)M);
+}
+
 /* ---- UCI multiplexed into the PUSCH (36.212 5.2.2.6-5.2.2.8), as far as the data decoder needs it ----
  * What the reference configures (UL_Sniffer_PUSCH.cc:429-450, defaults MCSTracking.cc:1534-1538): HARQ-ACK bits of the
  * downlink grants seen together with the DCI 0 (nof_ack 0/1/2, SubframeWorker.cc:318-336), and for an aperiodic CSI
@@ -214,7 +243,7 @@ int o_uci_layout(int M, int tbs, const o_uci_t* uci, uint8_t* cls, int* didx, in
 }
 
 /* One grant: DMRS channel estimate (LS on symbols 3 and 10, 3-tap frequency smoothing, one estimate per slot), 1-tap
- * MMSE equaliser, transform de-precoding (direct IDFT of size M_sc, summation in increasing carrier order, scale
+ * MMSE equaliser, transform de-precoding (mixed-radix IDFT of size M_sc = 2^a 3^b 5^c, o_idft_mixed, scale
  * 1/sqrt(M_sc)), soft demodulation, descrambling and channel de-interleaving -> e[nof_re * Qm] int16 (UL-SCH order).
  * noise_out / sigpow_out: scalar estimates (mean |ls - smoothed|^2, mean |smoothed|^2). Returns 0 or -1. */
 int o_pusch_demod_uci(const o_cell_t* cell, const o_ul_cfg_t* ul, uint32_t sf_idx, uint16_t rnti, const o_pusch_grant_t* g, uint32_t n_dmrs_dci,
@@ -237,11 +266,12 @@ int o_pusch_demod_uci(const o_cell_t* cell, const o_ul_cfg_t* ul, uint32_t sf_id
   ocf_t* hs = (ocf_t*)malloc(sizeof(ocf_t) * (size_t)(2 * M));
   float* tmp = (float*)malloc(sizeof(float) * (size_t)(2 * M));
   ocf_t* x = (ocf_t*)malloc(sizeof(ocf_t) * (size_t)M);
+  ocf_t* xt = (ocf_t*)malloc(sizeof(ocf_t) * (size_t)M);
   ocf_t* w = (ocf_t*)malloc(sizeof(ocf_t) * (size_t)M);
   uint8_t* c = (uint8_t*)malloc((size_t)(12 * M * Qm));
   uint8_t* cls = (uint8_t*)malloc((size_t)(12 * M));
   int* didx = (int*)malloc(sizeof(int) * (size_t)(12 * M));
-  if (o_uci_layout(M, g->tbs > 0 ? g->tbs : 16, uci, cls, didx, NULL, NULL, NULL) < 0) { free(cls); free(didx); free(c); free(base); free(ls); free(hs); free(tmp); free(x); free(w); return -1; }
+  if (o_uci_layout(M, g->tbs > 0 ? g->tbs : 16, uci, cls, didx, NULL, NULL, NULL) < 0) { free(cls); free(didx); free(c); free(base); free(ls); free(hs); free(tmp); free(x); free(xt); free(w); return -1; }
   uint32_t u = (((cell->id % 30u) + ul->delta_ss) % 30u) % 30u; /* group hopping off: u = f_ss^PUSCH */
   o_dmrs_base(u, M, base);
   o_idft_table(M, w);
@@ -286,16 +316,9 @@ int o_pusch_demod_uci(const o_cell_t* cell, const o_ul_cfg_t* ul, uint32_t sf_id
       x[n].r = t.r / den;
       x[n].i = t.i / den;
     }
-    for (int r = 0; r < M; r++) { /* z[r] = scale * sum_n x[n] exp(+2 pi j n r / M) */
-      float ar = 0.0f, ai = 0.0f;
-      int idx = 0;
-      for (int n = 0; n < M; n++) {
-        ocf_t p = cmul(x[n], w[idx]);
-        ar = ar + p.r;
-        ai = ai + p.i;
-        idx += r;
-        if (idx >= M) idx -= M;
-      }
+    o_idft_mixed(M, w, x, xt); /* z = IDFT_M(x), mixed-radix with the operation order defined above */
+    for (int r = 0; r < M; r++) {
+      const float ar = x[r].r, ai = x[r].i;
       float Lb[8];
       demod_llr(Qm, ar * scale, ai * scale, Lb);
       for (int b = 0; b < Qm; b++) {
@@ -313,7 +336,7 @@ int o_pusch_demod_uci(const o_cell_t* cell, const o_ul_cfg_t* ul, uint32_t sf_id
     }
     col++;
   }
-  free(base); free(ls); free(hs); free(tmp); free(x); free(w); free(c); free(cls); free(didx);
+  free(base); free(ls); free(hs); free(tmp); free(x); free(xt); free(w); free(c); free(cls); free(didx);
   return 0;
 }
 
