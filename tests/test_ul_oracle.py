@@ -270,3 +270,24 @@ def test_ul_mode_worker_learns_256qam_uplink_table():
     hit = sum((s["tti"] % 10240, s["rnti"], s["payload"]) in ul for s in late)
     assert len(late) > 30 and hit >= 0.7 * len(late), (hit, len(late))
     assert any(s["mod"] == 8 for s in late)
+
+
+def test_mixed_radix_idft_matches_numpy_for_every_allocation_size():
+    """o_idft_mixed (the operation order k_pusch_demod reproduces) against numpy's inverse FFT for all 34 valid PUSCH sizes"""
+    import ctypes as C
+    from lsn_testlib import oracle
+    o = oracle()
+    o.o_idft_table.argtypes = [C.c_int, C.c_void_p]
+    o.o_idft_mixed.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    rng = np.random.RandomState(1)
+    sizes = [L for L in range(1, 101) if o.o_ul_valid_prb(L)]
+    assert len(sizes) == 34
+    for L in sizes:
+        M = 12 * L
+        w = np.zeros(M, np.complex64)
+        o.o_idft_table(M, w.ctypes.data)
+        x = (rng.randn(M) + 1j * rng.randn(M)).astype(np.complex64)
+        ref = np.fft.ifft(x.astype(np.complex128)) * M
+        y, t = x.copy(), np.zeros(M, np.complex64)
+        o.o_idft_mixed(M, w.ctypes.data, y.ctypes.data, t.ctypes.data)
+        assert np.abs(y - ref).max() <= 3e-6 * np.abs(ref).max(), L
