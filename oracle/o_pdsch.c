@@ -350,6 +350,16 @@ static inline int ext_scale(int x)
   return x < 0 ? -a : a;
 }
 
+#ifdef O_TURBO_STATS
+/* instrumentation for tools/turbo_metric_ranges.py (a separate build of this file, never the test / bench library): the largest magnitudes the
+ * recursions see, i.e. the word length a fixed-point variant of the kernel would need.  [0] |alpha| (normalised to state 0), [1] |beta| (normalised),
+ * [2] |beta + gamma|, [3] |alpha + beta + gamma|, [4] |gamma| */
+long long o_turbo_stat_max[5];
+#define STAT(i, v) do { long long _a = (v) < 0 ? -(long long)(v) : (long long)(v); if (_a > o_turbo_stat_max[i]) o_turbo_stat_max[i] = _a; } while (0)
+#else
+#define STAT(i, v) do { } while (0)
+#endif
+
 /* one constituent decoder over all windows. idx[t] = position in natural order of trellis step t (identity for
  * DEC1, QPP for DEC2); par[t] in trellis order. a_init/b_init: [P][8] boundary metrics (in: previous iteration,
  * out: this iteration). beta_tail: [8] exact termination metrics for the last window. */
@@ -379,7 +389,8 @@ static void map_decode(int K, int P, const int16_t* sys, const int16_t* par, con
           if (m > nx[Sn]) nx[Sn] = m;
         }
       int32_t n0 = nx[0];
-      for (int S = 0; S < 8; S++) alpha[t + 1][S] = nx[S] - n0;
+      for (int S = 0; S < 8; S++) { alpha[t + 1][S] = nx[S] - n0; STAT(0, alpha[t + 1][S]); }
+      STAT(4, lsa + lp); STAT(4, lsa); STAT(4, lp);
     }
     memcpy(a_new[p], alpha[W], sizeof(int32_t[8]));
     int32_t beta[8], bn[8];
@@ -395,6 +406,7 @@ static void map_decode(int K, int P, const int16_t* sys, const int16_t* par, con
         int32_t g0 = (tr_par[S][0] ? lp : 0), g1 = lsa + (tr_par[S][1] ? lp : 0);
         int32_t b0 = beta[tr_next[S][0]] + g0, b1 = beta[tr_next[S][1]] + g1;
         int32_t v0 = alpha[t][S] + b0, v1 = alpha[t][S] + b1;
+        STAT(2, b0); STAT(2, b1); STAT(3, v0); STAT(3, v1);
         if (v0 > m0) m0 = v0;
         if (v1 > m1) m1 = v1;
         bn[S] = b0 > b1 ? b0 : b1;
@@ -403,7 +415,7 @@ static void map_decode(int K, int P, const int16_t* sys, const int16_t* par, con
       if (llr_out) llr_out[t0 + t] = L;
       ext[pos] = (int16_t)ext_scale(L - lsa);
       int32_t n0 = bn[0];
-      for (int S = 0; S < 8; S++) beta[S] = bn[S] - n0;
+      for (int S = 0; S < 8; S++) { beta[S] = bn[S] - n0; STAT(1, beta[S]); }
     }
     memcpy(b_new[p], beta, sizeof(beta));
   }
