@@ -333,6 +333,15 @@ void lsn_launch_rm(const LsnCbDev* cb, const int16_t* llr, uint32_t* spp, uint32
                                  // 64 threads: W <= 96 -> 4 slots, 128 threads: W <= 64 -> 2 slots
 
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+// EXPERIMENT (-DTB_MAX16, off by default): the per-step normalised recursions (alpha recompute, beta, LLR maxima) compare 16-bit wrapped metrics
+// with the full-rate v_max_i16 instead of the half-rate v_max_i32; needs |alpha + beta + gamma| < 32768, which tools/turbo_metric_ranges.py
+// measures (<= 19 920) but nothing proves yet; beta is normalised every step.  Measured with -DTB_S64=8 -DTB_S128=8 and two waves per SIMD:
+// identical records, 5 % SLOWER - kept for the record, not for use.
+#ifdef TB_MAX16
+__device__ __forceinline__ int imaxb(int a, int b) { int d; asm("v_max_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+#else
+__device__ __forceinline__ int imaxb(int a, int b) { return a > b ? a : b; }
+#endif
 __device__ __forceinline__ int ext_scale(int x)
 {
   int a = x < 0 ? -x : x;
@@ -353,8 +362,8 @@ __device__ __forceinline__ void step_fwd_raw(int* a, int lsa, int lp)
 __device__ __forceinline__ void step_fwd(int* a, int lsa, int lp)
 {
   const int g01 = lp, g10 = lsa, g11 = lsa + lp;
-  int n0 = imax(a[0], a[1] + g11), n1 = imax(a[2] + g10, a[3] + g01), n2 = imax(a[4] + g01, a[5] + g10), n3 = imax(a[6] + g11, a[7]);
-  int n4 = imax(a[0] + g11, a[1]), n5 = imax(a[2] + g01, a[3] + g10), n6 = imax(a[4] + g10, a[5] + g01), n7 = imax(a[6], a[7] + g11);
+  int n0 = imaxb(a[0], a[1] + g11), n1 = imaxb(a[2] + g10, a[3] + g01), n2 = imaxb(a[4] + g01, a[5] + g10), n3 = imaxb(a[6] + g11, a[7]);
+  int n4 = imaxb(a[0] + g11, a[1]), n5 = imaxb(a[2] + g01, a[3] + g10), n6 = imaxb(a[4] + g10, a[5] + g01), n7 = imaxb(a[6], a[7] + g11);
   a[0] = 0; a[1] = n1 - n0; a[2] = n2 - n0; a[3] = n3 - n0; a[4] = n4 - n0; a[5] = n5 - n0; a[6] = n6 - n0; a[7] = n7 - n0;
 }
 
@@ -506,17 +515,27 @@ __device__ __forceinline__ void map_pass(const TurboLds& m, int lane, bool activ
         const int x50 = b[6] + g01, x51 = b[2] + g10;
         const int x60 = b[7], x61 = b[3] + g11;
         const int x70 = b[3], x71 = b[7] + g11;
-        const int m0 = imax(imax(imax(x00, al1 + x10), imax(al2 + x20, al3 + x30)), imax(imax(al4 + x40, al5 + x50), imax(al6 + x60, al7 + x70)));
-        const int m1 = imax(imax(imax(x01, al1 + x11), imax(al2 + x21, al3 + x31)), imax(imax(al4 + x41, al5 + x51), imax(al6 + x61, al7 + x71)));
+        const int m0 = imaxb(imaxb(imaxb(x00, al1 + x10), imaxb(al2 + x20, al3 + x30)), imaxb(imaxb(al4 + x40, al5 + x50), imaxb(al6 + x60, al7 + x70)));
+        const int m1 = imaxb(imaxb(imaxb(x01, al1 + x11), imaxb(al2 + x21, al3 + x31)), imaxb(imaxb(al4 + x41, al5 + x51), imaxb(al6 + x61, al7 + x71)));
+#ifdef TB_MAX16
+        const int L = (int)(short)(m1 - m0);
+#else
         const int L = m1 - m0;
+#endif
         m.ext[ix[u]] = (int16_t)((ext_scale(L - lsa) << 1) | (L > 0 ? 1 : 0));  // idle lanes: spare slot ext[K]
-        b[0] = imax(x00, x01);  // no per-step normalisation (see step_fwd_raw): once per sub-block below
-        b[1] = imax(x10, x11); b[2] = imax(x20, x21); b[3] = imax(x30, x31); b[4] = imax(x40, x41);
-        b[5] = imax(x50, x51); b[6] = imax(x60, x61); b[7] = imax(x70, x71);
+        b[0] = imaxb(x00, x01);  // no per-step normalisation (see step_fwd_raw): once per sub-block below
+        b[1] = imaxb(x10, x11); b[2] = imaxb(x20, x21); b[3] = imaxb(x30, x31); b[4] = imaxb(x40, x41);
+        b[5] = imaxb(x50, x51); b[6] = imaxb(x60, x61); b[7] = imaxb(x70, x71);
+#ifdef TB_MAX16
+#pragma unroll
+        for (int s = 7; s >= 0; s--) b[s] -= b[0];  // every step: keeps alpha + beta + gamma inside 16 bits
+#endif
       }
     }
+#ifndef TB_MAX16
 #pragma unroll
     for (int s = 7; s >= 0; s--) b[s] -= b[0];
+#endif
       };
     if (n == TB_S) subblock(std::true_type{}); else subblock(std::false_type{});
   }
