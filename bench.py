@@ -1,21 +1,28 @@
 #!/usr/bin/env python3
-"""bench.py - subframes/s of the MI355X-native LTESniffer worker on BASELINE.json's metric config.
+"""bench.py - subframes/s of the MI355X-native LTESniffer worker on BASELINE.json's metric config (configs[2] = "cfg3").
 
-A "step" is one pass of the hot path (OFDM -> chest -> PCFICH/PDCCH -> exhaustive Viterbi -> FALCON search -> PDSCH demod ->
-rate de-matching -> turbo -> MAC PDUs into the MAC-LTE pcap writer) over `--reps` replays of a resident capture of `--nsf` synthetic
-subframes (the TTI keeps advancing, the sequential RNTI / MCS-table state carries across replays).  IQ is in HBM before the timed
-region starts.
+The stream (one definition, shared with tools/make_cfg3_golden.py): the cfg3 capture SURVEY.md 8(d) specifies - 20 000 DISTINCT synthetic
+subframes, 150 RNTIs, a fresh RNTI by RAR every 200 subframes (the MCS-tracking database crosses its 250 entries and ages), TM2/3/4 up to
+256QAM - replayed cyclically with the TTI advancing and all sequential state (RNTI histograms, MCS tables, meta formats) carried over; meta
+formats update every 500 subframes.  A "step" is one pass of the hot path (OFDM -> chest -> PCFICH/PDCCH -> exhaustive Viterbi -> FALCON
+search -> PDSCH demod -> rate de-matching -> turbo -> MAC PDUs into the MAC-LTE pcap writer) over the next --step-sf (4000) subframes of
+that stream.  IQ is in HBM before the timed region starts (`value`); the PCIe-inclusive rates - first H2D to last PDU, SURVEY 8(d) - are the
+`first_h2d_to_last_pdu` legs of the same line.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--nsf 6400] [--reps 10] [--config cfg3] [--cpu-sample 1600]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--step-sf 4000] [--batch 800] [--cpu-sample 1600]
+
+Parity gate: `pcap_diff` describes the TIMED stream against the CPU ORACLE.  The oracle walked the first 100 000 subframes of the stream once
+(one thread - its state is a sequential scan; 35 subframes/s) and its records were hashed per block of 200 subframes
+(tests/golden/cfg3_stream_oracle.json, made by tools/make_cfg3_golden.py, keyed by the xxh3 of the capture bytes).  The pcap writer hashes
+the records of the timed steps with the same block structure (lsn_pcap_set_digest_blocks); every block of the timed region must equal the
+oracle's block of the same stream position, record count and digest.  The same check covers the warm-up (cold-state) steps and both passes
+of every PCIe-inclusive leg.  On top, the oracle runs live on the first --cpu-sample subframes (cpu_baseline) and must reproduce the cached
+blocks on this host.
 
 N > 1: `--gpus N` launches N ranks itself (python -m torch.distributed.run, one process per GPU, backend nccl = RCCL) unless it already
 runs under one (RANK / WORLD_SIZE set, which is how the driver starts it).  Every rank replays its own synthetic cell (BASELINE
-configs[4]: cells shard with no data-path exchange) -> weak scaling; value = all ranks' subframes / max-over-ranks time.
-
-Parity gate (rank 0): `pcap_diff` describes the TIMED stream.  (1) the first `--cpu-sample` subframes of the capture from cold state:
-record stream == the CPU oracle's, record by record; (2) the records of the K timed steps (pipelined lsn_phy_submit_device, chunk size
---batch) hash to the same digest as a second Phy that walks the same W + K steps synchronously (lsn_phy_process_device, another chunk
-size) - the stream the oracle comparison anchors."""
+configs[4]: cells shard with no data-path exchange) -> weak scaling; value = all ranks' subframes / max-over-ranks time; rank 0's cell is
+the gated one."""
 import argparse
 import json
 import os
@@ -87,25 +94,40 @@ def _profile_json(key):
         return None, None
 
 
+GOLDEN = os.path.join(ROOT, "tests", "golden", "cfg3_stream_oracle.json")
+
+
+def _pcie_link(local):
+    """negotiated host link of the GPU (sysfs): GT/s x lanes -> GB/s per direction before protocol overhead"""
+    try:
+        pr = torch.cuda.get_device_properties(local)
+        bus = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        sp = open("/sys/bus/pci/devices/%s/current_link_speed" % bus).read().split()[0]
+        wd = int(open("/sys/bus/pci/devices/%s/current_link_width" % bus).read())
+        gts = float(sp)
+        return {"GT_per_s": gts, "lanes": wd, "raw_GB_per_s": round(gts * wd / 8.0 * (128.0 / 130.0), 1),
+                "measured_memcpy_GB_per_s": 57.5, "measured_by": "tools/ubench/h2d_bw.hip, profiles/r03_h2d_bw.txt"}
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--nsf", type=int, default=6400, help="length of the resident capture in subframes (multiple of --gen)")
-    ap.add_argument("--reps", type=int, default=10, help="replays of the resident capture per step (a step = nsf * reps subframes)")
-    ap.add_argument("--gen", type=int, default=1600, help="distinct synthetic subframes generated (multiple of 20); the capture is this block tiled")
+    ap.add_argument("--step-sf", type=int, default=4000, help="subframes per step: a divisor of the capture length and a multiple of 200")
+    ap.add_argument("--nsf", type=int, default=0, help="distinct subframes of the capture (0 = the gated stream's 20 000); other values run ungated")
     ap.add_argument("--config", default="cfg3", help="scenario preset: cfg3 = 20 MHz, 150 RNTIs, TM3/TM4 up to 256QAM")
     ap.add_argument("--batch", type=int, default=800, help="subframes per pipeline chunk inside a submit")
-    ap.add_argument("--cpu-sample", type=int, default=1600, help="subframes of the capture decoded by the CPU oracle from cold state (rank 0): parity gate + cpu_baseline")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the oracle leg (parity gate part 1 and cpu_baseline)")
-    ap.add_argument("--no-check", action="store_true", help="skip the synchronous second pass (parity gate part 2)")
+    ap.add_argument("--cpu-sample", type=int, default=1600, help="subframes the CPU oracle decodes live from cold state (rank 0): cpu_baseline + reproduction of the cached oracle blocks")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the live oracle leg (cpu_baseline)")
     ap.add_argument("--shard", choices=("cells", "capture"), default="cells",
                     help="N > 1: 'cells' = one synthetic cell per rank (weak scaling, the default and what BASELINE configs[4] asks for); 'capture' = ONE capture "
                          "whose chunks go round-robin to the N GPUs (lsn_phy_create_multi on rank 0; the other ranks only hold their GPU) - strong scaling, "
                          "bounded by the sequential FALCON search on one host thread")
-    ap.add_argument("--no-legs", action="store_true", help="skip the PCIe-inclusive legs (host buffers, capture file)")
-    ap.add_argument("--leg-nsf", type=int, default=12800, help="subframes of the capture file / host buffer of the PCIe-inclusive legs")
+    ap.add_argument("--no-legs", action="store_true", help="skip the PCIe-inclusive legs (host buffers, capture file, worker pool) and the other configs")
+    ap.add_argument("--gen-threads", type=int, default=0, help="threads of the synthetic transmitter (0 = the CPUs this process may use, at most 32)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -156,21 +178,57 @@ def main():
 
     import ltesniffer_amd as la
     from lsn_testlib import scenario
-    from parity import gen_subframes, gpu_records, oracle_records, run_oracle
+    from parity import gen_capture, run_oracle
     from ltesniffer_amd import dist as ld
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from make_cfg3_golden import BLOCK, META_PERIOD, NSF, capture_hash
 
-    gen = max(20, (min(args.gen, args.nsf) // 20) * 20)
-    nsf = max(gen, (args.nsf // gen) * gen)
-    reps = max(1, args.reps)
-    batch = min(args.batch or nsf, nsf)
-    sc = scenario(args.config, **ld.rank_workload(args.config, rank))  # one synthetic cell per rank
-    tti0, iq, _ = gen_subframes(sc, gen)
-    # resident capture [nsf][rx][15*N] interleaved cf32 in HBM: the generated block tiled nsf/gen times (its length is a multiple of 20
-    # subframes, so subframe indices and the SIB pattern stay consistent while the TTI keeps advancing)
-    d_iq = torch.from_numpy(iq.view(np.float32)).to(dev).repeat(nsf // gen, 1, 1).contiguous()
+    gated_cfg = args.config == "cfg3" and args.nsf in (0, NSF)
+    nsf = NSF if gated_cfg else max(BLOCK, (args.nsf or NSF) // BLOCK * BLOCK)
+    S = max(BLOCK, min(args.step_sf, nsf) // BLOCK * BLOCK)
+    while nsf % S:
+        S -= BLOCK  # a step never straddles the wrap of the capture
+    batch = min(args.batch or S, S)
+    sc = scenario(args.config, **ld.rank_workload(args.config, rank))  # one synthetic cell per rank; rank 0 = the gated stream
+    gen_threads = args.gen_threads or max(1, min(32, int(host_quota // max(1, world)) if host_quota else 8))
+    t_gen = time.perf_counter()
+    tti0, iq = gen_capture(sc, nsf, threads=gen_threads)
+    t_gen = time.perf_counter() - t_gen
+    sf_bytes = iq[0].nbytes
+    # the resident capture [nsf][rx][15*N] interleaved cf32 in HBM (9.8 GB at 20 MHz / 2 rx / 20 000 subframes), uploaded in slices
+    d_iq = torch.empty((nsf,) + iq.shape[1:] + (2,), dtype=torch.float32, device=dev)
+    for a in range(0, nsf, 2000):
+        d_iq[a:a + 2000].copy_(torch.from_numpy(iq[a:a + 2000].view(np.float32).reshape(-1, iq.shape[1], iq.shape[2], 2)))
     torch.cuda.synchronize()
     stream = torch.cuda.current_stream().cuda_stream
-    sf_per_step = nsf * reps
+
+    golden, golden_note = None, None
+    if rank == 0 and gated_cfg:
+        try:
+            g = json.load(open(GOLDEN))
+            chash, _ = capture_hash(iq)
+            if g["capture_xxh3_64"] != chash:
+                golden_note = "the capture rendered on this host (xxh3 %s) is not the one the cached oracle stream was made from (%s)" % (chash, g["capture_xxh3_64"])
+            elif g["stream"]["block_subframes"] != BLOCK or g["stream"]["tti0"] != tti0 or g["stream"]["meta_period"] != META_PERIOD:
+                golden_note = "cached oracle stream was made with another block / tti0 / meta period"
+            else:
+                golden = g
+        except Exception as ex:
+            golden_note = "no cached oracle stream: %s" % str(ex)[:120]
+
+    def block_check(blocks, first_block):
+        """product blocks [(digest, nrec)] against the oracle's blocks from stream position first_block on -> (covered, mismatching blocks, record diff)"""
+        if golden is None:
+            return 0, None, None
+        ob = golden["blocks"]
+        n = max(0, min(len(blocks), len(ob) - first_block))
+        bad, rd = 0, 0
+        for j in range(n):
+            d, c = blocks[j]
+            if "%016x" % d != ob[first_block + j][0] or c != ob[first_block + j][1]:
+                bad += 1
+                rd += abs(c - ob[first_block + j][1])
+        return n, bad, rd
 
     capture_mode = args.shard == "capture" and (world > 1 or os.environ.get("LSN_BENCH_DEVICES"))
     devices = None
@@ -181,23 +239,28 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
         return
-    pcap = la.PcapWriter(None)  # native MAC-LTE writer, the reference's pcap-emit surface; the timed stream is digested, not kept
+    pcap = la.PcapWriter(None)  # native MAC-LTE writer, the reference's pcap-emit surface; the stream is digested per block, not kept
     pcap.set_store(False)
+    pcap.set_digest_blocks(BLOCK, tti0)
     phy = la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=batch, device=local, pcapwriter=pcap, devices=devices)
     assert phy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"])
+    stride = sf_bytes
 
-    def submit_step(p, i, sync=False):
-        for r in range(reps):
-            t = (tti0 + (i * reps + r) * nsf) % 10240
-            if sync:
-                p.process_device(d_iq.data_ptr(), nsf, t, 500, stream)  # LTESniffer_Core.cc:434: meta-format update every 500 subframes
-            else:
-                p.submit_device(d_iq.data_ptr(), nsf, t, 500, stream)
+    def submit_step(p, i):
+        pos = (i * S) % nsf
+        p.submit_device(d_iq.data_ptr() + pos * stride, S, (tti0 + i * S) % 10240, META_PERIOD, stream)  # LTESniffer_Core.cc:434: meta-format update every 500 subframes
 
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
     for i in range(args.warmup):
         submit_step(phy, i)
     phy.wait()
+    dt_warm = time.perf_counter() - t0
+    pw = phy.perf()
+    warm_blocks = pcap.block_digests()
+    warm_records = pcap.nof_records()
     pcap.reset()
+    pcap.set_digest_blocks(BLOCK, (tti0 + args.warmup * S) % 10240)  # blocks of the timed region count from its first subframe
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -205,8 +268,8 @@ def main():
     ru0 = resource.getrusage(resource.RUSAGE_SELF)
     thr0 = _thread_cpu()
     t0 = time.perf_counter()
-    # the K steps are submitted back to back (lsn_phy_submit_device: a submit returns once its subframes are searched and queued, the
-    # decode / commit tail overlaps the next submit) and completed by one lsn_phy_wait inside the timed region
+    # the K steps are submitted back to back (lsn_phy_submit_device only queues; search / decode / commit / write of a step overlap the
+    # next one's stage A) and completed by one lsn_phy_wait inside the timed region
     for i in range(args.steps):
         submit_step(phy, args.warmup + i)
     phy.wait()
@@ -219,36 +282,65 @@ def main():
     p = phy.perf()
     timed_digest, timed_bytes = pcap.digest()
     timed_records = pcap.nof_records()
+    timed_blocks = pcap.block_digests()
     host_cores_busy = ((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) / dt
     if world > 1 and not capture_mode:
         rdev = dev if dist.get_backend() == "nccl" else None
-        dt, total = ld.reduce_max_sum(dt, args.steps * sf_per_step, rdev)
-        assert total == args.steps * sf_per_step * world
-    total_sf = args.steps * sf_per_step * (1 if capture_mode else world)
+        dt, total = ld.reduce_max_sum(dt, args.steps * S, rdev)
+        assert total == args.steps * S * world
+    total_sf = args.steps * S * (1 if capture_mode else world)
     value = total_sf / dt
     phy.close()
 
-    # ---------------------------------------------------------------- parity gate + CPU baseline (rank 0, outside the timed region)
+    # ---------------------------------------------------------------- parity gate (rank 0): timed blocks == the oracle's blocks
     cpu, parity, pcap_diff = None, None, None
     if rank == 0:
-        parity = {"timed_records": timed_records, "timed_bytes": timed_bytes, "timed_digest": "%016x" % timed_digest}
-        ns = max(20, min(args.cpu_sample, gen))
-        orecs = None
+        parity = {"reference": "CPU oracle (oracle/, scalar C restatement; unpinned against srsRAN soft values, DESIGN.md section 2), cached per 200-subframe block by tools/make_cfg3_golden.py",
+                  "timed_subframes": args.steps * S, "timed_records": timed_records, "timed_bytes": timed_bytes, "timed_digest": "%016x" % timed_digest,
+                  "block_subframes": BLOCK, "golden_note": golden_note}
+        if golden is not None:
+            nb = args.steps * S // BLOCK
+            cov, bad, rd = block_check(timed_blocks[:nb] + [(0, 0)] * max(0, nb - len(timed_blocks)), args.warmup * S // BLOCK)
+            wcov, wbad, _ = block_check(warm_blocks[:args.warmup * S // BLOCK], 0)
+            parity.update({"oracle_subframes": cov * BLOCK, "oracle_blocks_compared": cov, "oracle_blocks_mismatching": bad,
+                           "oracle_stream_subframes_cached": golden["oracle_subframes"], "oracle_source_hash": golden.get("source_hash"),
+                           "oracle_records_in_timed_region": sum(c for _, c in golden["blocks"][args.warmup * S // BLOCK:args.warmup * S // BLOCK + cov]),
+                           "timed_equals_oracle": bool(cov == nb and bad == 0), "warmup_blocks_compared": wcov, "warmup_blocks_mismatching": wbad,
+                           "distinct_subframes_in_timed_region": min(nsf, args.steps * S)})
+            if cov == nb:
+                pcap_diff = int(rd + (bad if rd == 0 else 0))
+        ns = max(BLOCK, min(args.cpu_sample, nsf) // BLOCK * BLOCK)
         if not args.no_cpu:
+            ow_blocks = la.PcapWriter(None)
+            ow_blocks.set_store(False)
+            ow_blocks.set_digest_blocks(BLOCK, tti0)
             t = time.perf_counter()
-            _, _, orecs = run_oracle(sc, tti0, iq[:ns], update_meta_period=500, taps=False)
+            _, _, orecs = run_oracle(sc, tti0, iq[:ns], update_meta_period=META_PERIOD, taps=False)
             dto = time.perf_counter() - t
             cpu = {"value": round(ns / dto, 2), "unit": "subframes/s", "cores": 1, "kind": "port",
                    "sample": "the first %d subframes of the same capture (cold RNTI state), scalar C oracle, 1 thread" % ns}
+            for r in orecs:  # the live oracle's records through the same block hash: the cached stream is reproducible on this host
+                c = r["ctx"]
+                fs = (c[10] << 8) | c[11]
+                ow_blocks.write(dict(tti=(fs >> 4) * 10 + (fs & 15), rnti=(c[4] << 8) | c[5], direction=c[1], rnti_type=c[2], crc_ok=c[13]), r["pdu"])
+            lb = ow_blocks.block_digests()[:ns // BLOCK]
+            if golden is not None:
+                cov, bad, _ = block_check(lb, 0)
+                parity["live_oracle_reproduces_cached_blocks"] = bool(cov == len(lb) and bad == 0)
+            if args.warmup * S >= ns:  # ... and the product's cold-state blocks equal the LIVE oracle's, cache or not
+                parity["warmup_equals_live_oracle_blocks"] = bool(warm_blocks[:len(lb)] == lb)
+                if golden is None and pcap_diff is None:
+                    parity["oracle_subframes"] = ns
+                    parity["note"] = "no cached oracle stream for this capture: only the first %d warm-up subframes are oracle-checked; pcap_diff stays null" % ns
             if world == 1:
                 # the same restatement on many cores: forked workers on independent 200-subframe slices, each with its own (cold) state - an
                 # upper bound for a subframe-parallel CPU run of this code (the sequential RNTI state is not shared), informational only
                 try:
                     import multiprocessing as mp
                     W = max(1, min(16, (os.cpu_count() or 2) // 2))
-                    per = min(200, gen)
+                    per = 200
                     global _CPU_CTX
-                    _CPU_CTX = (sc, tti0, iq, gen, per, run_oracle)
+                    _CPU_CTX = (sc, tti0, iq, nsf, per, run_oracle)
                     with mp.get_context("fork").Pool(W) as pool:
                         t = time.perf_counter()
                         pool.map(_cpu_slice, range(W))
@@ -257,94 +349,69 @@ def main():
                                        "sample": "%d forked workers x %d subframes, independent cold RNTI state each" % (W, per)}
                 except Exception as ex:
                     cpu["parallel"] = {"error": str(ex)[:200]}
-        if not args.no_check:
-            cw = la.PcapWriter(None)
-            chk = la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=96, device=local, pcapwriter=cw)
-            chk.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"])
-            # the walk below is the SAME subframe sequence the timed Phy saw (W + K steps from cold state), cut differently: first the
-            # oracle's sample as a call of its own (records kept and compared one by one), then the rest with only the digest kept
-            chk.process_device(d_iq.data_ptr(), ns, tti0 % 10240, 500, stream)
-            diff_oracle = None
-            if orecs is not None:
-                g, o = gpu_records(chk), oracle_records(orecs)
-                diff_oracle = 0 if g == o else max(1, abs(len(g) - len(o)) + sum(1 for a, b in zip(g, o) if a != b))
-                parity.update({"oracle_subframes": ns, "oracle_records": len(o), "oracle_mismatches": diff_oracle})
-            cw.set_store(False)
-            stride = d_iq[0].numel() * 4
-            first = True
-            for i in range(args.warmup + args.steps):
-                if i == args.warmup:
-                    cw.reset()
-                for r in range(reps):
-                    t = (tti0 + (i * reps + r) * nsf) % 10240
-                    if first:  # the part of the first replay behind the oracle's sample
-                        first = False
-                        if nsf > ns:
-                            chk.process_device(d_iq.data_ptr() + ns * stride, nsf - ns, (t + ns) % 10240, 500, stream)
-                    else:
-                        chk.process_device(d_iq.data_ptr(), nsf, t, 500, stream)
-            if args.warmup == 0:
-                parity["note"] = "warmup 0: the synchronous pass kept the oracle's sample out of its digest; digests are not comparable"
-            sd, sb = cw.digest()
-            same = (sd == timed_digest and sb == timed_bytes and cw.nof_records() == timed_records) if args.warmup > 0 else None
-            parity.update({"sync_records": cw.nof_records(), "sync_digest": "%016x" % sd, "timed_equals_sync": same})
-            chk.close()
-            if diff_oracle is not None and same is not None:
-                pcap_diff = diff_oracle + (0 if same else max(1, abs(cw.nof_records() - timed_records)))
 
-    # ---------------------------------------------------------------- PCIe-inclusive legs ("first H2D -> last PDU on host")
-    # Never `value`: the same capture (a) handed over as host buffers (lsn_phy_process_host: PCIe copies overlapped with the pipeline) and
-    # (b) replayed from a cf32 file in the page cache (lsn_phy_process_file, the reference's file mode, LTESniffer_Core.cc:240-262,365).
+    # ---------------------------------------------------------------- first H2D -> last PDU: the capture starts in HOST memory
+    # Never `value` (bench contract: inputs resident in HBM): the whole 20 000-subframe capture, two consecutive passes of the SAME stream
+    # from a fresh engine - pass 1 from cold state, pass 2 with the tables learnt - each gated block by block on the oracle like the headline:
+    # (a) host buffers (lsn_phy_process_host: PCIe copies overlapped with the pipeline), (b) a cf32 file in the page cache
+    # (lsn_phy_process_file, the reference's file mode, LTESniffer_Core.cc:240-262,365), (c) the reference's own boundary: the worker pool
+    # (getAvail / getBuffers / prepare / putPending / joinPending, LTESniffer_Core.cc:434-451) driven by tools/pool_driver.
     legs = None
     if rank == 0 and world == 1 and not args.no_legs:
-        legs = {}
-        try:
-            ln = max(nsf, (args.leg_nsf // nsf) * nsf)
-            sf_bytes = iq[0].nbytes
-            host = torch.from_numpy(np.tile(iq, (ln // gen, 1, 1))).pin_memory()
+        legs = {"pcie_link": _pcie_link(local)}
+
+        def two_passes(name, make_phy, run_pass, extra=None):
             lp = la.PcapWriter(None)
             lp.set_store(False)
-            lphy = la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=batch, device=local, pcapwriter=lp)
+            lphy = make_phy(lp)
             lphy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"])
-            for name, arr in (("host_pinned", host.numpy()), ("host_pageable", np.array(host.numpy()[:nsf]))):
-                lphy.process_host(arr, tti0 % 10240, 500)  # warm state / first-touch
+            out = {}
+            for k in range(2):
+                lp.reset()
+                lp.set_digest_blocks(BLOCK, (tti0 + k * nsf) % 10240)
                 t = time.perf_counter()
-                lphy.process_host(arr, tti0 % 10240, 500)
+                done = run_pass(lphy, (tti0 + k * nsf) % 10240)
                 dtl = time.perf_counter() - t
-                legs[name] = {"subframes_per_s": round(arr.shape[0] / dtl, 1), "GB_per_s_over_pcie": round(arr.shape[0] * sf_bytes / dtl / 1e9, 2),
-                              "subframes": int(arr.shape[0]), "pcie_gen5_x16_GB_per_s": 63.0}
+                cov, bad, rd = block_check(lp.block_digests()[:done // BLOCK], k * nsf // BLOCK)
+                out["pass%d_%s" % (k + 1, "cold" if k == 0 else "warm")] = {
+                    "subframes_per_s": round(done / dtl, 1), "GB_per_s": round(done * sf_bytes / dtl / 1e9, 2), "x_realtime": round(done / dtl / 1000.0, 1),
+                    "subframes": int(done), "records": lp.nof_records(), "oracle_blocks_compared": cov, "oracle_blocks_mismatching": bad,
+                    "pcap_diff": (int(rd + (bad if rd == 0 else 0)) if cov == done // BLOCK and cov else None)}
+            if extra:
+                out.update(extra)
+            lphy.close()
+            legs[name] = out
+
+        try:
+            host = torch.from_numpy(iq).pin_memory()
+            two_passes("host_pinned", lambda w: la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=batch, device=local, pcapwriter=w),
+                       lambda ph, t: (ph.process_host(host.numpy(), t, META_PERIOD), nsf)[1])
+            two_passes("host_pageable", lambda w: la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=batch, device=local, pcapwriter=w),
+                       lambda ph, t: (ph.process_host(iq, t, META_PERIOD), nsf)[1], {"note": "registered in place (hipHostRegister) for the call"})
+            # the reference's boundary: 1024 workers (1.5 GB pinned slab), chunks of up to 512 subframes; producer = 1 thread like LTESniffer_Core, then 4 copy threads
+            import ctypes as C
+            pd = C.CDLL(os.path.join(ROOT, "tools", "pool_driver", "_build", "libpool_driver.so"))
+            pd.pool_drive.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_double)]
+            for nthr in (1, 4):
+                def drive(ph, t, nthr=nthr):
+                    secs = C.c_double(0)
+                    rc = pd.pool_drive(ph._h, host.numpy().ctypes.data, nsf, sc["nof_rx"], iq.shape[2], t, META_PERIOD, nthr, C.byref(secs))
+                    assert rc == 0, "pool_drive failed: %d" % rc
+                    return nsf
+                two_passes("worker_pool_%d_producer_thread%s" % (nthr, "" if nthr == 1 else "s"),
+                           lambda w: la.Phy(nof_rx_antennas=sc["nof_rx"], nof_workers=1024, max_batch=512, device=local, pcapwriter=w), drive,
+                           {"nof_workers": 1024, "max_batch": 512, "driver": "tools/pool_driver (getAvail -> memcpy into getBuffers -> prepare -> putPending, joinPending)"})
+            del host
             path = "/dev/shm/lsn_bench_capture_%d.cf32" % os.getpid()
-            block = np.ascontiguousarray(np.transpose(iq, (0, 2, 1)))  # file mode: antennas interleaved per sample
-            with open(path, "wb") as f:
-                for _ in range(ln // gen):
-                    block.tofile(f)
+            with open(path, "wb") as f:  # file mode: antennas interleaved per sample
+                for a in range(0, nsf, 1000):
+                    np.ascontiguousarray(np.transpose(iq[a:a + 1000], (0, 2, 1))).tofile(f)
             try:
-                lphy.process_file(path, start_tti=tti0 % 10240, update_meta_period=500)  # warm page cache + state
-                t = time.perf_counter()
-                done = lphy.process_file(path, start_tti=tti0 % 10240, update_meta_period=500)
-                dtl = time.perf_counter() - t
-                legs["file_replay"] = {"subframes_per_s": round(done / dtl, 1), "GB_per_s_from_file": round(done * sf_bytes / dtl / 1e9, 2), "subframes": int(done),
-                                       "x_realtime": round(done / dtl / 1000.0, 1), "storage": "tmpfs (/dev/shm) = page cache; pread threads -> pinned blocks -> PCIe"}
+                two_passes("file_replay", lambda w: la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=batch, device=local, pcapwriter=w),
+                           lambda ph, t: ph.process_file(path, start_tti=t, update_meta_period=META_PERIOD),
+                           {"storage": "tmpfs (/dev/shm) = page cache; pread threads -> pinned blocks -> PCIe"})
             finally:
                 os.remove(path)
-            lphy.close()
-            del host
-            # cold state: a fresh engine (empty RNTI histograms, no MCS-table knowledge, default meta formats) on the resident capture - the
-            # start of a replay, where unknown-table grants are decoded twice and the search walks every format
-            cw0 = la.PcapWriter(None)
-            cw0.set_store(False)
-            cphy = la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=batch, device=local, pcapwriter=cw0)
-            cphy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"])
-            torch.cuda.synchronize()
-            t = time.perf_counter()
-            cphy.submit_device(d_iq.data_ptr(), nsf, tti0 % 10240, 500)
-            cphy.wait()
-            dtl = time.perf_counter() - t
-            cp = cphy.perf()
-            legs["cold_state_first_pass"] = {"subframes_per_s": round(nsf / dtl, 1), "subframes": int(nsf), "tb_decodes_per_subframe": round(cp.nof_tb_decodes / nsf, 2),
-                                             "turbo_iterations_per_subframe": round(cp.nof_turbo_iterations / nsf, 1),
-                                             "note": "includes pipeline fill and drain of one %d-subframe block" % nsf}
-            cphy.close()
         except Exception as ex:
             legs["error"] = str(ex)[:300]
 
@@ -354,8 +421,8 @@ def main():
     if legs is not None and "error" not in legs:
         try:
             sc2 = scenario("cfg2", seed=2)
-            t2, iq2, _ = gen_subframes(sc2, 400)
-            d2 = torch.from_numpy(iq2.view(np.float32)).to(dev).repeat(8, 1, 1).contiguous()
+            t2, iq2 = gen_capture(sc2, 3200, threads=gen_threads)
+            d2 = torch.from_numpy(iq2.view(np.float32)).to(dev)
             w2 = la.PcapWriter(None)
             w2.set_store(False)
             p2 = la.Phy(nof_rx_antennas=sc2["nof_rx"], max_batch=batch, device=local, pcapwriter=w2)
@@ -367,7 +434,7 @@ def main():
                 p2.submit_device(d2.data_ptr(), n2, (t2 + (r + 1) * n2) % 10240, 500, stream)
             p2.wait()
             dtl = time.perf_counter() - t
-            legs["cfg2_32_rnti_tm2_64qam"] = {"subframes_per_s": round(4 * n2 / dtl, 1), "subframes": 4 * n2, "records": w2.nof_records()}
+            legs["cfg2_32_rnti_tm2_64qam"] = {"subframes_per_s": round(4 * n2 / dtl, 1), "subframes": 4 * n2, "records": w2.nof_records(), "input": "resident in HBM"}
             p2.close()
             del d2
             from lsn_testlib import gen_ul_mode_subframes
@@ -399,24 +466,28 @@ def main():
         busiest = {k: round(v, 2) for k, v in sorted(per_thr.items(), key=lambda kv: -kv[1])[:8] if v >= 0.01}
         nk = len(la.KERNELS)
         dom = int(np.argmax(kms[:nk]))
-        sf_rank = args.steps * sf_per_step  # subframes this rank processed in the timed region
+        sf_rank = args.steps * S  # subframes this rank processed in the timed region
         # roofline of the dominant kernel (one of the two turbo-decoder variants).  Algorithmic bytes = what the decoder must move per code
-        # block: its K + 12 packed soft words (4 B each, written by k_rm) in, payload bytes out.  Duration: HIP events on the launch stream.
+        # block: its K + 12 packed soft words (4 B each, written by k_rm) in, payload bytes out.  Duration: HIP events on the launch stream,
+        # i.e. the launch's own span while it shares the GPU with the kernels of the other streams (NOT an exclusive time); the rocprofv3
+        # kernel trace of the same command (tools/gpu_profile.sh -> profiles/) gives the same average and the exclusive (union) time.
         k64, k128 = la.KERNELS.index("k_turbo<64>"), la.KERNELS.index("k_turbo<128>")
         kt = k128 if kms[k128] >= kms[k64] else k64
         kbytes = p.turbo128_algo_bytes if kt == k128 else p.turbo_algo_bytes - p.turbo128_algo_bytes
         ach = (kbytes / 1e9) / (kms[kt] / 1e3) if kms[kt] > 0 else 0.0
-        # HBM traffic of the same kernel from the PMC counters: SEPARATE rocprofv3 --pmc passes of this command (tools/gpu_profile.sh ->
-        # profiles/*_pmc_hbm.json), FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md; per launch like `achieved`
         traffic, traffic_src = None, None
         hj, hname = _profile_json("pmc_hbm")
         if hj and hj.get(la.KERNELS[kt]):
             e = hj[la.KERNELS[kt]]
             traffic = int(e["fetch_corrected_bytes_per_launch"] + e["write_bytes_per_launch"])
             traffic_src = "profiles/" + hname
-        # secondary view (the recursions are integer-VALU work): wave-level VALU instructions per SUBFRAME from a separate
-        # --pmc pass (a property of the workload), over this run's kernel time per subframe = instruction rate while the kernel is resident;
-        # peak = 256 CUs x 4 SIMDs x 2.4 GHz / cycles per wave64 VALU instruction as measured by tools/ubench/valu_rate on this chip
+        rp, rpname = _profile_json("kernel_trace")  # {kernel: {calls, avg_ms, exclusive_ms, ...}, _subframes, _wall_ms} of the driver's command
+        rocprof = None
+        if rp and rp.get(la.KERNELS[kt]):
+            e = rp[la.KERNELS[kt]]
+            hip_avg = kms[kt] / max(1, klaunch[kt])
+            rocprof = {"avg_launch_ms": e.get("avg_ms"), "launches": e.get("calls"), "exclusive_ms_per_subframe": e.get("exclusive_ms_per_subframe"),
+                       "hip_event_over_rocprof_avg": round(hip_avg / e["avg_ms"], 3) if e.get("avg_ms") else None, "source": "profiles/" + rpname}
         valu = None
         vj, vname = _profile_json("pmc_sq")
         try:
@@ -431,32 +502,39 @@ def main():
                         "chip_frac": round(allk * value / world / 1e9 / peak, 4), "source": "profiles/" + vname}
         except Exception:
             valu = None
+        cold = None
+        if args.warmup * S >= 2 * batch:
+            cold = {"subframes_per_s": round(args.warmup * S / dt_warm, 1), "subframes": args.warmup * S, "records": warm_records,
+                    "tb_decodes_per_subframe": round(pw.nof_tb_decodes / (args.warmup * S), 2), "turbo_iterations_per_subframe": round(pw.nof_turbo_iterations / (args.warmup * S), 1),
+                    "note": "the warm-up steps: a fresh engine (empty RNTI histograms, no MCS-table knowledge), pipeline fill and drain included"}
         out = {
             "metric": "subframes/s (20 MHz, 150 RNTIs)", "value": round(value, 1), "unit": "subframes/s", "n_gpus": world if not capture_mode or world > 1 else len(devices),
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "strong" if capture_mode else "weak", "vs_baseline": None, "dtype": "f32+int16", "data": "synthetic",
-            "x_realtime": round(value / 1000.0 / (1 if capture_mode else world), 2), "pcap_diff": pcap_diff, "parity": parity,
-            "config": {"workload": "%s: 20 MHz DL (100 PRB, 2 CRS ports, 2 rx), 150 active RNTIs, TM2/TM3/TM4 mix up to 256QAM, "
-                                   "CFI 3, 8-14 DL + 3-6 UL DCIs per subframe (BASELINE.json configs[2])" % args.config
+            "x_realtime": round(value / 1000.0 / (1 if capture_mode else world), 2), "pcap_diff": pcap_diff,
+            "parity_reference": "in-repo CPU oracle, unpinned vs srsRAN", "parity": parity,
+            "config": {"workload": "%s: 20 MHz DL (100 PRB, 2 CRS ports, 2 rx), 150 active RNTIs + a fresh RNTI by RAR every 200 subframes, TM2/TM3/TM4 mix up to 256QAM, "
+                                   "CFI 3, 8-14 DL + 3-6 UL DCIs per subframe (BASELINE.json configs[2], SURVEY 8d config 3)" % args.config
                        if args.config == "cfg3" else args.config,
-                       "subframes_per_step": sf_per_step, "resident_capture_subframes": nsf, "replays_per_step": reps, "steps_pipelined": True,
-                       "distinct_subframes": gen, "gpu_batch": batch, "cells": 1 if capture_mode else world,
+                       "subframes_per_step": S, "distinct_subframes": nsf, "stream": "capture replayed cyclically, TTI and sequential state carried over",
+                       "input": "resident in HBM", "steps_pipelined": True, "gpu_batch": batch, "cells": 1 if capture_mode else world, "capture_gen_s": round(t_gen, 1),
                        "parallelism": ("one capture, chunks round-robin over devices %s, shared sequential search" % devices) if capture_mode else "one cell per GPU, no collective"},
             "roofline": {"bound": "hbm", "kernel": la.KERNELS[kt], "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(ach / 8000.0, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": round(kms[kt] / max(1, klaunch[kt]), 4), "launches": int(klaunch[kt]),
-                         "algo_bytes_per_launch": int(kbytes / max(1, klaunch[kt])),
-                         "dominant_by_time": la.KERNELS[dom], "valu": valu},
-            "legs": legs, "cpu_baseline": cpu, "host": {"cpu_count": os.cpu_count(), "cpu_quota_cores": host_quota, "decode_threads": int(os.environ.get("LSN_DECODE_THREADS", "8")), "cores_busy_in_timed_region": round(host_cores_busy, 2),
-                                             "busiest_threads": busiest},
+                         "algo_bytes_per_launch": int(kbytes / max(1, klaunch[kt])), "timing": "HIP events on the launch streams inside the timed region (span of a launch that shares the GPU, not exclusive)",
+                         "rocprof": rocprof, "dominant_by_time": la.KERNELS[dom], "valu": valu},
+            "first_h2d_to_last_pdu": legs, "cold_state": cold, "cpu_baseline": cpu,
+            "host": {"cpu_count": os.cpu_count(), "cpu_quota_cores": host_quota, "decode_threads": int(os.environ.get("LSN_DECODE_THREADS", "8")), "cores_busy_in_timed_region": round(host_cores_busy, 2),
+                     "busiest_threads": busiest},
             "detail": {"pdus_per_subframe": round(p.nof_pdus / sf_rank, 3), "algo_bytes_per_subframe": int(p.algo_bytes / sf_rank),
                        "whole_path_GBps": round(p.algo_bytes * (1 if capture_mode else world) / 1e9 / dt, 2), "timed_region_s": round(dt, 3),
                        "per_6400_subframes": {k: round(getattr(p, k) * 6400.0 / sf_rank, 3) for k in
-                                              ("nof_tb_decodes", "nof_cb_decodes", "nof_turbo_iterations", "nof_ondemand_decodes", "turbo_cyc_rm", "turbo_cyc_map",
-                                               "turbo_cyc_out", "ms_ondemand_commit", "ms_stage_a", "ms_search", "ms_search_core", "ms_rar", "ms_stage_c", "ms_commit", "ms_wait_front",
+                                              ("nof_tb_decodes", "nof_cb_decodes", "nof_turbo_iterations", "nof_ondemand_decodes", "ms_ondemand_commit", "ms_stage_a", "ms_search", "ms_search_core", "ms_rar", "ms_stage_c", "ms_commit", "ms_wait_front",
                                                "ms_wait_slot", "ms_drain")},
                        "ondemand_at_commit_per_6400": [round(p.nof_ondemand_commit[k] * 6400.0 / sf_rank, 2) for k in range(4)],
-                       "kernel_ms_per_6400_subframes": {la.KERNELS[k]: round(kms[k] * 6400.0 / sf_rank, 4) for k in range(nk)}},
+                       "kernel_ms_per_6400_subframes": {la.KERNELS[k]: round(kms[k] * 6400.0 / sf_rank, 4) for k in range(nk)},
+                       "kernel_launches_per_step": {la.KERNELS[k]: round(float(klaunch[k]) / args.steps, 2) for k in range(nk)}},
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -158,6 +158,11 @@ void lsn_pcap_reset(lsn_pcap_t* p);
  * sequence agree); lsn_pcap_set_store(p, 0) keeps only the count and the digest (long streams that need not be kept) */
 int lsn_pcap_digest(lsn_pcap_t* p, uint64_t* digest, uint64_t* nbytes);
 void lsn_pcap_set_store(lsn_pcap_t* p, int on);
+/* Piecewise digests: the record stream is cut every `subframes_per_block` subframes counted from `origin_tti` (the TTI of the records
+ * is unwrapped modulo 10240 in arrival order); each block has its own digest chain and record count, so a long replay can be checked
+ * block by block against a reference produced elsewhere.  0 switches the blocks off; lsn_pcap_reset clears them. */
+void lsn_pcap_set_digest_blocks(lsn_pcap_t* p, uint32_t subframes_per_block, uint32_t origin_tti);
+uint32_t lsn_pcap_block_digests(lsn_pcap_t* p, uint64_t* digests, uint32_t* nof_records, uint32_t cap); /* -> number of blocks */
 void lsn_pcap_close(lsn_pcap_t* p);                          /* LTESniffer_pcap_writer::close */
 int lsn_phy_set_pcap_writer(lsn_phy_t* phy, lsn_pcap_t* p);  /* Phy ctor argument `LTESniffer_pcap_writer*` (Phy.h:31) */
 

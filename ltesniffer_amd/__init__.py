@@ -32,7 +32,7 @@ EXPORTS = ["lsn_phy_create", "lsn_phy_destroy", "lsn_phy_set_cell", "lsn_phy_get
            "lsn_pcap_reset", "lsn_pcap_close", "lsn_phy_set_pcap_writer", "lsn_phy_set_api_mode", "lsn_phy_tracked_ul_modulation", "lsn_phy_set_ul_config", "lsn_phy_get_ul_config", "lsn_sib2_decode", "lsn_phy_pusch_decode",
            "lsn_phy_tap_ul", "lsn_phy_set_prach_config", "lsn_phy_prach_detect", "lsn_phy_set_prach_sink", "lsn_prach_tti_opportunity", "lsn_phy_process_file", "lsn_phy_mib_decode", "lsn_phy_mib_decode_llr", "lsn_phy_submit_device", "lsn_phy_wait", "lsn_cell_search",
            "lsn_phy_set_shortcut_discovery", "lsn_phy_get_shortcut_discovery", "lsn_phy_set_histogram_threshold", "lsn_phy_print_stats",
-           "lsn_phy_set_mcs_update_interval", "lsn_phy_update_mcs_database", "lsn_phy_nof_tracked_rnti", "lsn_worker_buffers_offset", "lsn_pcap_digest", "lsn_pcap_set_store", "lsn_phy_create_multi", "lsn_phy_nof_devices"]
+           "lsn_phy_set_mcs_update_interval", "lsn_phy_update_mcs_database", "lsn_phy_nof_tracked_rnti", "lsn_worker_buffers_offset", "lsn_pcap_digest", "lsn_pcap_set_store", "lsn_pcap_set_digest_blocks", "lsn_pcap_block_digests", "lsn_phy_create_multi", "lsn_phy_nof_devices"]
 
 
 PRACH_NCS = [0, 13, 15, 18, 22, 26, 32, 38, 46, 59, 76, 93, 119, 167, 279, 419]  # 36.211 Table 5.7.2-2
@@ -246,6 +246,10 @@ def lib():
         L.lsn_pcap_digest.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.lsn_pcap_set_store.argtypes = [C.c_void_p, C.c_int]
         L.lsn_pcap_set_store.restype = None
+        L.lsn_pcap_set_digest_blocks.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32]
+        L.lsn_pcap_set_digest_blocks.restype = None
+        L.lsn_pcap_block_digests.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+        L.lsn_pcap_block_digests.restype = C.c_uint32
         L.lsn_pcap_close.restype = None
         L.lsn_phy_set_pcap_writer.argtypes = [C.c_void_p, C.c_void_p]
         L.lsn_phy_set_ul_config.argtypes = [C.c_void_p, C.POINTER(UlCfg)]
@@ -325,6 +329,17 @@ class PcapWriter:
 
     def set_store(self, on):
         lib().lsn_pcap_set_store(self._h, int(bool(on)))
+
+    def set_digest_blocks(self, subframes_per_block, origin_tti=0):
+        """cut the digest every n subframes counted from origin_tti (0 = off); clears the blocks collected so far"""
+        lib().lsn_pcap_set_digest_blocks(self._h, int(subframes_per_block), int(origin_tti) % 10240)
+
+    def block_digests(self):
+        """-> [(digest, nof_records)] per block of the stream since reset / set_digest_blocks"""
+        n = lib().lsn_pcap_block_digests(self._h, None, None, 0)
+        d, c = (C.c_uint64 * max(1, n))(), (C.c_uint32 * max(1, n))()
+        n = min(n, lib().lsn_pcap_block_digests(self._h, d, c, n))
+        return [(int(d[i]), int(c[i])) for i in range(n)]
 
     def reset(self):
         lib().lsn_pcap_reset(self._h)

@@ -5,17 +5,25 @@
 //   SubframeBuffer (3 * SF_LEN_PRB(100) samples per antenna)             /root/reference/src/src/SubframeBuffer.cc:25-28
 // The reference runs `nof_workers` CPU threads each calling SubframeWorker::work(); here ONE dispatcher thread drains the
 // pending queue in FIFO (= TTI) order into GPU batches, which is the reference's sequential (-W 1, file replay) semantic.
+// The pool is pipelined: the workers' IQ buffers are rows of ONE pinned slab ([worker][antenna][3 SF_LEN], SubframeBuffer.cc:25), a run
+// of pending workers crosses PCIe with a single strided copy straight from that slab (no staging memcpy) and is queued into the engine
+// (submit, not process); a worker returns to the avail queue as soon as the copy of its rows has completed - the search / decode /
+// commit / write stages of its subframe run on while the caller refills it.  Lossless file mode (blocking getAvail, LTESniffer_Core.cc:441)
+// lets batches grow towards half the pool; live mode (getAvailImmediate, :439) dispatches whatever is pending at once.
 #include "lsn_engine.h"
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <mutex>
 #include <thread>
+#include <time.h>
 
 struct lsn_worker {
   lsn_phy* phy = nullptr;
   float* buf[LSN_MAX_RX] = {nullptr, nullptr};
   float* buf_offset[2] = {nullptr, nullptr};  // SubframeBuffer::sf_buffer_offset (allocated on first use)
   uint32_t buf_len = 0;  // complex samples per antenna
+  uint32_t index = 0;    // position in the slab
   uint32_t sf_idx = 0, sfn = 0;
   int update_meta = 0;
   lsn_dl_sf_cfg_t sf_cfg{};
@@ -32,54 +40,118 @@ struct lsn_phy {
   std::vector<std::unique_ptr<lsn_worker>> workers;
   std::deque<lsn_worker*> avail, pending;
   std::mutex mtx;
-  std::condition_variable cv_avail, cv_pending, cv_idle;
-  std::thread dispatcher;
-  bool stop = false, busy = false;
-  float* staging = nullptr;  // pinned [max_batch][rx][sflen] cf32
+  std::condition_variable cv_avail, cv_pending, cv_idle, cv_release;
+  std::thread dispatcher, releaser;
+  bool stop = false, busy = false, flush = false, lossless = false;
+  float* slab = nullptr;       // pinned [nof_workers][rx][3 * sflen] cf32
+  size_t row_floats = 0;       // 3 * sflen * 2
+  struct InFlight { hipEvent_t ev = nullptr; std::vector<lsn_worker*> ws; };
+  std::deque<InFlight> inflight;   // batches whose rows are crossing PCIe (dispatcher -> releaser)
+  std::vector<hipEvent_t> ev_free;
   int last_error = 0;
 
   void dispatch_loop();
+  void release_loop();
+  void stop_threads();
 };
 
 void lsn_phy::dispatch_loop()
 {
   std::vector<lsn_worker*> batch;
+  const uint32_t maxb = engine->maxBatch();
+  const uint32_t target = std::max<uint32_t>(1, std::min<uint32_t>(maxb, (uint32_t)workers.size() / 2));
+  long linger_us = 2000;  // lossless mode: how long a partial batch may wait for more subframes
+  if (const char* e = getenv("LSN_POOL_LINGER_US")) linger_us = std::max(0, atoi(e));
   for (;;) {
+    hipEvent_t ev = nullptr;
     {
       std::unique_lock<std::mutex> lk(mtx);
       cv_pending.wait(lk, [&] { return stop || !pending.empty(); });
       if (pending.empty() && stop) return;
+      if (lossless && linger_us > 0) {
+        // file replay: larger batches amortise the per-chunk launches; a partial batch goes out when the caller has run out of workers
+        // (it is blocked in getAvail), when joinPending asks for a flush, or after the linger time
+        const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(linger_us);
+        cv_pending.wait_until(lk, deadline, [&] { return stop || flush || pending.size() >= target || avail.empty(); });
+      }
       batch.clear();
-      // consecutive TTIs only: a batch is a contiguous run of subframes (start_tti + i)
-      const uint32_t maxb = engine->maxBatch();
-      uint32_t prev_tti = 0;
+      // consecutive TTIs and consecutive slab rows only: a batch is one contiguous run of subframes (start_tti + i) and one strided copy
+      uint32_t prev_tti = 0, prev_idx = 0;
       while (!pending.empty() && batch.size() < maxb) {
         lsn_worker* w = pending.front();
         const uint32_t tti = w->sfn * 10 + w->sf_idx;
-        if (!batch.empty() && (tti != (prev_tti + 1) % 10240 || w->update_meta)) break;
-        prev_tti = tti;
+        if (!batch.empty() && (tti != (prev_tti + 1) % 10240 || w->update_meta || w->index != prev_idx + 1)) break;
+        prev_tti = tti; prev_idx = w->index;
         batch.push_back(w);
         pending.pop_front();
       }
       busy = true;
+      if (!ev_free.empty()) { ev = ev_free.back(); ev_free.pop_back(); }
     }
-    const uint32_t A = engine->nofRx(), sflen = engine->sfLen();
-    for (size_t i = 0; i < batch.size(); i++)
-      for (uint32_t rx = 0; rx < A; rx++)
-        std::memcpy(staging + ((i * A + rx) * sflen) * 2, batch[i]->buf[rx], (size_t)sflen * 2 * sizeof(float));
+    (void)hipSetDevice(engine->device());
+    if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
     // SubframeWorker::prepare's updateMetaFormats flag (LTESniffer_Core.cc:434) applies to the first subframe of the batch
     const uint32_t tti0 = batch[0]->sfn * 10 + batch[0]->sf_idx;
-    if (batch[0]->update_meta) engine->forceMetaUpdateNext();
-    const int r = engine->processHost(staging, (uint32_t)batch.size(), tti0, 0u);
+    const int r = ev ? engine->submitHostRows(batch[0]->buf[0], row_floats * sizeof(float), (uint32_t)batch.size(), tti0, batch[0]->update_meta != 0, ev)
+                     : LSN_ERROR;
     {
       std::unique_lock<std::mutex> lk(mtx);
-      if (r != LSN_SUCCESS) last_error = r;
-      for (auto* w : batch) avail.push_back(w);
+      if (r != LSN_SUCCESS) {
+        last_error = r;
+        for (auto* w : batch) avail.push_back(w);  // nothing was queued: the rows are free again
+        if (ev) ev_free.push_back(ev);
+      } else {
+        inflight.push_back({ev, batch});
+      }
       busy = false;
     }
+    cv_release.notify_one();
     cv_avail.notify_all();
     cv_idle.notify_all();
   }
+}
+
+// returns the workers of a batch to the pool when the copy of their rows has completed
+void lsn_phy::release_loop()
+{
+  for (;;) {
+    InFlight f;
+    {
+      std::unique_lock<std::mutex> lk(mtx);
+      cv_release.wait(lk, [&] { return stop || !inflight.empty(); });
+      if (inflight.empty()) return;
+      f = inflight.front();
+    }
+    (void)hipSetDevice(engine->device());
+    for (;;) {  // poll + nap (hipEventSynchronize spins on this runtime)
+      const hipError_t e = hipEventQuery(f.ev);
+      if (e != hipErrorNotReady) { (void)hipGetLastError(); break; }
+      timespec ts{0, 20000};
+      nanosleep(&ts, nullptr);
+    }
+    {
+      std::unique_lock<std::mutex> lk(mtx);
+      inflight.pop_front();
+      for (auto* w : f.ws) avail.push_back(w);
+      ev_free.push_back(f.ev);
+    }
+    cv_avail.notify_all();
+    cv_idle.notify_all();
+    cv_pending.notify_all();
+  }
+}
+
+void lsn_phy::stop_threads()
+{
+  {
+    std::unique_lock<std::mutex> lk(mtx);
+    stop = true;
+  }
+  cv_pending.notify_all();
+  if (dispatcher.joinable()) dispatcher.join();
+  cv_release.notify_all();
+  if (releaser.joinable()) releaser.join();
+  stop = false;
 }
 
 extern "C" {
@@ -114,8 +186,10 @@ int lsn_phy_create_multi(const lsn_phy_cfg_t* cfg, const int* devices, uint32_t 
   const int r = lsn_phy_create(&c0, out);
   if (r != LSN_SUCCESS) return r;
   if (cfg->sniffer_mode != 0 && n_devices > 1) { lsn_phy_destroy(*out); *out = nullptr; return LSN_ERROR_INVALID_INPUTS; }  // UL_MODE keeps per-chunk uplink state
-  int ndev = 0;
+  int ndev = 0, caller_dev = 0;
   (void)hipGetDeviceCount(&ndev);
+  (void)hipGetDevice(&caller_dev);
+  struct RestoreDev { int d; ~RestoreDev() { (void)hipSetDevice(d); } } restore{caller_dev};  // the calling thread keeps its current device
   try {
     for (uint32_t i = 1; i < n_devices; i++) {
       if (devices[i] < 0 || devices[i] >= ndev) throw std::invalid_argument("device");
@@ -124,7 +198,15 @@ int lsn_phy_create_multi(const lsn_phy_cfg_t* cfg, const int* devices, uint32_t 
       (*out)->more.emplace_back(new lsn::Engine(ci, (*out)->engine->sharedState()));
       if (devices[i] != devices[0]) {  // peer copies of the IQ blocks (xGMI); harmless when already enabled
         int can = 0;
-        if (hipDeviceCanAccessPeer(&can, devices[i], devices[0]) == hipSuccess && can) { (void)hipSetDevice(devices[i]); (void)hipDeviceEnablePeerAccess(devices[0], 0); (void)hipGetLastError(); }
+        if (hipDeviceCanAccessPeer(&can, devices[i], devices[0]) == hipSuccess && can) {
+          (void)hipSetDevice(devices[i]);
+          const hipError_t pe = hipDeviceEnablePeerAccess(devices[0], 0);
+          if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled)
+            fprintf(stderr, "ltesniffer_amd: peer access %d -> %d refused (%s): blocks resident on device %d are copied through the runtime's staging path\n", devices[i], devices[0], hipGetErrorString(pe), devices[0]);
+          (void)hipGetLastError();
+        } else {
+          fprintf(stderr, "ltesniffer_amd: no peer access %d -> %d (hipDeviceCanAccessPeer): device-resident blocks take the runtime's staging path\n", devices[i], devices[0]);
+        }
       }
     }
     return LSN_SUCCESS;
@@ -140,56 +222,39 @@ uint32_t lsn_phy_nof_devices(lsn_phy_t* phy) { return phy ? (uint32_t)phy->neng(
 void lsn_phy_destroy(lsn_phy_t* phy)
 {
   if (!phy) return;
-  {
-    std::unique_lock<std::mutex> lk(phy->mtx);
-    phy->stop = true;
-  }
-  phy->cv_pending.notify_all();
-  if (phy->dispatcher.joinable()) phy->dispatcher.join();
-  for (auto& w : phy->workers) {
-    for (auto& b : w->buf)
-      if (b) (void)hipHostFree(b);
+  if (phy->dispatcher.joinable()) { (void)lsn_phy_join_pending(phy); phy->stop_threads(); }
+  for (auto& w : phy->workers)
     for (auto& b : w->buf_offset) free(b);
-  }
-  if (phy->staging) (void)hipHostFree(phy->staging);
+  if (phy->slab) (void)hipHostFree(phy->slab);
+  for (auto& e : phy->ev_free) (void)hipEventDestroy(e);
   delete phy;
 }
 
 int lsn_phy_set_cell(lsn_phy_t* phy, const lsn_cell_t* cell)
 {
   if (!phy || !cell) return LSN_ERROR_INVALID_INPUTS;
-  if (phy->dispatcher.joinable()) {
-    lsn_phy_join_pending(phy);
-    {
-      std::unique_lock<std::mutex> lk(phy->mtx);
-      phy->stop = true;
-    }
-    phy->cv_pending.notify_all();
-    phy->dispatcher.join();
-    phy->stop = false;
-  }
+  if (phy->dispatcher.joinable()) { (void)lsn_phy_join_pending(phy); phy->stop_threads(); }
   const int r = phy->engine->setCell(*cell);
   if (r != LSN_SUCCESS) return r;
   for (auto& e : phy->more) { const int re = e->setCell(*cell); if (re != LSN_SUCCESS) return re; }
-  // worker pool: SubframeBuffer allocates 3 * SF_LEN per antenna (SubframeBuffer.cc:25)
-  for (auto& w : phy->workers) {
-    for (auto& b : w->buf)
-      if (b) { (void)hipHostFree(b); b = nullptr; }
+  // worker pool: SubframeBuffer allocates 3 * SF_LEN per antenna (SubframeBuffer.cc:25); all of them in one pinned slab
+  for (auto& w : phy->workers)
     for (auto& b : w->buf_offset) { free(b); b = nullptr; }
-  }
   phy->workers.clear(); phy->avail.clear(); phy->pending.clear();
-  if (phy->staging) { (void)hipHostFree(phy->staging); phy->staging = nullptr; }
+  if (phy->slab) { (void)hipHostFree(phy->slab); phy->slab = nullptr; }
   const uint32_t sflen = phy->engine->sfLen(), A = phy->engine->nofRx();
+  phy->row_floats = (size_t)3 * sflen * 2;
+  if (hipHostMalloc((void**)&phy->slab, (size_t)phy->cfg.nof_workers * A * phy->row_floats * sizeof(float)) != hipSuccess) { (void)hipGetLastError(); phy->slab = nullptr; return LSN_ERROR; }
   for (uint32_t i = 0; i < phy->cfg.nof_workers; i++) {
     std::unique_ptr<lsn_worker> w(new lsn_worker());
-    w->phy = phy; w->buf_len = 3 * sflen;
-    for (uint32_t rx = 0; rx < A; rx++)
-      if (hipHostMalloc((void**)&w->buf[rx], (size_t)w->buf_len * 2 * sizeof(float)) != hipSuccess) return LSN_ERROR;
+    w->phy = phy; w->buf_len = 3 * sflen; w->index = i;
+    for (uint32_t rx = 0; rx < A; rx++) w->buf[rx] = phy->slab + ((size_t)i * A + rx) * phy->row_floats;
     phy->avail.push_back(w.get());
     phy->workers.push_back(std::move(w));
   }
-  if (hipHostMalloc((void**)&phy->staging, (size_t)phy->engine->maxBatch() * A * sflen * 2 * sizeof(float)) != hipSuccess) return LSN_ERROR;
+  phy->lossless = false;
   phy->dispatcher = std::thread([phy] { phy->dispatch_loop(); });
+  phy->releaser = std::thread([phy] { phy->release_loop(); });
   return LSN_SUCCESS;
 }
 
@@ -197,7 +262,11 @@ lsn_worker_t* lsn_phy_get_avail(lsn_phy_t* phy, int blocking)
 {
   if (!phy) return nullptr;
   std::unique_lock<std::mutex> lk(phy->mtx);
-  if (blocking) phy->cv_avail.wait(lk, [&] { return !phy->avail.empty() || phy->workers.empty(); });
+  phy->lossless = blocking != 0;  // Phy::getAvail (file replay, lossless) vs getAvailImmediate (live capture, lossy)
+  if (blocking && phy->avail.empty()) {
+    phy->cv_pending.notify_all();  // the dispatcher sends a partial batch when the caller is out of workers
+    phy->cv_avail.wait(lk, [&] { return !phy->avail.empty() || phy->workers.empty(); });
+  }
   if (phy->avail.empty()) return nullptr;  // getAvailImmediate: nullptr when none (Phy.cc:84-89)
   lsn_worker* w = phy->avail.front();
   phy->avail.pop_front();
@@ -218,9 +287,16 @@ int lsn_phy_put_pending(lsn_phy_t* phy, lsn_worker_t* w)
 int lsn_phy_join_pending(lsn_phy_t* phy)
 {
   if (!phy) return LSN_ERROR_INVALID_INPUTS;
+  {
+    std::unique_lock<std::mutex> lk(phy->mtx);
+    phy->flush = true;
+    phy->cv_pending.notify_all();
+    phy->cv_idle.wait(lk, [&] { return phy->pending.empty() && !phy->busy && phy->inflight.empty(); });
+    phy->flush = false;
+  }
+  const int w = phy->engine->wait();  // every queued subframe has been searched, decoded and written (Phy::joinPending, Phy.cc:100-109)
   std::unique_lock<std::mutex> lk(phy->mtx);
-  phy->cv_idle.wait(lk, [&] { return phy->pending.empty() && !phy->busy; });
-  const int r = phy->last_error;
+  const int r = phy->last_error ? phy->last_error : w;
   phy->last_error = 0;
   return r;
 }

@@ -194,6 +194,7 @@ Engine::~Engine()
   for (auto& sa : stream_a)
     if (sa) (void)hipStreamDestroy(sa);
   if (ev_in) (void)hipEventDestroy(ev_in);
+  for (auto& e : peer_ev) if (e) (void)hipEventDestroy(e);
   if (copy_stream) (void)hipStreamDestroy(copy_stream);
   for (auto& e : copy_done) if (e) (void)hipEventDestroy(e);
 }
@@ -214,7 +215,12 @@ int Engine::setCell(const lsn_cell_t& c)
     cell.nof_prb = c.nof_prb; cell.nof_ports = c.nof_ports; cell.id = c.id; cell.phich_ng_x6 = ng_x6[c.phich_resources];
     buildTables();
     sib2_learned = false;
-    if (cfg.sniffer_mode == 1) uploadUlStatic();
+    if (cfg.sniffer_mode == 1) {
+      uploadUlStatic();
+      std::lock_guard<std::mutex> lk(mcs_mtx);  // uplink tracking database: sized here, never lazily on the commit thread
+      ulmod.assign(65536, 0); ul_uecfg.assign(65536, UeSpecConfig()); ul_time.assign(65536, 0); ul_active.assign(65536, 0); ul_success.assign(65536, 0);
+      ulmod_count = 0;
+    }
   } catch (const std::exception& ex) {
     fprintf(stderr, "ltesniffer_amd: %s\n", ex.what());
     return LSN_ERROR;
@@ -355,7 +361,7 @@ void Engine::searchChunk(Chunk& ch, uint32_t update_meta_period)
   for (uint32_t sf = 0; sf < ch.nsf; sf++) {
     SubframeCtx& c = ch.ctx[sf];
     if (sf + 2 < ch.nsf) prefetch_cand(ch.h_cand + (size_t)(sf + 2) * LSN_MAX_LOC * LSN_MAX_SIZES, ch.h_ccepow + (size_t)(sf + 2) * LSN_CCE_STRIDE);
-    const bool upd = (update_meta_period && (sf_cnt % update_meta_period) == 0) || force_meta_next;  // LTESniffer_Core.cc:434
+    const bool upd = (update_meta_period && (sf_cnt % update_meta_period) == 0) || force_meta_next || (sf == 0 && ch.force_meta);  // LTESniffer_Core.cc:434
     force_meta_next = false;
     sf_cnt++;
     const double ts0 = now_ms();
@@ -771,7 +777,7 @@ void Engine::buildCommitView(Chunk& ch)
 void Engine::emitPdu(Chunk& ch, JobRunner& r, const char* name, size_t payload_off, uint32_t len, uint16_t rnti, uint32_t tti, uint8_t tb)
 {
   r.perf.nof_pdus++;
-  if (!sink) return;
+  if (!sink && api_mode < 0) return;  // records feed the PDU sink and / or the security-API sinks
   lsn_pdu_ctx_t c{};
   c.tti = tti; c.direction = 1; c.crc_ok = 1; c.is_retx = 0; c.tb = tb;
   // LTESniffer_pcap_writer::write_dl_* (PcapWriter.cc:162-190)
@@ -954,8 +960,8 @@ void Engine::decodeLoop(int idx)
       ch = commit_queue.front();
       commit_queue.pop_front();
     }
-    std::string err;
-    try {
+    std::string err = ch->err;
+    if (err.empty()) try {
       (void)hipSetDevice(cfg.device);
       const double t0 = now_ms();
       trace((uint8_t)(2 + idx), TR_DEC_BEGIN, ch->trace_id);
@@ -1038,11 +1044,11 @@ void Engine::writerLoop()
       std::unique_lock<std::mutex> tl(sh->turn_mtx);
       sh->turn_cv.wait(tl, [&] { return sh->write_turn == ch->gseq || stop; });
     }
-    if (err.empty() && sink) {
+    if (err.empty() && (sink || api_mode >= 0)) {
       try {
         const uint8_t* base = ch->h_payload.data();
         for (const auto& rec : ch->recs) {
-          sink(sink_user, &rec.ctx, base + rec.off, rec.len);
+          if (sink) sink(sink_user, &rec.ctx, base + rec.off, rec.len);
           if (api_mode >= 0 && rec.ctx.direction == 1 && (rec.ctx.rnti_type == 1 || rec.ctx.rnti_type == 3)) {  // run_api_dl_mode, DL_Sniffer_PDSCH.cc:804-879
             ApiEvent ev[20];
             int nev = 0;
@@ -1096,18 +1102,24 @@ void Engine::frontLoop()
   pinThisThread(nullptr);
   prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0);
   std::deque<Chunk*> inflight;
+  // A chunk that failed somewhere keeps travelling with its error text (every later stage skips its work on it and the writer reports it):
+  // the turn counters and seq_written then advance exactly as for a good chunk and wait() can always drain the pipeline.
   auto finish_oldest = [&] {
     Chunk* cur = inflight.front();
     inflight.pop_front();
     const double t0 = now_ms();
-    finishStageA(*cur);
+    if (cur->err.empty()) {
+      try { finishStageA(*cur); } catch (const std::exception& ex) { cur->err = ex.what(); }
+    }
     trace(1, TR_A_DONE, cur->trace_id);
     perf_front.ms_stage_a += now_ms() - t0;
     {
       std::unique_lock<std::mutex> lk(mtx);
       spec_queue.push_back(cur);
+      seq_a_done++;
     }
     cv_spec.notify_one();
+    cv_done.notify_all();
   };
   for (;;) {
     FrontJob job;
@@ -1118,41 +1130,39 @@ void Engine::frontLoop()
       if (front_jobs.empty() && inflight.empty()) return;  // stop
       if (!front_jobs.empty()) { job = front_jobs.front(); front_jobs.pop_front(); have = true; }
     }
-    try {
-      (void)hipSetDevice(cfg.device);
-      if (!have) { finish_oldest(); continue; }
-      const uint32_t nchunks = (job.nsf_total + max_batch - 1) / max_batch;
-      const size_t sf_stride = (size_t)cfg.nof_rx_antennas * cd.sflen * sizeof(cf32);
-      for (uint32_t ci = 0; ci < nchunks; ci++) {
-        while (inflight.size() >= (size_t)NSTREAM_A) finish_oldest();
-        Chunk& ch = chunks[slot_counter++ % (uint64_t)nslots];  // slots rotate across submits
-        trace(1, TR_ACQ_BEGIN, ci);
-        {
-          const double tw = now_ms();
-          std::unique_lock<std::mutex> lk(mtx);
-          cv_done.wait(lk, [&] { return !ch.busy || stop; });
-          if (stop) return;
-          ch.busy = true;
-          perf_front.ms_wait_slot += now_ms() - tw;
-        }
-        const uint32_t base = ci * max_batch;
-        ch.nsf = std::min(max_batch, job.nsf_total - base);
-        ch.start_tti = job.start_tti + base;
-        ch.update_meta_period = job.update_meta_period;
-        ch.gseq = job.gseq0 + ci;
-        ch.jobs.clear(); ch.jres.clear(); ch.cdci.clear(); ch.setup_cfgs.clear(); ch.h_payload.clear(); ch.recs.clear(); ch.err.clear();
-        for (uint32_t i = 0; i < ch.nsf; i++) ch.ctx[i].reset(ch.start_tti + i);
-        ch.st_a = stream_a[(slot_counter - 1) % NSTREAM_A];
-        ch.trace_id = ci;
-        trace(1, TR_ACQ_END, ci);
-        launchStageA(ch, (const uint8_t*)job.d_iq + (size_t)base * sf_stride);
-        inflight.push_back(&ch);
+    (void)hipSetDevice(cfg.device);
+    if (!have) { finish_oldest(); continue; }
+    const uint32_t nchunks = (job.nsf_total + max_batch - 1) / max_batch;
+    const size_t sf_stride = (size_t)cfg.nof_rx_antennas * cd.sflen * sizeof(cf32);
+    for (uint32_t ci = 0; ci < nchunks; ci++) {
+      while (inflight.size() >= (size_t)NSTREAM_A) finish_oldest();
+      Chunk& ch = chunks[slot_counter++ % (uint64_t)nslots];  // slots rotate across submits
+      trace(1, TR_ACQ_BEGIN, ci);
+      {
+        const double tw = now_ms();
+        std::unique_lock<std::mutex> lk(mtx);
+        cv_done.wait(lk, [&] { return !ch.busy || stop; });
+        if (stop) return;
+        ch.busy = true;
+        perf_front.ms_wait_slot += now_ms() - tw;
       }
-    } catch (const std::exception& ex) {
-      std::unique_lock<std::mutex> lk(mtx);
-      if (commit_error.empty()) commit_error = ex.what();
-      inflight.clear();
-      cv_done.notify_all();
+      const uint32_t base = ci * max_batch;
+      ch.nsf = std::min(max_batch, job.nsf_total - base);
+      ch.start_tti = job.start_tti + base;
+      ch.update_meta_period = job.update_meta_period;
+      ch.force_meta = job.force_meta && ci == 0;
+      ch.gseq = job.gseq0 + ci;
+      ch.jobs.clear(); ch.jres.clear(); ch.cdci.clear(); ch.setup_cfgs.clear(); ch.h_payload.clear(); ch.recs.clear(); ch.err.clear();
+      for (uint32_t i = 0; i < ch.nsf; i++) ch.ctx[i].reset(ch.start_tti + i);
+      ch.st_a = stream_a[(slot_counter - 1) % NSTREAM_A];
+      ch.trace_id = ci;
+      trace(1, TR_ACQ_END, ci);
+      try {
+        launchStageA(ch, (const uint8_t*)job.d_iq + (size_t)base * sf_stride);
+      } catch (const std::exception& ex) {
+        ch.err = ex.what();
+      }
+      inflight.push_back(&ch);
     }
   }
 }
@@ -1172,22 +1182,21 @@ void Engine::searchLoop()
       cur = search_queue.front();
       search_queue.pop_front();
     }
-    if (!cur) continue;  // a chunk the spec thread gave up on: its error is already recorded
     {  // the sequential search state may be shared with the engines of other GPUs: chunk g is searched when chunks 0 .. g-1 have been
       std::unique_lock<std::mutex> tl(sh->turn_mtx);
       sh->turn_cv.wait(tl, [&] { return sh->search_turn == cur->gseq || stop; });
     }
-    try {
-      (void)hipSetDevice(cfg.device);
-      const double t1 = now_ms();
-      trace(0, TR_SEARCH_BEGIN, cur->trace_id);
-      searchChunk(*cur, cur->update_meta_period);
-      trace(0, TR_SEARCH_END, cur->trace_id);
-      perf_search.ms_search += now_ms() - t1;
-    } catch (const std::exception& ex) {
-      std::unique_lock<std::mutex> lk(mtx);
-      if (commit_error.empty()) commit_error = ex.what();
-      cv_done.notify_all();
+    if (cur->err.empty()) {
+      try {
+        (void)hipSetDevice(cfg.device);
+        const double t1 = now_ms();
+        trace(0, TR_SEARCH_BEGIN, cur->trace_id);
+        searchChunk(*cur, cur->update_meta_period);
+        trace(0, TR_SEARCH_END, cur->trace_id);
+        perf_search.ms_search += now_ms() - t1;
+      } catch (const std::exception& ex) {
+        cur->err = ex.what();
+      }
     }
     {
       std::unique_lock<std::mutex> tl(sh->turn_mtx);
@@ -1219,19 +1228,13 @@ void Engine::specLoop()
       cur = spec_queue.front();
       spec_queue.pop_front();
     }
-    if (cur) {
+    if (cur->err.empty()) {
       try {
         (void)hipSetDevice(cfg.device);
-        const double t0 = now_ms();
         speculateRar(*cur);
         trace(14, TR_SPEC_DONE, cur->trace_id);
-        runner_f.perf.ms_rar += 0.0;
-        (void)t0;
       } catch (const std::exception& ex) {
-        std::unique_lock<std::mutex> lk(mtx);
-        if (commit_error.empty()) commit_error = ex.what();
-        cur = nullptr;
-        cv_done.notify_all();
+        cur->err = ex.what();
       }
     }
     {
@@ -1251,7 +1254,7 @@ int Engine::process(const void* d_iq, uint32_t nsf_total, uint32_t start_tti, ui
   return r != LSN_SUCCESS ? r : w;
 }
 
-int Engine::submit(const void* d_iq, uint32_t nsf_total, uint32_t start_tti, uint32_t update_meta_period, hipStream_t stream)
+int Engine::submit(const void* d_iq, uint32_t nsf_total, uint32_t start_tti, uint32_t update_meta_period, hipStream_t stream, bool force_meta_first)
 {
   if (!cell_set) return LSN_ERROR;
   if (!d_iq && nsf_total) return LSN_ERROR_INVALID_INPUTS;
@@ -1274,7 +1277,7 @@ int Engine::submit(const void* d_iq, uint32_t nsf_total, uint32_t start_tti, uin
     const uint32_t nchunks = (nsf_total + max_batch - 1) / max_batch;
     {
       std::unique_lock<std::mutex> lk(mtx);
-      front_jobs.push_back({d_iq, nsf_total, start_tti, update_meta_period, sh->next_gseq.fetch_add(nchunks)});
+      front_jobs.push_back({d_iq, nsf_total, start_tti, update_meta_period, sh->next_gseq.fetch_add(nchunks), force_meta_first});
       chunks_expected += nchunks;
     }
     cv_front.notify_one();
@@ -1298,13 +1301,46 @@ int Engine::submitFrom(const void* d_iq, int src_device, uint32_t nsf, uint32_t 
     }
     const size_t sf_stride = (size_t)cfg.nof_rx_antennas * cd.sflen * sizeof(cf32);
     const uint32_t slot = peer_slot++ % 12u;  // the staging area holds twelve chunks
-    if (peer_marks[slot]) waitMark(peer_marks[slot]);
+    if (peer_marks[slot]) waitIqConsumed(peer_marks[slot]);
     uint8_t* dst = (uint8_t*)d_iq_staging + (size_t)slot * max_batch * sf_stride;
-    // the copy is ordered behind the caller's stream (the source block) and in front of this engine's stage A
-    HIP_CHECK(hipEventRecord(ev_in, stream));
-    HIP_CHECK(hipStreamWaitEvent(copy_stream, ev_in, 0));
+    // the copy is ordered behind the caller's stream (the source block) and in front of this engine's stage A.  The caller's stream lives on
+    // the SOURCE device: the event that marks "block ready" must be created and recorded there (an event of this engine's device is rejected
+    // with hipErrorInvalidHandle); waiting on it from a stream of another device is allowed.
+    if (src_device < 0 || src_device >= 16) return LSN_ERROR_INVALID_INPUTS;
+    HIP_CHECK(hipSetDevice(src_device));
+    if (!peer_ev[src_device]) HIP_CHECK(hipEventCreateWithFlags(&peer_ev[src_device], hipEventDisableTiming));
+    HIP_CHECK(hipEventRecord(peer_ev[src_device], stream));
+    HIP_CHECK(hipSetDevice(cfg.device));
+    HIP_CHECK(hipStreamWaitEvent(copy_stream, peer_ev[src_device], 0));
     HIP_CHECK(hipMemcpyPeerAsync(dst, cfg.device, d_iq, src_device, (size_t)nsf * sf_stride, copy_stream));
     const int rc = submit(dst, nsf, start_tti, update_meta_period, copy_stream);
+    peer_marks[slot] = submitMark();
+    return rc;
+  } catch (const std::exception& ex) {
+    fprintf(stderr, "ltesniffer_amd: %s\n", ex.what());
+    return LSN_ERROR;
+  }
+}
+
+int Engine::submitHostRows(const void* host_rows, size_t row_pitch, uint32_t nsf, uint32_t start_tti, bool force_meta_first, hipEvent_t copied)
+{
+  if (!cell_set || !host_rows || nsf == 0 || nsf > max_batch) return LSN_ERROR_INVALID_INPUTS;
+  try {
+    HIP_CHECK(hipSetDevice(cfg.device));
+    if (!copy_stream) {
+      HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+      for (auto& e : copy_done) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    const size_t row_bytes = (size_t)cd.sflen * sizeof(cf32), sf_stride = (size_t)cfg.nof_rx_antennas * row_bytes;
+    const uint32_t slot = peer_slot++ % 12u;
+    if (peer_marks[slot]) waitIqConsumed(peer_marks[slot]);
+    uint8_t* dst = (uint8_t*)d_iq_staging + (size_t)slot * max_batch * sf_stride;
+    if (row_pitch == row_bytes)
+      HIP_CHECK(hipMemcpyAsync(dst, host_rows, (size_t)nsf * sf_stride, hipMemcpyHostToDevice, copy_stream));
+    else
+      HIP_CHECK(hipMemcpy2DAsync(dst, row_bytes, host_rows, row_pitch, row_bytes, (size_t)nsf * cfg.nof_rx_antennas, hipMemcpyHostToDevice, copy_stream));
+    if (copied) HIP_CHECK(hipEventRecord(copied, copy_stream));
+    const int rc = submit(dst, nsf, start_tti, 0u, copy_stream, force_meta_first);
     peer_marks[slot] = submitMark();
     return rc;
   } catch (const std::exception& ex) {
@@ -1321,16 +1357,11 @@ int Engine::wait()
     {
       const double tw = now_ms();
       std::unique_lock<std::mutex> lk(mtx);
-      cv_done.wait(lk, [&] { return seq_written == chunks_expected || !commit_error.empty(); });
+      // drain: a failed chunk still passes every stage (skipping the work), so this always completes and the counters stay consistent
+      cv_done.wait(lk, [&] { return seq_written == chunks_expected; });
       perf.ms_drain += now_ms() - tw;
       err = commit_error;
-      if (!err.empty()) {  // give up on whatever is still in flight: the pipeline starts clean with the next submit
-        commit_error.clear();
-        front_jobs.clear();
-        chunks_expected = seq_written;
-        std::unique_lock<std::mutex> tl(sh->turn_mtx);
-        sh->search_turn = sh->commit_turn = sh->write_turn = sh->next_gseq.load();
-      }
+      commit_error.clear();
     }
     batch_open = false;
     if (!err.empty()) throw std::runtime_error(err);
@@ -1364,23 +1395,18 @@ int Engine::processHost(const float* iq, uint32_t nsf_total, uint32_t start_tti,
   try {
     HIP_CHECK(hipSetDevice(cfg.device));
     const size_t sf_stride = (size_t)cfg.nof_rx_antennas * cd.sflen * sizeof(cf32);
-    const uint32_t nring = 3;
-    const uint32_t blk = (uint32_t)std::max<size_t>(1, staging_sf / nring);  // subframes per staging block
-    if (!copy_stream) {
-      HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
-      for (auto& e : copy_done) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
-    hipPointerAttribute_t attr{};
-    const bool pinned = hipPointerGetAttributes(&attr, iq) == hipSuccess && attr.type == hipMemoryTypeHost;
-    if (!pinned && (size_t)nsf_total * sf_stride >= ((size_t)8 << 20))
-      registered = hipHostRegister((void*)iq, (size_t)nsf_total * sf_stride, hipHostRegisterDefault) == hipSuccess;
-    (void)hipGetLastError();
-    uint64_t marks[3] = {0, 0, 0};
+    // ring of staging blocks, one pipeline chunk each (max_batch subframes: 393 MB at 20 MHz / 2 rx / 800 subframes - large copies run at the
+    // link rate, tools/ubench/h2d_bw.hip).  A block is reusable as soon as stage A of its chunk has consumed the samples (not when the chunk has
+    // left the whole pipeline: with decode, commit and write behind stage A that is six or more chunk times later and throttled the copies to
+    // three blocks per pipeline latency - the 27 GB/s of round 2).  Copies are queued ahead on their own stream, so the link stays busy.
+    const uint32_t blk = max_batch;
+    const uint32_t nring = (uint32_t)std::max<size_t>(2, staging_sf / blk);
+    std::vector<uint64_t> marks(nring, 0);
     uint32_t k = 0;
     int rc = LSN_SUCCESS;
     for (uint32_t base = 0; base < nsf_total && rc == LSN_SUCCESS; base += blk, k++) {
       const uint32_t nsf = std::min(blk, nsf_total - base), slot = k % nring;
-      if (k >= nring) waitMark(marks[slot]);  // the block that used this staging buffer three blocks ago has left the pipeline
+      if (k >= nring) waitIqConsumed(marks[slot]);
       uint8_t* dst = (uint8_t*)d_iq_staging + (size_t)slot * blk * sf_stride;
       HIP_CHECK(hipMemcpyAsync(dst, (const uint8_t*)iq + (size_t)base * sf_stride, (size_t)nsf * sf_stride, hipMemcpyHostToDevice, copy_stream));
       rc = submit(dst, nsf, start_tti + base, update_meta_period, copy_stream);  // stage A of the block waits for the copy on the device

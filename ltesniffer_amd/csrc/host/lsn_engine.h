@@ -81,6 +81,7 @@ struct Chunk {
   uint64_t gseq = 0;                 // global chunk number (SharedSeq turn taking)
   uint32_t trace_id = 0;             // chunk number inside its submit (LSN_TRACE)
   uint32_t update_meta_period = 0;   // of the submit this chunk belongs to
+  bool force_meta = false;           // SubframeWorker::prepare(updateMetaFormats = true) on the first subframe of this chunk (worker pool)
 };
 
 // one stream + its device/host arenas for PDSCH decode launches
@@ -150,10 +151,17 @@ public:
   int setCell(const lsn_cell_t& cell);
   bool hasCell() const { return cell_set; }
   int process(const void* d_iq, uint32_t nsf, uint32_t start_tti, uint32_t update_meta_period, hipStream_t stream);
-  int submit(const void* d_iq, uint32_t nsf, uint32_t start_tti, uint32_t update_meta_period, hipStream_t stream);
+  int submit(const void* d_iq, uint32_t nsf, uint32_t start_tti, uint32_t update_meta_period, hipStream_t stream, bool force_meta_first = false);
+  // `nrows` = nsf x antennas rows of one subframe each (sflen samples), `row_pitch` bytes apart in PINNED host memory (the worker pool's slab:
+  // SubframeBuffer keeps 3 SF_LEN per antenna): one strided copy into the staging ring, then submit.  `copied` (optional) is recorded behind the
+  // copy: the caller may overwrite the rows once it has completed.  At most max_batch subframes.
+  int submitHostRows(const void* host_rows, size_t row_pitch, uint32_t nsf, uint32_t start_tti, bool force_meta_first, hipEvent_t copied);
   int wait();
   uint64_t submitMark() { std::unique_lock<std::mutex> lk(mtx); return chunks_expected; }            // position of the last submitted chunk
-  void waitMark(uint64_t mark) { std::unique_lock<std::mutex> lk(mtx); cv_done.wait(lk, [&] { return seq_written >= mark || !commit_error.empty(); }); }
+  // chunks up to `mark` have finished stage A: nothing reads their IQ block any more in DL mode (UL_MODE keeps it for the PRACH detector -> waitMark)
+  void waitStageAMark(uint64_t mark) { std::unique_lock<std::mutex> lk(mtx); cv_done.wait(lk, [&] { return seq_a_done >= mark || stop; }); }
+  void waitIqConsumed(uint64_t mark) { if (cfg.sniffer_mode == 1) waitMark(mark); else waitStageAMark(mark); }
+  void waitMark(uint64_t mark) { std::unique_lock<std::mutex> lk(mtx); cv_done.wait(lk, [&] { return seq_written >= mark || stop; }); }
   int mibDecode(const void* iq, bool on_device, lsn_mib_t* out, float* llr_raw480);
   int processFile(const char* path, const lsn_file_cfg_t& fc, uint32_t start_tti, uint64_t max_subframes, uint32_t update_meta_period,
                   uint64_t* subframes_done);
@@ -176,7 +184,7 @@ public:
   void uploadUlStatic();   // tables of the uplink OFDM demodulator that do not depend on SIB2
   bool getUlConfig(lsn_ul_cfg_t* u, lsn_prach_cfg_t* p, Sib2Config* sib) const;
   bool sib2Learned() const { return sib2_learned; }
-  int trackedModUl(uint16_t rnti) const { return ulmod.empty() ? 0 : (int)ulmod[rnti]; }
+  int trackedModUl(uint16_t rnti) { std::lock_guard<std::mutex> lk(mcs_mtx); return ulmod.empty() ? 0 : (int)ulmod[rnti]; }
   int puschDecode(const void* ul_iq, bool on_device, uint32_t nsf, uint32_t start_tti, const lsn_pusch_grant_t* grants, uint32_t ngrants,
                   lsn_pusch_result_t* results, uint8_t* payloads, size_t payload_cap);
   long tapUl(int what, uint32_t index, void* out, size_t cap);
@@ -243,7 +251,7 @@ private:
   void* d_iq_staging = nullptr;
   hipStream_t copy_stream = nullptr;          // host -> staging copies of processHost
   hipEvent_t copy_done[3] = {};
-  uint64_t peer_marks[12] = {};               // submitFrom: staging slot -> mark of the chunk that used it last
+  uint64_t peer_marks[12] = {};               // submitFrom / submitHostRows: staging slot -> mark of the chunk that used it last
   uint32_t peer_slot = 0;
   size_t staging_sf = 0;
   Chunk chunks[NSLOTS];
@@ -251,6 +259,7 @@ private:
   static constexpr int NSTREAM_A = 4;        // stage A of consecutive chunks overlaps on the GPU (kernels of one stream serialise)
   hipStream_t stream_a[NSTREAM_A] = {};
   hipEvent_t ev_in = nullptr;
+  hipEvent_t peer_ev[16] = {};                 // submitFrom: "source block ready" events, one per source device (created on that device)
   std::unique_ptr<FalconSearch>& search = sh->search;
   MCSTracking& mcs_tracking = sh->mcs_tracking;
   std::atomic<float>& default_p_a = sh->default_p_a;
@@ -279,7 +288,7 @@ public:
 private:
   // front thread: launches stage A chunk after chunk, hands finished chunks to the search (caller) thread
   std::thread front_thread;
-  struct FrontJob { const void* d_iq = nullptr; uint32_t nsf_total = 0, start_tti = 0, update_meta_period = 0; uint64_t gseq0 = 0; };
+  struct FrontJob { const void* d_iq = nullptr; uint32_t nsf_total = 0, start_tti = 0, update_meta_period = 0; uint64_t gseq0 = 0; bool force_meta = false; };
   std::deque<FrontJob> front_jobs;            // submits not yet cut into chunks (front thread)
   uint64_t chunks_expected = 0;               // chunks of all submits so far; wait() returns when as many have been written
   std::thread search_thread;                  // stage B: the sequential FALCON search, chunk after chunk
@@ -300,6 +309,7 @@ private:
   std::deque<Chunk*> write_queue;
   std::condition_variable cv_write;
   uint64_t seq_written = 0;
+  uint64_t seq_a_done = 0;                      // chunks whose stage A has completed (front thread, in submission order)
   uint64_t slot_counter = 0;                    // chunks acquired so far (front thread)
   uint64_t seq_pushed = 0, seq_committed = 0;  // chunks queued / committed (commit order = queue order)
   std::mutex mtx;

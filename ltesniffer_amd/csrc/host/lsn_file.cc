@@ -154,7 +154,7 @@ int Engine::processFile(const char* path, const lsn_file_cfg_t& fc, uint32_t sta
               const double tr0 = tnow();
               if (hipHostRegister(lo, len, hipHostRegisterDefault) == hipSuccess) { s.reg = lo; src = b; }
               if (fdebug) fprintf(stderr, "lsn_file: block at %.1f ms: touch %.1f ms, register %.1f ms (%s)\n", tb0 - t_begin, tr0 - tb0, tnow() - tr0, src ? "ok" : "failed");
-              else {  // this mapping cannot be page-locked: copy through pinned buffers from here on
+              if (!src) {  // this mapping cannot be page-locked: copy through pinned buffers from here on
                 (void)hipGetLastError();
                 use_mmap = false;
               }

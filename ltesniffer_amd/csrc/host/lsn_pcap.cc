@@ -26,7 +26,14 @@ struct lsn_pcap {
   }
   // order-sensitive 64-bit digest of the record stream without the timestamps (record length, 19-byte MAC-LTE context, PDU):
   // 8 bytes per multiply, the stream position is mixed in through the chaining
-  void mix(const uint8_t* d, size_t n)
+  // per-block digests (lsn_pcap_set_digest_blocks): the stream cut every `blk_period` subframes from the TTI `blk_origin`, each block
+  // hashed on its own chain - a long stream is then comparable piecewise with a reference that was produced elsewhere
+  struct Blk { uint64_t digest = 0x9E3779B97F4A7C15ull, nbytes = 0; uint32_t nrec = 0; };
+  std::vector<Blk> blks;
+  uint32_t blk_period = 0, blk_origin = 0;
+  int64_t blk_last = -1;   // unwrapped subframe number (since the origin) of the latest record
+  void mix(const uint8_t* d, size_t n) { mixInto(digest, nbytes, d, n); }
+  static void mixInto(uint64_t& digest, uint64_t& nbytes, const uint8_t* d, size_t n)
   {
     uint64_t h = digest;
     size_t i = 0;
@@ -107,6 +114,22 @@ int lsn_pcap_write(lsn_pcap_t* p, const lsn_pdu_ctx_t* c, const uint8_t* pdu, ui
   p->mix(h, sizeof(h));
   p->mix(pdu, len);
   p->nrec++;
+  if (p->blk_period) {
+    // the TTI counts modulo 10240: unwrap against the latest record (uplink records may step back a few subframes)
+    const int64_t ref = p->blk_last < 0 ? 0 : p->blk_last;
+    const int64_t want = ((int64_t)c->tti - (int64_t)p->blk_origin + 10240) % 10240;
+    int64_t d = (want - ref % 10240 + 10240 + 5120) % 10240 - 5120;
+    int64_t a = ref + d;
+    if (a < 0) a = 0;
+    if (a > p->blk_last) p->blk_last = a;
+    const size_t bi = (size_t)(a / p->blk_period);
+    if (p->blks.size() <= bi) p->blks.resize(bi + 1);
+    lsn_pcap::Blk& b = p->blks[bi];
+    lsn_pcap::mixInto(b.digest, b.nbytes, (const uint8_t*)&rec[2], 4);
+    lsn_pcap::mixInto(b.digest, b.nbytes, h, sizeof(h));
+    lsn_pcap::mixInto(b.digest, b.nbytes, pdu, len);
+    b.nrec++;
+  }
   return LSN_SUCCESS;
 }
 
@@ -126,6 +149,25 @@ void lsn_pcap_reset(lsn_pcap_t* p)
   if (p->to_mem) { p->mem.clear(); p->header(); }
   p->nrec = 0;
   p->digest = 0x9E3779B97F4A7C15ull; p->nbytes = 0;
+  p->blks.clear(); p->blk_last = -1;
+}
+void lsn_pcap_set_digest_blocks(lsn_pcap_t* p, uint32_t subframes_per_block, uint32_t origin_tti)
+{
+  if (!p) return;
+  std::lock_guard<std::mutex> lk(p->mtx);
+  p->blk_period = subframes_per_block; p->blk_origin = origin_tti % 10240;
+  p->blks.clear(); p->blk_last = -1;
+}
+uint32_t lsn_pcap_block_digests(lsn_pcap_t* p, uint64_t* digests, uint32_t* nof_records, uint32_t cap)
+{
+  if (!p) return 0;
+  std::lock_guard<std::mutex> lk(p->mtx);
+  const uint32_t n = (uint32_t)p->blks.size();
+  for (uint32_t i = 0; i < n && i < cap; i++) {
+    if (digests) digests[i] = p->blks[i].digest;
+    if (nof_records) nof_records[i] = p->blks[i].nrec;
+  }
+  return n;
 }
 void lsn_pcap_set_store(lsn_pcap_t* p, int on) { if (p) p->store = on != 0; }
 int lsn_pcap_digest(lsn_pcap_t* p, uint64_t* digest, uint64_t* nbytes)

@@ -70,7 +70,9 @@ void Engine::ulAgeDatabase()
 
 void Engine::commitChunkUl(Chunk& ch, JobRunner& r)
 {
-  if (ulmod.empty()) { ulmod.assign(65536, 0); ul_uecfg.assign(65536, UeSpecConfig()); ul_time.assign(65536, 0); ul_active.assign(65536, 0); ul_success.assign(65536, 0); }
+  // (the tracking vectors are sized in setCell; everything below that touches ulmod / ul_uecfg / ul_time / ul_active / ul_success / ulmod_count or
+  // mcs_tracking holds mcs_mtx, because the caller's timer - update_database_ul, nof_RNTI_member_ul, get_ue_config_rnti through the C ABI - runs
+  // on the caller's thread while chunks are in flight, LTESniffer_Core.cc:473-499)
   const uint32_t nsf = ch.nsf;
   std::vector<std::vector<PendingPdu>> out(nsf);            // records per subframe: downlink first, then uplink
   std::vector<std::vector<UlSchedGrant>> lists(nsf);        // PUSCH grants to try in each subframe
@@ -254,6 +256,7 @@ void Engine::commitChunkUl(Chunk& ch, JobRunner& r)
   // ---- phase 2: three waves, predicted with the tracking state as of now ----
   for (int wave = 0; wave < 3; wave++) {
     std::vector<Attempt> batch;
+    std::unique_lock<std::mutex> mcs_lk(mcs_mtx);
     for (uint32_t sf = 0; sf < nsf; sf++)
       for (uint32_t i = 0; i < lists[sf].size(); i++) {
         const UlSchedGrant& m = lists[sf][i];
@@ -268,11 +271,13 @@ void Engine::commitChunkUl(Chunk& ch, JobRunner& r)
         a[wave].sf = sf; a[wave].idx = i; a[wave].uci = uci;
         batch.push_back(a[wave]);
       }
+    mcs_lk.unlock();
     run_batch(batch);
   }
   // ---- phase 3 (sequential): the exact decision logic, records in (tti, downlink, uplink) order ----
   for (uint32_t sf = 0; sf < nsf; sf++) {
     const uint32_t tti = ch.ctx[sf].tti;  // already reduced mod 10240 (SubframeCtx::reset)
+    std::lock_guard<std::mutex> mcs_lk(mcs_mtx);  // per subframe, as commitChunk does
     if (cfg.mcs_tracking_mode && mcs_update_period && commit_sf_cnt && (commit_sf_cnt % mcs_update_period) == 0) ulAgeDatabase();  // LTESniffer_Core.cc:473-499
     for (auto& su : setups[sf]) {  // the downlink part of the subframe ran first (SubframeWorker.cc:299-347): update_default_ue_config / update_ue_config_rnti
       if (!mcs_tracking.check_default_config()) mcs_tracking.update_default_ue_config(su.second);
@@ -313,7 +318,7 @@ void Engine::commitChunkUl(Chunk& ch, JobRunner& r)
     for (auto& p : out[sf]) {
       if (p.ul) {  // write_ul_crnti, PcapWriter.cc:172-175: the payload joins the chunk's arena so that the writer thread finds it there
         r.perf.nof_pdus++;
-        if (sink) {
+        if (sink || api_mode >= 0) {
           lsn_pdu_ctx_t c{}; c.tti = tti; c.rnti = p.rnti; c.direction = 0; c.rnti_type = 3; c.crc_ok = 1;
           const size_t off = ch.h_payload.size();
           ch.h_payload.insert(ch.h_payload.end(), p.own.begin(), p.own.end());

@@ -20,6 +20,22 @@ def gen_subframes(sc, n, **txkw):
     return tti0, iq, truth
 
 
+def gen_capture(sc, n, threads=None, **txkw):
+    """the same capture as gen_subframes(sc, n)[:2] rendered by `threads` workers (txg_generate): -> (tti0, iq[n, rx, sf_len])"""
+    import ctypes as C
+    import os
+    tx = TxGen(**txkw, **sc)
+    lib = tx.lib
+    lib.txg_generate.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_int]
+    lib.txg_generate.restype = C.c_int
+    iq = np.empty((n, sc["nof_rx"], tx.sf_len), dtype=np.complex64)
+    if threads is None:
+        threads = max(1, min(32, len(os.sched_getaffinity(0))))
+    tti0 = lib.txg_generate(C.byref(tx.cfg), n, iq.ctypes.data, int(threads))
+    assert tti0 >= 0, "txg_generate failed"
+    return tti0, iq
+
+
 def run_oracle(sc, tti0, iq, update_meta_period=0, taps=True, mcs_update_interval=None, **okw):
     ow = OracleWorker(sc["nof_prb"], sc["nof_ports"], sc["cell_id"], sc["nof_rx"], sc["phich_ng_x6"], **okw)
     if mcs_update_interval is not None:

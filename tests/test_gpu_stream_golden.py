@@ -1,0 +1,109 @@
+"""GPU: the HIP path over the head of the gated cfg3 stream must write, block by block, what the cached CPU-oracle stream holds
+(tests/golden/cfg3_stream_oracle.json) - through the resident path, host buffers, the file source and the reference's worker pool."""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import ltesniffer_amd as la
+from lsn_testlib import scenario  # noqa: F401
+from parity import gen_capture
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import make_cfg3_golden as mg  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden", "cfg3_stream_oracle.json")
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not os.path.exists(GOLDEN), reason="no cached oracle stream")]
+N = 2400
+
+
+@pytest.fixture(scope="module")
+def head():
+    g = json.load(open(GOLDEN))
+    sc, nsf, blk, meta = mg.cfg3_stream()
+    tti0, iq = gen_capture(sc, N)
+    assert mg.capture_hash(iq)[1][:2] == g["capture_xxh3_64_per_1000"][:2]
+    return g, sc, blk, meta, tti0, iq
+
+
+def _phy(sc, **kw):
+    w = la.PcapWriter(None)
+    w.set_store(False)
+    phy = la.Phy(nof_rx_antennas=sc["nof_rx"], pcapwriter=w, **kw)
+    assert phy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"])
+    return phy, w
+
+
+def _check(w, g, blk, n):
+    b = w.block_digests()[:n // blk]
+    assert len(b) == n // blk
+    bad = [j for j, (d, c) in enumerate(b) if ["%016x" % d, c] != g["blocks"][j]]
+    assert not bad, "blocks %s differ from the oracle's (first: %s vs %s)" % (bad[:5], b[bad[0]], g["blocks"][bad[0]])
+
+
+def test_resident_pipelined_submit(head):
+    import torch
+    g, sc, blk, meta, tti0, iq = head
+    phy, w = _phy(sc, max_batch=300)
+    w.set_digest_blocks(blk, tti0)
+    d = torch.from_numpy(iq.view(np.float32)).to("cuda:0")
+    for a in range(0, N, 800):
+        phy.submit_device(d.data_ptr() + a * iq[0].nbytes, 800, (tti0 + a) % 10240, meta)
+    phy.wait()
+    _check(w, g, blk, N)
+    phy.close()
+
+
+def test_host_buffers_and_file(head, tmp_path):
+    g, sc, blk, meta, tti0, iq = head
+    phy, w = _phy(sc, max_batch=256)
+    w.set_digest_blocks(blk, tti0)
+    phy.process_host(iq, tti0, meta)
+    _check(w, g, blk, N)
+    phy.close()
+    path = str(tmp_path / "cap.cf32")
+    np.ascontiguousarray(np.transpose(iq, (0, 2, 1))).tofile(path)
+    phy, w = _phy(sc, max_batch=256)
+    w.set_digest_blocks(blk, tti0)
+    assert phy.process_file(path, start_tti=tti0, update_meta_period=meta) == N
+    _check(w, g, blk, N)
+    phy.close()
+
+
+@pytest.mark.parametrize("threads,workers,batch", [(1, 64, 24), (3, 700, 256)])
+def test_worker_pool_driven_like_ltesniffer_core(head, threads, workers, batch):
+    g, sc, blk, meta, tti0, iq = head
+    pd = C.CDLL(os.path.join(ROOT, "tools", "pool_driver", "_build", "libpool_driver.so"))
+    pd.pool_drive.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.POINTER(C.c_double)]
+    phy, w = _phy(sc, nof_workers=workers, max_batch=batch)
+    w.set_digest_blocks(blk, tti0)
+    secs = C.c_double(0)
+    assert pd.pool_drive(phy._h, iq.ctypes.data, N, sc["nof_rx"], iq.shape[2], tti0, meta, threads, C.byref(secs)) == 0
+    _check(w, g, blk, N)
+    phy.close()
+
+
+def test_live_mode_pool_is_lossy_but_ordered(head):
+    """getAvailImmediate (LTESniffer_Core.cc:439): no worker -> the subframe is dropped; what was queued comes out in order and complete"""
+    g, sc, blk, meta, tti0, iq = head
+    phy, w = _phy(sc, nof_workers=4, max_batch=4)
+    w.set_digest_blocks(blk, tti0)
+    queued = 0
+    for i in range(200):
+        wk = phy.getAvailImmediate()
+        if wk is None:
+            continue
+        b = wk.getBuffers()
+        for rx in range(sc["nof_rx"]):
+            b[rx][:iq.shape[2]] = iq[i, rx]
+        t = tti0 + i
+        wk.prepare(t % 10, (t // 10) % 1024, i % meta == 0)
+        phy.putPending(wk)
+        queued += 1
+    phy.joinPending()
+    assert 0 < queued <= 200 and w.nof_records() > 0
+    phy.close()

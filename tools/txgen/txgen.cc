@@ -10,6 +10,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <thread>
+#include <atomic>
 
 typedef std::complex<float> cf;
 typedef std::vector<uint8_t> bits_t;
@@ -24,6 +26,7 @@ struct Rng {
   uint32_t u32() { return (uint32_t)(next() >> 32); }
   uint32_t below(uint32_t n) { return n ? (uint32_t)(((uint64_t)u32() * n) >> 32) : 0; }
   double uni() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); }
+  void gauss2(double& a, double& b) { double u1 = uni(), u2 = uni(); if (u1 < 1e-300) u1 = 1e-300; const double r = std::sqrt(-2.0 * std::log(u1)), ph = 6.283185307179586 * u2; a = r * std::cos(ph); b = r * std::sin(ph); }
   double gauss() { double u1 = uni(), u2 = uni(); if (u1 < 1e-300) u1 = 1e-300; return std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2); }
 };
 
@@ -261,6 +264,8 @@ struct txg {
   std::vector<Ue> ues;
   RegInfo regs;
   uint32_t tti;
+  uint64_t count = 0;      // subframes produced so far: seeds the noise of each subframe (independent of the scheduling stream)
+  bool plan_only = false;  // txg_generate workers: walk the scheduler (every draw of `rng`) without synthesising the waveform
   cf h[2][2];
   explicit txg(const txg_cfg_t& cfg) : c(cfg), rng(cfg.seed) {}
 };
@@ -741,6 +746,12 @@ extern "C" int txg_next(txg_t* g, float* iq, txg_pdu_t* pdus, int max_pdus, uint
     if (npdu < max_pdus) { txg_pdu_t& pd = pdus[npdu++]; pd = txg_pdu_t{gr.rnti, 0, (uint8_t)gr.L, (uint16_t)gr.ncce, tti, 0, (uint32_t)start /* UL grants: offset = first PRB */, 0, 0, 0, 1, (uint32_t)Lc, gr.mcs[0], gr.cqi_req, (uint32_t)(gr.hop_bits + 1)}; }
   }
 
+  if (g->plan_only) {  // scheduler state advanced exactly as a rendering call would (the waveform below draws nothing from `rng`)
+    if (msg4_ue >= 0) g->ues[msg4_ue].p_a_db = msg4_p_a;
+    g->tti = (g->tti + 1) % 10240; g->count++;
+    return npdu;
+  }
+
   // ---- PDCCH ----
   {
     uint32_t nbits = 8 * g->regs.nregs[cfi - 1];
@@ -829,6 +840,7 @@ extern "C" int txg_next(txg_t* g, float* iq, txg_pdu_t* pdus, int max_pdus, uint
   }
   double sigma = std::sqrt(std::pow(10.0, -c.snr_db / 10.0) / (2.0 * N));  // per real dimension, time domain
   double fs = 15000.0 * N;
+  Rng noise((c.seed << 20) ^ ((g->count + 1) * 0xD6E8FEB86659FD93ull));  // per-subframe stream: captures can be rendered in parallel (txg_generate)
   for (uint32_t r = 0; r < c.nof_rx; r++) {
     float* out = iq + (size_t)r * sflen * 2;
     int dly = (r == 1) ? (int)c.delay_samples : 0;
@@ -836,12 +848,39 @@ extern "C" int txg_next(txg_t* g, float* iq, txg_pdu_t* pdus, int max_pdus, uint
       std::complex<double> y(0, 0);
       for (int p = 0; p < P; p++) { int m = n - dly; cf v = m >= 0 ? tx[p][m] : cf(0, 0); y += std::complex<double>(g->h[r][p]) * std::complex<double>(v); }
       if (c.cfo_hz != 0) { double ph = 2 * M_PI * c.cfo_hz * ((double)n + (double)(tti - c.start_tti) * sflen) / fs; y *= std::complex<double>(std::cos(ph), std::sin(ph)); }
-      out[2 * n] = (float)(y.real() + sigma * g->rng.gauss());
-      out[2 * n + 1] = (float)(y.imag() + sigma * g->rng.gauss());
+      double nr, ni; noise.gauss2(nr, ni);
+      out[2 * n] = (float)(y.real() + sigma * nr);
+      out[2 * n + 1] = (float)(y.imag() + sigma * ni);
     }
   }
-  g->tti = (g->tti + 1) % 10240;
+  g->tti = (g->tti + 1) % 10240; g->count++;
   return npdu;
+}
+
+extern "C" void txg_set_plan_only(txg_t* g, int on) { g->plan_only = on != 0; }
+
+// A whole capture [nsf][rx][15 N] cf32 rendered by `nthreads` workers: every worker walks the complete schedule (cheap) and synthesises the
+// subframes of its blocks; the result is the one nsf consecutive txg_next calls produce.  Returns the TTI of the first subframe, or -1.
+extern "C" int txg_generate(const txg_cfg_t* cfg, uint32_t nsf, float* iq, int nthreads) {
+  if (fft_size(cfg->nof_prb) < 0 || !iq) return -1;
+  const int T = std::max(1, nthreads);
+  const uint32_t blk = 25;
+  const size_t sf_floats = (size_t)cfg->nof_rx * 15u * (size_t)fft_size(cfg->nof_prb) * 2u;
+  std::vector<std::thread> th;
+  std::atomic<int> bad{0};
+  for (int t = 0; t < T; t++) th.emplace_back([&, t] {
+    txg_t* g = txg_new(cfg);
+    if (!g) { bad++; return; }
+    std::vector<txg_pdu_t> pdus(128);
+    std::vector<uint8_t> pbuf(1u << 19);
+    for (uint32_t i = 0; i < nsf; i++) {
+      g->plan_only = ((i / blk) % (uint32_t)T) != (uint32_t)t;
+      txg_next(g, iq + (size_t)i * sf_floats, pdus.data(), 128, pbuf.data(), (int)pbuf.size());
+    }
+    txg_free(g);
+  });
+  for (auto& x : th) x.join();
+  return bad.load() ? -1 : (int)cfg->start_tti;
 }
 
 // =====================================================================================================
