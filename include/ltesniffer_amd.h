@@ -279,6 +279,8 @@ typedef struct {
   uint32_t cyclic_shift;    /* SIB2 cyclicShift */
   uint32_t delta_ss;        /* SIB2 groupAssignmentPUSCH */
   uint32_t hopping_offset;  /* SIB2 pusch-HoppingOffset (ul_cfg.hopping.n_rb_ho, SubframeWorker.cc:271-273): second-slot position of type-1 hopping grants */
+  uint32_t group_hopping_enabled;     /* SIB2 ul-ReferenceSignalsPUSCH.groupHoppingEnabled (ULSchedule.cc:143-146): sequence group per slot, 36.211 5.5.1.3 */
+  uint32_t sequence_hopping_enabled;  /* ... sequenceHoppingEnabled: base sequence number per slot for >= 6 PRB, 36.211 5.5.1.4 */
 } lsn_ul_cfg_t;
 typedef struct {
   uint32_t sf;       /* subframe index inside ul_iq (tti = start_tti + sf) */
@@ -381,7 +383,9 @@ typedef struct {
   uint64_t nof_turbo_iterations_run;                     /* iterations executed (equals nof_turbo_iterations) */
   uint64_t nof_ondemand_commit[4];                       /* decodes created at commit: [0] p-a changed, [1] table known at commit but unknown when planned or vice versa, [2] no job planned at all, [3] other */
   double ms_ondemand_commit;                             /* commit-thread time inside those decodes */
-  uint64_t nof_pusch_2prb_skipped;                       /* UL_MODE: valid 2-PRB PUSCH grants that could not be attempted (36.211 Table 5.5.1.2-2 not built in) */
+  uint64_t nof_pusch_2prb_skipped;                       /* (always 0 since round 3: 2-PRB grants are decoded) */
+  uint64_t nof_pusch_on_unverified_dmrs;                 /* UL_MODE: PUSCH attempts on 1- / 2-PRB allocations, whose reference signals come from the restated (structure-checked, not text-verified) 36.211 Tables 5.5.1.2-1 / -2 */
+  uint64_t nof_tb_on_derived_tbs;                        /* transport-block decodes whose size came from the DERIVED TBS rows I_TBS 27..33 (spec/gen_tables.py): a real capture that fails exactly there points at the table */
 } lsn_perf_t;
 int lsn_phy_get_perf(lsn_phy_t* phy, lsn_perf_t* out);
 enum { LSN_K_OFDM = 0, LSN_K_CHEST, LSN_K_CHEST_FIN, LSN_K_PCFICH, LSN_K_PDCCH_LLR, LSN_K_CCE_POWER, LSN_K_VITERBI,

@@ -132,11 +132,12 @@ class Perf(C.Structure):
                 ("nof_cb_decodes", C.c_uint64), ("nof_turbo_iterations", C.c_uint64), ("nof_candidates_decoded", C.c_uint64),
                 ("nof_ondemand_decodes", C.c_uint64), ("nof_pdus", C.c_uint64), ("ms_search_core", C.c_double), ("ms_rar", C.c_double), ("turbo_cyc_rm", C.c_uint64),
                 ("turbo_cyc_map", C.c_uint64), ("turbo_cyc_out", C.c_uint64), ("ms_wait_front", C.c_double), ("ms_wait_slot", C.c_double), ("ms_drain", C.c_double),
-                ("nof_turbo_iterations_run", C.c_uint64), ("nof_ondemand_commit", C.c_uint64 * 4), ("ms_ondemand_commit", C.c_double), ("nof_pusch_2prb_skipped", C.c_uint64)]
+                ("nof_turbo_iterations_run", C.c_uint64), ("nof_ondemand_commit", C.c_uint64 * 4), ("ms_ondemand_commit", C.c_double), ("nof_pusch_2prb_skipped", C.c_uint64), ("nof_pusch_on_unverified_dmrs", C.c_uint64), ("nof_tb_on_derived_tbs", C.c_uint64)]
 
 
 class UlCfg(C.Structure):
-    _fields_ = [("cyclic_shift", C.c_uint32), ("delta_ss", C.c_uint32), ("hopping_offset", C.c_uint32)]
+    _fields_ = [("cyclic_shift", C.c_uint32), ("delta_ss", C.c_uint32), ("hopping_offset", C.c_uint32), ("group_hopping_enabled", C.c_uint32),
+                ("sequence_hopping_enabled", C.c_uint32)]
 
 
 class PuschGrant(C.Structure):
@@ -505,8 +506,8 @@ class Phy:
         return int(done.value)
 
     # ---- uplink ----
-    def setUlConfig(self, cyclic_shift, delta_ss, hopping_offset=0):
-        u = UlCfg(cyclic_shift, delta_ss, hopping_offset)
+    def setUlConfig(self, cyclic_shift, delta_ss, hopping_offset=0, group_hopping=0, sequence_hopping=0):
+        u = UlCfg(cyclic_shift, delta_ss, hopping_offset, int(group_hopping), int(sequence_hopping))
         return lib().lsn_phy_set_ul_config(self._h, C.byref(u)) == LSN_SUCCESS
 
     def setApiMode(self, api_mode, api_pcapwriter=None):
@@ -529,7 +530,8 @@ class Phy:
         u, s, f = UlCfg(), Sib2(), C.c_uint32(0)
         if lib().lsn_phy_get_ul_config(self._h, C.byref(u), C.byref(s), C.byref(f)) != 1:
             return None
-        return dict(cyclic_shift=u.cyclic_shift, delta_ss=u.delta_ss, hopping_offset=u.hopping_offset, from_sib2=bool(f.value),
+        return dict(cyclic_shift=u.cyclic_shift, delta_ss=u.delta_ss, hopping_offset=u.hopping_offset, group_hopping=u.group_hopping_enabled,
+                    sequence_hopping=u.sequence_hopping_enabled, from_sib2=bool(f.value),
                     sib2=s.as_dict() if f.value else None)
 
     def pusch_decode(self, ul_iq, start_tti, grants):

@@ -577,6 +577,7 @@ int lsn_phy_get_perf(lsn_phy_t* phy, lsn_perf_t* out)
     out->turbo_cyc_out += p.turbo_cyc_out; out->ms_wait_front += p.ms_wait_front; out->ms_wait_slot += p.ms_wait_slot; out->ms_drain = std::max(out->ms_drain, p.ms_drain);
     out->nof_turbo_iterations_run += p.nof_turbo_iterations_run; out->ms_ondemand_commit += p.ms_ondemand_commit;
     for (int k = 0; k < 4; k++) out->nof_ondemand_commit[k] += p.nof_ondemand_commit[k];
+    out->nof_pusch_on_unverified_dmrs += p.nof_pusch_on_unverified_dmrs; out->nof_tb_on_derived_tbs += p.nof_tb_on_derived_tbs;
   }
   return LSN_SUCCESS;
 }

@@ -195,6 +195,7 @@ Engine::~Engine()
     if (sa) (void)hipStreamDestroy(sa);
   if (ev_in) (void)hipEventDestroy(ev_in);
   for (auto& e : peer_ev) if (e) (void)hipEventDestroy(e);
+  for (auto& e : ev_pool) if (e) (void)hipEventDestroy(e);
   if (copy_stream) (void)hipStreamDestroy(copy_stream);
   for (auto& e : copy_done) if (e) (void)hipEventDestroy(e);
 }
@@ -248,6 +249,8 @@ void Engine::mergePerf(const lsn_perf_t& p)
   for (int k = 0; k < 4; k++) perf.nof_ondemand_commit[k] += p.nof_ondemand_commit[k];
   perf.ms_ondemand_commit += p.ms_ondemand_commit;
   perf.nof_pusch_2prb_skipped += p.nof_pusch_2prb_skipped;
+  perf.nof_pusch_on_unverified_dmrs += p.nof_pusch_on_unverified_dmrs;
+  perf.nof_tb_on_derived_tbs += p.nof_tb_on_derived_tbs;
   for (int k = 0; k < 16; k++) { perf.kernel_ms[k] += p.kernel_ms[k]; perf.kernel_launches[k] += p.kernel_launches[k]; }
 }
 
@@ -542,6 +545,7 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
       pay_n += (wp + 15) & ~15u;
       tbrefs.push_back(ref);
       pf.nof_tb_decodes++;
+      if (tbs_from_derived_rows(tb.tbs, g.nof_prb)) pf.nof_tb_on_derived_tbs++;
       pf.nof_cb_decodes += (uint64_t)s.C;
       pf.algo_bytes += 2ull * (uint64_t)tb.nof_bits * 2ull + (uint64_t)tb.tbs / 8ull;
     }
@@ -1158,11 +1162,16 @@ void Engine::frontLoop()
       ch.trace_id = ci;
       trace(1, TR_ACQ_END, ci);
       try {
+        if (job.ready) HIP_CHECK(hipStreamWaitEvent(ch.st_a, job.ready, 0));
         launchStageA(ch, (const uint8_t*)job.d_iq + (size_t)base * sf_stride);
       } catch (const std::exception& ex) {
         ch.err = ex.what();
       }
       inflight.push_back(&ch);
+    }
+    if (job.ready) {  // every chunk of the block has its wait queued: the event can carry another block
+      std::unique_lock<std::mutex> lk(mtx);
+      ev_pool.push_back(job.ready);
     }
   }
 }
@@ -1271,13 +1280,21 @@ int Engine::submit(const void* d_iq, uint32_t nsf_total, uint32_t start_tti, uin
       t_batch = now_ms();
       batch_open = true;
     }
-    // the caller's stream orders the IQ buffer: stage A starts after everything queued on it so far
-    HIP_CHECK(hipEventRecord(ev_in, stream));
-    for (auto& sa : stream_a) HIP_CHECK(hipStreamWaitEvent(sa, ev_in, 0));
+    // the caller's stream orders the IQ buffer: stage A of THIS block's chunks starts after everything queued on that stream so far.  The event
+    // travels with the block and is waited for by the stage-A stream a chunk is launched on, at launch time (front thread) - a wait inserted
+    // here into all stage-A streams would also hold back the chunks of EARLIER blocks that are launched after this call (with host -> device
+    // copies queued several blocks ahead that serialised copy and compute: the 27 GB/s ingest of round 2).
+    hipEvent_t ev = nullptr;
+    {
+      std::unique_lock<std::mutex> lk(mtx);
+      if (!ev_pool.empty()) { ev = ev_pool.back(); ev_pool.pop_back(); }
+    }
+    if (!ev) HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    HIP_CHECK(hipEventRecord(ev, stream));
     const uint32_t nchunks = (nsf_total + max_batch - 1) / max_batch;
     {
       std::unique_lock<std::mutex> lk(mtx);
-      front_jobs.push_back({d_iq, nsf_total, start_tti, update_meta_period, sh->next_gseq.fetch_add(nchunks), force_meta_first});
+      front_jobs.push_back({d_iq, nsf_total, start_tti, update_meta_period, sh->next_gseq.fetch_add(nchunks), force_meta_first, ev});
       chunks_expected += nchunks;
     }
     cv_front.notify_one();

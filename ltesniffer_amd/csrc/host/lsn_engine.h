@@ -259,6 +259,7 @@ private:
   static constexpr int NSTREAM_A = 4;        // stage A of consecutive chunks overlaps on the GPU (kernels of one stream serialise)
   hipStream_t stream_a[NSTREAM_A] = {};
   hipEvent_t ev_in = nullptr;
+  std::vector<hipEvent_t> ev_pool;            // recycled "block ready" events (guarded by mtx)
   hipEvent_t peer_ev[16] = {};                 // submitFrom: "source block ready" events, one per source device (created on that device)
   std::unique_ptr<FalconSearch>& search = sh->search;
   MCSTracking& mcs_tracking = sh->mcs_tracking;
@@ -288,7 +289,7 @@ public:
 private:
   // front thread: launches stage A chunk after chunk, hands finished chunks to the search (caller) thread
   std::thread front_thread;
-  struct FrontJob { const void* d_iq = nullptr; uint32_t nsf_total = 0, start_tti = 0, update_meta_period = 0; uint64_t gseq0 = 0; bool force_meta = false; };
+  struct FrontJob { const void* d_iq = nullptr; uint32_t nsf_total = 0, start_tti = 0, update_meta_period = 0; uint64_t gseq0 = 0; bool force_meta = false; hipEvent_t ready = nullptr; /* "block is in place" on the caller's stream */ };
   std::deque<FrontJob> front_jobs;            // submits not yet cut into chunks (front thread)
   uint64_t chunks_expected = 0;               // chunks of all submits so far; wait() returns when as many have been written
   std::thread search_thread;                  // stage B: the sequential FALCON search, chunk after chunk
@@ -338,6 +339,8 @@ private:
   bool decodeSib(Chunk& ch, JobRunner& r, uint32_t sf, Sib2Config& out, size_t& payload_off, uint32_t& len, uint8_t& tb);
   std::vector<int> ul_off;       // allocation size L -> offset into ul_base / ul_idft (-1: unsupported)
   uint32_t ul_npn[20] = {0};
+  uint32_t ul_base_stride = 0;   // cf32 per (u, v) variant of the base-sequence table
+  uint8_t ul_u[20] = {0}, ul_v[20] = {0};  // sequence group / base sequence number of the 20 slots (group / sequence hopping of SIB2)
   struct UlSchedGrant { uint16_t rnti = 0; PuschGrant g, g256; uint32_t n_dmrs = 0; bool hopping = false, is_rar = false; uint32_t nof_ack = 0; bool cqi_req = false; };
   std::map<uint32_t, std::vector<UlSchedGrant>> ul_sched, rar_sched;  // ULSchedule databases (touched in the commit turn only)
   std::vector<uint8_t> ulmod; uint32_t ulmod_count = 0;               // MCSTracking UL: 0 absent, 1 unknown, 2/3/4 = 16/64/256QAM max

@@ -194,6 +194,16 @@ static void distributed_vrb_to_prb(uint32_t nprb, bool gap2, uint32_t vrb, uint3
   prb_odd = (ob < Nt / 2 ? ob : ob + G - Nt / 2) + Nt * blk;
 }
 
+bool tbs_from_derived_rows(int tbs, uint32_t nof_prb)
+{
+  if (nof_prb < 1 || nof_prb > 110 || tbs <= 0) return false;
+  bool derived = false;
+  for (int r = 27; r < 34; r++) derived = derived || lsn_tbs_table[r][nof_prb - 1] == tbs;
+  if (!derived) return false;
+  for (int r = 0; r < 27; r++) if (lsn_tbs_table[r][nof_prb - 1] == tbs) return false;
+  return true;
+}
+
 bool ra_dl_grant_to_grant_prb_allocation(const Cell& cell, const DciDl& d, PdschGrant& g)
 {
   const uint32_t n = cell.nof_prb, P = ra_type0_P(n);

@@ -68,6 +68,8 @@ void dl_sniffer_ra_dl_dci_to_grant_both(const Cell& cell, uint32_t sf_idx, uint3
                                         PdschGrant& g256, bool& ok256);
 void dl_sniffer_grant_finish_both(const Cell& cell, uint32_t sf_idx, uint32_t cfi, const DciDl& dci, PdschGrant& g64, bool& ok64, PdschGrant& g256,
                                   bool& ok256);
+// true when `tbs` on `nof_prb` PRBs is a value only the DERIVED rows I_TBS 27..33 of spec/lte_tables.h hold (see spec/gen_tables.py)
+bool tbs_from_derived_rows(int tbs, uint32_t nof_prb);
 bool ra_dl_grant_to_grant_prb_allocation(const Cell& cell, const DciDl& dci, PdschGrant& g);
 bool ra_ul_dci_to_grant(const Cell& cell, const DciUl& dci, PuschGrant& g);
 // MAC RAR PDU (TS 36.321 6.1.5, 6.2.2, 6.2.3) -> one entry per sub-header (a sub-header without a body - backoff indicator - gives T-CRNTI 0,

@@ -69,24 +69,50 @@ int Engine::setUlConfig(const lsn_ul_cfg_t& u)
     (void)N;
     std::vector<cf32> ph(12), base, idft;
     for (int m = 0; m < 12; m++) { const double a = 2.0 * M_PI * m / 12.0; ph[m] = {(float)std::cos(a), (float)std::sin(a)}; }
-    const uint32_t fss = ((cell.id % 30u) + u.delta_ss) % 30u;  // group hopping off: u = f_ss^PUSCH, v = 0
+    const uint32_t fss = ((cell.id % 30u) + u.delta_ss) % 30u;  // f_ss^PUSCH
+    // Base sequences r_{u,v}(n) of every allocation size for all 30 sequence groups and both sequence numbers (36.211 5.5.1.1 / 5.5.1.2):
+    // variant (2 u + v) of size L starts at (2 u + v) * ul_base_stride + ul_off[L]; v = 1 only exists from 6 PRB on (else a copy of v = 0).
     ul_off.assign(111, -1);
+    uint32_t stride = 0;
     for (uint32_t L = 1; L <= cell.nof_prb; L++) {
-      if (!ul_valid_prb(L) || L == 2) continue;  // two PRB: 36.211 Table 5.5.1.2-2 is not reproduced
+      if (!ul_valid_prb(L)) continue;
+      ul_off[L] = (int)stride; stride += 12 * L;
+    }
+    ul_base_stride = stride;
+    base.resize((size_t)60 * stride);
+    for (uint32_t L = 1; L <= cell.nof_prb; L++) {
+      if (ul_off[L] < 0) continue;
       const int M = 12 * (int)L, Nzc = largest_prime_below(M);
-      ul_off[L] = (int)base.size();
-      const long long q = (long long)std::floor((double)Nzc * (double)(fss + 1) / 31.0 + 0.5);
-      for (int n = 0; n < M; n++) {
-        if (L == 1) {  // one PRB: the tabulated sequence exp(j phi(n) pi / 4) (Table 5.5.1.2-1, spec/lte_tables.h)
-          const double a = M_PI * (double)lsn_dmrs_phi12[fss % 30][n] / 4.0;
-          base.push_back({(float)std::cos(a), (float)std::sin(a)});
-          continue;
+      for (uint32_t uu = 0; uu < 30; uu++)
+        for (uint32_t vv = 0; vv < 2; vv++) {
+          cf32* dst = base.data() + (size_t)(2 * uu + vv) * stride + ul_off[L];
+          const double qb = (double)Nzc * (double)(uu + 1) / 31.0;
+          long long q = (long long)std::floor(qb + 0.5);
+          if (vv && M >= 72) q += ((long long)std::floor(2.0 * qb) & 1) ? -1 : 1;
+          for (int n = 0; n < M; n++) {
+            if (L <= 2) {  // one / two PRB: the tabulated sequences exp(j phi(n) pi / 4) (Tables 5.5.1.2-1 / -2, spec/lte_tables.h)
+              const double a = M_PI * (double)(L == 1 ? lsn_dmrs_phi12[uu][n] : lsn_dmrs_phi24[uu][n]) / 4.0;
+              dst[n] = {(float)std::cos(a), (float)std::sin(a)};
+              continue;
+            }
+            const long long m = n % Nzc;
+            const double a = M_PI * (double)((q * m * (m + 1)) % (2ll * Nzc)) / (double)Nzc;
+            dst[n] = {(float)std::cos(a), (float)(-std::sin(a))};
+          }
         }
-        const long long m = n % Nzc;
-        const double a = M_PI * (double)((q * m * (m + 1)) % (2ll * Nzc)) / (double)Nzc;
-        base.push_back({(float)std::cos(a), (float)(-std::sin(a))});
-      }
       for (int k = 0; k < M; k++) { const double a = 2.0 * M_PI * k / M; idft.push_back({(float)std::cos(a), (float)std::sin(a)}); }
+    }
+    // sequence group u(ns) and sequence number v(ns) of the 20 slots (5.5.1.3 / 5.5.1.4)
+    {
+      std::vector<uint8_t> cg(8 * 20 + 8), cs(32);
+      gold_sequence(cell.id / 30u, cg.data(), 8 * 20);
+      gold_sequence(((cell.id / 30u) << 5) + fss, cs.data(), 20);
+      for (uint32_t ns = 0; ns < 20; ns++) {
+        uint32_t fgh = 0;
+        if (u.group_hopping_enabled) { for (int i = 0; i < 8; i++) fgh += (uint32_t)cg[8 * ns + i] << i; fgh %= 30u; }
+        ul_u[ns] = (uint8_t)((fgh + fss) % 30u);
+        ul_v[ns] = (uint8_t)((!u.group_hopping_enabled && u.sequence_hopping_enabled) ? cs[ns] : 0);
+      }
     }
     uploadUlStatic();
     cd.ul_ph12 = upload_vec(dev_allocs, ph);
@@ -200,7 +226,11 @@ void Engine::puschDecodeGrid(const cf32* d_grid, uint32_t nsf, uint32_t start_tt
     d.sf = g.sf; d.n_prb = g.n_prb; d.n_prb2 = n_prb2; d.L_prb = g.L_prb; d.qm = g.mod;
     for (uint32_t sl = 0; sl < 2; sl++) d.ncs[sl] = (n_dmrs1[ul_cfg.cyclic_shift & 7] + n_dmrs2[g.n_dmrs & 7] + ul_npn[2 * sf_idx + sl]) % 12u;
     d.cinit = ((uint32_t)g.rnti << 14) | (sf_idx << 9) | cell.id;
-    d.base_off = (uint32_t)ul_off[g.L_prb]; d.idft_off = d.base_off;
+    for (uint32_t sl = 0; sl < 2; sl++) {
+      const uint32_t ns = 2 * sf_idx + sl, var = 2u * ul_u[ns] + (g.L_prb >= 6 ? ul_v[ns] : 0u);
+      (sl ? d.base_off1 : d.base_off) = var * ul_base_stride + (uint32_t)ul_off[g.L_prb];
+    }
+    d.idft_off = (uint32_t)ul_off[g.L_prb];
     d.hs_off = (uint32_t)hs_n; hs_n += 2 * M;
     d.llr_off = (uint32_t)llr_n; llr_n += ((size_t)G + 7) & ~(size_t)7;
     d.scale = 1.0f / sqrtf((float)M);

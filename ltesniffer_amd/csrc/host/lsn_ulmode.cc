@@ -93,9 +93,8 @@ void Engine::commitChunkUl(Chunk& ch, JobRunner& r)
       if (c.searched && decodeSib(ch, r, sf, s2, off, len, tb)) {
         out[sf].push_back({false, 'S', SIRNTI, tb, off, {}, len});
         // ULSchedule::set_config (ULSchedule.cc:140-158) + SubframeWorker.cc:256-282: DMRS, hopping offset, PRACH detector
-        if (s2.group_hopping_enabled || s2.sequence_hopping_enabled)
-          fprintf(stderr, "ltesniffer_amd: SIB2 enables group / sequence hopping of the PUSCH reference signal - not supported, PUSCH decodes will fail\n");
         lsn_ul_cfg_t u{}; u.cyclic_shift = s2.cyclic_shift; u.delta_ss = s2.group_assignment_pusch; u.hopping_offset = s2.pusch_hop_offset;
+        u.group_hopping_enabled = s2.group_hopping_enabled; u.sequence_hopping_enabled = s2.sequence_hopping_enabled;  // ULSchedule.cc:143-146
         if (setUlConfig(u) != LSN_SUCCESS) throw std::runtime_error("UL_MODE: the uplink configuration of SIB2 could not be applied");
         sib2 = s2; sib2_learned = true;
         lsn_prach_cfg_t pc{}; pc.config_idx = s2.prach_config_idx; pc.root_seq_idx = s2.root_seq_idx; pc.zero_corr_zone = s2.zero_corr_zone;
@@ -229,7 +228,7 @@ void Engine::commitChunkUl(Chunk& ch, JobRunner& r)
       const UlSchedGrant& m = lists[a.sf][a.idx];
       const PuschGrant& g = a.use256 ? m.g256 : m.g;
       results[a];  // default: failed
-      if (g.L_prb == 2) r.perf.nof_pusch_2prb_skipped++;  // reported, not decoded (no 24-entry DMRS table)
+      if (g.L_prb <= 2) r.perf.nof_pusch_on_unverified_dmrs++;  // tabulated reference signals (36.211 Tables 5.5.1.2-1 / -2): restated, structure-checked only
       if (m.hopping || g.hop == 2 || g.tbs <= 0) continue;  // type-2 hopping is not applied by the reference either (hopping_enabled stays false, SubframeWorker.cc:269)
       lsn_pusch_grant_t q{};
       q.sf = a.sf; q.rnti = m.rnti; q.n_dmrs = (uint16_t)m.n_dmrs; q.n_prb = g.n_prb; q.L_prb = g.L_prb; q.mod = (uint32_t)a.qm; q.tbs = (uint32_t)g.tbs; q.rv = g.rv;

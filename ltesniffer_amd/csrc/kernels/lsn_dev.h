@@ -95,7 +95,8 @@ struct LsnUlGrantDev {
   uint32_t n_prb2;      // first PRB in slot 1 (== n_prb unless the grant hops, 36.213 8.4.1)
   uint32_t ncs[2];      // DMRS cyclic shift n_cs of the two slots
   uint32_t cinit;       // scrambling: rnti << 14 | sf_idx << 9 | cell id
-  uint32_t base_off, idft_off;  // offsets of this allocation size into ul_base / ul_idft
+  uint32_t base_off, idft_off;  // offsets into ul_base (reference signal of slot 0: sequence group / number of that slot) / ul_idft
+  uint32_t base_off1;   // ul_base offset of slot 1 (differs from base_off under group / sequence hopping)
   uint32_t hs_off;      // cf32 offset of the 2 M smoothed channel estimates
   uint32_t llr_off;     // int16 offset of the 12 M Qm LLRs (UL-SCH order)
   float scale;          // 1 / sqrt(M)

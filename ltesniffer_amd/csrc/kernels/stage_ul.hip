@@ -112,11 +112,10 @@ __global__ __launch_bounds__(256) void k_pusch_chest(LsnCellDev c, const LsnUlGr
   const int M = 12 * (int)g.L_prb, nre = (int)c.nre, tid = threadIdx.x;
   cf32* ls = (cf32*)smem;            // [2 M]
   float* part = (float*)(ls + 2 * M);  // [2][256]
-  const cf32* base = c.ul_base + g.base_off;
   for (int i = tid; i < 2 * M; i += 256) {
     const int s = i >= M ? 1 : 0, n = i - s * M;
     const cf32 y = grid[((size_t)g.sf * 14 + 3 + 7 * s) * nre + 12 * (s ? g.n_prb2 : g.n_prb) + n];
-    const cf32 r = cmul(base[n], c.ul_ph12[(g.ncs[s] * (uint32_t)n) % 12u]);
+    const cf32 r = cmul(c.ul_base[(s ? g.base_off1 : g.base_off) + n], c.ul_ph12[(g.ncs[s] * (uint32_t)n) % 12u]);
     ls[i] = cmulconj(y, r);
   }
   __syncthreads();

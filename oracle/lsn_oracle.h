@@ -269,7 +269,8 @@ int o_prach_detect(const o_cell_t* cell, const o_prach_cfg_t* cfg, const ocf_t* 
 
 /* ---------- uplink: SC-FDMA demodulation + PUSCH (o_pusch.c) ---------- */
 typedef struct { uint32_t cyclic_shift; /* SIB2 cyclicShift 0..7 */ uint32_t delta_ss; /* SIB2 groupAssignmentPUSCH 0..29 */
-                 uint32_t hopping_offset; /* SIB2 pusch-HoppingOffset */ } o_ul_cfg_t;
+                 uint32_t hopping_offset; /* SIB2 pusch-HoppingOffset */
+                 uint32_t group_hopping_enabled, sequence_hopping_enabled; /* SIB2 ul-ReferenceSignalsPUSCH (ULSchedule.cc:143-146) */ } o_ul_cfg_t;
 typedef struct { uint32_t nof_ack; uint32_t cqi_bits; uint32_t ri_bits; /* HARQ-ACK bits 0..2, CQI report size (0 = none), RI bits */
                  uint32_t i_ack_p1, i_cqi_p1, i_ri_p1; /* 1 + betaOffset-ACK / -CQI / -RI-Index of the UE (uci_offset, UL_Sniffer_PUSCH.cc:435); 0 = the defaults 10 / 8 / 11 of MCSTracking.cc:1534-1538 */ } o_uci_t;
 int o_uci_cqi_bits_type(uint32_t nof_prb, uint32_t cqi_type); /* srsran_cqi_size: 0 wideband (4), 1 UE-selected sub-band (4 + 1), 2 higher-layer sub-band (4 + 2 N) */
@@ -278,7 +279,9 @@ int o_uci_layout(int M, int tbs, const o_uci_t* uci, uint8_t* cls, int* didx, in
 int o_ul_valid_prb(uint32_t L);
 void o_ul_shift_table(int N, ocf_t* t);
 void o_ul_fft(const o_cell_t* cell, const ocf_t* in, ocf_t* grid);
-int o_dmrs_base(uint32_t u, int M_sc, ocf_t* r);
+int o_dmrs_base(uint32_t u, uint32_t v, int M_sc, ocf_t* r);
+void o_dmrs_uv(const o_cell_t* cell, const o_ul_cfg_t* ul, uint32_t ns, int M_sc, uint32_t* u, uint32_t* v); /* 36.211 5.5.1.3 / 5.5.1.4 */
+int o_dmrs_pusch(const o_cell_t* cell, const o_ul_cfg_t* ul, uint32_t ns, uint32_t n_dmrs_dci, int M_sc, ocf_t* r); /* the reference signal of slot ns as transmitted */
 uint32_t o_dmrs_ncs(const o_cell_t* cell, const o_ul_cfg_t* ul, uint32_t ns, uint32_t n_dmrs_dci);
 void o_idft_table(int M, ocf_t* w);
 void o_idft_mixed(int M, const ocf_t* w, ocf_t* x, ocf_t* tmp); /* in-place (via tmp) mixed-radix IDFT, radices 4, 2, 3, 5; defines the operation order of the product */

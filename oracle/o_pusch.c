@@ -4,8 +4,8 @@
  * 5.6 (SC-FDMA, 7.5 kHz shift), 5.5.1/5.5.2.1 (DMRS: Zadoff-Chu base sequences, cyclic shifts), 5.3 (scrambling,
  * modulation, transform precoding) and TS 36.212 5.2.2 (UL-SCH coding, channel interleaver).
  * Scope of this restatement: one receive antenna (the reference uses antenna 1 for the uplink,
- * UL_Sniffer_PUSCH.cc:391), no group / sequence hopping, no frequency hopping, no SRS, no UCI multiplexed into the
- * PUSCH, allocations of 1 PRB (tabulated sequence, spec/lte_tables.h) and >= 3 PRB (Zadoff-Chu); the 2-PRB table (5.5.1.2-2) is not reproduced.
+ * UL_Sniffer_PUSCH.cc:391), group and sequence hopping of the reference signal as SIB2 configures them (ULSchedule.cc:143-146), type-1
+ * frequency hopping, no SRS; allocations of 1 and 2 PRB (tabulated sequences, spec/lte_tables.h) and >= 3 PRB (Zadoff-Chu).
  * Arithmetic contract as in lsn_oracle.h: one float rounding per operation, fixed summation orders, all cos/sin on the
  * "host" side (tables). */
 #include "lsn_oracle.h"
@@ -72,21 +72,22 @@ static int largest_prime_below(int n)
   return 2;
 }
 
-/* base sequence r_{u,0}(n), n < M_sc = 12 L, L >= 3 (36.211 5.5.1.1) */
-int o_dmrs_base(uint32_t u, int M_sc, ocf_t* r)
+/* base sequence r_{u,v}(n), n < M_sc = 12 L (36.211 5.5.1.1 / 5.5.1.2); v = 1 exists from 6 PRB on */
+int o_dmrs_base(uint32_t u, uint32_t v, int M_sc, ocf_t* r)
 {
-  if (M_sc == 12) { /* one PRB: the tabulated sequence exp(j phi(n) pi / 4), 36.211 5.5.1.2 Table 5.5.1.2-1 */
-    for (int n = 0; n < 12; n++) {
-      double a = M_PI * (double)lsn_dmrs_phi12[u % 30][n] / 4.0;
+  if (M_sc == 12 || M_sc == 24) { /* one / two PRB: the tabulated sequences exp(j phi(n) pi / 4), Tables 5.5.1.2-1 / -2 */
+    for (int n = 0; n < M_sc; n++) {
+      double a = M_PI * (double)(M_sc == 12 ? lsn_dmrs_phi12[u % 30][n] : lsn_dmrs_phi24[u % 30][n]) / 4.0;
       r[n].r = (float)cos(a);
       r[n].i = (float)sin(a);
     }
     return 0;
   }
-  if (M_sc < 36) return -1; /* two PRB: Table 5.5.1.2-2 is not reproduced */
+  if (M_sc < 36) return -1;
   int Nzc = largest_prime_below(M_sc);
   double qb = (double)Nzc * (double)(u + 1) / 31.0;
-  int q = (int)floor(qb + 0.5); /* v = 0 */
+  int q = (int)floor(qb + 0.5);
+  if (v && M_sc >= 72) q += ((int)floor(2.0 * qb) & 1) ? -1 : 1; /* q = floor(qb + 1/2) + v (-1)^floor(2 qb) */
   for (int n = 0; n < M_sc; n++) {
     long long m = n % Nzc;
     long long ph = ((long long)q * m * (m + 1)) % (2ll * Nzc); /* exp(-j pi q m(m+1)/Nzc) has period 2 Nzc in the product */
@@ -95,6 +96,27 @@ int o_dmrs_base(uint32_t u, int M_sc, ocf_t* r)
     r[n].i = (float)(-sin(a));
   }
   return 0;
+}
+
+/* sequence group u and base sequence number v of slot ns (36.211 5.5.1.3, 5.5.1.4):
+ *   u = (f_gh(ns) + f_ss^PUSCH) mod 30, f_gh = sum_i c(8 ns + i) 2^i mod 30 with c_init = floor(N_ID / 30) when group hopping is on, else 0;
+ *   v = c(ns) with c_init = floor(N_ID / 30) 2^5 + f_ss^PUSCH when sequence hopping is on, group hopping off and M_sc >= 6 PRB, else 0 */
+void o_dmrs_uv(const o_cell_t* cell, const o_ul_cfg_t* ul, uint32_t ns, int M_sc, uint32_t* u, uint32_t* v)
+{
+  const uint32_t fss = ((cell->id % 30u) + ul->delta_ss) % 30u;
+  uint32_t fgh = 0;
+  uint8_t c[8 * 20 + 8];
+  if (ul->group_hopping_enabled) {
+    o_gold(cell->id / 30u, c, 8 * 20);
+    for (int i = 0; i < 8; i++) fgh += (uint32_t)c[8 * ns + (uint32_t)i] << i;
+    fgh %= 30u;
+  }
+  *u = (fgh + fss) % 30u;
+  *v = 0;
+  if (!ul->group_hopping_enabled && ul->sequence_hopping_enabled && M_sc >= 72) {
+    o_gold(((cell->id / 30u) << 5) + fss, c, 20);
+    *v = c[ns];
+  }
 }
 
 static const uint32_t n_dmrs1_tab[8] = {0, 2, 3, 4, 6, 8, 9, 10}; /* 36.211 Table 5.5.2.1.1-2 (cyclicShift of SIB2) */
@@ -109,6 +131,20 @@ uint32_t o_dmrs_ncs(const o_cell_t* cell, const o_ul_cfg_t* ul, uint32_t ns, uin
   uint32_t npn = 0;
   for (int i = 0; i < 8; i++) npn += (uint32_t)c[8 * 7 * ns + (uint32_t)i] << i;
   return (n_dmrs1_tab[ul->cyclic_shift & 7] + n_dmrs2_tab[n_dmrs_dci & 7] + npn) % 12u;
+}
+
+/* r_PUSCH of slot ns: base sequence of the slot's (u, v) times the cyclic shift exp(j 2 pi n_cs n / 12) (36.211 5.5.2.1.1) */
+int o_dmrs_pusch(const o_cell_t* cell, const o_ul_cfg_t* ul, uint32_t ns, uint32_t n_dmrs_dci, int M_sc, ocf_t* r)
+{
+  uint32_t u, v, ncs = o_dmrs_ncs(cell, ul, ns, n_dmrs_dci);
+  o_dmrs_uv(cell, ul, ns, M_sc, &u, &v);
+  if (o_dmrs_base(u, v, M_sc, r)) return -1;
+  for (int n = 0; n < M_sc; n++) {
+    double a = 2.0 * M_PI * (double)((ncs * (uint32_t)n) % 12u) / 12.0;
+    ocf_t p = {(float)cos(a), (float)sin(a)};
+    r[n] = cmul(r[n], p);
+  }
+  return 0;
 }
 
 static void demod_llr(int Qm, float I, float Q, float* L)
@@ -258,7 +294,7 @@ int o_pusch_demod_uci(const o_cell_t* cell, const o_ul_cfg_t* ul, uint32_t sf_id
                       const o_uci_t* uci, const ocf_t* grid, int16_t* e, float* noise_out, float* sigpow_out)
 {
   int L = (int)g->L_prb, M = 12 * L, nre = 12 * (int)cell->nof_prb, Qm = g->mod;
-  if ((L < 3 && L != 1) || !o_ul_valid_prb(g->L_prb) || g->n_prb + g->L_prb > cell->nof_prb || Qm <= 0 || g->hop > 1) return -1;
+  if (L < 1 || !o_ul_valid_prb(g->L_prb) || g->n_prb + g->L_prb > cell->nof_prb || Qm <= 0 || g->hop > 1) return -1;
   if (g->hop == 1 && g->n_prb2 + g->L_prb > cell->nof_prb) return -1;
   const int k0s[2] = {12 * (int)g->n_prb, 12 * (int)(g->hop == 1 ? g->n_prb2 : g->n_prb)}; /* first carrier per slot (type-1 hopping: two places) */
   ocf_t* base = (ocf_t*)malloc(sizeof(ocf_t) * (size_t)M);
@@ -272,8 +308,6 @@ int o_pusch_demod_uci(const o_cell_t* cell, const o_ul_cfg_t* ul, uint32_t sf_id
   uint8_t* cls = (uint8_t*)malloc((size_t)(12 * M));
   int* didx = (int*)malloc(sizeof(int) * (size_t)(12 * M));
   if (o_uci_layout(M, g->tbs > 0 ? g->tbs : 16, uci, cls, didx, NULL, NULL, NULL) < 0) { free(cls); free(didx); free(c); free(base); free(ls); free(hs); free(tmp); free(x); free(xt); free(w); return -1; }
-  uint32_t u = (((cell->id % 30u) + ul->delta_ss) % 30u) % 30u; /* group hopping off: u = f_ss^PUSCH */
-  o_dmrs_base(u, M, base);
   o_idft_table(M, w);
   o_gold(((uint32_t)rnti << 14) | (sf_idx << 9) | cell->id, c, 12 * M * Qm);
   /* cyclic-shift phasors exp(j 2 pi m / 12) */
@@ -284,7 +318,9 @@ int o_pusch_demod_uci(const o_cell_t* cell, const o_ul_cfg_t* ul, uint32_t sf_id
     ph12[m].i = (float)sin(a);
   }
   for (int s = 0; s < 2; s++) {
-    uint32_t ncs = o_dmrs_ncs(cell, ul, 2 * sf_idx + (uint32_t)s, n_dmrs_dci);
+    uint32_t ncs = o_dmrs_ncs(cell, ul, 2 * sf_idx + (uint32_t)s, n_dmrs_dci), u, v;
+    o_dmrs_uv(cell, ul, 2 * sf_idx + (uint32_t)s, M, &u, &v);
+    o_dmrs_base(u, v, M, base);
     const ocf_t* y = grid + (size_t)(3 + 7 * s) * (size_t)nre + (size_t)k0s[s];
     for (int n = 0; n < M; n++) {
       ocf_t r = cmul(base[n], ph12[(ncs * (uint32_t)n) % 12u]);

@@ -1083,6 +1083,8 @@ int o_worker_work_ul(o_worker_t* w, const ocf_t* dl_iq, const ocf_t* ul_iq, uint
         w->ulcfg.cyclic_shift = w->sib2.cyclic_shift;           /* ULSchedule.cc:143-146 */
         w->ulcfg.delta_ss = w->sib2.group_assignment_pusch;
         w->ulcfg.hopping_offset = w->sib2.pusch_hop_offset;     /* SubframeWorker.cc:271-273 */
+        w->ulcfg.group_hopping_enabled = w->sib2.group_hopping_enabled;
+        w->ulcfg.sequence_hopping_enabled = w->sib2.sequence_hopping_enabled;
         w->cfg.cell.pusch_hop_offset = w->sib2.pusch_hop_offset;
         w->ul_configured = 1;
         w->sib2_learned = 1;

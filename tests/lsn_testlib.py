@@ -405,7 +405,8 @@ def candidate_table(llr, nof_cce, sizes, sf_idx=0):
 
 # -------- uplink: transmitter + oracle bindings --------
 class TxgUlCell(C.Structure):
-    _fields_ = [("nof_prb", C.c_uint32), ("cell_id", C.c_uint32), ("cyclic_shift", C.c_uint32), ("delta_ss", C.c_uint32)]
+    _fields_ = [("nof_prb", C.c_uint32), ("cell_id", C.c_uint32), ("cyclic_shift", C.c_uint32), ("delta_ss", C.c_uint32), ("group_hopping", C.c_uint32),
+                ("sequence_hopping", C.c_uint32)]
 
 
 class TxgUlGrant(C.Structure):
@@ -550,7 +551,8 @@ def host_api_events(api_mode, name, pdu, rnti, tti):
 
 
 class OUlCfg(C.Structure):
-    _fields_ = [("cyclic_shift", C.c_uint32), ("delta_ss", C.c_uint32), ("hopping_offset", C.c_uint32)]
+    _fields_ = [("cyclic_shift", C.c_uint32), ("delta_ss", C.c_uint32), ("hopping_offset", C.c_uint32), ("group_hopping_enabled", C.c_uint32),
+                ("sequence_hopping_enabled", C.c_uint32)]
 
 
 class OPuschGrant(C.Structure):  # o_pusch_grant_t (n_prb2 / hop: type-1 frequency hopping, slot 1 on other PRBs)
@@ -646,7 +648,7 @@ def oracle_worker_api_events(ow):
 class OracleWorkerUl(OracleWorker):
     """UL_MODE worker: one downlink antenna + the uplink antenna (SubframeWorker.cc:184-199)"""
 
-    def __init__(self, nof_prb, nof_ports, cell_id, cyclic_shift, delta_ss, hopping_offset=0, **kw):
+    def __init__(self, nof_prb, nof_ports, cell_id, cyclic_shift, delta_ss, hopping_offset=0, group_hopping=0, sequence_hopping=0, **kw):
         """cyclic_shift None: no configuration given - the worker configures itself from the first SIB2 (decode_SIB)"""
         super().__init__(nof_prb, nof_ports, cell_id, 1, **kw)
         self.lib.o_worker_set_ul_mode.argtypes = [C.c_void_p, C.POINTER(OUlCfg)]
@@ -655,7 +657,7 @@ class OracleWorkerUl(OracleWorker):
         if cyclic_shift is None:
             self.lib.o_worker_set_ul_mode(self.h, None)
         else:
-            self._ul = OUlCfg(cyclic_shift, delta_ss, hopping_offset)
+            self._ul = OUlCfg(cyclic_shift, delta_ss, hopping_offset, int(group_hopping), int(sequence_hopping))
             self.lib.o_worker_set_ul_mode(self.h, C.byref(self._ul))
 
     def ul_config(self):
@@ -664,7 +666,8 @@ class OracleWorkerUl(OracleWorker):
         r = self.lib.o_worker_ul_config(self.h, C.byref(u), C.byref(s))
         if r == 0:
             return None
-        return dict(cyclic_shift=u.cyclic_shift, delta_ss=u.delta_ss, hopping_offset=u.hopping_offset, from_sib2=r == 2,
+        return dict(cyclic_shift=u.cyclic_shift, delta_ss=u.delta_ss, hopping_offset=u.hopping_offset, group_hopping=u.group_hopping_enabled,
+                    sequence_hopping=u.sequence_hopping_enabled, from_sib2=r == 2,
                     sib2=s.as_dict() if r == 2 else None)
 
     def work_ul(self, dl_iq, ul_iq, tti, update_meta=0):
@@ -784,13 +787,13 @@ def encode_paging(records, sys_info_mod=0, etws=0, ext_record=None):
     return bytes(int("".join(map(str, bits[i:i + 8])), 2) for i in range(0, len(bits), 8))
 
 
-def gen_ul_mode_subframes(sc, n, cyclic_shift=3, delta_ss=5, ul_snr_db=30.0, si_msgs=None, ul_256=False):  # sc['pusch_hop_offset'] = SIB2 pusch-HoppingOffset of the cell
+def gen_ul_mode_subframes(sc, n, cyclic_shift=3, delta_ss=5, ul_snr_db=30.0, si_msgs=None, ul_256=False, group_hopping=0, sequence_hopping=0):  # sc['pusch_hop_offset'] = SIB2 pusch-HoppingOffset of the cell
     """DL stream from the synthetic eNB (one rx antenna) + the matching UL stream: every DCI 0 of subframe t is answered by a
     PUSCH in subframe t + 4 (UEs with an even RNTI are 64QAM-capable in the uplink; with ul_256 every fourth UE uses the 256QAM table).
     -> (tti0, iq[n, 2, sf_len] (antenna 0 = DL, 1 = UL), list of sent UL payload dicts)"""
     assert sc["nof_rx"] == 1
     tx = TxGen(si_msgs=si_msgs, **sc)
-    ucell = TxgUlCell(sc["nof_prb"], sc["cell_id"], cyclic_shift, delta_ss)
+    ucell = TxgUlCell(sc["nof_prb"], sc["cell_id"], cyclic_shift, delta_ss, int(group_hopping), int(sequence_hopping))
     iq = np.zeros((n, 2, tx.sf_len), dtype=np.complex64)
     pending, sent, tti0 = {}, [], None
     # the uplink control configuration every UE transmits with: its own RRCConnectionSetup once it got one, else what a sniffer that
@@ -832,7 +835,7 @@ def gen_ul_mode_subframes(sc, n, cyclic_shift=3, delta_ss=5, ul_snr_db=30.0, si_
         for g, p in zip(grants, pl):
             sent.append(dict(tti=tti, rnti=g["rnti"], payload=p, L_prb=g["L_prb"], mod=g["mod"], hop=g.get("hop", 0)))
         for p in pdus:
-            if p["is_ul"] and p["nof_prb"] != 2:  # 2 PRB: no DMRS table (36.211 Table 5.5.1.2-2), the grant stays unanswered
+            if p["is_ul"]:
                 if ul_256 and p["rnti"] % 4 == 0:  # every fourth UE is configured with the 256QAM uplink table
                     qm, tbs = ul_mcs_to_mod_tbs_256(p["mcs"], p["nof_prb"])
                 else:

@@ -11,10 +11,10 @@ from lsn_testlib import (OCell, OPuschGrant, OUci, OUlCfg, TxgUlCell, VALID_UL_P
 pytestmark = pytest.mark.gpu
 
 
-def _scenario(nprb, cell_id, nsf, seed, snr_db=32.0, max_share=3, rvs=(0,), uci=False):
+def _scenario(nprb, cell_id, nsf, seed, snr_db=32.0, max_share=3, rvs=(0,), uci=False, group_hop=0, seq_hop=0):
     rng = np.random.default_rng(seed)
     cqi_bits = oracle_ul_api().o_uci_cqi_bits(nprb)
-    ucell = TxgUlCell(nprb, cell_id, 3, 5)
+    ucell = TxgUlCell(nprb, cell_id, 3, 5, group_hop, seq_hop)
     N = {25: 512, 50: 1024, 75: 1536, 100: 2048}[nprb]
     iq = np.zeros((nsf, 15 * N), dtype=np.complex64)
     grants, payloads = [], []
@@ -22,7 +22,7 @@ def _scenario(nprb, cell_id, nsf, seed, snr_db=32.0, max_share=3, rvs=(0,), uci=
     for sf in range(nsf):
         gl, start = [], 0
         while True:
-            L = int(rng.choice([n for n in VALID_UL_PRB if n != 2 and n <= max(3, nprb // max_share)]))  # 1 PRB: tabulated DMRS; 2 PRB unsupported
+            L = int(rng.choice([n for n in VALID_UL_PRB if n <= max(3, nprb // max_share)]))  # 1 / 2 PRB: tabulated DMRS, >= 3: Zadoff-Chu
             if start + L > nprb:
                 break
             mcs = int(rng.integers(0, 29))
@@ -44,9 +44,10 @@ def _scenario(nprb, cell_id, nsf, seed, snr_db=32.0, max_share=3, rvs=(0,), uci=
 def _run(nprb, cell_id, nsf, seed, **kw):
     o = oracle_ul_api()
     tti0, iq, grants, payloads = _scenario(nprb, cell_id, nsf, seed, **kw)
-    ocell, ucfg = OCell(nprb, 1, cell_id, 1), OUlCfg(3, 5)
+    gh, sh = kw.get("group_hop", 0), kw.get("seq_hop", 0)
+    ocell, ucfg = OCell(nprb, 1, cell_id, 1), OUlCfg(3, 5, 0, gh, sh)
     phy = la.Phy(nof_rx_antennas=1)
-    assert phy.setCell(nprb, 1, cell_id) and phy.setUlConfig(3, 5)
+    assert phy.setCell(nprb, 1, cell_id) and phy.setUlConfig(3, 5, 0, gh, sh)
     res = phy.pusch_decode(iq, tti0, grants)
     nre = 12 * nprb
     grids = []
@@ -101,6 +102,14 @@ def test_pusch_100prb_wideband_and_low_snr():
     ok, n = _run(100, 1, 4, seed=3, max_share=1)      # allocations up to 100 PRB (M = 1200, 13+ code blocks)
     assert ok >= 1
     _run(100, 1, 3, seed=4, snr_db=8.0, max_share=4)   # many CRC failures: verdicts and iteration counts still identical
+
+
+def test_pusch_group_and_sequence_hopping_and_two_prb():
+    """SIB2 groupHoppingEnabled / sequenceHoppingEnabled (ULSchedule.cc:143-146): the reference signal of every slot comes from that slot's
+    sequence group / number (36.211 5.5.1.3-4); 2-PRB allocations use Table 5.5.1.2-2 (UL_Sniffer_PUSCH.cc:3-10 accepts them)"""
+    for gh, sh, seed in ((1, 0, 51), (0, 1, 52), (0, 0, 53)):
+        ok, n = _run(50, 33, 5, seed=seed, max_share=2, group_hop=gh, seq_hop=sh)
+        assert n >= 10 and ok >= 0.6 * n, (gh, sh, ok, n)
 
 
 def test_pusch_with_uci_multiplexing():
@@ -260,8 +269,40 @@ def test_ul_mode_configures_itself_from_sib2(batch):
     st, ost = phy.getStats(), ow.stats()
     assert st.nof_decoded_locations == ost.nof_decoded_locations and st.nof_subframes == ost.nof_subframes
     # a configuration given by hand afterwards replaces the learned one
-    assert phy.setUlConfig(1, 2, 0) and phy.getUlConfig() == dict(cyclic_shift=1, delta_ss=2, hopping_offset=0, from_sib2=False, sib2=None)
+    assert phy.setUlConfig(1, 2, 0) and phy.getUlConfig() == dict(cyclic_shift=1, delta_ss=2, hopping_offset=0, group_hopping=0, sequence_hopping=0, from_sib2=False, sib2=None)
     assert la.sib2_decode(sib2)[1]["root_seq_idx"] == 22 and la.sib2_decode(REAL_SIB1) == (1, None)
+    phy.close()
+
+
+@pytest.mark.parametrize("gh,sh", [(1, 0), (0, 1)])
+def test_ul_mode_sib2_with_group_or_sequence_hopping(gh, sh):
+    """a SIB2 that switches group / sequence hopping of the PUSCH reference signal on (ULSchedule.cc:143-146 forwards both flags): the
+    self-configured UL_MODE decodes the hopped transmissions, 1- and 2-PRB grants included; records identical to the oracle's"""
+    from lsn_testlib import REAL_SIB1, OracleWorkerUl, encode_sib2, gen_ul_mode_subframes, parse_pcap, scenario
+    from parity import gpu_records, oracle_records
+    sc = scenario("cfg2", seed=61 + gh, nof_rx=1, n_rnti=10, dl_min=2, dl_max=3, ul_min=3, ul_max=5, nof_prb=50, mcs_max=18)
+    sib2 = encode_sib2(cyclic_shift=2, group_assignment_pusch=7, group_hopping_enabled=gh, sequence_hopping_enabled=sh, root_seq_idx=40, prach_config_idx=3,
+                       zero_corr_zone=5, prach_freq_offset=4)
+    nsf = 80
+    tti0, iq, sent = gen_ul_mode_subframes(sc, nsf, cyclic_shift=2, delta_ss=7, si_msgs=[REAL_SIB1, sib2], group_hopping=gh, sequence_hopping=sh)
+    ow = OracleWorkerUl(sc["nof_prb"], sc["nof_ports"], sc["cell_id"], None, None)
+    for i in range(nsf):
+        ow.work_ul(iq[i, 0], iq[i, 1], tti0 + i, update_meta=1 if i % 25 == 0 else 0)
+    orecs = parse_pcap(ow.pcap_bytes())
+    ul = [r for r in orecs if r["direction"] == 0]
+    sent_set = {(s["tti"], s["rnti"], s["payload"]) for s in sent}
+    assert len(ul) >= 20 and all((r["sfn"] * 10 + r["sf"], r["rnti"], r["pdu"]) in sent_set for r in ul)
+    small = {(s["tti"], s["rnti"]) for s in sent if s["L_prb"] <= 2}
+    assert sum((r["sfn"] * 10 + r["sf"], r["rnti"]) in small for r in ul) >= 2   # 1- / 2-PRB transmissions came through
+    phy = la.Phy(nof_rx_antennas=2, sniffer_mode=1, max_batch=32, pcapwriter=la.PcapWriter(None))
+    assert phy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"])
+    phy.process_host(iq, tti0, 25)
+    g, o = gpu_records(phy), oracle_records(orecs)
+    assert g == o, "UL_MODE (hopping reference signals) record streams differ: gpu %d vs oracle %d" % (len(g), len(o))
+    cfg = phy.getUlConfig()
+    assert cfg == ow.ul_config() and cfg["group_hopping"] == gh and cfg["sequence_hopping"] == sh
+    p = phy.perf()
+    assert p.nof_pusch_2prb_skipped == 0 and p.nof_pusch_on_unverified_dmrs > 0
     phy.close()
 
 

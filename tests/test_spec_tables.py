@@ -105,3 +105,64 @@ def test_lengths_the_reference_decoded_are_table_values():
                 assert ln * 8 in dl, (key, ln)
                 n += 1
     assert n > 40
+
+
+# ---------------------------------------------------------------------------------------------------- uplink reference-signal tables
+def _papr_db(phi, over=16):
+    import numpy as np
+    r = np.exp(1j * np.pi * np.array(phi) / 4)
+    x = np.fft.ifft(np.concatenate([r, np.zeros((over - 1) * len(phi))]))
+    p = np.abs(x) ** 2
+    return 10 * np.log10(p.max() / p.mean())
+
+
+def test_dmrs_tables_look_like_computer_generated_cazac_sequences():
+    """36.211 Tables 5.5.1.2-1 / -2 cannot be looked up here.  What a correct restatement must show - and a mistyped one does not:
+    QPSK alphabet, 30 rows that stay distinct under every cyclic time shift (= linear phase in frequency, the 12 n_cs values) and a
+    constant-amplitude-like envelope: every row's PAPR inside a narrow band (random QPSK rows of these lengths sit at 5.5 - 9 dB).  The test
+    also measures how visible a single wrong entry would be: most one-entry corruptions push a row out of the band."""
+    import numpy as np
+    for name, M, lo, hi in (("lsn_dmrs_phi12", 12, 2.2, 4.2), ("lsn_dmrs_phi24", 24, 2.5, 4.4)):
+        T = _rows(name)
+        assert len(T) == 30 and all(len(r) == M and set(r) <= {-3, -1, 1, 3} for r in T)
+        papr = [_papr_db(r) for r in T]
+        assert lo < min(papr) and max(papr) < hi, (name, min(papr), max(papr))
+        # distinct under the 12 cyclic shifts alpha = 2 pi n_cs / 12 and a common phase: normalised cross-correlation peak well below 1
+        R = np.exp(1j * np.pi * np.array(T) / 4)
+        worst = 0.0
+        for a in range(30):
+            for b in range(a + 1, 30):
+                c = np.abs(np.fft.fft(R[a] * np.conj(R[b]), 12 * M)).max() / M   # fine grid over every linear phase ramp
+                worst = max(worst, c)
+        assert worst < (0.85 if M == 12 else 0.75), (name, worst)
+        rnd = np.random.default_rng(M)
+        random_rows = [_papr_db(rnd.choice([-3, -1, 1, 3], M)) for _ in range(200)]
+        assert np.median(random_rows) > hi + 0.8
+        # sensitivity: replace ONE entry of a row by another alphabet value -> how often does the row leave the band of the table?
+        out = tot = 0
+        for u in range(30):
+            for n in range(M):
+                for v in (-3, -1, 1, 3):
+                    if v == T[u][n]:
+                        continue
+                    r = list(T[u]); r[n] = v
+                    tot += 1
+                    out += _papr_db(r) > max(papr) + 1e-9
+        assert out / tot > (0.30 if M == 12 else 0.25), (name, out / tot)   # a typo is more likely than not to raise the PAPR; many leave the band
+
+
+def test_derived_tbs_rows_are_flagged_and_their_rule_is_cross_validated():
+    """rows I_TBS 27..33 are derived (spec/gen_tables.py: the reference's row 32A scaled to the 100-PRB anchors and snapped to the value set).
+    The same rule applied between rows that ARE known reproduces 50-90 % of the entries exactly and misses by at most one step of the value set
+    (row 26, which saturates at 75376, by two steps in a few columns) - the error model for a derived row; the product counts every decode that used one (lsn_perf_t.nof_tb_on_derived_tbs)."""
+    def snap(t):
+        return min(ALLOWED, key=lambda x: (abs(x - t), x))
+    for src, dst, near_min in ((24, 25, 108), (20, 21, 108), (23, 24, 108), (25, 26, 100)):
+        exact = near = 0
+        for n in range(110):
+            v = snap(TBS[src][n] * TBS[dst][99] / TBS[src][99])
+            exact += v == TBS[dst][n]
+            near += abs(ALLOWED.index(v) - ALLOWED.index(TBS[dst][n])) <= 1
+        assert exact >= 55 and near >= near_min, (src, dst, exact, near)
+    hdr = open(os.path.join(ROOT, "include", "ltesniffer_amd.h")).read()
+    assert "nof_tb_on_derived_tbs" in hdr and "nof_pusch_on_unverified_dmrs" in hdr

@@ -25,8 +25,8 @@ def test_pusch_loopback_all_modulations(nprb, cell_id):
         # pack a few non-overlapping grants into the band
         grants, start = [], 0
         while True:
-            # one PRB (tabulated DMRS sequence, 36.211 Table 5.5.1.2-1) and >= 3 PRB (Zadoff-Chu); two PRB is not supported
-            L = int(rng.choice([n for n in VALID_UL_PRB if n != 2 and n <= max(3, nprb // 3)]))
+            # one / two PRB (tabulated DMRS sequences, 36.211 Tables 5.5.1.2-1 / -2) and >= 3 PRB (Zadoff-Chu)
+            L = int(rng.choice([n for n in VALID_UL_PRB if n <= max(3, nprb // 3)]))
             if start + L > nprb:
                 break
             mcs = int(rng.integers(0, 29))
@@ -58,7 +58,7 @@ def test_pusch_rejects_unsupported_grants():
     ocell, ucfg = OCell(25, 1, 1, 1), OUlCfg(0, 0)
     grid = np.zeros(14 * 300, dtype=np.complex64)
     e = np.zeros(1 << 16, dtype=np.int16)
-    for L, n in ((2, 0), (7, 0), (10, 20), (0, 0)):
+    for L, n in ((7, 0), (10, 20), (0, 0), (11, 0)):
         og = OPuschGrant(L, n, 0, 2, 104, 0)
         assert o.o_pusch_demod(C.byref(ocell), C.byref(ucfg), 0, 70, C.byref(og), 0, grid.ctypes.data, e.ctypes.data, None, None) == -1
 
@@ -243,7 +243,8 @@ def test_ul_tracking_database_statistics_and_ageing():
     gone = [r for r in seen if last_tx[r] < 990]
     live = [r for r in seen if last_tx[r] > n - 100]
     assert gone and live
-    assert all(ow.lib.o_worker_tracked_mod_ul(ow.h, r) == 0 for r in gone)
+    # (one survivor allowed: a false DCI 0 that happens to carry the RNTI of a tracked UE refreshes its time stamp, find_tracking_info_RNTI_ul :52-53)
+    assert sum(ow.lib.o_worker_tracked_mod_ul(ow.h, r) == 0 for r in gone) >= len(gone) - 1
     assert sum(ow.lib.o_worker_tracked_mod_ul(ow.h, r) >= 2 for r in live) >= len(live) - 2   # 16QAM / 64QAM maximum learnt
     ul = [r for r in parse_pcap(ow.pcap_bytes()) if r["direction"] == 0]
     assert len(ul) > 0.7 * len([s for s in sent if (s["tti"] - tti0) % 10240 > 20])
@@ -291,3 +292,108 @@ def test_mixed_radix_idft_matches_numpy_for_every_allocation_size():
         y, t = x.copy(), np.zeros(M, np.complex64)
         o.o_idft_mixed(M, w.ctypes.data, y.ctypes.data, t.ctypes.data)
         assert np.abs(y - ref).max() <= 3e-6 * np.abs(ref).max(), L
+
+
+# ---------------------------------------------------------------------------------------------------- reference signals, independently
+def _gold(cinit, n):
+    """36.211 7.2, written from the definition (x1 / x2 as Python ints), independent of oracle / transmitter code"""
+    x1, x2 = 1, cinit & 0x7FFFFFFF
+    out = []
+    for i in range(1600 + n):
+        if i >= 1600:
+            out.append((x1 ^ x2) & 1)
+        x1 = (x1 >> 1) | ((((x1 >> 3) ^ x1) & 1) << 30)
+        x2 = (x2 >> 1) | ((((x2 >> 3) ^ (x2 >> 2) ^ (x2 >> 1) ^ x2) & 1) << 30)
+    return out
+
+
+def _np_dmrs(cell_id, cyclic_shift, delta_ss, group_hop, seq_hop, ns, n_dmrs_dci, M):
+    """r_PUSCH of slot ns, 36.211 5.5.1 / 5.5.2.1.1 in numpy (double precision, closed-form exponentials)"""
+    import re
+    import ast
+    import os
+    fss = (cell_id % 30 + delta_ss) % 30
+    fgh = 0
+    if group_hop:
+        c = _gold(cell_id // 30, 8 * 20)
+        fgh = sum(c[8 * ns + i] << i for i in range(8)) % 30
+    u = (fgh + fss) % 30
+    v = 0
+    if seq_hop and not group_hop and M >= 72:
+        v = _gold((cell_id // 30) * 32 + fss, 20)[ns]
+    n = np.arange(M)
+    if M in (12, 24):
+        src = open(os.path.join(os.path.dirname(__file__), "..", "spec", "gen_tables.py")).read()
+        tab = ast.literal_eval(re.search(r"^PHI%d=(\[\[.*\]\])$" % M, src, re.M).group(1))
+        base = np.exp(1j * np.pi * np.array(tab[u]) / 4)
+    else:
+        nzc = max(p for p in range(2, M) if all(p % d for d in range(2, int(p ** 0.5) + 1)))
+        qb = nzc * (u + 1) / 31.0
+        q = int(np.floor(qb + 0.5)) + v * (-1) ** int(np.floor(2 * qb))
+        m = n % nzc
+        base = np.exp(-1j * np.pi * q * m * (m + 1) / nzc)
+    d1, d2 = [0, 2, 3, 4, 6, 8, 9, 10], [0, 6, 3, 4, 2, 8, 10, 9]
+    c = _gold((cell_id // 30) * 32 + fss, 8 * 7 * 20 + 8)
+    npn = sum(c[8 * 7 * ns + i] << i for i in range(8))
+    ncs = (d1[cyclic_shift] + d2[n_dmrs_dci] + npn) % 12
+    return base * np.exp(2j * np.pi * ncs * n / 12)
+
+
+@pytest.mark.parametrize("group_hop,seq_hop", [(0, 0), (1, 0), (0, 1), (1, 1)])
+def test_reference_signal_equals_an_independent_numpy_generator(group_hop, seq_hop):
+    """every allocation size x a sample of cells, slots and shifts, with group / sequence hopping on and off"""
+    o = oracle_ul_api()
+    o.o_dmrs_pusch.argtypes = [C.POINTER(OCell), C.POINTER(OUlCfg), C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
+    rng = np.random.default_rng(7 + 2 * group_hop + seq_hop)
+    differs = 0
+    for L in VALID_UL_PRB:
+        for _ in range(3):
+            cid, cs, dss = int(rng.integers(0, 504)), int(rng.integers(0, 8)), int(rng.integers(0, 30))
+            ns, nd = int(rng.integers(0, 20)), int(rng.integers(0, 8))
+            ocell, ucfg = OCell(100, 1, cid, 1), OUlCfg(cs, dss, 0, group_hop, seq_hop)
+            r = np.zeros(12 * L, dtype=np.complex64)
+            assert o.o_dmrs_pusch(C.byref(ocell), C.byref(ucfg), ns, nd, 12 * L, r.ctypes.data) == 0
+            ref = _np_dmrs(cid, cs, dss, group_hop, seq_hop, ns, nd, 12 * L)
+            assert np.abs(r - ref).max() < 2e-6, (L, cid, ns)
+            plain = _np_dmrs(cid, cs, dss, 0, 0, ns, nd, 12 * L)
+            differs += int(np.abs(ref - plain).max() > 1e-3)
+    if group_hop:
+        assert differs > 60          # almost every slot lands in another sequence group
+    elif seq_hop:
+        assert 10 < differs < 60     # only >= 6 PRB, and only where c(ns) = 1
+    else:
+        assert differs == 0
+
+
+@pytest.mark.parametrize("group_hop,seq_hop", [(1, 0), (0, 1)])
+def test_pusch_loopback_with_group_and_sequence_hopping(group_hop, seq_hop):
+    o = oracle_ul_api()
+    nprb, cell_id = 50, 77
+    rng = np.random.default_rng(31 + group_hop)
+    ocell = OCell(nprb, 1, cell_id, 1)
+    ucell, ucfg, plain = TxgUlCell(nprb, cell_id, 2, 9, group_hop, seq_hop), OUlCfg(2, 9, 0, group_hop, seq_hop), OUlCfg(2, 9, 0, 0, 0)
+    ok = wrong_cfg_fails = 0
+    for it in range(5):
+        tti = int(rng.integers(0, 10240))
+        grants, start = [], 0
+        for L in (1, 2, 3, 6, 8, 12):
+            qm, tbs = ul_mcs_to_mod_tbs(int(rng.integers(2, 20)), L)
+            grants.append(dict(rnti=int(rng.integers(100, 60000)), n_dmrs=int(rng.integers(0, 8)), n_prb=start, L_prb=L, mod=qm, tbs=tbs, rv=0,
+                               phase_rad=float(rng.uniform(0, 6.28)), ta_samples=float(rng.uniform(0, 3))))
+            start += L + 1
+        iq, payloads = ul_make_subframe(ucell, tti, grants, snr_db=30.0, seed=it)
+        grid = np.zeros(14 * 12 * nprb, dtype=np.complex64)
+        o.o_ul_fft(C.byref(ocell), iq.ctypes.data, grid.ctypes.data)
+        for g, pl in zip(grants, payloads):
+            og = OPuschGrant(g["L_prb"], g["n_prb"], 0, g["mod"], g["tbs"], 0)
+            out = np.zeros(g["tbs"] // 8 + 8, dtype=np.uint8)
+            its, snr = C.c_int(0), C.c_float(0)
+            assert o.o_pusch_decode(C.byref(ocell), C.byref(ucfg), tti % 10, g["rnti"], C.byref(og), g["n_dmrs"], grid.ctypes.data, 12, out.ctypes.data,
+                                    C.byref(its), C.byref(snr)) == 1, (it, g)
+            assert bytes(out[:g["tbs"] // 8]) == pl
+            ok += 1
+            # a receiver that ignores the hopping configuration estimates the channel against the wrong sequence
+            if o.o_pusch_decode(C.byref(ocell), C.byref(plain), tti % 10, g["rnti"], C.byref(og), g["n_dmrs"], grid.ctypes.data, 4, out.ctypes.data,
+                                C.byref(its), C.byref(snr)) == 0:
+                wrong_cfg_fails += 1
+    assert ok == 30 and wrong_cfg_fails >= (20 if group_hop else 3)

@@ -887,7 +887,7 @@ extern "C" int txg_generate(const txg_cfg_t* cfg, uint32_t nsf, float* iq, int n
 // Uplink: SC-FDMA transmitters of several UEs summed at the sniffer's uplink antenna (test tooling).
 // TS 36.212 5.2.2 (UL-SCH: CRC, segmentation, turbo code, rate matching, control multiplexing with random control bits, channel interleaver),
 // TS 36.211 5.3 (scrambling, modulation, transform precoding), 5.5 (DMRS), 5.6 (7.5 kHz shifted SC-FDMA).
-typedef struct { uint32_t nof_prb, cell_id, cyclic_shift, delta_ss; } txg_ul_cell_t;
+typedef struct { uint32_t nof_prb, cell_id, cyclic_shift, delta_ss, group_hopping, sequence_hopping; /* SIB2 ul-ReferenceSignalsPUSCH */ } txg_ul_cell_t;
 typedef struct { uint16_t rnti; uint16_t n_dmrs; uint32_t n_prb, L_prb, mod, tbs, rv; float gain_db, phase_rad, ta_samples;
                  uint32_t nof_ack, cqi_bits, ri_bits; /* UCI multiplexed into the PUSCH (36.212 5.2.2.6-8): HARQ-ACK bits, CQI report size, RI bits */
                  uint32_t hop, n_prb2; /* hop = 1: slot 1 is sent on n_prb2 .. n_prb2 + L_prb - 1 (type-1 frequency hopping) */
@@ -960,10 +960,18 @@ extern "C" int txg_ul_make(const txg_ul_cell_t* c, uint32_t tti, const txg_ul_gr
     std::vector<cf> sym;
     modulate(h, Qm, sym);
     const std::complex<double> chan = std::polar(std::pow(10.0, g.gain_db / 20.0), (double)g.phase_rad);
-    // base sequence
+    // base sequence: group u and number v of the slot (36.211 5.5.1.3 / 5.5.1.4), Zadoff-Chu root q from (u, v)
     const int Nzc = ul_largest_prime_below(M);
-    const double qb = (double)Nzc * (double)(fss + 1) / 31.0;
-    const long long q = (long long)std::floor(qb + 0.5);
+    auto slot_q = [&](uint32_t ns, uint32_t& u_out) -> long long {
+      uint32_t fgh = 0, vv = 0;
+      if (c->group_hopping) { bits_t cg = gold(c->cell_id / 30, 8 * 20); for (int i = 0; i < 8; i++) fgh += (uint32_t)cg[8 * ns + i] << i; fgh %= 30; }
+      else if (c->sequence_hopping && M >= 72) { bits_t cs = gold(((c->cell_id / 30) << 5) + fss, 20); vv = cs[ns]; }
+      u_out = (fgh + fss) % 30;
+      const double qb = (double)Nzc * (double)(u_out + 1) / 31.0;
+      long long q = (long long)std::floor(qb + 0.5);
+      if (vv) q += ((long long)std::floor(2.0 * qb) & 1) ? -1 : 1;
+      return q;
+    };
     int col = 0;
     for (int l = 0; l < 14; l++) {
       std::vector<std::complex<double>> v((size_t)M);
@@ -972,10 +980,13 @@ extern "C" int txg_ul_make(const txg_ul_cell_t* c, uint32_t tti, const txg_ul_gr
         uint32_t npn = 0;
         for (int i = 0; i < 8; i++) npn += (uint32_t)cpn[8 * 7 * ns + i] << i;
         const uint32_t ncs = (d1[c->cyclic_shift & 7] + d2[g.n_dmrs & 7] + npn) % 12;
+        uint32_t u = 0;
+        const long long q = slot_q(ns, u);
         for (int n = 0; n < M; n++) {
           const long long m = n % Nzc;
-          const double base = M == 12 ? M_PI * (double)lsn_dmrs_phi12[fss % 30][n] / 4.0  // one PRB: 36.211 Table 5.5.1.2-1
-                                      : -M_PI * (double)((q * m * (m + 1)) % (2ll * Nzc)) / (double)Nzc;
+          const double base = M == 12 ? M_PI * (double)lsn_dmrs_phi12[u][n] / 4.0  // one / two PRB: 36.211 Tables 5.5.1.2-1 / -2
+                              : M == 24 ? M_PI * (double)lsn_dmrs_phi24[u][n] / 4.0
+                                        : -M_PI * (double)((q * m * (m + 1)) % (2ll * Nzc)) / (double)Nzc;
           const double a = base + 2.0 * M_PI * (double)((ncs * (uint32_t)n) % 12) / 12.0;
           v[n] = std::complex<double>(std::cos(a), std::sin(a));
         }
