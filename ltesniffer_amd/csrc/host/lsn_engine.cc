@@ -260,7 +260,7 @@ void Engine::launchStageA(Chunk& ch, const void* d_iq)
   hipStream_t st = ch.st_a;
   const uint32_t nsf = ch.nsf;
   for (uint32_t i = 0; i < nsf; i++) ch.h_sfidx[i] = ch.ctx[i].sf_idx;
-  HIP_CHECK(hipMemcpyAsync(ch.d_sfidx, ch.h_sfidx, nsf * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  lsn_launch_upload(ch.d_sfidx, ch.h_sfidx, nsf * sizeof(uint32_t), st);  // (pinned mirror; not through the copy engine, see lsn_dev.h)
   const cf32* iq = (const cf32*)d_iq;
   ch.d_iq_src = iq;
   int n = 0;
@@ -279,11 +279,12 @@ void Engine::launchStageA(Chunk& ch, const void* d_iq)
   timed([&] { lsn_launch_viterbi(cd, ch.d_llr, ch.d_ccepow, ch.d_cfi, ch.d_sfidx, ch.d_cand, nsf, st); });
   timed([&] { lsn_launch_rb_power(cd, ch.d_grid, ch.d_rbp, nsf, st); });
   if (cfg.sniffer_mode == 1) lsn_launch_ul_fft(cd, iq, cd.iq_nant, 1, ch.d_ul_grid, nsf, st);  // srsran_enb_ul_fft on antenna 1, UL_Sniffer_PUSCH.cc:391-392
-  HIP_CHECK(hipMemcpyAsync(ch.h_cand, ch.d_cand, (size_t)nsf * LSN_MAX_LOC * LSN_MAX_SIZES * sizeof(LsnCand), hipMemcpyDeviceToHost, st));
-  HIP_CHECK(hipMemcpyAsync(ch.h_ccepow, ch.d_ccepow, (size_t)nsf * LSN_CCE_STRIDE * sizeof(float), hipMemcpyDeviceToHost, st));
-  HIP_CHECK(hipMemcpyAsync(ch.h_chest, ch.d_chest, (size_t)nsf * sizeof(LsnChest), hipMemcpyDeviceToHost, st));
-  HIP_CHECK(hipMemcpyAsync(ch.h_cfi, ch.d_cfi, (size_t)nsf * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-  HIP_CHECK(hipMemcpyAsync(ch.h_rbp, ch.d_rbp, (size_t)nsf * 128 * sizeof(float), hipMemcpyDeviceToHost, st));
+  // mirrors for the host stages: posted writes of a copy kernel into the pinned buffers (not the copy engine, lsn_dev.h)
+  lsn_launch_download(ch.h_cand, ch.d_cand, (size_t)nsf * LSN_MAX_LOC * LSN_MAX_SIZES * sizeof(LsnCand), st);
+  lsn_launch_download(ch.h_ccepow, ch.d_ccepow, (size_t)nsf * LSN_CCE_STRIDE * sizeof(float), st);
+  lsn_launch_download(ch.h_chest, ch.d_chest, (size_t)nsf * sizeof(LsnChest), st);
+  lsn_launch_download(ch.h_cfi, ch.d_cfi, (size_t)nsf * sizeof(uint32_t), st);
+  lsn_launch_download(ch.h_rbp, ch.d_rbp, (size_t)nsf * 128 * sizeof(float), st);
   HIP_CHECK(hipEventRecord(ch.ev_a[16], st));
 }
 
@@ -572,9 +573,9 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
     grow_dev(r.d_items, r.items_cap, nitems + 1, st);
     grow_host(r.h_items_pinned, r.h_items_cap, nitems + 1, st);
     std::memcpy(r.h_items_pinned, r.h_items.data(), nitems * sizeof(uint32_t));
-    HIP_CHECK(hipMemcpyAsync(r.d_items, r.h_items_pinned, nitems * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    lsn_launch_upload(r.d_items, r.h_items_pinned, nitems * sizeof(uint32_t), st);
     std::memcpy(r.h_jobs_pinned, r.h_jobs.data(), njobs * sizeof(LsnGrantDev));
-    HIP_CHECK(hipMemcpyAsync(r.d_jobs, r.h_jobs_pinned, njobs * sizeof(LsnGrantDev), hipMemcpyHostToDevice, st));
+    lsn_launch_upload(r.d_jobs, r.h_jobs_pinned, njobs * sizeof(LsnGrantDev), st);
     if (ncb) {
       // launch order: two-wavefront blocks first, each class by descending size (longest jobs first)
       order.resize(ncb);
@@ -599,7 +600,7 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
       }
       n128 = n128p[0] + n128p[1];
       grow_dev(r.d_spp, r.spp_cap, spp_n + 16, st);
-      HIP_CHECK(hipMemcpyAsync(r.d_cbs, r.h_cbs_pinned, ncb * sizeof(LsnCbDev), hipMemcpyHostToDevice, st));
+      lsn_launch_upload(r.d_cbs, r.h_cbs_pinned, ncb * sizeof(LsnCbDev), st);
     }
     HIP_CHECK(hipMemsetAsync(r.d_llr16, 0, llr_n * sizeof(int16_t), st));
     HIP_CHECK(hipEventRecord(r.ev[0], st));
@@ -620,8 +621,8 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
         }
       }
       HIP_CHECK(hipEventRecord(r.ev[3], st));
-      HIP_CHECK(hipMemcpyAsync(r.h_cbres_pinned, r.d_cbres, ncb * sizeof(LsnCbRes), hipMemcpyDeviceToHost, st));
-      HIP_CHECK(hipMemcpyAsync(r.h_payload_pinned, r.d_payload, pay_n - pay0, hipMemcpyDeviceToHost, st));
+      lsn_launch_download(r.h_cbres_pinned, r.d_cbres, ncb * sizeof(LsnCbRes), st);
+      lsn_launch_download(r.h_payload_pinned, r.d_payload, pay_n - pay0, st);
     }
     HIP_CHECK(hipEventRecord(r.ev_done, st));
     waitEvent(r.ev_done);
@@ -1417,6 +1418,8 @@ int Engine::processHost(const float* iq, uint32_t nsf_total, uint32_t start_tti,
     // left the whole pipeline: with decode, commit and write behind stage A that is six or more chunk times later and throttled the copies to
     // three blocks per pipeline latency - the 27 GB/s of round 2).  Copies are queued ahead on their own stream, so the link stays busy.
     const uint32_t blk = max_batch;
+    static const bool host_debug = getenv("LSN_HOST_DEBUG") != nullptr;
+    const double t_host0 = now_ms();
     const uint32_t nring = (uint32_t)std::max<size_t>(2, staging_sf / blk);
     std::vector<uint64_t> marks(nring, 0);
     uint32_t k = 0;
@@ -1425,9 +1428,12 @@ int Engine::processHost(const float* iq, uint32_t nsf_total, uint32_t start_tti,
       const uint32_t nsf = std::min(blk, nsf_total - base), slot = k % nring;
       if (k >= nring) waitIqConsumed(marks[slot]);
       uint8_t* dst = (uint8_t*)d_iq_staging + (size_t)slot * blk * sf_stride;
+      const double tc0 = now_ms();
       HIP_CHECK(hipMemcpyAsync(dst, (const uint8_t*)iq + (size_t)base * sf_stride, (size_t)nsf * sf_stride, hipMemcpyHostToDevice, copy_stream));
+      const double tc1 = now_ms();
       rc = submit(dst, nsf, start_tti + base, update_meta_period, copy_stream);  // stage A of the block waits for the copy on the device
       marks[slot] = submitMark();
+      if (host_debug) fprintf(stderr, "process_host: block %u: hipMemcpyAsync call %.3f ms, submit %.3f ms (t = %.3f ms)\n", k, tc1 - tc0, now_ms() - tc1, tc0 - t_host0);
     }
     const int w = wait();
     if (registered) (void)hipHostUnregister((void*)iq);

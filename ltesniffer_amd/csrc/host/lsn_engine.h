@@ -355,6 +355,8 @@ private:
   JobRunner runner_u;
   cf32 *ul_d_iq = nullptr, *ul_d_grid = nullptr, *ul_d_hs = nullptr; float* ul_d_stat = nullptr; LsnUlGrantDev* ul_d_grants = nullptr;
   size_t ul_iq_cap = 0, ul_grid_cap = 0, ul_hs_cap = 0, ul_stat_cap = 0, ul_grants_cap = 0;
+  LsnUlGrantDev* ul_h_grants = nullptr; size_t ul_h_grants_cap = 0;
+  float* ul_h_stat = nullptr; size_t ul_h_stat_cap = 0;  // pinned mirror of the grant descriptors
   struct Prach {
     bool set = false;
     lsn_prach_cfg_t cfg{};

@@ -69,6 +69,8 @@ void Engine::freeDevice()
     auto df = [](auto*& p) { if (p) (void)hipFree(p); p = nullptr; };
     df(ul_d_iq); df(ul_d_grid); df(ul_d_hs); df(ul_d_stat); df(ul_d_grants);
     ul_iq_cap = ul_grid_cap = ul_hs_cap = ul_stat_cap = ul_grants_cap = 0;
+    if (ul_h_grants) { (void)hipHostFree(ul_h_grants); ul_h_grants = nullptr; ul_h_grants_cap = 0; }
+    if (ul_h_stat) { (void)hipHostFree(ul_h_stat); ul_h_stat = nullptr; ul_h_stat_cap = 0; }
     ul_set = false;
     df(prach.d_W); df(prach.d_V); df(prach.d_D); df(prach.d_Y); df(prach.d_corr); df(prach.d_out); df(prach.d_off);
     prach = Prach();

@@ -291,21 +291,46 @@ void Engine::puschDecodeGrid(const cf32* d_grid, uint32_t nsf, uint32_t start_tt
     if (lsn_turbo_nwin((int)sorted[i].K) > 64) { n128++; kmax128 = std::max(kmax128, sorted[i].K); } else kmax64 = std::max(kmax64, sorted[i].K);
   }
   grow_d(r.d_spp, r.spp_cap, spp_n + 16);
-  HIP_CHECK(hipMemcpyAsync(ul_d_grants, gd.data(), ng * sizeof(LsnUlGrantDev), hipMemcpyHostToDevice, st));
-  HIP_CHECK(hipMemcpyAsync(r.d_cbs, sorted.data(), ncb * sizeof(LsnCbDev), hipMemcpyHostToDevice, st));
+  // descriptors go through pinned mirrors and the upload kernel, not through the host -> device copy engine (its FIFO may hold IQ blocks, lsn_dev.h)
+  if (ng > ul_h_grants_cap) {
+    HIP_CHECK(hipStreamSynchronize(st));
+    if (ul_h_grants) HIP_CHECK(hipHostFree(ul_h_grants));
+    ul_h_grants_cap = ng + ng / 2 + 64;
+    HIP_CHECK(hipHostMalloc((void**)&ul_h_grants, ul_h_grants_cap * sizeof(LsnUlGrantDev)));
+  }
+  if (ncb > r.h_cbs_cap) {
+    HIP_CHECK(hipStreamSynchronize(st));
+    if (r.h_cbs_pinned) HIP_CHECK(hipHostFree(r.h_cbs_pinned));
+    r.h_cbs_cap = ncb + ncb / 2 + 1024;
+    HIP_CHECK(hipHostMalloc((void**)&r.h_cbs_pinned, r.h_cbs_cap * sizeof(LsnCbDev)));
+  }
+  std::memcpy(ul_h_grants, gd.data(), ng * sizeof(LsnUlGrantDev));
+  std::memcpy(r.h_cbs_pinned, sorted.data(), ncb * sizeof(LsnCbDev));
+  lsn_launch_upload(ul_d_grants, ul_h_grants, ng * sizeof(LsnUlGrantDev), st);
+  lsn_launch_upload(r.d_cbs, r.h_cbs_pinned, ncb * sizeof(LsnCbDev), st);
   HIP_CHECK(hipMemsetAsync(r.d_llr16, 0, llr_n * sizeof(int16_t), st));
-  HIP_CHECK(hipStreamSynchronize(st));  // gd / sorted are pageable host vectors
   lsn_launch_pusch_chest(cd, ul_d_grants, d_grid, ul_d_hs, ul_d_stat, ng, st);
   lsn_launch_pusch_demod(cd, ul_d_grants, d_grid, ul_d_hs, ul_d_stat, r.d_llr16, ng, st);
   lsn_launch_rm(r.d_cbs, r.d_llr16, r.d_spp, ncb, emax, st);
   lsn_launch_turbo(cd, r.d_cbs, r.d_spp, r.d_payload, r.d_cbres, n128, kmax128, ncb - n128, kmax64, st, nullptr);
-  std::vector<LsnCbRes> cbres(ncb);
-  std::vector<uint8_t> pay(pay_n);
-  std::vector<float> stat((size_t)2 * ng);
-  HIP_CHECK(hipMemcpyAsync(cbres.data(), r.d_cbres, ncb * sizeof(LsnCbRes), hipMemcpyDeviceToHost, st));
-  HIP_CHECK(hipMemcpyAsync(pay.data(), r.d_payload, pay_n, hipMemcpyDeviceToHost, st));
-  HIP_CHECK(hipMemcpyAsync(stat.data(), ul_d_stat, stat.size() * sizeof(float), hipMemcpyDeviceToHost, st));
+  // results come back through pinned mirrors written by the copy kernel (lsn_dev.h), not through the copy engine
+  auto grow_pinned = [&](auto*& p, size_t& cap, size_t need) {
+    if (need <= cap) return;
+    HIP_CHECK(hipStreamSynchronize(st));
+    if (p) HIP_CHECK(hipHostFree(p));
+    cap = need + need / 2 + 1024;
+    HIP_CHECK(hipHostMalloc((void**)&p, cap * sizeof(*p)));
+  };
+  grow_pinned(r.h_cbres_pinned, r.h_cbres_cap, ncb);
+  grow_pinned(r.h_payload_pinned, r.h_payload_cap, pay_n + 16);
+  grow_pinned(ul_h_stat, ul_h_stat_cap, (size_t)2 * ng);
+  lsn_launch_download(r.h_cbres_pinned, r.d_cbres, ncb * sizeof(LsnCbRes), st);
+  lsn_launch_download(r.h_payload_pinned, r.d_payload, pay_n, st);
+  lsn_launch_download(ul_h_stat, ul_d_stat, (size_t)2 * ng * sizeof(float), st);
   HIP_CHECK(hipStreamSynchronize(st));
+  const LsnCbRes* cbres = r.h_cbres_pinned;
+  const uint8_t* pay_base = r.h_payload_pinned;
+  const float* stat = ul_h_stat;
   for (size_t t = 0; t < tbs.size(); t++) {
     const TbRef& ref = tbs[t];
     bool all_ok = true;
@@ -318,7 +343,7 @@ void Engine::puschDecodeGrid(const cf32* d_grid, uint32_t nsf, uint32_t start_tt
       rem ^= crc24a_mulmod(cr.rem_a, crc24a_xpow(bits_after));
       bits_after += 8ull * r.h_cbs[ref.cb_first + q].out_bytes;
     }
-    const uint8_t* pl = pay.data() + ref.pay_off;
+    const uint8_t* pl = pay_base + ref.pay_off;
     const uint32_t par = ((uint32_t)pl[ref.tbs / 8] << 16) | ((uint32_t)pl[ref.tbs / 8 + 1] << 8) | pl[ref.tbs / 8 + 2];
     lsn_pusch_result_t& res = results[ref.grant];
     res.crc_ok = all_ok && rem == 0 && par != 0 && bits_after == (uint64_t)ref.tbs + 24;

@@ -105,6 +105,13 @@ struct LsnUlGrantDev {
 
 struct LsnCbRes { uint32_t ok, iters, rem_a, iters_run; uint32_t cyc_rm, cyc_map, cyc_out, cyc_all; };  // cyc_*: shader cycles per phase (s_memtime)
 
+// Descriptor upload without the SDMA queue: a few workgroups read `bytes` (rounded up to words; both buffers are allocated with slack) from PINNED host
+// memory and store them to device memory.  hipMemcpyAsync host -> device is served by one FIFO copy engine: a 3 KB descriptor upload queued behind the
+// 393 MB IQ blocks of the ingest path waits for all of them (tools/copy_kernel_timeline.py) - this does not.
+void lsn_launch_upload(void* dst_dev, const void* src_pinned, size_t bytes, hipStream_t s);
+// The way back (stage-A mirrors, code-block verdicts, payloads): device -> PINNED host memory by posted PCIe writes of a copy kernel.  The copy
+// engine serves both directions from one queue, so a hipMemcpyAsync device -> host would also wait behind the IQ blocks queued ahead.
+void lsn_launch_download(void* dst_pinned, const void* src_dev, size_t bytes, hipStream_t s);
 // launchers (stage_a.hip / stage_c.hip)
 void lsn_launch_ofdm(const LsnCellDev& c, const cf32* iq, const uint32_t* dphi, cf32* grid, uint32_t nsf, hipStream_t s);
 void lsn_launch_chest(const LsnCellDev& c, const cf32* grid, const uint32_t* sf_idx, cf32* ce, float* raw, uint32_t nsf, hipStream_t s);

@@ -9,6 +9,7 @@
 // Float arithmetic is written one rounding per operation (compiled with -ffp-contract=off) so that results are
 // bit-identical to the CPU oracle used by the tests.
 #include "lsn_dev.h"
+#include <algorithm>
 
 #define SQRT2F 1.41421356237309504880f
 
@@ -724,4 +725,38 @@ void lsn_launch_file_unpack(const cf32* raw, const cf32* rot, uint32_t sflen, ui
 {
   if (!nsf) return;
   hipLaunchKernelGGL(k_file_unpack, dim3((sflen + 255) / 256, nant, nsf), dim3(256), 0, s, raw, rot, sflen, nant, out);
+}
+
+// ------------------------------------------------------------------------------------------------ descriptor upload (see lsn_dev.h)
+__global__ __launch_bounds__(256) void k_upload_words(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, uint32_t n)
+{
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) dst[i] = src[i];
+}
+void lsn_launch_upload(void* dst_dev, const void* src_pinned, size_t bytes, hipStream_t s)
+{
+  const uint32_t n = (uint32_t)((bytes + 3) / 4);
+  if (!n) return;
+  const uint32_t blocks = std::min<uint32_t>((n + 255u) / 256u, 64u);
+  hipLaunchKernelGGL(k_upload_words, dim3(blocks), dim3(256), 0, s, (const uint32_t*)src_pinned, (uint32_t*)dst_dev, n);
+}
+
+__global__ __launch_bounds__(256) void k_download(const uint4* __restrict__ src, uint4* __restrict__ dst, uint32_t n16, const uint32_t* __restrict__ src_w,
+                                                  uint32_t* __restrict__ dst_w, uint32_t tail_first, uint32_t tail_n)
+{
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n16; i += gridDim.x * 256u) dst[i] = src[i];
+  if (blockIdx.x == 0 && threadIdx.x < tail_n) dst_w[tail_first + threadIdx.x] = src_w[tail_first + threadIdx.x];
+}
+void lsn_launch_download(void* dst_pinned, const void* src_dev, size_t bytes, hipStream_t s)
+{
+  if (!bytes) return;
+  const bool al = (((uintptr_t)dst_pinned | (uintptr_t)src_dev) & 15u) == 0;
+  const uint32_t words = (uint32_t)((bytes + 3) / 4), n16 = al ? words / 4 : 0, tail_first = n16 * 4, tail_n = words - tail_first;
+  if (!al || tail_n > 256) {  // unaligned buffers: word copy
+    const uint32_t blocks = std::min<uint32_t>((words + 255u) / 256u, 128u);
+    hipLaunchKernelGGL(k_upload_words, dim3(blocks), dim3(256), 0, s, (const uint32_t*)src_dev, (uint32_t*)dst_pinned, words);
+    return;
+  }
+  const uint32_t blocks = std::max<uint32_t>(1u, std::min<uint32_t>((n16 + 255u) / 256u, 128u));
+  hipLaunchKernelGGL(k_download, dim3(blocks), dim3(256), 0, s, (const uint4*)src_dev, (uint4*)dst_pinned, n16, (const uint32_t*)src_dev, (uint32_t*)dst_pinned, tail_first,
+                     tail_n);
 }

@@ -18,6 +18,20 @@ __global__ void k_pull(const float4* __restrict__ src, float4* __restrict__ dst,
   for (; i < n; i += stride) dst[i] = src[i];
 }
 
+// a compute hog: every CU busy with dependent integer work and some LDS traffic for `iters` rounds (stands in for the decode kernels)
+__global__ void k_busy(uint32_t* out, int iters)
+{
+  __shared__ uint32_t sm[1024];
+  uint32_t a = threadIdx.x + blockIdx.x, b = 0x9E3779B9u;
+  sm[threadIdx.x] = a;
+  __syncthreads();
+  for (int i = 0; i < iters; i++) {
+    a = a * 1664525u + 1013904223u; b ^= a >> 7; b += sm[(a >> 10) & 1023];
+    if ((i & 63) == 0) { sm[threadIdx.x] = b; __syncthreads(); }
+  }
+  if (a == 0x12345u) out[0] = b;
+}
+
 int main(int argc, char** argv)
 {
   const size_t MB = (size_t)1 << 20;
@@ -85,6 +99,45 @@ int main(int argc, char** argv)
       CK(hipMemcpyAsync((char*)d + half, (char*)h + half, half, hipMemcpyHostToDevice, st[1]));
       CK(hipDeviceSynchronize());
       printf("  kernel pull (half) + memcpyAsync (half) concurrently : %6.2f GB/s\n", total / (now() - t0) / 1e9);
+    }
+    // the same copies while the compute units are busy (what the pipeline sees: copies of the next blocks under the decode kernels)
+    {
+      uint32_t* dummy = nullptr;
+      CK(hipMalloc((void**)&dummy, 64));
+      for (int mode = 0; mode < 3; mode++) {
+        CK(hipDeviceSynchronize());
+        const int hog_blocks = mode == 2 ? 256 * 2 : 256 * 8;
+        hipLaunchKernelGGL(k_busy, dim3(hog_blocks), dim3(256), 0, st[2], dummy, 3000000);   // several hundred ms of busy CUs
+        const double t0 = now();
+        if (mode == 0 || mode == 2) {
+          size_t off = 0; const size_t blk = (size_t)384 * MB;
+          while (off + blk <= total) { CK(hipMemcpyAsync((char*)d + off, (char*)h + off, blk, hipMemcpyHostToDevice, st[0])); off += blk; }
+          CK(hipStreamSynchronize(st[0]));
+          printf("  memcpyAsync 384 MB blocks under a compute hog (%d workgroups) : %6.2f GB/s\n", hog_blocks, off / (now() - t0) / 1e9);
+        } else {
+          hipLaunchKernelGGL(k_pull, dim3(256), dim3(256), 0, st[0], (const float4*)h, (float4*)d, total / 16);
+          CK(hipStreamSynchronize(st[0]));
+          printf("  zero-copy kernel read (256 workgroups) under a compute hog : %6.2f GB/s\n", total / (now() - t0) / 1e9);
+        }
+        const double t1 = now();
+        CK(hipDeviceSynchronize());
+        printf("    (hog ran %.0f ms beyond the copy)\n", (now() - t1) * 1e3);
+      }
+      // a D2H stream of small blocks next to the H2D copies (candidate tables / payloads go back while the next block comes in)
+      {
+        CK(hipDeviceSynchronize());
+        const double t0 = now();
+        size_t off = 0; const size_t blk = (size_t)384 * MB;
+        while (off + blk <= total) {
+          CK(hipMemcpyAsync((char*)d + off, (char*)h + off, blk, hipMemcpyHostToDevice, st[0]));
+          for (int q = 0; q < 4; q++) CK(hipMemcpyAsync((char*)h + total - (q + 1) * 8 * MB, (char*)d + q * 8 * MB, 8 * MB, hipMemcpyDeviceToHost, st[1]));
+          off += blk;
+        }
+        CK(hipStreamSynchronize(st[0]));
+        printf("  memcpyAsync 384 MB blocks with 4 x 8 MB D2H per block on another stream : %6.2f GB/s\n", off / (now() - t0) / 1e9);
+        CK(hipDeviceSynchronize());
+      }
+      CK(hipFree(dummy));
     }
     // device -> host for completeness (candidate tables and payloads go this way)
     {
