@@ -462,7 +462,7 @@ static void grow_host(T*& p, size_t& cap, size_t need, hipStream_t st)
   HIP_CHECK(hipStreamSynchronize(st));
   if (p) HIP_CHECK(hipHostFree(p));
   cap = need + need / 2 + 1024;
-  HIP_CHECK(hipHostMalloc((void**)&p, cap * sizeof(T)));
+  HIP_CHECK(hipHostMalloc((void**)&p, cap * sizeof(T), hipHostMallocCoherent | hipHostMallocMapped));
 }
 
 void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
@@ -1126,53 +1126,85 @@ void Engine::frontLoop()
     cv_spec.notify_one();
     cv_done.notify_all();
   };
+  // One poll loop, two duties: (1) launch stage A of the next chunk as soon as a chunk slot is free, a stage-A stream is free and the chunk's
+  // input is IN PLACE - the "block ready" event of its submit is waited for HERE, on the host (hipEventQuery), never by the GPU queue: a
+  // barrier packet that waits for a copy several blocks ahead stalls every stream that shares the hardware queue (measured: the whole
+  // decode stage stood still until the last queued copy had finished, tools/copy_kernel_timeline.py); (2) collect finished stage-A chunks
+  // in order and pass them on.  Nothing to do -> nap 20 us (or sleep on the condition variable when the pipeline is empty).
+  FrontJob job;
+  bool have_job = false, ready_ok = false;
+  uint32_t ci = 0, nchunks = 0;
+  double t_wait_slot = -1.0;
   for (;;) {
-    FrontJob job;
-    bool have = false;
-    {
+    if (!have_job) {
       std::unique_lock<std::mutex> lk(mtx);
       if (inflight.empty()) cv_front.wait(lk, [&] { return stop || !front_jobs.empty(); });
       if (front_jobs.empty() && inflight.empty()) return;  // stop
-      if (!front_jobs.empty()) { job = front_jobs.front(); front_jobs.pop_front(); have = true; }
+      if (!front_jobs.empty()) {
+        job = front_jobs.front(); front_jobs.pop_front();
+        have_job = true; ready_ok = job.ready == nullptr; ci = 0;
+        nchunks = (job.nsf_total + max_batch - 1) / max_batch;
+      }
     }
     (void)hipSetDevice(cfg.device);
-    if (!have) { finish_oldest(); continue; }
-    const uint32_t nchunks = (job.nsf_total + max_batch - 1) / max_batch;
-    const size_t sf_stride = (size_t)cfg.nof_rx_antennas * cd.sflen * sizeof(cf32);
-    for (uint32_t ci = 0; ci < nchunks; ci++) {
-      while (inflight.size() >= (size_t)NSTREAM_A) finish_oldest();
-      Chunk& ch = chunks[slot_counter++ % (uint64_t)nslots];  // slots rotate across submits
-      trace(1, TR_ACQ_BEGIN, ci);
-      {
-        const double tw = now_ms();
-        std::unique_lock<std::mutex> lk(mtx);
-        cv_done.wait(lk, [&] { return !ch.busy || stop; });
-        if (stop) return;
-        ch.busy = true;
-        perf_front.ms_wait_slot += now_ms() - tw;
-      }
-      const uint32_t base = ci * max_batch;
-      ch.nsf = std::min(max_batch, job.nsf_total - base);
-      ch.start_tti = job.start_tti + base;
-      ch.update_meta_period = job.update_meta_period;
-      ch.force_meta = job.force_meta && ci == 0;
-      ch.gseq = job.gseq0 + ci;
-      ch.jobs.clear(); ch.jres.clear(); ch.cdci.clear(); ch.setup_cfgs.clear(); ch.h_payload.clear(); ch.recs.clear(); ch.err.clear();
-      for (uint32_t i = 0; i < ch.nsf; i++) ch.ctx[i].reset(ch.start_tti + i);
-      ch.st_a = stream_a[(slot_counter - 1) % NSTREAM_A];
-      ch.trace_id = ci;
-      trace(1, TR_ACQ_END, ci);
-      try {
-        if (job.ready) HIP_CHECK(hipStreamWaitEvent(ch.st_a, job.ready, 0));
-        launchStageA(ch, (const uint8_t*)job.d_iq + (size_t)base * sf_stride);
-      } catch (const std::exception& ex) {
-        ch.err = ex.what();
-      }
-      inflight.push_back(&ch);
+    bool progress = false;
+    // (2) the oldest chunk in flight
+    if (!inflight.empty()) {
+      Chunk* o = inflight.front();
+      const bool done = !o->err.empty() || hipEventQuery(o->ev_a[16]) != hipErrorNotReady;
+      if (done) { (void)hipGetLastError(); finish_oldest(); progress = true; }
     }
-    if (job.ready) {  // every chunk of the block has its wait queued: the event can carry another block
-      std::unique_lock<std::mutex> lk(mtx);
-      ev_pool.push_back(job.ready);
+    // (1) the next chunk of the current block
+    if (have_job && inflight.size() < (size_t)NSTREAM_A) {
+      static const bool gpu_wait = getenv("LSN_FRONT_GPU_WAIT") != nullptr;  // A/B: order stage A behind the block on the GPU (barrier packet) instead of waiting here
+      if (!ready_ok) {
+        const hipError_t q = gpu_wait ? hipSuccess : hipEventQuery(job.ready);
+        if (q != hipErrorNotReady) { (void)hipGetLastError(); ready_ok = true; }
+      }
+      Chunk& ch = chunks[slot_counter % (uint64_t)nslots];  // slots rotate across submits
+      bool slot_free = false;
+      if (ready_ok) {
+        std::unique_lock<std::mutex> lk(mtx);
+        if (stop) return;
+        slot_free = !ch.busy;
+        if (slot_free) ch.busy = true;
+      }
+      if (ready_ok && !slot_free && t_wait_slot < 0) { t_wait_slot = now_ms(); trace(1, TR_ACQ_BEGIN, ci); }
+      if (ready_ok && slot_free) {
+        if (t_wait_slot >= 0) { perf_front.ms_wait_slot += now_ms() - t_wait_slot; t_wait_slot = -1.0; } else trace(1, TR_ACQ_BEGIN, ci);
+        slot_counter++;
+        const uint32_t base = ci * max_batch;
+        const size_t sf_stride = (size_t)cfg.nof_rx_antennas * cd.sflen * sizeof(cf32);  // (the cell is set after this thread has started)
+        ch.nsf = std::min(max_batch, job.nsf_total - base);
+        ch.start_tti = job.start_tti + base;
+        ch.update_meta_period = job.update_meta_period;
+        ch.force_meta = job.force_meta && ci == 0;
+        ch.gseq = job.gseq0 + ci;
+        ch.jobs.clear(); ch.jres.clear(); ch.cdci.clear(); ch.setup_cfgs.clear(); ch.h_payload.clear(); ch.recs.clear(); ch.err.clear();
+        for (uint32_t i = 0; i < ch.nsf; i++) ch.ctx[i].reset(ch.start_tti + i);
+        ch.st_a = stream_a[(slot_counter - 1) % NSTREAM_A];
+        ch.trace_id = ci;
+        trace(1, TR_ACQ_END, ci);
+        try {
+          if (gpu_wait && job.ready) HIP_CHECK(hipStreamWaitEvent(ch.st_a, job.ready, 0));
+          launchStageA(ch, (const uint8_t*)job.d_iq + (size_t)base * sf_stride);
+        } catch (const std::exception& ex) {
+          ch.err = ex.what();
+        }
+        inflight.push_back(&ch);
+        progress = true;
+        if (++ci == nchunks) {
+          have_job = false;
+          if (job.ready) {  // the event can carry another block
+            std::unique_lock<std::mutex> lk(mtx);
+            ev_pool.push_back(job.ready);
+          }
+        }
+      }
+    }
+    if (!progress) {
+      timespec ts{0, 20000};
+      nanosleep(&ts, nullptr);
     }
   }
 }
@@ -1314,7 +1346,7 @@ int Engine::submitFrom(const void* d_iq, int src_device, uint32_t nsf, uint32_t 
   try {
     HIP_CHECK(hipSetDevice(cfg.device));
     if (!copy_stream) {
-      HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+      createCopyStream();
       for (auto& e : copy_done) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     const size_t sf_stride = (size_t)cfg.nof_rx_antennas * cd.sflen * sizeof(cf32);
@@ -1340,13 +1372,25 @@ int Engine::submitFrom(const void* d_iq, int src_device, uint32_t nsf, uint32_t 
   }
 }
 
+// The stream the IQ blocks are copied on.  Its markers ("copy done" events) are barrier packets that wait for a copy-engine signal; a hardware
+// queue is shared by the streams of one priority class, so the copy stream gets the lowest priority - a class of its own - and its
+// barriers hold up nobody else's kernels.
+void Engine::createCopyStream()
+{
+  int lo = 0, hi = 0;
+  (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+  static const int mode = getenv("LSN_COPY_STREAM_PRIO") ? atoi(getenv("LSN_COPY_STREAM_PRIO")) : 1;  // 0 default priority, 1 lowest, 2 highest
+  if (mode == 0) HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+  else HIP_CHECK(hipStreamCreateWithPriority(&copy_stream, hipStreamNonBlocking, mode == 1 ? lo : hi));
+}
+
 int Engine::submitHostRows(const void* host_rows, size_t row_pitch, uint32_t nsf, uint32_t start_tti, bool force_meta_first, hipEvent_t copied)
 {
   if (!cell_set || !host_rows || nsf == 0 || nsf > max_batch) return LSN_ERROR_INVALID_INPUTS;
   try {
     HIP_CHECK(hipSetDevice(cfg.device));
     if (!copy_stream) {
-      HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+      createCopyStream();
       for (auto& e : copy_done) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     }
     const size_t row_bytes = (size_t)cd.sflen * sizeof(cf32), sf_stride = (size_t)cfg.nof_rx_antennas * row_bytes;

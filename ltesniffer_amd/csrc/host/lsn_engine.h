@@ -198,6 +198,7 @@ private:
   static constexpr int NDEC = 12;            // max decode threads (each: plan + stage-C launches of one chunk; commits stay in order)
   static constexpr int NSLOTS = NDEC + 8;
   int ndec = 8, nslots = 16;                  // in use (LSN_DECODE_THREADS)
+  void createCopyStream();
   void freeDevice();
   void buildTables();
   void allocChunk(Chunk& ch);

@@ -102,13 +102,14 @@ void Engine::allocRunner(JobRunner& r)
   if (&r == &runner_s || &r == &runner_f || &r == &runner_u || &r == &runner_k) {
     HIP_CHECK(hipStreamCreateWithPriority(&r.stream, hipStreamNonBlocking, hi));
   } else {
-    // bulk decode streams leave a few CUs alone, so that the latency-critical launches (stage A, on-demand RAR decodes)
-    // never queue behind thousands of resident turbo workgroups
+    // bulk decode streams: lowest priority.  (LSN_RESERVED_CUS = n > 0 masks n CUs out of them instead, so that the latency-critical launches -
+    // stage A, on-demand RAR decodes - never queue behind resident turbo workgroups: round 2's default.  Measured in round 3 with the ingest
+    // path fixed: CU-masked streams stand still while host -> device copies are in flight and cost 12 % of the resident rate - off by default.)
     hipDeviceProp_t prop;
     HIP_CHECK(hipGetDeviceProperties(&prop, cfg.device));
     const int ncu = prop.multiProcessorCount;
     const char* env = getenv("LSN_RESERVED_CUS");
-    const int reserve = env ? atoi(env) : 8;
+    const int reserve = env ? atoi(env) : 0;
     std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
     for (int i = 0; i < ncu; i++)
       if (!(reserve > 0 && i % (ncu / (reserve > 0 ? reserve : 1)) == 0)) mask[i / 32] |= 1u << (i % 32);
@@ -123,7 +124,7 @@ template <typename T>
 static T* halloc(std::vector<void*>& allocs, size_t n)
 {
   void* h = nullptr;
-  HIP_CHECK(hipHostMalloc(&h, n * sizeof(T) + 16));
+  HIP_CHECK(hipHostMalloc(&h, n * sizeof(T) + 16, hipHostMallocCoherent | hipHostMallocMapped));  // fine-grained: GPU stores / loads go straight to host memory (copy kernels, lsn_dev.h)
   allocs.push_back(h);
   return (T*)h;
 }

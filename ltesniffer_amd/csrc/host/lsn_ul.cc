@@ -296,13 +296,13 @@ void Engine::puschDecodeGrid(const cf32* d_grid, uint32_t nsf, uint32_t start_tt
     HIP_CHECK(hipStreamSynchronize(st));
     if (ul_h_grants) HIP_CHECK(hipHostFree(ul_h_grants));
     ul_h_grants_cap = ng + ng / 2 + 64;
-    HIP_CHECK(hipHostMalloc((void**)&ul_h_grants, ul_h_grants_cap * sizeof(LsnUlGrantDev)));
+    HIP_CHECK(hipHostMalloc((void**)&ul_h_grants, ul_h_grants_cap * sizeof(LsnUlGrantDev), hipHostMallocCoherent | hipHostMallocMapped));
   }
   if (ncb > r.h_cbs_cap) {
     HIP_CHECK(hipStreamSynchronize(st));
     if (r.h_cbs_pinned) HIP_CHECK(hipHostFree(r.h_cbs_pinned));
     r.h_cbs_cap = ncb + ncb / 2 + 1024;
-    HIP_CHECK(hipHostMalloc((void**)&r.h_cbs_pinned, r.h_cbs_cap * sizeof(LsnCbDev)));
+    HIP_CHECK(hipHostMalloc((void**)&r.h_cbs_pinned, r.h_cbs_cap * sizeof(LsnCbDev), hipHostMallocCoherent | hipHostMallocMapped));
   }
   std::memcpy(ul_h_grants, gd.data(), ng * sizeof(LsnUlGrantDev));
   std::memcpy(r.h_cbs_pinned, sorted.data(), ncb * sizeof(LsnCbDev));
@@ -319,7 +319,7 @@ void Engine::puschDecodeGrid(const cf32* d_grid, uint32_t nsf, uint32_t start_tt
     HIP_CHECK(hipStreamSynchronize(st));
     if (p) HIP_CHECK(hipHostFree(p));
     cap = need + need / 2 + 1024;
-    HIP_CHECK(hipHostMalloc((void**)&p, cap * sizeof(*p)));
+    HIP_CHECK(hipHostMalloc((void**)&p, cap * sizeof(*p), hipHostMallocCoherent | hipHostMallocMapped));
   };
   grow_pinned(r.h_cbres_pinned, r.h_cbres_cap, ncb);
   grow_pinned(r.h_payload_pinned, r.h_payload_cap, pay_n + 16);

@@ -10,6 +10,7 @@
 // bit-identical to the CPU oracle used by the tests.
 #include "lsn_dev.h"
 #include <algorithm>
+#include <cstdlib>
 
 #define SQRT2F 1.41421356237309504880f
 
@@ -745,10 +746,13 @@ __global__ __launch_bounds__(256) void k_download(const uint4* __restrict__ src,
 {
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n16; i += gridDim.x * 256u) dst[i] = src[i];
   if (blockIdx.x == 0 && threadIdx.x < tail_n) dst_w[tail_first + threadIdx.x] = src_w[tail_first + threadIdx.x];
+  __threadfence_system();  // the stores to host memory are performed at system scope before the kernel (and the event behind it) completes
 }
 void lsn_launch_download(void* dst_pinned, const void* src_dev, size_t bytes, hipStream_t s)
 {
   if (!bytes) return;
+  static const bool use_memcpy = getenv("LSN_MIRROR_MEMCPY") && atoi(getenv("LSN_MIRROR_MEMCPY"));  // A/B: the copy engine instead of the copy kernel
+  if (use_memcpy) { (void)hipMemcpyAsync(dst_pinned, src_dev, bytes, hipMemcpyDeviceToHost, s); return; }
   const bool al = (((uintptr_t)dst_pinned | (uintptr_t)src_dev) & 15u) == 0;
   const uint32_t words = (uint32_t)((bytes + 3) / 4), n16 = al ? words / 4 : 0, tail_first = n16 * 4, tail_n = words - tail_first;
   if (!al || tail_n > 256) {  // unaligned buffers: word copy
