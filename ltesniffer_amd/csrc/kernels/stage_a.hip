@@ -10,6 +10,7 @@
 // bit-identical to the CPU oracle used by the tests.
 #include "lsn_dev.h"
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 
 #define SQRT2F 1.41421356237309504880f
