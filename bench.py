@@ -127,6 +127,7 @@ def main():
                          "whose chunks go round-robin to the N GPUs (lsn_phy_create_multi on rank 0; the other ranks only hold their GPU) - strong scaling, "
                          "bounded by the sequential FALCON search on one host thread")
     ap.add_argument("--no-legs", action="store_true", help="skip the PCIe-inclusive legs (host buffers, capture file, worker pool) and the other configs")
+    ap.add_argument("--leg-batch", type=int, default=0, help="pipeline chunk of the first-H2D-to-last-PDU legs (0 = --batch)")
     ap.add_argument("--gen-threads", type=int, default=0, help="threads of the synthetic transmitter (0 = the CPUs this process may use, at most 32)")
     args = ap.parse_args()
 
@@ -384,9 +385,11 @@ def main():
 
         try:
             host = torch.from_numpy(iq).pin_memory()
-            two_passes("host_pinned", lambda w: la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=batch, device=local, pcapwriter=w),
+            lbatch = args.leg_batch or batch
+            legs["chunk_subframes"] = lbatch
+            two_passes("host_pinned", lambda w: la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=lbatch, device=local, pcapwriter=w),
                        lambda ph, t: (ph.process_host(host.numpy(), t, META_PERIOD), nsf)[1])
-            two_passes("host_pageable", lambda w: la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=batch, device=local, pcapwriter=w),
+            two_passes("host_pageable", lambda w: la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=lbatch, device=local, pcapwriter=w),
                        lambda ph, t: (ph.process_host(iq, t, META_PERIOD), nsf)[1], {"note": "registered in place (hipHostRegister) for the call"})
             # the reference's boundary: 1024 workers (1.5 GB pinned slab), chunks of up to 512 subframes; producer = 1 thread like LTESniffer_Core, then 4 copy threads
             import ctypes as C
@@ -407,7 +410,7 @@ def main():
                 for a in range(0, nsf, 1000):
                     np.ascontiguousarray(np.transpose(iq[a:a + 1000], (0, 2, 1))).tofile(f)
             try:
-                two_passes("file_replay", lambda w: la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=batch, device=local, pcapwriter=w),
+                two_passes("file_replay", lambda w: la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=lbatch, device=local, pcapwriter=w),
                            lambda ph, t: ph.process_file(path, start_tti=t, update_meta_period=META_PERIOD),
                            {"storage": "tmpfs (/dev/shm) = page cache; pread threads -> pinned blocks -> PCIe"})
             finally:
