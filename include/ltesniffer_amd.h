@@ -261,7 +261,7 @@ int lsn_phy_process_file(lsn_phy_t* phy, const char* path, const lsn_file_cfg_t*
 typedef struct {
   uint32_t tti; uint16_t rnti;
   uint32_t id_type;   /* Sniffer_dependency.h:42-47: 0 ID_RAN_VAL, 1 ID_TMSI, 2 ID_CON_RES, 3 ID_IMSI, 4 ID_IMEI, 5 ID_IMEISV, 0xFFFFFFFF none */
-  uint32_t msg_type;  /* Sniffer_dependency.h:49-55: 0 MSG_CON_REQ, 1 MSG_CON_SET, 2 MSG_ATT_REQ, 3 MSG_ID_RES, 4 MSG_UE_CAP, 5 MSG_PAGING */
+  uint32_t msg_type;  /* Sniffer_dependency.h:49-55: 0 MSG_CON_REQ, 1 MSG_CON_SET, 2 MSG_ATT_REQ, 3 MSG_ID_RES, 4 MSG_UE_CAP, 5 MSG_PAGING, 6 MSG_CON_RECONFIG (M-TMSI of the GUTI an attach accept inside an RRCConnectionReconfiguration assigns) */
   char value[24];     /* the string print_api_dl receives */
 } lsn_api_event_t;
 typedef void (*lsn_api_sink_t)(void* user, const lsn_api_event_t* ev);

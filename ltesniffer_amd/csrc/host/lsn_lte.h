@@ -182,7 +182,7 @@ struct PagingId { bool is_imsi = false; uint32_t nof_digits = 0; uint8_t digits[
 int paging_decode(const uint8_t* pdu, int len, PagingId* out, int cap);
 struct ApiEvent { uint32_t tti = 0; uint16_t rnti = 0; uint32_t id_type = 0, msg_type = 0; char value[24] = {0}; };  // print_api_dl's arguments
 enum { API_ID_RAN_VAL = 0, API_ID_TMSI = 1, API_ID_CON_RES = 2, API_ID_IMSI = 3, API_ID_IMEI = 4, API_ID_IMEISV = 5, API_ID_NONE = 0xFFFFFFFFu,
-       API_MSG_CON_REQ = 0, API_MSG_CON_SET = 1, API_MSG_ATT_REQ = 2, API_MSG_ID_RES = 3, API_MSG_UE_CAP = 4, API_MSG_PAGING = 5 };  // Sniffer_dependency.h:42-55
+       API_MSG_CON_REQ = 0, API_MSG_CON_SET = 1, API_MSG_ATT_REQ = 2, API_MSG_ID_RES = 3, API_MSG_UE_CAP = 4, API_MSG_PAGING = 5, API_MSG_CON_RECONFIG = 6 };  // Sniffer_dependency.h:42-55
 // what run_api_dl_mode reports for one CRC-ok downlink block (name = first letter of the reference's RNTI name, api_mode 0 / 2 / 3):
 // events appended to ev (at most cap), return value = true when the block also goes to the API pcap (write_dl_paging_api / write_dl_crnti_api)
 // the uplink side for a decoded Msg3 (PUSCH of a RAR grant, api_mode 0 / 3; PUSCH_Decoder::decode_run :306-327 + decode_rrc_connection_request
@@ -191,6 +191,8 @@ bool api_ul_msg3_events(int api_mode, const uint8_t* pdu, int len, uint16_t rnti
 // any other decoded uplink block (api_mode 1 / 2 / 3; decode_run :328-372, decode_ul_dcch :95-143, decode_nas_ul :146-247): SRB messages behind
 // RLC AM + PDCP - UECapabilityInformation (modes 1, 3), attach request / identity response identities (modes 2, 3)
 bool api_ul_dcch_events(int api_mode, const uint8_t* pdu, int len, uint16_t rnti, uint32_t tti, ApiEvent* ev, int cap, int* nev);
+// RRCConnectionReconfiguration (DL-DCCH) whose first dedicatedInfoNAS is an attach accept with a GUTI -> its M-TMSI (decode_rrc_connection_reconfig, DL_Sniffer_PDSCH.cc:181-220)
+bool rrc_reconfig_attach_accept_tmsi(const uint8_t* sdu, int len, uint32_t& m_tmsi);
 bool api_dl_events(int api_mode, char name, const uint8_t* pdu, int len, uint16_t rnti, uint32_t tti, ApiEvent* ev, int cap, int* nev);
 
 // ---- MCSTracking (DL table learning + UE-specific configuration + database ageing; MCSTracking.cc:758-927,1269-1400,1444-1540) ----

@@ -584,6 +584,117 @@ bool api_ul_dcch_events(int api_mode, const uint8_t* pdu, int len, uint16_t rnti
   return ok;
 }
 
+// ------------------------------------------------------------------------------------------------ RRCConnectionReconfiguration -> NAS attach accept -> GUTI
+// PDSCH_Decoder::decode_rrc_connection_reconfig (DL_Sniffer_PDSCH.cc:181-220): DL-DCCH-Message, c1 = rrcConnectionReconfiguration-r8, the FIRST
+// dedicatedInfoNAS; liblte_mme_parse_msg_header + liblte_mme_unpack_attach_accept_msg [srsRAN, not in tree; TS 24.301 8.2.1, 9.9.3.12] -> M-TMSI of
+// the GUTI.  UPER walk per TS 36.331 6.2.2 / 6.3.5: the components in FRONT of the NAS list must be walked to find it - measConfig (object /
+// report / id lists, quantity configuration, gaps, s-Measure; Rel-8 roots) is, mobilityControlInfo (a handover command never carries an attach
+// accept) is not: such a message, or one with extension additions inside measConfig, is reported as "no identity" where srsRAN would decode it.
+// Pinned by the two RRCConnectionReconfiguration messages of the reference's own captures (tests/test_rrc_oracle.py).
+static void thresholdEutra(BitReader& b) { if (!b.flag()) b.get(7); else b.get(6); }  // CHOICE { threshold-RSRP (0..97), threshold-RSRQ (0..34) }
+static bool measConfigSkip(BitReader& b)
+{
+  if (b.flag()) return false;  // extension additions: not walked
+  bool opt[11];
+  for (bool& o : opt) o = b.flag();
+  if (opt[0]) { const uint32_t n = b.get(5) + 1; b.get(5 * n); }  // measObjectToRemoveList: (1..32) each
+  if (opt[1]) {
+    const uint32_t n = b.get(5) + 1;
+    for (uint32_t i = 0; i < n && !b.err; i++) {
+      b.get(5);                                   // measObjectId
+      if (b.flag() || b.get(2) != 0) return false;  // only measObjectEUTRA
+      if (b.flag()) return false;                 // MeasObjectEUTRA extension additions
+      bool o[6];
+      for (bool& x : o) x = b.flag();
+      b.get(16); b.get(3); b.get(1); b.get(2);    // carrierFreq, allowedMeasBandwidth, presenceAntennaPort1, neighCellConfig
+      if (o[0]) b.get(5);                         // offsetFreq
+      if (o[1]) { const uint32_t k = b.get(5) + 1; b.get(5 * k); }                       // cellsToRemoveList
+      if (o[2]) { const uint32_t k = b.get(5) + 1; for (uint32_t j = 0; j < k; j++) { b.get(5); b.get(9); b.get(5); } }  // cellsToAddModList
+      if (o[3]) { const uint32_t k = b.get(5) + 1; b.get(5 * k); }                       // blackCellsToRemoveList
+      if (o[4]) {                                 // blackCellsToAddModList: cellIndex + PhysCellIdRange { start, range OPTIONAL }
+        const uint32_t k = b.get(5) + 1;
+        for (uint32_t j = 0; j < k; j++) { b.get(5); const bool r = b.flag(); b.get(9); if (r) b.get(4); }
+      }
+      if (o[5]) b.get(9);                         // cellForWhichToReportCGI
+    }
+  }
+  if (opt[2]) { const uint32_t n = b.get(5) + 1; b.get(5 * n); }  // reportConfigToRemoveList
+  if (opt[3]) {
+    const uint32_t n = b.get(5) + 1;
+    for (uint32_t i = 0; i < n && !b.err; i++) {
+      b.get(5);                                   // reportConfigId
+      if (b.get(1) != 0) return false;            // only reportConfigEUTRA
+      if (b.flag()) return false;                 // extension additions
+      if (!b.flag()) {                            // triggerType: event
+        if (b.flag()) return false;               // eventId extension
+        switch (b.get(3)) {
+          case 0: case 1: case 3: thresholdEutra(b); break;   // a1, a2, a4
+          case 2: b.get(6); b.get(1); break;                   // a3: offset (-30..30), reportOnLeave
+          case 4: thresholdEutra(b); thresholdEutra(b); break; // a5
+          default: return false;
+        }
+        b.get(5); b.get(4);                       // hysteresis, timeToTrigger
+      } else {
+        b.get(1);                                 // periodical: purpose
+      }
+      b.get(1); b.get(1); b.get(3); b.get(4); b.get(3);  // triggerQuantity, reportQuantity, maxReportCells, reportInterval, reportAmount
+    }
+  }
+  if (opt[4]) { const uint32_t n = b.get(5) + 1; b.get(5 * n); }   // measIdToRemoveList
+  if (opt[5]) { const uint32_t n = b.get(5) + 1; b.get(15 * n); }  // measIdToAddModList: measId, measObjectId, reportConfigId
+  if (opt[6]) {                                   // quantityConfig
+    if (b.flag()) return false;
+    bool q[4];
+    for (bool& x : q) x = b.flag();
+    if (q[0]) { const bool r1 = b.flag(), r2 = b.flag(); for (bool r : {r1, r2}) if (r) { if (b.flag()) return false; b.get(4); } }  // filterCoefficientRSRP / RSRQ
+    if (q[1] || q[2] || q[3]) return false;       // UTRA / GERAN / CDMA2000 quantities: not walked
+  }
+  if (opt[7]) { if (b.flag()) { if (!b.flag()) b.get(6); else b.get(7); } }  // measGapConfig: release / setup { gp0 (0..39) | gp1 (0..79) }
+  if (opt[8]) b.get(7);                           // s-Measure (0..97)
+  if (opt[9] || opt[10]) return false;            // preRegistrationInfoHRPD, speedStatePars: not walked
+  return !b.err;
+}
+
+bool rrc_reconfig_attach_accept_tmsi(const uint8_t* sdu, int len, uint32_t& m_tmsi)
+{
+  if (len < 4) return false;
+  BitReader b{sdu, (uint32_t)len * 8u};
+  if (b.flag() || b.get(4) != 4) return false;    // DL-DCCH-MessageType c1, rrcConnectionReconfiguration
+  b.get(2);                                       // rrc-TransactionIdentifier
+  if (b.flag() || b.get(3) != 0) return false;    // criticalExtensions c1, rrcConnectionReconfiguration-r8
+  bool o[6];
+  for (bool& x : o) x = b.flag();                 // measConfig, mobilityControlInfo, dedicatedInfoNASList, radioResourceConfigDedicated, securityConfigHO, nonCriticalExtension
+  if (!o[2] || o[1]) return false;
+  if (o[0] && !measConfigSkip(b)) return false;
+  b.get(4);                                       // number of NAS messages - 1; the reference looks at the first one only
+  const uint32_t n = b.length();
+  if (b.err || n < 8 || b.pos + 8u * n > b.nbits) return false;
+  uint8_t nas[256];
+  if (n > sizeof(nas)) return false;
+  for (uint32_t i = 0; i < n; i++) nas[i] = (uint8_t)b.get(8);
+  // liblte_mme_parse_msg_header: plain NAS -> octet 1 is the message type; integrity protected (security header type 1..4) -> MAC (4) + sequence
+  // number (1) in front of the plain message
+  const uint32_t sht = nas[0] >> 4;
+  uint32_t p = 0;
+  if (sht == 0) p = 0;
+  else if (sht <= 4) p = 6;
+  else return false;
+  if (p + 2 > n || (nas[p] & 0x0Fu) != 0x07u || nas[p + 1] != 0x42u) return false;  // EPS mobility management, attach accept
+  p += 2;
+  p += 2;                                         // EPS attach result + spare half octet, T3412
+  if (p >= n) return false;
+  const uint32_t tai_len = nas[p];                // TAI list (LV, 6..96 octets)
+  if (tai_len < 6 || tai_len > 96) return false;
+  p += 1 + tai_len;
+  if (p + 2 > n) return false;
+  const uint32_t esm_len = ((uint32_t)nas[p] << 8) | nas[p + 1];  // ESM message container (LV-E)
+  p += 2 + esm_len;
+  if (p + 13 > n || nas[p] != 0x50u) return false;  // GUTI IE (IEI 0x50) is the first optional element
+  if (nas[p + 1] != 11 || (nas[p + 2] & 0x07u) != 6u) return false;  // EPS mobile identity of type GUTI
+  m_tmsi = ((uint32_t)nas[p + 9] << 24) | ((uint32_t)nas[p + 10] << 16) | ((uint32_t)nas[p + 11] << 8) | nas[p + 12];
+  return true;
+}
+
 bool api_dl_events(int api_mode, char name, const uint8_t* pdu, int len, uint16_t rnti, uint32_t tti, ApiEvent* ev, int cap, int* nev)
 {
   int n = 0;
@@ -619,7 +730,13 @@ bool api_dl_events(int api_mode, char name, const uint8_t* pdu, int len, uint16_
         UeSpecConfig c;
         if (rrc_conn_setup_decode(pdu + sub[i].off, (int)sub[i].len, c)) setup = true;
       } else if (sub[i].is_sdu && sub[i].lcid == 1) {
-        // RRCConnectionReconfiguration / NAS identities: not restated
+        // SRB1: RLC AM header (2) + PDCP sequence number (1) assumed in front of the DL-DCCH message (DL_Sniffer_PDSCH.cc:836-838)
+        uint32_t tmsi = 0;
+        if (sub[i].len > 3 && rrc_reconfig_attach_accept_tmsi(pdu + sub[i].off + 3, (int)sub[i].len - 3, tmsi)) {
+          char v[24];
+          std::snprintf(v, sizeof(v), "%08x", tmsi);
+          add(rnti, API_ID_TMSI, API_MSG_CON_RECONFIG, v);
+        }
       } else {
         if (nseen < 10) seen[nseen++] = i; else break;
       }

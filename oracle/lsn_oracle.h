@@ -328,6 +328,7 @@ int o_worker_ul_config(o_worker_t* w, o_ul_cfg_t* ul, o_sib2_t* sib2); /* 0 not 
 int o_worker_work_ul(o_worker_t*, const ocf_t* dl_iq, const ocf_t* ul_iq, uint32_t sf_idx, uint32_t sfn, int update_meta_formats);
 const o_stats_t* o_worker_stats(o_worker_t*);
 void o_worker_ue_cfg(o_worker_t* w, uint16_t rnti, o_ue_cfg_t* out); /* MCSTracking::get_ue_config_rnti */
+int o_rrc_reconfig_tmsi(const uint8_t* sdu, int len, uint32_t* m_tmsi); /* decode_rrc_connection_reconfig: M-TMSI of the attach accept's GUTI */
 void o_worker_set_api(o_worker_t* w, int api_mode, o_pcap_t* api_pcap); /* -a: -1 off, 0 identity mapping, 2 IMSI catching, 3 all */
 int o_worker_api_events(o_worker_t* w, o_api_event_t* out, int cap);     /* events reported so far (print_api_dl) */
 void o_worker_set_second_opinion(o_worker_t* w, int turbo, int viterbi); /* decode transport blocks / DCI candidates with o_second.c */

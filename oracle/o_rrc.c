@@ -374,6 +374,120 @@ int o_paging_decode(const uint8_t* pdu, int len, o_paging_id_t* out, int cap)
 }
 
 #include <stdio.h>
+/* ---------------- RRCConnectionReconfiguration -> attach accept -> GUTI (decode_rrc_connection_reconfig, DL_Sniffer_PDSCH.cc:181-220) ----------------
+ * The reference unpacks the DL-DCCH message with srsRAN's ASN.1 code and the first NAS container with liblte_mme [both not in tree]: TS 36.331
+ * 6.2.2 (RRCConnectionReconfiguration-r8-IEs), 6.3.5 (MeasConfig), TS 24.301 8.2.1 (attach accept), 9.9.3.12 (EPS mobile identity).  This
+ * restatement keeps a cursor over the bit string and consumes the components in front of dedicatedInfoNASList one by one. */
+typedef struct { const uint8_t* d; uint32_t n, at; int bad; } cur_t;
+static uint32_t take(cur_t* c, uint32_t k)
+{
+  uint32_t v = 0;
+  while (k--) {
+    if (c->at >= c->n) { c->bad = 1; return 0; }
+    v = (v << 1) | ((c->d[c->at >> 3] >> (7u - (c->at & 7u))) & 1u);
+    c->at++;
+  }
+  return v;
+}
+static void drop_list5(cur_t* c, uint32_t item_bits) /* SEQUENCE (SIZE (1..32)) OF fixed-width items */
+{
+  uint32_t cnt = take(c, 5) + 1;
+  for (uint32_t i = 0; i < cnt; i++) take(c, item_bits);
+}
+static void drop_threshold(cur_t* c) { take(c, take(c, 1) ? 6 : 7); }
+static int drop_meas_object(cur_t* c)
+{
+  take(c, 5);
+  if (take(c, 1)) return 0;          /* measObject choice extended */
+  if (take(c, 2) != 0) return 0;     /* UTRA / GERAN / CDMA2000 */
+  if (take(c, 1)) return 0;          /* MeasObjectEUTRA carries extension additions */
+  uint32_t has = take(c, 6);         /* offsetFreq, cellsToRemove, cellsToAddMod, blackCellsToRemove, blackCellsToAddMod, cellForWhichToReportCGI */
+  take(c, 16 + 3 + 1 + 2);
+  if (has & 32u) take(c, 5);
+  if (has & 16u) drop_list5(c, 5);
+  if (has & 8u) drop_list5(c, 19);
+  if (has & 4u) drop_list5(c, 5);
+  if (has & 2u) {
+    uint32_t cnt = take(c, 5) + 1;
+    for (uint32_t i = 0; i < cnt; i++) { take(c, 5); uint32_t rng = take(c, 1); take(c, 9); if (rng) take(c, 4); }
+  }
+  if (has & 1u) take(c, 9);
+  return !c->bad;
+}
+static int drop_report_config(cur_t* c)
+{
+  take(c, 5);
+  if (take(c, 1)) return 0;          /* reportConfigInterRAT */
+  if (take(c, 1)) return 0;          /* extension additions */
+  if (take(c, 1) == 0) {             /* event */
+    if (take(c, 1)) return 0;
+    uint32_t ev = take(c, 3);
+    if (ev == 0 || ev == 1 || ev == 3) drop_threshold(c);
+    else if (ev == 2) take(c, 7);
+    else if (ev == 4) { drop_threshold(c); drop_threshold(c); }
+    else return 0;
+    take(c, 5 + 4);
+  } else {
+    take(c, 1);
+  }
+  take(c, 1 + 1 + 3 + 4 + 3);
+  return !c->bad;
+}
+static int drop_meas_config(cur_t* c)
+{
+  if (take(c, 1)) return 0;
+  uint32_t has = take(c, 11); /* bit 10 = first optional component */
+  if (has & (1u << 10)) drop_list5(c, 5);
+  if (has & (1u << 9)) { uint32_t cnt = take(c, 5) + 1; for (uint32_t i = 0; i < cnt; i++) if (!drop_meas_object(c)) return 0; }
+  if (has & (1u << 8)) drop_list5(c, 5);
+  if (has & (1u << 7)) { uint32_t cnt = take(c, 5) + 1; for (uint32_t i = 0; i < cnt; i++) if (!drop_report_config(c)) return 0; }
+  if (has & (1u << 6)) drop_list5(c, 5);
+  if (has & (1u << 5)) drop_list5(c, 15);
+  if (has & (1u << 4)) {
+    if (take(c, 1)) return 0;
+    uint32_t q = take(c, 4);
+    if (q & 7u) return 0;
+    if (q & 8u) {
+      uint32_t d = take(c, 2);
+      for (int k = 1; k >= 0; k--) if (d & (1u << k)) { if (take(c, 1)) return 0; take(c, 4); }
+    }
+  }
+  if (has & (1u << 3)) { if (take(c, 1)) take(c, take(c, 1) ? 7 : 6); }
+  if (has & (1u << 2)) take(c, 7);
+  if (has & 3u) return 0;
+  return !c->bad;
+}
+
+/* 1 + *m_tmsi when the SDU (behind the assumed three header octets) is an RRCConnectionReconfiguration whose first NAS message is an attach
+ * accept that assigns a GUTI, else 0 */
+int o_rrc_reconfig_tmsi(const uint8_t* sdu, int len, uint32_t* m_tmsi)
+{
+  cur_t c = {sdu, len > 0 ? (uint32_t)len * 8u : 0u, 0, 0};
+  if (take(&c, 1) != 0 || take(&c, 4) != 4) return 0;
+  take(&c, 2);
+  if (take(&c, 1) != 0 || take(&c, 3) != 0) return 0;
+  uint32_t has = take(&c, 6);
+  if (!(has & 8u) || (has & 16u)) return 0; /* no NAS list, or mobilityControlInfo in front of it */
+  if ((has & 32u) && !drop_meas_config(&c)) return 0;
+  take(&c, 4);
+  uint32_t n = take(&c, 8);
+  if (n & 0x80u) { if (n & 0x40u) return 0; n = ((n & 0x3Fu) << 8) | take(&c, 8); }
+  if (c.bad || n < 8 || n > 256 || c.at + 8u * n > c.n) return 0;
+  uint8_t m[256];
+  for (uint32_t i = 0; i < n; i++) m[i] = (uint8_t)take(&c, 8);
+  uint32_t at = 0, sht = m[0] >> 4;
+  if (sht >= 1 && sht <= 4) at = 6; else if (sht != 0) return 0;
+  if (at + 2 > n || (m[at] & 15u) != 7u || m[at + 1] != 0x42u) return 0;
+  at += 4; /* message header, attach result, T3412 */
+  if (at >= n || m[at] < 6 || m[at] > 96) return 0;
+  at += 1u + m[at];
+  if (at + 2 > n) return 0;
+  at += 2u + (((uint32_t)m[at] << 8) | m[at + 1]);
+  if (at + 13 > n || m[at] != 0x50u || m[at + 1] != 11u || (m[at + 2] & 7u) != 6u) return 0;
+  *m_tmsi = ((uint32_t)m[at + 9] << 24) | ((uint32_t)m[at + 10] << 16) | ((uint32_t)m[at + 11] << 8) | (uint32_t)m[at + 12];
+  return 1;
+}
+
 int o_api_dl_events(int api_mode, char name, const uint8_t* pdu, int len, uint16_t rnti, uint32_t tti, o_api_event_t* ev, int cap, int* nev)
 {
   int n = 0, to_pcap = 0;
@@ -404,6 +518,13 @@ int o_api_dl_events(int api_mode, char name, const uint8_t* pdu, int len, uint16
         o_ue_cfg_t c;
         if (o_rrc_conn_setup_decode(pdu + sub[i].off, (int)sub[i].len, &c)) setup = 1;
       } else if (sub[i].is_sdu && sub[i].lcid == 1) {
+        uint32_t tm = 0; /* "sdu_ptr + 3": RLC + PDCP header octets assumed (DL_Sniffer_PDSCH.cc:836-838) */
+        if (sub[i].len > 3 && o_rrc_reconfig_tmsi(pdu + sub[i].off + 3, (int)sub[i].len - 3, &tm) && n < cap) {
+          o_api_event_t* e = &ev[n++];
+          memset(e, 0, sizeof(*e));
+          e->tti = tti; e->rnti = rnti; e->id_type = 1; e->msg_type = 6; /* ID_TMSI, MSG_CON_RECONFIG */
+          snprintf(e->value, sizeof(e->value), "%08x", tm);
+        }
       } else {
         if (nseen < 10) seen[nseen++] = i; else break;
       }

@@ -61,5 +61,8 @@ for name in ("ltesniffer_dl_mode.pcap", "ltesniffer_ul_mode.pcap", "api_collecto
     if name == "api_collector.pcap":
         out[name]["ul_dcch"] = [dict(rnti=q["rnti"], pdu=q["pdu"].hex()) for q in full if q["direction"] == 0 and len(q["pdu"]) > 7]
     out[name]["conn_setup"] = [dict(rnti=q["rnti"], pdu=q["pdu"].hex()) for q in dl if len(q["pdu"]) > 8 and q["pdu"][0] == 0x3C and (q["pdu"][1] & 31) == 0]
+    # downlink SRB1 blocks (first sub-header LCID 1 with a length field): the DL-DCCH messages of an attach - dlInformationTransfer, securityModeCommand,
+    # ueCapabilityEnquiry, the RRCConnectionReconfiguration that carries the attach accept, rrcConnectionRelease
+    out[name]["dl_dcch"] = [dict(rnti=q["rnti"], tti=q["tti"], pdu=q["pdu"].hex()) for q in dl if len(q["pdu"]) > 8 and q["pdu"][0] == 0x21 and q["pdu"][1] > 3]
 json.dump(out, open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "pcap_records.json"), "w"), indent=0)
 print({k: (v["nof_records"], len(v["records"])) for k, v in out.items()})

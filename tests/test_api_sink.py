@@ -252,3 +252,155 @@ def test_oracle_worker_reports_paging_and_connection_setups():
     main = [r["ctx"] + r["pdu"] for r in recs]
     assert all(r["ctx"] + r["pdu"] in main for r in api)
     assert {r["rnti_type"] for r in api} == {1, 3}
+
+
+# ---------------------------------------------------------------------------------------------------- RRCConnectionReconfiguration -> attach accept -> GUTI
+def _put(bits, v, n):
+    bits.extend((int(v) >> (n - 1 - i)) & 1 for i in range(n))
+
+
+def _encode_reconfig(nas, meas=None, mobility=False, rrcd=True):
+    """DL-DCCH-Message { rrcConnectionReconfiguration-r8 } in unaligned PER, written for this test (TS 36.331 6.2.2 / 6.3.5).  meas: None or
+    dict(objects=[(id, arfcn, offset or None, cells [(idx, pci, off)])], reports=[("a3", offset) | ("a1", rsrp) | ("periodical",)], ids=[(m, o, r)],
+    quantity=(rsrp_fc or None, rsrq_fc or None) or None, gap=None | ("gp0", v) | ("gp1", v) | "release", s_measure=None | v)"""
+    b = []
+    _put(b, 0, 1); _put(b, 4, 4); _put(b, 1, 2); _put(b, 0, 1); _put(b, 0, 3)
+    _put(b, 1 if meas is not None else 0, 1); _put(b, int(mobility), 1); _put(b, 1 if nas is not None else 0, 1); _put(b, int(rrcd), 1); _put(b, 0, 1); _put(b, 0, 1)
+    if meas is not None:
+        _put(b, 0, 1)
+        pres = [0, bool(meas.get("objects")), 0, bool(meas.get("reports")), 0, bool(meas.get("ids")), meas.get("quantity") is not None, meas.get("gap") is not None,
+                meas.get("s_measure") is not None, 0, 0]
+        for x in pres:
+            _put(b, int(bool(x)), 1)
+        if meas.get("objects"):
+            _put(b, len(meas["objects"]) - 1, 5)
+            for oid, arfcn, off, cells in meas["objects"]:
+                _put(b, oid - 1, 5); _put(b, 0, 1); _put(b, 0, 2); _put(b, 0, 1)
+                _put(b, int(off is not None), 1); _put(b, 0, 1); _put(b, int(bool(cells)), 1); _put(b, 0, 3)
+                _put(b, arfcn, 16); _put(b, 3, 3); _put(b, 1, 1); _put(b, 1, 2)
+                if off is not None:
+                    _put(b, off, 5)
+                if cells:
+                    _put(b, len(cells) - 1, 5)
+                    for ci, pci, co in cells:
+                        _put(b, ci - 1, 5); _put(b, pci, 9); _put(b, co, 5)
+        if meas.get("reports"):
+            _put(b, len(meas["reports"]) - 1, 5)
+            for k, rc in enumerate(meas["reports"]):
+                _put(b, k, 5); _put(b, 0, 1); _put(b, 0, 1)
+                if rc[0] == "periodical":
+                    _put(b, 1, 1); _put(b, 0, 1)
+                else:
+                    _put(b, 0, 1); _put(b, 0, 1)
+                    if rc[0] == "a3":
+                        _put(b, 2, 3); _put(b, rc[1] + 30, 6); _put(b, 0, 1)
+                    else:
+                        _put(b, 0, 3); _put(b, 0, 1); _put(b, rc[1], 7)
+                    _put(b, 4, 5); _put(b, 8, 4)
+                _put(b, 0, 1); _put(b, 1, 1); _put(b, 3, 3); _put(b, 6, 4); _put(b, 7, 3)
+        if meas.get("ids"):
+            _put(b, len(meas["ids"]) - 1, 5)
+            for m, o, r in meas["ids"]:
+                _put(b, m - 1, 5); _put(b, o - 1, 5); _put(b, r - 1, 5)
+        if meas.get("quantity") is not None:
+            _put(b, 0, 1); _put(b, 1, 1); _put(b, 0, 3)
+            q = meas["quantity"]
+            _put(b, int(q[0] is not None), 1); _put(b, int(q[1] is not None), 1)
+            for v in q:
+                if v is not None:
+                    _put(b, 0, 1); _put(b, v, 4)
+        if meas.get("gap") is not None:
+            g = meas["gap"]
+            if g == "release":
+                _put(b, 0, 1)
+            else:
+                _put(b, 1, 1); _put(b, 0 if g[0] == "gp0" else 1, 1); _put(b, g[1], 6 if g[0] == "gp0" else 7)
+        if meas.get("s_measure") is not None:
+            _put(b, meas["s_measure"], 7)
+    if nas is not None:
+        _put(b, 0, 4)
+        assert len(nas) < 128
+        _put(b, len(nas), 8)
+        for x in nas:
+            _put(b, x, 8)
+    if rrcd:
+        _put(b, 0, 1); _put(b, 0, 6)   # RadioResourceConfigDedicated with nothing in it
+    while len(b) % 8:
+        b.append(0)
+    return bytes(int("".join(map(str, b[i:i + 8])), 2) for i in range(0, len(b), 8))
+
+
+def _attach_accept(m_tmsi, guti=True, protected=True, esm=b"\x52\x01\xc1\x01\x07"):
+    plain = bytes([0x07, 0x42, 0x02, 0x3e, 0x06, 0x00, 0x09, 0xf1, 0x55, 0x00, 0x07]) + len(esm).to_bytes(2, "big") + esm
+    if guti:
+        plain += bytes([0x50, 0x0b, 0xf6, 0x09, 0xf1, 0x55, 0x00, 0x01, 0x1a]) + m_tmsi.to_bytes(4, "big")
+    plain += bytes([0x13, 0x09, 0xf1, 0x55, 0x00, 0x01])
+    return (bytes([0x27, 1, 2, 3, 4, 9]) + plain) if protected else plain
+
+
+def _dcch_pdu(rrc):
+    sdu = bytes([0xa0, 0x06, 0x06]) + rrc
+    return bytes([0x21, len(sdu), 0x1f]) + sdu + bytes(3)
+
+
+def test_recorded_reconfigurations_report_the_assigned_tmsi():
+    """the reference's own captures hold the whole attach of one UE on SRB1; the RRCConnectionReconfiguration that carries the attach accept
+    (measConfig + dedicatedInfoNASList + radioResourceConfigDedicated, integrity-protected NAS) yields the M-TMSI of the GUTI - the
+    identity print_api_dl reports as (ID_TMSI, MSG_CON_RECONFIG), DL_Sniffer_PDSCH.cc:836-848; the other DL-DCCH messages yield nothing"""
+    expect = {"ltesniffer_dl_mode.pcap": "cd5d47ec", "ltesniffer_ul_mode.pcap": None}
+    for cap, want in expect.items():
+        blocks = FIX[cap]["dl_dcch"]
+        assert len(blocks) >= 7
+        hits = []
+        for m in blocks:
+            pdu = bytes.fromhex(m["pdu"])
+            for api_mode in (0, 3):
+                ev, keep = oracle_api_events(api_mode, "C", pdu, m["rnti"], m["tti"])
+                assert (ev, keep) == host_api_events(api_mode, "C", pdu, m["rnti"], m["tti"]) and not keep
+            assert oracle_api_events(2, "C", pdu, m["rnti"], m["tti"]) == ([], False)
+            if ev:
+                hits.append(ev)
+        assert len(hits) == 1 and len(hits[0]) == 1   # exactly one reconfiguration per attach carries the accept
+        tti, rnti, id_type, msg_type, value = hits[0][0]
+        assert (rnti, id_type, msg_type) == (70, 1, 6) and len(value) == 8 and int(value, 16) > 0
+        if want:
+            assert value == want   # hand-decoded in DESIGN / this round's notes: GUTI 09f155-0001-1a-cd5d47ec
+
+
+def test_reconfiguration_walk_against_an_independent_encoder():
+    rng = np.random.default_rng(5)
+    n_hit = 0
+    for trial in range(60):
+        tmsi = int(rng.integers(1, 1 << 32))
+        meas = None
+        if trial % 3:
+            meas = dict(objects=[(1 + i, int(rng.integers(0, 65536)), (int(rng.integers(0, 31)) if rng.integers(0, 2) else None),
+                                  [(1 + j, int(rng.integers(0, 504)), int(rng.integers(0, 31))) for j in range(int(rng.integers(0, 4)))]) for i in range(int(rng.integers(1, 4)))],
+                        reports=[("a3", int(rng.integers(-30, 31))), ("a1", int(rng.integers(0, 98))), ("periodical",)][:int(rng.integers(0, 4))],
+                        ids=[(1, 1, 1), (2, 1, 2)][:int(rng.integers(0, 3))],
+                        quantity=[None, (None, None), (4, None), (6, 9)][int(rng.integers(0, 4))],
+                        gap=[None, "release", ("gp0", 17), ("gp1", 63)][int(rng.integers(0, 4))],
+                        s_measure=[None, 70][int(rng.integers(0, 2))])
+        guti, prot = bool(trial % 5), bool(trial % 2)
+        pdu = _dcch_pdu(_encode_reconfig(_attach_accept(tmsi, guti=guti, protected=prot), meas=meas))
+        ev, keep = oracle_api_events(3, "C", pdu, 4321, 77)
+        assert (ev, keep) == host_api_events(3, "C", pdu, 4321, 77)
+        if guti:
+            assert ev == [(77, 4321, 1, 6, "%08x" % tmsi)], (trial, meas)
+            n_hit += 1
+        else:
+            assert ev == []
+    assert n_hit >= 40
+    # not an attach accept / no NAS list / a handover command / truncated input: nothing, identically on both sides
+    other = bytes([0x27, 1, 2, 3, 4, 9, 0x07, 0x44]) + bytes(20)
+    for rrc in (_encode_reconfig(other), _encode_reconfig(None), _encode_reconfig(_attach_accept(5), mobility=True)):
+        pdu = _dcch_pdu(rrc)
+        assert oracle_api_events(0, "C", pdu, 9, 9) == ([], False) == host_api_events(0, "C", pdu, 9, 9)
+    good = _dcch_pdu(_encode_reconfig(_attach_accept(0xCAFEF00D), meas=dict(objects=[(1, 3400, None, [])], quantity=(None, None))))
+    for cut in range(6, len(good), 3):
+        p = good[:cut]
+        p = bytes([0x21, max(4, min(p[1], cut - 3)), 0x1f]) + p[3:]
+        assert oracle_api_events(0, "C", p, 9, 9) == host_api_events(0, "C", p, 9, 9)
+    for _ in range(200):
+        p = bytes([0x21, 40, 0x1f, 0xa0, 0, 0, 0x20 | int(rng.integers(0, 8))]) + bytes(rng.integers(0, 256, 45, dtype=np.uint8))
+        assert oracle_api_events(3, "C", p, 9, 9) == host_api_events(3, "C", p, 9, 9)
