@@ -119,7 +119,7 @@ def main():
     ap.add_argument("--step-sf", type=int, default=4000, help="subframes per step: a divisor of the capture length and a multiple of 200")
     ap.add_argument("--nsf", type=int, default=0, help="distinct subframes of the capture (0 = the gated stream's 20 000); other values run ungated")
     ap.add_argument("--config", default="cfg3", help="scenario preset: cfg3 = 20 MHz, 150 RNTIs, TM3/TM4 up to 256QAM")
-    ap.add_argument("--batch", type=int, default=800, help="subframes per pipeline chunk inside a submit")
+    ap.add_argument("--batch", type=int, default=400, help="subframes per pipeline chunk inside a submit (400-500 measured best on the 4 000-subframe steps: shorter fill / drain than 800, fewer launches than 200)")
     ap.add_argument("--cpu-sample", type=int, default=1600, help="subframes the CPU oracle decodes live from cold state (rank 0): cpu_baseline + reproduction of the cached oracle blocks")
     ap.add_argument("--no-cpu", action="store_true", help="skip the live oracle leg (cpu_baseline)")
     ap.add_argument("--shard", choices=("cells", "capture"), default="cells",

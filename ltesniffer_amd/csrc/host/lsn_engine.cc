@@ -300,6 +300,7 @@ void Engine::finishStageA(Chunk& ch)
   for (uint32_t i = 0; i < ch.nsf; i++) {
     SubframeCtx& c = ch.ctx[i];
     c.cfi = ch.h_cfi[i];
+    if (c.cfi < 1 || c.cfi > 3) throw std::runtime_error("stage A mirror of the CFI is out of range (device -> host mirror not in place?)");  // never index tables with it
     // host-side scalars, same expressions as the device-free part of the estimator
     c.snr_db = 10.0f * log10f(ch.h_chest[i].rsrp_avg / ch.h_chest[i].noise_avg);
     c.cfo_hz = atan2f(ch.h_chest[i].corr_i, ch.h_chest[i].corr_r) / (2.0f * (float)M_PI * 0.0005f);

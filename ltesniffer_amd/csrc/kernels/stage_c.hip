@@ -596,7 +596,13 @@ __global__ __launch_bounds__(NT) TB_WAVES_ATTR void k_turbo(const uint32_t* __re
                                               uint8_t* __restrict__ payload, LsnCbRes* res, uint32_t kmax)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const long long tc0 = clock64();
+  // phase cycle counters (LsnCbRes::cyc_*) only in instrumented builds (-DLSN_TURBO_CYCLES): the production kernel reads no clock
+#ifdef LSN_TURBO_CYCLES
+#define TB_CLOCK() clock64()
+#else
+#define TB_CLOCK() 0ll
+#endif
+  const long long tc0 = TB_CLOCK();
   const LsnCbDev cb = cbs[blockIdx.x];
   // The transport block of this code block is already lost when its first code block (decoded by an EARLIER launch on this stream)
   // failed: nothing this block could decode would reach the record stream, so it is not decoded at all
@@ -630,7 +636,7 @@ __global__ __launch_bounds__(NT) TB_WAVES_ATTR void k_turbo(const uint32_t* __re
     tail_beta(ts2, tp2, bt2);
   }
   __syncthreads();  // scratch is dead from here on: the area becomes the check-point store
-  const long long tc1 = clock64();
+  const long long tc1 = TB_CLOCK();
   const uint32_t poly = cb.crc_b ? 0x1800063u : 0x1864CFBu;
   // weight of this thread's window in the block polynomial: x^((P-1-window) W) mod g
   const uint32_t cw = active ? (cb.crc_b ? crc_tab_b : crc_tab_a)[(P - 1 - lane) * W] : 0u;
@@ -656,7 +662,7 @@ __global__ __launch_bounds__(NT) TB_WAVES_ATTR void k_turbo(const uint32_t* __re
     ok = wg_xor<NT>(rem, m.ckpt, lane) == 0;
   }
   const int it_run = it;
-  const long long tc2 = clock64();
+  const long long tc2 = TB_CLOCK();
   // ---- output: payload bytes of this code block + its CRC24A remainder contribution (each thread a contiguous run) ----
   const int nout = (int)cb.out_bytes;
   uint8_t* outp = payload + cb.out_off;
@@ -676,7 +682,7 @@ __global__ __launch_bounds__(NT) TB_WAVES_ATTR void k_turbo(const uint32_t* __re
   if (j0 < j1) rema = mulmod24(rema, crc_tab_a[8 * (nout - j1)], 0x1864CFBu);
   rema = wg_xor<NT>(rema, m.ckpt, lane);
   if (lane == 0) {
-    const long long tc3 = clock64();
+    const long long tc3 = TB_CLOCK();
     LsnCbRes r; r.ok = ok ? 1u : 0u; r.iters = (uint32_t)it; r.rem_a = rema; r.iters_run = (uint32_t)it_run;
     r.cyc_rm = (uint32_t)(tc1 - tc0); r.cyc_map = (uint32_t)(tc2 - tc1); r.cyc_out = (uint32_t)(tc3 - tc2); r.cyc_all = (uint32_t)(tc3 - tc0);
     res[cb.res_idx] = r;

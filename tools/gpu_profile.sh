@@ -7,7 +7,7 @@
 # counters, FETCH_SIZE, WRITE_SIZE; never combined with other trace domains).
 set -u
 TAG=${1:-prof}; shift || true
-STEPS=${LSN_PROFILE_STEPS:-20}; WARM=${LSN_PROFILE_WARMUP:-5}; STEP_SF=${LSN_PROFILE_STEP_SF:-4000}; BATCH=${LSN_PROFILE_BATCH:-800}
+STEPS=${LSN_PROFILE_STEPS:-20}; WARM=${LSN_PROFILE_WARMUP:-5}; STEP_SF=${LSN_PROFILE_STEP_SF:-4000}; BATCH=${LSN_PROFILE_BATCH:-400}
 ARGS=${*:---gpus 1 --steps $STEPS --warmup $WARM --step-sf $STEP_SF --batch $BATCH --no-cpu --no-legs}
 TIMED_SF=$((STEPS * STEP_SF)); ALL_SF=$(((STEPS + WARM) * STEP_SF)); TIMED_CHUNKS=$((TIMED_SF / BATCH))
 OUT=gpurun_out
