@@ -352,8 +352,8 @@ def main():
                     cpu["parallel"] = {"error": str(ex)[:200]}
 
     # ---------------------------------------------------------------- first H2D -> last PDU: the capture starts in HOST memory
-    # Never `value` (bench contract: inputs resident in HBM): the whole 20 000-subframe capture, two consecutive passes of the SAME stream
-    # from a fresh engine - pass 1 from cold state, pass 2 with the tables learnt - each gated block by block on the oracle like the headline:
+    # Never `value` (bench contract: inputs resident in HBM): the whole 20 000-subframe capture, three consecutive passes of the SAME stream
+    # from a fresh engine - pass 1 from cold state, passes 2 and 3 with the tables learnt - each gated block by block on the oracle like the headline:
     # (a) host buffers (lsn_phy_process_host: PCIe copies overlapped with the pipeline), (b) a cf32 file in the page cache
     # (lsn_phy_process_file, the reference's file mode, LTESniffer_Core.cc:240-262,365), (c) the reference's own boundary: the worker pool
     # (getAvail / getBuffers / prepare / putPending / joinPending, LTESniffer_Core.cc:434-451) driven by tools/pool_driver.
@@ -367,14 +367,14 @@ def main():
             lphy = make_phy(lp)
             lphy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"])
             out = {}
-            for k in range(2):
+            for k in range(3):
                 lp.reset()
                 lp.set_digest_blocks(BLOCK, (tti0 + k * nsf) % 10240)
                 t = time.perf_counter()
                 done = run_pass(lphy, (tti0 + k * nsf) % 10240)
                 dtl = time.perf_counter() - t
                 cov, bad, rd = block_check(lp.block_digests()[:done // BLOCK], k * nsf // BLOCK)
-                out["pass%d_%s" % (k + 1, "cold" if k == 0 else "warm")] = {
+                out["pass%d_%s" % (k + 1, "cold" if k == 0 else "warm")] = {   # (the third consecutive pass is the steady state: buffers grown, tables learnt)
                     "subframes_per_s": round(done / dtl, 1), "GB_per_s": round(done * sf_bytes / dtl / 1e9, 2), "x_realtime": round(done / dtl / 1000.0, 1),
                     "subframes": int(done), "records": lp.nof_records(), "oracle_blocks_compared": cov, "oracle_blocks_mismatching": bad,
                     "pcap_diff": (int(rd + (bad if rd == 0 else 0)) if cov == done // BLOCK and cov else None)}

@@ -16,13 +16,14 @@ from make_cfg3_golden import cfg3_stream  # noqa: E402
 from parity import gen_capture  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 8000
+batch = int(sys.argv[2]) if len(sys.argv) > 2 else 800
 sc, *_ = cfg3_stream()
 tti0, iq = gen_capture(sc, n)
 host = torch.from_numpy(iq).pin_memory()
 d = torch.from_numpy(iq.view(np.float32)).to("cuda:0")
 w = la.PcapWriter(None)
 w.set_store(False)
-phy = la.Phy(nof_rx_antennas=2, max_batch=800, pcapwriter=w)
+phy = la.Phy(nof_rx_antennas=2, max_batch=batch, pcapwriter=w)
 phy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"])
 phy.process_device(d.data_ptr(), n, tti0, 500)          # learn the tables
 t = 0
