@@ -1188,6 +1188,7 @@ void Engine::frontLoop()
         trace(1, TR_ACQ_END, ci);
         try {
           if (gpu_wait && job.ready) HIP_CHECK(hipStreamWaitEvent(ch.st_a, job.ready, 0));
+          if (job.inject_fail == (int)ci) throw std::runtime_error("injected stage-A failure (LSN_INJECT_STAGE_A_ERROR)");
           launchStageA(ch, (const uint8_t*)job.d_iq + (size_t)base * sf_stride);
         } catch (const std::exception& ex) {
           ch.err = ex.what();
@@ -1328,7 +1329,8 @@ int Engine::submit(const void* d_iq, uint32_t nsf_total, uint32_t start_tti, uin
     const uint32_t nchunks = (nsf_total + max_batch - 1) / max_batch;
     {
       std::unique_lock<std::mutex> lk(mtx);
-      front_jobs.push_back({d_iq, nsf_total, start_tti, update_meta_period, sh->next_gseq.fetch_add(nchunks), force_meta_first, ev});
+      const char* inj = getenv("LSN_INJECT_STAGE_A_ERROR");  // test hook of the error path: a chunk that fails must not wedge the pipeline
+      front_jobs.push_back({d_iq, nsf_total, start_tti, update_meta_period, sh->next_gseq.fetch_add(nchunks), force_meta_first, ev, inj ? atoi(inj) : -1});
       chunks_expected += nchunks;
     }
     cv_front.notify_one();

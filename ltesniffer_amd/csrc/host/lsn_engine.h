@@ -290,7 +290,8 @@ public:
 private:
   // front thread: launches stage A chunk after chunk, hands finished chunks to the search (caller) thread
   std::thread front_thread;
-  struct FrontJob { const void* d_iq = nullptr; uint32_t nsf_total = 0, start_tti = 0, update_meta_period = 0; uint64_t gseq0 = 0; bool force_meta = false; hipEvent_t ready = nullptr; /* "block is in place" on the caller's stream */ };
+  struct FrontJob { const void* d_iq = nullptr; uint32_t nsf_total = 0, start_tti = 0, update_meta_period = 0; uint64_t gseq0 = 0; bool force_meta = false; hipEvent_t ready = nullptr; /* "block is in place" on the caller's stream */
+                    int inject_fail = -1; /* test hook (LSN_INJECT_STAGE_A_ERROR=<chunk of this block>): that chunk fails in stage A */ };
   std::deque<FrontJob> front_jobs;            // submits not yet cut into chunks (front thread)
   uint64_t chunks_expected = 0;               // chunks of all submits so far; wait() returns when as many have been written
   std::thread search_thread;                  // stage B: the sequential FALCON search, chunk after chunk

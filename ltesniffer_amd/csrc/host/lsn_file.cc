@@ -88,7 +88,8 @@ int Engine::processFile(const char* path, const lsn_file_cfg_t& fc, uint32_t sta
         HIP_CHECK(hipMalloc((void**)&fb.d_iq, blk * sf_bytes));
         fb.bytes = blk * sf_bytes;
       }
-      if (!use_mmap && !fb.h_raw) HIP_CHECK(hipHostMalloc((void**)&fb.h_raw, fb.bytes, hipHostMallocDefault));
+      // (the pinned block of a slot is allocated by the reader when the slot is first used: a 393 MB hipHostMalloc takes ~40 ms, eight of them
+      // up front were most of the first call's time)
       s.h_raw = fb.h_raw; s.d_raw = fb.d_raw; s.d_iq = fb.d_iq;
     }
     if (fc.offset_freq_hz != 0.0f) {
@@ -204,7 +205,7 @@ int Engine::processFile(const char* path, const lsn_file_cfg_t& fc, uint32_t sta
       }
     });
     // block i is submitted (searched, queued for decoding) while block i-1 drains; its slot goes back to the reader once every chunk
-    // of it has been committed
+    // of it has been through stage A
     std::deque<int> inflight;  // submitted blocks whose slot the reader may not touch yet (pinned source + device buffers still in use)
     for (int i = 0;; i = (i + 1) % NSLOT) {
       Slot& s = slot[i];
@@ -220,7 +221,7 @@ int Engine::processFile(const char* path, const lsn_file_cfg_t& fc, uint32_t sta
       while ((int)inflight.size() > NSLOT - 2) {  // keep two slots for the reader, hand the oldest one back once its chunks are written
         const int o = inflight.front();
         inflight.pop_front();
-        waitMark(slot[o].mark);
+        waitIqConsumed(slot[o].mark);  // stage A has read the block (UL_MODE: its chunks are written): pinned source and device buffers are free
         { std::unique_lock<std::mutex> lk(fm); slot[o].state = 0; }
         fcv.notify_all();
       }

@@ -329,3 +329,35 @@ def test_mcs_database_ageing_matches_oracle():
     # end (the ones that went idle more than one whole second before the last update are gone)
     assert ow.nof_tracked() < nsf // 40 - 10, ow.nof_tracked()
     phy.close()
+
+
+def test_a_failing_chunk_is_reported_and_does_not_wedge_the_pipeline():
+    """round-2 advisor finding: an error inside the pipeline left the turn counters inconsistent and the next wait() hung.  Now a failed chunk
+    travels on with its error text: the call returns an error, every chunk before and after it is still written, and the engine keeps working"""
+    import os
+    import torch
+    sc = scenario("small", seed=77)
+    nsf = 40
+    tti0, iq, _ = gen_subframes(sc, nsf)
+    _, _, orecs = run_oracle(sc, tti0, iq, taps=False)
+    phy = la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=8, pcapwriter=la.PcapWriter(None))
+    assert phy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"])
+    d_iq = torch.from_numpy(iq.view(np.float32)).to("cuda:0")
+    os.environ["LSN_INJECT_STAGE_A_ERROR"] = "2"   # the third of five chunks
+    try:
+        with pytest.raises(RuntimeError):
+            phy.process_device(d_iq.data_ptr(), nsf, tti0, 0, torch.cuda.current_stream().cuda_stream)
+    finally:
+        del os.environ["LSN_INJECT_STAGE_A_ERROR"]
+    got = gpu_records(phy)
+    # subframes 16..23 are missing, everything in front of them is what the oracle wrote
+    head = [r for r in oracle_records(orecs)]
+    n_head = len([r for r in orecs if ((r["sfn"] * 10 + r["sf"]) - tti0) % 10240 < 16])
+    assert got[:n_head] == head[:n_head] and len(got) > n_head
+    ttis = {(((g[10] << 8) | g[11]) >> 4) * 10 + (((g[10] << 8) | g[11]) & 15) for g in got}
+    assert not any((t - tti0) % 10240 in range(16, 24) for t in ttis) and any((t - tti0) % 10240 >= 24 for t in ttis)
+    # the same engine decodes the next call completely (state differs from the oracle's by the lost chunk, so only completion and volume are checked)
+    phy.pcapwriter.reset()
+    phy.process_device(d_iq.data_ptr(), nsf, (tti0 + nsf) % 10240, 0, torch.cuda.current_stream().cuda_stream)
+    assert len(gpu_records(phy)) >= 0.8 * len(orecs)
+    phy.close()
