@@ -47,7 +47,8 @@ int Engine::processFile(const char* path, const lsn_file_cfg_t& fc, uint32_t sta
   const uint64_t file_off0 = (uint64_t)fc.offset_time_samples * nant * sizeof(cf32);
   const uint64_t sf_in_file = (uint64_t)sb.st_size > file_off0 ? ((uint64_t)sb.st_size - file_off0) / sf_bytes : 0;  // complete subframes only
   constexpr int NSLOT_MAX = 8;
-  int NSLOT = 8;  // blocks in flight: one being read, one crossing PCIe, the others inside the decode pipeline
+  int NSLOT = 4;  // blocks in flight: one being read, one crossing PCIe, two in stage A (a slot is free again when stage A has consumed its block;
+                  // round 2 held eight until their chunks were written - and paid 8 x 393 MB of pinned allocation on the first call)
   if (const char* e = getenv("LSN_FILE_SLOTS")) NSLOT = std::max(3, std::min(NSLOT_MAX, atoi(e)));
   const bool fdebug = getenv("LSN_FILE_DEBUG") != nullptr;
   auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -88,8 +89,7 @@ int Engine::processFile(const char* path, const lsn_file_cfg_t& fc, uint32_t sta
         HIP_CHECK(hipMalloc((void**)&fb.d_iq, blk * sf_bytes));
         fb.bytes = blk * sf_bytes;
       }
-      // (the pinned block of a slot is allocated by the reader when the slot is first used: a 393 MB hipHostMalloc takes ~40 ms, eight of them
-      // up front were most of the first call's time)
+      if (!use_mmap && !fb.h_raw) HIP_CHECK(hipHostMalloc((void**)&fb.h_raw, fb.bytes, hipHostMallocDefault));  // (kept by the engine: later calls find them)
       s.h_raw = fb.h_raw; s.d_raw = fb.d_raw; s.d_iq = fb.d_iq;
     }
     if (fc.offset_freq_hz != 0.0f) {

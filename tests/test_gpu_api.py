@@ -39,3 +39,23 @@ def test_api_events_and_api_pcap_match_oracle(api_mode):
     if api_mode == 0:
         assert {e[3] for e in oev} == {1}
     phy.close()
+
+
+def test_api_events_do_not_need_a_pdu_sink():
+    """round-2 advisor finding: lsn_phy_set_api_mode without a PDU sink / pcap writer silently produced nothing.  The identities and the API pcap
+    must be the same with the sink removed"""
+    paging = encode_paging([("imsi", "262019876543210"), ("tmsi", 0x21, 0xC0FFEE42)])
+    sc = scenario("small", seed=9, paging_period=8, msg4_period=7, msg4_p_a_idx=4)
+    n = 48
+    tti0, iq, _ = gen_subframes(sc, n, paging_msg=paging)
+    results = []
+    for with_sink in (True, False):
+        phy = la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=16, pcapwriter=la.PcapWriter(None))
+        api_pcap = la.PcapWriter(None)
+        assert phy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"]) and phy.setApiMode(3, api_pcap)
+        if not with_sink:
+            assert la.lib().lsn_phy_set_pcap_writer(phy._h, None) == 0   # neither pcap writer nor callback
+        phy.process_host(iq, tti0)
+        results.append((list(phy.api_events), api_pcap.bytes()))
+        phy.close()
+    assert results[0] == results[1] and len(results[0][0]) >= 4
