@@ -185,7 +185,6 @@ int lsn_phy_create_multi(const lsn_phy_cfg_t* cfg, const int* devices, uint32_t 
   c0.device = devices[0];
   const int r = lsn_phy_create(&c0, out);
   if (r != LSN_SUCCESS) return r;
-  if (cfg->sniffer_mode != 0 && n_devices > 1) { lsn_phy_destroy(*out); *out = nullptr; return LSN_ERROR_INVALID_INPUTS; }  // UL_MODE keeps per-chunk uplink state
   int ndev = 0, caller_dev = 0;
   (void)hipGetDeviceCount(&ndev);
   (void)hipGetDevice(&caller_dev);

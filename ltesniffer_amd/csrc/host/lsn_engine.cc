@@ -218,7 +218,7 @@ int Engine::setCell(const lsn_cell_t& c)
     sib2_learned = false;
     if (cfg.sniffer_mode == 1) {
       uploadUlStatic();
-      std::lock_guard<std::mutex> lk(mcs_mtx);  // uplink tracking database: sized here, never lazily on the commit thread
+      std::lock_guard<std::mutex> lk(mcs_mtx);  // uplink tracking database (shared by the engines of a capture): sized here, never lazily on the commit thread
       ulmod.assign(65536, 0); ul_uecfg.assign(65536, UeSpecConfig()); ul_time.assign(65536, 0); ul_active.assign(65536, 0); ul_success.assign(65536, 0);
       ulmod_count = 0;
     }

@@ -107,6 +107,9 @@ struct JobRunner {
   lsn_perf_t perf{};
 };
 
+// one entry of the ULSchedule databases (ULSchedule.cc:11-138): a DCI 0 / RAR grant waiting for its PUSCH subframe
+struct UlSchedGrant { uint16_t rnti = 0; PuschGrant g, g256; uint32_t n_dmrs = 0; bool hopping = false, is_rar = false; uint32_t nof_ack = 0; bool cqi_req = false; };
+
 // The SEQUENTIAL host state of one cell: the FALCON search with its RNTI manager, the MCS-tracking database and the clocks both run on.
 // One engine owns one of these; the engines of a capture that is spread over several GPUs (lsn_phy_create_multi: chunk g goes to engine
 // g mod G) share one and take turns on it - chunk g is searched, committed and written when chunks 0 .. g-1 have been, whichever engine
@@ -129,6 +132,19 @@ struct SharedSeq {
   double search_time_us = 0;              // time_blindsearch of the statistics (PhyCommon.cc:111-112)
   float est_cfo = 0;
   bool force_meta_next = false;
+  // UL_MODE (touched in the commit turn, or under mcs_mtx where the caller may look): ULSchedule databases, the uplink tracking database
+  // (MCSTracking UL: 0 absent, 1 unknown, 2/3/4 = 16/64/256QAM max; ue_spec_config, time in subframes, nof_active, nof_success_mgs) and the
+  // uplink configuration in force.  An engine whose device tables were built for an older epoch rebuilds them at its next commit turn
+  // (Engine::syncUlConfig), so a configuration learnt from SIB2 by one engine of a multi-GPU capture reaches the others in stream order.
+  std::map<uint32_t, std::vector<UlSchedGrant>> ul_sched, rar_sched;
+  std::vector<uint8_t> ulmod; uint32_t ulmod_count = 0;
+  std::vector<UeSpecConfig> ul_uecfg;
+  std::vector<uint32_t> ul_time, ul_active, ul_success;
+  float last_ul_snr = 0.0f;
+  lsn_ul_cfg_t ul_cfg{}; bool ul_set = false;
+  bool sib2_learned = false; Sib2Config sib2;
+  std::atomic<uint32_t> ul_cfg_epoch{0};
+  lsn_prach_cfg_t prach_cfg{}; bool prach_cfg_set = false; uint32_t prach_epoch = 0;
   // turn taking
   std::atomic<uint64_t> next_gseq{0};     // global chunk numbers in submission order
   std::mutex turn_mtx;
@@ -330,25 +346,28 @@ private:
   double& search_time_us = sh->search_time_us;
   Chunk* last_chunk = nullptr;
   bool& force_meta_next = sh->force_meta_next;
-  // uplink
-  lsn_ul_cfg_t ul_cfg{};
-  bool ul_set = false;
+  // uplink: the sequential state lives in SharedSeq (see there); per engine: the device tables of the configuration and the buffers
+  lsn_ul_cfg_t& ul_cfg = sh->ul_cfg;
+  bool& ul_set = sh->ul_set;
+  uint32_t ul_tables_epoch = 0, prach_tables_epoch = 0;   // shared epochs this engine's device tables were built for
+  int buildUlTables(const lsn_ul_cfg_t& u);             // DMRS base sequences, n_PN, u(ns) / v(ns), hopping offset: the device side of setUlConfig
+  void syncUlConfig();                                    // commit turn: pick up a configuration another engine (or the caller) has set since
   // device / pinned blocks of the file source, kept between lsn_phy_process_file calls (allocating them costs more than replaying a short capture)
   struct FileBuf { cf32* h_raw = nullptr; cf32* d_raw = nullptr; cf32* d_iq = nullptr; size_t bytes = 0; };
   FileBuf file_buf[8];
-  std::atomic<uint32_t> ul_cfg_epoch{0};  // bumped by every (re)configuration: chunks whose DCI 0 grants were converted earlier are converted again at commit
-  bool sib2_learned = false; Sib2Config sib2;  // the SIB2 the UL-mode commit stage configured itself from (decode_SIB), if any
+  std::atomic<uint32_t>& ul_cfg_epoch = sh->ul_cfg_epoch;  // bumped by every (re)configuration: chunks whose DCI 0 grants were converted earlier are converted again at commit
+  bool& sib2_learned = sh->sib2_learned; Sib2Config& sib2 = sh->sib2;  // the SIB2 the UL-mode commit stage configured itself from (decode_SIB), if any
   bool decodeSib(Chunk& ch, JobRunner& r, uint32_t sf, Sib2Config& out, size_t& payload_off, uint32_t& len, uint8_t& tb);
   std::vector<int> ul_off;       // allocation size L -> offset into ul_base / ul_idft (-1: unsupported)
   uint32_t ul_npn[20] = {0};
   uint32_t ul_base_stride = 0;   // cf32 per (u, v) variant of the base-sequence table
   uint8_t ul_u[20] = {0}, ul_v[20] = {0};  // sequence group / base sequence number of the 20 slots (group / sequence hopping of SIB2)
-  struct UlSchedGrant { uint16_t rnti = 0; PuschGrant g, g256; uint32_t n_dmrs = 0; bool hopping = false, is_rar = false; uint32_t nof_ack = 0; bool cqi_req = false; };
-  std::map<uint32_t, std::vector<UlSchedGrant>> ul_sched, rar_sched;  // ULSchedule databases (touched in the commit turn only)
-  std::vector<uint8_t> ulmod; uint32_t ulmod_count = 0;               // MCSTracking UL: 0 absent, 1 unknown, 2/3/4 = 16/64/256QAM max
-  std::vector<UeSpecConfig> ul_uecfg;                                 // ue_spec_config of the UL tracking entries (valid where ulmod != 0)
-  std::vector<uint32_t> ul_time, ul_active, ul_success;               // ul_sniffer_tracking_t::time (in subframes), nof_active, nof_success_mgs
-  float last_ul_snr = 0.0f;                                           // enb_ul.chest_res.snr_db of the most recent PUSCH attempt (UL_Sniffer_PUSCH.cc:572)
+  std::map<uint32_t, std::vector<UlSchedGrant>>& ul_sched = sh->ul_sched;  // ULSchedule databases (touched in the commit turn only)
+  std::map<uint32_t, std::vector<UlSchedGrant>>& rar_sched = sh->rar_sched;
+  std::vector<uint8_t>& ulmod = sh->ulmod; uint32_t& ulmod_count = sh->ulmod_count;
+  std::vector<UeSpecConfig>& ul_uecfg = sh->ul_uecfg;
+  std::vector<uint32_t>& ul_time = sh->ul_time; std::vector<uint32_t>& ul_active = sh->ul_active; std::vector<uint32_t>& ul_success = sh->ul_success;
+  float& last_ul_snr = sh->last_ul_snr;
   void ulTrackAdd(uint16_t rnti, int mod = 1);                        // add_RNTI_ul, MCSTracking.cc:57-69
   void ulAgeDatabase();                                               // update_database_ul, MCSTracking.cc:86-176
 

@@ -95,6 +95,8 @@ int Engine::setPrachConfig(const lsn_prach_cfg_t& p)
     HIP_CHECK(hipDeviceSynchronize());
     up(prach.d_W, W); up(prach.d_V, V); up(prach.d_D, D);
     prach.set = true;
+    sh->prach_cfg = prach.cfg; sh->prach_cfg_set = true;   // the other engines of a multi-GPU capture follow at their next commit turn (syncUlConfig)
+    prach_tables_epoch = ++sh->prach_epoch;
     return LSN_SUCCESS;
   } catch (const std::exception& ex) {
     fprintf(stderr, "ltesniffer_amd: %s\n", ex.what());

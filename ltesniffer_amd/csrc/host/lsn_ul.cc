@@ -59,8 +59,39 @@ bool Engine::getUlConfig(lsn_ul_cfg_t* u, lsn_prach_cfg_t* p, Sib2Config* sib) c
   return true;
 }
 
-// srsran_enb_ul_set_cell with the DMRS configuration of SIB2 (SubframeWorker.cc:258-262, ULSchedule.cc:140-158)
+// srsran_enb_ul_set_cell with the DMRS configuration of SIB2 (SubframeWorker.cc:258-262, ULSchedule.cc:140-158): the configuration becomes the
+// shared one (every engine of a multi-GPU capture follows it, syncUlConfig), this engine's device tables are built now
 int Engine::setUlConfig(const lsn_ul_cfg_t& u)
+{
+  if (!cell_set || u.cyclic_shift > 7 || u.delta_ss > 29) return LSN_ERROR_INVALID_INPUTS;
+  const int r = buildUlTables(u);
+  if (r != LSN_SUCCESS) return r;
+  ul_cfg = u;
+  ul_set = true;
+  sib2_learned = false;
+  ul_tables_epoch = ul_cfg_epoch.fetch_add(1, std::memory_order_release) + 1;
+  return LSN_SUCCESS;
+}
+
+// commit turn of an UL_MODE chunk: another engine of the capture (or the caller, through engine 0) may have (re)configured the uplink since this
+// engine built its tables
+void Engine::syncUlConfig()
+{
+  const uint32_t ep = ul_cfg_epoch.load(std::memory_order_acquire);
+  if (ul_set && ul_tables_epoch != ep) {
+    if (buildUlTables(ul_cfg) != LSN_SUCCESS) throw std::runtime_error("UL_MODE: the shared uplink configuration could not be applied on this device");
+    ul_tables_epoch = ep;
+  }
+  if (sh->prach_cfg_set && prach_tables_epoch != sh->prach_epoch) {
+    const uint32_t pe = sh->prach_epoch;
+    const lsn_prach_cfg_t pc = sh->prach_cfg;
+    if (setPrachConfig(pc) != LSN_SUCCESS) prach.set = false;
+    sh->prach_epoch = pe;          // (setPrachConfig counted a new epoch: this was a replay of the shared one)
+    prach_tables_epoch = pe;
+  }
+}
+
+int Engine::buildUlTables(const lsn_ul_cfg_t& u)
 {
   if (!cell_set || u.cyclic_shift > 7 || u.delta_ss > 29) return LSN_ERROR_INVALID_INPUTS;
   try {
@@ -126,12 +157,8 @@ int Engine::setUlConfig(const lsn_ul_cfg_t& u)
       for (int i = 0; i < 8; i++) npn += (uint32_t)c[8 * 7 * ns + i] << i;
       ul_npn[ns] = npn;
     }
-    ul_cfg = u;
     cell.pusch_hop_offset = u.hopping_offset;  // n_rb_ho of the DCI 0 -> grant conversion from now on (SubframeWorker.cc:271-277)
     search->setPuschHopOffset(u.hopping_offset);
-    ul_set = true;
-    sib2_learned = false;
-    ul_cfg_epoch.fetch_add(1, std::memory_order_release);
     if (!runner_u.stream) allocRunner(runner_u);
     return LSN_SUCCESS;
   } catch (const std::exception& ex) {

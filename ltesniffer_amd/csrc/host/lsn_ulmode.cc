@@ -74,6 +74,7 @@ void Engine::commitChunkUl(Chunk& ch, JobRunner& r)
   // mcs_tracking holds mcs_mtx, because the caller's timer - update_database_ul, nof_RNTI_member_ul, get_ue_config_rnti through the C ABI - runs
   // on the caller's thread while chunks are in flight, LTESniffer_Core.cc:473-499)
   const uint32_t nsf = ch.nsf;
+  syncUlConfig();
   std::vector<std::vector<PendingPdu>> out(nsf);            // records per subframe: downlink first, then uplink
   std::vector<std::vector<UlSchedGrant>> lists(nsf);        // PUSCH grants to try in each subframe
   std::vector<std::vector<std::pair<uint16_t, UeSpecConfig>>> setups(nsf);  // RRCConnectionSetups decoded in each subframe (run_decode, DL_Sniffer_PDSCH.cc:279-306)

@@ -65,3 +65,32 @@ def test_peer_copy_staging_path():
     env = dict(os.environ, LSN_FORCE_PEER_COPY="1")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_ul_mode_over_two_engines_equals_one_engine_and_the_oracle():
+    """UL_MODE on a capture that is spread over engines (round 2 refused it): the ULSchedule databases, the uplink tracking database and the
+    uplink configuration are part of the shared sequential state now.  The stream starts WITHOUT a configuration: the SIB2 is decoded by
+    whichever engine commits that chunk and the DMRS / hopping / PRACH tables of the other engine follow at its next commit turn; a PUSCH
+    whose DCI 0 sits in the previous chunk (n - 4, other engine) is decoded on the engine that holds subframe n."""
+    import torch
+    from lsn_testlib import REAL_SIB1, OracleWorkerUl, encode_sib2, gen_ul_mode_subframes, parse_pcap
+    sc = scenario("cfg2", seed=91, nof_rx=1, n_rnti=10, dl_min=2, dl_max=3, ul_min=2, ul_max=4, nof_prb=25, mcs_max=18, pusch_hop_offset=4, pct_hop=20)
+    sib2 = encode_sib2(cyclic_shift=3, group_assignment_pusch=5, pusch_hop_offset=4, group_hopping_enabled=1, root_seq_idx=22, prach_config_idx=3, zero_corr_zone=1,
+                       prach_freq_offset=2)
+    nsf = 90
+    tti0, iq, sent = gen_ul_mode_subframes(sc, nsf, si_msgs=[REAL_SIB1, sib2], group_hopping=1)
+    ow = OracleWorkerUl(sc["nof_prb"], sc["nof_ports"], sc["cell_id"], None, None)
+    for i in range(nsf):
+        ow.work_ul(iq[i, 0], iq[i, 1], tti0 + i, update_meta=1 if i % 25 == 0 else 0)
+    orecs = oracle_records(parse_pcap(ow.pcap_bytes()))
+    assert len([r for r in parse_pcap(ow.pcap_bytes()) if r["direction"] == 0]) >= 10
+    d = torch.from_numpy(iq.view(np.float32)).to("cuda:0")
+    got = {}
+    for devs in (None, [0, 0], [0, 0, 0]):
+        phy = la.Phy(nof_rx_antennas=2, sniffer_mode=1, max_batch=8, pcapwriter=la.PcapWriter(None), devices=devs)
+        assert phy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"]) and phy.getUlConfig() is None
+        phy.process_device(d.data_ptr(), nsf, tti0, 25, torch.cuda.current_stream().cuda_stream)
+        got[str(devs)] = (gpu_records(phy), phy.getUlConfig())
+        phy.close()
+    assert got["None"][0] == orecs and got["None"][1] == ow.ul_config()
+    assert got["[0, 0]"] == got["None"] and got["[0, 0, 0]"] == got["None"]
