@@ -316,73 +316,9 @@ void lsn_launch_rm(const LsnCbDev* cb, const int16_t* llr, uint32_t* spp, uint32
 // The interleaver addresses of the backward phase are generated by stepping the QPP recursion in reverse.
 // Window-boundary metrics of the previous iteration (next-iteration initialisation) stay in registers and move
 // between lanes with shuffles.
-// Sub-block length per kernel variant.  Build options kept from a measured experiment (MI355X, bit-identical results, interleaved A/B runs of
-// bench.py): -DTB_S128=8 with TB_WAVES_ATTR = amdgpu_waves_per_eu(2, 2) on k_turbo<128> fits 256 registers (20 spilled) = two waves per SIMD;
-// its own launches get shorter, the k_turbo<64> launches sharing the GPU get longer, the pipeline rate stays within run-to-run noise
-// (136.6 / 138.3 k vs 136.6 / 135.1 k subframes/s) - the instruction mix is dominated by half-rate VALU forms either way.
-#ifndef TB_S64
-#define TB_S64 16
-#endif
-#ifndef TB_S128
-#define TB_S128 16
-#endif
-#define TB_S_OF(NT) ((NT) == 128 ? TB_S128 : TB_S64)
-// check-point store (int16): sub-blocks 1 .. nsb-2, [slot][state][thread]; 64 threads: W <= 96, 128 threads: W <= 64
-#define TB_CKPT_SLOTS(NT) ((((NT) == 64 ? 96 : 64) + TB_S_OF(NT) - 1) / TB_S_OF(NT) - 2)
-#define TB_CKPT_I16_NT(NT) ((TB_CKPT_SLOTS(NT) < 2 ? 2 : TB_CKPT_SLOTS(NT)) * 7 * (NT) < 1100 ? 1100 : (TB_CKPT_SLOTS(NT) < 2 ? 2 : TB_CKPT_SLOTS(NT)) * 7 * (NT))
-                                 // 64 threads: W <= 96 -> 4 slots, 128 threads: W <= 64 -> 2 slots
-
-__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
-// EXPERIMENT (-DTB_MAX16, off by default): the per-step normalised recursions (alpha recompute, beta, LLR maxima) compare 16-bit wrapped metrics
-// with the full-rate v_max_i16 instead of the half-rate v_max_i32; needs |alpha + beta + gamma| < 32768, which tools/turbo_metric_ranges.py
-// measures (<= 19 920) but nothing proves yet; beta is normalised every step.  Measured with -DTB_S64=8 -DTB_S128=8 and two waves per SIMD:
-// identical records, 5 % SLOWER - kept for the record, not for use.
-#ifdef TB_MAX16
-__device__ __forceinline__ int imaxb(int a, int b) { int d; asm("v_max_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
-#else
-__device__ __forceinline__ int imaxb(int a, int b) { return a > b ? a : b; }
-#endif
-__device__ __forceinline__ int ext_scale(int x)
-{
-  int a = x < 0 ? -x : x;
-  a = (a + (a << 1)) >> 2;  // * 3/4
-  a = a > LSN_EXT_CLIP ? LSN_EXT_CLIP : a;
-  return x < 0 ? -a : a;
-}
-// forward step without the per-step normalisation (metrics only ever enter differences and maxima, so a common offset is
-// harmless as long as it fits: callers re-normalise every TB_S steps, growth <= 16 * 3069)
-__device__ __forceinline__ void step_fwd_raw(int* a, int lsa, int lp)
-{
-  const int g01 = lp, g10 = lsa, g11 = lsa + lp;
-  int n0 = imax(a[0], a[1] + g11), n1 = imax(a[2] + g10, a[3] + g01), n2 = imax(a[4] + g01, a[5] + g10), n3 = imax(a[6] + g11, a[7]);
-  int n4 = imax(a[0] + g11, a[1]), n5 = imax(a[2] + g01, a[3] + g10), n6 = imax(a[4] + g10, a[5] + g01), n7 = imax(a[6], a[7] + g11);
-  a[0] = n0; a[1] = n1; a[2] = n2; a[3] = n3; a[4] = n4; a[5] = n5; a[6] = n6; a[7] = n7;
-}
-// a[0] is always 0 after normalisation
-__device__ __forceinline__ void step_fwd(int* a, int lsa, int lp)
-{
-  const int g01 = lp, g10 = lsa, g11 = lsa + lp;
-  int n0 = imaxb(a[0], a[1] + g11), n1 = imaxb(a[2] + g10, a[3] + g01), n2 = imaxb(a[4] + g01, a[5] + g10), n3 = imaxb(a[6] + g11, a[7]);
-  int n4 = imaxb(a[0] + g11, a[1]), n5 = imaxb(a[2] + g01, a[3] + g10), n6 = imaxb(a[4] + g10, a[5] + g01), n7 = imaxb(a[6], a[7] + g11);
-  a[0] = 0; a[1] = n1 - n0; a[2] = n2 - n0; a[3] = n3 - n0; a[4] = n4 - n0; a[5] = n5 - n0; a[6] = n6 - n0; a[7] = n7 - n0;
-}
-
-struct TurboLds {
-  uint32_t* spp;   // [K] sys | p1 << 10 | p2 << 20 (10-bit two's complement fields), transposed
-  int16_t* ext;    // [K] extrinsic * 2 + hard bit, transposed
-  int16_t* ckpt;   // [slot][7][NT]; also the exchange buffer for the window-boundary metrics
-};
-
-// x -> (x % W) * P + x / W with full-rate 24-bit multiplies; magicW = ceil(2^20 / W) is exact for x < 6144, W <= 96
-// (error x / 2^20 < 1 / W)
-__device__ __forceinline__ int tr_idx(int x, int W, int P, uint32_t magicW)
-{
-  const int q = (int)(__umul24((uint32_t)x, magicW) >> 20);
-  return __mul24(x - __mul24(q, W), P) + q;
-}
-__device__ __forceinline__ int fld0(uint32_t w) { return (int)(w << 22) >> 22; }
-__device__ __forceinline__ int fld1(uint32_t w) { return (int)(w << 12) >> 22; }
-__device__ __forceinline__ int fld2(uint32_t w) { return (int)(w << 2) >> 22; }
+// Since round 3 the recursions run on packed int16 pairs (lsn_turbo_core.h: layouts, word-length argument, the per-lane text that
+// tests/native/test_turbo_core.cc runs on the CPU against the oracle's decoder).
+#include "lsn_turbo_core.h"
 
 // GF(2) polynomial product a*b mod g (24-bit CRC generators, poly includes the x^24 term)
 __device__ __forceinline__ uint32_t mulmod24(uint32_t a, uint32_t b, uint32_t poly)
@@ -397,163 +333,22 @@ __device__ __forceinline__ uint32_t mulmod24(uint32_t a, uint32_t b, uint32_t po
   return r & 0xFFFFFFu;
 }
 
-// one constituent decoder over all windows (lane = window); nii_a / nii_b: boundary metrics (states 1..7) in registers
+// one constituent decoder over all windows (lane = window); nii_a / nii_b: boundary metrics (layout C) in registers
 template <bool IL, int NT>
 __device__ __forceinline__ void map_pass(const TurboLds& m, int lane, bool active, int K, int P, int W, uint32_t magicW, int f1, int f2,
-                                         int* nii_a, int* nii_b, const int* beta_tail)
+                                         s2* nii_a, s2* nii_b, const s2* beta_tail)
 {
-  constexpr int TB_S = TB_S_OF(NT);  // sub-block length of this variant
-  const int wl = active ? lane : 0;  // window this lane computes (idle lanes shadow window 0 and never store soft data)
-  const int t0 = wl * W;
-  const int nsb = (W + TB_S - 1) / TB_S;
-  int a[8], b[8], a0[7];
-  a[0] = 0;
-#pragma unroll
-  for (int s = 1; s < 8; s++) { a[s] = (wl == 0) ? LSN_NEG_METRIC : nii_a[s - 1]; a0[s - 1] = a[s]; }
-  int pi = t0, gq = 0;
-  const int twof2 = (2 * f2) % K;
-  if (IL) {
-    pi = (int)(((long long)f1 * t0 + (long long)f2 * t0 % K * t0) % K);
-    gq = (int)(((long long)f1 + f2 + 2ll * f2 % K * t0) % K);
-  }
-  int g[TB_S];  // operands of one sub-block: lsa (low 16 bits) | lp << 16
-  // ---- forward sweep over sub-blocks 0 .. nsb-2 (the last one is covered by the recompute below) ----
-  for (int sb = 0; sb + 1 < nsb; sb++) {
-    if (sb >= 1) {
-#pragma unroll
-      for (int s = 1; s < 8; s++) m.ckpt[((sb - 1) * 7 + (s - 1)) * NT + lane] = (int16_t)a[s];
-    }
-    const int tb = sb * TB_S;
-#pragma unroll
-    for (int u = 0; u < TB_S; u++) {
-      const int nat = (tb + u) * P + wl;
-      if (IL) {
-        const int idx = tr_idx(pi, W, P, magicW);
-        pi += gq; pi = pi >= K ? pi - K : pi; gq += twof2; gq = gq >= K ? gq - K : gq;
-        g[u] = ((fld0(m.spp[idx]) + ((int)m.ext[idx] >> 1)) & 0xFFFF) | (fld2(m.spp[nat]) << 16);
-      } else {
-        const uint32_t w = m.spp[nat];
-        g[u] = ((fld0(w) + ((int)m.ext[nat] >> 1)) & 0xFFFF) | (fld1(w) << 16);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < TB_S; u++) step_fwd_raw(a, (int)(g[u] << 16) >> 16, g[u] >> 16);
-#pragma unroll
-    for (int s = 7; s >= 0; s--) a[s] -= a[0];  // one normalisation per sub-block (exactly what 16 normalised steps would leave)
-  }
-  if (IL) {  // interleaver state -> end of the window
-    for (int t = (nsb - 1) * TB_S; t < W; t++) { pi += gq; pi = pi >= K ? pi - K : pi; gq += twof2; gq = gq >= K ? gq - K : gq; }
-  }
-  int a_end[7];
-  b[0] = 0;
-#pragma unroll
-  for (int s = 1; s < 8; s++) b[s] = (wl == P - 1) ? beta_tail[s] : nii_b[s - 1];
-  // ---- backward, sub-block by sub-block ----
-  int ix[TB_S];          // LDS index of the systematic / extrinsic value of each step
-  uint32_t A[TB_S][4];   // alphas of the sub-block, packed int16: (a1,a2) (a3,a4) (a5,a6) (a7)
-  for (int sb = nsb - 1; sb >= 0; sb--) {
-    const int tb = sb * TB_S, n = (tb + TB_S < W) ? TB_S : W - tb;
-    if (sb + 1 < nsb) {
-      a[0] = 0;
-      if (sb == 0) {
-#pragma unroll
-        for (int s = 1; s < 8; s++) a[s] = a0[s - 1];
-      } else {
-#pragma unroll
-        for (int s = 1; s < 8; s++) a[s] = m.ckpt[((sb - 1) * 7 + (s - 1)) * NT + lane];
-      }
-    }
-    // (only the last sub-block of a window can be shorter than TB_S: the full-length variant carries no per-step guards)
-    auto subblock = [&](auto fullc) {
-      constexpr bool FULL = decltype(fullc)::value;
-    // operand burst, last step first (the QPP recursion runs in reverse)
-#pragma unroll
-    for (int u = TB_S - 1; u >= 0; u--) {
-      if (FULL || u < n) {
-        const int nat = (tb + u) * P + wl;
-        if (IL) {
-          gq -= twof2; gq = gq < 0 ? gq + K : gq; pi -= gq; pi = pi < 0 ? pi + K : pi;
-          const int idx = tr_idx(pi, W, P, magicW);
-          ix[u] = active ? idx : K;
-          g[u] = ((fld0(m.spp[idx]) + ((int)m.ext[idx] >> 1)) & 0xFFFF) | (fld2(m.spp[nat]) << 16);
-        } else {
-          const uint32_t w = m.spp[nat];
-          ix[u] = active ? nat : K;
-          g[u] = ((fld0(w) + ((int)m.ext[nat] >> 1)) & 0xFFFF) | (fld1(w) << 16);
-        }
-      }
-    }
-    // recompute the alphas of this sub-block into registers
-#pragma unroll
-    for (int u = 0; u < TB_S; u++) {
-      if (FULL || u < n) {
-        A[u][0] = ((uint32_t)a[1] & 0xFFFFu) | ((uint32_t)a[2] << 16);
-        A[u][1] = ((uint32_t)a[3] & 0xFFFFu) | ((uint32_t)a[4] << 16);
-        A[u][2] = ((uint32_t)a[5] & 0xFFFFu) | ((uint32_t)a[6] << 16);
-        A[u][3] = (uint32_t)a[7];
-        step_fwd(a, (int)(g[u] << 16) >> 16, g[u] >> 16);
-      }
-    }
-    if (sb == nsb - 1) {
-#pragma unroll
-      for (int s = 1; s < 8; s++) a_end[s - 1] = a[s];
-    }
-    // beta recursion + LLR + extrinsic
-#pragma unroll
-    for (int u = TB_S - 1; u >= 0; u--) {
-      if (FULL || u < n) {
-        const int lsa = (int)(g[u] << 16) >> 16, lp = g[u] >> 16;
-        const int al1 = (int)(A[u][0] << 16) >> 16, al2 = (int)A[u][0] >> 16, al3 = (int)(A[u][1] << 16) >> 16, al4 = (int)A[u][1] >> 16;
-        const int al5 = (int)(A[u][2] << 16) >> 16, al6 = (int)A[u][2] >> 16, al7 = (int)A[u][3];
-        const int g01 = lp, g10 = lsa, g11 = lsa + lp;
-        // branch metrics + beta of the successor, per state: x0 = input 0, x1 = input 1
-        const int x00 = b[0], x01 = b[4] + g11;
-        const int x10 = b[4], x11 = b[0] + g11;
-        const int x20 = b[5] + g01, x21 = b[1] + g10;
-        const int x30 = b[1] + g01, x31 = b[5] + g10;
-        const int x40 = b[2] + g01, x41 = b[6] + g10;
-        const int x50 = b[6] + g01, x51 = b[2] + g10;
-        const int x60 = b[7], x61 = b[3] + g11;
-        const int x70 = b[3], x71 = b[7] + g11;
-        const int m0 = imaxb(imaxb(imaxb(x00, al1 + x10), imaxb(al2 + x20, al3 + x30)), imaxb(imaxb(al4 + x40, al5 + x50), imaxb(al6 + x60, al7 + x70)));
-        const int m1 = imaxb(imaxb(imaxb(x01, al1 + x11), imaxb(al2 + x21, al3 + x31)), imaxb(imaxb(al4 + x41, al5 + x51), imaxb(al6 + x61, al7 + x71)));
-#ifdef TB_MAX16
-        const int L = (int)(short)(m1 - m0);
-#else
-        const int L = m1 - m0;
-#endif
-        m.ext[ix[u]] = (int16_t)((ext_scale(L - lsa) << 1) | (L > 0 ? 1 : 0));  // idle lanes: spare slot ext[K]
-        b[0] = imaxb(x00, x01);  // no per-step normalisation (see step_fwd_raw): once per sub-block below
-        b[1] = imaxb(x10, x11); b[2] = imaxb(x20, x21); b[3] = imaxb(x30, x31); b[4] = imaxb(x40, x41);
-        b[5] = imaxb(x50, x51); b[6] = imaxb(x60, x61); b[7] = imaxb(x70, x71);
-#ifdef TB_MAX16
-#pragma unroll
-        for (int s = 7; s >= 0; s--) b[s] -= b[0];  // every step: keeps alpha + beta + gamma inside 16 bits
-#endif
-      }
-    }
-#ifndef TB_MAX16
-#pragma unroll
-    for (int s = 7; s >= 0; s--) b[s] -= b[0];
-#endif
-      };
-    if (n == TB_S) subblock(std::true_type{}); else subblock(std::false_type{});
-  }
+  s2 a_end[4], b_out[4];
+  lsn_map_pass_lane<IL, NT>(m, lane, active, K, P, W, magicW, f1, f2, nii_a, nii_b, beta_tail, a_end, b_out);
   // next-iteration initialisation: window p starts from the end of window p-1 and ends at the start of window p+1.
-  // The exchange goes through the (now idle) check-point area: [14][NT] int16.
+  // The exchange goes through the (now idle) check-point area, slots 0 and 1.
   __syncthreads();
-#pragma unroll
-  for (int s = 1; s < 8; s++) {
-    m.ckpt[(s - 1) * NT + lane] = (int16_t)a_end[s - 1];
-    m.ckpt[(7 + s - 1) * NT + lane] = (int16_t)b[s];
-  }
+  lsn_ckpt_store<NT>(m.ckpt, 0, lane, a_end);
+  lsn_ckpt_store<NT>(m.ckpt, 1, lane, b_out);
   __syncthreads();
   const int lm = lane > 0 ? lane - 1 : 0, lq = lane + 1 < NT ? lane + 1 : lane;
-#pragma unroll
-  for (int s = 1; s < 8; s++) {
-    nii_a[s - 1] = m.ckpt[(s - 1) * NT + lm];
-    nii_b[s - 1] = m.ckpt[(7 + s - 1) * NT + lq];
-  }
+  lsn_ckpt_load<NT>(m.ckpt, 0, lm, nii_a);
+  lsn_ckpt_load<NT>(m.ckpt, 1, lq, nii_b);
   __syncthreads();
 }
 
@@ -615,9 +410,9 @@ __global__ __launch_bounds__(NT) TB_WAVES_ATTR void k_turbo(const uint32_t* __re
   const uint32_t magicW = ((1u << 20) + (uint32_t)W - 1u) / (uint32_t)W;
   const bool active = lane < P;
   TurboLds m;
-  m.spp = (uint32_t*)smem; m.ext = (int16_t*)(m.spp + kmax); m.ckpt = m.ext + kmax + 8;  // ext[K] = spare slot for idle lanes
+  m.spp = (uint32_t*)smem; m.ext = (int16_t*)(m.spp + kmax); m.ckpt = (uint8_t*)(m.ext + kmax + 8);  // ext[K] = spare slot for idle lanes
   // the check-point area doubles as scratch for the 12 termination values
-  int* tail = (int*)(m.ckpt + 1024);
+  int* tail = (int*)(m.ckpt + 2048);
   // ---- soft data of the block: K packed words (already in the transposed layout) + 12 termination values, written by k_rm ----
   {
     const uint32_t* src = spp_g + cb.spp_off;  // 16-byte aligned, K is a multiple of 8
@@ -627,22 +422,23 @@ __global__ __launch_bounds__(NT) TB_WAVES_ATTR void k_turbo(const uint32_t* __re
   }
   __syncthreads();
   // ---- termination (36.212 5.1.3.2.2): tail[s*4 + j] = stream s at position K + j ----
-  int bt1[8], bt2[8];
+  s2 bt1[4], bt2[4];
   {
     const int *s4 = tail, *q1 = tail + 4, *q2 = tail + 8;
     int ts1[3] = {s4[0], q2[0], q1[1]}, tp1[3] = {q1[0], s4[1], q2[1]};
     int ts2[3] = {s4[2], q2[2], q1[3]}, tp2[3] = {q1[2], s4[3], q2[3]};
-    tail_beta(ts1, tp1, bt1);
-    tail_beta(ts2, tp2, bt2);
+    int b8[8];
+    tail_beta(ts1, tp1, b8); lsn_pack_c(b8, bt1);
+    tail_beta(ts2, tp2, b8); lsn_pack_c(b8, bt2);
   }
   __syncthreads();  // scratch is dead from here on: the area becomes the check-point store
   const long long tc1 = TB_CLOCK();
   const uint32_t poly = cb.crc_b ? 0x1800063u : 0x1864CFBu;
   // weight of this thread's window in the block polynomial: x^((P-1-window) W) mod g
   const uint32_t cw = active ? (cb.crc_b ? crc_tab_b : crc_tab_a)[(P - 1 - lane) * W] : 0u;
-  int na1[7], nb1[7], na2[7], nb2[7];
+  s2 na1[4], nb1[4], na2[4], nb2[4];
 #pragma unroll
-  for (int s = 0; s < 7; s++) { na1[s] = 0; nb1[s] = 0; na2[s] = 0; nb2[s] = 0; }
+  for (int s = 0; s < 4; s++) { na1[s] = s2{0, 0}; nb1[s] = s2{0, 0}; na2[s] = s2{0, 0}; nb2[s] = s2{0, 0}; }
   int it = 0;
   bool ok = false;
   while (it < (int)cb.max_iter && !ok) {
@@ -659,7 +455,7 @@ __global__ __launch_bounds__(NT) TB_WAVES_ATTR void k_turbo(const uint32_t* __re
       }
       rem = mulmod24(rem, cw, poly);
     }
-    ok = wg_xor<NT>(rem, m.ckpt, lane) == 0;
+    ok = wg_xor<NT>(rem, (int16_t*)m.ckpt, lane) == 0;
   }
   const int it_run = it;
   const long long tc2 = TB_CLOCK();
@@ -680,7 +476,7 @@ __global__ __launch_bounds__(NT) TB_WAVES_ATTR void k_turbo(const uint32_t* __re
     outp[j] = (uint8_t)byte;
   }
   if (j0 < j1) rema = mulmod24(rema, crc_tab_a[8 * (nout - j1)], 0x1864CFBu);
-  rema = wg_xor<NT>(rema, m.ckpt, lane);
+  rema = wg_xor<NT>(rema, (int16_t*)m.ckpt, lane);
   if (lane == 0) {
     const long long tc3 = TB_CLOCK();
     LsnCbRes r; r.ok = ok ? 1u : 0u; r.iters = (uint32_t)it; r.rem_a = rema; r.iters_run = (uint32_t)it_run;
@@ -689,8 +485,8 @@ __global__ __launch_bounds__(NT) TB_WAVES_ATTR void k_turbo(const uint32_t* __re
   }
 }
 
-size_t lsn_turbo_lds_bytes(uint32_t kmax) { return 6 * (size_t)kmax + 16 + sizeof(int16_t) * TB_CKPT_I16_NT(64); }
-static size_t turbo_lds_bytes_nt(uint32_t kmax, int nt) { return 6 * (size_t)kmax + 16 + sizeof(int16_t) * (size_t)(nt == 64 ? TB_CKPT_I16_NT(64) : TB_CKPT_I16_NT(128)); }
+size_t lsn_turbo_lds_bytes(uint32_t kmax) { return 6 * (size_t)kmax + 16 + TB_CKPT_BYTES(64); }
+static size_t turbo_lds_bytes_nt(uint32_t kmax, int nt) { return 6 * (size_t)kmax + 16 + (nt == 64 ? TB_CKPT_BYTES(64) : TB_CKPT_BYTES(128)); }
 
 // cb[0 .. n128) use two wavefronts per code block (P > 64), cb[n128 .. ncb) one; each range is launched with the LDS
 // size of its largest block (40 KiB at K = 6144 -> four code blocks per CU)
