@@ -535,7 +535,7 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
         cb.crc_b = s.C > 1 ? 1u : 0u;
         cb.out_bytes = (uint32_t)(K - F - (s.C > 1 ? 24 : 0)) / 8;
         cb.out_off = (uint32_t)(pay_n - pay0) + wp;
-        qpp_params(K, cb.f1, cb.f2);
+        cb.il_off = turbo_il_offset(K);
         cb.max_iter = (uint32_t)cfg.max_turbo_iterations;
         // code blocks 1 .. C-1 are launched behind block 0 and skipped when it failed (the TB CRC verdict needs every block)
         cb.dep = (q > 0 && g_cb_skip) ? (uint32_t)(r.h_cbs.size() - (size_t)q) : LSN_CB_NODEP;
@@ -586,7 +586,7 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
         const bool dx = r.h_cbs[x].dep != LSN_CB_NODEP, dy = r.h_cbs[y].dep != LSN_CB_NODEP;
         if (dx != dy) return dy;
         const uint32_t kx = r.h_cbs[x].K, ky = r.h_cbs[y].K;
-        const bool bx = lsn_turbo_nwin((int)kx) > 64, by = lsn_turbo_nwin((int)ky) > 64;
+        const bool bx = lsn_turbo_two_wave_class((int)kx), by = lsn_turbo_two_wave_class((int)ky);
         if (bx != by) return bx;
         if (kx != ky) return kx > ky;
         return x < y;
@@ -597,7 +597,7 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
         emax = std::max(emax, q.E);
         r.h_cbs_pinned[i] = q;
         const int ph = q.dep != LSN_CB_NODEP ? 1 : 0;
-        if (lsn_turbo_nwin((int)q.K) > 64) { n128p[ph]++; kmax128 = std::max(kmax128, q.K); } else { n64p[ph]++; kmax64 = std::max(kmax64, q.K); }
+        if (lsn_turbo_two_wave_class((int)q.K)) { n128p[ph]++; kmax128 = std::max(kmax128, q.K); } else { n64p[ph]++; kmax64 = std::max(kmax64, q.K); }
       }
       n128 = n128p[0] + n128p[1];
       grow_dev(r.d_spp, r.spp_cap, spp_n + 16, st);
@@ -645,7 +645,7 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
       for (uint32_t i = 0; i < ncb; i++) {
         const uint64_t b = 4ull * (r.h_cbs_pinned[i].K + 12u) + r.h_cbs_pinned[i].out_bytes;
         pf.turbo_algo_bytes += b;
-        if (lsn_turbo_nwin((int)r.h_cbs_pinned[i].K) > 64) pf.turbo128_algo_bytes += b;
+        if (lsn_turbo_two_wave_class((int)r.h_cbs_pinned[i].K)) pf.turbo128_algo_bytes += b;
       }
     }
     ch.h_payload.resize(pay_n);

@@ -574,6 +574,12 @@ bool cbsegm(int tbs, CbSegm& s)
   s.F = s.Cp * s.Kp + s.Cm * s.Km - Bp;
   return true;
 }
+uint32_t turbo_il_offset(int K)
+{
+  uint32_t off = 0;
+  for (int i = 0; i < LSN_QPP_NSIZES; i++) { if (lsn_qpp_table[i][0] == K) return off; off += lsn_qpp_table[i][0]; }
+  return off;  // K not a block size: the total number of entries
+}
 bool qpp_params(int K, uint32_t& f1, uint32_t& f2)
 {
   for (int i = 0; i < LSN_QPP_NSIZES; i++) if (lsn_qpp_table[i][0] == K) { f1 = lsn_qpp_table[i][1]; f2 = lsn_qpp_table[i][2]; return true; }

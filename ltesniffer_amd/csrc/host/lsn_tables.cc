@@ -2,6 +2,7 @@
 // masks, Gold-sequence masks, CRC remainder tables) and device buffer allocation for the engine.
 #include "lsn_engine.h"
 #include "../../../spec/lte_tables.h"
+#include "../kernels/lsn_turbo_core.h"
 #include <cmath>
 #include <cstdio>
 #include <stdexcept>
@@ -320,6 +321,15 @@ void Engine::buildTables()
       b <<= 1; if (b & 0x1000000u) b ^= 0x1800063u;
     }
     cd.crc_tab_a = upload(dev_allocs, ta); cd.crc_tab_b = upload(dev_allocs, tb);
+  }
+  // interleaver address tables of the turbo decoder, one per block size (kernels/lsn_turbo_core.h)
+  {
+    std::vector<uint16_t> il(turbo_il_offset(0) + 8);
+    for (int i = 0; i < LSN_QPP_NSIZES; i++) {
+      const int K = lsn_qpp_table[i][0];
+      lsn_turbo_il_fill(il.data() + turbo_il_offset(K), K, lsn_qpp_table[i][1], lsn_qpp_table[i][2]);
+    }
+    cd.turbo_il = upload(dev_allocs, il);
   }
   // pipeline slots, decode runners, staging
   for (int i = 0; i < nslots; i++) allocChunk(chunks[i]);

@@ -276,7 +276,7 @@ void Engine::puschDecodeGrid(const cf32* d_grid, uint32_t nsf, uint32_t start_tt
       cb.crc_b = s.C > 1 ? 1u : 0u;
       cb.out_bytes = (uint32_t)(K - F - (s.C > 1 ? 24 : 0)) / 8;
       cb.out_off = (uint32_t)pay_n + wp;
-      qpp_params(K, cb.f1, cb.f2);
+      cb.il_off = turbo_il_offset(K);
       cb.max_iter = (uint32_t)cfg.max_turbo_iterations;
       cb.dep = LSN_CB_NODEP;  // every code block is decoded: the iteration count of a grant is part of what lsn_phy_pusch_decode reports
       wp += cb.out_bytes;
@@ -303,7 +303,7 @@ void Engine::puschDecodeGrid(const cf32* d_grid, uint32_t nsf, uint32_t start_tt
   for (uint32_t i = 0; i < ncb; i++) { r.h_cbs[i].res_idx = i; order[i] = i; }
   std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
     const uint32_t kx = r.h_cbs[x].K, ky = r.h_cbs[y].K;
-    const bool bx = lsn_turbo_nwin((int)kx) > 64, by = lsn_turbo_nwin((int)ky) > 64;
+    const bool bx = lsn_turbo_two_wave_class((int)kx), by = lsn_turbo_two_wave_class((int)ky);
     if (bx != by) return bx;
     if (kx != ky) return kx > ky;
     return x < y;
@@ -315,7 +315,7 @@ void Engine::puschDecodeGrid(const cf32* d_grid, uint32_t nsf, uint32_t start_tt
     sorted[i] = r.h_cbs[order[i]];
     sorted[i].spp_off = (uint32_t)spp_n; spp_n += LSN_SPP_WORDS(sorted[i].K);
     emax = std::max(emax, sorted[i].E);
-    if (lsn_turbo_nwin((int)sorted[i].K) > 64) { n128++; kmax128 = std::max(kmax128, sorted[i].K); } else kmax64 = std::max(kmax64, sorted[i].K);
+    if (lsn_turbo_two_wave_class((int)sorted[i].K)) { n128++; kmax128 = std::max(kmax128, sorted[i].K); } else kmax64 = std::max(kmax64, sorted[i].K);
   }
   grow_d(r.d_spp, r.spp_cap, spp_n + 16);
   // descriptors go through pinned mirrors and the upload kernel, not through the host -> device copy engine (its FIFO may hold IQ blocks, lsn_dev.h)

@@ -105,3 +105,7 @@ LSN_HD int lsn_turbo_nwin(int K)
     if (K % P == 0) { p1 = P; break; }
   return p2 >= 96 ? p2 : p1;
 }
+// Blocks of at most 64 windows whose K exceeds this bound are decoded by the two-wavefront kernel too (its second wavefront leaves at once):
+// their 40 KiB of LDS would otherwise set the LDS size - and with it the occupancy - of every one-wavefront launch they are part of.
+#define LSN_TURBO_ONE_WAVE_KMAX 3072
+LSN_HD bool lsn_turbo_two_wave_class(int K) { return lsn_turbo_nwin(K) > 64 || K > LSN_TURBO_ONE_WAVE_KMAX; }

@@ -49,6 +49,30 @@ LSN_HD s2 pks(s2 a, s2 b) { return a - b; }
 LSN_HD s2 pkmax(s2 a, s2 b) { return __builtin_elementwise_max(a, b); }
 LSN_HD uint32_t pk_u32(s2 v) { return __builtin_bit_cast(uint32_t, v); }
 LSN_HD s2 pk_s2(uint32_t w) { return __builtin_bit_cast(s2, w); }
+// packed add / subtract with a free choice of the source halves (VOP3P op_sel): result.lo = a.{AL} +- b.{BL}, result.hi = a.{AH} +- b.{BH}
+// (0 = low half, 1 = high half).  The compiler folds broadcasts into op_sel by itself but spends a v_alignbit on every swapped operand; the
+// device build therefore states the modifiers itself.
+#ifdef __HIP_DEVICE_COMPILE__
+template <int AL, int AH, int BL, int BH>
+__device__ __forceinline__ s2 pka_sel(s2 a, s2 b)
+{
+  s2 d;
+  asm("v_pk_add_u16 %0, %1, %2 op_sel:[%3,%4] op_sel_hi:[%5,%6]" : "=v"(d) : "v"(a), "v"(b), "n"(AL), "n"(BL), "n"(AH), "n"(BH));
+  return d;
+}
+template <int AL, int AH, int BL, int BH>
+__device__ __forceinline__ s2 pks_sel(s2 a, s2 b)
+{
+  s2 d;
+  asm("v_pk_sub_i16 %0, %1, %2 op_sel:[%3,%4] op_sel_hi:[%5,%6]" : "=v"(d) : "v"(a), "v"(b), "n"(AL), "n"(BL), "n"(AH), "n"(BH));
+  return d;
+}
+#else
+template <int AL, int AH, int BL, int BH>
+static inline s2 pka_sel(s2 a, s2 b) { return pka(s2{AL ? a.y : a.x, AH ? a.y : a.x}, s2{BL ? b.y : b.x, BH ? b.y : b.x}); }
+template <int AL, int AH, int BL, int BH>
+static inline s2 pks_sel(s2 a, s2 b) { return pks(s2{AL ? a.y : a.x, AH ? a.y : a.x}, s2{BL ? b.y : b.x, BH ? b.y : b.x}); }
+#endif
 
 // sign(x) * min(floor(3 |x| / 4), LSN_EXT_CLIP) without a select: (3x + (3x < 0 ? 3 : 0)) >> 2 truncates towards zero, v_med3 clips
 LSN_HD int lsn_ext_scale(int x)
@@ -62,16 +86,16 @@ LSN_HD int lsn_ext_scale(int x)
 template <bool NORM>
 LSN_HD void lsn_step_fwd_pk(s2* a, s2 q)
 {
-  const s2 gg = pka(q, q.yx);    // (g11, g11)
-  const s2 p = s2{0, gg.y};      // (0, g11)
-  const s2 x0 = pka(a[0].xx, p), y0 = pka(a[1].xx, p.yx);     // -> states 0, 4 from 0, 1
-  const s2 x1 = pka(a[2].xx, q), y1 = pka(a[3].xx, q.yx);     // -> 1, 5 from 2, 3
-  const s2 x2 = pka(a[0].yy, q.yx), y2 = pka(a[1].yy, q);     // -> 2, 6 from 4, 5
-  const s2 x3 = pka(a[2].yy, p.yx), y3 = pka(a[3].yy, p);     // -> 3, 7 from 6, 7
+  const s2 gg = pka_sel<0, 1, 1, 0>(q, q);                      // (g11, g11)
+  const s2 p = pk_s2(pk_u32(gg) & 0xFFFF0000u);                 // (0, g11)
+  const s2 x0 = pka_sel<0, 0, 0, 1>(a[0], p), y0 = pka_sel<0, 0, 1, 0>(a[1], p);  // -> states 0, 4 from 0 (+ 0, g11), 1 (+ g11, 0)
+  const s2 x1 = pka_sel<0, 0, 0, 1>(a[2], q), y1 = pka_sel<0, 0, 1, 0>(a[3], q);  // -> 1, 5 from 2 (+ g10, g01), 3 (+ g01, g10)
+  const s2 x2 = pka_sel<1, 1, 1, 0>(a[0], q), y2 = pka_sel<1, 1, 0, 1>(a[1], q);  // -> 2, 6 from 4 (+ g01, g10), 5 (+ g10, g01)
+  const s2 x3 = pka_sel<1, 1, 1, 0>(a[2], p), y3 = pka_sel<1, 1, 0, 1>(a[3], p);  // -> 3, 7 from 6 (+ g11, 0), 7 (+ 0, g11)
   a[0] = pkmax(x0, y0); a[1] = pkmax(x1, y1); a[2] = pkmax(x2, y2); a[3] = pkmax(x3, y3);
   if (NORM) {
-    const s2 n = a[0].xx;
-    a[0] = pks(a[0], n); a[1] = pks(a[1], n); a[2] = pks(a[2], n); a[3] = pks(a[3], n);
+    const s2 n = a[0];
+    a[0] = pks_sel<0, 1, 0, 0>(a[0], n); a[1] = pks_sel<0, 1, 0, 0>(a[1], n); a[2] = pks_sel<0, 1, 0, 0>(a[2], n); a[3] = pks_sel<0, 1, 0, 0>(a[3], n);
   }
 }
 
@@ -81,18 +105,18 @@ LSN_HD int lsn_step_bwd_pk(s2* b, const s2* A, s2 q)
 {
   const s2 G0 = __builtin_shufflevector(b[0], b[2], 0, 2), G1 = __builtin_shufflevector(b[0], b[2], 1, 3);  // (b0, b2) (b4, b6)
   const s2 G2 = __builtin_shufflevector(b[1], b[3], 0, 2), G3 = __builtin_shufflevector(b[1], b[3], 1, 3);  // (b1, b3) (b5, b7)
-  const s2 gg = pka(q, q.yx);
-  const s2 S = s2{0, q.y};       // (0, g01)
-  const s2 T = s2{gg.x, q.x};    // (g11, g10)
+  const s2 gg = pka_sel<0, 1, 1, 0>(q, q);
+  const s2 S = pk_s2(pk_u32(q) & 0xFFFF0000u);   // (0, g01)
+  const s2 T = s2{gg.x, q.x};                    // (g11, g10)
   // successor metric + branch metric, paired like alpha: (state k, state k + 4); input 0 and input 1
-  const s2 u00 = pka(G0, S), u01 = pka(G1, S), u02 = pka(G3, S.yx), u03 = pka(G2, S.yx);
-  const s2 u10 = pka(G1, T), u11 = pka(G0, T), u12 = pka(G2, T.yx), u13 = pka(G3, T.yx);
+  const s2 u00 = pka(G0, S), u01 = pka(G1, S), u02 = pka_sel<0, 1, 1, 0>(G3, S), u03 = pka_sel<0, 1, 1, 0>(G2, S);
+  const s2 u10 = pka(G1, T), u11 = pka(G0, T), u12 = pka_sel<0, 1, 1, 0>(G2, T), u13 = pka_sel<0, 1, 1, 0>(G3, T);
   const s2 M0 = pkmax(pkmax(pka(A[0], u00), pka(A[1], u01)), pkmax(pka(A[2], u02), pka(A[3], u03)));
   const s2 M1 = pkmax(pkmax(pka(A[0], u10), pka(A[1], u11)), pkmax(pka(A[2], u12), pka(A[3], u13)));
   const s2 m0 = pkmax(M0, M0.yx), m1 = pkmax(M1, M1.yx);
   b[0] = pkmax(u00, u10); b[1] = pkmax(u01, u11); b[2] = pkmax(u02, u12); b[3] = pkmax(u03, u13);
-  const s2 n = b[0].xx;
-  b[0] = pks(b[0], n); b[1] = pks(b[1], n); b[2] = pks(b[2], n); b[3] = pks(b[3], n);
+  const s2 n = b[0];
+  b[0] = pks_sel<0, 1, 0, 0>(b[0], n); b[1] = pks_sel<0, 1, 0, 0>(b[1], n); b[2] = pks_sel<0, 1, 0, 0>(b[2], n); b[3] = pks_sel<0, 1, 0, 0>(b[3], n);
   return (int)m1.x - (int)m0.x;
 }
 
@@ -105,21 +129,20 @@ LSN_HD void lsn_pack_c(const int* m, s2* c)
 struct TurboLds {
   uint32_t* spp;   // [K] sys | p1 << 10 | p2 << 20 (10-bit two's complement fields), transposed
   int16_t* ext;    // [K] extrinsic * 2 + hard bit, transposed
-  uint8_t* ckpt;   // check-point slots of 14 * NT bytes each: [3][NT] words (states 1|5, 2|6, 3|7) + [NT] halves (state 4); state 0 is 0
+  uint8_t* ckpt;   // check-point slots of 14 * nt bytes each: [3][nt] words (states 1|5, 2|6, 3|7) + [nt] halves (state 4); state 0 is 0
 };
-template <int NT>
-LSN_HD void lsn_ckpt_store(uint8_t* area, int slot, int lane, const s2* a)
+// nt = threads that work on the block (64, or 128 for the blocks with more than 64 windows)
+LSN_HD void lsn_ckpt_store(uint8_t* area, int nt, int slot, int lane, const s2* a)
 {
-  uint32_t* w = (uint32_t*)(area + (size_t)slot * 14 * NT);
-  w[lane] = pk_u32(a[1]); w[NT + lane] = pk_u32(a[2]); w[2 * NT + lane] = pk_u32(a[3]);
-  ((int16_t*)(w + 3 * NT))[lane] = a[0].y;
+  uint32_t* w = (uint32_t*)(area + (size_t)(slot * 14 * nt));
+  w[lane] = pk_u32(a[1]); w[nt + lane] = pk_u32(a[2]); w[2 * nt + lane] = pk_u32(a[3]);
+  ((int16_t*)(w + 3 * nt))[lane] = a[0].y;
 }
-template <int NT>
-LSN_HD void lsn_ckpt_load(const uint8_t* area, int slot, int lane, s2* a)
+LSN_HD void lsn_ckpt_load(const uint8_t* area, int nt, int slot, int lane, s2* a)
 {
-  const uint32_t* w = (const uint32_t*)(area + (size_t)slot * 14 * NT);
-  a[1] = pk_s2(w[lane]); a[2] = pk_s2(w[NT + lane]); a[3] = pk_s2(w[2 * NT + lane]);
-  a[0] = s2{0, ((const int16_t*)(w + 3 * NT))[lane]};
+  const uint32_t* w = (const uint32_t*)(area + (size_t)(slot * 14 * nt));
+  a[1] = pk_s2(w[lane]); a[2] = pk_s2(w[nt + lane]); a[3] = pk_s2(w[2 * nt + lane]);
+  a[0] = s2{0, ((const int16_t*)(w + 3 * nt))[lane]};
 }
 
 #ifdef __HIP_DEVICE_COMPILE__
@@ -144,20 +167,36 @@ LSN_HD int fld2(uint32_t w) { return (int)(w << 2) >> 22; }
 #ifndef TB_S
 #define TB_S 16
 #endif
-// check-point slots: sub-blocks 1 .. nsb-2; 64 threads: W <= 96, 128 threads: W <= 64.  The area also carries the window-boundary exchange
-// (2 slots) and, before the first iteration, the 12 termination values (48 bytes at offset 2048).
-#define TB_CKPT_SLOTS(NT) ((((NT) == 64 ? 96 : 64) + TB_S - 1) / TB_S - 2)
-#define TB_CKPT_BYTES(NT) ((size_t)((TB_CKPT_SLOTS(NT) < 2 ? 2 : TB_CKPT_SLOTS(NT)) * 14 * (NT)) < 2200 ? (size_t)2200 : (size_t)((TB_CKPT_SLOTS(NT) < 2 ? 2 : TB_CKPT_SLOTS(NT)) * 14 * (NT)))
+// check-point slots: sub-blocks 1 .. nsb-2.  64 working threads: W <= 95 -> 6 sub-blocks, 4 slots; 128: W <= 52 -> 4 sub-blocks, 2 slots - 3584 bytes
+// either way.  The area also carries the window-boundary exchange (2 slots) and, before the first iteration, the 12 termination values
+// (48 bytes at offset 2048).
+#define TB_CKPT_BYTES ((size_t)3584)
+static_assert(TB_S == 16, "the check-point area is sized for sub-blocks of 16 steps");
+
+// interleaver address table of one block size: dst[t * P + w] = transposed address of pi(w * W + t), pi(x) = (f1 x + f2 x^2) mod K (36.212 5.1.3.2.3)
+LSN_HD void lsn_turbo_il_fill(uint16_t* dst, int K, int f1, int f2)
+{
+  const int P = lsn_turbo_nwin(K), W = K / P;
+  for (int w = 0; w < P; w++)
+    for (int t = 0; t < W; t++) {
+      const long long x = (long long)w * W + t;
+      const int pi = (int)(((long long)f1 * x + (long long)f2 * x % K * x) % K);
+      dst[t * P + w] = (uint16_t)((pi % W) * P + pi / W);
+    }
+}
 
 // One constituent decoder, the part of one lane (= window `wl`; idle lanes shadow window 0 and write their soft output to the spare slot
 // ext[K]).  nii_a / nii_b: boundary metrics of the previous iteration (layout C); beta_tail: termination metrics (layout C);
 // a_end / b_out: this window's metrics at its end / start, for the exchange between the lanes (the caller's business).
-template <bool IL, int NT>
-LSN_HD void lsn_map_pass_lane(const TurboLds& m, int lane, bool active, int K, int P, int W, uint32_t magicW, int f1, int f2,
+// il (second decoder only): il[t * P + w] = transposed LDS address of the position the QPP interleaver gives step t of window w
+// (lsn_turbo_il_fill below; one table per block size, 1.1 MB for all 188 sizes, L2 resident).  The addresses of a sub-block are fetched one
+// sub-block ahead of their use: the L2 latency hides behind the recursion of the sub-block in hand.  (Rounds 1-2 stepped the QPP recursion
+// pi += g, g += 2 f2 per lane and divided by W with a multiply: 14 instructions per step and direction instead of one load.)
+template <bool IL>
+LSN_HD void lsn_map_pass_lane(const TurboLds& m, const uint16_t* il, int nt, int lane, bool active, int K, int P, int W,
                               const s2* nii_a, const s2* nii_b, const s2* beta_tail, s2* a_end, s2* b_out)
 {
   const int wl = active ? lane : 0;
-  const int t0 = wl * W;
   const int nsb = (W + TB_S - 1) / TB_S;
   s2 a[4], b[4], a0[4];
   if (wl == 0) {
@@ -167,23 +206,32 @@ LSN_HD void lsn_map_pass_lane(const TurboLds& m, int lane, bool active, int K, i
     for (int k = 0; k < 4; k++) a[k] = nii_a[k];
   }
   for (int k = 0; k < 4; k++) a0[k] = a[k];
-  int pi = t0, gq = 0;
-  const int twof2 = (2 * f2) % K;
-  if (IL) {
-    pi = (int)(((long long)f1 * t0 + (long long)f2 * t0 % K * t0) % K);
-    gq = (int)(((long long)f1 + f2 + 2ll * f2 % K * t0) % K);
-  }
+  uint16_t nx[TB_S];  // interleaver addresses of the sub-block that comes next
+  int cur[TB_S];      // ... of the sub-block in hand
+  auto il_load = [&](int sb) {
+#pragma unroll
+    for (int u = 0; u < TB_S; u++) {
+      int t = sb * TB_S + u;
+      t = t < W ? t : W - 1;
+      nx[u] = (il + (uint32_t)(t * P))[wl];  // uniform row address + lane offset
+    }
+  };
+  if (IL) il_load(0);
   uint32_t g[TB_S];  // operands of one sub-block: lsa (low half) | lp << 16
   // ---- forward sweep over sub-blocks 0 .. nsb-2 (the last one is covered by the recompute below) ----
   for (int sb = 0; sb + 1 < nsb; sb++) {
-    if (sb >= 1) lsn_ckpt_store<NT>(m.ckpt, sb - 1, lane, a);
+    if (sb >= 1) lsn_ckpt_store(m.ckpt, nt, sb - 1, lane, a);
     const int tb = sb * TB_S;
+    if (IL) {
+#pragma unroll
+      for (int u = 0; u < TB_S; u++) cur[u] = nx[u];
+      il_load(sb + 1);
+    }
 #pragma unroll
     for (int u = 0; u < TB_S; u++) {
       const int nat = (tb + u) * P + wl;
       if (IL) {
-        const int idx = tr_idx(pi, W, P, magicW);
-        pi += gq; pi = pi >= K ? pi - K : pi; gq += twof2; gq = gq >= K ? gq - K : gq;
+        const int idx = cur[u];
         g[u] = ((uint32_t)(fld0(m.spp[idx]) + ((int)m.ext[idx] >> 1)) & 0xFFFFu) | ((uint32_t)fld2(m.spp[nat]) << 16);
       } else {
         const uint32_t w = m.spp[nat];
@@ -195,9 +243,6 @@ LSN_HD void lsn_map_pass_lane(const TurboLds& m, int lane, bool active, int K, i
       lsn_step_fwd_pk<false>(a, pk_s2(g[u]));
       lsn_step_fwd_pk<true>(a, pk_s2(g[u + 1]));
     }
-  }
-  if (IL) {  // interleaver state -> end of the window
-    for (int t = (nsb - 1) * TB_S; t < W; t++) { pi += gq; pi = pi >= K ? pi - K : pi; gq += twof2; gq = gq >= K ? gq - K : gq; }
   }
   if (wl == P - 1) {
     for (int k = 0; k < 4; k++) b[k] = beta_tail[k];
@@ -213,20 +258,24 @@ LSN_HD void lsn_map_pass_lane(const TurboLds& m, int lane, bool active, int K, i
       if (sb == 0) {
         for (int k = 0; k < 4; k++) a[k] = a0[k];
       } else {
-        lsn_ckpt_load<NT>(m.ckpt, sb - 1, lane, a);
+        lsn_ckpt_load(m.ckpt, nt, sb - 1, lane, a);
       }
+    }
+    if (IL) {
+#pragma unroll
+      for (int u = 0; u < TB_S; u++) cur[u] = nx[u];
+      if (sb > 0) il_load(sb - 1);
     }
     // only the last sub-block of a window can be shorter than TB_S: the full-length variant carries no per-step guards
     auto subblock = [&](auto fullc) {
       constexpr bool FULL = decltype(fullc)::value;
-      // operand burst, last step first (the QPP recursion runs in reverse)
+      // operand burst
 #pragma unroll
       for (int u = TB_S - 1; u >= 0; u--) {
         if (FULL || u < n) {
           const int nat = (tb + u) * P + wl;
           if (IL) {
-            gq -= twof2; gq = gq < 0 ? gq + K : gq; pi -= gq; pi = pi < 0 ? pi + K : pi;
-            const int idx = tr_idx(pi, W, P, magicW);
+            const int idx = cur[u];
             ix[u] = active ? idx : K;
             g[u] = ((uint32_t)(fld0(m.spp[idx]) + ((int)m.ext[idx] >> 1)) & 0xFFFFu) | ((uint32_t)fld2(m.spp[nat]) << 16);
           } else {

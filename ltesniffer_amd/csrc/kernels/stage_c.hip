@@ -334,21 +334,21 @@ __device__ __forceinline__ uint32_t mulmod24(uint32_t a, uint32_t b, uint32_t po
 }
 
 // one constituent decoder over all windows (lane = window); nii_a / nii_b: boundary metrics (layout C) in registers
-template <bool IL, int NT>
-__device__ __forceinline__ void map_pass(const TurboLds& m, int lane, bool active, int K, int P, int W, uint32_t magicW, int f1, int f2,
+template <bool IL>
+__device__ __forceinline__ void map_pass(const TurboLds& m, const uint16_t* il, int nt, int lane, bool active, int K, int P, int W,
                                          s2* nii_a, s2* nii_b, const s2* beta_tail)
 {
   s2 a_end[4], b_out[4];
-  lsn_map_pass_lane<IL, NT>(m, lane, active, K, P, W, magicW, f1, f2, nii_a, nii_b, beta_tail, a_end, b_out);
+  lsn_map_pass_lane<IL>(m, il, nt, lane, active, K, P, W, nii_a, nii_b, beta_tail, a_end, b_out);
   // next-iteration initialisation: window p starts from the end of window p-1 and ends at the start of window p+1.
   // The exchange goes through the (now idle) check-point area, slots 0 and 1.
   __syncthreads();
-  lsn_ckpt_store<NT>(m.ckpt, 0, lane, a_end);
-  lsn_ckpt_store<NT>(m.ckpt, 1, lane, b_out);
+  lsn_ckpt_store(m.ckpt, nt, 0, lane, a_end);
+  lsn_ckpt_store(m.ckpt, nt, 1, lane, b_out);
   __syncthreads();
-  const int lm = lane > 0 ? lane - 1 : 0, lq = lane + 1 < NT ? lane + 1 : lane;
-  lsn_ckpt_load<NT>(m.ckpt, 0, lm, nii_a);
-  lsn_ckpt_load<NT>(m.ckpt, 1, lq, nii_b);
+  const int lm = lane > 0 ? lane - 1 : 0, lq = lane + 1 < nt ? lane + 1 : lane;
+  lsn_ckpt_load(m.ckpt, nt, 0, lm, nii_a);
+  lsn_ckpt_load(m.ckpt, nt, 1, lq, nii_b);
   __syncthreads();
 }
 
@@ -367,12 +367,11 @@ __device__ __forceinline__ void tail_beta(const int* ts, const int* tp, int* bet
   for (int S = 7; S >= 0; S--) beta[S] = b[S] - b[0];
 }
 
-// XOR-reduce a value over the workgroup (NT = 64: one wave; 128: two waves through LDS scratch)
-template <int NT>
-__device__ __forceinline__ uint32_t wg_xor(uint32_t v, int16_t* scratch, int tid)
+// XOR-reduce a value over the working threads of the workgroup (nt = 64: one wave; 128: two waves through LDS scratch)
+__device__ __forceinline__ uint32_t wg_xor(uint32_t v, int16_t* scratch, int tid, int nt)
 {
   for (int off = 32; off > 0; off >>= 1) v ^= __shfl_xor(v, off);
-  if (NT == 64) return v;
+  if (nt == 64) return v;
   uint32_t* w = (uint32_t*)scratch;
   __syncthreads();
   if ((tid & 63) == 0) w[tid >> 6] = v;
@@ -382,11 +381,13 @@ __device__ __forceinline__ uint32_t wg_xor(uint32_t v, int16_t* scratch, int tid
   return v;
 }
 
+// Two wavefronts per SIMD (256 registers; the 22 the allocator spills sit outside the trellis loops): measured + 4 % on the pipeline against
+// the 284-register build at one wavefront per SIMD (profiles/r03_experiments.txt) - the second wave covers the LDS waits of the first
 #ifndef TB_WAVES_ATTR
-#define TB_WAVES_ATTR  // e.g. __attribute__((amdgpu_waves_per_eu(NT == 128 ? 2 : 1, NT == 128 ? 2 : 8))) together with -DTB_S128=8
+#define TB_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
 #endif
 template <int NT>
-__global__ __launch_bounds__(NT) TB_WAVES_ATTR void k_turbo(const uint32_t* __restrict__ crc_tab_a, const uint32_t* __restrict__ crc_tab_b,
+__global__ __launch_bounds__(NT) TB_WAVES_ATTR void k_turbo(const uint32_t* __restrict__ crc_tab_a, const uint32_t* __restrict__ crc_tab_b, const uint16_t* __restrict__ il_tab,
                                               const LsnCbDev* __restrict__ cbs, const uint32_t* __restrict__ spp_g,
                                               uint8_t* __restrict__ payload, LsnCbRes* res, uint32_t kmax)
 {
@@ -408,7 +409,12 @@ __global__ __launch_bounds__(NT) TB_WAVES_ATTR void k_turbo(const uint32_t* __re
   const int lane = threadIdx.x, K = (int)cb.K, F = (int)cb.F;
   const int P = lsn_turbo_nwin(K), W = K / P;
   const uint32_t magicW = ((1u << 20) + (uint32_t)W - 1u) / (uint32_t)W;
+  // a block of at most 64 windows inside a two-wavefront launch (lsn_turbo_two_wave_class: its LDS need would cap the occupancy of the
+  // one-wavefront launches): the second wavefront leaves before the first barrier and the first one works as in k_turbo<64>
+  const int nt = (NT == 128 && P <= 64) ? 64 : NT;
+  if (lane >= nt) return;
   const bool active = lane < P;
+  const uint16_t* il = il_tab + cb.il_off;
   TurboLds m;
   m.spp = (uint32_t*)smem; m.ext = (int16_t*)(m.spp + kmax); m.ckpt = (uint8_t*)(m.ext + kmax + 8);  // ext[K] = spare slot for idle lanes
   // the check-point area doubles as scratch for the 12 termination values
@@ -416,8 +422,8 @@ __global__ __launch_bounds__(NT) TB_WAVES_ATTR void k_turbo(const uint32_t* __re
   // ---- soft data of the block: K packed words (already in the transposed layout) + 12 termination values, written by k_rm ----
   {
     const uint32_t* src = spp_g + cb.spp_off;  // 16-byte aligned, K is a multiple of 8
-    for (int i = 4 * lane; i < K; i += 4 * NT) *(uint4*)&m.spp[i] = *(const uint4*)&src[i];
-    for (int i = 8 * lane; i < K; i += 8 * NT) *(uint4*)&m.ext[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = 4 * lane; i < K; i += 4 * nt) *(uint4*)&m.spp[i] = *(const uint4*)&src[i];
+    for (int i = 8 * lane; i < K; i += 8 * nt) *(uint4*)&m.ext[i] = make_uint4(0u, 0u, 0u, 0u);
     if (lane < 12) tail[lane] = (int)src[K + lane];
   }
   __syncthreads();
@@ -442,8 +448,8 @@ __global__ __launch_bounds__(NT) TB_WAVES_ATTR void k_turbo(const uint32_t* __re
   int it = 0;
   bool ok = false;
   while (it < (int)cb.max_iter && !ok) {
-    map_pass<false, NT>(m, lane, active, K, P, W, magicW, (int)cb.f1, (int)cb.f2, na1, nb1, bt1);
-    map_pass<true, NT>(m, lane, active, K, P, W, magicW, (int)cb.f1, (int)cb.f2, na2, nb2, bt2);
+    map_pass<false>(m, il, nt, lane, active, K, P, W, na1, nb1, bt1);
+    map_pass<true>(m, il, nt, lane, active, K, P, W, na2, nb2, bt2);
     it++;
     // CRC over all K decided bits == 0  <=>  data || parity divisible by g(x): Horner over the thread's own window,
     // then weighting with x^((P-1-window) W) and an XOR reduction over the windows
@@ -455,14 +461,14 @@ __global__ __launch_bounds__(NT) TB_WAVES_ATTR void k_turbo(const uint32_t* __re
       }
       rem = mulmod24(rem, cw, poly);
     }
-    ok = wg_xor<NT>(rem, (int16_t*)m.ckpt, lane) == 0;
+    ok = wg_xor(rem, (int16_t*)m.ckpt, lane, nt) == 0;
   }
   const int it_run = it;
   const long long tc2 = TB_CLOCK();
   // ---- output: payload bytes of this code block + its CRC24A remainder contribution (each thread a contiguous run) ----
   const int nout = (int)cb.out_bytes;
   uint8_t* outp = payload + cb.out_off;
-  const int per = (nout + NT - 1) / NT, j0 = lane * per, j1 = (j0 + per < nout) ? j0 + per : nout;
+  const int per = (nout + nt - 1) / nt, j0 = lane * per, j1 = (j0 + per < nout) ? j0 + per : nout;
   uint32_t rema = 0;
   for (int j = j0; j < j1; j++) {
     uint32_t byte = 0;
@@ -476,7 +482,7 @@ __global__ __launch_bounds__(NT) TB_WAVES_ATTR void k_turbo(const uint32_t* __re
     outp[j] = (uint8_t)byte;
   }
   if (j0 < j1) rema = mulmod24(rema, crc_tab_a[8 * (nout - j1)], 0x1864CFBu);
-  rema = wg_xor<NT>(rema, (int16_t*)m.ckpt, lane);
+  rema = wg_xor(rema, (int16_t*)m.ckpt, lane, nt);
   if (lane == 0) {
     const long long tc3 = TB_CLOCK();
     LsnCbRes r; r.ok = ok ? 1u : 0u; r.iters = (uint32_t)it; r.rem_a = rema; r.iters_run = (uint32_t)it_run;
@@ -485,8 +491,8 @@ __global__ __launch_bounds__(NT) TB_WAVES_ATTR void k_turbo(const uint32_t* __re
   }
 }
 
-size_t lsn_turbo_lds_bytes(uint32_t kmax) { return 6 * (size_t)kmax + 16 + TB_CKPT_BYTES(64); }
-static size_t turbo_lds_bytes_nt(uint32_t kmax, int nt) { return 6 * (size_t)kmax + 16 + (nt == 64 ? TB_CKPT_BYTES(64) : TB_CKPT_BYTES(128)); }
+size_t lsn_turbo_lds_bytes(uint32_t kmax) { return 6 * (size_t)kmax + 16 + TB_CKPT_BYTES; }
+static size_t turbo_lds_bytes_nt(uint32_t kmax, int) { return lsn_turbo_lds_bytes(kmax); }
 
 // cb[0 .. n128) use two wavefronts per code block (P > 64), cb[n128 .. ncb) one; each range is launched with the LDS
 // size of its largest block (40 KiB at K = 6144 -> four code blocks per CU)
@@ -500,7 +506,7 @@ void lsn_launch_turbo(const LsnCellDev& c, const LsnCbDev* cb, const uint32_t* s
     attr_set = true;
   }
   auto fix = [](uint32_t k) { return ((k < 512 ? 512u : k) + 7u) & ~7u; };  // the scratch in the check-point area needs room
-  if (n128) hipLaunchKernelGGL(k_turbo<128>, dim3(n128), dim3(128), turbo_lds_bytes_nt(fix(kmax128), 128), s, c.crc_tab_a, c.crc_tab_b, cb, spp, payload, res, fix(kmax128));
+  if (n128) hipLaunchKernelGGL(k_turbo<128>, dim3(n128), dim3(128), turbo_lds_bytes_nt(fix(kmax128), 128), s, c.crc_tab_a, c.crc_tab_b, c.turbo_il, cb, spp, payload, res, fix(kmax128));
   if (between) (void)hipEventRecord(between, s);
-  if (n64) hipLaunchKernelGGL(k_turbo<64>, dim3(n64), dim3(64), turbo_lds_bytes_nt(fix(kmax64), 64), s, c.crc_tab_a, c.crc_tab_b, cb + n128, spp, payload, res, fix(kmax64));
+  if (n64) hipLaunchKernelGGL(k_turbo<64>, dim3(n64), dim3(64), turbo_lds_bytes_nt(fix(kmax64), 64), s, c.crc_tab_a, c.crc_tab_b, c.turbo_il, cb + n128, spp, payload, res, fix(kmax64));
 }

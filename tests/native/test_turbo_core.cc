@@ -43,9 +43,11 @@ static int decode_like_kernel(const int16_t* d3, int K, int max_iter, uint32_t p
   int f1, f2;
   o_qpp_find(K, &f1, &f2);
   const uint32_t magicW = ((1u << 20) + (uint32_t)W - 1u) / (uint32_t)W;
+  std::vector<uint16_t> il(K);
+  lsn_turbo_il_fill(il.data(), K, f1, f2);
   std::vector<uint32_t> spp(K + 16);
   std::vector<int16_t> ext(K + 16, 0);
-  std::vector<uint8_t> ckpt(TB_CKPT_BYTES(NT) + 64);
+  std::vector<uint8_t> ckpt(TB_CKPT_BYTES + 64);
   const int16_t *d0 = d3, *d1 = d3 + D, *d2 = d3 + 2 * D;
   for (int t = 0; t < K; t++) {  // k_rm's output order: slot t holds position x = (t % P) * W + t / P
     const int x = (t % P) * W + t / P;
@@ -66,18 +68,18 @@ static int decode_like_kernel(const int16_t* d3, int K, int max_iter, uint32_t p
   TurboLds m;
   m.spp = spp.data(); m.ext = ext.data(); m.ckpt = ckpt.data();
   std::vector<s2> na1(4 * NT, s2{0, 0}), nb1(4 * NT, s2{0, 0}), na2(4 * NT, s2{0, 0}), nb2(4 * NT, s2{0, 0}), ae(4 * NT), bo(4 * NT);
-  auto pass = [&](bool il, std::vector<s2>& na, std::vector<s2>& nb, const s2* bt) {
+  auto pass = [&](bool second, std::vector<s2>& na, std::vector<s2>& nb, const s2* bt) {
     for (int lane = 0; lane < NT; lane++) {
       const bool active = lane < P;
-      if (il) lsn_map_pass_lane<true, NT>(m, lane, active, K, P, W, magicW, f1, f2, &na[4 * lane], &nb[4 * lane], bt, &ae[4 * lane], &bo[4 * lane]);
-      else lsn_map_pass_lane<false, NT>(m, lane, active, K, P, W, magicW, f1, f2, &na[4 * lane], &nb[4 * lane], bt, &ae[4 * lane], &bo[4 * lane]);
+      if (second) lsn_map_pass_lane<true>(m, il.data(), NT, lane, active, K, P, W, &na[4 * lane], &nb[4 * lane], bt, &ae[4 * lane], &bo[4 * lane]);
+      else lsn_map_pass_lane<false>(m, il.data(), NT, lane, active, K, P, W, &na[4 * lane], &nb[4 * lane], bt, &ae[4 * lane], &bo[4 * lane]);
     }
     // exchange through the check-point area, as the kernel does it (7 halves per lane and direction)
-    for (int lane = 0; lane < NT; lane++) { lsn_ckpt_store<NT>(m.ckpt, 0, lane, &ae[4 * lane]); lsn_ckpt_store<NT>(m.ckpt, 1, lane, &bo[4 * lane]); }
+    for (int lane = 0; lane < NT; lane++) { lsn_ckpt_store(m.ckpt, NT, 0, lane, &ae[4 * lane]); lsn_ckpt_store(m.ckpt, NT, 1, lane, &bo[4 * lane]); }
     for (int lane = 0; lane < NT; lane++) {
       const int lm = lane > 0 ? lane - 1 : 0, lq = lane + 1 < NT ? lane + 1 : lane;
-      lsn_ckpt_load<NT>(m.ckpt, 0, lm, &na[4 * lane]);
-      lsn_ckpt_load<NT>(m.ckpt, 1, lq, &nb[4 * lane]);
+      lsn_ckpt_load(m.ckpt, NT, 0, lm, &na[4 * lane]);
+      lsn_ckpt_load(m.ckpt, NT, 1, lq, &nb[4 * lane]);
     }
   };
   int it = 0, ok = 0;
