@@ -439,10 +439,17 @@ __device__ __forceinline__ uint32_t ss_validate(uint32_t n, uint32_t ncce, uint3
 // tail-biting Viterbi over D = nbits + 16 steps whose symbols are in symw (LDS, signed-byte triples); one wavefront.
 // Returns the nbits decoded bits (bit i at position 63 - i) and, in lane 0, the CRC16 remainder XOR the received parity
 // (the RNTI of a DCI / the antenna-port mask of the PBCH).
-__device__ __forceinline__ void viterbi_tb(const int* symw, unsigned long long* dec, uint32_t D, uint32_t nbits, int lane, unsigned long long& bits_out,
-                                           uint32_t& rem_out)
+// lane `lane` of (lo, hi) := the 64-bit wave-uniform word w (v_writelane_b32; this clang has no builtin for it).  A scalar-register source
+// leaves no constant-bus slot for the lane select: it goes through M0.
+__device__ __forceinline__ void lsn_writelane64(unsigned long long w, int lane, int& lo, int& hi)
+{
+  asm("s_mov_b32 m0, %4\n\ts_nop 0\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
+      : "+v"(lo), "+v"(hi) : "s"((int)(unsigned)w), "s"((int)(unsigned)(w >> 32)), "s"(lane) : "m0");
+}
+__device__ __forceinline__ void viterbi_tb(const int* symw, uint32_t D_, uint32_t nbits, int lane, unsigned long long& bits_out, uint32_t& rem_out)
 {
   __syncthreads();
+  const int D = (int)D_;  // <= 80: the payload is returned in 64 bits
   // lane = new state j: input bit b = j&1, predecessors j>>1 and (j>>1)|32; generator masks on the old state
   const int b = lane & 1, s0 = lane >> 1;
   const int c0 = b ^ (__popc(s0 & 0x36) & 1), c1 = b ^ (__popc(s0 & 0x27) & 1), c2 = b ^ (__popc(s0 & 0x2B) & 1);
@@ -450,45 +457,67 @@ __device__ __forceinline__ void viterbi_tb(const int* symw, unsigned long long* 
   const int kconst = (c0 ? 127 : 128) + (c1 ? 127 : 128) + (c2 ? 127 : 128);
   const int pa = s0 << 2, pb = (s0 | 32) << 2;  // ds_bpermute byte addresses of the two predecessors
   int m = 0;
-  const int T = 3 * (int)D;  // 3 passes of D steps
-  auto step = [&](int t) {
-    const int bm0 = __builtin_amdgcn_sdot4(symw[t], signs, kconst, false);
+  // add-compare-select of the 64 states on symbol k (the same D symbols in every pass); returns the decision ballot
+  auto acs = [&](int k) -> unsigned long long {
+    const int bm0 = __builtin_amdgcn_sdot4(symw[k], signs, kconst, false);
     const int a0 = __builtin_amdgcn_ds_bpermute(pa, m) + bm0, a1 = __builtin_amdgcn_ds_bpermute(pb, m) + (765 - bm0);
     const bool d = a1 < a0;
     m = d ? a1 : a0;
-    dec[t] = __ballot(d);  // same value, same address from every lane
+    return __ballot(d);
   };
-  int t = 0;
-  for (; t + 4 <= T; t += 4) { step(t); step(t + 1); step(t + 2); step(t + 3); }  // four steps share one symbol fetch and two ballot stores
-  for (; t < T; t++) step(t);
+  // pass 1 only warms the path metrics up: no decision is kept
+  {
+    int k = 0;
+    for (; k + 4 <= D; k += 4) { acs(k); acs(k + 1); acs(k + 2); acs(k + 3); }  // four steps share one symbol fetch
+    for (; k < D; k++) acs(k);
+  }
+  // passes 2 and 3: the decision word of step k stays in lane k & 63 of a register pair (v_writelane from the ballot's SGPRs) - no LDS
+  // traffic for the decisions, and the trace-back finds them where it used to load them
+  int dl[4] = {0, 0, 0, 0}, dh[4] = {0, 0, 0, 0};  // pass 2 steps 0..63, 64..D-1; pass 3 steps 0..63, 64..D-1
+  const int n0 = D < 64 ? D : 64;
+  auto sweep = [&](int& lo0, int& hi0, int& lo1, int& hi1) {
+    auto put0 = [&](int k) {
+      const unsigned long long w = acs(k);
+      lsn_writelane64(w, k, lo0, hi0);
+    };
+    int k = 0;
+    for (; k + 4 <= n0; k += 4) { put0(k); put0(k + 1); put0(k + 2); put0(k + 3); }
+    for (; k < n0; k++) put0(k);
+    for (; k < D; k++) {
+      const unsigned long long w = acs(k);
+      lsn_writelane64(w, k - 64, lo1, hi1);
+    }
+  };
+  sweep(dl[0], dh[0], dl[1], dh[1]);
+  sweep(dl[2], dh[2], dl[3], dh[3]);
   // best end state: minimum metric, lowest index on ties
   unsigned long long key = ((unsigned long long)(unsigned)m << 6) | (unsigned)lane;
   for (int off = 32; off > 0; off >>= 1) {
     unsigned long long o2 = __shfl_xor(key, off);
     key = o2 < key ? o2 : key;
   }
-  __syncthreads();
-  // trace-back over passes 3 and 2 (t = T-1 .. D): the state walks in scalar registers
+  // trace-back over pass 3, then pass 2 (whose states are the output): the state walks in scalar registers
   int st = __builtin_amdgcn_readfirstlane((int)(key & 63ull));
   rem_out = 0;
   unsigned long long bits = 0;  // decoded bit i of the middle pass at position 63-i (payload); the 16 CRC bits go to tailcrc
   unsigned int tailcrc = 0;
-  for (int hi = T; hi > (int)D; hi -= 64) {
-    const int lo = hi - 64 > (int)D ? hi - 64 : (int)D;
-    const unsigned long long mine = (lo + lane < hi) ? dec[lo + lane] : 0ull;
-    const int mlo = (int)(unsigned)mine, mhi = (int)(unsigned)(mine >> 32);
-    for (int t = hi - 1; t >= lo; t--) {
-      if (t < 2 * (int)D) {
-        const int i = t - (int)D;
+  auto back = [&](int lo, int hi, int kbase, int kn, bool emit) {
+    for (int k = kn - 1; k >= 0; k--) {
+      if (emit) {
+        const int i = kbase + k;
         if (i < (int)nbits) bits |= (unsigned long long)(st & 1) << (63 - i);
         else tailcrc |= (unsigned)(st & 1) << (15 - (i - (int)nbits));
       }
-      const unsigned wlo = (unsigned)__builtin_amdgcn_readlane(mlo, t - lo), whi = (unsigned)__builtin_amdgcn_readlane(mhi, t - lo);
+      const unsigned wlo = (unsigned)__builtin_amdgcn_readlane(lo, k), whi = (unsigned)__builtin_amdgcn_readlane(hi, k);
       const unsigned long long w = ((unsigned long long)whi << 32) | wlo;
       const int dd = (int)((w >> st) & 1ull);
       st = (st >> 1) | (dd << 5);
     }
-  }
+  };
+  back(dl[3], dh[3], 64, D - n0, false);
+  back(dl[2], dh[2], 0, n0, false);
+  back(dl[1], dh[1], 64, D - n0, true);
+  back(dl[0], dh[0], 0, n0, true);
   if (lane == 0) {
     // CRC16 (x^16+x^12+x^5+1) over the payload, zero-augmented long division
     unsigned int reg = 0;
@@ -515,8 +544,7 @@ __global__ __launch_bounds__(64) void k_viterbi(LsnCellDev c, const float* __res
                                                 const uint32_t* __restrict__ cfi_arr, const uint32_t* __restrict__ sf_idx_arr,
                                                 LsnCand* __restrict__ cand)
 {
-  __shared__ __attribute__((aligned(16))) int symw[3 * LSN_MAX_DCI_D + 4];  // per step of the three passes: (q0 - 128) | (q1 - 128) << 8 | (q2 - 128) << 16, signed bytes
-  __shared__ __attribute__((aligned(16))) unsigned long long dec[3 * LSN_MAX_DCI_D];
+  __shared__ __attribute__((aligned(16))) int symw[LSN_MAX_DCI_D + 4];  // per trellis step: (q0 - 128) | (q1 - 128) << 8 | (q2 - 128) << 16, signed bytes
   const int lane = threadIdx.x, sf = blockIdx.z, sz = blockIdx.y;
   int li = blockIdx.x;
   LsnCand* out = cand + ((size_t)sf * LSN_MAX_LOC + blockIdx.x) * LSN_MAX_SIZES + sz;
@@ -560,14 +588,14 @@ __global__ __launch_bounds__(64) void k_viterbi(LsnCellDev c, const float* __res
       q = q > 255.0f ? 255.0f : q;
       word |= (((uint32_t)(unsigned char)q - 128u) & 0xFFu) << (8 * j);
     }
-    symw[t] = (int)word; symw[D + t] = (int)word; symw[2 * D + t] = (int)word;  // one copy per pass: the sweep reads straight through
+    symw[t] = (int)word;
   }
   if (__ballot(nz) == 0ull) {  // mean |llr| == 0: the reference skips the decode (falcon_pdcch.c:141)
     if (lane == 0) { out->bits = 0; out->rnti = 0; out->flags = 0; }
     return;
   }
   unsigned long long bits; uint32_t rnti;
-  viterbi_tb(symw, dec, D, nbits, lane, bits, rnti);
+  viterbi_tb(symw, D, nbits, lane, bits, rnti);
   if (lane == 0) {
     out->bits = bits;
     out->rnti = rnti;
@@ -649,8 +677,7 @@ __global__ __launch_bounds__(256) void k_pbch_llr(LsnCellDev c, const cf32* __re
 }
 __global__ __launch_bounds__(64) void k_pbch_viterbi(LsnCellDev c, const float* __restrict__ llr5, LsnCand* __restrict__ out4)
 {
-  __shared__ __attribute__((aligned(16))) int symw[3 * LSN_MAX_DCI_D + 4];
-  __shared__ __attribute__((aligned(16))) unsigned long long dec[3 * LSN_MAX_DCI_D];
+  __shared__ __attribute__((aligned(16))) int symw[LSN_MAX_DCI_D + 4];
   const int lane = threadIdx.x, q = blockIdx.x;
   const float* e = llr5 + 480 * (q + 1);
   const uint32_t D = 40, D3 = 120, E = 480;
@@ -669,10 +696,10 @@ __global__ __launch_bounds__(64) void k_pbch_viterbi(LsnCellDev c, const float* 
       qv = qv > 255.0f ? 255.0f : qv;
       word |= (((uint32_t)(unsigned char)qv - 128u) & 0xFFu) << (8 * j);
     }
-    symw[t] = (int)word; symw[D + t] = (int)word; symw[2 * D + t] = (int)word;  // one copy per pass: the sweep reads straight through
+    symw[t] = (int)word;
   }
   unsigned long long bits; uint32_t rem;
-  viterbi_tb(symw, dec, D, 24, lane, bits, rem);
+  viterbi_tb(symw, D, 24, lane, bits, rem);
   if (lane == 0) { out4[q].bits = bits; out4[q].rnti = rem; out4[q].flags = 1u; }
 }
 void lsn_launch_pbch(const LsnCellDev& c, const cf32* grid, const cf32* ce, const LsnChest* ch, float* llr5, LsnCand* out4, hipStream_t s)
