@@ -344,6 +344,9 @@ def hosttest():
         lib.lsnh_dl_grant.argtypes = [C.c_uint32] * 5 + [C.c_int, C.c_void_p, C.c_uint32, C.c_int, C.c_uint16, C.c_int, C.POINTER(OGrant)]
         lib.lsnh_ul_grant.argtypes = [C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint16, C.c_void_p]
         lib.lsnh_cbsegm.argtypes = [C.c_int, C.c_void_p]
+        lib.lsnh_turbo_il_offset.restype = C.c_uint32
+        lib.lsnh_turbo_il_offset.argtypes = [C.c_int]
+        lib.lsnh_turbo_two_wave_class.argtypes = [C.c_int]
         lib.lsnh_search_new.restype = C.c_void_p
         lib.lsnh_search_new.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_double, C.c_int]
         lib.lsnh_search_free.argtypes = [C.c_void_p]

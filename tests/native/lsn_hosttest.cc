@@ -1,6 +1,7 @@
 // Test glue (NOT product): exposes the HIP-free host logic of the product (lsn_lte.cc, lsn_search.cc) through a
 // C interface so that the CPU test-suite can compare it with the oracle without a GPU.
 #include "../../ltesniffer_amd/csrc/host/lsn_search.h"
+#include "../../ltesniffer_amd/csrc/kernels/lsn_rm.h"
 #include <chrono>
 #include <cstring>
 
@@ -97,6 +98,9 @@ int lsnh_ul_grant(uint32_t nof_prb, uint32_t nof_ports, const uint8_t* payload, 
   out6[0] = g.L_prb; out6[1] = g.n_prb; out6[2] = g.mcs_idx; out6[3] = (uint32_t)g.mod; out6[4] = (uint32_t)g.tbs; out6[5] = (uint32_t)g.rv;
   return 3;
 }
+
+uint32_t lsnh_turbo_il_offset(int K) { return turbo_il_offset(K); }
+int lsnh_turbo_two_wave_class(int K) { return lsn_turbo_two_wave_class(K) ? 1 : 0; }
 
 int lsnh_cbsegm(int tbs, int* out6)
 {
