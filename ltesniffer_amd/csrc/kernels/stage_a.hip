@@ -439,12 +439,17 @@ __device__ __forceinline__ uint32_t ss_validate(uint32_t n, uint32_t ncce, uint3
 // tail-biting Viterbi over D = nbits + 16 steps whose symbols are in symw (LDS, signed-byte triples); one wavefront.
 // Returns the nbits decoded bits (bit i at position 63 - i) and, in lane 0, the CRC16 remainder XOR the received parity
 // (the RNTI of a DCI / the antenna-port mask of the PBCH).
-// lane `lane` of (lo, hi) := the 64-bit wave-uniform word w (v_writelane_b32; this clang has no builtin for it).  A scalar-register source
-// leaves no constant-bus slot for the lane select: it goes through M0.
-__device__ __forceinline__ void lsn_writelane64(unsigned long long w, int lane, int& lo, int& hi)
+// da = sw . sa + ca, db = sw . sb + cb over four signed bytes: the non-accumulating VOP3P form (the builtin selects v_dot4c plus a move of
+// the constant).  gfx90a+ leaves the DOT -> VALU read hazard (3 wait states) to software and the hazard recogniser does not look into inline
+// assembly, hence the s_nop - it stalls this wave only, the SIMD issues from its other waves meanwhile.
+__device__ __forceinline__ void lsn_dot4x2(int sw, int sa, int ca, int sb, int cb, int& da, int& db)
 {
-  asm("s_mov_b32 m0, %4\n\ts_nop 0\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %3, m0"
-      : "+v"(lo), "+v"(hi) : "s"((int)(unsigned)w), "s"((int)(unsigned)(w >> 32)), "s"(lane) : "m0");
+  asm("v_dot4_i32_i8 %0, %2, %3, %4\n\tv_dot4_i32_i8 %1, %2, %5, %6\n\ts_nop 2" : "=&v"(da), "=&v"(db) : "v"(sw), "v"(sa), "v"(ca), "v"(sb), "v"(cb));
+}
+// bits = bits * 2 + (x < y): the decision of this lane's state is shifted into the lane's own history word (compare + add-with-carry)
+__device__ __forceinline__ void lsn_push_lt(int& bits, int x, int y)
+{
+  asm("v_cmp_lt_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(x), "v"(y) : "vcc");
 }
 __device__ __forceinline__ void viterbi_tb(const int* symw, uint32_t D_, uint32_t nbits, int lane, unsigned long long& bits_out, uint32_t& rem_out)
 {
@@ -453,43 +458,46 @@ __device__ __forceinline__ void viterbi_tb(const int* symw, uint32_t D_, uint32_
   // lane = new state j: input bit b = j&1, predecessors j>>1 and (j>>1)|32; generator masks on the old state
   const int b = lane & 1, s0 = lane >> 1;
   const int c0 = b ^ (__popc(s0 & 0x36) & 1), c1 = b ^ (__popc(s0 & 0x27) & 1), c2 = b ^ (__popc(s0 & 0x2B) & 1);
+  // branch metric from predecessor j>>1: sum of c_i ? 255 - q_i : q_i = dot(sign, q - 128) + k0; from (j>>1)|32 (all three outputs
+  // complemented): 765 - that = dot(-sign, q - 128) + (765 - k0)
   const int signs = (c0 ? 0xFF : 0x01) | (c1 ? 0xFF00 : 0x0100) | (c2 ? 0xFF0000 : 0x010000);
-  const int kconst = (c0 ? 127 : 128) + (c1 ? 127 : 128) + (c2 ? 127 : 128);
+  const int nsigns = (c0 ? 0x01 : 0xFF) | (c1 ? 0x0100 : 0xFF00) | (c2 ? 0x010000 : 0xFF0000);
+  const int k0c = (c0 ? 127 : 128) + (c1 ? 127 : 128) + (c2 ? 127 : 128), k1c = 765 - k0c;
   const int pa = s0 << 2, pb = (s0 | 32) << 2;  // ds_bpermute byte addresses of the two predecessors
   int m = 0;
-  // add-compare-select of the 64 states on symbol k (the same D symbols in every pass); returns the decision ballot
-  auto acs = [&](int k) -> unsigned long long {
-    const int bm0 = __builtin_amdgcn_sdot4(symw[k], signs, kconst, false);
-    const int a0 = __builtin_amdgcn_ds_bpermute(pa, m) + bm0, a1 = __builtin_amdgcn_ds_bpermute(pb, m) + (765 - bm0);
-    const bool d = a1 < a0;
-    m = d ? a1 : a0;
-    return __ballot(d);
-  };
   // pass 1 only warms the path metrics up: no decision is kept
   {
+    auto acs = [&](int k) {
+      int bm0, bm1;
+      lsn_dot4x2(symw[k], signs, k0c, nsigns, k1c, bm0, bm1);
+      const int a0 = __builtin_amdgcn_ds_bpermute(pa, m) + bm0, a1 = __builtin_amdgcn_ds_bpermute(pb, m) + bm1;
+      m = a1 < a0 ? a1 : a0;
+    };
     int k = 0;
     for (; k + 4 <= D; k += 4) { acs(k); acs(k + 1); acs(k + 2); acs(k + 3); }  // four steps share one symbol fetch
     for (; k < D; k++) acs(k);
   }
-  // passes 2 and 3: the decision word of step k stays in lane k & 63 of a register pair (v_writelane from the ballot's SGPRs) - no LDS
-  // traffic for the decisions, and the trace-back finds them where it used to load them
-  int dl[4] = {0, 0, 0, 0}, dh[4] = {0, 0, 0, 0};  // pass 2 steps 0..63, 64..D-1; pass 3 steps 0..63, 64..D-1
-  const int n0 = D < 64 ? D : 64;
-  auto sweep = [&](int& lo0, int& hi0, int& lo1, int& hi1) {
-    auto put0 = [&](int k) {
-      const unsigned long long w = acs(k);
-      lsn_writelane64(w, k, lo0, hi0);
-    };
-    int k = 0;
-    for (; k + 4 <= n0; k += 4) { put0(k); put0(k + 1); put0(k + 2); put0(k + 3); }
-    for (; k < n0; k++) put0(k);
-    for (; k < D; k++) {
-      const unsigned long long w = acs(k);
-      lsn_writelane64(w, k - 64, lo1, hi1);
+  // passes 2 and 3: every lane shifts the decisions of ITS state into a history word, 32 steps per register (D <= 80: three per pass) -
+  // no ballot, no LDS; the trace-back reads the word of the state it stands on with one v_readlane
+  int h2[3] = {0, 0, 0}, h3[3] = {0, 0, 0};
+  auto sweep = [&](int* h) {
+#pragma unroll
+    for (int g = 0; g < 3; g++) {
+      const int k1 = D < 32 * (g + 1) ? D : 32 * (g + 1);
+      auto acs = [&](int k) {
+        int bm0, bm1;
+        lsn_dot4x2(symw[k], signs, k0c, nsigns, k1c, bm0, bm1);
+        const int a0 = __builtin_amdgcn_ds_bpermute(pa, m) + bm0, a1 = __builtin_amdgcn_ds_bpermute(pb, m) + bm1;
+        lsn_push_lt(h[g], a1, a0);
+        m = a1 < a0 ? a1 : a0;
+      };
+      int k = 32 * g;
+      for (; k + 4 <= k1; k += 4) { acs(k); acs(k + 1); acs(k + 2); acs(k + 3); }
+      for (; k < k1; k++) acs(k);
     }
   };
-  sweep(dl[0], dh[0], dl[1], dh[1]);
-  sweep(dl[2], dh[2], dl[3], dh[3]);
+  sweep(h2);
+  sweep(h3);
   // best end state: minimum metric, lowest index on ties
   unsigned long long key = ((unsigned long long)(unsigned)m << 6) | (unsigned)lane;
   for (int off = 32; off > 0; off >>= 1) {
@@ -501,23 +509,23 @@ __device__ __forceinline__ void viterbi_tb(const int* symw, uint32_t D_, uint32_
   rem_out = 0;
   unsigned long long bits = 0;  // decoded bit i of the middle pass at position 63-i (payload); the 16 CRC bits go to tailcrc
   unsigned int tailcrc = 0;
-  auto back = [&](int lo, int hi, int kbase, int kn, bool emit) {
-    for (int k = kn - 1; k >= 0; k--) {
-      if (emit) {
-        const int i = kbase + k;
-        if (i < (int)nbits) bits |= (unsigned long long)(st & 1) << (63 - i);
-        else tailcrc |= (unsigned)(st & 1) << (15 - (i - (int)nbits));
+  auto back = [&](const int* h, bool emit) {
+#pragma unroll
+    for (int g = 2; g >= 0; g--) {
+      const int k1 = D < 32 * (g + 1) ? D : 32 * (g + 1);
+      for (int k = k1 - 1; k >= 32 * g; k--) {  // step k's decision sits at bit k1 - 1 - k of the group's word
+        if (emit) {
+          if (k < (int)nbits) bits |= (unsigned long long)(st & 1) << (63 - k);
+          else tailcrc |= (unsigned)(st & 1) << (15 - (k - (int)nbits));
+        }
+        const unsigned w = (unsigned)__builtin_amdgcn_readlane(h[g], st);
+        const int dd = (int)((w >> (k1 - 1 - k)) & 1u);
+        st = (st >> 1) | (dd << 5);
       }
-      const unsigned wlo = (unsigned)__builtin_amdgcn_readlane(lo, k), whi = (unsigned)__builtin_amdgcn_readlane(hi, k);
-      const unsigned long long w = ((unsigned long long)whi << 32) | wlo;
-      const int dd = (int)((w >> st) & 1ull);
-      st = (st >> 1) | (dd << 5);
     }
   };
-  back(dl[3], dh[3], 64, D - n0, false);
-  back(dl[2], dh[2], 0, n0, false);
-  back(dl[1], dh[1], 64, D - n0, true);
-  back(dl[0], dh[0], 0, n0, true);
+  back(h3, false);
+  back(h2, true);
   if (lane == 0) {
     // CRC16 (x^16+x^12+x^5+1) over the payload, zero-augmented long division
     unsigned int reg = 0;
