@@ -1,10 +1,10 @@
 #!/bin/bash
 # Builds a variant of the product library for A/B measurements without touching ltesniffer_amd/lib:
 #   tools/ab_build.sh <tag> [extra hipcc flags for kernels/stage_c.hip ...]
-#   e.g. tools/ab_build.sh tb8 -DTB_S128=8 '-DTB_WAVES_ATTR=__attribute__((amdgpu_waves_per_eu(2,2)))'
+#   e.g. tools/ab_build.sh w1 '-DTB_WAVES_ATTR='   (the turbo kernels at one wavefront per SIMD)
 # -> ltesniffer_amd/lib_<tag>/libltesniffer_amd.so (git-ignored, travels with gpurun); run with
-#   LSN_LIB_PATH=$PWD/ltesniffer_amd/lib_<tag>/libltesniffer_amd.so python bench.py --no-cpu --no-check --no-legs
-# bench.py prints the digest of the timed record stream (parity.timed_digest): equal digests = identical records on that workload.
+#   LSN_LIB_PATH=$PWD/ltesniffer_amd/lib_<tag>/libltesniffer_amd.so python bench.py --no-cpu --no-legs      (or tools/ab_old_new.sh "lib lib_<tag>")
+# every run is gated on the oracle (pcap_diff 0 = identical records on that workload).
 set -e
 cd "$(dirname "$0")/../ltesniffer_amd/csrc"
 TAG=$1; shift
