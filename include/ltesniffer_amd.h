@@ -91,7 +91,9 @@ void lsn_phy_destroy(lsn_phy_t* phy);                                     /* Phy
  * host state (FALCON search / RNTI manager, MCS tracking, record order) is shared and taken in turns, so the record stream is the one a
  * single device produces.  IQ blocks that live on another device travel by peer copies (xGMI).  devices[0] is the primary device (MIB,
  * uplink, taps); listing a device twice is allowed (two engines on one GPU).  Supported entry points in this mode: lsn_phy_process_device,
- * lsn_phy_submit_device, lsn_phy_wait and the getters; DL mode only.  Several CELLS are several Phys - one process per GPU, no exchange. */
+ * lsn_phy_submit_device, lsn_phy_wait and the getters; DL_MODE and UL_MODE (the ULSchedule / uplink tracking databases and the uplink
+ * configuration are part of the shared state; a SIB2 learnt by one engine reaches the device tables of the others at their next commit turn).
+ * Several CELLS are several Phys - one process per GPU, no exchange. */
 int lsn_phy_create_multi(const lsn_phy_cfg_t* cfg, const int* devices, uint32_t n_devices, lsn_phy_t** out);
 uint32_t lsn_phy_nof_devices(lsn_phy_t* phy);
 int lsn_phy_set_cell(lsn_phy_t* phy, const lsn_cell_t* cell);             /* Phy::setCell, Phy.cc:111 */
