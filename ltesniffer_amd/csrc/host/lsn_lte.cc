@@ -1,5 +1,9 @@
 // lsn_lte.cc - see lsn_lte.h.  Product code: must not include anything from oracle/.
 #include "lsn_lte.h"
+#ifdef __HIPCC__
+#include <hip/hip_runtime.h>  // lsn_rm.h marks its helpers __host__ __device__ under hipcc
+#endif
+#include "../kernels/lsn_rm.h"
 #include "../../../spec/lte_tables.h"
 #include <algorithm>
 
@@ -576,9 +580,20 @@ bool cbsegm(int tbs, CbSegm& s)
 }
 uint32_t turbo_il_offset(int K)
 {
-  uint32_t off = 0;
-  for (int i = 0; i < LSN_QPP_NSIZES; i++) { if (lsn_qpp_table[i][0] == K) return off; off += lsn_qpp_table[i][0]; }
-  return off;  // K not a block size: the total number of entries
+  // called once per code block by the decode threads: a table indexed by K / 8, built on first use (thread-safe static initialisation)
+  struct Tab {
+    uint32_t off[6144 / 8 + 1], total;
+    Tab()
+    {
+      uint32_t o = 0;
+      for (auto& v : off) v = 0xFFFFFFFFu;
+      for (int i = 0; i < LSN_QPP_NSIZES; i++) { off[lsn_qpp_table[i][0] / 8] = o; o += (uint32_t)lsn_turbo_il_words(lsn_qpp_table[i][0]); }
+      total = o;
+    }
+  };
+  static const Tab tab;
+  if (K <= 0 || K > 6144 || (K & 7) || tab.off[K / 8] == 0xFFFFFFFFu) return tab.total;  // K not a block size: the total number of words
+  return tab.off[K / 8];
 }
 bool qpp_params(int K, uint32_t& f1, uint32_t& f2)
 {

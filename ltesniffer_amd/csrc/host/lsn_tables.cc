@@ -324,7 +324,7 @@ void Engine::buildTables()
   }
   // interleaver address tables of the turbo decoder, one per block size (kernels/lsn_turbo_core.h)
   {
-    std::vector<uint16_t> il(turbo_il_offset(0) + 8);
+    std::vector<uint32_t> il(turbo_il_offset(0) + 8);
     for (int i = 0; i < LSN_QPP_NSIZES; i++) {
       const int K = lsn_qpp_table[i][0];
       lsn_turbo_il_fill(il.data() + turbo_il_offset(K), K, lsn_qpp_table[i][1], lsn_qpp_table[i][2]);

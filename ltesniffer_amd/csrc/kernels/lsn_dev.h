@@ -49,7 +49,7 @@ struct LsnCellDev {
   const uint32_t* gold_x2mask;     // [LSN_GOLD_LEN] x2(n+1600) = parity(mask & cinit)
   const uint32_t* crc_tab_a;       // [6144] x^j mod gCRC24A
   const uint32_t* crc_tab_b;       // [6144] x^j mod gCRC24B
-  const uint16_t* turbo_il;        // interleaver address tables of the turbo decoder, all 188 block sizes back to back (lsn_turbo_il_fill; LsnCbDev::il_off)
+  const uint32_t* turbo_il;        // interleaver address tables of the turbo decoder (two steps per word), all 188 block sizes back to back (lsn_turbo_il_fill; LsnCbDev::il_off)
   // uplink (valid after lsn_phy_set_ul_config)
   const cf32* ul_shift;            // [N] exp(-j pi n / N): 7.5 kHz shift
   const cf32* ul_base;             // DMRS base sequences r_{u,0}(n) of every valid allocation size, concatenated
@@ -81,7 +81,7 @@ struct LsnCbDev {
   uint32_t crc_b;     // 1: CRC24B (C>1), 0: CRC24A
   uint32_t out_off;   // byte offset in the payload arena
   uint32_t out_bytes; // (K - F - 24*crc_b)/8
-  uint32_t il_off;    // entry offset of this block size's table in LsnCellDev::turbo_il (turbo_il_offset(K))
+  uint32_t il_off;    // word offset of this block size's table in LsnCellDev::turbo_il (turbo_il_offset(K))
   uint32_t reserved;
   uint32_t max_iter;
   uint32_t res_idx;   // slot of this block's LsnCbRes (launch order is sorted by size, results are not)

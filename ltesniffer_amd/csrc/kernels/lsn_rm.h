@@ -108,4 +108,6 @@ LSN_HD int lsn_turbo_nwin(int K)
 // Blocks of at most 64 windows whose K exceeds this bound are decoded by the two-wavefront kernel too (its second wavefront leaves at once):
 // their 40 KiB of LDS would otherwise set the LDS size - and with it the occupancy - of every one-wavefront launch they are part of.
 #define LSN_TURBO_ONE_WAVE_KMAX 3072
+// words of the turbo decoder's interleaver address table of block size K (two trellis steps per word, lsn_turbo_core.h)
+LSN_HD int lsn_turbo_il_words(int K) { const int P = lsn_turbo_nwin(K), W = K / P; return ((W + 1) / 2) * P; }
 LSN_HD bool lsn_turbo_two_wave_class(int K) { return lsn_turbo_nwin(K) > 64 || K > LSN_TURBO_ONE_WAVE_KMAX; }

@@ -173,27 +173,29 @@ LSN_HD int fld2(uint32_t w) { return (int)(w << 2) >> 22; }
 #define TB_CKPT_BYTES ((size_t)3584)
 static_assert(TB_S == 16, "the check-point area is sized for sub-blocks of 16 steps");
 
-// interleaver address table of one block size: dst[t * P + w] = transposed address of pi(w * W + t), pi(x) = (f1 x + f2 x^2) mod K (36.212 5.1.3.2.3)
-LSN_HD void lsn_turbo_il_fill(uint16_t* dst, int K, int f1, int f2)
+// interleaver address table of one block size, two trellis steps per word: dst[(t / 2) * P + w] = a(t) | a(t + 1) << 16 for even t, with
+// a(t) = transposed address of pi(w * W + t), pi(x) = (f1 x + f2 x^2) mod K (36.212 5.1.3.2.3); lsn_turbo_il_words(K) words (lsn_rm.h)
+LSN_HD void lsn_turbo_il_fill(uint32_t* dst, int K, int f1, int f2)
 {
   const int P = lsn_turbo_nwin(K), W = K / P;
+  for (int i = 0; i < ((W + 1) / 2) * P; i++) dst[i] = 0;
   for (int w = 0; w < P; w++)
     for (int t = 0; t < W; t++) {
       const long long x = (long long)w * W + t;
       const int pi = (int)(((long long)f1 * x + (long long)f2 * x % K * x) % K);
-      dst[t * P + w] = (uint16_t)((pi % W) * P + pi / W);
+      dst[(t >> 1) * P + w] |= (uint32_t)((pi % W) * P + pi / W) << (16 * (t & 1));
     }
 }
 
 // One constituent decoder, the part of one lane (= window `wl`; idle lanes shadow window 0 and write their soft output to the spare slot
 // ext[K]).  nii_a / nii_b: boundary metrics of the previous iteration (layout C); beta_tail: termination metrics (layout C);
 // a_end / b_out: this window's metrics at its end / start, for the exchange between the lanes (the caller's business).
-// il (second decoder only): il[t * P + w] = transposed LDS address of the position the QPP interleaver gives step t of window w
-// (lsn_turbo_il_fill below; one table per block size, 1.1 MB for all 188 sizes, L2 resident).  The addresses of a sub-block are fetched one
+// il (second decoder only): il[(t / 2) * P + w] = transposed LDS addresses of the positions the QPP interleaver gives steps t, t + 1 of
+// window w, 16 bits each (lsn_turbo_il_fill above; one table per block size, 1.1 MB for all 188 sizes, L2 resident).  The addresses of a sub-block are fetched one
 // sub-block ahead of their use: the L2 latency hides behind the recursion of the sub-block in hand.  (Rounds 1-2 stepped the QPP recursion
 // pi += g, g += 2 f2 per lane and divided by W with a multiply: 14 instructions per step and direction instead of one load.)
 template <bool IL>
-LSN_HD void lsn_map_pass_lane(const TurboLds& m, const uint16_t* il, int nt, int lane, bool active, int K, int P, int W,
+LSN_HD void lsn_map_pass_lane(const TurboLds& m, const uint32_t* il, int nt, int lane, bool active, int K, int P, int W,
                               const s2* nii_a, const s2* nii_b, const s2* beta_tail, s2* a_end, s2* b_out)
 {
   const int wl = active ? lane : 0;
@@ -206,14 +208,15 @@ LSN_HD void lsn_map_pass_lane(const TurboLds& m, const uint16_t* il, int nt, int
     for (int k = 0; k < 4; k++) a[k] = nii_a[k];
   }
   for (int k = 0; k < 4; k++) a0[k] = a[k];
-  uint16_t nx[TB_S];  // interleaver addresses of the sub-block that comes next
-  int cur[TB_S];      // ... of the sub-block in hand
+  uint32_t nx[TB_S / 2];   // interleaver addresses (two steps per word) of the sub-block that comes next
+  uint32_t cur[TB_S / 2];  // ... of the sub-block in hand
+  const int wlast = (W - 1) >> 1;
   auto il_load = [&](int sb) {
 #pragma unroll
-    for (int u = 0; u < TB_S; u++) {
-      int t = sb * TB_S + u;
-      t = t < W ? t : W - 1;
-      nx[u] = (il + (uint32_t)(t * P))[wl];  // uniform row address + lane offset
+    for (int u = 0; u < TB_S / 2; u++) {
+      int t2 = sb * (TB_S / 2) + u;
+      t2 = t2 < wlast ? t2 : wlast;
+      nx[u] = (il + (uint32_t)(t2 * P))[wl];  // uniform row address + lane offset
     }
   };
   if (IL) il_load(0);
@@ -224,14 +227,14 @@ LSN_HD void lsn_map_pass_lane(const TurboLds& m, const uint16_t* il, int nt, int
     const int tb = sb * TB_S;
     if (IL) {
 #pragma unroll
-      for (int u = 0; u < TB_S; u++) cur[u] = nx[u];
+      for (int u = 0; u < TB_S / 2; u++) cur[u] = nx[u];
       il_load(sb + 1);
     }
 #pragma unroll
     for (int u = 0; u < TB_S; u++) {
       const int nat = (tb + u) * P + wl;
       if (IL) {
-        const int idx = cur[u];
+        const int idx = (int)((u & 1) ? cur[u >> 1] >> 16 : cur[u >> 1] & 0xFFFFu);
         g[u] = ((uint32_t)(fld0(m.spp[idx]) + ((int)m.ext[idx] >> 1)) & 0xFFFFu) | ((uint32_t)fld2(m.spp[nat]) << 16);
       } else {
         const uint32_t w = m.spp[nat];
@@ -263,7 +266,7 @@ LSN_HD void lsn_map_pass_lane(const TurboLds& m, const uint16_t* il, int nt, int
     }
     if (IL) {
 #pragma unroll
-      for (int u = 0; u < TB_S; u++) cur[u] = nx[u];
+      for (int u = 0; u < TB_S / 2; u++) cur[u] = nx[u];
       if (sb > 0) il_load(sb - 1);
     }
     // only the last sub-block of a window can be shorter than TB_S: the full-length variant carries no per-step guards
@@ -275,7 +278,7 @@ LSN_HD void lsn_map_pass_lane(const TurboLds& m, const uint16_t* il, int nt, int
         if (FULL || u < n) {
           const int nat = (tb + u) * P + wl;
           if (IL) {
-            const int idx = cur[u];
+            const int idx = (int)((u & 1) ? cur[u >> 1] >> 16 : cur[u >> 1] & 0xFFFFu);
             ix[u] = active ? idx : K;
             g[u] = ((uint32_t)(fld0(m.spp[idx]) + ((int)m.ext[idx] >> 1)) & 0xFFFFu) | ((uint32_t)fld2(m.spp[nat]) << 16);
           } else {

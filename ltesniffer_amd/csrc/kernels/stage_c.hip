@@ -335,7 +335,7 @@ __device__ __forceinline__ uint32_t mulmod24(uint32_t a, uint32_t b, uint32_t po
 
 // one constituent decoder over all windows (lane = window); nii_a / nii_b: boundary metrics (layout C) in registers
 template <bool IL>
-__device__ __forceinline__ void map_pass(const TurboLds& m, const uint16_t* il, int nt, int lane, bool active, int K, int P, int W,
+__device__ __forceinline__ void map_pass(const TurboLds& m, const uint32_t* il, int nt, int lane, bool active, int K, int P, int W,
                                          s2* nii_a, s2* nii_b, const s2* beta_tail)
 {
   s2 a_end[4], b_out[4];
@@ -387,7 +387,7 @@ __device__ __forceinline__ uint32_t wg_xor(uint32_t v, int16_t* scratch, int tid
 #define TB_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
 #endif
 template <int NT>
-__global__ __launch_bounds__(NT) TB_WAVES_ATTR void k_turbo(const uint32_t* __restrict__ crc_tab_a, const uint32_t* __restrict__ crc_tab_b, const uint16_t* __restrict__ il_tab,
+__global__ __launch_bounds__(NT) TB_WAVES_ATTR void k_turbo(const uint32_t* __restrict__ crc_tab_a, const uint32_t* __restrict__ crc_tab_b, const uint32_t* __restrict__ il_tab,
                                               const LsnCbDev* __restrict__ cbs, const uint32_t* __restrict__ spp_g,
                                               uint8_t* __restrict__ payload, LsnCbRes* res, uint32_t kmax)
 {
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(NT) TB_WAVES_ATTR void k_turbo(const uint32_t* __re
   const int nt = (NT == 128 && P <= 64) ? 64 : NT;
   if (lane >= nt) return;
   const bool active = lane < P;
-  const uint16_t* il = il_tab + cb.il_off;
+  const uint32_t* il = il_tab + cb.il_off;
   TurboLds m;
   m.spp = (uint32_t*)smem; m.ext = (int16_t*)(m.spp + kmax); m.ckpt = (uint8_t*)(m.ext + kmax + 8);  // ext[K] = spare slot for idle lanes
   // the check-point area doubles as scratch for the 12 termination values

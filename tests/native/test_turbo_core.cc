@@ -43,7 +43,7 @@ static int decode_like_kernel(const int16_t* d3, int K, int max_iter, uint32_t p
   int f1, f2;
   o_qpp_find(K, &f1, &f2);
   const uint32_t magicW = ((1u << 20) + (uint32_t)W - 1u) / (uint32_t)W;
-  std::vector<uint16_t> il(K);
+  std::vector<uint32_t> il(lsn_turbo_il_words(K));
   lsn_turbo_il_fill(il.data(), K, f1, f2);
   std::vector<uint32_t> spp(K + 16);
   std::vector<int16_t> ext(K + 16, 0);

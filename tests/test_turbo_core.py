@@ -22,7 +22,7 @@ def test_kernel_text_matches_the_oracle_decoder_on_every_block_size():
 
 
 def test_interleaver_table_offsets_cover_all_block_sizes():
-    """turbo_il_offset (host) and the table order: 188 sizes, offsets = running sum of K, and lsn_turbo_two_wave_class splits at 64 windows / K 3072"""
+    """turbo_il_offset (host) and the table order: 188 sizes, offsets = running sum of ceil(W / 2) * P words, and lsn_turbo_two_wave_class splits at 64 windows / K 3072"""
     from lsn_testlib import hosttest
     h = hosttest()
     import re
@@ -30,10 +30,15 @@ def test_interleaver_table_offsets_cover_all_block_sizes():
     m = re.search(r"lsn_qpp_table\[LSN_QPP_NSIZES\]\[3\] = \{(.*?)\};", txt, re.S)
     ks = [int(x.split(",")[0]) for x in re.findall(r"\{(\d+,\d+,\d+)\}", m.group(1))]
     assert len(ks) == 188
+    def nwin(K):
+        p1 = next(P for P in range(min(K // 32, 64), 0, -1) if K % P == 0)
+        p2 = next(P for P in range(min(K // 32, 128), 0, -1) if K % P == 0)
+        return p2 if p2 >= 96 else p1
     off = 0
     for k in ks:
         assert h.lsnh_turbo_il_offset(k) == off
-        off += k
-    assert h.lsnh_turbo_il_offset(0) == off == sum(ks)
+        P = nwin(k)
+        off += ((k // P + 1) // 2) * P  # two trellis steps per table word
+    assert h.lsnh_turbo_il_offset(0) == off
     two = [k for k in ks if h.lsnh_turbo_two_wave_class(k)]
     assert min(two) == 3072 and set(two) == set(k for k in ks if k >= 3072)  # K = 3072 has 96 windows; every larger size needs either two waves or > 22 KiB of LDS

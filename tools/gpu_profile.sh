@@ -26,8 +26,11 @@ if [ -n "$KT" ]; then
   python tools/kernel_trace_json.py $KT --last-ofdm $TIMED_CHUNKS --subframes $TIMED_SF --out $OUT/${TAG}_kernel_trace.json > $OUT/${TAG}_kernel_trace_stats.txt 2>&1
   python tools/timeline.py $KT --tail 0.75 > $OUT/${TAG}_timeline.txt 2>&1
 fi
+P1=""; P2=""
+if [ -z "${LSN_PROFILE_SKIP_SQ:-}" ]; then  # LSN_PROFILE_SKIP_SQ=1: kernel trace + HBM traffic passes only
 P1=$(run_prof pmc_sq1 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU)
 P2=$(run_prof pmc_sq2 --kernel-trace --pmc SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_IFETCH)
+fi
 P3=$(run_prof pmc_fetch --kernel-trace --pmc FETCH_SIZE)
 P4=$(run_prof pmc_write --kernel-trace --pmc WRITE_SIZE)
 [ -n "$P1$P2" ] && python tools/pmc_generic_summary.py $OUT/${TAG}_pmc_sq.json $P1 $P2 --subframes $ALL_SF > $OUT/${TAG}_pmc_sq.txt 2>&1
