@@ -4,8 +4,9 @@
 // range-checked against 32-bit arithmetic).
 //
 // One lane = one trellis window (see stage_c.hip for the schedule).  Round 3, second half: the recursions run on PACKED int16 pairs.
-// With one 381-register wavefront per SIMD a wave issues one VALU instruction per 4 cycles whatever its class (profiles/r03_valu_peak_isa.txt),
-// so v_pk_add_i16 / v_pk_max_i16 do two state updates for the price of one: 98 instead of 140 instructions per trellis step.
+// A wavefront alone on a SIMD issues one VALU instruction per 4 cycles whatever its class (profiles/r03_valu_peak_isa.txt),
+// and packed forms occupy the VALU port for 4 cycles at any occupancy, so v_pk_add_i16 / v_pk_max_i16 do two state updates for the price of one:
+// 106 instead of 140 vector instructions per trellis step in the first constituent decoder, 107 instead of 171 in the interleaved one.
 //
 // Layout C: four registers hold the eight state metrics as (m[k] | m[k+4] << 16), k = 0..3.
 //  * forward: butterfly k reads states 2k, 2k+1 and writes k, k+4 - with the operands taken as half-broadcasts (op_sel) layout C maps to
