@@ -42,10 +42,11 @@ def _tables(sc, n):
 
 
 def _pack(rows):
-    """a chunk's stage-A results as one byte array: per subframe tti, cfi (u32), snr (f32), table, powers"""
+    """a chunk's stage-A results as one byte array: per subframe a 16-byte header (tti, cfi as u32, snr as f32, padding - the candidate table holds
+    64-bit fields and stays 8-byte aligned on the wire), table, powers"""
     parts = []
     for tti, cfi, snr, cand, pw in rows:
-        parts += [np.array([tti, cfi], np.uint32).view(np.uint8), np.array([snr], np.float32).view(np.uint8), cand, pw.view(np.uint8)]
+        parts += [np.array([tti, cfi], np.uint32).view(np.uint8), np.array([snr, 0.0], np.float32).view(np.uint8), cand, pw.view(np.uint8)]
     return np.concatenate(parts)
 
 
@@ -56,7 +57,8 @@ def _search_chunk(h, hs, blob, nsf):
         b = blob[i * per:(i + 1) * per]
         tti, cfi = (int(v) for v in b[:8].view(np.uint32))
         snr = float(b[8:12].view(np.float32)[0])
-        cand, pw = np.ascontiguousarray(b[12:per - 96 * 4]), np.ascontiguousarray(b[per - 96 * 4:]).view(np.float32)
+        cand, pw = b[16:per - 96 * 4].copy(), b[per - 96 * 4:].copy().view(np.float32)
+        assert cand.ctypes.data % 8 == 0
         out = (C.c_uint32 * (64 * 6))()
         n = h.lsnh_search_run(hs, tti, cfi, snr, cand.ctypes.data, pw.ctypes.data, 0, out, 64 * 6)
         words.append(np.array([n] + list(out[:6 * n]), np.uint32))
