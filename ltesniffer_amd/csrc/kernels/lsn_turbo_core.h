@@ -78,7 +78,7 @@ static inline s2 pks_sel(s2 a, s2 b) { return pks(s2{AL ? a.y : a.x, AH ? a.y : 
 // sign(x) * min(floor(3 |x| / 4), LSN_EXT_CLIP) without a select: (3x + (3x < 0 ? 3 : 0)) >> 2 truncates towards zero, v_med3 clips
 LSN_HD int lsn_ext_scale(int x)
 {
-  const int t = x + (x << 1);
+  const int t = 3 * x;
   const int r = (t + (int)((uint32_t)t >> 30)) >> 2;  // |t| < 2^30: the two top bits are 11 exactly when t < 0
   return r < -LSN_EXT_CLIP ? -LSN_EXT_CLIP : (r > LSN_EXT_CLIP ? LSN_EXT_CLIP : r);
 }
@@ -307,7 +307,7 @@ LSN_HD void lsn_map_pass_lane(const TurboLds& m, const uint32_t* il, int nt, int
           const s2 q = pk_s2(g[u]);
           const int L = lsn_step_bwd_pk(b, A[u], q);
           const int hard = L < 0 ? 0 : (L > 1 ? 1 : L);  // v_med3_i32(L, 0, 1)
-          m.ext[ix[u]] = (int16_t)((lsn_ext_scale(L - (int)q.x) << 1) | hard);  // idle lanes: spare slot ext[K]
+          m.ext[ix[u]] = (int16_t)(lsn_ext_scale(L - (int)q.x) * 2 + hard);  // idle lanes: spare slot ext[K]
         }
       }
     };
