@@ -592,9 +592,32 @@ bool api_ul_dcch_events(int api_mode, const uint8_t* pdu, int len, uint16_t rnti
 // accept) is not: such a message, or one with extension additions inside measConfig, is reported as "no identity" where srsRAN would decode it.
 // Pinned by the two RRCConnectionReconfiguration messages of the reference's own captures (tests/test_rrc_oracle.py).
 static void thresholdEutra(BitReader& b) { if (!b.flag()) b.get(7); else b.get(6); }  // CHOICE { threshold-RSRP (0..97), threshold-RSRQ (0..34) }
+// X.691 10.9 / 19.7-19.9: the extension additions behind the root components of an extensible SEQUENCE - a presence bitmap whose length is a
+// "normally small" number, then every present addition (group) as an open type: length determinant + that many octets, which are skipped unread
+static bool skipOpenType(BitReader& b)
+{
+  uint32_t n = b.get(8);
+  if (n & 0x80u) {
+    if (n & 0x40u) return false;               // fragmented: never in these messages
+    n = ((n & 0x3Fu) << 8) | b.get(8);
+  }
+  if (b.err || b.pos + 8u * n > b.nbits) { b.err = true; return false; }
+  b.pos += 8u * n;
+  return true;
+}
+static bool skipExtAdditions(BitReader& b)
+{
+  if (b.flag()) return false;                  // more than 64 additions
+  const uint32_t n = b.get(6) + 1;
+  const uint64_t present = ((uint64_t)b.get(n > 32 ? n - 32 : 0) << 32) | b.get(n > 32 ? 32 : n);
+  for (uint32_t i = 0; i < n && !b.err; i++)
+    if ((present >> (n - 1 - i)) & 1u)
+      if (!skipOpenType(b)) return false;
+  return !b.err;
+}
 static bool measConfigSkip(BitReader& b)
 {
-  if (b.flag()) return false;  // extension additions: not walked
+  const bool ext_mc = b.flag();
   bool opt[11];
   for (bool& o : opt) o = b.flag();
   if (opt[0]) { const uint32_t n = b.get(5) + 1; b.get(5 * n); }  // measObjectToRemoveList: (1..32) each
@@ -603,7 +626,7 @@ static bool measConfigSkip(BitReader& b)
     for (uint32_t i = 0; i < n && !b.err; i++) {
       b.get(5);                                   // measObjectId
       if (b.flag() || b.get(2) != 0) return false;  // only measObjectEUTRA
-      if (b.flag()) return false;                 // MeasObjectEUTRA extension additions
+      const bool ext_mo = b.flag();               // MeasObjectEUTRA: extension additions (r10+) follow the root components
       bool o[6];
       for (bool& x : o) x = b.flag();
       b.get(16); b.get(3); b.get(1); b.get(2);    // carrierFreq, allowedMeasBandwidth, presenceAntennaPort1, neighCellConfig
@@ -616,6 +639,7 @@ static bool measConfigSkip(BitReader& b)
         for (uint32_t j = 0; j < k; j++) { b.get(5); const bool r = b.flag(); b.get(9); if (r) b.get(4); }
       }
       if (o[5]) b.get(9);                         // cellForWhichToReportCGI
+      if (ext_mo && !skipExtAdditions(b)) return false;
     }
   }
   if (opt[2]) { const uint32_t n = b.get(5) + 1; b.get(5 * n); }  // reportConfigToRemoveList
@@ -624,34 +648,42 @@ static bool measConfigSkip(BitReader& b)
     for (uint32_t i = 0; i < n && !b.err; i++) {
       b.get(5);                                   // reportConfigId
       if (b.get(1) != 0) return false;            // only reportConfigEUTRA
-      if (b.flag()) return false;                 // extension additions
+      const bool ext_rc = b.flag();               // ReportConfigEUTRA extension additions (r9+) at the end
       if (!b.flag()) {                            // triggerType: event
-        if (b.flag()) return false;               // eventId extension
-        switch (b.get(3)) {
-          case 0: case 1: case 3: thresholdEutra(b); break;   // a1, a2, a4
-          case 2: b.get(6); b.get(1); break;                   // a3: offset (-30..30), reportOnLeave
-          case 4: thresholdEutra(b); thresholdEutra(b); break; // a5
-          default: return false;
+        if (b.flag()) {                           // eventId beyond a5 (a6-r10 ...): index as a normally small number, the event as an open type
+          if (b.flag()) return false;
+          b.get(6);
+          if (!skipOpenType(b)) return false;
+        } else {
+          switch (b.get(3)) {
+            case 0: case 1: case 3: thresholdEutra(b); break;   // a1, a2, a4
+            case 2: b.get(6); b.get(1); break;                   // a3: offset (-30..30), reportOnLeave
+            case 4: thresholdEutra(b); thresholdEutra(b); break; // a5
+            default: return false;
+          }
         }
         b.get(5); b.get(4);                       // hysteresis, timeToTrigger
       } else {
         b.get(1);                                 // periodical: purpose
       }
       b.get(1); b.get(1); b.get(3); b.get(4); b.get(3);  // triggerQuantity, reportQuantity, maxReportCells, reportInterval, reportAmount
+      if (ext_rc && !skipExtAdditions(b)) return false;
     }
   }
   if (opt[4]) { const uint32_t n = b.get(5) + 1; b.get(5 * n); }   // measIdToRemoveList
   if (opt[5]) { const uint32_t n = b.get(5) + 1; b.get(15 * n); }  // measIdToAddModList: measId, measObjectId, reportConfigId
   if (opt[6]) {                                   // quantityConfig
-    if (b.flag()) return false;
+    const bool ext_qc = b.flag();
     bool q[4];
     for (bool& x : q) x = b.flag();
     if (q[0]) { const bool r1 = b.flag(), r2 = b.flag(); for (bool r : {r1, r2}) if (r) { if (b.flag()) return false; b.get(4); } }  // filterCoefficientRSRP / RSRQ
     if (q[1] || q[2] || q[3]) return false;       // UTRA / GERAN / CDMA2000 quantities: not walked
+    if (ext_qc && !skipExtAdditions(b)) return false;
   }
   if (opt[7]) { if (b.flag()) { if (!b.flag()) b.get(6); else b.get(7); } }  // measGapConfig: release / setup { gp0 (0..39) | gp1 (0..79) }
   if (opt[8]) b.get(7);                           // s-Measure (0..97)
   if (opt[9] || opt[10]) return false;            // preRegistrationInfoHRPD, speedStatePars: not walked
+  if (ext_mc && !skipExtAdditions(b)) return false;
   return !b.err;
 }
 

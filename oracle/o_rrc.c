@@ -395,12 +395,32 @@ static void drop_list5(cur_t* c, uint32_t item_bits) /* SEQUENCE (SIZE (1..32)) 
   for (uint32_t i = 0; i < cnt; i++) take(c, item_bits);
 }
 static void drop_threshold(cur_t* c) { take(c, take(c, 1) ? 6 : 7); }
+/* an open type (X.691 10.2): octet count in one or two octets, then the octets themselves, none of which is looked at */
+static int drop_open(cur_t* c)
+{
+  uint32_t octets = take(c, 8);
+  if (octets >= 0xC0u) return 0;
+  if (octets >= 0x80u) octets = ((octets - 0x80u) << 8) + take(c, 8);
+  for (uint32_t i = 0; i < octets; i++) take(c, 8);
+  return !c->bad;
+}
+/* what follows the root of an extensible SEQUENCE whose extension bit was set (X.691 19.7-19.9) */
+static int drop_additions(cur_t* c)
+{
+  if (take(c, 1)) return 0; /* a count above 64 */
+  uint32_t cnt = take(c, 6) + 1, sent = 0;
+  uint8_t mark[64];
+  for (uint32_t i = 0; i < cnt; i++) mark[i] = (uint8_t)take(c, 1);
+  for (uint32_t i = 0; i < cnt; i++) if (mark[i]) { if (!drop_open(c)) return 0; sent++; }
+  (void)sent;
+  return !c->bad;
+}
 static int drop_meas_object(cur_t* c)
 {
   take(c, 5);
   if (take(c, 1)) return 0;          /* measObject choice extended */
   if (take(c, 2) != 0) return 0;     /* UTRA / GERAN / CDMA2000 */
-  if (take(c, 1)) return 0;          /* MeasObjectEUTRA carries extension additions */
+  uint32_t more = take(c, 1);        /* MeasObjectEUTRA carries extension additions */
   uint32_t has = take(c, 6);         /* offsetFreq, cellsToRemove, cellsToAddMod, blackCellsToRemove, blackCellsToAddMod, cellForWhichToReportCGI */
   take(c, 16 + 3 + 1 + 2);
   if (has & 32u) take(c, 5);
@@ -412,30 +432,37 @@ static int drop_meas_object(cur_t* c)
     for (uint32_t i = 0; i < cnt; i++) { take(c, 5); uint32_t rng = take(c, 1); take(c, 9); if (rng) take(c, 4); }
   }
   if (has & 1u) take(c, 9);
+  if (more && !drop_additions(c)) return 0;
   return !c->bad;
 }
 static int drop_report_config(cur_t* c)
 {
   take(c, 5);
   if (take(c, 1)) return 0;          /* reportConfigInterRAT */
-  if (take(c, 1)) return 0;          /* extension additions */
+  uint32_t more = take(c, 1);        /* extension additions behind reportAmount */
   if (take(c, 1) == 0) {             /* event */
-    if (take(c, 1)) return 0;
-    uint32_t ev = take(c, 3);
-    if (ev == 0 || ev == 1 || ev == 3) drop_threshold(c);
-    else if (ev == 2) take(c, 7);
-    else if (ev == 4) { drop_threshold(c); drop_threshold(c); }
-    else return 0;
+    if (take(c, 1)) {                /* an event the r8 choice does not know (a6 ...): small index, then an open type */
+      if (take(c, 1)) return 0;
+      take(c, 6);
+      if (!drop_open(c)) return 0;
+    } else {
+      uint32_t ev = take(c, 3);
+      if (ev == 0 || ev == 1 || ev == 3) drop_threshold(c);
+      else if (ev == 2) take(c, 7);
+      else if (ev == 4) { drop_threshold(c); drop_threshold(c); }
+      else return 0;
+    }
     take(c, 5 + 4);
   } else {
     take(c, 1);
   }
   take(c, 1 + 1 + 3 + 4 + 3);
+  if (more && !drop_additions(c)) return 0;
   return !c->bad;
 }
 static int drop_meas_config(cur_t* c)
 {
-  if (take(c, 1)) return 0;
+  uint32_t more = take(c, 1);
   uint32_t has = take(c, 11); /* bit 10 = first optional component */
   if (has & (1u << 10)) drop_list5(c, 5);
   if (has & (1u << 9)) { uint32_t cnt = take(c, 5) + 1; for (uint32_t i = 0; i < cnt; i++) if (!drop_meas_object(c)) return 0; }
@@ -444,17 +471,19 @@ static int drop_meas_config(cur_t* c)
   if (has & (1u << 6)) drop_list5(c, 5);
   if (has & (1u << 5)) drop_list5(c, 15);
   if (has & (1u << 4)) {
-    if (take(c, 1)) return 0;
+    uint32_t qmore = take(c, 1);
     uint32_t q = take(c, 4);
     if (q & 7u) return 0;
     if (q & 8u) {
       uint32_t d = take(c, 2);
       for (int k = 1; k >= 0; k--) if (d & (1u << k)) { if (take(c, 1)) return 0; take(c, 4); }
     }
+    if (qmore && !drop_additions(c)) return 0;
   }
   if (has & (1u << 3)) { if (take(c, 1)) take(c, take(c, 1) ? 7 : 6); }
   if (has & (1u << 2)) take(c, 7);
   if (has & 3u) return 0;
+  if (more && !drop_additions(c)) return 0;
   return !c->bad;
 }
 

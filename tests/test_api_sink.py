@@ -259,23 +259,48 @@ def _put(bits, v, n):
     bits.extend((int(v) >> (n - 1 - i)) & 1 for i in range(n))
 
 
+def _put_open(b, octets):
+    """open type: general length determinant (one or two octets), then the octets"""
+    n = len(octets)
+    if n < 128:
+        _put(b, n, 8)
+    else:
+        _put(b, 0x8000 | n, 16)
+    for x in octets:
+        _put(b, x, 8)
+
+
+def _put_additions(b, adds):
+    """extension additions of a SEQUENCE whose extension bit is set (X.691 19.7-19.9): adds = [bytes | None, ...], at least one present"""
+    _put(b, 0, 1); _put(b, len(adds) - 1, 6)
+    for x in adds:
+        _put(b, int(x is not None), 1)
+    for x in adds:
+        if x is not None:
+            _put_open(b, x)
+
+
 def _encode_reconfig(nas, meas=None, mobility=False, rrcd=True):
     """DL-DCCH-Message { rrcConnectionReconfiguration-r8 } in unaligned PER, written for this test (TS 36.331 6.2.2 / 6.3.5).  meas: None or
-    dict(objects=[(id, arfcn, offset or None, cells [(idx, pci, off)])], reports=[("a3", offset) | ("a1", rsrp) | ("periodical",)], ids=[(m, o, r)],
-    quantity=(rsrp_fc or None, rsrq_fc or None) or None, gap=None | ("gp0", v) | ("gp1", v) | "release", s_measure=None | v)"""
+    dict(objects=[(id, arfcn, offset or None, cells [(idx, pci, off)], additions or None)], reports=[("a3", offset, adds) | ("a1", rsrp, adds) |
+    ("a6", octets, adds) | ("periodical", None, adds)], ids=[(m, o, r)], quantity=(rsrp_fc or None, rsrq_fc or None, adds) or None,
+    gap=None | ("gp0", v) | ("gp1", v) | "release", s_measure=None | v, additions=None | [bytes | None, ...]); "additions" are the extension
+    additions of later releases, which a release-8 reader has to step over"""
     b = []
     _put(b, 0, 1); _put(b, 4, 4); _put(b, 1, 2); _put(b, 0, 1); _put(b, 0, 3)
     _put(b, 1 if meas is not None else 0, 1); _put(b, int(mobility), 1); _put(b, 1 if nas is not None else 0, 1); _put(b, int(rrcd), 1); _put(b, 0, 1); _put(b, 0, 1)
     if meas is not None:
-        _put(b, 0, 1)
+        _put(b, int(bool(meas.get("additions"))), 1)
         pres = [0, bool(meas.get("objects")), 0, bool(meas.get("reports")), 0, bool(meas.get("ids")), meas.get("quantity") is not None, meas.get("gap") is not None,
                 meas.get("s_measure") is not None, 0, 0]
         for x in pres:
             _put(b, int(bool(x)), 1)
         if meas.get("objects"):
             _put(b, len(meas["objects"]) - 1, 5)
-            for oid, arfcn, off, cells in meas["objects"]:
-                _put(b, oid - 1, 5); _put(b, 0, 1); _put(b, 0, 2); _put(b, 0, 1)
+            for ob in meas["objects"]:
+                oid, arfcn, off, cells = ob[:4]
+                adds = ob[4] if len(ob) > 4 else None
+                _put(b, oid - 1, 5); _put(b, 0, 1); _put(b, 0, 2); _put(b, int(bool(adds)), 1)
                 _put(b, int(off is not None), 1); _put(b, 0, 1); _put(b, int(bool(cells)), 1); _put(b, 0, 3)
                 _put(b, arfcn, 16); _put(b, 3, 3); _put(b, 1, 1); _put(b, 1, 2)
                 if off is not None:
@@ -284,31 +309,41 @@ def _encode_reconfig(nas, meas=None, mobility=False, rrcd=True):
                     _put(b, len(cells) - 1, 5)
                     for ci, pci, co in cells:
                         _put(b, ci - 1, 5); _put(b, pci, 9); _put(b, co, 5)
+                if adds:
+                    _put_additions(b, adds)
         if meas.get("reports"):
             _put(b, len(meas["reports"]) - 1, 5)
             for k, rc in enumerate(meas["reports"]):
-                _put(b, k, 5); _put(b, 0, 1); _put(b, 0, 1)
+                adds = rc[2] if len(rc) > 2 else None
+                _put(b, k, 5); _put(b, 0, 1); _put(b, int(bool(adds)), 1)
                 if rc[0] == "periodical":
                     _put(b, 1, 1); _put(b, 0, 1)
                 else:
-                    _put(b, 0, 1); _put(b, 0, 1)
-                    if rc[0] == "a3":
-                        _put(b, 2, 3); _put(b, rc[1] + 30, 6); _put(b, 0, 1)
+                    _put(b, 0, 1)
+                    if rc[0] == "a6":      # eventId is an extensible CHOICE: a6-r10 is extension alternative 0, carried as an open type
+                        _put(b, 1, 1); _put(b, 0, 1); _put(b, 0, 6); _put_open(b, rc[1])
+                    elif rc[0] == "a3":
+                        _put(b, 0, 1); _put(b, 2, 3); _put(b, rc[1] + 30, 6); _put(b, 0, 1)
                     else:
-                        _put(b, 0, 3); _put(b, 0, 1); _put(b, rc[1], 7)
+                        _put(b, 0, 1); _put(b, 0, 3); _put(b, 0, 1); _put(b, rc[1], 7)
                     _put(b, 4, 5); _put(b, 8, 4)
                 _put(b, 0, 1); _put(b, 1, 1); _put(b, 3, 3); _put(b, 6, 4); _put(b, 7, 3)
+                if adds:
+                    _put_additions(b, adds)
         if meas.get("ids"):
             _put(b, len(meas["ids"]) - 1, 5)
             for m, o, r in meas["ids"]:
                 _put(b, m - 1, 5); _put(b, o - 1, 5); _put(b, r - 1, 5)
         if meas.get("quantity") is not None:
-            _put(b, 0, 1); _put(b, 1, 1); _put(b, 0, 3)
             q = meas["quantity"]
+            adds = q[2] if len(q) > 2 else None
+            _put(b, int(bool(adds)), 1); _put(b, 1, 1); _put(b, 0, 3)
             _put(b, int(q[0] is not None), 1); _put(b, int(q[1] is not None), 1)
-            for v in q:
+            for v in q[:2]:
                 if v is not None:
                     _put(b, 0, 1); _put(b, v, 4)
+            if adds:
+                _put_additions(b, adds)
         if meas.get("gap") is not None:
             g = meas["gap"]
             if g == "release":
@@ -317,6 +352,8 @@ def _encode_reconfig(nas, meas=None, mobility=False, rrcd=True):
                 _put(b, 1, 1); _put(b, 0 if g[0] == "gp0" else 1, 1); _put(b, g[1], 6 if g[0] == "gp0" else 7)
         if meas.get("s_measure") is not None:
             _put(b, meas["s_measure"], 7)
+        if meas.get("additions"):
+            _put_additions(b, meas["additions"])
     if nas is not None:
         _put(b, 0, 4)
         assert len(nas) < 128
@@ -340,7 +377,9 @@ def _attach_accept(m_tmsi, guti=True, protected=True, esm=b"\x52\x01\xc1\x01\x07
 
 def _dcch_pdu(rrc):
     sdu = bytes([0xa0, 0x06, 0x06]) + rrc
-    return bytes([0x21, len(sdu), 0x1f]) + sdu + bytes(3)
+    if len(sdu) < 128:
+        return bytes([0x21, len(sdu), 0x1f]) + sdu + bytes(3)
+    return bytes([0x21, 0x80 | (len(sdu) >> 8), len(sdu) & 0xFF, 0x1f]) + sdu + bytes(3)  # F = 1: 15-bit length
 
 
 def test_recorded_reconfigurations_report_the_assigned_tmsi():
@@ -404,3 +443,41 @@ def test_reconfiguration_walk_against_an_independent_encoder():
     for _ in range(200):
         p = bytes([0x21, 40, 0x1f, 0xa0, 0, 0, 0x20 | int(rng.integers(0, 8))]) + bytes(rng.integers(0, 256, 45, dtype=np.uint8))
         assert oracle_api_events(3, "C", p, 9, 9) == host_api_events(3, "C", p, 9, 9)
+
+
+def test_reconfiguration_walk_steps_over_later_release_extension_additions():
+    """measConfig of an LTE-A network: release 9-11 additions in MeasConfig, MeasObjectEUTRA, ReportConfigEUTRA and QuantityConfig and an event the
+    release-8 CHOICE does not know (a6) travel as open types behind the root components; the NAS list behind them must still be found.  Both
+    parsers (oracle o_rrc.c, product lsn_rrc.cc - two texts) against the encoder above, which knows nothing of either."""
+    rng = np.random.default_rng(11)
+
+    def adds(always=False):
+        if not always and rng.integers(0, 2):
+            return None
+        n = int(rng.integers(1, 5))
+        out = [bytes(rng.integers(0, 256, int(rng.integers(1, 5 if rng.integers(0, 8) else 140)), dtype=np.uint8)) if rng.integers(0, 3) else None for _ in range(n)]
+        if all(x is None for x in out):
+            out[0] = b"\x80"
+        return out
+
+    n_ext = 0
+    for trial in range(80):
+        tmsi = int(rng.integers(1, 1 << 32))
+        objects = [(1 + i, int(rng.integers(0, 65536)), (int(rng.integers(0, 31)) if rng.integers(0, 2) else None),
+                    [(1 + j, int(rng.integers(0, 504)), int(rng.integers(0, 31))) for j in range(int(rng.integers(0, 3)))], adds()) for i in range(int(rng.integers(1, 4)))]
+        reports = [("a3", int(rng.integers(-30, 31)), adds()), ("a6", bytes(rng.integers(0, 256, int(rng.integers(1, 4)), dtype=np.uint8)), adds()),
+                   ("a1", int(rng.integers(0, 98)), adds()), ("periodical", None, adds())][:int(rng.integers(1, 5))]
+        meas = dict(objects=objects, reports=reports, ids=[(1, 1, 1), (2, 1, 2)][:int(rng.integers(0, 3))],
+                    quantity=[None, (None, None, adds()), (4, None, adds(True)), (6, 9, adds())][int(rng.integers(0, 4))],
+                    gap=[None, "release", ("gp0", 17), ("gp1", 63)][int(rng.integers(0, 4))], s_measure=[None, 70][int(rng.integers(0, 2))], additions=adds())
+        n_ext += any(o[4] for o in objects) or any(r[2] for r in reports) or bool(meas["additions"])
+        pdu = _dcch_pdu(_encode_reconfig(_attach_accept(tmsi, protected=bool(trial % 2)), meas=meas))
+        ev, keep = oracle_api_events(3, "C", pdu, 4321, 77)
+        assert (ev, keep) == host_api_events(3, "C", pdu, 4321, 77)
+        assert ev == [(77, 4321, 1, 6, "%08x" % tmsi)], (trial, meas)
+        # truncations inside the additions are rejected identically, never read past the end
+        if pdu[1] < 128:
+            for cut in range(8, len(pdu) - 4, 7):
+                p = bytes([0x21, max(4, cut - 3), 0x1f]) + pdu[3:cut]
+                assert oracle_api_events(3, "C", p, 9, 9) == host_api_events(3, "C", p, 9, 9)
+    assert n_ext >= 40
