@@ -304,20 +304,21 @@ void lsn_launch_rm(const LsnCbDev* cb, const int16_t* llr, uint32_t* spp, uint32
 }
 
 // ------------------------------------------------------------------------------------------------ turbo decoder
-// One workgroup per code block, thread = trellis window (P = lsn_turbo_nwin(K) windows of W = K/P steps): one
-// wavefront when P <= 64, two when 96 <= P <= 128; four code blocks per CU (<= 40 KiB of LDS each).
+// One workgroup per code block, thread = trellis window (P = lsn_turbo_nwin(K) windows of W = K/P steps).  k_turbo<128>: blocks of more than
+// 64 windows (two working wavefronts) and the few blocks of <= 64 windows with K > 3072 (one working wavefront, the second leaves at once) -
+// 40 KiB of LDS at most, four per CU; k_turbo<64>: everything else, <= 22 KiB.  Two wavefronts per SIMD (256 registers).
 // LDS: spp[K] packs the three rate-dematched soft streams of a position (10-bit signed fields: systematic | parity 1 |
 // parity 2), ext[K] holds extrinsic * 2 + hard decision.  Both are stored TRANSPOSED, idx(x) = (x % W) * P + x / W:
 // the in-order decoder reads consecutive lanes = consecutive addresses and the QPP-interleaved one is (nearly)
 // conflict free by the contention-free property of the QPP (36.212 5.1.3.2.3).
 // Schedule per constituent decoder: forward sweep in sub-blocks of TB_S steps (operands of a sub-block are fetched
 // from LDS in one burst, the recursion then runs on registers), alpha check-pointed at sub-block starts; backward
-// sub-block by sub-block: burst fetch, recompute the TB_S alphas into registers (packed int16), beta + LLR + extrinsic.
-// The interleaver addresses of the backward phase are generated by stepping the QPP recursion in reverse.
-// Window-boundary metrics of the previous iteration (next-iteration initialisation) stay in registers and move
-// between lanes with shuffles.
-// Since round 3 the recursions run on packed int16 pairs (lsn_turbo_core.h: layouts, word-length argument, the per-lane text that
-// tests/native/test_turbo_core.cc runs on the CPU against the oracle's decoder).
+// sub-block by sub-block: burst fetch, recompute the TB_S alphas into registers, beta + LLR + extrinsic.
+// The interleaver addresses come from a table in global memory (L2), fetched one sub-block ahead.
+// Window-boundary metrics of the previous iteration (next-iteration initialisation) stay in registers and change lanes through the
+// check-point area.
+// The recursions run on packed int16 pairs: lsn_turbo_core.h holds the layouts, the word-length argument and the per-lane text, which
+// tests/native/test_turbo_core.cc also runs on the CPU against the oracle's decoder.
 #include "lsn_turbo_core.h"
 
 // GF(2) polynomial product a*b mod g (24-bit CRC generators, poly includes the x^24 term)
