@@ -2,7 +2,7 @@
  * (TS 36.212 5.1.4.2) + tail-biting Viterbi (K=7, r=1/3, g = 133,171,165 oct; 36.212 5.1.3.1) + CRC16
  * XOR -> RNTI.  Restates srsran_pdcch_dci_decode / srsran_rm_conv_rx / srsran_viterbi_decode_f [srsRAN, not
  * in tree] as called from /root/reference/lib/src/phy/falcon_phch/falcon_pdcch.c:142 (same bit handling as
- * the in-tree legacy variant falcon_pdcch.c:387-402). Quantisation: u8 = clamp(127.5 + 32*llr) truncated,
+ * the in-tree legacy variant falcon_pdcch.c:387-402). Quantisation: u8 = clamp(127.5 + 32*llr) truncated (scale and offset as the reference's own re-encoding check states them, falcon_pdcch.c:432),
  * 32-bit path metrics, three passes over the block (TB_ITER=3 of the SIMD srsRAN builds), middle pass output. */
 #include "lsn_oracle.h"
 #include "../spec/lte_tables.h"
