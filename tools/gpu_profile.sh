@@ -4,7 +4,7 @@
 # Default = the DRIVER's command (--gpus 1 --steps 20 --warmup 5) with the legs that run OUTSIDE its timed region switched off
 # (--no-cpu --no-legs; the timed region is unchanged).  Writes under gpurun_out/<tag>_*: the bench line, a kernel trace reduced to the timed
 # region (per-kernel avg + EXCLUSIVE time, JSON + text; concurrency timeline), and separate --pmc passes (SQ instruction / occupancy
-# counters, FETCH_SIZE, WRITE_SIZE; never combined with other trace domains).
+# counters, FETCH_SIZE, WRITE_SIZE; never combined with other trace domains).  LSN_PROFILE_SKIP_SQ=1 leaves the two SQ passes out (kernel trace + HBM traffic only).
 set -u
 TAG=${1:-prof}; shift || true
 STEPS=${LSN_PROFILE_STEPS:-20}; WARM=${LSN_PROFILE_WARMUP:-5}; STEP_SF=${LSN_PROFILE_STEP_SF:-4000}; BATCH=${LSN_PROFILE_BATCH:-400}
