@@ -67,6 +67,21 @@ def test_tbs_table_structure():
             assert TBS[i + 1][n] >= TBS[i][n] or (i, n + 1) == (6, 1), (i, n + 1)
 
 
+def test_tbs_full_band_columns_match_the_published_peak_rates():
+    """The full-band columns are the part of 36.213 Table 7.1.7.2.1-1 that is quoted everywhere as per-MCS peak rates: 25 / 50 / 100 PRB for
+    I_TBS 0..26 (e.g. 75 376 bits = 150.8 Mbit/s with two code words at 20 MHz, 36 696 = 73.4 Mbit/s at 10 MHz) and 55 056 at 75 PRB for I_TBS 26
+    (110 Mbit/s at 15 MHz).  Written down here independently of spec/gen_tables.py; round 3 found three restated entries one column off."""
+    col100 = [2792, 3624, 4584, 5736, 7224, 8760, 10296, 12216, 14112, 15840, 17568, 19848, 22920, 25456, 28336, 30576, 32856, 36696, 39232, 43816, 46888, 51024, 55056,
+              57336, 61664, 63776, 75376]
+    col50 = [1384, 1800, 2216, 2856, 3624, 4392, 5160, 6200, 6968, 7992, 8760, 9912, 11448, 12960, 14112, 15264, 16416, 18336, 19848, 21384, 22920, 25456, 27376, 28336,
+             30576, 31704, 36696]
+    col25 = [680, 904, 1096, 1416, 1800, 2216, 2600, 3112, 3496, 4008, 4392, 4968, 5736, 6456, 7224, 7736, 7992, 9144, 9912, 10680, 11448, 12576, 13536, 14112, 15264, 15840,
+             18336]
+    for i in range(27):
+        assert (TBS[i][24], TBS[i][49], TBS[i][99]) == (col25[i], col50[i], col100[i]), i
+    assert TBS[26][74] == 55056 and TBS[26][14] == 11064 and TBS[26][5] == 4392
+
+
 def test_rows_the_reference_carries_literally():
     # 36.213 row 32A (256QAM, the reference's only in-tree TBS row) sits between rows 32 and 33 of the restated table for every PRB count
     assert len(ROW32A) == 110 and all(v in set(ALLOWED) for v in ROW32A)
