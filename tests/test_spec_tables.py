@@ -80,6 +80,16 @@ def test_tbs_full_band_columns_match_the_published_peak_rates():
     for i in range(27):
         assert (TBS[i][24], TBS[i][49], TBS[i][99]) == (col25[i], col50[i], col100[i]), i
     assert TBS[26][74] == 55056 and TBS[26][14] == 11064 and TBS[26][5] == 4392
+    # the first page of the table (1, 2, 3, 4, 6, 10, 15 PRB: the 1.4 and 3 MHz bandwidths and the smallest allocations), again written down apart from the generator
+    small = {1: [16, 24, 32, 40, 56, 72, 328, 104, 120, 136, 144, 176, 208, 224, 256, 280, 328, 336, 376, 408, 440, 488, 520, 552, 584, 616, 712],
+             2: [32, 56, 72, 104, 120, 144, 176, 224, 256, 296, 328, 376, 440, 488, 552, 600, 632, 696, 776, 840, 904, 1000, 1064, 1128, 1192, 1256, 1480],
+             3: [56, 88, 144, 176, 208, 224, 256, 328, 392, 456, 504, 584, 680, 744, 840, 904, 968, 1064, 1160, 1288, 1384, 1480, 1608, 1736, 1800, 1864, 2216],
+             4: [88, 144, 176, 208, 256, 328, 392, 472, 536, 616, 680, 776, 904, 1000, 1128, 1224, 1288, 1416, 1544, 1736, 1864, 1992, 2152, 2280, 2408, 2536, 2984],
+             6: [152, 208, 256, 328, 408, 504, 600, 712, 808, 936, 1032, 1192, 1352, 1544, 1736, 1800, 1928, 2152, 2344, 2600, 2792, 2984, 3240, 3496, 3624, 3752, 4392],
+             10: [256, 344, 424, 568, 696, 872, 1032, 1224, 1384, 1544, 1736, 2024, 2280, 2536, 2856, 3112, 3240, 3624, 4008, 4264, 4584, 4968, 5352, 5736, 5992, 6200, 7480],
+             15: [392, 520, 648, 872, 1064, 1320, 1544, 1800, 2088, 2344, 2664, 2984, 3368, 3880, 4264, 4584, 4968, 5352, 5992, 6456, 6968, 7480, 7992, 8504, 9144, 9528, 11064]}
+    for n, col in small.items():
+        assert [TBS[i][n - 1] for i in range(27)] == col, n
 
 
 def test_rows_the_reference_carries_literally():
