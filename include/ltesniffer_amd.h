@@ -365,9 +365,21 @@ int lsn_prach_tti_opportunity(uint32_t config_idx, uint32_t tti); /* srsran_prac
 
 /* ---- measurement + parity taps (not part of the reference surface) ---- */
 enum { LSN_TAP_GRID = 0, LSN_TAP_CE = 1, LSN_TAP_PDCCH_LLR = 2, LSN_TAP_CHEST = 3, LSN_TAP_CFI = 4, LSN_TAP_CANDIDATES = 5,
-       LSN_TAP_CCE_POWER = 6, LSN_TAP_ACCEPTED = 7, LSN_TAP_RB_POWER = 8 };
+       LSN_TAP_CCE_POWER = 6, LSN_TAP_ACCEPTED = 7, LSN_TAP_RB_POWER = 8,
+       /* stage C (a14, srsran_ue_dl_decode_pdsch as called at DL_Sniffer_PDSCH.cc:997,1110,1207): retained only for batches processed after
+        * lsn_phy_set_stage_c_taps(phy, 1) - the arenas of a decode launch are recycled otherwise.  For these the index argument of lsn_phy_tap
+        * is the DECODE JOB of the chunk (one job = one decode call of one accepted DCI with one MCS table), not a subframe. */
+       LSN_TAP_PDSCH_JOBS = 9,    /* lsn_tap_job_t of every job of the chunk (index ignored) */
+       LSN_TAP_PDSCH_LLR16 = 10,  /* descrambled int16 soft bits of the job: codeword 0 (nof_re x Qm), then codeword 1 */
+       LSN_TAP_RM_WORDS = 11,     /* per code block (TB 0 blocks, then TB 1), K + 12 u32: the de-rate-matched block as k_rm hands it to k_turbo - word
+                                     (x % W) P + x / W = d0[x] | d1[x] << 10 | d2[x] << 20 (10-bit two's complement), P = windows, W = K / P; words K + 4 s + j =
+                                     stream s at position K + j (int32) */
+       LSN_TAP_CB_RESULT = 12 };  /* lsn_tap_cb_t per code block, same order */
+typedef struct { uint32_t sf, tti, rnti, nof_re, qm[2], llr_len[2], tbs[2], crc[2], ncb, have, done; float p_a_db; } lsn_tap_job_t;
+typedef struct { uint32_t tb, K, F, E, rv, ok, iters, skipped; } lsn_tap_cb_t;  /* skipped: not decoded because the first block of its TB had failed */
 /* copies tap `what` of subframe `sf_in_batch` of the LAST processed batch into out (host); returns bytes written or <0 */
 long lsn_phy_tap(lsn_phy_t* phy, int what, uint32_t sf_in_batch, void* out, size_t cap);
+int lsn_phy_set_stage_c_taps(lsn_phy_t* phy, int enable);
 /* lsn_phy_mib_decode + the 480 raw (not descrambled) PBCH soft bits of the subframe */
 int lsn_phy_mib_decode_llr(lsn_phy_t* phy, const void* iq, int iq_on_device, lsn_mib_t* out, float* llr_raw480);
 typedef struct {

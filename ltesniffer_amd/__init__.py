@@ -18,6 +18,7 @@ LIB_PATH = os.environ.get("LSN_LIB_PATH") or os.path.join(_HERE, "lib", "libltes
 
 LSN_SUCCESS, LSN_ERROR, LSN_ERROR_INVALID_INPUTS, LSN_ERROR_NO_DEVICE = 0, -1, -2, -3
 TAP_GRID, TAP_CE, TAP_PDCCH_LLR, TAP_CHEST, TAP_CFI, TAP_CANDIDATES, TAP_CCE_POWER, TAP_ACCEPTED, TAP_RB_POWER = range(9)
+TAP_PDSCH_JOBS, TAP_PDSCH_LLR16, TAP_RM_WORDS, TAP_CB_RESULT = 9, 10, 11, 12   # stage C: indexed by decode job (lsn_phy_set_stage_c_taps)
 KERNELS = ["k_ofdm", "k_chest", "k_chest_fin", "k_pcfich", "k_pdcch_llr", "k_cce_power", "k_viterbi", "k_pdsch_prep",
            "k_pdsch_demod", "k_turbo<64>", "k_rb_power", "k_turbo<128>", "k_rm"]
 
@@ -32,7 +33,22 @@ EXPORTS = ["lsn_phy_create", "lsn_phy_destroy", "lsn_phy_set_cell", "lsn_phy_get
            "lsn_pcap_reset", "lsn_pcap_close", "lsn_phy_set_pcap_writer", "lsn_phy_set_api_mode", "lsn_phy_tracked_ul_modulation", "lsn_phy_set_ul_config", "lsn_phy_get_ul_config", "lsn_sib2_decode", "lsn_phy_pusch_decode",
            "lsn_phy_tap_ul", "lsn_phy_set_prach_config", "lsn_phy_prach_detect", "lsn_phy_set_prach_sink", "lsn_prach_tti_opportunity", "lsn_phy_process_file", "lsn_phy_mib_decode", "lsn_phy_mib_decode_llr", "lsn_phy_submit_device", "lsn_phy_wait", "lsn_cell_search",
            "lsn_phy_set_shortcut_discovery", "lsn_phy_get_shortcut_discovery", "lsn_phy_set_histogram_threshold", "lsn_phy_print_stats",
-           "lsn_phy_set_mcs_update_interval", "lsn_phy_update_mcs_database", "lsn_phy_nof_tracked_rnti", "lsn_worker_buffers_offset", "lsn_pcap_digest", "lsn_pcap_set_store", "lsn_pcap_set_digest_blocks", "lsn_pcap_block_digests", "lsn_phy_create_multi", "lsn_phy_nof_devices"]
+           "lsn_phy_set_mcs_update_interval", "lsn_phy_update_mcs_database", "lsn_phy_nof_tracked_rnti", "lsn_worker_buffers_offset", "lsn_pcap_digest", "lsn_pcap_set_store", "lsn_pcap_set_digest_blocks", "lsn_pcap_block_digests", "lsn_phy_create_multi", "lsn_phy_nof_devices",
+           "lsn_phy_set_stage_c_taps"]
+
+
+def turbo_nwin(K):
+    """windows the turbo decoder cuts a block of K bits into (lsn_rm.h: lsn_turbo_nwin)"""
+    p1 = p2 = 1
+    for P in range(min(K // 32, 128), 0, -1):
+        if K % P == 0:
+            p2 = P
+            break
+    for P in range(min(K // 32, 64), 0, -1):
+        if K % P == 0:
+            p1 = P
+            break
+    return p2 if p2 >= 96 else p1
 
 
 PRACH_NCS = [0, 13, 15, 18, 22, 26, 32, 38, 46, 59, 76, 93, 119, 167, 279, 419]  # 36.211 Table 5.7.2-2
@@ -227,6 +243,7 @@ def lib():
         L.lsn_phy_process_host.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
         L.lsn_phy_tap.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_size_t]
         L.lsn_phy_tap.restype = C.c_long
+        L.lsn_phy_set_stage_c_taps.argtypes = [C.c_void_p, C.c_int]
         L.lsn_phy_get_perf.argtypes = [C.c_void_p, C.POINTER(Perf)]
         L.lsn_kernel_name.argtypes = [C.c_int]
         L.lsn_kernel_name.restype = C.c_char_p
@@ -605,6 +622,45 @@ class Phy:
         if n < 0:
             raise RuntimeError("tap %d failed: %d" % (what, n))
         return buf[: n // buf.itemsize]
+
+    def set_stage_c_taps(self, on=True):
+        """keep the soft bits / de-rate-matched words / per-code-block verdicts of every decode job of the batches processed from now on"""
+        _check(lib().lsn_phy_set_stage_c_taps(self._h, 1 if on else 0), "set_stage_c_taps")
+
+    def stage_c_jobs(self):
+        """decode jobs of the LAST chunk: list of dict(sf, tti, rnti, nof_re, qm, tbs, crc, p_a_db, llr=[cw0, cw1] int16, cbs=[dict(tb, K, F, E, rv, ok, iters, skipped,
+        d3=int16[3, K + 4] (the de-rate-matched streams unpacked from the kernel's transposed 10-bit words))])"""
+        jt = np.dtype([("sf", "<u4"), ("tti", "<u4"), ("rnti", "<u4"), ("nof_re", "<u4"), ("qm", "<u4", 2), ("llr_len", "<u4", 2), ("tbs", "<u4", 2), ("crc", "<u4", 2),
+                       ("ncb", "<u4"), ("have", "<u4"), ("done", "<u4"), ("p_a_db", "<f4")])
+        ct = np.dtype([("tb", "<u4"), ("K", "<u4"), ("F", "<u4"), ("E", "<u4"), ("rv", "<u4"), ("ok", "<u4"), ("iters", "<u4"), ("skipped", "<u4")])
+        hdr = self.tap(TAP_PDSCH_JOBS, 0, np.uint8, 1 << 22).view(jt)
+        out = []
+        for j, h in enumerate(hdr):
+            d = dict(job=j, sf=int(h["sf"]), tti=int(h["tti"]), rnti=int(h["rnti"]), nof_re=int(h["nof_re"]), qm=[int(x) for x in h["qm"]], tbs=[int(x) for x in h["tbs"]],
+                     crc=[int(x) for x in h["crc"]], p_a_db=float(h["p_a_db"]), have=bool(h["have"]), done=bool(h["done"]), llr=[None, None], cbs=[])
+            if h["have"]:
+                n0, n1 = int(h["llr_len"][0]), int(h["llr_len"][1])
+                llr = self.tap(TAP_PDSCH_LLR16, j, np.int16, n0 + n1 + 8)
+                d["llr"] = [llr[:n0].copy(), llr[n0:n0 + n1].copy()]
+                cbs = self.tap(TAP_CB_RESULT, j, np.uint8, 64 * ct.itemsize).view(ct)
+                words = self.tap(TAP_RM_WORDS, j, np.uint32, int(sum(int(c["K"]) + 12 for c in cbs)) + 8)
+                o = 0
+                for c in cbs:
+                    K = int(c["K"])
+                    w = words[o:o + K + 12]
+                    o += K + 12
+                    P = turbo_nwin(K)
+                    W = K // P
+                    x = np.arange(K)
+                    ww = w[(x % W) * P + x // W]
+                    d3 = np.zeros((3, K + 4), dtype=np.int16)
+                    for s_ in range(3):
+                        f = ((ww >> (10 * s_)) & 0x3FF).astype(np.int32)
+                        d3[s_, :K] = np.where(f >= 512, f - 1024, f)
+                        d3[s_, K:] = w[K + 4 * s_:K + 4 * s_ + 4].view(np.int32)
+                    d["cbs"].append(dict(tb=int(c["tb"]), K=K, F=int(c["F"]), E=int(c["E"]), rv=int(c["rv"]), ok=int(c["ok"]), iters=int(c["iters"]), skipped=int(c["skipped"]), d3=d3))
+            out.append(d)
+        return out
 
     def perf(self):
         p = Perf()

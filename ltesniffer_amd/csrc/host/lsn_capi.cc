@@ -559,6 +559,13 @@ long lsn_phy_tap(lsn_phy_t* phy, int what, uint32_t sf, void* out, size_t cap)
   if (!phy || !out) return LSN_ERROR_INVALID_INPUTS;
   return phy->engine->tap(what, sf, out, cap);
 }
+int lsn_phy_set_stage_c_taps(lsn_phy_t* phy, int enable)
+{
+  if (!phy) return LSN_ERROR_INVALID_INPUTS;
+  phy->engine->setStageCTaps(enable != 0);
+  for (auto& e : phy->more) e->setStageCTaps(enable != 0);
+  return LSN_SUCCESS;
+}
 int lsn_phy_get_perf(lsn_phy_t* phy, lsn_perf_t* out)
 {
   if (!phy || !out) return LSN_ERROR_INVALID_INPUTS;

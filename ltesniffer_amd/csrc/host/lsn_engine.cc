@@ -35,7 +35,7 @@ namespace lsn {
 static const bool g_spin_wait = getenv("LSN_SPIN_WAIT") && atoi(getenv("LSN_SPIN_WAIT"));
 // LSN_TURBO_FORK=1: k_turbo<64> on a second stream per runner next to k_turbo<128> (more HSA queues: measured slower beyond 6 decode threads)
 // LSN_NO_CB_SKIP=1: decode every code block even when the first block of its transport block has already failed (iteration counts then equal the oracle's)
-static const bool g_cb_skip = !(getenv("LSN_NO_CB_SKIP") && atoi(getenv("LSN_NO_CB_SKIP")));
+// (read when an engine is made: Engine::cb_skip)
 static const bool g_turbo_fork = getenv("LSN_TURBO_FORK") && atoi(getenv("LSN_TURBO_FORK"));
 static void waitEvent(hipEvent_t ev, long nap_ns = 50000)
 {
@@ -152,6 +152,9 @@ Engine::Engine(const lsn_phy_cfg_t& c, std::shared_ptr<SharedSeq> shared) : sh(s
   }
   HIP_CHECK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
   trace_path = getenv("LSN_TRACE");
+  cb_skip = !(getenv("LSN_NO_CB_SKIP") && atoi(getenv("LSN_NO_CB_SKIP")));
+  // test hook of the error path, read once per engine: chunk <n> of the first submitted block fails in stage A (and must not wedge the pipeline)
+  if (const char* e = getenv("LSN_INJECT_STAGE_A_ERROR")) inject_stage_a_fail = atoi(e);
   if (const char* e = getenv("LSN_DECODE_THREADS")) ndec = std::max(1, std::min((int)NDEC, atoi(e)));
   nslots = ndec + 8;
   front_thread = std::thread([this] { pthread_setname_np(pthread_self(), "lsn-front"); frontLoop(); });
@@ -481,6 +484,7 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
   size_t pay_n = pay0;
   struct TbRef { int job, tb; uint32_t cb_first, cb_count; };
   std::vector<TbRef> tbrefs;
+  std::vector<int> jid_of_hjob;
   for (int jid : todo) {
     DecodeJob& j = ch.jobs[jid];
     const PdschGrant& g = j.grant;
@@ -538,7 +542,7 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
         cb.il_off = turbo_il_offset(K);
         cb.max_iter = (uint32_t)cfg.max_turbo_iterations;
         // code blocks 1 .. C-1 are launched behind block 0 and skipped when it failed (the TB CRC verdict needs every block)
-        cb.dep = (q > 0 && g_cb_skip) ? (uint32_t)(r.h_cbs.size() - (size_t)q) : LSN_CB_NODEP;
+        cb.dep = (q > 0 && cb_skip) ? (uint32_t)(r.h_cbs.size() - (size_t)q) : LSN_CB_NODEP;
         wp += cb.out_bytes;
         rp += E;
         r.h_cbs.push_back(cb);
@@ -554,6 +558,7 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
     if (g.prb_lo <= g.prb_hi)
       for (uint32_t grp = g.prb_lo / 16; grp <= std::min<uint32_t>(g.prb_hi, nprb - 1) / 16; grp++) r.h_items.push_back(((uint32_t)r.h_jobs.size() << 8) | grp);
     r.h_jobs.push_back(d);
+    jid_of_hjob.push_back(jid);
   }
   const uint32_t njobs = (uint32_t)r.h_jobs.size(), ncb = (uint32_t)r.h_cbs.size();
   uint32_t n128 = 0, kmax128 = 0, kmax64 = 0, emax = 0, n128p[2] = {0, 0}, n64p[2] = {0, 0};
@@ -647,6 +652,30 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
         pf.turbo_algo_bytes += b;
         if (lsn_turbo_two_wave_class((int)r.h_cbs_pinned[i].K)) pf.turbo128_algo_bytes += b;
       }
+    }
+    if (keep_stage_c.load()) {  // parity taps: the arenas are recycled by the next launch of this runner
+      std::vector<int16_t> llr(llr_n);
+      std::vector<uint32_t> spp(spp_n);
+      if (llr_n) HIP_CHECK(hipMemcpy(llr.data(), r.d_llr16, llr_n * sizeof(int16_t), hipMemcpyDeviceToHost));
+      if (spp_n) HIP_CHECK(hipMemcpy(spp.data(), r.d_spp, spp_n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+      std::vector<uint32_t> spp_of(ncb, 0);
+      for (uint32_t i = 0; i < ncb; i++) spp_of[order[i]] = r.h_cbs_pinned[i].spp_off;
+      std::lock_guard<std::mutex> lk(tap_mtx);
+      if (ch.tapjobs.size() < ch.jobs.size()) ch.tapjobs.resize(ch.jobs.size());
+      for (uint32_t h = 0; h < njobs; h++) {
+        TapJob& t = ch.tapjobs[jid_of_hjob[h]];
+        t = TapJob{};
+        t.have = true; t.d = r.h_jobs[h];
+        for (int q = 0; q < 2; q++)
+          if (t.d.qm[q]) t.llr[q].assign(llr.begin() + t.d.llr_off[q], llr.begin() + t.d.llr_off[q] + (size_t)t.d.nof_re * t.d.qm[q]);
+      }
+      for (auto& tr : tbrefs)
+        for (uint32_t q = 0; q < tr.cb_count; q++) {
+          TapCb c;
+          c.cb = r.h_cbs[tr.cb_first + q]; c.tb = (uint32_t)tr.tb; c.res = r.h_cbres_pinned[tr.cb_first + q];
+          c.words.assign(spp.begin() + spp_of[tr.cb_first + q], spp.begin() + spp_of[tr.cb_first + q] + c.cb.K + 12);
+          ch.tapjobs[tr.job].cbs.push_back(std::move(c));
+        }
     }
     ch.h_payload.resize(pay_n);
     if (pay_n > pay0) std::memcpy(ch.h_payload.data() + pay0, r.h_payload_pinned, pay_n - pay0);
@@ -1152,8 +1181,13 @@ void Engine::frontLoop()
     // (2) the oldest chunk in flight
     if (!inflight.empty()) {
       Chunk* o = inflight.front();
-      const bool done = !o->err.empty() || hipEventQuery(o->ev_a[16]) != hipErrorNotReady;
-      if (done) { (void)hipGetLastError(); finish_oldest(); progress = true; }
+      // a query that fails for another reason than "not ready" is an error of this chunk, not its completion: the mirrors are not read
+      const hipError_t q = o->err.empty() ? hipEventQuery(o->ev_a[16]) : hipSuccess;
+      if (q != hipErrorNotReady) {
+        if (q != hipSuccess) { o->err = std::string("stage A: ") + hipGetErrorString(q); (void)hipGetLastError(); }
+        finish_oldest();
+        progress = true;
+      }
     }
     // (1) the next chunk of the current block
     if (have_job && inflight.size() < (size_t)NSTREAM_A) {
@@ -1181,7 +1215,7 @@ void Engine::frontLoop()
         ch.update_meta_period = job.update_meta_period;
         ch.force_meta = job.force_meta && ci == 0;
         ch.gseq = job.gseq0 + ci;
-        ch.jobs.clear(); ch.jres.clear(); ch.cdci.clear(); ch.setup_cfgs.clear(); ch.h_payload.clear(); ch.recs.clear(); ch.err.clear();
+        ch.jobs.clear(); ch.jres.clear(); ch.tapjobs.clear(); ch.cdci.clear(); ch.setup_cfgs.clear(); ch.h_payload.clear(); ch.recs.clear(); ch.err.clear();
         for (uint32_t i = 0; i < ch.nsf; i++) ch.ctx[i].reset(ch.start_tti + i);
         ch.st_a = stream_a[(slot_counter - 1) % NSTREAM_A];
         ch.trace_id = ci;
@@ -1192,6 +1226,8 @@ void Engine::frontLoop()
           launchStageA(ch, (const uint8_t*)job.d_iq + (size_t)base * sf_stride);
         } catch (const std::exception& ex) {
           ch.err = ex.what();
+          (void)hipStreamSynchronize(ch.st_a);  // kernels of this launch that were queued before it failed still write the chunk's buffers: the slot is released only behind them
+          (void)hipGetLastError();
         }
         inflight.push_back(&ch);
         progress = true;
@@ -1329,8 +1365,8 @@ int Engine::submit(const void* d_iq, uint32_t nsf_total, uint32_t start_tti, uin
     const uint32_t nchunks = (nsf_total + max_batch - 1) / max_batch;
     {
       std::unique_lock<std::mutex> lk(mtx);
-      const char* inj = getenv("LSN_INJECT_STAGE_A_ERROR");  // test hook of the error path: a chunk that fails must not wedge the pipeline
-      front_jobs.push_back({d_iq, nsf_total, start_tti, update_meta_period, sh->next_gseq.fetch_add(nchunks), force_meta_first, ev, inj ? atoi(inj) : -1});
+      front_jobs.push_back({d_iq, nsf_total, start_tti, update_meta_period, sh->next_gseq.fetch_add(nchunks), force_meta_first, ev, inject_stage_a_fail});
+      inject_stage_a_fail = -1;  // one shot
       chunks_expected += nchunks;
     }
     cv_front.notify_one();
@@ -1465,6 +1501,17 @@ int Engine::processHost(const float* iq, uint32_t nsf_total, uint32_t start_tti,
     // left the whole pipeline: with decode, commit and write behind stage A that is six or more chunk times later and throttled the copies to
     // three blocks per pipeline latency - the 27 GB/s of round 2).  Copies are queued ahead on their own stream, so the link stays busy.
     const uint32_t blk = max_batch;
+    if (!copy_stream) {
+      createCopyStream();
+      for (auto& e : copy_done) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    {
+      hipPointerAttribute_t attr{};
+      const bool pinned = hipPointerGetAttributes(&attr, iq) == hipSuccess && attr.type == hipMemoryTypeHost;
+      if (!pinned && (size_t)nsf_total * sf_stride >= ((size_t)8 << 20))
+        registered = hipHostRegister((void*)iq, (size_t)nsf_total * sf_stride, hipHostRegisterDefault) == hipSuccess;
+      (void)hipGetLastError();
+    }
     static const bool host_debug = getenv("LSN_HOST_DEBUG") != nullptr;
     const double t_host0 = now_ms();
     const uint32_t nring = (uint32_t)std::max<size_t>(2, staging_sf / blk);
@@ -1486,8 +1533,9 @@ int Engine::processHost(const float* iq, uint32_t nsf_total, uint32_t start_tti,
     if (registered) (void)hipHostUnregister((void*)iq);
     return rc != LSN_SUCCESS ? rc : w;
   } catch (const std::exception& ex) {
+    (void)wait();  // queued copies still read the caller's memory: drain before the registration goes away
+    if (copy_stream) (void)hipStreamSynchronize(copy_stream);
     if (registered) (void)hipHostUnregister((void*)iq);
-    (void)wait();
     fprintf(stderr, "ltesniffer_amd: %s\n", ex.what());
     return LSN_ERROR;
   }
@@ -1535,6 +1583,51 @@ long Engine::tap(int what, uint32_t sf, void* out, size_t cap)
       const float logdiv = 10.0f * log10f(14.0f);
       for (uint32_t i = 0; i < cell.nof_prb; i++) r[i] = 10.0f * log10f(ch.h_rbp[sf * 128 + i]) - logdiv;
       return h2h(r, cell.nof_prb * sizeof(float));
+    }
+    // ---- stage C (a14): `sf` is the decode job of the chunk; filled only after lsn_phy_set_stage_c_taps(phy, 1)
+    case LSN_TAP_PDSCH_JOBS: {
+      std::lock_guard<std::mutex> lk(tap_mtx);
+      std::vector<lsn_tap_job_t> v(ch.jobs.size());
+      for (size_t j = 0; j < ch.jobs.size(); j++) {
+        lsn_tap_job_t& o = v[j];
+        std::memset(&o, 0, sizeof(o));
+        const DecodeJob& dj = ch.jobs[j];
+        o.sf = dj.sf; o.tti = ch.ctx[dj.sf].tti; o.rnti = dj.rnti; o.nof_re = dj.grant.nof_re; o.p_a_db = dj.p_a; o.done = dj.done ? 1u : 0u;
+        for (int i = 0; i < 2; i++) { o.tbs[i] = dj.grant.tb[i].enabled ? (uint32_t)std::max(0, dj.grant.tb[i].tbs) : 0u; o.crc[i] = dj.crc[i] ? 1u : 0u; }
+        if (j < ch.tapjobs.size() && ch.tapjobs[j].have) {
+          const TapJob& t = ch.tapjobs[j];
+          o.have = 1; o.ncb = (uint32_t)t.cbs.size();
+          for (int q = 0; q < 2; q++) { o.qm[q] = t.d.qm[q]; o.llr_len[q] = (uint32_t)t.llr[q].size(); }
+        }
+      }
+      return h2h(v.data(), v.size() * sizeof(lsn_tap_job_t));
+    }
+    case LSN_TAP_PDSCH_LLR16: case LSN_TAP_RM_WORDS: case LSN_TAP_CB_RESULT: {
+      std::lock_guard<std::mutex> lk(tap_mtx);
+      if (sf >= ch.tapjobs.size() || !ch.tapjobs[sf].have) return 0;
+      const TapJob& t = ch.tapjobs[sf];
+      if (what == LSN_TAP_PDSCH_LLR16) {
+        const size_t n0 = t.llr[0].size() * 2, n1 = t.llr[1].size() * 2;
+        if (n0 + n1 > cap) return LSN_ERROR_INVALID_INPUTS;
+        if (n0) std::memcpy(out, t.llr[0].data(), n0);
+        if (n1) std::memcpy((uint8_t*)out + n0, t.llr[1].data(), n1);
+        return (long)(n0 + n1);
+      }
+      if (what == LSN_TAP_RM_WORDS) {
+        size_t n = 0;
+        for (auto& c : t.cbs) n += c.words.size() * 4;
+        if (n > cap) return LSN_ERROR_INVALID_INPUTS;
+        uint8_t* p = (uint8_t*)out;
+        for (auto& c : t.cbs) { std::memcpy(p, c.words.data(), c.words.size() * 4); p += c.words.size() * 4; }
+        return (long)n;
+      }
+      std::vector<lsn_tap_cb_t> v(t.cbs.size());
+      for (size_t i = 0; i < t.cbs.size(); i++) {
+        const TapCb& c = t.cbs[i];
+        const bool skipped = c.cb.dep != LSN_CB_NODEP && c.res.iters == 0;
+        v[i] = lsn_tap_cb_t{c.tb, c.cb.K, c.cb.F, c.cb.E, c.cb.rv, c.res.ok, c.res.iters, skipped ? 1u : 0u};
+      }
+      return h2h(v.data(), v.size() * sizeof(lsn_tap_cb_t));
     }
     default: return LSN_ERROR_INVALID_INPUTS;
   }

@@ -50,6 +50,10 @@ struct CommitDci {
   uint32_t di = 0;                                    // index in SubframeCtx::dl (slow path: a decode has to be created at commit)
 };
 
+// stage-C taps (lsn_phy_set_stage_c_taps): what one decode job left behind in the launch arenas, copied out before they are recycled
+struct TapCb { LsnCbDev cb; uint32_t tb = 0; LsnCbRes res{}; std::vector<uint32_t> words; };
+struct TapJob { bool have = false; LsnGrantDev d{}; std::vector<int16_t> llr[2]; std::vector<TapCb> cbs; };
+
 // everything one chunk of subframes owns while it travels through the pipeline
 struct Chunk {
   uint32_t nsf = 0, start_tti = 0;
@@ -66,6 +70,7 @@ struct Chunk {
   uint32_t ul_epoch = 0;             // Engine::ul_cfg_epoch when the DCI 0 grants of this chunk were converted
   std::vector<DecodeJob> jobs;
   std::vector<JobRes> jres;            // per job, same index as jobs
+  std::vector<TapJob> tapjobs;         // per job, filled only while the stage-C taps are switched on
   std::vector<CommitDci> cdci;         // built by planJobs
   std::vector<uint32_t> cdci_first;    // [nsf + 1] first CommitDci of each subframe
   std::vector<UeSpecConfig> setup_cfgs;
@@ -185,6 +190,7 @@ public:
   void setSink(lsn_pdu_sink_t cb, void* user) { sink = cb; sink_user = user; }
   void setApi(int mode, lsn_api_sink_t cb, void* user, lsn_pdu_sink_t pcap_cb, void* pcap) { api_mode = mode; api_sink = cb; api_user = user; api_pcap_sink = pcap_cb; api_pcap = pcap; }
   long tap(int what, uint32_t sf, void* out, size_t cap);
+  void setStageCTaps(bool on) { keep_stage_c.store(on); }
   void getPerf(lsn_perf_t* p) const { *p = perf; }
   void getStats(lsn_blind_stats_t* s) const;
   float estCfo() const { return est_cfo; }
@@ -309,6 +315,10 @@ private:
   struct FrontJob { const void* d_iq = nullptr; uint32_t nsf_total = 0, start_tti = 0, update_meta_period = 0; uint64_t gseq0 = 0; bool force_meta = false; hipEvent_t ready = nullptr; /* "block is in place" on the caller's stream */
                     int inject_fail = -1; /* test hook (LSN_INJECT_STAGE_A_ERROR=<chunk of this block>): that chunk fails in stage A */ };
   std::deque<FrontJob> front_jobs;            // submits not yet cut into chunks (front thread)
+  std::atomic<bool> keep_stage_c{false};      // lsn_phy_set_stage_c_taps: runJobs copies LLRs / de-rate-matched words / verdicts of every job out of its arenas
+  std::mutex tap_mtx;                         // (several runners may add jobs to one chunk: decode thread, search thread, commit thread)
+  bool cb_skip = true;                        // first-block gating of transport blocks (LSN_NO_CB_SKIP=1 switches it off: every code block is decoded)
+  int inject_stage_a_fail = -1;               // LSN_INJECT_STAGE_A_ERROR (test hook, read by the constructor, consumed by the first submit)
   uint64_t chunks_expected = 0;               // chunks of all submits so far; wait() returns when as many have been written
   std::thread search_thread;                  // stage B: the sequential FALCON search, chunk after chunk
   lsn_perf_t perf_search{};

@@ -609,7 +609,9 @@ static bool skipExtAdditions(BitReader& b)
 {
   if (b.flag()) return false;                  // more than 64 additions
   const uint32_t n = b.get(6) + 1;
-  const uint64_t present = ((uint64_t)b.get(n > 32 ? n - 32 : 0) << 32) | b.get(n > 32 ? 32 : n);
+  uint64_t present = 0;                        // (two sequenced reads: the reader is stateful)
+  if (n > 32) present = (uint64_t)b.get(n - 32) << 32;
+  present |= b.get(n > 32 ? 32 : n);
   for (uint32_t i = 0; i < n && !b.err; i++)
     if ((present >> (n - 1 - i)) & 1u)
       if (!skipOpenType(b)) return false;
@@ -680,7 +682,10 @@ static bool measConfigSkip(BitReader& b)
     if (q[1] || q[2] || q[3]) return false;       // UTRA / GERAN / CDMA2000 quantities: not walked
     if (ext_qc && !skipExtAdditions(b)) return false;
   }
-  if (opt[7]) { if (b.flag()) { if (!b.flag()) b.get(6); else b.get(7); } }  // measGapConfig: release / setup { gp0 (0..39) | gp1 (0..79) }
+  if (opt[7] && b.flag()) {                       // measGapConfig: release / setup { gapOffset CHOICE { gp0 (0..39), gp1 (0..79), ... } }
+    if (b.flag()) return false;                   // the choice is extensible: an alternative of a later release is not walked
+    if (!b.flag()) b.get(6); else b.get(7);
+  }
   if (opt[8]) b.get(7);                           // s-Measure (0..97)
   if (opt[9] || opt[10]) return false;            // preRegistrationInfoHRPD, speedStatePars: not walked
   if (ext_mc && !skipExtAdditions(b)) return false;

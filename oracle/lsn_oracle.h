@@ -196,6 +196,19 @@ int o_turbo_decode_cb(const int16_t* d3, int K, int max_iter, uint32_t crc_poly,
 int o_pdsch_decode_tb(const int16_t* e, int G, int tbs, int Qm, int nof_layers_rm, int rv, int max_iter,
                       uint8_t* payload, int* iters_total);
 int o_turbo_nwin(int K);
+/* ---------- stage-C recorder (o_trace.c): soft bits / de-rate-matched streams / per-code-block verdicts of every decode call ---------- */
+typedef struct { uint32_t tti, rnti, nof_re, qm[2], llr_len[2], ncb, cb_first, is_ul; } o_trace_job_hdr_t;
+typedef struct { uint32_t job, tb, K, F, E, rv, iters, ok; } o_trace_cb_hdr_t;
+void o_trace_enable(int on); /* also clears the log */
+int o_trace_enabled(void);
+void o_trace_begin_job(uint32_t tti, uint16_t rnti, uint32_t nof_re, const int* qm, const int16_t* llr0, const int16_t* llr1, int is_ul);
+void o_trace_set_tb(int tb);
+void o_trace_cb(int K, int F, int E, int rv, const int16_t* d3, int iters, int ok);
+uint32_t o_trace_njobs(void);
+uint32_t o_trace_ncbs(void);
+int o_trace_job(uint32_t i, o_trace_job_hdr_t* out);
+int o_trace_job_llr(uint32_t i, int cw, int16_t* out, uint32_t cap);
+int o_trace_cb_get(uint32_t i, o_trace_cb_hdr_t* out, int16_t* d3, uint32_t cap);
 /* ---------- second-opinion decoders (o_second.c): full-trellis 16-bit-input turbo, float tail-biting Viterbi ---------- */
 void o_pdsch_set_llr_clip(int clip); /* demodulator soft-bit clip, 511 by contract */
 int o_turbo_decode_cb_second(const int32_t* d3, int K, int max_iter, uint32_t crc_poly, uint8_t* bits, int* crc_ok);

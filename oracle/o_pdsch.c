@@ -503,6 +503,7 @@ int o_pdsch_decode_tb(const int16_t* e, int G, int tbs, int Qm, int NL, int rv, 
     o_rm_turbo_rx_cb(e + rp, E, K, F, rv, d3);
     int n = o_turbo_decode_cb(d3, K, max_iter, s.C > 1 ? O_CRC24B : O_CRC24A, cb, &ok);
     its += n > 0 ? n : 0;
+    if (o_trace_enabled()) o_trace_cb(K, F, E, rv, d3, n, ok);
     if (!ok) all_ok = 0;
     int take_n = K - F - (s.C > 1 ? 24 : 0);
     memcpy(tbbits + wp, cb + F, (size_t)take_n);

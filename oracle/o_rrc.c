@@ -480,7 +480,10 @@ static int drop_meas_config(cur_t* c)
     }
     if (qmore && !drop_additions(c)) return 0;
   }
-  if (has & (1u << 3)) { if (take(c, 1)) take(c, take(c, 1) ? 7 : 6); }
+  if ((has & (1u << 3)) && take(c, 1)) { /* measGapConfig setup: gapOffset is an extensible choice (36.331: gp0, gp1, ...) */
+    if (take(c, 1)) return 0;            /* an alternative behind the extension marker */
+    take(c, take(c, 1) ? 7 : 6);
+  }
   if (has & (1u << 2)) take(c, 7);
   if (has & 3u) return 0;
   if (more && !drop_additions(c)) return 0;

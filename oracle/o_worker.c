@@ -708,10 +708,17 @@ static void decode_grant(o_worker_t* w, const dl_entry_t* e, const o_pdsch_grant
                                      w->chest.chan_ref, p_a, w->llr0, w->llr1);
   if (w->second_turbo) o_pdsch_set_llr_clip(511);
   if (demod_rc) return;
+  if (o_trace_enabled()) {
+    int qm_cw[2] = {0, 0};
+    for (int i = 0; i < 2; i++)
+      if (g->tb[i].enabled) qm_cw[g->tb[i].cw_idx & 1] = g->tb[i].mod;
+    o_trace_begin_job(w->sfn * 10 + w->sf_idx, e->rnti, g->nof_re, qm_cw, w->llr0, w->llr1, 0);
+  }
   for (int i = 0; i < 2; i++)
     if (g->tb[i].enabled && g->tb[i].tbs > 0) {
       const int16_t* llr = (g->tb[i].cw_idx & 1) ? w->llr1 : w->llr0;
       int its = 0;
+      o_trace_set_tb(i);
       crc[i] = (w->second_turbo ? o_pdsch_decode_tb_second : o_pdsch_decode_tb)(llr, g->tb[i].nof_bits, g->tb[i].tbs, g->tb[i].mod, g->tx_scheme == O_TX_DIVERSITY ? 2 : 1,
                                  g->tb[i].rv, w->cfg.max_turbo_iter, w->payload + i * 8192 * 2, &its);
       w->total_iters += (uint64_t)its;
@@ -961,6 +968,7 @@ static int pusch_attempt(o_worker_t* w, const ulg_t* m, const o_pusch_grant_t* g
   const o_ue_cfg_t uc = ue_cfg_get(w, m->rnti);
   o_uci_t uci = {m->nof_ack, m->cqi_req ? (uint32_t)o_uci_cqi_bits_type(w->cfg.cell.nof_prb, uc.cqi_type) : 0u, m->cqi_req ? 1u : 0u,
                  uc.i_offset_ack + 1u, uc.i_offset_cqi + 1u, uc.i_offset_ri + 1u};
+  if (o_trace_enabled()) o_trace_begin_job(tti, m->rnti, 0, NULL, NULL, NULL, 1);
   int crc = o_pusch_decode_uci(&w->cfg.cell, &w->ulcfg, tti % 10, m->rnti, &gg, m->n_dmrs, &uci, w->ul_grid, w->cfg.max_turbo_iter, w->payload, &its, &snr);
   w->total_iters += (uint64_t)its;
   if (its > 0) w->last_ul_snr = snr; /* the channel estimate ran (an invalid grant leaves the previous estimate in place) */

@@ -209,6 +209,48 @@ class TxGen:
             pass
 
 
+class OTraceJob(C.Structure):
+    _fields_ = [("tti", C.c_uint32), ("rnti", C.c_uint32), ("nof_re", C.c_uint32), ("qm", C.c_uint32 * 2), ("llr_len", C.c_uint32 * 2), ("ncb", C.c_uint32),
+                ("cb_first", C.c_uint32), ("is_ul", C.c_uint32)]
+
+
+class OTraceCb(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("job", "tb", "K", "F", "E", "rv", "iters", "ok")]
+
+
+def oracle_trace_enable(on=True):
+    """stage-C recorder of the oracle (o_trace.c): switch on (clearing the log) before the subframes are worked"""
+    oracle().o_trace_enable(1 if on else 0)
+
+
+def oracle_trace():
+    """-> list of dict(tti, rnti, nof_re, qm, is_ul, llr=[cw0, cw1] int16, cbs=[dict(tb, K, F, E, rv, iters, ok, d3 int16[3, K + 4])]) of every decode call since
+    oracle_trace_enable()"""
+    lib = oracle()
+    lib.o_trace_njobs.restype = C.c_uint32
+    lib.o_trace_job.argtypes = [C.c_uint32, C.POINTER(OTraceJob)]
+    lib.o_trace_job_llr.argtypes = [C.c_uint32, C.c_int, C.c_void_p, C.c_uint32]
+    lib.o_trace_cb_get.argtypes = [C.c_uint32, C.POINTER(OTraceCb), C.c_void_p, C.c_uint32]
+    out = []
+    for i in range(lib.o_trace_njobs()):
+        h = OTraceJob()
+        assert lib.o_trace_job(i, C.byref(h)) == 0
+        llr = []
+        for q in range(2):
+            a = np.zeros(h.llr_len[q], dtype=np.int16)
+            assert lib.o_trace_job_llr(i, q, a.ctypes.data, a.size) == a.size
+            llr.append(a)
+        cbs = []
+        for k in range(h.cb_first, h.cb_first + h.ncb):
+            c = OTraceCb()
+            n = lib.o_trace_cb_get(k, C.byref(c), None, 0)
+            d3 = np.zeros(n, dtype=np.int16)
+            assert lib.o_trace_cb_get(k, C.byref(c), d3.ctypes.data, n) == n
+            cbs.append(dict(tb=c.tb, K=c.K, F=c.F, E=c.E, rv=c.rv, iters=c.iters, ok=c.ok, d3=d3.reshape(3, c.K + 4)))
+        out.append(dict(tti=h.tti, rnti=h.rnti, nof_re=h.nof_re, qm=[h.qm[0], h.qm[1]], is_ul=h.is_ul, llr=llr, cbs=cbs))
+    return out
+
+
 class OracleWorker:
     def __init__(self, nof_prb, nof_ports, cell_id, nof_rx, phich_ng_x6=1, threshold=5, split_ratio=0.99, skip_secondary=0,
                  mcs_tracking_mode=1, max_turbo_iter=12, enable_shortcut=1):
@@ -263,6 +305,10 @@ class OracleWorker:
     def set_mcs_update_interval(self, seconds):
         self.lib.o_worker_set_mcs_update_interval.argtypes = [C.c_void_p, C.c_uint32]
         self.lib.o_worker_set_mcs_update_interval(self.h, seconds)
+
+    def total_iters(self):
+        """turbo iterations summed over every code block of every decode call so far"""
+        return int(self.lib.o_worker_total_iters(self.h))
 
     def nof_tracked(self):
         self.lib.o_worker_nof_tracked.argtypes = [C.c_void_p]

@@ -3,7 +3,7 @@
 import numpy as np
 
 import ltesniffer_amd as la
-from lsn_testlib import OracleWorker, TxGen, parse_pcap, scenario
+from lsn_testlib import OracleWorker, TxGen, oracle_trace, oracle_trace_enable, parse_pcap, scenario
 
 
 def gen_subframes(sc, n, **txkw):
@@ -36,7 +36,9 @@ def gen_capture(sc, n, threads=None, **txkw):
     return tti0, iq
 
 
-def run_oracle(sc, tti0, iq, update_meta_period=0, taps=True, mcs_update_interval=None, **okw):
+def run_oracle(sc, tti0, iq, update_meta_period=0, taps=True, mcs_update_interval=None, trace=False, **okw):
+    """trace=True: the oracle's stage-C recorder runs over these subframes; read it with lsn_testlib.oracle_trace() afterwards"""
+    oracle_trace_enable(trace)
     ow = OracleWorker(sc["nof_prb"], sc["nof_ports"], sc["cell_id"], sc["nof_rx"], sc["phich_ng_x6"], **okw)
     if mcs_update_interval is not None:
         ow.set_mcs_update_interval(mcs_update_interval)
@@ -51,6 +53,61 @@ def run_oracle(sc, tti0, iq, update_meta_period=0, taps=True, mcs_update_interva
                                               [ch.noise_avg, ch.rsrp_avg, ch.snr_db, ch.cfo_hz, ch.chan_ref], dtype=np.float32)))
     recs = parse_pcap(ow.pcap_bytes())
     return ow, per_sf, recs
+
+
+def compare_stage_c(phy, otrace, first_tti, nsf, exact_iters=False):
+    """Stage C behind its by-products: every decode call the ORACLE made on the subframes of the last GPU chunk (first_tti .. first_tti + nsf) must have
+    a product decode job with bit-identical descrambled int16 soft bits (k_pdsch_demod), bit-identical de-rate-matched streams (k_rm, unpacked
+    from the transposed 10-bit words) and the same per-code-block verdict and iteration count (k_turbo).  The product decodes MORE jobs than the
+    oracle (speculative table attempts) - those are not looked at; a job planned with a p-a that commit later rejected leaves a second job with the
+    same key, so a call matches when ANY job with its key is identical.  Code blocks the product skipped because the first block of their
+    transport block had failed (first-block gating; none when exact_iters, i.e. under LSN_NO_CB_SKIP=1) carry no verdict to compare.
+    -> (list of mismatches, number of oracle calls compared, code blocks compared, iterations the oracle ran, iterations the product ran on them)"""
+    jobs = phy.stage_c_jobs()
+    by_key = {}
+    for j in jobs:
+        if j["have"]:
+            by_key.setdefault((j["tti"], j["rnti"], tuple(j["qm"]), j["nof_re"], tuple((c["tb"], c["K"], c["F"], c["E"], c["rv"]) for c in j["cbs"])), []).append(j)
+    bad, ncall, ncb, it_o, it_g = [], 0, 0, 0, 0
+    for o in otrace:
+        if o["is_ul"] or not (0 <= (o["tti"] - first_tti) % 10240 < nsf):
+            continue
+        ncall += 1
+        key = (o["tti"], o["rnti"], tuple(o["qm"]), o["nof_re"], tuple((c["tb"], c["K"], c["F"], c["E"], c["rv"]) for c in o["cbs"]))
+        cands = by_key.get(key)
+        if not cands:
+            bad.append(("no product job", key[:4]))
+            continue
+        why = None
+        for g in cands:
+            why = None
+            for q in range(2):
+                if o["qm"][q] and not np.array_equal(g["llr"][q], o["llr"][q]):
+                    d = np.nonzero(g["llr"][q] != o["llr"][q])[0]
+                    why = ("llr16", key[:4], q, int(d.size), int(d[0]), int(g["llr"][q][d[0]]), int(o["llr"][q][d[0]]))
+                    break
+            if why:
+                continue
+            for k, (cg, co) in enumerate(zip(g["cbs"], o["cbs"])):
+                if not np.array_equal(cg["d3"], co["d3"]):
+                    d = np.argwhere(cg["d3"] != co["d3"])
+                    why = ("rm_words", key[:4], k, int(len(d)), d[0].tolist(), int(cg["d3"][tuple(d[0])]), int(co["d3"][tuple(d[0])]))
+                    break
+                if cg["skipped"] and not exact_iters:
+                    continue
+                if (cg["ok"], cg["iters"]) != (co["ok"], co["iters"]):
+                    why = ("cb_result", key[:4], k, (cg["ok"], cg["iters"]), (co["ok"], co["iters"]))
+                    break
+            if not why:
+                for cg, co in zip(g["cbs"], o["cbs"]):
+                    if not cg["skipped"]:
+                        ncb += 1
+                        it_o += co["iters"]
+                        it_g += cg["iters"]
+                break
+        if why:
+            bad.append(why)
+    return bad, ncall, ncb, it_o, it_g
 
 
 def gpu_records(phy):

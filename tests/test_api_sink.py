@@ -349,7 +349,8 @@ def _encode_reconfig(nas, meas=None, mobility=False, rrcd=True):
             if g == "release":
                 _put(b, 0, 1)
             else:
-                _put(b, 1, 1); _put(b, 0 if g[0] == "gp0" else 1, 1); _put(b, g[1], 6 if g[0] == "gp0" else 7)
+                _put(b, 1, 1); _put(b, 0, 1)  # setup; gapOffset is an extensible CHOICE (36.331 MeasGapConfig: gp0, gp1, ...): extension bit 0
+                _put(b, 0 if g[0] == "gp0" else 1, 1); _put(b, g[1], 6 if g[0] == "gp0" else 7)
         if meas.get("s_measure") is not None:
             _put(b, meas["s_measure"], 7)
         if meas.get("additions"):

@@ -4,24 +4,44 @@ import pytest
 
 import ltesniffer_amd as la
 from lsn_testlib import scenario
-from parity import compare_candidate_tables, compare_taps, gen_subframes, gpu_records, oracle_records, run_oracle
+from lsn_testlib import oracle_trace
+from parity import compare_candidate_tables, compare_stage_c, compare_taps, gen_subframes, gpu_records, oracle_records, run_oracle
 
 pytestmark = pytest.mark.gpu
 
 
-def _run(scn, nsf, seed=1, batch=16, update_meta_period=0, **over):
+def _run(scn, nsf, seed=1, batch=16, update_meta_period=0, exact_iters=False, **over):
+    """stage-A taps, stage-C taps (int16 soft bits, de-rate-matched streams, per-code-block verdict + iterations), record stream and statistics
+    of the HIP path against the oracle; exact_iters: the engine runs without first-block gating (LSN_NO_CB_SKIP=1), so every code block of
+    every decode call the oracle made carries a verdict and the iteration totals must agree"""
+    import os
     sc = scenario(scn, seed=seed, **over)
     tti0, iq, truth = gen_subframes(sc, nsf)
-    ow, per_sf, orecs = run_oracle(sc, tti0, iq, update_meta_period=update_meta_period)
-    phy = la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=batch)
+    ow, per_sf, orecs = run_oracle(sc, tti0, iq, update_meta_period=update_meta_period, trace=True)
+    otrace = oracle_trace()
+    if exact_iters:
+        os.environ["LSN_NO_CB_SKIP"] = "1"   # read when the engine is made
+    try:
+        phy = la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=batch)
+    finally:
+        os.environ.pop("LSN_NO_CB_SKIP", None)
     assert phy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"])
-    bad = []
+    phy.set_stage_c_taps(True)
+    bad, badc, ncall, ncb, it_o, it_g = [], [], 0, 0, 0, 0
     for base in range(0, nsf, batch):
         n = min(batch, nsf - base)
         # update_meta_period counts subframes from the start of the stream, same as the oracle driver above
         phy.process_host(iq[base:base + n], tti0 + base, update_meta_period)
         bad += [(base,) + b for b in compare_taps(phy, per_sf, sc, base, n)]
+        b, c, k, io, ig = compare_stage_c(phy, otrace, tti0 + base, n, exact_iters=exact_iters)
+        badc += [(base,) + x for x in b]
+        ncall, ncb, it_o, it_g = ncall + c, ncb + k, it_o + io, it_g + ig
     assert not bad, bad[:5]
+    assert not badc, (len(badc), badc[:5])
+    assert ncall == len([o for o in otrace if not o["is_ul"]]) and (ncb > 0 or not orecs), (ncall, ncb)
+    assert it_o == it_g
+    if exact_iters:
+        assert it_o == ow.total_iters() and ncb == sum(len(o["cbs"]) for o in otrace)
     g, o = gpu_records(phy), oracle_records(orecs)
     assert len(o) > 0
     assert g == o, "record streams differ: gpu %d vs oracle %d" % (len(g), len(o))
@@ -125,6 +145,13 @@ def test_redundancy_versions_1_2_3():
 def test_mid_snr_many_crc_failures():
     n = _run("cfg3", 24, seed=33, snr_db=14.0)
     assert n > 0
+
+
+def test_iteration_counts_equal_the_oracles_without_first_block_gating():
+    """LSN_NO_CB_SKIP=1: every code block is decoded (the production engine skips blocks 1 .. C-1 of a transport block whose block 0 failed), so
+    the per-block iteration counts of ALL blocks - hopeless 12-iteration blocks at 14 dB included - and their sum equal the oracle's"""
+    _run("cfg3", 16, seed=34, snr_db=14.0, exact_iters=True)
+    _run("cfg2", 16, seed=36, exact_iters=True)
 
 
 def test_low_snr_subframes_are_skipped():
@@ -340,15 +367,15 @@ def test_a_failing_chunk_is_reported_and_does_not_wedge_the_pipeline():
     nsf = 40
     tti0, iq, _ = gen_subframes(sc, nsf)
     _, _, orecs = run_oracle(sc, tti0, iq, taps=False)
-    phy = la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=8, pcapwriter=la.PcapWriter(None))
-    assert phy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"])
-    d_iq = torch.from_numpy(iq.view(np.float32)).to("cuda:0")
-    os.environ["LSN_INJECT_STAGE_A_ERROR"] = "2"   # the third of five chunks
+    os.environ["LSN_INJECT_STAGE_A_ERROR"] = "2"   # the third of five chunks of the first block (read once, when the engine is made)
     try:
-        with pytest.raises(RuntimeError):
-            phy.process_device(d_iq.data_ptr(), nsf, tti0, 0, torch.cuda.current_stream().cuda_stream)
+        phy = la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=8, pcapwriter=la.PcapWriter(None))
     finally:
         del os.environ["LSN_INJECT_STAGE_A_ERROR"]
+    assert phy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"])
+    d_iq = torch.from_numpy(iq.view(np.float32)).to("cuda:0")
+    with pytest.raises(RuntimeError):
+        phy.process_device(d_iq.data_ptr(), nsf, tti0, 0, torch.cuda.current_stream().cuda_stream)
     got = gpu_records(phy)
     # subframes 16..23 are missing, everything in front of them is what the oracle wrote
     head = [r for r in oracle_records(orecs)]

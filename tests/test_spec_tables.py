@@ -102,6 +102,35 @@ def test_tbs_full_band_columns_match_the_published_peak_rates():
         assert [TBS[i][n - 1] for i in range(27)] == col, n
 
 
+def test_every_row_keeps_its_bits_per_prb_density_across_the_band():
+    """round-3 advisor finding: row I_TBS 26 sat one value-set step too high in 41 of the columns 42..99 (761..777 bits per PRB where its verified
+    25 / 50 / 75 / 100-PRB entries give 734), invisible to every product-vs-oracle comparison.  The table is built from a per-row spectral
+    efficiency, so TBS / N_PRB of a row stays in a narrow band over all columns: every entry from 11 PRB on must be the value-set member
+    nearest to (row density x N_PRB) or one of its two neighbours - density taken from the row's three full-band entries that are pinned on
+    published peak rates - and the max / min density of a row is bounded.  Row 26 saturates at 75 376 from 100 PRB on (the only exception)."""
+    for i in range(27):
+        row = TBS[i]
+        dens = sorted([row[24] / 25.0, row[49] / 50.0, row[99] / 100.0])[1]
+        last = 100 if i == 26 else 110
+        d = [row[n] / (n + 1.0) for n in range(10, last)]
+        assert max(d) / min(d) < 1.09, (i, min(d), max(d))   # (row 0: 8-bit steps on ~300-bit entries; the restated row 26 of round 3 reached 1.13)
+        for n in range(10, last):
+            j = min(range(len(ALLOWED)), key=lambda k: abs(ALLOWED[k] - dens * (n + 1)))
+            assert abs(ALLOWED.index(row[n]) - j) <= 1, (i, n + 1, row[n], ALLOWED[j])
+    # row 26 written down a second time, apart from the generator (decades of ten columns)
+    row26 = [712, 1480, 2216, 2984, 3752, 4392, 5160, 5992, 6712, 7480,
+             8248, 8760, 9528, 10296, 11064, 11832, 12576, 13536, 14112, 14688,
+             15264, 16416, 16992, 17568, 18336, 19080, 19848, 20616, 21384, 22152,
+             22920, 23688, 24496, 25456, 25456, 26416, 27376, 28336, 29296, 29296,
+             30576, 30576, 31704, 32856, 32856, 34008, 35160, 35160, 36696, 36696,
+             37888, 37888, 39232, 40576, 40576, 40576, 42368, 42368, 43816, 43816,
+             45352, 45352, 46888, 46888, 48936, 48936, 48936, 51024, 51024, 52752,
+             52752, 52752, 55056, 55056, 55056, 55056, 57336, 57336, 57336, 59256,
+             59256, 61664, 61664, 61664, 63776, 63776, 63776, 66592, 66592, 66592,
+             66592, 68808, 68808, 68808, 71112, 71112, 71112, 73712, 73712, 75376] + [75376] * 10
+    assert TBS[26] == row26
+
+
 def test_rows_the_reference_carries_literally():
     # 36.213 row 32A (256QAM, the reference's only in-tree TBS row) sits between rows 32 and 33 of the restated table for every PRB count
     assert len(ROW32A) == 110 and all(v in set(ALLOWED) for v in ROW32A)
@@ -188,16 +217,16 @@ def test_dmrs_tables_look_like_computer_generated_cazac_sequences():
 
 def test_derived_tbs_rows_are_flagged_and_their_rule_is_cross_validated():
     """rows I_TBS 27..33 are derived (spec/gen_tables.py: the reference's row 32A scaled to the 100-PRB anchors and snapped to the value set).
-    The same rule applied between rows that ARE known reproduces 50-90 % of the entries exactly and misses by at most one step of the value set
+    The same rule applied between rows that ARE known reproduces 40-90 % of the entries exactly and misses by at most one step of the value set
     (row 26, which saturates at 75376, by two steps in a few columns) - the error model for a derived row; the product counts every decode that used one (lsn_perf_t.nof_tb_on_derived_tbs)."""
     def snap(t):
         return min(ALLOWED, key=lambda x: (abs(x - t), x))
-    for src, dst, near_min in ((24, 25, 108), (20, 21, 108), (23, 24, 108), (25, 26, 100)):
+    for src, dst, near_min, exact_min in ((24, 25, 108, 55), (20, 21, 108, 55), (23, 24, 108, 55), (25, 26, 100, 40)):
         exact = near = 0
         for n in range(110):
             v = snap(TBS[src][n] * TBS[dst][99] / TBS[src][99])
             exact += v == TBS[dst][n]
             near += abs(ALLOWED.index(v) - ALLOWED.index(TBS[dst][n])) <= 1
-        assert exact >= 55 and near >= near_min, (src, dst, exact, near)
+        assert exact >= exact_min and near >= near_min, (src, dst, exact, near)
     hdr = open(os.path.join(ROOT, "include", "ltesniffer_amd.h")).read()
     assert "nof_tb_on_derived_tbs" in hdr and "nof_pusch_on_unverified_dmrs" in hdr
