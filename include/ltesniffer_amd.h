@@ -56,7 +56,8 @@ typedef struct {
   double meta_format_split_ratio;   /* Settings.h:55, default 0.99 */
   uint32_t histogram_threshold;     /* Settings.h:57, default 5 */
   int mcs_tracking_mode;            /* ArgManager.cc:52, default 1 */
-  int harq_mode;                    /* ArgManager.cc:50: always 0 in the reference; only 0 supported */
+  int harq_mode;                    /* 0 (ArgManager.cc:50: the reference's only reachable value) or 1: DL HARQ soft combining (HARQ.cc:71-190,
+                                       DL_Sniffer_PDSCH.cc:943-1020) for known-table C-RNTI grants; DL mode, one engine */
   int device;                       /* HIP device ordinal */
   int max_turbo_iterations;         /* SubframeWorker.cc:365, default 12 (0 = default) */
   int sniffer_mode;                 /* 0 = DL_MODE, 1 = UL_MODE (SubframeWorker.cc:166-199): antenna 0 = downlink, antenna 1 = uplink,
@@ -400,6 +401,12 @@ typedef struct {
   uint64_t nof_pusch_2prb_skipped;                       /* (always 0 since round 3: 2-PRB grants are decoded) */
   uint64_t nof_pusch_on_unverified_dmrs;                 /* UL_MODE: PUSCH attempts on 1- / 2-PRB allocations, whose reference signals come from the restated (structure-checked, not text-verified) 36.211 Tables 5.5.1.2-1 / -2 */
   uint64_t nof_tb_on_derived_tbs;                        /* transport-block decodes whose size came from the DERIVED TBS rows I_TBS 27..33 (spec/gen_tables.py): a real capture that fails exactly there points at the table */
+  uint64_t nof_decode_jobs, nof_decode_jobs_used, nof_speculative_jobs;  /* PDSCH decode calls run / of those the commit stage consumed (what the reference would have run) / run ahead only because the
+                                                            RNTI's table might be known by commit time (second-table attempt although the first one passed a CRC) */
+  /* decode jobs by why they were run: [0] first attempt of the plan, [1] second-table attempt after the first failed on every TB, [2] second-table attempt run
+   * ahead although the first passed a CRC (speculative), [3] RA-RNTI candidates decoded ahead of the search, [4] decoded on demand (search / commit turn);
+   * jobs / turbo iterations run, and the part of both the commit stage never looked at */
+  uint64_t jobs_by_kind[5], jobs_unused_by_kind[5], iters_by_kind[5], iters_unused_by_kind[5];
 } lsn_perf_t;
 int lsn_phy_get_perf(lsn_phy_t* phy, lsn_perf_t* out);
 enum { LSN_K_OFDM = 0, LSN_K_CHEST, LSN_K_CHEST_FIN, LSN_K_PCFICH, LSN_K_PDCCH_LLR, LSN_K_CCE_POWER, LSN_K_VITERBI,

@@ -584,6 +584,8 @@ int lsn_phy_get_perf(lsn_phy_t* phy, lsn_perf_t* out)
     out->nof_turbo_iterations_run += p.nof_turbo_iterations_run; out->ms_ondemand_commit += p.ms_ondemand_commit;
     for (int k = 0; k < 4; k++) out->nof_ondemand_commit[k] += p.nof_ondemand_commit[k];
     out->nof_pusch_on_unverified_dmrs += p.nof_pusch_on_unverified_dmrs; out->nof_tb_on_derived_tbs += p.nof_tb_on_derived_tbs;
+    out->nof_decode_jobs += p.nof_decode_jobs; out->nof_decode_jobs_used += p.nof_decode_jobs_used; out->nof_speculative_jobs += p.nof_speculative_jobs;
+    for (int k = 0; k < 5; k++) { out->jobs_by_kind[k] += p.jobs_by_kind[k]; out->jobs_unused_by_kind[k] += p.jobs_unused_by_kind[k]; out->iters_by_kind[k] += p.iters_by_kind[k]; out->iters_unused_by_kind[k] += p.iters_unused_by_kind[k]; }
   }
   return LSN_SUCCESS;
 }

@@ -136,7 +136,8 @@ Engine::Engine(const lsn_phy_cfg_t& c, std::shared_ptr<SharedSeq> shared) : sh(s
   if (cfg.nof_rx_antennas < 1 || cfg.nof_rx_antennas > LSN_MAX_RX) throw std::invalid_argument("nof_rx_antennas");
   if (cfg.sniffer_mode != 0 && cfg.sniffer_mode != 1) throw std::invalid_argument("sniffer_mode");
   if (cfg.sniffer_mode == 1 && cfg.nof_rx_antennas != 2) throw std::invalid_argument("UL_MODE needs two antenna buffers");
-  if (cfg.harq_mode != 0) throw std::invalid_argument("harq_mode");  // ArgManager.cc:50: always 0 in the reference
+  if (cfg.harq_mode != 0 && cfg.harq_mode != 1) throw std::invalid_argument("harq_mode");  // 0 (the reference's only reachable value, ArgManager.cc:50) or 1
+  if (cfg.harq_mode && (cfg.sniffer_mode != 0 || shared)) throw std::invalid_argument("harq_mode: DL mode on one engine only");  // (the soft-buffer pool lives on one device)
   max_batch = cfg.max_batch ? cfg.max_batch : 64;
   if (cfg.max_turbo_iterations <= 0) cfg.max_turbo_iterations = 12;  // SubframeWorker.cc:365
   if (cfg.meta_format_split_ratio <= 0.0) cfg.meta_format_split_ratio = 0.99;
@@ -254,6 +255,8 @@ void Engine::mergePerf(const lsn_perf_t& p)
   perf.nof_pusch_2prb_skipped += p.nof_pusch_2prb_skipped;
   perf.nof_pusch_on_unverified_dmrs += p.nof_pusch_on_unverified_dmrs;
   perf.nof_tb_on_derived_tbs += p.nof_tb_on_derived_tbs;
+  perf.nof_decode_jobs += p.nof_decode_jobs; perf.nof_decode_jobs_used += p.nof_decode_jobs_used; perf.nof_speculative_jobs += p.nof_speculative_jobs;
+  for (int k = 0; k < 5; k++) { perf.jobs_by_kind[k] += p.jobs_by_kind[k]; perf.jobs_unused_by_kind[k] += p.jobs_unused_by_kind[k]; perf.iters_by_kind[k] += p.iters_by_kind[k]; perf.iters_unused_by_kind[k] += p.iters_unused_by_kind[k]; }
   for (int k = 0; k < 16; k++) { perf.kernel_ms[k] += p.kernel_ms[k]; perf.kernel_launches[k] += p.kernel_launches[k]; }
 }
 
@@ -340,7 +343,7 @@ void Engine::speculateRar(Chunk& ch)
           DlEntry e;
           if (!search->buildDlEntry(c, (uint16_t)q.rnti, f, q.bits, e) || !e.ok64) continue;
           if (cfg.sniffer_mode == 0 && (!(e.grant64.tb[0].tbs > 0) || (dlRx() == 1 && e.grant64.nof_tb == 2))) continue;
-          const int j = newJob(ch, sf, e, 0, default_p_a.load(std::memory_order_relaxed));
+          const int j = newJob(ch, sf, e, 0, default_p_a.load(std::memory_order_relaxed), 3);
           if (j < 0) continue;
           ch.spec_rar.push_back({sf, (uint16_t)q.rnti, f, q.bits, j});
           ids.push_back(j);
@@ -392,7 +395,7 @@ void Engine::searchChunk(Chunk& ch, uint32_t update_meta_period)
       for (auto& s : ch.spec_rar)  // decoded ahead by the front thread?
         if (s.sf == sf && s.rnti == e.rnti && s.format == e.format && s.bits == e.bits && ch.jobs[s.job].done) { j = s.job; break; }
       if (j < 0) {
-        j = newJob(ch, sf, e, 0, default_p_a.load(std::memory_order_relaxed));
+        j = newJob(ch, sf, e, 0, default_p_a.load(std::memory_order_relaxed), 4);
         if (j < 0) continue;
         const double tr0 = now_ms();
         ensureJob(ch, runner_s, j);
@@ -400,6 +403,7 @@ void Engine::searchChunk(Chunk& ch, uint32_t update_meta_period)
         runner_s.perf.nof_ondemand_decodes++;
       }
       e.job[0] = j;
+      ch.jobs[j].used = 1;  // the search read it (and the commit will)
       for (int tb = 0; tb < 2; tb++) {
         const int len = ch.jobs[j].grant.tb[tb].tbs / 8;
         if (cfg.sniffer_mode == 1) {  // run_rar_decode parses pdsch_res->payload (TB 0) at the first CRC-ok TB and returns
@@ -428,10 +432,10 @@ void Engine::unpackRar(const uint8_t* p, int len, bool at_search)
 
 // ------------------------------------------------------------------------------------------------ stage C planning
 // one srsran_ue_dl_decode_pdsch call = one job; returns -1 when dl_sniffer_config_mimo rejects the grant
-int Engine::newJob(Chunk& ch, uint32_t sf, const DlEntry& e, int table, float p_a)
+int Engine::newJob(Chunk& ch, uint32_t sf, const DlEntry& e, int table, float p_a, int kind)
 {
   DecodeJob j;
-  j.sf = sf; j.rnti = e.rnti;
+  j.sf = sf; j.rnti = e.rnti; j.kind = (uint8_t)kind;
   // pdsch_cfg->p_a: DL mode looks the UE's p-a up before every decode (DL_Sniffer_PDSCH.cc:926-927); the UL-mode decoders never set
   // it and run with the -3 dB of SubframeWorker::set_pdsch_uecfg (SubframeWorker.cc:370)
   j.p_a = cfg.sniffer_mode == 1 ? -3.0f : p_a;
@@ -561,7 +565,7 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
     jid_of_hjob.push_back(jid);
   }
   const uint32_t njobs = (uint32_t)r.h_jobs.size(), ncb = (uint32_t)r.h_cbs.size();
-  uint32_t n128 = 0, kmax128 = 0, kmax64 = 0, emax = 0, n128p[2] = {0, 0}, n64p[2] = {0, 0};
+  uint32_t kmax128 = 0, kmax64 = 0, emax = 0, n128p[2] = {0, 0}, n64p[2] = {0, 0};
   size_t spp_n = 0;
   std::vector<uint32_t> order;
   if (njobs) {
@@ -604,12 +608,10 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
         const int ph = q.dep != LSN_CB_NODEP ? 1 : 0;
         if (lsn_turbo_two_wave_class((int)q.K)) { n128p[ph]++; kmax128 = std::max(kmax128, q.K); } else { n64p[ph]++; kmax64 = std::max(kmax64, q.K); }
       }
-      n128 = n128p[0] + n128p[1];
       grow_dev(r.d_spp, r.spp_cap, spp_n + 16, st);
       lsn_launch_upload(r.d_cbs, r.h_cbs_pinned, ncb * sizeof(LsnCbDev), st);
     }
-    HIP_CHECK(hipMemsetAsync(r.d_llr16, 0, llr_n * sizeof(int16_t), st));
-    HIP_CHECK(hipEventRecord(r.ev[0], st));
+    HIP_CHECK(hipEventRecord(r.ev[0], st));  // (no clear of the LLR arena: k_pdsch_demod writes every soft bit of every codeword it is given, zeros of unpaired SFBC REs included)
     lsn_launch_pdsch_prep(cd, r.d_jobs, r.d_prefix, njobs, st);
     HIP_CHECK(hipEventRecord(r.ev[1], st));
     lsn_launch_pdsch_demod(cd, r.d_jobs, r.d_items, nitems, r.d_prefix, ch.d_grid, ch.d_ce, ch.d_chest, r.d_llr16, st);
@@ -629,6 +631,29 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
       HIP_CHECK(hipEventRecord(r.ev[3], st));
       lsn_launch_download(r.h_cbres_pinned, r.d_cbres, ncb * sizeof(LsnCbRes), st);
       lsn_launch_download(r.h_payload_pinned, r.d_payload, pay_n - pay0, st);
+      if (cfg.harq_mode) {  // the soft data of this launch stays with the chunk until its commit (HARQ buffers are filled / combined there)
+        if (ch.keep_n + spp_n > ch.keep_cap) {
+          const size_t cap = (ch.keep_n + spp_n) * 2 + (1u << 20);
+          uint32_t* nb = nullptr;
+          HIP_CHECK(hipMalloc((void**)&nb, cap * sizeof(uint32_t)));
+          if (ch.keep_n) HIP_CHECK(hipMemcpy(nb, ch.d_keep, ch.keep_n * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+          if (ch.d_keep) HIP_CHECK(hipFree(ch.d_keep));
+          ch.d_keep = nb; ch.keep_cap = cap;
+        }
+        HIP_CHECK(hipMemcpyAsync(ch.d_keep + ch.keep_n, r.d_spp, spp_n * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+        std::vector<uint32_t> spp_of(ncb, 0);
+        for (uint32_t i = 0; i < ncb; i++) spp_of[order[i]] = r.h_cbs_pinned[i].spp_off;
+        for (auto& tr : tbrefs) {
+          DecodeJob& j = ch.jobs[tr.job];
+          j.keep_first[tr.tb] = (uint32_t)ch.keep_cbs.size(); j.keep_count[tr.tb] = tr.cb_count;
+          for (uint32_t q = 0; q < tr.cb_count; q++) {
+            LsnCbDev cb = r.h_cbs[tr.cb_first + q];
+            cb.spp_off = (uint32_t)(ch.keep_n + spp_of[tr.cb_first + q]);
+            ch.keep_cbs.push_back(cb);
+          }
+        }
+        ch.keep_n += spp_n;
+      }
     }
     HIP_CHECK(hipEventRecord(r.ev_done, st));
     waitEvent(r.ev_done);
@@ -716,6 +741,7 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
     }
   }
   for (int jid : todo) { ch.jobs[jid].done = true; ch.jres[jid].done = 1; }
+  pf.nof_decode_jobs += todo.size();
 }
 
 void Engine::ensureJob(Chunk& ch, JobRunner& r, int j)
@@ -725,6 +751,24 @@ void Engine::ensureJob(Chunk& ch, JobRunner& r, int j)
   ch.jobs[j].planned = false;
   runJobs(ch, r, one);
 }
+
+// the two tables give the same decode (low MCS indices map to the same modulation and transport block size in both): one job serves both attempts
+static bool same_decode(const PdschGrant& a, const PdschGrant& b)
+{
+  if (a.nof_tb != b.nof_tb || a.nof_re != b.nof_re || a.tx_scheme != b.tx_scheme || a.pmi != b.pmi || a.nof_layers != b.nof_layers) return false;
+  for (int i = 0; i < 2; i++) {
+    const GrantTb &x = a.tb[i], &y = b.tb[i];
+    if (x.enabled != y.enabled) return false;
+    if (x.enabled && (x.mod != y.mod || x.tbs != y.tbs || x.rv != y.rv || x.nof_bits != y.nof_bits || x.cw_idx != y.cw_idx)) return false;
+  }
+  return true;
+}
+// The 256QAM-table attempt of an unknown-table DCI (format > 1A) is run ahead even when its 64QAM-table attempt passed a CRC: the plan runs
+// thousands of subframes ahead of the commit, and a UE whose table the commit learns in between is then committed with the KNOWN table, which
+// wants exactly that attempt.  Measured in round 4 (LSN_SPECULATE_SECOND_TABLE=0): without them 6 % of the subframes need a decode inside the
+// sequential commit turn (one GPU round trip each) and the rate falls from 156 k to 56 k subframes/s; with them the engine runs 7 % more
+// turbo iterations.  Results are the same either way (the commit re-derives every decision).
+static const bool g_speculate_second_table = !(getenv("LSN_SPECULATE_SECOND_TABLE") && !atoi(getenv("LSN_SPECULATE_SECOND_TABLE")));
 
 // wave 1: the first decode the reference would attempt for every accepted DL DCI, predicted from the MCS-tracking
 // state as of now; wave 2: the 256QAM-table retry of "unknown table" grants whose first attempt failed on both TBs
@@ -759,11 +803,12 @@ void Engine::planJobs(Chunk& ch, JobRunner& r)
       if (dlRx() == 1 && (e.grant64.nof_tb == 2 || e.grant256.nof_tb == 2)) continue;
       if (e.job[first] < 0) e.job[first] = newJob(ch, sf, e, first, predictedPa(e.rnti));  // as of now; commit checks it
       if (e.job[first] >= 0) wave.push_back(e.job[first]);
+      if (e.job[first] >= 0 && e.job[1 - first] < 0 && e.ok64 && e.ok256 && same_decode(e.grant64, e.grant256)) e.job[1 - first] = e.job[first];
       // the 256QAM-table attempt: the reference makes it when both TBs failed with the 64QAM table.  A DCI of a format that can teach the
       // table (> 1A, DL_Sniffer_PDSCH.cc:1168-1171) may find its RNTI's table KNOWN by the time it is committed (the plan runs thousands of
       // subframes ahead of the commit while a new UE is being learned), and then commit wants exactly that attempt: decode it now rather
       // than as a GPU round trip of the sequential commit thread
-      if (table >= TABLE_UNKNOWN && e.ok256) retry.push_back({sf, di, e.format > FORMAT1A});
+      if (table >= TABLE_UNKNOWN && e.ok256 && e.job[1] < 0) retry.push_back({sf, di, g_speculate_second_table && e.format > FORMAT1A});
     }
   }
   const uint8_t trk = (uint8_t)(2 + (&r - runner_c));
@@ -775,7 +820,19 @@ void Engine::planJobs(Chunk& ch, JobRunner& r)
     DlEntry& e = ch.ctx[p.sf].dl[p.di];
     if (e.job[0] < 0 || !ch.jobs[e.job[0]].done) continue;
     if (!p.always && (ch.jobs[e.job[0]].crc[0] || ch.jobs[e.job[0]].crc[1])) continue;
-    if (e.job[1] < 0) e.job[1] = newJob(ch, p.sf, e, 1, ch.jobs[e.job[0]].p_a);
+    const bool spec = ch.jobs[e.job[0]].crc[0] || ch.jobs[e.job[0]].crc[1];
+    if (spec) {
+      // The speculative attempt serves a commit that finds the RNTI's table KNOWN as 256QAM.  A UE whose 64QAM-table attempt passed the CRC of
+      // EVERY enabled transport block is on the 64QAM table: nothing can have taught the commit otherwise, so the attempt (hopeless by
+      // construction: 12 iterations per block) is left out - measured in round 4: 3 326 speculative jobs per 6 400 subframes, 280 of them used,
+      // 15 % of all turbo iterations.  Kept: partial passes (one block of a two-block grant whose MCS index means the same in both tables).
+      const DecodeJob& j0 = ch.jobs[e.job[0]];
+      bool all_ok = true;
+      for (int i = 0; i < 2; i++) all_ok = all_ok && (!j0.grant.tb[i].enabled || !(j0.grant.tb[i].tbs > 0) || j0.crc[i]);
+      if (all_ok) continue;
+    }
+    if (spec) r.perf.nof_speculative_jobs++;
+    if (e.job[1] < 0) e.job[1] = newJob(ch, p.sf, e, 1, ch.jobs[e.job[0]].p_a, spec ? 2 : 1);
     if (e.job[1] >= 0) wave.push_back(e.job[1]);
   }
   runJobs(ch, r, wave);
@@ -859,6 +916,7 @@ void Engine::commitChunk(Chunk& ch, JobRunner& r)
     const uint32_t now = commit_sf_cnt;
     commit_pos.store(commit_sf_cnt, std::memory_order_relaxed);
     if (cfg.mcs_tracking_mode && mcs_update_period && commit_sf_cnt && (commit_sf_cnt % mcs_update_period) == 0) ageTrackingDatabase();
+    if (cfg.harq_mode && commit_sf_cnt && (commit_sf_cnt % 10000u) == 0) harq_db.update_database(commit_sf_cnt);  // the 10 s timer, LTESniffer_Core.cc:487-494
     if (!c.searched) continue;
     const uint32_t k0 = ch.cdci_first[sf], k1 = ch.cdci_first[sf + 1];
     // DCICollection.cc:107-134: the table of every DCI of this subframe is fixed before any of them is decoded
@@ -896,11 +954,11 @@ void Engine::commitChunk(Chunk& ch, JobRunner& r)
       auto run = [&](int t) -> int {
         if (!(t ? has256 : has64)) return -1;
         if (d.job[t] >= 0 && ch.jres[d.job[t]].p_a != p_a_now) d.job[t] = -1;
-        if (d.job[t] >= 0 && ch.jres[d.job[t]].done) return d.job[t];
+        if (d.job[t] >= 0 && ch.jres[d.job[t]].done) { r.perf.nof_decode_jobs_used++; ch.jobs[d.job[t]].used = 1; return d.job[t]; }
         DlEntry& e = c.dl[d.di];  // slow path
         const int why = (e.job[t] >= 0 && d.job[t] < 0) ? 0 : (e.job[t] < 0 ? (e.job[1 - t] >= 0 ? 1 : 2) : 3);
         e.job[t] = d.job[t];
-        if (e.job[t] < 0) e.job[t] = newJob(ch, sf, e, t, p_a_now);
+        if (e.job[t] < 0) e.job[t] = newJob(ch, sf, e, t, p_a_now, 4);
         if (e.job[t] >= 0 && !ch.jobs[e.job[t]].done) {
           const double t0 = now_ms();
           static const bool dbg = getenv("LSN_DEBUG_ONDEMAND") != nullptr;
@@ -910,6 +968,7 @@ void Engine::commitChunk(Chunk& ch, JobRunner& r)
           r.perf.nof_ondemand_decodes++; r.perf.nof_ondemand_commit[why]++; r.perf.ms_ondemand_commit += now_ms() - t0;
         }
         d.job[t] = e.job[t];
+        if (d.job[t] >= 0) { r.perf.nof_decode_jobs_used++; ch.jobs[d.job[t]].used = 1; }
         return d.job[t];
       };
       // dl_sniffer_config_mimo's verdict 0 / -1 / -2 / -3 for the statistics: a job exists exactly when it was 0 (newJob), so the
@@ -930,13 +989,34 @@ void Engine::commitChunk(Chunk& ch, JobRunner& r)
         const int j = run(cur_t);
         mimo_ret = cur_has ? mimo_of(cur_t, j) : -1;
         if (j >= 0) {
-          const JobRes& jr = ch.jres[j];
+          const JobRes jr = ch.jres[j];  // (by value: a combined decode below appends to the chunk's vectors)
           for (int tb = 0; tb < 2; tb++) {
             crc[tb] = jr.crc[tb] != 0;
+            uint32_t poff = jr.payload_off[tb];
+            bool combined = false;
+            if (cfg.harq_mode && name[0] == 'C' && jr.enabled[tb]) {  // :943-1020: new transmission / retransmission / already decoded, per transport block
+              const DlEntry& e = c.dl[d.di];
+              const int tbs = ch.jobs[j].grant.tb[tb].tbs;
+              int ent = -1;
+              const HarqRet hr = harq_db.is_retransmission(d.rnti, e.dci.pid, tb, e.dci.tb[tb].ndi != 0, tbs, c.sfn, c.sf_idx, ent);
+              const size_t slot = ent < 0 ? 0 : ((size_t)ent * HarqDatabase::NPID + (e.dci.pid & 7u)) * 2 + (size_t)tb;
+              if (hr == HARQ_NEW_TX) {
+                if (!crc[tb]) harqStore(ch, r, j, tb, slot);   // srsran_softbuffer_rx_reset_tbs + this transmission (the buffer is only read again if the block failed)
+              } else if (hr == HARQ_RE_TX) {
+                crc[tb] = harqCombinedDecode(ch, r, j, tb, slot, poff);
+                combined = true;
+              } else if (hr == HARQ_DECODED) {
+                crc[tb] = false;                 // decoded 8 subframes ago: not decoded again, nothing written
+              }
+              if (hr == HARQ_NEW_TX || hr == HARQ_RE_TX) harq_db.update(ent, e.dci.pid, tb, c.sfn, c.sf_idx, crc[tb], e.dci.tb[tb].ndi != 0, e.dci.tb[tb].rv, tbs, now);
+            }
             if (crc[tb] && jr.len[tb] > 0) {
-              emitPdu(ch, r, name, jr.payload_off[tb], (uint32_t)jr.len[tb], d.rnti, c.tti, (uint8_t)tb);
-              if (name[0] == 'R') unpackRar(ch.h_payload.data() + jr.payload_off[tb], jr.len[tb], false);
-              if (name[0] == 'C') learn(jr, tb);
+              emitPdu(ch, r, name, poff, (uint32_t)jr.len[tb], d.rnti, c.tti, (uint8_t)tb);
+              if (name[0] == 'R') unpackRar(ch.h_payload.data() + poff, jr.len[tb], false);
+              if (name[0] == 'C') {
+                if (combined) learnUeConfig(ch.h_payload.data() + poff, jr.len[tb], d.rnti);  // (not pre-parsed: the block was decoded in this turn)
+                else learn(jr, tb);
+              }
             }
           }
         }
@@ -977,6 +1057,88 @@ void Engine::commitChunk(Chunk& ch, JobRunner& r)
       publishPrediction(d.rnti);
     }
   }
+  for (const DecodeJob& j : ch.jobs) {
+    if (!j.done) continue;
+    const int k = j.kind < 5 ? j.kind : 0;
+    r.perf.jobs_by_kind[k]++; r.perf.iters_by_kind[k] += j.iters;
+    if (!j.used) { r.perf.jobs_unused_by_kind[k]++; r.perf.iters_unused_by_kind[k] += j.iters; }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ HARQ soft buffers (harq_mode = 1)
+// All buffer traffic runs on the commit runner's stream in commit order, so the pool always holds what the reference's softbuffer_rx of that
+// (RNTI, process, TB) would hold at this point of the stream.  Block q of a transport block sits at slot * HARQ_SLOT_WORDS + q * HARQ_CB_WORDS.
+void Engine::harqStore(Chunk& ch, JobRunner& r, int job, int tb, size_t slot)
+{
+  const DecodeJob& j = ch.jobs[job];
+  const uint32_t n = j.keep_count[tb];
+  if (!n || n > HARQ_MAX_CB) return;
+  grow_host(r.h_cbs_pinned, r.h_cbs_cap, n, r.stream);
+  grow_dev(r.d_cbs, r.cbs_cap, n, r.stream);
+  for (uint32_t q = 0; q < n; q++) {
+    LsnCbDev cb = ch.keep_cbs[j.keep_first[tb] + q];
+    cb.e_off = cb.spp_off;                                        // this transmission, in the chunk's keep store
+    cb.spp_off = (uint32_t)(slot * HARQ_SLOT_WORDS + q * HARQ_CB_WORDS);
+    r.h_cbs_pinned[q] = cb;
+  }
+  lsn_launch_upload(r.d_cbs, r.h_cbs_pinned, n * sizeof(LsnCbDev), r.stream);
+  lsn_launch_harq_combine(r.d_cbs, n, ch.d_keep, d_harq_pool, true, r.stream);
+  HIP_CHECK(hipStreamSynchronize(r.stream));  // (the pinned descriptor mirror is reused by the next call)
+}
+
+bool Engine::harqCombinedDecode(Chunk& ch, JobRunner& r, int job, int tb, size_t slot, uint32_t& payload_off)
+{
+  const DecodeJob& j = ch.jobs[job];
+  const uint32_t n = j.keep_count[tb];
+  if (!n || n > HARQ_MAX_CB) return false;
+  hipStream_t st = r.stream;
+  grow_host(r.h_cbs_pinned, r.h_cbs_cap, n, st);
+  grow_dev(r.d_cbs, r.cbs_cap, n, st);
+  if (n > r.cbres_cap) { grow_dev(r.d_cbres, r.cbres_cap, n, st); }
+  grow_host(r.h_cbres_pinned, r.h_cbres_cap, n, st);
+  // descriptors in launch order (two-wave class first); results stay in transport-block order through res_idx
+  std::vector<LsnCbDev> cbs(n);
+  uint32_t out = 0, n128 = 0, kmax128 = 0, kmax64 = 0;
+  for (uint32_t q = 0; q < n; q++) {
+    LsnCbDev cb = ch.keep_cbs[j.keep_first[tb] + q];
+    cb.e_off = cb.spp_off;
+    cb.spp_off = (uint32_t)(slot * HARQ_SLOT_WORDS + q * HARQ_CB_WORDS);
+    cb.res_idx = q; cb.dep = LSN_CB_NODEP; cb.out_off = out; out += cb.out_bytes;
+    cbs[q] = cb;
+  }
+  std::stable_sort(cbs.begin(), cbs.end(), [](const LsnCbDev& a, const LsnCbDev& b) { return lsn_turbo_two_wave_class((int)a.K) && !lsn_turbo_two_wave_class((int)b.K); });
+  for (uint32_t q = 0; q < n; q++) {
+    r.h_cbs_pinned[q] = cbs[q];
+    if (lsn_turbo_two_wave_class((int)cbs[q].K)) { n128++; kmax128 = std::max(kmax128, cbs[q].K); } else kmax64 = std::max(kmax64, cbs[q].K);
+  }
+  grow_dev(r.d_payload, r.payload_cap, (size_t)out + 16, st);
+  grow_host(r.h_payload_pinned, r.h_payload_cap, (size_t)out + 16, st);
+  lsn_launch_upload(r.d_cbs, r.h_cbs_pinned, n * sizeof(LsnCbDev), st);
+  lsn_launch_harq_combine(r.d_cbs, n, ch.d_keep, d_harq_pool, false, st);
+  lsn_launch_turbo(cd, r.d_cbs, d_harq_pool, r.d_payload, r.d_cbres, n128, kmax128, n - n128, kmax64, st, nullptr);
+  lsn_launch_download(r.h_cbres_pinned, r.d_cbres, n * sizeof(LsnCbRes), st);
+  lsn_launch_download(r.h_payload_pinned, r.d_payload, out, st);
+  HIP_CHECK(hipEventRecord(r.ev_done, st));
+  waitEvent(r.ev_done);
+  r.perf.nof_ondemand_decodes++;
+  // transport-block verdict, as in runJobs
+  bool all_ok = true;
+  uint32_t rem = 0;
+  uint64_t bits_after = 0;
+  for (int q = (int)n - 1; q >= 0; q--) {
+    const LsnCbRes& cr = r.h_cbres_pinned[q];
+    all_ok = all_ok && cr.ok != 0;
+    r.perf.nof_turbo_iterations += cr.iters;
+    rem ^= crc24a_mulmod(cr.rem_a, crc24a_xpow(bits_after));
+    bits_after += 8ull * ch.keep_cbs[j.keep_first[tb] + q].out_bytes;
+  }
+  const int tbs = j.grant.tb[tb].tbs;
+  payload_off = (uint32_t)ch.h_payload.size();
+  ch.h_payload.resize(ch.h_payload.size() + (((size_t)out + 15) & ~(size_t)15));
+  std::memcpy(ch.h_payload.data() + payload_off, r.h_payload_pinned, out);
+  const uint8_t* pl = ch.h_payload.data() + payload_off;
+  const uint32_t par = ((uint32_t)pl[tbs / 8] << 16) | ((uint32_t)pl[tbs / 8 + 1] << 8) | pl[tbs / 8 + 2];
+  return all_ok && rem == 0 && par != 0 && bits_after == (uint64_t)tbs + 24;
 }
 
 // decode threads: each takes the next chunk of the queue, plans and runs its PDSCH decodes on its own streams and hands the chunk
@@ -1215,7 +1377,7 @@ void Engine::frontLoop()
         ch.update_meta_period = job.update_meta_period;
         ch.force_meta = job.force_meta && ci == 0;
         ch.gseq = job.gseq0 + ci;
-        ch.jobs.clear(); ch.jres.clear(); ch.tapjobs.clear(); ch.cdci.clear(); ch.setup_cfgs.clear(); ch.h_payload.clear(); ch.recs.clear(); ch.err.clear();
+        ch.jobs.clear(); ch.jres.clear(); ch.tapjobs.clear(); ch.keep_cbs.clear(); ch.keep_n = 0; ch.cdci.clear(); ch.setup_cfgs.clear(); ch.h_payload.clear(); ch.recs.clear(); ch.err.clear();
         for (uint32_t i = 0; i < ch.nsf; i++) ch.ctx[i].reset(ch.start_tti + i);
         ch.st_a = stream_a[(slot_counter - 1) % NSTREAM_A];
         ch.trace_id = ci;
@@ -1545,7 +1707,9 @@ int Engine::processHost(const float* iq, uint32_t nsf_total, uint32_t start_tti,
 // taps address the LAST chunk of the last process call (tests use calls of at most max_batch subframes)
 long Engine::tap(int what, uint32_t sf, void* out, size_t cap)
 {
-  if (!cell_set || !last_chunk || sf >= last_chunk->nsf) return LSN_ERROR_INVALID_INPUTS;
+  if (!cell_set || !last_chunk) return LSN_ERROR_INVALID_INPUTS;
+  const bool by_job = what >= LSN_TAP_PDSCH_JOBS && what <= LSN_TAP_CB_RESULT;  // stage-C taps are indexed by decode job
+  if (!by_job && sf >= last_chunk->nsf) return LSN_ERROR_INVALID_INPUTS;
   Chunk& ch = *last_chunk;
   const size_t A = dlRx(), P = cell.nof_ports, nre = cd.nre;
   auto d2h = [&](const void* src, size_t n) -> long {

@@ -26,10 +26,12 @@ struct DecodeJob {
   uint32_t sf = 0; PdschGrant grant; uint16_t rnti = 0;
   float p_a = 0.0f;  // pdsch_cfg->p_a this decode runs with (dB)
   bool planned = false, done = false;
+  uint8_t kind = 0, used = 0;  // lsn_perf_t::jobs_by_kind; used: the commit stage looked at the result
   uint32_t cb_first = 0, cb_count[2] = {0, 0};
   uint32_t payload_off[2] = {0, 0};
   bool crc[2] = {false, false};
   uint32_t iters = 0;
+  uint32_t keep_first[2] = {0, 0}, keep_count[2] = {0, 0};  // harq_mode: this job's code blocks in Chunk::keep_cbs (their soft data sits in Chunk::d_keep)
 };
 
 // Compact views for the sequential commit thread (it walks them linearly instead of chasing the wide DlEntry / DecodeJob records that
@@ -70,6 +72,10 @@ struct Chunk {
   uint32_t ul_epoch = 0;             // Engine::ul_cfg_epoch when the DCI 0 grants of this chunk were converted
   std::vector<DecodeJob> jobs;
   std::vector<JobRes> jres;            // per job, same index as jobs
+  // harq_mode: the de-rate-matched soft data of every decode launch of this chunk is kept until the chunk is committed - the commit decides which
+  // transport blocks go into (new transmission that failed) or are combined with (retransmission) the soft buffers of their HARQ processes
+  uint32_t* d_keep = nullptr; size_t keep_cap = 0, keep_n = 0;
+  std::vector<LsnCbDev> keep_cbs;      // descriptors of the kept blocks (spp_off = word offset in d_keep)
   std::vector<TapJob> tapjobs;         // per job, filled only while the stage-C taps are switched on
   std::vector<CommitDci> cdci;         // built by planJobs
   std::vector<uint32_t> cdci_first;    // [nsf + 1] first CommitDci of each subframe
@@ -246,8 +252,14 @@ private:
     if (e.rnti >= RARNTI_START && e.rnti <= RARNTI_END) return true;
     return e.rnti > RARNTI_END && (e.format == FORMAT1 || e.format == FORMAT1A) && e.rnti != SIRNTI;
   }
-  int newJob(Chunk& ch, uint32_t sf, const DlEntry& e, int table, float p_a = 0.0f);
+  int newJob(Chunk& ch, uint32_t sf, const DlEntry& e, int table, float p_a = 0.0f, int kind = 0);
   void learnUeConfig(const uint8_t* pdu, int len, uint16_t rnti);
+  // HARQ soft combining (harq_mode = 1, DL mode, one engine): database + device pool of soft buffers, driven by the commit stage
+  HarqDatabase harq_db;
+  uint32_t* d_harq_pool = nullptr;
+  static constexpr size_t HARQ_CB_WORDS = LSN_SPP_WORDS(6144u), HARQ_MAX_CB = 16, HARQ_SLOT_WORDS = HARQ_CB_WORDS * HARQ_MAX_CB;
+  void harqStore(Chunk& ch, JobRunner& r, int job, int tb, size_t slot);                       // a failed new transmission goes into the buffer
+  bool harqCombinedDecode(Chunk& ch, JobRunner& r, int job, int tb, size_t slot, uint32_t& payload_off);  // retransmission: combine, decode, keep
 public:
   UeSpecConfig ueConfig(uint16_t rnti) { std::lock_guard<std::mutex> lk(mcs_mtx); return cfg.sniffer_mode == 1 ? ulUeConfig(rnti) : mcs_tracking.get_ue_config_rnti(rnti); }
 private:

@@ -844,4 +844,50 @@ uint32_t crc24a_xpow(uint64_t n)
   return result;
 }
 
+// ------------------------------------------------------------------------------------------------ HARQ database
+HarqRet HarqDatabase::is_retransmission(uint16_t rnti, uint32_t pid, int tid, bool ndi, int tbs, uint32_t sfn, uint32_t sf_idx, int& entity)
+{
+  int found = -1, avail = -1;
+  for (int i = 0; i < NENT; i++) {
+    if (ent[i].rnti == rnti) found = i;
+    else if (ent[i].rnti == 0) avail = i;  // the LAST free entity (HARQ.cc:84-90)
+  }
+  entity = found;
+  HarqRet r;
+  if (found < 0 && avail >= 0) {
+    ent[avail].rnti = rnti;
+    if (nof_aval > 0) nof_aval--;
+    entity = avail;
+    r = HARQ_NEW_TX;
+  } else if (found < 0) {
+    r = HARQ_FULL_BUFFER;
+  } else {
+    const Tb& t = ent[found].tb[pid & 7][tid];
+    const uint32_t last_tti = t.sfn * 10 + t.sf_idx, cur_tti = sfn * 10 + sf_idx;
+    if (!(cur_tti - last_tti == 8 || cur_tti + 10240 - last_tti == 8)) r = HARQ_NEW_TX;  // comparetti
+    else if (ndi != t.ndi || t.is_first || t.tbs != tbs) r = HARQ_NEW_TX;
+    else r = t.last_decoded ? HARQ_DECODED : HARQ_RE_TX;
+  }
+  stats[r]++;
+  return r;
+}
+void HarqDatabase::update(int entity, uint32_t pid, int tid, uint32_t sfn, uint32_t sf_idx, bool last_decoded, bool ndi, int rv, int tbs, uint32_t now)
+{
+  if (entity < 0) return;
+  Entity& e = ent[entity];
+  e.time = now;
+  Tb& t = e.tb[pid & 7][tid];
+  t.sfn = sfn; t.sf_idx = sf_idx; t.last_decoded = last_decoded; t.ndi = ndi; t.rv = rv; t.tbs = tbs; t.is_first = false;
+}
+void HarqDatabase::update_database(uint32_t now)
+{
+  if (nof_aval > 10) return;
+  for (Entity& e : ent)
+    if ((now - e.time) / 1000u > 5u) {  // (free entities included, as in the reference: nof_aval over-counts)
+      e.rnti = 0; e.time = 0;
+      for (auto& p : e.tb) for (Tb& t : p) { t.is_first = true; t.last_decoded = false; t.tbs = 0; t.sf_idx = 0; }
+      nof_aval++;
+    }
+}
+
 }  // namespace lsn

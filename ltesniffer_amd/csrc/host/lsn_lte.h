@@ -243,6 +243,28 @@ private:
   static constexpr uint16_t rar_thresold = 3;
 };
 
+// ---- HARQ (src/include/HARQ.h, src/src/HARQ.cc): which transport block of a known-table C-RNTI grant is a new transmission, a retransmission to be
+// soft-combined with the buffer of its (RNTI, process, TB), or already decoded.  150 entities from the constructor + 150 from init_HARQ (HARQ.cc:15-20,
+// 48-52), 8 processes x 2 transport blocks; clock() is replaced by the subframe count; the per-TB mutexes only matter between worker threads
+// (DL_SNIFFER_HARQ_BUSY cannot occur in the sequential commit order).  Off in the reference (ArgManager.cc:50,211-213).
+enum HarqRet { HARQ_NEW_TX = 0, HARQ_RE_TX = 1, HARQ_FULL_BUFFER = 2, HARQ_DECODED = 3, HARQ_BUSY = 4 };
+class HarqDatabase {
+public:
+  static constexpr int NENT = 300, NPID = 8;
+  HarqDatabase() : ent(NENT) {}
+  // HARQ::is_retransmission (HARQ.cc:71-135); entity: index of the RNTI's entity (-1: none) - with pid and tid it names the soft buffer
+  HarqRet is_retransmission(uint16_t rnti, uint32_t pid, int tid, bool ndi, int tbs, uint32_t sfn, uint32_t sf_idx, int& entity);
+  // HARQ::updateHARQRNTI / updateProcess (HARQ.cc:155-190)
+  void update(int entity, uint32_t pid, int tid, uint32_t sfn, uint32_t sf_idx, bool last_decoded, bool ndi, int rv, int tbs, uint32_t now);
+  void update_database(uint32_t now);   // HARQ::updateHARQDatabase (HARQ.cc:206-238), the 10 s timer of LTESniffer_Core.cc:487-494
+  uint64_t stats[5] = {0, 0, 0, 0, 0};  // verdicts so far, by HarqRet
+private:
+  struct Tb { uint32_t sfn = 0, sf_idx = 0; bool last_decoded = false, ndi = false, is_first = true; int rv = 0, tbs = 0; };
+  struct Entity { uint16_t rnti = 0; uint32_t time = 0; Tb tb[NPID][2]; };
+  std::vector<Entity> ent;
+  int nof_aval = 150;
+};
+
 // ---- GF(2) helpers for the transport-block CRC combine ----
 uint32_t crc24a_xpow(uint64_t n);                 // x^n mod g_CRC24A
 uint32_t crc24a_mulmod(uint32_t a, uint32_t b);   // a*b mod g_CRC24A

@@ -78,7 +78,8 @@ void Engine::freeDevice()
     df(mib_d_iq); df(mib_d_llr); df(mib_d_cand);
     for (auto& fb : file_buf) { if (fb.h_raw) (void)hipHostFree(fb.h_raw); df(fb.d_raw); df(fb.d_iq); fb.h_raw = nullptr; fb.bytes = 0; }
   }
-  d_dphi = nullptr; d_iq_staging = nullptr; staging_sf = 0;
+  d_dphi = nullptr; d_iq_staging = nullptr; staging_sf = 0; d_harq_pool = nullptr;
+  for (auto& ch : chunks) { if (ch.d_keep) (void)hipFree(ch.d_keep); ch.d_keep = nullptr; ch.keep_cap = ch.keep_n = 0; }
   last_chunk = nullptr;
 }
 
@@ -330,6 +331,10 @@ void Engine::buildTables()
       lsn_turbo_il_fill(il.data() + turbo_il_offset(K), K, lsn_qpp_table[i][1], lsn_qpp_table[i][2]);
     }
     cd.turbo_il = upload(dev_allocs, il);
+  }
+  if (cfg.harq_mode) {  // soft buffers of 300 entities x 8 processes x 2 transport blocks, 16 code blocks of K = 6144 each: 1.9 GB of the 288
+    d_harq_pool = dalloc<uint32_t>(dev_allocs, (size_t)HarqDatabase::NENT * HarqDatabase::NPID * 2 * HARQ_SLOT_WORDS);
+    harq_db = HarqDatabase();
   }
   // pipeline slots, decode runners, staging
   for (int i = 0; i < nslots; i++) allocChunk(chunks[i]);

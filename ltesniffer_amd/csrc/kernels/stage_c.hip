@@ -146,9 +146,17 @@ __global__ __launch_bounds__(192) void k_pdsch_demod(LsnCellDev c, const LsnGran
       break;
     }
     case 1: {  // transmit diversity (SFBC), pairs of consecutive REs of the mapping order
+      // A pair never leaves its PRB here: an RE without partner inside the PRB (odd number of PDSCH REs in a PRB of this symbol) carries zero soft
+      // bits, as in the oracle's zero-initialised buffer.  The kernel writes those zeros itself (rounds 1-3 cleared the whole arena in front of
+      // every launch: 0.29 MB of HBM traffic per subframe and one fill kernel per decode launch).
+      const unsigned hi = mask >> (kk + 1);
+      const bool lone = (idx & 1u) ? (mask & ((1u << kk) - 1u)) == 0u : hi == 0u;
+      if (lone) {
+        const uint32_t n0 = idx * g.qm[0];
+        for (uint32_t b = 0; b < g.qm[0]; b++) out0[n0 + b] = 0;
+        return;
+      }
       if (idx & 1u) return;
-      unsigned hi = mask >> (kk + 1);
-      if (!hi) return;
       const int k2 = k + 1 + (__ffs(hi) - 1);
       float x0r = 0, x0i = 0, x1r = 0, x1i = 0, hh = 0;
       for (int rx = 0; rx < A; rx++) {
@@ -301,6 +309,35 @@ void lsn_launch_rm(const LsnCbDev* cb, const int16_t* llr, uint32_t* spp, uint32
   const uint32_t seg = emax < cap ? emax : cap;
   const size_t lds = (((size_t)seg + 16) * 2 + 15) & ~(size_t)15;  // + the skew in front of e[0] and the tail of the last 16-byte load
   if (ncb) hipLaunchKernelGGL(k_rm, dim3(ncb), dim3(RM_NT), lds, s, cb, llr, spp, seg);
+}
+
+// ------------------------------------------------------------------------------------------------ HARQ soft combining
+// The soft buffer of a (RNTI, HARQ process, transport block) holds the de-rate-matched code blocks of the transmissions so far in the decoder's own
+// packed format (k_rm's output: K words of three 10-bit fields + 12 termination values).  A retransmission is combined field by field,
+// acc = clip(acc + cur, +-511), and decoded from the buffer; a new transmission overwrites it (srsran_softbuffer_rx_reset_tbs).  One workgroup per code
+// block; LsnCbDev::spp_off = the block's words in the buffer pool, LsnCbDev::e_off = the words of the current transmission (in `cur`).
+__global__ __launch_bounds__(256) void k_harq_combine(const LsnCbDev* __restrict__ cbs, const uint32_t* __restrict__ cur, uint32_t* __restrict__ pool, uint32_t overwrite)
+{
+  const LsnCbDev cb = cbs[blockIdx.x];
+  const uint32_t* c = cur + cb.e_off;
+  uint32_t* a = pool + cb.spp_off;
+  const int K = (int)cb.K;
+  auto clip = [](int v) { return v > LSN_LLR_CLIP ? LSN_LLR_CLIP : (v < -LSN_LLR_CLIP ? -LSN_LLR_CLIP : v); };
+  for (int t = threadIdx.x; t < K + 12; t += 256) {
+    const uint32_t w = c[t];
+    if (overwrite) { a[t] = w; continue; }
+    const uint32_t o = a[t];
+    if (t < K) {
+      const int v0 = clip(((int)(w << 22) >> 22) + ((int)(o << 22) >> 22)), v1 = clip(((int)(w << 12) >> 22) + ((int)(o << 12) >> 22)), v2 = clip(((int)(w << 2) >> 22) + ((int)(o << 2) >> 22));
+      a[t] = ((uint32_t)v0 & 0x3FFu) | (((uint32_t)v1 & 0x3FFu) << 10) | (((uint32_t)v2 & 0x3FFu) << 20);
+    } else {
+      a[t] = (uint32_t)clip((int)w + (int)o);
+    }
+  }
+}
+void lsn_launch_harq_combine(const LsnCbDev* cbs, uint32_t ncb, const uint32_t* cur, uint32_t* pool, bool overwrite, hipStream_t s)
+{
+  if (ncb) hipLaunchKernelGGL(k_harq_combine, dim3(ncb), dim3(256), 0, s, cbs, cur, pool, overwrite ? 1u : 0u);
 }
 
 // ------------------------------------------------------------------------------------------------ turbo decoder

@@ -487,6 +487,17 @@ int o_turbo_decode_cb(const int16_t* d3, int K, int max_iter, uint32_t crc_poly,
 int o_pdsch_decode_tb(const int16_t* e, int G, int tbs, int Qm, int NL, int rv, int max_iter, uint8_t* payload,
                       int* iters_total)
 {
+  return o_pdsch_decode_tb_harq(e, G, tbs, Qm, NL, rv, max_iter, payload, iters_total, NULL, 0);
+}
+
+/* ... with a HARQ soft buffer (the softbuffer_rx of srsran_ue_dl_decode_pdsch, HARQ.cc:71-190 / DL_Sniffer_PDSCH.cc:955-990): acc holds, per code
+ * block, the de-rate-matched streams d0|d1|d2 of the transmissions so far (O_HARQ_CB_STRIDE int16 each).  combine = 0: a new transmission, the
+ * buffer is overwritten (srsran_softbuffer_rx_reset_tbs); combine = 1: a retransmission, the streams of this redundancy version are added to the
+ * buffer, the sum clipped to the decoder's 10-bit soft values, and decoder and buffer both see the combined streams.  Design parameter of this
+ * restatement (srsRAN keeps int16 circular buffers; parity unpinned): the buffer holds clipped 10-bit values. */
+int o_pdsch_decode_tb_harq(const int16_t* e, int G, int tbs, int Qm, int NL, int rv, int max_iter, uint8_t* payload,
+                           int* iters_total, int16_t* acc, int combine)
+{
   o_cbsegm_t s;
   if (o_cbsegm(&s, tbs) || Qm <= 0 || G <= 0) return 0;
   int Gp = G / (NL * Qm), gamma = Gp % s.C;
@@ -501,6 +512,15 @@ int o_pdsch_decode_tb(const int16_t* e, int G, int tbs, int Qm, int NL, int rv, 
     int ok = 0;
     if (rp + E > G) E = G - rp;
     o_rm_turbo_rx_cb(e + rp, E, K, F, rv, d3);
+    if (acc) {
+      int16_t* a = acc + (size_t)r * O_HARQ_CB_STRIDE;
+      if (combine)
+        for (int i = 0; i < 3 * (K + 4); i++) {
+          int v = (int)a[i] + (int)d3[i];
+          d3[i] = (int16_t)(v > LLR_CLIP ? LLR_CLIP : (v < -LLR_CLIP ? -LLR_CLIP : v));
+        }
+      memcpy(a, d3, sizeof(int16_t) * 3 * (size_t)(K + 4));
+    }
     int n = o_turbo_decode_cb(d3, K, max_iter, s.C > 1 ? O_CRC24B : O_CRC24A, cb, &ok);
     its += n > 0 ? n : 0;
     if (o_trace_enabled()) o_trace_cb(K, F, E, rv, d3, n, ok);

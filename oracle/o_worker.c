@@ -42,6 +42,16 @@ typedef struct {
   uint32_t time, nof_active, nof_success_mgs, nof_unsupport_mimo, nof_pinfo, nof_other_mimo;
 } mcs_entry_t;
 
+/* ---------------- HARQ (src/include/HARQ.h, src/src/HARQ.cc) ----------------
+ * 150 entities from the constructor + 150 from init_HARQ(harq_mode) (HARQ.cc:15-20,48-52), 8 processes x 2 transport blocks each; the soft buffer of
+ * a (RNTI, process, TB) is allocated when first used.  clock() is replaced by the subframe count; the per-TB mutexes only
+ * matter between worker threads (DL_SNIFFER_HARQ_BUSY cannot occur in the sequential order this oracle defines). */
+#define O_HARQ_ENTITIES 300
+enum { O_HARQ_NEW_TX = 0, O_HARQ_RE_TX, O_HARQ_FULL_BUFFER, O_HARQ_DECODED, O_HARQ_BUSY };
+typedef struct { int last_decoded, ndi, rv, tbs, is_first; } o_harq_grant_t;
+typedef struct { uint32_t sfn, sf_idx; o_harq_grant_t grant; int16_t* acc; } o_harq_tb_t;
+struct o_harq_entity { uint16_t rnti; uint32_t time; uint32_t nof_active, nof_success, nof_retx_success, nof_retx[8]; o_harq_tb_t tb[8][2]; };
+
 struct o_worker {
   o_worker_cfg_t cfg;
   o_regs_t regs;
@@ -58,6 +68,10 @@ struct o_worker {
   uint32_t mcs_update_period; /* get_interval() x 1000 subframes (LTESniffer_Core.cc:473-485), 0 = never */
   uint32_t mcs_interval;      /* seconds, MCSTracking.h:162 */
   uint32_t nof_mcs_updates;
+  int harq_mode;                    /* -m harq: DL HARQ soft combining (HARQ.cc; off in the reference: ArgManager.cc:50,211-213) */
+  struct o_harq_entity* harq;       /* [O_HARQ_ENTITIES] */
+  int harq_nof_aval;
+  uint32_t harq_stats[5];           /* verdicts of is_retransmission so far: NEW_TX, RE_TX, FULL_BUFFER, DECODED, BUSY */
   int second_turbo, second_viterbi; /* second-opinion decoders (o_second.c) instead of the production restatement */
   o_ue_cfg_t* uecfg; /* [65536] ue_spec_config of the tracking-database entries (MCSTracking.h:37-43) */
   o_ue_cfg_t default_cfg;
@@ -693,8 +707,69 @@ static void unpack_rar(o_worker_t* w, const uint8_t* p, int len)
   }
 }
 
+void o_worker_set_harq(o_worker_t* w, int mode)
+{
+  w->harq_mode = mode;
+  if (mode && !w->harq) {
+    w->harq = (struct o_harq_entity*)calloc(O_HARQ_ENTITIES, sizeof(struct o_harq_entity));
+    for (int i = 0; i < O_HARQ_ENTITIES; i++)
+      for (int p = 0; p < 8; p++)
+        for (int t = 0; t < 2; t++) w->harq[i].tb[p][t].grant.is_first = 1; /* dl_sniffer_harq_grant_t default */
+    w->harq_nof_aval = 150; /* nof_aval = DL_SNIFFER_MAX_HARQ_SIZE */
+  }
+}
+void o_worker_harq_stats(o_worker_t* w, uint32_t* out5) { memcpy(out5, w->harq_stats, sizeof(w->harq_stats)); }
+
+/* HARQ::is_retransmission, HARQ.cc:71-135 */
+static int harq_is_retx(o_worker_t* w, uint16_t rnti, int pid, int tid, int ndi, int tbs, uint32_t sfn, uint32_t sf_idx, struct o_harq_entity** ent)
+{
+  struct o_harq_entity *found = NULL, *avail = NULL;
+  for (int i = 0; i < O_HARQ_ENTITIES; i++) {
+    if (w->harq[i].rnti == rnti) found = &w->harq[i];
+    else if (w->harq[i].rnti == 0) avail = &w->harq[i]; /* the LAST free entity */
+  }
+  *ent = found;
+  if (!found && avail) {
+    avail->rnti = rnti;
+    if (w->harq_nof_aval > 0) w->harq_nof_aval--;
+    *ent = avail;
+    return O_HARQ_NEW_TX;
+  }
+  if (!found) return O_HARQ_FULL_BUFFER;
+  o_harq_tb_t* t = &found->tb[pid][tid];
+  uint32_t last_tti = t->sfn * 10 + t->sf_idx, cur_tti = sfn * 10 + sf_idx;
+  if (!(cur_tti - last_tti == 8 || cur_tti + 10240 - last_tti == 8)) return O_HARQ_NEW_TX; /* comparetti */
+  if (ndi != t->grant.ndi || t->grant.is_first || t->grant.tbs != tbs) return O_HARQ_NEW_TX;
+  return t->grant.last_decoded ? O_HARQ_DECODED : O_HARQ_RE_TX;
+}
+/* HARQ::updateHARQRNTI / updateProcess, HARQ.cc:155-190 */
+static void harq_update(o_worker_t* w, struct o_harq_entity* e, int pid, int tid, uint32_t sfn, uint32_t sf_idx, int last_decoded, int ndi, int rv, int tbs)
+{
+  e->time = w->sf_count;
+  o_harq_tb_t* t = &e->tb[pid][tid];
+  t->sfn = sfn; t->sf_idx = sf_idx;
+  t->grant.last_decoded = last_decoded; t->grant.ndi = ndi; t->grant.rv = rv; t->grant.tbs = tbs; t->grant.is_first = 0;
+}
+/* HARQ::updateHARQDatabase, HARQ.cc:206-238, driven by the 10 s timer of LTESniffer_Core.cc:487-494: once fewer than 11 entities are free, the ones
+ * idle for more than `interval` = 5 whole seconds are released */
+static void harq_update_database(o_worker_t* w)
+{
+  if (w->harq_nof_aval > 10) return;
+  for (int i = 0; i < O_HARQ_ENTITIES; i++) {
+    struct o_harq_entity* e = &w->harq[i];
+    if ((w->sf_count - e->time) / 1000u > 5u) {
+      e->rnti = 0; e->time = 0;
+      for (int p = 0; p < 8; p++)
+        for (int t = 0; t < 2; t++) { e->tb[p][t].grant.is_first = 1; e->tb[p][t].grant.last_decoded = 0; e->tb[p][t].grant.tbs = 0; e->tb[p][t].sf_idx = 0; }
+      w->harq_nof_aval++;
+    }
+  }
+}
+
 /* one srsran_ue_dl_decode_pdsch call: returns crc[2]; payload of TB i at w->payload + i*8192 */
-static void decode_grant(o_worker_t* w, const dl_entry_t* e, const o_pdsch_grant_t* g, int* crc)
+static void decode_grant_harq(o_worker_t* w, const dl_entry_t* e, const o_pdsch_grant_t* g, int* crc, int16_t* const* acc, const int* combine);
+static void decode_grant(o_worker_t* w, const dl_entry_t* e, const o_pdsch_grant_t* g, int* crc) { decode_grant_harq(w, e, g, crc, NULL, NULL); }
+static void decode_grant_harq(o_worker_t* w, const dl_entry_t* e, const o_pdsch_grant_t* g, int* crc, int16_t* const* acc, const int* combine)
 {
   crc[0] = crc[1] = 0;
   if (!(g->tb[0].enabled || g->tb[1].enabled)) return;
@@ -719,6 +794,10 @@ static void decode_grant(o_worker_t* w, const dl_entry_t* e, const o_pdsch_grant
       const int16_t* llr = (g->tb[i].cw_idx & 1) ? w->llr1 : w->llr0;
       int its = 0;
       o_trace_set_tb(i);
+      if (acc && acc[i])
+        crc[i] = o_pdsch_decode_tb_harq(llr, g->tb[i].nof_bits, g->tb[i].tbs, g->tb[i].mod, g->tx_scheme == O_TX_DIVERSITY ? 2 : 1, g->tb[i].rv, w->cfg.max_turbo_iter,
+                                        w->payload + i * 8192 * 2, &its, acc[i], combine[i]);
+      else
       crc[i] = (w->second_turbo ? o_pdsch_decode_tb_second : o_pdsch_decode_tb)(llr, g->tb[i].nof_bits, g->tb[i].tbs, g->tb[i].mod, g->tx_scheme == O_TX_DIVERSITY ? 2 : 1,
                                  g->tb[i].rv, w->cfg.max_turbo_iter, w->payload + i * 8192 * 2, &its);
       w->total_iters += (uint64_t)its;
@@ -744,7 +823,30 @@ static void decode_dl_mode(o_worker_t* w)
     if (e->mcs_table == O_TABLE_64QAM || e->mcs_table == O_TABLE_256QAM) { /* :932-1083 */
       mimo_ret = o_config_mimo(&w->cfg.cell, e->format, &e->dci, cur);
       if (mimo_ret == 0) {
-        decode_grant(w, e, cur, crc);
+        if (w->harq_mode && name[0] == 'C') { /* :943-1020: new transmission / retransmission / already decoded, per transport block */
+          o_pdsch_grant_t gg = *cur; /* pdsch_cfg->grant */
+          int harq_ret[2] = {O_HARQ_NEW_TX, O_HARQ_NEW_TX}, combine[2] = {0, 0};
+          int16_t* acc[2] = {NULL, NULL};
+          struct o_harq_entity* ent[2] = {NULL, NULL};
+          for (int i = 0; i < 2; i++)
+            if (gg.tb[i].enabled) {
+              harq_ret[i] = harq_is_retx(w, e->rnti, (int)e->dci.pid, i, (int)e->dci.tb[i].ndi, gg.tb[i].tbs, w->sfn, w->sf_idx, &ent[i]);
+              w->harq_stats[harq_ret[i]]++;
+              if (harq_ret[i] == O_HARQ_NEW_TX || harq_ret[i] == O_HARQ_RE_TX) {
+                o_harq_tb_t* t = &ent[i]->tb[e->dci.pid][i];
+                if (!t->acc) t->acc = (int16_t*)calloc((size_t)O_HARQ_MAX_CB * O_HARQ_CB_STRIDE, sizeof(int16_t));
+                acc[i] = t->acc; combine[i] = harq_ret[i] == O_HARQ_RE_TX;
+              } else if (harq_ret[i] == O_HARQ_DECODED) {
+                gg.tb[i].enabled = 0; /* decoded 8 subframes ago: the block is not decoded again (and nothing is written for it) */
+              }
+            }
+          if (gg.tb[0].enabled || gg.tb[1].enabled) decode_grant_harq(w, e, &gg, crc, acc, combine);
+          for (int i = 0; i < 2; i++)
+            if (gg.tb[i].enabled && (harq_ret[i] == O_HARQ_NEW_TX || harq_ret[i] == O_HARQ_RE_TX))
+              harq_update(w, ent[i], (int)e->dci.pid, i, w->sfn, w->sf_idx, crc[i], (int)e->dci.tb[i].ndi, e->dci.tb[i].rv, cur->tb[i].tbs);
+        } else {
+          decode_grant(w, e, cur, crc);
+        }
         for (int tb = 0; tb < 2; tb++) {
           int len = cur->tb[tb].tbs / 8;
           if (crc[tb] && len > 0) {
@@ -807,6 +909,7 @@ int o_worker_work(o_worker_t* w, const ocf_t* const* iq, uint32_t sf_idx, uint32
   if (update_meta) update_formats(w); /* SubframeWorker.cc:148-151 */
   /* LTESniffer_Core.cc:473-499: every get_interval() x 1000 subframes the tracking database is aged (DL mode, mcs_tracking_mode on) */
   if (w->cfg.mcs_tracking_mode && w->mcs_update_period && w->sf_count && (w->sf_count % w->mcs_update_period) == 0) mcs_update_database(w);
+  if (w->harq_mode && w->sf_count && (w->sf_count % 10000u) == 0) harq_update_database(w); /* the 10 s timer, LTESniffer_Core.cc:487-494 */
   uint32_t dphi = cfo_hz != 0.0f ? o_nco_dphi(cfo_hz, o_fft_size(cell->nof_prb)) : 0;
   /* srsran_ue_dl_decode_fft_estimate, DCISearch.cc:562 */
   for (uint32_t rx = 0; rx < w->cfg.nof_rx; rx++) o_ofdm_rx(cell, iq[rx], dphi, w->grid + rx * 14u * nre);

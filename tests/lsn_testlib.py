@@ -50,7 +50,7 @@ class TxgCfg(C.Structure):
                 ("sib_period", C.c_uint32), ("rar_period", C.c_uint32), ("paging_period", C.c_uint32),
                 ("start_tti", C.c_uint32), ("fixed_L", C.c_uint32), ("pct_rv", C.c_uint32), ("pct_cqi_req", C.c_uint32), ("pct_hop", C.c_uint32), ("pusch_hop_offset", C.c_uint32),
                 ("msg4_period", C.c_uint32), ("msg4_p_a_idx", C.c_uint32), ("si_len", C.c_uint32 * 2), ("si_msg", (C.c_uint8 * 96) * 2),
-                ("pg_len", C.c_uint32), ("pg_msg", C.c_uint8 * 96)]
+                ("pg_len", C.c_uint32), ("pg_msg", C.c_uint8 * 96), ("pct_harq", C.c_uint32)]
 
 
 class TxgPdu(C.Structure):
@@ -150,6 +150,8 @@ def scenario(name, seed=1, **over):
     base = dict(nof_prb=100, nof_ports=2, cell_id=1, phich_ng_x6=1, nof_rx=2, snr_db=30.0, cfo_hz=0.0, delay_samples=0,
                 seed=seed, n_rnti=32, dl_min=6, dl_max=6, ul_min=2, ul_max=2, cfi=3, mix_tm3_pct=0, mix_tm4_pct=0,
                 pct_256qam=0, mcs_min=0, mcs_max=28, sib_period=1, rar_period=0, paging_period=0, start_tti=0, fixed_L=0, pct_rv=0, pct_cqi_req=0, pct_hop=0, pusch_hop_offset=0, msg4_period=0, msg4_p_a_idx=4)
+    if "pct_harq" in over:  # (only present when asked for: the scenario dict of the gated cfg3 stream is part of cached file keys)
+        base["pct_harq"] = 0
     presets = {
         # config 1: 10 MHz, single RNTI, TM1 QPSK, 1 port / 1 rx
         "cfg1": dict(nof_prb=50, nof_ports=1, nof_rx=1, snr_db=20.0, cfo_hz=300.0, n_rnti=1, dl_min=1, dl_max=1, ul_min=0,
@@ -305,6 +307,18 @@ class OracleWorker:
     def set_mcs_update_interval(self, seconds):
         self.lib.o_worker_set_mcs_update_interval.argtypes = [C.c_void_p, C.c_uint32]
         self.lib.o_worker_set_mcs_update_interval(self.h, seconds)
+
+    def set_harq(self, mode=1):
+        """DL HARQ soft combining (HARQ.cc; harq_mode is unreachable in the reference's CLI, ArgManager.cc:50,211-213)"""
+        self.lib.o_worker_set_harq.argtypes = [C.c_void_p, C.c_int]
+        self.lib.o_worker_set_harq(self.h, int(mode))
+
+    def harq_stats(self):
+        """verdicts of is_retransmission so far: [NEW_TX, RE_TX, FULL_BUFFER, DECODED, BUSY]"""
+        st = (C.c_uint32 * 5)()
+        self.lib.o_worker_harq_stats.argtypes = [C.c_void_p, C.c_void_p]
+        self.lib.o_worker_harq_stats(self.h, st)
+        return list(st)
 
     def total_iters(self):
         """turbo iterations summed over every code block of every decode call so far"""

@@ -388,3 +388,32 @@ def test_a_failing_chunk_is_reported_and_does_not_wedge_the_pipeline():
     phy.process_device(d_iq.data_ptr(), nsf, (tti0 + nsf) % 10240, 0, torch.cuda.current_stream().cuda_stream)
     assert len(gpu_records(phy)) >= 0.8 * len(orecs)
     phy.close()
+
+
+def test_harq_soft_combining_matches_oracle():
+    """harq_mode = 1 (HARQ.cc:71-190, DL_Sniffer_PDSCH.cc:943-1020): retransmissions 8 subframes after a failed transport block are
+    combined with the soft buffer of their HARQ process on the GPU (k_harq_combine), blocks decoded before are not decoded again - record stream
+    identical to the oracle's, which differs from the stream without HARQ"""
+    sc = scenario("small", seed=93, n_rnti=3, dl_min=2, dl_max=2, ul_min=0, ul_max=0, mcs_min=18, mcs_max=22, snr_db=11.0, pct_harq=60)
+    tti0, iq, _ = gen_subframes(sc, 90)
+    ow, _, orecs = run_oracle(sc, tti0, iq, taps=False, harq_mode=1, mcs_tracking_mode=0)
+    _, _, orecs_off = run_oracle(sc, tti0, iq, taps=False, mcs_tracking_mode=0)
+    st = ow.harq_stats()
+    assert st[1] > 5 and st[3] > 5 and oracle_records(orecs) != oracle_records(orecs_off)
+    for batch in (90, 16):  # one chunk; several chunks (a retransmission whose first transmission sits in the previous chunk)
+        phy = la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=batch, pcapwriter=la.PcapWriter(None), harq_mode=1, mcs_tracking_mode=0)
+        assert phy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"])
+        phy.process_host(iq, tti0, 0)
+        assert gpu_records(phy) == oracle_records(orecs), batch
+        phy.close()
+    # the same stream with 2 code words per grant (TM3) on 20 MHz: big transport blocks of several code blocks each
+    sc = scenario("cfg3", seed=95, n_rnti=4, dl_min=2, dl_max=2, ul_min=0, ul_max=0, mix_tm3_pct=100, mix_tm4_pct=0, pct_256qam=0, mcs_min=20, mcs_max=24, snr_db=13.0,
+                  rar_period=0, paging_period=0, pct_harq=60)
+    tti0, iq, _ = gen_subframes(sc, 40)
+    ow, _, orecs = run_oracle(sc, tti0, iq, taps=False, harq_mode=1, mcs_tracking_mode=0)
+    assert ow.harq_stats()[1] > 3
+    phy = la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=40, pcapwriter=la.PcapWriter(None), harq_mode=1, mcs_tracking_mode=0)
+    assert phy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"])
+    phy.process_host(iq, tti0, 0)
+    assert gpu_records(phy) == oracle_records(orecs) and len(orecs) > 0
+    phy.close()

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <memory>
 #include <thread>
 #include <atomic>
 
@@ -241,6 +242,7 @@ typedef struct {
   uint8_t si_msg[2][96];
   uint32_t pg_len;        // PCCH message sent with the P-RNTI (paging_period != 0) when not 0, else random bytes
   uint8_t pg_msg[96];
+  uint32_t pct_harq;      // share of C-RNTI downlink grants that are sent again 8 subframes later (same HARQ process, NDI not toggled, next redundancy version of 0 2 3 1, same payload)
 } txg_cfg_t;
 
 typedef struct { uint16_t rnti; uint8_t format, L; uint16_t ncce; uint32_t tti; uint32_t nbytes; uint32_t offset; uint8_t tb, mod, table256, is_ul; uint32_t nof_prb; uint32_t mcs; uint32_t cqi_req; uint32_t hop_bits_plus1; /* DCI 0: 0 = no hopping, else 1 + hopping bits */ } txg_pdu_t;
@@ -257,8 +259,11 @@ uint32_t txg_tti(const txg_t*);
 struct Ue { uint16_t rnti; int tm; bool t256; float p_a_db = 0.0f; };
 struct RegInfo { std::vector<uint16_t> k0[3]; std::vector<uint8_t> l[3]; uint32_t nregs[3], ncce[3]; uint16_t pcfich_k0[4]; };
 
+struct Grant;
+struct Retx { uint32_t due; int ui; int nr; int rvk; std::vector<uint8_t> payload[2]; std::shared_ptr<Grant> proto; };
 struct txg {
   txg_cfg_t c;
+  std::vector<Retx> retx;  // HARQ retransmissions waiting for their subframe (pct_harq)
   int N, nre;
   Rng rng;
   std::vector<Ue> ues;
@@ -648,6 +653,51 @@ extern "C" int txg_next(txg_t* g, float* iq, txg_pdu_t* pdus, int max_pdus, uint
   float msg4_p_a = 0.0f;
   uint32_t kdl = c.dl_min + g->rng.below(c.dl_max - c.dl_min + 1);
   std::vector<int> picked;
+  static const int rv_seq[4] = {0, 2, 3, 1};
+  // HARQ retransmissions due now (pct_harq): the grant of 8 subframes ago again - same process, NDI, MCS and number of resource block groups, next
+  // redundancy version, same transport blocks - placed in front of the new grants
+  auto maybe_retx = [&](const Grant& gr, int ui, int nr, int rvk, const uint8_t* p0, const uint8_t* p1) {
+    if (!c.pct_harq || rvk >= 3 || !(gr.rnti >= 0x000B && gr.rnti <= 0xFFF3) || g->rng.below(100) >= c.pct_harq) return;
+    Retx r; r.due = (tti + 8) % 10240; r.ui = ui; r.nr = nr; r.rvk = rvk + 1; r.proto = std::make_shared<Grant>(gr);
+    if (p0) r.payload[0].assign(p0, p0 + gr.tbs[0] / 8);
+    if (p1 && gr.ntb > 1) r.payload[1].assign(p1, p1 + gr.tbs[1] / 8);
+    g->retx.push_back(std::move(r));
+  };
+  for (size_t ri = 0; ri < g->retx.size();) {
+    if (g->retx[ri].due != tti) { ri++; continue; }
+    Retx r = g->retx[ri];
+    g->retx.erase(g->retx.begin() + (long)ri);
+    if (next_rbg + r.nr > (int)nrbg || r.ui >= (int)g->ues.size() || g->ues[r.ui].rnti != r.proto->rnti) continue;  // no room / the UE has left
+    Grant gr = *r.proto;
+    gr.L = pickL(); gr.prbs.clear();
+    const int r0 = next_rbg;
+    for (int q = r0; q < r0 + r.nr; q++) for (int p = q * (int)Prbg; p < (q + 1) * (int)Prbg && p < nprb; p++) gr.prbs.push_back(p);
+    gr.rbg_mask = 0;
+    for (int q = r0; q < r0 + r.nr; q++) gr.rbg_mask |= 1u << (nrbg - 1 - q);
+    if (!gr.type0) { int start = gr.prbs.front(), Lc = (int)gr.prbs.size(); gr.riv = (Lc - 1 <= nprb / 2) ? (uint32_t)(nprb * (Lc - 1) + start) : (uint32_t)(nprb * (nprb - Lc + 1) + (nprb - 1 - start)); }
+    if ((int)gr.prbs.size() != (int)r.proto->prbs.size()) continue;  // the last group of the band is shorter: the block size would change
+    for (int i = 0; i < gr.ntb; i++) gr.rv[i] = rv_seq[r.rvk];
+    const int nre_g = count_re(gr.prbs);
+    if (nre_g < 24) continue;
+    set_tbs(gr, nre_g);
+    if (gr.tbs[0] != r.proto->tbs[0] || (gr.ntb > 1 && gr.tbs[1] != r.proto->tbs[1])) continue;
+    if (!place(gr, false)) continue;
+    next_rbg += r.nr;
+    picked.push_back(r.ui);
+    grants.push_back(gr);
+    const uint8_t* pp[2] = {nullptr, nullptr};
+    for (int i = 0; i < gr.ntb; i++) {
+      const int nb = gr.tbs[i] / 8;
+      if (npdu < max_pdus && poff + nb <= pcap && (int)r.payload[i].size() == nb) {
+        memcpy(pbuf + poff, r.payload[i].data(), (size_t)nb);
+        pp[i] = pbuf + poff;
+        txg_pdu_t& pd = pdus[npdu++];
+        pd = txg_pdu_t{gr.rnti, (uint8_t)gr.format, (uint8_t)gr.L, (uint16_t)gr.ncce, tti, (uint32_t)nb, (uint32_t)poff, (uint8_t)i, (uint8_t)gr.qm[i], (uint8_t)gr.t256, 0, (uint32_t)gr.prbs.size(), gr.mcs[i]};
+        poff += nb;
+      }
+    }
+    maybe_retx(gr, r.ui, r.nr, r.rvk, pp[0], pp[1]);
+  }
   int rbg_left = (int)nrbg - next_rbg;
   if ((int)kdl > rbg_left) kdl = (uint32_t)std::max(rbg_left, 0);
   std::vector<int> share(kdl, 1);
@@ -692,9 +742,11 @@ extern "C" int txg_next(txg_t* g, float* iq, txg_pdu_t* pdus, int max_pdus, uint
     set_tbs(gr, nre_g);
     if (!place(gr, false)) continue;
     grants.push_back(gr);
+    const uint8_t* new_pp[2] = {nullptr, nullptr};
     for (int i = 0; i < gr.ntb; i++) {
       int nb = gr.tbs[i] / 8;
       if (npdu < max_pdus && poff + nb <= pcap) {
+        new_pp[i] = pbuf + poff;
         for (int b = 0; b < nb; b++) pbuf[poff + b] = (uint8_t)g->rng.u32();
         pbuf[poff] = 0x03;  // a well-formed MAC PDU: one subheader (E = 0, LCID 3 = a DTCH), the SDU takes the rest; never an all-zero TB
         if (i == 0 && q == 0 && c.msg4_period && (tti % c.msg4_period) == 5 % c.msg4_period && msg4_ue < 0) {
@@ -717,6 +769,7 @@ extern "C" int txg_next(txg_t* g, float* iq, txg_pdu_t* pdus, int max_pdus, uint
         poff += nb;
       }
     }
+    if (c.pct_harq && new_pp[0] && (gr.ntb < 2 || new_pp[1])) maybe_retx(gr, ui, nr, 0, new_pp[0], new_pp[1]);
   }
   // UL grants (DCI 0 only; PUSCH itself is not generated)
   uint32_t kul = c.ul_min + g->rng.below(c.ul_max - c.ul_min + 1);
