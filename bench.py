@@ -86,12 +86,27 @@ def _cpu_slice(k):
 
 
 def _profile_json(key):
-    """profiles/current.json names the rocprofv3 summaries of this tree (tools/gpu_profile.sh); None when absent"""
+    """profiles/current.json names the rocprofv3 summaries of this tree (tools/gpu_profile.sh); None when absent OR when they were taken from
+    another tree (current.json records the tree hash of the profiled sources)"""
     try:
         cur = json.load(open(os.path.join(ROOT, "profiles", "current.json")))
+        if cur.get("tree_hash") != tree_hash():
+            return None, None
         return json.load(open(os.path.join(ROOT, "profiles", cur[key]))), cur[key]
     except Exception:
         return None, None
+
+
+def _profile_state():
+    try:
+        cur = json.load(open(os.path.join(ROOT, "profiles", "current.json")))
+        return {"profiled_tree_hash": cur.get("tree_hash"), "this_tree_hash": tree_hash(), "match": cur.get("tree_hash") == tree_hash()}
+    except Exception:
+        return {"profiled_tree_hash": None, "this_tree_hash": tree_hash(), "match": False}
+
+
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from tree_hash import tree_hash  # noqa: E402  (hash of the product sources: profile summaries are only quoted for the tree they were taken from)
 
 
 GOLDEN = os.path.join(ROOT, "tests", "golden", "cfg3_stream_oracle.json")
@@ -466,6 +481,29 @@ def main():
             legs["cfg2_32_rnti_tm2_64qam"] = {"subframes_per_s": round(4 * n2 / dtl, 1), "subframes": 4 * n2, "records": w2.nof_records(), "input": "resident in HBM"}
             p2.close()
             del d2
+            # the metric's configuration at 16 dB instead of 30 dB: most code blocks need many iterations and many fail - the decoders' design
+            # parameters (LLR scale, clip, extrinsic scaling, window count) carry the result here; record parity at this operating point:
+            # tests/test_gpu_parity.py::test_mid_snr_many_crc_failures (stage-C taps + record stream)
+            sc16 = scenario("cfg3", seed=16, snr_db=16.0)
+            t16, iq16 = gen_capture(sc16, 3200, threads=gen_threads)
+            d16 = torch.from_numpy(iq16.view(np.float32)).to(dev)
+            w16 = la.PcapWriter(None)
+            w16.set_store(False)
+            p16 = la.Phy(nof_rx_antennas=sc16["nof_rx"], max_batch=batch, device=local, pcapwriter=w16)
+            p16.setCell(sc16["nof_prb"], sc16["nof_ports"], sc16["cell_id"])
+            n16 = d16.shape[0]
+            p16.process_device(d16.data_ptr(), n16, t16 % 10240, 500, stream)
+            t = time.perf_counter()
+            for r in range(4):
+                p16.submit_device(d16.data_ptr(), n16, (t16 + (r + 1) * n16) % 10240, 500, stream)
+            p16.wait()
+            dtl = time.perf_counter() - t
+            pf16 = p16.perf()
+            legs["cfg3_at_16_dB_snr"] = {"subframes_per_s": round(4 * n16 / dtl, 1), "subframes": 4 * n16, "records": w16.nof_records(), "input": "resident in HBM",
+                                         "turbo_iterations_per_subframe": round(pf16.nof_turbo_iterations / (4.0 * n16), 1), "tb_decodes_per_subframe": round(pf16.nof_tb_decodes / (4.0 * n16), 2),
+                                         "pdus_per_subframe": round(pf16.nof_pdus / (4.0 * n16), 2)}
+            p16.close()
+            del d16
             from lsn_testlib import gen_ul_mode_subframes
             sc4 = scenario("cfg2", seed=4, nof_rx=1, n_rnti=64, ul_min=2, ul_max=4, mcs_min=0, mcs_max=28, snr_db=28.0)
             t4, iq4, sent4 = gen_ul_mode_subframes(sc4, 200, ul_snr_db=22.0)
@@ -512,23 +550,45 @@ def main():
             traffic_src = "profiles/" + hname
         rp, rpname = _profile_json("kernel_trace")  # {kernel: {calls, avg_ms, exclusive_ms, ...}, _subframes, _wall_ms} of the driver's command
         rocprof = None
+        bytes_per_sf = kbytes / max(1, sf_rank)
         if rp and rp.get(la.KERNELS[kt]):
             e = rp[la.KERNELS[kt]]
             hip_avg = kms[kt] / max(1, klaunch[kt])
-            rocprof = {"avg_launch_ms": e.get("avg_ms"), "launches": e.get("calls"), "exclusive_ms_per_subframe": e.get("exclusive_ms_per_subframe"),
+            ex = e.get("exclusive_ms_per_subframe")
+            rocprof = {"avg_launch_ms": e.get("avg_ms"), "launches": e.get("calls"), "exclusive_ms_per_subframe": ex,
+                       # launches of one kernel overlap each other and the other kernels: launches x average span exceeds the step time.  The time that
+                       # can be ATTRIBUTED to the kernel is the union of its launch intervals (exclusive time); the rate on that time:
+                       "achieved_on_exclusive_time_GBps": round(bytes_per_sf / 1e9 / (ex / 1e3), 2) if ex else None,
+                       "frac_on_exclusive_time": round(bytes_per_sf / 1e9 / (ex / 1e3) / 8000.0, 6) if ex else None,
                        "hip_event_over_rocprof_avg": round(hip_avg / e["avg_ms"], 3) if e.get("avg_ms") else None, "source": "profiles/" + rpname}
-        valu = None
+        valu, saturation = None, None
         vj, vname = _profile_json("pmc_sq")
         try:
             if vj and vj.get(la.KERNELS[kt]) and kms[kt] > 0:
                 sub = float(vj["_subframes"])
+                # peak: 1024 SIMDs x 2.4 GHz / 2 cycles per wave-instruction (SIMD-32, MI355X_MICROARCH.md) = 1228.8 G/s; the packed 16-bit and
+                # 3-operand forms the two decoders are made of occupy the port for 4 cycles (profiles/r03_valu_peak_isa.txt): 614.4 G/s
                 peak = float(vj.get("_peak_G_wave_insts_per_s", 1228.8))
                 ins = vj[la.KERNELS[kt]]["SQ_INSTS_VALU"]["total"] / sub
                 g = ins / (kms[kt] / sf_rank * 1e6)
                 allk = sum(v["SQ_INSTS_VALU"]["total"] for k, v in vj.items() if not k.startswith("_") and "SQ_INSTS_VALU" in v and k.startswith("k_")) / sub
                 valu = {"kernel_wave_insts_per_subframe": int(ins), "achieved_G_per_s": round(g, 1), "peak_G_per_s": peak, "frac": round(g / peak, 4),
                         "all_kernels_wave_insts_per_subframe": int(allk), "chip_G_per_s_at_this_rate": round(allk * value / world / 1e9, 1),
-                        "chip_frac": round(allk * value / world / 1e9 / peak, 4), "source": "profiles/" + vname}
+                        "chip_frac": round(allk * value / world / 1e9 / peak, 4), "chip_frac_of_4_cycle_class_peak": round(allk * value / world / 1e9 / (peak / 2.0), 4),
+                        "source": "profiles/" + vname}
+                # how full is the GPU?  The counter passes run every kernel ALONE (rocprofv3 serialises profiled dispatches): the sum of those stand-alone
+                # launch times per subframe is what a one-kernel-at-a-time schedule would need; the pipelined engine needs 1 / value.  (A launch alone is
+                # far from its instruction time - the 12-iteration tail of hopeless code blocks leaves the chip to a few workgroups - so the ratio says
+                # how much of that idle time the overlap of 12 streams recovers, not how close the chip is to an instruction-issue bound.)
+                alone = {}
+                for k, v in vj.items():
+                    if k.startswith("_") or "SQ_WAVES" not in v:
+                        continue
+                    alone[k] = v["SQ_WAVES"]["ns"] / sub / 1e3
+                tot = sum(alone.values())
+                saturation = {"sum_of_standalone_kernel_us_per_subframe": round(tot, 3), "pipelined_us_per_subframe": round(1e6 * world / value, 3),
+                              "overlap_gain": round(tot / (1e6 * world / value), 2),
+                              "standalone_us_per_subframe": {k: round(v, 3) for k, v in sorted(alone.items(), key=lambda kv: -kv[1])[:8]}, "source": "profiles/" + vname}
         except Exception:
             valu = None
         cold = None
@@ -541,6 +601,10 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "strong" if capture_mode else "weak", "vs_baseline": None, "dtype": "f32+int16", "data": "synthetic",
             "x_realtime": round(value / 1000.0 / (1 if capture_mode else world), 2), "pcap_diff": pcap_diff,
+            # BASELINE.md section 3 times "first H2D -> last PDU on host"; the bench contract wants inputs resident in HBM for `value`.  Both are here:
+            # `value` = resident, `value_first_h2d_to_last_pdu` = the whole capture from pinned host memory through a FRESH engine (cold RNTI / MCS state, PCIe
+            # included), the number to hold against BASELINE's >= 50 x real time
+            "value_first_h2d_to_last_pdu": (legs or {}).get("host_pinned", {}).get("pass1_cold", {}).get("subframes_per_s") if legs else None,
             "parity_reference": "in-repo CPU oracle, unpinned vs srsRAN", "parity": parity,
             "config": {"workload": "%s: 20 MHz DL (100 PRB, 2 CRS ports, 2 rx), 150 active RNTIs + a fresh RNTI by RAR every 200 subframes, TM2/TM3/TM4 mix up to 256QAM, "
                                    "CFI 3, 8-14 DL + 3-6 UL DCIs per subframe (BASELINE.json configs[2], SURVEY 8d config 3)" % args.config
@@ -552,7 +616,7 @@ def main():
                          "frac": round(ach / 8000.0, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": round(kms[kt] / max(1, klaunch[kt]), 4), "launches": int(klaunch[kt]),
                          "algo_bytes_per_launch": int(kbytes / max(1, klaunch[kt])), "timing": "HIP events on the launch streams inside the timed region (span of a launch that shares the GPU, not exclusive)",
-                         "rocprof": rocprof, "dominant_by_time": la.KERNELS[dom], "valu": valu},
+                         "rocprof": rocprof, "dominant_by_time": la.KERNELS[dom], "valu": valu, "gpu_saturation": saturation, "profile": _profile_state()},
             "first_h2d_to_last_pdu": legs, "cold_state": cold, "cpu_baseline": cpu,
             "host": {"cpu_count": os.cpu_count(), "cpu_quota_cores": host_quota, "decode_threads": int(os.environ.get("LSN_DECODE_THREADS", "8")), "cores_busy_in_timed_region": round(host_cores_busy, 2),
                      "busiest_threads": busiest},

@@ -35,4 +35,7 @@ P3=$(run_prof pmc_fetch --kernel-trace --pmc FETCH_SIZE)
 P4=$(run_prof pmc_write --kernel-trace --pmc WRITE_SIZE)
 [ -n "$P1$P2" ] && python tools/pmc_generic_summary.py $OUT/${TAG}_pmc_sq.json $P1 $P2 --subframes $ALL_SF > $OUT/${TAG}_pmc_sq.txt 2>&1
 [ -n "$P3" ] && [ -n "$P4" ] && python tools/pmc_summary.py $P3 $P4 $OUT/${TAG}_pmc_hbm.json > $OUT/${TAG}_pmc_hbm.txt 2>&1
+# which tree these summaries describe: bench.py prints roofline figures taken from profiles/ only when this hash equals the running tree's
+python tools/tree_hash.py > $OUT/${TAG}_tree_hash.txt
+cat $OUT/${TAG}_tree_hash.txt
 ls -la $OUT | grep ${TAG}_ | tail -20
