@@ -628,6 +628,7 @@ def main():
                        "decode_jobs_by_kind_per_6400": {"kinds": ["first attempt", "second table after failure", "second table speculative", "RA-RNTI ahead of search", "on demand"],
                                                         "jobs": [round(p.jobs_by_kind[k] * 6400.0 / sf_rank, 1) for k in range(5)], "jobs_unused": [round(p.jobs_unused_by_kind[k] * 6400.0 / sf_rank, 1) for k in range(5)],
                                                         "iterations": [round(p.iters_by_kind[k] * 6400.0 / sf_rank, 1) for k in range(5)], "iterations_unused": [round(p.iters_unused_by_kind[k] * 6400.0 / sf_rank, 1) for k in range(5)]},
+                       "table_hints_engine_total": {"used": int(p.nof_table_hints_used), "missed": int(p.nof_table_hints_missed)},
                        "ondemand_at_commit_per_6400": [round(p.nof_ondemand_commit[k] * 6400.0 / sf_rank, 2) for k in range(4)],
                        "kernel_ms_per_6400_subframes": {la.KERNELS[k]: round(kms[k] * 6400.0 / sf_rank, 4) for k in range(nk)},
                        "kernel_launches_per_step": {la.KERNELS[k]: round(float(klaunch[k]) / args.steps, 2) for k in range(nk)}},

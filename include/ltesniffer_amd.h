@@ -407,6 +407,7 @@ typedef struct {
    * ahead although the first passed a CRC (speculative), [3] RA-RNTI candidates decoded ahead of the search, [4] decoded on demand (search / commit turn);
    * jobs / turbo iterations run, and the part of both the commit stage never looked at */
   uint64_t jobs_by_kind[5], jobs_unused_by_kind[5], iters_by_kind[5], iters_unused_by_kind[5];
+  uint64_t nof_table_hints_used, nof_table_hints_missed;  /* DCIs planned for the 256QAM table alone on the decode threads' own evidence / of those the commit wanted the 64QAM-table attempt of after all (engine totals) */
 } lsn_perf_t;
 int lsn_phy_get_perf(lsn_phy_t* phy, lsn_perf_t* out);
 enum { LSN_K_OFDM = 0, LSN_K_CHEST, LSN_K_CHEST_FIN, LSN_K_PCFICH, LSN_K_PDCCH_LLR, LSN_K_CCE_POWER, LSN_K_VITERBI,

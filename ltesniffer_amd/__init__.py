@@ -150,7 +150,8 @@ class Perf(C.Structure):
                 ("turbo_cyc_map", C.c_uint64), ("turbo_cyc_out", C.c_uint64), ("ms_wait_front", C.c_double), ("ms_wait_slot", C.c_double), ("ms_drain", C.c_double),
                 ("nof_turbo_iterations_run", C.c_uint64), ("nof_ondemand_commit", C.c_uint64 * 4), ("ms_ondemand_commit", C.c_double), ("nof_pusch_2prb_skipped", C.c_uint64), ("nof_pusch_on_unverified_dmrs", C.c_uint64), ("nof_tb_on_derived_tbs", C.c_uint64),
                 ("nof_decode_jobs", C.c_uint64), ("nof_decode_jobs_used", C.c_uint64), ("nof_speculative_jobs", C.c_uint64),
-                ("jobs_by_kind", C.c_uint64 * 5), ("jobs_unused_by_kind", C.c_uint64 * 5), ("iters_by_kind", C.c_uint64 * 5), ("iters_unused_by_kind", C.c_uint64 * 5)]
+                ("jobs_by_kind", C.c_uint64 * 5), ("jobs_unused_by_kind", C.c_uint64 * 5), ("iters_by_kind", C.c_uint64 * 5), ("iters_unused_by_kind", C.c_uint64 * 5),
+                ("nof_table_hints_used", C.c_uint64), ("nof_table_hints_missed", C.c_uint64)]
 
 
 class UlCfg(C.Structure):

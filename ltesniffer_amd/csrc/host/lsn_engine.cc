@@ -367,6 +367,7 @@ static inline void prefetch_cand(const LsnCand* cand, const float* ccepow)
 
 void Engine::searchChunk(Chunk& ch, uint32_t update_meta_period)
 {
+  ch.gpos0 = (uint32_t)sf_cnt;
   prefetch_cand(ch.h_cand, ch.h_ccepow);
   if (ch.nsf > 1) prefetch_cand(ch.h_cand + (size_t)LSN_MAX_LOC * LSN_MAX_SIZES, ch.h_ccepow + LSN_CCE_STRIDE);
   for (uint32_t sf = 0; sf < ch.nsf; sf++) {
@@ -770,6 +771,31 @@ static bool same_decode(const PdschGrant& a, const PdschGrant& b)
 // turbo iterations.  Results are the same either way (the commit re-derives every decision).
 static const bool g_speculate_second_table = !(getenv("LSN_SPECULATE_SECOND_TABLE") && !atoi(getenv("LSN_SPECULATE_SECOND_TABLE")));
 
+static const bool g_hints = !(getenv("LSN_NO_TABLE_HINTS") && atoi(getenv("LSN_NO_TABLE_HINTS")));
+bool Engine::hintedTable256(uint16_t rnti, uint32_t pos) const
+{
+  if (!g_hints || cfg.mcs_tracking_mode != 1) return false;
+  // the hints switch themselves off when the commit keeps asking for the attempts they left out (each costs a GPU round trip in the sequential turn)
+  const uint64_t used = sh->hint_used.load(std::memory_order_relaxed), missed = sh->hint_missed.load(std::memory_order_relaxed);
+  if (missed * 20 > used + 200) return false;
+  // events count from the last reset of the RNTI's entry: the database ageing in front of this DCI, a RAR naming the RNTI, an update by hand
+  uint32_t lo = mcs_update_period ? (pos / mcs_update_period) * mcs_update_period : 0u;
+  lo = std::max(lo, pred_rar_at[rnti].load(std::memory_order_relaxed));   // (position + 1 of the RAR subframe = first position after it)
+  lo = std::max(lo, sh->hint_floor.load(std::memory_order_relaxed));
+  int n = 0;
+  const std::atomic<uint32_t>* ring = &sh->hint_pos[(size_t)rnti * SharedSeq::HINT_RING];
+  for (int i = 0; i < SharedSeq::HINT_RING; i++) {
+    const uint32_t q = ring[i].load(std::memory_order_relaxed);  // position + 1
+    if (q && q - 1 >= lo && q - 1 < pos) n++;
+  }
+  return n >= SharedSeq::HINT_EVENTS;
+}
+void Engine::hintEvent(uint16_t rnti, uint32_t pos)
+{
+  const uint8_t k = sh->hint_next[rnti].fetch_add(1, std::memory_order_relaxed);
+  sh->hint_pos[(size_t)rnti * SharedSeq::HINT_RING + (k % SharedSeq::HINT_RING)].store(pos + 1, std::memory_order_relaxed);
+}
+
 // wave 1: the first decode the reference would attempt for every accepted DL DCI, predicted from the MCS-tracking
 // state as of now; wave 2: the 256QAM-table retry of "unknown table" grants whose first attempt failed on both TBs
 void Engine::planJobs(Chunk& ch, JobRunner& r)
@@ -796,6 +822,12 @@ void Engine::planJobs(Chunk& ch, JobRunner& r)
         table = (e.rnti == SIRNTI || e.rnti == PRNTI || rnti_israr(e.rnti) || e.format == FORMAT1A) ? TABLE_64QAM : predictedTable(e.rnti);
       else
         table = cfg.mcs_tracking_mode == 2 ? TABLE_UNKNOWN : TABLE_64QAM;
+      e.hinted = false;
+      if (table >= TABLE_UNKNOWN && e.format > FORMAT1A && e.ok64 && e.ok256 && e.job[0] < 0 && e.job[1] < 0 && hintedTable256(e.rnti, ch.gpos0 + sf)) {
+        table = TABLE_256QAM;   // the commit will have learnt it by then: no 64QAM-table attempt
+        e.hinted = true;
+        sh->hint_used.fetch_add(1, std::memory_order_relaxed);
+      }
       const int first = table == TABLE_256QAM ? 1 : 0;
       const PdschGrant& g = first ? e.grant256 : e.grant64;
       const bool ok = first ? e.ok256 : e.ok64;
@@ -836,6 +868,17 @@ void Engine::planJobs(Chunk& ch, JobRunner& r)
     if (e.job[1] >= 0) wave.push_back(e.job[1]);
   }
   runJobs(ch, r, wave);
+  // teaching decodes of this chunk (SharedSeq::hint_pos): 64QAM-table attempt failed on every block, 256QAM-table attempt passed with a learnable MCS index
+  if (cfg.mcs_tracking_mode == 1)
+    for (auto& p : retry) {
+      const DlEntry& e = ch.ctx[p.sf].dl[p.di];
+      if (!(e.format > FORMAT1A) || e.job[0] < 0 || e.job[1] < 0 || e.job[0] == e.job[1]) continue;
+      const DecodeJob &j0 = ch.jobs[e.job[0]], &j1 = ch.jobs[e.job[1]];
+      if (!j0.done || !j1.done || j0.crc[0] || j0.crc[1]) continue;
+      bool teach = false;
+      for (int i = 0; i < 2; i++) teach = teach || (j1.crc[i] && e.dci.tb[i].mcs_idx > 0 && e.dci.tb[i].mcs_idx < 28);
+      if (teach) hintEvent(e.rnti, ch.gpos0 + p.sf);
+    }
   buildCommitView(ch);
 }
 
@@ -956,6 +999,7 @@ void Engine::commitChunk(Chunk& ch, JobRunner& r)
         if (d.job[t] >= 0 && ch.jres[d.job[t]].p_a != p_a_now) d.job[t] = -1;
         if (d.job[t] >= 0 && ch.jres[d.job[t]].done) { r.perf.nof_decode_jobs_used++; ch.jobs[d.job[t]].used = 1; return d.job[t]; }
         DlEntry& e = c.dl[d.di];  // slow path
+        if (e.hinted && t == 0 && d.job[0] < 0) sh->hint_missed.fetch_add(1, std::memory_order_relaxed);
         const int why = (e.job[t] >= 0 && d.job[t] < 0) ? 0 : (e.job[t] < 0 ? (e.job[1 - t] >= 0 ? 1 : 2) : 3);
         e.job[t] = d.job[t];
         if (e.job[t] < 0) e.job[t] = newJob(ch, sf, e, t, p_a_now, 4);

@@ -91,6 +91,7 @@ struct Chunk {
   uint64_t seq = 0;                  // position in the commit order
   uint64_t gseq = 0;                 // global chunk number (SharedSeq turn taking)
   uint32_t trace_id = 0;             // chunk number inside its submit (LSN_TRACE)
+  uint32_t gpos0 = 0;                // stream position (subframes searched before) of the chunk's first subframe
   uint32_t update_meta_period = 0;   // of the submit this chunk belongs to
   bool force_meta = false;           // SubframeWorker::prepare(updateMetaFormats = true) on the first subframe of this chunk (worker pool)
 };
@@ -135,6 +136,17 @@ struct SharedSeq {
   std::unique_ptr<std::atomic<float>[]> pred_p_a{new std::atomic<float>[65536]};
   // a RAR the search has seen for this RNTI but the commit has not reached yet will reset the RNTI's table (update_rar_time_crnti): predict that
   std::unique_ptr<std::atomic<uint32_t>[]> pred_rar_at{new std::atomic<uint32_t>[65536]};  // 1 + subframe count (search side) of the latest RAR naming the RNTI, 0 = none
+  // Plan-side knowledge that bridges the plan -> commit lag (thousands of subframes with eight chunks in decode at once): positions of the last
+  // "teaching" decodes the DECODE threads have seen for an RNTI - an unknown-table DCI of a format > 1A whose 64QAM-table attempt failed on every
+  // block and whose 256QAM-table attempt passed with a learnable MCS index, i.e. exactly what makes the commit set the RNTI's table to 256QAM
+  // (update_RNTI_dl).  Once LSN_HINT_EVENTS (6: the first adds the entry, a RAR-introduced entry needs more than three messages first) such events lie
+  // between the last reset of the entry (RAR naming the RNTI, database ageing) and a DCI, the commit WILL find the table known when it gets there,
+  // and the plan leaves the hopeless 64QAM-table attempt out.  A prediction only: a commit that does want that attempt decodes it on demand.
+  static constexpr int HINT_RING = 16, HINT_EVENTS = 6;
+  std::unique_ptr<std::atomic<uint32_t>[]> hint_pos{new std::atomic<uint32_t>[65536 * HINT_RING]};  // position + 1 of an event, 0 = empty
+  std::unique_ptr<std::atomic<uint8_t>[]> hint_next{new std::atomic<uint8_t>[65536]};
+  std::atomic<uint32_t> hint_floor{0};     // events at positions below are void (the caller aged the database by hand)
+  std::atomic<uint64_t> hint_used{0}, hint_missed{0};
   std::atomic<uint32_t> commit_pos{0};    // subframes committed so far, published
   uint32_t commit_sf_cnt = 0;             // subframes committed so far = the tracking database's clock (1 subframe = 1 ms)
   uint32_t mcs_update_period = 5000;      // MCSTracking::get_interval() x 1000 subframes (LTESniffer_Core.cc:473-485); 0: never
@@ -163,7 +175,8 @@ struct SharedSeq {
   uint64_t search_turn = 0, commit_turn = 0, write_turn = 0;
   SharedSeq()
   {
-    for (uint32_t i = 0; i < 65536; i++) { pred_table[i].store(0xFF, std::memory_order_relaxed); pred_p_a[i].store(0.0f, std::memory_order_relaxed); pred_rar_at[i].store(0, std::memory_order_relaxed); }
+    for (uint32_t i = 0; i < 65536; i++) { pred_table[i].store(0xFF, std::memory_order_relaxed); pred_p_a[i].store(0.0f, std::memory_order_relaxed); pred_rar_at[i].store(0, std::memory_order_relaxed); hint_next[i].store(0, std::memory_order_relaxed); }
+    for (uint32_t i = 0; i < 65536u * HINT_RING; i++) hint_pos[i].store(0, std::memory_order_relaxed);
   }
 };
 
@@ -197,7 +210,7 @@ public:
   void setApi(int mode, lsn_api_sink_t cb, void* user, lsn_pdu_sink_t pcap_cb, void* pcap) { api_mode = mode; api_sink = cb; api_user = user; api_pcap_sink = pcap_cb; api_pcap = pcap; }
   long tap(int what, uint32_t sf, void* out, size_t cap);
   void setStageCTaps(bool on) { keep_stage_c.store(on); }
-  void getPerf(lsn_perf_t* p) const { *p = perf; }
+  void getPerf(lsn_perf_t* p) const { *p = perf; p->nof_table_hints_used = sh->hint_used.load(); p->nof_table_hints_missed = sh->hint_missed.load(); }
   void getStats(lsn_blind_stats_t* s) const;
   float estCfo() const { return est_cfo; }
   RNTIManager& rntiManager() { return search->rntiManager(); }
@@ -313,13 +326,15 @@ private:
   }
   float predictedPa(uint16_t rnti) const { return pred_table[rnti].load(std::memory_order_relaxed) == 0xFF ? default_p_a.load(std::memory_order_relaxed) : pred_p_a[rnti].load(std::memory_order_relaxed); }
   void publishPrediction(uint16_t rnti);
+  bool hintedTable256(uint16_t rnti, uint32_t pos) const;   // SharedSeq::hint_pos: will the commit find this RNTI on the 256QAM table at stream position pos?
+  void hintEvent(uint16_t rnti, uint32_t pos);
   void ageTrackingDatabase();
   uint32_t& commit_sf_cnt = sh->commit_sf_cnt;
   uint32_t& mcs_update_period = sh->mcs_update_period;
   uint64_t& nof_mcs_db_updates = sh->nof_mcs_db_updates;
 public:
   void setMcsUpdateInterval(uint32_t seconds) { mcs_tracking.set_interval(seconds); mcs_update_period = seconds * 1000u; }
-  void updateMcsDatabase() { std::lock_guard<std::mutex> lk(mcs_mtx); if (cfg.sniffer_mode == 1) ulAgeDatabase(); else ageTrackingDatabase(); }  // between process calls only
+  void updateMcsDatabase() { sh->hint_floor.store((uint32_t)sf_cnt, std::memory_order_relaxed); std::lock_guard<std::mutex> lk(mcs_mtx); if (cfg.sniffer_mode == 1) ulAgeDatabase(); else ageTrackingDatabase(); }  // between process calls only
   uint32_t nofTrackedRnti() { std::lock_guard<std::mutex> lk(mcs_mtx); return cfg.sniffer_mode == 1 ? ulmod_count : mcs_tracking.nof_RNTI_member_dl(); }  // nof_RNTI_member_dl / _ul
 private:
   // front thread: launches stage A chunk after chunk, hands finished chunks to the search (caller) thread

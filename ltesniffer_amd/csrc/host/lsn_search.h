@@ -30,6 +30,7 @@ struct DlEntry {  // DL_Sniffer_DCI_DL (Sniffer_dependency.h:90)
   bool alloc_ok = false, finished = false, unpacked = false;  // the sequential search only records (rnti, format, location, payload bits); unpacking, PRB allocation
                                                               // and MCS/TBS/RE counts are filled in by finishDlEntry / finishSubframe, off the search thread
   int job[2] = {-1, -1};                                          // decode job index per table
+  bool hinted = false;                                            // planned for the 256QAM table alone on the decode threads' own evidence (SharedSeq::hint_pos)
 };
 struct UlEntry { uint16_t rnti = 0; uint32_t nof_bits = 0, L = 0, ncce = 0, histval = 0; unsigned long long bits = 0; DciUl dci; PuschGrant grant, grant256; bool ok = false, finished = false; };
 

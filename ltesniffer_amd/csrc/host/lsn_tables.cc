@@ -120,6 +120,31 @@ void Engine::allocRunner(JobRunner& r)
   }
   for (auto& e : r.ev) HIP_CHECK(hipEventCreate(&e));
   HIP_CHECK(hipEventCreateWithFlags(&r.ev_done, hipEventDisableTiming));  // waited for with Engine's poll-and-sleep waitEvent()
+  // The arenas of a bulk decode runner start at the size a full chunk of a loaded cell needs (per subframe at 100 PRB: 16 decode calls, 32 code
+  // blocks, 0.5 M soft bits, 128 K packed words, 24 KB of payload), scaled with the bandwidth: a fresh engine otherwise grows each of them several
+  // times during its first chunks, every step a stream synchronisation + hipFree (a device-wide wait) - part of why the cold pass of a capture
+  // ran 10-15 % below the following ones.  On-demand runners (single decodes) keep growing from zero.
+  bool bulk = false;
+  for (int i = 0; i < NDEC; i++) bulk = bulk || &r == &runner_c[i];
+  if (bulk && !getenv("LSN_NO_PRESIZE")) {
+    const double scale = (double)cell.nof_prb / 100.0;
+    const size_t sfn_ = max_batch;
+    auto dev = [&](auto*& p, size_t& cap, double per_sf) {
+      const size_t n = (size_t)(per_sf * scale * (double)sfn_) + 4096;
+      HIP_CHECK(hipMalloc((void**)&p, n * sizeof(*p)));
+      cap = n;
+    };
+    auto host = [&](auto*& p, size_t& cap, double per_sf) {
+      const size_t n = (size_t)(per_sf * scale * (double)sfn_) + 4096;
+      HIP_CHECK(hipHostMalloc((void**)&p, n * sizeof(*p), hipHostMallocCoherent | hipHostMallocMapped));
+      cap = n;
+    };
+    dev(r.d_jobs, r.jobs_cap, 16); dev(r.d_cbs, r.cbs_cap, 32); dev(r.d_cbres, r.cbres_cap, 32);
+    dev(r.d_prefix, r.prefix_cap, 16.0 * (14 * 100 + 16)); dev(r.d_llr16, r.llr16_cap, 512.0 * 1024); dev(r.d_payload, r.payload_cap, 24.0 * 1024);
+    dev(r.d_items, r.items_cap, 64); dev(r.d_spp, r.spp_cap, 128.0 * 1024);
+    host(r.h_cbres_pinned, r.h_cbres_cap, 32); host(r.h_payload_pinned, r.h_payload_cap, 24.0 * 1024); host(r.h_jobs_pinned, r.h_jobs_cap, 16);
+    host(r.h_cbs_pinned, r.h_cbs_cap, 32); host(r.h_items_pinned, r.h_items_cap, 64);
+  }
 }
 
 template <typename T>

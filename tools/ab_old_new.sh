@@ -9,6 +9,6 @@ for v in $VARS; do
   python - <<PY
 import json
 d=json.load(open('gpurun_out/ab_${v}_$i.json'));k=d['detail']['kernel_ms_per_6400_subframes']
-print('%-8s'%'$v',d['value'],d['pcap_diff'],d['parity'].get('timed_equals_oracle'),d['parity']['timed_digest'],d['parity']['timed_records'],'cold',d['cold_state']['subframes_per_s'],'t128 %.1f t64 %.1f vit %.1f rm %.1f demod %.1f'%(k['k_turbo<128>'],k['k_turbo<64>'],k['k_viterbi'],k['k_rm'],k['k_pdsch_demod']))
+print('%-8s'%'$v',d['value'],d['pcap_diff'],d['parity'].get('timed_equals_oracle'),d['parity']['timed_digest'],d['parity']['timed_records'],'cold',d['cold_state']['subframes_per_s'],'t128 %.1f t64 %.1f vit %.1f rm %.1f demod %.1f'%(k['k_turbo<128>'],k['k_turbo<64>'],k['k_viterbi'],k['k_rm'],k['k_pdsch_demod']),'its',d['detail']['per_6400_subframes']['nof_turbo_iterations'],'ondemand',d['detail']['ondemand_at_commit_per_6400'],d['detail'].get('table_hints_engine_total'))
 PY
 done; done
