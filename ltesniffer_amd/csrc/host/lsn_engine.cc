@@ -286,11 +286,15 @@ void Engine::launchStageA(Chunk& ch, const void* d_iq)
   timed([&] { lsn_launch_rb_power(cd, ch.d_grid, ch.d_rbp, nsf, st); });
   if (cfg.sniffer_mode == 1) lsn_launch_ul_fft(cd, iq, cd.iq_nant, 1, ch.d_ul_grid, nsf, st);  // srsran_enb_ul_fft on antenna 1, UL_Sniffer_PUSCH.cc:391-392
   // mirrors for the host stages: posted writes of a copy kernel into the pinned buffers (not the copy engine, lsn_dev.h)
-  lsn_launch_download(ch.h_cand, ch.d_cand, (size_t)nsf * LSN_MAX_LOC * LSN_MAX_SIZES * sizeof(LsnCand), st);
-  lsn_launch_download(ch.h_ccepow, ch.d_ccepow, (size_t)nsf * LSN_CCE_STRIDE * sizeof(float), st);
-  lsn_launch_download(ch.h_chest, ch.d_chest, (size_t)nsf * sizeof(LsnChest), st);
-  lsn_launch_download(ch.h_cfi, ch.d_cfi, (size_t)nsf * sizeof(uint32_t), st);
-  lsn_launch_download(ch.h_rbp, ch.d_rbp, (size_t)nsf * 128 * sizeof(float), st);
+  {
+    LsnCopySegs sg;
+    sg.add(ch.h_cand, ch.d_cand, (size_t)nsf * LSN_MAX_LOC * LSN_MAX_SIZES * sizeof(LsnCand));
+    sg.add(ch.h_ccepow, ch.d_ccepow, (size_t)nsf * LSN_CCE_STRIDE * sizeof(float));
+    sg.add(ch.h_chest, ch.d_chest, (size_t)nsf * sizeof(LsnChest));
+    sg.add(ch.h_cfi, ch.d_cfi, (size_t)nsf * sizeof(uint32_t));
+    sg.add(ch.h_rbp, ch.d_rbp, (size_t)nsf * 128 * sizeof(float));
+    lsn_launch_copy_multi(sg, true, st);
+  }
   HIP_CHECK(hipEventRecord(ch.ev_a[16], st));
 }
 
@@ -583,10 +587,11 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
     const uint32_t nitems = (uint32_t)r.h_items.size();
     grow_dev(r.d_items, r.items_cap, nitems + 1, st);
     grow_host(r.h_items_pinned, r.h_items_cap, nitems + 1, st);
+    LsnCopySegs up;   // items, jobs and code-block descriptors go up in one launch
     std::memcpy(r.h_items_pinned, r.h_items.data(), nitems * sizeof(uint32_t));
-    lsn_launch_upload(r.d_items, r.h_items_pinned, nitems * sizeof(uint32_t), st);
+    up.add(r.d_items, r.h_items_pinned, nitems * sizeof(uint32_t));
     std::memcpy(r.h_jobs_pinned, r.h_jobs.data(), njobs * sizeof(LsnGrantDev));
-    lsn_launch_upload(r.d_jobs, r.h_jobs_pinned, njobs * sizeof(LsnGrantDev), st);
+    up.add(r.d_jobs, r.h_jobs_pinned, njobs * sizeof(LsnGrantDev));
     if (ncb) {
       // launch order: two-wavefront blocks first, each class by descending size (longest jobs first)
       order.resize(ncb);
@@ -610,8 +615,9 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
         if (lsn_turbo_two_wave_class((int)q.K)) { n128p[ph]++; kmax128 = std::max(kmax128, q.K); } else { n64p[ph]++; kmax64 = std::max(kmax64, q.K); }
       }
       grow_dev(r.d_spp, r.spp_cap, spp_n + 16, st);
-      lsn_launch_upload(r.d_cbs, r.h_cbs_pinned, ncb * sizeof(LsnCbDev), st);
+      up.add(r.d_cbs, r.h_cbs_pinned, ncb * sizeof(LsnCbDev));
     }
+    lsn_launch_copy_multi(up, false, st);
     HIP_CHECK(hipEventRecord(r.ev[0], st));  // (no clear of the LLR arena: k_pdsch_demod writes every soft bit of every codeword it is given, zeros of unpaired SFBC REs included)
     lsn_launch_pdsch_prep(cd, r.d_jobs, r.d_prefix, njobs, st);
     HIP_CHECK(hipEventRecord(r.ev[1], st));
@@ -630,8 +636,12 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
         }
       }
       HIP_CHECK(hipEventRecord(r.ev[3], st));
-      lsn_launch_download(r.h_cbres_pinned, r.d_cbres, ncb * sizeof(LsnCbRes), st);
-      lsn_launch_download(r.h_payload_pinned, r.d_payload, pay_n - pay0, st);
+      {
+        LsnCopySegs dn;
+        dn.add(r.h_cbres_pinned, r.d_cbres, ncb * sizeof(LsnCbRes));
+        dn.add(r.h_payload_pinned, r.d_payload, pay_n - pay0);
+        lsn_launch_copy_multi(dn, true, st);
+      }
       if (cfg.harq_mode) {  // the soft data of this launch stays with the chunk until its commit (HARQ buffers are filled / combined there)
         if (ch.keep_n + spp_n > ch.keep_cap) {
           const size_t cap = (ch.keep_n + spp_n) * 2 + (1u << 20);
@@ -1617,14 +1627,15 @@ int Engine::submitFrom(const void* d_iq, int src_device, uint32_t nsf, uint32_t 
   }
 }
 
-// The stream the IQ blocks are copied on.  Its markers ("copy done" events) are barrier packets that wait for a copy-engine signal; a hardware
-// queue is shared by the streams of one priority class, so the copy stream gets the lowest priority - a class of its own - and its
-// barriers hold up nobody else's kernels.
+// The stream the IQ blocks are copied on.  Round 3 gave it the lowest priority (a class of its own, so that its "copy done" barrier packets would
+// hold up nobody else's kernels); since the front thread waits for a block on the HOST (poll loop) no stage-A stream carries such a barrier any
+// more, and the low class only delays the copies themselves: measured in round 4 on one box (tools/host_leg_probe.py 12000 400) 85-88 k
+// subframes/s at lowest, 96-101 k at default, 90-93 k at highest priority.  Default priority.
 void Engine::createCopyStream()
 {
   int lo = 0, hi = 0;
   (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-  static const int mode = getenv("LSN_COPY_STREAM_PRIO") ? atoi(getenv("LSN_COPY_STREAM_PRIO")) : 1;  // 0 default priority, 1 lowest, 2 highest
+  static const int mode = getenv("LSN_COPY_STREAM_PRIO") ? atoi(getenv("LSN_COPY_STREAM_PRIO")) : 0;  // 0 default priority, 1 lowest, 2 highest
   if (mode == 0) HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
   else HIP_CHECK(hipStreamCreateWithPriority(&copy_stream, hipStreamNonBlocking, mode == 1 ? lo : hi));
 }

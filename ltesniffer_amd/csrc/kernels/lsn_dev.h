@@ -114,6 +114,12 @@ void lsn_launch_upload(void* dst_dev, const void* src_pinned, size_t bytes, hipS
 // The way back (stage-A mirrors, code-block verdicts, payloads): device -> PINNED host memory by posted PCIe writes of a copy kernel.  The copy
 // engine serves both directions from one queue, so a hipMemcpyAsync device -> host would also wait behind the IQ blocks queued ahead.
 void lsn_launch_download(void* dst_pinned, const void* src_dev, size_t bytes, hipStream_t s);
+// up to six of either in one launch (word counts; buffers are allocated with slack to a whole word)
+struct LsnCopySegs {
+  const void* src[6]; void* dst[6]; uint32_t words[6]; uint32_t n = 0;
+  void add(void* d, const void* s_, size_t bytes) { if (bytes && n < 6) { src[n] = s_; dst[n] = d; words[n] = (uint32_t)((bytes + 3) / 4); n++; } }
+};
+void lsn_launch_copy_multi(const LsnCopySegs& sg, bool to_host, hipStream_t s);
 // launchers (stage_a.hip / stage_c.hip)
 void lsn_launch_ofdm(const LsnCellDev& c, const cf32* iq, const uint32_t* dphi, cf32* grid, uint32_t nsf, hipStream_t s);
 void lsn_launch_chest(const LsnCellDev& c, const cf32* grid, const uint32_t* sf_idx, cf32* ce, float* raw, uint32_t nsf, hipStream_t s);

@@ -912,6 +912,32 @@ __global__ __launch_bounds__(256) void k_download(const uint4* __restrict__ src,
   if (blockIdx.x == 0 && threadIdx.x < tail_n) dst_w[tail_first + threadIdx.x] = src_w[tail_first + threadIdx.x];
   __threadfence_system();  // the stores to host memory are performed at system scope before the kernel (and the event behind it) completes
 }
+// several transfers in ONE launch (the mirrors of a stage-A chunk: five; the descriptors of a decode launch: three; its results: two): every launch of a
+// copy kernel occupies a hardware queue slot of the streams that share it, and the pipeline made 55 of them per 1000 subframes (round 3)
+__global__ __launch_bounds__(256) void k_copy_multi(LsnCopySegs sg, uint32_t to_host)
+{
+  for (uint32_t q = 0; q < sg.n; q++) {
+    const uint32_t words = sg.words[q];
+    const bool al = ((((uintptr_t)sg.src[q]) | ((uintptr_t)sg.dst[q])) & 15u) == 0;
+    const uint32_t n16 = al ? words / 4 : 0;
+    const uint4* a4 = (const uint4*)sg.src[q];
+    uint4* b4 = (uint4*)sg.dst[q];
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n16; i += gridDim.x * 256u) b4[i] = a4[i];
+    const uint32_t* a = (const uint32_t*)sg.src[q];
+    uint32_t* b = (uint32_t*)sg.dst[q];
+    for (uint32_t i = n16 * 4 + blockIdx.x * 256u + threadIdx.x; i < words; i += gridDim.x * 256u) b[i] = a[i];
+  }
+  if (to_host) __threadfence_system();  // the stores to host memory are performed at system scope before the kernel (and the event behind it) completes
+}
+void lsn_launch_copy_multi(const LsnCopySegs& sg, bool to_host, hipStream_t s)
+{
+  uint32_t total = 0;
+  for (uint32_t q = 0; q < sg.n; q++) total += sg.words[q];
+  if (!total) return;
+  const uint32_t blocks = std::max<uint32_t>(1u, std::min<uint32_t>((total / 4 + 255u) / 256u, 128u));
+  hipLaunchKernelGGL(k_copy_multi, dim3(blocks), dim3(256), 0, s, sg, to_host ? 1u : 0u);
+}
+
 void lsn_launch_download(void* dst_pinned, const void* src_dev, size_t bytes, hipStream_t s)
 {
   if (!bytes) return;
