@@ -661,6 +661,12 @@ __device__ __forceinline__ void viterbi_tb2(const int* symwA, const int* symwB, 
 // ballots are stored by a uniform, branch-free LDS write; the trace-back covers only passes 2 and 3, fetches 64 ballot
 // words per LDS read (one per lane) and then walks them with v_readlane + scalar shifts instead of one dependent LDS
 // round trip per step.
+// LSN_VITERBI_PAIRED: the two-candidates-per-wavefront variant (viterbi_tb2 above).  Built and measured in round 4 (tools/ab_build.sh with
+// -DLSN_VITERBI_PAIRED on stage_a): candidate tables bit-identical, half the ds_bpermute traffic - and the same 0.86 ms per 400-subframe launch alone,
+// 166.1 k against 166.7 k subframes/s in the pipeline, with 40 % MORE vector instructions per subframe (the two trace-backs and CRC divisions of a
+// wavefront no longer stay in scalar registers).  The kernel is bound by the dependent add-compare-select chain at eight wavefronts per SIMD, not by
+// the LDS crossbar; the one-candidate kernel stays the product.
+#ifdef LSN_VITERBI_PAIRED
 __global__ __launch_bounds__(64) void k_viterbi(LsnCellDev c, const float* __restrict__ llr, const float* __restrict__ pw,
                                                 const uint32_t* __restrict__ cfi_arr, const uint32_t* __restrict__ sf_idx_arr,
                                                 LsnCand* __restrict__ cand)
@@ -738,6 +744,70 @@ __global__ __launch_bounds__(64) void k_viterbi(LsnCellDev c, const float* __res
     }
   }
 }
+#else
+__global__ __launch_bounds__(64) void k_viterbi(LsnCellDev c, const float* __restrict__ llr, const float* __restrict__ pw,
+                                                const uint32_t* __restrict__ cfi_arr, const uint32_t* __restrict__ sf_idx_arr,
+                                                LsnCand* __restrict__ cand)
+{
+  __shared__ __attribute__((aligned(16))) int symw[LSN_MAX_DCI_D + 4];  // per trellis step: (q0 - 128) | (q1 - 128) << 8 | (q2 - 128) << 16, signed bytes
+  const int lane = threadIdx.x, sf = blockIdx.z, sz = blockIdx.y;
+  int li = blockIdx.x;
+  LsnCand* out = cand + ((size_t)sf * LSN_MAX_LOC + blockIdx.x) * LSN_MAX_SIZES + sz;
+  const uint32_t ncce_tot = c.nof_cce[cfi_arr[sf] - 1];
+  const uint32_t lim = ncce_tot < LSN_MAX_NUM_OF_CCE ? ncce_tot : LSN_MAX_NUM_OF_CCE;
+  // location enumeration of srsran_pdcch_ue_locations_all_map (falcon_pdcch.c:321-356)
+  int L = -1; uint32_t ncce = 0;
+  for (int l = 3; l >= 0; l--) {
+    int cnt = (int)(lim >> l);
+    if (li < cnt) { L = l; ncce = ((uint32_t)li % (ncce_tot >> l)) << l; break; }
+    li -= cnt;
+  }
+  bool ok = L >= 0;
+  const uint32_t E = ok ? (72u << L) : 0u;
+  if (ok && ncce * 72 + E > ncce_tot * 72) ok = false;
+  if (ok) {
+    for (uint32_t i = 0; i < (1u << L); i++)
+      if (pw[sf * LSN_CCE_STRIDE + ncce + i] < 0.7f) ok = false;  // location->sufficient_power (falcon_pdcch.c:610-614)
+  }
+  if (!ok) {
+    if (lane == 0) { out->bits = 0; out->rnti = 0; out->flags = 0; }
+    return;
+  }
+  const float* e = llr + (size_t)sf * LSN_LLR_STRIDE + ncce * 72;
+  const uint32_t nbits = c.sizes[sz], D = nbits + 16, D3 = 3 * D;
+  const uint16_t* rank = c.rankmap + sz * 3 * LSN_MAX_DCI_D;
+  bool nz = false;
+  for (uint32_t t = lane; t < D; t += 64) {
+    uint32_t word = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 3; j++) {
+      float acc = 0.0f;
+      bool first = true;
+      for (uint32_t k = rank[3 * t + j]; k < E; k += D3) {
+        float v = e[k];
+        if (v != 0.0f) nz = true;
+        if (first) { acc = v; first = false; } else acc = acc + v;
+      }
+      float q = 127.5f + 32.0f * acc;
+      q = q < 0.0f ? 0.0f : q;
+      q = q > 255.0f ? 255.0f : q;
+      word |= (((uint32_t)(unsigned char)q - 128u) & 0xFFu) << (8 * j);
+    }
+    symw[t] = (int)word;
+  }
+  if (__ballot(nz) == 0ull) {  // mean |llr| == 0: the reference skips the decode (falcon_pdcch.c:141)
+    if (lane == 0) { out->bits = 0; out->rnti = 0; out->flags = 0; }
+    return;
+  }
+  unsigned long long bits; uint32_t rnti;
+  viterbi_tb(symw, D, nbits, lane, bits, rnti);
+  if (lane == 0) {
+    out->bits = bits;
+    out->rnti = rnti;
+    out->flags = 1u | (ss_validate(ncce_tot, ncce, (uint32_t)L, sf_idx_arr[sf], rnti) << 1);  // bit 0: decoded, bits 1-2: search-space match
+  }
+}
+#endif
 // ------------------------------------------------------------------------------------------------ PBCH / MIB
 // srsran_ue_mib_decode on subframe 0 (LTESniffer_Core.cc:382-395).  k_pbch_llr: one workgroup; the 240 PBCH symbols
 // (72 centre carriers of symbols 7-10, CRS positions of four ports left out) are equalised like a REG (MRC or SFBC pairs),
@@ -847,7 +917,11 @@ void lsn_launch_pbch(const LsnCellDev& c, const cf32* grid, const cf32* ce, cons
 void lsn_launch_viterbi(const LsnCellDev& c, const float* llr, const float* pw, const uint32_t* cfi, const uint32_t* sf_idx, LsnCand* cand, uint32_t nsf,
                         hipStream_t s)
 {
+#ifdef LSN_VITERBI_PAIRED
   hipLaunchKernelGGL(k_viterbi, dim3((LSN_MAX_LOC + 1) / 2, c.nsizes, nsf), dim3(64), 0, s, c, llr, pw, cfi, sf_idx, cand);
+#else
+  hipLaunchKernelGGL(k_viterbi, dim3(LSN_MAX_LOC, c.nsizes, nsf), dim3(64), 0, s, c, llr, pw, cfi, sf_idx, cand);
+#endif
 }
 
 // SubframePower::computePower (SubframePower.cc:18-42) linear part: sum over 14 symbols of mean |x|^2 per PRB (antenna 0)
