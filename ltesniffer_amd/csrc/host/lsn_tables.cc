@@ -294,6 +294,19 @@ void Engine::buildTables()
           }
     }
     cd.rankmap = upload(dev_allocs, rank);
+    // CRC16 weights of the payload bits (k_viterbi computes the remainder lane-parallel): x^(n - 1 - i + 16) mod (x^16 + x^12 + x^5 + 1)
+    std::vector<uint16_t> cw((size_t)(LSN_MAX_SIZES + 1) * 64, 0);
+    auto fill = [&](uint16_t* row, uint32_t n) {
+      uint32_t w = 1;                       // x^0
+      for (int t = 0; t < 16; t++) { w <<= 1; if (w & 0x10000u) w ^= 0x11021u; }   // x^16 mod g: the weight of the LAST payload bit
+      for (int i = (int)n - 1; i >= 0; i--) {
+        if (i < 64) row[i] = (uint16_t)w;
+        w <<= 1; if (w & 0x10000u) w ^= 0x11021u;
+      }
+    };
+    for (uint32_t k = 0; k < cd.nsizes; k++) fill(cw.data() + (size_t)k * 64, cd.sizes[k]);
+    fill(cw.data() + (size_t)LSN_MAX_SIZES * 64, 24);
+    cd.crc16_w = upload(dev_allocs, cw);
     std::vector<uint16_t> prank(120, 0);  // PBCH block: 24 + 16 bits
     {
       const int D = 40, R = 2, KP = 64, ND = KP - D;

@@ -43,6 +43,7 @@ struct LsnCellDev {
   uint32_t sizes[LSN_MAX_SIZES];   // distinct DCI payload sizes, ascending
   const uint16_t* pbch_rank;       // [120] the same for the PBCH block (D = 40)
   const uint16_t* rankmap;         // [LSN_MAX_SIZES][3*LSN_MAX_DCI_D]: output position -> rank in the circular buffer
+  const uint16_t* crc16_w;         // [LSN_MAX_SIZES + 1][64]: weight x^(n - 1 - i + 16) mod g_CRC16 of payload bit i for each DCI payload size n; last row: the MIB (24 bits)
   // PDSCH
   const uint16_t* validmask;       // [3][14][nof_prb]: 12-bit mask of PDSCH-capable REs (class 0: sf0, 1: sf5, 2: other)
   const uint8_t* gold_x1;          // [LSN_GOLD_LEN] x1(n+1600)

@@ -456,26 +456,34 @@ __device__ __forceinline__ void lsn_push_lt(int& bits, int x, int y)
 {
   asm("v_cmp_lt_i32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(bits) : "v"(x), "v"(y) : "vcc");
 }
-__device__ __forceinline__ void viterbi_tb(const int* symw, uint32_t D_, uint32_t nbits, int lane, unsigned long long& bits_out, uint32_t& rem_out)
+// Add-compare-select on DOUBLED metrics shifted by a per-step constant: with the branch metric of predecessor j >> 1 written as dot + k0 and that of
+// (j >> 1) | 32 as 765 - (dot + k0) (all three outputs complemented), the comparison  mpa + dot + k0  <>  mpb + 765 - dot - k0  is the comparison
+// 2 mpa + e  <>  2 mpb - e  with e = 2 dot + 2 k0 - 765: ONE v_dot4 (sign word +-2, accumulator 2 k0 - 765) instead of two, and both candidates move
+// by the same amount per step, so decisions, the order of the end metrics and their ties are those of the plain recursion (M = 2 m - 765 t).
+// |M| <= 2 x 765 x 240 steps: no wrap in 32 bits.
+__device__ __forceinline__ int lsn_dot4_acc(int sw, int sg, int cc)
+{
+  int d;
+  asm("v_dot4_i32_i8 %0, %1, %2, %3\n\ts_nop 2" : "=&v"(d) : "v"(sw), "v"(sg), "v"(cc));
+  return d;
+}
+__device__ __forceinline__ void viterbi_tb(const int* symw, uint32_t D_, uint32_t nbits, const uint16_t* __restrict__ crcw, int lane, unsigned long long& bits_out, uint32_t& rem_out)
 {
   __syncthreads();
   const int D = (int)D_;  // <= 80: the payload is returned in 64 bits
   // lane = new state j: input bit b = j&1, predecessors j>>1 and (j>>1)|32; generator masks on the old state
   const int b = lane & 1, s0 = lane >> 1;
   const int c0 = b ^ (__popc(s0 & 0x36) & 1), c1 = b ^ (__popc(s0 & 0x27) & 1), c2 = b ^ (__popc(s0 & 0x2B) & 1);
-  // branch metric from predecessor j>>1: sum of c_i ? 255 - q_i : q_i = dot(sign, q - 128) + k0; from (j>>1)|32 (all three outputs
-  // complemented): 765 - that = dot(-sign, q - 128) + (765 - k0)
-  const int signs = (c0 ? 0xFF : 0x01) | (c1 ? 0xFF00 : 0x0100) | (c2 ? 0xFF0000 : 0x010000);
-  const int nsigns = (c0 ? 0x01 : 0xFF) | (c1 ? 0x0100 : 0xFF00) | (c2 ? 0x010000 : 0xFF0000);
-  const int k0c = (c0 ? 127 : 128) + (c1 ? 127 : 128) + (c2 ? 127 : 128), k1c = 765 - k0c;
+  // branch metric from predecessor j>>1: sum of c_i ? 255 - q_i : q_i = dot(sign, q - 128) + k0
+  const int signs2 = (c0 ? 0xFE : 0x02) | (c1 ? 0xFE00 : 0x0200) | (c2 ? 0xFE0000 : 0x020000);
+  const int k0c = (c0 ? 127 : 128) + (c1 ? 127 : 128) + (c2 ? 127 : 128), kap = 2 * k0c - 765;
   const int pa = s0 << 2, pb = (s0 | 32) << 2;  // ds_bpermute byte addresses of the two predecessors
   int m = 0;
   // pass 1 only warms the path metrics up: no decision is kept
   {
     auto acs = [&](int k) {
-      int bm0, bm1;
-      lsn_dot4x2(symw[k], signs, k0c, nsigns, k1c, bm0, bm1);
-      const int a0 = __builtin_amdgcn_ds_bpermute(pa, m) + bm0, a1 = __builtin_amdgcn_ds_bpermute(pb, m) + bm1;
+      const int e = lsn_dot4_acc(symw[k], signs2, kap);
+      const int a0 = __builtin_amdgcn_ds_bpermute(pa, m) + e, a1 = __builtin_amdgcn_ds_bpermute(pb, m) - e;
       m = a1 < a0 ? a1 : a0;
     };
     int k = 0;
@@ -490,9 +498,8 @@ __device__ __forceinline__ void viterbi_tb(const int* symw, uint32_t D_, uint32_
     for (int g = 0; g < 3; g++) {
       const int k1 = D < 32 * (g + 1) ? D : 32 * (g + 1);
       auto acs = [&](int k) {
-        int bm0, bm1;
-        lsn_dot4x2(symw[k], signs, k0c, nsigns, k1c, bm0, bm1);
-        const int a0 = __builtin_amdgcn_ds_bpermute(pa, m) + bm0, a1 = __builtin_amdgcn_ds_bpermute(pb, m) + bm1;
+        const int e = lsn_dot4_acc(symw[k], signs2, kap);
+        const int a0 = __builtin_amdgcn_ds_bpermute(pa, m) + e, a1 = __builtin_amdgcn_ds_bpermute(pb, m) - e;
         lsn_push_lt(h[g], a1, a0);
         m = a1 < a0 ? a1 : a0;
       };
@@ -503,8 +510,8 @@ __device__ __forceinline__ void viterbi_tb(const int* symw, uint32_t D_, uint32_
   };
   sweep(h2);
   sweep(h3);
-  // best end state: minimum metric, lowest index on ties
-  unsigned long long key = ((unsigned long long)(unsigned)m << 6) | (unsigned)lane;
+  // best end state: minimum metric, lowest index on ties (the metrics are negative by now: biased into an unsigned key)
+  unsigned long long key = ((unsigned long long)((unsigned)m ^ 0x80000000u) << 6) | (unsigned)lane;
   for (int off = 32; off > 0; off >>= 1) {
     unsigned long long o2 = __shfl_xor(key, off);
     key = o2 < key ? o2 : key;
@@ -531,16 +538,13 @@ __device__ __forceinline__ void viterbi_tb(const int* symw, uint32_t D_, uint32_
   };
   back(h3, false);
   back(h2, true);
-  if (lane == 0) {
-    // CRC16 (x^16+x^12+x^5+1) over the payload, zero-augmented long division
-    unsigned int reg = 0;
-    for (int i = 0; i < (int)nbits + 16; i++) {
-      unsigned int bit = i < (int)nbits ? (unsigned)((bits >> (63 - i)) & 1ull) : 0u;
-      reg = (reg << 1) | bit;
-      if (reg & 0x10000u) reg ^= 0x11021u;
-    }
-    const uint32_t rnti = (tailcrc ^ reg) & 0xFFFFu;
-    rem_out = rnti;
+  // CRC16 (x^16+x^12+x^5+1) of the payload, all lanes at once: payload bit i weighs x^(nbits - 1 - i + 16) mod g (crcw, built by the host per payload
+  // size), the remainder is the XOR of the weights of the set bits (rounds 1-3: a 60-step long division on lane 0 - a third of the kernel's vector
+  // instructions, issued for one working lane)
+  {
+    unsigned int v = (lane < (int)nbits && ((bits >> (63 - lane)) & 1ull)) ? (unsigned int)crcw[lane] : 0u;
+    for (int off = 32; off > 0; off >>= 1) v ^= __shfl_xor(v, off);
+    rem_out = (tailcrc ^ v) & 0xFFFFu;
   }
   bits_out = bits;
 }
@@ -800,7 +804,7 @@ __global__ __launch_bounds__(64) void k_viterbi(LsnCellDev c, const float* __res
     return;
   }
   unsigned long long bits; uint32_t rnti;
-  viterbi_tb(symw, D, nbits, lane, bits, rnti);
+  viterbi_tb(symw, D, nbits, c.crc16_w + sz * 64, lane, bits, rnti);
   if (lane == 0) {
     out->bits = bits;
     out->rnti = rnti;
@@ -905,7 +909,7 @@ __global__ __launch_bounds__(64) void k_pbch_viterbi(LsnCellDev c, const float* 
     symw[t] = (int)word;
   }
   unsigned long long bits; uint32_t rem;
-  viterbi_tb(symw, D, 24, lane, bits, rem);
+  viterbi_tb(symw, D, 24, c.crc16_w + LSN_MAX_SIZES * 64, lane, bits, rem);
   if (lane == 0) { out4[q].bits = bits; out4[q].rnti = rem; out4[q].flags = 1u; }
 }
 void lsn_launch_pbch(const LsnCellDev& c, const cf32* grid, const cf32* ce, const LsnChest* ch, float* llr5, LsnCand* out4, hipStream_t s)
