@@ -80,7 +80,7 @@ private:
   lsn_phy_t* h = nullptr;
   double interval = 5.0;                               // MCSTracking.h:162
 };
-class HARQ;        // HARQ.h: harq_mode is 0 in the reference (ArgManager.cc:50); accepted and ignored
+class HARQ;        // HARQ.h: the database lives inside the library (harq_mode 1: soft combining, DL mode; 0: the reference's only reachable value, ArgManager.cc:50); the pointer is accepted and ignored
 class ULSchedule;  // ULSchedule.h: the schedule lives inside the library; the SIB2 values are learned there (decode_SIB) or given through Phy::setUlConfig
 
 class Phy {
