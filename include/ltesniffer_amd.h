@@ -32,7 +32,7 @@ typedef struct lsn_worker lsn_worker_t; /* replaces class SubframeWorker (Subfra
 /* srsran_cell_t subset that crosses the boundary (SubframeWorker::setCell, SubframeWorker.cc:100-107) */
 typedef struct {
   uint32_t nof_prb;         /* 6, 15, 25, 50, 75, 100 */
-  uint32_t nof_ports;       /* 1 or 2 CRS ports */
+  uint32_t nof_ports;       /* 1, 2 or 4 CRS ports (4: transmit diversity on every channel; spatial-multiplexing grants are found and not decoded, as with the reference's srsRAN) */
   uint32_t id;              /* physical cell id */
   uint32_t cp;              /* 0 = normal (only value supported) */
   uint32_t phich_length;    /* 0 = normal */

@@ -208,7 +208,7 @@ int Engine::setCell(const lsn_cell_t& c)
 {
   static const uint32_t ng_x6[4] = {1, 3, 6, 12};
   if (c.cp != 0 || c.frame_type != 0 || c.phich_length != 0 || c.phich_resources > 3) return LSN_ERROR_INVALID_INPUTS;
-  if (c.nof_ports < 1 || c.nof_ports > 2 || c.id > 503) return LSN_ERROR_INVALID_INPUTS;
+  if ((c.nof_ports != 1 && c.nof_ports != 2 && c.nof_ports != 4) || c.id > 503) return LSN_ERROR_INVALID_INPUTS;
   switch (c.nof_prb) { case 6: case 15: case 25: case 50: case 75: case 100: break; default: return LSN_ERROR_INVALID_INPUTS; }
   cpu_set_t saved_mask;
   const bool pinned = pinThisThread(&saved_mask);  // pinned host buffers are first touched on the GPU's node
@@ -509,7 +509,7 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
     // demodulation possible? (srsran_pdsch_decode preconditions)
     bool demod_ok = (g.tb[0].enabled || g.tb[1].enabled) && g.nof_re > 0;
     if (g.tx_scheme == TXSCHEME_SPATIALMUX || g.tx_scheme == TXSCHEME_CDD) {
-      if (cell.nof_ports < 2) demod_ok = false;
+      if (cell.nof_ports != 2) demod_ok = false;  // one port: no such transmission; four ports: the reference's srsRAN precodes them for transmit diversity only
       if (g.nof_layers != 1 && dlRx() < 2) demod_ok = false;
     }
     if (g.tx_scheme == TXSCHEME_DIVERSITY && cell.nof_ports < 2) demod_ok = false;
@@ -1782,15 +1782,17 @@ long Engine::tap(int what, uint32_t sf, void* out, size_t cap)
     case LSN_TAP_CE: return d2h(ch.d_ce + (size_t)sf * P * A * 14 * nre, P * A * 14 * nre * sizeof(cf32));
     case LSN_TAP_PDCCH_LLR: return d2h(ch.d_llr + (size_t)sf * LSN_LLR_STRIDE, (size_t)cd.nof_cce[ch.ctx[sf].cfi - 1] * 72 * sizeof(float));
     case LSN_TAP_CHEST: {
-      // layout of the test-side record: noise[2][2], rsrp[2][2], cepow[2][2], corr_r, corr_i, noise_avg, rsrp_avg, snr_db, cfo_hz, chan_ref
-      float r[19] = {0};
+      // layout of the test-side record: noise[2][W], rsrp[2][W], cepow[2][W] with W = 2 (one or two ports) or 4, then corr_r, corr_i, noise_avg,
+      // rsrp_avg, snr_db, cfo_hz, chan_ref: 19 or 31 floats
+      float r[31] = {0};
       const LsnChest& h = ch.h_chest[sf];
+      const size_t W = P == 4 ? 4 : 2, T = 6 * W;
       for (size_t rx = 0; rx < A; rx++)
         for (size_t p = 0; p < P; p++) {
-          r[rx * 2 + p] = h.noise[rx * P + p]; r[4 + rx * 2 + p] = h.rsrp[rx * P + p]; r[8 + rx * 2 + p] = h.cepow[rx * P + p];
+          r[rx * W + p] = h.noise[rx * P + p]; r[2 * W + rx * W + p] = h.rsrp[rx * P + p]; r[4 * W + rx * W + p] = h.cepow[rx * P + p];
         }
-      r[12] = h.corr_r; r[13] = h.corr_i; r[14] = h.noise_avg; r[15] = h.rsrp_avg; r[16] = ch.ctx[sf].snr_db; r[17] = ch.ctx[sf].cfo_hz; r[18] = h.chan_ref;
-      return h2h(r, sizeof(r));
+      r[T] = h.corr_r; r[T + 1] = h.corr_i; r[T + 2] = h.noise_avg; r[T + 3] = h.rsrp_avg; r[T + 4] = ch.ctx[sf].snr_db; r[T + 5] = ch.ctx[sf].cfo_hz; r[T + 6] = h.chan_ref;
+      return h2h(r, (T + 7) * sizeof(float));
     }
     case LSN_TAP_CFI: return h2h(&ch.ctx[sf].cfi, sizeof(uint32_t));
     case LSN_TAP_CANDIDATES: return h2h(ch.h_cand + (size_t)sf * LSN_MAX_LOC * LSN_MAX_SIZES, (size_t)LSN_MAX_LOC * LSN_MAX_SIZES * sizeof(LsnCand));

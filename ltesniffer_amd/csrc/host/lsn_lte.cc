@@ -262,6 +262,7 @@ int ra_tbs_from_idx(int i_tbs, uint32_t n_prb)
 bool pdsch_re_usable(const Cell& cell, uint32_t sf_idx, uint32_t l, uint32_t k)
 {
   const bool crs_symbol = l == 0 || l == 4 || l == 7 || l == 11;
+  if (cell.nof_ports == 4 && (l == 1 || l == 8) && k % 3 == cell.id % 3) return false;  // CRS of ports 2, 3
   if (crs_symbol) {
     if (cell.nof_ports >= 2) { if (k % 3 == cell.id % 3) return false; }
     else if (k % 6 == (((l == 0 || l == 7) ? 0u : 3u) + cell.id % 6) % 6) return false;

@@ -208,17 +208,19 @@ void Engine::buildTables()
     const float s = 0.70710678118654752440f;
     std::vector<cf32> crs((size_t)10 * P * 4 * cd.nref);
     std::vector<uint8_t> c(440);
-    static const int sym[4] = {0, 4, 7, 11};
+    // ports 0 / 1 share pilot symbols 0, 4, 7, 11 and their sequences; ports 2 / 3 share symbols 1, 8 (rows 0, 1 of their [4][nref] block)
+    static const int sym01[4] = {0, 4, 7, 11}, sym23[2] = {1, 8};
     for (uint32_t sf = 0; sf < 10; sf++)
-      for (int q = 0; q < 4; q++) {
-        const uint32_t l = sym[q], ns = 2 * sf + (l >= 7 ? 1 : 0), lsl = l % 7;
-        gold_sequence(1024u * (7u * (ns + 1) + lsl + 1) * (2u * id + 1) + 2u * id + 1, c.data(), 440);
-        for (uint32_t m = 0; m < cd.nref; m++) {
-          const uint32_t mp = m + 110 - nprb;
-          cf32 v{c[2 * mp] ? -s : s, c[2 * mp + 1] ? -s : s};
-          for (uint32_t p = 0; p < P; p++) crs[((sf * P + p) * 4 + q) * cd.nref + m] = v;
+      for (uint32_t p0 = 0; p0 < P; p0 += 2)
+        for (int q = 0; q < (p0 == 0 ? 4 : 2); q++) {
+          const uint32_t l = p0 == 0 ? sym01[q] : sym23[q], ns = 2 * sf + (l >= 7 ? 1 : 0), lsl = l % 7;
+          gold_sequence(1024u * (7u * (ns + 1) + lsl + 1) * (2u * id + 1) + 2u * id + 1, c.data(), 440);
+          for (uint32_t m = 0; m < cd.nref; m++) {
+            const uint32_t mp = m + 110 - nprb;
+            cf32 v{c[2 * mp] ? -s : s, c[2 * mp + 1] ? -s : s};
+            for (uint32_t p = p0; p < p0 + 2 && p < P; p++) crs[((sf * P + p) * 4 + q) * cd.nref + m] = v;
+          }
         }
-      }
     cd.crs = upload(dev_allocs, crs);
   }
   // REGs: PCFICH (36.211 6.7.4), PHICH (6.9.3, normal duration), PDCCH quadruplet -> REG map (6.8.5)
@@ -234,13 +236,14 @@ void Engine::buildTables()
     for (int m = 0; m < ng; m++) for (int i = 0; i < 3; i++) used0[avail[((int)id + m + (i * na) / 3) % na]] = 1;
     std::vector<uint16_t> rk(3 * 800, 0);
     std::vector<uint8_t> rl(3 * 800, 0);
-    std::vector<uint16_t> rq(3 * 800, 0xFFFFu);  // natural REG index: symbol 0 has nre / 6 REGs, every later control symbol nre / 4
+    std::vector<uint16_t> rq(3 * 800, 0xFFFFu);  // natural REG index: symbol 0 (and symbol 1 of a four-port cell) has nre / 6 REGs, every later control symbol nre / 4
+    const int w1 = P == 4 ? 6 : 4;                // symbol 1 carries the CRS of ports 2, 3
     for (int cfi = 1; cfi <= 3; cfi++) {
       const int nsym = cfi + (nprb <= 10 ? 1 : 0);
       std::vector<std::pair<uint16_t, uint8_t>> regs;
       for (int k = 0; k < nre; k++)
         for (int l = 0; l < nsym; l++) {
-          const int w = l == 0 ? 6 : 4;
+          const int w = l == 0 ? 6 : l == 1 ? w1 : 4;
           if (k % w || (l == 0 && used0[k / 6])) continue;
           regs.push_back({(uint16_t)k, (uint8_t)l});
         }
@@ -252,7 +255,8 @@ void Engine::buildTables()
         const int q = perm[(mp + (int)id) % M];
         if (q < 800) {
           rk[(cfi - 1) * 800 + q] = regs[mp].first; rl[(cfi - 1) * 800 + q] = regs[mp].second;
-          const int l = regs[mp].second, nat = l == 0 ? regs[mp].first / 6 : n0 + (l - 1) * (nre / 4) + regs[mp].first / 4;
+          const int l = regs[mp].second;
+          const int nat = l == 0 ? regs[mp].first / 6 : l == 1 ? n0 + regs[mp].first / w1 : n0 + nre / w1 + (l - 2) * (nre / 4) + regs[mp].first / 4;
           if (nat < 800) rq[(cfi - 1) * 800 + nat] = (uint16_t)q;
         }
       }

@@ -7,7 +7,7 @@
 struct cf32 { float r, i; };
 
 #define LSN_MAX_RX 2
-#define LSN_MAX_PORTS 2
+#define LSN_MAX_PORTS 4
 #define LSN_LLR_STRIDE 6400   // PDCCH LLR floats reserved per subframe (>= 8*787)
 #define LSN_MAX_DCI_D 144     // payload + 16
 #define LSN_NEG_METRIC (-12000)
@@ -17,7 +17,7 @@ struct cf32 { float r, i; };
 // per-subframe channel estimation scalars produced on the device (the host adds snr_db / cfo_hz)
 struct LsnChest {
   float noise_avg, rsrp_avg, chan_ref, corr_r, corr_i;
-  float noise[4], rsrp[4], cepow[4];  // [rx*nof_ports + port]
+  float noise[LSN_MAX_RX * LSN_MAX_PORTS], rsrp[LSN_MAX_RX * LSN_MAX_PORTS], cepow[LSN_MAX_RX * LSN_MAX_PORTS];  // [rx*nof_ports + port]
   float pad[3];
 };
 
@@ -30,7 +30,7 @@ struct LsnCellDev {
   const cf32* twiddle3;     // N = 1536 only: [1536] exp(-2 pi i k/1536) of the radix-3 combination, else null
   const cf32* nco_coarse;   // [4096]
   const cf32* nco_fine;     // [1024]
-  const cf32* crs;          // [10][ports][4][nref]
+  const cf32* crs;          // [10][ports][4][nref]; ports 2, 3: rows 0, 1 = symbols 1, 8
   const uint16_t* reg_k0;   // [3][800] quadruplet -> first RE of its REG
   const uint8_t* reg_l;     // [3][800]
   const uint16_t* reg_q;    // [3][800] inverse map: REG in (symbol, frequency) order -> quadruplet of the PDCCH order, 0xFFFF = PCFICH / PHICH

@@ -132,7 +132,8 @@ void lsn_launch_ofdm(const LsnCellDev& c, const cf32* iq, const uint32_t* dphi, 
 // ------------------------------------------------------------------------------------------------ channel estimation
 __device__ __forceinline__ int crs_koff(const LsnCellDev& c, int port, int s)
 {
-  int v = (port == 0) ? ((s & 1) ? 3 : 0) : ((s & 1) ? 0 : 3);
+  // ports 0, 1: pilot symbols 0, 4, 7, 11 (s = 0..3); ports 2, 3: symbols 1, 8 (s = 0, 1) with v = 3 (n_s mod 2) / 3 + 3 (n_s mod 2), 36.211 6.10.1.2
+  int v = (port == 0) ? ((s & 1) ? 3 : 0) : (port == 1) ? ((s & 1) ? 0 : 3) : (port == 2) ? 3 * s : 3 + 3 * s;
   return (v + (int)(c.id % 6)) % 6;
 }
 
@@ -147,10 +148,11 @@ __global__ __launch_bounds__(256) void k_chest(LsnCellDev c, const cf32* __restr
   cf32* ls = (cf32*)smem;           // [4*nref]
   cf32* sm = ls + 4 * nref;         // [4*nref]
   float* part = (float*)(sm + 4 * nref);  // [6][256]
-  const int sym[4] = {0, 4, 7, 11};
+  const int S = p < 2 ? 4 : 2;  // pilot symbols of this port
+  const int sym[4] = {p < 2 ? 0 : 1, p < 2 ? 4 : 8, 7, 11};
   const cf32* g = grid + ((size_t)sf * A + rx) * 14 * nre;
   const cf32* crs = c.crs + ((size_t)sf_idx_arr[sf] * P + p) * 4 * nref;
-  const int n4 = 4 * nref;
+  const int n4 = S * nref;
   for (int i = tid; i < n4; i += 256) {
     int s = i / nref, m = i - s * nref;
     ls[i] = cmulconj(g[sym[s] * nre + 6 * m + crs_koff(c, p, s)], crs[i]);
@@ -178,11 +180,12 @@ __global__ __launch_bounds__(256) void k_chest(LsnCellDev c, const cf32* __restr
     p2 = p2 + ls[i].i;
     p3 = p3 + (sm[i].r * sm[i].r + sm[i].i * sm[i].i);
   }
-  for (int i = tid; i < 2 * nref; i += 256) {
-    cf32 t = (i < nref) ? cmulconj(ls[2 * nref + i], ls[i]) : cmulconj(ls[3 * nref + (i - nref)], ls[nref + (i - nref)]);
-    p4 = p4 + t.r;
-    p5 = p5 + t.i;
-  }
+  if (p < 2)  // the slot-to-slot correlation of the CFO estimate: ports 2, 3 change their subcarriers between the slots and stay out
+    for (int i = tid; i < 2 * nref; i += 256) {
+      cf32 t = (i < nref) ? cmulconj(ls[2 * nref + i], ls[i]) : cmulconj(ls[3 * nref + (i - nref)], ls[nref + (i - nref)]);
+      p4 = p4 + t.r;
+      p5 = p5 + t.i;
+    }
   part[0 * 256 + tid] = p0; part[1 * 256 + tid] = p1; part[2 * 256 + tid] = p2;
   part[3 * 256 + tid] = p3; part[4 * 256 + tid] = p4; part[5 * 256 + tid] = p5;
   __syncthreads();
@@ -200,6 +203,7 @@ __global__ __launch_bounds__(256) void k_chest(LsnCellDev c, const cf32* __restr
     cf32 row[4];
 #pragma unroll
     for (int s = 0; s < 4; s++) {
+      if (s >= S) break;
       int koff = crs_koff(c, p, s);
       const cf32* pl = sm + s * nref;
       int m = (k - koff) >= 0 ? (k - koff) / 6 : 0;
@@ -208,6 +212,17 @@ __global__ __launch_bounds__(256) void k_chest(LsnCellDev c, const cf32* __restr
       float f = (float)(k - (6 * m + koff));
       row[s].r = pl[m].r + dr * f;
       row[s].i = pl[m].i + di * f;
+    }
+    if (p >= 2) {  // ports 2, 3: one line through symbols 1 and 8 for the whole subframe
+      const cf32 c1 = row[0], c8 = row[1];
+      const float dr = (c8.r - c1.r) / 7.0f, di = (c8.i - c1.i) / 7.0f;
+      co[1 * nre + k] = c1; co[8 * nre + k] = c8;
+#pragma unroll
+      for (int l = 0; l < 14; l++) {
+        if (l == 1 || l == 8) continue;
+        cf32 v; v.r = c1.r + dr * (float)(l - 1); v.i = c1.i + di * (float)(l - 1); co[l * nre + k] = v;
+      }
+      continue;
     }
     cf32 c0 = row[0], c4 = row[1], c7 = row[2], c11 = row[3];
     float d01r = (c4.r - c0.r) / 4.0f, d01i = (c4.i - c0.i) / 4.0f;
@@ -236,13 +251,13 @@ __global__ void k_chest_fin(LsnCellDev c, const float* __restrict__ raw, LsnChes
   uint32_t sf = blockIdx.x * blockDim.x + threadIdx.x;
   if (sf >= nsf) return;
   const int A = (int)c.nof_rx, P = (int)c.nof_ports;
-  const float n = (float)(4 * c.nref);
   LsnChest o;
   float ns = 0.0f, rs = 0.0f, cp = 0.0f, cr = 0.0f, ci = 0.0f;
-  for (int q = 0; q < 4; q++) { o.noise[q] = 0.0f; o.rsrp[q] = 0.0f; o.cepow[q] = 0.0f; }
+  for (int q = 0; q < LSN_MAX_RX * LSN_MAX_PORTS; q++) { o.noise[q] = 0.0f; o.rsrp[q] = 0.0f; o.cepow[q] = 0.0f; }
   for (int rx = 0; rx < A; rx++)
     for (int p = 0; p < P; p++) {
       const float* r = raw + (((size_t)sf * A + rx) * P + p) * 8;
+      const float n = (float)((p < 2 ? 4 : 2) * c.nref);  // pilots of the port in one subframe
       float noise = r[0] / n, mr = r[1] / n, mi = r[2] / n, cepow = r[3] / n;
       float rsrp = mr * mr + mi * mi;
       o.noise[rx * P + p] = noise; o.rsrp[rx * P + p] = rsrp; o.cepow[rx * P + p] = cepow;
@@ -260,7 +275,7 @@ void lsn_launch_chest_fin(const LsnCellDev& c, const float* raw, LsnChest* out, 
 }
 
 // ------------------------------------------------------------------------------------------------ control region
-// equalise the 4 data REs of one REG (36.211 6.2.4) -> 4 QPSK symbols; single port: MRC/(|h|^2+noise), two ports: SFBC
+// equalise the 4 data REs of one REG (36.211 6.2.4) -> 4 QPSK symbols; single port: MRC/(|h|^2+noise), two ports: SFBC, four: SFBC-FSTD
 // g / ce point at symbol l of antenna 0 (port 0); rs = distance between antennas, ps = distance between ports (in REs), so the
 // same arithmetic runs on the global grids (rs = 14 nre, ps = A 14 nre) and on rows staged in LDS (rs = nre, ps = A nre)
 __device__ __forceinline__ void reg_equalise(const LsnCellDev& c, const cf32* __restrict__ g, const cf32* __restrict__ ce, float noise,
@@ -268,7 +283,7 @@ __device__ __forceinline__ void reg_equalise(const LsnCellDev& c, const cf32* __
 {
   const int A = (int)c.nof_rx;
   int kk[4], n = 0;
-  if (l == 0) {
+  if (l == 0 || (l == 1 && c.nof_ports == 4)) {  // the REG spans 6 REs, two of them CRS positions (symbol 1: ports 2, 3 of a four-port cell)
     for (int k = k0; k < k0 + 6; k++)
       if ((k % 3) != (int)(c.id % 3)) { if (n < 4) kk[n] = k; n++; }
   } else {
@@ -292,9 +307,11 @@ __device__ __forceinline__ void reg_equalise(const LsnCellDev& c, const cf32* __
 #pragma unroll
     for (int i = 0; i < 4; i += 2) {
       float x0r = 0, x0i = 0, x1r = 0, x1i = 0, hh = 0;
+      // two ports: SFBC on ports (0, 1); four ports (SFBC-FSTD, 36.211 6.3.4.3): first pair of the quadruplet on ports (0, 2), second on (1, 3)
+      const int pa = (c.nof_ports == 4 && i == 2) ? 1 : 0, pb = c.nof_ports == 4 ? pa + 2 : 1;
       for (int rx = 0; rx < A; rx++) {
-        const int b0 = rx * rs, b1 = ps + rx * rs;
-        cf32 r0 = g[b0 + kk[i]], r1 = g[b0 + kk[i + 1]];
+        const int bg = rx * rs, b0 = pa * ps + rx * rs, b1 = pb * ps + rx * rs;
+        cf32 r0 = g[bg + kk[i]], r1 = g[bg + kk[i + 1]];
         cf32 h00 = ce[b0 + kk[i]], h01 = ce[b0 + kk[i + 1]], h10 = ce[b1 + kk[i]], h11 = ce[b1 + kk[i + 1]];
         float hp = (h00.r * h00.r + h00.i * h00.i) + (h11.r * h11.r + h11.i * h11.i);
         cf32 a = cmulconj(r0, h00), b = cmulconj(h11, r1), cc = cmulconj(h10, r0), d = cmulconj(r1, h01);
@@ -357,6 +374,10 @@ __global__ __launch_bounds__(256) void k_pdcch_llr(LsnCellDev c, const cf32* __r
   const int nat = blockIdx.x * 256 + threadIdx.x;
   int l, k0;
   if (nat < n0) { l = 0; k0 = 6 * nat; }
+  else if (c.nof_ports == 4) {  // symbol 1 carries the CRS of ports 2, 3: 6-RE REGs like symbol 0
+    if (nat < 2 * n0) { l = 1; k0 = 6 * (nat - n0); }
+    else { const int r = nat - 2 * n0; l = 2 + r / n1; k0 = 4 * (r - (l - 2) * n1); }
+  }
   else { const int r = nat - n0; l = 1 + r / n1; k0 = 4 * (r - (l - 1) * n1); }
   if ((uint32_t)l >= cfi + (c.nof_prb <= 10 ? 1u : 0u) || nat >= 800) return;  // 36.211 6.7: one more control symbol at <= 10 PRB
   const uint32_t q = c.reg_q[(cfi - 1) * 800 + nat];
@@ -856,9 +877,12 @@ __global__ __launch_bounds__(256) void k_pbch_llr(LsnCellDev c, const cf32* __re
     i0 = 2 * tid;
     int l, ka, kb, l2; pbch_pos(c, i0, l, ka); pbch_pos(c, i0 + 1, l2, kb);
     float x0r = 0, x0i = 0, x1r = 0, x1i = 0, hh = 0;
+    // four ports (SFBC-FSTD): symbol pairs alternate between the port pairs (0, 2) and (1, 3)
+    const size_t pa = (c.nof_ports == 4 && (tid & 1)) ? 1 : 0, pb = c.nof_ports == 4 ? pa + 2 : 1;
     for (int rx = 0; rx < A; rx++) {
-      const size_t b0 = ((size_t)rx * 14 + l) * nre, b1 = (((size_t)A + rx) * 14 + l) * nre;
-      const cf32 r0 = g[b0 + ka], r1 = g[b0 + kb];
+      const size_t bg = ((size_t)rx * 14 + l) * nre;
+      const size_t b0 = ((pa * (size_t)A + rx) * 14 + l) * nre, b1 = ((pb * (size_t)A + rx) * 14 + l) * nre;
+      const cf32 r0 = g[bg + ka], r1 = g[bg + kb];
       const cf32 h00 = ce[b0 + ka], h01 = ce[b0 + kb], h10 = ce[b1 + ka], h11 = ce[b1 + kb];
       const float hp = (h00.r * h00.r + h00.i * h00.i) + (h11.r * h11.r + h11.i * h11.i);
       const cf32 a = cmulconj(r0, h00), b = cmulconj(h11, r1), cc = cmulconj(h10, r0), d = cmulconj(r1, h01);

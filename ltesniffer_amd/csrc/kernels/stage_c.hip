@@ -145,7 +145,7 @@ __global__ __launch_bounds__(192) void k_pdsch_demod(LsnCellDev c, const LsnGran
       emit(c, (int)g.qm[0], x, den / chan_ref, inv_amp, g.cinit[0], idx, out0);
       break;
     }
-    case 1: {  // transmit diversity (SFBC), pairs of consecutive REs of the mapping order
+    case 1: {  // transmit diversity (SFBC; SFBC-FSTD with four ports), pairs of consecutive REs of the mapping order
       // A pair never leaves its PRB here: an RE without partner inside the PRB (odd number of PDSCH REs in a PRB of this symbol) carries zero soft
       // bits, as in the oracle's zero-initialised buffer.  The kernel writes those zeros itself (rounds 1-3 cleared the whole arena in front of
       // every launch: 0.29 MB of HBM traffic per subframe and one fill kernel per decode launch).
@@ -159,9 +159,13 @@ __global__ __launch_bounds__(192) void k_pdsch_demod(LsnCellDev c, const LsnGran
       if (idx & 1u) return;
       const int k2 = k + 1 + (__ffs(hi) - 1);
       float x0r = 0, x0i = 0, x1r = 0, x1i = 0, hh = 0;
+      // four ports (SFBC-FSTD, 36.211 6.3.4.3): symbol pairs alternate between the port pairs (0, 2) and (1, 3); each pair sees half of the ports
+      // chan_ref sums over, so its weight doubles
+      const bool fstd = c.nof_ports == 4;
+      const int pa = (fstd && (idx & 2u)) ? 1 : 0, pb = fstd ? pa + 2 : 1;
       for (int rx = 0; rx < A; rx++) {
         cf32 r0 = GRID(rx, k), r1 = GRID(rx, k2);
-        cf32 h00 = CE(0, rx, k), h01 = CE(0, rx, k2), h10 = CE(1, rx, k), h11 = CE(1, rx, k2);
+        cf32 h00 = CE(pa, rx, k), h01 = CE(pa, rx, k2), h10 = CE(pb, rx, k), h11 = CE(pb, rx, k2);
         float hp = cabs2(h00) + cabs2(h11);
         cf32 a = cmulconj(r0, h00), b = cmulconj(h11, r1), cc = cmulconj(h10, r0), d = cmulconj(r1, h01);
         float t0r = a.r + b.r, t0i = a.i + b.i, t1r = d.r - cc.r, t1i = d.i - cc.i;
@@ -170,7 +174,7 @@ __global__ __launch_bounds__(192) void k_pdsch_demod(LsnCellDev c, const LsnGran
       }
       cf32 x0, x1;
       x0.r = x0r / hh * SQRT2F; x0.i = x0i / hh * SQRT2F; x1.r = x1r / hh * SQRT2F; x1.i = x1i / hh * SQRT2F;
-      float w = hh / chan_ref;
+      float w = hh * (fstd ? 2.0f : 1.0f) / chan_ref;
       emit(c, (int)g.qm[0], x0, w, inv_amp, g.cinit[0], idx, out0);
       emit(c, (int)g.qm[0], x1, w, inv_amp, g.cinit[0], idx + 1, out0);
       break;

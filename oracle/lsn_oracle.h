@@ -31,7 +31,7 @@ extern "C" {
 typedef struct { float r, i; } ocf_t;
 
 #define O_MAX_PRB 110
-#define O_MAX_PORTS 2
+#define O_MAX_PORTS 4
 #define O_MAX_RX 2
 #define O_NSYMB 14
 #define O_MAX_CCE 87
@@ -63,7 +63,7 @@ enum { O_TABLE_64QAM = 0, O_TABLE_256QAM = 1, O_TABLE_UNKNOWN = 2, O_TABLE_BOTH 
 
 typedef struct {
   uint32_t nof_prb;   /* 6,15,25,50,100 (power-of-two FFT sizes only) */
-  uint32_t nof_ports; /* 1 or 2 CRS ports */
+  uint32_t nof_ports; /* 1, 2 or 4 CRS ports (4: every channel in SFBC-FSTD transmit diversity; spatial multiplexing grants are not decodable, as in the reference's srsRAN) */
   uint32_t id;        /* physical cell id 0..503 */
   uint32_t phich_ng_x6; /* Ng*6: 1 (=1/6), 3, 6, 12 ; LTESniffer_Core.cc:211-212 forces 1/6 */
   uint32_t pusch_hop_offset; /* SIB2 pusch-HoppingOffset = n_rb_ho of the uplink grant conversion (SubframeWorker.cc:271-273); 0 until SIB2 is known */
@@ -98,7 +98,7 @@ typedef struct {
   float noise_avg, rsrp_avg, snr_db, cfo_hz, chan_ref; /* chan_ref = sum cepow */
 } o_chest_res_t;
 
-void o_crs_table(const o_cell_t* cell, uint32_t sf_idx, ocf_t* crs /* [port][4][2*nprb] */);
+void o_crs_table(const o_cell_t* cell, uint32_t sf_idx, ocf_t* crs /* [port][4][2*nprb]; ports 2, 3: rows 0, 1 = symbols 1, 8 */);
 /* grid[rx][14][nre] -> ce[port][rx][14][nre], pilots kept in work arrays */
 void o_chest(const o_cell_t* cell, uint32_t nof_rx, uint32_t sf_idx, const ocf_t* grid, ocf_t* ce,
              o_chest_res_t* res);

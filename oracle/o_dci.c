@@ -295,6 +295,9 @@ int o_tbs_from_idx(int i_tbs, uint32_t n_prb)
 int o_pdsch_re_ok(const o_cell_t* cell, uint32_t sf_idx, uint32_t l, uint32_t k)
 {
   uint32_t nprb = cell->nof_prb;
+  if (cell->nof_ports == 4 && (l == 1 || l == 8)) { /* CRS of ports 2, 3 */
+    if ((k % 3) == (cell->id % 3)) return 0;
+  }
   if (l == 0 || l == 4 || l == 7 || l == 11) {
     if (cell->nof_ports >= 2) {
       if ((k % 3) == (cell->id % 3)) return 0;

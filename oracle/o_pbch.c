@@ -5,7 +5,7 @@
  * c_init = N_cell_ID re-started every 40 ms, QPSK, single port or SFBC, 4 x 240 symbols on the 72 centre carriers of
  * symbols 0-3 of slot 1, the CRS positions of four ports left out) and TS 36.212 5.3.1 (MIB 24 bits + CRC16 masked with
  * 0x0000 / 0xFFFF / 0x5555 for 1 / 2 / 4 ports, tail-biting convolutional code, rate matching to 1920 bits).
- * The worker's OFDM + CRS estimate run first with the configured number of ports (1 or 2, like the rest of this restatement);
+ * The worker's OFDM + CRS estimate run first with the configured number of ports (1, 2 or 4, like the rest of this restatement);
  * every quarter of the BCH period holds four complete copies of the 120 coded bits, so one subframe 0 is decoded under the
  * four hypotheses "this is radio frame q of the period" and the CRC (and its port mask) picks the right one.
  * Parity unpinned against srsRAN itself; arithmetic contract as in lsn_oracle.h. */
@@ -49,9 +49,12 @@ void o_pbch_llr(const o_cell_t* cell, uint32_t nof_rx, const ocf_t* grid, const 
   } else {
     for (int i = 0; i < 240; i += 2) {
       float x0r = 0, x0i = 0, x1r = 0, x1i = 0, hh = 0;
+      /* four ports (SFBC-FSTD): symbol pairs alternate between the port pairs (0, 2) and (1, 3) */
+      const size_t pa = (cell->nof_ports == 4 && (i & 2)) ? 1 : 0, pb = cell->nof_ports == 4 ? pa + 2 : 1;
       for (uint32_t rx = 0; rx < nof_rx; rx++) {
-        size_t b0 = ((size_t)rx * 14 + pl[i]) * (size_t)nre, b1 = (((size_t)nof_rx + rx) * 14 + pl[i]) * (size_t)nre;
-        ocf_t r0 = grid[b0 + pk[i]], r1 = grid[b0 + pk[i + 1]];
+        size_t bg = ((size_t)rx * 14 + pl[i]) * (size_t)nre;
+        size_t b0 = ((pa * (size_t)nof_rx + rx) * 14 + pl[i]) * (size_t)nre, b1 = ((pb * (size_t)nof_rx + rx) * 14 + pl[i]) * (size_t)nre;
+        ocf_t r0 = grid[bg + pk[i]], r1 = grid[bg + pk[i + 1]];
         ocf_t h00 = ce[b0 + pk[i]], h01 = ce[b0 + pk[i + 1]], h10 = ce[b1 + pk[i]], h11 = ce[b1 + pk[i + 1]];
         float hp = (h00.r * h00.r + h00.i * h00.i) + (h11.r * h11.r + h11.i * h11.i);
         ocf_t a = cmulconj(r0, h00), b = cmulconj(h11, r1), c = cmulconj(h10, r0), d = cmulconj(r1, h01);

@@ -159,7 +159,7 @@ int o_pdsch_demod(const o_cell_t* cell, uint32_t nof_rx, uint32_t sf_idx, uint32
       c[q] = (uint8_t*)malloc((size_t)nofre * (size_t)qm_cw[q]);
       o_gold(((uint32_t)rnti << 14) | ((uint32_t)q << 13) | (sf_idx << 9) | cell->id, c[q], (int)nofre * qm_cw[q]);
     }
-  /* power allocation 36.213 5.2, p_b = 1 (SubframeWorker.cc:372): rho_B/rho_A = 4/5 (1 port), 1 (2 ports) */
+  /* power allocation 36.213 5.2, p_b = 1 (SubframeWorker.cc:372): rho_B/rho_A = 4/5 (1 port), 1 (2, 4 ports) */
   float rho_a = powf(10.0f, rho_a_db / 20.0f);
   float rho_b = (cell->nof_ports == 1) ? rho_a * sqrtf(0.8f) : rho_a;
   float inv_amp_a = 1.0f / rho_a, inv_amp_b = 1.0f / rho_b;
@@ -186,11 +186,16 @@ int o_pdsch_demod(const o_cell_t* cell, uint32_t nof_rx, uint32_t sf_idx, uint32
     }
     case O_TX_DIVERSITY: {
       int Qm = qm_cw[0];
+      /* four ports (SFBC-FSTD, 36.211 6.3.4.3): symbol pairs alternate between the port pairs (0, 2) and (1, 3); each pair sees half of the
+       * ports chan_ref sums over, so its weight doubles */
+      const int fstd = cell->nof_ports == 4;
+      const float wscale = fstd ? 2.0f : 1.0f;
       for (uint32_t i = 0; i + 1 < nofre; i += 2) {
         float x0r = 0, x0i = 0, x1r = 0, x1i = 0, hh = 0;
+        const uint32_t pa = (fstd && (i & 2u)) ? 1u : 0u, pb = fstd ? pa + 2u : 1u;
         for (uint32_t rx = 0; rx < nof_rx; rx++) {
           ocf_t r0 = GRID(rx, i), r1 = GRID(rx, i + 1);
-          ocf_t h00 = CE(0, rx, i), h01 = CE(0, rx, i + 1), h10 = CE(1, rx, i), h11 = CE(1, rx, i + 1);
+          ocf_t h00 = CE(pa, rx, i), h01 = CE(pa, rx, i + 1), h10 = CE(pb, rx, i), h11 = CE(pb, rx, i + 1);
           float hp = cabs2(h00) + cabs2(h11);
           ocf_t a = cmulconj(r0, h00), b = cmulconj(h11, r1), cc = cmulconj(h10, r0), d = cmulconj(r1, h01);
           float t0r = a.r + b.r, t0i = a.i + b.i, t1r = d.r - cc.r, t1i = d.i - cc.i;
@@ -198,7 +203,7 @@ int o_pdsch_demod(const o_cell_t* cell, uint32_t nof_rx, uint32_t sf_idx, uint32
           else { x0r = x0r + t0r; x0i = x0i + t0i; x1r = x1r + t1r; x1i = x1i + t1i; hh = hh + hp; }
         }
         ocf_t x0 = {x0r / hh * SQRT2F, x0i / hh * SQRT2F}, x1 = {x1r / hh * SQRT2F, x1i / hh * SQRT2F};
-        float w = hh / chan_ref;
+        float w = hh * wscale / chan_ref;
         emit(Qm, x0, w, INVAMP(i), c[0] + (size_t)i * (size_t)Qm, out[0] + (size_t)i * (size_t)Qm);
         emit(Qm, x1, w, INVAMP(i + 1), c[0] + (size_t)(i + 1) * (size_t)Qm, out[0] + (size_t)(i + 1) * (size_t)Qm);
       }
@@ -206,7 +211,7 @@ int o_pdsch_demod(const o_cell_t* cell, uint32_t nof_rx, uint32_t sf_idx, uint32
     }
     case O_TX_SPATIALMUX:
     case O_TX_CDD: {
-      if (cell->nof_ports < 2) { n = 0; break; }
+      if (cell->nof_ports != 2) { n = 0; break; } /* one port: no such transmission; four ports: not decodable (the reference's srsRAN precodes four ports for transmit diversity only) */
       if (g->nof_layers == 1) { /* closed-loop rank 1: w = [1, q]/sqrt2, q = 1,-1,j,-j */
         int Qm = qm_cw[0];
         for (uint32_t i = 0; i < nofre; i++) {

@@ -175,11 +175,21 @@ void o_ofdm_rx(const o_cell_t* cell, const ocf_t* in, uint32_t dphi, ocf_t* grid
 }
 
 /* ---- CRS (36.211 6.10.1) ---- */
-static const int crs_sym[4] = {0, 4, 7, 11};
+/* ports 0, 1: symbols 0, 4 of both slots; ports 2, 3: symbol 1 of both slots */
+static const int crs_sym01[4] = {0, 4, 7, 11};
+static const int crs_sym23[2] = {1, 8};
+static int crs_nsym(int port) { return port < 2 ? 4 : 2; }
+static int crs_l(int port, int s) { return port < 2 ? crs_sym01[s] : crs_sym23[s]; }
 
 static int crs_koff(const o_cell_t* cell, int port, int s)
 {
-  int v = (port == 0) ? ((s & 1) ? 3 : 0) : ((s & 1) ? 0 : 3);
+  int v;
+  switch (port) {
+    case 0: v = (s & 1) ? 3 : 0; break;
+    case 1: v = (s & 1) ? 0 : 3; break;
+    case 2: v = 3 * s; break;         /* 3 (n_s mod 2) */
+    default: v = 3 + 3 * s; break;    /* 3 + 3 (n_s mod 2) */
+  }
   return (v + (int)(cell->id % 6)) % 6;
 }
 
@@ -187,20 +197,21 @@ void o_crs_table(const o_cell_t* cell, uint32_t sf_idx, ocf_t* crs)
 {
   int nref = 2 * (int)cell->nof_prb;
   uint8_t c[2 * 220];
-  for (int s = 0; s < 4; s++) {
-    int l = crs_sym[s];
-    uint32_t ns = 2 * sf_idx + (l >= 7 ? 1u : 0u);
-    uint32_t lslot = (uint32_t)(l % 7);
-    uint32_t cinit = 1024u * (7u * (ns + 1u) + lslot + 1u) * (2u * cell->id + 1u) + 2u * cell->id + 1u;
-    o_gold(cinit, c, 2 * 220);
-    for (int m = 0; m < nref; m++) {
-      int mp = m + 110 - (int)cell->nof_prb;
-      ocf_t r;
-      r.r = c[2 * mp] ? -SQRT1_2F : SQRT1_2F;
-      r.i = c[2 * mp + 1] ? -SQRT1_2F : SQRT1_2F;
-      for (uint32_t p = 0; p < cell->nof_ports; p++) crs[(p * 4 + (uint32_t)s) * (uint32_t)nref + (uint32_t)m] = r;
+  for (uint32_t p = 0; p < cell->nof_ports; p += 2) /* ports 0/1 share their symbols and sequences, and so do ports 2/3 */
+    for (int s = 0; s < crs_nsym((int)p); s++) {
+      int l = crs_l((int)p, s);
+      uint32_t ns = 2 * sf_idx + (l >= 7 ? 1u : 0u);
+      uint32_t lslot = (uint32_t)(l % 7);
+      uint32_t cinit = 1024u * (7u * (ns + 1u) + lslot + 1u) * (2u * cell->id + 1u) + 2u * cell->id + 1u;
+      o_gold(cinit, c, 2 * 220);
+      for (int m = 0; m < nref; m++) {
+        int mp = m + 110 - (int)cell->nof_prb;
+        ocf_t r;
+        r.r = c[2 * mp] ? -SQRT1_2F : SQRT1_2F;
+        r.i = c[2 * mp + 1] ? -SQRT1_2F : SQRT1_2F;
+        for (uint32_t q = p; q < p + 2 && q < cell->nof_ports; q++) crs[(q * 4 + (uint32_t)s) * (uint32_t)nref + (uint32_t)m] = r;
+      }
     }
-  }
 }
 
 static void gauss_taps(float* t)
@@ -233,14 +244,15 @@ void o_chest(const o_cell_t* cell, uint32_t nof_rx, uint32_t sf_idx, const ocf_t
   for (uint32_t rx = 0; rx < nof_rx; rx++) {
     const ocf_t* g = grid + (size_t)rx * 14u * (size_t)nre;
     for (int p = 0; p < P; p++) {
+      const int S = crs_nsym(p), np = S * nref; /* pilot symbols of this port, pilots in the subframe */
       /* least squares at the pilots */
-      for (int s = 0; s < 4; s++) {
+      for (int s = 0; s < S; s++) {
         int koff = crs_koff(cell, p, s);
         for (int m = 0; m < nref; m++)
-          ls[s * nref + m] = cmulconj(g[crs_sym[s] * nre + 6 * m + koff], crs[(p * 4 + s) * nref + m]);
+          ls[s * nref + m] = cmulconj(g[crs_l(p, s) * nre + 6 * m + koff], crs[(p * 4 + s) * nref + m]);
       }
       /* Gaussian smoothing across frequency, zero-padded edges (conv "same") */
-      for (int s = 0; s < 4; s++)
+      for (int s = 0; s < S; s++)
         for (int m = 0; m < nref; m++) {
           float ar = 0.0f, ai = 0.0f;
           for (int j = 0; j < 5; j++) {
@@ -253,38 +265,40 @@ void o_chest(const o_cell_t* cell, uint32_t nof_rx, uint32_t sf_idx, const ocf_t
           sm[s * nref + m].i = ai;
         }
       /* noise (NOISE_ALG_REFS): mean |smoothed - ls|^2 */
-      for (int i = 0; i < 4 * nref; i++) {
+      for (int i = 0; i < np; i++) {
         float dr = sm[i].r - ls[i].r, di = sm[i].i - ls[i].i;
         tmp[i] = dr * dr + di * di;
       }
-      res->noise[rx][p] = o_reduce256(tmp, 4 * nref) / (float)(4 * nref);
+      res->noise[rx][p] = o_reduce256(tmp, np) / (float)np;
       /* RSRP: |mean ls|^2 */
-      for (int i = 0; i < 4 * nref; i++) tmp[i] = ls[i].r;
-      float mr = o_reduce256(tmp, 4 * nref) / (float)(4 * nref);
-      for (int i = 0; i < 4 * nref; i++) tmp[i] = ls[i].i;
-      float mi = o_reduce256(tmp, 4 * nref) / (float)(4 * nref);
+      for (int i = 0; i < np; i++) tmp[i] = ls[i].r;
+      float mr = o_reduce256(tmp, np) / (float)np;
+      for (int i = 0; i < np; i++) tmp[i] = ls[i].i;
+      float mi = o_reduce256(tmp, np) / (float)np;
       res->rsrp[rx][p] = mr * mr + mi * mi;
-      for (int i = 0; i < 4 * nref; i++) tmp[i] = sm[i].r * sm[i].r + sm[i].i * sm[i].i;
-      res->cepow[rx][p] = o_reduce256(tmp, 4 * nref) / (float)(4 * nref);
-      /* CFO: correlate pilots one slot (0.5 ms) apart: symbols (7 vs 0) and (11 vs 4) */
-      for (int m = 0; m < nref; m++) {
-        tmp[m] = cmulconj(ls[2 * nref + m], ls[0 * nref + m]).r;
-        tmp[nref + m] = cmulconj(ls[3 * nref + m], ls[1 * nref + m]).r;
+      for (int i = 0; i < np; i++) tmp[i] = sm[i].r * sm[i].r + sm[i].i * sm[i].i;
+      res->cepow[rx][p] = o_reduce256(tmp, np) / (float)np;
+      if (p < 2) {
+        /* CFO: correlate pilots one slot (0.5 ms) apart: symbols (7 vs 0) and (11 vs 4); ports 2, 3 change their subcarriers between the slots and stay out */
+        for (int m = 0; m < nref; m++) {
+          tmp[m] = cmulconj(ls[2 * nref + m], ls[0 * nref + m]).r;
+          tmp[nref + m] = cmulconj(ls[3 * nref + m], ls[1 * nref + m]).r;
+        }
+        float cr = o_reduce256(tmp, 2 * nref);
+        for (int m = 0; m < nref; m++) {
+          tmp[m] = cmulconj(ls[2 * nref + m], ls[0 * nref + m]).i;
+          tmp[nref + m] = cmulconj(ls[3 * nref + m], ls[1 * nref + m]).i;
+        }
+        float ci = o_reduce256(tmp, 2 * nref);
+        corr_tot.r = corr_tot.r + cr;
+        corr_tot.i = corr_tot.i + ci;
       }
-      float cr = o_reduce256(tmp, 2 * nref);
-      for (int m = 0; m < nref; m++) {
-        tmp[m] = cmulconj(ls[2 * nref + m], ls[0 * nref + m]).i;
-        tmp[nref + m] = cmulconj(ls[3 * nref + m], ls[1 * nref + m]).i;
-      }
-      float ci = o_reduce256(tmp, 2 * nref);
-      corr_tot.r = corr_tot.r + cr;
-      corr_tot.i = corr_tot.i + ci;
 
-      /* frequency interpolation (linear, pilot spacing 6, edge extrapolation) on the 4 pilot symbols */
+      /* frequency interpolation (linear, pilot spacing 6, edge extrapolation) on the pilot symbols */
       ocf_t* c = ce + ((size_t)p * nof_rx + rx) * 14u * (size_t)nre;
-      for (int s = 0; s < 4; s++) {
+      for (int s = 0; s < S; s++) {
         int koff = crs_koff(cell, p, s);
-        ocf_t* row = c + crs_sym[s] * nre;
+        ocf_t* row = c + crs_l(p, s) * nre;
         const ocf_t* pl = sm + s * nref;
         for (int k = 0; k < nre; k++) {
           int m = (k - koff) >= 0 ? (k - koff) / 6 : 0;
@@ -295,6 +309,19 @@ void o_chest(const o_cell_t* cell, uint32_t nof_rx, uint32_t sf_idx, const ocf_t
           row[k].r = pl[m].r + dr * f;
           row[k].i = pl[m].i + di * f;
         }
+      }
+      if (p >= 2) {
+        /* ports 2, 3 [srsRAN chest_dl.c interpolates its two pilot symbols the same way]: one line through symbols 1 and 8 for the whole subframe */
+        for (int k = 0; k < nre; k++) {
+          ocf_t c1 = c[1 * nre + k], c8 = c[8 * nre + k];
+          float dr = (c8.r - c1.r) / 7.0f, di = (c8.i - c1.i) / 7.0f;
+          for (int l = 0; l < 14; l++) {
+            if (l == 1 || l == 8) continue;
+            c[l * nre + k].r = c1.r + dr * (float)(l - 1);
+            c[l * nre + k].i = c1.i + di * (float)(l - 1);
+          }
+        }
+        continue;
       }
       /* time interpolation between pilot symbols 0,4,7,11; 12,13 continue the 7->11 slope */
       for (int k = 0; k < nre; k++) {
@@ -345,8 +372,8 @@ void o_chest(const o_cell_t* cell, uint32_t nof_rx, uint32_t sf_idx, const ocf_t
 /* ---- REGs (36.211 6.2.4), PCFICH (6.7.4), PHICH (6.9.3), PDCCH mapping (6.8.5) ---- */
 static int reg_width(const o_cell_t* cell, int l)
 {
-  (void)cell; /* 1 or 2 ports: only symbol 0 carries CRS */
-  return l == 0 ? 6 : 4;
+  /* symbol 0 always leaves the CRS positions of two ports out; with four ports symbol 1 carries the CRS of ports 2, 3 */
+  return (l == 0 || (l == 1 && cell->nof_ports == 4)) ? 6 : 4;
 }
 
 void o_regs_init(const o_cell_t* cell, o_regs_t* regs)
@@ -419,7 +446,7 @@ static void reg_equalise(const o_cell_t* cell, uint32_t nof_rx, const ocf_t* gri
 {
   int nre = 12 * (int)cell->nof_prb;
   int kk[4], n = 0;
-  if (l == 0) {
+  if (reg_width(cell, l) == 6) {
     for (int k = k0; k < k0 + 6; k++)
       if ((k % 3) != (int)(cell->id % 3)) kk[n++] = k;
   } else {
@@ -446,10 +473,13 @@ static void reg_equalise(const o_cell_t* cell, uint32_t nof_rx, const ocf_t* gri
   } else {
     for (int i = 0; i < 4; i += 2) {
       float x0r = 0, x0i = 0, x1r = 0, x1i = 0, hh = 0;
+      /* two ports: SFBC on ports (0, 1); four ports (SFBC-FSTD, 36.211 6.3.4.3): the first pair of the quadruplet on ports (0, 2), the second on (1, 3) */
+      const size_t pa = (cell->nof_ports == 4 && i == 2) ? 1 : 0, pb = cell->nof_ports == 4 ? pa + 2 : 1;
       for (uint32_t rx = 0; rx < nof_rx; rx++) {
-        size_t b0 = ((size_t)rx * 14 + (size_t)l) * (size_t)nre;
-        size_t b1 = (((size_t)nof_rx + rx) * 14 + (size_t)l) * (size_t)nre;
-        ocf_t r0 = grid[b0 + (size_t)kk[i]], r1 = grid[b0 + (size_t)kk[i + 1]];
+        size_t b0 = ((pa * (size_t)nof_rx + rx) * 14 + (size_t)l) * (size_t)nre;
+        size_t b1 = ((pb * (size_t)nof_rx + rx) * 14 + (size_t)l) * (size_t)nre;
+        size_t bg = ((size_t)rx * 14 + (size_t)l) * (size_t)nre;
+        ocf_t r0 = grid[bg + (size_t)kk[i]], r1 = grid[bg + (size_t)kk[i + 1]];
         ocf_t h00 = ce[b0 + (size_t)kk[i]], h01 = ce[b0 + (size_t)kk[i + 1]];
         ocf_t h10 = ce[b1 + (size_t)kk[i]], h11 = ce[b1 + (size_t)kk[i + 1]];
         float hp = (h00.r * h00.r + h00.i * h00.i) + (h11.r * h11.r + h11.i * h11.i);

@@ -146,7 +146,7 @@ static void update_formats(o_worker_t* w)
 
 o_worker_t* o_worker_new(const o_worker_cfg_t* cfg)
 {
-  if (o_fft_size(cfg->cell.nof_prb) < 0 || cfg->cell.nof_ports < 1 || cfg->cell.nof_ports > 2 || cfg->nof_rx < 1 ||
+  if (o_fft_size(cfg->cell.nof_prb) < 0 || cfg->cell.nof_ports < 1 || cfg->cell.nof_ports == 3 || cfg->cell.nof_ports > 4 || cfg->nof_rx < 1 ||
       cfg->nof_rx > O_MAX_RX)
     return NULL;
   o_worker_t* w = (o_worker_t*)calloc(1, sizeof(*w));

@@ -31,7 +31,8 @@ class OWorkerCfg(C.Structure):
 
 
 class OChestRes(C.Structure):
-    _fields_ = [("noise", C.c_float * 4), ("rsrp", C.c_float * 4), ("cepow", C.c_float * 4), ("cfo_corr", C.c_float * 2),
+    # noise / rsrp / cepow: [rx 0..1][port 0..3]
+    _fields_ = [("noise", C.c_float * 8), ("rsrp", C.c_float * 8), ("cepow", C.c_float * 8), ("cfo_corr", C.c_float * 2),
                 ("noise_avg", C.c_float), ("rsrp_avg", C.c_float), ("snr_db", C.c_float), ("cfo_hz", C.c_float),
                 ("chan_ref", C.c_float)]
 

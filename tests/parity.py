@@ -50,8 +50,11 @@ def run_oracle(sc, tti0, iq, update_meta_period=0, taps=True, mcs_update_interva
         ow.work(iq[i], tti0 + i, update_meta=upd)
         if taps:
             ch = ow.chest()
+            # the record of la.TAP_CHEST: noise, rsrp, cepow as [rx 0..1][port 0..W-1] with W = 2 (one or two ports) or 4, then seven scalars
+            W = 4 if sc["nof_ports"] == 4 else 2
+            per_port = [v[rx * 4 + p] for v in (ch.noise, ch.rsrp, ch.cepow) for rx in range(2) for p in range(W)]
             per_sf.append(dict(grid=ow.grid(), ce=ow.ce(), llr=ow.llr(), cfi=ow.cfi(), accepted=ow.accepted(), rb_power=ow.rb_power(),
-                               chest=np.array(list(ch.noise) + list(ch.rsrp) + list(ch.cepow) + list(ch.cfo_corr) +
+                               chest=np.array(per_port + list(ch.cfo_corr) +
                                               [ch.noise_avg, ch.rsrp_avg, ch.snr_db, ch.cfo_hz, ch.chan_ref], dtype=np.float32)))
     recs = parse_pcap(ow.pcap_bytes())
     return ow, per_sf, recs
@@ -142,7 +145,7 @@ def compare_taps(phy, per_sf, sc, base=0, nsf=None):
         llr = phy.tap(la.TAP_PDCCH_LLR, i, np.float32, 6400)
         if not np.array_equal(llr.view(np.uint32), o["llr"].view(np.uint32)):
             bad.append((i, "llr", len(llr), len(o["llr"])))
-        ch = phy.tap(la.TAP_CHEST, i, np.float32, 19)
+        ch = phy.tap(la.TAP_CHEST, i, np.float32, 31 if P == 4 else 19)
         if not np.array_equal(ch.view(np.uint32), o["chest"].view(np.uint32)):
             bad.append((i, "chest", ch.tolist(), o["chest"].tolist()))
         rbp = phy.tap(la.TAP_RB_POWER, i, np.float32, 110)

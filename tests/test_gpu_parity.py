@@ -25,7 +25,7 @@ def _run(scn, nsf, seed=1, batch=16, update_meta_period=0, exact_iters=False, **
         phy = la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=batch)
     finally:
         os.environ.pop("LSN_NO_CB_SKIP", None)
-    assert phy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"])
+    assert phy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"], {1: 0, 3: 1, 6: 2, 12: 3}[sc["phich_ng_x6"]])
     phy.set_stage_c_taps(True)
     bad, badc, ncall, ncb, it_o, it_g = [], [], 0, 0, 0, 0
     for base in range(0, nsf, batch):
@@ -74,6 +74,26 @@ def test_6prb_and_15prb():
     _run("small", 20, seed=6, nof_prb=15, cfi=2, dl_min=1, dl_max=2, n_rnti=3)
 
 
+def test_four_crs_ports_100prb_transmit_diversity():
+    """four CRS ports (VERDICT r3 missing 1): k_chest for ports 2 / 3 (pilot symbols 1, 8), the REG map with 6-RE REGs in symbol 1, SFBC-FSTD in
+    k_pcfich / k_pdcch_llr / k_pdsch_demod, the four-port RE masks and DCI sizes - every tap bit-exact, record stream identical"""
+    n = _run("cfg2", 32, seed=4, nof_ports=4, cfi=0, rar_period=16, paging_period=8)
+    assert n > 100
+
+
+def test_four_crs_ports_small_cells_and_one_rx_antenna():
+    _run("small", 30, seed=12, nof_ports=4)
+    _run("small", 20, seed=13, nof_ports=4, nof_prb=6, cfi=0, dl_min=1, dl_max=1, n_rnti=2)
+    _run("small", 20, seed=14, nof_ports=4, nof_prb=75, nof_rx=1, cell_id=77, cfi=0)
+    _run("small", 20, seed=15, nof_ports=4, nof_prb=15, cell_id=500, phich_ng_x6=12, cfi=0, snr_db=9.0)
+
+
+def test_four_crs_ports_tm3_tm4_grants_are_found_and_not_decoded():
+    """format 2 / 2A grants on a four-port cell ask for spatial multiplexing: accepted by the search at their four-port sizes, no decode job, no
+    record - the oracle's (and srsRAN's) behaviour; the other grants of the capture decode as usual"""
+    _run("cfg3", 40, seed=16, nof_ports=4, nof_prb=50, n_rnti=20, update_meta_period=20)
+
+
 def test_worker_pool_api_matches_oracle():
     """the reference's own call pattern: getAvail -> fill buffers -> prepare -> putPending ... joinPending"""
     sc = scenario("small", seed=21)
@@ -116,7 +136,7 @@ def test_device_resident_path_and_sink_callback():
 def test_invalid_inputs_are_rejected():
     phy = la.Phy(nof_rx_antennas=2)
     assert not phy.setCell(70, 2, 1)       # not an LTE bandwidth
-    assert not phy.setCell(100, 4, 1)      # 4 CRS ports not supported
+    assert not phy.setCell(100, 3, 1)      # 1, 2 or 4 CRS ports
     assert not phy.setCell(100, 2, 504)
     with pytest.raises(RuntimeError):
         phy.process_host(np.zeros((1, 2, 30720), dtype=np.complex64), 0)  # no cell set
@@ -125,7 +145,7 @@ def test_invalid_inputs_are_rejected():
 
 def test_exhaustive_candidate_table_matches_oracle_decoder():
     """k_viterbi / k_cce_power alone: all 157 locations x all DCI sizes, not only the entries the search happens to look at"""
-    for scn, n, over in (("small", 6, {}), ("cfg3", 4, {}), ("cfg1", 4, {})):
+    for scn, n, over in (("small", 6, {}), ("cfg3", 4, {}), ("cfg1", 4, {}), ("cfg2", 4, dict(nof_ports=4, cfi=0))):
         sc = scenario(scn, seed=51, **over)
         tti0, iq, _ = gen_subframes(sc, n)
         _, per_sf, _ = run_oracle(sc, tti0, iq)

@@ -12,7 +12,8 @@ from test_file_source import oracle_read, write_capture
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("scn,over", [("small", {}), ("cfg1", {}), ("cfg3", dict(dl_min=2, dl_max=3)), ("small", dict(cell_id=301, phich_ng_x6=6, snr_db=6.0))])
+@pytest.mark.parametrize("scn,over", [("small", {}), ("cfg1", {}), ("cfg3", dict(dl_min=2, dl_max=3)), ("small", dict(cell_id=301, phich_ng_x6=6, snr_db=6.0)),
+                                      ("small", dict(nof_ports=4)), ("cfg2", dict(nof_ports=4, cell_id=77, snr_db=7.0))])
 def test_mib_decode_matches_oracle(scn, over):
     sc = scenario(scn, seed=12, start_tti=10 * 1021 + 8, **over)
     tx = TxGen(**sc)

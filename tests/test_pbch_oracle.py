@@ -22,7 +22,8 @@ def oracle_mib(sc, iq, llr=None):
     return r, m
 
 
-@pytest.mark.parametrize("scn,over", [("small", {}), ("cfg1", {}), ("cfg3", dict(dl_min=2, dl_max=3)), ("small", dict(cell_id=301, phich_ng_x6=6, snr_db=8.0))])
+@pytest.mark.parametrize("scn,over", [("small", {}), ("cfg1", {}), ("cfg3", dict(dl_min=2, dl_max=3)), ("small", dict(cell_id=301, phich_ng_x6=6, snr_db=8.0)),
+                                      ("small", dict(nof_ports=4)), ("small", dict(nof_ports=4, nof_prb=100, cell_id=77, snr_db=8.0))])
 def test_mib_loopback_recovers_sfn_ports_and_bandwidth(scn, over):
     sc = scenario(scn, seed=12, start_tti=10 * 513 + 7, **over)  # starts in the middle of a frame, SFN 513
     tx = TxGen(**sc)

@@ -271,7 +271,7 @@ struct txg {
   uint32_t tti;
   uint64_t count = 0;      // subframes produced so far: seeds the noise of each subframe (independent of the scheduling stream)
   bool plan_only = false;  // txg_generate workers: walk the scheduler (every draw of `rng`) without synthesising the waveform
-  cf h[2][2];
+  cf h[2][4];
   explicit txg(const txg_cfg_t& cfg) : c(cfg), rng(cfg.seed) {}
 };
 
@@ -291,7 +291,7 @@ static void build_regs(txg* g) {
     int nsym = cfi + (nprb <= 10 ? 1 : 0);
     std::vector<uint16_t> tk; std::vector<uint8_t> tl;
     for (int k = 0; k < nre; k++) for (int l = 0; l < nsym; l++) {
-      int w = l == 0 ? 6 : 4;
+      int w = (l == 0 || (l == 1 && g->c.nof_ports == 4)) ? 6 : 4;  // symbol 1 carries the CRS of ports 2, 3
       if (k % w) continue;
       if (l == 0 && used0[k / 6]) continue;
       tk.push_back((uint16_t)k); tl.push_back((uint8_t)l);
@@ -315,6 +315,11 @@ extern "C" txg_t* txg_new(const txg_cfg_t* cfg) {
     double ph = g->rng.uni() * 2 * M_PI, mag = 0.7 + 0.5 * g->rng.uni();
     g->h[r][p] = cf((float)(mag * std::cos(ph)), (float)(mag * std::sin(ph)));
   }
+  if (cfg->nof_ports == 4)  // drawn after the gains of ports 0, 1, so that captures with one or two ports do not change
+    for (int r = 0; r < 2; r++) for (int p = 2; p < 4; p++) {
+      double ph = g->rng.uni() * 2 * M_PI, mag = 0.7 + 0.5 * g->rng.uni();
+      g->h[r][p] = cf((float)(mag * std::cos(ph)), (float)(mag * std::sin(ph)));
+    }
   for (uint32_t i = 0; i < cfg->n_rnti; i++) {
     Ue u; u.rnti = (uint16_t)(0x0100 + g->rng.below(0xFFF3 - 0x0100));
     bool dup = false; for (auto& o : g->ues) if (o.rnti == u.rnti) dup = true;
@@ -451,6 +456,7 @@ static void ss_candidates(uint32_t ncce, uint32_t sf, uint16_t rnti, int l, bool
 
 static bool pdsch_re_ok(const txg* g, uint32_t sf, int l, int k) {
   int nprb = g->c.nof_prb, id = g->c.cell_id;
+  if (g->c.nof_ports == 4 && (l == 1 || l == 8) && k % 3 == id % 3) return false;
   if (l == 0 || l == 4 || l == 7 || l == 11) {
     if (g->c.nof_ports >= 2) { if (k % 3 == id % 3) return false; }
     else { int v = (l == 0 || l == 7) ? 0 : 3; if (k % 6 == (v + id % 6) % 6) return false; }
@@ -483,7 +489,7 @@ extern "C" int txg_next(txg_t* g, float* iq, txg_pdu_t* pdus, int max_pdus, uint
     int l = crs_sym[s];
     uint32_t ns = 2 * sf + (l >= 7), lsl = l % 7;
     bits_t cc = gold(1024u * (7u * (ns + 1) + lsl + 1) * (2u * id + 1) + 2u * id + 1, 440);
-    for (int p = 0; p < P; p++) {
+    for (int p = 0; p < std::min(P, 2); p++) {
       int v = p == 0 ? ((s & 1) ? 3 : 0) : ((s & 1) ? 0 : 3), koff = (v + id % 6) % 6;
       for (int m = 0; m < 2 * nprb; m++) {
         int mp = m + 110 - nprb;
@@ -491,16 +497,33 @@ extern "C" int txg_next(txg_t* g, float* iq, txg_pdu_t* pdus, int max_pdus, uint
       }
     }
   }
+  if (P == 4)  // ports 2, 3: symbol 1 of both slots, v = 3 (n_s mod 2) / 3 + 3 (n_s mod 2)
+    for (int s = 0; s < 2; s++) {
+      int l = s ? 8 : 1;
+      uint32_t ns = 2 * sf + (uint32_t)s;
+      bits_t cc = gold(1024u * (7u * (ns + 1) + 1 + 1) * (2u * id + 1) + 2u * id + 1, 440);
+      for (int p = 2; p < 4; p++) {
+        int v = (p == 2 ? 0 : 3) + 3 * s, koff = (v + id % 6) % 6;
+        for (int m = 0; m < 2 * nprb; m++) {
+          int mp = m + 110 - nprb;
+          grid[p][l * nre + 6 * m + koff] = cf((1 - 2 * cc[2 * mp]) * 0.70710678f, (1 - 2 * cc[2 * mp + 1]) * 0.70710678f);
+        }
+      }
+    }
+  // transmit diversity of one symbol pair (the i-th of its channel) on two resource elements: SFBC on ports (0, 1); with four ports SFBC-FSTD
+  // (36.211 6.3.4.3): even pairs on ports (0, 2), odd pairs on ports (1, 3)
+  auto put_pair = [&](int i, cf x0, cf x1, int la, int ka, int lb, int kb, float amp) {
+    cf p0[2], p1[2]; sfbc_pair(x0, x1, p0, p1);
+    const int pa = (P == 4 && (i & 1)) ? 1 : 0, pb = P == 4 ? pa + 2 : 1;
+    grid[pa][la * nre + ka] = p0[0] * amp; grid[pa][lb * nre + kb] = p0[1] * amp;
+    grid[pb][la * nre + ka] = p1[0] * amp; grid[pb][lb * nre + kb] = p1[1] * amp;
+  };
   auto map_quad = [&](int k0, int l, const cf* x) {  // 4 symbols onto the data REs of a REG
     int kk[4], n = 0;
-    if (l == 0) { for (int k = k0; k < k0 + 6; k++) if (k % 3 != id % 3) kk[n++] = k; }
+    if (l == 0 || (l == 1 && P == 4)) { for (int k = k0; k < k0 + 6; k++) if (k % 3 != id % 3) kk[n++] = k; }
     else for (int k = k0; k < k0 + 4; k++) kk[n++] = k;
     if (P == 1) { for (int i = 0; i < 4; i++) grid[0][l * nre + kk[i]] = x[i]; }
-    else for (int i = 0; i < 4; i += 2) {
-      cf p0[2], p1[2]; sfbc_pair(x[i], x[i + 1], p0, p1);
-      grid[0][l * nre + kk[i]] = p0[0]; grid[0][l * nre + kk[i + 1]] = p0[1];
-      grid[1][l * nre + kk[i]] = p1[0]; grid[1][l * nre + kk[i + 1]] = p1[1];
-    }
+    else for (int i = 0; i < 4; i += 2) put_pair(i / 2, x[i], x[i + 1], l, kk[i], l, kk[i + 1], 1.0f);
   };
   // ---- PCFICH ----
   {
@@ -530,10 +553,7 @@ extern "C" int txg_next(txg_t* g, float* iq, txg_pdu_t* pdus, int max_pdus, uint
       for (int k = 6 * nprb - 36; k < 6 * nprb + 36; k++)
         if (!(l <= 8 && k % 3 == id % 3)) pos.push_back({l, k});
     if (P == 1) { for (int i = 0; i < 240; i++) grid[0][pos[i].first * nre + pos[i].second] = sy[i]; }
-    else for (int i = 0; i < 240; i += 2) {
-      cf p0[2], p1[2]; sfbc_pair(sy[i], sy[i + 1], p0, p1);
-      for (int j = 0; j < 2; j++) { grid[0][pos[i + j].first * nre + pos[i + j].second] = p0[j]; grid[1][pos[i + j].first * nre + pos[i + j].second] = p1[j]; }
-    }
+    else for (int i = 0; i < 240; i += 2) put_pair(i / 2, sy[i], sy[i + 1], pos[i].first, pos[i].second, pos[i + 1].first, pos[i + 1].second, 1.0f);
   }
 
   // ---- PSS / SSS (36.211 6.11, FDD): symbols 6 / 5 of subframes 0 and 5, 62 carriers around DC, antenna port 0 ----
@@ -721,6 +741,9 @@ extern "C" int txg_next(txg_t* g, float* iq, txg_pdu_t* pdus, int max_pdus, uint
       gr.format = u.tm == 3 ? TXG_FMT2A : TXG_FMT2; gr.ntb = 2; gr.swap = 0;
       if (u.tm == 3) { gr.scheme = 3; gr.nlayers = 2; gr.pinfo = 0; }
       else { gr.scheme = 2; gr.nlayers = 2; gr.pinfo = g->rng.below(2); gr.pmi = (int)gr.pinfo; }
+      // four ports: the receivers under test (like the reference's srsRAN) decode transmit diversity only; such a grant still goes out on the
+      // PDCCH (format 2 / 2A at their four-port sizes) with a diversity waveform of the first block on its PRBs, and no receiver decodes it
+      if (P == 4) gr.scheme = 4;
       for (int i = 0; i < 2; i++) {
         gr.mcs[i] = mlo + g->rng.below(mhi - mlo + 1); gr.rv[i] = 0; gr.ndi[i] = g->rng.below(2);
         if (c.pct_rv && g->rng.below(100) < c.pct_rv) { gr.rv[i] = (int)g->rng.below(4); if (gr.mcs[i] == 0 && gr.rv[i] == 1) gr.rv[i] = 2; }  // (mcs 0, rv 1) = TB disabled
@@ -859,11 +882,10 @@ extern "C" int txg_next(txg_t* g, float* iq, txg_pdu_t* pdus, int max_pdus, uint
       switch (gr.scheme) {
         case 0: *g0 = sym[0][i] * amp; break;
         case 1:
-          if ((i & 1) == 0 && i + 1 < nre_g) {
-            cf p0[2], p1[2]; sfbc_pair(sym[0][i], sym[0][i + 1], p0, p1);
-            int l2 = res[i + 1].first, k2 = res[i + 1].second;
-            *g0 = p0[0] * amp; *g1 = p1[0] * amp; grid[0][l2 * nre + k2] = p0[1] * amp; grid[1][l2 * nre + k2] = p1[1] * amp;
-          }
+          if ((i & 1) == 0 && i + 1 < nre_g) put_pair(i / 2, sym[0][i], sym[0][i + 1], l, k, res[i + 1].first, res[i + 1].second, amp);
+          break;
+        case 4:
+          if ((i & 1) == 0 && i + 1 < nre_g) put_pair(i / 2, sym[0][i], sym[0][i + 1], l, k, res[i + 1].first, res[i + 1].second, amp);
           break;
         case 3: { cf x0 = sym[0][i], x1 = sym[1][i]; float s = (i & 1) ? -1.f : 1.f; *g0 = (x0 + x1) * 0.5f * amp; *g1 = (x0 - x1) * (0.5f * s) * amp; break; }
         case 2:
