@@ -201,6 +201,12 @@ def test_ul_mode_end_to_end_matches_oracle():
     assert n_ul >= 10 and n_dl >= 5
 
 
+def test_ul_mode_on_a_four_port_cell():
+    """the downlink half of UL_MODE (one antenna) on four CRS ports: PDCCH in SFBC-FSTD, DCI 0 found, PUSCH decoded as on any other cell"""
+    n_ul, n_dl = _run_ul_mode(60, seed=6, batch=16, mcs_max=20, nof_ports=4, rar_period=15)
+    assert n_ul >= 10 and n_dl >= 5
+
+
 def test_ul_mode_with_rar_and_single_chunk():
     n_ul, n_dl = _run_ul_mode(48, seed=9, batch=64, rar_period=10, mcs_max=20, pct_cqi_req=50)
     assert n_ul >= 5
