@@ -328,6 +328,7 @@ private:
   void publishPrediction(uint16_t rnti);
   bool hintedTable256(uint16_t rnti, uint32_t pos) const;   // SharedSeq::hint_pos: will the commit find this RNTI on the 256QAM table at stream position pos?
   void hintEvent(uint16_t rnti, uint32_t pos);
+  int hintEvents(uint16_t rnti, uint32_t pos, uint32_t* lo_out) const;  // teaching events in the ring between the entry's last reset and pos; -1: hints are off
   void ageTrackingDatabase();
   uint32_t& commit_sf_cnt = sh->commit_sf_cnt;
   uint32_t& mcs_update_period = sh->mcs_update_period;
