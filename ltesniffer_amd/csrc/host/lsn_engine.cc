@@ -157,6 +157,7 @@ Engine::Engine(const lsn_phy_cfg_t& c, std::shared_ptr<SharedSeq> shared) : sh(s
   // test hook of the error path, read once per engine: chunk <n> of the first submitted block fails in stage A (and must not wedge the pipeline)
   if (const char* e = getenv("LSN_INJECT_STAGE_A_ERROR")) inject_stage_a_fail = atoi(e);
   if (const char* e = getenv("LSN_DECODE_THREADS")) ndec = std::max(1, std::min((int)NDEC, atoi(e)));
+  if (const char* e = getenv("LSN_KERNEL_TIMING_PERIOD")) timing_period = (uint32_t)std::max(0, atoi(e));
   nslots = ndec + 8;
   front_thread = std::thread([this] { pthread_setname_np(pthread_self(), "lsn-front"); frontLoop(); });
   commit_thread = std::thread([this] { pthread_setname_np(pthread_self(), "lsn-commit"); commitLoop(); });
@@ -270,10 +271,11 @@ void Engine::launchStageA(Chunk& ch, const void* d_iq)
   const cf32* iq = (const cf32*)d_iq;
   ch.d_iq_src = iq;
   int n = 0;
+  ch.timed_a = timing_period && (stage_a_passes++ % timing_period) == 0;
   auto timed = [&](auto&& fn) {
-    HIP_CHECK(hipEventRecord(ch.ev_a[2 * n], st));
+    if (ch.timed_a) HIP_CHECK(hipEventRecord(ch.ev_a[2 * n], st));
     fn();
-    HIP_CHECK(hipEventRecord(ch.ev_a[2 * n + 1], st));
+    if (ch.timed_a) HIP_CHECK(hipEventRecord(ch.ev_a[2 * n + 1], st));
     n++;
   };
   timed([&] { lsn_launch_ofdm(cd, iq, d_dphi, ch.d_grid, nsf, st); });
@@ -303,7 +305,7 @@ void Engine::finishStageA(Chunk& ch)
   waitEvent(ch.ev_a[16], 15000);
   for (int n = 0; n < 8; n++) {
     float ms = 0;
-    if (hipEventElapsedTime(&ms, ch.ev_a[2 * n], ch.ev_a[2 * n + 1]) == hipSuccess) perf_front.kernel_ms[kStageA[n]] += ms;
+    if (ch.timed_a && hipEventElapsedTime(&ms, ch.ev_a[2 * n], ch.ev_a[2 * n + 1]) == hipSuccess) perf_front.kernel_ms[kStageA[n]] += ms * (float)timing_period;  // (a sample of the chunks, scaled)
     perf_front.kernel_launches[kStageA[n]]++;
   }
   const uint64_t A = dlRx(), P = cell.nof_ports;
@@ -617,25 +619,26 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
       grow_dev(r.d_spp, r.spp_cap, spp_n + 16, st);
       up.add(r.d_cbs, r.h_cbs_pinned, ncb * sizeof(LsnCbDev));
     }
+    const bool tk = timing_period && (r.launches++ % timing_period) == 0;   // prep / demod / rm: timed on a sample of the launches; the decoders on every launch
     lsn_launch_copy_multi(up, false, st);
-    HIP_CHECK(hipEventRecord(r.ev[0], st));  // (no clear of the LLR arena: k_pdsch_demod writes every soft bit of every codeword it is given, zeros of unpaired SFBC REs included)
+    if (tk) HIP_CHECK(hipEventRecord(r.ev[0], st));  // (no clear of the LLR arena: k_pdsch_demod writes every soft bit of every codeword it is given, zeros of unpaired SFBC REs included)
     lsn_launch_pdsch_prep(cd, r.d_jobs, r.d_prefix, njobs, st);
-    HIP_CHECK(hipEventRecord(r.ev[1], st));
+    if (tk) HIP_CHECK(hipEventRecord(r.ev[1], st));
     lsn_launch_pdsch_demod(cd, r.d_jobs, r.d_items, nitems, r.d_prefix, ch.d_grid, ch.d_ce, ch.d_chest, r.d_llr16, st);
-    HIP_CHECK(hipEventRecord(r.ev[2], st));
+    if (tk) HIP_CHECK(hipEventRecord(r.ev[2], st));
     if (ncb) {
       lsn_launch_rm(r.d_cbs, r.d_llr16, r.d_spp, ncb, emax, st);
-      HIP_CHECK(hipEventRecord(r.ev[5], st));
+      if (timing_period) HIP_CHECK(hipEventRecord(r.ev[5], st));
       {
         // phase 0: [128-class | 64-class] of the independent blocks, phase 1: the same of the dependants (descriptor order = launch order)
-        lsn_launch_turbo(cd, r.d_cbs, r.d_spp, r.d_payload, r.d_cbres, n128p[0], kmax128, n64p[0], kmax64, st, r.ev[4]);
+        lsn_launch_turbo(cd, r.d_cbs, r.d_spp, r.d_payload, r.d_cbres, n128p[0], kmax128, n64p[0], kmax64, st, timing_period ? r.ev[4] : nullptr);
         const uint32_t o1 = n128p[0] + n64p[0];
         if (ncb > o1) {
-          HIP_CHECK(hipEventRecord(r.ev[8], st));
-          lsn_launch_turbo(cd, r.d_cbs + o1, r.d_spp, r.d_payload, r.d_cbres, n128p[1], kmax128, n64p[1], kmax64, st, r.ev[9]);
+          if (timing_period) HIP_CHECK(hipEventRecord(r.ev[8], st));
+          lsn_launch_turbo(cd, r.d_cbs + o1, r.d_spp, r.d_payload, r.d_cbres, n128p[1], kmax128, n64p[1], kmax64, st, timing_period ? r.ev[9] : nullptr);
         }
       }
-      HIP_CHECK(hipEventRecord(r.ev[3], st));
+      if (timing_period) HIP_CHECK(hipEventRecord(r.ev[3], st));
       {
         LsnCopySegs dn;
         dn.add(r.h_cbres_pinned, r.d_cbres, ncb * sizeof(LsnCbRes));
@@ -669,14 +672,16 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
     HIP_CHECK(hipEventRecord(r.ev_done, st));
     waitEvent(r.ev_done);
     float ms = 0;
-    if (hipEventElapsedTime(&ms, r.ev[0], r.ev[1]) == hipSuccess) pf.kernel_ms[LSN_K_PDSCH_PREP] += ms;
-    if (hipEventElapsedTime(&ms, r.ev[1], r.ev[2]) == hipSuccess) pf.kernel_ms[LSN_K_PDSCH_DEMOD] += ms;
+    const float scale = (float)timing_period;
+    if (tk && hipEventElapsedTime(&ms, r.ev[0], r.ev[1]) == hipSuccess) pf.kernel_ms[LSN_K_PDSCH_PREP] += ms * scale;
+    if (tk && hipEventElapsedTime(&ms, r.ev[1], r.ev[2]) == hipSuccess) pf.kernel_ms[LSN_K_PDSCH_DEMOD] += ms * scale;
     pf.kernel_launches[LSN_K_PDSCH_PREP]++; pf.kernel_launches[LSN_K_PDSCH_DEMOD]++;
     if (ncb) {
-      if (hipEventElapsedTime(&ms, r.ev[2], r.ev[5]) == hipSuccess) { pf.kernel_ms[LSN_K_RM] += ms; pf.kernel_launches[LSN_K_RM]++; }
+      if (tk && hipEventElapsedTime(&ms, r.ev[2], r.ev[5]) == hipSuccess) pf.kernel_ms[LSN_K_RM] += ms * scale;
+      pf.kernel_launches[LSN_K_RM]++;
       {
         const bool ph1 = ncb > n128p[0] + n64p[0];
-        auto acc = [&](int k, hipEvent_t a, hipEvent_t b) { if (hipEventElapsedTime(&ms, a, b) == hipSuccess) { pf.kernel_ms[k] += ms; pf.kernel_launches[k]++; } };
+        auto acc = [&](int k, hipEvent_t a, hipEvent_t b) { if (timing_period && hipEventElapsedTime(&ms, a, b) == hipSuccess) { pf.kernel_ms[k] += ms; pf.kernel_launches[k]++; } };
         if (n128p[0]) acc(LSN_K_TURBO128, r.ev[5], r.ev[4]);
         if (n64p[0]) acc(LSN_K_TURBO, r.ev[4], ph1 ? r.ev[8] : r.ev[3]);
         if (ph1 && n128p[1]) acc(LSN_K_TURBO128, r.ev[8], r.ev[9]);

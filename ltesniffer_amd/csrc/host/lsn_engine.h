@@ -85,6 +85,7 @@ struct Chunk {
   std::vector<PduRec> recs;          // records of this chunk in emission order (commit thread -> writer thread)
   std::string err;                   // first error on this chunk's way through the pipeline
   hipEvent_t ev_a[2 * 8 + 1] = {};  // per stage-A kernel class start/stop + "mirrors on host"
+  bool timed_a = false;             // this pass of the chunk carries the per-kernel timing events (every Engine::timing_period-th does)
   struct SpecRar { uint32_t sf; uint16_t rnti; DciFormat format; unsigned long long bits; int job; };
   std::vector<SpecRar> spec_rar;     // RA-RNTI grants decoded ahead of the search (front thread)
   bool busy = false;                 // owned by the pipeline (slot not reusable yet)
@@ -115,6 +116,7 @@ struct JobRunner {
   LsnCbDev* h_cbs_pinned = nullptr; size_t h_cbs_cap = 0;
   std::vector<LsnGrantDev> h_jobs; std::vector<LsnCbDev> h_cbs;
   hipEvent_t ev[10] = {};
+  uint32_t launches = 0;            // decode launches so far (per-kernel timing events ride on every Engine::timing_period-th)
   hipEvent_t ev_done = nullptr;  // blocking-sync event the owning thread waits on
   lsn_perf_t perf{};
 };
@@ -326,6 +328,10 @@ private:
   }
   float predictedPa(uint16_t rnti) const { return pred_table[rnti].load(std::memory_order_relaxed) == 0xFF ? default_p_a.load(std::memory_order_relaxed) : pred_p_a[rnti].load(std::memory_order_relaxed); }
   void publishPrediction(uint16_t rnti);
+  // Per-kernel HIP timing events cost 2.6 % of the resident rate when every launch carries them (36 event records per chunk; measured in round 4).
+  // The two decoder kernels - the roofline's subject - are timed on every launch; the other kernels on every timing_period-th chunk / decode launch,
+  // their sums scaled by the period (LSN_KERNEL_TIMING_PERIOD, default 8; 1 = every launch).
+  uint32_t timing_period = 8, stage_a_passes = 0;
   bool hintedTable256(uint16_t rnti, uint32_t pos) const;   // SharedSeq::hint_pos: will the commit find this RNTI on the 256QAM table at stream position pos?
   void hintEvent(uint16_t rnti, uint32_t pos);
   int hintEvents(uint16_t rnti, uint32_t pos, uint32_t* lo_out) const;  // teaching events in the ring between the entry's last reset and pos; -1: hints are off
