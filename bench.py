@@ -57,6 +57,11 @@ def _maybe_spawn(argv):
 
 _maybe_spawn(sys.argv[1:])
 
+# HIP runtime configuration of the host program (read when the runtime initialises, i.e. before the first HIP call): the engine keeps 12 decode chains +
+# 4 stage-A chains + copies in flight; on the runtime's default of 4 hardware queues they wait for each other's kernels (INTEGRATION.md section 2;
+# measured in round 4: + 2 % with 16).  An exported value wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 

@@ -571,6 +571,10 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
     r.h_jobs.push_back(d);
     jid_of_hjob.push_back(jid);
   }
+  // every block in the two-wavefront launch (a block of <= 64 windows sends its second wavefront home at once): ONE decoder launch per phase instead of
+  // two - + 5.7 % subframes/s in A/B pairs, although small blocks now reserve the LDS of the largest one (LSN_TURBO_TWO_CLASSES=1: rounds 2-4)
+  static const bool one_class = getenv("LSN_TURBO_TWO_CLASSES") == nullptr;
+  auto two_wave = [&](int K) { return one_class || lsn_turbo_two_wave_class(K); };
   const uint32_t njobs = (uint32_t)r.h_jobs.size(), ncb = (uint32_t)r.h_cbs.size();
   uint32_t kmax128 = 0, kmax64 = 0, emax = 0, n128p[2] = {0, 0}, n64p[2] = {0, 0};
   size_t spp_n = 0;
@@ -579,6 +583,7 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
     grow_dev(r.d_jobs, r.jobs_cap, njobs, st);
     grow_dev(r.d_cbs, r.cbs_cap, ncb, st);
     grow_dev(r.d_cbres, r.cbres_cap, ncb, st);
+    grow_dev(r.d_cbstate, r.cbstate_cap, ncb, st);
     grow_dev(r.d_prefix, r.prefix_cap, prefix_n, st);
     grow_dev(r.d_llr16, r.llr16_cap, llr_n + 8, st);
     grow_dev(r.d_payload, r.payload_cap, pay_n - pay0 + 16, st);
@@ -592,8 +597,9 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
     LsnCopySegs up;   // items, jobs and code-block descriptors go up in one launch
     std::memcpy(r.h_items_pinned, r.h_items.data(), nitems * sizeof(uint32_t));
     up.add(r.d_items, r.h_items_pinned, nitems * sizeof(uint32_t));
+    static const bool separate_upload = getenv("LSN_SEPARATE_UPLOAD") != nullptr;  // A/B: the descriptors go up in a launch of their own (rounds 1-4)
     std::memcpy(r.h_jobs_pinned, r.h_jobs.data(), njobs * sizeof(LsnGrantDev));
-    up.add(r.d_jobs, r.h_jobs_pinned, njobs * sizeof(LsnGrantDev));
+    if (separate_upload) up.add(r.d_jobs, r.h_jobs_pinned, njobs * sizeof(LsnGrantDev));
     if (ncb) {
       // launch order: two-wavefront blocks first, each class by descending size (longest jobs first)
       order.resize(ncb);
@@ -603,7 +609,7 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
         const bool dx = r.h_cbs[x].dep != LSN_CB_NODEP, dy = r.h_cbs[y].dep != LSN_CB_NODEP;
         if (dx != dy) return dy;
         const uint32_t kx = r.h_cbs[x].K, ky = r.h_cbs[y].K;
-        const bool bx = lsn_turbo_two_wave_class((int)kx), by = lsn_turbo_two_wave_class((int)ky);
+        const bool bx = two_wave((int)kx), by = two_wave((int)ky);
         if (bx != by) return bx;
         if (kx != ky) return kx > ky;
         return x < y;
@@ -614,22 +620,31 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
         emax = std::max(emax, q.E);
         r.h_cbs_pinned[i] = q;
         const int ph = q.dep != LSN_CB_NODEP ? 1 : 0;
-        if (lsn_turbo_two_wave_class((int)q.K)) { n128p[ph]++; kmax128 = std::max(kmax128, q.K); } else { n64p[ph]++; kmax64 = std::max(kmax64, q.K); }
+        if (two_wave((int)q.K)) { n128p[ph]++; kmax128 = std::max(kmax128, q.K); } else { n64p[ph]++; kmax64 = std::max(kmax64, q.K); }
       }
       grow_dev(r.d_spp, r.spp_cap, spp_n + 16, st);
       up.add(r.d_cbs, r.h_cbs_pinned, ncb * sizeof(LsnCbDev));
     }
     const bool tk = timing_period && (r.launches++ % timing_period) == 0;   // prep / demod / rm: timed on a sample of the launches; the decoders on every launch
-    lsn_launch_copy_multi(up, false, st);
+    if (separate_upload) lsn_launch_copy_multi(up, false, st);
     if (tk) HIP_CHECK(hipEventRecord(r.ev[0], st));  // (no clear of the LLR arena: k_pdsch_demod writes every soft bit of every codeword it is given, zeros of unpaired SFBC REs included)
-    lsn_launch_pdsch_prep(cd, r.d_jobs, r.d_prefix, njobs, st);
+    if (separate_upload) lsn_launch_pdsch_prep(cd, r.d_jobs, r.d_prefix, njobs, st);
+    else lsn_launch_pdsch_prep_up(cd, r.h_jobs_pinned, r.d_jobs, njobs, up, r.d_prefix, st);   // descriptors up + prefix tables in one launch
     if (tk) HIP_CHECK(hipEventRecord(r.ev[1], st));
     lsn_launch_pdsch_demod(cd, r.d_jobs, r.d_items, nitems, r.d_prefix, ch.d_grid, ch.d_ce, ch.d_chest, r.d_llr16, st);
     if (tk) HIP_CHECK(hipEventRecord(r.ev[2], st));
     if (ncb) {
-      lsn_launch_rm(r.d_cbs, r.d_llr16, r.d_spp, ncb, emax, st);
+      // LSN_TURBO_SINGLE_LAUNCH=1 (experiment, measured neutral: 192.4 k against 192.3 k subframes/s): ONE decoder launch per wave, the dependants sit
+      // behind the first code blocks in the grid and wait for their verdict on the device.  Only with every block in one class: a dependant must never
+      // wait for a block of a launch behind its own.  Default: the dependants get a launch of their own (few blocks, short).
+      static const bool single_launch = getenv("LSN_TURBO_SINGLE_LAUNCH") != nullptr;
+      const bool single = single_launch && n64p[0] == 0 && n64p[1] == 0;
+      lsn_launch_rm(r.d_cbs, r.d_llr16, r.d_spp, ncb, emax, st, single ? r.d_cbstate : nullptr);
       if (timing_period) HIP_CHECK(hipEventRecord(r.ev[5], st));
-      {
+      if (single) {
+        lsn_launch_turbo(cd, r.d_cbs, r.d_spp, r.d_payload, r.d_cbres, n128p[0] + n128p[1], kmax128, 0, kmax64, st, timing_period ? r.ev[4] : nullptr, r.d_cbstate);
+        n128p[0] += n128p[1]; n128p[1] = 0;   // (the timing code below: one launch)
+      } else {
         // phase 0: [128-class | 64-class] of the independent blocks, phase 1: the same of the dependants (descriptor order = launch order)
         lsn_launch_turbo(cd, r.d_cbs, r.d_spp, r.d_payload, r.d_cbres, n128p[0], kmax128, n64p[0], kmax64, st, timing_period ? r.ev[4] : nullptr);
         const uint32_t o1 = n128p[0] + n64p[0];
@@ -691,7 +706,7 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
       for (uint32_t i = 0; i < ncb; i++) {
         const uint64_t b = 4ull * (r.h_cbs_pinned[i].K + 12u) + r.h_cbs_pinned[i].out_bytes;
         pf.turbo_algo_bytes += b;
-        if (lsn_turbo_two_wave_class((int)r.h_cbs_pinned[i].K)) pf.turbo128_algo_bytes += b;
+        if (two_wave((int)r.h_cbs_pinned[i].K)) pf.turbo128_algo_bytes += b;
       }
     }
     if (keep_stage_c.load()) {  // parity taps: the arenas are recycled by the next launch of this runner

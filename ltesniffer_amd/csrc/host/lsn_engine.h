@@ -102,6 +102,7 @@ struct JobRunner {
   hipStream_t stream = nullptr;
   LsnGrantDev* d_jobs = nullptr; size_t jobs_cap = 0;
   LsnCbDev* d_cbs = nullptr; size_t cbs_cap = 0;
+  uint32_t* d_cbstate = nullptr; size_t cbstate_cap = 0;   // single-launch decoder: 0 = not decoded yet, 1 = failed, 2 = passed, by LsnCbDev::res_idx
   LsnCbRes* d_cbres = nullptr; size_t cbres_cap = 0;
   uint16_t* d_prefix = nullptr; size_t prefix_cap = 0;
   int16_t* d_llr16 = nullptr; size_t llr16_cap = 0;
@@ -240,7 +241,7 @@ public:
 private:
   static constexpr int NDEC = 12;            // max decode threads (each: plan + stage-C launches of one chunk; commits stay in order)
   static constexpr int NSLOTS = NDEC + 8;
-  int ndec = 8, nslots = 16;                  // in use (LSN_DECODE_THREADS)
+  int ndec = 12, nslots = 20;                 // in use (LSN_DECODE_THREADS; 8 until round 4: 12 threads on 16 hardware queues measured + 3 %)
   void createCopyStream();
   void freeDevice();
   void buildTables();

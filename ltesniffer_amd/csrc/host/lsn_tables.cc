@@ -87,7 +87,7 @@ void Engine::freeRunner(JobRunner& r)
 {
   auto df = [](auto*& p) { if (p) (void)hipFree(p); p = nullptr; };
   auto hf = [](auto*& p) { if (p) (void)hipHostFree(p); p = nullptr; };
-  df(r.d_jobs); df(r.d_cbs); df(r.d_cbres); df(r.d_prefix); df(r.d_llr16); df(r.d_payload); df(r.d_spp); df(r.d_items);
+  df(r.d_jobs); df(r.d_cbs); df(r.d_cbstate); df(r.d_cbres); df(r.d_prefix); df(r.d_llr16); df(r.d_payload); df(r.d_spp); df(r.d_items);
   hf(r.h_items_pinned); hf(r.h_payload_pinned); hf(r.h_cbres_pinned); hf(r.h_jobs_pinned); hf(r.h_cbs_pinned);
   r.items_cap = r.h_items_cap = r.spp_cap = r.jobs_cap = r.cbs_cap = r.cbres_cap = r.prefix_cap = r.llr16_cap = r.payload_cap = r.h_payload_cap = r.h_cbres_cap = r.h_jobs_cap = r.h_cbs_cap = 0;
   for (auto& e : r.ev)

@@ -121,6 +121,7 @@ struct LsnCopySegs {
   void add(void* d, const void* s_, size_t bytes) { if (bytes && n < 6) { src[n] = s_; dst[n] = d; words[n] = (uint32_t)((bytes + 3) / 4); n++; } }
 };
 void lsn_launch_copy_multi(const LsnCopySegs& sg, bool to_host, hipStream_t s);
+void lsn_launch_pdsch_prep_up(const LsnCellDev& c, const LsnGrantDev* jobs_host, LsnGrantDev* jobs_dev, uint32_t njobs, const LsnCopySegs& sg, uint16_t* prefix, hipStream_t s);
 // launchers (stage_a.hip / stage_c.hip)
 void lsn_launch_ofdm(const LsnCellDev& c, const cf32* iq, const uint32_t* dphi, cf32* grid, uint32_t nsf, hipStream_t s);
 void lsn_launch_chest(const LsnCellDev& c, const cf32* grid, const uint32_t* sf_idx, cf32* ce, float* raw, uint32_t nsf, hipStream_t s);
@@ -142,8 +143,8 @@ void lsn_launch_pusch_demod(const LsnCellDev& c, const LsnUlGrantDev* g, const c
 void lsn_launch_pdsch_prep(const LsnCellDev& c, const LsnGrantDev* g, uint16_t* prefix, uint32_t njobs, hipStream_t s);
 void lsn_launch_pdsch_demod(const LsnCellDev& c, const LsnGrantDev* g, const uint32_t* items, uint32_t nitems, const uint16_t* prefix, const cf32* grid, const cf32* ce,
                             const LsnChest* ch, int16_t* llr, hipStream_t s);
-void lsn_launch_rm(const LsnCbDev* cb, const int16_t* llr, uint32_t* spp, uint32_t ncb, uint32_t emax, hipStream_t s);
+void lsn_launch_rm(const LsnCbDev* cb, const int16_t* llr, uint32_t* spp, uint32_t ncb, uint32_t emax, hipStream_t s, uint32_t* state = nullptr);
 void lsn_launch_harq_combine(const LsnCbDev* cbs, uint32_t ncb, const uint32_t* cur, uint32_t* pool, bool overwrite, hipStream_t s);
 #define LSN_CB_NODEP 0xFFFFFFFFu
 void lsn_launch_turbo(const LsnCellDev& c, const LsnCbDev* cb, const uint32_t* spp, uint8_t* payload, LsnCbRes* res, uint32_t n128, uint32_t kmax128,
-                      uint32_t n64, uint32_t kmax64, hipStream_t s, hipEvent_t between);
+                      uint32_t n64, uint32_t kmax64, hipStream_t s, hipEvent_t between, uint32_t* state = nullptr);

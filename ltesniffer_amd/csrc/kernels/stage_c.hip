@@ -7,6 +7,7 @@
 // stores); turbo = one wavefront per code block, lane = trellis window, all soft data of the block staged in LDS,
 // forward metrics check-pointed every 16 steps and recomputed so that the block fits 2 workgroups per CU.
 #include "lsn_dev.h"
+#include <algorithm>
 #include "lsn_rm.h"
 #include <type_traits>
 
@@ -50,6 +51,69 @@ __global__ __launch_bounds__(64) void k_pdsch_prep(LsnCellDev c, const LsnGrantD
 void lsn_launch_pdsch_prep(const LsnCellDev& c, const LsnGrantDev* g, uint16_t* prefix, uint32_t njobs, hipStream_t s)
 {
   hipLaunchKernelGGL(k_pdsch_prep, dim3(njobs), dim3(64), 0, s, c, g, prefix);
+}
+
+// The same with the upload of the launch's descriptors folded in (one launch less in every decode chain - the chains' depth, not their work, bounds
+// the engine: DESIGN 3.2): workgroup j < njobs reads job j from the PINNED HOST array, stores the device copy the later kernels read and computes its
+// prefix table; the workgroups behind copy the other descriptor arrays (work items, code blocks) host -> device.
+__global__ __launch_bounds__(64) void k_pdsch_prep_up(LsnCellDev c, const LsnGrantDev* __restrict__ jobs_h, LsnGrantDev* __restrict__ jobs_d, uint32_t njobs,
+                                                      LsnCopySegs sg, uint16_t* __restrict__ prefix)
+{
+  const int lane = threadIdx.x, nprb = (int)c.nof_prb;
+  if (blockIdx.x >= njobs) {
+    const uint32_t w = blockIdx.x - njobs, nw = gridDim.x - njobs;
+    for (uint32_t q = 0; q < sg.n; q++) {
+      const uint32_t words = sg.words[q];
+      const bool al = ((((uintptr_t)sg.src[q]) | ((uintptr_t)sg.dst[q])) & 15u) == 0;
+      const uint32_t n16 = al ? words / 4 : 0;
+      const uint4* a4 = (const uint4*)sg.src[q];
+      uint4* b4 = (uint4*)sg.dst[q];
+      for (uint32_t i = w * 64u + (uint32_t)lane; i < n16; i += nw * 64u) b4[i] = a4[i];
+      const uint32_t* a = (const uint32_t*)sg.src[q];
+      uint32_t* b = (uint32_t*)sg.dst[q];
+      for (uint32_t i = n16 * 4 + w * 64u + (uint32_t)lane; i < words; i += nw * 64u) b[i] = a[i];
+    }
+    return;
+  }
+  __shared__ LsnGrantDev gs;
+  constexpr int NW = (int)(sizeof(LsnGrantDev) / 4);
+  static_assert(NW <= 64 && sizeof(LsnGrantDev) % 4 == 0, "one word per lane");
+  if (lane < NW) {
+    const uint32_t v = ((const uint32_t*)(jobs_h + blockIdx.x))[lane];
+    ((uint32_t*)&gs)[lane] = v;
+    ((uint32_t*)(jobs_d + blockIdx.x))[lane] = v;
+  }
+  __syncthreads();
+  const LsnGrantDev& g = gs;
+  uint16_t* pf = prefix + g.prefix_off;
+  const int cls = g.sf_idx == 0 ? 0 : (g.sf_idx == 5 ? 1 : 2);
+  uint32_t before = 0;
+  for (int l = 0; l < 14; l++) {
+    uint32_t run = 0;
+    for (int base = 0; base < nprb; base += 64) {
+      const int prb = base + lane;
+      uint32_t v = 0;
+      if (prb < nprb && l >= (int)g.l0 && ((g.prb_mask[l / 7][prb >> 5] >> (prb & 31)) & 1u)) v = (uint32_t)__popc((unsigned)c.validmask[(cls * 14 + l) * nprb + prb]);
+      uint32_t inc = v;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(inc, off);
+        if (lane >= off) inc += t;
+      }
+      if (prb < nprb) pf[l * nprb + prb] = (uint16_t)(run + inc - v);
+      run += __shfl(inc, 63);
+    }
+    if (lane == 0) pf[14 * nprb + l] = (uint16_t)before;
+    before += run;
+  }
+  if (lane == 0) pf[14 * nprb + 14] = (uint16_t)before;
+}
+void lsn_launch_pdsch_prep_up(const LsnCellDev& c, const LsnGrantDev* jobs_host, LsnGrantDev* jobs_dev, uint32_t njobs, const LsnCopySegs& sg, uint16_t* prefix, hipStream_t s)
+{
+  uint32_t total = 0;
+  for (uint32_t q = 0; q < sg.n; q++) total += sg.words[q];
+  const uint32_t ncopy = total ? std::max<uint32_t>(1u, std::min<uint32_t>((total / 4 + 63u) / 64u, 256u)) : 0u;
+  hipLaunchKernelGGL(k_pdsch_prep_up, dim3(njobs + ncopy), dim3(64), 0, s, c, jobs_host, jobs_dev, njobs, sg, prefix);
 }
 
 // ------------------------------------------------------------------------------------------------ soft demodulation
@@ -260,8 +324,9 @@ __device__ __forceinline__ int rm_sum(const int16_t* __restrict__ e, const int16
   for (int k = rank; k < E; k += nn) acc += STAGED ? (int)es[k] : (int)e[k];
   return acc > LSN_LLR_CLIP ? LSN_LLR_CLIP : (acc < -LSN_LLR_CLIP ? -LSN_LLR_CLIP : acc);
 }
-__global__ __launch_bounds__(RM_NT) void k_rm(const LsnCbDev* __restrict__ cbs, const int16_t* __restrict__ llr, uint32_t* __restrict__ spp_g, uint32_t seg)
+__global__ __launch_bounds__(RM_NT) void k_rm(const LsnCbDev* __restrict__ cbs, const int16_t* __restrict__ llr, uint32_t* __restrict__ spp_g, uint32_t seg, uint32_t* __restrict__ state)
 {
+  if (state && threadIdx.x == 0) state[cbs[blockIdx.x].res_idx] = 0u;  // "not decoded yet" for the single-launch decoder (k_turbo: dependants wait on their first block)
   extern __shared__ __attribute__((aligned(16))) unsigned char rm_smem[];
   __shared__ LsnRmGeom geom;
   int16_t* es = (int16_t*)rm_smem;
@@ -305,14 +370,14 @@ __global__ __launch_bounds__(RM_NT) void k_rm(const LsnCbDev* __restrict__ cbs, 
   }
 }
 // the staging area is sized by the largest E of the launch, capped at 64 KiB (two workgroups per CU at least)
-void lsn_launch_rm(const LsnCbDev* cb, const int16_t* llr, uint32_t* spp, uint32_t ncb, uint32_t emax, hipStream_t s)
+void lsn_launch_rm(const LsnCbDev* cb, const int16_t* llr, uint32_t* spp, uint32_t ncb, uint32_t emax, hipStream_t s, uint32_t* state)
 {
   static bool attr_set = false;
   if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_rm, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); attr_set = true; }
   const uint32_t cap = (65536 - 32) / 2;
   const uint32_t seg = emax < cap ? emax : cap;
   const size_t lds = (((size_t)seg + 16) * 2 + 15) & ~(size_t)15;  // + the skew in front of e[0] and the tail of the last 16-byte load
-  if (ncb) hipLaunchKernelGGL(k_rm, dim3(ncb), dim3(RM_NT), lds, s, cb, llr, spp, seg);
+  if (ncb) hipLaunchKernelGGL(k_rm, dim3(ncb), dim3(RM_NT), lds, s, cb, llr, spp, seg, state);
 }
 
 // ------------------------------------------------------------------------------------------------ HARQ soft combining
@@ -431,7 +496,7 @@ __device__ __forceinline__ uint32_t wg_xor(uint32_t v, int16_t* scratch, int tid
 template <int NT>
 __global__ __launch_bounds__(NT) TB_WAVES_ATTR void k_turbo(const uint32_t* __restrict__ crc_tab_a, const uint32_t* __restrict__ crc_tab_b, const uint32_t* __restrict__ il_tab,
                                               const LsnCbDev* __restrict__ cbs, const uint32_t* __restrict__ spp_g,
-                                              uint8_t* __restrict__ payload, LsnCbRes* res, uint32_t kmax)
+                                              uint8_t* __restrict__ payload, LsnCbRes* res, uint32_t kmax, uint32_t* state)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // phase cycle counters (LsnCbRes::cyc_*) only in instrumented builds (-DLSN_TURBO_CYCLES): the production kernel reads no clock
@@ -444,9 +509,26 @@ __global__ __launch_bounds__(NT) TB_WAVES_ATTR void k_turbo(const uint32_t* __re
   const LsnCbDev cb = cbs[blockIdx.x];
   // The transport block of this code block is already lost when its first code block (decoded by an EARLIER launch on this stream)
   // failed: nothing this block could decode would reach the record stream, so it is not decoded at all
-  if (cb.dep != LSN_CB_NODEP && res[cb.dep].ok == 0u) {
-    if (threadIdx.x == 0) { LsnCbRes r{}; res[cb.res_idx] = r; }
-    return;
+  // (state != null: the first code blocks are part of THIS launch, in front of their dependants in the grid - the dependant waits for the verdict:
+  //  0 = not decoded yet (k_rm), 1 = failed, 2 = passed)
+  if (cb.dep != LSN_CB_NODEP) {
+    bool lost;
+    if (state) {
+      __shared__ uint32_t verdict;
+      if (threadIdx.x == 0) {
+        uint32_t v;
+        while ((v = __hip_atomic_load(&state[cb.dep], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) == 0u) __builtin_amdgcn_s_sleep(100);
+        verdict = v;
+      }
+      __syncthreads();
+      lost = verdict == 1u;
+    } else {
+      lost = res[cb.dep].ok == 0u;
+    }
+    if (lost) {
+      if (threadIdx.x == 0) { LsnCbRes r{}; res[cb.res_idx] = r; }
+      return;
+    }
   }
   const int lane = threadIdx.x, K = (int)cb.K, F = (int)cb.F;
   const int P = lsn_turbo_nwin(K), W = K / P;
@@ -530,6 +612,7 @@ __global__ __launch_bounds__(NT) TB_WAVES_ATTR void k_turbo(const uint32_t* __re
     LsnCbRes r; r.ok = ok ? 1u : 0u; r.iters = (uint32_t)it; r.rem_a = rema; r.iters_run = (uint32_t)it_run;
     r.cyc_rm = (uint32_t)(tc1 - tc0); r.cyc_map = (uint32_t)(tc2 - tc1); r.cyc_out = (uint32_t)(tc3 - tc2); r.cyc_all = (uint32_t)(tc3 - tc0);
     res[cb.res_idx] = r;
+    if (state) __hip_atomic_store(&state[cb.res_idx], ok ? 2u : 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -539,7 +622,7 @@ static size_t turbo_lds_bytes_nt(uint32_t kmax, int) { return lsn_turbo_lds_byte
 // cb[0 .. n128) use two wavefronts per code block (P > 64), cb[n128 .. ncb) one; each range is launched with the LDS
 // size of its largest block (40 KiB at K = 6144 -> four code blocks per CU)
 void lsn_launch_turbo(const LsnCellDev& c, const LsnCbDev* cb, const uint32_t* spp, uint8_t* payload, LsnCbRes* res, uint32_t n128, uint32_t kmax128,
-                      uint32_t n64, uint32_t kmax64, hipStream_t s, hipEvent_t between)
+                      uint32_t n64, uint32_t kmax64, hipStream_t s, hipEvent_t between, uint32_t* state)
 {
   static bool attr_set = false;
   if (!attr_set) {
@@ -548,7 +631,7 @@ void lsn_launch_turbo(const LsnCellDev& c, const LsnCbDev* cb, const uint32_t* s
     attr_set = true;
   }
   auto fix = [](uint32_t k) { return ((k < 512 ? 512u : k) + 7u) & ~7u; };  // the scratch in the check-point area needs room
-  if (n128) hipLaunchKernelGGL(k_turbo<128>, dim3(n128), dim3(128), turbo_lds_bytes_nt(fix(kmax128), 128), s, c.crc_tab_a, c.crc_tab_b, c.turbo_il, cb, spp, payload, res, fix(kmax128));
+  if (n128) hipLaunchKernelGGL(k_turbo<128>, dim3(n128), dim3(128), turbo_lds_bytes_nt(fix(kmax128), 128), s, c.crc_tab_a, c.crc_tab_b, c.turbo_il, cb, spp, payload, res, fix(kmax128), state);
   if (between) (void)hipEventRecord(between, s);
-  if (n64) hipLaunchKernelGGL(k_turbo<64>, dim3(n64), dim3(64), turbo_lds_bytes_nt(fix(kmax64), 64), s, c.crc_tab_a, c.crc_tab_b, c.turbo_il, cb + n128, spp, payload, res, fix(kmax64));
+  if (n64) hipLaunchKernelGGL(k_turbo<64>, dim3(n64), dim3(64), turbo_lds_bytes_nt(fix(kmax64), 64), s, c.crc_tab_a, c.crc_tab_b, c.turbo_il, cb + n128, spp, payload, res, fix(kmax64), state);
 }
