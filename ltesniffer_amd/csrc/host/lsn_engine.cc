@@ -227,6 +227,10 @@ int Engine::setCell(const lsn_cell_t& c)
       ulmod.assign(65536, 0); ul_uecfg.assign(65536, UeSpecConfig()); ul_time.assign(65536, 0); ul_active.assign(65536, 0); ul_success.assign(65536, 0);
       ulmod_count = 0;
     }
+    // hipMemset on device memory (dalloc) is asynchronous to the host and runs on the null stream, which the engine's non-blocking streams do not
+    // wait for: without this barrier a clear still in flight could wipe what the first stage-A kernels of a fresh engine had just written (seen once
+    // the process ran on 16 hardware queues: the records of the first subframes missing in 1 of 40 runs)
+    HIP_CHECK(hipDeviceSynchronize());
   } catch (const std::exception& ex) {
     fprintf(stderr, "ltesniffer_amd: %s\n", ex.what());
     return LSN_ERROR;
