@@ -623,7 +623,7 @@ def main():
                          "algo_bytes_per_launch": int(kbytes / max(1, klaunch[kt])), "timing": "HIP events on the launch streams inside the timed region (span of a launch that shares the GPU, not exclusive)",
                          "rocprof": rocprof, "dominant_by_time": la.KERNELS[dom], "valu": valu, "gpu_saturation": saturation, "profile": _profile_state()},
             "first_h2d_to_last_pdu": legs, "cold_state": cold, "cpu_baseline": cpu,
-            "host": {"cpu_count": os.cpu_count(), "cpu_quota_cores": host_quota, "decode_threads": int(os.environ.get("LSN_DECODE_THREADS", "8")), "cores_busy_in_timed_region": round(host_cores_busy, 2),
+            "host": {"cpu_count": os.cpu_count(), "cpu_quota_cores": host_quota, "decode_threads": int(os.environ.get("LSN_DECODE_THREADS", "12")), "cores_busy_in_timed_region": round(host_cores_busy, 2),
                      "busiest_threads": busiest},
             "detail": {"pdus_per_subframe": round(p.nof_pdus / sf_rank, 3), "algo_bytes_per_subframe": int(p.algo_bytes / sf_rank),
                        "whole_path_GBps": round(p.algo_bytes * (1 if capture_mode else world) / 1e9 / dt, 2), "timed_region_s": round(dt, 3),
