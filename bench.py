@@ -486,6 +486,24 @@ def main():
             legs["cfg2_32_rnti_tm2_64qam"] = {"subframes_per_s": round(4 * n2 / dtl, 1), "subframes": 4 * n2, "records": w2.nof_records(), "input": "resident in HBM"}
             p2.close()
             del d2
+            # the same load on a FOUR-port cell (round 4: CRS ports 2 / 3, SFBC-FSTD on every channel; parity: tests/test_gpu_parity.py::test_four_crs_ports_*)
+            sc2 = scenario("cfg2", seed=2, nof_ports=4)
+            t2, iq2 = gen_capture(sc2, 3200, threads=gen_threads)
+            d2 = torch.from_numpy(iq2.view(np.float32)).to(dev)
+            w2 = la.PcapWriter(None)
+            w2.set_store(False)
+            p2 = la.Phy(nof_rx_antennas=sc2["nof_rx"], max_batch=batch, device=local, pcapwriter=w2)
+            p2.setCell(sc2["nof_prb"], sc2["nof_ports"], sc2["cell_id"])
+            n2 = d2.shape[0]
+            p2.process_device(d2.data_ptr(), n2, t2 % 10240, 500, stream)
+            t = time.perf_counter()
+            for r in range(4):
+                p2.submit_device(d2.data_ptr(), n2, (t2 + (r + 1) * n2) % 10240, 500, stream)
+            p2.wait()
+            dtl = time.perf_counter() - t
+            legs["cfg2_on_four_crs_ports"] = {"subframes_per_s": round(4 * n2 / dtl, 1), "subframes": 4 * n2, "records": w2.nof_records(), "input": "resident in HBM"}
+            p2.close()
+            del d2
             # the metric's configuration at 16 dB instead of 30 dB: most code blocks need many iterations and many fail - the decoders' design
             # parameters (LLR scale, clip, extrinsic scaling, window count) carry the result here; record parity at this operating point:
             # tests/test_gpu_parity.py::test_mid_snr_many_crc_failures (stage-C taps + record stream)
