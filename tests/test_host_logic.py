@@ -17,7 +17,8 @@ def test_rm_index_closed_form():
     assert out.startswith("OK")
 
 
-@pytest.mark.parametrize("nprb,ports", [(6, 1), (15, 2), (25, 1), (25, 2), (50, 1), (50, 2), (75, 1), (75, 2), (100, 1), (100, 2)])
+@pytest.mark.parametrize("nprb,ports", [(6, 1), (15, 2), (25, 1), (25, 2), (50, 1), (50, 2), (75, 1), (75, 2), (100, 1), (100, 2),
+                                        (6, 4), (15, 4), (25, 4), (50, 4), (75, 4), (100, 4)])
 def test_dci_sizes(nprb, ports):
     h, o = hosttest(), oracle()
     cell = OCell(nprb, ports, 1, 1)
@@ -54,7 +55,7 @@ def _oracle_grant_api():
     return o
 
 
-@pytest.mark.parametrize("nprb,ports", [(100, 2), (75, 2), (50, 1), (25, 2), (6, 1), (15, 2)])
+@pytest.mark.parametrize("nprb,ports", [(100, 2), (75, 2), (50, 1), (25, 2), (6, 1), (15, 2), (100, 4), (25, 4), (6, 4)])
 def test_dl_grants_random_payloads(nprb, ports):
     """random DCI payloads of every DL format -> identical unpack verdict, PRB set, TBS/modulation, nof_re, MIMO config"""
     h, o = hosttest(), _oracle_grant_api()
@@ -229,6 +230,12 @@ def test_falcon_search_cfg1():
 
 def test_falcon_search_15mhz_cell():
     _search_parity("cfg2", 12, seed=6, nof_prb=75, cell_id=77, n_rnti=20)
+
+
+def test_falcon_search_four_port_cells():
+    """the product's host search on four-port candidate tables (four-port DCI sizes of formats 2 / 2A, 76 CCEs at 20 MHz) == the oracle worker's"""
+    _search_parity("cfg2", 14, seed=7, nof_ports=4, cfi=0, n_rnti=12)
+    _search_parity("cfg3", 12, seed=8, nof_ports=4, nof_prb=50, n_rnti=20, rar_period=0)
 
 
 def test_falcon_search_cfg3_meta_update():
