@@ -639,6 +639,9 @@ def main():
                          "frac": round(ach / 8000.0, 6), "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": round(kms[kt] / max(1, klaunch[kt]), 4), "launches": int(klaunch[kt]),
                          "algo_bytes_per_launch": int(kbytes / max(1, klaunch[kt])), "timing": "HIP events on the launch streams inside the timed region (span of a launch that shares the GPU, not exclusive)",
+                         # how many launches of this kernel are in flight on average (launches x mean span / timed region): the spans of concurrent launches
+                         # stretch each other, so `frac` falls when the engine keeps more of them resident although the throughput rises
+                         "mean_launches_in_flight": round(float(kms[kt]) / (dt * 1e3), 2),
                          "rocprof": rocprof, "dominant_by_time": la.KERNELS[dom], "valu": valu, "gpu_saturation": saturation, "profile": _profile_state()},
             "first_h2d_to_last_pdu": legs, "cold_state": cold, "cpu_baseline": cpu,
             "host": {"cpu_count": os.cpu_count(), "cpu_quota_cores": host_quota, "decode_threads": int(os.environ.get("LSN_DECODE_THREADS", "12")), "cores_busy_in_timed_region": round(host_cores_busy, 2),
