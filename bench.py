@@ -5,11 +5,11 @@ The stream (one definition, shared with tools/make_cfg3_golden.py): the cfg3 cap
 subframes, 150 RNTIs, a fresh RNTI by RAR every 200 subframes (the MCS-tracking database crosses its 250 entries and ages), TM2/3/4 up to
 256QAM - replayed cyclically with the TTI advancing and all sequential state (RNTI histograms, MCS tables, meta formats) carried over; meta
 formats update every 500 subframes.  A "step" is one pass of the hot path (OFDM -> chest -> PCFICH/PDCCH -> exhaustive Viterbi -> FALCON
-search -> PDSCH demod -> rate de-matching -> turbo -> MAC PDUs into the MAC-LTE pcap writer) over the next --step-sf (4000) subframes of
+search -> PDSCH demod -> rate de-matching -> turbo -> MAC PDUs into the MAC-LTE pcap writer) over the next --step-sf (20 000) subframes of
 that stream.  IQ is in HBM before the timed region starts (`value`); the PCIe-inclusive rates - first H2D to last PDU, SURVEY 8(d) - are the
 `first_h2d_to_last_pdu` legs of the same line.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--step-sf 4000] [--batch 800] [--cpu-sample 1600]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--step-sf 20000] [--batch 400] [--cpu-sample 1600]
 
 Parity gate: `pcap_diff` describes the TIMED stream against the CPU ORACLE.  The oracle walked the first 100 000 subframes of the stream once
 (one thread - its state is a sequential scan; 35 subframes/s) and its records were hashed per block of 200 subframes
@@ -136,7 +136,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--step-sf", type=int, default=4000, help="subframes per step: a divisor of the capture length and a multiple of 200")
+    ap.add_argument("--step-sf", type=int, default=20000, help="subframes per step: a divisor of the capture length and a multiple of 200 (20 000 = one pass of the "
+                    "capture: the driver's 20 timed steps last 2 s; rounds 1-4 used 4 000, a timed region of 0.4 s of which pipeline fill / drain was 5 %%)")
     ap.add_argument("--nsf", type=int, default=0, help="distinct subframes of the capture (0 = the gated stream's 20 000); other values run ungated")
     ap.add_argument("--config", default="cfg3", help="scenario preset: cfg3 = 20 MHz, 150 RNTIs, TM3/TM4 up to 256QAM")
     ap.add_argument("--batch", type=int, default=400, help="subframes per pipeline chunk inside a submit (400-500 measured best on the 4 000-subframe steps: shorter fill / drain than 800, fewer launches than 200)")
@@ -210,7 +211,11 @@ def main():
     while nsf % S:
         S -= BLOCK  # a step never straddles the wrap of the capture
     batch = min(args.batch or S, S)
-    sc = scenario(args.config, **ld.rank_workload(args.config, rank))  # one synthetic cell per rank; rank 0 = the gated stream
+    # the work queue (which cell each rank replays: SURVEY 8d config 5, one capture per GPU; rank 0 = the gated stream) lives on rank 0 and is
+    # scattered - over RCCL / xGMI under the nccl backend: the path's only exchange step besides the timing reductions (BASELINE north_star)
+    rdev_ = dev if world > 1 and dist.get_backend() == "nccl" else None
+    work = ld.scatter_work([tuple(ld.rank_workload(args.config, r).values()) + (0, nsf) for r in range(world)] if rank == 0 else None, rdev_)
+    sc = scenario(args.config, seed=work["seed"], cell_id=work["cell_id"])
     gen_threads = args.gen_threads or max(1, min(32, int(host_quota // max(1, world)) if host_quota else 8))
     # N ranks share the host's cores: a rank other than 0 (its cell is not the gated stream) renders fewer distinct subframes when it has few
     # transmitter threads - its work per step is unchanged, the block is replayed.  Captures are kept in /dev/shm between the back-to-back runs
@@ -331,13 +336,39 @@ def main():
     timed_records = pcap.nof_records()
     timed_blocks = pcap.block_digests()
     host_cores_busy = ((ru1.ru_utime - ru0.ru_utime) + (ru1.ru_stime - ru0.ru_stime)) / dt
+    per_rank_cores = None
     if world > 1 and not capture_mode:
         rdev = dev if dist.get_backend() == "nccl" else None
+        per_rank_cores = [v / 100.0 for v in ld.gather_flags(int(round(host_cores_busy * 100)), rdev)]  # host CPU each rank kept busy in ITS timed region
         dt, total = ld.reduce_max_sum(dt, args.steps * S, rdev)
         assert total == args.steps * S * world
     total_sf = args.steps * S * (1 if capture_mode else world)
     value = total_sf / dt
     phy.close()
+
+    def live_oracle_blocks(n):
+        """the CPU oracle, live, over the first n subframes of THIS rank's capture from cold state -> (blocks [(digest, records)], seconds, records)"""
+        ob = la.PcapWriter(None)
+        ob.set_store(False)
+        ob.set_digest_blocks(BLOCK, tti0)
+        t = time.perf_counter()
+        _, _, orecs = run_oracle(sc, tti0, iq[:n], update_meta_period=META_PERIOD, taps=False)
+        dto = time.perf_counter() - t
+        for r in orecs:  # the oracle's records through the product's block hash
+            c = r["ctx"]
+            fs = (c[10] << 8) | c[11]
+            ob.write(dict(tti=(fs >> 4) * 10 + (fs & 15), rnti=(c[4] << 8) | c[5], direction=c[1], rnti_type=c[2], crc_ok=c[13]), r["pdu"])
+        return ob.block_digests()[:n // BLOCK], dto, len(orecs)
+
+    # ranks other than 0 replay cells of their own (no cached oracle stream): each checks the head of ITS cold-state stream - the first 400 subframes
+    # of the warm-up - against the oracle run live on its host cores; the verdicts travel to rank 0 (round-4 review: "ranks > 0 are ungated")
+    rank_flags = None
+    if world > 1 and not capture_mode:
+        flag = -1
+        if rank > 0 and not args.no_cpu and args.warmup * S >= 2 * BLOCK:
+            lb, _, _ = live_oracle_blocks(2 * BLOCK)
+            flag = 1 if (len(lb) == 2 and warm_blocks[:2] == lb) else 0
+        rank_flags = ld.gather_flags(flag, dev if dist.get_backend() == "nccl" else None)
 
     # ---------------------------------------------------------------- parity gate (rank 0): timed blocks == the oracle's blocks
     cpu, parity, pcap_diff = None, None, None
@@ -345,6 +376,8 @@ def main():
         parity = {"reference": "CPU oracle (oracle/, scalar C restatement; unpinned against srsRAN soft values, DESIGN.md section 2), cached per 200-subframe block by tools/make_cfg3_golden.py",
                   "timed_subframes": args.steps * S, "timed_records": timed_records, "timed_bytes": timed_bytes, "timed_digest": "%016x" % timed_digest,
                   "block_subframes": BLOCK, "golden_note": golden_note}
+        if rank_flags is not None:  # 1 = the rank's first 400 subframes equal the live oracle's, 0 = they differ, -1 = not checked (rank 0: gated on the cached stream)
+            parity["other_ranks_head_equals_live_oracle"] = rank_flags[1:]
         if golden is not None:
             nb = args.steps * S // BLOCK
             cov, bad, rd = block_check(timed_blocks[:nb] + [(0, 0)] * max(0, nb - len(timed_blocks)), args.warmup * S // BLOCK)
@@ -358,19 +391,9 @@ def main():
                 pcap_diff = int(rd + (bad if rd == 0 else 0))
         ns = max(BLOCK, min(args.cpu_sample, nsf) // BLOCK * BLOCK)
         if not args.no_cpu:
-            ow_blocks = la.PcapWriter(None)
-            ow_blocks.set_store(False)
-            ow_blocks.set_digest_blocks(BLOCK, tti0)
-            t = time.perf_counter()
-            _, _, orecs = run_oracle(sc, tti0, iq[:ns], update_meta_period=META_PERIOD, taps=False)
-            dto = time.perf_counter() - t
+            lb, dto, _ = live_oracle_blocks(ns)
             cpu = {"value": round(ns / dto, 2), "unit": "subframes/s", "cores": 1, "kind": "port",
                    "sample": "the first %d subframes of the same capture (cold RNTI state), scalar C oracle, 1 thread" % ns}
-            for r in orecs:  # the live oracle's records through the same block hash: the cached stream is reproducible on this host
-                c = r["ctx"]
-                fs = (c[10] << 8) | c[11]
-                ow_blocks.write(dict(tti=(fs >> 4) * 10 + (fs & 15), rnti=(c[4] << 8) | c[5], direction=c[1], rnti_type=c[2], crc_ok=c[13]), r["pdu"])
-            lb = ow_blocks.block_digests()[:ns // BLOCK]
             if golden is not None:
                 cov, bad, _ = block_check(lb, 0)
                 parity["live_oracle_reproduces_cached_blocks"] = bool(cov == len(lb) and bad == 0)
@@ -464,88 +487,67 @@ def main():
         except Exception as ex:
             legs["error"] = str(ex)[:300]
 
-    # ---------------------------------------------------------------- the other BASELINE.json configurations, one short resident pass each
-    # (configs[1]: 20 MHz, 32 RNTIs, TM2 64QAM; configs[3]: 20 MHz UL+DL, 64 RNTIs, PUSCH at n + 4 with 16/64QAM turbo decodes) - context
-    # numbers next to the headline, never `value`; their parity is covered by tests/test_gpu_parity.py and tests/test_gpu_ul.py
+    # ---------------------------------------------------------------- the other BASELINE.json configurations (tools/bench_legs.py: LEGS)
+    # configs[1] (20 MHz, 32 RNTIs, TM2 64QAM), the same on four CRS ports, configs[2] at 16 dB, the same with HARQ soft combining, configs[3]
+    # (UL_MODE, PUSCH at n + 4) - context numbers next to the headline, never `value`.  Since round 5 EVERY one of them is gated like the headline:
+    # the oracle walked each leg's whole stream (cold pass + timed passes, state carried over) once, tests/golden/leg_<name>.json holds its
+    # records hashed per 200-subframe block, and the leg prints oracle_blocks_compared / mismatching / pcap_diff for ALL its passes.
     if legs is not None and "error" not in legs:
-        try:
-            sc2 = scenario("cfg2", seed=2)
-            t2, iq2 = gen_capture(sc2, 3200, threads=gen_threads)
-            d2 = torch.from_numpy(iq2.view(np.float32)).to(dev)
-            w2 = la.PcapWriter(None)
-            w2.set_store(False)
-            p2 = la.Phy(nof_rx_antennas=sc2["nof_rx"], max_batch=batch, device=local, pcapwriter=w2)
-            p2.setCell(sc2["nof_prb"], sc2["nof_ports"], sc2["cell_id"])
-            n2 = d2.shape[0]
-            p2.process_device(d2.data_ptr(), n2, t2 % 10240, 500, stream)
-            t = time.perf_counter()
-            for r in range(4):
-                p2.submit_device(d2.data_ptr(), n2, (t2 + (r + 1) * n2) % 10240, 500, stream)
-            p2.wait()
-            dtl = time.perf_counter() - t
-            legs["cfg2_32_rnti_tm2_64qam"] = {"subframes_per_s": round(4 * n2 / dtl, 1), "subframes": 4 * n2, "records": w2.nof_records(), "input": "resident in HBM"}
-            p2.close()
-            del d2
-            # the same load on a FOUR-port cell (round 4: CRS ports 2 / 3, SFBC-FSTD on every channel; parity: tests/test_gpu_parity.py::test_four_crs_ports_*)
-            sc2 = scenario("cfg2", seed=2, nof_ports=4)
-            t2, iq2 = gen_capture(sc2, 3200, threads=gen_threads)
-            d2 = torch.from_numpy(iq2.view(np.float32)).to(dev)
-            w2 = la.PcapWriter(None)
-            w2.set_store(False)
-            p2 = la.Phy(nof_rx_antennas=sc2["nof_rx"], max_batch=batch, device=local, pcapwriter=w2)
-            p2.setCell(sc2["nof_prb"], sc2["nof_ports"], sc2["cell_id"])
-            n2 = d2.shape[0]
-            p2.process_device(d2.data_ptr(), n2, t2 % 10240, 500, stream)
-            t = time.perf_counter()
-            for r in range(4):
-                p2.submit_device(d2.data_ptr(), n2, (t2 + (r + 1) * n2) % 10240, 500, stream)
-            p2.wait()
-            dtl = time.perf_counter() - t
-            legs["cfg2_on_four_crs_ports"] = {"subframes_per_s": round(4 * n2 / dtl, 1), "subframes": 4 * n2, "records": w2.nof_records(), "input": "resident in HBM"}
-            p2.close()
-            del d2
-            # the metric's configuration at 16 dB instead of 30 dB: most code blocks need many iterations and many fail - the decoders' design
-            # parameters (LLR scale, clip, extrinsic scaling, window count) carry the result here; record parity at this operating point:
-            # tests/test_gpu_parity.py::test_mid_snr_many_crc_failures (stage-C taps + record stream)
-            sc16 = scenario("cfg3", seed=16, snr_db=16.0)
-            t16, iq16 = gen_capture(sc16, 3200, threads=gen_threads)
-            d16 = torch.from_numpy(iq16.view(np.float32)).to(dev)
-            w16 = la.PcapWriter(None)
-            w16.set_store(False)
-            p16 = la.Phy(nof_rx_antennas=sc16["nof_rx"], max_batch=batch, device=local, pcapwriter=w16)
-            p16.setCell(sc16["nof_prb"], sc16["nof_ports"], sc16["cell_id"])
-            n16 = d16.shape[0]
-            p16.process_device(d16.data_ptr(), n16, t16 % 10240, 500, stream)
-            t = time.perf_counter()
-            for r in range(4):
-                p16.submit_device(d16.data_ptr(), n16, (t16 + (r + 1) * n16) % 10240, 500, stream)
-            p16.wait()
-            dtl = time.perf_counter() - t
-            pf16 = p16.perf()
-            legs["cfg3_at_16_dB_snr"] = {"subframes_per_s": round(4 * n16 / dtl, 1), "subframes": 4 * n16, "records": w16.nof_records(), "input": "resident in HBM",
-                                         "turbo_iterations_per_subframe": round(pf16.nof_turbo_iterations / (4.0 * n16), 1), "tb_decodes_per_subframe": round(pf16.nof_tb_decodes / (4.0 * n16), 2),
-                                         "pdus_per_subframe": round(pf16.nof_pdus / (4.0 * n16), 2)}
-            p16.close()
-            del d16
-            from lsn_testlib import gen_ul_mode_subframes
-            sc4 = scenario("cfg2", seed=4, nof_rx=1, n_rnti=64, ul_min=2, ul_max=4, mcs_min=0, mcs_max=28, snr_db=28.0)
-            t4, iq4, sent4 = gen_ul_mode_subframes(sc4, 200, ul_snr_db=22.0)
-            h4 = torch.from_numpy(np.tile(iq4, (16, 1, 1))).pin_memory()
-            w4 = la.PcapWriter(None)
-            w4.set_store(False)
-            p4 = la.Phy(nof_rx_antennas=2, sniffer_mode=1, max_batch=200, device=local, pcapwriter=w4)
-            p4.setCell(sc4["nof_prb"], sc4["nof_ports"], sc4["cell_id"])
-            p4.setUlConfig(3, 5)
-            p4.process_host(h4.numpy(), t4 % 10240, 500)
-            w4.reset()
-            t = time.perf_counter()
-            p4.process_host(h4.numpy(), t4 % 10240, 500)
-            dtl = time.perf_counter() - t
-            legs["cfg4_ul_mode_64_rnti"] = {"subframes_per_s": round(h4.shape[0] / dtl, 1), "subframes": int(h4.shape[0]), "records": w4.nof_records(),
-                                            "pusch_sent_per_subframe": round(len(sent4) / 200.0, 2), "input": "host buffers (two antenna streams), PCIe included"}
-            p4.close()
-        except Exception as ex:
-            legs["other_configs_error"] = str(ex)[:300]
+        import bench_legs as bl
+        only = os.environ.get("LSN_BENCH_LEGS")  # development: comma-separated subset
+        for name, ld in bl.LEGS.items():
+            if only is not None and name not in only.split(","):
+                continue
+            try:
+                scl, tl, iql = bl.leg_capture(name, threads=gen_threads)
+                gl, gnote = bl.load_golden(name, iql, tl)
+                wl = la.PcapWriter(None)
+                wl.set_store(False)
+                wl.set_digest_blocks(bl.BLOCK, tl)
+                nl, npass = ld["nsf"], ld["passes"]
+                if ld["kind"] == "dl":
+                    pl = la.Phy(nof_rx_antennas=scl["nof_rx"], max_batch=batch, device=local, pcapwriter=wl, harq_mode=ld.get("harq_mode", 0))
+                    pl.setCell(scl["nof_prb"], scl["nof_ports"], scl["cell_id"])
+                    dl_ = torch.empty((nl,) + iql.shape[1:] + (2,), dtype=torch.float32, device=dev)
+                    for a_ in range(0, nl, 2000):
+                        dl_[a_:a_ + 2000].copy_(torch.from_numpy(iql[a_:a_ + 2000].view(np.float32).reshape(-1, iql.shape[1], iql.shape[2], 2)))
+                    torch.cuda.synchronize()
+                    pl.process_device(dl_.data_ptr(), nl, tl % 10240, bl.META_PERIOD, stream)   # pass 1: cold state, untimed
+                    t = time.perf_counter()
+                    for r in range(1, npass):
+                        pl.submit_device(dl_.data_ptr(), nl, (tl + r * nl) % 10240, bl.META_PERIOD, stream)
+                    pl.wait()
+                    dtl = time.perf_counter() - t
+                    inp = "resident in HBM"
+                    del dl_
+                else:
+                    hl = torch.from_numpy(iql).pin_memory()
+                    pl = la.Phy(nof_rx_antennas=2, sniffer_mode=1, max_batch=200, device=local, pcapwriter=wl)
+                    pl.setCell(scl["nof_prb"], scl["nof_ports"], scl["cell_id"])
+                    pl.setUlConfig(ld["cyclic_shift"], ld["delta_ss"])
+                    pl.process_host(hl.numpy(), tl % 10240, bl.META_PERIOD)
+                    t = time.perf_counter()
+                    for r in range(1, npass):
+                        pl.process_host(hl.numpy(), (tl + r * nl) % 10240, bl.META_PERIOD)
+                    dtl = time.perf_counter() - t
+                    inp = "host buffers (two antenna streams), PCIe included"
+                    del hl
+                pfl = pl.perf()  # (counters of the last submit ... wait span = the timed passes; UL_MODE: the last pass)
+                nb = npass * nl // bl.BLOCK
+                blocks = wl.block_digests()[:nb]
+                blocks += [(0x9E3779B97F4A7C15, 0)] * (nb - len(blocks))
+                cov, bad, rd = bl.check_blocks(gl, blocks, 0)
+                timed = (npass - 1) * nl
+                counted = timed if ld["kind"] == "dl" else nl
+                legs[name] = {"what": ld["what"], "subframes_per_s": round(timed / dtl, 1), "subframes": timed, "timed_s": round(dtl, 3), "records_all_passes": wl.nof_records(), "input": inp,
+                              "turbo_iterations_per_subframe": round(pfl.nof_turbo_iterations / float(counted), 1), "tb_decodes_per_subframe": round(pfl.nof_tb_decodes / float(counted), 2),
+                              "pdus_per_subframe": round(pfl.nof_pdus / float(counted), 2),
+                              "oracle_subframes": cov * bl.BLOCK, "oracle_blocks_compared": cov, "oracle_blocks_mismatching": bad,
+                              "pcap_diff": (int(rd + (bad if rd == 0 else 0)) if gl is not None and cov == nb else None), "golden_note": gnote}
+                pl.close()
+                del iql
+            except Exception as ex:
+                legs[name] = {"error": str(ex)[:300]}
 
     if rank == 0:
         kms = np.array(p.kernel_ms[:])
@@ -644,7 +646,7 @@ def main():
                          "mean_launches_in_flight": round(float(kms[kt]) / (dt * 1e3), 2),
                          "rocprof": rocprof, "dominant_by_time": la.KERNELS[dom], "valu": valu, "gpu_saturation": saturation, "profile": _profile_state()},
             "first_h2d_to_last_pdu": legs, "cold_state": cold, "cpu_baseline": cpu,
-            "host": {"cpu_count": os.cpu_count(), "cpu_quota_cores": host_quota, "decode_threads": int(os.environ.get("LSN_DECODE_THREADS", "12")), "cores_busy_in_timed_region": round(host_cores_busy, 2),
+            "host": {"cpu_count": os.cpu_count(), "cpu_quota_cores": host_quota, "decode_threads": int(os.environ.get("LSN_DECODE_THREADS", "12")), "cores_busy_in_timed_region": round(host_cores_busy, 2), "cores_busy_per_rank": per_rank_cores,
                      "busiest_threads": busiest},
             "detail": {"pdus_per_subframe": round(p.nof_pdus / sf_rank, 3), "algo_bytes_per_subframe": int(p.algo_bytes / sf_rank),
                        "whole_path_GBps": round(p.algo_bytes * (1 if capture_mode else world) / 1e9 / dt, 2), "timed_region_s": round(dt, 3),

@@ -13,9 +13,9 @@ import subprocess
 
 import numpy as np
 
-# the engine's 12 decode chains + 4 stage-A chains want more than the HIP runtime's default of 4 hardware queues (read at runtime initialisation: before
-# the first HIP call of the process; an exported value wins) - see INTEGRATION.md
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# (GPU_MAX_HW_QUEUES: the engine's 12 decode chains + 4 stage-A chains want 16 hardware queues, the HIP runtime's default is 4 and the value is read at
+#  runtime initialisation.  That is the HOST PROGRAM's business - bench.py and tests/conftest.py export it; importing this module changes nothing in the
+#  process environment (round-4 advisor finding) and the engine adapts its chain count to what it finds)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("LSN_LIB_PATH") or os.path.join(_HERE, "lib", "libltesniffer_amd.so")  # LSN_LIB_PATH: A/B builds of the same library (tools/)

@@ -157,6 +157,21 @@ Engine::Engine(const lsn_phy_cfg_t& c, std::shared_ptr<SharedSeq> shared) : sh(s
   // test hook of the error path, read once per engine: chunk <n> of the first submitted block fails in stage A (and must not wedge the pipeline)
   if (const char* e = getenv("LSN_INJECT_STAGE_A_ERROR")) inject_stage_a_fail = atoi(e);
   if (const char* e = getenv("LSN_DECODE_THREADS")) ndec = std::max(1, std::min((int)NDEC, atoi(e)));
+  else {
+    // The default of twelve decode chains (+ four stage-A chains + copies) is tuned for sixteen hardware queues; the HIP runtime gives a process four
+    // unless GPU_MAX_HW_QUEUES is exported BEFORE its first HIP call - something a library cannot do for its host (round-4 advisor finding: the Python
+    // binding used to set it on import).  On fewer queues the chains wait for each other's kernels: the engine then runs the eight chains measured best
+    // on four queues and says so once.
+    const char* q = getenv("GPU_MAX_HW_QUEUES");
+    const int nq = q ? atoi(q) : 4;
+    if (nq < 12) {
+      ndec = std::min(ndec, 8);
+      static std::atomic<bool> told{false};
+      if (!told.exchange(true) && !getenv("LSN_QUIET"))
+        fprintf(stderr, "ltesniffer_amd: %d hardware queues (GPU_MAX_HW_QUEUES %s): running %d decode chains instead of %d; export GPU_MAX_HW_QUEUES=16 before the "
+                        "first HIP call of the process for the tuned configuration (INTEGRATION.md section 2)\n", nq, q ? q : "unset", ndec, (int)NDEC);
+    }
+  }
   if (const char* e = getenv("LSN_KERNEL_TIMING_PERIOD")) timing_period = (uint32_t)std::max(0, atoi(e));
   nslots = ndec + 8;
   front_thread = std::thread([this] { pthread_setname_np(pthread_self(), "lsn-front"); frontLoop(); });

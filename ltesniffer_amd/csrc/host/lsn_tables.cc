@@ -89,7 +89,7 @@ void Engine::freeRunner(JobRunner& r)
   auto hf = [](auto*& p) { if (p) (void)hipHostFree(p); p = nullptr; };
   df(r.d_jobs); df(r.d_cbs); df(r.d_cbstate); df(r.d_cbres); df(r.d_prefix); df(r.d_llr16); df(r.d_payload); df(r.d_spp); df(r.d_items);
   hf(r.h_items_pinned); hf(r.h_payload_pinned); hf(r.h_cbres_pinned); hf(r.h_jobs_pinned); hf(r.h_cbs_pinned);
-  r.items_cap = r.h_items_cap = r.spp_cap = r.jobs_cap = r.cbs_cap = r.cbres_cap = r.prefix_cap = r.llr16_cap = r.payload_cap = r.h_payload_cap = r.h_cbres_cap = r.h_jobs_cap = r.h_cbs_cap = 0;
+  r.items_cap = r.h_items_cap = r.spp_cap = r.jobs_cap = r.cbs_cap = r.cbstate_cap = r.cbres_cap = r.prefix_cap = r.llr16_cap = r.payload_cap = r.h_payload_cap = r.h_cbres_cap = r.h_jobs_cap = r.h_cbs_cap = 0;
   for (auto& e : r.ev)
     if (e) { (void)hipEventDestroy(e); e = nullptr; }
   if (r.ev_done) { (void)hipEventDestroy(r.ev_done); r.ev_done = nullptr; }
@@ -128,15 +128,22 @@ void Engine::allocRunner(JobRunner& r)
   for (int i = 0; i < NDEC; i++) bulk = bulk || &r == &runner_c[i];
   if (bulk && !getenv("LSN_NO_PRESIZE")) {
     const double scale = (double)cell.nof_prb / 100.0;
-    const size_t sfn_ = max_batch;
+    // The pre-size is a start-up optimisation, never a requirement (round-4 advisor finding): it is bounded by the chunk a runner can meet
+    // (max_batch) AND by a share of the memory that is free right now - all bulk runners together take at most a quarter of it - and an
+    // allocation that fails anyway leaves the arena to the lazy growth of runJobs (grow_dev / grow_host) instead of failing setCell.
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
+    const double per_sf_bytes = (16.0 * (sizeof(LsnGrantDev) + 2.0 * (14 * 100 + 16)) + 32.0 * (sizeof(LsnCbDev) + sizeof(LsnCbRes)) + 512.0 * 1024 * 2 + 24.0 * 1024 + 64 * 4 + 128.0 * 1024 * 4) * scale;
+    size_t sfn_ = max_batch;
+    if (free_b) sfn_ = std::min<size_t>(sfn_, (size_t)((double)free_b / 4.0 / (double)NDEC / per_sf_bytes));
     auto dev = [&](auto*& p, size_t& cap, double per_sf) {
       const size_t n = (size_t)(per_sf * scale * (double)sfn_) + 4096;
-      HIP_CHECK(hipMalloc((void**)&p, n * sizeof(*p)));
+      if (hipMalloc((void**)&p, n * sizeof(*p)) != hipSuccess) { (void)hipGetLastError(); p = nullptr; cap = 0; return; }
       cap = n;
     };
     auto host = [&](auto*& p, size_t& cap, double per_sf) {
       const size_t n = (size_t)(per_sf * scale * (double)sfn_) + 4096;
-      HIP_CHECK(hipHostMalloc((void**)&p, n * sizeof(*p), hipHostMallocCoherent | hipHostMallocMapped));
+      if (hipHostMalloc((void**)&p, n * sizeof(*p), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); p = nullptr; cap = 0; return; }
       cap = n;
     };
     dev(r.d_jobs, r.jobs_cap, 16); dev(r.d_cbs, r.cbs_cap, 32); dev(r.d_cbres, r.cbres_cap, 32);

@@ -2,7 +2,33 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
+#include <stdexcept>
+#include <string>
 #include "../host/lsn_types.h"
+
+// A launch the runtime rejects (LDS request above the function's limit on this device, an empty or oversized grid, no code object for the
+// device) does not fail at the call site: the kernel never runs and the error sits in the thread until some later runtime call reports it -
+// stale results at the next event wait.  Every launcher therefore asks right behind its launch and throws; the engine's stage wrappers turn
+// the text into the chunk's error (round-4 review, weak 9).
+#define LSN_LAUNCH(kernel, grid, block, lds, stream, ...)                                                                      \
+  do {                                                                                                                         \
+    hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                                         \
+    const hipError_t _le = hipGetLastError();                                                                                  \
+    if (_le != hipSuccess) throw std::runtime_error(std::string("launch of " #kernel " failed: ") + hipGetErrorString(_le));   \
+  } while (0)
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to the function ON ONE DEVICE: an engine on a second GPU of the process needs its own call
+// (rounds 1-4 set it once per process).  `done` = one bit per device ordinal.
+inline void lsn_func_max_lds(const void* fn, int bytes, std::atomic<uint64_t>& done, const char* name)
+{
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) throw std::runtime_error("hipGetDevice failed");
+  const uint64_t bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) throw std::runtime_error(std::string("hipFuncSetAttribute(") + name + ") failed: " + hipGetErrorString(e));
+  done.fetch_or(bit, std::memory_order_release);
+}
 
 struct cf32 { float r, i; };
 

@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void k_ofdm(LsnCellDev c, const cf32* __restri
 void lsn_launch_ofdm(const LsnCellDev& c, const cf32* iq, const uint32_t* dphi, cf32* grid, uint32_t nsf, hipStream_t s)
 {
   size_t lds = sizeof(cf32) * (c.N + c.N / 2);
-  hipLaunchKernelGGL(k_ofdm, dim3(nsf * c.nof_rx * 14), dim3(256), lds, s, c, iq, dphi, grid);
+  LSN_LAUNCH(k_ofdm, dim3(nsf * c.nof_rx * 14), dim3(256), lds, s, c, iq, dphi, grid);
 }
 
 // ------------------------------------------------------------------------------------------------ channel estimation
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void k_chest(LsnCellDev c, const cf32* __restr
 void lsn_launch_chest(const LsnCellDev& c, const cf32* grid, const uint32_t* sf_idx, cf32* ce, float* raw, uint32_t nsf, hipStream_t s)
 {
   size_t lds = sizeof(cf32) * 8 * c.nref + sizeof(float) * 6 * 256;
-  hipLaunchKernelGGL(k_chest, dim3(nsf * c.nof_rx * c.nof_ports), dim3(256), lds, s, c, grid, sf_idx, ce, raw);
+  LSN_LAUNCH(k_chest, dim3(nsf * c.nof_rx * c.nof_ports), dim3(256), lds, s, c, grid, sf_idx, ce, raw);
 }
 
 __global__ void k_chest_fin(LsnCellDev c, const float* __restrict__ raw, LsnChest* __restrict__ out, uint32_t nsf)
@@ -271,7 +271,7 @@ __global__ void k_chest_fin(LsnCellDev c, const float* __restrict__ raw, LsnChes
 }
 void lsn_launch_chest_fin(const LsnCellDev& c, const float* raw, LsnChest* out, uint32_t nsf, hipStream_t s)
 {
-  hipLaunchKernelGGL(k_chest_fin, dim3((nsf + 63) / 64), dim3(64), 0, s, c, raw, out, nsf);
+  LSN_LAUNCH(k_chest_fin, dim3((nsf + 63) / 64), dim3(64), 0, s, c, raw, out, nsf);
 }
 
 // ------------------------------------------------------------------------------------------------ control region
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(64) void k_pcfich(LsnCellDev c, const cf32* __restr
 }
 void lsn_launch_pcfich(const LsnCellDev& c, const cf32* grid, const cf32* ce, const LsnChest* ch, const uint32_t* sf_idx, uint32_t* cfi, float* corr, uint32_t nsf, hipStream_t s)
 {
-  hipLaunchKernelGGL(k_pcfich, dim3(nsf), dim3(64), 0, s, c, grid, ce, ch, sf_idx, cfi, corr);
+  LSN_LAUNCH(k_pcfich, dim3(nsf), dim3(64), 0, s, c, grid, ce, ch, sf_idx, cfi, corr);
 }
 
 // One thread per REG in (symbol, frequency) order: consecutive lanes read consecutive REGs of the received grid and of the channel
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256) void k_pdcch_llr(LsnCellDev c, const cf32* __r
 void lsn_launch_pdcch_llr(const LsnCellDev& c, const cf32* grid, const cf32* ce, const LsnChest* ch, const uint32_t* sf_idx, const uint32_t* cfi, float* llr, uint32_t nsf, hipStream_t s)
 {
   const uint32_t nreg = c.nre / 6 + (c.nof_prb <= 10 ? 3u : 2u) * (c.nre / 4);  // REGs of the widest control region
-  hipLaunchKernelGGL(k_pdcch_llr, dim3((nreg + 255) / 256, nsf), dim3(256), 0, s, c, grid, ce, ch, sf_idx, cfi, llr);
+  LSN_LAUNCH(k_pdcch_llr, dim3((nreg + 255) / 256, nsf), dim3(256), 0, s, c, grid, ce, ch, sf_idx, cfi, llr);
 }
 
 // falcon_pdcch.c:595-620: mean |llr| over the 72 LLRs of each CCE, accumulated in double in index order
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(128) void k_cce_power(LsnCellDev c, const float* __
 }
 void lsn_launch_cce_power(const LsnCellDev& c, const float* llr, const uint32_t* cfi, float* pw, uint32_t nsf, hipStream_t s)
 {
-  hipLaunchKernelGGL(k_cce_power, dim3(nsf), dim3(128), 0, s, c, llr, cfi, pw);
+  LSN_LAUNCH(k_cce_power, dim3(nsf), dim3(128), 0, s, c, llr, cfi, pw);
 }
 
 // ------------------------------------------------------------------------------------------------ search space
@@ -938,17 +938,17 @@ __global__ __launch_bounds__(64) void k_pbch_viterbi(LsnCellDev c, const float* 
 }
 void lsn_launch_pbch(const LsnCellDev& c, const cf32* grid, const cf32* ce, const LsnChest* ch, float* llr5, LsnCand* out4, hipStream_t s)
 {
-  hipLaunchKernelGGL(k_pbch_llr, dim3(1), dim3(256), 0, s, c, grid, ce, ch, llr5);
-  hipLaunchKernelGGL(k_pbch_viterbi, dim3(4), dim3(64), 0, s, c, llr5, out4);
+  LSN_LAUNCH(k_pbch_llr, dim3(1), dim3(256), 0, s, c, grid, ce, ch, llr5);
+  LSN_LAUNCH(k_pbch_viterbi, dim3(4), dim3(64), 0, s, c, llr5, out4);
 }
 
 void lsn_launch_viterbi(const LsnCellDev& c, const float* llr, const float* pw, const uint32_t* cfi, const uint32_t* sf_idx, LsnCand* cand, uint32_t nsf,
                         hipStream_t s)
 {
 #ifdef LSN_VITERBI_PAIRED
-  hipLaunchKernelGGL(k_viterbi, dim3((LSN_MAX_LOC + 1) / 2, c.nsizes, nsf), dim3(64), 0, s, c, llr, pw, cfi, sf_idx, cand);
+  LSN_LAUNCH(k_viterbi, dim3((LSN_MAX_LOC + 1) / 2, c.nsizes, nsf), dim3(64), 0, s, c, llr, pw, cfi, sf_idx, cand);
 #else
-  hipLaunchKernelGGL(k_viterbi, dim3(LSN_MAX_LOC, c.nsizes, nsf), dim3(64), 0, s, c, llr, pw, cfi, sf_idx, cand);
+  LSN_LAUNCH(k_viterbi, dim3(LSN_MAX_LOC, c.nsizes, nsf), dim3(64), 0, s, c, llr, pw, cfi, sf_idx, cand);
 #endif
 }
 
@@ -968,7 +968,7 @@ __global__ void k_rb_power(LsnCellDev c, const cf32* __restrict__ grid, float* _
 }
 void lsn_launch_rb_power(const LsnCellDev& c, const cf32* grid, float* rbp, uint32_t nsf, hipStream_t s)
 {
-  hipLaunchKernelGGL(k_rb_power, dim3(nsf), dim3(128), 0, s, c, grid, rbp);
+  LSN_LAUNCH(k_rb_power, dim3(nsf), dim3(128), 0, s, c, grid, rbp);
 }
 
 // ------------------------------------------------------------------------------------------------ IQ capture file source
@@ -991,7 +991,7 @@ __global__ __launch_bounds__(256) void k_file_unpack(const cf32* __restrict__ ra
 void lsn_launch_file_unpack(const cf32* raw, const cf32* rot, uint32_t sflen, uint32_t nant, cf32* out, uint32_t nsf, hipStream_t s)
 {
   if (!nsf) return;
-  hipLaunchKernelGGL(k_file_unpack, dim3((sflen + 255) / 256, nant, nsf), dim3(256), 0, s, raw, rot, sflen, nant, out);
+  LSN_LAUNCH(k_file_unpack, dim3((sflen + 255) / 256, nant, nsf), dim3(256), 0, s, raw, rot, sflen, nant, out);
 }
 
 // ------------------------------------------------------------------------------------------------ descriptor upload (see lsn_dev.h)
@@ -1004,7 +1004,7 @@ void lsn_launch_upload(void* dst_dev, const void* src_pinned, size_t bytes, hipS
   const uint32_t n = (uint32_t)((bytes + 3) / 4);
   if (!n) return;
   const uint32_t blocks = std::min<uint32_t>((n + 255u) / 256u, 64u);
-  hipLaunchKernelGGL(k_upload_words, dim3(blocks), dim3(256), 0, s, (const uint32_t*)src_pinned, (uint32_t*)dst_dev, n);
+  LSN_LAUNCH(k_upload_words, dim3(blocks), dim3(256), 0, s, (const uint32_t*)src_pinned, (uint32_t*)dst_dev, n);
 }
 
 __global__ __launch_bounds__(256) void k_download(const uint4* __restrict__ src, uint4* __restrict__ dst, uint32_t n16, const uint32_t* __restrict__ src_w,
@@ -1037,7 +1037,7 @@ void lsn_launch_copy_multi(const LsnCopySegs& sg, bool to_host, hipStream_t s)
   for (uint32_t q = 0; q < sg.n; q++) total += sg.words[q];
   if (!total) return;
   const uint32_t blocks = std::max<uint32_t>(1u, std::min<uint32_t>((total / 4 + 255u) / 256u, 128u));
-  hipLaunchKernelGGL(k_copy_multi, dim3(blocks), dim3(256), 0, s, sg, to_host ? 1u : 0u);
+  LSN_LAUNCH(k_copy_multi, dim3(blocks), dim3(256), 0, s, sg, to_host ? 1u : 0u);
 }
 
 void lsn_launch_download(void* dst_pinned, const void* src_dev, size_t bytes, hipStream_t s)
@@ -1049,10 +1049,10 @@ void lsn_launch_download(void* dst_pinned, const void* src_dev, size_t bytes, hi
   const uint32_t words = (uint32_t)((bytes + 3) / 4), n16 = al ? words / 4 : 0, tail_first = n16 * 4, tail_n = words - tail_first;
   if (!al || tail_n > 256) {  // unaligned buffers: word copy
     const uint32_t blocks = std::min<uint32_t>((words + 255u) / 256u, 128u);
-    hipLaunchKernelGGL(k_upload_words, dim3(blocks), dim3(256), 0, s, (const uint32_t*)src_dev, (uint32_t*)dst_pinned, words);
+    LSN_LAUNCH(k_upload_words, dim3(blocks), dim3(256), 0, s, (const uint32_t*)src_dev, (uint32_t*)dst_pinned, words);
     return;
   }
   const uint32_t blocks = std::max<uint32_t>(1u, std::min<uint32_t>((n16 + 255u) / 256u, 128u));
-  hipLaunchKernelGGL(k_download, dim3(blocks), dim3(256), 0, s, (const uint4*)src_dev, (uint4*)dst_pinned, n16, (const uint32_t*)src_dev, (uint32_t*)dst_pinned, tail_first,
+  LSN_LAUNCH(k_download, dim3(blocks), dim3(256), 0, s, (const uint4*)src_dev, (uint4*)dst_pinned, n16, (const uint32_t*)src_dev, (uint32_t*)dst_pinned, tail_first,
                      tail_n);
 }

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(64) void k_pdsch_prep(LsnCellDev c, const LsnGrantD
 }
 void lsn_launch_pdsch_prep(const LsnCellDev& c, const LsnGrantDev* g, uint16_t* prefix, uint32_t njobs, hipStream_t s)
 {
-  hipLaunchKernelGGL(k_pdsch_prep, dim3(njobs), dim3(64), 0, s, c, g, prefix);
+  LSN_LAUNCH(k_pdsch_prep, dim3(njobs), dim3(64), 0, s, c, g, prefix);
 }
 
 // The same with the upload of the launch's descriptors folded in (one launch less in every decode chain - the chains' depth, not their work, bounds
@@ -113,7 +113,7 @@ void lsn_launch_pdsch_prep_up(const LsnCellDev& c, const LsnGrantDev* jobs_host,
   uint32_t total = 0;
   for (uint32_t q = 0; q < sg.n; q++) total += sg.words[q];
   const uint32_t ncopy = total ? std::max<uint32_t>(1u, std::min<uint32_t>((total / 4 + 63u) / 64u, 256u)) : 0u;
-  hipLaunchKernelGGL(k_pdsch_prep_up, dim3(njobs + ncopy), dim3(64), 0, s, c, jobs_host, jobs_dev, njobs, sg, prefix);
+  LSN_LAUNCH(k_pdsch_prep_up, dim3(njobs + ncopy), dim3(64), 0, s, c, jobs_host, jobs_dev, njobs, sg, prefix);
 }
 
 // ------------------------------------------------------------------------------------------------ soft demodulation
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(192) void k_pdsch_demod(LsnCellDev c, const LsnGran
 void lsn_launch_pdsch_demod(const LsnCellDev& c, const LsnGrantDev* g, const uint32_t* items, uint32_t nitems, const uint16_t* prefix, const cf32* grid,
                             const cf32* ce, const LsnChest* ch, int16_t* llr, hipStream_t s)
 {
-  if (nitems) hipLaunchKernelGGL(k_pdsch_demod, dim3(nitems, 14), dim3(192), 0, s, c, g, items, prefix, grid, ce, ch, llr);
+  if (nitems) LSN_LAUNCH(k_pdsch_demod, dim3(nitems, 14), dim3(192), 0, s, c, g, items, prefix, grid, ce, ch, llr);
 }
 
 // ------------------------------------------------------------------------------------------------ rate de-matching
@@ -372,12 +372,12 @@ __global__ __launch_bounds__(RM_NT) void k_rm(const LsnCbDev* __restrict__ cbs, 
 // the staging area is sized by the largest E of the launch, capped at 64 KiB (two workgroups per CU at least)
 void lsn_launch_rm(const LsnCbDev* cb, const int16_t* llr, uint32_t* spp, uint32_t ncb, uint32_t emax, hipStream_t s, uint32_t* state)
 {
-  static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_rm, hipFuncAttributeMaxDynamicSharedMemorySize, 65536); attr_set = true; }
+  static std::atomic<uint64_t> attr_done{0};
+  lsn_func_max_lds((const void*)k_rm, 65536, attr_done, "k_rm");
   const uint32_t cap = (65536 - 32) / 2;
   const uint32_t seg = emax < cap ? emax : cap;
   const size_t lds = (((size_t)seg + 16) * 2 + 15) & ~(size_t)15;  // + the skew in front of e[0] and the tail of the last 16-byte load
-  if (ncb) hipLaunchKernelGGL(k_rm, dim3(ncb), dim3(RM_NT), lds, s, cb, llr, spp, seg, state);
+  if (ncb) LSN_LAUNCH(k_rm, dim3(ncb), dim3(RM_NT), lds, s, cb, llr, spp, seg, state);
 }
 
 // ------------------------------------------------------------------------------------------------ HARQ soft combining
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(256) void k_harq_combine(const LsnCbDev* __restrict
 }
 void lsn_launch_harq_combine(const LsnCbDev* cbs, uint32_t ncb, const uint32_t* cur, uint32_t* pool, bool overwrite, hipStream_t s)
 {
-  if (ncb) hipLaunchKernelGGL(k_harq_combine, dim3(ncb), dim3(256), 0, s, cbs, cur, pool, overwrite ? 1u : 0u);
+  if (ncb) LSN_LAUNCH(k_harq_combine, dim3(ncb), dim3(256), 0, s, cbs, cur, pool, overwrite ? 1u : 0u);
 }
 
 // ------------------------------------------------------------------------------------------------ turbo decoder
@@ -624,14 +624,11 @@ static size_t turbo_lds_bytes_nt(uint32_t kmax, int) { return lsn_turbo_lds_byte
 void lsn_launch_turbo(const LsnCellDev& c, const LsnCbDev* cb, const uint32_t* spp, uint8_t* payload, LsnCbRes* res, uint32_t n128, uint32_t kmax128,
                       uint32_t n64, uint32_t kmax64, hipStream_t s, hipEvent_t between, uint32_t* state)
 {
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)k_turbo<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)turbo_lds_bytes_nt(6144, 64));
-    (void)hipFuncSetAttribute((const void*)k_turbo<128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)turbo_lds_bytes_nt(6144, 128));
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> attr64{0}, attr128{0};
+  lsn_func_max_lds((const void*)k_turbo<64>, (int)turbo_lds_bytes_nt(6144, 64), attr64, "k_turbo<64>");
+  lsn_func_max_lds((const void*)k_turbo<128>, (int)turbo_lds_bytes_nt(6144, 128), attr128, "k_turbo<128>");
   auto fix = [](uint32_t k) { return ((k < 512 ? 512u : k) + 7u) & ~7u; };  // the scratch in the check-point area needs room
-  if (n128) hipLaunchKernelGGL(k_turbo<128>, dim3(n128), dim3(128), turbo_lds_bytes_nt(fix(kmax128), 128), s, c.crc_tab_a, c.crc_tab_b, c.turbo_il, cb, spp, payload, res, fix(kmax128), state);
+  if (n128) LSN_LAUNCH(k_turbo<128>, dim3(n128), dim3(128), turbo_lds_bytes_nt(fix(kmax128), 128), s, c.crc_tab_a, c.crc_tab_b, c.turbo_il, cb, spp, payload, res, fix(kmax128), state);
   if (between) (void)hipEventRecord(between, s);
-  if (n64) hipLaunchKernelGGL(k_turbo<64>, dim3(n64), dim3(64), turbo_lds_bytes_nt(fix(kmax64), 64), s, c.crc_tab_a, c.crc_tab_b, c.turbo_il, cb + n128, spp, payload, res, fix(kmax64), state);
+  if (n64) LSN_LAUNCH(k_turbo<64>, dim3(n64), dim3(64), turbo_lds_bytes_nt(fix(kmax64), 64), s, c.crc_tab_a, c.crc_tab_b, c.turbo_il, cb + n128, spp, payload, res, fix(kmax64), state);
 }

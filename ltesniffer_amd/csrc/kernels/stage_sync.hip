@@ -148,10 +148,10 @@ __global__ __launch_bounds__(512) void k_sync_fin(const cf32* __restrict__ x, co
 
 void lsn_launch_pss_corr(const cf32* x, const cf32* p, uint32_t N, uint32_t W5, uint32_t P, uint32_t nroots, float* C, hipStream_t s)
 {
-  hipLaunchKernelGGL(k_pss_corr, dim3((W5 + SYNC_TILE - 1) / SYNC_TILE), dim3(SYNC_TILE), 0, s, x, p, N, W5, P, nroots, C);
+  LSN_LAUNCH(k_pss_corr, dim3((W5 + SYNC_TILE - 1) / SYNC_TILE), dim3(SYNC_TILE), 0, s, x, p, N, W5, P, nroots, C);
 }
 void lsn_launch_sync_fin(const cf32* x, const cf32* p, const cf32* w, const cf32* d, const int8_t* sss, uint32_t N, uint32_t W5, uint32_t P, uint32_t bn,
                          uint32_t cp, void* out, hipStream_t s)
 {
-  hipLaunchKernelGGL(k_sync_fin, dim3(1), dim3(512), 0, s, x, p, w, d, sss, N, W5, P, bn, cp, (LsnSyncFin*)out);
+  LSN_LAUNCH(k_sync_fin, dim3(1), dim3(512), 0, s, x, p, w, d, sss, N, W5, P, bn, cp, (LsnSyncFin*)out);
 }

@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void k_ul_fft(LsnCellDev c, const cf32* __rest
 
 void lsn_launch_ul_fft(const LsnCellDev& c, const cf32* iq, uint32_t nant, uint32_t ant, cf32* grid, uint32_t nsf, hipStream_t s)
 {
-  hipLaunchKernelGGL(k_ul_fft, dim3(nsf * 14), dim3(256), sizeof(cf32) * (c.N + c.N / 2), s, c, iq, nant, ant, grid);
+  LSN_LAUNCH(k_ul_fft, dim3(nsf * 14), dim3(256), sizeof(cf32) * (c.N + c.N / 2), s, c, iq, nant, ant, grid);
 }
 
 // ------------------------------------------------------------------------------------------------ DMRS estimate
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void k_pusch_chest(LsnCellDev c, const LsnUlGr
 
 void lsn_launch_pusch_chest(const LsnCellDev& c, const LsnUlGrantDev* g, const cf32* grid, cf32* hs, float* stat, uint32_t ngrants, hipStream_t s)
 {
-  hipLaunchKernelGGL(k_pusch_chest, dim3(ngrants), dim3(256), sizeof(cf32) * 2 * 1200 + sizeof(float) * 512, s, c, g, grid, hs, stat);
+  LSN_LAUNCH(k_pusch_chest, dim3(ngrants), dim3(256), sizeof(cf32) * 2 * 1200 + sizeof(float) * 512, s, c, g, grid, hs, stat);
 }
 
 // ------------------------------------------------------------------------------------------------ equalise + IDFT + demod
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256) void k_pusch_demod(LsnCellDev c, const LsnUlGr
 void lsn_launch_pusch_demod(const LsnCellDev& c, const LsnUlGrantDev* g, const cf32* grid, const cf32* hs, const float* stat, int16_t* llr,
                             uint32_t ngrants, hipStream_t s)
 {
-  hipLaunchKernelGGL(k_pusch_demod, dim3(12, ngrants), dim3(256), sizeof(cf32) * 3 * 1200, s, c, g, grid, hs, stat, llr);
+  LSN_LAUNCH(k_pusch_demod, dim3(12, ngrants), dim3(256), sizeof(cf32) * 3 * 1200, s, c, g, grid, hs, stat, llr);
 }
 
 // ------------------------------------------------------------------------------------------------ PRACH detection
@@ -345,7 +345,7 @@ void lsn_launch_prach(const cf32* iq, const uint64_t* occ_off, uint32_t nocc, co
                       int nroots, int ncs, int nwin, cf32* Y, float* corr, float* out, hipStream_t s)
 {
   if (!nocc) return;
-  hipLaunchKernelGGL(k_prach_bins, dim3(LSN_NZC, nocc), dim3(256), 0, s, iq, occ_off, W, N12, Ncp, b0, Y);
-  hipLaunchKernelGGL(k_prach_corr, dim3(LSN_NZC, nroots, nocc), dim3(256), 0, s, Y, D, V, nroots, corr);
-  hipLaunchKernelGGL(k_prach_peaks, dim3(nroots, nocc), dim3(256), 0, s, corr, nroots, ncs, nwin, out);
+  LSN_LAUNCH(k_prach_bins, dim3(LSN_NZC, nocc), dim3(256), 0, s, iq, occ_off, W, N12, Ncp, b0, Y);
+  LSN_LAUNCH(k_prach_corr, dim3(LSN_NZC, nroots, nocc), dim3(256), 0, s, Y, D, V, nroots, corr);
+  LSN_LAUNCH(k_prach_peaks, dim3(nroots, nocc), dim3(256), 0, s, corr, nroots, ncs, nwin, out);
 }

@@ -38,66 +38,39 @@ def reduce_max_sum(value, count, device=None):
     return float(t.item()), float(c.item())
 
 
-class DescriptorExchange:
-    """The exchange step one capture spread over several RANK PROCESSES really has (SURVEY.md 8e "Collective"): the stateless DSP of a chunk of
-    subframes runs on the rank that owns the chunk, the sequential FALCON search runs on ONE rank (`search_rank`).  Per chunk:
+WORK_FIELDS = ("seed", "cell_id", "first_subframe", "nof_subframes")
 
-        owner --- candidate table + CCE powers + (cfi, snr) per subframe --->  search rank        (`tables_up`)
-        owner <-- accepted-DCI descriptors of the chunk (6 words per DCI) ---  search rank        (`grants_down`)
 
-    KB-scale messages, latency- not bandwidth-bound: one message per chunk and direction.  Built on torch.distributed point-to-point calls -
-    ncclSend / ncclRecv over xGMI with the nccl (= RCCL) backend (tensors on `device`), TCP under gloo (the CPU test,
-    tests/test_dist_exchange.py).  A chunk owned by the search rank itself never touches the network.  The single-process multi-GPU mode
-    (lsn_phy_create_multi) makes the same hand-off through pinned host memory."""
+def scatter_work(items=None, device=None, src=0):
+    """The one exchange step of the multi-process path (SURVEY.md 8e / BASELINE north_star: "RCCL over xGMI only for the work-queue scatter"):
+    rank `src` owns the work queue - one descriptor per rank, WORK_FIELDS as int64 (which synthetic cell / capture the rank replays and which
+    subframe range of it) - and scatters it; every rank returns ITS descriptor as a dict.  dist.scatter on `device` tensors = ncclScatter-style
+    send/recv over xGMI under the nccl (= RCCL) backend, TCP under gloo (tests/test_dist_gloo.py).  Not initialised: items[0].
+    One capture spread over the GPUs of a node does NOT go through rank processes at all: lsn_phy_create_multi runs the engines of all devices in
+    one process around one sequential search and hands chunks over through pinned host memory - the per-chunk descriptor
+    exchange between rank processes that rounds 2-4 carried as an unused interface was removed in round 5."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return dict(zip(WORK_FIELDS, (int(v) for v in items[0])))
+    rank, world = dist.get_rank(), dist.get_world_size()
+    out = torch.zeros(len(WORK_FIELDS), dtype=torch.int64, device=device)
+    if rank == src:
+        assert items is not None and len(items) == world, "one work descriptor per rank"
+        parts = [torch.tensor([int(v) for v in it], dtype=torch.int64, device=device) for it in items]
+        dist.scatter(out, parts, src=src)
+    else:
+        dist.scatter(out, None, src=src)
+    return dict(zip(WORK_FIELDS, (int(v) for v in out.cpu().tolist())))
 
-    def __init__(self, search_rank=0, device=None):
-        import torch
-        import torch.distributed as dist
-        self.torch, self.dist = torch, dist
-        self.rank, self.world = dist.get_rank(), dist.get_world_size()
-        self.search_rank = search_rank
-        self.device = device
 
-    @staticmethod
-    def owner_of(chunk, world):
-        """chunks go round-robin to the ranks (contiguous chunks of >= 64 subframes amortise the launches)"""
-        return chunk % world
-
-    def _send(self, arr, dst):
-        t = self.torch.from_numpy(arr.view("uint8").reshape(-1))
-        if self.device is not None:
-            t = t.to(self.device)
-        n = self.torch.tensor([t.numel()], dtype=self.torch.int64, device=self.device)
-        self.dist.send(n, dst)
-        self.dist.send(t, dst)
-
-    def _recv(self, src):
-        n = self.torch.zeros(1, dtype=self.torch.int64, device=self.device)
-        self.dist.recv(n, src)
-        t = self.torch.empty(int(n.item()), dtype=self.torch.uint8, device=self.device)
-        self.dist.recv(t, src)
-        return t.cpu().numpy()
-
-    def tables_up(self, chunk, payload=None):
-        """owner: payload = bytes-like numpy array of the chunk's stage-A results -> returns it on the search rank, None elsewhere"""
-        owner = self.owner_of(chunk, self.world)
-        if owner == self.search_rank:
-            return payload if self.rank == owner else None
-        if self.rank == owner:
-            self._send(payload, self.search_rank)
-            return None
-        if self.rank == self.search_rank:
-            return self._recv(owner)
-        return None
-
-    def grants_down(self, chunk, payload=None):
-        """search rank: payload = the chunk's accepted-DCI descriptors -> returns them on the chunk's owner, None elsewhere"""
-        owner = self.owner_of(chunk, self.world)
-        if owner == self.search_rank:
-            return payload if self.rank == owner else None
-        if self.rank == self.search_rank:
-            self._send(payload, owner)
-            return None
-        if self.rank == owner:
-            return self._recv(self.search_rank)
-        return None
+def gather_flags(flag, device=None):
+    """every rank contributes one small integer (e.g. "my cell's head equals the live oracle's": 1 / 0 / -1 = not checked) -> list over ranks, on every rank"""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return [int(flag)]
+    t = torch.tensor([int(flag)], dtype=torch.int64, device=device)
+    outs = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(outs, t)
+    return [int(o.item()) for o in outs]

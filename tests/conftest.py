@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# host-program configuration of the HIP runtime, read at its initialisation (= before the first HIP call of the test process): the engine's
+# twelve decode chains are tuned for sixteen hardware queues; an exported value wins
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:

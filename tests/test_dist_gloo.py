@@ -17,7 +17,11 @@ def _worker(rank, world, port, q):
     from lsn_testlib import OracleWorker, TxGen, parse_pcap, scenario
     dist.init_process_group("gloo", rank=rank, world_size=world)
     assert ld.env_rank_world() == (rank, world, rank)
-    wl = ld.rank_workload("small", rank)
+    # the work queue lives on rank 0 and is scattered (bench.py --gpus N does exactly this over RCCL)
+    work = ld.scatter_work([tuple(ld.rank_workload("small", r).values()) + (0, 12) for r in range(world)] if rank == 0 else None)
+    assert work["first_subframe"] == 0 and work["nof_subframes"] == 12
+    wl = dict(seed=work["seed"], cell_id=work["cell_id"])
+    assert wl == ld.rank_workload("small", rank)
     sc = scenario("small", **wl)
     tx = TxGen(**sc)
     ow = OracleWorker(sc["nof_prb"], sc["nof_ports"], sc["cell_id"], sc["nof_rx"])
@@ -28,6 +32,8 @@ def _worker(rank, world, port, q):
     nrec = len(parse_pcap(ow.pcap_bytes()))
     dist.barrier()
     tmax, total = ld.reduce_max_sum(1.0 + rank, n)
+    flags = ld.gather_flags(1 if nrec > 0 else 0)   # per-rank parity verdicts travel to every rank
+    assert flags == [1] * world
     q.put((rank, wl["cell_id"], nrec, tmax, total, ld.shard_ranges(95, world)))
     dist.barrier()
     dist.destroy_process_group()

@@ -36,6 +36,16 @@ def _stream(devices, sc, tti0, iq, batch, cuts):
     return recs, stats, tracked
 
 
+def _device_sets():
+    """two and three engines: on the GPUs that are there (a multi-GPU node runs them on DIFFERENT devices - peer copies of the blocks, function
+    attributes per device, one HIP context each), all on device 0 on a one-GPU box"""
+    import torch
+    n = torch.cuda.device_count()
+    if n < 2:
+        return [[0, 0], [0, 0, 0]]
+    return [[0, 1], list(range(min(n, 3))) if n >= 3 else [0, 1, 0]]
+
+
 def test_two_and_three_engines_reproduce_the_single_engine_stream():
     sc = scenario("cfg3", seed=88, n_rnti=60)
     nsf = 200
@@ -44,7 +54,7 @@ def test_two_and_three_engines_reproduce_the_single_engine_stream():
     cuts = [0, 37, 150, nsf]
     one = _stream(None, sc, tti0, iq, 16, cuts)
     assert one[0] == oracle_records(orecs) and len(orecs) > 1000
-    for devs in ([0, 0], [0, 0, 0]):
+    for devs in _device_sets():
         got = _stream(devs, sc, tti0, iq, 16, cuts)
         assert got[0] == one[0], devs
         assert got[1] == one[1] and got[2] == one[2] == ow.nof_tracked(), devs
@@ -59,7 +69,8 @@ def test_peer_copy_staging_path():
             "from test_gpu_multi import _stream\n"
             "sc = scenario('cfg2', seed=89)\n"
             "tti0, iq, _ = gen_subframes(sc, 120)\n"
-            "a = _stream(None, sc, tti0, iq, 10, [0, 55, 120]); b = _stream([0, 0], sc, tti0, iq, 10, [0, 55, 120])\n"
+            "from test_gpu_multi import _device_sets\n"
+            "a = _stream(None, sc, tti0, iq, 10, [0, 55, 120]); b = _stream(_device_sets()[0], sc, tti0, iq, 10, [0, 55, 120])\n"
             "assert a == b and len(a[0]) > 300, (len(a[0]), len(b[0]))\n"
             "print('OK', len(a[0]))\n") % (ROOT, os.path.join(ROOT, "tests"))
     env = dict(os.environ, LSN_FORCE_PEER_COPY="1")
@@ -86,7 +97,7 @@ def test_ul_mode_over_two_engines_equals_one_engine_and_the_oracle():
     assert len([r for r in parse_pcap(ow.pcap_bytes()) if r["direction"] == 0]) >= 10
     d = torch.from_numpy(iq.view(np.float32)).to("cuda:0")
     got = {}
-    for devs in (None, [0, 0], [0, 0, 0]):
+    for devs in [None] + _device_sets():
         phy = la.Phy(nof_rx_antennas=2, sniffer_mode=1, max_batch=8, pcapwriter=la.PcapWriter(None), devices=devs)
         assert phy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"]) and phy.getUlConfig() is None
         phy.process_device(d.data_ptr(), nsf, tti0, 25, torch.cuda.current_stream().cuda_stream)

@@ -107,3 +107,23 @@ def test_live_mode_pool_is_lossy_but_ordered(head):
     phy.joinPending()
     assert 0 < queued <= 200 and w.nof_records() > 0
     phy.close()
+
+
+def test_twenty_fresh_engines_write_the_oracles_first_blocks(head):
+    """The race rounds 1-4 carried (an asynchronous hipMemset of the chunk buffers in setCell that the engine's non-blocking streams never waited
+    for wiped the first subframes' results of a FRESH engine in 1 of 40 runs, found by chance) shows only on the first chunks of a new engine
+    with every hardware queue in use: twenty engines in a row, each created, fed the first 400 subframes as two pipelined submits the moment
+    setCell returns, checked block by block against the oracle, and destroyed (round-4 review, next-round item 8)."""
+    import torch
+    g, sc, blk, meta, tti0, iq = head
+    d = torch.from_numpy(iq[:400].view(np.float32)).to("cuda:0")
+    torch.cuda.synchronize()
+    for k in range(20):
+        phy, w = _phy(sc, max_batch=100)
+        w.set_digest_blocks(blk, tti0)
+        phy.submit_device(d.data_ptr(), 200, tti0 % 10240, meta)
+        phy.submit_device(d.data_ptr() + 200 * iq[0].nbytes, 200, (tti0 + 200) % 10240, meta)
+        phy.wait()
+        b = w.block_digests()[:2]
+        assert [["%016x" % x, c] for x, c in b] == g["blocks"][:2], "fresh engine %d: first blocks differ from the oracle's" % k
+        phy.close()

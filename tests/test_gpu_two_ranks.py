@@ -29,3 +29,6 @@ def test_bench_spawns_two_product_ranks():
     # cold-state blocks must equal its blocks; pcap_diff (which describes the timed region) stays null
     assert j["parity"]["warmup_equals_live_oracle_blocks"] is True and j["parity"]["oracle_subframes"] == 400 and j["pcap_diff"] is None
     assert j["cpu_baseline"]["value"] > 0
+    # rank 1 replays its own cell: the head of its cold-state stream is checked against the oracle run live in ITS process, the verdict travels to rank 0
+    assert j["parity"]["other_ranks_head_equals_live_oracle"] == [1]
+    assert len(j["host"]["cores_busy_per_rank"]) == 2 and all(c > 0 for c in j["host"]["cores_busy_per_rank"])
