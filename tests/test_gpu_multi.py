@@ -104,4 +104,5 @@ def test_ul_mode_over_two_engines_equals_one_engine_and_the_oracle():
         got[str(devs)] = (gpu_records(phy), phy.getUlConfig())
         phy.close()
     assert got["None"][0] == orecs and got["None"][1] == ow.ul_config()
-    assert got["[0, 0]"] == got["None"] and got["[0, 0, 0]"] == got["None"]
+    for devs in _device_sets():
+        assert got[str(devs)] == got["None"], devs
