@@ -462,6 +462,7 @@ int Engine::newJob(Chunk& ch, uint32_t sf, const DlEntry& e, int table, float p_
 {
   DecodeJob j;
   j.sf = sf; j.rnti = e.rnti; j.kind = (uint8_t)kind;
+  j.risky = kind == 2;  // the speculative second-table attempt
   // pdsch_cfg->p_a: DL mode looks the UE's p-a up before every decode (DL_Sniffer_PDSCH.cc:926-927); the UL-mode decoders never set
   // it and run with the -3 dB of SubframeWorker::set_pdsch_uecfg (SubframeWorker.cc:370)
   j.p_a = cfg.sniffer_mode == 1 ? -3.0f : p_a;
@@ -514,6 +515,7 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
   size_t pay_n = pay0;
   struct TbRef { int job, tb; uint32_t cb_first, cb_count; };
   std::vector<TbRef> tbrefs;
+  std::vector<uint8_t> cb_risky;   // per code block of r.h_cbs: its job is a table guess (DecodeJob::risky)
   std::vector<int> jid_of_hjob;
   for (int jid : todo) {
     DecodeJob& j = ch.jobs[jid];
@@ -576,6 +578,7 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
         wp += cb.out_bytes;
         rp += E;
         r.h_cbs.push_back(cb);
+        cb_risky.push_back(j.risky ? 1 : 0);
       }
       j.cb_count[i] = (uint32_t)s.C;
       pay_n += (wp + 15) & ~15u;
@@ -624,9 +627,13 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
       order.resize(ncb);
       for (uint32_t i = 0; i < ncb; i++) { r.h_cbs[i].res_idx = i; order[i] = i; }
       // two phases: first every block that nothing depends on having passed (block 0 of each transport block), then the dependants
+      // LSN_RISKY_FIRST=1 (round 5): blocks of attempts that may well be hopeless (a table guess for a UE whose table is not known: 12 iterations when the
+      // guess is wrong) go to the front of their phase - their 12 iterations then run UNDER the short blocks of the launch instead of behind them
+      static const bool risky_first = getenv("LSN_RISKY_FIRST") && atoi(getenv("LSN_RISKY_FIRST"));
       std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
         const bool dx = r.h_cbs[x].dep != LSN_CB_NODEP, dy = r.h_cbs[y].dep != LSN_CB_NODEP;
         if (dx != dy) return dy;
+        if (risky_first && cb_risky[x] != cb_risky[y]) return cb_risky[x] > cb_risky[y];
         const uint32_t kx = r.h_cbs[x].K, ky = r.h_cbs[y].K;
         const bool bx = two_wave((int)kx), by = two_wave((int)ky);
         if (bx != by) return bx;
@@ -645,21 +652,23 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
       up.add(r.d_cbs, r.h_cbs_pinned, ncb * sizeof(LsnCbDev));
     }
     const bool tk = timing_period && (r.launches++ % timing_period) == 0;   // prep / demod / rm: timed on a sample of the launches; the decoders on every launch
-    if (separate_upload) lsn_launch_copy_multi(up, false, st);
-    if (tk) HIP_CHECK(hipEventRecord(r.ev[0], st));  // (no clear of the LLR arena: k_pdsch_demod writes every soft bit of every codeword it is given, zeros of unpaired SFBC REs included)
-    if (separate_upload) lsn_launch_pdsch_prep(cd, r.d_jobs, r.d_prefix, njobs, st);
-    else lsn_launch_pdsch_prep_up(cd, r.h_jobs_pinned, r.d_jobs, njobs, up, r.d_prefix, st);   // descriptors up + prefix tables in one launch
-    if (tk) HIP_CHECK(hipEventRecord(r.ev[1], st));
-    lsn_launch_pdsch_demod(cd, r.d_jobs, r.d_items, nitems, r.d_prefix, ch.d_grid, ch.d_ce, ch.d_chest, r.d_llr16, st);
-    if (tk) HIP_CHECK(hipEventRecord(r.ev[2], st));
+    hipStream_t sl = r.stream_light ? r.stream_light : st;   // the light kernels of the chain (JobRunner::stream_light)
+    if (separate_upload) lsn_launch_copy_multi(up, false, sl);
+    if (tk) HIP_CHECK(hipEventRecord(r.ev[0], sl));  // (no clear of the LLR arena: k_pdsch_demod writes every soft bit of every codeword it is given, zeros of unpaired SFBC REs included)
+    if (separate_upload) lsn_launch_pdsch_prep(cd, r.d_jobs, r.d_prefix, njobs, sl);
+    else lsn_launch_pdsch_prep_up(cd, r.h_jobs_pinned, r.d_jobs, njobs, up, r.d_prefix, sl);   // descriptors up + prefix tables in one launch
+    if (tk) HIP_CHECK(hipEventRecord(r.ev[1], sl));
+    lsn_launch_pdsch_demod(cd, r.d_jobs, r.d_items, nitems, r.d_prefix, ch.d_grid, ch.d_ce, ch.d_chest, r.d_llr16, sl);
+    if (tk) HIP_CHECK(hipEventRecord(r.ev[2], sl));
     if (ncb) {
       // LSN_TURBO_SINGLE_LAUNCH=1 (experiment, measured neutral: 192.4 k against 192.3 k subframes/s): ONE decoder launch per wave, the dependants sit
       // behind the first code blocks in the grid and wait for their verdict on the device.  Only with every block in one class: a dependant must never
       // wait for a block of a launch behind its own.  Default: the dependants get a launch of their own (few blocks, short).
       static const bool single_launch = getenv("LSN_TURBO_SINGLE_LAUNCH") != nullptr;
       const bool single = single_launch && n64p[0] == 0 && n64p[1] == 0;
-      lsn_launch_rm(r.d_cbs, r.d_llr16, r.d_spp, ncb, emax, st, single ? r.d_cbstate : nullptr);
-      if (timing_period) HIP_CHECK(hipEventRecord(r.ev[5], st));
+      lsn_launch_rm(r.d_cbs, r.d_llr16, r.d_spp, ncb, emax, sl, single ? r.d_cbstate : nullptr);
+      if (timing_period) HIP_CHECK(hipEventRecord(r.ev[5], sl));
+      if (sl != st) { HIP_CHECK(hipEventRecord(r.ev_light, sl)); HIP_CHECK(hipStreamWaitEvent(st, r.ev_light, 0)); }
       if (single) {
         lsn_launch_turbo(cd, r.d_cbs, r.d_spp, r.d_payload, r.d_cbres, n128p[0] + n128p[1], kmax128, 0, kmax64, st, timing_period ? r.ev[4] : nullptr, r.d_cbstate);
         n128p[0] += n128p[1]; n128p[1] = 0;   // (the timing code below: one launch)
@@ -897,7 +906,10 @@ void Engine::planJobs(Chunk& ch, JobRunner& r)
         if (seen[k].second >= SharedSeq::HINT_EVENTS) { deferred.push_back({sf, di, false}); continue; }
         seen[k].second++;
       }
-      if (e.job[first] < 0) e.job[first] = newJob(ch, sf, e, first, predictedPa(e.rnti));  // as of now; commit checks it
+      if (e.job[first] < 0) {
+        e.job[first] = newJob(ch, sf, e, first, predictedPa(e.rnti));  // as of now; commit checks it
+        if (e.job[first] >= 0 && table >= TABLE_UNKNOWN && e.format > FORMAT1A) ch.jobs[e.job[first]].risky = true;
+      }
       if (e.job[first] >= 0) wave.push_back(e.job[first]);
       if (e.job[first] >= 0 && e.job[1 - first] < 0 && e.ok64 && e.ok256 && same_decode(e.grant64, e.grant256)) e.job[1 - first] = e.job[first];
       // the 256QAM-table attempt: the reference makes it when both TBs failed with the 64QAM table.  A DCI of a format that can teach the

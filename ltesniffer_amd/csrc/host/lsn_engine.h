@@ -26,6 +26,7 @@ struct DecodeJob {
   uint32_t sf = 0; PdschGrant grant; uint16_t rnti = 0;
   float p_a = 0.0f;  // pdsch_cfg->p_a this decode runs with (dB)
   bool planned = false, done = false;
+  bool risky = false;  // a table guess for a UE whose MCS table is unknown: hopeless (12 iterations per first block) when the guess is wrong
   uint8_t kind = 0, used = 0;  // lsn_perf_t::jobs_by_kind; used: the commit stage looked at the result
   uint32_t cb_first = 0, cb_count[2] = {0, 0};
   uint32_t payload_off[2] = {0, 0};
@@ -100,6 +101,11 @@ struct Chunk {
 // one stream + its device/host arenas for PDSCH decode launches
 struct JobRunner {
   hipStream_t stream = nullptr;
+  // LSN_LIGHT_STREAM=1 (round 5): the short, memory-bound kernels of a decode chain (descriptor upload + prefix tables, demodulation, rate de-matching)
+  // on a stream of their own at NORMAL priority, the turbo decoder behind them on `stream` at the lowest: when a resident decoder workgroup leaves, the
+  // dispatcher hands its wave slots and LDS to the queued light kernels of the other chains before the next decoder workgroup of a running launch
+  hipStream_t stream_light = nullptr;
+  hipEvent_t ev_light = nullptr;
   LsnGrantDev* d_jobs = nullptr; size_t jobs_cap = 0;
   LsnCbDev* d_cbs = nullptr; size_t cbs_cap = 0;
   uint32_t* d_cbstate = nullptr; size_t cbstate_cap = 0;   // single-launch decoder: 0 = not decoded yet, 1 = failed, 2 = passed, by LsnCbDev::res_idx
@@ -239,7 +245,7 @@ public:
   void forceMetaUpdateNext() { force_meta_next = true; }
 
 private:
-  static constexpr int NDEC = 12;            // max decode threads (each: plan + stage-C launches of one chunk; commits stay in order)
+  static constexpr int NDEC = 16;            // max decode threads (each: plan + stage-C launches of one chunk; commits stay in order)
   static constexpr int NSLOTS = NDEC + 8;
   int ndec = 12, nslots = 20;                 // in use (LSN_DECODE_THREADS; 8 until round 4: 12 threads on 16 hardware queues measured + 3 %)
   void createCopyStream();

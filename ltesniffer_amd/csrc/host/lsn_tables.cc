@@ -94,6 +94,8 @@ void Engine::freeRunner(JobRunner& r)
     if (e) { (void)hipEventDestroy(e); e = nullptr; }
   if (r.ev_done) { (void)hipEventDestroy(r.ev_done); r.ev_done = nullptr; }
   if (r.stream) { (void)hipStreamDestroy(r.stream); r.stream = nullptr; }
+  if (r.stream_light) { (void)hipStreamDestroy(r.stream_light); r.stream_light = nullptr; }
+  if (r.ev_light) { (void)hipEventDestroy(r.ev_light); r.ev_light = nullptr; }
 }
 
 void Engine::allocRunner(JobRunner& r)
@@ -119,6 +121,15 @@ void Engine::allocRunner(JobRunner& r)
       HIP_CHECK(hipStreamCreateWithPriority(&r.stream, hipStreamNonBlocking, lo));
   }
   for (auto& e : r.ev) HIP_CHECK(hipEventCreate(&e));
+  {
+    bool bulk_ = false;
+    for (int i = 0; i < NDEC; i++) bulk_ = bulk_ || &r == &runner_c[i];
+    const char* ls = getenv("LSN_LIGHT_STREAM");
+    if (bulk_ && ls && atoi(ls)) {
+      HIP_CHECK(hipStreamCreateWithPriority(&r.stream_light, hipStreamNonBlocking, atoi(ls) >= 2 ? hi : (lo + hi) / 2));  // 1: normal, 2: highest
+      HIP_CHECK(hipEventCreateWithFlags(&r.ev_light, hipEventDisableTiming));
+    }
+  }
   HIP_CHECK(hipEventCreateWithFlags(&r.ev_done, hipEventDisableTiming));  // waited for with Engine's poll-and-sleep waitEvent()
   // The arenas of a bulk decode runner start at the size a full chunk of a loaded cell needs (per subframe at 100 PRB: 16 decode calls, 32 code
   // blocks, 0.5 M soft bits, 128 K packed words, 24 KB of payload), scaled with the bandwidth: a fresh engine otherwise grows each of them several

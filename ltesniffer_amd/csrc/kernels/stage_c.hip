@@ -624,11 +624,16 @@ static size_t turbo_lds_bytes_nt(uint32_t kmax, int) { return lsn_turbo_lds_byte
 void lsn_launch_turbo(const LsnCellDev& c, const LsnCbDev* cb, const uint32_t* spp, uint8_t* payload, LsnCbRes* res, uint32_t n128, uint32_t kmax128,
                       uint32_t n64, uint32_t kmax64, hipStream_t s, hipEvent_t between, uint32_t* state)
 {
+  // LSN_TURBO_MIN_LDS=<bytes> (round 5 experiment): a two-wavefront launch asks for at least this much LDS per workgroup, i.e. FEWER decoder workgroups
+  // per CU (54 000: three instead of four) - what they leave (40 KB of LDS, the registers of two SIMD lanes' second wave) keeps the memory-bound kernels
+  // of the other chains resident next to the decoders instead of queueing behind them
+  static const size_t min_lds = getenv("LSN_TURBO_MIN_LDS") ? std::min<size_t>((size_t)atol(getenv("LSN_TURBO_MIN_LDS")), 160u * 1024u) : 0;
   static std::atomic<uint64_t> attr64{0}, attr128{0};
   lsn_func_max_lds((const void*)k_turbo<64>, (int)turbo_lds_bytes_nt(6144, 64), attr64, "k_turbo<64>");
-  lsn_func_max_lds((const void*)k_turbo<128>, (int)turbo_lds_bytes_nt(6144, 128), attr128, "k_turbo<128>");
+  lsn_func_max_lds((const void*)k_turbo<128>, (int)std::max(turbo_lds_bytes_nt(6144, 128), min_lds), attr128, "k_turbo<128>");
   auto fix = [](uint32_t k) { return ((k < 512 ? 512u : k) + 7u) & ~7u; };  // the scratch in the check-point area needs room
-  if (n128) LSN_LAUNCH(k_turbo<128>, dim3(n128), dim3(128), turbo_lds_bytes_nt(fix(kmax128), 128), s, c.crc_tab_a, c.crc_tab_b, c.turbo_il, cb, spp, payload, res, fix(kmax128), state);
+  const size_t lds128 = std::max(turbo_lds_bytes_nt(fix(kmax128), 128), min_lds);
+  if (n128) LSN_LAUNCH(k_turbo<128>, dim3(n128), dim3(128), lds128, s, c.crc_tab_a, c.crc_tab_b, c.turbo_il, cb, spp, payload, res, fix(kmax128), state);
   if (between) (void)hipEventRecord(between, s);
   if (n64) LSN_LAUNCH(k_turbo<64>, dim3(n64), dim3(64), turbo_lds_bytes_nt(fix(kmax64), 64), s, c.crc_tab_a, c.crc_tab_b, c.turbo_il, cb + n128, spp, payload, res, fix(kmax64), state);
 }
