@@ -147,6 +147,8 @@ def main():
                     help="N > 1: 'cells' = one synthetic cell per rank (weak scaling, the default and what BASELINE configs[4] asks for); 'capture' = ONE capture "
                          "whose chunks go round-robin to the N GPUs (lsn_phy_create_multi on rank 0; the other ranks only hold their GPU) - strong scaling, "
                          "bounded by the sequential FALCON search on one host thread")
+    ap.add_argument("--workload", default="", help="a downlink leg of tools/bench_legs.py (e.g. cfg3_at_16_dB_snr) as the TIMED stream instead of the headline capture - its capture, "
+                    "its cached oracle stream, the same gate: how the second operating point is profiled (tools/gpu_profile.sh) with its own roofline figures; never the driver's line")
     ap.add_argument("--no-legs", action="store_true", help="skip the PCIe-inclusive legs (host buffers, capture file, worker pool) and the other configs")
     ap.add_argument("--leg-batch", type=int, default=0, help="pipeline chunk of the first-H2D-to-last-PDU legs (0 = --batch)")
     ap.add_argument("--gen-threads", type=int, default=0, help="threads of the synthetic transmitter (0 = the CPUs this process may use, at most 32)")
@@ -205,8 +207,13 @@ def main():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from make_cfg3_golden import BLOCK, META_PERIOD, NSF, capture_hash
 
-    gated_cfg = args.config == "cfg3" and args.nsf in (0, NSF)
-    nsf = NSF if gated_cfg else max(BLOCK, (args.nsf or NSF) // BLOCK * BLOCK)
+    wl_leg = None
+    if args.workload:
+        import bench_legs as bl_
+        wl_leg = bl_.LEGS[args.workload]
+        assert wl_leg["kind"] == "dl" and world == 1, "--workload: a downlink leg on one GPU"
+    gated_cfg = (args.config == "cfg3" and args.nsf in (0, NSF)) or wl_leg is not None
+    nsf = wl_leg["nsf"] if wl_leg else (NSF if gated_cfg else max(BLOCK, (args.nsf or NSF) // BLOCK * BLOCK))
     S = max(BLOCK, min(args.step_sf, nsf) // BLOCK * BLOCK)
     while nsf % S:
         S -= BLOCK  # a step never straddles the wrap of the capture
@@ -215,7 +222,7 @@ def main():
     # scattered - over RCCL / xGMI under the nccl backend: the path's only exchange step besides the timing reductions (BASELINE north_star)
     rdev_ = dev if world > 1 and dist.get_backend() == "nccl" else None
     work = ld.scatter_work([tuple(ld.rank_workload(args.config, r).values()) + (0, nsf) for r in range(world)] if rank == 0 else None, rdev_)
-    sc = scenario(args.config, seed=work["seed"], cell_id=work["cell_id"])
+    sc = scenario(args.config, seed=work["seed"], cell_id=work["cell_id"]) if wl_leg is None else bl_.leg_scenario(args.workload)
     gen_threads = args.gen_threads or max(1, min(32, int(host_quota // max(1, world)) if host_quota else 8))
     # N ranks share the host's cores: a rank other than 0 (its cell is not the gated stream) renders fewer distinct subframes when it has few
     # transmitter threads - its work per step is unchanged, the block is replayed.  Captures are kept in /dev/shm between the back-to-back runs
@@ -255,7 +262,9 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
 
     golden, golden_note = None, None
-    if rank == 0 and gated_cfg:
+    if rank == 0 and wl_leg is not None:
+        golden, golden_note = bl_.load_golden(args.workload, iq, tti0)
+    elif rank == 0 and gated_cfg:
         try:
             g = json.load(open(GOLDEN))
             chash, _ = capture_hash(iq)
@@ -294,7 +303,7 @@ def main():
     pcap = la.PcapWriter(None)  # native MAC-LTE writer, the reference's pcap-emit surface; the stream is digested per block, not kept
     pcap.set_store(False)
     pcap.set_digest_blocks(BLOCK, tti0)
-    phy = la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=batch, device=local, pcapwriter=pcap, devices=devices)
+    phy = la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=batch, device=local, pcapwriter=pcap, devices=devices, harq_mode=(wl_leg or {}).get("harq_mode", 0))
     assert phy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"])
     stride = sf_bytes
 
@@ -479,7 +488,12 @@ def main():
                 for a in range(0, nsf, 1000):
                     np.ascontiguousarray(np.transpose(iq[a:a + 1000], (0, 2, 1))).tofile(f)
             try:
-                two_passes("file_replay", lambda w: la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=lbatch, device=local, pcapwriter=w),
+                def file_phy(w):   # file mode is known at start-up (the reference parses -i first): the block buffers are reserved with the engine (lsn_phy_prepare_file)
+                    ph = la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=lbatch, device=local, pcapwriter=w)
+                    ph.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"])
+                    ph.prepare_file()
+                    return ph
+                two_passes("file_replay", file_phy,
                            lambda ph, t: ph.process_file(path, start_tti=t, update_meta_period=META_PERIOD),
                            {"storage": "tmpfs (/dev/shm) = page cache; pread threads -> pinned blocks -> PCIe"})
             finally:
@@ -633,7 +647,7 @@ def main():
             "parity_reference": "in-repo CPU oracle, unpinned vs srsRAN", "parity": parity,
             "config": {"workload": "%s: 20 MHz DL (100 PRB, 2 CRS ports, 2 rx), 150 active RNTIs + a fresh RNTI by RAR every 200 subframes, TM2/TM3/TM4 mix up to 256QAM, "
                                    "CFI 3, 8-14 DL + 3-6 UL DCIs per subframe (BASELINE.json configs[2], SURVEY 8d config 3)" % args.config
-                       if args.config == "cfg3" else args.config,
+                       if args.config == "cfg3" and wl_leg is None else (args.workload + ": " + wl_leg["what"] if wl_leg else args.config),
                        "subframes_per_step": S, "distinct_subframes": nsf, "stream": "capture replayed cyclically, TTI and sequential state carried over",
                        "input": "resident in HBM", "steps_pipelined": True, "gpu_batch": batch, "cells": 1 if capture_mode else world, "capture_gen_s": round(t_gen, 1),
                        "parallelism": ("one capture, chunks round-robin over devices %s, shared sequential search" % devices) if capture_mode else "one cell per GPU, no collective"},

@@ -34,7 +34,7 @@ typedef struct {
   uint32_t nof_prb;         /* 6, 15, 25, 50, 75, 100 */
   uint32_t nof_ports;       /* 1, 2 or 4 CRS ports (4: transmit diversity on every channel; spatial-multiplexing grants are found and not decoded, as with the reference's srsRAN) */
   uint32_t id;              /* physical cell id */
-  uint32_t cp;              /* 0 = normal (only value supported) */
+  uint32_t cp;              /* 0 = normal, 1 = extended cyclic prefix (6 symbols per slot; downlink path - an UL_MODE engine refuses it; PBCH / cell search helpers: normal only) */
   uint32_t phich_length;    /* 0 = normal */
   uint32_t phich_resources; /* 0: 1/6, 1: 1/2, 2: 1, 3: 2 (LTESniffer_Core.cc:211-212 forces 1/6) */
   uint32_t frame_type;      /* 0 = FDD */
@@ -247,6 +247,11 @@ typedef struct {
 } lsn_file_cfg_t;
 int lsn_phy_process_file(lsn_phy_t* phy, const char* path, const lsn_file_cfg_t* cfg, uint32_t start_tti, uint64_t max_subframes /* 0 = to the end */,
                          uint32_t update_meta_period, uint64_t* subframes_done);
+/* Reserves the file source's block buffers (page-locked read blocks + device blocks, 4.7 GB at 20 MHz / 2 antennas) ahead of the first replay:
+ * the reference knows at start-up that it replays a file (args.input_file_name, LTESniffer_Core.cc:240-262) - call this behind lsn_phy_set_cell and the
+ * first lsn_phy_process_file does not pay for page-locking 1.5 GB inside the replay.  Optional (lsn_phy_process_file reserves what is missing).
+ * nof_antennas = lsn_file_cfg_t.nof_antennas of the replay. */
+int lsn_phy_prepare_file(lsn_phy_t* phy, uint32_t nof_antennas);
 
 /* ---- security-API sink (the step behind the path: PDSCH_Decoder::run_api_dl_mode, DL_Sniffer_PDSCH.cc:804-879) ----
  * api_mode as ArgManager's -a (ArgManager.cc:63,218): -1 off (default), 0 identity mapping, 2 IMSI catching, 3 all.  For every CRC-ok

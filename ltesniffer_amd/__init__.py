@@ -38,7 +38,7 @@ EXPORTS = ["lsn_phy_create", "lsn_phy_destroy", "lsn_phy_set_cell", "lsn_phy_get
            "lsn_phy_tap_ul", "lsn_phy_set_prach_config", "lsn_phy_prach_detect", "lsn_phy_set_prach_sink", "lsn_prach_tti_opportunity", "lsn_phy_process_file", "lsn_phy_mib_decode", "lsn_phy_mib_decode_llr", "lsn_phy_submit_device", "lsn_phy_wait", "lsn_cell_search",
            "lsn_phy_set_shortcut_discovery", "lsn_phy_get_shortcut_discovery", "lsn_phy_set_histogram_threshold", "lsn_phy_print_stats",
            "lsn_phy_set_mcs_update_interval", "lsn_phy_update_mcs_database", "lsn_phy_nof_tracked_rnti", "lsn_worker_buffers_offset", "lsn_pcap_digest", "lsn_pcap_set_store", "lsn_pcap_set_digest_blocks", "lsn_pcap_block_digests", "lsn_phy_create_multi", "lsn_phy_nof_devices",
-           "lsn_phy_set_stage_c_taps"]
+           "lsn_phy_set_stage_c_taps", "lsn_phy_prepare_file"]
 
 
 def turbo_nwin(K):
@@ -291,6 +291,7 @@ def lib():
         L.lsn_phy_mib_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Mib)]
         L.lsn_phy_mib_decode_llr.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(Mib), C.c_void_p]
         L.lsn_phy_process_file.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(FileCfg), C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64)]
+        L.lsn_phy_prepare_file.argtypes = [C.c_void_p, C.c_uint32]
         L.lsn_phy_set_prach_config.argtypes = [C.c_void_p, C.POINTER(PrachCfg)]
         L.lsn_phy_prach_detect.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_uint32, C.POINTER(PrachDet), C.c_uint32]
         L.lsn_phy_set_prach_sink.argtypes = [C.c_void_p, PRACH_SINK, C.c_void_p]
@@ -441,8 +442,9 @@ class Phy:
         else:
             self.pdus.append((d, data))
 
-    def setCell(self, nof_prb, nof_ports, cell_id, phich_resources=0):
-        self.cell = Cell(nof_prb, nof_ports, cell_id, 0, 0, phich_resources, 0)
+    def setCell(self, nof_prb, nof_ports, cell_id, phich_resources=0, cp=0):
+        """cp: srsran_cell_t.cp - 0 normal, 1 extended cyclic prefix (downlink path)"""
+        self.cell = Cell(nof_prb, nof_ports, cell_id, cp, 0, phich_resources, 0)
         rc = lib().lsn_phy_set_cell(self._h, C.byref(self.cell))
         return rc == LSN_SUCCESS
 
@@ -519,6 +521,10 @@ class Phy:
             _check(r, "mib_decode")
         d = {n: int(getattr(m, n)) for n, _ in Mib._fields_}
         return (d, llr) if with_llr else d
+
+    def prepare_file(self):
+        """reserve the file source's block buffers ahead of the first replay (lsn_phy_prepare_file)"""
+        _check(lib().lsn_phy_prepare_file(self._h, self.nof_rx_antennas), "prepare_file")
 
     def process_file(self, path, start_tti=0, offset_time=0, offset_freq=0.0, max_subframes=0, update_meta_period=0):
         """file mode of the reference (-i file -O offset_time -o offset_freq): replay a cf32 capture (antennas interleaved per sample);

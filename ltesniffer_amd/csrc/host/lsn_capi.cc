@@ -484,6 +484,11 @@ int lsn_phy_process_file(lsn_phy_t* phy, const char* path, const lsn_file_cfg_t*
   if (!phy || !path || !cfg) return LSN_ERROR_INVALID_INPUTS;
   return phy->engine->processFile(path, *cfg, start_tti, max_subframes, update_meta_period, subframes_done);
 }
+int lsn_phy_prepare_file(lsn_phy_t* phy, uint32_t nof_antennas)
+{
+  if (!phy) return LSN_ERROR_INVALID_INPUTS;
+  return phy->engine->reserveFileBuffers(nof_antennas);
+}
 int lsn_phy_set_ul_config(lsn_phy_t* phy, const lsn_ul_cfg_t* cfg)
 {
   if (!phy || !cfg) return LSN_ERROR_INVALID_INPUTS;

@@ -223,7 +223,8 @@ Engine::~Engine()
 int Engine::setCell(const lsn_cell_t& c)
 {
   static const uint32_t ng_x6[4] = {1, 3, 6, 12};
-  if (c.cp != 0 || c.frame_type != 0 || c.phich_length != 0 || c.phich_resources > 3) return LSN_ERROR_INVALID_INPUTS;
+  if (c.cp > 1 || c.frame_type != 0 || c.phich_length != 0 || c.phich_resources > 3) return LSN_ERROR_INVALID_INPUTS;
+  if (c.cp == 1 && cfg.sniffer_mode == 1) return LSN_ERROR_INVALID_INPUTS;  // extended CP: downlink path only (the uplink's 10-symbol PUSCH is not built)
   if ((c.nof_ports != 1 && c.nof_ports != 2 && c.nof_ports != 4) || c.id > 503) return LSN_ERROR_INVALID_INPUTS;
   switch (c.nof_prb) { case 6: case 15: case 25: case 50: case 75: case 100: break; default: return LSN_ERROR_INVALID_INPUTS; }
   cpu_set_t saved_mask;
@@ -233,7 +234,7 @@ int Engine::setCell(const lsn_cell_t& c)
     HIP_CHECK(hipSetDevice(cfg.device));
     (void)hipDeviceSynchronize();
     freeDevice();
-    cell.nof_prb = c.nof_prb; cell.nof_ports = c.nof_ports; cell.id = c.id; cell.phich_ng_x6 = ng_x6[c.phich_resources];
+    cell.nof_prb = c.nof_prb; cell.nof_ports = c.nof_ports; cell.id = c.id; cell.phich_ng_x6 = ng_x6[c.phich_resources]; cell.cp = c.cp;
     buildTables();
     sib2_learned = false;
     if (cfg.sniffer_mode == 1) {
@@ -525,7 +526,7 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
     d.sf = j.sf; d.sf_idx = c.sf_idx; d.l0 = c.cfi + (nprb <= 10 ? 1u : 0u);
     for (int s = 0; s < 2; s++)
       for (uint32_t rb = g.prb_lo; rb <= g.prb_hi && rb < nprb; rb++)
-        if (g.prb_idx[s][rb]) d.prb_mask[s][rb >> 5] |= 1u << (rb & 31);
+        if (g.prb_idx[s][rb]) d.prb_mask[s][rb >> 5] |= 1u << (rb & 31);   // (per slot: the kernels index it with l >= nslot)
     d.nof_re = g.nof_re; d.tx_scheme = (uint32_t)g.tx_scheme; d.pmi = g.pmi; d.nof_layers = g.nof_layers;
     for (int i = 0; i < 2; i++)
       if (g.tb[i].enabled) d.qm[g.tb[i].cw_idx & 1] = (uint32_t)g.tb[i].mod;
@@ -593,19 +594,19 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
     r.h_jobs.push_back(d);
     jid_of_hjob.push_back(jid);
   }
-  // every block in the two-wavefront launch (a block of <= 64 windows sends its second wavefront home at once): ONE decoder launch per phase instead of
-  // two - + 5.7 % subframes/s in A/B pairs, although small blocks now reserve the LDS of the largest one (LSN_TURBO_TWO_CLASSES=1: rounds 2-4)
-  static const bool one_class = getenv("LSN_TURBO_TWO_CLASSES") == nullptr;
-  auto two_wave = [&](int K) { return one_class || lsn_turbo_two_wave_class(K); };
+  // ONE decoder launch per phase (late round 4: + 5.7 % against one launch per wavefront class).  Round 5: the blocks of at most 64 windows - one working
+  // wavefront - share workgroups two by two (k_turbo, stage_c.hip) instead of holding a whole LDS / wavefront slot each with the second wavefront idle:
+  // half of the metric's code blocks, half of the decoder's slot time.  LSN_TURBO_NO_PAIRS=1: every block alone in its workgroup (rounds 2-4).
+  static const bool no_pairs = getenv("LSN_TURBO_NO_PAIRS") && atoi(getenv("LSN_TURBO_NO_PAIRS"));
+  auto pairable = [&](uint32_t K) { return !no_pairs && K <= LSN_TURBO_PAIR_KMAX && lsn_turbo_nwin((int)K) <= 64; };
   const uint32_t njobs = (uint32_t)r.h_jobs.size(), ncb = (uint32_t)r.h_cbs.size();
-  uint32_t kmax128 = 0, kmax64 = 0, emax = 0, n128p[2] = {0, 0}, n64p[2] = {0, 0};
+  uint32_t kmax_solo = 0, kmax_pair = 0, emax = 0, nsolo[2] = {0, 0}, npair[2] = {0, 0};
   size_t spp_n = 0;
   std::vector<uint32_t> order;
   if (njobs) {
     grow_dev(r.d_jobs, r.jobs_cap, njobs, st);
     grow_dev(r.d_cbs, r.cbs_cap, ncb, st);
     grow_dev(r.d_cbres, r.cbres_cap, ncb, st);
-    grow_dev(r.d_cbstate, r.cbstate_cap, ncb, st);
     grow_dev(r.d_prefix, r.prefix_cap, prefix_n, st);
     grow_dev(r.d_llr16, r.llr16_cap, llr_n + 8, st);
     grow_dev(r.d_payload, r.payload_cap, pay_n - pay0 + 16, st);
@@ -623,20 +624,21 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
     std::memcpy(r.h_jobs_pinned, r.h_jobs.data(), njobs * sizeof(LsnGrantDev));
     if (separate_upload) up.add(r.d_jobs, r.h_jobs_pinned, njobs * sizeof(LsnGrantDev));
     if (ncb) {
-      // launch order: two-wavefront blocks first, each class by descending size (longest jobs first)
+      // launch order: per phase the blocks that get a workgroup of their own first, then the blocks that share one; each class by descending size (longest
+      // jobs first; the two blocks of a pair are neighbours in size, so their wavefronts run for about the same time)
       order.resize(ncb);
       for (uint32_t i = 0; i < ncb; i++) { r.h_cbs[i].res_idx = i; order[i] = i; }
       // two phases: first every block that nothing depends on having passed (block 0 of each transport block), then the dependants
-      // LSN_RISKY_FIRST=1 (round 5): blocks of attempts that may well be hopeless (a table guess for a UE whose table is not known: 12 iterations when the
-      // guess is wrong) go to the front of their phase - their 12 iterations then run UNDER the short blocks of the launch instead of behind them
+      // LSN_RISKY_FIRST=1 (round 5, measured neutral): blocks of attempts that may well be hopeless (a table guess for a UE whose table is not known: 12
+      // iterations when the guess is wrong) go to the front of their class - their 12 iterations then run UNDER the short blocks of the launch instead of behind them
       static const bool risky_first = getenv("LSN_RISKY_FIRST") && atoi(getenv("LSN_RISKY_FIRST"));
       std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
         const bool dx = r.h_cbs[x].dep != LSN_CB_NODEP, dy = r.h_cbs[y].dep != LSN_CB_NODEP;
         if (dx != dy) return dy;
-        if (risky_first && cb_risky[x] != cb_risky[y]) return cb_risky[x] > cb_risky[y];
         const uint32_t kx = r.h_cbs[x].K, ky = r.h_cbs[y].K;
-        const bool bx = two_wave((int)kx), by = two_wave((int)ky);
-        if (bx != by) return bx;
+        const bool px = pairable(kx), py = pairable(ky);
+        if (px != py) return py;
+        if (risky_first && cb_risky[x] != cb_risky[y]) return cb_risky[x] > cb_risky[y];
         if (kx != ky) return kx > ky;
         return x < y;
       });
@@ -646,7 +648,7 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
         emax = std::max(emax, q.E);
         r.h_cbs_pinned[i] = q;
         const int ph = q.dep != LSN_CB_NODEP ? 1 : 0;
-        if (two_wave((int)q.K)) { n128p[ph]++; kmax128 = std::max(kmax128, q.K); } else { n64p[ph]++; kmax64 = std::max(kmax64, q.K); }
+        if (pairable(q.K)) { npair[ph]++; kmax_pair = std::max(kmax_pair, q.K); } else { nsolo[ph]++; kmax_solo = std::max(kmax_solo, q.K); }
       }
       grow_dev(r.d_spp, r.spp_cap, spp_n + 16, st);
       up.add(r.d_cbs, r.h_cbs_pinned, ncb * sizeof(LsnCbDev));
@@ -661,25 +663,15 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
     lsn_launch_pdsch_demod(cd, r.d_jobs, r.d_items, nitems, r.d_prefix, ch.d_grid, ch.d_ce, ch.d_chest, r.d_llr16, sl);
     if (tk) HIP_CHECK(hipEventRecord(r.ev[2], sl));
     if (ncb) {
-      // LSN_TURBO_SINGLE_LAUNCH=1 (experiment, measured neutral: 192.4 k against 192.3 k subframes/s): ONE decoder launch per wave, the dependants sit
-      // behind the first code blocks in the grid and wait for their verdict on the device.  Only with every block in one class: a dependant must never
-      // wait for a block of a launch behind its own.  Default: the dependants get a launch of their own (few blocks, short).
-      static const bool single_launch = getenv("LSN_TURBO_SINGLE_LAUNCH") != nullptr;
-      const bool single = single_launch && n64p[0] == 0 && n64p[1] == 0;
-      lsn_launch_rm(r.d_cbs, r.d_llr16, r.d_spp, ncb, emax, sl, single ? r.d_cbstate : nullptr);
+      lsn_launch_rm(r.d_cbs, r.d_llr16, r.d_spp, ncb, emax, sl);
       if (timing_period) HIP_CHECK(hipEventRecord(r.ev[5], sl));
       if (sl != st) { HIP_CHECK(hipEventRecord(r.ev_light, sl)); HIP_CHECK(hipStreamWaitEvent(st, r.ev_light, 0)); }
-      if (single) {
-        lsn_launch_turbo(cd, r.d_cbs, r.d_spp, r.d_payload, r.d_cbres, n128p[0] + n128p[1], kmax128, 0, kmax64, st, timing_period ? r.ev[4] : nullptr, r.d_cbstate);
-        n128p[0] += n128p[1]; n128p[1] = 0;   // (the timing code below: one launch)
-      } else {
-        // phase 0: [128-class | 64-class] of the independent blocks, phase 1: the same of the dependants (descriptor order = launch order)
-        lsn_launch_turbo(cd, r.d_cbs, r.d_spp, r.d_payload, r.d_cbres, n128p[0], kmax128, n64p[0], kmax64, st, timing_period ? r.ev[4] : nullptr);
-        const uint32_t o1 = n128p[0] + n64p[0];
-        if (ncb > o1) {
-          if (timing_period) HIP_CHECK(hipEventRecord(r.ev[8], st));
-          lsn_launch_turbo(cd, r.d_cbs + o1, r.d_spp, r.d_payload, r.d_cbres, n128p[1], kmax128, n64p[1], kmax64, st, timing_period ? r.ev[9] : nullptr);
-        }
+      // phase 0: the independent blocks [solo | paired], phase 1: the same of the dependants (descriptor order = launch order)
+      lsn_launch_turbo_packed(cd, r.d_cbs, r.d_spp, r.d_payload, r.d_cbres, nsolo[0], kmax_solo, npair[0], kmax_pair, st);
+      const uint32_t o1 = nsolo[0] + npair[0];
+      if (ncb > o1) {
+        if (timing_period) HIP_CHECK(hipEventRecord(r.ev[8], st));
+        lsn_launch_turbo_packed(cd, r.d_cbs + o1, r.d_spp, r.d_payload, r.d_cbres, nsolo[1], kmax_solo, npair[1], kmax_pair, st);
       }
       if (timing_period) HIP_CHECK(hipEventRecord(r.ev[3], st));
       {
@@ -723,18 +715,16 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
       if (tk && hipEventElapsedTime(&ms, r.ev[2], r.ev[5]) == hipSuccess) pf.kernel_ms[LSN_K_RM] += ms * scale;
       pf.kernel_launches[LSN_K_RM]++;
       {
-        const bool ph1 = ncb > n128p[0] + n64p[0];
+        const bool ph1 = ncb > nsolo[0] + npair[0];
         auto acc = [&](int k, hipEvent_t a, hipEvent_t b) { if (timing_period && hipEventElapsedTime(&ms, a, b) == hipSuccess) { pf.kernel_ms[k] += ms; pf.kernel_launches[k]++; } };
-        if (n128p[0]) acc(LSN_K_TURBO128, r.ev[5], r.ev[4]);
-        if (n64p[0]) acc(LSN_K_TURBO, r.ev[4], ph1 ? r.ev[8] : r.ev[3]);
-        if (ph1 && n128p[1]) acc(LSN_K_TURBO128, r.ev[8], r.ev[9]);
-        if (ph1 && n64p[1]) acc(LSN_K_TURBO, r.ev[9], r.ev[3]);
+        acc(LSN_K_TURBO128, r.ev[5], ph1 ? r.ev[8] : r.ev[3]);
+        if (ph1) acc(LSN_K_TURBO128, r.ev[8], r.ev[3]);
       }
       // algorithmic bytes of the decoder kernels: every code block reads its K + 12 packed soft words (k_rm's output) and writes its payload
       for (uint32_t i = 0; i < ncb; i++) {
         const uint64_t b = 4ull * (r.h_cbs_pinned[i].K + 12u) + r.h_cbs_pinned[i].out_bytes;
         pf.turbo_algo_bytes += b;
-        if (two_wave((int)r.h_cbs_pinned[i].K)) pf.turbo128_algo_bytes += b;
+        pf.turbo128_algo_bytes += b;   // (every downlink block runs in the two-wavefront instance)
       }
     }
     if (keep_stage_c.load()) {  // parity taps: the arenas are recycled by the next launch of this runner

@@ -108,7 +108,6 @@ struct JobRunner {
   hipEvent_t ev_light = nullptr;
   LsnGrantDev* d_jobs = nullptr; size_t jobs_cap = 0;
   LsnCbDev* d_cbs = nullptr; size_t cbs_cap = 0;
-  uint32_t* d_cbstate = nullptr; size_t cbstate_cap = 0;   // single-launch decoder: 0 = not decoded yet, 1 = failed, 2 = passed, by LsnCbDev::res_idx
   LsnCbRes* d_cbres = nullptr; size_t cbres_cap = 0;
   uint16_t* d_prefix = nullptr; size_t prefix_cap = 0;
   int16_t* d_llr16 = nullptr; size_t llr16_cap = 0;
@@ -214,6 +213,7 @@ public:
   int mibDecode(const void* iq, bool on_device, lsn_mib_t* out, float* llr_raw480);
   int processFile(const char* path, const lsn_file_cfg_t& fc, uint32_t start_tti, uint64_t max_subframes, uint32_t update_meta_period,
                   uint64_t* subframes_done);
+  int reserveFileBuffers(uint32_t nof_antennas);   // lsn_phy_prepare_file: pinned read blocks + device blocks of the file source, ahead of the first replay
   int processHost(const float* iq, uint32_t nsf, uint32_t start_tti, uint32_t update_meta_period);
   void setSink(lsn_pdu_sink_t cb, void* user) { sink = cb; sink_user = user; }
   void setApi(int mode, lsn_api_sink_t cb, void* user, lsn_pdu_sink_t pcap_cb, void* pcap) { api_mode = mode; api_sink = cb; api_user = user; api_pcap_sink = pcap_cb; api_pcap = pcap; }

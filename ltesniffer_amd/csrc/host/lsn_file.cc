@@ -29,6 +29,50 @@
 
 namespace lsn {
 
+// block geometry of the file source: subframes per block (393 MB at 20 MHz / 2 antennas), pread threads per block, blocks in flight (one being
+// read, one crossing PCIe, two in stage A; a slot is free again when stage A has consumed its block)
+static void file_geometry(uint32_t& blk, uint32_t& nrd, int& nslot)
+{
+  blk = 800; nrd = 12; nslot = 4;
+  if (const char* e = getenv("LSN_FILE_BLOCK")) blk = (uint32_t)std::max(1, atoi(e));
+  if (const char* e = getenv("LSN_FILE_READERS")) nrd = (uint32_t)std::max(1, std::min(32, atoi(e)));
+  if (const char* e = getenv("LSN_FILE_SLOTS")) nslot = std::max(3, std::min(8, atoi(e)));
+}
+
+// The pinned read blocks and the device blocks of the file source (4 x 393 MB page-locked + 8 x 393 MB of HBM at 20 MHz / 2 antennas).  Page-locking
+// 1.5 GB takes longer than replaying 10 000 subframes: rounds 2-4 paid it inside the first lsn_phy_process_file call (43.6 k subframes/s on the first
+// pass of a 20 000-subframe capture against 96 k on the second, round-4 review).  A caller that knows it will replay a file - the reference does
+// when it parses -i (LTESniffer_Core.cc:240-262) - reserves them up front with lsn_phy_prepare_file; processFile calls this as well (no-op then).
+int Engine::reserveFileBuffers(uint32_t nof_antennas)
+{
+  if (!cell_set) return LSN_ERROR;
+  if (nof_antennas != cd.iq_nant) return LSN_ERROR_INVALID_INPUTS;
+  uint32_t blk, nrd; int nslot;
+  file_geometry(blk, nrd, nslot);
+  const size_t sf_bytes = (size_t)cd.sflen * nof_antennas * sizeof(cf32);
+  const bool use_mmap = getenv("LSN_FILE_MMAP") && atoi(getenv("LSN_FILE_MMAP")) != 0;
+  try {
+    HIP_CHECK(hipSetDevice(cfg.device));
+    for (int si = 0; si < nslot; si++) {
+      FileBuf& fb = file_buf[si];
+      if (fb.bytes < blk * sf_bytes) {
+        if (fb.h_raw) { (void)hipHostFree(fb.h_raw); fb.h_raw = nullptr; }
+        if (fb.d_raw) { (void)hipFree(fb.d_raw); fb.d_raw = nullptr; }
+        if (fb.d_iq) { (void)hipFree(fb.d_iq); fb.d_iq = nullptr; }
+        fb.bytes = 0;
+        HIP_CHECK(hipMalloc((void**)&fb.d_raw, blk * sf_bytes));
+        HIP_CHECK(hipMalloc((void**)&fb.d_iq, blk * sf_bytes));
+        fb.bytes = blk * sf_bytes;
+      }
+      if (!use_mmap && !fb.h_raw) HIP_CHECK(hipHostMalloc((void**)&fb.h_raw, fb.bytes, hipHostMallocDefault));
+    }
+  } catch (const std::exception& ex) {
+    fprintf(stderr, "ltesniffer_amd: %s\n", ex.what());
+    return LSN_ERROR;
+  }
+  return LSN_SUCCESS;
+}
+
 int Engine::processFile(const char* path, const lsn_file_cfg_t& fc, uint32_t start_tti, uint64_t max_subframes, uint32_t update_meta_period,
                         uint64_t* subframes_done)
 {
@@ -41,15 +85,12 @@ int Engine::processFile(const char* path, const lsn_file_cfg_t& fc, uint32_t sta
   if (fstat(fd, &sb)) { close(fd); return LSN_ERROR_INVALID_INPUTS; }
   const uint32_t nant = fc.nof_antennas, sflen = cd.sflen;
   const size_t sf_bytes = (size_t)sflen * nant * sizeof(cf32);
-  uint32_t blk = 800, nrd = 12;  // subframes per block (393 MB at 20 MHz / 2 antennas), page-touch / pread threads per block
-  if (const char* e = getenv("LSN_FILE_BLOCK")) blk = (uint32_t)std::max(1, atoi(e));
-  if (const char* e = getenv("LSN_FILE_READERS")) nrd = (uint32_t)std::max(1, std::min(32, atoi(e)));
+  uint32_t blk, nrd;  // subframes per block, page-touch / pread threads per block
+  int NSLOT;          // blocks in flight (round 2 held eight until their chunks were written - and paid 8 x 393 MB of pinned allocation on the first call)
+  file_geometry(blk, nrd, NSLOT);
   const uint64_t file_off0 = (uint64_t)fc.offset_time_samples * nant * sizeof(cf32);
   const uint64_t sf_in_file = (uint64_t)sb.st_size > file_off0 ? ((uint64_t)sb.st_size - file_off0) / sf_bytes : 0;  // complete subframes only
   constexpr int NSLOT_MAX = 8;
-  int NSLOT = 4;  // blocks in flight: one being read, one crossing PCIe, two in stage A (a slot is free again when stage A has consumed its block;
-                  // round 2 held eight until their chunks were written - and paid 8 x 393 MB of pinned allocation on the first call)
-  if (const char* e = getenv("LSN_FILE_SLOTS")) NSLOT = std::max(3, std::min(NSLOT_MAX, atoi(e)));
   const bool fdebug = getenv("LSN_FILE_DEBUG") != nullptr;
   auto tnow = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t_begin = tnow();
@@ -77,19 +118,10 @@ int Engine::processFile(const char* path, const lsn_file_cfg_t& fc, uint32_t sta
   try {
     HIP_CHECK(hipSetDevice(cfg.device));
     HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-    for (int si = 0; si < NSLOT; si++) {  // block buffers live in the engine and are reused by later calls
+    if (reserveFileBuffers(nant) != LSN_SUCCESS) throw std::runtime_error("file source: block buffers");  // (kept by the engine: no-op when lsn_phy_prepare_file or an earlier call made them)
+    for (int si = 0; si < NSLOT; si++) {
       Slot& s = slot[si];
       FileBuf& fb = file_buf[si];
-      if (fb.bytes < blk * sf_bytes) {
-        if (fb.h_raw) { (void)hipHostFree(fb.h_raw); fb.h_raw = nullptr; }
-        if (fb.d_raw) { (void)hipFree(fb.d_raw); fb.d_raw = nullptr; }
-        if (fb.d_iq) { (void)hipFree(fb.d_iq); fb.d_iq = nullptr; }
-        fb.bytes = 0;
-        HIP_CHECK(hipMalloc((void**)&fb.d_raw, blk * sf_bytes));
-        HIP_CHECK(hipMalloc((void**)&fb.d_iq, blk * sf_bytes));
-        fb.bytes = blk * sf_bytes;
-      }
-      if (!use_mmap && !fb.h_raw) HIP_CHECK(hipHostMalloc((void**)&fb.h_raw, fb.bytes, hipHostMallocDefault));  // (kept by the engine: later calls find them)
       s.h_raw = fb.h_raw; s.d_raw = fb.d_raw; s.d_iq = fb.d_iq;
     }
     if (fc.offset_freq_hz != 0.0f) {

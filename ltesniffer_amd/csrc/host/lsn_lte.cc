@@ -261,16 +261,18 @@ int ra_tbs_from_idx(int i_tbs, uint32_t n_prb)
 
 bool pdsch_re_usable(const Cell& cell, uint32_t sf_idx, uint32_t l, uint32_t k)
 {
-  const bool crs_symbol = l == 0 || l == 4 || l == 7 || l == 11;
-  if (cell.nof_ports == 4 && (l == 1 || l == 8) && k % 3 == cell.id % 3) return false;  // CRS of ports 2, 3
+  const uint32_t nsl = cell.nslot(), lq = l % nsl;
+  if (l >= cell.nsym()) return false;  // extended CP: rows 12, 13 of the 14-row grids do not exist
+  const bool crs_symbol = cell.crs_symbol01(l);
+  if (cell.nof_ports == 4 && lq == 1 && k % 3 == cell.id % 3) return false;  // CRS of ports 2, 3
   if (crs_symbol) {
     if (cell.nof_ports >= 2) { if (k % 3 == cell.id % 3) return false; }
-    else if (k % 6 == (((l == 0 || l == 7) ? 0u : 3u) + cell.id % 6) % 6) return false;
+    else if (k % 6 == ((lq == 0 ? 0u : 3u) + cell.id % 6) % 6) return false;
   }
   const uint32_t lo = 6 * cell.nof_prb - 36;
   if (k >= lo && k < lo + 72) {
-    if ((sf_idx == 0 || sf_idx == 5) && (l == 5 || l == 6)) return false;
-    if (sf_idx == 0 && l >= 7 && l <= 10) return false;
+    if ((sf_idx == 0 || sf_idx == 5) && (l == nsl - 2 || l == nsl - 1)) return false;  // SSS, PSS: the last two symbols of slots 0 and 10
+    if (sf_idx == 0 && l >= nsl && l <= nsl + 3) return false;                           // PBCH: symbols 0-3 of slot 1
   }
   return true;
 }
@@ -284,11 +286,11 @@ void cell_build_re_tables(Cell& cell)
   plain.re_count.reset();
   for (uint32_t cl = 0; cl < 3; cl++)
     for (uint32_t l0 = 0; l0 < 5; l0++)
-      for (uint32_t l = l0; l < 14; l++)
+      for (uint32_t l = l0; l < cell.nsym(); l++)
         for (uint32_t prb = 0; prb < n; prb++) {
           uint16_t c = 0;
           for (uint32_t k = 12 * prb; k < 12 * prb + 12; k++) c += pdsch_re_usable(plain, cls_sf[cl], l, k) ? 1 : 0;
-          (*t)[((cl * 5 + l0) * 2 + l / 7) * n + prb] += c;
+          (*t)[((cl * 5 + l0) * 2 + l / cell.nslot()) * n + prb] += c;
         }
   cell.re_count = t;
   for (int f = 0; f < 9; f++) cell.fmt_size[f] = 0;
@@ -306,9 +308,9 @@ static uint32_t ra_dl_compute_nof_re(const Cell& cell, uint32_t sf_idx, uint32_t
     for (uint32_t prb = g.prb_lo; prb <= g.prb_hi && prb < cell.nof_prb; prb++) n += (g.prb_idx[0][prb] ? t0[prb] : 0u) + (g.prb_idx[1][prb] ? t1[prb] : 0u);
     return n;
   }
-  for (uint32_t l = l0; l < 14; l++)
+  for (uint32_t l = l0; l < cell.nsym(); l++)
     for (uint32_t prb = 0; prb < cell.nof_prb; prb++)
-      if (g.prb_idx[l / 7][prb])
+      if (g.prb_idx[l / cell.nslot()][prb])
         for (uint32_t k = 12 * prb; k < 12 * prb + 12; k++) n += pdsch_re_usable(cell, sf_idx, l, k) ? 1 : 0;
   return n;
 }

@@ -28,6 +28,10 @@ inline bool rnti_israr(uint16_t r) { return r >= RARNTI_START && r <= RARNTI_END
 struct Cell {
   uint32_t nof_prb = 0, nof_ports = 0, id = 0, phich_ng_x6 = 1;
   uint32_t pusch_hop_offset = 0;  // SIB2 pusch-HoppingOffset = n_rb_ho of the uplink grant conversion (SubframeWorker.cc:271-273); 0 until known
+  uint32_t cp = 0;                // srsran_cell_t.cp: 0 normal (7 symbols per slot), 1 extended (6 symbols per slot; 36.211 Table 6.2.3-1)
+  uint32_t nslot() const { return cp ? 6u : 7u; }
+  uint32_t nsym() const { return cp ? 12u : 14u; }
+  bool crs_symbol01(uint32_t l) const { const uint32_t q = l % nslot(); return q == 0 || q == nslot() - 3; }  // CRS of ports 0, 1: symbols 0 and N_symb - 3 of both slots
   // optional acceleration table built by cell_build_re_tables(): PDSCH-capable REs per (subframe class, first PDSCH
   // symbol l0 0..4, slot, PRB); class 0: subframe 0, 1: subframe 5, 2: any other (srsran_ra_dl_compute_nof_re [srsRAN])
   std::shared_ptr<std::vector<uint16_t>> re_count;

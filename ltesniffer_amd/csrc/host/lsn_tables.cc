@@ -87,9 +87,9 @@ void Engine::freeRunner(JobRunner& r)
 {
   auto df = [](auto*& p) { if (p) (void)hipFree(p); p = nullptr; };
   auto hf = [](auto*& p) { if (p) (void)hipHostFree(p); p = nullptr; };
-  df(r.d_jobs); df(r.d_cbs); df(r.d_cbstate); df(r.d_cbres); df(r.d_prefix); df(r.d_llr16); df(r.d_payload); df(r.d_spp); df(r.d_items);
+  df(r.d_jobs); df(r.d_cbs); df(r.d_cbres); df(r.d_prefix); df(r.d_llr16); df(r.d_payload); df(r.d_spp); df(r.d_items);
   hf(r.h_items_pinned); hf(r.h_payload_pinned); hf(r.h_cbres_pinned); hf(r.h_jobs_pinned); hf(r.h_cbs_pinned);
-  r.items_cap = r.h_items_cap = r.spp_cap = r.jobs_cap = r.cbs_cap = r.cbstate_cap = r.cbres_cap = r.prefix_cap = r.llr16_cap = r.payload_cap = r.h_payload_cap = r.h_cbres_cap = r.h_jobs_cap = r.h_cbs_cap = 0;
+  r.items_cap = r.h_items_cap = r.spp_cap = r.jobs_cap = r.cbs_cap = r.cbres_cap = r.prefix_cap = r.llr16_cap = r.payload_cap = r.h_payload_cap = r.h_cbres_cap = r.h_jobs_cap = r.h_cbs_cap = 0;
   for (auto& e : r.ev)
     if (e) { (void)hipEventDestroy(e); e = nullptr; }
   if (r.ev_done) { (void)hipEventDestroy(r.ev_done); r.ev_done = nullptr; }
@@ -210,6 +210,8 @@ void Engine::buildTables()
   const int Nsub = N == 1536 ? 512 : N;  // 15 MHz: three interleaved 512-point transforms + a radix-3 combination
   cd.N = (uint32_t)N; cd.nsub = (uint32_t)Nsub; cd.lgN = 0; while ((1 << cd.lgN) < Nsub) cd.lgN++;
   cd.nre = 12 * nprb; cd.nref = 2 * nprb; cd.sflen = 15u * (uint32_t)N;
+  cd.cp = cell.cp; cd.nsym = cell.nsym(); cd.nslot = cell.nslot();
+  cd.reg_w6 = 1u | (P == 4 ? 2u : 0u) | (cell.cp ? 8u : 0u);
   // FFT twiddles and NCO tables (double -> float, same generation as the oracle's definition)
   std::vector<cf32> tw((size_t)Nsub / 2), coarse(4096), fine(1024);
   for (int k = 0; k < Nsub / 2; k++) { double a = 2.0 * M_PI * k / Nsub; tw[k] = {(float)std::cos(a), (float)(-std::sin(a))}; }
@@ -226,13 +228,14 @@ void Engine::buildTables()
     const float s = 0.70710678118654752440f;
     std::vector<cf32> crs((size_t)10 * P * 4 * cd.nref);
     std::vector<uint8_t> c(440);
-    // ports 0 / 1 share pilot symbols 0, 4, 7, 11 and their sequences; ports 2 / 3 share symbols 1, 8 (rows 0, 1 of their [4][nref] block)
-    static const int sym01[4] = {0, 4, 7, 11}, sym23[2] = {1, 8};
+    // ports 0 / 1 share pilot symbols 0, 4, 7, 11 (extended CP: 0, 3, 6, 9) and their sequences; ports 2 / 3 share symbols 1, 8 (1, 7): rows 0, 1 of their
+    // [4][nref] block.  c_init carries N_CP = 1 (normal) / 0 (extended), 36.211 6.10.1.1
+    const uint32_t nsl = cell.nslot();
     for (uint32_t sf = 0; sf < 10; sf++)
       for (uint32_t p0 = 0; p0 < P; p0 += 2)
         for (int q = 0; q < (p0 == 0 ? 4 : 2); q++) {
-          const uint32_t l = p0 == 0 ? sym01[q] : sym23[q], ns = 2 * sf + (l >= 7 ? 1 : 0), lsl = l % 7;
-          gold_sequence(1024u * (7u * (ns + 1) + lsl + 1) * (2u * id + 1) + 2u * id + 1, c.data(), 440);
+          const uint32_t l = p0 == 0 ? (uint32_t)(q >> 1) * nsl + ((q & 1) ? nsl - 3 : 0) : (uint32_t)q * nsl + 1, ns = 2 * sf + (l >= nsl ? 1 : 0), lsl = l % nsl;
+          gold_sequence(1024u * (7u * (ns + 1) + lsl + 1) * (2u * id + 1) + 2u * id + (cell.cp ? 0u : 1u), c.data(), 440);
           for (uint32_t m = 0; m < cd.nref; m++) {
             const uint32_t mp = m + 110 - nprb;
             cf32 v{c[2 * mp] ? -s : s, c[2 * mp + 1] ? -s : s};
@@ -254,14 +257,14 @@ void Engine::buildTables()
     for (int m = 0; m < ng; m++) for (int i = 0; i < 3; i++) used0[avail[((int)id + m + (i * na) / 3) % na]] = 1;
     std::vector<uint16_t> rk(3 * 800, 0);
     std::vector<uint8_t> rl(3 * 800, 0);
-    std::vector<uint16_t> rq(3 * 800, 0xFFFFu);  // natural REG index: symbol 0 (and symbol 1 of a four-port cell) has nre / 6 REGs, every later control symbol nre / 4
-    const int w1 = P == 4 ? 6 : 4;                // symbol 1 carries the CRS of ports 2, 3
+    std::vector<uint16_t> rq(3 * 800, 0xFFFFu);  // natural REG index: symbol by symbol, nre / 6 REGs in a symbol that carries CRS (cd.reg_w6), nre / 4 in the others
+    auto wof = [&](int l) { return ((cd.reg_w6 >> l) & 1u) ? 6 : 4; };
     for (int cfi = 1; cfi <= 3; cfi++) {
       const int nsym = cfi + (nprb <= 10 ? 1 : 0);
       std::vector<std::pair<uint16_t, uint8_t>> regs;
       for (int k = 0; k < nre; k++)
         for (int l = 0; l < nsym; l++) {
-          const int w = l == 0 ? 6 : l == 1 ? w1 : 4;
+          const int w = wof(l);
           if (k % w || (l == 0 && used0[k / 6])) continue;
           regs.push_back({(uint16_t)k, (uint8_t)l});
         }
@@ -274,7 +277,8 @@ void Engine::buildTables()
         if (q < 800) {
           rk[(cfi - 1) * 800 + q] = regs[mp].first; rl[(cfi - 1) * 800 + q] = regs[mp].second;
           const int l = regs[mp].second;
-          const int nat = l == 0 ? regs[mp].first / 6 : l == 1 ? n0 + regs[mp].first / w1 : n0 + nre / w1 + (l - 2) * (nre / 4) + regs[mp].first / 4;
+          int nat = regs[mp].first / wof(l);
+          for (int j = 0; j < l; j++) nat += nre / wof(j);
           if (nat < 800) rq[(cfi - 1) * 800 + nat] = (uint16_t)q;
         }
       }

@@ -52,6 +52,9 @@ struct LsnCellDev {
   uint32_t nof_prb, nof_ports, id, nof_rx, N, lgN, nre, nref, sflen;
   uint32_t iq_nant;         // antennas interleaved in the IQ buffer ([sf][antenna][sflen]); nof_rx of them carry the downlink
   uint32_t nsub;            // power-of-two transform length: N, or 512 when N = 1536 = 3 x 512 (15 MHz); lgN = log2(nsub)
+  uint32_t cp, nsym, nslot; // cyclic prefix (0 normal, 1 extended), symbols per subframe (14 / 12) and per slot (7 / 6).  Grids keep 14 rows per antenna;
+                            // an extended-CP subframe fills rows 0 .. 11, rows 12, 13 stay zero (cleared once in setCell)
+  uint32_t reg_w6;          // bit l set: the REGs of control symbol l span 6 REs (CRS in the symbol): symbol 0, symbol 1 of a four-port cell, symbol 3 with the extended CP
   const cf32* twiddle;      // [nsub/2] exp(-2 pi i k/nsub)
   const cf32* twiddle3;     // N = 1536 only: [1536] exp(-2 pi i k/1536) of the radix-3 combination, else null
   const cf32* nco_coarse;   // [4096]
@@ -169,8 +172,12 @@ void lsn_launch_pusch_demod(const LsnCellDev& c, const LsnUlGrantDev* g, const c
 void lsn_launch_pdsch_prep(const LsnCellDev& c, const LsnGrantDev* g, uint16_t* prefix, uint32_t njobs, hipStream_t s);
 void lsn_launch_pdsch_demod(const LsnCellDev& c, const LsnGrantDev* g, const uint32_t* items, uint32_t nitems, const uint16_t* prefix, const cf32* grid, const cf32* ce,
                             const LsnChest* ch, int16_t* llr, hipStream_t s);
-void lsn_launch_rm(const LsnCbDev* cb, const int16_t* llr, uint32_t* spp, uint32_t ncb, uint32_t emax, hipStream_t s, uint32_t* state = nullptr);
+void lsn_launch_rm(const LsnCbDev* cb, const int16_t* llr, uint32_t* spp, uint32_t ncb, uint32_t emax, hipStream_t s);
 void lsn_launch_harq_combine(const LsnCbDev* cbs, uint32_t ncb, const uint32_t* cur, uint32_t* pool, bool overwrite, hipStream_t s);
 #define LSN_CB_NODEP 0xFFFFFFFFu
 void lsn_launch_turbo(const LsnCellDev& c, const LsnCbDev* cb, const uint32_t* spp, uint8_t* payload, LsnCbRes* res, uint32_t n128, uint32_t kmax128,
-                      uint32_t n64, uint32_t kmax64, hipStream_t s, hipEvent_t between, uint32_t* state = nullptr);
+                      uint32_t n64, uint32_t kmax64, hipStream_t s, hipEvent_t between);
+// largest code block two of which share one decoder workgroup (one wavefront and half of the LDS slot each): 2 x (6 K + 16 + 3584) <= 40 960 = a quarter of the CU's LDS
+#define LSN_TURBO_PAIR_KMAX 2752u
+void lsn_launch_turbo_packed(const LsnCellDev& c, const LsnCbDev* cb, const uint32_t* spp, uint8_t* payload, LsnCbRes* res, uint32_t nsolo, uint32_t kmax_solo,
+                             uint32_t npair, uint32_t kmax_pair, hipStream_t s);

@@ -56,10 +56,12 @@ __global__ __launch_bounds__(256) void k_ofdm(LsnCellDev c, const cf32* __restri
   const int N = (int)c.N, lgN = (int)c.lgN, tid = threadIdx.x;
   cf32* a = (cf32*)smem;
   cf32* w = a + N;
-  const int blk = blockIdx.x, l = blk % 14, rx = (blk / 14) % (int)c.nof_rx, sf = blk / (14 * (int)c.nof_rx);
+  const int nsym = (int)c.nsym;  // 14, or 12 with the extended cyclic prefix (rows 12, 13 of the grid are never written)
+  const int blk = blockIdx.x, l = blk % nsym, rx = (blk / nsym) % (int)c.nof_rx, sf = blk / (nsym * (int)c.nof_rx);
   const int cp0 = 160 * N / 2048, cp1 = 144 * N / 2048;
   const int slot = l / 7, ls = l % 7;
-  const int pos = slot * (cp0 + 6 * cp1 + 7 * N) + cp0 + ls * (N + cp1);
+  // 36.211 Table 6.12-1: normal CP 160 / 144 samples (at N = 2048), extended CP N / 4 on every symbol
+  const int pos = c.cp ? l * (N + N / 4) + N / 4 : slot * (cp0 + 6 * cp1 + 7 * N) + cp0 + ls * (N + cp1);
   const cf32* in = iq + ((size_t)sf * c.iq_nant + rx) * c.sflen + pos;
   const uint32_t dphi = dphi_sf ? dphi_sf[sf] : 0u;
   const int nre = (int)c.nre;
@@ -126,7 +128,7 @@ __global__ __launch_bounds__(256) void k_ofdm(LsnCellDev c, const cf32* __restri
 void lsn_launch_ofdm(const LsnCellDev& c, const cf32* iq, const uint32_t* dphi, cf32* grid, uint32_t nsf, hipStream_t s)
 {
   size_t lds = sizeof(cf32) * (c.N + c.N / 2);
-  LSN_LAUNCH(k_ofdm, dim3(nsf * c.nof_rx * 14), dim3(256), lds, s, c, iq, dphi, grid);
+  LSN_LAUNCH(k_ofdm, dim3(nsf * c.nof_rx * c.nsym), dim3(256), lds, s, c, iq, dphi, grid);
 }
 
 // ------------------------------------------------------------------------------------------------ channel estimation
@@ -149,7 +151,9 @@ __global__ __launch_bounds__(256) void k_chest(LsnCellDev c, const cf32* __restr
   cf32* sm = ls + 4 * nref;         // [4*nref]
   float* part = (float*)(sm + 4 * nref);  // [6][256]
   const int S = p < 2 ? 4 : 2;  // pilot symbols of this port
-  const int sym[4] = {p < 2 ? 0 : 1, p < 2 ? 4 : 8, 7, 11};
+  // pilot symbols: ports 0, 1 on symbols 0 and N_symb - 3 of both slots (0, 4, 7, 11; extended CP 0, 3, 6, 9), ports 2, 3 on symbol 1 of both slots (1, 8 / 1, 7)
+  const int nsl = (int)c.nslot, nsym = (int)c.nsym;
+  const int sym[4] = {p < 2 ? 0 : 1, p < 2 ? nsl - 3 : nsl + 1, nsl, 2 * nsl - 3};
   const cf32* g = grid + ((size_t)sf * A + rx) * 14 * nre;
   const cf32* crs = c.crs + ((size_t)sf_idx_arr[sf] * P + p) * 4 * nref;
   const int n4 = S * nref;
@@ -213,30 +217,29 @@ __global__ __launch_bounds__(256) void k_chest(LsnCellDev c, const cf32* __restr
       row[s].r = pl[m].r + dr * f;
       row[s].i = pl[m].i + di * f;
     }
-    if (p >= 2) {  // ports 2, 3: one line through symbols 1 and 8 for the whole subframe
+    if (p >= 2) {  // ports 2, 3: one line through their two pilot symbols for the whole subframe
       const cf32 c1 = row[0], c8 = row[1];
-      const float dr = (c8.r - c1.r) / 7.0f, di = (c8.i - c1.i) / 7.0f;
-      co[1 * nre + k] = c1; co[8 * nre + k] = c8;
-#pragma unroll
-      for (int l = 0; l < 14; l++) {
-        if (l == 1 || l == 8) continue;
-        cf32 v; v.r = c1.r + dr * (float)(l - 1); v.i = c1.i + di * (float)(l - 1); co[l * nre + k] = v;
+      const int la = sym[0], lb = sym[1];
+      const float dl = (float)(lb - la);
+      const float dr = (c8.r - c1.r) / dl, di = (c8.i - c1.i) / dl;
+      co[la * nre + k] = c1; co[lb * nre + k] = c8;
+      for (int l = 0; l < nsym; l++) {
+        if (l == la || l == lb) continue;
+        cf32 v; v.r = c1.r + dr * (float)(l - la); v.i = c1.i + di * (float)(l - la); co[l * nre + k] = v;
       }
       continue;
     }
     cf32 c0 = row[0], c4 = row[1], c7 = row[2], c11 = row[3];
-    float d01r = (c4.r - c0.r) / 4.0f, d01i = (c4.i - c0.i) / 4.0f;
-    float d12r = (c7.r - c4.r) / 3.0f, d12i = (c7.i - c4.i) / 3.0f;
-    float d23r = (c11.r - c7.r) / 4.0f, d23i = (c11.i - c7.i) / 4.0f;
-    co[0 * nre + k] = c0; co[4 * nre + k] = c4; co[7 * nre + k] = c7; co[11 * nre + k] = c11;
-#pragma unroll
-    for (int l = 1; l <= 3; l++) { cf32 v; v.r = c0.r + d01r * (float)l; v.i = c0.i + d01i * (float)l; co[l * nre + k] = v; }
-#pragma unroll
-    for (int l = 5; l <= 6; l++) { cf32 v; v.r = c4.r + d12r * (float)(l - 4); v.i = c4.i + d12i * (float)(l - 4); co[l * nre + k] = v; }
-#pragma unroll
-    for (int l = 8; l <= 10; l++) { cf32 v; v.r = c7.r + d23r * (float)(l - 7); v.i = c7.i + d23i * (float)(l - 7); co[l * nre + k] = v; }
-#pragma unroll
-    for (int l = 12; l <= 13; l++) { cf32 v; v.r = c11.r + d23r * (float)(l - 11); v.i = c11.i + d23i * (float)(l - 11); co[l * nre + k] = v; }
+    const int q0 = sym[0], q1 = sym[1], q2 = sym[2], q3 = sym[3];
+    const float w01 = (float)(q1 - q0), w12 = (float)(q2 - q1), w23 = (float)(q3 - q2);
+    float d01r = (c4.r - c0.r) / w01, d01i = (c4.i - c0.i) / w01;
+    float d12r = (c7.r - c4.r) / w12, d12i = (c7.i - c4.i) / w12;
+    float d23r = (c11.r - c7.r) / w23, d23i = (c11.i - c7.i) / w23;
+    co[q0 * nre + k] = c0; co[q1 * nre + k] = c4; co[q2 * nre + k] = c7; co[q3 * nre + k] = c11;
+    for (int l = q0 + 1; l < q1; l++) { cf32 v; v.r = c0.r + d01r * (float)(l - q0); v.i = c0.i + d01i * (float)(l - q0); co[l * nre + k] = v; }
+    for (int l = q1 + 1; l < q2; l++) { cf32 v; v.r = c4.r + d12r * (float)(l - q1); v.i = c4.i + d12i * (float)(l - q1); co[l * nre + k] = v; }
+    for (int l = q2 + 1; l < q3; l++) { cf32 v; v.r = c7.r + d23r * (float)(l - q2); v.i = c7.i + d23i * (float)(l - q2); co[l * nre + k] = v; }
+    for (int l = q3 + 1; l < nsym; l++) { cf32 v; v.r = c11.r + d23r * (float)(l - q3); v.i = c11.i + d23i * (float)(l - q3); co[l * nre + k] = v; }   // behind the last pilot: its slope continues
   }
 }
 
@@ -283,7 +286,7 @@ __device__ __forceinline__ void reg_equalise(const LsnCellDev& c, const cf32* __
 {
   const int A = (int)c.nof_rx;
   int kk[4], n = 0;
-  if (l == 0 || (l == 1 && c.nof_ports == 4)) {  // the REG spans 6 REs, two of them CRS positions (symbol 1: ports 2, 3 of a four-port cell)
+  if ((c.reg_w6 >> l) & 1u) {  // the REG spans 6 REs, two of them CRS positions (symbol 0; symbol 1: ports 2, 3 of a four-port cell; symbol 3 with the extended CP)
     for (int k = k0; k < k0 + 6; k++)
       if ((k % 3) != (int)(c.id % 3)) { if (n < 4) kk[n] = k; n++; }
   } else {
@@ -372,13 +375,14 @@ __global__ __launch_bounds__(256) void k_pdcch_llr(LsnCellDev c, const cf32* __r
   const uint32_t cfi = cfi_arr[sf];
   const int nre = (int)c.nre, A = (int)c.nof_rx, n0 = nre / 6, n1 = nre / 4;
   const int nat = blockIdx.x * 256 + threadIdx.x;
-  int l, k0;
-  if (nat < n0) { l = 0; k0 = 6 * nat; }
-  else if (c.nof_ports == 4) {  // symbol 1 carries the CRS of ports 2, 3: 6-RE REGs like symbol 0
-    if (nat < 2 * n0) { l = 1; k0 = 6 * (nat - n0); }
-    else { const int r = nat - 2 * n0; l = 2 + r / n1; k0 = 4 * (r - (l - 2) * n1); }
+  // natural REG order: symbol by symbol; a symbol that carries CRS (c.reg_w6) has nre / 6 REGs of 6 REs, the others nre / 4 of 4
+  int l = 0, k0 = 0, r = nat;
+  for (;; l++) {
+    const int six = (int)((c.reg_w6 >> l) & 1u), cnt = six ? n0 : n1;
+    if (r < cnt || l == 3) { k0 = (six ? 6 : 4) * r; break; }
+    r -= cnt;
   }
-  else { const int r = nat - n0; l = 1 + r / n1; k0 = 4 * (r - (l - 1) * n1); }
+  if (k0 >= nre) return;
   if ((uint32_t)l >= cfi + (c.nof_prb <= 10 ? 1u : 0u) || nat >= 800) return;  // 36.211 6.7: one more control symbol at <= 10 PRB
   const uint32_t q = c.reg_q[(cfi - 1) * 800 + nat];
   if (q >= c.nof_cce[cfi - 1] * 9) return;  // PCFICH / PHICH REG (0xFFFF) or behind the last whole CCE
@@ -401,7 +405,7 @@ __global__ __launch_bounds__(256) void k_pdcch_llr(LsnCellDev c, const cf32* __r
 }
 void lsn_launch_pdcch_llr(const LsnCellDev& c, const cf32* grid, const cf32* ce, const LsnChest* ch, const uint32_t* sf_idx, const uint32_t* cfi, float* llr, uint32_t nsf, hipStream_t s)
 {
-  const uint32_t nreg = c.nre / 6 + (c.nof_prb <= 10 ? 3u : 2u) * (c.nre / 4);  // REGs of the widest control region
+  const uint32_t nreg = c.nre / 6 + (c.nof_prb <= 10 ? 3u : 2u) * (c.nre / 4);  // REGs of the widest control region (an upper bound: symbols with CRS hold fewer)
   LSN_LAUNCH(k_pdcch_llr, dim3((nreg + 255) / 256, nsf), dim3(256), 0, s, c, grid, ce, ch, sf_idx, cfi, llr);
 }
 

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(64) void k_pdsch_prep(LsnCellDev c, const LsnGrantD
     for (int base = 0; base < nprb; base += 64) {
       const int prb = base + lane;
       uint32_t v = 0;
-      if (prb < nprb && l >= (int)g.l0 && ((g.prb_mask[l / 7][prb >> 5] >> (prb & 31)) & 1u)) v = (uint32_t)__popc((unsigned)c.validmask[(cls * 14 + l) * nprb + prb]);
+      if (prb < nprb && l >= (int)g.l0 && ((g.prb_mask[l >= (int)c.nslot ? 1 : 0][prb >> 5] >> (prb & 31)) & 1u)) v = (uint32_t)__popc((unsigned)c.validmask[(cls * 14 + l) * nprb + prb]);
       uint32_t inc = v;  // inclusive scan over the 64 lanes
 #pragma unroll
       for (int off = 1; off < 64; off <<= 1) {
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(64) void k_pdsch_prep_up(LsnCellDev c, const LsnGra
     for (int base = 0; base < nprb; base += 64) {
       const int prb = base + lane;
       uint32_t v = 0;
-      if (prb < nprb && l >= (int)g.l0 && ((g.prb_mask[l / 7][prb >> 5] >> (prb & 31)) & 1u)) v = (uint32_t)__popc((unsigned)c.validmask[(cls * 14 + l) * nprb + prb]);
+      if (prb < nprb && l >= (int)g.l0 && ((g.prb_mask[l >= (int)c.nslot ? 1 : 0][prb >> 5] >> (prb & 31)) & 1u)) v = (uint32_t)__popc((unsigned)c.validmask[(cls * 14 + l) * nprb + prb]);
       uint32_t inc = v;
 #pragma unroll
       for (int off = 1; off < 64; off <<= 1) {
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(192) void k_pdsch_demod(LsnCellDev c, const LsnGran
   const int nprb = (int)c.nof_prb, nre = (int)c.nre, A = (int)c.nof_rx;
   const int l = blockIdx.y, prb = (int)(item & 255u) * 16 + (int)threadIdx.x / 12, kk = (int)threadIdx.x % 12;
   if (l < (int)g.l0 || prb >= nprb) return;
-  if (!((g.prb_mask[l / 7][prb >> 5] >> (prb & 31)) & 1u)) return;
+  if (!((g.prb_mask[l >= (int)c.nslot ? 1 : 0][prb >> 5] >> (prb & 31)) & 1u)) return;
   const int cls = g.sf_idx == 0 ? 0 : (g.sf_idx == 5 ? 1 : 2);
   const unsigned mask = c.validmask[(cls * 14 + l) * nprb + prb];
   if (!((mask >> kk) & 1u)) return;
@@ -188,7 +188,8 @@ __global__ __launch_bounds__(192) void k_pdsch_demod(LsnCellDev c, const LsnGran
   const int k = 12 * prb + kk;
   const LsnChest ch = chest[g.sf];
   const float noise = ch.noise_avg, chan_ref = ch.chan_ref;
-  const float inv_amp = (l == 0 || l == 4 || l == 7 || l == 11) ? g.inv_amp_b : g.inv_amp_a;
+  const int lq = l >= (int)c.nslot ? l - (int)c.nslot : l;
+  const float inv_amp = (lq == 0 || lq == (int)c.nslot - 3) ? g.inv_amp_b : g.inv_amp_a;   // rho_B on the symbols with the CRS of ports 0, 1 (36.213 Table 5.2-2)
   const cf32* gr = grid + (size_t)g.sf * A * 14 * nre;
   const cf32* ch0 = ce + (size_t)g.sf * c.nof_ports * A * 14 * nre;
 #define GRID(rx, kq) gr[((size_t)(rx) * 14 + l) * nre + (kq)]
@@ -324,9 +325,8 @@ __device__ __forceinline__ int rm_sum(const int16_t* __restrict__ e, const int16
   for (int k = rank; k < E; k += nn) acc += STAGED ? (int)es[k] : (int)e[k];
   return acc > LSN_LLR_CLIP ? LSN_LLR_CLIP : (acc < -LSN_LLR_CLIP ? -LSN_LLR_CLIP : acc);
 }
-__global__ __launch_bounds__(RM_NT) void k_rm(const LsnCbDev* __restrict__ cbs, const int16_t* __restrict__ llr, uint32_t* __restrict__ spp_g, uint32_t seg, uint32_t* __restrict__ state)
+__global__ __launch_bounds__(RM_NT) void k_rm(const LsnCbDev* __restrict__ cbs, const int16_t* __restrict__ llr, uint32_t* __restrict__ spp_g, uint32_t seg)
 {
-  if (state && threadIdx.x == 0) state[cbs[blockIdx.x].res_idx] = 0u;  // "not decoded yet" for the single-launch decoder (k_turbo: dependants wait on their first block)
   extern __shared__ __attribute__((aligned(16))) unsigned char rm_smem[];
   __shared__ LsnRmGeom geom;
   int16_t* es = (int16_t*)rm_smem;
@@ -370,14 +370,14 @@ __global__ __launch_bounds__(RM_NT) void k_rm(const LsnCbDev* __restrict__ cbs, 
   }
 }
 // the staging area is sized by the largest E of the launch, capped at 64 KiB (two workgroups per CU at least)
-void lsn_launch_rm(const LsnCbDev* cb, const int16_t* llr, uint32_t* spp, uint32_t ncb, uint32_t emax, hipStream_t s, uint32_t* state)
+void lsn_launch_rm(const LsnCbDev* cb, const int16_t* llr, uint32_t* spp, uint32_t ncb, uint32_t emax, hipStream_t s)
 {
   static std::atomic<uint64_t> attr_done{0};
   lsn_func_max_lds((const void*)k_rm, 65536, attr_done, "k_rm");
   const uint32_t cap = (65536 - 32) / 2;
   const uint32_t seg = emax < cap ? emax : cap;
   const size_t lds = (((size_t)seg + 16) * 2 + 15) & ~(size_t)15;  // + the skew in front of e[0] and the tail of the last 16-byte load
-  if (ncb) LSN_LAUNCH(k_rm, dim3(ncb), dim3(RM_NT), lds, s, cb, llr, spp, seg, state);
+  if (ncb) LSN_LAUNCH(k_rm, dim3(ncb), dim3(RM_NT), lds, s, cb, llr, spp, seg);
 }
 
 // ------------------------------------------------------------------------------------------------ HARQ soft combining
@@ -440,6 +440,18 @@ __device__ __forceinline__ uint32_t mulmod24(uint32_t a, uint32_t b, uint32_t po
   return r & 0xFFFFFFu;
 }
 
+// Synchronisation among the threads that work on ONE code block: a block of more than 64 windows is decoded by both wavefronts of its workgroup
+// (workgroup barrier); a block of at most 64 windows by one wavefront - its partner in the workgroup has left, or decodes ANOTHER block at its own
+// pace (paired launch, k_turbo below), so a workgroup barrier would be wrong: the LDS operations of one wavefront complete in order, what is needed is
+// that the compiler keeps them in order.
+__device__ __forceinline__ void tb_sync(int nt)
+{
+  if (nt == 128) { __syncthreads(); return; }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // one constituent decoder over all windows (lane = window); nii_a / nii_b: boundary metrics (layout C) in registers
 template <bool IL>
 __device__ __forceinline__ void map_pass(const TurboLds& m, const uint32_t* il, int nt, int lane, bool active, int K, int P, int W,
@@ -449,14 +461,14 @@ __device__ __forceinline__ void map_pass(const TurboLds& m, const uint32_t* il, 
   lsn_map_pass_lane<IL>(m, il, nt, lane, active, K, P, W, nii_a, nii_b, beta_tail, a_end, b_out);
   // next-iteration initialisation: window p starts from the end of window p-1 and ends at the start of window p+1.
   // The exchange goes through the (now idle) check-point area, slots 0 and 1.
-  __syncthreads();
+  tb_sync(nt);
   lsn_ckpt_store(m.ckpt, nt, 0, lane, a_end);
   lsn_ckpt_store(m.ckpt, nt, 1, lane, b_out);
-  __syncthreads();
+  tb_sync(nt);
   const int lm = lane > 0 ? lane - 1 : 0, lq = lane + 1 < nt ? lane + 1 : lane;
   lsn_ckpt_load(m.ckpt, nt, 0, lm, nii_a);
   lsn_ckpt_load(m.ckpt, nt, 1, lq, nii_b);
-  __syncthreads();
+  tb_sync(nt);
 }
 
 __device__ __forceinline__ void tail_beta(const int* ts, const int* tp, int* beta)
@@ -493,12 +505,20 @@ __device__ __forceinline__ uint32_t wg_xor(uint32_t v, int16_t* scratch, int tid
 #ifndef TB_WAVES_ATTR
 #define TB_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(2, 2)))
 #endif
+// Launch layout (round 5).  A decoder workgroup holds one of the CU's four 40 KB LDS slots and two of its eight wavefront slots whatever it decodes, and
+// the engine is bound by exactly those slots (profiles/r05_experiments.txt: three workgroups per CU instead of four cost 16 %).  Half of the code blocks
+// of the metric's workload have at most 64 windows - ONE working wavefront - and rounds 2-4 gave each of them a whole slot with an idle second
+// wavefront.  Now:
+//   workgroups [0, nsolo):  one code block each (cbs[wg]): two working wavefronts when it has more than 64 windows, else the second leaves at once;
+//   workgroups [nsolo, ..): TWO code blocks of at most 64 windows, one per wavefront (cbs[nsolo + 2 (wg - nsolo) + wave]), each with its own half of
+//                           the workgroup's LDS (pair_bytes per half) - the host pairs blocks of K <= LSN_TURBO_PAIR_KMAX so that two halves fit a slot.
+// The two wavefronts of a pair never synchronise with each other (tb_sync).
 template <int NT>
 __global__ __launch_bounds__(NT) TB_WAVES_ATTR void k_turbo(const uint32_t* __restrict__ crc_tab_a, const uint32_t* __restrict__ crc_tab_b, const uint32_t* __restrict__ il_tab,
                                               const LsnCbDev* __restrict__ cbs, const uint32_t* __restrict__ spp_g,
-                                              uint8_t* __restrict__ payload, LsnCbRes* res, uint32_t kmax, uint32_t* state)
+                                              uint8_t* __restrict__ payload, LsnCbRes* res, uint32_t kmax, uint32_t nsolo, uint32_t ncb, uint32_t kmax_pair, uint32_t pair_bytes)
 {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
   // phase cycle counters (LsnCbRes::cyc_*) only in instrumented builds (-DLSN_TURBO_CYCLES): the production kernel reads no clock
 #ifdef LSN_TURBO_CYCLES
 #define TB_CLOCK() clock64()
@@ -506,36 +526,24 @@ __global__ __launch_bounds__(NT) TB_WAVES_ATTR void k_turbo(const uint32_t* __re
 #define TB_CLOCK() 0ll
 #endif
   const long long tc0 = TB_CLOCK();
-  const LsnCbDev cb = cbs[blockIdx.x];
+  const bool paired = NT == 128 && blockIdx.x >= nsolo;
+  const uint32_t wave = threadIdx.x >> 6;
+  const uint32_t cbi = paired ? nsolo + 2u * (blockIdx.x - nsolo) + wave : blockIdx.x;
+  if (cbi >= ncb) return;  // (the odd block of the pairs: its partner wavefront has nothing to decode)
+  unsigned char* smem = smem_all + (paired ? (size_t)wave * pair_bytes : (size_t)0);
+  if (paired) kmax = kmax_pair;
+  const LsnCbDev cb = cbs[cbi];
   // The transport block of this code block is already lost when its first code block (decoded by an EARLIER launch on this stream)
   // failed: nothing this block could decode would reach the record stream, so it is not decoded at all
-  // (state != null: the first code blocks are part of THIS launch, in front of their dependants in the grid - the dependant waits for the verdict:
-  //  0 = not decoded yet (k_rm), 1 = failed, 2 = passed)
-  if (cb.dep != LSN_CB_NODEP) {
-    bool lost;
-    if (state) {
-      __shared__ uint32_t verdict;
-      if (threadIdx.x == 0) {
-        uint32_t v;
-        while ((v = __hip_atomic_load(&state[cb.dep], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) == 0u) __builtin_amdgcn_s_sleep(100);
-        verdict = v;
-      }
-      __syncthreads();
-      lost = verdict == 1u;
-    } else {
-      lost = res[cb.dep].ok == 0u;
-    }
-    if (lost) {
-      if (threadIdx.x == 0) { LsnCbRes r{}; res[cb.res_idx] = r; }
-      return;
-    }
+  if (cb.dep != LSN_CB_NODEP && res[cb.dep].ok == 0u) {
+    if ((paired ? (threadIdx.x & 63u) : threadIdx.x) == 0) { LsnCbRes r{}; res[cb.res_idx] = r; }
+    return;
   }
-  const int lane = threadIdx.x, K = (int)cb.K, F = (int)cb.F;
+  const int lane = paired ? (int)(threadIdx.x & 63u) : (int)threadIdx.x, K = (int)cb.K, F = (int)cb.F;
   const int P = lsn_turbo_nwin(K), W = K / P;
   const uint32_t magicW = ((1u << 20) + (uint32_t)W - 1u) / (uint32_t)W;
-  // a block of at most 64 windows inside a two-wavefront launch (lsn_turbo_two_wave_class: its LDS need would cap the occupancy of the
-  // one-wavefront launches): the second wavefront leaves before the first barrier and the first one works as in k_turbo<64>
-  const int nt = (NT == 128 && P <= 64) ? 64 : NT;
+  // a block of at most 64 windows: one working wavefront (solo: the second wavefront leaves before the first barrier)
+  const int nt = (NT == 128 && (paired || P <= 64)) ? 64 : NT;
   if (lane >= nt) return;
   const bool active = lane < P;
   const uint32_t* il = il_tab + cb.il_off;
@@ -550,7 +558,7 @@ __global__ __launch_bounds__(NT) TB_WAVES_ATTR void k_turbo(const uint32_t* __re
     for (int i = 8 * lane; i < K; i += 8 * nt) *(uint4*)&m.ext[i] = make_uint4(0u, 0u, 0u, 0u);
     if (lane < 12) tail[lane] = (int)src[K + lane];
   }
-  __syncthreads();
+  tb_sync(nt);
   // ---- termination (36.212 5.1.3.2.2): tail[s*4 + j] = stream s at position K + j ----
   s2 bt1[4], bt2[4];
   {
@@ -561,7 +569,7 @@ __global__ __launch_bounds__(NT) TB_WAVES_ATTR void k_turbo(const uint32_t* __re
     tail_beta(ts1, tp1, b8); lsn_pack_c(b8, bt1);
     tail_beta(ts2, tp2, b8); lsn_pack_c(b8, bt2);
   }
-  __syncthreads();  // scratch is dead from here on: the area becomes the check-point store
+  tb_sync(nt);  // scratch is dead from here on: the area becomes the check-point store
   const long long tc1 = TB_CLOCK();
   const uint32_t poly = cb.crc_b ? 0x1800063u : 0x1864CFBu;
   // weight of this thread's window in the block polynomial: x^((P-1-window) W) mod g
@@ -612,28 +620,39 @@ __global__ __launch_bounds__(NT) TB_WAVES_ATTR void k_turbo(const uint32_t* __re
     LsnCbRes r; r.ok = ok ? 1u : 0u; r.iters = (uint32_t)it; r.rem_a = rema; r.iters_run = (uint32_t)it_run;
     r.cyc_rm = (uint32_t)(tc1 - tc0); r.cyc_map = (uint32_t)(tc2 - tc1); r.cyc_out = (uint32_t)(tc3 - tc2); r.cyc_all = (uint32_t)(tc3 - tc0);
     res[cb.res_idx] = r;
-    if (state) __hip_atomic_store(&state[cb.res_idx], ok ? 2u : 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
 size_t lsn_turbo_lds_bytes(uint32_t kmax) { return 6 * (size_t)kmax + 16 + TB_CKPT_BYTES; }
 static size_t turbo_lds_bytes_nt(uint32_t kmax, int) { return lsn_turbo_lds_bytes(kmax); }
 
-// cb[0 .. n128) use two wavefronts per code block (P > 64), cb[n128 .. ncb) one; each range is launched with the LDS
-// size of its largest block (40 KiB at K = 6144 -> four code blocks per CU)
+// Classic form (uplink, HARQ re-decodes): cb[0 .. n128) in two-wavefront workgroups, cb[n128 .. n128 + n64) in one-wavefront workgroups; each range is
+// launched with the LDS size of its largest block (40 KiB at K = 6144 -> four code blocks per CU)
 void lsn_launch_turbo(const LsnCellDev& c, const LsnCbDev* cb, const uint32_t* spp, uint8_t* payload, LsnCbRes* res, uint32_t n128, uint32_t kmax128,
-                      uint32_t n64, uint32_t kmax64, hipStream_t s, hipEvent_t between, uint32_t* state)
+                      uint32_t n64, uint32_t kmax64, hipStream_t s, hipEvent_t between)
 {
-  // LSN_TURBO_MIN_LDS=<bytes> (round 5 experiment): a two-wavefront launch asks for at least this much LDS per workgroup, i.e. FEWER decoder workgroups
-  // per CU (54 000: three instead of four) - what they leave (40 KB of LDS, the registers of two SIMD lanes' second wave) keeps the memory-bound kernels
-  // of the other chains resident next to the decoders instead of queueing behind them
-  static const size_t min_lds = getenv("LSN_TURBO_MIN_LDS") ? std::min<size_t>((size_t)atol(getenv("LSN_TURBO_MIN_LDS")), 160u * 1024u) : 0;
-  static std::atomic<uint64_t> attr64{0}, attr128{0};
+  lsn_launch_turbo_packed(c, cb, spp, payload, res, n128, kmax128, 0, 0, s);
+  if (between) (void)hipEventRecord(between, s);
+  static std::atomic<uint64_t> attr64{0};
   lsn_func_max_lds((const void*)k_turbo<64>, (int)turbo_lds_bytes_nt(6144, 64), attr64, "k_turbo<64>");
+  auto fix = [](uint32_t k) { return ((k < 512 ? 512u : k) + 7u) & ~7u; };  // the scratch in the check-point area needs room
+  if (n64) LSN_LAUNCH(k_turbo<64>, dim3(n64), dim3(64), turbo_lds_bytes_nt(fix(kmax64), 64), s, c.crc_tab_a, c.crc_tab_b, c.turbo_il, cb + n128, spp, payload, res, fix(kmax64), n64, n64, 0u, 0u);
+}
+
+// One launch for a whole decode phase: cb[0 .. nsolo) one block per workgroup, cb[nsolo .. nsolo + npair) two blocks (K <= LSN_TURBO_PAIR_KMAX, at most 64
+// windows each) per workgroup - see k_turbo
+void lsn_launch_turbo_packed(const LsnCellDev& c, const LsnCbDev* cb, const uint32_t* spp, uint8_t* payload, LsnCbRes* res, uint32_t nsolo, uint32_t kmax_solo,
+                             uint32_t npair, uint32_t kmax_pair, hipStream_t s)
+{
+  // LSN_TURBO_MIN_LDS=<bytes> (round 5 experiment, negative: profiles/r05_experiments.txt): a launch asks for at least this much LDS per workgroup, i.e. FEWER
+  // decoder workgroups per CU (54 000: three instead of four)
+  static const size_t min_lds = getenv("LSN_TURBO_MIN_LDS") ? std::min<size_t>((size_t)atol(getenv("LSN_TURBO_MIN_LDS")), 160u * 1024u) : 0;
+  static std::atomic<uint64_t> attr128{0};
   lsn_func_max_lds((const void*)k_turbo<128>, (int)std::max(turbo_lds_bytes_nt(6144, 128), min_lds), attr128, "k_turbo<128>");
   auto fix = [](uint32_t k) { return ((k < 512 ? 512u : k) + 7u) & ~7u; };  // the scratch in the check-point area needs room
-  const size_t lds128 = std::max(turbo_lds_bytes_nt(fix(kmax128), 128), min_lds);
-  if (n128) LSN_LAUNCH(k_turbo<128>, dim3(n128), dim3(128), lds128, s, c.crc_tab_a, c.crc_tab_b, c.turbo_il, cb, spp, payload, res, fix(kmax128), state);
-  if (between) (void)hipEventRecord(between, s);
-  if (n64) LSN_LAUNCH(k_turbo<64>, dim3(n64), dim3(64), turbo_lds_bytes_nt(fix(kmax64), 64), s, c.crc_tab_a, c.crc_tab_b, c.turbo_il, cb + n128, spp, payload, res, fix(kmax64), state);
+  if (!nsolo && !npair) return;
+  const uint32_t ks = nsolo ? fix(kmax_solo) : 512u, kp = npair ? fix(kmax_pair) : 512u;
+  const size_t half = npair ? ((turbo_lds_bytes_nt(kp, 64) + 15) & ~(size_t)15) : 0;
+  const size_t lds = std::max(std::max(nsolo ? turbo_lds_bytes_nt(ks, 128) : (size_t)0, 2 * half), min_lds);
+  LSN_LAUNCH(k_turbo<128>, dim3(nsolo + (npair + 1) / 2), dim3(128), lds, s, c.crc_tab_a, c.crc_tab_b, c.turbo_il, cb, spp, payload, res, ks, nsolo, nsolo + npair, kp, (uint32_t)half);
 }

@@ -67,7 +67,17 @@ typedef struct {
   uint32_t id;        /* physical cell id 0..503 */
   uint32_t phich_ng_x6; /* Ng*6: 1 (=1/6), 3, 6, 12 ; LTESniffer_Core.cc:211-212 forces 1/6 */
   uint32_t pusch_hop_offset; /* SIB2 pusch-HoppingOffset = n_rb_ho of the uplink grant conversion (SubframeWorker.cc:271-273); 0 until SIB2 is known */
+  uint32_t cp;        /* srsran_cell_t.cp: 0 = normal cyclic prefix (7 symbols per slot), 1 = extended (6 symbols per slot, CP of N/4 samples).  The reference
+                       * hands whatever the cell search found to srsran_ue_dl_set_cell (SubframeWorker.cc:102, LTESniffer_Core.cc:292-299; file and manual
+                       * mode force normal, :210,243).  Grids keep 14 rows per antenna; an extended-CP subframe fills rows 0..11, rows 12, 13 stay zero. */
 } o_cell_t;
+/* symbols per slot / per subframe (36.211 Table 6.2.3-1) */
+static inline int o_nslot(const o_cell_t* c) { return c->cp ? 6 : 7; }
+static inline int o_nsym(const o_cell_t* c) { return c->cp ? 12 : 14; }
+/* CRS-bearing symbols (36.211 6.10.1.2): ports 0, 1 on symbols 0 and N_symb - 3 of both slots, ports 2, 3 on symbol 1 of both slots */
+static inline int o_crs_sym01(const o_cell_t* c, int s) { const int ns = o_nslot(c); return (s >> 1) * ns + ((s & 1) ? ns - 3 : 0); }
+static inline int o_crs_sym23(const o_cell_t* c, int s) { return s * o_nslot(c) + 1; }
+static inline int o_is_crs_sym01(const o_cell_t* c, int l) { const int ns = o_nslot(c), q = l % ns; return q == 0 || q == ns - 3; }
 
 /* ---------- bit-level primitives (o_bits.c) ---------- */
 uint32_t o_crc_bits(uint32_t poly, int order, const uint8_t* bits, int n);

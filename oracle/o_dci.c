@@ -295,21 +295,22 @@ int o_tbs_from_idx(int i_tbs, uint32_t n_prb)
 int o_pdsch_re_ok(const o_cell_t* cell, uint32_t sf_idx, uint32_t l, uint32_t k)
 {
   uint32_t nprb = cell->nof_prb;
-  if (cell->nof_ports == 4 && (l == 1 || l == 8)) { /* CRS of ports 2, 3 */
+  const uint32_t nsl = (uint32_t)o_nslot(cell), lq = l % nsl;
+  if (cell->nof_ports == 4 && lq == 1) { /* CRS of ports 2, 3 */
     if ((k % 3) == (cell->id % 3)) return 0;
   }
-  if (l == 0 || l == 4 || l == 7 || l == 11) {
+  if (o_is_crs_sym01(cell, (int)l)) {
     if (cell->nof_ports >= 2) {
       if ((k % 3) == (cell->id % 3)) return 0;
     } else {
-      uint32_t v = (l == 0 || l == 7) ? 0u : 3u;
+      uint32_t v = lq == 0 ? 0u : 3u;
       if ((k % 6) == (v + cell->id % 6) % 6) return 0;
     }
   }
   uint32_t kc0 = 6 * nprb - 36;
   if (k >= kc0 && k < kc0 + 72) {
-    if ((sf_idx == 0 || sf_idx == 5) && (l == 5 || l == 6)) return 0; /* SSS, PSS */
-    if (sf_idx == 0 && l >= 7 && l <= 10) return 0;                    /* PBCH */
+    if ((sf_idx == 0 || sf_idx == 5) && (l == nsl - 2 || l == nsl - 1)) return 0; /* SSS, PSS: the last two symbols of slots 0 and 10 */
+    if (sf_idx == 0 && l >= nsl && l <= nsl + 3) return 0;                          /* PBCH: symbols 0-3 of slot 1 */
   }
   return 1;
 }
@@ -317,9 +318,9 @@ int o_pdsch_re_ok(const o_cell_t* cell, uint32_t sf_idx, uint32_t l, uint32_t k)
 uint32_t o_ra_nof_re(const o_cell_t* cell, uint32_t sf_idx, uint32_t cfi, const o_pdsch_grant_t* g)
 {
   uint32_t n = 0, l0 = cfi + (cell->nof_prb <= 10 ? 1u : 0u);
-  for (uint32_t l = l0; l < 14; l++)
+  for (uint32_t l = l0; l < (uint32_t)o_nsym(cell); l++)
     for (uint32_t prb = 0; prb < cell->nof_prb; prb++)
-      if (g->prb_idx[l / 7][prb])
+      if (g->prb_idx[l / (uint32_t)o_nslot(cell)][prb])
         for (uint32_t k = 12 * prb; k < 12 * prb + 12; k++) n += (uint32_t)o_pdsch_re_ok(cell, sf_idx, l, k);
   return n;
 }

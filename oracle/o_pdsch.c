@@ -138,9 +138,9 @@ int o_pdsch_demod(const o_cell_t* cell, uint32_t nof_rx, uint32_t sf_idx, uint32
   uint16_t* rl = (uint16_t*)malloc(sizeof(uint16_t) * nofre);
   uint16_t* rk = (uint16_t*)malloc(sizeof(uint16_t) * nofre);
   uint32_t n = 0, l0 = cfi + (nprb <= 10 ? 1u : 0u);
-  for (uint32_t l = l0; l < 14; l++)
+  for (uint32_t l = l0; l < (uint32_t)o_nsym(cell); l++)
     for (uint32_t prb = 0; prb < nprb; prb++)
-      if (g->prb_idx[l / 7][prb])
+      if (g->prb_idx[l / (uint32_t)o_nslot(cell)][prb])
         for (uint32_t k = 12 * prb; k < 12 * prb + 12; k++)
           if (o_pdsch_re_ok(cell, sf_idx, l, k) && n < nofre) {
             rl[n] = (uint16_t)l;
@@ -165,7 +165,7 @@ int o_pdsch_demod(const o_cell_t* cell, uint32_t nof_rx, uint32_t sf_idx, uint32
   float inv_amp_a = 1.0f / rho_a, inv_amp_b = 1.0f / rho_b;
 #define GRID(rx, i) grid[((size_t)(rx) * 14 + rl[i]) * nre + rk[i]]
 #define CE(p, rx, i) ce[(((size_t)(p) * nof_rx + (rx)) * 14 + rl[i]) * nre + rk[i]]
-#define INVAMP(i) ((rl[i] == 0 || rl[i] == 4 || rl[i] == 7 || rl[i] == 11) ? inv_amp_b : inv_amp_a)
+#define INVAMP(i) (o_is_crs_sym01(cell, (int)rl[i]) ? inv_amp_b : inv_amp_a)   /* rho_B on the symbols that carry the CRS of ports 0, 1 (36.213 Table 5.2-2) */
   switch (g->tx_scheme) {
     case O_TX_PORT0: {
       int Qm = qm_cw[0];

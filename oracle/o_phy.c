@@ -151,8 +151,8 @@ void o_ofdm_rx(const o_cell_t* cell, const ocf_t* in, uint32_t dphi, ocf_t* grid
   }
   o_fft_twiddles(N, w);
   int pos = 0;
-  for (int l = 0; l < 14; l++) {
-    int cp = ((l % 7) == 0 ? 160 : 144) * N / 2048;
+  for (int l = 0; l < o_nsym(cell); l++) {
+    int cp = cell->cp ? 512 * N / 2048 : ((l % 7) == 0 ? 160 : 144) * N / 2048; /* 36.211 Table 6.12-1: extended CP = N/4 on every symbol, 12 x 1.25 N = 15 N */
     pos += cp;
     for (int n = 0; n < N; n++) {
       ocf_t x = in[pos + n];
@@ -175,11 +175,9 @@ void o_ofdm_rx(const o_cell_t* cell, const ocf_t* in, uint32_t dphi, ocf_t* grid
 }
 
 /* ---- CRS (36.211 6.10.1) ---- */
-/* ports 0, 1: symbols 0, 4 of both slots; ports 2, 3: symbol 1 of both slots */
-static const int crs_sym01[4] = {0, 4, 7, 11};
-static const int crs_sym23[2] = {1, 8};
+/* ports 0, 1: symbols 0 and N_symb - 3 of both slots (normal CP: 0, 4, 7, 11; extended: 0, 3, 6, 9); ports 2, 3: symbol 1 of both slots (1, 8 / 1, 7) */
 static int crs_nsym(int port) { return port < 2 ? 4 : 2; }
-static int crs_l(int port, int s) { return port < 2 ? crs_sym01[s] : crs_sym23[s]; }
+static int crs_l(const o_cell_t* cell, int port, int s) { return port < 2 ? o_crs_sym01(cell, s) : o_crs_sym23(cell, s); }
 
 static int crs_koff(const o_cell_t* cell, int port, int s)
 {
@@ -199,10 +197,10 @@ void o_crs_table(const o_cell_t* cell, uint32_t sf_idx, ocf_t* crs)
   uint8_t c[2 * 220];
   for (uint32_t p = 0; p < cell->nof_ports; p += 2) /* ports 0/1 share their symbols and sequences, and so do ports 2/3 */
     for (int s = 0; s < crs_nsym((int)p); s++) {
-      int l = crs_l((int)p, s);
-      uint32_t ns = 2 * sf_idx + (l >= 7 ? 1u : 0u);
-      uint32_t lslot = (uint32_t)(l % 7);
-      uint32_t cinit = 1024u * (7u * (ns + 1u) + lslot + 1u) * (2u * cell->id + 1u) + 2u * cell->id + 1u;
+      int l = crs_l(cell, (int)p, s);
+      uint32_t ns = 2 * sf_idx + (l >= o_nslot(cell) ? 1u : 0u);
+      uint32_t lslot = (uint32_t)(l % o_nslot(cell));
+      uint32_t cinit = 1024u * (7u * (ns + 1u) + lslot + 1u) * (2u * cell->id + 1u) + 2u * cell->id + (cell->cp ? 0u : 1u); /* N_CP = 1 normal, 0 extended */
       o_gold(cinit, c, 2 * 220);
       for (int m = 0; m < nref; m++) {
         int mp = m + 110 - (int)cell->nof_prb;
@@ -249,7 +247,7 @@ void o_chest(const o_cell_t* cell, uint32_t nof_rx, uint32_t sf_idx, const ocf_t
       for (int s = 0; s < S; s++) {
         int koff = crs_koff(cell, p, s);
         for (int m = 0; m < nref; m++)
-          ls[s * nref + m] = cmulconj(g[crs_l(p, s) * nre + 6 * m + koff], crs[(p * 4 + s) * nref + m]);
+          ls[s * nref + m] = cmulconj(g[crs_l(cell, p, s) * nre + 6 * m + koff], crs[(p * 4 + s) * nref + m]);
       }
       /* Gaussian smoothing across frequency, zero-padded edges (conv "same") */
       for (int s = 0; s < S; s++)
@@ -298,7 +296,7 @@ void o_chest(const o_cell_t* cell, uint32_t nof_rx, uint32_t sf_idx, const ocf_t
       ocf_t* c = ce + ((size_t)p * nof_rx + rx) * 14u * (size_t)nre;
       for (int s = 0; s < S; s++) {
         int koff = crs_koff(cell, p, s);
-        ocf_t* row = c + crs_l(p, s) * nre;
+        ocf_t* row = c + crs_l(cell, p, s) * nre;
         const ocf_t* pl = sm + s * nref;
         for (int k = 0; k < nre; k++) {
           int m = (k - koff) >= 0 ? (k - koff) / 6 : 0;
@@ -310,40 +308,45 @@ void o_chest(const o_cell_t* cell, uint32_t nof_rx, uint32_t sf_idx, const ocf_t
           row[k].i = pl[m].i + di * f;
         }
       }
+      const int nsym = o_nsym(cell);
       if (p >= 2) {
-        /* ports 2, 3 [srsRAN chest_dl.c interpolates its two pilot symbols the same way]: one line through symbols 1 and 8 for the whole subframe */
+        /* ports 2, 3 [srsRAN chest_dl.c interpolates its two pilot symbols the same way]: one line through symbols 1 and 8 (extended CP: 1 and 7) for the whole subframe */
+        const int la = crs_l(cell, p, 0), lb = crs_l(cell, p, 1);
+        const float dl_ = (float)(lb - la);
         for (int k = 0; k < nre; k++) {
-          ocf_t c1 = c[1 * nre + k], c8 = c[8 * nre + k];
-          float dr = (c8.r - c1.r) / 7.0f, di = (c8.i - c1.i) / 7.0f;
-          for (int l = 0; l < 14; l++) {
-            if (l == 1 || l == 8) continue;
-            c[l * nre + k].r = c1.r + dr * (float)(l - 1);
-            c[l * nre + k].i = c1.i + di * (float)(l - 1);
+          ocf_t c1 = c[la * nre + k], c8 = c[lb * nre + k];
+          float dr = (c8.r - c1.r) / dl_, di = (c8.i - c1.i) / dl_;
+          for (int l = 0; l < nsym; l++) {
+            if (l == la || l == lb) continue;
+            c[l * nre + k].r = c1.r + dr * (float)(l - la);
+            c[l * nre + k].i = c1.i + di * (float)(l - la);
           }
         }
         continue;
       }
-      /* time interpolation between pilot symbols 0,4,7,11; 12,13 continue the 7->11 slope */
+      /* time interpolation between the pilot symbols (normal CP 0, 4, 7, 11; extended 0, 3, 6, 9); the symbols behind the last pilot continue its slope */
+      const int q0 = crs_l(cell, p, 0), q1 = crs_l(cell, p, 1), q2 = crs_l(cell, p, 2), q3 = crs_l(cell, p, 3);
+      const float w01 = (float)(q1 - q0), w12 = (float)(q2 - q1), w23 = (float)(q3 - q2);
       for (int k = 0; k < nre; k++) {
-        ocf_t c0 = c[0 * nre + k], c4 = c[4 * nre + k], c7 = c[7 * nre + k], c11 = c[11 * nre + k];
-        float d01r = (c4.r - c0.r) / 4.0f, d01i = (c4.i - c0.i) / 4.0f;
-        float d12r = (c7.r - c4.r) / 3.0f, d12i = (c7.i - c4.i) / 3.0f;
-        float d23r = (c11.r - c7.r) / 4.0f, d23i = (c11.i - c7.i) / 4.0f;
-        for (int l = 1; l <= 3; l++) {
-          c[l * nre + k].r = c0.r + d01r * (float)l;
-          c[l * nre + k].i = c0.i + d01i * (float)l;
+        ocf_t c0 = c[q0 * nre + k], c4 = c[q1 * nre + k], c7 = c[q2 * nre + k], c11 = c[q3 * nre + k];
+        float d01r = (c4.r - c0.r) / w01, d01i = (c4.i - c0.i) / w01;
+        float d12r = (c7.r - c4.r) / w12, d12i = (c7.i - c4.i) / w12;
+        float d23r = (c11.r - c7.r) / w23, d23i = (c11.i - c7.i) / w23;
+        for (int l = q0 + 1; l < q1; l++) {
+          c[l * nre + k].r = c0.r + d01r * (float)(l - q0);
+          c[l * nre + k].i = c0.i + d01i * (float)(l - q0);
         }
-        for (int l = 5; l <= 6; l++) {
-          c[l * nre + k].r = c4.r + d12r * (float)(l - 4);
-          c[l * nre + k].i = c4.i + d12i * (float)(l - 4);
+        for (int l = q1 + 1; l < q2; l++) {
+          c[l * nre + k].r = c4.r + d12r * (float)(l - q1);
+          c[l * nre + k].i = c4.i + d12i * (float)(l - q1);
         }
-        for (int l = 8; l <= 10; l++) {
-          c[l * nre + k].r = c7.r + d23r * (float)(l - 7);
-          c[l * nre + k].i = c7.i + d23i * (float)(l - 7);
+        for (int l = q2 + 1; l < q3; l++) {
+          c[l * nre + k].r = c7.r + d23r * (float)(l - q2);
+          c[l * nre + k].i = c7.i + d23i * (float)(l - q2);
         }
-        for (int l = 12; l <= 13; l++) {
-          c[l * nre + k].r = c11.r + d23r * (float)(l - 11);
-          c[l * nre + k].i = c11.i + d23i * (float)(l - 11);
+        for (int l = q3 + 1; l < nsym; l++) {
+          c[l * nre + k].r = c11.r + d23r * (float)(l - q3);
+          c[l * nre + k].i = c11.i + d23i * (float)(l - q3);
         }
       }
     }
@@ -372,8 +375,9 @@ void o_chest(const o_cell_t* cell, uint32_t nof_rx, uint32_t sf_idx, const ocf_t
 /* ---- REGs (36.211 6.2.4), PCFICH (6.7.4), PHICH (6.9.3), PDCCH mapping (6.8.5) ---- */
 static int reg_width(const o_cell_t* cell, int l)
 {
-  /* symbol 0 always leaves the CRS positions of two ports out; with four ports symbol 1 carries the CRS of ports 2, 3 */
-  return (l == 0 || (l == 1 && cell->nof_ports == 4)) ? 6 : 4;
+  /* symbol 0 always leaves the CRS positions of two ports out; with four ports symbol 1 carries the CRS of ports 2, 3; with the extended CP symbol 3
+   * (the fourth control symbol of a cell of at most 10 PRB) is the slot's second CRS symbol (36.211 6.2.4) */
+  return (l == 0 || (l == 1 && cell->nof_ports == 4) || (l == 3 && cell->cp)) ? 6 : 4;
 }
 
 void o_regs_init(const o_cell_t* cell, o_regs_t* regs)
@@ -391,7 +395,7 @@ void o_regs_init(const o_cell_t* cell, o_regs_t* regs)
   }
   /* PHICH, normal duration: all in symbol 0; Ng/6 */
   int ng = (int)((cell->phich_ng_x6 * (uint32_t)nprb + 47u) / 48u); /* ceil(Ng * nprb / 8) with Ng = x/6 */
-  regs->ngroups_phich = (uint32_t)ng;
+  regs->ngroups_phich = (uint32_t)(cell->cp ? 2 * ng : ng); /* extended CP: twice the groups, two of them per mapping unit (36.211 6.9, 6.9.3: m' = m / 2) - the REGs are the same */
   int navail = 0;
   int* avail = (int*)malloc(sizeof(int) * (size_t)n0);
   for (int i = 0; i < n0; i++)

@@ -21,7 +21,8 @@ def _ensure(path, mkdir):
 
 
 class OCell(C.Structure):
-    _fields_ = [("nof_prb", C.c_uint32), ("nof_ports", C.c_uint32), ("id", C.c_uint32), ("phich_ng_x6", C.c_uint32), ("pusch_hop_offset", C.c_uint32)]
+    _fields_ = [("nof_prb", C.c_uint32), ("nof_ports", C.c_uint32), ("id", C.c_uint32), ("phich_ng_x6", C.c_uint32), ("pusch_hop_offset", C.c_uint32),
+                ("cp", C.c_uint32)]  # 0 = normal cyclic prefix, 1 = extended
 
 
 class OWorkerCfg(C.Structure):
@@ -51,7 +52,7 @@ class TxgCfg(C.Structure):
                 ("sib_period", C.c_uint32), ("rar_period", C.c_uint32), ("paging_period", C.c_uint32),
                 ("start_tti", C.c_uint32), ("fixed_L", C.c_uint32), ("pct_rv", C.c_uint32), ("pct_cqi_req", C.c_uint32), ("pct_hop", C.c_uint32), ("pusch_hop_offset", C.c_uint32),
                 ("msg4_period", C.c_uint32), ("msg4_p_a_idx", C.c_uint32), ("si_len", C.c_uint32 * 2), ("si_msg", (C.c_uint8 * 96) * 2),
-                ("pg_len", C.c_uint32), ("pg_msg", C.c_uint8 * 96), ("pct_harq", C.c_uint32)]
+                ("pg_len", C.c_uint32), ("pg_msg", C.c_uint8 * 96), ("pct_harq", C.c_uint32), ("cp", C.c_uint32)]
 
 
 class TxgPdu(C.Structure):
@@ -153,6 +154,8 @@ def scenario(name, seed=1, **over):
                 pct_256qam=0, mcs_min=0, mcs_max=28, sib_period=1, rar_period=0, paging_period=0, start_tti=0, fixed_L=0, pct_rv=0, pct_cqi_req=0, pct_hop=0, pusch_hop_offset=0, msg4_period=0, msg4_p_a_idx=4)
     if "pct_harq" in over:  # (only present when asked for: the scenario dict of the gated cfg3 stream is part of cached file keys)
         base["pct_harq"] = 0
+    if "cp" in over:  # extended cyclic prefix (cp = 1): same rule
+        base["cp"] = 0
     presets = {
         # config 1: 10 MHz, single RNTI, TM1 QPSK, 1 port / 1 rx
         "cfg1": dict(nof_prb=50, nof_ports=1, nof_rx=1, snr_db=20.0, cfo_hz=300.0, n_rnti=1, dl_min=1, dl_max=1, ul_min=0,
@@ -256,9 +259,9 @@ def oracle_trace():
 
 class OracleWorker:
     def __init__(self, nof_prb, nof_ports, cell_id, nof_rx, phich_ng_x6=1, threshold=5, split_ratio=0.99, skip_secondary=0,
-                 mcs_tracking_mode=1, max_turbo_iter=12, enable_shortcut=1):
+                 mcs_tracking_mode=1, max_turbo_iter=12, enable_shortcut=1, cp=0):
         self.lib = oracle()
-        self.cfg = OWorkerCfg(OCell(nof_prb, nof_ports, cell_id, phich_ng_x6), nof_rx, threshold, split_ratio, skip_secondary,
+        self.cfg = OWorkerCfg(OCell(nof_prb, nof_ports, cell_id, phich_ng_x6, 0, cp), nof_rx, threshold, split_ratio, skip_secondary,
                               mcs_tracking_mode, max_turbo_iter, enable_shortcut)
         self.h = self.lib.o_worker_new(C.byref(self.cfg))
         assert self.h

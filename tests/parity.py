@@ -39,6 +39,7 @@ def gen_capture(sc, n, threads=None, **txkw):
 def run_oracle(sc, tti0, iq, update_meta_period=0, taps=True, mcs_update_interval=None, trace=False, harq_mode=0, **okw):
     """trace=True: the oracle's stage-C recorder runs over these subframes; read it with lsn_testlib.oracle_trace() afterwards"""
     oracle_trace_enable(trace)
+    okw.setdefault("cp", sc.get("cp", 0))
     ow = OracleWorker(sc["nof_prb"], sc["nof_ports"], sc["cell_id"], sc["nof_rx"], sc["phich_ng_x6"], **okw)
     if harq_mode:
         ow.set_harq(harq_mode)

@@ -25,7 +25,7 @@ def _run(scn, nsf, seed=1, batch=16, update_meta_period=0, exact_iters=False, **
         phy = la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=batch)
     finally:
         os.environ.pop("LSN_NO_CB_SKIP", None)
-    assert phy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"], {1: 0, 3: 1, 6: 2, 12: 3}[sc["phich_ng_x6"]])
+    assert phy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"], {1: 0, 3: 1, 6: 2, 12: 3}[sc["phich_ng_x6"]], cp=sc.get("cp", 0))
     phy.set_stage_c_taps(True)
     bad, badc, ncall, ncb, it_o, it_g = [], [], 0, 0, 0, 0
     for base in range(0, nsf, batch):
@@ -92,6 +92,33 @@ def test_four_crs_ports_tm3_tm4_grants_are_found_and_not_decoded():
     """format 2 / 2A grants on a four-port cell ask for spatial multiplexing: accepted by the search at their four-port sizes, no decode job, no
     record - the oracle's (and srsRAN's) behaviour; the other grants of the capture decode as usual"""
     _run("cfg3", 40, seed=16, nof_ports=4, nof_prb=50, n_rnti=20, update_meta_period=20)
+
+
+def test_extended_cyclic_prefix_25_and_100_prb():
+    """extended CP (round-4 review, missing 1; the reference hands whatever cell its search found to srsran_ue_dl_set_cell, SubframeWorker.cc:102):
+    12-symbol subframes with a CP of N / 4, CRS on symbols 0 / 3 of each slot (ports 2, 3: symbol 1), N_CP = 0 in their sequences, the time
+    interpolation between pilots 0, 3, 6, 9, the PDSCH RE masks (PSS / SSS on symbols 5 / 4, PBCH on 6 - 9), rho_B symbols - every stage-A tap,
+    every stage-C tap and the record stream identical to the oracle's, TM2 / TM3 / TM4 up to 256QAM at 100 PRB"""
+    n = _run("small", 40, seed=31, cp=1)
+    assert n > 40
+    n = _run("cfg3", 40, seed=32, cp=1, n_rnti=40, update_meta_period=20)
+    assert n > 150
+
+
+def test_extended_cyclic_prefix_ports_bandwidths_and_four_control_symbols():
+    """one and four CRS ports, one rx antenna, 6 PRB with CFI 3 (four control symbols: symbol 3 carries CRS -> 6-RE REGs), 15 / 50 / 75 PRB"""
+    _run("small", 20, seed=33, cp=1, nof_prb=6, cfi=3, dl_min=1, dl_max=1, n_rnti=2)
+    _run("small", 20, seed=34, cp=1, nof_prb=6, cfi=0, nof_ports=4, dl_min=1, dl_max=1, n_rnti=2)
+    _run("small", 20, seed=35, cp=1, nof_prb=50, nof_ports=1, nof_rx=1, cfo_hz=200.0)
+    _run("small", 20, seed=36, cp=1, nof_prb=75, nof_ports=4, cfi=0, cell_id=77)
+    _run("small", 20, seed=37, cp=1, nof_prb=15, cfi=0, cell_id=500, phich_ng_x6=12, snr_db=12.0)
+
+
+def test_extended_cp_is_refused_where_it_is_not_built():
+    """UL_MODE engines and the PBCH helper: lsn_phy_set_cell / lsn_phy_mib_decode return LSN_ERROR_INVALID_INPUTS instead of decoding with the wrong symbol grid"""
+    phy = la.Phy(nof_rx_antennas=2, sniffer_mode=1)
+    assert not phy.setCell(25, 2, 1, cp=1)
+    phy.close()
 
 
 def test_worker_pool_api_matches_oracle():

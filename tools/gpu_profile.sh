@@ -7,8 +7,8 @@
 # counters, FETCH_SIZE, WRITE_SIZE; never combined with other trace domains).  LSN_PROFILE_SKIP_SQ=1 leaves the two SQ passes out (kernel trace + HBM traffic only).
 set -u
 TAG=${1:-prof}; shift || true
-STEPS=${LSN_PROFILE_STEPS:-20}; WARM=${LSN_PROFILE_WARMUP:-5}; STEP_SF=${LSN_PROFILE_STEP_SF:-4000}; BATCH=${LSN_PROFILE_BATCH:-400}
-ARGS=${*:---gpus 1 --steps $STEPS --warmup $WARM --step-sf $STEP_SF --batch $BATCH --no-cpu --no-legs}
+STEPS=${LSN_PROFILE_STEPS:-20}; WARM=${LSN_PROFILE_WARMUP:-5}; STEP_SF=${LSN_PROFILE_STEP_SF:-20000}; BATCH=${LSN_PROFILE_BATCH:-400}
+ARGS=${*:---gpus 1 --steps $STEPS --warmup $WARM --step-sf $STEP_SF --batch $BATCH --no-cpu --no-legs ${LSN_PROFILE_EXTRA:-}}   # LSN_PROFILE_EXTRA="--workload cfg3_at_16_dB_snr": the second operating point
 TIMED_SF=$((STEPS * STEP_SF)); ALL_SF=$(((STEPS + WARM) * STEP_SF)); TIMED_CHUNKS=$((TIMED_SF / BATCH))
 OUT=gpurun_out
 mkdir -p $OUT

@@ -4,8 +4,8 @@
 # "every kernel alone" (roofline.gpu_saturation) is only that on one queue.  Instruction counts do not depend on it.   tools/gpu_profile_sq_serial.sh <tag>
 set -u
 TAG=${1:-prof}
-STEPS=20; WARM=5; STEP_SF=4000; BATCH=400
-ARGS="--gpus 1 --steps $STEPS --warmup $WARM --step-sf $STEP_SF --batch $BATCH --no-cpu --no-legs"
+STEPS=${LSN_PROFILE_STEPS:-20}; WARM=${LSN_PROFILE_WARMUP:-5}; STEP_SF=${LSN_PROFILE_STEP_SF:-20000}; BATCH=${LSN_PROFILE_BATCH:-400}
+ARGS="--gpus 1 --steps $STEPS --warmup $WARM --step-sf $STEP_SF --batch $BATCH --no-cpu --no-legs ${LSN_PROFILE_EXTRA:-}"
 ALL_SF=$(((STEPS + WARM) * STEP_SF))
 OUT=gpurun_out; mkdir -p $OUT; export TMPDIR=/tmp; R=$(pwd)
 export GPU_MAX_HW_QUEUES=1

@@ -243,6 +243,7 @@ typedef struct {
   uint32_t pg_len;        // PCCH message sent with the P-RNTI (paging_period != 0) when not 0, else random bytes
   uint8_t pg_msg[96];
   uint32_t pct_harq;      // share of C-RNTI downlink grants that are sent again 8 subframes later (same HARQ process, NDI not toggled, next redundancy version of 0 2 3 1, same payload)
+  uint32_t cp;            // 0 = normal cyclic prefix, 1 = extended (6 symbols per slot, CP = N / 4; 36.211 Table 6.2.3-1 / 6.12-1)
 } txg_cfg_t;
 
 typedef struct { uint16_t rnti; uint8_t format, L; uint16_t ncce; uint32_t tti; uint32_t nbytes; uint32_t offset; uint8_t tb, mod, table256, is_ul; uint32_t nof_prb; uint32_t mcs; uint32_t cqi_req; uint32_t hop_bits_plus1; /* DCI 0: 0 = no hopping, else 1 + hopping bits */ } txg_pdu_t;
@@ -277,6 +278,11 @@ struct txg {
 
 static int fft_size(uint32_t nprb) { switch (nprb) { case 6: return 128; case 15: return 256; case 25: return 512; case 50: return 1024; case 75: return 1536; case 100: return 2048; default: return -1; } }
 
+// symbols per slot / subframe and the CRS symbols of ports 0, 1 (0 and N_symb - 3 of both slots) for the cell's cyclic prefix
+static inline int nslot_of(const txg_cfg_t& c) { return c.cp ? 6 : 7; }
+static inline int nsym_of(const txg_cfg_t& c) { return c.cp ? 12 : 14; }
+static inline bool is_crs01(const txg_cfg_t& c, int l) { const int q = l % nslot_of(c); return q == 0 || q == nslot_of(c) - 3; }
+
 static void build_regs(txg* g) {
   int nprb = g->c.nof_prb, nre = 12 * nprb, n0 = nre / 6, id = g->c.cell_id;
   std::vector<uint8_t> used0(n0, 0);
@@ -291,7 +297,7 @@ static void build_regs(txg* g) {
     int nsym = cfi + (nprb <= 10 ? 1 : 0);
     std::vector<uint16_t> tk; std::vector<uint8_t> tl;
     for (int k = 0; k < nre; k++) for (int l = 0; l < nsym; l++) {
-      int w = (l == 0 || (l == 1 && g->c.nof_ports == 4)) ? 6 : 4;  // symbol 1 carries the CRS of ports 2, 3
+      int w = (l == 0 || (l == 1 && g->c.nof_ports == 4) || (l == 3 && g->c.cp)) ? 6 : 4;  // symbol 1 carries the CRS of ports 2, 3; extended CP: symbol 3 is a CRS symbol
       if (k % w) continue;
       if (l == 0 && used0[k / 6]) continue;
       tk.push_back((uint16_t)k); tl.push_back((uint8_t)l);
@@ -456,15 +462,16 @@ static void ss_candidates(uint32_t ncce, uint32_t sf, uint16_t rnti, int l, bool
 
 static bool pdsch_re_ok(const txg* g, uint32_t sf, int l, int k) {
   int nprb = g->c.nof_prb, id = g->c.cell_id;
-  if (g->c.nof_ports == 4 && (l == 1 || l == 8) && k % 3 == id % 3) return false;
-  if (l == 0 || l == 4 || l == 7 || l == 11) {
+  const int nsl = nslot_of(g->c), lq = l % nsl;
+  if (g->c.nof_ports == 4 && lq == 1 && k % 3 == id % 3) return false;
+  if (is_crs01(g->c, l)) {
     if (g->c.nof_ports >= 2) { if (k % 3 == id % 3) return false; }
-    else { int v = (l == 0 || l == 7) ? 0 : 3; if (k % 6 == (v + id % 6) % 6) return false; }
+    else { int v = lq == 0 ? 0 : 3; if (k % 6 == (v + id % 6) % 6) return false; }
   }
   int kc0 = 6 * nprb - 36;
   if (k >= kc0 && k < kc0 + 72) {
-    if ((sf == 0 || sf == 5) && (l == 5 || l == 6)) return false;
-    if (sf == 0 && l >= 7 && l <= 10) return false;
+    if ((sf == 0 || sf == 5) && (l == nsl - 2 || l == nsl - 1)) return false;
+    if (sf == 0 && l >= nsl && l <= nsl + 3) return false;
   }
   return true;
 }
@@ -484,11 +491,12 @@ extern "C" int txg_next(txg_t* g, float* iq, txg_pdu_t* pdus, int max_pdus, uint
   int npdu = 0, poff = 0;
 
   // ---- CRS ----
-  static const int crs_sym[4] = {0, 4, 7, 11};
+  const int nsl = nslot_of(c), nsym = nsym_of(c);
+  const uint32_t ncp = c.cp ? 0u : 1u;  // N_CP of the CRS sequence initialisation (36.211 6.10.1.1)
   for (int s = 0; s < 4; s++) {
-    int l = crs_sym[s];
-    uint32_t ns = 2 * sf + (l >= 7), lsl = l % 7;
-    bits_t cc = gold(1024u * (7u * (ns + 1) + lsl + 1) * (2u * id + 1) + 2u * id + 1, 440);
+    int l = (s >> 1) * nsl + ((s & 1) ? nsl - 3 : 0);
+    uint32_t ns = 2 * sf + (l >= nsl), lsl = l % nsl;
+    bits_t cc = gold(1024u * (7u * (ns + 1) + lsl + 1) * (2u * id + 1) + 2u * id + ncp, 440);
     for (int p = 0; p < std::min(P, 2); p++) {
       int v = p == 0 ? ((s & 1) ? 3 : 0) : ((s & 1) ? 0 : 3), koff = (v + id % 6) % 6;
       for (int m = 0; m < 2 * nprb; m++) {
@@ -499,9 +507,9 @@ extern "C" int txg_next(txg_t* g, float* iq, txg_pdu_t* pdus, int max_pdus, uint
   }
   if (P == 4)  // ports 2, 3: symbol 1 of both slots, v = 3 (n_s mod 2) / 3 + 3 (n_s mod 2)
     for (int s = 0; s < 2; s++) {
-      int l = s ? 8 : 1;
+      int l = s * nsl + 1;
       uint32_t ns = 2 * sf + (uint32_t)s;
-      bits_t cc = gold(1024u * (7u * (ns + 1) + 1 + 1) * (2u * id + 1) + 2u * id + 1, 440);
+      bits_t cc = gold(1024u * (7u * (ns + 1) + 1 + 1) * (2u * id + 1) + 2u * id + ncp, 440);
       for (int p = 2; p < 4; p++) {
         int v = (p == 2 ? 0 : 3) + 3 * s, koff = (v + id % 6) % 6;
         for (int m = 0; m < 2 * nprb; m++) {
@@ -520,7 +528,7 @@ extern "C" int txg_next(txg_t* g, float* iq, txg_pdu_t* pdus, int max_pdus, uint
   };
   auto map_quad = [&](int k0, int l, const cf* x) {  // 4 symbols onto the data REs of a REG
     int kk[4], n = 0;
-    if (l == 0 || (l == 1 && P == 4)) { for (int k = k0; k < k0 + 6; k++) if (k % 3 != id % 3) kk[n++] = k; }
+    if (l == 0 || (l == 1 && P == 4) || (l == 3 && c.cp)) { for (int k = k0; k < k0 + 6; k++) if (k % 3 != id % 3) kk[n++] = k; }
     else for (int k = k0; k < k0 + 4; k++) kk[n++] = k;
     if (P == 1) { for (int i = 0; i < 4; i++) grid[0][l * nre + kk[i]] = x[i]; }
     else for (int i = 0; i < 4; i += 2) put_pair(i / 2, x[i], x[i + 1], l, kk[i], l, kk[i + 1], 1.0f);
@@ -545,15 +553,18 @@ extern "C" int txg_next(txg_t* g, float* iq, txg_pdu_t* pdus, int max_pdus, uint
     put(mib, (sfn >> 2) & 0xFF, 8);
     put(mib, 0, 10);
     crc_attach(mib, 0x11021, 16, P == 1 ? 0x0000u : (P == 2 ? 0xFFFFu : 0x5555u));
-    bits_t e = rm_conv_tx(conv_encode(mib), 1920), scr = gold((uint32_t)id, 1920), q(480);
-    for (int i = 0; i < 480; i++) q[i] = e[480 * (sfn & 3) + i] ^ scr[480 * (sfn & 3) + i];
-    std::vector<cf> sy; modulate(q, 2, sy);
+    // normal CP: 240 symbols per radio frame (CRS positions of four ports left out of symbols 0, 1 of slot 1), E = 1920 bits per 40 ms;
+    // extended CP: symbol 3 of the slot carries CRS as well -> 216 symbols, E = 1728 (36.211 6.6.4, 36.212 5.3.1.3)
     std::vector<std::pair<int, int>> pos;
-    for (int l = 7; l <= 10; l++)
+    for (int l = nsl; l <= nsl + 3; l++)
       for (int k = 6 * nprb - 36; k < 6 * nprb + 36; k++)
-        if (!(l <= 8 && k % 3 == id % 3)) pos.push_back({l, k});
-    if (P == 1) { for (int i = 0; i < 240; i++) grid[0][pos[i].first * nre + pos[i].second] = sy[i]; }
-    else for (int i = 0; i < 240; i += 2) put_pair(i / 2, sy[i], sy[i + 1], pos[i].first, pos[i].second, pos[i + 1].first, pos[i + 1].second, 1.0f);
+        if (!((l <= nsl + 1 || (c.cp && l == nsl + 3)) && k % 3 == id % 3)) pos.push_back({l, k});
+    const int nps = (int)pos.size(), E4 = 2 * nps;
+    bits_t e = rm_conv_tx(conv_encode(mib), 4 * E4), scr = gold((uint32_t)id, 4 * E4), q(E4);
+    for (int i = 0; i < E4; i++) q[i] = e[E4 * (sfn & 3) + i] ^ scr[E4 * (sfn & 3) + i];
+    std::vector<cf> sy; modulate(q, 2, sy);
+    if (P == 1) { for (int i = 0; i < nps; i++) grid[0][pos[i].first * nre + pos[i].second] = sy[i]; }
+    else for (int i = 0; i < nps; i += 2) put_pair(i / 2, sy[i], sy[i + 1], pos[i].first, pos[i].second, pos[i + 1].first, pos[i + 1].second, 1.0f);
   }
 
   // ---- PSS / SSS (36.211 6.11, FDD): symbols 6 / 5 of subframes 0 and 5, 62 carriers around DC, antenna port 0 ----
@@ -573,7 +584,7 @@ extern "C" int txg_next(txg_t* g, float* iq, txg_pdu_t* pdus, int max_pdus, uint
       const int k = 6 * nprb - 31 + n;
       const int a = n < 31 ? n * (n + 1) : (n + 1) * (n + 2);
       const double ph = -M_PI * u * (double)(a % 126) / 63.0;
-      grid[0][6 * nre + k] = cf((float)std::cos(ph), (float)std::sin(ph));
+      grid[0][(nsl - 1) * nre + k] = cf((float)std::cos(ph), (float)std::sin(ph));   // PSS: last symbol of slots 0 and 10
       const int i = n / 2;
       const int s0 = 1 - 2 * xs[(i + m0) % 31], s1 = 1 - 2 * xs[(i + m1) % 31];
       const int c0 = 1 - 2 * xc[(i + n2) % 31], c1 = 1 - 2 * xc[(i + n2 + 3) % 31];
@@ -581,7 +592,7 @@ extern "C" int txg_next(txg_t* g, float* iq, txg_pdu_t* pdus, int max_pdus, uint
       int d;
       if (n % 2 == 0) d = (sf == 0 ? s0 : s1) * c0;
       else d = sf == 0 ? s1 * c1 * z0 : s0 * c1 * z1;
-      grid[0][5 * nre + k] = cf((float)d, 0.0f);
+      grid[0][(nsl - 2) * nre + k] = cf((float)d, 0.0f);   // SSS: the symbol in front of it
     }
   }
 
@@ -608,7 +619,7 @@ extern "C" int txg_next(txg_t* g, float* iq, txg_pdu_t* pdus, int max_pdus, uint
   uint32_t Prbg = ra_P(nprb), nrbg = (nprb + Prbg - 1) / Prbg;
   int next_rbg = 0;  // RBGs handed out left to right
 
-  auto count_re = [&](const std::vector<int>& prbs) { int n = 0; for (int l = l0; l < 14; l++) for (int p : prbs) for (int k = 12 * p; k < 12 * p + 12; k++) n += pdsch_re_ok(g, sf, l, k); return n; };
+  auto count_re = [&](const std::vector<int>& prbs) { int n = 0; for (int l = l0; l < nsym; l++) for (int p : prbs) for (int k = 12 * p; k < 12 * p + 12; k++) n += pdsch_re_ok(g, sf, l, k); return n; };
   auto set_tbs = [&](Grant& gr, int nre_g) {
     for (int i = 0; i < gr.ntb; i++) {
       int mcs = (int)gr.mcs[i];
@@ -859,7 +870,7 @@ extern "C" int txg_next(txg_t* g, float* iq, txg_pdu_t* pdus, int max_pdus, uint
     if (gr.is_ul) continue;
     while (pdu_i < npdu && !(pdus[pdu_i].rnti == gr.rnti && !pdus[pdu_i].is_ul)) pdu_i++;
     std::vector<std::pair<int, int>> res;
-    for (int l = l0; l < 14; l++) for (int p : gr.prbs) for (int k = 12 * p; k < 12 * p + 12; k++) if (pdsch_re_ok(g, sf, l, k)) res.push_back({l, k});
+    for (int l = l0; l < nsym; l++) for (int p : gr.prbs) for (int k = 12 * p; k < 12 * p + 12; k++) if (pdsch_re_ok(g, sf, l, k)) res.push_back({l, k});
     int nre_g = (int)res.size();
     float rho_a = 1.0f;
     for (auto& u : g->ues) if (u.rnti == gr.rnti) rho_a = std::pow(10.0f, u.p_a_db / 20.0f);
@@ -876,7 +887,7 @@ extern "C" int txg_next(txg_t* g, float* iq, txg_pdu_t* pdus, int max_pdus, uint
     pdu_i += gr.ntb;
     for (int i = 0; i < nre_g; i++) {
       int l = res[i].first, k = res[i].second;
-      float amp = rho_a * ((l == 0 || l == 4 || l == 7 || l == 11) ? rho_b : 1.0f);  // 36.213 5.2: rho_A from the UE's p-a, rho_B / rho_A from p-b = 1
+      float amp = rho_a * (is_crs01(c, l) ? rho_b : 1.0f);  // 36.213 5.2: rho_A from the UE's p-a, rho_B / rho_A from p-b = 1
       cf* g0 = &grid[0][l * nre + k];
       cf* g1 = P > 1 ? &grid[1][l * nre + k] : nullptr;
       switch (gr.scheme) {
@@ -903,8 +914,8 @@ extern "C" int txg_next(txg_t* g, float* iq, txg_pdu_t* pdus, int max_pdus, uint
   std::vector<std::complex<double>> buf(N);
   for (int p = 0; p < P; p++) {
     int pos = 0;
-    for (int l = 0; l < 14; l++) {
-      int cp = ((l % 7) == 0 ? 160 : 144) * N / 2048;
+    for (int l = 0; l < nsym; l++) {
+      int cp = c.cp ? 512 * N / 2048 : ((l % 7) == 0 ? 160 : 144) * N / 2048;
       for (auto& v : buf) v = 0;
       for (int k = 0; k < nre; k++) { int bin = k < nre / 2 ? N - nre / 2 + k : k - nre / 2 + 1; buf[bin] = grid[p][l * nre + k]; }
       fft_d(buf, true);
