@@ -23,11 +23,13 @@ except Exception as ex:
 PY
   tail -1 $OUT
 }
+WL=""
+case "$*" in *WORKLOAD=16*) WL="--workload cfg3_at_16_dB_snr";; esac
 for v in "$@"; do
-  one "base" "LSN_X=1" ""
+  one "base" "LSN_X=1" "$WL"
   extra=""
   case "$v" in *BATCH=*) b=${v##*BATCH=}; b=${b%% *}; extra="--batch $b";; esac
-  one "$v" "$v" "$extra"
+  one "$v" "$v" "$extra $WL"
 done
-one "base" "LSN_X=1" ""
+one "base" "LSN_X=1" "$WL"
 cat $OUT
