@@ -224,7 +224,6 @@ int Engine::setCell(const lsn_cell_t& c)
 {
   static const uint32_t ng_x6[4] = {1, 3, 6, 12};
   if (c.cp > 1 || c.frame_type != 0 || c.phich_length != 0 || c.phich_resources > 3) return LSN_ERROR_INVALID_INPUTS;
-  if (c.cp == 1 && cfg.sniffer_mode == 1) return LSN_ERROR_INVALID_INPUTS;  // extended CP: downlink path only (the uplink's 10-symbol PUSCH is not built)
   if ((c.nof_ports != 1 && c.nof_ports != 2 && c.nof_ports != 4) || c.id > 503) return LSN_ERROR_INVALID_INPUTS;
   switch (c.nof_prb) { case 6: case 15: case 25: case 50: case 75: case 100: break; default: return LSN_ERROR_INVALID_INPUTS; }
   cpu_set_t saved_mask;

@@ -154,7 +154,7 @@ int Engine::buildUlTables(const lsn_ul_cfg_t& u)
     gold_sequence(((cell.id / 30u) << 5) + fss, c.data(), (int)c.size());
     for (uint32_t ns = 0; ns < 20; ns++) {
       uint32_t npn = 0;
-      for (int i = 0; i < 8; i++) npn += (uint32_t)c[8 * 7 * ns + i] << i;
+      for (int i = 0; i < 8; i++) npn += (uint32_t)c[8 * (int)cell.nslot() * ns + i] << i;   // n_PN(ns) = sum c(8 N_symb^UL ns + i) 2^i (36.211 5.5.2.1.1)
       ul_npn[ns] = npn;
     }
     cell.pusch_hop_offset = u.hopping_offset;  // n_rb_ho of the DCI 0 -> grant conversion from now on (SubframeWorker.cc:271-277)
@@ -230,13 +230,14 @@ void Engine::puschDecodeGrid(const cf32* d_grid, uint32_t nsf, uint32_t start_tt
                     (g.mod == 2 || g.mod == 4 || g.mod == 6 || g.mod == 8) && ul_off[g.L_prb] >= 0 && g.rv >= 0 && g.rv < 4;
     if (!ok) continue;
     const uint32_t M = 12 * g.L_prb, sf_idx = (start_tti + g.sf) % 10;
+    const uint32_t C = 2 * (cell.nslot() - 1);  // N_symb^PUSCH: 12 SC-FDMA data symbols per subframe, 10 with the extended CP (= columns of the channel interleaver)
     CbSegm s;
     if (!cbsegm((int)g.tbs, s)) continue;
     // control resources Q' = min(ceil(O M_sc N_symb beta / sum K_r), cap) (36.212 5.2.2.6), beta in eighths
     const long long sumK = (long long)s.Cp * s.Kp + (long long)s.Cm * s.Km;
     auto qprime = [&](uint32_t O, long long beta8, uint32_t cap) -> uint32_t {
       if (!O) return 0u;
-      const long long q = ((long long)O * M * 12 * beta8 + 8 * sumK - 1) / (8 * sumK);
+      const long long q = ((long long)O * M * C * beta8 + 8 * sumK - 1) / (8 * sumK);
       return (uint32_t)std::min<long long>(q, cap);
     };
     if (g.nof_ack > 2 || g.ri_bits > 2 || g.cqi_bits > 64) continue;
@@ -246,9 +247,9 @@ void Engine::puschDecodeGrid(const cf32* d_grid, uint32_t nsf, uint32_t start_tt
     if (ia > 15 || ic > 15 || ir > 15) continue;
     if ((g.nof_ack && !lsn_beta_ack8[ia]) || (g.ri_bits && !lsn_beta_ri8[ir]) || (g.cqi_bits && !lsn_beta_cqi8[ic])) continue;  // reserved index
     const uint32_t q_ack = qprime(g.nof_ack, lsn_beta_ack8[ia], 4 * M), q_ri = qprime(g.ri_bits, lsn_beta_ri8[ir], 4 * M);
-    const uint32_t q_cqi = g.cqi_bits ? qprime(g.cqi_bits + (g.cqi_bits > 11 ? 8u : 0u), lsn_beta_cqi8[ic], 12 * M - q_ri) : 0u;
-    if (q_ri + q_cqi >= 12 * M) continue;
-    const int G = (int)((12 * M - q_ri - q_cqi) * g.mod);
+    const uint32_t q_cqi = g.cqi_bits ? qprime(g.cqi_bits + (g.cqi_bits > 11 ? 8u : 0u), lsn_beta_cqi8[ic], C * M - q_ri) : 0u;
+    if (q_ri + q_cqi >= C * M) continue;
+    const int G = (int)((C * M - q_ri - q_cqi) * g.mod);
     LsnUlGrantDev d{};
     d.sf = g.sf; d.n_prb = g.n_prb; d.n_prb2 = n_prb2; d.L_prb = g.L_prb; d.qm = g.mod;
     for (uint32_t sl = 0; sl < 2; sl++) d.ncs[sl] = (n_dmrs1[ul_cfg.cyclic_shift & 7] + n_dmrs2[g.n_dmrs & 7] + ul_npn[2 * sf_idx + sl]) % 12u;
@@ -392,7 +393,7 @@ long Engine::tapUl(int what, uint32_t index, void* out, size_t cap)
     for (size_t i = 0; i < ul_last_idx.size(); i++)
       if ((uint32_t)ul_last_idx[i] == index) d = &ul_last_gd[i];
     if (!d) return LSN_ERROR_INVALID_INPUTS;
-    n = ((size_t)12 * 12 * d->L_prb - d->q_ri - d->q_cqi) * d->qm * sizeof(int16_t); src = runner_u.d_llr16 + d->llr_off;
+    n = ((size_t)2 * (cell.nslot() - 1) * 12 * d->L_prb - d->q_ri - d->q_cqi) * d->qm * sizeof(int16_t); src = runner_u.d_llr16 + d->llr_off;
   } else return LSN_ERROR_INVALID_INPUTS;
   if (n > cap) return LSN_ERROR_INVALID_INPUTS;
   if (hipMemcpy(out, src, n, hipMemcpyDeviceToHost) != hipSuccess) return LSN_ERROR;

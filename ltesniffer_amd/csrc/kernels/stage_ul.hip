@@ -49,10 +49,11 @@ __global__ __launch_bounds__(256) void k_ul_fft(LsnCellDev c, const cf32* __rest
   const int N = (int)c.N, lgN = (int)c.lgN, tid = threadIdx.x;
   cf32* a = (cf32*)smem;
   cf32* w = a + N;
-  const int l = blockIdx.x % 14, sf = blockIdx.x / 14;
+  const int nsym = (int)c.nsym;  // 14, or 12 with the extended cyclic prefix (rows 12, 13 of the grid stay zero)
+  const int l = blockIdx.x % nsym, sf = blockIdx.x / nsym;
   const int cp0 = 160 * N / 2048, cp1 = 144 * N / 2048;
   const int slot = l / 7, ls = l % 7;
-  const int pos = slot * (cp0 + 6 * cp1 + 7 * N) + cp0 + ls * (N + cp1);
+  const int pos = c.cp ? l * (N + N / 4) + N / 4 : slot * (cp0 + 6 * cp1 + 7 * N) + cp0 + ls * (N + cp1);
   const cf32* in = iq + ((size_t)sf * nant + ant) * c.sflen + pos;
   const int nre = (int)c.nre;
   cf32* out = grid + ((size_t)sf * 14 + l) * nre;
@@ -98,11 +99,11 @@ __global__ __launch_bounds__(256) void k_ul_fft(LsnCellDev c, const cf32* __rest
 
 void lsn_launch_ul_fft(const LsnCellDev& c, const cf32* iq, uint32_t nant, uint32_t ant, cf32* grid, uint32_t nsf, hipStream_t s)
 {
-  LSN_LAUNCH(k_ul_fft, dim3(nsf * 14), dim3(256), sizeof(cf32) * (c.N + c.N / 2), s, c, iq, nant, ant, grid);
+  LSN_LAUNCH(k_ul_fft, dim3(nsf * c.nsym), dim3(256), sizeof(cf32) * (c.N + c.N / 2), s, c, iq, nant, ant, grid);
 }
 
 // ------------------------------------------------------------------------------------------------ DMRS estimate
-// one workgroup per grant: LS on symbols 3 / 10, 3-tap smoothing per slot, noise = mean |smoothed - ls|^2,
+// one workgroup per grant: LS on the reference-signal symbols (3 / 10; extended CP 2 / 8), 3-tap smoothing per slot, noise = mean |smoothed - ls|^2,
 // signal = mean |smoothed|^2 (both over the 2 M values in the fixed 256-way order)
 __global__ __launch_bounds__(256) void k_pusch_chest(LsnCellDev c, const LsnUlGrantDev* __restrict__ grants, const cf32* __restrict__ grid,
                                                      cf32* __restrict__ hs_out, float* __restrict__ stat)
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(256) void k_pusch_chest(LsnCellDev c, const LsnUlGr
   float* part = (float*)(ls + 2 * M);  // [2][256]
   for (int i = tid; i < 2 * M; i += 256) {
     const int s = i >= M ? 1 : 0, n = i - s * M;
-    const cf32 y = grid[((size_t)g.sf * 14 + 3 + 7 * s) * nre + 12 * (s ? g.n_prb2 : g.n_prb) + n];
+    const cf32 y = grid[((size_t)g.sf * 14 + (c.nslot - 4) + c.nslot * s) * nre + 12 * (s ? g.n_prb2 : g.n_prb) + n];   // reference signal: symbol 3 of each slot (extended CP: 2)
     const cf32 r = cmul(c.ul_base[(s ? g.base_off1 : g.base_off) + n], c.ul_ph12[(g.ncs[s] * (uint32_t)n) % 12u]);
     ls[i] = cmulconj(y, r);
   }
@@ -170,7 +171,7 @@ __device__ __forceinline__ void ul_demod_llr(int Qm, float I, float Q, float* L)
   }
 }
 
-// one workgroup per (data symbol 0..11, grant): equalised carriers, a ping-pong buffer and the IDFT twiddles in LDS; transform de-precoding as
+// one workgroup per (data symbol 0..11 - 0..9 with the extended CP -, grant): equalised carriers, a ping-pong buffer and the IDFT twiddles in LDS; transform de-precoding as
 // an autosort (Stockham) decimation-in-frequency IDFT over the radices 4 (while the remaining length divides by 4), 2, 3, 5 - one thread per
 // output of a stage, terms added in index order: the operation order of the oracle's o_idft_mixed (M = 1200: 21 complex MACs per output
 // instead of 1200); LLRs written in UL-SCH order
@@ -179,13 +180,15 @@ __global__ __launch_bounds__(256) void k_pusch_demod(LsnCellDev c, const LsnUlGr
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const LsnUlGrantDev g = grants[blockIdx.y];
-  const int col = blockIdx.x, l = col < 3 ? col : (col < 9 ? col + 1 : col + 2);
+  // data symbol `col` of the subframe (12, or 10 with the extended CP) -> symbol l: the reference-signal symbol of each slot is skipped
+  const int nsl = (int)c.nslot, dm = nsl - 4, ncol = 2 * (nsl - 1);
+  const int col = blockIdx.x, l = col < dm ? col : (col < nsl - 1 + dm ? col + 1 : col + 2);
   const int M = 12 * (int)g.L_prb, nre = (int)c.nre, Qm = (int)g.qm, tid = threadIdx.x;
   cf32* xa = (cf32*)smem;  // [M]
   cf32* xb = xa + M;       // [M]
   cf32* w = xb + M;        // [M] exp(+2 pi j k / M)
-  const cf32* y = grid + ((size_t)g.sf * 14 + l) * nre + 12 * (l >= 7 ? g.n_prb2 : g.n_prb);
-  const cf32* h = hs_all + g.hs_off + (l / 7) * M;
+  const cf32* y = grid + ((size_t)g.sf * 14 + l) * nre + 12 * (l >= nsl ? g.n_prb2 : g.n_prb);
+  const cf32* h = hs_all + g.hs_off + (l >= nsl ? 1 : 0) * M;
   const cf32* wt = c.ul_idft + g.idft_off;
   const float noise = stat[2 * blockIdx.y];
   for (int n = tid; n < M; n += 256) {
@@ -228,14 +231,15 @@ __global__ __launch_bounds__(256) void k_pusch_demod(LsnCellDev c, const LsnUlGr
       int before = 0; bool is_ri = false;
 #pragma unroll
       for (int slot = 0; slot < 4; slot++) {
-        const int cc = slot == 0 ? 1 : (slot == 1 ? 4 : (slot == 2 ? 7 : 10)), n = in_col(qri, slot), top = M - n;
+        // column sets of 36.212 Tables 5.2.2.8-1 / -2: rank indication 1 4 7 10 (extended CP 0 3 5 8), HARQ-ACK 2 3 8 9 (1 2 6 7)
+        const int cc = c.cp ? (slot == 0 ? 0 : (slot == 1 ? 3 : (slot == 2 ? 5 : 8))) : (slot == 0 ? 1 : (slot == 1 ? 4 : (slot == 2 ? 7 : 10))), n = in_col(qri, slot), top = M - n;
         before += r > top ? r - top : 0;             // RI cells of this column in the rows above r
         if (n && r >= top && cc < col) before += 1;  // ... and to the left in row r
         if (n && r >= top && cc == col) is_ri = true;
-        const int ca = slot == 0 ? 2 : (slot == 1 ? 3 : (slot == 2 ? 8 : 9));
+        const int ca = c.cp ? (slot == 0 ? 1 : (slot == 1 ? 2 : (slot == 2 ? 6 : 7))) : (slot == 0 ? 2 : (slot == 1 ? 3 : (slot == 2 ? 8 : 9)));
         if (ca == col && r >= M - in_col(qack, slot) && in_col(qack, slot)) is_ack = true;
       }
-      const int rank = r * 12 + col - before;
+      const int rank = r * ncol + col - before;
       dcell = (is_ri || rank < qcqi) ? -1 : rank - qcqi;
     }
     float Lb[8];
@@ -257,7 +261,7 @@ __global__ __launch_bounds__(256) void k_pusch_demod(LsnCellDev c, const LsnUlGr
 void lsn_launch_pusch_demod(const LsnCellDev& c, const LsnUlGrantDev* g, const cf32* grid, const cf32* hs, const float* stat, int16_t* llr,
                             uint32_t ngrants, hipStream_t s)
 {
-  LSN_LAUNCH(k_pusch_demod, dim3(12, ngrants), dim3(256), sizeof(cf32) * 3 * 1200, s, c, g, grid, hs, stat, llr);
+  LSN_LAUNCH(k_pusch_demod, dim3(2 * (c.nslot - 1), ngrants), dim3(256), sizeof(cf32) * 3 * 1200, s, c, g, grid, hs, stat, llr);
 }
 
 // ------------------------------------------------------------------------------------------------ PRACH detection

@@ -303,6 +303,7 @@ typedef struct { uint32_t nof_ack; uint32_t cqi_bits; uint32_t ri_bits; /* HARQ-
 int o_uci_cqi_bits_type(uint32_t nof_prb, uint32_t cqi_type); /* srsran_cqi_size: 0 wideband (4), 1 UE-selected sub-band (4 + 1), 2 higher-layer sub-band (4 + 2 N) */
 int o_uci_cqi_bits(uint32_t nof_prb);
 int o_uci_layout(int M, int tbs, const o_uci_t* uci, uint8_t* cls, int* didx, int* q_ack, int* q_ri, int* q_cqi);
+int o_uci_layout_cp(int M, int tbs, const o_uci_t* uci, int cp /* 1: extended CP - 10 columns, RI on 0 3 5 8, HARQ-ACK on 1 2 6 7 */, uint8_t* cls, int* didx, int* q_ack, int* q_ri, int* q_cqi);
 int o_ul_valid_prb(uint32_t L);
 void o_ul_shift_table(int N, ocf_t* t);
 void o_ul_fft(const o_cell_t* cell, const ocf_t* in, ocf_t* grid);

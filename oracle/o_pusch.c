@@ -51,8 +51,8 @@ void o_ul_fft(const o_cell_t* cell, const ocf_t* in, ocf_t* grid)
   o_fft_twiddles(N, w);
   o_ul_shift_table(N, sh);
   int pos = 0;
-  for (int l = 0; l < 14; l++) {
-    pos += ((l % 7) == 0 ? 160 : 144) * N / 2048;
+  for (int l = 0; l < o_nsym(cell); l++) {
+    pos += cell->cp ? 512 * N / 2048 : ((l % 7) == 0 ? 160 : 144) * N / 2048; /* extended CP: N / 4 on every symbol (36.211 Table 5.6-1) */
     for (int n = 0; n < N; n++) buf[n] = cmul(in[pos + n], sh[n]);
     o_fft(N, w, buf);
     for (int k = 0; k < nre; k++) grid[l * nre + k] = buf[(k < nre / 2) ? (N - nre / 2 + k) : (k - nre / 2)];
@@ -129,7 +129,7 @@ uint32_t o_dmrs_ncs(const o_cell_t* cell, const o_ul_cfg_t* ul, uint32_t ns, uin
   uint8_t c[8 * 7 * 20 + 8];
   o_gold(((cell->id / 30u) << 5) + fss, c, 8 * 7 * 20 + 8);
   uint32_t npn = 0;
-  for (int i = 0; i < 8; i++) npn += (uint32_t)c[8 * 7 * ns + (uint32_t)i] << i;
+  for (int i = 0; i < 8; i++) npn += (uint32_t)c[8u * (uint32_t)o_nslot(cell) * ns + (uint32_t)i] << i; /* n_PN(ns) = sum c(8 N_symb^UL ns + i) 2^i */
   return (n_dmrs1_tab[ul->cyclic_shift & 7] + n_dmrs2_tab[n_dmrs_dci & 7] + npn) % 12u;
 }
 
@@ -229,20 +229,21 @@ int o_uci_cqi_bits_type(uint32_t nof_prb, uint32_t cqi_type)
   return o_uci_cqi_bits(nof_prb);
 }
 
-static int uci_qprime(int O, int M, int beta8, int sumK, int cap)
+static int uci_qprime(int O, int M, int nsymb, int beta8, int sumK, int cap)
 {
   if (O <= 0) return 0;
-  long long num = (long long)O * M * 12 * beta8, den = 8ll * sumK;
+  long long num = (long long)O * M * nsymb * beta8, den = 8ll * sumK;
   int q = (int)((num + den - 1) / den);
   return q < cap ? q : cap;
 }
 
-/* cls[r * 12 + c]: 0 data, 1 CQI, 2 RI, 3 HARQ-ACK; didx: UL-SCH symbol index of a data / ACK-punctured cell.
- * Built by running the standard's procedure literally. Returns the number of UL-SCH symbols (G / Qm), -1 on error. */
-int o_uci_layout(int M, int tbs, const o_uci_t* uci, uint8_t* cls, int* didx, int* q_ack, int* q_ri, int* q_cqi)
+/* cls[r * C + c]: 0 data, 1 CQI, 2 RI, 3 HARQ-ACK; didx: UL-SCH symbol index of a data / ACK-punctured cell; C = N_symb^PUSCH = 12 columns (normal CP) or 10
+ * (extended).  Built by running the standard's procedure literally. Returns the number of UL-SCH symbols (G / Qm), -1 on error. */
+int o_uci_layout_cp(int M, int tbs, const o_uci_t* uci, int cp, uint8_t* cls, int* didx, int* q_ack, int* q_ri, int* q_cqi)
 {
   o_cbsegm_t sg;
   int sumK = 0;
+  const int C = cp ? 10 : 12;
   if (o_cbsegm(&sg, tbs)) return -1;
   sumK = sg.Cp * sg.Kp + sg.Cm * sg.Km;
   /* beta offsets of 36.213 Tables 8.6.3-1/-2/-3 in eighths (spec/lte_tables.h); a reserved index makes the grant undecodable */
@@ -251,31 +252,38 @@ int o_uci_layout(int M, int tbs, const o_uci_t* uci, uint8_t* cls, int* didx, in
   if (ia > 15 || ic > 15 || ir > 15) return -1;
   int Oc = uci ? (int)uci->cqi_bits : 0;
   if (uci && ((uci->nof_ack && !lsn_beta_ack8[ia]) || (uci->ri_bits && !lsn_beta_ri8[ir]) || (Oc && !lsn_beta_cqi8[ic]))) return -1;
-  const int Qa = uci ? uci_qprime((int)uci->nof_ack, M, lsn_beta_ack8[ia], sumK, 4 * M) : 0;
-  const int Qr = uci ? uci_qprime((int)uci->ri_bits, M, lsn_beta_ri8[ir], sumK, 4 * M) : 0;
-  const int Qc = Oc ? uci_qprime(Oc + (Oc > 11 ? 8 : 0), M, lsn_beta_cqi8[ic], sumK, 12 * M - Qr) : 0;
-  static const int ri_cols[4] = {1, 4, 7, 10}, ack_cols[4] = {2, 3, 8, 9};
-  memset(cls, 0, (size_t)(12 * M));
+  const int Qa = uci ? uci_qprime((int)uci->nof_ack, M, C, lsn_beta_ack8[ia], sumK, 4 * M) : 0;
+  const int Qr = uci ? uci_qprime((int)uci->ri_bits, M, C, lsn_beta_ri8[ir], sumK, 4 * M) : 0;
+  const int Qc = Oc ? uci_qprime(Oc + (Oc > 11 ? 8 : 0), M, C, lsn_beta_cqi8[ic], sumK, C * M - Qr) : 0;
+  /* 36.212 Tables 5.2.2.8-1 / -2: column sets of the rank indication and of the HARQ-ACK */
+  static const int ri_cols_n[4] = {1, 4, 7, 10}, ack_cols_n[4] = {2, 3, 8, 9}, ri_cols_e[4] = {0, 3, 5, 8}, ack_cols_e[4] = {1, 2, 6, 7};
+  const int* ri_cols = cp ? ri_cols_e : ri_cols_n;
+  const int* ack_cols = cp ? ack_cols_e : ack_cols_n;
+  memset(cls, 0, (size_t)(C * M));
   for (int i = 0, j = 0, r = M - 1; i < Qr;) { /* 5.2.2.8: rank indication first, bottom row upwards */
-    cls[r * 12 + ri_cols[j]] = 2;
+    cls[r * C + ri_cols[j]] = 2;
     i++; r = M - 1 - i / 4; j = (j + 3) % 4;
   }
   int k = 0; /* then CQI followed by data, row by row, skipping the RI cells */
   for (int r = 0; r < M; r++)
-    for (int c = 0; c < 12; c++) {
-      if (cls[r * 12 + c] == 2) { didx[r * 12 + c] = -1; continue; }
-      if (k < Qc) { cls[r * 12 + c] = 1; didx[r * 12 + c] = -1; }
-      else didx[r * 12 + c] = k - Qc;
+    for (int c = 0; c < C; c++) {
+      if (cls[r * C + c] == 2) { didx[r * C + c] = -1; continue; }
+      if (k < Qc) { cls[r * C + c] = 1; didx[r * C + c] = -1; }
+      else didx[r * C + c] = k - Qc;
       k++;
     }
   for (int i = 0, j = 0, r = M - 1; i < Qa;) { /* HARQ-ACK overwrites */
-    cls[r * 12 + ack_cols[j]] = 3;
+    cls[r * C + ack_cols[j]] = 3;
     i++; r = M - 1 - i / 4; j = (j + 3) % 4;
   }
   if (q_ack) *q_ack = Qa;
   if (q_ri) *q_ri = Qr;
   if (q_cqi) *q_cqi = Qc;
-  return 12 * M - Qr - Qc;
+  return C * M - Qr - Qc;
+}
+int o_uci_layout(int M, int tbs, const o_uci_t* uci, uint8_t* cls, int* didx, int* q_ack, int* q_ri, int* q_cqi)
+{
+  return o_uci_layout_cp(M, tbs, uci, 0, cls, didx, q_ack, q_ri, q_cqi);
 }
 
 /* One grant: DMRS channel estimate (LS on symbols 3 and 10, 3-tap frequency smoothing, one estimate per slot), 1-tap
@@ -304,12 +312,13 @@ int o_pusch_demod_uci(const o_cell_t* cell, const o_ul_cfg_t* ul, uint32_t sf_id
   ocf_t* x = (ocf_t*)malloc(sizeof(ocf_t) * (size_t)M);
   ocf_t* xt = (ocf_t*)malloc(sizeof(ocf_t) * (size_t)M);
   ocf_t* w = (ocf_t*)malloc(sizeof(ocf_t) * (size_t)M);
+  const int C = cell->cp ? 10 : 12, nsl = o_nslot(cell), dm = nsl - 4; /* PUSCH symbols per subframe; the reference signal sits on symbol 3 (extended CP: 2) of each slot */
   uint8_t* c = (uint8_t*)malloc((size_t)(12 * M * Qm));
   uint8_t* cls = (uint8_t*)malloc((size_t)(12 * M));
   int* didx = (int*)malloc(sizeof(int) * (size_t)(12 * M));
-  if (o_uci_layout(M, g->tbs > 0 ? g->tbs : 16, uci, cls, didx, NULL, NULL, NULL) < 0) { free(cls); free(didx); free(c); free(base); free(ls); free(hs); free(tmp); free(x); free(xt); free(w); return -1; }
+  if (o_uci_layout_cp(M, g->tbs > 0 ? g->tbs : 16, uci, (int)cell->cp, cls, didx, NULL, NULL, NULL) < 0) { free(cls); free(didx); free(c); free(base); free(ls); free(hs); free(tmp); free(x); free(xt); free(w); return -1; }
   o_idft_table(M, w);
-  o_gold(((uint32_t)rnti << 14) | (sf_idx << 9) | cell->id, c, 12 * M * Qm);
+  o_gold(((uint32_t)rnti << 14) | (sf_idx << 9) | cell->id, c, C * M * Qm);
   /* cyclic-shift phasors exp(j 2 pi m / 12) */
   ocf_t ph12[12];
   for (int m = 0; m < 12; m++) {
@@ -321,7 +330,7 @@ int o_pusch_demod_uci(const o_cell_t* cell, const o_ul_cfg_t* ul, uint32_t sf_id
     uint32_t ncs = o_dmrs_ncs(cell, ul, 2 * sf_idx + (uint32_t)s, n_dmrs_dci), u, v;
     o_dmrs_uv(cell, ul, 2 * sf_idx + (uint32_t)s, M, &u, &v);
     o_dmrs_base(u, v, M, base);
-    const ocf_t* y = grid + (size_t)(3 + 7 * s) * (size_t)nre + (size_t)k0s[s];
+    const ocf_t* y = grid + (size_t)(dm + nsl * s) * (size_t)nre + (size_t)k0s[s];
     for (int n = 0; n < M; n++) {
       ocf_t r = cmul(base[n], ph12[(ncs * (uint32_t)n) % 12u]);
       ls[s * M + n] = cmulconj(y[n], r);
@@ -342,10 +351,10 @@ int o_pusch_demod_uci(const o_cell_t* cell, const o_ul_cfg_t* ul, uint32_t sf_id
   if (sigpow_out) *sigpow_out = sigpow;
   const float scale = 1.0f / sqrtf((float)M);
   int col = 0;
-  for (int l = 0; l < 14; l++) {
-    if (l == 3 || l == 10) continue;
-    const ocf_t* y = grid + (size_t)l * (size_t)nre + (size_t)k0s[l / 7];
-    const ocf_t* h = hs + (l / 7) * M;
+  for (int l = 0; l < 2 * nsl; l++) {
+    if (l == dm || l == nsl + dm) continue;
+    const ocf_t* y = grid + (size_t)l * (size_t)nre + (size_t)k0s[l / nsl];
+    const ocf_t* h = hs + (l / nsl) * M;
     for (int n = 0; n < M; n++) {
       ocf_t t = cmulconj(y[n], h[n]);
       float den = (h[n].r * h[n].r + h[n].i * h[n].i) + noise;
@@ -365,9 +374,9 @@ int o_pusch_demod_uci(const o_cell_t* cell, const o_ul_cfg_t* ul, uint32_t sf_id
         /* scrambling runs over the transmitted (column-major) order, the decoder wants the row-major UL-SCH order
          * (36.212 5.2.2.8: R_mux x 12 matrix written row by row, read column by column) */
         if (c[((size_t)col * (size_t)M + (size_t)r) * (size_t)Qm + (size_t)b]) q = (int16_t)-q;
-        const int cell_cls = cls[r * 12 + col];
-        if (cell_cls == 1 || cell_cls == 2 || didx[r * 12 + col] < 0) continue; /* CQI / RI (also under a HARQ-ACK symbol that overwrote a CQI cell): not part of the UL-SCH stream */
-        e[(size_t)didx[r * 12 + col] * (size_t)Qm + (size_t)b] = cell_cls == 3 ? (int16_t)0 : q; /* HARQ-ACK punctures */
+        const int cell_cls = cls[r * C + col];
+        if (cell_cls == 1 || cell_cls == 2 || didx[r * C + col] < 0) continue; /* CQI / RI (also under a HARQ-ACK symbol that overwrote a CQI cell): not part of the UL-SCH stream */
+        e[(size_t)didx[r * C + col] * (size_t)Qm + (size_t)b] = cell_cls == 3 ? (int16_t)0 : q; /* HARQ-ACK punctures */
       }
     }
     col++;
@@ -386,11 +395,11 @@ int o_pusch_decode_uci(const o_cell_t* cell, const o_ul_cfg_t* ul, uint32_t sf_i
                        const o_uci_t* uci, const ocf_t* grid, int max_iter, uint8_t* payload, int* iters, float* snr_db)
 {
   if (g->tbs <= 0) return 0;
-  int M = 12 * (int)g->L_prb, G = 12 * M * g->mod;
+  int M = 12 * (int)g->L_prb, G = (cell->cp ? 10 : 12) * M * g->mod;
   if (uci) {
     uint8_t* cls = (uint8_t*)malloc((size_t)(12 * M));
     int* didx = (int*)malloc(sizeof(int) * (size_t)(12 * M));
-    int nsym = o_uci_layout(M, g->tbs, uci, cls, didx, NULL, NULL, NULL);
+    int nsym = o_uci_layout_cp(M, g->tbs, uci, (int)cell->cp, cls, didx, NULL, NULL, NULL);
     free(cls); free(didx);
     if (nsym <= 0) return 0;
     G = nsym * g->mod;

@@ -473,7 +473,7 @@ def candidate_table(llr, nof_cce, sizes, sf_idx=0):
 # -------- uplink: transmitter + oracle bindings --------
 class TxgUlCell(C.Structure):
     _fields_ = [("nof_prb", C.c_uint32), ("cell_id", C.c_uint32), ("cyclic_shift", C.c_uint32), ("delta_ss", C.c_uint32), ("group_hopping", C.c_uint32),
-                ("sequence_hopping", C.c_uint32)]
+                ("sequence_hopping", C.c_uint32), ("cp", C.c_uint32)]  # cp = 1: extended cyclic prefix
 
 
 class TxgUlGrant(C.Structure):
@@ -860,7 +860,7 @@ def gen_ul_mode_subframes(sc, n, cyclic_shift=3, delta_ss=5, ul_snr_db=30.0, si_
     -> (tti0, iq[n, 2, sf_len] (antenna 0 = DL, 1 = UL), list of sent UL payload dicts)"""
     assert sc["nof_rx"] == 1
     tx = TxGen(si_msgs=si_msgs, **sc)
-    ucell = TxgUlCell(sc["nof_prb"], sc["cell_id"], cyclic_shift, delta_ss, int(group_hopping), int(sequence_hopping))
+    ucell = TxgUlCell(sc["nof_prb"], sc["cell_id"], cyclic_shift, delta_ss, int(group_hopping), int(sequence_hopping), sc.get("cp", 0))
     iq = np.zeros((n, 2, tx.sf_len), dtype=np.complex64)
     pending, sent, tti0 = {}, [], None
     # the uplink control configuration every UE transmits with: its own RRCConnectionSetup once it got one, else what a sniffer that

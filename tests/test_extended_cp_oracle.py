@@ -52,3 +52,50 @@ def test_structure():
     mid = 6 * 25 - 36
     assert all(o.o_pdsch_re_ok(C.byref(cell), 0, l, mid + 5) == 0 for l in range(4, 10))
     assert o.o_pdsch_re_ok(C.byref(cell), 0, 10, mid + 5) == 1
+
+
+def test_pusch_loopback_extended_cp_with_control_information():
+    """uplink with the extended CP: 12 SC-FDMA symbols (CP N / 4), reference signal on symbol 2 of each slot with n_PN over 8 * 6 bits per slot, a
+    10-column channel interleaver with the rank indication on columns 0 3 5 8 and the HARQ-ACK on 1 2 6 7 (36.212 Tables 5.2.2.8-1 / -2), Q' from
+    N_symb^PUSCH = 10 - transmitter -> oracle, every modulation, with and without multiplexed control information; a normal-CP receiver fails"""
+    from lsn_testlib import OPuschGrant, OUci, OUlCfg, TxgUlCell, VALID_UL_PRB, oracle_ul_api, ul_make_subframe, ul_mcs_to_mod_tbs
+    o = oracle_ul_api()
+    ok = bad_n = 0
+    for nprb, cell_id in ((25, 7), (100, 1)):
+        rng = np.random.default_rng(nprb + 1)
+        ocell, ncell = OCell(nprb, 1, cell_id, 1, 0, 1), OCell(nprb, 1, cell_id, 1, 0, 0)
+        ucell, ucfg = TxgUlCell(nprb, cell_id, 3, 5, 0, 0, 1), OUlCfg(3, 5)
+        cqi_bits = o.o_uci_cqi_bits(nprb)
+        for it in range(4):
+            tti = int(rng.integers(0, 10240))
+            grants, start = [], 0
+            while True:
+                L = int(rng.choice([n for n in VALID_UL_PRB if 3 <= n <= max(3, nprb // 3)]))
+                if start + L > nprb:
+                    break
+                qm, tbs = ul_mcs_to_mod_tbs(int(rng.integers(0, 27)), L)
+                g = dict(rnti=int(rng.integers(100, 60000)), n_dmrs=int(rng.integers(0, 8)), n_prb=start, L_prb=L, mod=qm, tbs=tbs, rv=0,
+                         gain_db=float(rng.uniform(-3, 3)), phase_rad=float(rng.uniform(0, 6.28)), ta_samples=float(rng.uniform(0, 3)))
+                if it % 2:
+                    cq = int(rng.integers(0, 2)) * cqi_bits
+                    g.update(nof_ack=int(rng.integers(0, 3)), cqi_bits=cq, ri_bits=1 if cq else 0)
+                grants.append(g)
+                start += L + int(rng.integers(0, 3))
+            iq, payloads = ul_make_subframe(ucell, tti, grants, snr_db=35.0, seed=it)
+            grid = np.zeros(14 * 12 * nprb, dtype=np.complex64)
+            o.o_ul_fft(C.byref(ocell), iq.ctypes.data, grid.ctypes.data)
+            assert not np.any(grid[12 * 12 * nprb:])
+            ngrid = np.zeros(14 * 12 * nprb, dtype=np.complex64)
+            o.o_ul_fft(C.byref(ncell), iq.ctypes.data, ngrid.ctypes.data)
+            for g, pl in zip(grants, payloads):
+                og = OPuschGrant(g["L_prb"], g["n_prb"], 0, g["mod"], g["tbs"], 0)
+                uci = OUci(g.get("nof_ack", 0), g.get("cqi_bits", 0), g.get("ri_bits", 0))
+                out = np.zeros(g["tbs"] // 8 + 8, dtype=np.uint8)
+                its, snr = C.c_int(0), C.c_float(0)
+                crc = o.o_pusch_decode_uci(C.byref(ocell), C.byref(ucfg), tti % 10, g["rnti"], C.byref(og), g["n_dmrs"], C.byref(uci), grid.ctypes.data, 12,
+                                           out.ctypes.data, C.byref(its), C.byref(snr))
+                assert crc == 1 and bytes(out[:g["tbs"] // 8]) == pl, (nprb, it, g)
+                ok += 1
+                bad_n += o.o_pusch_decode_uci(C.byref(ncell), C.byref(ucfg), tti % 10, g["rnti"], C.byref(og), g["n_dmrs"], C.byref(uci), ngrid.ctypes.data, 4,
+                                              out.ctypes.data, C.byref(its), C.byref(snr))
+    assert ok >= 12 and bad_n == 0

@@ -177,12 +177,12 @@ def _run_ul_mode(nsf, seed, batch, hopping_offset=0, ul_256=False, ul_snr_db=30.
     kw.update(over)
     sc = scenario("cfg2", seed=seed, **kw)
     tti0, iq, sent = gen_ul_mode_subframes(sc, nsf, ul_256=ul_256, ul_snr_db=ul_snr_db)
-    ow = OracleWorkerUl(sc["nof_prb"], sc["nof_ports"], sc["cell_id"], 3, 5, hopping_offset)
+    ow = OracleWorkerUl(sc["nof_prb"], sc["nof_ports"], sc["cell_id"], 3, 5, hopping_offset, cp=sc.get("cp", 0))
     for i in range(nsf):
         ow.work_ul(iq[i, 0], iq[i, 1], tti0 + i, update_meta=1 if i % 25 == 0 else 0)
     orecs = parse_pcap(ow.pcap_bytes())
     phy = la.Phy(nof_rx_antennas=2, sniffer_mode=1, max_batch=batch, pcapwriter=la.PcapWriter(None))
-    assert phy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"]) and phy.setUlConfig(3, 5, hopping_offset)
+    assert phy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"], cp=sc.get("cp", 0)) and phy.setUlConfig(3, 5, hopping_offset)
     phy.process_host(iq, tti0, 25)
     g, o = gpu_records(phy), oracle_records(orecs)
     assert g == o, "UL_MODE record streams differ: gpu %d vs oracle %d" % (len(g), len(o))
@@ -205,6 +205,15 @@ def test_ul_mode_on_a_four_port_cell():
     """the downlink half of UL_MODE (one antenna) on four CRS ports: PDCCH in SFBC-FSTD, DCI 0 found, PUSCH decoded as on any other cell"""
     n_ul, n_dl = _run_ul_mode(60, seed=6, batch=16, mcs_max=20, nof_ports=4, rar_period=15)
     assert n_ul >= 10 and n_dl >= 5
+
+
+def test_ul_mode_extended_cyclic_prefix():
+    """UL_MODE on an extended-CP cell: both grids have 12 symbols, the PUSCH 10 data symbols with the reference signal on symbol 2 of each slot, a
+    10-column channel interleaver (control information on the extended-CP column sets) - record streams identical to the oracle's worker"""
+    n_ul, n_dl = _run_ul_mode(60, seed=61, batch=16, mcs_max=20, cp=1)
+    assert n_ul >= 10 and n_dl >= 5
+    n_ul, n_dl = _run_ul_mode(48, seed=62, batch=64, rar_period=10, mcs_max=20, pct_cqi_req=50, cp=1, nof_prb=50)
+    assert n_ul >= 5
 
 
 def test_ul_mode_with_rar_and_single_chunk():

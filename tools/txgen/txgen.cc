@@ -973,7 +973,7 @@ extern "C" int txg_generate(const txg_cfg_t* cfg, uint32_t nsf, float* iq, int n
 // Uplink: SC-FDMA transmitters of several UEs summed at the sniffer's uplink antenna (test tooling).
 // TS 36.212 5.2.2 (UL-SCH: CRC, segmentation, turbo code, rate matching, control multiplexing with random control bits, channel interleaver),
 // TS 36.211 5.3 (scrambling, modulation, transform precoding), 5.5 (DMRS), 5.6 (7.5 kHz shifted SC-FDMA).
-typedef struct { uint32_t nof_prb, cell_id, cyclic_shift, delta_ss, group_hopping, sequence_hopping; /* SIB2 ul-ReferenceSignalsPUSCH */ } txg_ul_cell_t;
+typedef struct { uint32_t nof_prb, cell_id, cyclic_shift, delta_ss, group_hopping, sequence_hopping; /* SIB2 ul-ReferenceSignalsPUSCH */ uint32_t cp; /* 1: extended cyclic prefix (6 symbols per slot, reference signal on symbol 2) */ } txg_ul_cell_t;
 typedef struct { uint16_t rnti; uint16_t n_dmrs; uint32_t n_prb, L_prb, mod, tbs, rv; float gain_db, phase_rad, ta_samples;
                  uint32_t nof_ack, cqi_bits, ri_bits; /* UCI multiplexed into the PUSCH (36.212 5.2.2.6-8): HARQ-ACK bits, CQI report size, RI bits */
                  uint32_t hop, n_prb2; /* hop = 1: slot 1 is sent on n_prb2 .. n_prb2 + L_prb - 1 (type-1 frequency hopping) */
@@ -991,13 +991,14 @@ extern "C" int txg_ul_make(const txg_ul_cell_t* c, uint32_t tti, const txg_ul_gr
   switch (nprb) { case 6: N = 128; break; case 15: N = 256; break; case 25: N = 512; break; case 50: N = 1024; break; case 75: N = 1536; break; case 100: N = 2048; break; default: return -1; }
   const uint32_t sf = tti % 10;
   std::vector<std::complex<double>> grid((size_t)14 * nre, 0.0);
+  const int nsl = c->cp ? 6 : 7, C = 2 * (nsl - 1), dm = nsl - 4;  // symbols per slot, PUSCH symbols per subframe (channel-interleaver columns), reference-signal symbol of a slot
   static const uint32_t d1[8] = {0, 2, 3, 4, 6, 8, 9, 10}, d2[8] = {0, 6, 3, 4, 2, 8, 10, 9};
   const uint32_t fss = ((c->cell_id % 30) + c->delta_ss) % 30;
   bits_t cpn = gold(((c->cell_id / 30) << 5) + fss, 8 * 7 * 20 + 8);
   uint32_t used = 0;
   for (int gi = 0; gi < ngr; gi++) {
     const txg_ul_grant_t& g = gr[gi];
-    const int M = 12 * (int)g.L_prb, Qm = (int)g.mod, H = 12 * M * Qm;
+    const int M = 12 * (int)g.L_prb, Qm = (int)g.mod, H = C * M * Qm;
     const int k0s[2] = {12 * (int)g.n_prb, 12 * (int)(g.hop == 1 ? g.n_prb2 : g.n_prb)};
     payload_off[gi] = used;
     uint8_t* pl = payloads + used;
@@ -1006,7 +1007,7 @@ extern "C" int txg_ul_make(const txg_ul_cell_t* c, uint32_t tti, const txg_ul_gr
     // control resources, 36.212 5.2.2.6: Q' = min(ceil(O M_sc N_symb beta / sum K_r), cap), beta from the UE's betaOffset indices
     Segm sg; cbsegm((int)g.tbs, sg);
     const double sumK = (double)sg.Cp * sg.Kp + (double)sg.Cm * sg.Km;
-    auto qprime = [&](int O, double beta, int cap) { if (O <= 0) return 0; int q = (int)std::ceil((double)O * M * 12.0 * beta / sumK - 1e-9); return q < cap ? q : cap; };
+    auto qprime = [&](int O, double beta, int cap) { if (O <= 0) return 0; int q = (int)std::ceil((double)O * M * (double)C * beta / sumK - 1e-9); return q < cap ? q : cap; };
     // 36.213 Tables 8.6.3-1/-2/-3
     static const double b_ack[16] = {2.0, 2.5, 3.125, 4.0, 5.0, 6.25, 8.0, 10.0, 12.625, 15.875, 20.0, 31.0, 50.0, 80.0, 126.0, 0.0};
     static const double b_ri[16] = {1.25, 1.625, 2.0, 2.5, 3.125, 4.0, 5.0, 6.25, 8.0, 10.0, 12.625, 15.875, 20.0, 0.0, 0.0, 0.0};
@@ -1014,33 +1015,35 @@ extern "C" int txg_ul_make(const txg_ul_cell_t* c, uint32_t tti, const txg_ul_gr
     const double beta_ack = b_ack[g.i_ack_p1 ? (g.i_ack_p1 - 1) & 15 : 10], beta_ri = b_ri[g.i_ri_p1 ? (g.i_ri_p1 - 1) & 15 : 11],
                  beta_cqi = b_cqi[g.i_cqi_p1 ? (g.i_cqi_p1 - 1) & 15 : 8];
     const int Qa = qprime((int)g.nof_ack, beta_ack, 4 * M), Qr = qprime((int)g.ri_bits, beta_ri, 4 * M);
-    const int Oc = (int)g.cqi_bits, Qc = Oc ? qprime(Oc + (Oc > 11 ? 8 : 0), beta_cqi, 12 * M - Qr) : 0;
-    const int G = (12 * M - Qr - Qc) * Qm;
+    const int Oc = (int)g.cqi_bits, Qc = Oc ? qprime(Oc + (Oc > 11 ? 8 : 0), beta_cqi, C * M - Qr) : 0;
+    const int G = (C * M - Qr - Qc) * Qm;
     bits_t f = dlsch_encode(pl, (int)g.tbs, G, Qm, 1, (int)g.rv);
     // channel interleaver 5.2.2.8: M rows x 12 columns of Qm-bit cells; RI first (bottom rows, columns 1,4,7,10), then CQI + data row by
     // row, then HARQ-ACK overwriting (bottom rows, columns 2,3,8,9); control bits are random here
-    std::vector<int> owner((size_t)12 * M, 0);  // 0 free, 2 RI
+    std::vector<int> owner((size_t)C * M, 0);  // 0 free, 2 RI
     bits_t mat((size_t)H);
-    static const int ri_cols[4] = {1, 4, 7, 10}, ack_cols[4] = {2, 3, 8, 9};
+    static const int ri_cols_n[4] = {1, 4, 7, 10}, ack_cols_n[4] = {2, 3, 8, 9}, ri_cols_e[4] = {0, 3, 5, 8}, ack_cols_e[4] = {1, 2, 6, 7};  // 36.212 Tables 5.2.2.8-1 / -2
+    const int* ri_cols = c->cp ? ri_cols_e : ri_cols_n;
+    const int* ack_cols = c->cp ? ack_cols_e : ack_cols_n;
     for (int i = 0, j = 0, r = M - 1; i < Qr; i++, r = M - 1 - i / 4, j = (j + 3) % 4) {
-      owner[(size_t)r * 12 + ri_cols[j]] = 2;
-      for (int b = 0; b < Qm; b++) mat[((size_t)r * 12 + ri_cols[j]) * Qm + b] = (uint8_t)rng.below(2);
+      owner[(size_t)r * C + ri_cols[j]] = 2;
+      for (int b = 0; b < Qm; b++) mat[((size_t)r * C + ri_cols[j]) * Qm + b] = (uint8_t)rng.below(2);
     }
     {
       int k = 0;
       for (int r = 0; r < M; r++)
-        for (int cc = 0; cc < 12; cc++) {
-          if (owner[(size_t)r * 12 + cc] == 2) continue;
-          for (int b = 0; b < Qm; b++) mat[((size_t)r * 12 + cc) * Qm + b] = k < Qc ? (uint8_t)rng.below(2) : f[(size_t)(k - Qc) * Qm + b];
+        for (int cc = 0; cc < C; cc++) {
+          if (owner[(size_t)r * C + cc] == 2) continue;
+          for (int b = 0; b < Qm; b++) mat[((size_t)r * C + cc) * Qm + b] = k < Qc ? (uint8_t)rng.below(2) : f[(size_t)(k - Qc) * Qm + b];
           k++;
         }
     }
     for (int i = 0, j = 0, r = M - 1; i < Qa; i++, r = M - 1 - i / 4, j = (j + 3) % 4)
-      for (int b = 0; b < Qm; b++) mat[((size_t)r * 12 + ack_cols[j]) * Qm + b] = (uint8_t)rng.below(2);
+      for (int b = 0; b < Qm; b++) mat[((size_t)r * C + ack_cols[j]) * Qm + b] = (uint8_t)rng.below(2);
     bits_t h((size_t)H);
-    for (int col = 0; col < 12; col++)
+    for (int col = 0; col < C; col++)
       for (int r = 0; r < M; r++)
-        for (int b = 0; b < Qm; b++) h[((size_t)col * M + r) * Qm + b] = mat[((size_t)r * 12 + col) * Qm + b];
+        for (int b = 0; b < Qm; b++) h[((size_t)col * M + r) * Qm + b] = mat[((size_t)r * C + col) * Qm + b];
     bits_t scr = gold(((uint32_t)g.rnti << 14) | (sf << 9) | c->cell_id, H);
     for (int i = 0; i < H; i++) h[i] ^= scr[i];
     std::vector<cf> sym;
@@ -1059,12 +1062,12 @@ extern "C" int txg_ul_make(const txg_ul_cell_t* c, uint32_t tti, const txg_ul_gr
       return q;
     };
     int col = 0;
-    for (int l = 0; l < 14; l++) {
+    for (int l = 0; l < 2 * nsl; l++) {
       std::vector<std::complex<double>> v((size_t)M);
-      if (l == 3 || l == 10) {
-        const uint32_t ns = 2 * sf + (l == 10 ? 1 : 0);
+      if (l == dm || l == nsl + dm) {
+        const uint32_t ns = 2 * sf + (l >= nsl ? 1 : 0);
         uint32_t npn = 0;
-        for (int i = 0; i < 8; i++) npn += (uint32_t)cpn[8 * 7 * ns + i] << i;
+        for (int i = 0; i < 8; i++) npn += (uint32_t)cpn[8 * nsl * ns + i] << i;
         const uint32_t ncs = (d1[c->cyclic_shift & 7] + d2[g.n_dmrs & 7] + npn) % 12;
         uint32_t u = 0;
         const long long q = slot_q(ns, u);
@@ -1087,7 +1090,7 @@ extern "C" int txg_ul_make(const txg_ul_cell_t* c, uint32_t tti, const txg_ul_gr
         }
         col++;
       }
-      const int k0 = k0s[l / 7];
+      const int k0 = k0s[l / nsl];
       for (int k = 0; k < M; k++) {
         // timing advance error = linear phase over the carriers (carrier k sits at (k - nre/2 + 1/2) * 15 kHz)
         const double fk = (double)(k0 + k) - nre / 2.0 + 0.5;
@@ -1101,8 +1104,8 @@ extern "C" int txg_ul_make(const txg_ul_cell_t* c, uint32_t tti, const txg_ul_gr
   std::vector<std::complex<double>> buf(N);
   const double sigma = std::sqrt(std::pow(10.0, -snr_db / 10.0) / (2.0 * N));
   int pos = 0;
-  for (int l = 0; l < 14; l++) {
-    const int cp = ((l % 7) == 0 ? 160 : 144) * N / 2048;
+  for (int l = 0; l < 2 * nsl; l++) {
+    const int cp = c->cp ? 512 * N / 2048 : ((l % 7) == 0 ? 160 : 144) * N / 2048;
     for (auto& v : buf) v = 0;
     for (int k = 0; k < nre; k++) buf[k < nre / 2 ? N - nre / 2 + k : k - nre / 2] = grid[(size_t)l * nre + k];
     fft_d(buf, true);
