@@ -588,8 +588,9 @@ bool api_ul_dcch_events(int api_mode, const uint8_t* pdu, int len, uint16_t rnti
 // PDSCH_Decoder::decode_rrc_connection_reconfig (DL_Sniffer_PDSCH.cc:181-220): DL-DCCH-Message, c1 = rrcConnectionReconfiguration-r8, the FIRST
 // dedicatedInfoNAS; liblte_mme_parse_msg_header + liblte_mme_unpack_attach_accept_msg [srsRAN, not in tree; TS 24.301 8.2.1, 9.9.3.12] -> M-TMSI of
 // the GUTI.  UPER walk per TS 36.331 6.2.2 / 6.3.5: the components in FRONT of the NAS list must be walked to find it - measConfig (object /
-// report / id lists, quantity configuration, gaps, s-Measure; Rel-8 roots) is, mobilityControlInfo (a handover command never carries an attach
-// accept) is not: such a message, or one with extension additions inside measConfig, is reported as "no identity" where srsRAN would decode it.
+// report / id lists of every RAT, quantity configuration, gaps, s-Measure, HRPD pre-registration, speed-state parameters; Rel-8 roots, later additions
+// stepped over) is; mobilityControlInfo is not: a handover command never carries an attach accept (dedicatedInfoNASList is conditional on "nonHO",
+// 36.331 6.2.2), so such a message has no identity for the reference either.
 // Pinned by the two RRCConnectionReconfiguration messages of the reference's own captures (tests/test_rrc_oracle.py).
 static void thresholdEutra(BitReader& b) { if (!b.flag()) b.get(7); else b.get(6); }  // CHOICE { threshold-RSRP (0..97), threshold-RSRQ (0..34) }
 // X.691 10.9 / 19.7-19.9: the extension additions behind the root components of an extensible SEQUENCE - a presence bitmap whose length is a
@@ -617,6 +618,87 @@ static bool skipExtAdditions(BitReader& b)
       if (!skipOpenType(b)) return false;
   return !b.err;
 }
+// Inter-RAT measurement objects and report configurations in front of the NAS list (round-4 review, missing 4): restated from TS 36.331 6.3.5 (Rel-8
+// roots; what later releases added travels behind the extension marker and is stepped over unread).  Not pinned by any capture the reference ships
+// (its two reconfiguration messages configure E-UTRA measurements only): the test's independent encoder is the check.
+//   MeasObjectUTRA  { carrierFreq (0..16383), offsetFreq (-15..15) DEFAULT 0, cellsToRemoveList OPTIONAL, cellsToAddModList CHOICE { FDD: (cellIndex, physCellId
+//                     0..511), TDD: (cellIndex, physCellId 0..127) } OPTIONAL, cellForWhichToReportCGI CHOICE { FDD, TDD } OPTIONAL, ... }
+//   MeasObjectGERAN { carrierFreqs { startingARFCN (0..1023), bandIndicator, followingARFCNs CHOICE { explicit list (0..31 x 10 bits), equally spaced (1..8, 0..31),
+//                     variable bit map (1..16 octets) } }, offsetFreq DEFAULT 0, ncc-Permitted BIT STRING (8) DEFAULT, cellForWhichToReportCGI { ncc (3), bcc (3) } OPTIONAL, ... }
+//   MeasObjectCDMA2000 { cdma2000-Type, carrierFreq { bandClass (32 values, extensible), arfcn (0..2047) }, searchWindowSize (0..15) OPTIONAL, offsetFreq DEFAULT 0,
+//                     cellsToRemoveList OPTIONAL, cellsToAddModList ((cellIndex, physCellId 0..511)) OPTIONAL, cellForWhichToReportCGI (0..511) OPTIONAL, ... }
+static bool measObjectInterRatSkip(BitReader& b, uint32_t rat)
+{
+  const bool ext = b.flag();
+  if (rat == 1) {
+    bool o[4];
+    for (bool& x : o) x = b.flag();
+    b.get(14);
+    if (o[0]) b.get(5);
+    if (o[1]) { const uint32_t k = b.get(5) + 1; b.get(5 * k); }
+    if (o[2]) { const bool tdd = b.flag(); const uint32_t k = b.get(5) + 1; for (uint32_t j = 0; j < k && !b.err; j++) { b.get(5); b.get(tdd ? 7 : 9); } }
+    if (o[3]) { const bool tdd = b.flag(); b.get(tdd ? 7 : 9); }
+  } else if (rat == 2) {
+    bool o[3];
+    for (bool& x : o) x = b.flag();
+    b.get(10); b.get(1);
+    switch (b.get(2)) {
+      case 0: { const uint32_t k = b.get(5); for (uint32_t j = 0; j < k && !b.err; j++) b.get(10); break; }
+      case 1: b.get(3); b.get(5); break;
+      case 2: { const uint32_t k = b.get(4) + 1; for (uint32_t j = 0; j < k && !b.err; j++) b.get(8); break; }
+      default: return false;
+    }
+    if (o[0]) b.get(5);
+    if (o[1]) b.get(8);
+    if (o[2]) b.get(6);
+  } else {
+    bool o[5];
+    for (bool& x : o) x = b.flag();
+    b.get(1);
+    if (b.flag()) return false;                   // bandClass behind its extension marker
+    b.get(5); b.get(11);
+    if (o[0]) b.get(4);
+    if (o[1]) b.get(5);
+    if (o[2]) { const uint32_t k = b.get(5) + 1; b.get(5 * k); }
+    if (o[3]) { const uint32_t k = b.get(5) + 1; for (uint32_t j = 0; j < k && !b.err; j++) { b.get(5); b.get(9); } }
+    if (o[4]) b.get(9);
+  }
+  if (ext && !skipExtAdditions(b)) return false;
+  return !b.err;
+}
+//   ReportConfigInterRAT { triggerType CHOICE { event { eventId CHOICE { eventB1 { b1-Threshold CHOICE { UTRA, GERAN, CDMA2000 } }, eventB2 { b2-Threshold1 ThresholdEUTRA,
+//                     b2-Threshold2 CHOICE { UTRA, GERAN, CDMA2000 } }, ... }, hysteresis, timeToTrigger }, periodical { purpose (3 values) } }, maxReportCells, reportInterval,
+//                     reportAmount, ... };  ThresholdUTRA CHOICE { utra-RSCP (-5..91), utra-EcN0 (0..49) }, ThresholdGERAN / ThresholdCDMA2000 (0..63)
+static bool thresholdInterRat(BitReader& b)
+{
+  switch (b.get(2)) {
+    case 0: if (!b.flag()) b.get(7); else b.get(6); return true;
+    case 1: case 2: b.get(6); return true;
+    default: return false;
+  }
+}
+static bool reportConfigInterRatSkip(BitReader& b)
+{
+  const bool ext = b.flag();
+  if (!b.flag()) {                                // event
+    if (b.flag()) {                               // an event behind the extension marker: small index, then an open type
+      if (b.flag()) return false;
+      b.get(6);
+      if (!skipOpenType(b)) return false;
+    } else if (!b.flag()) {                       // b1
+      if (!thresholdInterRat(b)) return false;
+    } else {                                      // b2
+      thresholdEutra(b);
+      if (!thresholdInterRat(b)) return false;
+    }
+    b.get(5); b.get(4);
+  } else {
+    b.get(2);                                     // periodical: purpose
+  }
+  b.get(3); b.get(4); b.get(3);
+  if (ext && !skipExtAdditions(b)) return false;
+  return !b.err;
+}
 static bool measConfigSkip(BitReader& b)
 {
   const bool ext_mc = b.flag();
@@ -627,7 +709,9 @@ static bool measConfigSkip(BitReader& b)
     const uint32_t n = b.get(5) + 1;
     for (uint32_t i = 0; i < n && !b.err; i++) {
       b.get(5);                                   // measObjectId
-      if (b.flag() || b.get(2) != 0) return false;  // only measObjectEUTRA
+      if (b.flag()) return false;                 // measObject: an alternative behind the extension marker
+      const uint32_t rat = b.get(2);              // measObjectEUTRA, measObjectUTRA, measObjectGERAN, measObjectCDMA2000
+      if (rat != 0) { if (!measObjectInterRatSkip(b, rat)) return false; continue; }
       const bool ext_mo = b.flag();               // MeasObjectEUTRA: extension additions (r10+) follow the root components
       bool o[6];
       for (bool& x : o) x = b.flag();
@@ -649,7 +733,7 @@ static bool measConfigSkip(BitReader& b)
     const uint32_t n = b.get(5) + 1;
     for (uint32_t i = 0; i < n && !b.err; i++) {
       b.get(5);                                   // reportConfigId
-      if (b.get(1) != 0) return false;            // only reportConfigEUTRA
+      if (b.get(1) != 0) { if (!reportConfigInterRatSkip(b)) return false; continue; }  // reportConfigInterRAT
       const bool ext_rc = b.flag();               // ReportConfigEUTRA extension additions (r9+) at the end
       if (!b.flag()) {                            // triggerType: event
         if (b.flag()) {                           // eventId beyond a5 (a6-r10 ...): index as a normally small number, the event as an open type
@@ -679,7 +763,11 @@ static bool measConfigSkip(BitReader& b)
     bool q[4];
     for (bool& x : q) x = b.flag();
     if (q[0]) { const bool r1 = b.flag(), r2 = b.flag(); for (bool r : {r1, r2}) if (r) { if (b.flag()) return false; b.get(4); } }  // filterCoefficientRSRP / RSRQ
-    if (q[1] || q[2] || q[3]) return false;       // UTRA / GERAN / CDMA2000 quantities: not walked
+    // QuantityConfigUTRA { measQuantityUTRA-FDD (2 values), measQuantityUTRA-TDD (1 value: no bits), filterCoefficient DEFAULT fc4 },
+    // QuantityConfigGERAN { measQuantityGERAN (1 value), filterCoefficient DEFAULT fc2 }, QuantityConfigCDMA2000 { measQuantityCDMA2000 (2 values) }
+    if (q[1]) { const bool fc = b.flag(); b.get(1); if (fc) { if (b.flag()) return false; b.get(4); } }
+    if (q[2]) { const bool fc = b.flag(); if (fc) { if (b.flag()) return false; b.get(4); } }
+    if (q[3]) b.get(1);
     if (ext_qc && !skipExtAdditions(b)) return false;
   }
   if (opt[7] && b.flag()) {                       // measGapConfig: release / setup { gapOffset CHOICE { gp0 (0..39), gp1 (0..79), ... } }
@@ -687,7 +775,13 @@ static bool measConfigSkip(BitReader& b)
     if (!b.flag()) b.get(6); else b.get(7);
   }
   if (opt[8]) b.get(7);                           // s-Measure (0..97)
-  if (opt[9] || opt[10]) return false;            // preRegistrationInfoHRPD, speedStatePars: not walked
+  if (opt[9]) {                                   // preRegistrationInfoHRPD { preRegistrationAllowed, preRegistrationZoneId (0..255) OPTIONAL, secondaryPreRegistrationZoneIdList (1..2) OPTIONAL }
+    const bool z = b.flag(), sl = b.flag();
+    b.get(1);
+    if (z) b.get(8);
+    if (sl) { const uint32_t k = b.get(1) + 1; b.get(8 * k); }
+  }
+  if (opt[10] && b.flag()) b.get(3 + 3 + 4 + 4 + 2 + 2);  // speedStatePars setup: MobilityStateParameters (t-Evaluation, t-HystNormal, n-CellChangeMedium, n-CellChangeHigh) + SpeedStateScaleFactors
   if (ext_mc && !skipExtAdditions(b)) return false;
   return !b.err;
 }

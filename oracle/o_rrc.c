@@ -415,11 +415,51 @@ static int drop_additions(cur_t* c)
   (void)sent;
   return !c->bad;
 }
+/* the other radio access technologies (TS 36.331 6.3.5, release-8 components; later additions are open types behind the roots):
+ * 1 UTRA: ARFCN 14 bits | offset 5 | cells to remove | cells to add: FDD (5 + 9 bits each) or TDD (5 + 7) | cell for CGI: FDD 9 / TDD 7
+ * 2 GERAN: ARFCN 10, band 1, following ARFCNs as list (count 0..31, 10 bits each) / spacing 3 + count 5 / bit map of 1..16 octets | offset 5 | NCC mask 8 | cell for CGI 3 + 3
+ * 3 CDMA2000: type 1, band class 1 + 5, ARFCN 11 | search window 4 | offset 5 | cells to remove | cells to add (5 + 9 each) | cell for CGI 9 */
+static int drop_meas_object_other_rat(cur_t* c, uint32_t which)
+{
+  uint32_t more = take(c, 1);
+  if (which == 1) {
+    uint32_t has = take(c, 4);
+    take(c, 14);
+    if (has & 8u) take(c, 5);
+    if (has & 4u) drop_list5(c, 5);
+    if (has & 2u) { uint32_t tdd = take(c, 1); drop_list5(c, tdd ? 12 : 14); }
+    if (has & 1u) { uint32_t tdd = take(c, 1); take(c, tdd ? 7 : 9); }
+  } else if (which == 2) {
+    uint32_t has = take(c, 3);
+    take(c, 11);
+    uint32_t form = take(c, 2);
+    if (form == 0) { uint32_t cnt = take(c, 5); for (uint32_t i = 0; i < cnt; i++) take(c, 10); }
+    else if (form == 1) take(c, 8);
+    else if (form == 2) { uint32_t cnt = take(c, 4) + 1; for (uint32_t i = 0; i < cnt; i++) take(c, 8); }
+    else return 0;
+    if (has & 4u) take(c, 5);
+    if (has & 2u) take(c, 8);
+    if (has & 1u) take(c, 6);
+  } else {
+    uint32_t has = take(c, 5);
+    take(c, 1);
+    if (take(c, 1)) return 0;
+    take(c, 16);
+    if (has & 16u) take(c, 4);
+    if (has & 8u) take(c, 5);
+    if (has & 4u) drop_list5(c, 5);
+    if (has & 2u) drop_list5(c, 14);
+    if (has & 1u) take(c, 9);
+  }
+  if (more && !drop_additions(c)) return 0;
+  return !c->bad;
+}
 static int drop_meas_object(cur_t* c)
 {
   take(c, 5);
   if (take(c, 1)) return 0;          /* measObject choice extended */
-  if (take(c, 2) != 0) return 0;     /* UTRA / GERAN / CDMA2000 */
+  uint32_t which = take(c, 2);
+  if (which != 0) return drop_meas_object_other_rat(c, which); /* UTRA / GERAN / CDMA2000 */
   uint32_t more = take(c, 1);        /* MeasObjectEUTRA carries extension additions */
   uint32_t has = take(c, 6);         /* offsetFreq, cellsToRemove, cellsToAddMod, blackCellsToRemove, blackCellsToAddMod, cellForWhichToReportCGI */
   take(c, 16 + 3 + 1 + 2);
@@ -435,10 +475,43 @@ static int drop_meas_object(cur_t* c)
   if (more && !drop_additions(c)) return 0;
   return !c->bad;
 }
+/* ThresholdUTRA (RSCP 7 bits / EcN0 6 bits), ThresholdGERAN, ThresholdCDMA2000 (6 bits each) */
+static int drop_threshold_other_rat(cur_t* c)
+{
+  uint32_t rat = take(c, 2);
+  if (rat == 0) take(c, take(c, 1) ? 6 : 7);
+  else if (rat <= 2) take(c, 6);
+  else return 0;
+  return 1;
+}
+/* ReportConfigInterRAT: event b1 (threshold of the other RAT) / b2 (E-UTRA threshold + threshold of the other RAT) with hysteresis and time to trigger, or periodical with a
+ * purpose of three values; then maxReportCells 3, reportInterval 4, reportAmount 3 */
+static int drop_report_config_inter_rat(cur_t* c)
+{
+  uint32_t more = take(c, 1);
+  if (take(c, 1) == 0) {
+    if (take(c, 1)) {
+      if (take(c, 1)) return 0;
+      take(c, 6);
+      if (!drop_open(c)) return 0;
+    } else if (take(c, 1) == 0) {
+      if (!drop_threshold_other_rat(c)) return 0;
+    } else {
+      drop_threshold(c);
+      if (!drop_threshold_other_rat(c)) return 0;
+    }
+    take(c, 9);
+  } else {
+    take(c, 2);
+  }
+  take(c, 10);
+  if (more && !drop_additions(c)) return 0;
+  return !c->bad;
+}
 static int drop_report_config(cur_t* c)
 {
   take(c, 5);
-  if (take(c, 1)) return 0;          /* reportConfigInterRAT */
+  if (take(c, 1)) return drop_report_config_inter_rat(c);
   uint32_t more = take(c, 1);        /* extension additions behind reportAmount */
   if (take(c, 1) == 0) {             /* event */
     if (take(c, 1)) {                /* an event the r8 choice does not know (a6 ...): small index, then an open type */
@@ -473,11 +546,13 @@ static int drop_meas_config(cur_t* c)
   if (has & (1u << 4)) {
     uint32_t qmore = take(c, 1);
     uint32_t q = take(c, 4);
-    if (q & 7u) return 0;
     if (q & 8u) {
       uint32_t d = take(c, 2);
       for (int k = 1; k >= 0; k--) if (d & (1u << k)) { if (take(c, 1)) return 0; take(c, 4); }
     }
+    if (q & 4u) { uint32_t fc = take(c, 1); take(c, 1); if (fc) { if (take(c, 1)) return 0; take(c, 4); } } /* UTRA: FDD quantity (2 values), TDD quantity (1 value), filter */
+    if (q & 2u) { uint32_t fc = take(c, 1); if (fc) { if (take(c, 1)) return 0; take(c, 4); } }             /* GERAN: quantity (1 value), filter */
+    if (q & 1u) take(c, 1);                                                                                  /* CDMA2000: quantity (2 values) */
     if (qmore && !drop_additions(c)) return 0;
   }
   if ((has & (1u << 3)) && take(c, 1)) { /* measGapConfig setup: gapOffset is an extensible choice (36.331: gp0, gp1, ...) */
@@ -485,7 +560,13 @@ static int drop_meas_config(cur_t* c)
     take(c, take(c, 1) ? 7 : 6);
   }
   if (has & (1u << 2)) take(c, 7);
-  if (has & 3u) return 0;
+  if (has & 2u) { /* HRPD pre-registration: allowed flag, zone id, one or two secondary zone ids */
+    uint32_t o = take(c, 2);
+    take(c, 1);
+    if (o & 2u) take(c, 8);
+    if (o & 1u) { uint32_t cnt = take(c, 1) + 1; take(c, 8 * cnt); }
+  }
+  if ((has & 1u) && take(c, 1)) take(c, 18); /* speed-state parameters set up: two timers (3 + 3), two counts (4 + 4), two scale factors (2 + 2) */
   if (more && !drop_additions(c)) return 0;
   return !c->bad;
 }

@@ -280,6 +280,68 @@ def _put_additions(b, adds):
             _put_open(b, x)
 
 
+def _put_irat_object(b, ob):
+    """MeasObjectToAddMod with measObjectUTRA / GERAN / CDMA2000 (TS 36.331 6.3.5, release-8 components), written for this test"""
+    rat, oid, c = ob[0], ob[1], ob[2]
+    adds = ob[3] if len(ob) > 3 else None
+    _put(b, oid - 1, 5); _put(b, 0, 1); _put(b, {"utra": 1, "geran": 2, "cdma2000": 3}[rat], 2); _put(b, int(bool(adds)), 1)
+    if rat == "utra":
+        _put(b, int(c.get("offset") is not None), 1); _put(b, int(bool(c.get("remove"))), 1); _put(b, int(bool(c.get("cells"))), 1); _put(b, int(c.get("cgi") is not None), 1)
+        _put(b, c["arfcn"], 14)
+        if c.get("offset") is not None:
+            _put(b, c["offset"] + 15, 5)
+        if c.get("remove"):
+            _put(b, len(c["remove"]) - 1, 5)
+            for v in c["remove"]:
+                _put(b, v - 1, 5)
+        if c.get("cells"):
+            _put(b, int(c["tdd"]), 1); _put(b, len(c["cells"]) - 1, 5)
+            for ci, pci in c["cells"]:
+                _put(b, ci - 1, 5); _put(b, pci, 7 if c["tdd"] else 9)
+        if c.get("cgi") is not None:
+            _put(b, int(c["tdd"]), 1); _put(b, c["cgi"], 7 if c["tdd"] else 9)
+    elif rat == "geran":
+        _put(b, int(c.get("offset") is not None), 1); _put(b, int(c.get("ncc") is not None), 1); _put(b, int(c.get("cgi") is not None), 1)
+        _put(b, c["arfcn"], 10); _put(b, c["band"], 1)
+        f = c["following"]
+        if f[0] == "list":
+            _put(b, 0, 2); _put(b, len(f[1]), 5)
+            for v in f[1]:
+                _put(b, v, 10)
+        elif f[0] == "spaced":
+            _put(b, 1, 2); _put(b, f[1] - 1, 3); _put(b, f[2], 5)
+        else:
+            _put(b, 2, 2); _put(b, len(f[1]) - 1, 4)
+            for v in f[1]:
+                _put(b, v, 8)
+        if c.get("offset") is not None:
+            _put(b, c["offset"] + 15, 5)
+        if c.get("ncc") is not None:
+            _put(b, c["ncc"], 8)
+        if c.get("cgi") is not None:
+            _put(b, c["cgi"][0], 3); _put(b, c["cgi"][1], 3)
+    else:
+        _put(b, int(c.get("window") is not None), 1); _put(b, int(c.get("offset") is not None), 1); _put(b, int(bool(c.get("remove"))), 1)
+        _put(b, int(bool(c.get("cells"))), 1); _put(b, int(c.get("cgi") is not None), 1)
+        _put(b, c["type"], 1); _put(b, 0, 1); _put(b, c["band"], 5); _put(b, c["arfcn"], 11)
+        if c.get("window") is not None:
+            _put(b, c["window"], 4)
+        if c.get("offset") is not None:
+            _put(b, c["offset"] + 15, 5)
+        if c.get("remove"):
+            _put(b, len(c["remove"]) - 1, 5)
+            for v in c["remove"]:
+                _put(b, v - 1, 5)
+        if c.get("cells"):
+            _put(b, len(c["cells"]) - 1, 5)
+            for ci, pci in c["cells"]:
+                _put(b, ci - 1, 5); _put(b, pci, 9)
+        if c.get("cgi") is not None:
+            _put(b, c["cgi"], 9)
+    if adds:
+        _put_additions(b, adds)
+
+
 def _encode_reconfig(nas, meas=None, mobility=False, rrcd=True):
     """DL-DCCH-Message { rrcConnectionReconfiguration-r8 } in unaligned PER, written for this test (TS 36.331 6.2.2 / 6.3.5).  meas: None or
     dict(objects=[(id, arfcn, offset or None, cells [(idx, pci, off)], additions or None)], reports=[("a3", offset, adds) | ("a1", rsrp, adds) |
@@ -292,12 +354,15 @@ def _encode_reconfig(nas, meas=None, mobility=False, rrcd=True):
     if meas is not None:
         _put(b, int(bool(meas.get("additions"))), 1)
         pres = [0, bool(meas.get("objects")), 0, bool(meas.get("reports")), 0, bool(meas.get("ids")), meas.get("quantity") is not None, meas.get("gap") is not None,
-                meas.get("s_measure") is not None, 0, 0]
+                meas.get("s_measure") is not None, meas.get("prereg") is not None, meas.get("speed") is not None]
         for x in pres:
             _put(b, int(bool(x)), 1)
         if meas.get("objects"):
             _put(b, len(meas["objects"]) - 1, 5)
             for ob in meas["objects"]:
+                if isinstance(ob[0], str):   # another radio access technology: ("utra" | "geran" | "cdma2000", measObjectId, dict of components, additions)
+                    _put_irat_object(b, ob)
+                    continue
                 oid, arfcn, off, cells = ob[:4]
                 adds = ob[4] if len(ob) > 4 else None
                 _put(b, oid - 1, 5); _put(b, 0, 1); _put(b, 0, 2); _put(b, int(bool(adds)), 1)
@@ -315,6 +380,28 @@ def _encode_reconfig(nas, meas=None, mobility=False, rrcd=True):
             _put(b, len(meas["reports"]) - 1, 5)
             for k, rc in enumerate(meas["reports"]):
                 adds = rc[2] if len(rc) > 2 else None
+                if rc[0] in ("b1", "b2", "periodical_irat"):   # ReportConfigInterRAT
+                    _put(b, k, 5); _put(b, 1, 1); _put(b, int(bool(adds)), 1)
+                    if rc[0] == "periodical_irat":
+                        _put(b, 1, 1); _put(b, rc[1], 2)
+                    else:
+                        _put(b, 0, 1); _put(b, 0, 1); _put(b, 0 if rc[0] == "b1" else 1, 1)
+                        th = rc[1]
+                        if rc[0] == "b2":
+                            _put(b, 0, 1); _put(b, th["eutra_rsrp"], 7)
+                        _put(b, {"utra": 0, "geran": 1, "cdma2000": 2}[th["rat"]], 2)
+                        if th["rat"] == "utra":
+                            if "rscp" in th:
+                                _put(b, 0, 1); _put(b, th["rscp"] + 5, 7)
+                            else:
+                                _put(b, 1, 1); _put(b, th["ecn0"], 6)
+                        else:
+                            _put(b, th["v"], 6)
+                        _put(b, 3, 5); _put(b, 5, 4)
+                    _put(b, 4, 3); _put(b, 6, 4); _put(b, 7, 3)
+                    if adds:
+                        _put_additions(b, adds)
+                    continue
                 _put(b, k, 5); _put(b, 0, 1); _put(b, int(bool(adds)), 1)
                 if rc[0] == "periodical":
                     _put(b, 1, 1); _put(b, 0, 1)
@@ -337,11 +424,24 @@ def _encode_reconfig(nas, meas=None, mobility=False, rrcd=True):
         if meas.get("quantity") is not None:
             q = meas["quantity"]
             adds = q[2] if len(q) > 2 else None
-            _put(b, int(bool(adds)), 1); _put(b, 1, 1); _put(b, 0, 3)
+            other = q[3] if len(q) > 3 and q[3] else {}   # dict(utra=(fdd quantity, filter or None), geran=(filter or None,), cdma2000=quantity)
+            _put(b, int(bool(adds)), 1); _put(b, 1, 1); _put(b, int("utra" in other), 1); _put(b, int("geran" in other), 1); _put(b, int("cdma2000" in other), 1)
             _put(b, int(q[0] is not None), 1); _put(b, int(q[1] is not None), 1)
             for v in q[:2]:
                 if v is not None:
                     _put(b, 0, 1); _put(b, v, 4)
+            if "utra" in other:
+                fq, fc = other["utra"]
+                _put(b, int(fc is not None), 1); _put(b, fq, 1)
+                if fc is not None:
+                    _put(b, 0, 1); _put(b, fc, 4)
+            if "geran" in other:
+                fc = other["geran"][0]
+                _put(b, int(fc is not None), 1)
+                if fc is not None:
+                    _put(b, 0, 1); _put(b, fc, 4)
+            if "cdma2000" in other:
+                _put(b, other["cdma2000"], 1)
             if adds:
                 _put_additions(b, adds)
         if meas.get("gap") is not None:
@@ -353,6 +453,21 @@ def _encode_reconfig(nas, meas=None, mobility=False, rrcd=True):
                 _put(b, 0 if g[0] == "gp0" else 1, 1); _put(b, g[1], 6 if g[0] == "gp0" else 7)
         if meas.get("s_measure") is not None:
             _put(b, meas["s_measure"], 7)
+        if meas.get("prereg") is not None:   # (allowed, zone id or None, [secondary zone ids] or None)
+            al, z, sec = meas["prereg"]
+            _put(b, int(z is not None), 1); _put(b, int(bool(sec)), 1); _put(b, int(al), 1)
+            if z is not None:
+                _put(b, z, 8)
+            if sec:
+                _put(b, len(sec) - 1, 1)
+                for v in sec:
+                    _put(b, v, 8)
+        if meas.get("speed") is not None:    # "release" | (t_eval, t_hyst, n_medium, n_high, sf_medium, sf_high)
+            sp = meas["speed"]
+            if sp == "release":
+                _put(b, 0, 1)
+            else:
+                _put(b, 1, 1); _put(b, sp[0], 3); _put(b, sp[1], 3); _put(b, sp[2] - 1, 4); _put(b, sp[3] - 1, 4); _put(b, sp[4], 2); _put(b, sp[5], 2)
         if meas.get("additions"):
             _put_additions(b, meas["additions"])
     if nas is not None:
@@ -482,3 +597,85 @@ def test_reconfiguration_walk_steps_over_later_release_extension_additions():
                 p = bytes([0x21, max(4, cut - 3), 0x1f]) + pdu[3:cut]
                 assert oracle_api_events(3, "C", p, 9, 9) == host_api_events(3, "C", p, 9, 9)
     assert n_ext >= 40
+
+
+def test_reconfiguration_walk_steps_over_inter_rat_measurement_configuration():
+    """measConfig of a network with 3G / 2G / CDMA2000 neighbours (round-4 review, missing 4): MeasObjectUTRA / GERAN / CDMA2000, ReportConfigInterRAT (events b1, b2,
+    periodical), the inter-RAT quantity configurations, HRPD pre-registration and speed-state parameters sit in FRONT of the NAS list - both parsers (oracle o_rrc.c,
+    product lsn_rrc.cc: two texts) must step over all of them and still find the attach accept; the encoder above knows nothing of either"""
+    rng = np.random.default_rng(23)
+
+    def adds():
+        if rng.integers(0, 3):
+            return None
+        return [bytes(rng.integers(0, 256, int(rng.integers(1, 6)), dtype=np.uint8)) if rng.integers(0, 2) else None for _ in range(int(rng.integers(1, 4)))] or None
+
+    def opt(v):
+        return v if rng.integers(0, 2) else None
+
+    def irat_object(i):
+        kind = ["utra", "geran", "cdma2000", "eutra"][int(rng.integers(0, 4))]
+        if kind == "eutra":
+            return (1 + i, int(rng.integers(0, 65536)), opt(int(rng.integers(0, 31))), [(1 + j, int(rng.integers(0, 504)), int(rng.integers(0, 31))) for j in range(int(rng.integers(0, 3)))], None)
+        a = adds()
+        if a is not None and all(x is None for x in a):
+            a = None
+        if kind == "utra":
+            tdd = bool(rng.integers(0, 2))
+            return ("utra", 1 + i, dict(arfcn=int(rng.integers(0, 16384)), offset=opt(int(rng.integers(-15, 16))), remove=opt([1 + int(v) for v in rng.integers(0, 32, int(rng.integers(1, 4)))]),
+                                         tdd=tdd, cells=opt([(1 + j, int(rng.integers(0, 128 if tdd else 512))) for j in range(int(rng.integers(1, 5)))]),
+                                         cgi=opt(int(rng.integers(0, 128 if tdd else 512)))), a)
+        if kind == "geran":
+            f = [("list", [int(v) for v in rng.integers(0, 1024, int(rng.integers(0, 6)))]), ("spaced", int(rng.integers(1, 9)), int(rng.integers(0, 32))),
+                 ("bitmap", [int(v) for v in rng.integers(0, 256, int(rng.integers(1, 17)))])][int(rng.integers(0, 3))]
+            return ("geran", 1 + i, dict(arfcn=int(rng.integers(0, 1024)), band=int(rng.integers(0, 2)), following=f, offset=opt(int(rng.integers(-15, 16))), ncc=opt(int(rng.integers(0, 256))),
+                                          cgi=opt((int(rng.integers(0, 8)), int(rng.integers(0, 8))))), a)
+        return ("cdma2000", 1 + i, dict(type=int(rng.integers(0, 2)), band=int(rng.integers(0, 18)), arfcn=int(rng.integers(0, 2048)), window=opt(int(rng.integers(0, 16))),
+                                         offset=opt(int(rng.integers(-15, 16))), remove=opt([1 + int(v) for v in rng.integers(0, 32, int(rng.integers(1, 3)))]),
+                                         cells=opt([(1 + j, int(rng.integers(0, 512))) for j in range(int(rng.integers(1, 4)))]), cgi=opt(int(rng.integers(0, 512)))), a)
+
+    def threshold():
+        rat = ["utra", "geran", "cdma2000"][int(rng.integers(0, 3))]
+        if rat == "utra":
+            return dict(rat=rat, rscp=int(rng.integers(-5, 92))) if rng.integers(0, 2) else dict(rat=rat, ecn0=int(rng.integers(0, 50)))
+        return dict(rat=rat, v=int(rng.integers(0, 64)))
+
+    def report():
+        k = int(rng.integers(0, 5))
+        if k == 0:
+            return ("b1", threshold(), None)
+        if k == 1:
+            return ("b2", dict(threshold(), eutra_rsrp=int(rng.integers(0, 98))), None)
+        if k == 2:
+            return ("periodical_irat", int(rng.integers(0, 3)), None)
+        if k == 3:
+            return ("a3", int(rng.integers(-30, 31)), None)
+        return ("periodical", None, None)
+
+    n_irat = 0
+    for trial in range(120):
+        tmsi = int(rng.integers(1, 1 << 32))
+        objects = [irat_object(i) for i in range(int(rng.integers(1, 5)))]
+        reports = [report() for _ in range(int(rng.integers(0, 4)))]
+        other = {}
+        if rng.integers(0, 2):
+            other["utra"] = (int(rng.integers(0, 2)), opt(int(rng.integers(0, 16))))
+        if rng.integers(0, 2):
+            other["geran"] = (opt(int(rng.integers(0, 16))),)
+        if rng.integers(0, 2):
+            other["cdma2000"] = int(rng.integers(0, 2))
+        meas = dict(objects=objects, reports=reports, ids=[(1, 1, 1)][:int(rng.integers(0, 2))],
+                    quantity=[None, (opt(4), opt(7), None, other)][int(rng.integers(0, 2))],
+                    gap=[None, ("gp0", 17)][int(rng.integers(0, 2))], s_measure=opt(70),
+                    prereg=[None, (True, None, None), (False, 17, [3]), (True, 200, [1, 255])][int(rng.integers(0, 4))],
+                    speed=[None, "release", (3, 5, 4, 16, 1, 2)][int(rng.integers(0, 3))])
+        n_irat += any(isinstance(o[0], str) for o in objects) or any(r[0] in ("b1", "b2", "periodical_irat") for r in reports)
+        pdu = _dcch_pdu(_encode_reconfig(_attach_accept(tmsi, protected=bool(trial % 2)), meas=meas))
+        ev, keep = oracle_api_events(3, "C", pdu, 4321, 77)
+        assert (ev, keep) == host_api_events(3, "C", pdu, 4321, 77)
+        assert ev == [(77, 4321, 1, 6, "%08x" % tmsi)], (trial, meas)
+        if pdu[1] < 128:   # truncated messages: rejected identically, never read past the end
+            for cut in range(8, len(pdu) - 4, 5):
+                p = bytes([0x21, max(4, cut - 3), 0x1f]) + pdu[3:cut]
+                assert oracle_api_events(3, "C", p, 9, 9) == host_api_events(3, "C", p, 9, 9)
+    assert n_irat >= 80
