@@ -154,6 +154,7 @@ Engine::Engine(const lsn_phy_cfg_t& c, std::shared_ptr<SharedSeq> shared) : sh(s
   HIP_CHECK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
   trace_path = getenv("LSN_TRACE");
   cb_skip = !(getenv("LSN_NO_CB_SKIP") && atoi(getenv("LSN_NO_CB_SKIP")));
+  if (cfg.harq_mode) cb_skip = false;  // the soft buffer remembers every code block that passed, also behind a failed first block (HarqKeep): all blocks are decoded
   // test hook of the error path, read once per engine: chunk <n> of the first submitted block fails in stage A (and must not wedge the pipeline)
   if (const char* e = getenv("LSN_INJECT_STAGE_A_ERROR")) inject_stage_a_fail = atoi(e);
   if (const char* e = getenv("LSN_DECODE_THREADS")) ndec = std::max(1, std::min((int)NDEC, atoi(e)));
@@ -772,6 +773,10 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
       const uint8_t* pl = ch.h_payload.data() + j.payload_off[t.tb];
       const uint32_t par = ((uint32_t)pl[tbs / 8] << 16) | ((uint32_t)pl[tbs / 8 + 1] << 8) | pl[tbs / 8 + 2];
       j.crc[t.tb] = all_ok && rem == 0 && par != 0 && bits_after == (uint64_t)tbs + 24;
+      if (cfg.harq_mode) {  // per-block verdicts of this transmission, next to the kept soft data (harqStore / harqCombinedDecode)
+        if (ch.keep_res.size() < ch.keep_cbs.size()) ch.keep_res.resize(ch.keep_cbs.size());
+        for (uint32_t q = 0; q < t.cb_count && j.keep_count[t.tb] == t.cb_count; q++) ch.keep_res[j.keep_first[t.tb] + q] = r.h_cbres_pinned[t.cb_first + q];
+      }
       JobRes& jr = ch.jres[t.job];
       jr.crc[t.tb] = j.crc[t.tb] ? 1 : 0;
       jr.payload_off[t.tb] = j.payload_off[t.tb];
@@ -1227,8 +1232,17 @@ void Engine::harqStore(Chunk& ch, JobRunner& r, int job, int tb, size_t slot)
   if (!n || n > HARQ_MAX_CB) return;
   grow_host(r.h_cbs_pinned, r.h_cbs_cap, n, r.stream);
   grow_dev(r.d_cbs, r.cbs_cap, n, r.stream);
+  // cb_crc / data of the soft buffer: what passed in this (failed) transmission is remembered, a retransmission decodes the other blocks only
+  HarqKeep& hk = harq_keep[slot];
+  hk.ncb = n;
+  uint32_t boff = 0;
   for (uint32_t q = 0; q < n; q++) {
     LsnCbDev cb = ch.keep_cbs[j.keep_first[tb] + q];
+    const LsnCbRes cr = j.keep_first[tb] + q < ch.keep_res.size() ? ch.keep_res[j.keep_first[tb] + q] : LsnCbRes{};
+    hk.ok[q] = cr.ok ? 1 : 0; hk.rem_a[q] = cr.rem_a;
+    const uint8_t* pb = ch.h_payload.data() + j.payload_off[tb] + boff;
+    hk.bytes[q].assign(pb, pb + cb.out_bytes);
+    boff += cb.out_bytes;
     cb.e_off = cb.spp_off;                                        // this transmission, in the chunk's keep store
     cb.spp_off = (uint32_t)(slot * HARQ_SLOT_WORDS + q * HARQ_CB_WORDS);
     r.h_cbs_pinned[q] = cb;
@@ -1248,47 +1262,69 @@ bool Engine::harqCombinedDecode(Chunk& ch, JobRunner& r, int job, int tb, size_t
   grow_dev(r.d_cbs, r.cbs_cap, n, st);
   if (n > r.cbres_cap) { grow_dev(r.d_cbres, r.cbres_cap, n, st); }
   grow_host(r.h_cbres_pinned, r.h_cbres_cap, n, st);
-  // descriptors in launch order (two-wave class first); results stay in transport-block order through res_idx
-  std::vector<LsnCbDev> cbs(n);
-  uint32_t out = 0, n128 = 0, kmax128 = 0, kmax64 = 0;
+  HarqKeep& hk = harq_keep[slot];
+  if (hk.ncb != n) { hk = HarqKeep{}; hk.ncb = n; }  // (no first transmission on record for this geometry: nothing passed before)
+  // descriptors of the blocks that have NOT passed yet, in launch order (two-wave class first); results stay in transport-block order through res_idx
+  std::vector<LsnCbDev> cbs;
+  uint32_t out = 0, n128 = 0, kmax128 = 0, kmax64 = 0, out_off[HARQ_MAX_CB] = {};
   for (uint32_t q = 0; q < n; q++) {
     LsnCbDev cb = ch.keep_cbs[j.keep_first[tb] + q];
+    out_off[q] = out;
+    if (hk.ok[q]) continue;   // srsRAN: if (!softbuffer->cb_crc[cb_idx]) { rate de-matching into the buffer, decoding } - a passed block is left alone
     cb.e_off = cb.spp_off;
     cb.spp_off = (uint32_t)(slot * HARQ_SLOT_WORDS + q * HARQ_CB_WORDS);
     cb.res_idx = q; cb.dep = LSN_CB_NODEP; cb.out_off = out; out += cb.out_bytes;
-    cbs[q] = cb;
+    cbs.push_back(cb);
   }
-  std::stable_sort(cbs.begin(), cbs.end(), [](const LsnCbDev& a, const LsnCbDev& b) { return lsn_turbo_two_wave_class((int)a.K) && !lsn_turbo_two_wave_class((int)b.K); });
-  for (uint32_t q = 0; q < n; q++) {
-    r.h_cbs_pinned[q] = cbs[q];
-    if (lsn_turbo_two_wave_class((int)cbs[q].K)) { n128++; kmax128 = std::max(kmax128, cbs[q].K); } else kmax64 = std::max(kmax64, cbs[q].K);
+  const uint32_t nd = (uint32_t)cbs.size();
+  if (nd) {
+    std::stable_sort(cbs.begin(), cbs.end(), [](const LsnCbDev& a, const LsnCbDev& b) { return lsn_turbo_two_wave_class((int)a.K) && !lsn_turbo_two_wave_class((int)b.K); });
+    for (uint32_t q = 0; q < nd; q++) {
+      r.h_cbs_pinned[q] = cbs[q];
+      if (lsn_turbo_two_wave_class((int)cbs[q].K)) { n128++; kmax128 = std::max(kmax128, cbs[q].K); } else kmax64 = std::max(kmax64, cbs[q].K);
+    }
+    grow_dev(r.d_payload, r.payload_cap, (size_t)out + 16, st);
+    grow_host(r.h_payload_pinned, r.h_payload_cap, (size_t)out + 16, st);
+    lsn_launch_upload(r.d_cbs, r.h_cbs_pinned, nd * sizeof(LsnCbDev), st);
+    lsn_launch_harq_combine(r.d_cbs, nd, ch.d_keep, d_harq_pool, false, st);
+    lsn_launch_turbo(cd, r.d_cbs, d_harq_pool, r.d_payload, r.d_cbres, n128, kmax128, nd - n128, kmax64, st, nullptr);
+    lsn_launch_download(r.h_cbres_pinned, r.d_cbres, n * sizeof(LsnCbRes), st);
+    lsn_launch_download(r.h_payload_pinned, r.d_payload, out, st);
+    HIP_CHECK(hipEventRecord(r.ev_done, st));
+    waitEvent(r.ev_done);
+    r.perf.nof_ondemand_decodes++;
+    for (uint32_t q = 0; q < n; q++) {
+      if (hk.ok[q]) continue;
+      const LsnCbRes& cr = r.h_cbres_pinned[q];
+      r.perf.nof_turbo_iterations += cr.iters;
+      hk.rem_a[q] = cr.rem_a;
+      const uint32_t nb = ch.keep_cbs[j.keep_first[tb] + q].out_bytes;
+      hk.bytes[q].assign(r.h_payload_pinned + out_off[q], r.h_payload_pinned + out_off[q] + nb);
+      // (ok is set below, after the verdict of THIS pass has been taken)
+    }
   }
-  grow_dev(r.d_payload, r.payload_cap, (size_t)out + 16, st);
-  grow_host(r.h_payload_pinned, r.h_payload_cap, (size_t)out + 16, st);
-  lsn_launch_upload(r.d_cbs, r.h_cbs_pinned, n * sizeof(LsnCbDev), st);
-  lsn_launch_harq_combine(r.d_cbs, n, ch.d_keep, d_harq_pool, false, st);
-  lsn_launch_turbo(cd, r.d_cbs, d_harq_pool, r.d_payload, r.d_cbres, n128, kmax128, n - n128, kmax64, st, nullptr);
-  lsn_launch_download(r.h_cbres_pinned, r.d_cbres, n * sizeof(LsnCbRes), st);
-  lsn_launch_download(r.h_payload_pinned, r.d_payload, out, st);
-  HIP_CHECK(hipEventRecord(r.ev_done, st));
-  waitEvent(r.ev_done);
-  r.perf.nof_ondemand_decodes++;
-  // transport-block verdict, as in runJobs
+  // transport-block verdict, as in runJobs: every block passed (now or in an earlier transmission), CRC24A over the assembled blocks
   bool all_ok = true;
-  uint32_t rem = 0;
+  uint32_t rem = 0, total = 0;
   uint64_t bits_after = 0;
   for (int q = (int)n - 1; q >= 0; q--) {
-    const LsnCbRes& cr = r.h_cbres_pinned[q];
-    all_ok = all_ok && cr.ok != 0;
-    r.perf.nof_turbo_iterations += cr.iters;
-    rem ^= crc24a_mulmod(cr.rem_a, crc24a_xpow(bits_after));
+    const bool okq = hk.ok[q] || (nd && r.h_cbres_pinned[q].ok != 0);
+    all_ok = all_ok && okq;
+    rem ^= crc24a_mulmod(hk.rem_a[q], crc24a_xpow(bits_after));
     bits_after += 8ull * ch.keep_cbs[j.keep_first[tb] + q].out_bytes;
   }
+  for (uint32_t q = 0; q < n; q++) total += (uint32_t)hk.bytes[q].size();
   const int tbs = j.grant.tb[tb].tbs;
   payload_off = (uint32_t)ch.h_payload.size();
-  ch.h_payload.resize(ch.h_payload.size() + (((size_t)out + 15) & ~(size_t)15));
-  std::memcpy(ch.h_payload.data() + payload_off, r.h_payload_pinned, out);
+  ch.h_payload.resize(ch.h_payload.size() + (((size_t)total + 15) & ~(size_t)15));
+  {
+    uint8_t* dst = ch.h_payload.data() + payload_off;
+    for (uint32_t q = 0; q < n; q++) { std::memcpy(dst, hk.bytes[q].data(), hk.bytes[q].size()); dst += hk.bytes[q].size(); }
+  }
+  for (uint32_t q = 0; q < n; q++)
+    if (!hk.ok[q] && nd && r.h_cbres_pinned[q].ok) hk.ok[q] = 1;
   const uint8_t* pl = ch.h_payload.data() + payload_off;
+  if ((uint64_t)total * 8ull < (uint64_t)tbs + 24ull) return false;
   const uint32_t par = ((uint32_t)pl[tbs / 8] << 16) | ((uint32_t)pl[tbs / 8 + 1] << 8) | pl[tbs / 8 + 2];
   return all_ok && rem == 0 && par != 0 && bits_after == (uint64_t)tbs + 24;
 }
@@ -1529,7 +1565,7 @@ void Engine::frontLoop()
         ch.update_meta_period = job.update_meta_period;
         ch.force_meta = job.force_meta && ci == 0;
         ch.gseq = job.gseq0 + ci;
-        ch.jobs.clear(); ch.jres.clear(); ch.tapjobs.clear(); ch.keep_cbs.clear(); ch.keep_n = 0; ch.cdci.clear(); ch.setup_cfgs.clear(); ch.h_payload.clear(); ch.recs.clear(); ch.err.clear();
+        ch.jobs.clear(); ch.jres.clear(); ch.tapjobs.clear(); ch.keep_cbs.clear(); ch.keep_res.clear(); ch.keep_n = 0; ch.cdci.clear(); ch.setup_cfgs.clear(); ch.h_payload.clear(); ch.recs.clear(); ch.err.clear();
         for (uint32_t i = 0; i < ch.nsf; i++) ch.ctx[i].reset(ch.start_tti + i);
         ch.st_a = stream_a[(slot_counter - 1) % NSTREAM_A];
         ch.trace_id = ci;

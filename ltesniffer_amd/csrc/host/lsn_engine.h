@@ -18,6 +18,7 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 namespace lsn {
@@ -77,6 +78,7 @@ struct Chunk {
   // transport blocks go into (new transmission that failed) or are combined with (retransmission) the soft buffers of their HARQ processes
   uint32_t* d_keep = nullptr; size_t keep_cap = 0, keep_n = 0;
   std::vector<LsnCbDev> keep_cbs;      // descriptors of the kept blocks (spp_off = word offset in d_keep)
+  std::vector<LsnCbRes> keep_res;      // ... and their verdicts from the decode of THIS transmission (same index)
   std::vector<TapJob> tapjobs;         // per job, filled only while the stage-C taps are switched on
   std::vector<CommitDci> cdci;         // built by planJobs
   std::vector<uint32_t> cdci_first;    // [nsf + 1] first CommitDci of each subframe
@@ -280,6 +282,11 @@ private:
   HarqDatabase harq_db;
   uint32_t* d_harq_pool = nullptr;
   static constexpr size_t HARQ_CB_WORDS = LSN_SPP_WORDS(6144u), HARQ_MAX_CB = 16, HARQ_SLOT_WORDS = HARQ_CB_WORDS * HARQ_MAX_CB;
+  // What srsran_softbuffer_rx_t holds besides the soft values (round-4 advisor finding): per code block cb_crc and the decoded data of a block whose CRC
+  // passed - a retransmission neither combines nor decodes such a block again (sch.c decode_tb_cb [srsRAN]).  Kept on the host, by soft-buffer slot, owned
+  // by the commit thread: verdict, CRC24A contribution and payload bytes of every code block of the transport block the slot holds.
+  struct HarqKeep { uint32_t ncb = 0; uint8_t ok[16] = {}; uint32_t rem_a[16] = {}; std::vector<uint8_t> bytes[16]; };
+  std::unordered_map<size_t, HarqKeep> harq_keep;
   void harqStore(Chunk& ch, JobRunner& r, int job, int tb, size_t slot);                       // a failed new transmission goes into the buffer
   bool harqCombinedDecode(Chunk& ch, JobRunner& r, int job, int tb, size_t slot, uint32_t& payload_off);  // retransmission: combine, decode, keep
 public:

@@ -207,8 +207,9 @@ int o_pdsch_decode_tb(const int16_t* e, int G, int tbs, int Qm, int nof_layers_r
                       uint8_t* payload, int* iters_total);
 #define O_HARQ_CB_STRIDE (3 * (6144 + 4))
 #define O_HARQ_MAX_CB 16
+#define O_HARQ_KEEP_STRIDE (1 + 6144) /* per code block: passed flag + decoded bits */
 int o_pdsch_decode_tb_harq(const int16_t* e, int G, int tbs, int Qm, int nof_layers_rm, int rv, int max_iter,
-                           uint8_t* payload, int* iters_total, int16_t* acc /* [C][O_HARQ_CB_STRIDE] or NULL */, int combine);
+                           uint8_t* payload, int* iters_total, int16_t* acc, int combine, uint8_t* keep);
 int o_turbo_nwin(int K);
 /* ---------- stage-C recorder (o_trace.c): soft bits / de-rate-matched streams / per-code-block verdicts of every decode call ---------- */
 typedef struct { uint32_t tti, rnti, nof_re, qm[2], llr_len[2], ncb, cb_first, is_ul; } o_trace_job_hdr_t;

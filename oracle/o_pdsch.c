@@ -492,7 +492,7 @@ int o_turbo_decode_cb(const int16_t* d3, int K, int max_iter, uint32_t crc_poly,
 int o_pdsch_decode_tb(const int16_t* e, int G, int tbs, int Qm, int NL, int rv, int max_iter, uint8_t* payload,
                       int* iters_total)
 {
-  return o_pdsch_decode_tb_harq(e, G, tbs, Qm, NL, rv, max_iter, payload, iters_total, NULL, 0);
+  return o_pdsch_decode_tb_harq(e, G, tbs, Qm, NL, rv, max_iter, payload, iters_total, NULL, 0, NULL);
 }
 
 /* ... with a HARQ soft buffer (the softbuffer_rx of srsran_ue_dl_decode_pdsch, HARQ.cc:71-190 / DL_Sniffer_PDSCH.cc:955-990): acc holds, per code
@@ -500,8 +500,12 @@ int o_pdsch_decode_tb(const int16_t* e, int G, int tbs, int Qm, int NL, int rv, 
  * buffer is overwritten (srsran_softbuffer_rx_reset_tbs); combine = 1: a retransmission, the streams of this redundancy version are added to the
  * buffer, the sum clipped to the decoder's 10-bit soft values, and decoder and buffer both see the combined streams.  Design parameter of this
  * restatement (srsRAN keeps int16 circular buffers; parity unpinned): the buffer holds clipped 10-bit values. */
+/* keep (round 5, advisor finding): srsran_softbuffer_rx_t also holds, per code block, cb_crc and the decoded bits of a block whose CRC passed
+ * (softbuffer.h / sch.c decode_tb_cb [srsRAN]): such a block is neither combined nor decoded again by a retransmission - its bits come from the buffer.
+ * keep[r * O_HARQ_KEEP_STRIDE] = 1 when block r passed in an earlier transmission of this transport block, followed by its K decoded bits; a new
+ * transmission clears the flags (srsran_softbuffer_rx_reset_tbs). */
 int o_pdsch_decode_tb_harq(const int16_t* e, int G, int tbs, int Qm, int NL, int rv, int max_iter, uint8_t* payload,
-                           int* iters_total, int16_t* acc, int combine)
+                           int* iters_total, int16_t* acc, int combine, uint8_t* keep)
 {
   o_cbsegm_t s;
   if (o_cbsegm(&s, tbs) || Qm <= 0 || G <= 0) return 0;
@@ -516,6 +520,15 @@ int o_pdsch_decode_tb_harq(const int16_t* e, int G, int tbs, int Qm, int NL, int
     int E = (r <= s.C - gamma - 1) ? NL * Qm * (Gp / s.C) : NL * Qm * ((Gp + s.C - 1) / s.C);
     int ok = 0;
     if (rp + E > G) E = G - rp;
+    uint8_t* kp = keep ? keep + (size_t)r * O_HARQ_KEEP_STRIDE : NULL;
+    if (kp && !combine) kp[0] = 0;
+    if (kp && combine && kp[0]) { /* passed before: taken from the buffer, not decoded again */
+      int take_k = K - F - (s.C > 1 ? 24 : 0);
+      memcpy(tbbits + wp, kp + 1 + F, (size_t)take_k);
+      wp += take_k;
+      rp += E;
+      continue;
+    }
     o_rm_turbo_rx_cb(e + rp, E, K, F, rv, d3);
     if (acc) {
       int16_t* a = acc + (size_t)r * O_HARQ_CB_STRIDE;
@@ -530,6 +543,7 @@ int o_pdsch_decode_tb_harq(const int16_t* e, int G, int tbs, int Qm, int NL, int
     its += n > 0 ? n : 0;
     if (o_trace_enabled()) o_trace_cb(K, F, E, rv, d3, n, ok);
     if (!ok) all_ok = 0;
+    if (kp && ok) { kp[0] = 1; memcpy(kp + 1, cb, (size_t)K); }
     int take_n = K - F - (s.C > 1 ? 24 : 0);
     memcpy(tbbits + wp, cb + F, (size_t)take_n);
     wp += take_n;

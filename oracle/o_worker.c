@@ -49,7 +49,7 @@ typedef struct {
 #define O_HARQ_ENTITIES 300
 enum { O_HARQ_NEW_TX = 0, O_HARQ_RE_TX, O_HARQ_FULL_BUFFER, O_HARQ_DECODED, O_HARQ_BUSY };
 typedef struct { int last_decoded, ndi, rv, tbs, is_first; } o_harq_grant_t;
-typedef struct { uint32_t sfn, sf_idx; o_harq_grant_t grant; int16_t* acc; } o_harq_tb_t;
+typedef struct { uint32_t sfn, sf_idx; o_harq_grant_t grant; int16_t* acc; uint8_t* keep; /* per code block: passed flag + decoded bits (cb_crc / data of softbuffer_rx) */ } o_harq_tb_t;
 struct o_harq_entity { uint16_t rnti; uint32_t time; uint32_t nof_active, nof_success, nof_retx_success, nof_retx[8]; o_harq_tb_t tb[8][2]; };
 
 struct o_worker {
@@ -193,6 +193,12 @@ void o_worker_free(o_worker_t* w)
   o_rntiman_free(w->rm);
   free(w->grid); free(w->ce); free(w->llr); free(w->mcs); free(w->uecfg); free(w->api_ev); free(w->llr0); free(w->llr1); free(w->payload);
   free(w->ul_grid); free(w->ul_sched); free(w->rar_sched); free(w->ulmod); free(w->ul_time); free(w->ul_active); free(w->ul_success);
+  if (w->harq) {
+    for (int i = 0; i < O_HARQ_ENTITIES; i++)
+      for (int p = 0; p < 8; p++)
+        for (int t = 0; t < 2; t++) { free(w->harq[i].tb[p][t].acc); free(w->harq[i].tb[p][t].keep); }
+    free(w->harq);
+  }
   free(w);
 }
 void o_worker_set_pcap(o_worker_t* w, o_pcap_t* p) { w->pcap = p; }
@@ -767,9 +773,9 @@ static void harq_update_database(o_worker_t* w)
 }
 
 /* one srsran_ue_dl_decode_pdsch call: returns crc[2]; payload of TB i at w->payload + i*8192 */
-static void decode_grant_harq(o_worker_t* w, const dl_entry_t* e, const o_pdsch_grant_t* g, int* crc, int16_t* const* acc, const int* combine);
-static void decode_grant(o_worker_t* w, const dl_entry_t* e, const o_pdsch_grant_t* g, int* crc) { decode_grant_harq(w, e, g, crc, NULL, NULL); }
-static void decode_grant_harq(o_worker_t* w, const dl_entry_t* e, const o_pdsch_grant_t* g, int* crc, int16_t* const* acc, const int* combine)
+static void decode_grant_harq(o_worker_t* w, const dl_entry_t* e, const o_pdsch_grant_t* g, int* crc, int16_t* const* acc, const int* combine, uint8_t* const* keep);
+static void decode_grant(o_worker_t* w, const dl_entry_t* e, const o_pdsch_grant_t* g, int* crc) { decode_grant_harq(w, e, g, crc, NULL, NULL, NULL); }
+static void decode_grant_harq(o_worker_t* w, const dl_entry_t* e, const o_pdsch_grant_t* g, int* crc, int16_t* const* acc, const int* combine, uint8_t* const* keep)
 {
   crc[0] = crc[1] = 0;
   if (!(g->tb[0].enabled || g->tb[1].enabled)) return;
@@ -796,7 +802,7 @@ static void decode_grant_harq(o_worker_t* w, const dl_entry_t* e, const o_pdsch_
       o_trace_set_tb(i);
       if (acc && acc[i])
         crc[i] = o_pdsch_decode_tb_harq(llr, g->tb[i].nof_bits, g->tb[i].tbs, g->tb[i].mod, g->tx_scheme == O_TX_DIVERSITY ? 2 : 1, g->tb[i].rv, w->cfg.max_turbo_iter,
-                                        w->payload + i * 8192 * 2, &its, acc[i], combine[i]);
+                                        w->payload + i * 8192 * 2, &its, acc[i], combine[i], keep ? keep[i] : NULL);
       else
       crc[i] = (w->second_turbo ? o_pdsch_decode_tb_second : o_pdsch_decode_tb)(llr, g->tb[i].nof_bits, g->tb[i].tbs, g->tb[i].mod, g->tx_scheme == O_TX_DIVERSITY ? 2 : 1,
                                  g->tb[i].rv, w->cfg.max_turbo_iter, w->payload + i * 8192 * 2, &its);
@@ -827,6 +833,7 @@ static void decode_dl_mode(o_worker_t* w)
           o_pdsch_grant_t gg = *cur; /* pdsch_cfg->grant */
           int harq_ret[2] = {O_HARQ_NEW_TX, O_HARQ_NEW_TX}, combine[2] = {0, 0};
           int16_t* acc[2] = {NULL, NULL};
+          uint8_t* keep[2] = {NULL, NULL};
           struct o_harq_entity* ent[2] = {NULL, NULL};
           for (int i = 0; i < 2; i++)
             if (gg.tb[i].enabled) {
@@ -835,12 +842,13 @@ static void decode_dl_mode(o_worker_t* w)
               if (harq_ret[i] == O_HARQ_NEW_TX || harq_ret[i] == O_HARQ_RE_TX) {
                 o_harq_tb_t* t = &ent[i]->tb[e->dci.pid][i];
                 if (!t->acc) t->acc = (int16_t*)calloc((size_t)O_HARQ_MAX_CB * O_HARQ_CB_STRIDE, sizeof(int16_t));
-                acc[i] = t->acc; combine[i] = harq_ret[i] == O_HARQ_RE_TX;
+                if (!t->keep) t->keep = (uint8_t*)calloc((size_t)O_HARQ_MAX_CB * O_HARQ_KEEP_STRIDE, 1);
+                acc[i] = t->acc; keep[i] = t->keep; combine[i] = harq_ret[i] == O_HARQ_RE_TX;
               } else if (harq_ret[i] == O_HARQ_DECODED) {
                 gg.tb[i].enabled = 0; /* decoded 8 subframes ago: the block is not decoded again (and nothing is written for it) */
               }
             }
-          if (gg.tb[0].enabled || gg.tb[1].enabled) decode_grant_harq(w, e, &gg, crc, acc, combine);
+          if (gg.tb[0].enabled || gg.tb[1].enabled) decode_grant_harq(w, e, &gg, crc, acc, combine, keep);
           for (int i = 0; i < 2; i++)
             if (gg.tb[i].enabled && (harq_ret[i] == O_HARQ_NEW_TX || harq_ret[i] == O_HARQ_RE_TX))
               harq_update(w, ent[i], (int)e->dci.pid, i, w->sfn, w->sf_idx, crc[i], (int)e->dci.tb[i].ndi, e->dci.tb[i].rv, cur->tb[i].tbs);
