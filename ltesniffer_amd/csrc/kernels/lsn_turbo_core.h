@@ -131,19 +131,26 @@ struct TurboLds {
   uint32_t* spp;   // [K] sys | p1 << 10 | p2 << 20 (10-bit two's complement fields), transposed
   int16_t* ext;    // [K] extrinsic * 2 + hard bit, transposed
   uint8_t* ckpt;   // check-point slots of 14 * nt bytes each: [3][nt] words (states 1|5, 2|6, 3|7) + [nt] halves (state 4); state 0 is 0
+  // A workgroup that decodes TWO blocks (k_turbo: one wavefront each) keeps the three pointers the same for both - compile-time LDS offsets in every
+  // access, as in a one-block workgroup - and moves the second block through its INDICES: `bias` is added to every spp / ext index (the arrays of the two
+  // blocks lie side by side: spp0 spp1 ext0 ext1, kmax + 8 entries each), cw / ch to the lane index of the check-point words / halves (ckpt0 ckpt1).  A
+  // run-time LDS base per wavefront instead cost 60 more spilled registers (round 5).
+  int bias = 0, cw = 0, ch = 0;
 };
 // nt = threads that work on the block (64, or 128 for the blocks with more than 64 windows)
-LSN_HD void lsn_ckpt_store(uint8_t* area, int nt, int slot, int lane, const s2* a)
+LSN_HD void lsn_ckpt_store(uint8_t* area, int nt, int slot, int lane, const s2* a, int cw = 0, int ch = 0)
 {
   uint32_t* w = (uint32_t*)(area + (size_t)(slot * 14 * nt));
-  w[lane] = pk_u32(a[1]); w[nt + lane] = pk_u32(a[2]); w[2 * nt + lane] = pk_u32(a[3]);
-  ((int16_t*)(w + 3 * nt))[lane] = a[0].y;
+  const int lw = lane + cw;
+  w[lw] = pk_u32(a[1]); w[nt + lw] = pk_u32(a[2]); w[2 * nt + lw] = pk_u32(a[3]);
+  ((int16_t*)(w + 3 * nt))[lane + ch] = a[0].y;
 }
-LSN_HD void lsn_ckpt_load(const uint8_t* area, int nt, int slot, int lane, s2* a)
+LSN_HD void lsn_ckpt_load(const uint8_t* area, int nt, int slot, int lane, s2* a, int cw = 0, int ch = 0)
 {
   const uint32_t* w = (const uint32_t*)(area + (size_t)(slot * 14 * nt));
-  a[1] = pk_s2(w[lane]); a[2] = pk_s2(w[nt + lane]); a[3] = pk_s2(w[2 * nt + lane]);
-  a[0] = s2{0, ((const int16_t*)(w + 3 * nt))[lane]};
+  const int lw = lane + cw;
+  a[1] = pk_s2(w[lw]); a[2] = pk_s2(w[nt + lw]); a[3] = pk_s2(w[2 * nt + lw]);
+  a[0] = s2{0, ((const int16_t*)(w + 3 * nt))[lane + ch]};
 }
 
 #ifdef __HIP_DEVICE_COMPILE__
@@ -200,6 +207,8 @@ LSN_HD void lsn_map_pass_lane(const TurboLds& m, const uint32_t* il, int nt, int
                               const s2* nii_a, const s2* nii_b, const s2* beta_tail, s2* a_end, s2* b_out)
 {
   const int wl = active ? lane : 0;
+  const int wlb = wl + m.bias;   // index of this window's column in the (possibly second) block's arrays
+  const uint32_t bias2 = (uint32_t)m.bias * 0x10001u;  // (addresses stay below 2^16: K + bias <= 2 * 2760)
   const int nsb = (W + TB_S - 1) / TB_S;
   s2 a[4], b[4], a0[4];
   if (wl == 0) {
@@ -217,14 +226,14 @@ LSN_HD void lsn_map_pass_lane(const TurboLds& m, const uint32_t* il, int nt, int
     for (int u = 0; u < TB_S / 2; u++) {
       int t2 = sb * (TB_S / 2) + u;
       t2 = t2 < wlast ? t2 : wlast;
-      nx[u] = (il + (uint32_t)(t2 * P))[wl];  // uniform row address + lane offset
+      nx[u] = (il + (uint32_t)(t2 * P))[wl] + bias2;  // uniform row address + lane offset; both 16-bit addresses of the word move by the block's index bias
     }
   };
   if (IL) il_load(0);
   uint32_t g[TB_S];  // operands of one sub-block: lsa (low half) | lp << 16
   // ---- forward sweep over sub-blocks 0 .. nsb-2 (the last one is covered by the recompute below) ----
   for (int sb = 0; sb + 1 < nsb; sb++) {
-    if (sb >= 1) lsn_ckpt_store(m.ckpt, nt, sb - 1, lane, a);
+    if (sb >= 1) lsn_ckpt_store(m.ckpt, nt, sb - 1, lane, a, m.cw, m.ch);
     const int tb = sb * TB_S;
     if (IL) {
 #pragma unroll
@@ -233,7 +242,7 @@ LSN_HD void lsn_map_pass_lane(const TurboLds& m, const uint32_t* il, int nt, int
     }
 #pragma unroll
     for (int u = 0; u < TB_S; u++) {
-      const int nat = (tb + u) * P + wl;
+      const int nat = (tb + u) * P + wlb;
       if (IL) {
         const int idx = (int)((u & 1) ? cur[u >> 1] >> 16 : cur[u >> 1] & 0xFFFFu);
         g[u] = ((uint32_t)(fld0(m.spp[idx]) + ((int)m.ext[idx] >> 1)) & 0xFFFFu) | ((uint32_t)fld2(m.spp[nat]) << 16);
@@ -262,7 +271,7 @@ LSN_HD void lsn_map_pass_lane(const TurboLds& m, const uint32_t* il, int nt, int
       if (sb == 0) {
         for (int k = 0; k < 4; k++) a[k] = a0[k];
       } else {
-        lsn_ckpt_load(m.ckpt, nt, sb - 1, lane, a);
+        lsn_ckpt_load(m.ckpt, nt, sb - 1, lane, a, m.cw, m.ch);
       }
     }
     if (IL) {
@@ -277,14 +286,14 @@ LSN_HD void lsn_map_pass_lane(const TurboLds& m, const uint32_t* il, int nt, int
 #pragma unroll
       for (int u = TB_S - 1; u >= 0; u--) {
         if (FULL || u < n) {
-          const int nat = (tb + u) * P + wl;
+          const int nat = (tb + u) * P + wlb;
           if (IL) {
             const int idx = (int)((u & 1) ? cur[u >> 1] >> 16 : cur[u >> 1] & 0xFFFFu);
-            ix[u] = active ? idx : K;
+            ix[u] = active ? idx : K + m.bias;
             g[u] = ((uint32_t)(fld0(m.spp[idx]) + ((int)m.ext[idx] >> 1)) & 0xFFFFu) | ((uint32_t)fld2(m.spp[nat]) << 16);
           } else {
             const uint32_t w = m.spp[nat];
-            ix[u] = active ? nat : K;
+            ix[u] = active ? nat : K + m.bias;
             g[u] = ((uint32_t)(fld0(w) + ((int)m.ext[nat] >> 1)) & 0xFFFFu) | ((uint32_t)fld1(w) << 16);
           }
         }

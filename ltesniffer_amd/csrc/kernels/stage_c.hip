@@ -462,12 +462,12 @@ __device__ __forceinline__ void map_pass(const TurboLds& m, const uint32_t* il, 
   // next-iteration initialisation: window p starts from the end of window p-1 and ends at the start of window p+1.
   // The exchange goes through the (now idle) check-point area, slots 0 and 1.
   tb_sync(nt);
-  lsn_ckpt_store(m.ckpt, nt, 0, lane, a_end);
-  lsn_ckpt_store(m.ckpt, nt, 1, lane, b_out);
+  lsn_ckpt_store(m.ckpt, nt, 0, lane, a_end, m.cw, m.ch);
+  lsn_ckpt_store(m.ckpt, nt, 1, lane, b_out, m.cw, m.ch);
   tb_sync(nt);
   const int lm = lane > 0 ? lane - 1 : 0, lq = lane + 1 < nt ? lane + 1 : lane;
-  lsn_ckpt_load(m.ckpt, nt, 0, lm, nii_a);
-  lsn_ckpt_load(m.ckpt, nt, 1, lq, nii_b);
+  lsn_ckpt_load(m.ckpt, nt, 0, lm, nii_a, m.cw, m.ch);
+  lsn_ckpt_load(m.ckpt, nt, 1, lq, nii_b, m.cw, m.ch);
   tb_sync(nt);
 }
 
@@ -511,14 +511,14 @@ __device__ __forceinline__ uint32_t wg_xor(uint32_t v, int16_t* scratch, int tid
 // wavefront.  Now:
 //   workgroups [0, nsolo):  one code block each (cbs[wg]): two working wavefronts when it has more than 64 windows, else the second leaves at once;
 //   workgroups [nsolo, ..): TWO code blocks of at most 64 windows, one per wavefront (cbs[nsolo + 2 (wg - nsolo) + wave]), each with its own half of
-//                           the workgroup's LDS (pair_bytes per half) - the host pairs blocks of K <= LSN_TURBO_PAIR_KMAX so that two halves fit a slot.
+//                           the workgroup's LDS (TurboLds: index biases) - the host pairs blocks of K <= LSN_TURBO_PAIR_KMAX so that two halves fit a slot.
 // The two wavefronts of a pair never synchronise with each other (tb_sync).
 template <int NT>
 __global__ __launch_bounds__(NT) TB_WAVES_ATTR void k_turbo(const uint32_t* __restrict__ crc_tab_a, const uint32_t* __restrict__ crc_tab_b, const uint32_t* __restrict__ il_tab,
                                               const LsnCbDev* __restrict__ cbs, const uint32_t* __restrict__ spp_g,
-                                              uint8_t* __restrict__ payload, LsnCbRes* res, uint32_t kmax, uint32_t nsolo, uint32_t ncb, uint32_t kmax_pair, uint32_t pair_bytes)
+                                              uint8_t* __restrict__ payload, LsnCbRes* res, uint32_t kmax, uint32_t nsolo, uint32_t ncb, uint32_t kmax_pair)
 {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_all[];
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // phase cycle counters (LsnCbRes::cyc_*) only in instrumented builds (-DLSN_TURBO_CYCLES): the production kernel reads no clock
 #ifdef LSN_TURBO_CYCLES
 #define TB_CLOCK() clock64()
@@ -527,10 +527,9 @@ __global__ __launch_bounds__(NT) TB_WAVES_ATTR void k_turbo(const uint32_t* __re
 #endif
   const long long tc0 = TB_CLOCK();
   const bool paired = NT == 128 && blockIdx.x >= nsolo;
-  const uint32_t wave = threadIdx.x >> 6;
+  const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: in a scalar register, so that the index biases below are scalars too
   const uint32_t cbi = paired ? nsolo + 2u * (blockIdx.x - nsolo) + wave : blockIdx.x;
   if (cbi >= ncb) return;  // (the odd block of the pairs: its partner wavefront has nothing to decode)
-  unsigned char* smem = smem_all + (paired ? (size_t)wave * pair_bytes : (size_t)0);
   if (paired) kmax = kmax_pair;
   const LsnCbDev cb = cbs[cbi];
   // The transport block of this code block is already lost when its first code block (decoded by an EARLIER launch on this stream)
@@ -548,14 +547,18 @@ __global__ __launch_bounds__(NT) TB_WAVES_ATTR void k_turbo(const uint32_t* __re
   const bool active = lane < P;
   const uint32_t* il = il_tab + cb.il_off;
   TurboLds m;
-  m.spp = (uint32_t*)smem; m.ext = (int16_t*)(m.spp + kmax); m.ckpt = (uint8_t*)(m.ext + kmax + 8);  // ext[K] = spare slot for idle lanes
+  // one block: spp[kmax] ext[kmax + 8] ckpt (ext[K] = spare slot for idle lanes); two blocks: spp0 spp1 (kmax + 8 words each) ext0 ext1 (kmax + 8 halves each)
+  // ckpt0 ckpt1 - the second block is reached through index biases, the three pointers are the same for both wavefronts (TurboLds)
+  const uint32_t kk = kmax + 8u;
+  m.spp = (uint32_t*)smem; m.ext = (int16_t*)(m.spp + (paired ? 2u * kk : kmax)); m.ckpt = (uint8_t*)(m.ext + (paired ? 2u * kk : kk));
+  m.bias = paired ? (int)(wave * kk) : 0; m.cw = paired ? (int)(wave * (uint32_t)(TB_CKPT_BYTES / 4)) : 0; m.ch = 2 * m.cw;
   // the check-point area doubles as scratch for the 12 termination values
-  int* tail = (int*)(m.ckpt + 2048);
+  int* tail = (int*)(m.ckpt + 2048) + m.cw;
   // ---- soft data of the block: K packed words (already in the transposed layout) + 12 termination values, written by k_rm ----
   {
     const uint32_t* src = spp_g + cb.spp_off;  // 16-byte aligned, K is a multiple of 8
-    for (int i = 4 * lane; i < K; i += 4 * nt) *(uint4*)&m.spp[i] = *(const uint4*)&src[i];
-    for (int i = 8 * lane; i < K; i += 8 * nt) *(uint4*)&m.ext[i] = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = 4 * lane; i < K; i += 4 * nt) *(uint4*)&m.spp[i + m.bias] = *(const uint4*)&src[i];
+    for (int i = 8 * lane; i < K; i += 8 * nt) *(uint4*)&m.ext[i + m.bias] = make_uint4(0u, 0u, 0u, 0u);
     if (lane < 12) tail[lane] = (int)src[K + lane];
   }
   tb_sync(nt);
@@ -588,7 +591,7 @@ __global__ __launch_bounds__(NT) TB_WAVES_ATTR void k_turbo(const uint32_t* __re
     uint32_t rem = 0;
     if (active) {
       for (int t = 0; t < W; t++) {
-        rem = (rem << 1) | ((uint32_t)m.ext[t * P + lane] & 1u);
+        rem = (rem << 1) | ((uint32_t)m.ext[t * P + lane + m.bias] & 1u);
         rem ^= (rem & 0x1000000u) ? poly : 0u;
       }
       rem = mulmod24(rem, cw, poly);
@@ -606,7 +609,7 @@ __global__ __launch_bounds__(NT) TB_WAVES_ATTR void k_turbo(const uint32_t* __re
     uint32_t byte = 0;
 #pragma unroll
     for (int q = 0; q < 8; q++) {
-      const uint32_t bit = (uint32_t)m.ext[tr_idx(F + 8 * j + q, W, P, magicW)] & 1u;
+      const uint32_t bit = (uint32_t)m.ext[tr_idx(F + 8 * j + q, W, P, magicW) + m.bias] & 1u;
       byte = (byte << 1) | bit;
       rema = (rema << 1) | bit;
       rema ^= (rema & 0x1000000u) ? 0x1864CFBu : 0u;
@@ -636,7 +639,7 @@ void lsn_launch_turbo(const LsnCellDev& c, const LsnCbDev* cb, const uint32_t* s
   static std::atomic<uint64_t> attr64{0};
   lsn_func_max_lds((const void*)k_turbo<64>, (int)turbo_lds_bytes_nt(6144, 64), attr64, "k_turbo<64>");
   auto fix = [](uint32_t k) { return ((k < 512 ? 512u : k) + 7u) & ~7u; };  // the scratch in the check-point area needs room
-  if (n64) LSN_LAUNCH(k_turbo<64>, dim3(n64), dim3(64), turbo_lds_bytes_nt(fix(kmax64), 64), s, c.crc_tab_a, c.crc_tab_b, c.turbo_il, cb + n128, spp, payload, res, fix(kmax64), n64, n64, 0u, 0u);
+  if (n64) LSN_LAUNCH(k_turbo<64>, dim3(n64), dim3(64), turbo_lds_bytes_nt(fix(kmax64), 64), s, c.crc_tab_a, c.crc_tab_b, c.turbo_il, cb + n128, spp, payload, res, fix(kmax64), n64, n64, 0u);
 }
 
 // One launch for a whole decode phase: cb[0 .. nsolo) one block per workgroup, cb[nsolo .. nsolo + npair) two blocks (K <= LSN_TURBO_PAIR_KMAX, at most 64
@@ -652,7 +655,7 @@ void lsn_launch_turbo_packed(const LsnCellDev& c, const LsnCbDev* cb, const uint
   auto fix = [](uint32_t k) { return ((k < 512 ? 512u : k) + 7u) & ~7u; };  // the scratch in the check-point area needs room
   if (!nsolo && !npair) return;
   const uint32_t ks = nsolo ? fix(kmax_solo) : 512u, kp = npair ? fix(kmax_pair) : 512u;
-  const size_t half = npair ? ((turbo_lds_bytes_nt(kp, 64) + 15) & ~(size_t)15) : 0;
-  const size_t lds = std::max(std::max(nsolo ? turbo_lds_bytes_nt(ks, 128) : (size_t)0, 2 * half), min_lds);
-  LSN_LAUNCH(k_turbo<128>, dim3(nsolo + (npair + 1) / 2), dim3(128), lds, s, c.crc_tab_a, c.crc_tab_b, c.turbo_il, cb, spp, payload, res, ks, nsolo, nsolo + npair, kp, (uint32_t)half);
+  const size_t pair_lds = npair ? 12 * ((size_t)kp + 8) + 2 * TB_CKPT_BYTES : 0;   // spp0 spp1 ext0 ext1 ckpt0 ckpt1 (k_turbo)
+  const size_t lds = std::max(std::max(nsolo ? turbo_lds_bytes_nt(ks, 128) : (size_t)0, pair_lds), min_lds);
+  LSN_LAUNCH(k_turbo<128>, dim3(nsolo + (npair + 1) / 2), dim3(128), lds, s, c.crc_tab_a, c.crc_tab_b, c.turbo_il, cb, spp, payload, res, ks, nsolo, nsolo + npair, kp);
 }
