@@ -209,7 +209,7 @@ int lsn_phy_mib_decode(lsn_phy_t* phy, const void* iq, int iq_on_device, lsn_mib
  * of the subframe-0/5 boundaries and the carrier offset - for a recording also the -O offset and -c cell id that the
  * reference's file mode asks the user for.  The MIB (bandwidth, ports, PHICH, SFN) then comes from lsn_phy_mib_decode.
  * Needs no Phy.  iq: one antenna, contiguous cf32 at the sampling rate of nof_prb (15 kHz * N), at least
- * (nof_periods + 1) * 75 * N + N samples.  FDD, normal cyclic prefix.
+ * (nof_periods + 1) * 75 * N + N samples.  FDD; the cyclic prefix is detected (out->cp).
  * Returns 1 when a cell was found (pss_p2avg >= threshold), 0 when not (out still holds the best guess), < 0 on error. */
 typedef struct {
   uint32_t nof_periods;  /* 5 ms periods whose PSS correlation powers are added (1..16; 0 = 1) */
@@ -225,6 +225,7 @@ typedef struct {
   float sss_metric, sss_second;  /* best and second best of the 336 SSS hypotheses */
   float cfo_hz;                  /* from the phase turn between the SSS and PSS symbols (+-7 kHz) */
   float cfo_coarse_hz;           /* from the two halves of the PSS symbol (+-15 kHz; disturbed by the other carriers of a loaded cell) */
+  uint32_t cp;                   /* 0 normal, 1 extended cyclic prefix (lsn_cell_t.cp): which of the two SSS positions in front of the PSS symbol carried the better SSS */
 } lsn_cell_search_t;
 int lsn_cell_search(int device, const void* iq, int iq_on_device, uint64_t nof_samples, uint32_t nof_prb, const lsn_cell_search_cfg_t* cfg,
                     lsn_cell_search_t* out, float* corr_out /* optional, host: [3][75 N] accumulated PSS correlation powers */);

@@ -77,7 +77,7 @@ class CellSearchCfg(C.Structure):
 class CellSearch(C.Structure):
     _fields_ = [("found", C.c_uint32), ("cell_id", C.c_uint32), ("n_id_2", C.c_uint32), ("n_id_1", C.c_uint32), ("sf_idx", C.c_uint32),
                 ("pss_pos", C.c_uint32), ("sf_start", C.c_uint32), ("pss_peak", C.c_float), ("pss_p2avg", C.c_float),
-                ("sss_metric", C.c_float), ("sss_second", C.c_float), ("cfo_hz", C.c_float), ("cfo_coarse_hz", C.c_float)]
+                ("sss_metric", C.c_float), ("sss_second", C.c_float), ("cfo_hz", C.c_float), ("cfo_coarse_hz", C.c_float), ("cp", C.c_uint32)]
 
 
 class FileCfg(C.Structure):

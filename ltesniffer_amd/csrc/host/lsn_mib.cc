@@ -21,7 +21,6 @@ int Engine::mibDecode(const void* iq, bool on_device, lsn_mib_t* out, float* llr
 {
   if (!cell_set) return LSN_ERROR;
   if (!iq || !out) return LSN_ERROR_INVALID_INPUTS;
-  if (cell.cp != 0) return LSN_ERROR_INVALID_INPUTS;  // PBCH of an extended-CP cell (216 symbols, E = 1728): not built - the reference's own MIB step there is srsRAN's cell search in live mode (LTESniffer_Core.cc:195-204), file mode forces the normal CP (:243)
   if (batch_open) return LSN_ERROR;  // borrows a chunk slot: not while submitted blocks are in flight (call lsn_phy_wait first)
   std::memset(out, 0, sizeof(*out));
   try {

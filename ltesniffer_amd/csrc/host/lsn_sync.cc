@@ -117,7 +117,7 @@ int cell_search(int device, const cf32* iq, bool on_device, uint64_t nsamples, u
   const uint32_t N = sync_fft_size(nof_prb);
   const uint32_t P = cfg.nof_periods ? cfg.nof_periods : 1;
   if (!iq || !N || P > 16 || cfg.force_n_id_2 > 2 || cfg.force_n_id_2 < -1) return LSN_ERROR_INVALID_INPUTS;
-  const uint32_t W5 = 75 * N, cp = 144 * N / 2048;
+  const uint32_t W5 = 75 * N;
   const uint64_t need = (uint64_t)(P + 1) * W5 + N;
   if (nsamples < need) return LSN_ERROR_INVALID_INPUTS;
   int ndev = 0;
@@ -182,41 +182,52 @@ int cell_search(int device, const cf32* iq, bool on_device, uint64_t nsamples, u
   cf32* d_w = bw.alloc<cf32>(N);
   cf32* d_d = bd.alloc<cf32>(62);
   int8_t* d_s = bs.alloc<int8_t>(sss.size());
-  SyncFin* d_o = bo.alloc<SyncFin>(1);
+  SyncFin* d_o = bo.alloc<SyncFin>(2);
   HIP_CHECK(hipMemcpyAsync(d_w, w.data(), N * sizeof(cf32), hipMemcpyHostToDevice, st));
   HIP_CHECK(hipMemcpyAsync(d_d, d, sizeof d, hipMemcpyHostToDevice, st));
   HIP_CHECK(hipMemcpyAsync(d_s, sss.data(), sss.size(), hipMemcpyHostToDevice, st));
-  lsn_launch_sync_fin(d_x, d_p + (size_t)br * N, d_w, d_d, d_s, N, W5, P, bn, cp, d_o, st);
-  SyncFin fin;
-  HIP_CHECK(hipMemcpyAsync(&fin, d_o, sizeof fin, hipMemcpyDeviceToHost, st));
+  // The cyclic prefix of the cell (the reference's search reports it, LTESniffer_Core.cc:195-204): the SSS symbol sits N + 144 (x N / 2048) samples in front of
+  // the PSS symbol with the normal CP, N + 512 with the extended one - both positions are evaluated, the larger best SSS metric decides (normal on a tie)
+  const uint32_t cps[2] = {144 * N / 2048, 512 * N / 2048};
+  for (int hyp = 0; hyp < 2; hyp++) lsn_launch_sync_fin(d_x, d_p + (size_t)br * N, d_w, d_d, d_s, N, W5, P, bn, cps[hyp], d_o + hyp, st);
+  SyncFin fin2[2];
+  HIP_CHECK(hipMemcpyAsync(fin2, d_o, sizeof fin2, hipMemcpyDeviceToHost, st));
   HIP_CHECK(hipStreamSynchronize(st));
-  {
-    const float cr = fin.y[0][0] * fin.y[1][0] + fin.y[0][1] * fin.y[1][1], ci = fin.y[0][0] * fin.y[1][1] - fin.y[0][1] * fin.y[1][0];  // conj(y0) y1
-    out.cfo_coarse_hz = atan2f(ci, cr) / (float)M_PI * 15000.0f;
-  }
-  float m1 = -1.0f, m2 = -1.0f, hr = 0.0f, hi = 0.0f;
-  uint32_t bh = 0;
-  for (uint32_t h = 0; h < 336; h++) {
-    const float ar = fin.hyp[h][0], ai = fin.hyp[h][1];
-    const float mt = ar * ar + ai * ai;
-    if (mt > m1) { m2 = m1; m1 = mt; bh = h; hr = ar; hi = ai; }
-    else if (mt > m2) m2 = mt;
-  }
-  out.n_id_1 = bh >> 1;
-  out.cell_id = 3 * out.n_id_1 + n_id_2;
-  out.sss_metric = m1;
-  out.sss_second = m2;
-  out.cfo_hz = -atan2f(hi, hr) / (2.0f * (float)M_PI) * (15000.0f * (float)N / (float)(N + cp));
-  // subframe timing: the useful part of the PSS symbol starts 160 + 6 (N + 144) [x N / 2048] samples into subframes 0 and 5
-  const uint32_t pss_off = 160 * N / 2048 + 6 * (N + cp);
-  const uint32_t sf_used = (bh & 1u) ? 5u : 0u;                      // of the occurrence the SSS was taken from
-  const uint32_t sf_bn = (fin.j & 1u) ? (sf_used + 5) % 10 : sf_used;  // of the first occurrence
-  if (bn >= pss_off) {
-    out.sf_start = bn - pss_off;
-    out.sf_idx = sf_bn;
-  } else {
-    out.sf_start = bn + W5 - pss_off;
-    out.sf_idx = (sf_bn + 5) % 10;
+  float win_m1 = -1.0f;
+  for (uint32_t hyp = 0; hyp < 2; hyp++) {
+    const SyncFin& fin = fin2[hyp];
+    const uint32_t cp = cps[hyp];
+    float m1 = -1.0f, m2 = -1.0f, hr = 0.0f, hi = 0.0f;
+    uint32_t bh = 0;
+    for (uint32_t h = 0; h < 336; h++) {
+      const float ar = fin.hyp[h][0], ai = fin.hyp[h][1];
+      const float mt = ar * ar + ai * ai;
+      if (mt > m1) { m2 = m1; m1 = mt; bh = h; hr = ar; hi = ai; }
+      else if (mt > m2) m2 = mt;
+    }
+    if (!(m1 > win_m1)) continue;
+    win_m1 = m1;
+    out.cp = hyp;
+    {
+      const float cr = fin.y[0][0] * fin.y[1][0] + fin.y[0][1] * fin.y[1][1], ci = fin.y[0][0] * fin.y[1][1] - fin.y[0][1] * fin.y[1][0];  // conj(y0) y1
+      out.cfo_coarse_hz = atan2f(ci, cr) / (float)M_PI * 15000.0f;
+    }
+    out.n_id_1 = bh >> 1;
+    out.cell_id = 3 * out.n_id_1 + n_id_2;
+    out.sss_metric = m1;
+    out.sss_second = m2;
+    out.cfo_hz = -atan2f(hi, hr) / (2.0f * (float)M_PI) * (15000.0f * (float)N / (float)(N + cp));
+    // subframe timing: the useful part of the PSS symbol starts 160 + 6 (N + 144) [x N / 2048] samples into subframes 0 and 5 (normal CP), 5 (N + 512) + 512 (extended)
+    const uint32_t pss_off = hyp ? 5 * (N + cp) + cp : 160 * N / 2048 + 6 * (N + cp);
+    const uint32_t sf_used = (bh & 1u) ? 5u : 0u;                      // of the occurrence the SSS was taken from
+    const uint32_t sf_bn = (fin.j & 1u) ? (sf_used + 5) % 10 : sf_used;  // of the first occurrence
+    if (bn >= pss_off) {
+      out.sf_start = bn - pss_off;
+      out.sf_idx = sf_bn;
+    } else {
+      out.sf_start = bn + W5 - pss_off;
+      out.sf_idx = (sf_bn + 5) % 10;
+    }
   }
   return out.found ? 1 : 0;
 }

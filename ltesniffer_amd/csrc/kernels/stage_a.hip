@@ -843,17 +843,24 @@ __global__ __launch_bounds__(64) void k_viterbi(LsnCellDev c, const float* __res
 // turned into QPSK soft bits and written once raw and once descrambled for each of the four radio-frame positions of the
 // 40 ms BCH period (c_init = N_cell_ID).  k_pbch_viterbi: one wavefront per hypothesis, the DCI decoder's tail-biting
 // Viterbi on 40 steps (24 MIB bits + CRC16 whose mask tells the number of CRS ports).
+// PBCH resource element i in mapping order: symbols 0-3 of slot 1, 72 centre carriers, the CRS positions of four ports left out of the symbols that carry CRS
+// (normal CP: symbols 0, 1 -> 48 + 48 + 72 + 72 = 240 elements; extended CP: symbols 0, 1, 3 -> 48 + 48 + 72 + 48 = 216; 36.211 6.6.4)
+__device__ __forceinline__ int pbch_count(const LsnCellDev& c) { return c.cp ? 216 : 240; }
 __device__ __forceinline__ void pbch_pos(const LsnCellDev& c, int i, int& l, int& k)
 {
-  const int k0 = (int)c.nre / 2 - 36;
-  if (i < 96) {
-    l = 7 + i / 48;
-    const int j = i % 48, r = (int)(c.id % 3);
+  const int k0 = (int)c.nre / 2 - 36, l0 = (int)c.nslot;
+  int s, j;
+  bool crs;
+  if (i < 96) { s = i / 48; j = i % 48; crs = true; }
+  else if (i < 168) { s = 2; j = i - 96; crs = false; }
+  else { s = 3; j = i - 168; crs = c.cp != 0; }
+  l = l0 + s;
+  if (crs) {
+    const int r = (int)(c.id % 3);
     const int d0 = r == 0 ? 1 : 0, d1 = r == 2 ? 1 : 2;  // the two carriers of a group of three that carry data
     k = k0 + 3 * (j >> 1) + ((j & 1) ? d1 : d0);
   } else {
-    l = 9 + (i - 96) / 72;
-    k = k0 + (i - 96) % 72;
+    k = k0 + j;
   }
 }
 __global__ __launch_bounds__(256) void k_pbch_llr(LsnCellDev c, const cf32* __restrict__ g, const cf32* __restrict__ ce, const LsnChest* __restrict__ ch,
@@ -861,10 +868,12 @@ __global__ __launch_bounds__(256) void k_pbch_llr(LsnCellDev c, const cf32* __re
 {
   const int tid = threadIdx.x, nre = (int)c.nre, A = (int)c.nof_rx;
   const float noise = ch[0].noise_avg;
+  const int np = pbch_count(c), E4 = 2 * np;  // symbols / coded bits of one radio frame's PBCH
+  if (tid < 480 - E4) out[E4 + tid] = 0.0f;   // (extended CP: the raw row keeps its 480 entries, the 48 behind the 432 soft bits are zero)
   cf32 x0, x1;
   int i0 = -1;
   if (c.nof_ports == 1) {
-    if (tid < 240) {
+    if (tid < np) {
       i0 = tid;
       int l, k; pbch_pos(c, tid, l, k);
       float nr = 0.0f, ni = 0.0f, den = 0.0f;
@@ -877,7 +886,7 @@ __global__ __launch_bounds__(256) void k_pbch_llr(LsnCellDev c, const cf32* __re
       den = den + noise;
       x0.r = nr / den; x0.i = ni / den;
     }
-  } else if (tid < 120) {
+  } else if (tid < np / 2) {
     i0 = 2 * tid;
     int l, ka, kb, l2; pbch_pos(c, i0, l, ka); pbch_pos(c, i0 + 1, l2, kb);
     float x0r = 0, x0i = 0, x1r = 0, x1i = 0, hh = 0;
@@ -906,7 +915,7 @@ __global__ __launch_bounds__(256) void k_pbch_llr(LsnCellDev c, const cf32* __re
       const int n = 2 * (i0 + s) + j;
       out[n] = v[j];
       for (int q = 0; q < 4; q++) {
-        const uint32_t m = 480u * (uint32_t)q + (uint32_t)n;
+        const uint32_t m = (uint32_t)E4 * (uint32_t)q + (uint32_t)n;   // the scrambling sequence runs over the 4 x E4 bits of the 40 ms period
         const uint32_t cbit = (uint32_t)c.gold_x1[m] ^ (uint32_t)(__popc(c.gold_x2mask[m] & c.id) & 1);
         out[480 * (q + 1) + n] = cbit ? -v[j] : v[j];
       }
@@ -918,14 +927,18 @@ __global__ __launch_bounds__(64) void k_pbch_viterbi(LsnCellDev c, const float* 
   __shared__ __attribute__((aligned(16))) int symw[LSN_MAX_DCI_D + 4];
   const int lane = threadIdx.x, q = blockIdx.x;
   const float* e = llr5 + 480 * (q + 1);
-  const uint32_t D = 40, D3 = 120, E = 480;
+  const uint32_t D = 40, D3 = 120, E = c.cp ? 432u : 480u;
   for (uint32_t t = lane; t < D; t += 64) {
     uint32_t word = 0;
 #pragma unroll
     for (uint32_t j = 0; j < 3; j++) {
       float acc = 0.0f;
       bool first = true;
-      for (uint32_t k = c.pbch_rank[3 * t + j]; k < E; k += D3) {
+      // radio frame q of the 40 ms period holds bits [E q, E (q + 1)) of the rate-matched sequence: with the extended CP (E = 432) that piece starts
+      // (E q) mod 120 positions into the circular buffer, so the first soft bit of buffer entry r is e[(r - off) mod 120]
+      int k0 = (int)c.pbch_rank[3 * t + j] - (int)((E * (uint32_t)q) % D3);
+      if (k0 < 0) k0 += (int)D3;
+      for (uint32_t k = (uint32_t)k0; k < E; k += D3) {
         const float v = e[k];
         if (first) { acc = v; first = false; } else acc = acc + v;
       }

@@ -133,6 +133,8 @@ void o_subframe_power(const o_cell_t* cell, const ocf_t* grid_ant0, float* rb_po
 
 /* ---------- convolutional code / DCI candidate decode (o_conv.c) ---------- */
 void o_rm_conv_rx(const float* e, int E, float* out, int D3 /* 3*(n+16) */);
+void o_rm_conv_rx_off(const float* e, int E, float* out, int D3, int skip /* positions of the circular buffer in front of e[0] */);
+uint16_t o_dci_decode_off(const float* llr, int E, int nof_bits, uint8_t* payload, int skip);
 void o_viterbi_tb(const uint8_t* sym /* 3*D quantised */, int D, uint8_t* bits);
 /* decode one candidate: llr points at ncce*72, E = 72<<L, n payload bits; returns crc_rem (=RNTI) */
 uint16_t o_dci_decode(const float* llr, int E, int nof_bits, uint8_t* payload);
@@ -232,7 +234,7 @@ uint16_t o_dci_decode_second(const float* llr, int E, int nof_bits, uint8_t* pay
 
 /* ---------- PBCH / MIB (o_pbch.c) ---------- */
 typedef struct { int found; uint32_t sfn /* MIB SFN + radio-frame position */, sfn_offset, nof_prb, nof_ports, phich_length, phich_ng_x6, mib_bits; } o_mib_t;
-void o_pbch_positions(const o_cell_t* cell, uint8_t* l, uint16_t* k);
+int o_pbch_positions(const o_cell_t* cell, uint8_t* l, uint16_t* k);
 void o_pbch_llr(const o_cell_t* cell, uint32_t nof_rx, const ocf_t* grid, const ocf_t* ce, float noise, float* llr);
 int o_pbch_decode(const o_cell_t* cell, uint32_t nof_rx, const ocf_t* grid, const ocf_t* ce, float noise, o_mib_t* out, float* llr_out);
 int o_mib_decode_subframe(const o_cell_t* cell, uint32_t nof_rx, const ocf_t* iq, o_mib_t* out, float* llr_out);
@@ -270,6 +272,7 @@ typedef struct {
   uint32_t pss_pos;  /* first sample of the PSS symbol's useful part, 0 <= pss_pos < 5 ms */
   uint32_t sf_start; /* 0 <= sf_start < 5 ms */
   float pss_peak, pss_p2avg, sss_metric, sss_second, cfo_hz, cfo_coarse_hz;
+  uint32_t cp;       /* 0 normal, 1 extended cyclic prefix: which of the two SSS positions in front of the PSS symbol carried the better SSS */
 } o_sync_t;
 void o_pss_seq(uint32_t n_id_2, ocf_t* d);
 void o_sss_m0m1(uint32_t n_id_1, uint32_t* m0, uint32_t* m1);

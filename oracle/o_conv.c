@@ -8,7 +8,11 @@
 #include "../spec/lte_tables.h"
 #include <string.h>
 
-void o_rm_conv_rx(const float* e, int E, float* out, int D3)
+void o_rm_conv_rx(const float* e, int E, float* out, int D3) { o_rm_conv_rx_off(e, E, out, D3, 0); }
+/* ... for a piece of the rate-matched sequence that starts `skip` (non-<NULL>) positions into the circular buffer: the PBCH of one radio frame is bits
+ * [E q, E (q + 1)) of the 4 E bits of a 40 ms period, and with the extended CP (E = 432) that is not a whole number of turns of the 120-bit buffer
+ * (srsRAN de-rate-matches the whole period with the other three quarters marked absent - the same positions) */
+void o_rm_conv_rx_off(const float* e, int E, float* out, int D3, int skip)
 {
   int D = D3 / 3;
   int R = (D + 31) / 32, KP = 32 * R, ND = KP - D;
@@ -23,11 +27,13 @@ void o_rm_conv_rx(const float* e, int E, float* out, int D3)
   static uint8_t seen[3 * O_DCI_MAX_BITS + 64];
   memset(seen, 0, (size_t)D3);
   for (int i = 0; i < D3; i++) out[i] = 0.0f;
-  int j = 0, k = 0;
+  int j = 0, k = -skip;
   while (k < E) {
     int o = map[j];
     if (o >= 0) {
-      if (!seen[o]) {
+      if (k < 0) {
+        /* in front of the piece */
+      } else if (!seen[o]) {
         out[o] = e[k];
         seen[o] = 1;
       } else {
@@ -83,13 +89,14 @@ void o_viterbi_tb(const uint8_t* sym, int D, uint8_t* bits)
   }
 }
 
-uint16_t o_dci_decode(const float* llr, int E, int nof_bits, uint8_t* payload)
+uint16_t o_dci_decode(const float* llr, int E, int nof_bits, uint8_t* payload) { return o_dci_decode_off(llr, E, nof_bits, payload, 0); }
+uint16_t o_dci_decode_off(const float* llr, int E, int nof_bits, uint8_t* payload, int skip)
 {
   int D = nof_bits + 16;
   float rm[3 * (O_DCI_MAX_BITS + 16)];
   uint8_t q[3 * (O_DCI_MAX_BITS + 16)];
   uint8_t bits[O_DCI_MAX_BITS + 16];
-  o_rm_conv_rx(llr, E, rm, 3 * D);
+  o_rm_conv_rx_off(llr, E, rm, 3 * D, skip);
   for (int i = 0; i < 3 * D; i++) {
     float v = 127.5f + 32.0f * rm[i];
     if (v < 0.0f) v = 0.0f;

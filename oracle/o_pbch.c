@@ -16,15 +16,17 @@
 #define SQRT2F 1.41421356237309504880f
 static inline ocf_t cmulconj(ocf_t a, ocf_t b) { ocf_t c = {a.r * b.r + a.i * b.i, a.i * b.r - a.r * b.i}; return c; }
 
-/* the 240 PBCH resource elements of subframe 0 in mapping order (k fastest): l[i], k[i] */
-void o_pbch_positions(const o_cell_t* cell, uint8_t* l, uint16_t* k)
+/* the PBCH resource elements of subframe 0 in mapping order (k fastest): l[i], k[i]; returns their number - 240 with the normal CP (symbols 0-3 of slot 1, the CRS
+ * positions of four ports left out of symbols 0, 1), 216 with the extended CP (symbol 3 of the slot carries CRS as well; 36.211 6.6.4) */
+int o_pbch_positions(const o_cell_t* cell, uint8_t* l, uint16_t* k)
 {
-  int nre = 12 * (int)cell->nof_prb, k0 = nre / 2 - 36, n = 0;
-  for (int s = 7; s <= 10; s++)
+  int nre = 12 * (int)cell->nof_prb, k0 = nre / 2 - 36, n = 0, nsl = o_nslot(cell);
+  for (int s = nsl; s <= nsl + 3; s++)
     for (int c = k0; c < k0 + 72; c++) {
-      if (s <= 8 && (c % 3) == (int)(cell->id % 3)) continue; /* CRS of ports 0..3 */
+      if ((s <= nsl + 1 || (cell->cp && s == nsl + 3)) && (c % 3) == (int)(cell->id % 3)) continue; /* CRS of ports 0..3 */
       l[n] = (uint8_t)s; k[n] = (uint16_t)c; n++;
     }
+  return n;
 }
 
 /* llr[480]: QPSK soft bits of the subframe's PBCH symbols, NOT descrambled (sign: positive = bit 1, like o_pdcch_llr) */
@@ -32,10 +34,10 @@ void o_pbch_llr(const o_cell_t* cell, uint32_t nof_rx, const ocf_t* grid, const 
 {
   int nre = 12 * (int)cell->nof_prb;
   uint8_t pl[240]; uint16_t pk[240];
-  o_pbch_positions(cell, pl, pk);
+  const int np = o_pbch_positions(cell, pl, pk);
   ocf_t x[240];
   if (cell->nof_ports == 1) {
-    for (int i = 0; i < 240; i++) {
+    for (int i = 0; i < np; i++) {
       float nr = 0.0f, ni = 0.0f, den = 0.0f;
       for (uint32_t rx = 0; rx < nof_rx; rx++) {
         size_t b = ((size_t)rx * 14 + pl[i]) * (size_t)nre + pk[i];
@@ -47,7 +49,7 @@ void o_pbch_llr(const o_cell_t* cell, uint32_t nof_rx, const ocf_t* grid, const 
       x[i].r = nr / den; x[i].i = ni / den;
     }
   } else {
-    for (int i = 0; i < 240; i += 2) {
+    for (int i = 0; i < np; i += 2) {
       float x0r = 0, x0i = 0, x1r = 0, x1i = 0, hh = 0;
       /* four ports (SFBC-FSTD): symbol pairs alternate between the port pairs (0, 2) and (1, 3) */
       const size_t pa = (cell->nof_ports == 4 && (i & 2)) ? 1 : 0, pb = cell->nof_ports == 4 ? pa + 2 : 1;
@@ -66,7 +68,8 @@ void o_pbch_llr(const o_cell_t* cell, uint32_t nof_rx, const ocf_t* grid, const 
       x[i + 1].r = x1r / hh * SQRT2F; x[i + 1].i = x1i / hh * SQRT2F;
     }
   }
-  for (int i = 0; i < 240; i++) { llr[2 * i] = -(x[i].r * SQRT2F); llr[2 * i + 1] = -(x[i].i * SQRT2F); }
+  for (int i = 0; i < np; i++) { llr[2 * i] = -(x[i].r * SQRT2F); llr[2 * i + 1] = -(x[i].i * SQRT2F); }
+  for (int i = 2 * np; i < 480; i++) llr[i] = 0.0f;
 }
 
 /* 36.331 MasterInformationBlock: dl-Bandwidth(3) phich-Duration(1) phich-Resource(2) systemFrameNumber(8) spare(10) */
@@ -90,13 +93,14 @@ int o_pbch_decode(const o_cell_t* cell, uint32_t nof_rx, const ocf_t* grid, cons
 {
   float llr[480], d[480];
   uint8_t c[1920], bits[24];
+  const int E4 = cell->cp ? 432 : 480; /* coded bits per radio frame: 4 x E4 = 1920 / 1728 per 40 ms (36.212 5.3.1.3) */
   o_pbch_llr(cell, nof_rx, grid, ce, noise, llr);
   if (llr_out) memcpy(llr_out, llr, sizeof(llr));
-  o_gold(cell->id, c, 1920);
+  o_gold(cell->id, c, 4 * E4);
   memset(out, 0, sizeof(*out));
   for (uint32_t q = 0; q < 4; q++) {
-    for (int i = 0; i < 480; i++) d[i] = c[480 * q + (uint32_t)i] ? -llr[i] : llr[i];
-    uint16_t mask = o_dci_decode(d, 480, 24, bits);
+    for (int i = 0; i < E4; i++) d[i] = c[(uint32_t)E4 * q + (uint32_t)i] ? -llr[i] : llr[i];
+    uint16_t mask = o_dci_decode_off(d, E4, 24, bits, (int)(((uint32_t)E4 * q) % 120u)); /* frame q of the period starts E4 q bits into the rate-matched sequence */
     uint32_t ports = mask == 0x0000 ? 1u : (mask == 0xFFFF ? 2u : (mask == 0x5555 ? 4u : 0u));
     if (!ports) continue;
     int nz = 0;

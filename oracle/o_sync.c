@@ -107,7 +107,7 @@ int o_cell_search(const ocf_t* x, uint64_t nsamples, uint32_t nof_prb, const o_s
   memset(out, 0, sizeof *out);
   const uint32_t N = (uint32_t)o_fft_size(nof_prb);
   if (!N || (int)N < 0) return -1;
-  const uint32_t sflen = 15 * N, W5 = 5 * sflen, cp = 144 * N / 2048;
+  const uint32_t sflen = 15 * N, W5 = 5 * sflen;
   const uint32_t P = cfg->nof_periods ? cfg->nof_periods : 1;
   if (cfg->force_n_id_2 > 2) return -1;
   if (nsamples < (uint64_t)(P + 1) * W5 + N) return -1;
@@ -148,104 +148,116 @@ int o_cell_search(const ocf_t* x, uint64_t nsamples, uint32_t nof_prb, const o_s
   out->pss_p2avg = mean > 0.0 ? (float)((double)best / mean) : 0.0f;
   out->found = out->pss_p2avg >= cfg->threshold;
 
-  /* Which of the P + 1 PSS occurrences at this lag to take the SSS and the carrier offset from: the strongest one (a
-   * capture may start with dead samples) whose SSS symbol lies inside the buffer.  Per occurrence: the matched filter in
-   * two halves (srsran_pss_cfo_compute: the phase turn between the halves is the carrier offset). */
-  uint32_t jb = 0;
-  float cjb = -1.0f;
-  ocf_t yb[2] = {{0, 0}, {0, 0}};
-  for (uint32_t j = bn >= N + cp ? 0u : 1u; j <= P; j++) {
-    const ocf_t* xj = x + (size_t)j * W5 + bn;
-    ocf_t y[2];
-    float eh[2];
-    for (int h = 0; h < 2; h++) {
-      float ar = 0.0f, ai = 0.0f, e = 0.0f;
-      for (uint32_t k = h * (N / 2); k < (h + 1) * (N / 2); k++) {
-        const float t1 = xj[k].r * pbest[k].r, t2 = xj[k].i * pbest[k].i, t3 = xj[k].i * pbest[k].r, t4 = xj[k].r * pbest[k].i;
-        ar = ar + (t1 + t2);
-        ai = ai + (t3 - t4);
-        e = e + (xj[k].r * xj[k].r + xj[k].i * xj[k].i);
-      }
-      y[h].r = ar;
-      y[h].i = ai;
-      eh[h] = e;
-    }
-    const float sr = y[0].r + y[1].r, si = y[0].i + y[1].i, et = eh[0] + eh[1];
-    const float cj = et > 0.0f ? (sr * sr + si * si) / et : 0.0f;
-    if (cj > cjb) { cjb = cj; jb = j; yb[0] = y[0]; yb[1] = y[1]; }
-  }
-  const uint32_t q0 = bn + jb * W5;
-  const int flipped = (int)(jb & 1u);
-  const ocf_t* xp = x + q0;
-  const ocf_t* xs = x + q0 - (N + cp);
-  {
-    const float cr = yb[0].r * yb[1].r + yb[0].i * yb[1].i, ci = yb[0].r * yb[1].i - yb[0].i * yb[1].r; /* conj(y0) y1 */
-    out->cfo_coarse_hz = atan2f(ci, cr) / (float)M_PI * 15000.0f; /* +-15 kHz, disturbed by the other carriers of a loaded cell */
-  }
-  /* 62 carriers of the PSS and SSS symbols: direct DFT, twiddles from a table */
+  /* The cyclic prefix of the cell (srsran_sync_detect_cp [srsRAN]: the search reports it, LTESniffer_Core.cc:195-204 hands it on): the SSS symbol sits
+   * one symbol in front of the PSS symbol, N + 144 (x N / 2048) samples earlier with the normal CP, N + 512 with the extended one.  Both positions are
+   * tried; the larger best SSS metric decides (the normal CP on a tie). */
   ocf_t* w = (ocf_t*)malloc((size_t)N * sizeof(ocf_t));
   for (uint32_t i = 0; i < N; i++) {
     const double ph = -2.0 * M_PI * (double)i / (double)N;
     w[i].r = (float)cos(ph);
     w[i].i = (float)sin(ph);
   }
-  ocf_t d[62], z[62];
+  ocf_t d[62];
   o_pss_seq(bu, d);
-  for (int m = 0; m < 62; m++) {
-    const uint32_t kb = (uint32_t)sync_bin(m, (int)N);
-    ocf_t Y[2];
-    for (int s = 0; s < 2; s++) {
-      const ocf_t* xx = s ? xs : xp;
-      float ar = 0.0f, ai = 0.0f;
-      for (uint32_t n = 0; n < N; n++) {
-        const ocf_t ww = w[(uint32_t)(((uint64_t)kb * n) % N)];
-        const float t1 = xx[n].r * ww.r, t2 = xx[n].i * ww.i, t3 = xx[n].r * ww.i, t4 = xx[n].i * ww.r;
-        ar = ar + (t1 - t2);
-        ai = ai + (t3 + t4);
+  float win_m1 = -1.0f;
+  for (uint32_t hyp = 0; hyp < 2; hyp++) {
+    const uint32_t cpl = (hyp ? 512u : 144u) * N / 2048;
+    /* Which of the P + 1 PSS occurrences at this lag to take the SSS and the carrier offset from: the strongest one (a
+     * capture may start with dead samples) whose SSS symbol lies inside the buffer.  Per occurrence: the matched filter in
+     * two halves (srsran_pss_cfo_compute: the phase turn between the halves is the carrier offset). */
+    uint32_t jb = 0;
+    float cjb = -1.0f;
+    ocf_t yb[2] = {{0, 0}, {0, 0}};
+    for (uint32_t j = bn >= N + cpl ? 0u : 1u; j <= P; j++) {
+      const ocf_t* xj = x + (size_t)j * W5 + bn;
+      ocf_t y[2];
+      float eh[2];
+      for (int h = 0; h < 2; h++) {
+        float ar = 0.0f, ai = 0.0f, e = 0.0f;
+        for (uint32_t k = h * (N / 2); k < (h + 1) * (N / 2); k++) {
+          const float t1 = xj[k].r * pbest[k].r, t2 = xj[k].i * pbest[k].i, t3 = xj[k].i * pbest[k].r, t4 = xj[k].r * pbest[k].i;
+          ar = ar + (t1 + t2);
+          ai = ai + (t3 - t4);
+          e = e + (xj[k].r * xj[k].r + xj[k].i * xj[k].i);
+        }
+        y[h].r = ar;
+        y[h].i = ai;
+        eh[h] = e;
       }
-      Y[s].r = ar;
-      Y[s].i = ai;
+      const float sr = y[0].r + y[1].r, si = y[0].i + y[1].i, et = eh[0] + eh[1];
+      const float cj = et > 0.0f ? (sr * sr + si * si) / et : 0.0f;
+      if (cj > cjb) { cjb = cj; jb = j; yb[0] = y[0]; yb[1] = y[1]; }
     }
-    /* H = Ypss conj(d); z = Ysss conj(H) */
-    const float hr = Y[0].r * d[m].r + Y[0].i * d[m].i, hi = Y[0].i * d[m].r - Y[0].r * d[m].i;
-    z[m].r = Y[1].r * hr + Y[1].i * hi;
-    z[m].i = Y[1].i * hr - Y[1].r * hi;
+    const uint32_t q0 = bn + jb * W5;
+    const int flipped = (int)(jb & 1u);
+    const ocf_t* xp = x + q0;
+    const ocf_t* xs = x + q0 - (N + cpl);
+    /* 62 carriers of the PSS and SSS symbols: direct DFT, twiddles from a table */
+    ocf_t z[62];
+    for (int m = 0; m < 62; m++) {
+      const uint32_t kb = (uint32_t)sync_bin(m, (int)N);
+      ocf_t Y[2];
+      for (int sy = 0; sy < 2; sy++) {
+        const ocf_t* xx = sy ? xs : xp;
+        float ar = 0.0f, ai = 0.0f;
+        for (uint32_t n = 0; n < N; n++) {
+          const ocf_t ww = w[(uint32_t)(((uint64_t)kb * n) % N)];
+          const float t1 = xx[n].r * ww.r, t2 = xx[n].i * ww.i, t3 = xx[n].r * ww.i, t4 = xx[n].i * ww.r;
+          ar = ar + (t1 - t2);
+          ai = ai + (t3 + t4);
+        }
+        Y[sy].r = ar;
+        Y[sy].i = ai;
+      }
+      /* H = Ypss conj(d); z = Ysss conj(H) */
+      const float hr = Y[0].r * d[m].r + Y[0].i * d[m].i, hi = Y[0].i * d[m].r - Y[0].r * d[m].i;
+      z[m].r = Y[1].r * hr + Y[1].i * hi;
+      z[m].i = Y[1].i * hr - Y[1].r * hi;
+    }
+    float m1 = -1.0f, m2 = -1.0f, br = 0.0f, bi = 0.0f;
+    uint32_t bh = 0;
+    for (uint32_t h = 0; h < 336; h++) { /* h = 2 N_id_1 + (subframe 5) */
+      int8_t sq[62];
+      o_sss_seq(h >> 1, bu, (int)(h & 1), sq);
+      float ar = 0.0f, ai = 0.0f;
+      for (int m = 0; m < 62; m++) {
+        const float sg = (float)sq[m];
+        ar = ar + z[m].r * sg;
+        ai = ai + z[m].i * sg;
+      }
+      const float mt = ar * ar + ai * ai;
+      if (mt > m1) { m2 = m1; m1 = mt; bh = h; br = ar; bi = ai; }
+      else if (mt > m2) m2 = mt;
+    }
+    if (!(m1 > win_m1)) continue; /* the other hypothesis stays */
+    win_m1 = m1;
+    out->cp = hyp;
+    {
+      const float cr = yb[0].r * yb[1].r + yb[0].i * yb[1].i, ci = yb[0].r * yb[1].i - yb[0].i * yb[1].r; /* conj(y0) y1 */
+      out->cfo_coarse_hz = atan2f(ci, cr) / (float)M_PI * 15000.0f; /* +-15 kHz, disturbed by the other carriers of a loaded cell */
+    }
+    out->n_id_1 = bh >> 1;
+    out->cell_id = 3 * out->n_id_1 + bu;
+    out->sss_metric = m1;
+    out->sss_second = m2;
+    /* fine carrier offset: the SSS symbol, equalised with the channel seen by the PSS symbol one symbol (N + cp samples)
+     * later, is turned by -2 pi f (N + cp) / fs; unambiguous within +-7 kHz */
+    out->cfo_hz = -atan2f(bi, br) / (2.0f * (float)M_PI) * (15000.0f * (float)N / (float)(N + cpl));
+    /* subframe timing: the PSS symbol's useful part starts 160 + 6 (N + 144) [x N/2048] samples into subframe 0 / 5 (normal CP: the seventh symbol),
+     * 5 (N + 512) + 512 with the extended CP (the sixth symbol) */
+    const uint32_t pss_off = hyp ? 5 * (N + cpl) + cpl : 160 * N / 2048 + 6 * (N + cpl);
+    uint32_t sf_of_q0 = (bh & 1) ? 5u : 0u;
+    uint32_t sf_of_bn = flipped ? (sf_of_q0 + 5) % 10 : sf_of_q0;
+    if (bn >= pss_off) {
+      out->sf_start = bn - pss_off;
+      out->sf_idx = sf_of_bn;
+    } else {
+      out->sf_start = bn + W5 - pss_off;
+      out->sf_idx = (sf_of_bn + 5) % 10;
+    }
   }
   free(w);
   free(p);
   free(pbest);
-  float m1 = -1.0f, m2 = -1.0f, br = 0.0f, bi = 0.0f;
-  uint32_t bh = 0;
-  for (uint32_t h = 0; h < 336; h++) { /* h = 2 N_id_1 + (subframe 5) */
-    int8_t s[62];
-    o_sss_seq(h >> 1, bu, (int)(h & 1), s);
-    float ar = 0.0f, ai = 0.0f;
-    for (int m = 0; m < 62; m++) {
-      const float sg = (float)s[m];
-      ar = ar + z[m].r * sg;
-      ai = ai + z[m].i * sg;
-    }
-    const float mt = ar * ar + ai * ai;
-    if (mt > m1) { m2 = m1; m1 = mt; bh = h; br = ar; bi = ai; }
-    else if (mt > m2) m2 = mt;
-  }
-  out->n_id_1 = bh >> 1;
-  out->cell_id = 3 * out->n_id_1 + bu;
-  out->sss_metric = m1;
-  out->sss_second = m2;
-  /* fine carrier offset: the SSS symbol, equalised with the channel seen by the PSS symbol one symbol (N + cp samples)
-   * later, is turned by -2 pi f (N + cp) / fs; unambiguous within +-7 kHz */
-  out->cfo_hz = -atan2f(bi, br) / (2.0f * (float)M_PI) * (15000.0f * (float)N / (float)(N + cp));
-  /* subframe timing: the PSS symbol's useful part starts 160 + 6 (N + 144) [x N/2048] samples into subframe 0 / 5 */
-  const uint32_t pss_off = 160 * N / 2048 + 6 * (N + cp);
-  uint32_t sf_of_q0 = (bh & 1) ? 5u : 0u;
-  uint32_t sf_of_bn = flipped ? (sf_of_q0 + 5) % 10 : sf_of_q0;
-  if (bn >= pss_off) {
-    out->sf_start = bn - pss_off;
-    out->sf_idx = sf_of_bn;
-  } else {
-    out->sf_start = bn + W5 - pss_off;
-    out->sf_idx = (sf_of_bn + 5) % 10;
-  }
   return out->found ? 1 : 0;
 }

@@ -78,7 +78,10 @@ def test_process_file_matches_oracle_worker(tmp_path, monkeypatch, scn, nsf, lea
     assert gpu_records(phy) == orecs
     # max_subframes stops early; a wrong antenna count is refused
     phy2 = la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=8, pcapwriter=la.PcapWriter(None))
+    assert la.lib().lsn_phy_prepare_file(phy2._h, sc["nof_rx"]) == la.LSN_ERROR          # no cell yet
     assert phy2.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"])
+    assert la.lib().lsn_phy_prepare_file(phy2._h, sc["nof_rx"] + 1) == la.LSN_ERROR_INVALID_INPUTS
+    phy2.prepare_file()   # block buffers reserved ahead of the replay (lsn_phy_prepare_file): the replay finds them
     assert phy2.process_file(p, start_tti=tti0, offset_time=lead, offset_freq=cfo, max_subframes=block + 3) == block + 3
     fc = la.FileCfg(sc["nof_rx"] + 1, 0, 0.0)
     assert la.lib().lsn_phy_process_file(phy2._h, os.fsencode(p), C.byref(fc), 0, 0, 0, None) == la.LSN_ERROR_INVALID_INPUTS

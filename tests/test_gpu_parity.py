@@ -114,18 +114,6 @@ def test_extended_cyclic_prefix_ports_bandwidths_and_four_control_symbols():
     _run("small", 20, seed=37, cp=1, nof_prb=15, cfi=0, cell_id=500, phich_ng_x6=12, snr_db=12.0)
 
 
-def test_extended_cp_mib_helper_is_refused():
-    """the PBCH helper of the file source is built for the normal CP only (the reference's file mode forces it, LTESniffer_Core.cc:243): an extended-CP
-    engine answers lsn_phy_mib_decode with LSN_ERROR_INVALID_INPUTS instead of decoding on the wrong symbol grid"""
-    import ctypes as C
-    phy = la.Phy(nof_rx_antennas=1)
-    assert phy.setCell(25, 2, 1, cp=1)
-    iq = np.zeros((1, 15 * 512), dtype=np.complex64)
-    out = la.Mib()
-    assert la.lib().lsn_phy_mib_decode(phy._h, iq.ctypes.data, 0, C.byref(out)) == la.LSN_ERROR_INVALID_INPUTS
-    phy.close()
-
-
 def test_worker_pool_api_matches_oracle():
     """the reference's own call pattern: getAvail -> fill buffers -> prepare -> putPending ... joinPending"""
     sc = scenario("small", seed=21)

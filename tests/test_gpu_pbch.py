@@ -13,12 +13,13 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("scn,over", [("small", {}), ("cfg1", {}), ("cfg3", dict(dl_min=2, dl_max=3)), ("small", dict(cell_id=301, phich_ng_x6=6, snr_db=6.0)),
-                                      ("small", dict(nof_ports=4)), ("cfg2", dict(nof_ports=4, cell_id=77, snr_db=7.0))])
+                                      ("small", dict(nof_ports=4)), ("cfg2", dict(nof_ports=4, cell_id=77, snr_db=7.0)),
+                                      ("small", dict(cp=1)), ("cfg1", dict(cp=1, cell_id=11)), ("small", dict(cp=1, nof_ports=4, nof_prb=50, snr_db=8.0))])
 def test_mib_decode_matches_oracle(scn, over):
     sc = scenario(scn, seed=12, start_tti=10 * 1021 + 8, **over)
     tx = TxGen(**sc)
     phy = la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=4)
-    assert phy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"])
+    assert phy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"], cp=sc.get("cp", 0))
     found = 0
     for _ in range(45):
         tti, iq, _ = tx.next()

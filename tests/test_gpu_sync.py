@@ -12,7 +12,7 @@ from test_sync_oracle import oracle_cell_search
 
 pytestmark = pytest.mark.gpu
 
-FIELDS = ("found", "cell_id", "n_id_2", "n_id_1", "sf_idx", "pss_pos", "sf_start")
+FIELDS = ("found", "cell_id", "n_id_2", "n_id_1", "sf_idx", "pss_pos", "sf_start", "cp")
 FLOATS = ("pss_peak", "pss_p2avg", "sss_metric", "sss_second", "cfo_hz", "cfo_coarse_hz")
 
 
@@ -30,6 +30,9 @@ def same(g, o):
     ("small", dict(cell_id=100, nof_prb=15), 5000, 400.0, 1, 1),
     ("cfg1", dict(cell_id=150), 60001, 0.0, 2, 0),
     ("cfg3", dict(cell_id=37, dl_min=2, dl_max=3), 20000, -700.0, 1, 1),
+    ("small", dict(cell_id=301, cp=1), 1234, 0.0, 1, -1),                      # extended cyclic prefix: the SSS sits N + N / 4 in front of the PSS
+    ("small", dict(cell_id=44, cp=1, nof_prb=50, nof_ports=1, nof_rx=1), 30001, 600.0, 2, -1),
+    ("small", dict(cell_id=503, cp=1, nof_prb=6), 77, -2500.0, 3, 1),
 ])
 def test_cell_search_matches_oracle(scn, over, lead, cfo, periods, force):
     sc = scenario(scn, seed=5, start_tti=10 * 77 + 3, cfo_hz=cfo, **over)
@@ -39,7 +42,7 @@ def test_cell_search_matches_oracle(scn, over, lead, cfo, periods, force):
     assert np.array_equal(gcorr.view(np.uint32), ocorr.view(np.uint32)), float(np.abs(gcorr - ocorr).max())
     assert rg == ro == 1
     same(sg, so)
-    assert sg.cell_id == sc["cell_id"]
+    assert sg.cell_id == sc["cell_id"] and sg.cp == sc.get("cp", 0)
 
 
 def test_cell_search_on_noise_device_input_and_invalid_arguments():
@@ -83,6 +86,31 @@ def test_recording_with_unknown_offset_cell_and_sfn_is_replayed_like_the_oracle(
     orecs = oracle_records(parse_pcap(ow.pcap_bytes()))
     phy = la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=8, pcapwriter=la.PcapWriter(None))
     assert phy.setCell(sc["nof_prb"], sc["nof_ports"], s.cell_id)
+    assert phy.process_file(p, start_tti=la.TTI_FROM_MIB, offset_time=off, update_meta_period=20) == 50 - first
+    assert gpu_records(phy) == orecs and orecs
+    phy.close()
+
+
+def test_extended_cp_recording_search_mib_and_replay(tmp_path):
+    """the chain of a recording from an extended-CP cell: lsn_cell_search reports cp = 1 and the subframe boundary, lsn_phy_set_cell takes the CP, the PBCH (216
+    symbols, 4 x 432 bits per 40 ms) gives the SFN, the replay writes what the oracle's worker writes"""
+    sc = scenario("small", seed=18, start_tti=10 * 300 + 4, cell_id=101, cp=1)
+    tti0, iq, _ = gen_subframes(sc, 50)
+    lead = 2222
+    p = str(tmp_path / "cap.cf32")
+    write_capture(p, iq, lead=lead)
+    raw = np.fromfile(p, dtype=np.complex64).reshape(-1, sc["nof_rx"])
+    rc, s = la.cell_search(raw[:, 0], sc["nof_prb"], nof_periods=2)
+    sflen = iq.shape[2]
+    assert rc == 1 and s.cell_id == sc["cell_id"] and s.cp == 1 and s.sf_start == lead + sflen and s.sf_idx == 5
+    off = s.sf_start + 5 * sflen
+    first = (off - lead) // sflen
+    ow = OracleWorker(sc["nof_prb"], sc["nof_ports"], s.cell_id, sc["nof_rx"], cp=1)
+    for i in range(first, 50):
+        ow.work(iq[i], tti0 + i, update_meta=1 if (i - first) % 20 == 0 else 0)
+    orecs = oracle_records(parse_pcap(ow.pcap_bytes()))
+    phy = la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=8, pcapwriter=la.PcapWriter(None))
+    assert phy.setCell(sc["nof_prb"], sc["nof_ports"], s.cell_id, cp=s.cp)
     assert phy.process_file(p, start_tti=la.TTI_FROM_MIB, offset_time=off, update_meta_period=20) == 50 - first
     assert gpu_records(phy) == orecs and orecs
     phy.close()

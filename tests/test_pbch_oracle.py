@@ -15,7 +15,7 @@ class OMib(C.Structure):
 def oracle_mib(sc, iq, llr=None):
     o = oracle()
     o.o_mib_decode_subframe.argtypes = [C.POINTER(OCell), C.c_uint32, C.c_void_p, C.POINTER(OMib), C.c_void_p]
-    cell = OCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"], sc["phich_ng_x6"])
+    cell = OCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"], sc["phich_ng_x6"], 0, sc.get("cp", 0))
     m = OMib()
     iq = np.ascontiguousarray(iq, dtype=np.complex64)
     r = o.o_mib_decode_subframe(C.byref(cell), sc["nof_rx"], iq.ctypes.data, C.byref(m), llr.ctypes.data if llr is not None else None)
@@ -23,7 +23,8 @@ def oracle_mib(sc, iq, llr=None):
 
 
 @pytest.mark.parametrize("scn,over", [("small", {}), ("cfg1", {}), ("cfg3", dict(dl_min=2, dl_max=3)), ("small", dict(cell_id=301, phich_ng_x6=6, snr_db=8.0)),
-                                      ("small", dict(nof_ports=4)), ("small", dict(nof_ports=4, nof_prb=100, cell_id=77, snr_db=8.0))])
+                                      ("small", dict(nof_ports=4)), ("small", dict(nof_ports=4, nof_prb=100, cell_id=77, snr_db=8.0)),
+                                      ("small", dict(cp=1)), ("cfg1", dict(cp=1, cell_id=11)), ("small", dict(cp=1, nof_ports=4, nof_prb=50, snr_db=8.0))])  # extended CP: 216 symbols, E = 1728
 def test_mib_loopback_recovers_sfn_ports_and_bandwidth(scn, over):
     sc = scenario(scn, seed=12, start_tti=10 * 513 + 7, **over)  # starts in the middle of a frame, SFN 513
     tx = TxGen(**sc)

@@ -114,3 +114,16 @@ def oracle_cell_search(x, nof_prb, periods, force, threshold):
     x = np.ascontiguousarray(x, dtype=np.complex64)
     r = o.o_cell_search(x.ctypes.data, x.size, nof_prb, C.byref(cfg), C.byref(s), corr.ctypes.data)
     return r, s, corr
+
+
+def test_cell_search_detects_the_cyclic_prefix():
+    """the SSS symbol sits N + 144 (x N / 2048) samples in front of the PSS symbol with the normal CP, N + 512 with the extended one: the search tries both
+    and reports which carried the better SSS, the subframe boundary follows from it"""
+    for cp, nprb, cid, lead in ((1, 25, 301, 1234), (1, 6, 77, 5000), (0, 25, 301, 1234), (1, 50, 500, 99)):
+        sc = scenario("small", seed=5, start_tti=10 * 77 + 3, cell_id=cid, nof_prb=nprb, cp=cp)
+        x, first_tti = sync_capture(sc, lead, 2)
+        r, s, _ = oracle_cell_search(x, nprb, 2, -1, 20.0)
+        N = {6: 128, 25: 512, 50: 1024}[nprb]
+        assert r == 1 and s.cell_id == cid and s.cp == cp, (cp, nprb, s.cell_id, s.cp)
+        # the capture starts `lead` samples in front of subframe 3: the first subframe 0 / 5 boundary is subframe 5, two subframes on
+        assert s.sf_idx == 5 and s.sf_start == lead + 2 * 15 * N, (s.sf_idx, s.sf_start)
