@@ -34,7 +34,7 @@ typedef struct {
   uint32_t nof_prb;         /* 6, 15, 25, 50, 75, 100 */
   uint32_t nof_ports;       /* 1, 2 or 4 CRS ports (4: transmit diversity on every channel; spatial-multiplexing grants are found and not decoded, as with the reference's srsRAN) */
   uint32_t id;              /* physical cell id */
-  uint32_t cp;              /* 0 = normal, 1 = extended cyclic prefix (6 symbols per slot; downlink path - an UL_MODE engine refuses it; PBCH / cell search helpers: normal only) */
+  uint32_t cp;              /* 0 = normal, 1 = extended cyclic prefix (6 symbols per slot; DL mode and UL_MODE; lsn_cell_search reports it) */
   uint32_t phich_length;    /* 0 = normal */
   uint32_t phich_resources; /* 0: 1/6, 1: 1/2, 2: 1, 3: 2 (LTESniffer_Core.cc:211-212 forces 1/6) */
   uint32_t frame_type;      /* 0 = FDD */

@@ -399,6 +399,7 @@ void Engine::buildTables()
   if (cfg.harq_mode) {  // soft buffers of 300 entities x 8 processes x 2 transport blocks, 16 code blocks of K = 6144 each: 1.9 GB of the 288
     d_harq_pool = dalloc<uint32_t>(dev_allocs, (size_t)HarqDatabase::NENT * HarqDatabase::NPID * 2 * HARQ_SLOT_WORDS);
     harq_db = HarqDatabase();
+    harq_keep.clear();
   }
   // pipeline slots, decode runners, staging
   for (int i = 0; i < nslots; i++) allocChunk(chunks[i]);
