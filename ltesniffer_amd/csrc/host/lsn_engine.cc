@@ -298,14 +298,14 @@ void Engine::launchStageA(Chunk& ch, const void* d_iq)
     if (ch.timed_a) HIP_CHECK(hipEventRecord(ch.ev_a[2 * n + 1], st));
     n++;
   };
-  timed([&] { lsn_launch_ofdm(cd, iq, d_dphi, ch.d_grid, nsf, st); });
+  timed([&] { lsn_launch_ofdm(cd, iq, d_dphi, ch.d_grid, nsf, st, ch.d_rbp_part); });
   timed([&] { lsn_launch_chest(cd, ch.d_grid, ch.d_sfidx, ch.d_ce, ch.d_chest_raw, nsf, st); });
   timed([&] { lsn_launch_chest_fin(cd, ch.d_chest_raw, ch.d_chest, nsf, st); });
   timed([&] { lsn_launch_pcfich(cd, ch.d_grid, ch.d_ce, ch.d_chest, ch.d_sfidx, ch.d_cfi, ch.d_pcfich_corr, nsf, st); });
   timed([&] { lsn_launch_pdcch_llr(cd, ch.d_grid, ch.d_ce, ch.d_chest, ch.d_sfidx, ch.d_cfi, ch.d_llr, nsf, st); });
   timed([&] { lsn_launch_cce_power(cd, ch.d_llr, ch.d_cfi, ch.d_ccepow, nsf, st); });
   timed([&] { lsn_launch_viterbi(cd, ch.d_llr, ch.d_ccepow, ch.d_cfi, ch.d_sfidx, ch.d_cand, nsf, st); });
-  timed([&] { lsn_launch_rb_power(cd, ch.d_grid, ch.d_rbp, nsf, st); });
+  timed([&] { lsn_launch_rb_power(cd, ch.d_rbp_part, ch.d_rbp, nsf, st); });
   if (cfg.sniffer_mode == 1) lsn_launch_ul_fft(cd, iq, cd.iq_nant, 1, ch.d_ul_grid, nsf, st);  // srsran_enb_ul_fft on antenna 1, UL_Sniffer_PUSCH.cc:391-392
   // mirrors for the host stages: posted writes of a copy kernel into the pinned buffers (not the copy engine, lsn_dev.h)
   {

@@ -64,7 +64,7 @@ struct Chunk {
   cf32 *d_grid = nullptr, *d_ce = nullptr, *d_ul_grid = nullptr;
   hipStream_t st_a = nullptr;        // stage-A stream of this trip through the pipeline
   const cf32* d_iq_src = nullptr;    // the caller's samples of this chunk ([sf][antenna][sflen]), valid until the call returns
-  float *d_chest_raw = nullptr, *d_llr = nullptr, *d_ccepow = nullptr, *d_pcfich_corr = nullptr, *d_rbp = nullptr;
+  float *d_chest_raw = nullptr, *d_llr = nullptr, *d_ccepow = nullptr, *d_pcfich_corr = nullptr, *d_rbp = nullptr, *d_rbp_part = nullptr;
   LsnChest* d_chest = nullptr;
   uint32_t *d_cfi = nullptr, *d_sfidx = nullptr;
   LsnCand* d_cand = nullptr;

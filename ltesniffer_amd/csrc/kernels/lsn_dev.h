@@ -152,7 +152,7 @@ struct LsnCopySegs {
 void lsn_launch_copy_multi(const LsnCopySegs& sg, bool to_host, hipStream_t s);
 void lsn_launch_pdsch_prep_up(const LsnCellDev& c, const LsnGrantDev* jobs_host, LsnGrantDev* jobs_dev, uint32_t njobs, const LsnCopySegs& sg, uint16_t* prefix, hipStream_t s);
 // launchers (stage_a.hip / stage_c.hip)
-void lsn_launch_ofdm(const LsnCellDev& c, const cf32* iq, const uint32_t* dphi, cf32* grid, uint32_t nsf, hipStream_t s);
+void lsn_launch_ofdm(const LsnCellDev& c, const cf32* iq, const uint32_t* dphi, cf32* grid, uint32_t nsf, hipStream_t s, float* rbp_part = nullptr /* [sf][14][128]: per-symbol PRB power terms of antenna 0 */);
 void lsn_launch_chest(const LsnCellDev& c, const cf32* grid, const uint32_t* sf_idx, cf32* ce, float* raw, uint32_t nsf, hipStream_t s);
 void lsn_launch_chest_fin(const LsnCellDev& c, const float* raw, LsnChest* out, uint32_t nsf, hipStream_t s);
 void lsn_launch_pcfich(const LsnCellDev& c, const cf32* grid, const cf32* ce, const LsnChest* ch, const uint32_t* sf_idx, uint32_t* cfi, float* corr, uint32_t nsf, hipStream_t s);
@@ -160,7 +160,7 @@ void lsn_launch_pdcch_llr(const LsnCellDev& c, const cf32* grid, const cf32* ce,
 void lsn_launch_cce_power(const LsnCellDev& c, const float* llr, const uint32_t* cfi, float* pw, uint32_t nsf, hipStream_t s);
 void lsn_launch_viterbi(const LsnCellDev& c, const float* llr, const float* pw, const uint32_t* cfi, const uint32_t* sf_idx, LsnCand* cand, uint32_t nsf,
                         hipStream_t s);
-void lsn_launch_rb_power(const LsnCellDev& c, const cf32* grid, float* rbp, uint32_t nsf, hipStream_t s);
+void lsn_launch_rb_power(const LsnCellDev& c, const float* rbp_part, float* rbp, uint32_t nsf, hipStream_t s);
 void lsn_launch_ul_fft(const LsnCellDev& c, const cf32* iq, uint32_t nant, uint32_t ant, cf32* grid, uint32_t nsf, hipStream_t s);
 void lsn_launch_pbch(const LsnCellDev& c, const cf32* grid, const cf32* ce, const LsnChest* ch, float* llr5, LsnCand* out4, hipStream_t s);
 void lsn_launch_file_unpack(const cf32* raw, const cf32* rot, uint32_t sflen, uint32_t nant, cf32* out, uint32_t nsf, hipStream_t s);

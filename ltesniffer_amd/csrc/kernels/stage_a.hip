@@ -49,8 +49,20 @@ __device__ __forceinline__ void fft_pass(cf32* a, const cf32* w, int s, int N, i
   }
 }
 
+// rbp_part (optional): [sf][14][128] - the per-symbol term of SubframePower::computePower (SubframePower.cc:26-30: mean |x|^2 over the 12 REs of every PRB of
+// antenna 0), written here from the symbol the workgroup has just produced; k_rb_power then only adds the 14 terms of a PRB in symbol order (rounds 1-4: a
+// kernel that read the whole grid a second time, 0.13 MB per subframe)
+__device__ __forceinline__ void ofdm_rb_power(const LsnCellDev& c, const cf32* out, float* __restrict__ rbp_part, int sf, int l, int tid)
+{
+  __syncthreads();  // the row this workgroup stored is read back (L2)
+  if (tid < (int)c.nof_prb) {
+    float s = 0.0f;
+    for (int k = 0; k < 12; k++) { const cf32 x = out[tid * 12 + k]; s = s + (x.r * x.r + x.i * x.i); }
+    rbp_part[((size_t)sf * 14 + l) * 128 + tid] = s / 12.0f;
+  }
+}
 __global__ __launch_bounds__(256) void k_ofdm(LsnCellDev c, const cf32* __restrict__ iq, const uint32_t* __restrict__ dphi_sf,
-                                              cf32* __restrict__ grid)
+                                              cf32* __restrict__ grid, float* __restrict__ rbp_part)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int N = (int)c.N, lgN = (int)c.lgN, tid = threadIdx.x;
@@ -98,6 +110,7 @@ __global__ __launch_bounds__(256) void k_ofdm(LsnCellDev c, const cf32* __restri
       X.i = si + t2.i;
       out[k] = X;
     }
+    if (rbp_part && rx == 0) ofdm_rb_power(c, out, rbp_part, sf, l, tid);
     return;
   }
   for (int n = tid; n < N / 2; n += 256) w[n] = c.twiddle[n];
@@ -123,12 +136,13 @@ __global__ __launch_bounds__(256) void k_ofdm(LsnCellDev c, const cf32* __restri
     int bin = (k < nre / 2) ? (N - nre / 2 + k) : (k - nre / 2 + 1);
     out[k] = a[bin];
   }
+  if (rbp_part && rx == 0) ofdm_rb_power(c, out, rbp_part, sf, l, tid);
 }
 
-void lsn_launch_ofdm(const LsnCellDev& c, const cf32* iq, const uint32_t* dphi, cf32* grid, uint32_t nsf, hipStream_t s)
+void lsn_launch_ofdm(const LsnCellDev& c, const cf32* iq, const uint32_t* dphi, cf32* grid, uint32_t nsf, hipStream_t s, float* rbp_part)
 {
   size_t lds = sizeof(cf32) * (c.N + c.N / 2);
-  LSN_LAUNCH(k_ofdm, dim3(nsf * c.nof_rx * c.nsym), dim3(256), lds, s, c, iq, dphi, grid);
+  LSN_LAUNCH(k_ofdm, dim3(nsf * c.nof_rx * c.nsym), dim3(256), lds, s, c, iq, dphi, grid, rbp_part);
 }
 
 // ------------------------------------------------------------------------------------------------ channel estimation
@@ -969,23 +983,19 @@ void lsn_launch_viterbi(const LsnCellDev& c, const float* llr, const float* pw, 
 #endif
 }
 
-// SubframePower::computePower (SubframePower.cc:18-42) linear part: sum over 14 symbols of mean |x|^2 per PRB (antenna 0)
-__global__ void k_rb_power(LsnCellDev c, const cf32* __restrict__ grid, float* __restrict__ rbp)
+// SubframePower::computePower (SubframePower.cc:18-42) linear part: sum over 14 symbols of mean |x|^2 per PRB (antenna 0).  The per-symbol terms come from
+// k_ofdm (rbp_part); this kernel adds them in symbol order (the rows of an extended-CP subframe behind symbol 11 are zero, as in the 14-row grid)
+__global__ void k_rb_power(LsnCellDev c, const float* __restrict__ part, float* __restrict__ rbp)
 {
   const int sf = blockIdx.x, prb = threadIdx.x;
   if (prb >= (int)c.nof_prb) return;
-  const cf32* g = grid + (size_t)sf * c.nof_rx * 14 * c.nre;
   float acc = 0.0f;
-  for (int j = 0; j < 14; j++) {
-    float s = 0.0f;
-    for (int k = 0; k < 12; k++) { cf32 x = g[j * c.nre + prb * 12 + k]; s = s + (x.r * x.r + x.i * x.i); }
-    acc = acc + s / 12.0f;
-  }
+  for (int j = 0; j < 14; j++) acc = acc + part[((size_t)sf * 14 + j) * 128 + prb];
   rbp[sf * 128 + prb] = acc;
 }
-void lsn_launch_rb_power(const LsnCellDev& c, const cf32* grid, float* rbp, uint32_t nsf, hipStream_t s)
+void lsn_launch_rb_power(const LsnCellDev& c, const float* part, float* rbp, uint32_t nsf, hipStream_t s)
 {
-  LSN_LAUNCH(k_rb_power, dim3(nsf), dim3(128), 0, s, c, grid, rbp);
+  LSN_LAUNCH(k_rb_power, dim3(nsf), dim3(128), 0, s, c, part, rbp);
 }
 
 // ------------------------------------------------------------------------------------------------ IQ capture file source
