@@ -1214,6 +1214,7 @@ void Engine::commitChunk(Chunk& ch, JobRunner& r)
       publishPrediction(d.rnti);
     }
   }
+  if (cfg.harq_mode) harqFlushStores(ch, r);   // the chunk's keep store is recycled with the chunk: its queued soft-buffer copies go out now
   for (const DecodeJob& j : ch.jobs) {
     if (!j.done) continue;
     const int k = j.kind < 5 ? j.kind : 0;
@@ -1245,11 +1246,24 @@ void Engine::harqStore(Chunk& ch, JobRunner& r, int job, int tb, size_t slot)
     boff += cb.out_bytes;
     cb.e_off = cb.spp_off;                                        // this transmission, in the chunk's keep store
     cb.spp_off = (uint32_t)(slot * HARQ_SLOT_WORDS + q * HARQ_CB_WORDS);
-    r.h_cbs_pinned[q] = cb;
+    harq_store_q.push_back(cb);
   }
+  // Nothing reads a stored block before a retransmission combines with it: the copies are queued and go to the GPU in ONE launch in front of the next
+  // combine or at the end of the chunk's commit turn (harqFlushStores) - rounds 4 / early 5 paid an upload, a launch and a stream synchronisation per
+  // failed transport block here (2.7 k subframes/s on the gated HARQ leg)
+}
+
+void Engine::harqFlushStores(Chunk& ch, JobRunner& r)
+{
+  const uint32_t n = (uint32_t)harq_store_q.size();
+  if (!n) return;
+  grow_host(r.h_cbs_pinned, r.h_cbs_cap, n, r.stream);
+  grow_dev(r.d_cbs, r.cbs_cap, n, r.stream);
+  std::memcpy(r.h_cbs_pinned, harq_store_q.data(), n * sizeof(LsnCbDev));
+  harq_store_q.clear();
   lsn_launch_upload(r.d_cbs, r.h_cbs_pinned, n * sizeof(LsnCbDev), r.stream);
   lsn_launch_harq_combine(r.d_cbs, n, ch.d_keep, d_harq_pool, true, r.stream);
-  HIP_CHECK(hipStreamSynchronize(r.stream));  // (the pinned descriptor mirror is reused by the next call)
+  HIP_CHECK(hipStreamSynchronize(r.stream));  // (the pinned descriptor mirror is reused by the next call; the chunk's keep store is recycled with the chunk)
 }
 
 bool Engine::harqCombinedDecode(Chunk& ch, JobRunner& r, int job, int tb, size_t slot, uint32_t& payload_off)
@@ -1262,6 +1276,7 @@ bool Engine::harqCombinedDecode(Chunk& ch, JobRunner& r, int job, int tb, size_t
   grow_dev(r.d_cbs, r.cbs_cap, n, st);
   if (n > r.cbres_cap) { grow_dev(r.d_cbres, r.cbres_cap, n, st); }
   grow_host(r.h_cbres_pinned, r.h_cbres_cap, n, st);
+  harqFlushStores(ch, r);   // the buffer this retransmission combines with may still sit in the store queue
   HarqKeep& hk = harq_keep[slot];
   if (hk.ncb != n) { hk = HarqKeep{}; hk.ncb = n; }  // (no first transmission on record for this geometry: nothing passed before)
   // descriptors of the blocks that have NOT passed yet, in launch order (two-wave class first); results stay in transport-block order through res_idx
@@ -1393,6 +1408,7 @@ void Engine::commitLoop()
       r.perf.ms_commit += now_ms() - t1;
     } catch (const std::exception& ex) {
       err = ex.what();
+      harq_store_q.clear();   // (queued soft-buffer copies point into this chunk's keep store)
     }
     {
       std::unique_lock<std::mutex> tl(sh->turn_mtx);

@@ -287,7 +287,9 @@ private:
   // by the commit thread: verdict, CRC24A contribution and payload bytes of every code block of the transport block the slot holds.
   struct HarqKeep { uint32_t ncb = 0; uint8_t ok[16] = {}; uint32_t rem_a[16] = {}; std::vector<uint8_t> bytes[16]; };
   std::unordered_map<size_t, HarqKeep> harq_keep;
-  void harqStore(Chunk& ch, JobRunner& r, int job, int tb, size_t slot);                       // a failed new transmission goes into the buffer
+  void harqStore(Chunk& ch, JobRunner& r, int job, int tb, size_t slot);                       // a failed new transmission goes into the buffer (queued: harqFlushStores)
+  void harqFlushStores(Chunk& ch, JobRunner& r);
+  std::vector<LsnCbDev> harq_store_q;   // soft-buffer copies of the chunk in commit that have not been launched yet (commit thread only)
   bool harqCombinedDecode(Chunk& ch, JobRunner& r, int job, int tb, size_t slot, uint32_t& payload_off);  // retransmission: combine, decode, keep
 public:
   UeSpecConfig ueConfig(uint16_t rnti) { std::lock_guard<std::mutex> lk(mcs_mtx); return cfg.sniffer_mode == 1 ? ulUeConfig(rnti) : mcs_tracking.get_ue_config_rnti(rnti); }

@@ -32,7 +32,7 @@ def same(g, o):
     ("cfg3", dict(cell_id=37, dl_min=2, dl_max=3), 20000, -700.0, 1, 1),
     ("small", dict(cell_id=301, cp=1), 1234, 0.0, 1, -1),                      # extended cyclic prefix: the SSS sits N + N / 4 in front of the PSS
     ("small", dict(cell_id=44, cp=1, nof_prb=50, nof_ports=1, nof_rx=1), 30001, 600.0, 2, -1),
-    ("small", dict(cell_id=503, cp=1, nof_prb=6), 77, -2500.0, 3, 1),
+    ("small", dict(cell_id=503, cp=1, nof_prb=6), 77, -2500.0, 3, 2),
 ])
 def test_cell_search_matches_oracle(scn, over, lead, cfo, periods, force):
     sc = scenario(scn, seed=5, start_tti=10 * 77 + 3, cfo_hz=cfo, **over)
