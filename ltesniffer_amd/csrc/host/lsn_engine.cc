@@ -1234,6 +1234,10 @@ void Engine::harqStore(Chunk& ch, JobRunner& r, int job, int tb, size_t slot)
   grow_host(r.h_cbs_pinned, r.h_cbs_cap, n, r.stream);
   grow_dev(r.d_cbs, r.cbs_cap, n, r.stream);
   // cb_crc / data of the soft buffer: what passed in this (failed) transmission is remembered, a retransmission decodes the other blocks only
+  {  // a later new transmission into the same buffer replaces a queued one (one launch copies all queued blocks: two writers of one slot would race)
+    const uint32_t lo = (uint32_t)(slot * HARQ_SLOT_WORDS), hi = lo + (uint32_t)HARQ_SLOT_WORDS;
+    harq_store_q.erase(std::remove_if(harq_store_q.begin(), harq_store_q.end(), [&](const LsnCbDev& q) { return q.spp_off >= lo && q.spp_off < hi; }), harq_store_q.end());
+  }
   HarqKeep& hk = harq_keep[slot];
   hk.ncb = n;
   uint32_t boff = 0;
