@@ -1214,7 +1214,7 @@ void Engine::commitChunk(Chunk& ch, JobRunner& r)
       publishPrediction(d.rnti);
     }
   }
-  if (cfg.harq_mode) harqFlushStores(ch, r);   // the chunk's keep store is recycled with the chunk: its queued soft-buffer copies go out now
+  if (cfg.harq_mode) harqFlushStores(ch, r, true);   // the chunk's keep store is recycled with the chunk: its queued soft-buffer copies go out now
   for (const DecodeJob& j : ch.jobs) {
     if (!j.done) continue;
     const int k = j.kind < 5 ? j.kind : 0;
@@ -1257,17 +1257,20 @@ void Engine::harqStore(Chunk& ch, JobRunner& r, int job, int tb, size_t slot)
   // failed transport block here (2.7 k subframes/s on the gated HARQ leg)
 }
 
-void Engine::harqFlushStores(Chunk& ch, JobRunner& r)
+void Engine::harqFlushStores(Chunk& ch, JobRunner& r, bool sync)
 {
   const uint32_t n = (uint32_t)harq_store_q.size();
   if (!n) return;
-  grow_host(r.h_cbs_pinned, r.h_cbs_cap, n, r.stream);
-  grow_dev(r.d_cbs, r.cbs_cap, n, r.stream);
-  std::memcpy(r.h_cbs_pinned, harq_store_q.data(), n * sizeof(LsnCbDev));
+  // descriptors of the queued copies travel through a pinned mirror of their own (the runner's mirror belongs to the decode that may follow on the stream)
+  grow_host(harq_h_store, harq_h_store_cap, n, r.stream);
+  grow_dev(harq_d_store, harq_d_store_cap, n, r.stream);
+  std::memcpy(harq_h_store, harq_store_q.data(), n * sizeof(LsnCbDev));
   harq_store_q.clear();
-  lsn_launch_upload(r.d_cbs, r.h_cbs_pinned, n * sizeof(LsnCbDev), r.stream);
-  lsn_launch_harq_combine(r.d_cbs, n, ch.d_keep, d_harq_pool, true, r.stream);
-  HIP_CHECK(hipStreamSynchronize(r.stream));  // (the pinned descriptor mirror is reused by the next call; the chunk's keep store is recycled with the chunk)
+  lsn_launch_upload(harq_d_store, harq_h_store, n * sizeof(LsnCbDev), r.stream);
+  lsn_launch_harq_combine(harq_d_store, n, ch.d_keep, d_harq_pool, true, r.stream);
+  // sync = false: the caller waits for later work on the same stream before anything here is reused (harqCombinedDecode); at the end of the chunk's commit
+  // turn the wait is here - the chunk's keep store is recycled with the chunk
+  if (sync) HIP_CHECK(hipStreamSynchronize(r.stream));
 }
 
 bool Engine::harqCombinedDecode(Chunk& ch, JobRunner& r, int job, int tb, size_t slot, uint32_t& payload_off)
@@ -1280,7 +1283,8 @@ bool Engine::harqCombinedDecode(Chunk& ch, JobRunner& r, int job, int tb, size_t
   grow_dev(r.d_cbs, r.cbs_cap, n, st);
   if (n > r.cbres_cap) { grow_dev(r.d_cbres, r.cbres_cap, n, st); }
   grow_host(r.h_cbres_pinned, r.h_cbres_cap, n, st);
-  harqFlushStores(ch, r);   // the buffer this retransmission combines with may still sit in the store queue
+  const bool flushed = !harq_store_q.empty();
+  harqFlushStores(ch, r, false);   // the buffer this retransmission combines with may still sit in the store queue (stream order: no wait needed here)
   HarqKeep& hk = harq_keep[slot];
   if (hk.ncb != n) { hk = HarqKeep{}; hk.ncb = n; }  // (no first transmission on record for this geometry: nothing passed before)
   // descriptors of the blocks that have NOT passed yet, in launch order (two-wave class first); results stay in transport-block order through res_idx
@@ -1307,10 +1311,14 @@ bool Engine::harqCombinedDecode(Chunk& ch, JobRunner& r, int job, int tb, size_t
     lsn_launch_upload(r.d_cbs, r.h_cbs_pinned, nd * sizeof(LsnCbDev), st);
     lsn_launch_harq_combine(r.d_cbs, nd, ch.d_keep, d_harq_pool, false, st);
     lsn_launch_turbo(cd, r.d_cbs, d_harq_pool, r.d_payload, r.d_cbres, n128, kmax128, nd - n128, kmax64, st, nullptr);
-    lsn_launch_download(r.h_cbres_pinned, r.d_cbres, n * sizeof(LsnCbRes), st);
-    lsn_launch_download(r.h_payload_pinned, r.d_payload, out, st);
+    {
+      LsnCopySegs dn;   // verdicts + payload bytes down in one launch
+      dn.add(r.h_cbres_pinned, r.d_cbres, n * sizeof(LsnCbRes));
+      dn.add(r.h_payload_pinned, r.d_payload, out);
+      lsn_launch_copy_multi(dn, true, st);
+    }
     HIP_CHECK(hipEventRecord(r.ev_done, st));
-    waitEvent(r.ev_done);
+    waitEvent(r.ev_done, 3000);   // a round trip inside the sequential commit turn: short naps (the decode threads' waits are milliseconds long and nap 50 us)
     r.perf.nof_ondemand_decodes++;
     for (uint32_t q = 0; q < n; q++) {
       if (hk.ok[q]) continue;
@@ -1322,6 +1330,7 @@ bool Engine::harqCombinedDecode(Chunk& ch, JobRunner& r, int job, int tb, size_t
       // (ok is set below, after the verdict of THIS pass has been taken)
     }
   }
+  if (!nd && flushed) HIP_CHECK(hipStreamSynchronize(st));   // (nothing was decoded, so nothing waited for the flush)
   // transport-block verdict, as in runJobs: every block passed (now or in an earlier transmission), CRC24A over the assembled blocks
   bool all_ok = true;
   uint32_t rem = 0, total = 0;

@@ -288,7 +288,8 @@ private:
   struct HarqKeep { uint32_t ncb = 0; uint8_t ok[16] = {}; uint32_t rem_a[16] = {}; std::vector<uint8_t> bytes[16]; };
   std::unordered_map<size_t, HarqKeep> harq_keep;
   void harqStore(Chunk& ch, JobRunner& r, int job, int tb, size_t slot);                       // a failed new transmission goes into the buffer (queued: harqFlushStores)
-  void harqFlushStores(Chunk& ch, JobRunner& r);
+  void harqFlushStores(Chunk& ch, JobRunner& r, bool sync);
+  LsnCbDev *harq_h_store = nullptr, *harq_d_store = nullptr; size_t harq_h_store_cap = 0, harq_d_store_cap = 0;
   std::vector<LsnCbDev> harq_store_q;   // soft-buffer copies of the chunk in commit that have not been launched yet (commit thread only)
   bool harqCombinedDecode(Chunk& ch, JobRunner& r, int job, int tb, size_t slot, uint32_t& payload_off);  // retransmission: combine, decode, keep
 public:

@@ -79,6 +79,9 @@ void Engine::freeDevice()
     for (auto& fb : file_buf) { if (fb.h_raw) (void)hipHostFree(fb.h_raw); df(fb.d_raw); df(fb.d_iq); fb.h_raw = nullptr; fb.bytes = 0; }
   }
   d_dphi = nullptr; d_iq_staging = nullptr; staging_sf = 0; d_harq_pool = nullptr;
+  if (harq_h_store) { (void)hipHostFree(harq_h_store); harq_h_store = nullptr; harq_h_store_cap = 0; }
+  if (harq_d_store) { (void)hipFree(harq_d_store); harq_d_store = nullptr; harq_d_store_cap = 0; }
+  harq_store_q.clear();
   for (auto& ch : chunks) { if (ch.d_keep) (void)hipFree(ch.d_keep); ch.d_keep = nullptr; ch.keep_cap = ch.keep_n = 0; }
   last_chunk = nullptr;
 }
