@@ -5,8 +5,13 @@
 //
 // One lane = one trellis window (see stage_c.hip for the schedule).  Round 3, second half: the recursions run on PACKED int16 pairs.
 // A wavefront alone on a SIMD issues one VALU instruction per 4 cycles whatever its class (profiles/r03_valu_peak_isa.txt),
-// and packed forms occupy the VALU port for 4 cycles at any occupancy, so v_pk_add_i16 / v_pk_max_i16 do two state updates for the price of one:
-// 106 instead of 140 vector instructions per trellis step in the first constituent decoder, 107 instead of 171 in the interleaved one.
+// and packed forms occupy the VALU port for 4 cycles at any occupancy, so v_pk_add_i16 / v_pk_max_i16 do two state updates for the price of one.
+// Vector instructions per trellis step in the full-length sub-blocks (counted in the ISA; first / interleaved constituent decoder):
+//                                  rounds 3-4      round 5 (second half)
+//   forward sweep                  25.4 / 27.8     23.4 / 26.8     operands of two steps built together (lsn_operands2)
+//   alpha recompute                27.3 / 28.3     23.3 / 25.3     ... and normalised every second step only
+//   beta + soft output             50.9 / 49.9     44.9 / 44.5     soft outputs of two steps on packed halves (lsn_ext_two), (g10, g11) with one add,
+//                                                                  lanes without a window masked instead of redirected per step
 //
 // Layout C: four registers hold the eight state metrics as (m[k] | m[k+4] << 16), k = 0..3.
 //  * forward: butterfly k reads states 2k, 2k+1 and writes k, k+4 - with the operands taken as half-broadcasts (op_sel) layout C maps to
@@ -17,10 +22,14 @@
 //   |gamma| <= |sys| + |ext| + |par| <= 512 + 2047 + 512 = 3071 per step.  Any state is reached from any state in 3 steps, so a metric
 //   vector normalised to state 0 spreads at most 3 * 3071 = 9213 once it is 3 steps away from its initialisation; the initialisations are
 //   (0, -12000 x 7), the termination metrics (<= 3 * 1022) and boundary metrics of the previous iteration (<= 9213), i.e. <= 12000 + 2 * 3071
-//   = 18142 in the first two steps of the first window and <= 15355 elsewhere.  Alpha is normalised every step where it is stored (every
-//   second step in the forward sweep: + 3071), beta every step, and a window is at least 32 steps long, so the two "young" ends never meet:
-//   |alpha + beta + gamma| <= max(18142 + 9213, 9213 + 15355) + 3071 = 30426 < 32768.  (tools/turbo_metric_ranges.py measures <= 19920.)
-//   L = m1 - m0 is formed in 32 bits.
+//   = 18142 in the first two steps of the first window and <= 15355 elsewhere.  Alpha is normalised every SECOND step, in the forward sweep
+//   and (round 5) in the recompute: an alpha vector that meets beta is either normalised (<= 9213) or one step past a normalised one
+//   (<= 9213 + 3071 = 12284; in the first two steps of the first window <= 18142 as above); beta is normalised every step, and a window is at
+//   least 32 steps long, so the two "young" ends never meet:
+//   |alpha + beta + gamma| <= max(18142 + 9213, 12284 + 15355) + 3071 = 30710 < 32768.  (tools/turbo_metric_ranges.py measures <= 19920 with
+//   alpha normalised every step; the host build of this file checks every packed add and subtract.)  Check-points and the window-boundary
+//   exchange store normalised vectors only (state 0 = 0 is not stored).
+//   L = m1 - m0 is formed in 32 bits, or in 16 bits with saturation where that is proven equal (lsn_ext_two).
 #pragma once
 #include <stdint.h>
 #include <type_traits>
@@ -100,25 +109,84 @@ LSN_HD void lsn_step_fwd_pk(s2* a, s2 q)
   }
 }
 
-// backward step: b (layout C, normalised) becomes the beta vector one step earlier (normalised); A = the alphas in front of this step (layout C,
-// normalised); returns L = max over branches with input 1 - max over branches with input 0
-LSN_HD int lsn_step_bwd_pk(s2* b, const s2* A, s2 q)
+// backward step: b (layout C, normalised) becomes the beta vector one step earlier (normalised); A = the alphas in front of this step (layout C);
+// M0 / M1 = max over the branches with input 0 / 1 of alpha + branch + beta, still split over the two halves (max(M.x, M.y) is the maximum)
+LSN_HD void lsn_step_bwd_pk(s2* b, const s2* A, s2 q, s2* M0o, s2* M1o)
 {
   const s2 G0 = __builtin_shufflevector(b[0], b[2], 0, 2), G1 = __builtin_shufflevector(b[0], b[2], 1, 3);  // (b0, b2) (b4, b6)
   const s2 G2 = __builtin_shufflevector(b[1], b[3], 0, 2), G3 = __builtin_shufflevector(b[1], b[3], 1, 3);  // (b1, b3) (b5, b7)
-  const s2 gg = pka_sel<0, 1, 1, 0>(q, q);
   const s2 S = pk_s2(pk_u32(q) & 0xFFFF0000u);   // (0, g01)
-  const s2 T = s2{gg.x, q.x};                    // (g11, g10)
+  const s2 T = pka_sel<0, 0, 0, 1>(q, S);        // (g10, g11): one add (round 5; rounds 3-4 built (g11, g10) with an add and a v_perm)
   // successor metric + branch metric, paired like alpha: (state k, state k + 4); input 0 and input 1
   const s2 u00 = pka(G0, S), u01 = pka(G1, S), u02 = pka_sel<0, 1, 1, 0>(G3, S), u03 = pka_sel<0, 1, 1, 0>(G2, S);
-  const s2 u10 = pka(G1, T), u11 = pka(G0, T), u12 = pka_sel<0, 1, 1, 0>(G2, T), u13 = pka_sel<0, 1, 1, 0>(G3, T);
-  const s2 M0 = pkmax(pkmax(pka(A[0], u00), pka(A[1], u01)), pkmax(pka(A[2], u02), pka(A[3], u03)));
-  const s2 M1 = pkmax(pkmax(pka(A[0], u10), pka(A[1], u11)), pkmax(pka(A[2], u12), pka(A[3], u13)));
-  const s2 m0 = pkmax(M0, M0.yx), m1 = pkmax(M1, M1.yx);
+  const s2 u10 = pka_sel<0, 1, 1, 0>(G1, T), u11 = pka_sel<0, 1, 1, 0>(G0, T), u12 = pka(G2, T), u13 = pka(G3, T);
+  *M0o = pkmax(pkmax(pka(A[0], u00), pka(A[1], u01)), pkmax(pka(A[2], u02), pka(A[3], u03)));
+  *M1o = pkmax(pkmax(pka(A[0], u10), pka(A[1], u11)), pkmax(pka(A[2], u12), pka(A[3], u13)));
   b[0] = pkmax(u00, u10); b[1] = pkmax(u01, u11); b[2] = pkmax(u02, u12); b[3] = pkmax(u03, u13);
   const s2 n = b[0];
   b[0] = pks_sel<0, 1, 0, 0>(b[0], n); b[1] = pks_sel<0, 1, 0, 0>(b[1], n); b[2] = pks_sel<0, 1, 0, 0>(b[2], n); b[3] = pks_sel<0, 1, 0, 0>(b[3], n);
-  return (int)m1.x - (int)m0.x;
+}
+// soft output of one step: extrinsic * 2 + hard decision (L = m1 - m0 in 32 bits)
+LSN_HD int16_t lsn_ext_one(s2 M0, s2 M1, s2 q)
+{
+  const s2 m0 = pkmax(M0, M0.yx), m1 = pkmax(M1, M1.yx);
+  const int L = (int)m1.x - (int)m0.x;
+  const int hard = L < 0 ? 0 : (L > 1 ? 1 : L);  // v_med3_i32(L, 0, 1)
+  return (int16_t)(lsn_ext_scale(L - (int)q.x) * 2 + hard);
+}
+// ... of TWO steps at once on packed halves (step a in the low half, step b in the high half): 8 instead of 12 vector instructions per step.
+// Equal to lsn_ext_one although L is formed in 16 bits WITH SATURATION (v_pk_sub_i16 clamp): the extrinsic value is
+// sign(x) min(floor(3 |x| / 4), 2047) with x = L - lsa, |lsa| <= 2558, and every |x| >= 2730 gives 2047 (3 * 2730 / 4 = 2047.5) - so x may be clamped to
+// +- 2730 first, a saturated L (|L| >= 32767) keeps |L - lsa| >= 30209 on the same side, and 3 * 2730 fits 16 bits; the hard decision is the
+// sign of L, which saturation keeps.
+LSN_HD s2 lsn_sat_sub(s2 a, s2 b)
+{
+#ifdef __HIP_DEVICE_COMPILE__
+  return __builtin_elementwise_sub_sat(a, b);
+#else
+  const int x = (int)a.x - (int)b.x, y = (int)a.y - (int)b.y;
+  return s2{(short)(x < -32768 ? -32768 : (x > 32767 ? 32767 : x)), (short)(y < -32768 ? -32768 : (y > 32767 ? 32767 : y))};
+#endif
+}
+LSN_HD s2 lsn_ext_two(s2 M0a, s2 M1a, s2 qa, s2 M0b, s2 M1b, s2 qb)
+{
+#ifdef __HIP_DEVICE_COMPILE__
+  // Stated instruction by instruction, in ONE asm block.  Left to itself the compiler turns the sign mask and the hard decision into compare / select
+  // pairs per half and re-packs them with v_perm (21 instructions instead of 16); the maxima over the two halves of M land directly in the half of
+  // their step (SDWA).  gfx940-class parts need a wait state between a VALU write with dst_sel != DWORD and a VALU read of that register, and the
+  // compiler's hazard recogniser does not look inside inline asm: the order below keeps one instruction between every such pair.
+  s2 r0, r1, r2, r3, out;
+  asm("v_max_i16_sdwa %0, %5, %5 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t"         // r0 = m0 (step a)
+      "v_max_i16_sdwa %1, %6, %6 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1\n\t"         // r1 = m1 (step a)
+      "v_max_i16_sdwa %0, %7, %7 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_1\n\t"    //      m0 (step b) into the high half
+      "v_max_i16_sdwa %1, %8, %8 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_0 src1_sel:WORD_1\n\t"
+      "v_perm_b32 %3, %10, %9, %11\n\t"                 // r3 = (lsa a, lsa b)
+      "v_pk_sub_i16 %2, %1, %0 clamp\n\t"               // r2 = L = m1 - m0, saturated
+      "v_pk_sub_i16 %3, %2, %3 clamp\n\t"               // r3 = x = L - lsa
+      "v_pk_max_i16 %3, %3, %12\n\t"                    //      clamped to +- 2730
+      "v_pk_min_i16 %3, %3, %13\n\t"
+      "v_pk_ashrrev_i16 %0, 15, %3 op_sel_hi:[0,1]\n\t" // r0 = -1 where x < 0
+      "v_and_b32 %0, %14, %0\n\t"                       //      3 where x < 0
+      "v_pk_mad_u16 %0, %3, 3, %0 op_sel_hi:[1,0,1]\n\t" // r0 = t = 3 x + (x < 0 ? 3 : 0);  t >> 2 truncates 3 x / 4 towards zero
+      "v_pk_max_i16 %1, %2, 0\n\t"                      // r1 = hard decision: min(max(L, 0), 1)
+      "v_pk_min_i16 %1, %1, 1 op_sel_hi:[1,0]\n\t"
+      "v_pk_ashrrev_i16 %0, 1, %0 op_sel_hi:[0,1]\n\t"  // (t >> 2) * 2 = (t >> 1) & ~1
+      "v_and_or_b32 %4, %0, %15, %1"
+      : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(out)
+      : "v"(M0a), "v"(M1a), "v"(M0b), "v"(M1b), "v"(qa), "v"(qb), "s"(0x05040100u), "s"(0xF556F556u), "s"(0x0AAA0AAAu), "s"(0x00030003u), "s"(0xFFFEFFFEu));
+  return out;
+#else
+  const s2 m0a = pkmax(M0a, M0a.yx), m1a = pkmax(M1a, M1a.yx), m0b = pkmax(M0b, M0b.yx), m1b = pkmax(M1b, M1b.yx);
+  const s2 m0 = s2{m0a.x, m0b.x}, m1 = s2{m1a.x, m1b.x};
+  const s2 L = lsn_sat_sub(m1, m0);
+  s2 x = lsn_sat_sub(L, s2{qa.x, qb.x});
+  const s2 lim = s2{2730, 2730};
+  x = __builtin_elementwise_min(pkmax(x, -lim), lim);
+  const s2 neg = x >> 15;                                 // -1 where x < 0
+  const s2 r = (x * (short)3 + (neg & (short)3)) >> 2;     // truncation towards zero, as lsn_ext_scale
+  const s2 hard = __builtin_elementwise_min(pkmax(L, s2{0, 0}), s2{1, 1});
+  return r * (short)2 + hard;
+#endif
 }
 
 // eight 32-bit metrics (state order) -> layout C
@@ -170,6 +238,40 @@ LSN_HD int fld0(uint32_t w) { return (int)(w << 22) >> 22; }
 LSN_HD int fld1(uint32_t w) { return (int)(w << 12) >> 22; }
 LSN_HD int fld2(uint32_t w) { return (int)(w << 2) >> 22; }
 
+// Branch-metric operands of two consecutive trellis steps, (lsa | lp << 16) each: lsa = systematic field of ws + extrinsic value (es = ext * 2 + hard bit,
+// 16 bits as loaded), lp = the 10-bit field at bit PF of wp.  The sums of both steps are formed in one packed register (v_perm to pair the halves, packed
+// shifts and add), each parity field costs one v_bfe_i32 and one v_perm that also picks the step's half of the sums: 10 vector instructions per two
+// steps (rounds 3-4: 14 - shift / shift / and / or per parity field).
+LSN_HD uint32_t lsn_perm(uint32_t hi, uint32_t lo, uint32_t sel)
+{
+#ifdef __HIP_DEVICE_COMPILE__
+  return __builtin_amdgcn_perm(hi, lo, sel);
+#else
+  const uint64_t v = ((uint64_t)hi << 32) | lo;
+  uint32_t d = 0;
+  for (int k = 0; k < 4; k++) d |= (uint32_t)((v >> (8 * ((sel >> (8 * k)) & 7u))) & 0xFFu) << (8 * k);
+  return d;
+#endif
+}
+template <int PF>
+LSN_HD int lsn_par_field(uint32_t w)
+{
+#ifdef __HIP_DEVICE_COMPILE__
+  return __builtin_amdgcn_sbfe((int)w, PF, 10);
+#else
+  return (int)(w << (22 - PF)) >> 22;
+#endif
+}
+template <int PF>
+LSN_HD void lsn_operands2(uint32_t ws0, uint32_t ws1, uint32_t es0, uint32_t es1, uint32_t wp0, uint32_t wp1, uint32_t* g0, uint32_t* g1)
+{
+  const s2 sys = (pk_s2(lsn_perm(ws1, ws0, 0x05040100u)) << 6) >> 6;
+  const s2 apr = pk_s2(lsn_perm(es1, es0, 0x05040100u)) >> 1;
+  const uint32_t sum = pk_u32(pka(sys, apr));
+  *g0 = lsn_perm((uint32_t)lsn_par_field<PF>(wp0), sum, 0x05040100u);
+  *g1 = lsn_perm((uint32_t)lsn_par_field<PF>(wp1), sum, 0x05040302u);
+}
+
 // Sub-block length (steps whose operands are fetched in one burst and whose alphas are kept in registers); even: the forward sweep
 // normalises every second step
 #ifndef TB_S
@@ -195,18 +297,18 @@ LSN_HD void lsn_turbo_il_fill(uint32_t* dst, int K, int f1, int f2)
     }
 }
 
-// One constituent decoder, the part of one lane (= window `wl`; idle lanes shadow window 0 and write their soft output to the spare slot
-// ext[K]).  nii_a / nii_b: boundary metrics of the previous iteration (layout C); beta_tail: termination metrics (layout C);
+// One constituent decoder, the part of one lane (= window `wl`; only lanes with a window run it - the caller masks the others, they meet the working
+// lanes again at the caller's barriers).  nii_a / nii_b: boundary metrics of the previous iteration (layout C); beta_tail: termination metrics (layout C);
 // a_end / b_out: this window's metrics at its end / start, for the exchange between the lanes (the caller's business).
 // il (second decoder only): il[(t / 2) * P + w] = transposed LDS addresses of the positions the QPP interleaver gives steps t, t + 1 of
 // window w, 16 bits each (lsn_turbo_il_fill above; one table per block size, 1.1 MB for all 188 sizes, L2 resident).  The addresses of a sub-block are fetched one
 // sub-block ahead of their use: the L2 latency hides behind the recursion of the sub-block in hand.  (Rounds 1-2 stepped the QPP recursion
 // pi += g, g += 2 f2 per lane and divided by W with a multiply: 14 instructions per step and direction instead of one load.)
 template <bool IL>
-LSN_HD void lsn_map_pass_lane(const TurboLds& m, const uint32_t* il, int nt, int lane, bool active, int K, int P, int W,
+LSN_HD void lsn_map_pass_lane(const TurboLds& m, const uint32_t* il, int nt, int wl, int K, int P, int W,
                               const s2* nii_a, const s2* nii_b, const s2* beta_tail, s2* a_end, s2* b_out)
 {
-  const int wl = active ? lane : 0;
+  const int lane = wl;
   const int wlb = wl + m.bias;   // index of this window's column in the (possibly second) block's arrays
   const uint32_t bias2 = (uint32_t)m.bias * 0x10001u;  // (addresses stay below 2^16: K + bias <= 2 * 2760)
   const int nsb = (W + TB_S - 1) / TB_S;
@@ -231,6 +333,17 @@ LSN_HD void lsn_map_pass_lane(const TurboLds& m, const uint32_t* il, int nt, int
   };
   if (IL) il_load(0);
   uint32_t g[TB_S];  // operands of one sub-block: lsa (low half) | lp << 16
+  // operands of steps tb + u, tb + u + 1 (u even); a step past the end of the window (odd W, last pair) reads the spare entries behind the block
+  auto build2 = [&](int tb, int u) {
+    const int nat0 = (tb + u) * P + wlb, nat1 = nat0 + P;
+    if (IL) {
+      const int i0 = (int)(cur[u >> 1] & 0xFFFFu), i1 = (int)(cur[u >> 1] >> 16);
+      lsn_operands2<20>(m.spp[i0], m.spp[i1], (uint16_t)m.ext[i0], (uint16_t)m.ext[i1], m.spp[nat0], m.spp[nat1], &g[u], &g[u + 1]);
+    } else {
+      const uint32_t w0 = m.spp[nat0], w1 = m.spp[nat1];
+      lsn_operands2<10>(w0, w1, (uint16_t)m.ext[nat0], (uint16_t)m.ext[nat1], w0, w1, &g[u], &g[u + 1]);
+    }
+  };
   // ---- forward sweep over sub-blocks 0 .. nsb-2 (the last one is covered by the recompute below) ----
   for (int sb = 0; sb + 1 < nsb; sb++) {
     if (sb >= 1) lsn_ckpt_store(m.ckpt, nt, sb - 1, lane, a, m.cw, m.ch);
@@ -241,16 +354,7 @@ LSN_HD void lsn_map_pass_lane(const TurboLds& m, const uint32_t* il, int nt, int
       il_load(sb + 1);
     }
 #pragma unroll
-    for (int u = 0; u < TB_S; u++) {
-      const int nat = (tb + u) * P + wlb;
-      if (IL) {
-        const int idx = (int)((u & 1) ? cur[u >> 1] >> 16 : cur[u >> 1] & 0xFFFFu);
-        g[u] = ((uint32_t)(fld0(m.spp[idx]) + ((int)m.ext[idx] >> 1)) & 0xFFFFu) | ((uint32_t)fld2(m.spp[nat]) << 16);
-      } else {
-        const uint32_t w = m.spp[nat];
-        g[u] = ((uint32_t)(fld0(w) + ((int)m.ext[nat] >> 1)) & 0xFFFFu) | ((uint32_t)fld1(w) << 16);
-      }
-    }
+    for (int u = 0; u < TB_S; u += 2) build2(tb, u);
 #pragma unroll
     for (int u = 0; u < TB_S; u += 2) {
       lsn_step_fwd_pk<false>(a, pk_s2(g[u]));
@@ -263,8 +367,9 @@ LSN_HD void lsn_map_pass_lane(const TurboLds& m, const uint32_t* il, int nt, int
     for (int k = 0; k < 4; k++) b[k] = nii_b[k];
   }
   // ---- backward, sub-block by sub-block ----
-  int ix[TB_S];     // LDS index of the systematic / extrinsic value of each step
   s2 A[TB_S][4];    // alphas in front of each step of the sub-block
+  // LDS index of the systematic / extrinsic value of step tb + u
+  auto ext_index = [&](int tb, int u) { return IL ? (int)((u & 1) ? cur[u >> 1] >> 16 : cur[u >> 1] & 0xFFFFu) : (tb + u) * P + wlb; };
   for (int sb = nsb - 1; sb >= 0; sb--) {
     const int tb = sb * TB_S, n = (tb + TB_S < W) ? TB_S : W - tb;
     if (sb + 1 < nsb) {
@@ -284,39 +389,41 @@ LSN_HD void lsn_map_pass_lane(const TurboLds& m, const uint32_t* il, int nt, int
       constexpr bool FULL = decltype(fullc)::value;
       // operand burst
 #pragma unroll
-      for (int u = TB_S - 1; u >= 0; u--) {
-        if (FULL || u < n) {
-          const int nat = (tb + u) * P + wlb;
-          if (IL) {
-            const int idx = (int)((u & 1) ? cur[u >> 1] >> 16 : cur[u >> 1] & 0xFFFFu);
-            ix[u] = active ? idx : K + m.bias;
-            g[u] = ((uint32_t)(fld0(m.spp[idx]) + ((int)m.ext[idx] >> 1)) & 0xFFFFu) | ((uint32_t)fld2(m.spp[nat]) << 16);
-          } else {
-            const uint32_t w = m.spp[nat];
-            ix[u] = active ? nat : K + m.bias;
-            g[u] = ((uint32_t)(fld0(w) + ((int)m.ext[nat] >> 1)) & 0xFFFFu) | ((uint32_t)fld1(w) << 16);
-          }
-        }
-      }
-      // recompute the alphas of this sub-block into registers
+      for (int u = TB_S - 2; u >= 0; u -= 2)
+        if (FULL || u < n) build2(tb, u);
+      // recompute the alphas of this sub-block into registers.  Normalised every SECOND step (as in the forward sweep): the alphas in front of the
+      // odd steps carry the growth of one step (word-length argument at the top)
 #pragma unroll
       for (int u = 0; u < TB_S; u++) {
         if (FULL || u < n) {
           A[u][0] = a[0]; A[u][1] = a[1]; A[u][2] = a[2]; A[u][3] = a[3];
-          lsn_step_fwd_pk<true>(a, pk_s2(g[u]));
+          if (u & 1) lsn_step_fwd_pk<true>(a, pk_s2(g[u])); else lsn_step_fwd_pk<false>(a, pk_s2(g[u]));
         }
       }
       if (sb == nsb - 1) {
-        for (int k = 0; k < 4; k++) a_end[k] = a[k];
+        // (the caller wants a normalised vector: the next iteration starts a window from it)
+        const s2 nn = a[0];
+        for (int k = 0; k < 4; k++) a_end[k] = pks_sel<0, 1, 0, 0>(a[k], nn);
       }
       // beta recursion + LLR + extrinsic
+      if (FULL) {
 #pragma unroll
-      for (int u = TB_S - 1; u >= 0; u--) {
-        if (FULL || u < n) {
-          const s2 q = pk_s2(g[u]);
-          const int L = lsn_step_bwd_pk(b, A[u], q);
-          const int hard = L < 0 ? 0 : (L > 1 ? 1 : L);  // v_med3_i32(L, 0, 1)
-          m.ext[ix[u]] = (int16_t)(lsn_ext_scale(L - (int)q.x) * 2 + hard);  // idle lanes: spare slot ext[K]
+        for (int u = TB_S - 1; u >= 0; u -= 2) {
+          s2 M0a, M1a, M0b, M1b;
+          lsn_step_bwd_pk(b, A[u], pk_s2(g[u]), &M0a, &M1a);
+          lsn_step_bwd_pk(b, A[u - 1], pk_s2(g[u - 1]), &M0b, &M1b);
+          const s2 e = lsn_ext_two(M0a, M1a, pk_s2(g[u]), M0b, M1b, pk_s2(g[u - 1]));
+          m.ext[ext_index(tb, u)] = e.x;
+          m.ext[ext_index(tb, u - 1)] = e.y;
+        }
+      } else {
+#pragma unroll
+        for (int u = TB_S - 1; u >= 0; u--) {
+          if (u < n) {
+            s2 M0, M1;
+            lsn_step_bwd_pk(b, A[u], pk_s2(g[u]), &M0, &M1);
+            m.ext[ext_index(tb, u)] = lsn_ext_one(M0, M1, pk_s2(g[u]));
+          }
         }
       }
     };

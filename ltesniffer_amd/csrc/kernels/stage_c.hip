@@ -457,8 +457,9 @@ template <bool IL>
 __device__ __forceinline__ void map_pass(const TurboLds& m, const uint32_t* il, int nt, int lane, bool active, int K, int P, int W,
                                          s2* nii_a, s2* nii_b, const s2* beta_tail)
 {
-  s2 a_end[4], b_out[4];
-  lsn_map_pass_lane<IL>(m, il, nt, lane, active, K, P, W, nii_a, nii_b, beta_tail, a_end, b_out);
+  s2 a_end[4] = {s2{0, 0}, s2{0, 0}, s2{0, 0}, s2{0, 0}}, b_out[4] = {s2{0, 0}, s2{0, 0}, s2{0, 0}, s2{0, 0}};
+  // lanes without a window sit the pass out (one exec-mask update per pass; rounds 2-4 let them shadow window 0 and paid a select per step for it)
+  if (active) lsn_map_pass_lane<IL>(m, il, nt, lane, K, P, W, nii_a, nii_b, beta_tail, a_end, b_out);
   // next-iteration initialisation: window p starts from the end of window p-1 and ends at the start of window p+1.
   // The exchange goes through the (now idle) check-point area, slots 0 and 1.
   tb_sync(nt);

@@ -45,8 +45,8 @@ static int decode_like_kernel(const int16_t* d3, int K, int max_iter, uint32_t p
   const uint32_t magicW = ((1u << 20) + (uint32_t)W - 1u) / (uint32_t)W;
   std::vector<uint32_t> il(lsn_turbo_il_words(K));
   lsn_turbo_il_fill(il.data(), K, f1, f2);
-  std::vector<uint32_t> spp(K + 16);
-  std::vector<int16_t> ext(K + 16, 0);
+  std::vector<uint32_t> spp(K + 256, 0);   // (an odd window length reads one step past the block: lsn_map_pass_lane)
+  std::vector<int16_t> ext(K + 256, 0);
   std::vector<uint8_t> ckpt(TB_CKPT_BYTES + 64);
   const int16_t *d0 = d3, *d1 = d3 + D, *d2 = d3 + 2 * D;
   for (int t = 0; t < K; t++) {  // k_rm's output order: slot t holds position x = (t % P) * W + t / P
@@ -70,9 +70,10 @@ static int decode_like_kernel(const int16_t* d3, int K, int max_iter, uint32_t p
   std::vector<s2> na1(4 * NT, s2{0, 0}), nb1(4 * NT, s2{0, 0}), na2(4 * NT, s2{0, 0}), nb2(4 * NT, s2{0, 0}), ae(4 * NT), bo(4 * NT);
   auto pass = [&](bool second, std::vector<s2>& na, std::vector<s2>& nb, const s2* bt) {
     for (int lane = 0; lane < NT; lane++) {
-      const bool active = lane < P;
-      if (second) lsn_map_pass_lane<true>(m, il.data(), NT, lane, active, K, P, W, &na[4 * lane], &nb[4 * lane], bt, &ae[4 * lane], &bo[4 * lane]);
-      else lsn_map_pass_lane<false>(m, il.data(), NT, lane, active, K, P, W, &na[4 * lane], &nb[4 * lane], bt, &ae[4 * lane], &bo[4 * lane]);
+      for (int k = 0; k < 4; k++) ae[4 * lane + k] = bo[4 * lane + k] = s2{0, 0};
+      if (lane >= P) continue;  // lanes without a window sit the pass out (stage_c.hip: map_pass)
+      if (second) lsn_map_pass_lane<true>(m, il.data(), NT, lane, K, P, W, &na[4 * lane], &nb[4 * lane], bt, &ae[4 * lane], &bo[4 * lane]);
+      else lsn_map_pass_lane<false>(m, il.data(), NT, lane, K, P, W, &na[4 * lane], &nb[4 * lane], bt, &ae[4 * lane], &bo[4 * lane]);
     }
     // exchange through the check-point area, as the kernel does it (7 halves per lane and direction)
     for (int lane = 0; lane < NT; lane++) { lsn_ckpt_store(m.ckpt, NT, 0, lane, &ae[4 * lane]); lsn_ckpt_store(m.ckpt, NT, 1, lane, &bo[4 * lane]); }
