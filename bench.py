@@ -670,6 +670,9 @@ def main():
                        "decode_jobs_by_kind_per_6400": {"kinds": ["first attempt", "second table after failure", "second table speculative", "RA-RNTI ahead of search", "on demand"],
                                                         "jobs": [round(p.jobs_by_kind[k] * 6400.0 / sf_rank, 1) for k in range(5)], "jobs_unused": [round(p.jobs_unused_by_kind[k] * 6400.0 / sf_rank, 1) for k in range(5)],
                                                         "iterations": [round(p.iters_by_kind[k] * 6400.0 / sf_rank, 1) for k in range(5)], "iterations_unused": [round(p.iters_unused_by_kind[k] * 6400.0 / sf_rank, 1) for k in range(5)]},
+                       # only a library built with -DLSN_TURBO_CYCLES fills these (tools/ab/): s_memtime ticks spent by the decoder's code blocks, per subframe
+                       "turbo_clock_ticks_per_subframe": ({"load": round(p.turbo_cyc_rm / sf_rank, 1), "iterations": round(p.turbo_cyc_map / sf_rank, 1), "output": round(p.turbo_cyc_out / sf_rank, 1)}
+                                                          if (p.turbo_cyc_rm or p.turbo_cyc_map) else None),
                        "table_hints_engine_total": {"used": int(p.nof_table_hints_used), "missed": int(p.nof_table_hints_missed)},
                        "ondemand_at_commit_per_6400": [round(p.nof_ondemand_commit[k] * 6400.0 / sf_rank, 2) for k in range(4)],
                        "kernel_ms_per_6400_subframes": {la.KERNELS[k]: round(kms[k] * 6400.0 / sf_rank, 4) for k in range(nk)},
