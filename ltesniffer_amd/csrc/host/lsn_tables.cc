@@ -120,17 +120,7 @@ void Engine::allocRunner(JobRunner& r)
     std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
     for (int i = 0; i < ncu; i++)
       if (!(reserve > 0 && i % (ncu / (reserve > 0 ? reserve : 1)) == 0)) mask[i / 32] |= 1u << (i % 32);
-    // LSN_SPLIT_CUS = n (round 5 experiment): the chip is PARTITIONED for the bulk decode chains - their light kernels (stream_light) run on the first n
-    // bits of the CU mask (the driver deals mask bits round-robin over the XCDs, so n = 64 is eight CUs of every XCD), the decoder and the result copy
-    // on the other CUs
-    const int split = getenv("LSN_SPLIT_CUS") ? atoi(getenv("LSN_SPLIT_CUS")) : 0;
-    if (split > 0 && split < ncu) {
-      std::vector<uint32_t> md((size_t)(ncu + 31) / 32, 0u), ml((size_t)(ncu + 31) / 32, 0u);
-      for (int i = 0; i < ncu; i++) (i < split ? ml : md)[i / 32] |= 1u << (i % 32);
-      HIP_CHECK(hipExtStreamCreateWithCUMask(&r.stream, (uint32_t)md.size(), md.data()));
-      HIP_CHECK(hipExtStreamCreateWithCUMask(&r.stream_light, (uint32_t)ml.size(), ml.data()));
-      HIP_CHECK(hipEventCreateWithFlags(&r.ev_light, hipEventDisableTiming));
-    } else if (reserve <= 0 || reserve >= ncu || hipExtStreamCreateWithCUMask(&r.stream, (uint32_t)mask.size(), mask.data()) != hipSuccess)
+    if (reserve <= 0 || reserve >= ncu || hipExtStreamCreateWithCUMask(&r.stream, (uint32_t)mask.size(), mask.data()) != hipSuccess)
       HIP_CHECK(hipStreamCreateWithPriority(&r.stream, hipStreamNonBlocking, lo));
   }
   for (auto& e : r.ev) HIP_CHECK(hipEventCreate(&e));
@@ -138,7 +128,7 @@ void Engine::allocRunner(JobRunner& r)
     bool bulk_ = false;
     for (int i = 0; i < NDEC; i++) bulk_ = bulk_ || &r == &runner_c[i];
     const char* ls = getenv("LSN_LIGHT_STREAM");
-    if (bulk_ && ls && atoi(ls) && !r.stream_light) {
+    if (bulk_ && ls && atoi(ls)) {
       HIP_CHECK(hipStreamCreateWithPriority(&r.stream_light, hipStreamNonBlocking, atoi(ls) >= 2 ? hi : (lo + hi) / 2));  // 1: normal, 2: highest
       HIP_CHECK(hipEventCreateWithFlags(&r.ev_light, hipEventDisableTiming));
     }

@@ -7,15 +7,6 @@
 #include <string>
 #include "../host/lsn_types.h"
 
-// Wave priority of every kernel except the turbo decoder (s_setprio: 0 = the reset value .. 3).  The decoder's wavefronts live for tens of microseconds to
-// a millisecond and keep the vector port of their SIMD 94 % busy, two per SIMD; the instruction arbiter prefers the OLDEST wavefront, so a short-lived
-// wavefront of a memory-bound kernel that lands on such a SIMD crawls behind them - and its kernel, a link of some chunk's launch chain, ends only when its
-// slowest wavefront does (round 5, profiles/r05_experiments.txt).  With a raised priority the light wavefronts issue when they have something to issue
-// (they mostly wait for memory) and are gone.
-#ifndef LSN_LIGHT_WAVE_PRIO
-#define LSN_LIGHT_WAVE_PRIO 0
-#endif
-#define LSN_WAVE_PRIO() do { if (LSN_LIGHT_WAVE_PRIO) __builtin_amdgcn_s_setprio(LSN_LIGHT_WAVE_PRIO); } while (0)
 // A launch the runtime rejects (LDS request above the function's limit on this device, an empty or oversized grid, no code object for the
 // device) does not fail at the call site: the kernel never runs and the error sits in the thread until some later runtime call reports it -
 // stale results at the next event wait.  Every launcher therefore asks right behind its launch and throws; the engine's stage wrappers turn

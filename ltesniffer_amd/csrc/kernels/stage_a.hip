@@ -64,7 +64,6 @@ __device__ __forceinline__ void ofdm_rb_power(const LsnCellDev& c, const cf32* o
 __global__ __launch_bounds__(256) void k_ofdm(LsnCellDev c, const cf32* __restrict__ iq, const uint32_t* __restrict__ dphi_sf,
                                               cf32* __restrict__ grid, float* __restrict__ rbp_part)
 {
-  LSN_WAVE_PRIO();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int N = (int)c.N, lgN = (int)c.lgN, tid = threadIdx.x;
   cf32* a = (cf32*)smem;
@@ -158,7 +157,6 @@ __device__ __forceinline__ int crs_koff(const LsnCellDev& c, int port, int s)
 __global__ __launch_bounds__(256) void k_chest(LsnCellDev c, const cf32* __restrict__ grid, const uint32_t* __restrict__ sf_idx_arr,
                                                cf32* __restrict__ ce, float* __restrict__ raw)
 {
-  LSN_WAVE_PRIO();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int nre = (int)c.nre, nref = (int)c.nref, tid = threadIdx.x;
   const int P = (int)c.nof_ports, A = (int)c.nof_rx;
@@ -267,7 +265,6 @@ void lsn_launch_chest(const LsnCellDev& c, const cf32* grid, const uint32_t* sf_
 
 __global__ void k_chest_fin(LsnCellDev c, const float* __restrict__ raw, LsnChest* __restrict__ out, uint32_t nsf)
 {
-  LSN_WAVE_PRIO();
   uint32_t sf = blockIdx.x * blockDim.x + threadIdx.x;
   if (sf >= nsf) return;
   const int A = (int)c.nof_rx, P = (int)c.nof_ports;
@@ -349,7 +346,6 @@ __global__ __launch_bounds__(64) void k_pcfich(LsnCellDev c, const cf32* __restr
                                                const LsnChest* __restrict__ ch, const uint32_t* __restrict__ sf_idx_arr,
                                                uint32_t* __restrict__ cfi_out, float* __restrict__ corr_out)
 {
-  LSN_WAVE_PRIO();
   __shared__ float llr[32];
   const int sf = blockIdx.x, lane = threadIdx.x;
   const cf32* g = grid + (size_t)sf * c.nof_rx * 14 * c.nre;
@@ -389,7 +385,6 @@ __global__ __launch_bounds__(256) void k_pdcch_llr(LsnCellDev c, const cf32* __r
                                                    const LsnChest* __restrict__ ch, const uint32_t* __restrict__ sf_idx_arr,
                                                    const uint32_t* __restrict__ cfi_arr, float* __restrict__ llr)
 {
-  LSN_WAVE_PRIO();
   const int sf = blockIdx.y;
   const uint32_t cfi = cfi_arr[sf];
   const int nre = (int)c.nre, A = (int)c.nof_rx, n0 = nre / 6, n1 = nre / 4;
@@ -432,7 +427,6 @@ void lsn_launch_pdcch_llr(const LsnCellDev& c, const cf32* grid, const cf32* ce,
 __global__ __launch_bounds__(128) void k_cce_power(LsnCellDev c, const float* __restrict__ llr, const uint32_t* __restrict__ cfi_arr,
                                                    float* __restrict__ pw)
 {
-  LSN_WAVE_PRIO();
   const int sf = blockIdx.x, cce = threadIdx.x;
   if (cce >= LSN_CCE_STRIDE) return;
   float out = 0.0f;
@@ -720,7 +714,6 @@ __global__ __launch_bounds__(64) void k_viterbi(LsnCellDev c, const float* __res
                                                 const uint32_t* __restrict__ cfi_arr, const uint32_t* __restrict__ sf_idx_arr,
                                                 LsnCand* __restrict__ cand)
 {
-  LSN_WAVE_PRIO();
   // per trellis step: (q0 - 128) | (q1 - 128) << 8 | (q2 - 128) << 16, signed bytes; one array per candidate of the pair (locations 2 bx, 2 bx + 1)
   __shared__ __attribute__((aligned(16))) int symw[2][LSN_MAX_DCI_D + 4];
   const int lane = threadIdx.x, sf = blockIdx.z, sz = blockIdx.y;
@@ -799,7 +792,6 @@ __global__ __launch_bounds__(64) void k_viterbi(LsnCellDev c, const float* __res
                                                 const uint32_t* __restrict__ cfi_arr, const uint32_t* __restrict__ sf_idx_arr,
                                                 LsnCand* __restrict__ cand)
 {
-  LSN_WAVE_PRIO();
   __shared__ __attribute__((aligned(16))) int symw[LSN_MAX_DCI_D + 4];  // per trellis step: (q0 - 128) | (q1 - 128) << 8 | (q2 - 128) << 16, signed bytes
   const int lane = threadIdx.x, sf = blockIdx.z, sz = blockIdx.y;
   int li = blockIdx.x;
@@ -888,7 +880,6 @@ __device__ __forceinline__ void pbch_pos(const LsnCellDev& c, int i, int& l, int
 __global__ __launch_bounds__(256) void k_pbch_llr(LsnCellDev c, const cf32* __restrict__ g, const cf32* __restrict__ ce, const LsnChest* __restrict__ ch,
                                                   float* __restrict__ out /* [5][480]: raw, then 4 descrambled */)
 {
-  LSN_WAVE_PRIO();
   const int tid = threadIdx.x, nre = (int)c.nre, A = (int)c.nof_rx;
   const float noise = ch[0].noise_avg;
   const int np = pbch_count(c), E4 = 2 * np;  // symbols / coded bits of one radio frame's PBCH
@@ -947,7 +938,6 @@ __global__ __launch_bounds__(256) void k_pbch_llr(LsnCellDev c, const cf32* __re
 }
 __global__ __launch_bounds__(64) void k_pbch_viterbi(LsnCellDev c, const float* __restrict__ llr5, LsnCand* __restrict__ out4)
 {
-  LSN_WAVE_PRIO();
   __shared__ __attribute__((aligned(16))) int symw[LSN_MAX_DCI_D + 4];
   const int lane = threadIdx.x, q = blockIdx.x;
   const float* e = llr5 + 480 * (q + 1);
@@ -997,7 +987,6 @@ void lsn_launch_viterbi(const LsnCellDev& c, const float* llr, const float* pw, 
 // k_ofdm (rbp_part); this kernel adds them in symbol order (the rows of an extended-CP subframe behind symbol 11 are zero, as in the 14-row grid)
 __global__ void k_rb_power(LsnCellDev c, const float* __restrict__ part, float* __restrict__ rbp)
 {
-  LSN_WAVE_PRIO();
   const int sf = blockIdx.x, prb = threadIdx.x;
   if (prb >= (int)c.nof_prb) return;
   float acc = 0.0f;
@@ -1016,7 +1005,6 @@ void lsn_launch_rb_power(const LsnCellDev& c, const float* part, float* rbp, uin
 __global__ __launch_bounds__(256) void k_file_unpack(const cf32* __restrict__ raw, const cf32* __restrict__ rot, uint32_t sflen, uint32_t nant,
                                                      cf32* __restrict__ out)
 {
-  LSN_WAVE_PRIO();
   const uint32_t n = blockIdx.x * 256 + threadIdx.x, a = blockIdx.y, sf = blockIdx.z;
   if (n >= sflen) return;
   cf32 x = raw[((size_t)sf * sflen + n) * nant + a];
@@ -1036,7 +1024,6 @@ void lsn_launch_file_unpack(const cf32* raw, const cf32* rot, uint32_t sflen, ui
 // ------------------------------------------------------------------------------------------------ descriptor upload (see lsn_dev.h)
 __global__ __launch_bounds__(256) void k_upload_words(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, uint32_t n)
 {
-  LSN_WAVE_PRIO();
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) dst[i] = src[i];
 }
 void lsn_launch_upload(void* dst_dev, const void* src_pinned, size_t bytes, hipStream_t s)
@@ -1050,7 +1037,6 @@ void lsn_launch_upload(void* dst_dev, const void* src_pinned, size_t bytes, hipS
 __global__ __launch_bounds__(256) void k_download(const uint4* __restrict__ src, uint4* __restrict__ dst, uint32_t n16, const uint32_t* __restrict__ src_w,
                                                   uint32_t* __restrict__ dst_w, uint32_t tail_first, uint32_t tail_n)
 {
-  LSN_WAVE_PRIO();
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n16; i += gridDim.x * 256u) dst[i] = src[i];
   if (blockIdx.x == 0 && threadIdx.x < tail_n) dst_w[tail_first + threadIdx.x] = src_w[tail_first + threadIdx.x];
   __threadfence_system();  // the stores to host memory are performed at system scope before the kernel (and the event behind it) completes
@@ -1059,7 +1045,6 @@ __global__ __launch_bounds__(256) void k_download(const uint4* __restrict__ src,
 // copy kernel occupies a hardware queue slot of the streams that share it, and the pipeline made 55 of them per 1000 subframes (round 3)
 __global__ __launch_bounds__(256) void k_copy_multi(LsnCopySegs sg, uint32_t to_host)
 {
-  LSN_WAVE_PRIO();
   for (uint32_t q = 0; q < sg.n; q++) {
     const uint32_t words = sg.words[q];
     const bool al = ((((uintptr_t)sg.src[q]) | ((uintptr_t)sg.dst[q])) & 15u) == 0;

@@ -23,7 +23,6 @@ __device__ __forceinline__ float cabs2(cf32 a) { return a.r * a.r + a.i * a.i; }
 // One wavefront per job: lanes are PRBs (two rounds cover 110), the exclusive prefix over the PRBs of a symbol is a shuffle scan.
 __global__ __launch_bounds__(64) void k_pdsch_prep(LsnCellDev c, const LsnGrantDev* __restrict__ jobs, uint16_t* __restrict__ prefix)
 {
-  LSN_WAVE_PRIO();
   const LsnGrantDev& g = jobs[blockIdx.x];
   const int lane = threadIdx.x, nprb = (int)c.nof_prb;
   uint16_t* pf = prefix + g.prefix_off;
@@ -60,7 +59,6 @@ void lsn_launch_pdsch_prep(const LsnCellDev& c, const LsnGrantDev* g, uint16_t* 
 __global__ __launch_bounds__(64) void k_pdsch_prep_up(LsnCellDev c, const LsnGrantDev* __restrict__ jobs_h, LsnGrantDev* __restrict__ jobs_d, uint32_t njobs,
                                                       LsnCopySegs sg, uint16_t* __restrict__ prefix)
 {
-  LSN_WAVE_PRIO();
   const int lane = threadIdx.x, nprb = (int)c.nof_prb;
   if (blockIdx.x >= njobs) {
     const uint32_t w = blockIdx.x - njobs, nw = gridDim.x - njobs;
@@ -176,7 +174,6 @@ __global__ __launch_bounds__(192) void k_pdsch_demod(LsnCellDev c, const LsnGran
                                                      const cf32* __restrict__ grid, const cf32* __restrict__ ce,
                                                      const LsnChest* __restrict__ chest, int16_t* __restrict__ llr)
 {
-  LSN_WAVE_PRIO();
   const uint32_t item = items[blockIdx.x];
   const LsnGrantDev& g = jobs[item >> 8];
   const int nprb = (int)c.nof_prb, nre = (int)c.nre, A = (int)c.nof_rx;
@@ -330,7 +327,6 @@ __device__ __forceinline__ int rm_sum(const int16_t* __restrict__ e, const int16
 }
 __global__ __launch_bounds__(RM_NT) void k_rm(const LsnCbDev* __restrict__ cbs, const int16_t* __restrict__ llr, uint32_t* __restrict__ spp_g, uint32_t seg)
 {
-  LSN_WAVE_PRIO();
   extern __shared__ __attribute__((aligned(16))) unsigned char rm_smem[];
   __shared__ LsnRmGeom geom;
   int16_t* es = (int16_t*)rm_smem;
@@ -391,7 +387,6 @@ void lsn_launch_rm(const LsnCbDev* cb, const int16_t* llr, uint32_t* spp, uint32
 // block; LsnCbDev::spp_off = the block's words in the buffer pool, LsnCbDev::e_off = the words of the current transmission (in `cur`).
 __global__ __launch_bounds__(256) void k_harq_combine(const LsnCbDev* __restrict__ cbs, const uint32_t* __restrict__ cur, uint32_t* __restrict__ pool, uint32_t overwrite)
 {
-  LSN_WAVE_PRIO();
   const LsnCbDev cb = cbs[blockIdx.x];
   const uint32_t* c = cur + cb.e_off;
   uint32_t* a = pool + cb.spp_off;

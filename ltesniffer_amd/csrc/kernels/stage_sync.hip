@@ -17,7 +17,6 @@
 __global__ __launch_bounds__(SYNC_TILE) void k_pss_corr(const cf32* __restrict__ x, const cf32* __restrict__ p /* [nroots][N] */, uint32_t N, uint32_t W5,
                                                         uint32_t P, uint32_t nroots, float* __restrict__ C /* [nroots][W5] */)
 {
-  LSN_WAVE_PRIO();
   __shared__ cf32 xs[SYNC_TILE + 2048];
   const cf32* __restrict__ ps = p;  // uniform index: scalar loads
   const uint32_t t = threadIdx.x, n0 = blockIdx.x * SYNC_TILE, n = n0 + t;
@@ -75,7 +74,6 @@ __global__ __launch_bounds__(512) void k_sync_fin(const cf32* __restrict__ x, co
                                                   const int8_t* __restrict__ sss /* [336][62] */, uint32_t N, uint32_t W5, uint32_t P, uint32_t bn,
                                                   uint32_t cp, LsnSyncFin* __restrict__ out)
 {
-  LSN_WAVE_PRIO();
   __shared__ float yh[17][2][3];  // [occurrence][half][re / im / energy]
   __shared__ cf32 Y[2][62];
   __shared__ cf32 z[62];

@@ -45,7 +45,6 @@ __device__ __forceinline__ void ul_fft_pass(cf32* a, const cf32* w, int s, int N
 // one workgroup per (subframe, symbol): CP strip, 7.5 kHz shift, radix-8/4/2 DIT FFT in LDS, carrier extract (no DC gap)
 __global__ __launch_bounds__(256) void k_ul_fft(LsnCellDev c, const cf32* __restrict__ iq, uint32_t nant, uint32_t ant, cf32* __restrict__ grid)
 {
-  LSN_WAVE_PRIO();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int N = (int)c.N, lgN = (int)c.lgN, tid = threadIdx.x;
   cf32* a = (cf32*)smem;
@@ -109,7 +108,6 @@ void lsn_launch_ul_fft(const LsnCellDev& c, const cf32* iq, uint32_t nant, uint3
 __global__ __launch_bounds__(256) void k_pusch_chest(LsnCellDev c, const LsnUlGrantDev* __restrict__ grants, const cf32* __restrict__ grid,
                                                      cf32* __restrict__ hs_out, float* __restrict__ stat)
 {
-  LSN_WAVE_PRIO();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const LsnUlGrantDev g = grants[blockIdx.x];
   const int M = 12 * (int)g.L_prb, nre = (int)c.nre, tid = threadIdx.x;
@@ -180,7 +178,6 @@ __device__ __forceinline__ void ul_demod_llr(int Qm, float I, float Q, float* L)
 __global__ __launch_bounds__(256) void k_pusch_demod(LsnCellDev c, const LsnUlGrantDev* __restrict__ grants, const cf32* __restrict__ grid,
                                                      const cf32* __restrict__ hs_all, const float* __restrict__ stat, int16_t* __restrict__ llr)
 {
-  LSN_WAVE_PRIO();
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const LsnUlGrantDev g = grants[blockIdx.y];
   // data symbol `col` of the subframe (12, or 10 with the extended CP) -> symbol l: the reference-signal symbol of each slot is skipped
@@ -290,7 +287,6 @@ __device__ __forceinline__ void tree256_2(float* pr, float* pi, int tid)
 __global__ __launch_bounds__(256) void k_prach_bins(const cf32* __restrict__ iq, const uint64_t* __restrict__ occ_off, const cf32* __restrict__ W,
                                                     int N12, int Ncp, int b0, cf32* __restrict__ Y)
 {
-  LSN_WAVE_PRIO();
   __shared__ float pr[256], pi[256];
   const int j = blockIdx.x, o = blockIdx.y, tid = threadIdx.x;
   const cf32* x = iq + occ_off[o] + Ncp;
@@ -312,7 +308,6 @@ __global__ __launch_bounds__(256) void k_prach_bins(const cf32* __restrict__ iq,
 __global__ __launch_bounds__(256) void k_prach_corr(const cf32* __restrict__ Y, const cf32* __restrict__ D, const cf32* __restrict__ V, int nroots,
                                                     float* __restrict__ corr)
 {
-  LSN_WAVE_PRIO();
   __shared__ float pr[256], pi[256];
   const int k = blockIdx.x, root = blockIdx.y, o = blockIdx.z, tid = threadIdx.x;
   const cf32* y = Y + (size_t)o * LSN_NZC;
@@ -330,7 +325,6 @@ __global__ __launch_bounds__(256) void k_prach_corr(const cf32* __restrict__ Y, 
 // grid (nroots, nocc).  out[(o * nroots + root) * 130 + {0: mean, 1: unused, 2 + 2 w: peak of window w, 3 + 2 w: its lag}]
 __global__ __launch_bounds__(256) void k_prach_peaks(const float* __restrict__ corr, int nroots, int ncs, int nwin, float* __restrict__ out)
 {
-  LSN_WAVE_PRIO();
   __shared__ float pr[256], pi[256];
   const int root = blockIdx.x, o = blockIdx.y, tid = threadIdx.x;
   const float* c = corr + ((size_t)o * nroots + root) * LSN_NZC;
