@@ -149,7 +149,13 @@ Engine::Engine(const lsn_phy_cfg_t& c, std::shared_ptr<SharedSeq> shared) : sh(s
   {
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-    for (auto& sa : stream_a) HIP_CHECK(hipStreamCreateWithPriority(&sa, hipStreamNonBlocking, hi));  // stage A feeds the sequential search
+    // Stage A runs at the SAME (lowest) stream priority as the bulk decode chains since the second half of round 5.  Rounds 1-4 gave it the highest
+    // ("stage A feeds the sequential search"): its kernels - k_viterbi alone is 384 000 wavefronts per chunk - then take the chip whenever they are
+    // queued and the decode chains, which bound the engine, stand still meanwhile: 208-212 k subframes/s against 220-222 k with equal priorities,
+    // 119 k against 129 k at 16 dB (profiles/r05_exp_session14.txt, r05_exp_session15.txt; decode chains ABOVE stage A: 219-220 k, then stage A is what
+    // the decode threads wait for).  LSN_STAGE_A_PRIO = 2 / 1 restores the highest / the normal level (A/B).
+    const int pa = getenv("LSN_STAGE_A_PRIO") ? atoi(getenv("LSN_STAGE_A_PRIO")) : 0;
+    for (auto& sa : stream_a) HIP_CHECK(hipStreamCreateWithPriority(&sa, hipStreamNonBlocking, pa >= 2 ? hi : (pa == 1 ? (lo + hi) / 2 : lo)));
   }
   HIP_CHECK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
   trace_path = getenv("LSN_TRACE");

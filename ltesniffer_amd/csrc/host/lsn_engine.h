@@ -323,7 +323,10 @@ private:
   size_t staging_sf = 0;
   Chunk chunks[NSLOTS];
   JobRunner runner_c[NDEC], runner_s, runner_f, runner_k;  // decode threads / search thread (on-demand RAR decodes) / front thread (speculative RAR decodes) / commit thread (on-demand decodes)
-  static constexpr int NSTREAM_A = 4;        // stage A of consecutive chunks overlaps on the GPU (kernels of one stream serialise)
+#ifndef LSN_NSTREAM_A
+#define LSN_NSTREAM_A 4
+#endif
+  static constexpr int NSTREAM_A = LSN_NSTREAM_A;        // stage A of consecutive chunks overlaps on the GPU (kernels of one stream serialise)
   hipStream_t stream_a[NSTREAM_A] = {};
   hipEvent_t ev_in = nullptr;
   std::vector<hipEvent_t> ev_pool;            // recycled "block ready" events (guarded by mtx)
