@@ -136,8 +136,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--step-sf", type=int, default=20000, help="subframes per step: a divisor of the capture length and a multiple of 200 (20 000 = one pass of the "
-                    "capture: the driver's 20 timed steps last 2 s; rounds 1-4 used 4 000, a timed region of 0.4 s of which pipeline fill / drain was 5 %%)")
+    ap.add_argument("--step-sf", type=int, default=0, help="subframes per step: a divisor of the capture length and a multiple of 200.  0 (default) = 20 000 (one pass of the "
+                    "capture: the driver's 20 timed steps last 2 s; rounds 1-4 used 4 000, a timed region of 0.4 s of which pipeline fill / drain was 5 %%) when the cached "
+                    "oracle stream covers (warmup + steps) x 20 000 subframes, otherwise the largest step the cache covers completely: the headline is never printed ungated "
+                    "because the cache is shorter than the run")
     ap.add_argument("--nsf", type=int, default=0, help="distinct subframes of the capture (0 = the gated stream's 20 000); other values run ungated")
     ap.add_argument("--config", default="cfg3", help="scenario preset: cfg3 = 20 MHz, 150 RNTIs, TM3/TM4 up to 256QAM")
     ap.add_argument("--batch", type=int, default=400, help="subframes per pipeline chunk inside a submit (400-500 measured best on the 4 000-subframe steps: shorter fill / drain than 800, fewer launches than 200)")
@@ -214,6 +216,19 @@ def main():
         assert wl_leg["kind"] == "dl" and world == 1, "--workload: a downlink leg on one GPU"
     gated_cfg = (args.config == "cfg3" and args.nsf in (0, NSF)) or wl_leg is not None
     nsf = wl_leg["nsf"] if wl_leg else (NSF if gated_cfg else max(BLOCK, (args.nsf or NSF) // BLOCK * BLOCK))
+    step_sf_auto = None
+    if args.step_sf <= 0:
+        # every rank reads the same file, so every rank arrives at the same step
+        args.step_sf = 20000
+        try:
+            cached = json.load(open(bl_.golden_path(args.workload) if wl_leg is not None else GOLDEN))["oracle_subframes"] if gated_cfg else 0
+        except Exception:
+            cached = 0
+        if cached:
+            fit = [s_ for s_ in (20000, 10000, 5000, 4000, 2000, 1000, 400, 200) if nsf % s_ == 0 and (args.steps + args.warmup) * s_ <= cached]
+            args.step_sf = fit[0] if fit else BLOCK
+            step_sf_auto = {"cached_oracle_subframes": cached, "chosen": args.step_sf,
+                            "rule": "largest of 20000 / 10000 / 5000 / 4000 / 2000 / 1000 / 400 / 200 with (warmup + steps) x step <= cached oracle subframes"}
     S = max(BLOCK, min(args.step_sf, nsf) // BLOCK * BLOCK)
     while nsf % S:
         S -= BLOCK  # a step never straddles the wrap of the capture
@@ -648,7 +663,7 @@ def main():
             "config": {"workload": "%s: 20 MHz DL (100 PRB, 2 CRS ports, 2 rx), 150 active RNTIs + a fresh RNTI by RAR every 200 subframes, TM2/TM3/TM4 mix up to 256QAM, "
                                    "CFI 3, 8-14 DL + 3-6 UL DCIs per subframe (BASELINE.json configs[2], SURVEY 8d config 3)" % args.config
                        if args.config == "cfg3" and wl_leg is None else (args.workload + ": " + wl_leg["what"] if wl_leg else args.config),
-                       "subframes_per_step": S, "distinct_subframes": nsf, "stream": "capture replayed cyclically, TTI and sequential state carried over",
+                       "subframes_per_step": S, "subframes_per_step_auto": step_sf_auto, "distinct_subframes": nsf, "stream": "capture replayed cyclically, TTI and sequential state carried over",
                        "input": "resident in HBM", "steps_pipelined": True, "gpu_batch": batch, "cells": 1 if capture_mode else world, "capture_gen_s": round(t_gen, 1),
                        "parallelism": ("one capture, chunks round-robin over devices %s, shared sequential search" % devices) if capture_mode else "one cell per GPU, no collective"},
             "roofline": {"bound": "hbm", "kernel": la.KERNELS[kt], "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s",
