@@ -278,4 +278,21 @@ void lsnh_mcs_get(void* m, uint16_t rnti, uint32_t* out)
   out[1] = c.i_offset_ack; out[2] = c.i_offset_cqi; out[3] = c.i_offset_ri; out[4] = c.cqi_type; out[5] = c.has_ue_config;
 }
 
+// the product's RNTIManager on its own (tests/test_ref_rnti_manager.py: operation sequences against the REFERENCE's RNTIManager.cc, oracle/_ref)
+void* lsnh_rm_new(uint32_t nformats, uint32_t maxcand, uint32_t threshold) { return new RNTIManager(nformats, maxcand, threshold); }
+void lsnh_rm_free(void* h) { delete (RNTIManager*)h; }
+void lsnh_rm_add_evergreen(void* h, uint16_t a, uint16_t b, uint32_t f) { ((RNTIManager*)h)->addEvergreen(a, b, f); }
+void lsnh_rm_add_forbidden(void* h, uint16_t a, uint16_t b, uint32_t f) { ((RNTIManager*)h)->addForbidden(a, b, f); }
+void lsnh_rm_add_candidate(void* h, uint16_t rnti, uint32_t f) { ((RNTIManager*)h)->addCandidate(rnti, f); }
+int lsnh_rm_validate(void* h, uint16_t rnti, uint32_t f) { return ((RNTIManager*)h)->validate(rnti, f) ? 1 : 0; }
+int lsnh_rm_validate_and_refresh(void* h, uint16_t rnti, uint32_t f) { return ((RNTIManager*)h)->validateAndRefresh(rnti, f) ? 1 : 0; }
+void lsnh_rm_activate_and_refresh(void* h, uint16_t rnti, uint32_t f, int reason) { ((RNTIManager*)h)->activateAndRefresh(rnti, f, (ActivationReason)reason); }
+int lsnh_rm_is_evergreen(void* h, uint16_t rnti, uint32_t f) { return ((RNTIManager*)h)->isEvergreen(rnti, f) ? 1 : 0; }
+int lsnh_rm_is_forbidden(void* h, uint16_t rnti, uint32_t f) { return ((RNTIManager*)h)->isForbidden(rnti, f) ? 1 : 0; }
+void lsnh_rm_step_time(void* h, uint32_t n) { while (n--) ((RNTIManager*)h)->stepTime(); }
+uint32_t lsnh_rm_get_frequency(void* h, uint16_t rnti, uint32_t f) { return ((RNTIManager*)h)->getFrequency(rnti, f); }
+int lsnh_rm_get_activation_reason(void* h, uint16_t rnti) { return (int)((RNTIManager*)h)->getActivationReason(rnti); }
+void lsnh_rm_set_threshold(void* h, uint32_t t) { ((RNTIManager*)h)->setHistogramThreshold(t); }
+uint32_t lsnh_rm_nof_active(void* h) { return ((RNTIManager*)h)->nofActive(); }
+
 }  // extern "C"
