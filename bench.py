@@ -131,6 +131,13 @@ def _pcie_link(local):
         return None
 
 
+def auto_step_sf(nsf, steps, warmup, cached, block=200):
+    """--step-sf 0: the largest step (a divisor of the capture, a multiple of the digest block) whose whole run - warm-up and timed steps - lies inside the
+    cached oracle stream, so that every timed block has an oracle block to be compared with"""
+    fit = [s_ for s_ in (20000, 10000, 5000, 4000, 2000, 1000, 400, 200) if s_ % block == 0 and nsf % s_ == 0 and (steps + warmup) * s_ <= cached]
+    return fit[0] if fit else block
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -225,8 +232,7 @@ def main():
         except Exception:
             cached = 0
         if cached:
-            fit = [s_ for s_ in (20000, 10000, 5000, 4000, 2000, 1000, 400, 200) if nsf % s_ == 0 and (args.steps + args.warmup) * s_ <= cached]
-            args.step_sf = fit[0] if fit else BLOCK
+            args.step_sf = auto_step_sf(nsf, args.steps, args.warmup, cached, BLOCK)
             step_sf_auto = {"cached_oracle_subframes": cached, "chosen": args.step_sf,
                             "rule": "largest of 20000 / 10000 / 5000 / 4000 / 2000 / 1000 / 400 / 200 with (warmup + steps) x step <= cached oracle subframes"}
     S = max(BLOCK, min(args.step_sf, nsf) // BLOCK * BLOCK)
