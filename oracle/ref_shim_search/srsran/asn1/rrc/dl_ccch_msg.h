@@ -1,0 +1,2 @@
+#pragma once
+#include "srsran/asn1/rrc/standin_rrc.h"
