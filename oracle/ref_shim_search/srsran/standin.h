@@ -120,7 +120,8 @@ typedef struct {
   uint32_t hopping_offset, n_sb, n_rb_ho, current_tx_nb; bool hopping_enabled;
 } srsran_pusch_hopping_cfg_t;
 typedef struct { uint32_t I_offset_cqi, I_offset_ri, I_offset_ack; } srsran_uci_offset_cfg_t;
-typedef struct { bool data_enable, pmi_present, four_antenna_ports, rank_is_not_one, subband_label_2_bits; uint32_t scell_index, L, N, type, ri_len; } srsran_cqi_cfg_t;
+typedef enum { SRSRAN_CQI_TYPE_WIDEBAND = 0, SRSRAN_CQI_TYPE_SUBBAND_UE, SRSRAN_CQI_TYPE_SUBBAND_HL } srsran_cqi_type_t;
+typedef struct { bool data_enable, pmi_present, four_antenna_ports, rank_is_not_one, subband_label_2_bits; uint32_t scell_index, L, N; srsran_cqi_type_t type; uint32_t ri_len; } srsran_cqi_cfg_t;
 typedef struct { uint32_t n_prb_lowest, n_dmrs, I_phich; } srsran_phich_grant_t;
 typedef struct { uint32_t max_cb; int16_t** buffer_f; uint8_t** data; bool* cb_crc; bool tb_crc; } srsran_softbuffer_rx_t;
 typedef struct { uint32_t cyclic_shift, cyclic_shift_for_dmrs, delta_ss; bool group_hopping_en, sequence_hopping_en; } srsran_refsignal_dmrs_pusch_cfg_t;
@@ -156,6 +157,9 @@ uint32_t srsran_crc_checksum(srsran_crc_t* h, uint8_t* data, int len);
 uint32_t srsran_bit_pack(uint8_t** bits, int nof_bits);
 void srsran_bit_fprint(FILE* stream, uint8_t* bits, int nof_bits);
 float srsran_vec_avg_power_cf(const cf_t* x, const uint32_t len);
+int srsran_softbuffer_rx_init(srsran_softbuffer_rx_t* q, uint32_t nof_prb);
+void srsran_softbuffer_rx_free(srsran_softbuffer_rx_t* q);
+void srsran_softbuffer_rx_reset(srsran_softbuffer_rx_t* q);
 #ifdef __cplusplus
 }
 #endif

@@ -278,6 +278,19 @@ void lsnh_mcs_get(void* m, uint16_t rnti, uint32_t* out)
   out[1] = c.i_offset_ack; out[2] = c.i_offset_cqi; out[3] = c.i_offset_ri; out[4] = c.cqi_type; out[5] = c.has_ue_config;
 }
 
+// the product's downlink HARQ database on its own (tests/test_ref_harq.py: random grant sequences against the REFERENCE's HARQ.cc, oracle/_ref)
+void* lsnh_harq_new() { return new HarqDatabase(); }
+void lsnh_harq_free(void* h) { delete (HarqDatabase*)h; }
+int lsnh_harq_is_retransmission(void* h, uint16_t rnti, uint32_t pid, int tid, int ndi, int tbs, uint32_t sfn, uint32_t sf_idx, int* entity)
+{
+  return (int)((HarqDatabase*)h)->is_retransmission(rnti, pid, tid, ndi != 0, tbs, sfn, sf_idx, *entity);
+}
+void lsnh_harq_update(void* h, int entity, uint32_t pid, int tid, uint32_t sfn, uint32_t sf_idx, int decoded, int ndi, int rv, int tbs, uint32_t now)
+{
+  ((HarqDatabase*)h)->update(entity, pid, tid, sfn, sf_idx, decoded != 0, ndi != 0, rv, tbs, now);
+}
+void lsnh_harq_update_database(void* h, uint32_t now) { ((HarqDatabase*)h)->update_database(now); }
+
 // the product's RNTIManager on its own (tests/test_ref_rnti_manager.py: operation sequences against the REFERENCE's RNTIManager.cc, oracle/_ref)
 void* lsnh_rm_new(uint32_t nformats, uint32_t maxcand, uint32_t threshold) { return new RNTIManager(nformats, maxcand, threshold); }
 void lsnh_rm_free(void* h) { delete (RNTIManager*)h; }

@@ -169,3 +169,175 @@ def test_idle_entries_leave_after_more_than_interval_whole_seconds():
         assert h.lsnh_mcs_peek(m, 300) == -1
     finally:
         h.lsnh_mcs_free(m)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------------
+# The same database pinned on the REFERENCE'S OWN CODE: /root/reference/src/src/MCSTracking.cc compiled verbatim into oracle/_ref/libref_falcon_mcs.so
+# (oracle/Makefile.ref; no srsRAN function is called, clock() is bound to a settable clock of 1 ms per subframe: oracle/ref_shim_search/mcs_glue.cc).
+# Random lives of a database - look-ups, statistics with MIMO errors, table updates, random-access responses, ageing passes - go through the
+# reference, the product (lsn_lte.cc: MCSTracking) and the Python model above; what each answers (every look-up, and after every ageing pass the
+# population and every entry's table) is reduced to a digest.  tests/golden/mcs_tracking_ref.json holds the reference's digests
+# (tests/golden/make_mcs_fixture.py); the library itself runs again where it is present.
+import hashlib
+import json
+import os
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MCS_REF_SO = os.path.join(_ROOT, "oracle", "_ref", "libref_falcon_mcs.so")
+MCS_FIX = os.path.join(_ROOT, "tests", "golden", "mcs_tracking_ref.json")
+LIFE_SEEDS = (11, 12, 13, 14, 15, 16)
+
+
+class _Product:
+    name = "product"
+
+    def __init__(self):
+        self.h = _bind(hosttest())
+        self.m = self.h.lsnh_mcs_new()
+        self.now = 0
+
+    def set_now(self, now): self.now = now
+    def find(self, r): return self.h.lsnh_mcs_find(self.m, r, self.now)
+    def stat(self, r, fmt, t, en, ok, mimo): self.h.lsnh_mcs_stat(self.m, r, fmt, t, int(en[0]), int(en[1]), int(ok[0]), int(ok[1]), mimo, self.now)
+    def update(self, r, t): self.h.lsnh_mcs_update(self.m, r, t, self.now)
+    def rar(self, r): self.h.lsnh_mcs_rar(self.m, r, self.now)
+    def update_database(self): self.h.lsnh_mcs_update_database(self.m, self.now)
+    def count(self): return self.h.lsnh_mcs_count(self.m)
+    def peek(self, r): return self.h.lsnh_mcs_peek(self.m, r)
+    def close(self): self.h.lsnh_mcs_free(self.m)
+
+
+class _Model:
+    name = "python model"
+
+    def __init__(self):
+        self.m = RefModel()
+        self.now = 0
+
+    def set_now(self, now): self.now = now
+    def find(self, r): return self.m.find(r, self.now)
+    def stat(self, r, fmt, t, en, ok, mimo): self.m.statistic(r, fmt, t, en, ok, mimo, self.now)
+    def update(self, r, t): self.m.update(r, t, self.now)
+    def rar(self, r): self.m.rar(r, self.now)
+    def update_database(self): self.m.update_database(self.now)
+    def count(self): return len(self.m.db)
+    def peek(self, r): return self.m.db[r]["table"] if r in self.m.db else -1
+    def close(self): pass
+
+
+class _Reference:
+    name = "reference"
+
+    def __init__(self):
+        L = self.lib = C.CDLL(MCS_REF_SO)
+        L.ref_mcs_new.restype = C.c_void_p
+        L.ref_mcs_new.argtypes = [C.c_int]
+        L.ref_mcs_free.argtypes = [C.c_void_p]
+        L.ref_mcs_set_now_ms.argtypes = [C.c_uint64]
+        L.ref_mcs_find.argtypes = [C.c_void_p, C.c_uint16]
+        L.ref_mcs_update.argtypes = [C.c_void_p, C.c_uint16, C.c_int]
+        L.ref_mcs_rar.argtypes = [C.c_void_p, C.c_uint16]
+        L.ref_mcs_stat.argtypes = [C.c_void_p, C.c_uint16] + [C.c_int] * 7 + [C.c_uint32] * 2
+        L.ref_mcs_update_database.argtypes = [C.c_void_p]
+        L.ref_mcs_count.argtypes = [C.c_void_p]
+        L.ref_mcs_count.restype = C.c_uint32
+        L.ref_mcs_peek.argtypes = [C.c_void_p, C.c_uint16, C.c_void_p]
+        L.ref_mcs_get_ue_config.argtypes = [C.c_void_p, C.c_uint16, C.c_void_p]
+        self.m = L.ref_mcs_new(0)
+
+    def set_now(self, now): self.lib.ref_mcs_set_now_ms(now)
+    def find(self, r): return self.lib.ref_mcs_find(self.m, r)
+    def stat(self, r, fmt, t, en, ok, mimo): self.lib.ref_mcs_stat(self.m, r, fmt, t, int(en[0]), int(en[1]), int(ok[0]), int(ok[1]), mimo, 5, 9)
+    def update(self, r, t): self.lib.ref_mcs_update(self.m, r, t)
+    def rar(self, r): self.lib.ref_mcs_rar(self.m, r)
+    def update_database(self): self.lib.ref_mcs_update_database(self.m)
+    def count(self): return self.lib.ref_mcs_count(self.m)
+    def peek(self, r): return self.lib.ref_mcs_peek(self.m, r, None)
+    def close(self): self.lib.ref_mcs_free(self.m)
+
+
+def life(seed, b, steps=40000):
+    """one life of a database on back-end b -> (digest of everything it answered, counters)"""
+    rng = random.Random(seed)
+    pool = [rng.randrange(11, 0xFFF4) for _ in range(300 + 40 * (seed % 4))]
+    core = pool[:40 + 10 * (seed % 3)]
+    h = hashlib.sha256()
+    now, passes, aged, full, after_rar = 0, 0, 0, 0, 0
+    for step in range(steps):
+        now += rng.choice((1, 1, 1, 2, 5, 30 if seed % 2 else 1))
+        b.set_now(now)
+        r = rng.choice(core) if rng.random() < 0.7 else rng.choice(pool)
+        ev = rng.random()
+        if ev < 0.45:
+            t = b.find(r)
+            h.update(b"f%d:%d;" % (r, t))
+            full += t == TFULL
+            en = (1, rng.random() < 0.4)
+            ok = tuple(int(e and rng.random() < (0.05 if r % 7 == 0 else 0.9)) for e in en)
+            mimo = rng.choice((0, 0, 0, 0, -1, -2, -3)) if r % 11 == 0 else 0
+            b.stat(r, rng.choice((1, 2, 6, 7)), t if t != TFULL else T64, en, ok, mimo)
+        elif ev < 0.75:
+            b.update(r, rng.choice((T64, T256)))
+        elif ev < 0.80:
+            b.rar(r)
+            after_rar += 1
+        if now // 5000 != (now - 30) // 5000 and rng.random() < 0.5:
+            before = b.count()
+            b.update_database()
+            passes += 1
+            aged += before - b.count()
+            h.update(b"u%d:" % b.count())
+            h.update(",".join("%d" % b.peek(x) for x in pool).encode())
+    h.update(b"e%d:" % b.count())
+    h.update(",".join("%d" % b.peek(x) for x in pool).encode())
+    return h.hexdigest()[:32], dict(ageing_passes=passes, entries_aged_out=aged, full_buffer_answers=full, rar=after_rar, population_at_the_end=b.count())
+
+
+def _life_on(cls, seed):
+    b = cls()
+    try:
+        return life(seed, b)
+    finally:
+        b.close()
+
+
+@pytest.mark.parametrize("seed", LIFE_SEEDS)
+def test_product_database_answers_like_the_references_own_mcs_tracking(seed):
+    fix = json.load(open(MCS_FIX))
+    want = fix["lives"][str(seed)]
+    got, info = _life_on(_Product, seed)
+    assert info == want["counters"], "the product's database ages / fills differently from the reference's MCSTracking.cc"
+    assert got == want["digest"]
+    assert _life_on(_Model, seed)[0] == want["digest"]   # and so does the Python model the tests above are written against
+
+
+def test_the_lives_reach_the_corners():
+    fix = json.load(open(MCS_FIX))
+    c = [v["counters"] for v in fix["lives"].values()]
+    assert all(x["entries_aged_out"] > 100 and x["ageing_passes"] > 10 and x["rar"] > 1000 for x in c)
+    assert any(x["full_buffer_answers"] > 0 for x in c), "no life filled the 250 entries"
+    assert fix["default_ue_config_of_an_unknown_rnti"] == [0, 10, 8, 11, 2, 0]   # p_a bits, I_offset ack / cqi / ri, CQI type (higher-layer sub-band), has_ue_config
+
+
+@pytest.mark.skipif(not os.path.exists(MCS_REF_SO), reason="oracle/_ref/libref_falcon_mcs.so not built (needs /root/reference: make -C oracle -f Makefile.ref)")
+@pytest.mark.parametrize("seed", LIFE_SEEDS)
+def test_reference_library_reproduces_the_committed_mcs_fixture(seed):
+    fix = json.load(open(MCS_FIX))
+    got, info = _life_on(_Reference, seed)
+    assert (got, info) == (fix["lives"][str(seed)]["digest"], fix["lives"][str(seed)]["counters"])
+
+
+def test_default_ue_configuration_is_the_references():
+    fix = json.load(open(MCS_FIX))
+    h = _bind(hosttest())
+    m = h.lsnh_mcs_new()
+    out = (C.c_uint32 * 6)()
+    h.lsnh_mcs_get.argtypes = [C.c_void_p, C.c_uint16, C.c_void_p]
+    h.lsnh_mcs_get(m, 0x1234, out)
+    h.lsnh_mcs_free(m)
+    assert list(out) == fix["default_ue_config_of_an_unknown_rnti"]
+    if os.path.exists(MCS_REF_SO):
+        r = _Reference()
+        r.lib.ref_mcs_get_ue_config(r.m, 0x1234, out)
+        r.close()
+        assert list(out) == fix["default_ue_config_of_an_unknown_rnti"]
