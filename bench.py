@@ -674,7 +674,7 @@ def main():
             # `value` = resident, `value_first_h2d_to_last_pdu` = the whole capture from pinned host memory through a FRESH engine (cold RNTI / MCS state, PCIe
             # included), the number to hold against BASELINE's >= 50 x real time
             "value_first_h2d_to_last_pdu": (legs or {}).get("host_pinned", {}).get("pass1_cold", {}).get("subframes_per_s") if legs else None,
-            "parity_reference": "in-repo CPU oracle, unpinned vs srsRAN", "parity": parity,
+            "parity_reference": "in-repo CPU oracle; its DSP is unpinned vs srsRAN (absent dependency); its search / grant / tracking logic is pinned on the reference's own compiled code (oracle/_ref, CPU suite)", "parity": parity,
             "config": {"workload": "%s: 20 MHz DL (100 PRB, 2 CRS ports, 2 rx), 150 active RNTIs + a fresh RNTI by RAR every 200 subframes, TM2/TM3/TM4 mix up to 256QAM, "
                                    "CFI 3, 8-14 DL + 3-6 UL DCIs per subframe (BASELINE.json configs[2], SURVEY 8d config 3)" % args.config
                        if args.config == "cfg3" and wl_leg is None else (args.workload + ": " + wl_leg["what"] if wl_leg else args.config),
