@@ -243,5 +243,22 @@ uint32_t ref_search_validate_location(uint32_t nof_cce, uint32_t ncce, uint32_t 
 {
   return srsran_pdcch_validate_location(nof_cce, ncce, l, nsubframe, rnti);
 }
+/* the two search-space enumerations written in this file against the reference's own statement of them: srsran_pdcch_ue_locations_check
+ * (falcon_pdcch.c:49-103) answers whether a first CCE belongs to the UE-specific or the common search space of an RNTI in a subframe */
+uint32_t ref_search_locations_check(uint32_t nof_cce, uint32_t nsubframe, uint16_t rnti, uint32_t ncce)
+{
+  srsran_pdcch_t q;
+  memset(&q, 0, sizeof(q));
+  q.nof_cce[0] = nof_cce;
+  return srsran_pdcch_ue_locations_check(&q, nsubframe, 1, rnti, ncce);
+}
+uint32_t ref_search_glue_locations(uint32_t nof_cce, uint32_t nsubframe, uint16_t rnti, uint32_t* out2 /* (L, ncce) pairs, room for 22 */)
+{
+  srsran_dci_location_t loc[22];
+  uint32_t n = srsran_pdcch_ue_locations_ncce(nof_cce, loc, 22, nsubframe, rnti);
+  n += srsran_pdcch_common_locations_ncce(nof_cce, &loc[n], 22 - n);
+  for (uint32_t i = 0; i < n; i++) { out2[2 * i] = loc[i].L; out2[2 * i + 1] = loc[i].ncce; }
+  return n;
+}
 
 } /* extern "C" */

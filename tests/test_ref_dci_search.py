@@ -141,6 +141,30 @@ def test_search_space_validation_of_the_reference_and_the_oracle_agree_everywher
     assert n > 40000
 
 
+@pytest.mark.skipif(not HAVE_LIB, reason="oracle/_ref/libref_falcon_search.so not built")
+def test_the_glues_search_space_enumerations_are_the_ones_the_reference_states():
+    """search_glue.cc writes srsRAN's two enumerations of TS 36.213 9.1.1 (absent dependency).  The reference states the same sets itself, as a membership test
+    (srsran_pdcch_ue_locations_check, falcon_pdcch.c:49-103): a first CCE passes it exactly when the glue's lists hold a candidate that starts there."""
+    import ctypes as C
+    lib = C.CDLL(R.REF_SO)
+    lib.ref_search_locations_check.restype = C.c_uint32
+    lib.ref_search_locations_check.argtypes = [C.c_uint32, C.c_uint32, C.c_uint16, C.c_uint32]
+    lib.ref_search_glue_locations.restype = C.c_uint32
+    lib.ref_search_glue_locations.argtypes = [C.c_uint32, C.c_uint32, C.c_uint16, C.c_void_p]
+    buf = (C.c_uint32 * 44)()
+    n = 0
+    for nof_cce in (1, 2, 5, 8, 12, 21, 27, 41, 55, 84, 87):
+        for sf in range(10):
+            for rnti in (0x000B, 0x0100, 0x1234, 0x2AF1, 0x4F21, 0x8000, 0xC35A, 0xFFF3):
+                k = lib.ref_search_glue_locations(nof_cce, sf, rnti, buf)
+                starts = {buf[2 * i + 1] for i in range(k)}
+                assert all(buf[2 * i + 1] + (1 << buf[2 * i]) <= nof_cce for i in range(k))
+                for ncce in range(nof_cce + 2):
+                    assert bool(lib.ref_search_locations_check(nof_cce, sf, rnti, ncce)) == (ncce in starts), (nof_cce, sf, hex(rnti), ncce)
+                    n += 1
+    assert n > 25000
+
+
 def test_fixture_was_made_from_the_reference_sources_that_are_here():
     if not os.path.isdir("/root/reference/src/src"):
         pytest.skip("no /root/reference on this host")
