@@ -44,12 +44,14 @@ def main():
         print("%-36s %5d subframes, %6d accepted DCI, oracle == reference: %s (%.0f s)" % (name, nsf, f["accepted"], o["digest"] == f["digest"], time.time() - t), flush=True)
         if a.long:
             t = time.time()
-            r = R.walk(case, nsf=nsf_long, with_reference=True)
+            prod = 10 ** 6 if okw.get("enable_shortcut", 1) else 0   # the product's host-test glue has no switch for shortcut discovery
+            r = R.walk(case, nsf=nsf_long, with_reference=True, product_subframes=prod)
             f, o = r["reference"], r["oracle"]
-            c["long_run"] = dict(subframes=nsf_long, searched=r["searched"], llr_sha256=r["llr_sha256"], reference_digest=f["digest"], oracle_digest=o["digest"],
+            c["long_run"] = dict(product_host_search_equal=(r["product"]["per_sf"] == f["per_sf"]) if prod else None,
+                                 subframes=nsf_long, searched=r["searched"], llr_sha256=r["llr_sha256"], reference_digest=f["digest"], oracle_digest=o["digest"],
                                  equal=o["digest"] == f["digest"], accepted=f["accepted"], reference_stats=f["stats"], oracle_stats=o["stats"],
                                  activation_reasons=f["reasons"], accepted_by_format_level_dci0_of_rar_rntis=f["probes"], first_difference=R.first_difference(o["per_sf"], f["per_sf"]))
-            print("%-36s %5d subframes, %6d accepted DCI, oracle == reference: %s (%.0f s)" % ("  long run", nsf_long, f["accepted"], o["digest"] == f["digest"], time.time() - t), flush=True)
+            print("%-36s %5d subframes, %6d accepted DCI, oracle == reference: %s, product == reference: %s (%.0f s)" % ("  long run", nsf_long, f["accepted"], o["digest"] == f["digest"], c["long_run"]["product_host_search_equal"], time.time() - t), flush=True)
         elif name in old["cases"] and "long_run" in old["cases"][name]:
             c["long_run"] = old["cases"][name]["long_run"]
         out["cases"][name] = c

@@ -3,6 +3,7 @@
 #include "../../ltesniffer_amd/csrc/host/lsn_search.h"
 #include "../../ltesniffer_amd/csrc/kernels/lsn_rm.h"
 #include <chrono>
+#include <cmath>
 #include <cstring>
 
 using namespace lsn;
@@ -276,6 +277,48 @@ void lsnh_mcs_get(void* m, uint16_t rnti, uint32_t* out)
   const UeSpecConfig c = ((MCSTracking*)m)->get_ue_config_rnti(rnti);
   std::memcpy(&out[0], &c.p_a, 4);
   out[1] = c.i_offset_ack; out[2] = c.i_offset_cqi; out[3] = c.i_offset_ri; out[4] = c.cqi_type; out[5] = c.has_ue_config;
+}
+
+// tests/lsn_testlib.py: candidate_table() in C (the Python loops are the definition; tests/test_ref_dci_search.py checks that both build the same tables): what
+// k_viterbi + k_cce_power produce for one subframe, computed with the ORACLE's candidate decoder and search-space check, handed in as function pointers
+typedef uint16_t (*lsnh_decode_fn)(const float* llr, int E, int nof_bits, uint8_t* payload);
+typedef uint32_t (*lsnh_validate_fn)(uint32_t nof_cce, uint32_t ncce, uint32_t l, uint32_t nsubframe, uint16_t rnti);
+void lsnh_candidate_table(const float* llr, uint32_t nof_cce, const uint32_t* sizes, uint32_t nsizes, uint32_t sf_idx, void* decode_fn, void* validate_fn,
+                          LsnCand* cand /* [160 * 8], zeroed here */, float* pw /* [96], zeroed here */)
+{
+  const lsnh_decode_fn decode = (lsnh_decode_fn)decode_fn;
+  const lsnh_validate_fn validate = (lsnh_validate_fn)validate_fn;
+  std::memset(cand, 0, sizeof(LsnCand) * 160 * 8);
+  std::memset(pw, 0, sizeof(float) * 96);
+  for (uint32_t c = 0; c < nof_cce; c++) {
+    double m = 0.0;
+    for (int i = 0; i < 72; i++) m += std::fabs((double)llr[72 * c + i]);
+    pw[c] = (float)(m / 72);
+  }
+  const uint32_t lim = nof_cce < 84 ? nof_cce : 84;
+  uint32_t li = 0;
+  uint8_t payload[256];
+  for (int l = 3; l >= 0; l--) {
+    const uint32_t L = 1u << l;
+    for (uint32_t i = 0; i < lim / L; i++, li++) {
+      const uint32_t ncce = L * (i % (nof_cce / L)), E = 72 * L;
+      bool ok = ncce * 72 + E <= nof_cce * 72;
+      for (uint32_t q = 0; ok && q < L; q++) ok = pw[ncce + q] >= 0.7f;
+      if (ok) {
+        bool any = false;
+        for (uint32_t k = 0; k < E && !any; k++) any = llr[ncce * 72 + k] != 0.f;
+        ok = any;
+      }
+      if (!ok) continue;
+      for (uint32_t si = 0; si < nsizes; si++) {
+        const uint16_t rnti = decode(llr + ncce * 72, (int)E, (int)sizes[si], payload);
+        unsigned long long bits = 0;
+        for (uint32_t b = 0; b < sizes[si]; b++) bits |= (unsigned long long)payload[b] << (63 - b);
+        LsnCand& e = cand[li * 8 + si];
+        e.bits = bits; e.rnti = rnti; e.flags = 1u | (validate(nof_cce, ncce, (uint32_t)l, sf_idx, rnti) << 1);
+      }
+    }
+  }
 }
 
 // the product's downlink HARQ database on its own (tests/test_ref_harq.py: random grant sequences against the REFERENCE's HARQ.cc, oracle/_ref)

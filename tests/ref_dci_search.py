@@ -20,7 +20,7 @@ REF_SOURCES = ["src/src/DCISearch.cc", "lib/src/phy/falcon_phch/falcon_pdcch.c",
 
 # the streams: (name, scenario, subframes in the suite, subframes of the long run recorded in the fixture, meta-format period, worker options)
 CASES = [
-    ("cfg3_100prb_150rnti_rar", dict(name="cfg3", seed=3), 300, 6000, 500, {}),
+    ("cfg3_100prb_150rnti_rar", dict(name="cfg3", seed=3), 300, 20000, 500, {}),   # long run = the whole distinct capture of the gated bench stream (tools/make_cfg3_golden.py)
     ("cfg2_100prb_32rnti", dict(name="cfg2", seed=2), 150, 2000, 500, {}),
     ("cfg3_threshold_8_split_0.8", dict(name="cfg3", seed=5), 200, 1500, 200, dict(threshold=8, split_ratio=0.8)),
     ("cfg3_skip_secondary_no_shortcut", dict(name="cfg3", seed=6), 150, 1000, 100, dict(skip_secondary=1, enable_shortcut=0, split_ratio=0.6)),
@@ -29,7 +29,7 @@ CASES = [
     ("cfg1_50prb_low_snr_gate", dict(name="cfg1", seed=9, snr_db=4.0), 200, 1000, 100, {}),
     ("cfg3_15prb_cfi_small_region", dict(name="cfg3", seed=10, nof_prb=15, n_rnti=12, dl_min=1, dl_max=3, ul_min=0, ul_max=2, rar_period=40), 500, 4000, 100, {}),
 ]
-PRODUCT_SUBFRAMES = {100: 40, 50: 80, 25: 150, 15: 200}  # subframes of the product's host search per case (its candidate tables are decoded in Python loops)
+PRODUCT_SUBFRAMES = {100: 10 ** 6, 50: 10 ** 6, 25: 10 ** 6, 15: 10 ** 6}  # the product's host search walks every stream to its end (candidate tables built in C)
 
 
 def rar_temp_crntis(pdu):
@@ -143,9 +143,21 @@ class ProductSearch:
         self.hs = self.h.lsnh_search_new(sc["nof_prb"], sc["nof_ports"], sc["cell_id"], self.regs_cce, threshold, split_ratio, skip_secondary)
         self.sizes = [self.h.lsnh_search_size(self.hs, k) for k in range(self.h.lsnh_search_nof_sizes(self.hs))]
 
+    def table(self, llr, cfi, tti):
+        """lsn_testlib.candidate_table() through its C twin in the host-test glue (tests/native/lsn_hosttest.cc: lsnh_candidate_table) -> (cand, ccepow)"""
+        from lsn_testlib import CCE_STRIDE, MAX_LOC, MAX_SIZES, LsnCand
+        o = oracle()
+        cand = (LsnCand * (MAX_LOC * MAX_SIZES))()
+        pw = np.zeros(CCE_STRIDE, dtype=np.float32)
+        llr = np.ascontiguousarray(llr, dtype=np.float32)
+        sizes = (C.c_uint32 * len(self.sizes))(*self.sizes)
+        self.h.lsnh_candidate_table.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        self.h.lsnh_candidate_table(llr.ctypes.data, self.regs_cce[cfi - 1], sizes, len(self.sizes), tti % 10, C.cast(o.o_dci_decode, C.c_void_p),
+                                    C.cast(o.o_validate_location, C.c_void_p), cand, pw.ctypes.data)
+        return cand, pw
+
     def subframe(self, llr, cfi, tti, snr_db, update_meta):
-        from lsn_testlib import candidate_table
-        cand, pw = candidate_table(llr, self.regs_cce[cfi - 1], self.sizes, tti % 10)
+        cand, pw = self.table(llr, cfi, tti)
         out = (C.c_uint32 * (64 * 6))()
         n = self.h.lsnh_search_run(self.hs, tti, cfi, float(snr_db), cand, pw.ctypes.data, int(update_meta), out, 64 * 6)
         if not snr_db > 6.0:

@@ -59,6 +59,7 @@ def test_fixture_covers_the_cases_and_was_equal_when_made():
         assert (f["scenario"], f["subframes"], f["meta_period"], f["worker"]) == (c[1], c[2], c[4], c[5]), "the case list changed: run the generator again"
         assert f["oracle_equal_when_made"] and len(f["reference"]["per_subframe"]) == f["subframes"]
         assert f["long_run"]["equal"] and f["long_run"]["subframes"] == c[3] and f["long_run"]["first_difference"] is None
+        assert f["long_run"]["product_host_search_equal"] is (True if c[5].get("enable_shortcut", 1) else None)
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
@@ -79,6 +80,23 @@ def test_product_host_search_decides_like_the_reference(name):
     n = _prefix(CASES[name])
     assert len(r["product"]["per_sf"]) == min(n, r["subframes"])
     _against_fixture(name, "the product's FalconSearch", r["product"]["per_sf"], n)
+
+
+def test_candidate_tables_built_in_c_are_the_python_ones():
+    """the product's search is fed with candidate tables built by lsnh_candidate_table (C, fast enough for whole streams); lsn_testlib.candidate_table (Python
+    loops, used by tests/test_host_logic.py) is the definition: same entries, same CCE powers"""
+    from lsn_testlib import OracleWorker, candidate_table
+    case = CASES["cfg3_50prb_four_ports"]
+    sc, tti0, iq = R.case_capture(case, 6)
+    ow = OracleWorker(sc["nof_prb"], sc["nof_ports"], sc["cell_id"], sc["nof_rx"], sc["phich_ng_x6"])
+    p = R.ProductSearch(sc)
+    for i in range(6):
+        ow.work(iq[i], tti0 + i)
+        c1, w1 = p.table(ow.llr(), ow.cfi(), tti0 + i)
+        c2, w2 = candidate_table(ow.llr(), p.regs_cce[ow.cfi() - 1], p.sizes, (tti0 + i) % 10)
+        assert bytes(c1) == bytes(c2) and w1.tobytes() == w2.tobytes()
+        assert sum(1 for e in c1 if e.flags & 1) > 100
+    p.close()
 
 
 def test_the_streams_walk_through_the_tree():
