@@ -3,7 +3,7 @@ tree), lib/src/phy/falcon_phch/falcon_pdcch.c (location map, CCE power, search-s
 lib/src/util/RNTIManager.cc are compiled verbatim into oracle/_ref/libref_falcon_search.so (oracle/Makefile.ref; srsRAN - an absent dependency - is
 replaced by type declarations under oracle/ref_shim_search/ and by the oracle's own two DSP primitives, see search_glue.cc) and run subframe by
 subframe on the oracle's PDCCH soft bits.  What the reference decided on eight streams is committed (tests/golden/dci_search_ref.json, made by
-tests/golden/make_dci_search_fixture.py, which also records long runs of up to 6 000 subframes): per subframe the accepted DCI - RNTI, format,
+tests/golden/make_dci_search_fixture.py, which also records long runs of up to 20 000 subframes - the whole capture of the gated bench stream): per subframe the accepted DCI - RNTI, format,
 aggregation level, first CCE, size, histogram value, in the order DCICollection::addCandidate receives them - plus the search statistics, the final
 primary / secondary format split and the activation reasons in the RNTI manager.  The oracle's restatement (o_worker.c: blind_search / inspect) and the
 product's host search (lsn_search.cc: FalconSearch, fed with candidate tables as k_viterbi produces them) must decide the same, subframe by subframe.
@@ -119,7 +119,7 @@ def test_the_streams_walk_through_the_tree():
     for n in c:
         lr = c[n]["long_run"]
         assert lr["accepted"] > lr["subframes"] and lr["reference_stats"][:4] == lr["oracle_stats"][:4]
-    assert sum(c[n]["long_run"]["subframes"] for n in c) >= 20000 and sum(c[n]["long_run"]["accepted"] for n in c) >= 150000
+    assert sum(c[n]["long_run"]["subframes"] for n in c) >= 35000 and sum(c[n]["long_run"]["accepted"] for n in c) >= 380000
     assert sum(c[n]["long_run"]["accepted_by_format_level_dci0_of_rar_rntis"]["dci0_of_rar_rntis"] for n in c) >= 5000
 
 
