@@ -20,9 +20,9 @@ REF_SOURCES = ["src/src/DCISearch.cc", "lib/src/phy/falcon_phch/falcon_pdcch.c",
 
 # the streams: (name, scenario, subframes in the suite, subframes of the long run recorded in the fixture, meta-format period, worker options)
 CASES = [
-    ("cfg3_100prb_150rnti_rar", dict(name="cfg3", seed=3), 300, 20000, 500, {}),   # long run = the whole distinct capture of the gated bench stream (tools/make_cfg3_golden.py)
+    ("cfg3_100prb_150rnti_rar", dict(name="cfg3", seed=3), 200, 20000, 500, {}),   # long run = the whole distinct capture of the gated bench stream (tools/make_cfg3_golden.py)
     ("cfg2_100prb_32rnti", dict(name="cfg2", seed=2), 150, 2000, 500, {}),
-    ("cfg3_threshold_8_split_0.8", dict(name="cfg3", seed=5), 200, 1500, 200, dict(threshold=8, split_ratio=0.8)),
+    ("cfg3_threshold_8_split_0.8", dict(name="cfg3", seed=5), 120, 1500, 200, dict(threshold=8, split_ratio=0.8)),
     ("cfg3_skip_secondary_no_shortcut", dict(name="cfg3", seed=6), 150, 1000, 100, dict(skip_secondary=1, enable_shortcut=0, split_ratio=0.6)),
     ("small_25prb_16dB", dict(name="small", seed=7, snr_db=16.0, rar_period=50), 400, 4000, 100, {}),
     ("cfg3_50prb_four_ports", dict(name="cfg3", seed=8, nof_prb=50, nof_ports=4, n_rnti=40, dl_min=3, dl_max=6, ul_min=1, ul_max=3), 200, 2000, 100, {}),
