@@ -44,10 +44,10 @@ def main():
         print("%-36s %5d subframes, %6d accepted DCI, oracle == reference: %s (%.0f s)" % (name, nsf, f["accepted"], o["digest"] == f["digest"], time.time() - t), flush=True)
         if a.long:
             t = time.time()
-            prod = 10 ** 6 if okw.get("enable_shortcut", 1) else 0   # the product's host-test glue has no switch for shortcut discovery
+            prod = 10 ** 6
             r = R.walk(case, nsf=nsf_long, with_reference=True, product_subframes=prod)
             f, o = r["reference"], r["oracle"]
-            c["long_run"] = dict(product_host_search_equal=(r["product"]["per_sf"] == f["per_sf"]) if prod else None,
+            c["long_run"] = dict(product_host_search_equal=r["product"]["per_sf"] == f["per_sf"],
                                  subframes=nsf_long, searched=r["searched"], llr_sha256=r["llr_sha256"], reference_digest=f["digest"], oracle_digest=o["digest"],
                                  equal=o["digest"] == f["digest"], accepted=f["accepted"], reference_stats=f["stats"], oracle_stats=o["stats"],
                                  activation_reasons=f["reasons"], accepted_by_format_level_dci0_of_rar_rntis=f["probes"], first_difference=R.first_difference(o["per_sf"], f["per_sf"]))

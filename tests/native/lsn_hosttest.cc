@@ -121,6 +121,7 @@ hsearch* lsnh_search_new(uint32_t nof_prb, uint32_t nof_ports, uint32_t cell_id,
   return h;
 }
 void lsnh_search_free(hsearch* h) { delete h; }
+void lsnh_search_set_shortcut_discovery(hsearch* h, int enable) { h->s->setShortcutDiscovery(enable != 0); }
 int lsnh_search_size_index(hsearch* h, int format) { return h->s->sizeIndexOfFormat(format); }
 uint32_t lsnh_search_nof_sizes(hsearch* h) { return h->s->nofSizes(); }
 uint32_t lsnh_search_size(hsearch* h, uint32_t i) { return h->s->sizes()[i]; }

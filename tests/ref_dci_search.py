@@ -133,7 +133,6 @@ class ProductSearch:
         class Regs(C.Structure):
             _fields_ = [("nof_regs", C.c_uint32 * 3), ("nof_cce", C.c_uint32 * 3), ("k0", (C.c_uint16 * 800) * 3),
                         ("l", (C.c_uint8 * 800) * 3), ("pcfich_k0", C.c_uint16 * 4), ("ngroups_phich", C.c_uint32)]
-        assert enable_shortcut == 1, "the host-test glue has no switch for shortcut discovery"
         self.h = hosttest()
         regs = Regs()
         cell = OCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"], sc["phich_ng_x6"], 0, sc.get("cp", 0))
@@ -142,6 +141,8 @@ class ProductSearch:
         self.regs_cce = (C.c_uint32 * 3)(*regs.nof_cce)
         self.hs = self.h.lsnh_search_new(sc["nof_prb"], sc["nof_ports"], sc["cell_id"], self.regs_cce, threshold, split_ratio, skip_secondary)
         self.sizes = [self.h.lsnh_search_size(self.hs, k) for k in range(self.h.lsnh_search_nof_sizes(self.hs))]
+        self.h.lsnh_search_set_shortcut_discovery.argtypes = [C.c_void_p, C.c_int]
+        self.h.lsnh_search_set_shortcut_discovery(self.hs, int(enable_shortcut))
 
     def table(self, llr, cfi, tti):
         """lsn_testlib.candidate_table() through its C twin in the host-test glue (tests/native/lsn_hosttest.cc: lsnh_candidate_table) -> (cand, ccepow)"""

@@ -26,8 +26,6 @@ _walks = {}
 
 def _prefix(case):
     name, sc_kw, nsf, nsf_long, meta, okw = case
-    if not okw.get("enable_shortcut", 1):
-        return 0   # the host-test glue of the product has no switch for shortcut discovery
     kw = dict(sc_kw)
     return R.PRODUCT_SUBFRAMES[R.scenario(kw.pop("name"), **kw)["nof_prb"]]
 
@@ -59,7 +57,7 @@ def test_fixture_covers_the_cases_and_was_equal_when_made():
         assert (f["scenario"], f["subframes"], f["meta_period"], f["worker"]) == (c[1], c[2], c[4], c[5]), "the case list changed: run the generator again"
         assert f["oracle_equal_when_made"] and len(f["reference"]["per_subframe"]) == f["subframes"]
         assert f["long_run"]["equal"] and f["long_run"]["subframes"] == c[3] and f["long_run"]["first_difference"] is None
-        assert f["long_run"]["product_host_search_equal"] is (True if c[5].get("enable_shortcut", 1) else None)
+        assert f["long_run"]["product_host_search_equal"] is True
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
