@@ -93,7 +93,6 @@ typedef struct { uint32_t rbg_bitmask; } srsran_ra_type0_t;
 typedef struct { uint32_t vrb_bitmask, rbg_subset; bool shift; } srsran_ra_type1_t;
 typedef struct { uint32_t riv; int n_prb1a, n_gap, mode; } srsran_ra_type2_t;
 typedef struct { srsran_mod_t mod; int tbs, rv; uint32_t nof_bits, cw_idx; bool enabled; uint32_t mcs_idx; } srsran_ra_tb_t;
-typedef struct { int _; } srsran_dci_dl_t_body;
 typedef struct {
   uint16_t rnti; srsran_dci_format_t format; srsran_dci_location_t location; uint32_t ue_cc_idx;
   srsran_ra_type_t alloc_type; srsran_ra_type0_t type0_alloc; srsran_ra_type1_t type1_alloc; srsran_ra_type2_t type2_alloc;
@@ -156,7 +155,6 @@ int srsran_viterbi_decode_f(srsran_viterbi_t* q, float* symbols, uint8_t* data, 
 uint32_t srsran_crc_checksum(srsran_crc_t* h, uint8_t* data, int len);
 uint32_t srsran_bit_pack(uint8_t** bits, int nof_bits);
 void srsran_bit_fprint(FILE* stream, uint8_t* bits, int nof_bits);
-float srsran_vec_avg_power_cf(const cf_t* x, const uint32_t len);
 int srsran_softbuffer_rx_init(srsran_softbuffer_rx_t* q, uint32_t nof_prb);
 void srsran_softbuffer_rx_free(srsran_softbuffer_rx_t* q);
 void srsran_softbuffer_rx_reset(srsran_softbuffer_rx_t* q);
