@@ -51,6 +51,10 @@ def main():
                                  subframes=nsf_long, searched=r["searched"], llr_sha256=r["llr_sha256"], reference_digest=f["digest"], oracle_digest=o["digest"],
                                  equal=o["digest"] == f["digest"], accepted=f["accepted"], reference_stats=f["stats"], oracle_stats=o["stats"],
                                  activation_reasons=f["reasons"], accepted_by_format_level_dci0_of_rar_rntis=f["probes"], first_difference=R.first_difference(o["per_sf"], f["per_sf"]))
+            if name == "cfg3_100prb_150rnti_rar":   # the same bytes as the gated bench stream's capture (tests/golden/cfg3_stream_oracle.json)
+                sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(HERE)), "tools"))
+                from make_cfg3_golden import capture_hash
+                c["long_run"]["capture_xxh3_64"] = capture_hash(R.case_capture(case, nsf_long)[2])[0]
             print("%-36s %5d subframes, %6d accepted DCI, oracle == reference: %s, product == reference: %s (%.0f s)" % ("  long run", nsf_long, f["accepted"], o["digest"] == f["digest"], c["long_run"]["product_host_search_equal"], time.time() - t), flush=True)
         elif name in old["cases"] and "long_run" in old["cases"][name]:
             c["long_run"] = old["cases"][name]["long_run"]

@@ -80,6 +80,14 @@ def test_product_host_search_decides_like_the_reference(name):
     _against_fixture(name, "the product's FalconSearch", r["product"]["per_sf"], n)
 
 
+def test_the_longest_run_is_the_capture_of_the_gated_bench_stream():
+    """cfg3, seed 3, 20 000 subframes: the bytes the reference's search, the oracle and the product's host search walked in the long run are the bytes bench.py replays"""
+    lr = FIX["cases"]["cfg3_100prb_150rnti_rar"]["long_run"]
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg3_stream_oracle.json")))
+    assert lr["capture_xxh3_64"] == g["capture_xxh3_64"] and lr["subframes"] == g["stream"]["distinct_subframes"] == 20000
+    assert lr["equal"] and lr["product_host_search_equal"] and lr["accepted"] > 300000
+
+
 def test_candidate_tables_built_in_c_are_the_python_ones():
     """the product's search is fed with candidate tables built by lsnh_candidate_table (C, fast enough for whole streams); lsn_testlib.candidate_table (Python
     loops, used by tests/test_host_logic.py) is the definition: same entries, same CCE powers"""
