@@ -25,6 +25,7 @@ OUT = os.path.join(HERE, "dci_search_ref.json")
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--long", action="store_true")
+    ap.add_argument("--long-missing", action="store_true", help="long runs only of the cases the present fixture has none for")
     a = ap.parse_args()
     old = json.load(open(OUT)) if os.path.exists(OUT) else {"cases": {}}
     out = {"made_by": "tests/golden/make_dci_search_fixture.py", "reference_sources": R.REF_SOURCES, "reference_sources_sha256": R.reference_sources_sha256(),
@@ -42,7 +43,7 @@ def main():
                                 accepted_by_format_level_dci0_of_rar_rntis=f["probes"], first_subframes=[x for x in f["per_sf"][:6]]),
                  oracle_equal_when_made=o["digest"] == f["digest"])
         print("%-36s %5d subframes, %6d accepted DCI, oracle == reference: %s (%.0f s)" % (name, nsf, f["accepted"], o["digest"] == f["digest"], time.time() - t), flush=True)
-        if a.long:
+        if a.long or (a.long_missing and "long_run" not in old["cases"].get(name, {})):
             t = time.time()
             prod = 10 ** 6
             r = R.walk(case, nsf=nsf_long, with_reference=True, product_subframes=prod)

@@ -28,8 +28,10 @@ CASES = [
     ("cfg3_50prb_four_ports", dict(name="cfg3", seed=8, nof_prb=50, nof_ports=4, n_rnti=40, dl_min=3, dl_max=6, ul_min=1, ul_max=3), 200, 2000, 100, {}),
     ("cfg1_50prb_low_snr_gate", dict(name="cfg1", seed=9, snr_db=4.0), 200, 1000, 100, {}),
     ("cfg3_15prb_cfi_small_region", dict(name="cfg3", seed=10, nof_prb=15, n_rnti=12, dl_min=1, dl_max=3, ul_min=0, ul_max=2, rar_period=40), 500, 4000, 100, {}),
+    ("small_6prb_cfi_varies", dict(name="small", seed=31, nof_prb=6, n_rnti=3, dl_min=1, dl_max=1, ul_min=0, ul_max=1, cfi=0, rar_period=30), 600, 4000, 100, {}),
+    ("cfg3_75prb_cfi_varies", dict(name="cfg3", seed=32, nof_prb=75, n_rnti=60, dl_min=4, dl_max=8, ul_min=1, ul_max=4, cfi=0, rar_period=100), 120, 1500, 100, {}),
 ]
-PRODUCT_SUBFRAMES = {100: 10 ** 6, 50: 10 ** 6, 25: 10 ** 6, 15: 10 ** 6}  # the product's host search walks every stream to its end (candidate tables built in C)
+PRODUCT_SUBFRAMES = {100: 10 ** 6, 75: 10 ** 6, 50: 10 ** 6, 25: 10 ** 6, 15: 10 ** 6, 6: 10 ** 6}  # the product's host search walks every stream to its end (candidate tables built in C)
 
 
 def rar_temp_crntis(pdu):

@@ -2,7 +2,7 @@
 tree), lib/src/phy/falcon_phch/falcon_pdcch.c (location map, CCE power, search-space validation, missed CCEs), src/src/MetaFormats.cc and
 lib/src/util/RNTIManager.cc are compiled verbatim into oracle/_ref/libref_falcon_search.so (oracle/Makefile.ref; srsRAN - an absent dependency - is
 replaced by type declarations under oracle/ref_shim_search/ and by the oracle's own two DSP primitives, see search_glue.cc) and run subframe by
-subframe on the oracle's PDCCH soft bits.  What the reference decided on eight streams is committed (tests/golden/dci_search_ref.json, made by
+subframe on the oracle's PDCCH soft bits.  What the reference decided on ten streams is committed (tests/golden/dci_search_ref.json, made by
 tests/golden/make_dci_search_fixture.py, which also records long runs of up to 20 000 subframes - the whole capture of the gated bench stream): per subframe the accepted DCI - RNTI, format,
 aggregation level, first CCE, size, histogram value, in the order DCICollection::addCandidate receives them - plus the search statistics, the final
 primary / secondary format split and the activation reasons in the RNTI manager.  The oracle's restatement (o_worker.c: blind_search / inspect) and the
