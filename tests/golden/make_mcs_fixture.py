@@ -27,6 +27,10 @@ def main():
     r.lib.ref_mcs_get_ue_config(r.m, 0x1234, buf)
     r.close()
     out["default_ue_config_of_an_unknown_rnti"] = list(buf)
+    r = T._Reference()
+    out["corner_script"] = T.corners(r)
+    r.close()
+    print("corner script", out["corner_script"])
     json.dump(out, open(os.path.join(HERE, "mcs_tracking_ref.json"), "w"), indent=1)
 
 

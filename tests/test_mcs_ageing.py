@@ -293,6 +293,55 @@ def life(seed, b, steps=40000):
     return h.hexdigest()[:32], dict(ageing_passes=passes, entries_aged_out=aged, full_buffer_answers=full, rar=after_rar, population_at_the_end=b.count())
 
 
+def corners(b):
+    """a scripted life for what random lives hit too rarely: a success rate of EXACTLY 15 % (kept: the reference drops a table below 15 %), a success flag on a
+    disabled transport block (counted by the reference), exactly rar_thresold messages behind a RAR (not enough), an entry idle for exactly the interval"""
+    out = []
+    b.set_now(10)
+    for r in (500, 501, 502, 503):
+        out.append(b.find(r))
+    b.update(500, T256); b.update(500, T256)            # first call creates the entry (unknown), second sets the table
+    for i in range(20):                                   # 20 decodes, 3 good: 15 %
+        b.stat(500, 7, T256, (1, 0), (1 if i < 3 else 0, 0), 0)
+    b.update(501, T64); b.update(501, T64)
+    for i in range(20):                                   # 20 decodes, 2 good on the enabled block + 1 success flag on the disabled one: 15 % only if that one counts
+        b.stat(501, 7, T64, (1, 0), (1 if i < 2 else 0, 1 if i == 5 else 0), 0)
+    b.update(502, T64); b.update(502, T64)
+    for i in range(20):                                   # 10 %: dropped
+        b.stat(502, 7, T64, (1, 0), (1 if i < 2 else 0, 0), 0)
+    b.rar(503)
+    for i in range(3):                                    # exactly rar_thresold = 3 messages above format 1A behind the RAR
+        b.stat(503, 7, TUNK, (1, 0), (1, 0), 0)
+    b.update(503, T256)
+    out += [b.peek(r) for r in (500, 501, 502, 503)]
+    b.stat(503, 7, TUNK, (1, 0), (1, 0), 0)              # the fourth
+    b.update(503, T256)
+    out.append(b.peek(503))
+    b.set_now(2000)
+    b.update_database()
+    out += [b.count()] + [b.peek(r) for r in (500, 501, 502, 503)]
+    out += [b.find(r) for r in (500, 501, 502, 503)]      # look-ups refresh the entries' time: 2000
+    b.set_now(3000)
+    out.append(b.find(500))                               # 500 once more, a second later
+    b.set_now(2000 + 5999)
+    b.update_database()                                   # idle for 5.999 s: 5 whole seconds, not more than the interval - all stay
+    out += [b.count()]
+    b.set_now(2000 + 6000)
+    b.update_database()                                   # 6 whole seconds: gone, except 500 (idle for exactly 5)
+    out += [b.count()] + [b.peek(r) for r in (500, 501, 502, 503)]
+    return out
+
+
+def test_product_database_corner_script_is_the_references():
+    fix = json.load(open(MCS_FIX))
+    for cls in (_Product, _Model) + ((_Reference,) if os.path.exists(MCS_REF_SO) else ()):
+        b = cls()
+        try:
+            assert corners(b) == fix["corner_script"], cls.name
+        finally:
+            b.close()
+
+
 def _life_on(cls, seed):
     b = cls()
     try:

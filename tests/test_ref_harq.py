@@ -122,6 +122,52 @@ def life(seed, b, steps=30000):
     return h.hexdigest()[:32], count
 
 
+def corners(b):
+    """a scripted life for what the random ones hit too rarely: the ageing pass that only runs when at most 10 of the 150 counted entities are free
+    (updateHARQDatabase, HARQ.cc:206-238), on both sides of that limit, and a retransmission that arrives one whole TTI period + 8 subframes late
+    (10 248 ms: the reference compares TTIs modulo 10 240 and still calls it a retransmission)"""
+    out = []
+    tti0 = 100
+    for k in range(139):                                   # 139 UEs: 11 of the 150 counted entities stay free
+        t = k
+        b.set_now(t)
+        tti = (tti0 + t) % 10240
+        out.append(b.ask(1000 + k, 0, 0, 0, 0, 1000, tti // 10, tti % 10))
+        b.update(1000 + k, 0, 0, tti // 10, tti % 10, 0, 0, 0, 1000)
+    t = 10248
+    b.set_now(t)
+    tti = (tti0 + t) % 10240                               # = tti0 + 8
+    b.age()                                                # 11 free: the pass does nothing, although every entity has been idle for 10 s
+    out.append(b.ask(1000, 0, 0, 0, 2, 1000, tti // 10, tti % 10))   # UE 1000 again, same NDI and size, "8 subframes" later: a retransmission
+    b.update(1000, 0, 0, tti // 10, tti % 10, 1, 0, 2, 1000)           # ... which decodes
+    tti2 = (tti + 8) % 10240
+    b.set_now(t + 8)
+    out.append(b.ask(1000, 0, 0, 0, 3, 1000, tti2 // 10, tti2 % 10))  # and again: already decoded
+    out.append(b.ask(2000, 3, 1, 1, 0, 2536, tti2 // 10, tti2 % 10))  # the 140th UE: 10 free
+    b.update(2000, 3, 1, tti2 // 10, tti2 % 10, 0, 1, 0, 2536)
+    b.set_now(t + 8 + 5999)
+    b.age()                                                # now the pass runs: idle for more than 5 whole seconds -> freed (UE 1000 and 2000: 5.999 s, kept)
+    tti3 = (tti2 + 5999) % 10240
+    out.append(b.ask(1001, 0, 0, 0, 0, 1000, tti3 // 10, tti3 % 10))  # a UE of the first group: its entity is gone, a new transmission on a fresh one
+    b.update(1001, 0, 0, tti3 // 10, tti3 % 10, 0, 0, 0, 1000)
+    tti4 = (tti3 + 8) % 10240
+    b.set_now(t + 8 + 5999 + 8)
+    out.append(b.ask(1001, 0, 0, 0, 2, 1000, tti4 // 10, tti4 % 10))  # its retransmission
+    out.append(b.ask(2000, 3, 1, 1, 2, 2536, tti4 // 10, tti4 % 10))  # UE 2000 survived the pass; 6007 subframes later is no retransmission
+    return out
+
+
+def test_product_harq_corner_script_is_the_references():
+    want = json.load(open(FIX))["corner_script"]
+    assert want[:139] == [NEW_TX] * 139 and want[139:] == [RE_TX, DECODED, NEW_TX, NEW_TX, RE_TX, NEW_TX]
+    for cls in (Product,) + ((Reference,) if os.path.exists(REF_SO) else ()):
+        b = cls()
+        try:
+            assert corners(b) == want, cls.__name__
+        finally:
+            b.close()
+
+
 def _life_on(cls, seed):
     b = cls()
     try:
@@ -172,4 +218,8 @@ if __name__ == "__main__":   # the fixture generator
         p = _life_on(Product, seed)
         out["lives"][str(seed)] = {"digest": d, "verdicts_new_retx_full_decoded_busy": c, "product_equal_when_made": p == (d, c)}
         print(seed, d, c, p == (d, c))
+    r = Reference()
+    out["corner_script"] = corners(r)
+    r.close()
+    print("corner script", out["corner_script"][139:])
     json.dump(out, open(FIX, "w"), indent=1)
