@@ -1085,11 +1085,7 @@ void Engine::commitChunk(Chunk& ch, JobRunner& r)
     tables.resize(k1 - k0);
     for (uint32_t k = k0; k < k1; k++) {
       const CommitDci& d = ch.cdci[k];
-      if (cfg.mcs_tracking_mode == 1)
-        tables[k - k0] = (d.rnti == SIRNTI || d.rnti == PRNTI || rnti_israr(d.rnti) || d.format == FORMAT1A) ? TABLE_64QAM
-                                                                                                           : mcs_tracking.find_tracking_info_RNTI_dl(d.rnti, now);
-      else
-        tables[k - k0] = cfg.mcs_tracking_mode == 2 ? TABLE_UNKNOWN : TABLE_64QAM;
+      tables[k - k0] = collection_table(cfg.mcs_tracking_mode, d.rnti, (DciFormat)d.format, mcs_tracking, now);
     }
     // addCandidate looks the table up for EVERY accepted DCI, format 0 included: an uplink grant refreshes the entry's time stamp too
     if (cfg.mcs_tracking_mode == 1)
@@ -1099,9 +1095,14 @@ void Engine::commitChunk(Chunk& ch, JobRunner& r)
       CommitDci& d = ch.cdci[k];
       const McsTable table = tables[k - k0];
       const bool unpack_ok = d.flags & 1, ok64 = d.flags & 2, ok256 = d.flags & 4;
-      const bool has64 = unpack_ok && (table == TABLE_64QAM || table >= TABLE_UNKNOWN);
-      const bool has256 = unpack_ok && (table == TABLE_256QAM || table >= TABLE_UNKNOWN);
-      const bool dci_rnti_ok = d.rnti > 0 && !(has64 && !ok64) && !(has256 && !ok256);  // falcon_dci.c:286,293,300,305
+      const TableView tv = table_view(table, d.rnti, unpack_ok, ok64, ok256);  // falcon_dci.c:284-310
+      const bool has64 = tv.has64, has256 = tv.has256, dci_rnti_ok = tv.dci_rnti_ok;
+      // DCICollection.cc:236-251: a reserved MCS index of a 64QAM-table grant takes its size from the HARQ database (harq_mode only).  The plan knew no size for
+      // it (0): whatever it decoded for this entry is dropped and the grant is decoded on demand with the size in
+      if (cfg.harq_mode && has64 && collection_last_tbs(true, table, c.dl[d.di], harq_db)) {
+        d.tbs0_64 = c.dl[d.di].grant64.tb[0].tbs;
+        d.job[0] = -1; c.dl[d.di].job[0] = -1;
+      }
       const int cur_t = table == TABLE_256QAM ? 1 : 0;
       const bool cur_has = cur_t ? has256 : has64;
       const int32_t cur_tbs0 = cur_has ? (cur_t ? d.tbs0_256 : d.tbs0_64) : 0;

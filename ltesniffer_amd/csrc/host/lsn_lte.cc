@@ -882,6 +882,14 @@ void HarqDatabase::update(int entity, uint32_t pid, int tid, uint32_t sfn, uint3
   Tb& t = e.tb[pid & 7][tid];
   t.sfn = sfn; t.sf_idx = sf_idx; t.last_decoded = last_decoded; t.ndi = ndi; t.rv = rv; t.tbs = tbs; t.is_first = false;
 }
+int HarqDatabase::getlastTbs(uint16_t rnti, uint32_t pid, int tid) const
+{
+  int tbs = 0;
+  for (const Entity& e : ent)
+    if (e.rnti == rnti) tbs = e.tb[pid & 7u][tid & 1].tbs;
+  return tbs;
+}
+
 void HarqDatabase::update_database(uint32_t now)
 {
   if (nof_aval > 10) return;

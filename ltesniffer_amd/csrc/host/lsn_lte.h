@@ -261,6 +261,7 @@ public:
   // HARQ::updateHARQRNTI / updateProcess (HARQ.cc:155-190)
   void update(int entity, uint32_t pid, int tid, uint32_t sfn, uint32_t sf_idx, bool last_decoded, bool ndi, int rv, int tbs, uint32_t now);
   void update_database(uint32_t now);   // HARQ::updateHARQDatabase (HARQ.cc:206-238), the 10 s timer of LTESniffer_Core.cc:487-494
+  int getlastTbs(uint16_t rnti, uint32_t pid, int tid) const;  // HARQ::getlastTbs (HARQ.cc:262-274): the size the RNTI's (last) entity remembers for (process, block), 0 without entity
   uint64_t stats[5] = {0, 0, 0, 0, 0};  // verdicts so far, by HarqRet
 private:
   struct Tb { uint32_t sfn = 0, sf_idx = 0; bool last_decoded = false, ndi = false, is_first = true; int rv = 0, tbs = 0; };

@@ -138,4 +138,35 @@ private:
 
 const char* rnti_name(uint16_t r);  // DL_Sniffer_PDSCH.cc:1398-1418
 
+// DCICollection::addCandidate, DCICollection.cc:107-134: the MCS table an accepted DCI is collected under (the tracking database is asked for every user
+// RNTI that does not come in format 1A - the look-up refreshes the entry's time stamp)
+inline McsTable collection_table(int mcs_tracking_mode, uint16_t rnti, DciFormat format, MCSTracking& mcs_tracking, uint32_t now)
+{
+  if (mcs_tracking_mode == 1)
+    return (rnti == SIRNTI || rnti == PRNTI || rnti_israr(rnti) || format == FORMAT1A) ? TABLE_64QAM : mcs_tracking.find_tracking_info_RNTI_dl(rnti, now);
+  return mcs_tracking_mode == 2 ? TABLE_UNKNOWN : TABLE_64QAM;
+}
+// srsran_dci_msg_to_trace_timestamp, falcon_dci.c:284-310: which of the two grants of a downlink entry the reference computes under that table, and
+// whether the unpacked DCI keeps its RNTI (a failed conversion sets it to 0: "to avoid decode")
+// DCICollection.cc:236-251: with HARQ on, a reserved MCS index (29-31: "the size of the previous transmission") of a 64QAM-table grant takes the size the HARQ
+// database remembers for (RNTI, process, block).  (The reference's 256QAM-table branch writes into the grant it did not compute for that entry: no effect.)
+// Returns true when a size was put in.
+inline bool collection_last_tbs(bool harq_mode, McsTable table, DlEntry& e, const HarqDatabase& harq)
+{
+  bool put = false;
+  if (harq_mode && table == TABLE_64QAM && e.unpack_ok)
+    for (int i = 0; i < 2; i++)
+      if (e.grant64.tb[i].enabled && e.grant64.tb[i].mcs_idx > 28) { e.grant64.tb[i].tbs = harq.getlastTbs(e.rnti, e.dci.pid, i); put = true; }
+  return put;
+}
+struct TableView { bool has64, has256, dci_rnti_ok; };
+inline TableView table_view(McsTable table, uint16_t rnti, bool unpack_ok, bool ok64, bool ok256)
+{
+  TableView v;
+  v.has64 = unpack_ok && (table == TABLE_64QAM || table >= TABLE_UNKNOWN);
+  v.has256 = unpack_ok && (table == TABLE_256QAM || table >= TABLE_UNKNOWN);
+  v.dci_rnti_ok = rnti > 0 && !(v.has64 && !ok64) && !(v.has256 && !ok256);
+  return v;
+}
+
 }  // namespace lsn

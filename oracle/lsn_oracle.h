@@ -381,6 +381,14 @@ uint32_t o_worker_accepted(o_worker_t*, uint32_t* out6, uint32_t max);
 o_rntiman_t* o_worker_rntiman(o_worker_t*);
 uint64_t o_worker_total_iters(o_worker_t*);
 uint64_t o_worker_algo_bytes(o_worker_t*);
+/* probes for tests/test_ref_collect.py: DCICollection::addCandidate on given DCI bits (flat words: 64 per downlink entry, 32 per uplink entry - the layout of
+ * oracle/ref_shim_search/collect_glue.cc) and what the decoders feed back between subframes */
+void o_worker_collect_begin(o_worker_t* w, uint32_t sfn, uint32_t sf_idx, uint32_t cfi);
+void o_worker_collect_add(o_worker_t* w, uint16_t rnti, int format, uint32_t L, uint32_t ncce, uint32_t histval, const uint8_t* payload, uint32_t nof_bits);
+uint32_t o_worker_collect_end(o_worker_t* w, uint32_t* dl, uint32_t dl_cap, uint32_t* ul, uint32_t ul_cap, uint16_t* map_dl, uint16_t* map_ul, uint32_t* counts2);
+void o_worker_collect_mcs_update(o_worker_t* w, uint16_t rnti, int table);
+void o_worker_collect_harq_update(o_worker_t* w, uint16_t rnti, int pid, int tid, uint32_t sfn, uint32_t sf_idx, int decoded, int ndi, int rv, int tbs);
+void o_worker_collect_set_hop_offset(o_worker_t* w, uint32_t n_rb_ho);
 
 #ifdef __cplusplus
 }

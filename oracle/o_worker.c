@@ -30,6 +30,7 @@ typedef struct { /* DL_Sniffer_DCI_DL */
   uint16_t rnti; int format; uint32_t nof_bits, L, ncce, histval; int mcs_table;
   o_dci_dl_t dci; uint16_t dci_rnti; /* ran_dci_dl->rnti, zeroed on grant failure */
   o_pdsch_grant_t g64, g256; int has64, has256;
+  int check; /* DCI_BASE::check: a size was taken from the HARQ database */
 } dl_entry_t;
 typedef struct { uint16_t rnti; uint32_t nof_bits, L, ncce, histval; o_dci_ul_t dci; o_pusch_grant_t g, g256; int ok; } ul_entry_t;
 /* one entry of ULSchedule (DCI_UL): grants of both UL MCS tables */
@@ -356,7 +357,7 @@ static void add_candidate(o_worker_t* w, const cand_t* c, uint32_t L, uint32_t n
     if (c->rnti == O_SIRNTI || c->rnti == O_PRNTI || O_RNTI_ISRAR(c->rnti) || fmt == O_FMT1A)
       table = O_TABLE_64QAM;
     else
-      table = mcs_find(w, c->rnti);
+      table = w->ul_mode ? O_TABLE_UNKNOWN : mcs_find(w, c->rnti); /* DCICollection.cc:117-121: the database is asked in DL_MODE only */
   } else if (w->cfg.mcs_tracking_mode == 2) {
     table = O_TABLE_UNKNOWN;
   } else {
@@ -404,6 +405,17 @@ static void add_candidate(o_worker_t* w, const cand_t* c, uint32_t L, uint32_t n
       if (w->rb_map_dl[rb] != 0) w->dl_collision = 1;
       w->rb_map_dl[rb] = c->rnti;
     }
+  /* DCICollection.cc:236-251: with HARQ on, a reserved MCS (29-31: "same size as the previous transmission") of a 64QAM-table grant takes the size the HARQ
+   * database remembers for (RNTI, process, block).  The reference's 256QAM-table branch writes into the grant it did not compute for that entry (no effect). */
+  if (w->harq_mode && table == O_TABLE_64QAM && e->has64)
+    for (int i = 0; i < 2; i++)
+      if (e->g64.tb[i].enabled && e->g64.tb[i].mcs_idx > 28) {
+        int tbs = 0; /* HARQ::getlastTbs, HARQ.cc:262-274: the last entity of that RNTI */
+        for (int k = 0; k < O_HARQ_ENTITIES; k++)
+          if (w->harq[k].rnti == c->rnti) tbs = w->harq[k].tb[e->dci.pid & 7][i].grant.tbs;
+        e->g64.tb[i].tbs = tbs;
+        e->check = 1;
+      }
   for (int i = 0; i < 2; i++) { /* DCICollection.cc:252-259 */
     if (e->g64.tb[i].nof_bits <= 0) e->g64.tb[i].enabled = 0;
     if (e->g256.tb[i].nof_bits <= 0) e->g256.tb[i].enabled = 0;
@@ -1235,3 +1247,83 @@ int o_worker_work_ul(o_worker_t* w, const ocf_t* dl_iq, const ocf_t* ul_iq, uint
   w->sf_count++;
   return w->records;
 }
+
+
+/* ================================================================================================ probes for tests/test_ref_collect.py
+ * DCICollection::addCandidate (add_candidate above) on given DCI bits, and what the decoders feed back between subframes.  Flat words, the layout of
+ * oracle/ref_shim_search/collect_glue.cc: 64 per downlink entry, 32 per uplink entry. */
+void o_worker_collect_begin(o_worker_t* w, uint32_t sfn, uint32_t sf_idx, uint32_t cfi)
+{
+  w->sfn = sfn; w->sf_idx = sf_idx; w->cfi = cfi;
+  w->ndl = w->nul = w->nacc = 0;
+  w->dl_collision = w->ul_collision = 0;
+  memset(w->rb_map_dl, 0, sizeof(w->rb_map_dl));
+  memset(w->rb_map_ul, 0, sizeof(w->rb_map_ul));
+}
+void o_worker_collect_add(o_worker_t* w, uint16_t rnti, int format, uint32_t L, uint32_t ncce, uint32_t histval, const uint8_t* payload, uint32_t nof_bits)
+{
+  cand_t c;
+  memset(&c, 0, sizeof(c));
+  c.rnti = rnti; c.msg.rnti = rnti; c.msg.format = format; c.msg.nof_bits = nof_bits;
+  memcpy(c.msg.payload, payload, nof_bits);
+  add_candidate(w, &c, L, ncce, histval);
+}
+static void put_mask(uint32_t* o, const uint8_t* prb, uint32_t n)
+{
+  o[0] = o[1] = o[2] = o[3] = 0;
+  for (uint32_t i = 0; i < n && i < 128; i++)
+    if (prb[i]) o[i >> 5] |= 1u << (i & 31);
+}
+static void put_dl_grant(uint32_t* o, const o_pdsch_grant_t* g, uint32_t nof_prb)
+{
+  o[0] = g->nof_prb; o[1] = g->nof_re; o[2] = g->nof_tb;
+  put_mask(o + 3, g->prb_idx[0], nof_prb);
+  put_mask(o + 7, g->prb_idx[1], nof_prb);
+  for (int i = 0; i < 2; i++) {
+    uint32_t* t = o + 11 + 7 * i;
+    t[0] = (uint32_t)g->tb[i].enabled; t[1] = g->tb[i].enabled ? (uint32_t)g->tb[i].mod : 0; t[2] = (uint32_t)g->tb[i].tbs; t[3] = (uint32_t)g->tb[i].nof_bits;
+    t[4] = (uint32_t)g->tb[i].rv; t[5] = g->tb[i].mcs_idx; t[6] = g->tb[i].cw_idx;
+  }
+}
+static void put_ul_grant(uint32_t* o, const o_pusch_grant_t* g, const o_cell_t* cell, int ok)
+{
+  memset(o, 0, 9 * sizeof(uint32_t));
+  if (!ok) return;
+  o[0] = g->L_prb; o[1] = g->n_prb; o[2] = g->hop == 1 ? g->n_prb2 : g->n_prb; o[3] = g->hop; o[4] = g->L_prb ? (uint32_t)g->mod : 0; o[5] = (uint32_t)g->tbs;
+  o[6] = (uint32_t)g->rv; o[7] = g->mcs_idx; o[8] = g->L_prb * 12u * (uint32_t)(2 * (o_nslot(cell) - 1));
+}
+uint32_t o_worker_collect_end(o_worker_t* w, uint32_t* dl, uint32_t dl_cap, uint32_t* ul, uint32_t ul_cap, uint16_t* map_dl, uint16_t* map_ul, uint32_t* counts2)
+{
+  const o_cell_t* cell = &w->cfg.cell;
+  for (uint32_t i = 0; i < w->ndl && i < dl_cap; i++) {
+    const dl_entry_t* e = &w->dl[i];
+    uint32_t* o = dl + (size_t)i * 64;
+    memset(o, 0, 64 * sizeof(uint32_t));
+    o[0] = e->rnti; o[1] = (uint32_t)e->format; o[2] = (uint32_t)e->mcs_table; o[3] = e->dci_rnti; o[4] = e->dci.pid; o[5] = e->dci.pinfo; o[6] = e->dci.tb_cw_swap;
+    for (int t = 0; t < 2; t++) { o[7 + 3 * t] = e->dci.tb[t].mcs_idx; o[8 + 3 * t] = (uint32_t)e->dci.tb[t].rv; o[9 + 3 * t] = e->dci.tb[t].ndi; }
+    o[13] = (uint32_t)e->check;
+    if (e->has64) put_dl_grant(o + 14, &e->g64, cell->nof_prb);
+    if (e->has256) put_dl_grant(o + 39, &e->g256, cell->nof_prb);
+  }
+  for (uint32_t i = 0; i < w->nul && i < ul_cap; i++) {
+    const ul_entry_t* u = &w->ul[i];
+    uint32_t* o = ul + (size_t)i * 32;
+    memset(o, 0, 32 * sizeof(uint32_t));
+    o[0] = u->rnti; o[1] = u->dci.rnti; o[2] = u->dci.n_dmrs; o[3] = u->dci.cqi_req; o[4] = u->dci.ndi; o[5] = u->dci.tpc; o[6] = (uint32_t)u->dci.hop_type; o[7] = u->dci.riv;
+    o[8] = u->dci.mcs_idx; o[9] = (uint32_t)u->dci.rv;
+    put_ul_grant(o + 10, &u->g, cell, u->ok);
+    put_ul_grant(o + 19, &u->g256, cell, u->ok);
+    o[28] = u->ok ? u->g.L_prb : 0; o[29] = u->ok ? u->g.n_prb : 0;
+  }
+  for (uint32_t i = 0; i < cell->nof_prb; i++) { map_dl[i] = w->rb_map_dl[i]; map_ul[i] = w->rb_map_ul[i]; }
+  counts2[0] = w->ndl; counts2[1] = w->nul;
+  return (w->dl_collision ? 1u : 0u) | (w->ul_collision ? 2u : 0u);
+}
+void o_worker_collect_mcs_update(o_worker_t* w, uint16_t rnti, int table) { mcs_update(w, rnti, table); }
+void o_worker_collect_harq_update(o_worker_t* w, uint16_t rnti, int pid, int tid, uint32_t sfn, uint32_t sf_idx, int decoded, int ndi, int rv, int tbs)
+{
+  struct o_harq_entity* ent = NULL;
+  const int verdict = harq_is_retx(w, rnti, pid, tid, ndi, tbs, sfn, sf_idx, &ent); /* finds or takes an entity, DL_Sniffer_PDSCH.cc:954 */
+  if (ent && (verdict == O_HARQ_NEW_TX || verdict == O_HARQ_RE_TX)) harq_update(w, ent, pid, tid, sfn, sf_idx, decoded, ndi, rv, tbs); /* :1008-1014 */
+}
+void o_worker_collect_set_hop_offset(o_worker_t* w, uint32_t n_rb_ho) { w->cfg.cell.pusch_hop_offset = n_rb_ho; }

@@ -335,6 +335,118 @@ void lsnh_harq_update(void* h, int entity, uint32_t pid, int tid, uint32_t sfn, 
 }
 void lsnh_harq_update_database(void* h, uint32_t now) { ((HarqDatabase*)h)->update_database(now); }
 
+// one random-access response with the given 20-bit grant through rar_parse (falcon_dci.c:636-683 + DL_Sniffer_PDSCH.cc:632-671): out = hopping, riv, mcs, tpc, ul_delay,
+// csi_req, grant_ok, then the 9 grant words of put_ul_grant
+int lsnh_rar_grant(uint32_t nof_prb, uint32_t cp, uint32_t n_rb_ho, uint32_t grant20, uint32_t* out)
+{
+  Cell c; c.nof_prb = nof_prb; c.nof_ports = 1; c.cp = cp; c.pusch_hop_offset = n_rb_ho;
+  const uint8_t pdu[7] = {0x41, 0x00, (uint8_t)(0x10 | ((grant20 >> 16) & 0xF)), (uint8_t)(grant20 >> 8), (uint8_t)grant20, 0x12, 0x34};
+  RarEntry r[2];
+  if (rar_parse(c, pdu, 7, r, 2) != 1) return -1;
+  out[0] = r[0].hopping; out[1] = r[0].riv; out[2] = r[0].mcs; out[3] = r[0].tpc; out[4] = r[0].ul_delay; out[5] = r[0].csi_req; out[6] = r[0].grant_ok ? 1 : 0;
+  std::memset(out + 7, 0, 9 * sizeof(uint32_t));
+  if (r[0].grant_ok) {
+    const PuschGrant& g = r[0].grant;
+    out[7] = g.L_prb; out[8] = g.n_prb; out[9] = g.hop == 1 ? g.n_prb2 : g.n_prb; out[10] = g.hop; out[11] = g.L_prb ? (uint32_t)g.mod : 0; out[12] = (uint32_t)g.tbs;
+    out[13] = (uint32_t)g.rv; out[14] = g.mcs_idx; out[15] = g.L_prb * 12u * 2u * (c.nslot() - 1);
+  }
+  return r[0].t_crnti == 0x1234 && r[0].rapid == 1 && r[0].ta == 1 ? 0 : -2;
+}
+
+// ---- DCICollection::addCandidate as the product does it (tests/test_ref_collect.py: the REFERENCE's DCICollection.cc / falcon_dci.c, oracle/_ref) ----
+// FalconSearch::finishSubframe (unpack, both grant conversions, collision statistics) + the commit-side helpers of lsn_search.h the engine itself uses
+// (collection_table, table_view, collection_last_tbs).  Rows in the flat layout of oracle/ref_shim_search/collect_glue.cc.
+struct hcollect { Cell cell; std::unique_ptr<FalconSearch> s; MCSTracking mcs; HarqDatabase harq; int mode = 1, harq_mode = 0; uint32_t now = 0; };
+static void put_mask(uint32_t* o, const bool* prb, uint32_t n)
+{
+  o[0] = o[1] = o[2] = o[3] = 0;
+  for (uint32_t i = 0; i < n && i < 128; i++)
+    if (prb[i]) o[i >> 5] |= 1u << (i & 31);
+}
+static void put_dl_grant(uint32_t* o, const PdschGrant& g, uint32_t nof_prb)
+{
+  o[0] = g.nof_prb; o[1] = g.nof_re; o[2] = g.nof_tb;
+  put_mask(o + 3, g.prb_idx[0], nof_prb);
+  put_mask(o + 7, g.prb_idx[1], nof_prb);
+  for (int i = 0; i < 2; i++) {
+    uint32_t* t = o + 11 + 7 * i;
+    t[0] = g.tb[i].enabled; t[1] = g.tb[i].enabled ? (uint32_t)g.tb[i].mod : 0; t[2] = (uint32_t)g.tb[i].tbs; t[3] = (uint32_t)g.tb[i].nof_bits;
+    t[4] = (uint32_t)g.tb[i].rv; t[5] = g.tb[i].mcs_idx; t[6] = g.tb[i].cw_idx;
+  }
+}
+static void put_ul_grant(uint32_t* o, const PuschGrant& g, const Cell& cell)
+{
+  o[0] = g.L_prb; o[1] = g.n_prb; o[2] = g.hop == 1 ? g.n_prb2 : g.n_prb; o[3] = g.hop; o[4] = g.L_prb ? (uint32_t)g.mod : 0; o[5] = (uint32_t)g.tbs;
+  o[6] = (uint32_t)g.rv; o[7] = g.mcs_idx; o[8] = g.L_prb * 12u * 2u * (cell.nslot() - 1);
+}
+void* lsnh_collect_new(uint32_t nof_prb, uint32_t nof_ports, uint32_t cell_id, uint32_t cp, int mcs_tracking_mode, int harq_mode)
+{
+  hcollect* h = new hcollect();
+  h->cell.nof_prb = nof_prb; h->cell.nof_ports = nof_ports; h->cell.id = cell_id; h->cell.cp = cp;
+  h->mode = mcs_tracking_mode; h->harq_mode = harq_mode;
+  h->s.reset(new FalconSearch(5, 0.99, false));
+  const uint32_t ncce[3] = {20, 54, 87};
+  h->s->setCell(h->cell, ncce);
+  return h;
+}
+void lsnh_collect_free(void* p) { delete (hcollect*)p; }
+void lsnh_collect_set_hop_offset(void* p, uint32_t n_rb_ho) { ((hcollect*)p)->s->setPuschHopOffset(n_rb_ho); ((hcollect*)p)->cell.pusch_hop_offset = n_rb_ho; }
+void lsnh_collect_set_now(void* p, uint32_t now) { ((hcollect*)p)->now = now; }
+void lsnh_collect_mcs_update(void* p, uint16_t rnti, int table) { hcollect* h = (hcollect*)p; h->mcs.update_RNTI_dl(rnti, (McsTable)table, h->now); }
+void lsnh_collect_harq_update(void* p, uint16_t rnti, uint32_t pid, int tid, uint32_t sfn, uint32_t sf_idx, int decoded, int ndi, int rv, int tbs)
+{
+  hcollect* h = (hcollect*)p;
+  int ent = -1;
+  const HarqRet hr = h->harq.is_retransmission(rnti, pid, tid, ndi != 0, tbs, sfn, sf_idx, ent);
+  if (hr == HARQ_NEW_TX || hr == HARQ_RE_TX) h->harq.update(ent, pid, tid, sfn, sf_idx, decoded != 0, ndi != 0, rv, tbs, h->now);
+}
+// n accepted DCI: (rnti, format, L, ncce, histval, nof_bits) x n in meta6, payload bits (one byte per bit, 128 per DCI) in bits.  Returns the collision flags.
+uint32_t lsnh_collect_subframe(void* p, uint32_t sfn, uint32_t sf_idx, uint32_t cfi, uint32_t n, const uint32_t* meta6, const uint8_t* bits, uint32_t* dl, uint32_t* ul,
+                               uint32_t* counts2)
+{
+  hcollect* h = (hcollect*)p;
+  SubframeCtx c;
+  c.reset(sfn * 10 + sf_idx);
+  c.cfi = cfi; c.searched = true;
+  for (uint32_t i = 0; i < n; i++) {
+    const uint32_t* m = meta6 + 6 * i;
+    unsigned long long w = 0;
+    for (uint32_t b = 0; b < m[5] && b < 64; b++) w |= (unsigned long long)(bits[128 * i + b] & 1) << (63 - b);
+    c.raw.push_back(AcceptedDci{(uint16_t)m[0], (uint8_t)m[1], (uint8_t)m[2], (uint16_t)m[3], (uint16_t)m[5], m[4], w});
+  }
+  const BlindStats b0 = h->s->getStats();
+  h->s->finishSubframe(c);
+  const BlindStats b1 = h->s->getStats();
+  // the engine's commit turn (lsn_engine.cc: commitChunk): tables of every DCI first, then the uplink look-ups, then entry by entry
+  std::vector<McsTable> tables;
+  for (const DlEntry& e : c.dl) tables.push_back(collection_table(h->mode, e.rnti, e.format, h->mcs, h->now));
+  if (h->mode == 1)
+    for (const UlEntry& u : c.ul)
+      if (!(u.rnti == SIRNTI || u.rnti == PRNTI || rnti_israr(u.rnti))) (void)h->mcs.find_tracking_info_RNTI_dl(u.rnti, h->now);
+  for (size_t i = 0; i < c.dl.size(); i++) {
+    DlEntry& e = c.dl[i];
+    uint32_t* o = dl + i * 64;
+    std::memset(o, 0, 64 * sizeof(uint32_t));
+    const TableView tv = table_view(tables[i], e.rnti, e.unpack_ok, e.ok64, e.ok256);
+    const bool check = collection_last_tbs(h->harq_mode != 0, tables[i], e, h->harq);
+    o[0] = e.rnti; o[1] = (uint32_t)e.format; o[2] = (uint32_t)tables[i]; o[3] = tv.dci_rnti_ok ? e.rnti : 0; o[4] = e.dci.pid; o[5] = e.dci.pinfo; o[6] = e.dci.tb_cw_swap;
+    for (int t = 0; t < 2; t++) { o[7 + 3 * t] = e.dci.tb[t].mcs_idx; o[8 + 3 * t] = (uint32_t)e.dci.tb[t].rv; o[9 + 3 * t] = e.dci.tb[t].ndi; }
+    o[13] = check ? 1 : 0;
+    if (tv.has64) put_dl_grant(o + 14, e.grant64, h->cell.nof_prb);
+    if (tv.has256) put_dl_grant(o + 39, e.grant256, h->cell.nof_prb);
+  }
+  for (size_t i = 0; i < c.ul.size(); i++) {
+    const UlEntry& u = c.ul[i];
+    uint32_t* o = ul + i * 32;
+    std::memset(o, 0, 32 * sizeof(uint32_t));
+    o[0] = u.rnti; o[1] = u.ok ? u.rnti : 0; o[2] = u.dci.n_dmrs; o[3] = u.dci.cqi_req; o[4] = u.dci.ndi; o[5] = u.dci.tpc; o[6] = (uint32_t)u.dci.hop_type; o[7] = u.dci.riv;
+    o[8] = u.dci.mcs_idx; o[9] = 0;
+    if (u.ok) { put_ul_grant(o + 10, u.grant, h->cell); put_ul_grant(o + 19, u.grant256, h->cell); o[28] = u.grant.L_prb; o[29] = u.grant.n_prb; }
+  }
+  counts2[0] = (uint32_t)c.dl.size(); counts2[1] = (uint32_t)c.ul.size();
+  return (b1.nof_subframe_collisions_dw != b0.nof_subframe_collisions_dw ? 1u : 0u) | (b1.nof_subframe_collisions_up != b0.nof_subframe_collisions_up ? 2u : 0u);
+}
+
 // the product's RNTIManager on its own (tests/test_ref_rnti_manager.py: operation sequences against the REFERENCE's RNTIManager.cc, oracle/_ref)
 void* lsnh_rm_new(uint32_t nformats, uint32_t maxcand, uint32_t threshold) { return new RNTIManager(nformats, maxcand, threshold); }
 void lsnh_rm_free(void* h) { delete (RNTIManager*)h; }
