@@ -374,6 +374,15 @@ def main():
         assert total == args.steps * S * world
     total_sf = args.steps * S * (1 if capture_mode else world)
     value = total_sf / dt
+    # proof of what ran where: the collective backend torch.distributed really used, the world it saw, every rank's device (PCI bus id) - gathered over that backend
+    pr_ = torch.cuda.get_device_properties(local)
+    my_bus = (int(pr_.pci_domain_id) << 16) | (int(pr_.pci_bus_id) << 8) | int(pr_.pci_device_id)
+    dist_echo = {"backend": None, "world_size": world, "devices_pci": ["%04x:%02x:%02x" % (my_bus >> 16, (my_bus >> 8) & 0xFF, my_bus & 0xFF)], "device_count_visible": torch.cuda.device_count()}
+    if world > 1 and not capture_mode:
+        rdev2 = dev if dist.get_backend() == "nccl" else None
+        buses = ld.gather_flags(my_bus, rdev2)
+        dist_echo.update({"backend": dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else ""), "world_size": dist.get_world_size(),
+                          "devices_pci": ["%04x:%02x:%02x" % (b >> 16, (b >> 8) & 0xFF, b & 0xFF) for b in buses], "distinct_devices": len(set(buses))})
     phy.close()
 
     def live_oracle_blocks(n):
@@ -433,6 +442,19 @@ def main():
                     parity["oracle_subframes"] = ns
                     parity["note"] = "no cached oracle stream for this capture: only the first %d warm-up subframes are oracle-checked; pcap_diff stays null" % ns
             if world == 1:
+                # BASELINE.json configs[0] / BASELINE.md section 3: 10 MHz, one RNTI, TM1 QPSK, one CRS port, one rx antenna, CFO 300 Hz - the CPU path on this host's cores
+                try:
+                    sc1 = scenario("cfg1", seed=1)
+                    n1 = 2000
+                    t1, iq1 = gen_capture(sc1, n1, threads=gen_threads)
+                    t = time.perf_counter()
+                    _, _, r1 = run_oracle(sc1, t1, iq1, update_meta_period=META_PERIOD, taps=False)
+                    dt1 = time.perf_counter() - t
+                    cpu["configs0"] = {"value": round(n1 / dt1, 1), "unit": "subframes/s", "x_realtime": round(n1 / dt1 / 1000.0, 3), "cores": 1, "kind": "port", "records": len(r1),
+                                       "sample": "BASELINE configs[0]: %d subframes of a synthetic 10 MHz capture (50 PRB, 1 port, 1 rx, one C-RNTI, TM1 QPSK, SIB1, CFO 300 Hz), scalar C oracle, 1 thread" % n1}
+                    del iq1
+                except Exception as ex:
+                    cpu["configs0"] = {"error": str(ex)[:200]}
                 # the same restatement on many cores: forked workers on independent 200-subframe slices, each with its own (cold) state - an
                 # upper bound for a subframe-parallel CPU run of this code (the sequential RNTI state is not shared), informational only
                 try:
@@ -460,9 +482,10 @@ def main():
     if rank == 0 and world == 1 and not args.no_legs:
         legs = {"pcie_link": _pcie_link(local)}
 
-        def two_passes(name, make_phy, run_pass, extra=None):
-            lp = la.PcapWriter(None)
-            lp.set_store(False)
+        def two_passes(name, make_phy, run_pass, extra=None, pcap_path=None):
+            lp = la.PcapWriter(pcap_path)   # pcap_path: the records go to a FILE like the reference's (PcapWriter.cc:75-118), digested on the way
+            if pcap_path is None:
+                lp.set_store(False)
             lphy = make_phy(lp)
             lphy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"])
             out = {}
@@ -480,6 +503,10 @@ def main():
             if extra:
                 out.update(extra)
             lphy.close()
+            if pcap_path is not None:
+                lp.close()
+                out["pcap_file_bytes"] = os.path.getsize(pcap_path)
+                os.remove(pcap_path)
             legs[name] = out
 
         try:
@@ -488,6 +515,10 @@ def main():
             legs["chunk_subframes"] = lbatch
             two_passes("host_pinned", lambda w: la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=lbatch, device=local, pcapwriter=w),
                        lambda ph, t: (ph.process_host(host.numpy(), t, META_PERIOD), nsf)[1])
+            two_passes("host_pinned_pcap_to_file", lambda w: la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=lbatch, device=local, pcapwriter=w),
+                       lambda ph, t: (ph.process_host(host.numpy(), t, META_PERIOD), nsf)[1],
+                       {"note": "as host_pinned, the MAC-LTE records written to a pcap file on tmpfs (three passes in one file) instead of only digested"},
+                       pcap_path="/dev/shm/lsn_bench_%d.pcap" % os.getpid())
             two_passes("host_pageable", lambda w: la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=lbatch, device=local, pcapwriter=w),
                        lambda ph, t: (ph.process_host(iq, t, META_PERIOD), nsf)[1], {"note": "registered in place (hipHostRegister) for the call"})
             # the reference's boundary: 1024 workers (1.5 GB pinned slab), chunks of up to 512 subframes; producer = 1 thread like LTESniffer_Core, then 4 copy threads
@@ -665,21 +696,37 @@ def main():
             cold = {"subframes_per_s": round(args.warmup * S / dt_warm, 1), "subframes": args.warmup * S, "records": warm_records,
                     "tb_decodes_per_subframe": round(pw.nof_tb_decodes / (args.warmup * S), 2), "turbo_iterations_per_subframe": round(pw.nof_turbo_iterations / (args.warmup * S), 1),
                     "note": "the warm-up steps: a fresh engine (empty RNTI histograms, no MCS-table knowledge), pipeline fill and drain included"}
+        def leg_rate(name, which):
+            return ((legs or {}).get(name) or {}).get(which, {}).get("subframes_per_s") if legs else None
+
+        def leg_diffs(name):
+            e = (legs or {}).get(name) or {}
+            return [e.get(k, {}).get("pcap_diff") for k in ("pass1_cold", "pass2_warm", "pass3_warm")] if e else None
+        h2d_cold, h2d_warm = leg_rate("host_pinned", "pass1_cold"), leg_rate("host_pinned", "pass3_warm")
         out = {
             "metric": "subframes/s (20 MHz, 150 RNTIs)", "value": round(value, 1), "unit": "subframes/s", "n_gpus": world if not capture_mode or world > 1 else len(devices),
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "strong" if capture_mode else "weak", "vs_baseline": None, "dtype": "f32+int16", "data": "synthetic",
-            "x_realtime": round(value / 1000.0 / (1 if capture_mode else world), 2), "pcap_diff": pcap_diff,
+            # `value` follows the bench contract (the capture is resident in HBM when the timed region starts).  BASELINE.md section 3's clock - first H2D -> last PDU on the
+            # host, PCIe included, fresh engine - is value_first_h2d_to_last_pdu (cold pass) / _warm (third pass); x_realtime is given on both clocks, by name
+            "value_resident": round(value, 1), "x_realtime": round(value / 1000.0 / (1 if capture_mode else world), 2),
+            "x_realtime_resident": round(value / 1000.0 / (1 if capture_mode else world), 2),
+            "x_realtime_first_h2d_to_last_pdu": {"cold": round(h2d_cold / 1000.0, 1) if h2d_cold else None, "warm": round(h2d_warm / 1000.0, 1) if h2d_warm else None},
+            "pcap_diff": pcap_diff,
             # BASELINE.md section 3 times "first H2D -> last PDU on host"; the bench contract wants inputs resident in HBM for `value`.  Both are here:
             # `value` = resident, `value_first_h2d_to_last_pdu` = the whole capture from pinned host memory through a FRESH engine (cold RNTI / MCS state, PCIe
             # included), the number to hold against BASELINE's >= 50 x real time
-            "value_first_h2d_to_last_pdu": (legs or {}).get("host_pinned", {}).get("pass1_cold", {}).get("subframes_per_s") if legs else None,
+            "value_first_h2d_to_last_pdu": h2d_cold, "value_first_h2d_to_last_pdu_warm": h2d_warm,
             "parity_reference": "in-repo CPU oracle; its DSP is unpinned vs srsRAN (absent dependency); its search / grant / tracking logic is pinned on the reference's own compiled code (oracle/_ref, CPU suite)", "parity": parity,
             "config": {"workload": "%s: 20 MHz DL (100 PRB, 2 CRS ports, 2 rx), 150 active RNTIs + a fresh RNTI by RAR every 200 subframes, TM2/TM3/TM4 mix up to 256QAM, "
                                    "CFI 3, 8-14 DL + 3-6 UL DCIs per subframe (BASELINE.json configs[2], SURVEY 8d config 3)" % args.config
                        if args.config == "cfg3" and wl_leg is None else (args.workload + ": " + wl_leg["what"] if wl_leg else args.config),
                        "subframes_per_step": S, "subframes_per_step_auto": step_sf_auto, "distinct_subframes": nsf, "stream": "capture replayed cyclically, TTI and sequential state carried over",
                        "input": "resident in HBM", "steps_pipelined": True, "gpu_batch": batch, "cells": 1 if capture_mode else world, "capture_gen_s": round(t_gen, 1),
+                       # (the driver keeps `config`: the other clock and the proof of what ran, in short)
+                       "first_h2d_to_last_pdu_subframes_per_s": {"cold": h2d_cold, "warm": h2d_warm, "pcap_to_file_cold": leg_rate("host_pinned_pcap_to_file", "pass1_cold"),
+                                                                 "pcap_to_file_warm": leg_rate("host_pinned_pcap_to_file", "pass3_warm")},
+                       "pcap_diff": pcap_diff, "dist": dist_echo,
                        "parallelism": ("one capture, chunks round-robin over devices %s, shared sequential search" % devices) if capture_mode else "one cell per GPU, no collective"},
             "roofline": {"bound": "hbm", "kernel": la.KERNELS[kt], "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(ach / 8000.0, 6), "traffic": traffic, "traffic_source": traffic_src,
@@ -708,6 +755,14 @@ def main():
                        "kernel_ms_per_6400_subframes": {la.KERNELS[k]: round(kms[k] * 6400.0 / sf_rank, 4) for k in range(nk)},
                        "kernel_launches_per_step": {la.KERNELS[k]: round(float(klaunch[k]) / args.steps, 2) for k in range(nk)}},
         }
+        # the last 1.5 kB of the line (what a tail keeps): every headline figure with its gate
+        out["summary"] = {"value_resident": round(value, 1), "pcap_diff": pcap_diff, "timed_subframes": total_sf, "n_gpus": out["n_gpus"], "dist": dist_echo,
+                          "first_h2d_to_last_pdu": {k: {"cold_warm_warm": [leg_rate(k, w) for w in ("pass1_cold", "pass2_warm", "pass3_warm")], "pcap_diff": leg_diffs(k)}
+                                                    for k in ("host_pinned", "host_pinned_pcap_to_file", "host_pageable", "worker_pool_1_producer_thread", "worker_pool_4_producer_threads", "file_replay")
+                                                    if legs and k in legs},
+                          "other_configs": {k: [v.get("subframes_per_s"), v.get("pcap_diff")] for k, v in (legs or {}).items() if isinstance(v, dict) and "what" in v},
+                          "roofline_frac": out["roofline"]["frac"], "cpu_baseline": [cpu.get("value"), (cpu.get("configs0") or {}).get("value")] if cpu else None,
+                          "host_cores_busy": round(host_cores_busy, 2)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -108,6 +108,12 @@ int lsn_phy_add_evergreen(lsn_phy_t* phy, uint16_t rnti_start, uint16_t rnti_end
 int lsn_phy_add_forbidden(lsn_phy_t* phy, uint16_t rnti_start, uint16_t rnti_end, uint32_t format_idx); /* RNTIManager::addForbidden */
 int lsn_phy_setup_default_rnti_intervals(lsn_phy_t* phy);                 /* LTESniffer_Core.cc:398-417 in one call */
 uint32_t lsn_phy_nof_active_rnti(lsn_phy_t* phy);
+/* Phy::getMetaFormats (Phy.h:45, Phy.cc:152; DCIMetaFormats, MetaFormats.h): the primary / secondary split of the nine DCI formats the search is working with,
+ * as indices into falcon_ue_all_formats (DCISearch.cc:84-95; = srsran_dci_format_t values 0..8).  Each list has room for 9.  Between process calls / after wait. */
+int lsn_phy_get_meta_formats(lsn_phy_t* phy, uint32_t* primary, uint32_t* nof_primary, uint32_t* secondary, uint32_t* nof_secondary);
+/* Phy::getWorkers (Phy.h:46, Phy.cc:112): the pool's workers by index, whoever holds them at the moment */
+uint32_t lsn_phy_nof_workers(lsn_phy_t* phy);
+lsn_worker_t* lsn_phy_worker(lsn_phy_t* phy, uint32_t index);
 /* UE-specific configuration learned from RRCConnectionSetup messages on the downlink (MCSTracking::get_ue_config_rnti,
  * MCSTracking.cc:1482-1516; filled by PDSCH_Decoder::decode_rrc_connection_setup, DL_Sniffer_PDSCH.cc:129-181): the entry of the
  * RNTI, or the default (the first connection setup seen; before that p_a 0 dB, offsets 10 / 8 / 11, higher-layer sub-band CQI).

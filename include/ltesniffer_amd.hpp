@@ -2,8 +2,11 @@
 // (ltesniffer_amd.h).  It keeps the names, argument order and meaning of
 //   class Phy            /root/reference/src/include/Phy.h:22-66
 //   class SubframeWorker /root/reference/src/include/SubframeWorker.h:16-86
-// so that LTESniffer_Core.cc compiles against it unchanged apart from the srsRAN PODs (re-declared in the C header)
-// and the singletons this library owns itself (RNTIManager, MCSTracking, DCIMetaFormats live behind lsn_phy_t).
+// and every member LTESniffer_Core.cc calls on them (constructor :63-90, loop :292-299,361-451, shutdown :547-562, :603-621): tests/native/test_hpp.cc
+// repeats those call sites, in the reference's spelling, against this header.  What does NOT carry over unchanged: the srsRAN PODs (re-declared in the C
+// header), the singletons this library owns itself (RNTIManager, MCSTracking, DCIMetaFormats live behind lsn_phy_t and are reached through the facades
+// below - same member names, other class names), and the translation unit as a whole - LTESniffer_Core.cc also includes boost::program_options, srsue
+// and the srsRAN radio / synchronisation API, none of which exist in this image, so it has never been compiled against this header.
 #pragma once
 #include "ltesniffer_amd.h"
 #include <complex>
@@ -11,6 +14,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 namespace lsn_amd {
 
@@ -49,8 +53,50 @@ private:
   friend class Phy;
   lsn_phy_t* h = nullptr;
 };
+// PhyCommon's DCI consumer hook (PhyCommon.h:57-62, SubframeInfoConsumer.h).  LTESniffer_Core builds a DCIConsumerList and hands it over
+// (LTESniffer_Core.cc:88-98, 603-609); the one call that would feed it - common.consumeDCICollection(subframeInfo) - is a comment in the reference's
+// worker (SubframeWorker.cc:205), so the consumer is stored and never invoked there.  Same here.
+class SubframeInfo;
+class SubframeInfoConsumer {
+public:
+  virtual ~SubframeInfoConsumer() {}
+  virtual void consumeDCICollection(const SubframeInfo& subframeInfo) = 0;
+};
+class DCIToFile : public SubframeInfoConsumer {   // SubframeInfoConsumer.h: the default consumer, a FILE* holder
+public:
+  DCIToFile() : dci_file(stdout) {}
+  explicit DCIToFile(FILE* f) : dci_file(f) {}
+  void setFile(FILE* f) { dci_file = f; }
+  FILE* getFile() { return dci_file; }
+  void consumeDCICollection(const SubframeInfo&) override {}
+private:
+  FILE* dci_file;
+};
+class DCIConsumerList : public SubframeInfoConsumer {   // SubframeInfoConsumer.cc:10-19
+public:
+  void consumeDCICollection(const SubframeInfo& s) override { for (auto& c : consumers) c->consumeDCICollection(s); }
+  void addConsumer(std::shared_ptr<SubframeInfoConsumer> consumer) { consumers.push_back(consumer); }
+private:
+  std::vector<std::shared_ptr<SubframeInfoConsumer>> consumers;
+};
+// phy->getMetaFormats() (Phy.h:45): the primary / secondary split of the nine DCI formats, read from the library
+class DCIMetaFormatsFacade {
+public:
+  uint32_t getNofPrimaryMetaFormats() { refresh(); return np; }
+  uint32_t getNofSecondaryMetaFormats() { refresh(); return ns; }
+  const uint32_t* getPrimaryMetaFormats() { refresh(); return prim; }       // indices into falcon_ue_all_formats (= srsran_dci_format_t 0..8)
+  const uint32_t* getSecondaryMetaFormats() { refresh(); return sec; }
+private:
+  friend class Phy;
+  void refresh() { if (h) lsn_phy_get_meta_formats(h, prim, &np, sec, &ns); }
+  lsn_phy_t* h = nullptr;
+  uint32_t prim[9] = {0}, sec[9] = {0}, np = 0, ns = 0;
+};
 class PhyCommonFacade {     // phy->getCommon()
 public:
+  FILE* getDCIFile() { return dci_file; }                                                                  // PhyCommon.cc:48-50 (opened like PhyCommon.cc:19-24)
+  void setDCIConsumer(std::shared_ptr<SubframeInfoConsumer> consumer) { dciConsumer = consumer; }          // PhyCommon.cc:77-79
+  void resetDCIConsumer() { dciConsumer = defaultDCIConsumer; }                                            // PhyCommon.cc:81-83
   void setShortcutDiscovery(bool enable) { lsn_phy_set_shortcut_discovery(h, enable ? 1 : 0); }           // PhyCommon.cc:69-71
   bool getShortcutDiscovery() const { return lsn_phy_get_shortcut_discovery(h) != 0; }
   void printStats() { lsn_phy_print_stats(h, stats_file); }                                                // PhyCommon.cc:65-67
@@ -61,6 +107,9 @@ private:
   friend class Phy;
   lsn_phy_t* h = nullptr;
   FILE* stats_file = nullptr;
+  FILE* dci_file = stdout;
+  std::shared_ptr<DCIToFile> defaultDCIConsumer{new DCIToFile()};
+  std::shared_ptr<SubframeInfoConsumer> dciConsumer{defaultDCIConsumer};
   RNTIManagerFacade rm;
 };
 // The caller's MCSTracking object (LTESniffer_Core.cc:422-426,473-499): the database it used to own is inside the library; what the main
@@ -93,8 +142,10 @@ public:
       int harq_mode, ULSchedule* ulsche, int device = 0, int sniffer_mode = 0 /* DL_MODE; 1 = UL_MODE */, uint32_t max_batch = 0)
       : nof_rx_antennas(nof_rx_antennas), nof_workers(nof_workers)
   {
-    (void)dciFileName; (void)harq; (void)ulsche;
+    (void)harq; (void)ulsche;
     init(skipSecondaryMetaFormats, metaFormatSplitRatio, histogramThreshold, pcapwriter, mcs_tracking_mode, harq_mode, device, sniffer_mode, max_batch);
+    if (!dciFileName.empty()) { common.dci_file = fopen(dciFileName.c_str(), "w"); if (!common.dci_file) common.dci_file = stdout; }   // PhyCommon.cc:19-24
+    common.defaultDCIConsumer->setFile(common.dci_file);                                                                               // PhyCommon.cc:33
     if (!statsFileName.empty()) common.stats_file = fopen(statsFileName.c_str(), "w");
     if (mcs_tracking) mcs_tracking->attach(h);
   }
@@ -105,7 +156,7 @@ public:
   {
     init(skipSecondaryMetaFormats, metaFormatSplitRatio, histogramThreshold, pcapwriter, mcs_tracking_mode, harq_mode, device, sniffer_mode, 0);
   }
-  ~Phy() { lsn_phy_destroy(h); if (common.stats_file) fclose(common.stats_file); }
+  ~Phy() { lsn_phy_destroy(h); if (common.stats_file) fclose(common.stats_file); if (common.dci_file && common.dci_file != stdout) fclose(common.dci_file); }
   Phy(const Phy&) = delete;
   Phy& operator=(const Phy&) = delete;
   bool setCell(const lsn_cell_t& cell) { return lsn_phy_set_cell(h, &cell) == LSN_SUCCESS; }               // Phy.cc:111
@@ -116,6 +167,13 @@ public:
   void setPduSink(lsn_pdu_sink_t cb, void* user) { lsn_phy_set_pdu_sink(h, cb, user); }
   lsn_blind_stats_t getStats() { lsn_blind_stats_t s{}; lsn_phy_get_stats(h, &s); return s; }              // PhyCommon::getStats
   PhyCommonFacade& getCommon() { return common; }                                                           // Phy.h:44
+  DCIMetaFormatsFacade& getMetaFormats() { return metaFormats; }                                            // Phy.h:45
+  std::vector<std::shared_ptr<SubframeWorker>>& getWorkers()                                                // Phy.h:46: every worker of the pool, by index
+  {
+    if (workers.empty())
+      for (uint32_t i = 0; i < lsn_phy_nof_workers(h); i++) workers.push_back(wrap(lsn_phy_worker(h, i)));
+    return workers;
+  }
   void printStats() { common.printStats(); }                                                               // Phy.cc:144
   void setChestCFOEstimateEnable(bool, uint32_t) {}   // Phy.h:49-50: the estimator of this path always reports its CFO (getEstCfo)
   void setChestAverageSubframe(bool) {}
@@ -157,9 +215,11 @@ private:
     if (r != LSN_SUCCESS) throw std::runtime_error("lsn_phy_create failed");
     lsn_phy_setup_default_rnti_intervals(h);  // LTESniffer_Core.cc:398-417
     if (pcapwriter) lsn_phy_set_pcap_writer(h, pcapwriter);
-    common.h = h; common.rm.h = h;
+    common.h = h; common.rm.h = h; metaFormats.h = h;
   }
   PhyCommonFacade common;
+  DCIMetaFormatsFacade metaFormats;
+  std::vector<std::shared_ptr<SubframeWorker>> workers;
   static std::shared_ptr<SubframeWorker> wrap(lsn_worker_t* w) { return w ? std::shared_ptr<SubframeWorker>(new SubframeWorker(w)) : nullptr; }
   lsn_phy_t* h = nullptr;
 };

@@ -38,7 +38,7 @@ EXPORTS = ["lsn_phy_create", "lsn_phy_destroy", "lsn_phy_set_cell", "lsn_phy_get
            "lsn_phy_tap_ul", "lsn_phy_set_prach_config", "lsn_phy_prach_detect", "lsn_phy_set_prach_sink", "lsn_prach_tti_opportunity", "lsn_phy_process_file", "lsn_phy_mib_decode", "lsn_phy_mib_decode_llr", "lsn_phy_submit_device", "lsn_phy_wait", "lsn_cell_search",
            "lsn_phy_set_shortcut_discovery", "lsn_phy_get_shortcut_discovery", "lsn_phy_set_histogram_threshold", "lsn_phy_print_stats",
            "lsn_phy_set_mcs_update_interval", "lsn_phy_update_mcs_database", "lsn_phy_nof_tracked_rnti", "lsn_worker_buffers_offset", "lsn_pcap_digest", "lsn_pcap_set_store", "lsn_pcap_set_digest_blocks", "lsn_pcap_block_digests", "lsn_phy_create_multi", "lsn_phy_nof_devices",
-           "lsn_phy_set_stage_c_taps", "lsn_phy_prepare_file"]
+           "lsn_phy_set_stage_c_taps", "lsn_phy_prepare_file", "lsn_phy_get_meta_formats", "lsn_phy_nof_workers", "lsn_phy_worker"]
 
 
 def turbo_nwin(K):

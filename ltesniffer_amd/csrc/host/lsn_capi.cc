@@ -391,6 +391,17 @@ int lsn_phy_update_mcs_database(lsn_phy_t* phy)
 uint32_t lsn_phy_nof_tracked_rnti(lsn_phy_t* phy) { return phy ? phy->engine->nofTrackedRnti() : 0; }
 int lsn_phy_tracked_ul_modulation(lsn_phy_t* phy, uint16_t rnti) { return phy ? phy->engine->trackedModUl(rnti) : 0; }
 uint32_t lsn_phy_nof_active_rnti(lsn_phy_t* phy) { return phy ? phy->engine->rntiManager().nofActive() : 0; }
+int lsn_phy_get_meta_formats(lsn_phy_t* phy, uint32_t* primary, uint32_t* nof_primary, uint32_t* secondary, uint32_t* nof_secondary)
+{
+  if (!phy || !primary || !nof_primary || !secondary || !nof_secondary) return LSN_ERROR_INVALID_INPUTS;
+  lsn::DCIMetaFormats& m = phy->engine->searchRef().metaFormats();
+  *nof_primary = m.getNofPrimaryMetaFormats(); *nof_secondary = m.getNofSecondaryMetaFormats();
+  for (uint32_t i = 0; i < *nof_primary && i < 9; i++) primary[i] = m.getPrimaryMetaFormats()[i]->global_index;
+  for (uint32_t i = 0; i < *nof_secondary && i < 9; i++) secondary[i] = m.getSecondaryMetaFormats()[i]->global_index;
+  return LSN_SUCCESS;
+}
+uint32_t lsn_phy_nof_workers(lsn_phy_t* phy) { return phy ? (uint32_t)phy->workers.size() : 0; }
+lsn_worker_t* lsn_phy_worker(lsn_phy_t* phy, uint32_t index) { return phy && index < phy->workers.size() ? phy->workers[index].get() : nullptr; }
 int lsn_phy_get_ue_config(lsn_phy_t* phy, uint16_t rnti, lsn_ue_config_t* out)
 {
   if (!phy || !out) return LSN_ERROR_INVALID_INPUTS;

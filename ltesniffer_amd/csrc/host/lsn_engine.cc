@@ -31,18 +31,11 @@ namespace lsn {
 // for hipEventBlockingSync events (measured: thread CPU time == wall time in the wait, six decode threads = four cores of
 // polling per rank), which starves the search thread when several ranks share a CPU quota.  Poll-and-sleep instead: the
 // waits are 2-15 ms long; the decode threads nap 50 us, the front thread (which feeds the sequential search) 15 us, with the
-// threads' timer slack set to 1 us so the naps are that short.  LSN_SPIN_WAIT=1 spins.
-static const bool g_spin_wait = getenv("LSN_SPIN_WAIT") && atoi(getenv("LSN_SPIN_WAIT"));
-// LSN_TURBO_FORK=1: k_turbo<64> on a second stream per runner next to k_turbo<128> (more HSA queues: measured slower beyond 6 decode threads)
+// threads' timer slack set to 1 us so the naps are that short.  (Spinning instead was measured in round 5: no gain, profiles/r05_exp_session21.txt.)
 // LSN_NO_CB_SKIP=1: decode every code block even when the first block of its transport block has already failed (iteration counts then equal the oracle's)
-// (read when an engine is made: Engine::cb_skip)
-static const bool g_turbo_fork = getenv("LSN_TURBO_FORK") && atoi(getenv("LSN_TURBO_FORK"));
+// (read when an engine is made: Engine::cb_skip; the GPU suite runs with it)
 static void waitEvent(hipEvent_t ev, long nap_ns = 50000)
 {
-  if (g_spin_wait) {
-    HIP_CHECK(hipEventSynchronize(ev));
-    return;
-  }
   for (;;) {
     const hipError_t e = hipEventQuery(ev);
     if (e == hipSuccess) return;
@@ -153,9 +146,9 @@ Engine::Engine(const lsn_phy_cfg_t& c, std::shared_ptr<SharedSeq> shared) : sh(s
     // ("stage A feeds the sequential search"): its kernels - k_viterbi alone is 384 000 wavefronts per chunk - then take the chip whenever they are
     // queued and the decode chains, which bound the engine, stand still meanwhile: 208-212 k subframes/s against 220-222 k with equal priorities,
     // 119 k against 129 k at 16 dB (profiles/r05_exp_session14.txt, r05_exp_session15.txt; decode chains ABOVE stage A: 219-220 k, then stage A is what
-    // the decode threads wait for).  LSN_STAGE_A_PRIO = 2 / 1 restores the highest / the normal level (A/B).
-    const int pa = getenv("LSN_STAGE_A_PRIO") ? atoi(getenv("LSN_STAGE_A_PRIO")) : 0;
-    for (auto& sa : stream_a) HIP_CHECK(hipStreamCreateWithPriority(&sa, hipStreamNonBlocking, pa >= 2 ? hi : (pa == 1 ? (lo + hi) / 2 : lo)));
+    // the decode threads wait for).
+    (void)hi;
+    for (auto& sa : stream_a) HIP_CHECK(hipStreamCreateWithPriority(&sa, hipStreamNonBlocking, lo));
   }
   HIP_CHECK(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
   trace_path = getenv("LSN_TRACE");
@@ -522,7 +515,6 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
   size_t pay_n = pay0;
   struct TbRef { int job, tb; uint32_t cb_first, cb_count; };
   std::vector<TbRef> tbrefs;
-  std::vector<uint8_t> cb_risky;   // per code block of r.h_cbs: its job is a table guess (DecodeJob::risky)
   std::vector<int> jid_of_hjob;
   for (int jid : todo) {
     DecodeJob& j = ch.jobs[jid];
@@ -585,7 +577,6 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
         wp += cb.out_bytes;
         rp += E;
         r.h_cbs.push_back(cb);
-        cb_risky.push_back(j.risky ? 1 : 0);
       }
       j.cb_count[i] = (uint32_t)s.C;
       pay_n += (wp + 15) & ~15u;
@@ -602,9 +593,8 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
   }
   // ONE decoder launch per phase (late round 4: + 5.7 % against one launch per wavefront class).  Round 5: the blocks of at most 64 windows - one working
   // wavefront - share workgroups two by two (k_turbo, stage_c.hip) instead of holding a whole LDS / wavefront slot each with the second wavefront idle:
-  // half of the metric's code blocks, half of the decoder's slot time.  LSN_TURBO_NO_PAIRS=1: every block alone in its workgroup (rounds 2-4).
-  static const bool no_pairs = getenv("LSN_TURBO_NO_PAIRS") && atoi(getenv("LSN_TURBO_NO_PAIRS"));
-  auto pairable = [&](uint32_t K) { return !no_pairs && K <= LSN_TURBO_PAIR_KMAX && lsn_turbo_nwin((int)K) <= 64; };
+  // half of the metric's code blocks, half of the decoder's slot time (every block alone in its workgroup, rounds 2-4: - 3 %, profiles/r05_ab_session*.txt).
+  auto pairable = [&](uint32_t K) { return K <= LSN_TURBO_PAIR_KMAX && lsn_turbo_nwin((int)K) <= 64; };
   const uint32_t njobs = (uint32_t)r.h_jobs.size(), ncb = (uint32_t)r.h_cbs.size();
   uint32_t kmax_solo = 0, kmax_pair = 0, emax = 0, nsolo[2] = {0, 0}, npair[2] = {0, 0};
   size_t spp_n = 0;
@@ -626,25 +616,19 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
     LsnCopySegs up;   // items, jobs and code-block descriptors go up in one launch
     std::memcpy(r.h_items_pinned, r.h_items.data(), nitems * sizeof(uint32_t));
     up.add(r.d_items, r.h_items_pinned, nitems * sizeof(uint32_t));
-    static const bool separate_upload = getenv("LSN_SEPARATE_UPLOAD") != nullptr;  // A/B: the descriptors go up in a launch of their own (rounds 1-4)
     std::memcpy(r.h_jobs_pinned, r.h_jobs.data(), njobs * sizeof(LsnGrantDev));
-    if (separate_upload) up.add(r.d_jobs, r.h_jobs_pinned, njobs * sizeof(LsnGrantDev));
     if (ncb) {
       // launch order: per phase the blocks that get a workgroup of their own first, then the blocks that share one; each class by descending size (longest
       // jobs first; the two blocks of a pair are neighbours in size, so their wavefronts run for about the same time)
       order.resize(ncb);
       for (uint32_t i = 0; i < ncb; i++) { r.h_cbs[i].res_idx = i; order[i] = i; }
       // two phases: first every block that nothing depends on having passed (block 0 of each transport block), then the dependants
-      // LSN_RISKY_FIRST=1 (round 5, measured neutral): blocks of attempts that may well be hopeless (a table guess for a UE whose table is not known: 12
-      // iterations when the guess is wrong) go to the front of their class - their 12 iterations then run UNDER the short blocks of the launch instead of behind them
-      static const bool risky_first = getenv("LSN_RISKY_FIRST") && atoi(getenv("LSN_RISKY_FIRST"));
       std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
         const bool dx = r.h_cbs[x].dep != LSN_CB_NODEP, dy = r.h_cbs[y].dep != LSN_CB_NODEP;
         if (dx != dy) return dy;
         const uint32_t kx = r.h_cbs[x].K, ky = r.h_cbs[y].K;
         const bool px = pairable(kx), py = pairable(ky);
         if (px != py) return py;
-        if (risky_first && cb_risky[x] != cb_risky[y]) return cb_risky[x] > cb_risky[y];
         if (kx != ky) return kx > ky;
         return x < y;
       });
@@ -660,18 +644,15 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
       up.add(r.d_cbs, r.h_cbs_pinned, ncb * sizeof(LsnCbDev));
     }
     const bool tk = timing_period && (r.launches++ % timing_period) == 0;   // prep / demod / rm: timed on a sample of the launches; the decoders on every launch
-    hipStream_t sl = r.stream_light ? r.stream_light : st;   // the light kernels of the chain (JobRunner::stream_light)
-    if (separate_upload) lsn_launch_copy_multi(up, false, sl);
+    hipStream_t sl = st;
     if (tk) HIP_CHECK(hipEventRecord(r.ev[0], sl));  // (no clear of the LLR arena: k_pdsch_demod writes every soft bit of every codeword it is given, zeros of unpaired SFBC REs included)
-    if (separate_upload) lsn_launch_pdsch_prep(cd, r.d_jobs, r.d_prefix, njobs, sl);
-    else lsn_launch_pdsch_prep_up(cd, r.h_jobs_pinned, r.d_jobs, njobs, up, r.d_prefix, sl);   // descriptors up + prefix tables in one launch
+    lsn_launch_pdsch_prep_up(cd, r.h_jobs_pinned, r.d_jobs, njobs, up, r.d_prefix, sl);   // descriptors up + prefix tables in one launch
     if (tk) HIP_CHECK(hipEventRecord(r.ev[1], sl));
     lsn_launch_pdsch_demod(cd, r.d_jobs, r.d_items, nitems, r.d_prefix, ch.d_grid, ch.d_ce, ch.d_chest, r.d_llr16, sl);
     if (tk) HIP_CHECK(hipEventRecord(r.ev[2], sl));
     if (ncb) {
       lsn_launch_rm(r.d_cbs, r.d_llr16, r.d_spp, ncb, emax, sl);
       if (timing_period) HIP_CHECK(hipEventRecord(r.ev[5], sl));
-      if (sl != st) { HIP_CHECK(hipEventRecord(r.ev_light, sl)); HIP_CHECK(hipStreamWaitEvent(st, r.ev_light, 0)); }
       // phase 0: the independent blocks [solo | paired], phase 1: the same of the dependants (descriptor order = launch order)
       lsn_launch_turbo_packed(cd, r.d_cbs, r.d_spp, r.d_payload, r.d_cbres, nsolo[0], kmax_solo, npair[0], kmax_pair, st);
       const uint32_t o1 = nsolo[0] + npair[0];
@@ -827,9 +808,9 @@ static bool same_decode(const PdschGrant& a, const PdschGrant& b)
 // wants exactly that attempt.  Measured in round 4 (LSN_SPECULATE_SECOND_TABLE=0): without them 6 % of the subframes need a decode inside the
 // sequential commit turn (one GPU round trip each) and the rate falls from 156 k to 56 k subframes/s; with them the engine runs 7 % more
 // turbo iterations.  Results are the same either way (the commit re-derives every decision).
-static const bool g_speculate_second_table = !(getenv("LSN_SPECULATE_SECOND_TABLE") && !atoi(getenv("LSN_SPECULATE_SECOND_TABLE")));
+static const bool g_speculate_second_table = true;
 
-static const bool g_hints = !(getenv("LSN_NO_TABLE_HINTS") && atoi(getenv("LSN_NO_TABLE_HINTS")));
+static const bool g_hints = true;
 int Engine::hintEvents(uint16_t rnti, uint32_t pos, uint32_t* lo_out) const
 {
   if (!g_hints || cfg.mcs_tracking_mode != 1) return -1;
@@ -866,7 +847,7 @@ void Engine::planJobs(Chunk& ch, JobRunner& r)
   // In-chunk learning (round 4): a UE whose table the plan does not know yet gets its first HINT_EVENTS teachable grants of the chunk decoded the
   // reference's way (64QAM table, then 256QAM table) - the rest wait for those verdicts in a third wave.  Before, all grants of a new 256QAM UE in
   // the chunks in flight (about 200 per UE) ran a hopeless 64QAM-table attempt the commit never read: 19 % of all turbo iterations.
-  static const bool g_defer = !(getenv("LSN_NO_DEFER") && atoi(getenv("LSN_NO_DEFER")));
+  static const bool g_defer = true;
   std::vector<std::pair<uint16_t, uint8_t>> seen;   // (rnti, teachable unknown-table grants so far in this chunk): a handful of UEs
   ch.ul_epoch = ul_cfg_epoch.load(std::memory_order_acquire);
   for (uint32_t sf = 0; sf < ch.nsf; sf++) search->finishSubframe(ch.ctx[sf]);  // DCI unpack, grants and collision statistics of every accepted DCI (deferred from the sequential search)
@@ -1237,7 +1218,7 @@ void Engine::harqStore(Chunk& ch, JobRunner& r, int job, int tb, size_t slot)
 {
   const DecodeJob& j = ch.jobs[job];
   const uint32_t n = j.keep_count[tb];
-  if (!n || n > HARQ_MAX_CB) return;
+  if (!n || n > HARQ_MAX_CB) { harq_keep.erase(slot); return; }   // nothing stored for this transmission: what the slot held belongs to an older one and must not be combined with
   grow_host(r.h_cbs_pinned, r.h_cbs_cap, n, r.stream);
   grow_dev(r.d_cbs, r.cbs_cap, n, r.stream);
   // cb_crc / data of the soft buffer: what passed in this (failed) transmission is remembered, a retransmission decodes the other blocks only
@@ -1428,7 +1409,11 @@ void Engine::commitLoop()
       r.perf.ms_commit += now_ms() - t1;
     } catch (const std::exception& ex) {
       err = ex.what();
-      harq_store_q.clear();   // (queued soft-buffer copies point into this chunk's keep store)
+      // The queued soft-buffer copies point into this chunk's keep store and never went out: what the slots were about to remember (harq_keep, and the
+      // database's "stored" marks behind it) no longer matches the pool.  A retransmission that later combined with such a slot would trust flags and
+      // bytes of a transmission whose soft bits never arrived (round-5 advisor finding): the turn failed, so the whole soft-buffer state is dropped -
+      // every later block of these processes is a new transmission, which costs combining gain for 8 subframes and nothing else.
+      if (cfg.harq_mode) { harq_store_q.clear(); harq_keep.clear(); harq_db = HarqDatabase(); }
     }
     {
       std::unique_lock<std::mutex> tl(sh->turn_mtx);
@@ -1577,9 +1562,8 @@ void Engine::frontLoop()
     }
     // (1) the next chunk of the current block
     if (have_job && inflight.size() < (size_t)NSTREAM_A) {
-      static const bool gpu_wait = getenv("LSN_FRONT_GPU_WAIT") != nullptr;  // A/B: order stage A behind the block on the GPU (barrier packet) instead of waiting here
       if (!ready_ok) {
-        const hipError_t q = gpu_wait ? hipSuccess : hipEventQuery(job.ready);
+        const hipError_t q = hipEventQuery(job.ready);   // the block is waited for HERE (a GPU-side wait would be a barrier packet in stage A's hardware queue)
         if (q != hipErrorNotReady) { (void)hipGetLastError(); ready_ok = true; }
       }
       Chunk& ch = chunks[slot_counter % (uint64_t)nslots];  // slots rotate across submits
@@ -1607,7 +1591,6 @@ void Engine::frontLoop()
         ch.trace_id = ci;
         trace(1, TR_ACQ_END, ci);
         try {
-          if (gpu_wait && job.ready) HIP_CHECK(hipStreamWaitEvent(ch.st_a, job.ready, 0));
           if (job.inject_fail == (int)ci) throw std::runtime_error("injected stage-A failure (LSN_INJECT_STAGE_A_ERROR)");
           launchStageA(ch, (const uint8_t*)job.d_iq + (size_t)base * sf_stride);
         } catch (const std::exception& ex) {
@@ -1803,11 +1786,7 @@ int Engine::submitFrom(const void* d_iq, int src_device, uint32_t nsf, uint32_t 
 // subframes/s at lowest, 96-101 k at default, 90-93 k at highest priority.  Default priority.
 void Engine::createCopyStream()
 {
-  int lo = 0, hi = 0;
-  (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-  static const int mode = getenv("LSN_COPY_STREAM_PRIO") ? atoi(getenv("LSN_COPY_STREAM_PRIO")) : 0;  // 0 default priority, 1 lowest, 2 highest
-  if (mode == 0) HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
-  else HIP_CHECK(hipStreamCreateWithPriority(&copy_stream, hipStreamNonBlocking, mode == 1 ? lo : hi));
+  HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
 }
 
 int Engine::submitHostRows(const void* host_rows, size_t row_pitch, uint32_t nsf, uint32_t start_tti, bool force_meta_first, hipEvent_t copied)

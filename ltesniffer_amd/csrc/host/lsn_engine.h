@@ -103,11 +103,6 @@ struct Chunk {
 // one stream + its device/host arenas for PDSCH decode launches
 struct JobRunner {
   hipStream_t stream = nullptr;
-  // LSN_LIGHT_STREAM=1 (round 5): the short, memory-bound kernels of a decode chain (descriptor upload + prefix tables, demodulation, rate de-matching)
-  // on a stream of their own at NORMAL priority, the turbo decoder behind them on `stream` at the lowest: when a resident decoder workgroup leaves, the
-  // dispatcher hands its wave slots and LDS to the queued light kernels of the other chains before the next decoder workgroup of a running launch
-  hipStream_t stream_light = nullptr;
-  hipEvent_t ev_light = nullptr;
   LsnGrantDev* d_jobs = nullptr; size_t jobs_cap = 0;
   LsnCbDev* d_cbs = nullptr; size_t cbs_cap = 0;
   LsnCbRes* d_cbres = nullptr; size_t cbres_cap = 0;

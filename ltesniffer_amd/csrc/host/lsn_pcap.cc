@@ -69,6 +69,7 @@ lsn_pcap_t* lsn_pcap_open(const char* path)
   lsn_pcap* p = new lsn_pcap();
   p->f = fopen(path, "wb");
   if (!p->f) { delete p; return nullptr; }
+  setvbuf(p->f, nullptr, _IOFBF, (size_t)4 << 20);  // records are a few hundred bytes each: one write() per 4 MB instead of one per 4 KB (0.7-1.6 GB/s of records at replay speed)
   p->header();
   return p;
 }

@@ -97,8 +97,6 @@ void Engine::freeRunner(JobRunner& r)
     if (e) { (void)hipEventDestroy(e); e = nullptr; }
   if (r.ev_done) { (void)hipEventDestroy(r.ev_done); r.ev_done = nullptr; }
   if (r.stream) { (void)hipStreamDestroy(r.stream); r.stream = nullptr; }
-  if (r.stream_light) { (void)hipStreamDestroy(r.stream_light); r.stream_light = nullptr; }
-  if (r.ev_light) { (void)hipEventDestroy(r.ev_light); r.ev_light = nullptr; }
 }
 
 void Engine::allocRunner(JobRunner& r)
@@ -109,30 +107,11 @@ void Engine::allocRunner(JobRunner& r)
   if (&r == &runner_s || &r == &runner_f || &r == &runner_u || &r == &runner_k) {
     HIP_CHECK(hipStreamCreateWithPriority(&r.stream, hipStreamNonBlocking, hi));
   } else {
-    // bulk decode streams: lowest priority.  (LSN_RESERVED_CUS = n > 0 masks n CUs out of them instead, so that the latency-critical launches -
-    // stage A, on-demand RAR decodes - never queue behind resident turbo workgroups: round 2's default.  Measured in round 3 with the ingest
-    // path fixed: CU-masked streams stand still while host -> device copies are in flight and cost 12 % of the resident rate - off by default.)
-    hipDeviceProp_t prop;
-    HIP_CHECK(hipGetDeviceProperties(&prop, cfg.device));
-    const int ncu = prop.multiProcessorCount;
-    const char* env = getenv("LSN_RESERVED_CUS");
-    const int reserve = env ? atoi(env) : 0;
-    std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
-    for (int i = 0; i < ncu; i++)
-      if (!(reserve > 0 && i % (ncu / (reserve > 0 ? reserve : 1)) == 0)) mask[i / 32] |= 1u << (i % 32);
-    if (reserve <= 0 || reserve >= ncu || hipExtStreamCreateWithCUMask(&r.stream, (uint32_t)mask.size(), mask.data()) != hipSuccess)
-      HIP_CHECK(hipStreamCreateWithPriority(&r.stream, hipStreamNonBlocking, lo));
+    // bulk decode streams: lowest priority.  (Round 2 masked a few CUs out of them instead; CU-masked streams stand still while host -> device copies
+    // are in flight on this runtime and cost 12 % of the resident rate: DESIGN 3.1, point 5.)
+    HIP_CHECK(hipStreamCreateWithPriority(&r.stream, hipStreamNonBlocking, lo));
   }
   for (auto& e : r.ev) HIP_CHECK(hipEventCreate(&e));
-  {
-    bool bulk_ = false;
-    for (int i = 0; i < NDEC; i++) bulk_ = bulk_ || &r == &runner_c[i];
-    const char* ls = getenv("LSN_LIGHT_STREAM");
-    if (bulk_ && ls && atoi(ls)) {
-      HIP_CHECK(hipStreamCreateWithPriority(&r.stream_light, hipStreamNonBlocking, atoi(ls) >= 2 ? hi : (lo + hi) / 2));  // 1: normal, 2: highest
-      HIP_CHECK(hipEventCreateWithFlags(&r.ev_light, hipEventDisableTiming));
-    }
-  }
   HIP_CHECK(hipEventCreateWithFlags(&r.ev_done, hipEventDisableTiming));  // waited for with Engine's poll-and-sleep waitEvent()
   // The arenas of a bulk decode runner start at the size a full chunk of a loaded cell needs (per subframe at 100 PRB: 16 decode calls, 32 code
   // blocks, 0.5 M soft bits, 128 K packed words, 24 KB of payload), scaled with the bandwidth: a fresh engine otherwise grows each of them several

@@ -10,9 +10,12 @@
 // A launch the runtime rejects (LDS request above the function's limit on this device, an empty or oversized grid, no code object for the
 // device) does not fail at the call site: the kernel never runs and the error sits in the thread until some later runtime call reports it -
 // stale results at the next event wait.  Every launcher therefore asks right behind its launch and throws; the engine's stage wrappers turn
-// the text into the chunk's error (round-4 review, weak 9).
+// the text into the chunk's error (round-4 review, weak 9).  The thread's error state is drained FIRST: the engine tolerates non-success codes elsewhere
+// (hipEventQuery's NotReady while polling, a best-effort hipMalloc), and a code left behind by one of those must not be blamed on this kernel
+// (round-5 advisor finding).
 #define LSN_LAUNCH(kernel, grid, block, lds, stream, ...)                                                                      \
   do {                                                                                                                         \
+    (void)hipGetLastError();                                                                                                   \
     hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                                         \
     const hipError_t _le = hipGetLastError();                                                                                  \
     if (_le != hipSuccess) throw std::runtime_error(std::string("launch of " #kernel " failed: ") + hipGetErrorString(_le));   \

@@ -485,11 +485,6 @@ __device__ __forceinline__ void lsn_dot4x2(int sw, int sa, int ca, int sb, int c
 {
   asm("v_dot4_i32_i8 %0, %2, %3, %4\n\tv_dot4_i32_i8 %1, %2, %5, %6\n\ts_nop 2" : "=&v"(da), "=&v"(db) : "v"(sw), "v"(sa), "v"(ca), "v"(sb), "v"(cb));
 }
-// the same for two symbol words and one sign word (two candidates per wavefront, viterbi_tb2)
-__device__ __forceinline__ void lsn_dot4_2sym(int swa, int swb, int sg, int cc, int& da, int& db)
-{
-  asm("v_dot4_i32_i8 %0, %2, %4, %5\n\tv_dot4_i32_i8 %1, %3, %4, %5\n\ts_nop 2" : "=&v"(da), "=&v"(db) : "v"(swa), "v"(swb), "v"(sg), "v"(cc));
-}
 // bits = bits * 2 + (x < y): the decision of this lane's state is shifted into the lane's own history word (compare + add-with-carry)
 __device__ __forceinline__ void lsn_push_lt(int& bits, int x, int y)
 {
@@ -588,113 +583,6 @@ __device__ __forceinline__ void viterbi_tb(const int* symw, uint32_t D_, uint32_
   bits_out = bits;
 }
 
-// TWO candidates of one payload size per wavefront, path metrics packed as two wrapping 16-bit halves (A | B << 16): one ds_bpermute per
-// predecessor moves both candidates (half the LDS crossbar traffic per candidate: the kernel's second bound next to vector issue), the
-// add-compare-select runs on packed forms.  16-bit metrics wrap, so every comparison is made on differences read as int16:
-// new metric = a0 + min(a1 - a0, 0), decision = sign of the difference.  Exact as long as |a1 - a0| < 2^15, i.e. the spread of a metric vector
-// plus one branch metric stays below 32 768; any state is reached from any state in 6 steps, so the spread is at most 6 x 765 = 4 590
-// (tools/viterbi_packed_design.py runs both decoders on noise, saturated noise and noisy code words: identical decisions and end states,
-// largest spread 2 541).  Branch metric of the second predecessor = 765 - that of the first (all three outputs complemented): one packed subtract
-// instead of two more v_dot4.  Decisions: bit 15 / bit 31 of the packed difference, shifted into the per-lane history words by v_alignbit.
-typedef unsigned short lsn_us2 __attribute__((ext_vector_type(2)));
-typedef short lsn_ss2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void viterbi_tb2(const int* symwA, const int* symwB, uint32_t D_, uint32_t nbits, int lane, unsigned long long& bits_out, uint32_t& rem_out)
-{
-  __syncthreads();
-  const int D = (int)D_;
-  const int b = lane & 1, s0 = lane >> 1;
-  const int c0 = b ^ (__popc(s0 & 0x36) & 1), c1 = b ^ (__popc(s0 & 0x27) & 1), c2 = b ^ (__popc(s0 & 0x2B) & 1);
-  const int signs = (c0 ? 0xFF : 0x01) | (c1 ? 0xFF00 : 0x0100) | (c2 ? 0xFF0000 : 0x010000);
-  const int k0c = (c0 ? 127 : 128) + (c1 ? 127 : 128) + (c2 ? 127 : 128);
-  const int pa = s0 << 2, pb = (s0 | 32) << 2;
-  const uint32_t c765 = 765u | (765u << 16);
-  uint32_t m = 0;
-  auto U = [](uint32_t x) { return __builtin_bit_cast(lsn_us2, x); };
-  auto W = [](lsn_us2 x) { return __builtin_bit_cast(uint32_t, x); };
-  // one trellis step of both candidates; returns the packed difference a1 - a0 (its sign bits are the decisions)
-  auto acs = [&](int k) -> uint32_t {
-    int bmA, bmB;
-    lsn_dot4_2sym(symwA[k], symwB[k], signs, k0c, bmA, bmB);
-    const uint32_t g0 = ((uint32_t)bmB << 16) | (uint32_t)bmA;          // v_lshl_or_b32: both metrics are in 0 .. 765
-    const uint32_t g1 = W(U(c765) - U(g0));
-    const uint32_t a0 = W(U((uint32_t)__builtin_amdgcn_ds_bpermute(pa, (int)m)) + U(g0));
-    const uint32_t a1 = W(U((uint32_t)__builtin_amdgcn_ds_bpermute(pb, (int)m)) + U(g1));
-    const uint32_t d = W(U(a1) - U(a0));
-    const lsn_ss2 mn = __builtin_elementwise_min(__builtin_bit_cast(lsn_ss2, d), lsn_ss2{0, 0});
-    m = W(U(a0) + __builtin_bit_cast(lsn_us2, mn));
-    return d;
-  };
-  {
-    int k = 0;
-    for (; k + 4 <= D; k += 4) { (void)acs(k); (void)acs(k + 1); (void)acs(k + 2); (void)acs(k + 3); }
-    for (; k < D; k++) (void)acs(k);
-  }
-  uint32_t hA2[3] = {0, 0, 0}, hA3[3] = {0, 0, 0}, hB2[3] = {0, 0, 0}, hB3[3] = {0, 0, 0};
-  auto sweep = [&](uint32_t* hA, uint32_t* hB) {
-#pragma unroll
-    for (int g = 0; g < 3; g++) {
-      const int k1 = D < 32 * (g + 1) ? D : 32 * (g + 1);
-      auto step = [&](int k) {
-        const uint32_t d = acs(k);
-        hB[g] = __builtin_amdgcn_alignbit(hB[g], d, 31);         // hB * 2 + bit 31 of d
-        hA[g] = __builtin_amdgcn_alignbit(hA[g], d << 16, 31);   // hA * 2 + bit 15 of d
-      };
-      int k = 32 * g;
-      for (; k + 4 <= k1; k += 4) { step(k); step(k + 1); step(k + 2); step(k + 3); }
-      for (; k < k1; k++) step(k);
-    }
-  };
-  sweep(hA2, hB2);
-  sweep(hA3, hB3);
-  // best end state of each candidate: minimum of the metrics relative to lane 0 (int16 differences), lowest index on ties
-  const uint32_t rel = W(U(m) - U((uint32_t)__builtin_amdgcn_readfirstlane((int)m)));
-  uint32_t keyA = ((uint32_t)((int)(short)(rel & 0xFFFFu) + 32768) << 6) | (uint32_t)lane;
-  uint32_t keyB = ((uint32_t)((int)(short)(rel >> 16) + 32768) << 6) | (uint32_t)lane;
-  for (int off = 32; off > 0; off >>= 1) {
-    const uint32_t oa = __shfl_xor(keyA, off), ob = __shfl_xor(keyB, off);
-    keyA = oa < keyA ? oa : keyA;
-    keyB = ob < keyB ? ob : keyB;
-  }
-  unsigned long long bitsv[2] = {0, 0};
-  unsigned int tailv[2] = {0, 0};
-  for (int c = 0; c < 2; c++) {
-    int st = __builtin_amdgcn_readfirstlane((int)((c ? keyB : keyA) & 63u));
-    unsigned long long bits = 0;
-    unsigned int tailcrc = 0;
-    auto back = [&](const uint32_t* h, bool emit) {
-#pragma unroll
-      for (int g = 2; g >= 0; g--) {
-        const int k1 = D < 32 * (g + 1) ? D : 32 * (g + 1);
-        for (int k = k1 - 1; k >= 32 * g; k--) {
-          if (emit) {
-            if (k < (int)nbits) bits |= (unsigned long long)(st & 1) << (63 - k);
-            else tailcrc |= (unsigned)(st & 1) << (15 - (k - (int)nbits));
-          }
-          const unsigned w = (unsigned)__builtin_amdgcn_readlane((int)h[g], st);
-          const int dd = (int)((w >> (k1 - 1 - k)) & 1u);
-          st = (st >> 1) | (dd << 5);
-        }
-      }
-    };
-    back(c ? hB3 : hA3, false);
-    back(c ? hB2 : hA2, true);
-    bitsv[c] = bits; tailv[c] = tailcrc;
-  }
-  // lane 0 finishes candidate A, lane 1 candidate B: CRC16 (x^16+x^12+x^5+1) over the payload, zero-augmented long division
-  const unsigned long long bits = lane == 1 ? bitsv[1] : bitsv[0];
-  const unsigned int tailcrc = lane == 1 ? tailv[1] : tailv[0];
-  rem_out = 0;
-  if (lane < 2) {
-    unsigned int reg = 0;
-    for (int i = 0; i < (int)nbits + 16; i++) {
-      unsigned int bit = i < (int)nbits ? (unsigned)((bits >> (63 - i)) & 1ull) : 0u;
-      reg = (reg << 1) | bit;
-      if (reg & 0x10000u) reg ^= 0x11021u;
-    }
-    rem_out = (tailcrc ^ reg) & 0xFFFFu;
-  }
-  bits_out = bits;
-}
 
 // One wavefront per (location, size, subframe).  Rate de-matching is a gather through a host-built rank table;
 // u8 quantisation 127.5 + 32*llr (truncated); 32-bit path metrics; 3 passes over the tail-biting block, middle pass kept.
@@ -704,90 +592,8 @@ __device__ __forceinline__ void viterbi_tb2(const int* symwA, const int* symwB, 
 // ballots are stored by a uniform, branch-free LDS write; the trace-back covers only passes 2 and 3, fetches 64 ballot
 // words per LDS read (one per lane) and then walks them with v_readlane + scalar shifts instead of one dependent LDS
 // round trip per step.
-// LSN_VITERBI_PAIRED: the two-candidates-per-wavefront variant (viterbi_tb2 above).  Built and measured in round 4 (tools/ab_build.sh with
-// -DLSN_VITERBI_PAIRED on stage_a): candidate tables bit-identical, half the ds_bpermute traffic - and the same 0.86 ms per 400-subframe launch alone,
-// 166.1 k against 166.7 k subframes/s in the pipeline, with 40 % MORE vector instructions per subframe (the two trace-backs and CRC divisions of a
-// wavefront no longer stay in scalar registers).  The kernel is bound by the dependent add-compare-select chain at eight wavefronts per SIMD, not by
-// the LDS crossbar; the one-candidate kernel stays the product.
-#ifdef LSN_VITERBI_PAIRED
-__global__ __launch_bounds__(64) void k_viterbi(LsnCellDev c, const float* __restrict__ llr, const float* __restrict__ pw,
-                                                const uint32_t* __restrict__ cfi_arr, const uint32_t* __restrict__ sf_idx_arr,
-                                                LsnCand* __restrict__ cand)
-{
-  // per trellis step: (q0 - 128) | (q1 - 128) << 8 | (q2 - 128) << 16, signed bytes; one array per candidate of the pair (locations 2 bx, 2 bx + 1)
-  __shared__ __attribute__((aligned(16))) int symw[2][LSN_MAX_DCI_D + 4];
-  const int lane = threadIdx.x, sf = blockIdx.z, sz = blockIdx.y;
-  const uint32_t ncce_tot = c.nof_cce[cfi_arr[sf] - 1];
-  const uint32_t lim = ncce_tot < LSN_MAX_NUM_OF_CCE ? ncce_tot : LSN_MAX_NUM_OF_CCE;
-  const uint32_t nbits = c.sizes[sz], D = nbits + 16, D3 = 3 * D;
-  const uint16_t* rank = c.rankmap + sz * 3 * LSN_MAX_DCI_D;
-  bool okv[2];
-  uint32_t nccev[2];
-  int Lv[2];
-  LsnCand* outv[2];
-  for (int q = 0; q < 2; q++) {
-    int li = 2 * (int)blockIdx.x + q;
-    outv[q] = cand + ((size_t)sf * LSN_MAX_LOC + (size_t)li) * LSN_MAX_SIZES + sz;
-    // location enumeration of srsran_pdcch_ue_locations_all_map (falcon_pdcch.c:321-356)
-    int L = -1; uint32_t ncce = 0;
-    if (li < LSN_MAX_LOC)
-      for (int l = 3; l >= 0; l--) {
-        int cnt = (int)(lim >> l);
-        if (li < cnt) { L = l; ncce = ((uint32_t)li % (ncce_tot >> l)) << l; break; }
-        li -= cnt;
-      }
-    bool ok = L >= 0;
-    const uint32_t E = ok ? (72u << L) : 0u;
-    if (ok && ncce * 72 + E > ncce_tot * 72) ok = false;
-    if (ok) {
-      for (uint32_t i = 0; i < (1u << L); i++)
-        if (pw[sf * LSN_CCE_STRIDE + ncce + i] < 0.7f) ok = false;  // location->sufficient_power (falcon_pdcch.c:610-614)
-    }
-    bool nz = false;
-    if (ok) {
-      const float* e = llr + (size_t)sf * LSN_LLR_STRIDE + ncce * 72;
-      for (uint32_t t = lane; t < D; t += 64) {
-        uint32_t word = 0;
-#pragma unroll
-        for (uint32_t j = 0; j < 3; j++) {
-          float acc = 0.0f;
-          bool first = true;
-          for (uint32_t k = rank[3 * t + j]; k < E; k += D3) {
-            float v = e[k];
-            if (v != 0.0f) nz = true;
-            if (first) { acc = v; first = false; } else acc = acc + v;
-          }
-          float qv = 127.5f + 32.0f * acc;
-          qv = qv < 0.0f ? 0.0f : qv;
-          qv = qv > 255.0f ? 255.0f : qv;
-          word |= (((uint32_t)(unsigned char)qv - 128u) & 0xFFu) << (8 * j);
-        }
-        symw[q][t] = (int)word;
-      }
-      if (__ballot(nz) == 0ull) ok = false;  // mean |llr| == 0: the reference skips the decode (falcon_pdcch.c:141)
-    }
-    if (!ok)
-      for (uint32_t t = lane; t < D; t += 64) symw[q][t] = 0;  // the other candidate of the pair still decodes; this half's result is dropped
-    okv[q] = ok; nccev[q] = ncce; Lv[q] = L;
-  }
-  if (!okv[0] && !okv[1]) {
-    if (lane < 2 && 2 * (int)blockIdx.x + lane < LSN_MAX_LOC) { outv[lane]->bits = 0; outv[lane]->rnti = 0; outv[lane]->flags = 0; }
-    return;
-  }
-  unsigned long long bits; uint32_t rnti;
-  viterbi_tb2(symw[0], symw[1], D, nbits, lane, bits, rnti);
-  if (lane < 2 && 2 * (int)blockIdx.x + lane < LSN_MAX_LOC) {
-    LsnCand* out = outv[lane];
-    if (okv[lane]) {
-      out->bits = bits;
-      out->rnti = rnti;
-      out->flags = 1u | (ss_validate(ncce_tot, nccev[lane], (uint32_t)Lv[lane], sf_idx_arr[sf], rnti) << 1);  // bit 0: decoded, bits 1-2: search-space match
-    } else {
-      out->bits = 0; out->rnti = 0; out->flags = 0;
-    }
-  }
-}
-#else
+// A two-candidates-per-wavefront variant on packed wrapping 16-bit metrics was built and measured in round 4 (bit-identical candidate tables, half the ds_bpermute
+// traffic, 40 % more vector instructions, the same launch time and pipeline rate: DESIGN 5.2, tools/viterbi_packed_design.py); it is not part of the product.
 __global__ __launch_bounds__(64) void k_viterbi(LsnCellDev c, const float* __restrict__ llr, const float* __restrict__ pw,
                                                 const uint32_t* __restrict__ cfi_arr, const uint32_t* __restrict__ sf_idx_arr,
                                                 LsnCand* __restrict__ cand)
@@ -850,7 +656,6 @@ __global__ __launch_bounds__(64) void k_viterbi(LsnCellDev c, const float* __res
     out->flags = 1u | (ss_validate(ncce_tot, ncce, (uint32_t)L, sf_idx_arr[sf], rnti) << 1);  // bit 0: decoded, bits 1-2: search-space match
   }
 }
-#endif
 // ------------------------------------------------------------------------------------------------ PBCH / MIB
 // srsran_ue_mib_decode on subframe 0 (LTESniffer_Core.cc:382-395).  k_pbch_llr: one workgroup; the 240 PBCH symbols
 // (72 centre carriers of symbols 7-10, CRS positions of four ports left out) are equalised like a REG (MRC or SFBC pairs),
@@ -976,11 +781,7 @@ void lsn_launch_pbch(const LsnCellDev& c, const cf32* grid, const cf32* ce, cons
 void lsn_launch_viterbi(const LsnCellDev& c, const float* llr, const float* pw, const uint32_t* cfi, const uint32_t* sf_idx, LsnCand* cand, uint32_t nsf,
                         hipStream_t s)
 {
-#ifdef LSN_VITERBI_PAIRED
-  LSN_LAUNCH(k_viterbi, dim3((LSN_MAX_LOC + 1) / 2, c.nsizes, nsf), dim3(64), 0, s, c, llr, pw, cfi, sf_idx, cand);
-#else
   LSN_LAUNCH(k_viterbi, dim3(LSN_MAX_LOC, c.nsizes, nsf), dim3(64), 0, s, c, llr, pw, cfi, sf_idx, cand);
-#endif
 }
 
 // SubframePower::computePower (SubframePower.cc:18-42) linear part: sum over 14 symbols of mean |x|^2 per PRB (antenna 0).  The per-symbol terms come from
@@ -1070,8 +871,6 @@ void lsn_launch_copy_multi(const LsnCopySegs& sg, bool to_host, hipStream_t s)
 void lsn_launch_download(void* dst_pinned, const void* src_dev, size_t bytes, hipStream_t s)
 {
   if (!bytes) return;
-  static const bool use_memcpy = getenv("LSN_MIRROR_MEMCPY") && atoi(getenv("LSN_MIRROR_MEMCPY"));  // A/B: the copy engine instead of the copy kernel
-  if (use_memcpy) { (void)hipMemcpyAsync(dst_pinned, src_dev, bytes, hipMemcpyDeviceToHost, s); return; }
   const bool al = (((uintptr_t)dst_pinned | (uintptr_t)src_dev) & 15u) == 0;
   const uint32_t words = (uint32_t)((bytes + 3) / 4), n16 = al ? words / 4 : 0, tail_first = n16 * 4, tail_n = words - tail_first;
   if (!al || tail_n > 256) {  // unaligned buffers: word copy

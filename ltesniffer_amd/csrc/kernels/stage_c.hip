@@ -648,15 +648,12 @@ void lsn_launch_turbo(const LsnCellDev& c, const LsnCbDev* cb, const uint32_t* s
 void lsn_launch_turbo_packed(const LsnCellDev& c, const LsnCbDev* cb, const uint32_t* spp, uint8_t* payload, LsnCbRes* res, uint32_t nsolo, uint32_t kmax_solo,
                              uint32_t npair, uint32_t kmax_pair, hipStream_t s)
 {
-  // LSN_TURBO_MIN_LDS=<bytes> (round 5 experiment, negative: profiles/r05_experiments.txt): a launch asks for at least this much LDS per workgroup, i.e. FEWER
-  // decoder workgroups per CU (54 000: three instead of four)
-  static const size_t min_lds = getenv("LSN_TURBO_MIN_LDS") ? std::min<size_t>((size_t)atol(getenv("LSN_TURBO_MIN_LDS")), 160u * 1024u) : 0;
   static std::atomic<uint64_t> attr128{0};
-  lsn_func_max_lds((const void*)k_turbo<128>, (int)std::max(turbo_lds_bytes_nt(6144, 128), min_lds), attr128, "k_turbo<128>");
+  lsn_func_max_lds((const void*)k_turbo<128>, (int)turbo_lds_bytes_nt(6144, 128), attr128, "k_turbo<128>");
   auto fix = [](uint32_t k) { return ((k < 512 ? 512u : k) + 7u) & ~7u; };  // the scratch in the check-point area needs room
   if (!nsolo && !npair) return;
   const uint32_t ks = nsolo ? fix(kmax_solo) : 512u, kp = npair ? fix(kmax_pair) : 512u;
   const size_t pair_lds = npair ? 12 * ((size_t)kp + 8) + 2 * TB_CKPT_BYTES : 0;   // spp0 spp1 ext0 ext1 ckpt0 ckpt1 (k_turbo)
-  const size_t lds = std::max(std::max(nsolo ? turbo_lds_bytes_nt(ks, 128) : (size_t)0, pair_lds), min_lds);
+  const size_t lds = std::max(nsolo ? turbo_lds_bytes_nt(ks, 128) : (size_t)0, pair_lds);
   LSN_LAUNCH(k_turbo<128>, dim3(nsolo + (npair + 1) / 2), dim3(128), lds, s, c.crc_tab_a, c.crc_tab_b, c.turbo_il, cb, spp, payload, res, ks, nsolo, nsolo + npair, kp);
 }
