@@ -771,7 +771,7 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
       // so that the commit thread never touches the payload
       if (j.crc[t.tb] && tbs >= 8 && cfg.sniffer_mode == 0 && rnti_name(j.rnti)[0] == 'C') {
         UeSpecConfig sc[20];
-        const int n = MCSTracking::setups_of_pdu(pl, tbs / 8, sc, 20);
+        const int n = MCSTracking::setups_of_pdu(pl, tbs / 8, sc, 20, true);   // every SDU: which of them count is the commit's decision (known-table branch: LCID 0 only)
         if (n > 0) {
           jr.setup_first[t.tb] = (uint32_t)ch.setup_cfgs.size();
           jr.nsetup[t.tb] = (uint8_t)n;
@@ -1124,8 +1124,8 @@ void Engine::commitChunk(Chunk& ch, JobRunner& r)
         PdschGrant g = t ? e.grant256 : e.grant64;
         return -dl_sniffer_config_mimo(cell, e.format, e.dci, g);
       };
-      auto learn = [&](const JobRes& jr, int tb) {  // :1041-1070 with the PDU walked ahead of time (runJobs)
-        if (jr.nsetup[tb] && mcs_tracking.learn_setups(ch.setup_cfgs.data() + jr.setup_first[tb], jr.nsetup[tb], d.rnti, now))
+      auto learn = [&](const JobRes& jr, int tb, bool any_lcid) {  // :1041-1070 / :1133-1160 with the PDU walked ahead of time (runJobs)
+        if (jr.nsetup[tb] && mcs_tracking.learn_setups(ch.setup_cfgs.data() + jr.setup_first[tb], jr.nsetup[tb], d.rnti, now, any_lcid))
           default_p_a.store(mcs_tracking.default_p_a(), std::memory_order_relaxed);
       };
       bool crc[2] = {false, false};   // pdsch_res[].crc as the statistics see it at the end of the iteration
@@ -1160,7 +1160,7 @@ void Engine::commitChunk(Chunk& ch, JobRunner& r)
               if (name[0] == 'R') unpackRar(ch.h_payload.data() + poff, jr.len[tb], false);
               if (name[0] == 'C') {
                 if (combined) learnUeConfig(ch.h_payload.data() + poff, jr.len[tb], d.rnti);  // (not pre-parsed: the block was decoded in this turn)
-                else learn(jr, tb);
+                else learn(jr, tb, false);
               }
             }
           }
@@ -1175,7 +1175,7 @@ void Engine::commitChunk(Chunk& ch, JobRunner& r)
             if (crc[tb] && jr.len[tb] > 0) {
               emitPdu(ch, r, name, jr.payload_off[tb], (uint32_t)jr.len[tb], d.rnti, c.tti, (uint8_t)tb);
               if (name[0] == 'R') unpackRar(ch.h_payload.data() + jr.payload_off[tb], jr.len[tb], false);
-              if (name[0] == 'C') learn(jr, tb);  // :1133-1160
+              if (name[0] == 'C') learn(jr, tb, true);  // :1133-1160: every SDU, whatever its logical channel
               if (d.mcs_idx[tb] > 0 && d.mcs_idx[tb] < 29 && d.format > FORMAT1A) mcs_tracking.update_RNTI_dl(d.rnti, TABLE_64QAM, now);
             }
           }

@@ -754,25 +754,30 @@ void MCSTracking::update_ue_config_rnti(uint16_t rnti, const UeSpecConfig& c, ui
   add_RNTI_dl(rnti, now);
   ue_cfg[rnti] = c;
 }
-int MCSTracking::setups_of_pdu(const uint8_t* pdu, int len, UeSpecConfig* out, int cap)
+int MCSTracking::setups_of_pdu(const uint8_t* pdu, int len, UeSpecConfig* out, int cap, bool any_lcid)
 {
   MacSubheader sub[20];
   const int n = mac_dlsch_parse(pdu, len, sub, 20);
   int k = 0;
   for (int i = 0; i < n && k < cap; i++) {
-    if (!(sub[i].is_sdu && sub[i].lcid == 0)) continue;
+    if (!(sub[i].is_sdu && (any_lcid || sub[i].lcid == 0))) continue;
     UeSpecConfig c;
-    if (rrc_conn_setup_decode(pdu + sub[i].off, (int)sub[i].len, c)) out[k++] = c;
+    if (rrc_conn_setup_decode(pdu + sub[i].off, (int)sub[i].len, c)) { c.from_lcid0 = sub[i].lcid == 0; out[k++] = c; }
   }
   return k;
 }
-bool MCSTracking::learn_setups(const UeSpecConfig* c, int n, uint16_t rnti, uint32_t now)
+bool MCSTracking::learn_setups(const UeSpecConfig* c, int n, uint16_t rnti, uint32_t now, bool any_lcid)
 {
+  bool any = false;
   for (int i = 0; i < n; i++) {
-    if (!has_default) update_default_ue_config(c[i]);  // the first connection setup seen, DL_Sniffer_PDSCH.cc:1061-1065
-    update_ue_config_rnti(rnti, c[i], now);
+    if (!any_lcid && !c[i].from_lcid0) continue;
+    UeSpecConfig u = c[i];
+    u.from_lcid0 = true;
+    if (!has_default) update_default_ue_config(u);  // the first connection setup seen, DL_Sniffer_PDSCH.cc:1061-1065
+    update_ue_config_rnti(rnti, u, now);
+    any = true;
   }
-  return n > 0;
+  return any;
 }
 bool MCSTracking::learn_from_pdu(const uint8_t* pdu, int len, uint16_t rnti, uint32_t now)
 {

@@ -167,6 +167,7 @@ struct UeSpecConfig {  // ltesniffer_ue_spec_config_t, MCSTracking.h:37-43
   float p_a = 0.0f;                                         // dB
   uint32_t i_offset_ack = 10, i_offset_cqi = 8, i_offset_ri = 11;  // MCSTracking::set_default_of_default_config, MCSTracking.cc:1531-1540
   uint32_t cqi_type = 2;                                    // 0 wideband, 1 UE-selected sub-band, 2 higher-layer sub-band
+  bool from_lcid0 = true;                                   // (book-keeping of setups_of_pdu: the SDU this came from sat on logical channel 0)
 };
 // PDSCH_Decoder::decode_rrc_connection_setup: true when the CCCH SDU is an RRCConnectionSetup (out filled)
 bool rrc_conn_setup_decode(const uint8_t* sdu, int len, UeSpecConfig& out);
@@ -214,8 +215,10 @@ public:
   // one decoded C-RNTI transport block: every CCCH SDU is tried as RRCConnectionSetup (DL_Sniffer_PDSCH.cc:1041-1070); true when one was
   bool learn_from_pdu(const uint8_t* pdu, int len, uint16_t rnti, uint32_t now);
   // the same with the PDU already walked (setups_of_pdu): the commit thread applies what a decode thread parsed
-  bool learn_setups(const UeSpecConfig* c, int n, uint16_t rnti, uint32_t now);
-  static int setups_of_pdu(const uint8_t* pdu, int len, UeSpecConfig* out, int cap);  // RRCConnectionSetups among the CCCH SDUs, in order
+  // any_lcid: also the ones that did not come on logical channel 0 - the 64QAM-table attempt of decode_dl_mode's unknown-table branch tries EVERY SDU of the block
+  // (DL_Sniffer_PDSCH.cc:1140 has no LCID test; the known-table branch, :1049, and run_decode, :286, have)
+  bool learn_setups(const UeSpecConfig* c, int n, uint16_t rnti, uint32_t now, bool any_lcid = false);
+  static int setups_of_pdu(const uint8_t* pdu, int len, UeSpecConfig* out, int cap, bool any_lcid = false);  // RRCConnectionSetups among the SDUs, in order (from_lcid0 says which)
   McsTable find_tracking_info_RNTI_dl(uint16_t rnti, uint32_t now);  // refreshes the entry's time stamp (:778-779)
   void update_RNTI_dl(uint16_t rnti, McsTable t, uint32_t now);
   void update_rar_time_crnti(uint16_t crnti, uint32_t now);

@@ -389,6 +389,13 @@ uint32_t o_worker_collect_end(o_worker_t* w, uint32_t* dl, uint32_t dl_cap, uint
 void o_worker_collect_mcs_update(o_worker_t* w, uint16_t rnti, int table);
 void o_worker_collect_harq_update(o_worker_t* w, uint16_t rnti, int pid, int tid, uint32_t sfn, uint32_t sf_idx, int decoded, int ndi, int rv, int tbs);
 void o_worker_collect_set_hop_offset(o_worker_t* w, uint32_t n_rb_ho);
+/* probes for tests/test_ref_decode.py: decode_dl_mode on the collected entries, every decode call answered by a scripted decoder (call16 = {tti, rnti, nof_re, tx_scheme,
+ * pmi, nof_layers, per block: enabled, modulation bits, tbs, rv, cw_idx}; it writes the payloads and two CRC verdicts) */
+void o_worker_set_script_decoder(o_worker_t* w, int (*fn)(void* user, const uint32_t* call16, float p_a, uint8_t* payload0, uint8_t* payload1, int32_t* crc2), void* user);
+void o_worker_collect_set_now(o_worker_t* w, uint32_t subframes);
+void o_worker_collect_decode_dl_mode(o_worker_t* w);
+int o_worker_collect_find_table(o_worker_t* w, uint16_t rnti);
+void o_worker_collect_update_database(o_worker_t* w);
 
 #ifdef __cplusplus
 }

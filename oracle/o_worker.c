@@ -112,6 +112,9 @@ struct o_worker {
   uint32_t *ul_time, *ul_active, *ul_success; /* [65536] ul_sniffer_tracking_t::time (subframes), nof_active, nof_success_mgs */
   float last_ul_snr;  /* enb_ul.chest_res.snr_db: the estimate of the most recent PUSCH attempt (UL_Sniffer_PUSCH.cc:572) */
   uint32_t nof_ul_updates;
+  /* scripted decoder (tests/test_ref_decode.py): when set, a decode call is described to this function instead of being demodulated and decoded */
+  int (*script_fn)(void* user, const uint32_t* call16, float p_a, uint8_t* payload0, uint8_t* payload1, int32_t* crc2);
+  void* script_user;
 };
 
 
@@ -259,13 +262,14 @@ static void ul_add(o_worker_t* w, uint16_t rnti, int mod)
   w->uecfg[rnti].has_ue_config = 0;
 }
 /* a decoded C-RNTI transport block: sch_pdu walk, every CCCH SDU (LCID 0) is tried as RRCConnectionSetup; the first one ever
- * seen also becomes the default of RNTIs without entry (DL_Sniffer_PDSCH.cc:1041-1070, 1133-1160) */
-static void learn_conn_setup(o_worker_t* w, const uint8_t* pdu, int len, uint16_t rnti)
+ * seen also becomes the default of RNTIs without entry (DL_Sniffer_PDSCH.cc:1041-1070).  any_lcid: the 64QAM-table attempt of the unknown-table branch
+ * tries EVERY SDU, whatever its logical channel (:1140 has no LCID test) - found by the pin on the compiled reference (tests/test_ref_decode.py) */
+static void learn_conn_setup(o_worker_t* w, const uint8_t* pdu, int len, uint16_t rnti, int any_lcid)
 {
   o_mac_subh_t sub[20];
   const int n = o_mac_dlsch_parse(pdu, len, sub, 20);
   for (int i = 0; i < n; i++) {
-    if (!(sub[i].is_sdu && sub[i].lcid == 0)) continue;
+    if (!(sub[i].is_sdu && (any_lcid || sub[i].lcid == 0))) continue;
     o_ue_cfg_t c;
     if (!o_rrc_conn_setup_decode(pdu + sub[i].off, (int)sub[i].len, &c)) continue;
     if (!w->has_default_cfg) {
@@ -791,6 +795,20 @@ static void decode_grant_harq(o_worker_t* w, const dl_entry_t* e, const o_pdsch_
 {
   crc[0] = crc[1] = 0;
   if (!(g->tb[0].enabled || g->tb[1].enabled)) return;
+  if (w->script_fn) { /* the decode call as srsran_ue_dl_decode_pdsch would receive it: {tti, rnti, nof_re, tx_scheme, pmi, nof_layers, per block: enabled, modulation bits, tbs, rv, cw_idx} */
+    uint32_t call[16] = {w->sfn * 10 + w->sf_idx, e->rnti, g->nof_re, (uint32_t)g->tx_scheme, g->pmi, g->nof_layers};
+    for (int i = 0; i < 2; i++) {
+      uint32_t* t = call + 6 + 5 * i;
+      t[0] = (uint32_t)g->tb[i].enabled; t[1] = g->tb[i].enabled ? (uint32_t)g->tb[i].mod : 0; t[2] = g->tb[i].enabled ? (uint32_t)g->tb[i].tbs : 0;
+      t[3] = g->tb[i].enabled ? (uint32_t)g->tb[i].rv : 0; t[4] = g->tb[i].enabled ? g->tb[i].cw_idx : 0;
+    }
+    int32_t c2[2] = {0, 0};
+    w->script_fn(w->script_user, call, w->ul_mode ? -3.0f : ue_cfg_get(w, e->rnti).p_a, w->payload, w->payload + 16384, c2);
+    for (int i = 0; i < 2; i++)
+      if (g->tb[i].enabled && g->tb[i].tbs > 0) crc[i] = c2[i] != 0;
+    (void)acc; (void)combine; (void)keep;
+    return;
+  }
   memset(w->llr0, 0, sizeof(int16_t) * g->nof_re * 8);
   memset(w->llr1, 0, sizeof(int16_t) * g->nof_re * 8);
   /* pdsch_cfg->p_a: the UE's p-a from its RRCConnectionSetup (or the default) in DL mode, DL_Sniffer_PDSCH.cc:926-927; the UL-mode
@@ -872,7 +890,7 @@ static void decode_dl_mode(o_worker_t* w)
           if (crc[tb] && len > 0) {
             write_pcap(w, name, w->payload + tb * 16384, (uint32_t)len, e->rnti, tti);
             if (name[0] == 'R') unpack_rar(w, w->payload + tb * 16384, len);
-            if (name[0] == 'C') learn_conn_setup(w, w->payload + tb * 16384, len, e->rnti);
+            if (name[0] == 'C') learn_conn_setup(w, w->payload + tb * 16384, len, e->rnti, 0);
           }
         }
       }
@@ -885,7 +903,7 @@ static void decode_dl_mode(o_worker_t* w)
           if (crc[tb] && len > 0) {
             write_pcap(w, name, w->payload + tb * 16384, (uint32_t)len, e->rnti, tti);
             if (name[0] == 'R') unpack_rar(w, w->payload + tb * 16384, len);
-            if (name[0] == 'C') learn_conn_setup(w, w->payload + tb * 16384, len, e->rnti);
+            if (name[0] == 'C') learn_conn_setup(w, w->payload + tb * 16384, len, e->rnti, 1);
             if (e->dci.tb[tb].mcs_idx > 0 && e->dci.tb[tb].mcs_idx < 29 && e->format > O_FMT1A) mcs_update(w, e->rnti, O_TABLE_64QAM);
           }
         }
@@ -1036,7 +1054,7 @@ static void decode_ul_mode_dl(o_worker_t* w, ulslot_t* rar_out)
         for (int tb = 0; tb < 2; tb++)
           if (crc[tb]) {
             write_pcap(w, rnti_name(e->rnti), w->payload + tb * 16384, (uint32_t)(cur->tb[tb].tbs / 8), e->rnti, tti);
-            learn_conn_setup(w, w->payload + tb * 16384, cur->tb[tb].tbs / 8, e->rnti); /* run_decode, :279-306: betaOffset indices + CQI mode for the PUSCH decoder */
+            learn_conn_setup(w, w->payload + tb * 16384, cur->tb[tb].tbs / 8, e->rnti, 0); /* run_decode, :279-306: betaOffset indices + CQI mode for the PUSCH decoder */
           }
       }
     }
@@ -1327,3 +1345,10 @@ void o_worker_collect_harq_update(o_worker_t* w, uint16_t rnti, int pid, int tid
   if (ent && (verdict == O_HARQ_NEW_TX || verdict == O_HARQ_RE_TX)) harq_update(w, ent, pid, tid, sfn, sf_idx, decoded, ndi, rv, tbs); /* :1008-1014 */
 }
 void o_worker_collect_set_hop_offset(o_worker_t* w, uint32_t n_rb_ho) { w->cfg.cell.pusch_hop_offset = n_rb_ho; }
+
+/* ---- probes for tests/test_ref_decode.py: PDSCH_Decoder::decode_dl_mode (decode_dl_mode above) on the collected entries with a scripted decoder ---- */
+void o_worker_set_script_decoder(o_worker_t* w, int (*fn)(void*, const uint32_t*, float, uint8_t*, uint8_t*, int32_t*), void* user) { w->script_fn = fn; w->script_user = user; }
+void o_worker_collect_set_now(o_worker_t* w, uint32_t subframes) { w->sf_count = subframes; }
+void o_worker_collect_decode_dl_mode(o_worker_t* w) { decode_dl_mode(w); }
+int o_worker_collect_find_table(o_worker_t* w, uint16_t rnti) { return mcs_find(w, rnti); } /* MCSTracking::find_tracking_info_RNTI_dl: refreshes the entry's time stamp */
+void o_worker_collect_update_database(o_worker_t* w) { mcs_update_database(w); }

@@ -1,0 +1,3 @@
+/* see srsran/standin_l2.h */
+#pragma once
+#include "srsran/standin_l2.h"

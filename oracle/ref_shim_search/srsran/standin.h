@@ -147,6 +147,19 @@ typedef struct {
   srsran_cell_t cell; uint32_t nof_rx_antennas; srsran_pdcch_t pdcch; srsran_chest_dl_res_t chest_res; cf_t* sf_symbols[SRSRAN_MAX_PORTS];
 } srsran_ue_dl_t;
 
+/* what PDSCH_Decoder hands to the PDSCH decoder and gets back (DL_Sniffer_PDSCH.cc): the members it touches */
+typedef struct { srsran_softbuffer_rx_t* rx[SRSRAN_MAX_CODEWORDS]; } srsran_pdsch_softbuffers_standin_t;
+typedef struct {
+  srsran_pdsch_grant_t grant; uint16_t rnti; srsran_pdsch_softbuffers_standin_t softbuffers; float p_a; bool use_tbs_index_alt, power_scale, csi_enable, meas_evm_en, meas_time_en;
+  uint32_t max_nof_iterations; int decoder_type;
+} srsran_pdsch_cfg_t;
+typedef struct { uint8_t* payload; bool crc; float avg_iterations_block, evm; uint32_t ack_value; } srsran_pdsch_res_t;
+#define ZERO_OBJECT(x) memset(&(x), 0x0, sizeof((x)))
+uint8_t* srsran_vec_u8_malloc(uint32_t len);
+void srsran_vec_u8_zero(uint8_t* ptr, uint32_t nsamples);
+void srsran_softbuffer_rx_reset_tbs(srsran_softbuffer_rx_t* q, uint32_t tbs);
+int srsran_ue_dl_decode_pdsch(srsran_ue_dl_t* q, srsran_dl_sf_cfg_t* sf, srsran_pdsch_cfg_t* pdsch_cfg, srsran_pdsch_res_t data[SRSRAN_MAX_CODEWORDS]);
+
 /* functions the compiled reference files call (definitions: search_glue.cc) */
 uint32_t srsran_dci_format_sizeof(const srsran_cell_t* cell, srsran_dl_sf_cfg_t* sf, srsran_dci_cfg_t* cfg, srsran_dci_format_t format);
 const char* srsran_dci_format_string(srsran_dci_format_t format);
