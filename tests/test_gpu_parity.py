@@ -212,6 +212,21 @@ def test_frequency_selective_channel_and_cfo():
     _run("cfg2", 20, seed=37, delay_samples=9, cfo_hz=450.0)
 
 
+@pytest.mark.parametrize("model,doppler,snr,at_least", [(1, 5.0, 22.0, 400), (2, 70.0, 24.0, 300), (3, 70.0, 30.0, 20), (3, 300.0, 26.0, 1)])
+def test_multipath_fading_channels_of_ts_36_101(model, doppler, snr, at_least):
+    """EPA 5 Hz / EVA 70 Hz / ETU 300 Hz (TS 36.101 Annex B.2: seven / nine taps, an independent Rayleigh process per rx antenna, CRS port and tap, a fractional
+    sampling offset on top): the estimator's smoothing and interpolation, the equalisers and the decoders on frequency-selective, time-varying channels - every stage
+    tap, every soft bit, every code block's iteration count and the record stream equal to the oracle's.  ETU's 5 us delay spread is beyond the reference's estimator
+    settings (5-tap smoothing over pilots 90 kHz apart, SubframeWorker.cc:381-390; profiles/r06_frc_36101.txt): few records there, the taps still have to agree"""
+    n = _run("cfg3", 40, seed=70 + model, snr_db=snr, n_rnti=24, chan_model=model, doppler_hz=doppler, timing_offset_samples=0.37, update_meta_period=20)
+    assert n >= at_least, n
+
+
+def test_multipath_fading_four_ports_and_extended_cp():
+    _run("cfg2", 24, seed=75, nof_ports=4, nof_prb=50, snr_db=24.0, chan_model=2, doppler_hz=70.0)
+    _run("cfg3", 24, seed=76, cp=1, nof_prb=75, snr_db=26.0, n_rnti=16, chan_model=3, doppler_hz=70.0)
+
+
 def test_one_rx_antenna_two_ports():
     """TM2 decodes on one rx antenna; two-codeword grants are gated off (DL_Sniffer_PDSCH.cc:887-889)"""
     _run("cfg3", 20, seed=39, nof_rx=1, n_rnti=20)

@@ -244,6 +244,11 @@ typedef struct {
   uint8_t pg_msg[96];
   uint32_t pct_harq;      // share of C-RNTI downlink grants that are sent again 8 subframes later (same HARQ process, NDI not toggled, next redundancy version of 0 2 3 1, same payload)
   uint32_t cp;            // 0 = normal cyclic prefix, 1 = extended (6 symbols per slot, CP = N / 4; 36.211 Table 6.2.3-1 / 6.12-1)
+  // multipath fading (round 6): 0 = the static flat channel above; 1 / 2 / 3 = the tapped-delay-line profiles EPA / EVA / ETU of TS 36.101 Annex B.2.1 with an
+  // independent Rayleigh process per (rx antenna, CRS port, tap) - "low correlation" - of maximum Doppler frequency doppler_hz (B.2.2: 5 / 70 / 300 Hz)
+  uint32_t chan_model;
+  float doppler_hz;
+  float timing_offset_samples;  // a fractional sampling-time offset of the receiver, in samples of the cell's own rate (applied as extra delay of every tap)
 } txg_cfg_t;
 
 typedef struct { uint16_t rnti; uint8_t format, L; uint16_t ncce; uint32_t tti; uint32_t nbytes; uint32_t offset; uint8_t tb, mod, table256, is_ul; uint32_t nof_prb; uint32_t mcs; uint32_t cqi_req; uint32_t hop_bits_plus1; /* DCI 0: 0 = no hopping, else 1 + hopping bits */ } txg_pdu_t;
@@ -273,6 +278,11 @@ struct txg {
   uint64_t count = 0;      // subframes produced so far: seeds the noise of each subframe (independent of the scheduling stream)
   bool plan_only = false;  // txg_generate workers: walk the scheduler (every draw of `rng`) without synthesising the waveform
   cf h[2][4];
+  // fading channel (chan_model != 0): per tap its delay in samples and amplitude; per (rx, port, tap) a sum of NSIN sinusoids (Jakes / Clarke: arrival angles
+  // evenly spread with a random offset, random phases) evaluated on ABSOLUTE time, so that a capture rendered in parallel blocks is the one a sequential run renders
+  static constexpr int NSIN = 16, FIR_HALF = 8;
+  std::vector<double> tap_delay, tap_amp;
+  std::vector<double> jk_w, jk_ph;   // [rx][port][tap][NSIN]: angular Doppler frequency (rad / s) and phase
   explicit txg(const txg_cfg_t& cfg) : c(cfg), rng(cfg.seed) {}
 };
 
@@ -326,6 +336,23 @@ extern "C" txg_t* txg_new(const txg_cfg_t* cfg) {
       double ph = g->rng.uni() * 2 * M_PI, mag = 0.7 + 0.5 * g->rng.uni();
       g->h[r][p] = cf((float)(mag * std::cos(ph)), (float)(mag * std::sin(ph)));
     }
+  if (cfg->chan_model) {  // TS 36.101 Table B.2.1-2 / -3 / -4: excess tap delay (ns), relative power (dB)
+    static const double epa[][2] = {{0, 0.0}, {30, -1.0}, {70, -2.0}, {90, -3.0}, {110, -8.0}, {190, -17.2}, {410, -20.8}};
+    static const double eva[][2] = {{0, 0.0}, {30, -1.5}, {150, -1.4}, {310, -3.6}, {370, -0.6}, {710, -9.1}, {1090, -7.0}, {1730, -12.0}, {2510, -16.9}};
+    static const double etu[][2] = {{0, -1.0}, {50, -1.0}, {120, -1.0}, {200, 0.0}, {230, 0.0}, {500, 0.0}, {1600, -3.0}, {2300, -5.0}, {5000, -7.0}};
+    const double (*tab)[2] = cfg->chan_model == 1 ? epa : cfg->chan_model == 2 ? eva : etu;
+    const int nt = cfg->chan_model == 1 ? 7 : 9;
+    const double fs = 15000.0 * g->N;
+    double tot = 0;
+    for (int i = 0; i < nt; i++) tot += std::pow(10.0, tab[i][1] / 10.0);
+    for (int i = 0; i < nt; i++) { g->tap_delay.push_back(tab[i][0] * 1e-9 * fs + (double)cfg->timing_offset_samples); g->tap_amp.push_back(std::sqrt(std::pow(10.0, tab[i][1] / 10.0) / tot)); }
+    Rng fr((cfg->seed << 8) ^ 0xFAD1C0DEull);  // a stream of its own: the scheduling draws of a capture do not change with the channel model
+    const double wd = 2 * M_PI * (double)cfg->doppler_hz;
+    for (int r = 0; r < 2; r++) for (int p = 0; p < 4; p++) for (int i = 0; i < nt; i++) {
+      const double a0 = fr.uni() * 2 * M_PI;
+      for (int m = 0; m < txg::NSIN; m++) { g->jk_w.push_back(wd * std::cos(a0 + 2 * M_PI * (m + 0.5) / txg::NSIN + (fr.uni() - 0.5) * 2 * M_PI / txg::NSIN)); g->jk_ph.push_back(fr.uni() * 2 * M_PI); }
+    }
+  }
   for (uint32_t i = 0; i < cfg->n_rnti; i++) {
     Ue u; u.rnti = (uint16_t)(0x0100 + g->rng.below(0xFFF3 - 0x0100));
     bool dup = false; for (auto& o : g->ues) if (o.rnti == u.rnti) dup = true;
@@ -927,12 +954,46 @@ extern "C" int txg_next(txg_t* g, float* iq, txg_pdu_t* pdus, int max_pdus, uint
   double sigma = std::sqrt(std::pow(10.0, -c.snr_db / 10.0) / (2.0 * N));  // per real dimension, time domain
   double fs = 15000.0 * N;
   Rng noise((c.seed << 20) ^ ((g->count + 1) * 0xD6E8FEB86659FD93ull));  // per-subframe stream: captures can be rendered in parallel (txg_generate)
+  // fading: per (rx, port) and per block of 64 samples ONE complex FIR = sum over the taps of (Rayleigh gain at the block's time) x (Hann-windowed sinc at the tap's
+  // fractional delay); the samples in front of the subframe count as zero (the last taps of a subframe's very first samples fall into the cyclic prefix of symbol 0)
+  std::vector<std::vector<std::complex<double>>> faded;
+  if (c.chan_model) {
+    const int nt = (int)g->tap_delay.size(), H = txg::FIR_HALF, BL = 64;
+    const int Lh = (int)std::ceil(g->tap_delay[nt - 1]) + 2 * H + 2;
+    faded.assign((size_t)c.nof_rx, std::vector<std::complex<double>>((size_t)sflen));
+    std::vector<std::vector<double>> sinc((size_t)nt, std::vector<double>((size_t)(2 * H + 1)));
+    std::vector<int> d0((size_t)nt);
+    for (int i = 0; i < nt; i++) {
+      d0[i] = (int)std::floor(g->tap_delay[i]);
+      const double fr = g->tap_delay[i] - d0[i];
+      for (int k = -H; k <= H; k++) { const double x = k - fr, w = 0.5 * (1 + std::cos(M_PI * x / (H + 1))); sinc[i][k + H] = (std::fabs(x) < 1e-12 ? 1.0 : std::sin(M_PI * x) / (M_PI * x)) * (std::fabs(x) <= H + 1 ? w : 0.0); }
+    }
+    std::vector<std::complex<double>> fir((size_t)Lh);
+    for (uint32_t r = 0; r < c.nof_rx; r++) for (int p = 0; p < P; p++)
+      for (int b0 = 0; b0 < sflen; b0 += BL) {
+        const double t = ((double)g->count * sflen + b0 + BL / 2) / fs;
+        for (auto& v : fir) v = 0;
+        for (int i = 0; i < nt; i++) {
+          const size_t base = (((size_t)r * 4 + (size_t)p) * (size_t)nt + (size_t)i) * txg::NSIN;
+          std::complex<double> gn(0, 0);
+          for (int m = 0; m < txg::NSIN; m++) { const double a = g->jk_w[base + m] * t + g->jk_ph[base + m]; gn += std::complex<double>(std::cos(a), std::sin(a)); }
+          gn *= g->tap_amp[i] / std::sqrt((double)txg::NSIN);
+          for (int k = -H; k <= H; k++) { const int idx = d0[i] + k + H; if (idx >= 0 && idx < Lh) fir[(size_t)idx] += gn * sinc[i][k + H]; }
+        }
+        for (int n = b0; n < b0 + BL && n < sflen; n++) {
+          std::complex<double> acc(0, 0);
+          for (int j = 0; j < Lh; j++) { const int m = n - j + H; if (m >= 0 && m < sflen) acc += fir[(size_t)j] * std::complex<double>(tx[p][m]); }
+          faded[r][n] += acc;
+        }
+      }
+  }
   for (uint32_t r = 0; r < c.nof_rx; r++) {
     float* out = iq + (size_t)r * sflen * 2;
     int dly = (r == 1) ? (int)c.delay_samples : 0;
     for (int n = 0; n < sflen; n++) {
       std::complex<double> y(0, 0);
-      for (int p = 0; p < P; p++) { int m = n - dly; cf v = m >= 0 ? tx[p][m] : cf(0, 0); y += std::complex<double>(g->h[r][p]) * std::complex<double>(v); }
+      if (c.chan_model) y = faded[r][n];
+      else for (int p = 0; p < P; p++) { int m = n - dly; cf v = m >= 0 ? tx[p][m] : cf(0, 0); y += std::complex<double>(g->h[r][p]) * std::complex<double>(v); }
       if (c.cfo_hz != 0) { double ph = 2 * M_PI * c.cfo_hz * ((double)n + (double)(tti - c.start_tti) * sflen) / fs; y *= std::complex<double>(std::cos(ph), std::sin(ph)); }
       double nr, ni; noise.gauss2(nr, ni);
       out[2 * n] = (float)(y.real() + sigma * nr);
