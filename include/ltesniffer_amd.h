@@ -104,6 +104,15 @@ int lsn_phy_join_pending(lsn_phy_t* phy);                                 /* Phy
 int lsn_phy_set_pdu_sink(lsn_phy_t* phy, lsn_pdu_sink_t cb, void* user);  /* stands in for the pcapwriter ctor argument */
 int lsn_phy_get_stats(lsn_phy_t* phy, lsn_blind_stats_t* out);            /* PhyCommon::getStats, PhyCommon.cc:60 */
 float lsn_phy_get_est_cfo(lsn_phy_t* phy);                                /* SubframeWorker.cc:203 est_cfo */
+/* CFO correction inside the OFDM kernel (an NCO on the samples as the FFT loads them).  Replaces, for this path, what srsran_ue_sync does to the samples before
+ * they reach SubframeWorker::work: ue_sync.cfo_correct_enable_track = !args.disable_cfo (LTESniffer_Core.cc:344), started from the cell search's offset
+ * (ue_sync.cfo_current_value = search_cell_cfo / 15000, :312-316) and kept on the carrier by srsran_ue_sync_set_cfo_ref with the CRS estimate.
+ *   mode 0: off (the reference's file replay without -o)          mode 1: remove the fixed offset cfo_hz          mode 2: track - start from cfo_hz, then
+ *   each chunk of max_batch subframes is corrected by c += alpha * (m - c), m = the absolute offset (correction + mean CRS residual) measured on the chunk
+ *   LSN_NSTREAM_A (4) chunks earlier; 0 < alpha <= 1.  est_cfo keeps reporting the CRS estimate of the corrected samples (the residual), as in the reference.
+ * Takes effect with the next chunk that enters the pipeline; call it between process calls.  mode 2 is refused on a handle of lsn_phy_create_multi. */
+int lsn_phy_set_cfo_correction(lsn_phy_t* phy, int mode, float cfo_hz, float alpha);
+float lsn_phy_get_cfo_correction(lsn_phy_t* phy);                         /* the offset removed from the chunk launched last (srsran_ue_sync_get_cfo) */
 int lsn_phy_add_evergreen(lsn_phy_t* phy, uint16_t rnti_start, uint16_t rnti_end, uint32_t format_idx); /* RNTIManager::addEvergreen */
 int lsn_phy_add_forbidden(lsn_phy_t* phy, uint16_t rnti_start, uint16_t rnti_end, uint32_t format_idx); /* RNTIManager::addForbidden */
 int lsn_phy_setup_default_rnti_intervals(lsn_phy_t* phy);                 /* LTESniffer_Core.cc:398-417 in one call */

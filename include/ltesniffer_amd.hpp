@@ -180,6 +180,9 @@ public:
   void setRNTI(uint16_t) {}                           // Phy.h:48 (single-RNTI filter of the legacy path; unused by LTESniffer_Core)
   uint32_t nof_rx_antennas, nof_workers;              // Phy.h:54-55
   float getEstCfo() { return lsn_phy_get_est_cfo(h); }                                                      // SubframeWorker.cc:203
+  // what ue_sync's CFO tracking does ahead of the reference's workers (LTESniffer_Core.cc:312-316,344), here inside the OFDM kernel
+  bool setCfoCorrection(int mode, float cfoHz = 0.0f, float alpha = 0.25f) { return lsn_phy_set_cfo_correction(h, mode, cfoHz, alpha) == LSN_SUCCESS; }
+  float getCfoCorrection() { return lsn_phy_get_cfo_correction(h); }                                       // srsran_ue_sync_get_cfo
   // UL_MODE: what ULSchedule::set_config hands to the workers once SIB2 is known (ULSchedule.cc:140-158)
   bool setUlConfig(uint32_t cyclicShift, uint32_t groupAssignmentPUSCH, uint32_t puschHoppingOffset = 0)    // SubframeWorker.cc:258-277
   {

@@ -38,7 +38,7 @@ EXPORTS = ["lsn_phy_create", "lsn_phy_destroy", "lsn_phy_set_cell", "lsn_phy_get
            "lsn_phy_tap_ul", "lsn_phy_set_prach_config", "lsn_phy_prach_detect", "lsn_phy_set_prach_sink", "lsn_prach_tti_opportunity", "lsn_phy_process_file", "lsn_phy_mib_decode", "lsn_phy_mib_decode_llr", "lsn_phy_submit_device", "lsn_phy_wait", "lsn_cell_search",
            "lsn_phy_set_shortcut_discovery", "lsn_phy_get_shortcut_discovery", "lsn_phy_set_histogram_threshold", "lsn_phy_print_stats",
            "lsn_phy_set_mcs_update_interval", "lsn_phy_update_mcs_database", "lsn_phy_nof_tracked_rnti", "lsn_worker_buffers_offset", "lsn_pcap_digest", "lsn_pcap_set_store", "lsn_pcap_set_digest_blocks", "lsn_pcap_block_digests", "lsn_phy_create_multi", "lsn_phy_nof_devices",
-           "lsn_phy_set_stage_c_taps", "lsn_phy_prepare_file", "lsn_phy_get_meta_formats", "lsn_phy_nof_workers", "lsn_phy_worker"]
+           "lsn_phy_set_cfo_correction", "lsn_phy_get_cfo_correction", "lsn_phy_set_stage_c_taps", "lsn_phy_prepare_file", "lsn_phy_get_meta_formats", "lsn_phy_nof_workers", "lsn_phy_worker"]
 
 
 def turbo_nwin(K):
@@ -231,6 +231,9 @@ def lib():
         L.lsn_phy_get_stats.argtypes = [C.c_void_p, C.POINTER(BlindStats)]
         L.lsn_phy_get_est_cfo.argtypes = [C.c_void_p]
         L.lsn_phy_get_est_cfo.restype = C.c_float
+        L.lsn_phy_set_cfo_correction.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float]
+        L.lsn_phy_get_cfo_correction.argtypes = [C.c_void_p]
+        L.lsn_phy_get_cfo_correction.restype = C.c_float
         L.lsn_phy_add_evergreen.argtypes = [C.c_void_p, C.c_uint16, C.c_uint16, C.c_uint32]
         L.lsn_phy_add_forbidden.argtypes = [C.c_void_p, C.c_uint16, C.c_uint16, C.c_uint32]
         L.lsn_phy_setup_default_rnti_intervals.argtypes = [C.c_void_p]
@@ -687,6 +690,16 @@ class Phy:
 
     def est_cfo(self):
         return lib().lsn_phy_get_est_cfo(self._h)
+
+    CFO_OFF, CFO_FIXED, CFO_TRACK = 0, 1, 2
+
+    def setCfoCorrection(self, mode, cfo_hz=0.0, alpha=0.25):
+        """CFO correction inside the OFDM kernel - what srsran_ue_sync's tracking does ahead of the reference's workers (LTESniffer_Core.cc:312-316,344).
+        CFO_FIXED removes cfo_hz; CFO_TRACK starts there and follows the CRS estimate chunk by chunk (include/ltesniffer_amd.h)"""
+        _check(lib().lsn_phy_set_cfo_correction(self._h, int(mode), float(cfo_hz), float(alpha)), "setCfoCorrection")
+
+    def getCfoCorrection(self):
+        return lib().lsn_phy_get_cfo_correction(self._h)
 
     def nof_active_rnti(self):
         return lib().lsn_phy_nof_active_rnti(self._h)

@@ -332,6 +332,15 @@ int lsn_phy_get_stats(lsn_phy_t* phy, lsn_blind_stats_t* out)
 }
 
 float lsn_phy_get_est_cfo(lsn_phy_t* phy) { return phy ? phy->engine->estCfo() : 0.0f; }
+int lsn_phy_set_cfo_correction(lsn_phy_t* phy, int mode, float cfo_hz, float alpha)
+{
+  if (!phy) return LSN_ERROR_INVALID_INPUTS;
+  if (mode == 2 && !phy->more.empty()) return LSN_ERROR_INVALID_INPUTS;  // one loop over one stream of chunks: several engines share a capture chunk by chunk
+  int rc = phy->engine->setCfoCorrection(mode, cfo_hz, alpha);
+  for (auto& e : phy->more) if (rc == LSN_SUCCESS) rc = e->setCfoCorrection(mode, cfo_hz, alpha);
+  return rc;
+}
+float lsn_phy_get_cfo_correction(lsn_phy_t* phy) { return phy ? phy->engine->cfoCorrection() : 0.0f; }
 
 int lsn_phy_add_evergreen(lsn_phy_t* phy, uint16_t a, uint16_t b, uint32_t f)
 {

@@ -289,6 +289,25 @@ void Engine::launchStageA(Chunk& ch, const void* d_iq)
   lsn_launch_upload(ch.d_sfidx, ch.h_sfidx, nsf * sizeof(uint32_t), st);  // (pinned mirror; not through the copy engine, see lsn_dev.h)
   const cf32* iq = (const cf32*)d_iq;
   ch.d_iq_src = iq;
+  // CFO correction (lsn_engine.h): this chunk's offset from the loop, as the NCO increment of every subframe
+  const uint32_t* d_dphi = nullptr;
+  ch.cfo_corr_hz = 0.0f; ch.cfo_slot = -1;
+  if (const int mode = cfo_mode.load()) {
+    if (cfo_epoch_seen != cfo_epoch.load()) { cfo_epoch_seen = cfo_epoch.load(); cfo_launched = 0; cfo_c = cfo_start_hz.load(); }
+    if (mode == 2 && cfo_launched >= (uint64_t)NSTREAM_A) {
+      const float m = cfo_meas[(cfo_launched - (uint64_t)NSTREAM_A) % 16];
+      cfo_c = (float)((double)cfo_c + (double)cfo_alpha.load() * ((double)m - (double)cfo_c));  // (products of two floats are exact in double: no contraction can change this)
+    }
+    ch.cfo_corr_hz = cfo_c; ch.cfo_slot = (int)(cfo_launched % 16);
+    cfo_meas[ch.cfo_slot] = cfo_c;  // until finishStageA has measured (a chunk that fails keeps the loop where it is)
+    cfo_launched++;
+    cfo_current.store(cfo_c);
+    // phase increment per sample, 2^32 = one turn, that REMOVES cfo_c (the oracle's o_nco_dphi, same expression)
+    const uint32_t dphi = (uint32_t)(int32_t)llrint(-(double)cfo_c / (15000.0 * (double)cd.N) * 4294967296.0);
+    for (uint32_t i = 0; i < nsf; i++) ch.h_dphi[i] = dphi;
+    lsn_launch_upload(ch.d_dphi, ch.h_dphi, nsf * sizeof(uint32_t), st);
+    d_dphi = ch.d_dphi;
+  }
   int n = 0;
   ch.timed_a = timing_period && (stage_a_passes++ % timing_period) == 0;
   auto timed = [&](auto&& fn) {
@@ -338,6 +357,20 @@ void Engine::finishStageA(Chunk& ch)
     perf_front.algo_bytes += A * cd.sflen * 8ull + 2ull * A * 14ull * cd.nre * 8ull + 2ull * P * A * 14ull * cd.nre * 8ull +
                        2ull * cd.nof_cce[c.cfi - 1] * 72ull * 4ull;
   }
+  if (ch.cfo_slot >= 0) {  // the tracking loop's measurement of this chunk: what was removed + the mean of what the CRS estimator still saw
+    double s = 0.0;
+    for (uint32_t i = 0; i < ch.nsf; i++) s += (double)ch.ctx[i].cfo_hz;
+    cfo_meas[ch.cfo_slot] = (float)((double)ch.cfo_corr_hz + s / (double)ch.nsf);
+  }
+}
+
+int Engine::setCfoCorrection(int mode, float cfo_hz, float alpha)
+{
+  if (mode < 0 || mode > 2 || !std::isfinite(cfo_hz) || !(alpha > 0.0f && alpha <= 1.0f)) return LSN_ERROR_INVALID_INPUTS;
+  cfo_start_hz.store(cfo_hz); cfo_alpha.store(alpha); cfo_mode.store(mode);
+  cfo_current.store(mode ? cfo_hz : 0.0f);
+  cfo_epoch.fetch_add(1);  // the next chunk that is launched starts the loop again from cfo_hz
+  return LSN_SUCCESS;
 }
 
 // RA-RNTI grants feed the RNTI manager between two subframes of the sequential search (DL_Sniffer_PDSCH.cc:782-797).

@@ -70,6 +70,9 @@ struct Chunk {
   LsnCand* d_cand = nullptr;
   LsnCand* h_cand = nullptr; float* h_ccepow = nullptr; LsnChest* h_chest = nullptr; uint32_t* h_cfi = nullptr; float* h_rbp = nullptr;
   uint32_t* h_sfidx = nullptr;
+  uint32_t *d_dphi = nullptr, *h_dphi = nullptr;  // per-subframe NCO increment of k_ofdm (CFO correction on), device + pinned mirror
+  float cfo_corr_hz = 0.0f;          // the carrier offset k_ofdm removes from this chunk (0 = correction off)
+  int cfo_slot = -1;                 // where finishStageA leaves this chunk's absolute CFO measurement for the tracking loop (-1: correction off)
   std::vector<SubframeCtx> ctx;
   uint32_t ul_epoch = 0;             // Engine::ul_cfg_epoch when the DCI 0 grants of this chunk were converted
   std::vector<DecodeJob> jobs;
@@ -219,6 +222,8 @@ public:
   void getPerf(lsn_perf_t* p) const { *p = perf; p->nof_table_hints_used = sh->hint_used.load(); p->nof_table_hints_missed = sh->hint_missed.load(); }
   void getStats(lsn_blind_stats_t* s) const;
   float estCfo() const { return est_cfo; }
+  int setCfoCorrection(int mode, float cfo_hz, float alpha);
+  float cfoCorrection() const { return cfo_current.load(); }
   RNTIManager& rntiManager() { return search->rntiManager(); }
   FalconSearch& searchRef() { return *search; }
   double searchTimeUs() const { return search_time_us; }
@@ -309,7 +314,19 @@ private:
   uint32_t max_batch = 64;
   LsnCellDev cd{};
   std::vector<void*> dev_allocs, host_allocs;
-  uint32_t* d_dphi = nullptr;
+  // CFO correction in the OFDM front end (the north-star's "OFDM FFT + CFO correction"): what srsran_ue_sync does for the reference AHEAD of the worker
+  // (cfo_correct_enable_track, LTESniffer_Core.cc:312-316,344; srsran_ue_sync_set_cfo_ref fed by the CRS estimate) happens here inside k_ofdm - an NCO on the
+  // samples as they are loaded for the FFT, no extra pass over the capture.  mode 0: off.  mode 1: the fixed offset cfo_start_hz.  mode 2: a tracking loop over
+  // the chunks in flight: chunk g is corrected by c[g] = c[g-1] + alpha * (m[g-D] - c[g-1]) with D = NSTREAM_A chunks of loop delay (stage A of D chunks is in
+  // flight at once, so m[g-D] is the newest measurement that is ALWAYS there when g is launched - the loop is deterministic, whatever the GPU's timing) and
+  // m[k] = c[k] + mean of the chunk's CRS residual estimates: an average of ABSOLUTE offsets, stable for any 0 < alpha <= 1 whatever the delay.
+  // All loop state lives on the front thread; the setter only posts a request (cfo_epoch) that the next launched chunk picks up.
+  std::atomic<int> cfo_mode{0};
+  std::atomic<float> cfo_start_hz{0.0f}, cfo_alpha{0.25f}, cfo_current{0.0f};
+  std::atomic<uint32_t> cfo_epoch{0};
+  uint32_t cfo_epoch_seen = 0;
+  uint64_t cfo_launched = 0;
+  float cfo_c = 0.0f, cfo_meas[16] = {};
   void* d_iq_staging = nullptr;
   hipStream_t copy_stream = nullptr;          // host -> staging copies of processHost
   hipEvent_t copy_done[3] = {};

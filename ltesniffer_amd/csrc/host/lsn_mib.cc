@@ -40,7 +40,7 @@ int Engine::mibDecode(const void* iq, bool on_device, lsn_mib_t* out, float* llr
     }
     ch.h_sfidx[0] = 0;
     HIP_CHECK(hipMemcpyAsync(ch.d_sfidx, ch.h_sfidx, sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    lsn_launch_ofdm(cd, d_iq, d_dphi, ch.d_grid, 1, st);
+    lsn_launch_ofdm(cd, d_iq, nullptr, ch.d_grid, 1, st);
     lsn_launch_chest(cd, ch.d_grid, ch.d_sfidx, ch.d_ce, ch.d_chest_raw, 1, st);
     lsn_launch_chest_fin(cd, ch.d_chest_raw, ch.d_chest, 1, st);
     lsn_launch_pbch(cd, ch.d_grid, ch.d_ce, ch.d_chest, mib_d_llr, mib_d_cand, st);

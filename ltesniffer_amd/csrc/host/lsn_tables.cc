@@ -78,7 +78,7 @@ void Engine::freeDevice()
     df(mib_d_iq); df(mib_d_llr); df(mib_d_cand);
     for (auto& fb : file_buf) { if (fb.h_raw) (void)hipHostFree(fb.h_raw); df(fb.d_raw); df(fb.d_iq); fb.h_raw = nullptr; fb.bytes = 0; }
   }
-  d_dphi = nullptr; d_iq_staging = nullptr; staging_sf = 0; d_harq_pool = nullptr;
+  d_iq_staging = nullptr; staging_sf = 0; d_harq_pool = nullptr;
   if (harq_h_store) { (void)hipHostFree(harq_h_store); harq_h_store = nullptr; harq_h_store_cap = 0; }
   if (harq_d_store) { (void)hipFree(harq_d_store); harq_d_store = nullptr; harq_d_store_cap = 0; }
   harq_store_q.clear();
@@ -166,6 +166,7 @@ void Engine::allocChunk(Chunk& ch)
   ch.d_chest = dalloc<LsnChest>(dev_allocs, B);
   ch.d_cfi = dalloc<uint32_t>(dev_allocs, B);
   ch.d_sfidx = dalloc<uint32_t>(dev_allocs, B);
+  ch.d_dphi = dalloc<uint32_t>(dev_allocs, B);
   ch.d_pcfich_corr = dalloc<float>(dev_allocs, B * 3);
   ch.d_llr = dalloc<float>(dev_allocs, B * LSN_LLR_STRIDE);
   ch.d_ccepow = dalloc<float>(dev_allocs, B * LSN_CCE_STRIDE);
@@ -178,6 +179,7 @@ void Engine::allocChunk(Chunk& ch)
   ch.h_cfi = halloc<uint32_t>(host_allocs, B);
   ch.h_rbp = halloc<float>(host_allocs, B * 128);
   ch.h_sfidx = halloc<uint32_t>(host_allocs, B);
+  ch.h_dphi = halloc<uint32_t>(host_allocs, B);
   ch.ctx.assign(B, SubframeCtx());
   for (auto& e : ch.ev_a) HIP_CHECK(hipEventCreate(&e));
   (void)hipEventDestroy(ch.ev_a[16]);  // the "stage A results are on the host" marker is only waited for, never timed

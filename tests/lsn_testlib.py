@@ -53,7 +53,7 @@ class TxgCfg(C.Structure):
                 ("start_tti", C.c_uint32), ("fixed_L", C.c_uint32), ("pct_rv", C.c_uint32), ("pct_cqi_req", C.c_uint32), ("pct_hop", C.c_uint32), ("pusch_hop_offset", C.c_uint32),
                 ("msg4_period", C.c_uint32), ("msg4_p_a_idx", C.c_uint32), ("si_len", C.c_uint32 * 2), ("si_msg", (C.c_uint8 * 96) * 2),
                 ("pg_len", C.c_uint32), ("pg_msg", C.c_uint8 * 96), ("pct_harq", C.c_uint32), ("cp", C.c_uint32),
-                ("chan_model", C.c_uint32), ("doppler_hz", C.c_float), ("timing_offset_samples", C.c_float)]  # TS 36.101 B.2 fading: 1 EPA, 2 EVA, 3 ETU
+                ("chan_model", C.c_uint32), ("doppler_hz", C.c_float), ("timing_offset_samples", C.c_float), ("cfo_drift_hz_per_s", C.c_float)]  # TS 36.101 B.2 fading: 1 EPA, 2 EVA, 3 ETU
 
 
 class TxgPdu(C.Structure):
@@ -159,6 +159,8 @@ def scenario(name, seed=1, **over):
         base["cp"] = 0
     if "chan_model" in over:  # multipath fading (TS 36.101 B.2: 1 EPA, 2 EVA, 3 ETU; doppler_hz; timing_offset_samples): same rule
         base.update(chan_model=0, doppler_hz=0.0, timing_offset_samples=0.0)
+    if "cfo_drift_hz_per_s" in over:
+        base["cfo_drift_hz_per_s"] = 0.0
     presets = {
         # config 1: 10 MHz, single RNTI, TM1 QPSK, 1 port / 1 rx
         "cfg1": dict(nof_prb=50, nof_ports=1, nof_rx=1, snr_db=20.0, cfo_hz=300.0, n_rnti=1, dl_min=1, dl_max=1, ul_min=0,

@@ -36,7 +36,35 @@ def gen_capture(sc, n, threads=None, **txkw):
     return tti0, iq
 
 
-def run_oracle(sc, tti0, iq, update_meta_period=0, taps=True, mcs_update_interval=None, trace=False, harq_mode=0, **okw):
+class CfoLoop:
+    """The engine's CFO correction (lsn_engine.h, lsn_phy_set_cfo_correction) restated for the oracle driver: the offset removed from chunk g of `batch` subframes is
+    c[g] = c[g-1] + alpha * (m[g-D] - c[g-1]) (mode 2; D = 4 chunks of loop delay), m[k] = c[k] + mean CRS residual of chunk k; mode 1: the fixed offset.
+    Arithmetic as in the engine: doubles, rounded to float once per value."""
+    D = 4
+
+    def __init__(self, mode, cfo_hz, alpha, batch):
+        self.mode, self.c, self.alpha, self.batch = mode, float(np.float32(cfo_hz)), float(np.float32(alpha)), batch
+        self.meas, self.hist, self.acc = [], [], []
+
+    def cfo(self, i):
+        if i % self.batch == 0:  # a new chunk is launched
+            g = i // self.batch
+            if self.mode == 2 and g >= self.D:
+                self.c = float(np.float32(self.c + self.alpha * (self.meas[g - self.D] - self.c)))
+            self.hist.append(self.c)
+            self.acc = []
+        return self.c
+
+    def seen(self, i, n_total, est_hz):
+        self.acc.append(float(est_hz))
+        if (i + 1) % self.batch == 0 or i + 1 == n_total:
+            s = 0.0
+            for v in self.acc:
+                s += v
+            self.meas.append(float(np.float32(self.c + s / len(self.acc))))
+
+
+def run_oracle(sc, tti0, iq, update_meta_period=0, taps=True, mcs_update_interval=None, trace=False, harq_mode=0, cfo_loop=None, **okw):
     """trace=True: the oracle's stage-C recorder runs over these subframes; read it with lsn_testlib.oracle_trace() afterwards"""
     oracle_trace_enable(trace)
     okw.setdefault("cp", sc.get("cp", 0))
@@ -48,7 +76,9 @@ def run_oracle(sc, tti0, iq, update_meta_period=0, taps=True, mcs_update_interva
     per_sf = []
     for i in range(iq.shape[0]):
         upd = 1 if (update_meta_period and i % update_meta_period == 0) else 0
-        ow.work(iq[i], tti0 + i, update_meta=upd)
+        ow.work(iq[i], tti0 + i, update_meta=upd, cfo_hz=cfo_loop.cfo(i) if cfo_loop else 0.0)
+        if cfo_loop:
+            cfo_loop.seen(i, iq.shape[0], ow.chest().cfo_hz)
         if taps:
             ch = ow.chest()
             # the record of la.TAP_CHEST: noise, rsrp, cepow as [rx 0..1][port 0..W-1] with W = 2 (one or two ports) or 4, then seven scalars

@@ -5,19 +5,20 @@ import pytest
 import ltesniffer_amd as la
 from lsn_testlib import scenario
 from lsn_testlib import oracle_trace
-from parity import compare_candidate_tables, compare_stage_c, compare_taps, gen_subframes, gpu_records, oracle_records, run_oracle
+from parity import CfoLoop, compare_candidate_tables, compare_stage_c, compare_taps, gen_subframes, gpu_records, oracle_records, run_oracle
 
 pytestmark = pytest.mark.gpu
 
 
-def _run(scn, nsf, seed=1, batch=16, update_meta_period=0, exact_iters=False, **over):
+def _run(scn, nsf, seed=1, batch=16, update_meta_period=0, exact_iters=False, cfo_correction=None, **over):
     """stage-A taps, stage-C taps (int16 soft bits, de-rate-matched streams, per-code-block verdict + iterations), record stream and statistics
     of the HIP path against the oracle; exact_iters: the engine runs without first-block gating (LSN_NO_CB_SKIP=1), so every code block of
     every decode call the oracle made carries a verdict and the iteration totals must agree"""
     import os
     sc = scenario(scn, seed=seed, **over)
     tti0, iq, truth = gen_subframes(sc, nsf)
-    ow, per_sf, orecs = run_oracle(sc, tti0, iq, update_meta_period=update_meta_period, trace=True)
+    loop = CfoLoop(*cfo_correction, batch) if cfo_correction else None   # (mode, start offset, alpha): the engine's correction loop restated for the oracle driver
+    ow, per_sf, orecs = run_oracle(sc, tti0, iq, update_meta_period=update_meta_period, trace=True, cfo_loop=loop)
     otrace = oracle_trace()
     if exact_iters:
         os.environ["LSN_NO_CB_SKIP"] = "1"   # read when the engine is made
@@ -27,12 +28,16 @@ def _run(scn, nsf, seed=1, batch=16, update_meta_period=0, exact_iters=False, **
         os.environ.pop("LSN_NO_CB_SKIP", None)
     assert phy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"], {1: 0, 3: 1, 6: 2, 12: 3}[sc["phich_ng_x6"]], cp=sc.get("cp", 0))
     phy.set_stage_c_taps(True)
+    if cfo_correction:
+        phy.setCfoCorrection(*cfo_correction)
     bad, badc, ncall, ncb, it_o, it_g = [], [], 0, 0, 0, 0
     for base in range(0, nsf, batch):
         n = min(batch, nsf - base)
         # update_meta_period counts subframes from the start of the stream, same as the oracle driver above
         phy.process_host(iq[base:base + n], tti0 + base, update_meta_period)
         bad += [(base,) + b for b in compare_taps(phy, per_sf, sc, base, n)]
+        if loop and np.float32(phy.getCfoCorrection()) != np.float32(loop.hist[base // batch]):
+            bad.append((base, "cfo correction", phy.getCfoCorrection(), loop.hist[base // batch]))
         b, c, k, io, ig = compare_stage_c(phy, otrace, tti0 + base, n, exact_iters=exact_iters)
         badc += [(base,) + x for x in b]
         ncall, ncb, it_o, it_g = ncall + c, ncb + k, it_o + io, it_g + ig
@@ -50,6 +55,8 @@ def _run(scn, nsf, seed=1, batch=16, update_meta_period=0, exact_iters=False, **
               "nof_subframe_collisions_dw", "nof_subframe_collisions_up"):
         assert getattr(st, f) == getattr(ost, f), f
     phy.close()
+    if loop:
+        return len(o), loop
     return len(o)
 
 
@@ -225,6 +232,27 @@ def test_multipath_fading_channels_of_ts_36_101(model, doppler, snr, at_least):
 def test_multipath_fading_four_ports_and_extended_cp():
     _run("cfg2", 24, seed=75, nof_ports=4, nof_prb=50, snr_db=24.0, chan_model=2, doppler_hz=70.0)
     _run("cfg3", 24, seed=76, cp=1, nof_prb=75, snr_db=26.0, n_rnti=16, chan_model=3, doppler_hz=70.0)
+
+
+def test_cfo_correction_fixed_offset_in_the_ofdm_kernel():
+    """3 kHz of carrier offset (a fifth of the subcarrier spacing): uncorrected the receiver delivers next to nothing; with the NCO of k_ofdm set to the offset the
+    stream decodes - grid, estimates, soft bits and records equal to the oracle fed the same correction (o_ofdm_rx's NCO)"""
+    sc = scenario("cfg2", seed=81, cfo_hz=3000.0, snr_db=26.0)
+    tti0, iq, _ = gen_subframes(sc, 16)
+    n0 = len(run_oracle(sc, tti0, iq, taps=False)[2])
+    n1, _ = _run("cfg2", 16, seed=81, cfo_hz=3000.0, snr_db=26.0, cfo_correction=(1, 3000.0, 0.25))
+    assert n1 > 60 and n0 < 5, (n0, n1)
+
+
+def test_cfo_tracking_follows_a_drifting_oscillator():
+    """the offset starts at 900 Hz (the loop is told 600, as a cell search would be off) and drifts by 6 kHz/s; the loop - chunks of 8 subframes, four chunks of
+    delay - pulls the residual the CRS estimator sees to a fraction of the offset; every chunk's correction and every tap equal to the oracle driven by the same
+    loop rule"""
+    n, loop = _run("cfg2", 96, seed=82, batch=8, cfo_hz=900.0, cfo_drift_hz_per_s=6000.0, snr_db=26.0, cfo_correction=(2, 600.0, 0.5))
+    true_end = 900.0 + 6000.0 * 0.092   # at the middle of the last chunk
+    assert abs(loop.meas[-1] - true_end) < 30.0, (loop.meas, true_end)      # the measurement (correction + residual) is on the true offset ...
+    assert 0.0 < true_end - loop.hist[-1] < 300.0, (loop.hist, true_end)    # ... and the correction lags a ramp this steep (6 kHz/s) by its loop delay, no more
+    assert n > 350, n    # (uncorrected: no record at all - the offset leaves the +-1 kHz range of the CRS estimator within 17 ms)
 
 
 def test_one_rx_antenna_two_ports():

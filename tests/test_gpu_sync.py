@@ -114,3 +114,40 @@ def test_extended_cp_recording_search_mib_and_replay(tmp_path):
     assert phy.process_file(p, start_tti=la.TTI_FROM_MIB, offset_time=off, update_meta_period=20) == 50 - first
     assert gpu_records(phy) == orecs and orecs
     phy.close()
+
+
+def test_recording_with_a_drifting_oscillator_is_tracked_through_the_replay(tmp_path):
+    """what ue_sync's CFO tracking does for the live reference (LTESniffer_Core.cc:312-316,344): the cell search's offset starts the loop (search_cell_cfo ->
+    ue_sync.cfo_current_value), the CRS estimate of every chunk keeps it on the carrier while the oscillator drifts from 1.4 kHz by 1.5 kHz/s through a replay -
+    records equal to the oracle driven by the same loop rule; without correction the offset is beyond the CRS estimator's +-1 kHz and nothing decodes"""
+    from parity import CfoLoop
+    sc = scenario("small", seed=28, start_tti=10 * 500 + 4, cell_id=77, cfo_hz=1400.0, cfo_drift_hz_per_s=1500.0)
+    nsf, batch = 126, 8
+    tti0, iq, _ = gen_subframes(sc, nsf)
+    p = str(tmp_path / "cap.cf32")
+    write_capture(p, iq, lead=0)
+    raw = np.fromfile(p, dtype=np.complex64).reshape(-1, sc["nof_rx"])
+    rc, s = la.cell_search(raw[:, 0], sc["nof_prb"], nof_periods=2)
+    assert rc == 1 and s.cell_id == 77 and abs(s.cfo_hz - 1400.0) < 150.0, (rc, s.cell_id, s.cfo_hz)
+    sflen = iq.shape[2]
+    off = s.sf_start + (5 * sflen if s.sf_idx == 5 else 0)
+    first = off // sflen
+    loop = CfoLoop(2, s.cfo_hz, 0.5, batch)
+    ow = OracleWorker(sc["nof_prb"], sc["nof_ports"], s.cell_id, sc["nof_rx"])
+    n = nsf - first
+    for i in range(n):
+        ow.work(iq[first + i], tti0 + first + i, update_meta=1 if i % 24 == 0 else 0, cfo_hz=loop.cfo(i))
+        loop.seen(i, n, ow.chest().cfo_hz)
+    orecs = oracle_records(parse_pcap(ow.pcap_bytes()))
+    ow0 = OracleWorker(sc["nof_prb"], sc["nof_ports"], s.cell_id, sc["nof_rx"])
+    for i in range(n):
+        ow0.work(iq[first + i], tti0 + first + i, update_meta=1 if i % 24 == 0 else 0)
+    assert len(parse_pcap(ow0.pcap_bytes())) < len(orecs) // 4 and len(orecs) > 100, (len(parse_pcap(ow0.pcap_bytes())), len(orecs))
+    phy = la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=batch, pcapwriter=la.PcapWriter(None))
+    assert phy.setCell(sc["nof_prb"], sc["nof_ports"], s.cell_id)
+    phy.setCfoCorrection(la.Phy.CFO_TRACK, s.cfo_hz, 0.5)
+    assert phy.process_file(p, start_tti=la.TTI_FROM_MIB, offset_time=off, update_meta_period=24) == n
+    assert gpu_records(phy) == orecs
+    assert np.float32(phy.getCfoCorrection()) == np.float32(loop.hist[-1])
+    assert abs(loop.meas[-1] - (1400.0 + 1500.0 * (nsf - batch / 2) * 1e-3)) < 40.0, loop.meas
+    phy.close()

@@ -249,6 +249,7 @@ typedef struct {
   uint32_t chan_model;
   float doppler_hz;
   float timing_offset_samples;  // a fractional sampling-time offset of the receiver, in samples of the cell's own rate (applied as extra delay of every tap)
+  float cfo_drift_hz_per_s;     // the carrier offset moves: cfo_hz + cfo_drift_hz_per_s * t (a warming oscillator), phase continuous
 } txg_cfg_t;
 
 typedef struct { uint16_t rnti; uint8_t format, L; uint16_t ncce; uint32_t tti; uint32_t nbytes; uint32_t offset; uint8_t tb, mod, table256, is_ul; uint32_t nof_prb; uint32_t mcs; uint32_t cqi_req; uint32_t hop_bits_plus1; /* DCI 0: 0 = no hopping, else 1 + hopping bits */ } txg_pdu_t;
@@ -994,7 +995,12 @@ extern "C" int txg_next(txg_t* g, float* iq, txg_pdu_t* pdus, int max_pdus, uint
       std::complex<double> y(0, 0);
       if (c.chan_model) y = faded[r][n];
       else for (int p = 0; p < P; p++) { int m = n - dly; cf v = m >= 0 ? tx[p][m] : cf(0, 0); y += std::complex<double>(g->h[r][p]) * std::complex<double>(v); }
-      if (c.cfo_hz != 0) { double ph = 2 * M_PI * c.cfo_hz * ((double)n + (double)(tti - c.start_tti) * sflen) / fs; y *= std::complex<double>(std::cos(ph), std::sin(ph)); }
+      if (c.cfo_hz != 0 || c.cfo_drift_hz_per_s != 0) {
+        const double t = ((double)n + (double)g->count * sflen) / fs;  // (count = subframes since the start, also across the 10240-subframe wrap of the TTI)
+        const double ph = c.cfo_drift_hz_per_s != 0 ? 2 * M_PI * ((double)c.cfo_hz * t + 0.5 * (double)c.cfo_drift_hz_per_s * t * t)
+                                                    : 2 * M_PI * c.cfo_hz * ((double)n + (double)(tti - c.start_tti) * sflen) / fs;
+        y *= std::complex<double>(std::cos(ph), std::sin(ph));
+      }
       double nr, ni; noise.gauss2(nr, ni);
       out[2 * n] = (float)(y.real() + sigma * nr);
       out[2 * n + 1] = (float)(y.imag() + sigma * ni);
