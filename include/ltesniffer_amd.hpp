@@ -5,8 +5,10 @@
 // and every member LTESniffer_Core.cc calls on them (constructor :63-90, loop :292-299,361-451, shutdown :547-562, :603-621): tests/native/test_hpp.cc
 // repeats those call sites, in the reference's spelling, against this header.  What does NOT carry over unchanged: the srsRAN PODs (re-declared in the C
 // header), the singletons this library owns itself (RNTIManager, MCSTracking, DCIMetaFormats live behind lsn_phy_t and are reached through the facades
-// below - same member names, other class names), and the translation unit as a whole - LTESniffer_Core.cc also includes boost::program_options, srsue
-// and the srsRAN radio / synchronisation API, none of which exist in this image, so it has never been compiled against this header.
+// below - same member names, other class names).  Since round 6 the reference's own LTESniffer_Core.cc IS compiled against this header in the CPU suite
+// (tests/test_reference_caller.py, through ltesniffer_amd_compat.hpp: its class header with the worker-side includes swapped, nothing else touched;
+// boost::program_options, srsue and the srsRAN radio / synchronisation API - absent from this image and outside the path - are DECLARED by
+// tests/native/core_shim, so the check is of syntax and types, not a link).
 #pragma once
 #include "ltesniffer_amd.h"
 #include <complex>
@@ -18,7 +20,11 @@
 
 namespace lsn_amd {
 
+#ifdef LSN_AMD_SRSRAN_CF_T
+using ::cf_t;                      // the caller's own srsRAN headers are in scope: their cf_t (float _Complex), so that getBuffers() goes into srsran_ue_sync_zerocopy unchanged
+#else
 typedef std::complex<float> cf_t;  // srsRAN cf_t = float _Complex, same layout
+#endif
 
 class Phy;
 
@@ -30,6 +36,11 @@ public:
   void prepare(uint32_t sf_idx, uint32_t sfn, bool updateMetaFormats, const lsn_dl_sf_cfg_t& dl_sf)  // SubframeWorker.h:32
   {
     if (lsn_worker_prepare(h, sf_idx, sfn, updateMetaFormats ? 1 : 0, &dl_sf) != LSN_SUCCESS) throw std::invalid_argument("prepare");
+  }
+  // the caller's srsran_dl_sf_cfg_t (SubframeWorker.h:32; LTESniffer_Core.cc:429-434): tti and sf_type cross the boundary, the CFI is decoded per subframe
+  template <class DlSfCfg> void prepare(uint32_t sf_idx, uint32_t sfn, bool updateMetaFormats, const DlSfCfg& dl_sf)
+  {
+    prepare(sf_idx, sfn, updateMetaFormats, lsn_dl_sf_cfg_t{(uint32_t)dl_sf.tti, 0u, (uint32_t)dl_sf.sf_type});
   }
   uint32_t getSfidx() const { return lsn_worker_sf_idx(h); }
   uint32_t getSfn() const { return lsn_worker_sfn(h); }
@@ -160,6 +171,11 @@ public:
   Phy(const Phy&) = delete;
   Phy& operator=(const Phy&) = delete;
   bool setCell(const lsn_cell_t& cell) { return lsn_phy_set_cell(h, &cell) == LSN_SUCCESS; }               // Phy.cc:111
+  // the caller's srsran_cell_t (LTESniffer_Core.cc:292): its enums count like lsn_cell_t's fields (SRSRAN_CP_NORM 0 / EXT 1, SRSRAN_PHICH_NORM 0, SRSRAN_PHICH_R_1_6 0 ... R_2 3)
+  template <class SrsranCell> bool setCell(const SrsranCell& c)
+  {
+    return setCell(lsn_cell_t{(uint32_t)c.nof_prb, (uint32_t)c.nof_ports, (uint32_t)c.id, (uint32_t)c.cp, (uint32_t)c.phich_length, (uint32_t)c.phich_resources, 0u});
+  }
   std::shared_ptr<SubframeWorker> getAvail() { return wrap(lsn_phy_get_avail(h, 1)); }                      // Phy.cc:79 (blocking)
   std::shared_ptr<SubframeWorker> getAvailImmediate() { return wrap(lsn_phy_get_avail(h, 0)); }             // Phy.cc:84
   void putPending(std::shared_ptr<SubframeWorker> w) { lsn_phy_put_pending(h, w->h); }                      // Phy.cc:95

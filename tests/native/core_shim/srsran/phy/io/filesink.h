@@ -1,0 +1,2 @@
+#pragma once
+#include "core_standin.h"
