@@ -479,6 +479,34 @@ bool ra_ul_dci_to_grant_256(const Cell& cell, const DciUl& d, PuschGrant& g)
   return true;
 }
 
+int ulTrialPlan(uint32_t mcs, int qb, uint32_t L256, int mod256, int mod, UlTry a[3])
+{
+  const bool ok256 = L256 < 110 && L256 > 0;
+  const int q16 = qb > 4 ? 4 : qb;
+  int n = 0;
+  auto add = [&](bool use256, int qm, int l) { a[n].use256 = use256; a[n].qm = qm; a[n].learn = l; n++; };
+  if (mcs > 20 && mcs < 29) {
+    if (mod == 2) add(false, 4, 0);
+    else if (mod == 3) add(false, qb, 0);
+    else if (mod == 4) { if (ok256) add(true, mod256, 0); }
+    else if (mod == 1) { add(false, 4, 2); add(false, qb, 3); if (ok256) add(true, mod256, 4); }
+  } else if (mcs <= 20) {  // decode_run's second rule (UL_Sniffer_PUSCH.cc:300-303): a passing 256QAM-table attempt with MCS > 0 reports 256QAM_MAX
+    const int l256 = mcs > 0 ? 4 : 0;
+    if (mod == 2 || mod == 3) add(false, q16, 0);
+    else if (mod == 4) { if (ok256) add(true, mod256, l256); }
+    else if (mod == 1) { add(false, q16, 0); if (ok256) add(true, mod256, l256); }
+  }
+  return n;
+}
+
+bool ulGrantValid(uint16_t rnti, bool is_rar, int tbs, int tbs_256, uint32_t L_prb)
+{
+  if (rnti == 0) return false;
+  if (is_rar) return true;
+  if (tbs == 0 || tbs_256 == 0) return false;
+  return ul_valid_prb(L_prb) && L_prb <= 100;
+}
+
 bool ul_valid_prb(uint32_t L)
 {
   if (L == 0 || L > 110) return false;

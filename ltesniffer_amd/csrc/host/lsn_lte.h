@@ -81,6 +81,14 @@ bool ra_ul_dci_to_grant(const Cell& cell, const DciUl& dci, PuschGrant& g);
 struct RarEntry { uint32_t rapid = 0, ta = 0, hopping = 0, riv = 0, mcs = 0, tpc = 0, ul_delay = 0, csi_req = 0; uint16_t t_crnti = 0; bool grant_ok = false; PuschGrant grant; };
 int rar_parse(const Cell& cell, const uint8_t* p, int len, RarEntry* out, int cap);
 bool ra_ul_dci_to_grant_256(const Cell& cell, const DciUl& dci, PuschGrant& g);  // ulsniffer_ra_ul_dci_to_grant_256, ul_sniffer_pusch.c:138-172
+// PUSCH_Decoder::decode's trial order for one scheduled grant (UL_Sniffer_PUSCH.cc:451-568), given the tracked maximum modulation of its RNTI
+// (find_tracking_info_RNTI_ul: 1 unknown, 2 / 3 / 4 = 16 / 64 / 256QAM maximum, 5 database full): up to three decode attempts, tried in order until one passes -
+// use256: the 256QAM-table grant, qm: modulation bits the decoder runs with (16QAM where the reference leaves enable_64qam off), learn: what update_RNTI_ul is told
+// when this attempt passes (decode_run :288-303; 0 = nothing).  Pinned on the compiled reference: tests/test_ref_ul_decode.py.
+struct UlTry { bool use256; int qm; int learn; };
+int ulTrialPlan(uint32_t mcs_idx, int grant_mod_bits, uint32_t L_prb_256, int mod_bits_256, int tracked, UlTry out[3]);
+// investigate_valid_ul_grant (UL_Sniffer_PUSCH.cc:894-918) + the RNTI test of :419
+bool ulGrantValid(uint16_t rnti, bool is_rar, int tbs, int tbs_256, uint32_t L_prb);
 bool ul_valid_prb(uint32_t L);                                                    // valid_prb_ul, UL_Sniffer_PUSCH.cc:3-10
 int dl_sniffer_config_mimo(const Cell& cell, DciFormat f, const DciDl& dci, PdschGrant& g);  // 0 ok
 bool pdsch_re_usable(const Cell& cell, uint32_t sf_idx, uint32_t l, uint32_t k);

@@ -182,31 +182,13 @@ void Engine::commitChunkUl(Chunk& ch, JobRunner& r)
   while (rar_sched.size() > 64) rar_sched.erase(rar_sched.begin());
 
   // ---- the reference's trial order as a list of attempts, given the tracked maximum modulation ----
-  auto valid_grant = [&](const UlSchedGrant& m) {  // investigate_valid_ul_grant, UL_Sniffer_PUSCH.cc:894-918 (+ rnti != 0, :419)
-    if (m.rnti == 0) return false;
-    if (m.is_rar) return true;
-    if (m.g.tbs == 0 || m.g256.tbs == 0) return false;
-    return ul_valid_prb(m.g.L_prb) && m.g.L_prb <= 100;
-  };
+  auto valid_grant = [&](const UlSchedGrant& m) { return ulGrantValid(m.rnti, m.is_rar, m.g.tbs, m.g256.tbs, m.g.L_prb); };  // investigate_valid_ul_grant (lsn_lte.cc)
   auto mod_of = [&](uint16_t rnti) -> int { return ulmod[rnti] ? ulmod[rnti] : (ulmod_count < 250 ? 1 : 5); };  // find_tracking_info_RNTI_ul; 5 = FULL_BUFFER
   auto trial = [&](const UlSchedGrant& m, int mod, Attempt* a, int* learn) -> int {
-    // returns the number of attempts (tried in order until one passes); learn[i]: modulation learnt if attempt i passes (0: none)
-    const uint32_t mcs = m.g.mcs_idx;
-    const bool ok256 = m.g256.L_prb < 110 && m.g256.L_prb > 0;
-    const int qb = m.g.mod, q16 = qb > 4 ? 4 : qb;
-    int n = 0;
-    auto add = [&](bool use256, int qm, int l) { a[n].use256 = use256; a[n].qm = qm; learn[n] = l; n++; };
-    if (mcs > 20 && mcs < 29) {
-      if (mod == 2) add(false, 4, 0);
-      else if (mod == 3) add(false, qb, 0);
-      else if (mod == 4) { if (ok256) add(true, m.g256.mod, 0); }
-      else if (mod == 1) { add(false, 4, 2); add(false, qb, 3); if (ok256) add(true, m.g256.mod, 4); }
-    } else if (mcs <= 20) {  // decode_run's second rule (UL_Sniffer_PUSCH.cc:300-303): a passing 256QAM-table attempt with MCS > 0 reports 256QAM_MAX
-      const int l256 = mcs > 0 ? 4 : 0;
-      if (mod == 2 || mod == 3) add(false, q16, 0);
-      else if (mod == 4) { if (ok256) add(true, m.g256.mod, l256); }
-      else if (mod == 1) { add(false, q16, 0); if (ok256) add(true, m.g256.mod, l256); }
-    }
+    // returns the number of attempts (tried in order until one passes); learn[i]: modulation learnt if attempt i passes (0: none) - ulTrialPlan, lsn_lte.cc
+    UlTry t[3];
+    const int n = ulTrialPlan(m.g.mcs_idx, m.g.mod, m.g256.L_prb, m.g256.mod, mod, t);
+    for (int i = 0; i < n; i++) { a[i].use256 = t[i].use256; a[i].qm = t[i].qm; learn[i] = t[i].learn; }
     return n;
   };
   // uci_cfg of an attempt, UL_Sniffer_PUSCH.cc:429-450: HARQ-ACK bits come with the grant; an aperiodic CSI request adds a CQI report of the

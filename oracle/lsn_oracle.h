@@ -389,6 +389,12 @@ uint32_t o_worker_collect_end(o_worker_t* w, uint32_t* dl, uint32_t dl_cap, uint
 void o_worker_collect_mcs_update(o_worker_t* w, uint16_t rnti, int table);
 void o_worker_collect_harq_update(o_worker_t* w, uint16_t rnti, int pid, int tid, uint32_t sfn, uint32_t sf_idx, int decoded, int ndi, int rv, int tbs);
 void o_worker_collect_set_hop_offset(o_worker_t* w, uint32_t n_rb_ho);
+/* probes for tests/test_ref_ul_decode.py: PUSCH_Decoder::decode on a given schedule, every attempt answered by a scripted uplink decoder (o_worker.c) */
+void o_worker_set_ul_script(o_worker_t* w, int (*fn)(void* user, const uint32_t* call16, float* snr_db, uint8_t* payload), void* user);
+void o_worker_set_last_ul_snr(o_worker_t* w, float snr_db);
+void o_worker_ul_decode_probe(o_worker_t* w, uint32_t tti, uint32_t n, const uint32_t* e12);
+void o_worker_ul_update_database(o_worker_t* w);
+void o_worker_ul_set_ue_config(o_worker_t* w, uint16_t rnti, uint32_t i_ack, uint32_t i_cqi, uint32_t i_ri, uint32_t cqi_type);
 /* probes for tests/test_ref_decode.py: decode_dl_mode on the collected entries, every decode call answered by a scripted decoder (call16 = {tti, rnti, nof_re, tx_scheme,
  * pmi, nof_layers, per block: enabled, modulation bits, tbs, rv, cw_idx}; it writes the payloads and two CRC verdicts) */
 void o_worker_set_script_decoder(o_worker_t* w, int (*fn)(void* user, const uint32_t* call16, float p_a, uint8_t* payload0, uint8_t* payload1, int32_t* crc2), void* user);

@@ -115,6 +115,11 @@ struct o_worker {
   /* scripted decoder (tests/test_ref_decode.py): when set, a decode call is described to this function instead of being demodulated and decoded */
   int (*script_fn)(void* user, const uint32_t* call16, float p_a, uint8_t* payload0, uint8_t* payload1, int32_t* crc2);
   void* script_user;
+  /* scripted uplink decoder (tests/test_ref_ul_decode.py): one PUSCH attempt is described to this function - 16 words {tti, rnti, L_prb, n_prb, mcs_idx, modulation bits
+   * tried, tbs, -, nof_ack, CSI requested, report type, I_offset_ack, I_offset_cqi, I_offset_ri, RI bits, CQI bits} - which answers with the CRC verdict and the SNR the
+   * estimator would report */
+  int (*ul_script_fn)(void* user, const uint32_t* call16, float* snr_db, uint8_t* payload);
+  void* ul_script_user;
 };
 
 
@@ -1109,6 +1114,15 @@ static int pusch_attempt(o_worker_t* w, const ulg_t* m, const o_pusch_grant_t* g
   const o_ue_cfg_t uc = ue_cfg_get(w, m->rnti);
   o_uci_t uci = {m->nof_ack, m->cqi_req ? (uint32_t)o_uci_cqi_bits_type(w->cfg.cell.nof_prb, uc.cqi_type) : 0u, m->cqi_req ? 1u : 0u,
                  uc.i_offset_ack + 1u, uc.i_offset_cqi + 1u, uc.i_offset_ri + 1u};
+  if (w->ul_script_fn) {
+    const uint32_t call[16] = {tti, m->rnti, gg.L_prb, gg.n_prb, gg.mcs_idx, (uint32_t)qm, (uint32_t)gg.tbs, 0, m->nof_ack, m->cqi_req, uc.cqi_type,
+                               uc.i_offset_ack, uc.i_offset_cqi, uc.i_offset_ri, uci.ri_bits, uci.cqi_bits};
+    memset(w->payload, 0, (size_t)(gg.tbs / 8));
+    const int c = w->ul_script_fn(w->ul_script_user, call, &snr, w->payload);
+    w->last_ul_snr = snr;
+    if (c) write_pcap_ul(w, w->payload, (uint32_t)(gg.tbs / 8), m->rnti, tti, m->is_rar);
+    return c;
+  }
   if (o_trace_enabled()) o_trace_begin_job(tti, m->rnti, 0, NULL, NULL, NULL, 1);
   int crc = o_pusch_decode_uci(&w->cfg.cell, &w->ulcfg, tti % 10, m->rnti, &gg, m->n_dmrs, &uci, w->ul_grid, w->cfg.max_turbo_iter, w->payload, &its, &snr);
   w->total_iters += (uint64_t)its;
@@ -1150,6 +1164,7 @@ uint32_t o_worker_nof_tracked_ul(o_worker_t* w) { return w->ulmod_count; }
 int o_worker_tracked_mod_ul(o_worker_t* w, uint16_t rnti) { return w->ulmod ? (int)w->ulmod[rnti] : 0; }
 
 /* PUSCH_Decoder::decode, UL_Sniffer_PUSCH.cc:389-583 (statistics / debug printing dropped) */
+static void decode_pusch_list(o_worker_t* w, uint32_t tti, ulg_t* list, int n);
 static void decode_pusch(o_worker_t* w, uint32_t tti)
 {
   uint32_t t4 = (tti + 10240 - 4) % 10240, t6 = (tti + 10240 - 6) % 10240;
@@ -1162,6 +1177,10 @@ static void decode_pusch(o_worker_t* w, uint32_t tti)
   if (have_r) for (int i = 0; i < r->n; i++) list[n++] = r->g[i];
   if (have_a) a->valid = 0;
   if (have_r) r->valid = 0;
+  decode_pusch_list(w, tti, list, n);
+}
+static void decode_pusch_list(o_worker_t* w, uint32_t tti, ulg_t* list, int n)
+{
   for (int i = 0; i < n; i++) {
     ulg_t* m = &list[i];
     int valid = 1; /* investigate_valid_ul_grant, :894-918 */
@@ -1345,6 +1364,39 @@ void o_worker_collect_harq_update(o_worker_t* w, uint16_t rnti, int pid, int tid
   if (ent && (verdict == O_HARQ_NEW_TX || verdict == O_HARQ_RE_TX)) harq_update(w, ent, pid, tid, sfn, sf_idx, decoded, ndi, rv, tbs); /* :1008-1014 */
 }
 void o_worker_collect_set_hop_offset(o_worker_t* w, uint32_t n_rb_ho) { w->cfg.cell.pusch_hop_offset = n_rb_ho; }
+
+/* ---- probes for tests/test_ref_ul_decode.py: PUSCH_Decoder::decode on a given schedule with a scripted uplink decoder ---- */
+void o_worker_set_ul_script(o_worker_t* w, int (*fn)(void*, const uint32_t*, float*, uint8_t*), void* user) { w->ul_script_fn = fn; w->ul_script_user = user; }
+void o_worker_set_last_ul_snr(o_worker_t* w, float snr_db) { w->last_ul_snr = snr_db; }
+/* n entries x 12 words {rnti, is_rar, mcs_idx, L_prb, n_prb, modulation bits, tbs, L_prb of the 256QAM-table grant, its modulation bits, its tbs, cqi_request, nof_ack};
+ * the DCI 0 entries first, then the RAR entries - the order PUSCH_Decoder::decode walks them (UL_Sniffer_PUSCH.cc:395-412) */
+void o_worker_ul_decode_probe(o_worker_t* w, uint32_t tti, uint32_t n, const uint32_t* e12)
+{
+  ulg_t list[192];
+  int k = 0;
+  w->records = 0;
+  for (int pass = 0; pass < 2; pass++)
+    for (uint32_t i = 0; i < n && k < 192; i++) {
+      const uint32_t* e = e12 + 12 * i;
+      if ((int)(e[1] != 0) != pass) continue;
+      ulg_t* m = &list[k++];
+      memset(m, 0, sizeof(*m));
+      m->rnti = (uint16_t)e[0]; m->is_rar = e[1] != 0; m->cqi_req = e[10]; m->nof_ack = e[11];
+      m->g.mcs_idx = m->g256.mcs_idx = e[2]; m->g.L_prb = e[3]; m->g.n_prb = m->g256.n_prb = e[4]; m->g.mod = (int)e[5]; m->g.tbs = (int)e[6];
+      m->g256.L_prb = e[7]; m->g256.mod = (int)e[8]; m->g256.tbs = (int)e[9];
+    }
+  decode_pusch_list(w, tti, list, k);
+  w->sf_count++;
+}
+void o_worker_ul_update_database(o_worker_t* w) { ul_update_database(w); }
+void o_worker_ul_set_ue_config(o_worker_t* w, uint16_t rnti, uint32_t i_ack, uint32_t i_cqi, uint32_t i_ri, uint32_t cqi_type)
+{
+  o_ue_cfg_t c = ue_cfg_get(w, rnti);
+  c.i_offset_ack = i_ack; c.i_offset_cqi = i_cqi; c.i_offset_ri = i_ri; c.cqi_type = cqi_type;
+  ul_add(w, rnti, 1); /* update_ue_config_rnti, UL_MODE branch (MCSTracking.cc:1464-1479) */
+  c.has_ue_config = 1;
+  w->uecfg[rnti] = c;
+}
 
 /* ---- probes for tests/test_ref_decode.py: PDSCH_Decoder::decode_dl_mode (decode_dl_mode above) on the collected entries with a scripted decoder ---- */
 void o_worker_set_script_decoder(o_worker_t* w, int (*fn)(void*, const uint32_t*, float, uint8_t*, uint8_t*, int32_t*), void* user) { w->script_fn = fn; w->script_user = user; }

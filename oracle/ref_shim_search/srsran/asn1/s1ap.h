@@ -1,0 +1,3 @@
+/* see srsran/standin_ul.h */
+#pragma once
+#include "srsran/standin_ul.h"

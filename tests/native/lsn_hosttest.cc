@@ -464,4 +464,13 @@ int lsnh_rm_get_activation_reason(void* h, uint16_t rnti) { return (int)((RNTIMa
 void lsnh_rm_set_threshold(void* h, uint32_t t) { ((RNTIManager*)h)->setHistogramThreshold(t); }
 uint32_t lsnh_rm_nof_active(void* h) { return ((RNTIManager*)h)->nofActive(); }
 
+// PUSCH_Decoder::decode's trial order and grant test (lsn_lte.cc: ulTrialPlan, ulGrantValid) for tests/test_ref_ul_decode.py: out = n x {use256, qm, learn}
+int lsn_host_ul_trial(uint32_t mcs_idx, int grant_mod_bits, uint32_t L_prb_256, int mod_bits_256, int tracked, int32_t* out9)
+{
+  lsn::UlTry t[3];
+  const int n = lsn::ulTrialPlan(mcs_idx, grant_mod_bits, L_prb_256, mod_bits_256, tracked, t);
+  for (int i = 0; i < n; i++) { out9[3 * i] = t[i].use256; out9[3 * i + 1] = t[i].qm; out9[3 * i + 2] = t[i].learn; }
+  return n;
+}
+int lsn_host_ul_grant_valid(uint32_t rnti, int is_rar, int tbs, int tbs_256, uint32_t L_prb) { return lsn::ulGrantValid((uint16_t)rnti, is_rar != 0, tbs, tbs_256, L_prb) ? 1 : 0; }
 }  // extern "C"
