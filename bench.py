@@ -359,6 +359,8 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    if os.environ.get("LSN_BENCH_STAMP"):   # wall-clock stamps of the timed region: processes that share a GPU (tools/r6_session6.sh) show whether their regions overlapped
+        print("[stamp] timed region %.3f .. %.3f (unix s)" % (time.time() - dt, time.time()), file=sys.stderr)
     ru1 = resource.getrusage(resource.RUSAGE_SELF)
     thr1 = _thread_cpu()
     p = phy.perf()
@@ -631,6 +633,8 @@ def main():
         for k, v in thr1.items():
             per_thr[k[1]] = per_thr.get(k[1], 0.0) + (v - thr0.get(k, 0.0)) / dt
         busiest = {k: round(v, 2) for k, v in sorted(per_thr.items(), key=lambda kv: -kv[1])[:8] if v >= 0.01}
+        if os.environ.get("LSN_BENCH_ALL_THREADS"):
+            print("[threads] " + json.dumps({k: round(v, 3) for k, v in sorted(per_thr.items(), key=lambda kv: -kv[1]) if v >= 0.005}), file=sys.stderr)
         nk = len(la.KERNELS)
         dom = int(np.argmax(kms[:nk]))
         sf_rank = args.steps * S  # subframes this rank processed in the timed region

@@ -34,6 +34,8 @@ namespace lsn {
 // threads' timer slack set to 1 us so the naps are that short.  (Spinning instead was measured in round 5: no gain, profiles/r05_exp_session21.txt.)
 // LSN_NO_CB_SKIP=1: decode every code block even when the first block of its transport block has already failed (iteration counts then equal the oracle's)
 // (read when an engine is made: Engine::cb_skip; the GPU suite runs with it)
+// (Round 6: naps of 200 / 500 us in the decode threads and 60 us in the front thread were measured - same rate, same busy cores: the polling is not what the
+// decode threads' CPU time goes into, profiles/r06_host_cost.txt.)
 static void waitEvent(hipEvent_t ev, long nap_ns = 50000)
 {
   for (;;) {
@@ -653,18 +655,18 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
     if (ncb) {
       // launch order: per phase the blocks that get a workgroup of their own first, then the blocks that share one; each class by descending size (longest
       // jobs first; the two blocks of a pair are neighbours in size, so their wavefronts run for about the same time)
+      // two phases: first every block that nothing depends on having passed (block 0 of each transport block), then the dependants.  The key (phase, solo before
+      // paired, K descending, index ascending) has 2 x 6 144 values: a counting sort - the comparison sort this replaces cost 1.5 us of decode-thread CPU per
+      // subframe (round 6, thread-CPU sections)
       order.resize(ncb);
-      for (uint32_t i = 0; i < ncb; i++) { r.h_cbs[i].res_idx = i; order[i] = i; }
-      // two phases: first every block that nothing depends on having passed (block 0 of each transport block), then the dependants
-      std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) {
-        const bool dx = r.h_cbs[x].dep != LSN_CB_NODEP, dy = r.h_cbs[y].dep != LSN_CB_NODEP;
-        if (dx != dy) return dy;
-        const uint32_t kx = r.h_cbs[x].K, ky = r.h_cbs[y].K;
-        const bool px = pairable(kx), py = pairable(ky);
-        if (px != py) return py;
-        if (kx != ky) return kx > ky;
-        return x < y;
-      });
+      {
+        static thread_local std::vector<uint32_t> cnt;
+        cnt.assign(2 * 2 * 6145 + 1, 0);
+        auto key = [&](const LsnCbDev& q) { return ((q.dep != LSN_CB_NODEP ? 1u : 0u) * 2u + (pairable(q.K) ? 1u : 0u)) * 6145u + (6144u - std::min<uint32_t>(q.K, 6144u)); };
+        for (uint32_t i = 0; i < ncb; i++) { r.h_cbs[i].res_idx = i; cnt[key(r.h_cbs[i]) + 1]++; }
+        for (size_t k = 1; k < cnt.size(); k++) cnt[k] += cnt[k - 1];
+        for (uint32_t i = 0; i < ncb; i++) order[cnt[key(r.h_cbs[i])]++] = i;   // stable: equal keys keep ascending index
+      }
       for (uint32_t i = 0; i < ncb; i++) {
         LsnCbDev q = r.h_cbs[order[i]];
         q.spp_off = (uint32_t)spp_n; spp_n += LSN_SPP_WORDS(q.K);
@@ -780,14 +782,17 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
       bool all_ok = true;
       uint32_t rem = 0;
       uint64_t bits_after = 0;
+      uint32_t shift = 1;   // x^bits_after mod g, carried along: one or two multiplications per block instead of a modular power
       for (int q = (int)t.cb_count - 1; q >= 0; q--) {
         const LsnCbRes& cr = r.h_cbres_pinned[t.cb_first + q];
         all_ok = all_ok && cr.ok != 0;
         j.iters += cr.iters;
         pf.nof_turbo_iterations += cr.iters; pf.nof_turbo_iterations_run += cr.iters_run;
         pf.turbo_cyc_rm += cr.cyc_rm; pf.turbo_cyc_map += cr.cyc_map; pf.turbo_cyc_out += cr.cyc_out;
-        rem ^= crc24a_mulmod(cr.rem_a, crc24a_xpow(bits_after));
-        bits_after += 8ull * r.h_cbs[t.cb_first + q].out_bytes;
+        rem ^= bits_after ? crc24a_mulmod(cr.rem_a, shift) : (cr.rem_a & 0xFFFFFFu);
+        const uint32_t nb = r.h_cbs[t.cb_first + q].out_bytes;
+        bits_after += 8ull * nb;
+        if (q > 0) shift = crc24a_mulmod(shift, crc24a_xpow_bytes(nb));
       }
       const int tbs = j.grant.tb[t.tb].tbs;
       const uint8_t* pl = ch.h_payload.data() + j.payload_off[t.tb];

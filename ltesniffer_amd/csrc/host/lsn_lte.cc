@@ -1,4 +1,5 @@
 // lsn_lte.cc - see lsn_lte.h.  Product code: must not include anything from oracle/.
+#include <atomic>
 #include "lsn_lte.h"
 #ifdef __HIPCC__
 #include <hip/hip_runtime.h>  // lsn_rm.h marks its helpers __host__ __device__ under hipcc
@@ -872,6 +873,15 @@ uint32_t crc24a_mulmod(uint32_t a, uint32_t b)
     if ((b >> i) & 1u) r ^= a;
   }
   return r & 0xFFFFFFu;
+}
+// x^(8 nbytes) mod g for the payload sizes of code blocks (at most 768 bytes): computed once per size
+uint32_t crc24a_xpow_bytes(uint32_t nbytes)
+{
+  static std::atomic<uint32_t> memo[1024];   // 0 = not computed yet (a power of x is never 0 mod g)
+  if (nbytes >= 1024) return crc24a_xpow(8ull * nbytes);
+  uint32_t v = memo[nbytes].load(std::memory_order_relaxed);
+  if (!v) { v = crc24a_xpow(8ull * nbytes); memo[nbytes].store(v, std::memory_order_relaxed); }
+  return v;
 }
 uint32_t crc24a_xpow(uint64_t n)
 {

@@ -283,6 +283,7 @@ private:
 
 // ---- GF(2) helpers for the transport-block CRC combine ----
 uint32_t crc24a_xpow(uint64_t n);                 // x^n mod g_CRC24A
+uint32_t crc24a_xpow_bytes(uint32_t nbytes);      // x^(8 nbytes) mod g_CRC24A, memoised per code-block payload size
 uint32_t crc24a_mulmod(uint32_t a, uint32_t b);   // a*b mod g_CRC24A
 uint32_t crc_bits(uint32_t poly, int order, const uint8_t* bits, int n);
 
