@@ -109,10 +109,10 @@ def script(life):
             # (a RAR entry whose grant conversion failed - size 0 - is still handed to srsRAN by the reference, :419 lets every RAR entry through, and refused there; the
             # oracle and the product do not make that call.  Its only trace would be the estimator's SNR, and a failed conversion has no valid PRB count for the
             # estimator either: the lives keep RAR entries decodable)
-            tbs = 0 if (mcs >= 29 or (rng.random() < 0.03 and not is_rar)) else 8 * (3 + (_mix(seed, mcs, L) % 300))
+            tbs = 0 if ((mcs >= 29 and rng.random() < 0.5) or (rng.random() < 0.03 and not is_rar)) else 8 * (3 + (_mix(seed, mcs, L) % 300))   # (MCS 29-31: a retransmission takes the size of the grant before it - or has none)
             L256 = L if rng.random() < 0.9 else rng.choice((0, 110, 120))
             mod256 = 2 if mcs < 6 else 4 if mcs < 14 else 6 if mcs < 23 else 8
-            tbs256 = 0 if (mcs >= 29 or (rng.random() < 0.03 and not is_rar)) else tbs + 8 * (1 + mcs % 5)
+            tbs256 = 0 if (tbs == 0 and mcs >= 29) or (rng.random() < 0.03 and not is_rar) else tbs + 8 * (1 + mcs % 5)
             ent.append((r, is_rar, mcs, L, n_prb, mod, tbs, L256, mod256, tbs256, 1 if rng.random() < 0.2 else 0, rng.randrange(3)))
             by_grant[(tti, r)] = (mcs, mod, tbs, mod256, tbs256)
         ev.append(("sf", tti, ent))
