@@ -583,7 +583,7 @@ def main():
                 wl.set_digest_blocks(bl.BLOCK, tl)
                 nl, npass = ld["nsf"], ld["passes"]
                 if ld["kind"] == "dl":
-                    pl = la.Phy(nof_rx_antennas=scl["nof_rx"], max_batch=batch, device=local, pcapwriter=wl, harq_mode=ld.get("harq_mode", 0))
+                    pl = la.Phy(nof_rx_antennas=scl["nof_rx"], max_batch=int(os.environ.get("LSN_HARQ_LEG_BATCH", batch)) if ld.get("harq_mode") else batch, device=local, pcapwriter=wl, harq_mode=ld.get("harq_mode", 0))
                     pl.setCell(scl["nof_prb"], scl["nof_ports"], scl["cell_id"])
                     dl_ = torch.empty((nl,) + iql.shape[1:] + (2,), dtype=torch.float32, device=dev)
                     for a_ in range(0, nl, 2000):
@@ -621,6 +621,9 @@ def main():
                               "pdus_per_subframe": round(pfl.nof_pdus / float(counted), 2),
                               "oracle_subframes": cov * bl.BLOCK, "oracle_blocks_compared": cov, "oracle_blocks_mismatching": bad,
                               "pcap_diff": (int(rd + (bad if rd == 0 else 0)) if gl is not None and cov == nb else None), "golden_note": gnote}
+                if ld.get("harq_mode"):   # retransmissions: batches run ahead of the commit walk / combined decodes taken from a batch / decoded alone inside the turn / batch results never asked for
+                    legs[name]["harq_combines"] = dict(zip(("batches", "from_a_batch", "alone_in_the_commit_turn", "batch_results_unused"), [int(x) for x in pfl.nof_harq_combines]))
+                    legs[name]["harq_commit_ms"] = {"scout": round(pfl.ms_harq[0], 1), "batches": round(pfl.ms_harq[1], 1), "flush": round(pfl.ms_harq[2], 1), "commit_turns_all": round(pfl.ms_commit, 1), "stage_c_all_threads": round(pfl.ms_stage_c, 1)}
                 pl.close()
                 del iql
             except Exception as ex:

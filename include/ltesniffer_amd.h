@@ -429,6 +429,8 @@ typedef struct {
    * jobs / turbo iterations run, and the part of both the commit stage never looked at */
   uint64_t jobs_by_kind[5], jobs_unused_by_kind[5], iters_by_kind[5], iters_unused_by_kind[5];
   uint64_t nof_table_hints_used, nof_table_hints_missed;  /* DCIs planned for the 256QAM table alone on the decode threads' own evidence / of those the commit wanted the 64QAM-table attempt of after all (engine totals) */
+  double ms_harq[3];              /* harq_mode = 1, commit-thread time: [0] predicting the retransmissions of the chunks (harqScout), [1] inside the batches (descriptors, launches, wait), [2] bringing the touched buffers home at the end of the turns */
+  uint64_t nof_harq_combines[4];  /* harq_mode = 1: [0] batches of retransmissions combined and decoded ahead of the commit walk, [1] combined decodes the walk took from a batch, [2] ... it had to run alone inside its turn, [3] batch results nobody asked for */
 } lsn_perf_t;
 int lsn_phy_get_perf(lsn_phy_t* phy, lsn_perf_t* out);
 enum { LSN_K_OFDM = 0, LSN_K_CHEST, LSN_K_CHEST_FIN, LSN_K_PCFICH, LSN_K_PDCCH_LLR, LSN_K_CCE_POWER, LSN_K_VITERBI,

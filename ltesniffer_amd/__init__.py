@@ -155,7 +155,7 @@ class Perf(C.Structure):
                 ("nof_turbo_iterations_run", C.c_uint64), ("nof_ondemand_commit", C.c_uint64 * 4), ("ms_ondemand_commit", C.c_double), ("nof_pusch_2prb_skipped", C.c_uint64), ("nof_pusch_on_unverified_dmrs", C.c_uint64), ("nof_tb_on_derived_tbs", C.c_uint64),
                 ("nof_decode_jobs", C.c_uint64), ("nof_decode_jobs_used", C.c_uint64), ("nof_speculative_jobs", C.c_uint64),
                 ("jobs_by_kind", C.c_uint64 * 5), ("jobs_unused_by_kind", C.c_uint64 * 5), ("iters_by_kind", C.c_uint64 * 5), ("iters_unused_by_kind", C.c_uint64 * 5),
-                ("nof_table_hints_used", C.c_uint64), ("nof_table_hints_missed", C.c_uint64)]
+                ("nof_table_hints_used", C.c_uint64), ("nof_table_hints_missed", C.c_uint64), ("ms_harq", C.c_double * 3), ("nof_harq_combines", C.c_uint64 * 4)]
 
 
 class UlCfg(C.Structure):

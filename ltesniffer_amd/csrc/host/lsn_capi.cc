@@ -200,11 +200,15 @@ int lsn_phy_create_multi(const lsn_phy_cfg_t* cfg, const int* devices, uint32_t 
         if (hipDeviceCanAccessPeer(&can, devices[i], devices[0]) == hipSuccess && can) {
           (void)hipSetDevice(devices[i]);
           const hipError_t pe = hipDeviceEnablePeerAccess(devices[0], 0);
-          if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled)
+          if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) {
             fprintf(stderr, "ltesniffer_amd: peer access %d -> %d refused (%s): blocks resident on device %d are copied through the runtime's staging path\n", devices[i], devices[0], hipGetErrorString(pe), devices[0]);
+            // harq_mode = 1: the soft-buffer pool lives on the first device and this engine's combine / copy kernels read and write it in place
+            if (ci.harq_mode) throw std::invalid_argument("harq_mode on several GPUs needs peer access to the first device (soft-buffer pool)");
+          }
           (void)hipGetLastError();
         } else {
           fprintf(stderr, "ltesniffer_amd: no peer access %d -> %d (hipDeviceCanAccessPeer): device-resident blocks take the runtime's staging path\n", devices[i], devices[0]);
+          if (ci.harq_mode) throw std::invalid_argument("harq_mode on several GPUs needs peer access to the first device (soft-buffer pool)");
         }
       }
     }
@@ -608,6 +612,8 @@ int lsn_phy_get_perf(lsn_phy_t* phy, lsn_perf_t* out)
     out->turbo_cyc_out += p.turbo_cyc_out; out->ms_wait_front += p.ms_wait_front; out->ms_wait_slot += p.ms_wait_slot; out->ms_drain = std::max(out->ms_drain, p.ms_drain);
     out->nof_turbo_iterations_run += p.nof_turbo_iterations_run; out->ms_ondemand_commit += p.ms_ondemand_commit;
     for (int k = 0; k < 4; k++) out->nof_ondemand_commit[k] += p.nof_ondemand_commit[k];
+    for (int k = 0; k < 4; k++) out->nof_harq_combines[k] += p.nof_harq_combines[k];
+    for (int k = 0; k < 3; k++) out->ms_harq[k] += p.ms_harq[k];
     out->nof_pusch_on_unverified_dmrs += p.nof_pusch_on_unverified_dmrs; out->nof_tb_on_derived_tbs += p.nof_tb_on_derived_tbs;
     out->nof_decode_jobs += p.nof_decode_jobs; out->nof_decode_jobs_used += p.nof_decode_jobs_used; out->nof_speculative_jobs += p.nof_speculative_jobs;
     for (int k = 0; k < 5; k++) { out->jobs_by_kind[k] += p.jobs_by_kind[k]; out->jobs_unused_by_kind[k] += p.jobs_unused_by_kind[k]; out->iters_by_kind[k] += p.iters_by_kind[k]; out->iters_unused_by_kind[k] += p.iters_unused_by_kind[k]; }

@@ -132,7 +132,7 @@ Engine::Engine(const lsn_phy_cfg_t& c, std::shared_ptr<SharedSeq> shared) : sh(s
   if (cfg.sniffer_mode != 0 && cfg.sniffer_mode != 1) throw std::invalid_argument("sniffer_mode");
   if (cfg.sniffer_mode == 1 && cfg.nof_rx_antennas != 2) throw std::invalid_argument("UL_MODE needs two antenna buffers");
   if (cfg.harq_mode != 0 && cfg.harq_mode != 1) throw std::invalid_argument("harq_mode");  // 0 (the reference's only reachable value, ArgManager.cc:50) or 1
-  if (cfg.harq_mode && (cfg.sniffer_mode != 0 || shared)) throw std::invalid_argument("harq_mode: DL mode on one engine only");  // (the soft-buffer pool lives on one device)
+  if (cfg.harq_mode && cfg.sniffer_mode != 0) throw std::invalid_argument("harq_mode: DL mode only");
   max_batch = cfg.max_batch ? cfg.max_batch : 64;
   if (cfg.max_turbo_iterations <= 0) cfg.max_turbo_iterations = 12;  // SubframeWorker.cc:365
   if (cfg.meta_format_split_ratio <= 0.0) cfg.meta_format_split_ratio = 0.99;
@@ -274,6 +274,8 @@ void Engine::mergePerf(const lsn_perf_t& p)
   perf.nof_candidates_decoded += p.nof_candidates_decoded; perf.nof_ondemand_decodes += p.nof_ondemand_decodes; perf.nof_pdus += p.nof_pdus;
   for (int k = 0; k < 4; k++) perf.nof_ondemand_commit[k] += p.nof_ondemand_commit[k];
   perf.ms_ondemand_commit += p.ms_ondemand_commit;
+  for (int k = 0; k < 4; k++) perf.nof_harq_combines[k] += p.nof_harq_combines[k];
+  for (int k = 0; k < 3; k++) perf.ms_harq[k] += p.ms_harq[k];
   perf.nof_pusch_2prb_skipped += p.nof_pusch_2prb_skipped;
   perf.nof_pusch_on_unverified_dmrs += p.nof_pusch_on_unverified_dmrs;
   perf.nof_tb_on_derived_tbs += p.nof_tb_on_derived_tbs;
@@ -703,6 +705,7 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
         lsn_launch_copy_multi(dn, true, st);
       }
       if (cfg.harq_mode) {  // the soft data of this launch stays with the chunk until its commit (HARQ buffers are filled / combined there)
+        if (ch.keep_n + spp_n >= ((size_t)1 << 30)) throw std::runtime_error("harq_mode: the soft data of one chunk exceeds 4 GB (2^30 words) - process smaller batches");   // (HarqKeep::loc: 30-bit word offsets)
         if (ch.keep_n + spp_n > ch.keep_cap) {
           const size_t cap = (ch.keep_n + spp_n) * 2 + (1u << 20);
           uint32_t* nb = nullptr;
@@ -1089,6 +1092,26 @@ void Engine::ageTrackingDatabase()
 void Engine::commitChunk(Chunk& ch, JobRunner& r)
 {
   std::vector<McsTable> tables;
+  if (cfg.harq_mode) {
+    // the retransmissions of this chunk, combined and decoded in a few batches ahead of the walk (harqScout): pass p serves the p-th retransmission in a row
+    // of the same buffer.  The scratch area is empty here (harqFlush of the previous turn): it may be given a new size
+    harq_scratch_n = 0;
+    const size_t want = std::min<size_t>(ch.keep_n + 4096, (size_t)(1u << 30) - 1);
+    if (want > harq_scratch_cap) grow_dev(d_harq_scratch, harq_scratch_cap, want, r.stream);
+    std::vector<HarqReq> reqs;
+    for (int pass = 0; pass < 8; pass++) {
+      const double t0 = now_ms();
+      harqScout(ch, reqs, pass == 0);
+      r.perf.ms_harq[0] += now_ms() - t0;
+      if (reqs.empty()) break;
+      size_t need = 0;
+      for (const HarqReq& q : reqs)
+        for (uint32_t b = 0; b < q.n; b++)
+          if (!q.ok[b]) need += LSN_SPP_WORDS(ch.keep_cbs[ch.jobs[q.job].keep_first[q.tb] + b].K);
+      if (harq_scratch_n + need > harq_scratch_cap) break;   // (what does not fit is decoded by the walk itself)
+      harqRunBatch(ch, r, reqs);
+    }
+  }
   for (uint32_t sf = 0; sf < ch.nsf; sf++, commit_sf_cnt++) {
     SubframeCtx& c = ch.ctx[sf];
     // the tracking database is only WRITTEN here (commit thread); decode threads read the published prediction arrays, the API getter
@@ -1240,7 +1263,7 @@ void Engine::commitChunk(Chunk& ch, JobRunner& r)
       publishPrediction(d.rnti);
     }
   }
-  if (cfg.harq_mode) harqFlushStores(ch, r, true);   // the chunk's keep store is recycled with the chunk: its queued soft-buffer copies go out now
+  if (cfg.harq_mode) harqFlush(ch, r);   // the chunk's keep store is recycled with the chunk: what its buffers hold there (and in the scratch area) goes home now
   for (const DecodeJob& j : ch.jobs) {
     if (!j.done) continue;
     const int k = j.kind < 5 ? j.kind : 0;
@@ -1250,53 +1273,287 @@ void Engine::commitChunk(Chunk& ch, JobRunner& r)
 }
 
 // ------------------------------------------------------------------------------------------------ HARQ soft buffers (harq_mode = 1)
-// All buffer traffic runs on the commit runner's stream in commit order, so the pool always holds what the reference's softbuffer_rx of that
-// (RNTI, process, TB) would hold at this point of the stream.  Block q of a transport block sits at slot * HARQ_SLOT_WORDS + q * HARQ_CB_WORDS.
+// Block q of the buffer of a (RNTI entity, process, transport block) has its home in the pool at slot * HARQ_SLOT_WORDS + q * HARQ_CB_WORDS.  Inside a commit
+// turn the content may lie elsewhere (HarqKeep::loc): a failed new transmission stays in the chunk's keep store, a combination in the turn's scratch area;
+// harqFlush brings everything home before the chunk (and with it the keep store) is recycled.  Round 6: retransmissions are combined and decoded in batches
+// ahead of the walk (lsn_engine.h: HarqReq) - rounds 4-5 paid one GPU round trip per retransmission inside the sequential turn.
+uint64_t Engine::harqMix(uint64_t a, uint64_t b, uint64_t c, uint64_t d)
+{
+  auto sm = [](uint64_t x) { x += 0x9E3779B97F4A7C15ull; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull; return x ^ (x >> 31); };
+  return sm(sm(sm(sm(a) ^ b) ^ c) ^ d);
+}
+
+// The request a retransmission (job, block) makes when it meets a buffer in the state (ncb_have, ver, ok, loc) - the SAME function serves the walk and the
+// scout, so that equal states give equal keys.  A buffer without a first transmission on record for this geometry (ncb_have != n) is taken as it lies in
+// the pool, nothing passed (rounds 4-5: hk = HarqKeep{}); the pool does not change inside a turn, so (slot, n) names that content.  false: every block has
+// passed already, nothing to combine or decode.
+bool Engine::harqRequest(const Chunk& ch, int job, int tb, size_t slot, uint32_t n, uint32_t ncb_have, uint64_t ver, const uint8_t* ok, const uint32_t* loc, HarqReq& q) const
+{
+  (void)ch;
+  q = HarqReq{};
+  q.job = job; q.tb = tb; q.slot = slot; q.n = n;
+  uint64_t okmask = 0;
+  if (ncb_have != n) {
+    q.ver = harqMix(0x52455345u /* reset */, slot, n, 0);
+    for (uint32_t i = 0; i < n; i++) { q.ok[i] = 0; q.loc[i] = HARQ_LOC_POOL | (uint32_t)(slot * HARQ_SLOT_WORDS + i * HARQ_CB_WORDS); }
+  } else {
+    q.ver = ver;
+    for (uint32_t i = 0; i < n; i++) { q.ok[i] = ok[i] ? 1 : 0; q.loc[i] = loc[i]; okmask |= (uint64_t)(ok[i] ? 1 : 0) << i; }
+  }
+  q.key = harqMix(q.ver, ((uint64_t)(uint32_t)job << 1) | (uint64_t)(tb & 1), okmask, n);
+  return okmask != ((1ull << n) - 1ull);
+}
+
 void Engine::harqStore(Chunk& ch, JobRunner& r, int job, int tb, size_t slot)
 {
+  (void)r;
   const DecodeJob& j = ch.jobs[job];
   const uint32_t n = j.keep_count[tb];
   if (!n || n > HARQ_MAX_CB) { harq_keep.erase(slot); return; }   // nothing stored for this transmission: what the slot held belongs to an older one and must not be combined with
-  grow_host(r.h_cbs_pinned, r.h_cbs_cap, n, r.stream);
-  grow_dev(r.d_cbs, r.cbs_cap, n, r.stream);
   // cb_crc / data of the soft buffer: what passed in this (failed) transmission is remembered, a retransmission decodes the other blocks only
-  {  // a later new transmission into the same buffer replaces a queued one (one launch copies all queued blocks: two writers of one slot would race)
-    const uint32_t lo = (uint32_t)(slot * HARQ_SLOT_WORDS), hi = lo + (uint32_t)HARQ_SLOT_WORDS;
-    harq_store_q.erase(std::remove_if(harq_store_q.begin(), harq_store_q.end(), [&](const LsnCbDev& q) { return q.spp_off >= lo && q.spp_off < hi; }), harq_store_q.end());
-  }
   HarqKeep& hk = harq_keep[slot];
   hk.ncb = n;
+  hk.ver = harqMix(0x53544F52u /* store */, ch.gseq, (uint64_t)(uint32_t)job, (uint64_t)tb);
   uint32_t boff = 0;
   for (uint32_t q = 0; q < n; q++) {
-    LsnCbDev cb = ch.keep_cbs[j.keep_first[tb] + q];
+    const LsnCbDev& cb = ch.keep_cbs[j.keep_first[tb] + q];
     const LsnCbRes cr = j.keep_first[tb] + q < ch.keep_res.size() ? ch.keep_res[j.keep_first[tb] + q] : LsnCbRes{};
-    hk.ok[q] = cr.ok ? 1 : 0; hk.rem_a[q] = cr.rem_a;
+    hk.ok[q] = cr.ok ? 1 : 0; hk.rem_a[q] = cr.rem_a; hk.K[q] = cb.K;
     const uint8_t* pb = ch.h_payload.data() + j.payload_off[tb] + boff;
     hk.bytes[q].assign(pb, pb + cb.out_bytes);
     boff += cb.out_bytes;
-    cb.e_off = cb.spp_off;                                        // this transmission, in the chunk's keep store
-    cb.spp_off = (uint32_t)(slot * HARQ_SLOT_WORDS + q * HARQ_CB_WORDS);
-    harq_store_q.push_back(cb);
+    hk.loc[q] = HARQ_LOC_KEEP | cb.spp_off;   // this transmission, where it lies in the chunk's keep store: nothing reads it before a retransmission combines with it
   }
-  // Nothing reads a stored block before a retransmission combines with it: the copies are queued and go to the GPU in ONE launch in front of the next
-  // combine or at the end of the chunk's commit turn (harqFlushStores) - rounds 4 / early 5 paid an upload, a launch and a stream synchronisation per
-  // failed transport block here (2.7 k subframes/s on the gated HARQ leg)
+  harq_touched.push_back(slot);
 }
 
-void Engine::harqFlushStores(Chunk& ch, JobRunner& r, bool sync)
+// end of the commit turn: the blocks that do not lie at home go there in at most one launch (rounds 4 / early 5 paid an upload, a launch and a stream
+// synchronisation per failed transport block: 2.7 k subframes/s on the gated HARQ leg)
+void Engine::harqFlush(Chunk& ch, JobRunner& r)
 {
-  const uint32_t n = (uint32_t)harq_store_q.size();
-  if (!n) return;
-  // descriptors of the queued copies travel through a pinned mirror of their own (the runner's mirror belongs to the decode that may follow on the stream)
+  struct Timer { double t0, &acc; ~Timer() { acc += now_ms() - t0; } } timer{now_ms(), r.perf.ms_harq[2]};
+  std::vector<LsnCbDev> cp;
+  std::sort(harq_touched.begin(), harq_touched.end());
+  harq_touched.erase(std::unique(harq_touched.begin(), harq_touched.end()), harq_touched.end());
+  for (size_t slot : harq_touched) {
+    auto it = harq_keep.find(slot);
+    if (it == harq_keep.end()) continue;
+    HarqKeep& hk = it->second;
+    for (uint32_t q = 0; q < hk.ncb && q < HARQ_MAX_CB; q++) {
+      const uint32_t home = HARQ_LOC_POOL | (uint32_t)(slot * HARQ_SLOT_WORDS + q * HARQ_CB_WORDS);
+      if (hk.loc[q] == home) continue;
+      LsnCbDev cb{};
+      cb.K = hk.K[q]; cb.reserved = hk.loc[q]; cb.spp_off = home;
+      cp.push_back(cb);
+      hk.loc[q] = home;
+    }
+  }
+  harq_touched.clear();
+  for (auto& kv : harq_cache) if (!kv.second.used) r.perf.nof_harq_combines[3]++;
+  harq_cache.clear();
+  harq_scratch_n = 0;
+  (void)ch;
+  if (cp.empty()) return;
+  const uint32_t n = (uint32_t)cp.size();
   grow_host(harq_h_store, harq_h_store_cap, n, r.stream);
   grow_dev(harq_d_store, harq_d_store_cap, n, r.stream);
-  std::memcpy(harq_h_store, harq_store_q.data(), n * sizeof(LsnCbDev));
-  harq_store_q.clear();
+  std::memcpy(harq_h_store, cp.data(), n * sizeof(LsnCbDev));
   lsn_launch_upload(harq_d_store, harq_h_store, n * sizeof(LsnCbDev), r.stream);
-  lsn_launch_harq_combine(harq_d_store, n, ch.d_keep, d_harq_pool, true, r.stream);
-  // sync = false: the caller waits for later work on the same stream before anything here is reused (harqCombinedDecode); at the end of the chunk's commit
-  // turn the wait is here - the chunk's keep store is recycled with the chunk
-  if (sync) HIP_CHECK(hipStreamSynchronize(r.stream));
+  lsn_launch_harq_combine(harq_d_store, n, ch.d_keep, d_harq_pool, d_harq_scratch, true, r.stream);
+  HIP_CHECK(hipStreamSynchronize(r.stream));   // the chunk's keep store is recycled with the chunk
+}
+
+// combine + decode a batch of requests: one descriptor upload, one combination launch, one decoder launch per wavefront class, one download, one wait
+void Engine::harqRunBatch(Chunk& ch, JobRunner& r, const std::vector<HarqReq>& reqs)
+{
+  if (reqs.empty()) return;
+  struct Timer { double t0, &acc; ~Timer() { acc += now_ms() - t0; } } timer{now_ms(), r.perf.ms_harq[1]};
+  hipStream_t st = r.stream;
+  struct Ref { uint32_t req, q, out; };
+  std::vector<LsnCbDev> cbs;
+  std::vector<Ref> refs;
+  uint32_t out = 0;
+  size_t words = harq_scratch_n;
+  for (uint32_t i = 0; i < reqs.size(); i++) {
+    const HarqReq& q = reqs[i];
+    const DecodeJob& j = ch.jobs[q.job];
+    for (uint32_t b = 0; b < q.n; b++) {
+      if (q.ok[b]) continue;   // srsRAN: if (!softbuffer->cb_crc[cb_idx]) { rate de-matching into the buffer, decoding } - a passed block is left alone
+      LsnCbDev cb = ch.keep_cbs[j.keep_first[q.tb] + b];
+      cb.e_off = cb.spp_off;                       // this transmission, in the chunk's keep store
+      cb.reserved = q.loc[b];                      // what the buffer holds, wherever it lies
+      cb.spp_off = (uint32_t)words; words += LSN_SPP_WORDS(cb.K);
+      cb.res_idx = (uint32_t)cbs.size(); cb.dep = LSN_CB_NODEP; cb.out_off = out;
+      refs.push_back({i, b, out});
+      out += cb.out_bytes;
+      cbs.push_back(cb);
+    }
+  }
+  const uint32_t nd = (uint32_t)cbs.size();
+  if (!nd) return;
+  if (words > harq_scratch_cap || words >= (1u << 30)) throw std::runtime_error("HARQ scratch area exhausted");   // (sized by the caller: harqEnsureScratch)
+  harq_scratch_n = words;
+  grow_host(r.h_cbs_pinned, r.h_cbs_cap, nd, st);
+  grow_dev(r.d_cbs, r.cbs_cap, nd, st);
+  if (nd > r.cbres_cap) grow_dev(r.d_cbres, r.cbres_cap, nd, st);
+  grow_host(r.h_cbres_pinned, r.h_cbres_cap, nd, st);
+  grow_dev(r.d_payload, r.payload_cap, (size_t)out + 16, st);
+  grow_host(r.h_payload_pinned, r.h_payload_cap, (size_t)out + 16, st);
+  // launch order: two-wavefront class first, each class by descending size (the longest first); results stay addressable through res_idx
+  std::vector<uint32_t> order(nd);
+  for (uint32_t i = 0; i < nd; i++) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+    const bool ca = lsn_turbo_two_wave_class((int)cbs[a].K), cb2 = lsn_turbo_two_wave_class((int)cbs[b].K);
+    if (ca != cb2) return ca;
+    return cbs[a].K > cbs[b].K;
+  });
+  uint32_t n128 = 0, kmax128 = 0, kmax64 = 0;
+  for (uint32_t i = 0; i < nd; i++) {
+    const LsnCbDev& c = cbs[order[i]];
+    r.h_cbs_pinned[i] = c;
+    if (lsn_turbo_two_wave_class((int)c.K)) { n128++; kmax128 = std::max(kmax128, c.K); } else kmax64 = std::max(kmax64, c.K);
+  }
+  lsn_launch_upload(r.d_cbs, r.h_cbs_pinned, nd * sizeof(LsnCbDev), st);
+  lsn_launch_harq_combine(r.d_cbs, nd, ch.d_keep, d_harq_pool, d_harq_scratch, false, st);
+  lsn_launch_turbo(cd, r.d_cbs, d_harq_scratch, r.d_payload, r.d_cbres, n128, kmax128, nd - n128, kmax64, st, nullptr);
+  {
+    LsnCopySegs dn;   // verdicts + payload bytes down in one launch
+    dn.add(r.h_cbres_pinned, r.d_cbres, nd * sizeof(LsnCbRes));
+    dn.add(r.h_payload_pinned, r.d_payload, out);
+    lsn_launch_copy_multi(dn, true, st);
+  }
+  HIP_CHECK(hipEventRecord(r.ev_done, st));
+  waitEvent(r.ev_done, 3000);   // inside the sequential commit turn: short naps (the decode threads' waits are milliseconds long and nap 50 us)
+  r.perf.nof_harq_combines[0]++;
+  for (uint32_t i = 0; i < reqs.size(); i++) { HarqDone& d = harq_cache[reqs[i].key]; d = HarqDone{}; d.req = reqs[i]; }
+  for (uint32_t k = 0; k < nd; k++) {
+    const Ref& f = refs[k];
+    HarqDone& d = harq_cache[reqs[f.req].key];
+    const LsnCbRes& cr = r.h_cbres_pinned[k];   // (res_idx = k: the index before sorting)
+    d.ok[f.q] = cr.ok ? 1 : 0; d.rem_a[f.q] = cr.rem_a; d.iters[f.q] = cr.iters;
+    d.loc[f.q] = HARQ_LOC_SCRATCH | cbs[k].spp_off;
+    d.bytes[f.q].assign(r.h_payload_pinned + f.out, r.h_payload_pinned + f.out + cbs[k].out_bytes);
+  }
+}
+
+// The combined decodes the walk over this chunk will probably ask for, as far as their inputs are known now: the walk's HARQ decisions (commitChunk,
+// known-table branch) replayed on COPIES of the process database and of the touched buffers' states, with the tables, jobs and p-a values as they stand at
+// the start of the turn.  A retransmission whose result is in harq_cache continues its buffer's chain; one without becomes a request, and the chain of that
+// buffer stops for this pass (its later retransmissions need the result first).  Nothing but speed depends on how well this guesses: the walk makes its own
+// requests and takes a result only under the key of exactly its inputs.
+void Engine::harqScout(Chunk& ch, std::vector<HarqReq>& out, bool first_pass)
+{
+  out.clear();
+  struct View { uint32_t ncb = 0; uint8_t ok[16] = {}; uint32_t rem_a[16] = {}, loc[16] = {}; uint64_t ver = 0; bool pending = false; };
+  std::unordered_map<size_t, View> ov;
+  auto view = [&](size_t slot) -> View& {
+    auto it = ov.find(slot);
+    if (it != ov.end()) return it->second;
+    View v;
+    auto k = harq_keep.find(slot);
+    if (k != harq_keep.end()) {
+      v.ncb = k->second.ncb; v.ver = k->second.ver;
+      for (int q = 0; q < 16; q++) { v.ok[q] = k->second.ok[q]; v.rem_a[q] = k->second.rem_a[q]; v.loc[q] = k->second.loc[q]; }
+    }
+    return ov.emplace(slot, v).first->second;
+  };
+  // The transport blocks the walk will put to the process database, in walk order (tables, jobs and p-a values as they stand at the start of the turn: the
+  // same in every pass of this turn, so the list is made by the first pass and replayed by the others).  job < 0: the database's 10 s timer.
+  if (first_pass) {
+    harq_events.clear();
+    uint32_t cnt = commit_sf_cnt;
+    for (uint32_t sf = 0; sf < ch.nsf; sf++, cnt++) {
+      const SubframeCtx& c = ch.ctx[sf];
+      if (cnt && (cnt % 10000u) == 0) { HarqEvent ev; ev.job = -1; ev.now = cnt; harq_events.push_back(ev); }
+      if (!c.searched) continue;
+      for (uint32_t k = ch.cdci_first[sf]; k < ch.cdci_first[sf + 1]; k++) {
+        const CommitDci& d = ch.cdci[k];
+        const char* name = rnti_name(d.rnti);
+        if (name[0] != 'C') continue;
+        McsTable table = TABLE_64QAM;
+        if (cfg.mcs_tracking_mode == 1) table = (DciFormat)d.format == FORMAT1A ? TABLE_64QAM : mcs_tracking.peek(d.rnti);
+        else if (cfg.mcs_tracking_mode == 2) table = TABLE_UNKNOWN;
+        if (!(table == TABLE_64QAM || table == TABLE_256QAM)) continue;
+        const TableView tv = table_view(table, d.rnti, d.flags & 1, d.flags & 2, d.flags & 4);
+        const DlEntry& e = c.dl[d.di];
+        if (table == TABLE_64QAM && e.unpack_ok && ((e.grant64.tb[0].enabled && e.grant64.tb[0].mcs_idx > 28) || (e.grant64.tb[1].enabled && e.grant64.tb[1].mcs_idx > 28)))
+          continue;   // (a reserved MCS index takes its size from the database at commit and is decoded there)
+        const int cur_t = table == TABLE_256QAM ? 1 : 0;
+        const bool cur_has = cur_t ? tv.has256 : tv.has64;
+        const int32_t cur_tbs0 = cur_has ? (cur_t ? d.tbs0_256 : d.tbs0_64) : 0;
+        const bool two_tb = (tv.has64 && (d.flags & 8)) || (tv.has256 && (d.flags & 16));
+        if (!(cur_tbs0 > 0 && tv.dci_rnti_ok && !(dlRx() == 1 && two_tb))) continue;
+        const int j = d.job[cur_t];
+        if (!cur_has || j < 0 || !ch.jres[j].done || ch.jres[j].p_a != mcs_tracking.get_ue_config_rnti(d.rnti).p_a) continue;
+        const JobRes& jr = ch.jres[j];
+        for (int tb = 0; tb < 2; tb++) {
+          if (!jr.enabled[tb]) continue;
+          HarqEvent ev;
+          ev.job = j; ev.now = cnt; ev.sfn = c.sfn; ev.sf_idx = c.sf_idx; ev.rnti = d.rnti; ev.pid = (uint8_t)e.dci.pid; ev.tb = (uint8_t)tb;
+          ev.ndi = e.dci.tb[tb].ndi != 0; ev.rv = (uint8_t)e.dci.tb[tb].rv; ev.tbs = ch.jobs[j].grant.tb[tb].tbs; ev.crc = jr.crc[tb] != 0; ev.n = ch.jobs[j].keep_count[tb];
+          harq_events.push_back(ev);
+        }
+      }
+    }
+  }
+  HarqDatabase db = harq_db;
+  for (const HarqEvent& ev : harq_events) {
+    if (ev.job < 0) { db.update_database(ev.now); continue; }
+    const int j = ev.job, tb = ev.tb;
+    int ent = -1;
+    const HarqRet hr = db.is_retransmission(ev.rnti, ev.pid, tb, ev.ndi, ev.tbs, ev.sfn, ev.sf_idx, ent);
+    const size_t slot = ent < 0 ? 0 : ((size_t)ent * HarqDatabase::NPID + (ev.pid & 7u)) * 2 + (size_t)tb;
+    bool crc = ev.crc;
+    const uint32_t n = ev.n;
+    if (hr == HARQ_NEW_TX) {
+      if (!crc) {
+        View& v = view(slot);
+        v = View{};
+        if (n && n <= HARQ_MAX_CB) {
+          v.ncb = n; v.ver = harqMix(0x53544F52u, ch.gseq, (uint64_t)(uint32_t)j, (uint64_t)tb);
+          for (uint32_t q = 0; q < n; q++) {
+            const size_t ki = ch.jobs[j].keep_first[tb] + q;
+            const LsnCbRes cr = ki < ch.keep_res.size() ? ch.keep_res[ki] : LsnCbRes{};
+            v.ok[q] = cr.ok ? 1 : 0; v.rem_a[q] = cr.rem_a; v.loc[q] = HARQ_LOC_KEEP | ch.keep_cbs[ki].spp_off;
+          }
+        }
+      }
+    } else if (hr == HARQ_RE_TX) {
+      crc = false;
+      if (n && n <= HARQ_MAX_CB) {
+        View& v = view(slot);
+        if (!v.pending) {
+          HarqReq q;
+          const bool work = harqRequest(ch, j, tb, slot, n, v.ncb, v.ver, v.ok, v.loc, q);
+          if (v.ncb != n) { v = View{}; v.ncb = n; v.ver = q.ver; for (uint32_t b = 0; b < n; b++) v.loc[b] = q.loc[b]; }
+          bool have = true;
+          if (work) {
+            auto it = harq_cache.find(q.key);
+            if (it == harq_cache.end()) { out.push_back(q); v.pending = true; have = false; }
+            else {
+              const HarqDone& dn = it->second;
+              for (uint32_t b = 0; b < n; b++)
+                if (!v.ok[b]) { v.rem_a[b] = dn.rem_a[b]; v.loc[b] = dn.loc[b]; v.ok[b] = dn.ok[b]; }
+              v.ver = q.key;
+            }
+          }
+          if (have) {  // the verdict as far as the scout can tell (every block passed, CRC24A over the blocks; the parity-word and length tests are the walk's)
+            bool all_ok = true;
+            uint32_t rem = 0, shift = 1;
+            for (int b = (int)n - 1; b >= 0; b--) {
+              all_ok = all_ok && v.ok[b];
+              rem ^= b == (int)n - 1 ? (v.rem_a[b] & 0xFFFFFFu) : crc24a_mulmod(v.rem_a[b], shift);
+              if (b > 0) shift = crc24a_mulmod(shift, crc24a_xpow_bytes(ch.keep_cbs[ch.jobs[j].keep_first[tb] + b].out_bytes));
+            }
+            crc = all_ok && rem == 0;
+          }
+        }
+      }
+    } else if (hr == HARQ_DECODED) {
+      crc = false;
+    }
+    if (hr == HARQ_NEW_TX || hr == HARQ_RE_TX) db.update(ent, ev.pid, tb, ev.sfn, ev.sf_idx, crc, ev.ndi, ev.rv, ev.tbs, ev.now);
+  }
 }
 
 bool Engine::harqCombinedDecode(Chunk& ch, JobRunner& r, int job, int tb, size_t slot, uint32_t& payload_off)
@@ -1304,79 +1561,71 @@ bool Engine::harqCombinedDecode(Chunk& ch, JobRunner& r, int job, int tb, size_t
   const DecodeJob& j = ch.jobs[job];
   const uint32_t n = j.keep_count[tb];
   if (!n || n > HARQ_MAX_CB) return false;
-  hipStream_t st = r.stream;
-  grow_host(r.h_cbs_pinned, r.h_cbs_cap, n, st);
-  grow_dev(r.d_cbs, r.cbs_cap, n, st);
-  if (n > r.cbres_cap) { grow_dev(r.d_cbres, r.cbres_cap, n, st); }
-  grow_host(r.h_cbres_pinned, r.h_cbres_cap, n, st);
-  const bool flushed = !harq_store_q.empty();
-  harqFlushStores(ch, r, false);   // the buffer this retransmission combines with may still sit in the store queue (stream order: no wait needed here)
   HarqKeep& hk = harq_keep[slot];
-  if (hk.ncb != n) { hk = HarqKeep{}; hk.ncb = n; }  // (no first transmission on record for this geometry: nothing passed before)
-  // descriptors of the blocks that have NOT passed yet, in launch order (two-wave class first); results stay in transport-block order through res_idx
-  std::vector<LsnCbDev> cbs;
-  uint32_t out = 0, n128 = 0, kmax128 = 0, kmax64 = 0, out_off[HARQ_MAX_CB] = {};
-  for (uint32_t q = 0; q < n; q++) {
-    LsnCbDev cb = ch.keep_cbs[j.keep_first[tb] + q];
-    out_off[q] = out;
-    if (hk.ok[q]) continue;   // srsRAN: if (!softbuffer->cb_crc[cb_idx]) { rate de-matching into the buffer, decoding } - a passed block is left alone
-    cb.e_off = cb.spp_off;
-    cb.spp_off = (uint32_t)(slot * HARQ_SLOT_WORDS + q * HARQ_CB_WORDS);
-    cb.res_idx = q; cb.dep = LSN_CB_NODEP; cb.out_off = out; out += cb.out_bytes;
-    cbs.push_back(cb);
+  HarqReq q;
+  const bool work = harqRequest(ch, job, tb, slot, n, hk.ncb, hk.ver, hk.ok, hk.loc, q);
+  if (hk.ncb != n) {  // (no first transmission on record for this geometry: nothing passed before)
+    hk = HarqKeep{};
+    hk.ncb = n; hk.ver = q.ver;
+    for (uint32_t b = 0; b < n; b++) hk.loc[b] = q.loc[b];
   }
-  const uint32_t nd = (uint32_t)cbs.size();
-  if (nd) {
-    std::stable_sort(cbs.begin(), cbs.end(), [](const LsnCbDev& a, const LsnCbDev& b) { return lsn_turbo_two_wave_class((int)a.K) && !lsn_turbo_two_wave_class((int)b.K); });
-    for (uint32_t q = 0; q < nd; q++) {
-      r.h_cbs_pinned[q] = cbs[q];
-      if (lsn_turbo_two_wave_class((int)cbs[q].K)) { n128++; kmax128 = std::max(kmax128, cbs[q].K); } else kmax64 = std::max(kmax64, cbs[q].K);
+  for (uint32_t b = 0; b < n; b++) hk.K[b] = ch.keep_cbs[j.keep_first[tb] + b].K;
+  const HarqDone* dn = nullptr;
+  if (work) {
+    auto it = harq_cache.find(q.key);
+    if (it != harq_cache.end() && !(it->second.req.ver == q.ver && it->second.req.job == job && it->second.req.tb == tb && it->second.req.n == n && std::memcmp(it->second.req.ok, q.ok, 16) == 0)) it = harq_cache.end();  // (a hash collision)
+    if (it == harq_cache.end()) {
+      // not foreseen by the scout: decoded now, alone (a round trip inside the turn, as every retransmission was in rounds 4-5)
+      size_t need = 0;
+      for (uint32_t b = 0; b < n; b++) if (!q.ok[b]) need += LSN_SPP_WORDS(hk.K[b]);
+      if (harq_scratch_n + need > harq_scratch_cap) {  // scratch area full: everything goes home first (the unused results of the batches are lost with it)
+        harqFlush(ch, r);
+        harqRequest(ch, job, tb, slot, n, hk.ncb, hk.ver, hk.ok, hk.loc, q);
+        if (need > harq_scratch_cap) { HIP_CHECK(hipStreamSynchronize(r.stream)); grow_dev(d_harq_scratch, harq_scratch_cap, need, r.stream); }
+      }
+      std::vector<HarqReq> one{q};
+      harqRunBatch(ch, r, one);
+      r.perf.nof_harq_combines[2]++;
+      r.perf.nof_ondemand_decodes++;
+      it = harq_cache.find(q.key);
+    } else {
+      r.perf.nof_harq_combines[1]++;
     }
-    grow_dev(r.d_payload, r.payload_cap, (size_t)out + 16, st);
-    grow_host(r.h_payload_pinned, r.h_payload_cap, (size_t)out + 16, st);
-    lsn_launch_upload(r.d_cbs, r.h_cbs_pinned, nd * sizeof(LsnCbDev), st);
-    lsn_launch_harq_combine(r.d_cbs, nd, ch.d_keep, d_harq_pool, false, st);
-    lsn_launch_turbo(cd, r.d_cbs, d_harq_pool, r.d_payload, r.d_cbres, n128, kmax128, nd - n128, kmax64, st, nullptr);
-    {
-      LsnCopySegs dn;   // verdicts + payload bytes down in one launch
-      dn.add(r.h_cbres_pinned, r.d_cbres, n * sizeof(LsnCbRes));
-      dn.add(r.h_payload_pinned, r.d_payload, out);
-      lsn_launch_copy_multi(dn, true, st);
-    }
-    HIP_CHECK(hipEventRecord(r.ev_done, st));
-    waitEvent(r.ev_done, 3000);   // a round trip inside the sequential commit turn: short naps (the decode threads' waits are milliseconds long and nap 50 us)
-    r.perf.nof_ondemand_decodes++;
-    for (uint32_t q = 0; q < n; q++) {
-      if (hk.ok[q]) continue;
-      const LsnCbRes& cr = r.h_cbres_pinned[q];
-      r.perf.nof_turbo_iterations += cr.iters;
-      hk.rem_a[q] = cr.rem_a;
-      const uint32_t nb = ch.keep_cbs[j.keep_first[tb] + q].out_bytes;
-      hk.bytes[q].assign(r.h_payload_pinned + out_off[q], r.h_payload_pinned + out_off[q] + nb);
+    it->second.used = true;
+    dn = &it->second;
+    for (uint32_t b = 0; b < n; b++) {
+      if (hk.ok[b]) continue;
+      r.perf.nof_turbo_iterations += dn->iters[b];
+      hk.rem_a[b] = dn->rem_a[b];
+      hk.bytes[b] = dn->bytes[b];
+      hk.loc[b] = dn->loc[b];
       // (ok is set below, after the verdict of THIS pass has been taken)
     }
+    hk.ver = q.key;
+    harq_touched.push_back(slot);
   }
-  if (!nd && flushed) HIP_CHECK(hipStreamSynchronize(st));   // (nothing was decoded, so nothing waited for the flush)
   // transport-block verdict, as in runJobs: every block passed (now or in an earlier transmission), CRC24A over the assembled blocks
   bool all_ok = true;
-  uint32_t rem = 0, total = 0;
+  uint32_t rem = 0, total = 0, shift = 1;   // shift = x^bits_after mod g, carried along (as in runJobs)
   uint64_t bits_after = 0;
-  for (int q = (int)n - 1; q >= 0; q--) {
-    const bool okq = hk.ok[q] || (nd && r.h_cbres_pinned[q].ok != 0);
-    all_ok = all_ok && okq;
-    rem ^= crc24a_mulmod(hk.rem_a[q], crc24a_xpow(bits_after));
-    bits_after += 8ull * ch.keep_cbs[j.keep_first[tb] + q].out_bytes;
+  for (int b = (int)n - 1; b >= 0; b--) {
+    const bool okb = hk.ok[b] || (dn && dn->ok[b] != 0);
+    all_ok = all_ok && okb;
+    rem ^= bits_after ? crc24a_mulmod(hk.rem_a[b], shift) : (hk.rem_a[b] & 0xFFFFFFu);
+    const uint32_t nb = ch.keep_cbs[j.keep_first[tb] + b].out_bytes;
+    bits_after += 8ull * nb;
+    if (b > 0) shift = crc24a_mulmod(shift, crc24a_xpow_bytes(nb));
   }
-  for (uint32_t q = 0; q < n; q++) total += (uint32_t)hk.bytes[q].size();
+  for (uint32_t b = 0; b < n; b++) total += (uint32_t)hk.bytes[b].size();
   const int tbs = j.grant.tb[tb].tbs;
   payload_off = (uint32_t)ch.h_payload.size();
   ch.h_payload.resize(ch.h_payload.size() + (((size_t)total + 15) & ~(size_t)15));
   {
     uint8_t* dst = ch.h_payload.data() + payload_off;
-    for (uint32_t q = 0; q < n; q++) { std::memcpy(dst, hk.bytes[q].data(), hk.bytes[q].size()); dst += hk.bytes[q].size(); }
+    for (uint32_t b = 0; b < n; b++) { std::memcpy(dst, hk.bytes[b].data(), hk.bytes[b].size()); dst += hk.bytes[b].size(); }
   }
-  for (uint32_t q = 0; q < n; q++)
-    if (!hk.ok[q] && nd && r.h_cbres_pinned[q].ok) hk.ok[q] = 1;
+  for (uint32_t b = 0; b < n; b++)
+    if (!hk.ok[b] && dn && dn->ok[b]) hk.ok[b] = 1;
   const uint8_t* pl = ch.h_payload.data() + payload_off;
   if ((uint64_t)total * 8ull < (uint64_t)tbs + 24ull) return false;
   const uint32_t par = ((uint32_t)pl[tbs / 8] << 16) | ((uint32_t)pl[tbs / 8 + 1] << 8) | pl[tbs / 8 + 2];
@@ -1451,7 +1700,7 @@ void Engine::commitLoop()
       // database's "stored" marks behind it) no longer matches the pool.  A retransmission that later combined with such a slot would trust flags and
       // bytes of a transmission whose soft bits never arrived (round-5 advisor finding): the turn failed, so the whole soft-buffer state is dropped -
       // every later block of these processes is a new transmission, which costs combining gain for 8 subframes and nothing else.
-      if (cfg.harq_mode) { harq_store_q.clear(); harq_keep.clear(); harq_db = HarqDatabase(); }
+      if (cfg.harq_mode) { harq_cache.clear(); harq_touched.clear(); harq_scratch_n = 0; harq_keep.clear(); harq_db = HarqDatabase(); }
     }
     {
       std::unique_lock<std::mutex> tl(sh->turn_mtx);

@@ -134,6 +134,14 @@ struct UlSchedGrant { uint16_t rnti = 0; PuschGrant g, g256; uint32_t n_dmrs = 0
 // One engine owns one of these; the engines of a capture that is spread over several GPUs (lsn_phy_create_multi: chunk g goes to engine
 // g mod G) share one and take turns on it - chunk g is searched, committed and written when chunks 0 .. g-1 have been, whichever engine
 // holds them - so the record stream is the one a single engine would produce.
+// harq_mode = 1: what srsran_softbuffer_rx_t holds besides the soft values (round-4 advisor finding): per code block cb_crc and the decoded data of a block whose
+// CRC passed - a retransmission neither combines nor decodes such a block again (sch.c decode_tb_cb [srsRAN]).  Kept on the host, by soft-buffer slot, touched in
+// the commit turn only: verdict, CRC24A contribution and payload bytes of every code block of the transport block the slot holds.
+// ver / loc (round 6): WHICH content the buffer holds (a number that names the chain of stores and combinations that produced it - equal numbers, equal
+// soft values) and WHERE each of its blocks lies at this point of the commit turn (HARQ_LOC_*: pool, the turn's scratch area, the chunk's keep store).
+enum : uint32_t { HARQ_LOC_POOL = 0u, HARQ_LOC_SCRATCH = 1u << 30, HARQ_LOC_KEEP = 2u << 30, HARQ_LOC_PLACE = 3u << 30 };
+struct HarqKeep { uint32_t ncb = 0; uint8_t ok[16] = {}; uint32_t rem_a[16] = {}; std::vector<uint8_t> bytes[16]; uint64_t ver = 0; uint32_t loc[16] = {}, K[16] = {}; };
+
 struct SharedSeq {
   std::unique_ptr<FalconSearch> search;
   MCSTracking mcs_tracking;
@@ -157,6 +165,13 @@ struct SharedSeq {
   std::atomic<uint64_t> hint_used{0}, hint_missed{0};
   std::atomic<uint32_t> commit_pos{0};    // subframes committed so far, published
   uint32_t commit_sf_cnt = 0;             // subframes committed so far = the tracking database's clock (1 subframe = 1 ms)
+  // HARQ soft combining (harq_mode = 1): the process database, the host side of the soft buffers and the device pool they live in.  With several engines on
+  // one capture the pool belongs to the FIRST engine's device and the others reach it over the peer link (lsn_phy_create_multi enables the access): the
+  // commit turns are sequential, so one engine at a time reads or writes it
+  HarqDatabase harq_db;
+  std::unordered_map<size_t, HarqKeep> harq_keep;
+  uint32_t* d_harq_pool = nullptr;
+  const void* harq_pool_owner = nullptr;   // the engine whose device holds the pool (and frees it)
   uint32_t mcs_update_period = 5000;      // MCSTracking::get_interval() x 1000 subframes (LTESniffer_Core.cc:473-485); 0: never
   uint64_t nof_mcs_db_updates = 0;
   uint64_t sf_cnt = 0;                    // subframes searched so far
@@ -278,20 +293,28 @@ private:
   }
   int newJob(Chunk& ch, uint32_t sf, const DlEntry& e, int table, float p_a = 0.0f, int kind = 0);
   void learnUeConfig(const uint8_t* pdu, int len, uint16_t rnti);
-  // HARQ soft combining (harq_mode = 1, DL mode, one engine): database + device pool of soft buffers, driven by the commit stage
-  HarqDatabase harq_db;
-  uint32_t* d_harq_pool = nullptr;
+  // HARQ soft combining (harq_mode = 1, DL mode): database + device pool of soft buffers (SharedSeq), driven by the commit stage
   static constexpr size_t HARQ_CB_WORDS = LSN_SPP_WORDS(6144u), HARQ_MAX_CB = 16, HARQ_SLOT_WORDS = HARQ_CB_WORDS * HARQ_MAX_CB;
-  // What srsran_softbuffer_rx_t holds besides the soft values (round-4 advisor finding): per code block cb_crc and the decoded data of a block whose CRC
-  // passed - a retransmission neither combines nor decodes such a block again (sch.c decode_tb_cb [srsRAN]).  Kept on the host, by soft-buffer slot, owned
-  // by the commit thread: verdict, CRC24A contribution and payload bytes of every code block of the transport block the slot holds.
-  struct HarqKeep { uint32_t ncb = 0; uint8_t ok[16] = {}; uint32_t rem_a[16] = {}; std::vector<uint8_t> bytes[16]; };
-  std::unordered_map<size_t, HarqKeep> harq_keep;
-  void harqStore(Chunk& ch, JobRunner& r, int job, int tb, size_t slot);                       // a failed new transmission goes into the buffer (queued: harqFlushStores)
-  void harqFlushStores(Chunk& ch, JobRunner& r, bool sync);
-  LsnCbDev *harq_h_store = nullptr, *harq_d_store = nullptr; size_t harq_h_store_cap = 0, harq_d_store_cap = 0;
-  std::vector<LsnCbDev> harq_store_q;   // soft-buffer copies of the chunk in commit that have not been launched yet (commit thread only)
-  bool harqCombinedDecode(Chunk& ch, JobRunner& r, int job, int tb, size_t slot, uint32_t& payload_off);  // retransmission: combine, decode, keep
+  // Retransmissions are combined and decoded in BATCHES ahead of the sequential commit walk (round-5 review: one GPU round trip per retransmission inside
+  // the commit turn held the gated HARQ leg at 4.6 k subframes/s).  A request names its inputs completely: the current transmission (job, block), the content
+  // of the buffer it meets (HarqKeep::ver) and the blocks that have passed already; its key is a hash of exactly those, so a result found under the key of
+  // the request the walk makes IS the result the walk would have computed.  harqScout predicts the walk's requests on copies of the HARQ state (a guess -
+  // nothing but speed depends on it), harqRunBatch runs them into the scratch area, the walk takes what fits and decodes the rest alone, as before.
+  struct HarqReq { int job = -1, tb = 0; size_t slot = 0; uint64_t key = 0, ver = 0; uint32_t n = 0; uint8_t ok[16] = {}; uint32_t loc[16] = {}; };
+  struct HarqDone { HarqReq req; uint8_t ok[16] = {}; uint32_t rem_a[16] = {}, iters[16] = {}, loc[16] = {}; std::vector<uint8_t> bytes[16]; bool used = false; };
+  std::unordered_map<uint64_t, HarqDone> harq_cache;   // results of this commit turn's batches, by request key
+  std::vector<size_t> harq_touched;                    // buffers whose content is not (all) in the pool: copied there at the end of the turn
+  uint32_t* d_harq_scratch = nullptr; size_t harq_scratch_cap = 0, harq_scratch_n = 0;
+  LsnCbDev *harq_h_store = nullptr, *harq_d_store = nullptr; size_t harq_h_store_cap = 0, harq_d_store_cap = 0;   // descriptors of the end-of-turn copies
+  static uint64_t harqMix(uint64_t a, uint64_t b, uint64_t c, uint64_t d);
+  bool harqRequest(const Chunk& ch, int job, int tb, size_t slot, uint32_t n, uint32_t ncb_have, uint64_t ver, const uint8_t* ok, const uint32_t* loc, HarqReq& q) const;
+  void harqStore(Chunk& ch, JobRunner& r, int job, int tb, size_t slot);                       // a failed new transmission becomes the buffer's content (it stays in the keep store until harqFlush)
+  void harqFlush(Chunk& ch, JobRunner& r);                                                       // end of the turn: every touched buffer into the pool
+  struct HarqEvent { int job = -1; uint32_t now = 0, sfn = 0, sf_idx = 0, n = 0; int tbs = 0; uint16_t rnti = 0; uint8_t pid = 0, tb = 0, rv = 0; bool ndi = false, crc = false; };
+  std::vector<HarqEvent> harq_events;   // harqScout: the transport blocks of the chunk in commit that go to the process database
+  void harqScout(Chunk& ch, std::vector<HarqReq>& out, bool first_pass);                                          // the combined decodes the walk over this chunk will probably ask for and that have no result yet
+  void harqRunBatch(Chunk& ch, JobRunner& r, const std::vector<HarqReq>& reqs);                  // combine + decode all of them, results into harq_cache
+  bool harqCombinedDecode(Chunk& ch, JobRunner& r, int job, int tb, size_t slot, uint32_t& payload_off);  // retransmission: result of the combined decode (from a batch, else decoded now)
 public:
   UeSpecConfig ueConfig(uint16_t rnti) { std::lock_guard<std::mutex> lk(mcs_mtx); return cfg.sniffer_mode == 1 ? ulUeConfig(rnti) : mcs_tracking.get_ue_config_rnti(rnti); }
 private:
@@ -345,6 +368,9 @@ private:
   hipEvent_t peer_ev[16] = {};                 // submitFrom: "source block ready" events, one per source device (created on that device)
   std::unique_ptr<FalconSearch>& search = sh->search;
   MCSTracking& mcs_tracking = sh->mcs_tracking;
+  HarqDatabase& harq_db = sh->harq_db;   // harq_mode = 1: process database, host side of the soft buffers, device pool (shared by the engines of a capture)
+  std::unordered_map<size_t, HarqKeep>& harq_keep = sh->harq_keep;
+  uint32_t*& d_harq_pool = sh->d_harq_pool;
   std::atomic<float>& default_p_a = sh->default_p_a;
   std::mutex& mcs_mtx = sh->mcs_mtx;
   std::unique_ptr<std::atomic<uint8_t>[]>& pred_table = sh->pred_table;

@@ -893,15 +893,20 @@ uint32_t crc24a_xpow(uint64_t n)
 // ------------------------------------------------------------------------------------------------ HARQ database
 HarqRet HarqDatabase::is_retransmission(uint16_t rnti, uint32_t pid, int tid, bool ndi, int tbs, uint32_t sfn, uint32_t sf_idx, int& entity)
 {
-  int found = -1, avail = -1;
-  for (int i = 0; i < NENT; i++) {
-    if (ent[i].rnti == rnti) found = i;
-    else if (ent[i].rnti == 0) avail = i;  // the LAST free entity (HARQ.cc:84-90)
-  }
+  // The reference scans its 300 entities for the RNTI and remembers the LAST free one on the way (HARQ.cc:84-90).  An RNTI owns at most one entity (one is
+  // only given out when the scan found none), so the scan's answer is an index look-up; the free entity is only needed when there is none, which is rare.
+  // (Round 6: the scan ran once per transport block in the commit walk and in every pass of harqScout - most of the HARQ leg's commit time.)
+  int found = rnti ? (int)ent_of_rnti[rnti] : -1, avail = -1;
+  if (found < 0)
+    for (int i = 0; i < NENT; i++) {
+      if (ent[i].rnti == rnti) found = i;   // (rnti 0: every free entity "matches", as in the reference's scan)
+      else if (ent[i].rnti == 0) avail = i;
+    }
   entity = found;
   HarqRet r;
   if (found < 0 && avail >= 0) {
     ent[avail].rnti = rnti;
+    if (rnti) ent_of_rnti[rnti] = (int16_t)avail;
     if (nof_aval > 0) nof_aval--;
     entity = avail;
     r = HARQ_NEW_TX;
@@ -936,12 +941,15 @@ int HarqDatabase::getlastTbs(uint16_t rnti, uint32_t pid, int tid) const
 void HarqDatabase::update_database(uint32_t now)
 {
   if (nof_aval > 10) return;
-  for (Entity& e : ent)
+  for (size_t i = 0; i < ent.size(); i++) {
+    Entity& e = ent[i];
     if ((now - e.time) / 1000u > 5u) {  // (free entities included, as in the reference: nof_aval over-counts)
+      if (e.rnti) ent_of_rnti[e.rnti] = -1;
       e.rnti = 0; e.time = 0;
       for (auto& p : e.tb) for (Tb& t : p) { t.is_first = true; t.last_decoded = false; t.tbs = 0; t.sf_idx = 0; }
       nof_aval++;
     }
+  }
 }
 
 }  // namespace lsn

@@ -266,7 +266,7 @@ enum HarqRet { HARQ_NEW_TX = 0, HARQ_RE_TX = 1, HARQ_FULL_BUFFER = 2, HARQ_DECOD
 class HarqDatabase {
 public:
   static constexpr int NENT = 300, NPID = 8;
-  HarqDatabase() : ent(NENT) {}
+  HarqDatabase() : ent(NENT), ent_of_rnti(65536, (int16_t)-1) {}
   // HARQ::is_retransmission (HARQ.cc:71-135); entity: index of the RNTI's entity (-1: none) - with pid and tid it names the soft buffer
   HarqRet is_retransmission(uint16_t rnti, uint32_t pid, int tid, bool ndi, int tbs, uint32_t sfn, uint32_t sf_idx, int& entity);
   // HARQ::updateHARQRNTI / updateProcess (HARQ.cc:155-190)
@@ -278,6 +278,7 @@ private:
   struct Tb { uint32_t sfn = 0, sf_idx = 0; bool last_decoded = false, ndi = false, is_first = true; int rv = 0, tbs = 0; };
   struct Entity { uint16_t rnti = 0; uint32_t time = 0; Tb tb[NPID][2]; };
   std::vector<Entity> ent;
+  std::vector<int16_t> ent_of_rnti;   // [65536] the entity an RNTI owns, -1: none (is_retransmission)
   int nof_aval = 150;
 };
 

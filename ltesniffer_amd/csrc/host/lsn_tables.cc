@@ -78,10 +78,12 @@ void Engine::freeDevice()
     df(mib_d_iq); df(mib_d_llr); df(mib_d_cand);
     for (auto& fb : file_buf) { if (fb.h_raw) (void)hipHostFree(fb.h_raw); df(fb.d_raw); df(fb.d_iq); fb.h_raw = nullptr; fb.bytes = 0; }
   }
-  d_iq_staging = nullptr; staging_sf = 0; d_harq_pool = nullptr;
+  d_iq_staging = nullptr; staging_sf = 0;
+  if (sh->harq_pool_owner == this) { d_harq_pool = nullptr; sh->harq_pool_owner = nullptr; }   // (freed with this engine's device allocations)
   if (harq_h_store) { (void)hipHostFree(harq_h_store); harq_h_store = nullptr; harq_h_store_cap = 0; }
   if (harq_d_store) { (void)hipFree(harq_d_store); harq_d_store = nullptr; harq_d_store_cap = 0; }
-  harq_store_q.clear();
+  if (d_harq_scratch) { (void)hipFree(d_harq_scratch); d_harq_scratch = nullptr; harq_scratch_cap = 0; harq_scratch_n = 0; }
+  harq_cache.clear(); harq_touched.clear();
   for (auto& ch : chunks) { if (ch.d_keep) (void)hipFree(ch.d_keep); ch.d_keep = nullptr; ch.keep_cap = ch.keep_n = 0; }
   last_chunk = nullptr;
 }
@@ -382,9 +384,13 @@ void Engine::buildTables()
     cd.turbo_il = upload(dev_allocs, il);
   }
   if (cfg.harq_mode) {  // soft buffers of 300 entities x 8 processes x 2 transport blocks, 16 code blocks of K = 6144 each: 1.9 GB of the 288
-    d_harq_pool = dalloc<uint32_t>(dev_allocs, (size_t)HarqDatabase::NENT * HarqDatabase::NPID * 2 * HARQ_SLOT_WORDS);
-    harq_db = HarqDatabase();
-    harq_keep.clear();
+    // (several engines on one capture: the first one to get here owns the pool, the others reach it over the peer link)
+    if (!sh->harq_pool_owner || sh->harq_pool_owner == this) {
+      d_harq_pool = dalloc<uint32_t>(dev_allocs, (size_t)HarqDatabase::NENT * HarqDatabase::NPID * 2 * HARQ_SLOT_WORDS);
+      sh->harq_pool_owner = this;
+      harq_db = HarqDatabase();
+      harq_keep.clear();
+    }
   }
   // pipeline slots, decode runners, staging
   for (int i = 0; i < nslots; i++) allocChunk(chunks[i]);

@@ -176,7 +176,7 @@ void lsn_launch_pdsch_prep(const LsnCellDev& c, const LsnGrantDev* g, uint16_t* 
 void lsn_launch_pdsch_demod(const LsnCellDev& c, const LsnGrantDev* g, const uint32_t* items, uint32_t nitems, const uint16_t* prefix, const cf32* grid, const cf32* ce,
                             const LsnChest* ch, int16_t* llr, hipStream_t s);
 void lsn_launch_rm(const LsnCbDev* cb, const int16_t* llr, uint32_t* spp, uint32_t ncb, uint32_t emax, hipStream_t s);
-void lsn_launch_harq_combine(const LsnCbDev* cbs, uint32_t ncb, const uint32_t* cur, uint32_t* pool, bool overwrite, hipStream_t s);
+void lsn_launch_harq_combine(const LsnCbDev* cbs, uint32_t ncb, const uint32_t* keep, uint32_t* pool, uint32_t* scratch, bool copy, hipStream_t s);
 #define LSN_CB_NODEP 0xFFFFFFFFu
 void lsn_launch_turbo(const LsnCellDev& c, const LsnCbDev* cb, const uint32_t* spp, uint8_t* payload, LsnCbRes* res, uint32_t n128, uint32_t kmax128,
                       uint32_t n64, uint32_t kmax64, hipStream_t s, hipEvent_t between);

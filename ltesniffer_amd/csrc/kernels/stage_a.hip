@@ -501,6 +501,26 @@ __device__ __forceinline__ int lsn_dot4_acc(int sw, int sg, int cc)
   asm("v_dot4_i32_i8 %0, %1, %2, %3\n\ts_nop 2" : "=&v"(d) : "v"(sw), "v"(sg), "v"(cc));
   return d;
 }
+// ... for FOUR steps at once: the three wait states between a DOT and the first VALU read of its result are filled by the other three DOTs for e0 (the
+// add-compare-select chain consumes e0 first), one s_nop 2 covers e3 - one wait instruction per four steps instead of one per step
+__device__ __forceinline__ void lsn_dot4_acc4(int w0, int w1, int w2, int w3, int sg, int cc, int& e0, int& e1, int& e2, int& e3)
+{
+  asm("v_dot4_i32_i8 %0, %4, %8, %9\n\tv_dot4_i32_i8 %1, %5, %8, %9\n\tv_dot4_i32_i8 %2, %6, %8, %9\n\tv_dot4_i32_i8 %3, %7, %8, %9\n\ts_nop 2"
+      : "=&v"(e0), "=&v"(e1), "=&v"(e2), "=&v"(e3) : "v"(w0), "v"(w1), "v"(w2), "v"(w3), "v"(sg), "v"(cc));
+}
+// four trace-back steps at the compile-time bit positions P .. P + 3 of a history word (see viterbi_tb): H = 2 H + bit P of the word of state H & 63
+template <int P>
+__device__ __forceinline__ void lsn_tb_walk4(int hw, unsigned& H)
+{
+  // (the lane select of v_readlane is the low six bits of its operand.  One asm block: left to the compiler the step costs five instructions - shift, extract, or,
+  // and a wait state for a hazard that is not there: the recogniser sees the SGPR the previous v_readlane wrote being used as a lane select after the SALU rewrote it)
+  unsigned w;
+  asm("v_readlane_b32 %1, %2, %0\n\ts_bitcmp1_b32 %1, %3\n\ts_addc_u32 %0, %0, %0\n\t"
+      "v_readlane_b32 %1, %2, %0\n\ts_bitcmp1_b32 %1, %4\n\ts_addc_u32 %0, %0, %0\n\t"
+      "v_readlane_b32 %1, %2, %0\n\ts_bitcmp1_b32 %1, %5\n\ts_addc_u32 %0, %0, %0\n\t"
+      "v_readlane_b32 %1, %2, %0\n\ts_bitcmp1_b32 %1, %6\n\ts_addc_u32 %0, %0, %0"
+      : "+s"(H), "=&s"(w) : "v"(hw), "n"(P), "n"(P + 1), "n"(P + 2), "n"(P + 3) : "scc");
+}
 __device__ __forceinline__ void viterbi_tb(const int* symw, uint32_t D_, uint32_t nbits, const uint16_t* __restrict__ crcw, int lane, unsigned long long& bits_out, uint32_t& rem_out)
 {
   __syncthreads();
@@ -515,14 +535,17 @@ __device__ __forceinline__ void viterbi_tb(const int* symw, uint32_t D_, uint32_
   int m = 0;
   // pass 1 only warms the path metrics up: no decision is kept
   {
-    auto acs = [&](int k) {
-      const int e = lsn_dot4_acc(symw[k], signs2, kap);
+    auto step = [&](int e) {
       const int a0 = __builtin_amdgcn_ds_bpermute(pa, m) + e, a1 = __builtin_amdgcn_ds_bpermute(pb, m) - e;
       m = a1 < a0 ? a1 : a0;
     };
     int k = 0;
-    for (; k + 4 <= D; k += 4) { acs(k); acs(k + 1); acs(k + 2); acs(k + 3); }  // four steps share one symbol fetch
-    for (; k < D; k++) acs(k);
+    for (; k + 4 <= D; k += 4) {  // four steps share one symbol fetch and one wait for the DOT results
+      int e0, e1, e2, e3;
+      lsn_dot4_acc4(symw[k], symw[k + 1], symw[k + 2], symw[k + 3], signs2, kap, e0, e1, e2, e3);
+      step(e0); step(e1); step(e2); step(e3);
+    }
+    for (; k < D; k++) step(lsn_dot4_acc(symw[k], signs2, kap));
   }
   // passes 2 and 3: every lane shifts the decisions of ITS state into a history word, 32 steps per register (D <= 80: three per pass) -
   // no ballot, no LDS; the trace-back reads the word of the state it stands on with one v_readlane
@@ -531,15 +554,18 @@ __device__ __forceinline__ void viterbi_tb(const int* symw, uint32_t D_, uint32_
 #pragma unroll
     for (int g = 0; g < 3; g++) {
       const int k1 = D < 32 * (g + 1) ? D : 32 * (g + 1);
-      auto acs = [&](int k) {
-        const int e = lsn_dot4_acc(symw[k], signs2, kap);
+      auto step = [&](int e) {
         const int a0 = __builtin_amdgcn_ds_bpermute(pa, m) + e, a1 = __builtin_amdgcn_ds_bpermute(pb, m) - e;
         lsn_push_lt(h[g], a1, a0);
         m = a1 < a0 ? a1 : a0;
       };
       int k = 32 * g;
-      for (; k + 4 <= k1; k += 4) { acs(k); acs(k + 1); acs(k + 2); acs(k + 3); }
-      for (; k < k1; k++) acs(k);
+      for (; k + 4 <= k1; k += 4) {
+        int e0, e1, e2, e3;
+        lsn_dot4_acc4(symw[k], symw[k + 1], symw[k + 2], symw[k + 3], signs2, kap, e0, e1, e2, e3);
+        step(e0); step(e1); step(e2); step(e3);
+      }
+      for (; k < k1; k++) step(lsn_dot4_acc(symw[k], signs2, kap));
     }
   };
   sweep(h2);
@@ -550,28 +576,52 @@ __device__ __forceinline__ void viterbi_tb(const int* symw, uint32_t D_, uint32_
     unsigned long long o2 = __shfl_xor(key, off);
     key = o2 < key ? o2 : key;
   }
-  // trace-back over pass 3, then pass 2 (whose states are the output): the state walks in scalar registers
-  int st = __builtin_amdgcn_readfirstlane((int)(key & 63ull));
-  rem_out = 0;
-  unsigned long long bits = 0;  // decoded bit i of the middle pass at position 63-i (payload); the 16 CRC bits go to tailcrc
-  unsigned int tailcrc = 0;
-  auto back = [&](const int* h, bool emit) {
+  // Trace-back over pass 3, then pass 2 (whose states are the output), on the scalar unit.  The walk st <- (st >> 1) | (d << 5), d = the decision of state
+  // st at this step, is kept BIT-REVERSED: with rs = bitrev6(st) it reads rs <- ((rs << 1) | d) & 63, i.e. the decisions are shifted into ONE history
+  // register H whose low six bits are the state - three instructions per step (v_readlane, s_bfe, s_lshl1_add: H = 2 H + d), and the decoded
+  // bits need no work of their own: the input bit of step k is the decision read six steps further down the walk, so after the walk they all stand
+  // in H.  (Rounds 2-5 walked st itself and placed every decoded bit with a 64-bit shift / or under two branches: 10 scalar instructions per step in
+  // the pass that is not emitted, 19 in the one that is - more wave-instructions on the scalar unit than on the vector unit for the whole kernel.)
+  // The history words change lanes once so that lane j holds the word of state bitrev6(j): the lane select is H & 63 as it stands.
+  const int rl = (int)(__brev((unsigned)lane) >> 26) << 2;
+  int p2[3], p3[3];
 #pragma unroll
-    for (int g = 2; g >= 0; g--) {
-      const int k1 = D < 32 * (g + 1) ? D : 32 * (g + 1);
-      for (int k = k1 - 1; k >= 32 * g; k--) {  // step k's decision sits at bit k1 - 1 - k of the group's word
-        if (emit) {
-          if (k < (int)nbits) bits |= (unsigned long long)(st & 1) << (63 - k);
-          else tailcrc |= (unsigned)(st & 1) << (15 - (k - (int)nbits));
-        }
-        const unsigned w = (unsigned)__builtin_amdgcn_readlane(h[g], st);
-        const int dd = (int)((w >> (k1 - 1 - k)) & 1u);
-        st = (st >> 1) | (dd << 5);
-      }
+  for (int g = 0; g < 3; g++) { p2[g] = __builtin_amdgcn_ds_bpermute(rl, h2[g]); p3[g] = __builtin_amdgcn_ds_bpermute(rl, h3[g]); }
+  unsigned H = (unsigned)__builtin_amdgcn_readfirstlane((int)(__brev((unsigned)(key & 63ull)) >> 26));
+  // one group of decisions: step k of the group's cnt steps sits at bit k1 - 1 - k of its word, the walk goes up the bit positions
+  auto walk = [&](int hw, int cnt) {
+    if (cnt >= 4) { lsn_tb_walk4<0>(hw, H);
+    if (cnt >= 8) { lsn_tb_walk4<4>(hw, H);
+    if (cnt >= 12) { lsn_tb_walk4<8>(hw, H);
+    if (cnt >= 16) { lsn_tb_walk4<12>(hw, H);
+    if (cnt >= 20) { lsn_tb_walk4<16>(hw, H);
+    if (cnt >= 24) { lsn_tb_walk4<20>(hw, H);
+    if (cnt >= 28) { lsn_tb_walk4<24>(hw, H);
+    if (cnt >= 32) { lsn_tb_walk4<28>(hw, H); } } } } } } } }
+    for (int p = cnt & ~3; p < cnt; p++) {
+      H = (H << 1) + (((unsigned)__builtin_amdgcn_readlane(hw, (int)(H & 63u)) >> p) & 1u);
     }
   };
-  back(h3, false);
-  back(h2, true);
+  int cnt[3];
+#pragma unroll
+  for (int g = 0; g < 3; g++) {
+    const int k1 = D < 32 * (g + 1) ? D : 32 * (g + 1);
+    cnt[g] = k1 > 32 * g ? k1 - 32 * g : 0;
+  }
+  walk(p3[2], cnt[2]); walk(p3[1], cnt[1]); walk(p3[0], cnt[0]);
+  const unsigned rs0 = H & 63u;   // the state pass 2 ends in (reversed)
+  unsigned G[3];
+#pragma unroll
+  for (int g = 2; g >= 0; g--) {
+    walk(p2[g], cnt[g]);
+    G[g] = cnt[g] >= 32 ? H : (H & ((1u << cnt[g]) - 1u));   // decision of step 32 g + i at bit i
+  }
+  // all D decisions as one number, the end state on top: the input bit of step k is bit k + 6 of it (D <= 80)
+  unsigned __int128 hb = (unsigned __int128)G[0] | ((unsigned __int128)G[1] << 32) | ((unsigned __int128)G[2] << 64) | ((unsigned __int128)rs0 << D);
+  hb >>= 6;
+  // decoded bit i of the middle pass at position 63 - i (payload); the 16 CRC bits behind it, first bit on top
+  const unsigned long long bits = nbits ? (__brevll((unsigned long long)hb) & (~0ull << (64u - nbits))) : 0ull;
+  const unsigned int tailcrc = __brev((unsigned)(hb >> nbits) & 0xFFFFu) >> 16;
   // CRC16 (x^16+x^12+x^5+1) of the payload, all lanes at once: payload bit i weighs x^(nbits - 1 - i + 16) mod g (crcw, built by the host per payload
   // size), the remainder is the XOR of the weights of the set bits (rounds 1-3: a 60-step long division on lane 0 - a third of the kernel's vector
   // instructions, issued for one working lane)

@@ -383,30 +383,42 @@ void lsn_launch_rm(const LsnCbDev* cb, const int16_t* llr, uint32_t* spp, uint32
 // ------------------------------------------------------------------------------------------------ HARQ soft combining
 // The soft buffer of a (RNTI, HARQ process, transport block) holds the de-rate-matched code blocks of the transmissions so far in the decoder's own
 // packed format (k_rm's output: K words of three 10-bit fields + 12 termination values).  A retransmission is combined field by field,
-// acc = clip(acc + cur, +-511), and decoded from the buffer; a new transmission overwrites it (srsran_softbuffer_rx_reset_tbs).  One workgroup per code
-// block; LsnCbDev::spp_off = the block's words in the buffer pool, LsnCbDev::e_off = the words of the current transmission (in `cur`).
-__global__ __launch_bounds__(256) void k_harq_combine(const LsnCbDev* __restrict__ cbs, const uint32_t* __restrict__ cur, uint32_t* __restrict__ pool, uint32_t overwrite)
+// acc = clip(acc + cur, +-511), and decoded from the result; a new transmission replaces the buffer (srsran_softbuffer_rx_reset_tbs).
+// Round 6: the combination never writes the pool.  Inside one commit turn the content of a buffer lives in one of three places - the pool (what earlier
+// chunks left), the chunk's keep store (a failed new transmission of this chunk) or the turn's scratch area (an earlier combination of this chunk) - and
+// every combination writes a NEW piece of the scratch area, so that a whole batch of retransmissions can be combined and decoded ahead of the sequential
+// commit walk without touching anything the walk may still want in its old state (lsn_engine.cc: harqScout / harqRunBatch).  The pool is written by the
+// copy form only, once per touched buffer at the end of the turn.
+// One workgroup per code block.  LsnCbDev::reserved = where the accumulated values are read (place in the two top bits: 0 pool, 1 scratch, 2 keep store;
+// word offset below), e_off = the words of the current transmission in the keep store (combine form), spp_off = where the result goes (combine: scratch,
+// copy: pool).
+__global__ __launch_bounds__(256) void k_harq_combine(const LsnCbDev* __restrict__ cbs, const uint32_t* __restrict__ keep, uint32_t* pool, uint32_t* scratch, uint32_t copy)
 {
   const LsnCbDev cb = cbs[blockIdx.x];
-  const uint32_t* c = cur + cb.e_off;
-  uint32_t* a = pool + cb.spp_off;
+  const uint32_t place = cb.reserved >> 30, off = cb.reserved & 0x3FFFFFFFu;
+  const uint32_t* a = (place == 0u ? (const uint32_t*)pool : place == 1u ? (const uint32_t*)scratch : keep) + off;
   const int K = (int)cb.K;
+  if (copy) {
+    uint32_t* d = pool + cb.spp_off;
+    for (int t = threadIdx.x; t < K + 12; t += 256) d[t] = a[t];
+    return;
+  }
+  const uint32_t* c = keep + cb.e_off;
+  uint32_t* d = scratch + cb.spp_off;
   auto clip = [](int v) { return v > LSN_LLR_CLIP ? LSN_LLR_CLIP : (v < -LSN_LLR_CLIP ? -LSN_LLR_CLIP : v); };
   for (int t = threadIdx.x; t < K + 12; t += 256) {
-    const uint32_t w = c[t];
-    if (overwrite) { a[t] = w; continue; }
-    const uint32_t o = a[t];
+    const uint32_t w = c[t], o = a[t];
     if (t < K) {
       const int v0 = clip(((int)(w << 22) >> 22) + ((int)(o << 22) >> 22)), v1 = clip(((int)(w << 12) >> 22) + ((int)(o << 12) >> 22)), v2 = clip(((int)(w << 2) >> 22) + ((int)(o << 2) >> 22));
-      a[t] = ((uint32_t)v0 & 0x3FFu) | (((uint32_t)v1 & 0x3FFu) << 10) | (((uint32_t)v2 & 0x3FFu) << 20);
+      d[t] = ((uint32_t)v0 & 0x3FFu) | (((uint32_t)v1 & 0x3FFu) << 10) | (((uint32_t)v2 & 0x3FFu) << 20);
     } else {
-      a[t] = (uint32_t)clip((int)w + (int)o);
+      d[t] = (uint32_t)clip((int)w + (int)o);
     }
   }
 }
-void lsn_launch_harq_combine(const LsnCbDev* cbs, uint32_t ncb, const uint32_t* cur, uint32_t* pool, bool overwrite, hipStream_t s)
+void lsn_launch_harq_combine(const LsnCbDev* cbs, uint32_t ncb, const uint32_t* keep, uint32_t* pool, uint32_t* scratch, bool copy, hipStream_t s)
 {
-  if (ncb) LSN_LAUNCH(k_harq_combine, dim3(ncb), dim3(256), 0, s, cbs, cur, pool, overwrite ? 1u : 0u);
+  if (ncb) LSN_LAUNCH(k_harq_combine, dim3(ncb), dim3(256), 0, s, cbs, keep, pool, scratch, copy ? 1u : 0u);
 }
 
 // ------------------------------------------------------------------------------------------------ turbo decoder

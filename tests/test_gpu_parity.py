@@ -500,3 +500,31 @@ def test_harq_soft_combining_matches_oracle():
     phy.process_host(iq, tti0, 0)
     assert gpu_records(phy) == oracle_records(orecs) and len(orecs) > 0
     phy.close()
+
+
+def test_harq_retransmissions_are_decoded_in_batches_and_on_several_engines():
+    """Round 6: the retransmissions of a chunk are combined and decoded in batches AHEAD of the sequential commit walk (Engine::harqScout /
+    harqRunBatch; the walk takes a result only under the key of exactly its inputs, else decodes alone as rounds 4-5 did) - same records as the
+    oracle, nearly every combined decode served from a batch, also for chains of several retransmissions of one process inside a chunk; and with
+    the capture spread over two engines (lsn_phy_create_multi: database, buffers and pool shared, one commit turn at a time) the same again"""
+    sc = scenario("cfg3", seed=97, n_rnti=6, dl_min=3, dl_max=4, ul_min=0, ul_max=0, mix_tm3_pct=50, mix_tm4_pct=0, pct_256qam=0, mcs_min=19, mcs_max=25, snr_db=12.0,
+                  rar_period=0, paging_period=0, pct_harq=70)
+    nsf = 120
+    tti0, iq, _ = gen_subframes(sc, nsf)
+    ow, _, orecs = run_oracle(sc, tti0, iq, taps=False, harq_mode=1, mcs_tracking_mode=0)
+    st = ow.harq_stats()
+    assert st[1] > 40 and len(orecs) > 100
+    for devices, batch in ((None, 120), (None, 40), ([0, 0], 24), ([0, 0, 0], 16)):
+        import torch
+        phy = la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=batch, pcapwriter=la.PcapWriter(None), harq_mode=1, mcs_tracking_mode=0, devices=devices)
+        assert phy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"])
+        d = torch.from_numpy(iq.view(np.float32)).to("cuda:0")
+        torch.cuda.synchronize()
+        stride = iq[0].size * 8
+        for a in range(0, nsf, batch):   # (one submit per chunk: with several engines chunk g goes to engine g mod G)
+            phy.submit_device(d.data_ptr() + a * stride, min(batch, nsf - a), tti0 + a, 0, torch.cuda.current_stream().cuda_stream)
+        phy.wait()
+        assert gpu_records(phy) == oracle_records(orecs), (devices, batch)
+        hc = list(phy.perf().nof_harq_combines)
+        assert hc[0] >= 1 and hc[1] > 0 and hc[2] <= hc[1] // 10, (devices, batch, hc)   # batches were run; the walk found (nearly) all of its combined decodes there
+        phy.close()
