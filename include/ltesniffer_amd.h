@@ -57,7 +57,8 @@ typedef struct {
   uint32_t histogram_threshold;     /* Settings.h:57, default 5 */
   int mcs_tracking_mode;            /* ArgManager.cc:52, default 1 */
   int harq_mode;                    /* 0 (ArgManager.cc:50: the reference's only reachable value) or 1: DL HARQ soft combining (HARQ.cc:71-190,
-                                       DL_Sniffer_PDSCH.cc:943-1020) for known-table C-RNTI grants; DL mode, one engine */
+                                       DL_Sniffer_PDSCH.cc:943-1020) for known-table C-RNTI grants; DL mode.  With lsn_phy_create_multi the soft-buffer pool lives on the
+                                       first device and the other engines need peer access to it (the call fails otherwise) */
   int device;                       /* HIP device ordinal */
   int max_turbo_iterations;         /* SubframeWorker.cc:365, default 12 (0 = default) */
   int sniffer_mode;                 /* 0 = DL_MODE, 1 = UL_MODE (SubframeWorker.cc:166-199): antenna 0 = downlink, antenna 1 = uplink,
