@@ -583,7 +583,7 @@ def main():
                 wl.set_digest_blocks(bl.BLOCK, tl)
                 nl, npass = ld["nsf"], ld["passes"]
                 if ld["kind"] == "dl":
-                    pl = la.Phy(nof_rx_antennas=scl["nof_rx"], max_batch=int(os.environ.get("LSN_HARQ_LEG_BATCH", batch)) if ld.get("harq_mode") else batch, device=local, pcapwriter=wl, harq_mode=ld.get("harq_mode", 0))
+                    pl = la.Phy(nof_rx_antennas=scl["nof_rx"], max_batch=batch, device=local, pcapwriter=wl, harq_mode=ld.get("harq_mode", 0))
                     pl.setCell(scl["nof_prb"], scl["nof_ports"], scl["cell_id"])
                     dl_ = torch.empty((nl,) + iql.shape[1:] + (2,), dtype=torch.float32, device=dev)
                     for a_ in range(0, nl, 2000):

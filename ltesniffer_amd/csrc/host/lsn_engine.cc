@@ -234,7 +234,7 @@ int Engine::setCell(const lsn_cell_t& c)
   try {
     HIP_CHECK(hipSetDevice(cfg.device));
     (void)hipDeviceSynchronize();
-    freeDevice();
+    freeDevice(true);
     cell.nof_prb = c.nof_prb; cell.nof_ports = c.nof_ports; cell.id = c.id; cell.phich_ng_x6 = ng_x6[c.phich_resources]; cell.cp = c.cp;
     buildTables();
     sib2_learned = false;

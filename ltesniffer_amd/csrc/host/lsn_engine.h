@@ -266,7 +266,7 @@ private:
   static constexpr int NSLOTS = NDEC + 8;
   int ndec = 12, nslots = 20;                 // in use (LSN_DECODE_THREADS; 8 until round 4: 12 threads on 16 hardware queues measured + 3 %)
   void createCopyStream();
-  void freeDevice();
+  void freeDevice(bool keep_file_buffers = false);
   void buildTables();
   void allocChunk(Chunk& ch);
   void allocRunner(JobRunner& r);

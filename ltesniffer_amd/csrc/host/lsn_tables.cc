@@ -50,7 +50,7 @@ static T* dalloc(std::vector<void*>& allocs, size_t n)
   return (T*)d;
 }
 
-void Engine::freeDevice()
+void Engine::freeDevice(bool keep_file_buffers)
 {
   for (void* p : dev_allocs) (void)hipFree(p);
   dev_allocs.clear();
@@ -76,7 +76,10 @@ void Engine::freeDevice()
     df(prach.d_W); df(prach.d_V); df(prach.d_D); df(prach.d_Y); df(prach.d_corr); df(prach.d_out); df(prach.d_off);
     prach = Prach();
     df(mib_d_iq); df(mib_d_llr); df(mib_d_cand);
-    for (auto& fb : file_buf) { if (fb.h_raw) (void)hipHostFree(fb.h_raw); df(fb.d_raw); df(fb.d_iq); fb.h_raw = nullptr; fb.bytes = 0; }
+    // the file source's block buffers hold raw bytes, not cell tables: a cell that is set (again) keeps them - page-locking 1.5 GB costs more than replaying
+    // 10 000 subframes, and a caller that reserved them (lsn_phy_prepare_file) and then sets its cell must not pay for them a second time inside its first replay
+    if (!keep_file_buffers)
+      for (auto& fb : file_buf) { if (fb.h_raw) (void)hipHostFree(fb.h_raw); df(fb.d_raw); df(fb.d_iq); fb.h_raw = nullptr; fb.bytes = 0; }
   }
   d_iq_staging = nullptr; staging_sf = 0;
   if (sh->harq_pool_owner == this) { d_harq_pool = nullptr; sh->harq_pool_owner = nullptr; }   // (freed with this engine's device allocations)
