@@ -749,7 +749,7 @@ def main():
             "detail": {"pdus_per_subframe": round(p.nof_pdus / sf_rank, 3), "algo_bytes_per_subframe": int(p.algo_bytes / sf_rank),
                        "whole_path_GBps": round(p.algo_bytes * (1 if capture_mode else world) / 1e9 / dt, 2), "timed_region_s": round(dt, 3),
                        "per_6400_subframes": {k: round(getattr(p, k) * 6400.0 / sf_rank, 3) for k in
-                                              ("nof_tb_decodes", "nof_cb_decodes", "nof_turbo_iterations", "nof_decode_jobs", "nof_decode_jobs_used", "nof_speculative_jobs", "nof_ondemand_decodes", "ms_ondemand_commit", "ms_stage_a", "ms_search", "ms_search_core", "ms_rar", "ms_stage_c", "ms_commit", "ms_wait_front",
+                                              ("nof_tb_decodes", "nof_cb_decodes", "nof_turbo_iterations", "nof_decode_jobs", "nof_decode_jobs_used", "nof_speculative_jobs", "nof_ondemand_decodes", "nof_candidate_misses", "ms_ondemand_commit", "ms_stage_a", "ms_search", "ms_search_core", "ms_rar", "ms_stage_c", "ms_commit", "ms_wait_front",
                                                "ms_wait_slot", "ms_drain")},
                        "decode_jobs_by_kind_per_6400": {"kinds": ["first attempt", "second table after failure", "second table speculative", "RA-RNTI ahead of search", "on demand"],
                                                         "jobs": [round(p.jobs_by_kind[k] * 6400.0 / sf_rank, 1) for k in range(5)], "jobs_unused": [round(p.jobs_unused_by_kind[k] * 6400.0 / sf_rank, 1) for k in range(5)],

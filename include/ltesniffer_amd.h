@@ -114,6 +114,15 @@ float lsn_phy_get_est_cfo(lsn_phy_t* phy);                                /* Sub
  * Takes effect with the next chunk that enters the pipeline; call it between process calls.  mode 2 is refused on a handle of lsn_phy_create_multi. */
 int lsn_phy_set_cfo_correction(lsn_phy_t* phy, int mode, float cfo_hz, float alpha);
 float lsn_phy_get_cfo_correction(lsn_phy_t* phy);                         /* the offset removed from the chunk launched last (srsran_ue_sync_get_cfo) */
+/* Blind DCI decoding (srsran_pdcch_decode_msg_limit_avg_llr_power per location and format, falcon_pdcch.c:110-170; DCISearch.cc:102-447): which (location, size)
+ * slots of a subframe's candidate table the GPU decodes ahead of the sequential search.
+ *   mode 0: all of them (rounds 1-5)
+ *   mode 1 (default): the aggregation levels in four launches, 8 -> 1 CCEs; a slot under a location that holds a candidate the search is predicted to accept (its own
+ *           stateless tests + the RNTI evergreen, or active in the newest published snapshot of the RNTI manager and not forbidden) is left out, and decoded
+ *           on demand if the search comes there after all (lsn_perf_t.nof_candidate_misses) - the table the search sees is the exhaustive one
+ *   mode 2: test - every RNTI counts as active, so that the on-demand path carries the search
+ * Takes effect with the next chunk that enters the pipeline. */
+int lsn_phy_set_candidate_pruning(lsn_phy_t* phy, int mode);
 int lsn_phy_add_evergreen(lsn_phy_t* phy, uint16_t rnti_start, uint16_t rnti_end, uint32_t format_idx); /* RNTIManager::addEvergreen */
 int lsn_phy_add_forbidden(lsn_phy_t* phy, uint16_t rnti_start, uint16_t rnti_end, uint32_t format_idx); /* RNTIManager::addForbidden */
 int lsn_phy_setup_default_rnti_intervals(lsn_phy_t* phy);                 /* LTESniffer_Core.cc:398-417 in one call */
@@ -430,6 +439,7 @@ typedef struct {
    * jobs / turbo iterations run, and the part of both the commit stage never looked at */
   uint64_t jobs_by_kind[5], jobs_unused_by_kind[5], iters_by_kind[5], iters_unused_by_kind[5];
   uint64_t nof_table_hints_used, nof_table_hints_missed;  /* DCIs planned for the 256QAM table alone on the decode threads' own evidence / of those the commit wanted the 64QAM-table attempt of after all (engine totals) */
+  uint64_t nof_candidate_misses;  /* slots of the candidate table the blind decoder had left out (lsn_phy_set_candidate_pruning) and the search had decoded on demand */
   double ms_harq[3];              /* harq_mode = 1, commit-thread time: [0] predicting the retransmissions of the chunks (harqScout), [1] inside the batches (descriptors, launches, wait), [2] bringing the touched buffers home at the end of the turns */
   uint64_t nof_harq_combines[4];  /* harq_mode = 1: [0] batches of retransmissions combined and decoded ahead of the commit walk, [1] combined decodes the walk took from a batch, [2] ... it had to run alone inside its turn, [3] batch results nobody asked for */
 } lsn_perf_t;

@@ -38,7 +38,7 @@ EXPORTS = ["lsn_phy_create", "lsn_phy_destroy", "lsn_phy_set_cell", "lsn_phy_get
            "lsn_phy_tap_ul", "lsn_phy_set_prach_config", "lsn_phy_prach_detect", "lsn_phy_set_prach_sink", "lsn_prach_tti_opportunity", "lsn_phy_process_file", "lsn_phy_mib_decode", "lsn_phy_mib_decode_llr", "lsn_phy_submit_device", "lsn_phy_wait", "lsn_cell_search",
            "lsn_phy_set_shortcut_discovery", "lsn_phy_get_shortcut_discovery", "lsn_phy_set_histogram_threshold", "lsn_phy_print_stats",
            "lsn_phy_set_mcs_update_interval", "lsn_phy_update_mcs_database", "lsn_phy_nof_tracked_rnti", "lsn_worker_buffers_offset", "lsn_pcap_digest", "lsn_pcap_set_store", "lsn_pcap_set_digest_blocks", "lsn_pcap_block_digests", "lsn_phy_create_multi", "lsn_phy_nof_devices",
-           "lsn_phy_set_cfo_correction", "lsn_phy_get_cfo_correction", "lsn_phy_set_stage_c_taps", "lsn_phy_prepare_file", "lsn_phy_get_meta_formats", "lsn_phy_nof_workers", "lsn_phy_worker"]
+           "lsn_phy_set_cfo_correction", "lsn_phy_get_cfo_correction", "lsn_phy_set_candidate_pruning", "lsn_phy_set_stage_c_taps", "lsn_phy_prepare_file", "lsn_phy_get_meta_formats", "lsn_phy_nof_workers", "lsn_phy_worker"]
 
 
 def turbo_nwin(K):
@@ -155,7 +155,7 @@ class Perf(C.Structure):
                 ("nof_turbo_iterations_run", C.c_uint64), ("nof_ondemand_commit", C.c_uint64 * 4), ("ms_ondemand_commit", C.c_double), ("nof_pusch_2prb_skipped", C.c_uint64), ("nof_pusch_on_unverified_dmrs", C.c_uint64), ("nof_tb_on_derived_tbs", C.c_uint64),
                 ("nof_decode_jobs", C.c_uint64), ("nof_decode_jobs_used", C.c_uint64), ("nof_speculative_jobs", C.c_uint64),
                 ("jobs_by_kind", C.c_uint64 * 5), ("jobs_unused_by_kind", C.c_uint64 * 5), ("iters_by_kind", C.c_uint64 * 5), ("iters_unused_by_kind", C.c_uint64 * 5),
-                ("nof_table_hints_used", C.c_uint64), ("nof_table_hints_missed", C.c_uint64), ("ms_harq", C.c_double * 3), ("nof_harq_combines", C.c_uint64 * 4)]
+                ("nof_table_hints_used", C.c_uint64), ("nof_table_hints_missed", C.c_uint64), ("nof_candidate_misses", C.c_uint64), ("ms_harq", C.c_double * 3), ("nof_harq_combines", C.c_uint64 * 4)]
 
 
 class UlCfg(C.Structure):
@@ -232,6 +232,7 @@ def lib():
         L.lsn_phy_get_est_cfo.argtypes = [C.c_void_p]
         L.lsn_phy_get_est_cfo.restype = C.c_float
         L.lsn_phy_set_cfo_correction.argtypes = [C.c_void_p, C.c_int, C.c_float, C.c_float]
+        L.lsn_phy_set_candidate_pruning.argtypes = [C.c_void_p, C.c_int]
         L.lsn_phy_get_cfo_correction.argtypes = [C.c_void_p]
         L.lsn_phy_get_cfo_correction.restype = C.c_float
         L.lsn_phy_add_evergreen.argtypes = [C.c_void_p, C.c_uint16, C.c_uint16, C.c_uint32]
@@ -697,6 +698,13 @@ class Phy:
         """CFO correction inside the OFDM kernel - what srsran_ue_sync's tracking does ahead of the reference's workers (LTESniffer_Core.cc:312-316,344).
         CFO_FIXED removes cfo_hz; CFO_TRACK starts there and follows the CRS estimate chunk by chunk (include/ltesniffer_amd.h)"""
         _check(lib().lsn_phy_set_cfo_correction(self._h, int(mode), float(cfo_hz), float(alpha)), "setCfoCorrection")
+
+    PRUNE_OFF, PRUNE_ON, PRUNE_TEST = 0, 1, 2
+
+    def setCandidatePruning(self, mode):
+        """which slots of the candidate table the blind decoder computes ahead of the search (lsn_phy_set_candidate_pruning): PRUNE_OFF = all, PRUNE_ON (default) =
+        not those under a location the search is predicted to accept (decoded on demand if it comes there after all), PRUNE_TEST = the prediction claims everything"""
+        _check(lib().lsn_phy_set_candidate_pruning(self._h, int(mode)), "setCandidatePruning")
 
     def getCfoCorrection(self):
         return lib().lsn_phy_get_cfo_correction(self._h)

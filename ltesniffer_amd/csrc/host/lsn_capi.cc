@@ -345,6 +345,13 @@ int lsn_phy_set_cfo_correction(lsn_phy_t* phy, int mode, float cfo_hz, float alp
   return rc;
 }
 float lsn_phy_get_cfo_correction(lsn_phy_t* phy) { return phy ? phy->engine->cfoCorrection() : 0.0f; }
+int lsn_phy_set_candidate_pruning(lsn_phy_t* phy, int mode)
+{
+  if (!phy) return LSN_ERROR_INVALID_INPUTS;
+  int rc = phy->engine->setCandidatePruning(mode);
+  for (auto& e : phy->more) if (rc == LSN_SUCCESS) rc = e->setCandidatePruning(mode);
+  return rc;
+}
 
 int lsn_phy_add_evergreen(lsn_phy_t* phy, uint16_t a, uint16_t b, uint32_t f)
 {
@@ -613,6 +620,7 @@ int lsn_phy_get_perf(lsn_phy_t* phy, lsn_perf_t* out)
     out->nof_turbo_iterations_run += p.nof_turbo_iterations_run; out->ms_ondemand_commit += p.ms_ondemand_commit;
     for (int k = 0; k < 4; k++) out->nof_ondemand_commit[k] += p.nof_ondemand_commit[k];
     for (int k = 0; k < 4; k++) out->nof_harq_combines[k] += p.nof_harq_combines[k];
+    out->nof_candidate_misses += p.nof_candidate_misses;
     for (int k = 0; k < 3; k++) out->ms_harq[k] += p.ms_harq[k];
     out->nof_pusch_on_unverified_dmrs += p.nof_pusch_on_unverified_dmrs; out->nof_tb_on_derived_tbs += p.nof_tb_on_derived_tbs;
     out->nof_decode_jobs += p.nof_decode_jobs; out->nof_decode_jobs_used += p.nof_decode_jobs_used; out->nof_speculative_jobs += p.nof_speculative_jobs;

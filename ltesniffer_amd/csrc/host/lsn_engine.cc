@@ -272,6 +272,7 @@ void Engine::mergePerf(const lsn_perf_t& p)
   perf.ms_search_core += p.ms_search_core; perf.ms_rar += p.ms_rar;
   perf.turbo_cyc_rm += p.turbo_cyc_rm; perf.turbo_cyc_map += p.turbo_cyc_map; perf.turbo_cyc_out += p.turbo_cyc_out; perf.nof_turbo_iterations_run += p.nof_turbo_iterations_run; perf.ms_wait_slot += p.ms_wait_slot;
   perf.nof_candidates_decoded += p.nof_candidates_decoded; perf.nof_ondemand_decodes += p.nof_ondemand_decodes; perf.nof_pdus += p.nof_pdus;
+  perf.nof_candidate_misses += p.nof_candidate_misses;
   for (int k = 0; k < 4; k++) perf.nof_ondemand_commit[k] += p.nof_ondemand_commit[k];
   perf.ms_ondemand_commit += p.ms_ondemand_commit;
   for (int k = 0; k < 4; k++) perf.nof_harq_combines[k] += p.nof_harq_combines[k];
@@ -326,7 +327,14 @@ void Engine::launchStageA(Chunk& ch, const void* d_iq)
   timed([&] { lsn_launch_pcfich(cd, ch.d_grid, ch.d_ce, ch.d_chest, ch.d_sfidx, ch.d_cfi, ch.d_pcfich_corr, nsf, st); });
   timed([&] { lsn_launch_pdcch_llr(cd, ch.d_grid, ch.d_ce, ch.d_chest, ch.d_sfidx, ch.d_cfi, ch.d_llr, nsf, st); });
   timed([&] { lsn_launch_cce_power(cd, ch.d_llr, ch.d_cfi, ch.d_ccepow, nsf, st); });
-  timed([&] { lsn_launch_viterbi(cd, ch.d_llr, ch.d_ccepow, ch.d_cfi, ch.d_sfidx, ch.d_cand, nsf, st); });
+  timed([&] {
+    const LsnPruneCfg pc = pruneConfig();
+    if (pc.on) {  // the newest snapshot of the RNTI manager's state the search has published
+      const uint32_t pub = prune_pub.load(std::memory_order_acquire);
+      lsn_launch_upload(ch.d_prune_snap, h_prune_ring + (size_t)((pub + PRUNE_RING - 1) % PRUNE_RING) * LSN_PRUNE_SNAP_WORDS, LSN_PRUNE_SNAP_WORDS * sizeof(uint32_t), st);
+    }
+    lsn_launch_viterbi(cd, ch.d_llr, ch.d_ccepow, ch.d_cfi, ch.d_sfidx, ch.d_cand, nsf, pc, ch.d_prune_snap, ch.d_acc, st);
+  });
   timed([&] { lsn_launch_rb_power(cd, ch.d_rbp_part, ch.d_rbp, nsf, st); });
   if (cfg.sniffer_mode == 1) lsn_launch_ul_fft(cd, iq, cd.iq_nant, 1, ch.d_ul_grid, nsf, st);  // srsran_enb_ul_fft on antenna 1, UL_Sniffer_PUSCH.cc:391-392
   // mirrors for the host stages: posted writes of a copy kernel into the pinned buffers (not the copy engine, lsn_dev.h)
@@ -340,6 +348,69 @@ void Engine::launchStageA(Chunk& ch, const void* d_iq)
     lsn_launch_copy_multi(sg, true, st);
   }
   HIP_CHECK(hipEventRecord(ch.ev_a[16], st));
+}
+
+// candidate pruning (stage_a.hip: k_viterbi): the stateless half of the prediction, from the search's format table and the RNTI manager's intervals
+LsnPruneCfg Engine::pruneConfig()
+{
+  LsnPruneCfg pc{};
+  pc.on = prune_mode.load() != 0 ? 1u : 0u;
+  RNTIManager& rm = search->rntiManager();
+  for (uint32_t f = 0; f < 9u && f < (uint32_t)NOF_FORMATS; f++) {
+    pc.fmt_size[f] = (uint32_t)search->sizeIndexOfFormat((int)f);
+    const auto& ev = rm.evergreenOf(f);
+    const auto& fb = rm.forbiddenOf(f);
+    if (ev.size() > 4 || fb.size() > 4) pc.on = 0;   // (more intervals than the kernel's table holds: exhaustive decode)
+    pc.n_ever[f] = (uint32_t)std::min<size_t>(ev.size(), 4); pc.n_forb[f] = (uint32_t)std::min<size_t>(fb.size(), 4);
+    for (uint32_t i = 0; i < pc.n_ever[f]; i++) pc.ever[f][i] = (uint32_t)ev[i].start | ((uint32_t)ev[i].end << 16);
+    for (uint32_t i = 0; i < pc.n_forb[f]; i++) pc.forb[f][i] = (uint32_t)fb[i].start | ((uint32_t)fb[i].end << 16);
+  }
+  return pc;
+}
+// the search thread, after a chunk: what the RNTI manager and the meta formats hold now
+void Engine::publishPruneSnapshot()
+{
+  if (!h_prune_ring || !search) return;
+  const uint32_t pub = prune_pub.load(std::memory_order_relaxed);
+  uint32_t* slot = h_prune_ring + (size_t)(pub % PRUNE_RING) * LSN_PRUNE_SNAP_WORDS;
+  if (prune_mode.load() == 2) std::memset(slot, 0xFF, 2048 * sizeof(uint32_t));
+  else search->rntiManager().activeFreshBits(slot);
+  slot[2048] = search->metaFormats().primaryMask();
+  prune_pub.store(pub + 1, std::memory_order_release);
+}
+const LsnCand& Engine::candMissTramp(void* ctx, uint32_t li, uint32_t szi)
+{
+  CandMissCtx* c = (CandMissCtx*)ctx;
+  return c->e->candidateMiss(*c->ch, c->sf, li, szi);
+}
+// The search came to a slot the blind decoder had left out (the prediction claimed an acceptance that the sequential state did not bear out): decoded now, on the
+// search runner's stream - a round trip inside the sequential search, which is why the prediction only claims what is all but certain
+const LsnCand& Engine::candidateMiss(Chunk& ch, uint32_t sf, uint32_t li, uint32_t szi)
+{
+  hipStream_t st = runner_s.stream;
+  const size_t idx = ((size_t)sf * LSN_MAX_LOC + li) * LSN_MAX_SIZES + szi;
+  // A claim that did not hold leaves a whole sub-tree undecoded, and the search walks all of it: everything still missing in the 8-CCE block of this slot is
+  // decoded in ONE launch and mirrored level by level (the first version decoded slot by slot: 24 round trips per false claim)
+  const uint32_t ncce_tot = cd.nof_cce[ch.ctx[sf].cfi - 1], lim = std::min<uint32_t>(ncce_tot, LSN_MAX_NUM_OF_CCE);
+  int L = -1; uint32_t r = li;
+  for (int l = 3; l >= 0; l--) { const uint32_t cnt = lim >> l; if (r < cnt) { L = l; break; } r -= cnt; }
+  if (L < 0) throw std::runtime_error("candidate miss outside the location table");
+  const uint32_t block = r >> (3 - L);
+  lsn_launch_viterbi_block(cd, ch.d_llr, ch.d_ccepow, ch.d_cfi, ch.d_sfidx, ch.d_cand, sf, block, pruneConfig(), ch.d_prune_snap, ch.d_acc, st);
+  uint32_t off = 0;
+  for (int l = 3; l >= 0; l--) {
+    const uint32_t cnt = lim >> l, first = block << (3 - l);
+    if (first < cnt) {
+      const uint32_t n = std::min<uint32_t>(1u << (3 - l), cnt - first);
+      const size_t at = ((size_t)sf * LSN_MAX_LOC + off + first) * LSN_MAX_SIZES;
+      HIP_CHECK(hipMemcpyAsync(ch.h_cand + at, ch.d_cand + at, (size_t)n * LSN_MAX_SIZES * sizeof(LsnCand), hipMemcpyDeviceToHost, st));
+    }
+    off += cnt;
+  }
+  HIP_CHECK(hipStreamSynchronize(st));
+  perf_search.nof_candidate_misses++;
+  if (ch.h_cand[idx].flags & LSN_CAND_NOT_COMPUTED) throw std::runtime_error("candidate decode on demand left the slot marked");
+  return ch.h_cand[idx];
 }
 
 void Engine::finishStageA(Chunk& ch)
@@ -439,6 +510,8 @@ void Engine::searchChunk(Chunk& ch, uint32_t update_meta_period)
     force_meta_next = false;
     sf_cnt++;
     const double ts0 = now_ms();
+    cand_miss_ctx = {this, &ch, sf};
+    search->setCandMiss(&Engine::candMissTramp, &cand_miss_ctx);
     search->search(c, ch.h_cand + (size_t)sf * LSN_MAX_LOC * LSN_MAX_SIZES, ch.h_ccepow + (size_t)sf * LSN_CCE_STRIDE, upd);
     { const double dt = now_ms() - ts0; perf_search.ms_search_core += dt; search_time_us += dt * 1e3; }
     est_cfo = c.cfo_hz;  // SubframeWorker.cc:203
@@ -477,6 +550,8 @@ void Engine::searchChunk(Chunk& ch, uint32_t update_meta_period)
       }
     }
   }
+  search->setCandMiss(nullptr, nullptr);
+  publishPruneSnapshot();   // the blind decoder of the chunks that are launched from now on predicts the search with this state (k_viterbi)
 }
 
 // MAC RAR PDU (TS 36.321 6.1.5) walked like srsran::rar_pdu; DL_Sniffer_PDSCH.cc:782-797

@@ -67,6 +67,7 @@ struct Chunk {
   float *d_chest_raw = nullptr, *d_llr = nullptr, *d_ccepow = nullptr, *d_pcfich_corr = nullptr, *d_rbp = nullptr, *d_rbp_part = nullptr;
   LsnChest* d_chest = nullptr;
   uint32_t *d_cfi = nullptr, *d_sfidx = nullptr;
+  uint32_t* d_prune_snap = nullptr; uint8_t* d_acc = nullptr;   // candidate pruning (k_viterbi): the RNTI manager's snapshot this chunk was decoded with; what each decoded slot lets the search do
   LsnCand* d_cand = nullptr;
   LsnCand* h_cand = nullptr; float* h_ccepow = nullptr; LsnChest* h_chest = nullptr; uint32_t* h_cfi = nullptr; float* h_rbp = nullptr;
   uint32_t* h_sfidx = nullptr;
@@ -238,6 +239,10 @@ public:
   void getStats(lsn_blind_stats_t* s) const;
   float estCfo() const { return est_cfo; }
   int setCfoCorrection(int mode, float cfo_hz, float alpha);
+  // Candidate pruning of the blind decoder (stage_a.hip: k_viterbi): 0 = exhaustive table, 1 = slots under a location whose candidate the search is predicted
+  // to accept are left out and decoded on demand if the search comes there after all (default), 2 = test: every RNTI counts as active (the prediction claims
+  // far too much, the on-demand path carries the search)
+  int setCandidatePruning(int mode) { if (mode < 0 || mode > 2) return LSN_ERROR_INVALID_INPUTS; prune_mode.store(mode); return LSN_SUCCESS; }
   float cfoCorrection() const { return cfo_current.load(); }
   RNTIManager& rntiManager() { return search->rntiManager(); }
   FalconSearch& searchRef() { return *search; }
@@ -414,6 +419,18 @@ private:
   uint64_t chunks_expected = 0;               // chunks of all submits so far; wait() returns when as many have been written
   std::thread search_thread;                  // stage B: the sequential FALCON search, chunk after chunk
   lsn_perf_t perf_search{};
+  // candidate pruning: snapshots of the RNTI manager's state (active RNTIs as bits + the primary-format mask), published by the search after every chunk into a
+  // pinned ring; the front thread uploads the newest one with the stage-A launches of its next chunk.  A prediction only: a snapshot that is old, or torn by a
+  // publish that overtakes the upload, costs on-demand decodes, never a wrong table
+  static constexpr uint32_t PRUNE_RING = 64;
+  uint32_t* h_prune_ring = nullptr;
+  std::atomic<uint32_t> prune_pub{0};
+  std::atomic<int> prune_mode{1};
+  LsnPruneCfg pruneConfig();
+  void publishPruneSnapshot();
+  struct CandMissCtx { Engine* e; Chunk* ch; uint32_t sf; } cand_miss_ctx{nullptr, nullptr, 0};
+  static const LsnCand& candMissTramp(void* ctx, uint32_t li, uint32_t szi);
+  const LsnCand& candidateMiss(Chunk& ch, uint32_t sf, uint32_t li, uint32_t szi);
   void searchLoop();
   std::deque<Chunk*> search_queue, spec_queue;   // front -> spec (speculative RA-RNTI decodes) -> search
   std::thread spec_thread;

@@ -685,13 +685,14 @@ RNTIManager::RNTIManager(uint32_t nf, uint32_t maxCand, uint32_t thr)
       maxCandidatesPerStepPerFormat(maxCand), remainingCandidates(nf, (int32_t)maxCand)
 {
   totals.assign(65536, 0);
+  active_bits.assign(2048, 0u);
   for (auto& h : histograms) h.setTotals(totals.data());
 }
 void RNTIManager::addCandidate(uint16_t rnti, uint32_t f) { histograms[f].add(rnti); remainingCandidates[f]--; }
 bool RNTIManager::isEvergreen(uint16_t rnti, uint32_t f) const { for (auto& i : evergreen[f]) if (i.matches(rnti)) return true; return false; }
 bool RNTIManager::isForbidden(uint16_t rnti, uint32_t f) const { for (auto& i : forbidden[f]) if (i.matches(rnti)) return true; return false; }
-void RNTIManager::activateRNTI(uint16_t rnti, ActivationReason r) { if (!active[rnti]) { active[rnti] = 1; reason[rnti] = (uint8_t)r; nactive++; } }
-void RNTIManager::deactivateRNTI(uint16_t rnti) { if (active[rnti]) { active[rnti] = 0; assocFormatIdx[rnti] = 0; nactive--; } }
+void RNTIManager::activateRNTI(uint16_t rnti, ActivationReason r) { if (!active[rnti]) { active[rnti] = 1; active_bits[rnti >> 5] |= 1u << (rnti & 31u); reason[rnti] = (uint8_t)r; nactive++; } }
+void RNTIManager::deactivateRNTI(uint16_t rnti) { if (active[rnti]) { active[rnti] = 0; active_bits[rnti >> 5] &= ~(1u << (rnti & 31u)); assocFormatIdx[rnti] = 0; nactive--; } }
 uint32_t RNTIManager::getLikelyDlFormatIdx(uint16_t rnti) const
 {
   uint32_t best = 0, mx = 0;

@@ -133,6 +133,20 @@ public:
   ActivationReason getActivationReason(uint16_t rnti) const { return active[rnti] ? (ActivationReason)reason[rnti] : RM_ACT_UNSET; }
   uint32_t nofActive() const { return nactive; }
   void setHistogramThreshold(uint32_t t) { threshold = t; }  // RNTIManager.cc:442-444
+  // what the candidate pruning of the blind decoder wants to know (k_viterbi): the active RNTIs as bits, the static intervals of a format
+  const uint32_t* activeBits() const { return active_bits.data(); }
+  // ... without the RNTIs whose activation has run out (validate, :705-708, only notices when the RNTI shows up again: a cell's departed UEs stay "active" for
+  // good, and a random CRC that hits one of them would be claimed acceptable by the pruning and refused by the search)
+  void activeFreshBits(uint32_t* out2048) const
+  {
+    for (uint32_t w = 0; w < 2048; w++) {
+      uint32_t m = active_bits[w], keep = 0;
+      for (uint32_t t = m; t; t &= t - 1) { const uint32_t b = (uint32_t)__builtin_ctz(t); if (timestamp - lastSeen[w * 32 + b] < lifetime) keep |= 1u << b; }
+      out2048[w] = keep;
+    }
+  }
+  const std::vector<Interval>& evergreenOf(uint32_t f) const { return evergreen[f]; }
+  const std::vector<Interval>& forbiddenOf(uint32_t f) const { return forbidden[f]; }
 private:
   uint32_t getLikelyDlFormatIdx(uint16_t rnti) const;
   void activateRNTI(uint16_t rnti, ActivationReason r);
@@ -141,6 +155,7 @@ private:
   std::vector<Histogram> histograms;
   std::vector<std::vector<Interval>> evergreen, forbidden;
   std::vector<uint8_t> active, reason;
+  std::vector<uint32_t> active_bits;   // active[], one bit per RNTI (2048 words)
   std::vector<uint32_t> lastSeen, assocFormatIdx, totals;
   uint32_t nactive, timestamp, lifetime, threshold, maxCandidatesPerStepPerFormat;
   std::vector<int32_t> remainingCandidates;
@@ -156,6 +171,7 @@ public:
   MetaFormat** getSecondaryMetaFormats() { return secondary.data(); }
   uint32_t getNofPrimaryMetaFormats() const { return nprimary; }
   uint32_t getNofSecondaryMetaFormats() const { return nsecondary; }
+  uint32_t primaryMask() const { uint32_t m = 0; for (uint32_t i = 0; i < nprimary; i++) m |= 1u << primary[i]->global_index; return m; }   // bit f: format f is tried in the primary pass
   void setSkipSecondaryMetaFormats(bool s) { skip_secondary = s; }
   bool skipSecondaryMetaFormats() const { return skip_secondary; }
 private:

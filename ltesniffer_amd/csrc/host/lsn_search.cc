@@ -253,7 +253,8 @@ int FalconSearch::inspect_dci_location_recursively(SubframeCtx& c, const int16_t
   for (uint32_t fi = 0; fi < nof_formats; fi++) {
     {  // srsran_pdcch_decode_msg_limit_avg_llr_power (falcon_pdcch.c:110-170) as a lookup in the exhaustive candidate table (decodeCandidate)
       const DciFormat format = metas[fi]->format;
-      const LsnCand& t = row[size_index_of_format[format]];
+      const LsnCand& t0 = row[size_index_of_format[format]];
+      const LsnCand& t = (t0.flags & LSN_CAND_NOT_COMPUTED) && cand_miss ? cand_miss(cand_miss_ctx, (uint32_t)li, (uint32_t)size_index_of_format[format]) : t0;
       DciCandidate& d = cand[fi];
       if (t.flags & 1u) {
         d.rnti = (uint16_t)t.rnti;

@@ -79,6 +79,7 @@ public:
   uint32_t nofSizes() const { return nsizes; }
   const uint32_t* sizes() const { return size_list; }
   void setupDefaultIntervals();  // LTESniffer_Core.cc:398-417
+  void setCandMiss(const LsnCand& (*fn)(void*, uint32_t, uint32_t), void* ctx) { cand_miss = fn; cand_miss_ctx = ctx; }   // who decodes a slot the blind decoder left out
   void setShortcutDiscovery(bool enable) { shortcut_discovery = enable; }  // PhyCommon::setShortcutDiscovery, PhyCommon.cc:69-71
   bool getShortcutDiscovery() const { return shortcut_discovery; }
   // the DL entry addCandidate() would build for this candidate (no state is touched): used to decode RA-RNTI grants ahead
@@ -131,6 +132,9 @@ private:
   const LocTemplate* cur_tp = nullptr;
   LocTemplate loc_template[3];
   const LsnCand* cur_cand = nullptr;
+  // a slot the blind decoder left out (LSN_CAND_NOT_COMPUTED): the owner of the table decodes it now and returns it (Engine::candidateMiss)
+  const LsnCand& (*cand_miss)(void* ctx, uint32_t li, uint32_t size_index) = nullptr;
+  void* cand_miss_ctx = nullptr;
   const float* cur_ccepow = nullptr;
   BlindStats stats;
   bool shortcut_discovery = true;  // Settings.h / ArgManager default (DCISearch.cc:200: enableShortcutDiscovery)

@@ -171,6 +171,8 @@ void Engine::allocChunk(Chunk& ch)
   ch.d_chest = dalloc<LsnChest>(dev_allocs, B);
   ch.d_cfi = dalloc<uint32_t>(dev_allocs, B);
   ch.d_sfidx = dalloc<uint32_t>(dev_allocs, B);
+  ch.d_prune_snap = dalloc<uint32_t>(dev_allocs, LSN_PRUNE_SNAP_WORDS);
+  ch.d_acc = dalloc<uint8_t>(dev_allocs, B * LSN_MAX_LOC * LSN_MAX_SIZES);   // (zeroed: the slots of sizes the cell does not have are never written and must read 0)
   ch.d_dphi = dalloc<uint32_t>(dev_allocs, B);
   ch.d_pcfich_corr = dalloc<float>(dev_allocs, B * 3);
   ch.d_llr = dalloc<float>(dev_allocs, B * LSN_LLR_STRIDE);
@@ -395,6 +397,10 @@ void Engine::buildTables()
       harq_keep.clear();
     }
   }
+  h_prune_ring = halloc<uint32_t>(host_allocs, (size_t)PRUNE_RING * LSN_PRUNE_SNAP_WORDS);
+  std::memset(h_prune_ring, 0, (size_t)PRUNE_RING * LSN_PRUNE_SNAP_WORDS * sizeof(uint32_t));
+  prune_pub.store(0);
+  publishPruneSnapshot();
   // pipeline slots, decode runners, staging
   for (int i = 0; i < nslots; i++) allocChunk(chunks[i]);
   for (int i = 0; i < ndec; i++) allocRunner(runner_c[i]);

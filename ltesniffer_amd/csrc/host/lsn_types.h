@@ -12,5 +12,18 @@ struct LsnCand {
   unsigned long long bits;  // payload bit i at position 63-i
   uint32_t rnti;            // CRC remainder = RNTI (falcon_pdcch.c:399-402)
   uint32_t flags;           // bit 0: decoded (0 = skipped: location out of range / insufficient power / all-zero LLRs);
-                            // bits 1-2: search-space verdict of (location, rnti): 0 invalid, 1 ambiguous with L-1, 2 valid
+                            // bits 1-2: search-space verdict of (location, rnti): 0 invalid, 1 ambiguous with L-1, 2 valid;
+                            // LSN_CAND_NOT_COMPUTED: the slot was left out (an ancestor location holds a candidate the search was predicted to accept) -
+                            // a search that comes here all the same has it decoded on demand
 };
+#define LSN_CAND_NOT_COMPUTED 0x80u
+// Candidate pruning (k_viterbi, stage_a.hip): the stateless part of the prediction - the RNTI manager's format table as the kernel needs it.  Format f =
+// index in falcon_ue_all_formats = the RNTI manager's format index = DciFormat.  Intervals: first | last << 16, at most four per format and kind (more: pruning off).
+// The stateful part (active RNTIs as 2048 words of bits, then the primary-format mask) travels per chunk: LSN_PRUNE_SNAP_WORDS words.
+struct LsnPruneCfg {
+  uint32_t on;             // 0: exhaustive table (every slot decoded, as rounds 1-5)
+  uint32_t fmt_size[9];    // size index of format f
+  uint32_t n_ever[9], n_forb[9];
+  uint32_t ever[9][4], forb[9][4];
+};
+#define LSN_PRUNE_SNAP_WORDS 2052

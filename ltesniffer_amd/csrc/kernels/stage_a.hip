@@ -644,23 +644,85 @@ __device__ __forceinline__ void viterbi_tb(const int* symw, uint32_t D_, uint32_
 // round trip per step.
 // A two-candidates-per-wavefront variant on packed wrapping 16-bit metrics was built and measured in round 4 (bit-identical candidate tables, half the ds_bpermute
 // traffic, 40 % more vector instructions, the same launch time and pipeline rate: DESIGN 5.2, tools/viterbi_packed_design.py); it is not part of the product.
+// Round 6: the table is no longer exhaustive by default.  The sequential search reads about 180 of the 960 (location, size) slots of a loaded 20 MHz subframe: a
+// DCI it accepts at a location closes everything underneath (DCISearch.cc:371-376: the CCEs become occupied), and the decoder was a third of the chip's
+// vector work.  Whether a candidate is accepted depends on the RNTI manager's sequential state, so the kernel cannot know - but it can make a SAFE guess from a
+// snapshot of that state (the active RNTIs as a bitmap, the primary / secondary split of the meta formats): "this location holds a candidate the search
+// will accept" is only claimed when the candidate passes the search's own stateless tests (format, RNTI ranges, search space: inspect_dci_location_recursively
+// :139-214) and its RNTI is evergreen, or active in the snapshot and not forbidden.  The levels are decoded in four launches, 8 -> 4 -> 2 -> 1 CCEs; a wavefront
+// whose ancestor made the claim leaves without decoding and marks its slot LSN_CAND_NOT_COMPUTED.  The guess errs on the side of decoding (an RNTI activated since
+// the snapshot, shortcut discoveries, histogram validations: all "not claimed"); where it claims too much (an RNTI that expired since) the search finds the mark
+// and has the slot decoded on demand (Engine::candidateMiss) - the table the search SEES is the exhaustive one, entry for entry.
+// acc[sf][location][size]: what the decoded candidate of that slot lets the search do, one byte: bit 0 / 1 = acceptable in the primary pass with a
+// search-space verdict of 1 / 2 (verdict 1: the search still looks into the second half of the location, :288-298), bit 2 / 3 = the same in the secondary pass
+// (recorded, not used for closing: see below).
+__device__ __forceinline__ bool lsn_in_intervals(const uint32_t* iv, uint32_t n, uint32_t r)
+{
+  bool hit = false;
+  for (uint32_t i = 0; i < n && i < 4u; i++) hit = hit || (r >= (iv[i] & 0xFFFFu) && r <= (iv[i] >> 16));
+  return hit;
+}
+__device__ __forceinline__ uint32_t lsn_cand_claim(const LsnPruneCfg& pc, const uint32_t* __restrict__ snap, uint32_t sz, unsigned long long bits, uint32_t rnti, uint32_t ss)
+{
+  if (ss == 0u || rnti > 0xFFFFu) return 0u;
+  const uint32_t primary = snap[2048];
+  const bool active = (snap[rnti >> 5] >> (rnti & 31u)) & 1u;
+  uint32_t claim = 0;
+  for (uint32_t f = 0; f < 9u; f++) {
+    if (pc.fmt_size[f] != sz) continue;
+    // falcon_pdcch.c:147-148: a payload of the format 0 / 1A size is a format 0 or a format 1A by its first bit; :163 the meta format must be that format
+    if ((f == 0u || f == 2u) && ((bits >> 63) == 0ull) != (f == 0u)) continue;
+    if (f == 4u && rnti > 0x000Au && rnti < 0xFFFEu) continue;                         // :174 format 1C carries no C-RNTI
+    if (rnti > 0x0001u && rnti < 0x000Au && f != 2u && f != 4u) continue;              // :181-197 RA-RNTIs come in 1A / 1C
+    const bool valid = lsn_in_intervals(pc.ever[f], pc.n_ever[f], rnti) || (!lsn_in_intervals(pc.forb[f], pc.n_forb[f], rnti) && active);
+    if (!valid) continue;
+    claim |= ((primary >> f) & 1u) ? (ss == 1u ? 1u : 2u) : (ss == 1u ? 4u : 8u);
+  }
+  return claim;
+}
+
+// level: 3 .. 0 = the locations of that aggregation level only (blockIdx.x counts them), -1 = every location (the exhaustive table of rounds 1-5, pc.on = 0),
+// -2 = decode on demand: every slot that is still marked LSN_CAND_NOT_COMPUTED among the (up to 15) locations of the 8-CCE block one_li of subframe one_sf
+// (blockIdx.x: 0 = the block's level-3 location, 1-2 level 2, 3-6 level 1, 7-14 level 0; blockIdx.y = size), whatever their ancestors say
 __global__ __launch_bounds__(64) void k_viterbi(LsnCellDev c, const float* __restrict__ llr, const float* __restrict__ pw,
                                                 const uint32_t* __restrict__ cfi_arr, const uint32_t* __restrict__ sf_idx_arr,
-                                                LsnCand* __restrict__ cand)
+                                                LsnCand* __restrict__ cand, LsnPruneCfg pc, const uint32_t* __restrict__ snap, uint8_t* __restrict__ acc, int level,
+                                                uint32_t one_sf, uint32_t one_li, uint32_t one_sz)
 {
   __shared__ __attribute__((aligned(16))) int symw[LSN_MAX_DCI_D + 4];  // per trellis step: (q0 - 128) | (q1 - 128) << 8 | (q2 - 128) << 16, signed bytes
-  const int lane = threadIdx.x, sf = blockIdx.z, sz = blockIdx.y;
-  int li = blockIdx.x;
-  LsnCand* out = cand + ((size_t)sf * LSN_MAX_LOC + blockIdx.x) * LSN_MAX_SIZES + sz;
+  const int lane = threadIdx.x, sf = level == -2 ? (int)one_sf : (int)blockIdx.z, sz = (int)blockIdx.y;
   const uint32_t ncce_tot = c.nof_cce[cfi_arr[sf] - 1];
   const uint32_t lim = ncce_tot < LSN_MAX_NUM_OF_CCE ? ncce_tot : LSN_MAX_NUM_OF_CCE;
-  // location enumeration of srsran_pdcch_ue_locations_all_map (falcon_pdcch.c:321-356)
-  int L = -1; uint32_t ncce = 0;
-  for (int l = 3; l >= 0; l--) {
-    int cnt = (int)(lim >> l);
-    if (li < cnt) { L = l; ncce = ((uint32_t)li % (ncce_tot >> l)) << l; break; }
-    li -= cnt;
+  // location enumeration of srsran_pdcch_ue_locations_all_map (falcon_pdcch.c:321-356): level 3 first, then 2, 1, 0; the slots behind the last location are cleared
+  int li, L = -1; uint32_t ncce = 0;
+  if (level >= 0) {
+    // the per-level launches have the largest count of their level as grid (84 >> level; level 0: three more): an index behind this subframe's count takes
+    // one of the 160 - nloc unused slots, so that every slot of the table is written exactly once per chunk
+    const uint32_t cnt = lim >> level, nloc = (lim >> 3) + (lim >> 2) + (lim >> 1) + lim;
+    uint32_t off = 0, spare = 0;
+    for (int l = 3; l > level; l--) { off += lim >> l; spare += (LSN_MAX_NUM_OF_CCE >> l) - (lim >> l); }
+    if (blockIdx.x < cnt) { li = (int)(off + blockIdx.x); L = level; ncce = (blockIdx.x % (ncce_tot >> level)) << level; }
+    else { li = (int)(nloc + spare + (blockIdx.x - cnt)); if (li >= LSN_MAX_LOC) return; }
+  } else if (level == -2) {
+    const int bl = blockIdx.x == 0 ? 3 : (blockIdx.x < 3 ? 2 : (blockIdx.x < 7 ? 1 : 0));      // level of this block-local location
+    const uint32_t j = blockIdx.x - ((1u << (3 - bl)) - 1u);                                    // ... and its place among the block's locations of that level
+    const uint32_t idx = (one_li << (3 - bl)) + j;                                               // index among ALL locations of the level
+    if (idx >= (lim >> bl)) return;
+    uint32_t off = 0;
+    for (int l = 3; l > bl; l--) off += lim >> l;
+    li = (int)(off + idx); L = bl; ncce = idx << bl;
+    if (!(cand[((size_t)sf * LSN_MAX_LOC + li) * LSN_MAX_SIZES + sz].flags & LSN_CAND_NOT_COMPUTED)) return;   // computed before (by the level launches or an earlier miss)
+  } else {
+    li = (int)blockIdx.x;
+    int r = li;
+    for (int l = 3; l >= 0; l--) {
+      int cnt = (int)(lim >> l);
+      if (r < cnt) { L = l; ncce = ((uint32_t)r % (ncce_tot >> l)) << l; break; }
+      r -= cnt;
+    }
   }
+  LsnCand* out = cand + ((size_t)sf * LSN_MAX_LOC + li) * LSN_MAX_SIZES + sz;
+  uint8_t* aout = acc + ((size_t)sf * LSN_MAX_LOC + li) * LSN_MAX_SIZES + sz;
   bool ok = L >= 0;
   const uint32_t E = ok ? (72u << L) : 0u;
   if (ok && ncce * 72 + E > ncce_tot * 72) ok = false;
@@ -669,8 +731,36 @@ __global__ __launch_bounds__(64) void k_viterbi(LsnCellDev c, const float* __res
       if (pw[sf * LSN_CCE_STRIDE + ncce + i] < 0.7f) ok = false;  // location->sufficient_power (falcon_pdcch.c:610-614)
   }
   if (!ok) {
-    if (lane == 0) { out->bits = 0; out->rnti = 0; out->flags = 0; }
+    if (lane == 0) { out->bits = 0; out->rnti = 0; out->flags = 0; if (pc.on) *aout = 0; }
     return;
+  }
+  if (pc.on && level >= 0 && L < 3) {
+    // Does the search come here for this size?  In its primary pass only if no ancestor is accepted there (or this location lies in the second half of an
+    // ancestor accepted with verdict 1); in its secondary pass only if, besides, no ancestor was accepted in the primary pass at all (its CCEs are occupied then)
+    const uint32_t primary = snap[2048];
+    bool has_p = false, has_s = false;
+    for (uint32_t f = 0; f < 9u; f++)
+      if (pc.fmt_size[f] == (uint32_t)sz) { if ((primary >> f) & 1u) has_p = true; else has_s = true; }
+    bool closed_p = false, closed_s = false;
+    uint32_t offA = 0;
+    for (int la = 3; la > L; la--) {
+      const uint32_t idxA = ncce >> la;
+      if (idxA < (lim >> la)) {
+        const unsigned long long w = *(const unsigned long long*)(acc + ((size_t)sf * LSN_MAX_LOC + offA + idxA) * LSN_MAX_SIZES);   // the eight size slots of the ancestor
+        uint32_t m = (uint32_t)(w | (w >> 32));
+        m |= m >> 16; m |= m >> 8;
+        const bool first_half = ((ncce >> (la - 1)) & 1u) == 0u;
+        if ((m & 3u) && (first_half || !(m & 1u))) closed_p = true;
+        // (a candidate of the ancestor that only the SECONDARY pass could accept closes nothing here: that pass does not come to the ancestor at all once any
+        // location underneath it was accepted in the primary pass - which the launches of the deeper levels have not told yet)
+        if (m & 3u) closed_s = true;
+      }
+      offA += lim >> la;
+    }
+    if (!((has_p && !closed_p) || (has_s && !closed_s))) {
+      if (lane == 0) { out->bits = 0; out->rnti = 0; out->flags = LSN_CAND_NOT_COMPUTED; *aout = 0; }
+      return;
+    }
   }
   const float* e = llr + (size_t)sf * LSN_LLR_STRIDE + ncce * 72;
   const uint32_t nbits = c.sizes[sz], D = nbits + 16, D3 = 3 * D;
@@ -695,15 +785,17 @@ __global__ __launch_bounds__(64) void k_viterbi(LsnCellDev c, const float* __res
     symw[t] = (int)word;
   }
   if (__ballot(nz) == 0ull) {  // mean |llr| == 0: the reference skips the decode (falcon_pdcch.c:141)
-    if (lane == 0) { out->bits = 0; out->rnti = 0; out->flags = 0; }
+    if (lane == 0) { out->bits = 0; out->rnti = 0; out->flags = 0; if (pc.on) *aout = 0; }
     return;
   }
   unsigned long long bits; uint32_t rnti;
   viterbi_tb(symw, D, nbits, c.crc16_w + sz * 64, lane, bits, rnti);
   if (lane == 0) {
+    const uint32_t ss = ss_validate(ncce_tot, ncce, (uint32_t)L, sf_idx_arr[sf], rnti);
     out->bits = bits;
     out->rnti = rnti;
-    out->flags = 1u | (ss_validate(ncce_tot, ncce, (uint32_t)L, sf_idx_arr[sf], rnti) << 1);  // bit 0: decoded, bits 1-2: search-space match
+    out->flags = 1u | (ss << 1);  // bit 0: decoded, bits 1-2: search-space match
+    if (pc.on && level >= 0) *aout = (uint8_t)lsn_cand_claim(pc, snap, (uint32_t)sz, bits, rnti, ss);
   }
 }
 // ------------------------------------------------------------------------------------------------ PBCH / MIB
@@ -829,9 +921,23 @@ void lsn_launch_pbch(const LsnCellDev& c, const cf32* grid, const cf32* ce, cons
 }
 
 void lsn_launch_viterbi(const LsnCellDev& c, const float* llr, const float* pw, const uint32_t* cfi, const uint32_t* sf_idx, LsnCand* cand, uint32_t nsf,
-                        hipStream_t s)
+                        const LsnPruneCfg& pc, const uint32_t* snap, uint8_t* acc, hipStream_t s)
 {
-  LSN_LAUNCH(k_viterbi, dim3(LSN_MAX_LOC, c.nsizes, nsf), dim3(64), 0, s, c, llr, pw, cfi, sf_idx, cand);
+  if (!pc.on) {
+    LSN_LAUNCH(k_viterbi, dim3(LSN_MAX_LOC, c.nsizes, nsf), dim3(64), 0, s, c, llr, pw, cfi, sf_idx, cand, pc, snap, acc, -1, 0u, 0u, 0u);
+    return;
+  }
+  static_assert((LSN_MAX_NUM_OF_CCE >> 3) + (LSN_MAX_NUM_OF_CCE >> 2) + (LSN_MAX_NUM_OF_CCE >> 1) + LSN_MAX_NUM_OF_CCE + 3 == LSN_MAX_LOC, "the spare slots are taken by the level-0 launch");
+  for (int level = 3; level >= 0; level--)
+    LSN_LAUNCH(k_viterbi, dim3((LSN_MAX_NUM_OF_CCE >> level) + (level == 0 ? 3 : 0), c.nsizes, nsf), dim3(64), 0, s, c, llr, pw, cfi, sf_idx, cand, pc, snap, acc, level, 0u, 0u, 0u);
+}
+// decode on demand: the slots of one 8-CCE block of one subframe that are still marked LSN_CAND_NOT_COMPUTED (the search found one of them)
+void lsn_launch_viterbi_block(const LsnCellDev& c, const float* llr, const float* pw, const uint32_t* cfi, const uint32_t* sf_idx, LsnCand* cand, uint32_t sf, uint32_t block,
+                              const LsnPruneCfg& pc, const uint32_t* snap, uint8_t* acc, hipStream_t s)
+{
+  LsnPruneCfg off = pc;
+  off.on = 0;
+  LSN_LAUNCH(k_viterbi, dim3(15, c.nsizes, 1), dim3(64), 0, s, c, llr, pw, cfi, sf_idx, cand, off, snap, acc, -2, sf, block, 0u);
 }
 
 // SubframePower::computePower (SubframePower.cc:18-42) linear part: sum over 14 symbols of mean |x|^2 per PRB (antenna 0).  The per-symbol terms come from

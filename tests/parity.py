@@ -188,7 +188,7 @@ def compare_taps(phy, per_sf, sc, base=0, nsf=None):
     return bad
 
 
-def compare_candidate_tables(phy, per_sf, sc, tti0, base=0, nsf=None):
+def compare_candidate_tables(phy, per_sf, sc, tti0, base=0, nsf=None, skip_not_computed=False):
     """the exhaustive blind-decode table of the GPU (every location x every DCI size: payload bits, CRC remainder = RNTI,
     search-space verdict) and the per-CCE LLR power against the oracle's candidate decoder run over the same LLRs"""
     import ctypes as C
@@ -210,6 +210,9 @@ def compare_candidate_tables(phy, per_sf, sc, tti0, base=0, nsf=None):
         for li in range(MAX_LOC):
             for si in range(len(sizes)):
                 a, b = got[li * MAX_SIZES + si], ref[li * MAX_SIZES + si]
+                if skip_not_computed and (int(a["flags"]) & 0x80):   # LSN_CAND_NOT_COMPUTED: left out by the pruning (reported, not an error) - unless the search had it decoded
+                    bad.append((i, "left_out", li, si))
+                    continue
                 if (a["flags"] & 1) != (b["flags"] & 1) or ((b["flags"] & 1) and (a["bits"] != b["bits"] or a["rnti"] != b["rnti"] or a["flags"] != b["flags"])):
                     bad.append((i, "cand", li, si, int(a["bits"]), int(b["bits"]), int(a["rnti"]), int(b["rnti"]), int(a["flags"]), int(b["flags"])))
     return bad

@@ -178,10 +178,44 @@ def test_exhaustive_candidate_table_matches_oracle_decoder():
         _, per_sf, _ = run_oracle(sc, tti0, iq)
         phy = la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=n)
         assert phy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"])
+        phy.setCandidatePruning(la.Phy.PRUNE_OFF)   # every slot (the default leaves out what the search is predicted not to read: next test)
         phy.process_host(iq, tti0, 0)
         bad = compare_candidate_tables(phy, per_sf, sc, tti0, 0, n)
         assert not bad, (scn, bad[:3])
         phy.close()
+
+
+def test_pruned_candidate_table_and_decode_on_demand():
+    """Round 6: by default the blind decoder leaves out the slots under a location whose candidate the search is predicted to accept (k_viterbi: four launches,
+    8 -> 1 CCEs, the prediction from the search's stateless tests + a snapshot of the active RNTIs) and the search has a left-out slot decoded on demand when it
+    comes there after all.  (1) every slot the pruned table DOES hold equals the oracle's decoder, and once the RNTIs are active a good part of the loaded
+    subframes' slots is left out; (2) the record stream is the oracle's with the prediction as it is, with pruning off, and with a prediction that claims
+    everything (PRUNE_TEST: every RNTI counts as active, so the search keeps running into left-out slots - the on-demand path carries it)"""
+    sc = scenario("cfg3", seed=52, n_rnti=40)
+    n = 48
+    tti0, iq, _ = gen_subframes(sc, n)
+    _, per_sf, orecs = run_oracle(sc, tti0, iq)
+    want = oracle_records(orecs)
+    assert len(want) > 300
+    left_out = {}
+    for mode, batch in ((la.Phy.PRUNE_ON, 8), (la.Phy.PRUNE_OFF, 8), (la.Phy.PRUNE_TEST, 8), (la.Phy.PRUNE_ON, 48)):
+        phy = la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=batch, pcapwriter=la.PcapWriter(None))
+        assert phy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"])
+        phy.setCandidatePruning(mode)
+        misses = 0
+        for a in range(0, n, batch):
+            phy.process_host(iq[a:a + batch], tti0 + a, 0)
+            misses += phy.perf().nof_candidate_misses
+        assert gpu_records(phy) == want, (mode, batch)
+        # the table of the last chunk: computed slots against the oracle's decoder, left-out slots counted
+        base = n - batch
+        bad = compare_candidate_tables(phy, per_sf, sc, tti0, base, batch, skip_not_computed=True)
+        assert not [b for b in bad if b[1] != "left_out"], (mode, bad[:3])
+        left_out[(mode, batch)] = (len([b for b in bad if b[1] == "left_out"]) / float(batch), misses)
+        phy.close()
+    assert left_out[(la.Phy.PRUNE_OFF, 8)] == (0.0, 0)
+    assert left_out[(la.Phy.PRUNE_ON, 8)][0] > 50 and left_out[(la.Phy.PRUNE_ON, 8)][1] <= 8, left_out   # slots per subframe left out; hardly any of them missed
+    assert left_out[(la.Phy.PRUNE_TEST, 8)][1] > 20, left_out                                               # the forced prediction: the on-demand path was exercised
 
 
 # ---------------------------------------------------------------------------------------------- edge cases
