@@ -33,7 +33,7 @@ LEGS = {
     "cfg3_at_16_dB_snr": dict(kind="dl", preset="cfg3", over=dict(seed=16, snr_db=16.0), nsf=20000, passes=4,
                               what="BASELINE configs[2] at 16 dB instead of 30 dB: most code blocks need many iterations, many fail"),
     "cfg3_16_dB_harq_mode_1": dict(kind="dl", preset="cfg3", over=dict(seed=17, snr_db=16.0, pct_harq=50), nsf=3200, passes=3, harq_mode=1,
-                                   what="configs[2] at 16 dB, half of the transport blocks sent again 8 subframes later, harq_mode = 1 (soft combining in the commit turn)"),
+                                   what="configs[2] at 16 dB, half of the transport blocks sent again 8 subframes later, harq_mode = 1 (soft combining: retransmissions combined and decoded in batches ahead of the commit walk)"),
     "cfg3_on_eva70_fading": dict(kind="dl", preset="cfg3", over=dict(seed=18, snr_db=24.0, chan_model=2, doppler_hz=70.0, timing_offset_samples=0.37), nsf=1600, passes=3,
                                  what="configs[2] through the EVA channel of TS 36.101 B.2 at 70 Hz Doppler (independent Rayleigh taps per antenna and port), 24 dB, 0.37 samples of timing offset"),
     "cfg4_ul_mode_64_rnti": dict(kind="ul", preset="cfg2", over=dict(seed=4, nof_rx=1, n_rnti=64, ul_min=2, ul_max=4, mcs_min=0, mcs_max=28, snr_db=28.0),
