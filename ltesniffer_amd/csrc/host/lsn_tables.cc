@@ -56,6 +56,7 @@ void Engine::freeDevice(bool keep_file_buffers)
   dev_allocs.clear();
   for (void* p : host_allocs) (void)hipHostFree(p);
   host_allocs.clear();
+  h_prune_ring = nullptr;   // (one of them)
   for (auto& ch : chunks) {
     for (auto& e : ch.ev_a)
       if (e) { (void)hipEventDestroy(e); e = nullptr; }

@@ -380,7 +380,7 @@ def test_full_load_properties_round_trip_and_pipeline_invariance():
 
 
 # ---------------------------------------------------------------------------------------------- BASELINE.json sizes
-def _run_stream(scn, nsf, seed, batch, update_meta_period=0, submit=False, **over):
+def _run_stream(scn, nsf, seed, batch, update_meta_period=0, submit=False, pruning=None, min_records_per_sf=5.0, **over):
     """record stream + learned state of a long stream at the scenario's full RNTI count (no per-subframe taps: the tap comparisons
     above cover the stages; here the sequential state - RNTI manager, MCS tables, p-a - runs for hundreds of subframes)"""
     import torch
@@ -388,7 +388,9 @@ def _run_stream(scn, nsf, seed, batch, update_meta_period=0, submit=False, **ove
     tti0, iq, _ = gen_subframes(sc, nsf)
     ow, _, orecs = run_oracle(sc, tti0, iq, update_meta_period=update_meta_period, taps=False)
     phy = la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=batch, pcapwriter=la.PcapWriter(None))
-    assert phy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"])
+    assert phy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"], cp=sc.get("cp", 0))
+    if pruning is not None:
+        phy.setCandidatePruning(pruning)
     if submit:  # the pipelined entry point bench.py times: resident capture, several submits, one wait
         d = torch.from_numpy(iq.view(np.float32)).to("cuda:0")
         stride = iq[0].size * 8
@@ -400,7 +402,7 @@ def _run_stream(scn, nsf, seed, batch, update_meta_period=0, submit=False, **ove
     else:
         phy.process_host(iq, tti0, update_meta_period)
     g, o = gpu_records(phy), oracle_records(orecs)
-    assert len(o) > 5 * nsf
+    assert len(o) > min_records_per_sf * nsf
     assert g == o, "record streams differ: gpu %d vs oracle %d" % (len(g), len(o))
     st, ost = phy.getStats(), ow.stats()
     for f in ("nof_locations", "nof_decoded_locations", "nof_cce", "nof_missed_cce", "nof_subframes", "nof_subframe_collisions_dw", "nof_subframe_collisions_up"):
@@ -408,6 +410,15 @@ def _run_stream(scn, nsf, seed, batch, update_meta_period=0, submit=False, **ove
     assert phy.nofTrackedRnti() == ow.nof_tracked()
     assert phy.nof_active_rnti() == ow.nof_active()
     phy.close()
+
+
+@pytest.mark.parametrize("scn,nsf,over", [("small", 160, {}), ("small", 160, dict(nof_prb=6, cfi=3, dl_min=1, dl_max=1, n_rnti=2)), ("small", 160, dict(nof_prb=15, cfi=2, dl_min=1, dl_max=2, n_rnti=3)),
+                                          ("cfg1", 120, {}), ("cfg2", 120, dict(nof_ports=4)), ("cfg3", 120, dict(cp=1, n_rnti=40)), ("cfg3", 160, dict(nof_prb=75, n_rnti=40))])
+def test_candidate_pruning_claims_everything_on_other_cells(scn, nsf, over):
+    """the decode-on-demand path of the candidate pruning (k_viterbi level launches, Engine::candidateMiss) under the prediction that claims everything
+    (PRUNE_TEST), on cells whose location tables differ from the 20 MHz / CFI 3 one: few CCEs (levels without a location, blocks without an 8-CCE parent),
+    one and four CRS ports, extended CP, 75 PRB - record stream, search statistics and learned state equal the oracle's"""
+    _run_stream(scn, nsf, seed=77, batch=24, update_meta_period=50, pruning=la.Phy.PRUNE_TEST, min_records_per_sf=0.5, **over)
 
 
 def test_baseline_cfg2_32_rnti_400_subframes():
