@@ -199,6 +199,8 @@ public:
   // what ue_sync's CFO tracking does ahead of the reference's workers (LTESniffer_Core.cc:312-316,344), here inside the OFDM kernel
   bool setCfoCorrection(int mode, float cfoHz = 0.0f, float alpha = 0.25f) { return lsn_phy_set_cfo_correction(h, mode, cfoHz, alpha) == LSN_SUCCESS; }
   float getCfoCorrection() { return lsn_phy_get_cfo_correction(h); }                                       // srsran_ue_sync_get_cfo
+  // which slots of the blind-decode table are computed ahead of the search (no counterpart in the reference, whose search decodes as it goes: DCISearch.cc:102-447): 0 all, 1 default, 2 test
+  bool setCandidatePruning(int mode) { return lsn_phy_set_candidate_pruning(h, mode) == LSN_SUCCESS; }
   // UL_MODE: what ULSchedule::set_config hands to the workers once SIB2 is known (ULSchedule.cc:140-158)
   bool setUlConfig(uint32_t cyclicShift, uint32_t groupAssignmentPUSCH, uint32_t puschHoppingOffset = 0)    // SubframeWorker.cc:258-277
   {
