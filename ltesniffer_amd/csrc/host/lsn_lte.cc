@@ -635,14 +635,23 @@ bool qpp_params(int K, uint32_t& f1, uint32_t& f2)
 
 // ---------------------------------------------------------------------------------------------- Histogram / RNTIManager
 Histogram::Histogram(uint32_t itemCount, uint32_t valueRange)
-    : rnti_histogram(valueRange, 0), rnti_history(itemCount, 0), rnti_history_current(0), rnti_history_end(itemCount), rnti_histogram_ready(false) {}
+    : rnti_histogram(valueRange, 0), rnti_history(itemCount, 0), rnti_history_current(0), rnti_history_end(itemCount), rnti_histogram_ready(false),
+      nz_pos(itemCount + 1, 0), nz_head(0), nz_tail(0) {}
+// The window is a ring that is written in order, so its non-zero entries leave it in the order they came: their positions wait in a queue (nz_pos), and
+// moving the window over a stretch of padding costs a look at the head of that queue instead of a look at every slot (round 6: the nine windows of a
+// subframe were a fifth of the sequential search's time - and that thread is what bounds one cell).
 void Histogram::add(uint16_t item, uint32_t nTimes)
 {
   while (nTimes-- > 0) {
-    if (rnti_histogram_ready) { rnti_histogram[rnti_history[rnti_history_current]]--; total[rnti_history[rnti_history_current]]--; }
+    if (rnti_histogram_ready) {
+      const uint16_t old = rnti_history[rnti_history_current];
+      rnti_histogram[old]--; total[old]--;
+      if (old) { if (++nz_head == nz_pos.size()) nz_head = 0; }   // (the oldest non-zero entry: the head of the queue)
+    }
     rnti_history[rnti_history_current] = item;
     rnti_histogram[item]++;
     total[item]++;
+    if (item) { nz_pos[nz_tail] = rnti_history_current; if (++nz_tail == nz_pos.size()) nz_tail = 0; }
     if (++rnti_history_current == rnti_history_end) { rnti_histogram_ready = true; rnti_history_current = 0; }
   }
 }
@@ -650,30 +659,21 @@ void Histogram::add(uint16_t item, uint32_t nTimes)
 void Histogram::addZeros(uint32_t nTimes)
 {
   uint32_t gained = 0;  // net increase of the count of item 0
-  // fast path: the window is full and the next nTimes slots hold 0 already (the usual case: most of the history is padding)
-  while (rnti_histogram_ready && nTimes >= 16 && rnti_history_current + 16 <= rnti_history_end) {
-    uint64_t w[4];
-    std::memcpy(w, &rnti_history[rnti_history_current], 32);
-    if ((w[0] | w[1] | w[2] | w[3]) != 0) break;
-    rnti_history_current += 16; nTimes -= 16;
-    if (rnti_history_current == rnti_history_end) rnti_history_current = 0;
-  }
-  while (rnti_histogram_ready && nTimes >= 4 && rnti_history_current + 4 <= rnti_history_end) {
-    uint64_t w;
-    std::memcpy(&w, &rnti_history[rnti_history_current], 8);
-    if (w != 0) break;
-    rnti_history_current += 4; nTimes -= 4;
-    if (rnti_history_current == rnti_history_end) rnti_history_current = 0;
-  }
-  while (nTimes-- > 0) {
-    if (rnti_histogram_ready) {
-      const uint16_t old = rnti_history[rnti_history_current];
-      if (old) { rnti_histogram[old]--; total[old]--; rnti_history[rnti_history_current] = 0; gained++; }
-    } else {
-      rnti_history[rnti_history_current] = 0;
-      gained++;
-    }
+  while (nTimes > 0 && !rnti_histogram_ready) {   // the first turn of the window: nothing leaves it
+    rnti_history[rnti_history_current] = 0;
+    gained++; nTimes--;
     if (++rnti_history_current == rnti_history_end) { rnti_histogram_ready = true; rnti_history_current = 0; }
+  }
+  while (nTimes > 0) {
+    const uint32_t n = std::min(nTimes, rnti_history_end - rnti_history_current), lim = rnti_history_current + n;   // (no wrap inside this stretch)
+    while (nz_head != nz_tail && nz_pos[nz_head] >= rnti_history_current && nz_pos[nz_head] < lim) {   // the non-zero entries of the stretch leave the window
+      const uint32_t p = nz_pos[nz_head];
+      const uint16_t old = rnti_history[p];
+      rnti_histogram[old]--; total[old]--; rnti_history[p] = 0; gained++;
+      if (++nz_head == nz_pos.size()) nz_head = 0;
+    }
+    rnti_history_current = lim == rnti_history_end ? 0 : lim;
+    nTimes -= n;
   }
   rnti_histogram[0] += gained;
   total[0] += gained;
@@ -686,13 +686,23 @@ RNTIManager::RNTIManager(uint32_t nf, uint32_t maxCand, uint32_t thr)
 {
   totals.assign(65536, 0);
   active_bits.assign(2048, 0u);
+  rar_bits.assign(2048, 0u);
   for (auto& h : histograms) h.setTotals(totals.data());
 }
 void RNTIManager::addCandidate(uint16_t rnti, uint32_t f) { histograms[f].add(rnti); remainingCandidates[f]--; }
 bool RNTIManager::isEvergreen(uint16_t rnti, uint32_t f) const { for (auto& i : evergreen[f]) if (i.matches(rnti)) return true; return false; }
 bool RNTIManager::isForbidden(uint16_t rnti, uint32_t f) const { for (auto& i : forbidden[f]) if (i.matches(rnti)) return true; return false; }
-void RNTIManager::activateRNTI(uint16_t rnti, ActivationReason r) { if (!active[rnti]) { active[rnti] = 1; active_bits[rnti >> 5] |= 1u << (rnti & 31u); reason[rnti] = (uint8_t)r; nactive++; } }
-void RNTIManager::deactivateRNTI(uint16_t rnti) { if (active[rnti]) { active[rnti] = 0; active_bits[rnti >> 5] &= ~(1u << (rnti & 31u)); assocFormatIdx[rnti] = 0; nactive--; } }
+void RNTIManager::activateRNTI(uint16_t rnti, ActivationReason r)
+{
+  if (!active[rnti]) {
+    active[rnti] = 1; active_bits[rnti >> 5] |= 1u << (rnti & 31u); reason[rnti] = (uint8_t)r; nactive++;
+    if (r == RM_ACT_RAR) rar_bits[rnti >> 5] |= 1u << (rnti & 31u);
+  }
+}
+void RNTIManager::deactivateRNTI(uint16_t rnti)
+{
+  if (active[rnti]) { active[rnti] = 0; active_bits[rnti >> 5] &= ~(1u << (rnti & 31u)); rar_bits[rnti >> 5] &= ~(1u << (rnti & 31u)); assocFormatIdx[rnti] = 0; nactive--; }
+}
 uint32_t RNTIManager::getLikelyDlFormatIdx(uint16_t rnti) const
 {
   uint32_t best = 0, mx = 0;
@@ -703,7 +713,7 @@ bool RNTIManager::validate(uint16_t rnti, uint32_t f)
 {
   if (isEvergreen(rnti, f)) return true;
   if (isForbidden(rnti, f)) return false;
-  if (active[rnti]) {
+  if ((active_bits[rnti >> 5] >> (rnti & 31u)) & 1u) {   // (active[rnti], from the 8 KB of bits instead of the 64 KB of bytes: the search asks for random RNTIs)
     if (timestamp - lastSeen[rnti] < lifetime) return true;
     deactivateRNTI(rnti);
   }

@@ -113,6 +113,8 @@ private:
   std::vector<uint16_t> rnti_history;
   uint32_t rnti_history_current, rnti_history_end;
   bool rnti_histogram_ready;
+  std::vector<uint32_t> nz_pos;   // positions of the window's non-zero entries, oldest first (a ring of its own)
+  size_t nz_head, nz_tail;
   uint32_t* total = nullptr;
 };
 struct Interval { uint16_t start, end; bool matches(uint16_t v) const { return v >= start && v <= end; } };
@@ -131,6 +133,7 @@ public:
   void stepTime();
   uint32_t getFrequency(uint16_t rnti, uint32_t formatIdx) const { return histograms[formatIdx].getFrequency(rnti); }
   ActivationReason getActivationReason(uint16_t rnti) const { return active[rnti] ? (ActivationReason)reason[rnti] : RM_ACT_UNSET; }
+  bool activatedByRar(uint16_t rnti) const { return (rar_bits[rnti >> 5] >> (rnti & 31u)) & 1u; }   // getActivationReason(rnti) == RM_ACT_RAR, one bit test (the search asks it of every format 0 candidate)
   uint32_t nofActive() const { return nactive; }
   void setHistogramThreshold(uint32_t t) { threshold = t; }  // RNTIManager.cc:442-444
   // what the candidate pruning of the blind decoder wants to know (k_viterbi): the active RNTIs as bits, the static intervals of a format
@@ -156,6 +159,7 @@ private:
   std::vector<std::vector<Interval>> evergreen, forbidden;
   std::vector<uint8_t> active, reason;
   std::vector<uint32_t> active_bits;   // active[], one bit per RNTI (2048 words)
+  std::vector<uint32_t> rar_bits;      // active[] && reason[] == RM_ACT_RAR
   std::vector<uint32_t> lastSeen, assocFormatIdx, totals;
   uint32_t nactive, timestamp, lifetime, threshold, maxCandidatesPerStepPerFormat;
   std::vector<int32_t> remainingCandidates;

@@ -116,6 +116,10 @@ void FalconSearch::setCell(const Cell& c, const uint32_t n[3])
     for (uint32_t m = 0; m < LSN_MAX_NUM_OF_CCE; m++)  // (a later location of the same level overwrites an earlier one in the map, like the reference's pointer map)
       for (int a = 0; a < 4; a++)
         if (tp.map[m][a] >= 0) tp.cover[m].set((uint32_t)tp.map[m][a]);
+    for (auto& cm : tp.ccemask) cm[0] = cm[1] = 0;
+    for (uint32_t m = 0; m < LSN_MAX_NUM_OF_CCE; m++)
+      for (uint32_t q = 0; q < LSN_MAX_LOC; q++)
+        if (tp.cover[m].test(q)) tp.ccemask[q][m >> 6] |= 1ull << (m & 63);
   }
 }
 
@@ -266,7 +270,7 @@ int FalconSearch::inspect_dci_location_recursively(SubframeCtx& c, const int16_t
         d.rnti = 0; d.search_space_match_result = 0; d.msg.bits = 0; d.msg.nof_bits = 0; d.msg.format = FORMAT0;
       }
     }
-    if (cand[fi].msg.format == FORMAT0 && rnti_manager->getActivationReason(cand[fi].rnti) == RM_ACT_RAR) {  // :139-158
+    if (cand[fi].msg.format == FORMAT0 && rnti_manager->activatedByRar(cand[fi].rnti)) {  // :139-158 (getActivationReason(rnti) == RM_ACT_RAR)
       bool add = true;
       for (auto& t : temp_dci0)
         if (t.format == cand[fi].msg.format && t.rnti == cand[fi].rnti && t.ncce == ncce) add = false;
@@ -392,9 +396,13 @@ void FalconSearch::recursive_blind_dci_search(SubframeCtx& c)
     f_checked.clear();
     pass(meta_formats->getSecondaryMetaFormats(), meta_formats->getNofSecondaryMetaFormats());
   }
-  uint32_t missed = 0;  // falcon_pdcch.c:561-593
-  for (uint32_t cc = 0; cc < lim; cc++)
-    missed += (uint32_t)(!((low[cc >> 6] >> (cc & 63)) & 1ull) & !f_used.intersects(tp.cover[cc]));
+  // falcon_pdcch.c:561-593: CCEs with power that no used location covers.  (f_used.intersects(cover[cc]) for every CCE, turned round: the CCEs of the used
+  // locations - a dozen - are collected once)
+  uint64_t covered[2] = {0, 0};
+  for (int k = 0; k < LOCW; k++)
+    for (uint64_t m = f_used.w[k]; m; m &= m - 1) { const uint32_t q = 64u * (uint32_t)k + (uint32_t)__builtin_ctzll(m); covered[0] |= tp.ccemask[q][0]; covered[1] |= tp.ccemask[q][1]; }
+  const uint64_t in0 = lim >= 64 ? ~0ull : ((1ull << lim) - 1ull), in1 = lim > 64 ? ((1ull << (lim - 64)) - 1ull) : 0ull;
+  const uint32_t missed = (uint32_t)__builtin_popcountll(~low[0] & ~covered[0] & in0) + (uint32_t)__builtin_popcountll(~low[1] & ~covered[1] & in1);
   stats.nof_missed_cce += missed;
   rnti_manager->stepTime();
 }

@@ -110,6 +110,7 @@ private:
     FalconLocation locations[LSN_MAX_LOC];
     int16_t map[LSN_MAX_NUM_OF_CCE][4];   // CCE -> the location of every aggregation level that covers it (-1: none)
     LocSet cover[LSN_MAX_NUM_OF_CCE];     // the same as a set
+    uint64_t ccemask[LSN_MAX_LOC][2];     // ... and turned round: the CCEs whose cover holds the location (bit cc)
     uint32_t nloc = 0;
   };
   struct TempDci0 { uint16_t rnti; uint32_t L, ncce; DciFormat format; DciCandidate cand; };
