@@ -333,7 +333,7 @@ void Engine::launchStageA(Chunk& ch, const void* d_iq)
       const uint32_t pub = prune_pub.load(std::memory_order_acquire);
       lsn_launch_upload(ch.d_prune_snap, h_prune_ring + (size_t)((pub + PRUNE_RING - 1) % PRUNE_RING) * LSN_PRUNE_SNAP_WORDS, LSN_PRUNE_SNAP_WORDS * sizeof(uint32_t), st);
     }
-    lsn_launch_viterbi(cd, ch.d_llr, ch.d_ccepow, ch.d_cfi, ch.d_sfidx, ch.d_cand, nsf, pc, ch.d_prune_snap, ch.d_acc, st);
+    lsn_launch_viterbi(cd, ch.d_llr, ch.d_ccepow, ch.d_cfi, ch.d_sfidx, ch.d_cand, ch.d_cand4, nsf, pc, ch.d_prune_snap, ch.d_acc, st);
   });
   timed([&] { lsn_launch_rb_power(cd, ch.d_rbp_part, ch.d_rbp, nsf, st); });
   if (cfg.sniffer_mode == 1) lsn_launch_ul_fft(cd, iq, cd.iq_nant, 1, ch.d_ul_grid, nsf, st);  // srsran_enb_ul_fft on antenna 1, UL_Sniffer_PUSCH.cc:391-392
@@ -341,6 +341,7 @@ void Engine::launchStageA(Chunk& ch, const void* d_iq)
   {
     LsnCopySegs sg;
     sg.add(ch.h_cand, ch.d_cand, (size_t)nsf * LSN_MAX_LOC * LSN_MAX_SIZES * sizeof(LsnCand));
+    sg.add(ch.h_cand4, ch.d_cand4, (size_t)nsf * LSN_MAX_LOC * LSN_MAX_SIZES * sizeof(uint32_t));
     sg.add(ch.h_ccepow, ch.d_ccepow, (size_t)nsf * LSN_CCE_STRIDE * sizeof(float));
     sg.add(ch.h_chest, ch.d_chest, (size_t)nsf * sizeof(LsnChest));
     sg.add(ch.h_cfi, ch.d_cfi, (size_t)nsf * sizeof(uint32_t));
@@ -378,14 +379,14 @@ void Engine::publishPruneSnapshot()
   slot[2048] = search->metaFormats().primaryMask();
   prune_pub.store(pub + 1, std::memory_order_release);
 }
-const LsnCand& Engine::candMissTramp(void* ctx, uint32_t li, uint32_t szi)
+void Engine::candMissTramp(void* ctx, uint32_t li, uint32_t szi)
 {
   CandMissCtx* c = (CandMissCtx*)ctx;
-  return c->e->candidateMiss(*c->ch, c->sf, li, szi);
+  c->e->candidateMiss(*c->ch, c->sf, li, szi);
 }
 // The search came to a slot the blind decoder had left out (the prediction claimed an acceptance that the sequential state did not bear out): decoded now, on the
 // search runner's stream - a round trip inside the sequential search, which is why the prediction only claims what is all but certain
-const LsnCand& Engine::candidateMiss(Chunk& ch, uint32_t sf, uint32_t li, uint32_t szi)
+void Engine::candidateMiss(Chunk& ch, uint32_t sf, uint32_t li, uint32_t szi)
 {
   hipStream_t st = runner_s.stream;
   const size_t idx = ((size_t)sf * LSN_MAX_LOC + li) * LSN_MAX_SIZES + szi;
@@ -396,7 +397,7 @@ const LsnCand& Engine::candidateMiss(Chunk& ch, uint32_t sf, uint32_t li, uint32
   for (int l = 3; l >= 0; l--) { const uint32_t cnt = lim >> l; if (r < cnt) { L = l; break; } r -= cnt; }
   if (L < 0) throw std::runtime_error("candidate miss outside the location table");
   const uint32_t block = r >> (3 - L);
-  lsn_launch_viterbi_block(cd, ch.d_llr, ch.d_ccepow, ch.d_cfi, ch.d_sfidx, ch.d_cand, sf, block, pruneConfig(), ch.d_prune_snap, ch.d_acc, st);
+  lsn_launch_viterbi_block(cd, ch.d_llr, ch.d_ccepow, ch.d_cfi, ch.d_sfidx, ch.d_cand, ch.d_cand4, sf, block, pruneConfig(), ch.d_prune_snap, ch.d_acc, st);
   uint32_t off = 0;
   for (int l = 3; l >= 0; l--) {
     const uint32_t cnt = lim >> l, first = block << (3 - l);
@@ -404,13 +405,13 @@ const LsnCand& Engine::candidateMiss(Chunk& ch, uint32_t sf, uint32_t li, uint32
       const uint32_t n = std::min<uint32_t>(1u << (3 - l), cnt - first);
       const size_t at = ((size_t)sf * LSN_MAX_LOC + off + first) * LSN_MAX_SIZES;
       HIP_CHECK(hipMemcpyAsync(ch.h_cand + at, ch.d_cand + at, (size_t)n * LSN_MAX_SIZES * sizeof(LsnCand), hipMemcpyDeviceToHost, st));
+      HIP_CHECK(hipMemcpyAsync(ch.h_cand4 + at, ch.d_cand4 + at, (size_t)n * LSN_MAX_SIZES * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     }
     off += cnt;
   }
   HIP_CHECK(hipStreamSynchronize(st));
   perf_search.nof_candidate_misses++;
-  if (ch.h_cand[idx].flags & LSN_CAND_NOT_COMPUTED) throw std::runtime_error("candidate decode on demand left the slot marked");
-  return ch.h_cand[idx];
+  if ((ch.h_cand[idx].flags & LSN_CAND_NOT_COMPUTED) || (ch.h_cand4[idx] & (LSN_CAND_NOT_COMPUTED << 16))) throw std::runtime_error("candidate decode on demand left the slot marked");
 }
 
 void Engine::finishStageA(Chunk& ch)
@@ -489,11 +490,12 @@ void Engine::speculateRar(Chunk& ch)
 
 // ------------------------------------------------------------------------------------------------ stage B (caller thread)
 // The candidate tables were just written by DMA, i.e. none of their lines is in a CPU cache: pull the next subframe's
-// table (157 locations x 128 B) towards the core while the current subframe is searched.
-static inline void prefetch_cand(const LsnCand* cand, const float* ccepow)
+// one-word view (157 locations x 32 B; round 6 - the 16-byte entries, 20 KB per subframe, cost the search thread a third of its time) towards the core while the
+// current subframe is searched.
+static inline void prefetch_cand(const uint32_t* cand4, const float* ccepow)
 {
-  const char* p = (const char*)cand;
-  for (size_t off = 0; off < (size_t)LSN_MAX_LOC * LSN_MAX_SIZES * sizeof(LsnCand); off += 64) __builtin_prefetch(p + off, 0, 3);
+  const char* p = (const char*)cand4;   // (the one-word view: 5 KB per subframe; the payload lines are asked for one by one when a candidate shows up)
+  for (size_t off = 0; off < (size_t)LSN_MAX_LOC * LSN_MAX_SIZES * sizeof(uint32_t); off += 64) __builtin_prefetch(p + off, 0, 3);
   const char* q = (const char*)ccepow;
   for (size_t off = 0; off < LSN_CCE_STRIDE * sizeof(float); off += 64) __builtin_prefetch(q + off, 0, 3);
 }
@@ -501,18 +503,18 @@ static inline void prefetch_cand(const LsnCand* cand, const float* ccepow)
 void Engine::searchChunk(Chunk& ch, uint32_t update_meta_period)
 {
   ch.gpos0 = (uint32_t)sf_cnt;
-  prefetch_cand(ch.h_cand, ch.h_ccepow);
-  if (ch.nsf > 1) prefetch_cand(ch.h_cand + (size_t)LSN_MAX_LOC * LSN_MAX_SIZES, ch.h_ccepow + LSN_CCE_STRIDE);
+  prefetch_cand(ch.h_cand4, ch.h_ccepow);
+  if (ch.nsf > 1) prefetch_cand(ch.h_cand4 + (size_t)LSN_MAX_LOC * LSN_MAX_SIZES, ch.h_ccepow + LSN_CCE_STRIDE);
   for (uint32_t sf = 0; sf < ch.nsf; sf++) {
     SubframeCtx& c = ch.ctx[sf];
-    if (sf + 2 < ch.nsf) prefetch_cand(ch.h_cand + (size_t)(sf + 2) * LSN_MAX_LOC * LSN_MAX_SIZES, ch.h_ccepow + (size_t)(sf + 2) * LSN_CCE_STRIDE);
+    if (sf + 2 < ch.nsf) prefetch_cand(ch.h_cand4 + (size_t)(sf + 2) * LSN_MAX_LOC * LSN_MAX_SIZES, ch.h_ccepow + (size_t)(sf + 2) * LSN_CCE_STRIDE);
     const bool upd = (update_meta_period && (sf_cnt % update_meta_period) == 0) || force_meta_next || (sf == 0 && ch.force_meta);  // LTESniffer_Core.cc:434
     force_meta_next = false;
     sf_cnt++;
     const double ts0 = now_ms();
     cand_miss_ctx = {this, &ch, sf};
     search->setCandMiss(&Engine::candMissTramp, &cand_miss_ctx);
-    search->search(c, ch.h_cand + (size_t)sf * LSN_MAX_LOC * LSN_MAX_SIZES, ch.h_ccepow + (size_t)sf * LSN_CCE_STRIDE, upd);
+    search->search(c, ch.h_cand + (size_t)sf * LSN_MAX_LOC * LSN_MAX_SIZES, ch.h_ccepow + (size_t)sf * LSN_CCE_STRIDE, upd, ch.h_cand4 + (size_t)sf * LSN_MAX_LOC * LSN_MAX_SIZES);
     { const double dt = now_ms() - ts0; perf_search.ms_search_core += dt; search_time_us += dt * 1e3; }
     est_cfo = c.cfo_hz;  // SubframeWorker.cc:203
     if (!c.searched) continue;

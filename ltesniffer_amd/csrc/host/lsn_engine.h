@@ -69,6 +69,7 @@ struct Chunk {
   uint32_t *d_cfi = nullptr, *d_sfidx = nullptr;
   uint32_t* d_prune_snap = nullptr; uint8_t* d_acc = nullptr;   // candidate pruning (k_viterbi): the RNTI manager's snapshot this chunk was decoded with; what each decoded slot lets the search do
   LsnCand* d_cand = nullptr;
+  uint32_t *d_cand4 = nullptr, *h_cand4 = nullptr;   // the search's one-word view of the candidate table (LSN_CAND_HOT) and its host mirror
   LsnCand* h_cand = nullptr; float* h_ccepow = nullptr; LsnChest* h_chest = nullptr; uint32_t* h_cfi = nullptr; float* h_rbp = nullptr;
   uint32_t* h_sfidx = nullptr;
   uint32_t *d_dphi = nullptr, *h_dphi = nullptr;  // per-subframe NCO increment of k_ofdm (CFO correction on), device + pinned mirror
@@ -429,8 +430,8 @@ private:
   LsnPruneCfg pruneConfig();
   void publishPruneSnapshot();
   struct CandMissCtx { Engine* e; Chunk* ch; uint32_t sf; } cand_miss_ctx{nullptr, nullptr, 0};
-  static const LsnCand& candMissTramp(void* ctx, uint32_t li, uint32_t szi);
-  const LsnCand& candidateMiss(Chunk& ch, uint32_t sf, uint32_t li, uint32_t szi);
+  static void candMissTramp(void* ctx, uint32_t li, uint32_t szi);
+  void candidateMiss(Chunk& ch, uint32_t sf, uint32_t li, uint32_t szi);
   void searchLoop();
   std::deque<Chunk*> search_queue, spec_queue;   // front -> spec (speculative RA-RNTI decodes) -> search
   std::thread spec_thread;

@@ -129,7 +129,7 @@ void FalconSearch::setCell(const Cell& c, const uint32_t n[3])
 // "exists" for the reference is resolved at commit time, when the MCS-tracking state of the subframe is known.
 void FalconSearch::addCandidate(SubframeCtx& c, const DciCandidate& cand, uint32_t L, uint32_t ncce, uint32_t histval)
 {
-  c.raw.push_back(AcceptedDci{cand.rnti, (uint8_t)cand.msg.format, (uint8_t)L, (uint16_t)ncce, (uint16_t)cand.msg.nof_bits, histval, cand.msg.bits});
+  c.raw.push_back(AcceptedDci{cand.rnti, (uint8_t)cand.msg.format, (uint8_t)L, (uint16_t)ncce, (uint16_t)cand.msg.nof_bits, histval, (unsigned long long)cand.slot});   // (bits: the slot for now - FalconSearch::search puts the payload in)
 }
 
 void FalconSearch::materialize(SubframeCtx& c)
@@ -250,24 +250,28 @@ int FalconSearch::inspect_dci_location_recursively(SubframeCtx& c, const int16_t
   // only the first nof_formats entries exist (children index their parent's candidates with the same format list)
   alignas(DciCandidate) unsigned char cand_raw[sizeof(DciCandidate) * NOF_FORMATS];
   DciCandidate* cand = reinterpret_cast<DciCandidate*>(cand_raw);
-  const LsnCand* row = cur_cand + (size_t)li * LSN_MAX_SIZES;
   stats.nof_decoded_locations += nof_formats;
   nof_lookups += nof_formats;
 
   for (uint32_t fi = 0; fi < nof_formats; fi++) {
     {  // srsran_pdcch_decode_msg_limit_avg_llr_power (falcon_pdcch.c:110-170) as a lookup in the exhaustive candidate table (decodeCandidate)
+      // (the one-word view of the slot, LSN_CAND_HOT: everything the decisions below read; the payload bits stay in the table until a candidate is accepted)
       const DciFormat format = metas[fi]->format;
-      const LsnCand& t0 = row[size_index_of_format[format]];
-      const LsnCand& t = (t0.flags & LSN_CAND_NOT_COMPUTED) && cand_miss ? cand_miss(cand_miss_ctx, (uint32_t)li, (uint32_t)size_index_of_format[format]) : t0;
+      const uint32_t slot = (uint32_t)li * LSN_MAX_SIZES + (uint32_t)size_index_of_format[format];
+      auto hot = [&]() -> uint32_t { return cur_cand4 ? cur_cand4[slot] : LSN_CAND_HOT(cur_cand[slot].bits, cur_cand[slot].rnti, cur_cand[slot].flags); };
+      uint32_t t = hot();
+      if ((t & (LSN_CAND_NOT_COMPUTED << 16)) && cand_miss) { cand_miss(cand_miss_ctx, (uint32_t)li, (uint32_t)size_index_of_format[format]); t = hot(); }
       DciCandidate& d = cand[fi];
-      if (t.flags & 1u) {
-        d.rnti = (uint16_t)t.rnti;
-        d.search_space_match_result = (t.flags >> 1) & 3u;
-        d.msg.bits = t.bits;
+      d.slot = (uint16_t)slot;
+      d.msg.bits = 0;
+      if (t & (1u << 16)) {
+        d.rnti = (uint16_t)t;
+        d.search_space_match_result = (t >> 17) & 3u;
         d.msg.nof_bits = size_of_format[format];
-        d.msg.format = (format == FORMAT0 || format == FORMAT1A) ? ((t.bits >> 63) == 0 ? FORMAT0 : FORMAT1A) : format;  // falcon_pdcch.c:147-148
+        d.msg.format = (format == FORMAT0 || format == FORMAT1A) ? (((t >> 19) & 1u) == 0 ? FORMAT0 : FORMAT1A) : format;  // falcon_pdcch.c:147-148
+        if (d.search_space_match_result) __builtin_prefetch(&cur_cand[slot], 0, 1);   // it may be accepted: its payload is read when the subframe's search ends
       } else {
-        d.rnti = 0; d.search_space_match_result = 0; d.msg.bits = 0; d.msg.nof_bits = 0; d.msg.format = FORMAT0;
+        d.rnti = 0; d.search_space_match_result = 0; d.msg.nof_bits = 0; d.msg.format = FORMAT0;
       }
     }
     if (cand[fi].msg.format == FORMAT0 && rnti_manager->activatedByRar(cand[fi].rnti)) {  // :139-158 (getActivationReason(rnti) == RM_ACT_RAR)
@@ -407,13 +411,15 @@ void FalconSearch::recursive_blind_dci_search(SubframeCtx& c)
   rnti_manager->stepTime();
 }
 
-void FalconSearch::search(SubframeCtx& c, const LsnCand* cand, const float* ccepow, bool update_meta)
+void FalconSearch::search(SubframeCtx& c, const LsnCand* cand, const float* ccepow, bool update_meta, const uint32_t* cand4)
 {
-  cur_cand = cand; cur_ccepow = ccepow;
+  cur_cand = cand; cur_cand4 = cand4; cur_ccepow = ccepow;
   temp_dci0.clear();
   if (update_meta) meta_formats->update_formats();  // SubframeWorker.cc:148-151
   c.searched = c.snr_db > 6.0f;                     // DCISearch.cc:568-574
+  const size_t first = c.raw.size();
   if (c.searched) recursive_blind_dci_search(c);
+  for (size_t i = first; i < c.raw.size(); i++) c.raw[i].bits = cur_cand[c.raw[i].bits].bits;   // the payloads of the accepted DCIs (their lines were asked for when the candidates showed up)
   stats.nof_subframes++;
 }
 

@@ -20,7 +20,7 @@ struct DciMsg {
   DciFormat format = FORMAT0;
   void unpack(uint8_t* payload) const { for (uint32_t i = 0; i < nof_bits; i++) payload[i] = (uint8_t)((bits >> (63 - i)) & 1ull); }
 };
-struct DciCandidate { uint16_t rnti = 0; DciMsg msg; uint32_t search_space_match_result = 0; };
+struct DciCandidate { uint16_t rnti = 0; uint16_t slot = 0; DciMsg msg; uint32_t search_space_match_result = 0; };   // slot: location * LSN_MAX_SIZES + size index (where the payload bits are; msg.bits is filled in for accepted candidates only)
 
 struct DlEntry {  // DL_Sniffer_DCI_DL (Sniffer_dependency.h:90)
   uint16_t rnti = 0; DciFormat format = FORMAT1; uint32_t nof_bits = 0, L = 0, ncce = 0, histval = 0;
@@ -70,7 +70,8 @@ public:
   void setCell(const Cell& cell, const uint32_t nof_cce_per_cfi[3]);
   void setPuschHopOffset(uint32_t n_rb_ho) { cell.pusch_hop_offset = n_rb_ho; }  // SIB2 pusch-HoppingOffset, once known
   // cand: [LSN_MAX_LOC][LSN_MAX_SIZES] of this subframe, ccepow: [LSN_CCE_STRIDE]; c.cfi / c.snr_db / c.sf_idx must be set
-  void search(SubframeCtx& c, const LsnCand* cand, const float* ccepow, bool update_meta);
+  // cand4: the one-word view of the same slots (LSN_CAND_HOT; what the GPU writes next to the table), nullptr: derived from cand on the fly
+  void search(SubframeCtx& c, const LsnCand* cand, const float* ccepow, bool update_meta, const uint32_t* cand4 = nullptr);
   RNTIManager& rntiManager() { return *rnti_manager; }
   DCIMetaFormats& metaFormats() { return *meta_formats; }
   BlindStats getStats() const { BlindStats b = stats; b.nof_subframe_collisions_dw = coll_dw.load(); b.nof_subframe_collisions_up = coll_up.load(); return b; }
@@ -79,7 +80,7 @@ public:
   uint32_t nofSizes() const { return nsizes; }
   const uint32_t* sizes() const { return size_list; }
   void setupDefaultIntervals();  // LTESniffer_Core.cc:398-417
-  void setCandMiss(const LsnCand& (*fn)(void*, uint32_t, uint32_t), void* ctx) { cand_miss = fn; cand_miss_ctx = ctx; }   // who decodes a slot the blind decoder left out
+  void setCandMiss(void (*fn)(void*, uint32_t, uint32_t), void* ctx) { cand_miss = fn; cand_miss_ctx = ctx; }   // who decodes a slot the blind decoder left out
   void setShortcutDiscovery(bool enable) { shortcut_discovery = enable; }  // PhyCommon::setShortcutDiscovery, PhyCommon.cc:69-71
   bool getShortcutDiscovery() const { return shortcut_discovery; }
   // the DL entry addCandidate() would build for this candidate (no state is touched): used to decode RA-RNTI grants ahead
@@ -134,7 +135,8 @@ private:
   LocTemplate loc_template[3];
   const LsnCand* cur_cand = nullptr;
   // a slot the blind decoder left out (LSN_CAND_NOT_COMPUTED): the owner of the table decodes it now and returns it (Engine::candidateMiss)
-  const LsnCand& (*cand_miss)(void* ctx, uint32_t li, uint32_t size_index) = nullptr;
+  void (*cand_miss)(void* ctx, uint32_t li, uint32_t size_index) = nullptr;   // (fills the slot in both views)
+  const uint32_t* cur_cand4 = nullptr;
   void* cand_miss_ctx = nullptr;
   const float* cur_ccepow = nullptr;
   BlindStats stats;

@@ -179,9 +179,11 @@ void Engine::allocChunk(Chunk& ch)
   ch.d_llr = dalloc<float>(dev_allocs, B * LSN_LLR_STRIDE);
   ch.d_ccepow = dalloc<float>(dev_allocs, B * LSN_CCE_STRIDE);
   ch.d_cand = dalloc<LsnCand>(dev_allocs, B * LSN_MAX_LOC * LSN_MAX_SIZES);
+  ch.d_cand4 = dalloc<uint32_t>(dev_allocs, B * LSN_MAX_LOC * LSN_MAX_SIZES);
   ch.d_rbp = dalloc<float>(dev_allocs, B * 128);
   ch.d_rbp_part = dalloc<float>(dev_allocs, B * 14 * 128);   // per-symbol terms of the PRB power, written by k_ofdm (zeroed once: rows 12, 13 of an extended-CP cell stay zero)
   ch.h_cand = halloc<LsnCand>(host_allocs, B * LSN_MAX_LOC * LSN_MAX_SIZES);
+  ch.h_cand4 = halloc<uint32_t>(host_allocs, B * LSN_MAX_LOC * LSN_MAX_SIZES);
   ch.h_ccepow = halloc<float>(host_allocs, B * LSN_CCE_STRIDE);
   ch.h_chest = halloc<LsnChest>(host_allocs, B);
   ch.h_cfi = halloc<uint32_t>(host_allocs, B);

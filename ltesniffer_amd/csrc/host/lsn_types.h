@@ -17,6 +17,10 @@ struct LsnCand {
                             // a search that comes here all the same has it decoded on demand
 };
 #define LSN_CAND_NOT_COMPUTED 0x80u
+// The sequential search decides on RNTI, search-space verdict and the first payload bit (format 0 or 1A); the payload itself is only wanted of the dozen DCIs
+// it accepts.  Its view of a slot is therefore one word - 5 KB per subframe to pull into the search thread's cache instead of 20 (that thread bounds a cell, and a
+// third of its time was waiting for the table): bits 0-15 the CRC remainder, 16 decoded, 17-18 the verdict, 19 payload bit 0, 23 LSN_CAND_NOT_COMPUTED
+#define LSN_CAND_HOT(bits, rnti, flags) (((uint32_t)(rnti) & 0xFFFFu) | (((uint32_t)(flags) & 0x87u) << 16) | ((uint32_t)((unsigned long long)(bits) >> 63) << 19))
 // Candidate pruning (k_viterbi, stage_a.hip): the stateless part of the prediction - the RNTI manager's format table as the kernel needs it.  Format f =
 // index in falcon_ue_all_formats = the RNTI manager's format index = DciFormat.  Intervals: first | last << 16, at most four per format and kind (more: pruning off).
 // The stateful part (active RNTIs as 2048 words of bits, then the primary-format mask) travels per chunk: LSN_PRUNE_SNAP_WORDS words.

@@ -161,9 +161,9 @@ void lsn_launch_chest_fin(const LsnCellDev& c, const float* raw, LsnChest* out, 
 void lsn_launch_pcfich(const LsnCellDev& c, const cf32* grid, const cf32* ce, const LsnChest* ch, const uint32_t* sf_idx, uint32_t* cfi, float* corr, uint32_t nsf, hipStream_t s);
 void lsn_launch_pdcch_llr(const LsnCellDev& c, const cf32* grid, const cf32* ce, const LsnChest* ch, const uint32_t* sf_idx, const uint32_t* cfi, float* llr, uint32_t nsf, hipStream_t s);
 void lsn_launch_cce_power(const LsnCellDev& c, const float* llr, const uint32_t* cfi, float* pw, uint32_t nsf, hipStream_t s);
-void lsn_launch_viterbi(const LsnCellDev& c, const float* llr, const float* pw, const uint32_t* cfi, const uint32_t* sf_idx, LsnCand* cand, uint32_t nsf,
+void lsn_launch_viterbi(const LsnCellDev& c, const float* llr, const float* pw, const uint32_t* cfi, const uint32_t* sf_idx, LsnCand* cand, uint32_t* cand4, uint32_t nsf,
                         const LsnPruneCfg& pc, const uint32_t* snap, uint8_t* acc, hipStream_t s);
-void lsn_launch_viterbi_block(const LsnCellDev& c, const float* llr, const float* pw, const uint32_t* cfi, const uint32_t* sf_idx, LsnCand* cand, uint32_t sf, uint32_t block,
+void lsn_launch_viterbi_block(const LsnCellDev& c, const float* llr, const float* pw, const uint32_t* cfi, const uint32_t* sf_idx, LsnCand* cand, uint32_t* cand4, uint32_t sf, uint32_t block,
                               const LsnPruneCfg& pc, const uint32_t* snap, uint8_t* acc, hipStream_t s);
 void lsn_launch_rb_power(const LsnCellDev& c, const float* rbp_part, float* rbp, uint32_t nsf, hipStream_t s);
 void lsn_launch_ul_fft(const LsnCellDev& c, const cf32* iq, uint32_t nant, uint32_t ant, cf32* grid, uint32_t nsf, hipStream_t s);

@@ -686,7 +686,7 @@ __device__ __forceinline__ uint32_t lsn_cand_claim(const LsnPruneCfg& pc, const 
 // (blockIdx.x: 0 = the block's level-3 location, 1-2 level 2, 3-6 level 1, 7-14 level 0; blockIdx.y = size), whatever their ancestors say
 __global__ __launch_bounds__(64) void k_viterbi(LsnCellDev c, const float* __restrict__ llr, const float* __restrict__ pw,
                                                 const uint32_t* __restrict__ cfi_arr, const uint32_t* __restrict__ sf_idx_arr,
-                                                LsnCand* __restrict__ cand, LsnPruneCfg pc, const uint32_t* __restrict__ snap, uint8_t* __restrict__ acc, int level,
+                                                LsnCand* __restrict__ cand, uint32_t* __restrict__ cand4, LsnPruneCfg pc, const uint32_t* __restrict__ snap, uint8_t* __restrict__ acc, int level,
                                                 uint32_t one_sf, uint32_t one_li, uint32_t one_sz)
 {
   __shared__ __attribute__((aligned(16))) int symw[LSN_MAX_DCI_D + 4];  // per trellis step: (q0 - 128) | (q1 - 128) << 8 | (q2 - 128) << 16, signed bytes
@@ -722,6 +722,7 @@ __global__ __launch_bounds__(64) void k_viterbi(LsnCellDev c, const float* __res
     }
   }
   LsnCand* out = cand + ((size_t)sf * LSN_MAX_LOC + li) * LSN_MAX_SIZES + sz;
+  uint32_t* out4 = cand4 + ((size_t)sf * LSN_MAX_LOC + li) * LSN_MAX_SIZES + sz;   // the search's view of the slot: LSN_CAND_HOT (lsn_types.h)
   uint8_t* aout = acc + ((size_t)sf * LSN_MAX_LOC + li) * LSN_MAX_SIZES + sz;
   bool ok = L >= 0;
   const uint32_t E = ok ? (72u << L) : 0u;
@@ -731,7 +732,7 @@ __global__ __launch_bounds__(64) void k_viterbi(LsnCellDev c, const float* __res
       if (pw[sf * LSN_CCE_STRIDE + ncce + i] < 0.7f) ok = false;  // location->sufficient_power (falcon_pdcch.c:610-614)
   }
   if (!ok) {
-    if (lane == 0) { out->bits = 0; out->rnti = 0; out->flags = 0; if (pc.on) *aout = 0; }
+    if (lane == 0) { out->bits = 0; out->rnti = 0; out->flags = 0; *out4 = 0; if (pc.on) *aout = 0; }
     return;
   }
   if (pc.on && level >= 0 && L < 3) {
@@ -758,7 +759,7 @@ __global__ __launch_bounds__(64) void k_viterbi(LsnCellDev c, const float* __res
       offA += lim >> la;
     }
     if (!((has_p && !closed_p) || (has_s && !closed_s))) {
-      if (lane == 0) { out->bits = 0; out->rnti = 0; out->flags = LSN_CAND_NOT_COMPUTED; *aout = 0; }
+      if (lane == 0) { out->bits = 0; out->rnti = 0; out->flags = LSN_CAND_NOT_COMPUTED; *out4 = LSN_CAND_HOT(0ull, 0u, LSN_CAND_NOT_COMPUTED); *aout = 0; }
       return;
     }
   }
@@ -785,7 +786,7 @@ __global__ __launch_bounds__(64) void k_viterbi(LsnCellDev c, const float* __res
     symw[t] = (int)word;
   }
   if (__ballot(nz) == 0ull) {  // mean |llr| == 0: the reference skips the decode (falcon_pdcch.c:141)
-    if (lane == 0) { out->bits = 0; out->rnti = 0; out->flags = 0; if (pc.on) *aout = 0; }
+    if (lane == 0) { out->bits = 0; out->rnti = 0; out->flags = 0; *out4 = 0; if (pc.on) *aout = 0; }
     return;
   }
   unsigned long long bits; uint32_t rnti;
@@ -795,6 +796,7 @@ __global__ __launch_bounds__(64) void k_viterbi(LsnCellDev c, const float* __res
     out->bits = bits;
     out->rnti = rnti;
     out->flags = 1u | (ss << 1);  // bit 0: decoded, bits 1-2: search-space match
+    *out4 = LSN_CAND_HOT(bits, rnti, 1u | (ss << 1));
     if (pc.on && level >= 0) *aout = (uint8_t)lsn_cand_claim(pc, snap, (uint32_t)sz, bits, rnti, ss);
   }
 }
@@ -920,24 +922,24 @@ void lsn_launch_pbch(const LsnCellDev& c, const cf32* grid, const cf32* ce, cons
   LSN_LAUNCH(k_pbch_viterbi, dim3(4), dim3(64), 0, s, c, llr5, out4);
 }
 
-void lsn_launch_viterbi(const LsnCellDev& c, const float* llr, const float* pw, const uint32_t* cfi, const uint32_t* sf_idx, LsnCand* cand, uint32_t nsf,
+void lsn_launch_viterbi(const LsnCellDev& c, const float* llr, const float* pw, const uint32_t* cfi, const uint32_t* sf_idx, LsnCand* cand, uint32_t* cand4, uint32_t nsf,
                         const LsnPruneCfg& pc, const uint32_t* snap, uint8_t* acc, hipStream_t s)
 {
   if (!pc.on) {
-    LSN_LAUNCH(k_viterbi, dim3(LSN_MAX_LOC, c.nsizes, nsf), dim3(64), 0, s, c, llr, pw, cfi, sf_idx, cand, pc, snap, acc, -1, 0u, 0u, 0u);
+    LSN_LAUNCH(k_viterbi, dim3(LSN_MAX_LOC, c.nsizes, nsf), dim3(64), 0, s, c, llr, pw, cfi, sf_idx, cand, cand4, pc, snap, acc, -1, 0u, 0u, 0u);
     return;
   }
   static_assert((LSN_MAX_NUM_OF_CCE >> 3) + (LSN_MAX_NUM_OF_CCE >> 2) + (LSN_MAX_NUM_OF_CCE >> 1) + LSN_MAX_NUM_OF_CCE + 3 == LSN_MAX_LOC, "the spare slots are taken by the level-0 launch");
   for (int level = 3; level >= 0; level--)
-    LSN_LAUNCH(k_viterbi, dim3((LSN_MAX_NUM_OF_CCE >> level) + (level == 0 ? 3 : 0), c.nsizes, nsf), dim3(64), 0, s, c, llr, pw, cfi, sf_idx, cand, pc, snap, acc, level, 0u, 0u, 0u);
+    LSN_LAUNCH(k_viterbi, dim3((LSN_MAX_NUM_OF_CCE >> level) + (level == 0 ? 3 : 0), c.nsizes, nsf), dim3(64), 0, s, c, llr, pw, cfi, sf_idx, cand, cand4, pc, snap, acc, level, 0u, 0u, 0u);
 }
 // decode on demand: the slots of one 8-CCE block of one subframe that are still marked LSN_CAND_NOT_COMPUTED (the search found one of them)
-void lsn_launch_viterbi_block(const LsnCellDev& c, const float* llr, const float* pw, const uint32_t* cfi, const uint32_t* sf_idx, LsnCand* cand, uint32_t sf, uint32_t block,
+void lsn_launch_viterbi_block(const LsnCellDev& c, const float* llr, const float* pw, const uint32_t* cfi, const uint32_t* sf_idx, LsnCand* cand, uint32_t* cand4, uint32_t sf, uint32_t block,
                               const LsnPruneCfg& pc, const uint32_t* snap, uint8_t* acc, hipStream_t s)
 {
   LsnPruneCfg off = pc;
   off.on = 0;
-  LSN_LAUNCH(k_viterbi, dim3(15, c.nsizes, 1), dim3(64), 0, s, c, llr, pw, cfi, sf_idx, cand, off, snap, acc, -2, sf, block, 0u);
+  LSN_LAUNCH(k_viterbi, dim3(15, c.nsizes, 1), dim3(64), 0, s, c, llr, pw, cfi, sf_idx, cand, cand4, off, snap, acc, -2, sf, block, 0u);
 }
 
 // SubframePower::computePower (SubframePower.cc:18-42) linear part: sum over 14 symbols of mean |x|^2 per PRB (antenna 0).  The per-symbol terms come from
