@@ -685,6 +685,7 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
         cb.out_bytes = (uint32_t)(K - F - (s.C > 1 ? 24 : 0)) / 8;
         cb.out_off = (uint32_t)(pay_n - pay0) + wp;
         cb.il_off = turbo_il_offset(K);
+        cb.nwin = turbo_nwin(K);
         cb.max_iter = (uint32_t)cfg.max_turbo_iterations;
         // code blocks 1 .. C-1 are launched behind block 0 and skipped when it failed (the TB CRC verdict needs every block)
         cb.dep = (q > 0 && cb_skip) ? (uint32_t)(r.h_cbs.size() - (size_t)q) : LSN_CB_NODEP;
@@ -708,7 +709,7 @@ void Engine::runJobs(Chunk& ch, JobRunner& r, std::vector<int>& ids)
   // ONE decoder launch per phase (late round 4: + 5.7 % against one launch per wavefront class).  Round 5: the blocks of at most 64 windows - one working
   // wavefront - share workgroups two by two (k_turbo, stage_c.hip) instead of holding a whole LDS / wavefront slot each with the second wavefront idle:
   // half of the metric's code blocks, half of the decoder's slot time (every block alone in its workgroup, rounds 2-4: - 3 %, profiles/r05_ab_session*.txt).
-  auto pairable = [&](uint32_t K) { return K <= LSN_TURBO_PAIR_KMAX && lsn_turbo_nwin((int)K) <= 64; };
+  auto pairable = [&](uint32_t K) { return K <= LSN_TURBO_PAIR_KMAX && turbo_nwin((int)K) <= 64; };
   const uint32_t njobs = (uint32_t)r.h_jobs.size(), ncb = (uint32_t)r.h_cbs.size();
   uint32_t kmax_solo = 0, kmax_pair = 0, emax = 0, nsolo[2] = {0, 0}, npair[2] = {0, 0};
   size_t spp_n = 0;
@@ -1480,7 +1481,7 @@ void Engine::harqRunBatch(Chunk& ch, JobRunner& r, const std::vector<HarqReq>& r
   std::vector<uint32_t> order(nd);
   for (uint32_t i = 0; i < nd; i++) order[i] = i;
   std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
-    const bool ca = lsn_turbo_two_wave_class((int)cbs[a].K), cb2 = lsn_turbo_two_wave_class((int)cbs[b].K);
+    const bool ca = turbo_nwin((int)cbs[a].K) > 64 || cbs[a].K > LSN_TURBO_ONE_WAVE_KMAX, cb2 = turbo_nwin((int)cbs[b].K) > 64 || cbs[b].K > LSN_TURBO_ONE_WAVE_KMAX;
     if (ca != cb2) return ca;
     return cbs[a].K > cbs[b].K;
   });

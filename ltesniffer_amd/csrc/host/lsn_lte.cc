@@ -627,6 +627,18 @@ uint32_t turbo_il_offset(int K)
   if (K <= 0 || K > 6144 || (K & 7) || tab.off[K / 8] == 0xFFFFFFFFu) return tab.total;  // K not a block size: the total number of words
   return tab.off[K / 8];
 }
+uint32_t turbo_nwin(int K)
+{
+  // lsn_turbo_nwin(K) (lsn_rm.h: a search over the divisors of K) from a table by K / 8, built on first use: the decode threads ask it three times per code block,
+  // and the kernels take it from the descriptor (LsnCbDev::nwin) instead of running the search once per THREAD (round 6: a third of k_rm's vector instructions)
+  struct Tab {
+    uint8_t n[6144 / 8 + 1];
+    Tab() { for (int k = 0; k <= 6144 / 8; k++) n[k] = (uint8_t)(k ? lsn_turbo_nwin(8 * k) : 1); }
+  };
+  static const Tab tab;
+  if (K <= 0 || K > 6144 || (K & 7)) return (uint32_t)lsn_turbo_nwin(K);
+  return tab.n[K / 8];
+}
 bool qpp_params(int K, uint32_t& f1, uint32_t& f2)
 {
   for (int i = 0; i < LSN_QPP_NSIZES; i++) if (lsn_qpp_table[i][0] == K) { f1 = lsn_qpp_table[i][1]; f2 = lsn_qpp_table[i][2]; return true; }

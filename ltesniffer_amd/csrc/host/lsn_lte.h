@@ -98,6 +98,7 @@ uint32_t pdcch_validate_location(uint32_t nof_cce, uint32_t ncce, uint32_t l, ui
 struct CbSegm { int C = 0, Cp = 0, Cm = 0, Kp = 0, Km = 0, F = 0; };
 bool cbsegm(int tbs, CbSegm& s);
 bool qpp_params(int K, uint32_t& f1, uint32_t& f2);
+uint32_t turbo_nwin(int K);      // lsn_turbo_nwin(K) from a table (the number of trellis windows of a code block of K bits)
 uint32_t turbo_il_offset(int K);  // word offset of block size K in the interleaver address tables (sizes in table order, lsn_turbo_il_words(K) words each); K = 0: total
 
 // ---- Histogram / RNTIManager ----

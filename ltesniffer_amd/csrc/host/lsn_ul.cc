@@ -278,6 +278,7 @@ void Engine::puschDecodeGrid(const cf32* d_grid, uint32_t nsf, uint32_t start_tt
       cb.out_bytes = (uint32_t)(K - F - (s.C > 1 ? 24 : 0)) / 8;
       cb.out_off = (uint32_t)pay_n + wp;
       cb.il_off = turbo_il_offset(K);
+      cb.nwin = turbo_nwin(K);
       cb.max_iter = (uint32_t)cfg.max_turbo_iterations;
       cb.dep = LSN_CB_NODEP;  // every code block is decoded: the iteration count of a grant is part of what lsn_phy_pusch_decode reports
       wp += cb.out_bytes;

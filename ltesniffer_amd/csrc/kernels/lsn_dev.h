@@ -121,6 +121,7 @@ struct LsnCbDev {
   uint32_t dep;       // res_idx of the FIRST code block of the same transport block when this one may be skipped once that one has failed
                       // (a transport block fails as soon as any of its code blocks fails); 0xFFFFFFFF: always decode
   uint32_t spp_off;   // u32 word offset (multiple of 4) of the block's de-rate-matched soft data: K packed words + 12 termination values (k_rm -> k_turbo)
+  uint32_t nwin;      // lsn_turbo_nwin(K), from the host's table (0: the kernel works it out itself)
 };
 #define LSN_SPP_WORDS(K) (((K) + 12u + 3u) & ~3u)
 // one PUSCH grant to decode

@@ -332,7 +332,7 @@ __global__ __launch_bounds__(RM_NT) void k_rm(const LsnCbDev* __restrict__ cbs, 
   int16_t* es = (int16_t*)rm_smem;
   const LsnCbDev cb = cbs[blockIdx.x];
   const int tid = threadIdx.x, K = (int)cb.K, F = (int)cb.F, E = (int)cb.E;
-  const int P = lsn_turbo_nwin(K), W = K / P;
+  const int P = cb.nwin ? (int)cb.nwin : lsn_turbo_nwin(K), W = K / P;
   const int16_t* e = llr + cb.e_off;  // e_off is a multiple of 8 entries (16 bytes) for the first block of a codeword only
   const bool staged = (uint32_t)E <= seg;
   if (tid == 0) lsn_rm_geom(geom, K, F, (int)cb.rv);
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(NT) TB_WAVES_ATTR void k_turbo(const uint32_t* __re
     return;
   }
   const int lane = paired ? (int)(threadIdx.x & 63u) : (int)threadIdx.x, K = (int)cb.K, F = (int)cb.F;
-  const int P = lsn_turbo_nwin(K), W = K / P;
+  const int P = cb.nwin ? (int)cb.nwin : lsn_turbo_nwin(K), W = K / P;
   const uint32_t magicW = ((1u << 20) + (uint32_t)W - 1u) / (uint32_t)W;
   // a block of at most 64 windows: one working wavefront (solo: the second wavefront leaves before the first barrier)
   const int nt = (NT == 128 && (paired || P <= 64)) ? 64 : NT;
