@@ -398,6 +398,8 @@ int lsn_prach_tti_opportunity(uint32_t config_idx, uint32_t tti); /* srsran_prac
 /* ---- measurement + parity taps (not part of the reference surface) ---- */
 enum { LSN_TAP_GRID = 0, LSN_TAP_CE = 1, LSN_TAP_PDCCH_LLR = 2, LSN_TAP_CHEST = 3, LSN_TAP_CFI = 4, LSN_TAP_CANDIDATES = 5,
        LSN_TAP_CCE_POWER = 6, LSN_TAP_ACCEPTED = 7, LSN_TAP_RB_POWER = 8,
+       /* (LSN_TAP_CANDIDATES: [160 locations][8 sizes] of {u64 payload bits, u32 CRC remainder, u32 flags}; with candidate pruning on, a slot the blind decoder left
+        * out and the search never asked for has flags = 0x80 - lsn_phy_set_candidate_pruning(phy, 0) gives the exhaustive table) */
        /* stage C (a14, srsran_ue_dl_decode_pdsch as called at DL_Sniffer_PDSCH.cc:997,1110,1207): retained only for batches processed after
         * lsn_phy_set_stage_c_taps(phy, 1) - the arenas of a decode launch are recycled otherwise.  For these the index argument of lsn_phy_tap
         * is the DECODE JOB of the chunk (one job = one decode call of one accepted DCI with one MCS table), not a subframe. */
