@@ -46,22 +46,21 @@ LSN_HD int lsn_rm_cum_v1(const LsnRmGeom& g, int col, int row)
 }
 LSN_HD int lsn_rm_cum_v2(const LsnRmGeom& g, int col, int row) { return lsn_rm_cum_v1(g, col, row) + (lsn_rm_isnull01_cr(g, col, row) ? 0 : 1); }
 
-LSN_HD void lsn_rm_geom(LsnRmGeom& g, int K, int F, int rv)
+// The geometry in two parts, so that the de-rate-matching kernel fills it with 32 lanes (one buffer column each, the prefix sums by a shuffle scan) while
+// the host fills it in a loop: the <NULL> counts of one column ...
+LSN_HD void lsn_rm_geom_col(int ND, int F, int c, int* cnt01, int* first2, int* cnt2)
+{
+  const int p = lsn_perm_tc_f(c), T01 = ND + F;
+  *cnt01 = (T01 > p) ? (T01 - p + 31) / 32 : 0;
+  *first2 = (p + 1 < ND) ? 1 : 0;  // the row-0 entry of this column of v2 is <NULL>
+  *cnt2 = *first2 + ((p == 31 && ND > 0) ? 1 : 0);
+}
+// ... and the scalars, once cnt01 / first2 / pre01[0..32] / pre2[0..32] stand
+LSN_HD void lsn_rm_geom_finish(LsnRmGeom& g, int K, int F, int rv)
 {
   g.K = K; g.D = K + 4; g.R = (g.D + 31) / 32; g.KP = 32 * g.R; g.ND = g.KP - g.D; g.F = F; g.Ncb = 3 * g.KP;
-  int T01 = g.ND + F, a01 = 0, a2 = 0;
-  for (int c = 0; c < 32; c++) {
-    int p = lsn_perm_tc_f(c);
-    int c01 = (T01 > p) ? (T01 - p + 31) / 32 : 0;
-    g.cnt01[c] = (uint8_t)c01;
-    g.pre01[c] = a01; a01 += c01;
-    g.first2[c] = (uint8_t)((p + 1 < g.ND) ? 1 : 0);  // the row-0 entry of this column of v2 is <NULL>
-    int c2 = (int)g.first2[c] + ((p == 31 && g.ND > 0) ? 1 : 0);
-    g.pre2[c] = a2; a2 += c2;
-  }
-  g.pre01[32] = a01; g.pre2[32] = a2;
-  g.nn0 = g.KP - a01;
-  g.nn = 3 * g.KP - 2 * a01 - a2;
+  g.nn0 = g.KP - g.pre01[32];
+  g.nn = 3 * g.KP - 2 * g.pre01[32] - g.pre2[32];
   const int c0 = 2 * ((g.Ncb + 8 * g.R - 1) / (8 * g.R)) * rv + 2;  // k0 = R * c0: always at row 0 of a column
   g.k0 = g.R * c0;
   if (c0 < 32) {
@@ -70,6 +69,21 @@ LSN_HD void lsn_rm_geom(LsnRmGeom& g, int K, int F, int rv)
     const int jp = g.k0 - g.KP, k = jp >> 1, col = k / g.R, row = k - col * g.R;
     g.cum_k0 = (col >= 32) ? g.nn : ((jp & 1) ? lsn_rm_cum_v2(g, col, row) : lsn_rm_cum_v1(g, col, row));
   }
+}
+LSN_HD void lsn_rm_geom(LsnRmGeom& g, int K, int F, int rv)
+{
+  const int D = K + 4, R = (D + 31) / 32, ND = 32 * R - D;
+  g.R = R;
+  int a01 = 0, a2 = 0;
+  for (int c = 0; c < 32; c++) {
+    int c01, f2, c2;
+    lsn_rm_geom_col(ND, F, c, &c01, &f2, &c2);
+    g.cnt01[c] = (uint8_t)c01; g.first2[c] = (uint8_t)f2;
+    g.pre01[c] = a01; a01 += c01;
+    g.pre2[c] = a2; a2 += c2;
+  }
+  g.pre01[32] = a01; g.pre2[32] = a2;
+  lsn_rm_geom_finish(g, K, F, rv);
 }
 
 // first e index that lands on buffer position with `cum` non-<NULL> predecessors
@@ -91,6 +105,43 @@ LSN_HD int lsn_rm_rank(const LsnRmGeom& g, int s, int i)
   if (z < 0) z += g.KP;
   const int row = z >> 5, col = lsn_perm_tc_f(z & 31);
   return lsn_rm_eidx(g, lsn_rm_cum_v2(g, col, row));
+}
+
+// The same ranks from ONE 8-byte table entry per buffer column (k_rm: the entry is an LDS read, everything else registers):
+//   a = (col R - pre01[col] - cum_k0) * 256 + cnt01[col],   b = (nn0 + 2 col R - pre01[col] - pre2[col] - cum_k0) * 256 + first2[col]
+// so that with m = min(row, cnt01)  rank(v0) = (a >> 8) + row - m,  rank(v1) = (b >> 8) + 2 row - m - (row > 0 ? first2 : 0),
+// rank(v2) = rank(v1) + (row >= cnt01), each + nn when negative (lsn_rm_eidx).  y = i + ND for the streams 0 / 1, z = i + ND - 1 for stream 2
+// (ND is 4, 12, 20 or 28 for the block sizes of 36.212 Table 5.1.3-3 - K is a multiple of 8 -, so z never wraps).
+struct LsnRmCol { int32_t a, b; };
+LSN_HD LsnRmCol lsn_rm_fast_col(const LsnRmGeom& g, int c)
+{
+  LsnRmCol o;
+  o.a = (c * g.R - g.pre01[c] - g.cum_k0) * 256 + (int)g.cnt01[c];
+  o.b = (g.nn0 + 2 * c * g.R - g.pre01[c] - g.pre2[c] - g.cum_k0) * 256 + (int)g.first2[c];
+  return o;
+}
+LSN_HD int lsn_rm_col_of(int y)
+{
+#ifdef __HIP_DEVICE_COMPILE__
+  return (int)(__builtin_bitreverse32((uint32_t)y) >> 27);
+#else
+  return lsn_perm_tc_f(y & 31);
+#endif
+}
+// filler positions (i < F) are the caller's business: the ranks returned for them are meaningless
+LSN_HD void lsn_rm_rank01_fast(LsnRmCol e, int nn, int y, int* r0, int* r1)
+{
+  const int row = y >> 5, cnt = e.a & 255, m = row < cnt ? row : cnt;
+  int a = (e.a >> 8) + row - m;
+  int b = (e.b >> 8) + 2 * row - m - (row > 0 ? (e.b & 1) : 0);
+  *r0 = a < 0 ? a + nn : a;
+  *r1 = b < 0 ? b + nn : b;
+}
+LSN_HD int lsn_rm_rank2_fast(LsnRmCol e, int nn, int z)
+{
+  const int row = z >> 5, cnt = e.a & 255, m = row < cnt ? row : cnt;
+  const int b = (e.b >> 8) + 2 * row - m - (row > 0 ? (e.b & 1) : 0) + (row < cnt ? 0 : 1);
+  return b < 0 ? b + nn : b;
 }
 
 // Number of trellis windows the turbo decoder cuts a code block of K bits into (windows of W = K / P >= 32 steps,

@@ -317,11 +317,13 @@ void lsn_launch_pdsch_demod(const LsnCellDev& c, const LsnGrantDev* g, const uin
 // twelve termination values (stream s, position K + j at K + 4 s + j) as int32.  Blocks whose E exceeds the staging
 // area read e[] from global memory instead (same arithmetic).
 #define RM_NT 256
+// Round 6 (last session): the ranks come from ONE 8-byte LDS entry per buffer column (lsn_rm.h: lsn_rm_rank01_fast / lsn_rm_rank2_fast - the streams 0 and 1 of a
+// position share their column), the geometry is filled by 32 lanes of the first wavefront instead of one thread, and without repetition (E <= nn: every
+// block of the downlink workloads) a value is one LDS read at min(rank, E) - e[E] is staged as zero - instead of a loop behind a branch.
 template <bool STAGED>
 __device__ __forceinline__ int rm_sum(const int16_t* __restrict__ e, const int16_t* es, int rank, int E, int nn)
 {
   int acc = 0;
-  if (rank < 0) return 0;
   for (int k = rank; k < E; k += nn) acc += STAGED ? (int)es[k] : (int)e[k];
   return acc > LSN_LLR_CLIP ? LSN_LLR_CLIP : (acc < -LSN_LLR_CLIP ? -LSN_LLR_CLIP : acc);
 }
@@ -329,44 +331,83 @@ __global__ __launch_bounds__(RM_NT) void k_rm(const LsnCbDev* __restrict__ cbs, 
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char rm_smem[];
   __shared__ LsnRmGeom geom;
+  __shared__ LsnRmCol tab[32];
   int16_t* es = (int16_t*)rm_smem;
   const LsnCbDev cb = cbs[blockIdx.x];
   const int tid = threadIdx.x, K = (int)cb.K, F = (int)cb.F, E = (int)cb.E;
   const int P = cb.nwin ? (int)cb.nwin : lsn_turbo_nwin(K), W = K / P;
+  const int ND = 32 * ((K + 4 + 31) >> 5) - (K + 4);
   const int16_t* e = llr + cb.e_off;  // e_off is a multiple of 8 entries (16 bytes) for the first block of a codeword only
   const bool staged = (uint32_t)E <= seg;
-  if (tid == 0) lsn_rm_geom(geom, K, F, (int)cb.rv);
+  if (tid < 64) {
+    // geometry: lane c < 32 counts the <NULL>s of buffer column c, an inclusive shuffle scan gives the prefix sums (the lanes 32..63 carry zeros)
+    int c01 = 0, f2 = 0, c2 = 0;
+    if (tid < 32) lsn_rm_geom_col(ND, F, tid, &c01, &f2, &c2);
+    int i01 = c01, i2 = c2;
+#pragma unroll
+    for (int off = 1; off < 32; off <<= 1) {
+      const int t = __shfl_up(i01, off), u = __shfl_up(i2, off);
+      if (tid >= off) { i01 += t; i2 += u; }
+    }
+    if (tid < 32) { geom.cnt01[tid] = (uint8_t)c01; geom.first2[tid] = (uint8_t)f2; geom.pre01[tid] = i01 - c01; geom.pre2[tid] = i2 - c2; }
+    if (tid == 31) { geom.pre01[32] = i01; geom.pre2[32] = i2; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (tid == 0) lsn_rm_geom_finish(geom, K, F, (int)cb.rv);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (tid < 32) tab[tid] = lsn_rm_fast_col(geom, tid);
+  }
   if (staged) {
-    // 16-byte loads from the aligned address at or below e
+    // 16-byte loads from the aligned address at or below e; the entry behind the last one, e[E], is staged as zero (what a rank >= E reads)
     const uintptr_t a0 = (uintptr_t)e & ~(uintptr_t)15;
     const int skew = (int)(((uintptr_t)e - a0) >> 1);  // entries between the aligned address and e[0]
     const uint4* src = (const uint4*)a0;
-    const int nv = (skew + E + 7) >> 3;
-    for (int v = tid; v < nv; v += RM_NT) ((uint4*)es)[v] = src[v];
+    const int end = skew + E, vend = end >> 3;
+    for (int v = tid; v <= vend; v += RM_NT) {
+      uint4 d = make_uint4(0u, 0u, 0u, 0u);
+      if (8 * v < end) d = src[v];
+      if (v == vend) {
+        const int q = end & 7;
+        const uint32_t keep = (q & 1) ? 0x0000FFFFu : 0u;   // the word of entry `end`: its low half stays when `end` is the high half
+        switch (q >> 1) { case 0: d.x &= keep; break; case 1: d.y &= keep; break; case 2: d.z &= keep; break; default: d.w &= keep; break; }
+      }
+      ((uint4*)es)[v] = d;
+    }
     es += skew;
   }
   __syncthreads();
   const int nn = geom.nn;
   uint32_t* out = spp_g + cb.spp_off;
-  for (int t = tid; t < K + 12; t += RM_NT) {
-    if (t < K) {
-      const int x = (t % P) * W + t / P;
-      int v0, v1, v2;
-      if (staged) {
-        v0 = x < F ? -LSN_LLR_CLIP : rm_sum<true>(e, es, lsn_rm_rank(geom, 0, x), E, nn);
-        v1 = x < F ? -LSN_LLR_CLIP : rm_sum<true>(e, es, lsn_rm_rank(geom, 1, x), E, nn);
-        v2 = rm_sum<true>(e, es, lsn_rm_rank(geom, 2, x), E, nn);
-      } else {
-        v0 = x < F ? -LSN_LLR_CLIP : rm_sum<false>(e, es, lsn_rm_rank(geom, 0, x), E, nn);
-        v1 = x < F ? -LSN_LLR_CLIP : rm_sum<false>(e, es, lsn_rm_rank(geom, 1, x), E, nn);
-        v2 = rm_sum<false>(e, es, lsn_rm_rank(geom, 2, x), E, nn);
-      }
-      out[t] = ((uint32_t)v0 & 0x3FFu) | (((uint32_t)v1 & 0x3FFu) << 10) | (((uint32_t)v2 & 0x3FFu) << 20);
+  const bool single = staged && E <= nn;
+  // the three streams of trellis position x
+  auto streams = [&](int x, int& v0, int& v1, int& v2) {
+    const int y = x + ND;
+    int r0, r1;
+    lsn_rm_rank01_fast(tab[lsn_rm_col_of(y)], nn, y, &r0, &r1);
+    const int r2 = lsn_rm_rank2_fast(tab[lsn_rm_col_of(y - 1)], nn, y - 1);
+    if (single) {
+      v0 = (int)es[r0 < E ? r0 : E]; v1 = (int)es[r1 < E ? r1 : E]; v2 = (int)es[r2 < E ? r2 : E];
+    } else if (staged) {
+      v0 = rm_sum<true>(e, es, r0, E, nn); v1 = rm_sum<true>(e, es, r1, E, nn); v2 = rm_sum<true>(e, es, r2, E, nn);
     } else {
-      const int s = (t - K) >> 2, x = K + ((t - K) & 3);
-      const int r = lsn_rm_rank(geom, s, x);
-      out[t] = (uint32_t)(staged ? rm_sum<true>(e, es, r, E, nn) : rm_sum<false>(e, es, r, E, nn));
+      v0 = rm_sum<false>(e, es, r0, E, nn); v1 = rm_sum<false>(e, es, r1, E, nn); v2 = rm_sum<false>(e, es, r2, E, nn);
     }
+  };
+  // word t of the transposed layout, t = tq * P + tr with tq, tr carried along from one pass of the workgroup to the next
+  int tq = tid / P, tr = tid - tq * P;
+  const int dq = RM_NT / P, dr = RM_NT - dq * P;
+  for (int t = tid; t < K; t += RM_NT, tq += dq, tr += dr) {
+    if (tr >= P) { tr -= P; tq++; }
+    const int x = tr * W + tq;   // = (t % P) * W + t / P
+    int v0, v1, v2;
+    streams(x, v0, v1, v2);
+    if (x < F) v0 = v1 = -LSN_LLR_CLIP;   // filler bits are known zeros
+    out[t] = ((uint32_t)v0 & 0x3FFu) | (((uint32_t)v1 & 0x3FFu) << 10) | (((uint32_t)v2 & 0x3FFu) << 20);
+  }
+  // the twelve termination values: stream s, position K + j at word K + 4 s + j
+  if (tid < 4) {
+    int v0, v1, v2;
+    streams(K + tid, v0, v1, v2);
+    out[K + tid] = (uint32_t)v0; out[K + 4 + tid] = (uint32_t)v1; out[K + 8 + tid] = (uint32_t)v2;
   }
 }
 // the staging area is sized by the largest E of the launch, capped at 64 KiB (two workgroups per CU at least)

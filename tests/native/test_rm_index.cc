@@ -33,11 +33,26 @@ int main()
           int o = map[(k0 + j) % Ncb];
           if (o >= 0) rank[o] = k++;
         }
+        LsnRmCol tab[32];
+        for (int c = 0; c < 32; c++) tab[c] = lsn_rm_fast_col(g, c);
+        if (ND != 4 && ND != 12 && ND != 20 && ND != 28) { printf("ND = %d\n", ND); return 1; }
         if (k != g.nn) { printf("nn mismatch K=%d F=%d rv=%d: %d vs %d\n", K, F, rv, k, g.nn); return 1; }
         for (int s = 0; s < 3; s++)
           for (int i = 0; i < D; i++) {
             int r = lsn_rm_rank(g, s, i);
             if (r != rank[s * D + i]) { printf("rank mismatch K=%d F=%d rv=%d s=%d i=%d: %d vs %d\n", K, F, rv, s, i, r, rank[s * D + i]); return 1; }
+            // the one-entry-per-column form the de-rate-matching kernel uses (k_rm)
+            if (!(s < 2 && i < F)) {
+              int f;
+              if (s < 2) {
+                int r0, r1;
+                lsn_rm_rank01_fast(tab[lsn_rm_col_of(i + ND)], g.nn, i + ND, &r0, &r1);
+                f = s == 0 ? r0 : r1;
+              } else {
+                f = lsn_rm_rank2_fast(tab[lsn_rm_col_of(i + ND - 1)], g.nn, i + ND - 1);
+              }
+              if (r >= 0 && f != r) { printf("fast rank mismatch K=%d F=%d rv=%d s=%d i=%d: %d vs %d\n", K, F, rv, s, i, f, r); return 1; }
+            }
             checked++;
           }
       }
