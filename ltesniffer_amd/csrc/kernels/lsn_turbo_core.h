@@ -7,27 +7,42 @@
 // A wavefront alone on a SIMD issues one VALU instruction per 4 cycles whatever its class (profiles/r03_valu_peak_isa.txt),
 // and packed forms occupy the VALU port for 4 cycles at any occupancy, so v_pk_add_i16 / v_pk_max_i16 do two state updates for the price of one.
 // Vector instructions per trellis step in the full-length sub-blocks (counted in the ISA; first / interleaved constituent decoder):
-//                                  rounds 3-4      round 5 (second half)
-//   forward sweep                  25.4 / 27.8     23.4 / 26.8     operands of two steps built together (lsn_operands2)
-//   alpha recompute                27.3 / 28.3     23.3 / 25.3     ... and normalised every second step only
-//   beta + soft output             50.9 / 49.9     44.9 / 44.5     soft outputs of two steps on packed halves (lsn_ext_two), (g10, g11) with one add,
-//                                                                  lanes without a window masked instead of redirected per step
+//                                  rounds 3-4      round 5 (second half)   round 6 (last session)
+//   forward sweep                  25.4 / 27.8     23.4 / 26.8             23.4 / 26.8
+//   alpha recompute                27.3 / 28.3     23.3 / 25.3             23.6 / 25.6
+//   beta + soft output             50.9 / 49.9     44.9 / 44.5             37.7 / 37.3
+//   per step of a 64-step window   (forward sweep over 48 of the 64 steps)  85.8 / 89.9  ->  78.9 / 83.0
+//   round 5: operands of two steps built together (lsn_operands2), alpha normalised every second step in the recompute too, soft outputs of two steps on packed
+//   halves (lsn_ext_two), (g10, g11) with one add, lanes without a window masked instead of redirected per step;
+//   round 6: no shuffles inside a full-length sub-block (the cycle of seven register layouts, lsn_turbo_cyc.h: - 3.75 per step), beta normalised behind every
+//   second step (- 2), the sign mask of the soft output from one shift (- 0.5).
 //
 // Layout C: four registers hold the eight state metrics as (m[k] | m[k+4] << 16), k = 0..3.
 //  * forward: butterfly k reads states 2k, 2k+1 and writes k, k+4 - with the operands taken as half-broadcasts (op_sel) layout C maps to
 //    itself: 8 v_pk_add + 4 v_pk_max per step.
 //  * backward: the pairs that meet alpha (k, k+4) need beta pairs (0,2) (4,6) (1,3) (5,7): four v_perm per step, then 8 v_pk_add
-//    (branch + beta), 8 v_pk_add (+ alpha), 6 + 4 v_pk_max; the result is layout C again.
+//    (branch + beta), 8 v_pk_add (+ alpha), 6 + 4 v_pk_max; the result is layout C again.  (The short last sub-block of a window; the full-length ones
+//    walk through the seven layouts of lsn_turbo_cyc.h, in which neither direction shuffles.)
 // Word length (int16, no wrap-around anywhere - v_pk_max_i16 compares values, not residues):
 //   |gamma| <= |sys| + |ext| + |par| <= 512 + 2047 + 512 = 3071 per step.  Any state is reached from any state in 3 steps, so a metric
 //   vector normalised to state 0 spreads at most 3 * 3071 = 9213 once it is 3 steps away from its initialisation; the initialisations are
-//   (0, -12000 x 7), the termination metrics (<= 3 * 1022) and boundary metrics of the previous iteration (<= 9213), i.e. <= 12000 + 2 * 3071
-//   = 18142 in the first two steps of the first window and <= 15355 elsewhere.  Alpha is normalised every SECOND step, in the forward sweep
-//   and (round 5) in the recompute: an alpha vector that meets beta is either normalised (<= 9213) or one step past a normalised one
-//   (<= 9213 + 3071 = 12284; in the first two steps of the first window <= 18142 as above); beta is normalised every step, and a window is at
-//   least 32 steps long, so the two "young" ends never meet:
-//   |alpha + beta + gamma| <= max(18142 + 9213, 12284 + 15355) + 3071 = 30710 < 32768.  (tools/turbo_metric_ranges.py measures <= 19920 with
-//   alpha normalised every step; the host build of this file checks every packed add and subtract.)  Check-points and the window-boundary
+//   (0, -12000 x 7), the termination metrics (<= 3 * 1022) and boundary metrics of the previous iteration (<= 9213).
+//   Alpha is normalised behind every ODD step (forward sweep and recompute; sub-blocks start at even steps).  In front of an even step t it is normalised:
+//   <= 9213 at t = 0 (boundary metrics), <= 15355 at t = 2 (two steps of growth), <= 9213 from t = 4 on; in front of an odd step it carries the growth of
+//   one more step: <= 12284 at t = 1, <= 18426 at t = 3, <= 12284 from t = 5 on.  The first window starts from (0, -12000 x 7) instead: 12000 at t = 0,
+//   <= 15071 at t = 1 and <= 18142 at t = 2 - on the NEGATIVE side only (the states that cannot be reached yet still carry the initial -12000, the reached
+//   ones are within 2 * 3071) -, and as every other window from t = 3 on.
+//   Beta (round 6, last session) is normalised behind every EVEN step of a full-length sub-block and behind every step of the short last one.  Let N(t) bound
+//   the NORMALISED vector that enters step t: N(W-1) = 9213 (the initialisation), N(W-2) = 12284, N(W-3) = 15355, N(t) = 9213 below (three steps away).
+//   A vector that enters an odd step is normalised (<= N(t)); one that enters an even step is at worst the raw result of the odd step behind it,
+//   <= N(t+1) + 3071 (<= 12284 in general, 18426 at t = W-4, 15355 at t = W-3, 12284 at t = W-2).  A window has at least 32 steps, so the young ends never meet:
+//     odd t:   |alpha| + |beta| + |gamma| <= max(12284 + 15355, 18426 + 9213) + 3071 = 30710
+//     even t:  <= max(9213 + 18426, 15355 + 12284) + 3071 = 30710;  first window, t = 0: 12000 + 12284 + 3071;  t = 2: 18142 + 12284 + 3071 = 33497 - beyond int16, but on the
+//              negative side only and only in sums over states that cannot be reached yet.  The alpha + (beta + gamma) adds SATURATE (pka_sat: v_pk_add_i16 clamp):
+//              a saturated sum is below -32768 in exact arithmetic while the maximum it competes in is at least the state-0 term >= -(12284 + 3071), so it
+//              loses either way and every maximum equals the exact one.  beta + gamma alone stays within 18426 + 3071.
+//   (tools/turbo_metric_ranges.py measured <= 19920 with both recursions normalised every step; the host build of this file - tests/native/test_turbo_core.cc -
+//   checks every packed add and subtract, and aborts when a saturating add leaves the range on the positive side.)  Check-points and the window-boundary
 //   exchange store normalised vectors only (state 0 = 0 is not stored).
 //   L = m1 - m0 is formed in 32 bits, or in 16 bits with saturation where that is proven equal (lsn_ext_two).
 #pragma once
@@ -57,6 +72,25 @@ LSN_HD s2 pka(s2 a, s2 b) { return a + b; }
 LSN_HD s2 pks(s2 a, s2 b) { return a - b; }
 #endif
 LSN_HD s2 pkmax(s2 a, s2 b) { return __builtin_elementwise_max(a, b); }
+// alpha + (beta + branch): saturating (v_pk_add_i16 clamp - the same issue slot as the wrapping add).  A sum can leave the int16 range on the NEGATIVE side
+// only, and only at step 2 of the first window, where the states that cannot be reached yet still carry the initial -12000 (word-length argument above):
+// such a sum loses every maximum it takes part in whether it saturates or not.  The host build checks exactly that: a positive overflow aborts.
+#ifdef LSN_TURBO_RANGE_CHECK
+static inline s2 pka_sat(s2 a, s2 b)
+{
+  const int x = (int)a.x + (int)b.x, y = (int)a.y + (int)b.y;
+  if (x > 32767 || y > 32767) { std::fprintf(stderr, "int16 range exceeded on the positive side in alpha + beta: %d %d\n", x, y); std::abort(); }
+  return s2{(short)(x < -32768 ? -32768 : x), (short)(y < -32768 ? -32768 : y)};
+}
+#elif defined(__HIP_DEVICE_COMPILE__)
+LSN_HD s2 pka_sat(s2 a, s2 b) { return __builtin_elementwise_add_sat(a, b); }
+#else
+static inline s2 pka_sat(s2 a, s2 b)
+{
+  const int x = (int)a.x + (int)b.x, y = (int)a.y + (int)b.y;
+  return s2{(short)(x < -32768 ? -32768 : (x > 32767 ? 32767 : x)), (short)(y < -32768 ? -32768 : (y > 32767 ? 32767 : y))};
+}
+#endif
 LSN_HD uint32_t pk_u32(s2 v) { return __builtin_bit_cast(uint32_t, v); }
 LSN_HD s2 pk_s2(uint32_t w) { return __builtin_bit_cast(s2, w); }
 // packed add / subtract with a free choice of the source halves (VOP3P op_sel): result.lo = a.{AL} +- b.{BL}, result.hi = a.{AH} +- b.{BH}
@@ -109,8 +143,12 @@ LSN_HD void lsn_step_fwd_pk(s2* a, s2 q)
   }
 }
 
-// backward step: b (layout C, normalised) becomes the beta vector one step earlier (normalised); A = the alphas in front of this step (layout C);
-// M0 / M1 = max over the branches with input 0 / 1 of alpha + branch + beta, still split over the two halves (max(M.x, M.y) is the maximum)
+// backward step: b (layout C) becomes the beta vector one step earlier; A = the alphas in front of this step (layout C);
+// M0 / M1 = max over the branches with input 0 / 1 of alpha + branch + beta, still split over the two halves (max(M.x, M.y) is the maximum).
+// NORM: the new vector is normalised to its state 0.  The full-length sub-blocks normalise behind the EVEN steps only (round 6, last session; as the alpha
+// recursion does behind the odd ones): a beta vector that enters an odd step is normalised, one that enters an even step carries the growth of one step - and
+// meets an alpha vector that is normalised (word-length argument at the top).
+template <bool NORM = true>
 LSN_HD void lsn_step_bwd_pk(s2* b, const s2* A, s2 q, s2* M0o, s2* M1o)
 {
   const s2 G0 = __builtin_shufflevector(b[0], b[2], 0, 2), G1 = __builtin_shufflevector(b[0], b[2], 1, 3);  // (b0, b2) (b4, b6)
@@ -120,11 +158,13 @@ LSN_HD void lsn_step_bwd_pk(s2* b, const s2* A, s2 q, s2* M0o, s2* M1o)
   // successor metric + branch metric, paired like alpha: (state k, state k + 4); input 0 and input 1
   const s2 u00 = pka(G0, S), u01 = pka(G1, S), u02 = pka_sel<0, 1, 1, 0>(G3, S), u03 = pka_sel<0, 1, 1, 0>(G2, S);
   const s2 u10 = pka_sel<0, 1, 1, 0>(G1, T), u11 = pka_sel<0, 1, 1, 0>(G0, T), u12 = pka(G2, T), u13 = pka(G3, T);
-  *M0o = pkmax(pkmax(pka(A[0], u00), pka(A[1], u01)), pkmax(pka(A[2], u02), pka(A[3], u03)));
-  *M1o = pkmax(pkmax(pka(A[0], u10), pka(A[1], u11)), pkmax(pka(A[2], u12), pka(A[3], u13)));
+  *M0o = pkmax(pkmax(pka_sat(A[0], u00), pka_sat(A[1], u01)), pkmax(pka_sat(A[2], u02), pka_sat(A[3], u03)));
+  *M1o = pkmax(pkmax(pka_sat(A[0], u10), pka_sat(A[1], u11)), pkmax(pka_sat(A[2], u12), pka_sat(A[3], u13)));
   b[0] = pkmax(u00, u10); b[1] = pkmax(u01, u11); b[2] = pkmax(u02, u12); b[3] = pkmax(u03, u13);
-  const s2 n = b[0];
-  b[0] = pks_sel<0, 1, 0, 0>(b[0], n); b[1] = pks_sel<0, 1, 0, 0>(b[1], n); b[2] = pks_sel<0, 1, 0, 0>(b[2], n); b[3] = pks_sel<0, 1, 0, 0>(b[3], n);
+  if (NORM) {
+    const s2 n = b[0];
+    b[0] = pks_sel<0, 1, 0, 0>(b[0], n); b[1] = pks_sel<0, 1, 0, 0>(b[1], n); b[2] = pks_sel<0, 1, 0, 0>(b[2], n); b[3] = pks_sel<0, 1, 0, 0>(b[3], n);
+  }
 }
 // soft output of one step: extrinsic * 2 + hard decision (L = m1 - m0 in 32 bits)
 LSN_HD int16_t lsn_ext_one(s2 M0, s2 M1, s2 q)
@@ -152,7 +192,7 @@ LSN_HD s2 lsn_ext_two(s2 M0a, s2 M1a, s2 qa, s2 M0b, s2 M1b, s2 qb)
 {
 #ifdef __HIP_DEVICE_COMPILE__
   // Stated instruction by instruction, in ONE asm block.  Left to itself the compiler turns the sign mask and the hard decision into compare / select
-  // pairs per half and re-packs them with v_perm (21 instructions instead of 16); the maxima over the two halves of M land directly in the half of
+  // pairs per half and re-packs them with v_perm (21 instructions instead of 15); the maxima over the two halves of M land directly in the half of
   // their step (SDWA).  gfx940-class parts need a wait state between a VALU write with dst_sel != DWORD and a VALU read of that register, and the
   // compiler's hazard recogniser does not look inside inline asm: the order below keeps one instruction between every such pair.
   s2 r0, r1, r2, r3, out;
@@ -165,15 +205,14 @@ LSN_HD s2 lsn_ext_two(s2 M0a, s2 M1a, s2 qa, s2 M0b, s2 M1b, s2 qb)
       "v_pk_sub_i16 %3, %2, %3 clamp\n\t"               // r3 = x = L - lsa
       "v_pk_max_i16 %3, %3, %12\n\t"                    //      clamped to +- 2730
       "v_pk_min_i16 %3, %3, %13\n\t"
-      "v_pk_ashrrev_i16 %0, 15, %3 op_sel_hi:[0,1]\n\t" // r0 = -1 where x < 0
-      "v_and_b32 %0, %14, %0\n\t"                       //      3 where x < 0
+      "v_pk_lshrrev_b16 %0, 14, %3 op_sel_hi:[0,1]\n\t" // r0 = 3 where x < 0, else 0: the two top bits of a value in +- 2730 are its sign
       "v_pk_mad_u16 %0, %3, 3, %0 op_sel_hi:[1,0,1]\n\t" // r0 = t = 3 x + (x < 0 ? 3 : 0);  t >> 2 truncates 3 x / 4 towards zero
       "v_pk_max_i16 %1, %2, 0\n\t"                      // r1 = hard decision: min(max(L, 0), 1)
       "v_pk_min_i16 %1, %1, 1 op_sel_hi:[1,0]\n\t"
       "v_pk_ashrrev_i16 %0, 1, %0 op_sel_hi:[0,1]\n\t"  // (t >> 2) * 2 = (t >> 1) & ~1
-      "v_and_or_b32 %4, %0, %15, %1"
+      "v_and_or_b32 %4, %0, %14, %1"
       : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(out)
-      : "v"(M0a), "v"(M1a), "v"(M0b), "v"(M1b), "v"(qa), "v"(qb), "s"(0x05040100u), "s"(0xF556F556u), "s"(0x0AAA0AAAu), "s"(0x00030003u), "s"(0xFFFEFFFEu));
+      : "v"(M0a), "v"(M1a), "v"(M0b), "v"(M1b), "v"(qa), "v"(qb), "s"(0x05040100u), "s"(0xF556F556u), "s"(0x0AAA0AAAu), "s"(0xFFFEFFFEu));
   return out;
 #else
   const s2 m0a = pkmax(M0a, M0a.yx), m1a = pkmax(M1a, M1a.yx), m0b = pkmax(M0b, M0b.yx), m1b = pkmax(M1b, M1b.yx);
@@ -271,6 +310,9 @@ LSN_HD void lsn_operands2(uint32_t ws0, uint32_t ws1, uint32_t es0, uint32_t es1
   *g0 = lsn_perm((uint32_t)lsn_par_field<PF>(wp0), sum, 0x05040100u);
   *g1 = lsn_perm((uint32_t)lsn_par_field<PF>(wp1), sum, 0x05040302u);
 }
+
+// the same steps over a cycle of seven register layouts (no shuffles inside a full-length sub-block): generated, see tools/turbo_layouts.py
+#include "lsn_turbo_cyc.h"
 
 // Sub-block length (steps whose operands are fetched in one burst and whose alphas are kept in registers); even: the forward sweep
 // normalises every second step
@@ -392,31 +434,56 @@ LSN_HD void lsn_map_pass_lane(const TurboLds& m, const uint32_t* il, int nt, int
       for (int u = TB_S - 2; u >= 0; u -= 2)
         if (FULL || u < n) build2(tb, u);
       // recompute the alphas of this sub-block into registers.  Normalised every SECOND step (as in the forward sweep): the alphas in front of the
-      // odd steps carry the growth of one step (word-length argument at the top)
-#pragma unroll
-      for (int u = 0; u < TB_S; u++) {
-        if (FULL || u < n) {
+      // odd steps carry the growth of one step (word-length argument at the top).
+      // Full-length sub-block (round 6, last session): the alphas in front of step u are kept in register layout u mod 7 (lsn_turbo_cyc.h) - the forward step
+      // from layout L to L + 1 and the backward step from L + 1 to L need no shuffle -, the beta vector enters through one conversion from layout C and
+      // leaves step 0 in layout C again, normalised (check-points, window boundaries and the short last sub-block stay in layout C).
+      if constexpr (FULL) {
+        auto fwd1 = [&](auto uc) {
+          constexpr int u = decltype(uc)::value;
           A[u][0] = a[0]; A[u][1] = a[1]; A[u][2] = a[2]; A[u][3] = a[3];
-          if (u & 1) lsn_step_fwd_pk<true>(a, pk_s2(g[u])); else lsn_step_fwd_pk<false>(a, pk_s2(g[u]));
+          lsn_cyc_fwd<u % 7>(a, pk_s2(g[u]));
+          if (u & 1) {
+            const s2 n0 = a[0];
+            a[0] = pks_sel<0, 1, 0, 0>(a[0], n0); a[1] = pks_sel<0, 1, 0, 0>(a[1], n0); a[2] = pks_sel<0, 1, 0, 0>(a[2], n0); a[3] = pks_sel<0, 1, 0, 0>(a[3], n0);
+          }
+        };
+#define LSN_IC(n) std::integral_constant<int, n>{}
+        fwd1(LSN_IC(0)); fwd1(LSN_IC(1)); fwd1(LSN_IC(2)); fwd1(LSN_IC(3)); fwd1(LSN_IC(4)); fwd1(LSN_IC(5)); fwd1(LSN_IC(6)); fwd1(LSN_IC(7));
+        fwd1(LSN_IC(8)); fwd1(LSN_IC(9)); fwd1(LSN_IC(10)); fwd1(LSN_IC(11)); fwd1(LSN_IC(12)); fwd1(LSN_IC(13)); fwd1(LSN_IC(14)); fwd1(LSN_IC(15));
+        if (sb == nsb - 1) {
+          // (the caller wants a normalised vector in layout C: the next iteration starts a window from it)
+          lsn_cyc_to_c<TB_S % 7>(a);
+          const s2 nn = a[0];
+          for (int k = 0; k < 4; k++) a_end[k] = pks_sel<0, 1, 0, 0>(a[k], nn);
         }
-      }
-      if (sb == nsb - 1) {
-        // (the caller wants a normalised vector: the next iteration starts a window from it)
-        const s2 nn = a[0];
-        for (int k = 0; k < 4; k++) a_end[k] = pks_sel<0, 1, 0, 0>(a[k], nn);
-      }
-      // beta recursion + LLR + extrinsic
-      if (FULL) {
-#pragma unroll
-        for (int u = TB_S - 1; u >= 0; u -= 2) {
+        // beta recursion + LLR + extrinsic, two steps at a time: normalised behind the even step only
+        lsn_cyc_from_c<TB_S % 7>(b);
+        auto bwd2 = [&](auto uc) {
+          constexpr int u = decltype(uc)::value;   // odd
           s2 M0a, M1a, M0b, M1b;
-          lsn_step_bwd_pk(b, A[u], pk_s2(g[u]), &M0a, &M1a);
-          lsn_step_bwd_pk(b, A[u - 1], pk_s2(g[u - 1]), &M0b, &M1b);
+          lsn_cyc_bwd<u % 7, false>(b, A[u], pk_s2(g[u]), &M0a, &M1a);
+          lsn_cyc_bwd<(u - 1) % 7, true>(b, A[u - 1], pk_s2(g[u - 1]), &M0b, &M1b);
           const s2 e = lsn_ext_two(M0a, M1a, pk_s2(g[u]), M0b, M1b, pk_s2(g[u - 1]));
           m.ext[ext_index(tb, u)] = e.x;
           m.ext[ext_index(tb, u - 1)] = e.y;
-        }
+        };
+        bwd2(LSN_IC(15)); bwd2(LSN_IC(13)); bwd2(LSN_IC(11)); bwd2(LSN_IC(9)); bwd2(LSN_IC(7)); bwd2(LSN_IC(5)); bwd2(LSN_IC(3)); bwd2(LSN_IC(1));
+#undef LSN_IC
       } else {
+#pragma unroll
+        for (int u = 0; u < TB_S; u++) {
+          if (u < n) {
+            A[u][0] = a[0]; A[u][1] = a[1]; A[u][2] = a[2]; A[u][3] = a[3];
+            if (u & 1) lsn_step_fwd_pk<true>(a, pk_s2(g[u])); else lsn_step_fwd_pk<false>(a, pk_s2(g[u]));
+          }
+        }
+        if (sb == nsb - 1) {
+          // (the caller wants a normalised vector: the next iteration starts a window from it)
+          const s2 nn = a[0];
+          for (int k = 0; k < 4; k++) a_end[k] = pks_sel<0, 1, 0, 0>(a[k], nn);
+        }
+        // beta recursion + LLR + extrinsic
 #pragma unroll
         for (int u = TB_S - 1; u >= 0; u--) {
           if (u < n) {
