@@ -681,15 +681,29 @@ __global__ __launch_bounds__(NT) TB_WAVES_ATTR void k_turbo(const uint32_t* __re
     map_pass<false>(m, il, nt, lane, active, K, P, W, na1, nb1, bt1);
     map_pass<true>(m, il, nt, lane, active, K, P, W, na2, nb2, bt2);
     it++;
-    // CRC over all K decided bits == 0  <=>  data || parity divisible by g(x): Horner over the thread's own window,
-    // then weighting with x^((P-1-window) W) and an XOR reduction over the windows
+    // CRC over all K decided bits == 0  <=>  data || parity divisible by g(x).  The thread sums, over its own window, the weights x^(K-1-x) mod g of the
+    // positions whose decided bit is 1: it walks the window from its END, where the weight is cw, and multiplies the weight by x per step (rounds 1-5 ran a
+    // Horner scheme over the window and multiplied the result by cw - 24 more shift / reduce / add steps per thread and iteration).  The decided bits are read
+    // eight steps per burst: one LDS round trip per burst instead of one per step.  An XOR reduction over the windows follows.
     uint32_t rem = 0;
     if (active) {
-      for (int t = 0; t < W; t++) {
-        rem = (rem << 1) | ((uint32_t)m.ext[t * P + lane + m.bias] & 1u);
-        rem ^= (rem & 0x1000000u) ? poly : 0u;
+      uint32_t q = cw;
+      auto step = [&](uint32_t e) {
+        uint32_t mk;   // all ones when the decided bit is 1 (stated as the instruction: the compiler turns every C form of it into and / compare / select)
+        asm("v_bfe_i32 %0, %1, 0, 1" : "=v"(mk) : "v"(e));
+        rem ^= mk & q;
+        q <<= 1;
+        q ^= (q & 0x1000000u) ? poly : 0u;
+      };
+      int t = W - 1;
+      for (int k = W & 7; k > 0; k--, t--) step((uint32_t)m.ext[t * P + lane + m.bias]);   // (window lengths are 32 .. 95: the W mod 8 steps at the end first)
+      for (; t >= 7; t -= 8) {
+        uint32_t e[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) e[k] = (uint32_t)m.ext[(t - k) * P + lane + m.bias];
+#pragma unroll
+        for (int k = 0; k < 8; k++) step(e[k]);
       }
-      rem = mulmod24(rem, cw, poly);
     }
     ok = wg_xor(rem, (int16_t*)m.ckpt, lane, nt) == 0;
   }
@@ -701,10 +715,12 @@ __global__ __launch_bounds__(NT) TB_WAVES_ATTR void k_turbo(const uint32_t* __re
   const int per = (nout + nt - 1) / nt, j0 = lane * per, j1 = (j0 + per < nout) ? j0 + per : nout;
   uint32_t rema = 0;
   for (int j = j0; j < j1; j++) {
-    uint32_t byte = 0;
+    uint32_t byte = 0, e[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) e[q] = (uint32_t)m.ext[tr_idx(F + 8 * j + q, W, P, magicW) + m.bias];   // the eight reads of a byte in one burst
 #pragma unroll
     for (int q = 0; q < 8; q++) {
-      const uint32_t bit = (uint32_t)m.ext[tr_idx(F + 8 * j + q, W, P, magicW) + m.bias] & 1u;
+      const uint32_t bit = e[q] & 1u;
       byte = (byte << 1) | bit;
       rema = (rema << 1) | bit;
       rema ^= (rema & 0x1000000u) ? 0x1864CFBu : 0u;

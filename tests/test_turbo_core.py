@@ -42,3 +42,19 @@ def test_interleaver_table_offsets_cover_all_block_sizes():
     assert h.lsnh_turbo_il_offset(0) == off
     two = [k for k in ks if h.lsnh_turbo_two_wave_class(k)]
     assert min(two) == 3072 and set(two) == set(k for k in ks if k >= 3072)  # K = 3072 has 96 windows; every larger size needs either two waves or > 22 KiB of LDS
+
+
+def test_layout_cycle_header_is_what_the_generator_derives():
+    """lsn_turbo_cyc.h (the shuffle-free steps over seven register layouts) is generated: tools/turbo_layouts.py derives the cycle from the constituent code's
+    transitions, checks every step it emits against an eight-state reference, and must reproduce the committed header byte for byte."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("turbo_layouts", os.path.join(ROOT, "tools", "turbo_layouts.py"))
+    tl = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tl)
+    assert len(tl.T) == 7 and tl.T[0] == [(0, 4), (1, 5), (2, 6), (3, 7)]
+    for L in range(7):  # every state once per layout, state 0 in the low half of register 0 (the half the normalisation subtracts)
+        assert sorted(s for pr in tl.T[L] for s in pr) == list(range(8)) and tl.T[L][0][0] == 0
+        assert set(map(frozenset, tl.need(tl.T[L]))) == set(map(frozenset, tl.T[(L + 1) % 7]))   # the pairing the next step's beta vector must have
+    tl.check()
+    committed = open(os.path.join(ROOT, "ltesniffer_amd", "csrc", "kernels", "lsn_turbo_cyc.h")).read()
+    assert tl.emit() == committed
