@@ -351,17 +351,29 @@ LSN_HD void lsn_map_pass_lane(const TurboLds& m, const uint32_t* il, int nt, int
                               const s2* nii_a, const s2* nii_b, const s2* beta_tail, s2* a_end, s2* b_out)
 {
   const int lane = wl;
-  const int wlb = wl + m.bias;   // index of this window's column in the (possibly second) block's arrays
+  int wlb = wl + m.bias;   // index of this window's column in the (possibly second) block's arrays
+  // The LDS addresses of a sub-block are lane + a multiple of P.  The sub-block the backward pass starts with is the same in every pass, and the compiler computes
+  // its sixteen-odd address vectors once per kernel and keeps them alive across all iterations - beyond the 256 registers: 14 of them went to scratch memory and
+  // came back once per pass (5 MB of scratch write-back per launch).  Declaring the lane term opaque at the top of every sub-block keeps the addresses local
+  // to their sub-block (a few adds per sub-block instead of a spill).
+#ifdef __HIP_DEVICE_COMPILE__
+#define LSN_LOCAL_ADDR(x) asm volatile("" : "+v"(x))
+#else
+#define LSN_LOCAL_ADDR(x) (void)(x)
+#endif
   const uint32_t bias2 = (uint32_t)m.bias * 0x10001u;  // (addresses stay below 2^16: K + bias <= 2 * 2760)
   const int nsb = (W + TB_S - 1) / TB_S;
-  s2 a[4], b[4], a0[4];
-  if (wl == 0) {
-    a[0] = s2{0, (short)LSN_NEG_METRIC};
-    a[1] = a[2] = a[3] = s2{(short)LSN_NEG_METRIC, (short)LSN_NEG_METRIC};
-  } else {
-    for (int k = 0; k < 4; k++) a[k] = nii_a[k];
-  }
-  for (int k = 0; k < 4; k++) a0[k] = a[k];
+  s2 a[4], b[4];
+  // the window's first alpha vector: wanted again when the backward pass reaches sub-block 0 (read from the caller's registers a second time rather than kept)
+  auto a_start = [&]() {
+    if (wl == 0) {
+      a[0] = s2{0, (short)LSN_NEG_METRIC};
+      a[1] = a[2] = a[3] = s2{(short)LSN_NEG_METRIC, (short)LSN_NEG_METRIC};
+    } else {
+      for (int k = 0; k < 4; k++) a[k] = nii_a[k];
+    }
+  };
+  a_start();
   uint32_t nx[TB_S / 2];   // interleaver addresses (two steps per word) of the sub-block that comes next
   uint32_t cur[TB_S / 2];  // ... of the sub-block in hand
   const int wlast = (W - 1) >> 1;
@@ -388,6 +400,7 @@ LSN_HD void lsn_map_pass_lane(const TurboLds& m, const uint32_t* il, int nt, int
   };
   // ---- forward sweep over sub-blocks 0 .. nsb-2 (the last one is covered by the recompute below) ----
   for (int sb = 0; sb + 1 < nsb; sb++) {
+    LSN_LOCAL_ADDR(wlb);
     if (sb >= 1) lsn_ckpt_store(m.ckpt, nt, sb - 1, lane, a, m.cw, m.ch);
     const int tb = sb * TB_S;
     if (IL) {
@@ -413,10 +426,11 @@ LSN_HD void lsn_map_pass_lane(const TurboLds& m, const uint32_t* il, int nt, int
   // LDS index of the systematic / extrinsic value of step tb + u
   auto ext_index = [&](int tb, int u) { return IL ? (int)((u & 1) ? cur[u >> 1] >> 16 : cur[u >> 1] & 0xFFFFu) : (tb + u) * P + wlb; };
   for (int sb = nsb - 1; sb >= 0; sb--) {
+    LSN_LOCAL_ADDR(wlb);
     const int tb = sb * TB_S, n = (tb + TB_S < W) ? TB_S : W - tb;
     if (sb + 1 < nsb) {
       if (sb == 0) {
-        for (int k = 0; k < 4; k++) a[k] = a0[k];
+        a_start();
       } else {
         lsn_ckpt_load(m.ckpt, nt, sb - 1, lane, a, m.cw, m.ch);
       }

@@ -658,14 +658,21 @@ __global__ __launch_bounds__(NT) TB_WAVES_ATTR void k_turbo(const uint32_t* __re
   }
   tb_sync(nt);
   // ---- termination (36.212 5.1.3.2.2): tail[s*4 + j] = stream s at position K + j ----
-  s2 bt1[4], bt2[4];
-  {
+  // The two termination vectors (layout C) are wanted by ONE lane - the last window - at the turn of every pass: they live in LDS behind the check-point
+  // area(s), not in eight registers of every lane (round 6, last session: with the registers of the layout cycle the allocator had started to spill the
+  // values that live across passes - 5 MB of scratch write-back per launch)
+  s2* bt1 = (s2*)(m.ckpt + (paired ? 2u : 1u) * TB_CKPT_BYTES) + (paired ? 8u * wave : 0u);
+  s2* bt2 = bt1 + 4;
+  if (lane == 0) {
     const int *s4 = tail, *q1 = tail + 4, *q2 = tail + 8;
     int ts1[3] = {s4[0], q2[0], q1[1]}, tp1[3] = {q1[0], s4[1], q2[1]};
     int ts2[3] = {s4[2], q2[2], q1[3]}, tp2[3] = {q1[2], s4[3], q2[3]};
     int b8[8];
-    tail_beta(ts1, tp1, b8); lsn_pack_c(b8, bt1);
-    tail_beta(ts2, tp2, b8); lsn_pack_c(b8, bt2);
+    s2 v[4];
+    tail_beta(ts1, tp1, b8); lsn_pack_c(b8, v);
+    for (int k = 0; k < 4; k++) bt1[k] = v[k];
+    tail_beta(ts2, tp2, b8); lsn_pack_c(b8, v);
+    for (int k = 0; k < 4; k++) bt2[k] = v[k];
   }
   tb_sync(nt);  // scratch is dead from here on: the area becomes the check-point store
   const long long tc1 = TB_CLOCK();
@@ -737,7 +744,7 @@ __global__ __launch_bounds__(NT) TB_WAVES_ATTR void k_turbo(const uint32_t* __re
   }
 }
 
-size_t lsn_turbo_lds_bytes(uint32_t kmax) { return 6 * (size_t)kmax + 16 + TB_CKPT_BYTES; }
+size_t lsn_turbo_lds_bytes(uint32_t kmax) { return 6 * (size_t)kmax + 16 + TB_CKPT_BYTES + 64; }   // spp ext check-points termination vectors
 static size_t turbo_lds_bytes_nt(uint32_t kmax, int) { return lsn_turbo_lds_bytes(kmax); }
 
 // Classic form (uplink, HARQ re-decodes): cb[0 .. n128) in two-wavefront workgroups, cb[n128 .. n128 + n64) in one-wavefront workgroups; each range is
@@ -763,7 +770,7 @@ void lsn_launch_turbo_packed(const LsnCellDev& c, const LsnCbDev* cb, const uint
   auto fix = [](uint32_t k) { return ((k < 512 ? 512u : k) + 7u) & ~7u; };  // the scratch in the check-point area needs room
   if (!nsolo && !npair) return;
   const uint32_t ks = nsolo ? fix(kmax_solo) : 512u, kp = npair ? fix(kmax_pair) : 512u;
-  const size_t pair_lds = npair ? 12 * ((size_t)kp + 8) + 2 * TB_CKPT_BYTES : 0;   // spp0 spp1 ext0 ext1 ckpt0 ckpt1 (k_turbo)
+  const size_t pair_lds = npair ? 12 * ((size_t)kp + 8) + 2 * TB_CKPT_BYTES + 64 : 0;   // spp0 spp1 ext0 ext1 ckpt0 ckpt1 bt0 bt1 (k_turbo)
   const size_t lds = std::max(nsolo ? turbo_lds_bytes_nt(ks, 128) : (size_t)0, pair_lds);
   LSN_LAUNCH(k_turbo<128>, dim3(nsolo + (npair + 1) / 2), dim3(128), lds, s, c.crc_tab_a, c.crc_tab_b, c.turbo_il, cb, spp, payload, res, ks, nsolo, nsolo + npair, kp);
 }
