@@ -298,11 +298,12 @@ def main():
         except Exception as ex:
             golden_note = "no cached oracle stream: %s" % str(ex)[:120]
 
-    def block_check(blocks, first_block):
+    def block_check(blocks, first_block, gold=None):
         """product blocks [(digest, nrec)] against the oracle's blocks from stream position first_block on -> (covered, mismatching blocks, record diff)"""
-        if golden is None:
+        gold = gold or golden
+        if gold is None:
             return 0, None, None
-        ob = golden["blocks"]
+        ob = gold["blocks"]
         n = max(0, min(len(blocks), len(ob) - first_block))
         bad, rd = 0, 0
         for j in range(n):
@@ -484,7 +485,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_legs:
         legs = {"pcie_link": _pcie_link(local)}
 
-        def two_passes(name, make_phy, run_pass, extra=None, pcap_path=None):
+        def two_passes(name, make_phy, run_pass, extra=None, pcap_path=None, gold=None, sf_bytes=sf_bytes):
             lp = la.PcapWriter(pcap_path)   # pcap_path: the records go to a FILE like the reference's (PcapWriter.cc:75-118), digested on the way
             if pcap_path is None:
                 lp.set_store(False)
@@ -497,7 +498,7 @@ def main():
                 t = time.perf_counter()
                 done = run_pass(lphy, (tti0 + k * nsf) % 10240)
                 dtl = time.perf_counter() - t
-                cov, bad, rd = block_check(lp.block_digests()[:done // BLOCK], k * nsf // BLOCK)
+                cov, bad, rd = block_check(lp.block_digests()[:done // BLOCK], k * nsf // BLOCK, gold)
                 out["pass%d_%s" % (k + 1, "cold" if k == 0 else "warm")] = {   # (the third consecutive pass is the steady state: buffers grown, tables learnt)
                     "subframes_per_s": round(done / dtl, 1), "GB_per_s": round(done * sf_bytes / dtl / 1e9, 2), "x_realtime": round(done / dtl / 1000.0, 1),
                     "subframes": int(done), "records": lp.nof_records(), "oracle_blocks_compared": cov, "oracle_blocks_mismatching": bad,
@@ -561,6 +562,38 @@ def main():
                            {"storage": "tmpfs (/dev/shm) = page cache, read once after it was written (%.2f s, outside the timed passes); pread threads -> pinned blocks -> PCIe" % t_pre})
             finally:
                 os.remove(path)
+            # The same capture as a 16-bit recording (lsn_file_cfg_t.sample_format = LSN_FILE_SC16: int16 I/Q pairs, what the radio sends over its link;
+            # an extension - the reference's file mode opens cf32 only): half the bytes per subframe cross PCIe, the GPU converts.  Gated on its OWN
+            # oracle stream (tests/golden/cfg3_stream_sc16_oracle.json: the oracle walked the dequantised subframes, tools/make_cfg3_golden.py --sc16).
+            try:
+                from make_cfg3_golden import sc16_capture
+                q16, lsb = sc16_capture(iq)
+                g16, note16 = None, None
+                try:
+                    g16 = json.load(open(os.path.join(ROOT, "tests", "golden", "cfg3_stream_sc16_oracle.json")))
+                    if capture_hash(q16)[0] != g16["capture_xxh3_64"] or g16["stream"]["tti0"] != tti0 or g16["stream"]["block_subframes"] != BLOCK:
+                        g16, note16 = None, "the 16-bit recording made on this host is not the one the cached oracle stream was made from"
+                except Exception as ex:
+                    g16, note16 = None, "no cached oracle stream: %s" % str(ex)[:120]
+                path = "/dev/shm/lsn_bench_capture_%d.sc16" % os.getpid()
+                with open(path, "wb") as f:
+                    for a in range(0, nsf, 1000):
+                        np.ascontiguousarray(np.transpose(q16[a:a + 1000], (0, 2, 1, 3))).tofile(f)
+                del q16
+                with open(path, "rb", buffering=0) as f:
+                    buf = bytearray(64 << 20)
+                    while f.readinto(buf):
+                        pass
+                try:
+                    two_passes("file_replay_sc16", file_phy,
+                               lambda ph, t: ph.process_file(path, start_tti=t, update_meta_period=META_PERIOD, sample_format=la.FILE_SC16, sample_scale=lsb),
+                               {"sample_format": "int16 I/Q pairs, one LSB = %g (a power of two: the conversion on the GPU is exact)" % lsb, "bytes_per_subframe": sf_bytes // 2,
+                                "oracle_stream": "tests/golden/cfg3_stream_sc16_oracle.json (its own: the oracle on the dequantised subframes)", "golden_note": note16},
+                               gold=g16 or {"blocks": []}, sf_bytes=sf_bytes // 2)
+                finally:
+                    os.remove(path)
+            except Exception as ex:
+                legs["file_replay_sc16"] = {"error": str(ex)[:300]}
         except Exception as ex:
             legs["error"] = str(ex)[:300]
 
@@ -765,7 +798,7 @@ def main():
         # the last 1.5 kB of the line (what a tail keeps): every headline figure with its gate
         out["summary"] = {"value_resident": round(value, 1), "pcap_diff": pcap_diff, "timed_subframes": total_sf, "n_gpus": out["n_gpus"], "dist": dist_echo,
                           "first_h2d_to_last_pdu": {k: {"cold_warm_warm": [leg_rate(k, w) for w in ("pass1_cold", "pass2_warm", "pass3_warm")], "pcap_diff": leg_diffs(k)}
-                                                    for k in ("host_pinned", "host_pinned_pcap_to_file", "host_pageable", "worker_pool_1_producer_thread", "worker_pool_4_producer_threads", "file_replay")
+                                                    for k in ("host_pinned", "host_pinned_pcap_to_file", "host_pageable", "worker_pool_1_producer_thread", "worker_pool_4_producer_threads", "file_replay", "file_replay_sc16")
                                                     if legs and k in legs},
                           "other_configs": {k: [v.get("subframes_per_s"), v.get("pcap_diff")] for k, v in (legs or {}).items() if isinstance(v, dict) and "what" in v},
                           "roofline_frac": out["roofline"]["frac"], "cpu_baseline": [cpu.get("value"), (cpu.get("configs0") or {}).get("value")] if cpu else None,

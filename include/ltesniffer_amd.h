@@ -258,7 +258,7 @@ int lsn_cell_search(int device, const void* iq, int iq_on_device, uint64_t nof_s
 /* ---- IQ capture file replay ----
  * Replaces the file source of the reference's file mode: srsran_ue_sync_init_file_multi(&ue_sync, nof_prb, file, offset_time,
  * offset_freq, nof_rx_antennas) + one srsran_ue_sync_zerocopy per subframe (LTESniffer_Core.cc:252-258,365; options -O / -o,
- * ArgManager.cc:144-149).  File format: complex float32, antennas interleaved sample by sample, subframe aligned after the
+ * ArgManager.cc:144-149).  File format: complex float32 (or integer pairs, sample_format below), antennas interleaved sample by sample, subframe aligned after the
  * offset (file mode has no PSS tracking); every 15*N samples per antenna are one subframe, counted from start_tti.
  * offset_freq_hz != 0: every subframe is multiplied by exp(-j 2 pi offset_freq n / fs) with n restarting per subframe.
  * The SFN the reference takes from the MIB (LTESniffer_Core.cc:382-420) is an input here (start_tti).
@@ -266,10 +266,20 @@ int lsn_cell_search(int device, const void* iq, int iq_on_device, uint64_t nof_s
  * (LSN_FILE_SLOTS, default 8, blocks in flight): LSN_FILE_READERS (default 12) threads pread() a block into a pinned buffer;
  * LSN_FILE_MMAP=1 page-locks the blocks in a mapping of the file instead (no CPU copy; slower on the boxes measured).  The block
  * buffers stay allocated between calls, so the first call pays ~0.15 s of allocation. */
+/* sample_format: LSN_FILE_CF32 is the reference's (srsran_filesource_init(.., SRSRAN_COMPLEX_FLOAT_BIN) behind srsran_ue_sync_init_file_multi).
+ * LSN_FILE_SC16 / LSN_FILE_SC8 are an extension: integer I/Q pairs (int16 / int8, little endian, I first) as the radio delivers them over its
+ * link and as srsRAN's SRSRAN_COMPLEX_SHORT_BIN files hold them; the GPU converts, sample = (float)integer * sample_scale (exact for a power of
+ * two, one float rounding otherwise), everything behind that is the cf32 path.  A subframe is 245 760 B instead of 491 520 B at 20 MHz / 2 antennas,
+ * so a host link that feeds 108 k subframes/s of cf32 feeds twice that of sc16. */
+#define LSN_FILE_CF32 0u
+#define LSN_FILE_SC16 1u
+#define LSN_FILE_SC8 2u
 typedef struct {
   uint32_t nof_antennas;        /* interleaved antennas in the file = nof_rx_antennas of the Phy */
   int64_t offset_time_samples;  /* -O: samples (per antenna) skipped at the start */
   float offset_freq_hz;         /* -o: frequency offset correction */
+  uint32_t sample_format;       /* LSN_FILE_CF32 (0, the reference's), LSN_FILE_SC16, LSN_FILE_SC8; anything else is refused */
+  float sample_scale;           /* integer formats: value of one LSB; 0 = full scale +-1 (1/32768, 1/128); ignored for cf32 */
 } lsn_file_cfg_t;
 int lsn_phy_process_file(lsn_phy_t* phy, const char* path, const lsn_file_cfg_t* cfg, uint32_t start_tti, uint64_t max_subframes /* 0 = to the end */,
                          uint32_t update_meta_period, uint64_t* subframes_done);

@@ -81,7 +81,11 @@ class CellSearch(C.Structure):
 
 
 class FileCfg(C.Structure):
-    _fields_ = [("nof_antennas", C.c_uint32), ("offset_time_samples", C.c_int64), ("offset_freq_hz", C.c_float)]
+    _fields_ = [("nof_antennas", C.c_uint32), ("offset_time_samples", C.c_int64), ("offset_freq_hz", C.c_float), ("sample_format", C.c_uint32),
+                ("sample_scale", C.c_float)]
+
+
+FILE_CF32, FILE_SC16, FILE_SC8 = 0, 1, 2
 
 
 class ApiEvent(C.Structure):
@@ -530,10 +534,10 @@ class Phy:
         """reserve the file source's block buffers ahead of the first replay (lsn_phy_prepare_file)"""
         _check(lib().lsn_phy_prepare_file(self._h, self.nof_rx_antennas), "prepare_file")
 
-    def process_file(self, path, start_tti=0, offset_time=0, offset_freq=0.0, max_subframes=0, update_meta_period=0):
+    def process_file(self, path, start_tti=0, offset_time=0, offset_freq=0.0, max_subframes=0, update_meta_period=0, sample_format=FILE_CF32, sample_scale=0.0):
         """file mode of the reference (-i file -O offset_time -o offset_freq): replay a cf32 capture (antennas interleaved per sample);
-        returns the number of subframes processed"""
-        fc = FileCfg(self.nof_rx_antennas, int(offset_time), float(offset_freq))
+        sample_format FILE_SC16 / FILE_SC8: integer I/Q pairs, one LSB = sample_scale (0: full scale +-1); returns the number of subframes processed"""
+        fc = FileCfg(self.nof_rx_antennas, int(offset_time), float(offset_freq), int(sample_format), float(sample_scale))
         done = C.c_uint64(0)
         _check(lib().lsn_phy_process_file(self._h, os.fsencode(path), C.byref(fc), start_tti if start_tti == TTI_FROM_MIB else start_tti % 10240, max_subframes, update_meta_period, C.byref(done)),
                "process_file")

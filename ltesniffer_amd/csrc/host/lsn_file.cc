@@ -1,6 +1,6 @@
 // lsn_file.cc - replay of an IQ capture file through the engine: the file source of the reference's file mode
 // (srsran_ue_sync_init_file_multi + srsran_ue_sync_zerocopy, /root/reference/src/src/LTESniffer_Core.cc:252-258,365;
-// options -O / -o, ArgManager.cc:144-149).  cf32 samples, antennas interleaved sample by sample; `offset_time` samples per
+// options -O / -o, ArgManager.cc:144-149).  cf32 samples (or int16 / int8 pairs: lsn_file_cfg_t.sample_format), antennas interleaved sample by sample; `offset_time` samples per
 // antenna are skipped once; the stream is taken as subframe aligned (no PSS tracking in file mode), the subframe counter
 // starts at start_tti; a non-zero `offset_freq` rotates every subframe by exp(-j 2 pi f n / fs), n restarting per subframe.
 // A reader thread hands blocks of the file to the GPU and runs k_file_unpack on its own stream while the engine processes the
@@ -78,17 +78,21 @@ int Engine::processFile(const char* path, const lsn_file_cfg_t& fc, uint32_t sta
 {
   if (subframes_done) *subframes_done = 0;
   if (!cell_set) return LSN_ERROR;
-  if (!path || fc.nof_antennas != cd.iq_nant || fc.offset_time_samples < 0) return LSN_ERROR_INVALID_INPUTS;
+  if (!path || fc.nof_antennas != cd.iq_nant || fc.offset_time_samples < 0 || fc.sample_format > LSN_FILE_SC8) return LSN_ERROR_INVALID_INPUTS;
+  if (fc.sample_format != LSN_FILE_CF32 && !(fc.sample_scale >= 0.0f && fc.sample_scale < INFINITY)) return LSN_ERROR_INVALID_INPUTS;
   const int fd = open(path, O_RDONLY);
   if (fd < 0) return LSN_ERROR_INVALID_INPUTS;
   struct stat sb;
   if (fstat(fd, &sb)) { close(fd); return LSN_ERROR_INVALID_INPUTS; }
-  const uint32_t nant = fc.nof_antennas, sflen = cd.sflen;
-  const size_t sf_bytes = (size_t)sflen * nant * sizeof(cf32);
+  const uint32_t nant = fc.nof_antennas, sflen = cd.sflen, fmt = fc.sample_format;
+  // bytes of one complex sample in the file; the block buffers are sized for cf32, the widest
+  const size_t smp_bytes = fmt == LSN_FILE_SC16 ? 4 : fmt == LSN_FILE_SC8 ? 2 : sizeof(cf32);
+  const float smp_scale = fmt == LSN_FILE_CF32 ? 1.0f : fc.sample_scale != 0.0f ? fc.sample_scale : fmt == LSN_FILE_SC16 ? 1.0f / 32768.0f : 1.0f / 128.0f;
+  const size_t sf_bytes = (size_t)sflen * nant * smp_bytes;
   uint32_t blk, nrd;  // subframes per block, page-touch / pread threads per block
   int NSLOT;          // blocks in flight (round 2 held eight until their chunks were written - and paid 8 x 393 MB of pinned allocation on the first call)
   file_geometry(blk, nrd, NSLOT);
-  const uint64_t file_off0 = (uint64_t)fc.offset_time_samples * nant * sizeof(cf32);
+  const uint64_t file_off0 = (uint64_t)fc.offset_time_samples * nant * smp_bytes;
   const uint64_t sf_in_file = (uint64_t)sb.st_size > file_off0 ? ((uint64_t)sb.st_size - file_off0) / sf_bytes : 0;  // complete subframes only
   constexpr int NSLOT_MAX = 8;
   const bool fdebug = getenv("LSN_FILE_DEBUG") != nullptr;
@@ -142,7 +146,7 @@ int Engine::processFile(const char* path, const lsn_file_cfg_t& fc, uint32_t sta
         if (pread(fd, one.data(), sf_bytes, (off_t)(file_off0 + i * sf_bytes)) != (ssize_t)sf_bytes) break;
         HIP_CHECK(hipMemcpyAsync(slot[0].d_raw, one.data(), sf_bytes, hipMemcpyHostToDevice, st));
         HIP_CHECK(hipStreamSynchronize(st));
-        lsn_launch_file_unpack(slot[0].d_raw, d_rot, sflen, nant, slot[0].d_iq, 1, st);
+        lsn_launch_file_unpack(slot[0].d_raw, fmt, smp_scale, d_rot, sflen, nant, slot[0].d_iq, 1, st);
         HIP_CHECK(hipStreamSynchronize(st));
         lsn_mib_t mib;
         const int r = mibDecode(slot[0].d_iq, true, &mib, nullptr);
@@ -217,7 +221,7 @@ int Engine::processFile(const char* path, const lsn_file_cfg_t& fc, uint32_t sta
             // the copy and the de-interleave are only QUEUED here (stream st); the submit below is ordered behind them on the device, so
             // the reader goes straight on to the next block while this one crosses PCIe
             HIP_CHECK(hipMemcpyAsync(s.d_raw, src, got * sf_bytes, hipMemcpyHostToDevice, st));
-            lsn_launch_file_unpack(s.d_raw, d_rot, sflen, nant, s.d_iq, (uint32_t)got, st);
+            lsn_launch_file_unpack(s.d_raw, fmt, smp_scale, d_rot, sflen, nant, s.d_iq, (uint32_t)got, st);
             pos += got;
           }
           left -= got;

@@ -169,7 +169,7 @@ void lsn_launch_viterbi_block(const LsnCellDev& c, const float* llr, const float
 void lsn_launch_rb_power(const LsnCellDev& c, const float* rbp_part, float* rbp, uint32_t nsf, hipStream_t s);
 void lsn_launch_ul_fft(const LsnCellDev& c, const cf32* iq, uint32_t nant, uint32_t ant, cf32* grid, uint32_t nsf, hipStream_t s);
 void lsn_launch_pbch(const LsnCellDev& c, const cf32* grid, const cf32* ce, const LsnChest* ch, float* llr5, LsnCand* out4, hipStream_t s);
-void lsn_launch_file_unpack(const cf32* raw, const cf32* rot, uint32_t sflen, uint32_t nant, cf32* out, uint32_t nsf, hipStream_t s);
+void lsn_launch_file_unpack(const void* raw, uint32_t fmt /* LSN_FILE_* */, float scale, const cf32* rot, uint32_t sflen, uint32_t nant, cf32* out, uint32_t nsf, hipStream_t s);
 void lsn_launch_prach(const cf32* iq, const uint64_t* occ_off, uint32_t nocc, const cf32* W, const cf32* D, const cf32* V, int N12, int Ncp, int b0,
                       int nroots, int ncs, int nwin, cf32* Y, float* corr, float* out, hipStream_t s);
 void lsn_launch_pusch_chest(const LsnCellDev& c, const LsnUlGrantDev* g, const cf32* grid, cf32* hs, float* stat, uint32_t ngrants, hipStream_t s);

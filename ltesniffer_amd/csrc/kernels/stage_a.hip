@@ -959,14 +959,28 @@ void lsn_launch_rb_power(const LsnCellDev& c, const float* part, float* rbp, uin
 
 // ------------------------------------------------------------------------------------------------ IQ capture file source
 // srsran_ue_sync_zerocopy in file mode (LTESniffer_Core.cc:365): de-interleave the antennas of a block of raw file samples
-// ([subframe][sample][antenna] cf32) into the engine's [subframe][antenna][sample] layout and, with a frequency offset,
+// ([subframe][sample][antenna]) into the engine's [subframe][antenna][sample] cf32 layout and, with a frequency offset,
 // multiply every subframe by rot[n] = exp(-j 2 pi offset_freq n / fs) (the phase restarts in every subframe).  HBM-bound copy.
-__global__ __launch_bounds__(256) void k_file_unpack(const cf32* __restrict__ raw, const cf32* __restrict__ rot, uint32_t sflen, uint32_t nant,
-                                                     cf32* __restrict__ out)
+// FMT: LSN_FILE_CF32 (the reference's file format), LSN_FILE_SC16 / LSN_FILE_SC8 - integer I/Q pairs as the radio sends them over its
+// link (srsRAN's SRSRAN_COMPLEX_SHORT_BIN file type), x = (float)integer * scale (the conversion is exact, the product rounds once):
+// half / a quarter of the bytes per subframe cross PCIe.
+template <int FMT>
+__global__ __launch_bounds__(256) void k_file_unpack(const void* __restrict__ raw, const cf32* __restrict__ rot, uint32_t sflen, uint32_t nant,
+                                                     float scale, cf32* __restrict__ out)
 {
   const uint32_t n = blockIdx.x * 256 + threadIdx.x, a = blockIdx.y, sf = blockIdx.z;
   if (n >= sflen) return;
-  cf32 x = raw[((size_t)sf * sflen + n) * nant + a];
+  const size_t src = ((size_t)sf * sflen + n) * nant + a;
+  cf32 x;
+  if (FMT == 1) {
+    const short2 q = ((const short2*)raw)[src];
+    x.r = (float)q.x * scale; x.i = (float)q.y * scale;
+  } else if (FMT == 2) {
+    const char2 q = ((const char2*)raw)[src];
+    x.r = (float)q.x * scale; x.i = (float)q.y * scale;
+  } else {
+    x = ((const cf32*)raw)[src];
+  }
   if (rot) {
     const cf32 w = rot[n];
     cf32 y; y.r = x.r * w.r - x.i * w.i; y.i = x.r * w.i + x.i * w.r;
@@ -974,10 +988,13 @@ __global__ __launch_bounds__(256) void k_file_unpack(const cf32* __restrict__ ra
   }
   out[((size_t)sf * nant + a) * sflen + n] = x;
 }
-void lsn_launch_file_unpack(const cf32* raw, const cf32* rot, uint32_t sflen, uint32_t nant, cf32* out, uint32_t nsf, hipStream_t s)
+void lsn_launch_file_unpack(const void* raw, uint32_t fmt, float scale, const cf32* rot, uint32_t sflen, uint32_t nant, cf32* out, uint32_t nsf, hipStream_t s)
 {
   if (!nsf) return;
-  LSN_LAUNCH(k_file_unpack, dim3((sflen + 255) / 256, nant, nsf), dim3(256), 0, s, raw, rot, sflen, nant, out);
+  const dim3 g((sflen + 255) / 256, nant, nsf);
+  if (fmt == 1) LSN_LAUNCH(k_file_unpack<1>, g, dim3(256), 0, s, raw, rot, sflen, nant, scale, out);
+  else if (fmt == 2) LSN_LAUNCH(k_file_unpack<2>, g, dim3(256), 0, s, raw, rot, sflen, nant, scale, out);
+  else LSN_LAUNCH(k_file_unpack<0>, g, dim3(256), 0, s, raw, rot, sflen, nant, scale, out);
 }
 
 // ------------------------------------------------------------------------------------------------ descriptor upload (see lsn_dev.h)

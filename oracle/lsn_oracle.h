@@ -283,6 +283,8 @@ int o_cell_search(const ocf_t* x, uint64_t nsamples, uint32_t nof_prb, const o_s
 
 /* ---------- IQ capture file source (o_file.c) ---------- */
 long o_file_read(const char* path, uint32_t nof_prb, uint32_t nant, long offset_time, float offset_freq, uint32_t first_sf, uint32_t nsf, ocf_t* out);
+long o_file_read_fmt(const char* path, uint32_t nof_prb, uint32_t nant, long offset_time, float offset_freq, uint32_t first_sf, uint32_t nsf,
+                     uint32_t fmt /* 0 cf32, 1 int16 pairs, 2 int8 pairs */, float scale /* one LSB; 0 = full scale +-1 */, ocf_t* out);
 
 /* ---------- uplink: PRACH detection (o_prach.c) ---------- */
 typedef struct {

@@ -49,6 +49,24 @@ def capture_hash(iq, step=1000):
     return h.hexdigest(), parts
 
 
+def sc16_capture(iq, step=1000):
+    """the capture as a 16-bit recording (lsn_file_cfg_t.sample_format = LSN_FILE_SC16): int16 I/Q pairs [nsf, antennas, sf_len, 2] at the largest
+    power-of-two gain that keeps the peak inside 98 % of full scale -> (integers, value of one LSB)"""
+    import numpy as np
+    peak = max(float(max(np.abs(iq[a:a + step].real).max(), np.abs(iq[a:a + step].imag).max())) for a in range(0, iq.shape[0], step))
+    gain = 2.0 ** np.floor(np.log2(0.98 * 32767 / peak))
+    q = np.empty(iq.shape + (2,), dtype=np.int16)
+    for a in range(0, iq.shape[0], step):
+        q[a:a + step] = np.rint(iq[a:a + step].view(np.float32).reshape(iq[a:a + step].shape + (2,)) * np.float32(gain)).astype(np.int16)
+    return q, float(1.0 / gain)
+
+
+def sc16_subframes(q, lsb):
+    """what the file source makes of the recording: (float)integer * lsb, complex64 [n, antennas, sf_len]"""
+    import numpy as np
+    return np.ascontiguousarray(q.astype(np.float32) * np.float32(lsb)).view(np.complex64)[..., 0]
+
+
 def source_hash():
     """what the cached stream depends on: the oracle, the tables, the transmitter (a change there means: run this tool again)"""
     h = hashlib.sha256()
@@ -65,6 +83,8 @@ def main():
     ap.add_argument("--subframes", type=int, default=100000)
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden", "cfg3_stream_oracle.json"))
     ap.add_argument("--threads", type=int, default=None)
+    ap.add_argument("--sc16", action="store_true", help="the stream of the capture recorded as int16 pairs (bench.py's file_replay_sc16 leg); "
+                    "--out tests/golden/cfg3_stream_sc16_oracle.json --subframes 60000")
     args = ap.parse_args()
     import ctypes as C
     import ltesniffer_amd as la
@@ -77,6 +97,19 @@ def main():
     tti0, iq = gen_capture(sc, nsf, threads=args.threads)
     chash, cparts = capture_hash(iq)
     print("capture: %d subframes in %.0f s, xxh3 %s" % (nsf, time.time() - t, chash), flush=True)
+    extra = {}
+    if args.sc16:
+        q, lsb = sc16_capture(iq)
+        del iq
+        qhash, cparts = capture_hash(q)
+        extra = {"sample_format": "sc16", "lsb": lsb, "cf32_capture_xxh3_64": chash}
+        chash = qhash
+        print("as a 16-bit recording: one LSB = %g, xxh3 %s" % (lsb, chash), flush=True)
+
+        class _Deq:   # the oracle walks what the file source delivers: (float)integer * lsb
+            def __getitem__(self, i):
+                return sc16_subframes(q[i:i + 1], lsb)[0]
+        iq = _Deq()
 
     ow = OracleWorker(sc["nof_prb"], sc["nof_ports"], sc["cell_id"], sc["nof_rx"], sc["phich_ng_x6"])
     w = la.PcapWriter(None)           # the product's writer, used here as the hash function over the ORACLE's records
@@ -101,18 +134,19 @@ def main():
             if (i + 1) % (10 * blk) == 0:
                 dt = time.time() - t
                 print("oracle: %d / %d subframes, %.1f sf/s, %d records" % (i + 1, total, (i + 1) / dt, w.nof_records()), flush=True)
-                _save(args.out, sc, nsf, blk, meta, tti0, chash, cparts, w, i + 1)
-    _save(args.out, sc, nsf, blk, meta, tti0, chash, cparts, w, total)
+                _save(args.out, sc, nsf, blk, meta, tti0, chash, cparts, w, i + 1, extra)
+    _save(args.out, sc, nsf, blk, meta, tti0, chash, cparts, w, total, extra)
     print("wrote", args.out)
 
 
-def _save(path, sc, nsf, blk, meta, tti0, chash, cparts, w, done):
+def _save(path, sc, nsf, blk, meta, tti0, chash, cparts, w, done, extra=None):
     blocks = w.block_digests()[:done // blk]
     out = {"stream": {"config": "cfg3", "seed": SEED, "distinct_subframes": nsf, "block_subframes": blk, "meta_period": meta, "tti0": tti0,
                       "scenario": sc},
            "capture_xxh3_64": chash, "capture_xxh3_64_per_1000": cparts, "source_hash": source_hash(),
            "oracle_subframes": done, "oracle_records": sum(c for _, c in blocks),
            "blocks": [["%016x" % d, c] for d, c in blocks]}
+    out.update(extra or {})
     tmp = path + ".tmp"
     json.dump(out, open(tmp, "w"))
     os.replace(tmp, path)
