@@ -67,3 +67,35 @@ def test_cached_oracle_stream_matches_todays_sources():
         w.write(dict(tti=(fs >> 4) * 10 + (fs & 15), rnti=(c[4] << 8) | c[5], direction=c[1], rnti_type=c[2], crc_ok=c[13]), r["pdu"])
     got = [["%016x" % d, n] for d, n in w.block_digests()[:nb]]
     assert got == g["blocks"][:nb], "oracle / tables / transmitter changed the stream: run tools/make_cfg3_golden.py again"
+
+
+GOLDEN_SC16 = os.path.join(ROOT, "tests", "golden", "cfg3_stream_sc16_oracle.json")
+
+
+@pytest.mark.skipif(not os.path.exists(GOLDEN_SC16), reason="no cached oracle stream of the 16-bit recording (tools/make_cfg3_golden.py --sc16)")
+def test_cached_sc16_oracle_stream_matches_todays_sources():
+    """the stream behind bench.py's file_replay_sc16 leg: the same capture recorded as int16 pairs, the oracle on what the file source makes of
+    them ((float)integer * lsb).  The head of the recording quantises to the cached bytes and the oracle reproduces the first two cached blocks."""
+    g = json.load(open(GOLDEN_SC16))
+    sc, nsf, blk, meta = mg.cfg3_stream()
+    assert g["sample_format"] == "sc16" and g["stream"]["distinct_subframes"] == nsf and g["stream"]["block_subframes"] == blk and g["stream"]["scenario"] == sc
+    assert g["oracle_subframes"] >= 3 * nsf and len(g["blocks"]) == g["oracle_subframes"] // blk   # the leg's three passes
+    assert g["cf32_capture_xxh3_64"] == json.load(open(GOLDEN))["capture_xxh3_64"]               # made from the headline's capture
+    lsb = g["lsb"]
+    assert np.log2(lsb) == np.round(np.log2(lsb))                                                # a power of two: the conversion is exact
+    tti0, iq = gen_capture(sc, 1000)
+    q, lsb2 = mg.sc16_capture(iq, gain=1.0 / lsb)
+    assert lsb2 == lsb and np.abs(q).max() <= int(0.98 * 32767) + 1
+    assert mg.capture_hash(q)[1][0] == g["capture_xxh3_64_per_1000"][0]
+    nb = 2
+    sub = mg.sc16_subframes(q[:nb * blk], lsb)
+    assert sub.dtype == np.complex64 and np.abs(sub - iq[:nb * blk]).max() <= 0.71 * lsb
+    _, _, recs = run_oracle(sc, tti0, sub, update_meta_period=meta, taps=False)
+    w = la.PcapWriter(None)
+    w.set_digest_blocks(blk, tti0)
+    for r in recs:
+        c = r["ctx"]
+        fs = (c[10] << 8) | c[11]
+        w.write(dict(tti=(fs >> 4) * 10 + (fs & 15), rnti=(c[4] << 8) | c[5], direction=c[1], rnti_type=c[2], crc_ok=c[13]), r["pdu"])
+    got = [["%016x" % d, n] for d, n in w.block_digests()[:nb]]
+    assert got == g["blocks"][:nb], "oracle / tables / transmitter changed the stream: run tools/make_cfg3_golden.py --sc16 again"

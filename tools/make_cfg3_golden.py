@@ -49,12 +49,13 @@ def capture_hash(iq, step=1000):
     return h.hexdigest(), parts
 
 
-def sc16_capture(iq, step=1000):
+def sc16_capture(iq, step=1000, gain=None):
     """the capture as a 16-bit recording (lsn_file_cfg_t.sample_format = LSN_FILE_SC16): int16 I/Q pairs [nsf, antennas, sf_len, 2] at the largest
-    power-of-two gain that keeps the peak inside 98 % of full scale -> (integers, value of one LSB)"""
+    power-of-two gain that keeps the peak inside 98 % of full scale (or at `gain`) -> (integers, value of one LSB)"""
     import numpy as np
-    peak = max(float(max(np.abs(iq[a:a + step].real).max(), np.abs(iq[a:a + step].imag).max())) for a in range(0, iq.shape[0], step))
-    gain = 2.0 ** np.floor(np.log2(0.98 * 32767 / peak))
+    if gain is None:
+        peak = max(float(max(np.abs(iq[a:a + step].real).max(), np.abs(iq[a:a + step].imag).max())) for a in range(0, iq.shape[0], step))
+        gain = 2.0 ** np.floor(np.log2(0.98 * 32767 / peak))
     q = np.empty(iq.shape + (2,), dtype=np.int16)
     for a in range(0, iq.shape[0], step):
         q[a:a + step] = np.rint(iq[a:a + step].view(np.float32).reshape(iq[a:a + step].shape + (2,)) * np.float32(gain)).astype(np.int16)
