@@ -579,7 +579,15 @@ def main():
                 with open(path, "wb") as f:
                     for a in range(0, nsf, 1000):
                         np.ascontiguousarray(np.transpose(q16[a:a + 1000], (0, 2, 1, 3))).tofile(f)
+                # ... and in pinned host buffers (lsn_phy_process_host_int: what a radio driver delivers when asked not to convert), same stream, same gate
+                hq = torch.from_numpy(q16).pin_memory()
                 del q16
+                two_passes("host_pinned_sc16", lambda w: la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=lbatch, device=local, pcapwriter=w),
+                           lambda ph, t: (ph.process_host_int(hq.numpy(), t, META_PERIOD, sample_scale=lsb), nsf)[1],
+                           {"sample_format": "int16 I/Q pairs in pinned host memory, one LSB = %g" % lsb, "bytes_per_subframe": sf_bytes // 2,
+                            "oracle_stream": "tests/golden/cfg3_stream_sc16_oracle.json", "golden_note": note16},
+                           gold=g16 or {"blocks": []}, sf_bytes=sf_bytes // 2)
+                del hq
                 with open(path, "rb", buffering=0) as f:
                     buf = bytearray(64 << 20)
                     while f.readinto(buf):
@@ -751,7 +759,10 @@ def main():
             # host, PCIe included, fresh engine - is value_first_h2d_to_last_pdu (cold pass) / _warm (third pass); x_realtime is given on both clocks, by name
             "value_resident": round(value, 1), "x_realtime": round(value / 1000.0 / (1 if capture_mode else world), 2),
             "x_realtime_resident": round(value / 1000.0 / (1 if capture_mode else world), 2),
-            "x_realtime_first_h2d_to_last_pdu": {"cold": round(h2d_cold / 1000.0, 1) if h2d_cold else None, "warm": round(h2d_warm / 1000.0, 1) if h2d_warm else None},
+            "x_realtime_first_h2d_to_last_pdu": {"cold": round(h2d_cold / 1000.0, 1) if h2d_cold else None, "warm": round(h2d_warm / 1000.0, 1) if h2d_warm else None,
+                                                 # the same capture held as int16 pairs (the radio's own sample format; an extension, lsn_phy_process_host_int): half the bytes
+                                                 "cold_int16_samples": round(leg_rate("host_pinned_sc16", "pass1_cold") / 1000.0, 1) if leg_rate("host_pinned_sc16", "pass1_cold") else None,
+                                                 "warm_int16_samples": round(leg_rate("host_pinned_sc16", "pass3_warm") / 1000.0, 1) if leg_rate("host_pinned_sc16", "pass3_warm") else None},
             "pcap_diff": pcap_diff,
             # BASELINE.md section 3 times "first H2D -> last PDU on host"; the bench contract wants inputs resident in HBM for `value`.  Both are here:
             # `value` = resident, `value_first_h2d_to_last_pdu` = the whole capture from pinned host memory through a FRESH engine (cold RNTI / MCS state, PCIe
@@ -798,7 +809,7 @@ def main():
         # the last 1.5 kB of the line (what a tail keeps): every headline figure with its gate
         out["summary"] = {"value_resident": round(value, 1), "pcap_diff": pcap_diff, "timed_subframes": total_sf, "n_gpus": out["n_gpus"], "dist": dist_echo,
                           "first_h2d_to_last_pdu": {k: {"cold_warm_warm": [leg_rate(k, w) for w in ("pass1_cold", "pass2_warm", "pass3_warm")], "pcap_diff": leg_diffs(k)}
-                                                    for k in ("host_pinned", "host_pinned_pcap_to_file", "host_pageable", "worker_pool_1_producer_thread", "worker_pool_4_producer_threads", "file_replay", "file_replay_sc16")
+                                                    for k in ("host_pinned", "host_pinned_pcap_to_file", "host_pageable", "worker_pool_1_producer_thread", "worker_pool_4_producer_threads", "file_replay", "host_pinned_sc16", "file_replay_sc16")
                                                     if legs and k in legs},
                           "other_configs": {k: [v.get("subframes_per_s"), v.get("pcap_diff")] for k, v in (legs or {}).items() if isinstance(v, dict) and "what" in v},
                           "roofline_frac": out["roofline"]["frac"], "cpu_baseline": [cpu.get("value"), (cpu.get("configs0") or {}).get("value")] if cpu else None,

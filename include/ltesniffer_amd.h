@@ -202,6 +202,12 @@ int lsn_phy_process_device(lsn_phy_t* phy, const void* d_iq, uint32_t n_subframe
                            uint32_t update_meta_period, void* stream);
 /* same, from host memory (copies through pinned staging) */
 int lsn_phy_process_host(lsn_phy_t* phy, const float* iq, uint32_t n_subframes, uint32_t start_tti, uint32_t update_meta_period);
+/* same, for INTEGER samples as a radio driver delivers them when asked not to convert (UHD cpu format sc16 / sc8; the reference asks srsran_rf for cf_t,
+ * LTESniffer_Core.cc:156,591-600: srsran_rf_recv_with_time_multi into cf_t buffers, so this has no counterpart there): iq [subframe][antenna][15*N] pairs of int16 (LSN_FILE_SC16) or int8 (LSN_FILE_SC8), I first;
+ * sample = (float)integer * sample_scale (0 = full scale +-1), converted on the GPU behind the copy - half / a quarter of the bytes of lsn_phy_process_host
+ * cross PCIe.  Formats and conversion are lsn_file_cfg_t's (below); LSN_FILE_CF32 is refused (that is lsn_phy_process_host). */
+int lsn_phy_process_host_int(lsn_phy_t* phy, const void* iq, uint32_t sample_format, float sample_scale, uint32_t n_subframes, uint32_t start_tti,
+                             uint32_t update_meta_period);
 /* Pipelined form of lsn_phy_process_device: submit returns as soon as every subframe of the block has been searched and queued for
  * decoding, so the decode / commit tail of one block overlaps the front of the next; lsn_phy_wait returns when everything submitted
  * has been committed (PDUs delivered, in order).  The IQ buffer of a submit must stay valid until the next lsn_phy_wait.

@@ -31,7 +31,7 @@ EXPORTS = ["lsn_phy_create", "lsn_phy_destroy", "lsn_phy_set_cell", "lsn_phy_get
            "lsn_phy_join_pending", "lsn_phy_set_pdu_sink", "lsn_phy_get_stats", "lsn_phy_get_est_cfo",
            "lsn_phy_add_evergreen", "lsn_phy_add_forbidden", "lsn_phy_setup_default_rnti_intervals",
            "lsn_phy_nof_active_rnti", "lsn_phy_get_ue_config", "lsn_worker_buffers", "lsn_worker_buffer_len", "lsn_worker_prepare",
-           "lsn_worker_sf_idx", "lsn_worker_sfn", "lsn_phy_process_device", "lsn_phy_process_host", "lsn_phy_tap",
+           "lsn_worker_sf_idx", "lsn_worker_sfn", "lsn_phy_process_device", "lsn_phy_process_host", "lsn_phy_process_host_int", "lsn_phy_tap",
            "lsn_phy_get_perf", "lsn_kernel_name", "lsn_version", "lsn_pcap_open", "lsn_pcap_open_mem",
            "lsn_pcap_set_wall_clock", "lsn_pcap_write", "lsn_pcap_sink", "lsn_pcap_mem", "lsn_pcap_nof_records",
            "lsn_pcap_reset", "lsn_pcap_close", "lsn_phy_set_pcap_writer", "lsn_phy_set_api_mode", "lsn_phy_tracked_ul_modulation", "lsn_phy_set_ul_config", "lsn_phy_get_ul_config", "lsn_sib2_decode", "lsn_phy_pusch_decode",
@@ -256,6 +256,7 @@ def lib():
         L.lsn_worker_sfn.restype = C.c_uint32
         L.lsn_phy_process_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         L.lsn_phy_process_host.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.lsn_phy_process_host_int.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_float, C.c_uint32, C.c_uint32, C.c_uint32]
         L.lsn_phy_tap.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p, C.c_size_t]
         L.lsn_phy_tap.restype = C.c_long
         L.lsn_phy_set_stage_c_taps.argtypes = [C.c_void_p, C.c_int]
@@ -507,6 +508,13 @@ class Phy:
         """iq: complex64 [n_subframes, nof_rx, 15*N]"""
         iq = np.ascontiguousarray(iq, dtype=np.complex64)
         _check(lib().lsn_phy_process_host(self._h, iq.ctypes.data, iq.shape[0], start_tti, update_meta_period), "process_host")
+
+    def process_host_int(self, q, start_tti, update_meta_period=0, sample_scale=0.0):
+        """q: int16 or int8 [n_subframes, nof_rx, 15*N, 2] (I, Q); one LSB = sample_scale (0: full scale +-1) - lsn_phy_process_host_int"""
+        assert q.dtype in (np.int16, np.int8) and q.ndim == 4 and q.shape[3] == 2
+        q = np.ascontiguousarray(q)
+        _check(lib().lsn_phy_process_host_int(self._h, q.ctypes.data, FILE_SC16 if q.dtype == np.int16 else FILE_SC8, float(sample_scale), q.shape[0], start_tti,
+                                              update_meta_period), "process_host_int")
 
     def process_device(self, dev_ptr, n_subframes, start_tti, update_meta_period=0, stream=None):
         _check(lib().lsn_phy_process_device(self._h, C.c_void_p(dev_ptr), n_subframes, start_tti, update_meta_period,

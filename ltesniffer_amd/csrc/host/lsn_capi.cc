@@ -499,6 +499,12 @@ int lsn_phy_process_host(lsn_phy_t* phy, const float* iq, uint32_t n, uint32_t s
   return phy->engine->processHost(iq, n, start_tti, update_meta_period);
 }
 
+int lsn_phy_process_host_int(lsn_phy_t* phy, const void* iq, uint32_t sample_format, float sample_scale, uint32_t n, uint32_t start_tti, uint32_t update_meta_period)
+{
+  if (!phy || (!iq && n) || (sample_format != LSN_FILE_SC16 && sample_format != LSN_FILE_SC8)) return LSN_ERROR_INVALID_INPUTS;
+  return phy->engine->processHost(iq, n, start_tti, update_meta_period, sample_format, sample_scale);
+}
+
 int lsn_phy_mib_decode(lsn_phy_t* phy, const void* iq, int iq_on_device, lsn_mib_t* out)
 {
   if (!phy) return LSN_ERROR_INVALID_INPUTS;

@@ -2219,14 +2219,20 @@ int Engine::wait()
 // copy stream of their own while the pipeline works on the blocks before them (submit() only queues).  Caller memory that is not pinned
 // yet is registered for the duration of the call so that the copies are real DMA transfers; if the registration is refused the copies
 // fall back to the runtime's bounce buffers (still overlapped with the compute of earlier blocks).
-int Engine::processHost(const float* iq, uint32_t nsf_total, uint32_t start_tti, uint32_t update_meta_period)
+// sample_format LSN_FILE_SC16 / LSN_FILE_SC8 (lsn_phy_process_host_int): the caller's buffers hold integer I/Q pairs in the same [subframe][antenna][sample]
+// order; a block crosses PCIe as it is (half / a quarter of the bytes) into a raw ring and is converted into its staging block by the file source's kernel
+// (k_file_unpack with one "antenna" of nof_rx * sflen samples = a flat conversion) on the copy stream, in front of the submit.
+int Engine::processHost(const void* iq, uint32_t nsf_total, uint32_t start_tti, uint32_t update_meta_period, uint32_t fmt, float scale)
 {
   if (!cell_set) return LSN_ERROR;
-  if (!iq && nsf_total) return LSN_ERROR_INVALID_INPUTS;
+  if ((!iq && nsf_total) || fmt > LSN_FILE_SC8) return LSN_ERROR_INVALID_INPUTS;
+  if (fmt != LSN_FILE_CF32 && !(scale >= 0.0f && scale < INFINITY)) return LSN_ERROR_INVALID_INPUTS;
+  if (fmt != LSN_FILE_CF32 && scale == 0.0f) scale = fmt == LSN_FILE_SC16 ? 1.0f / 32768.0f : 1.0f / 128.0f;
   bool registered = false;
   try {
     HIP_CHECK(hipSetDevice(cfg.device));
     const size_t sf_stride = (size_t)cfg.nof_rx_antennas * cd.sflen * sizeof(cf32);
+    const size_t in_stride = fmt == LSN_FILE_SC16 ? sf_stride / 2 : fmt == LSN_FILE_SC8 ? sf_stride / 4 : sf_stride;  // bytes of one subframe in the caller's memory
     // ring of staging blocks, one pipeline chunk each (max_batch subframes: 393 MB at 20 MHz / 2 rx / 800 subframes - large copies run at the
     // link rate, tools/ubench/h2d_bw.hip).  A block is reusable as soon as stage A of its chunk has consumed the samples (not when the chunk has
     // left the whole pipeline: with decode, commit and write behind stage A that is six or more chunk times later and throttled the copies to
@@ -2239,13 +2245,18 @@ int Engine::processHost(const float* iq, uint32_t nsf_total, uint32_t start_tti,
     {
       hipPointerAttribute_t attr{};
       const bool pinned = hipPointerGetAttributes(&attr, iq) == hipSuccess && attr.type == hipMemoryTypeHost;
-      if (!pinned && (size_t)nsf_total * sf_stride >= ((size_t)8 << 20))
-        registered = hipHostRegister((void*)iq, (size_t)nsf_total * sf_stride, hipHostRegisterDefault) == hipSuccess;
+      if (!pinned && (size_t)nsf_total * in_stride >= ((size_t)8 << 20))
+        registered = hipHostRegister((void*)iq, (size_t)nsf_total * in_stride, hipHostRegisterDefault) == hipSuccess;
       (void)hipGetLastError();
     }
     static const bool host_debug = getenv("LSN_HOST_DEBUG") != nullptr;
     const double t_host0 = now_ms();
     const uint32_t nring = (uint32_t)std::max<size_t>(2, staging_sf / blk);
+    if (fmt != LSN_FILE_CF32 && d_iq_raw_bytes < (size_t)nring * blk * in_stride) {
+      if (d_iq_raw) { (void)hipFree(d_iq_raw); d_iq_raw = nullptr; d_iq_raw_bytes = 0; }
+      HIP_CHECK(hipMalloc(&d_iq_raw, (size_t)nring * blk * in_stride));
+      d_iq_raw_bytes = (size_t)nring * blk * in_stride;
+    }
     std::vector<uint64_t> marks(nring, 0);
     uint32_t k = 0;
     int rc = LSN_SUCCESS;
@@ -2254,7 +2265,13 @@ int Engine::processHost(const float* iq, uint32_t nsf_total, uint32_t start_tti,
       if (k >= nring) waitIqConsumed(marks[slot]);
       uint8_t* dst = (uint8_t*)d_iq_staging + (size_t)slot * blk * sf_stride;
       const double tc0 = now_ms();
-      HIP_CHECK(hipMemcpyAsync(dst, (const uint8_t*)iq + (size_t)base * sf_stride, (size_t)nsf * sf_stride, hipMemcpyHostToDevice, copy_stream));
+      if (fmt == LSN_FILE_CF32) {
+        HIP_CHECK(hipMemcpyAsync(dst, (const uint8_t*)iq + (size_t)base * sf_stride, (size_t)nsf * sf_stride, hipMemcpyHostToDevice, copy_stream));
+      } else {  // (the raw slot is free when the staging slot is: the conversion that read it ran in front of the stage A that `marks` waits for)
+        uint8_t* raw = (uint8_t*)d_iq_raw + (size_t)slot * blk * in_stride;
+        HIP_CHECK(hipMemcpyAsync(raw, (const uint8_t*)iq + (size_t)base * in_stride, (size_t)nsf * in_stride, hipMemcpyHostToDevice, copy_stream));
+        lsn_launch_file_unpack(raw, fmt, scale, nullptr, cfg.nof_rx_antennas * cd.sflen, 1, (cf32*)dst, nsf, copy_stream);
+      }
       const double tc1 = now_ms();
       rc = submit(dst, nsf, start_tti + base, update_meta_period, copy_stream);  // stage A of the block waits for the copy on the device
       marks[slot] = submitMark();

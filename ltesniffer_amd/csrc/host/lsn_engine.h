@@ -231,7 +231,7 @@ public:
   int processFile(const char* path, const lsn_file_cfg_t& fc, uint32_t start_tti, uint64_t max_subframes, uint32_t update_meta_period,
                   uint64_t* subframes_done);
   int reserveFileBuffers(uint32_t nof_antennas);   // lsn_phy_prepare_file: pinned read blocks + device blocks of the file source, ahead of the first replay
-  int processHost(const float* iq, uint32_t nsf, uint32_t start_tti, uint32_t update_meta_period);
+  int processHost(const void* iq, uint32_t nsf, uint32_t start_tti, uint32_t update_meta_period, uint32_t sample_format = 0 /* LSN_FILE_* */, float sample_scale = 0.0f);
   void setSink(lsn_pdu_sink_t cb, void* user) { sink = cb; sink_user = user; }
   void setApi(int mode, lsn_api_sink_t cb, void* user, lsn_pdu_sink_t pcap_cb, void* pcap) { api_mode = mode; api_sink = cb; api_user = user; api_pcap_sink = pcap_cb; api_pcap = pcap; }
   long tap(int what, uint32_t sf, void* out, size_t cap);
@@ -357,6 +357,8 @@ private:
   uint64_t cfo_launched = 0;
   float cfo_c = 0.0f, cfo_meas[16] = {};
   void* d_iq_staging = nullptr;
+  void* d_iq_raw = nullptr;                   // processHost on integer samples: the raw blocks in front of the conversion (made on first use)
+  size_t d_iq_raw_bytes = 0;
   hipStream_t copy_stream = nullptr;          // host -> staging copies of processHost
   hipEvent_t copy_done[3] = {};
   uint64_t peer_marks[12] = {};               // submitFrom / submitHostRows: staging slot -> mark of the chunk that used it last

@@ -83,6 +83,7 @@ void Engine::freeDevice(bool keep_file_buffers)
       for (auto& fb : file_buf) { if (fb.h_raw) (void)hipHostFree(fb.h_raw); df(fb.d_raw); df(fb.d_iq); fb.h_raw = nullptr; fb.bytes = 0; }
   }
   d_iq_staging = nullptr; staging_sf = 0;
+  if (d_iq_raw) { (void)hipFree(d_iq_raw); d_iq_raw = nullptr; d_iq_raw_bytes = 0; }
   if (sh->harq_pool_owner == this) { d_harq_pool = nullptr; sh->harq_pool_owner = nullptr; }   // (freed with this engine's device allocations)
   if (harq_h_store) { (void)hipHostFree(harq_h_store); harq_h_store = nullptr; harq_h_store_cap = 0; }
   if (harq_d_store) { (void)hipFree(harq_d_store); harq_d_store = nullptr; harq_d_store_cap = 0; }

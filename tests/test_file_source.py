@@ -168,3 +168,31 @@ def test_process_file_matches_oracle_worker(tmp_path, monkeypatch, scn, nsf, lea
     fc = la.FileCfg(sc["nof_rx"] + 1, 0, 0.0)
     assert la.lib().lsn_phy_process_file(phy2._h, os.fsencode(p), C.byref(fc), 0, 0, 0, None) == la.LSN_ERROR_INVALID_INPUTS
     phy.close(); phy2.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt,pow2", [(1, True), (2, False)])
+def test_process_host_integer_samples_match_oracle_worker(tmp_path, fmt, pow2):
+    """lsn_phy_process_host_int: integer I/Q pairs in the caller's memory ([subframe][antenna][sample], what a radio driver delivers unconverted) cross
+    PCIe as they are and are converted behind the copy - the records are the oracle's on (float)integer * lsb; 15 blocks through a ring of 12"""
+    import ltesniffer_amd as la
+    from parity import gpu_records
+    sc = scenario("small", seed=33)
+    nsf = 118
+    tti0, iq, _ = gen_subframes(sc, nsf)
+    lsb, q = write_integer_capture(str(tmp_path / "unused"), iq, fmt, pow2=pow2)
+    sub = (q[..., 0].astype(np.float32) * np.float32(lsb) + 1j * (q[..., 1].astype(np.float32) * np.float32(lsb))).astype(np.complex64)
+    ow = OracleWorker(sc["nof_prb"], sc["nof_ports"], sc["cell_id"], sc["nof_rx"])
+    for i in range(nsf):
+        ow.work(sub[i], tti0 + i, update_meta=1 if i % 20 == 0 else 0)
+    orecs = oracle_records(parse_pcap(ow.pcap_bytes()))
+    assert len(orecs) >= nsf // 2
+    phy = la.Phy(nof_rx_antennas=sc["nof_rx"], max_batch=8, pcapwriter=la.PcapWriter(None))
+    assert phy.setCell(sc["nof_prb"], sc["nof_ports"], sc["cell_id"])
+    phy.process_host_int(q, tti0, update_meta_period=20, sample_scale=lsb)
+    assert gpu_records(phy) == orecs
+    L = la.lib()   # cf32 belongs to lsn_phy_process_host; a scale that is not a number is refused
+    assert L.lsn_phy_process_host_int(phy._h, q.ctypes.data, la.FILE_CF32, 1.0, 1, 0, 0) == la.LSN_ERROR_INVALID_INPUTS
+    assert L.lsn_phy_process_host_int(phy._h, q.ctypes.data, 3, 1.0, 1, 0, 0) == la.LSN_ERROR_INVALID_INPUTS
+    assert L.lsn_phy_process_host_int(phy._h, q.ctypes.data, fmt, float("nan"), 1, 0, 0) == la.LSN_ERROR_INVALID_INPUTS
+    phy.close()
