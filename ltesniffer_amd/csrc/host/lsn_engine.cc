@@ -599,6 +599,7 @@ template <typename T>
 static void grow_dev(T*& p, size_t& cap, size_t need, hipStream_t st)
 {
   if (need <= cap) return;
+  if (getenv("LSN_HOST_DEBUG")) fprintf(stderr, "grow_dev: %zu -> %zu elements of %zu B\n", cap, need + need / 2 + 1024, sizeof(T));
   HIP_CHECK(hipStreamSynchronize(st));
   if (p) HIP_CHECK(hipFree(p));
   cap = need + need / 2 + 1024;
@@ -608,6 +609,7 @@ template <typename T>
 static void grow_host(T*& p, size_t& cap, size_t need, hipStream_t st)
 {
   if (need <= cap) return;
+  if (getenv("LSN_HOST_DEBUG")) fprintf(stderr, "grow_host: %zu -> %zu elements of %zu B\n", cap, need + need / 2 + 1024, sizeof(T));
   HIP_CHECK(hipStreamSynchronize(st));
   if (p) HIP_CHECK(hipHostFree(p));
   cap = need + need / 2 + 1024;

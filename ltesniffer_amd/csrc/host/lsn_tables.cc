@@ -123,10 +123,13 @@ void Engine::allocRunner(JobRunner& r)
   // The arenas of a bulk decode runner start at the size a full chunk of a loaded cell needs (per subframe at 100 PRB: 16 decode calls, 32 code
   // blocks, 0.5 M soft bits, 128 K packed words, 24 KB of payload), scaled with the bandwidth: a fresh engine otherwise grows each of them several
   // times during its first chunks, every step a stream synchronisation + hipFree (a device-wide wait) - part of why the cold pass of a capture
-  // ran 10-15 % below the following ones.  On-demand runners (single decodes) keep growing from zero.
+  // ran 10-15 % below the following ones.  On-demand runners (single decodes by the search, front and commit threads) start at four subframes' worth
+  // (12 MB each): they grew from zero until the last session of round 6 - some forty steps spread over the first TWO passes of a capture (a runner that
+  // meets its first large grant in the second pass starts its ladder there), which is what kept the second pass of the PCIe-inclusive legs 10-17 %
+  // below the third (profiles/r06_exp_int16_chunks.txt; LSN_HOST_DEBUG prints every step).
   bool bulk = false;
   for (int i = 0; i < NDEC; i++) bulk = bulk || &r == &runner_c[i];
-  if (bulk && !getenv("LSN_NO_PRESIZE")) {
+  if (!getenv("LSN_NO_PRESIZE")) {
     const double scale = (double)cell.nof_prb / 100.0;
     // The pre-size is a start-up optimisation, never a requirement (round-4 advisor finding): it is bounded by the chunk a runner can meet
     // (max_batch) AND by a share of the memory that is free right now - all bulk runners together take at most a quarter of it - and an
@@ -134,7 +137,7 @@ void Engine::allocRunner(JobRunner& r)
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = 0; }
     const double per_sf_bytes = (16.0 * (sizeof(LsnGrantDev) + 2.0 * (14 * 100 + 16)) + 32.0 * (sizeof(LsnCbDev) + sizeof(LsnCbRes)) + 512.0 * 1024 * 2 + 24.0 * 1024 + 64 * 4 + 128.0 * 1024 * 4) * scale;
-    size_t sfn_ = max_batch;
+    size_t sfn_ = bulk ? max_batch : std::min<size_t>(max_batch, 4);
     if (free_b) sfn_ = std::min<size_t>(sfn_, (size_t)((double)free_b / 4.0 / (double)NDEC / per_sf_bytes));
     auto dev = [&](auto*& p, size_t& cap, double per_sf) {
       const size_t n = (size_t)(per_sf * scale * (double)sfn_) + 4096;
